@@ -1,0 +1,99 @@
+"""ctypes view of include/afquant.h (struct layouts and prototypes).
+
+Kept separate from the loader so the CPU oracle binding (oracle/oracle.py, test
+infrastructure) can share the struct definitions without loading the HIP library.
+"""
+import ctypes as C
+
+AFQ_ABI_VERSION = 1
+
+AFQ_OK = 0
+AFQ_ERR_INVALID_ARG = -1
+AFQ_ERR_BAD_INPUT = -2
+AFQ_ERR_UNSUPPORTED = -3
+AFQ_ERR_HIP = -4
+AFQ_ERR_NO_DEVICE = -5
+AFQ_ERR_STATE = -6
+AFQ_ERR_OOM = -7
+
+# ResolutionStrategy spellings of the CLI (src/quant.rs:98-111 of the reference)
+RESOLUTIONS = {
+    "trivial": 0,
+    "cr-like": 1,
+    "cr-like-em": 2,
+    "parsimony-em": 3,
+    "parsimony": 4,
+    "parsimony-gene-em": 5,
+    "parsimony-gene": 6,
+}
+
+CELL_TINY_PATH = 0x1
+CELL_ALT_RES = 0x2
+CELL_EMPTY = 0x4
+
+
+class AfqConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32),
+        ("resolution", C.c_uint32),
+        ("sa_model", C.c_uint32),
+        ("usa_mode", C.c_uint32),
+        ("num_genes", C.c_uint32),
+        ("num_rows", C.c_uint32),
+        ("small_thresh", C.c_uint32),
+        ("large_graph_thresh", C.c_uint32),
+        ("pug_exact_umi", C.c_uint32),
+        ("em_init_uniform", C.c_uint32),
+        ("bc_bytes", C.c_uint32),
+        ("umi_bytes", C.c_uint32),
+        ("profile", C.c_uint32),
+        ("reserved", C.c_uint32 * 3),
+    ]
+
+
+class AfqResult(C.Structure):
+    _fields_ = [
+        ("n_cells", C.c_uint64),
+        ("first_cell_index", C.c_uint64),
+        ("nnz", C.c_uint64),
+        ("cell_ptr", C.POINTER(C.c_uint64)),
+        ("gene", C.POINTER(C.c_uint32)),
+        ("val", C.POINTER(C.c_float)),
+        ("bc", C.POINTER(C.c_uint64)),
+        ("nrec", C.POINTER(C.c_uint32)),
+        ("flags", C.POINTER(C.c_uint8)),
+        ("mmrate", C.POINTER(C.c_double)),
+        ("opaque", C.c_void_p),
+    ]
+
+
+class AfqKernelTime(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("ms", C.c_double), ("launches", C.c_uint32), ("pad", C.c_uint32)]
+
+
+class AfqBatchStats(C.Structure):
+    _fields_ = [
+        ("n_records", C.c_uint64),
+        ("n_ref_words", C.c_uint64),
+        ("n_keys", C.c_uint64),
+        ("n_buckets", C.c_uint64),
+        ("n_overflow_buckets", C.c_uint64),
+        ("input_bytes", C.c_uint64),
+    ]
+
+
+# every symbol include/afquant.h declares (tests check the .so exports them all)
+EXPORTS = [
+    "afq_create",
+    "afq_destroy",
+    "afq_submit",
+    "afq_submit_device",
+    "afq_collect",
+    "afq_result_release",
+    "afq_atac_dedup",
+    "afq_free",
+    "afq_get_kernel_times",
+    "afq_get_batch_stats",
+    "afq_last_error",
+    "afq_abi_version",
+]

@@ -1,0 +1,259 @@
+"""Host-side mirror of the reference's per-cell quant interface, over the C ABI.
+
+The reference is compiled Rust whose hot path has no plugin/FFI surface: it is
+called from `run_worker_thread` (src/quant.rs:659-1325) and configured by
+`WorkerConfig` (src/quant.rs:398-416).  `WorkerConfig` below carries the same
+fields with the same meaning; `Quantifier.quant_chunks` takes collated chunk
+bytes (one chunk = one cell) and returns the rows the worker would have emitted.
+
+There is no CPU fallback: if csrc/libafquant.so (hand-written HIP for gfx950) is
+missing or no device is usable, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _abi
+from ._abi import AfqBatchStats, AfqConfig, AfqKernelTime, AfqResult, RESOLUTIONS
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libafquant.so")
+
+
+class AfqError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"afquant error {code}: {msg}")
+        self.code = code
+
+
+@dataclass
+class WorkerConfig:
+    """Field-for-field WorkerConfig (src/quant.rs:398-416) + record field widths."""
+
+    resolution: str = "cr-like"
+    usa_mode: bool = False
+    num_genes: int = 0  # gene-id space of tid_to_gid (USA: 2*G)
+    num_rows: int = 0  # output columns (USA: 3*G)
+    small_thresh: int = 100  # tiny_cell_thresh, DEFAULT_SMALL_CELL_FAST_THRESHOLD quant.rs:449
+    large_graph_thresh: int = 0  # main.rs:332-341: 1000 for parsimony*, else 0
+    pug_exact_umi: bool = True  # main.rs:652-703: umi-edit-dist 0 unless parsimony*
+    sa_model: str = "winner-take-all"
+    em_init_uniform: bool = False
+    bc_bytes: int = 4
+    umi_bytes: int = 4
+    profile: bool = False
+
+    @staticmethod
+    def for_resolution(resolution: str, **kw) -> "WorkerConfig":
+        """Apply the CLI's conditional defaults (src/main.rs:320-341, 652-703)."""
+        pars = resolution.startswith("parsimony")
+        d = dict(resolution=resolution, large_graph_thresh=1000 if pars else 0, pug_exact_umi=not pars)
+        d.update(kw)
+        return WorkerConfig(**d)
+
+    def to_c(self) -> AfqConfig:
+        if self.resolution not in RESOLUTIONS:
+            raise ValueError(f"unknown resolution {self.resolution!r}")
+        c = AfqConfig()
+        c.abi_version = _abi.AFQ_ABI_VERSION
+        c.resolution = RESOLUTIONS[self.resolution]
+        c.sa_model = {"winner-take-all": 0, "prefer-ambig": 1}[self.sa_model]
+        c.usa_mode = int(self.usa_mode)
+        c.num_genes = self.num_genes
+        c.num_rows = self.num_rows
+        c.small_thresh = self.small_thresh
+        c.large_graph_thresh = self.large_graph_thresh
+        c.pug_exact_umi = int(self.pug_exact_umi)
+        c.em_init_uniform = int(self.em_init_uniform)
+        c.bc_bytes = self.bc_bytes
+        c.umi_bytes = self.umi_bytes
+        c.profile = int(self.profile)
+        return c
+
+
+@dataclass
+class QuantResult:
+    """Rows for a run of cells: CSR of (output column, f32 count) + per-cell scalars."""
+
+    first_cell_index: int
+    cell_ptr: np.ndarray
+    gene: np.ndarray
+    val: np.ndarray
+    bc: np.ndarray
+    nrec: np.ndarray
+    flags: np.ndarray
+    mmrate: np.ndarray
+
+    @property
+    def n_cells(self) -> int:
+        return len(self.bc)
+
+    def row(self, i: int):
+        a, b = int(self.cell_ptr[i]), int(self.cell_ptr[i + 1])
+        return self.gene[a:b], self.val[a:b]
+
+    def cell_stats(self, i: int):
+        """sum/max/num_expr/mean_by_max/num_genes_over_mean as src/quant.rs:1150-1196."""
+        _, v = self.row(i)
+        s = np.float32(0.0)
+        for x in v:  # f32 sum in gene-index order
+            s = np.float32(s + x)
+        mx = np.float32(v.max()) if len(v) else np.float32(0)
+        n = len(v)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            mean = np.float32(s) / np.float32(n)
+            over = int((v > mean).sum())
+            return dict(sum_umi=float(s), max_umi=float(mx), num_expr=n, mean_by_max=float(mean / mx),
+                        num_genes_over_mean=over, dedup_rate=float(s / np.float32(self.nrec[i])))
+
+
+def result_from_c(res: AfqResult) -> QuantResult:
+    n, nnz = int(res.n_cells), int(res.nnz)
+
+    def arr(ptr, count, dt):
+        if count == 0:
+            return np.zeros(0, dtype=dt)
+        return np.ctypeslib.as_array(ptr, shape=(count,)).astype(dt, copy=True)
+
+    return QuantResult(int(res.first_cell_index), arr(res.cell_ptr, n + 1, np.uint64), arr(res.gene, nnz, np.uint32),
+                       arr(res.val, nnz, np.float32), arr(res.bc, n, np.uint64), arr(res.nrec, n, np.uint32),
+                       arr(res.flags, n, np.uint8), arr(res.mmrate, n, np.float64))
+
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH):
+    """dlopen the HIP library and declare prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            f"{path} not found: the HIP extension is not built (run __graft_entry__.build()). "
+            "There is no CPU fallback for the quant hot path."
+        )
+    lib = C.CDLL(path)
+    p = C.POINTER
+    lib.afq_create.argtypes = [p(AfqConfig), p(C.c_uint32), C.c_uint32, C.c_int, p(C.c_void_p)]
+    lib.afq_create.restype = C.c_int
+    lib.afq_destroy.argtypes = [C.c_void_p]
+    lib.afq_destroy.restype = None
+    lib.afq_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, p(C.c_uint64), C.c_uint32, C.c_uint64]
+    lib.afq_submit.restype = C.c_int
+    lib.afq_submit_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, p(C.c_uint64), C.c_uint32, C.c_uint64]
+    lib.afq_submit_device.restype = C.c_int
+    lib.afq_collect.argtypes = [C.c_void_p, p(AfqResult)]
+    lib.afq_collect.restype = C.c_int
+    lib.afq_result_release.argtypes = [p(AfqResult)]
+    lib.afq_result_release.restype = None
+    lib.afq_atac_dedup.argtypes = [C.c_void_p, p(C.c_uint32), p(C.c_uint32), p(C.c_uint16), p(C.c_uint64), C.c_uint32,
+                                   p(p(C.c_uint64)), p(p(C.c_uint32)), p(p(C.c_uint32)), p(p(C.c_uint16)), p(p(C.c_uint16))]
+    lib.afq_atac_dedup.restype = C.c_int
+    lib.afq_free.argtypes = [C.c_void_p]
+    lib.afq_free.restype = None
+    lib.afq_get_kernel_times.argtypes = [C.c_void_p, p(AfqKernelTime), C.c_uint32]
+    lib.afq_get_kernel_times.restype = C.c_int
+    lib.afq_get_batch_stats.argtypes = [C.c_void_p, p(AfqBatchStats)]
+    lib.afq_get_batch_stats.restype = C.c_int
+    lib.afq_last_error.argtypes = [C.c_void_p]
+    lib.afq_last_error.restype = C.c_char_p
+    lib.afq_abi_version.argtypes = []
+    lib.afq_abi_version.restype = C.c_int
+    if lib.afq_abi_version() != _abi.AFQ_ABI_VERSION:
+        raise RuntimeError("libafquant.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+class Quantifier:
+    """One per device: config + tid_to_gid resident on the GPU (afq_ctx)."""
+
+    def __init__(self, cfg: WorkerConfig, tid_to_gid: np.ndarray, device: int = 0):
+        self.lib = load_library()
+        self.cfg = cfg
+        self._t2g = np.ascontiguousarray(tid_to_gid, dtype=np.uint32)
+        ccfg = cfg.to_c()
+        h = C.c_void_p()
+        rc = self.lib.afq_create(C.byref(ccfg), self._t2g.ctypes.data_as(C.POINTER(C.c_uint32)), len(self._t2g),
+                                 device, C.byref(h))
+        if rc != 0:
+            raise AfqError(rc, (self.lib.afq_last_error(None) or b"").decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.afq_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise AfqError(rc, (self.lib.afq_last_error(self._h) or b"").decode())
+
+    def submit(self, chunk_bytes, chunk_off, first_cell_index: int = 0):
+        b = np.ascontiguousarray(np.frombuffer(chunk_bytes, dtype=np.uint8) if not isinstance(chunk_bytes, np.ndarray) else chunk_bytes)
+        off = np.ascontiguousarray(chunk_off, dtype=np.uint64)
+        self._keep = (b, off)
+        self._check(self.lib.afq_submit(self._h, b.ctypes.data_as(C.c_void_p), b.nbytes,
+                                        off.ctypes.data_as(C.POINTER(C.c_uint64)), len(off), first_cell_index))
+
+    def submit_device(self, d_ptr: int, n_bytes: int, chunk_off, first_cell_index: int = 0):
+        off = np.ascontiguousarray(chunk_off, dtype=np.uint64)
+        self._keep = (off,)
+        self._check(self.lib.afq_submit_device(self._h, C.c_void_p(d_ptr), n_bytes,
+                                               off.ctypes.data_as(C.POINTER(C.c_uint64)), len(off), first_cell_index))
+
+    def collect(self) -> QuantResult:
+        res = AfqResult()
+        self._check(self.lib.afq_collect(self._h, C.byref(res)))
+        try:
+            return result_from_c(res)
+        finally:
+            self.lib.afq_result_release(C.byref(res))
+
+    def quant_chunks(self, chunk_bytes, chunk_off, first_cell_index: int = 0) -> QuantResult:
+        self.submit(chunk_bytes, chunk_off, first_cell_index)
+        return self.collect()
+
+    def kernel_times(self):
+        buf = (AfqKernelTime * 64)()
+        n = self.lib.afq_get_kernel_times(self._h, buf, 64)
+        if n < 0:
+            self._check(n)
+        return {buf[i].name.decode(): (buf[i].ms, buf[i].launches) for i in range(n)}
+
+    def batch_stats(self) -> dict:
+        s = AfqBatchStats()
+        self._check(self.lib.afq_get_batch_stats(self._h, C.byref(s)))
+        return {k: int(getattr(s, k)) for k, _ in s._fields_}
+
+    def atac_dedup(self, ref, start, frag_len, cell_ptr):
+        ref = np.ascontiguousarray(ref, np.uint32)
+        start = np.ascontiguousarray(start, np.uint32)
+        frag_len = np.ascontiguousarray(frag_len, np.uint16)
+        cell_ptr = np.ascontiguousarray(cell_ptr, np.uint64)
+        n_cells = len(cell_ptr) - 1
+        o_ptr, o_ref, o_start = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)()
+        o_len, o_cnt = C.POINTER(C.c_uint16)(), C.POINTER(C.c_uint16)()
+        self._check(self.lib.afq_atac_dedup(
+            self._h, ref.ctypes.data_as(C.POINTER(C.c_uint32)), start.ctypes.data_as(C.POINTER(C.c_uint32)),
+            frag_len.ctypes.data_as(C.POINTER(C.c_uint16)), cell_ptr.ctypes.data_as(C.POINTER(C.c_uint64)), n_cells,
+            C.byref(o_ptr), C.byref(o_ref), C.byref(o_start), C.byref(o_len), C.byref(o_cnt)))
+        try:
+            ptr = np.ctypeslib.as_array(o_ptr, shape=(n_cells + 1,)).copy()
+            n = int(ptr[-1])
+            mk = lambda p_, dt: (np.ctypeslib.as_array(p_, shape=(n,)).astype(dt, copy=True) if n else np.zeros(0, dt))
+            return ptr, mk(o_ref, np.uint32), mk(o_start, np.uint32), mk(o_len, np.uint16), mk(o_cnt, np.uint16)
+        finally:
+            for q in (o_ptr, o_ref, o_start, o_len, o_cnt):
+                self.lib.afq_free(q)

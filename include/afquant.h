@@ -1,0 +1,183 @@
+/*
+ * afquant.h — C ABI of the MI355X-native `alevin-fry quant` hot path.
+ *
+ * The reference (COMBINE-lab/alevin-fry v0.18.0, pure Rust) has no FFI layer:
+ * the hot path is the body of the per-cell loop in `run_worker_thread`
+ * (src/quant.rs:733-1322), configured by `WorkerConfig` (src/quant.rs:398-416).
+ * This header is the seam a Rust host would bind instead of that loop body:
+ * "collated chunk bytes in -> sparse row + flags out".  Every entry point
+ * cites the reference item it replaces.  Plain pointers and sizes only.
+ *
+ * All functions return 0 on success or a negative AFQ_ERR_* code; the text of
+ * the last error on a context is available from afq_last_error().  Nothing in
+ * this library aborts the process (the reference panics / exit(1)s instead:
+ * src/pugutils.rs:1148-1151, Cargo.toml:100-108).
+ */
+#ifndef AFQUANT_H
+#define AFQUANT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AFQ_ABI_VERSION 1
+
+/* error codes */
+#define AFQ_OK 0
+#define AFQ_ERR_INVALID_ARG (-1)  /* null pointer, bad enum, inconsistent sizes  */
+#define AFQ_ERR_BAD_INPUT (-2)    /* malformed chunk bytes / ref id out of range */
+#define AFQ_ERR_UNSUPPORTED (-3)  /* valid request the device path cannot take   */
+#define AFQ_ERR_HIP (-4)          /* a HIP runtime call failed                   */
+#define AFQ_ERR_NO_DEVICE (-5)    /* no usable gfx950 device                     */
+#define AFQ_ERR_STATE (-6)        /* call sequence error (collect before submit) */
+#define AFQ_ERR_OOM (-7)
+
+/* ResolutionStrategy, src/quant.rs:82-114 (CLI spellings in the comments). */
+typedef enum afq_resolution {
+    AFQ_RES_TRIVIAL = 0,           /* trivial            */
+    AFQ_RES_CR_LIKE = 1,           /* cr-like            */
+    AFQ_RES_CR_LIKE_EM = 2,        /* cr-like-em         */
+    AFQ_RES_PARSIMONY_EM = 3,      /* parsimony-em       */
+    AFQ_RES_PARSIMONY = 4,         /* parsimony          */
+    AFQ_RES_PARSIMONY_GENE_EM = 5, /* parsimony-gene-em  */
+    AFQ_RES_PARSIMONY_GENE = 6     /* parsimony-gene     */
+} afq_resolution;
+
+/* SplicedAmbiguityModel (src/quant.rs, `--sa-model`). */
+typedef enum afq_sa_model { AFQ_SA_WINNER_TAKE_ALL = 0, AFQ_SA_PREFER_AMBIG = 1 } afq_sa_model;
+
+/* per-cell flag bits in afq_result.flags */
+#define AFQ_CELL_TINY_PATH 0x1u /* used_fast_path,   src/quant.rs:794-797      */
+#define AFQ_CELL_ALT_RES 0x2u   /* alt_resolution,   src/quant.rs:966, 1131     */
+#define AFQ_CELL_EMPTY 0x4u     /* num_expr == 0,    src/quant.rs:1173          */
+
+/*
+ * Mirror of WorkerConfig (src/quant.rs:398-416) — the part of QuantOpts
+ * (src/prog_opts.rs:24-44) that reaches the per-cell code — plus the record
+ * field widths the reference gets from the RAD prelude (src/convert.rs:323-344).
+ * POD; copied by afq_create.
+ */
+typedef struct afq_config {
+    uint32_t abi_version;        /* AFQ_ABI_VERSION                                              */
+    uint32_t resolution;         /* afq_resolution                                               */
+    uint32_t sa_model;           /* afq_sa_model (forced to WTA when !usa_mode, quant.rs:1456)   */
+    uint32_t usa_mode;           /* 3-column tg-map: spliced gid even, unspliced odd             */
+    uint32_t num_genes;          /* gene-id space of tid_to_gid (USA: 2*G, spliced/unspliced)    */
+    uint32_t num_rows;           /* output columns: num_genes, or 3*G in USA (quant.rs:1627-1645)*/
+    uint32_t small_thresh;       /* tiny_cell_thresh; cells with nrec < this take the tiny path  */
+    uint32_t large_graph_thresh; /* PUG component size above which cr-like is used (pugutils.rs:1055) */
+    uint32_t pug_exact_umi;      /* 1: only identical UMIs induce PUG edges (--umi-edit-dist 0)  */
+    uint32_t em_init_uniform;    /* EmInitType::Uniform instead of Informative (em.rs:37-41)     */
+    uint32_t bc_bytes;           /* width of the barcode field in a record: 1,2,4,8              */
+    uint32_t umi_bytes;          /* width of the UMI field in a record: 1,2,4,8                  */
+    uint32_t profile;            /* 1: bracket every kernel with HIP events (afq_get_kernel_times)*/
+    uint32_t reserved[3];
+} afq_config;
+
+typedef struct afq_ctx afq_ctx;
+
+/*
+ * One result batch = what run_worker_thread accumulates for a run of cells:
+ * `expressed_ind/expressed_vec` per cell (src/quant.rs:1156-1168, 808-845) as
+ * CSR, plus the per-cell scalars it logs.  Library-owned until
+ * afq_result_release(); all pointers are host memory.
+ */
+typedef struct afq_result {
+    uint64_t n_cells;
+    uint64_t first_cell_index; /* cell_num of cell 0 (MetaChunk.first_chunk_index, quant.rs:734) */
+    uint64_t nnz;
+    const uint64_t* cell_ptr; /* [n_cells+1] offsets into gene/val                               */
+    const uint32_t* gene;     /* [nnz] output column, ascending within a cell                     */
+    const float* val;         /* [nnz] count > 0                                                  */
+    const uint64_t* bc;       /* [n_cells] collate_key of the cell's first record (quant.rs:757)  */
+    const uint32_t* nrec;     /* [n_cells] records in the chunk                                   */
+    const uint8_t* flags;     /* [n_cells] AFQ_CELL_*                                             */
+    const double* mmrate;     /* [n_cells] multi-mapping rate, `trivial` only (quant.rs:936) else 0 */
+    void* opaque;
+} afq_result;
+
+/*
+ * Replaces the worker set-up of do_quantify (src/quant.rs:1678-1765): builds a
+ * per-device context holding the config and the transcript->gene table
+ * (`tid_to_gid`, src/utils.rs:487-662; len = ref_count).  `device` is the HIP
+ * device ordinal.  One context per device; contexts are independent.
+ */
+int afq_create(const afq_config* cfg, const uint32_t* tid_to_gid, uint32_t ref_count, int device,
+               afq_ctx** out);
+void afq_destroy(afq_ctx* ctx);
+
+/*
+ * Replaces handing a MetaChunk of cells to a worker (src/quant.rs:733-757).
+ * `bytes` are collated-RAD chunks exactly as on disk, back to back or not:
+ * chunk i starts at bytes[chunk_off[i]] with its 8-byte header
+ * (nbytes:u32 incl. header, nrec:u32; src/convert.rs:473-481) followed by nrec
+ * records `na:u32, bc, umi, na x u32(ori<<31|ref)` (src/convert.rs:124-144).
+ * One chunk = one cell.  The caller keeps ownership; the bytes are copied to
+ * the device before return.  Results are produced asynchronously on the
+ * context's stream; afq_collect waits for them.
+ */
+int afq_submit(afq_ctx* ctx, const uint8_t* bytes, size_t n_bytes, const uint64_t* chunk_off,
+               uint32_t n_cells, uint64_t first_cell_index);
+
+/*
+ * Same, for chunk bytes already resident in this context's device memory
+ * (what a host that overlaps H2D itself would use; bench.py times this form).
+ * `d_bytes` must stay valid until afq_collect returns.  `chunk_off` is host
+ * memory.
+ */
+int afq_submit_device(afq_ctx* ctx, const void* d_bytes, size_t n_bytes, const uint64_t* chunk_off,
+                      uint32_t n_cells, uint64_t first_cell_index);
+
+/* Waits for the submitted batch and returns its rows (src/quant.rs:1131-1179, 1266-1268). */
+int afq_collect(afq_ctx* ctx, afq_result* out);
+void afq_result_release(afq_result* res);
+
+/*
+ * Per-cell fragment de-duplication of `alevin-fry atac deduplicate`
+ * (src/atac/deduplicate.rs:199-237, HitInfo order src/atac/sort.rs:37-64).
+ * Input per cell: the (ref, start, frag_len) of every record that has exactly
+ * one alignment of map_type 4; output: distinct fragments in
+ * (ref,start,frag_len) order with their multiplicity (u16, as in the reference).
+ * `cell_ptr` has n_cells+1 entries.  Output arrays are malloc'd; free with
+ * afq_free().
+ */
+int afq_atac_dedup(afq_ctx* ctx, const uint32_t* ref, const uint32_t* start,
+                   const uint16_t* frag_len, const uint64_t* cell_ptr, uint32_t n_cells,
+                   uint64_t** out_cell_ptr, uint32_t** out_ref, uint32_t** out_start,
+                   uint16_t** out_frag_len, uint16_t** out_count);
+void afq_free(void* p);
+
+/*
+ * Kernel timing of the last collected batch (HIP events on the context's own
+ * stream; only when cfg.profile != 0).  Fills up to `cap` entries; returns the
+ * number of kernels, or a negative error.  `name[i]` points to static storage.
+ */
+typedef struct afq_kernel_time {
+    const char* name;
+    double ms;       /* summed over launches   */
+    uint32_t launches;
+    uint32_t pad;
+} afq_kernel_time;
+int afq_get_kernel_times(afq_ctx* ctx, afq_kernel_time* out, uint32_t cap);
+
+/* Number of records / keys the last collected batch processed (for the bench's byte model). */
+typedef struct afq_batch_stats {
+    uint64_t n_records;
+    uint64_t n_ref_words;  /* sum of na                                            */
+    uint64_t n_keys;       /* (umi,gene) pairs after per-read gene dedup           */
+    uint64_t n_buckets;
+    uint64_t n_overflow_buckets;
+    uint64_t input_bytes;
+} afq_batch_stats;
+int afq_get_batch_stats(afq_ctx* ctx, afq_batch_stats* out);
+
+const char* afq_last_error(const afq_ctx* ctx); /* ctx may be NULL: last create error */
+int afq_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AFQUANT_H */

@@ -1,0 +1,116 @@
+"""ctypes binding of the CPU oracle (oracle/libafq_oracle.so).
+
+TEST INFRASTRUCTURE: import only from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Never from the product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import importlib
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_pkg = importlib.import_module("alevin-fry_amd")
+_abi = _pkg._abi
+_afq = importlib.import_module("alevin-fry_amd.afquant")
+
+LIB_PATH = os.path.join(_HERE, "libafq_oracle.so")
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        p = C.POINTER
+        L.ora_quant.argtypes = [p(_abi.AfqConfig), p(C.c_uint32), C.c_uint32, C.c_void_p, C.c_size_t, p(C.c_uint64),
+                                C.c_uint32, C.c_uint64, C.c_int, p(_abi.AfqResult)]
+        L.ora_quant.restype = C.c_int
+        L.ora_result_release.argtypes = [p(_abi.AfqResult)]
+        L.ora_result_em_iters.argtypes = [p(_abi.AfqResult)]
+        L.ora_result_em_iters.restype = p(C.c_uint32)
+        L.ora_last_error.restype = C.c_char_p
+        L.ora_em.argtypes = [p(C.c_uint32), p(C.c_uint32), p(C.c_uint32), C.c_uint32, C.c_uint32, C.c_int, C.c_int,
+                             C.c_int, C.c_uint32, C.c_uint32, C.c_int, p(C.c_float), p(C.c_uint32)]
+        L.ora_em.restype = C.c_int
+        L.ora_has_edge.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int]
+        L.ora_has_edge.restype = C.c_int
+        L.ora_atac_dedup.argtypes = [p(C.c_uint32), p(C.c_uint32), p(C.c_uint16), p(C.c_uint64), C.c_uint32,
+                                     p(C.c_uint64), p(C.c_uint32), p(C.c_uint32), p(C.c_uint16), p(C.c_uint16)]
+        L.ora_atac_dedup.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+class OracleError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"oracle error {code}: {msg}")
+        self.code = code
+
+
+def quant(cfg, tid_to_gid, chunk_bytes, chunk_off, first_cell_index=0, force_route=0, want_iters=False):
+    """cfg: WorkerConfig.  Returns QuantResult (same container as the product)."""
+    L = lib()
+    ccfg = cfg.to_c()
+    t2g = np.ascontiguousarray(tid_to_gid, dtype=np.uint32)
+    b = np.ascontiguousarray(np.frombuffer(chunk_bytes, dtype=np.uint8) if not isinstance(chunk_bytes, np.ndarray) else chunk_bytes)
+    off = np.ascontiguousarray(chunk_off, dtype=np.uint64)
+    res = _abi.AfqResult()
+    rc = L.ora_quant(C.byref(ccfg), t2g.ctypes.data_as(C.POINTER(C.c_uint32)), len(t2g), b.ctypes.data_as(C.c_void_p),
+                     b.nbytes, off.ctypes.data_as(C.POINTER(C.c_uint64)), len(off), first_cell_index, force_route,
+                     C.byref(res))
+    if rc != 0:
+        raise OracleError(rc, L.ora_last_error().decode())
+    try:
+        out = _afq.result_from_c(res)
+        if want_iters:
+            n = out.n_cells
+            it = np.ctypeslib.as_array(L.ora_result_em_iters(C.byref(res)), shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+            return out, it
+        return out
+    finally:
+        L.ora_result_release(C.byref(res))
+
+
+def em(labels, counts, num_alphas, only_unique=False, init_uniform=False, usa_offsets=None, dense=False):
+    """labels: list of label lists; counts: per-class counts.  Returns (alphas f32[num_alphas], iters)."""
+    L = lib()
+    flat = np.asarray([x for l in labels for x in l], dtype=np.uint32)
+    start = np.zeros(len(labels) + 1, dtype=np.uint32)
+    start[1:] = np.cumsum([len(l) for l in labels])
+    cnt = np.asarray(counts, dtype=np.uint32)
+    out = np.zeros(num_alphas, dtype=np.float32)
+    iters = C.c_uint32(0)
+    uo, ao = usa_offsets if usa_offsets else (0, 0)
+    p32 = C.POINTER(C.c_uint32)
+    L.ora_em(flat.ctypes.data_as(p32), start.ctypes.data_as(p32), cnt.ctypes.data_as(p32), len(labels), num_alphas,
+             int(only_unique), int(init_uniform), int(usa_offsets is not None), uo, ao, int(dense),
+             out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(iters))
+    return out, iters.value
+
+
+def has_edge(xu, xc, yu, yc, exact=False):
+    return lib().ora_has_edge(xu, xc, yu, yc, int(exact))
+
+
+def atac_dedup(ref, start, frag_len, cell_ptr):
+    L = lib()
+    ref = np.ascontiguousarray(ref, np.uint32); start = np.ascontiguousarray(start, np.uint32)
+    frag_len = np.ascontiguousarray(frag_len, np.uint16); cell_ptr = np.ascontiguousarray(cell_ptr, np.uint64)
+    n = len(ref); nc = len(cell_ptr) - 1
+    o_ptr = np.zeros(nc + 1, np.uint64); o_ref = np.zeros(n, np.uint32); o_start = np.zeros(n, np.uint32)
+    o_len = np.zeros(n, np.uint16); o_cnt = np.zeros(n, np.uint16)
+    a = lambda x, t: x.ctypes.data_as(C.POINTER(t))
+    L.ora_atac_dedup(a(ref, C.c_uint32), a(start, C.c_uint32), a(frag_len, C.c_uint16), a(cell_ptr, C.c_uint64), nc,
+                     a(o_ptr, C.c_uint64), a(o_ref, C.c_uint32), a(o_start, C.c_uint32), a(o_len, C.c_uint16), a(o_cnt, C.c_uint16))
+    m = int(o_ptr[-1])
+    return o_ptr, o_ref[:m], o_start[:m], o_len[:m], o_cnt[:m]
