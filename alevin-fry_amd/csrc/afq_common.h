@@ -1,0 +1,60 @@
+// afq_common.h — layouts shared by the host planner (afq_api.cpp) and the gfx950
+// kernels (afq_kernels.hip).  Product code; nothing here touches oracle/.
+#pragma once
+#include <stdint.h>
+
+namespace afq {
+
+// ---- key layout -----------------------------------------------------------
+// One key per (read, distinct gene of the read): umi << 20 | gene.  Sorting keys
+// ascending is the (umi, gene) order the reference sorts its triplets in
+// (src/pugutils.rs:652).  20 gene bits cover USA gene-id spaces up to 2^20;
+// 44 UMI bits cover UMIs up to 22 nt.  Wider inputs are refused, not truncated.
+constexpr int kGeneBits = 20;
+constexpr uint32_t kGeneMask = (1u << kGeneBits) - 1u;
+constexpr int kUmiBits = 64 - kGeneBits;
+constexpr uint64_t kKeySentinel = ~0ull;
+
+// ---- bucket geometry ------------------------------------------------------
+// A cell's keys are split into 2^lg_nb buckets by a multiplicative hash of the
+// UMI (all keys of one UMI share a bucket, which is all cr-like needs); one
+// workgroup sorts and resolves one bucket in LDS.
+constexpr uint32_t kBucketCap = 2048;    // keys a bucket workgroup holds in LDS
+constexpr uint32_t kBucketTarget = 512;  // planned mean keys per bucket
+constexpr uint32_t kMaxLgNb = 20;
+constexpr uint64_t kHashMul = 0x9E3779B97F4A7C15ull;
+
+__host__ __device__ inline uint32_t bucket_of(uint64_t umi, uint32_t lg_nb) {
+    return lg_nb == 0 ? 0u : (uint32_t)((umi * kHashMul) >> (64 - lg_nb));
+}
+
+// Per-cell plan computed on the host from the chunk header.
+struct CellMeta {
+    uint64_t chunk_off;    // byte offset of the chunk header in the input
+    uint64_t key_off;      // first slot of this cell in keys0/keys1 (capacity n_ref)
+    uint32_t nbytes;       // chunk size incl. 8-byte header
+    uint32_t nrec;
+    uint32_t n_ref;        // sum of na = key capacity
+    uint32_t bucket_base;  // first global bucket id of the cell
+    uint32_t lg_nb;        // log2(#buckets)
+    int32_t dense_row;     // row in the dense count scratch, -1 for single-bucket cells
+};
+
+// device-side error / statistics block
+struct DevStatus {
+    uint32_t err_code;       // first error (0 = none)
+    uint32_t err_cell;
+    uint32_t n_overflow;     // buckets larger than kBucketCap
+    uint32_t pad;
+    unsigned long long n_keys;
+};
+
+constexpr uint32_t kErrRecordWalk = 1;   // records do not tile the chunk
+constexpr uint32_t kErrRefRange = 2;     // ref id >= ref_count
+constexpr uint32_t kErrUmiWide = 3;      // UMI needs more than kUmiBits bits
+constexpr uint32_t kErrGeneRange = 4;    // gene id >= 2^kGeneBits or >= num_genes
+constexpr uint32_t kErrSlotRange = 5;    // resolved slot >= num_rows
+
+struct OverflowEnt { uint32_t bucket; uint32_t n; };
+
+}  // namespace afq

@@ -1,0 +1,653 @@
+// afq_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the quant hot path.
+//
+// Pipeline for winner-take-all ("cr-like") resolution of a batch of cells
+// (replaces src/quant.rs:469-657 / src/pugutils.rs:644-850 / src/utils.rs:673-756
+// of the reference; semantics: SURVEY.md appendix B.2):
+//   k_decode        raw collated-RAD chunk bytes -> (umi<<20|gene) keys, one per
+//                   (read, distinct gene); one wave walks one chunk window by window
+//   k_bucket_scan   per-cell exclusive scan of the UMI-hash bucket histogram
+//   k_scatter       keys -> per-(cell,bucket) ranges
+//   k_resolve       one workgroup per bucket: LDS bitonic sort, run-length count of
+//                   (umi,gene), per-UMI arg-max with ties, USA slot rules, then
+//                   either finishes the cell in LDS (single-bucket cells) or adds
+//                   into the cell's dense count row (multi-bucket cells)
+//   k_resolve_big   same algorithm out of global scratch for buckets over the LDS cap
+//   k_extract_dense dense row -> sorted (column,count) pairs
+//   k_compact       per-cell pairs -> final CSR
+// Integer/byte work bound by HBM and LDS; no MFMA anywhere by design.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "afq_common.h"
+#include "afq_kernels.h"
+
+namespace afq {
+
+// ---------------------------------------------------------------------------
+// wave / block primitives (wave = 64 lanes)
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t& total) {
+    uint32_t x = v;
+    const uint32_t lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t y = __shfl_up(x, d);
+        if (lane >= (uint32_t)d) x += y;
+    }
+    total = __shfl(x, 63);
+    return x - v;
+}
+
+// exclusive scan over the NT threads of a block; ws needs NT/64 words of LDS.
+template <int NT>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* ws, uint32_t& total) {
+    constexpr int NW = NT / 64;
+    uint32_t wtot;
+    uint32_t ex = wave_excl_scan(v, wtot);
+    const uint32_t w = threadIdx.x >> 6;
+    __syncthreads();  // ws may still be read from a previous call
+    if (lane_id() == 63) ws[w] = wtot;
+    __syncthreads();
+    uint32_t pre = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        uint32_t t = ws[i];
+        if ((uint32_t)i < w) pre += t;
+        tot += t;
+    }
+    total = tot;
+    return pre + ex;
+}
+
+// Normalised bitonic network: every comparator is ascending, so positions >= n
+// behave as +inf without being stored and any n (not only powers of two) sorts
+// in place.  Barrier after every stage.
+template <int NT, typename T>
+__device__ __forceinline__ void bitonic_sort(T* a, uint32_t n) {
+    if (n < 2) return;
+    uint32_t np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    const uint32_t half = np2 >> 1;
+    for (uint32_t k = 2; k <= np2; k <<= 1) {
+        const uint32_t hk = k >> 1;
+        // mirror stage
+        for (uint32_t i = threadIdx.x; i < half; i += NT) {
+            uint32_t blk = i / hk, o = i - blk * hk;
+            uint32_t l = blk * k + o, r = blk * k + (k - 1 - o);
+            if (r < n) {
+                T x = a[l], y = a[r];
+                if (x > y) { a[l] = y; a[r] = x; }
+            }
+        }
+        __syncthreads();
+        for (uint32_t j = hk >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < half; i += NT) {
+                uint32_t l = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                uint32_t r = l + j;
+                if (r < n) {
+                    T x = a[l], y = a[r];
+                    if (x > y) { a[l] = y; a[r] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// little-endian field loads at arbitrary byte alignment
+template <int W>
+__device__ __forceinline__ uint64_t ld_le(const uint8_t* p) {
+    if constexpr (W == 4) {
+        if ((((uintptr_t)p) & 3) == 0) return *(const uint32_t*)p;
+    }
+    if constexpr (W == 8) {
+        if ((((uintptr_t)p) & 7) == 0) return *(const uint64_t*)p;
+    }
+    uint64_t v = 0;
+#pragma unroll
+    for (int i = 0; i < W; ++i) v |= (uint64_t)p[i] << (8 * i);
+    return v;
+}
+__device__ __forceinline__ uint32_t ld_u32(const uint8_t* p, bool aligned) {
+    if (aligned) return *(const uint32_t*)p;
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+__device__ __forceinline__ void set_err(DevStatus* st, uint32_t code, uint32_t cell) {
+    if (atomicCAS(&st->err_code, 0u, code) == 0u) st->err_cell = cell;
+}
+
+// ---------------------------------------------------------------------------
+// chunk headers of device-resident input -> (nbytes, nrec) per cell
+__global__ void k_gather_headers(const uint8_t* __restrict__ bytes, size_t n_bytes,
+                                 const uint64_t* __restrict__ chunk_off, uint32_t n_cells,
+                                 uint32_t* __restrict__ hdr) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cells) return;
+    uint64_t off = chunk_off[i];
+    uint32_t a = 0, b = 0;
+    if (off + 8 <= n_bytes) {
+        a = (uint32_t)ld_le<4>(bytes + off);
+        b = (uint32_t)ld_le<4>(bytes + off + 4);
+    }
+    hdr[2 * i] = a;
+    hdr[2 * i + 1] = b;
+}
+
+// ---------------------------------------------------------------------------
+// k_decode: one wave per chunk.  The record stream has no self-synchronisation
+// (a record's length is its own na field), so the wave walks it: each 256-byte
+// window is loaded coalesced (one dword per lane), a scalar loop follows
+// na -> next-record with v_readlane, marking the lanes whose dword starts a
+// record; those lanes then decode their record in parallel (gene projection =
+// the per-read sort+dedup of src/pugutils.rs:774-781, done as first-occurrence
+// dedup since the key order is re-established by the bucket sort).
+template <int BW, int UW>
+__global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ bytes, size_t n_bytes,
+                                               const CellMeta* __restrict__ meta, uint32_t n_cells,
+                                               const uint32_t* __restrict__ t2g, uint32_t ref_count,
+                                               uint32_t num_genes, uint64_t* __restrict__ keys0,
+                                               uint32_t* __restrict__ cell_nkeys,
+                                               uint32_t* __restrict__ bucket_cnt,
+                                               uint64_t* __restrict__ bc_out, DevStatus* st) {
+    constexpr uint32_t HDR = 4 + BW + UW;
+    constexpr bool AL = (BW % 4 == 0) && (UW % 4 == 0);
+    const uint32_t lane = lane_id();
+    const uint32_t cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (cell >= n_cells) return;
+    const CellMeta m = meta[cell];
+    const uint64_t abase = m.chunk_off & ~3ull;         // dword-aligned base of the walk
+    const uint32_t mis = (uint32_t)(m.chunk_off - abase);
+    uint64_t pos = (uint64_t)mis + 8;                    // next record start, bytes from abase
+    const uint64_t end = (uint64_t)mis + m.nbytes;       // chunk end, bytes from abase
+    const bool al_chunk = AL && mis == 0;
+    uint32_t nk_total = 0, rec_seen = 0;
+    bool bad = false;
+
+    while (pos < end) {
+        const uint64_t w = pos >> 8;  // window index
+        const uint64_t wbyte = abase + (w << 8) + lane * 4;
+        uint32_t v_cur = 0, v_next = 0;
+        if (wbyte + 4 <= n_bytes) v_cur = *(const uint32_t*)(bytes + wbyte);
+        else if (wbyte < n_bytes) { for (uint64_t q = wbyte; q < n_bytes; ++q) v_cur |= (uint32_t)bytes[q] << (8 * (q - wbyte)); }
+        if (!al_chunk) {
+            const uint64_t nb = wbyte + 256;
+            if (nb + 4 <= n_bytes) v_next = *(const uint32_t*)(bytes + nb);
+            else if (nb < n_bytes) { for (uint64_t q = nb; q < n_bytes; ++q) v_next |= (uint32_t)bytes[q] << (8 * (q - nb)); }
+        }
+        const uint64_t wend = ((w + 1) << 8) < end ? ((w + 1) << 8) : end;
+        uint64_t mask = 0, sub0 = 0, sub1 = 0;
+        // scalar walk over the records that start in this window
+        while (pos < wend) {
+            const uint32_t idx = __builtin_amdgcn_readfirstlane((uint32_t)(pos >> 2) & 63u);
+            uint32_t na = __builtin_amdgcn_readlane(v_cur, idx);
+            if (!al_chunk) {
+                const uint32_t sh = ((uint32_t)pos & 3u) * 8u;
+                if (sh) {
+                    uint32_t hi = idx < 63 ? __builtin_amdgcn_readlane(v_cur, idx + 1)
+                                           : __builtin_amdgcn_readlane(v_next, 0);
+                    na = (na >> sh) | (hi << (32 - sh));
+                }
+                if (pos & 1) sub0 |= 1ull << idx;
+                if (pos & 2) sub1 |= 1ull << idx;
+            }
+            mask |= 1ull << idx;
+            const uint64_t rec_bytes = (uint64_t)HDR + 4ull * na;
+            if (pos + rec_bytes > end) { bad = true; pos = end; break; }
+            pos += rec_bytes;
+        }
+        rec_seen += (uint32_t)__popcll(mask);
+
+        // lanes whose dword starts a record decode it
+        const bool is_start = (mask >> lane) & 1ull;
+        uint32_t g[8];
+        uint32_t k = 0, na = 0, kcnt = 0;
+        bool ovf = false;
+        uint64_t umi = 0;
+        const uint8_t* rp = nullptr;
+        if (is_start && !bad) {
+            const uint32_t sub = al_chunk ? 0u : (uint32_t)((sub0 >> lane) & 1ull) | ((uint32_t)((sub1 >> lane) & 1ull) << 1);
+            const uint64_t roff = abase + (w << 8) + lane * 4 + sub;
+            const uint8_t* rec = bytes + roff;
+            na = al_chunk ? v_cur : ld_u32(rec, false);
+            umi = ld_le<UW>(rec + 4 + BW);
+            if (roff == m.chunk_off + 8) bc_out[cell] = ld_le<BW>(rec + 4);
+            if (UW == 8 && (umi >> kUmiBits)) { set_err(st, kErrUmiWide, cell); na = 0; }
+            rp = rec + HDR;
+            const bool ral = ((((uintptr_t)rp) & 3) == 0);
+            for (uint32_t j = 0; j < na; ++j) {
+                uint32_t t = ld_u32(rp + 4 * j, ral) & 0x7FFFFFFFu;
+                if (t >= ref_count) { set_err(st, kErrRefRange, cell); continue; }
+                uint32_t gid = t2g[t];
+                if (gid >= num_genes) { set_err(st, kErrGeneRange, cell); continue; }
+                bool dup = false;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dup |= ((uint32_t)i < k) && (g[i] == gid);
+                if (!dup) {
+                    if (k < 8) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) if ((uint32_t)i == k) g[i] = gid;
+                        ++k;
+                    } else { ovf = true; break; }
+                }
+            }
+            kcnt = k;
+            if (ovf) {  // > 8 distinct genes: count by first occurrence, O(na^2), rare
+                kcnt = 0;
+                for (uint32_t j = 0; j < na; ++j) {
+                    uint32_t tj = ld_u32(rp + 4 * j, ral) & 0x7FFFFFFFu;
+                    if (tj >= ref_count) continue;
+                    uint32_t gj = t2g[tj];
+                    if (gj >= num_genes) continue;
+                    bool first = true;
+                    for (uint32_t i = 0; i < j && first; ++i) {
+                        uint32_t ti = ld_u32(rp + 4 * i, ral) & 0x7FFFFFFFu;
+                        if (ti < ref_count && t2g[ti] == gj) first = false;
+                    }
+                    kcnt += first;
+                }
+            }
+        }
+        uint32_t tot;
+        const uint32_t ex = wave_excl_scan(kcnt, tot);
+        if (kcnt) {
+            const uint32_t o0 = nk_total + ex;
+            uint64_t* dst = keys0 + m.key_off;
+            const uint32_t bslot = m.bucket_base + bucket_of(umi, m.lg_nb);
+            if (o0 + kcnt <= m.n_ref) {
+                if (!ovf) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if ((uint32_t)i < k) dst[o0 + i] = (umi << kGeneBits) | g[i];
+                } else {
+                    const bool ral = ((((uintptr_t)rp) & 3) == 0);
+                    uint32_t o = o0;
+                    for (uint32_t j = 0; j < na; ++j) {
+                        uint32_t tj = ld_u32(rp + 4 * j, ral) & 0x7FFFFFFFu;
+                        if (tj >= ref_count) continue;
+                        uint32_t gj = t2g[tj];
+                        if (gj >= num_genes) continue;
+                        bool first = true;
+                        for (uint32_t i = 0; i < j && first; ++i) {
+                            uint32_t ti = ld_u32(rp + 4 * i, ral) & 0x7FFFFFFFu;
+                            if (ti < ref_count && t2g[ti] == gj) first = false;
+                        }
+                        if (first) dst[o++] = (umi << kGeneBits) | gj;
+                    }
+                }
+                if (m.lg_nb) atomicAdd(&bucket_cnt[bslot], kcnt);
+            } else bad = true;
+        }
+        nk_total += tot;
+        bad = __any(bad);
+        if (bad) break;
+    }
+    if (bad || pos != end || rec_seen != m.nrec) {
+        if (lane == 0) set_err(st, kErrRecordWalk, cell);
+        nk_total = 0;
+    }
+    if (lane == 0) {
+        cell_nkeys[cell] = nk_total;
+        atomicAdd(&st->n_keys, (unsigned long long)nk_total);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// per-cell exclusive scan of bucket counts (in place): wave per multi-bucket cell
+__global__ __launch_bounds__(256) void k_bucket_scan(const uint32_t* __restrict__ multi_cells, uint32_t n_multi,
+                                                    const CellMeta* __restrict__ meta,
+                                                    uint32_t* __restrict__ bucket_cnt) {
+    const uint32_t ci = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ci >= n_multi) return;
+    const CellMeta m = meta[multi_cells[ci]];
+    const uint32_t nb = 1u << m.lg_nb;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nb; base += 64) {
+        const uint32_t i = base + lane_id();
+        uint32_t c = i < nb ? bucket_cnt[m.bucket_base + i] : 0u, tot;
+        uint32_t ex = wave_excl_scan(c, tot);
+        if (i < nb) bucket_cnt[m.bucket_base + i] = carry + ex;
+        carry += tot;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// keys0 -> keys1 grouped by bucket.  After the kernel cursor[b] = end offset of
+// bucket b inside its cell's region (start = previous bucket's end).
+constexpr uint32_t kScatterTile = kScatterTileHost;
+__global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ multi_cells,
+                                                const uint32_t* __restrict__ tile_prefix, uint32_t n_multi,
+                                                const CellMeta* __restrict__ meta,
+                                                const uint32_t* __restrict__ cell_nkeys,
+                                                const uint64_t* __restrict__ keys0, uint64_t* __restrict__ keys1,
+                                                uint32_t* __restrict__ cursor) {
+    // binary search: tile_prefix[ci] <= blockIdx.x < tile_prefix[ci+1]
+    uint32_t lo = 0, hi = n_multi;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (tile_prefix[mid] <= blockIdx.x) lo = mid; else hi = mid;
+    }
+    const uint32_t cell = multi_cells[lo];
+    const CellMeta m = meta[cell];
+    const uint32_t nk = cell_nkeys[cell];
+    const uint32_t t0 = (blockIdx.x - tile_prefix[lo]) * kScatterTile;
+    const uint32_t t1 = min(nk, t0 + kScatterTile);
+    const uint64_t* src = keys0 + m.key_off;
+    uint64_t* dst = keys1 + m.key_off;
+    for (uint32_t i = t0 + threadIdx.x; i < t1; i += 256) {
+        const uint64_t key = src[i];
+        const uint32_t b = bucket_of(key >> kGeneBits, m.lg_nb);
+        const uint32_t p = atomicAdd(&cursor[m.bucket_base + b], 1u);
+        dst[p] = key;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// resolve core, shared by the LDS and the global-scratch variants.
+struct ResolveCfg {
+    uint32_t usa, num_rows, uo, ao, row_stride;
+};
+
+__device__ __forceinline__ bool is_spliced(uint32_t g) { return (g & 1u) == 0; }
+__device__ __forceinline__ bool same_gene(uint32_t a, uint32_t b) { return (a & ~1u) == (b & ~1u); }
+
+// keys[0..n) sorted ascending.  Builds run starts, then for every UMI picks the
+// winner / tie set and maps it to an output column (non-USA: unique winner only,
+// src/quant.rs:563-565; USA: src/utils.rs:688-753 == src/quant.rs:557-605).
+// emit(col) is called once per resolved UMI.
+template <int NT, typename Emit>
+__device__ __forceinline__ void resolve_sorted(const uint64_t* keys, uint32_t n, uint32_t* run_start,
+                                               uint32_t* ws, const ResolveCfg& rc, Emit&& emit) {
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n; base += NT) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t f = (i < n) && (i == 0 || keys[i] != keys[i - 1]);
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<NT>(f, ws, tot);
+        if (f) run_start[carry + ex] = i;
+        carry += tot;
+    }
+    const uint32_t nruns = carry;
+    if (threadIdx.x == 0) run_start[nruns] = n;
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < nruns; r += NT) {
+        const uint64_t umi = keys[run_start[r]] >> kGeneBits;
+        if (r > 0 && (keys[run_start[r - 1]] >> kGeneBits) == umi) continue;  // not the UMI's first run
+        uint32_t maxc = 0;
+        for (uint32_t q = r; q < nruns; ++q) {
+            const uint32_t s = run_start[q];
+            if ((keys[s] >> kGeneBits) != umi) break;
+            const uint32_t c = run_start[q + 1] - s;
+            maxc = c > maxc ? c : maxc;
+        }
+        uint32_t nb = 0, g1 = 0, g2 = 0, nsp = 0, first_sp = 0;
+        bool prev_first_sp = false, sp_followed = false;
+        for (uint32_t q = r; q < nruns; ++q) {
+            const uint32_t s = run_start[q];
+            const uint64_t kq = keys[s];
+            if ((kq >> kGeneBits) != umi) break;
+            if (run_start[q + 1] - s != maxc) continue;
+            const uint32_t g = (uint32_t)kq & kGeneMask;
+            ++nb;
+            if (nb == 1) g1 = g;
+            if (nb == 2) g2 = g;
+            if (prev_first_sp) { sp_followed = same_gene(first_sp, g); prev_first_sp = false; }
+            if (is_spliced(g)) {
+                ++nsp;
+                if (nsp == 1) { first_sp = g; prev_first_sp = true; }
+            }
+        }
+        uint32_t col = 0xFFFFFFFFu;
+        if (!rc.usa) {
+            if (nb == 1) col = g1;
+        } else if (nb == 1) {
+            col = is_spliced(g1) ? (g1 >> 1) : rc.uo + (g1 >> 1);
+        } else if (nb == 2) {
+            if (same_gene(g1, g2)) col = rc.ao + (g1 >> 1);
+            else if (is_spliced(g1) && !is_spliced(g2)) col = g1 >> 1;
+            else if (!is_spliced(g1) && is_spliced(g2)) col = g2 >> 1;
+        } else if (nb <= 10) {
+            if (nsp == 1) col = sp_followed ? rc.ao + (first_sp >> 1) : (first_sp >> 1);
+        }
+        if (col != 0xFFFFFFFFu) emit(col);
+    }
+}
+
+constexpr int kResolveNT = 256;
+
+__global__ __launch_bounds__(kResolveNT) void k_resolve(const CellMeta* __restrict__ meta,
+                                                       const uint32_t* __restrict__ bucket_cell,
+                                                       const uint32_t* __restrict__ cell_nkeys,
+                                                       const uint32_t* __restrict__ cursor,
+                                                       uint64_t* __restrict__ keys0,
+                                                       const uint64_t* __restrict__ keys1,
+                                                       uint32_t* __restrict__ dense, uint32_t* __restrict__ nnz,
+                                                       OverflowEnt* __restrict__ ovf_list, DevStatus* st,
+                                                       ResolveCfg rc) {
+    __shared__ uint64_t s_keys[kBucketCap];
+    __shared__ uint32_t s_run[kBucketCap + 1];
+    __shared__ uint32_t s_cols[kBucketCap];
+    __shared__ uint32_t s_ws[kResolveNT / 64];
+    __shared__ uint32_t s_ncols;
+    const uint32_t b = blockIdx.x;
+    const uint32_t cell = bucket_cell[b];
+    const CellMeta m = meta[cell];
+    const uint64_t* src;
+    uint32_t n;
+    if (m.lg_nb == 0) {
+        src = keys0 + m.key_off;
+        n = cell_nkeys[cell];
+    } else {
+        const uint32_t beg = (b == m.bucket_base) ? 0u : cursor[b - 1];
+        const uint32_t end = cursor[b];
+        src = keys1 + m.key_off + beg;
+        n = end - beg;
+    }
+    if (n == 0) {
+        if (m.lg_nb == 0 && threadIdx.x == 0) nnz[cell] = 0;
+        return;
+    }
+    if (n > kBucketCap) {  // only multi-bucket cells can get here (planner keeps single buckets <= target)
+        if (threadIdx.x == 0) {
+            uint32_t k = atomicAdd(&st->n_overflow, 1u);
+            ovf_list[k].bucket = b;
+            ovf_list[k].n = n;
+        }
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += kResolveNT) s_keys[i] = src[i];
+    if (threadIdx.x == 0) s_ncols = 0;
+    __syncthreads();
+    bitonic_sort<kResolveNT>(s_keys, n);
+    if (m.lg_nb != 0) {
+        uint32_t* row = dense + (size_t)m.dense_row * rc.row_stride;
+        resolve_sorted<kResolveNT>(s_keys, n, s_run, s_ws, rc, [&](uint32_t col) {
+            if (col >= rc.num_rows) { set_err(st, kErrSlotRange, cell); return; }
+            atomicAdd(&row[col], 1u);
+        });
+        return;
+    }
+    // single-bucket cell: finish here.  columns -> LDS, sort, run-length, write pairs
+    resolve_sorted<kResolveNT>(s_keys, n, s_run, s_ws, rc, [&](uint32_t col) {
+        if (col >= rc.num_rows) { set_err(st, kErrSlotRange, cell); return; }
+        s_cols[atomicAdd(&s_ncols, 1u)] = col;
+    });
+    __syncthreads();
+    const uint32_t nc = s_ncols;
+    bitonic_sort<kResolveNT>(s_cols, nc);
+    uint2* out = reinterpret_cast<uint2*>(keys0 + m.key_off);  // the cell's key slots are dead: reuse as pair staging
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nc; base += kResolveNT) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t f = (i < nc) && (i == 0 || s_cols[i] != s_cols[i - 1]);
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<kResolveNT>(f, s_ws, tot);
+        if (f) s_run[carry + ex] = i;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) { s_run[carry] = nc; nnz[cell] = carry; }
+    __syncthreads();
+    for (uint32_t h = threadIdx.x; h < carry; h += kResolveNT)
+        out[h] = make_uint2(s_cols[s_run[h]], s_run[h + 1] - s_run[h]);
+}
+
+// Buckets larger than the LDS cap (heavy PCR duplication of one UMI, adversarial
+// input): same algorithm with the bucket sorted in place in keys1 and the run
+// table in the matching, dead window of keys0.  Persistent blocks loop over the
+// overflow list; with no overflow every block exits at once.
+constexpr int kBigNT = 1024;
+__global__ __launch_bounds__(kBigNT) void k_resolve_big(const CellMeta* __restrict__ meta,
+                                                       const uint32_t* __restrict__ bucket_cell,
+                                                       const uint32_t* __restrict__ cursor,
+                                                       uint64_t* __restrict__ keys0, uint64_t* __restrict__ keys1,
+                                                       uint32_t* __restrict__ dense,
+                                                       const OverflowEnt* __restrict__ ovf_list, DevStatus* st,
+                                                       ResolveCfg rc) {
+    __shared__ uint32_t s_ws[kBigNT / 64];
+    const uint32_t novf = st->n_overflow;
+    for (uint32_t e = blockIdx.x; e < novf; e += gridDim.x) {
+        const uint32_t b = ovf_list[e].bucket;
+        const uint32_t cell = bucket_cell[b];
+        const CellMeta m = meta[cell];
+        const uint32_t beg = (b == m.bucket_base) ? 0u : cursor[b - 1];
+        const uint32_t n = cursor[b] - beg;
+        uint64_t* keys = keys1 + m.key_off + beg;
+        uint32_t* run = reinterpret_cast<uint32_t*>(keys0 + m.key_off + beg);  // 2n words >= n+1
+        __syncthreads();
+        bitonic_sort<kBigNT>(keys, n);
+        uint32_t* row = dense + (size_t)m.dense_row * rc.row_stride;
+        resolve_sorted<kBigNT>(keys, n, run, s_ws, rc, [&](uint32_t col) {
+            if (col >= rc.num_rows) { set_err(st, kErrSlotRange, cell); return; }
+            atomicAdd(&row[col], 1u);
+        });
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// dense count row of a multi-bucket cell -> ascending (column,count) pairs
+__global__ __launch_bounds__(256) void k_extract_dense(const uint32_t* __restrict__ multi_cells,
+                                                      const CellMeta* __restrict__ meta,
+                                                      const uint32_t* __restrict__ dense, uint64_t* __restrict__ keys0,
+                                                      uint32_t* __restrict__ nnz, ResolveCfg rc) {
+    __shared__ uint32_t s_ws[4];
+    const uint32_t cell = multi_cells[blockIdx.x];
+    const CellMeta m = meta[cell];
+    const uint4* row = reinterpret_cast<const uint4*>(dense + (size_t)m.dense_row * rc.row_stride);
+    uint2* out = reinterpret_cast<uint2*>(keys0 + m.key_off);
+    const uint32_t nq = rc.row_stride >> 2;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nq; base += 256) {
+        const uint32_t q = base + threadIdx.x;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (q < nq) v = row[q];
+        const uint32_t c = (v.x != 0) + (v.y != 0) + (v.z != 0) + (v.w != 0);
+        uint32_t tot;
+        uint32_t o = carry + block_excl_scan<256>(c, s_ws, tot);
+        if (c) {
+            const uint32_t col = q << 2;
+            if (v.x) out[o++] = make_uint2(col, v.x);
+            if (v.y) out[o++] = make_uint2(col + 1, v.y);
+            if (v.z) out[o++] = make_uint2(col + 2, v.z);
+            if (v.w) out[o++] = make_uint2(col + 3, v.w);
+        }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) nnz[cell] = carry;
+}
+
+// ---------------------------------------------------------------------------
+// staging pairs -> final CSR (wave per cell)
+__global__ __launch_bounds__(256) void k_compact(const CellMeta* __restrict__ meta, uint32_t n_cells,
+                                                const uint64_t* __restrict__ keys0,
+                                                const uint32_t* __restrict__ nnz,
+                                                const uint64_t* __restrict__ cell_ptr, uint32_t* __restrict__ gene,
+                                                float* __restrict__ val) {
+    const uint32_t cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (cell >= n_cells) return;
+    const uint2* src = reinterpret_cast<const uint2*>(keys0 + meta[cell].key_off);
+    const uint32_t n = nnz[cell];
+    const uint64_t o = cell_ptr[cell];
+    for (uint32_t i = lane_id(); i < n; i += 64) {
+        const uint2 p = src[i];
+        gene[o + i] = p.x;
+        val[o + i] = (float)p.y;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+#define AFQ_LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
+
+void launch_gather_headers(hipStream_t s, const uint8_t* bytes, size_t n_bytes, const uint64_t* chunk_off,
+                           uint32_t n_cells, uint32_t* hdr) {
+    if (!n_cells) return;
+    AFQ_LAUNCH(k_gather_headers, (n_cells + 255) / 256, 256, s, bytes, n_bytes, chunk_off, n_cells, hdr);
+}
+
+template <int BW, int UW>
+static void launch_decode_t(hipStream_t s, const DecodeArgs& a) {
+    AFQ_LAUNCH((k_decode<BW, UW>), (a.n_cells + 3) / 4, 256, s, a.bytes, a.n_bytes, a.meta, a.n_cells, a.t2g,
+               a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bucket_cnt, a.bc_out, a.st);
+}
+
+int launch_decode(hipStream_t s, const DecodeArgs& a, uint32_t bw, uint32_t uw) {
+    if (!a.n_cells) return 0;
+#define AFQ_CASE(B, U) if (bw == B && uw == U) { launch_decode_t<B, U>(s, a); return 0; }
+    AFQ_CASE(4, 4) AFQ_CASE(4, 8) AFQ_CASE(8, 4) AFQ_CASE(8, 8)
+    AFQ_CASE(1, 1) AFQ_CASE(1, 2) AFQ_CASE(1, 4) AFQ_CASE(1, 8)
+    AFQ_CASE(2, 1) AFQ_CASE(2, 2) AFQ_CASE(2, 4) AFQ_CASE(2, 8)
+    AFQ_CASE(4, 1) AFQ_CASE(4, 2) AFQ_CASE(8, 1) AFQ_CASE(8, 2)
+#undef AFQ_CASE
+    return -1;
+}
+
+void launch_bucket_scan(hipStream_t s, const uint32_t* multi_cells, uint32_t n_multi, const CellMeta* meta,
+                        uint32_t* bucket_cnt) {
+    if (!n_multi) return;
+    AFQ_LAUNCH(k_bucket_scan, (n_multi + 3) / 4, 256, s, multi_cells, n_multi, meta, bucket_cnt);
+}
+
+void launch_scatter(hipStream_t s, uint32_t n_tiles, const uint32_t* multi_cells, const uint32_t* tile_prefix,
+                    uint32_t n_multi, const CellMeta* meta, const uint32_t* cell_nkeys, const uint64_t* keys0,
+                    uint64_t* keys1, uint32_t* cursor) {
+    if (!n_tiles) return;
+    AFQ_LAUNCH(k_scatter, n_tiles, 256, s, multi_cells, tile_prefix, n_multi, meta, cell_nkeys, keys0, keys1, cursor);
+}
+
+static ResolveCfg make_rc(const ResolveArgs& a) {
+    ResolveCfg rc;
+    rc.usa = a.usa; rc.num_rows = a.num_rows; rc.uo = a.num_rows / 3; rc.ao = 2 * (a.num_rows / 3);
+    rc.row_stride = a.row_stride;
+    return rc;
+}
+
+void launch_resolve(hipStream_t s, const ResolveArgs& a) {
+    if (!a.n_buckets) return;
+    ResolveCfg rc = make_rc(a);
+    AFQ_LAUNCH(k_resolve, a.n_buckets, kResolveNT, s, a.meta, a.bucket_cell, a.cell_nkeys, a.cursor, a.keys0, a.keys1,
+               a.dense, a.nnz, a.ovf_list, a.st, rc);
+}
+
+void launch_resolve_big(hipStream_t s, const ResolveArgs& a) {
+    if (!a.n_multi) return;
+    ResolveCfg rc = make_rc(a);
+    AFQ_LAUNCH(k_resolve_big, 256, kBigNT, s, a.meta, a.bucket_cell, a.cursor, a.keys0, a.keys1, a.dense, a.ovf_list,
+               a.st, rc);
+}
+
+void launch_extract_dense(hipStream_t s, const ResolveArgs& a) {
+    if (!a.n_multi) return;
+    ResolveCfg rc = make_rc(a);
+    AFQ_LAUNCH(k_extract_dense, a.n_multi, 256, s, a.multi_cells, a.meta, a.dense, a.keys0, a.nnz, rc);
+}
+
+void launch_compact(hipStream_t s, const CellMeta* meta, uint32_t n_cells, const uint64_t* keys0, const uint32_t* nnz,
+                    const uint64_t* cell_ptr, uint32_t* gene, float* val) {
+    if (!n_cells) return;
+    AFQ_LAUNCH(k_compact, (n_cells + 3) / 4, 256, s, meta, n_cells, keys0, nnz, cell_ptr, gene, val);
+}
+
+}  // namespace afq

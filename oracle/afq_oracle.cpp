@@ -545,8 +545,12 @@ static void em_optimize_dense(const GeneEqc& eqc, u32 num_alphas, bool only_uniq
 }
 
 // em_optimize_subset_impl, src/em.rs:306-456 (sparse support; optional USA coupling)
+// `full_support` walks every alpha instead of the cell's support: that is the
+// `dense_reference` of the reference's own unit tests (em.rs:1049-1133), which
+// must agree bit for bit with the sparse-support variant.
 static void em_optimize_subset(const IdxEq& q, u32 num_alphas, bool only_unique, bool init_uniform,
-                               bool usa, u32 uo, u32 ao, std::vector<float>& alphas, u32* iters_out) {
+                               bool usa, u32 uo, u32 ao, std::vector<float>& alphas, u32* iters_out,
+                               bool full_support = false) {
     std::vector<float> ain(num_alphas, 0.0f), aout(num_alphas, 0.0f);
     bool needs_em = false;
     for (size_t c = 0; c + 1 < q.start.size(); ++c) {
@@ -558,7 +562,8 @@ static void em_optimize_subset(const IdxEq& q, u32 num_alphas, bool only_unique,
     // prepare_support, em.rs:87-113
     std::vector<u32> support; std::vector<u8> member(num_alphas, 0);
     auto mark = [&](u32 i) { if (!member[i]) { member[i] = 1; support.push_back(i); } };
-    for (size_t c = 0; c + 1 < q.start.size(); ++c)
+    if (full_support) for (u32 i = 0; i < num_alphas; ++i) mark(i);
+    for (size_t c = 0; c + 1 < q.start.size() && !full_support; ++c)
         for (u32 j = q.start[c]; j < q.start[c + 1]; ++j) {
             u32 idx = q.labels[j];
             mark(idx);
@@ -731,12 +736,13 @@ void ora_result_release(afq_result* r) {
 
 // Stand-alone EM entry points for the em.rs known-answer cases (em.rs:1035-1215).
 // labels/start: CSR of class labels, count per class.  usa: couple S/U/A with
-// offsets (uo, ao).  dense != 0 runs em_optimize (dense), else the subset variant.
+// offsets (uo, ao).  dense: 0 = sparse-support subset variant (em.rs:306-456), 1 = em_optimize
+// (em.rs:487-582), 2 = the subset algorithm over every alpha (dense_reference, em.rs:1049-1133).
 int ora_em(const uint32_t* labels, const uint32_t* start, const uint32_t* count, uint32_t n_classes,
            uint32_t num_alphas, int only_unique, int init_uniform, int usa, uint32_t uo, uint32_t ao,
            int dense, float* alphas_out, uint32_t* iters_out) {
     std::vector<float> a;
-    if (dense) {
+    if (dense == 1) {
         GeneEqc eqc;
         for (uint32_t c = 0; c < n_classes; ++c)
             eqc[std::vector<u32>(labels + start[c], labels + start[c + 1])] += count[c];
@@ -746,7 +752,8 @@ int ora_em(const uint32_t* labels, const uint32_t* start, const uint32_t* count,
         q.labels.assign(labels, labels + start[n_classes]);
         q.start.assign(start, start + n_classes + 1);
         q.count.assign(count, count + n_classes);
-        em_optimize_subset(q, num_alphas, only_unique != 0, init_uniform != 0, usa != 0, uo, ao, a, iters_out);
+        em_optimize_subset(q, num_alphas, only_unique != 0, init_uniform != 0, usa != 0, uo, ao, a, iters_out,
+                           dense == 2 /* dense_reference of em.rs:1049-1133 */);
     }
     std::memcpy(alphas_out, a.data(), sizeof(float) * num_alphas);
     return 0;

@@ -81,7 +81,7 @@ def quant(cfg, tid_to_gid, chunk_bytes, chunk_off, first_cell_index=0, force_rou
         L.ora_result_release(C.byref(res))
 
 
-def em(labels, counts, num_alphas, only_unique=False, init_uniform=False, usa_offsets=None, dense=False):
+def em(labels, counts, num_alphas, only_unique=False, init_uniform=False, usa_offsets=None, dense=0):
     """labels: list of label lists; counts: per-class counts.  Returns (alphas f32[num_alphas], iters)."""
     L = lib()
     flat = np.asarray([x for l in labels for x in l], dtype=np.uint32)

@@ -1,0 +1,55 @@
+"""CPU tests of the boundary: the C-ABI library loads and exports every symbol of include/afquant.h."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from util import ROOT, pkg
+
+
+def test_header_symbols_match_export_list():
+    hdr = open(os.path.join(ROOT, "include", "afquant.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)  # prototypes only, not prose
+    declared = set(re.findall(r"\b(afq_[a-z_]+)\s*\(", hdr))
+    assert declared == set(pkg._abi.EXPORTS)
+
+
+def test_library_exports_every_symbol():
+    path = pkg.afquant.LIB_PATH
+    if not os.path.exists(path):
+        import __graft_entry__ as ge  # noqa
+
+        ge.build()
+    lib = ctypes.CDLL(path)
+    for name in pkg._abi.EXPORTS:
+        assert hasattr(lib, name), name
+    lib.afq_abi_version.restype = ctypes.c_int
+    assert lib.afq_abi_version() == pkg._abi.AFQ_ABI_VERSION
+
+
+def test_config_struct_layout():
+    c = pkg.WorkerConfig.for_resolution("parsimony-em", num_genes=10, num_rows=10).to_c()
+    assert ctypes.sizeof(c) == 16 * 4
+    assert c.resolution == 3 and c.large_graph_thresh == 1000 and c.pug_exact_umi == 0 and c.small_thresh == 100
+    c = pkg.WorkerConfig.for_resolution("cr-like", num_genes=10, num_rows=10).to_c()
+    assert c.resolution == 1 and c.large_graph_thresh == 0 and c.pug_exact_umi == 1
+
+
+def test_create_rejects_bad_arguments_without_a_gpu():
+    """Argument validation happens before any device call, so it is testable on CPU."""
+    lib = pkg.load_library()
+    import numpy as np
+
+    t2g = np.zeros(4, np.uint32)
+    h = ctypes.c_void_p()
+    cfg = pkg.WorkerConfig.for_resolution("cr-like", num_genes=1, num_rows=1, bc_bytes=3).to_c()
+    rc = lib.afq_create(ctypes.byref(cfg), t2g.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), 4, 0, ctypes.byref(h))
+    assert rc == pkg._abi.AFQ_ERR_INVALID_ARG and b"bc_bytes" in lib.afq_last_error(None)
+    cfg = pkg.WorkerConfig.for_resolution("cr-like", usa_mode=True, num_genes=4, num_rows=5).to_c()
+    rc = lib.afq_create(ctypes.byref(cfg), t2g.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), 4, 0, ctypes.byref(h))
+    assert rc == pkg._abi.AFQ_ERR_INVALID_ARG
+    t2g[2] = 9
+    cfg = pkg.WorkerConfig.for_resolution("cr-like", num_genes=4, num_rows=4).to_c()
+    rc = lib.afq_create(ctypes.byref(cfg), t2g.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), 4, 0, ctypes.byref(h))
+    assert rc == pkg._abi.AFQ_ERR_INVALID_ARG and b"tid_to_gid" in lib.afq_last_error(None)

@@ -1,0 +1,160 @@
+"""GPU parity tests (bit-exact): HIP cr-like path through the C ABI vs the CPU oracle."""
+import numpy as np
+import pytest
+
+from util import assert_same_result, cfg_for, load_golden, pkg, rows_of
+
+pytestmark = pytest.mark.gpu
+rad = pkg.rad
+synth = pkg.synth
+
+
+def run_both(oracle, cfg, t2g, b, off):
+    q = pkg.Quantifier(cfg, t2g)
+    try:
+        got = q.quant_chunks(b, off)
+        st = q.batch_stats()
+    finally:
+        q.close()
+    want = oracle.quant(cfg, t2g, b, off)
+    return got, want, st
+
+
+@pytest.mark.parametrize("small_thresh", [0, 100])
+def test_hand_cases(oracle, small_thresh):
+    for case in load_golden("crlike_hand_cases.json")["cases"]:
+        cells = [(c["bc"], [(u, r) for u, r in c["reads"]]) for c in case["cells"]]
+        b, off = rad.encode_cells(cells, 4, 4)
+        cfg = pkg.WorkerConfig.for_resolution("cr-like", usa_mode=case["usa"], num_genes=case["num_genes"],
+                                              num_rows=case["num_rows"], small_thresh=small_thresh)
+        got, want, _ = run_both(oracle, cfg, np.asarray(case["t2g"], np.uint32), b, off)
+        for c, g in zip(case["cells"], rows_of(got)):
+            assert [[int(a), int(v)] for a, v in g] == c["expected"], (case["name"], c["bc"], c["why"])
+        assert_same_result(got, want, what=case["name"])
+
+
+@pytest.mark.parametrize("bw,uw", [(1, 1), (2, 2), (8, 8), (2, 4), (4, 2), (8, 4), (1, 8)])
+def test_field_widths(oracle, bw, uw):
+    """Unaligned record layouts take the byte-granular walk."""
+    case = load_golden("crlike_hand_cases.json")["cases"][0]
+    cells = [(c["bc"], [(u, r) for u, r in c["reads"]]) for c in case["cells"]]
+    b, off = rad.encode_cells(cells, bw, uw)
+    cfg = pkg.WorkerConfig.for_resolution("cr-like", num_genes=4, num_rows=4, bc_bytes=bw, umi_bytes=uw)
+    got, want, _ = run_both(oracle, cfg, np.asarray(case["t2g"], np.uint32), b, off)
+    assert_same_result(got, want)
+    for c, g in zip(case["cells"], rows_of(got)):
+        assert [[int(a), int(v)] for a, v in g] == c["expected"]
+
+
+@pytest.mark.parametrize("usa", [False, True])
+def test_config1_plumbing(oracle, usa):
+    """BASELINE config 1: 1k cells x 50 reads (all cells take the tiny path in the reference)."""
+    s = synth.synth(1, [50] * 1000, num_genes=1000, usa=usa)
+    b, off = s.encode()
+    got, want, st = run_both(oracle, cfg_for(s), s.tid_to_gid, b, off)
+    assert_same_result(got, want)
+    assert st["n_records"] == 50_000 and st["n_overflow_buckets"] == 0
+    assert (got.flags & pkg._abi.CELL_TINY_PATH).all()
+
+
+@pytest.mark.parametrize("usa", [False, True])
+def test_multi_bucket_cells(oracle, usa):
+    """Cells from 1 read to 60k reads: single-bucket LDS finish, multi-bucket dense rows, ragged sizes."""
+    sizes = [60000, 33000, 9000, 5000, 2100, 1025, 513, 512, 300, 251, 250, 100, 99, 64, 63, 2, 1]
+    s = synth.synth(2, sizes, num_genes=3000, usa=usa, dup=0.45, zipf=0.6, max_extra_na=20)
+    b, off = s.encode()
+    got, want, st = run_both(oracle, cfg_for(s), s.tid_to_gid, b, off)
+    assert_same_result(got, want)
+    assert st["n_buckets"] > len(sizes)
+
+
+def test_overflow_bucket_falls_back_to_global_scratch(oracle):
+    """One UMI carried by 7000 reads lands in one bucket (> LDS cap) and must still resolve exactly."""
+    s = synth.synth(3, [9000, 400], num_genes=500, dup=0.3)
+    umi = s.umi.copy()
+    umi[:7000] = 0x123456
+    s.umi = umi
+    b, off = s.encode()
+    got, want, st = run_both(oracle, cfg_for(s), s.tid_to_gid, b, off)
+    assert st["n_overflow_buckets"] >= 1
+    assert_same_result(got, want)
+
+
+def test_degenerate_records(oracle):
+    """na == 0 records, reads with > 8 distinct genes, duplicate-heavy UMIs, max-width ref lists."""
+    t2g = np.arange(40, dtype=np.uint32)
+    cells = [
+        (5, [(1, []), (2, [3]), (2, []), (7, list(range(0, 30))), (7, list(range(0, 30))), (7, [4])]),
+        (6, [(9, list(range(5, 17))), (9, [5])] + [(100 + i, [i % 40]) for i in range(300)]),
+        (7, [(1, [])]),
+    ]
+    b, off = rad.encode_cells(cells, 4, 4)
+    cfg = pkg.WorkerConfig.for_resolution("cr-like", num_genes=40, num_rows=40)
+    got, want, _ = run_both(oracle, cfg, t2g, b, off)
+    assert_same_result(got, want)
+    assert rows_of(got)[0] == [(3, 1.0), (4, 1.0)]  # UMI7: gene4 has 3 votes, genes 0..29 two each
+    assert got.flags[2] & pkg._abi.CELL_EMPTY
+
+
+def test_device_resident_submit_and_order_independence(oracle):
+    """afq_submit_device on a torch buffer; shuffling reads inside cells leaves counts unchanged."""
+    import torch
+
+    s = synth.synth(4, [3000, 800, 120], num_genes=400, dup=0.4)
+    b, off = s.encode()
+    cfg = cfg_for(s)
+    want = oracle.quant(cfg, s.tid_to_gid, b, off)
+    d = torch.from_numpy(np.asarray(b).copy()).to("cuda:0")
+    q = pkg.Quantifier(cfg, s.tid_to_gid)
+    try:
+        q.submit_device(d.data_ptr(), d.numel(), off)
+        got = q.collect()
+        assert_same_result(got, want)
+        # permute the reads of each cell
+        rng = np.random.default_rng(0)
+        cells = []
+        for i in range(len(off)):
+            bc, reads = rad.decode_chunk(bytes(b), int(off[i]), 4, 4)
+            rng.shuffle(reads)
+            cells.append((bc, reads))
+        b2, off2 = rad.encode_cells(cells, 4, 4)
+        got2 = q.quant_chunks(b2, off2)
+        assert_same_result(got2, want)
+    finally:
+        q.close()
+
+
+def test_bad_input_is_reported_not_crashed():
+    s = synth.synth(5, [200, 200], num_genes=50)
+    b, off = s.encode()
+    cfg = cfg_for(s)
+    q = pkg.Quantifier(cfg, s.tid_to_gid)
+    try:
+        bad = np.asarray(b).copy()
+        bad[8 + int(off[1])] = 77  # first record's na in cell 1 no longer tiles the chunk
+        with pytest.raises(pkg.AfqError) as e:
+            q.quant_chunks(bad, off)
+        assert e.value.code == pkg._abi.AFQ_ERR_BAD_INPUT and "cell 1" in str(e.value)
+        # the context stays usable
+        q.quant_chunks(b, off)
+    finally:
+        q.close()
+    q = pkg.Quantifier(cfg, s.tid_to_gid[: len(s.tid_to_gid) // 2])  # ref ids now out of range
+    try:
+        with pytest.raises(pkg.AfqError) as e:
+            q.quant_chunks(b, off)
+        assert e.value.code == pkg._abi.AFQ_ERR_BAD_INPUT
+    finally:
+        q.close()
+
+
+def test_unsupported_resolutions_fail_loudly():
+    s = synth.synth(6, [50], num_genes=20)
+    b, off = s.encode()
+    q = pkg.Quantifier(cfg_for(s, "trivial"), s.tid_to_gid)
+    try:
+        with pytest.raises(pkg.AfqError) as e:
+            q.quant_chunks(b, off)
+        assert e.value.code == pkg._abi.AFQ_ERR_UNSUPPORTED
+    finally:
+        q.close()

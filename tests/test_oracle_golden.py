@@ -1,0 +1,137 @@
+"""CPU tests: the oracle against the hand-derived / reference-derived known answers."""
+import numpy as np
+import pytest
+
+from util import load_golden, pkg, rows_of
+
+rad = pkg.rad
+
+
+@pytest.mark.parametrize("small_thresh", [0, 100])
+@pytest.mark.parametrize("route", [0, 1, 2])
+def test_crlike_hand_cases(oracle, small_thresh, route):
+    """Tiny path, from-reads route and EqMap route all give the hand-derived counts."""
+    for case in load_golden("crlike_hand_cases.json")["cases"]:
+        cells = [(c["bc"], [(u, r) for u, r in c["reads"]]) for c in case["cells"]]
+        b, off = rad.encode_cells(cells, 4, 4)
+        cfg = pkg.WorkerConfig.for_resolution("cr-like", usa_mode=case["usa"], num_genes=case["num_genes"],
+                                              num_rows=case["num_rows"], small_thresh=small_thresh)
+        res = oracle.quant(cfg, np.asarray(case["t2g"], np.uint32), b, off, force_route=route)
+        got = rows_of(res)
+        for c, g in zip(case["cells"], got):
+            assert [[int(a), int(b_)] for a, b_ in g] == c["expected"], (case["name"], c["bc"], c["why"])
+        for i, c in enumerate(case["cells"]):
+            assert int(res.bc[i]) == c["bc"] and int(res.nrec[i]) == len(c["reads"])
+            tiny = bool(res.flags[i] & pkg._abi.CELL_TINY_PATH)
+            assert tiny == (route == 0 and len(c["reads"]) < small_thresh)
+            assert bool(res.flags[i] & pkg._abi.CELL_EMPTY) == (len(c["expected"]) == 0)
+
+
+@pytest.mark.parametrize("bw,uw", [(1, 1), (2, 2), (4, 4), (8, 8), (2, 4), (4, 2), (8, 4)])
+def test_field_widths(oracle, bw, uw):
+    """Record field widths 1/2/4/8 bytes (src/convert.rs:323-344) decode identically."""
+    case = load_golden("crlike_hand_cases.json")["cases"][0]
+    cells = [(c["bc"], [(u, r) for u, r in c["reads"]]) for c in case["cells"]]
+    b, off = rad.encode_cells(cells, bw, uw)
+    cfg = pkg.WorkerConfig.for_resolution("cr-like", num_genes=4, num_rows=4, bc_bytes=bw, umi_bytes=uw)
+    res = oracle.quant(cfg, np.asarray(case["t2g"], np.uint32), b, off)
+    for c, g in zip(case["cells"], rows_of(res)):
+        assert [[int(a), int(b_)] for a, b_ in g] == c["expected"]
+
+
+def test_three_crlike_routes_agree_on_synthetic(oracle):
+    """quant.rs:794-880: tiny / <=250 / EqMap routes are the same function of the cell."""
+    for usa in (False, True):
+        s = pkg.synth.synth(7, [40, 90, 200, 260, 600, 1500], num_genes=60, usa=usa, dup=0.5, max_extra_na=12)
+        b, off = s.encode()
+        cfg = pkg.WorkerConfig.for_resolution("cr-like", usa_mode=usa, num_genes=s.num_genes, num_rows=s.num_rows)
+        r0 = oracle.quant(cfg, s.tid_to_gid, b, off, force_route=0)
+        r1 = oracle.quant(cfg, s.tid_to_gid, b, off, force_route=1)
+        r2 = oracle.quant(cfg, s.tid_to_gid, b, off, force_route=2)
+        for r in (r1, r2):
+            assert np.array_equal(r0.cell_ptr, r.cell_ptr) and np.array_equal(r0.gene, r.gene) and np.array_equal(r0.val, r.val)
+        assert r0.val.sum() > 0
+
+
+def test_oracle_rejects_corrupt_chunks(oracle):
+    case = load_golden("crlike_hand_cases.json")["cases"][0]
+    cells = [(c["bc"], [(u, r) for u, r in c["reads"]]) for c in case["cells"]]
+    b, off = rad.encode_cells(cells, 4, 4)
+    cfg = pkg.WorkerConfig.for_resolution("cr-like", num_genes=4, num_rows=4)
+    t2g = np.asarray(case["t2g"], np.uint32)
+    bad = bytearray(b)
+    bad[8] = 200  # first record's na
+    with pytest.raises(oracle.OracleError):
+        oracle.quant(cfg, t2g, bytes(bad), off)
+    with pytest.raises(oracle.OracleError):  # ref id out of range
+        oracle.quant(cfg, t2g[:3], b, off)
+
+
+def test_em_known_answers(oracle):
+    """The reference's own EM unit tests (src/em.rs:1176-1215 and the two before): the sparse-support
+    EM equals `dense_reference` bit for bit, for Uniform/Informative init, non-USA and USA, and at the
+    0.01 output threshold where the result must contain an exact 0.0."""
+    eq = [[0], [1], [0, 1], [1, 2], [2, 3, 4]]
+    cases = [[], [(0, 7)], [(0, 20), (1, 4), (2, 8), (3, 1), (4, 2)]]
+    for uni in (True, False):
+        for cd in cases:
+            labels = [eq[i] for i, _ in cd]
+            counts = [c for _, c in cd]
+            sp, _ = oracle.em(labels, counts, 8, init_uniform=uni, dense=0)
+            de, _ = oracle.em(labels, counts, 8, init_uniform=uni, dense=2)
+            assert np.array_equal(sp.view(np.uint32), de.view(np.uint32))
+    eq = [[0, 1], [3, 4], [6, 7], [0, 4, 8], [2]]
+    cases = [[(0, 5)], [(1, 5)], [(2, 5)], [(0, 3), (1, 4), (2, 5), (3, 7), (4, 2)]]
+    for uni in (True, False):
+        for cd in cases:
+            labels = [eq[i] for i, _ in cd]
+            counts = [c for _, c in cd]
+            sp, _ = oracle.em(labels, counts, 9, init_uniform=uni, usa_offsets=(3, 6), dense=0)
+            de, _ = oracle.em(labels, counts, 9, init_uniform=uni, usa_offsets=(3, 6), dense=2)
+            assert np.array_equal(sp.view(np.uint32), de.view(np.uint32))
+            assert abs(float(sp.sum()) - sum(counts)) < 0.05 * sum(counts) + 0.1
+    labels = [[0], [0, 1], [1, 2], [2, 3, 4]]
+    counts = [10000, 1, 1, 1]
+    sp, _ = oracle.em(labels, counts, 6, dense=0)
+    de, _ = oracle.em(labels, counts, 6, dense=2)
+    assert np.array_equal(sp.view(np.uint32), de.view(np.uint32))
+    assert (sp == 0.0).any(), "threshold case must contain an exact 0.0 (em.rs:1176-1215)"
+    # only_unique returns the singleton counts untouched (em.rs:499-514)
+    u, _ = oracle.em([[0], [1], [0, 1]], [3, 4, 5], 4, only_unique=True, dense=1)
+    assert u.tolist() == [3.0, 4.0, 0.0, 0.0]
+
+
+def test_em_by_hand(oracle):
+    """Two classes {0}:2, {0,1}:2, informative init a0=(2+.5)e-3, a1=.5e-3 (em.rs:519-531).
+    Update (em.rs:458-485): a1' = 2*a1/(a0+a1), a0' = 4 - a1'.  a1 = 1/3, 1/6, ... halves each round.
+    Round 6: a1'=.0104 > .01 and |delta| = .0104 > .01 -> not converged; round 7: a1'=.0052 <= .01 is
+    not checked and |delta a0| = .0052 -> converged after 7 rounds (em.rs:538-565).  The 0.01 output
+    floor (em.rs:568-572) then zeroes a1, leaving a0 = 4 - (1/3)/64."""
+    a, it = oracle.em([[0], [0, 1]], [2, 2], 2, dense=1)
+    assert it == 7
+    assert a[1] == 0.0 and abs(float(a[0]) - (4.0 - (1.0 / 3.0) / 64.0)) < 1e-5
+
+
+def test_has_edge_boundaries(oracle):
+    """pugutils.rs:76-99.  Returns 0 none, 1 x->y, 2 y->x, 3 bidirected."""
+    A = 0b000000
+    B = 0b000001  # one base differs
+    C = 0b000101  # two bases differ from A
+    assert oracle.has_edge(A, 5, B, 2) == 1  # 5 > 2*2-1
+    assert oracle.has_edge(A, 2, B, 5) == 2
+    assert oracle.has_edge(A, 3, B, 2) == 3  # 3 > 3 false, 2 > 5 false
+    assert oracle.has_edge(A, 4, B, 2) == 1  # 4 > 3
+    assert oracle.has_edge(A, 1, A, 9) == 3  # identical UMIs
+    assert oracle.has_edge(A, 1, C, 1) == 0
+    assert oracle.has_edge(A, 5, B, 2, exact=True) == 0
+    assert oracle.has_edge(0b11, 1, 0b00, 1) == 3  # both bits of one base differ: still distance 1
+
+
+def test_atac_dedup_known_answer(oracle):
+    """atac/deduplicate.rs:199-237: sort by (chr,start,frag_len), run-length count."""
+    ref = [1, 0, 1, 0, 1]
+    start = [10, 5, 10, 5, 10]
+    flen = [100, 50, 100, 60, 100]
+    ptr, r, s, f, c = oracle.atac_dedup(ref, start, flen, [0, 5])
+    assert ptr.tolist() == [0, 3]
+    assert list(zip(r.tolist(), s.tolist(), f.tolist(), c.tolist())) == [(0, 5, 50, 1), (0, 5, 60, 1), (1, 10, 100, 3)]
