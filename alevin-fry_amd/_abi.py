@@ -79,6 +79,7 @@ class AfqBatchStats(C.Structure):
         ("n_buckets", C.c_uint64),
         ("n_overflow_buckets", C.c_uint64),
         ("input_bytes", C.c_uint64),
+        ("n_fallback_cells", C.c_uint64),
     ]
 
 

@@ -111,17 +111,36 @@ class QuantResult:
                         num_genes_over_mean=over, dedup_rate=float(s / np.float32(self.nrec[i])))
 
 
-def result_from_c(res: AfqResult) -> QuantResult:
+class _ResultOwner:
+    """Keeps a library-owned afq_result alive while numpy views point into it."""
+
+    def __init__(self, release, res: AfqResult):
+        self._release, self._res = release, res
+
+    def __del__(self):
+        try:
+            self._release(C.byref(self._res))
+        except Exception:
+            pass
+
+
+def result_from_c(res: AfqResult, owner=None) -> QuantResult:
+    """With `owner` the big CSR arrays are zero-copy views of the library's pinned buffers
+    (the owner releases them when the QuantResult is garbage collected); without, everything is copied."""
     n, nnz = int(res.n_cells), int(res.nnz)
 
-    def arr(ptr, count, dt):
+    def arr(ptr, count, dt, view=False):
         if count == 0:
             return np.zeros(0, dtype=dt)
-        return np.ctypeslib.as_array(ptr, shape=(count,)).astype(dt, copy=True)
+        a = np.ctypeslib.as_array(ptr, shape=(count,))
+        return a if view else a.astype(dt, copy=True)
 
-    return QuantResult(int(res.first_cell_index), arr(res.cell_ptr, n + 1, np.uint64), arr(res.gene, nnz, np.uint32),
-                       arr(res.val, nnz, np.float32), arr(res.bc, n, np.uint64), arr(res.nrec, n, np.uint32),
-                       arr(res.flags, n, np.uint8), arr(res.mmrate, n, np.float64))
+    z = owner is not None
+    out = QuantResult(int(res.first_cell_index), arr(res.cell_ptr, n + 1, np.uint64), arr(res.gene, nnz, np.uint32, z),
+                      arr(res.val, nnz, np.float32, z), arr(res.bc, n, np.uint64), arr(res.nrec, n, np.uint32),
+                      arr(res.flags, n, np.uint8), arr(res.mmrate, n, np.float64))
+    out._owner = owner
+    return out
 
 
 _lib = None
@@ -132,6 +151,14 @@ def load_library(path: str = LIB_PATH):
     global _lib
     if _lib is not None:
         return _lib
+    # libafquant.so needs libamdhip64.so.7.  PyTorch-ROCm bundles its own copy under the same
+    # soname; a process must hold exactly one HIP/HSA runtime, so when torch is installed it is
+    # imported first and the library binds to the runtime torch already mapped (a torch-free
+    # host gets /opt/rocm's).  See DESIGN.md "one HIP runtime per process".
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise FileNotFoundError(
             f"{path} not found: the HIP extension is not built (run __graft_entry__.build()). "
@@ -216,10 +243,7 @@ class Quantifier:
     def collect(self) -> QuantResult:
         res = AfqResult()
         self._check(self.lib.afq_collect(self._h, C.byref(res)))
-        try:
-            return result_from_c(res)
-        finally:
-            self.lib.afq_result_release(C.byref(res))
+        return result_from_c(res, owner=_ResultOwner(self.lib.afq_result_release, res))
 
     def quant_chunks(self, chunk_bytes, chunk_off, first_cell_index: int = 0) -> QuantResult:
         self.submit(chunk_bytes, chunk_off, first_cell_index)

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -40,19 +41,74 @@ struct DevBuf {
     template <class T> T* as() { return reinterpret_cast<T*>(p); }
 };
 
-enum KernelId { K_GATHER = 0, K_DECODE, K_BSCAN, K_SCATTER, K_RESOLVE, K_RESOLVE_BIG, K_EXTRACT, K_COMPACT, K_COUNT };
-const char* const kKernelNames[K_COUNT] = {"k_gather_headers", "k_decode", "k_bucket_scan", "k_scatter",
+enum KernelId { K_GATHER = 0, K_DECODE_PAR, K_DECODE, K_BSCAN, K_SCATTER, K_RESOLVE, K_RESOLVE_BIG, K_EXTRACT, K_COMPACT, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"k_gather_headers", "k_decode_par", "k_decode", "k_bucket_scan", "k_scatter",
                                            "k_resolve", "k_resolve_big", "k_extract_dense", "k_compact"};
 
 struct TimedLaunch { int id; hipEvent_t a, b; };
 
+// Pinned, grow-only host array (D2H lands here directly; handed to the caller zero-copy).
+template <class T>
+struct PinnedVec {
+    T* p = nullptr;
+    size_t n = 0, cap = 0;
+    hipError_t reserve(size_t want) {
+        if (want <= cap) return hipSuccess;
+        size_t nc = std::max(want + want / 4, (size_t)4096);
+        T* q = nullptr;
+        hipError_t e = hipHostMalloc((void**)&q, nc * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        if (n) std::memcpy(q, p, n * sizeof(T));
+        if (p) (void)hipHostFree(p);
+        p = q; cap = nc;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; n = cap = 0; }
+};
+
+struct ResultPool;
 struct HostResult {
     std::vector<uint64_t> cell_ptr, bc;
-    std::vector<uint32_t> gene, nrec;
-    std::vector<float> val;
+    std::vector<uint32_t> nrec;
+    PinnedVec<uint32_t> gene;
+    PinnedVec<float> val;
     std::vector<uint8_t> flags;
     std::vector<double> mmrate;
+    ResultPool* pool = nullptr;
+    void clear() { cell_ptr.clear(); bc.clear(); nrec.clear(); flags.clear(); mmrate.clear(); gene.n = 0; val.n = 0; }
 };
+
+// Results outlive a collect call (library-owned until afq_result_release), and pinning
+// host memory is slow, so result storage is recycled through a small per-context pool.
+struct ResultPool {
+    std::mutex mu;
+    std::vector<HostResult*> free_list;
+    bool ctx_alive = true;
+    int outstanding = 0;
+};
+
+HostResult* pool_get(ResultPool* P) {
+    std::lock_guard<std::mutex> g(P->mu);
+    HostResult* r;
+    if (!P->free_list.empty()) { r = P->free_list.back(); P->free_list.pop_back(); }
+    else { r = new HostResult(); r->pool = P; }
+    r->clear();
+    ++P->outstanding;
+    return r;
+}
+
+void pool_put(HostResult* r) {
+    ResultPool* P = r->pool;
+    bool destroy_pool = false;
+    {
+        std::lock_guard<std::mutex> g(P->mu);
+        --P->outstanding;
+        if (P->ctx_alive && P->free_list.size() < 2) { P->free_list.push_back(r); r = nullptr; }
+        else destroy_pool = !P->ctx_alive && P->outstanding == 0;
+    }
+    if (r) { r->gene.release(); r->val.release(); delete r; }
+    if (destroy_pool) delete P;
+}
 
 struct Range { uint32_t c0, c1; };
 
@@ -71,7 +127,9 @@ struct afq_ctx {
     size_t n_bytes = 0;
     // per-range device state
     DevBuf d_meta, d_keys0, d_keys1, d_cell_nkeys, d_bucket_cnt, d_bucket_cell, d_multi_cells, d_tile_prefix, d_dense,
-        d_nnz, d_ovf, d_status, d_bc, d_cell_ptr, d_gene, d_val, d_chunk_off, d_hdr;
+        d_nnz, d_ovf, d_status, d_bc, d_cell_ptr, d_gene, d_val, d_chunk_off, d_hdr, d_chk, d_slab_prefix, d_wg_cell;
+    bool all_aligned = true;  // every chunk offset is a multiple of 4
+    ResultPool* pool = nullptr;
     // host planning state
     std::vector<uint64_t> chunk_off;
     std::vector<uint32_t> hdr;  // nbytes, nrec per cell
@@ -157,10 +215,12 @@ int plan_ranges(afq_ctx* c) {
     const double budget = 0.80 * (double)(free_b + held);
     const size_t row_stride = ((size_t)c->cfg.num_rows + 3) & ~(size_t)3;
     c->ranges.clear();
+    c->all_aligned = true;
     double used = 0;
     uint32_t c0 = 0;
     for (uint32_t i = 0; i < c->n_cells; ++i) {
         const uint64_t off = c->chunk_off[i];
+        if (off & 3) c->all_aligned = false;
         const uint32_t nbytes = c->hdr[2 * i], nrec = c->hdr[2 * i + 1];
         if (off + 8 > c->n_bytes || nbytes < 8 || off + nbytes > c->n_bytes)
             return fail(c, AFQ_ERR_BAD_INPUT, "cell " + std::to_string(i) + ": chunk header/size out of range");
@@ -185,8 +245,10 @@ int run_range(afq_ctx* c, Range r) {
     const uint32_t H = hdr_bytes(g);
     const uint32_t n = r.c1 - r.c0;
     c->meta.resize(n);
-    std::vector<uint32_t> multi, tile_prefix, bucket_cell;
-    uint64_t key_off = 0, n_buckets = 0, n_tiles = 0;
+    std::vector<uint32_t> multi, tile_prefix, bucket_cell, slab_prefix, wg_cell;
+    const bool par = c->all_aligned && decode_par_supported(g.bc_bytes, g.umi_bytes);
+    uint64_t key_off = 0, n_buckets = 0, n_tiles = 0, n_slabs = 0;
+    if (par) slab_prefix.reserve(n + 1);
     uint64_t nrec_total = 0;
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t ci = r.c0 + i;
@@ -209,6 +271,20 @@ int run_range(afq_ctx* c, Range r) {
             n_tiles += (m.n_ref + kScatterTileHost - 1) / kScatterTileHost;
         } else m.dense_row = -1;
         nrec_total += m.nrec;
+        if (par) {
+            slab_prefix.push_back((uint32_t)n_slabs);
+            n_slabs += ((uint64_t)(m.nbytes >> 2) + kSlabWords - 1) / kSlabWords;
+        }
+    }
+    if (n_slabs >= 0xFFFFFFF0ull) return fail(c, AFQ_ERR_UNSUPPORTED, "batch too large for 32-bit slab ids");
+    if (par) {
+        slab_prefix.push_back((uint32_t)n_slabs);
+        wg_cell.resize((n_slabs + 3) / 4);
+        uint32_t cell = 0;
+        for (size_t w = 0; w < wg_cell.size(); ++w) {
+            while (cell + 1 < n && slab_prefix[cell + 1] <= 4 * w) ++cell;
+            wg_cell[w] = cell;
+        }
     }
     if (n_buckets >= 0xFFFFFFF0ull || n_tiles >= 0xFFFFFFF0ull || key_off >= (1ull << 40))
         return fail(c, AFQ_ERR_UNSUPPORTED, "batch too large for 32-bit bucket/tile ids");
@@ -234,8 +310,19 @@ int run_range(afq_ctx* c, Range r) {
     HIP_TRY(c, c->d_ovf.ensure(sizeof(OverflowEnt) * std::max<uint64_t>(n_buckets, 1)));
     HIP_TRY(c, c->d_status.ensure(sizeof(DevStatus)));
     HIP_TRY(c, c->d_bc.ensure(8ull * n));
+    if (par) {
+        HIP_TRY(c, c->d_chk.ensure(sizeof(CellChk) * n));
+        HIP_TRY(c, c->d_slab_prefix.ensure(4ull * (n + 1)));
+        HIP_TRY(c, c->d_wg_cell.ensure(4ull * std::max<size_t>(wg_cell.size(), 1)));
+    }
 
     hipStream_t s = c->stream;
+    if (par) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_slab_prefix.p, slab_prefix.data(), 4ull * (n + 1), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(c->d_wg_cell.p, wg_cell.data(), 4ull * wg_cell.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemsetAsync(c->d_chk.p, 0, sizeof(CellChk) * n, s));
+        HIP_TRY(c, hipMemsetAsync(c->d_cell_nkeys.p, 0, 4ull * n, s));
+    }
     HIP_TRY(c, hipMemcpyAsync(c->d_meta.p, c->meta.data(), sizeof(CellMeta) * n, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->d_bucket_cell.p, bucket_cell.data(), 4 * n_buckets, hipMemcpyHostToDevice, s));
     if (n_multi) {
@@ -252,8 +339,14 @@ int run_range(afq_ctx* c, Range r) {
 
     DecodeArgs da{c->d_bytes, c->n_bytes, c->d_meta.as<CellMeta>(), n, c->d_t2g.as<uint32_t>(), c->ref_count,
                   g.num_genes, c->d_keys0.as<uint64_t>(), c->d_cell_nkeys.as<uint32_t>(),
-                  c->d_bucket_cnt.as<uint32_t>(), c->d_bc.as<uint64_t>(), c->d_status.as<DevStatus>()};
-    {
+                  c->d_bucket_cnt.as<uint32_t>(), c->d_bc.as<uint64_t>(), c->d_status.as<DevStatus>(),
+                  par ? c->d_chk.as<CellChk>() : nullptr, c->d_slab_prefix.as<uint32_t>(), c->d_wg_cell.as<uint32_t>(),
+                  (uint32_t)n_slabs};
+    if (par) {
+        ScopedTimer t(c, K_DECODE_PAR);
+        if (launch_decode_par(s, da, g.bc_bytes, g.umi_bytes)) return fail(c, AFQ_ERR_INVALID_ARG, "bad field widths");
+    }
+    {   // sequential walk: the whole decode for unaligned layouts, the verified fix-up otherwise
         ScopedTimer t(c, K_DECODE);
         if (launch_decode(s, da, g.bc_bytes, g.umi_bytes)) return fail(c, AFQ_ERR_INVALID_ARG, "bad field widths");
     }
@@ -304,6 +397,7 @@ int finish_range(afq_ctx* c) {
     }
     c->stats.n_keys += st.n_keys;
     c->stats.n_overflow_buckets += st.n_overflow;
+    c->stats.n_fallback_cells += st.n_fallback;
     std::vector<uint32_t> nnz(n);
     std::vector<uint64_t> bc(n), ptr(n + 1);
     HIP_TRY(c, hipMemcpy(nnz.data(), c->d_nnz.p, 4ull * n, hipMemcpyDeviceToHost));
@@ -321,12 +415,13 @@ int finish_range(afq_ctx* c) {
                        c->d_cell_ptr.as<uint64_t>(), c->d_gene.as<uint32_t>(), c->d_val.as<float>());
     }
     HostResult& R = *c->res;
-    const size_t g0 = R.gene.size();
-    R.gene.resize(g0 + tot);
-    R.val.resize(g0 + tot);
+    const size_t g0 = R.gene.n;
+    HIP_TRY(c, R.gene.reserve(g0 + tot));
+    HIP_TRY(c, R.val.reserve(g0 + tot));
+    R.gene.n = R.val.n = g0 + tot;
     if (tot) {
-        HIP_TRY(c, hipMemcpyAsync(R.gene.data() + g0, c->d_gene.p, 4 * tot, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipMemcpyAsync(R.val.data() + g0, c->d_val.p, 4 * tot, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(R.gene.p + g0, c->d_gene.p, 4 * tot, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(R.val.p + g0, c->d_val.p, 4 * tot, hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, hipGetLastError());
@@ -350,8 +445,8 @@ int finish_range(afq_ctx* c) {
 int submit_common(afq_ctx* c, uint32_t n_cells, uint64_t first_cell_index) {
     c->n_cells = n_cells;
     c->first_cell_index = first_cell_index;
-    delete c->res;
-    c->res = new HostResult();
+    if (c->res) pool_put(c->res);
+    c->res = pool_get(c->pool);
     c->res->cell_ptr.push_back(0);
     c->stats = afq_batch_stats{};
     c->stats.input_bytes = c->n_bytes;
@@ -405,6 +500,7 @@ int afq_create(const afq_config* cfg, const uint32_t* tid_to_gid, uint32_t ref_c
     if (!c->cfg.usa_mode) c->cfg.sa_model = AFQ_SA_WINNER_TAKE_ALL;  // src/quant.rs:1456-1469
     c->device = device;
     c->ref_count = ref_count;
+    c->pool = new ResultPool();
     auto bail = [&](int code, const std::string& m) { g_create_err = m; afq_destroy(c); return code; };
     if (hipSetDevice(device) != hipSuccess) return bail(AFQ_ERR_NO_DEVICE, "hipSetDevice failed");
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(AFQ_ERR_HIP, "hipStreamCreate failed");
@@ -423,10 +519,22 @@ void afq_destroy(afq_ctx* c) {
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&c->d_t2g, &c->d_bytes_own, &c->d_meta, &c->d_keys0, &c->d_keys1, &c->d_cell_nkeys,
                       &c->d_bucket_cnt, &c->d_bucket_cell, &c->d_multi_cells, &c->d_tile_prefix, &c->d_dense, &c->d_nnz,
-                      &c->d_ovf, &c->d_status, &c->d_bc, &c->d_cell_ptr, &c->d_gene, &c->d_val, &c->d_chunk_off, &c->d_hdr};
+                      &c->d_ovf, &c->d_status, &c->d_bc, &c->d_cell_ptr, &c->d_gene, &c->d_val, &c->d_chunk_off, &c->d_hdr,
+                      &c->d_chk, &c->d_slab_prefix, &c->d_wg_cell};
     for (auto b : bufs) b->release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
-    delete c->res;
+    if (c->res) pool_put(c->res);
+    if (c->pool) {
+        bool del = false;
+        {
+            std::lock_guard<std::mutex> g(c->pool->mu);
+            c->pool->ctx_alive = false;
+            for (auto r : c->pool->free_list) { r->gene.release(); r->val.release(); delete r; }
+            c->pool->free_list.clear();
+            del = c->pool->outstanding == 0;
+        }
+        if (del) delete c->pool;
+    }
     delete c;
 }
 
@@ -495,10 +603,10 @@ int afq_collect(afq_ctx* c, afq_result* out) {
     std::memset(out, 0, sizeof(*out));
     out->n_cells = c->n_cells;
     out->first_cell_index = c->first_cell_index;
-    out->nnz = R->gene.size();
+    out->nnz = R->gene.n;
     out->cell_ptr = R->cell_ptr.data();
-    out->gene = R->gene.data();
-    out->val = R->val.data();
+    out->gene = R->gene.p;
+    out->val = R->val.p;
     out->bc = R->bc.data();
     out->nrec = R->nrec.data();
     out->flags = R->flags.data();
@@ -509,7 +617,7 @@ int afq_collect(afq_ctx* c, afq_result* out) {
 
 void afq_result_release(afq_result* res) {
     if (res && res->opaque) {
-        delete reinterpret_cast<HostResult*>(res->opaque);
+        pool_put(reinterpret_cast<HostResult*>(res->opaque));
         std::memset(res, 0, sizeof(*res));
     }
 }

@@ -45,9 +45,21 @@ struct DevStatus {
     uint32_t err_code;       // first error (0 = none)
     uint32_t err_cell;
     uint32_t n_overflow;     // buckets larger than kBucketCap
-    uint32_t pad;
+    uint32_t n_fallback;     // cells re-decoded by the sequential walk
     unsigned long long n_keys;
 };
+
+// Per-cell verification block of the walk-free decode (k_decode_par): the candidate
+// record starts it used are exactly the sequential parse iff ok==0, count==nrec and
+// words==nbytes/4-2 (proof in DESIGN.md "walk-free decode").
+struct CellChk {
+    uint32_t count;  // candidate records decoded
+    uint32_t words;  // sum of their sizes in dwords
+    uint32_t fail;   // a local check failed
+    uint32_t pad;
+};
+
+constexpr uint32_t kSlabWords = 256;  // dwords one wave of k_decode_par covers (1 KiB)
 
 constexpr uint32_t kErrRecordWalk = 1;   // records do not tile the chunk
 constexpr uint32_t kErrRefRange = 2;     // ref id >= ref_count

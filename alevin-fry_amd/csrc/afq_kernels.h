@@ -21,6 +21,11 @@ struct DecodeArgs {
     uint32_t* bucket_cnt;
     uint64_t* bc_out;
     DevStatus* st;
+    // walk-free decode (k_decode_par) + fix-up mode of k_decode; null chk = plain sequential decode
+    const CellChk* chk;
+    const uint32_t* slab_prefix;  // [n_cells+1] 1 KiB slabs per cell, prefix
+    const uint32_t* wg_cell;      // [ceil(n_slabs/4)] cell of each workgroup's first slab
+    uint32_t n_slabs;
 };
 
 struct ResolveArgs {
@@ -45,6 +50,8 @@ struct ResolveArgs {
 void launch_gather_headers(hipStream_t s, const uint8_t* bytes, size_t n_bytes, const uint64_t* chunk_off,
                            uint32_t n_cells, uint32_t* hdr);
 int launch_decode(hipStream_t s, const DecodeArgs& a, uint32_t bw, uint32_t uw);
+bool decode_par_supported(uint32_t bw, uint32_t uw);
+int launch_decode_par(hipStream_t s, const DecodeArgs& a, uint32_t bw, uint32_t uw);
 void launch_bucket_scan(hipStream_t s, const uint32_t* multi_cells, uint32_t n_multi, const CellMeta* meta,
                         uint32_t* bucket_cnt);
 void launch_scatter(hipStream_t s, uint32_t n_tiles, const uint32_t* multi_cells, const uint32_t* tile_prefix,

@@ -151,13 +151,26 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ byte
                                                uint32_t num_genes, uint64_t* __restrict__ keys0,
                                                uint32_t* __restrict__ cell_nkeys,
                                                uint32_t* __restrict__ bucket_cnt,
-                                               uint64_t* __restrict__ bc_out, DevStatus* st) {
+                                               uint64_t* __restrict__ bc_out, DevStatus* st,
+                                               const CellChk* __restrict__ chk) {
     constexpr uint32_t HDR = 4 + BW + UW;
     constexpr bool AL = (BW % 4 == 0) && (UW % 4 == 0);
     const uint32_t lane = lane_id();
     const uint32_t cell = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (cell >= n_cells) return;
     const CellMeta m = meta[cell];
+    if (chk) {
+        // fix-up mode after k_decode_par: cells whose candidate set verified are done;
+        // the others are re-decoded here by the sequential walk (and report real errors).
+        const CellChk c = chk[cell];
+        if (c.fail == 0 && c.count == m.nrec && c.words == m.nbytes / 4 - 2) {
+            if (lane == 0) atomicAdd(&st->n_keys, (unsigned long long)cell_nkeys[cell]);
+            return;
+        }
+        if (m.lg_nb) for (uint32_t i = lane; i < (1u << m.lg_nb); i += 64) bucket_cnt[m.bucket_base + i] = 0;
+        __threadfence();
+        if (lane == 0) atomicAdd(&st->n_fallback, 1u);
+    }
     const uint64_t abase = m.chunk_off & ~3ull;         // dword-aligned base of the walk
     const uint32_t mis = (uint32_t)(m.chunk_off - abase);
     uint64_t pos = (uint64_t)mis + 8;                    // next record start, bytes from abase
@@ -292,6 +305,173 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ byte
         cell_nkeys[cell] = nk_total;
         atomicAdd(&st->n_keys, (unsigned long long)nk_total);
     }
+}
+
+// ---------------------------------------------------------------------------
+// k_decode_par: walk-free decode for dword-aligned layouts (bc/umi of 4 or 8 bytes).
+// In a collated chunk every record carries the cell's barcode, so a record start
+// is a dword i whose barcode field equals the barcode of the chunk's first record.
+// One wave takes a 1 KiB slab: ballot the candidate starts of four 64-dword
+// windows into an LDS list, then one lane per candidate decodes the record.
+// Per candidate it also checks that the position right after the record is again a
+// candidate (or the chunk end); with the per-cell sums of candidate count and
+// candidate sizes this proves the candidate set IS the sequential parse
+// (DESIGN.md "walk-free decode").  Cells that fail the proof are re-decoded by
+// the sequential k_decode, so a barcode-valued UMI/ref word costs time, never
+// correctness.  Keys of a cell land in arbitrary order (wave-level atomic
+// reservation); order is re-established by the bucket sort.
+template <int BW, int UW>
+__global__ __launch_bounds__(256) void k_decode_par(const uint8_t* __restrict__ bytes,
+                                                   const CellMeta* __restrict__ meta, uint32_t n_cells,
+                                                   const uint32_t* __restrict__ slab_prefix,
+                                                   const uint32_t* __restrict__ wg_cell, uint32_t n_slabs,
+                                                   const uint32_t* __restrict__ t2g, uint32_t ref_count,
+                                                   uint32_t num_genes, uint64_t* __restrict__ keys0,
+                                                   uint32_t* __restrict__ cell_nkeys,
+                                                   uint32_t* __restrict__ bucket_cnt,
+                                                   uint64_t* __restrict__ bc_out, CellChk* __restrict__ chk) {
+    static_assert(BW % 4 == 0 && UW % 4 == 0, "aligned layouts only");
+    constexpr uint32_t BWW = BW / 4, UWW = UW / 4, HW = 1 + BWW + UWW;
+    __shared__ uint32_t s_list[4][kSlabWords];
+    const uint32_t lane = lane_id();
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t slab = blockIdx.x * 4 + wv;
+    if (slab >= n_slabs) return;
+    uint32_t cell = wg_cell[blockIdx.x];
+    while (cell + 1 < n_cells && slab_prefix[cell + 1] <= slab) ++cell;
+    cell = __builtin_amdgcn_readfirstlane(cell);
+    const CellMeta m = meta[cell];
+    const uint32_t* __restrict__ W = reinterpret_cast<const uint32_t*>(bytes + m.chunk_off);
+    const uint32_t nwords = m.nbytes >> 2;
+    const uint32_t s0 = (slab - slab_prefix[cell]) * kSlabWords;
+    if (nwords < 2 + HW) {  // cannot hold a record; nrec >= 1 is guaranteed by the planner
+        if (s0 == 0 && lane == 0) atomicOr(&chk[cell].fail, 1u);
+        return;
+    }
+    const uint32_t bc_lo = W[3];
+    const uint32_t bc_hi = BWW == 2 ? W[4] : 0u;
+    // candidate starts of the slab -> s_list (ascending)
+    uint32_t ncand = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t i = s0 + r * 64 + lane;
+        bool cand = false;
+        if (i >= 2 && i + HW <= nwords) {
+            cand = W[i + 1] == bc_lo;
+            if (BWW == 2) cand = cand && (W[i + 2] == bc_hi);
+        }
+        const uint64_t mk = __ballot(cand);
+        if (cand) s_list[wv][ncand + __popcll(mk & ((1ull << lane) - 1))] = i;
+        ncand += (uint32_t)__popcll(mk);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    bool fail = false;
+    if (s0 == 0) {  // (1) the first record starts right after the chunk header
+        const bool first_ok = ncand > 0 && s_list[wv][0] == 2;
+        if (!first_ok) fail = true;
+    }
+    uint32_t sum_words = 0;
+    for (uint32_t base = 0; base < ncand; base += 64) {
+        const uint32_t c = base + lane;
+        const bool act = c < ncand;
+        uint32_t i = 0, na = 0, kcnt = 0, k = 0;
+        bool ovf = false;
+        uint64_t umi = 0;
+        uint32_t g[8];
+        if (act) {
+            i = s_list[wv][c];
+            na = W[i];
+            if (na > nwords || i + HW + na > nwords) { fail = true; na = 0; }
+            else {
+                const uint32_t succ = i + HW + na;  // (2) the next record starts where this one ends
+                if (succ != nwords) {
+                    bool ok = succ + HW <= nwords && W[succ + 1] == bc_lo;
+                    if (BWW == 2 && ok) ok = W[succ + 2] == bc_hi;
+                    if (!ok) fail = true;
+                }
+                sum_words += HW + na;
+                umi = W[i + 1 + BWW];
+                if (UWW == 2) umi |= (uint64_t)W[i + 2 + BWW] << 32;
+                if (UWW == 2 && (umi >> kUmiBits)) fail = true;
+                if (i == 2) bc_out[cell] = BWW == 2 ? ((uint64_t)bc_hi << 32 | bc_lo) : (uint64_t)bc_lo;
+                const uint32_t* rp = W + i + HW;
+                for (uint32_t j = 0; j < na; ++j) {
+                    const uint32_t t = rp[j] & 0x7FFFFFFFu;
+                    if (t >= ref_count) { fail = true; continue; }
+                    const uint32_t gid = t2g[t];
+                    if (gid >= num_genes) { fail = true; continue; }
+                    bool dup = false;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) dup |= ((uint32_t)q < k) && (g[q] == gid);
+                    if (!dup) {
+                        if (k < 8) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) if ((uint32_t)q == k) g[q] = gid;
+                            ++k;
+                        } else { ovf = true; break; }
+                    }
+                }
+                kcnt = k;
+                if (ovf) {  // > 8 distinct genes: first-occurrence count, O(na^2), rare
+                    kcnt = 0;
+                    for (uint32_t j = 0; j < na; ++j) {
+                        const uint32_t tj = rp[j] & 0x7FFFFFFFu;
+                        if (tj >= ref_count) continue;
+                        const uint32_t gj = t2g[tj];
+                        if (gj >= num_genes) continue;
+                        bool first = true;
+                        for (uint32_t q = 0; q < j && first; ++q) {
+                            const uint32_t tq = rp[q] & 0x7FFFFFFFu;
+                            if (tq < ref_count && t2g[tq] == gj) first = false;
+                        }
+                        kcnt += first;
+                    }
+                }
+            }
+        }
+        uint32_t tot;
+        const uint32_t ex = wave_excl_scan(kcnt, tot);
+        uint32_t wbase = 0;
+        if (tot) {
+            if (lane == 0) wbase = atomicAdd(&cell_nkeys[cell], tot);
+            wbase = __builtin_amdgcn_readfirstlane(wbase);
+            if (wbase + tot > m.n_ref) { fail = true; kcnt = 0; }
+        }
+        if (kcnt) {
+            uint64_t* dst = keys0 + m.key_off + wbase + ex;
+            if (!ovf) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) if ((uint32_t)q < k) dst[q] = (umi << kGeneBits) | g[q];
+            } else {
+                const uint32_t* rp = W + i + HW;
+                uint32_t o = 0;
+                for (uint32_t j = 0; j < na; ++j) {
+                    const uint32_t tj = rp[j] & 0x7FFFFFFFu;
+                    if (tj >= ref_count) continue;
+                    const uint32_t gj = t2g[tj];
+                    if (gj >= num_genes) continue;
+                    bool first = true;
+                    for (uint32_t q = 0; q < j && first; ++q) {
+                        const uint32_t tq = rp[q] & 0x7FFFFFFFu;
+                        if (tq < ref_count && t2g[tq] == gj) first = false;
+                    }
+                    if (first) dst[o++] = (umi << kGeneBits) | gj;
+                }
+            }
+            if (m.lg_nb) atomicAdd(&bucket_cnt[m.bucket_base + bucket_of(umi, m.lg_nb)], kcnt);
+        }
+    }
+    // per-cell sums for the proof
+    uint32_t wsum = sum_words;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) wsum += __shfl_xor(wsum, d);
+    if (lane == 0) {
+        atomicAdd(&chk[cell].count, ncand);
+        atomicAdd(&chk[cell].words, wsum);
+    }
+    if (__any(fail) && lane == 0) atomicOr(&chk[cell].fail, 1u);
 }
 
 // ---------------------------------------------------------------------------
@@ -590,7 +770,7 @@ void launch_gather_headers(hipStream_t s, const uint8_t* bytes, size_t n_bytes, 
 template <int BW, int UW>
 static void launch_decode_t(hipStream_t s, const DecodeArgs& a) {
     AFQ_LAUNCH((k_decode<BW, UW>), (a.n_cells + 3) / 4, 256, s, a.bytes, a.n_bytes, a.meta, a.n_cells, a.t2g,
-               a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bucket_cnt, a.bc_out, a.st);
+               a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bucket_cnt, a.bc_out, a.st, a.chk);
 }
 
 int launch_decode(hipStream_t s, const DecodeArgs& a, uint32_t bw, uint32_t uw) {
@@ -601,6 +781,24 @@ int launch_decode(hipStream_t s, const DecodeArgs& a, uint32_t bw, uint32_t uw) 
     AFQ_CASE(2, 1) AFQ_CASE(2, 2) AFQ_CASE(2, 4) AFQ_CASE(2, 8)
     AFQ_CASE(4, 1) AFQ_CASE(4, 2) AFQ_CASE(8, 1) AFQ_CASE(8, 2)
 #undef AFQ_CASE
+    return -1;
+}
+
+template <int BW, int UW>
+static void launch_decode_par_t(hipStream_t s, const DecodeArgs& a) {
+    AFQ_LAUNCH((k_decode_par<BW, UW>), (a.n_slabs + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix, a.wg_cell,
+               a.n_slabs, a.t2g, a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bucket_cnt, a.bc_out,
+               const_cast<CellChk*>(a.chk));
+}
+
+bool decode_par_supported(uint32_t bw, uint32_t uw) { return (bw == 4 || bw == 8) && (uw == 4 || uw == 8); }
+
+int launch_decode_par(hipStream_t s, const DecodeArgs& a, uint32_t bw, uint32_t uw) {
+    if (!a.n_slabs) return 0;
+    if (bw == 4 && uw == 4) { launch_decode_par_t<4, 4>(s, a); return 0; }
+    if (bw == 4 && uw == 8) { launch_decode_par_t<4, 8>(s, a); return 0; }
+    if (bw == 8 && uw == 4) { launch_decode_par_t<8, 4>(s, a); return 0; }
+    if (bw == 8 && uw == 8) { launch_decode_par_t<8, 8>(s, a); return 0; }
     return -1;
 }
 

@@ -36,8 +36,14 @@ struct Gen {
         uint64_t u = mk & umask;
         uint32_t gene;
         if (p.zipf > 0) {
-            double x = u01(mix(mk ^ 2));
-            gene = (uint32_t)std::min<double>(p.num_genes - 1, std::floor(p.num_genes * std::pow(x, 1.0 + 3.0 * p.zipf)));
+            const double x = u01(mix(mk ^ 2)), e = 1.0 + 3.0 * p.zipf;
+            double xe;
+            const int ei = (int)e;
+            if ((double)ei == e && ei >= 1 && ei <= 64 && (ei & (ei - 1)) == 0) {  // power-of-two exponent: squarings
+                xe = x;
+                for (int q = ei; q > 1; q >>= 1) xe *= xe;
+            } else xe = std::pow(x, e);
+            gene = (uint32_t)std::min<double>(p.num_genes - 1, std::floor(p.num_genes * xe));
         } else gene = (uint32_t)(mix(mk ^ 2) % p.num_genes);
         const double rn = u01(mix(base ^ 3));
         uint32_t na = rn < p.p_na3 ? 3 : (rn < p.p_na3 + p.p_na2 ? 2 : 1);

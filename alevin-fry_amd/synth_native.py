@@ -50,7 +50,7 @@ class NativeRad:
 
 
 def generate(seed=2, n_cells=11000, median_reads=30000.0, sigma=0.6, num_genes=36601, txp_per_gene=5, usa=False,
-             umi_len=12, dup=0.4, p_na2=0.2, p_na3=0.1, cross=0.5, umi_err=0.01, zipf=0.37, p_unspliced=0.35,
+             umi_len=12, dup=0.4, p_na2=0.2, p_na3=0.1, cross=0.5, umi_err=0.01, zipf=5.0, p_unspliced=0.35,
              p_both=0.08, min_reads=1, n_threads=0, pinned_out=None) -> NativeRad:
     lib = C.CDLL(LIB_PATH)
     P = C.POINTER

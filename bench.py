@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""bench.py — M reads/s through the `quant` hot path (cr-like) on N MI355X GPUs.
+
+A "step" is one pass of the whole hot path (afq_submit_device + afq_collect: decode ->
+bucket -> resolve -> extract -> CSR on the host) over one batch of synthetic collated RAD
+that is already resident in HBM.  Workload at every N: BASELINE.json configs[1] — a
+PBMC-10k-like 10x-v3 collated RAD (11 000 cells, log-normal reads/cell with median 3e4,
+36 601 genes, cr-like), one such shard PER RANK (weak scaling: cells are independent, so
+ranks share nothing on the data path; the only collectives are the timing barrier and a
+max/sum of scalars).
+
+One JSON line on rank 0; see DESIGN.md §Measurement for how roofline/cpu_baseline are built.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  (imported before libafquant.so: one HIP runtime per process)
+import torch.distributed as dist  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cells", type=int, default=11000)
+    ap.add_argument("--median-reads", type=float, default=30000.0)
+    ap.add_argument("--sigma", type=float, default=0.6)
+    ap.add_argument("--genes", type=int, default=36601)
+    ap.add_argument("--usa", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (rank 0, N=1 only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    pkg = importlib.import_module("alevin-fry_amd")
+    sn = importlib.import_module("alevin-fry_amd.synth_native")
+
+    # ---- synthetic input (config 2), one shard per rank, then resident in HBM -------------
+    t0 = time.time()
+    rad = sn.generate(seed=2 + rank, n_cells=args.cells, median_reads=args.median_reads, sigma=args.sigma,
+                      num_genes=args.genes, txp_per_gene=5, usa=args.usa)
+    t_gen = time.time() - t0
+    d_bytes = torch.from_numpy(rad.data).to(dev)
+    cfg = pkg.WorkerConfig.for_resolution("cr-like", usa_mode=rad.usa, num_genes=rad.num_genes,
+                                          num_rows=rad.num_rows, profile=True)
+    q = pkg.Quantifier(cfg, rad.tid_to_gid, device=local_rank)
+
+    def step():
+        q.submit_device(d_bytes.data_ptr(), d_bytes.numel(), rad.chunk_off)
+        return q.collect()
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+
+    res = None
+    for _ in range(args.warmup):
+        res = step()
+    sync_all()
+    t0 = time.perf_counter()
+    ktimes = {}
+    for _ in range(args.steps):
+        res = step()
+        for k, (ms, n) in q.kernel_times().items():  # HIP events on the library's own stream
+            a = ktimes.setdefault(k, [0.0, 0])
+            a[0] += ms
+            a[1] += n
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        r = torch.tensor([float(rad.n_reads), float(args.cells)], dtype=torch.float64, device=dev)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        total_reads, total_cells = float(r[0].item()), float(r[1].item())
+    else:
+        total_reads, total_cells = float(rad.n_reads), float(args.cells)
+
+    if rank != 0:
+        q.close()
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    st = q.batch_stats()
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = total_reads * args.steps / elapsed / 1e6
+
+    # ---- size-independent sanity on the full-size result --------------------------------
+    nnz = int(res.cell_ptr[-1])
+    assert res.n_cells == args.cells and (np.diff(res.cell_ptr.astype(np.int64)) >= 0).all()
+    assert (res.val > 0).all() and float(res.val.sum()) <= rad.n_reads
+    assert np.array_equal(res.nrec, rad.cell_nrec)
+
+    # ---- roofline of the dominant kernel -------------------------------------------------
+    # algorithmic bytes of one pass: every record read once (12+4*na), the chunk
+    # headers, and 8 B per emitted non-zero.  The dominant kernel is charged with all of them:
+    # it is the share of the path's wall time that decides the path's achieved bandwidth.
+    alg_bytes = float(st["input_bytes"]) + 8.0 * nnz
+    dom = max(ktimes.items(), key=lambda kv: kv[1][0]) if ktimes else None
+    roofline = None
+    if dom:
+        name, (ms_tot, launches) = dom
+        avg_ms = ms_tot / max(1, launches)
+        launches_per_step = launches / args.steps
+        achieved = alg_bytes / launches_per_step / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(achieved / 8000.0, 5), "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
+                    "alg_bytes_per_step": alg_bytes,
+                    "all_kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in ktimes.items()}}
+
+    # ---- CPU baseline: the oracle (a port, not the Rust binary) on a bounded sample ---------
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as ora
+
+        ora.lib()
+        # sample = every k-th cell so the size mix matches the workload; grow until the budget is used
+        order = np.arange(args.cells)
+        ncores = os.cpu_count() or 1
+        k = max(1, args.cells // max(64, 4 * ncores))
+        done_reads, t_cpu, ncell = 0, 0.0, 0
+        start = 0
+        while t_cpu < args.cpu_seconds and start < k:
+            idx = order[start::k]
+            start += 1
+            offs = rad.chunk_off[idx]
+            tb = time.perf_counter()
+            want = ora.quant(cfg, rad.tid_to_gid, rad.data, offs, n_threads=ncores)
+            t_cpu += time.perf_counter() - tb
+            done_reads += int(rad.cell_nrec[idx].sum())
+            ncell += len(idx)
+            # the sample doubles as a full-size parity check: GPU rows == oracle rows, bit for bit
+            for j, ci in enumerate(idx):
+                g0, v0 = res.row(int(ci))
+                g1, v1 = want.row(j)
+                assert np.array_equal(g0, g1) and np.array_equal(v0.view(np.uint32), v1.view(np.uint32)), \
+                    f"GPU/oracle mismatch on cell {ci}"
+        cpu = {"value": round(done_reads / t_cpu / 1e6, 4), "unit": "M reads/s", "cores": ncores, "kind": "port",
+               "sample": f"{ncell} of {args.cells} cells (every {k}-th, in rounds), {done_reads} reads, {t_cpu:.1f} s, "
+                         f"C++ restatement (oracle/) with one worker thread per host core over whole cells, input "
+                         f"already parsed from RAM; rows compared bit-exact with the GPU's"}
+
+    out = {
+        "metric": "M reads/s through quant (PUG dedup+eq-class) at 1/2/4/8 GPUs; cells/s",
+        "value": round(value, 3),
+        "unit": "M reads/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {"workload": "configs[1]: PBMC-10k-like 10x-v3 collated RAD, cr-like, per GPU: "
+                               f"{args.cells} cells, log-normal reads/cell median {args.median_reads:g} sigma {args.sigma:g}, "
+                               f"{args.genes} genes" + (", USA" if args.usa else ""),
+                   "reads_per_gpu": rad.n_reads, "input_bytes_per_gpu": st["input_bytes"], "resolution": "cr-like",
+                   "sharding": f"{world} x independent cell shards, no data-path collective"},
+        "cells_per_s": round(total_cells * args.steps / elapsed, 1),
+        "nnz": nnz,
+        "keys": st["n_keys"],
+        "overflow_buckets": st["n_overflow_buckets"],
+        "gen_seconds": round(t_gen, 1),
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    q.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -171,6 +171,7 @@ typedef struct afq_batch_stats {
     uint64_t n_buckets;
     uint64_t n_overflow_buckets;
     uint64_t input_bytes;
+    uint64_t n_fallback_cells; /* cells the walk-free decode could not prove and re-decoded sequentially */
 } afq_batch_stats;
 int afq_get_batch_stats(afq_ctx* ctx, afq_batch_stats* out);
 

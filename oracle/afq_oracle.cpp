@@ -42,6 +42,7 @@
 #include <map>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -183,7 +184,14 @@ struct EqMap {
 
 static void eqmap_build(const Cell& c, const u32* t2g, bool gene_level, EqMap& m) {
     m.labels.clear(); m.label_start.clear(); m.umis.clear();
-    std::map<std::vector<u32>, u32> ids;  // class id = first-appearance order (eq_class.rs:890)
+    struct VH {
+        size_t operator()(const std::vector<u32>& v) const {
+            u64 h = 0x9E3779B97F4A7C15ull ^ v.size();
+            for (u32 x : v) { h ^= x; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 29; }
+            return (size_t)h;
+        }
+    };
+    std::unordered_map<std::vector<u32>, u32, VH> ids;  // class id = first-appearance order (eq_class.rs:890)
     std::vector<u32> key;
     for (u32 r = 0; r < c.nrec; ++r) {
         if (gene_level) gene_set_of(c.rp(r), c.na(r), t2g, key);  // eq_class.rs:740-746
@@ -720,6 +728,48 @@ int ora_quant(const afq_config* cfg, const uint32_t* t2g, uint32_t ref_count, co
         R->cell_ptr.push_back(R->gene.size());
         R->bc.push_back(c.bc); R->nrec.push_back(c.nrec); R->flags.push_back(o.flags);
         R->mmrate.push_back(o.mmrate); R->em_iters.push_back(o.em_iters);
+    }
+    out->n_cells = n_cells; out->first_cell_index = first_cell_index; out->nnz = R->gene.size();
+    out->cell_ptr = R->cell_ptr.data(); out->gene = R->gene.data(); out->val = R->val.data();
+    out->bc = R->bc.data(); out->nrec = R->nrec.data(); out->flags = R->flags.data();
+    out->mmrate = R->mmrate.data(); out->opaque = R;
+    return 0;
+}
+
+// Same, with the cells spread over n_threads worker threads (the reference runs
+// t-1 workers over a chunk queue, src/quant.rs:1567-1571).  Used for the CPU baseline.
+int ora_quant_mt(const afq_config* cfg, const uint32_t* t2g, uint32_t ref_count, const uint8_t* bytes,
+                 size_t n_bytes, const uint64_t* chunk_off, uint32_t n_cells, uint64_t first_cell_index,
+                 uint32_t n_threads, afq_result* out) {
+    if (!cfg || !t2g || !bytes || !chunk_off || !out) { g_err = "null argument"; return AFQ_ERR_INVALID_ARG; }
+    if (n_threads < 1) n_threads = 1;
+    std::vector<CellOut> outs(n_cells);
+    std::vector<u64> bcs(n_cells);
+    std::vector<u32> nrecs(n_cells);
+    std::vector<int> rcs(n_threads, 0);
+    std::vector<std::string> errs(n_threads);
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < n_threads; ++t)
+        th.emplace_back([&, t]() {
+            Cell c; std::string err;
+            for (uint32_t i = t; i < n_cells && rcs[t] == 0; i += n_threads) {
+                int rc = chunk_off[i] > n_bytes ? AFQ_ERR_BAD_INPUT
+                                                : parse_chunk(bytes + chunk_off[i], n_bytes - chunk_off[i], cfg->bc_bytes, cfg->umi_bytes, c, err);
+                if (!rc) rc = quant_cell(*cfg, t2g, ref_count, c, 0, outs[i], err);
+                if (rc) { rcs[t] = rc; errs[t] = "cell " + std::to_string(i) + ": " + err; }
+                bcs[i] = c.bc; nrecs[i] = c.nrec;
+            }
+        });
+    for (auto& x : th) x.join();
+    for (uint32_t t = 0; t < n_threads; ++t) if (rcs[t]) { g_err = errs[t]; return rcs[t]; }
+    auto* R = new Result();
+    R->cell_ptr.push_back(0);
+    for (uint32_t i = 0; i < n_cells; ++i) {
+        R->gene.insert(R->gene.end(), outs[i].ind.begin(), outs[i].ind.end());
+        R->val.insert(R->val.end(), outs[i].val.begin(), outs[i].val.end());
+        R->cell_ptr.push_back(R->gene.size());
+        R->bc.push_back(bcs[i]); R->nrec.push_back(nrecs[i]); R->flags.push_back(outs[i].flags);
+        R->mmrate.push_back(outs[i].mmrate); R->em_iters.push_back(outs[i].em_iters);
     }
     out->n_cells = n_cells; out->first_cell_index = first_cell_index; out->nnz = R->gene.size();
     out->cell_ptr = R->cell_ptr.data(); out->gene = R->gene.data(); out->val = R->val.data();

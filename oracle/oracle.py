@@ -35,6 +35,9 @@ def lib():
         L.ora_quant.argtypes = [p(_abi.AfqConfig), p(C.c_uint32), C.c_uint32, C.c_void_p, C.c_size_t, p(C.c_uint64),
                                 C.c_uint32, C.c_uint64, C.c_int, p(_abi.AfqResult)]
         L.ora_quant.restype = C.c_int
+        L.ora_quant_mt.argtypes = [p(_abi.AfqConfig), p(C.c_uint32), C.c_uint32, C.c_void_p, C.c_size_t, p(C.c_uint64),
+                                   C.c_uint32, C.c_uint64, C.c_uint32, p(_abi.AfqResult)]
+        L.ora_quant_mt.restype = C.c_int
         L.ora_result_release.argtypes = [p(_abi.AfqResult)]
         L.ora_result_em_iters.argtypes = [p(_abi.AfqResult)]
         L.ora_result_em_iters.restype = p(C.c_uint32)
@@ -57,17 +60,24 @@ class OracleError(RuntimeError):
         self.code = code
 
 
-def quant(cfg, tid_to_gid, chunk_bytes, chunk_off, first_cell_index=0, force_route=0, want_iters=False):
-    """cfg: WorkerConfig.  Returns QuantResult (same container as the product)."""
+def quant(cfg, tid_to_gid, chunk_bytes, chunk_off, first_cell_index=0, force_route=0, want_iters=False, n_threads=1):
+    """cfg: WorkerConfig.  Returns QuantResult (same container as the product).
+    n_threads > 1 spreads cells over worker threads (reference dispatch only)."""
     L = lib()
     ccfg = cfg.to_c()
     t2g = np.ascontiguousarray(tid_to_gid, dtype=np.uint32)
     b = np.ascontiguousarray(np.frombuffer(chunk_bytes, dtype=np.uint8) if not isinstance(chunk_bytes, np.ndarray) else chunk_bytes)
     off = np.ascontiguousarray(chunk_off, dtype=np.uint64)
     res = _abi.AfqResult()
-    rc = L.ora_quant(C.byref(ccfg), t2g.ctypes.data_as(C.POINTER(C.c_uint32)), len(t2g), b.ctypes.data_as(C.c_void_p),
-                     b.nbytes, off.ctypes.data_as(C.POINTER(C.c_uint64)), len(off), first_cell_index, force_route,
-                     C.byref(res))
+    if n_threads > 1:
+        assert force_route == 0
+        rc = L.ora_quant_mt(C.byref(ccfg), t2g.ctypes.data_as(C.POINTER(C.c_uint32)), len(t2g), b.ctypes.data_as(C.c_void_p),
+                            b.nbytes, off.ctypes.data_as(C.POINTER(C.c_uint64)), len(off), first_cell_index, n_threads,
+                            C.byref(res))
+    else:
+        rc = L.ora_quant(C.byref(ccfg), t2g.ctypes.data_as(C.POINTER(C.c_uint32)), len(t2g), b.ctypes.data_as(C.c_void_p),
+                         b.nbytes, off.ctypes.data_as(C.POINTER(C.c_uint64)), len(off), first_cell_index, force_route,
+                         C.byref(res))
     if rc != 0:
         raise OracleError(rc, L.ora_last_error().decode())
     try:
