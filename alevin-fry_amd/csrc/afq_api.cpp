@@ -41,9 +41,9 @@ struct DevBuf {
     template <class T> T* as() { return reinterpret_cast<T*>(p); }
 };
 
-enum KernelId { K_GATHER = 0, K_DECODE_PAR, K_DECODE, K_BSCAN, K_SCATTER, K_RESOLVE, K_RESOLVE_BIG, K_EXTRACT, K_COMPACT, K_COUNT };
-const char* const kKernelNames[K_COUNT] = {"k_gather_headers", "k_decode_par", "k_decode", "k_bucket_scan", "k_scatter",
-                                           "k_resolve", "k_resolve_big", "k_extract_dense", "k_compact"};
+enum KernelId { K_GATHER = 0, K_DECODE_PAR, K_DECODE, K_HIST, K_BSCAN, K_SCATTER, K_RESOLVE, K_RESOLVE_BIG, K_CELL_HIST, K_COMPACT, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"k_gather_headers", "k_decode_par", "k_decode", "k_hist", "k_bucket_scan", "k_scatter",
+                                           "k_resolve", "k_resolve_big", "k_cell_hist", "k_compact"};
 
 struct TimedLaunch { int id; hipEvent_t a, b; };
 
@@ -126,7 +126,7 @@ struct afq_ctx {
     const uint8_t* d_bytes = nullptr;
     size_t n_bytes = 0;
     // per-range device state
-    DevBuf d_meta, d_keys0, d_keys1, d_cell_nkeys, d_bucket_cnt, d_bucket_cell, d_multi_cells, d_tile_prefix, d_dense,
+    DevBuf d_meta, d_keys0, d_keys1, d_cell_nkeys, d_bucket_cnt, d_bucket_cell, d_multi_cells, d_tile_prefix, d_ncols,
         d_nnz, d_ovf, d_status, d_bc, d_cell_ptr, d_gene, d_val, d_chunk_off, d_hdr, d_chk, d_slab_prefix, d_wg_cell;
     bool all_aligned = true;  // every chunk offset is a multiple of 4
     ResultPool* pool = nullptr;
@@ -211,9 +211,8 @@ int plan_ranges(afq_ctx* c) {
     size_t free_b = 0, total_b = 0;
     HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
     // buffers already held by this context are reusable
-    size_t held = c->d_keys0.cap + c->d_keys1.cap + c->d_dense.cap;
+    size_t held = c->d_keys0.cap + c->d_keys1.cap;
     const double budget = 0.80 * (double)(free_b + held);
-    const size_t row_stride = ((size_t)c->cfg.num_rows + 3) & ~(size_t)3;
     c->ranges.clear();
     c->all_aligned = true;
     double used = 0;
@@ -229,8 +228,8 @@ int plan_ranges(afq_ctx* c) {
         if (fixed > nbytes || ((nbytes - fixed) & 3))
             return fail(c, AFQ_ERR_BAD_INPUT, "cell " + std::to_string(i) + ": chunk nbytes does not match its records");
         const uint64_t n_ref = (nbytes - fixed) / 4;
-        double need = 16.0 * (double)n_ref + 64.0;
-        if (n_ref > kBucketTarget) need += 4.0 * (double)row_stride + 8.0 * (double)(n_ref / kBucketTarget + 1);
+        double need = 16.0 * (double)n_ref + 128.0;
+        if (n_ref > kBucketTarget) need += 16.0 * (double)(n_ref / kBucketTarget + 1);
         if (need > budget) return fail(c, AFQ_ERR_OOM, "cell " + std::to_string(i) + " alone exceeds device memory");
         if (used + need > budget) { c->ranges.push_back({c0, i}); c0 = i; used = 0; }
         used += need;
@@ -258,7 +257,7 @@ int run_range(afq_ctx* c, Range r) {
         m.nrec = c->hdr[2 * ci + 1];
         m.n_ref = (uint32_t)((m.nbytes - 8ull - (uint64_t)m.nrec * H) / 4);
         m.key_off = key_off;
-        key_off += std::max<uint32_t>(m.n_ref, 1);
+        key_off += (uint64_t)m.n_ref + 1;
         uint32_t lg = 0;
         while (((uint64_t)kBucketTarget << lg) < m.n_ref && lg < kMaxLgNb) ++lg;
         m.lg_nb = lg;
@@ -295,7 +294,6 @@ int run_range(afq_ctx* c, Range r) {
         std::fill(bucket_cell.begin() + m.bucket_base, bucket_cell.begin() + m.bucket_base + (1u << m.lg_nb), i);
     }
     const uint32_t n_multi = (uint32_t)multi.size();
-    const uint32_t row_stride = (g.num_rows + 3u) & ~3u;
 
     HIP_TRY(c, c->d_meta.ensure(sizeof(CellMeta) * n));
     HIP_TRY(c, c->d_keys0.ensure(8 * key_off));
@@ -305,7 +303,7 @@ int run_range(afq_ctx* c, Range r) {
     HIP_TRY(c, c->d_bucket_cell.ensure(4 * n_buckets));
     HIP_TRY(c, c->d_multi_cells.ensure(4ull * std::max<uint32_t>(n_multi, 1)));
     HIP_TRY(c, c->d_tile_prefix.ensure(4ull * (n_multi + 1)));
-    HIP_TRY(c, c->d_dense.ensure(std::max<size_t>(4ull * n_multi * row_stride, 16)));
+    HIP_TRY(c, c->d_ncols.ensure(4ull * n));
     HIP_TRY(c, c->d_nnz.ensure(4ull * n));
     HIP_TRY(c, c->d_ovf.ensure(sizeof(OverflowEnt) * std::max<uint64_t>(n_buckets, 1)));
     HIP_TRY(c, c->d_status.ensure(sizeof(DevStatus)));
@@ -328,10 +326,10 @@ int run_range(afq_ctx* c, Range r) {
     if (n_multi) {
         HIP_TRY(c, hipMemcpyAsync(c->d_multi_cells.p, multi.data(), 4ull * n_multi, hipMemcpyHostToDevice, s));
         HIP_TRY(c, hipMemcpyAsync(c->d_tile_prefix.p, tile_prefix.data(), 4ull * (n_multi + 1), hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemsetAsync(c->d_dense.p, 0, 4ull * n_multi * row_stride, s));
     }
     HIP_TRY(c, hipMemsetAsync(c->d_bucket_cnt.p, 0, 4 * n_buckets, s));
     HIP_TRY(c, hipMemsetAsync(c->d_nnz.p, 0, 4ull * n, s));
+    HIP_TRY(c, hipMemsetAsync(c->d_ncols.p, 0, 4ull * n, s));
     HIP_TRY(c, hipMemsetAsync(c->d_status.p, 0, sizeof(DevStatus), s));
     HIP_TRY(c, hipMemsetAsync(c->d_bc.p, 0, 8ull * n, s));
     // the host copies above are sourced from stack/vector memory: make sure they are consumed
@@ -339,7 +337,7 @@ int run_range(afq_ctx* c, Range r) {
 
     DecodeArgs da{c->d_bytes, c->n_bytes, c->d_meta.as<CellMeta>(), n, c->d_t2g.as<uint32_t>(), c->ref_count,
                   g.num_genes, c->d_keys0.as<uint64_t>(), c->d_cell_nkeys.as<uint32_t>(),
-                  c->d_bucket_cnt.as<uint32_t>(), c->d_bc.as<uint64_t>(), c->d_status.as<DevStatus>(),
+                  c->d_bc.as<uint64_t>(), c->d_status.as<DevStatus>(),
                   par ? c->d_chk.as<CellChk>() : nullptr, c->d_slab_prefix.as<uint32_t>(), c->d_wg_cell.as<uint32_t>(),
                   (uint32_t)n_slabs};
     if (par) {
@@ -351,20 +349,19 @@ int run_range(afq_ctx* c, Range r) {
         if (launch_decode(s, da, g.bc_bytes, g.umi_bytes)) return fail(c, AFQ_ERR_INVALID_ARG, "bad field widths");
     }
     ResolveArgs ra{c->d_meta.as<CellMeta>(), c->d_bucket_cell.as<uint32_t>(), c->d_multi_cells.as<uint32_t>(),
-                   c->d_cell_nkeys.as<uint32_t>(), c->d_bucket_cnt.as<uint32_t>(), c->d_keys0.as<uint64_t>(),
-                   c->d_keys1.as<uint64_t>(), c->d_dense.as<uint32_t>(), c->d_nnz.as<uint32_t>(),
-                   c->d_ovf.as<OverflowEnt>(), c->d_status.as<DevStatus>(), (uint32_t)n_buckets, n_multi,
-                   g.usa_mode, g.num_rows, row_stride};
+                   c->d_tile_prefix.as<uint32_t>(), c->d_cell_nkeys.as<uint32_t>(), c->d_bucket_cnt.as<uint32_t>(),
+                   c->d_keys0.as<uint64_t>(), c->d_keys1.as<uint64_t>(), c->d_ncols.as<uint32_t>(),
+                   c->d_nnz.as<uint32_t>(), c->d_ovf.as<OverflowEnt>(), c->d_status.as<DevStatus>(),
+                   (uint32_t)n_buckets, n_multi, (uint32_t)n_tiles, g.usa_mode, g.num_rows};
     if (n_multi) {
-        { ScopedTimer t(c, K_BSCAN); launch_bucket_scan(s, ra.multi_cells, n_multi, ra.meta, ra.cursor); }
-        { ScopedTimer t(c, K_SCATTER);
-          launch_scatter(s, (uint32_t)n_tiles, ra.multi_cells, c->d_tile_prefix.as<uint32_t>(), n_multi, ra.meta,
-                         ra.cell_nkeys, ra.keys0, ra.keys1, ra.cursor); }
+        { ScopedTimer t(c, K_HIST); launch_hist(s, ra); }
+        { ScopedTimer t(c, K_BSCAN); launch_bucket_scan(s, ra); }
+        { ScopedTimer t(c, K_SCATTER); launch_scatter(s, ra); }
     }
     { ScopedTimer t(c, K_RESOLVE); launch_resolve(s, ra); }
     if (n_multi) {
         { ScopedTimer t(c, K_RESOLVE_BIG); launch_resolve_big(s, ra); }
-        { ScopedTimer t(c, K_EXTRACT); launch_extract_dense(s, ra); }
+        { ScopedTimer t(c, K_CELL_HIST); launch_cell_hist(s, ra); }
     }
     HIP_TRY(c, hipGetLastError());
     c->cur = r;
@@ -411,7 +408,7 @@ int finish_range(afq_ctx* c) {
     HIP_TRY(c, hipMemcpyAsync(c->d_cell_ptr.p, ptr.data(), 8ull * (n + 1), hipMemcpyHostToDevice, s));
     {
         ScopedTimer t(c, K_COMPACT);
-        launch_compact(s, c->d_meta.as<CellMeta>(), n, c->d_keys0.as<uint64_t>(), c->d_nnz.as<uint32_t>(),
+        launch_compact(s, c->d_meta.as<CellMeta>(), n, c->d_keys0.as<uint64_t>(), c->d_keys1.as<uint64_t>(), c->d_nnz.as<uint32_t>(),
                        c->d_cell_ptr.as<uint64_t>(), c->d_gene.as<uint32_t>(), c->d_val.as<float>());
     }
     HostResult& R = *c->res;
@@ -518,7 +515,7 @@ void afq_destroy(afq_ctx* c) {
     harvest_timers(c);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&c->d_t2g, &c->d_bytes_own, &c->d_meta, &c->d_keys0, &c->d_keys1, &c->d_cell_nkeys,
-                      &c->d_bucket_cnt, &c->d_bucket_cell, &c->d_multi_cells, &c->d_tile_prefix, &c->d_dense, &c->d_nnz,
+                      &c->d_bucket_cnt, &c->d_bucket_cell, &c->d_multi_cells, &c->d_tile_prefix, &c->d_ncols, &c->d_nnz,
                       &c->d_ovf, &c->d_status, &c->d_bc, &c->d_cell_ptr, &c->d_gene, &c->d_val, &c->d_chunk_off, &c->d_hdr,
                       &c->d_chk, &c->d_slab_prefix, &c->d_wg_cell};
     for (auto b : bufs) b->release();

@@ -18,7 +18,6 @@ struct DecodeArgs {
     uint32_t num_genes;
     uint64_t* keys0;
     uint32_t* cell_nkeys;
-    uint32_t* bucket_cnt;
     uint64_t* bc_out;
     DevStatus* st;
     // walk-free decode (k_decode_par) + fix-up mode of k_decode; null chk = plain sequential decode
@@ -32,19 +31,20 @@ struct ResolveArgs {
     const CellMeta* meta;
     const uint32_t* bucket_cell;
     const uint32_t* multi_cells;
+    const uint32_t* tile_prefix;
     const uint32_t* cell_nkeys;
-    uint32_t* cursor;
+    uint32_t* cursor;      // per-bucket: count -> exclusive offset -> end offset
     uint64_t* keys0;
     uint64_t* keys1;
-    uint32_t* dense;
+    uint32_t* cell_ncols;  // per-cell length of the resolved-column list (multi-bucket cells)
     uint32_t* nnz;
     OverflowEnt* ovf_list;
     DevStatus* st;
     uint32_t n_buckets;
     uint32_t n_multi;
+    uint32_t n_tiles;
     uint32_t usa;
     uint32_t num_rows;
-    uint32_t row_stride;
 };
 
 void launch_gather_headers(hipStream_t s, const uint8_t* bytes, size_t n_bytes, const uint64_t* chunk_off,
@@ -52,17 +52,15 @@ void launch_gather_headers(hipStream_t s, const uint8_t* bytes, size_t n_bytes, 
 int launch_decode(hipStream_t s, const DecodeArgs& a, uint32_t bw, uint32_t uw);
 bool decode_par_supported(uint32_t bw, uint32_t uw);
 int launch_decode_par(hipStream_t s, const DecodeArgs& a, uint32_t bw, uint32_t uw);
-void launch_bucket_scan(hipStream_t s, const uint32_t* multi_cells, uint32_t n_multi, const CellMeta* meta,
-                        uint32_t* bucket_cnt);
-void launch_scatter(hipStream_t s, uint32_t n_tiles, const uint32_t* multi_cells, const uint32_t* tile_prefix,
-                    uint32_t n_multi, const CellMeta* meta, const uint32_t* cell_nkeys, const uint64_t* keys0,
-                    uint64_t* keys1, uint32_t* cursor);
+void launch_hist(hipStream_t s, const ResolveArgs& a);
+void launch_bucket_scan(hipStream_t s, const ResolveArgs& a);
+void launch_scatter(hipStream_t s, const ResolveArgs& a);
 void launch_resolve(hipStream_t s, const ResolveArgs& a);
 void launch_resolve_big(hipStream_t s, const ResolveArgs& a);
-void launch_extract_dense(hipStream_t s, const ResolveArgs& a);
-void launch_compact(hipStream_t s, const CellMeta* meta, uint32_t n_cells, const uint64_t* keys0, const uint32_t* nnz,
-                    const uint64_t* cell_ptr, uint32_t* gene, float* val);
+void launch_cell_hist(hipStream_t s, const ResolveArgs& a);
+void launch_compact(hipStream_t s, const CellMeta* meta, uint32_t n_cells, const uint64_t* keys0, const uint64_t* keys1,
+                    const uint32_t* nnz, const uint64_t* cell_ptr, uint32_t* gene, float* val);
 
-constexpr uint32_t kScatterTileHost = 2048;  // must equal kScatterTile in afq_kernels.hip
+constexpr uint32_t kScatterTileHost = 2048;  // keys per histogram/scatter tile
 
 }  // namespace afq

@@ -150,7 +150,6 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ byte
                                                const uint32_t* __restrict__ t2g, uint32_t ref_count,
                                                uint32_t num_genes, uint64_t* __restrict__ keys0,
                                                uint32_t* __restrict__ cell_nkeys,
-                                               uint32_t* __restrict__ bucket_cnt,
                                                uint64_t* __restrict__ bc_out, DevStatus* st,
                                                const CellChk* __restrict__ chk) {
     constexpr uint32_t HDR = 4 + BW + UW;
@@ -167,8 +166,6 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ byte
             if (lane == 0) atomicAdd(&st->n_keys, (unsigned long long)cell_nkeys[cell]);
             return;
         }
-        if (m.lg_nb) for (uint32_t i = lane; i < (1u << m.lg_nb); i += 64) bucket_cnt[m.bucket_base + i] = 0;
-        __threadfence();
         if (lane == 0) atomicAdd(&st->n_fallback, 1u);
     }
     const uint64_t abase = m.chunk_off & ~3ull;         // dword-aligned base of the walk
@@ -268,7 +265,6 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ byte
         if (kcnt) {
             const uint32_t o0 = nk_total + ex;
             uint64_t* dst = keys0 + m.key_off;
-            const uint32_t bslot = m.bucket_base + bucket_of(umi, m.lg_nb);
             if (o0 + kcnt <= m.n_ref) {
                 if (!ovf) {
 #pragma unroll
@@ -290,7 +286,6 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ byte
                         if (first) dst[o++] = (umi << kGeneBits) | gj;
                     }
                 }
-                if (m.lg_nb) atomicAdd(&bucket_cnt[bslot], kcnt);
             } else bad = true;
         }
         nk_total += tot;
@@ -328,7 +323,6 @@ __global__ __launch_bounds__(256) void k_decode_par(const uint8_t* __restrict__ 
                                                    const uint32_t* __restrict__ t2g, uint32_t ref_count,
                                                    uint32_t num_genes, uint64_t* __restrict__ keys0,
                                                    uint32_t* __restrict__ cell_nkeys,
-                                                   uint32_t* __restrict__ bucket_cnt,
                                                    uint64_t* __restrict__ bc_out, CellChk* __restrict__ chk) {
     static_assert(BW % 4 == 0 && UW % 4 == 0, "aligned layouts only");
     constexpr uint32_t BWW = BW / 4, UWW = UW / 4, HW = 1 + BWW + UWW;
@@ -460,7 +454,6 @@ __global__ __launch_bounds__(256) void k_decode_par(const uint8_t* __restrict__ 
                     if (first) dst[o++] = (umi << kGeneBits) | gj;
                 }
             }
-            if (m.lg_nb) atomicAdd(&bucket_cnt[m.bucket_base + bucket_of(umi, m.lg_nb)], kcnt);
         }
     }
     // per-cell sums for the proof
@@ -474,7 +467,62 @@ __global__ __launch_bounds__(256) void k_decode_par(const uint8_t* __restrict__ 
     if (__any(fail) && lane == 0) atomicOr(&chk[cell].fail, 1u);
 }
 
+
 // ---------------------------------------------------------------------------
+// Bucket histogram.  Device-scope atomics leave the XCD (every one is a fabric
+// transaction on this 8-XCD part: rocprof WRITE_SIZE showed 3-5x the payload when
+// they were issued per record), so counts are first combined in LDS over a tile
+// of kTileKeys keys and flushed with one atomic per non-empty bucket per tile.
+constexpr uint32_t kTileKeys = kScatterTileHost;  // 2048
+constexpr uint32_t kLdsBins = 2048;               // buckets per cell the LDS paths can hold
+
+__device__ __forceinline__ void tile_to_cell(const uint32_t* __restrict__ tile_prefix, uint32_t n_multi,
+                                             uint32_t tile, uint32_t* s_bcast, uint32_t& ci, uint32_t& local_tile) {
+    if (threadIdx.x == 0) {
+        uint32_t lo = 0, hi = n_multi;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (tile_prefix[mid] <= tile) lo = mid; else hi = mid;
+        }
+        s_bcast[0] = lo;
+    }
+    __syncthreads();
+    ci = s_bcast[0];
+    local_tile = tile - tile_prefix[ci];
+}
+
+__global__ __launch_bounds__(256) void k_hist(const uint32_t* __restrict__ multi_cells,
+                                             const uint32_t* __restrict__ tile_prefix, uint32_t n_multi,
+                                             const CellMeta* __restrict__ meta,
+                                             const uint32_t* __restrict__ cell_nkeys,
+                                             const uint64_t* __restrict__ keys0, uint32_t* __restrict__ bucket_cnt) {
+    __shared__ uint32_t s_hist[kLdsBins];
+    __shared__ uint32_t s_b[1];
+    uint32_t ci, lt;
+    tile_to_cell(tile_prefix, n_multi, blockIdx.x, s_b, ci, lt);
+    const uint32_t cell = multi_cells[ci];
+    const CellMeta m = meta[cell];
+    const uint32_t nk = cell_nkeys[cell];
+    const uint32_t t0 = lt * kTileKeys;
+    if (t0 >= nk) return;
+    const uint32_t t1 = min(nk, t0 + kTileKeys);
+    const uint64_t* src = keys0 + m.key_off;
+    uint32_t* gcnt = bucket_cnt + m.bucket_base;
+    const uint32_t nb = 1u << m.lg_nb;
+    if (nb > kLdsBins) {  // giant cell: straight to global
+        for (uint32_t i = t0 + threadIdx.x; i < t1; i += 256) atomicAdd(&gcnt[bucket_of(src[i] >> kGeneBits, m.lg_nb)], 1u);
+        return;
+    }
+    for (uint32_t b = threadIdx.x; b < nb; b += 256) s_hist[b] = 0;
+    __syncthreads();
+    for (uint32_t i = t0 + threadIdx.x; i < t1; i += 256) atomicAdd(&s_hist[bucket_of(src[i] >> kGeneBits, m.lg_nb)], 1u);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += 256) {
+        const uint32_t c = s_hist[b];
+        if (c) atomicAdd(&gcnt[b], c);
+    }
+}
+
 // per-cell exclusive scan of bucket counts (in place): wave per multi-bucket cell
 __global__ __launch_bounds__(256) void k_bucket_scan(const uint32_t* __restrict__ multi_cells, uint32_t n_multi,
                                                     const CellMeta* __restrict__ meta,
@@ -494,40 +542,186 @@ __global__ __launch_bounds__(256) void k_bucket_scan(const uint32_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------
-// keys0 -> keys1 grouped by bucket.  After the kernel cursor[b] = end offset of
-// bucket b inside its cell's region (start = previous bucket's end).
-constexpr uint32_t kScatterTile = kScatterTileHost;
+// keys0 -> keys1 grouped by bucket: LDS multisplit of a kTileKeys tile.  Ranks
+// inside a bucket come from LDS atomics, one global atomic per non-empty bucket
+// reserves the tile's range, and the tile is written out bucket-major so the
+// stores of a bucket's run are contiguous.  After the kernel cursor[b] = end
+// offset of bucket b inside its cell's region (start = previous bucket's end).
 __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ multi_cells,
                                                 const uint32_t* __restrict__ tile_prefix, uint32_t n_multi,
                                                 const CellMeta* __restrict__ meta,
                                                 const uint32_t* __restrict__ cell_nkeys,
                                                 const uint64_t* __restrict__ keys0, uint64_t* __restrict__ keys1,
                                                 uint32_t* __restrict__ cursor) {
-    // binary search: tile_prefix[ci] <= blockIdx.x < tile_prefix[ci+1]
-    uint32_t lo = 0, hi = n_multi;
-    while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (tile_prefix[mid] <= blockIdx.x) lo = mid; else hi = mid;
-    }
-    const uint32_t cell = multi_cells[lo];
+    constexpr uint32_t E = kTileKeys / 256;
+    __shared__ uint64_t s_keys[kTileKeys];
+    __shared__ uint32_t s_cnt[kLdsBins];   // per-bucket count, then tile-local exclusive offset
+    __shared__ uint32_t s_base[kLdsBins];  // global position of the tile's first key of the bucket
+    __shared__ uint32_t s_ws[4];
+    __shared__ uint32_t s_b[1];
+    uint32_t ci, lt;
+    tile_to_cell(tile_prefix, n_multi, blockIdx.x, s_b, ci, lt);
+    const uint32_t cell = multi_cells[ci];
     const CellMeta m = meta[cell];
     const uint32_t nk = cell_nkeys[cell];
-    const uint32_t t0 = (blockIdx.x - tile_prefix[lo]) * kScatterTile;
-    const uint32_t t1 = min(nk, t0 + kScatterTile);
+    const uint32_t t0 = lt * kTileKeys;
+    if (t0 >= nk) return;
+    const uint32_t t1 = min(nk, t0 + kTileKeys);
     const uint64_t* src = keys0 + m.key_off;
     uint64_t* dst = keys1 + m.key_off;
-    for (uint32_t i = t0 + threadIdx.x; i < t1; i += 256) {
-        const uint64_t key = src[i];
-        const uint32_t b = bucket_of(key >> kGeneBits, m.lg_nb);
-        const uint32_t p = atomicAdd(&cursor[m.bucket_base + b], 1u);
-        dst[p] = key;
+    uint32_t* gcur = cursor + m.bucket_base;
+    const uint32_t nb = 1u << m.lg_nb;
+    if (nb > kLdsBins) {  // giant cell: per-key global atomics
+        for (uint32_t i = t0 + threadIdx.x; i < t1; i += 256) {
+            const uint64_t key = src[i];
+            dst[atomicAdd(&gcur[bucket_of(key >> kGeneBits, m.lg_nb)], 1u)] = key;
+        }
+        return;
     }
+    for (uint32_t b = threadIdx.x; b < nb; b += 256) s_cnt[b] = 0;
+    __syncthreads();
+    uint64_t key[E];
+    uint32_t rank[E];
+#pragma unroll
+    for (uint32_t e = 0; e < E; ++e) {
+        const uint32_t i = t0 + e * 256 + threadIdx.x;
+        key[e] = kKeySentinel;
+        rank[e] = 0;
+        if (i < t1) {
+            key[e] = src[i];
+            rank[e] = atomicAdd(&s_cnt[bucket_of(key[e] >> kGeneBits, m.lg_nb)], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the bucket counts (tile-local offsets) + global reservation
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nb; base += 256) {
+        const uint32_t b = base + threadIdx.x;
+        const uint32_t c = b < nb ? s_cnt[b] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<256>(c, s_ws, tot);
+        if (b < nb) {
+            s_cnt[b] = carry + ex;
+            s_base[b] = c ? atomicAdd(&gcur[b], c) : 0u;
+        }
+        carry += tot;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t e = 0; e < E; ++e) {
+        const uint32_t i = t0 + e * 256 + threadIdx.x;
+        if (i < t1) s_keys[s_cnt[bucket_of(key[e] >> kGeneBits, m.lg_nb)] + rank[e]] = key[e];
+    }
+    __syncthreads();
+    const uint32_t nt = t1 - t0;
+    for (uint32_t i = threadIdx.x; i < nt; i += 256) {
+        const uint64_t kx = s_keys[i];
+        const uint32_t b = bucket_of(kx >> kGeneBits, m.lg_nb);
+        dst[s_base[b] + (i - s_cnt[b])] = kx;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Workgroup sort with the data in registers.  Thread t of wave w holds E
+// elements; element h of lane l is position w*64*E + h*64 + l of the block of
+// N = NT*E elements.  A bitonic compare-exchange at distance j is a cross-lane
+// shuffle (j < 64), a register swap inside the thread (64 <= j < 64*E) or, only
+// for j >= 64*E, a trip through LDS with barriers - 3 such stages for N <= 2048
+// instead of one barrier per stage (45-66) with the data in LDS.
+template <typename T>
+__device__ __forceinline__ T shfl_xor_t(T v, int j);
+template <>
+__device__ __forceinline__ uint64_t shfl_xor_t<uint64_t>(uint64_t v, int j) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl_xor(lo, j);
+    hi = __shfl_xor(hi, j);
+    return ((uint64_t)hi << 32) | lo;
+}
+template <>
+__device__ __forceinline__ uint32_t shfl_xor_t<uint32_t>(uint32_t v, int j) { return __shfl_xor(v, j); }
+
+template <int E, int JH, typename T>
+__device__ __forceinline__ void reg_stage(T (&a)[E], uint32_t idx0, uint32_t k) {
+#pragma unroll
+    for (int h = 0; h < E; ++h) {
+        if ((h & JH) == 0 && (h | JH) < E) {
+            const bool asc = ((idx0 + h * 64) & k) == 0;
+            const T x = a[h], y = a[h | JH];
+            const bool sw = asc ? (x > y) : (x < y);
+            a[h] = sw ? y : x;
+            a[h | JH] = sw ? x : y;
+        }
+    }
+}
+
+template <int NT, int E, typename T>
+__device__ __forceinline__ void reg_bitonic_sort(T (&a)[E], T* s_x) {
+    constexpr uint32_t N = NT * E;
+    const uint32_t lane = lane_id();
+    const uint32_t wbase = (threadIdx.x >> 6) * 64 * E;
+    for (uint32_t k = 2; k <= N; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            if (j < 64) {
+#pragma unroll
+                for (int h = 0; h < E; ++h) {
+                    const uint32_t idx = wbase + h * 64 + lane;
+                    const T o = shfl_xor_t<T>(a[h], (int)j);
+                    const bool want_min = (((idx & j) == 0) == ((idx & k) == 0));
+                    const T mn = a[h] < o ? a[h] : o, mx = a[h] < o ? o : a[h];
+                    a[h] = want_min ? mn : mx;
+                }
+            } else if (j < 64 * E) {
+                // partner is another register of the same thread; keep the indices compile-time
+                if (E >= 2 && j == 64) reg_stage<E, 1, T>(a, wbase + lane, k);
+                else if (E >= 4 && j == 128) reg_stage<E, 2, T>(a, wbase + lane, k);
+                else if (E >= 8 && j == 256) reg_stage<E, 4, T>(a, wbase + lane, k);
+            } else {
+                __syncthreads();
+#pragma unroll
+                for (int h = 0; h < E; ++h) s_x[wbase + h * 64 + lane] = a[h];
+                __syncthreads();
+#pragma unroll
+                for (int h = 0; h < E; ++h) {
+                    const uint32_t idx = wbase + h * 64 + lane;
+                    const T o = s_x[idx ^ j];
+                    const bool want_min = (((idx & j) == 0) == ((idx & k) == 0));
+                    const T mn = a[h] < o ? a[h] : o, mx = a[h] < o ? o : a[h];
+                    a[h] = want_min ? mn : mx;
+                }
+            }
+        }
+    }
+}
+
+// load n (<= NT*E) elements, sort ascending, leave them sorted in s_x[0..n)
+template <int NT, int E, typename T>
+__device__ __forceinline__ void block_sort_to_lds(const T* src, uint32_t n, T* s_x, T sentinel) {
+    T a[E];
+    const uint32_t wbase = (threadIdx.x >> 6) * 64 * E;
+#pragma unroll
+    for (int h = 0; h < E; ++h) {
+        const uint32_t idx = wbase + h * 64 + lane_id();
+        a[h] = idx < n ? src[idx] : sentinel;
+    }
+    reg_bitonic_sort<NT, E, T>(a, s_x);
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < E; ++h) s_x[wbase + h * 64 + lane_id()] = a[h];
+    __syncthreads();
+}
+
+template <int NT, typename T>
+__device__ __forceinline__ void block_sort_any(const T* src, uint32_t n, T* s_x, T sentinel) {
+    if (n <= NT) block_sort_to_lds<NT, 1, T>(src, n, s_x, sentinel);
+    else if (n <= 2 * NT) block_sort_to_lds<NT, 2, T>(src, n, s_x, sentinel);
+    else if (n <= 4 * NT) block_sort_to_lds<NT, 4, T>(src, n, s_x, sentinel);
+    else block_sort_to_lds<NT, 8, T>(src, n, s_x, sentinel);
 }
 
 // ---------------------------------------------------------------------------
 // resolve core, shared by the LDS and the global-scratch variants.
 struct ResolveCfg {
-    uint32_t usa, num_rows, uo, ao, row_stride;
+    uint32_t usa, num_rows, uo, ao;
 };
 
 __device__ __forceinline__ bool is_spliced(uint32_t g) { return (g & 1u) == 0; }
@@ -550,8 +744,8 @@ __device__ __forceinline__ void resolve_sorted(const uint64_t* keys, uint32_t n,
         carry += tot;
     }
     const uint32_t nruns = carry;
-    if (threadIdx.x == 0) run_start[nruns] = n;
     __syncthreads();
+    auto run_end = [&](uint32_t q) { return q + 1 < nruns ? run_start[q + 1] : n; };  // no sentinel slot needed
     for (uint32_t r = threadIdx.x; r < nruns; r += NT) {
         const uint64_t umi = keys[run_start[r]] >> kGeneBits;
         if (r > 0 && (keys[run_start[r - 1]] >> kGeneBits) == umi) continue;  // not the UMI's first run
@@ -559,7 +753,7 @@ __device__ __forceinline__ void resolve_sorted(const uint64_t* keys, uint32_t n,
         for (uint32_t q = r; q < nruns; ++q) {
             const uint32_t s = run_start[q];
             if ((keys[s] >> kGeneBits) != umi) break;
-            const uint32_t c = run_start[q + 1] - s;
+            const uint32_t c = run_end(q) - s;
             maxc = c > maxc ? c : maxc;
         }
         uint32_t nb = 0, g1 = 0, g2 = 0, nsp = 0, first_sp = 0;
@@ -568,7 +762,7 @@ __device__ __forceinline__ void resolve_sorted(const uint64_t* keys, uint32_t n,
             const uint32_t s = run_start[q];
             const uint64_t kq = keys[s];
             if ((kq >> kGeneBits) != umi) break;
-            if (run_start[q + 1] - s != maxc) continue;
+            if (run_end(q) - s != maxc) continue;
             const uint32_t g = (uint32_t)kq & kGeneMask;
             ++nb;
             if (nb == 1) g1 = g;
@@ -597,20 +791,25 @@ __device__ __forceinline__ void resolve_sorted(const uint64_t* keys, uint32_t n,
 
 constexpr int kResolveNT = 256;
 
+// One workgroup per bucket.  Single-bucket cells are finished here (columns
+// sorted and run-length counted in LDS, pairs written over the cell's dead key
+// slots).  Buckets of multi-bucket cells append their resolved columns to the
+// cell's column list (one global atomic per bucket reserves the range); the
+// per-cell count happens in k_cell_hist.
 __global__ __launch_bounds__(kResolveNT) void k_resolve(const CellMeta* __restrict__ meta,
                                                        const uint32_t* __restrict__ bucket_cell,
                                                        const uint32_t* __restrict__ cell_nkeys,
                                                        const uint32_t* __restrict__ cursor,
                                                        uint64_t* __restrict__ keys0,
                                                        const uint64_t* __restrict__ keys1,
-                                                       uint32_t* __restrict__ dense, uint32_t* __restrict__ nnz,
+                                                       uint32_t* __restrict__ cell_ncols, uint32_t* __restrict__ nnz,
                                                        OverflowEnt* __restrict__ ovf_list, DevStatus* st,
                                                        ResolveCfg rc) {
     __shared__ uint64_t s_keys[kBucketCap];
     __shared__ uint32_t s_run[kBucketCap + 1];
     __shared__ uint32_t s_cols[kBucketCap];
     __shared__ uint32_t s_ws[kResolveNT / 64];
-    __shared__ uint32_t s_ncols;
+    __shared__ uint32_t s_ncols, s_gbase;
     const uint32_t b = blockIdx.x;
     const uint32_t cell = bucket_cell[b];
     const CellMeta m = meta[cell];
@@ -637,31 +836,30 @@ __global__ __launch_bounds__(kResolveNT) void k_resolve(const CellMeta* __restri
         }
         return;
     }
-    for (uint32_t i = threadIdx.x; i < n; i += kResolveNT) s_keys[i] = src[i];
     if (threadIdx.x == 0) s_ncols = 0;
-    __syncthreads();
-    bitonic_sort<kResolveNT>(s_keys, n);
-    if (m.lg_nb != 0) {
-        uint32_t* row = dense + (size_t)m.dense_row * rc.row_stride;
-        resolve_sorted<kResolveNT>(s_keys, n, s_run, s_ws, rc, [&](uint32_t col) {
-            if (col >= rc.num_rows) { set_err(st, kErrSlotRange, cell); return; }
-            atomicAdd(&row[col], 1u);
-        });
-        return;
-    }
-    // single-bucket cell: finish here.  columns -> LDS, sort, run-length, write pairs
+    block_sort_any<kResolveNT, uint64_t>(src, n, s_keys, kKeySentinel);
     resolve_sorted<kResolveNT>(s_keys, n, s_run, s_ws, rc, [&](uint32_t col) {
         if (col >= rc.num_rows) { set_err(st, kErrSlotRange, cell); return; }
         s_cols[atomicAdd(&s_ncols, 1u)] = col;
     });
     __syncthreads();
     const uint32_t nc = s_ncols;
-    bitonic_sort<kResolveNT>(s_cols, nc);
-    uint2* out = reinterpret_cast<uint2*>(keys0 + m.key_off);  // the cell's key slots are dead: reuse as pair staging
+    if (m.lg_nb != 0) {
+        if (nc == 0) return;
+        if (threadIdx.x == 0) s_gbase = atomicAdd(&cell_ncols[cell], nc);
+        __syncthreads();
+        uint32_t* out = reinterpret_cast<uint32_t*>(keys0 + m.key_off) + s_gbase;  // keys0 slots are dead after k_scatter
+        for (uint32_t i = threadIdx.x; i < nc; i += kResolveNT) out[i] = s_cols[i];
+        return;
+    }
+    // single-bucket cell: sort the columns, run-length count, write (column,count) pairs
+    uint32_t* s_sorted = reinterpret_cast<uint32_t*>(s_keys);  // keys are dead
+    block_sort_any<kResolveNT, uint32_t>(s_cols, nc, s_sorted, 0xFFFFFFFFu);
+    uint2* out = reinterpret_cast<uint2*>(keys0 + m.key_off);
     uint32_t carry = 0;
     for (uint32_t base = 0; base < nc; base += kResolveNT) {
         const uint32_t i = base + threadIdx.x;
-        const uint32_t f = (i < nc) && (i == 0 || s_cols[i] != s_cols[i - 1]);
+        const uint32_t f = (i < nc) && (i == 0 || s_sorted[i] != s_sorted[i - 1]);
         uint32_t tot;
         const uint32_t ex = block_excl_scan<kResolveNT>(f, s_ws, tot);
         if (f) s_run[carry + ex] = i;
@@ -670,19 +868,20 @@ __global__ __launch_bounds__(kResolveNT) void k_resolve(const CellMeta* __restri
     if (threadIdx.x == 0) { s_run[carry] = nc; nnz[cell] = carry; }
     __syncthreads();
     for (uint32_t h = threadIdx.x; h < carry; h += kResolveNT)
-        out[h] = make_uint2(s_cols[s_run[h]], s_run[h + 1] - s_run[h]);
+        out[h] = make_uint2(s_sorted[s_run[h]], s_run[h + 1] - s_run[h]);
 }
 
 // Buckets larger than the LDS cap (heavy PCR duplication of one UMI, adversarial
-// input): same algorithm with the bucket sorted in place in keys1 and the run
-// table in the matching, dead window of keys0.  Persistent blocks loop over the
-// overflow list; with no overflow every block exits at once.
+// input): same algorithm with the bucket sorted in place in keys1 (normalised
+// bitonic network, any n) and the run table in a scratch area past the cell's
+// column list.  Persistent blocks loop over the overflow list; with no overflow
+// every block exits at once.
 constexpr int kBigNT = 1024;
 __global__ __launch_bounds__(kBigNT) void k_resolve_big(const CellMeta* __restrict__ meta,
                                                        const uint32_t* __restrict__ bucket_cell,
                                                        const uint32_t* __restrict__ cursor,
                                                        uint64_t* __restrict__ keys0, uint64_t* __restrict__ keys1,
-                                                       uint32_t* __restrict__ dense,
+                                                       uint32_t* __restrict__ cell_ncols,
                                                        const OverflowEnt* __restrict__ ovf_list, DevStatus* st,
                                                        ResolveCfg rc) {
     __shared__ uint32_t s_ws[kBigNT / 64];
@@ -694,46 +893,64 @@ __global__ __launch_bounds__(kBigNT) void k_resolve_big(const CellMeta* __restri
         const uint32_t beg = (b == m.bucket_base) ? 0u : cursor[b - 1];
         const uint32_t n = cursor[b] - beg;
         uint64_t* keys = keys1 + m.key_off + beg;
-        uint32_t* run = reinterpret_cast<uint32_t*>(keys0 + m.key_off + beg);  // 2n words >= n+1
+        // keys0 region of the cell = 2*n_ref words: words [0, n_ref) hold the column list (<= nkeys <= n_ref
+        // entries); the run table of this bucket (<= n entries) lives at words [n_ref + beg, n_ref + beg + n),
+        // disjoint between buckets because their [beg, beg+n) key ranges are.
+        uint32_t* run = reinterpret_cast<uint32_t*>(keys0 + m.key_off) + m.n_ref + beg;
         __syncthreads();
         bitonic_sort<kBigNT>(keys, n);
-        uint32_t* row = dense + (size_t)m.dense_row * rc.row_stride;
+        uint32_t* cols = reinterpret_cast<uint32_t*>(keys0 + m.key_off);
         resolve_sorted<kBigNT>(keys, n, run, s_ws, rc, [&](uint32_t col) {
             if (col >= rc.num_rows) { set_err(st, kErrSlotRange, cell); return; }
-            atomicAdd(&row[col], 1u);
+            cols[atomicAdd(&cell_ncols[cell], 1u)] = col;
         });
         __syncthreads();
     }
 }
 
 // ---------------------------------------------------------------------------
-// dense count row of a multi-bucket cell -> ascending (column,count) pairs
-__global__ __launch_bounds__(256) void k_extract_dense(const uint32_t* __restrict__ multi_cells,
+// Per-cell count of the resolved columns of a multi-bucket cell: one workgroup
+// per cell histograms the column list into LDS (32768 bins per pass = 128 KiB of
+// the CU's 160 KiB; ceil(num_rows/32768) passes over the L2-resident list), then
+// compacts the non-zero bins in column order into (column,count) pairs written
+// over the cell's dead keys1 slots.  No global atomics, no dense scratch rows.
+constexpr int kHistNT = 1024;
+constexpr uint32_t kHistBins = 32768;
+__global__ __launch_bounds__(kHistNT) void k_cell_hist(const uint32_t* __restrict__ multi_cells,
                                                       const CellMeta* __restrict__ meta,
-                                                      const uint32_t* __restrict__ dense, uint64_t* __restrict__ keys0,
+                                                      const uint64_t* __restrict__ keys0, uint64_t* __restrict__ keys1,
+                                                      const uint32_t* __restrict__ cell_ncols,
                                                       uint32_t* __restrict__ nnz, ResolveCfg rc) {
-    __shared__ uint32_t s_ws[4];
+    __shared__ uint32_t s_hist[kHistBins];
+    __shared__ uint32_t s_ws[kHistNT / 64];
     const uint32_t cell = multi_cells[blockIdx.x];
     const CellMeta m = meta[cell];
-    const uint4* row = reinterpret_cast<const uint4*>(dense + (size_t)m.dense_row * rc.row_stride);
-    uint2* out = reinterpret_cast<uint2*>(keys0 + m.key_off);
-    const uint32_t nq = rc.row_stride >> 2;
+    const uint32_t* cols = reinterpret_cast<const uint32_t*>(keys0 + m.key_off);
+    uint2* out = reinterpret_cast<uint2*>(keys1 + m.key_off);
+    const uint32_t nc = cell_ncols[cell];
     uint32_t carry = 0;
-    for (uint32_t base = 0; base < nq; base += 256) {
-        const uint32_t q = base + threadIdx.x;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (q < nq) v = row[q];
-        const uint32_t c = (v.x != 0) + (v.y != 0) + (v.z != 0) + (v.w != 0);
-        uint32_t tot;
-        uint32_t o = carry + block_excl_scan<256>(c, s_ws, tot);
-        if (c) {
-            const uint32_t col = q << 2;
-            if (v.x) out[o++] = make_uint2(col, v.x);
-            if (v.y) out[o++] = make_uint2(col + 1, v.y);
-            if (v.z) out[o++] = make_uint2(col + 2, v.z);
-            if (v.w) out[o++] = make_uint2(col + 3, v.w);
+    for (uint32_t lo = 0; lo < rc.num_rows; lo += kHistBins) {
+        const uint32_t nbins = min(kHistBins, rc.num_rows - lo);
+        for (uint32_t i = threadIdx.x; i < nbins; i += kHistNT) s_hist[i] = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nc; i += kHistNT) {
+            const uint32_t c = cols[i] - lo;
+            if (c < nbins) atomicAdd(&s_hist[c], 1u);
         }
-        carry += tot;
+        __syncthreads();
+        for (uint32_t base = 0; base < nbins; base += kHistNT * 4) {
+            const uint32_t q = base + threadIdx.x * 4;
+            uint32_t v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (q + e < nbins) ? s_hist[q + e] : 0u;
+            const uint32_t c = (v[0] != 0) + (v[1] != 0) + (v[2] != 0) + (v[3] != 0);
+            uint32_t tot;
+            uint32_t o = carry + block_excl_scan<kHistNT>(c, s_ws, tot);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (v[e]) out[o++] = make_uint2(lo + q + e, v[e]);
+            carry += tot;
+        }
+        __syncthreads();
     }
     if (threadIdx.x == 0) nnz[cell] = carry;
 }
@@ -741,13 +958,14 @@ __global__ __launch_bounds__(256) void k_extract_dense(const uint32_t* __restric
 // ---------------------------------------------------------------------------
 // staging pairs -> final CSR (wave per cell)
 __global__ __launch_bounds__(256) void k_compact(const CellMeta* __restrict__ meta, uint32_t n_cells,
-                                                const uint64_t* __restrict__ keys0,
+                                                const uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
                                                 const uint32_t* __restrict__ nnz,
                                                 const uint64_t* __restrict__ cell_ptr, uint32_t* __restrict__ gene,
                                                 float* __restrict__ val) {
     const uint32_t cell = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (cell >= n_cells) return;
-    const uint2* src = reinterpret_cast<const uint2*>(keys0 + meta[cell].key_off);
+    const CellMeta m = meta[cell];
+    const uint2* src = reinterpret_cast<const uint2*>((m.lg_nb ? keys1 : keys0) + m.key_off);
     const uint32_t n = nnz[cell];
     const uint64_t o = cell_ptr[cell];
     for (uint32_t i = lane_id(); i < n; i += 64) {
@@ -770,7 +988,7 @@ void launch_gather_headers(hipStream_t s, const uint8_t* bytes, size_t n_bytes, 
 template <int BW, int UW>
 static void launch_decode_t(hipStream_t s, const DecodeArgs& a) {
     AFQ_LAUNCH((k_decode<BW, UW>), (a.n_cells + 3) / 4, 256, s, a.bytes, a.n_bytes, a.meta, a.n_cells, a.t2g,
-               a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bucket_cnt, a.bc_out, a.st, a.chk);
+               a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out, a.st, a.chk);
 }
 
 int launch_decode(hipStream_t s, const DecodeArgs& a, uint32_t bw, uint32_t uw) {
@@ -787,7 +1005,7 @@ int launch_decode(hipStream_t s, const DecodeArgs& a, uint32_t bw, uint32_t uw) 
 template <int BW, int UW>
 static void launch_decode_par_t(hipStream_t s, const DecodeArgs& a) {
     AFQ_LAUNCH((k_decode_par<BW, UW>), (a.n_slabs + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix, a.wg_cell,
-               a.n_slabs, a.t2g, a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bucket_cnt, a.bc_out,
+               a.n_slabs, a.t2g, a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out,
                const_cast<CellChk*>(a.chk));
 }
 
@@ -802,23 +1020,25 @@ int launch_decode_par(hipStream_t s, const DecodeArgs& a, uint32_t bw, uint32_t 
     return -1;
 }
 
-void launch_bucket_scan(hipStream_t s, const uint32_t* multi_cells, uint32_t n_multi, const CellMeta* meta,
-                        uint32_t* bucket_cnt) {
-    if (!n_multi) return;
-    AFQ_LAUNCH(k_bucket_scan, (n_multi + 3) / 4, 256, s, multi_cells, n_multi, meta, bucket_cnt);
+void launch_hist(hipStream_t s, const ResolveArgs& a) {
+    if (!a.n_tiles) return;
+    AFQ_LAUNCH(k_hist, a.n_tiles, 256, s, a.multi_cells, a.tile_prefix, a.n_multi, a.meta, a.cell_nkeys, a.keys0, a.cursor);
 }
 
-void launch_scatter(hipStream_t s, uint32_t n_tiles, const uint32_t* multi_cells, const uint32_t* tile_prefix,
-                    uint32_t n_multi, const CellMeta* meta, const uint32_t* cell_nkeys, const uint64_t* keys0,
-                    uint64_t* keys1, uint32_t* cursor) {
-    if (!n_tiles) return;
-    AFQ_LAUNCH(k_scatter, n_tiles, 256, s, multi_cells, tile_prefix, n_multi, meta, cell_nkeys, keys0, keys1, cursor);
+void launch_bucket_scan(hipStream_t s, const ResolveArgs& a) {
+    if (!a.n_multi) return;
+    AFQ_LAUNCH(k_bucket_scan, (a.n_multi + 3) / 4, 256, s, a.multi_cells, a.n_multi, a.meta, a.cursor);
+}
+
+void launch_scatter(hipStream_t s, const ResolveArgs& a) {
+    if (!a.n_tiles) return;
+    AFQ_LAUNCH(k_scatter, a.n_tiles, 256, s, a.multi_cells, a.tile_prefix, a.n_multi, a.meta, a.cell_nkeys, a.keys0,
+               a.keys1, a.cursor);
 }
 
 static ResolveCfg make_rc(const ResolveArgs& a) {
     ResolveCfg rc;
     rc.usa = a.usa; rc.num_rows = a.num_rows; rc.uo = a.num_rows / 3; rc.ao = 2 * (a.num_rows / 3);
-    rc.row_stride = a.row_stride;
     return rc;
 }
 
@@ -826,26 +1046,26 @@ void launch_resolve(hipStream_t s, const ResolveArgs& a) {
     if (!a.n_buckets) return;
     ResolveCfg rc = make_rc(a);
     AFQ_LAUNCH(k_resolve, a.n_buckets, kResolveNT, s, a.meta, a.bucket_cell, a.cell_nkeys, a.cursor, a.keys0, a.keys1,
-               a.dense, a.nnz, a.ovf_list, a.st, rc);
+               a.cell_ncols, a.nnz, a.ovf_list, a.st, rc);
 }
 
 void launch_resolve_big(hipStream_t s, const ResolveArgs& a) {
     if (!a.n_multi) return;
     ResolveCfg rc = make_rc(a);
-    AFQ_LAUNCH(k_resolve_big, 256, kBigNT, s, a.meta, a.bucket_cell, a.cursor, a.keys0, a.keys1, a.dense, a.ovf_list,
-               a.st, rc);
+    AFQ_LAUNCH(k_resolve_big, 256, kBigNT, s, a.meta, a.bucket_cell, a.cursor, a.keys0, a.keys1, a.cell_ncols,
+               a.ovf_list, a.st, rc);
 }
 
-void launch_extract_dense(hipStream_t s, const ResolveArgs& a) {
+void launch_cell_hist(hipStream_t s, const ResolveArgs& a) {
     if (!a.n_multi) return;
     ResolveCfg rc = make_rc(a);
-    AFQ_LAUNCH(k_extract_dense, a.n_multi, 256, s, a.multi_cells, a.meta, a.dense, a.keys0, a.nnz, rc);
+    AFQ_LAUNCH(k_cell_hist, a.n_multi, kHistNT, s, a.multi_cells, a.meta, a.keys0, a.keys1, a.cell_ncols, a.nnz, rc);
 }
 
-void launch_compact(hipStream_t s, const CellMeta* meta, uint32_t n_cells, const uint64_t* keys0, const uint32_t* nnz,
-                    const uint64_t* cell_ptr, uint32_t* gene, float* val) {
+void launch_compact(hipStream_t s, const CellMeta* meta, uint32_t n_cells, const uint64_t* keys0, const uint64_t* keys1,
+                    const uint32_t* nnz, const uint64_t* cell_ptr, uint32_t* gene, float* val) {
     if (!n_cells) return;
-    AFQ_LAUNCH(k_compact, (n_cells + 3) / 4, 256, s, meta, n_cells, keys0, nnz, cell_ptr, gene, val);
+    AFQ_LAUNCH(k_compact, (n_cells + 3) / 4, 256, s, meta, n_cells, keys0, keys1, nnz, cell_ptr, gene, val);
 }
 
 }  // namespace afq
