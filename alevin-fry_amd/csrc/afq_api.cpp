@@ -127,7 +127,7 @@ struct afq_ctx {
     size_t n_bytes = 0;
     // per-range device state
     DevBuf d_meta, d_keys0, d_keys1, d_cell_nkeys, d_bucket_cnt, d_bucket_cell, d_multi_cells, d_tile_prefix, d_ncols,
-        d_nnz, d_ovf, d_status, d_bc, d_cell_ptr, d_gene, d_val, d_chunk_off, d_hdr, d_chk, d_slab_prefix, d_wg_cell;
+        d_nnz, d_ovf, d_status, d_bc, d_cell_ptr, d_gene, d_val, d_chunk_off, d_hdr, d_chk, d_slab_prefix, d_slab_cell, d_cell_bc, d_bdesc;
     bool all_aligned = true;  // every chunk offset is a multiple of 4
     ResultPool* pool = nullptr;
     // host planning state
@@ -244,7 +244,7 @@ int run_range(afq_ctx* c, Range r) {
     const uint32_t H = hdr_bytes(g);
     const uint32_t n = r.c1 - r.c0;
     c->meta.resize(n);
-    std::vector<uint32_t> multi, tile_prefix, bucket_cell, slab_prefix, wg_cell;
+    std::vector<uint32_t> multi, tile_prefix, bucket_cell, slab_prefix;
     const bool par = c->all_aligned && decode_par_supported(g.bc_bytes, g.umi_bytes);
     uint64_t key_off = 0, n_buckets = 0, n_tiles = 0, n_slabs = 0;
     if (par) slab_prefix.reserve(n + 1);
@@ -278,12 +278,6 @@ int run_range(afq_ctx* c, Range r) {
     if (n_slabs >= 0xFFFFFFF0ull) return fail(c, AFQ_ERR_UNSUPPORTED, "batch too large for 32-bit slab ids");
     if (par) {
         slab_prefix.push_back((uint32_t)n_slabs);
-        wg_cell.resize((n_slabs + 3) / 4);
-        uint32_t cell = 0;
-        for (size_t w = 0; w < wg_cell.size(); ++w) {
-            while (cell + 1 < n && slab_prefix[cell + 1] <= 4 * w) ++cell;
-            wg_cell[w] = cell;
-        }
     }
     if (n_buckets >= 0xFFFFFFF0ull || n_tiles >= 0xFFFFFFF0ull || key_off >= (1ull << 40))
         return fail(c, AFQ_ERR_UNSUPPORTED, "batch too large for 32-bit bucket/tile ids");
@@ -306,18 +300,19 @@ int run_range(afq_ctx* c, Range r) {
     HIP_TRY(c, c->d_ncols.ensure(4ull * n));
     HIP_TRY(c, c->d_nnz.ensure(4ull * n));
     HIP_TRY(c, c->d_ovf.ensure(sizeof(OverflowEnt) * std::max<uint64_t>(n_buckets, 1)));
+    HIP_TRY(c, c->d_bdesc.ensure(bucket_desc_bytes() * std::max<uint64_t>(n_buckets, 1)));
     HIP_TRY(c, c->d_status.ensure(sizeof(DevStatus)));
     HIP_TRY(c, c->d_bc.ensure(8ull * n));
     if (par) {
         HIP_TRY(c, c->d_chk.ensure(sizeof(CellChk) * n));
         HIP_TRY(c, c->d_slab_prefix.ensure(4ull * (n + 1)));
-        HIP_TRY(c, c->d_wg_cell.ensure(4ull * std::max<size_t>(wg_cell.size(), 1)));
+        HIP_TRY(c, c->d_slab_cell.ensure(4ull * std::max<uint64_t>(n_slabs, 1)));
+        HIP_TRY(c, c->d_cell_bc.ensure(8ull * n));
     }
 
     hipStream_t s = c->stream;
     if (par) {
         HIP_TRY(c, hipMemcpyAsync(c->d_slab_prefix.p, slab_prefix.data(), 4ull * (n + 1), hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemcpyAsync(c->d_wg_cell.p, wg_cell.data(), 4ull * wg_cell.size(), hipMemcpyHostToDevice, s));
         HIP_TRY(c, hipMemsetAsync(c->d_chk.p, 0, sizeof(CellChk) * n, s));
         HIP_TRY(c, hipMemsetAsync(c->d_cell_nkeys.p, 0, 4ull * n, s));
     }
@@ -338,7 +333,8 @@ int run_range(afq_ctx* c, Range r) {
     DecodeArgs da{c->d_bytes, c->n_bytes, c->d_meta.as<CellMeta>(), n, c->d_t2g.as<uint32_t>(), c->ref_count,
                   g.num_genes, c->d_keys0.as<uint64_t>(), c->d_cell_nkeys.as<uint32_t>(),
                   c->d_bc.as<uint64_t>(), c->d_status.as<DevStatus>(),
-                  par ? c->d_chk.as<CellChk>() : nullptr, c->d_slab_prefix.as<uint32_t>(), c->d_wg_cell.as<uint32_t>(),
+                  par ? c->d_chk.as<CellChk>() : nullptr, c->d_slab_prefix.as<uint32_t>(), c->d_slab_cell.as<uint32_t>(),
+                  c->d_cell_bc.as<uint64_t>(),
                   (uint32_t)n_slabs};
     if (par) {
         ScopedTimer t(c, K_DECODE_PAR);
@@ -351,7 +347,7 @@ int run_range(afq_ctx* c, Range r) {
     ResolveArgs ra{c->d_meta.as<CellMeta>(), c->d_bucket_cell.as<uint32_t>(), c->d_multi_cells.as<uint32_t>(),
                    c->d_tile_prefix.as<uint32_t>(), c->d_cell_nkeys.as<uint32_t>(), c->d_bucket_cnt.as<uint32_t>(),
                    c->d_keys0.as<uint64_t>(), c->d_keys1.as<uint64_t>(), c->d_ncols.as<uint32_t>(),
-                   c->d_nnz.as<uint32_t>(), c->d_ovf.as<OverflowEnt>(), c->d_status.as<DevStatus>(),
+                   c->d_nnz.as<uint32_t>(), c->d_ovf.as<OverflowEnt>(), c->d_bdesc.p, c->d_status.as<DevStatus>(),
                    (uint32_t)n_buckets, n_multi, (uint32_t)n_tiles, g.usa_mode, g.num_rows};
     if (n_multi) {
         { ScopedTimer t(c, K_HIST); launch_hist(s, ra); }
@@ -517,7 +513,7 @@ void afq_destroy(afq_ctx* c) {
     DevBuf* bufs[] = {&c->d_t2g, &c->d_bytes_own, &c->d_meta, &c->d_keys0, &c->d_keys1, &c->d_cell_nkeys,
                       &c->d_bucket_cnt, &c->d_bucket_cell, &c->d_multi_cells, &c->d_tile_prefix, &c->d_ncols, &c->d_nnz,
                       &c->d_ovf, &c->d_status, &c->d_bc, &c->d_cell_ptr, &c->d_gene, &c->d_val, &c->d_chunk_off, &c->d_hdr,
-                      &c->d_chk, &c->d_slab_prefix, &c->d_wg_cell};
+                      &c->d_chk, &c->d_slab_prefix, &c->d_slab_cell, &c->d_cell_bc, &c->d_bdesc};
     for (auto b : bufs) b->release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->res) pool_put(c->res);

@@ -23,7 +23,8 @@ struct DecodeArgs {
     // walk-free decode (k_decode_par) + fix-up mode of k_decode; null chk = plain sequential decode
     const CellChk* chk;
     const uint32_t* slab_prefix;  // [n_cells+1] 1 KiB slabs per cell, prefix
-    const uint32_t* wg_cell;      // [ceil(n_slabs/4)] cell of each workgroup's first slab
+    uint32_t* slab_cell;          // [n_slabs] device-filled: cell of each slab
+    uint64_t* cell_bc;            // [n_cells] device-filled: barcode words of each cell's first record
     uint32_t n_slabs;
 };
 
@@ -39,6 +40,7 @@ struct ResolveArgs {
     uint32_t* cell_ncols;  // per-cell length of the resolved-column list (multi-bucket cells)
     uint32_t* nnz;
     OverflowEnt* ovf_list;
+    void* bucket_desc;     // [n_buckets] x bucket_desc_bytes()
     DevStatus* st;
     uint32_t n_buckets;
     uint32_t n_multi;
@@ -55,6 +57,7 @@ int launch_decode_par(hipStream_t s, const DecodeArgs& a, uint32_t bw, uint32_t 
 void launch_hist(hipStream_t s, const ResolveArgs& a);
 void launch_bucket_scan(hipStream_t s, const ResolveArgs& a);
 void launch_scatter(hipStream_t s, const ResolveArgs& a);
+size_t bucket_desc_bytes();
 void launch_resolve(hipStream_t s, const ResolveArgs& a);
 void launch_resolve_big(hipStream_t s, const ResolveArgs& a);
 void launch_cell_hist(hipStream_t s, const ResolveArgs& a);

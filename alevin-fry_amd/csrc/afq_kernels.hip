@@ -303,11 +303,37 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ byte
 }
 
 // ---------------------------------------------------------------------------
+// k_slab_setup: per cell, record which cell every 1 KiB slab belongs to and the
+// cell's barcode words, so the decode waves start with one dependent load, not five.
+template <int BW, int UW>
+__global__ __launch_bounds__(256) void k_slab_setup(const uint8_t* __restrict__ bytes,
+                                                   const CellMeta* __restrict__ meta, uint32_t n_cells,
+                                                   const uint32_t* __restrict__ slab_prefix,
+                                                   uint32_t* __restrict__ slab_cell, uint64_t* __restrict__ cell_bc) {
+    constexpr uint32_t BWW = BW / 4, UWW = UW / 4, HW = 1 + BWW + UWW;
+    const uint32_t cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (cell >= n_cells) return;
+    const uint32_t a = slab_prefix[cell], b = slab_prefix[cell + 1];
+    for (uint32_t s = a + lane_id(); s < b; s += 64) slab_cell[s] = cell;
+    if (lane_id() == 0) {
+        const CellMeta m = meta[cell];
+        const uint32_t* W = reinterpret_cast<const uint32_t*>(bytes + m.chunk_off);
+        uint64_t bc = 0;
+        if ((m.nbytes >> 2) >= 2 + HW) bc = BWW == 2 ? ((uint64_t)W[4] << 32 | W[3]) : (uint64_t)W[3];
+        cell_bc[cell] = bc;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // k_decode_par: walk-free decode for dword-aligned layouts (bc/umi of 4 or 8 bytes).
 // In a collated chunk every record carries the cell's barcode, so a record start
 // is a dword i whose barcode field equals the barcode of the chunk's first record.
-// One wave takes a 1 KiB slab: ballot the candidate starts of four 64-dword
-// windows into an LDS list, then one lane per candidate decodes the record.
+// One wave takes kSlabsPerWave consecutive 1 KiB slabs.  Per slab: stage the slab
+// (+ a 64-dword halo) in LDS with coalesced loads, ballot the candidate starts of
+// its four 64-dword windows into an LDS list, then one lane per candidate decodes
+// the record out of LDS (na, umi, refs), gathers tid_to_gid and emits keys.  The
+// raw dwords of the next slab are requested before the current slab's gathers are
+// consumed, so the HBM latency of the stream overlaps the L2 latency of the gathers.
 // Per candidate it also checks that the position right after the record is again a
 // candidate (or the chunk end); with the per-cell sums of candidate count and
 // candidate sizes this proves the candidate set IS the sequential parse
@@ -315,84 +341,169 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ byte
 // the sequential k_decode, so a barcode-valued UMI/ref word costs time, never
 // correctness.  Keys of a cell land in arbitrary order (wave-level atomic
 // reservation); order is re-established by the bucket sort.
+constexpr uint32_t kSlabsPerWave = 4;
+constexpr uint32_t kHalo = 64;
+constexpr uint32_t kDecodeCols = 8192;
+constexpr uint32_t kStage = kSlabWords + kHalo;  // 320 dwords = 5 per lane
+
 template <int BW, int UW>
 __global__ __launch_bounds__(256) void k_decode_par(const uint8_t* __restrict__ bytes,
                                                    const CellMeta* __restrict__ meta, uint32_t n_cells,
                                                    const uint32_t* __restrict__ slab_prefix,
-                                                   const uint32_t* __restrict__ wg_cell, uint32_t n_slabs,
+                                                   const uint32_t* __restrict__ slab_cell,
+                                                   const uint64_t* __restrict__ cell_bc, uint32_t n_slabs,
                                                    const uint32_t* __restrict__ t2g, uint32_t ref_count,
                                                    uint32_t num_genes, uint64_t* __restrict__ keys0,
                                                    uint32_t* __restrict__ cell_nkeys,
                                                    uint64_t* __restrict__ bc_out, CellChk* __restrict__ chk) {
     static_assert(BW % 4 == 0 && UW % 4 == 0, "aligned layouts only");
     constexpr uint32_t BWW = BW / 4, UWW = UW / 4, HW = 1 + BWW + UWW;
+    __shared__ uint32_t s_stage[4][kStage];
     __shared__ uint32_t s_list[4][kSlabWords];
     const uint32_t lane = lane_id();
     const uint32_t wv = threadIdx.x >> 6;
-    const uint32_t slab = blockIdx.x * 4 + wv;
-    if (slab >= n_slabs) return;
-    uint32_t cell = wg_cell[blockIdx.x];
-    while (cell + 1 < n_cells && slab_prefix[cell + 1] <= slab) ++cell;
-    cell = __builtin_amdgcn_readfirstlane(cell);
-    const CellMeta m = meta[cell];
-    const uint32_t* __restrict__ W = reinterpret_cast<const uint32_t*>(bytes + m.chunk_off);
-    const uint32_t nwords = m.nbytes >> 2;
-    const uint32_t s0 = (slab - slab_prefix[cell]) * kSlabWords;
-    if (nwords < 2 + HW) {  // cannot hold a record; nrec >= 1 is guaranteed by the planner
-        if (s0 == 0 && lane == 0) atomicOr(&chk[cell].fail, 1u);
-        return;
-    }
-    const uint32_t bc_lo = W[3];
-    const uint32_t bc_hi = BWW == 2 ? W[4] : 0u;
-    // candidate starts of the slab -> s_list (ascending)
-    uint32_t ncand = 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const uint32_t i = s0 + r * 64 + lane;
-        bool cand = false;
-        if (i >= 2 && i + HW <= nwords) {
-            cand = W[i + 1] == bc_lo;
-            if (BWW == 2) cand = cand && (W[i + 2] == bc_hi);
-        }
-        const uint64_t mk = __ballot(cand);
-        if (cand) s_list[wv][ncand + __popcll(mk & ((1ull << lane) - 1))] = i;
-        ncand += (uint32_t)__popcll(mk);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint32_t* stage = s_stage[wv];
+    uint32_t* list = s_list[wv];
+    // Waves that run at the same time are spread over the whole input (column-major walk of the
+    // slab groups): neighbouring groups belong to one cell and would serialise on that cell's
+    // key-reservation counter (same-address device atomics).
+    const uint32_t n_groups = (n_slabs + kSlabsPerWave - 1) / kSlabsPerWave;
+    const uint32_t n_cols = min(n_groups, kDecodeCols);
+    const uint32_t n_rows = (n_groups + n_cols - 1) / n_cols;
+    const uint32_t wid = blockIdx.x * 4 + wv;
+    const uint32_t grp = (wid % n_cols) * n_rows + wid / n_cols;
+    if (wid >= n_cols * n_rows || grp >= n_groups) return;
+    const uint32_t slab_a = grp * kSlabsPerWave;
+    const uint32_t slab_b = min(n_slabs, slab_a + kSlabsPerWave);
+    // the (up to 4) cells of this wave's slabs
+    uint32_t my_cell = 0;
+    if (lane < slab_b - slab_a) my_cell = slab_cell[slab_a + lane];
+
+    uint32_t cur_cell = 0xFFFFFFFFu;
+    CellMeta m{};
+    const uint32_t* __restrict__ W = nullptr;
+    uint32_t nwords = 0, sp0 = 0, bc_lo = 0, bc_hi = 0;
+    uint32_t acc_count = 0, acc_words = 0;
     bool fail = false;
-    if (s0 == 0) {  // (1) the first record starts right after the chunk header
-        const bool first_ok = ncand > 0 && s_list[wv][0] == 2;
-        if (!first_ok) fail = true;
-    }
-    uint32_t sum_words = 0;
-    for (uint32_t base = 0; base < ncand; base += 64) {
-        const uint32_t c = base + lane;
-        const bool act = c < ncand;
-        uint32_t i = 0, na = 0, kcnt = 0, k = 0;
-        bool ovf = false;
-        uint64_t umi = 0;
-        uint32_t g[8];
-        if (act) {
-            i = s_list[wv][c];
-            na = W[i];
-            if (na > nwords || i + HW + na > nwords) { fail = true; na = 0; }
-            else {
-                const uint32_t succ = i + HW + na;  // (2) the next record starts where this one ends
-                if (succ != nwords) {
-                    bool ok = succ + HW <= nwords && W[succ + 1] == bc_lo;
-                    if (BWW == 2 && ok) ok = W[succ + 2] == bc_hi;
-                    if (!ok) fail = true;
+    uint32_t R[5];
+
+    auto load_cell = [&](uint32_t cell) {
+        cur_cell = cell;
+        m = meta[cell];
+        const uint64_t bc = cell_bc[cell];
+        bc_lo = (uint32_t)bc; bc_hi = (uint32_t)(bc >> 32);
+        W = reinterpret_cast<const uint32_t*>(bytes + m.chunk_off);
+        nwords = m.nbytes >> 2;
+        sp0 = slab_prefix[cell];
+    };
+    auto flush_chk = [&]() {
+        if (cur_cell == 0xFFFFFFFFu) return;
+        uint32_t ws = acc_words;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) ws += __shfl_xor(ws, d);
+        const bool any_fail = __any(fail);
+        if (lane == 0) {
+            if (acc_count) atomicAdd(&chk[cur_cell].count, acc_count);
+            if (ws) atomicAdd(&chk[cur_cell].words, ws);
+            if (any_fail) atomicOr(&chk[cur_cell].fail, 1u);
+        }
+        acc_count = 0; acc_words = 0; fail = false;
+    };
+    auto issue_slab_loads = [&](uint32_t s0) {
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const uint32_t i = s0 + r * 64 + lane;
+            R[r] = i < nwords ? W[i] : 0u;
+        }
+    };
+
+    load_cell(__builtin_amdgcn_readlane(my_cell, 0));
+    issue_slab_loads((slab_a - sp0) * kSlabWords);
+
+    for (uint32_t slab = slab_a; slab < slab_b; ++slab) {
+        const uint32_t s0 = (slab - sp0) * kSlabWords;
+        // stage this slab (its dwords were requested one iteration ago)
+#pragma unroll
+        for (int r = 0; r < 5; ++r) stage[r * 64 + lane] = R[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t ncand = 0;
+        if (nwords >= 2 + HW) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t il = r * 64 + lane, i = s0 + il;
+                bool cand = false;
+                if (i >= 2 && i + HW <= nwords) {
+                    cand = stage[il + 1] == bc_lo;
+                    if (BWW == 2) cand = cand && (stage[il + 2] == bc_hi);
                 }
-                sum_words += HW + na;
-                umi = W[i + 1 + BWW];
-                if (UWW == 2) umi |= (uint64_t)W[i + 2 + BWW] << 32;
-                if (UWW == 2 && (umi >> kUmiBits)) fail = true;
-                if (i == 2) bc_out[cell] = BWW == 2 ? ((uint64_t)bc_hi << 32 | bc_lo) : (uint64_t)bc_lo;
-                const uint32_t* rp = W + i + HW;
-                for (uint32_t j = 0; j < na; ++j) {
-                    const uint32_t t = rp[j] & 0x7FFFFFFFu;
+                const uint64_t mk = __ballot(cand);
+                if (cand) list[ncand + __popcll(mk & ((1ull << lane) - 1))] = il;
+                ncand += (uint32_t)__popcll(mk);
+            }
+        } else if (s0 == 0) fail = true;  // cannot hold a record; nrec >= 1 is guaranteed by the planner
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (s0 == 0 && nwords >= 2 + HW) {  // (1) the first record starts right after the chunk header
+            if (!(ncand > 0 && list[0] == 2)) fail = true;
+        }
+        acc_count += ncand;
+        // decide what the next iteration needs before the long-latency part
+        const bool has_next = slab + 1 < slab_b;
+        const uint32_t next_cell = has_next ? __builtin_amdgcn_readlane(my_cell, (int)(slab + 1 - slab_a)) : cur_cell;
+        const bool same_next = has_next && next_cell == cur_cell;
+        bool prefetched = false;
+
+        for (uint32_t base = 0; base < ncand; base += 64) {
+            const uint32_t c = base + lane;
+            const bool act = c < ncand;
+            uint32_t il = 0, i = 0, na = 0, kcnt = 0, k = 0;
+            bool ovf = false;
+            uint64_t umi = 0;
+            uint32_t g[8];
+            auto refw = [&](uint32_t j) -> uint32_t {  // j-th alignment word of this lane's record
+                const uint32_t p = il + HW + j;
+                return (p < kStage ? stage[p] : W[i + HW + j]) & 0x7FFFFFFFu;
+            };
+            uint32_t gid0 = 0;
+            bool ok0 = false;
+            if (act) {
+                il = list[c];
+                i = s0 + il;
+                na = stage[il];
+                if (na > nwords || i + HW + na > nwords) { fail = true; na = 0; }
+                else {
+                    const uint32_t succ = i + HW + na, sl = il + HW + na;  // (2) the next record starts where this one ends
+                    if (succ != nwords) {
+                        bool ok = succ + HW <= nwords;
+                        if (ok) {
+                            const uint32_t w1 = sl + 1 < kStage ? stage[sl + 1] : W[succ + 1];
+                            ok = w1 == bc_lo;
+                            if (BWW == 2 && ok) ok = (sl + 2 < kStage ? stage[sl + 2] : W[succ + 2]) == bc_hi;
+                        }
+                        if (!ok) fail = true;
+                    }
+                    acc_words += HW + na;
+                    umi = stage[il + 1 + BWW];
+                    if (UWW == 2) umi |= (uint64_t)stage[il + 2 + BWW] << 32;
+                    if (UWW == 2 && (umi >> kUmiBits)) fail = true;
+                    if (i == 2) bc_out[cur_cell] = BWW == 2 ? ((uint64_t)bc_hi << 32 | bc_lo) : (uint64_t)bc_lo;
+                    if (na) {
+                        const uint32_t t = refw(0);
+                        if (t < ref_count) { gid0 = t2g[t]; ok0 = true; } else fail = true;
+                    }
+                }
+            }
+            // request the next slab's dwords while the gathers above are in flight
+            if (!prefetched && same_next) { issue_slab_loads(s0 + kSlabWords); prefetched = true; }
+            if (act && na) {
+                if (ok0) {
+                    if (gid0 < num_genes) { g[0] = gid0; k = 1; } else fail = true;
+                }
+                for (uint32_t j = 1; j < na; ++j) {
+                    const uint32_t t = refw(j);
                     if (t >= ref_count) { fail = true; continue; }
                     const uint32_t gid = t2g[t];
                     if (gid >= num_genes) { fail = true; continue; }
@@ -411,62 +522,62 @@ __global__ __launch_bounds__(256) void k_decode_par(const uint8_t* __restrict__ 
                 if (ovf) {  // > 8 distinct genes: first-occurrence count, O(na^2), rare
                     kcnt = 0;
                     for (uint32_t j = 0; j < na; ++j) {
-                        const uint32_t tj = rp[j] & 0x7FFFFFFFu;
+                        const uint32_t tj = refw(j);
                         if (tj >= ref_count) continue;
                         const uint32_t gj = t2g[tj];
                         if (gj >= num_genes) continue;
                         bool first = true;
                         for (uint32_t q = 0; q < j && first; ++q) {
-                            const uint32_t tq = rp[q] & 0x7FFFFFFFu;
+                            const uint32_t tq = refw(q);
                             if (tq < ref_count && t2g[tq] == gj) first = false;
                         }
                         kcnt += first;
                     }
                 }
             }
-        }
-        uint32_t tot;
-        const uint32_t ex = wave_excl_scan(kcnt, tot);
-        uint32_t wbase = 0;
-        if (tot) {
-            if (lane == 0) wbase = atomicAdd(&cell_nkeys[cell], tot);
-            wbase = __builtin_amdgcn_readfirstlane(wbase);
-            if (wbase + tot > m.n_ref) { fail = true; kcnt = 0; }
-        }
-        if (kcnt) {
-            uint64_t* dst = keys0 + m.key_off + wbase + ex;
-            if (!ovf) {
+            uint32_t tot;
+            const uint32_t ex = wave_excl_scan(kcnt, tot);
+            uint32_t wbase = 0;
+            if (tot) {
+                if (lane == 0) wbase = atomicAdd(&cell_nkeys[cur_cell], tot);
+                wbase = __builtin_amdgcn_readfirstlane(wbase);
+                if (wbase + tot > m.n_ref) { fail = true; kcnt = 0; }
+            }
+            if (kcnt) {
+                uint64_t* dst = keys0 + m.key_off + wbase + ex;
+                if (!ovf) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) if ((uint32_t)q < k) dst[q] = (umi << kGeneBits) | g[q];
-            } else {
-                const uint32_t* rp = W + i + HW;
-                uint32_t o = 0;
-                for (uint32_t j = 0; j < na; ++j) {
-                    const uint32_t tj = rp[j] & 0x7FFFFFFFu;
-                    if (tj >= ref_count) continue;
-                    const uint32_t gj = t2g[tj];
-                    if (gj >= num_genes) continue;
-                    bool first = true;
-                    for (uint32_t q = 0; q < j && first; ++q) {
-                        const uint32_t tq = rp[q] & 0x7FFFFFFFu;
-                        if (tq < ref_count && t2g[tq] == gj) first = false;
+                    for (int q = 0; q < 8; ++q) if ((uint32_t)q < k) dst[q] = (umi << kGeneBits) | g[q];
+                } else {
+                    uint32_t o = 0;
+                    for (uint32_t j = 0; j < na; ++j) {
+                        const uint32_t tj = refw(j);
+                        if (tj >= ref_count) continue;
+                        const uint32_t gj = t2g[tj];
+                        if (gj >= num_genes) continue;
+                        bool first = true;
+                        for (uint32_t q = 0; q < j && first; ++q) {
+                            const uint32_t tq = refw(q);
+                            if (tq < ref_count && t2g[tq] == gj) first = false;
+                        }
+                        if (first) dst[o++] = (umi << kGeneBits) | gj;
                     }
-                    if (first) dst[o++] = (umi << kGeneBits) | gj;
                 }
             }
         }
+        // all lanes are done reading this slab's stage/list before the next iteration overwrites them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (has_next) {
+            if (!same_next) {
+                flush_chk();
+                load_cell(next_cell);
+                issue_slab_loads((slab + 1 - sp0) * kSlabWords);
+            } else if (!prefetched) issue_slab_loads(s0 + kSlabWords);
+        }
     }
-    // per-cell sums for the proof
-    uint32_t wsum = sum_words;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) wsum += __shfl_xor(wsum, d);
-    if (lane == 0) {
-        atomicAdd(&chk[cell].count, ncand);
-        atomicAdd(&chk[cell].words, wsum);
-    }
-    if (__any(fail) && lane == 0) atomicOr(&chk[cell].fail, 1u);
+    flush_chk();
 }
-
 
 // ---------------------------------------------------------------------------
 // Bucket histogram.  Device-scope atomics leave the XCD (every one is a fabric
@@ -731,8 +842,8 @@ __device__ __forceinline__ bool same_gene(uint32_t a, uint32_t b) { return (a & 
 // winner / tie set and maps it to an output column (non-USA: unique winner only,
 // src/quant.rs:563-565; USA: src/utils.rs:688-753 == src/quant.rs:557-605).
 // emit(col) is called once per resolved UMI.
-template <int NT, typename Emit>
-__device__ __forceinline__ void resolve_sorted(const uint64_t* keys, uint32_t n, uint32_t* run_start,
+template <int NT, typename RunT, typename Emit>
+__device__ __forceinline__ void resolve_sorted(const uint64_t* keys, uint32_t n, RunT* run_start,
                                                uint32_t* ws, const ResolveCfg& rc, Emit&& emit) {
     uint32_t carry = 0;
     for (uint32_t base = 0; base < n; base += NT) {
@@ -740,12 +851,12 @@ __device__ __forceinline__ void resolve_sorted(const uint64_t* keys, uint32_t n,
         const uint32_t f = (i < n) && (i == 0 || keys[i] != keys[i - 1]);
         uint32_t tot;
         const uint32_t ex = block_excl_scan<NT>(f, ws, tot);
-        if (f) run_start[carry + ex] = i;
+        if (f) run_start[carry + ex] = (RunT)i;
         carry += tot;
     }
     const uint32_t nruns = carry;
     __syncthreads();
-    auto run_end = [&](uint32_t q) { return q + 1 < nruns ? run_start[q + 1] : n; };  // no sentinel slot needed
+    auto run_end = [&](uint32_t q) -> uint32_t { return q + 1 < nruns ? (uint32_t)run_start[q + 1] : n; };  // no sentinel slot needed
     for (uint32_t r = threadIdx.x; r < nruns; r += NT) {
         const uint64_t umi = keys[run_start[r]] >> kGeneBits;
         if (r > 0 && (keys[run_start[r - 1]] >> kGeneBits) == umi) continue;  // not the UMI's first run
@@ -789,97 +900,154 @@ __device__ __forceinline__ void resolve_sorted(const uint64_t* keys, uint32_t n,
     }
 }
 
-constexpr int kResolveNT = 256;
+// ---------------------------------------------------------------------------
+// Per-bucket descriptors: everything a resolve workgroup needs in one 32-byte load
+// (instead of the dependent chain bucket -> cell -> meta -> cursor -> keys).
+struct BucketDesc {
+    uint64_t src_off;  // first key of the bucket: slot in keys1 (multi-bucket cell) or keys0 (single)
+    uint64_t out_off;  // the cell's key_off (column list / pair staging live in its keys0 slots)
+    uint32_t n;        // keys in the bucket
+    uint32_t cell;
+    uint32_t single;   // 1: the bucket is the whole cell
+    uint32_t pad;
+};
 
-// One workgroup per bucket.  Single-bucket cells are finished here (columns
-// sorted and run-length counted in LDS, pairs written over the cell's dead key
-// slots).  Buckets of multi-bucket cells append their resolved columns to the
-// cell's column list (one global atomic per bucket reserves the range); the
-// per-cell count happens in k_cell_hist.
-__global__ __launch_bounds__(kResolveNT) void k_resolve(const CellMeta* __restrict__ meta,
-                                                       const uint32_t* __restrict__ bucket_cell,
-                                                       const uint32_t* __restrict__ cell_nkeys,
-                                                       const uint32_t* __restrict__ cursor,
+__global__ void k_bucket_desc(const CellMeta* __restrict__ meta, const uint32_t* __restrict__ bucket_cell,
+                              const uint32_t* __restrict__ cell_nkeys, const uint32_t* __restrict__ cursor,
+                              uint32_t n_buckets, BucketDesc* __restrict__ desc) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_buckets) return;
+    const uint32_t cell = bucket_cell[b];
+    const CellMeta m = meta[cell];
+    BucketDesc d;
+    d.cell = cell; d.out_off = m.key_off; d.pad = 0;
+    if (m.lg_nb == 0) { d.single = 1; d.src_off = m.key_off; d.n = cell_nkeys[cell]; }
+    else {
+        const uint32_t beg = (b == m.bucket_base) ? 0u : cursor[b - 1];
+        d.single = 0; d.src_off = m.key_off + beg; d.n = cursor[b] - beg;
+    }
+    desc[b] = d;
+}
+
+// Sort + resolve one bucket held in LDS.  NT threads, up to NT*8 keys.
+template <int NT>
+__device__ __forceinline__ void resolve_bucket_lds(const BucketDesc& d, uint64_t* __restrict__ keys0,
+                                                   const uint64_t* __restrict__ keys1,
+                                                   uint32_t* __restrict__ cell_ncols, uint32_t* __restrict__ nnz,
+                                                   DevStatus* st, const ResolveCfg& rc, uint64_t* s_keys,
+                                                   uint16_t* s_run, uint32_t* s_cols, uint32_t* s_ws,
+                                                   uint32_t* s_misc /* [2] */) {
+    const uint32_t n = d.n;
+    const uint64_t* src = (d.single ? keys0 : keys1) + d.src_off;
+    if (threadIdx.x == 0) s_misc[0] = 0;
+    block_sort_any<NT, uint64_t>(src, n, s_keys, kKeySentinel);
+    resolve_sorted<NT>(s_keys, n, s_run, s_ws, rc, [&](uint32_t col) {
+        if (col >= rc.num_rows) { set_err(st, kErrSlotRange, d.cell); return; }
+        s_cols[atomicAdd(&s_misc[0], 1u)] = col;
+    });
+    __syncthreads();
+    const uint32_t nc = s_misc[0];
+    if (!d.single) {
+        if (nc == 0) return;
+        if (threadIdx.x == 0) s_misc[1] = atomicAdd(&cell_ncols[d.cell], nc);
+        __syncthreads();
+        uint32_t* out = reinterpret_cast<uint32_t*>(keys0 + d.out_off) + s_misc[1];  // keys0 slots are dead after k_scatter
+        for (uint32_t i = threadIdx.x; i < nc; i += NT) out[i] = s_cols[i];
+        return;
+    }
+    // single-bucket cell: sort the columns, run-length count, write (column,count) pairs
+    uint32_t* s_sorted = reinterpret_cast<uint32_t*>(s_keys);  // keys are dead
+    block_sort_any<NT, uint32_t>(s_cols, nc, s_sorted, 0xFFFFFFFFu);
+    uint2* out = reinterpret_cast<uint2*>(keys0 + d.out_off);
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nc; base += NT) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t f = (i < nc) && (i == 0 || s_sorted[i] != s_sorted[i - 1]);
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<NT>(f, s_ws, tot);
+        if (f) s_run[carry + ex] = (uint16_t)i;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) nnz[d.cell] = carry;
+    __syncthreads();
+    for (uint32_t h = threadIdx.x; h < carry; h += NT) {
+        const uint32_t a = s_run[h], e = h + 1 < carry ? (uint32_t)s_run[h + 1] : nc;
+        out[h] = make_uint2(s_sorted[a], e - a);
+    }
+}
+
+// One 2-wave workgroup per bucket (up to kBucketCap keys).  Small workgroups keep
+// many buckets in flight per CU, which is what hides the load -> sort -> reserve ->
+// store latency chain; blocks that run together are spread over different cells
+// (column-major walk) so their reservations do not pile onto one counter.
+// Single-bucket cells are finished here; buckets of multi-bucket cells append their
+// resolved columns to the cell's column list, counted later by k_cell_hist.
+constexpr int kResolveNT = 128;
+constexpr uint32_t kResolveCols = 8192;
+static_assert(kBucketCap == kResolveNT * 8, "bucket cap = 8 keys per thread");
+__global__ __launch_bounds__(kResolveNT) void k_resolve(const BucketDesc* __restrict__ desc, uint32_t n_buckets,
                                                        uint64_t* __restrict__ keys0,
                                                        const uint64_t* __restrict__ keys1,
                                                        uint32_t* __restrict__ cell_ncols, uint32_t* __restrict__ nnz,
                                                        OverflowEnt* __restrict__ ovf_list, DevStatus* st,
                                                        ResolveCfg rc) {
     __shared__ uint64_t s_keys[kBucketCap];
-    __shared__ uint32_t s_run[kBucketCap + 1];
+    __shared__ uint16_t s_run[kBucketCap];
     __shared__ uint32_t s_cols[kBucketCap];
     __shared__ uint32_t s_ws[kResolveNT / 64];
-    __shared__ uint32_t s_ncols, s_gbase;
-    const uint32_t b = blockIdx.x;
-    const uint32_t cell = bucket_cell[b];
-    const CellMeta m = meta[cell];
-    const uint64_t* src;
-    uint32_t n;
-    if (m.lg_nb == 0) {
-        src = keys0 + m.key_off;
-        n = cell_nkeys[cell];
-    } else {
-        const uint32_t beg = (b == m.bucket_base) ? 0u : cursor[b - 1];
-        const uint32_t end = cursor[b];
-        src = keys1 + m.key_off + beg;
-        n = end - beg;
-    }
-    if (n == 0) {
-        if (m.lg_nb == 0 && threadIdx.x == 0) nnz[cell] = 0;
+    __shared__ uint32_t s_misc[2];
+    const uint32_t n_cols = min(n_buckets, kResolveCols);
+    const uint32_t n_rows = (n_buckets + n_cols - 1) / n_cols;
+    const uint32_t b = (blockIdx.x % n_cols) * n_rows + blockIdx.x / n_cols;
+    if (b >= n_buckets) return;
+    const BucketDesc d = desc[b];
+    if (d.n == 0) {
+        if (d.single && threadIdx.x == 0) nnz[d.cell] = 0;
         return;
     }
-    if (n > kBucketCap) {  // only multi-bucket cells can get here (planner keeps single buckets <= target)
+    if (d.n > kBucketCap) {  // only multi-bucket cells can get here (planner keeps single buckets <= target)
         if (threadIdx.x == 0) {
-            uint32_t k = atomicAdd(&st->n_overflow, 1u);
+            const uint32_t k = atomicAdd(&st->n_overflow, 1u);
             ovf_list[k].bucket = b;
-            ovf_list[k].n = n;
+            ovf_list[k].n = d.n;
         }
         return;
     }
-    if (threadIdx.x == 0) s_ncols = 0;
-    block_sort_any<kResolveNT, uint64_t>(src, n, s_keys, kKeySentinel);
-    resolve_sorted<kResolveNT>(s_keys, n, s_run, s_ws, rc, [&](uint32_t col) {
-        if (col >= rc.num_rows) { set_err(st, kErrSlotRange, cell); return; }
-        s_cols[atomicAdd(&s_ncols, 1u)] = col;
-    });
-    __syncthreads();
-    const uint32_t nc = s_ncols;
-    if (m.lg_nb != 0) {
-        if (nc == 0) return;
-        if (threadIdx.x == 0) s_gbase = atomicAdd(&cell_ncols[cell], nc);
-        __syncthreads();
-        uint32_t* out = reinterpret_cast<uint32_t*>(keys0 + m.key_off) + s_gbase;  // keys0 slots are dead after k_scatter
-        for (uint32_t i = threadIdx.x; i < nc; i += kResolveNT) out[i] = s_cols[i];
-        return;
-    }
-    // single-bucket cell: sort the columns, run-length count, write (column,count) pairs
-    uint32_t* s_sorted = reinterpret_cast<uint32_t*>(s_keys);  // keys are dead
-    block_sort_any<kResolveNT, uint32_t>(s_cols, nc, s_sorted, 0xFFFFFFFFu);
-    uint2* out = reinterpret_cast<uint2*>(keys0 + m.key_off);
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < nc; base += kResolveNT) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t f = (i < nc) && (i == 0 || s_sorted[i] != s_sorted[i - 1]);
-        uint32_t tot;
-        const uint32_t ex = block_excl_scan<kResolveNT>(f, s_ws, tot);
-        if (f) s_run[carry + ex] = i;
-        carry += tot;
-    }
-    if (threadIdx.x == 0) { s_run[carry] = nc; nnz[cell] = carry; }
-    __syncthreads();
-    for (uint32_t h = threadIdx.x; h < carry; h += kResolveNT)
-        out[h] = make_uint2(s_sorted[s_run[h]], s_run[h + 1] - s_run[h]);
+    resolve_bucket_lds<kResolveNT>(d, keys0, keys1, cell_ncols, nnz, st, rc, s_keys, s_run, s_cols, s_ws, s_misc);
 }
 
-// Buckets larger than the LDS cap (heavy PCR duplication of one UMI, adversarial
+// Buckets over the 2-wave cap but within LDS reach (<= kMidCap keys): persistent
+// 1024-thread workgroups loop over the overflow list.
+constexpr int kMidNT = 1024;
+constexpr uint32_t kMidCap = kMidNT * 8;
+__global__ __launch_bounds__(kMidNT) void k_resolve_mid(const BucketDesc* __restrict__ desc,
+                                                       uint64_t* __restrict__ keys0,
+                                                       const uint64_t* __restrict__ keys1,
+                                                       uint32_t* __restrict__ cell_ncols, uint32_t* __restrict__ nnz,
+                                                       const OverflowEnt* __restrict__ ovf_list, DevStatus* st,
+                                                       ResolveCfg rc) {
+    __shared__ uint64_t s_keys[kMidCap];
+    __shared__ uint16_t s_run[kMidCap];
+    __shared__ uint32_t s_cols[kMidCap];
+    __shared__ uint32_t s_ws[kMidNT / 64];
+    __shared__ uint32_t s_misc[2];
+    const uint32_t novf = st->n_overflow;
+    for (uint32_t e = blockIdx.x; e < novf; e += gridDim.x) {
+        if (ovf_list[e].n > kMidCap) continue;
+        const BucketDesc d = desc[ovf_list[e].bucket];
+        __syncthreads();
+        resolve_bucket_lds<kMidNT>(d, keys0, keys1, cell_ncols, nnz, st, rc, s_keys, s_run, s_cols, s_ws, s_misc);
+        __syncthreads();
+    }
+}
+
+// Buckets beyond LDS reach (one UMI carried by thousands of reads, adversarial
 // input): same algorithm with the bucket sorted in place in keys1 (normalised
-// bitonic network, any n) and the run table in a scratch area past the cell's
-// column list.  Persistent blocks loop over the overflow list; with no overflow
-// every block exits at once.
+// bitonic network, any n) and the run table in the upper half of the cell's keys0
+// slots.  Persistent blocks loop over the overflow list.
 constexpr int kBigNT = 1024;
-__global__ __launch_bounds__(kBigNT) void k_resolve_big(const CellMeta* __restrict__ meta,
-                                                       const uint32_t* __restrict__ bucket_cell,
-                                                       const uint32_t* __restrict__ cursor,
+__global__ __launch_bounds__(kBigNT) void k_resolve_big(const BucketDesc* __restrict__ desc,
+                                                       const CellMeta* __restrict__ meta,
                                                        uint64_t* __restrict__ keys0, uint64_t* __restrict__ keys1,
                                                        uint32_t* __restrict__ cell_ncols,
                                                        const OverflowEnt* __restrict__ ovf_list, DevStatus* st,
@@ -887,22 +1055,22 @@ __global__ __launch_bounds__(kBigNT) void k_resolve_big(const CellMeta* __restri
     __shared__ uint32_t s_ws[kBigNT / 64];
     const uint32_t novf = st->n_overflow;
     for (uint32_t e = blockIdx.x; e < novf; e += gridDim.x) {
-        const uint32_t b = ovf_list[e].bucket;
-        const uint32_t cell = bucket_cell[b];
-        const CellMeta m = meta[cell];
-        const uint32_t beg = (b == m.bucket_base) ? 0u : cursor[b - 1];
-        const uint32_t n = cursor[b] - beg;
-        uint64_t* keys = keys1 + m.key_off + beg;
+        if (ovf_list[e].n <= kMidCap) continue;
+        const BucketDesc d = desc[ovf_list[e].bucket];
+        const uint32_t n = d.n;
+        const uint32_t n_ref = meta[d.cell].n_ref;
+        const uint32_t beg = (uint32_t)(d.src_off - d.out_off);
+        uint64_t* keys = keys1 + d.src_off;
         // keys0 region of the cell = 2*n_ref words: words [0, n_ref) hold the column list (<= nkeys <= n_ref
         // entries); the run table of this bucket (<= n entries) lives at words [n_ref + beg, n_ref + beg + n),
         // disjoint between buckets because their [beg, beg+n) key ranges are.
-        uint32_t* run = reinterpret_cast<uint32_t*>(keys0 + m.key_off) + m.n_ref + beg;
+        uint32_t* run = reinterpret_cast<uint32_t*>(keys0 + d.out_off) + n_ref + beg;
         __syncthreads();
         bitonic_sort<kBigNT>(keys, n);
-        uint32_t* cols = reinterpret_cast<uint32_t*>(keys0 + m.key_off);
+        uint32_t* cols = reinterpret_cast<uint32_t*>(keys0 + d.out_off);
         resolve_sorted<kBigNT>(keys, n, run, s_ws, rc, [&](uint32_t col) {
-            if (col >= rc.num_rows) { set_err(st, kErrSlotRange, cell); return; }
-            cols[atomicAdd(&cell_ncols[cell], 1u)] = col;
+            if (col >= rc.num_rows) { set_err(st, kErrSlotRange, d.cell); return; }
+            cols[atomicAdd(&cell_ncols[d.cell], 1u)] = col;
         });
         __syncthreads();
     }
@@ -1004,8 +1172,13 @@ int launch_decode(hipStream_t s, const DecodeArgs& a, uint32_t bw, uint32_t uw) 
 
 template <int BW, int UW>
 static void launch_decode_par_t(hipStream_t s, const DecodeArgs& a) {
-    AFQ_LAUNCH((k_decode_par<BW, UW>), (a.n_slabs + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix, a.wg_cell,
-               a.n_slabs, a.t2g, a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out,
+    AFQ_LAUNCH((k_slab_setup<BW, UW>), (a.n_cells + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix,
+               a.slab_cell, a.cell_bc);
+    const uint32_t n_groups = (a.n_slabs + kSlabsPerWave - 1) / kSlabsPerWave;
+    const uint32_t n_cols = n_groups < kDecodeCols ? n_groups : kDecodeCols;
+    const uint32_t n_waves = n_cols * ((n_groups + n_cols - 1) / n_cols);
+    AFQ_LAUNCH((k_decode_par<BW, UW>), (n_waves + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix, a.slab_cell,
+               a.cell_bc, a.n_slabs, a.t2g, a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out,
                const_cast<CellChk*>(a.chk));
 }
 
@@ -1045,16 +1218,22 @@ static ResolveCfg make_rc(const ResolveArgs& a) {
 void launch_resolve(hipStream_t s, const ResolveArgs& a) {
     if (!a.n_buckets) return;
     ResolveCfg rc = make_rc(a);
-    AFQ_LAUNCH(k_resolve, a.n_buckets, kResolveNT, s, a.meta, a.bucket_cell, a.cell_nkeys, a.cursor, a.keys0, a.keys1,
-               a.cell_ncols, a.nnz, a.ovf_list, a.st, rc);
+    BucketDesc* desc = reinterpret_cast<BucketDesc*>(a.bucket_desc);
+    AFQ_LAUNCH(k_bucket_desc, (a.n_buckets + 255) / 256, 256, s, a.meta, a.bucket_cell, a.cell_nkeys, a.cursor, a.n_buckets, desc);
+    const uint32_t n_cols = a.n_buckets < kResolveCols ? a.n_buckets : kResolveCols;
+    const uint32_t grid = n_cols * ((a.n_buckets + n_cols - 1) / n_cols);
+    AFQ_LAUNCH(k_resolve, grid, kResolveNT, s, desc, a.n_buckets, a.keys0, a.keys1, a.cell_ncols, a.nnz, a.ovf_list, a.st, rc);
 }
 
 void launch_resolve_big(hipStream_t s, const ResolveArgs& a) {
     if (!a.n_multi) return;
     ResolveCfg rc = make_rc(a);
-    AFQ_LAUNCH(k_resolve_big, 256, kBigNT, s, a.meta, a.bucket_cell, a.cursor, a.keys0, a.keys1, a.cell_ncols,
-               a.ovf_list, a.st, rc);
+    BucketDesc* desc = reinterpret_cast<BucketDesc*>(a.bucket_desc);
+    AFQ_LAUNCH(k_resolve_mid, 256, kMidNT, s, desc, a.keys0, a.keys1, a.cell_ncols, a.nnz, a.ovf_list, a.st, rc);
+    AFQ_LAUNCH(k_resolve_big, 256, kBigNT, s, desc, a.meta, a.keys0, a.keys1, a.cell_ncols, a.ovf_list, a.st, rc);
 }
+
+size_t bucket_desc_bytes() { return sizeof(BucketDesc); }
 
 void launch_cell_hist(hipStream_t s, const ResolveArgs& a) {
     if (!a.n_multi) return;

@@ -68,11 +68,13 @@ def test_multi_bucket_cells(oracle, usa):
     assert st["n_buckets"] > len(sizes)
 
 
-def test_overflow_bucket_falls_back_to_global_scratch(oracle):
-    """One UMI carried by 7000 reads lands in one bucket (> LDS cap) and must still resolve exactly."""
-    s = synth.synth(3, [9000, 400], num_genes=500, dup=0.3)
+@pytest.mark.parametrize("n_same", [1500, 7000, 12000])
+def test_overflow_buckets(oracle, n_same):
+    """One UMI carried by n_same reads lands in one bucket: 1500 -> over the 2-wave cap (LDS mid path),
+    12000 -> beyond LDS reach (in-place sort in global scratch).  Must still resolve exactly."""
+    s = synth.synth(3, [n_same + 2000, 400], num_genes=500, dup=0.3)
     umi = s.umi.copy()
-    umi[:7000] = 0x123456
+    umi[:n_same] = 0x123456
     s.umi = umi
     b, off = s.encode()
     got, want, st = run_both(oracle, cfg_for(s), s.tid_to_gid, b, off)
