@@ -198,8 +198,8 @@ bool valid_width(uint32_t w) { return w == 1 || w == 2 || w == 4 || w == 8; }
 // What the device path implements today.  Anything else is refused loudly.
 int check_supported(afq_ctx* c) {
     const afq_config& g = c->cfg;
-    if (g.resolution != AFQ_RES_CR_LIKE)
-        return fail(c, AFQ_ERR_UNSUPPORTED, "device path implements resolution cr-like only (so far)");
+    if (g.resolution != AFQ_RES_CR_LIKE && g.resolution != AFQ_RES_TRIVIAL)
+        return fail(c, AFQ_ERR_UNSUPPORTED, "device path implements resolutions cr-like and trivial only (so far)");
     if (g.usa_mode && g.sa_model != AFQ_SA_WINNER_TAKE_ALL)
         return fail(c, AFQ_ERR_UNSUPPORTED, "sa_model prefer-ambig is not implemented on the device path");
     return 0;
@@ -264,11 +264,13 @@ int run_range(afq_ctx* c, Range r) {
         m.bucket_base = (uint32_t)n_buckets;
         n_buckets += 1ull << lg;
         if (lg) {
-            m.dense_row = (int32_t)multi.size();
             multi.push_back(i);
             tile_prefix.push_back((uint32_t)n_tiles);
             n_tiles += (m.n_ref + kScatterTileHost - 1) / kScatterTileHost;
-        } else m.dense_row = -1;
+        }
+        // strategy dispatch of src/quant.rs:794-938: tiny cells take the cr-like fast path whatever -r says
+        const bool tiny = g.sa_model == AFQ_SA_WINNER_TAKE_ALL && m.nrec < g.small_thresh;
+        m.mode = (g.resolution == AFQ_RES_TRIVIAL && !tiny) ? kModeTrivial : kModeCrLike;
         nrec_total += m.nrec;
         if (par) {
             slab_prefix.push_back((uint32_t)n_slabs);
@@ -615,9 +617,77 @@ void afq_result_release(afq_result* res) {
     }
 }
 
-int afq_atac_dedup(afq_ctx* c, const uint32_t*, const uint32_t*, const uint16_t*, const uint64_t*, uint32_t,
-                   uint64_t**, uint32_t**, uint32_t**, uint16_t**, uint16_t**) {
-    return fail(c, AFQ_ERR_UNSUPPORTED, "afq_atac_dedup: device kernel not implemented yet");
+int afq_atac_dedup(afq_ctx* c, const uint32_t* ref, const uint32_t* start, const uint16_t* frag_len,
+                   const uint64_t* cell_ptr, uint32_t n_cells, uint64_t** out_cell_ptr, uint32_t** out_ref,
+                   uint32_t** out_start, uint16_t** out_frag_len, uint16_t** out_count) {
+    if (!c) return AFQ_ERR_INVALID_ARG;
+    if (!cell_ptr || !out_cell_ptr || !out_ref || !out_start || !out_frag_len || !out_count)
+        return fail(c, AFQ_ERR_INVALID_ARG, "null argument");
+    if (c->pending) return fail(c, AFQ_ERR_STATE, "a quant batch is pending on this context");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint64_t n = cell_ptr[n_cells];
+    if (n && (!ref || !start || !frag_len)) return fail(c, AFQ_ERR_INVALID_ARG, "null argument");
+    for (uint32_t i = 0; i < n_cells; ++i)
+        if (cell_ptr[i + 1] < cell_ptr[i] || cell_ptr[i + 1] - cell_ptr[i] > 0x7FFFFFFFull)
+            return fail(c, AFQ_ERR_INVALID_ARG, "cell_ptr must be non-decreasing");
+    DevBuf d_ref, d_start, d_flen, d_ptr, d_scr, d_oref, d_ostart, d_oflen, d_ocnt, d_on;
+    auto cleanup = [&]() { for (DevBuf* b : {&d_ref, &d_start, &d_flen, &d_ptr, &d_scr, &d_oref, &d_ostart, &d_oflen, &d_ocnt, &d_on}) b->release(); };
+    hipStream_t s = c->stream;
+    const uint64_t n1 = std::max<uint64_t>(n, 1);
+    hipError_t e = hipSuccess;
+    auto T = [&](hipError_t x) { if (e == hipSuccess) e = x; };
+    T(d_ref.ensure(4 * n1)); T(d_start.ensure(4 * n1)); T(d_flen.ensure(2 * n1)); T(d_ptr.ensure(8ull * (n_cells + 1)));
+    T(d_scr.ensure(16 * n1)); T(d_oref.ensure(4 * n1)); T(d_ostart.ensure(4 * n1)); T(d_oflen.ensure(2 * n1));
+    T(d_ocnt.ensure(2 * n1)); T(d_on.ensure(4ull * std::max<uint32_t>(n_cells, 1)));
+    std::vector<uint32_t> on(n_cells);
+    std::vector<uint32_t> t_ref(n), t_start(n);
+    std::vector<uint16_t> t_flen(n), t_cnt(n);
+    if (e == hipSuccess && n) {
+        T(hipMemcpyAsync(d_ref.p, ref, 4 * n, hipMemcpyHostToDevice, s));
+        T(hipMemcpyAsync(d_start.p, start, 4 * n, hipMemcpyHostToDevice, s));
+        T(hipMemcpyAsync(d_flen.p, frag_len, 2 * n, hipMemcpyHostToDevice, s));
+    }
+    if (e == hipSuccess) T(hipMemcpyAsync(d_ptr.p, cell_ptr, 8ull * (n_cells + 1), hipMemcpyHostToDevice, s));
+    if (e == hipSuccess) {
+        launch_atac_dedup(s, n_cells, d_ref.as<uint32_t>(), d_start.as<uint32_t>(), d_flen.as<uint16_t>(), d_ptr.as<uint64_t>(),
+                          d_scr.p, d_oref.as<uint32_t>(), d_ostart.as<uint32_t>(), d_oflen.as<uint16_t>(),
+                          d_ocnt.as<uint16_t>(), d_on.as<uint32_t>());
+        T(hipGetLastError());
+    }
+    if (e == hipSuccess && n_cells) T(hipMemcpyAsync(on.data(), d_on.p, 4ull * n_cells, hipMemcpyDeviceToHost, s));
+    if (e == hipSuccess && n) {
+        T(hipMemcpyAsync(t_ref.data(), d_oref.p, 4 * n, hipMemcpyDeviceToHost, s));
+        T(hipMemcpyAsync(t_start.data(), d_ostart.p, 4 * n, hipMemcpyDeviceToHost, s));
+        T(hipMemcpyAsync(t_flen.data(), d_oflen.p, 2 * n, hipMemcpyDeviceToHost, s));
+        T(hipMemcpyAsync(t_cnt.data(), d_ocnt.p, 2 * n, hipMemcpyDeviceToHost, s));
+    }
+    if (e == hipSuccess) T(hipStreamSynchronize(s));
+    cleanup();
+    if (e != hipSuccess) return fail(c, e == hipErrorOutOfMemory ? AFQ_ERR_OOM : AFQ_ERR_HIP, std::string("afq_atac_dedup: ") + hipGetErrorString(e));
+    uint64_t tot = 0;
+    for (uint32_t i = 0; i < n_cells; ++i) tot += on[i];
+    uint64_t* optr = (uint64_t*)std::malloc(8ull * (n_cells + 1));
+    uint32_t* oref = (uint32_t*)std::malloc(4 * std::max<uint64_t>(tot, 1));
+    uint32_t* ostart = (uint32_t*)std::malloc(4 * std::max<uint64_t>(tot, 1));
+    uint16_t* oflen = (uint16_t*)std::malloc(2 * std::max<uint64_t>(tot, 1));
+    uint16_t* ocnt = (uint16_t*)std::malloc(2 * std::max<uint64_t>(tot, 1));
+    if (!optr || !oref || !ostart || !oflen || !ocnt) {
+        std::free(optr); std::free(oref); std::free(ostart); std::free(oflen); std::free(ocnt);
+        return fail(c, AFQ_ERR_OOM, "afq_atac_dedup: host allocation failed");
+    }
+    uint64_t w = 0;
+    optr[0] = 0;
+    for (uint32_t i = 0; i < n_cells; ++i) {  // per-cell output sits at the cell's input offset on the device
+        const uint64_t b0 = cell_ptr[i];
+        std::memcpy(oref + w, t_ref.data() + b0, 4ull * on[i]);
+        std::memcpy(ostart + w, t_start.data() + b0, 4ull * on[i]);
+        std::memcpy(oflen + w, t_flen.data() + b0, 2ull * on[i]);
+        std::memcpy(ocnt + w, t_cnt.data() + b0, 2ull * on[i]);
+        w += on[i];
+        optr[i + 1] = w;
+    }
+    *out_cell_ptr = optr; *out_ref = oref; *out_start = ostart; *out_frag_len = oflen; *out_count = ocnt;
+    return 0;
 }
 
 void afq_free(void* p) { std::free(p); }

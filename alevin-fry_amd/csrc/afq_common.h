@@ -37,7 +37,7 @@ struct CellMeta {
     uint32_t n_ref;        // sum of na = key capacity
     uint32_t bucket_base;  // first global bucket id of the cell
     uint32_t lg_nb;        // log2(#buckets)
-    int32_t dense_row;     // row in the dense count scratch, -1 for single-bucket cells
+    uint32_t mode;         // kModeCrLike / kModeTrivial: how this cell is resolved (tiny cells are always cr-like)
 };
 
 // device-side error / statistics block
@@ -58,6 +58,9 @@ struct CellChk {
     uint32_t fail;   // a local check failed
     uint32_t pad;
 };
+
+constexpr uint32_t kModeCrLike = 0;   // winner-take-all (cr-like; every tiny cell, src/quant.rs:794-845)
+constexpr uint32_t kModeTrivial = 1;  // `trivial`: single-gene reads only, distinct UMIs per gene (src/pugutils.rs:852-911)
 
 constexpr uint32_t kSlabWords = 256;  // dwords one wave of k_decode_par covers (1 KiB)
 

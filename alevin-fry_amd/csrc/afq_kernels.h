@@ -58,6 +58,9 @@ void launch_hist(hipStream_t s, const ResolveArgs& a);
 void launch_bucket_scan(hipStream_t s, const ResolveArgs& a);
 void launch_scatter(hipStream_t s, const ResolveArgs& a);
 size_t bucket_desc_bytes();
+void launch_atac_dedup(hipStream_t s, uint32_t n_cells, const uint32_t* ref, const uint32_t* start, const uint16_t* flen,
+                       const uint64_t* cell_ptr, void* scratch /* 16 B per fragment */, uint32_t* o_ref, uint32_t* o_start,
+                       uint16_t* o_flen, uint16_t* o_cnt, uint32_t* o_n);
 void launch_resolve(hipStream_t s, const ResolveArgs& a);
 void launch_resolve_big(hipStream_t s, const ResolveArgs& a);
 void launch_cell_hist(hipStream_t s, const ResolveArgs& a);

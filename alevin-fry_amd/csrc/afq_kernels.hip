@@ -260,6 +260,7 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ byte
                 }
             }
         }
+        if (m.mode == kModeTrivial && kcnt != 1) kcnt = 0;  // multi-gene reads are discarded (pugutils.rs:870-891)
         uint32_t tot;
         const uint32_t ex = wave_excl_scan(kcnt, tot);
         if (kcnt) {
@@ -535,6 +536,7 @@ __global__ __launch_bounds__(256) void k_decode_par(const uint8_t* __restrict__ 
                     }
                 }
             }
+            if (m.mode == kModeTrivial && kcnt != 1) kcnt = 0;  // multi-gene reads are discarded (pugutils.rs:870-891)
             uint32_t tot;
             const uint32_t ex = wave_excl_scan(kcnt, tot);
             uint32_t wbase = 0;
@@ -833,6 +835,7 @@ __device__ __forceinline__ void block_sort_any(const T* src, uint32_t n, T* s_x,
 // resolve core, shared by the LDS and the global-scratch variants.
 struct ResolveCfg {
     uint32_t usa, num_rows, uo, ao;
+    uint32_t mode;  // filled per bucket from its descriptor
 };
 
 __device__ __forceinline__ bool is_spliced(uint32_t g) { return (g & 1u) == 0; }
@@ -857,6 +860,12 @@ __device__ __forceinline__ void resolve_sorted(const uint64_t* keys, uint32_t n,
     const uint32_t nruns = carry;
     __syncthreads();
     auto run_end = [&](uint32_t q) -> uint32_t { return q + 1 < nruns ? (uint32_t)run_start[q + 1] : n; };  // no sentinel slot needed
+    if (rc.mode == kModeTrivial) {
+        // `trivial`: every distinct (umi, gene) of the single-gene reads is one molecule of that gene
+        // (pugutils.rs:899-907); the column is the raw gene id (counts has num_genes entries, pugutils.rs:858).
+        for (uint32_t r = threadIdx.x; r < nruns; r += NT) emit((uint32_t)keys[run_start[r]] & kGeneMask);
+        return;
+    }
     for (uint32_t r = threadIdx.x; r < nruns; r += NT) {
         const uint64_t umi = keys[run_start[r]] >> kGeneBits;
         if (r > 0 && (keys[run_start[r - 1]] >> kGeneBits) == umi) continue;  // not the UMI's first run
@@ -909,7 +918,7 @@ struct BucketDesc {
     uint32_t n;        // keys in the bucket
     uint32_t cell;
     uint32_t single;   // 1: the bucket is the whole cell
-    uint32_t pad;
+    uint32_t mode;     // kMode* of the cell
 };
 
 __global__ void k_bucket_desc(const CellMeta* __restrict__ meta, const uint32_t* __restrict__ bucket_cell,
@@ -920,7 +929,7 @@ __global__ void k_bucket_desc(const CellMeta* __restrict__ meta, const uint32_t*
     const uint32_t cell = bucket_cell[b];
     const CellMeta m = meta[cell];
     BucketDesc d;
-    d.cell = cell; d.out_off = m.key_off; d.pad = 0;
+    d.cell = cell; d.out_off = m.key_off; d.mode = m.mode;
     if (m.lg_nb == 0) { d.single = 1; d.src_off = m.key_off; d.n = cell_nkeys[cell]; }
     else {
         const uint32_t beg = (b == m.bucket_base) ? 0u : cursor[b - 1];
@@ -939,9 +948,11 @@ __device__ __forceinline__ void resolve_bucket_lds(const BucketDesc& d, uint64_t
                                                    uint32_t* s_misc /* [2] */) {
     const uint32_t n = d.n;
     const uint64_t* src = (d.single ? keys0 : keys1) + d.src_off;
+    ResolveCfg rcb = rc;
+    rcb.mode = d.mode;
     if (threadIdx.x == 0) s_misc[0] = 0;
     block_sort_any<NT, uint64_t>(src, n, s_keys, kKeySentinel);
-    resolve_sorted<NT>(s_keys, n, s_run, s_ws, rc, [&](uint32_t col) {
+    resolve_sorted<NT>(s_keys, n, s_run, s_ws, rcb, [&](uint32_t col) {
         if (col >= rc.num_rows) { set_err(st, kErrSlotRange, d.cell); return; }
         s_cols[atomicAdd(&s_misc[0], 1u)] = col;
     });
@@ -1068,7 +1079,9 @@ __global__ __launch_bounds__(kBigNT) void k_resolve_big(const BucketDesc* __rest
         __syncthreads();
         bitonic_sort<kBigNT>(keys, n);
         uint32_t* cols = reinterpret_cast<uint32_t*>(keys0 + d.out_off);
-        resolve_sorted<kBigNT>(keys, n, run, s_ws, rc, [&](uint32_t col) {
+        ResolveCfg rcb = rc;
+        rcb.mode = d.mode;
+        resolve_sorted<kBigNT>(keys, n, run, s_ws, rcb, [&](uint32_t col) {
             if (col >= rc.num_rows) { set_err(st, kErrSlotRange, d.cell); return; }
             cols[atomicAdd(&cell_ncols[d.cell], 1u)] = col;
         });
@@ -1144,6 +1157,60 @@ __global__ __launch_bounds__(256) void k_compact(const CellMeta* __restrict__ me
 }
 
 // ---------------------------------------------------------------------------
+// ATAC per-cell fragment de-duplication (src/atac/deduplicate.rs:199-237): sort a
+// cell's fragments by (chr, start, frag_len) — HitInfo's Ord, src/atac/sort.rs:47-58;
+// the barcode is constant within a cell — and run-length count them.  One
+// 1024-thread workgroup per cell sorts in place in a global scratch copy (the
+// normalised bitonic network takes any n); cells are independent.
+struct Frag {
+    uint64_t hi;  // chr << 32 | start
+    uint64_t lo;  // frag_len
+};
+__device__ __forceinline__ bool operator>(const Frag& a, const Frag& b) { return a.hi > b.hi || (a.hi == b.hi && a.lo > b.lo); }
+__device__ __forceinline__ bool operator!=(const Frag& a, const Frag& b) { return a.hi != b.hi || a.lo != b.lo; }
+
+constexpr int kAtacNT = 1024;
+__global__ __launch_bounds__(kAtacNT) void k_atac_dedup(const uint32_t* __restrict__ ref, const uint32_t* __restrict__ start,
+                                                       const uint16_t* __restrict__ flen,
+                                                       const uint64_t* __restrict__ cell_ptr, Frag* __restrict__ scratch,
+                                                       uint32_t* __restrict__ o_ref, uint32_t* __restrict__ o_start,
+                                                       uint16_t* __restrict__ o_flen, uint16_t* __restrict__ o_cnt,
+                                                       uint32_t* __restrict__ o_n) {
+    __shared__ uint32_t s_ws[kAtacNT / 64];
+    const uint32_t cell = blockIdx.x;
+    const uint64_t b0 = cell_ptr[cell];
+    const uint32_t n = (uint32_t)(cell_ptr[cell + 1] - b0);
+    Frag* f = scratch + b0;
+    for (uint32_t i = threadIdx.x; i < n; i += kAtacNT) {
+        Frag x;
+        x.hi = ((uint64_t)ref[b0 + i] << 32) | start[b0 + i];
+        x.lo = flen[b0 + i];
+        f[i] = x;
+    }
+    __syncthreads();
+    bitonic_sort<kAtacNT>(f, n);
+    // run heads -> output slot; run length = distance to the next head (found by scanning forward)
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n; base += kAtacNT) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t h = (i < n) && (i == 0 || f[i] != f[i - 1]);
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<kAtacNT>(h, s_ws, tot);
+        if (h) {
+            uint32_t e = i + 1;
+            while (e < n && !(f[e] != f[i])) ++e;
+            const uint64_t o = b0 + carry + ex;
+            o_ref[o] = (uint32_t)(f[i].hi >> 32);
+            o_start[o] = (uint32_t)f[i].hi;
+            o_flen[o] = (uint16_t)f[i].lo;
+            o_cnt[o] = (uint16_t)(e - i);  // `count as u16`, deduplicate.rs:220
+        }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) o_n[cell] = carry;
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 #define AFQ_LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
 
@@ -1211,7 +1278,7 @@ void launch_scatter(hipStream_t s, const ResolveArgs& a) {
 
 static ResolveCfg make_rc(const ResolveArgs& a) {
     ResolveCfg rc;
-    rc.usa = a.usa; rc.num_rows = a.num_rows; rc.uo = a.num_rows / 3; rc.ao = 2 * (a.num_rows / 3);
+    rc.usa = a.usa; rc.num_rows = a.num_rows; rc.uo = a.num_rows / 3; rc.ao = 2 * (a.num_rows / 3); rc.mode = 0;
     return rc;
 }
 
@@ -1234,6 +1301,14 @@ void launch_resolve_big(hipStream_t s, const ResolveArgs& a) {
 }
 
 size_t bucket_desc_bytes() { return sizeof(BucketDesc); }
+
+void launch_atac_dedup(hipStream_t s, uint32_t n_cells, const uint32_t* ref, const uint32_t* start, const uint16_t* flen,
+                       const uint64_t* cell_ptr, void* scratch, uint32_t* o_ref, uint32_t* o_start, uint16_t* o_flen,
+                       uint16_t* o_cnt, uint32_t* o_n) {
+    if (!n_cells) return;
+    AFQ_LAUNCH(k_atac_dedup, n_cells, kAtacNT, s, ref, start, flen, cell_ptr, reinterpret_cast<Frag*>(scratch), o_ref, o_start,
+               o_flen, o_cnt, o_n);
+}
 
 void launch_cell_hist(hipStream_t s, const ResolveArgs& a) {
     if (!a.n_multi) return;

@@ -153,7 +153,7 @@ def test_bad_input_is_reported_not_crashed():
 def test_unsupported_resolutions_fail_loudly():
     s = synth.synth(6, [50], num_genes=20)
     b, off = s.encode()
-    q = pkg.Quantifier(cfg_for(s, "trivial"), s.tid_to_gid)
+    q = pkg.Quantifier(cfg_for(s, "parsimony-em"), s.tid_to_gid)
     try:
         with pytest.raises(pkg.AfqError) as e:
             q.quant_chunks(b, off)
@@ -198,3 +198,48 @@ def test_unaligned_chunk_offsets_use_the_sequential_walk(oracle):
     b2 = np.concatenate(parts)
     got, want, st = run_both(oracle, cfg_for(s), s.tid_to_gid, b2, np.asarray(offs, np.uint64))
     assert_same_result(got, want)
+
+
+@pytest.mark.parametrize("usa", [False, True])
+@pytest.mark.parametrize("small_thresh", [100, 0])
+def test_trivial_resolution(oracle, usa, small_thresh):
+    """`trivial` (pugutils.rs:852-911): single-gene reads only, distinct UMIs per gene; cells under
+    --small-thresh still take the cr-like tiny path (quant.rs:794-845)."""
+    sizes = [30000, 4000, 700, 260, 120, 99, 40, 3]
+    s = synth.synth(12, sizes, num_genes=800, usa=usa, dup=0.5, zipf=0.8, max_extra_na=10)
+    b, off = s.encode()
+    cfg = cfg_for(s, "trivial", small_thresh=small_thresh)
+    got, want, _ = run_both(oracle, cfg, s.tid_to_gid, b, off)
+    assert_same_result(got, want)
+    # trivial really differs from cr-like on this input
+    other = oracle.quant(cfg_for(s, "cr-like", small_thresh=small_thresh), s.tid_to_gid, b, off)
+    assert not np.array_equal(other.val, want.val) or not np.array_equal(other.gene, want.gene)
+
+
+def test_atac_dedup(oracle):
+    """afq_atac_dedup vs the oracle (atac/deduplicate.rs:199-237): config-5-like fragments, 20 % exact duplicates,
+    an empty cell, a cell of one fragment, u16 count wrap-around."""
+    rng = np.random.default_rng(5)
+    sizes = [3000, 0, 1, 777, 2500, 64, 65, 1024, 1025, 70000]
+    refs, starts, lens = [], [], []
+    for n in sizes:
+        r = rng.integers(0, 25, n).astype(np.uint32)
+        st = rng.integers(0, 1_000_000, n).astype(np.uint32)
+        ln = np.clip(np.round(np.exp(rng.normal(5.0, 0.6, n))), 30, 2500).astype(np.uint16)
+        d = rng.random(n) < 0.2
+        src = rng.integers(0, max(n, 1), n)
+        r, st, ln = np.where(d, r[src], r), np.where(d, st[src], st), np.where(d, ln[src], ln)
+        refs.append(r); starts.append(st); lens.append(ln)
+    # last cell: one fragment repeated 66000 times -> count wraps to 66000 & 0xFFFF like `count as u16`
+    refs[-1][:66000] = 3; starts[-1][:66000] = 12345; lens[-1][:66000] = 150
+    ref, start, flen = np.concatenate(refs), np.concatenate(starts), np.concatenate(lens)
+    ptr = np.concatenate(([0], np.cumsum(sizes))).astype(np.uint64)
+    want = oracle.atac_dedup(ref, start, flen, ptr)
+    q = pkg.Quantifier(pkg.WorkerConfig.for_resolution("cr-like", num_genes=1, num_rows=1), np.zeros(1, np.uint32))
+    try:
+        got = q.atac_dedup(ref, start, flen, ptr)
+    finally:
+        q.close()
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    assert (66000 & 0xFFFF) in got[4][int(got[0][-2]):].tolist()
