@@ -41,9 +41,9 @@ struct DevBuf {
     template <class T> T* as() { return reinterpret_cast<T*>(p); }
 };
 
-enum KernelId { K_GATHER = 0, K_DECODE_PAR, K_DECODE, K_HIST, K_BSCAN, K_SCATTER, K_RESOLVE, K_RESOLVE_BIG, K_CELL_HIST, K_COMPACT, K_COUNT };
+enum KernelId { K_GATHER = 0, K_DECODE_PAR, K_DECODE, K_HIST, K_BSCAN, K_SCATTER, K_RESOLVE, K_RESOLVE_BIG, K_CELL_HIST, K_EM, K_COMPACT, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"k_gather_headers", "k_decode_par", "k_decode", "k_hist", "k_bucket_scan", "k_scatter",
-                                           "k_resolve", "k_resolve_big", "k_cell_hist", "k_compact"};
+                                           "k_resolve", "k_resolve_big", "k_cell_hist", "k_em", "k_compact"};
 
 struct TimedLaunch { int id; hipEvent_t a, b; };
 
@@ -127,7 +127,8 @@ struct afq_ctx {
     size_t n_bytes = 0;
     // per-range device state
     DevBuf d_meta, d_keys0, d_keys1, d_cell_nkeys, d_bucket_cnt, d_bucket_cell, d_multi_cells, d_tile_prefix, d_ncols,
-        d_nnz, d_ovf, d_status, d_bc, d_cell_ptr, d_gene, d_val, d_chunk_off, d_hdr, d_chk, d_slab_prefix, d_slab_cell, d_cell_bc, d_bdesc;
+        d_nnz, d_ovf, d_status, d_bc, d_cell_ptr, d_gene, d_val, d_chunk_off, d_hdr, d_chk, d_slab_prefix, d_slab_cell, d_cell_bc, d_bdesc, d_lab, d_lab_cnt, d_em_off, d_em_scratch, d_em_nnz;
+    ResolveArgs last_ra{};
     bool all_aligned = true;  // every chunk offset is a multiple of 4
     ResultPool* pool = nullptr;
     // host planning state
@@ -198,8 +199,8 @@ bool valid_width(uint32_t w) { return w == 1 || w == 2 || w == 4 || w == 8; }
 // What the device path implements today.  Anything else is refused loudly.
 int check_supported(afq_ctx* c) {
     const afq_config& g = c->cfg;
-    if (g.resolution != AFQ_RES_CR_LIKE && g.resolution != AFQ_RES_TRIVIAL)
-        return fail(c, AFQ_ERR_UNSUPPORTED, "device path implements resolutions cr-like and trivial only (so far)");
+    if (g.resolution != AFQ_RES_CR_LIKE && g.resolution != AFQ_RES_TRIVIAL && g.resolution != AFQ_RES_CR_LIKE_EM)
+        return fail(c, AFQ_ERR_UNSUPPORTED, "device path implements resolutions cr-like, cr-like-em and trivial only (so far)");
     if (g.usa_mode && g.sa_model != AFQ_SA_WINNER_TAKE_ALL)
         return fail(c, AFQ_ERR_UNSUPPORTED, "sa_model prefer-ambig is not implemented on the device path");
     return 0;
@@ -228,7 +229,7 @@ int plan_ranges(afq_ctx* c) {
         if (fixed > nbytes || ((nbytes - fixed) & 3))
             return fail(c, AFQ_ERR_BAD_INPUT, "cell " + std::to_string(i) + ": chunk nbytes does not match its records");
         const uint64_t n_ref = (nbytes - fixed) / 4;
-        double need = 16.0 * (double)n_ref + 128.0;
+        double need = (c->cfg.resolution == AFQ_RES_CR_LIKE_EM ? 24.0 + 40.0 * (c->cfg.usa_mode ? 3 : 1) : 16.0) * (double)n_ref + 128.0;
         if (n_ref > kBucketTarget) need += 16.0 * (double)(n_ref / kBucketTarget + 1);
         if (need > budget) return fail(c, AFQ_ERR_OOM, "cell " + std::to_string(i) + " alone exceeds device memory");
         if (used + need > budget) { c->ranges.push_back({c0, i}); c0 = i; used = 0; }
@@ -270,7 +271,9 @@ int run_range(afq_ctx* c, Range r) {
         }
         // strategy dispatch of src/quant.rs:794-938: tiny cells take the cr-like fast path whatever -r says
         const bool tiny = g.sa_model == AFQ_SA_WINNER_TAKE_ALL && m.nrec < g.small_thresh;
-        m.mode = (g.resolution == AFQ_RES_TRIVIAL && !tiny) ? kModeTrivial : kModeCrLike;
+        m.mode = tiny ? kModeCrLike
+                 : g.resolution == AFQ_RES_TRIVIAL ? kModeTrivial
+                 : g.resolution == AFQ_RES_CR_LIKE_EM ? kModeCrLikeEm : kModeCrLike;
         nrec_total += m.nrec;
         if (par) {
             slab_prefix.push_back((uint32_t)n_slabs);
@@ -303,6 +306,11 @@ int run_range(afq_ctx* c, Range r) {
     HIP_TRY(c, c->d_nnz.ensure(4ull * n));
     HIP_TRY(c, c->d_ovf.ensure(sizeof(OverflowEnt) * std::max<uint64_t>(n_buckets, 1)));
     HIP_TRY(c, c->d_bdesc.ensure(bucket_desc_bytes() * std::max<uint64_t>(n_buckets, 1)));
+    const bool em = g.resolution == AFQ_RES_CR_LIKE_EM;
+    if (em) {
+        HIP_TRY(c, c->d_lab.ensure(8 * key_off));
+        HIP_TRY(c, c->d_lab_cnt.ensure(8ull * n));
+    }
     HIP_TRY(c, c->d_status.ensure(sizeof(DevStatus)));
     HIP_TRY(c, c->d_bc.ensure(8ull * n));
     if (par) {
@@ -327,6 +335,7 @@ int run_range(afq_ctx* c, Range r) {
     HIP_TRY(c, hipMemsetAsync(c->d_bucket_cnt.p, 0, 4 * n_buckets, s));
     HIP_TRY(c, hipMemsetAsync(c->d_nnz.p, 0, 4ull * n, s));
     HIP_TRY(c, hipMemsetAsync(c->d_ncols.p, 0, 4ull * n, s));
+    if (em) HIP_TRY(c, hipMemsetAsync(c->d_lab_cnt.p, 0, 8ull * n, s));
     HIP_TRY(c, hipMemsetAsync(c->d_status.p, 0, sizeof(DevStatus), s));
     HIP_TRY(c, hipMemsetAsync(c->d_bc.p, 0, 8ull * n, s));
     // the host copies above are sourced from stack/vector memory: make sure they are consumed
@@ -349,7 +358,8 @@ int run_range(afq_ctx* c, Range r) {
     ResolveArgs ra{c->d_meta.as<CellMeta>(), c->d_bucket_cell.as<uint32_t>(), c->d_multi_cells.as<uint32_t>(),
                    c->d_tile_prefix.as<uint32_t>(), c->d_cell_nkeys.as<uint32_t>(), c->d_bucket_cnt.as<uint32_t>(),
                    c->d_keys0.as<uint64_t>(), c->d_keys1.as<uint64_t>(), c->d_ncols.as<uint32_t>(),
-                   c->d_nnz.as<uint32_t>(), c->d_ovf.as<OverflowEnt>(), c->d_bdesc.p, c->d_status.as<DevStatus>(),
+                   c->d_nnz.as<uint32_t>(), c->d_ovf.as<OverflowEnt>(), c->d_bdesc.p, em ? c->d_lab.as<uint32_t>() : nullptr,
+                   em ? c->d_lab_cnt.as<uint32_t>() : nullptr, c->d_status.as<DevStatus>(),
                    (uint32_t)n_buckets, n_multi, (uint32_t)n_tiles, g.usa_mode, g.num_rows};
     if (n_multi) {
         { ScopedTimer t(c, K_HIST); launch_hist(s, ra); }
@@ -362,6 +372,7 @@ int run_range(afq_ctx* c, Range r) {
         { ScopedTimer t(c, K_CELL_HIST); launch_cell_hist(s, ra); }
     }
     HIP_TRY(c, hipGetLastError());
+    c->last_ra = ra;
     c->cur = r;
     c->range_in_flight = true;
     c->stats.n_records += nrec_total;
@@ -395,7 +406,27 @@ int finish_range(afq_ctx* c) {
     c->stats.n_fallback_cells += st.n_fallback;
     std::vector<uint32_t> nnz(n);
     std::vector<uint64_t> bc(n), ptr(n + 1);
+    const bool em = c->cfg.resolution == AFQ_RES_CR_LIKE_EM;
     HIP_TRY(c, hipMemcpy(nnz.data(), c->d_nnz.p, 4ull * n, hipMemcpyDeviceToHost));
+    if (em) {
+        // per-cell EM (src/em.rs) over the single-label counts + the ambiguous molecules' labels
+        std::vector<uint32_t> lc(2ull * n);
+        std::vector<uint64_t> eoff(n + 1);
+        HIP_TRY(c, hipMemcpy(lc.data(), c->d_lab_cnt.p, 8ull * n, hipMemcpyDeviceToHost));
+        eoff[0] = 0;
+        for (uint32_t i = 0; i < n; ++i) eoff[i + 1] = eoff[i] + em_scratch_words(nnz[i], lc[2 * i], lc[2 * i + 1], c->cfg.usa_mode != 0);
+        HIP_TRY(c, c->d_em_off.ensure(8ull * (n + 1)));
+        HIP_TRY(c, c->d_em_scratch.ensure(4 * eoff[n] + 16));
+        HIP_TRY(c, c->d_em_nnz.ensure(4ull * n));
+        HIP_TRY(c, hipMemcpyAsync(c->d_em_off.p, eoff.data(), 8ull * (n + 1), hipMemcpyHostToDevice, s));
+        {
+            ScopedTimer t(c, K_EM);
+            launch_em(s, c->last_ra, n, c->d_em_off.as<uint64_t>(), c->d_em_scratch.as<uint32_t>(), c->d_em_nnz.as<uint32_t>(),
+                      c->cfg.usa_mode ? c->cfg.num_rows : c->cfg.num_genes, c->cfg.em_init_uniform);
+        }
+        HIP_TRY(c, hipStreamSynchronize(s));
+        HIP_TRY(c, hipMemcpy(nnz.data(), c->d_em_nnz.p, 4ull * n, hipMemcpyDeviceToHost));
+    }
     HIP_TRY(c, hipMemcpy(bc.data(), c->d_bc.p, 8ull * n, hipMemcpyDeviceToHost));
     ptr[0] = 0;
     for (uint32_t i = 0; i < n; ++i) ptr[i + 1] = ptr[i] + nnz[i];
@@ -406,8 +437,12 @@ int finish_range(afq_ctx* c) {
     HIP_TRY(c, hipMemcpyAsync(c->d_cell_ptr.p, ptr.data(), 8ull * (n + 1), hipMemcpyHostToDevice, s));
     {
         ScopedTimer t(c, K_COMPACT);
-        launch_compact(s, c->d_meta.as<CellMeta>(), n, c->d_keys0.as<uint64_t>(), c->d_keys1.as<uint64_t>(), c->d_nnz.as<uint32_t>(),
-                       c->d_cell_ptr.as<uint64_t>(), c->d_gene.as<uint32_t>(), c->d_val.as<float>());
+        if (em)
+            launch_compact_em(s, n, c->d_em_off.as<uint64_t>(), c->d_em_scratch.as<uint32_t>(), c->d_em_nnz.as<uint32_t>(),
+                              c->d_cell_ptr.as<uint64_t>(), c->d_gene.as<uint32_t>(), c->d_val.as<float>());
+        else
+            launch_compact(s, c->d_meta.as<CellMeta>(), n, c->d_keys0.as<uint64_t>(), c->d_keys1.as<uint64_t>(), c->d_nnz.as<uint32_t>(),
+                           c->d_cell_ptr.as<uint64_t>(), c->d_gene.as<uint32_t>(), c->d_val.as<float>());
     }
     HostResult& R = *c->res;
     const size_t g0 = R.gene.n;
@@ -515,7 +550,8 @@ void afq_destroy(afq_ctx* c) {
     DevBuf* bufs[] = {&c->d_t2g, &c->d_bytes_own, &c->d_meta, &c->d_keys0, &c->d_keys1, &c->d_cell_nkeys,
                       &c->d_bucket_cnt, &c->d_bucket_cell, &c->d_multi_cells, &c->d_tile_prefix, &c->d_ncols, &c->d_nnz,
                       &c->d_ovf, &c->d_status, &c->d_bc, &c->d_cell_ptr, &c->d_gene, &c->d_val, &c->d_chunk_off, &c->d_hdr,
-                      &c->d_chk, &c->d_slab_prefix, &c->d_slab_cell, &c->d_cell_bc, &c->d_bdesc};
+                      &c->d_chk, &c->d_slab_prefix, &c->d_slab_cell, &c->d_cell_bc, &c->d_bdesc, &c->d_lab, &c->d_lab_cnt, &c->d_em_off,
+                      &c->d_em_scratch, &c->d_em_nnz};
     for (auto b : bufs) b->release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->res) pool_put(c->res);

@@ -60,6 +60,7 @@ struct CellChk {
 };
 
 constexpr uint32_t kModeCrLike = 0;   // winner-take-all (cr-like; every tiny cell, src/quant.rs:794-845)
+constexpr uint32_t kModeCrLikeEm = 2; // cr-like-em: ties are kept as gene-level classes and resolved by the EM (quant.rs:882-924)
 constexpr uint32_t kModeTrivial = 1;  // `trivial`: single-gene reads only, distinct UMIs per gene (src/pugutils.rs:852-911)
 
 constexpr uint32_t kSlabWords = 256;  // dwords one wave of k_decode_par covers (1 KiB)

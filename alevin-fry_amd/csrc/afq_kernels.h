@@ -41,6 +41,8 @@ struct ResolveArgs {
     uint32_t* nnz;
     OverflowEnt* ovf_list;
     void* bucket_desc;     // [n_buckets] x bucket_desc_bytes()
+    uint32_t* lab;         // EM modes: label area, 2 words per key slot (null otherwise)
+    uint32_t* lab_cnt;     // EM modes: per cell (label words, ambiguous molecules)
     DevStatus* st;
     uint32_t n_buckets;
     uint32_t n_multi;
@@ -58,6 +60,11 @@ void launch_hist(hipStream_t s, const ResolveArgs& a);
 void launch_bucket_scan(hipStream_t s, const ResolveArgs& a);
 void launch_scatter(hipStream_t s, const ResolveArgs& a);
 size_t bucket_desc_bytes();
+uint64_t em_scratch_words(uint32_t nU, uint32_t W, uint32_t M, bool usa);
+void launch_em(hipStream_t s, const ResolveArgs& a, uint32_t n_cells, const uint64_t* em_off, uint32_t* scratch,
+               uint32_t* out_nnz, uint32_t num_alphas, uint32_t init_uniform);
+void launch_compact_em(hipStream_t s, uint32_t n_cells, const uint64_t* em_off, const uint32_t* scratch, const uint32_t* nnz,
+                       const uint64_t* cell_ptr, uint32_t* gene, float* val);
 void launch_atac_dedup(hipStream_t s, uint32_t n_cells, const uint32_t* ref, const uint32_t* start, const uint16_t* flen,
                        const uint64_t* cell_ptr, void* scratch /* 16 B per fragment */, uint32_t* o_ref, uint32_t* o_start,
                        uint16_t* o_flen, uint16_t* o_cnt, uint32_t* o_n);

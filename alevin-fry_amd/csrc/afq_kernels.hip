@@ -95,6 +95,37 @@ __device__ __forceinline__ void bitonic_sort(T* a, uint32_t n) {
     }
 }
 
+template <int NT, typename T, typename Gt>
+__device__ __forceinline__ void bitonic_sort_by(T* a, uint32_t n, Gt gt) {
+    if (n < 2) return;
+    uint32_t np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    const uint32_t half = np2 >> 1;
+    for (uint32_t k = 2; k <= np2; k <<= 1) {
+        const uint32_t hk = k >> 1;
+        for (uint32_t i = threadIdx.x; i < half; i += NT) {
+            uint32_t blk = i / hk, o = i - blk * hk;
+            uint32_t l = blk * k + o, r = blk * k + (k - 1 - o);
+            if (r < n) {
+                T x = a[l], y = a[r];
+                if (gt(x, y)) { a[l] = y; a[r] = x; }
+            }
+        }
+        __syncthreads();
+        for (uint32_t j = hk >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < half; i += NT) {
+                uint32_t l = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                uint32_t r = l + j;
+                if (r < n) {
+                    T x = a[l], y = a[r];
+                    if (gt(x, y)) { a[l] = y; a[r] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // little-endian field loads at arbitrary byte alignment
 template <int W>
@@ -837,6 +868,7 @@ struct ResolveCfg {
     uint32_t usa, num_rows, uo, ao;
     uint32_t mode;  // filled per bucket from its descriptor
 };
+__device__ __forceinline__ bool mode_is_em(uint32_t mode) { return mode == kModeCrLikeEm; }
 
 __device__ __forceinline__ bool is_spliced(uint32_t g) { return (g & 1u) == 0; }
 __device__ __forceinline__ bool same_gene(uint32_t a, uint32_t b) { return (a & ~1u) == (b & ~1u); }
@@ -845,9 +877,11 @@ __device__ __forceinline__ bool same_gene(uint32_t a, uint32_t b) { return (a & 
 // winner / tie set and maps it to an output column (non-USA: unique winner only,
 // src/quant.rs:563-565; USA: src/utils.rs:688-753 == src/quant.rs:557-605).
 // emit(col) is called once per resolved UMI.
-template <int NT, typename RunT, typename Emit>
+// In the EM modes (cr-like-em) a UMI whose tie set is not a single output column is kept as a
+// gene-level equivalence class (quant.rs:882-924): lab_alloc(nb) returns room for its nb tie genes.
+template <int NT, typename RunT, typename Emit, typename LabAlloc>
 __device__ __forceinline__ void resolve_sorted(const uint64_t* keys, uint32_t n, RunT* run_start,
-                                               uint32_t* ws, const ResolveCfg& rc, Emit&& emit) {
+                                               uint32_t* ws, const ResolveCfg& rc, Emit&& emit, LabAlloc&& lab_alloc) {
     uint32_t carry = 0;
     for (uint32_t base = 0; base < n; base += NT) {
         const uint32_t i = base + threadIdx.x;
@@ -894,7 +928,24 @@ __device__ __forceinline__ void resolve_sorted(const uint64_t* keys, uint32_t n,
             }
         }
         uint32_t col = 0xFFFFFFFFu;
-        if (!rc.usa) {
+        if (mode_is_em(rc.mode)) {
+            // single-label classes are counted as columns; for USA that is a label whose S/U/A rewrite
+            // (utils.rs:865-925) has one entry: one gene id, or S and U of the same gene
+            if (nb == 1) col = !rc.usa ? g1 : (is_spliced(g1) ? (g1 >> 1) : rc.uo + (g1 >> 1));
+            else if (rc.usa && nb == 2 && same_gene(g1, g2)) col = rc.ao + (g1 >> 1);
+            else {
+                uint32_t* dst = lab_alloc(nb);
+                if (dst) {
+                    uint32_t w = 0;
+                    for (uint32_t q = r; q < nruns; ++q) {
+                        const uint32_t s = run_start[q];
+                        const uint64_t kq = keys[s];
+                        if ((kq >> kGeneBits) != umi) break;
+                        if (run_end(q) - s == maxc) dst[w++] = (uint32_t)kq & kGeneMask;
+                    }
+                }
+            }
+        } else if (!rc.usa) {
             if (nb == 1) col = g1;
         } else if (nb == 1) {
             col = is_spliced(g1) ? (g1 >> 1) : rc.uo + (g1 >> 1);
@@ -917,8 +968,8 @@ struct BucketDesc {
     uint64_t out_off;  // the cell's key_off (column list / pair staging live in its keys0 slots)
     uint32_t n;        // keys in the bucket
     uint32_t cell;
-    uint32_t single;   // 1: the bucket is the whole cell
-    uint32_t mode;     // kMode* of the cell
+    uint32_t mode_single;  // kMode* of the cell | single << 8 (1: the bucket is the whole cell)
+    uint32_t n_ref;        // the cell's key capacity (locates its label area)
 };
 
 __global__ void k_bucket_desc(const CellMeta* __restrict__ meta, const uint32_t* __restrict__ bucket_cell,
@@ -929,13 +980,29 @@ __global__ void k_bucket_desc(const CellMeta* __restrict__ meta, const uint32_t*
     const uint32_t cell = bucket_cell[b];
     const CellMeta m = meta[cell];
     BucketDesc d;
-    d.cell = cell; d.out_off = m.key_off; d.mode = m.mode;
-    if (m.lg_nb == 0) { d.single = 1; d.src_off = m.key_off; d.n = cell_nkeys[cell]; }
+    d.cell = cell; d.out_off = m.key_off; d.n_ref = m.n_ref;
+    if (m.lg_nb == 0) { d.mode_single = m.mode | 0x100u; d.src_off = m.key_off; d.n = cell_nkeys[cell]; }
     else {
         const uint32_t beg = (b == m.bucket_base) ? 0u : cursor[b - 1];
-        d.single = 0; d.src_off = m.key_off + beg; d.n = cursor[b] - beg;
+        d.mode_single = m.mode; d.src_off = m.key_off + beg; d.n = cursor[b] - beg;
     }
     desc[b] = d;
+}
+
+// Where a cell's gene-level classes (EM modes) are collected: lab[2*key_off ...] holds the label
+// words of the cell's ambiguous molecules, followed (from word n_ref+1) by (offset,len) descriptors.
+struct LabArea {
+    uint32_t* lab;      // [2 * total key slots] or null outside the EM modes
+    uint32_t* lab_cnt;  // per cell: [2*cell] words used, [2*cell+1] molecules
+};
+
+__device__ __forceinline__ uint32_t* lab_alloc_global(const LabArea& la, uint32_t cell, uint64_t key_off, uint32_t n_ref,
+                                                      uint32_t nb) {
+    const uint32_t off = atomicAdd(&la.lab_cnt[2 * cell], nb), di = atomicAdd(&la.lab_cnt[2 * cell + 1], 1u);
+    uint32_t* gw = la.lab + 2 * key_off;
+    uint32_t* gd = gw + n_ref + 1;
+    gd[2 * di] = off; gd[2 * di + 1] = nb;
+    return gw + off;
 }
 
 // Sort + resolve one bucket held in LDS.  NT threads, up to NT*8 keys.
@@ -943,22 +1010,45 @@ template <int NT>
 __device__ __forceinline__ void resolve_bucket_lds(const BucketDesc& d, uint64_t* __restrict__ keys0,
                                                    const uint64_t* __restrict__ keys1,
                                                    uint32_t* __restrict__ cell_ncols, uint32_t* __restrict__ nnz,
-                                                   DevStatus* st, const ResolveCfg& rc, uint64_t* s_keys,
-                                                   uint16_t* s_run, uint32_t* s_cols, uint32_t* s_ws,
-                                                   uint32_t* s_misc /* [2] */) {
+                                                   DevStatus* st, const ResolveCfg& rc, const LabArea& la,
+                                                   uint64_t* s_keys, uint16_t* s_run, uint32_t* s_cols,
+                                                   uint32_t* s_lab, uint32_t* s_ldesc, uint32_t* s_ws,
+                                                   uint32_t* s_misc /* [6] */) {
     const uint32_t n = d.n;
-    const uint64_t* src = (d.single ? keys0 : keys1) + d.src_off;
+    const bool single = (d.mode_single >> 8) != 0;
+    const uint64_t* src = (single ? keys0 : keys1) + d.src_off;
     ResolveCfg rcb = rc;
-    rcb.mode = d.mode;
-    if (threadIdx.x == 0) s_misc[0] = 0;
+    rcb.mode = d.mode_single & 0xFFu;
+    if (threadIdx.x < 6) s_misc[threadIdx.x] = 0;
     block_sort_any<NT, uint64_t>(src, n, s_keys, kKeySentinel);
     resolve_sorted<NT>(s_keys, n, s_run, s_ws, rcb, [&](uint32_t col) {
         if (col >= rc.num_rows) { set_err(st, kErrSlotRange, d.cell); return; }
         s_cols[atomicAdd(&s_misc[0], 1u)] = col;
+    }, [&](uint32_t nb) -> uint32_t* {
+        if (!la.lab) return nullptr;
+        if (!s_lab) return lab_alloc_global(la, d.cell, d.out_off, d.n_ref, nb);
+        const uint32_t off = atomicAdd(&s_misc[2], nb), di = atomicAdd(&s_misc[3], 1u);
+        s_ldesc[2 * di] = off; s_ldesc[2 * di + 1] = nb;
+        return s_lab + off;
     });
     __syncthreads();
     const uint32_t nc = s_misc[0];
-    if (!d.single) {
+    if (s_lab && s_misc[3]) {  // hand the bucket's ambiguous molecules to the cell's label area
+        const uint32_t lw = s_misc[2], ln = s_misc[3];
+        if (threadIdx.x == 0) {
+            s_misc[4] = atomicAdd(&la.lab_cnt[2 * d.cell], lw);
+            s_misc[5] = atomicAdd(&la.lab_cnt[2 * d.cell + 1], ln);
+        }
+        __syncthreads();
+        uint32_t* gw = la.lab + 2 * d.out_off;
+        uint32_t* gd = gw + d.n_ref + 1;
+        for (uint32_t i = threadIdx.x; i < lw; i += NT) gw[s_misc[4] + i] = s_lab[i];
+        for (uint32_t i = threadIdx.x; i < ln; i += NT) {
+            gd[2 * (s_misc[5] + i)] = s_ldesc[2 * i] + s_misc[4];
+            gd[2 * (s_misc[5] + i) + 1] = s_ldesc[2 * i + 1];
+        }
+    }
+    if (!single) {
         if (nc == 0) return;
         if (threadIdx.x == 0) s_misc[1] = atomicAdd(&cell_ncols[d.cell], nc);
         __syncthreads();
@@ -996,24 +1086,29 @@ __device__ __forceinline__ void resolve_bucket_lds(const BucketDesc& d, uint64_t
 constexpr int kResolveNT = 128;
 constexpr uint32_t kResolveCols = 8192;
 static_assert(kBucketCap == kResolveNT * 8, "bucket cap = 8 keys per thread");
+template <bool EM>
 __global__ __launch_bounds__(kResolveNT) void k_resolve(const BucketDesc* __restrict__ desc, uint32_t n_buckets,
                                                        uint64_t* __restrict__ keys0,
                                                        const uint64_t* __restrict__ keys1,
                                                        uint32_t* __restrict__ cell_ncols, uint32_t* __restrict__ nnz,
                                                        OverflowEnt* __restrict__ ovf_list, DevStatus* st,
-                                                       ResolveCfg rc) {
+                                                       ResolveCfg rc, LabArea la) {
     __shared__ uint64_t s_keys[kBucketCap];
     __shared__ uint16_t s_run[kBucketCap];
     __shared__ uint32_t s_cols[kBucketCap];
+    __shared__ uint32_t s_lab_store[EM ? kBucketCap : 1];
+    __shared__ uint32_t s_ldesc_store[EM ? kBucketCap : 1];
     __shared__ uint32_t s_ws[kResolveNT / 64];
-    __shared__ uint32_t s_misc[2];
+    __shared__ uint32_t s_misc[6];
+    uint32_t* s_lab = EM ? s_lab_store : nullptr;
+    uint32_t* s_ldesc = EM ? s_ldesc_store : nullptr;
     const uint32_t n_cols = min(n_buckets, kResolveCols);
     const uint32_t n_rows = (n_buckets + n_cols - 1) / n_cols;
     const uint32_t b = (blockIdx.x % n_cols) * n_rows + blockIdx.x / n_cols;
     if (b >= n_buckets) return;
     const BucketDesc d = desc[b];
     if (d.n == 0) {
-        if (d.single && threadIdx.x == 0) nnz[d.cell] = 0;
+        if ((d.mode_single >> 8) && threadIdx.x == 0) nnz[d.cell] = 0;
         return;
     }
     if (d.n > kBucketCap) {  // only multi-bucket cells can get here (planner keeps single buckets <= target)
@@ -1024,7 +1119,8 @@ __global__ __launch_bounds__(kResolveNT) void k_resolve(const BucketDesc* __rest
         }
         return;
     }
-    resolve_bucket_lds<kResolveNT>(d, keys0, keys1, cell_ncols, nnz, st, rc, s_keys, s_run, s_cols, s_ws, s_misc);
+    resolve_bucket_lds<kResolveNT>(d, keys0, keys1, cell_ncols, nnz, st, rc, la, s_keys, s_run, s_cols, s_lab, s_ldesc, s_ws,
+                                   s_misc);
 }
 
 // Buckets over the 2-wave cap but within LDS reach (<= kMidCap keys): persistent
@@ -1036,18 +1132,21 @@ __global__ __launch_bounds__(kMidNT) void k_resolve_mid(const BucketDesc* __rest
                                                        const uint64_t* __restrict__ keys1,
                                                        uint32_t* __restrict__ cell_ncols, uint32_t* __restrict__ nnz,
                                                        const OverflowEnt* __restrict__ ovf_list, DevStatus* st,
-                                                       ResolveCfg rc) {
+                                                       ResolveCfg rc, LabArea la) {
     __shared__ uint64_t s_keys[kMidCap];
     __shared__ uint16_t s_run[kMidCap];
     __shared__ uint32_t s_cols[kMidCap];
     __shared__ uint32_t s_ws[kMidNT / 64];
-    __shared__ uint32_t s_misc[2];
+    __shared__ uint32_t s_misc[6];
+    // EM modes: this rare path writes labels straight to the cell's label area (global atomics per molecule)
+    uint32_t* s_lab = nullptr;
+    uint32_t* s_ldesc = nullptr;
     const uint32_t novf = st->n_overflow;
     for (uint32_t e = blockIdx.x; e < novf; e += gridDim.x) {
         if (ovf_list[e].n > kMidCap) continue;
         const BucketDesc d = desc[ovf_list[e].bucket];
         __syncthreads();
-        resolve_bucket_lds<kMidNT>(d, keys0, keys1, cell_ncols, nnz, st, rc, s_keys, s_run, s_cols, s_ws, s_misc);
+        resolve_bucket_lds<kMidNT>(d, keys0, keys1, cell_ncols, nnz, st, rc, la, s_keys, s_run, s_cols, s_lab, s_ldesc, s_ws, s_misc);
         __syncthreads();
     }
 }
@@ -1062,7 +1161,7 @@ __global__ __launch_bounds__(kBigNT) void k_resolve_big(const BucketDesc* __rest
                                                        uint64_t* __restrict__ keys0, uint64_t* __restrict__ keys1,
                                                        uint32_t* __restrict__ cell_ncols,
                                                        const OverflowEnt* __restrict__ ovf_list, DevStatus* st,
-                                                       ResolveCfg rc) {
+                                                       ResolveCfg rc, LabArea la) {
     __shared__ uint32_t s_ws[kBigNT / 64];
     const uint32_t novf = st->n_overflow;
     for (uint32_t e = blockIdx.x; e < novf; e += gridDim.x) {
@@ -1080,10 +1179,12 @@ __global__ __launch_bounds__(kBigNT) void k_resolve_big(const BucketDesc* __rest
         bitonic_sort<kBigNT>(keys, n);
         uint32_t* cols = reinterpret_cast<uint32_t*>(keys0 + d.out_off);
         ResolveCfg rcb = rc;
-        rcb.mode = d.mode;
+        rcb.mode = d.mode_single & 0xFFu;
         resolve_sorted<kBigNT>(keys, n, run, s_ws, rcb, [&](uint32_t col) {
             if (col >= rc.num_rows) { set_err(st, kErrSlotRange, d.cell); return; }
             cols[atomicAdd(&cell_ncols[d.cell], 1u)] = col;
+        }, [&](uint32_t nb) -> uint32_t* {
+            return la.lab ? lab_alloc_global(la, d.cell, d.out_off, d.n_ref, nb) : nullptr;
         });
         __syncthreads();
     }
@@ -1134,6 +1235,277 @@ __global__ __launch_bounds__(kHistNT) void k_cell_hist(const uint32_t* __restric
         __syncthreads();
     }
     if (threadIdx.x == 0) nnz[cell] = carry;
+}
+
+// ---------------------------------------------------------------------------
+// Per-cell EM over the gene-level equivalence classes (src/em.rs).  One workgroup per cell.
+//   inputs : the cell's single-label counts = sorted (column,count) pairs (k_cell_hist / k_resolve),
+//            and the labels of its ambiguous molecules (label area, written by resolve)
+//   steps  : group identical labels into classes (lexicographic order), rewrite USA labels to S/U/A
+//            slots (utils.rs:865-925), build the support (labels, and in USA their sibling statuses,
+//            em.rs:87-113), then iterate.  One round = (A) thread per class: denominator in label order;
+//            (B) thread per support entry: the single-label count first, then the contributions of the
+//            classes containing it in class order - the same f32 operation sequence as the sequential
+//            loop of em_update (em.rs:189-248, 458-485) under the oracle's canonical class order, so
+//            results are bit-identical to the oracle; (C) convergence vote.
+//   schedule: non-USA = em_optimize (em.rs:536-572); USA = em_optimize_subset_impl with the extra
+//            round after zeroing < 0.01 (em.rs:391-451).
+// All arrays live in a per-cell global scratch slice (L2 resident); sizes are tiny next to the decode.
+struct EmCfg {
+    uint32_t usa, num_alphas, uo, ao, init_uniform;
+};
+constexpr int kEmNT = 256;
+constexpr float kMinOutputAlpha = 0.01f, kAlphaCheckCutoff = 1e-2f, kRelDiffTol = 1e-2f;
+constexpr uint32_t kMinIter = 2, kMaxIter = 100;
+
+__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* a, uint32_t n, uint32_t x) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[mid] < x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+__global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta, const uint32_t* __restrict__ nnz_unique,
+                                             const uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
+                                             const uint32_t* __restrict__ lab, const uint32_t* __restrict__ lab_cnt,
+                                             const uint64_t* __restrict__ em_off, uint32_t* __restrict__ scratch,
+                                             uint32_t* __restrict__ out_nnz, EmCfg cfg) {
+    __shared__ uint32_t s_ws[kEmNT / 64];
+    __shared__ uint32_t s_flag[2];
+    const uint32_t cell = blockIdx.x;
+    const CellMeta m = meta[cell];
+    const uint32_t nU = nnz_unique[cell];
+    const uint2* U = reinterpret_cast<const uint2*>((m.lg_nb ? keys1 : keys0) + m.key_off);
+    const uint32_t W = lab_cnt[2 * cell], M = lab_cnt[2 * cell + 1];
+    const uint32_t* lw = lab + 2 * m.key_off;
+    const uint32_t* ld = lw + m.n_ref + 1;
+    const uint32_t mult = cfg.usa ? 3u : 1u;
+    const uint32_t capS = (nU + W) * mult;
+    // scratch carve (u32 words)
+    uint32_t* p = scratch + em_off[cell];
+    uint2* out = reinterpret_cast<uint2*>(p); p += 2 * (capS + 1);           // (column, f32 bits); 8-byte aligned by construction
+    uint64_t* inv_pairs = reinterpret_cast<uint64_t*>(p); p += 2 * (W + 1);  // (support idx << 32 | class)
+    uint32_t* order = p; p += M + 1;       // molecule indices sorted by label
+    uint32_t* cls_first = p; p += M + 1;   // class -> position in `order` of its first molecule
+    uint32_t* cls_cnt = p; p += M + 1;
+    uint32_t* cls_woff = p; p += M + 2;    // class -> offset of its EM label in cls_w
+    uint32_t* cls_w = p; p += W + 1;       // EM labels (slots)
+    uint32_t* cls_sidx = p; p += W + 1;    // ... as support indices
+    float* inv = reinterpret_cast<float*>(p); p += M + 1;
+    uint32_t* support = p; p += capS + 1;
+    uint32_t* sib1 = p; p += capS + 1;
+    uint32_t* sib2 = p; p += capS + 1;
+    uint32_t* ucnt = p; p += capS + 1;
+    float* a_in = reinterpret_cast<float*>(p); p += capS + 1;
+    float* a_out = reinterpret_cast<float*>(p); p += capS + 1;
+    uint32_t* slot_off = p; p += capS + 2;
+
+    if (M == 0) {  // no multi-label class: the counts are the single-label counts (em.rs:339-341, 499-514)
+        for (uint32_t i = threadIdx.x; i < nU; i += kEmNT) out[i] = make_uint2(U[i].x, __float_as_uint((float)U[i].y));
+        if (threadIdx.x == 0) out_nnz[cell] = nU;
+        return;
+    }
+    auto lab_gt = [&](uint32_t a, uint32_t b) {  // lexicographic a > b on the gene-level labels
+        const uint32_t oa = ld[2 * a], na = ld[2 * a + 1], ob = ld[2 * b], nb = ld[2 * b + 1];
+        const uint32_t nm = na < nb ? na : nb;
+        for (uint32_t i = 0; i < nm; ++i) {
+            const uint32_t x = lw[oa + i], y = lw[ob + i];
+            if (x != y) return x > y;
+        }
+        return na > nb;
+    };
+    auto lab_ne = [&](uint32_t a, uint32_t b) { return lab_gt(a, b) || lab_gt(b, a); };
+    // 1. classes = runs of equal labels in lexicographic order
+    for (uint32_t i = threadIdx.x; i < M; i += kEmNT) order[i] = i;
+    __syncthreads();
+    bitonic_sort_by<kEmNT>(order, M, lab_gt);
+    uint32_t K = 0;
+    for (uint32_t base = 0; base < M; base += kEmNT) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t h = (i < M) && (i == 0 || lab_ne(order[i], order[i - 1]));
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<kEmNT>(h, s_ws, tot);
+        if (h) cls_first[K + ex] = i;
+        K += tot;
+    }
+    __syncthreads();
+    // 2. EM label of each class: length, then contents
+    auto em_label = [&](uint32_t c, uint32_t* dst) -> uint32_t {  // returns the length; writes when dst != null
+        const uint32_t mol = order[cls_first[c]];
+        const uint32_t o = ld[2 * mol], n = ld[2 * mol + 1];
+        uint32_t w = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t gn = lw[o + i];
+            uint32_t idx = gn;
+            if (cfg.usa) {
+                idx = gn >> 1;
+                if (is_spliced(gn)) {
+                    if (i + 1 < n && same_gene(gn, lw[o + i + 1])) { idx += cfg.ao; ++i; }
+                } else idx += cfg.uo;
+            }
+            if (dst) dst[w] = idx;
+            ++w;
+        }
+        return w;
+    };
+    uint32_t Wc = 0;
+    for (uint32_t base = 0; base < K; base += kEmNT) {
+        const uint32_t c = base + threadIdx.x;
+        const uint32_t len = c < K ? em_label(c, nullptr) : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<kEmNT>(len, s_ws, tot);
+        if (c < K) {
+            cls_woff[c] = Wc + ex;
+            cls_cnt[c] = (c + 1 < K ? cls_first[c + 1] : M) - cls_first[c];
+        }
+        Wc += tot;
+    }
+    if (threadIdx.x == 0) cls_woff[K] = Wc;
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < K; c += kEmNT) em_label(c, cls_w + cls_woff[c]);
+    __syncthreads();
+    // 3. support = single-label columns + label slots (+ USA sibling statuses), sorted, distinct
+    uint32_t nC = 0;
+    {
+        const uint32_t nsrc = nU + Wc;
+        for (uint32_t i = threadIdx.x; i < nsrc; i += kEmNT) {
+            const uint32_t x = i < nU ? U[i].x : cls_w[i - nU];
+            support[i * mult] = x;
+            if (cfg.usa) {
+                uint32_t s1, s2;
+                if (x >= cfg.ao) { s1 = x - cfg.uo; s2 = x - cfg.ao; }
+                else if (x >= cfg.uo) { s1 = x + cfg.uo; s2 = x - cfg.uo; }
+                else { s1 = x + cfg.ao; s2 = x + cfg.uo; }
+                support[i * mult + 1] = s1;
+                support[i * mult + 2] = s2;
+            }
+        }
+        nC = nsrc * mult;
+    }
+    __syncthreads();
+    bitonic_sort<kEmNT>(support, nC);
+    uint32_t S = 0;
+    for (uint32_t base = 0; base < nC; base += kEmNT) {  // in-place unique: position S+ex <= i, so reads stay ahead of writes
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nC ? support[i] : 0u;
+        const uint32_t h = (i < nC) && (i == 0 || v != support[i - 1]);
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<kEmNT>(h, s_ws, tot);
+        __syncthreads();
+        if (h) support[S + ex] = v;
+        S += tot;
+        __syncthreads();
+    }
+    // NOTE on the USA support: the reference marks, for a label x, x and its siblings so that reads of
+    // get_abundance_for are reset every round (em.rs:351-356).  Marking both siblings for every status is a
+    // superset of em.rs:101-109 (which marks exactly the statuses get_abundance_for reads); the extra entries
+    // hold 0 throughout and never change a sum.
+    for (uint32_t s = threadIdx.x; s < S; s += kEmNT) {
+        ucnt[s] = 0;
+        sib1[s] = 0xFFFFFFFFu; sib2[s] = 0xFFFFFFFFu;
+        if (cfg.usa) {
+            const uint32_t x = support[s];
+            if (x >= cfg.ao) { sib1[s] = lower_bound_u32(support, S, x - cfg.uo); sib2[s] = lower_bound_u32(support, S, x - cfg.ao); }
+            else if (x >= cfg.uo) sib1[s] = lower_bound_u32(support, S, x + cfg.uo);
+            else sib1[s] = lower_bound_u32(support, S, x + cfg.ao);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nU; i += kEmNT) ucnt[lower_bound_u32(support, S, U[i].x)] = U[i].y;
+    for (uint32_t c = threadIdx.x; c < K; c += kEmNT)
+        for (uint32_t w = cls_woff[c]; w < cls_woff[c + 1]; ++w) {
+            const uint32_t s = lower_bound_u32(support, S, cls_w[w]);
+            cls_sidx[w] = s;
+            inv_pairs[w] = ((uint64_t)s << 32) | c;
+        }
+    __syncthreads();
+    // 4. inverted index: for every support entry the classes containing it, ascending class
+    bitonic_sort<kEmNT>(inv_pairs, Wc);
+    for (uint32_t s = threadIdx.x; s <= S; s += kEmNT) {  // slot_off[s] = first pair with support idx >= s
+        uint32_t lo = 0, hi = Wc;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)(inv_pairs[mid] >> 32) < s) lo = mid + 1; else hi = mid; }
+        slot_off[s] = lo;
+    }
+    // 5. init (em.rs:370-383, 519-531)
+    const float uni = 1.0f / (float)cfg.num_alphas;
+    for (uint32_t s = threadIdx.x; s < S; s += kEmNT) {
+        a_in[s] = cfg.init_uniform ? uni : ((float)ucnt[s] + 0.5f) * 1e-3f;
+        a_out[s] = 0.0f;
+    }
+    __syncthreads();
+    auto abundance = [&](uint32_t s) -> float {  // get_abundance_for, em.rs:167-187
+        if (!cfg.usa) return a_in[s];
+        if (sib2[s] != 0xFFFFFFFFu) return a_in[sib1[s]] + a_in[sib2[s]] + a_in[s];
+        return a_in[sib1[s]] + a_in[s];
+    };
+    uint32_t it = 0;
+    bool conv = true, last_round = false;
+    while (it < kMinIter || (it < kMaxIter && !conv) || last_round) {
+        // (A) per class: denominator in label order
+        for (uint32_t c = threadIdx.x; c < K; c += kEmNT) {
+            float denom = 0.0f;
+            for (uint32_t w = cls_woff[c]; w < cls_woff[c + 1]; ++w) denom += abundance(cls_sidx[w]);
+            inv[c] = denom > 0.0f ? (float)cls_cnt[c] / denom : -1.0f;
+        }
+        if (threadIdx.x == 0) s_flag[0] = 0;
+        __syncthreads();
+        // (B) per support entry: single-label count, then class contributions in class order
+        bool bad = false;
+        for (uint32_t s = threadIdx.x; s < S; s += kEmNT) {
+            float acc = 0.0f;
+            if (ucnt[s]) acc += (float)ucnt[s];
+            const float ab = abundance(s);
+            for (uint32_t q = slot_off[s]; q < slot_off[s + 1]; ++q) {
+                const float iv = inv[(uint32_t)inv_pairs[q]];
+                if (iv >= 0.0f) acc += ab * iv;
+            }
+            a_out[s] = acc;
+            if (acc > kAlphaCheckCutoff && fabsf(a_in[s] - acc) > kRelDiffTol) bad = true;
+        }
+        if (bad) s_flag[0] = 1;
+        __syncthreads();
+        conv = s_flag[0] == 0;
+        for (uint32_t s = threadIdx.x; s < S; s += kEmNT) { a_in[s] = a_out[s]; a_out[s] = 0.0f; }
+        ++it;
+        __syncthreads();
+        if (cfg.usa) {
+            if (last_round) break;
+            if (it >= kMinIter && conv) {
+                for (uint32_t s = threadIdx.x; s < S; s += kEmNT) if (a_in[s] < kMinOutputAlpha) a_in[s] = 0.0f;
+                last_round = true;
+                __syncthreads();
+            }
+        }
+    }
+    // 6. floor and emit the non-zero alphas in column order
+    uint32_t nout = 0;
+    for (uint32_t base = 0; base < S; base += kEmNT) {
+        const uint32_t s = base + threadIdx.x;
+        float v = s < S ? a_in[s] : 0.0f;
+        if (v < kMinOutputAlpha) v = 0.0f;
+        const uint32_t h = v > 0.0f;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<kEmNT>(h, s_ws, tot);
+        if (h) out[nout + ex] = make_uint2(support[s], __float_as_uint(v));
+        nout += tot;
+    }
+    if (threadIdx.x == 0) out_nnz[cell] = nout;
+}
+
+// EM output pairs -> final CSR
+__global__ __launch_bounds__(256) void k_compact_em(uint32_t n_cells, const uint64_t* __restrict__ em_off,
+                                                   const uint32_t* __restrict__ scratch, const uint32_t* __restrict__ nnz,
+                                                   const uint64_t* __restrict__ cell_ptr, uint32_t* __restrict__ gene,
+                                                   float* __restrict__ val) {
+    const uint32_t cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (cell >= n_cells) return;
+    const uint2* src = reinterpret_cast<const uint2*>(scratch + em_off[cell]);
+    const uint32_t n = nnz[cell];
+    const uint64_t o = cell_ptr[cell];
+    for (uint32_t i = lane_id(); i < n; i += 64) {
+        const uint2 p = src[i];
+        gene[o + i] = p.x;
+        val[o + i] = __uint_as_float(p.y);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1285,19 +1657,52 @@ static ResolveCfg make_rc(const ResolveArgs& a) {
 void launch_resolve(hipStream_t s, const ResolveArgs& a) {
     if (!a.n_buckets) return;
     ResolveCfg rc = make_rc(a);
+    LabArea la{a.lab, a.lab_cnt};
     BucketDesc* desc = reinterpret_cast<BucketDesc*>(a.bucket_desc);
     AFQ_LAUNCH(k_bucket_desc, (a.n_buckets + 255) / 256, 256, s, a.meta, a.bucket_cell, a.cell_nkeys, a.cursor, a.n_buckets, desc);
     const uint32_t n_cols = a.n_buckets < kResolveCols ? a.n_buckets : kResolveCols;
     const uint32_t grid = n_cols * ((a.n_buckets + n_cols - 1) / n_cols);
-    AFQ_LAUNCH(k_resolve, grid, kResolveNT, s, desc, a.n_buckets, a.keys0, a.keys1, a.cell_ncols, a.nnz, a.ovf_list, a.st, rc);
+    if (a.lab)
+        AFQ_LAUNCH(k_resolve<true>, grid, kResolveNT, s, desc, a.n_buckets, a.keys0, a.keys1, a.cell_ncols, a.nnz, a.ovf_list, a.st, rc, la);
+    else
+        AFQ_LAUNCH(k_resolve<false>, grid, kResolveNT, s, desc, a.n_buckets, a.keys0, a.keys1, a.cell_ncols, a.nnz, a.ovf_list, a.st, rc, la);
 }
 
 void launch_resolve_big(hipStream_t s, const ResolveArgs& a) {
     if (!a.n_multi) return;
     ResolveCfg rc = make_rc(a);
+    LabArea la{a.lab, a.lab_cnt};
     BucketDesc* desc = reinterpret_cast<BucketDesc*>(a.bucket_desc);
-    AFQ_LAUNCH(k_resolve_mid, 256, kMidNT, s, desc, a.keys0, a.keys1, a.cell_ncols, a.nnz, a.ovf_list, a.st, rc);
-    AFQ_LAUNCH(k_resolve_big, 256, kBigNT, s, desc, a.meta, a.keys0, a.keys1, a.cell_ncols, a.ovf_list, a.st, rc);
+    AFQ_LAUNCH(k_resolve_mid, 256, kMidNT, s, desc, a.keys0, a.keys1, a.cell_ncols, a.nnz, a.ovf_list, a.st, rc, la);
+    AFQ_LAUNCH(k_resolve_big, 256, kBigNT, s, desc, a.meta, a.keys0, a.keys1, a.cell_ncols, a.ovf_list, a.st, rc, la);
+}
+
+// words of per-cell EM scratch for nU single-label columns, W label words, M ambiguous molecules
+uint64_t em_scratch_words(uint32_t nU, uint32_t W, uint32_t M, bool usa) {
+    const uint64_t capS = ((uint64_t)nU + W) * (usa ? 3u : 1u);
+    // mirrors the carve at the top of k_em
+    uint64_t w = 2 * (capS + 1)            // out
+                 + 2 * ((uint64_t)W + 1)   // inv_pairs
+                 + 3 * ((uint64_t)M + 1)   // order, cls_first, cls_cnt
+                 + ((uint64_t)M + 2)       // cls_woff
+                 + 2 * ((uint64_t)W + 1)   // cls_w, cls_sidx
+                 + ((uint64_t)M + 1)       // inv
+                 + 6 * (capS + 1)          // support, sib1, sib2, ucnt, a_in, a_out
+                 + (capS + 2);             // slot_off
+    return (w + 1) & ~1ull;  // keep slices 8-byte aligned
+}
+
+void launch_em(hipStream_t s, const ResolveArgs& a, uint32_t n_cells, const uint64_t* em_off, uint32_t* scratch,
+               uint32_t* out_nnz, uint32_t num_alphas, uint32_t init_uniform) {
+    if (!n_cells) return;
+    EmCfg cfg{a.usa, num_alphas, a.num_rows / 3, 2 * (a.num_rows / 3), init_uniform};
+    AFQ_LAUNCH(k_em, n_cells, kEmNT, s, a.meta, a.nnz, a.keys0, a.keys1, a.lab, a.lab_cnt, em_off, scratch, out_nnz, cfg);
+}
+
+void launch_compact_em(hipStream_t s, uint32_t n_cells, const uint64_t* em_off, const uint32_t* scratch, const uint32_t* nnz,
+                       const uint64_t* cell_ptr, uint32_t* gene, float* val) {
+    if (!n_cells) return;
+    AFQ_LAUNCH(k_compact_em, (n_cells + 3) / 4, 256, s, n_cells, em_off, scratch, nnz, cell_ptr, gene, val);
 }
 
 size_t bucket_desc_bytes() { return sizeof(BucketDesc); }

@@ -492,6 +492,26 @@ static void eqc_to_idx(const GeneEqc& eqc, IdxEq& q) {
     }
 }
 
+// Canonical class order for the EM's f32 accumulation.  The reference walks a HashMap
+// (em.rs:464; cell_data is filled in hash order, utils.rs:865) so its order is unpinnable;
+// this restatement fixes: every single-label class first (ascending label), then the
+// multi-label classes in lexicographic order of their gene-level labels (the order the
+// caller built them in).  Integer adds first, fractional ones after, per output index.
+static void canonical_em_order(IdxEq& q) {
+    const size_t K = q.count.size();
+    std::vector<u32> ord;
+    for (u32 c = 0; c < K; ++c) if (q.start[c + 1] - q.start[c] == 1) ord.push_back(c);
+    std::stable_sort(ord.begin(), ord.end(), [&](u32 a, u32 b) { return q.labels[q.start[a]] < q.labels[q.start[b]]; });
+    for (u32 c = 0; c < K; ++c) if (q.start[c + 1] - q.start[c] != 1) ord.push_back(c);
+    IdxEq r; r.start.push_back(0);
+    for (u32 c : ord) {
+        r.labels.insert(r.labels.end(), q.labels.begin() + q.start[c], q.labels.begin() + q.start[c + 1]);
+        r.start.push_back((u32)r.labels.size());
+        r.count.push_back(q.count[c]);
+    }
+    q = std::move(r);
+}
+
 // ---------------------------------------------------------------------------
 // EM, src/em.rs
 constexpr float MIN_OUTPUT_ALPHA = 0.01f, ALPHA_CHECK_CUTOFF = 1e-2f, REL_DIFF_TOLERANCE = 1e-2f;
@@ -525,8 +545,9 @@ static void em_update(const IdxEq& q, const float* ain, float* aout, bool usa, u
 
 // em_optimize, src/em.rs:487-582 (dense over num_alphas)
 static void em_optimize_dense(const GeneEqc& eqc, u32 num_alphas, bool only_unique, bool init_uniform,
-                              std::vector<float>& alphas, u32* iters_out) {
+                              std::vector<float>& alphas, u32* iters_out, bool canon = false) {
     IdxEq q; eqc_to_idx(eqc, q);
+    if (canon) canonical_em_order(q);
     std::vector<float> ain(num_alphas, 0.0f), aout(num_alphas, 0.0f);
     for (size_t c = 0; c + 1 < q.start.size(); ++c)
         if (q.start[c + 1] - q.start[c] == 1) ain[q.labels[q.start[c]]] += (float)q.count[c];
@@ -665,8 +686,9 @@ static int quant_cell(const afq_config& cfg, const u32* t2g, u32 ref_count, cons
         if (usa && only_unique) extract_counts(eqc, cfg.num_rows, counts);
         else if (usa) {
             IdxEq q; extract_usa_eqmap(eqc, cfg.num_rows, q);
+            canonical_em_order(q);
             em_optimize_subset(q, cfg.num_rows, false, init_uni, true, uo, ao, counts, &o.em_iters);
-        } else em_optimize_dense(eqc, cfg.num_genes, only_unique, init_uni, counts, &o.em_iters);
+        } else em_optimize_dense(eqc, cfg.num_genes, only_unique, init_uni, counts, &o.em_iters, true);
     };
     u32 res = cfg.resolution;
     if (res == AFQ_RES_CR_LIKE || res == AFQ_RES_CR_LIKE_EM) {

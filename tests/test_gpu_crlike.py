@@ -243,3 +243,35 @@ def test_atac_dedup(oracle):
     for g, w in zip(got, want):
         assert np.array_equal(g, w)
     assert (66000 & 0xFFFF) in got[4][int(got[0][-2]):].tolist()
+
+
+@pytest.mark.parametrize("usa", [False, True])
+@pytest.mark.parametrize("init_uniform", [False, True])
+def test_crlike_em(oracle, usa, init_uniform):
+    """cr-like-em: winner-take-all ties kept as gene-level classes + per-cell EM (em.rs).  The device runs the
+    same f32 operation sequence as the oracle (canonical class order), so the comparison is bitwise; the
+    north-star tolerance for EM resolutions is 1e-4 relative."""
+    sizes = [20000, 6000, 1500, 700, 260, 250, 120, 99, 40, 3]
+    s = synth.synth(14, sizes, num_genes=300, usa=usa, dup=0.5, zipf=0.5, cross=0.7, max_extra_na=6)
+    b, off = s.encode()
+    cfg = cfg_for(s, "cr-like-em", em_init_uniform=init_uniform)
+    got, want, _ = run_both(oracle, cfg, s.tid_to_gid, b, off)
+    assert np.array_equal(got.cell_ptr, want.cell_ptr) and np.array_equal(got.gene, want.gene)
+    np.testing.assert_allclose(got.val, want.val, rtol=1e-4, atol=0)
+    assert_same_result(got, want)  # and in fact bit-identical
+    # the EM really ran: some counts are fractional, and mass is above plain cr-like
+    plain = oracle.quant(cfg_for(s, "cr-like"), s.tid_to_gid, b, off)
+    assert (got.val != np.round(got.val)).any() and got.val.sum() > plain.val.sum()
+
+
+def test_crlike_em_overflow_paths(oracle):
+    """EM labels emitted from the mid-size and global-scratch bucket paths."""
+    for n_same in (1500, 12000):
+        s = synth.synth(15, [n_same + 3000, 500], num_genes=120, dup=0.3, cross=0.8)
+        umi = s.umi.copy()
+        umi[:n_same] = 0x00F0F0
+        s.umi = umi
+        b, off = s.encode()
+        got, want, st = run_both(oracle, cfg_for(s, "cr-like-em"), s.tid_to_gid, b, off)
+        assert st["n_overflow_buckets"] >= 1
+        assert_same_result(got, want)
