@@ -41,9 +41,9 @@ struct DevBuf {
     template <class T> T* as() { return reinterpret_cast<T*>(p); }
 };
 
-enum KernelId { K_GATHER = 0, K_DECODE_PAR, K_DECODE, K_HIST, K_BSCAN, K_SCATTER, K_RESOLVE, K_RESOLVE_BIG, K_CELL_HIST, K_EM, K_COMPACT, K_COUNT };
+enum KernelId { K_GATHER = 0, K_DECODE_PAR, K_DECODE, K_HIST, K_BSCAN, K_SCATTER, K_RESOLVE, K_RESOLVE_BIG, K_PUG, K_CELL_HIST, K_EM, K_COMPACT, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"k_gather_headers", "k_decode_par", "k_decode", "k_hist", "k_bucket_scan", "k_scatter",
-                                           "k_resolve", "k_resolve_big", "k_cell_hist", "k_em", "k_compact"};
+                                           "k_resolve", "k_resolve_big", "k_pug_cell", "k_cell_hist", "k_em", "k_compact"};
 
 struct TimedLaunch { int id; hipEvent_t a, b; };
 
@@ -127,7 +127,8 @@ struct afq_ctx {
     size_t n_bytes = 0;
     // per-range device state
     DevBuf d_meta, d_keys0, d_keys1, d_cell_nkeys, d_bucket_cnt, d_bucket_cell, d_multi_cells, d_tile_prefix, d_ncols,
-        d_nnz, d_ovf, d_status, d_bc, d_cell_ptr, d_gene, d_val, d_chunk_off, d_hdr, d_chk, d_slab_prefix, d_slab_cell, d_cell_bc, d_bdesc, d_lab, d_lab_cnt, d_em_off, d_em_scratch, d_em_nnz;
+        d_nnz, d_ovf, d_status, d_bc, d_cell_ptr, d_gene, d_val, d_chunk_off, d_hdr, d_chk, d_slab_prefix, d_slab_cell, d_cell_bc, d_bdesc, d_lab, d_lab_cnt, d_em_off, d_em_scratch, d_em_nnz,
+        d_pug_cells, d_rd_off, d_rd_h, d_rd_u, d_rd_o, d_pug_scr_off, d_pug_scratch, d_epool, d_epool_cur, d_alt, d_hist_cells;
     ResolveArgs last_ra{};
     bool all_aligned = true;  // every chunk offset is a multiple of 4
     ResultPool* pool = nullptr;
@@ -199,8 +200,11 @@ bool valid_width(uint32_t w) { return w == 1 || w == 2 || w == 4 || w == 8; }
 // What the device path implements today.  Anything else is refused loudly.
 int check_supported(afq_ctx* c) {
     const afq_config& g = c->cfg;
-    if (g.resolution != AFQ_RES_CR_LIKE && g.resolution != AFQ_RES_TRIVIAL && g.resolution != AFQ_RES_CR_LIKE_EM)
-        return fail(c, AFQ_ERR_UNSUPPORTED, "device path implements resolutions cr-like, cr-like-em and trivial only (so far)");
+    if (g.resolution == AFQ_RES_PARSIMONY_GENE || g.resolution == AFQ_RES_PARSIMONY_GENE_EM)
+        return fail(c, AFQ_ERR_UNSUPPORTED, "device path does not implement the gene-level parsimony variants yet");
+    if ((g.resolution == AFQ_RES_PARSIMONY || g.resolution == AFQ_RES_PARSIMONY_EM) &&
+        !decode_par_supported(g.bc_bytes, g.umi_bytes))
+        return fail(c, AFQ_ERR_UNSUPPORTED, "device parsimony needs 4- or 8-byte barcode/UMI fields");
     if (g.usa_mode && g.sa_model != AFQ_SA_WINNER_TAKE_ALL)
         return fail(c, AFQ_ERR_UNSUPPORTED, "sa_model prefer-ambig is not implemented on the device path");
     return 0;
@@ -229,7 +233,10 @@ int plan_ranges(afq_ctx* c) {
         if (fixed > nbytes || ((nbytes - fixed) & 3))
             return fail(c, AFQ_ERR_BAD_INPUT, "cell " + std::to_string(i) + ": chunk nbytes does not match its records");
         const uint64_t n_ref = (nbytes - fixed) / 4;
-        double need = (c->cfg.resolution == AFQ_RES_CR_LIKE_EM ? 24.0 + 40.0 * (c->cfg.usa_mode ? 3 : 1) : 16.0) * (double)n_ref + 128.0;
+        const bool em_res = c->cfg.resolution == AFQ_RES_CR_LIKE_EM || c->cfg.resolution == AFQ_RES_PARSIMONY_EM;
+        const bool pug_res = c->cfg.resolution == AFQ_RES_PARSIMONY || c->cfg.resolution == AFQ_RES_PARSIMONY_EM;
+        double need = (em_res ? 24.0 + 40.0 * (c->cfg.usa_mode ? 3 : 1) : 16.0) * (double)n_ref + 128.0;
+        if (pug_res) need += 4.0 * (double)pug_scratch_words(nrec) + 20.0 * nrec + 64.0 * nrec;
         if (n_ref > kBucketTarget) need += 16.0 * (double)(n_ref / kBucketTarget + 1);
         if (need > budget) return fail(c, AFQ_ERR_OOM, "cell " + std::to_string(i) + " alone exceeds device memory");
         if (used + need > budget) { c->ranges.push_back({c0, i}); c0 = i; used = 0; }
@@ -245,7 +252,9 @@ int run_range(afq_ctx* c, Range r) {
     const uint32_t H = hdr_bytes(g);
     const uint32_t n = r.c1 - r.c0;
     c->meta.resize(n);
-    std::vector<uint32_t> multi, tile_prefix, bucket_cell, slab_prefix;
+    std::vector<uint32_t> multi, tile_prefix, bucket_cell, slab_prefix, pug_cells, hist_cells;
+    std::vector<uint64_t> rd_off(n, 0), pug_scr;
+    uint64_t n_pug_reads = 0, pug_words = 0;
     const bool par = c->all_aligned && decode_par_supported(g.bc_bytes, g.umi_bytes);
     uint64_t key_off = 0, n_buckets = 0, n_tiles = 0, n_slabs = 0;
     if (par) slab_prefix.reserve(n + 1);
@@ -273,7 +282,10 @@ int run_range(afq_ctx* c, Range r) {
         const bool tiny = g.sa_model == AFQ_SA_WINNER_TAKE_ALL && m.nrec < g.small_thresh;
         m.mode = tiny ? kModeCrLike
                  : g.resolution == AFQ_RES_TRIVIAL ? kModeTrivial
-                 : g.resolution == AFQ_RES_CR_LIKE_EM ? kModeCrLikeEm : kModeCrLike;
+                 : g.resolution == AFQ_RES_CR_LIKE_EM ? kModeCrLikeEm
+                 : g.resolution == AFQ_RES_PARSIMONY ? kModePug
+                 : g.resolution == AFQ_RES_PARSIMONY_EM ? kModePugEm : kModeCrLike;
+        if (mode_is_pug(m.mode)) { pug_cells.push_back(i); rd_off[i] = n_pug_reads; n_pug_reads += m.nrec; pug_scr.push_back(pug_words); pug_words += pug_scratch_words(m.nrec); }
         nrec_total += m.nrec;
         if (par) {
             slab_prefix.push_back((uint32_t)n_slabs);
@@ -306,7 +318,25 @@ int run_range(afq_ctx* c, Range r) {
     HIP_TRY(c, c->d_nnz.ensure(4ull * n));
     HIP_TRY(c, c->d_ovf.ensure(sizeof(OverflowEnt) * std::max<uint64_t>(n_buckets, 1)));
     HIP_TRY(c, c->d_bdesc.ensure(bucket_desc_bytes() * std::max<uint64_t>(n_buckets, 1)));
-    const bool em = g.resolution == AFQ_RES_CR_LIKE_EM;
+    const bool em = g.resolution == AFQ_RES_CR_LIKE_EM || g.resolution == AFQ_RES_PARSIMONY_EM;
+    const uint32_t n_pug = (uint32_t)pug_cells.size();
+    if (n_pug && !par) return fail(c, AFQ_ERR_UNSUPPORTED, "device parsimony needs dword-aligned chunk offsets");
+    hist_cells = multi;
+    hist_cells.insert(hist_cells.end(), pug_cells.begin(), pug_cells.end());
+    const uint64_t epool_words = 16 * n_pug_reads + (1ull << 22);
+    if (n_pug) {
+        HIP_TRY(c, c->d_pug_cells.ensure(4ull * n_pug));
+        HIP_TRY(c, c->d_rd_off.ensure(8ull * n));
+        HIP_TRY(c, c->d_rd_h.ensure(8 * n_pug_reads + 8));
+        HIP_TRY(c, c->d_rd_u.ensure(8 * n_pug_reads + 8));
+        HIP_TRY(c, c->d_rd_o.ensure(4 * n_pug_reads + 8));
+        HIP_TRY(c, c->d_pug_scr_off.ensure(8ull * n_pug));
+        HIP_TRY(c, c->d_pug_scratch.ensure(4 * pug_words + 64));
+        HIP_TRY(c, c->d_epool.ensure(4 * epool_words));
+        HIP_TRY(c, c->d_epool_cur.ensure(8));
+    }
+    HIP_TRY(c, c->d_alt.ensure(4ull * n));
+    HIP_TRY(c, c->d_hist_cells.ensure(4ull * std::max<size_t>(hist_cells.size(), 1)));
     if (em) {
         HIP_TRY(c, c->d_lab.ensure(8 * key_off));
         HIP_TRY(c, c->d_lab_cnt.ensure(8ull * n));
@@ -336,6 +366,15 @@ int run_range(afq_ctx* c, Range r) {
     HIP_TRY(c, hipMemsetAsync(c->d_nnz.p, 0, 4ull * n, s));
     HIP_TRY(c, hipMemsetAsync(c->d_ncols.p, 0, 4ull * n, s));
     if (em) HIP_TRY(c, hipMemsetAsync(c->d_lab_cnt.p, 0, 8ull * n, s));
+    HIP_TRY(c, hipMemsetAsync(c->d_alt.p, 0, 4ull * n, s));
+    if (!hist_cells.empty())
+        HIP_TRY(c, hipMemcpyAsync(c->d_hist_cells.p, hist_cells.data(), 4ull * hist_cells.size(), hipMemcpyHostToDevice, s));
+    if (n_pug) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_pug_cells.p, pug_cells.data(), 4ull * n_pug, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(c->d_rd_off.p, rd_off.data(), 8ull * n, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(c->d_pug_scr_off.p, pug_scr.data(), 8ull * n_pug, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemsetAsync(c->d_epool_cur.p, 0, 8, s));
+    }
     HIP_TRY(c, hipMemsetAsync(c->d_status.p, 0, sizeof(DevStatus), s));
     HIP_TRY(c, hipMemsetAsync(c->d_bc.p, 0, 8ull * n, s));
     // the host copies above are sourced from stack/vector memory: make sure they are consumed
@@ -346,7 +385,8 @@ int run_range(afq_ctx* c, Range r) {
                   c->d_bc.as<uint64_t>(), c->d_status.as<DevStatus>(),
                   par ? c->d_chk.as<CellChk>() : nullptr, c->d_slab_prefix.as<uint32_t>(), c->d_slab_cell.as<uint32_t>(),
                   c->d_cell_bc.as<uint64_t>(),
-                  (uint32_t)n_slabs};
+                  (uint32_t)n_slabs,
+                  PugOut{c->d_rd_h.as<uint64_t>(), c->d_rd_u.as<uint64_t>(), c->d_rd_o.as<uint32_t>(), c->d_rd_off.as<uint64_t>()}};
     if (par) {
         ScopedTimer t(c, K_DECODE_PAR);
         if (launch_decode_par(s, da, g.bc_bytes, g.umi_bytes)) return fail(c, AFQ_ERR_INVALID_ARG, "bad field widths");
@@ -360,17 +400,28 @@ int run_range(afq_ctx* c, Range r) {
                    c->d_keys0.as<uint64_t>(), c->d_keys1.as<uint64_t>(), c->d_ncols.as<uint32_t>(),
                    c->d_nnz.as<uint32_t>(), c->d_ovf.as<OverflowEnt>(), c->d_bdesc.p, em ? c->d_lab.as<uint32_t>() : nullptr,
                    em ? c->d_lab_cnt.as<uint32_t>() : nullptr, c->d_status.as<DevStatus>(),
-                   (uint32_t)n_buckets, n_multi, (uint32_t)n_tiles, g.usa_mode, g.num_rows};
+                   (uint32_t)n_buckets, n_multi, (uint32_t)n_tiles, c->d_hist_cells.as<uint32_t>(),
+                   (uint32_t)hist_cells.size(), g.usa_mode, g.num_rows};
     if (n_multi) {
         { ScopedTimer t(c, K_HIST); launch_hist(s, ra); }
         { ScopedTimer t(c, K_BSCAN); launch_bucket_scan(s, ra); }
         { ScopedTimer t(c, K_SCATTER); launch_scatter(s, ra); }
     }
     { ScopedTimer t(c, K_RESOLVE); launch_resolve(s, ra); }
-    if (n_multi) {
-        { ScopedTimer t(c, K_RESOLVE_BIG); launch_resolve_big(s, ra); }
-        { ScopedTimer t(c, K_CELL_HIST); launch_cell_hist(s, ra); }
+    if (n_multi) { ScopedTimer t(c, K_RESOLVE_BIG); launch_resolve_big(s, ra); }
+    if (n_pug) {
+        PugCellArgs pa{};
+        pa.bytes = c->d_bytes; pa.meta = ra.meta; pa.pug_cells = c->d_pug_cells.as<uint32_t>(); pa.cell_nkeys = ra.cell_nkeys;
+        pa.rd = da.pug; pa.scr_off = c->d_pug_scr_off.as<uint64_t>(); pa.scratch = c->d_pug_scratch.as<uint32_t>();
+        pa.epool = c->d_epool.as<uint32_t>(); pa.epool_cursor = c->d_epool_cur.as<unsigned long long>(); pa.epool_cap = epool_words;
+        pa.t2g = c->d_t2g.as<uint32_t>(); pa.keys0 = ra.keys0; pa.cell_ncols = ra.cell_ncols; pa.lab = ra.lab; pa.lab_cnt = ra.lab_cnt;
+        pa.alt = c->d_alt.as<uint32_t>(); pa.st = ra.st; pa.ref_count = c->ref_count; pa.num_genes = g.num_genes; pa.usa = g.usa_mode;
+        pa.num_rows = g.num_rows; pa.em = em ? 1u : 0u; pa.exact_umi = g.pug_exact_umi; pa.large_thresh = g.large_graph_thresh;
+        pa.hw = 1 + g.bc_bytes / 4 + g.umi_bytes / 4; pa.umi_pairs = std::min<uint32_t>(g.umi_bytes * 4, 22);
+        ScopedTimer t(c, K_PUG);
+        launch_pug(s, pa, n_pug);
     }
+    if (!hist_cells.empty()) { ScopedTimer t(c, K_CELL_HIST); launch_cell_hist(s, ra); }
     HIP_TRY(c, hipGetLastError());
     c->last_ra = ra;
     c->cur = r;
@@ -398,6 +449,9 @@ int finish_range(afq_ctx* c) {
             case kErrGeneRange: return fail(c, AFQ_ERR_BAD_INPUT, cell + "gene id out of range of num_genes");
             case kErrUmiWide: return fail(c, AFQ_ERR_UNSUPPORTED, cell + "UMI wider than 22 nt is not supported");
             case kErrSlotRange: return fail(c, AFQ_ERR_BAD_INPUT, cell + "resolved column >= num_rows");
+            case kErrLabelHash: return fail(c, AFQ_ERR_UNSUPPORTED, cell + "two ref lists share a 64-bit label hash");
+            case kErrPugLimit: return fail(c, AFQ_ERR_UNSUPPORTED, cell + "a device-side PUG limit was exceeded (2^20 vertices, 4096-vertex component, 64 genes per molecule, or a vertex with an empty label)");
+            case kErrPugPool: return fail(c, AFQ_ERR_OOM, cell + "PUG edge pool exhausted");
             default: return fail(c, AFQ_ERR_HIP, cell + "unknown device error");
         }
     }
@@ -406,7 +460,9 @@ int finish_range(afq_ctx* c) {
     c->stats.n_fallback_cells += st.n_fallback;
     std::vector<uint32_t> nnz(n);
     std::vector<uint64_t> bc(n), ptr(n + 1);
-    const bool em = c->cfg.resolution == AFQ_RES_CR_LIKE_EM;
+    const bool em = c->cfg.resolution == AFQ_RES_CR_LIKE_EM || c->cfg.resolution == AFQ_RES_PARSIMONY_EM;
+    std::vector<uint32_t> alt(n);
+    HIP_TRY(c, hipMemcpy(alt.data(), c->d_alt.p, 4ull * n, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(nnz.data(), c->d_nnz.p, 4ull * n, hipMemcpyDeviceToHost));
     if (em) {
         // per-cell EM (src/em.rs) over the single-label counts + the ambiguous molecules' labels
@@ -462,6 +518,7 @@ int finish_range(afq_ctx* c) {
         // used_fast_path, src/quant.rs:794-797 (same counts as the general cr-like route)
         if (g.sa_model == AFQ_SA_WINNER_TAKE_ALL && nrec < g.small_thresh) f |= AFQ_CELL_TINY_PATH;
         if (nnz[i] == 0) f |= AFQ_CELL_EMPTY;
+        if (alt[i]) f |= AFQ_CELL_ALT_RES;
         R.cell_ptr.push_back(g0 + ptr[i + 1]);
         R.bc.push_back(bc[i]);
         R.nrec.push_back(nrec);
@@ -551,7 +608,8 @@ void afq_destroy(afq_ctx* c) {
                       &c->d_bucket_cnt, &c->d_bucket_cell, &c->d_multi_cells, &c->d_tile_prefix, &c->d_ncols, &c->d_nnz,
                       &c->d_ovf, &c->d_status, &c->d_bc, &c->d_cell_ptr, &c->d_gene, &c->d_val, &c->d_chunk_off, &c->d_hdr,
                       &c->d_chk, &c->d_slab_prefix, &c->d_slab_cell, &c->d_cell_bc, &c->d_bdesc, &c->d_lab, &c->d_lab_cnt, &c->d_em_off,
-                      &c->d_em_scratch, &c->d_em_nnz};
+                      &c->d_em_scratch, &c->d_em_nnz, &c->d_pug_cells, &c->d_rd_off, &c->d_rd_h, &c->d_rd_u, &c->d_rd_o, &c->d_pug_scr_off,
+                      &c->d_pug_scratch, &c->d_epool, &c->d_epool_cur, &c->d_alt, &c->d_hist_cells};
     for (auto b : bufs) b->release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->res) pool_put(c->res);

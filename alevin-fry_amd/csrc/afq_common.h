@@ -61,6 +61,8 @@ struct CellChk {
 
 constexpr uint32_t kModeCrLike = 0;   // winner-take-all (cr-like; every tiny cell, src/quant.rs:794-845)
 constexpr uint32_t kModeCrLikeEm = 2; // cr-like-em: ties are kept as gene-level classes and resolved by the EM (quant.rs:882-924)
+constexpr uint32_t kModePug = 3;       // parsimony / parsimony-em: PUG + monochromatic cover (pugutils.rs:65-391, 989-1331)
+constexpr uint32_t kModePugEm = 4;
 constexpr uint32_t kModeTrivial = 1;  // `trivial`: single-gene reads only, distinct UMIs per gene (src/pugutils.rs:852-911)
 
 constexpr uint32_t kSlabWords = 256;  // dwords one wave of k_decode_par covers (1 KiB)
@@ -72,5 +74,25 @@ constexpr uint32_t kErrGeneRange = 4;    // gene id >= 2^kGeneBits or >= num_gen
 constexpr uint32_t kErrSlotRange = 5;    // resolved slot >= num_rows
 
 struct OverflowEnt { uint32_t bucket; uint32_t n; };
+
+constexpr uint32_t kErrLabelHash = 6;    // two different ref lists with the same 64-bit label hash
+constexpr uint32_t kErrPugLimit = 7;     // a PUG size limit of the device path was exceeded
+constexpr uint32_t kErrPugPool = 8;      // edge pool exhausted
+
+__host__ __device__ inline bool mode_is_pug(uint32_t m) { return m == kModePug || m == kModePugEm; }
+
+// Per-read output of the decode for PUG cells: 64-bit hash of the read's ref-list label, its UMI, and the
+// dword offset of the record inside its chunk (= appearance order, and where the label lives).
+struct PugOut {
+    uint64_t* h;
+    uint64_t* u;
+    uint32_t* o;
+    const uint64_t* rd_off;  // [n_cells] first read slot of a PUG cell
+};
+__host__ __device__ inline uint64_t label_hash_init(uint32_t na) { return 0x9E3779B97F4A7C15ull ^ na; }
+__host__ __device__ inline uint64_t label_hash_step(uint64_t h, uint32_t t) {
+    h = (h ^ t) * 0xBF58476D1CE4E5B9ull;
+    return h ^ (h >> 29);
+}
 
 }  // namespace afq

@@ -26,6 +26,7 @@ struct DecodeArgs {
     uint32_t* slab_cell;          // [n_slabs] device-filled: cell of each slab
     uint64_t* cell_bc;            // [n_cells] device-filled: barcode words of each cell's first record
     uint32_t n_slabs;
+    PugOut pug;                   // PUG cells: per-read outputs (null pointers when the batch has none)
 };
 
 struct ResolveArgs {
@@ -47,6 +48,8 @@ struct ResolveArgs {
     uint32_t n_buckets;
     uint32_t n_multi;
     uint32_t n_tiles;
+    const uint32_t* hist_cells;  // cells counted by k_cell_hist: multi-bucket cells + PUG cells
+    uint32_t n_hist;
     uint32_t usa;
     uint32_t num_rows;
 };
@@ -73,6 +76,31 @@ void launch_resolve_big(hipStream_t s, const ResolveArgs& a);
 void launch_cell_hist(hipStream_t s, const ResolveArgs& a);
 void launch_compact(hipStream_t s, const CellMeta* meta, uint32_t n_cells, const uint64_t* keys0, const uint64_t* keys1,
                     const uint32_t* nnz, const uint64_t* cell_ptr, uint32_t* gene, float* val);
+
+// ---- parsimony (afq_pug.hip) ----
+struct PugCellArgs {
+    const uint8_t* bytes;
+    const CellMeta* meta;
+    const uint32_t* pug_cells;
+    const uint32_t* cell_nkeys;   // reads the decode emitted per cell
+    PugOut rd;
+    const uint64_t* scr_off;      // [n_pug] word offset of the cell's scratch slice
+    uint32_t* scratch;
+    uint32_t* epool;              // edge pool (u32 words) + multi-word adjacency rows
+    unsigned long long* epool_cursor;
+    unsigned long long epool_cap;
+    const uint32_t* t2g;
+    uint64_t* keys0;
+    uint32_t* cell_ncols;
+    uint32_t* lab;
+    uint32_t* lab_cnt;
+    uint32_t* alt;                // [n_cells] set to 1 when a component took the cr-like fallback
+    DevStatus* st;
+    uint32_t ref_count, num_genes, usa, num_rows, em, exact_umi, large_thresh, hw, umi_pairs;
+};
+
+void launch_pug(hipStream_t s, const PugCellArgs& a, uint32_t n_pug);
+uint64_t pug_scratch_words(uint32_t nrec);
 
 constexpr uint32_t kScatterTileHost = 2048;  // keys per histogram/scatter tile
 

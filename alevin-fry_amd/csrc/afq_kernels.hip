@@ -20,135 +20,9 @@
 
 #include "afq_common.h"
 #include "afq_kernels.h"
+#include "afq_prims.h"
 
 namespace afq {
-
-// ---------------------------------------------------------------------------
-// wave / block primitives (wave = 64 lanes)
-__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
-
-__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t& total) {
-    uint32_t x = v;
-    const uint32_t lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t y = __shfl_up(x, d);
-        if (lane >= (uint32_t)d) x += y;
-    }
-    total = __shfl(x, 63);
-    return x - v;
-}
-
-// exclusive scan over the NT threads of a block; ws needs NT/64 words of LDS.
-template <int NT>
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* ws, uint32_t& total) {
-    constexpr int NW = NT / 64;
-    uint32_t wtot;
-    uint32_t ex = wave_excl_scan(v, wtot);
-    const uint32_t w = threadIdx.x >> 6;
-    __syncthreads();  // ws may still be read from a previous call
-    if (lane_id() == 63) ws[w] = wtot;
-    __syncthreads();
-    uint32_t pre = 0, tot = 0;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-        uint32_t t = ws[i];
-        if ((uint32_t)i < w) pre += t;
-        tot += t;
-    }
-    total = tot;
-    return pre + ex;
-}
-
-// Normalised bitonic network: every comparator is ascending, so positions >= n
-// behave as +inf without being stored and any n (not only powers of two) sorts
-// in place.  Barrier after every stage.
-template <int NT, typename T>
-__device__ __forceinline__ void bitonic_sort(T* a, uint32_t n) {
-    if (n < 2) return;
-    uint32_t np2 = 1;
-    while (np2 < n) np2 <<= 1;
-    const uint32_t half = np2 >> 1;
-    for (uint32_t k = 2; k <= np2; k <<= 1) {
-        const uint32_t hk = k >> 1;
-        // mirror stage
-        for (uint32_t i = threadIdx.x; i < half; i += NT) {
-            uint32_t blk = i / hk, o = i - blk * hk;
-            uint32_t l = blk * k + o, r = blk * k + (k - 1 - o);
-            if (r < n) {
-                T x = a[l], y = a[r];
-                if (x > y) { a[l] = y; a[r] = x; }
-            }
-        }
-        __syncthreads();
-        for (uint32_t j = hk >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = threadIdx.x; i < half; i += NT) {
-                uint32_t l = ((i & ~(j - 1)) << 1) | (i & (j - 1));
-                uint32_t r = l + j;
-                if (r < n) {
-                    T x = a[l], y = a[r];
-                    if (x > y) { a[l] = y; a[r] = x; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
-template <int NT, typename T, typename Gt>
-__device__ __forceinline__ void bitonic_sort_by(T* a, uint32_t n, Gt gt) {
-    if (n < 2) return;
-    uint32_t np2 = 1;
-    while (np2 < n) np2 <<= 1;
-    const uint32_t half = np2 >> 1;
-    for (uint32_t k = 2; k <= np2; k <<= 1) {
-        const uint32_t hk = k >> 1;
-        for (uint32_t i = threadIdx.x; i < half; i += NT) {
-            uint32_t blk = i / hk, o = i - blk * hk;
-            uint32_t l = blk * k + o, r = blk * k + (k - 1 - o);
-            if (r < n) {
-                T x = a[l], y = a[r];
-                if (gt(x, y)) { a[l] = y; a[r] = x; }
-            }
-        }
-        __syncthreads();
-        for (uint32_t j = hk >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = threadIdx.x; i < half; i += NT) {
-                uint32_t l = ((i & ~(j - 1)) << 1) | (i & (j - 1));
-                uint32_t r = l + j;
-                if (r < n) {
-                    T x = a[l], y = a[r];
-                    if (gt(x, y)) { a[l] = y; a[r] = x; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// little-endian field loads at arbitrary byte alignment
-template <int W>
-__device__ __forceinline__ uint64_t ld_le(const uint8_t* p) {
-    if constexpr (W == 4) {
-        if ((((uintptr_t)p) & 3) == 0) return *(const uint32_t*)p;
-    }
-    if constexpr (W == 8) {
-        if ((((uintptr_t)p) & 7) == 0) return *(const uint64_t*)p;
-    }
-    uint64_t v = 0;
-#pragma unroll
-    for (int i = 0; i < W; ++i) v |= (uint64_t)p[i] << (8 * i);
-    return v;
-}
-__device__ __forceinline__ uint32_t ld_u32(const uint8_t* p, bool aligned) {
-    if (aligned) return *(const uint32_t*)p;
-    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
-}
-
-__device__ __forceinline__ void set_err(DevStatus* st, uint32_t code, uint32_t cell) {
-    if (atomicCAS(&st->err_code, 0u, code) == 0u) st->err_cell = cell;
-}
 
 // ---------------------------------------------------------------------------
 // chunk headers of device-resident input -> (nbytes, nrec) per cell
@@ -182,7 +56,7 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ byte
                                                uint32_t num_genes, uint64_t* __restrict__ keys0,
                                                uint32_t* __restrict__ cell_nkeys,
                                                uint64_t* __restrict__ bc_out, DevStatus* st,
-                                               const CellChk* __restrict__ chk) {
+                                               const CellChk* __restrict__ chk, PugOut pug) {
     constexpr uint32_t HDR = 4 + BW + UW;
     constexpr bool AL = (BW % 4 == 0) && (UW % 4 == 0);
     const uint32_t lane = lane_id();
@@ -244,9 +118,9 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ byte
         // lanes whose dword starts a record decode it
         const bool is_start = (mask >> lane) & 1ull;
         uint32_t g[8];
-        uint32_t k = 0, na = 0, kcnt = 0;
-        bool ovf = false;
-        uint64_t umi = 0;
+        uint32_t k = 0, na = 0, kcnt = 0, rec_dw = 0;
+        bool ovf = false, pug_rec = false;
+        uint64_t umi = 0, lhash = 0;
         const uint8_t* rp = nullptr;
         if (is_start && !bad) {
             const uint32_t sub = al_chunk ? 0u : (uint32_t)((sub0 >> lane) & 1ull) | ((uint32_t)((sub1 >> lane) & 1ull) << 1);
@@ -258,6 +132,17 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ byte
             if (UW == 8 && (umi >> kUmiBits)) { set_err(st, kErrUmiWide, cell); na = 0; }
             rp = rec + HDR;
             const bool ral = ((((uintptr_t)rp) & 3) == 0);
+            if (mode_is_pug(m.mode)) {  // PUG cells: one (label hash, umi, record offset) per read
+                lhash = label_hash_init(na);
+                for (uint32_t j = 0; j < na; ++j) {
+                    const uint32_t t = ld_u32(rp + 4 * j, ral) & 0x7FFFFFFFu;
+                    if (t >= ref_count) set_err(st, kErrRefRange, cell);
+                    lhash = label_hash_step(lhash, t);
+                }
+                rec_dw = (uint32_t)((roff - m.chunk_off) >> 2);
+                pug_rec = true;
+                na = 0;
+            }
             for (uint32_t j = 0; j < na; ++j) {
                 uint32_t t = ld_u32(rp + 4 * j, ral) & 0x7FFFFFFFu;
                 if (t >= ref_count) { set_err(st, kErrRefRange, cell); continue; }
@@ -292,9 +177,16 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ byte
             }
         }
         if (m.mode == kModeTrivial && kcnt != 1) kcnt = 0;  // multi-gene reads are discarded (pugutils.rs:870-891)
+        if (pug_rec) kcnt = 1;
         uint32_t tot;
         const uint32_t ex = wave_excl_scan(kcnt, tot);
-        if (kcnt) {
+        if (pug_rec) {
+            const uint32_t o0 = nk_total + ex;
+            if (o0 < m.nrec) {
+                const uint64_t slot = pug.rd_off[cell] + o0;
+                pug.h[slot] = lhash; pug.u[slot] = umi; pug.o[slot] = rec_dw;
+            } else bad = true;
+        } else if (kcnt) {
             const uint32_t o0 = nk_total + ex;
             uint64_t* dst = keys0 + m.key_off;
             if (o0 + kcnt <= m.n_ref) {
@@ -387,7 +279,8 @@ __global__ __launch_bounds__(256) void k_decode_par(const uint8_t* __restrict__ 
                                                    const uint32_t* __restrict__ t2g, uint32_t ref_count,
                                                    uint32_t num_genes, uint64_t* __restrict__ keys0,
                                                    uint32_t* __restrict__ cell_nkeys,
-                                                   uint64_t* __restrict__ bc_out, CellChk* __restrict__ chk) {
+                                                   uint64_t* __restrict__ bc_out, CellChk* __restrict__ chk,
+                                                   PugOut pug) {
     static_assert(BW % 4 == 0 && UW % 4 == 0, "aligned layouts only");
     constexpr uint32_t BWW = BW / 4, UWW = UW / 4, HW = 1 + BWW + UWW;
     __shared__ uint32_t s_stage[4][kStage];
@@ -530,7 +423,17 @@ __global__ __launch_bounds__(256) void k_decode_par(const uint8_t* __restrict__ 
             }
             // request the next slab's dwords while the gathers above are in flight
             if (!prefetched && same_next) { issue_slab_loads(s0 + kSlabWords); prefetched = true; }
-            if (act && na) {
+            const bool pug_rec = act && mode_is_pug(m.mode);
+            uint64_t lhash = 0;
+            if (pug_rec) {  // PUG cells: one (label hash, umi, record offset) per read
+                lhash = label_hash_init(na);
+                for (uint32_t j = 0; j < na; ++j) {
+                    const uint32_t t = refw(j);
+                    if (t >= ref_count) fail = true;
+                    lhash = label_hash_step(lhash, t);
+                }
+            }
+            if (act && na && !pug_rec) {
                 if (ok0) {
                     if (gid0 < num_genes) { g[0] = gid0; k = 1; } else fail = true;
                 }
@@ -568,15 +471,21 @@ __global__ __launch_bounds__(256) void k_decode_par(const uint8_t* __restrict__ 
                 }
             }
             if (m.mode == kModeTrivial && kcnt != 1) kcnt = 0;  // multi-gene reads are discarded (pugutils.rs:870-891)
+            if (pug_rec) kcnt = 1;
             uint32_t tot;
             const uint32_t ex = wave_excl_scan(kcnt, tot);
             uint32_t wbase = 0;
             if (tot) {
                 if (lane == 0) wbase = atomicAdd(&cell_nkeys[cur_cell], tot);
                 wbase = __builtin_amdgcn_readfirstlane(wbase);
-                if (wbase + tot > m.n_ref) { fail = true; kcnt = 0; }
+                if (wbase + tot > (mode_is_pug(m.mode) ? m.nrec : m.n_ref)) { fail = true; kcnt = 0; }
             }
-            if (kcnt) {
+            if (pug_rec) {
+                if (kcnt) {
+                    const uint64_t slot = pug.rd_off[cur_cell] + wbase + ex;
+                    pug.h[slot] = lhash; pug.u[slot] = umi; pug.o[slot] = i;
+                }
+            } else if (kcnt) {
                 uint64_t* dst = keys0 + m.key_off + wbase + ex;
                 if (!ovf) {
 #pragma unroll
@@ -646,7 +555,7 @@ __global__ __launch_bounds__(256) void k_hist(const uint32_t* __restrict__ multi
     tile_to_cell(tile_prefix, n_multi, blockIdx.x, s_b, ci, lt);
     const uint32_t cell = multi_cells[ci];
     const CellMeta m = meta[cell];
-    const uint32_t nk = cell_nkeys[cell];
+    const uint32_t nk = mode_is_pug(m.mode) ? 0u : cell_nkeys[cell];  // PUG cells emit reads, not keys
     const uint32_t t0 = lt * kTileKeys;
     if (t0 >= nk) return;
     const uint32_t t1 = min(nk, t0 + kTileKeys);
@@ -707,7 +616,7 @@ __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ mu
     tile_to_cell(tile_prefix, n_multi, blockIdx.x, s_b, ci, lt);
     const uint32_t cell = multi_cells[ci];
     const CellMeta m = meta[cell];
-    const uint32_t nk = cell_nkeys[cell];
+    const uint32_t nk = mode_is_pug(m.mode) ? 0u : cell_nkeys[cell];  // PUG cells emit reads, not keys
     const uint32_t t0 = lt * kTileKeys;
     if (t0 >= nk) return;
     const uint32_t t1 = min(nk, t0 + kTileKeys);
@@ -981,10 +890,10 @@ __global__ void k_bucket_desc(const CellMeta* __restrict__ meta, const uint32_t*
     const CellMeta m = meta[cell];
     BucketDesc d;
     d.cell = cell; d.out_off = m.key_off; d.n_ref = m.n_ref;
-    if (m.lg_nb == 0) { d.mode_single = m.mode | 0x100u; d.src_off = m.key_off; d.n = cell_nkeys[cell]; }
+    if (m.lg_nb == 0) { d.mode_single = m.mode | 0x100u; d.src_off = m.key_off; d.n = mode_is_pug(m.mode) ? 0u : cell_nkeys[cell]; }
     else {
         const uint32_t beg = (b == m.bucket_base) ? 0u : cursor[b - 1];
-        d.mode_single = m.mode; d.src_off = m.key_off + beg; d.n = cursor[b] - beg;
+        d.mode_single = m.mode; d.src_off = m.key_off + beg; d.n = mode_is_pug(m.mode) ? 0u : cursor[b] - beg;
     }
     desc[b] = d;
 }
@@ -1258,11 +1167,6 @@ constexpr int kEmNT = 256;
 constexpr float kMinOutputAlpha = 0.01f, kAlphaCheckCutoff = 1e-2f, kRelDiffTol = 1e-2f;
 constexpr uint32_t kMinIter = 2, kMaxIter = 100;
 
-__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* a, uint32_t n, uint32_t x) {
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[mid] < x) lo = mid + 1; else hi = mid; }
-    return lo;
-}
 
 __global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta, const uint32_t* __restrict__ nnz_unique,
                                              const uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
@@ -1274,7 +1178,7 @@ __global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta,
     const uint32_t cell = blockIdx.x;
     const CellMeta m = meta[cell];
     const uint32_t nU = nnz_unique[cell];
-    const uint2* U = reinterpret_cast<const uint2*>((m.lg_nb ? keys1 : keys0) + m.key_off);
+    const uint2* U = reinterpret_cast<const uint2*>(((m.lg_nb || mode_is_pug(m.mode)) ? keys1 : keys0) + m.key_off);
     const uint32_t W = lab_cnt[2 * cell], M = lab_cnt[2 * cell + 1];
     const uint32_t* lw = lab + 2 * m.key_off;
     const uint32_t* ld = lw + m.n_ref + 1;
@@ -1518,7 +1422,7 @@ __global__ __launch_bounds__(256) void k_compact(const CellMeta* __restrict__ me
     const uint32_t cell = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (cell >= n_cells) return;
     const CellMeta m = meta[cell];
-    const uint2* src = reinterpret_cast<const uint2*>((m.lg_nb ? keys1 : keys0) + m.key_off);
+    const uint2* src = reinterpret_cast<const uint2*>(((m.lg_nb || mode_is_pug(m.mode)) ? keys1 : keys0) + m.key_off);
     const uint32_t n = nnz[cell];
     const uint64_t o = cell_ptr[cell];
     for (uint32_t i = lane_id(); i < n; i += 64) {
@@ -1595,7 +1499,7 @@ void launch_gather_headers(hipStream_t s, const uint8_t* bytes, size_t n_bytes, 
 template <int BW, int UW>
 static void launch_decode_t(hipStream_t s, const DecodeArgs& a) {
     AFQ_LAUNCH((k_decode<BW, UW>), (a.n_cells + 3) / 4, 256, s, a.bytes, a.n_bytes, a.meta, a.n_cells, a.t2g,
-               a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out, a.st, a.chk);
+               a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out, a.st, a.chk, a.pug);
 }
 
 int launch_decode(hipStream_t s, const DecodeArgs& a, uint32_t bw, uint32_t uw) {
@@ -1618,7 +1522,7 @@ static void launch_decode_par_t(hipStream_t s, const DecodeArgs& a) {
     const uint32_t n_waves = n_cols * ((n_groups + n_cols - 1) / n_cols);
     AFQ_LAUNCH((k_decode_par<BW, UW>), (n_waves + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix, a.slab_cell,
                a.cell_bc, a.n_slabs, a.t2g, a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out,
-               const_cast<CellChk*>(a.chk));
+               const_cast<CellChk*>(a.chk), a.pug);
 }
 
 bool decode_par_supported(uint32_t bw, uint32_t uw) { return (bw == 4 || bw == 8) && (uw == 4 || uw == 8); }
@@ -1716,9 +1620,9 @@ void launch_atac_dedup(hipStream_t s, uint32_t n_cells, const uint32_t* ref, con
 }
 
 void launch_cell_hist(hipStream_t s, const ResolveArgs& a) {
-    if (!a.n_multi) return;
+    if (!a.n_hist) return;
     ResolveCfg rc = make_rc(a);
-    AFQ_LAUNCH(k_cell_hist, a.n_multi, kHistNT, s, a.multi_cells, a.meta, a.keys0, a.keys1, a.cell_ncols, a.nnz, rc);
+    AFQ_LAUNCH(k_cell_hist, a.n_hist, kHistNT, s, a.hist_cells, a.meta, a.keys0, a.keys1, a.cell_ncols, a.nnz, rc);
 }
 
 void launch_compact(hipStream_t s, const CellMeta* meta, uint32_t n_cells, const uint64_t* keys0, const uint64_t* keys1,

@@ -1,0 +1,676 @@
+// afq_pug.hip — parsimony resolution on gfx950: per-cell equivalence-class map, parsimonious UMI
+// graph (PUG), weakly connected components and the greedy monochromatic-arborescence cover.
+//
+// Replaces, for one cell (reference paths relative to /root/reference):
+//   EqMap::init_from_chunk               src/eq_class.rs:823-1036   (classes by exact ref list, (umi,count) per class)
+//   extract_graph / has_edge             src/pugutils.rs:65-267, src/utils.rs:389-393
+//   weakly_connected_components          src/pugutils.rs:278-301
+//   collapse_vertices                    src/pugutils.rs:308-391
+//   get_num_molecules (+large component) src/pugutils.rs:989-1331, 916-982
+// Semantics: SURVEY.md appendix B.3-B.5.  Tie-break between equal-size arborescences = ascending
+// vertex id in the reference's vertex numbering (class-major, class id = first appearance, UMI
+// rank inside the class) - the oracle's canonical order; the reference itself walks a hash set.
+//
+// One 1024-thread workgroup owns one cell and runs every phase out of a per-cell slice of global
+// scratch (L2 resident), so nothing here needs a device-scope atomic except the edge-pool bump.
+// Most components are singletons (lane-parallel), small ones (<= 64 vertices) are covered by one
+// wave with the adjacency as one 64-bit mask per lane, larger ones (<= 4096) by the workgroup with
+// multi-word masks (one mask word per lane, candidate vertices spread over the waves).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "afq_common.h"
+#include "afq_kernels.h"
+#include "afq_prims.h"
+
+namespace afq {
+
+constexpr int kPugNT = 1024;
+constexpr uint32_t kVidBits = 20;                 // vertices per cell < 2^20
+constexpr uint32_t kMaxGenesPerLabel = 64;        // distinct genes of one molecule the device path carries
+constexpr uint32_t kMaxBigComp = 4096;            // vertices of a component the multi-word cover handles
+
+struct SortRec {
+    uint64_t h, u;
+    uint32_t o, pad;
+};
+__device__ __forceinline__ bool rec_gt(const SortRec& a, const SortRec& b) {
+    return a.h > b.h || (a.h == b.h && (a.u > b.u || (a.u == b.u && a.o > b.o)));
+}
+
+struct PugCtx {
+    // cell
+    const uint32_t* W;       // chunk dwords
+    uint32_t HW;             // header dwords of a record
+    const uint32_t* t2g;
+    uint32_t ref_count, num_genes;
+    // config
+    uint32_t usa, num_rows, uo, ao, em, exact_umi, large_thresh, umi_pairs;
+    // outputs
+    uint32_t* cols;          // the cell's column list (u32), positions from s_ncols
+    uint32_t* labw;          // EM label words
+    uint32_t* labd;          // EM label descriptors (off,len)
+    uint32_t cols_cap, lab_cap;
+    uint32_t* s_cnt;         // LDS: [0] ncols, [1] label words, [2] label count, [3] error flag
+    DevStatus* st;
+    uint32_t cell;
+};
+
+struct Lab {
+    const uint32_t* p;
+    uint32_t n;
+};
+__device__ __forceinline__ Lab rec_label(const PugCtx& c, uint32_t rec_dw) {
+    Lab l;
+    l.n = c.W[rec_dw];
+    l.p = c.W + rec_dw + c.HW;
+    return l;
+}
+__device__ __forceinline__ bool lab_contains(const Lab& l, uint32_t t) {  // refs ascending (pugutils.rs:375)
+    uint32_t lo = 0, hi = l.n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint32_t v = l.p[mid] & 0x7FFFFFFFu;
+        if (v < t) lo = mid + 1; else hi = mid;
+    }
+    return lo < l.n && (l.p[lo] & 0x7FFFFFFFu) == t;
+}
+__device__ __forceinline__ bool lab_overlap(const Lab& a, const Lab& b) {  // share >= 1 ref (pugutils.rs:187-204)
+    uint32_t i = 0, j = 0;
+    while (i < a.n && j < b.n) {
+        const uint32_t x = a.p[i] & 0x7FFFFFFFu, y = b.p[j] & 0x7FFFFFFFu;
+        if (x == y) return true;
+        if (x < y) ++i; else ++j;
+    }
+    return false;
+}
+__device__ __forceinline__ bool lab_equal(const Lab& a, const Lab& b) {
+    if (a.n != b.n) return false;
+    for (uint32_t i = 0; i < a.n; ++i) if ((a.p[i] ^ b.p[i]) & 0x7FFFFFFFu) return false;
+    return true;
+}
+
+// sorted distinct gene ids of a list of refs (pugutils.rs:1213-1225, 1296-1298); returns the count
+// or 0xFFFFFFFF when more than kMaxGenesPerLabel distinct genes turn up.
+template <typename GetRef>
+__device__ __forceinline__ uint32_t genes_of(const PugCtx& c, uint32_t n, GetRef&& ref, uint32_t* g) {
+    uint32_t k = 0;
+    for (uint32_t j = 0; j < n; ++j) {
+        const uint32_t gid = c.t2g[ref(j)];
+        uint32_t p = 0;
+        while (p < k && g[p] < gid) ++p;
+        if (p < k && g[p] == gid) continue;
+        if (k == kMaxGenesPerLabel) return 0xFFFFFFFFu;
+        for (uint32_t q = k; q > p; --q) g[q] = g[q - 1];
+        g[p] = gid;
+        ++k;
+    }
+    return k;
+}
+
+// One resolved molecule with gene label g[0..ng): a column, a gene-level class for the EM, or nothing.
+// (quant.rs:974-1024 -> extract_counts utils.rs:688-753 / em_optimize(only_unique) em.rs:499-514 / EM)
+__device__ __forceinline__ void emit_molecule(const PugCtx& c, const uint32_t* g, uint32_t ng) {
+    if (ng == 0xFFFFFFFFu) { c.s_cnt[3] = kErrPugLimit; return; }
+    if (ng == 0) return;
+    uint32_t col = 0xFFFFFFFFu;
+    if (c.em) {
+        if (ng == 1) col = !c.usa ? g[0] : ((g[0] & 1u) == 0 ? (g[0] >> 1) : c.uo + (g[0] >> 1));
+        else if (c.usa && ng == 2 && ((g[0] ^ g[1]) & ~1u) == 0) col = c.ao + (g[0] >> 1);
+        else {
+            const uint32_t off = atomicAdd(&c.s_cnt[1], ng), di = atomicAdd(&c.s_cnt[2], 1u);
+            if (off + ng > c.lab_cap || 2 * (di + 1) > c.lab_cap) { c.s_cnt[3] = kErrPugLimit; return; }
+            for (uint32_t i = 0; i < ng; ++i) c.labw[off + i] = g[i];
+            c.labd[2 * di] = off; c.labd[2 * di + 1] = ng;
+            return;
+        }
+    } else if (!c.usa) {
+        if (ng == 1) col = g[0];
+    } else if (ng == 1) {
+        col = (g[0] & 1u) == 0 ? (g[0] >> 1) : c.uo + (g[0] >> 1);
+    } else if (ng == 2) {
+        const bool s1 = (g[0] & 1u) == 0, s2 = (g[1] & 1u) == 0;
+        if (((g[0] ^ g[1]) & ~1u) == 0) col = c.ao + (g[0] >> 1);
+        else if (s1 && !s2) col = g[0] >> 1;
+        else if (!s1 && s2) col = g[1] >> 1;
+    } else if (ng <= 10) {
+        uint32_t nsp = 0, sidx = 0;
+        for (uint32_t i = 0; i < ng; ++i) if ((g[i] & 1u) == 0) { if (nsp == 0) sidx = i; ++nsp; }
+        if (nsp == 1) {
+            const uint32_t sg = g[sidx];
+            col = (sidx + 1 < ng && ((sg ^ g[sidx + 1]) & ~1u) == 0) ? c.ao + (sg >> 1) : (sg >> 1);
+        }
+    }
+    if (col == 0xFFFFFFFFu) return;
+    if (col >= c.num_rows) { c.s_cnt[3] = kErrSlotRange; return; }
+    const uint32_t p = atomicAdd(&c.s_cnt[0], 1u);
+    if (p >= c.cols_cap) { c.s_cnt[3] = kErrPugLimit; return; }
+    c.cols[p] = col;
+}
+
+__device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { lo |= __shfl_xor(lo, d); hi |= __shfl_xor(hi, d); }
+    return ((uint64_t)hi << 32) | lo;
+}
+
+
+__global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
+    __shared__ uint32_t s_ws[kPugNT / 64];
+    __shared__ uint32_t s_cnt[4];
+    __shared__ uint32_t s_flag[2];
+    __shared__ unsigned long long s_ebase;
+    __shared__ uint64_t s_mask[4][64];   // multi-word cover: UC, best, scratch
+    __shared__ uint32_t s_bestv[kPugNT / 64], s_bestsz[kPugNT / 64];
+    const uint32_t cell = A.pug_cells[blockIdx.x];
+    const CellMeta m = A.meta[cell];
+    const uint32_t R = m.nrec;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    if (tid < 4) s_cnt[tid] = 0;
+    if (tid < 2) s_flag[tid] = 0;
+    __syncthreads();
+    PugCtx C;
+    C.W = reinterpret_cast<const uint32_t*>(A.bytes + m.chunk_off);
+    C.HW = A.hw; C.t2g = A.t2g; C.ref_count = A.ref_count; C.num_genes = A.num_genes;
+    C.usa = A.usa; C.num_rows = A.num_rows; C.uo = A.num_rows / 3; C.ao = 2 * (A.num_rows / 3); C.em = A.em;
+    C.exact_umi = A.exact_umi; C.large_thresh = A.large_thresh; C.umi_pairs = A.umi_pairs;
+    C.cols = reinterpret_cast<uint32_t*>(A.keys0 + m.key_off);
+    C.cols_cap = 2 * m.n_ref + 2;
+    C.labw = A.lab ? A.lab + 2 * m.key_off : nullptr;
+    C.labd = A.lab ? C.labw + m.n_ref + 1 : nullptr;
+    C.lab_cap = m.n_ref + 1;
+    C.s_cnt = s_cnt; C.st = A.st; C.cell = cell;
+    if (A.cell_nkeys[cell] != R) { if (tid == 0) set_err(A.st, kErrRecordWalk, cell); return; }
+    if (R >= (1u << kVidBits)) { if (tid == 0) set_err(A.st, kErrPugLimit, cell); return; }
+
+    // ---- scratch carve (u32 words; see pug_scratch_words) ----
+    uint32_t* p = A.scratch + A.scr_off[blockIdx.x];
+    SortRec* sr = reinterpret_cast<SortRec*>(p); p += 6 * (size_t)R;           // slab A
+    uint64_t* v_umi = reinterpret_cast<uint64_t*>(p); p += 2 * (size_t)R;      // slab B (hash order)
+    uint32_t* v_cnt = p; p += R;
+    uint32_t* v_cls = p; p += R;
+    uint64_t* vv_umi = reinterpret_cast<uint64_t*>(p); p += 2 * (size_t)R;     // slab C (by vertex id)
+    uint32_t* vv_cnt = p; p += R;
+    uint32_t* vv_rec = p; p += R;          // a record (dword offset) carrying the vertex's label
+    uint32_t* vv_cls = p; p += R;
+    uint32_t* c_vstart = p; p += R + 1;    // slab D (classes, hash order)
+    uint32_t* c_minoff = p; p += R;
+    uint32_t* c_rep = p; p += R;
+    uint32_t* c_base = p; p += R;
+    uint32_t* c_order = p; p += R;
+    uint32_t* deg = p; p += R + 2;         // out-degree, then edge offsets
+    uint32_t* comp_start = p; p += R + 2;
+    // aliases into slab A once the sorted reads are consumed
+    uint64_t* us = reinterpret_cast<uint64_t*>(sr);                    // 2R : (umi << 20 | vid), sorted
+    uint64_t* comp_sorted = us + R;                                    // 2R : (root << 20 | vid), sorted
+    uint32_t* wlab = reinterpret_cast<uint32_t*>(comp_sorted + R);     // R  : WCC label
+    uint32_t* local_idx = wlab + R;                                    // R  : vid -> index inside its component
+
+    // ---- 1. reads sorted by (label hash, umi, offset) ----
+    {
+        const uint64_t base = A.rd.rd_off[cell];
+        for (uint32_t i = tid; i < R; i += kPugNT) {
+            SortRec r; r.h = A.rd.h[base + i]; r.u = A.rd.u[base + i]; r.o = A.rd.o[base + i]; r.pad = 0;
+            sr[i] = r;
+        }
+    }
+    __syncthreads();
+    bitonic_sort_by<kPugNT>(sr, R, [](const SortRec& a, const SortRec& b) { return rec_gt(a, b); });
+    // ---- 2. vertices = distinct (label, umi); classes = distinct labels ----
+    uint32_t V = 0, K = 0;
+    for (uint32_t base = 0; base < R; base += kPugNT) {
+        const uint32_t i = base + tid;
+        bool vh = false, ch = false;
+        if (i < R) {
+            ch = i == 0 || sr[i].h != sr[i - 1].h;
+            vh = ch || sr[i].u != sr[i - 1].u;
+        }
+        uint32_t tv, tc;
+        const uint32_t ev = block_excl_scan<kPugNT>(vh, s_ws, tv);
+        const uint32_t ec = block_excl_scan<kPugNT>(ch, s_ws, tc);
+        if (i < R) {
+            const uint32_t vi = V + ev;  // index of the vertex whose first read this is (when vh)
+            if (vh) {
+                v_umi[vi] = sr[i].u;
+                v_cls[vi] = K + ec - (ch ? 0 : 1);
+                v_cnt[vi] = 0;
+            }
+            if (ch) {
+                const uint32_t ki = K + ec;
+                c_vstart[ki] = vi;
+                c_rep[ki] = sr[i].o;        // smallest offset of the class's first UMI; min over the class below
+                c_minoff[ki] = 0xFFFFFFFFu;
+            }
+        }
+        V += tv; K += tc;
+    }
+    if (tid == 0) c_vstart[K] = V;
+    __syncthreads();
+    // per-read pass: vertex multiplicities, class first appearance, hash-collision check.
+    {
+        // vertices are in read order, so the vertex of read i = (#vertex heads <= i) - 1: a second scan.
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < R; base += kPugNT) {
+            const uint32_t i = base + tid;
+            bool vh = false;
+            if (i < R) vh = i == 0 || sr[i].h != sr[i - 1].h || sr[i].u != sr[i - 1].u;
+            uint32_t tv;
+            const uint32_t ev = block_excl_scan<kPugNT>(vh, s_ws, tv);
+            if (i < R) {
+                const uint32_t vi = carry + ev + (vh ? 1 : 0) - 1;
+                atomicAdd(&v_cnt[vi], 1u);
+                const uint32_t k = v_cls[vi];
+                atomicMin(&c_minoff[k], sr[i].o);
+                if (!lab_equal(rec_label(C, sr[i].o), rec_label(C, c_rep[k]))) s_cnt[3] = kErrLabelHash;
+            }
+            carry += tv;
+        }
+    }
+    __syncthreads();
+    if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], cell); return; }
+    // ---- 3. class ids by first appearance; reference vertex ids ----
+    for (uint32_t k = tid; k < K; k += kPugNT) c_order[k] = k;
+    __syncthreads();
+    bitonic_sort_by<kPugNT>(c_order, K, [&](uint32_t a, uint32_t b) { return c_minoff[a] > c_minoff[b]; });
+    {
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < K; base += kPugNT) {
+            const uint32_t r = base + tid;
+            const uint32_t k = r < K ? c_order[r] : 0u;
+            const uint32_t nv = r < K ? c_vstart[k + 1] - c_vstart[k] : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<kPugNT>(nv, s_ws, tot);
+            if (r < K) c_base[k] = carry + ex;
+            carry += tot;
+        }
+    }
+    __syncthreads();
+    for (uint32_t j = tid; j < V; j += kPugNT) {
+        const uint32_t k = v_cls[j];
+        const uint32_t vid = c_base[k] + (j - c_vstart[k]);
+        vv_umi[vid] = v_umi[j]; vv_cnt[vid] = v_cnt[j]; vv_rec[vid] = c_rep[k]; vv_cls[vid] = k;
+    }
+    __syncthreads();
+    // ---- 4. vertices sorted by UMI for neighbour probing ----
+    for (uint32_t v = tid; v < V; v += kPugNT) {
+        if (vv_umi[v] >> (64 - kVidBits)) s_cnt[3] = kErrPugLimit;
+        us[v] = (vv_umi[v] << kVidBits) | v;
+    }
+    __syncthreads();
+    if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], cell); return; }
+    bitonic_sort<kPugNT>(us, V);
+    // out-neighbours of x: vertices y != x with overlapping labels and UMI distance 0, or distance 1 and
+    // count(y) < 2*count(x)  (has_edge, pugutils.rs:76-99: X->Y unless cy >= 2cx)
+    auto for_each_out = [&](uint32_t x, auto&& f) {
+        const uint64_t ux = vv_umi[x];
+        const uint32_t cx = vv_cnt[x], kx = vv_cls[x];
+        const Lab lx = rec_label(C, vv_rec[x]);
+        const uint32_t nprobe = C.exact_umi ? 1u : 1u + 3u * C.umi_pairs;
+        for (uint32_t pr = 0; pr < nprobe; ++pr) {
+            uint64_t pu = ux;
+            if (pr) {
+                const uint32_t b = (pr - 1) / 3, d = (pr - 1) % 3 + 1;
+                pu = ux ^ ((uint64_t)d << (2 * b));
+            }
+            if (pu >> (64 - kVidBits)) continue;
+            const uint64_t key = pu << kVidBits;
+            uint32_t lo = 0, hi = V;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (us[mid] < key) lo = mid + 1; else hi = mid; }
+            for (; lo < V && (us[lo] >> kVidBits) == pu; ++lo) {
+                const uint32_t y = (uint32_t)us[lo] & ((1u << kVidBits) - 1);
+                if (y == x) continue;
+                if (pr && !(vv_cnt[y] < 2 * cx)) continue;
+                if (vv_cls[y] != kx && !lab_overlap(lx, rec_label(C, vv_rec[y]))) continue;
+                f(y);
+            }
+        }
+    };
+    for (uint32_t x = tid; x < V; x += kPugNT) {
+        uint32_t d = 0;
+        for_each_out(x, [&](uint32_t) { ++d; });
+        deg[x] = d;
+    }
+    __syncthreads();
+    uint32_t E = 0;
+    for (uint32_t base = 0; base < V; base += kPugNT) {
+        const uint32_t x = base + tid;
+        const uint32_t d = x < V ? deg[x] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<kPugNT>(d, s_ws, tot);
+        __syncthreads();
+        if (x < V) deg[x] = E + ex;
+        E += tot;
+    }
+    if (tid == 0) {
+        deg[V] = E;
+        s_ebase = atomicAdd(A.epool_cursor, (unsigned long long)E);
+    }
+    __syncthreads();
+    if (s_ebase + E > A.epool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, cell); return; }
+    uint32_t* edges = A.epool + s_ebase;
+    for (uint32_t x = tid; x < V; x += kPugNT) {
+        uint32_t o = deg[x];
+        for_each_out(x, [&](uint32_t y) { edges[o++] = y; });
+    }
+    __syncthreads();
+    // ---- 5. weakly connected components: min-label propagation + pointer jumping ----
+    for (uint32_t v = tid; v < V; v += kPugNT) wlab[v] = v;
+    __syncthreads();
+    for (;;) {
+        if (tid == 0) s_flag[0] = 0;
+        __syncthreads();
+        bool ch = false;
+        for (uint32_t x = tid; x < V; x += kPugNT) {
+            for (uint32_t e = deg[x]; e < deg[x + 1]; ++e) {
+                const uint32_t y = edges[e];
+                const uint32_t a = wlab[x], b = wlab[y];
+                if (a < b) { atomicMin(&wlab[y], a); ch = true; }
+                else if (b < a) { atomicMin(&wlab[x], b); ch = true; }
+            }
+        }
+        if (ch) s_flag[0] = 1;
+        __syncthreads();
+        for (int it = 0; it < 4; ++it) {
+            for (uint32_t v = tid; v < V; v += kPugNT) { const uint32_t l = wlab[v]; const uint32_t ll = wlab[l]; if (ll < l) wlab[v] = ll; }
+            __syncthreads();
+        }
+        if (!s_flag[0]) break;
+    }
+    // a label may still point at a non-root after the last sweep; chase it
+    for (uint32_t v = tid; v < V; v += kPugNT) { uint32_t l = wlab[v]; while (wlab[l] != l) l = wlab[l]; comp_sorted[v] = ((uint64_t)l << kVidBits) | v; }
+    __syncthreads();
+    bitonic_sort<kPugNT>(comp_sorted, V);
+    uint32_t NC = 0;
+    for (uint32_t base = 0; base < V; base += kPugNT) {
+        const uint32_t i = base + tid;
+        const bool h = i < V && (i == 0 || (comp_sorted[i] >> kVidBits) != (comp_sorted[i - 1] >> kVidBits));
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<kPugNT>(h, s_ws, tot);
+        if (h) comp_start[NC + ex] = i;
+        NC += tot;
+    }
+    if (tid == 0) comp_start[NC] = V;
+    __syncthreads();
+    for (uint32_t c = tid; c < NC; c += kPugNT)  // vid -> position inside its component (components are short on average)
+        if (comp_start[c + 1] - comp_start[c] <= 64)
+            for (uint32_t i = comp_start[c]; i < comp_start[c + 1]; ++i) local_idx[(uint32_t)comp_sorted[i] & ((1u << kVidBits) - 1)] = i - comp_start[c];
+    __syncthreads();
+    auto vid_at = [&](uint32_t i) { return (uint32_t)comp_sorted[i] & ((1u << kVidBits) - 1); };
+
+    // ---- 6a. single-vertex components: the label's genes (pugutils.rs:1262-1322) ----
+    for (uint32_t c = tid; c < NC; c += kPugNT) {
+        if (comp_start[c + 1] - comp_start[c] != 1) continue;
+        const Lab l = rec_label(C, vv_rec[vid_at(comp_start[c])]);
+        uint32_t g[kMaxGenesPerLabel];
+        const uint32_t ng = genes_of(C, l.n, [&](uint32_t j) { return l.p[j] & 0x7FFFFFFFu; }, g);
+        emit_molecule(C, g, ng);
+    }
+    // ---- 6b. components of 2..64 vertices: one wave each, adjacency = one 64-bit mask per lane ----
+    for (uint32_t c = wv; c < NC; c += kPugNT / 64) {
+        const uint32_t c0 = comp_start[c], n = comp_start[c + 1] - c0;
+        if (n < 2 || n > 64 || n > C.large_thresh) continue;
+        const bool act = lane < n;
+        const uint32_t myv = act ? vid_at(c0 + lane) : 0u;
+        const Lab myl = act ? rec_label(C, vv_rec[myv]) : Lab{nullptr, 0};
+        uint64_t adj = 0;
+        if (act)
+            for (uint32_t e = deg[myv]; e < deg[myv + 1]; ++e) adj |= 1ull << local_idx[edges[e]];
+        uint64_t UC = n == 64 ? ~0ull : ((1ull << n) - 1);
+        while (UC) {
+            const uint32_t remaining = (uint32_t)__popcll(UC);
+            uint64_t best = 0;
+            uint32_t best_sz = 0;
+            for (uint64_t it = UC; it; it &= it - 1) {   // ascending vertex id
+                const uint32_t v = (uint32_t)__builtin_ctzll(it);
+                const uint32_t vrec = __shfl(act ? vv_rec[myv] : 0u, (int)v);
+                const Lab lv = rec_label(C, vrec);
+                uint64_t mv = 0;
+                uint32_t mv_sz = 0;
+                for (uint32_t j = 0; j < lv.n; ++j) {
+                    const uint32_t t = lv.p[j] & 0x7FFFFFFFu;
+                    const uint64_t At = __ballot(act && ((UC >> lane) & 1ull) && lab_contains(myl, t));
+                    uint64_t Rm = 1ull << v, F = Rm;
+                    while (F) {
+                        const uint64_t N = wave_or64(((F >> lane) & 1ull) ? adj : 0ull);
+                        F = N & At & ~Rm;
+                        Rm |= F;
+                    }
+                    const uint32_t sz = (uint32_t)__popcll(Rm);
+                    if (sz > mv_sz) { mv_sz = sz; mv = Rm; }
+                }
+                if (mv_sz > best_sz) { best_sz = mv_sz; best = mv; }
+                if (mv_sz == remaining) break;
+            }
+            if (best == 0) { if (lane == 0) s_cnt[3] = kErrPugLimit; break; }  // vertex with an empty label
+            // transcripts common to every vertex of the arborescence (pugutils.rs:1161-1188) -> genes
+            const uint32_t fv = (uint32_t)__builtin_ctzll(best);
+            const uint32_t frec = __shfl(act ? vv_rec[myv] : 0u, (int)fv);
+            const Lab lf = rec_label(C, frec);
+            uint32_t g[kMaxGenesPerLabel];
+            uint32_t ng = 0;
+            bool wide = false;
+            for (uint32_t j = 0; j < lf.n; ++j) {
+                const uint32_t t = lf.p[j] & 0x7FFFFFFFu;
+                const uint64_t has = __ballot(act && ((best >> lane) & 1ull) && lab_contains(myl, t));
+                if (has != best) continue;
+                if (lane == 0) {
+                    const uint32_t gid = C.t2g[t];
+                    uint32_t q = 0;
+                    while (q < ng && g[q] < gid) ++q;
+                    if (!(q < ng && g[q] == gid)) {
+                        if (ng == kMaxGenesPerLabel) wide = true;
+                        else { for (uint32_t r = ng; r > q; --r) g[r] = g[r - 1]; g[q] = gid; ++ng; }
+                    }
+                }
+            }
+            if (lane == 0) emit_molecule(C, g, wide ? 0xFFFFFFFFu : ng);
+            UC &= ~best;
+        }
+    }
+    __syncthreads();
+    // ---- 6c. larger components, one at a time by the whole workgroup ----
+    for (uint32_t c = 0; c < NC; ++c) {
+        const uint32_t c0 = comp_start[c], n = comp_start[c + 1] - c0;
+        if (n <= 64 && n <= C.large_thresh) continue;
+        if (n < 2) continue;
+        if (n > C.large_thresh) {
+            // get_num_molecules_large_component (pugutils.rs:916-982): winner-take-all over the component's
+            // (umi, gene, count) triplets.  Rare; thread 0 walks the triplets sorted by the workgroup.
+            // triplets live in the edge pool: 4 words each (umi lo, umi hi, gene, count)
+            if (tid == 0) { s_flag[1] = 0; }
+            __syncthreads();
+            // count triplets
+            uint32_t cnt = 0;
+            for (uint32_t i = tid; i < n; i += kPugNT) {
+                const Lab l = rec_label(C, vv_rec[vid_at(c0 + i)]);
+                uint32_t g[kMaxGenesPerLabel];
+                const uint32_t ng = genes_of(C, l.n, [&](uint32_t j) { return l.p[j] & 0x7FFFFFFFu; }, g);
+                if (ng == 0xFFFFFFFFu) s_cnt[3] = kErrPugLimit; else cnt += ng;
+            }
+            uint32_t tot;
+            (void)block_excl_scan<kPugNT>(cnt, s_ws, tot);
+            if (tid == 0) s_ebase = atomicAdd(A.epool_cursor, 4ull * tot + 4);
+            __syncthreads();
+            if (s_ebase + 4ull * tot + 4 > A.epool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, cell); return; }
+            uint4* trip = reinterpret_cast<uint4*>(A.epool + ((s_ebase + 3) & ~3ull));
+            if (tid == 0) s_flag[1] = 0;
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += kPugNT) {
+                const uint32_t v = vid_at(c0 + i);
+                const Lab l = rec_label(C, vv_rec[v]);
+                uint32_t g[kMaxGenesPerLabel];
+                const uint32_t ng = genes_of(C, l.n, [&](uint32_t j) { return l.p[j] & 0x7FFFFFFFu; }, g);
+                if (ng == 0xFFFFFFFFu) continue;
+                const uint32_t o = atomicAdd(&s_flag[1], ng);
+                for (uint32_t q = 0; q < ng; ++q) trip[o + q] = make_uint4((uint32_t)vv_umi[v], (uint32_t)(vv_umi[v] >> 32), g[q], vv_cnt[v]);
+            }
+            __syncthreads();
+            const uint32_t nt = s_flag[1];
+            bitonic_sort_by<kPugNT>(trip, nt, [](const uint4& a, const uint4& b) {
+                if (a.y != b.y) return a.y > b.y;
+                if (a.x != b.x) return a.x > b.x;
+                if (a.z != b.z) return a.z > b.z;
+                return a.w > b.w;
+            });
+            if (tid == 0 && nt) {  // resolve_num_molecules_crlike_from_vec, pugutils.rs:644-749
+                uint32_t best[kMaxGenesPerLabel];
+                uint32_t nbest = 0, maxc = 0, aggr = 0;
+                uint32_t cu_lo = trip[0].x, cu_hi = trip[0].y, cg = trip[0].z;
+                bool wide = false;
+                for (uint32_t i = 0; i < nt; ++i) {
+                    const uint4 t = trip[i];
+                    if (t.x != cu_lo || t.y != cu_hi) {
+                        emit_molecule(C, best, wide ? 0xFFFFFFFFu : nbest);
+                        cu_lo = t.x; cu_hi = t.y; cg = t.z;
+                        nbest = 1; best[0] = t.z; aggr = t.w; maxc = t.w; wide = false;
+                    } else {
+                        if (t.z == cg) aggr += t.w; else { aggr = t.w; cg = t.z; }
+                        if (aggr > maxc) {
+                            maxc = aggr;
+                            if (!(nbest == 1 && best[0] == t.z)) { nbest = 1; best[0] = t.z; wide = false; }
+                        } else if (aggr == maxc) {
+                            if (nbest == kMaxGenesPerLabel) wide = true; else best[nbest++] = t.z;
+                        }
+                    }
+                }
+                emit_molecule(C, best, wide ? 0xFFFFFFFFu : nbest);
+            }
+            if (tid == 0) A.alt[cell] = 1;  // used_alternative_strategy, pugutils.rs:1070
+            __syncthreads();
+            continue;
+        }
+        if (n > kMaxBigComp) { if (tid == 0) set_err(A.st, kErrPugLimit, cell); return; }
+        // multi-word cover: nw mask words, lane l of a wave holds word l; rows of the adjacency in the pool
+        const uint32_t nw = (n + 63) / 64;
+        if (tid == 0) s_ebase = atomicAdd(A.epool_cursor, 2ull * n * nw + 2);
+        __syncthreads();
+        if (s_ebase + 2ull * n * nw + 2 > A.epool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, cell); return; }
+        uint64_t* rows = reinterpret_cast<uint64_t*>(A.epool + ((s_ebase + 1) & ~1ull));
+        for (uint32_t i = tid; i < n * nw; i += kPugNT) rows[i] = 0;
+        for (uint32_t i = tid; i < n; i += kPugNT) local_idx[vid_at(c0 + i)] = i;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += kPugNT) {
+            const uint32_t v = vid_at(c0 + i);
+            for (uint32_t e = deg[v]; e < deg[v + 1]; ++e) { const uint32_t y = local_idx[edges[e]]; rows[(size_t)i * nw + (y >> 6)] |= 1ull << (y & 63); }
+        }
+        if (tid < nw) s_mask[0][tid] = (tid + 1 < nw || (n & 63) == 0) ? ~0ull : ((1ull << (n & 63)) - 1);
+        __syncthreads();
+        for (;;) {
+            // uncovered count
+            uint32_t rem = 0;
+            for (uint32_t w = 0; w < nw; ++w) rem += (uint32_t)__popcll(s_mask[0][w]);
+            if (rem == 0) break;
+            // every wave evaluates candidates v = k-th uncovered vertex for k = wv, wv+16, ...
+            uint32_t my_best_sz = 0, my_best_v = 0xFFFFFFFFu;
+            uint64_t my_best_word = 0;  // lane l: word l of this wave's best arborescence
+            const uint64_t ucw = lane < nw ? s_mask[0][lane] : 0ull;
+            uint32_t seen = 0;
+            for (uint32_t w = 0; w < nw; ++w) {
+                uint64_t bits = s_mask[0][w];
+                for (; bits; bits &= bits - 1, ++seen) {
+                    if (seen % (kPugNT / 64) != wv) continue;
+                    const uint32_t v = w * 64 + (uint32_t)__builtin_ctzll(bits);
+                    const Lab lv = rec_label(C, vv_rec[vid_at(c0 + v)]);
+                    uint64_t mvw = 0; uint32_t mv_sz = 0;
+                    for (uint32_t j = 0; j < lv.n; ++j) {
+                        const uint32_t t = lv.p[j] & 0x7FFFFFFFu;
+                        // A_t: uncovered vertices whose label contains t (chunks of 64 vertices, lane = vertex)
+                        uint64_t Aw = 0;
+                        for (uint32_t cw = 0; cw < nw; ++cw) {
+                            const uint32_t i = cw * 64 + lane;
+                            const uint64_t ucb = __shfl((uint32_t)(ucw >> 32), (int)cw);
+                            const uint64_t uca = __shfl((uint32_t)ucw, (int)cw);
+                            const uint64_t ucword = (ucb << 32) | uca;
+                            const bool in = i < n && ((ucword >> lane) & 1ull) && lab_contains(rec_label(C, vv_rec[vid_at(c0 + i)]), t);
+                            const uint64_t word = __ballot(in);
+                            if (lane == cw) Aw = word;
+                        }
+                        uint64_t Rw = (lane == (v >> 6)) ? (1ull << (v & 63)) : 0ull, Fw = Rw;
+                        for (;;) {
+                            // N = OR of the rows of the frontier vertices
+                            uint64_t Nw = 0;
+                            for (uint32_t fw = 0; fw < nw; ++fw) {
+                                const uint32_t flo = __shfl((uint32_t)Fw, (int)fw), fhi = __shfl((uint32_t)(Fw >> 32), (int)fw);
+                                uint64_t fb = ((uint64_t)fhi << 32) | flo;
+                                for (; fb; fb &= fb - 1) {
+                                    const uint32_t x = fw * 64 + (uint32_t)__builtin_ctzll(fb);
+                                    if (lane < nw) Nw |= rows[(size_t)x * nw + lane];
+                                }
+                            }
+                            Fw = Nw & Aw & ~Rw;
+                            Rw |= Fw;
+                            if (!__any(Fw != 0)) break;
+                        }
+                        uint32_t sz = (uint32_t)__popcll(Rw);
+#pragma unroll
+                        for (int d = 32; d > 0; d >>= 1) sz += __shfl_xor(sz, d);
+                        if (sz > mv_sz) { mv_sz = sz; mvw = Rw; }
+                    }
+                    if (mv_sz > my_best_sz) { my_best_sz = mv_sz; my_best_v = v; my_best_word = mvw; }
+                }
+            }
+            if (lane == 0) { s_bestv[wv] = my_best_v; s_bestsz[wv] = my_best_sz; }
+            __syncthreads();
+            // winner: largest size, then smallest vertex (= first in ascending scan order)
+            uint32_t win = 0;
+            for (uint32_t w = 1; w < kPugNT / 64; ++w)
+                if (s_bestsz[w] > s_bestsz[win] || (s_bestsz[w] == s_bestsz[win] && s_bestv[w] < s_bestv[win])) win = w;
+            if (s_bestsz[win] == 0) { if (tid == 0) s_cnt[3] = kErrPugLimit; break; }
+            if (wv == win && lane < nw) s_mask[1][lane] = my_best_word;
+            __syncthreads();
+            if (wv == 0) {
+                // common transcripts of the arborescence -> genes
+                uint32_t fv = 0xFFFFFFFFu;
+                for (uint32_t w = 0; w < nw && fv == 0xFFFFFFFFu; ++w) if (s_mask[1][w]) fv = w * 64 + (uint32_t)__builtin_ctzll(s_mask[1][w]);
+                const Lab lf = rec_label(C, vv_rec[vid_at(c0 + fv)]);
+                uint32_t g[kMaxGenesPerLabel];
+                uint32_t ng = 0;
+                bool wide = false;
+                for (uint32_t j = 0; j < lf.n; ++j) {
+                    const uint32_t t = lf.p[j] & 0x7FFFFFFFu;
+                    bool all = true;
+                    for (uint32_t cw = 0; cw < nw; ++cw) {
+                        const uint32_t i = cw * 64 + lane;
+                        const bool inb = i < n && ((s_mask[1][cw] >> lane) & 1ull);
+                        const bool miss = inb && !lab_contains(rec_label(C, vv_rec[vid_at(c0 + i)]), t);
+                        if (__any(miss)) { all = false; break; }
+                    }
+                    if (!all) continue;
+                    if (lane == 0) {
+                        const uint32_t gid = C.t2g[t];
+                        uint32_t q = 0;
+                        while (q < ng && g[q] < gid) ++q;
+                        if (!(q < ng && g[q] == gid)) {
+                            if (ng == kMaxGenesPerLabel) wide = true;
+                            else { for (uint32_t r = ng; r > q; --r) g[r] = g[r - 1]; g[q] = gid; ++ng; }
+                        }
+                    }
+                }
+                if (lane == 0) emit_molecule(C, g, wide ? 0xFFFFFFFFu : ng);
+            }
+            __syncthreads();
+            if (tid < nw) s_mask[0][tid] &= ~s_mask[1][tid];
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], cell); return; }
+    if (tid == 0) {
+        A.cell_ncols[cell] = s_cnt[0];
+        if (A.lab_cnt) { A.lab_cnt[2 * cell] = s_cnt[1]; A.lab_cnt[2 * cell + 1] = s_cnt[2]; }
+    }
+}
+
+void launch_pug(hipStream_t s, const PugCellArgs& a, uint32_t n_pug) {
+    if (!n_pug) return;
+    hipLaunchKernelGGL(k_pug_cell, dim3(n_pug), dim3(kPugNT), 0, s, a);
+}
+
+uint64_t pug_scratch_words(uint32_t nrec) {
+    const uint64_t R = nrec;
+    return 6 * R + 4 * R + 5 * R + (R + 1) + 4 * R + (R + 2) + (R + 2) + 16;
+}
+
+}  // namespace afq

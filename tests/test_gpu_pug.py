@@ -1,0 +1,85 @@
+"""GPU parity tests for the parsimony (PUG) path through the C ABI vs the CPU oracle."""
+import numpy as np
+import pytest
+
+from util import assert_same_result, cfg_for, load_golden, pkg, rows_of
+
+pytestmark = pytest.mark.gpu
+rad = pkg.rad
+synth = pkg.synth
+
+
+def run_both(oracle, cfg, t2g, b, off):
+    q = pkg.Quantifier(cfg, t2g)
+    try:
+        got = q.quant_chunks(b, off)
+    finally:
+        q.close()
+    return got, oracle.quant(cfg, t2g, b, off)
+
+
+def test_pug_hand_cases(oracle):
+    d = load_golden("pug_hand_cases.json")
+    cells = [(c["bc"], [(u, r) for u, r in c["reads"]]) for c in d["cells"]]
+    b, off = rad.encode_cells(cells, 4, 4)
+    t2g = np.asarray(d["t2g"], np.uint32)
+    cfg = pkg.WorkerConfig.for_resolution("parsimony", num_genes=d["num_genes"], num_rows=d["num_genes"], small_thresh=0)
+    got, want = run_both(oracle, cfg, t2g, b, off)
+    for c, g in zip(d["cells"], rows_of(got)):
+        assert [[int(a), int(v)] for a, v in g] == c["expected"], (c["bc"], c["why"])
+    assert_same_result(got, want)
+
+
+@pytest.mark.parametrize("usa", [False, True])
+@pytest.mark.parametrize("res", ["parsimony", "parsimony-em"])
+def test_parsimony_synthetic(oracle, usa, res):
+    """Ragged cells incl. tiny ones (cr-like fast path), 3 % UMI errors so the PUG has real components."""
+    sizes = [12000, 5000, 1500, 700, 260, 250, 120, 99, 40, 3]
+    s = synth.synth(31, sizes, num_genes=250, txp_per_gene=3, usa=usa, dup=0.55, zipf=0.5, cross=0.3, umi_err=0.03, max_extra_na=5)
+    b, off = s.encode()
+    cfg = cfg_for(s, res)
+    got, want = run_both(oracle, cfg, s.tid_to_gid, b, off)
+    assert np.array_equal(got.cell_ptr, want.cell_ptr) and np.array_equal(got.gene, want.gene)
+    np.testing.assert_allclose(got.val, want.val, rtol=1e-4, atol=0)  # the north-star tolerance for EM resolutions
+    assert_same_result(got, want)  # and in fact bit-identical
+    plain = oracle.quant(cfg_for(s, "cr-like"), s.tid_to_gid, b, off)
+    assert not np.array_equal(plain.val, want.val) or not np.array_equal(plain.gene, want.gene)
+
+
+def test_parsimony_exact_umi_and_small_thresh(oracle):
+    """--umi-edit-dist 0 (only identical UMIs induce edges) and --small-thresh 0."""
+    s = synth.synth(32, [3000, 500, 60], num_genes=120, txp_per_gene=3, dup=0.5, cross=0.3, umi_err=0.05)
+    b, off = s.encode()
+    for kw in (dict(pug_exact_umi=True), dict(small_thresh=0), dict(pug_exact_umi=True, small_thresh=0)):
+        cfg = cfg_for(s, "parsimony", **kw)
+        got, want = run_both(oracle, cfg, s.tid_to_gid, b, off)
+        assert_same_result(got, want, what=str(kw))
+
+
+def test_large_component_fallback_sets_alt_flag(oracle):
+    """Components above --large-graph-thresh are resolved cr-like and the cell is flagged (pugutils.rs:1055-1072)."""
+    s = synth.synth(33, [2500, 800], num_genes=60, txp_per_gene=2, dup=0.6, cross=0.2, umi_err=0.25)
+    b, off = s.encode()
+    cfg = cfg_for(s, "parsimony", large_graph_thresh=3)
+    got, want = run_both(oracle, cfg, s.tid_to_gid, b, off)
+    assert (want.flags & pkg._abi.CELL_ALT_RES).any()
+    assert_same_result(got, want)
+
+
+def test_components_beyond_one_wave(oracle):
+    """All 256 UMIs over 4 positions on one transcript form one 256-vertex component (each vertex has 12
+    neighbours); a second, overlapping class splits the cover.  Exercises the multi-word cover."""
+    reads = []
+    for u in range(256):
+        umi = (u & 3) | (((u >> 2) & 3) << 4) | (((u >> 4) & 3) << 10) | (((u >> 6) & 3) << 20)
+        reads.append((umi, [0] if u % 3 else [0, 2]))
+        if u % 5 == 0:
+            reads.append((umi, [0]))
+    reads += [(0x555555, [4]), (0x555554, [4]), (0x555554, [4]), (0x555554, [4])]
+    cells = [(77, reads), (78, reads[:130])]
+    b, off = rad.encode_cells(cells, 4, 4)
+    t2g = np.asarray([0, 0, 1, 1, 2, 2], np.uint32)
+    for res in ("parsimony", "parsimony-em"):
+        cfg = pkg.WorkerConfig.for_resolution(res, num_genes=3, num_rows=3, small_thresh=0)
+        got, want = run_both(oracle, cfg, t2g, b, off)
+        assert_same_result(got, want, what=res)

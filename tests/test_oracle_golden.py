@@ -135,3 +135,29 @@ def test_atac_dedup_known_answer(oracle):
     ptr, r, s, f, c = oracle.atac_dedup(ref, start, flen, [0, 5])
     assert ptr.tolist() == [0, 3]
     assert list(zip(r.tolist(), s.tolist(), f.tolist(), c.tolist())) == [(0, 5, 50, 1), (0, 5, 60, 1), (1, 10, 100, 3)]
+
+
+def test_pug_hand_cases(oracle):
+    """Hand-derived parsimony known-answers (tests/golden/pug_hand_cases.json)."""
+    d = load_golden("pug_hand_cases.json")
+    cells = [(c["bc"], [(u, r) for u, r in c["reads"]]) for c in d["cells"]]
+    b, off = rad.encode_cells(cells, 4, 4)
+    t2g = np.asarray(d["t2g"], np.uint32)
+    cfg = pkg.WorkerConfig.for_resolution("parsimony", num_genes=d["num_genes"], num_rows=d["num_genes"], small_thresh=0)
+    for c, g in zip(d["cells"], rows_of(oracle.quant(cfg, t2g, b, off))):
+        assert [[int(a), int(v)] for a, v in g] == c["expected"], (c["bc"], c["why"])
+    cr = pkg.WorkerConfig.for_resolution("cr-like", num_genes=d["num_genes"], num_rows=d["num_genes"], small_thresh=0)
+    for c, g in zip(d["cells"], rows_of(oracle.quant(cr, t2g, b, off))):
+        if "crlike" in c:
+            assert [[int(a), int(v)] for a, v in g] == c["crlike"]
+    # the reference's structural known-answer (tests/multi_barcode_integration.rs:1404-1556): on cells whose reads all
+    # hit two genes with distinct UMIs, cr-like mass is 0 while parsimony-em --small-thresh 0 keeps the mass
+    case = load_golden("crlike_hand_cases.json")["cases"][3]
+    cells = [(c["bc"], [(u, r) for u, r in c["reads"]]) for c in case["cells"]][:1]
+    b, off = rad.encode_cells(cells, 4, 4)
+    t2g = np.asarray(case["t2g"], np.uint32)
+    pem = pkg.WorkerConfig.for_resolution("parsimony-em", num_genes=10, num_rows=10, small_thresh=0)
+    r_em = oracle.quant(pem, t2g, b, off)
+    r_tiny = oracle.quant(pkg.WorkerConfig.for_resolution("parsimony-em", num_genes=10, num_rows=10), t2g, b, off)
+    assert abs(float(r_em.val.sum()) - 8.0) < 0.1 and float(r_tiny.val.sum()) == 0.0
+    assert (r_tiny.flags & pkg._abi.CELL_TINY_PATH).all() and not (r_em.flags & pkg._abi.CELL_TINY_PATH).any()
