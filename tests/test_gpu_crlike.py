@@ -153,7 +153,7 @@ def test_bad_input_is_reported_not_crashed():
 def test_unsupported_resolutions_fail_loudly():
     s = synth.synth(6, [50], num_genes=20)
     b, off = s.encode()
-    q = pkg.Quantifier(cfg_for(s, "parsimony-em"), s.tid_to_gid)
+    q = pkg.Quantifier(cfg_for(s, "parsimony-gene"), s.tid_to_gid)
     try:
         with pytest.raises(pkg.AfqError) as e:
             q.quant_chunks(b, off)
