@@ -200,9 +200,7 @@ bool valid_width(uint32_t w) { return w == 1 || w == 2 || w == 4 || w == 8; }
 // What the device path implements today.  Anything else is refused loudly.
 int check_supported(afq_ctx* c) {
     const afq_config& g = c->cfg;
-    if (g.resolution == AFQ_RES_PARSIMONY_GENE || g.resolution == AFQ_RES_PARSIMONY_GENE_EM)
-        return fail(c, AFQ_ERR_UNSUPPORTED, "device path does not implement the gene-level parsimony variants yet");
-    if ((g.resolution == AFQ_RES_PARSIMONY || g.resolution == AFQ_RES_PARSIMONY_EM) &&
+    if (g.resolution >= AFQ_RES_PARSIMONY_EM && g.resolution <= AFQ_RES_PARSIMONY_GENE &&
         !decode_par_supported(g.bc_bytes, g.umi_bytes))
         return fail(c, AFQ_ERR_UNSUPPORTED, "device parsimony needs 4- or 8-byte barcode/UMI fields");
     if (g.usa_mode && g.sa_model != AFQ_SA_WINNER_TAKE_ALL)
@@ -233,10 +231,11 @@ int plan_ranges(afq_ctx* c) {
         if (fixed > nbytes || ((nbytes - fixed) & 3))
             return fail(c, AFQ_ERR_BAD_INPUT, "cell " + std::to_string(i) + ": chunk nbytes does not match its records");
         const uint64_t n_ref = (nbytes - fixed) / 4;
-        const bool em_res = c->cfg.resolution == AFQ_RES_CR_LIKE_EM || c->cfg.resolution == AFQ_RES_PARSIMONY_EM;
-        const bool pug_res = c->cfg.resolution == AFQ_RES_PARSIMONY || c->cfg.resolution == AFQ_RES_PARSIMONY_EM;
+        const uint32_t rs = c->cfg.resolution;
+        const bool em_res = rs == AFQ_RES_CR_LIKE_EM || rs == AFQ_RES_PARSIMONY_EM || rs == AFQ_RES_PARSIMONY_GENE_EM;
+        const bool pug_res = rs >= AFQ_RES_PARSIMONY_EM && rs <= AFQ_RES_PARSIMONY_GENE;
         double need = (em_res ? 24.0 + 40.0 * (c->cfg.usa_mode ? 3 : 1) : 16.0) * (double)n_ref + 128.0;
-        if (pug_res) need += 4.0 * (double)pug_scratch_words(nrec) + 20.0 * nrec + 64.0 * nrec;
+        if (pug_res) need += 4.0 * (double)pug_scratch_words(nrec, (uint32_t)n_ref, true) + 20.0 * nrec + 64.0 * nrec;
         if (n_ref > kBucketTarget) need += 16.0 * (double)(n_ref / kBucketTarget + 1);
         if (need > budget) return fail(c, AFQ_ERR_OOM, "cell " + std::to_string(i) + " alone exceeds device memory");
         if (used + need > budget) { c->ranges.push_back({c0, i}); c0 = i; used = 0; }
@@ -284,8 +283,13 @@ int run_range(afq_ctx* c, Range r) {
                  : g.resolution == AFQ_RES_TRIVIAL ? kModeTrivial
                  : g.resolution == AFQ_RES_CR_LIKE_EM ? kModeCrLikeEm
                  : g.resolution == AFQ_RES_PARSIMONY ? kModePug
-                 : g.resolution == AFQ_RES_PARSIMONY_EM ? kModePugEm : kModeCrLike;
-        if (mode_is_pug(m.mode)) { pug_cells.push_back(i); rd_off[i] = n_pug_reads; n_pug_reads += m.nrec; pug_scr.push_back(pug_words); pug_words += pug_scratch_words(m.nrec); }
+                 : g.resolution == AFQ_RES_PARSIMONY_EM ? kModePugEm
+                 : g.resolution == AFQ_RES_PARSIMONY_GENE ? kModePugGene
+                 : g.resolution == AFQ_RES_PARSIMONY_GENE_EM ? kModePugGeneEm : kModeCrLike;
+        if (mode_is_pug(m.mode)) {
+            pug_cells.push_back(i); rd_off[i] = n_pug_reads; n_pug_reads += m.nrec; pug_scr.push_back(pug_words);
+            pug_words += pug_scratch_words(m.nrec, m.n_ref, mode_pug_gene(m.mode));
+        }
         nrec_total += m.nrec;
         if (par) {
             slab_prefix.push_back((uint32_t)n_slabs);
@@ -318,7 +322,7 @@ int run_range(afq_ctx* c, Range r) {
     HIP_TRY(c, c->d_nnz.ensure(4ull * n));
     HIP_TRY(c, c->d_ovf.ensure(sizeof(OverflowEnt) * std::max<uint64_t>(n_buckets, 1)));
     HIP_TRY(c, c->d_bdesc.ensure(bucket_desc_bytes() * std::max<uint64_t>(n_buckets, 1)));
-    const bool em = g.resolution == AFQ_RES_CR_LIKE_EM || g.resolution == AFQ_RES_PARSIMONY_EM;
+    const bool em = g.resolution == AFQ_RES_CR_LIKE_EM || g.resolution == AFQ_RES_PARSIMONY_EM || g.resolution == AFQ_RES_PARSIMONY_GENE_EM;
     const uint32_t n_pug = (uint32_t)pug_cells.size();
     if (n_pug && !par) return fail(c, AFQ_ERR_UNSUPPORTED, "device parsimony needs dword-aligned chunk offsets");
     hist_cells = multi;
@@ -418,6 +422,7 @@ int run_range(afq_ctx* c, Range r) {
         pa.alt = c->d_alt.as<uint32_t>(); pa.st = ra.st; pa.ref_count = c->ref_count; pa.num_genes = g.num_genes; pa.usa = g.usa_mode;
         pa.num_rows = g.num_rows; pa.em = em ? 1u : 0u; pa.exact_umi = g.pug_exact_umi; pa.large_thresh = g.large_graph_thresh;
         pa.hw = 1 + g.bc_bytes / 4 + g.umi_bytes / 4; pa.umi_pairs = std::min<uint32_t>(g.umi_bytes * 4, 22);
+        pa.gene_level = (g.resolution == AFQ_RES_PARSIMONY_GENE || g.resolution == AFQ_RES_PARSIMONY_GENE_EM) ? 1u : 0u;
         ScopedTimer t(c, K_PUG);
         launch_pug(s, pa, n_pug);
     }
@@ -460,7 +465,8 @@ int finish_range(afq_ctx* c) {
     c->stats.n_fallback_cells += st.n_fallback;
     std::vector<uint32_t> nnz(n);
     std::vector<uint64_t> bc(n), ptr(n + 1);
-    const bool em = c->cfg.resolution == AFQ_RES_CR_LIKE_EM || c->cfg.resolution == AFQ_RES_PARSIMONY_EM;
+    const bool em = c->cfg.resolution == AFQ_RES_CR_LIKE_EM || c->cfg.resolution == AFQ_RES_PARSIMONY_EM ||
+                    c->cfg.resolution == AFQ_RES_PARSIMONY_GENE_EM;
     std::vector<uint32_t> alt(n);
     HIP_TRY(c, hipMemcpy(alt.data(), c->d_alt.p, 4ull * n, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(nnz.data(), c->d_nnz.p, 4ull * n, hipMemcpyDeviceToHost));

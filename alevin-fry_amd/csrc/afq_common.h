@@ -63,6 +63,8 @@ constexpr uint32_t kModeCrLike = 0;   // winner-take-all (cr-like; every tiny ce
 constexpr uint32_t kModeCrLikeEm = 2; // cr-like-em: ties are kept as gene-level classes and resolved by the EM (quant.rs:882-924)
 constexpr uint32_t kModePug = 3;       // parsimony / parsimony-em: PUG + monochromatic cover (pugutils.rs:65-391, 989-1331)
 constexpr uint32_t kModePugEm = 4;
+constexpr uint32_t kModePugGene = 5;   // parsimony-gene / parsimony-gene-em: gene-level EqMap (eq_class.rs:723-821)
+constexpr uint32_t kModePugGeneEm = 6;
 constexpr uint32_t kModeTrivial = 1;  // `trivial`: single-gene reads only, distinct UMIs per gene (src/pugutils.rs:852-911)
 
 constexpr uint32_t kSlabWords = 256;  // dwords one wave of k_decode_par covers (1 KiB)
@@ -79,7 +81,15 @@ constexpr uint32_t kErrLabelHash = 6;    // two different ref lists with the sam
 constexpr uint32_t kErrPugLimit = 7;     // a PUG size limit of the device path was exceeded
 constexpr uint32_t kErrPugPool = 8;      // edge pool exhausted
 
-__host__ __device__ inline bool mode_is_pug(uint32_t m) { return m == kModePug || m == kModePugEm; }
+__host__ __device__ inline bool mode_is_pug(uint32_t m) { return m >= kModePug && m <= kModePugGeneEm; }
+__host__ __device__ inline bool mode_pug_gene(uint32_t m) { return m == kModePugGene || m == kModePugGeneEm; }
+// order-independent hash of a set of gene ids (gene-level class labels)
+__host__ __device__ inline uint64_t gene_set_hash_term(uint32_t g) {
+    uint64_t x = (uint64_t)g + 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
 
 // Per-read output of the decode for PUG cells: 64-bit hash of the read's ref-list label, its UMI, and the
 // dword offset of the record inside its chunk (= appearance order, and where the label lives).

@@ -96,11 +96,11 @@ struct PugCellArgs {
     uint32_t* lab_cnt;
     uint32_t* alt;                // [n_cells] set to 1 when a component took the cr-like fallback
     DevStatus* st;
-    uint32_t ref_count, num_genes, usa, num_rows, em, exact_umi, large_thresh, hw, umi_pairs;
+    uint32_t ref_count, num_genes, usa, num_rows, em, exact_umi, large_thresh, hw, umi_pairs, gene_level;
 };
 
 void launch_pug(hipStream_t s, const PugCellArgs& a, uint32_t n_pug);
-uint64_t pug_scratch_words(uint32_t nrec);
+uint64_t pug_scratch_words(uint32_t nrec, uint32_t n_ref, bool gene_level);
 
 constexpr uint32_t kScatterTileHost = 2048;  // keys per histogram/scatter tile
 

@@ -132,15 +132,14 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ byte
             if (UW == 8 && (umi >> kUmiBits)) { set_err(st, kErrUmiWide, cell); na = 0; }
             rp = rec + HDR;
             const bool ral = ((((uintptr_t)rp) & 3) == 0);
-            if (mode_is_pug(m.mode)) {  // PUG cells: one (label hash, umi, record offset) per read
+            if (mode_is_pug(m.mode)) { rec_dw = (uint32_t)((roff - m.chunk_off) >> 2); pug_rec = true; }
+            if (mode_is_pug(m.mode) && !mode_pug_gene(m.mode)) {  // txp-level PUG: hash of the ref list
                 lhash = label_hash_init(na);
                 for (uint32_t j = 0; j < na; ++j) {
                     const uint32_t t = ld_u32(rp + 4 * j, ral) & 0x7FFFFFFFu;
                     if (t >= ref_count) set_err(st, kErrRefRange, cell);
                     lhash = label_hash_step(lhash, t);
                 }
-                rec_dw = (uint32_t)((roff - m.chunk_off) >> 2);
-                pug_rec = true;
                 na = 0;
             }
             for (uint32_t j = 0; j < na; ++j) {
@@ -173,7 +172,15 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ byte
                         if (ti < ref_count && t2g[ti] == gj) first = false;
                     }
                     kcnt += first;
+                    if (first && mode_pug_gene(m.mode)) lhash += gene_set_hash_term(gj);
                 }
+            }
+            if (mode_pug_gene(m.mode)) {  // gene-level PUG: order-independent hash of the read's gene set
+                if (!ovf) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) if ((uint32_t)i < k) lhash += gene_set_hash_term(g[i]);
+                }
+                lhash ^= (uint64_t)kcnt * kHashMul;
             }
         }
         if (m.mode == kModeTrivial && kcnt != 1) kcnt = 0;  // multi-gene reads are discarded (pugutils.rs:870-891)
@@ -425,7 +432,8 @@ __global__ __launch_bounds__(256) void k_decode_par(const uint8_t* __restrict__ 
             if (!prefetched && same_next) { issue_slab_loads(s0 + kSlabWords); prefetched = true; }
             const bool pug_rec = act && mode_is_pug(m.mode);
             uint64_t lhash = 0;
-            if (pug_rec) {  // PUG cells: one (label hash, umi, record offset) per read
+            const bool pug_gene = pug_rec && mode_pug_gene(m.mode);
+            if (pug_rec && !pug_gene) {  // txp-level PUG: hash of the ref list
                 lhash = label_hash_init(na);
                 for (uint32_t j = 0; j < na; ++j) {
                     const uint32_t t = refw(j);
@@ -433,7 +441,7 @@ __global__ __launch_bounds__(256) void k_decode_par(const uint8_t* __restrict__ 
                     lhash = label_hash_step(lhash, t);
                 }
             }
-            if (act && na && !pug_rec) {
+            if (act && na && (!pug_rec || pug_gene)) {
                 if (ok0) {
                     if (gid0 < num_genes) { g[0] = gid0; k = 1; } else fail = true;
                 }
@@ -467,7 +475,15 @@ __global__ __launch_bounds__(256) void k_decode_par(const uint8_t* __restrict__ 
                             if (tq < ref_count && t2g[tq] == gj) first = false;
                         }
                         kcnt += first;
+                        if (first && pug_gene) lhash += gene_set_hash_term(gj);
                     }
+                }
+                if (pug_gene) {  // gene-level PUG: order-independent hash of the read's gene set
+                    if (!ovf) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) if ((uint32_t)q < k) lhash += gene_set_hash_term(g[q]);
+                    }
+                    lhash ^= (uint64_t)kcnt * kHashMul;
                 }
             }
             if (m.mode == kModeTrivial && kcnt != 1) kcnt = 0;  // multi-gene reads are discarded (pugutils.rs:870-891)

@@ -45,7 +45,7 @@ struct PugCtx {
     const uint32_t* t2g;
     uint32_t ref_count, num_genes;
     // config
-    uint32_t usa, num_rows, uo, ao, em, exact_umi, large_thresh, umi_pairs;
+    uint32_t usa, num_rows, uo, ao, em, exact_umi, large_thresh, umi_pairs, gene_level;
     // outputs
     uint32_t* cols;          // the cell's column list (u32), positions from s_ncols
     uint32_t* labw;          // EM label words
@@ -96,7 +96,7 @@ template <typename GetRef>
 __device__ __forceinline__ uint32_t genes_of(const PugCtx& c, uint32_t n, GetRef&& ref, uint32_t* g) {
     uint32_t k = 0;
     for (uint32_t j = 0; j < n; ++j) {
-        const uint32_t gid = c.t2g[ref(j)];
+        const uint32_t gid = c.gene_level ? ref(j) : c.t2g[ref(j)];  // gene-level labels already hold gene ids
         uint32_t p = 0;
         while (p < k && g[p] < gid) ++p;
         if (p < k && g[p] == gid) continue;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     C.W = reinterpret_cast<const uint32_t*>(A.bytes + m.chunk_off);
     C.HW = A.hw; C.t2g = A.t2g; C.ref_count = A.ref_count; C.num_genes = A.num_genes;
     C.usa = A.usa; C.num_rows = A.num_rows; C.uo = A.num_rows / 3; C.ao = 2 * (A.num_rows / 3); C.em = A.em;
-    C.exact_umi = A.exact_umi; C.large_thresh = A.large_thresh; C.umi_pairs = A.umi_pairs;
+    C.exact_umi = A.exact_umi; C.large_thresh = A.large_thresh; C.umi_pairs = A.umi_pairs; C.gene_level = A.gene_level;
     C.cols = reinterpret_cast<uint32_t*>(A.keys0 + m.key_off);
     C.cols_cap = 2 * m.n_ref + 2;
     C.labw = A.lab ? A.lab + 2 * m.key_off : nullptr;
@@ -201,6 +201,8 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     uint32_t* c_order = p; p += R;
     uint32_t* deg = p; p += R + 2;         // out-degree, then edge offsets
     uint32_t* comp_start = p; p += R + 2;
+    uint32_t* c_goff = p; p += A.gene_level ? R + 2 : 0;           // gene-level: class -> offset of its gene list
+    uint32_t* c_glab = p; p += A.gene_level ? m.n_ref + 2 : 0;      // gene-level: the sorted distinct gene lists
     // aliases into slab A once the sorted reads are consumed
     uint64_t* us = reinterpret_cast<uint64_t*>(sr);                    // 2R : (umi << 20 | vid), sorted
     uint64_t* comp_sorted = us + R;                                    // 2R : (root << 20 | vid), sorted
@@ -247,6 +249,46 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     }
     if (tid == 0) c_vstart[K] = V;
     __syncthreads();
+    // gene-level EqMap (init_from_chunk_gene_level, eq_class.rs:723-821): a class label is the sorted distinct
+    // gene ids of its ref list; materialise one list per class (the decode grouped reads by a hash of that set)
+    auto gene_list = [&](uint32_t rec_dw, uint32_t* g) -> uint32_t {
+        const Lab l = rec_label(C, rec_dw);
+        uint32_t k = 0;
+        for (uint32_t j = 0; j < l.n; ++j) {
+            const uint32_t gid = C.t2g[l.p[j] & 0x7FFFFFFFu];
+            uint32_t q = 0;
+            while (q < k && g[q] < gid) ++q;
+            if (q < k && g[q] == gid) continue;
+            if (k == kMaxGenesPerLabel) return 0xFFFFFFFFu;
+            for (uint32_t r = k; r > q; --r) g[r] = g[r - 1];
+            g[q] = gid;
+            ++k;
+        }
+        return k;
+    };
+    if (C.gene_level) {
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < K; base += kPugNT) {
+            const uint32_t k = base + tid;
+            uint32_t g[kMaxGenesPerLabel];
+            uint32_t len = k < K ? gene_list(c_rep[k], g) : 0u;
+            if (len == 0xFFFFFFFFu) { s_cnt[3] = kErrPugLimit; len = 0; }
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<kPugNT>(len, s_ws, tot);
+            if (k < K) {
+                c_goff[k] = carry + ex;
+                for (uint32_t i = 0; i < len; ++i) c_glab[carry + ex + i] = g[i];
+            }
+            carry += tot;
+        }
+        if (tid == 0) c_goff[K] = carry;
+        __syncthreads();
+    }
+    auto vlab = [&](uint32_t v) -> Lab {  // label of a vertex: its class's ref list, or gene list at gene level
+        if (!C.gene_level) return rec_label(C, vv_rec[v]);
+        const uint32_t k = vv_cls[v];
+        return Lab{c_glab + c_goff[k], c_goff[k + 1] - c_goff[k]};
+    };
     // per-read pass: vertex multiplicities, class first appearance, hash-collision check.
     {
         // vertices are in read order, so the vertex of read i = (#vertex heads <= i) - 1: a second scan.
@@ -262,7 +304,15 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                 atomicAdd(&v_cnt[vi], 1u);
                 const uint32_t k = v_cls[vi];
                 atomicMin(&c_minoff[k], sr[i].o);
-                if (!lab_equal(rec_label(C, sr[i].o), rec_label(C, c_rep[k]))) s_cnt[3] = kErrLabelHash;
+                if (!C.gene_level) {
+                    if (!lab_equal(rec_label(C, sr[i].o), rec_label(C, c_rep[k]))) s_cnt[3] = kErrLabelHash;
+                } else {
+                    uint32_t g[kMaxGenesPerLabel];
+                    const uint32_t len = gene_list(sr[i].o, g);
+                    bool same = len == c_goff[k + 1] - c_goff[k];
+                    for (uint32_t q = 0; same && q < len; ++q) same = g[q] == c_glab[c_goff[k] + q];
+                    if (!same) s_cnt[3] = kErrLabelHash;
+                }
             }
             carry += tv;
         }
@@ -305,7 +355,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     auto for_each_out = [&](uint32_t x, auto&& f) {
         const uint64_t ux = vv_umi[x];
         const uint32_t cx = vv_cnt[x], kx = vv_cls[x];
-        const Lab lx = rec_label(C, vv_rec[x]);
+        const Lab lx = vlab(x);
         const uint32_t nprobe = C.exact_umi ? 1u : 1u + 3u * C.umi_pairs;
         for (uint32_t pr = 0; pr < nprobe; ++pr) {
             uint64_t pu = ux;
@@ -321,7 +371,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                 const uint32_t y = (uint32_t)us[lo] & ((1u << kVidBits) - 1);
                 if (y == x) continue;
                 if (pr && !(vv_cnt[y] < 2 * cx)) continue;
-                if (vv_cls[y] != kx && !lab_overlap(lx, rec_label(C, vv_rec[y]))) continue;
+                if (vv_cls[y] != kx && !lab_overlap(lx, vlab(y))) continue;
                 f(y);
             }
         }
@@ -401,7 +451,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     // ---- 6a. single-vertex components: the label's genes (pugutils.rs:1262-1322) ----
     for (uint32_t c = tid; c < NC; c += kPugNT) {
         if (comp_start[c + 1] - comp_start[c] != 1) continue;
-        const Lab l = rec_label(C, vv_rec[vid_at(comp_start[c])]);
+        const Lab l = vlab(vid_at(comp_start[c]));
         uint32_t g[kMaxGenesPerLabel];
         const uint32_t ng = genes_of(C, l.n, [&](uint32_t j) { return l.p[j] & 0x7FFFFFFFu; }, g);
         emit_molecule(C, g, ng);
@@ -412,7 +462,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         if (n < 2 || n > 64 || n > C.large_thresh) continue;
         const bool act = lane < n;
         const uint32_t myv = act ? vid_at(c0 + lane) : 0u;
-        const Lab myl = act ? rec_label(C, vv_rec[myv]) : Lab{nullptr, 0};
+        const Lab myl = act ? vlab(myv) : Lab{nullptr, 0};
         uint64_t adj = 0;
         if (act)
             for (uint32_t e = deg[myv]; e < deg[myv + 1]; ++e) adj |= 1ull << local_idx[edges[e]];
@@ -423,8 +473,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
             uint32_t best_sz = 0;
             for (uint64_t it = UC; it; it &= it - 1) {   // ascending vertex id
                 const uint32_t v = (uint32_t)__builtin_ctzll(it);
-                const uint32_t vrec = __shfl(act ? vv_rec[myv] : 0u, (int)v);
-                const Lab lv = rec_label(C, vrec);
+                const Lab lv = vlab(__shfl(myv, (int)v));
                 uint64_t mv = 0;
                 uint32_t mv_sz = 0;
                 for (uint32_t j = 0; j < lv.n; ++j) {
@@ -445,8 +494,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
             if (best == 0) { if (lane == 0) s_cnt[3] = kErrPugLimit; break; }  // vertex with an empty label
             // transcripts common to every vertex of the arborescence (pugutils.rs:1161-1188) -> genes
             const uint32_t fv = (uint32_t)__builtin_ctzll(best);
-            const uint32_t frec = __shfl(act ? vv_rec[myv] : 0u, (int)fv);
-            const Lab lf = rec_label(C, frec);
+            const Lab lf = vlab(__shfl(myv, (int)fv));
             uint32_t g[kMaxGenesPerLabel];
             uint32_t ng = 0;
             bool wide = false;
@@ -455,7 +503,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                 const uint64_t has = __ballot(act && ((best >> lane) & 1ull) && lab_contains(myl, t));
                 if (has != best) continue;
                 if (lane == 0) {
-                    const uint32_t gid = C.t2g[t];
+                    const uint32_t gid = C.gene_level ? t : C.t2g[t];
                     uint32_t q = 0;
                     while (q < ng && g[q] < gid) ++q;
                     if (!(q < ng && g[q] == gid)) {
@@ -483,7 +531,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
             // count triplets
             uint32_t cnt = 0;
             for (uint32_t i = tid; i < n; i += kPugNT) {
-                const Lab l = rec_label(C, vv_rec[vid_at(c0 + i)]);
+                const Lab l = vlab(vid_at(c0 + i));
                 uint32_t g[kMaxGenesPerLabel];
                 const uint32_t ng = genes_of(C, l.n, [&](uint32_t j) { return l.p[j] & 0x7FFFFFFFu; }, g);
                 if (ng == 0xFFFFFFFFu) s_cnt[3] = kErrPugLimit; else cnt += ng;
@@ -498,7 +546,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
             __syncthreads();
             for (uint32_t i = tid; i < n; i += kPugNT) {
                 const uint32_t v = vid_at(c0 + i);
-                const Lab l = rec_label(C, vv_rec[v]);
+                const Lab l = vlab(v);
                 uint32_t g[kMaxGenesPerLabel];
                 const uint32_t ng = genes_of(C, l.n, [&](uint32_t j) { return l.p[j] & 0x7FFFFFFFu; }, g);
                 if (ng == 0xFFFFFFFFu) continue;
@@ -571,7 +619,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                 for (; bits; bits &= bits - 1, ++seen) {
                     if (seen % (kPugNT / 64) != wv) continue;
                     const uint32_t v = w * 64 + (uint32_t)__builtin_ctzll(bits);
-                    const Lab lv = rec_label(C, vv_rec[vid_at(c0 + v)]);
+                    const Lab lv = vlab(vid_at(c0 + v));
                     uint64_t mvw = 0; uint32_t mv_sz = 0;
                     for (uint32_t j = 0; j < lv.n; ++j) {
                         const uint32_t t = lv.p[j] & 0x7FFFFFFFu;
@@ -582,7 +630,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                             const uint64_t ucb = __shfl((uint32_t)(ucw >> 32), (int)cw);
                             const uint64_t uca = __shfl((uint32_t)ucw, (int)cw);
                             const uint64_t ucword = (ucb << 32) | uca;
-                            const bool in = i < n && ((ucword >> lane) & 1ull) && lab_contains(rec_label(C, vv_rec[vid_at(c0 + i)]), t);
+                            const bool in = i < n && ((ucword >> lane) & 1ull) && lab_contains(vlab(vid_at(c0 + i)), t);
                             const uint64_t word = __ballot(in);
                             if (lane == cw) Aw = word;
                         }
@@ -623,7 +671,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                 // common transcripts of the arborescence -> genes
                 uint32_t fv = 0xFFFFFFFFu;
                 for (uint32_t w = 0; w < nw && fv == 0xFFFFFFFFu; ++w) if (s_mask[1][w]) fv = w * 64 + (uint32_t)__builtin_ctzll(s_mask[1][w]);
-                const Lab lf = rec_label(C, vv_rec[vid_at(c0 + fv)]);
+                const Lab lf = vlab(vid_at(c0 + fv));
                 uint32_t g[kMaxGenesPerLabel];
                 uint32_t ng = 0;
                 bool wide = false;
@@ -633,12 +681,12 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                     for (uint32_t cw = 0; cw < nw; ++cw) {
                         const uint32_t i = cw * 64 + lane;
                         const bool inb = i < n && ((s_mask[1][cw] >> lane) & 1ull);
-                        const bool miss = inb && !lab_contains(rec_label(C, vv_rec[vid_at(c0 + i)]), t);
+                        const bool miss = inb && !lab_contains(vlab(vid_at(c0 + i)), t);
                         if (__any(miss)) { all = false; break; }
                     }
                     if (!all) continue;
                     if (lane == 0) {
-                        const uint32_t gid = C.t2g[t];
+                        const uint32_t gid = C.gene_level ? t : C.t2g[t];
                         uint32_t q = 0;
                         while (q < ng && g[q] < gid) ++q;
                         if (!(q < ng && g[q] == gid)) {
@@ -668,9 +716,9 @@ void launch_pug(hipStream_t s, const PugCellArgs& a, uint32_t n_pug) {
     hipLaunchKernelGGL(k_pug_cell, dim3(n_pug), dim3(kPugNT), 0, s, a);
 }
 
-uint64_t pug_scratch_words(uint32_t nrec) {
+uint64_t pug_scratch_words(uint32_t nrec, uint32_t n_ref, bool gene_level) {
     const uint64_t R = nrec;
-    return 6 * R + 4 * R + 5 * R + (R + 1) + 4 * R + (R + 2) + (R + 2) + 16;
+    return 6 * R + 4 * R + 5 * R + (R + 1) + 4 * R + (R + 2) + (R + 2) + (gene_level ? R + 2 + (uint64_t)n_ref + 2 : 0) + 16;
 }
 
 }  // namespace afq

@@ -150,54 +150,27 @@ def test_bad_input_is_reported_not_crashed():
         q.close()
 
 
-def test_unsupported_resolutions_fail_loudly():
-    s = synth.synth(6, [50], num_genes=20)
+def test_unsupported_requests_fail_loudly():
+    """What the device path does not implement is refused with AFQ_ERR_UNSUPPORTED, never approximated."""
+    s = synth.synth(6, [50], num_genes=20, usa=True)
     b, off = s.encode()
-    q = pkg.Quantifier(cfg_for(s, "parsimony-gene"), s.tid_to_gid)
+    q = pkg.Quantifier(cfg_for(s, "cr-like", sa_model="prefer-ambig"), s.tid_to_gid)  # hidden --sa-model flag
     try:
         with pytest.raises(pkg.AfqError) as e:
             q.quant_chunks(b, off)
         assert e.value.code == pkg._abi.AFQ_ERR_UNSUPPORTED
     finally:
         q.close()
-
-
-def test_walk_free_decode_falls_back_when_a_umi_equals_the_barcode(oracle):
-    """A UMI word equal to the cell barcode makes a false record-start candidate; the proof fails and the
-    cell is re-decoded by the sequential walk — still exact (DESIGN.md "walk-free decode")."""
-    s = synth.synth(8, [500, 700, 300], num_genes=100, dup=0.3)
-    s.cell_bc = np.asarray([0x00ABCDEF, 0x12345678, 0x00000044], dtype=np.uint64)
-    umi = s.umi.copy()
-    umi[10] = 0x00ABCDEF  # cell 0: UMI == barcode
-    s.umi = umi
-    refs = s.refs.copy()
-    na0 = int(s.na[: 500 + 700].sum())
-    refs[na0] = 0x44  # cell 2: first ref of its first read == barcode value (orientation bit set on the wire -> no match)
-    s.refs = refs
-    b, off = s.encode()
-    got, want, st = run_both(oracle, cfg_for(s), s.tid_to_gid, b, off)
-    assert st["n_fallback_cells"] >= 1
-    assert_same_result(got, want)
-
-
-def test_unaligned_chunk_offsets_use_the_sequential_walk(oracle):
-    """Chunks that do not start on a dword boundary (caller-chosen offsets) cannot take the walk-free path."""
-    s = synth.synth(9, [900, 40, 2600], num_genes=200, dup=0.4)
-    b, off = s.encode()
-    b = np.asarray(b)
-    pad = [3, 1, 2]
-    parts, offs, p = [], [], 0
-    for i in range(len(off)):
-        a = int(off[i])
-        e = int(off[i + 1]) if i + 1 < len(off) else len(b)
-        parts.append(np.zeros(pad[i], np.uint8))
-        p += pad[i]
-        offs.append(p)
-        parts.append(b[a:e])
-        p += e - a
-    b2 = np.concatenate(parts)
-    got, want, st = run_both(oracle, cfg_for(s), s.tid_to_gid, b2, np.asarray(offs, np.uint64))
-    assert_same_result(got, want)
+    s = synth.synth(6, [50], num_genes=20)
+    cells = [(1, [(5, [0])])]
+    b, off = rad.encode_cells(cells, 2, 2)  # parsimony needs dword fields
+    q = pkg.Quantifier(pkg.WorkerConfig.for_resolution("parsimony", num_genes=20, num_rows=20, bc_bytes=2, umi_bytes=2), s.tid_to_gid)
+    try:
+        with pytest.raises(pkg.AfqError) as e:
+            q.quant_chunks(b, off)
+        assert e.value.code == pkg._abi.AFQ_ERR_UNSUPPORTED
+    finally:
+        q.close()
 
 
 @pytest.mark.parametrize("usa", [False, True])

@@ -31,7 +31,7 @@ def test_pug_hand_cases(oracle):
 
 
 @pytest.mark.parametrize("usa", [False, True])
-@pytest.mark.parametrize("res", ["parsimony", "parsimony-em"])
+@pytest.mark.parametrize("res", ["parsimony", "parsimony-em", "parsimony-gene", "parsimony-gene-em"])
 def test_parsimony_synthetic(oracle, usa, res):
     """Ragged cells incl. tiny ones (cr-like fast path), 3 % UMI errors so the PUG has real components."""
     sizes = [12000, 5000, 1500, 700, 260, 250, 120, 99, 40, 3]
@@ -79,7 +79,7 @@ def test_components_beyond_one_wave(oracle):
     cells = [(77, reads), (78, reads[:130])]
     b, off = rad.encode_cells(cells, 4, 4)
     t2g = np.asarray([0, 0, 1, 1, 2, 2], np.uint32)
-    for res in ("parsimony", "parsimony-em"):
+    for res in ("parsimony", "parsimony-em", "parsimony-gene"):
         cfg = pkg.WorkerConfig.for_resolution(res, num_genes=3, num_rows=3, small_thresh=0)
         got, want = run_both(oracle, cfg, t2g, b, off)
         assert_same_result(got, want, what=res)
