@@ -1191,6 +1191,7 @@ __global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta,
                                              uint32_t* __restrict__ out_nnz, EmCfg cfg) {
     __shared__ uint32_t s_ws[kEmNT / 64];
     __shared__ uint32_t s_flag[2];
+    __shared__ __attribute__((aligned(16))) uint32_t s_tile[8192];  // 32 KiB sort tile
     const uint32_t cell = blockIdx.x;
     const CellMeta m = meta[cell];
     const uint32_t nU = nnz_unique[cell];
@@ -1237,7 +1238,7 @@ __global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta,
     // 1. classes = runs of equal labels in lexicographic order
     for (uint32_t i = threadIdx.x; i < M; i += kEmNT) order[i] = i;
     __syncthreads();
-    bitonic_sort_by<kEmNT>(order, M, lab_gt);
+    tiled_bitonic_sort_by<kEmNT, 8192>(order, M, lab_gt, s_tile);
     uint32_t K = 0;
     for (uint32_t base = 0; base < M; base += kEmNT) {
         const uint32_t i = base + threadIdx.x;
@@ -1302,7 +1303,7 @@ __global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta,
         nC = nsrc * mult;
     }
     __syncthreads();
-    bitonic_sort<kEmNT>(support, nC);
+    tiled_bitonic_sort_by<kEmNT, 8192>(support, nC, [](uint32_t a, uint32_t b) { return a > b; }, s_tile);
     uint32_t S = 0;
     for (uint32_t base = 0; base < nC; base += kEmNT) {  // in-place unique: position S+ex <= i, so reads stay ahead of writes
         const uint32_t i = base + threadIdx.x;
@@ -1339,7 +1340,7 @@ __global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta,
         }
     __syncthreads();
     // 4. inverted index: for every support entry the classes containing it, ascending class
-    bitonic_sort<kEmNT>(inv_pairs, Wc);
+    tiled_bitonic_sort_by<kEmNT, 4096>(inv_pairs, Wc, [](uint64_t a, uint64_t b) { return a > b; }, reinterpret_cast<uint64_t*>(s_tile));
     for (uint32_t s = threadIdx.x; s <= S; s += kEmNT) {  // slot_off[s] = first pair with support idx >= s
         uint32_t lo = 0, hi = Wc;
         while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)(inv_pairs[mid] >> 32) < s) lo = mid + 1; else hi = mid; }

@@ -135,6 +135,101 @@ __device__ __forceinline__ void set_err(DevStatus* st, uint32_t code, uint32_t c
 }
 
 
+
+// Same normalised network, but every run of stages whose comparators stay inside an aligned TILE of
+// elements is executed on an LDS copy of that tile: for n elements only the stages with a partner
+// distance >= TILE touch global memory (1+2+...+log2(np2/TILE) of them instead of log2(np2)^2/2).
+template <int NT, uint32_t TILE, typename T, typename Gt>
+__device__ __forceinline__ void tiled_bitonic_sort_by(T* a, uint32_t n, Gt gt, T* tile) {
+    if (n < 2) return;
+    uint32_t np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    auto ce_tile = [&](uint32_t l, uint32_t r, uint32_t lim) {
+        if (r < lim) {
+            T x = tile[l], y = tile[r];
+            if (gt(x, y)) { tile[l] = y; tile[r] = x; }
+        }
+    };
+    // stages with distance < TILE for level k (kk = min(k, TILE) gives the first in-tile stage), tile by tile
+    auto tile_pass = [&](uint32_t k, bool with_mirror) {
+        for (uint32_t t0 = 0; t0 < n; t0 += TILE) {
+            const uint32_t lim = (n - t0 < TILE) ? n - t0 : TILE;
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < lim; i += NT) tile[i] = a[t0 + i];
+            __syncthreads();
+            const uint32_t kk = k < TILE ? k : TILE;
+            if (with_mirror) {  // only when k <= TILE: the whole level lives in the tile
+                const uint32_t hk = kk >> 1;
+                for (uint32_t i = threadIdx.x; i < TILE / 2; i += NT) {
+                    const uint32_t blk = i / hk, o = i - blk * hk;
+                    ce_tile(blk * kk + o, blk * kk + (kk - 1 - o), lim);
+                }
+                __syncthreads();
+            }
+            for (uint32_t j = with_mirror ? (kk >> 2) : (TILE >> 1); j > 0; j >>= 1) {
+                for (uint32_t i = threadIdx.x; i < TILE / 2; i += NT) {
+                    const uint32_t l = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                    ce_tile(l, l + j, lim);
+                }
+                __syncthreads();
+            }
+            for (uint32_t i = threadIdx.x; i < lim; i += NT) a[t0 + i] = tile[i];
+        }
+        __syncthreads();
+    };
+    // levels that fit a tile: sort every tile completely in one visit
+    {
+        for (uint32_t t0 = 0; t0 < n; t0 += TILE) {
+            const uint32_t lim = (n - t0 < TILE) ? n - t0 : TILE;
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < lim; i += NT) tile[i] = a[t0 + i];
+            __syncthreads();
+            for (uint32_t k = 2; k <= TILE && k <= np2; k <<= 1) {
+                const uint32_t hk = k >> 1;
+                for (uint32_t i = threadIdx.x; i < TILE / 2; i += NT) {
+                    const uint32_t blk = i / hk, o = i - blk * hk;
+                    ce_tile(blk * k + o, blk * k + (k - 1 - o), lim);
+                }
+                __syncthreads();
+                for (uint32_t j = hk >> 1; j > 0; j >>= 1) {
+                    for (uint32_t i = threadIdx.x; i < TILE / 2; i += NT) {
+                        const uint32_t l = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                        ce_tile(l, l + j, lim);
+                    }
+                    __syncthreads();
+                }
+            }
+            for (uint32_t i = threadIdx.x; i < lim; i += NT) a[t0 + i] = tile[i];
+        }
+        __syncthreads();
+    }
+    const uint32_t half = np2 >> 1;
+    for (uint32_t k = 2 * TILE; k <= np2; k <<= 1) {
+        const uint32_t hk = k >> 1;
+        for (uint32_t i = threadIdx.x; i < half; i += NT) {  // mirror stage, global
+            const uint32_t blk = i / hk, o = i - blk * hk;
+            const uint32_t l = blk * k + o, r = blk * k + (k - 1 - o);
+            if (r < n) {
+                T x = a[l], y = a[r];
+                if (gt(x, y)) { a[l] = y; a[r] = x; }
+            }
+        }
+        __syncthreads();
+        for (uint32_t j = hk >> 1; j >= TILE; j >>= 1) {  // global stages
+            for (uint32_t i = threadIdx.x; i < half; i += NT) {
+                const uint32_t l = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                const uint32_t r = l + j;
+                if (r < n) {
+                    T x = a[l], y = a[r];
+                    if (gt(x, y)) { a[l] = y; a[r] = x; }
+                }
+            }
+            __syncthreads();
+        }
+        tile_pass(k, false);  // j = TILE/2 ... 1 inside the tiles
+    }
+}
+
 __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* a, uint32_t n, uint32_t x) {
     uint32_t lo = 0, hi = n;
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[mid] < x) lo = mid + 1; else hi = mid; }

@@ -25,6 +25,12 @@
 
 namespace afq {
 
+#ifdef AFQ_PUG_TIMING
+#define PUG_MARK(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) tmark[i] = wall_clock64(); } while (0)
+#else
+#define PUG_MARK(i) do {} while (0)
+#endif
+
 constexpr int kPugNT = 1024;
 constexpr uint32_t kVidBits = 20;                 // vertices per cell < 2^20
 constexpr uint32_t kMaxGenesPerLabel = 64;        // distinct genes of one molecule the device path carries
@@ -162,7 +168,15 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     __shared__ uint32_t s_flag[2];
     __shared__ unsigned long long s_ebase;
     __shared__ uint64_t s_mask[4][64];   // multi-word cover: UC, best, scratch
+    // 2^20-bit presence filter over the cell's UMIs (128 KiB of the CU's 160 KiB LDS): almost every one of the
+    // 1 + 3L neighbour probes of a vertex is a UMI that does not occur in the cell and is rejected here
+    // without touching the sorted vertex array.
+    __shared__ __attribute__((aligned(16))) uint32_t s_big[1u << 15];   // 128 KiB: sort tiles first, the filter later
+    uint32_t* s_bloom = s_big;
     __shared__ uint32_t s_bestv[kPugNT / 64], s_bestsz[kPugNT / 64];
+#ifdef AFQ_PUG_TIMING
+    __shared__ unsigned long long tmark[16];
+#endif
     const uint32_t cell = A.pug_cells[blockIdx.x];
     const CellMeta m = A.meta[cell];
     const uint32_t R = m.nrec;
@@ -209,6 +223,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     uint32_t* wlab = reinterpret_cast<uint32_t*>(comp_sorted + R);     // R  : WCC label
     uint32_t* local_idx = wlab + R;                                    // R  : vid -> index inside its component
 
+    PUG_MARK(0);
     // ---- 1. reads sorted by (label hash, umi, offset) ----
     {
         const uint64_t base = A.rd.rd_off[cell];
@@ -218,7 +233,9 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         }
     }
     __syncthreads();
-    bitonic_sort_by<kPugNT>(sr, R, [](const SortRec& a, const SortRec& b) { return rec_gt(a, b); });
+    tiled_bitonic_sort_by<kPugNT, 4096>(sr, R, [](const SortRec& a, const SortRec& b) { return rec_gt(a, b); },
+                                        reinterpret_cast<SortRec*>(s_big));
+    PUG_MARK(1);
     // ---- 2. vertices = distinct (label, umi); classes = distinct labels ----
     uint32_t V = 0, K = 0;
     for (uint32_t base = 0; base < R; base += kPugNT) {
@@ -319,6 +336,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     }
     __syncthreads();
     if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], cell); return; }
+    PUG_MARK(2);
     // ---- 3. class ids by first appearance; reference vertex ids ----
     for (uint32_t k = tid; k < K; k += kPugNT) c_order[k] = k;
     __syncthreads();
@@ -342,6 +360,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         vv_umi[vid] = v_umi[j]; vv_cnt[vid] = v_cnt[j]; vv_rec[vid] = c_rep[k]; vv_cls[vid] = k;
     }
     __syncthreads();
+    PUG_MARK(3);
     // ---- 4. vertices sorted by UMI for neighbour probing ----
     for (uint32_t v = tid; v < V; v += kPugNT) {
         if (vv_umi[v] >> (64 - kVidBits)) s_cnt[3] = kErrPugLimit;
@@ -349,38 +368,75 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     }
     __syncthreads();
     if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], cell); return; }
-    bitonic_sort<kPugNT>(us, V);
-    // out-neighbours of x: vertices y != x with overlapping labels and UMI distance 0, or distance 1 and
-    // count(y) < 2*count(x)  (has_edge, pugutils.rs:76-99: X->Y unless cy >= 2cx)
-    auto for_each_out = [&](uint32_t x, auto&& f) {
+    tiled_bitonic_sort_by<kPugNT, 8192>(us, V, [](uint64_t a, uint64_t b) { return a > b; }, reinterpret_cast<uint64_t*>(s_big));
+    for (uint32_t i = tid; i < (1u << 15); i += kPugNT) s_bloom[i] = 0;
+    __syncthreads();
+    auto bloom_bit = [](uint64_t umi) -> uint32_t { return (uint32_t)((umi * kHashMul) >> 44); };
+    auto bloom_bit2 = [](uint64_t umi) -> uint32_t { return (uint32_t)(((umi ^ (umi >> 23)) * 0xD6E8FEB86659FD93ull) >> 44); };
+    for (uint32_t v = tid; v < V; v += kPugNT) {
+        const uint32_t b = bloom_bit(vv_umi[v]), b2 = bloom_bit2(vv_umi[v]);
+        atomicOr(&s_bloom[b >> 5], 1u << (b & 31));
+        atomicOr(&s_bloom[b2 >> 5], 1u << (b2 & 31));
+    }
+    __syncthreads();
+    PUG_MARK(4);
+    // Edge generation in two steps so that the expensive part runs with full waves: (A) every vertex tests
+    // its 1 + 3L probe UMIs against the LDS filter and the survivors (probe UMI, vertex) go to a candidate
+    // list; (B) one thread per candidate binary-searches the UMI-sorted vertices and applies the edge rule.
+    const uint32_t nprobe = C.exact_umi ? 1u : 1u + 3u * C.umi_pairs;
+    auto probe_umi = [&](uint64_t ux, uint32_t pr) -> uint64_t {
+        if (!pr) return ux;
+        const uint32_t b = (pr - 1) / 3, d = (pr - 1) % 3 + 1;
+        return ux ^ ((uint64_t)d << (2 * b));
+    };
+    auto passes = [&](uint64_t pu) -> bool {
+        if (pu >> (64 - kVidBits)) return false;
+        const uint32_t b = bloom_bit(pu), b2 = bloom_bit2(pu);
+        return ((s_bloom[b >> 5] >> (b & 31)) & (s_bloom[b2 >> 5] >> (b2 & 31))) & 1u;
+    };
+    // (A) count, reserve, write candidates (pu << 20 | x)
+    uint32_t ncand_mine = 0;
+    for (uint32_t x = tid; x < V; x += kPugNT) {
         const uint64_t ux = vv_umi[x];
-        const uint32_t cx = vv_cnt[x], kx = vv_cls[x];
-        const Lab lx = vlab(x);
-        const uint32_t nprobe = C.exact_umi ? 1u : 1u + 3u * C.umi_pairs;
-        for (uint32_t pr = 0; pr < nprobe; ++pr) {
-            uint64_t pu = ux;
-            if (pr) {
-                const uint32_t b = (pr - 1) / 3, d = (pr - 1) % 3 + 1;
-                pu = ux ^ ((uint64_t)d << (2 * b));
-            }
-            if (pu >> (64 - kVidBits)) continue;
-            const uint64_t key = pu << kVidBits;
-            uint32_t lo = 0, hi = V;
-            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (us[mid] < key) lo = mid + 1; else hi = mid; }
-            for (; lo < V && (us[lo] >> kVidBits) == pu; ++lo) {
-                const uint32_t y = (uint32_t)us[lo] & ((1u << kVidBits) - 1);
-                if (y == x) continue;
-                if (pr && !(vv_cnt[y] < 2 * cx)) continue;
-                if (vv_cls[y] != kx && !lab_overlap(lx, vlab(y))) continue;
-                f(y);
+        for (uint32_t pr = 0; pr < nprobe; ++pr) ncand_mine += passes(probe_umi(ux, pr));
+    }
+    uint32_t NCAND;
+    const uint32_t cand_off = block_excl_scan<kPugNT>(ncand_mine, s_ws, NCAND);
+    if (tid == 0) s_ebase = atomicAdd(A.epool_cursor, 2ull * NCAND + 2);
+    __syncthreads();
+    if (s_ebase + 2ull * NCAND + 2 > A.epool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, cell); return; }
+    uint64_t* cand = reinterpret_cast<uint64_t*>(A.epool + ((s_ebase + 1) & ~1ull));
+    {
+        uint32_t o = cand_off;
+        for (uint32_t x = tid; x < V; x += kPugNT) {
+            const uint64_t ux = vv_umi[x];
+            for (uint32_t pr = 0; pr < nprobe; ++pr) {
+                const uint64_t pu = probe_umi(ux, pr);
+                if (passes(pu)) cand[o++] = (pu << kVidBits) | x;
             }
         }
-    };
-    for (uint32_t x = tid; x < V; x += kPugNT) {
-        uint32_t d = 0;
-        for_each_out(x, [&](uint32_t) { ++d; });
-        deg[x] = d;
     }
+    for (uint32_t x = tid; x <= V; x += kPugNT) deg[x] = 0;
+    __syncthreads();
+    // out-neighbours of x: vertices y != x with overlapping labels and UMI distance 0, or distance 1 and
+    // count(y) < 2*count(x)  (has_edge, pugutils.rs:76-99: X->Y unless cy >= 2cx)
+    auto for_each_edge_of = [&](uint64_t cd, auto&& f) {
+        const uint32_t x = (uint32_t)cd & ((1u << kVidBits) - 1);
+        const uint64_t pu = cd >> kVidBits;
+        const bool same = pu == vv_umi[x];
+        const uint32_t cx = vv_cnt[x], kx = vv_cls[x];
+        const uint64_t key = pu << kVidBits;
+        uint32_t lo = 0, hi = V;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (us[mid] < key) lo = mid + 1; else hi = mid; }
+        for (; lo < V && (us[lo] >> kVidBits) == pu; ++lo) {
+            const uint32_t y = (uint32_t)us[lo] & ((1u << kVidBits) - 1);
+            if (y == x) continue;
+            if (!same && !(vv_cnt[y] < 2 * cx)) continue;
+            if (vv_cls[y] != kx && !lab_overlap(vlab(x), vlab(y))) continue;
+            f(x, y);
+        }
+    };
+    for (uint32_t i = tid; i < NCAND; i += kPugNT) for_each_edge_of(cand[i], [&](uint32_t x, uint32_t) { atomicAdd(&deg[x], 1u); });
     __syncthreads();
     uint32_t E = 0;
     for (uint32_t base = 0; base < V; base += kPugNT) {
@@ -389,7 +445,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         uint32_t tot;
         const uint32_t ex = block_excl_scan<kPugNT>(d, s_ws, tot);
         __syncthreads();
-        if (x < V) deg[x] = E + ex;
+        if (x < V) { deg[x] = E + ex; c_order[x] = E + ex; }  // c_order (dead after phase 3) = per-vertex fill cursor
         E += tot;
     }
     if (tid == 0) {
@@ -399,11 +455,10 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     __syncthreads();
     if (s_ebase + E > A.epool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, cell); return; }
     uint32_t* edges = A.epool + s_ebase;
-    for (uint32_t x = tid; x < V; x += kPugNT) {
-        uint32_t o = deg[x];
-        for_each_out(x, [&](uint32_t y) { edges[o++] = y; });
-    }
+    for (uint32_t i = tid; i < NCAND; i += kPugNT)
+        for_each_edge_of(cand[i], [&](uint32_t x, uint32_t y) { edges[atomicAdd(&c_order[x], 1u)] = y; });
     __syncthreads();
+    PUG_MARK(5);
     // ---- 5. weakly connected components: min-label propagation + pointer jumping ----
     for (uint32_t v = tid; v < V; v += kPugNT) wlab[v] = v;
     __syncthreads();
@@ -427,10 +482,11 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         }
         if (!s_flag[0]) break;
     }
+    PUG_MARK(6);
     // a label may still point at a non-root after the last sweep; chase it
     for (uint32_t v = tid; v < V; v += kPugNT) { uint32_t l = wlab[v]; while (wlab[l] != l) l = wlab[l]; comp_sorted[v] = ((uint64_t)l << kVidBits) | v; }
     __syncthreads();
-    bitonic_sort<kPugNT>(comp_sorted, V);
+    tiled_bitonic_sort_by<kPugNT, 8192>(comp_sorted, V, [](uint64_t a, uint64_t b) { return a > b; }, reinterpret_cast<uint64_t*>(s_big));
     uint32_t NC = 0;
     for (uint32_t base = 0; base < V; base += kPugNT) {
         const uint32_t i = base + tid;
@@ -447,7 +503,22 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
             for (uint32_t i = comp_start[c]; i < comp_start[c + 1]; ++i) local_idx[(uint32_t)comp_sorted[i] & ((1u << kVidBits) - 1)] = i - comp_start[c];
     __syncthreads();
     auto vid_at = [&](uint32_t i) { return (uint32_t)comp_sorted[i] & ((1u << kVidBits) - 1); };
+    // work lists: almost every component is a single vertex; list the others once instead of rescanning
+    uint32_t* mid_list = reinterpret_cast<uint32_t*>(v_umi);  // slab B is dead: 2..64-vertex components
+    uint32_t* big_list = v_cnt;                               // > 64 vertices or over the large-graph threshold
+    if (tid < 2) s_flag[tid] = 0;
+    __syncthreads();
+    for (uint32_t c = tid; c < NC; c += kPugNT) {
+        const uint32_t n = comp_start[c + 1] - comp_start[c];
+        if (n < 2) continue;
+        if (n <= 64 && n <= C.large_thresh) mid_list[atomicAdd(&s_flag[0], 1u)] = c;
+        else big_list[atomicAdd(&s_flag[1], 1u)] = c;
+    }
+    __syncthreads();
+    const uint32_t n_mid = s_flag[0], n_big = s_flag[1];
+    __syncthreads();
 
+    PUG_MARK(7);
     // ---- 6a. single-vertex components: the label's genes (pugutils.rs:1262-1322) ----
     for (uint32_t c = tid; c < NC; c += kPugNT) {
         if (comp_start[c + 1] - comp_start[c] != 1) continue;
@@ -456,13 +527,24 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         const uint32_t ng = genes_of(C, l.n, [&](uint32_t j) { return l.p[j] & 0x7FFFFFFFu; }, g);
         emit_molecule(C, g, ng);
     }
+    PUG_MARK(8);
     // ---- 6b. components of 2..64 vertices: one wave each, adjacency = one 64-bit mask per lane ----
-    for (uint32_t c = wv; c < NC; c += kPugNT / 64) {
+    for (uint32_t ci = wv; ci < n_mid; ci += kPugNT / 64) {
+        const uint32_t c = mid_list[ci];
         const uint32_t c0 = comp_start[c], n = comp_start[c + 1] - c0;
-        if (n < 2 || n > 64 || n > C.large_thresh) continue;
         const bool act = lane < n;
         const uint32_t myv = act ? vid_at(c0 + lane) : 0u;
         const Lab myl = act ? vlab(myv) : Lab{nullptr, 0};
+        // labels are short: keep up to four refs of the lane's label in registers
+        uint32_t lr0 = 0xFFFFFFFFu, lr1 = 0xFFFFFFFFu, lr2 = 0xFFFFFFFFu, lr3 = 0xFFFFFFFFu;
+        if (myl.n > 0) lr0 = myl.p[0] & 0x7FFFFFFFu;
+        if (myl.n > 1) lr1 = myl.p[1] & 0x7FFFFFFFu;
+        if (myl.n > 2) lr2 = myl.p[2] & 0x7FFFFFFFu;
+        if (myl.n > 3) lr3 = myl.p[3] & 0x7FFFFFFFu;
+        auto my_contains = [&](uint32_t t) -> bool {
+            if (myl.n <= 4) return t == lr0 || t == lr1 || t == lr2 || t == lr3;
+            return lab_contains(myl, t);
+        };
         uint64_t adj = 0;
         if (act)
             for (uint32_t e = deg[myv]; e < deg[myv + 1]; ++e) adj |= 1ull << local_idx[edges[e]];
@@ -478,7 +560,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                 uint32_t mv_sz = 0;
                 for (uint32_t j = 0; j < lv.n; ++j) {
                     const uint32_t t = lv.p[j] & 0x7FFFFFFFu;
-                    const uint64_t At = __ballot(act && ((UC >> lane) & 1ull) && lab_contains(myl, t));
+                    const uint64_t At = __ballot(act && ((UC >> lane) & 1ull) && my_contains(t));
                     uint64_t Rm = 1ull << v, F = Rm;
                     while (F) {
                         const uint64_t N = wave_or64(((F >> lane) & 1ull) ? adj : 0ull);
@@ -500,7 +582,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
             bool wide = false;
             for (uint32_t j = 0; j < lf.n; ++j) {
                 const uint32_t t = lf.p[j] & 0x7FFFFFFFu;
-                const uint64_t has = __ballot(act && ((best >> lane) & 1ull) && lab_contains(myl, t));
+                const uint64_t has = __ballot(act && ((best >> lane) & 1ull) && my_contains(t));
                 if (has != best) continue;
                 if (lane == 0) {
                     const uint32_t gid = C.gene_level ? t : C.t2g[t];
@@ -517,11 +599,11 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         }
     }
     __syncthreads();
+    PUG_MARK(9);
     // ---- 6c. larger components, one at a time by the whole workgroup ----
-    for (uint32_t c = 0; c < NC; ++c) {
+    for (uint32_t ci = 0; ci < n_big; ++ci) {
+        const uint32_t c = big_list[ci];
         const uint32_t c0 = comp_start[c], n = comp_start[c + 1] - c0;
-        if (n <= 64 && n <= C.large_thresh) continue;
-        if (n < 2) continue;
         if (n > C.large_thresh) {
             // get_num_molecules_large_component (pugutils.rs:916-982): winner-take-all over the component's
             // (umi, gene, count) triplets.  Rare; thread 0 walks the triplets sorted by the workgroup.
@@ -704,6 +786,10 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         __syncthreads();
     }
     __syncthreads();
+    PUG_MARK(10);
+#ifdef AFQ_PUG_TIMING
+    if (tid == 0 && blockIdx.x == 0) { printf("pug cell R=%u:", R); for (int i = 1; i <= 10; ++i) printf(" p%d=%.2fms", i - 1, (double)(tmark[i] - tmark[i - 1]) / 1e5); printf("\n"); }
+#endif
     if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], cell); return; }
     if (tid == 0) {
         A.cell_ncols[cell] = s_cnt[0];
