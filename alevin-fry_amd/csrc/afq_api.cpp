@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -24,6 +25,18 @@ using namespace afq;
 namespace {
 
 thread_local std::string g_create_err;
+
+// AFQ_HOST_TIMING=1 prints where the host side of a batch spends its time (stderr)
+struct HostClock {
+    bool on = std::getenv("AFQ_HOST_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[afq host] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 
 struct DevBuf {
     void* p = nullptr;
@@ -247,6 +260,7 @@ int plan_ranges(afq_ctx* c) {
 
 // Plan + enqueue one range of cells on the context's stream.
 int run_range(afq_ctx* c, Range r) {
+    HostClock hc;
     const afq_config& g = c->cfg;
     const uint32_t H = hdr_bytes(g);
     const uint32_t n = r.c1 - r.c0;
@@ -354,6 +368,7 @@ int run_range(afq_ctx* c, Range r) {
         HIP_TRY(c, c->d_cell_bc.ensure(8ull * n));
     }
 
+    hc.lap("run: plan + ensure buffers");
     hipStream_t s = c->stream;
     if (par) {
         HIP_TRY(c, hipMemcpyAsync(c->d_slab_prefix.p, slab_prefix.data(), 4ull * (n + 1), hipMemcpyHostToDevice, s));
@@ -383,6 +398,7 @@ int run_range(afq_ctx* c, Range r) {
     HIP_TRY(c, hipMemsetAsync(c->d_bc.p, 0, 8ull * n, s));
     // the host copies above are sourced from stack/vector memory: make sure they are consumed
     HIP_TRY(c, hipStreamSynchronize(s));
+    hc.lap("run: uploads + memsets");
 
     DecodeArgs da{c->d_bytes, c->n_bytes, c->d_meta.as<CellMeta>(), n, c->d_t2g.as<uint32_t>(), c->ref_count,
                   g.num_genes, c->d_keys0.as<uint64_t>(), c->d_cell_nkeys.as<uint32_t>(),
@@ -390,7 +406,8 @@ int run_range(afq_ctx* c, Range r) {
                   par ? c->d_chk.as<CellChk>() : nullptr, c->d_slab_prefix.as<uint32_t>(), c->d_slab_cell.as<uint32_t>(),
                   c->d_cell_bc.as<uint64_t>(),
                   (uint32_t)n_slabs,
-                  PugOut{c->d_rd_h.as<uint64_t>(), c->d_rd_u.as<uint64_t>(), c->d_rd_o.as<uint32_t>(), c->d_rd_off.as<uint64_t>()}};
+                  n_pug ? PugOut{c->d_rd_h.as<uint64_t>(), c->d_rd_u.as<uint64_t>(), c->d_rd_o.as<uint32_t>(), c->d_rd_off.as<uint64_t>()}
+                        : PugOut{nullptr, nullptr, nullptr, nullptr}};
     if (par) {
         ScopedTimer t(c, K_DECODE_PAR);
         if (launch_decode_par(s, da, g.bc_bytes, g.umi_bytes)) return fail(c, AFQ_ERR_INVALID_ARG, "bad field widths");
@@ -428,6 +445,7 @@ int run_range(afq_ctx* c, Range r) {
     }
     if (!hist_cells.empty()) { ScopedTimer t(c, K_CELL_HIST); launch_cell_hist(s, ra); }
     HIP_TRY(c, hipGetLastError());
+    hc.lap("run: enqueue kernels");
     c->last_ra = ra;
     c->cur = r;
     c->range_in_flight = true;
@@ -441,9 +459,11 @@ int run_range(afq_ctx* c, Range r) {
 int finish_range(afq_ctx* c) {
     if (!c->range_in_flight) return 0;
     c->range_in_flight = false;
+    HostClock hc;
     const uint32_t n = c->cur.c1 - c->cur.c0;
     hipStream_t s = c->stream;
     HIP_TRY(c, hipStreamSynchronize(s));
+    hc.lap("finish: wait for kernels");
     DevStatus st{};
     HIP_TRY(c, hipMemcpy(&st, c->d_status.p, sizeof(st), hipMemcpyDeviceToHost));
     if (st.err_code) {
@@ -493,6 +513,7 @@ int finish_range(afq_ctx* c) {
     ptr[0] = 0;
     for (uint32_t i = 0; i < n; ++i) ptr[i + 1] = ptr[i] + nnz[i];
     const uint64_t tot = ptr[n];
+    hc.lap("finish: small D2H + prefix");
     HIP_TRY(c, c->d_cell_ptr.ensure(8ull * (n + 1)));
     HIP_TRY(c, c->d_gene.ensure(std::max<uint64_t>(4 * tot, 16)));
     HIP_TRY(c, c->d_val.ensure(std::max<uint64_t>(4 * tot, 16)));
@@ -517,6 +538,7 @@ int finish_range(afq_ctx* c) {
     }
     HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, hipGetLastError());
+    hc.lap("finish: compact + D2H of CSR");
     const afq_config& g = c->cfg;
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t nrec = c->hdr[2 * (c->cur.c0 + i) + 1];
@@ -532,6 +554,7 @@ int finish_range(afq_ctx* c) {
         R.mmrate.push_back(0.0);
     }
     harvest_timers(c);
+    hc.lap("finish: host result");
     return 0;
 }
 

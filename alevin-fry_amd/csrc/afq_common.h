@@ -19,8 +19,8 @@ constexpr uint64_t kKeySentinel = ~0ull;
 // A cell's keys are split into 2^lg_nb buckets by a multiplicative hash of the
 // UMI (all keys of one UMI share a bucket, which is all cr-like needs); one
 // workgroup sorts and resolves one bucket in LDS.
-constexpr uint32_t kBucketCap = 1024;    // keys the 2-wave resolve workgroup holds in LDS
-constexpr uint32_t kBucketTarget = 512;  // planned mean keys per bucket
+constexpr uint32_t kBucketCap = 512;     // keys the one-wave resolve workgroup holds in LDS
+constexpr uint32_t kBucketTarget = 256;  // planned mean keys per bucket
 constexpr uint32_t kMaxLgNb = 20;
 constexpr uint64_t kHashMul = 0x9E3779B97F4A7C15ull;
 

@@ -277,8 +277,8 @@ constexpr uint32_t kHalo = 64;
 constexpr uint32_t kDecodeCols = 8192;
 constexpr uint32_t kStage = kSlabWords + kHalo;  // 320 dwords = 5 per lane
 
-template <int BW, int UW>
-__global__ __launch_bounds__(256) void k_decode_par(const uint8_t* __restrict__ bytes,
+template <int BW, int UW, bool PUG>
+__global__ __launch_bounds__(256, 6) void k_decode_par(const uint8_t* __restrict__ bytes,
                                                    const CellMeta* __restrict__ meta, uint32_t n_cells,
                                                    const uint32_t* __restrict__ slab_prefix,
                                                    const uint32_t* __restrict__ slab_cell,
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void k_decode_par(const uint8_t* __restrict__ 
             }
             // request the next slab's dwords while the gathers above are in flight
             if (!prefetched && same_next) { issue_slab_loads(s0 + kSlabWords); prefetched = true; }
-            const bool pug_rec = act && mode_is_pug(m.mode);
+            const bool pug_rec = PUG && act && mode_is_pug(m.mode);
             uint64_t lhash = 0;
             const bool pug_gene = pug_rec && mode_pug_gene(m.mode);
             if (pug_rec && !pug_gene) {  // txp-level PUG: hash of the ref list
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void k_decode_par(const uint8_t* __restrict__ 
             if (tot) {
                 if (lane == 0) wbase = atomicAdd(&cell_nkeys[cur_cell], tot);
                 wbase = __builtin_amdgcn_readfirstlane(wbase);
-                if (wbase + tot > (mode_is_pug(m.mode) ? m.nrec : m.n_ref)) { fail = true; kcnt = 0; }
+                if (wbase + tot > ((PUG && mode_is_pug(m.mode)) ? m.nrec : m.n_ref)) { fail = true; kcnt = 0; }
             }
             if (pug_rec) {
                 if (kcnt) {
@@ -697,17 +697,49 @@ __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ mu
 // shuffle (j < 64), a register swap inside the thread (64 <= j < 64*E) or, only
 // for j >= 64*E, a trip through LDS with barriers - 3 such stages for N <= 2048
 // instead of one barrier per stage (45-66) with the data in LDS.
-template <typename T>
-__device__ __forceinline__ T shfl_xor_t(T v, int j);
-template <>
-__device__ __forceinline__ uint64_t shfl_xor_t<uint64_t>(uint64_t v, int j) {
-    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    lo = __shfl_xor(lo, j);
-    hi = __shfl_xor(hi, j);
-    return ((uint64_t)hi << 32) | lo;
+// Cross-lane exchange lane <-> lane^J on the VALU instead of ds_bpermute (which occupies the LDS pipe, the
+// bottleneck of the bitonic sort): DPP quad permutes for J = 1, 2; two bank-masked DPP row shifts for J = 4, 8;
+// gfx950's v_permlane16_swap / v_permlane32_swap for J = 16, 32 (semantics checked on hardware, scratch/dpp_probe.hip).
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+template <int J>
+__device__ __forceinline__ uint32_t xor_lane32(uint32_t x) {
+    if constexpr (J == 1) return __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false);
+    else if constexpr (J == 2) return __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false);
+    else if constexpr (J == 4) {
+        uint32_t t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);   // row_shl:4 into banks 0,2
+        return __builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false);          // row_shr:4 into banks 1,3
+    } else if constexpr (J == 8) {
+        uint32_t t = __builtin_amdgcn_update_dpp(x, x, 0x108, 0xF, 0x3, false);   // row_shl:8 into banks 0,1
+        return __builtin_amdgcn_update_dpp(t, x, 0x118, 0xF, 0xC, false);          // row_shr:8 into banks 2,3
+    } else if constexpr (J == 16) {
+        const v2u_t p = __builtin_amdgcn_permlane16_swap(x, x, false, false);      // .x = rows {0,0,2,2}, .y = rows {1,1,3,3}
+        return (lane_id() & 16u) ? p.x : p.y;
+    } else {
+        const v2u_t p = __builtin_amdgcn_permlane32_swap(x, x, false, false);      // .x = lower half twice, .y = upper half twice
+        return (lane_id() & 32u) ? p.x : p.y;
+    }
 }
-template <>
-__device__ __forceinline__ uint32_t shfl_xor_t<uint32_t>(uint32_t v, int j) { return __shfl_xor(v, j); }
+template <int J, typename T>
+__device__ __forceinline__ T xor_lane(T v);
+template <int J, typename T>
+__device__ __forceinline__ T xor_lane(T v) {
+    if constexpr (sizeof(T) == 8) {
+        const uint32_t lo = xor_lane32<J>((uint32_t)v), hi = xor_lane32<J>((uint32_t)((uint64_t)v >> 32));
+        return (T)(((uint64_t)hi << 32) | lo);
+    } else return (T)xor_lane32<J>((uint32_t)v);
+}
+
+template <int E, int J, typename T>
+__device__ __forceinline__ void lane_stage(T (&a)[E], uint32_t idx0, uint32_t k) {
+#pragma unroll
+    for (int h = 0; h < E; ++h) {
+        const uint32_t idx = idx0 + h * 64;
+        const T o = xor_lane<J, T>(a[h]);
+        const bool want_min = (((idx & J) == 0) == ((idx & k) == 0));
+        const T mn = a[h] < o ? a[h] : o, mx = a[h] < o ? o : a[h];
+        a[h] = want_min ? mn : mx;
+    }
+}
 
 template <int E, int JH, typename T>
 __device__ __forceinline__ void reg_stage(T (&a)[E], uint32_t idx0, uint32_t k) {
@@ -731,13 +763,13 @@ __device__ __forceinline__ void reg_bitonic_sort(T (&a)[E], T* s_x) {
     for (uint32_t k = 2; k <= N; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
             if (j < 64) {
-#pragma unroll
-                for (int h = 0; h < E; ++h) {
-                    const uint32_t idx = wbase + h * 64 + lane;
-                    const T o = shfl_xor_t<T>(a[h], (int)j);
-                    const bool want_min = (((idx & j) == 0) == ((idx & k) == 0));
-                    const T mn = a[h] < o ? a[h] : o, mx = a[h] < o ? o : a[h];
-                    a[h] = want_min ? mn : mx;
+                switch (j) {
+                    case 1: lane_stage<E, 1, T>(a, wbase + lane, k); break;
+                    case 2: lane_stage<E, 2, T>(a, wbase + lane, k); break;
+                    case 4: lane_stage<E, 4, T>(a, wbase + lane, k); break;
+                    case 8: lane_stage<E, 8, T>(a, wbase + lane, k); break;
+                    case 16: lane_stage<E, 16, T>(a, wbase + lane, k); break;
+                    default: lane_stage<E, 32, T>(a, wbase + lane, k); break;
                 }
             } else if (j < 64 * E) {
                 // partner is another register of the same thread; keep the indices compile-time
@@ -1008,9 +1040,9 @@ __device__ __forceinline__ void resolve_bucket_lds(const BucketDesc& d, uint64_t
 // (column-major walk) so their reservations do not pile onto one counter.
 // Single-bucket cells are finished here; buckets of multi-bucket cells append their
 // resolved columns to the cell's column list, counted later by k_cell_hist.
-constexpr int kResolveNT = 128;
+constexpr int kResolveNT = 64;
 constexpr uint32_t kResolveCols = 8192;
-static_assert(kBucketCap == kResolveNT * 8, "bucket cap = 8 keys per thread");
+static_assert(kBucketCap <= kResolveNT * 8, "bucket cap <= 8 keys per thread");
 template <bool EM>
 __global__ __launch_bounds__(kResolveNT) void k_resolve(const BucketDesc* __restrict__ desc, uint32_t n_buckets,
                                                        uint64_t* __restrict__ keys0,
@@ -1537,9 +1569,14 @@ static void launch_decode_par_t(hipStream_t s, const DecodeArgs& a) {
     const uint32_t n_groups = (a.n_slabs + kSlabsPerWave - 1) / kSlabsPerWave;
     const uint32_t n_cols = n_groups < kDecodeCols ? n_groups : kDecodeCols;
     const uint32_t n_waves = n_cols * ((n_groups + n_cols - 1) / n_cols);
-    AFQ_LAUNCH((k_decode_par<BW, UW>), (n_waves + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix, a.slab_cell,
-               a.cell_bc, a.n_slabs, a.t2g, a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out,
-               const_cast<CellChk*>(a.chk), a.pug);
+    if (a.pug.h)  // the batch has PUG cells: instance that also emits (label hash, umi, offset) per read
+        AFQ_LAUNCH((k_decode_par<BW, UW, true>), (n_waves + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix, a.slab_cell,
+                   a.cell_bc, a.n_slabs, a.t2g, a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out,
+                   const_cast<CellChk*>(a.chk), a.pug);
+    else
+        AFQ_LAUNCH((k_decode_par<BW, UW, false>), (n_waves + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix, a.slab_cell,
+                   a.cell_bc, a.n_slabs, a.t2g, a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out,
+                   const_cast<CellChk*>(a.chk), a.pug);
 }
 
 bool decode_par_supported(uint32_t bw, uint32_t uw) { return (bw == 4 || bw == 8) && (uw == 4 || uw == 8); }
