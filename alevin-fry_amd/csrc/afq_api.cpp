@@ -125,6 +125,26 @@ void pool_put(HostResult* r) {
 
 struct Range { uint32_t c0, c1; };
 
+struct RangeState {
+    hipStream_t stream = nullptr;
+    DevBuf d_meta, d_keys0, d_keys1, d_cell_nkeys, d_bucket_cnt, d_bucket_cell, d_multi_cells, d_tile_prefix, d_ncols,
+        d_nnz, d_ovf, d_status, d_bc, d_cell_ptr, d_gene, d_val, d_chk, d_slab_prefix, d_slab_cell, d_cell_bc, d_bdesc, d_lab,
+        d_lab_cnt, d_em_off, d_em_scratch, d_em_nnz, d_pug_cells, d_rd_off, d_rd_h, d_rd_u, d_rd_o, d_pug_scr_off,
+        d_pug_scratch, d_epool, d_epool_cur, d_alt, d_hist_cells;
+    ResolveArgs last_ra{};
+    std::vector<CellMeta> meta;
+    Range cur{};
+    bool in_flight = false;
+    hipEvent_t kernels_done = nullptr;
+    std::vector<TimedLaunch> launches;  // HIP-event brackets of this range's kernels (cfg.profile)
+    std::vector<DevBuf*> all() {
+        return {&d_meta, &d_keys0, &d_keys1, &d_cell_nkeys, &d_bucket_cnt, &d_bucket_cell, &d_multi_cells, &d_tile_prefix,
+                &d_ncols, &d_nnz, &d_ovf, &d_status, &d_bc, &d_cell_ptr, &d_gene, &d_val, &d_chk, &d_slab_prefix, &d_slab_cell,
+                &d_cell_bc, &d_bdesc, &d_lab, &d_lab_cnt, &d_em_off, &d_em_scratch, &d_em_nnz, &d_pug_cells, &d_rd_off, &d_rd_h,
+                &d_rd_u, &d_rd_o, &d_pug_scr_off, &d_pug_scratch, &d_epool, &d_epool_cur, &d_alt, &d_hist_cells};
+    }
+};
+
 }  // namespace
 
 struct afq_ctx {
@@ -138,21 +158,16 @@ struct afq_ctx {
     DevBuf d_bytes_own;
     const uint8_t* d_bytes = nullptr;
     size_t n_bytes = 0;
-    // per-range device state
-    DevBuf d_meta, d_keys0, d_keys1, d_cell_nkeys, d_bucket_cnt, d_bucket_cell, d_multi_cells, d_tile_prefix, d_ncols,
-        d_nnz, d_ovf, d_status, d_bc, d_cell_ptr, d_gene, d_val, d_chunk_off, d_hdr, d_chk, d_slab_prefix, d_slab_cell, d_cell_bc, d_bdesc, d_lab, d_lab_cnt, d_em_off, d_em_scratch, d_em_nnz,
-        d_pug_cells, d_rd_off, d_rd_h, d_rd_u, d_rd_o, d_pug_scr_off, d_pug_scratch, d_epool, d_epool_cur, d_alt, d_hist_cells;
-    ResolveArgs last_ra{};
+    DevBuf d_chunk_off, d_hdr;
+    // Two sets of per-range device state: while the rows of range i cross PCIe, the kernels of range i+1 run.
+    RangeState rs[2];
     bool all_aligned = true;  // every chunk offset is a multiple of 4
     ResultPool* pool = nullptr;
     // host planning state
     std::vector<uint64_t> chunk_off;
     std::vector<uint32_t> hdr;  // nbytes, nrec per cell
-    std::vector<CellMeta> meta;  // current range
     std::vector<Range> ranges;
     size_t next_range = 0;
-    bool range_in_flight = false;
-    Range cur{};
     uint64_t first_cell_index = 0;
     uint32_t n_cells = 0;
     bool pending = false;
@@ -187,16 +202,18 @@ hipEvent_t get_event(afq_ctx* c) {
 }
 
 struct ScopedTimer {
-    afq_ctx* c; int id; hipEvent_t a = nullptr, b = nullptr;
-    ScopedTimer(afq_ctx* c_, int id_) : c(c_), id(id_) {
-        if (c->cfg.profile) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, c->stream); }
+    afq_ctx* c; int id; hipStream_t s; std::vector<TimedLaunch>* sink; hipEvent_t a = nullptr, b = nullptr;
+    ScopedTimer(afq_ctx* c_, int id_, hipStream_t s_ = nullptr, std::vector<TimedLaunch>* sink_ = nullptr)
+        : c(c_), id(id_), s(s_ ? s_ : c_->stream), sink(sink_ ? sink_ : &c_->launches) {
+        if (c->cfg.profile) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, s); }
     }
     ~ScopedTimer() {
-        if (c->cfg.profile) { (void)hipEventRecord(b, c->stream); c->launches.push_back({id, a, b}); }
+        if (c->cfg.profile) { (void)hipEventRecord(b, s); sink->push_back({id, a, b}); }
     }
 };
 
-void harvest_timers(afq_ctx* c) {
+void harvest_timers(afq_ctx* c, std::vector<TimedLaunch>* list = nullptr) {
+    if (list) { c->launches.insert(c->launches.end(), list->begin(), list->end()); list->clear(); }
     for (auto& t : c->launches) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { c->k_ms[t.id] += ms; c->k_launches[t.id] += 1; }
@@ -227,12 +244,16 @@ int plan_ranges(afq_ctx* c) {
     size_t free_b = 0, total_b = 0;
     HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
     // buffers already held by this context are reusable
-    size_t held = c->d_keys0.cap + c->d_keys1.cap;
-    const double budget = 0.80 * (double)(free_b + held);
-    c->ranges.clear();
+    size_t held = 0;
+    for (auto& rs : c->rs) for (DevBuf* b : rs.all()) held += b->cap;
+    const double mem_budget = 0.40 * (double)(free_b + held);  // two range buffer sets are alive at a time
+    const uint32_t res = c->cfg.resolution;
+    const bool em_res = res == AFQ_RES_CR_LIKE_EM || res == AFQ_RES_PARSIMONY_EM || res == AFQ_RES_PARSIMONY_GENE_EM;
+    const bool pug_res = res >= AFQ_RES_PARSIMONY_EM && res <= AFQ_RES_PARSIMONY_GENE;
+    // pass 1: validate the chunk headers, device bytes each cell needs
+    std::vector<double> need(c->n_cells);
+    double total_need = 0;
     c->all_aligned = true;
-    double used = 0;
-    uint32_t c0 = 0;
     for (uint32_t i = 0; i < c->n_cells; ++i) {
         const uint64_t off = c->chunk_off[i];
         if (off & 3) c->all_aligned = false;
@@ -244,27 +265,38 @@ int plan_ranges(afq_ctx* c) {
         if (fixed > nbytes || ((nbytes - fixed) & 3))
             return fail(c, AFQ_ERR_BAD_INPUT, "cell " + std::to_string(i) + ": chunk nbytes does not match its records");
         const uint64_t n_ref = (nbytes - fixed) / 4;
-        const uint32_t rs = c->cfg.resolution;
-        const bool em_res = rs == AFQ_RES_CR_LIKE_EM || rs == AFQ_RES_PARSIMONY_EM || rs == AFQ_RES_PARSIMONY_GENE_EM;
-        const bool pug_res = rs >= AFQ_RES_PARSIMONY_EM && rs <= AFQ_RES_PARSIMONY_GENE;
-        double need = (em_res ? 24.0 + 40.0 * (c->cfg.usa_mode ? 3 : 1) : 16.0) * (double)n_ref + 128.0;
-        if (pug_res) need += 4.0 * (double)pug_scratch_words(nrec, (uint32_t)n_ref, true) + 20.0 * nrec + 64.0 * nrec;
-        if (n_ref > kBucketTarget) need += 16.0 * (double)(n_ref / kBucketTarget + 1);
-        if (need > budget) return fail(c, AFQ_ERR_OOM, "cell " + std::to_string(i) + " alone exceeds device memory");
-        if (used + need > budget) { c->ranges.push_back({c0, i}); c0 = i; used = 0; }
-        used += need;
+        double nd = (em_res ? 24.0 + 40.0 * (c->cfg.usa_mode ? 3 : 1) : 16.0) * (double)n_ref + 128.0;
+        if (pug_res) nd += 4.0 * (double)pug_scratch_words(nrec, (uint32_t)n_ref, true) + 20.0 * nrec + 64.0 * nrec;
+        if (n_ref > kBucketTarget) nd += 16.0 * (double)(n_ref / kBucketTarget + 1);
+        if (nd > mem_budget) return fail(c, AFQ_ERR_OOM, "cell " + std::to_string(i) + " alone exceeds device memory");
+        need[i] = nd;
+        total_need += nd;
+    }
+    // pass 2: cut into ranges.  Big batches are cut into about kPipeRanges ranges of equal work even when memory
+    // would allow one, so that the D2H of one range's rows hides under the kernels of the next.
+    constexpr double kPipeRanges = 4.0;
+    double budget = mem_budget;
+    if (c->n_bytes >= (256u << 20)) budget = std::min(budget, total_need / kPipeRanges * 1.02 + 1.0);
+    if (const char* e = std::getenv("AFQ_RANGE_BYTES")) budget = std::min(budget, std::atof(e));  // tests: force many ranges
+    c->ranges.clear();
+    double used = 0;
+    uint32_t c0 = 0;
+    for (uint32_t i = 0; i < c->n_cells; ++i) {
+        if (used + need[i] > budget && i > c0) { c->ranges.push_back({c0, i}); c0 = i; used = 0; }
+        used += need[i];
     }
     if (c->n_cells > c0) c->ranges.push_back({c0, c->n_cells});
     return 0;
 }
 
 // Plan + enqueue one range of cells on the context's stream.
-int run_range(afq_ctx* c, Range r) {
+int run_range(afq_ctx* c, Range r, int slot) {
     HostClock hc;
+    RangeState& B = c->rs[slot];
     const afq_config& g = c->cfg;
     const uint32_t H = hdr_bytes(g);
     const uint32_t n = r.c1 - r.c0;
-    c->meta.resize(n);
+    B.meta.resize(n);
     std::vector<uint32_t> multi, tile_prefix, bucket_cell, slab_prefix, pug_cells, hist_cells;
     std::vector<uint64_t> rd_off(n, 0), pug_scr;
     uint64_t n_pug_reads = 0, pug_words = 0;
@@ -274,7 +306,7 @@ int run_range(afq_ctx* c, Range r) {
     uint64_t nrec_total = 0;
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t ci = r.c0 + i;
-        CellMeta& m = c->meta[i];
+        CellMeta& m = B.meta[i];
         m.chunk_off = c->chunk_off[ci];
         m.nbytes = c->hdr[2 * ci];
         m.nrec = c->hdr[2 * ci + 1];
@@ -319,23 +351,23 @@ int run_range(afq_ctx* c, Range r) {
     tile_prefix.push_back((uint32_t)n_tiles);
     bucket_cell.resize(n_buckets);
     for (uint32_t i = 0; i < n; ++i) {
-        const CellMeta& m = c->meta[i];
+        const CellMeta& m = B.meta[i];
         std::fill(bucket_cell.begin() + m.bucket_base, bucket_cell.begin() + m.bucket_base + (1u << m.lg_nb), i);
     }
     const uint32_t n_multi = (uint32_t)multi.size();
 
-    HIP_TRY(c, c->d_meta.ensure(sizeof(CellMeta) * n));
-    HIP_TRY(c, c->d_keys0.ensure(8 * key_off));
-    HIP_TRY(c, c->d_keys1.ensure(n_multi ? 8 * key_off : 8));
-    HIP_TRY(c, c->d_cell_nkeys.ensure(4ull * n));
-    HIP_TRY(c, c->d_bucket_cnt.ensure(4 * n_buckets));
-    HIP_TRY(c, c->d_bucket_cell.ensure(4 * n_buckets));
-    HIP_TRY(c, c->d_multi_cells.ensure(4ull * std::max<uint32_t>(n_multi, 1)));
-    HIP_TRY(c, c->d_tile_prefix.ensure(4ull * (n_multi + 1)));
-    HIP_TRY(c, c->d_ncols.ensure(4ull * n));
-    HIP_TRY(c, c->d_nnz.ensure(4ull * n));
-    HIP_TRY(c, c->d_ovf.ensure(sizeof(OverflowEnt) * std::max<uint64_t>(n_buckets, 1)));
-    HIP_TRY(c, c->d_bdesc.ensure(bucket_desc_bytes() * std::max<uint64_t>(n_buckets, 1)));
+    HIP_TRY(c, B.d_meta.ensure(sizeof(CellMeta) * n));
+    HIP_TRY(c, B.d_keys0.ensure(8 * key_off));
+    HIP_TRY(c, B.d_keys1.ensure(n_multi ? 8 * key_off : 8));
+    HIP_TRY(c, B.d_cell_nkeys.ensure(4ull * n));
+    HIP_TRY(c, B.d_bucket_cnt.ensure(4 * n_buckets));
+    HIP_TRY(c, B.d_bucket_cell.ensure(4 * n_buckets));
+    HIP_TRY(c, B.d_multi_cells.ensure(4ull * std::max<uint32_t>(n_multi, 1)));
+    HIP_TRY(c, B.d_tile_prefix.ensure(4ull * (n_multi + 1)));
+    HIP_TRY(c, B.d_ncols.ensure(4ull * n));
+    HIP_TRY(c, B.d_nnz.ensure(4ull * n));
+    HIP_TRY(c, B.d_ovf.ensure(sizeof(OverflowEnt) * std::max<uint64_t>(n_buckets, 1)));
+    HIP_TRY(c, B.d_bdesc.ensure(bucket_desc_bytes() * std::max<uint64_t>(n_buckets, 1)));
     const bool em = g.resolution == AFQ_RES_CR_LIKE_EM || g.resolution == AFQ_RES_PARSIMONY_EM || g.resolution == AFQ_RES_PARSIMONY_GENE_EM;
     const uint32_t n_pug = (uint32_t)pug_cells.size();
     if (n_pug && !par) return fail(c, AFQ_ERR_UNSUPPORTED, "device parsimony needs dword-aligned chunk offsets");
@@ -343,112 +375,119 @@ int run_range(afq_ctx* c, Range r) {
     hist_cells.insert(hist_cells.end(), pug_cells.begin(), pug_cells.end());
     const uint64_t epool_words = 16 * n_pug_reads + (1ull << 22);
     if (n_pug) {
-        HIP_TRY(c, c->d_pug_cells.ensure(4ull * n_pug));
-        HIP_TRY(c, c->d_rd_off.ensure(8ull * n));
-        HIP_TRY(c, c->d_rd_h.ensure(8 * n_pug_reads + 8));
-        HIP_TRY(c, c->d_rd_u.ensure(8 * n_pug_reads + 8));
-        HIP_TRY(c, c->d_rd_o.ensure(4 * n_pug_reads + 8));
-        HIP_TRY(c, c->d_pug_scr_off.ensure(8ull * n_pug));
-        HIP_TRY(c, c->d_pug_scratch.ensure(4 * pug_words + 64));
-        HIP_TRY(c, c->d_epool.ensure(4 * epool_words));
-        HIP_TRY(c, c->d_epool_cur.ensure(8));
+        HIP_TRY(c, B.d_pug_cells.ensure(4ull * n_pug));
+        HIP_TRY(c, B.d_rd_off.ensure(8ull * n));
+        HIP_TRY(c, B.d_rd_h.ensure(8 * n_pug_reads + 8));
+        HIP_TRY(c, B.d_rd_u.ensure(8 * n_pug_reads + 8));
+        HIP_TRY(c, B.d_rd_o.ensure(4 * n_pug_reads + 8));
+        HIP_TRY(c, B.d_pug_scr_off.ensure(8ull * n_pug));
+        HIP_TRY(c, B.d_pug_scratch.ensure(4 * pug_words + 64));
+        HIP_TRY(c, B.d_epool.ensure(4 * epool_words));
+        HIP_TRY(c, B.d_epool_cur.ensure(8));
     }
-    HIP_TRY(c, c->d_alt.ensure(4ull * n));
-    HIP_TRY(c, c->d_hist_cells.ensure(4ull * std::max<size_t>(hist_cells.size(), 1)));
+    HIP_TRY(c, B.d_alt.ensure(4ull * n));
+    HIP_TRY(c, B.d_hist_cells.ensure(4ull * std::max<size_t>(hist_cells.size(), 1)));
     if (em) {
-        HIP_TRY(c, c->d_lab.ensure(8 * key_off));
-        HIP_TRY(c, c->d_lab_cnt.ensure(8ull * n));
+        HIP_TRY(c, B.d_lab.ensure(8 * key_off));
+        HIP_TRY(c, B.d_lab_cnt.ensure(8ull * n));
     }
-    HIP_TRY(c, c->d_status.ensure(sizeof(DevStatus)));
-    HIP_TRY(c, c->d_bc.ensure(8ull * n));
+    HIP_TRY(c, B.d_status.ensure(sizeof(DevStatus)));
+    HIP_TRY(c, B.d_bc.ensure(8ull * n));
     if (par) {
-        HIP_TRY(c, c->d_chk.ensure(sizeof(CellChk) * n));
-        HIP_TRY(c, c->d_slab_prefix.ensure(4ull * (n + 1)));
-        HIP_TRY(c, c->d_slab_cell.ensure(4ull * std::max<uint64_t>(n_slabs, 1)));
-        HIP_TRY(c, c->d_cell_bc.ensure(8ull * n));
+        HIP_TRY(c, B.d_chk.ensure(sizeof(CellChk) * n));
+        HIP_TRY(c, B.d_slab_prefix.ensure(4ull * (n + 1)));
+        HIP_TRY(c, B.d_slab_cell.ensure(4ull * std::max<uint64_t>(n_slabs, 1)));
+        HIP_TRY(c, B.d_cell_bc.ensure(8ull * n));
     }
 
     hc.lap("run: plan + ensure buffers");
-    hipStream_t s = c->stream;
+    hipStream_t s = B.stream;
+    {   // this range's kernels start after the previous range's kernels (clean per-kernel timings, no cache
+        // thrash between ranges); what overlaps them is the previous range's D2H
+        RangeState& O = c->rs[slot ^ 1];
+        if (O.in_flight && O.kernels_done) HIP_TRY(c, hipStreamWaitEvent(s, O.kernels_done, 0));
+    }
     if (par) {
-        HIP_TRY(c, hipMemcpyAsync(c->d_slab_prefix.p, slab_prefix.data(), 4ull * (n + 1), hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemsetAsync(c->d_chk.p, 0, sizeof(CellChk) * n, s));
-        HIP_TRY(c, hipMemsetAsync(c->d_cell_nkeys.p, 0, 4ull * n, s));
+        HIP_TRY(c, hipMemcpyAsync(B.d_slab_prefix.p, slab_prefix.data(), 4ull * (n + 1), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemsetAsync(B.d_chk.p, 0, sizeof(CellChk) * n, s));
+        HIP_TRY(c, hipMemsetAsync(B.d_cell_nkeys.p, 0, 4ull * n, s));
     }
-    HIP_TRY(c, hipMemcpyAsync(c->d_meta.p, c->meta.data(), sizeof(CellMeta) * n, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->d_bucket_cell.p, bucket_cell.data(), 4 * n_buckets, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(B.d_meta.p, B.meta.data(), sizeof(CellMeta) * n, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(B.d_bucket_cell.p, bucket_cell.data(), 4 * n_buckets, hipMemcpyHostToDevice, s));
     if (n_multi) {
-        HIP_TRY(c, hipMemcpyAsync(c->d_multi_cells.p, multi.data(), 4ull * n_multi, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemcpyAsync(c->d_tile_prefix.p, tile_prefix.data(), 4ull * (n_multi + 1), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(B.d_multi_cells.p, multi.data(), 4ull * n_multi, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(B.d_tile_prefix.p, tile_prefix.data(), 4ull * (n_multi + 1), hipMemcpyHostToDevice, s));
     }
-    HIP_TRY(c, hipMemsetAsync(c->d_bucket_cnt.p, 0, 4 * n_buckets, s));
-    HIP_TRY(c, hipMemsetAsync(c->d_nnz.p, 0, 4ull * n, s));
-    HIP_TRY(c, hipMemsetAsync(c->d_ncols.p, 0, 4ull * n, s));
-    if (em) HIP_TRY(c, hipMemsetAsync(c->d_lab_cnt.p, 0, 8ull * n, s));
-    HIP_TRY(c, hipMemsetAsync(c->d_alt.p, 0, 4ull * n, s));
+    HIP_TRY(c, hipMemsetAsync(B.d_bucket_cnt.p, 0, 4 * n_buckets, s));
+    HIP_TRY(c, hipMemsetAsync(B.d_nnz.p, 0, 4ull * n, s));
+    HIP_TRY(c, hipMemsetAsync(B.d_ncols.p, 0, 4ull * n, s));
+    if (em) HIP_TRY(c, hipMemsetAsync(B.d_lab_cnt.p, 0, 8ull * n, s));
+    HIP_TRY(c, hipMemsetAsync(B.d_alt.p, 0, 4ull * n, s));
     if (!hist_cells.empty())
-        HIP_TRY(c, hipMemcpyAsync(c->d_hist_cells.p, hist_cells.data(), 4ull * hist_cells.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(B.d_hist_cells.p, hist_cells.data(), 4ull * hist_cells.size(), hipMemcpyHostToDevice, s));
     if (n_pug) {
-        HIP_TRY(c, hipMemcpyAsync(c->d_pug_cells.p, pug_cells.data(), 4ull * n_pug, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemcpyAsync(c->d_rd_off.p, rd_off.data(), 8ull * n, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemcpyAsync(c->d_pug_scr_off.p, pug_scr.data(), 8ull * n_pug, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemsetAsync(c->d_epool_cur.p, 0, 8, s));
+        HIP_TRY(c, hipMemcpyAsync(B.d_pug_cells.p, pug_cells.data(), 4ull * n_pug, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(B.d_rd_off.p, rd_off.data(), 8ull * n, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(B.d_pug_scr_off.p, pug_scr.data(), 8ull * n_pug, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemsetAsync(B.d_epool_cur.p, 0, 8, s));
     }
-    HIP_TRY(c, hipMemsetAsync(c->d_status.p, 0, sizeof(DevStatus), s));
-    HIP_TRY(c, hipMemsetAsync(c->d_bc.p, 0, 8ull * n, s));
+    HIP_TRY(c, hipMemsetAsync(B.d_status.p, 0, sizeof(DevStatus), s));
+    HIP_TRY(c, hipMemsetAsync(B.d_bc.p, 0, 8ull * n, s));
     // the host copies above are sourced from stack/vector memory: make sure they are consumed
     HIP_TRY(c, hipStreamSynchronize(s));
     hc.lap("run: uploads + memsets");
 
-    DecodeArgs da{c->d_bytes, c->n_bytes, c->d_meta.as<CellMeta>(), n, c->d_t2g.as<uint32_t>(), c->ref_count,
-                  g.num_genes, c->d_keys0.as<uint64_t>(), c->d_cell_nkeys.as<uint32_t>(),
-                  c->d_bc.as<uint64_t>(), c->d_status.as<DevStatus>(),
-                  par ? c->d_chk.as<CellChk>() : nullptr, c->d_slab_prefix.as<uint32_t>(), c->d_slab_cell.as<uint32_t>(),
-                  c->d_cell_bc.as<uint64_t>(),
+    DecodeArgs da{c->d_bytes, c->n_bytes, B.d_meta.as<CellMeta>(), n, c->d_t2g.as<uint32_t>(), c->ref_count,
+                  g.num_genes, B.d_keys0.as<uint64_t>(), B.d_cell_nkeys.as<uint32_t>(),
+                  B.d_bc.as<uint64_t>(), B.d_status.as<DevStatus>(),
+                  par ? B.d_chk.as<CellChk>() : nullptr, B.d_slab_prefix.as<uint32_t>(), B.d_slab_cell.as<uint32_t>(),
+                  B.d_cell_bc.as<uint64_t>(),
                   (uint32_t)n_slabs,
-                  n_pug ? PugOut{c->d_rd_h.as<uint64_t>(), c->d_rd_u.as<uint64_t>(), c->d_rd_o.as<uint32_t>(), c->d_rd_off.as<uint64_t>()}
+                  n_pug ? PugOut{B.d_rd_h.as<uint64_t>(), B.d_rd_u.as<uint64_t>(), B.d_rd_o.as<uint32_t>(), B.d_rd_off.as<uint64_t>()}
                         : PugOut{nullptr, nullptr, nullptr, nullptr}};
     if (par) {
-        ScopedTimer t(c, K_DECODE_PAR);
+        ScopedTimer t(c, K_DECODE_PAR, s, &B.launches);
         if (launch_decode_par(s, da, g.bc_bytes, g.umi_bytes)) return fail(c, AFQ_ERR_INVALID_ARG, "bad field widths");
     }
     {   // sequential walk: the whole decode for unaligned layouts, the verified fix-up otherwise
-        ScopedTimer t(c, K_DECODE);
+        ScopedTimer t(c, K_DECODE, s, &B.launches);
         if (launch_decode(s, da, g.bc_bytes, g.umi_bytes)) return fail(c, AFQ_ERR_INVALID_ARG, "bad field widths");
     }
-    ResolveArgs ra{c->d_meta.as<CellMeta>(), c->d_bucket_cell.as<uint32_t>(), c->d_multi_cells.as<uint32_t>(),
-                   c->d_tile_prefix.as<uint32_t>(), c->d_cell_nkeys.as<uint32_t>(), c->d_bucket_cnt.as<uint32_t>(),
-                   c->d_keys0.as<uint64_t>(), c->d_keys1.as<uint64_t>(), c->d_ncols.as<uint32_t>(),
-                   c->d_nnz.as<uint32_t>(), c->d_ovf.as<OverflowEnt>(), c->d_bdesc.p, em ? c->d_lab.as<uint32_t>() : nullptr,
-                   em ? c->d_lab_cnt.as<uint32_t>() : nullptr, c->d_status.as<DevStatus>(),
-                   (uint32_t)n_buckets, n_multi, (uint32_t)n_tiles, c->d_hist_cells.as<uint32_t>(),
+    ResolveArgs ra{B.d_meta.as<CellMeta>(), B.d_bucket_cell.as<uint32_t>(), B.d_multi_cells.as<uint32_t>(),
+                   B.d_tile_prefix.as<uint32_t>(), B.d_cell_nkeys.as<uint32_t>(), B.d_bucket_cnt.as<uint32_t>(),
+                   B.d_keys0.as<uint64_t>(), B.d_keys1.as<uint64_t>(), B.d_ncols.as<uint32_t>(),
+                   B.d_nnz.as<uint32_t>(), B.d_ovf.as<OverflowEnt>(), B.d_bdesc.p, em ? B.d_lab.as<uint32_t>() : nullptr,
+                   em ? B.d_lab_cnt.as<uint32_t>() : nullptr, B.d_status.as<DevStatus>(),
+                   (uint32_t)n_buckets, n_multi, (uint32_t)n_tiles, B.d_hist_cells.as<uint32_t>(),
                    (uint32_t)hist_cells.size(), g.usa_mode, g.num_rows};
     if (n_multi) {
-        { ScopedTimer t(c, K_HIST); launch_hist(s, ra); }
-        { ScopedTimer t(c, K_BSCAN); launch_bucket_scan(s, ra); }
-        { ScopedTimer t(c, K_SCATTER); launch_scatter(s, ra); }
+        { ScopedTimer t(c, K_HIST, s, &B.launches); launch_hist(s, ra); }
+        { ScopedTimer t(c, K_BSCAN, s, &B.launches); launch_bucket_scan(s, ra); }
+        { ScopedTimer t(c, K_SCATTER, s, &B.launches); launch_scatter(s, ra); }
     }
-    { ScopedTimer t(c, K_RESOLVE); launch_resolve(s, ra); }
-    if (n_multi) { ScopedTimer t(c, K_RESOLVE_BIG); launch_resolve_big(s, ra); }
+    { ScopedTimer t(c, K_RESOLVE, s, &B.launches); launch_resolve(s, ra); }
+    if (n_multi) { ScopedTimer t(c, K_RESOLVE_BIG, s, &B.launches); launch_resolve_big(s, ra); }
     if (n_pug) {
         PugCellArgs pa{};
-        pa.bytes = c->d_bytes; pa.meta = ra.meta; pa.pug_cells = c->d_pug_cells.as<uint32_t>(); pa.cell_nkeys = ra.cell_nkeys;
-        pa.rd = da.pug; pa.scr_off = c->d_pug_scr_off.as<uint64_t>(); pa.scratch = c->d_pug_scratch.as<uint32_t>();
-        pa.epool = c->d_epool.as<uint32_t>(); pa.epool_cursor = c->d_epool_cur.as<unsigned long long>(); pa.epool_cap = epool_words;
+        pa.bytes = c->d_bytes; pa.meta = ra.meta; pa.pug_cells = B.d_pug_cells.as<uint32_t>(); pa.cell_nkeys = ra.cell_nkeys;
+        pa.rd = da.pug; pa.scr_off = B.d_pug_scr_off.as<uint64_t>(); pa.scratch = B.d_pug_scratch.as<uint32_t>();
+        pa.epool = B.d_epool.as<uint32_t>(); pa.epool_cursor = B.d_epool_cur.as<unsigned long long>(); pa.epool_cap = epool_words;
         pa.t2g = c->d_t2g.as<uint32_t>(); pa.keys0 = ra.keys0; pa.cell_ncols = ra.cell_ncols; pa.lab = ra.lab; pa.lab_cnt = ra.lab_cnt;
-        pa.alt = c->d_alt.as<uint32_t>(); pa.st = ra.st; pa.ref_count = c->ref_count; pa.num_genes = g.num_genes; pa.usa = g.usa_mode;
+        pa.alt = B.d_alt.as<uint32_t>(); pa.st = ra.st; pa.ref_count = c->ref_count; pa.num_genes = g.num_genes; pa.usa = g.usa_mode;
         pa.num_rows = g.num_rows; pa.em = em ? 1u : 0u; pa.exact_umi = g.pug_exact_umi; pa.large_thresh = g.large_graph_thresh;
         pa.hw = 1 + g.bc_bytes / 4 + g.umi_bytes / 4; pa.umi_pairs = std::min<uint32_t>(g.umi_bytes * 4, 22);
         pa.gene_level = (g.resolution == AFQ_RES_PARSIMONY_GENE || g.resolution == AFQ_RES_PARSIMONY_GENE_EM) ? 1u : 0u;
-        ScopedTimer t(c, K_PUG);
+        ScopedTimer t(c, K_PUG, s, &B.launches);
         launch_pug(s, pa, n_pug);
     }
-    if (!hist_cells.empty()) { ScopedTimer t(c, K_CELL_HIST); launch_cell_hist(s, ra); }
+    if (!hist_cells.empty()) { ScopedTimer t(c, K_CELL_HIST, s, &B.launches); launch_cell_hist(s, ra); }
     HIP_TRY(c, hipGetLastError());
+    if (!B.kernels_done) HIP_TRY(c, hipEventCreateWithFlags(&B.kernels_done, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(B.kernels_done, s));
     hc.lap("run: enqueue kernels");
-    c->last_ra = ra;
-    c->cur = r;
-    c->range_in_flight = true;
+    B.last_ra = ra;
+    B.cur = r;
+    B.in_flight = true;
     c->stats.n_records += nrec_total;
     c->stats.n_ref_words += key_off;
     c->stats.n_buckets += n_buckets;
@@ -456,18 +495,19 @@ int run_range(afq_ctx* c, Range r) {
 }
 
 // Wait for the range in flight, compact its rows and append them to the host result.
-int finish_range(afq_ctx* c) {
-    if (!c->range_in_flight) return 0;
-    c->range_in_flight = false;
+int finish_range(afq_ctx* c, int slot) {
+    RangeState& B = c->rs[slot];
+    if (!B.in_flight) return 0;
+    B.in_flight = false;
     HostClock hc;
-    const uint32_t n = c->cur.c1 - c->cur.c0;
-    hipStream_t s = c->stream;
+    const uint32_t n = B.cur.c1 - B.cur.c0;
+    hipStream_t s = B.stream;
     HIP_TRY(c, hipStreamSynchronize(s));
     hc.lap("finish: wait for kernels");
     DevStatus st{};
-    HIP_TRY(c, hipMemcpy(&st, c->d_status.p, sizeof(st), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(&st, B.d_status.p, sizeof(st), hipMemcpyDeviceToHost));
     if (st.err_code) {
-        const std::string cell = "cell " + std::to_string(c->cur.c0 + st.err_cell) + ": ";
+        const std::string cell = "cell " + std::to_string(B.cur.c0 + st.err_cell) + ": ";
         switch (st.err_code) {
             case kErrRecordWalk: return fail(c, AFQ_ERR_BAD_INPUT, cell + "chunk nbytes does not match its records");
             case kErrRefRange: return fail(c, AFQ_ERR_BAD_INPUT, cell + "ref id out of range");
@@ -488,44 +528,44 @@ int finish_range(afq_ctx* c) {
     const bool em = c->cfg.resolution == AFQ_RES_CR_LIKE_EM || c->cfg.resolution == AFQ_RES_PARSIMONY_EM ||
                     c->cfg.resolution == AFQ_RES_PARSIMONY_GENE_EM;
     std::vector<uint32_t> alt(n);
-    HIP_TRY(c, hipMemcpy(alt.data(), c->d_alt.p, 4ull * n, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(nnz.data(), c->d_nnz.p, 4ull * n, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(alt.data(), B.d_alt.p, 4ull * n, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(nnz.data(), B.d_nnz.p, 4ull * n, hipMemcpyDeviceToHost));
     if (em) {
         // per-cell EM (src/em.rs) over the single-label counts + the ambiguous molecules' labels
         std::vector<uint32_t> lc(2ull * n);
         std::vector<uint64_t> eoff(n + 1);
-        HIP_TRY(c, hipMemcpy(lc.data(), c->d_lab_cnt.p, 8ull * n, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(lc.data(), B.d_lab_cnt.p, 8ull * n, hipMemcpyDeviceToHost));
         eoff[0] = 0;
         for (uint32_t i = 0; i < n; ++i) eoff[i + 1] = eoff[i] + em_scratch_words(nnz[i], lc[2 * i], lc[2 * i + 1], c->cfg.usa_mode != 0);
-        HIP_TRY(c, c->d_em_off.ensure(8ull * (n + 1)));
-        HIP_TRY(c, c->d_em_scratch.ensure(4 * eoff[n] + 16));
-        HIP_TRY(c, c->d_em_nnz.ensure(4ull * n));
-        HIP_TRY(c, hipMemcpyAsync(c->d_em_off.p, eoff.data(), 8ull * (n + 1), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, B.d_em_off.ensure(8ull * (n + 1)));
+        HIP_TRY(c, B.d_em_scratch.ensure(4 * eoff[n] + 16));
+        HIP_TRY(c, B.d_em_nnz.ensure(4ull * n));
+        HIP_TRY(c, hipMemcpyAsync(B.d_em_off.p, eoff.data(), 8ull * (n + 1), hipMemcpyHostToDevice, s));
         {
-            ScopedTimer t(c, K_EM);
-            launch_em(s, c->last_ra, n, c->d_em_off.as<uint64_t>(), c->d_em_scratch.as<uint32_t>(), c->d_em_nnz.as<uint32_t>(),
+            ScopedTimer t(c, K_EM, s, &B.launches);
+            launch_em(s, B.last_ra, n, B.d_em_off.as<uint64_t>(), B.d_em_scratch.as<uint32_t>(), B.d_em_nnz.as<uint32_t>(),
                       c->cfg.usa_mode ? c->cfg.num_rows : c->cfg.num_genes, c->cfg.em_init_uniform);
         }
         HIP_TRY(c, hipStreamSynchronize(s));
-        HIP_TRY(c, hipMemcpy(nnz.data(), c->d_em_nnz.p, 4ull * n, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(nnz.data(), B.d_em_nnz.p, 4ull * n, hipMemcpyDeviceToHost));
     }
-    HIP_TRY(c, hipMemcpy(bc.data(), c->d_bc.p, 8ull * n, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(bc.data(), B.d_bc.p, 8ull * n, hipMemcpyDeviceToHost));
     ptr[0] = 0;
     for (uint32_t i = 0; i < n; ++i) ptr[i + 1] = ptr[i] + nnz[i];
     const uint64_t tot = ptr[n];
     hc.lap("finish: small D2H + prefix");
-    HIP_TRY(c, c->d_cell_ptr.ensure(8ull * (n + 1)));
-    HIP_TRY(c, c->d_gene.ensure(std::max<uint64_t>(4 * tot, 16)));
-    HIP_TRY(c, c->d_val.ensure(std::max<uint64_t>(4 * tot, 16)));
-    HIP_TRY(c, hipMemcpyAsync(c->d_cell_ptr.p, ptr.data(), 8ull * (n + 1), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, B.d_cell_ptr.ensure(8ull * (n + 1)));
+    HIP_TRY(c, B.d_gene.ensure(std::max<uint64_t>(4 * tot, 16)));
+    HIP_TRY(c, B.d_val.ensure(std::max<uint64_t>(4 * tot, 16)));
+    HIP_TRY(c, hipMemcpyAsync(B.d_cell_ptr.p, ptr.data(), 8ull * (n + 1), hipMemcpyHostToDevice, s));
     {
-        ScopedTimer t(c, K_COMPACT);
+        ScopedTimer t(c, K_COMPACT, s, &B.launches);
         if (em)
-            launch_compact_em(s, n, c->d_em_off.as<uint64_t>(), c->d_em_scratch.as<uint32_t>(), c->d_em_nnz.as<uint32_t>(),
-                              c->d_cell_ptr.as<uint64_t>(), c->d_gene.as<uint32_t>(), c->d_val.as<float>());
+            launch_compact_em(s, n, B.d_em_off.as<uint64_t>(), B.d_em_scratch.as<uint32_t>(), B.d_em_nnz.as<uint32_t>(),
+                              B.d_cell_ptr.as<uint64_t>(), B.d_gene.as<uint32_t>(), B.d_val.as<float>());
         else
-            launch_compact(s, c->d_meta.as<CellMeta>(), n, c->d_keys0.as<uint64_t>(), c->d_keys1.as<uint64_t>(), c->d_nnz.as<uint32_t>(),
-                           c->d_cell_ptr.as<uint64_t>(), c->d_gene.as<uint32_t>(), c->d_val.as<float>());
+            launch_compact(s, B.d_meta.as<CellMeta>(), n, B.d_keys0.as<uint64_t>(), B.d_keys1.as<uint64_t>(), B.d_nnz.as<uint32_t>(),
+                           B.d_cell_ptr.as<uint64_t>(), B.d_gene.as<uint32_t>(), B.d_val.as<float>());
     }
     HostResult& R = *c->res;
     const size_t g0 = R.gene.n;
@@ -533,15 +573,15 @@ int finish_range(afq_ctx* c) {
     HIP_TRY(c, R.val.reserve(g0 + tot));
     R.gene.n = R.val.n = g0 + tot;
     if (tot) {
-        HIP_TRY(c, hipMemcpyAsync(R.gene.p + g0, c->d_gene.p, 4 * tot, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipMemcpyAsync(R.val.p + g0, c->d_val.p, 4 * tot, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(R.gene.p + g0, B.d_gene.p, 4 * tot, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(R.val.p + g0, B.d_val.p, 4 * tot, hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, hipGetLastError());
     hc.lap("finish: compact + D2H of CSR");
     const afq_config& g = c->cfg;
     for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t nrec = c->hdr[2 * (c->cur.c0 + i) + 1];
+        const uint32_t nrec = c->hdr[2 * (B.cur.c0 + i) + 1];
         uint8_t f = 0;
         // used_fast_path, src/quant.rs:794-797 (same counts as the general cr-like route)
         if (g.sa_model == AFQ_SA_WINNER_TAKE_ALL && nrec < g.small_thresh) f |= AFQ_CELL_TINY_PATH;
@@ -553,7 +593,7 @@ int finish_range(afq_ctx* c) {
         R.flags.push_back(f);
         R.mmrate.push_back(0.0);
     }
-    harvest_timers(c);
+    harvest_timers(c, &B.launches);
     hc.lap("finish: host result");
     return 0;
 }
@@ -571,15 +611,19 @@ int submit_common(afq_ctx* c, uint32_t n_cells, uint64_t first_cell_index) {
     if (rc) return rc;
     c->next_range = 0;
     c->pending = true;
-    // all but the last range are finished here; the last one stays in flight until afq_collect
-    while (c->next_range < c->ranges.size()) {
-        rc = run_range(c, c->ranges[c->next_range++]);
+    // Software pipeline over the ranges with two buffer sets: range i is enqueued before range i-1 is
+    // finished (sync + compaction + D2H of its rows), so that copy overlaps range i's kernels.  The last range
+    // stays in flight until afq_collect.
+    const size_t k = c->ranges.size();
+    for (size_t i = 0; i < k; ++i) {
+        rc = run_range(c, c->ranges[i], (int)(i & 1));
         if (rc) { c->pending = false; return rc; }
-        if (c->next_range < c->ranges.size()) {
-            rc = finish_range(c);
+        if (i > 0) {
+            rc = finish_range(c, (int)((i - 1) & 1));
             if (rc) { c->pending = false; return rc; }
         }
     }
+    c->next_range = k;
     return 0;
 }
 
@@ -620,6 +664,8 @@ int afq_create(const afq_config* cfg, const uint32_t* tid_to_gid, uint32_t ref_c
     auto bail = [&](int code, const std::string& m) { g_create_err = m; afq_destroy(c); return code; };
     if (hipSetDevice(device) != hipSuccess) return bail(AFQ_ERR_NO_DEVICE, "hipSetDevice failed");
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(AFQ_ERR_HIP, "hipStreamCreate failed");
+    for (auto& rs : c->rs)
+        if (hipStreamCreateWithFlags(&rs.stream, hipStreamNonBlocking) != hipSuccess) return bail(AFQ_ERR_HIP, "hipStreamCreate failed");
     if (c->d_t2g.ensure(4ull * ref_count) != hipSuccess) return bail(AFQ_ERR_OOM, "tid_to_gid allocation failed");
     if (hipMemcpy(c->d_t2g.p, tid_to_gid, 4ull * ref_count, hipMemcpyHostToDevice) != hipSuccess)
         return bail(AFQ_ERR_HIP, "tid_to_gid upload failed");
@@ -633,12 +679,13 @@ void afq_destroy(afq_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     harvest_timers(c);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = {&c->d_t2g, &c->d_bytes_own, &c->d_meta, &c->d_keys0, &c->d_keys1, &c->d_cell_nkeys,
-                      &c->d_bucket_cnt, &c->d_bucket_cell, &c->d_multi_cells, &c->d_tile_prefix, &c->d_ncols, &c->d_nnz,
-                      &c->d_ovf, &c->d_status, &c->d_bc, &c->d_cell_ptr, &c->d_gene, &c->d_val, &c->d_chunk_off, &c->d_hdr,
-                      &c->d_chk, &c->d_slab_prefix, &c->d_slab_cell, &c->d_cell_bc, &c->d_bdesc, &c->d_lab, &c->d_lab_cnt, &c->d_em_off,
-                      &c->d_em_scratch, &c->d_em_nnz, &c->d_pug_cells, &c->d_rd_off, &c->d_rd_h, &c->d_rd_u, &c->d_rd_o, &c->d_pug_scr_off,
-                      &c->d_pug_scratch, &c->d_epool, &c->d_epool_cur, &c->d_alt, &c->d_hist_cells};
+    for (auto& rs : c->rs) {
+        if (rs.stream) (void)hipStreamSynchronize(rs.stream);
+        for (DevBuf* b : rs.all()) b->release();
+        if (rs.kernels_done) (void)hipEventDestroy(rs.kernels_done);
+        if (rs.stream) (void)hipStreamDestroy(rs.stream);
+    }
+    DevBuf* bufs[] = {&c->d_t2g, &c->d_bytes_own, &c->d_chunk_off, &c->d_hdr};
     for (auto b : bufs) b->release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->res) pool_put(c->res);
@@ -714,7 +761,7 @@ int afq_collect(afq_ctx* c, afq_result* out) {
     if (!c->pending) return fail(c, AFQ_ERR_STATE, "afq_collect without a submitted batch");
     HIP_TRY(c, hipSetDevice(c->device));
     c->pending = false;
-    int rc = finish_range(c);
+    int rc = c->ranges.empty() ? 0 : finish_range(c, (int)((c->ranges.size() - 1) & 1));
     if (rc) return rc;
     HostResult* R = c->res;
     c->res = nullptr;

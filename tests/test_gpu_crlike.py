@@ -248,3 +248,15 @@ def test_crlike_em_overflow_paths(oracle):
         got, want, st = run_both(oracle, cfg_for(s, "cr-like-em"), s.tid_to_gid, b, off)
         assert st["n_overflow_buckets"] >= 1
         assert_same_result(got, want)
+
+
+def test_many_ranges_pipeline(oracle, monkeypatch):
+    """A batch cut into many ranges (forced by AFQ_RANGE_BYTES) goes through the two-buffer-set pipeline
+    and yields the same rows in the same cell order."""
+    monkeypatch.setenv("AFQ_RANGE_BYTES", "200000")
+    sizes = [5000, 3000, 2500, 2000, 1500, 1200, 900, 600, 300, 120, 60, 20, 5, 1]
+    for res in ("cr-like", "cr-like-em", "parsimony-em"):
+        s = synth.synth(41, sizes, num_genes=200, txp_per_gene=3, dup=0.5, cross=0.4, umi_err=0.02)
+        b, off = s.encode()
+        got, want, st = run_both(oracle, cfg_for(s, res), s.tid_to_gid, b, off)
+        assert_same_result(got, want, what=res)
