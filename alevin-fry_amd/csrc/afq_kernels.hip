@@ -17,6 +17,7 @@
 // Integer/byte work bound by HBM and LDS; no MFMA anywhere by design.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "afq_common.h"
 #include "afq_kernels.h"
@@ -731,13 +732,13 @@ __device__ __forceinline__ T xor_lane(T v) {
 
 template <int E, int J, typename T>
 __device__ __forceinline__ void lane_stage(T (&a)[E], uint32_t idx0, uint32_t k) {
+    const bool lower = (idx0 & J) == 0;  // J < 64: a property of the lane only
 #pragma unroll
     for (int h = 0; h < E; ++h) {
-        const uint32_t idx = idx0 + h * 64;
+        const bool want_min = lower == (((idx0 + h * 64) & k) == 0);
         const T o = xor_lane<J, T>(a[h]);
-        const bool want_min = (((idx & J) == 0) == ((idx & k) == 0));
-        const T mn = a[h] < o ? a[h] : o, mx = a[h] < o ? o : a[h];
-        a[h] = want_min ? mn : mx;
+        // keep own value iff it is on the wanted side of the partner's: one compare, one select
+        a[h] = ((a[h] < o) == want_min) ? a[h] : o;
     }
 }
 
@@ -962,6 +963,13 @@ __device__ __forceinline__ uint32_t* lab_alloc_global(const LabArea& la, uint32_
     return gw + off;
 }
 
+#ifdef AFQ_RESOLVE_TIMING
+__device__ unsigned long long g_dbg[8];
+#define RT_MARK(i) do { if (threadIdx.x == 0 && (blockIdx.x & 1023) == 0) { unsigned long long t_ = clock64(); atomicAdd(&g_dbg[i], t_ - tprev_); atomicAdd(&g_dbg[4 + (i & 3)], 1ull); tprev_ = t_; } } while (0)
+#else
+#define RT_MARK(i) do {} while (0)
+#endif
+
 // Sort + resolve one bucket held in LDS.  NT threads, up to NT*8 keys.
 template <int NT>
 __device__ __forceinline__ void resolve_bucket_lds(const BucketDesc& d, uint64_t* __restrict__ keys0,
@@ -977,7 +985,11 @@ __device__ __forceinline__ void resolve_bucket_lds(const BucketDesc& d, uint64_t
     ResolveCfg rcb = rc;
     rcb.mode = d.mode_single & 0xFFu;
     if (threadIdx.x < 6) s_misc[threadIdx.x] = 0;
+#ifdef AFQ_RESOLVE_TIMING
+    unsigned long long tprev_ = clock64();
+#endif
     block_sort_any<NT, uint64_t>(src, n, s_keys, kKeySentinel);
+    RT_MARK(0);
     resolve_sorted<NT>(s_keys, n, s_run, s_ws, rcb, [&](uint32_t col) {
         if (col >= rc.num_rows) { set_err(st, kErrSlotRange, d.cell); return; }
         s_cols[atomicAdd(&s_misc[0], 1u)] = col;
@@ -989,6 +1001,7 @@ __device__ __forceinline__ void resolve_bucket_lds(const BucketDesc& d, uint64_t
         return s_lab + off;
     });
     __syncthreads();
+    RT_MARK(1);
     const uint32_t nc = s_misc[0];
     if (s_lab && s_misc[3]) {  // hand the bucket's ambiguous molecules to the cell's label area
         const uint32_t lw = s_misc[2], ln = s_misc[3];
@@ -1010,7 +1023,9 @@ __device__ __forceinline__ void resolve_bucket_lds(const BucketDesc& d, uint64_t
         if (threadIdx.x == 0) s_misc[1] = atomicAdd(&cell_ncols[d.cell], nc);
         __syncthreads();
         uint32_t* out = reinterpret_cast<uint32_t*>(keys0 + d.out_off) + s_misc[1];  // keys0 slots are dead after k_scatter
+        RT_MARK(2);
         for (uint32_t i = threadIdx.x; i < nc; i += NT) out[i] = s_cols[i];
+        RT_MARK(3);
         return;
     }
     // single-bucket cell: sort the columns, run-length count, write (column,count) pairs
@@ -1664,6 +1679,13 @@ void launch_compact_em(hipStream_t s, uint32_t n_cells, const uint64_t* em_off, 
 }
 
 size_t bucket_desc_bytes() { return sizeof(BucketDesc); }
+#ifdef AFQ_RESOLVE_TIMING
+extern "C" void afq_debug_dump() {
+    unsigned long long h[8];
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg), sizeof(h));
+    fprintf(stderr, "[resolve cycles/bucket] sort+load=%llu resolve=%llu atomic=%llu store=%llu (n=%llu)\n", h[0] / (h[4] + 1), h[1] / (h[5] + 1), h[2] / (h[6] + 1), h[3] / (h[7] + 1), h[4]);
+}
+#endif
 
 void launch_atac_dedup(hipStream_t s, uint32_t n_cells, const uint32_t* ref, const uint32_t* start, const uint16_t* flen,
                        const uint64_t* cell_ptr, void* scratch, uint32_t* o_ref, uint32_t* o_start, uint16_t* o_flen,
