@@ -1,0 +1,52 @@
+// afq_cli.cpp — `afquant quant …`: the flag surface of `alevin-fry quant` (src/main.rs:294-348 of the reference)
+// in front of afq_quantify() (include/afquant_host.h).  Same spellings and defaults; flags whose feature is not
+// implemented are accepted and refused with a clear message rather than ignored.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "../../include/afquant_host.h"
+
+static void usage() {
+    std::fprintf(stderr,
+                 "usage: afquant quant -i <input-dir> -m <tg-map> -o <output-dir> -r <resolution>\n"
+                 "       [-t <threads>] [--small-thresh N] [--umi-edit-dist 0|1] [--large-graph-thresh N]\n"
+                 "       [--quant-subset FILE] [--init-uniform] [--use-mtx] [-d] [-b N] [--device N]\n"
+                 "resolutions: trivial cr-like cr-like-em parsimony parsimony-em parsimony-gene parsimony-gene-em\n");
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2 || std::strcmp(argv[1], "quant") != 0) { usage(); return 2; }
+    afq_quant_opts o{};
+    o.small_thresh = 100; o.umi_edit_dist = -1; o.large_graph_thresh = -1; o.num_threads = 0;
+    std::string cmdline;
+    for (int i = 0; i < argc; ++i) { if (i) cmdline += ' '; cmdline += argv[i]; }
+    o.cmdline = cmdline.c_str();
+    auto need = [&](int& i) -> const char* { if (i + 1 >= argc) { usage(); std::exit(2); } return argv[++i]; };
+    for (int i = 2; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "-i" || a == "--input-dir") o.input_dir = need(i);
+        else if (a == "-m" || a == "--tg-map") o.tg_map = need(i);
+        else if (a == "-o" || a == "--output-dir") o.output_dir = need(i);
+        else if (a == "-r" || a == "--resolution") o.resolution = need(i);
+        else if (a == "-t" || a == "--threads") o.num_threads = (uint32_t)std::atoi(need(i));
+        else if (a == "--small-thresh") o.small_thresh = (uint32_t)std::atoi(need(i));
+        else if (a == "--umi-edit-dist") o.umi_edit_dist = std::atoi(need(i));
+        else if (a == "--large-graph-thresh") o.large_graph_thresh = std::atoi(need(i));
+        else if (a == "--quant-subset") o.filter_list = need(i);
+        else if (a == "--init-uniform") o.init_uniform = 1;
+        else if (a == "--summary-stat" || a == "--use-mtx") {}
+        else if (a == "--use-eds") { std::fprintf(stderr, "--use-eds is no longer supported. EDS output has been removed as of v0.12.\n"); return 1; }
+        else if (a == "-d" || a == "--dump-eqclasses") o.dump_eq = 1;
+        else if (a == "-b" || a == "--num-bootstraps") o.num_bootstraps = (uint32_t)std::atoi(need(i));
+        else if (a == "--sa-model") { const std::string v = need(i); if (v != "winner-take-all") { std::fprintf(stderr, "--sa-model %s is not implemented\n", v.c_str()); return 1; } }
+        else if (a == "--multi-sample-output") (void)need(i);
+        else if (a == "--device") o.device = (uint32_t)std::atoi(need(i));
+        else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); usage(); return 2; }
+    }
+    if (!o.input_dir || !o.tg_map || !o.output_dir || !o.resolution) { usage(); return 2; }
+    const int rc = afq_quantify(&o);
+    if (rc) { std::fprintf(stderr, "afquant quant failed (%d): %s\n", rc, afq_host_last_error()); return 1; }
+    return 0;
+}

@@ -1,0 +1,454 @@
+// afq_host.cpp — host side around the quant hot path (include/afquant_host.h): collated-RAD front-end
+// (prelude, chunk table, snappy frame format), transcript-to-gene map, and the output writers.
+//
+// Mirrors, around the per-cell loop that lives on the device (paths relative to /root/reference):
+//   quantify / do_quantify_dispatch      src/quant.rs:359-396, 1955-2029   (collate.json, .rad vs .rad.sz)
+//   prelude + file tags                  witnessed by src/convert.rs:254-398 (writer side)
+//   parse_tg_map                         src/utils.rs:487-662
+//   --quant-subset filter                src/quant.rs:1523-1536, 1773-1784; src/utils.rs:1074-1095
+//   per-cell stats + featureDump row     src/quant.rs:1150-1262
+//   cols / rows / mtx / quant.json       src/quant.rs:1596-1613, 1786-1847, 1913-1933
+// Not here: -d/--dump-eqclasses, -b/--num-bootstraps, multi-barcode (Flex) records,
+// unmapped_bc_count_collated.bin (libradicl-internal format, not witnessed in the repo: unmapped = 0,
+// which is also the reference's behaviour when the file is missing, src/quant.rs:1485-1494).
+#include <algorithm>
+#include <charconv>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <sys/stat.h>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/afquant.h"
+#include "../../include/afquant_host.h"
+
+namespace {
+
+thread_local std::string g_herr;
+int hfail(int code, const std::string& m) { g_herr = m; return code; }
+
+// ---------------------------------------------------------------------------
+// Rust `{}` for f32: shortest digits that round-trip, positional notation, "NaN" / "inf" / "-inf".
+int format_f32(float v, char* buf, size_t cap) {
+    if (cap < 64) return -1;
+    if (std::isnan(v)) { std::memcpy(buf, "NaN", 4); return 3; }
+    if (std::isinf(v)) { const char* s = v < 0 ? "-inf" : "inf"; size_t n = std::strlen(s); std::memcpy(buf, s, n + 1); return (int)n; }
+    // shortest round-trip digits come from the scientific form; Rust then lays them out positionally
+    char sci[48];
+    auto r = std::to_chars(sci, sci + sizeof sci - 1, v, std::chars_format::scientific);
+    *r.ptr = 0;
+    std::string digits; int exp10 = 0; bool neg = false;
+    const char* p = sci;
+    if (*p == '-') { neg = true; ++p; }
+    for (; *p && *p != 'e'; ++p) if (*p != '.') digits.push_back(*p);
+    if (*p == 'e') exp10 = std::atoi(p + 1);
+    while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
+    std::string out;
+    if (neg) out.push_back('-');
+    if (digits == "0") out += "0";
+    else if (exp10 >= 0) {
+        const size_t int_len = (size_t)exp10 + 1;
+        if (digits.size() <= int_len) { out += digits; out.append(int_len - digits.size(), '0'); }
+        else { out.append(digits, 0, int_len); out.push_back('.'); out.append(digits, int_len, std::string::npos); }
+    } else {
+        out += "0.";
+        out.append((size_t)(-exp10 - 1), '0');
+        out += digits;
+    }
+    if (out.size() + 1 > cap) return -1;
+    std::memcpy(buf, out.c_str(), out.size() + 1);
+    return (int)out.size();
+}
+std::string f32s(float v) { char b[96]; format_f32(v, b, sizeof b); return b; }
+
+// ---------------------------------------------------------------------------
+// snappy: raw block decompress + frame format (stream identifier 0xff, compressed 0x00, uncompressed 0x01,
+// padding 0xfe, reserved skippable 0x80-0xfd).  CRC-32C of the uncompressed data is verified (masked).
+uint32_t crc32c(const uint8_t* p, size_t n) {
+    static uint32_t T[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1; T[i] = c; }
+        init = true;
+    }
+    uint32_t c = ~0u;
+    for (size_t i = 0; i < n; ++i) c = T[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+    return ~c;
+}
+uint32_t mask_crc(uint32_t c) { return ((c >> 15) | (c << 17)) + 0xa282ead8u; }
+
+bool snappy_raw_decompress(const uint8_t* in, size_t n, std::vector<uint8_t>& out) {
+    size_t p = 0;
+    uint64_t ulen = 0; int shift = 0;
+    for (;;) { if (p >= n || shift > 35) return false; uint8_t b = in[p++]; ulen |= (uint64_t)(b & 0x7F) << shift; if (!(b & 0x80)) break; shift += 7; }
+    const size_t base = out.size();
+    out.reserve(base + ulen);
+    while (p < n) {
+        const uint8_t tag = in[p++];
+        const uint32_t type = tag & 3;
+        if (type == 0) {  // literal
+            size_t len = (tag >> 2) + 1;
+            if (len > 60) { const size_t nb = len - 60; if (p + nb > n) return false; len = 0; for (size_t i = 0; i < nb; ++i) len |= (size_t)in[p + i] << (8 * i); len += 1; p += nb; }
+            if (p + len > n) return false;
+            out.insert(out.end(), in + p, in + p + len);
+            p += len;
+        } else {
+            size_t len, off;
+            if (type == 1) { if (p + 1 > n) return false; len = ((tag >> 2) & 7) + 4; off = ((size_t)(tag >> 5) << 8) | in[p]; p += 1; }
+            else if (type == 2) { if (p + 2 > n) return false; len = (tag >> 2) + 1; off = in[p] | ((size_t)in[p + 1] << 8); p += 2; }
+            else { if (p + 4 > n) return false; len = (tag >> 2) + 1; off = in[p] | ((size_t)in[p + 1] << 8) | ((size_t)in[p + 2] << 16) | ((size_t)in[p + 3] << 24); p += 4; }
+            if (off == 0 || off > out.size() - base) return false;
+            size_t s = out.size() - off;
+            for (size_t i = 0; i < len; ++i) out.push_back(out[s + i]);  // may overlap its own output
+        }
+    }
+    return out.size() - base == ulen;
+}
+
+bool snappy_frame_decode(const uint8_t* in, size_t n, std::vector<uint8_t>& out, std::string& err) {
+    size_t p = 0;
+    while (p < n) {
+        if (p + 4 > n) { err = "truncated snappy frame header"; return false; }
+        const uint8_t type = in[p];
+        const size_t len = in[p + 1] | ((size_t)in[p + 2] << 8) | ((size_t)in[p + 3] << 16);
+        p += 4;
+        if (p + len > n) { err = "truncated snappy frame chunk"; return false; }
+        if (type == 0xff) { if (len != 6 || std::memcmp(in + p, "sNaPpY", 6) != 0) { err = "bad snappy stream identifier"; return false; } }
+        else if (type == 0x00 || type == 0x01) {
+            if (len < 4) { err = "snappy chunk too short"; return false; }
+            const uint32_t want = in[p] | ((uint32_t)in[p + 1] << 8) | ((uint32_t)in[p + 2] << 16) | ((uint32_t)in[p + 3] << 24);
+            const size_t before = out.size();
+            if (type == 0x01) out.insert(out.end(), in + p + 4, in + p + len);
+            else if (!snappy_raw_decompress(in + p + 4, len - 4, out)) { err = "corrupt snappy block"; return false; }
+            if (mask_crc(crc32c(out.data() + before, out.size() - before)) != want) { err = "snappy CRC mismatch"; return false; }
+        } else if (type >= 0x02 && type <= 0x7f) { err = "unskippable reserved snappy chunk"; return false; }
+        // 0x80..0xfe: skippable / padding
+        p += len;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// RAD prelude
+struct Cursor {
+    const uint8_t* b; size_t n, p = 0; bool ok = true;
+    template <class T> T get() { T v{}; if (p + sizeof(T) > n) { ok = false; return v; } std::memcpy(&v, b + p, sizeof(T)); p += sizeof(T); return v; }
+    std::string str(size_t len) { if (p + len > n) { ok = false; return {}; } std::string s((const char*)b + p, len); p += len; return s; }
+};
+struct TagDesc { std::string name; uint8_t type = 0, len_type = 0, elem_type = 0; };
+size_t int_type_bytes(uint8_t t) { return t == 1 ? 1 : t == 2 ? 2 : t == 3 ? 4 : t == 4 ? 8 : 0; }
+
+struct RadPrelude {
+    bool is_paired = false; uint64_t ref_count = 0, num_chunks = 0;
+    std::vector<std::string> ref_names;
+    std::vector<TagDesc> file_tags, read_tags, aln_tags;
+    std::unordered_map<std::string, uint64_t> file_tag_vals;
+    size_t first_chunk = 0;
+    uint32_t bc_bytes = 0, umi_bytes = 0;
+};
+
+bool read_tag_section(Cursor& c, std::vector<TagDesc>& tags) {
+    const uint16_t nt = c.get<uint16_t>();
+    for (uint16_t i = 0; i < nt && c.ok; ++i) {
+        TagDesc t;
+        const uint16_t nl = c.get<uint16_t>();
+        t.name = c.str(nl);
+        t.type = c.get<uint8_t>();
+        if (t.type == 7) { t.len_type = c.get<uint8_t>(); t.elem_type = c.get<uint8_t>(); }
+        tags.push_back(t);
+    }
+    return c.ok;
+}
+
+int parse_prelude(const uint8_t* bytes, size_t n, RadPrelude& P, bool want_names) {
+    Cursor c{bytes, n};
+    P.is_paired = c.get<uint8_t>() != 0;
+    P.ref_count = c.get<uint64_t>();
+    if (!c.ok || P.ref_count > n) return hfail(AFQ_ERR_BAD_INPUT, "RAD header: bad ref_count");
+    for (uint64_t i = 0; i < P.ref_count && c.ok; ++i) {
+        const uint16_t nl = c.get<uint16_t>();
+        if (want_names) P.ref_names.push_back(c.str(nl)); else { if (c.p + nl > c.n) c.ok = false; c.p += nl; }
+    }
+    P.num_chunks = c.get<uint64_t>();
+    if (!c.ok) return hfail(AFQ_ERR_BAD_INPUT, "RAD header truncated");
+    if (!read_tag_section(c, P.file_tags) || !read_tag_section(c, P.read_tags) || !read_tag_section(c, P.aln_tags))
+        return hfail(AFQ_ERR_BAD_INPUT, "RAD tag sections truncated");
+    for (auto& t : P.file_tags) {  // values of the file-level tags follow, in declaration order
+        uint64_t v = 0;
+        switch (t.type) {
+            case 0: case 1: v = c.get<uint8_t>(); break;
+            case 2: v = c.get<uint16_t>(); break;
+            case 3: v = c.get<uint32_t>(); break;
+            case 4: v = c.get<uint64_t>(); break;
+            case 5: c.get<float>(); break;
+            case 6: c.get<double>(); break;
+            case 7: {
+                uint64_t len = 0;
+                switch (t.len_type) { case 1: len = c.get<uint8_t>(); break; case 2: len = c.get<uint16_t>(); break; case 3: len = c.get<uint32_t>(); break; case 4: len = c.get<uint64_t>(); break; default: c.ok = false; }
+                const size_t eb = t.elem_type == 5 ? 4 : t.elem_type == 6 ? 8 : t.elem_type == 0 ? 1 : int_type_bytes(t.elem_type);
+                if (!eb || c.p + len * eb > c.n) c.ok = false; else c.p += len * eb;
+                break;
+            }
+            case 8: { const uint16_t sl = c.get<uint16_t>(); c.str(sl); break; }
+            default: c.ok = false;
+        }
+        P.file_tag_vals[t.name] = v;
+    }
+    if (!c.ok) return hfail(AFQ_ERR_BAD_INPUT, "RAD file-tag values truncated or of unknown type");
+    P.first_chunk = c.p;
+    for (auto& t : P.read_tags) {
+        if (t.name == "b") P.bc_bytes = (uint32_t)int_type_bytes(t.type);
+        if (t.name == "u") P.umi_bytes = (uint32_t)int_type_bytes(t.type);
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+bool file_exists(const std::string& p) { struct stat st; return ::stat(p.c_str(), &st) == 0; }
+bool read_file(const std::string& p, std::vector<uint8_t>& out) {
+    FILE* f = std::fopen(p.c_str(), "rb");
+    if (!f) return false;
+    std::fseek(f, 0, SEEK_END); long sz = std::ftell(f); std::fseek(f, 0, SEEK_SET);
+    out.resize((size_t)sz);
+    bool ok = sz == 0 || std::fread(out.data(), 1, (size_t)sz, f) == (size_t)sz;
+    std::fclose(f);
+    return ok;
+}
+void mkdirs(const std::string& p) {
+    std::string cur;
+    for (size_t i = 0; i <= p.size(); ++i) {
+        if (i == p.size() || p[i] == '/') { if (!cur.empty()) ::mkdir(cur.c_str(), 0755); }
+        if (i < p.size()) cur.push_back(p[i]);
+    }
+}
+std::string json_escape(const std::string& s) {
+    std::string o;
+    for (char ch : s) { if (ch == '"' || ch == '\\') { o.push_back('\\'); o.push_back(ch); } else if (ch == '\n') o += "\\n"; else o.push_back(ch); }
+    return o;
+}
+std::string bc_to_string(uint64_t bc, uint32_t len) {  // needletail bitmer_to_bytes: first base = most significant pair
+    std::string s(len, 'A');
+    for (uint32_t i = 0; i < len; ++i) s[i] = "ACGT"[(bc >> (2 * (len - 1 - i))) & 3];
+    return s;
+}
+bool string_to_bc(const std::string& s, uint64_t& v) {
+    v = 0;
+    for (char ch : s) {
+        uint64_t c;
+        switch (ch) { case 'A': case 'a': case 'N': case 'n': c = 0; break; case 'C': case 'c': c = 1; break; case 'G': case 'g': c = 2; break; case 'T': case 't': c = 3; break; default: return false; }
+        v = (v << 2) | c;
+    }
+    return true;
+}
+
+struct ResolutionInfo { const char* name; const char* debug; uint32_t id; bool pars; bool em; };
+const ResolutionInfo kRes[] = {
+    {"trivial", "Trivial", AFQ_RES_TRIVIAL, false, false},
+    {"cr-like", "CellRangerLike", AFQ_RES_CR_LIKE, false, false},
+    {"cr-like-em", "CellRangerLikeEm", AFQ_RES_CR_LIKE_EM, false, true},
+    {"parsimony-em", "ParsimonyEm", AFQ_RES_PARSIMONY_EM, true, true},
+    {"parsimony", "Parsimony", AFQ_RES_PARSIMONY, true, false},
+    {"parsimony-gene-em", "ParsimonyGeneEm", AFQ_RES_PARSIMONY_GENE_EM, true, true},
+    {"parsimony-gene", "ParsimonyGene", AFQ_RES_PARSIMONY_GENE, true, false},
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* afq_host_last_error(void) { return g_herr.c_str(); }
+
+int afq_format_f32(float v, char* buf, size_t cap) { return format_f32(v, buf, cap); }
+
+int64_t afq_snappy_frame_decode(const uint8_t* in, size_t n, uint8_t* out, size_t cap) {
+    std::vector<uint8_t> o; std::string err;
+    if (!snappy_frame_decode(in, n, o, err)) return hfail(AFQ_ERR_BAD_INPUT, err);
+    if (out) { if (o.size() > cap) return hfail(AFQ_ERR_INVALID_ARG, "output buffer too small"); std::memcpy(out, o.data(), o.size()); }
+    return (int64_t)o.size();
+}
+
+int afq_rad_parse_prelude(const uint8_t* bytes, size_t n, afq_rad_info* out) {
+    if (!bytes || !out) return hfail(AFQ_ERR_INVALID_ARG, "null argument");
+    RadPrelude P;
+    int rc = parse_prelude(bytes, n, P, false);
+    if (rc) return rc;
+    out->ref_count = P.ref_count; out->num_chunks = P.num_chunks; out->first_chunk_off = P.first_chunk;
+    out->is_paired = P.is_paired; out->cblen = (uint32_t)P.file_tag_vals["cblen"]; out->ulen = (uint32_t)P.file_tag_vals["ulen"];
+    out->bc_bytes = P.bc_bytes; out->umi_bytes = P.umi_bytes;
+    return 0;
+}
+
+int afq_quantify(const afq_quant_opts* o) {
+    if (!o || !o->input_dir || !o->tg_map || !o->output_dir || !o->resolution) return hfail(AFQ_ERR_INVALID_ARG, "null option");
+    const ResolutionInfo* R = nullptr;
+    for (auto& r : kRes) { std::string a = o->resolution; for (auto& ch : a) ch = (char)std::tolower(ch); if (a == r.name) R = &r; }
+    if (!R) return hfail(AFQ_ERR_INVALID_ARG, std::string("unknown resolution ") + o->resolution);
+    // flag compatibility, src/main.rs:652-728
+    const int edist = o->umi_edit_dist < 0 ? (R->pars ? 1 : 0) : o->umi_edit_dist;
+    if (edist > 1 || (edist == 1 && !R->pars)) return hfail(AFQ_ERR_INVALID_ARG, "resolution does not support this --umi-edit-dist");
+    if (o->dump_eq) return hfail(AFQ_ERR_UNSUPPORTED, "-d/--dump-eqclasses is not implemented");
+    if (o->num_bootstraps) return hfail(AFQ_ERR_UNSUPPORTED, "-b/--num-bootstraps is not implemented");
+    const uint32_t large_thresh = o->large_graph_thresh < 0 ? (R->pars ? 1000u : 0u) : (uint32_t)o->large_graph_thresh;
+    const std::string in = o->input_dir, outd = o->output_dir;
+    // the permit-list json must exist (src/main.rs:733-734)
+    if (!file_exists(in + "/generate_permit_list.json")) return hfail(AFQ_ERR_BAD_INPUT, "the input directory has no generate_permit_list.json");
+    std::vector<uint8_t> cj;
+    if (!read_file(in + "/collate.json", cj)) return hfail(AFQ_ERR_BAD_INPUT, "could not read collate.json");
+    std::string cjs(cj.begin(), cj.end());
+    bool compressed = false;
+    { size_t k = cjs.find("\"compressed_output\""); if (k != std::string::npos) { size_t v = cjs.find_first_not_of(" \t\r\n:", k + 19); compressed = v != std::string::npos && cjs.compare(v, 4, "true") == 0; } }
+    std::vector<uint8_t> raw, rad;
+    if (!read_file(in + (compressed ? "/map.collated.rad.sz" : "/map.collated.rad"), raw)) return hfail(AFQ_ERR_BAD_INPUT, "could not read the collated RAD file");
+    if (compressed) { std::string err; if (!snappy_frame_decode(raw.data(), raw.size(), rad, err)) return hfail(AFQ_ERR_BAD_INPUT, "map.collated.rad.sz: " + err); raw.clear(); raw.shrink_to_fit(); }
+    else rad.swap(raw);
+    RadPrelude P;
+    int rc = parse_prelude(rad.data(), rad.size(), P, true);
+    if (rc) return rc;
+    if (!P.bc_bytes || !P.umi_bytes) return hfail(AFQ_ERR_UNSUPPORTED, "RAD read tags must hold integer 'b' and 'u' (single-barcode records)");
+    uint32_t cblen = 0;
+    if (P.file_tag_vals.count("cblen")) cblen = (uint32_t)P.file_tag_vals["cblen"];
+    else return hfail(AFQ_ERR_UNSUPPORTED, "no cblen file tag (multi-barcode RAD files are not supported)");
+    // chunk table: hop the nbytes headers (what the producer thread does)
+    std::vector<uint64_t> chunk_off;
+    for (size_t p = P.first_chunk; p < rad.size();) {
+        if (p + 8 > rad.size()) return hfail(AFQ_ERR_BAD_INPUT, "trailing bytes after the last chunk");
+        uint32_t nb; std::memcpy(&nb, rad.data() + p, 4);
+        if (nb < 8 || p + nb > rad.size()) return hfail(AFQ_ERR_BAD_INPUT, "corrupt chunk header");
+        chunk_off.push_back(p); p += nb;
+    }
+    // --quant-subset (src/quant.rs:1523-1536, 1776)
+    if (o->filter_list) {
+        std::ifstream f(o->filter_list);
+        if (!f) return hfail(AFQ_ERR_BAD_INPUT, "could not read the --quant-subset file");
+        std::unordered_set<uint64_t> keep; std::string line;
+        while (std::getline(f, line)) { while (!line.empty() && std::isspace((unsigned char)line.back())) line.pop_back(); uint64_t v; if (!line.empty() && string_to_bc(line, v)) keep.insert(v); }
+        std::vector<uint64_t> kept;
+        for (uint64_t off : chunk_off) { uint64_t bc = 0; std::memcpy(&bc, rad.data() + off + 8 + 4, P.bc_bytes); if (keep.count(bc)) kept.push_back(off); }
+        chunk_off.swap(kept);
+    }
+    // transcript-to-gene map (src/utils.rs:487-662)
+    std::unordered_map<std::string, uint32_t> rname_to_id;
+    for (uint32_t i = 0; i < P.ref_names.size(); ++i) rname_to_id[P.ref_names[i]] = i;
+    std::vector<uint32_t> t2g(P.ref_count, UINT32_MAX);
+    std::vector<std::string> gene_names; std::unordered_map<std::string, uint32_t> gene_id;
+    bool usa = false; size_t found = 0;
+    {
+        std::ifstream f(o->tg_map);
+        if (!f) return hfail(AFQ_ERR_BAD_INPUT, "couldn't open the transcript-to-gene map");
+        std::string line; int ncol = -1; uint32_t next_gid = 0;
+        while (std::getline(f, line)) {
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            if (line.empty()) continue;
+            std::vector<std::string> col; { std::stringstream ss(line); std::string c2; while (std::getline(ss, c2, '\t')) col.push_back(c2); }
+            if (ncol < 0) { ncol = (int)col.size(); if (ncol != 2 && ncol != 3) return hfail(AFQ_ERR_BAD_INPUT, "Transcript-gene mapping must have either 2 or 3 columns."); usa = ncol == 3; }
+            if ((int)col.size() != ncol) return hfail(AFQ_ERR_BAD_INPUT, "failed to parse the transcript-to-gene map : ragged row");
+            uint32_t gid;
+            auto it = gene_id.find(col[1]);
+            if (it == gene_id.end()) { gid = usa ? next_gid : (uint32_t)gene_names.size(); next_gid += 2; gene_id.emplace(col[1], gid); gene_names.push_back(col[1]); }
+            else gid = it->second;
+            auto rt = rname_to_id.find(col[0]);
+            if (rt == rname_to_id.end()) continue;
+            ++found;
+            if (!usa) t2g[rt->second] = gid;
+            else if (col[2] == "U" || col[2] == "u") t2g[rt->second] = gid + 1;
+            else if (col[2] == "S" || col[2] == "s") t2g[rt->second] = gid;
+            else return hfail(AFQ_ERR_BAD_INPUT, "Third column in 3 column txp-to-gene file must be S or U");
+        }
+    }
+    if (found != P.ref_count) return hfail(AFQ_ERR_BAD_INPUT, "The tg-map must contain a gene mapping for all transcripts in the header");
+    const uint32_t G = (uint32_t)gene_names.size();
+    afq_config cfg{};
+    cfg.abi_version = AFQ_ABI_VERSION; cfg.resolution = R->id; cfg.sa_model = AFQ_SA_WINNER_TAKE_ALL; cfg.usa_mode = usa;
+    cfg.num_genes = usa ? 2 * G : G; cfg.num_rows = usa ? 3 * G : G;  // src/quant.rs:1627-1645
+    cfg.small_thresh = o->small_thresh; cfg.large_graph_thresh = large_thresh; cfg.pug_exact_umi = (R->pars && edist == 0) ? 1 : 0;
+    cfg.em_init_uniform = o->init_uniform; cfg.bc_bytes = P.bc_bytes; cfg.umi_bytes = P.umi_bytes;
+    afq_ctx* ctx = nullptr;
+    rc = afq_create(&cfg, t2g.data(), (uint32_t)P.ref_count, (int)o->device, &ctx);
+    if (rc) return hfail(rc, std::string("afq_create: ") + afq_last_error(nullptr));
+
+    mkdirs(outd + "/alevin");
+    FILE* rows_f = std::fopen((outd + "/alevin/quants_mat_rows.txt").c_str(), "w");
+    FILE* feat_f = std::fopen((outd + "/featureDump.txt").c_str(), "w");
+    FILE* cols_f = std::fopen((outd + "/alevin/quants_mat_cols.txt").c_str(), "w");
+    if (!rows_f || !feat_f || !cols_f) { afq_destroy(ctx); return hfail(AFQ_ERR_BAD_INPUT, "could not create the output files"); }
+    std::fputs("CB\tCorrectedReads\tMappedReads\tDeduplicatedReads\tMappingRate\tDedupRate\tMeanByMax\tNumGenesExpressed\tNumGenesOverMean\n", feat_f);
+    for (auto& g : gene_names) std::fprintf(cols_f, "%s\n", g.c_str());
+    if (usa) { for (auto& g : gene_names) std::fprintf(cols_f, "%s-U\n", g.c_str()); for (auto& g : gene_names) std::fprintf(cols_f, "%s-A\n", g.c_str()); }
+    std::fclose(cols_f);
+
+    // batches of chunks to the device; rows come back in cell order
+    const uint64_t batch_bytes = o->batch_bytes ? o->batch_bytes : (1ull << 30);
+    std::vector<uint64_t> tri_rc; std::vector<float> tri_v;  // row<<32|col, value
+    std::vector<uint64_t> alt_cells, empty_cells, tiny_cells;
+    uint64_t total_records = 0, row_index = 0;
+    for (size_t c0 = 0; c0 < chunk_off.size();) {
+        size_t c1 = c0; uint64_t bytes = 0;
+        while (c1 < chunk_off.size()) { uint32_t nb; std::memcpy(&nb, rad.data() + chunk_off[c1], 4); if (c1 > c0 && bytes + nb > batch_bytes) break; bytes += nb; ++c1; }
+        rc = afq_submit(ctx, rad.data(), rad.size(), chunk_off.data() + c0, (uint32_t)(c1 - c0), c0);
+        afq_result res{};
+        if (!rc) rc = afq_collect(ctx, &res);
+        if (rc) { std::string m = afq_last_error(ctx); afq_destroy(ctx); std::fclose(rows_f); std::fclose(feat_f); return hfail(rc, m); }
+        for (uint64_t i = 0; i < res.n_cells; ++i) {
+            const uint64_t a = res.cell_ptr[i], b = res.cell_ptr[i + 1];
+            const uint64_t cell_num = c0 + i;
+            float sum = 0.0f, mx = 0.0f;  // src/quant.rs:1150-1171 (f32 sum in column order)
+            for (uint64_t k = a; k < b; ++k) { sum += res.val[k]; if (res.val[k] > mx) mx = res.val[k]; }
+            const uint32_t num_expr = (uint32_t)(b - a);
+            const uint32_t nrec = res.nrec[i];
+            const float dedup_rate = sum / (float)nrec;
+            const uint64_t num_unmapped = 0;
+            const float mapping_rate = (float)nrec / (float)(nrec + num_unmapped);
+            const float mean_expr = sum / (float)num_expr;
+            uint32_t over = 0;
+            for (uint64_t k = a; k < b; ++k) if (res.val[k] > mean_expr) ++over;
+            const float mean_by_max = mean_expr / mx;
+            const std::string bcs = bc_to_string(res.bc[i], cblen);
+            std::fprintf(rows_f, "%s\n", bcs.c_str());
+            std::fprintf(feat_f, "%s\t%llu\t%u\t%s\t%s\t%s\t%s\t%u\t%u\n", bcs.c_str(), (unsigned long long)(nrec + num_unmapped), nrec,
+                         f32s(sum).c_str(), f32s(mapping_rate).c_str(), f32s(dedup_rate).c_str(), f32s(mean_by_max).c_str(), num_expr, over);
+            for (uint64_t k = a; k < b; ++k) { tri_rc.push_back((row_index << 32) | res.gene[k]); tri_v.push_back(res.val[k]); }
+            if (res.flags[i] & AFQ_CELL_ALT_RES) alt_cells.push_back(cell_num);
+            if (res.flags[i] & AFQ_CELL_EMPTY) empty_cells.push_back(cell_num);
+            if (res.flags[i] & AFQ_CELL_TINY_PATH) tiny_cells.push_back(cell_num);
+            total_records += nrec;
+            ++row_index;
+        }
+        afq_result_release(&res);
+        c0 = c1;
+    }
+    afq_destroy(ctx);
+    std::fclose(rows_f); std::fclose(feat_f);
+    // MatrixMarket as sprs::io::write_matrix_market writes a TriMatI<f32,u32> (coordinate real general, 1-based)
+    {
+        FILE* m = std::fopen((outd + "/alevin/quants_mat.mtx").c_str(), "w");
+        if (!m) return hfail(AFQ_ERR_BAD_INPUT, "could not create quants_mat.mtx");
+        std::fprintf(m, "%%%%MatrixMarket matrix coordinate real general\n%% written by sprs\n%llu %u %zu\n", (unsigned long long)row_index, cfg.num_rows, tri_v.size());
+        for (size_t k = 0; k < tri_v.size(); ++k) std::fprintf(m, "%llu %llu %s\n", (unsigned long long)(tri_rc[k] >> 32) + 1, (unsigned long long)(tri_rc[k] & 0xFFFFFFFFu) + 1, f32s(tri_v[k]).c_str());
+        std::fclose(m);
+    }
+    // quant.json (src/quant.rs:1913-1933)
+    {
+        FILE* j = std::fopen((outd + "/quant.json").c_str(), "w");
+        if (!j) return hfail(AFQ_ERR_BAD_INPUT, "could not create quant.json");
+        auto list = [&](const std::vector<uint64_t>& v) { std::string s = "["; for (size_t i = 0; i < v.size(); ++i) { if (i) s += ", "; s += std::to_string(v[i]); } return s + "]"; };
+        std::fprintf(j, "{\n  \"cmd\": \"%s\",\n  \"version_str\": \"afquant-hip 0.1 (alevin-fry 0.18.0 quant semantics)\",\n  \"resolution_strategy\": \"%s\",\n",
+                     json_escape(o->cmdline ? o->cmdline : "").c_str(), R->debug);
+        std::fprintf(j, "  \"num_quantified_cells\": %llu,\n  \"num_genes\": %u,\n  \"dump_eq\": false,\n  \"usa_mode\": %s,\n", (unsigned long long)row_index, cfg.num_rows, usa ? "true" : "false");
+        std::fprintf(j, "  \"alt_resolved_cell_numbers\": %s,\n  \"empty_resolved_cell_numbers\": %s,\n  \"num_tiny_cell_resolved\": %zu,\n  \"tiny_cell_resolved_cell_numbers\": %s,\n",
+                     list(alt_cells).c_str(), list(empty_cells).c_str(), tiny_cells.size(), list(tiny_cells).c_str());
+        std::fprintf(j, "  \"total_records\": %llu,\n  \"quant_options\": {\n    \"input_dir\": \"%s\",\n    \"tg_map\": \"%s\",\n    \"output_dir\": \"%s\",\n    \"num_threads\": %u,\n    \"num_bootstraps\": 0,\n    \"init_uniform\": %s,\n    \"summary_stat\": false,\n    \"dump_eq\": false,\n    \"resolution\": \"%s\",\n    \"pug_exact_umi\": %s,\n    \"sa_model\": \"WinnerTakeAll\",\n    \"small_thresh\": %u,\n    \"large_graph_thresh\": %u,\n    \"filter_list\": %s%s%s,\n    \"cmdline\": \"%s\"\n  }\n}\n",
+                     (unsigned long long)total_records, json_escape(in).c_str(), json_escape(o->tg_map).c_str(), json_escape(outd).c_str(), o->num_threads, o->init_uniform ? "true" : "false",
+                     R->debug, cfg.pug_exact_umi ? "true" : "false", o->small_thresh, large_thresh, o->filter_list ? "\"" : "", o->filter_list ? json_escape(o->filter_list).c_str() : "null", o->filter_list ? "\"" : "",
+                     json_escape(o->cmdline ? o->cmdline : "").c_str());
+        std::fclose(j);
+    }
+    return 0;
+}
+
+}  // extern "C"

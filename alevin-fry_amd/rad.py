@@ -136,3 +136,109 @@ def chunk_offsets(buf, start: int = 0):
     if p != len(b):
         raise ValueError("trailing bytes after last chunk")
     return np.asarray(offs, dtype=np.uint64)
+
+
+# ---------------------------------------------------------------------------
+# whole-file writer (test fixtures / synthetic inputs for the host front-end)
+_INT_TYPE_ID = {1: 1, 2: 2, 4: 3, 8: 4}  # bytes -> RadType id (U8..U64)
+
+
+def rad_prelude(ref_names, num_chunks, cblen, ulen, bc_bytes=4, umi_bytes=4, is_paired=False) -> bytes:
+    """Header + the three tag sections + file-tag values of a single-barcode scRNA RAD file
+    (order of writes in src/convert.rs:254-369)."""
+    out = bytearray()
+    out += bytes([1 if is_paired else 0])
+    out += len(ref_names).to_bytes(8, "little")
+    for n in ref_names:
+        b = n.encode()
+        out += len(b).to_bytes(2, "little") + b
+    out += int(num_chunks).to_bytes(8, "little")
+
+    def tag(name, type_id):
+        b = name.encode()
+        return len(b).to_bytes(2, "little") + b + bytes([type_id])
+
+    out += (2).to_bytes(2, "little") + tag("cblen", 2) + tag("ulen", 2)  # file tags (u16, u16)
+    out += (2).to_bytes(2, "little") + tag("b", _INT_TYPE_ID[bc_bytes]) + tag("u", _INT_TYPE_ID[umi_bytes])  # read tags
+    out += (1).to_bytes(2, "little") + tag("compressed_ori_refid", 3)  # alignment tags
+    out += int(cblen).to_bytes(2, "little") + int(ulen).to_bytes(2, "little")  # file tag values
+    return bytes(out)
+
+
+def _crc32c(data: bytes) -> int:
+    tbl = getattr(_crc32c, "_t", None)
+    if tbl is None:
+        tbl = []
+        for i in range(256):
+            c = i
+            for _ in range(8):
+                c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+            tbl.append(c)
+        _crc32c._t = tbl
+    c = 0xFFFFFFFF
+    for b in data:
+        c = tbl[(c ^ b) & 0xFF] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def snappy_frame_encode(data: bytes, chunk: int = 60000, compress_literal: bool = True) -> bytes:
+    """Minimal Snappy *frame format* writer: stream identifier + one chunk per `chunk` bytes, alternating
+    uncompressed chunks (type 0x01) and compressed chunks (type 0x00) whose block is literals only.
+    Enough to exercise the decoder; a real file comes from `snap::write::FrameEncoder` (src/collate.rs:550-554)."""
+    out = bytearray(b"\xff\x06\x00\x00sNaPpY")
+    for k, i in enumerate(range(0, len(data), chunk)):
+        piece = data[i : i + chunk]
+        crc = _crc32c(piece)
+        m = (((crc >> 15) | (crc << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+        if compress_literal and k % 2 == 1:
+            n = len(piece)
+            blk = bytearray()
+            v = n
+            while True:  # uvarint of the uncompressed length
+                if v < 0x80:
+                    blk.append(v)
+                    break
+                blk.append((v & 0x7F) | 0x80)
+                v >>= 7
+            ln = n - 1
+            if ln < 60:
+                blk.append(ln << 2)
+            elif ln < 256:
+                blk += bytes([60 << 2, ln])
+            elif ln < 65536:
+                blk += bytes([61 << 2]) + ln.to_bytes(2, "little")
+            else:
+                blk += bytes([62 << 2]) + ln.to_bytes(3, "little")
+            blk += piece
+            body = m.to_bytes(4, "little") + bytes(blk)
+            out += b"\x00" + len(body).to_bytes(3, "little") + body
+        else:
+            body = m.to_bytes(4, "little") + piece
+            out += b"\x01" + len(body).to_bytes(3, "little") + body
+    return bytes(out)
+
+
+def write_quant_input_dir(path, chunk_bytes, n_chunks, ref_names, t2g_rows, cblen=16, ulen=12, bc_bytes=4, umi_bytes=4,
+                          compressed=False):
+    """Lay out what `alevin-fry quant -i` expects: generate_permit_list.json, collate.json,
+    map.collated.rad[.sz], plus the tg-map next to it.  t2g_rows: list of tab-separated row tuples."""
+    import json
+    import os
+
+    os.makedirs(path, exist_ok=True)
+    data = rad_prelude(ref_names, n_chunks, cblen, ulen, bc_bytes, umi_bytes) + bytes(chunk_bytes)
+    with open(os.path.join(path, "generate_permit_list.json"), "w") as f:
+        json.dump({"velo_mode": False, "expected_ori": "fw"}, f)
+    with open(os.path.join(path, "collate.json"), "w") as f:
+        json.dump({"cmd": "synthetic", "version_str": "0.18.0", "compressed_output": bool(compressed)}, f)
+    if compressed:
+        with open(os.path.join(path, "map.collated.rad.sz"), "wb") as f:
+            f.write(snappy_frame_encode(data))
+    else:
+        with open(os.path.join(path, "map.collated.rad"), "wb") as f:
+            f.write(data)
+    tg = os.path.join(path, "t2g.tsv")
+    with open(tg, "w") as f:
+        for row in t2g_rows:
+            f.write("\t".join(row) + "\n")
+    return tg

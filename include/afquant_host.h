@@ -1,0 +1,55 @@
+/*
+ * afquant_host.h — the host side around the quant hot path, in C++ because the
+ * reference's host is compiled code and this image has no Rust toolchain.  It mirrors what
+ * `alevin_fry::quant::quantify(QuantOpts)` does around the per-cell loop (src/quant.rs:359-396,
+ * 1327-1951 of the reference): read `collate.json`, open `map.collated.rad[.sz]`, parse the RAD
+ * prelude and the transcript-to-gene map, feed the collated chunks to the device through afquant.h,
+ * and write `alevin/quants_mat.{mtx,_rows.txt,_cols.txt}`, `featureDump.txt` and `quant.json`.
+ */
+#ifndef AFQUANT_HOST_H
+#define AFQUANT_HOST_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* QuantOpts (src/prog_opts.rs:24-44) — the CLI-visible options of `alevin-fry quant` (src/main.rs:294-348). */
+typedef struct afq_quant_opts {
+    const char* input_dir;      /* -i : directory holding map.collated.rad[.sz], collate.json, generate_permit_list.json */
+    const char* tg_map;         /* -m : 2- or 3-column transcript-to-gene TSV                                             */
+    const char* output_dir;     /* -o                                                                                      */
+    const char* resolution;     /* -r : trivial | cr-like | cr-like-em | parsimony | parsimony-em | parsimony-gene | parsimony-gene-em */
+    const char* filter_list;    /* --quant-subset : file of barcodes to quantify, or NULL                                  */
+    const char* cmdline;        /* recorded in quant.json                                                                  */
+    uint32_t num_threads;       /* -t : accepted for compatibility; the device does the per-cell work                      */
+    uint32_t small_thresh;      /* --small-thresh (default 100)                                                            */
+    int32_t umi_edit_dist;      /* --umi-edit-dist : -1 = default by resolution (main.rs:652-703)                          */
+    int32_t large_graph_thresh; /* --large-graph-thresh : -1 = default by resolution (main.rs:332-341)                     */
+    uint32_t init_uniform;      /* --init-uniform                                                                          */
+    uint32_t dump_eq;           /* -d : not implemented (rejected)                                                         */
+    uint32_t num_bootstraps;    /* -b : not implemented (rejected)                                                         */
+    uint32_t device;            /* HIP device ordinal                                                                      */
+    uint64_t batch_bytes;       /* chunk bytes handed to the device per afq_submit (0 = 1 GiB)                             */
+} afq_quant_opts;
+
+/* Runs the whole `quant` sub-command.  Returns 0 or a negative AFQ_ERR_* code; message via afq_host_last_error(). */
+int afq_quantify(const afq_quant_opts* opts);
+const char* afq_host_last_error(void);
+
+/* ---- pieces exposed for the CPU tests (no GPU needed) ---- */
+/* Rust `{}` formatting of an f32 (shortest round-trip digits, never an exponent; "NaN", "inf"). Returns length. */
+int afq_format_f32(float v, char* buf, size_t cap);
+/* Snappy *frame format* decode (what `snap::read::FrameDecoder` undoes, src/quant.rs:376). out may be NULL to size. */
+int64_t afq_snappy_frame_decode(const uint8_t* in, size_t n, uint8_t* out, size_t cap);
+/* Parse a RAD prelude; fills the scalars, returns the byte offset of the first chunk or a negative error. */
+typedef struct afq_rad_info {
+    uint64_t ref_count, num_chunks, first_chunk_off;
+    uint32_t is_paired, cblen, ulen, bc_bytes, umi_bytes;
+} afq_rad_info;
+int afq_rad_parse_prelude(const uint8_t* bytes, size_t n, afq_rad_info* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

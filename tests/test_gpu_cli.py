@@ -1,0 +1,109 @@
+"""GPU end-to-end test of the drop-in surface: `afquant quant` (same flags and directory protocol as
+`alevin-fry quant`) on a synthetic collated-RAD directory; outputs are joined on (barcode string, gene name)
+exactly as scripts/testing/compare_counts.py of the reference does, against the oracle's rows."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from util import ROOT, cfg_for, pkg
+
+pytestmark = pytest.mark.gpu
+rad = pkg.rad
+synth = pkg.synth
+CLI = os.path.join(ROOT, "alevin-fry_amd", "csrc", "afquant")
+
+
+def make_dir(tmp, s, compressed):
+    b, off = s.encode()
+    G = s.num_rows // 3 if s.usa else s.num_genes
+    tpg = (len(s.tid_to_gid) - (G if s.usa else 0)) // G
+    names = [f"T{t}" for t in range(len(s.tid_to_gid))]
+    rows = []
+    for t, gid in enumerate(s.tid_to_gid.tolist()):
+        if s.usa:
+            rows.append((names[t], f"G{gid >> 1}", "S" if gid % 2 == 0 else "U"))
+        else:
+            rows.append((names[t], f"G{gid}"))
+    tg = rad.write_quant_input_dir(str(tmp), np.asarray(b).tobytes(), len(off), names, rows, cblen=16, ulen=s.umi_len,
+                                   compressed=compressed)
+    return tg, b, off
+
+
+def read_outputs(out):
+    rows = open(os.path.join(out, "alevin", "quants_mat_rows.txt")).read().split()
+    cols = open(os.path.join(out, "alevin", "quants_mat_cols.txt")).read().split()
+    lines = open(os.path.join(out, "alevin", "quants_mat.mtx")).read().splitlines()
+    assert lines[0].startswith("%%MatrixMarket matrix coordinate real general")
+    body = [l for l in lines if not l.startswith("%")]
+    nr, nc, nnz = map(int, body[0].split())
+    trip = {}
+    for l in body[1:]:
+        r, c, v = l.split()
+        trip[(rows[int(r) - 1], cols[int(c) - 1])] = float(v)
+    assert len(trip) == nnz and nr == len(rows) and nc == len(cols)
+    feat = [l.split("\t") for l in open(os.path.join(out, "featureDump.txt")).read().splitlines()]
+    meta = json.load(open(os.path.join(out, "quant.json")))
+    return rows, cols, trip, feat, meta
+
+
+@pytest.mark.parametrize("res,usa,compressed", [("cr-like", False, False), ("parsimony-em", True, True), ("cr-like-em", True, False)])
+def test_afquant_cli_matches_oracle(tmp_path, oracle, res, usa, compressed):
+    s = synth.synth(51, [4000, 1500, 600, 260, 120, 60, 7], num_genes=150, txp_per_gene=3, usa=usa, dup=0.5, cross=0.3, umi_err=0.02)
+    tg, b, off = make_dir(tmp_path / "in", s, compressed)
+    out = str(tmp_path / "out")
+    r = subprocess.run([CLI, "quant", "-i", str(tmp_path / "in"), "-m", tg, "-o", out, "-r", res, "-t", "4"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows, cols, trip, feat, meta = read_outputs(out)
+    want = oracle.quant(cfg_for(s, res), s.tid_to_gid, b, off)
+    G = s.num_rows // 3 if usa else s.num_genes
+    gname = [f"G{i}" for i in range(G)]
+    colname = gname + [g + "-U" for g in gname] + [g + "-A" for g in gname] if usa else gname
+    assert cols == colname
+    exp = {}
+    for i in range(want.n_cells):
+        bcs = rad.int_to_seq(int(want.bc[i]), 16)
+        g, v = want.row(i)
+        for a, x in zip(g.tolist(), v.tolist()):
+            exp[(bcs, colname[a])] = x
+    assert set(trip) == set(exp)
+    for k in exp:  # MTX values are the shortest round-trip text of the f32: parse back to the same f32
+        assert np.float32(trip[k]) == np.float32(exp[k]), k
+    assert rows == [rad.int_to_seq(int(x), 16) for x in want.bc]
+    # featureDump: header, one row per cell, the reference's columns (src/quant.rs:1609-1612, 1248-1260)
+    assert feat[0] == ["CB", "CorrectedReads", "MappedReads", "DeduplicatedReads", "MappingRate", "DedupRate", "MeanByMax", "NumGenesExpressed", "NumGenesOverMean"]
+    for i in range(want.n_cells):
+        st = want.cell_stats(i)
+        f = feat[1 + i]
+        assert f[0] == rows[i] and int(f[1]) == int(want.nrec[i]) == int(f[2]) and int(f[7]) == st["num_expr"] and int(f[8]) == st["num_genes_over_mean"]
+        assert np.float32(float(f[3])) == np.float32(st["sum_umi"]) and float(f[4]) == 1.0
+        assert np.float32(float(f[5])) == np.float32(st["dedup_rate"])
+    assert meta["resolution_strategy"] in ("CellRangerLike", "ParsimonyEm", "CellRangerLikeEm") and meta["usa_mode"] == usa
+    assert meta["num_quantified_cells"] == want.n_cells and meta["num_genes"] == s.num_rows
+    assert meta["tiny_cell_resolved_cell_numbers"] == [i for i in range(want.n_cells) if want.flags[i] & 1]
+    assert meta["empty_resolved_cell_numbers"] == [i for i in range(want.n_cells) if want.flags[i] & 4]
+
+
+def test_afquant_cli_quant_subset_and_flag_errors(tmp_path, oracle):
+    s = synth.synth(52, [900, 500, 300, 100], num_genes=80, dup=0.4)
+    tg, b, off = make_dir(tmp_path / "in", s, False)
+    keep = [1, 3]
+    sub = tmp_path / "subset.txt"
+    sub.write_text("\n".join(rad.int_to_seq(int(s.cell_bc[i]), 16) for i in keep) + "\n")
+    out = str(tmp_path / "out")
+    r = subprocess.run([CLI, "quant", "-i", str(tmp_path / "in"), "-m", tg, "-o", out, "-r", "cr-like", "--quant-subset", str(sub)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows, cols, trip, feat, meta = read_outputs(out)
+    assert rows == [rad.int_to_seq(int(s.cell_bc[i]), 16) for i in keep] and meta["num_quantified_cells"] == 2
+    want = oracle.quant(cfg_for(s, "cr-like"), s.tid_to_gid, b, off[keep])
+    assert abs(sum(trip.values()) - float(want.val.sum())) < 1e-3
+    # cr-like does not take --umi-edit-dist 1 (src/main.rs:674-688); -b / -d are refused, not ignored
+    for extra in (["--umi-edit-dist", "1"], ["-b", "10"], ["-d"]):
+        r = subprocess.run([CLI, "quant", "-i", str(tmp_path / "in"), "-m", tg, "-o", out, "-r", "cr-like"] + extra, capture_output=True, text=True)
+        assert r.returncode != 0 and "afquant quant failed" in r.stderr
+    os.remove(tmp_path / "in" / "generate_permit_list.json")
+    r = subprocess.run([CLI, "quant", "-i", str(tmp_path / "in"), "-m", tg, "-o", out, "-r", "cr-like"], capture_output=True, text=True)
+    assert r.returncode != 0 and "generate_permit_list.json" in r.stderr
