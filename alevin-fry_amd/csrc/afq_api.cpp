@@ -720,12 +720,24 @@ int afq_submit(afq_ctx* c, const uint8_t* bytes, size_t n_bytes, const uint64_t*
         c->hdr[2 * i] = h[0];
         c->hdr[2 * i + 1] = h[1];
     }
-    HIP_TRY(c, c->d_bytes_own.ensure(n_bytes + 16));
-    if (n_bytes) HIP_TRY(c, hipMemcpyAsync(c->d_bytes_own.p, bytes, n_bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemsetAsync((uint8_t*)c->d_bytes_own.p + n_bytes, 0, 16, c->stream));
+    // A RAD file's prelude has an arbitrary length, so chunk offsets inside the caller's buffer are usually not
+    // dword-aligned although every chunk size is a multiple of 4.  The bytes are copied anyway: land them shifted so
+    // that the chunks start on dword boundaries on the device (that is what the walk-free decode and the PUG path need).
+    uint32_t shift = 0;
+    if (n_cells) {
+        const uint32_t r = (uint32_t)(chunk_off[0] & 3);
+        bool same = true;
+        for (uint32_t i = 1; i < n_cells && same; ++i) same = (chunk_off[i] & 3) == r;
+        if (same) shift = (4 - r) & 3;
+    }
+    HIP_TRY(c, c->d_bytes_own.ensure(n_bytes + shift + 16));
+    if (shift) HIP_TRY(c, hipMemsetAsync(c->d_bytes_own.p, 0, 4, c->stream));
+    if (n_bytes) HIP_TRY(c, hipMemcpyAsync((uint8_t*)c->d_bytes_own.p + shift, bytes, n_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync((uint8_t*)c->d_bytes_own.p + shift + n_bytes, 0, 16, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller keeps ownership of `bytes`
+    if (shift) for (auto& o : c->chunk_off) o += shift;
     c->d_bytes = c->d_bytes_own.as<uint8_t>();
-    c->n_bytes = n_bytes;
+    c->n_bytes = n_bytes + shift;
     return submit_common(c, n_cells, first_cell_index);
 }
 
