@@ -963,12 +963,50 @@ __device__ __forceinline__ uint32_t* lab_alloc_global(const LabArea& la, uint32_
     return gw + off;
 }
 
+
 #ifdef AFQ_RESOLVE_TIMING
 __device__ unsigned long long g_dbg[8];
 #define RT_MARK(i) do { if (threadIdx.x == 0 && (blockIdx.x & 1023) == 0) { unsigned long long t_ = clock64(); atomicAdd(&g_dbg[i], t_ - tprev_); atomicAdd(&g_dbg[4 + (i & 3)], 1ull); tprev_ = t_; } } while (0)
 #else
 #define RT_MARK(i) do {} while (0)
 #endif
+
+// What follows the resolution of one bucket: s_cols[0..nc) are its molecules' columns.  A bucket of a
+// multi-bucket cell appends them to the cell's column list (one reservation per bucket); a single-bucket
+// cell is finished here (columns sorted, run-length counted, written as (column,count) pairs).
+template <int NT>
+__device__ __forceinline__ void bucket_tail(const BucketDesc& d, uint64_t* __restrict__ keys0,
+                                            uint32_t* __restrict__ cell_ncols, uint32_t* __restrict__ nnz,
+                                            const uint32_t* s_cols, uint32_t nc, uint32_t* s_sorted, uint16_t* s_run,
+                                            uint32_t* s_ws, uint32_t* s_misc) {
+    const bool single = (d.mode_single >> 8) != 0;
+    if (!single) {
+        if (nc == 0) return;
+        if (threadIdx.x == 0) s_misc[1] = atomicAdd(&cell_ncols[d.cell], nc);
+        __syncthreads();
+        uint32_t* out = reinterpret_cast<uint32_t*>(keys0 + d.out_off) + s_misc[1];  // keys0 slots are dead after k_scatter
+        for (uint32_t i = threadIdx.x; i < nc; i += NT) out[i] = s_cols[i];
+        return;
+    }
+    // single-bucket cell: sort the columns, run-length count, write (column,count) pairs
+    block_sort_any<NT, uint32_t>(s_cols, nc, s_sorted, 0xFFFFFFFFu);
+    uint2* out = reinterpret_cast<uint2*>(keys0 + d.out_off);
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nc; base += NT) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t f = (i < nc) && (i == 0 || s_sorted[i] != s_sorted[i - 1]);
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<NT>(f, s_ws, tot);
+        if (f) s_run[carry + ex] = (uint16_t)i;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) nnz[d.cell] = carry;
+    __syncthreads();
+    for (uint32_t h = threadIdx.x; h < carry; h += NT) {
+        const uint32_t a = s_run[h], e = h + 1 < carry ? (uint32_t)s_run[h + 1] : nc;
+        out[h] = make_uint2(s_sorted[a], e - a);
+    }
+}
 
 // Sort + resolve one bucket held in LDS.  NT threads, up to NT*8 keys.
 template <int NT>
@@ -989,7 +1027,6 @@ __device__ __forceinline__ void resolve_bucket_lds(const BucketDesc& d, uint64_t
     unsigned long long tprev_ = clock64();
 #endif
     block_sort_any<NT, uint64_t>(src, n, s_keys, kKeySentinel);
-    RT_MARK(0);
     resolve_sorted<NT>(s_keys, n, s_run, s_ws, rcb, [&](uint32_t col) {
         if (col >= rc.num_rows) { set_err(st, kErrSlotRange, d.cell); return; }
         s_cols[atomicAdd(&s_misc[0], 1u)] = col;
@@ -1001,7 +1038,6 @@ __device__ __forceinline__ void resolve_bucket_lds(const BucketDesc& d, uint64_t
         return s_lab + off;
     });
     __syncthreads();
-    RT_MARK(1);
     const uint32_t nc = s_misc[0];
     if (s_lab && s_misc[3]) {  // hand the bucket's ambiguous molecules to the cell's label area
         const uint32_t lw = s_misc[2], ln = s_misc[3];
@@ -1018,41 +1054,204 @@ __device__ __forceinline__ void resolve_bucket_lds(const BucketDesc& d, uint64_t
             gd[2 * (s_misc[5] + i) + 1] = s_ldesc[2 * i + 1];
         }
     }
-    if (!single) {
-        if (nc == 0) return;
-        if (threadIdx.x == 0) s_misc[1] = atomicAdd(&cell_ncols[d.cell], nc);
-        __syncthreads();
-        uint32_t* out = reinterpret_cast<uint32_t*>(keys0 + d.out_off) + s_misc[1];  // keys0 slots are dead after k_scatter
-        RT_MARK(2);
-        for (uint32_t i = threadIdx.x; i < nc; i += NT) out[i] = s_cols[i];
-        RT_MARK(3);
-        return;
-    }
-    // single-bucket cell: sort the columns, run-length count, write (column,count) pairs
-    uint32_t* s_sorted = reinterpret_cast<uint32_t*>(s_keys);  // keys are dead
-    block_sort_any<NT, uint32_t>(s_cols, nc, s_sorted, 0xFFFFFFFFu);
-    uint2* out = reinterpret_cast<uint2*>(keys0 + d.out_off);
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < nc; base += NT) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t f = (i < nc) && (i == 0 || s_sorted[i] != s_sorted[i - 1]);
-        uint32_t tot;
-        const uint32_t ex = block_excl_scan<NT>(f, s_ws, tot);
-        if (f) s_run[carry + ex] = (uint16_t)i;
-        carry += tot;
-    }
-    if (threadIdx.x == 0) nnz[d.cell] = carry;
-    __syncthreads();
-    for (uint32_t h = threadIdx.x; h < carry; h += NT) {
-        const uint32_t a = s_run[h], e = h + 1 < carry ? (uint32_t)s_run[h + 1] : nc;
-        out[h] = make_uint2(s_sorted[a], e - a);
-    }
+    bucket_tail<NT>(d, keys0, cell_ncols, nnz, s_cols, nc, reinterpret_cast<uint32_t*>(s_keys), s_run, s_ws, s_misc);
 }
 
-// One 2-wave workgroup per bucket (up to kBucketCap keys).  Small workgroups keep
-// many buckets in flight per CU, which is what hides the load -> sort -> reserve ->
-// store latency chain; blocks that run together are spread over different cells
-// (column-major walk) so their reservations do not pile onto one counter.
+
+// ---- hash-table resolution of a cr-like bucket (one wave) ----
+// A bucket holds every (umi, gene) key of the UMIs that hash to it, so the winner-take-all rule needs no
+// order, only grouping: the wave inserts its keys into an LDS open-addressing table keyed by UMI whose slots
+// carry up to kHtPairs (gene:20 | reads:12) counters, then walks the slots once and maps each UMI's
+// most-supported gene(s) to a column.  O(1) LDS atomics per key instead of the O(log^2 n) compare-exchanges
+// of a sort.  Anything the slots cannot express (a UMI seen with more than kHtPairs genes, a UMI that does
+// not fit 32 bits) sends the whole bucket down the sort path - same result, just slower.
+constexpr uint32_t kHtKeys = 256;            // buckets up to this many keys take the table (nearly all: the planner aims at kBucketTarget)
+constexpr uint32_t kHtCap = 2 * kHtKeys;      // slots: load factor <= 0.5
+constexpr uint32_t kHtPairs = 3;
+constexpr uint32_t kNoCol = 0xFFFFFFFFu;
+static_assert(kHtKeys < (1u << 12), "per-bucket read counts fit the 12-bit counter");
+
+__device__ __forceinline__ uint32_t ht_slot(uint32_t umi, uint32_t mask) {
+    uint32_t x = umi ^ (umi >> 15);
+    x *= 0x85EBCA6Bu;
+    return (x >> 16) & mask;
+}
+
+// column of one UMI from its (gene, reads) counters; same rule table as resolve_sorted
+__device__ __forceinline__ uint32_t col_from_pairs(uint32_t p0, uint32_t p1, uint32_t p2, const ResolveCfg& rc) {
+    const uint32_t c0 = p0 & 0xFFFu, c1 = p1 & 0xFFFu, c2 = p2 & 0xFFFu;  // unused counter: 0 reads
+    const uint32_t maxc = max(c0, max(c1, c2));
+    uint32_t a = c0 == maxc ? p0 >> 12 : kNoCol, b = c1 == maxc ? p1 >> 12 : kNoCol, c = c2 == maxc ? p2 >> 12 : kNoCol;
+    uint32_t t;
+    if (a > b) { t = a; a = b; b = t; }
+    if (b > c) { t = b; b = c; c = t; }
+    if (a > b) { t = a; a = b; b = t; }
+    const uint32_t nb = (a != kNoCol) + (b != kNoCol) + (c != kNoCol);   // winners a <= b <= c, ascending gene id
+    if (!rc.usa) return nb == 1 ? a : kNoCol;
+    if (nb == 1) return is_spliced(a) ? (a >> 1) : rc.uo + (a >> 1);
+    if (nb == 2) {
+        if (same_gene(a, b)) return rc.ao + (a >> 1);
+        if (is_spliced(a) && !is_spliced(b)) return a >> 1;
+        if (!is_spliced(a) && is_spliced(b)) return b >> 1;
+        return kNoCol;
+    }
+    const uint32_t nsp = is_spliced(a) + is_spliced(b) + is_spliced(c);
+    if (nsp != 1) return kNoCol;
+    if (is_spliced(a)) return same_gene(a, b) ? rc.ao + (a >> 1) : (a >> 1);
+    if (is_spliced(b)) return same_gene(b, c) ? rc.ao + (b >> 1) : (b >> 1);
+    return c >> 1;
+}
+
+// A UMI seen with more than kHtPairs genes parks the extra keys in a short list and is resolved by one lane
+// walking that list (rare: a fraction of a percent of the UMIs).  Same rule table again, stated on order-free
+// aggregates of the winner set W: |W|, its two smallest genes, its spliced members, and whether the sibling
+// (g+1) of its smallest spliced gene is in W - which is what "the next winner in gene order is the same
+// gene" means for ascending ids 2g, 2g+1.
+constexpr uint32_t kHtOvf = 64;
+template <typename ForEach>
+__device__ __forceinline__ uint32_t col_from_candidates(ForEach&& for_each, const ResolveCfg& rc) {
+    uint32_t maxc = 0;
+    for_each([&](uint32_t, uint32_t c) { maxc = c > maxc ? c : maxc; });
+    uint32_t nb = 0, g1 = kNoCol, g2 = kNoCol, nsp = 0, first_sp = kNoCol;
+    for_each([&](uint32_t g, uint32_t c) {
+        if (c != maxc) return;
+        ++nb;
+        if (g < g1) { g2 = g1; g1 = g; } else if (g < g2) g2 = g;
+        if (is_spliced(g)) { ++nsp; first_sp = g < first_sp ? g : first_sp; }
+    });
+    if (!rc.usa) return nb == 1 ? g1 : kNoCol;
+    if (nb == 1) return is_spliced(g1) ? (g1 >> 1) : rc.uo + (g1 >> 1);
+    if (nb == 2) {
+        if (same_gene(g1, g2)) return rc.ao + (g1 >> 1);
+        if (is_spliced(g1) && !is_spliced(g2)) return g1 >> 1;
+        if (!is_spliced(g1) && is_spliced(g2)) return g2 >> 1;
+        return kNoCol;
+    }
+    if (nb > 10 || nsp != 1) return kNoCol;
+    bool followed = false;
+    for_each([&](uint32_t g, uint32_t c) { if (c == maxc && g == first_sp + 1) followed = true; });
+    return followed ? rc.ao + (first_sp >> 1) : (first_sp >> 1);
+}
+
+// One wave, n <= kHtKeys.  Slot = one 64-bit word (umi:32 | gene:20 | reads:12) holding the UMI and its first
+// gene's counter - a UMI seen with one gene, the common case, costs one CAS plus one add per further read - and
+// kHtPairs-1 more (gene | reads) counters.  The lane whose CAS claims a slot owns that UMI and resolves it.
+// On success the bucket's columns are in s_cols[0..nc) and true is returned.
+__device__ __forceinline__ bool resolve_bucket_hash(const uint64_t* __restrict__ src, uint32_t n, const ResolveCfg& rc,
+                                                    unsigned long long* s_slot, uint32_t* s_pair, uint64_t* s_ovf,
+                                                    uint32_t* s_flag, uint32_t* s_novf, uint32_t* s_cols, DevStatus* st,
+                                                    uint32_t cell, uint32_t& nc_out) {
+    constexpr uint32_t E = kHtKeys / 64;
+    constexpr unsigned long long kEmpty64 = ~0ull;
+    const uint32_t lane = threadIdx.x;
+#ifdef AFQ_RESOLVE_TIMING
+    unsigned long long tprev_ = clock64();
+#endif
+    uint64_t key[E];
+#pragma unroll
+    for (uint32_t h = 0; h < E; ++h) key[h] = h * 64 + lane < n ? src[h * 64 + lane] : 0ull;
+    uint32_t cap = 128;
+    while (cap < 2 * n) cap <<= 1;
+    const uint32_t mask = cap - 1;
+    {
+        uint4* u4 = reinterpret_cast<uint4*>(s_slot);
+        uint4* p4 = reinterpret_cast<uint4*>(s_pair);
+        for (uint32_t i = lane; i < cap / 2; i += 64) u4[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+        for (uint32_t i = lane; i < cap * (kHtPairs - 1) / 4; i += 64) p4[i] = make_uint4(0, 0, 0, 0);
+        if (lane < kHtCap / 32) s_flag[lane] = 0;
+        if (lane == 0) *s_novf = 0;
+    }
+    __syncthreads();
+#ifdef AFQ_RESOLVE_TIMING
+    if (key[0] == 1234567ull) return false;  // wait for the loads so that their latency lands in phase 0
+#endif
+    RT_MARK(0);
+    bool bad = false;
+    uint32_t own_slot[E];
+#pragma unroll
+    for (uint32_t h = 0; h < E; ++h) {
+        own_slot[h] = kNoCol;
+        if (h * 64 >= n) break;
+        if (h * 64 + lane < n) {
+            const uint64_t u64 = key[h] >> kGeneBits;
+            const uint32_t gene = (uint32_t)key[h] & kGeneMask;
+            if (u64 >= 0xFFFFFFFFull) bad = true;  // does not fit the slot word (or would read as "empty")
+            else {
+                const uint32_t umi = (uint32_t)u64;
+                const unsigned long long mine = ((unsigned long long)umi << 32) | (gene << 12) | 1u;
+                uint32_t slot = ht_slot(umi, mask);
+                bool done = false;
+                for (;;) {
+                    const unsigned long long old = atomicCAS(&s_slot[slot], kEmpty64, mine);
+                    if (old == kEmpty64) { own_slot[h] = slot; done = true; break; }
+                    if ((uint32_t)(old >> 32) == umi) {
+                        if ((((uint32_t)old) >> 12) == gene) { atomicAdd(&s_slot[slot], 1ull); done = true; }
+                        break;
+                    }
+                    slot = (slot + 1) & mask;
+                }
+                if (!done) {
+                    uint32_t* pr = s_pair + slot * (kHtPairs - 1);
+#pragma unroll
+                    for (uint32_t q = 0; q < kHtPairs - 1; ++q) {
+                        if (!done) {
+                            const uint32_t old = atomicCAS(&pr[q], 0u, (gene << 12) | 1u);
+                            if (old == 0u) done = true;
+                            else if ((old >> 12) == gene) { atomicAdd(&pr[q], 1u); done = true; }
+                        }
+                    }
+                }
+                if (!done) {  // the UMI's counters are taken by other genes (and this gene can never get one)
+                    const uint32_t k = atomicAdd(s_novf, 1u);
+                    if (k < kHtOvf) { s_ovf[k] = key[h]; atomicOr(&s_flag[slot >> 5], 1u << (slot & 31)); }
+                    else bad = true;
+                }
+            }
+        }
+    }
+    if (__any(bad)) return false;
+    __syncthreads();
+    RT_MARK(1);
+    const uint32_t novf = *s_novf;
+    uint32_t nc = 0;
+#pragma unroll
+    for (uint32_t h = 0; h < E; ++h) {
+        if (h * 64 >= n) break;
+        uint32_t col = kNoCol;
+        const uint32_t slot = own_slot[h];
+        if (slot != kNoCol) {
+            const uint32_t p0 = (uint32_t)s_slot[slot], umi = (uint32_t)(key[h] >> kGeneBits);
+            const uint32_t p1 = s_pair[slot * (kHtPairs - 1)], p2 = s_pair[slot * (kHtPairs - 1) + 1];
+            if (!novf || !((s_flag[slot >> 5] >> (slot & 31)) & 1u)) col = col_from_pairs(p0, p1, p2, rc);
+            else
+                col = col_from_candidates([&](auto&& f) {
+                    f(p0 >> 12, p0 & 0xFFFu); f(p1 >> 12, p1 & 0xFFFu); f(p2 >> 12, p2 & 0xFFFu);
+                    for (uint32_t i = 0; i < novf; ++i) {
+                        const uint64_t ki = s_ovf[i];
+                        if ((uint32_t)(ki >> kGeneBits) != umi) continue;
+                        uint32_t cnt = 0;
+                        bool first = true;
+                        for (uint32_t j = 0; j < novf; ++j)
+                            if (s_ovf[j] == ki) { ++cnt; if (j < i) first = false; }
+                        if (first) f((uint32_t)ki & kGeneMask, cnt);
+                    }
+                }, rc);
+            if (col != kNoCol && col >= rc.num_rows) { set_err(st, kErrSlotRange, cell); col = kNoCol; }
+        }
+        const uint64_t m = __ballot(col != kNoCol);
+        if (col != kNoCol) s_cols[nc + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = col;
+        nc += (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    RT_MARK(2);
+    nc_out = nc;
+    return true;
+}
+
+// One wave per bucket (up to kBucketCap keys).  Small workgroups keep many buckets
+// in flight per CU, which is what hides the load -> group -> reserve -> store latency
+// chain; blocks that run together are spread over different cells (column-major walk)
+// so their reservations do not pile onto one counter.
 // Single-bucket cells are finished here; buckets of multi-bucket cells append their
 // resolved columns to the cell's column list, counted later by k_cell_hist.
 constexpr int kResolveNT = 64;
@@ -1065,15 +1264,18 @@ __global__ __launch_bounds__(kResolveNT) void k_resolve(const BucketDesc* __rest
                                                        uint32_t* __restrict__ cell_ncols, uint32_t* __restrict__ nnz,
                                                        OverflowEnt* __restrict__ ovf_list, DevStatus* st,
                                                        ResolveCfg rc, LabArea la) {
-    __shared__ uint64_t s_keys[kBucketCap];
-    __shared__ uint16_t s_run[kBucketCap];
-    __shared__ uint32_t s_cols[kBucketCap];
-    __shared__ uint32_t s_lab_store[EM ? kBucketCap : 1];
-    __shared__ uint32_t s_ldesc_store[EM ? kBucketCap : 1];
+    // one LDS block carved two ways: the hash table (slot UMIs | counters), or the sort path's arrays
+    constexpr uint32_t kSortWords = 2 * kBucketCap + kBucketCap / 2 + kBucketCap + (EM ? 2 * kBucketCap : 0);
+    constexpr uint32_t kHashWords = kHtCap * (1 + kHtPairs) + 2 * kHtOvf + kHtCap / 32 + 2 + kHtKeys;
+    constexpr uint32_t kWords = kSortWords > kHashWords ? kSortWords : kHashWords;
+    __shared__ __attribute__((aligned(16))) uint32_t s_raw[kWords];
     __shared__ uint32_t s_ws[kResolveNT / 64];
     __shared__ uint32_t s_misc[6];
-    uint32_t* s_lab = EM ? s_lab_store : nullptr;
-    uint32_t* s_ldesc = EM ? s_ldesc_store : nullptr;
+    uint64_t* s_keys = reinterpret_cast<uint64_t*>(s_raw);
+    uint16_t* s_run = reinterpret_cast<uint16_t*>(s_raw + 2 * kBucketCap);
+    uint32_t* s_cols = s_raw + 2 * kBucketCap + kBucketCap / 2;
+    uint32_t* s_lab = EM ? s_cols + kBucketCap : nullptr;
+    uint32_t* s_ldesc = EM ? s_lab + kBucketCap : nullptr;
     const uint32_t n_cols = min(n_buckets, kResolveCols);
     const uint32_t n_rows = (n_buckets + n_cols - 1) / n_cols;
     const uint32_t b = (blockIdx.x % n_cols) * n_rows + blockIdx.x / n_cols;
@@ -1090,6 +1292,23 @@ __global__ __launch_bounds__(kResolveNT) void k_resolve(const BucketDesc* __rest
             ovf_list[k].n = d.n;
         }
         return;
+    }
+    if ((d.mode_single & 0xFFu) == kModeCrLike && d.n <= kHtKeys) {
+        const bool single = (d.mode_single >> 8) != 0;
+        unsigned long long* s_slot = reinterpret_cast<unsigned long long*>(s_raw);      // 2 words per slot
+        uint32_t* s_pair = s_raw + 2 * kHtCap;                                            // kHtPairs-1 words per slot
+        uint64_t* s_ovf = reinterpret_cast<uint64_t*>(s_raw + kHtCap * (1 + kHtPairs));
+        uint32_t* s_flag = s_raw + kHtCap * (1 + kHtPairs) + 2 * kHtOvf;
+        uint32_t* s_hcols = s_flag + kHtCap / 32 + 2;
+        uint32_t nc = 0;
+        if (resolve_bucket_hash((single ? keys0 : keys1) + d.src_off, d.n, rc, s_slot, s_pair, s_ovf, s_flag, s_flag + kHtCap / 32,
+                                s_hcols, st, d.cell, nc)) {
+            // the table is dead: its space is the tail's scratch (sorted columns, run starts)
+            bucket_tail<kResolveNT>(d, keys0, cell_ncols, nnz, s_hcols, nc, s_raw, reinterpret_cast<uint16_t*>(s_raw + kHtKeys),
+                                    s_ws, s_misc);
+            return;
+        }
+        __syncthreads();
     }
     resolve_bucket_lds<kResolveNT>(d, keys0, keys1, cell_ncols, nnz, st, rc, la, s_keys, s_run, s_cols, s_lab, s_ldesc, s_ws,
                                    s_misc);
@@ -1683,7 +1902,7 @@ size_t bucket_desc_bytes() { return sizeof(BucketDesc); }
 extern "C" void afq_debug_dump() {
     unsigned long long h[8];
     hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg), sizeof(h));
-    fprintf(stderr, "[resolve cycles/bucket] sort+load=%llu resolve=%llu atomic=%llu store=%llu (n=%llu)\n", h[0] / (h[4] + 1), h[1] / (h[5] + 1), h[2] / (h[6] + 1), h[3] / (h[7] + 1), h[4]);
+    fprintf(stderr, "[resolve cycles/bucket] load+clear=%llu insert=%llu emit=%llu tail=%llu (n=%llu)\n", h[0] / (h[4] + 1), h[1] / (h[5] + 1), h[2] / (h[6] + 1), h[3] / (h[7] + 1), h[4]);
 }
 #endif
 

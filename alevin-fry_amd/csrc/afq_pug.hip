@@ -26,7 +26,7 @@
 namespace afq {
 
 #ifdef AFQ_PUG_TIMING
-#define PUG_MARK(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) tmark[i] = wall_clock64(); } while (0)
+#define PUG_MARK(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 4) tmark[i] = wall_clock64(); } while (0)
 #else
 #define PUG_MARK(i) do {} while (0)
 #endif
@@ -788,7 +788,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     __syncthreads();
     PUG_MARK(10);
 #ifdef AFQ_PUG_TIMING
-    if (tid == 0 && blockIdx.x == 0) { printf("pug cell R=%u:", R); for (int i = 1; i <= 10; ++i) printf(" p%d=%.2fms", i - 1, (double)(tmark[i] - tmark[i - 1]) / 1e5); printf("\n"); }
+    if (tid == 0 && blockIdx.x < 4) { printf("pug cell R=%u V=%u K=%u NC=%u nmid=%u nbig=%u:", R, V, K, NC, n_mid, n_big); for (int i = 1; i <= 10; ++i) printf(" p%d=%.2fms", i - 1, (double)(tmark[i] - tmark[i - 1]) / 1e5); printf("\n"); }
 #endif
     if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], cell); return; }
     if (tid == 0) {

@@ -260,3 +260,43 @@ def test_many_ranges_pipeline(oracle, monkeypatch):
         b, off = s.encode()
         got, want, st = run_both(oracle, cfg_for(s, res), s.tid_to_gid, b, off)
         assert_same_result(got, want, what=res)
+
+
+@pytest.mark.parametrize("usa", [False, True])
+@pytest.mark.parametrize("pad_reads", [0, 3000])
+def test_tie_shapes_and_wide_umis(oracle, usa, pad_reads):
+    """Every way a UMI's (gene, reads) counters can look: 1-6 genes per UMI, ties of 2 and 3 winners, spliced /
+    unspliced siblings, plus UMIs that do not fit 32 bits (8-byte UMI field) including 0xFFFFFFFF itself.
+    pad_reads > 0 pushes the cell over one bucket."""
+    rng = np.random.default_rng(11)
+    n_txp = 64
+    t2g = (np.arange(n_txp, dtype=np.uint32) % 32) if not usa else np.arange(n_txp, dtype=np.uint32) % 32
+    num_genes = 32
+    reads = []
+    umi = 1000
+    for n_genes in range(1, 7):
+        for shape in range(40):
+            umi += 7
+            txps = rng.choice(n_txp // 2, size=n_genes, replace=False)
+            if usa and shape % 3 == 0 and n_genes >= 2:
+                txps[1] = txps[0] ^ 1  # spliced/unspliced sibling pair (gene ids 2g, 2g+1)
+            counts = rng.integers(1, 4, size=n_genes)
+            if shape % 2 == 0:
+                counts[:] = counts[0]  # all tied
+            for t, c in zip(txps, counts):
+                reads += [(umi, [int(t)])] * int(c)
+            if shape % 5 == 0:
+                reads.append((umi, sorted(int(x) for x in txps)))  # one multi-mapping read over all of them
+    for wide in (0xFFFFFFFF, 0xFFFFFFFE, 0x100000005, 0xABC12345678):
+        reads += [(wide, [3]), (wide, [3]), (wide, [9])]
+    for _ in range(pad_reads):
+        reads.append((int(rng.integers(1 << 20, 1 << 24)), [int(rng.integers(0, n_txp))]))
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    cells = [(5, reads), (6, reads[: len(reads) // 3])]
+    b, off = rad.encode_cells(cells, 4, 8)
+    cfg = pkg.WorkerConfig.for_resolution("cr-like", usa_mode=usa, num_genes=num_genes, num_rows=(num_genes // 2) * 3 if usa else num_genes,
+                                          bc_bytes=4, umi_bytes=8, small_thresh=0)
+    got, want, _ = run_both(oracle, cfg, t2g.astype(np.uint32), b, off)
+    assert_same_result(got, want)
+    assert got.val.sum() > 0
