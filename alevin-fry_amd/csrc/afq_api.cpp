@@ -444,7 +444,8 @@ int run_range(afq_ctx* c, Range r, int slot) {
                   B.d_cell_bc.as<uint64_t>(),
                   (uint32_t)n_slabs,
                   n_pug ? PugOut{B.d_rd_h.as<uint64_t>(), B.d_rd_u.as<uint64_t>(), B.d_rd_o.as<uint32_t>(), B.d_rd_off.as<uint64_t>()}
-                        : PugOut{nullptr, nullptr, nullptr, nullptr}};
+                        : PugOut{nullptr, nullptr, nullptr, nullptr},
+                  g.resolution == AFQ_RES_TRIVIAL ? 1u : 0u};
     if (par) {
         ScopedTimer t(c, K_DECODE_PAR, s, &B.launches);
         if (launch_decode_par(s, da, g.bc_bytes, g.umi_bytes)) return fail(c, AFQ_ERR_INVALID_ARG, "bad field widths");

@@ -27,6 +27,7 @@ struct DecodeArgs {
     uint64_t* cell_bc;            // [n_cells] device-filled: barcode words of each cell's first record
     uint32_t n_slabs;
     PugOut pug;                   // PUG cells: per-read outputs (null pointers when the batch has none)
+    uint32_t trivial;             // the batch has cells in `trivial` mode
 };
 
 struct ResolveArgs {

@@ -538,6 +538,349 @@ __global__ __launch_bounds__(256, 6) void k_decode_par(const uint8_t* __restrict
     flush_chk();
 }
 
+#ifdef AFQ_DECODE_TIMING
+__device__ unsigned long long g_dtm[16];
+#define DT_MARK(i) do { if (lane == 0 && (blockIdx.x & 255) == 0 && wv == 0) { unsigned long long t_ = clock64(); atomicAdd(&g_dtm[i], t_ - tprev_); atomicAdd(&g_dtm[8 + i], 1ull); tprev_ = t_; } } while (0)
+extern "C" void afq_debug_dump_decode() {
+    unsigned long long h[16];
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dtm), sizeof(h));
+    fprintf(stderr, "[decode cycles/slab]");
+    for (int i = 0; i < 8; ++i) if (h[8 + i]) fprintf(stderr, " p%d=%llu", i, h[i] / h[8 + i]);
+    fprintf(stderr, " (n=%llu)\n", h[8]);
+}
+#else
+#define DT_MARK(i) do {} while (0)
+#endif
+
+// ---------------------------------------------------------------------------
+// k_decode_keys: the walk-free decode for batches without parsimony cells, with one lane per DWORD instead
+// of one lane per record.  Every dword of a slab asks "which record am I in" - the last candidate start at
+// or before it, found with a ballot mask and a count-leading-zeros, or the record carried in from before
+// the slab - and, if it is one of that record's alignment words, gathers its gene and emits the key
+// (umi << 20 | gene) unless an earlier alignment word of the same record already named that gene.  All the
+// tid_to_gid gathers of a slab are independent and issued together (the per-record version chased them one
+// alignment at a time), and the work per slab is a fixed, short instruction sequence: the duplicate test
+// looks at the three preceding dwords' genes; records with more alignments than that, or that started in an
+// earlier slab, take a compact slow loop that exists once in the code.  Candidate lanes also accumulate the
+// same proof terms as k_decode_par (count, sizes, successor check).
+// A record that starts before the wave's first slab is found by a cooperative backward scan (64 dwords per
+// step); inside the wave it is carried from slab to slab.
+template <int BW, int UW, bool TRIVIAL>
+__global__ __launch_bounds__(256, 6) void k_decode_keys(const uint8_t* __restrict__ bytes,
+                                                    const CellMeta* __restrict__ meta, uint32_t n_cells,
+                                                    const uint32_t* __restrict__ slab_prefix,
+                                                    const uint32_t* __restrict__ slab_cell,
+                                                    const uint64_t* __restrict__ cell_bc, uint32_t n_slabs,
+                                                    const uint32_t* __restrict__ t2g, uint32_t ref_count,
+                                                    uint32_t num_genes, uint64_t* __restrict__ keys0,
+                                                    uint32_t* __restrict__ cell_nkeys,
+                                                    uint64_t* __restrict__ bc_out, CellChk* __restrict__ chk) {
+    static_assert(BW % 4 == 0 && UW % 4 == 0, "aligned layouts only");
+    constexpr uint32_t BWW = BW / 4, UWW = UW / 4, HW = 1 + BWW + UWW;
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    __shared__ uint32_t s_stage[4][kStage];
+    __shared__ uint32_t s_gene[4][4 + kSlabWords];   // [4 pad] + gene of every alignment word of the slab (kNone elsewhere)
+    __shared__ uint32_t s_first[4][kSlabWords];  // dword index of the first alignment word of the dword's record
+    const uint32_t lane = lane_id();
+    const uint32_t wv = threadIdx.x >> 6;
+    uint32_t* stage = s_stage[wv];
+    uint32_t* gene_l = s_gene[wv];
+    uint32_t* first_l = s_first[wv];
+    const uint32_t n_groups = (n_slabs + kSlabsPerWave - 1) / kSlabsPerWave;
+    const uint32_t n_cols = min(n_groups, kDecodeCols);
+    const uint32_t n_rows = (n_groups + n_cols - 1) / n_cols;
+    const uint32_t wid = blockIdx.x * 4 + wv;
+    const uint32_t grp = (wid % n_cols) * n_rows + wid / n_cols;
+    if (wid >= n_cols * n_rows || grp >= n_groups) return;
+    const uint32_t slab_a = grp * kSlabsPerWave;
+    const uint32_t slab_b = min(n_slabs, slab_a + kSlabsPerWave);
+    uint32_t my_cell = 0;
+    if (lane < slab_b - slab_a) my_cell = slab_cell[slab_a + lane];
+
+    uint32_t cur_cell = kNone;
+    CellMeta m{};
+    const uint32_t* __restrict__ W = nullptr;
+    uint32_t nwords = 0, sp0 = 0, bc_lo = 0, bc_hi = 0;
+    uint32_t acc_count = 0, acc_words = 0;
+    bool fail = false;
+    uint32_t R[5];
+    uint32_t cin_s = kNone, cin_na = 0, cin_ulo = 0, cin_uhi = 0;  // the record covering the slab's first dword
+
+    auto load_cell = [&](uint32_t cell) {
+        cur_cell = cell;
+        m = meta[cell];
+        const uint64_t bc = cell_bc[cell];
+        bc_lo = (uint32_t)bc; bc_hi = (uint32_t)(bc >> 32);
+        W = reinterpret_cast<const uint32_t*>(bytes + m.chunk_off);
+        nwords = m.nbytes >> 2;
+        sp0 = slab_prefix[cell];
+        cin_s = kNone;
+    };
+    auto flush_chk = [&]() {
+        if (cur_cell == kNone) return;
+        uint32_t ws = acc_words;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) ws += __shfl_xor(ws, d);
+        const bool any_fail = __any(fail);
+        if (lane == 0) {
+            if (acc_count) atomicAdd(&chk[cur_cell].count, acc_count);
+            if (ws) atomicAdd(&chk[cur_cell].words, ws);
+            if (any_fail) atomicOr(&chk[cur_cell].fail, 1u);
+        }
+        acc_count = 0; acc_words = 0; fail = false;
+    };
+    auto issue_slab_loads = [&](uint32_t s0) {
+        if (s0 + kStage <= nwords) {
+#pragma unroll
+            for (int r = 0; r < 5; ++r) R[r] = W[s0 + r * 64 + lane];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const uint32_t i = s0 + r * 64 + lane;
+                R[r] = i < nwords ? W[i] : 0u;
+            }
+        }
+    };
+    auto find_carry = [&](uint32_t s0) {  // last candidate start before dword s0
+        cin_s = kNone;
+        uint32_t back = min(s0, nwords), steps = 0;
+        while (back > 2 && cin_s == kNone && steps < (1u << 16)) {
+            const uint32_t lo = back >= 64 ? back - 64 : 0u;
+            const uint32_t q = lo + lane;
+            bool c = q < back && q >= 2 && q + HW <= nwords;
+            if (c) { c = W[q + 1] == bc_lo; if (BWW == 2 && c) c = W[q + 2] == bc_hi; }
+            const uint64_t mk = __ballot(c);
+            if (mk) cin_s = lo + 63 - (uint32_t)__builtin_clzll(mk);
+            back = lo;
+            ++steps;
+        }
+        if (cin_s != kNone) {
+            cin_na = W[cin_s];
+            cin_ulo = W[cin_s + 1 + BWW];
+            cin_uhi = UWW == 2 ? W[cin_s + 2 + BWW] : 0u;
+        }
+    };
+    auto gene_at = [&](uint32_t q, uint32_t s0) -> uint32_t {  // gene of alignment word q (< nwords) of the current cell
+        if (q >= s0 && q < s0 + kSlabWords) return gene_l[4 + q - s0];
+        const uint32_t t = W[q] & 0x7FFFFFFFu;
+        return t < ref_count ? t2g[t] : kNone;
+    };
+
+    load_cell(__builtin_amdgcn_readlane(my_cell, 0));
+    {
+        const uint32_t s0 = (slab_a - sp0) * kSlabWords;
+        issue_slab_loads(s0);
+        if (s0) find_carry(s0);
+    }
+    const uint64_t le_mask = lane == 63 ? ~0ull : ((2ull << lane) - 1);
+#ifdef AFQ_DECODE_TIMING
+    unsigned long long tprev_ = clock64();
+#endif
+
+    // The loop body is written as unconditional LDS reads + selects: the compiler turns `c ? lds[i] : x` into
+    // exec-mask branches (and once even into flat loads), which tripled the instruction count of this kernel.
+    for (uint32_t slab = slab_a; slab < slab_b; ++slab) {
+        const uint32_t s0 = (slab - sp0) * kSlabWords;
+        uint32_t own[4];
+#ifdef AFQ_DECODE_TIMING
+        if (R[0] == 0x12345677u && R[4] == 0x7654321u) fail = true;  // wait for the slab's loads
+#endif
+        DT_MARK(0);
+#pragma unroll
+        for (int r = 0; r < 5; ++r) stage[r * 64 + lane] = R[r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) own[r] = R[r];
+        if (lane < 4) gene_l[lane] = kNone;  // pad in front of the slab's genes (the duplicate test looks back 3)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the next slab's dwords are requested now; nothing below depends on them
+        const bool has_next = slab + 1 < slab_b;
+        const uint32_t next_cell = has_next ? __builtin_amdgcn_readlane(my_cell, (int)(slab + 1 - slab_a)) : cur_cell;
+        const bool same_next = has_next && next_cell == cur_cell;
+        if (same_next) issue_slab_loads(s0 + kSlabWords);
+
+        uint64_t mk[4];
+        const bool triv = TRIVIAL && m.mode == kModeTrivial;  // tiny cells of a trivial run are cr-like (quant.rs:794-938)
+        const bool room = nwords >= 2 + HW;
+        // dword i can start a record iff 2 <= i and i + HW <= nwords: one unsigned compare of i - 2
+        const uint32_t cand_lim = room ? nwords - HW - 1 : 0u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t il = r * 64 + lane, i = s0 + il;
+            const uint32_t w1 = stage[il + 1];
+            bool cand = w1 == bc_lo && (i - 2u) < cand_lim;
+            if (BWW == 2) { const uint32_t w2 = stage[il + 2]; cand = cand && w2 == bc_hi; }
+            mk[r] = __ballot(cand);
+        }
+        if (s0 == 0 && (!room || !(mk[0] & 4ull))) fail = true;  // (1) the first record starts right after the chunk header
+        acc_count += (uint32_t)(__popcll(mk[0]) + __popcll(mk[1]) + __popcll(mk[2]) + __popcll(mk[3]));
+        DT_MARK(1);
+
+        // which record is each dword in; alignment words gather their gene
+        uint32_t gid[4], ulo[4], uhi[4];
+        uint32_t pos[4];               // index of the dword among its record's alignment words, kNone if it is not one
+        uint32_t last_before = kNone;  // il of the last candidate in the windows before r (wave-uniform)
+        const uint32_t cin_na_eff = cin_s != kNone ? cin_na : 0u;
+        bool slow = false;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t il = r * 64 + lane, i = s0 + il;
+            const uint64_t within = mk[r] & le_mask;
+            const uint32_t sil_w = (uint32_t)(r * 64 + 63) - (uint32_t)__builtin_clzll(within | 1ull);
+            const uint32_t sil = within ? sil_w : last_before;
+            const bool in_stage = sil != kNone;
+            const uint32_t sc = in_stage ? sil : 0u;
+            const uint32_t l_na = stage[sc], l_u0 = stage[sc + 1 + BWW], l_u1 = UWW == 2 ? stage[sc + 2 + BWW] : 0u;
+            const uint32_t na = in_stage ? l_na : cin_na_eff;
+            ulo[r] = in_stage ? l_u0 : cin_ulo;
+            uhi[r] = in_stage ? l_u1 : cin_uhi;
+            const uint32_t fr = (in_stage ? s0 + sc : cin_s) + HW;
+            const uint32_t p = i - fr;  // wraps for the header dwords of the record
+            const uint32_t t = own[r] & 0x7FFFFFFFu;
+            bool isref = i >= fr && p < na && i < nwords;
+            if (isref && t >= ref_count) { fail = true; isref = false; }
+            // straight-line gather (lanes that are not alignment words read entry 0): the four windows' loads stay in flight together
+            gid[r] = t2g[isref ? t : 0u];
+            pos[r] = isref ? p : kNone;
+            first_l[il] = fr;
+            // more alignments back than the fast duplicate test covers, or some of them in an earlier slab
+            slow = slow || (isref && p > 0 && (p > 3 || fr < s0)) || (triv && isref && p == 0 && na > 1);
+            if (mk[r]) last_before = (uint32_t)(r * 64 + 63) - (uint32_t)__builtin_clzll(mk[r]);
+        }
+        // (2) proof terms of the records that start here
+        auto mk_at = [&](uint32_t r) -> uint64_t { return r == 0 ? mk[0] : r == 1 ? mk[1] : r == 2 ? mk[2] : mk[3]; };
+        bool far_succ = false;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t il = r * 64 + lane, i = s0 + il;
+            const bool st = (mk[r] >> lane) & 1ull;
+            const uint32_t na_s = own[r];
+            const bool fits = na_s <= nwords && i + HW + na_s <= nwords;
+            const uint32_t succ = i + HW + na_s, sl = il + HW + na_s;
+            const bool in_lds = fits && sl + BWW < kStage;
+            const uint32_t slc = in_lds ? sl : 0u;
+            const uint32_t w1 = stage[slc + 1], w2 = BWW == 2 ? stage[slc + 2] : 0u;
+            const bool at_end = succ == nwords;
+            const bool succ_ok = succ + HW <= nwords && w1 == bc_lo && (BWW == 1 || w2 == bc_hi);
+            if (st && (!fits || (!at_end && in_lds && !succ_ok))) fail = true;
+            far_succ = far_succ || (st && fits && !at_end && !in_lds);
+            acc_words += (st && fits) ? HW + na_s : 0u;
+            if (UWW == 2) { const uint32_t uh = stage[il + 2 + BWW]; if (st && (uh >> (kUmiBits - 32))) fail = true; }
+        }
+        if (__any(far_succ)) {  // a record reaching past the staged halo: its successor is checked in global memory
+#pragma unroll 1
+            for (uint32_t r = 0; r < 4; ++r) {
+                const uint32_t il = r * 64 + lane, i = s0 + il;
+                if (!((mk_at(r) >> lane) & 1ull)) continue;
+                const uint32_t na_s = stage[il];
+                if (na_s > nwords || i + HW + na_s > nwords) continue;
+                const uint32_t succ = i + HW + na_s, sl = il + HW + na_s;
+                if (succ == nwords || sl + BWW < kStage) continue;
+                bool ok = succ + HW <= nwords;
+                if (ok) { ok = W[succ + 1] == bc_lo; if (BWW == 2 && ok) ok = W[succ + 2] == bc_hi; }
+                if (!ok) fail = true;
+            }
+        }
+        if (s0 == 0 && lane == 2 && ((mk[0] >> 2) & 1ull)) bc_out[cur_cell] = BWW == 2 ? ((uint64_t)bc_hi << 32 | bc_lo) : (uint64_t)bc_lo;
+        DT_MARK(2);
+        // the record the next slab starts in: this slab's last candidate, else the one carried in
+        uint32_t ncin_s = cin_s, ncin_na = cin_na, ncin_ulo = cin_ulo, ncin_uhi = cin_uhi;
+        if (last_before != kNone) {
+            ncin_s = s0 + last_before; ncin_na = stage[last_before]; ncin_ulo = stage[last_before + 1 + BWW];
+            ncin_uhi = UWW == 2 ? stage[last_before + 2 + BWW] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool isref = pos[r] != kNone;
+            if (isref && gid[r] >= num_genes) fail = true;
+            gid[r] = (isref && gid[r] < num_genes) ? gid[r] : kNone;
+            gene_l[4 + r * 64 + lane] = gid[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        DT_MARK(3);
+        if (__any(slow)) {
+            // one copy of the general rule; a dword that loses clears its gene (a duplicate's own first
+            // occurrence stays, so clearing never hides a gene from a later dword of the record)
+#pragma unroll 1
+            for (uint32_t r = 0; r < 4; ++r) {
+                const uint32_t il = r * 64 + lane, i = s0 + il;
+                const uint32_t g = gene_l[4 + il], fr = first_l[il];
+                if (g == kNone || i < fr) continue;
+                const uint32_t p = i - fr;
+                bool lose = false;
+                if (triv) {  // only reads whose alignments name one gene count (pugutils.rs:870-891)
+                    if (p > 0) continue;  // handled by the fast rule below (never emits)
+                    const uint32_t S = fr - HW;
+                    const uint32_t na = S >= s0 ? stage[S - s0] : W[S];
+                    for (uint32_t q = fr + 1; q < fr + na && q < nwords && !lose; ++q) lose = gene_at(q, s0) != g;
+                    if (lose) gene_l[4 + il] = kNone - 1;  // "not a single-gene read", still a gene for nobody else
+                } else {
+                    if (!(p > 3 || (p > 0 && fr < s0))) continue;
+                    for (uint32_t q = fr; q < i && !lose; ++q) lose = gene_at(q, s0) == g;
+                    if (lose) gene_l[4 + il] = kNone;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        // first occurrence of the gene inside its record
+        uint64_t bal[4];
+        uint32_t tot = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t il = r * 64 + lane;
+            const uint32_t g0 = gene_l[4 + il], g1 = gene_l[3 + il], g2 = gene_l[2 + il], g3 = gene_l[1 + il];
+            const uint32_t p = pos[r];
+            bool e = gid[r] != kNone;
+            if (triv) e = e && p == 0 && g0 == gid[r];
+            else {
+                const bool deep = p > 3 || p > il;  // the slow loop decided (p > il: the record started before the slab)
+                const bool dup = (p >= 1 && g1 == gid[r]) || (p >= 2 && g2 == gid[r]) || (p >= 3 && g3 == gid[r]);
+                e = e && !(deep ? g0 == kNone : dup);
+            }
+            bal[r] = __ballot(e);
+            gid[r] = e ? gid[r] : kNone;
+            tot += (uint32_t)__popcll(bal[r]);
+        }
+        DT_MARK(4);
+        if (tot) {
+            uint32_t wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&cell_nkeys[cur_cell], tot);
+            wbase = __builtin_amdgcn_readfirstlane(wbase);
+            DT_MARK(5);
+            if (wbase + tot > m.n_ref) fail = true;
+            else {
+                uint64_t* dst = keys0 + m.key_off + wbase;
+                uint32_t o = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (gid[r] != kNone) {
+                        const uint64_t umi = UWW == 2 ? ((uint64_t)uhi[r] << 32 | ulo[r]) : (uint64_t)ulo[r];
+                        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[r] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[r], 0u));
+                        dst[o + before] = (umi << kGeneBits) | gid[r];
+                    }
+                    o += (uint32_t)__popcll(bal[r]);
+                }
+            }
+        }
+        DT_MARK(6);
+        cin_s = ncin_s; cin_na = ncin_na; cin_ulo = ncin_ulo; cin_uhi = ncin_uhi;
+        // all lanes are done reading this slab's stage before the next iteration overwrites it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (has_next && !same_next) {
+            flush_chk();
+            load_cell(next_cell);
+            issue_slab_loads((slab + 1 - sp0) * kSlabWords);
+        }
+    }
+    flush_chk();
+}
+
 // ---------------------------------------------------------------------------
 // Bucket histogram.  Device-scope atomics leave the XCD (every one is a fabric
 // transaction on this 8-XCD part: rocprof WRITE_SIZE showed 3-5x the payload when
@@ -1807,10 +2150,14 @@ static void launch_decode_par_t(hipStream_t s, const DecodeArgs& a) {
         AFQ_LAUNCH((k_decode_par<BW, UW, true>), (n_waves + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix, a.slab_cell,
                    a.cell_bc, a.n_slabs, a.t2g, a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out,
                    const_cast<CellChk*>(a.chk), a.pug);
-    else
-        AFQ_LAUNCH((k_decode_par<BW, UW, false>), (n_waves + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix, a.slab_cell,
+    else if (a.trivial)
+        AFQ_LAUNCH((k_decode_keys<BW, UW, true>), (n_waves + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix, a.slab_cell,
                    a.cell_bc, a.n_slabs, a.t2g, a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out,
-                   const_cast<CellChk*>(a.chk), a.pug);
+                   const_cast<CellChk*>(a.chk));
+    else
+        AFQ_LAUNCH((k_decode_keys<BW, UW, false>), (n_waves + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix, a.slab_cell,
+                   a.cell_bc, a.n_slabs, a.t2g, a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out,
+                   const_cast<CellChk*>(a.chk));
 }
 
 bool decode_par_supported(uint32_t bw, uint32_t uw) { return (bw == 4 || bw == 8) && (uw == 4 || uw == 8); }
