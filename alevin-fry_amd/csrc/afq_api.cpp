@@ -289,6 +289,16 @@ int plan_ranges(afq_ctx* c) {
     return 0;
 }
 
+// Which walk-free decoder suits the batch: lane-per-record when records are short (few alignment words each),
+// lane-per-dword otherwise.  AFQ_DECODE=recs|keys overrides (tests run both).
+static uint32_t decode_short_records(uint64_t n_ref_words, uint64_t n_records) {
+    if (const char* e = getenv("AFQ_DECODE")) {
+        if (!strcmp(e, "recs")) return 1;
+        if (!strcmp(e, "keys")) return 0;
+    }
+    return n_ref_words < 2 * n_records ? 1u : 0u;
+}
+
 // Plan + enqueue one range of cells on the context's stream.
 int run_range(afq_ctx* c, Range r, int slot) {
     HostClock hc;
@@ -445,7 +455,7 @@ int run_range(afq_ctx* c, Range r, int slot) {
                   (uint32_t)n_slabs,
                   n_pug ? PugOut{B.d_rd_h.as<uint64_t>(), B.d_rd_u.as<uint64_t>(), B.d_rd_o.as<uint32_t>(), B.d_rd_off.as<uint64_t>()}
                         : PugOut{nullptr, nullptr, nullptr, nullptr},
-                  g.resolution == AFQ_RES_TRIVIAL ? 1u : 0u};
+                  g.resolution == AFQ_RES_TRIVIAL ? 1u : 0u, decode_short_records(key_off - n, nrec_total)};
     if (par) {
         ScopedTimer t(c, K_DECODE_PAR, s, &B.launches);
         if (launch_decode_par(s, da, g.bc_bytes, g.umi_bytes)) return fail(c, AFQ_ERR_INVALID_ARG, "bad field widths");

@@ -28,6 +28,7 @@ struct DecodeArgs {
     uint32_t n_slabs;
     PugOut pug;                   // PUG cells: per-read outputs (null pointers when the batch has none)
     uint32_t trivial;             // the batch has cells in `trivial` mode
+    uint32_t short_records;       // the batch averages < 2 alignment words per record: lane-per-record decode
 };
 
 struct ResolveArgs {

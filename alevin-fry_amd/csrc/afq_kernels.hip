@@ -882,6 +882,251 @@ __global__ __launch_bounds__(256, 6) void k_decode_keys(const uint8_t* __restric
 }
 
 // ---------------------------------------------------------------------------
+// k_decode_recs: walk-free decode with one lane per RECORD, for inputs whose records carry few alignments
+// (the planner picks it when the batch averages < 2 alignment words per record; k_decode_keys - one lane per
+// dword - is the one that stays flat as records get longer).  The candidates of a slab are compacted into a
+// list, then one lane per candidate reads na, the UMI and up to kInl alignment words out of LDS, issues all
+// its tid_to_gid gathers together, drops repeated genes with a handful of compares and stores its keys.
+// Output positions come from ballots (all first keys, then all second keys, ...), so consecutive lanes write
+// consecutive slots.  Records with more alignments, or reaching past the staged halo, go through a serial
+// per-lane loop that exists once in the code.  Same proof terms as the other two decoders.
+constexpr uint32_t kInl = 3;
+template <int BW, int UW, bool TRIVIAL>
+__global__ __launch_bounds__(256, 8) void k_decode_recs(const uint8_t* __restrict__ bytes,
+                                                    const CellMeta* __restrict__ meta, uint32_t n_cells,
+                                                    const uint32_t* __restrict__ slab_prefix,
+                                                    const uint32_t* __restrict__ slab_cell,
+                                                    const uint64_t* __restrict__ cell_bc, uint32_t n_slabs,
+                                                    const uint32_t* __restrict__ t2g, uint32_t ref_count,
+                                                    uint32_t num_genes, uint64_t* __restrict__ keys0,
+                                                    uint32_t* __restrict__ cell_nkeys,
+                                                    uint64_t* __restrict__ bc_out, CellChk* __restrict__ chk) {
+    static_assert(BW % 4 == 0 && UW % 4 == 0, "aligned layouts only");
+    constexpr uint32_t BWW = BW / 4, UWW = UW / 4, HW = 1 + BWW + UWW;
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    __shared__ uint32_t s_stage[4][kStage];
+    __shared__ uint32_t s_list[4][kSlabWords];
+    const uint32_t lane = lane_id();
+    const uint32_t wv = threadIdx.x >> 6;
+    uint32_t* stage = s_stage[wv];
+    uint32_t* list = s_list[wv];
+    const uint32_t n_groups = (n_slabs + kSlabsPerWave - 1) / kSlabsPerWave;
+    const uint32_t n_cols = min(n_groups, kDecodeCols);
+    const uint32_t n_rows = (n_groups + n_cols - 1) / n_cols;
+    const uint32_t wid = blockIdx.x * 4 + wv;
+    const uint32_t grp = (wid % n_cols) * n_rows + wid / n_cols;
+    if (wid >= n_cols * n_rows || grp >= n_groups) return;
+    const uint32_t slab_a = grp * kSlabsPerWave;
+    const uint32_t slab_b = min(n_slabs, slab_a + kSlabsPerWave);
+    uint32_t my_cell = 0;
+    if (lane < slab_b - slab_a) my_cell = slab_cell[slab_a + lane];
+
+    uint32_t cur_cell = kNone;
+    CellMeta m{};
+    const uint32_t* __restrict__ W = nullptr;
+    uint32_t nwords = 0, sp0 = 0, bc_lo = 0, bc_hi = 0;
+    uint32_t acc_count = 0, acc_words = 0;
+    bool fail = false;
+    uint32_t R[5];
+
+    auto load_cell = [&](uint32_t cell) {
+        cur_cell = cell;
+        m = meta[cell];
+        const uint64_t bc = cell_bc[cell];
+        bc_lo = (uint32_t)bc; bc_hi = (uint32_t)(bc >> 32);
+        W = reinterpret_cast<const uint32_t*>(bytes + m.chunk_off);
+        nwords = m.nbytes >> 2;
+        sp0 = slab_prefix[cell];
+    };
+    auto flush_chk = [&]() {
+        if (cur_cell == kNone) return;
+        uint32_t ws = acc_words;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) ws += __shfl_xor(ws, d);
+        const bool any_fail = __any(fail);
+        if (lane == 0) {
+            if (acc_count) atomicAdd(&chk[cur_cell].count, acc_count);
+            if (ws) atomicAdd(&chk[cur_cell].words, ws);
+            if (any_fail) atomicOr(&chk[cur_cell].fail, 1u);
+        }
+        acc_count = 0; acc_words = 0; fail = false;
+    };
+    auto issue_slab_loads = [&](uint32_t s0) {
+        if (s0 + kStage <= nwords) {
+#pragma unroll
+            for (int r = 0; r < 5; ++r) R[r] = W[s0 + r * 64 + lane];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const uint32_t i = s0 + r * 64 + lane;
+                R[r] = i < nwords ? W[i] : 0u;
+            }
+        }
+    };
+
+    load_cell(__builtin_amdgcn_readlane(my_cell, 0));
+    issue_slab_loads((slab_a - sp0) * kSlabWords);
+#ifdef AFQ_DECODE_TIMING
+    unsigned long long tprev_ = clock64();
+#endif
+
+    for (uint32_t slab = slab_a; slab < slab_b; ++slab) {
+        const uint32_t s0 = (slab - sp0) * kSlabWords;
+#ifdef AFQ_DECODE_TIMING
+        if (R[0] == 0x12345677u && R[4] == 0x7654321u) fail = true;  // wait for the slab's loads
+#endif
+        DT_MARK(0);
+#pragma unroll
+        for (int r = 0; r < 5; ++r) stage[r * 64 + lane] = R[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const bool has_next = slab + 1 < slab_b;
+        const uint32_t next_cell = has_next ? __builtin_amdgcn_readlane(my_cell, (int)(slab + 1 - slab_a)) : cur_cell;
+        const bool same_next = has_next && next_cell == cur_cell;
+        if (same_next) issue_slab_loads(s0 + kSlabWords);
+
+        const bool triv = TRIVIAL && m.mode == kModeTrivial;  // tiny cells of a trivial run are cr-like (quant.rs:794-938)
+        const bool room = nwords >= 2 + HW;
+        const uint32_t cand_lim = room ? nwords - HW - 1 : 0u;  // dword i can start a record iff (i - 2) < cand_lim
+        uint32_t ncand = 0;
+        uint64_t mk0 = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t il = r * 64 + lane, i = s0 + il;
+            const uint32_t w1 = stage[il + 1];
+            bool cand = w1 == bc_lo && (i - 2u) < cand_lim;
+            if (BWW == 2) { const uint32_t w2 = stage[il + 2]; cand = cand && w2 == bc_hi; }
+            const uint64_t mk = __ballot(cand);
+            if (r == 0) mk0 = mk;
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+            if (cand) list[ncand + before] = il;
+            ncand += (uint32_t)__popcll(mk);
+        }
+        if (s0 == 0 && (!room || !(mk0 & 4ull))) fail = true;  // (1) the first record starts right after the chunk header
+        if (s0 == 0 && lane == 2 && ((mk0 >> 2) & 1ull)) bc_out[cur_cell] = BWW == 2 ? ((uint64_t)bc_hi << 32 | bc_lo) : (uint64_t)bc_lo;
+        acc_count += ncand;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        DT_MARK(1);
+
+        for (uint32_t base = 0; base < ncand; base += 64) {
+            const uint32_t c = base + lane;
+            const bool act = c < ncand;
+            const uint32_t il = list[act ? c : 0u], i = s0 + il;
+            const uint32_t na = stage[il], u0 = stage[il + 1 + BWW], u1 = UWW == 2 ? stage[il + 2 + BWW] : 0u;
+            const bool fits = act && na <= nwords && i + HW + na <= nwords;
+            // (2) the next record starts where this one ends
+            const uint32_t succ = i + HW + na, sl = il + HW + na;
+            const bool in_lds = fits && sl + BWW < kStage;
+            const uint32_t slc = in_lds ? sl : 0u;
+            const uint32_t w1 = stage[slc + 1], w2 = BWW == 2 ? stage[slc + 2] : 0u;
+            const bool at_end = succ == nwords;
+            const bool succ_ok = succ + HW <= nwords && w1 == bc_lo && (BWW == 1 || w2 == bc_hi);
+            if (act && (!fits || (!at_end && in_lds && !succ_ok))) fail = true;
+            if (fits && !at_end && !in_lds) {  // the record reaches past the staged halo (rare)
+                bool ok = succ + HW <= nwords;
+                if (ok) { ok = W[succ + 1] == bc_lo; if (BWW == 2 && ok) ok = W[succ + 2] == bc_hi; }
+                if (!ok) fail = true;
+            }
+            acc_words += fits ? HW + na : 0u;
+            if (UWW == 2 && fits && (u1 >> (kUmiBits - 32))) fail = true;
+            const uint64_t umi = UWW == 2 ? ((uint64_t)u1 << 32 | u0) : (uint64_t)u0;
+            // alignments: up to kInl inline, all gathers in flight together
+            const uint32_t na_eff = fits ? na : 0u;
+            const bool slowrec = na_eff > kInl || il + HW + kInl > kStage;
+            uint32_t t[kInl], g[kInl];
+            bool v[kInl];
+#pragma unroll
+            for (uint32_t j = 0; j < kInl; ++j) {
+                const uint32_t pj = il + HW + j;
+                t[j] = stage[pj < kStage ? pj : kStage - 1] & 0x7FFFFFFFu;
+                v[j] = !slowrec && j < na_eff;
+                if (v[j] && t[j] >= ref_count) { fail = true; v[j] = false; }
+                g[j] = t2g[v[j] ? t[j] : 0u];
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < kInl; ++j) {
+                if (v[j] && g[j] >= num_genes) { fail = true; v[j] = false; }
+#pragma unroll
+                for (uint32_t q = 0; q < j; ++q) v[j] = v[j] && !(v[q] && g[q] == g[j]);
+            }
+            if (triv) {  // only reads whose alignments name one gene count (pugutils.rs:870-891)
+                bool multi = false;
+#pragma unroll
+                for (uint32_t j = 1; j < kInl; ++j) { multi = multi || v[j]; v[j] = false; }
+                v[0] = v[0] && !multi;
+            }
+            uint64_t bal[kInl];
+            uint32_t tot = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < kInl; ++j) { bal[j] = __ballot(v[j]); tot += (uint32_t)__popcll(bal[j]); }
+            // long records: serial count now, serial emission after the reservation
+            uint32_t scnt = 0, sex = 0;
+            auto ref_at = [&](uint32_t j) -> uint32_t {
+                const uint32_t pj = il + HW + j;
+                return (pj < kStage ? stage[pj] : W[i + HW + j]) & 0x7FFFFFFFu;
+            };
+            auto for_each_first_gene = [&](auto&& f) {  // distinct genes of the record in first-occurrence order
+                for (uint32_t j = 0; j < na_eff; ++j) {
+                    const uint32_t tj = ref_at(j);
+                    if (tj >= ref_count) { fail = true; continue; }
+                    const uint32_t gj = t2g[tj];
+                    if (gj >= num_genes) { fail = true; continue; }
+                    bool first = true;
+                    for (uint32_t q = 0; q < j && first; ++q) {
+                        const uint32_t tq = ref_at(q);
+                        if (tq < ref_count && t2g[tq] == gj) first = false;
+                    }
+                    if (first) f(gj);
+                }
+            };
+            const bool any_slow = __any(slowrec && na_eff > 0);
+            if (any_slow) {
+                if (slowrec) for_each_first_gene([&](uint32_t) { ++scnt; });
+                if (triv) scnt = scnt == 1 ? 1u : 0u;
+                uint32_t stot;
+                sex = tot + wave_excl_scan(scnt, stot);
+                tot += stot;
+            }
+            DT_MARK(2);
+            if (tot) {
+                uint32_t wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&cell_nkeys[cur_cell], tot);
+                wbase = __builtin_amdgcn_readfirstlane(wbase);
+                DT_MARK(3);
+                if (wbase + tot > m.n_ref) fail = true;
+                else {
+                    uint64_t* dst = keys0 + m.key_off + wbase;
+                    uint32_t o = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < kInl; ++j) {
+                        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[j], 0u));
+                        if (v[j]) dst[o + before] = (umi << kGeneBits) | g[j];
+                        o += (uint32_t)__popcll(bal[j]);
+                    }
+                    if (any_slow && slowrec && scnt) {
+                        uint32_t w = sex;
+                        for_each_first_gene([&](uint32_t gj) { dst[w++] = (umi << kGeneBits) | gj; });
+                    }
+                }
+            }
+            DT_MARK(4);
+        }
+        // all lanes are done reading this slab's stage/list before the next iteration overwrites them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (has_next && !same_next) {
+            flush_chk();
+            load_cell(next_cell);
+            issue_slab_loads((slab + 1 - sp0) * kSlabWords);
+        }
+    }
+    flush_chk();
+}
+
+// ---------------------------------------------------------------------------
 // Bucket histogram.  Device-scope atomics leave the XCD (every one is a fabric
 // transaction on this 8-XCD part: rocprof WRITE_SIZE showed 3-5x the payload when
 // they were issued per record), so counts are first combined in LDS over a tile
@@ -2150,6 +2395,14 @@ static void launch_decode_par_t(hipStream_t s, const DecodeArgs& a) {
         AFQ_LAUNCH((k_decode_par<BW, UW, true>), (n_waves + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix, a.slab_cell,
                    a.cell_bc, a.n_slabs, a.t2g, a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out,
                    const_cast<CellChk*>(a.chk), a.pug);
+    else if (a.short_records && a.trivial)
+        AFQ_LAUNCH((k_decode_recs<BW, UW, true>), (n_waves + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix, a.slab_cell,
+                   a.cell_bc, a.n_slabs, a.t2g, a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out,
+                   const_cast<CellChk*>(a.chk));
+    else if (a.short_records)
+        AFQ_LAUNCH((k_decode_recs<BW, UW, false>), (n_waves + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix, a.slab_cell,
+                   a.cell_bc, a.n_slabs, a.t2g, a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out,
+                   const_cast<CellChk*>(a.chk));
     else if (a.trivial)
         AFQ_LAUNCH((k_decode_keys<BW, UW, true>), (n_waves + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix, a.slab_cell,
                    a.cell_bc, a.n_slabs, a.t2g, a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out,
