@@ -2047,6 +2047,12 @@ __global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta,
     __shared__ uint32_t s_flag[2];
     __shared__ __attribute__((aligned(16))) uint32_t s_tile[8192];  // 32 KiB sort tile
     const uint32_t cell = blockIdx.x;
+#ifdef AFQ_EM_TIMING
+    __shared__ unsigned long long tmark[12];
+#define EM_MARK(i) do { __syncthreads(); if (threadIdx.x == 0 && (blockIdx.x % 1000) == 7) tmark[i] = wall_clock64(); } while (0)
+#else
+#define EM_MARK(i) do {} while (0)
+#endif
     const CellMeta m = meta[cell];
     const uint32_t nU = nnz_unique[cell];
     const uint2* U = reinterpret_cast<const uint2*>(((m.lg_nb || mode_is_pug(m.mode)) ? keys1 : keys0) + m.key_off);
@@ -2070,9 +2076,15 @@ __global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta,
     uint32_t* sib1 = p; p += capS + 1;
     uint32_t* sib2 = p; p += capS + 1;
     uint32_t* ucnt = p; p += capS + 1;
-    float* a_in = reinterpret_cast<float*>(p); p += capS + 1;
-    float* a_out = reinterpret_cast<float*>(p); p += capS + 1;
+    float* a_in = reinterpret_cast<float*>(p); p += capS + 2;
+    float* a_out = reinterpret_cast<float*>(p); p += capS + 2;
     uint32_t* slot_off = p; p += capS + 2;
+    uint32_t* aid = p; p += capS + 1;          // support idx -> active idx
+    p += (4 - ((p - scratch) & 3)) & 3;        // 16-byte records below (slices start 8-byte aligned)
+    uint4* ent = reinterpret_cast<uint4*>(p); p += 4 * (nU + W + 2);   // per active entry: count, sibling ids, first membership
+    uint4* lw3 = reinterpret_cast<uint4*>(p); p += 4 * (W + 1);        // per label word: its entry and the entry's siblings
+    uint32_t* act_col = p; p += nU + W + 2;
+    uint32_t* memb = p; p += W + 1;            // class ids of the memberships, entry-major
 
     if (M == 0) {  // no multi-label class: the counts are the single-label counts (em.rs:339-341, 499-514)
         for (uint32_t i = threadIdx.x; i < nU; i += kEmNT) out[i] = make_uint2(U[i].x, __float_as_uint((float)U[i].y));
@@ -2089,6 +2101,7 @@ __global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta,
         return na > nb;
     };
     auto lab_ne = [&](uint32_t a, uint32_t b) { return lab_gt(a, b) || lab_gt(b, a); };
+    EM_MARK(0);
     // 1. classes = runs of equal labels in lexicographic order
     for (uint32_t i = threadIdx.x; i < M; i += kEmNT) order[i] = i;
     __syncthreads();
@@ -2103,6 +2116,7 @@ __global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta,
         K += tot;
     }
     __syncthreads();
+    EM_MARK(1);
     // 2. EM label of each class: length, then contents
     auto em_label = [&](uint32_t c, uint32_t* dst) -> uint32_t {  // returns the length; writes when dst != null
         const uint32_t mol = order[cls_first[c]];
@@ -2138,6 +2152,7 @@ __global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta,
     __syncthreads();
     for (uint32_t c = threadIdx.x; c < K; c += kEmNT) em_label(c, cls_w + cls_woff[c]);
     __syncthreads();
+    EM_MARK(2);
     // 3. support = single-label columns + label slots (+ USA sibling statuses), sorted, distinct
     uint32_t nC = 0;
     {
@@ -2193,6 +2208,7 @@ __global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta,
             inv_pairs[w] = ((uint64_t)s << 32) | c;
         }
     __syncthreads();
+    EM_MARK(3);
     // 4. inverted index: for every support entry the classes containing it, ascending class
     tiled_bitonic_sort_by<kEmNT, 4096>(inv_pairs, Wc, [](uint64_t a, uint64_t b) { return a > b; }, reinterpret_cast<uint64_t*>(s_tile));
     for (uint32_t s = threadIdx.x; s <= S; s += kEmNT) {  // slot_off[s] = first pair with support idx >= s
@@ -2200,70 +2216,115 @@ __global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta,
         while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)(inv_pairs[mid] >> 32) < s) lo = mid + 1; else hi = mid; }
         slot_off[s] = lo;
     }
-    // 5. init (em.rs:370-383, 519-531)
-    const float uni = 1.0f / (float)cfg.num_alphas;
-    for (uint32_t s = threadIdx.x; s < S; s += kEmNT) {
-        a_in[s] = cfg.init_uniform ? uni : ((float)ucnt[s] + 0.5f) * 1e-3f;
-        a_out[s] = 0.0f;
+    EM_MARK(4);
+    // 4b. The rounds only ever change entries that have a single-label count or sit in some class label
+    // ("active"); every other support entry (the USA sibling statuses marked for em.rs:351-356) is produced
+    // as 0 by each round.  Compact the active entries and express everything the rounds touch in active ids:
+    // per entry one 16-byte record, per label word one, the memberships as plain class ids.  Two extra slots
+    // stand for "an inactive sibling" (the initial value in round 1, 0 afterwards) and "no sibling" (0; adding
+    // +0.0f to a non-negative float is exact, so one three-term formula serves every status).
+    uint32_t A = 0;
+    for (uint32_t base = 0; base < S; base += kEmNT) {
+        const uint32_t s2 = base + threadIdx.x;
+        const uint32_t h = s2 < S && (ucnt[s2] != 0 || slot_off[s2 + 1] > slot_off[s2]);
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<kEmNT>(h, s_ws, tot);
+        if (s2 < S) aid[s2] = h ? A + ex : 0xFFFFFFFFu;
+        A += tot;
     }
     __syncthreads();
-    auto abundance = [&](uint32_t s) -> float {  // get_abundance_for, em.rs:167-187
-        if (!cfg.usa) return a_in[s];
-        if (sib2[s] != 0xFFFFFFFFu) return a_in[sib1[s]] + a_in[sib2[s]] + a_in[s];
-        return a_in[sib1[s]] + a_in[s];
+    const uint32_t Z0 = A, Z1 = A + 1;
+    auto amap = [&](uint32_t x) -> uint32_t {
+        if (x == 0xFFFFFFFFu) return Z1;
+        const uint32_t a = aid[x];
+        return a == 0xFFFFFFFFu ? Z0 : a;
     };
+    for (uint32_t s2 = threadIdx.x; s2 < S; s2 += kEmNT) {
+        const uint32_t a = aid[s2];
+        if (a == 0xFFFFFFFFu) continue;
+        ent[a] = make_uint4(ucnt[s2], amap(sib1[s2]), amap(sib2[s2]), slot_off[s2]);
+        act_col[a] = support[s2];
+    }
+    if (threadIdx.x == 0) ent[A] = make_uint4(0u, Z1, Z1, Wc);
+    for (uint32_t w = threadIdx.x; w < Wc; w += kEmNT) {
+        const uint32_t s2 = cls_sidx[w];
+        lw3[w] = make_uint4(aid[s2], amap(sib1[s2]), amap(sib2[s2]), 0u);
+        memb[w] = (uint32_t)inv_pairs[w];
+    }
+    EM_MARK(4);
+    // 5. init (em.rs:370-383, 519-531).  The abundances live in LDS when the cell's active set fits the sort tile.
+    const bool in_lds = A + 2 <= 8192;
+    float* vin = in_lds ? reinterpret_cast<float*>(s_tile) : a_in;
+    float* vout = a_out;
+    __syncthreads();
+    const float uni = 1.0f / (float)cfg.num_alphas;
+    for (uint32_t a = threadIdx.x; a < A; a += kEmNT) vin[a] = cfg.init_uniform ? uni : ((float)ent[a].x + 0.5f) * 1e-3f;
+    if (threadIdx.x == 0) { vin[Z0] = cfg.init_uniform ? uni : ((float)0u + 0.5f) * 1e-3f; vin[Z1] = 0.0f; }
+    __syncthreads();
     uint32_t it = 0;
     bool conv = true, last_round = false;
     while (it < kMinIter || (it < kMaxIter && !conv) || last_round) {
-        // (A) per class: denominator in label order
+        // (A) per class: denominator in label order (get_abundance_for, em.rs:167-187)
         for (uint32_t c = threadIdx.x; c < K; c += kEmNT) {
             float denom = 0.0f;
-            for (uint32_t w = cls_woff[c]; w < cls_woff[c + 1]; ++w) denom += abundance(cls_sidx[w]);
+            for (uint32_t w = cls_woff[c]; w < cls_woff[c + 1]; ++w) {
+                const uint4 l = lw3[w];
+                denom += (vin[l.y] + vin[l.z]) + vin[l.x];
+            }
             inv[c] = denom > 0.0f ? (float)cls_cnt[c] / denom : -1.0f;
         }
         if (threadIdx.x == 0) s_flag[0] = 0;
         __syncthreads();
-        // (B) per support entry: single-label count, then class contributions in class order
+        // (B) per active entry: single-label count, then class contributions in class order
         bool bad = false;
-        for (uint32_t s = threadIdx.x; s < S; s += kEmNT) {
+        for (uint32_t a = threadIdx.x; a < A; a += kEmNT) {
+            const uint4 e = ent[a];
+            const uint32_t qend = ent[a + 1].w;
             float acc = 0.0f;
-            if (ucnt[s]) acc += (float)ucnt[s];
-            const float ab = abundance(s);
-            for (uint32_t q = slot_off[s]; q < slot_off[s + 1]; ++q) {
-                const float iv = inv[(uint32_t)inv_pairs[q]];
+            if (e.x) acc += (float)e.x;
+            const float old = vin[a];
+            const float ab = (vin[e.y] + vin[e.z]) + old;
+            for (uint32_t q = e.w; q < qend; ++q) {
+                const float iv = inv[memb[q]];
                 if (iv >= 0.0f) acc += ab * iv;
             }
-            a_out[s] = acc;
-            if (acc > kAlphaCheckCutoff && fabsf(a_in[s] - acc) > kRelDiffTol) bad = true;
+            vout[a] = acc;
+            if (acc > kAlphaCheckCutoff && fabsf(old - acc) > kRelDiffTol) bad = true;
         }
         if (bad) s_flag[0] = 1;
         __syncthreads();
         conv = s_flag[0] == 0;
-        for (uint32_t s = threadIdx.x; s < S; s += kEmNT) { a_in[s] = a_out[s]; a_out[s] = 0.0f; }
+        for (uint32_t a = threadIdx.x; a < A; a += kEmNT) vin[a] = vout[a];
+        if (threadIdx.x == 0) vin[Z0] = 0.0f;  // inactive entries come out of every round as 0
         ++it;
         __syncthreads();
         if (cfg.usa) {
             if (last_round) break;
             if (it >= kMinIter && conv) {
-                for (uint32_t s = threadIdx.x; s < S; s += kEmNT) if (a_in[s] < kMinOutputAlpha) a_in[s] = 0.0f;
+                for (uint32_t a = threadIdx.x; a < A; a += kEmNT) if (vin[a] < kMinOutputAlpha) vin[a] = 0.0f;
                 last_round = true;
                 __syncthreads();
             }
         }
     }
-    // 6. floor and emit the non-zero alphas in column order
+    EM_MARK(5);
+    // 6. floor and emit the non-zero alphas in column order (active ids ascend with the column)
     uint32_t nout = 0;
-    for (uint32_t base = 0; base < S; base += kEmNT) {
-        const uint32_t s = base + threadIdx.x;
-        float v = s < S ? a_in[s] : 0.0f;
+    for (uint32_t base = 0; base < A; base += kEmNT) {
+        const uint32_t a = base + threadIdx.x;
+        float v = a < A ? vin[a] : 0.0f;
         if (v < kMinOutputAlpha) v = 0.0f;
         const uint32_t h = v > 0.0f;
         uint32_t tot;
         const uint32_t ex = block_excl_scan<kEmNT>(h, s_ws, tot);
-        if (h) out[nout + ex] = make_uint2(support[s], __float_as_uint(v));
+        if (h) out[nout + ex] = make_uint2(act_col[a], __float_as_uint(v));
         nout += tot;
     }
     if (threadIdx.x == 0) out_nnz[cell] = nout;
+    EM_MARK(6);
+#ifdef AFQ_EM_TIMING
+    if (threadIdx.x == 0 && (blockIdx.x % 1000) == 7) { printf("em cell nrec=%u nU=%u M=%u K=%u S=%u Wc=%u it=%u:", m.nrec, nU, M, K, S, Wc, it); for (int i = 1; i <= 6; ++i) printf(" p%d=%.3fms", i, (double)(tmark[i] - tmark[i - 1]) / 1e5); printf("\n"); }
+#endif
 }
 
 // EM output pairs -> final CSR
@@ -2479,9 +2540,16 @@ uint64_t em_scratch_words(uint32_t nU, uint32_t W, uint32_t M, bool usa) {
                  + ((uint64_t)M + 2)       // cls_woff
                  + 2 * ((uint64_t)W + 1)   // cls_w, cls_sidx
                  + ((uint64_t)M + 1)       // inv
-                 + 6 * (capS + 1)          // support, sib1, sib2, ucnt, a_in, a_out
-                 + (capS + 2);             // slot_off
-    return (w + 1) & ~1ull;  // keep slices 8-byte aligned
+                 + 4 * (capS + 1)          // support, sib1, sib2, ucnt
+                 + 2 * (capS + 2)          // a_in, a_out
+                 + (capS + 2)              // slot_off
+                 + (capS + 1)              // aid
+                 + 4 * ((uint64_t)nU + W + 2)  // ent
+                 + 4 * ((uint64_t)W + 1)   // lw3
+                 + ((uint64_t)nU + W + 2)  // act_col
+                 + ((uint64_t)W + 1)       // memb
+                 + 4;                      // alignment slack for the 16-byte records
+    return (w + 3) & ~3ull;  // keep slices 16-byte aligned
 }
 
 void launch_em(hipStream_t s, const ResolveArgs& a, uint32_t n_cells, const uint64_t* em_off, uint32_t* scratch,
