@@ -47,7 +47,8 @@ class AfqConfig(C.Structure):
         ("bc_bytes", C.c_uint32),
         ("umi_bytes", C.c_uint32),
         ("profile", C.c_uint32),
-        ("reserved", C.c_uint32 * 3),
+        ("umi_len", C.c_uint32),
+        ("reserved", C.c_uint32 * 2),
     ]
 
 

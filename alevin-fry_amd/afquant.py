@@ -45,6 +45,7 @@ class WorkerConfig:
     em_init_uniform: bool = False
     bc_bytes: int = 4
     umi_bytes: int = 4
+    umi_len: int = 0  # UMI length in bases if known (RAD file tag ulen); 0 = unknown
     profile: bool = False
 
     @staticmethod
@@ -72,6 +73,7 @@ class WorkerConfig:
         c.bc_bytes = self.bc_bytes
         c.umi_bytes = self.umi_bytes
         c.profile = int(self.profile)
+        c.umi_len = int(self.umi_len)
         return c
 
 

@@ -235,6 +235,7 @@ int check_supported(afq_ctx* c) {
         return fail(c, AFQ_ERR_UNSUPPORTED, "device parsimony needs 4- or 8-byte barcode/UMI fields");
     if (g.usa_mode && g.sa_model != AFQ_SA_WINNER_TAKE_ALL)
         return fail(c, AFQ_ERR_UNSUPPORTED, "sa_model prefer-ambig is not implemented on the device path");
+    if (g.umi_len > 4 * g.umi_bytes) return fail(c, AFQ_ERR_INVALID_ARG, "umi_len does not fit the UMI field");
     return 0;
 }
 
@@ -252,7 +253,7 @@ int plan_ranges(afq_ctx* c) {
     const bool pug_res = res >= AFQ_RES_PARSIMONY_EM && res <= AFQ_RES_PARSIMONY_GENE;
     // pass 1: validate the chunk headers, device bytes each cell needs
     std::vector<double> need(c->n_cells);
-    double total_need = 0;
+    double total_need = 0, pug_fixed = 0;
     c->all_aligned = true;
     for (uint32_t i = 0; i < c->n_cells; ++i) {
         const uint64_t off = c->chunk_off[i];
@@ -266,7 +267,10 @@ int plan_ranges(afq_ctx* c) {
             return fail(c, AFQ_ERR_BAD_INPUT, "cell " + std::to_string(i) + ": chunk nbytes does not match its records");
         const uint64_t n_ref = (nbytes - fixed) / 4;
         double nd = (em_res ? 24.0 + 40.0 * (c->cfg.usa_mode ? 3 : 1) : 16.0) * (double)n_ref + 128.0;
-        if (pug_res) nd += 4.0 * (double)pug_scratch_words(nrec, (uint32_t)n_ref, true) + 20.0 * nrec + 64.0 * nrec;
+        if (pug_res) {  // per read: decode outputs + edge pool; the PUG scratch is per workgroup (sized for the largest cell)
+            nd += 20.0 * nrec + 64.0 * nrec;
+            pug_fixed = std::max(pug_fixed, 4.0 * (double)pug_scratch_words(nrec, (uint32_t)n_ref, true) * pug_max_blocks());
+        }
         if (n_ref > kBucketTarget) nd += 16.0 * (double)(n_ref / kBucketTarget + 1);
         if (nd > mem_budget) return fail(c, AFQ_ERR_OOM, "cell " + std::to_string(i) + " alone exceeds device memory");
         need[i] = nd;
@@ -275,7 +279,8 @@ int plan_ranges(afq_ctx* c) {
     // pass 2: cut into ranges.  Big batches are cut into about kPipeRanges ranges of equal work even when memory
     // would allow one, so that the D2H of one range's rows hides under the kernels of the next.
     constexpr double kPipeRanges = 4.0;
-    double budget = mem_budget;
+    if (pug_fixed > 0.5 * mem_budget) return fail(c, AFQ_ERR_OOM, "the largest parsimony cell's scratch does not fit device memory");
+    double budget = mem_budget - pug_fixed;
     if (c->n_bytes >= (256u << 20)) budget = std::min(budget, total_need / kPipeRanges * 1.02 + 1.0);
     if (const char* e = std::getenv("AFQ_RANGE_BYTES")) budget = std::min(budget, std::atof(e));  // tests: force many ranges
     c->ranges.clear();
@@ -308,8 +313,8 @@ int run_range(afq_ctx* c, Range r, int slot) {
     const uint32_t n = r.c1 - r.c0;
     B.meta.resize(n);
     std::vector<uint32_t> multi, tile_prefix, bucket_cell, slab_prefix, pug_cells, hist_cells;
-    std::vector<uint64_t> rd_off(n, 0), pug_scr;
-    uint64_t n_pug_reads = 0, pug_words = 0;
+    std::vector<uint64_t> rd_off(n, 0);
+    uint64_t n_pug_reads = 0, pug_words = 0;  // pug_words: scratch of the largest parsimony cell
     const bool par = c->all_aligned && decode_par_supported(g.bc_bytes, g.umi_bytes);
     uint64_t key_off = 0, n_buckets = 0, n_tiles = 0, n_slabs = 0;
     if (par) slab_prefix.reserve(n + 1);
@@ -343,8 +348,8 @@ int run_range(afq_ctx* c, Range r, int slot) {
                  : g.resolution == AFQ_RES_PARSIMONY_GENE ? kModePugGene
                  : g.resolution == AFQ_RES_PARSIMONY_GENE_EM ? kModePugGeneEm : kModeCrLike;
         if (mode_is_pug(m.mode)) {
-            pug_cells.push_back(i); rd_off[i] = n_pug_reads; n_pug_reads += m.nrec; pug_scr.push_back(pug_words);
-            pug_words += pug_scratch_words(m.nrec, m.n_ref, mode_pug_gene(m.mode));
+            pug_cells.push_back(i); rd_off[i] = n_pug_reads; n_pug_reads += m.nrec;
+            pug_words = std::max<uint64_t>(pug_words, pug_scratch_words(m.nrec, m.n_ref, mode_pug_gene(m.mode)));
         }
         nrec_total += m.nrec;
         if (par) {
@@ -380,6 +385,9 @@ int run_range(afq_ctx* c, Range r, int slot) {
     HIP_TRY(c, B.d_bdesc.ensure(bucket_desc_bytes() * std::max<uint64_t>(n_buckets, 1)));
     const bool em = g.resolution == AFQ_RES_CR_LIKE_EM || g.resolution == AFQ_RES_PARSIMONY_EM || g.resolution == AFQ_RES_PARSIMONY_GENE_EM;
     const uint32_t n_pug = (uint32_t)pug_cells.size();
+    const uint32_t n_pug_blocks = std::min<uint32_t>(n_pug, pug_max_blocks());
+    // largest cells first: the persistent workgroups take them in list order, so the long ones do not end up as the tail
+    std::stable_sort(pug_cells.begin(), pug_cells.end(), [&](uint32_t a, uint32_t b) { return B.meta[a].nrec > B.meta[b].nrec; });
     if (n_pug && !par) return fail(c, AFQ_ERR_UNSUPPORTED, "device parsimony needs dword-aligned chunk offsets");
     hist_cells = multi;
     hist_cells.insert(hist_cells.end(), pug_cells.begin(), pug_cells.end());
@@ -390,8 +398,8 @@ int run_range(afq_ctx* c, Range r, int slot) {
         HIP_TRY(c, B.d_rd_h.ensure(8 * n_pug_reads + 8));
         HIP_TRY(c, B.d_rd_u.ensure(8 * n_pug_reads + 8));
         HIP_TRY(c, B.d_rd_o.ensure(4 * n_pug_reads + 8));
-        HIP_TRY(c, B.d_pug_scr_off.ensure(8ull * n_pug));
-        HIP_TRY(c, B.d_pug_scratch.ensure(4 * pug_words + 64));
+        HIP_TRY(c, B.d_pug_scr_off.ensure(8));  // work counter
+        HIP_TRY(c, B.d_pug_scratch.ensure(4 * pug_words * n_pug_blocks + 64));
         HIP_TRY(c, B.d_epool.ensure(4 * epool_words));
         HIP_TRY(c, B.d_epool_cur.ensure(8));
     }
@@ -438,7 +446,7 @@ int run_range(afq_ctx* c, Range r, int slot) {
     if (n_pug) {
         HIP_TRY(c, hipMemcpyAsync(B.d_pug_cells.p, pug_cells.data(), 4ull * n_pug, hipMemcpyHostToDevice, s));
         HIP_TRY(c, hipMemcpyAsync(B.d_rd_off.p, rd_off.data(), 8ull * n, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemcpyAsync(B.d_pug_scr_off.p, pug_scr.data(), 8ull * n_pug, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemsetAsync(B.d_pug_scr_off.p, 0, 8, s));
         HIP_TRY(c, hipMemsetAsync(B.d_epool_cur.p, 0, 8, s));
     }
     HIP_TRY(c, hipMemsetAsync(B.d_status.p, 0, sizeof(DevStatus), s));
@@ -481,15 +489,15 @@ int run_range(afq_ctx* c, Range r, int slot) {
     if (n_pug) {
         PugCellArgs pa{};
         pa.bytes = c->d_bytes; pa.meta = ra.meta; pa.pug_cells = B.d_pug_cells.as<uint32_t>(); pa.cell_nkeys = ra.cell_nkeys;
-        pa.rd = da.pug; pa.scr_off = B.d_pug_scr_off.as<uint64_t>(); pa.scratch = B.d_pug_scratch.as<uint32_t>();
+        pa.rd = da.pug; pa.scr_stride = pug_words; pa.scratch = B.d_pug_scratch.as<uint32_t>(); pa.work_counter = B.d_pug_scr_off.as<uint32_t>(); pa.n_pug = n_pug;
         pa.epool = B.d_epool.as<uint32_t>(); pa.epool_cursor = B.d_epool_cur.as<unsigned long long>(); pa.epool_cap = epool_words;
         pa.t2g = c->d_t2g.as<uint32_t>(); pa.keys0 = ra.keys0; pa.cell_ncols = ra.cell_ncols; pa.lab = ra.lab; pa.lab_cnt = ra.lab_cnt;
         pa.alt = B.d_alt.as<uint32_t>(); pa.st = ra.st; pa.ref_count = c->ref_count; pa.num_genes = g.num_genes; pa.usa = g.usa_mode;
         pa.num_rows = g.num_rows; pa.em = em ? 1u : 0u; pa.exact_umi = g.pug_exact_umi; pa.large_thresh = g.large_graph_thresh;
-        pa.hw = 1 + g.bc_bytes / 4 + g.umi_bytes / 4; pa.umi_pairs = std::min<uint32_t>(g.umi_bytes * 4, 22);
+        pa.hw = 1 + g.bc_bytes / 4 + g.umi_bytes / 4; pa.umi_pairs = std::min<uint32_t>(g.umi_len ? g.umi_len : g.umi_bytes * 4, 22);
         pa.gene_level = (g.resolution == AFQ_RES_PARSIMONY_GENE || g.resolution == AFQ_RES_PARSIMONY_GENE_EM) ? 1u : 0u;
         ScopedTimer t(c, K_PUG, s, &B.launches);
-        launch_pug(s, pa, n_pug);
+        launch_pug(s, pa, n_pug_blocks);
     }
     if (!hist_cells.empty()) { ScopedTimer t(c, K_CELL_HIST, s, &B.launches); launch_cell_hist(s, ra); }
     HIP_TRY(c, hipGetLastError());

@@ -367,7 +367,7 @@ int afq_quantify(const afq_quant_opts* o) {
     cfg.abi_version = AFQ_ABI_VERSION; cfg.resolution = R->id; cfg.sa_model = AFQ_SA_WINNER_TAKE_ALL; cfg.usa_mode = usa;
     cfg.num_genes = usa ? 2 * G : G; cfg.num_rows = usa ? 3 * G : G;  // src/quant.rs:1627-1645
     cfg.small_thresh = o->small_thresh; cfg.large_graph_thresh = large_thresh; cfg.pug_exact_umi = (R->pars && edist == 0) ? 1 : 0;
-    cfg.em_init_uniform = o->init_uniform; cfg.bc_bytes = P.bc_bytes; cfg.umi_bytes = P.umi_bytes;
+    cfg.em_init_uniform = o->init_uniform; cfg.bc_bytes = P.bc_bytes; cfg.umi_bytes = P.umi_bytes; { const uint64_t ul = P.file_tag_vals.count("ulen") ? P.file_tag_vals["ulen"] : 0; cfg.umi_len = ul <= 4ull * P.umi_bytes ? (uint32_t)ul : 0u; }
     afq_ctx* ctx = nullptr;
     rc = afq_create(&cfg, t2g.data(), (uint32_t)P.ref_count, (int)o->device, &ctx);
     if (rc) return hfail(rc, std::string("afq_create: ") + afq_last_error(nullptr));

@@ -86,8 +86,10 @@ struct PugCellArgs {
     const uint32_t* pug_cells;
     const uint32_t* cell_nkeys;   // reads the decode emitted per cell
     PugOut rd;
-    const uint64_t* scr_off;      // [n_pug] word offset of the cell's scratch slice
+    uint64_t scr_stride;          // words of scratch per WORKGROUP (sized for the largest cell of the batch, reused cell after cell)
     uint32_t* scratch;
+    uint32_t* work_counter;       // next entry of pug_cells to take (persistent workgroups)
+    uint32_t n_pug;
     uint32_t* epool;              // edge pool (u32 words) + multi-word adjacency rows
     unsigned long long* epool_cursor;
     unsigned long long epool_cap;
@@ -101,7 +103,8 @@ struct PugCellArgs {
     uint32_t ref_count, num_genes, usa, num_rows, em, exact_umi, large_thresh, hw, umi_pairs, gene_level;
 };
 
-void launch_pug(hipStream_t s, const PugCellArgs& a, uint32_t n_pug);
+void launch_pug(hipStream_t s, const PugCellArgs& a, uint32_t n_blocks);
+uint32_t pug_max_blocks();
 uint64_t pug_scratch_words(uint32_t nrec, uint32_t n_ref, bool gene_level);
 
 constexpr uint32_t kScatterTileHost = 2048;  // keys per histogram/scatter tile

@@ -175,12 +175,22 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     uint32_t* s_bloom = s_big;
     __shared__ uint32_t s_bestv[kPugNT / 64], s_bestsz[kPugNT / 64];
 #ifdef AFQ_PUG_TIMING
-    __shared__ unsigned long long tmark[16];
+    __shared__ unsigned long long tmark[24];
 #endif
-    const uint32_t cell = A.pug_cells[blockIdx.x];
+    __shared__ uint32_t s_next;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  // Persistent workgroup: takes the next cell of the (largest-first) list until the list is empty.  Its scratch
+  // slice is reused cell after cell, so the working set of a CU stays the size of ONE cell instead of wandering
+  // over a slice per cell (the random probes of the edge phase were paying a TLB miss each).
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) s_next = atomicAdd(A.work_counter, 1u);
+    __syncthreads();
+    const uint32_t work = s_next;
+    if (work >= A.n_pug) return;
+    const uint32_t cell = A.pug_cells[work];
     const CellMeta m = A.meta[cell];
     const uint32_t R = m.nrec;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     if (tid < 4) s_cnt[tid] = 0;
     if (tid < 2) s_flag[tid] = 0;
     __syncthreads();
@@ -199,7 +209,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     if (R >= (1u << kVidBits)) { if (tid == 0) set_err(A.st, kErrPugLimit, cell); return; }
 
     // ---- scratch carve (u32 words; see pug_scratch_words) ----
-    uint32_t* p = A.scratch + A.scr_off[blockIdx.x];
+    uint32_t* p = A.scratch + A.scr_stride * blockIdx.x;
     SortRec* sr = reinterpret_cast<SortRec*>(p); p += 6 * (size_t)R;           // slab A
     uint64_t* v_umi = reinterpret_cast<uint64_t*>(p); p += 2 * (size_t)R;      // slab B (hash order)
     uint32_t* v_cnt = p; p += R;
@@ -215,6 +225,10 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     uint32_t* c_order = p; p += R;
     uint32_t* deg = p; p += R + 2;         // out-degree, then edge offsets
     uint32_t* comp_start = p; p += R + 2;
+    uint32_t ht_cap = 64;
+    while (ht_cap < 2 * R) ht_cap <<= 1;
+    p += (p - A.scratch) & 1;              // 8-byte align
+    unsigned long long* htab = reinterpret_cast<unsigned long long*>(p); p += 2 * (size_t)ht_cap;   // vertices by UMI (open addressing)
     uint32_t* c_goff = p; p += A.gene_level ? R + 2 : 0;           // gene-level: class -> offset of its gene list
     uint32_t* c_glab = p; p += A.gene_level ? m.n_ref + 2 : 0;      // gene-level: the sorted distinct gene lists
     // aliases into slab A once the sorted reads are consumed
@@ -361,16 +375,31 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     }
     __syncthreads();
     PUG_MARK(3);
-    // ---- 4. vertices sorted by UMI for neighbour probing ----
-    for (uint32_t v = tid; v < V; v += kPugNT) {
-        if (vv_umi[v] >> (64 - kVidBits)) s_cnt[3] = kErrPugLimit;
-        us[v] = (vv_umi[v] << kVidBits) | v;
-    }
+    // ---- 4. vertices hashed by UMI for neighbour probing ----
+    // (every vertex with a given UMI sits on the probe run that starts at the UMI's home slot)
+    constexpr unsigned long long kHtEmpty = ~0ull;
+    const uint32_t ht_mask = ht_cap - 1;
+    const uint32_t ht_shift = 64 - (uint32_t)__builtin_ctz(ht_cap);
+    auto ht_home = [&](uint64_t umi) -> uint32_t { return (uint32_t)((umi * 0xD6E8FEB86659FD93ull) >> ht_shift); };
+    for (uint32_t i = tid; i < ht_cap; i += kPugNT) htab[i] = kHtEmpty;
+    for (uint32_t i = tid; i < (1u << 15); i += kPugNT) s_bloom[i] = 0;
+    for (uint32_t v = tid; v < V; v += kPugNT) if (vv_umi[v] >> (64 - kVidBits)) s_cnt[3] = kErrPugLimit;
     __syncthreads();
     if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], cell); return; }
-    tiled_bitonic_sort_by<kPugNT, 8192>(us, V, [](uint64_t a, uint64_t b) { return a > b; }, reinterpret_cast<uint64_t*>(s_big));
-    for (uint32_t i = tid; i < (1u << 15); i += kPugNT) s_bloom[i] = 0;
+    uint32_t* vflag = c_minoff;  // dead after phase 3: 1 = another vertex carries the same UMI
+    for (uint32_t v = tid; v < V; v += kPugNT) vflag[v] = 0;
     __syncthreads();
+    for (uint32_t v = tid; v < V; v += kPugNT) {
+        const uint64_t umi = vv_umi[v];
+        const unsigned long long e = ((unsigned long long)umi << kVidBits) | v;
+        for (uint32_t slot = ht_home(umi);; slot = (slot + 1) & ht_mask) {
+            const unsigned long long old = atomicCAS(&htab[slot], kHtEmpty, e);
+            if (old == kHtEmpty) break;
+            // same UMI under another label: whichever of the two is inserted second walks over the first
+            if ((old >> kVidBits) == umi) { vflag[v] = 1; vflag[(uint32_t)old & ((1u << kVidBits) - 1)] = 1; }
+        }
+    }
+    PUG_MARK(11);
     auto bloom_bit = [](uint64_t umi) -> uint32_t { return (uint32_t)((umi * kHashMul) >> 44); };
     auto bloom_bit2 = [](uint64_t umi) -> uint32_t { return (uint32_t)(((umi ^ (umi >> 23)) * 0xD6E8FEB86659FD93ull) >> 44); };
     for (uint32_t v = tid; v < V; v += kPugNT) {
@@ -398,8 +427,10 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     uint32_t ncand_mine = 0;
     for (uint32_t x = tid; x < V; x += kPugNT) {
         const uint64_t ux = vv_umi[x];
-        for (uint32_t pr = 0; pr < nprobe; ++pr) ncand_mine += passes(probe_umi(ux, pr));
+        ncand_mine += vflag[x];  // the distance-0 probe only matters when the UMI occurs under another label too
+        for (uint32_t pr = 1; pr < nprobe; ++pr) ncand_mine += passes(probe_umi(ux, pr));
     }
+    PUG_MARK(12);
     uint32_t NCAND;
     const uint32_t cand_off = block_excl_scan<kPugNT>(ncand_mine, s_ws, NCAND);
     if (tid == 0) s_ebase = atomicAdd(A.epool_cursor, 2ull * NCAND + 2);
@@ -410,12 +441,14 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         uint32_t o = cand_off;
         for (uint32_t x = tid; x < V; x += kPugNT) {
             const uint64_t ux = vv_umi[x];
-            for (uint32_t pr = 0; pr < nprobe; ++pr) {
+            if (vflag[x]) cand[o++] = (ux << kVidBits) | x;
+            for (uint32_t pr = 1; pr < nprobe; ++pr) {
                 const uint64_t pu = probe_umi(ux, pr);
                 if (passes(pu)) cand[o++] = (pu << kVidBits) | x;
             }
         }
     }
+    PUG_MARK(13);
     for (uint32_t x = tid; x <= V; x += kPugNT) deg[x] = 0;
     __syncthreads();
     // out-neighbours of x: vertices y != x with overlapping labels and UMI distance 0, or distance 1 and
@@ -425,19 +458,34 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         const uint64_t pu = cd >> kVidBits;
         const bool same = pu == vv_umi[x];
         const uint32_t cx = vv_cnt[x], kx = vv_cls[x];
-        const uint64_t key = pu << kVidBits;
-        uint32_t lo = 0, hi = V;
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (us[mid] < key) lo = mid + 1; else hi = mid; }
-        for (; lo < V && (us[lo] >> kVidBits) == pu; ++lo) {
-            const uint32_t y = (uint32_t)us[lo] & ((1u << kVidBits) - 1);
+        for (uint32_t slot = ht_home(pu);; slot = (slot + 1) & ht_mask) {
+            const unsigned long long e = htab[slot];
+            if (e == kHtEmpty) break;
+            if ((e >> kVidBits) != pu) continue;
+            const uint32_t y = (uint32_t)e & ((1u << kVidBits) - 1);
             if (y == x) continue;
             if (!same && !(vv_cnt[y] < 2 * cx)) continue;
             if (vv_cls[y] != kx && !lab_overlap(vlab(x), vlab(y))) continue;
             f(x, y);
         }
     };
-    for (uint32_t i = tid; i < NCAND; i += kPugNT) for_each_edge_of(cand[i], [&](uint32_t x, uint32_t) { atomicAdd(&deg[x], 1u); });
+    // one walk per candidate: the edges found go to a pair list (and are counted per source); the CSR is filled
+    // from the list.  The list has room for NCAND + V pairs; only a cell with piles of same-UMI vertices can
+    // overflow it, and then the candidates are simply walked a second time.
+    const uint32_t pair_cap = NCAND + V;
+    if (tid == 0) { s_ebase = atomicAdd(A.epool_cursor, 2ull * pair_cap + 2); s_flag[0] = 0; }
     __syncthreads();
+    if (s_ebase + 2ull * pair_cap + 2 > A.epool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, cell); return; }
+    uint64_t* pairs = reinterpret_cast<uint64_t*>(A.epool + ((s_ebase + 1) & ~1ull));
+    for (uint32_t i = tid; i < NCAND; i += kPugNT)
+        for_each_edge_of(cand[i], [&](uint32_t x, uint32_t y) {
+            atomicAdd(&deg[x], 1u);
+            const uint32_t k = atomicAdd(&s_flag[0], 1u);
+            if (k < pair_cap) pairs[k] = ((uint64_t)x << 32) | y;
+        });
+    __syncthreads();
+    const uint32_t n_pairs = s_flag[0];
+    PUG_MARK(14);
     uint32_t E = 0;
     for (uint32_t base = 0; base < V; base += kPugNT) {
         const uint32_t x = base + tid;
@@ -455,8 +503,15 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     __syncthreads();
     if (s_ebase + E > A.epool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, cell); return; }
     uint32_t* edges = A.epool + s_ebase;
-    for (uint32_t i = tid; i < NCAND; i += kPugNT)
-        for_each_edge_of(cand[i], [&](uint32_t x, uint32_t y) { edges[atomicAdd(&c_order[x], 1u)] = y; });
+    if (n_pairs <= pair_cap) {
+        for (uint32_t k = tid; k < n_pairs; k += kPugNT) {
+            const uint64_t pr = pairs[k];
+            edges[atomicAdd(&c_order[(uint32_t)(pr >> 32)], 1u)] = (uint32_t)pr;
+        }
+    } else {
+        for (uint32_t i = tid; i < NCAND; i += kPugNT)
+            for_each_edge_of(cand[i], [&](uint32_t x, uint32_t y) { edges[atomicAdd(&c_order[x], 1u)] = y; });
+    }
     __syncthreads();
     PUG_MARK(5);
     // ---- 5. weakly connected components: min-label propagation + pointer jumping ----
@@ -510,7 +565,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     __syncthreads();
     for (uint32_t c = tid; c < NC; c += kPugNT) {
         const uint32_t n = comp_start[c + 1] - comp_start[c];
-        if (n < 2) continue;
+        if (n < 2 || (n == 2 && n <= C.large_thresh)) continue;  // singletons and pairs are resolved lane-parallel below
         if (n <= 64 && n <= C.large_thresh) mid_list[atomicAdd(&s_flag[0], 1u)] = c;
         else big_list[atomicAdd(&s_flag[1], 1u)] = c;
     }
@@ -520,11 +575,32 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
 
     PUG_MARK(7);
     // ---- 6a. single-vertex components: the label's genes (pugutils.rs:1262-1322) ----
+    // A two-vertex component is always one molecule: it is weakly connected, so one of the two can reach the
+    // other through a shared transcript and the greedy cover takes that 2-vertex arborescence first; its label
+    // is the transcripts the two labels share (pugutils.rs:1161-1188) - never empty, an edge needs an overlap.
     for (uint32_t c = tid; c < NC; c += kPugNT) {
-        if (comp_start[c + 1] - comp_start[c] != 1) continue;
+        const uint32_t n = comp_start[c + 1] - comp_start[c];
+        if (n > 2 || (n == 2 && n > C.large_thresh)) continue;
         const Lab l = vlab(vid_at(comp_start[c]));
         uint32_t g[kMaxGenesPerLabel];
-        const uint32_t ng = genes_of(C, l.n, [&](uint32_t j) { return l.p[j] & 0x7FFFFFFFu; }, g);
+        uint32_t ng;
+        if (n == 1) ng = genes_of(C, l.n, [&](uint32_t j) { return l.p[j] & 0x7FFFFFFFu; }, g);
+        else {
+            const Lab l2 = vlab(vid_at(comp_start[c] + 1));
+            ng = 0;
+            for (uint32_t j = 0; j < l.n && ng != 0xFFFFFFFFu; ++j) {
+                const uint32_t t = l.p[j] & 0x7FFFFFFFu;
+                if (!lab_contains(l2, t)) continue;
+                const uint32_t gid = C.gene_level ? t : C.t2g[t];
+                uint32_t q = 0;
+                while (q < ng && g[q] < gid) ++q;
+                if (q < ng && g[q] == gid) continue;
+                if (ng == kMaxGenesPerLabel) { ng = 0xFFFFFFFFu; break; }
+                for (uint32_t r = ng; r > q; --r) g[r] = g[r - 1];
+                g[q] = gid;
+                ++ng;
+            }
+        }
         emit_molecule(C, g, ng);
     }
     PUG_MARK(8);
@@ -788,23 +864,33 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     __syncthreads();
     PUG_MARK(10);
 #ifdef AFQ_PUG_TIMING
-    if (tid == 0 && blockIdx.x < 4) { printf("pug cell R=%u V=%u K=%u NC=%u nmid=%u nbig=%u:", R, V, K, NC, n_mid, n_big); for (int i = 1; i <= 10; ++i) printf(" p%d=%.2fms", i - 1, (double)(tmark[i] - tmark[i - 1]) / 1e5); printf("\n"); }
+    if (tid == 0 && blockIdx.x < 4 && (work % 1024) < 4) { printf("pug cell R=%u V=%u K=%u NC=%u nmid=%u nbig=%u:", R, V, K, NC, n_mid, n_big); for (int i = 1; i <= 10; ++i) printf(" p%d=%.2fms", i - 1, (double)(tmark[i] - tmark[i - 1]) / 1e5); printf(" | ht+bloom=%.2f countA=%.2f writeA=%.2f degB=%.2f fillB=%.2f NCAND=%u E=%u\n", (double)(tmark[11] - tmark[4]) / 1e5, (double)(tmark[12] - tmark[11]) / 1e5, (double)(tmark[13] - tmark[12]) / 1e5, (double)(tmark[14] - tmark[13]) / 1e5, (double)(tmark[5] - tmark[14]) / 1e5, NCAND, E); }
 #endif
     if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], cell); return; }
     if (tid == 0) {
         A.cell_ncols[cell] = s_cnt[0];
         if (A.lab_cnt) { A.lab_cnt[2 * cell] = s_cnt[1]; A.lab_cnt[2 * cell + 1] = s_cnt[2]; }
     }
+  }
 }
 
-void launch_pug(hipStream_t s, const PugCellArgs& a, uint32_t n_pug) {
-    if (!n_pug) return;
-    hipLaunchKernelGGL(k_pug_cell, dim3(n_pug), dim3(kPugNT), 0, s, a);
+void launch_pug(hipStream_t s, const PugCellArgs& a, uint32_t n_blocks) {
+    if (!n_blocks) return;
+    hipLaunchKernelGGL(k_pug_cell, dim3(n_blocks), dim3(kPugNT), 0, s, a);
+}
+
+// one workgroup per CU fits (LDS filter + 1024 threads)
+uint32_t pug_max_blocks() {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    return (uint32_t)(cus > 0 ? cus : 256);
 }
 
 uint64_t pug_scratch_words(uint32_t nrec, uint32_t n_ref, bool gene_level) {
     const uint64_t R = nrec;
-    return 6 * R + 4 * R + 5 * R + (R + 1) + 4 * R + (R + 2) + (R + 2) + (gene_level ? R + 2 + (uint64_t)n_ref + 2 : 0) + 16;
+    uint64_t ht_cap = 64;
+    while (ht_cap < 2 * R) ht_cap <<= 1;
+    return 6 * R + 4 * R + 5 * R + (R + 1) + 4 * R + (R + 2) + (R + 2) + 1 + 2 * ht_cap + (gene_level ? R + 2 + (uint64_t)n_ref + 2 : 0) + 16;
 }
 
 }  // namespace afq

@@ -63,7 +63,7 @@ def main():
     t_gen = time.time() - t0
     d_bytes = torch.from_numpy(rad.data).to(dev)
     cfg = pkg.WorkerConfig.for_resolution(args.resolution, usa_mode=rad.usa, num_genes=rad.num_genes,
-                                          num_rows=rad.num_rows, profile=True)
+                                          num_rows=rad.num_rows, profile=True, umi_len=12)  # umi_len: what the RAD header's `ulen` tag says
     q = pkg.Quantifier(cfg, rad.tid_to_gid, device=local_rank)
 
     res = None

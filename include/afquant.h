@@ -74,7 +74,10 @@ typedef struct afq_config {
     uint32_t bc_bytes;           /* width of the barcode field in a record: 1,2,4,8              */
     uint32_t umi_bytes;          /* width of the UMI field in a record: 1,2,4,8                  */
     uint32_t profile;            /* 1: bracket every kernel with HIP events (afq_get_kernel_times)*/
-    uint32_t reserved[3];
+    uint32_t umi_len;            /* UMI length in bases when the caller knows it (the RAD file tag `ulen`); 0 = unknown.
+                                    Only bounds the 1-mismatch neighbour probes of the PUG (positions past the UMI
+                                    cannot differ), so a value that is too SMALL would lose edges: pass 0 when unsure. */
+    uint32_t reserved[2];
 } afq_config;
 
 typedef struct afq_ctx afq_ctx;
