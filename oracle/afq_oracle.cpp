@@ -415,7 +415,9 @@ static void trivial_counts(const EqMap& m, const u32* t2g, u32 num_genes, std::v
         }
         total += m.umis[e].size();
         if (multi_gene) multi += m.umis[e].size();
-        else { auto& v = gene_map[prev]; for (auto& uc : m.umis[e]) v.push_back(uc.first); }
+        else if (prev != UINT32_MAX) { auto& v = gene_map[prev]; for (auto& uc : m.umis[e]) v.push_back(uc.first); }
+        // (an alignment-free record would index counts[u32::MAX] in the reference and panic, pugutils.rs:891-907;
+        //  mappers do not emit such records - the oracle and the device path leave them out)
     }
     for (auto& kv : gene_map) {
         auto& v = kv.second;

@@ -300,3 +300,36 @@ def test_tie_shapes_and_wide_umis(oracle, usa, pad_reads):
     got, want, _ = run_both(oracle, cfg, t2g.astype(np.uint32), b, off)
     assert_same_result(got, want)
     assert got.val.sum() > 0
+
+
+@pytest.mark.parametrize("decoder", ["recs", "keys"])
+@pytest.mark.parametrize("resolution", ["cr-like", "trivial"])
+def test_long_and_straddling_records(oracle, monkeypatch, decoder, resolution):
+    """Records of every awkward length for the walk-free decoders: 0 alignments, just around the inline limits
+    (3, 4), around the 64-dword halo, around a whole 256-dword slab, and thousands of alignments (a record that
+    spans many slabs, so later slabs start in the middle of it).  Alignments repeat genes on purpose.  Both
+    decoders (one lane per record / one lane per dword) must agree with the oracle bit for bit."""
+    monkeypatch.setenv("AFQ_DECODE", decoder)
+    rng = np.random.default_rng(5)
+    n_txp, n_genes = 6000, 700
+    t2g = (rng.permutation(n_txp) % n_genes).astype(np.uint32)
+    lens = [0, 1, 2, 3, 4, 5, 8, 9, 59, 60, 61, 62, 63, 64, 65, 66, 250, 251, 252, 253, 254, 255, 256, 257, 258, 319, 320, 321,
+            1000, 5000]
+    cells = []
+    for ci in range(3):
+        reads = []
+        umi = 50
+        for rep in range(3):
+            for n in rng.permutation(lens):
+                umi += int(rng.integers(1, 3))
+                refs = sorted(int(x) for x in rng.choice(n_txp, size=int(n), replace=False)) if n else []
+                reads.append((umi, refs))
+                for _ in range(int(rng.integers(0, 4))):  # short records in between, some sharing the UMI
+                    reads.append((umi + int(rng.integers(0, 2)), sorted(int(x) for x in rng.choice(n_txp, size=int(rng.integers(1, 4)), replace=False))))
+        cells.append((0x5A5A0000 + ci, reads if ci else reads[: len(reads) // 2]))  # a barcode no UMI / ref / count collides with
+    b, off = rad.encode_cells(cells, 4, 4)
+    cfg = pkg.WorkerConfig.for_resolution(resolution, num_genes=n_genes, num_rows=n_genes, small_thresh=0)
+    got, want, st = run_both(oracle, cfg, t2g, b, off)
+    assert_same_result(got, want)
+    assert st["n_fallback_cells"] == 0  # the walk-free proof held; nothing went through the sequential walk
+    assert got.val.sum() > 0
