@@ -134,8 +134,22 @@ def main():
         avg_ms = ms_tot / max(1, launches)
         launches_per_step = launches / args.steps
         achieved = alg_bytes / launches_per_step / (avg_ms * 1e-3) / 1e9
+        # HBM bytes per launch of that kernel from the committed PMC passes (profiles/*_traffic.json: FETCH_SIZE doubled
+        # per the gfx950 note + WRITE_SIZE); only meaningful for the default workload the profile was taken on
+        traffic = None
+        default_wl = (args.cells, args.median_reads, args.sigma, args.genes, args.usa, args.resolution) == \
+            (11000, 30000.0, 0.6, 36601, False, "cr-like")
+        tfiles = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")) \
+            if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+        if default_wl and tfiles:
+            kern = json.load(open(os.path.join(ROOT, "profiles", tfiles[-1])))["kernels"]
+            alias = {"k_decode_par": ("k_decode_recs", "k_decode_keys", "k_decode_par")}
+            for cand in alias.get(name, (name,)):
+                if cand in kern:
+                    traffic = kern[cand]["bytes_per_launch_fetch_doubled"]
+                    break
         roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(achieved / 8000.0, 5), "traffic": None,
+                    "frac": round(achieved / 8000.0, 5), "traffic": traffic,
                     "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
                     "alg_bytes_per_step": alg_bytes,
                     "all_kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in ktimes.items()}}

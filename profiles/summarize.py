@@ -27,7 +27,7 @@ def main(tag):
         out.append("bench.py HIP-event kernel ms/step: " + json.dumps(b["roofline"]["all_kernels_ms_per_step"]))
     except Exception as e:  # noqa
         out.append(f"(no bench json: {e})")
-    for sub in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_tcc"):
+    for sub in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_tcc"):
         p = os.path.join(root, sub, "pmc_results.db")
         if not os.path.exists(p):
             continue
