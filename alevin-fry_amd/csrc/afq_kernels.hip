@@ -2265,31 +2265,78 @@ __global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta,
     bool conv = true, last_round = false;
     while (it < kMinIter || (it < kMaxIter && !conv) || last_round) {
         // (A) per class: denominator in label order (get_abundance_for, em.rs:167-187)
-        for (uint32_t c = threadIdx.x; c < K; c += kEmNT) {
-            float denom = 0.0f;
-            for (uint32_t w = cls_woff[c]; w < cls_woff[c + 1]; ++w) {
-                const uint4 l = lw3[w];
-                denom += (vin[l.y] + vin[l.z]) + vin[l.x];
+        // four classes per thread per trip, their loads issued together: the rounds are chains of dependent
+        // L2 round trips, and a thread walking its classes one at a time has only one chain in flight
+        for (uint32_t c0 = threadIdx.x; c0 < K; c0 += 4 * kEmNT) {
+            uint32_t wb[4], we[4], cn[4];
+            uint4 l0[4], l1[4], l2[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t c = c0 + j * kEmNT;
+                const bool ok = c < K;
+                wb[j] = ok ? cls_woff[c] : 0u;
+                we[j] = ok ? cls_woff[c + 1] : 0u;
+                cn[j] = ok ? cls_cnt[c] : 0u;
             }
-            inv[c] = denom > 0.0f ? (float)cls_cnt[c] / denom : -1.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                l0[j] = lw3[wb[j] < we[j] ? wb[j] : 0u];
+                l1[j] = lw3[wb[j] + 1 < we[j] ? wb[j] + 1 : 0u];
+                l2[j] = lw3[wb[j] + 2 < we[j] ? wb[j] + 2 : 0u];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t c = c0 + j * kEmNT;
+                if (c >= K) continue;
+                float denom = 0.0f;
+                if (wb[j] < we[j]) denom += (vin[l0[j].y] + vin[l0[j].z]) + vin[l0[j].x];
+                if (wb[j] + 1 < we[j]) denom += (vin[l1[j].y] + vin[l1[j].z]) + vin[l1[j].x];
+                if (wb[j] + 2 < we[j]) denom += (vin[l2[j].y] + vin[l2[j].z]) + vin[l2[j].x];
+                for (uint32_t w = wb[j] + 3; w < we[j]; ++w) {
+                    const uint4 l = lw3[w];
+                    denom += (vin[l.y] + vin[l.z]) + vin[l.x];
+                }
+                inv[c] = denom > 0.0f ? (float)cn[j] / denom : -1.0f;
+            }
         }
         if (threadIdx.x == 0) s_flag[0] = 0;
         __syncthreads();
         // (B) per active entry: single-label count, then class contributions in class order
         bool bad = false;
-        for (uint32_t a = threadIdx.x; a < A; a += kEmNT) {
-            const uint4 e = ent[a];
-            const uint32_t qend = ent[a + 1].w;
-            float acc = 0.0f;
-            if (e.x) acc += (float)e.x;
-            const float old = vin[a];
-            const float ab = (vin[e.y] + vin[e.z]) + old;
-            for (uint32_t q = e.w; q < qend; ++q) {
-                const float iv = inv[memb[q]];
-                if (iv >= 0.0f) acc += ab * iv;
+        for (uint32_t a0 = threadIdx.x; a0 < A; a0 += 4 * kEmNT) {
+            uint4 e[4];
+            uint32_t qe[4], m0[4], m1[4];
+            float i0[4], i1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t a = a0 + j * kEmNT;
+                e[j] = ent[a < A ? a : A];         // ent[A] is the sentinel record
+                qe[j] = ent[a < A ? a + 1 : A].w;
             }
-            vout[a] = acc;
-            if (acc > kAlphaCheckCutoff && fabsf(old - acc) > kRelDiffTol) bad = true;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                m0[j] = memb[e[j].w < qe[j] ? e[j].w : 0u];
+                m1[j] = memb[e[j].w + 1 < qe[j] ? e[j].w + 1 : 0u];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { i0[j] = inv[m0[j]]; i1[j] = inv[m1[j]]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t a = a0 + j * kEmNT;
+                if (a >= A) continue;
+                float acc = 0.0f;
+                if (e[j].x) acc += (float)e[j].x;
+                const float old = vin[a];
+                const float ab = (vin[e[j].y] + vin[e[j].z]) + old;
+                if (e[j].w < qe[j] && i0[j] >= 0.0f) acc += ab * i0[j];
+                if (e[j].w + 1 < qe[j] && i1[j] >= 0.0f) acc += ab * i1[j];
+                for (uint32_t q = e[j].w + 2; q < qe[j]; ++q) {
+                    const float iv = inv[memb[q]];
+                    if (iv >= 0.0f) acc += ab * iv;
+                }
+                vout[a] = acc;
+                if (acc > kAlphaCheckCutoff && fabsf(old - acc) > kRelDiffTol) bad = true;
+            }
         }
         if (bad) s_flag[0] = 1;
         __syncthreads();
