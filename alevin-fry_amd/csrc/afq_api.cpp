@@ -130,7 +130,7 @@ struct RangeState {
     DevBuf d_meta, d_keys0, d_keys1, d_cell_nkeys, d_bucket_cnt, d_bucket_cell, d_multi_cells, d_tile_prefix, d_ncols,
         d_nnz, d_ovf, d_status, d_bc, d_cell_ptr, d_gene, d_val, d_chk, d_slab_prefix, d_slab_cell, d_cell_bc, d_bdesc, d_lab,
         d_lab_cnt, d_em_off, d_em_scratch, d_em_nnz, d_pug_cells, d_rd_off, d_rd_h, d_rd_u, d_rd_o, d_pug_scr_off,
-        d_pug_scratch, d_epool, d_epool_cur, d_alt, d_hist_cells;
+        d_pug_scratch, d_epool, d_epool_cur, d_alt, d_hist_cells, d_fix;
     ResolveArgs last_ra{};
     std::vector<CellMeta> meta;
     Range cur{};
@@ -141,7 +141,7 @@ struct RangeState {
         return {&d_meta, &d_keys0, &d_keys1, &d_cell_nkeys, &d_bucket_cnt, &d_bucket_cell, &d_multi_cells, &d_tile_prefix,
                 &d_ncols, &d_nnz, &d_ovf, &d_status, &d_bc, &d_cell_ptr, &d_gene, &d_val, &d_chk, &d_slab_prefix, &d_slab_cell,
                 &d_cell_bc, &d_bdesc, &d_lab, &d_lab_cnt, &d_em_off, &d_em_scratch, &d_em_nnz, &d_pug_cells, &d_rd_off, &d_rd_h,
-                &d_rd_u, &d_rd_o, &d_pug_scr_off, &d_pug_scratch, &d_epool, &d_epool_cur, &d_alt, &d_hist_cells};
+                &d_rd_u, &d_rd_o, &d_pug_scr_off, &d_pug_scratch, &d_epool, &d_epool_cur, &d_alt, &d_hist_cells, &d_fix};
     }
 };
 
@@ -413,6 +413,7 @@ int run_range(afq_ctx* c, Range r, int slot) {
     HIP_TRY(c, B.d_bc.ensure(8ull * n));
     if (par) {
         HIP_TRY(c, B.d_chk.ensure(sizeof(CellChk) * n));
+        HIP_TRY(c, B.d_fix.ensure(4ull * n));
         HIP_TRY(c, B.d_slab_prefix.ensure(4ull * (n + 1)));
         HIP_TRY(c, B.d_slab_cell.ensure(4ull * std::max<uint64_t>(n_slabs, 1)));
         HIP_TRY(c, B.d_cell_bc.ensure(8ull * n));
@@ -463,7 +464,7 @@ int run_range(afq_ctx* c, Range r, int slot) {
                   (uint32_t)n_slabs,
                   n_pug ? PugOut{B.d_rd_h.as<uint64_t>(), B.d_rd_u.as<uint64_t>(), B.d_rd_o.as<uint32_t>(), B.d_rd_off.as<uint64_t>()}
                         : PugOut{nullptr, nullptr, nullptr, nullptr},
-                  g.resolution == AFQ_RES_TRIVIAL ? 1u : 0u, decode_short_records(key_off - n, nrec_total)};
+                  g.resolution == AFQ_RES_TRIVIAL ? 1u : 0u, decode_short_records(key_off - n, nrec_total), par ? B.d_fix.as<uint32_t>() : nullptr};
     if (par) {
         ScopedTimer t(c, K_DECODE_PAR, s, &B.launches);
         if (launch_decode_par(s, da, g.bc_bytes, g.umi_bytes)) return fail(c, AFQ_ERR_INVALID_ARG, "bad field widths");

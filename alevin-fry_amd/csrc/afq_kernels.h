@@ -29,6 +29,7 @@ struct DecodeArgs {
     PugOut pug;                   // PUG cells: per-read outputs (null pointers when the batch has none)
     uint32_t trivial;             // the batch has cells in `trivial` mode
     uint32_t short_records;       // the batch averages < 2 alignment words per record: lane-per-record decode
+    uint32_t* fix_list;           // [n_cells] cells whose walk-free proof failed (filled by k_verify_cells)
 };
 
 struct ResolveArgs {

@@ -57,23 +57,16 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ byte
                                                uint32_t num_genes, uint64_t* __restrict__ keys0,
                                                uint32_t* __restrict__ cell_nkeys,
                                                uint64_t* __restrict__ bc_out, DevStatus* st,
-                                               const CellChk* __restrict__ chk, PugOut pug) {
+                                               const uint32_t* __restrict__ fix_list, PugOut pug) {
     constexpr uint32_t HDR = 4 + BW + UW;
     constexpr bool AL = (BW % 4 == 0) && (UW % 4 == 0);
     const uint32_t lane = lane_id();
-    const uint32_t cell = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (cell >= n_cells) return;
+    // plain mode: wave w takes cell w.  Fix-up mode (after a walk-free decoder): the waves loop over the
+    // cells k_verify_cells listed as failing the proof (normally none) and re-decode them here.
+    const uint32_t n_work = fix_list ? st->n_fallback : n_cells;
+  for (uint32_t work = blockIdx.x * 4 + (threadIdx.x >> 6); work < n_work; work += gridDim.x * 4) {
+    const uint32_t cell = fix_list ? fix_list[work] : work;
     const CellMeta m = meta[cell];
-    if (chk) {
-        // fix-up mode after k_decode_par: cells whose candidate set verified are done;
-        // the others are re-decoded here by the sequential walk (and report real errors).
-        const CellChk c = chk[cell];
-        if (c.fail == 0 && c.count == m.nrec && c.words == m.nbytes / 4 - 2) {
-            if (lane == 0) atomicAdd(&st->n_keys, (unsigned long long)cell_nkeys[cell]);
-            return;
-        }
-        if (lane == 0) atomicAdd(&st->n_fallback, 1u);
-    }
     const uint64_t abase = m.chunk_off & ~3ull;         // dword-aligned base of the walk
     const uint32_t mis = (uint32_t)(m.chunk_off - abase);
     uint64_t pos = (uint64_t)mis + 8;                    // next record start, bytes from abase
@@ -232,6 +225,32 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ byte
         cell_nkeys[cell] = nk_total;
         atomicAdd(&st->n_keys, (unsigned long long)nk_total);
     }
+  }
+}
+
+// Walk-free proof, final step: per cell compare the accumulated candidate count and sizes
+// with the chunk header; cells that pass add their key count to the batch total (one atomic per workgroup),
+// cells that fail are listed for the sequential re-decode.
+__global__ __launch_bounds__(256) void k_verify_cells(const CellMeta* __restrict__ meta, uint32_t n_cells,
+                                                     const CellChk* __restrict__ chk,
+                                                     const uint32_t* __restrict__ cell_nkeys, DevStatus* st,
+                                                     uint32_t* __restrict__ fix_list) {
+    __shared__ unsigned long long s_sum;
+    if (threadIdx.x == 0) s_sum = 0;
+    __syncthreads();
+    const uint32_t cell = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long keys = 0;
+    if (cell < n_cells) {
+        const CellMeta m = meta[cell];
+        const CellChk c = chk[cell];
+        if (c.fail == 0 && c.count == m.nrec && c.words == m.nbytes / 4 - 2) keys = cell_nkeys[cell];
+        else fix_list[atomicAdd(&st->n_fallback, 1u)] = cell;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) keys += __shfl_xor(keys, d);
+    if (lane_id() == 0 && keys) atomicAdd(&s_sum, keys);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_sum) atomicAdd(&st->n_keys, s_sum);
 }
 
 // ---------------------------------------------------------------------------
@@ -2477,8 +2496,13 @@ void launch_gather_headers(hipStream_t s, const uint8_t* bytes, size_t n_bytes, 
 
 template <int BW, int UW>
 static void launch_decode_t(hipStream_t s, const DecodeArgs& a) {
-    AFQ_LAUNCH((k_decode<BW, UW>), (a.n_cells + 3) / 4, 256, s, a.bytes, a.n_bytes, a.meta, a.n_cells, a.t2g,
-               a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out, a.st, a.chk, a.pug);
+    uint32_t grid = (a.n_cells + 3) / 4;
+    if (a.chk) {  // fix-up mode: verify every cell's proof, then a modest persistent grid walks the (normally empty) list
+        AFQ_LAUNCH(k_verify_cells, (a.n_cells + 255) / 256, 256, s, a.meta, a.n_cells, a.chk, a.cell_nkeys, a.st, a.fix_list);
+        grid = grid < 1024 ? grid : 1024;
+    }
+    AFQ_LAUNCH((k_decode<BW, UW>), grid, 256, s, a.bytes, a.n_bytes, a.meta, a.n_cells, a.t2g,
+               a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out, a.st, a.chk ? a.fix_list : nullptr, a.pug);
 }
 
 int launch_decode(hipStream_t s, const DecodeArgs& a, uint32_t bw, uint32_t uw) {
