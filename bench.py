@@ -41,17 +41,25 @@ def main():
     ap.add_argument("--umi-err", type=float, default=0.01)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) by default; gloo + --share-gpu exercises the N>1 logic on a 1-GPU box")
+    ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.share_gpu:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.dist_backend, rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rdev = dev if args.dist_backend == "nccl" else torch.device("cpu")  # where the scalar reductions live
 
     pkg = importlib.import_module("alevin-fry_amd")
     sn = importlib.import_module("alevin-fry_amd.synth_native")
@@ -97,10 +105,10 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        r = torch.tensor([float(rad.n_reads), float(args.cells)], dtype=torch.float64, device=dev)
+        r = torch.tensor([float(rad.n_reads), float(args.cells)], dtype=torch.float64, device=rdev)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
         total_reads, total_cells = float(r[0].item()), float(r[1].item())
     else:
