@@ -276,18 +276,24 @@ int plan_ranges(afq_ctx* c) {
         need[i] = nd;
         total_need += nd;
     }
-    // pass 2: cut into ranges.  Big batches are cut into about kPipeRanges ranges of equal work even when memory
-    // would allow one, so that the D2H of one range's rows hides under the kernels of the next.
-    constexpr double kPipeRanges = 4.0;
+    // pass 2: cut into ranges.  Big batches are cut into a handful of ranges even when memory
+    // would allow one, so that the D2H of one range's rows hides under the kernels of the next.  The ranges taper:
+    // the last one's compaction + D2H is the only part nothing hides, so it is the smallest.
+    static const double kTaper[] = {0.28, 0.56, 0.78, 0.92, 1.0};
     if (pug_fixed > 0.5 * mem_budget) return fail(c, AFQ_ERR_OOM, "the largest parsimony cell's scratch does not fit device memory");
     double budget = mem_budget - pug_fixed;
-    if (c->n_bytes >= (256u << 20)) budget = std::min(budget, total_need / kPipeRanges * 1.02 + 1.0);
+    const bool pipe = c->n_bytes >= (256u << 20);
     if (const char* e = std::getenv("AFQ_RANGE_BYTES")) budget = std::min(budget, std::atof(e));  // tests: force many ranges
     c->ranges.clear();
-    double used = 0;
+    double used = 0, done = 0;
     uint32_t c0 = 0;
+    size_t step = 0;
     for (uint32_t i = 0; i < c->n_cells; ++i) {
-        if (used + need[i] > budget && i > c0) { c->ranges.push_back({c0, i}); c0 = i; used = 0; }
+        const bool taper_cut = pipe && step + 1 < sizeof(kTaper) / sizeof(kTaper[0]) && done + used >= kTaper[step] * total_need;
+        if ((used + need[i] > budget || taper_cut) && i > c0) {
+            c->ranges.push_back({c0, i}); c0 = i; done += used; used = 0;
+            while (step + 1 < sizeof(kTaper) / sizeof(kTaper[0]) && done >= kTaper[step] * total_need) ++step;
+        }
         used += need[i];
     }
     if (c->n_cells > c0) c->ranges.push_back({c0, c->n_cells});
@@ -421,11 +427,6 @@ int run_range(afq_ctx* c, Range r, int slot) {
 
     hc.lap("run: plan + ensure buffers");
     hipStream_t s = B.stream;
-    {   // this range's kernels start after the previous range's kernels (clean per-kernel timings, no cache
-        // thrash between ranges); what overlaps them is the previous range's D2H
-        RangeState& O = c->rs[slot ^ 1];
-        if (O.in_flight && O.kernels_done) HIP_TRY(c, hipStreamWaitEvent(s, O.kernels_done, 0));
-    }
     if (par) {
         HIP_TRY(c, hipMemcpyAsync(B.d_slab_prefix.p, slab_prefix.data(), 4ull * (n + 1), hipMemcpyHostToDevice, s));
         HIP_TRY(c, hipMemsetAsync(B.d_chk.p, 0, sizeof(CellChk) * n, s));
@@ -452,8 +453,15 @@ int run_range(afq_ctx* c, Range r, int slot) {
     }
     HIP_TRY(c, hipMemsetAsync(B.d_status.p, 0, sizeof(DevStatus), s));
     HIP_TRY(c, hipMemsetAsync(B.d_bc.p, 0, 8ull * n, s));
-    // the host copies above are sourced from stack/vector memory: make sure they are consumed
+    // the host copies above are sourced from stack/vector memory: make sure they are consumed.  They only touch
+    // this slot's buffers (idle since the range before last was finished), so they - and this wait - do not
+    // depend on the range still executing in the other slot; the kernels below do:
     HIP_TRY(c, hipStreamSynchronize(s));
+    {   // this range's kernels start after the previous range's kernels (clean per-kernel timings, no cache
+        // thrash between ranges); what overlaps them is the previous range's D2H and this range's enqueue
+        RangeState& O = c->rs[slot ^ 1];
+        if (O.in_flight && O.kernels_done) HIP_TRY(c, hipStreamWaitEvent(s, O.kernels_done, 0));
+    }
     hc.lap("run: uploads + memsets");
 
     DecodeArgs da{c->d_bytes, c->n_bytes, B.d_meta.as<CellMeta>(), n, c->d_t2g.as<uint32_t>(), c->ref_count,
