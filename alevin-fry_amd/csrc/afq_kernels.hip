@@ -1715,6 +1715,7 @@ __device__ __forceinline__ uint32_t col_from_pairs(uint32_t p0, uint32_t p1, uin
 // (g+1) of its smallest spliced gene is in W - which is what "the next winner in gene order is the same
 // gene" means for ascending ids 2g, 2g+1.
 constexpr uint32_t kHtOvf = 64;
+constexpr uint32_t kHtMerge = 8;   // genes of one UMI the in-register merge holds (more: the bucket takes the sort path)
 template <typename ForEach>
 __device__ __forceinline__ uint32_t col_from_candidates(ForEach&& for_each, const ResolveCfg& rc) {
     uint32_t maxc = 0;
@@ -1830,25 +1831,40 @@ __device__ __forceinline__ bool resolve_bucket_hash(const uint64_t* __restrict__
             const uint32_t p0 = (uint32_t)s_slot[slot], umi = (uint32_t)(key[h] >> kGeneBits);
             const uint32_t p1 = s_pair[slot * (kHtPairs - 1)], p2 = s_pair[slot * (kHtPairs - 1) + 1];
             if (!novf || !((s_flag[slot >> 5] >> (slot & 31)) & 1u)) col = col_from_pairs(p0, p1, p2, rc);
-            else
-                col = col_from_candidates([&](auto&& f) {
-                    f(p0 >> 12, p0 & 0xFFFu); f(p1 >> 12, p1 & 0xFFFu); f(p2 >> 12, p2 & 0xFFFu);
-                    for (uint32_t i = 0; i < novf; ++i) {
-                        const uint64_t ki = s_ovf[i];
-                        if ((uint32_t)(ki >> kGeneBits) != umi) continue;
-                        uint32_t cnt = 0;
-                        bool first = true;
-                        for (uint32_t j = 0; j < novf; ++j)
-                            if (s_ovf[j] == ki) { ++cnt; if (j < i) first = false; }
-                        if (first) f((uint32_t)ki & kGeneMask, cnt);
+            else {
+                // the UMI's three counters plus its parked keys, merged into at most kHtMerge (gene, reads) entries held
+                // in registers (predicated writes, no dynamic indexing), then one pass for the rule's aggregates
+                uint32_t cg[kHtMerge], cc[kHtMerge];
+#pragma unroll
+                for (uint32_t q = 0; q < kHtMerge; ++q) { cg[q] = kNoCol; cc[q] = 0; }
+                cg[0] = p0 >> 12; cc[0] = p0 & 0xFFFu; cg[1] = p1 >> 12; cc[1] = p1 & 0xFFFu; cg[2] = p2 >> 12; cc[2] = p2 & 0xFFFu;
+                uint32_t k = 3;
+                for (uint32_t i = 0; i < novf; ++i) {
+                    const uint64_t ki = s_ovf[i];
+                    if ((uint32_t)(ki >> kGeneBits) != umi) continue;
+                    const uint32_t g = (uint32_t)ki & kGeneMask;
+                    bool found = false;
+#pragma unroll
+                    for (uint32_t q = 3; q < kHtMerge; ++q) if (q < k && cg[q] == g) { ++cc[q]; found = true; }
+                    if (!found) {
+                        if (k == kHtMerge) { bad = true; break; }
+#pragma unroll
+                        for (uint32_t q = 3; q < kHtMerge; ++q) if (q == k) { cg[q] = g; cc[q] = 1; }
+                        ++k;
                     }
+                }
+                col = col_from_candidates([&](auto&& f) {
+#pragma unroll
+                    for (uint32_t q = 0; q < kHtMerge; ++q) if (cc[q]) f(cg[q], cc[q]);
                 }, rc);
+            }
             if (col != kNoCol && col >= rc.num_rows) { set_err(st, kErrSlotRange, cell); col = kNoCol; }
         }
         const uint64_t m = __ballot(col != kNoCol);
         if (col != kNoCol) s_cols[nc + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = col;
         nc += (uint32_t)__popcll(m);
     }
+    if (__any(bad)) return false;  // a UMI with more genes than the merge holds: nothing global was written yet
     __syncthreads();
     RT_MARK(2);
     nc_out = nc;
