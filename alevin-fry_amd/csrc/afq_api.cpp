@@ -670,6 +670,7 @@ int afq_create(const afq_config* cfg, const uint32_t* tid_to_gid, uint32_t ref_c
     if (cfg->resolution > AFQ_RES_PARSIMONY_GENE) return fail(nullptr, AFQ_ERR_INVALID_ARG, "bad resolution");
     if (!valid_width(cfg->bc_bytes) || !valid_width(cfg->umi_bytes))
         return fail(nullptr, AFQ_ERR_INVALID_ARG, "bc_bytes/umi_bytes must be 1, 2, 4 or 8");
+    if (cfg->umi_len > 4 * cfg->umi_bytes) return fail(nullptr, AFQ_ERR_INVALID_ARG, "umi_len does not fit the UMI field");
     if (cfg->num_genes == 0 || cfg->num_rows == 0 || ref_count == 0)
         return fail(nullptr, AFQ_ERR_INVALID_ARG, "num_genes, num_rows and ref_count must be non-zero");
     if (cfg->num_genes > (1u << kGeneBits))

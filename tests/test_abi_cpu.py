@@ -53,3 +53,32 @@ def test_create_rejects_bad_arguments_without_a_gpu():
     cfg = pkg.WorkerConfig.for_resolution("cr-like", num_genes=4, num_rows=4).to_c()
     rc = lib.afq_create(ctypes.byref(cfg), t2g.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), 4, 0, ctypes.byref(h))
     assert rc == pkg._abi.AFQ_ERR_INVALID_ARG and b"tid_to_gid" in lib.afq_last_error(None)
+
+
+def test_every_declared_function_of_every_header_is_exported():
+    """include/*.h (boundary, host front-end, synthetic generator): each declared function is in the library."""
+    import glob
+
+    lib = ctypes.CDLL(pkg.afquant.LIB_PATH)
+    n = 0
+    for path in sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        hdr = open(path).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        hdr = re.sub(r"//[^\n]*", "", hdr)
+        for name in set(re.findall(r"\b(afq_[a-z0-9_]+)\s*\(", hdr)):
+            assert hasattr(lib, name), f"{os.path.basename(path)}: {name} is declared but not exported"
+            n += 1
+    assert n >= 20
+
+
+def test_umi_len_hint_is_validated():
+    lib = pkg.load_library()
+    import numpy as np
+
+    t2g = np.zeros(4, np.uint32)
+    h = ctypes.c_void_p()
+    cfg = pkg.WorkerConfig.for_resolution("parsimony", num_genes=4, num_rows=4, umi_bytes=2, umi_len=9).to_c()
+    assert cfg.umi_len == 9
+    # a UMI of 9 bases does not fit a 2-byte field: refused before any device work
+    rc = lib.afq_create(ctypes.byref(cfg), t2g.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), 4, 0, ctypes.byref(h))
+    assert rc == pkg._abi.AFQ_ERR_INVALID_ARG and b"umi_len" in lib.afq_last_error(None) and not h.value
