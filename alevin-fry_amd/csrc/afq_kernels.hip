@@ -2073,13 +2073,46 @@ constexpr float kMinOutputAlpha = 0.01f, kAlphaCheckCutoff = 1e-2f, kRelDiffTol 
 constexpr uint32_t kMinIter = 2, kMaxIter = 100;
 
 
+// Per-cell EM scratch (u32 words; mirrored by em_scratch_words).  Filled by k_em (setup), consumed by k_em_rounds.
+struct EmScratch {
+    uint2* out; uint64_t* inv_pairs; uint32_t *order, *cls_first, *cls_cnt, *cls_woff, *cls_w, *cls_sidx; float* inv;
+    uint32_t *support, *sib1, *sib2, *ucnt; float *a_in, *a_out; uint32_t *slot_off, *aid; uint4 *ent, *lw3;
+    uint32_t *act_col, *memb;
+};
+__device__ __forceinline__ EmScratch em_carve(uint32_t* scratch, uint64_t off, uint32_t nU, uint32_t W, uint32_t M, uint32_t capS) {
+    EmScratch e;
+    uint32_t* p = scratch + off;
+    e.out = reinterpret_cast<uint2*>(p); p += 2 * (capS + 1);           // (column, f32 bits); 8-byte aligned by construction
+    e.inv_pairs = reinterpret_cast<uint64_t*>(p); p += 2 * (W + 1);     // (support idx << 32 | class)
+    e.order = p; p += M + 1;       // molecule indices sorted by label
+    e.cls_first = p; p += M + 1;   // class -> position in `order` of its first molecule
+    e.cls_cnt = p; p += M + 1;
+    e.cls_woff = p; p += M + 2;    // class -> offset of its EM label in cls_w
+    e.cls_w = p; p += W + 1;       // EM labels (slots)
+    e.cls_sidx = p; p += W + 1;    // ... as support indices
+    e.inv = reinterpret_cast<float*>(p); p += M + 1;
+    e.support = p; p += capS + 1;
+    e.sib1 = p; p += capS + 1;
+    e.sib2 = p; p += capS + 1;
+    e.ucnt = p; p += capS + 1;
+    e.a_in = reinterpret_cast<float*>(p); p += capS + 2;
+    e.a_out = reinterpret_cast<float*>(p); p += capS + 2;
+    e.slot_off = p; p += capS + 2;
+    e.aid = p; p += capS + 1;          // support idx -> active idx
+    p += (4 - ((p - scratch) & 3)) & 3;        // 16-byte records below (slices start 16-byte aligned)
+    e.ent = reinterpret_cast<uint4*>(p); p += 4 * (nU + W + 2);   // per active entry: count, sibling ids, first membership
+    e.lw3 = reinterpret_cast<uint4*>(p); p += 4 * (W + 1);        // per label word: its entry and the entry's siblings
+    e.act_col = p; p += nU + W + 2;
+    e.memb = p; p += W + 1;            // class ids of the memberships, entry-major
+    return e;
+}
+
 __global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta, const uint32_t* __restrict__ nnz_unique,
                                              const uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
                                              const uint32_t* __restrict__ lab, const uint32_t* __restrict__ lab_cnt,
                                              const uint64_t* __restrict__ em_off, uint32_t* __restrict__ scratch,
-                                             uint32_t* __restrict__ out_nnz, EmCfg cfg) {
+                                             uint32_t* __restrict__ out_nnz, uint4* __restrict__ em_hdr, EmCfg cfg) {
     __shared__ uint32_t s_ws[kEmNT / 64];
-    __shared__ uint32_t s_flag[2];
     __shared__ __attribute__((aligned(16))) uint32_t s_tile[8192];  // 32 KiB sort tile
     const uint32_t cell = blockIdx.x;
 #ifdef AFQ_EM_TIMING
@@ -2096,34 +2129,15 @@ __global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta,
     const uint32_t* ld = lw + m.n_ref + 1;
     const uint32_t mult = cfg.usa ? 3u : 1u;
     const uint32_t capS = (nU + W) * mult;
-    // scratch carve (u32 words)
-    uint32_t* p = scratch + em_off[cell];
-    uint2* out = reinterpret_cast<uint2*>(p); p += 2 * (capS + 1);           // (column, f32 bits); 8-byte aligned by construction
-    uint64_t* inv_pairs = reinterpret_cast<uint64_t*>(p); p += 2 * (W + 1);  // (support idx << 32 | class)
-    uint32_t* order = p; p += M + 1;       // molecule indices sorted by label
-    uint32_t* cls_first = p; p += M + 1;   // class -> position in `order` of its first molecule
-    uint32_t* cls_cnt = p; p += M + 1;
-    uint32_t* cls_woff = p; p += M + 2;    // class -> offset of its EM label in cls_w
-    uint32_t* cls_w = p; p += W + 1;       // EM labels (slots)
-    uint32_t* cls_sidx = p; p += W + 1;    // ... as support indices
-    float* inv = reinterpret_cast<float*>(p); p += M + 1;
-    uint32_t* support = p; p += capS + 1;
-    uint32_t* sib1 = p; p += capS + 1;
-    uint32_t* sib2 = p; p += capS + 1;
-    uint32_t* ucnt = p; p += capS + 1;
-    float* a_in = reinterpret_cast<float*>(p); p += capS + 2;
-    float* a_out = reinterpret_cast<float*>(p); p += capS + 2;
-    uint32_t* slot_off = p; p += capS + 2;
-    uint32_t* aid = p; p += capS + 1;          // support idx -> active idx
-    p += (4 - ((p - scratch) & 3)) & 3;        // 16-byte records below (slices start 8-byte aligned)
-    uint4* ent = reinterpret_cast<uint4*>(p); p += 4 * (nU + W + 2);   // per active entry: count, sibling ids, first membership
-    uint4* lw3 = reinterpret_cast<uint4*>(p); p += 4 * (W + 1);        // per label word: its entry and the entry's siblings
-    uint32_t* act_col = p; p += nU + W + 2;
-    uint32_t* memb = p; p += W + 1;            // class ids of the memberships, entry-major
-
+    const EmScratch sc = em_carve(scratch, em_off[cell], nU, W, M, capS);
+    uint2* out = sc.out; uint64_t* inv_pairs = sc.inv_pairs; uint32_t* order = sc.order; uint32_t* cls_first = sc.cls_first;
+    uint32_t* cls_cnt = sc.cls_cnt; uint32_t* cls_woff = sc.cls_woff; uint32_t* cls_w = sc.cls_w; uint32_t* cls_sidx = sc.cls_sidx;
+    uint32_t* support = sc.support; uint32_t* sib1 = sc.sib1; uint32_t* sib2 = sc.sib2; uint32_t* ucnt = sc.ucnt;
+    uint32_t* slot_off = sc.slot_off; uint32_t* aid = sc.aid; uint4* ent = sc.ent; uint4* lw3 = sc.lw3;
+    uint32_t* act_col = sc.act_col; uint32_t* memb = sc.memb;
     if (M == 0) {  // no multi-label class: the counts are the single-label counts (em.rs:339-341, 499-514)
         for (uint32_t i = threadIdx.x; i < nU; i += kEmNT) out[i] = make_uint2(U[i].x, __float_as_uint((float)U[i].y));
-        if (threadIdx.x == 0) out_nnz[cell] = nU;
+        if (threadIdx.x == 0) { out_nnz[cell] = nU; em_hdr[cell] = make_uint4(0u, 0u, 0u, 1u); }
         return;
     }
     auto lab_gt = [&](uint32_t a, uint32_t b) {  // lexicographic a > b on the gene-level labels
@@ -2287,125 +2301,326 @@ __global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta,
         memb[w] = (uint32_t)inv_pairs[w];
     }
     EM_MARK(4);
-    // 5. init (em.rs:370-383, 519-531).  The abundances live in LDS when the cell's active set fits the sort tile.
-    const bool in_lds = A + 2 <= 8192;
-    float* vin = in_lds ? reinterpret_cast<float*>(s_tile) : a_in;
-    float* vout = a_out;
-    __syncthreads();
-    const float uni = 1.0f / (float)cfg.num_alphas;
-    for (uint32_t a = threadIdx.x; a < A; a += kEmNT) vin[a] = cfg.init_uniform ? uni : ((float)ent[a].x + 0.5f) * 1e-3f;
-    if (threadIdx.x == 0) { vin[Z0] = cfg.init_uniform ? uni : ((float)0u + 0.5f) * 1e-3f; vin[Z1] = 0.0f; }
-    __syncthreads();
-    uint32_t it = 0;
-    bool conv = true, last_round = false;
-    while (it < kMinIter || (it < kMaxIter && !conv) || last_round) {
-        // (A) per class: denominator in label order (get_abundance_for, em.rs:167-187)
-        // four classes per thread per trip, their loads issued together: the rounds are chains of dependent
-        // L2 round trips, and a thread walking its classes one at a time has only one chain in flight
-        for (uint32_t c0 = threadIdx.x; c0 < K; c0 += 4 * kEmNT) {
-            uint32_t wb[4], we[4], cn[4];
-            uint4 l0[4], l1[4], l2[4];
+    if (threadIdx.x == 0) em_hdr[cell] = make_uint4(A, K, Wc, 0u);  // the rounds run in k_em_rounds
+}
+
+// acc + sum over q in [q0, q1), in that order, of (iv(q) >= 0 ? ab * iv(q) : 0) - by the whole wave: the loads
+// of 64 memberships go out together, the additions stay one after the other (float addition is not associative
+// and the order is the parity contract).  An entry that sits in hundreds of classes (a highly expressed gene)
+// otherwise makes its one thread walk hundreds of dependent loads per round while the wave waits.
+// All 64 lanes must call it with the same arguments; every lane returns the result.
+constexpr uint32_t kEmHeavy = 8;   // memberships above which an entry is summed by the wave
+template <typename InvAt>
+__device__ __forceinline__ float wave_ordered_sum(float acc, float ab, uint32_t q0, uint32_t q1, InvAt&& inv_at) {
+    const uint32_t lane = lane_id();
+    for (uint32_t base = q0; base < q1; base += 64) {
+        const uint32_t q = base + lane;
+        const float iv = q < q1 ? inv_at(q) : -1.0f;
+        // every lane forms its own term; a skipped term is +0.0f, which leaves a non-negative sum bit for bit
+        // unchanged, so the chain below needs no branches: 64 dependent adds fed by constant-lane reads
+        const float term = iv >= 0.0f ? ab * iv : 0.0f;
+        const uint32_t tb = __float_as_uint(term);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t c = c0 + j * kEmNT;
-                const bool ok = c < K;
-                wb[j] = ok ? cls_woff[c] : 0u;
-                we[j] = ok ? cls_woff[c + 1] : 0u;
-                cn[j] = ok ? cls_cnt[c] : 0u;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                l0[j] = lw3[wb[j] < we[j] ? wb[j] : 0u];
-                l1[j] = lw3[wb[j] + 1 < we[j] ? wb[j] + 1 : 0u];
-                l2[j] = lw3[wb[j] + 2 < we[j] ? wb[j] + 2 : 0u];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t c = c0 + j * kEmNT;
-                if (c >= K) continue;
-                float denom = 0.0f;
-                if (wb[j] < we[j]) denom += (vin[l0[j].y] + vin[l0[j].z]) + vin[l0[j].x];
-                if (wb[j] + 1 < we[j]) denom += (vin[l1[j].y] + vin[l1[j].z]) + vin[l1[j].x];
-                if (wb[j] + 2 < we[j]) denom += (vin[l2[j].y] + vin[l2[j].z]) + vin[l2[j].x];
-                for (uint32_t w = wb[j] + 3; w < we[j]; ++w) {
-                    const uint4 l = lw3[w];
-                    denom += (vin[l.y] + vin[l.z]) + vin[l.x];
-                }
-                inv[c] = denom > 0.0f ? (float)cn[j] / denom : -1.0f;
-            }
-        }
-        if (threadIdx.x == 0) s_flag[0] = 0;
-        __syncthreads();
-        // (B) per active entry: single-label count, then class contributions in class order
-        bool bad = false;
-        for (uint32_t a0 = threadIdx.x; a0 < A; a0 += 4 * kEmNT) {
-            uint4 e[4];
-            uint32_t qe[4], m0[4], m1[4];
-            float i0[4], i1[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t a = a0 + j * kEmNT;
-                e[j] = ent[a < A ? a : A];         // ent[A] is the sentinel record
-                qe[j] = ent[a < A ? a + 1 : A].w;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                m0[j] = memb[e[j].w < qe[j] ? e[j].w : 0u];
-                m1[j] = memb[e[j].w + 1 < qe[j] ? e[j].w + 1 : 0u];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { i0[j] = inv[m0[j]]; i1[j] = inv[m1[j]]; }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t a = a0 + j * kEmNT;
-                if (a >= A) continue;
-                float acc = 0.0f;
-                if (e[j].x) acc += (float)e[j].x;
-                const float old = vin[a];
-                const float ab = (vin[e[j].y] + vin[e[j].z]) + old;
-                if (e[j].w < qe[j] && i0[j] >= 0.0f) acc += ab * i0[j];
-                if (e[j].w + 1 < qe[j] && i1[j] >= 0.0f) acc += ab * i1[j];
-                for (uint32_t q = e[j].w + 2; q < qe[j]; ++q) {
-                    const float iv = inv[memb[q]];
-                    if (iv >= 0.0f) acc += ab * iv;
-                }
-                vout[a] = acc;
-                if (acc > kAlphaCheckCutoff && fabsf(old - acc) > kRelDiffTol) bad = true;
-            }
-        }
-        if (bad) s_flag[0] = 1;
-        __syncthreads();
-        conv = s_flag[0] == 0;
-        for (uint32_t a = threadIdx.x; a < A; a += kEmNT) vin[a] = vout[a];
-        if (threadIdx.x == 0) vin[Z0] = 0.0f;  // inactive entries come out of every round as 0
-        ++it;
-        __syncthreads();
-        if (cfg.usa) {
-            if (last_round) break;
-            if (it >= kMinIter && conv) {
-                for (uint32_t a = threadIdx.x; a < A; a += kEmNT) if (vin[a] < kMinOutputAlpha) vin[a] = 0.0f;
-                last_round = true;
-                __syncthreads();
-            }
-        }
+        for (int i = 0; i < 64; ++i) acc += __uint_as_float(__builtin_amdgcn_readlane(tb, i));
     }
-    EM_MARK(5);
-    // 6. floor and emit the non-zero alphas in column order (active ids ascend with the column)
+    return acc;
+}
+__device__ __forceinline__ uint32_t bcast_u32(uint32_t v, uint32_t src_lane) { return __builtin_amdgcn_readlane(v, (int)src_lane); }
+__device__ __forceinline__ float bcast_f32(float v, uint32_t src_lane) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), (int)src_lane)); }
+
+// ---------------------------------------------------------------------------
+// The EM rounds.  k_em left, per cell, the compact structures of section 4b in global scratch; the rounds
+// themselves used to stream them from L2/HBM every round (~1.5 MB of cache lines per round and cell - with a
+// thousand cells in flight that is the memory system's full throughput, for 20-100 rounds).  Here one
+// 1024-thread workgroup takes a cell and keeps everything the rounds touch ON CHIP: abundances, 1/denominators,
+// class offsets/counts, label words and memberships (16-bit ids) in LDS, the per-entry records in registers
+// (8 entries per thread).  A round is then LDS traffic and three barriers.  Cells too big for that (more than
+// 8192 active entries or classes, or > 144 KiB of LDS) run the same arithmetic out of global memory.
+// Arithmetic and its order are unchanged (bit-identical to the oracle).
+constexpr int kEmRNT = 1024;
+constexpr uint32_t kEmPer = 8;
+constexpr uint32_t kEmLdsWords = 36 * 1024;
+__global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict__ meta, const uint32_t* __restrict__ nnz_unique,
+                                                     const uint32_t* __restrict__ lab_cnt, const uint64_t* __restrict__ em_off,
+                                                     uint32_t* __restrict__ scratch, uint32_t* __restrict__ out_nnz,
+                                                     const uint4* __restrict__ em_hdr, EmCfg cfg) {
+    __shared__ uint32_t s_ws[kEmRNT / 64];
+    __shared__ uint32_t s_flag[2];
+    __shared__ __attribute__((aligned(16))) uint32_t s_mem[kEmLdsWords];
+    const uint32_t cell = blockIdx.x;
+#ifdef AFQ_EM_TIMING
+    __shared__ unsigned long long tm2[6];
+#define EM2_MARK(i) do { __syncthreads(); if (threadIdx.x == 0 && (blockIdx.x % 1000) == 7) tm2[i] = wall_clock64(); } while (0)
+#else
+#define EM2_MARK(i) do {} while (0)
+#endif
+    const uint4 hdr = em_hdr[cell];
+    if (hdr.w) return;  // no multi-label class: k_em already wrote the row
+    const uint32_t A = hdr.x, K = hdr.y, Wc = hdr.z;
+    const uint32_t nU = nnz_unique[cell], W = lab_cnt[2 * cell], M = lab_cnt[2 * cell + 1];
+    const uint32_t capS = (nU + W) * (cfg.usa ? 3u : 1u);
+    const EmScratch sc = em_carve(scratch, em_off[cell], nU, W, M, capS);
+    uint2* out = sc.out;
+    const uint4* ent = sc.ent;
+    const uint4* lw3 = sc.lw3;
+    const uint32_t* memb = sc.memb;
+    const uint32_t* cls_woff = sc.cls_woff;
+    const uint32_t* cls_cnt = sc.cls_cnt;
+    const uint32_t* act_col = sc.act_col;
+    const uint32_t Z0 = A, Z1 = A + 1;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lw_words = (3 * Wc + 1) / 2, mb_words = (Wc + 1) / 2;
+    const uint32_t need = (A + 2) + K + (K + 1) + K + lw_words + mb_words;
+    const bool fits = need <= kEmLdsWords && A <= kEmPer * kEmRNT && K <= kEmPer * kEmRNT;
     uint32_t nout = 0;
-    for (uint32_t base = 0; base < A; base += kEmNT) {
-        const uint32_t a = base + threadIdx.x;
-        float v = a < A ? vin[a] : 0.0f;
-        if (v < kMinOutputAlpha) v = 0.0f;
-        const uint32_t h = v > 0.0f;
-        uint32_t tot;
-        const uint32_t ex = block_excl_scan<kEmNT>(h, s_ws, tot);
-        if (h) out[nout + ex] = make_uint2(act_col[a], __float_as_uint(v));
-        nout += tot;
+    [[maybe_unused]] uint32_t it_dbg = 0;
+    EM2_MARK(0);
+    if (fits) {
+        float* vin = reinterpret_cast<float*>(s_mem);
+        float* inv = vin + (A + 2);
+        uint32_t* woff = reinterpret_cast<uint32_t*>(inv + K);
+        uint32_t* cnt = woff + (K + 1);
+        uint16_t* lw16 = reinterpret_cast<uint16_t*>(cnt + K);
+        uint16_t* mb16 = reinterpret_cast<uint16_t*>(cnt + K + lw_words);
+        for (uint32_t c = tid; c <= K; c += kEmRNT) woff[c] = cls_woff[c];
+        for (uint32_t c = tid; c < K; c += kEmRNT) cnt[c] = cls_cnt[c];
+        for (uint32_t w = tid; w < Wc; w += kEmRNT) {
+            const uint4 l = lw3[w];
+            lw16[3 * w] = (uint16_t)l.x; lw16[3 * w + 1] = (uint16_t)l.y; lw16[3 * w + 2] = (uint16_t)l.z;
+            mb16[w] = (uint16_t)memb[w];
+        }
+        uint32_t e_cnt[kEmPer], e_sib[kEmPer], e_q0[kEmPer], e_q1[kEmPer];
+        float acc[kEmPer];
+        const float uni = 1.0f / (float)cfg.num_alphas;
+#pragma unroll
+        for (uint32_t j = 0; j < kEmPer; ++j) {
+            const uint32_t a = tid + j * kEmRNT;
+            e_cnt[j] = 0; e_sib[j] = 0; e_q0[j] = 0; e_q1[j] = 0; acc[j] = 0.0f;
+            if (a < A) {
+                const uint4 e = ent[a];
+                e_cnt[j] = e.x; e_sib[j] = e.y | (e.z << 16); e_q0[j] = e.w; e_q1[j] = ent[a + 1].w;
+                vin[a] = cfg.init_uniform ? uni : ((float)e.x + 0.5f) * 1e-3f;
+            }
+        }
+        if (tid == 0) { vin[Z0] = cfg.init_uniform ? uni : ((float)0u + 0.5f) * 1e-3f; vin[Z1] = 0.0f; }
+        __syncthreads();
+        EM2_MARK(1);
+        uint32_t it = 0;
+        bool conv = true, last_round = false;
+        while (it < kMinIter || (it < kMaxIter && !conv) || last_round) {
+            // (A) per class: denominator in label order (get_abundance_for, em.rs:167-187)
+#pragma unroll
+            for (uint32_t j = 0; j < kEmPer; ++j) {
+                const uint32_t c = tid + j * kEmRNT;
+                if (c < K) {
+                    float denom = 0.0f;
+                    const uint32_t we = woff[c + 1];
+                    for (uint32_t w = woff[c]; w < we; ++w)
+                        denom += (vin[lw16[3 * w + 1]] + vin[lw16[3 * w + 2]]) + vin[lw16[3 * w]];
+                    inv[c] = denom > 0.0f ? (float)cnt[c] / denom : -1.0f;
+                }
+            }
+            if (tid == 0) s_flag[0] = 0;
+            __syncthreads();
+            // (B) per active entry: single-label count, then class contributions in class order
+            bool bad = false;
+#pragma unroll
+            for (uint32_t j = 0; j < kEmPer; ++j) {
+                const uint32_t a = tid + j * kEmRNT;
+                const bool valid = a < A;
+                const bool heavy = valid && e_q1[j] - e_q0[j] > kEmHeavy;
+                float x = 0.0f, old = 0.0f, ab = 0.0f;
+                if (valid) {
+                    if (e_cnt[j]) x += (float)e_cnt[j];
+                    old = vin[a];
+                    ab = (vin[e_sib[j] & 0xFFFFu] + vin[e_sib[j] >> 16]) + old;
+                    if (!heavy)
+                        for (uint32_t q = e_q0[j]; q < e_q1[j]; ++q) {
+                            const float iv = inv[mb16[q]];
+                            if (iv >= 0.0f) x += ab * iv;
+                        }
+                }
+                for (uint64_t hm = __ballot(heavy); hm; hm &= hm - 1) {
+                    const uint32_t L = (uint32_t)__builtin_ctzll(hm);
+                    const float r = wave_ordered_sum(bcast_f32(x, L), bcast_f32(ab, L), bcast_u32(e_q0[j], L), bcast_u32(e_q1[j], L),
+                                                     [&](uint32_t q) { return inv[mb16[q]]; });
+                    if (lane_id() == L) x = r;
+                }
+                if (valid) {
+                    acc[j] = x;
+                    if (x > kAlphaCheckCutoff && fabsf(old - x) > kRelDiffTol) bad = true;
+                }
+            }
+            if (bad) s_flag[0] = 1;
+            __syncthreads();  // every read of the old abundances is done
+            conv = s_flag[0] == 0;
+#pragma unroll
+            for (uint32_t j = 0; j < kEmPer; ++j) {
+                const uint32_t a = tid + j * kEmRNT;
+                if (a < A) vin[a] = acc[j];
+            }
+            if (tid == 0) vin[Z0] = 0.0f;  // inactive entries come out of every round as 0
+            ++it;
+            __syncthreads();
+            if (cfg.usa) {
+                if (last_round) break;
+                if (it >= kMinIter && conv) {
+#pragma unroll
+                    for (uint32_t j = 0; j < kEmPer; ++j) {
+                        const uint32_t a = tid + j * kEmRNT;
+                        if (a < A && vin[a] < kMinOutputAlpha) vin[a] = 0.0f;
+                    }
+                    last_round = true;
+                    __syncthreads();
+                }
+            }
+        }
+        it_dbg = it;
+        EM2_MARK(2);
+        // floor and emit the non-zero alphas in column order (active ids ascend with the column)
+        for (uint32_t base = 0; base < A; base += kEmRNT) {
+            const uint32_t a = base + tid;
+            float v = a < A ? vin[a] : 0.0f;
+            if (v < kMinOutputAlpha) v = 0.0f;
+            const uint32_t h = v > 0.0f;
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<kEmRNT>(h, s_ws, tot);
+            if (h) out[nout + ex] = make_uint2(act_col[a], __float_as_uint(v));
+            nout += tot;
+        }
+    } else {
+        // bigger cells: the two randomly accessed arrays (abundances, 1/denominators) still live in LDS when they
+        // fit; the entry / label-word / membership records are streamed, coalesced, from global memory
+        const bool mid = (A + 2) + K <= kEmLdsWords;
+        float* vin = mid ? reinterpret_cast<float*>(s_mem) : sc.a_in;
+        float* vout = sc.a_out;
+        float* inv = mid ? reinterpret_cast<float*>(s_mem) + (A + 2) : sc.inv;
+        const float uni = 1.0f / (float)cfg.num_alphas;
+        for (uint32_t a = threadIdx.x; a < A; a += kEmRNT) vin[a] = cfg.init_uniform ? uni : ((float)ent[a].x + 0.5f) * 1e-3f;
+        if (threadIdx.x == 0) { vin[Z0] = cfg.init_uniform ? uni : ((float)0u + 0.5f) * 1e-3f; vin[Z1] = 0.0f; }
+        __syncthreads();
+        uint32_t it = 0;
+        bool conv = true, last_round = false;
+        while (it < kMinIter || (it < kMaxIter && !conv) || last_round) {
+            // (A) per class: denominator in label order (get_abundance_for, em.rs:167-187)
+            // four classes per thread per trip, their loads issued together: the rounds are chains of dependent
+            // L2 round trips, and a thread walking its classes one at a time has only one chain in flight
+            for (uint32_t c0 = threadIdx.x; c0 < K; c0 += 4 * kEmRNT) {
+                uint32_t wb[4], we[4], cn[4];
+                uint4 l0[4], l1[4], l2[4];
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t c = c0 + j * kEmRNT;
+                    const bool ok = c < K;
+                    wb[j] = ok ? cls_woff[c] : 0u;
+                    we[j] = ok ? cls_woff[c + 1] : 0u;
+                    cn[j] = ok ? cls_cnt[c] : 0u;
+                }
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    l0[j] = lw3[wb[j] < we[j] ? wb[j] : 0u];
+                    l1[j] = lw3[wb[j] + 1 < we[j] ? wb[j] + 1 : 0u];
+                    l2[j] = lw3[wb[j] + 2 < we[j] ? wb[j] + 2 : 0u];
+                }
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t c = c0 + j * kEmRNT;
+                    if (c >= K) continue;
+                    float denom = 0.0f;
+                    if (wb[j] < we[j]) denom += (vin[l0[j].y] + vin[l0[j].z]) + vin[l0[j].x];
+                    if (wb[j] + 1 < we[j]) denom += (vin[l1[j].y] + vin[l1[j].z]) + vin[l1[j].x];
+                    if (wb[j] + 2 < we[j]) denom += (vin[l2[j].y] + vin[l2[j].z]) + vin[l2[j].x];
+                    for (uint32_t w = wb[j] + 3; w < we[j]; ++w) {
+                        const uint4 l = lw3[w];
+                        denom += (vin[l.y] + vin[l.z]) + vin[l.x];
+                    }
+                    inv[c] = denom > 0.0f ? (float)cn[j] / denom : -1.0f;
+                }
+            }
+            if (threadIdx.x == 0) s_flag[0] = 0;
+            __syncthreads();
+            // (B) per active entry: single-label count, then class contributions in class order
+            bool bad = false;
+            for (uint32_t a0 = threadIdx.x; a0 - lane_id() < A; a0 += 4 * kEmRNT) {  // wave-uniform trip count: the heavy-entry sums need every lane
+                uint4 e[4];
+                uint32_t qe[4], m0[4], m1[4];
+                float i0[4], i1[4];
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t a = a0 + j * kEmRNT;
+                    e[j] = ent[a < A ? a : A];         // ent[A] is the sentinel record
+                    qe[j] = ent[a < A ? a + 1 : A].w;
+                }
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    m0[j] = memb[e[j].w < qe[j] ? e[j].w : 0u];
+                    m1[j] = memb[e[j].w + 1 < qe[j] ? e[j].w + 1 : 0u];
+                }
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) { i0[j] = inv[m0[j]]; i1[j] = inv[m1[j]]; }
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t a = a0 + j * kEmRNT;
+                    const bool valid = a < A;
+                    const bool heavy = valid && qe[j] - e[j].w > 2 + kEmHeavy;
+                    float acc = 0.0f, old = 0.0f, ab = 0.0f;
+                    if (valid) {
+                        if (e[j].x) acc += (float)e[j].x;
+                        old = vin[a];
+                        ab = (vin[e[j].y] + vin[e[j].z]) + old;
+                        if (e[j].w < qe[j] && i0[j] >= 0.0f) acc += ab * i0[j];
+                        if (e[j].w + 1 < qe[j] && i1[j] >= 0.0f) acc += ab * i1[j];
+                        if (!heavy)
+                            for (uint32_t q = e[j].w + 2; q < qe[j]; ++q) {
+                                const float iv = inv[memb[q]];
+                                if (iv >= 0.0f) acc += ab * iv;
+                            }
+                    }
+                    for (uint64_t hm = __ballot(heavy); hm; hm &= hm - 1) {
+                        const uint32_t L = (uint32_t)__builtin_ctzll(hm);
+                        const float r = wave_ordered_sum(bcast_f32(acc, L), bcast_f32(ab, L), bcast_u32(e[j].w, L) + 2, bcast_u32(qe[j], L),
+                                                         [&](uint32_t q) { return inv[memb[q]]; });
+                        if (lane_id() == L) acc = r;
+                    }
+                    if (valid) {
+                        vout[a] = acc;
+                        if (acc > kAlphaCheckCutoff && fabsf(old - acc) > kRelDiffTol) bad = true;
+                    }
+                }
+            }
+            if (bad) s_flag[0] = 1;
+            __syncthreads();
+            conv = s_flag[0] == 0;
+            for (uint32_t a = threadIdx.x; a < A; a += kEmRNT) vin[a] = vout[a];
+            if (threadIdx.x == 0) vin[Z0] = 0.0f;  // inactive entries come out of every round as 0
+            ++it;
+            __syncthreads();
+            if (cfg.usa) {
+                if (last_round) break;
+                if (it >= kMinIter && conv) {
+                    for (uint32_t a = threadIdx.x; a < A; a += kEmRNT) if (vin[a] < kMinOutputAlpha) vin[a] = 0.0f;
+                    last_round = true;
+                    __syncthreads();
+                }
+            }
+        }
+        // 6. floor and emit the non-zero alphas in column order (active ids ascend with the column)
+        uint32_t nout = 0;
+        for (uint32_t base = 0; base < A; base += kEmRNT) {
+            const uint32_t a = base + threadIdx.x;
+            float v = a < A ? vin[a] : 0.0f;
+            if (v < kMinOutputAlpha) v = 0.0f;
+            const uint32_t h = v > 0.0f;
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<kEmRNT>(h, s_ws, tot);
+            if (h) out[nout + ex] = make_uint2(act_col[a], __float_as_uint(v));
+            nout += tot;
+        }
     }
     if (threadIdx.x == 0) out_nnz[cell] = nout;
-    EM_MARK(6);
+    EM2_MARK(3);
 #ifdef AFQ_EM_TIMING
-    if (threadIdx.x == 0 && (blockIdx.x % 1000) == 7) { printf("em cell nrec=%u nU=%u M=%u K=%u S=%u Wc=%u it=%u:", m.nrec, nU, M, K, S, Wc, it); for (int i = 1; i <= 6; ++i) printf(" p%d=%.3fms", i, (double)(tmark[i] - tmark[i - 1]) / 1e5); printf("\n"); }
+    if (threadIdx.x == 0 && (blockIdx.x % 1000) == 7) printf("em rounds cell nrec=%u A=%u K=%u Wc=%u need=%u fits=%d it=%u: load=%.3f rounds=%.3f out=%.3f total=%.3f ms\n", meta[cell].nrec, A, K, Wc, need, (int)fits, it_dbg, (double)(tm2[1]-tm2[0])/1e5, (double)(tm2[2]-tm2[1])/1e5, (double)(tm2[3]-tm2[2])/1e5, (double)(tm2[3]-tm2[0])/1e5);
 #endif
 }
 
@@ -2640,10 +2855,12 @@ uint64_t em_scratch_words(uint32_t nU, uint32_t W, uint32_t M, bool usa) {
 }
 
 void launch_em(hipStream_t s, const ResolveArgs& a, uint32_t n_cells, const uint64_t* em_off, uint32_t* scratch,
-               uint32_t* out_nnz, uint32_t num_alphas, uint32_t init_uniform) {
+               uint32_t* out_nnz, void* em_hdr_v, uint32_t num_alphas, uint32_t init_uniform) {
+    uint4* em_hdr = reinterpret_cast<uint4*>(em_hdr_v);
     if (!n_cells) return;
     EmCfg cfg{a.usa, num_alphas, a.num_rows / 3, 2 * (a.num_rows / 3), init_uniform};
-    AFQ_LAUNCH(k_em, n_cells, kEmNT, s, a.meta, a.nnz, a.keys0, a.keys1, a.lab, a.lab_cnt, em_off, scratch, out_nnz, cfg);
+    AFQ_LAUNCH(k_em, n_cells, kEmNT, s, a.meta, a.nnz, a.keys0, a.keys1, a.lab, a.lab_cnt, em_off, scratch, out_nnz, em_hdr, cfg);
+    AFQ_LAUNCH(k_em_rounds, n_cells, kEmRNT, s, a.meta, a.nnz, a.lab_cnt, em_off, scratch, out_nnz, em_hdr, cfg);
 }
 
 void launch_compact_em(hipStream_t s, uint32_t n_cells, const uint64_t* em_off, const uint32_t* scratch, const uint32_t* nnz,
