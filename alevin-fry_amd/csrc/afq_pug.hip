@@ -469,22 +469,83 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
             f(x, y);
         }
     };
-    // one walk per candidate: the edges found go to a pair list (and are counted per source); the CSR is filled
-    // from the list.  The list has room for NCAND + V pairs; only a cell with piles of same-UMI vertices can
-    // overflow it, and then the candidates are simply walked a second time.
+    // The UMI matches of the candidates go to a list with room for NCAND + V entries; only a cell with piles of
+    // same-UMI vertices can overflow it, and then the candidates are walked the plain way (twice: count, fill).
     const uint32_t pair_cap = NCAND + V;
     if (tid == 0) { s_ebase = atomicAdd(A.epool_cursor, 2ull * pair_cap + 2); s_flag[0] = 0; }
     __syncthreads();
     if (s_ebase + 2ull * pair_cap + 2 > A.epool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, cell); return; }
     uint64_t* pairs = reinterpret_cast<uint64_t*>(A.epool + ((s_ebase + 1) & ~1ull));
-    for (uint32_t i = tid; i < NCAND; i += kPugNT)
-        for_each_edge_of(cand[i], [&](uint32_t x, uint32_t y) {
-            atomicAdd(&deg[x], 1u);
-            const uint32_t k = atomicAdd(&s_flag[0], 1u);
-            if (k < pair_cap) pairs[k] = ((uint64_t)x << 32) | y;
-        });
+    // Two stages, each with four independent load chains per thread (a probe of the vertex table or of a
+    // label is a far random access - the time goes into waiting, not computing):
+    //  stage 1 walks the probe run of every candidate and lists the vertices that carry the probed UMI;
+    //  stage 2 applies the edge rule (read counts, then labels) to the listed matches only - about a third
+    //  of the candidates - and counts the out-degree of the survivors.
+    constexpr uint64_t kNoPair = ~0ull;
+    const uint32_t vmask = (1u << kVidBits) - 1;
+    for (uint32_t i0 = tid; i0 < NCAND; i0 += 4 * kPugNT) {
+        uint64_t cd[4], ux[4];
+        unsigned long long e[4];
+        uint32_t slot[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t i = i0 + j * kPugNT;
+            cd[j] = i < NCAND ? cand[i] : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t i = i0 + j * kPugNT;
+            slot[j] = ht_home(cd[j] >> kVidBits);
+            e[j] = i < NCAND ? htab[slot[j]] : kHtEmpty;
+            ux[j] = vv_umi[(uint32_t)cd[j] & vmask];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t x = (uint32_t)cd[j] & vmask;
+            const uint64_t pu = cd[j] >> kVidBits;
+            while (e[j] != kHtEmpty) {
+                const uint32_t y = (uint32_t)e[j] & vmask;
+                if ((e[j] >> kVidBits) == pu && y != x) {
+                    const uint32_t k = atomicAdd(&s_flag[0], 1u);
+                    if (k < pair_cap) pairs[k] = ((uint64_t)(pu == ux[j]) << 63) | ((uint64_t)x << 32) | y;
+                }
+                slot[j] = (slot[j] + 1) & ht_mask;
+                e[j] = htab[slot[j]];
+            }
+        }
+    }
     __syncthreads();
     const uint32_t n_pairs = s_flag[0];
+    if (n_pairs <= pair_cap) {
+        for (uint32_t k0 = tid; k0 < n_pairs; k0 += 4 * kPugNT) {
+            uint64_t pr[4];
+            uint32_t cx[4], cy[4], kx[4], ky[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t k = k0 + j * kPugNT;
+                pr[j] = k < n_pairs ? pairs[k] : kNoPair;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t x = pr[j] == kNoPair ? 0u : (uint32_t)(pr[j] >> 32) & vmask, y = pr[j] == kNoPair ? 0u : (uint32_t)pr[j] & vmask;
+                cx[j] = vv_cnt[x]; cy[j] = vv_cnt[y]; kx[j] = vv_cls[x]; ky[j] = vv_cls[y];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t k = k0 + j * kPugNT;
+                if (k >= n_pairs) continue;
+                const uint32_t x = (uint32_t)(pr[j] >> 32) & vmask, y = (uint32_t)pr[j] & vmask;
+                const bool same = (pr[j] >> 63) != 0;
+                bool keep = same || cy[j] < 2 * cx[j];
+                if (keep && ky[j] != kx[j]) keep = lab_overlap(vlab(x), vlab(y));
+                if (keep) atomicAdd(&deg[x], 1u);
+                pairs[k] = keep ? (((uint64_t)x << 32) | y) : kNoPair;
+            }
+        }
+    } else {
+        for (uint32_t i = tid; i < NCAND; i += kPugNT) for_each_edge_of(cand[i], [&](uint32_t x, uint32_t) { atomicAdd(&deg[x], 1u); });
+    }
+    __syncthreads();
     PUG_MARK(14);
     uint32_t E = 0;
     for (uint32_t base = 0; base < V; base += kPugNT) {
@@ -506,7 +567,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     if (n_pairs <= pair_cap) {
         for (uint32_t k = tid; k < n_pairs; k += kPugNT) {
             const uint64_t pr = pairs[k];
-            edges[atomicAdd(&c_order[(uint32_t)(pr >> 32)], 1u)] = (uint32_t)pr;
+            if (pr != ~0ull) edges[atomicAdd(&c_order[(uint32_t)(pr >> 32)], 1u)] = (uint32_t)pr;
         }
     } else {
         for (uint32_t i = tid; i < NCAND; i += kPugNT)
