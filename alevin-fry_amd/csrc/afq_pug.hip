@@ -506,7 +506,13 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
             while (e[j] != kHtEmpty) {
                 const uint32_t y = (uint32_t)e[j] & vmask;
                 if ((e[j] >> kVidBits) == pu && y != x) {
-                    const uint32_t k = atomicAdd(&s_flag[0], 1u);
+                    // one LDS atomic per wave, not per match (same-address atomics serialise across the whole CU)
+                    const uint64_t am = __ballot(true);
+                    const uint32_t leader = (uint32_t)__builtin_ctzll(am);
+                    uint32_t base = 0;
+                    if (lane == leader) base = atomicAdd(&s_flag[0], (uint32_t)__popcll(am));
+                    base = __builtin_amdgcn_readlane(base, (int)leader);
+                    const uint32_t k = base + (uint32_t)__popcll(am & ((1ull << lane) - 1));
                     if (k < pair_cap) pairs[k] = ((uint64_t)(pu == ux[j]) << 63) | ((uint64_t)x << 32) | y;
                 }
                 slot[j] = (slot[j] + 1) & ht_mask;
