@@ -2025,6 +2025,36 @@ __global__ __launch_bounds__(kHistNT) void k_cell_hist(const uint32_t* __restric
     uint2* out = reinterpret_cast<uint2*>(keys1 + m.key_off);
     const uint32_t nc = cell_ncols[cell];
     uint32_t carry = 0;
+    if (nc < 65536u) {
+        // no column can be counted 65536 times: two 16-bit bins per LDS word, 65536 bins per pass - one pass
+        // for a gene-level matrix of up to 65536 columns (half the clearing and scanning of the 32-bit version)
+        constexpr uint32_t kBins16 = 2 * kHistBins;
+        for (uint32_t lo = 0; lo < rc.num_rows; lo += kBins16) {
+            const uint32_t nbins = min(kBins16, rc.num_rows - lo), nwords = (nbins + 1) / 2;
+            for (uint32_t i = threadIdx.x; i < nwords; i += kHistNT) s_hist[i] = 0;
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < nc; i += kHistNT) {
+                const uint32_t c = cols[i] - lo;
+                if (c < nbins) atomicAdd(&s_hist[c >> 1], 1u << (16 * (c & 1u)));
+            }
+            __syncthreads();
+            for (uint32_t base = 0; base < nwords; base += kHistNT * 2) {
+                const uint32_t q = base + threadIdx.x * 2;   // two words = four bins per thread
+                uint32_t v[4];
+                const uint32_t w0 = q < nwords ? s_hist[q] : 0u, w1 = q + 1 < nwords ? s_hist[q + 1] : 0u;
+                v[0] = w0 & 0xFFFFu; v[1] = w0 >> 16; v[2] = w1 & 0xFFFFu; v[3] = w1 >> 16;
+                const uint32_t c = (v[0] != 0) + (v[1] != 0) + (v[2] != 0) + (v[3] != 0);
+                uint32_t tot;
+                uint32_t o = carry + block_excl_scan<kHistNT>(c, s_ws, tot);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (v[e]) out[o++] = make_uint2(lo + 2 * q + e, v[e]);
+                carry += tot;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) nnz[cell] = carry;
+        return;
+    }
     for (uint32_t lo = 0; lo < rc.num_rows; lo += kHistBins) {
         const uint32_t nbins = min(kHistBins, rc.num_rows - lo);
         for (uint32_t i = threadIdx.x; i < nbins; i += kHistNT) s_hist[i] = 0;
