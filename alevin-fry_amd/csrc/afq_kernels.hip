@@ -2635,7 +2635,6 @@ __global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict
             }
         }
         // 6. floor and emit the non-zero alphas in column order (active ids ascend with the column)
-        uint32_t nout = 0;
         for (uint32_t base = 0; base < A; base += kEmRNT) {
             const uint32_t a = base + threadIdx.x;
             float v = a < A ? vin[a] : 0.0f;
