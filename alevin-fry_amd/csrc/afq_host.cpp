@@ -20,7 +20,12 @@
 #include <fstream>
 #include <sstream>
 #include <string>
+#include <chrono>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -39,6 +44,13 @@ int format_f32(float v, char* buf, size_t cap) {
     if (cap < 64) return -1;
     if (std::isnan(v)) { std::memcpy(buf, "NaN", 4); return 3; }
     if (std::isinf(v)) { const char* s = v < 0 ? "-inf" : "inf"; size_t n = std::strlen(s); std::memcpy(buf, s, n + 1); return (int)n; }
+    if (v >= 0.0f && v < 16777216.0f && v == (float)(uint32_t)v && !(v == 0.0f && std::signbit(v))) {  // whole counts: the common case
+        char tmp[12]; int k = 0; uint32_t u = (uint32_t)v;
+        do { tmp[k++] = (char)('0' + u % 10); u /= 10; } while (u);
+        for (int i = 0; i < k; ++i) buf[i] = tmp[k - 1 - i];
+        buf[k] = 0;
+        return k;
+    }
     // shortest round-trip digits come from the scientific form; Rust then lays them out positionally
     char sci[48];
     auto r = std::to_chars(sci, sci + sizeof sci - 1, v, std::chars_format::scientific);
@@ -220,6 +232,41 @@ bool read_file(const std::string& p, std::vector<uint8_t>& out) {
     std::fclose(f);
     return ok;
 }
+// read-only mapping of a (large) input file: the collated RAD is handed to afq_submit straight out of the page cache
+struct MappedFile {
+    const uint8_t* p = nullptr; size_t n = 0; int fd = -1;
+    bool open(const std::string& path) {
+        fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (::fstat(fd, &st) != 0) return false;
+        n = (size_t)st.st_size;
+        if (n == 0) return true;
+        void* m = ::mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) return false;
+        ::madvise(m, n, MADV_SEQUENTIAL);
+        p = static_cast<const uint8_t*>(m);
+        return true;
+    }
+    ~MappedFile() { if (p) ::munmap(const_cast<uint8_t*>(p), n); if (fd >= 0) ::close(fd); }
+};
+struct PhaseClock {
+    bool on = std::getenv("AFQ_HOST_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[afquant] %-34s %8.3f s\n", what, std::chrono::duration<double>(n - t).count());
+        t = n;
+    }
+};
+// decimal digits of v into p, returns the end
+inline char* put_u64(char* p, unsigned long long v) {
+    char tmp[24]; int k = 0;
+    do { tmp[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (k) *p++ = tmp[--k];
+    return p;
+}
 void mkdirs(const std::string& p) {
     std::string cur;
     for (size_t i = 0; i <= p.size(); ++i) {
@@ -303,10 +350,13 @@ int afq_quantify(const afq_quant_opts* o) {
     std::string cjs(cj.begin(), cj.end());
     bool compressed = false;
     { size_t k = cjs.find("\"compressed_output\""); if (k != std::string::npos) { size_t v = cjs.find_first_not_of(" \t\r\n:", k + 19); compressed = v != std::string::npos && cjs.compare(v, 4, "true") == 0; } }
-    std::vector<uint8_t> raw, rad;
-    if (!read_file(in + (compressed ? "/map.collated.rad.sz" : "/map.collated.rad"), raw)) return hfail(AFQ_ERR_BAD_INPUT, "could not read the collated RAD file");
-    if (compressed) { std::string err; if (!snappy_frame_decode(raw.data(), raw.size(), rad, err)) return hfail(AFQ_ERR_BAD_INPUT, "map.collated.rad.sz: " + err); raw.clear(); raw.shrink_to_fit(); }
-    else rad.swap(raw);
+    PhaseClock pc;
+    MappedFile mf;
+    std::vector<uint8_t> rad_owned;
+    if (!mf.open(in + (compressed ? "/map.collated.rad.sz" : "/map.collated.rad"))) return hfail(AFQ_ERR_BAD_INPUT, "could not read the collated RAD file");
+    if (compressed) { std::string err; if (!snappy_frame_decode(mf.p, mf.n, rad_owned, err)) return hfail(AFQ_ERR_BAD_INPUT, "map.collated.rad.sz: " + err); }
+    struct { const uint8_t* p; size_t n; const uint8_t* data() const { return p; } size_t size() const { return n; } } rad{compressed ? rad_owned.data() : mf.p, compressed ? rad_owned.size() : mf.n};
+    pc.lap(compressed ? "map + snappy decode" : "map the RAD file");
     RadPrelude P;
     int rc = parse_prelude(rad.data(), rad.size(), P, true);
     if (rc) return rc;
@@ -390,7 +440,13 @@ int afq_quantify(const afq_quant_opts* o) {
     for (size_t c0 = 0; c0 < chunk_off.size();) {
         size_t c1 = c0; uint64_t bytes = 0;
         while (c1 < chunk_off.size()) { uint32_t nb; std::memcpy(&nb, rad.data() + chunk_off[c1], 4); if (c1 > c0 && bytes + nb > batch_bytes) break; bytes += nb; ++c1; }
-        rc = afq_submit(ctx, rad.data(), rad.size(), chunk_off.data() + c0, (uint32_t)(c1 - c0), c0);
+        // hand over just this batch's byte span (offsets relative to it), not the whole file
+        const uint64_t span0 = chunk_off[c0];
+        std::vector<uint64_t> rel(c1 - c0);
+        for (size_t k = c0; k < c1; ++k) rel[k - c0] = chunk_off[k] - span0;
+        uint32_t last_nb; std::memcpy(&last_nb, rad.data() + chunk_off[c1 - 1], 4);
+        const uint64_t span1 = chunk_off[c1 - 1] + last_nb;   // with --quant-subset the span also covers chunks that were filtered out
+        rc = afq_submit(ctx, rad.data() + span0, (size_t)(span1 - span0), rel.data(), (uint32_t)(c1 - c0), c0);
         afq_result res{};
         if (!rc) rc = afq_collect(ctx, &res);
         if (rc) { std::string m = afq_last_error(ctx); afq_destroy(ctx); std::fclose(rows_f); std::fclose(feat_f); return hfail(rc, m); }
@@ -424,13 +480,39 @@ int afq_quantify(const afq_quant_opts* o) {
     }
     afq_destroy(ctx);
     std::fclose(rows_f); std::fclose(feat_f);
+    pc.lap("device batches + per-cell rows");
     // MatrixMarket as sprs::io::write_matrix_market writes a TriMatI<f32,u32> (coordinate real general, 1-based)
     {
         FILE* m = std::fopen((outd + "/alevin/quants_mat.mtx").c_str(), "w");
         if (!m) return hfail(AFQ_ERR_BAD_INPUT, "could not create quants_mat.mtx");
         std::fprintf(m, "%%%%MatrixMarket matrix coordinate real general\n%% written by sprs\n%llu %u %zu\n", (unsigned long long)row_index, cfg.num_rows, tri_v.size());
-        for (size_t k = 0; k < tri_v.size(); ++k) std::fprintf(m, "%llu %llu %s\n", (unsigned long long)(tri_rc[k] >> 32) + 1, (unsigned long long)(tri_rc[k] & 0xFFFFFFFFu) + 1, f32s(tri_v[k]).c_str());
+        // the entries are formatted by -t threads into per-slice buffers (same text as one fprintf per entry), written in order
+        const size_t nz = tri_v.size();
+        const unsigned nth = std::max(1u, std::min(o->num_threads ? o->num_threads : 1u, 64u));
+        const size_t slice = 1u << 20;
+        for (size_t base = 0; base < nz; base += slice * nth) {
+            std::vector<std::string> bufs(nth);
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nth; ++t) {
+                const size_t a = base + t * slice, b = std::min(nz, a + slice);
+                if (a >= nz) break;
+                th.emplace_back([&, t, a, b]() {
+                    std::string& out = bufs[t];
+                    out.resize((b - a) * 112);  // 2 x <= 20 digits + an f32 in positional notation (<= 48 chars) + separators
+                    char* p = &out[0];
+                    for (size_t k = a; k < b; ++k) {
+                        p = put_u64(p, (unsigned long long)(tri_rc[k] >> 32) + 1); *p++ = ' ';
+                        p = put_u64(p, (unsigned long long)(tri_rc[k] & 0xFFFFFFFFu) + 1); *p++ = ' ';
+                        p += format_f32(tri_v[k], p, 64); *p++ = '\n';
+                    }
+                    out.resize((size_t)(p - &out[0]));
+                });
+            }
+            for (auto& x : th) x.join();
+            for (auto& bsl : bufs) if (!bsl.empty()) std::fwrite(bsl.data(), 1, bsl.size(), m);
+        }
         std::fclose(m);
+        pc.lap("quants_mat.mtx");
     }
     // quant.json (src/quant.rs:1913-1933)
     {
