@@ -282,7 +282,7 @@ int plan_ranges(afq_ctx* c) {
     static const double kTaper[] = {0.28, 0.56, 0.78, 0.92, 1.0};
     if (pug_fixed > 0.5 * mem_budget) return fail(c, AFQ_ERR_OOM, "the largest parsimony cell's scratch does not fit device memory");
     double budget = mem_budget - pug_fixed;
-    const bool pipe = c->n_bytes >= (256u << 20);
+    const bool pipe = c->n_bytes >= (256u << 20) && !std::getenv("AFQ_NO_PIPELINE");  // (profiling: one range, no overlap between kernels)
     if (const char* e = std::getenv("AFQ_RANGE_BYTES")) budget = std::min(budget, std::atof(e));  // tests: force many ranges
     c->ranges.clear();
     double used = 0, done = 0;
@@ -334,16 +334,6 @@ int run_range(afq_ctx* c, Range r, int slot) {
         m.n_ref = (uint32_t)((m.nbytes - 8ull - (uint64_t)m.nrec * H) / 4);
         m.key_off = key_off;
         key_off += (uint64_t)m.n_ref + 1;
-        uint32_t lg = 0;
-        while (((uint64_t)kBucketTarget << lg) < m.n_ref && lg < kMaxLgNb) ++lg;
-        m.lg_nb = lg;
-        m.bucket_base = (uint32_t)n_buckets;
-        n_buckets += 1ull << lg;
-        if (lg) {
-            multi.push_back(i);
-            tile_prefix.push_back((uint32_t)n_tiles);
-            n_tiles += (m.n_ref + kScatterTileHost - 1) / kScatterTileHost;
-        }
         // strategy dispatch of src/quant.rs:794-938: tiny cells take the cr-like fast path whatever -r says
         const bool tiny = g.sa_model == AFQ_SA_WINNER_TAKE_ALL && m.nrec < g.small_thresh;
         m.mode = tiny ? kModeCrLike
@@ -353,6 +343,17 @@ int run_range(afq_ctx* c, Range r, int slot) {
                  : g.resolution == AFQ_RES_PARSIMONY_EM ? kModePugEm
                  : g.resolution == AFQ_RES_PARSIMONY_GENE ? kModePugGene
                  : g.resolution == AFQ_RES_PARSIMONY_GENE_EM ? kModePugGeneEm : kModeCrLike;
+        // parsimony cells emit reads, not keys: they take no part in the bucket pipeline (one empty bucket, no tiles)
+        uint32_t lg = 0;
+        if (!mode_is_pug(m.mode)) while (((uint64_t)kBucketTarget << lg) < m.n_ref && lg < kMaxLgNb) ++lg;
+        m.lg_nb = lg;
+        m.bucket_base = (uint32_t)n_buckets;
+        n_buckets += 1ull << lg;
+        if (lg) {
+            multi.push_back(i);
+            tile_prefix.push_back((uint32_t)n_tiles);
+            n_tiles += (m.n_ref + kScatterTileHost - 1) / kScatterTileHost;
+        }
         if (mode_is_pug(m.mode)) {
             pug_cells.push_back(i); rd_off[i] = n_pug_reads; n_pug_reads += m.nrec;
             pug_words = std::max<uint64_t>(pug_words, pug_scratch_words(m.nrec, m.n_ref, mode_pug_gene(m.mode)));
@@ -379,7 +380,7 @@ int run_range(afq_ctx* c, Range r, int slot) {
 
     HIP_TRY(c, B.d_meta.ensure(sizeof(CellMeta) * n));
     HIP_TRY(c, B.d_keys0.ensure(8 * key_off));
-    HIP_TRY(c, B.d_keys1.ensure(n_multi ? 8 * key_off : 8));
+    HIP_TRY(c, B.d_keys1.ensure((n_multi || !pug_cells.empty()) ? 8 * key_off : 8));  // pair staging of multi-bucket and parsimony cells
     HIP_TRY(c, B.d_cell_nkeys.ensure(4ull * n));
     HIP_TRY(c, B.d_bucket_cnt.ensure(4 * n_buckets));
     HIP_TRY(c, B.d_bucket_cell.ensure(4 * n_buckets));
