@@ -2232,38 +2232,81 @@ __global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta,
     for (uint32_t c = threadIdx.x; c < K; c += kEmNT) em_label(c, cls_w + cls_woff[c]);
     __syncthreads();
     EM_MARK(2);
-    // 3. support = single-label columns + label slots (+ USA sibling statuses), sorted, distinct
-    uint32_t nC = 0;
-    {
-        const uint32_t nsrc = nU + Wc;
-        for (uint32_t i = threadIdx.x; i < nsrc; i += kEmNT) {
+    // 3. support = single-label columns + label slots (+ USA sibling statuses), sorted, distinct.
+    // When one bit per output column fits the LDS tile next to its rank table (num_alphas <= 131072: every gene-level
+    // matrix in practice), the support is a bitmap: mark, prefix-popcount, and "index of column x in the support" is
+    // two LDS reads instead of a sort of 3(nU + W) values and a binary search per lookup.
+    const uint32_t nwb = (cfg.num_alphas + 31) >> 5;
+    const bool bm = 2 * nwb <= 8192;
+    uint32_t* bm_bits = s_tile;
+    uint32_t* bm_rank = s_tile + nwb;
+    uint32_t S = 0;
+    if (bm) {
+        for (uint32_t i = threadIdx.x; i < nwb; i += kEmNT) bm_bits[i] = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nU + Wc; i += kEmNT) {
             const uint32_t x = i < nU ? U[i].x : cls_w[i - nU];
-            support[i * mult] = x;
+            atomicOr(&bm_bits[x >> 5], 1u << (x & 31));
             if (cfg.usa) {
                 uint32_t s1, s2;
                 if (x >= cfg.ao) { s1 = x - cfg.uo; s2 = x - cfg.ao; }
                 else if (x >= cfg.uo) { s1 = x + cfg.uo; s2 = x - cfg.uo; }
                 else { s1 = x + cfg.ao; s2 = x + cfg.uo; }
-                support[i * mult + 1] = s1;
-                support[i * mult + 2] = s2;
+                atomicOr(&bm_bits[s1 >> 5], 1u << (s1 & 31));
+                atomicOr(&bm_bits[s2 >> 5], 1u << (s2 & 31));
             }
         }
-        nC = nsrc * mult;
-    }
-    __syncthreads();
-    tiled_bitonic_sort_by<kEmNT, 8192>(support, nC, [](uint32_t a, uint32_t b) { return a > b; }, s_tile);
-    uint32_t S = 0;
-    for (uint32_t base = 0; base < nC; base += kEmNT) {  // in-place unique: position S+ex <= i, so reads stay ahead of writes
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t v = i < nC ? support[i] : 0u;
-        const uint32_t h = (i < nC) && (i == 0 || v != support[i - 1]);
-        uint32_t tot;
-        const uint32_t ex = block_excl_scan<kEmNT>(h, s_ws, tot);
         __syncthreads();
-        if (h) support[S + ex] = v;
-        S += tot;
+        for (uint32_t base = 0; base < nwb; base += kEmNT) {
+            const uint32_t w = base + threadIdx.x;
+            const uint32_t c = w < nwb ? (uint32_t)__popc(bm_bits[w]) : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<kEmNT>(c, s_ws, tot);
+            if (w < nwb) bm_rank[w] = S + ex;
+            S += tot;
+        }
         __syncthreads();
+        for (uint32_t w = threadIdx.x; w < nwb; w += kEmNT) {
+            uint32_t b = bm_bits[w], o = bm_rank[w];
+            for (; b; b &= b - 1) support[o++] = (w << 5) + (uint32_t)__builtin_ctz(b);
+        }
+        __syncthreads();
+    } else {
+        uint32_t nC = 0;
+        {
+            const uint32_t nsrc = nU + Wc;
+            for (uint32_t i = threadIdx.x; i < nsrc; i += kEmNT) {
+                const uint32_t x = i < nU ? U[i].x : cls_w[i - nU];
+                support[i * mult] = x;
+                if (cfg.usa) {
+                    uint32_t s1, s2;
+                    if (x >= cfg.ao) { s1 = x - cfg.uo; s2 = x - cfg.ao; }
+                    else if (x >= cfg.uo) { s1 = x + cfg.uo; s2 = x - cfg.uo; }
+                    else { s1 = x + cfg.ao; s2 = x + cfg.uo; }
+                    support[i * mult + 1] = s1;
+                    support[i * mult + 2] = s2;
+                }
+            }
+            nC = nsrc * mult;
+        }
+        __syncthreads();
+        tiled_bitonic_sort_by<kEmNT, 8192>(support, nC, [](uint32_t a, uint32_t b) { return a > b; }, s_tile);
+        for (uint32_t base = 0; base < nC; base += kEmNT) {  // in-place unique: position S+ex <= i, so reads stay ahead of writes
+            const uint32_t i = base + threadIdx.x;
+            const uint32_t v = i < nC ? support[i] : 0u;
+            const uint32_t h = (i < nC) && (i == 0 || v != support[i - 1]);
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<kEmNT>(h, s_ws, tot);
+            __syncthreads();
+            if (h) support[S + ex] = v;
+            S += tot;
+            __syncthreads();
+        }
     }
+    auto sup_index = [&](uint32_t x) -> uint32_t {  // position of column x in the support (x is in it)
+        if (bm) return bm_rank[x >> 5] + (uint32_t)__popc(bm_bits[x >> 5] & ((1u << (x & 31)) - 1u));
+        return lower_bound_u32(support, S, x);
+    };
     // NOTE on the USA support: the reference marks, for a label x, x and its siblings so that reads of
     // get_abundance_for are reset every round (em.rs:351-356).  Marking both siblings for every status is a
     // superset of em.rs:101-109 (which marks exactly the statuses get_abundance_for reads); the extra entries
@@ -2273,16 +2316,16 @@ __global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta,
         sib1[s] = 0xFFFFFFFFu; sib2[s] = 0xFFFFFFFFu;
         if (cfg.usa) {
             const uint32_t x = support[s];
-            if (x >= cfg.ao) { sib1[s] = lower_bound_u32(support, S, x - cfg.uo); sib2[s] = lower_bound_u32(support, S, x - cfg.ao); }
-            else if (x >= cfg.uo) sib1[s] = lower_bound_u32(support, S, x + cfg.uo);
-            else sib1[s] = lower_bound_u32(support, S, x + cfg.ao);
+            if (x >= cfg.ao) { sib1[s] = sup_index(x - cfg.uo); sib2[s] = sup_index(x - cfg.ao); }
+            else if (x >= cfg.uo) sib1[s] = sup_index(x + cfg.uo);
+            else sib1[s] = sup_index(x + cfg.ao);
         }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nU; i += kEmNT) ucnt[lower_bound_u32(support, S, U[i].x)] = U[i].y;
+    for (uint32_t i = threadIdx.x; i < nU; i += kEmNT) ucnt[sup_index(U[i].x)] = U[i].y;
     for (uint32_t c = threadIdx.x; c < K; c += kEmNT)
         for (uint32_t w = cls_woff[c]; w < cls_woff[c + 1]; ++w) {
-            const uint32_t s = lower_bound_u32(support, S, cls_w[w]);
+            const uint32_t s = sup_index(cls_w[w]);
             cls_sidx[w] = s;
             inv_pairs[w] = ((uint64_t)s << 32) | c;
         }
