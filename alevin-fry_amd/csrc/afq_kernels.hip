@@ -2182,13 +2182,36 @@ __global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta,
     auto lab_ne = [&](uint32_t a, uint32_t b) { return lab_gt(a, b) || lab_gt(b, a); };
     EM_MARK(0);
     // 1. classes = runs of equal labels in lexicographic order
-    for (uint32_t i = threadIdx.x; i < M; i += kEmNT) order[i] = i;
+    // The sort runs on 16-byte records out of LDS: a 63-bit key holding the label's first three genes (+1, a missing
+    // gene is 0, so key order IS the lexicographic order with shorter labels first) and the molecule index; only labels
+    // that tie on three genes and are longer than that fall back to the pointer-chasing comparison.
+    struct LabKey { uint64_t key; uint32_t idx, len; };
+    LabKey* lk = reinterpret_cast<LabKey*>(inv_pairs);  // 4 words per molecule; inv_pairs holds 2(W+1) >= 4M+2 words (every label has >= 2 genes)
+    for (uint32_t i = threadIdx.x; i < M; i += kEmNT) {
+        const uint32_t o = ld[2 * i], n = ld[2 * i + 1];
+        uint64_t key = (uint64_t)(lw[o] + 1u) << 42;
+        if (n > 1) key |= (uint64_t)(lw[o + 1] + 1u) << 21;
+        if (n > 2) key |= (uint64_t)(lw[o + 2] + 1u);
+        lk[i] = LabKey{key, i, n};
+    }
     __syncthreads();
-    tiled_bitonic_sort_by<kEmNT, 8192>(order, M, lab_gt, s_tile);
+    auto lk_gt = [&](const LabKey& a, const LabKey& b) {
+        if (a.key != b.key) return a.key > b.key;
+        if (a.len <= 3 && b.len <= 3) return false;  // same three-or-fewer genes: the same label
+        return lab_gt(a.idx, b.idx);
+    };
+    tiled_bitonic_sort_by<kEmNT, 2048>(lk, M, lk_gt, reinterpret_cast<LabKey*>(s_tile));
+    for (uint32_t i = threadIdx.x; i < M; i += kEmNT) order[i] = lk[i].idx;
+    __syncthreads();
     uint32_t K = 0;
     for (uint32_t base = 0; base < M; base += kEmNT) {
         const uint32_t i = base + threadIdx.x;
-        const uint32_t h = (i < M) && (i == 0 || lab_ne(order[i], order[i - 1]));
+        bool head = i < M;
+        if (head && i > 0) {
+            const LabKey a = lk[i], b = lk[i - 1];
+            head = a.key != b.key || ((a.len > 3 || b.len > 3) && lab_ne(a.idx, b.idx));
+        }
+        const uint32_t h = head;
         uint32_t tot;
         const uint32_t ex = block_excl_scan<kEmNT>(h, s_ws, tot);
         if (h) cls_first[K + ex] = i;
@@ -2333,11 +2356,23 @@ __global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta,
     EM_MARK(3);
     // 4. inverted index: for every support entry the classes containing it, ascending class
     tiled_bitonic_sort_by<kEmNT, 4096>(inv_pairs, Wc, [](uint64_t a, uint64_t b) { return a > b; }, reinterpret_cast<uint64_t*>(s_tile));
-    for (uint32_t s = threadIdx.x; s <= S; s += kEmNT) {  // slot_off[s] = first pair with support idx >= s
-        uint32_t lo = 0, hi = Wc;
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)(inv_pairs[mid] >> 32) < s) lo = mid + 1; else hi = mid; }
-        slot_off[s] = lo;
+    // slot_off[s] = first pair with support idx >= s: count the memberships per entry, exclusive scan
+    for (uint32_t s = threadIdx.x; s <= S; s += kEmNT) slot_off[s] = 0;
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < Wc; q += kEmNT) atomicAdd(&slot_off[(uint32_t)(inv_pairs[q] >> 32)], 1u);
+    __syncthreads();
+    {
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base <= S; base += kEmNT) {
+            const uint32_t s = base + threadIdx.x;
+            const uint32_t c = s <= S ? slot_off[s] : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<kEmNT>(c, s_ws, tot);
+            if (s <= S) slot_off[s] = carry + ex;
+            carry += tot;
+        }
     }
+    __syncthreads();
     EM_MARK(4);
     // 4b. The rounds only ever change entries that have a single-label count or sit in some class label
     // ("active"); every other support entry (the USA sibling statuses marked for em.rs:351-356) is produced
@@ -2375,6 +2410,10 @@ __global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta,
     }
     EM_MARK(4);
     if (threadIdx.x == 0) em_hdr[cell] = make_uint4(A, K, Wc, 0u);  // the rounds run in k_em_rounds
+#ifdef AFQ_EM_TIMING
+    EM_MARK(5);
+    if (threadIdx.x == 0 && (blockIdx.x % 1000) == 7) { printf("em setup nrec=%u nU=%u M=%u K=%u S=%u Wc=%u A=%u:", m.nrec, nU, M, K, S, Wc, A); for (int i = 1; i <= 5; ++i) printf(" p%d=%.3fms", i, (double)(tmark[i] - tmark[i - 1]) / 1e5); printf("\n"); }
+#endif
 }
 
 // acc + sum over q in [q0, q1), in that order, of (iv(q) >= 0 ? ab * iv(q) : 0) - by the whole wave: the loads
