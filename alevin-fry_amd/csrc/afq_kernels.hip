@@ -1615,6 +1615,25 @@ __device__ __forceinline__ void bucket_tail(const BucketDesc& d, uint64_t* __res
     }
 }
 
+// hand the bucket's staged ambiguous molecules (s_misc[2] label words, s_misc[3] molecules) to the cell's label area
+template <int NT>
+__device__ __forceinline__ void flush_bucket_labels(const BucketDesc& d, const LabArea& la, const uint32_t* s_lab,
+                                                    const uint32_t* s_ldesc, uint32_t* s_misc) {
+    const uint32_t lw = s_misc[2], ln = s_misc[3];
+    if (threadIdx.x == 0) {
+        s_misc[4] = atomicAdd(&la.lab_cnt[2 * d.cell], lw);
+        s_misc[5] = atomicAdd(&la.lab_cnt[2 * d.cell + 1], ln);
+    }
+    __syncthreads();
+    uint32_t* gw = la.lab + 2 * d.out_off;
+    uint32_t* gd = gw + d.n_ref + 1;
+    for (uint32_t i = threadIdx.x; i < lw; i += NT) gw[s_misc[4] + i] = s_lab[i];
+    for (uint32_t i = threadIdx.x; i < ln; i += NT) {
+        gd[2 * (s_misc[5] + i)] = s_ldesc[2 * i] + s_misc[4];
+        gd[2 * (s_misc[5] + i) + 1] = s_ldesc[2 * i + 1];
+    }
+}
+
 // Sort + resolve one bucket held in LDS.  NT threads, up to NT*8 keys.
 template <int NT>
 __device__ __forceinline__ void resolve_bucket_lds(const BucketDesc& d, uint64_t* __restrict__ keys0,
@@ -1646,21 +1665,7 @@ __device__ __forceinline__ void resolve_bucket_lds(const BucketDesc& d, uint64_t
     });
     __syncthreads();
     const uint32_t nc = s_misc[0];
-    if (s_lab && s_misc[3]) {  // hand the bucket's ambiguous molecules to the cell's label area
-        const uint32_t lw = s_misc[2], ln = s_misc[3];
-        if (threadIdx.x == 0) {
-            s_misc[4] = atomicAdd(&la.lab_cnt[2 * d.cell], lw);
-            s_misc[5] = atomicAdd(&la.lab_cnt[2 * d.cell + 1], ln);
-        }
-        __syncthreads();
-        uint32_t* gw = la.lab + 2 * d.out_off;
-        uint32_t* gd = gw + d.n_ref + 1;
-        for (uint32_t i = threadIdx.x; i < lw; i += NT) gw[s_misc[4] + i] = s_lab[i];
-        for (uint32_t i = threadIdx.x; i < ln; i += NT) {
-            gd[2 * (s_misc[5] + i)] = s_ldesc[2 * i] + s_misc[4];
-            gd[2 * (s_misc[5] + i) + 1] = s_ldesc[2 * i + 1];
-        }
-    }
+    if (s_lab && s_misc[3]) flush_bucket_labels<NT>(d, la, s_lab, s_ldesc, s_misc);
     bucket_tail<NT>(d, keys0, cell_ncols, nnz, s_cols, nc, reinterpret_cast<uint32_t*>(s_keys), s_run, s_ws, s_misc);
 }
 
@@ -1741,6 +1746,41 @@ __device__ __forceinline__ uint32_t col_from_candidates(ForEach&& for_each, cons
     return followed ? rc.ao + (first_sp >> 1) : (first_sp >> 1);
 }
 
+// cr-like-em: a UMI whose winners are one output column is counted as that column; any other winner set becomes a
+// gene-level equivalence class (quant.rs:882-924) = the winners in ascending gene order, staged in LDS.
+struct EmStage {
+    uint32_t* lab;     // label words
+    uint32_t* ldesc;   // (offset, length) per staged molecule
+    uint32_t* cnt;     // [0] words used, [1] molecules
+};
+__device__ __forceinline__ uint32_t em_single_column(uint32_t nb, uint32_t g1, uint32_t g2, const ResolveCfg& rc) {
+    if (nb == 1) return !rc.usa ? g1 : (is_spliced(g1) ? (g1 >> 1) : rc.uo + (g1 >> 1));
+    if (rc.usa && nb == 2 && same_gene(g1, g2)) return rc.ao + (g1 >> 1);
+    return kNoCol;
+}
+__device__ __forceinline__ uint32_t* em_stage_label(const EmStage& es, uint32_t nb) {
+    const uint32_t off = atomicAdd(&es.cnt[0], nb), di = atomicAdd(&es.cnt[1], 1u);
+    es.ldesc[2 * di] = off; es.ldesc[2 * di + 1] = nb;
+    return es.lab + off;
+}
+// winners of the three in-slot counters -> column, or a staged label (returns kNoCol then)
+__device__ __forceinline__ uint32_t em_from_pairs(uint32_t p0, uint32_t p1, uint32_t p2, const ResolveCfg& rc, const EmStage& es) {
+    const uint32_t c0 = p0 & 0xFFFu, c1 = p1 & 0xFFFu, c2 = p2 & 0xFFFu;
+    const uint32_t maxc = max(c0, max(c1, c2));
+    uint32_t a = c0 == maxc ? p0 >> 12 : kNoCol, b = c1 == maxc ? p1 >> 12 : kNoCol, c = c2 == maxc ? p2 >> 12 : kNoCol;
+    uint32_t t;
+    if (a > b) { t = a; a = b; b = t; }
+    if (b > c) { t = b; b = c; c = t; }
+    if (a > b) { t = a; a = b; b = t; }
+    const uint32_t nb = (a != kNoCol) + (b != kNoCol) + (c != kNoCol);
+    const uint32_t col = em_single_column(nb, a, b, rc);
+    if (col != kNoCol) return col;
+    uint32_t* dst = em_stage_label(es, nb);
+    dst[0] = a; dst[1] = b;
+    if (nb > 2) dst[2] = c;
+    return kNoCol;
+}
+
 // One wave, n <= kHtKeys.  Slot = one 64-bit word (umi:32 | gene:20 | reads:12) holding the UMI and its first
 // gene's counter - a UMI seen with one gene, the common case, costs one CAS plus one add per further read - and
 // kHtPairs-1 more (gene | reads) counters.  The lane whose CAS claims a slot owns that UMI and resolves it.
@@ -1748,7 +1788,7 @@ __device__ __forceinline__ uint32_t col_from_candidates(ForEach&& for_each, cons
 __device__ __forceinline__ bool resolve_bucket_hash(const uint64_t* __restrict__ src, uint32_t n, const ResolveCfg& rc,
                                                     unsigned long long* s_slot, uint32_t* s_pair, uint64_t* s_ovf,
                                                     uint32_t* s_flag, uint32_t* s_novf, uint32_t* s_cols, DevStatus* st,
-                                                    uint32_t cell, uint32_t& nc_out) {
+                                                    uint32_t cell, uint32_t& nc_out, bool em, const EmStage& es) {
     constexpr uint32_t E = kHtKeys / 64;
     constexpr unsigned long long kEmpty64 = ~0ull;
     const uint32_t lane = threadIdx.x;
@@ -1830,7 +1870,7 @@ __device__ __forceinline__ bool resolve_bucket_hash(const uint64_t* __restrict__
         if (slot != kNoCol) {
             const uint32_t p0 = (uint32_t)s_slot[slot], umi = (uint32_t)(key[h] >> kGeneBits);
             const uint32_t p1 = s_pair[slot * (kHtPairs - 1)], p2 = s_pair[slot * (kHtPairs - 1) + 1];
-            if (!novf || !((s_flag[slot >> 5] >> (slot & 31)) & 1u)) col = col_from_pairs(p0, p1, p2, rc);
+            if (!novf || !((s_flag[slot >> 5] >> (slot & 31)) & 1u)) col = em ? em_from_pairs(p0, p1, p2, rc, es) : col_from_pairs(p0, p1, p2, rc);
             else {
                 // the UMI's three counters plus its parked keys, merged into at most kHtMerge (gene, reads) entries held
                 // in registers (predicated writes, no dynamic indexing), then one pass for the rule's aggregates
@@ -1853,10 +1893,32 @@ __device__ __forceinline__ bool resolve_bucket_hash(const uint64_t* __restrict__
                         ++k;
                     }
                 }
-                col = col_from_candidates([&](auto&& f) {
+                if (!em) {
+                    col = col_from_candidates([&](auto&& f) {
 #pragma unroll
-                    for (uint32_t q = 0; q < kHtMerge; ++q) if (cc[q]) f(cg[q], cc[q]);
-                }, rc);
+                        for (uint32_t q = 0; q < kHtMerge; ++q) if (cc[q]) f(cg[q], cc[q]);
+                    }, rc);
+                } else if (!bad) {
+                    uint32_t maxc = 0, nb = 0, g1 = kNoCol, g2 = kNoCol;
+#pragma unroll
+                    for (uint32_t q = 0; q < kHtMerge; ++q) maxc = cc[q] > maxc ? cc[q] : maxc;
+#pragma unroll
+                    for (uint32_t q = 0; q < kHtMerge; ++q)
+                        if (cc[q] == maxc) { ++nb; if (cg[q] < g1) { g2 = g1; g1 = cg[q]; } else if (cg[q] < g2) g2 = cg[q]; }
+                    col = em_single_column(nb, g1, g2, rc);
+                    if (col == kNoCol) {  // the winners in ascending gene order: repeated minimum over <= kHtMerge entries
+                        uint32_t* dst = em_stage_label(es, nb);
+                        uint32_t last = 0;
+                        for (uint32_t w = 0; w < nb; ++w) {
+                            uint32_t best = kNoCol;
+#pragma unroll
+                            for (uint32_t q = 0; q < kHtMerge; ++q)
+                                if (cc[q] == maxc && cg[q] < best && (w == 0 || cg[q] > last)) best = cg[q];
+                            dst[w] = best;
+                            last = best;
+                        }
+                    }
+                }
             }
             if (col != kNoCol && col >= rc.num_rows) { set_err(st, kErrSlotRange, cell); col = kNoCol; }
         }
@@ -1889,7 +1951,7 @@ __global__ __launch_bounds__(kResolveNT) void k_resolve(const BucketDesc* __rest
                                                        ResolveCfg rc, LabArea la) {
     // one LDS block carved two ways: the hash table (slot UMIs | counters), or the sort path's arrays
     constexpr uint32_t kSortWords = 2 * kBucketCap + kBucketCap / 2 + kBucketCap + (EM ? 2 * kBucketCap : 0);
-    constexpr uint32_t kHashWords = kHtCap * (1 + kHtPairs) + 2 * kHtOvf + kHtCap / 32 + 2 + kHtKeys;
+    constexpr uint32_t kHashWords = kHtCap * (1 + kHtPairs) + 2 * kHtOvf + kHtCap / 32 + 2 + kHtKeys + (EM ? 2 * kHtKeys : 0);
     constexpr uint32_t kWords = kSortWords > kHashWords ? kSortWords : kHashWords;
     __shared__ __attribute__((aligned(16))) uint32_t s_raw[kWords];
     __shared__ uint32_t s_ws[kResolveNT / 64];
@@ -1916,16 +1978,21 @@ __global__ __launch_bounds__(kResolveNT) void k_resolve(const BucketDesc* __rest
         }
         return;
     }
-    if ((d.mode_single & 0xFFu) == kModeCrLike && d.n <= kHtKeys) {
+    const uint32_t bmode = d.mode_single & 0xFFu;
+    if ((bmode == kModeCrLike || (EM && bmode == kModeCrLikeEm && la.lab)) && d.n <= kHtKeys) {
         const bool single = (d.mode_single >> 8) != 0;
         unsigned long long* s_slot = reinterpret_cast<unsigned long long*>(s_raw);      // 2 words per slot
         uint32_t* s_pair = s_raw + 2 * kHtCap;                                            // kHtPairs-1 words per slot
         uint64_t* s_ovf = reinterpret_cast<uint64_t*>(s_raw + kHtCap * (1 + kHtPairs));
         uint32_t* s_flag = s_raw + kHtCap * (1 + kHtPairs) + 2 * kHtOvf;
         uint32_t* s_hcols = s_flag + kHtCap / 32 + 2;
+        uint32_t* s_hlab = s_hcols + kHtKeys;          // EM only: staged label words / descriptors of this bucket
+        if (threadIdx.x < 6) s_misc[threadIdx.x] = 0;
+        const EmStage es{s_hlab, s_hlab + kHtKeys, &s_misc[2]};
         uint32_t nc = 0;
         if (resolve_bucket_hash((single ? keys0 : keys1) + d.src_off, d.n, rc, s_slot, s_pair, s_ovf, s_flag, s_flag + kHtCap / 32,
-                                s_hcols, st, d.cell, nc)) {
+                                s_hcols, st, d.cell, nc, EM && bmode == kModeCrLikeEm, es)) {
+            if (EM && s_misc[3]) flush_bucket_labels<kResolveNT>(d, la, es.lab, es.ldesc, s_misc);
             // the table is dead: its space is the tail's scratch (sorted columns, run starts)
             bucket_tail<kResolveNT>(d, keys0, cell_ncols, nnz, s_hcols, nc, s_raw, reinterpret_cast<uint16_t*>(s_raw + kHtKeys),
                                     s_ws, s_misc);
