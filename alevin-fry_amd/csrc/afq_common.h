@@ -100,6 +100,17 @@ struct PugOut {
     const uint64_t* rd_off;  // [n_cells] first read slot of a PUG cell
 };
 __host__ __device__ inline uint64_t label_hash_init(uint32_t na) { return 0x9E3779B97F4A7C15ull ^ na; }
+// The 64-bit class key of a label.  Labels of one or two ids (transcripts at txp level, genes at gene level; ids < 2^31)
+// are carried IN the key - tag 1: the id; tag 2: (smaller id, larger id) - so equal keys mean equal labels by
+// construction and nothing needs to be re-read to verify them; an empty label is key 0.  Longer labels keep a
+// 62-bit hash under tag 3 and are verified against the record (kErrLabelHash on a collision).
+__host__ __device__ inline uint64_t label_key(uint64_t hash, uint32_t n, uint32_t a, uint32_t b) {
+    if (n == 0) return 0;
+    if (n == 1) return (1ull << 62) | a;
+    if (n == 2) return (2ull << 62) | ((uint64_t)(a < b ? a : b) << 31) | (a < b ? b : a);
+    return (3ull << 62) | (hash >> 2);
+}
+__host__ __device__ inline bool label_key_is_exact(uint64_t key) { return (key >> 62) != 3; }
 __host__ __device__ inline uint64_t label_hash_step(uint64_t h, uint32_t t) {
     h = (h ^ t) * 0xBF58476D1CE4E5B9ull;
     return h ^ (h >> 29);

@@ -129,11 +129,14 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ byte
             if (mode_is_pug(m.mode)) { rec_dw = (uint32_t)((roff - m.chunk_off) >> 2); pug_rec = true; }
             if (mode_is_pug(m.mode) && !mode_pug_gene(m.mode)) {  // txp-level PUG: hash of the ref list
                 lhash = label_hash_init(na);
+                uint32_t t01[2] = {0, 0};
                 for (uint32_t j = 0; j < na; ++j) {
                     const uint32_t t = ld_u32(rp + 4 * j, ral) & 0x7FFFFFFFu;
                     if (t >= ref_count) set_err(st, kErrRefRange, cell);
                     lhash = label_hash_step(lhash, t);
+                    if (j < 2) t01[j] = t;
                 }
+                lhash = label_key(lhash, na, t01[0], t01[1]);
                 na = 0;
             }
             for (uint32_t j = 0; j < na; ++j) {
@@ -175,6 +178,7 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ byte
                     for (int i = 0; i < 8; ++i) if ((uint32_t)i < k) lhash += gene_set_hash_term(g[i]);
                 }
                 lhash ^= (uint64_t)kcnt * kHashMul;
+                lhash = label_key(lhash, kcnt, g[0], g[1]);  // (kcnt <= 2 implies !ovf: g[0], g[1] are the read's genes)
             }
         }
         if (m.mode == kModeTrivial && kcnt != 1) kcnt = 0;  // multi-gene reads are discarded (pugutils.rs:870-891)
@@ -455,11 +459,15 @@ __global__ __launch_bounds__(256, 6) void k_decode_par(const uint8_t* __restrict
             const bool pug_gene = pug_rec && mode_pug_gene(m.mode);
             if (pug_rec && !pug_gene) {  // txp-level PUG: hash of the ref list
                 lhash = label_hash_init(na);
+                uint32_t t0 = 0, t1 = 0;
                 for (uint32_t j = 0; j < na; ++j) {
                     const uint32_t t = refw(j);
                     if (t >= ref_count) fail = true;
                     lhash = label_hash_step(lhash, t);
+                    if (j == 0) t0 = t;
+                    if (j == 1) t1 = t;
                 }
+                lhash = label_key(lhash, na, t0, t1);
             }
             if (act && na && (!pug_rec || pug_gene)) {
                 if (ok0) {
@@ -504,6 +512,7 @@ __global__ __launch_bounds__(256, 6) void k_decode_par(const uint8_t* __restrict
                         for (int q = 0; q < 8; ++q) if ((uint32_t)q < k) lhash += gene_set_hash_term(g[q]);
                     }
                     lhash ^= (uint64_t)kcnt * kHashMul;
+                    lhash = label_key(lhash, kcnt, g[0], g[1]);  // (kcnt <= 2 implies !ovf: g[0], g[1] are the read's genes)
                 }
             }
             if (m.mode == kModeTrivial && kcnt != 1) kcnt = 0;  // multi-gene reads are discarded (pugutils.rs:870-891)

@@ -335,7 +335,9 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                 atomicAdd(&v_cnt[vi], 1u);
                 const uint32_t k = v_cls[vi];
                 atomicMin(&c_minoff[k], sr[i].o);
-                if (!C.gene_level) {
+                if (label_key_is_exact(sr[i].h)) {
+                    // the key carries the label itself (<= 2 ids): equal keys are equal labels, nothing to re-read
+                } else if (!C.gene_level) {
                     if (!lab_equal(rec_label(C, sr[i].o), rec_label(C, c_rep[k]))) s_cnt[3] = kErrLabelHash;
                 } else {
                     uint32_t g[kMaxGenesPerLabel];
