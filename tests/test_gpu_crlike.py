@@ -333,3 +333,23 @@ def test_long_and_straddling_records(oracle, monkeypatch, decoder, resolution):
     assert_same_result(got, want)
     assert st["n_fallback_cells"] == 0  # the walk-free proof held; nothing went through the sequential walk
     assert got.val.sum() > 0
+
+
+@pytest.mark.parametrize("resolution", ["cr-like", "cr-like-em", "parsimony-em", "trivial"])
+def test_empty_and_single_cell_batches(oracle, resolution):
+    """A batch with no cells gives an empty result (no error); a one-read cell and a one-cell batch work in every mode."""
+    s = synth.synth(9, [1, 700, 3], num_genes=60, dup=0.3)
+    b, off = s.encode()
+    cfg = cfg_for(s, resolution, small_thresh=0 if resolution != "cr-like" else 100)
+    q = pkg.Quantifier(cfg, s.tid_to_gid)
+    try:
+        none = q.quant_chunks(b, off[:0])
+        assert none.n_cells == 0 and len(none.gene) == 0 and list(none.cell_ptr) == [0]
+        for sel in ([0], [1], [2], [0, 1, 2]):
+            got = q.quant_chunks(b, off[sel])
+            want = oracle.quant(cfg, s.tid_to_gid, b, off[sel])
+            assert_same_result(got, want, what=f"{resolution} cells {sel}")
+        again = q.quant_chunks(b, off[:0])   # and an empty batch after real ones
+        assert again.n_cells == 0
+    finally:
+        q.close()
