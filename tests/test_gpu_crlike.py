@@ -353,3 +353,14 @@ def test_empty_and_single_cell_batches(oracle, resolution):
         assert again.n_cells == 0
     finally:
         q.close()
+
+
+@pytest.mark.parametrize("usa", [False, True])
+def test_giant_cell_beyond_the_lds_histogram(oracle, usa):
+    """A 600 k-read cell gets 4096 buckets - more than the LDS histogram / multisplit hold (2048) - so its tiles
+    take the straight-to-global paths of k_hist and k_scatter; a small neighbour rides along."""
+    s = synth.synth(21, [600000, 50], num_genes=3000, usa=usa, dup=0.4, zipf=0.8)
+    b, off = s.encode()
+    got, want, st = run_both(oracle, cfg_for(s), s.tid_to_gid, b, off)
+    assert st["n_buckets"] >= 4096
+    assert_same_result(got, want)
