@@ -130,7 +130,7 @@ struct RangeState {
     DevBuf d_meta, d_keys0, d_keys1, d_cell_nkeys, d_bucket_cnt, d_bucket_cell, d_multi_cells, d_tile_prefix, d_ncols,
         d_nnz, d_ovf, d_status, d_bc, d_cell_ptr, d_gene, d_val, d_chk, d_slab_prefix, d_slab_cell, d_cell_bc, d_bdesc, d_lab,
         d_lab_cnt, d_em_off, d_em_scratch, d_em_nnz, d_pug_cells, d_rd_off, d_rd_h, d_rd_u, d_rd_o, d_pug_scr_off,
-        d_pug_scratch, d_epool, d_epool_cur, d_alt, d_hist_cells, d_fix, d_em_hdr;
+        d_pug_scratch, d_epool, d_epool_cur, d_alt, d_hist_cells, d_fix, d_em_hdr, d_em_order;
     ResolveArgs last_ra{};
     std::vector<CellMeta> meta;
     Range cur{};
@@ -141,7 +141,7 @@ struct RangeState {
         return {&d_meta, &d_keys0, &d_keys1, &d_cell_nkeys, &d_bucket_cnt, &d_bucket_cell, &d_multi_cells, &d_tile_prefix,
                 &d_ncols, &d_nnz, &d_ovf, &d_status, &d_bc, &d_cell_ptr, &d_gene, &d_val, &d_chk, &d_slab_prefix, &d_slab_cell,
                 &d_cell_bc, &d_bdesc, &d_lab, &d_lab_cnt, &d_em_off, &d_em_scratch, &d_em_nnz, &d_pug_cells, &d_rd_off, &d_rd_h,
-                &d_rd_u, &d_rd_o, &d_pug_scr_off, &d_pug_scratch, &d_epool, &d_epool_cur, &d_alt, &d_hist_cells, &d_fix, &d_em_hdr};
+                &d_rd_u, &d_rd_o, &d_pug_scr_off, &d_pug_scratch, &d_epool, &d_epool_cur, &d_alt, &d_hist_cells, &d_fix, &d_em_hdr, &d_em_order};
     }
 };
 
@@ -571,9 +571,14 @@ int finish_range(afq_ctx* c, int slot) {
         HIP_TRY(c, B.d_em_nnz.ensure(4ull * n));
         HIP_TRY(c, B.d_em_hdr.ensure(16ull * n));
         HIP_TRY(c, hipMemcpyAsync(B.d_em_off.p, eoff.data(), 8ull * (n + 1), hipMemcpyHostToDevice, s));
+        std::vector<uint32_t> em_order(n);
+        for (uint32_t i = 0; i < n; ++i) em_order[i] = i;
+        std::stable_sort(em_order.begin(), em_order.end(), [&](uint32_t a, uint32_t b) { return B.meta[a].nrec > B.meta[b].nrec; });
+        HIP_TRY(c, B.d_em_order.ensure(4ull * n));
+        HIP_TRY(c, hipMemcpyAsync(B.d_em_order.p, em_order.data(), 4ull * n, hipMemcpyHostToDevice, s));
         {
             ScopedTimer t(c, K_EM, s, &B.launches);
-            launch_em(s, B.last_ra, n, B.d_em_off.as<uint64_t>(), B.d_em_scratch.as<uint32_t>(), B.d_em_nnz.as<uint32_t>(), B.d_em_hdr.p,
+            launch_em(s, B.last_ra, n, B.d_em_off.as<uint64_t>(), B.d_em_scratch.as<uint32_t>(), B.d_em_nnz.as<uint32_t>(), B.d_em_hdr.p, B.d_em_order.as<uint32_t>(),
                       c->cfg.usa_mode ? c->cfg.num_rows : c->cfg.num_genes, c->cfg.em_init_uniform);
         }
         HIP_TRY(c, hipStreamSynchronize(s));

@@ -2217,10 +2217,10 @@ __global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta,
                                              const uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
                                              const uint32_t* __restrict__ lab, const uint32_t* __restrict__ lab_cnt,
                                              const uint64_t* __restrict__ em_off, uint32_t* __restrict__ scratch,
-                                             uint32_t* __restrict__ out_nnz, uint4* __restrict__ em_hdr, EmCfg cfg) {
+                                             uint32_t* __restrict__ out_nnz, uint4* __restrict__ em_hdr, const uint32_t* __restrict__ em_order, EmCfg cfg) {
     __shared__ uint32_t s_ws[kEmNT / 64];
     __shared__ __attribute__((aligned(16))) uint32_t s_tile[8192];  // 32 KiB sort tile
-    const uint32_t cell = blockIdx.x;
+    const uint32_t cell = em_order[blockIdx.x];  // largest cells first (the host sorts: input order is arbitrary in real data)
 #ifdef AFQ_EM_TIMING
     __shared__ unsigned long long tmark[12];
 #define EM_MARK(i) do { __syncthreads(); if (threadIdx.x == 0 && (blockIdx.x % 1000) == 7) tmark[i] = wall_clock64(); } while (0)
@@ -2531,11 +2531,11 @@ constexpr uint32_t kEmLdsWords = 36 * 1024;
 __global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict__ meta, const uint32_t* __restrict__ nnz_unique,
                                                      const uint32_t* __restrict__ lab_cnt, const uint64_t* __restrict__ em_off,
                                                      uint32_t* __restrict__ scratch, uint32_t* __restrict__ out_nnz,
-                                                     const uint4* __restrict__ em_hdr, EmCfg cfg) {
+                                                     const uint4* __restrict__ em_hdr, const uint32_t* __restrict__ em_order, EmCfg cfg) {
     __shared__ uint32_t s_ws[kEmRNT / 64];
     __shared__ uint32_t s_flag[2];
     __shared__ __attribute__((aligned(16))) uint32_t s_mem[kEmLdsWords];
-    const uint32_t cell = blockIdx.x;
+    const uint32_t cell = em_order[blockIdx.x];
 #ifdef AFQ_EM_TIMING
     __shared__ unsigned long long tm2[6];
 #define EM2_MARK(i) do { __syncthreads(); if (threadIdx.x == 0 && (blockIdx.x % 1000) == 7) tm2[i] = wall_clock64(); } while (0)
@@ -3042,12 +3042,12 @@ uint64_t em_scratch_words(uint32_t nU, uint32_t W, uint32_t M, bool usa) {
 }
 
 void launch_em(hipStream_t s, const ResolveArgs& a, uint32_t n_cells, const uint64_t* em_off, uint32_t* scratch,
-               uint32_t* out_nnz, void* em_hdr_v, uint32_t num_alphas, uint32_t init_uniform) {
+               uint32_t* out_nnz, void* em_hdr_v, const uint32_t* em_order, uint32_t num_alphas, uint32_t init_uniform) {
     uint4* em_hdr = reinterpret_cast<uint4*>(em_hdr_v);
     if (!n_cells) return;
     EmCfg cfg{a.usa, num_alphas, a.num_rows / 3, 2 * (a.num_rows / 3), init_uniform};
-    AFQ_LAUNCH(k_em, n_cells, kEmNT, s, a.meta, a.nnz, a.keys0, a.keys1, a.lab, a.lab_cnt, em_off, scratch, out_nnz, em_hdr, cfg);
-    AFQ_LAUNCH(k_em_rounds, n_cells, kEmRNT, s, a.meta, a.nnz, a.lab_cnt, em_off, scratch, out_nnz, em_hdr, cfg);
+    AFQ_LAUNCH(k_em, n_cells, kEmNT, s, a.meta, a.nnz, a.keys0, a.keys1, a.lab, a.lab_cnt, em_off, scratch, out_nnz, em_hdr, em_order, cfg);
+    AFQ_LAUNCH(k_em_rounds, n_cells, kEmRNT, s, a.meta, a.nnz, a.lab_cnt, em_off, scratch, out_nnz, em_hdr, em_order, cfg);
 }
 
 void launch_compact_em(hipStream_t s, uint32_t n_cells, const uint64_t* em_off, const uint32_t* scratch, const uint32_t* nnz,
