@@ -451,7 +451,8 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         }
     }
     PUG_MARK(13);
-    for (uint32_t x = tid; x <= V; x += kPugNT) deg[x] = 0;
+    uint32_t* tch = c_base;  // dead after phase 3: 1 = the vertex is the target of some edge
+    for (uint32_t x = tid; x <= V; x += kPugNT) { deg[x] = 0; if (x < V) tch[x] = 0; }
     __syncthreads();
     // out-neighbours of x: vertices y != x with overlapping labels and UMI distance 0, or distance 1 and
     // count(y) < 2*count(x)  (has_edge, pugutils.rs:76-99: X->Y unless cy >= 2cx)
@@ -575,22 +576,35 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     if (n_pairs <= pair_cap) {
         for (uint32_t k = tid; k < n_pairs; k += kPugNT) {
             const uint64_t pr = pairs[k];
-            if (pr != ~0ull) edges[atomicAdd(&c_order[(uint32_t)(pr >> 32)], 1u)] = (uint32_t)pr;
+            if (pr != ~0ull) { edges[atomicAdd(&c_order[(uint32_t)(pr >> 32)], 1u)] = (uint32_t)pr; tch[(uint32_t)pr] = 1; }
         }
     } else {
         for (uint32_t i = tid; i < NCAND; i += kPugNT)
-            for_each_edge_of(cand[i], [&](uint32_t x, uint32_t y) { edges[atomicAdd(&c_order[x], 1u)] = y; });
+            for_each_edge_of(cand[i], [&](uint32_t x, uint32_t y) { edges[atomicAdd(&c_order[x], 1u)] = y; tch[y] = 1; });
     }
     __syncthreads();
     PUG_MARK(5);
     // ---- 5. weakly connected components: min-label propagation + pointer jumping ----
+    // Only vertices with an edge take part (~15 % of them: most molecules have no UMI neighbour); the others are
+    // their own components and are resolved straight from their labels in 6a, without being listed or sorted.
+    uint32_t* tl = v_cls;   // slab B is dead: the vertices that have an edge, ascending
+    uint32_t NT = 0;
+    for (uint32_t base = 0; base < V; base += kPugNT) {
+        const uint32_t v = base + tid;
+        const bool h = v < V && (deg[v + 1] > deg[v] || tch[v]);
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<kPugNT>(h, s_ws, tot);
+        if (h) tl[NT + ex] = v;
+        NT += tot;
+    }
     for (uint32_t v = tid; v < V; v += kPugNT) wlab[v] = v;
     __syncthreads();
     for (;;) {
         if (tid == 0) s_flag[0] = 0;
         __syncthreads();
         bool ch = false;
-        for (uint32_t x = tid; x < V; x += kPugNT) {
+        for (uint32_t i = tid; i < NT; i += kPugNT) {
+            const uint32_t x = tl[i];
             for (uint32_t e = deg[x]; e < deg[x + 1]; ++e) {
                 const uint32_t y = edges[e];
                 const uint32_t a = wlab[x], b = wlab[y];
@@ -601,26 +615,26 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         if (ch) s_flag[0] = 1;
         __syncthreads();
         for (int it = 0; it < 4; ++it) {
-            for (uint32_t v = tid; v < V; v += kPugNT) { const uint32_t l = wlab[v]; const uint32_t ll = wlab[l]; if (ll < l) wlab[v] = ll; }
+            for (uint32_t i = tid; i < NT; i += kPugNT) { const uint32_t v = tl[i]; const uint32_t l = wlab[v]; const uint32_t ll = wlab[l]; if (ll < l) wlab[v] = ll; }
             __syncthreads();
         }
         if (!s_flag[0]) break;
     }
     PUG_MARK(6);
     // a label may still point at a non-root after the last sweep; chase it
-    for (uint32_t v = tid; v < V; v += kPugNT) { uint32_t l = wlab[v]; while (wlab[l] != l) l = wlab[l]; comp_sorted[v] = ((uint64_t)l << kVidBits) | v; }
+    for (uint32_t i = tid; i < NT; i += kPugNT) { const uint32_t v = tl[i]; uint32_t l = wlab[v]; while (wlab[l] != l) l = wlab[l]; comp_sorted[i] = ((uint64_t)l << kVidBits) | v; }
     __syncthreads();
-    tiled_bitonic_sort_by<kPugNT, 8192>(comp_sorted, V, [](uint64_t a, uint64_t b) { return a > b; }, reinterpret_cast<uint64_t*>(s_big));
-    uint32_t NC = 0;
-    for (uint32_t base = 0; base < V; base += kPugNT) {
+    tiled_bitonic_sort_by<kPugNT, 8192>(comp_sorted, NT, [](uint64_t a, uint64_t b) { return a > b; }, reinterpret_cast<uint64_t*>(s_big));
+    uint32_t NC = 0;   // components of two or more vertices
+    for (uint32_t base = 0; base < NT; base += kPugNT) {
         const uint32_t i = base + tid;
-        const bool h = i < V && (i == 0 || (comp_sorted[i] >> kVidBits) != (comp_sorted[i - 1] >> kVidBits));
+        const bool h = i < NT && (i == 0 || (comp_sorted[i] >> kVidBits) != (comp_sorted[i - 1] >> kVidBits));
         uint32_t tot;
         const uint32_t ex = block_excl_scan<kPugNT>(h, s_ws, tot);
         if (h) comp_start[NC + ex] = i;
         NC += tot;
     }
-    if (tid == 0) comp_start[NC] = V;
+    if (tid == 0) comp_start[NC] = NT;
     __syncthreads();
     for (uint32_t c = tid; c < NC; c += kPugNT)  // vid -> position inside its component (components are short on average)
         if (comp_start[c + 1] - comp_start[c] <= 64)
@@ -647,14 +661,20 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     // A two-vertex component is always one molecule: it is weakly connected, so one of the two can reach the
     // other through a shared transcript and the greedy cover takes that 2-vertex arborescence first; its label
     // is the transcripts the two labels share (pugutils.rs:1161-1188) - never empty, an edge needs an overlap.
+    for (uint32_t v = tid; v < V; v += kPugNT) {   // vertices without an edge: one molecule each, the label's genes
+        if (deg[v + 1] > deg[v] || tch[v]) continue;
+        const Lab l = vlab(v);
+        uint32_t g[kMaxGenesPerLabel];
+        const uint32_t ng = genes_of(C, l.n, [&](uint32_t j) { return l.p[j] & 0x7FFFFFFFu; }, g);
+        emit_molecule(C, g, ng);
+    }
     for (uint32_t c = tid; c < NC; c += kPugNT) {
         const uint32_t n = comp_start[c + 1] - comp_start[c];
-        if (n > 2 || (n == 2 && n > C.large_thresh)) continue;
+        if (n != 2 || n > C.large_thresh) continue;
         const Lab l = vlab(vid_at(comp_start[c]));
         uint32_t g[kMaxGenesPerLabel];
         uint32_t ng;
-        if (n == 1) ng = genes_of(C, l.n, [&](uint32_t j) { return l.p[j] & 0x7FFFFFFFu; }, g);
-        else {
+        {
             const Lab l2 = vlab(vid_at(comp_start[c] + 1));
             ng = 0;
             for (uint32_t j = 0; j < l.n && ng != 0xFFFFFFFFu; ++j) {
