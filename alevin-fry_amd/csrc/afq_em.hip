@@ -1,0 +1,722 @@
+// afq_em.hip - per-cell EM over gene-level equivalence classes on gfx950 (src/em.rs of the reference):
+//   k_em          setup: classes, support, inverted index, compact active set
+//   k_em_rounds   the rounds, with the round state on chip
+//   k_compact_em  EM output pairs -> CSR
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "afq_common.h"
+#include "afq_kernels.h"
+#include "afq_prims.h"
+
+namespace afq {
+// ---------------------------------------------------------------------------
+// Per-cell EM over the gene-level equivalence classes (src/em.rs).  One workgroup per cell.
+//   inputs : the cell's single-label counts = sorted (column,count) pairs (k_cell_hist / k_resolve),
+//            and the labels of its ambiguous molecules (label area, written by resolve)
+//   steps  : group identical labels into classes (lexicographic order), rewrite USA labels to S/U/A
+//            slots (utils.rs:865-925), build the support (labels, and in USA their sibling statuses,
+//            em.rs:87-113), then iterate.  One round = (A) thread per class: denominator in label order;
+//            (B) thread per support entry: the single-label count first, then the contributions of the
+//            classes containing it in class order - the same f32 operation sequence as the sequential
+//            loop of em_update (em.rs:189-248, 458-485) under the oracle's canonical class order, so
+//            results are bit-identical to the oracle; (C) convergence vote.
+//   schedule: non-USA = em_optimize (em.rs:536-572); USA = em_optimize_subset_impl with the extra
+//            round after zeroing < 0.01 (em.rs:391-451).
+// All arrays live in a per-cell global scratch slice (L2 resident); sizes are tiny next to the decode.
+struct EmCfg {
+    uint32_t usa, num_alphas, uo, ao, init_uniform;
+};
+constexpr int kEmNT = 256;
+constexpr float kMinOutputAlpha = 0.01f, kAlphaCheckCutoff = 1e-2f, kRelDiffTol = 1e-2f;
+constexpr uint32_t kMinIter = 2, kMaxIter = 100;
+
+
+// Per-cell EM scratch (u32 words; mirrored by em_scratch_words).  Filled by k_em (setup), consumed by k_em_rounds.
+struct EmScratch {
+    uint2* out; uint64_t* inv_pairs; uint32_t *order, *cls_first, *cls_cnt, *cls_woff, *cls_w, *cls_sidx; float* inv;
+    uint32_t *support, *sib1, *sib2, *ucnt; float *a_in, *a_out; uint32_t *slot_off, *aid; uint4 *ent, *lw3;
+    uint32_t *act_col, *memb;
+};
+__device__ __forceinline__ EmScratch em_carve(uint32_t* scratch, uint64_t off, uint32_t nU, uint32_t W, uint32_t M, uint32_t capS) {
+    EmScratch e;
+    uint32_t* p = scratch + off;
+    e.out = reinterpret_cast<uint2*>(p); p += 2 * (capS + 1);           // (column, f32 bits); 8-byte aligned by construction
+    e.inv_pairs = reinterpret_cast<uint64_t*>(p); p += 2 * (W + 1);     // (support idx << 32 | class)
+    e.order = p; p += M + 1;       // molecule indices sorted by label
+    e.cls_first = p; p += M + 1;   // class -> position in `order` of its first molecule
+    e.cls_cnt = p; p += M + 1;
+    e.cls_woff = p; p += M + 2;    // class -> offset of its EM label in cls_w
+    e.cls_w = p; p += W + 1;       // EM labels (slots)
+    e.cls_sidx = p; p += W + 1;    // ... as support indices
+    e.inv = reinterpret_cast<float*>(p); p += M + 1;
+    e.support = p; p += capS + 1;
+    e.sib1 = p; p += capS + 1;
+    e.sib2 = p; p += capS + 1;
+    e.ucnt = p; p += capS + 1;
+    e.a_in = reinterpret_cast<float*>(p); p += capS + 2;
+    e.a_out = reinterpret_cast<float*>(p); p += capS + 2;
+    e.slot_off = p; p += capS + 2;
+    e.aid = p; p += capS + 1;          // support idx -> active idx
+    p += (4 - ((p - scratch) & 3)) & 3;        // 16-byte records below (slices start 16-byte aligned)
+    e.ent = reinterpret_cast<uint4*>(p); p += 4 * (nU + W + 2);   // per active entry: count, sibling ids, first membership
+    e.lw3 = reinterpret_cast<uint4*>(p); p += 4 * (W + 1);        // per label word: its entry and the entry's siblings
+    e.act_col = p; p += nU + W + 2;
+    e.memb = p; p += W + 1;            // class ids of the memberships, entry-major
+    return e;
+}
+
+__global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta, const uint32_t* __restrict__ nnz_unique,
+                                             const uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
+                                             const uint32_t* __restrict__ lab, const uint32_t* __restrict__ lab_cnt,
+                                             const uint64_t* __restrict__ em_off, uint32_t* __restrict__ scratch,
+                                             uint32_t* __restrict__ out_nnz, uint4* __restrict__ em_hdr, const uint32_t* __restrict__ em_order, EmCfg cfg) {
+    __shared__ uint32_t s_ws[kEmNT / 64];
+    __shared__ __attribute__((aligned(16))) uint32_t s_tile[8192];  // 32 KiB sort tile
+    const uint32_t cell = em_order[blockIdx.x];  // largest cells first (the host sorts: input order is arbitrary in real data)
+#ifdef AFQ_EM_TIMING
+    __shared__ unsigned long long tmark[12];
+#define EM_MARK(i) do { __syncthreads(); if (threadIdx.x == 0 && (blockIdx.x % 1000) == 7) tmark[i] = wall_clock64(); } while (0)
+#else
+#define EM_MARK(i) do {} while (0)
+#endif
+    const CellMeta m = meta[cell];
+    const uint32_t nU = nnz_unique[cell];
+    const uint2* U = reinterpret_cast<const uint2*>(((m.lg_nb || mode_is_pug(m.mode)) ? keys1 : keys0) + m.key_off);
+    const uint32_t W = lab_cnt[2 * cell], M = lab_cnt[2 * cell + 1];
+    const uint32_t* lw = lab + 2 * m.key_off;
+    const uint32_t* ld = lw + m.n_ref + 1;
+    const uint32_t mult = cfg.usa ? 3u : 1u;
+    const uint32_t capS = (nU + W) * mult;
+    const EmScratch sc = em_carve(scratch, em_off[cell], nU, W, M, capS);
+    uint2* out = sc.out; uint64_t* inv_pairs = sc.inv_pairs; uint32_t* order = sc.order; uint32_t* cls_first = sc.cls_first;
+    uint32_t* cls_cnt = sc.cls_cnt; uint32_t* cls_woff = sc.cls_woff; uint32_t* cls_w = sc.cls_w; uint32_t* cls_sidx = sc.cls_sidx;
+    uint32_t* support = sc.support; uint32_t* sib1 = sc.sib1; uint32_t* sib2 = sc.sib2; uint32_t* ucnt = sc.ucnt;
+    uint32_t* slot_off = sc.slot_off; uint32_t* aid = sc.aid; uint4* ent = sc.ent; uint4* lw3 = sc.lw3;
+    uint32_t* act_col = sc.act_col; uint32_t* memb = sc.memb;
+    if (M == 0) {  // no multi-label class: the counts are the single-label counts (em.rs:339-341, 499-514)
+        for (uint32_t i = threadIdx.x; i < nU; i += kEmNT) out[i] = make_uint2(U[i].x, __float_as_uint((float)U[i].y));
+        if (threadIdx.x == 0) { out_nnz[cell] = nU; em_hdr[cell] = make_uint4(0u, 0u, 0u, 1u); }
+        return;
+    }
+    auto lab_gt = [&](uint32_t a, uint32_t b) {  // lexicographic a > b on the gene-level labels
+        const uint32_t oa = ld[2 * a], na = ld[2 * a + 1], ob = ld[2 * b], nb = ld[2 * b + 1];
+        const uint32_t nm = na < nb ? na : nb;
+        for (uint32_t i = 0; i < nm; ++i) {
+            const uint32_t x = lw[oa + i], y = lw[ob + i];
+            if (x != y) return x > y;
+        }
+        return na > nb;
+    };
+    auto lab_ne = [&](uint32_t a, uint32_t b) { return lab_gt(a, b) || lab_gt(b, a); };
+    EM_MARK(0);
+    // 1. classes = runs of equal labels in lexicographic order
+    // The sort runs on 16-byte records out of LDS: a 63-bit key holding the label's first three genes (+1, a missing
+    // gene is 0, so key order IS the lexicographic order with shorter labels first) and the molecule index; only labels
+    // that tie on three genes and are longer than that fall back to the pointer-chasing comparison.
+    struct LabKey { uint64_t key; uint32_t idx, len; };
+    LabKey* lk = reinterpret_cast<LabKey*>(inv_pairs);  // 4 words per molecule; inv_pairs holds 2(W+1) >= 4M+2 words (every label has >= 2 genes)
+    for (uint32_t i = threadIdx.x; i < M; i += kEmNT) {
+        const uint32_t o = ld[2 * i], n = ld[2 * i + 1];
+        uint64_t key = (uint64_t)(lw[o] + 1u) << 42;
+        if (n > 1) key |= (uint64_t)(lw[o + 1] + 1u) << 21;
+        if (n > 2) key |= (uint64_t)(lw[o + 2] + 1u);
+        lk[i] = LabKey{key, i, n};
+    }
+    __syncthreads();
+    auto lk_gt = [&](const LabKey& a, const LabKey& b) {
+        if (a.key != b.key) return a.key > b.key;
+        if (a.len <= 3 && b.len <= 3) return false;  // same three-or-fewer genes: the same label
+        return lab_gt(a.idx, b.idx);
+    };
+    tiled_bitonic_sort_by<kEmNT, 2048>(lk, M, lk_gt, reinterpret_cast<LabKey*>(s_tile));
+    for (uint32_t i = threadIdx.x; i < M; i += kEmNT) order[i] = lk[i].idx;
+    __syncthreads();
+    uint32_t K = 0;
+    for (uint32_t base = 0; base < M; base += kEmNT) {
+        const uint32_t i = base + threadIdx.x;
+        bool head = i < M;
+        if (head && i > 0) {
+            const LabKey a = lk[i], b = lk[i - 1];
+            head = a.key != b.key || ((a.len > 3 || b.len > 3) && lab_ne(a.idx, b.idx));
+        }
+        const uint32_t h = head;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<kEmNT>(h, s_ws, tot);
+        if (h) cls_first[K + ex] = i;
+        K += tot;
+    }
+    __syncthreads();
+    EM_MARK(1);
+    // 2. EM label of each class: length, then contents
+    auto em_label = [&](uint32_t c, uint32_t* dst) -> uint32_t {  // returns the length; writes when dst != null
+        const uint32_t mol = order[cls_first[c]];
+        const uint32_t o = ld[2 * mol], n = ld[2 * mol + 1];
+        uint32_t w = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t gn = lw[o + i];
+            uint32_t idx = gn;
+            if (cfg.usa) {
+                idx = gn >> 1;
+                if (is_spliced(gn)) {
+                    if (i + 1 < n && same_gene(gn, lw[o + i + 1])) { idx += cfg.ao; ++i; }
+                } else idx += cfg.uo;
+            }
+            if (dst) dst[w] = idx;
+            ++w;
+        }
+        return w;
+    };
+    uint32_t Wc = 0;
+    for (uint32_t base = 0; base < K; base += kEmNT) {
+        const uint32_t c = base + threadIdx.x;
+        const uint32_t len = c < K ? em_label(c, nullptr) : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<kEmNT>(len, s_ws, tot);
+        if (c < K) {
+            cls_woff[c] = Wc + ex;
+            cls_cnt[c] = (c + 1 < K ? cls_first[c + 1] : M) - cls_first[c];
+        }
+        Wc += tot;
+    }
+    if (threadIdx.x == 0) cls_woff[K] = Wc;
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < K; c += kEmNT) em_label(c, cls_w + cls_woff[c]);
+    __syncthreads();
+    EM_MARK(2);
+    // 3. support = single-label columns + label slots (+ USA sibling statuses), sorted, distinct.
+    // When one bit per output column fits the LDS tile next to its rank table (num_alphas <= 131072: every gene-level
+    // matrix in practice), the support is a bitmap: mark, prefix-popcount, and "index of column x in the support" is
+    // two LDS reads instead of a sort of 3(nU + W) values and a binary search per lookup.
+    const uint32_t nwb = (cfg.num_alphas + 31) >> 5;
+    const bool bm = 2 * nwb <= 8192;
+    uint32_t* bm_bits = s_tile;
+    uint32_t* bm_rank = s_tile + nwb;
+    uint32_t S = 0;
+    if (bm) {
+        for (uint32_t i = threadIdx.x; i < nwb; i += kEmNT) bm_bits[i] = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nU + Wc; i += kEmNT) {
+            const uint32_t x = i < nU ? U[i].x : cls_w[i - nU];
+            atomicOr(&bm_bits[x >> 5], 1u << (x & 31));
+            if (cfg.usa) {
+                uint32_t s1, s2;
+                if (x >= cfg.ao) { s1 = x - cfg.uo; s2 = x - cfg.ao; }
+                else if (x >= cfg.uo) { s1 = x + cfg.uo; s2 = x - cfg.uo; }
+                else { s1 = x + cfg.ao; s2 = x + cfg.uo; }
+                atomicOr(&bm_bits[s1 >> 5], 1u << (s1 & 31));
+                atomicOr(&bm_bits[s2 >> 5], 1u << (s2 & 31));
+            }
+        }
+        __syncthreads();
+        for (uint32_t base = 0; base < nwb; base += kEmNT) {
+            const uint32_t w = base + threadIdx.x;
+            const uint32_t c = w < nwb ? (uint32_t)__popc(bm_bits[w]) : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<kEmNT>(c, s_ws, tot);
+            if (w < nwb) bm_rank[w] = S + ex;
+            S += tot;
+        }
+        __syncthreads();
+        for (uint32_t w = threadIdx.x; w < nwb; w += kEmNT) {
+            uint32_t b = bm_bits[w], o = bm_rank[w];
+            for (; b; b &= b - 1) support[o++] = (w << 5) + (uint32_t)__builtin_ctz(b);
+        }
+        __syncthreads();
+    } else {
+        uint32_t nC = 0;
+        {
+            const uint32_t nsrc = nU + Wc;
+            for (uint32_t i = threadIdx.x; i < nsrc; i += kEmNT) {
+                const uint32_t x = i < nU ? U[i].x : cls_w[i - nU];
+                support[i * mult] = x;
+                if (cfg.usa) {
+                    uint32_t s1, s2;
+                    if (x >= cfg.ao) { s1 = x - cfg.uo; s2 = x - cfg.ao; }
+                    else if (x >= cfg.uo) { s1 = x + cfg.uo; s2 = x - cfg.uo; }
+                    else { s1 = x + cfg.ao; s2 = x + cfg.uo; }
+                    support[i * mult + 1] = s1;
+                    support[i * mult + 2] = s2;
+                }
+            }
+            nC = nsrc * mult;
+        }
+        __syncthreads();
+        tiled_bitonic_sort_by<kEmNT, 8192>(support, nC, [](uint32_t a, uint32_t b) { return a > b; }, s_tile);
+        for (uint32_t base = 0; base < nC; base += kEmNT) {  // in-place unique: position S+ex <= i, so reads stay ahead of writes
+            const uint32_t i = base + threadIdx.x;
+            const uint32_t v = i < nC ? support[i] : 0u;
+            const uint32_t h = (i < nC) && (i == 0 || v != support[i - 1]);
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<kEmNT>(h, s_ws, tot);
+            __syncthreads();
+            if (h) support[S + ex] = v;
+            S += tot;
+            __syncthreads();
+        }
+    }
+    auto sup_index = [&](uint32_t x) -> uint32_t {  // position of column x in the support (x is in it)
+        if (bm) return bm_rank[x >> 5] + (uint32_t)__popc(bm_bits[x >> 5] & ((1u << (x & 31)) - 1u));
+        return lower_bound_u32(support, S, x);
+    };
+    // NOTE on the USA support: the reference marks, for a label x, x and its siblings so that reads of
+    // get_abundance_for are reset every round (em.rs:351-356).  Marking both siblings for every status is a
+    // superset of em.rs:101-109 (which marks exactly the statuses get_abundance_for reads); the extra entries
+    // hold 0 throughout and never change a sum.
+    for (uint32_t s = threadIdx.x; s < S; s += kEmNT) {
+        ucnt[s] = 0;
+        sib1[s] = 0xFFFFFFFFu; sib2[s] = 0xFFFFFFFFu;
+        if (cfg.usa) {
+            const uint32_t x = support[s];
+            if (x >= cfg.ao) { sib1[s] = sup_index(x - cfg.uo); sib2[s] = sup_index(x - cfg.ao); }
+            else if (x >= cfg.uo) sib1[s] = sup_index(x + cfg.uo);
+            else sib1[s] = sup_index(x + cfg.ao);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nU; i += kEmNT) ucnt[sup_index(U[i].x)] = U[i].y;
+    for (uint32_t c = threadIdx.x; c < K; c += kEmNT)
+        for (uint32_t w = cls_woff[c]; w < cls_woff[c + 1]; ++w) {
+            const uint32_t s = sup_index(cls_w[w]);
+            cls_sidx[w] = s;
+            inv_pairs[w] = ((uint64_t)s << 32) | c;
+        }
+    __syncthreads();
+    EM_MARK(3);
+    // 4. inverted index: for every support entry the classes containing it, ascending class
+    tiled_bitonic_sort_by<kEmNT, 4096>(inv_pairs, Wc, [](uint64_t a, uint64_t b) { return a > b; }, reinterpret_cast<uint64_t*>(s_tile));
+    // slot_off[s] = first pair with support idx >= s: count the memberships per entry, exclusive scan
+    for (uint32_t s = threadIdx.x; s <= S; s += kEmNT) slot_off[s] = 0;
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < Wc; q += kEmNT) atomicAdd(&slot_off[(uint32_t)(inv_pairs[q] >> 32)], 1u);
+    __syncthreads();
+    {
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base <= S; base += kEmNT) {
+            const uint32_t s = base + threadIdx.x;
+            const uint32_t c = s <= S ? slot_off[s] : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<kEmNT>(c, s_ws, tot);
+            if (s <= S) slot_off[s] = carry + ex;
+            carry += tot;
+        }
+    }
+    __syncthreads();
+    EM_MARK(4);
+    // 4b. The rounds only ever change entries that have a single-label count or sit in some class label
+    // ("active"); every other support entry (the USA sibling statuses marked for em.rs:351-356) is produced
+    // as 0 by each round.  Compact the active entries and express everything the rounds touch in active ids:
+    // per entry one 16-byte record, per label word one, the memberships as plain class ids.  Two extra slots
+    // stand for "an inactive sibling" (the initial value in round 1, 0 afterwards) and "no sibling" (0; adding
+    // +0.0f to a non-negative float is exact, so one three-term formula serves every status).
+    uint32_t A = 0;
+    for (uint32_t base = 0; base < S; base += kEmNT) {
+        const uint32_t s2 = base + threadIdx.x;
+        const uint32_t h = s2 < S && (ucnt[s2] != 0 || slot_off[s2 + 1] > slot_off[s2]);
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<kEmNT>(h, s_ws, tot);
+        if (s2 < S) aid[s2] = h ? A + ex : 0xFFFFFFFFu;
+        A += tot;
+    }
+    __syncthreads();
+    const uint32_t Z0 = A, Z1 = A + 1;
+    auto amap = [&](uint32_t x) -> uint32_t {
+        if (x == 0xFFFFFFFFu) return Z1;
+        const uint32_t a = aid[x];
+        return a == 0xFFFFFFFFu ? Z0 : a;
+    };
+    for (uint32_t s2 = threadIdx.x; s2 < S; s2 += kEmNT) {
+        const uint32_t a = aid[s2];
+        if (a == 0xFFFFFFFFu) continue;
+        ent[a] = make_uint4(ucnt[s2], amap(sib1[s2]), amap(sib2[s2]), slot_off[s2]);
+        act_col[a] = support[s2];
+    }
+    if (threadIdx.x == 0) ent[A] = make_uint4(0u, Z1, Z1, Wc);
+    for (uint32_t w = threadIdx.x; w < Wc; w += kEmNT) {
+        const uint32_t s2 = cls_sidx[w];
+        lw3[w] = make_uint4(aid[s2], amap(sib1[s2]), amap(sib2[s2]), 0u);
+        memb[w] = (uint32_t)inv_pairs[w];
+    }
+    EM_MARK(4);
+    if (threadIdx.x == 0) em_hdr[cell] = make_uint4(A, K, Wc, 0u);  // the rounds run in k_em_rounds
+#ifdef AFQ_EM_TIMING
+    EM_MARK(5);
+    if (threadIdx.x == 0 && (blockIdx.x % 1000) == 7) { printf("em setup nrec=%u nU=%u M=%u K=%u S=%u Wc=%u A=%u:", m.nrec, nU, M, K, S, Wc, A); for (int i = 1; i <= 5; ++i) printf(" p%d=%.3fms", i, (double)(tmark[i] - tmark[i - 1]) / 1e5); printf("\n"); }
+#endif
+}
+
+// acc + sum over q in [q0, q1), in that order, of (iv(q) >= 0 ? ab * iv(q) : 0) - by the whole wave: the loads
+// of 64 memberships go out together, the additions stay one after the other (float addition is not associative
+// and the order is the parity contract).  An entry that sits in hundreds of classes (a highly expressed gene)
+// otherwise makes its one thread walk hundreds of dependent loads per round while the wave waits.
+// All 64 lanes must call it with the same arguments; every lane returns the result.
+constexpr uint32_t kEmHeavy = 8;   // memberships above which an entry is summed by the wave
+template <typename InvAt>
+__device__ __forceinline__ float wave_ordered_sum(float acc, float ab, uint32_t q0, uint32_t q1, InvAt&& inv_at) {
+    const uint32_t lane = lane_id();
+    for (uint32_t base = q0; base < q1; base += 64) {
+        const uint32_t q = base + lane;
+        const float iv = q < q1 ? inv_at(q) : -1.0f;
+        // every lane forms its own term; a skipped term is +0.0f, which leaves a non-negative sum bit for bit
+        // unchanged, so the chain below needs no branches: 64 dependent adds fed by constant-lane reads
+        const float term = iv >= 0.0f ? ab * iv : 0.0f;
+        const uint32_t tb = __float_as_uint(term);
+#pragma unroll
+        for (int i = 0; i < 64; ++i) acc += __uint_as_float(__builtin_amdgcn_readlane(tb, i));
+    }
+    return acc;
+}
+__device__ __forceinline__ uint32_t bcast_u32(uint32_t v, uint32_t src_lane) { return __builtin_amdgcn_readlane(v, (int)src_lane); }
+__device__ __forceinline__ float bcast_f32(float v, uint32_t src_lane) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), (int)src_lane)); }
+
+// ---------------------------------------------------------------------------
+// The EM rounds.  k_em left, per cell, the compact structures of section 4b in global scratch; the rounds
+// themselves used to stream them from L2/HBM every round (~1.5 MB of cache lines per round and cell - with a
+// thousand cells in flight that is the memory system's full throughput, for 20-100 rounds).  Here one
+// 1024-thread workgroup takes a cell and keeps everything the rounds touch ON CHIP: abundances, 1/denominators,
+// class offsets/counts, label words and memberships (16-bit ids) in LDS, the per-entry records in registers
+// (8 entries per thread).  A round is then LDS traffic and three barriers.  Cells too big for that (more than
+// 8192 active entries or classes, or > 144 KiB of LDS) run the same arithmetic out of global memory.
+// Arithmetic and its order are unchanged (bit-identical to the oracle).
+constexpr int kEmRNT = 1024;
+constexpr uint32_t kEmPer = 8;
+constexpr uint32_t kEmLdsWords = 36 * 1024;
+__global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict__ meta, const uint32_t* __restrict__ nnz_unique,
+                                                     const uint32_t* __restrict__ lab_cnt, const uint64_t* __restrict__ em_off,
+                                                     uint32_t* __restrict__ scratch, uint32_t* __restrict__ out_nnz,
+                                                     const uint4* __restrict__ em_hdr, const uint32_t* __restrict__ em_order, EmCfg cfg) {
+    __shared__ uint32_t s_ws[kEmRNT / 64];
+    __shared__ uint32_t s_flag[2];
+    __shared__ __attribute__((aligned(16))) uint32_t s_mem[kEmLdsWords];
+    const uint32_t cell = em_order[blockIdx.x];
+#ifdef AFQ_EM_TIMING
+    __shared__ unsigned long long tm2[6];
+#define EM2_MARK(i) do { __syncthreads(); if (threadIdx.x == 0 && (blockIdx.x % 1000) == 7) tm2[i] = wall_clock64(); } while (0)
+#else
+#define EM2_MARK(i) do {} while (0)
+#endif
+    const uint4 hdr = em_hdr[cell];
+    if (hdr.w) return;  // no multi-label class: k_em already wrote the row
+    const uint32_t A = hdr.x, K = hdr.y, Wc = hdr.z;
+    const uint32_t nU = nnz_unique[cell], W = lab_cnt[2 * cell], M = lab_cnt[2 * cell + 1];
+    const uint32_t capS = (nU + W) * (cfg.usa ? 3u : 1u);
+    const EmScratch sc = em_carve(scratch, em_off[cell], nU, W, M, capS);
+    uint2* out = sc.out;
+    const uint4* ent = sc.ent;
+    const uint4* lw3 = sc.lw3;
+    const uint32_t* memb = sc.memb;
+    const uint32_t* cls_woff = sc.cls_woff;
+    const uint32_t* cls_cnt = sc.cls_cnt;
+    const uint32_t* act_col = sc.act_col;
+    const uint32_t Z0 = A, Z1 = A + 1;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lw_words = (3 * Wc + 1) / 2, mb_words = (Wc + 1) / 2;
+    const uint32_t need = (A + 2) + K + (K + 1) + K + lw_words + mb_words;
+    const bool fits = need <= kEmLdsWords && A <= kEmPer * kEmRNT && K <= kEmPer * kEmRNT;
+    uint32_t nout = 0;
+    [[maybe_unused]] uint32_t it_dbg = 0;
+    EM2_MARK(0);
+    if (fits) {
+        float* vin = reinterpret_cast<float*>(s_mem);
+        float* inv = vin + (A + 2);
+        uint32_t* woff = reinterpret_cast<uint32_t*>(inv + K);
+        uint32_t* cnt = woff + (K + 1);
+        uint16_t* lw16 = reinterpret_cast<uint16_t*>(cnt + K);
+        uint16_t* mb16 = reinterpret_cast<uint16_t*>(cnt + K + lw_words);
+        for (uint32_t c = tid; c <= K; c += kEmRNT) woff[c] = cls_woff[c];
+        for (uint32_t c = tid; c < K; c += kEmRNT) cnt[c] = cls_cnt[c];
+        for (uint32_t w = tid; w < Wc; w += kEmRNT) {
+            const uint4 l = lw3[w];
+            lw16[3 * w] = (uint16_t)l.x; lw16[3 * w + 1] = (uint16_t)l.y; lw16[3 * w + 2] = (uint16_t)l.z;
+            mb16[w] = (uint16_t)memb[w];
+        }
+        uint32_t e_cnt[kEmPer], e_sib[kEmPer], e_q0[kEmPer], e_q1[kEmPer];
+        float acc[kEmPer];
+        const float uni = 1.0f / (float)cfg.num_alphas;
+#pragma unroll
+        for (uint32_t j = 0; j < kEmPer; ++j) {
+            const uint32_t a = tid + j * kEmRNT;
+            e_cnt[j] = 0; e_sib[j] = 0; e_q0[j] = 0; e_q1[j] = 0; acc[j] = 0.0f;
+            if (a < A) {
+                const uint4 e = ent[a];
+                e_cnt[j] = e.x; e_sib[j] = e.y | (e.z << 16); e_q0[j] = e.w; e_q1[j] = ent[a + 1].w;
+                vin[a] = cfg.init_uniform ? uni : ((float)e.x + 0.5f) * 1e-3f;
+            }
+        }
+        if (tid == 0) { vin[Z0] = cfg.init_uniform ? uni : ((float)0u + 0.5f) * 1e-3f; vin[Z1] = 0.0f; }
+        __syncthreads();
+        EM2_MARK(1);
+        uint32_t it = 0;
+        bool conv = true, last_round = false;
+        while (it < kMinIter || (it < kMaxIter && !conv) || last_round) {
+            // (A) per class: denominator in label order (get_abundance_for, em.rs:167-187)
+#pragma unroll
+            for (uint32_t j = 0; j < kEmPer; ++j) {
+                const uint32_t c = tid + j * kEmRNT;
+                if (c < K) {
+                    float denom = 0.0f;
+                    const uint32_t we = woff[c + 1];
+                    for (uint32_t w = woff[c]; w < we; ++w)
+                        denom += (vin[lw16[3 * w + 1]] + vin[lw16[3 * w + 2]]) + vin[lw16[3 * w]];
+                    inv[c] = denom > 0.0f ? (float)cnt[c] / denom : -1.0f;
+                }
+            }
+            if (tid == 0) s_flag[0] = 0;
+            __syncthreads();
+            // (B) per active entry: single-label count, then class contributions in class order
+            bool bad = false;
+#pragma unroll
+            for (uint32_t j = 0; j < kEmPer; ++j) {
+                const uint32_t a = tid + j * kEmRNT;
+                const bool valid = a < A;
+                const bool heavy = valid && e_q1[j] - e_q0[j] > kEmHeavy;
+                float x = 0.0f, old = 0.0f, ab = 0.0f;
+                if (valid) {
+                    if (e_cnt[j]) x += (float)e_cnt[j];
+                    old = vin[a];
+                    ab = (vin[e_sib[j] & 0xFFFFu] + vin[e_sib[j] >> 16]) + old;
+                    if (!heavy)
+                        for (uint32_t q = e_q0[j]; q < e_q1[j]; ++q) {
+                            const float iv = inv[mb16[q]];
+                            if (iv >= 0.0f) x += ab * iv;
+                        }
+                }
+                for (uint64_t hm = __ballot(heavy); hm; hm &= hm - 1) {
+                    const uint32_t L = (uint32_t)__builtin_ctzll(hm);
+                    const float r = wave_ordered_sum(bcast_f32(x, L), bcast_f32(ab, L), bcast_u32(e_q0[j], L), bcast_u32(e_q1[j], L),
+                                                     [&](uint32_t q) { return inv[mb16[q]]; });
+                    if (lane_id() == L) x = r;
+                }
+                if (valid) {
+                    acc[j] = x;
+                    if (x > kAlphaCheckCutoff && fabsf(old - x) > kRelDiffTol) bad = true;
+                }
+            }
+            if (bad) s_flag[0] = 1;
+            __syncthreads();  // every read of the old abundances is done
+            conv = s_flag[0] == 0;
+#pragma unroll
+            for (uint32_t j = 0; j < kEmPer; ++j) {
+                const uint32_t a = tid + j * kEmRNT;
+                if (a < A) vin[a] = acc[j];
+            }
+            if (tid == 0) vin[Z0] = 0.0f;  // inactive entries come out of every round as 0
+            ++it;
+            __syncthreads();
+            if (cfg.usa) {
+                if (last_round) break;
+                if (it >= kMinIter && conv) {
+#pragma unroll
+                    for (uint32_t j = 0; j < kEmPer; ++j) {
+                        const uint32_t a = tid + j * kEmRNT;
+                        if (a < A && vin[a] < kMinOutputAlpha) vin[a] = 0.0f;
+                    }
+                    last_round = true;
+                    __syncthreads();
+                }
+            }
+        }
+        it_dbg = it;
+        EM2_MARK(2);
+        // floor and emit the non-zero alphas in column order (active ids ascend with the column)
+        for (uint32_t base = 0; base < A; base += kEmRNT) {
+            const uint32_t a = base + tid;
+            float v = a < A ? vin[a] : 0.0f;
+            if (v < kMinOutputAlpha) v = 0.0f;
+            const uint32_t h = v > 0.0f;
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<kEmRNT>(h, s_ws, tot);
+            if (h) out[nout + ex] = make_uint2(act_col[a], __float_as_uint(v));
+            nout += tot;
+        }
+    } else {
+        // bigger cells: the two randomly accessed arrays (abundances, 1/denominators) still live in LDS when they
+        // fit; the entry / label-word / membership records are streamed, coalesced, from global memory
+        const bool mid = (A + 2) + K <= kEmLdsWords;
+        float* vin = mid ? reinterpret_cast<float*>(s_mem) : sc.a_in;
+        float* vout = sc.a_out;
+        float* inv = mid ? reinterpret_cast<float*>(s_mem) + (A + 2) : sc.inv;
+        const float uni = 1.0f / (float)cfg.num_alphas;
+        for (uint32_t a = threadIdx.x; a < A; a += kEmRNT) vin[a] = cfg.init_uniform ? uni : ((float)ent[a].x + 0.5f) * 1e-3f;
+        if (threadIdx.x == 0) { vin[Z0] = cfg.init_uniform ? uni : ((float)0u + 0.5f) * 1e-3f; vin[Z1] = 0.0f; }
+        __syncthreads();
+        uint32_t it = 0;
+        bool conv = true, last_round = false;
+        while (it < kMinIter || (it < kMaxIter && !conv) || last_round) {
+            // (A) per class: denominator in label order (get_abundance_for, em.rs:167-187)
+            // four classes per thread per trip, their loads issued together: the rounds are chains of dependent
+            // L2 round trips, and a thread walking its classes one at a time has only one chain in flight
+            for (uint32_t c0 = threadIdx.x; c0 < K; c0 += 4 * kEmRNT) {
+                uint32_t wb[4], we[4], cn[4];
+                uint4 l0[4], l1[4], l2[4];
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t c = c0 + j * kEmRNT;
+                    const bool ok = c < K;
+                    wb[j] = ok ? cls_woff[c] : 0u;
+                    we[j] = ok ? cls_woff[c + 1] : 0u;
+                    cn[j] = ok ? cls_cnt[c] : 0u;
+                }
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    l0[j] = lw3[wb[j] < we[j] ? wb[j] : 0u];
+                    l1[j] = lw3[wb[j] + 1 < we[j] ? wb[j] + 1 : 0u];
+                    l2[j] = lw3[wb[j] + 2 < we[j] ? wb[j] + 2 : 0u];
+                }
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t c = c0 + j * kEmRNT;
+                    if (c >= K) continue;
+                    float denom = 0.0f;
+                    if (wb[j] < we[j]) denom += (vin[l0[j].y] + vin[l0[j].z]) + vin[l0[j].x];
+                    if (wb[j] + 1 < we[j]) denom += (vin[l1[j].y] + vin[l1[j].z]) + vin[l1[j].x];
+                    if (wb[j] + 2 < we[j]) denom += (vin[l2[j].y] + vin[l2[j].z]) + vin[l2[j].x];
+                    for (uint32_t w = wb[j] + 3; w < we[j]; ++w) {
+                        const uint4 l = lw3[w];
+                        denom += (vin[l.y] + vin[l.z]) + vin[l.x];
+                    }
+                    inv[c] = denom > 0.0f ? (float)cn[j] / denom : -1.0f;
+                }
+            }
+            if (threadIdx.x == 0) s_flag[0] = 0;
+            __syncthreads();
+            // (B) per active entry: single-label count, then class contributions in class order
+            bool bad = false;
+            for (uint32_t a0 = threadIdx.x; a0 - lane_id() < A; a0 += 4 * kEmRNT) {  // wave-uniform trip count: the heavy-entry sums need every lane
+                uint4 e[4];
+                uint32_t qe[4], m0[4], m1[4];
+                float i0[4], i1[4];
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t a = a0 + j * kEmRNT;
+                    e[j] = ent[a < A ? a : A];         // ent[A] is the sentinel record
+                    qe[j] = ent[a < A ? a + 1 : A].w;
+                }
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    m0[j] = memb[e[j].w < qe[j] ? e[j].w : 0u];
+                    m1[j] = memb[e[j].w + 1 < qe[j] ? e[j].w + 1 : 0u];
+                }
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) { i0[j] = inv[m0[j]]; i1[j] = inv[m1[j]]; }
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t a = a0 + j * kEmRNT;
+                    const bool valid = a < A;
+                    const bool heavy = valid && qe[j] - e[j].w > 2 + kEmHeavy;
+                    float acc = 0.0f, old = 0.0f, ab = 0.0f;
+                    if (valid) {
+                        if (e[j].x) acc += (float)e[j].x;
+                        old = vin[a];
+                        ab = (vin[e[j].y] + vin[e[j].z]) + old;
+                        if (e[j].w < qe[j] && i0[j] >= 0.0f) acc += ab * i0[j];
+                        if (e[j].w + 1 < qe[j] && i1[j] >= 0.0f) acc += ab * i1[j];
+                        if (!heavy)
+                            for (uint32_t q = e[j].w + 2; q < qe[j]; ++q) {
+                                const float iv = inv[memb[q]];
+                                if (iv >= 0.0f) acc += ab * iv;
+                            }
+                    }
+                    for (uint64_t hm = __ballot(heavy); hm; hm &= hm - 1) {
+                        const uint32_t L = (uint32_t)__builtin_ctzll(hm);
+                        const float r = wave_ordered_sum(bcast_f32(acc, L), bcast_f32(ab, L), bcast_u32(e[j].w, L) + 2, bcast_u32(qe[j], L),
+                                                         [&](uint32_t q) { return inv[memb[q]]; });
+                        if (lane_id() == L) acc = r;
+                    }
+                    if (valid) {
+                        vout[a] = acc;
+                        if (acc > kAlphaCheckCutoff && fabsf(old - acc) > kRelDiffTol) bad = true;
+                    }
+                }
+            }
+            if (bad) s_flag[0] = 1;
+            __syncthreads();
+            conv = s_flag[0] == 0;
+            for (uint32_t a = threadIdx.x; a < A; a += kEmRNT) vin[a] = vout[a];
+            if (threadIdx.x == 0) vin[Z0] = 0.0f;  // inactive entries come out of every round as 0
+            ++it;
+            __syncthreads();
+            if (cfg.usa) {
+                if (last_round) break;
+                if (it >= kMinIter && conv) {
+                    for (uint32_t a = threadIdx.x; a < A; a += kEmRNT) if (vin[a] < kMinOutputAlpha) vin[a] = 0.0f;
+                    last_round = true;
+                    __syncthreads();
+                }
+            }
+        }
+        // 6. floor and emit the non-zero alphas in column order (active ids ascend with the column)
+        for (uint32_t base = 0; base < A; base += kEmRNT) {
+            const uint32_t a = base + threadIdx.x;
+            float v = a < A ? vin[a] : 0.0f;
+            if (v < kMinOutputAlpha) v = 0.0f;
+            const uint32_t h = v > 0.0f;
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<kEmRNT>(h, s_ws, tot);
+            if (h) out[nout + ex] = make_uint2(act_col[a], __float_as_uint(v));
+            nout += tot;
+        }
+    }
+    if (threadIdx.x == 0) out_nnz[cell] = nout;
+    EM2_MARK(3);
+#ifdef AFQ_EM_TIMING
+    if (threadIdx.x == 0 && (blockIdx.x % 1000) == 7) printf("em rounds cell nrec=%u A=%u K=%u Wc=%u need=%u fits=%d it=%u: load=%.3f rounds=%.3f out=%.3f total=%.3f ms\n", meta[cell].nrec, A, K, Wc, need, (int)fits, it_dbg, (double)(tm2[1]-tm2[0])/1e5, (double)(tm2[2]-tm2[1])/1e5, (double)(tm2[3]-tm2[2])/1e5, (double)(tm2[3]-tm2[0])/1e5);
+#endif
+}
+
+// EM output pairs -> final CSR
+__global__ __launch_bounds__(256) void k_compact_em(uint32_t n_cells, const uint64_t* __restrict__ em_off,
+                                                   const uint32_t* __restrict__ scratch, const uint32_t* __restrict__ nnz,
+                                                   const uint64_t* __restrict__ cell_ptr, uint32_t* __restrict__ gene,
+                                                   float* __restrict__ val) {
+    const uint32_t cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (cell >= n_cells) return;
+    const uint2* src = reinterpret_cast<const uint2*>(scratch + em_off[cell]);
+    const uint32_t n = nnz[cell];
+    const uint64_t o = cell_ptr[cell];
+    for (uint32_t i = lane_id(); i < n; i += 64) {
+        const uint2 p = src[i];
+        gene[o + i] = p.x;
+        val[o + i] = __uint_as_float(p.y);
+    }
+}
+
+// words of per-cell EM scratch for nU single-label columns, W label words, M ambiguous molecules
+uint64_t em_scratch_words(uint32_t nU, uint32_t W, uint32_t M, bool usa) {
+    const uint64_t capS = ((uint64_t)nU + W) * (usa ? 3u : 1u);
+    // mirrors the carve at the top of k_em
+    uint64_t w = 2 * (capS + 1)            // out
+                 + 2 * ((uint64_t)W + 1)   // inv_pairs
+                 + 3 * ((uint64_t)M + 1)   // order, cls_first, cls_cnt
+                 + ((uint64_t)M + 2)       // cls_woff
+                 + 2 * ((uint64_t)W + 1)   // cls_w, cls_sidx
+                 + ((uint64_t)M + 1)       // inv
+                 + 4 * (capS + 1)          // support, sib1, sib2, ucnt
+                 + 2 * (capS + 2)          // a_in, a_out
+                 + (capS + 2)              // slot_off
+                 + (capS + 1)              // aid
+                 + 4 * ((uint64_t)nU + W + 2)  // ent
+                 + 4 * ((uint64_t)W + 1)   // lw3
+                 + ((uint64_t)nU + W + 2)  // act_col
+                 + ((uint64_t)W + 1)       // memb
+                 + 4;                      // alignment slack for the 16-byte records
+    return (w + 3) & ~3ull;  // keep slices 16-byte aligned
+}
+
+void launch_em(hipStream_t s, const ResolveArgs& a, uint32_t n_cells, const uint64_t* em_off, uint32_t* scratch,
+               uint32_t* out_nnz, void* em_hdr_v, const uint32_t* em_order, uint32_t num_alphas, uint32_t init_uniform) {
+    uint4* em_hdr = reinterpret_cast<uint4*>(em_hdr_v);
+    if (!n_cells) return;
+    EmCfg cfg{a.usa, num_alphas, a.num_rows / 3, 2 * (a.num_rows / 3), init_uniform};
+    AFQ_LAUNCH(k_em, n_cells, kEmNT, s, a.meta, a.nnz, a.keys0, a.keys1, a.lab, a.lab_cnt, em_off, scratch, out_nnz, em_hdr, em_order, cfg);
+    AFQ_LAUNCH(k_em_rounds, n_cells, kEmRNT, s, a.meta, a.nnz, a.lab_cnt, em_off, scratch, out_nnz, em_hdr, em_order, cfg);
+}
+
+void launch_compact_em(hipStream_t s, uint32_t n_cells, const uint64_t* em_off, const uint32_t* scratch, const uint32_t* nnz,
+                       const uint64_t* cell_ptr, uint32_t* gene, float* val) {
+    if (!n_cells) return;
+    AFQ_LAUNCH(k_compact_em, (n_cells + 3) / 4, 256, s, n_cells, em_off, scratch, nnz, cell_ptr, gene, val);
+}
+
+}  // namespace afq

@@ -236,4 +236,10 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* a, uint32_t 
     return lo;
 }
 
+// USA gene-id convention (3-column tg-map): spliced ids even, the unspliced sibling = id | 1
+__device__ __forceinline__ bool is_spliced(uint32_t g) { return (g & 1u) == 0; }
+__device__ __forceinline__ bool same_gene(uint32_t a, uint32_t b) { return (a & ~1u) == (b & ~1u); }
+
+#define AFQ_LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
+
 }  // namespace afq
