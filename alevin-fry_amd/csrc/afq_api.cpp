@@ -159,6 +159,7 @@ struct afq_ctx {
     const uint8_t* d_bytes = nullptr;
     size_t n_bytes = 0;
     DevBuf d_chunk_off, d_hdr;
+    DevBuf atac[16];  // afq_atac_dedup's device buffers, kept between calls
     // Two sets of per-range device state: while the rows of range i cross PCIe, the kernels of range i+1 run.
     RangeState rs[2];
     bool all_aligned = true;  // every chunk offset is a multiple of 4
@@ -723,6 +724,7 @@ void afq_destroy(afq_ctx* c) {
     }
     DevBuf* bufs[] = {&c->d_t2g, &c->d_bytes_own, &c->d_chunk_off, &c->d_hdr};
     for (auto b : bufs) b->release();
+    for (auto& b : c->atac) b.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->res) pool_put(c->res);
     if (c->pool) {
@@ -848,61 +850,79 @@ int afq_atac_dedup(afq_ctx* c, const uint32_t* ref, const uint32_t* start, const
     for (uint32_t i = 0; i < n_cells; ++i)
         if (cell_ptr[i + 1] < cell_ptr[i] || cell_ptr[i + 1] - cell_ptr[i] > 0x7FFFFFFFull)
             return fail(c, AFQ_ERR_INVALID_ARG, "cell_ptr must be non-decreasing");
-    DevBuf d_ref, d_start, d_flen, d_ptr, d_scr, d_oref, d_ostart, d_oflen, d_ocnt, d_on;
-    auto cleanup = [&]() { for (DevBuf* b : {&d_ref, &d_start, &d_flen, &d_ptr, &d_scr, &d_oref, &d_ostart, &d_oflen, &d_ocnt, &d_on}) b->release(); };
+    HostClock hc;
+    // device buffers live in the context and are reused by the next call (hipMalloc/hipFree of GBs is not free)
+    DevBuf &d_ref = c->atac[0], &d_start = c->atac[1], &d_flen = c->atac[2], &d_ptr = c->atac[3], &d_scr = c->atac[4],
+           &d_oref = c->atac[5], &d_ostart = c->atac[6], &d_oflen = c->atac[7], &d_ocnt = c->atac[8], &d_on = c->atac[9],
+           &d_optr = c->atac[10], &d_cref = c->atac[11], &d_cstart = c->atac[12], &d_cflen = c->atac[13], &d_ccnt = c->atac[14],
+           &d_flag = c->atac[15];
     hipStream_t s = c->stream;
     const uint64_t n1 = std::max<uint64_t>(n, 1);
     hipError_t e = hipSuccess;
     auto T = [&](hipError_t x) { if (e == hipSuccess) e = x; };
     T(d_ref.ensure(4 * n1)); T(d_start.ensure(4 * n1)); T(d_flen.ensure(2 * n1)); T(d_ptr.ensure(8ull * (n_cells + 1)));
     T(d_scr.ensure(16 * n1)); T(d_oref.ensure(4 * n1)); T(d_ostart.ensure(4 * n1)); T(d_oflen.ensure(2 * n1));
-    T(d_ocnt.ensure(2 * n1)); T(d_on.ensure(4ull * std::max<uint32_t>(n_cells, 1)));
+    T(d_ocnt.ensure(2 * n1)); T(d_on.ensure(4ull * std::max<uint32_t>(n_cells, 1))); T(d_optr.ensure(8ull * (n_cells + 1)));
+    T(d_flag.ensure(4));
     std::vector<uint32_t> on(n_cells);
-    std::vector<uint32_t> t_ref(n), t_start(n);
-    std::vector<uint16_t> t_flen(n), t_cnt(n);
     if (e == hipSuccess && n) {
         T(hipMemcpyAsync(d_ref.p, ref, 4 * n, hipMemcpyHostToDevice, s));
         T(hipMemcpyAsync(d_start.p, start, 4 * n, hipMemcpyHostToDevice, s));
         T(hipMemcpyAsync(d_flen.p, frag_len, 2 * n, hipMemcpyHostToDevice, s));
     }
     if (e == hipSuccess) T(hipMemcpyAsync(d_ptr.p, cell_ptr, 8ull * (n_cells + 1), hipMemcpyHostToDevice, s));
+    if (e == hipSuccess) T(hipMemsetAsync(d_flag.p, 0, 4, s));
+    if (hc.on) { T(hipStreamSynchronize(s)); hc.lap("atac: alloc + H2D"); }
+    uint32_t wide = 0;
     if (e == hipSuccess) {
+        launch_atac_dedup64(s, n_cells, d_ref.as<uint32_t>(), d_start.as<uint32_t>(), d_flen.as<uint16_t>(), d_ptr.as<uint64_t>(),
+                            d_scr.p, d_oref.as<uint32_t>(), d_ostart.as<uint32_t>(), d_oflen.as<uint16_t>(),
+                            d_ocnt.as<uint16_t>(), d_on.as<uint32_t>(), d_flag.as<uint32_t>());
+        T(hipGetLastError());
+        T(hipMemcpyAsync(&wide, d_flag.p, 4, hipMemcpyDeviceToHost, s));
+        T(hipStreamSynchronize(s));
+    }
+    if (e == hipSuccess && wide) {  // a reference id >= 65536: the 16-byte-record kernel
         launch_atac_dedup(s, n_cells, d_ref.as<uint32_t>(), d_start.as<uint32_t>(), d_flen.as<uint16_t>(), d_ptr.as<uint64_t>(),
                           d_scr.p, d_oref.as<uint32_t>(), d_ostart.as<uint32_t>(), d_oflen.as<uint16_t>(),
                           d_ocnt.as<uint16_t>(), d_on.as<uint32_t>());
         T(hipGetLastError());
     }
     if (e == hipSuccess && n_cells) T(hipMemcpyAsync(on.data(), d_on.p, 4ull * n_cells, hipMemcpyDeviceToHost, s));
-    if (e == hipSuccess && n) {
-        T(hipMemcpyAsync(t_ref.data(), d_oref.p, 4 * n, hipMemcpyDeviceToHost, s));
-        T(hipMemcpyAsync(t_start.data(), d_ostart.p, 4 * n, hipMemcpyDeviceToHost, s));
-        T(hipMemcpyAsync(t_flen.data(), d_oflen.p, 2 * n, hipMemcpyDeviceToHost, s));
-        T(hipMemcpyAsync(t_cnt.data(), d_ocnt.p, 2 * n, hipMemcpyDeviceToHost, s));
-    }
     if (e == hipSuccess) T(hipStreamSynchronize(s));
-    cleanup();
+    hc.lap("atac: kernel");
     if (e != hipSuccess) return fail(c, e == hipErrorOutOfMemory ? AFQ_ERR_OOM : AFQ_ERR_HIP, std::string("afq_atac_dedup: ") + hipGetErrorString(e));
-    uint64_t tot = 0;
-    for (uint32_t i = 0; i < n_cells; ++i) tot += on[i];
     uint64_t* optr = (uint64_t*)std::malloc(8ull * (n_cells + 1));
-    uint32_t* oref = (uint32_t*)std::malloc(4 * std::max<uint64_t>(tot, 1));
-    uint32_t* ostart = (uint32_t*)std::malloc(4 * std::max<uint64_t>(tot, 1));
-    uint16_t* oflen = (uint16_t*)std::malloc(2 * std::max<uint64_t>(tot, 1));
-    uint16_t* ocnt = (uint16_t*)std::malloc(2 * std::max<uint64_t>(tot, 1));
-    if (!optr || !oref || !ostart || !oflen || !ocnt) {
+    if (!optr) return fail(c, AFQ_ERR_OOM, "afq_atac_dedup: host allocation failed");
+    optr[0] = 0;
+    for (uint32_t i = 0; i < n_cells; ++i) optr[i + 1] = optr[i] + on[i];
+    const uint64_t tot = optr[n_cells], tot1 = std::max<uint64_t>(tot, 1);
+    uint32_t* oref = (uint32_t*)std::malloc(4 * tot1);
+    uint32_t* ostart = (uint32_t*)std::malloc(4 * tot1);
+    uint16_t* oflen = (uint16_t*)std::malloc(2 * tot1);
+    uint16_t* ocnt = (uint16_t*)std::malloc(2 * tot1);
+    if (!oref || !ostart || !oflen || !ocnt) {
         std::free(optr); std::free(oref); std::free(ostart); std::free(oflen); std::free(ocnt);
         return fail(c, AFQ_ERR_OOM, "afq_atac_dedup: host allocation failed");
     }
-    uint64_t w = 0;
-    optr[0] = 0;
-    for (uint32_t i = 0; i < n_cells; ++i) {  // per-cell output sits at the cell's input offset on the device
-        const uint64_t b0 = cell_ptr[i];
-        std::memcpy(oref + w, t_ref.data() + b0, 4ull * on[i]);
-        std::memcpy(ostart + w, t_start.data() + b0, 4ull * on[i]);
-        std::memcpy(oflen + w, t_flen.data() + b0, 2ull * on[i]);
-        std::memcpy(ocnt + w, t_cnt.data() + b0, 2ull * on[i]);
-        w += on[i];
-        optr[i + 1] = w;
+    // dense runs on the device, then straight into the caller's arrays
+    T(d_cref.ensure(4 * tot1)); T(d_cstart.ensure(4 * tot1)); T(d_cflen.ensure(2 * tot1)); T(d_ccnt.ensure(2 * tot1));
+    if (e == hipSuccess) T(hipMemcpyAsync(d_optr.p, optr, 8ull * (n_cells + 1), hipMemcpyHostToDevice, s));
+    if (e == hipSuccess && tot) {
+        launch_atac_compact(s, n_cells, d_ptr.as<uint64_t>(), d_optr.as<uint64_t>(), d_oref.as<uint32_t>(), d_ostart.as<uint32_t>(),
+                            d_oflen.as<uint16_t>(), d_ocnt.as<uint16_t>(), d_cref.as<uint32_t>(), d_cstart.as<uint32_t>(),
+                            d_cflen.as<uint16_t>(), d_ccnt.as<uint16_t>());
+        T(hipGetLastError());
+        T(hipMemcpyAsync(oref, d_cref.p, 4 * tot, hipMemcpyDeviceToHost, s));
+        T(hipMemcpyAsync(ostart, d_cstart.p, 4 * tot, hipMemcpyDeviceToHost, s));
+        T(hipMemcpyAsync(oflen, d_cflen.p, 2 * tot, hipMemcpyDeviceToHost, s));
+        T(hipMemcpyAsync(ocnt, d_ccnt.p, 2 * tot, hipMemcpyDeviceToHost, s));
+    }
+    if (e == hipSuccess) T(hipStreamSynchronize(s));
+    hc.lap("atac: compact + D2H");
+    if (e != hipSuccess) {
+        std::free(optr); std::free(oref); std::free(ostart); std::free(oflen); std::free(ocnt);
+        return fail(c, e == hipErrorOutOfMemory ? AFQ_ERR_OOM : AFQ_ERR_HIP, std::string("afq_atac_dedup: ") + hipGetErrorString(e));
     }
     *out_cell_ptr = optr; *out_ref = oref; *out_start = ostart; *out_frag_len = oflen; *out_count = ocnt;
     return 0;

@@ -75,6 +75,12 @@ void launch_compact_em(hipStream_t s, uint32_t n_cells, const uint64_t* em_off, 
 void launch_atac_dedup(hipStream_t s, uint32_t n_cells, const uint32_t* ref, const uint32_t* start, const uint16_t* flen,
                        const uint64_t* cell_ptr, void* scratch /* 16 B per fragment */, uint32_t* o_ref, uint32_t* o_start,
                        uint16_t* o_flen, uint16_t* o_cnt, uint32_t* o_n);
+void launch_atac_dedup64(hipStream_t s, uint32_t n_cells, const uint32_t* ref, const uint32_t* start, const uint16_t* flen,
+                         const uint64_t* cell_ptr, void* scratch, uint32_t* o_ref, uint32_t* o_start, uint16_t* o_flen,
+                         uint16_t* o_cnt, uint32_t* o_n, uint32_t* flag);
+void launch_atac_compact(hipStream_t s, uint32_t n_cells, const uint64_t* cell_ptr, const uint64_t* out_ptr, const uint32_t* i_ref,
+                         const uint32_t* i_start, const uint16_t* i_flen, const uint16_t* i_cnt, uint32_t* o_ref, uint32_t* o_start,
+                         uint16_t* o_flen, uint16_t* o_cnt);
 void launch_resolve(hipStream_t s, const ResolveArgs& a);
 void launch_resolve_big(hipStream_t s, const ResolveArgs& a);
 void launch_cell_hist(hipStream_t s, const ResolveArgs& a);

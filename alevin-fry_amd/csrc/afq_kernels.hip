@@ -1094,6 +1094,67 @@ __global__ __launch_bounds__(kAtacNT) void k_atac_dedup(const uint32_t* __restri
     if (threadIdx.x == 0) o_n[cell] = carry;
 }
 
+// Fast variant for reference ids below 65536 (every chromosome-level genome): one 64-bit key
+// ref:16 | start:32 | frag_len:16 per fragment - its integer order is the (ref, start, frag_len) order - sorted
+// with the LDS-tiled bitonic network (16384 keys = 128 KiB per tile) instead of 16-byte records out of global
+// memory.  A cell that holds a larger reference id raises *flag and the host reruns the batch with k_atac_dedup.
+__global__ __launch_bounds__(kAtacNT) void k_atac_dedup64(const uint32_t* __restrict__ ref, const uint32_t* __restrict__ start,
+                                                         const uint16_t* __restrict__ flen,
+                                                         const uint64_t* __restrict__ cell_ptr, uint64_t* __restrict__ scratch,
+                                                         uint32_t* __restrict__ o_ref, uint32_t* __restrict__ o_start,
+                                                         uint16_t* __restrict__ o_flen, uint16_t* __restrict__ o_cnt,
+                                                         uint32_t* __restrict__ o_n, uint32_t* __restrict__ flag) {
+    __shared__ uint32_t s_ws[kAtacNT / 64];
+    __shared__ __attribute__((aligned(16))) uint64_t s_tile[16384];
+    const uint32_t cell = blockIdx.x;
+    const uint64_t b0 = cell_ptr[cell];
+    const uint32_t n = (uint32_t)(cell_ptr[cell + 1] - b0);
+    uint64_t* f = scratch + b0;
+    bool wide = false;
+    for (uint32_t i = threadIdx.x; i < n; i += kAtacNT) {
+        const uint32_t r = ref[b0 + i];
+        wide = wide || r > 0xFFFFu;
+        f[i] = ((uint64_t)r << 48) | ((uint64_t)start[b0 + i] << 16) | flen[b0 + i];
+    }
+    if (wide) *flag = 1;
+    __syncthreads();
+    tiled_bitonic_sort_by<kAtacNT, 16384>(f, n, [](uint64_t a, uint64_t b) { return a > b; }, s_tile);
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n; base += kAtacNT) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t h = (i < n) && (i == 0 || f[i] != f[i - 1]);
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<kAtacNT>(h, s_ws, tot);
+        if (h) {
+            const uint64_t k = f[i];
+            uint32_t e = i + 1;
+            while (e < n && f[e] == k) ++e;
+            const uint64_t o = b0 + carry + ex;
+            o_ref[o] = (uint32_t)(k >> 48);
+            o_start[o] = (uint32_t)(k >> 16);
+            o_flen[o] = (uint16_t)k;
+            o_cnt[o] = (uint16_t)(e - i);  // `count as u16`, deduplicate.rs:220
+        }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) o_n[cell] = carry;
+}
+
+// per-cell results (at the cell's input offset) -> one dense run per array, cells in order
+__global__ __launch_bounds__(256) void k_atac_compact(const uint64_t* __restrict__ cell_ptr, const uint64_t* __restrict__ out_ptr,
+                                                     const uint32_t* __restrict__ i_ref, const uint32_t* __restrict__ i_start,
+                                                     const uint16_t* __restrict__ i_flen, const uint16_t* __restrict__ i_cnt,
+                                                     uint32_t* __restrict__ o_ref, uint32_t* __restrict__ o_start,
+                                                     uint16_t* __restrict__ o_flen, uint16_t* __restrict__ o_cnt) {
+    const uint32_t cell = blockIdx.x;
+    const uint64_t src = cell_ptr[cell], dst = out_ptr[cell];
+    const uint32_t n = (uint32_t)(out_ptr[cell + 1] - dst);
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        o_ref[dst + i] = i_ref[src + i]; o_start[dst + i] = i_start[src + i];
+        o_flen[dst + i] = i_flen[src + i]; o_cnt[dst + i] = i_cnt[src + i];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // launchers
 
@@ -1166,6 +1227,21 @@ void launch_atac_dedup(hipStream_t s, uint32_t n_cells, const uint32_t* ref, con
     if (!n_cells) return;
     AFQ_LAUNCH(k_atac_dedup, n_cells, kAtacNT, s, ref, start, flen, cell_ptr, reinterpret_cast<Frag*>(scratch), o_ref, o_start,
                o_flen, o_cnt, o_n);
+}
+
+void launch_atac_dedup64(hipStream_t s, uint32_t n_cells, const uint32_t* ref, const uint32_t* start, const uint16_t* flen,
+                         const uint64_t* cell_ptr, void* scratch, uint32_t* o_ref, uint32_t* o_start, uint16_t* o_flen,
+                         uint16_t* o_cnt, uint32_t* o_n, uint32_t* flag) {
+    if (!n_cells) return;
+    AFQ_LAUNCH(k_atac_dedup64, n_cells, kAtacNT, s, ref, start, flen, cell_ptr, reinterpret_cast<uint64_t*>(scratch), o_ref, o_start,
+               o_flen, o_cnt, o_n, flag);
+}
+
+void launch_atac_compact(hipStream_t s, uint32_t n_cells, const uint64_t* cell_ptr, const uint64_t* out_ptr, const uint32_t* i_ref,
+                         const uint32_t* i_start, const uint16_t* i_flen, const uint16_t* i_cnt, uint32_t* o_ref, uint32_t* o_start,
+                         uint16_t* o_flen, uint16_t* o_cnt) {
+    if (!n_cells) return;
+    AFQ_LAUNCH(k_atac_compact, n_cells, 256, s, cell_ptr, out_ptr, i_ref, i_start, i_flen, i_cnt, o_ref, o_start, o_flen, o_cnt);
 }
 
 void launch_cell_hist(hipStream_t s, const ResolveArgs& a) {

@@ -216,6 +216,21 @@ def test_atac_dedup(oracle):
     for g, w in zip(got, want):
         assert np.array_equal(g, w)
     assert (66000 & 0xFFFF) in got[4][int(got[0][-2]):].tolist()
+    # reference ids that do not fit the packed 64-bit key (>= 65536: contig-level assemblies) take the 16-byte-record
+    # kernel; and a second call on the same context reuses its device buffers
+    ref2 = ref.copy()
+    ref2[::7] += 70000
+    want2 = oracle.atac_dedup(ref2, start, flen, ptr)
+    q = pkg.Quantifier(pkg.WorkerConfig.for_resolution("cr-like", num_genes=1, num_rows=1), np.zeros(1, np.uint32))
+    try:
+        got2 = q.atac_dedup(ref2, start, flen, ptr)
+        got1 = q.atac_dedup(ref, start, flen, ptr)
+    finally:
+        q.close()
+    for g, w in zip(got2, want2):
+        assert np.array_equal(g, w)
+    for g, w in zip(got1, want):
+        assert np.array_equal(g, w)
 
 
 @pytest.mark.parametrize("usa", [False, True])
