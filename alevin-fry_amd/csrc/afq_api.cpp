@@ -54,9 +54,9 @@ struct DevBuf {
     template <class T> T* as() { return reinterpret_cast<T*>(p); }
 };
 
-enum KernelId { K_GATHER = 0, K_DECODE_PAR, K_DECODE, K_HIST, K_BSCAN, K_SCATTER, K_RESOLVE, K_RESOLVE_BIG, K_PUG, K_CELL_HIST, K_EM, K_COMPACT, K_COUNT };
+enum KernelId { K_GATHER = 0, K_DECODE_PAR, K_DECODE, K_HIST, K_BSCAN, K_SCATTER, K_RESOLVE, K_RESOLVE_BIG, K_PUG, K_CELL_HIST, K_EM, K_COMPACT, K_ATAC, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"k_gather_headers", "k_decode_par", "k_decode", "k_hist", "k_bucket_scan", "k_scatter",
-                                           "k_resolve", "k_resolve_big", "k_pug_cell", "k_cell_hist", "k_em", "k_compact"};
+                                           "k_resolve", "k_resolve_big", "k_pug_cell", "k_cell_hist", "k_em", "k_compact", "k_atac_dedup"};
 
 struct TimedLaunch { int id; hipEvent_t a, b; };
 
@@ -874,15 +874,20 @@ int afq_atac_dedup(afq_ctx* c, const uint32_t* ref, const uint32_t* start, const
     if (e == hipSuccess) T(hipMemsetAsync(d_flag.p, 0, 4, s));
     if (hc.on) { T(hipStreamSynchronize(s)); hc.lap("atac: alloc + H2D"); }
     uint32_t wide = 0;
+    for (int i = 0; i < K_COUNT; ++i) { c->k_ms[i] = 0; c->k_launches[i] = 0; }
     if (e == hipSuccess) {
+        ScopedTimer t(c, K_ATAC, s);
         launch_atac_dedup64(s, n_cells, d_ref.as<uint32_t>(), d_start.as<uint32_t>(), d_flen.as<uint16_t>(), d_ptr.as<uint64_t>(),
                             d_scr.p, d_oref.as<uint32_t>(), d_ostart.as<uint32_t>(), d_oflen.as<uint16_t>(),
                             d_ocnt.as<uint16_t>(), d_on.as<uint32_t>(), d_flag.as<uint32_t>());
         T(hipGetLastError());
+    }
+    if (e == hipSuccess) {
         T(hipMemcpyAsync(&wide, d_flag.p, 4, hipMemcpyDeviceToHost, s));
         T(hipStreamSynchronize(s));
     }
     if (e == hipSuccess && wide) {  // a reference id >= 65536: the 16-byte-record kernel
+        ScopedTimer t(c, K_ATAC, s);
         launch_atac_dedup(s, n_cells, d_ref.as<uint32_t>(), d_start.as<uint32_t>(), d_flen.as<uint16_t>(), d_ptr.as<uint64_t>(),
                           d_scr.p, d_oref.as<uint32_t>(), d_ostart.as<uint32_t>(), d_oflen.as<uint16_t>(),
                           d_ocnt.as<uint16_t>(), d_on.as<uint32_t>());
@@ -920,6 +925,7 @@ int afq_atac_dedup(afq_ctx* c, const uint32_t* ref, const uint32_t* start, const
     }
     if (e == hipSuccess) T(hipStreamSynchronize(s));
     hc.lap("atac: compact + D2H");
+    harvest_timers(c);
     if (e != hipSuccess) {
         std::free(optr); std::free(oref); std::free(ostart); std::free(oflen); std::free(ocnt);
         return fail(c, e == hipErrorOutOfMemory ? AFQ_ERR_OOM : AFQ_ERR_HIP, std::string("afq_atac_dedup: ") + hipGetErrorString(e));
