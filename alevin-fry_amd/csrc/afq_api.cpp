@@ -14,6 +14,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/afquant.h"
@@ -160,6 +161,8 @@ struct afq_ctx {
     size_t n_bytes = 0;
     DevBuf d_chunk_off, d_hdr;
     DevBuf atac[16];  // afq_atac_dedup's device buffers, kept between calls
+    void* stage[3] = {nullptr, nullptr, nullptr};          // pinned staging for large host->device input copies
+    hipEvent_t stage_ev[3] = {nullptr, nullptr, nullptr};
     // Two sets of per-range device state: while the rows of range i cross PCIe, the kernels of range i+1 run.
     RangeState rs[2];
     bool all_aligned = true;  // every chunk offset is a multiple of 4
@@ -634,6 +637,37 @@ int finish_range(afq_ctx* c, int slot) {
     return 0;
 }
 
+// Large pageable (or file-mapped) input -> device: the runtime's own pageable path is one staging thread (~8 GB/s,
+// slower still when every page of a mapped file faults on first touch); here several threads fill pinned pieces
+// while the previous piece is on the wire.
+constexpr size_t kStagePiece = 64u << 20;
+int staged_h2d(afq_ctx* c, uint8_t* dst, const uint8_t* src, size_t n, hipStream_t s) {
+    if (n < 2 * kStagePiece) { HIP_TRY(c, hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, s)); return 0; }
+    for (int i = 0; i < 3; ++i) {
+        if (!c->stage[i]) HIP_TRY(c, hipHostMalloc(&c->stage[i], kStagePiece, hipHostMallocDefault));
+        if (!c->stage_ev[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming));
+    }
+    const unsigned nth = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    size_t off = 0;
+    for (int i = 0; off < n; ++i) {
+        const int b = i % 3;
+        const size_t len = std::min(kStagePiece, n - off);
+        if (i >= 3) HIP_TRY(c, hipEventSynchronize(c->stage_ev[b]));   // the copy that last used this piece is done
+        std::vector<std::thread> th;
+        const size_t slice = (len + nth - 1) / nth;
+        for (unsigned t = 0; t < nth; ++t) {
+            const size_t a = t * slice, e = std::min(len, a + slice);
+            if (a >= e) break;
+            th.emplace_back([=]() { std::memcpy((uint8_t*)c->stage[b] + a, src + off + a, e - a); });
+        }
+        for (auto& x : th) x.join();
+        HIP_TRY(c, hipMemcpyAsync(dst + off, c->stage[b], len, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipEventRecord(c->stage_ev[b], s));
+        off += len;
+    }
+    return 0;
+}
+
 int submit_common(afq_ctx* c, uint32_t n_cells, uint64_t first_cell_index) {
     c->n_cells = n_cells;
     c->first_cell_index = first_cell_index;
@@ -725,6 +759,8 @@ void afq_destroy(afq_ctx* c) {
     DevBuf* bufs[] = {&c->d_t2g, &c->d_bytes_own, &c->d_chunk_off, &c->d_hdr};
     for (auto b : bufs) b->release();
     for (auto& b : c->atac) b.release();
+    for (auto& p : c->stage) if (p) (void)hipHostFree(p);
+    for (auto& ev : c->stage_ev) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->res) pool_put(c->res);
     if (c->pool) {
@@ -770,7 +806,7 @@ int afq_submit(afq_ctx* c, const uint8_t* bytes, size_t n_bytes, const uint64_t*
     }
     HIP_TRY(c, c->d_bytes_own.ensure(n_bytes + shift + 16));
     if (shift) HIP_TRY(c, hipMemsetAsync(c->d_bytes_own.p, 0, 4, c->stream));
-    if (n_bytes) HIP_TRY(c, hipMemcpyAsync((uint8_t*)c->d_bytes_own.p + shift, bytes, n_bytes, hipMemcpyHostToDevice, c->stream));
+    if (n_bytes) { int rc2 = staged_h2d(c, (uint8_t*)c->d_bytes_own.p + shift, bytes, n_bytes, c->stream); if (rc2) return rc2; }
     HIP_TRY(c, hipMemsetAsync((uint8_t*)c->d_bytes_own.p + shift + n_bytes, 0, 16, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller keeps ownership of `bytes`
     if (shift) for (auto& o : c->chunk_off) o += shift;

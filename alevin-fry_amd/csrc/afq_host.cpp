@@ -434,9 +434,13 @@ int afq_quantify(const afq_quant_opts* o) {
 
     // batches of chunks to the device; rows come back in cell order
     const uint64_t batch_bytes = o->batch_bytes ? o->batch_bytes : (1ull << 30);
-    std::vector<uint64_t> tri_rc; std::vector<float> tri_v;  // row<<32|col, value
+    std::vector<uint32_t> all_gene; std::vector<float> all_val;   // the count matrix as CSR (bulk-appended per batch)
+    std::vector<uint64_t> row_ptr(1, 0);
     std::vector<uint64_t> alt_cells, empty_cells, tiny_cells;
     uint64_t total_records = 0, row_index = 0;
+    double t_submit = 0, t_collect = 0, t_rows = 0;
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     for (size_t c0 = 0; c0 < chunk_off.size();) {
         size_t c1 = c0; uint64_t bytes = 0;
         while (c1 < chunk_off.size()) { uint32_t nb; std::memcpy(&nb, rad.data() + chunk_off[c1], 4); if (c1 > c0 && bytes + nb > batch_bytes) break; bytes += nb; ++c1; }
@@ -446,9 +450,13 @@ int afq_quantify(const afq_quant_opts* o) {
         for (size_t k = c0; k < c1; ++k) rel[k - c0] = chunk_off[k] - span0;
         uint32_t last_nb; std::memcpy(&last_nb, rad.data() + chunk_off[c1 - 1], 4);
         const uint64_t span1 = chunk_off[c1 - 1] + last_nb;   // with --quant-subset the span also covers chunks that were filtered out
+        auto ta = now();
         rc = afq_submit(ctx, rad.data() + span0, (size_t)(span1 - span0), rel.data(), (uint32_t)(c1 - c0), c0);
+        auto tb = now();
         afq_result res{};
         if (!rc) rc = afq_collect(ctx, &res);
+        auto tc = now();
+        t_submit += secs(ta, tb); t_collect += secs(tb, tc);
         if (rc) { std::string m = afq_last_error(ctx); afq_destroy(ctx); std::fclose(rows_f); std::fclose(feat_f); return hfail(rc, m); }
         for (uint64_t i = 0; i < res.n_cells; ++i) {
             const uint64_t a = res.cell_ptr[i], b = res.cell_ptr[i + 1];
@@ -468,16 +476,20 @@ int afq_quantify(const afq_quant_opts* o) {
             std::fprintf(rows_f, "%s\n", bcs.c_str());
             std::fprintf(feat_f, "%s\t%llu\t%u\t%s\t%s\t%s\t%s\t%u\t%u\n", bcs.c_str(), (unsigned long long)(nrec + num_unmapped), nrec,
                          f32s(sum).c_str(), f32s(mapping_rate).c_str(), f32s(dedup_rate).c_str(), f32s(mean_by_max).c_str(), num_expr, over);
-            for (uint64_t k = a; k < b; ++k) { tri_rc.push_back((row_index << 32) | res.gene[k]); tri_v.push_back(res.val[k]); }
+            row_ptr.push_back(row_ptr.back() + (b - a));
             if (res.flags[i] & AFQ_CELL_ALT_RES) alt_cells.push_back(cell_num);
             if (res.flags[i] & AFQ_CELL_EMPTY) empty_cells.push_back(cell_num);
             if (res.flags[i] & AFQ_CELL_TINY_PATH) tiny_cells.push_back(cell_num);
             total_records += nrec;
             ++row_index;
         }
+        all_gene.insert(all_gene.end(), res.gene, res.gene + res.nnz);
+        all_val.insert(all_val.end(), res.val, res.val + res.nnz);
         afq_result_release(&res);
+        t_rows += secs(tc, now());
         c0 = c1;
     }
+    if (pc.on) std::fprintf(stderr, "[afquant]   afq_submit %.3f s, afq_collect %.3f s, per-cell rows %.3f s\n", t_submit, t_collect, t_rows);
     afq_destroy(ctx);
     std::fclose(rows_f); std::fclose(feat_f);
     pc.lap("device batches + per-cell rows");
@@ -485,9 +497,10 @@ int afq_quantify(const afq_quant_opts* o) {
     {
         FILE* m = std::fopen((outd + "/alevin/quants_mat.mtx").c_str(), "w");
         if (!m) return hfail(AFQ_ERR_BAD_INPUT, "could not create quants_mat.mtx");
-        std::fprintf(m, "%%%%MatrixMarket matrix coordinate real general\n%% written by sprs\n%llu %u %zu\n", (unsigned long long)row_index, cfg.num_rows, tri_v.size());
-        // the entries are formatted by -t threads into per-slice buffers (same text as one fprintf per entry), written in order
-        const size_t nz = tri_v.size();
+        std::fprintf(m, "%%%%MatrixMarket matrix coordinate real general\n%% written by sprs\n%llu %u %zu\n", (unsigned long long)row_index, cfg.num_rows, all_val.size());
+        // the entries are formatted by -t threads into per-slice buffers (same text as one fprintf per entry), written in order;
+        // a slice is a run of consecutive entries, its first row found by binary search in row_ptr
+        const size_t nz = all_val.size();
         const unsigned nth = std::max(1u, std::min(o->num_threads ? o->num_threads : 1u, 64u));
         const size_t slice = 1u << 20;
         for (size_t base = 0; base < nz; base += slice * nth) {
@@ -500,10 +513,12 @@ int afq_quantify(const afq_quant_opts* o) {
                     std::string& out = bufs[t];
                     out.resize((b - a) * 112);  // 2 x <= 20 digits + an f32 in positional notation (<= 48 chars) + separators
                     char* p = &out[0];
+                    size_t row = (size_t)(std::upper_bound(row_ptr.begin(), row_ptr.end(), (uint64_t)a) - row_ptr.begin()) - 1;
                     for (size_t k = a; k < b; ++k) {
-                        p = put_u64(p, (unsigned long long)(tri_rc[k] >> 32) + 1); *p++ = ' ';
-                        p = put_u64(p, (unsigned long long)(tri_rc[k] & 0xFFFFFFFFu) + 1); *p++ = ' ';
-                        p += format_f32(tri_v[k], p, 64); *p++ = '\n';
+                        while (row_ptr[row + 1] <= k) ++row;   // skips empty rows too
+                        p = put_u64(p, (unsigned long long)row + 1); *p++ = ' ';
+                        p = put_u64(p, (unsigned long long)all_gene[k] + 1); *p++ = ' ';
+                        p += format_f32(all_val[k], p, 64); *p++ = '\n';
                     }
                     out.resize((size_t)(p - &out[0]));
                 });
