@@ -19,6 +19,8 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <chrono>
 #include <fcntl.h>
@@ -82,49 +84,68 @@ std::string f32s(float v) { char b[96]; format_f32(v, b, sizeof b); return b; }
 // ---------------------------------------------------------------------------
 // snappy: raw block decompress + frame format (stream identifier 0xff, compressed 0x00, uncompressed 0x01,
 // padding 0xfe, reserved skippable 0x80-0xfd).  CRC-32C of the uncompressed data is verified (masked).
+// CRC-32C (Castagnoli), slicing-by-8
 uint32_t crc32c(const uint8_t* p, size_t n) {
-    static uint32_t T[256];
-    static bool init = false;
-    if (!init) {
-        for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1; T[i] = c; }
-        init = true;
-    }
+    static uint32_t T[8][256];
+    static std::once_flag once;
+    std::call_once(once, []() {
+        for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1; T[0][i] = c; }
+        for (uint32_t i = 0; i < 256; ++i) for (int t = 1; t < 8; ++t) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xFF];
+    });
     uint32_t c = ~0u;
-    for (size_t i = 0; i < n; ++i) c = T[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+    while (n >= 8) {
+        uint64_t w; std::memcpy(&w, p, 8);
+        w ^= c;
+        c = T[7][w & 0xFF] ^ T[6][(w >> 8) & 0xFF] ^ T[5][(w >> 16) & 0xFF] ^ T[4][(w >> 24) & 0xFF] ^
+            T[3][(w >> 32) & 0xFF] ^ T[2][(w >> 40) & 0xFF] ^ T[1][(w >> 48) & 0xFF] ^ T[0][(w >> 56) & 0xFF];
+        p += 8; n -= 8;
+    }
+    for (size_t i = 0; i < n; ++i) c = T[0][(c ^ p[i]) & 0xFF] ^ (c >> 8);
     return ~c;
 }
 uint32_t mask_crc(uint32_t c) { return ((c >> 15) | (c << 17)) + 0xa282ead8u; }
 
-bool snappy_raw_decompress(const uint8_t* in, size_t n, std::vector<uint8_t>& out) {
-    size_t p = 0;
-    uint64_t ulen = 0; int shift = 0;
-    for (;;) { if (p >= n || shift > 35) return false; uint8_t b = in[p++]; ulen |= (uint64_t)(b & 0x7F) << shift; if (!(b & 0x80)) break; shift += 7; }
-    const size_t base = out.size();
-    out.reserve(base + ulen);
+// uncompressed length of a raw snappy block (leading uvarint); returns false on a malformed prefix
+bool snappy_raw_length(const uint8_t* in, size_t n, uint64_t& ulen, size_t& hdr) {
+    ulen = 0; int shift = 0; size_t p = 0;
+    for (;;) { if (p >= n || shift > 35) return false; const uint8_t b = in[p++]; ulen |= (uint64_t)(b & 0x7F) << shift; if (!(b & 0x80)) break; shift += 7; }
+    hdr = p;
+    return true;
+}
+// raw snappy block -> exactly ulen bytes at dst
+bool snappy_raw_decompress_into(const uint8_t* in, size_t n, uint8_t* dst, uint64_t ulen) {
+    uint64_t declared; size_t p;
+    if (!snappy_raw_length(in, n, declared, p) || declared != ulen) return false;
+    uint64_t w = 0;
     while (p < n) {
         const uint8_t tag = in[p++];
         const uint32_t type = tag & 3;
         if (type == 0) {  // literal
             size_t len = (tag >> 2) + 1;
             if (len > 60) { const size_t nb = len - 60; if (p + nb > n) return false; len = 0; for (size_t i = 0; i < nb; ++i) len |= (size_t)in[p + i] << (8 * i); len += 1; p += nb; }
-            if (p + len > n) return false;
-            out.insert(out.end(), in + p, in + p + len);
-            p += len;
+            if (p + len > n || w + len > ulen) return false;
+            std::memcpy(dst + w, in + p, len);
+            p += len; w += len;
         } else {
             size_t len, off;
             if (type == 1) { if (p + 1 > n) return false; len = ((tag >> 2) & 7) + 4; off = ((size_t)(tag >> 5) << 8) | in[p]; p += 1; }
             else if (type == 2) { if (p + 2 > n) return false; len = (tag >> 2) + 1; off = in[p] | ((size_t)in[p + 1] << 8); p += 2; }
             else { if (p + 4 > n) return false; len = (tag >> 2) + 1; off = in[p] | ((size_t)in[p + 1] << 8) | ((size_t)in[p + 2] << 16) | ((size_t)in[p + 3] << 24); p += 4; }
-            if (off == 0 || off > out.size() - base) return false;
-            size_t s = out.size() - off;
-            for (size_t i = 0; i < len; ++i) out.push_back(out[s + i]);  // may overlap its own output
+            if (off == 0 || off > w || w + len > ulen) return false;
+            if (off >= len) std::memcpy(dst + w, dst + w - off, len);
+            else for (size_t i = 0; i < len; ++i) dst[w + i] = dst[w - off + i];  // overlaps its own output (run-length)
+            w += len;
         }
     }
-    return out.size() - base == ulen;
+    return w == ulen;
 }
 
-bool snappy_frame_decode(const uint8_t* in, size_t n, std::vector<uint8_t>& out, std::string& err) {
+// Snappy frame format.  The data chunks of a frame are independent (<= 64 KiB of output each), so the stream is
+// planned in one cheap pass over the chunk headers and decoded by several threads.
+struct SnappyChunk { size_t in_off, in_len; uint64_t out_off, ulen; uint32_t crc; bool compressed; };
+bool snappy_frame_plan(const uint8_t* in, size_t n, std::vector<SnappyChunk>& chunks, uint64_t& total, std::string& err) {
     size_t p = 0;
+    total = 0;
     while (p < n) {
         if (p + 4 > n) { err = "truncated snappy frame header"; return false; }
         const uint8_t type = in[p];
@@ -134,16 +155,47 @@ bool snappy_frame_decode(const uint8_t* in, size_t n, std::vector<uint8_t>& out,
         if (type == 0xff) { if (len != 6 || std::memcmp(in + p, "sNaPpY", 6) != 0) { err = "bad snappy stream identifier"; return false; } }
         else if (type == 0x00 || type == 0x01) {
             if (len < 4) { err = "snappy chunk too short"; return false; }
-            const uint32_t want = in[p] | ((uint32_t)in[p + 1] << 8) | ((uint32_t)in[p + 2] << 16) | ((uint32_t)in[p + 3] << 24);
-            const size_t before = out.size();
-            if (type == 0x01) out.insert(out.end(), in + p + 4, in + p + len);
-            else if (!snappy_raw_decompress(in + p + 4, len - 4, out)) { err = "corrupt snappy block"; return false; }
-            if (mask_crc(crc32c(out.data() + before, out.size() - before)) != want) { err = "snappy CRC mismatch"; return false; }
+            SnappyChunk c;
+            c.crc = in[p] | ((uint32_t)in[p + 1] << 8) | ((uint32_t)in[p + 2] << 16) | ((uint32_t)in[p + 3] << 24);
+            c.in_off = p + 4; c.in_len = len - 4; c.out_off = total; c.compressed = type == 0x00;
+            if (c.compressed) { size_t h; if (!snappy_raw_length(in + c.in_off, c.in_len, c.ulen, h)) { err = "corrupt snappy block"; return false; } }
+            else c.ulen = c.in_len;
+            total += c.ulen;
+            chunks.push_back(c);
         } else if (type >= 0x02 && type <= 0x7f) { err = "unskippable reserved snappy chunk"; return false; }
         // 0x80..0xfe: skippable / padding
         p += len;
     }
     return true;
+}
+bool snappy_frame_run(const uint8_t* in, const std::vector<SnappyChunk>& chunks, uint8_t* out, unsigned nthreads, std::string& err) {
+    nthreads = std::max(1u, std::min<unsigned>(nthreads, 64u));
+    if (chunks.size() < 64) nthreads = 1;
+    std::vector<int> bad(nthreads, 0);   // 1 = corrupt block, 2 = CRC mismatch
+    auto work = [&](unsigned t) {
+        const size_t a = chunks.size() * t / nthreads, b = chunks.size() * (t + 1) / nthreads;
+        for (size_t i = a; i < b && !bad[t]; ++i) {
+            const SnappyChunk& c = chunks[i];
+            if (!c.compressed) std::memcpy(out + c.out_off, in + c.in_off, c.ulen);
+            else if (!snappy_raw_decompress_into(in + c.in_off, c.in_len, out + c.out_off, c.ulen)) { bad[t] = 1; break; }
+            if (mask_crc(crc32c(out + c.out_off, c.ulen)) != c.crc) bad[t] = 2;
+        }
+    };
+    if (nthreads == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nthreads; ++t) th.emplace_back(work, t);
+        for (auto& x : th) x.join();
+    }
+    for (int b : bad) if (b) { err = b == 1 ? "corrupt snappy block" : "snappy CRC mismatch"; return false; }
+    return true;
+}
+bool snappy_frame_decode(const uint8_t* in, size_t n, std::vector<uint8_t>& out, std::string& err, unsigned nthreads = 1) {
+    std::vector<SnappyChunk> chunks;
+    uint64_t total = 0;
+    if (!snappy_frame_plan(in, n, chunks, total, err)) return false;
+    out.resize(total);
+    return snappy_frame_run(in, chunks, out.data(), nthreads, err);
 }
 
 // ---------------------------------------------------------------------------
@@ -315,7 +367,7 @@ int afq_format_f32(float v, char* buf, size_t cap) { return format_f32(v, buf, c
 
 int64_t afq_snappy_frame_decode(const uint8_t* in, size_t n, uint8_t* out, size_t cap) {
     std::vector<uint8_t> o; std::string err;
-    if (!snappy_frame_decode(in, n, o, err)) return hfail(AFQ_ERR_BAD_INPUT, err);
+    if (!snappy_frame_decode(in, n, o, err, std::min(8u, std::max(1u, std::thread::hardware_concurrency())))) return hfail(AFQ_ERR_BAD_INPUT, err);
     if (out) { if (o.size() > cap) return hfail(AFQ_ERR_INVALID_ARG, "output buffer too small"); std::memcpy(out, o.data(), o.size()); }
     return (int64_t)o.size();
 }
@@ -352,10 +404,18 @@ int afq_quantify(const afq_quant_opts* o) {
     { size_t k = cjs.find("\"compressed_output\""); if (k != std::string::npos) { size_t v = cjs.find_first_not_of(" \t\r\n:", k + 19); compressed = v != std::string::npos && cjs.compare(v, 4, "true") == 0; } }
     PhaseClock pc;
     MappedFile mf;
-    std::vector<uint8_t> rad_owned;
     if (!mf.open(in + (compressed ? "/map.collated.rad.sz" : "/map.collated.rad"))) return hfail(AFQ_ERR_BAD_INPUT, "could not read the collated RAD file");
-    if (compressed) { std::string err; if (!snappy_frame_decode(mf.p, mf.n, rad_owned, err)) return hfail(AFQ_ERR_BAD_INPUT, "map.collated.rad.sz: " + err); }
-    struct { const uint8_t* p; size_t n; const uint8_t* data() const { return p; } size_t size() const { return n; } } rad{compressed ? rad_owned.data() : mf.p, compressed ? rad_owned.size() : mf.n};
+    std::unique_ptr<uint8_t[]> rad_buf;   // (not a vector: no point zero-filling gigabytes that are about to be overwritten)
+    uint64_t rad_buf_n = 0;
+    if (compressed) {
+        std::string err;
+        std::vector<SnappyChunk> chunks;
+        if (!snappy_frame_plan(mf.p, mf.n, chunks, rad_buf_n, err)) return hfail(AFQ_ERR_BAD_INPUT, "map.collated.rad.sz: " + err);
+        rad_buf.reset(new (std::nothrow) uint8_t[rad_buf_n ? rad_buf_n : 1]);
+        if (!rad_buf) return hfail(AFQ_ERR_OOM, "map.collated.rad.sz: not enough host memory for the decompressed file");
+        if (!snappy_frame_run(mf.p, chunks, rad_buf.get(), o->num_threads ? o->num_threads : 1, err)) return hfail(AFQ_ERR_BAD_INPUT, "map.collated.rad.sz: " + err);
+    }
+    struct { const uint8_t* p; size_t n; const uint8_t* data() const { return p; } size_t size() const { return n; } } rad{compressed ? rad_buf.get() : mf.p, compressed ? (size_t)rad_buf_n : mf.n};
     pc.lap(compressed ? "map + snappy decode" : "map the RAD file");
     RadPrelude P;
     int rc = parse_prelude(rad.data(), rad.size(), P, true);

@@ -181,16 +181,28 @@ def _crc32c(data: bytes) -> int:
     return c ^ 0xFFFFFFFF
 
 
-def snappy_frame_encode(data: bytes, chunk: int = 60000, compress_literal: bool = True) -> bytes:
-    """Minimal Snappy *frame format* writer: stream identifier + one chunk per `chunk` bytes, alternating
-    uncompressed chunks (type 0x01) and compressed chunks (type 0x00) whose block is literals only.
-    Enough to exercise the decoder; a real file comes from `snap::write::FrameEncoder` (src/collate.rs:550-554)."""
+def snappy_frame_encode(data: bytes, chunk: int = 60000, compress_literal: bool = True, real: bool = True) -> bytes:
+    """Snappy *frame format* writer: stream identifier + one chunk per `chunk` bytes, alternating uncompressed
+    chunks (type 0x01) and compressed chunks (type 0x00).  With `real` (and pyarrow importable) the compressed
+    blocks come from Google's snappy through pyarrow - back-references and all, i.e. what
+    `snap::write::FrameEncoder` (src/collate.rs:550-554) puts in a real file; otherwise they are literal-only blocks."""
+    codec = None
+    if real:
+        try:
+            import pyarrow as pa
+
+            codec = pa.Codec("snappy") if pa.Codec.is_available("snappy") else None
+        except Exception:  # noqa
+            codec = None
     out = bytearray(b"\xff\x06\x00\x00sNaPpY")
     for k, i in enumerate(range(0, len(data), chunk)):
         piece = data[i : i + chunk]
         crc = _crc32c(piece)
         m = (((crc >> 15) | (crc << 17)) + 0xA282EAD8) & 0xFFFFFFFF
-        if compress_literal and k % 2 == 1:
+        if codec is not None and compress_literal and k % 2 == 1:
+            body = m.to_bytes(4, "little") + codec.compress(bytes(piece), asbytes=True)
+            out += b"\x00" + len(body).to_bytes(3, "little") + body
+        elif compress_literal and k % 2 == 1:
             n = len(piece)
             blk = bytearray()
             v = n

@@ -70,6 +70,18 @@ def test_snappy_frame_decode(lib):
     bad = bytearray(enc)
     bad[20] ^= 0xFF  # payload corruption -> CRC mismatch
     assert lib.afq_snappy_frame_decode(bytes(bad), len(bad), None, 0) < 0
+    # blocks compressed by Google's snappy (through pyarrow): RAD-like data is full of back-references (the barcode
+    # repeats in every record), overlapping copies (runs) included; many chunks, so the threaded path runs too
+    pa = pytest.importorskip("pyarrow")
+    if not pa.Codec.is_available("snappy"):
+        pytest.skip("pyarrow without snappy")
+    rec = np.zeros((300_000, 4), np.uint32)
+    rec[:, 0] = 1; rec[:, 1] = 0x5A5A1234; rec[:, 2] = rng.integers(0, 1 << 24, len(rec)); rec[:, 3] = rng.integers(0, 5000, len(rec)) | 0x80000000
+    data2 = rec.tobytes() + b"\x00" * 70_000 + bytes(rng.integers(0, 4, 100_000, dtype=np.uint8))
+    enc2 = rad.snappy_frame_encode(data2, chunk=65_536)
+    assert len(enc2) < 0.8 * len(data2)  # it did compress (i.e. the real codec ran)
+    out2 = C.create_string_buffer(len(data2))
+    assert lib.afq_snappy_frame_decode(enc2, len(enc2), out2, len(data2)) == len(data2) and out2.raw == data2
 
 
 def test_rad_prelude_roundtrip(lib):
