@@ -16,3 +16,4 @@ for res in ("cr-like",):
     print(res, "rc", p.returncode, "wall %.2f s" % dt, "-> %.1f M reads/s end to end" % (r.n_reads / dt / 1e6))
     print(p.stderr[-1500:])
     print({f: os.path.getsize(os.path.join(o, "alevin", f)) for f in os.listdir(os.path.join(o, "alevin"))})
+
