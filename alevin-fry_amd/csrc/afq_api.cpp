@@ -402,7 +402,7 @@ int run_range(afq_ctx* c, Range r, int slot) {
     if (n_pug && !par) return fail(c, AFQ_ERR_UNSUPPORTED, "device parsimony needs dword-aligned chunk offsets");
     hist_cells = multi;
     hist_cells.insert(hist_cells.end(), pug_cells.begin(), pug_cells.end());
-    const uint64_t epool_words = 16 * n_pug_reads + (1ull << 22);
+    const uint64_t epool_words = 24 * n_pug_reads + (1ull << 22);
     if (n_pug) {
         HIP_TRY(c, B.d_pug_cells.ensure(4ull * n_pug));
         HIP_TRY(c, B.d_rd_off.ensure(8ull * n));

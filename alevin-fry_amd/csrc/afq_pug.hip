@@ -425,28 +425,57 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         const uint32_t b = bloom_bit(pu), b2 = bloom_bit2(pu);
         return ((s_bloom[b >> 5] >> (b & 31)) & (s_bloom[b2 >> 5] >> (b2 & 31))) & 1u;
     };
-    // (A) count, reserve, write candidates (pu << 20 | x)
-    uint32_t ncand_mine = 0;
-    for (uint32_t x = tid; x < V; x += kPugNT) {
-        const uint64_t ux = vv_umi[x];
-        ncand_mine += vflag[x];  // the distance-0 probe only matters when the UMI occurs under another label too
-        for (uint32_t pr = 1; pr < nprobe; ++pr) ncand_mine += passes(probe_umi(ux, pr));
-    }
-    PUG_MARK(12);
-    uint32_t NCAND;
-    const uint32_t cand_off = block_excl_scan<kPugNT>(ncand_mine, s_ws, NCAND);
-    if (tid == 0) s_ebase = atomicAdd(A.epool_cursor, 2ull * NCAND + 2);
-    __syncthreads();
-    if (s_ebase + 2ull * NCAND + 2 > A.epool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, cell); return; }
-    uint64_t* cand = reinterpret_cast<uint64_t*>(A.epool + ((s_ebase + 1) & ~1ull));
+    // (A) candidates (pu << 20 | x) appended in one pass to a list with room for 4V + 4096 of them (one LDS atomic per
+    // wave and probe round); a cell whose filter lets more through than that takes the exact two-pass route
+    // (count, reserve, write).
+    uint32_t NCAND = 0;
+    uint64_t* cand = nullptr;
     {
-        uint32_t o = cand_off;
+        const uint32_t cand_cap = 4 * V + 4096;
+        if (tid == 0) { s_ebase = atomicAdd(A.epool_cursor, 2ull * cand_cap + 2); s_flag[1] = 0; }
+        __syncthreads();
+        if (s_ebase + 2ull * cand_cap + 2 > A.epool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, cell); return; }
+        cand = reinterpret_cast<uint64_t*>(A.epool + ((s_ebase + 1) & ~1ull));
+        auto append = [&](uint64_t c) {   // called under divergence: the active lanes share one reservation
+            const uint64_t am = __ballot(true);
+            const uint32_t leader = (uint32_t)__builtin_ctzll(am);
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&s_flag[1], (uint32_t)__popcll(am));
+            base = __builtin_amdgcn_readlane(base, (int)leader);
+            const uint32_t k = base + (uint32_t)__popcll(am & ((1ull << lane) - 1));
+            if (k < cand_cap) cand[k] = c;
+        };
         for (uint32_t x = tid; x < V; x += kPugNT) {
             const uint64_t ux = vv_umi[x];
-            if (vflag[x]) cand[o++] = (ux << kVidBits) | x;
+            if (vflag[x]) append((ux << kVidBits) | x);  // the distance-0 probe only matters when the UMI occurs under another label too
             for (uint32_t pr = 1; pr < nprobe; ++pr) {
                 const uint64_t pu = probe_umi(ux, pr);
-                if (passes(pu)) cand[o++] = (pu << kVidBits) | x;
+                if (passes(pu)) append((pu << kVidBits) | x);
+            }
+        }
+        __syncthreads();
+        NCAND = s_flag[1];
+        PUG_MARK(12);
+        if (NCAND > cand_cap) {
+            uint32_t ncand_mine = 0;
+            for (uint32_t x = tid; x < V; x += kPugNT) {
+                const uint64_t ux = vv_umi[x];
+                ncand_mine += vflag[x];
+                for (uint32_t pr = 1; pr < nprobe; ++pr) ncand_mine += passes(probe_umi(ux, pr));
+            }
+            const uint32_t cand_off = block_excl_scan<kPugNT>(ncand_mine, s_ws, NCAND);
+            if (tid == 0) s_ebase = atomicAdd(A.epool_cursor, 2ull * NCAND + 2);
+            __syncthreads();
+            if (s_ebase + 2ull * NCAND + 2 > A.epool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, cell); return; }
+            cand = reinterpret_cast<uint64_t*>(A.epool + ((s_ebase + 1) & ~1ull));
+            uint32_t o = cand_off;
+            for (uint32_t x = tid; x < V; x += kPugNT) {
+                const uint64_t ux = vv_umi[x];
+                if (vflag[x]) cand[o++] = (ux << kVidBits) | x;
+                for (uint32_t pr = 1; pr < nprobe; ++pr) {
+                    const uint64_t pu = probe_umi(ux, pr);
+                    if (passes(pu)) cand[o++] = (pu << kVidBits) | x;
+                }
             }
         }
     }
