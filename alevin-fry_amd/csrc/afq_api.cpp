@@ -237,8 +237,7 @@ int check_supported(afq_ctx* c) {
     if (g.resolution >= AFQ_RES_PARSIMONY_EM && g.resolution <= AFQ_RES_PARSIMONY_GENE &&
         !decode_par_supported(g.bc_bytes, g.umi_bytes))
         return fail(c, AFQ_ERR_UNSUPPORTED, "device parsimony needs 4- or 8-byte barcode/UMI fields");
-    if (g.usa_mode && g.sa_model != AFQ_SA_WINNER_TAKE_ALL)
-        return fail(c, AFQ_ERR_UNSUPPORTED, "sa_model prefer-ambig is not implemented on the device path");
+    if (g.sa_model > AFQ_SA_PREFER_AMBIG) return fail(c, AFQ_ERR_INVALID_ARG, "unknown sa_model");
     if (g.umi_len > 4 * g.umi_bytes) return fail(c, AFQ_ERR_INVALID_ARG, "umi_len does not fit the UMI field");
     return 0;
 }
@@ -492,7 +491,8 @@ int run_range(afq_ctx* c, Range r, int slot) {
                    B.d_nnz.as<uint32_t>(), B.d_ovf.as<OverflowEnt>(), B.d_bdesc.p, em ? B.d_lab.as<uint32_t>() : nullptr,
                    em ? B.d_lab_cnt.as<uint32_t>() : nullptr, B.d_status.as<DevStatus>(),
                    (uint32_t)n_buckets, n_multi, (uint32_t)n_tiles, B.d_hist_cells.as<uint32_t>(),
-                   (uint32_t)hist_cells.size(), g.usa_mode, g.num_rows};
+                   (uint32_t)hist_cells.size(), g.usa_mode, g.num_rows,
+                   (g.usa_mode && g.sa_model == AFQ_SA_PREFER_AMBIG) ? 1u : 0u};
     if (n_multi) {
         { ScopedTimer t(c, K_HIST, s, &B.launches); launch_hist(s, ra); }
         { ScopedTimer t(c, K_BSCAN, s, &B.launches); launch_bucket_scan(s, ra); }

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <string>
 
+#include "../../include/afquant.h"
 #include "../../include/afquant_host.h"
 
 static void usage() {
@@ -40,7 +41,12 @@ int main(int argc, char** argv) {
         else if (a == "--use-eds") { std::fprintf(stderr, "--use-eds is no longer supported. EDS output has been removed as of v0.12.\n"); return 1; }
         else if (a == "-d" || a == "--dump-eqclasses") o.dump_eq = 1;
         else if (a == "-b" || a == "--num-bootstraps") o.num_bootstraps = (uint32_t)std::atoi(need(i));
-        else if (a == "--sa-model") { const std::string v = need(i); if (v != "winner-take-all") { std::fprintf(stderr, "--sa-model %s is not implemented\n", v.c_str()); return 1; } }
+        else if (a == "--sa-model") {
+            const std::string v = need(i);
+            if (v == "winner-take-all") o.sa_model = AFQ_SA_WINNER_TAKE_ALL;
+            else if (v == "prefer-ambig") o.sa_model = AFQ_SA_PREFER_AMBIG;
+            else { std::fprintf(stderr, "invalid value '%s' for '--sa-model': possible values: prefer-ambig, winner-take-all\n", v.c_str()); return 2; }
+        }
         else if (a == "--multi-sample-output") (void)need(i);
         else if (a == "--device") o.device = (uint32_t)std::atoi(need(i));
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); usage(); return 2; }

@@ -474,7 +474,13 @@ int afq_quantify(const afq_quant_opts* o) {
     if (found != P.ref_count) return hfail(AFQ_ERR_BAD_INPUT, "The tg-map must contain a gene mapping for all transcripts in the header");
     const uint32_t G = (uint32_t)gene_names.size();
     afq_config cfg{};
-    cfg.abi_version = AFQ_ABI_VERSION; cfg.resolution = R->id; cfg.sa_model = AFQ_SA_WINNER_TAKE_ALL; cfg.usa_mode = usa;
+    cfg.abi_version = AFQ_ABI_VERSION; cfg.resolution = R->id; cfg.usa_mode = usa;
+    if (o->sa_model > AFQ_SA_PREFER_AMBIG) return hfail(AFQ_ERR_INVALID_ARG, "unknown sa_model");
+    cfg.sa_model = o->sa_model;
+    if (!usa && cfg.sa_model != AFQ_SA_WINNER_TAKE_ALL) {   // src/quant.rs:1456-1469
+        std::fprintf(stderr, "When not operating in USA-mode (all-in-one unspliced/spliced/ambiguous), the SplicedAmbiguityModel will be ignored.\n");
+        cfg.sa_model = AFQ_SA_WINNER_TAKE_ALL;
+    }
     cfg.num_genes = usa ? 2 * G : G; cfg.num_rows = usa ? 3 * G : G;  // src/quant.rs:1627-1645
     cfg.small_thresh = o->small_thresh; cfg.large_graph_thresh = large_thresh; cfg.pug_exact_umi = (R->pars && edist == 0) ? 1 : 0;
     cfg.em_init_uniform = o->init_uniform; cfg.bc_bytes = P.bc_bytes; cfg.umi_bytes = P.umi_bytes; { const uint64_t ul = P.file_tag_vals.count("ulen") ? P.file_tag_vals["ulen"] : 0; cfg.umi_len = ul <= 4ull * P.umi_bytes ? (uint32_t)ul : 0u; }
@@ -599,9 +605,9 @@ int afq_quantify(const afq_quant_opts* o) {
         std::fprintf(j, "  \"num_quantified_cells\": %llu,\n  \"num_genes\": %u,\n  \"dump_eq\": false,\n  \"usa_mode\": %s,\n", (unsigned long long)row_index, cfg.num_rows, usa ? "true" : "false");
         std::fprintf(j, "  \"alt_resolved_cell_numbers\": %s,\n  \"empty_resolved_cell_numbers\": %s,\n  \"num_tiny_cell_resolved\": %zu,\n  \"tiny_cell_resolved_cell_numbers\": %s,\n",
                      list(alt_cells).c_str(), list(empty_cells).c_str(), tiny_cells.size(), list(tiny_cells).c_str());
-        std::fprintf(j, "  \"total_records\": %llu,\n  \"quant_options\": {\n    \"input_dir\": \"%s\",\n    \"tg_map\": \"%s\",\n    \"output_dir\": \"%s\",\n    \"num_threads\": %u,\n    \"num_bootstraps\": 0,\n    \"init_uniform\": %s,\n    \"summary_stat\": false,\n    \"dump_eq\": false,\n    \"resolution\": \"%s\",\n    \"pug_exact_umi\": %s,\n    \"sa_model\": \"WinnerTakeAll\",\n    \"small_thresh\": %u,\n    \"large_graph_thresh\": %u,\n    \"filter_list\": %s%s%s,\n    \"cmdline\": \"%s\"\n  }\n}\n",
+        std::fprintf(j, "  \"total_records\": %llu,\n  \"quant_options\": {\n    \"input_dir\": \"%s\",\n    \"tg_map\": \"%s\",\n    \"output_dir\": \"%s\",\n    \"num_threads\": %u,\n    \"num_bootstraps\": 0,\n    \"init_uniform\": %s,\n    \"summary_stat\": false,\n    \"dump_eq\": false,\n    \"resolution\": \"%s\",\n    \"pug_exact_umi\": %s,\n    \"sa_model\": \"%s\",\n    \"small_thresh\": %u,\n    \"large_graph_thresh\": %u,\n    \"filter_list\": %s%s%s,\n    \"cmdline\": \"%s\"\n  }\n}\n",
                      (unsigned long long)total_records, json_escape(in).c_str(), json_escape(o->tg_map).c_str(), json_escape(outd).c_str(), o->num_threads, o->init_uniform ? "true" : "false",
-                     R->debug, cfg.pug_exact_umi ? "true" : "false", o->small_thresh, large_thresh, o->filter_list ? "\"" : "", o->filter_list ? json_escape(o->filter_list).c_str() : "null", o->filter_list ? "\"" : "",
+                     R->debug, cfg.pug_exact_umi ? "true" : "false", cfg.sa_model == AFQ_SA_PREFER_AMBIG ? "PreferAmbiguity" : "WinnerTakeAll", o->small_thresh, large_thresh, o->filter_list ? "\"" : "", o->filter_list ? json_escape(o->filter_list).c_str() : "null", o->filter_list ? "\"" : "",
                      json_escape(o->cmdline ? o->cmdline : "").c_str());
         std::fclose(j);
     }

@@ -55,6 +55,7 @@ struct ResolveArgs {
     uint32_t n_hist;
     uint32_t usa;
     uint32_t num_rows;
+    uint32_t prefer_ambig;       // --sa-model prefer-ambig in USA mode (cr-like, cr-like-em)
 };
 
 void launch_gather_headers(hipStream_t s, const uint8_t* bytes, size_t n_bytes, const uint64_t* chunk_off,

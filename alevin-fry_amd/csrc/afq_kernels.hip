@@ -306,6 +306,7 @@ __device__ __forceinline__ void block_sort_any(const T* src, uint32_t n, T* s_x,
 struct ResolveCfg {
     uint32_t usa, num_rows, uo, ao;
     uint32_t mode;  // filled per bucket from its descriptor
+    uint32_t pa;    // --sa-model prefer-ambig (USA only): reads of a UMI are tallied per gene, S and U together
 };
 __device__ __forceinline__ bool mode_is_em(uint32_t mode) { return mode == kModeCrLikeEm; }
 
@@ -331,6 +332,23 @@ __device__ __forceinline__ void resolve_sorted(const uint64_t* keys, uint32_t n,
     const uint32_t nruns = carry;
     __syncthreads();
     auto run_end = [&](uint32_t q) -> uint32_t { return q + 1 < nruns ? (uint32_t)run_start[q + 1] : n; };  // no sentinel slot needed
+    // reads behind run q's claim on its UMI.  winner-take-all: the run's own (pugutils.rs:644-749); prefer-ambig: the
+    // run's plus those of the same gene's other splicing state, ids 2k / 2k+1 being neighbours in key order - a gene
+    // seen both ways then wins or ties with both ids in the label (pugutils.rs:505-641)
+    auto cnt = [&](uint32_t q) -> uint32_t {
+        const uint32_t s = run_start[q];
+        uint32_t c = run_end(q) - s;
+        if (rc.pa) {
+            const uint64_t k = keys[s];
+            if (!(k & 1)) {
+                if (q + 1 < nruns) { const uint32_t s2 = run_start[q + 1]; if (keys[s2] == k + 1) c += run_end(q + 1) - s2; }
+            } else if (q > 0) {
+                const uint32_t s0 = run_start[q - 1];
+                if (keys[s0] == k - 1) c += s - s0;
+            }
+        }
+        return c;
+    };
     if (rc.mode == kModeTrivial) {
         // `trivial`: every distinct (umi, gene) of the single-gene reads is one molecule of that gene
         // (pugutils.rs:899-907); the column is the raw gene id (counts has num_genes entries, pugutils.rs:858).
@@ -344,7 +362,7 @@ __device__ __forceinline__ void resolve_sorted(const uint64_t* keys, uint32_t n,
         for (uint32_t q = r; q < nruns; ++q) {
             const uint32_t s = run_start[q];
             if ((keys[s] >> kGeneBits) != umi) break;
-            const uint32_t c = run_end(q) - s;
+            const uint32_t c = cnt(q);
             maxc = c > maxc ? c : maxc;
         }
         uint32_t nb = 0, g1 = 0, g2 = 0, nsp = 0, first_sp = 0;
@@ -353,7 +371,7 @@ __device__ __forceinline__ void resolve_sorted(const uint64_t* keys, uint32_t n,
             const uint32_t s = run_start[q];
             const uint64_t kq = keys[s];
             if ((kq >> kGeneBits) != umi) break;
-            if (run_end(q) - s != maxc) continue;
+            if (cnt(q) != maxc) continue;
             const uint32_t g = (uint32_t)kq & kGeneMask;
             ++nb;
             if (nb == 1) g1 = g;
@@ -378,7 +396,7 @@ __device__ __forceinline__ void resolve_sorted(const uint64_t* keys, uint32_t n,
                         const uint32_t s = run_start[q];
                         const uint64_t kq = keys[s];
                         if ((kq >> kGeneBits) != umi) break;
-                        if (run_end(q) - s == maxc) dst[w++] = (uint32_t)kq & kGeneMask;
+                        if (cnt(q) == maxc) dst[w++] = (uint32_t)kq & kGeneMask;
                     }
                 }
             }
@@ -851,7 +869,7 @@ __global__ __launch_bounds__(kResolveNT) void k_resolve(const BucketDesc* __rest
         return;
     }
     const uint32_t bmode = d.mode_single & 0xFFu;
-    if ((bmode == kModeCrLike || (EM && bmode == kModeCrLikeEm && la.lab)) && d.n <= kHtKeys) {
+    if ((bmode == kModeCrLike || (EM && bmode == kModeCrLikeEm && la.lab)) && d.n <= kHtKeys && !rc.pa) {
         const bool single = (d.mode_single >> 8) != 0;
         unsigned long long* s_slot = reinterpret_cast<unsigned long long*>(s_raw);      // 2 words per slot
         uint32_t* s_pair = s_raw + 2 * kHtCap;                                            // kHtPairs-1 words per slot
@@ -1183,6 +1201,7 @@ void launch_scatter(hipStream_t s, const ResolveArgs& a) {
 static ResolveCfg make_rc(const ResolveArgs& a) {
     ResolveCfg rc;
     rc.usa = a.usa; rc.num_rows = a.num_rows; rc.uo = a.num_rows / 3; rc.ao = 2 * (a.num_rows / 3); rc.mode = 0;
+    rc.pa = a.prefer_ambig;
     return rc;
 }
 

@@ -31,6 +31,8 @@ typedef struct afq_quant_opts {
     uint32_t num_bootstraps;    /* -b : not implemented (rejected)                                                         */
     uint32_t device;            /* HIP device ordinal                                                                      */
     uint64_t batch_bytes;       /* chunk bytes handed to the device per afq_submit (0 = 1 GiB)                             */
+    uint32_t sa_model;          /* --sa-model (hidden): afq_sa_model; ignored with a log line outside USA mode (quant.rs:1456) */
+    uint32_t reserved;
 } afq_quant_opts;
 
 /* Runs the whole `quant` sub-command.  Returns 0 or a negative AFQ_ERR_* code; message via afq_host_last_error(). */

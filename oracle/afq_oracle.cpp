@@ -157,19 +157,56 @@ static void crlike_walk(std::vector<Triplet>& v, F&& commit) {
     }
 }
 
-static void crlike_into_eqc(std::vector<Triplet>& v, GeneEqc& eqc) {
-    crlike_walk(v, [&](const std::vector<u32>& best, u64) { eqc[best] += 1; });
+// resolve_num_molecules_crlike_from_vec_prefer_ambig, src/pugutils.rs:505-641 (hidden `--sa-model prefer-ambig`,
+// USA mode only): the same walk, but the reads of a UMI are tallied per gene with both splicing states together
+// (same_gene(.., true), utils.rs:414-416); `curr` holds the ids of the gene seen so far - [S], [U] or [S, U] - and
+// it is `curr`, not the single id, that replaces or joins the best set.
+template <class F>
+static void crlike_walk_prefer_ambig(std::vector<Triplet>& v, F&& commit) {
+    if (v.empty()) return;
+    std::sort(v.begin(), v.end(), trip_less);
+    u64 curr_umi = v[0].umi;
+    std::vector<u32> curr{v[0].gene};          // ArrayVec<u32, 2> in the reference
+    u32 max_count = 0, count_aggr = 0;
+    std::vector<u32> best;
+    for (size_t i = 0; i < v.size(); ++i) {
+        const Triplet& t = v[i];
+        if (t.umi != curr_umi) {               // pugutils.rs:544-563
+            commit(best, curr_umi);
+            curr_umi = t.umi;
+            curr.assign(1, t.gene);
+            best.assign(1, t.gene);
+            count_aggr = t.ct; max_count = t.ct;
+        } else {                               // pugutils.rs:564-629
+            const u32 prev = curr.back();
+            if (prev == t.gene || (prev >> 1) == (t.gene >> 1)) {
+                if (prev != t.gene) curr.push_back(t.gene);   // spliced -> unspliced transition of one gene
+                count_aggr += t.ct;
+            } else {
+                count_aggr = t.ct;
+                curr.assign(1, t.gene);
+            }
+            if (count_aggr > max_count) { max_count = count_aggr; best = curr; }
+            else if (count_aggr == max_count) best.insert(best.end(), curr.begin(), curr.end());
+        }
+        if (i + 1 == v.size()) commit(best, curr_umi);   // pugutils.rs:633-638
+    }
+}
+
+static void crlike_into_eqc(std::vector<Triplet>& v, GeneEqc& eqc, bool prefer_ambig = false) {
+    if (prefer_ambig) crlike_walk_prefer_ambig(v, [&](const std::vector<u32>& best, u64) { eqc[best] += 1; });
+    else crlike_walk(v, [&](const std::vector<u32>& best, u64) { eqc[best] += 1; });
 }
 
 // get_num_molecules_cell_ranger_like_small, src/pugutils.rs:751-797
-static void crlike_from_reads(const Cell& c, const u32* t2g, GeneEqc& eqc) {
+static void crlike_from_reads(const Cell& c, const u32* t2g, GeneEqc& eqc, bool prefer_ambig = false) {
     std::vector<Triplet> v;
     std::vector<u32> g;
     for (u32 r = 0; r < c.nrec; ++r) {
         gene_set_of(c.rp(r), c.na(r), t2g, g);
         for (u32 x : g) v.push_back({c.umi[r], x, 1});
     }
-    crlike_into_eqc(v, eqc);
+    crlike_into_eqc(v, eqc, prefer_ambig);   // sa_model switch, pugutils.rs:786-797
 }
 
 // ---------------------------------------------------------------------------
@@ -220,7 +257,7 @@ static void eqmap_build(const Cell& c, const u32* t2g, bool gene_level, EqMap& m
 }
 
 // get_num_molecules_cell_ranger_like, src/pugutils.rs:799-850
-static void crlike_from_eqmap(const EqMap& m, const u32* t2g, GeneEqc& eqc) {
+static void crlike_from_eqmap(const EqMap& m, const u32* t2g, GeneEqc& eqc, bool prefer_ambig = false) {
     std::vector<Triplet> v;
     std::vector<u32> g;
     for (u32 e = 0; e < m.n(); ++e) {
@@ -228,7 +265,7 @@ static void crlike_from_eqmap(const EqMap& m, const u32* t2g, GeneEqc& eqc) {
         for (auto& uc : m.umis[e])
             for (u32 x : g) v.push_back({uc.first, x, uc.second});
     }
-    crlike_into_eqc(v, eqc);
+    crlike_into_eqc(v, eqc, prefer_ambig);   // sa_model switch, pugutils.rs:839-850
 }
 
 // ---------------------------------------------------------------------------
@@ -670,7 +707,8 @@ static int quant_cell(const afq_config& cfg, const u32* t2g, u32 ref_count, cons
     o = CellOut();
     bool usa = cfg.usa_mode != 0;
     u32 sa = usa ? cfg.sa_model : (u32)AFQ_SA_WINNER_TAKE_ALL;  // quant.rs:1456-1469
-    if (sa != AFQ_SA_WINNER_TAKE_ALL) { err = "oracle: prefer-ambig not restated"; return AFQ_ERR_UNSUPPORTED; }
+    if (sa > AFQ_SA_PREFER_AMBIG) { err = "bad sa_model"; return AFQ_ERR_INVALID_ARG; }
+    const bool pa = sa == AFQ_SA_PREFER_AMBIG;
     for (u32 x : c.refs) if (x >= ref_count) { err = "ref id out of range"; return AFQ_ERR_BAD_INPUT; }
     if (c.nrec == 0) { err = "chunk with no reads"; return AFQ_ERR_BAD_INPUT; }  // quant.rs:756 panics
     if (sa == AFQ_SA_WINNER_TAKE_ALL && c.nrec < cfg.small_thresh && force_route == 0) {
@@ -697,8 +735,8 @@ static int quant_cell(const afq_config& cfg, const u32* t2g, u32 ref_count, cons
         bool small_cell = c.nrec <= 250;  // quant.rs:853
         if (force_route == 1) small_cell = true;
         if (force_route == 2) small_cell = false;
-        if (small_cell) crlike_from_reads(c, t2g, eqc);
-        else { eqmap_build(c, t2g, false, m); crlike_from_eqmap(m, t2g, eqc); }
+        if (small_cell) crlike_from_reads(c, t2g, eqc, pa);
+        else { eqmap_build(c, t2g, false, m); crlike_from_eqmap(m, t2g, eqc, pa); }
         finish(res == AFQ_RES_CR_LIKE);
     } else if (res == AFQ_RES_TRIVIAL) {
         eqmap_build(c, t2g, false, m);

@@ -33,6 +33,42 @@ def test_hand_cases(oracle, small_thresh):
         assert_same_result(got, want, what=case["name"])
 
 
+def test_prefer_ambig_hand_cases(oracle):
+    """Hidden `--sa-model prefer-ambig` (pugutils.rs:505-641) against the hand-derived counts and the oracle."""
+    for case in load_golden("prefer_ambig_hand_cases.json")["cases"]:
+        cells = [(c["bc"], [(u, r) for u, r in c["reads"]]) for c in case["cells"]]
+        b, off = rad.encode_cells(cells, 4, 4)
+        t2g = np.asarray(case["t2g"], np.uint32)
+        kw = dict(usa_mode=case["usa"], num_genes=case["num_genes"], num_rows=case["num_rows"])
+        got, want, _ = run_both(oracle, pkg.WorkerConfig.for_resolution("cr-like", sa_model="prefer-ambig", **kw), t2g, b, off)
+        for c, g in zip(case["cells"], rows_of(got)):
+            assert [[int(a), int(v)] for a, v in g] == c["expected"], (case["name"], c["bc"], c["why"])
+        assert_same_result(got, want, what=case["name"])
+        got, want, _ = run_both(oracle, pkg.WorkerConfig.for_resolution("cr-like", **kw), t2g, b, off)
+        for c, g in zip(case["cells"], rows_of(got)):
+            assert [[int(a), int(v)] for a, v in g] == c["expected_wta"], (case["name"], c["bc"], "winner-take-all")
+
+
+@pytest.mark.parametrize("resolution", ["cr-like", "cr-like-em", "parsimony", "trivial"])
+def test_prefer_ambig_synthetic(oracle, resolution):
+    """prefer-ambig on USA data with S/U-ambiguous molecules: tiny cells lose their fast path (quant.rs:794) and go
+    through -r's own strategy; cells from a few reads to multi-bucket sizes; result differs from winner-take-all."""
+    s = synth.synth(23, [5, 40, 99, 100, 250, 251, 900, 5000, 60000], num_genes=300, usa=True, dup=0.6, max_extra_na=6)
+    b, off = s.encode()
+    got, want, _ = run_both(oracle, cfg_for(s, resolution, sa_model="prefer-ambig"), s.tid_to_gid, b, off)
+    assert_same_result(got, want, what=resolution)
+    assert not (got.flags & pkg._abi.CELL_TINY_PATH).any()
+    if resolution.startswith("cr-like"):
+        wta, _, _ = run_both(oracle, cfg_for(s, resolution), s.tid_to_gid, b, off)
+        assert not (np.array_equal(wta.gene, got.gene) and np.array_equal(wta.val, got.val))
+    # outside USA mode the switch is ignored (quant.rs:1456-1469)
+    s2 = synth.synth(24, [50, 3000], num_genes=100)
+    b2, off2 = s2.encode()
+    got2, want2, _ = run_both(oracle, cfg_for(s2, "cr-like", sa_model="prefer-ambig"), s2.tid_to_gid, b2, off2)
+    assert_same_result(got2, want2)
+    assert bool(got2.flags[0] & pkg._abi.CELL_TINY_PATH)
+
+
 @pytest.mark.parametrize("bw,uw", [(1, 1), (2, 2), (8, 8), (2, 4), (4, 2), (8, 4), (1, 8)])
 def test_field_widths(oracle, bw, uw):
     """Unaligned record layouts take the byte-granular walk."""
@@ -152,15 +188,6 @@ def test_bad_input_is_reported_not_crashed():
 
 def test_unsupported_requests_fail_loudly():
     """What the device path does not implement is refused with AFQ_ERR_UNSUPPORTED, never approximated."""
-    s = synth.synth(6, [50], num_genes=20, usa=True)
-    b, off = s.encode()
-    q = pkg.Quantifier(cfg_for(s, "cr-like", sa_model="prefer-ambig"), s.tid_to_gid)  # hidden --sa-model flag
-    try:
-        with pytest.raises(pkg.AfqError) as e:
-            q.quant_chunks(b, off)
-        assert e.value.code == pkg._abi.AFQ_ERR_UNSUPPORTED
-    finally:
-        q.close()
     s = synth.synth(6, [50], num_genes=20)
     cells = [(1, [(5, [0])])]
     b, off = rad.encode_cells(cells, 2, 2)  # parsimony needs dword fields

@@ -27,6 +27,32 @@ def test_crlike_hand_cases(oracle, small_thresh, route):
             assert bool(res.flags[i] & pkg._abi.CELL_EMPTY) == (len(c["expected"]) == 0)
 
 
+@pytest.mark.parametrize("route", [0, 1, 2])
+def test_prefer_ambig_hand_cases(oracle, route):
+    """`--sa-model prefer-ambig` (pugutils.rs:505-641): reads of a UMI are tallied per gene, both splicing states together;
+    the tiny-cell path is off (quant.rs:794), both remaining routes give the hand-derived counts, and the same cell
+    under winner-take-all gives the contrasting ones."""
+    for case in load_golden("prefer_ambig_hand_cases.json")["cases"]:
+        cells = [(c["bc"], [(u, r) for u, r in c["reads"]]) for c in case["cells"]]
+        b, off = rad.encode_cells(cells, 4, 4)
+        t2g = np.asarray(case["t2g"], np.uint32)
+        kw = dict(usa_mode=case["usa"], num_genes=case["num_genes"], num_rows=case["num_rows"])
+        res = oracle.quant(pkg.WorkerConfig.for_resolution("cr-like", sa_model="prefer-ambig", **kw), t2g, b, off, force_route=route)
+        wta = oracle.quant(pkg.WorkerConfig.for_resolution("cr-like", **kw), t2g, b, off, force_route=route)
+        for c, g, w in zip(case["cells"], rows_of(res), rows_of(wta)):
+            assert [[int(a), int(v)] for a, v in g] == c["expected"], (case["name"], c["bc"], c["why"])
+            assert [[int(a), int(v)] for a, v in w] == c["expected_wta"], (case["name"], c["bc"], "winner-take-all")
+        assert not (res.flags & pkg._abi.CELL_TINY_PATH).any()
+    # outside USA mode the switch is ignored (quant.rs:1456-1469)
+    case = load_golden("crlike_hand_cases.json")["cases"][0]
+    cells = [(c["bc"], [(u, r) for u, r in c["reads"]]) for c in case["cells"]]
+    b, off = rad.encode_cells(cells, 4, 4)
+    res = oracle.quant(pkg.WorkerConfig.for_resolution("cr-like", sa_model="prefer-ambig", num_genes=4, num_rows=4),
+                       np.asarray(case["t2g"], np.uint32), b, off, force_route=route)
+    for c, g in zip(case["cells"], rows_of(res)):
+        assert [[int(a), int(v)] for a, v in g] == c["expected"]
+
+
 @pytest.mark.parametrize("bw,uw", [(1, 1), (2, 2), (4, 4), (8, 8), (2, 4), (4, 2), (8, 4)])
 def test_field_widths(oracle, bw, uw):
     """Record field widths 1/2/4/8 bytes (src/convert.rs:323-344) decode identically."""
