@@ -490,6 +490,33 @@ int afq_quantify(const afq_quant_opts* o) {
 
     mkdirs(outd + "/alevin");
     FILE* rows_f = std::fopen((outd + "/alevin/quants_mat_rows.txt").c_str(), "w");
+    // Unmapped reads per corrected barcode (quant.rs:1484-1494; only CorrectedReads / MappingRate of featureDump use
+    // them).  Any failure to read the file means "no unmapped reads", as in the reference.  The layout read here is
+    // the bincode HashMap<u64, u32> one (count:u64, then key:u64 value:u32 pairs - atac/collate.rs:258-282 writes it);
+    // the self-describing layout of libradicl 0.18's CollatedUnmappedCounts is not witnessed anywhere under the
+    // reference tree, so a file that does not tile as the former is reported and ignored.
+    std::unordered_map<uint64_t, uint32_t> unmapped;
+    {
+        FILE* uf = std::fopen((in + "/unmapped_bc_count_collated.bin").c_str(), "rb");
+        if (uf) {
+            std::vector<uint8_t> ub;
+            uint8_t tmp[1 << 16];
+            size_t got;
+            while ((got = std::fread(tmp, 1, sizeof tmp, uf)) > 0) ub.insert(ub.end(), tmp, tmp + got);
+            std::fclose(uf);
+            uint64_t n = 0;
+            if (ub.size() >= 8) std::memcpy(&n, ub.data(), 8);
+            if (ub.size() >= 8 && n <= (ub.size() - 8) / 12 && ub.size() == 8 + 12 * n) {
+                unmapped.reserve((size_t)n);
+                for (uint64_t i = 0; i < n; ++i) {
+                    uint64_t k; uint32_t v;
+                    std::memcpy(&k, ub.data() + 8 + 12 * i, 8); std::memcpy(&v, ub.data() + 16 + 12 * i, 4);
+                    unmapped[k] += v;
+                }
+            } else if (!ub.empty())
+                std::fprintf(stderr, "unmapped_bc_count_collated.bin is not in the (count, key/value pairs) layout; unmapped reads are taken as 0\n");
+        }
+    }
     FILE* feat_f = std::fopen((outd + "/featureDump.txt").c_str(), "w");
     FILE* cols_f = std::fopen((outd + "/alevin/quants_mat_cols.txt").c_str(), "w");
     if (!rows_f || !feat_f || !cols_f) { afq_destroy(ctx); return hfail(AFQ_ERR_BAD_INPUT, "could not create the output files"); }
@@ -532,7 +559,8 @@ int afq_quantify(const afq_quant_opts* o) {
             const uint32_t num_expr = (uint32_t)(b - a);
             const uint32_t nrec = res.nrec[i];
             const float dedup_rate = sum / (float)nrec;
-            const uint64_t num_unmapped = 0;
+            uint64_t num_unmapped = 0;
+            if (!unmapped.empty()) { auto it = unmapped.find(res.bc[i]); if (it != unmapped.end()) num_unmapped = it->second; }
             const float mapping_rate = (float)nrec / (float)(nrec + num_unmapped);
             const float mean_expr = sum / (float)num_expr;
             uint32_t over = 0;

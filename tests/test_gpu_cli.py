@@ -56,6 +56,13 @@ def test_afquant_cli_matches_oracle(tmp_path, oracle, res, usa, compressed, sa):
     s = synth.synth(51, [4000, 1500, 600, 260, 120, 60, 7], num_genes=150, txp_per_gene=3, usa=usa, dup=0.5, cross=0.3, umi_err=0.02)
     tg, b, off = make_dir(tmp_path / "in", s, compressed)
     out = str(tmp_path / "out")
+    # unmapped reads per corrected barcode (count:u64, then key:u64 value:u32 pairs): cells 0, 2 and a barcode not in the file
+    unm = {int(s.cell_bc[0]): 1234, int(s.cell_bc[2]): 7, 0xFFFFFFF0: 99} if res == "cr-like" else {}
+    if unm:
+        with open(tmp_path / "in" / "unmapped_bc_count_collated.bin", "wb") as f:
+            f.write(len(unm).to_bytes(8, "little") + b"".join(k.to_bytes(8, "little") + v.to_bytes(4, "little") for k, v in unm.items()))
+    elif res == "cr-like-em":
+        (tmp_path / "in" / "unmapped_bc_count_collated.bin").write_bytes(b"\x01\x02\x03")  # unreadable = no unmapped reads
     r = subprocess.run([CLI, "quant", "-i", str(tmp_path / "in"), "-m", tg, "-o", out, "-r", res, "-t", "4"] + (["--sa-model", sa] if sa else []),
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
@@ -84,8 +91,11 @@ def test_afquant_cli_matches_oracle(tmp_path, oracle, res, usa, compressed, sa):
     for i in range(want.n_cells):
         st = want.cell_stats(i)
         f = feat[1 + i]
-        assert f[0] == rows[i] and int(f[1]) == int(want.nrec[i]) == int(f[2]) and int(f[7]) == st["num_expr"] and int(f[8]) == st["num_genes_over_mean"]
-        assert np.float32(float(f[3])) == np.float32(st["sum_umi"]) and float(f[4]) == 1.0
+        nu = unm.get(int(want.bc[i]), 0)
+        assert f[0] == rows[i] and int(f[1]) == int(want.nrec[i]) + nu and int(f[2]) == int(want.nrec[i])
+        assert int(f[7]) == st["num_expr"] and int(f[8]) == st["num_genes_over_mean"]
+        assert np.float32(float(f[3])) == np.float32(st["sum_umi"])
+        assert np.float32(float(f[4])) == np.float32(want.nrec[i]) / np.float32(int(want.nrec[i]) + nu)   # quant.rs:1185-1187
         assert np.float32(float(f[5])) == np.float32(st["dedup_rate"])
     assert meta["resolution_strategy"] in ("CellRangerLike", "ParsimonyEm", "CellRangerLikeEm") and meta["usa_mode"] == usa
     assert meta["num_quantified_cells"] == want.n_cells and meta["num_genes"] == s.num_rows
