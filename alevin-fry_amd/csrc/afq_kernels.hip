@@ -568,15 +568,15 @@ __device__ __forceinline__ void resolve_bucket_lds(const BucketDesc& d, uint64_t
 // of a sort.  Anything the slots cannot express (a UMI seen with more than kHtPairs genes, a UMI that does
 // not fit 32 bits) sends the whole bucket down the sort path - same result, just slower.
 constexpr uint32_t kHtKeys = 256;            // buckets up to this many keys take the table (nearly all: the planner aims at kBucketTarget)
-constexpr uint32_t kHtCap = 2 * kHtKeys;      // slots: load factor <= 0.5
+constexpr uint32_t kHtCap = kHtKeys + kHtKeys / 2;   // slots: load factor <= 2/3 (of distinct UMIs, usually far fewer than keys)
 constexpr uint32_t kHtPairs = 3;
 constexpr uint32_t kNoCol = 0xFFFFFFFFu;
 static_assert(kHtKeys < (1u << 12), "per-bucket read counts fit the 12-bit counter");
 
-__device__ __forceinline__ uint32_t ht_slot(uint32_t umi, uint32_t mask) {
+__device__ __forceinline__ uint32_t ht_slot(uint32_t umi, uint32_t cap) {
     uint32_t x = umi ^ (umi >> 15);
     x *= 0x85EBCA6Bu;
-    return (x >> 16) & mask;
+    return ((x >> 16) * cap) >> 16;   // cap need not be a power of two
 }
 
 // column of one UMI from its (gene, reads) counters; same rule table as resolve_sorted
@@ -688,9 +688,8 @@ __device__ __forceinline__ bool resolve_bucket_hash(const uint64_t* __restrict__
     uint64_t key[E];
 #pragma unroll
     for (uint32_t h = 0; h < E; ++h) key[h] = h * 64 + lane < n ? src[h * 64 + lane] : 0ull;
-    uint32_t cap = 128;
-    while (cap < 2 * n) cap <<= 1;
-    const uint32_t mask = cap - 1;
+    uint32_t cap = (n + (n >> 1) + 63) & ~63u;   // multiples of 64 slots: 1.5 n rounded up
+    cap = cap < 128 ? 128 : cap;
     {
         uint4* u4 = reinterpret_cast<uint4*>(s_slot);
         uint4* p4 = reinterpret_cast<uint4*>(s_pair);
@@ -717,7 +716,7 @@ __device__ __forceinline__ bool resolve_bucket_hash(const uint64_t* __restrict__
             else {
                 const uint32_t umi = (uint32_t)u64;
                 const unsigned long long mine = ((unsigned long long)umi << 32) | (gene << 12) | 1u;
-                uint32_t slot = ht_slot(umi, mask);
+                uint32_t slot = ht_slot(umi, cap);
                 bool done = false;
                 for (;;) {
                     const unsigned long long old = atomicCAS(&s_slot[slot], kEmpty64, mine);
@@ -726,7 +725,7 @@ __device__ __forceinline__ bool resolve_bucket_hash(const uint64_t* __restrict__
                         if ((((uint32_t)old) >> 12) == gene) { atomicAdd(&s_slot[slot], 1ull); done = true; }
                         break;
                     }
-                    slot = (slot + 1) & mask;
+                    slot = slot + 1 == cap ? 0u : slot + 1;
                 }
                 if (!done) {
                     uint32_t* pr = s_pair + slot * (kHtPairs - 1);
