@@ -48,7 +48,8 @@ class AfqConfig(C.Structure):
         ("umi_bytes", C.c_uint32),
         ("profile", C.c_uint32),
         ("umi_len", C.c_uint32),
-        ("reserved", C.c_uint32 * 2),
+        ("dump_eq", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 
@@ -65,6 +66,18 @@ class AfqResult(C.Structure):
         ("flags", C.POINTER(C.c_uint8)),
         ("mmrate", C.POINTER(C.c_double)),
         ("opaque", C.c_void_p),
+    ]
+
+
+class AfqEqclasses(C.Structure):
+    _fields_ = [
+        ("n_cells", C.c_uint64),
+        ("n_classes", C.c_uint64),
+        ("n_words", C.c_uint64),
+        ("cell_ptr", C.POINTER(C.c_uint64)),
+        ("label_ptr", C.POINTER(C.c_uint64)),
+        ("labels", C.POINTER(C.c_uint32)),
+        ("count", C.POINTER(C.c_uint32)),
     ]
 
 
@@ -92,6 +105,7 @@ EXPORTS = [
     "afq_submit_device",
     "afq_collect",
     "afq_result_release",
+    "afq_result_eqclasses",
     "afq_atac_dedup",
     "afq_free",
     "afq_get_kernel_times",

@@ -18,7 +18,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _abi
-from ._abi import AfqBatchStats, AfqConfig, AfqKernelTime, AfqResult, RESOLUTIONS
+from ._abi import AfqBatchStats, AfqConfig, AfqEqclasses, AfqKernelTime, AfqResult, RESOLUTIONS
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libafquant.so")
@@ -46,6 +46,7 @@ class WorkerConfig:
     bc_bytes: int = 4
     umi_bytes: int = 4
     umi_len: int = 0  # UMI length in bases if known (RAD file tag ulen); 0 = unknown
+    dump_eq: bool = False  # -d: keep each cell's gene-level equivalence classes (QuantResult.eqclasses; -em resolutions)
     profile: bool = False
 
     @staticmethod
@@ -74,6 +75,7 @@ class WorkerConfig:
         c.umi_bytes = self.umi_bytes
         c.profile = int(self.profile)
         c.umi_len = int(self.umi_len)
+        c.dump_eq = 1 if self.dump_eq else 0
         return c
 
 
@@ -111,6 +113,31 @@ class QuantResult:
             over = int((v > mean).sum())
             return dict(sum_umi=float(s), max_umi=float(mx), num_expr=n, mean_by_max=float(mean / mx),
                         num_genes_over_mean=over, dedup_rate=float(s / np.float32(self.nrec[i])))
+
+
+@dataclass
+class EqClasses:
+    """-d: per-cell gene-level equivalence classes (label = ascending gene ids, count = molecules), CSR over CSR."""
+
+    cell_ptr: np.ndarray
+    label_ptr: np.ndarray
+    labels: np.ndarray
+    count: np.ndarray
+
+    def cell(self, i: int):
+        """Classes of cell i as a sorted list of (label tuple, count) - the reference's order is a hash map's."""
+        a, b = int(self.cell_ptr[i]), int(self.cell_ptr[i + 1])
+        lp = self.label_ptr
+        return sorted((tuple(int(x) for x in self.labels[int(lp[k]):int(lp[k + 1])]), int(self.count[k])) for k in range(a, b))
+
+
+def eqclasses_from_c(ec) -> EqClasses:
+    def arr(ptr, count, dt):
+        return np.ctypeslib.as_array(ptr, shape=(count,)).astype(dt, copy=True) if count else np.zeros(0, dtype=dt)
+
+    n, k, w = int(ec.n_cells), int(ec.n_classes), int(ec.n_words)
+    return EqClasses(arr(ec.cell_ptr, n + 1, np.uint64), arr(ec.label_ptr, k + 1, np.uint64), arr(ec.labels, w, np.uint32),
+                     arr(ec.count, k, np.uint32))
 
 
 class _ResultOwner:
@@ -180,6 +207,8 @@ def load_library(path: str = LIB_PATH):
     lib.afq_collect.restype = C.c_int
     lib.afq_result_release.argtypes = [p(AfqResult)]
     lib.afq_result_release.restype = None
+    lib.afq_result_eqclasses.argtypes = [p(AfqResult), p(AfqEqclasses)]
+    lib.afq_result_eqclasses.restype = C.c_int
     lib.afq_atac_dedup.argtypes = [C.c_void_p, p(C.c_uint32), p(C.c_uint32), p(C.c_uint16), p(C.c_uint64), C.c_uint32,
                                    p(p(C.c_uint64)), p(p(C.c_uint32)), p(p(C.c_uint32)), p(p(C.c_uint16)), p(p(C.c_uint16))]
     lib.afq_atac_dedup.restype = C.c_int
@@ -245,7 +274,12 @@ class Quantifier:
     def collect(self) -> QuantResult:
         res = AfqResult()
         self._check(self.lib.afq_collect(self._h, C.byref(res)))
-        return result_from_c(res, owner=_ResultOwner(self.lib.afq_result_release, res))
+        out = result_from_c(res, owner=_ResultOwner(self.lib.afq_result_release, res))
+        if self.cfg.dump_eq:
+            ec = AfqEqclasses()
+            self._check(self.lib.afq_result_eqclasses(C.byref(res), C.byref(ec)))
+            out.eqclasses = eqclasses_from_c(ec)
+        return out
 
     def quant_chunks(self, chunk_bytes, chunk_off, first_cell_index: int = 0) -> QuantResult:
         self.submit(chunk_bytes, chunk_off, first_cell_index)

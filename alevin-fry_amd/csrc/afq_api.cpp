@@ -88,8 +88,14 @@ struct HostResult {
     PinnedVec<float> val;
     std::vector<uint8_t> flags;
     std::vector<double> mmrate;
+    // -d: gene-level equivalence classes per cell (cfg.dump_eq): CSR cell -> classes -> label words
+    std::vector<uint64_t> eq_cell_ptr, eq_label_ptr;
+    std::vector<uint32_t> eq_labels, eq_count;
     ResultPool* pool = nullptr;
-    void clear() { cell_ptr.clear(); bc.clear(); nrec.clear(); flags.clear(); mmrate.clear(); gene.n = 0; val.n = 0; }
+    void clear() {
+        cell_ptr.clear(); bc.clear(); nrec.clear(); flags.clear(); mmrate.clear(); gene.n = 0; val.n = 0;
+        eq_cell_ptr.clear(); eq_label_ptr.clear(); eq_labels.clear(); eq_count.clear();
+    }
 };
 
 // Results outlive a collect call (library-owned until afq_result_release), and pinning
@@ -131,7 +137,8 @@ struct RangeState {
     DevBuf d_meta, d_keys0, d_keys1, d_cell_nkeys, d_bucket_cnt, d_bucket_cell, d_multi_cells, d_tile_prefix, d_ncols,
         d_nnz, d_ovf, d_status, d_bc, d_cell_ptr, d_gene, d_val, d_chk, d_slab_prefix, d_slab_cell, d_cell_bc, d_bdesc, d_lab,
         d_lab_cnt, d_em_off, d_em_scratch, d_em_nnz, d_pug_cells, d_rd_off, d_rd_h, d_rd_u, d_rd_o, d_pug_scr_off,
-        d_pug_scratch, d_epool, d_epool_cur, d_alt, d_hist_cells, d_fix, d_em_hdr, d_em_order;
+        d_pug_scratch, d_epool, d_epool_cur, d_alt, d_hist_cells, d_fix, d_em_hdr, d_em_order, d_eq_ncls, d_eq_nw, d_eq_cptr,
+        d_eq_wptr, d_eq_len, d_eq_cnt, d_eq_lab;
     ResolveArgs last_ra{};
     std::vector<CellMeta> meta;
     Range cur{};
@@ -142,7 +149,8 @@ struct RangeState {
         return {&d_meta, &d_keys0, &d_keys1, &d_cell_nkeys, &d_bucket_cnt, &d_bucket_cell, &d_multi_cells, &d_tile_prefix,
                 &d_ncols, &d_nnz, &d_ovf, &d_status, &d_bc, &d_cell_ptr, &d_gene, &d_val, &d_chk, &d_slab_prefix, &d_slab_cell,
                 &d_cell_bc, &d_bdesc, &d_lab, &d_lab_cnt, &d_em_off, &d_em_scratch, &d_em_nnz, &d_pug_cells, &d_rd_off, &d_rd_h,
-                &d_rd_u, &d_rd_o, &d_pug_scr_off, &d_pug_scratch, &d_epool, &d_epool_cur, &d_alt, &d_hist_cells, &d_fix, &d_em_hdr, &d_em_order};
+                &d_rd_u, &d_rd_o, &d_pug_scr_off, &d_pug_scratch, &d_epool, &d_epool_cur, &d_alt, &d_hist_cells, &d_fix, &d_em_hdr, &d_em_order,
+                &d_eq_ncls, &d_eq_nw, &d_eq_cptr, &d_eq_wptr, &d_eq_len, &d_eq_cnt, &d_eq_lab};
     }
 };
 
@@ -238,6 +246,9 @@ int check_supported(afq_ctx* c) {
         !decode_par_supported(g.bc_bytes, g.umi_bytes))
         return fail(c, AFQ_ERR_UNSUPPORTED, "device parsimony needs 4- or 8-byte barcode/UMI fields");
     if (g.sa_model > AFQ_SA_PREFER_AMBIG) return fail(c, AFQ_ERR_INVALID_ARG, "unknown sa_model");
+    if (g.dump_eq && !(g.resolution == AFQ_RES_CR_LIKE_EM || g.resolution == AFQ_RES_PARSIMONY_EM || g.resolution == AFQ_RES_PARSIMONY_GENE_EM))
+        return fail(c, AFQ_ERR_UNSUPPORTED, "dump_eq: the gene-level classes are kept only by the -em resolutions (they resolve to the same "
+                                            "classes as their plain siblings; afq_quantify runs the sibling for -d)");
     if (g.umi_len > 4 * g.umi_bytes) return fail(c, AFQ_ERR_INVALID_ARG, "umi_len does not fit the UMI field");
     return 0;
 }
@@ -587,6 +598,41 @@ int finish_range(afq_ctx* c, int slot) {
         }
         HIP_TRY(c, hipStreamSynchronize(s));
         HIP_TRY(c, hipMemcpy(nnz.data(), B.d_em_nnz.p, 4ull * n, hipMemcpyDeviceToHost));
+        if (c->cfg.dump_eq) {
+            // the cells' gene-level classes, read back off the EM set-up (k_eqc_dump): size, prefix on the host, fill
+            HostResult& R = *c->res;
+            const uint32_t na = c->cfg.usa_mode ? c->cfg.num_rows : c->cfg.num_genes;
+            HIP_TRY(c, B.d_eq_ncls.ensure(4ull * n)); HIP_TRY(c, B.d_eq_nw.ensure(4ull * n));
+            launch_eqc_dump(s, B.last_ra, n, B.d_em_off.as<uint64_t>(), B.d_em_scratch.as<uint32_t>(), B.d_em_hdr.p, na,
+                            B.d_eq_ncls.as<uint32_t>(), B.d_eq_nw.as<uint32_t>(), nullptr, nullptr, nullptr, nullptr, nullptr);
+            std::vector<uint32_t> ncls(n), nw(n);
+            HIP_TRY(c, hipMemcpyAsync(ncls.data(), B.d_eq_ncls.p, 4ull * n, hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipMemcpyAsync(nw.data(), B.d_eq_nw.p, 4ull * n, hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            std::vector<uint64_t> cp(n + 1), wp(n + 1);
+            cp[0] = wp[0] = 0;
+            for (uint32_t i = 0; i < n; ++i) { cp[i + 1] = cp[i] + ncls[i]; wp[i + 1] = wp[i] + nw[i]; }
+            HIP_TRY(c, B.d_eq_cptr.ensure(8ull * (n + 1))); HIP_TRY(c, B.d_eq_wptr.ensure(8ull * (n + 1)));
+            HIP_TRY(c, B.d_eq_len.ensure(std::max<uint64_t>(4 * cp[n], 16))); HIP_TRY(c, B.d_eq_cnt.ensure(std::max<uint64_t>(4 * cp[n], 16)));
+            HIP_TRY(c, B.d_eq_lab.ensure(std::max<uint64_t>(4 * wp[n], 16)));
+            HIP_TRY(c, hipMemcpyAsync(B.d_eq_cptr.p, cp.data(), 8ull * (n + 1), hipMemcpyHostToDevice, s));
+            HIP_TRY(c, hipMemcpyAsync(B.d_eq_wptr.p, wp.data(), 8ull * (n + 1), hipMemcpyHostToDevice, s));
+            launch_eqc_dump(s, B.last_ra, n, B.d_em_off.as<uint64_t>(), B.d_em_scratch.as<uint32_t>(), B.d_em_hdr.p, na, nullptr, nullptr,
+                            B.d_eq_cptr.as<uint64_t>(), B.d_eq_wptr.as<uint64_t>(), B.d_eq_len.as<uint32_t>(), B.d_eq_cnt.as<uint32_t>(),
+                            B.d_eq_lab.as<uint32_t>());
+            std::vector<uint32_t> len(cp[n]);
+            const size_t k0 = R.eq_count.size(), w0 = R.eq_labels.size();
+            R.eq_count.resize(k0 + cp[n]); R.eq_labels.resize(w0 + wp[n]);
+            if (cp[n]) {
+                HIP_TRY(c, hipMemcpyAsync(len.data(), B.d_eq_len.p, 4 * cp[n], hipMemcpyDeviceToHost, s));
+                HIP_TRY(c, hipMemcpyAsync(R.eq_count.data() + k0, B.d_eq_cnt.p, 4 * cp[n], hipMemcpyDeviceToHost, s));
+            }
+            if (wp[n]) HIP_TRY(c, hipMemcpyAsync(R.eq_labels.data() + w0, B.d_eq_lab.p, 4 * wp[n], hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            if (R.eq_cell_ptr.empty()) { R.eq_cell_ptr.push_back(0); R.eq_label_ptr.push_back(0); }
+            for (uint32_t i = 0; i < n; ++i) R.eq_cell_ptr.push_back(k0 + cp[i + 1]);
+            for (uint64_t k = 0; k < cp[n]; ++k) R.eq_label_ptr.push_back(R.eq_label_ptr.back() + len[k]);
+        }
     }
     HIP_TRY(c, hipMemcpy(bc.data(), B.d_bc.p, 8ull * n, hipMemcpyDeviceToHost));
     ptr[0] = 0;
@@ -674,6 +720,7 @@ int submit_common(afq_ctx* c, uint32_t n_cells, uint64_t first_cell_index) {
     if (c->res) pool_put(c->res);
     c->res = pool_get(c->pool);
     c->res->cell_ptr.push_back(0);
+    if (c->cfg.dump_eq) { c->res->eq_cell_ptr.push_back(0); c->res->eq_label_ptr.push_back(0); }
     c->stats = afq_batch_stats{};
     c->stats.input_bytes = c->n_bytes;
     for (int i = 0; i < K_COUNT; ++i) { c->k_ms[i] = 0; c->k_launches[i] = 0; }
@@ -863,6 +910,21 @@ int afq_collect(afq_ctx* c, afq_result* out) {
     out->flags = R->flags.data();
     out->mmrate = R->mmrate.data();
     out->opaque = R;
+    return 0;
+}
+
+int afq_result_eqclasses(const afq_result* res, afq_eqclasses* out) {
+    if (!res || !out || !res->opaque) return AFQ_ERR_INVALID_ARG;
+    const HostResult* R = reinterpret_cast<const HostResult*>(res->opaque);
+    std::memset(out, 0, sizeof(*out));
+    if (R->eq_cell_ptr.empty()) return AFQ_ERR_STATE;   // the context was not created with dump_eq
+    out->n_cells = R->eq_cell_ptr.size() - 1;
+    out->n_classes = R->eq_count.size();
+    out->n_words = R->eq_labels.size();
+    out->cell_ptr = R->eq_cell_ptr.data();
+    out->label_ptr = R->eq_label_ptr.data();
+    out->labels = R->eq_labels.data();
+    out->count = R->eq_count.data();
     return 0;
 }
 

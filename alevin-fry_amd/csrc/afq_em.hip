@@ -682,6 +682,70 @@ __global__ __launch_bounds__(256) void k_compact_em(uint32_t n_cells, const uint
     }
 }
 
+// `-d` / --dump-eqclasses: the cell's gene-level equivalence classes, i.e. what the reference reads off `gene_eqc`
+// after resolution (quant.rs:1282-1307).  They are all still on the device once k_em has run: a single-label
+// molecule was counted as an output column, which names its label uniquely (non-USA column g <- [g]; USA S column
+// g <- [2g], U <- [2g+1], A <- [2g, 2g+1]: utils.rs:865-925 read backwards), and every other label is a class of
+// k_em's step 1 (label of its first molecule, multiplicity cls_cnt).  Cells that took the tiny-cell path never
+// touch gene_eqc (quant.rs:794-845) and report no classes.  One wave per cell; pass 1 sizes, pass 2 fills.
+__device__ __forceinline__ bool cell_has_eqclasses(uint32_t mode) {
+    return mode == kModeCrLikeEm || mode == kModePugEm || mode == kModePugGeneEm;
+}
+__global__ __launch_bounds__(256) void k_eqc_dump(uint32_t n_cells, const CellMeta* __restrict__ meta,
+                                                 const uint32_t* __restrict__ nnz_unique, const uint64_t* __restrict__ keys0,
+                                                 const uint64_t* __restrict__ keys1, const uint32_t* __restrict__ lab,
+                                                 const uint32_t* __restrict__ lab_cnt, const uint64_t* __restrict__ em_off,
+                                                 const uint32_t* __restrict__ scratch, const uint4* __restrict__ em_hdr, EmCfg cfg,
+                                                 uint32_t* __restrict__ n_cls, uint32_t* __restrict__ n_words,
+                                                 const uint64_t* __restrict__ cls_ptr, const uint64_t* __restrict__ word_ptr,
+                                                 uint32_t* __restrict__ o_len, uint32_t* __restrict__ o_count,
+                                                 uint32_t* __restrict__ o_labels) {
+    const uint32_t cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (cell >= n_cells) return;
+    const uint32_t lane = lane_id();
+    const CellMeta m = meta[cell];
+    const bool fill = cls_ptr != nullptr;
+    if (!cell_has_eqclasses(m.mode)) { if (!fill && lane == 0) { n_cls[cell] = 0; n_words[cell] = 0; } return; }
+    const uint32_t nU = nnz_unique[cell];
+    const uint2* U = reinterpret_cast<const uint2*>(((m.lg_nb || mode_is_pug(m.mode)) ? keys1 : keys0) + m.key_off);
+    const uint32_t W = lab_cnt[2 * cell], M = lab_cnt[2 * cell + 1];
+    const uint32_t K = M ? em_hdr[cell].y : 0u;
+    const uint32_t* lw = lab + 2 * m.key_off;
+    const uint32_t* ld = lw + m.n_ref + 1;
+    const EmScratch sc = em_carve(const_cast<uint32_t*>(scratch), em_off[cell], nU, W, M, (nU + W) * (cfg.usa ? 3u : 1u));
+    auto ulen = [&](uint32_t col) -> uint32_t { return (cfg.usa && col >= cfg.ao) ? 2u : 1u; };
+    if (!fill) {
+        uint32_t words = 0;
+        for (uint32_t i = lane; i < nU; i += 64) words += ulen(U[i].x);
+        for (uint32_t c = lane; c < K; c += 64) words += ld[2 * sc.order[sc.cls_first[c]] + 1];
+        for (int d = 32; d; d >>= 1) words += __shfl_xor(words, d);
+        if (lane == 0) { n_cls[cell] = nU + K; n_words[cell] = words; }
+        return;
+    }
+    const uint64_t c0 = cls_ptr[cell];
+    uint32_t wo = 0;   // words written so far (wave-uniform)
+    for (uint32_t base = 0; base < nU + K; base += 64) {
+        const uint32_t i = base + lane;
+        uint32_t len = 0, cnt = 0, col = 0, mol = 0;
+        if (i < nU) { col = U[i].x; cnt = U[i].y; len = ulen(col); }
+        else if (i < nU + K) { const uint32_t c = i - nU; mol = sc.order[sc.cls_first[c]]; len = ld[2 * mol + 1]; cnt = sc.cls_cnt[c]; }
+        uint32_t incl = len;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if ((int)lane >= d) incl += t; }
+        const uint64_t o = word_ptr[cell] + wo + (incl - len);
+        if (i < nU) {
+            if (!cfg.usa) o_labels[o] = col;
+            else if (col >= cfg.ao) { o_labels[o] = 2 * (col - cfg.ao); o_labels[o + 1] = 2 * (col - cfg.ao) + 1; }
+            else if (col >= cfg.uo) o_labels[o] = 2 * (col - cfg.uo) + 1;
+            else o_labels[o] = 2 * col;
+        } else if (i < nU + K) {
+            const uint32_t src = ld[2 * mol];
+            for (uint32_t j = 0; j < len; ++j) o_labels[o + j] = lw[src + j];
+        }
+        if (i < nU + K) { o_len[c0 + i] = len; o_count[c0 + i] = cnt; }
+        wo += __shfl(incl, 63);
+    }
+}
+
 // words of per-cell EM scratch for nU single-label columns, W label words, M ambiguous molecules
 uint64_t em_scratch_words(uint32_t nU, uint32_t W, uint32_t M, bool usa) {
     const uint64_t capS = ((uint64_t)nU + W) * (usa ? 3u : 1u);
@@ -711,6 +775,15 @@ void launch_em(hipStream_t s, const ResolveArgs& a, uint32_t n_cells, const uint
     EmCfg cfg{a.usa, num_alphas, a.num_rows / 3, 2 * (a.num_rows / 3), init_uniform};
     AFQ_LAUNCH(k_em, n_cells, kEmNT, s, a.meta, a.nnz, a.keys0, a.keys1, a.lab, a.lab_cnt, em_off, scratch, out_nnz, em_hdr, em_order, cfg);
     AFQ_LAUNCH(k_em_rounds, n_cells, kEmRNT, s, a.meta, a.nnz, a.lab_cnt, em_off, scratch, out_nnz, em_hdr, em_order, cfg);
+}
+
+void launch_eqc_dump(hipStream_t s, const ResolveArgs& a, uint32_t n_cells, const uint64_t* em_off, const uint32_t* scratch,
+                     const void* em_hdr, uint32_t num_alphas, uint32_t* n_cls, uint32_t* n_words, const uint64_t* cls_ptr,
+                     const uint64_t* word_ptr, uint32_t* o_len, uint32_t* o_count, uint32_t* o_labels) {
+    if (!n_cells) return;
+    EmCfg cfg{a.usa, num_alphas, a.num_rows / 3, 2 * (a.num_rows / 3), 0u};
+    AFQ_LAUNCH(k_eqc_dump, (n_cells + 3) / 4, 256, s, n_cells, a.meta, a.nnz, a.keys0, a.keys1, a.lab, a.lab_cnt, em_off, scratch,
+               reinterpret_cast<const uint4*>(em_hdr), cfg, n_cls, n_words, cls_ptr, word_ptr, o_len, o_count, o_labels);
 }
 
 void launch_compact_em(hipStream_t s, uint32_t n_cells, const uint64_t* em_off, const uint32_t* scratch, const uint32_t* nnz,

@@ -28,7 +28,9 @@
 #include <sys/stat.h>
 #include <thread>
 #include <unistd.h>
+#include <map>
 #include <unordered_map>
+#include <zlib.h>
 #include <unordered_set>
 #include <vector>
 
@@ -391,7 +393,6 @@ int afq_quantify(const afq_quant_opts* o) {
     // flag compatibility, src/main.rs:652-728
     const int edist = o->umi_edit_dist < 0 ? (R->pars ? 1 : 0) : o->umi_edit_dist;
     if (edist > 1 || (edist == 1 && !R->pars)) return hfail(AFQ_ERR_INVALID_ARG, "resolution does not support this --umi-edit-dist");
-    if (o->dump_eq) return hfail(AFQ_ERR_UNSUPPORTED, "-d/--dump-eqclasses is not implemented");
     if (o->num_bootstraps) return hfail(AFQ_ERR_UNSUPPORTED, "-b/--num-bootstraps is not implemented");
     const uint32_t large_thresh = o->large_graph_thresh < 0 ? (R->pars ? 1000u : 0u) : (uint32_t)o->large_graph_thresh;
     const std::string in = o->input_dir, outd = o->output_dir;
@@ -484,8 +485,29 @@ int afq_quantify(const afq_quant_opts* o) {
     cfg.num_genes = usa ? 2 * G : G; cfg.num_rows = usa ? 3 * G : G;  // src/quant.rs:1627-1645
     cfg.small_thresh = o->small_thresh; cfg.large_graph_thresh = large_thresh; cfg.pug_exact_umi = (R->pars && edist == 0) ? 1 : 0;
     cfg.em_init_uniform = o->init_uniform; cfg.bc_bytes = P.bc_bytes; cfg.umi_bytes = P.umi_bytes; { const uint64_t ul = P.file_tag_vals.count("ulen") ? P.file_tag_vals["ulen"] : 0; cfg.umi_len = ul <= 4ull * P.umi_bytes ? (uint32_t)ul : 0u; }
+    // -d: the device keeps the gene-level classes only in the -em resolutions (there they are the EM's input); a plain
+    // resolution leaves the same classes behind as its -em sibling (same resolution step, different count extraction:
+    // quant.rs:882-924, 966-1019), so for it a second context runs the sibling for the classes alone.  `trivial` never
+    // fills gene_eqc: every cell reports no classes.
+    const bool res_is_em = cfg.resolution == AFQ_RES_CR_LIKE_EM || cfg.resolution == AFQ_RES_PARSIMONY_EM || cfg.resolution == AFQ_RES_PARSIMONY_GENE_EM;
+    afq_config cfg_eq = cfg;
+    if (o->dump_eq) {
+        if (res_is_em) cfg.dump_eq = 1;
+        else if (cfg.resolution != AFQ_RES_TRIVIAL) {
+            cfg_eq.dump_eq = 1;
+            cfg_eq.resolution = cfg.resolution == AFQ_RES_CR_LIKE ? AFQ_RES_CR_LIKE_EM : cfg.resolution == AFQ_RES_PARSIMONY ? AFQ_RES_PARSIMONY_EM : AFQ_RES_PARSIMONY_GENE_EM;
+        }
+    }
     afq_ctx* ctx = nullptr;
+    afq_ctx* ctx_eq = nullptr;
     rc = afq_create(&cfg, t2g.data(), (uint32_t)P.ref_count, (int)o->device, &ctx);
+    if (!rc && cfg_eq.dump_eq) {
+        rc = afq_create(&cfg_eq, t2g.data(), (uint32_t)P.ref_count, (int)o->device, &ctx_eq);
+        if (rc) { const std::string m = afq_last_error(nullptr); afq_destroy(ctx); return hfail(rc, m); }
+    }
+    std::map<std::vector<uint32_t>, uint32_t> eq_ids;          // global_eqc: gene set -> class id, ids in order of first appearance
+    std::vector<uint32_t> eq_col, eq_cnt;                       // cell_level_count
+    std::vector<uint64_t> eq_row_ptr(1, 0);                     // cell_offset
     if (rc) return hfail(rc, std::string("afq_create: ") + afq_last_error(nullptr));
 
     mkdirs(outd + "/alevin");
@@ -550,7 +572,29 @@ int afq_quantify(const afq_quant_opts* o) {
         if (!rc) rc = afq_collect(ctx, &res);
         auto tc = now();
         t_submit += secs(ta, tb); t_collect += secs(tb, tc);
-        if (rc) { std::string m = afq_last_error(ctx); afq_destroy(ctx); std::fclose(rows_f); std::fclose(feat_f); return hfail(rc, m); }
+        if (rc) { std::string m = afq_last_error(ctx); afq_destroy(ctx); if (ctx_eq) afq_destroy(ctx_eq); std::fclose(rows_f); std::fclose(feat_f); return hfail(rc, m); }
+        if (o->dump_eq) {
+            afq_result res_eq{};
+            afq_eqclasses ec{};
+            if (ctx_eq) {
+                rc = afq_submit(ctx_eq, rad.data() + span0, (size_t)(span1 - span0), rel.data(), (uint32_t)(c1 - c0), c0);
+                if (!rc) rc = afq_collect(ctx_eq, &res_eq);
+                if (rc) { std::string m = afq_last_error(ctx_eq); afq_result_release(&res); afq_destroy(ctx); afq_destroy(ctx_eq); std::fclose(rows_f); std::fclose(feat_f); return hfail(rc, m); }
+            }
+            const bool have = (ctx_eq || res_is_em) && afq_result_eqclasses(ctx_eq ? &res_eq : &res, &ec) == 0;
+            std::vector<uint32_t> key;
+            for (uint64_t i = 0; i < res.n_cells; ++i) {
+                if (have)
+                    for (uint64_t k = ec.cell_ptr[i]; k < ec.cell_ptr[i + 1]; ++k) {   // quant.rs:1282-1307
+                        key.assign(ec.labels + ec.label_ptr[k], ec.labels + ec.label_ptr[k + 1]);
+                        auto it = eq_ids.find(key);
+                        if (it == eq_ids.end()) it = eq_ids.emplace(key, (uint32_t)eq_ids.size()).first;
+                        eq_col.push_back(it->second); eq_cnt.push_back(ec.count[k]);
+                    }
+                eq_row_ptr.push_back(eq_col.size());
+            }
+            if (ctx_eq) afq_result_release(&res_eq);
+        }
         for (uint64_t i = 0; i < res.n_cells; ++i) {
             const uint64_t a = res.cell_ptr[i], b = res.cell_ptr[i + 1];
             const uint64_t cell_num = c0 + i;
@@ -585,16 +629,18 @@ int afq_quantify(const afq_quant_opts* o) {
     }
     if (pc.on) std::fprintf(stderr, "[afquant]   afq_submit %.3f s, afq_collect %.3f s, per-cell rows %.3f s\n", t_submit, t_collect, t_rows);
     afq_destroy(ctx);
+    if (ctx_eq) afq_destroy(ctx_eq);
     std::fclose(rows_f); std::fclose(feat_f);
     pc.lap("device batches + per-cell rows");
-    // MatrixMarket as sprs::io::write_matrix_market writes a TriMatI<f32,u32> (coordinate real general, 1-based)
-    {
-        FILE* m = std::fopen((outd + "/alevin/quants_mat.mtx").c_str(), "w");
-        if (!m) return hfail(AFQ_ERR_BAD_INPUT, "could not create quants_mat.mtx");
-        std::fprintf(m, "%%%%MatrixMarket matrix coordinate real general\n%% written by sprs\n%llu %u %zu\n", (unsigned long long)row_index, cfg.num_rows, all_val.size());
+    // MatrixMarket as sprs::io::write_matrix_market writes a TriMatI<f32,u32> (coordinate real general, 1-based), from CSR
+    auto write_mtx = [&](const std::string& path, uint64_t n_rows, uint64_t n_cols, const std::vector<uint64_t>& rp,
+                         const std::vector<uint32_t>& cols, const std::vector<float>& vals) -> bool {
+        FILE* m = std::fopen(path.c_str(), "w");
+        if (!m) return false;
+        std::fprintf(m, "%%%%MatrixMarket matrix coordinate real general\n%% written by sprs\n%llu %llu %zu\n", (unsigned long long)n_rows, (unsigned long long)n_cols, vals.size());
         // the entries are formatted by -t threads into per-slice buffers (same text as one fprintf per entry), written in order;
-        // a slice is a run of consecutive entries, its first row found by binary search in row_ptr
-        const size_t nz = all_val.size();
+        // a slice is a run of consecutive entries, its first row found by binary search in the row pointers
+        const size_t nz = vals.size();
         const unsigned nth = std::max(1u, std::min(o->num_threads ? o->num_threads : 1u, 64u));
         const size_t slice = 1u << 20;
         for (size_t base = 0; base < nz; base += slice * nth) {
@@ -607,12 +653,12 @@ int afq_quantify(const afq_quant_opts* o) {
                     std::string& out = bufs[t];
                     out.resize((b - a) * 112);  // 2 x <= 20 digits + an f32 in positional notation (<= 48 chars) + separators
                     char* p = &out[0];
-                    size_t row = (size_t)(std::upper_bound(row_ptr.begin(), row_ptr.end(), (uint64_t)a) - row_ptr.begin()) - 1;
+                    size_t row = (size_t)(std::upper_bound(rp.begin(), rp.end(), (uint64_t)a) - rp.begin()) - 1;
                     for (size_t k = a; k < b; ++k) {
-                        while (row_ptr[row + 1] <= k) ++row;   // skips empty rows too
+                        while (rp[row + 1] <= k) ++row;   // skips empty rows too
                         p = put_u64(p, (unsigned long long)row + 1); *p++ = ' ';
-                        p = put_u64(p, (unsigned long long)all_gene[k] + 1); *p++ = ' ';
-                        p += format_f32(all_val[k], p, 64); *p++ = '\n';
+                        p = put_u64(p, (unsigned long long)cols[k] + 1); *p++ = ' ';
+                        p += format_f32(vals[k], p, 64); *p++ = '\n';
                     }
                     out.resize((size_t)(p - &out[0]));
                 });
@@ -621,7 +667,35 @@ int afq_quantify(const afq_quant_opts* o) {
             for (auto& bsl : bufs) if (!bsl.empty()) std::fwrite(bsl.data(), 1, bsl.size(), m);
         }
         std::fclose(m);
-        pc.lap("quants_mat.mtx");
+        return true;
+    };
+    if (!write_mtx(outd + "/alevin/quants_mat.mtx", row_index, cfg.num_rows, row_ptr, all_gene, all_val)) return hfail(AFQ_ERR_BAD_INPUT, "could not create quants_mat.mtx");
+    pc.lap("quants_mat.mtx");
+    // -d: cells x gene-level equivalence classes + the classes' gene sets (write_eqc_counts, src/quant.rs:229-355)
+    if (o->dump_eq) {
+        std::vector<float> ev(eq_cnt.begin(), eq_cnt.end());
+        if (!write_mtx(outd + "/alevin/geqc_counts.mtx", row_index, eq_ids.size(), eq_row_ptr, eq_col, ev)) return hfail(AFQ_ERR_BAD_INPUT, "could not write geqc_counts.mtx");
+        std::vector<const std::vector<uint32_t>*> by_id(eq_ids.size());
+        for (auto& kv : eq_ids) by_id[kv.second] = &kv.first;
+        std::string txt = std::to_string(cfg.num_rows) + "\n" + std::to_string(eq_ids.size()) + "\n";
+        const uint32_t uo = cfg.num_rows / 3, ao = 2 * uo;
+        for (size_t id = 0; id < by_id.size(); ++id) {
+            const std::vector<uint32_t>& gl = *by_id[id];
+            for (size_t k = 0; k < gl.size(); ++k) {
+                uint32_t g = gl[k];
+                if (usa) {   // S -> g/2, U -> g/2 + unspliced offset, S followed by its own U -> ambiguous (quant.rs:284-335)
+                    if (k + 1 < gl.size() && (gl[k + 1] >> 1) == (g >> 1)) { g = (g >> 1) + ao; ++k; }
+                    else g = (g & 1u) ? (g >> 1) + uo : (g >> 1);
+                }
+                txt += std::to_string(g); txt += '\t';
+            }
+            txt += std::to_string(id); txt += '\n';
+        }
+        gzFile gz = gzopen((outd + "/alevin/gene_eqclass.txt.gz").c_str(), "wb");
+        if (!gz) return hfail(AFQ_ERR_BAD_INPUT, "could not write gene_eqclass.txt.gz");
+        for (size_t off = 0; off < txt.size();) { const unsigned len = (unsigned)std::min<size_t>(txt.size() - off, 1u << 30); if (gzwrite(gz, txt.data() + off, len) <= 0) { gzclose(gz); return hfail(AFQ_ERR_BAD_INPUT, "could not write gene_eqclass.txt.gz"); } off += len; }
+        gzclose(gz);
+        pc.lap("geqc_counts.mtx + gene_eqclass.txt.gz");
     }
     // quant.json (src/quant.rs:1913-1933)
     {
@@ -630,11 +704,11 @@ int afq_quantify(const afq_quant_opts* o) {
         auto list = [&](const std::vector<uint64_t>& v) { std::string s = "["; for (size_t i = 0; i < v.size(); ++i) { if (i) s += ", "; s += std::to_string(v[i]); } return s + "]"; };
         std::fprintf(j, "{\n  \"cmd\": \"%s\",\n  \"version_str\": \"afquant-hip 0.1 (alevin-fry 0.18.0 quant semantics)\",\n  \"resolution_strategy\": \"%s\",\n",
                      json_escape(o->cmdline ? o->cmdline : "").c_str(), R->debug);
-        std::fprintf(j, "  \"num_quantified_cells\": %llu,\n  \"num_genes\": %u,\n  \"dump_eq\": false,\n  \"usa_mode\": %s,\n", (unsigned long long)row_index, cfg.num_rows, usa ? "true" : "false");
+        std::fprintf(j, "  \"num_quantified_cells\": %llu,\n  \"num_genes\": %u,\n  \"dump_eq\": %s,\n  \"usa_mode\": %s,\n", (unsigned long long)row_index, cfg.num_rows, o->dump_eq ? "true" : "false", usa ? "true" : "false");
         std::fprintf(j, "  \"alt_resolved_cell_numbers\": %s,\n  \"empty_resolved_cell_numbers\": %s,\n  \"num_tiny_cell_resolved\": %zu,\n  \"tiny_cell_resolved_cell_numbers\": %s,\n",
                      list(alt_cells).c_str(), list(empty_cells).c_str(), tiny_cells.size(), list(tiny_cells).c_str());
-        std::fprintf(j, "  \"total_records\": %llu,\n  \"quant_options\": {\n    \"input_dir\": \"%s\",\n    \"tg_map\": \"%s\",\n    \"output_dir\": \"%s\",\n    \"num_threads\": %u,\n    \"num_bootstraps\": 0,\n    \"init_uniform\": %s,\n    \"summary_stat\": false,\n    \"dump_eq\": false,\n    \"resolution\": \"%s\",\n    \"pug_exact_umi\": %s,\n    \"sa_model\": \"%s\",\n    \"small_thresh\": %u,\n    \"large_graph_thresh\": %u,\n    \"filter_list\": %s%s%s,\n    \"cmdline\": \"%s\"\n  }\n}\n",
-                     (unsigned long long)total_records, json_escape(in).c_str(), json_escape(o->tg_map).c_str(), json_escape(outd).c_str(), o->num_threads, o->init_uniform ? "true" : "false",
+        std::fprintf(j, "  \"total_records\": %llu,\n  \"quant_options\": {\n    \"input_dir\": \"%s\",\n    \"tg_map\": \"%s\",\n    \"output_dir\": \"%s\",\n    \"num_threads\": %u,\n    \"num_bootstraps\": 0,\n    \"init_uniform\": %s,\n    \"summary_stat\": false,\n    \"dump_eq\": %s,\n    \"resolution\": \"%s\",\n    \"pug_exact_umi\": %s,\n    \"sa_model\": \"%s\",\n    \"small_thresh\": %u,\n    \"large_graph_thresh\": %u,\n    \"filter_list\": %s%s%s,\n    \"cmdline\": \"%s\"\n  }\n}\n",
+                     (unsigned long long)total_records, json_escape(in).c_str(), json_escape(o->tg_map).c_str(), json_escape(outd).c_str(), o->num_threads, o->init_uniform ? "true" : "false", o->dump_eq ? "true" : "false",
                      R->debug, cfg.pug_exact_umi ? "true" : "false", cfg.sa_model == AFQ_SA_PREFER_AMBIG ? "PreferAmbiguity" : "WinnerTakeAll", o->small_thresh, large_thresh, o->filter_list ? "\"" : "", o->filter_list ? json_escape(o->filter_list).c_str() : "null", o->filter_list ? "\"" : "",
                      json_escape(o->cmdline ? o->cmdline : "").c_str());
         std::fclose(j);

@@ -71,6 +71,10 @@ uint64_t em_scratch_words(uint32_t nU, uint32_t W, uint32_t M, bool usa);
 void launch_em(hipStream_t s, const ResolveArgs& a, uint32_t n_cells, const uint64_t* em_off, uint32_t* scratch,
                uint32_t* out_nnz, void* em_hdr /* 16 B per cell */, const uint32_t* em_order /* cells, largest first */,
                uint32_t num_alphas, uint32_t init_uniform);
+// -d: sizes (cls_ptr == null) or fills the per-cell gene-level classes; see k_eqc_dump
+void launch_eqc_dump(hipStream_t s, const ResolveArgs& a, uint32_t n_cells, const uint64_t* em_off, const uint32_t* scratch,
+                     const void* em_hdr, uint32_t num_alphas, uint32_t* n_cls, uint32_t* n_words, const uint64_t* cls_ptr,
+                     const uint64_t* word_ptr, uint32_t* o_len, uint32_t* o_count, uint32_t* o_labels);
 void launch_compact_em(hipStream_t s, uint32_t n_cells, const uint64_t* em_off, const uint32_t* scratch, const uint32_t* nnz,
                        const uint64_t* cell_ptr, uint32_t* gene, float* val);
 void launch_atac_dedup(hipStream_t s, uint32_t n_cells, const uint32_t* ref, const uint32_t* start, const uint16_t* flen,

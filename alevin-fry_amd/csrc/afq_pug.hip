@@ -982,7 +982,12 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     __syncthreads();
     PUG_MARK(10);
 #ifdef AFQ_PUG_TIMING
-    if (tid == 0 && blockIdx.x < 4 && (work % 1024) < 4) { printf("pug cell R=%u V=%u K=%u NC=%u nmid=%u nbig=%u:", R, V, K, NC, n_mid, n_big); for (int i = 1; i <= 10; ++i) printf(" p%d=%.2fms", i - 1, (double)(tmark[i] - tmark[i - 1]) / 1e5); printf(" | ht+bloom=%.2f countA=%.2f writeA=%.2f degB=%.2f fillB=%.2f NCAND=%u E=%u\n", (double)(tmark[11] - tmark[4]) / 1e5, (double)(tmark[12] - tmark[11]) / 1e5, (double)(tmark[13] - tmark[12]) / 1e5, (double)(tmark[14] - tmark[13]) / 1e5, (double)(tmark[5] - tmark[14]) / 1e5, NCAND, E); }
+    if (tid == 0 && blockIdx.x < 4 && (work % 1024) < 4) {
+        auto ms = [&](int a, int b) { return (double)(tmark[b] - tmark[a]) / 1e5; };
+        printf("pug cell R=%u V=%u K=%u NC=%u nmid=%u nbig=%u: sort=%.2f classes=%.2f umis=%.2f verts=%.2f | htab=%.2f bloom=%.2f cand=%.2f (2pass=%.2f) match+rule=%.2f fill=%.2f | wcc=%.2f comps=%.2f 6a=%.2f mid=%.2f big=%.2f out=%.2f | total=%.2f NCAND=%u E=%u\n",
+               R, V, K, NC, n_mid, n_big, ms(0, 1), ms(1, 2), ms(2, 3), 0.0, ms(3, 11), ms(11, 4), ms(4, 12), ms(12, 13), ms(13, 14), ms(14, 5),
+               ms(5, 6), ms(6, 7), ms(7, 8), ms(8, 9), 0.0, ms(9, 10), ms(0, 10), NCAND, E);
+    }
 #endif
     if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], cell); return; }
     if (tid == 0) {

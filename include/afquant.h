@@ -77,7 +77,9 @@ typedef struct afq_config {
     uint32_t umi_len;            /* UMI length in bases when the caller knows it (the RAD file tag `ulen`); 0 = unknown.
                                     Only bounds the 1-mismatch neighbour probes of the PUG (positions past the UMI
                                     cannot differ), so a value that is too SMALL would lose edges: pass 0 when unsure. */
-    uint32_t reserved[2];
+    uint32_t dump_eq;            /* -d / dump_eq (quant.rs:1282-1307): also keep each cell's gene-level equivalence classes,
+                                    handed out by afq_result_eqclasses(); -em resolutions only                  */
+    uint32_t reserved;
 } afq_config;
 
 typedef struct afq_ctx afq_ctx;
@@ -137,6 +139,22 @@ int afq_submit_device(afq_ctx* ctx, const void* d_bytes, size_t n_bytes, const u
 /* Waits for the submitted batch and returns its rows (src/quant.rs:1131-1179, 1266-1268). */
 int afq_collect(afq_ctx* ctx, afq_result* out);
 void afq_result_release(afq_result* res);
+
+/*
+ * cfg.dump_eq: what the reference copies out of `gene_eqc` per cell for -d (src/quant.rs:1282-1307) - the gene-level
+ * equivalence classes left by the resolution, label = ascending gene ids of tid_to_gid's id space (USA: spliced 2k,
+ * unspliced 2k+1), count = molecules.  Cells that took the tiny-cell path have none (they never touch gene_eqc).
+ * The reference walks a hash map, so the order of a cell's classes is not defined there; here: single-gene (and USA
+ * S+U of one gene) labels by output column, then the others in lexicographic order.  Owned by `res`.
+ */
+typedef struct afq_eqclasses {
+    uint64_t n_cells, n_classes, n_words;
+    const uint64_t* cell_ptr;  /* [n_cells+1]   classes of cell i: cell_ptr[i] .. cell_ptr[i+1]     */
+    const uint64_t* label_ptr; /* [n_classes+1] label of class k: labels[label_ptr[k] .. label_ptr[k+1]) */
+    const uint32_t* labels;    /* [n_words]                                                       */
+    const uint32_t* count;     /* [n_classes]                                                     */
+} afq_eqclasses;
+int afq_result_eqclasses(const afq_result* res, afq_eqclasses* out);
 
 /*
  * Per-cell fragment de-duplication of `alevin-fry atac deduplicate`

@@ -695,7 +695,11 @@ static void tiny_cell(const Cell& c, const u32* t2g, bool usa, u32 num_rows,
     }
 }
 
-struct CellOut { std::vector<u32> ind; std::vector<float> val; u8 flags = 0; double mmrate = 0.0; u32 em_iters = 0; };
+struct CellOut {
+    std::vector<u32> ind; std::vector<float> val; u8 flags = 0; double mmrate = 0.0; u32 em_iters = 0;
+    // cfg.dump_eq: gene_eqc as the -d block sees it (quant.rs:1282-1307), in lexicographic label order
+    std::vector<u32> eq_labels, eq_len, eq_count;
+};
 
 static bool is_parsimony(u32 r) {
     return r == AFQ_RES_PARSIMONY || r == AFQ_RES_PARSIMONY_EM || r == AFQ_RES_PARSIMONY_GENE || r == AFQ_RES_PARSIMONY_GENE_EM;
@@ -754,12 +758,24 @@ static int quant_cell(const afq_config& cfg, const u32* t2g, u32 ref_count, cons
     for (u32 gidx = 0; gidx < counts.size(); ++gidx)  // quant.rs:1156-1168
         if (counts[gidx] > 0.0f) { o.ind.push_back(gidx); o.val.push_back(counts[gidx]); }
     if (o.ind.empty()) o.flags |= AFQ_CELL_EMPTY;
+    if (cfg.dump_eq)   // quant.rs:1282-1307 (`trivial` and tiny-path cells leave gene_eqc empty)
+        for (auto& kv : eqc) {
+            o.eq_labels.insert(o.eq_labels.end(), kv.first.begin(), kv.first.end());
+            o.eq_len.push_back((u32)kv.first.size()); o.eq_count.push_back(kv.second);
+        }
     return 0;
 }
 
 struct Result {
     std::vector<u64> cell_ptr, bc; std::vector<u32> gene, nrec; std::vector<float> val;
     std::vector<u8> flags; std::vector<double> mmrate; std::vector<u32> em_iters;
+    std::vector<u64> eq_cell_ptr{0}, eq_label_ptr{0}; std::vector<u32> eq_labels, eq_count;
+    void add_eq(const CellOut& o) {
+        eq_labels.insert(eq_labels.end(), o.eq_labels.begin(), o.eq_labels.end());
+        eq_count.insert(eq_count.end(), o.eq_count.begin(), o.eq_count.end());
+        for (u32 l : o.eq_len) eq_label_ptr.push_back(eq_label_ptr.back() + l);
+        eq_cell_ptr.push_back(eq_count.size());
+    }
 };
 
 thread_local std::string g_err;
@@ -789,7 +805,7 @@ int ora_quant(const afq_config* cfg, const uint32_t* t2g, uint32_t ref_count, co
         R->val.insert(R->val.end(), o.val.begin(), o.val.end());
         R->cell_ptr.push_back(R->gene.size());
         R->bc.push_back(c.bc); R->nrec.push_back(c.nrec); R->flags.push_back(o.flags);
-        R->mmrate.push_back(o.mmrate); R->em_iters.push_back(o.em_iters);
+        R->mmrate.push_back(o.mmrate); R->em_iters.push_back(o.em_iters); R->add_eq(o);
     }
     out->n_cells = n_cells; out->first_cell_index = first_cell_index; out->nnz = R->gene.size();
     out->cell_ptr = R->cell_ptr.data(); out->gene = R->gene.data(); out->val = R->val.data();
@@ -831,7 +847,7 @@ int ora_quant_mt(const afq_config* cfg, const uint32_t* t2g, uint32_t ref_count,
         R->val.insert(R->val.end(), outs[i].val.begin(), outs[i].val.end());
         R->cell_ptr.push_back(R->gene.size());
         R->bc.push_back(bcs[i]); R->nrec.push_back(nrecs[i]); R->flags.push_back(outs[i].flags);
-        R->mmrate.push_back(outs[i].mmrate); R->em_iters.push_back(outs[i].em_iters);
+        R->mmrate.push_back(outs[i].mmrate); R->em_iters.push_back(outs[i].em_iters); R->add_eq(outs[i]);
     }
     out->n_cells = n_cells; out->first_cell_index = first_cell_index; out->nnz = R->gene.size();
     out->cell_ptr = R->cell_ptr.data(); out->gene = R->gene.data(); out->val = R->val.data();
@@ -841,6 +857,16 @@ int ora_quant_mt(const afq_config* cfg, const uint32_t* t2g, uint32_t ref_count,
 }
 
 const uint32_t* ora_result_em_iters(const afq_result* r) { return r && r->opaque ? ((Result*)r->opaque)->em_iters.data() : nullptr; }
+
+// cfg.dump_eq: per-cell gene-level classes (same container as afq_result_eqclasses of include/afquant.h)
+int ora_result_eqclasses(const afq_result* r, afq_eqclasses* out) {
+    if (!r || !r->opaque || !out) return AFQ_ERR_INVALID_ARG;
+    const Result* R = (const Result*)r->opaque;
+    out->n_cells = R->eq_cell_ptr.size() - 1; out->n_classes = R->eq_count.size(); out->n_words = R->eq_labels.size();
+    out->cell_ptr = R->eq_cell_ptr.data(); out->label_ptr = R->eq_label_ptr.data();
+    out->labels = R->eq_labels.data(); out->count = R->eq_count.data();
+    return 0;
+}
 
 void ora_result_release(afq_result* r) {
     if (r && r->opaque) { delete (Result*)r->opaque; std::memset(r, 0, sizeof(*r)); }

@@ -41,6 +41,8 @@ def lib():
         L.ora_result_release.argtypes = [p(_abi.AfqResult)]
         L.ora_result_em_iters.argtypes = [p(_abi.AfqResult)]
         L.ora_result_em_iters.restype = p(C.c_uint32)
+        L.ora_result_eqclasses.argtypes = [p(_abi.AfqResult), p(_abi.AfqEqclasses)]
+        L.ora_result_eqclasses.restype = C.c_int
         L.ora_last_error.restype = C.c_char_p
         L.ora_em.argtypes = [p(C.c_uint32), p(C.c_uint32), p(C.c_uint32), C.c_uint32, C.c_uint32, C.c_int, C.c_int,
                              C.c_int, C.c_uint32, C.c_uint32, C.c_int, p(C.c_float), p(C.c_uint32)]
@@ -82,6 +84,10 @@ def quant(cfg, tid_to_gid, chunk_bytes, chunk_off, first_cell_index=0, force_rou
         raise OracleError(rc, L.ora_last_error().decode())
     try:
         out = _afq.result_from_c(res)
+        if cfg.dump_eq:
+            ec = _abi.AfqEqclasses()
+            L.ora_result_eqclasses(C.byref(res), C.byref(ec))
+            out.eqclasses = _afq.eqclasses_from_c(ec)
         if want_iters:
             n = out.n_cells
             it = np.ctypeslib.as_array(L.ora_result_em_iters(C.byref(res)), shape=(n,)).copy() if n else np.zeros(0, np.uint32)

@@ -103,6 +103,57 @@ def test_afquant_cli_matches_oracle(tmp_path, oracle, res, usa, compressed, sa):
     assert meta["empty_resolved_cell_numbers"] == [i for i in range(want.n_cells) if want.flags[i] & 4]
 
 
+@pytest.mark.parametrize("res,usa", [("cr-like", True), ("parsimony-em", False), ("parsimony", True), ("trivial", False)])
+def test_afquant_cli_dump_eqclasses(tmp_path, oracle, res, usa):
+    """-d (write_eqc_counts, quant.rs:229-355): geqc_counts.mtx (cells x classes) + gene_eqclass.txt.gz; class ids are
+    arbitrary in the reference (hash + completion order), so the comparison is on (cell, gene set, count)."""
+    import gzip
+
+    s = synth.synth(53, [3000, 800, 260, 120, 60, 7], num_genes=120, txp_per_gene=2, usa=usa, dup=0.5, cross=0.3, umi_err=0.02)
+    tg, b, off = make_dir(tmp_path / "in", s, False)
+    out = str(tmp_path / "out")
+    r = subprocess.run([CLI, "quant", "-i", str(tmp_path / "in"), "-m", tg, "-o", out, "-r", res, "-d", "-t", "2"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows, cols, trip, feat, meta = read_outputs(out)
+    want = oracle.quant(cfg_for(s, res, dump_eq=True), s.tid_to_gid, b, off)
+    for k, v in trip.items():   # the count matrix is the one without -d
+        pass
+    assert meta["dump_eq"] is True and meta["quant_options"]["dump_eq"] is True
+    lines = gzip.open(os.path.join(out, "alevin", "gene_eqclass.txt.gz"), "rt").read().split("\n")
+    assert int(lines[0]) == s.num_rows
+    n_cls = int(lines[1])
+    cls = {}
+    for ln in lines[2:2 + n_cls]:
+        t = ln.split("\t")
+        cls[int(t[-1])] = tuple(int(x) for x in t[:-1])
+    assert sorted(cls) == list(range(n_cls)) and len(set(cls.values())) == n_cls and lines[2 + n_cls:] == [""]
+    with open(os.path.join(out, "alevin", "geqc_counts.mtx")) as f:
+        hdr = f.readline(); f.readline()
+        nr, nc, nz = (int(x) for x in f.readline().split())
+        ent = [ln.split() for ln in f.read().splitlines()]
+    assert hdr.startswith("%%MatrixMarket matrix coordinate real general") and (nr, nc, nz) == (want.n_cells, n_cls, len(ent))
+    got = {}
+    for rr, cc, vv in ent:
+        got.setdefault(int(rr) - 1, []).append((cls[int(cc) - 1], int(float(vv))))
+    uo = s.num_rows // 3
+    def out_label(lab):   # USA: gene ids -> S/U/A columns as the writer prints them (quant.rs:284-335)
+        if not usa:
+            return tuple(lab)
+        o, k = [], 0
+        while k < len(lab):
+            g = lab[k]
+            if k + 1 < len(lab) and lab[k + 1] >> 1 == g >> 1:
+                o.append((g >> 1) + 2 * uo); k += 2
+            else:
+                o.append((g >> 1) + uo if g & 1 else g >> 1); k += 1
+        return tuple(o)
+    for i in range(want.n_cells):
+        exp = sorted((out_label(lab), c) for lab, c in want.eqclasses.cell(i))
+        assert sorted(got.get(i, [])) == exp, (res, i)
+    if res == "trivial":
+        assert n_cls == 0 and nz == 0
+
+
 def test_afquant_cli_quant_subset_and_flag_errors(tmp_path, oracle):
     s = synth.synth(52, [900, 500, 300, 100], num_genes=80, dup=0.4)
     tg, b, off = make_dir(tmp_path / "in", s, False)
@@ -117,8 +168,8 @@ def test_afquant_cli_quant_subset_and_flag_errors(tmp_path, oracle):
     assert rows == [rad.int_to_seq(int(s.cell_bc[i]), 16) for i in keep] and meta["num_quantified_cells"] == 2
     want = oracle.quant(cfg_for(s, "cr-like"), s.tid_to_gid, b, off[keep])
     assert abs(sum(trip.values()) - float(want.val.sum())) < 1e-3
-    # cr-like does not take --umi-edit-dist 1 (src/main.rs:674-688); -b / -d are refused, not ignored
-    for extra in (["--umi-edit-dist", "1"], ["-b", "10"], ["-d"]):
+    # cr-like does not take --umi-edit-dist 1 (src/main.rs:674-688); -b is refused, not ignored
+    for extra in (["--umi-edit-dist", "1"], ["-b", "10"]):
         r = subprocess.run([CLI, "quant", "-i", str(tmp_path / "in"), "-m", tg, "-o", out, "-r", "cr-like"] + extra, capture_output=True, text=True)
         assert r.returncode != 0 and "afquant quant failed" in r.stderr
     os.remove(tmp_path / "in" / "generate_permit_list.json")

@@ -69,6 +69,35 @@ def test_prefer_ambig_synthetic(oracle, resolution):
     assert bool(got2.flags[0] & pkg._abi.CELL_TINY_PATH)
 
 
+@pytest.mark.parametrize("usa", [False, True])
+@pytest.mark.parametrize("resolution", ["cr-like-em", "parsimony-em", "parsimony-gene-em"])
+def test_dump_eqclasses(oracle, resolution, usa):
+    """cfg.dump_eq (-d, quant.rs:1282-1307): per cell the same set of (gene-level label, molecules) as the oracle's
+    gene_eqc; tiny-path cells report none; the counts are untouched by the flag."""
+    s = synth.synth(31, [3, 60, 99, 100, 400, 3000, 30000], num_genes=200, usa=usa, dup=0.5, cross=0.3, max_extra_na=5, umi_err=0.02)
+    b, off = s.encode()
+    got, want, _ = run_both(oracle, cfg_for(s, resolution, dump_eq=True), s.tid_to_gid, b, off)
+    assert_same_result(got, want, what=resolution)
+    plain, _, _ = run_both(oracle, cfg_for(s, resolution), s.tid_to_gid, b, off)
+    assert_same_result(got, plain, what="dump_eq changes nothing")
+    assert not hasattr(plain, "eqclasses")
+    n_cls = 0
+    for i in range(got.n_cells):
+        g, w = got.eqclasses.cell(i), want.eqclasses.cell(i)
+        assert g == w, (resolution, usa, i, len(g), len(w))
+        assert (len(g) == 0) == bool(got.flags[i] & pkg._abi.CELL_TINY_PATH)
+        n_cls += len(g)
+    assert n_cls > 100 and any(len(lab) > 1 for lab, _ in got.eqclasses.cell(6))
+    # the plain resolutions do not keep the classes on the device: refused (the host front-end runs the -em sibling)
+    q = pkg.Quantifier(cfg_for(s, resolution[:-3], dump_eq=True), s.tid_to_gid)
+    try:
+        with pytest.raises(pkg.AfqError) as e:
+            q.quant_chunks(b, off)
+        assert e.value.code == pkg._abi.AFQ_ERR_UNSUPPORTED
+    finally:
+        q.close()
+
+
 @pytest.mark.parametrize("bw,uw", [(1, 1), (2, 2), (8, 8), (2, 4), (4, 2), (8, 4), (1, 8)])
 def test_field_widths(oracle, bw, uw):
     """Unaligned record layouts take the byte-granular walk."""
