@@ -5,7 +5,7 @@ infrastructure) can share the struct definitions without loading the HIP library
 """
 import ctypes as C
 
-AFQ_ABI_VERSION = 1
+AFQ_ABI_VERSION = 2
 
 AFQ_OK = 0
 AFQ_ERR_INVALID_ARG = -1
@@ -50,6 +50,9 @@ class AfqConfig(C.Structure):
         ("umi_len", C.c_uint32),
         ("dump_eq", C.c_uint32),
         ("reserved", C.c_uint32),
+        ("num_bootstraps", C.c_uint32),
+        ("summary_stat", C.c_uint32),
+        ("boot_seed", C.c_uint64),
     ]
 
 
@@ -81,6 +84,14 @@ class AfqEqclasses(C.Structure):
     ]
 
 
+class AfqBootstraps(C.Structure):
+    _fields_ = [
+        ("n_cells", C.c_uint64),
+        ("mean_ptr", C.POINTER(C.c_uint64)), ("mean_col", C.POINTER(C.c_uint32)), ("mean_val", C.POINTER(C.c_float)),
+        ("var_ptr", C.POINTER(C.c_uint64)), ("var_col", C.POINTER(C.c_uint32)), ("var_val", C.POINTER(C.c_float)),
+    ]
+
+
 class AfqKernelTime(C.Structure):
     _fields_ = [("name", C.c_char_p), ("ms", C.c_double), ("launches", C.c_uint32), ("pad", C.c_uint32)]
 
@@ -106,6 +117,7 @@ EXPORTS = [
     "afq_collect",
     "afq_result_release",
     "afq_result_eqclasses",
+    "afq_result_bootstraps",
     "afq_atac_dedup",
     "afq_free",
     "afq_get_kernel_times",

@@ -18,7 +18,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _abi
-from ._abi import AfqBatchStats, AfqConfig, AfqEqclasses, AfqKernelTime, AfqResult, RESOLUTIONS
+from ._abi import AfqBatchStats, AfqBootstraps, AfqConfig, AfqEqclasses, AfqKernelTime, AfqResult, RESOLUTIONS
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libafquant.so")
@@ -47,6 +47,9 @@ class WorkerConfig:
     umi_bytes: int = 4
     umi_len: int = 0  # UMI length in bases if known (RAD file tag ulen); 0 = unknown
     dump_eq: bool = False  # -d: keep each cell's gene-level equivalence classes (QuantResult.eqclasses; -em resolutions)
+    num_bootstraps: int = 0  # -b: bootstrap replicates per non-tiny cell (QuantResult.bootstraps; -em resolutions)
+    summary_stat: bool = False  # --summary-stat: population variance of the replicates instead of the n-1 sample variance
+    boot_seed: int = 0  # key of the counter-based generator behind the bootstrap draws
     profile: bool = False
 
     @staticmethod
@@ -76,6 +79,9 @@ class WorkerConfig:
         c.profile = int(self.profile)
         c.umi_len = int(self.umi_len)
         c.dump_eq = 1 if self.dump_eq else 0
+        c.num_bootstraps = int(self.num_bootstraps)
+        c.summary_stat = 1 if self.summary_stat else 0
+        c.boot_seed = int(self.boot_seed)
         return c
 
 
@@ -129,6 +135,37 @@ class EqClasses:
         a, b = int(self.cell_ptr[i]), int(self.cell_ptr[i + 1])
         lp = self.label_ptr
         return sorted((tuple(int(x) for x in self.labels[int(lp[k]):int(lp[k + 1])]), int(self.count[k])) for k in range(a, b))
+
+
+@dataclass
+class Bootstraps:
+    """-b: per-cell non-zero bootstrap means and variances (two CSR matrices; columns = gene ids of gene_eqc's labels)."""
+
+    mean_ptr: np.ndarray
+    mean_col: np.ndarray
+    mean_val: np.ndarray
+    var_ptr: np.ndarray
+    var_col: np.ndarray
+    var_val: np.ndarray
+
+    def mean(self, i: int):
+        a, b = int(self.mean_ptr[i]), int(self.mean_ptr[i + 1])
+        return self.mean_col[a:b], self.mean_val[a:b]
+
+    def var(self, i: int):
+        a, b = int(self.var_ptr[i]), int(self.var_ptr[i + 1])
+        return self.var_col[a:b], self.var_val[a:b]
+
+
+def bootstraps_from_c(bs) -> Bootstraps:
+    def arr(ptr, count, dt):
+        return np.ctypeslib.as_array(ptr, shape=(count,)).astype(dt, copy=True) if count else np.zeros(0, dtype=dt)
+
+    n = int(bs.n_cells)
+    mp, vp = arr(bs.mean_ptr, n + 1, np.uint64), arr(bs.var_ptr, n + 1, np.uint64)
+    nm, nv = int(mp[-1]), int(vp[-1])
+    return Bootstraps(mp, arr(bs.mean_col, nm, np.uint32), arr(bs.mean_val, nm, np.float32), vp, arr(bs.var_col, nv, np.uint32),
+                      arr(bs.var_val, nv, np.float32))
 
 
 def eqclasses_from_c(ec) -> EqClasses:
@@ -209,6 +246,8 @@ def load_library(path: str = LIB_PATH):
     lib.afq_result_release.restype = None
     lib.afq_result_eqclasses.argtypes = [p(AfqResult), p(AfqEqclasses)]
     lib.afq_result_eqclasses.restype = C.c_int
+    lib.afq_result_bootstraps.argtypes = [p(AfqResult), p(AfqBootstraps)]
+    lib.afq_result_bootstraps.restype = C.c_int
     lib.afq_atac_dedup.argtypes = [C.c_void_p, p(C.c_uint32), p(C.c_uint32), p(C.c_uint16), p(C.c_uint64), C.c_uint32,
                                    p(p(C.c_uint64)), p(p(C.c_uint32)), p(p(C.c_uint32)), p(p(C.c_uint16)), p(p(C.c_uint16))]
     lib.afq_atac_dedup.restype = C.c_int
@@ -279,6 +318,10 @@ class Quantifier:
             ec = AfqEqclasses()
             self._check(self.lib.afq_result_eqclasses(C.byref(res), C.byref(ec)))
             out.eqclasses = eqclasses_from_c(ec)
+        if self.cfg.num_bootstraps:
+            bs = AfqBootstraps()
+            self._check(self.lib.afq_result_bootstraps(C.byref(res), C.byref(bs)))
+            out.bootstraps = bootstraps_from_c(bs)
         return out
 
     def quant_chunks(self, chunk_bytes, chunk_off, first_cell_index: int = 0) -> QuantResult:

@@ -55,9 +55,9 @@ struct DevBuf {
     template <class T> T* as() { return reinterpret_cast<T*>(p); }
 };
 
-enum KernelId { K_GATHER = 0, K_DECODE_PAR, K_DECODE, K_HIST, K_BSCAN, K_SCATTER, K_RESOLVE, K_RESOLVE_BIG, K_PUG, K_CELL_HIST, K_EM, K_COMPACT, K_ATAC, K_COUNT };
+enum KernelId { K_GATHER = 0, K_DECODE_PAR, K_DECODE, K_HIST, K_BSCAN, K_SCATTER, K_RESOLVE, K_RESOLVE_BIG, K_PUG, K_CELL_HIST, K_EM, K_BOOT, K_COMPACT, K_ATAC, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"k_gather_headers", "k_decode_par", "k_decode", "k_hist", "k_bucket_scan", "k_scatter",
-                                           "k_resolve", "k_resolve_big", "k_pug_cell", "k_cell_hist", "k_em", "k_compact", "k_atac_dedup"};
+                                           "k_resolve", "k_resolve_big", "k_pug_cell", "k_cell_hist", "k_em", "k_boot", "k_compact", "k_atac_dedup"};
 
 struct TimedLaunch { int id; hipEvent_t a, b; };
 
@@ -91,10 +91,15 @@ struct HostResult {
     // -d: gene-level equivalence classes per cell (cfg.dump_eq): CSR cell -> classes -> label words
     std::vector<uint64_t> eq_cell_ptr, eq_label_ptr;
     std::vector<uint32_t> eq_labels, eq_count;
+    // -b: bootstrap mean / variance per cell, non-zero entries (cfg.num_bootstraps)
+    std::vector<uint64_t> bm_ptr, bv_ptr;
+    std::vector<uint32_t> bm_col, bv_col;
+    std::vector<float> bm_val, bv_val;
     ResultPool* pool = nullptr;
     void clear() {
         cell_ptr.clear(); bc.clear(); nrec.clear(); flags.clear(); mmrate.clear(); gene.n = 0; val.n = 0;
         eq_cell_ptr.clear(); eq_label_ptr.clear(); eq_labels.clear(); eq_count.clear();
+        bm_ptr.clear(); bv_ptr.clear(); bm_col.clear(); bv_col.clear(); bm_val.clear(); bv_val.clear();
     }
 };
 
@@ -138,7 +143,8 @@ struct RangeState {
         d_nnz, d_ovf, d_status, d_bc, d_cell_ptr, d_gene, d_val, d_chk, d_slab_prefix, d_slab_cell, d_cell_bc, d_bdesc, d_lab,
         d_lab_cnt, d_em_off, d_em_scratch, d_em_nnz, d_pug_cells, d_rd_off, d_rd_h, d_rd_u, d_rd_o, d_pug_scr_off,
         d_pug_scratch, d_epool, d_epool_cur, d_alt, d_hist_cells, d_fix, d_em_hdr, d_em_order, d_eq_ncls, d_eq_nw, d_eq_cptr,
-        d_eq_wptr, d_eq_len, d_eq_cnt, d_eq_lab;
+        d_eq_wptr, d_eq_len, d_eq_cnt, d_eq_lab, d_bt_off, d_bt_scratch, d_bt_ns, d_bt_col, d_bt_mean, d_bt_var, d_bt_sptr, d_bt_ccol,
+        d_bt_cmean, d_bt_cvar;
     ResolveArgs last_ra{};
     std::vector<CellMeta> meta;
     Range cur{};
@@ -150,7 +156,8 @@ struct RangeState {
                 &d_ncols, &d_nnz, &d_ovf, &d_status, &d_bc, &d_cell_ptr, &d_gene, &d_val, &d_chk, &d_slab_prefix, &d_slab_cell,
                 &d_cell_bc, &d_bdesc, &d_lab, &d_lab_cnt, &d_em_off, &d_em_scratch, &d_em_nnz, &d_pug_cells, &d_rd_off, &d_rd_h,
                 &d_rd_u, &d_rd_o, &d_pug_scr_off, &d_pug_scratch, &d_epool, &d_epool_cur, &d_alt, &d_hist_cells, &d_fix, &d_em_hdr, &d_em_order,
-                &d_eq_ncls, &d_eq_nw, &d_eq_cptr, &d_eq_wptr, &d_eq_len, &d_eq_cnt, &d_eq_lab};
+                &d_eq_ncls, &d_eq_nw, &d_eq_cptr, &d_eq_wptr, &d_eq_len, &d_eq_cnt, &d_eq_lab, &d_bt_off, &d_bt_scratch, &d_bt_ns, &d_bt_col,
+                &d_bt_mean, &d_bt_var, &d_bt_sptr, &d_bt_ccol, &d_bt_cmean, &d_bt_cvar};
     }
 };
 
@@ -246,6 +253,8 @@ int check_supported(afq_ctx* c) {
         !decode_par_supported(g.bc_bytes, g.umi_bytes))
         return fail(c, AFQ_ERR_UNSUPPORTED, "device parsimony needs 4- or 8-byte barcode/UMI fields");
     if (g.sa_model > AFQ_SA_PREFER_AMBIG) return fail(c, AFQ_ERR_INVALID_ARG, "unknown sa_model");
+    if (g.num_bootstraps && !(g.resolution == AFQ_RES_CR_LIKE_EM || g.resolution == AFQ_RES_PARSIMONY_EM || g.resolution == AFQ_RES_PARSIMONY_GENE_EM))
+        return fail(c, AFQ_ERR_INVALID_ARG, "bootstrapping can only be used with the cr-like-em, parsimony-em, or parsimony-gene-em resolution strategies");   // main.rs:713-724
     if (g.dump_eq && !(g.resolution == AFQ_RES_CR_LIKE_EM || g.resolution == AFQ_RES_PARSIMONY_EM || g.resolution == AFQ_RES_PARSIMONY_GENE_EM))
         return fail(c, AFQ_ERR_UNSUPPORTED, "dump_eq: the gene-level classes are kept only by the -em resolutions (they resolve to the same "
                                             "classes as their plain siblings; afq_quantify runs the sibling for -d)");
@@ -598,7 +607,7 @@ int finish_range(afq_ctx* c, int slot) {
         }
         HIP_TRY(c, hipStreamSynchronize(s));
         HIP_TRY(c, hipMemcpy(nnz.data(), B.d_em_nnz.p, 4ull * n, hipMemcpyDeviceToHost));
-        if (c->cfg.dump_eq) {
+        if (c->cfg.dump_eq || c->cfg.num_bootstraps) {
             // the cells' gene-level classes, read back off the EM set-up (k_eqc_dump): size, prefix on the host, fill
             HostResult& R = *c->res;
             const uint32_t na = c->cfg.usa_mode ? c->cfg.num_rows : c->cfg.num_genes;
@@ -620,18 +629,68 @@ int finish_range(afq_ctx* c, int slot) {
             launch_eqc_dump(s, B.last_ra, n, B.d_em_off.as<uint64_t>(), B.d_em_scratch.as<uint32_t>(), B.d_em_hdr.p, na, nullptr, nullptr,
                             B.d_eq_cptr.as<uint64_t>(), B.d_eq_wptr.as<uint64_t>(), B.d_eq_len.as<uint32_t>(), B.d_eq_cnt.as<uint32_t>(),
                             B.d_eq_lab.as<uint32_t>());
-            std::vector<uint32_t> len(cp[n]);
-            const size_t k0 = R.eq_count.size(), w0 = R.eq_labels.size();
-            R.eq_count.resize(k0 + cp[n]); R.eq_labels.resize(w0 + wp[n]);
-            if (cp[n]) {
-                HIP_TRY(c, hipMemcpyAsync(len.data(), B.d_eq_len.p, 4 * cp[n], hipMemcpyDeviceToHost, s));
-                HIP_TRY(c, hipMemcpyAsync(R.eq_count.data() + k0, B.d_eq_cnt.p, 4 * cp[n], hipMemcpyDeviceToHost, s));
+            if (c->cfg.dump_eq) {
+                std::vector<uint32_t> len(cp[n]);
+                const size_t k0 = R.eq_count.size(), w0 = R.eq_labels.size();
+                R.eq_count.resize(k0 + cp[n]); R.eq_labels.resize(w0 + wp[n]);
+                if (cp[n]) {
+                    HIP_TRY(c, hipMemcpyAsync(len.data(), B.d_eq_len.p, 4 * cp[n], hipMemcpyDeviceToHost, s));
+                    HIP_TRY(c, hipMemcpyAsync(R.eq_count.data() + k0, B.d_eq_cnt.p, 4 * cp[n], hipMemcpyDeviceToHost, s));
+                }
+                if (wp[n]) HIP_TRY(c, hipMemcpyAsync(R.eq_labels.data() + w0, B.d_eq_lab.p, 4 * wp[n], hipMemcpyDeviceToHost, s));
+                HIP_TRY(c, hipStreamSynchronize(s));
+                for (uint32_t i = 0; i < n; ++i) R.eq_cell_ptr.push_back(k0 + cp[i + 1]);
+                for (uint64_t k = 0; k < cp[n]; ++k) R.eq_label_ptr.push_back(R.eq_label_ptr.back() + len[k]);
             }
-            if (wp[n]) HIP_TRY(c, hipMemcpyAsync(R.eq_labels.data() + w0, B.d_eq_lab.p, 4 * wp[n], hipMemcpyDeviceToHost, s));
-            HIP_TRY(c, hipStreamSynchronize(s));
-            if (R.eq_cell_ptr.empty()) { R.eq_cell_ptr.push_back(0); R.eq_label_ptr.push_back(0); }
-            for (uint32_t i = 0; i < n; ++i) R.eq_cell_ptr.push_back(k0 + cp[i + 1]);
-            for (uint64_t k = 0; k < cp[n]; ++k) R.eq_label_ptr.push_back(R.eq_label_ptr.back() + len[k]);
+            if (c->cfg.num_bootstraps) {
+                // bootstrap replicates over those classes (k_boot), then the per-entry summaries compacted and filtered to non-zeros
+                const uint32_t NB = c->cfg.num_bootstraps;
+                const bool ss = c->cfg.summary_stat != 0;
+                std::vector<uint64_t> so(n + 1);
+                so[0] = 0;
+                for (uint32_t i = 0; i < n; ++i) so[i + 1] = so[i] + ((boot_scratch_words(ncls[i], nw[i], NB, ss) + 1) & ~1ull);
+                HIP_TRY(c, B.d_bt_off.ensure(8ull * (n + 1))); HIP_TRY(c, B.d_bt_scratch.ensure(4 * so[n] + 16));
+                HIP_TRY(c, B.d_bt_ns.ensure(4ull * n));
+                const uint64_t wtot = std::max<uint64_t>(wp[n], 4);
+                HIP_TRY(c, B.d_bt_col.ensure(4 * wtot)); HIP_TRY(c, B.d_bt_mean.ensure(4 * wtot)); HIP_TRY(c, B.d_bt_var.ensure(4 * wtot));
+                HIP_TRY(c, hipMemcpyAsync(B.d_bt_off.p, so.data(), 8ull * (n + 1), hipMemcpyHostToDevice, s));
+                {
+                    ScopedTimer t(c, K_BOOT, s, &B.launches);
+                    launch_boot(s, n, B.d_eq_cptr.as<uint64_t>(), B.d_eq_wptr.as<uint64_t>(), B.d_eq_len.as<uint32_t>(), B.d_eq_cnt.as<uint32_t>(),
+                                B.d_eq_lab.as<uint32_t>(), B.d_bt_off.as<uint64_t>(), B.d_bt_scratch.as<uint32_t>(), NB, ss ? 1u : 0u, c->cfg.boot_seed,
+                                c->first_cell_index + B.cur.c0, B.d_bt_ns.as<uint32_t>(), B.d_bt_col.as<uint32_t>(), B.d_bt_mean.as<float>(),
+                                B.d_bt_var.as<float>());
+                }
+                std::vector<uint32_t> ns(n);
+                HIP_TRY(c, hipMemcpyAsync(ns.data(), B.d_bt_ns.p, 4ull * n, hipMemcpyDeviceToHost, s));
+                HIP_TRY(c, hipStreamSynchronize(s));
+                std::vector<uint64_t> sp(n + 1);
+                sp[0] = 0;
+                for (uint32_t i = 0; i < n; ++i) sp[i + 1] = sp[i] + ns[i];
+                const uint64_t stot = std::max<uint64_t>(sp[n], 4);
+                HIP_TRY(c, B.d_bt_sptr.ensure(8ull * (n + 1)));
+                HIP_TRY(c, B.d_bt_ccol.ensure(4 * stot)); HIP_TRY(c, B.d_bt_cmean.ensure(4 * stot)); HIP_TRY(c, B.d_bt_cvar.ensure(4 * stot));
+                HIP_TRY(c, hipMemcpyAsync(B.d_bt_sptr.p, sp.data(), 8ull * (n + 1), hipMemcpyHostToDevice, s));
+                launch_boot_compact(s, n, B.d_eq_wptr.as<uint64_t>(), B.d_bt_sptr.as<uint64_t>(), B.d_bt_col.as<uint32_t>(), B.d_bt_mean.as<float>(),
+                                    B.d_bt_var.as<float>(), B.d_bt_ccol.as<uint32_t>(), B.d_bt_cmean.as<float>(), B.d_bt_cvar.as<float>());
+                std::vector<uint32_t> col(sp[n]);
+                std::vector<float> mean(sp[n]), var(sp[n]);
+                if (sp[n]) {
+                    HIP_TRY(c, hipMemcpyAsync(col.data(), B.d_bt_ccol.p, 4 * sp[n], hipMemcpyDeviceToHost, s));
+                    HIP_TRY(c, hipMemcpyAsync(mean.data(), B.d_bt_cmean.p, 4 * sp[n], hipMemcpyDeviceToHost, s));
+                    HIP_TRY(c, hipMemcpyAsync(var.data(), B.d_bt_cvar.p, 4 * sp[n], hipMemcpyDeviceToHost, s));
+                }
+                HIP_TRY(c, hipStreamSynchronize(s));
+                for (uint32_t i = 0; i < n; ++i) {
+                    for (uint64_t k = sp[i]; k < sp[i + 1]; ++k) {
+                        // record_cell keeps the non-zero entries of each vector (quant.rs:171-180); from replicates a variance
+                        // is only looked at where the mean is non-zero (quant.rs:192-206) - k_boot leaves it 0 there
+                        if (mean[k] != 0.0f) { R.bm_col.push_back(col[k]); R.bm_val.push_back(mean[k]); }
+                        if (var[k] != 0.0f) { R.bv_col.push_back(col[k]); R.bv_val.push_back(var[k]); }
+                    }
+                    R.bm_ptr.push_back(R.bm_col.size()); R.bv_ptr.push_back(R.bv_col.size());
+                }
+            }
         }
     }
     HIP_TRY(c, hipMemcpy(bc.data(), B.d_bc.p, 8ull * n, hipMemcpyDeviceToHost));
@@ -721,6 +780,7 @@ int submit_common(afq_ctx* c, uint32_t n_cells, uint64_t first_cell_index) {
     c->res = pool_get(c->pool);
     c->res->cell_ptr.push_back(0);
     if (c->cfg.dump_eq) { c->res->eq_cell_ptr.push_back(0); c->res->eq_label_ptr.push_back(0); }
+    if (c->cfg.num_bootstraps) { c->res->bm_ptr.push_back(0); c->res->bv_ptr.push_back(0); }
     c->stats = afq_batch_stats{};
     c->stats.input_bytes = c->n_bytes;
     for (int i = 0; i < K_COUNT; ++i) { c->k_ms[i] = 0; c->k_launches[i] = 0; }
@@ -925,6 +985,17 @@ int afq_result_eqclasses(const afq_result* res, afq_eqclasses* out) {
     out->label_ptr = R->eq_label_ptr.data();
     out->labels = R->eq_labels.data();
     out->count = R->eq_count.data();
+    return 0;
+}
+
+int afq_result_bootstraps(const afq_result* res, afq_bootstraps* out) {
+    if (!res || !out || !res->opaque) return AFQ_ERR_INVALID_ARG;
+    const HostResult* R = reinterpret_cast<const HostResult*>(res->opaque);
+    std::memset(out, 0, sizeof(*out));
+    if (R->bm_ptr.empty()) return AFQ_ERR_STATE;   // the context was created with num_bootstraps = 0
+    out->n_cells = R->bm_ptr.size() - 1;
+    out->mean_ptr = R->bm_ptr.data(); out->mean_col = R->bm_col.data(); out->mean_val = R->bm_val.data();
+    out->var_ptr = R->bv_ptr.data(); out->var_col = R->bv_col.data(); out->var_val = R->bv_val.data();
     return 0;
 }
 

@@ -37,7 +37,9 @@ int main(int argc, char** argv) {
         else if (a == "--large-graph-thresh") o.large_graph_thresh = std::atoi(need(i));
         else if (a == "--quant-subset") o.filter_list = need(i);
         else if (a == "--init-uniform") o.init_uniform = 1;
-        else if (a == "--summary-stat" || a == "--use-mtx") {}
+        else if (a == "--summary-stat") o.summary_stat = 1;
+        else if (a == "--boot-seed") o.boot_seed = std::strtoull(need(i), nullptr, 10);
+        else if (a == "--use-mtx") {}
         else if (a == "--use-eds") { std::fprintf(stderr, "--use-eds is no longer supported. EDS output has been removed as of v0.12.\n"); return 1; }
         else if (a == "-d" || a == "--dump-eqclasses") o.dump_eq = 1;
         else if (a == "-b" || a == "--num-bootstraps") o.num_bootstraps = (uint32_t)std::atoi(need(i));
@@ -52,6 +54,10 @@ int main(int argc, char** argv) {
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); usage(); return 2; }
     }
     if (!o.input_dir || !o.tg_map || !o.output_dir || !o.resolution) { usage(); return 2; }
+    if ((o.summary_stat || o.init_uniform) && !o.num_bootstraps) {   // clap `requires("num-bootstraps")`, main.rs:306-307
+        std::fprintf(stderr, "error: the following required arguments were not provided:\n  --num-bootstraps <NUMBOOTSTRAPS>\n");
+        return 2;
+    }
     const int rc = afq_quantify(&o);
     if (rc) { std::fprintf(stderr, "afquant quant failed (%d): %s\n", rc, afq_host_last_error()); return 1; }
     return 0;

@@ -746,6 +746,251 @@ __global__ __launch_bounds__(256) void k_eqc_dump(uint32_t n_cells, const CellMe
     }
 }
 
+// ---------------------------------------------------------------------------
+// -b / --num-bootstraps (run_bootstrap_subset_with_scratch, em.rs:585-690; Multinomial, multinomial.rs:9-49; summaries
+// quant.rs:157-210).  Input: the cell's gene-level classes as k_eqc_dump left them (the canonical class order).  Per
+// replicate the class counts are redrawn - N = sum of counts draws, each a uniform integer below N located in the
+// cumulative counts - and re-estimated by the EM of em_optimize_subset_impl with usa_offsets = None (labels are gene_eqc's
+// gene ids as they are, also in USA mode: quant.rs:1028-1038) from a random start.  The reference's generator is an
+// unseeded ThreadRng; here Philox4x32-10 keyed by the seed and counted by (cell index, replicate, draw), the streams
+// being those of the oracle's header, so that the two agree bit for bit.  f32 order: a class's denominator adds its
+// label in label order, an alpha adds its classes' shares in class order (pairs (entry, class) sorted) - the order of the
+// sequential loop (em.rs:189-218).  One workgroup per cell.
+constexpr int kBootNT = 512;
+constexpr uint32_t kBootLds = 6144;   // classes / support entries whose working arrays live in LDS
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&o)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+struct BootCfg { uint32_t B, summary_stat; uint64_t seed, first_cell_index; };
+
+// per-cell scratch words for K classes with W label words
+uint64_t boot_scratch_words(uint64_t K, uint64_t W, uint32_t B, bool summary_stat) {
+    return (K + 1) + 3 * K + 3 * W + 2 * W + (W + 1) + 2 * W + (summary_stat ? 2 * W : (uint64_t)B * W) + 8;
+}
+
+__global__ __launch_bounds__(kBootNT) void k_boot(const uint64_t* __restrict__ cls_ptr, const uint64_t* __restrict__ word_ptr,
+                                                 const uint32_t* __restrict__ g_len, const uint32_t* __restrict__ g_cnt,
+                                                 const uint32_t* __restrict__ g_lab, const uint64_t* __restrict__ scr_off,
+                                                 uint32_t* __restrict__ scratch, BootCfg cfg, uint32_t* __restrict__ n_support,
+                                                 uint32_t* __restrict__ o_col, float* __restrict__ o_mean, float* __restrict__ o_var) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_buf[4 * kBootLds + 2048];   // sort tile (8192 u32 / 4096 u64), then the EM arrays
+    __shared__ uint32_t s_ws[kBootNT / 64];
+    __shared__ uint32_t s_flag[2];
+    const uint32_t cell = blockIdx.x, tid = threadIdx.x;
+    const uint64_t c0 = cls_ptr[cell], w0 = word_ptr[cell];
+    const uint32_t K = (uint32_t)(cls_ptr[cell + 1] - c0), W = (uint32_t)(word_ptr[cell + 1] - w0);
+    if (K == 0) { if (tid == 0) n_support[cell] = 0; return; }   // tiny-path cell (or nothing resolved): no bootstraps
+    const uint32_t* len = g_len + c0; const uint32_t* cnt0 = g_cnt + c0; const uint32_t* lab = g_lab + w0;
+    uint32_t* p = scratch + scr_off[cell];
+    uint32_t* woff = p; p += K + 1;
+    uint32_t* cum_g = p; p += K;
+    uint32_t* cntb_g = p; p += K;
+    float* inv_g = reinterpret_cast<float*>(p); p += K;
+    uint32_t* sup = p; p += W;
+    uint32_t* supc = p; p += W;
+    uint32_t* widx = p; p += W;
+    p += (p - scratch) & 1;   // 8-byte alignment
+    uint64_t* pairs = reinterpret_cast<uint64_t*>(p); p += 2 * W;
+    uint32_t* seg = p; p += W + 1;
+    float* ain_g = reinterpret_cast<float*>(p); p += W;
+    float* aout_g = reinterpret_cast<float*>(p); p += W;
+    float* acc = reinterpret_cast<float*>(p);   // summary: sum[W], sq[W]; otherwise the replicates [B][S]
+    // 1. label offsets, cumulative counts
+    uint32_t wo = 0, N = 0, multi = 0;
+    for (uint32_t base = 0; base < K; base += kBootNT) {
+        const uint32_t k = base + tid;
+        const uint32_t l = k < K ? len[k] : 0u, c = k < K ? cnt0[k] : 0u;
+        uint32_t tl, tc;
+        const uint32_t el = block_excl_scan<kBootNT>(l, s_ws, tl);
+        const uint32_t ec = block_excl_scan<kBootNT>(c, s_ws, tc);
+        if (k < K) { woff[k] = wo + el; cum_g[k] = N + ec + c; }
+        multi |= l > 1;
+        wo += tl; N += tc;
+    }
+    if (tid == 0) { woff[K] = wo; s_flag[0] = 0; }
+    __syncthreads();
+    if (multi) s_flag[0] = 1;
+    // 2. possible support: the distinct gene ids, ascending
+    for (uint32_t i = tid; i < W; i += kBootNT) sup[i] = lab[i];
+    __syncthreads();
+    const bool needs_em = s_flag[0] != 0;
+    tiled_bitonic_sort_by<kBootNT, 8192>(sup, W, [](uint32_t a, uint32_t b) { return a > b; }, s_buf);
+    uint32_t S = 0;
+    for (uint32_t base = 0; base < W; base += kBootNT) {
+        const uint32_t i = base + tid;
+        const uint32_t h = i < W && (i == 0 || sup[i] != sup[i - 1]);
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<kBootNT>(h, s_ws, tot);
+        if (h) supc[S + ex] = sup[i];
+        S += tot;
+    }
+    __syncthreads();
+    // 3. label word -> support index; (entry, class) pairs sorted: an entry's classes, ascending
+    for (uint32_t i = tid; i < W; i += kBootNT) {
+        const uint32_t g = lab[i];
+        uint32_t lo = 0, hi = S;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (supc[mid] < g) lo = mid + 1; else hi = mid; }
+        widx[i] = lo;
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < K; k += kBootNT)
+        for (uint32_t j = woff[k]; j < woff[k + 1]; ++j) pairs[j] = ((uint64_t)widx[j] << 32) | k;
+    __syncthreads();
+    tiled_bitonic_sort_by<kBootNT, 4096>(pairs, W, [](uint64_t a, uint64_t b) { return a > b; }, reinterpret_cast<uint64_t*>(s_buf));
+    for (uint32_t s = tid; s <= S; s += kBootNT) {
+        const uint64_t key = (uint64_t)s << 32;
+        uint32_t lo = 0, hi = W;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (pairs[mid] < key) lo = mid + 1; else hi = mid; }
+        seg[s] = lo;
+    }
+    __syncthreads();
+    // working arrays: LDS when the cell fits, its scratch otherwise
+    const bool in_lds = K <= kBootLds && S <= kBootLds;
+    uint32_t* cum = in_lds ? s_buf : cum_g;                                   // draws only; shares its space with inv
+    float* inv = in_lds ? reinterpret_cast<float*>(s_buf) : inv_g;
+    uint32_t* cntb = in_lds ? s_buf + kBootLds : cntb_g;
+    float* ain = in_lds ? reinterpret_cast<float*>(s_buf + 2 * kBootLds) : ain_g;
+    float* aout = in_lds ? reinterpret_cast<float*>(s_buf + 3 * kBootLds) : aout_g;
+    if (cfg.summary_stat) for (uint32_t s = tid; s < 2 * S; s += kBootNT) acc[s] = 0.0f;
+    const uint64_t cell_index = cfg.first_cell_index + cell;
+    const uint32_t k0 = (uint32_t)cfg.seed, k1 = (uint32_t)(cfg.seed >> 32), ci0 = (uint32_t)cell_index, ci1 = (uint32_t)(cell_index >> 32);
+    for (uint32_t b = 0; b < cfg.B; ++b) {
+        __syncthreads();
+        // a. multinomial redraw of the class counts
+        if (in_lds) for (uint32_t k = tid; k < K; k += kBootNT) cum[k] = cum_g[k];
+        for (uint32_t k = tid; k < K; k += kBootNT) cntb[k] = 0;
+        __syncthreads();
+        for (uint32_t q = tid; q < (N + 3) / 4; q += kBootNT) {
+            uint32_t w[4];
+            philox4x32_10(q, b, ci0, ci1, k0, k1, w);
+#pragma unroll
+            for (uint32_t t = 0; t < 4; ++t) {
+                if (4 * q + t < N) {
+                    const uint32_t x = (uint32_t)(((uint64_t)w[t] * N) >> 32);
+                    uint32_t lo = 0, hi = K;   // first class whose cumulative count exceeds x
+                    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cum[mid] <= x) lo = mid + 1; else hi = mid; }
+                    atomicAdd(&cntb[lo], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        // b. EM from a random start (single-label counts only when nothing is ambiguous, em.rs:335-341)
+        if (!needs_em) {
+            for (uint32_t s = tid; s < S; s += kBootNT) {
+                float a = 0.0f;
+                for (uint32_t j = seg[s]; j < seg[s + 1]; ++j) a += (float)cntb[(uint32_t)pairs[j]];
+                ain[s] = a;
+            }
+        } else {
+            for (uint32_t q = tid; q < (S + 3) / 4; q += kBootNT) {
+                uint32_t w[4];
+                philox4x32_10(q, b | 0x80000000u, ci0, ci1, k0, k1, w);
+#pragma unroll
+                for (uint32_t t = 0; t < 4; ++t) if (4 * q + t < S) ain[4 * q + t] = (float)(w[t] >> 8) * (1.0f / 16777216.0f) + 1e-5f;
+            }
+            uint32_t it = 0;
+            bool conv = true, last_round = false;
+            while (it < kMinIter || (it < kMaxIter && !conv) || last_round) {
+                __syncthreads();
+                if (tid == 0) s_flag[1] = 0;
+                for (uint32_t k = tid; k < K; k += kBootNT) {   // (A) inv_denominator of the multi-label classes
+                    const uint32_t a = woff[k], e = woff[k + 1];
+                    float v = -1.0f;                              // single label, or denominator 0: no share
+                    if (e - a > 1) {
+                        float den = 0.0f;
+                        for (uint32_t j = a; j < e; ++j) den += ain[widx[j]];
+                        if (den > 0.0f) v = (float)cntb[k] / den;
+                    }
+                    inv[k] = v;
+                }
+                __syncthreads();
+                bool bad = false;
+                for (uint32_t s = tid; s < S; s += kBootNT) {   // (B) alphas_out, classes in order
+                    const float ai = ain[s];
+                    float o = 0.0f;
+                    for (uint32_t j = seg[s]; j < seg[s + 1]; ++j) {
+                        const uint32_t k = (uint32_t)pairs[j];
+                        if (woff[k + 1] - woff[k] == 1) o += (float)cntb[k];
+                        else { const float iv = inv[k]; if (iv >= 0.0f) { const float c = ai * iv; o += c; } }
+                    }
+                    if (o > kAlphaCheckCutoff && fabsf(ai - o) > kRelDiffTol) bad = true;
+                    aout[s] = o;
+                }
+                if (bad) s_flag[1] = 1;
+                __syncthreads();
+                conv = s_flag[1] == 0;
+                ++it;
+                const bool floor_now = !last_round && it >= kMinIter && conv;
+                for (uint32_t s = tid; s < S; s += kBootNT) { const float o = aout[s]; ain[s] = (floor_now && o < kMinOutputAlpha) ? 0.0f : o; }
+                if (last_round) break;
+                if (floor_now) last_round = true;
+            }
+            __syncthreads();
+            for (uint32_t s = tid; s < S; s += kBootNT) if (ain[s] < kMinOutputAlpha) ain[s] = 0.0f;
+        }
+        __syncthreads();
+        // c. running sums (em.rs:662-666) or the replicate itself
+        for (uint32_t s = tid; s < S; s += kBootNT) {
+            const float a = ain[s];
+            if (cfg.summary_stat) { acc[s] += a; acc[S + s] += a * a; }
+            else acc[(uint64_t)b * S + s] = a;
+        }
+    }
+    __syncthreads();
+    // mean / variance per support entry (em.rs:673-683 | quant.rs:185-210); the host keeps the non-zero ones
+    const float n = (float)cfg.B;
+    for (uint32_t s = tid; s < S; s += kBootNT) {
+        float mean, var = 0.0f;
+        if (cfg.summary_stat) {
+            mean = acc[s] / n;
+            var = (acc[S + s] / n) - (mean * mean);
+        } else {
+            float s1 = 0.0f;
+            for (uint32_t b = 0; b < cfg.B; ++b) s1 += acc[(uint64_t)b * S + s];
+            mean = s1 / n;
+            if (mean != 0.0f) {
+                float s2 = 0.0f;
+                for (uint32_t b = 0; b < cfg.B; ++b) { const float d = acc[(uint64_t)b * S + s] - mean; s2 += d * d; }
+                var = s2 / fmaxf(n - 1.0f, 1.0f);
+            }
+        }
+        o_col[w0 + s] = supc[s]; o_mean[w0 + s] = mean; o_var[w0 + s] = var;
+    }
+    if (tid == 0) n_support[cell] = S;
+}
+
+__global__ __launch_bounds__(256) void k_boot_compact(uint32_t n_cells, const uint64_t* __restrict__ word_ptr, const uint64_t* __restrict__ sup_ptr,
+                                                     const uint32_t* __restrict__ i_col, const float* __restrict__ i_mean, const float* __restrict__ i_var,
+                                                     uint32_t* __restrict__ o_col, float* __restrict__ o_mean, float* __restrict__ o_var) {
+    const uint32_t cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (cell >= n_cells) return;
+    const uint64_t src = word_ptr[cell], dst = sup_ptr[cell];
+    const uint32_t S = (uint32_t)(sup_ptr[cell + 1] - dst);
+    for (uint32_t i = lane_id(); i < S; i += 64) { o_col[dst + i] = i_col[src + i]; o_mean[dst + i] = i_mean[src + i]; o_var[dst + i] = i_var[src + i]; }
+}
+
+void launch_boot_compact(hipStream_t s, uint32_t n_cells, const uint64_t* word_ptr, const uint64_t* sup_ptr, const uint32_t* i_col,
+                         const float* i_mean, const float* i_var, uint32_t* o_col, float* o_mean, float* o_var) {
+    if (!n_cells) return;
+    AFQ_LAUNCH(k_boot_compact, (n_cells + 3) / 4, 256, s, n_cells, word_ptr, sup_ptr, i_col, i_mean, i_var, o_col, o_mean, o_var);
+}
+
+void launch_boot(hipStream_t s, uint32_t n_cells, const uint64_t* cls_ptr, const uint64_t* word_ptr, const uint32_t* len,
+                 const uint32_t* cnt, const uint32_t* lab, const uint64_t* scr_off, uint32_t* scratch, uint32_t B, uint32_t summary_stat,
+                 uint64_t seed, uint64_t first_cell_index, uint32_t* n_support, uint32_t* o_col, float* o_mean, float* o_var) {
+    if (!n_cells) return;
+    BootCfg cfg{B, summary_stat, seed, first_cell_index};
+    AFQ_LAUNCH(k_boot, n_cells, kBootNT, s, cls_ptr, word_ptr, len, cnt, lab, scr_off, scratch, cfg, n_support, o_col, o_mean, o_var);
+}
+
 // words of per-cell EM scratch for nU single-label columns, W label words, M ambiguous molecules
 uint64_t em_scratch_words(uint32_t nU, uint32_t W, uint32_t M, bool usa) {
     const uint64_t capS = ((uint64_t)nU + W) * (usa ? 3u : 1u);

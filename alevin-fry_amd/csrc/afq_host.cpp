@@ -393,8 +393,15 @@ int afq_quantify(const afq_quant_opts* o) {
     // flag compatibility, src/main.rs:652-728
     const int edist = o->umi_edit_dist < 0 ? (R->pars ? 1 : 0) : o->umi_edit_dist;
     if (edist > 1 || (edist == 1 && !R->pars)) return hfail(AFQ_ERR_INVALID_ARG, "resolution does not support this --umi-edit-dist");
-    if (o->num_bootstraps) return hfail(AFQ_ERR_UNSUPPORTED, "-b/--num-bootstraps is not implemented");
     const uint32_t large_thresh = o->large_graph_thresh < 0 ? (R->pars ? 1000u : 0u) : (uint32_t)o->large_graph_thresh;
+    if (o->dump_eq && R->id == AFQ_RES_TRIVIAL)   // src/main.rs:705-711
+        return hfail(AFQ_ERR_INVALID_ARG, "Gene equivalence classes are not meaningful in case of Trivial resolution.");
+    if (o->num_bootstraps && !(R->id == AFQ_RES_CR_LIKE_EM || R->id == AFQ_RES_PARSIMONY_EM || R->id == AFQ_RES_PARSIMONY_GENE_EM))   // src/main.rs:713-728
+        return hfail(AFQ_ERR_INVALID_ARG, "The num_bootstraps argument was set to " + std::to_string(o->num_bootstraps) +
+                     ", but bootstrapping can only be used with the cr-like-em, parsimony-em, or parsimony-gene-em resolution strategies");
+    if (o->num_bootstraps && !o->summary_stat)   // BootstrapHelper::new, src/quant.rs:142-148
+        std::fprintf(stderr, "NOTE: Full per-replicate bootstrap output is not yet supported in MTX format. Summary statistics (mean, variance) will be written instead. "
+                             "Full replicate output will be available in a future release via AnnData/h5ad.\n");
     const std::string in = o->input_dir, outd = o->output_dir;
     // the permit-list json must exist (src/main.rs:733-734)
     if (!file_exists(in + "/generate_permit_list.json")) return hfail(AFQ_ERR_BAD_INPUT, "the input directory has no generate_permit_list.json");
@@ -490,6 +497,7 @@ int afq_quantify(const afq_quant_opts* o) {
     // quant.rs:882-924, 966-1019), so for it a second context runs the sibling for the classes alone.  `trivial` never
     // fills gene_eqc: every cell reports no classes.
     const bool res_is_em = cfg.resolution == AFQ_RES_CR_LIKE_EM || cfg.resolution == AFQ_RES_PARSIMONY_EM || cfg.resolution == AFQ_RES_PARSIMONY_GENE_EM;
+    cfg.num_bootstraps = o->num_bootstraps; cfg.summary_stat = o->summary_stat; cfg.boot_seed = o->boot_seed;
     afq_config cfg_eq = cfg;
     if (o->dump_eq) {
         if (res_is_em) cfg.dump_eq = 1;
@@ -508,6 +516,8 @@ int afq_quantify(const afq_quant_opts* o) {
     std::map<std::vector<uint32_t>, uint32_t> eq_ids;          // global_eqc: gene set -> class id, ids in order of first appearance
     std::vector<uint32_t> eq_col, eq_cnt;                       // cell_level_count
     std::vector<uint64_t> eq_row_ptr(1, 0);                     // cell_offset
+    std::vector<uint32_t> bm_col, bv_col; std::vector<float> bm_val, bv_val;   // BootstrapHelper's mean / variance triplets, as CSR
+    std::vector<uint64_t> bm_ptr(1, 0), bv_ptr(1, 0);
     if (rc) return hfail(rc, std::string("afq_create: ") + afq_last_error(nullptr));
 
     mkdirs(outd + "/alevin");
@@ -573,6 +583,17 @@ int afq_quantify(const afq_quant_opts* o) {
         auto tc = now();
         t_submit += secs(ta, tb); t_collect += secs(tb, tc);
         if (rc) { std::string m = afq_last_error(ctx); afq_destroy(ctx); if (ctx_eq) afq_destroy(ctx_eq); std::fclose(rows_f); std::fclose(feat_f); return hfail(rc, m); }
+        if (o->num_bootstraps) {   // quant.rs:1270-1277
+            afq_bootstraps bs{};
+            if (afq_result_bootstraps(&res, &bs) == 0) {
+                bm_col.insert(bm_col.end(), bs.mean_col, bs.mean_col + bs.mean_ptr[bs.n_cells]);
+                bm_val.insert(bm_val.end(), bs.mean_val, bs.mean_val + bs.mean_ptr[bs.n_cells]);
+                bv_col.insert(bv_col.end(), bs.var_col, bs.var_col + bs.var_ptr[bs.n_cells]);
+                bv_val.insert(bv_val.end(), bs.var_val, bs.var_val + bs.var_ptr[bs.n_cells]);
+                const uint64_t m0 = bm_ptr.back(), v0 = bv_ptr.back();
+                for (uint64_t i = 0; i < bs.n_cells; ++i) { bm_ptr.push_back(m0 + bs.mean_ptr[i + 1]); bv_ptr.push_back(v0 + bs.var_ptr[i + 1]); }
+            }
+        }
         if (o->dump_eq) {
             afq_result res_eq{};
             afq_eqclasses ec{};
@@ -671,6 +692,13 @@ int afq_quantify(const afq_quant_opts* o) {
     };
     if (!write_mtx(outd + "/alevin/quants_mat.mtx", row_index, cfg.num_rows, row_ptr, all_gene, all_val)) return hfail(AFQ_ERR_BAD_INPUT, "could not create quants_mat.mtx");
     pc.lap("quants_mat.mtx");
+    // -b: bootstrap summary matrices, cells x num_rows (src/quant.rs:1850-1877; nothing is written when no cell had a bootstrap)
+    if (o->num_bootstraps && !bm_val.empty()) {
+        if (!write_mtx(outd + "/alevin/bootstraps_mean.mtx", row_index, cfg.num_rows, bm_ptr, bm_col, bm_val) ||
+            !write_mtx(outd + "/alevin/bootstraps_var.mtx", row_index, cfg.num_rows, bv_ptr, bv_col, bv_val))
+            return hfail(AFQ_ERR_BAD_INPUT, "could not write the bootstrap matrices");
+        pc.lap("bootstraps_mean.mtx + bootstraps_var.mtx");
+    }
     // -d: cells x gene-level equivalence classes + the classes' gene sets (write_eqc_counts, src/quant.rs:229-355)
     if (o->dump_eq) {
         std::vector<float> ev(eq_cnt.begin(), eq_cnt.end());
@@ -707,8 +735,8 @@ int afq_quantify(const afq_quant_opts* o) {
         std::fprintf(j, "  \"num_quantified_cells\": %llu,\n  \"num_genes\": %u,\n  \"dump_eq\": %s,\n  \"usa_mode\": %s,\n", (unsigned long long)row_index, cfg.num_rows, o->dump_eq ? "true" : "false", usa ? "true" : "false");
         std::fprintf(j, "  \"alt_resolved_cell_numbers\": %s,\n  \"empty_resolved_cell_numbers\": %s,\n  \"num_tiny_cell_resolved\": %zu,\n  \"tiny_cell_resolved_cell_numbers\": %s,\n",
                      list(alt_cells).c_str(), list(empty_cells).c_str(), tiny_cells.size(), list(tiny_cells).c_str());
-        std::fprintf(j, "  \"total_records\": %llu,\n  \"quant_options\": {\n    \"input_dir\": \"%s\",\n    \"tg_map\": \"%s\",\n    \"output_dir\": \"%s\",\n    \"num_threads\": %u,\n    \"num_bootstraps\": 0,\n    \"init_uniform\": %s,\n    \"summary_stat\": false,\n    \"dump_eq\": %s,\n    \"resolution\": \"%s\",\n    \"pug_exact_umi\": %s,\n    \"sa_model\": \"%s\",\n    \"small_thresh\": %u,\n    \"large_graph_thresh\": %u,\n    \"filter_list\": %s%s%s,\n    \"cmdline\": \"%s\"\n  }\n}\n",
-                     (unsigned long long)total_records, json_escape(in).c_str(), json_escape(o->tg_map).c_str(), json_escape(outd).c_str(), o->num_threads, o->init_uniform ? "true" : "false", o->dump_eq ? "true" : "false",
+        std::fprintf(j, "  \"total_records\": %llu,\n  \"quant_options\": {\n    \"input_dir\": \"%s\",\n    \"tg_map\": \"%s\",\n    \"output_dir\": \"%s\",\n    \"num_threads\": %u,\n    \"num_bootstraps\": %u,\n    \"init_uniform\": %s,\n    \"summary_stat\": %s,\n    \"dump_eq\": %s,\n    \"resolution\": \"%s\",\n    \"pug_exact_umi\": %s,\n    \"sa_model\": \"%s\",\n    \"small_thresh\": %u,\n    \"large_graph_thresh\": %u,\n    \"filter_list\": %s%s%s,\n    \"cmdline\": \"%s\"\n  }\n}\n",
+                     (unsigned long long)total_records, json_escape(in).c_str(), json_escape(o->tg_map).c_str(), json_escape(outd).c_str(), o->num_threads, o->num_bootstraps, o->init_uniform ? "true" : "false", o->summary_stat ? "true" : "false", o->dump_eq ? "true" : "false",
                      R->debug, cfg.pug_exact_umi ? "true" : "false", cfg.sa_model == AFQ_SA_PREFER_AMBIG ? "PreferAmbiguity" : "WinnerTakeAll", o->small_thresh, large_thresh, o->filter_list ? "\"" : "", o->filter_list ? json_escape(o->filter_list).c_str() : "null", o->filter_list ? "\"" : "",
                      json_escape(o->cmdline ? o->cmdline : "").c_str());
         std::fclose(j);

@@ -75,6 +75,13 @@ void launch_em(hipStream_t s, const ResolveArgs& a, uint32_t n_cells, const uint
 void launch_eqc_dump(hipStream_t s, const ResolveArgs& a, uint32_t n_cells, const uint64_t* em_off, const uint32_t* scratch,
                      const void* em_hdr, uint32_t num_alphas, uint32_t* n_cls, uint32_t* n_words, const uint64_t* cls_ptr,
                      const uint64_t* word_ptr, uint32_t* o_len, uint32_t* o_count, uint32_t* o_labels);
+// -b: bootstrap mean / variance per support entry of every cell, from the dumped classes; see k_boot
+uint64_t boot_scratch_words(uint64_t K, uint64_t W, uint32_t B, bool summary_stat);
+void launch_boot(hipStream_t s, uint32_t n_cells, const uint64_t* cls_ptr, const uint64_t* word_ptr, const uint32_t* len,
+                 const uint32_t* cnt, const uint32_t* lab, const uint64_t* scr_off, uint32_t* scratch, uint32_t B, uint32_t summary_stat,
+                 uint64_t seed, uint64_t first_cell_index, uint32_t* n_support, uint32_t* o_col, float* o_mean, float* o_var);
+void launch_boot_compact(hipStream_t s, uint32_t n_cells, const uint64_t* word_ptr, const uint64_t* sup_ptr, const uint32_t* i_col,
+                         const float* i_mean, const float* i_var, uint32_t* o_col, float* o_mean, float* o_var);
 void launch_compact_em(hipStream_t s, uint32_t n_cells, const uint64_t* em_off, const uint32_t* scratch, const uint32_t* nnz,
                        const uint64_t* cell_ptr, uint32_t* gene, float* val);
 void launch_atac_dedup(hipStream_t s, uint32_t n_cells, const uint32_t* ref, const uint32_t* start, const uint16_t* flen,

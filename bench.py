@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--resolution", default="cr-like",
                     help="default cr-like = configs[1] (the headline line); parsimony-em with --usa = configs[2]")
     ap.add_argument("--umi-err", type=float, default=0.01)
+    ap.add_argument("--bootstraps", type=int, default=0, help="-b: bootstrap replicates per cell (-em resolutions; extra measurement, not the default)")
     ap.add_argument("--atac", action="store_true", help="configs[4]: scATAC fragment dedup (extra line, not the default)")
     ap.add_argument("--frags-per-cell", type=int, default=20000)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (rank 0, N=1 only)")
@@ -75,7 +76,7 @@ def main():
     t_gen = time.time() - t0
     d_bytes = torch.from_numpy(rad.data).to(dev)
     cfg = pkg.WorkerConfig.for_resolution(args.resolution, usa_mode=rad.usa, num_genes=rad.num_genes,
-                                          num_rows=rad.num_rows, profile=True, umi_len=12)  # umi_len: what the RAD header's `ulen` tag says
+                                          num_rows=rad.num_rows, profile=True, umi_len=12, num_bootstraps=args.bootstraps, summary_stat=True)  # umi_len: what the RAD header's `ulen` tag says
     q = pkg.Quantifier(cfg, rad.tid_to_gid, device=local_rank)
 
     res = None
@@ -216,7 +217,7 @@ def main():
                                f": PBMC-10k-like 10x-v3 collated RAD, {args.resolution}, per GPU: "
                                f"{args.cells} cells, log-normal reads/cell median {args.median_reads:g} sigma {args.sigma:g}, "
                                f"{args.genes} genes" + (", USA" if args.usa else ""),
-                   "reads_per_gpu": rad.n_reads, "input_bytes_per_gpu": st["input_bytes"], "resolution": args.resolution,
+                   "reads_per_gpu": rad.n_reads, "input_bytes_per_gpu": st["input_bytes"], "resolution": args.resolution, **({"bootstraps": args.bootstraps} if args.bootstraps else {}),
                    "sharding": f"{world} x independent cell shards, no data-path collective"},
         "cells_per_s": round(total_cells * args.steps / elapsed, 1),
         "nnz": nnz,

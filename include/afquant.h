@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AFQ_ABI_VERSION 1
+#define AFQ_ABI_VERSION 2
 
 /* error codes */
 #define AFQ_OK 0
@@ -80,6 +80,16 @@ typedef struct afq_config {
     uint32_t dump_eq;            /* -d / dump_eq (quant.rs:1282-1307): also keep each cell's gene-level equivalence classes,
                                     handed out by afq_result_eqclasses(); -em resolutions only                  */
     uint32_t reserved;
+    /* -b / --num-bootstraps with --summary-stat (src/quant.rs:1028-1038, em.rs:585-757; -em resolutions only, main.rs:713-724):
+       per non-tiny cell, num_bootstraps times: the counts of its gene-level classes are redrawn from a multinomial over the
+       observed counts and re-estimated by the EM from a random start; afq_result_bootstraps() hands out the per-column mean
+       and variance.  The reference draws from an unseeded thread RNG - its numbers are not reproducible; here the draws
+       are Philox4x32-10 keyed by boot_seed and the cell's index (first_cell_index + i), so a run is reproducible and does
+       not depend on batching. */
+    uint32_t num_bootstraps;
+    uint32_t summary_stat;       /* 1: mean and E[x^2]-mean^2 (em.rs:673-683); 0: mean and the n-1 sample variance over the
+                                    replicates (quant.rs:185-210).  Either way only the two summaries are produced, as in the reference */
+    uint64_t boot_seed;
 } afq_config;
 
 typedef struct afq_ctx afq_ctx;
@@ -155,6 +165,20 @@ typedef struct afq_eqclasses {
     const uint32_t* count;     /* [n_classes]                                                     */
 } afq_eqclasses;
 int afq_result_eqclasses(const afq_result* res, afq_eqclasses* out);
+
+/*
+ * cfg.num_bootstraps > 0: what BootstrapHelper::record_cell[_from_replicates] collects (src/quant.rs:157-210): per cell
+ * the non-zero bootstrap means and variances, as two CSR matrices over the same cells.  Columns are the alpha indices the
+ * reference's run_bootstrap uses - the gene ids of gene_eqc's labels (in USA mode that is the spliced/unspliced id 2k /
+ * 2k+1, NOT the S/U/A output column: run_bootstrap_with_scratch is handed gene_eqc as is, quant.rs:1028-1038).
+ * Tiny-path cells have no bootstraps.  Owned by `res`.
+ */
+typedef struct afq_bootstraps {
+    uint64_t n_cells;
+    const uint64_t* mean_ptr; const uint32_t* mean_col; const float* mean_val;   /* [n_cells+1], [nnz], [nnz] */
+    const uint64_t* var_ptr;  const uint32_t* var_col;  const float* var_val;
+} afq_bootstraps;
+int afq_result_bootstraps(const afq_result* res, afq_bootstraps* out);
 
 /*
  * Per-cell fragment de-duplication of `alevin-fry atac deduplicate`

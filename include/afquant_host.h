@@ -27,12 +27,13 @@ typedef struct afq_quant_opts {
     int32_t umi_edit_dist;      /* --umi-edit-dist : -1 = default by resolution (main.rs:652-703)                          */
     int32_t large_graph_thresh; /* --large-graph-thresh : -1 = default by resolution (main.rs:332-341)                     */
     uint32_t init_uniform;      /* --init-uniform                                                                          */
-    uint32_t dump_eq;           /* -d : not implemented (rejected)                                                         */
-    uint32_t num_bootstraps;    /* -b : not implemented (rejected)                                                         */
+    uint32_t dump_eq;           /* -d : also write geqc_counts.mtx + gene_eqclass.txt.gz (quant.rs:229-355)                */
+    uint32_t num_bootstraps;    /* -b : bootstrap replicates; writes bootstraps_mean.mtx + bootstraps_var.mtx (quant.rs:1850-1877) */
     uint32_t device;            /* HIP device ordinal                                                                      */
     uint64_t batch_bytes;       /* chunk bytes handed to the device per afq_submit (0 = 1 GiB)                             */
     uint32_t sa_model;          /* --sa-model (hidden): afq_sa_model; ignored with a log line outside USA mode (quant.rs:1456) */
-    uint32_t reserved;
+    uint32_t summary_stat;      /* --summary-stat (requires -b)                                                            */
+    uint64_t boot_seed;         /* seed of the bootstrap draws (the reference's are unseeded); --boot-seed, default 0     */
 } afq_quant_opts;
 
 /* Runs the whole `quant` sub-command.  Returns 0 or a negative AFQ_ERR_* code; message via afq_host_last_error(). */

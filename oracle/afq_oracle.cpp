@@ -667,6 +667,138 @@ static void em_optimize_subset(const IdxEq& q, u32 num_alphas, bool only_unique,
 }
 
 // ---------------------------------------------------------------------------
+// Bootstraps, src/em.rs:585-757 (run_bootstrap_with_scratch -> run_bootstrap_subset_with_scratch), the multinomial of
+// src/multinomial.rs:9-49 (nsamp draws from a WeightedIndex = uniform integer below the total, binary search in the
+// cumulative weights) and the summaries of src/quant.rs:157-210.
+// The reference's generator is `rand::rng()` (unseeded ThreadRng): its numbers are not reproducible and no run of it can
+// be matched - parity here is statistical by construction.  To make the oracle and the device comparable bit for bit the
+// draws are restated on a counter-based generator both sides implement independently from the published algorithm
+// (Philox4x32-10, Salmon et al., SC'11; known-answer vectors of the Random123 distribution in tests/):
+//   draw j of replicate b of cell c   = word j&3 of philox(ctr = (j>>2, b, c_lo, c_hi), key = (seed_lo, seed_hi))
+//   start value of support entry s    = word s&3 of philox(ctr = (s>>2, b | 2^31, c_lo, c_hi), same key)
+// Hash-order dependent pieces get a canonical order (parity unpinned, as everywhere else): classes = first the labels that
+// are one output column (by column), then the rest lexicographically - the order the device keeps them in; support = gene
+// ids ascending (the reference's is first-touch order, which only decides which entry gets which random start).
+static inline void philox4x32_10(const u32 ctr[4], const u32 key[2], u32 out[4]) {
+    u32 c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        const u64 p0 = (u64)0xD2511F53u * c0, p1 = (u64)0xCD9E8D57u * c2;
+        const u32 n0 = (u32)(p1 >> 32) ^ c1 ^ k0, n1 = (u32)p1, n2 = (u32)(p0 >> 32) ^ c3 ^ k1, n3 = (u32)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+struct BootOut { std::vector<u32> mean_col, var_col; std::vector<float> mean_val, var_val; };
+
+static int64_t single_column_of(const std::vector<u32>& lab, bool usa, u32 uo, u32 ao) {
+    if (lab.size() == 1) return !usa ? (int64_t)lab[0] : (is_spliced(lab[0]) ? (int64_t)(lab[0] >> 1) : (int64_t)uo + (lab[0] >> 1));
+    if (usa && lab.size() == 2 && same_gene(lab[0], lab[1])) return (int64_t)ao + (lab[0] >> 1);
+    return -1;
+}
+
+static void bootstrap_cell(const GeneEqc& eqc, bool usa, u32 num_rows, u32 num_alphas, u32 B, bool summary_stat, u64 seed,
+                           u64 cell_index, BootOut& o) {
+    o = BootOut();
+    if (eqc.empty() || B == 0) return;
+    const u32 uo = num_rows / 3, ao = 2 * uo;
+    // cell_data in the canonical class order
+    std::vector<std::pair<int64_t, const std::vector<u32>*>> single;
+    std::vector<const std::vector<u32>*> order;
+    for (auto& kv : eqc) { int64_t c = single_column_of(kv.first, usa, uo, ao); if (c >= 0) single.push_back({c, &kv.first}); }
+    std::sort(single.begin(), single.end(), [](auto& a, auto& b) { return a.first < b.first; });
+    for (auto& x : single) order.push_back(x.second);
+    for (auto& kv : eqc) if (single_column_of(kv.first, usa, uo, ao) < 0) order.push_back(&kv.first);
+    const size_t K = order.size();
+    std::vector<u32> base(K);
+    std::vector<u64> cum(K);
+    u64 N = 0;
+    bool needs_em = false;
+    for (size_t k = 0; k < K; ++k) { base[k] = eqc.at(*order[k]); N += base[k]; cum[k] = N; if (order[k]->size() > 1) needs_em = true; }
+    // possible support (prepare_support, em.rs:87-113, no USA siblings: usa_offsets is None for the bootstrap, em.rs:632)
+    std::vector<u32> support;
+    for (auto* l : order) support.insert(support.end(), l->begin(), l->end());
+    std::sort(support.begin(), support.end());
+    support.erase(std::unique(support.begin(), support.end()), support.end());
+    for (u32 g : support) if (g >= num_alphas) return;   // the reference asserts (em.rs:72-75); cannot happen: ids < num_genes <= num_alphas
+    const size_t S = support.size();
+    std::vector<float> ain(num_alphas, 0.0f), aout(num_alphas, 0.0f), sum(S, 0.0f), sq(S, 0.0f), reps;
+    if (!summary_stat) reps.assign((size_t)B * S, 0.0f);
+    const u32 key[2] = {(u32)seed, (u32)(seed >> 32)};
+    std::vector<u32> cnt(K);
+    for (u32 b = 0; b < B; ++b) {
+        // Multinomial::sample_u32, multinomial.rs:37-48
+        std::fill(cnt.begin(), cnt.end(), 0u);
+        u32 w[4];
+        for (u64 j = 0; j < N; ++j) {
+            if ((j & 3) == 0) { const u32 ctr[4] = {(u32)(j >> 2), b, (u32)cell_index, (u32)(cell_index >> 32)}; philox4x32_10(ctr, key, w); }
+            const u64 x = ((u64)w[j & 3] * N) >> 32;   // uniform below the total weight
+            const size_t k = (size_t)(std::upper_bound(cum.begin(), cum.end(), x) - cum.begin());
+            cnt[k] += 1;
+        }
+        // em_optimize_subset_impl(.., EmInitType::Random, .., only_unique = false, usa_offsets = None, ..), em.rs:306-456
+        for (u32 g : support) { ain[g] = 0.0f; aout[g] = 0.0f; }
+        for (size_t k = 0; k < K; ++k) if (order[k]->size() == 1) ain[(*order[k])[0]] += (float)cnt[k];
+        if (needs_em) {
+            for (size_t si = 0; si < S; ++si) {
+                if ((si & 3) == 0) { const u32 ctr[4] = {(u32)(si >> 2), b | 0x80000000u, (u32)cell_index, (u32)(cell_index >> 32)}; philox4x32_10(ctr, key, w); }
+                ain[support[si]] = (float)(w[si & 3] >> 8) * (1.0f / 16777216.0f) + 1e-5f;   // rng.random::<f32>() + 1e-5, em.rs:379-381
+            }
+            u32 it = 0; bool conv = true, last_round = false;
+            while (it < MIN_ITER || (it < MAX_ITER && !conv) || last_round) {
+                for (size_t k = 0; k < K; ++k) {   // em_update_subset, em.rs:189-218
+                    const std::vector<u32>& lab = *order[k];
+                    if (lab.size() > 1) {
+                        float den = 0.0f;
+                        for (u32 l : lab) den += ain[l];
+                        if (den > 0.0f) {
+                            const float inv = (float)cnt[k] / den;
+                            for (u32 l : lab) { const float c = ain[l] * inv; aout[l] += c; }
+                        }
+                    } else aout[lab[0]] += (float)cnt[k];
+                }
+                conv = true;
+                for (u32 i : support) {
+                    if (aout[i] > ALPHA_CHECK_CUTOFF) { if (std::fabs(ain[i] - aout[i]) > REL_DIFF_TOLERANCE) conv = false; }
+                    ain[i] = aout[i]; aout[i] = 0.0f;
+                }
+                ++it;
+                if (last_round) break;
+                if (it >= MIN_ITER && conv) { for (u32 i : support) if (ain[i] < MIN_OUTPUT_ALPHA) ain[i] = 0.0f; last_round = true; }
+            }
+            for (u32 i : support) if (ain[i] < MIN_OUTPUT_ALPHA) ain[i] = 0.0f;
+        }
+        for (size_t si = 0; si < S; ++si) {
+            const float a = ain[support[si]];
+            if (summary_stat) { sum[si] += a; sq[si] += a * a; }   // em.rs:662-666
+            else reps[(size_t)b * S + si] = a;
+        }
+    }
+    for (size_t si = 0; si < S; ++si) {
+        float mean, var;
+        if (summary_stat) {   // em.rs:673-683, then record_cell keeps the non-zero entries of each (quant.rs:159-182)
+            mean = sum[si] / (float)B;
+            var = (sq[si] / (float)B) - (mean * mean);
+            if (mean != 0.0f) { o.mean_col.push_back(support[si]); o.mean_val.push_back(mean); }
+            if (var != 0.0f) { o.var_col.push_back(support[si]); o.var_val.push_back(var); }
+        } else {              // record_cell_from_replicates, quant.rs:185-210
+            const float n = (float)B;
+            float s1 = 0.0f;
+            for (u32 b = 0; b < B; ++b) s1 += reps[(size_t)b * S + si];
+            mean = s1 / n;
+            if (mean != 0.0f) {
+                o.mean_col.push_back(support[si]); o.mean_val.push_back(mean);
+                float s2 = 0.0f;
+                for (u32 b = 0; b < B; ++b) { const float d = reps[(size_t)b * S + si] - mean; s2 += d * d; }
+                var = s2 / std::max(n - 1.0f, 1.0f);
+                if (var != 0.0f) { o.var_col.push_back(support[si]); o.var_val.push_back(var); }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // tiny-cell sparse path, src/quant.rs:469-657 + caller RLE 808-845
 static void tiny_cell(const Cell& c, const u32* t2g, bool usa, u32 num_rows,
                       std::vector<u32>& ind, std::vector<float>& val) {
@@ -699,6 +831,7 @@ struct CellOut {
     std::vector<u32> ind; std::vector<float> val; u8 flags = 0; double mmrate = 0.0; u32 em_iters = 0;
     // cfg.dump_eq: gene_eqc as the -d block sees it (quant.rs:1282-1307), in lexicographic label order
     std::vector<u32> eq_labels, eq_len, eq_count;
+    BootOut boot;
 };
 
 static bool is_parsimony(u32 r) {
@@ -707,11 +840,15 @@ static bool is_parsimony(u32 r) {
 
 // body of the per-cell loop of run_worker_thread, src/quant.rs:794-1179
 static int quant_cell(const afq_config& cfg, const u32* t2g, u32 ref_count, const Cell& c, int force_route,
-                      CellOut& o, std::string& err) {
+                      CellOut& o, std::string& err, u64 cell_index = 0) {
     o = CellOut();
     bool usa = cfg.usa_mode != 0;
     u32 sa = usa ? cfg.sa_model : (u32)AFQ_SA_WINNER_TAKE_ALL;  // quant.rs:1456-1469
     if (sa > AFQ_SA_PREFER_AMBIG) { err = "bad sa_model"; return AFQ_ERR_INVALID_ARG; }
+    if (cfg.num_bootstraps > 0 && !(cfg.resolution == AFQ_RES_CR_LIKE_EM || cfg.resolution == AFQ_RES_PARSIMONY_EM || cfg.resolution == AFQ_RES_PARSIMONY_GENE_EM)) {
+        err = "bootstrapping can only be used with the cr-like-em, parsimony-em, or parsimony-gene-em resolution strategies";   // main.rs:713-728
+        return AFQ_ERR_INVALID_ARG;
+    }
     const bool pa = sa == AFQ_SA_PREFER_AMBIG;
     for (u32 x : c.refs) if (x >= ref_count) { err = "ref id out of range"; return AFQ_ERR_BAD_INPUT; }
     if (c.nrec == 0) { err = "chunk with no reads"; return AFQ_ERR_BAD_INPUT; }  // quant.rs:756 panics
@@ -758,6 +895,9 @@ static int quant_cell(const afq_config& cfg, const u32* t2g, u32 ref_count, cons
     for (u32 gidx = 0; gidx < counts.size(); ++gidx)  // quant.rs:1156-1168
         if (counts[gidx] > 0.0f) { o.ind.push_back(gidx); o.val.push_back(counts[gidx]); }
     if (o.ind.empty()) o.flags |= AFQ_CELL_EMPTY;
+    if (cfg.num_bootstraps > 0 && (res == AFQ_RES_CR_LIKE_EM || res == AFQ_RES_PARSIMONY_EM || res == AFQ_RES_PARSIMONY_GENE_EM))
+        // quant.rs:1028-1038: gene_eqc as is, num_alphas = counts.len() (main.rs:713-724 admits the -em resolutions only)
+        bootstrap_cell(eqc, usa, cfg.num_rows, (u32)counts.size(), cfg.num_bootstraps, cfg.summary_stat != 0, cfg.boot_seed, cell_index, o.boot);
     if (cfg.dump_eq)   // quant.rs:1282-1307 (`trivial` and tiny-path cells leave gene_eqc empty)
         for (auto& kv : eqc) {
             o.eq_labels.insert(o.eq_labels.end(), kv.first.begin(), kv.first.end());
@@ -770,11 +910,17 @@ struct Result {
     std::vector<u64> cell_ptr, bc; std::vector<u32> gene, nrec; std::vector<float> val;
     std::vector<u8> flags; std::vector<double> mmrate; std::vector<u32> em_iters;
     std::vector<u64> eq_cell_ptr{0}, eq_label_ptr{0}; std::vector<u32> eq_labels, eq_count;
+    std::vector<u64> bm_ptr{0}, bv_ptr{0}; std::vector<u32> bm_col, bv_col; std::vector<float> bm_val, bv_val;
     void add_eq(const CellOut& o) {
         eq_labels.insert(eq_labels.end(), o.eq_labels.begin(), o.eq_labels.end());
         eq_count.insert(eq_count.end(), o.eq_count.begin(), o.eq_count.end());
         for (u32 l : o.eq_len) eq_label_ptr.push_back(eq_label_ptr.back() + l);
         eq_cell_ptr.push_back(eq_count.size());
+        bm_col.insert(bm_col.end(), o.boot.mean_col.begin(), o.boot.mean_col.end());
+        bm_val.insert(bm_val.end(), o.boot.mean_val.begin(), o.boot.mean_val.end());
+        bv_col.insert(bv_col.end(), o.boot.var_col.begin(), o.boot.var_col.end());
+        bv_val.insert(bv_val.end(), o.boot.var_val.begin(), o.boot.var_val.end());
+        bm_ptr.push_back(bm_col.size()); bv_ptr.push_back(bv_col.size());
     }
 };
 
@@ -799,7 +945,7 @@ int ora_quant(const afq_config* cfg, const uint32_t* t2g, uint32_t ref_count, co
     for (uint32_t i = 0; i < n_cells; ++i) {
         if (chunk_off[i] > n_bytes) { delete R; g_err = "chunk offset out of range"; return AFQ_ERR_BAD_INPUT; }
         int rc = parse_chunk(bytes + chunk_off[i], n_bytes - chunk_off[i], cfg->bc_bytes, cfg->umi_bytes, c, err);
-        if (!rc) rc = quant_cell(*cfg, t2g, ref_count, c, force_route, o, err);
+        if (!rc) rc = quant_cell(*cfg, t2g, ref_count, c, force_route, o, err, first_cell_index + i);
         if (rc) { delete R; g_err = "cell " + std::to_string(i) + ": " + err; return rc; }
         R->gene.insert(R->gene.end(), o.ind.begin(), o.ind.end());
         R->val.insert(R->val.end(), o.val.begin(), o.val.end());
@@ -833,7 +979,7 @@ int ora_quant_mt(const afq_config* cfg, const uint32_t* t2g, uint32_t ref_count,
             for (uint32_t i = t; i < n_cells && rcs[t] == 0; i += n_threads) {
                 int rc = chunk_off[i] > n_bytes ? AFQ_ERR_BAD_INPUT
                                                 : parse_chunk(bytes + chunk_off[i], n_bytes - chunk_off[i], cfg->bc_bytes, cfg->umi_bytes, c, err);
-                if (!rc) rc = quant_cell(*cfg, t2g, ref_count, c, 0, outs[i], err);
+                if (!rc) rc = quant_cell(*cfg, t2g, ref_count, c, 0, outs[i], err, first_cell_index + i);
                 if (rc) { rcs[t] = rc; errs[t] = "cell " + std::to_string(i) + ": " + err; }
                 bcs[i] = c.bc; nrecs[i] = c.nrec;
             }
@@ -867,6 +1013,19 @@ int ora_result_eqclasses(const afq_result* r, afq_eqclasses* out) {
     out->labels = R->eq_labels.data(); out->count = R->eq_count.data();
     return 0;
 }
+
+// cfg.num_bootstraps: per-cell bootstrap mean / variance (same container as afq_result_bootstraps)
+int ora_result_bootstraps(const afq_result* r, afq_bootstraps* out) {
+    if (!r || !r->opaque || !out) return AFQ_ERR_INVALID_ARG;
+    const Result* R = (const Result*)r->opaque;
+    out->n_cells = R->bm_ptr.size() - 1;
+    out->mean_ptr = R->bm_ptr.data(); out->mean_col = R->bm_col.data(); out->mean_val = R->bm_val.data();
+    out->var_ptr = R->bv_ptr.data(); out->var_col = R->bv_col.data(); out->var_val = R->bv_val.data();
+    return 0;
+}
+
+// Philox4x32-10 block, exported so the tests can pin it on the published known-answer vectors
+void ora_philox4x32_10(const uint32_t* ctr, const uint32_t* key, uint32_t* out) { philox4x32_10(ctr, key, out); }
 
 void ora_result_release(afq_result* r) {
     if (r && r->opaque) { delete (Result*)r->opaque; std::memset(r, 0, sizeof(*r)); }

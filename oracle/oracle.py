@@ -43,6 +43,10 @@ def lib():
         L.ora_result_em_iters.restype = p(C.c_uint32)
         L.ora_result_eqclasses.argtypes = [p(_abi.AfqResult), p(_abi.AfqEqclasses)]
         L.ora_result_eqclasses.restype = C.c_int
+        L.ora_result_bootstraps.argtypes = [p(_abi.AfqResult), p(_abi.AfqBootstraps)]
+        L.ora_result_bootstraps.restype = C.c_int
+        L.ora_philox4x32_10.argtypes = [p(C.c_uint32), p(C.c_uint32), p(C.c_uint32)]
+        L.ora_philox4x32_10.restype = None
         L.ora_last_error.restype = C.c_char_p
         L.ora_em.argtypes = [p(C.c_uint32), p(C.c_uint32), p(C.c_uint32), C.c_uint32, C.c_uint32, C.c_int, C.c_int,
                              C.c_int, C.c_uint32, C.c_uint32, C.c_int, p(C.c_float), p(C.c_uint32)]
@@ -88,6 +92,10 @@ def quant(cfg, tid_to_gid, chunk_bytes, chunk_off, first_cell_index=0, force_rou
             ec = _abi.AfqEqclasses()
             L.ora_result_eqclasses(C.byref(res), C.byref(ec))
             out.eqclasses = _afq.eqclasses_from_c(ec)
+        if cfg.num_bootstraps:
+            bs = _abi.AfqBootstraps()
+            L.ora_result_bootstraps(C.byref(res), C.byref(bs))
+            out.bootstraps = _afq.bootstraps_from_c(bs)
         if want_iters:
             n = out.n_cells
             it = np.ctypeslib.as_array(L.ora_result_em_iters(C.byref(res)), shape=(n,)).copy() if n else np.zeros(0, np.uint32)
@@ -95,6 +103,13 @@ def quant(cfg, tid_to_gid, chunk_bytes, chunk_off, first_cell_index=0, force_rou
         return out
     finally:
         L.ora_result_release(C.byref(res))
+
+
+def philox4x32_10(ctr, key):
+    """One Philox4x32-10 block of the oracle's restatement (for the published known-answer vectors)."""
+    c = (C.c_uint32 * 4)(*ctr); k = (C.c_uint32 * 2)(*key); o = (C.c_uint32 * 4)()
+    lib().ora_philox4x32_10(c, k, o)
+    return [int(x) for x in o]
 
 
 def em(labels, counts, num_alphas, only_unique=False, init_uniform=False, usa_offsets=None, dense=0):

@@ -30,7 +30,8 @@ def test_library_exports_every_symbol():
 
 def test_config_struct_layout():
     c = pkg.WorkerConfig.for_resolution("parsimony-em", num_genes=10, num_rows=10).to_c()
-    assert ctypes.sizeof(c) == 16 * 4
+    assert ctypes.sizeof(c) == 20 * 4   # ABI version 2: + num_bootstraps, summary_stat, boot_seed (u64, 8-byte aligned at offset 72)
+    assert pkg._abi.AfqConfig.boot_seed.offset == 72 and pkg._abi.AfqConfig.dump_eq.offset == 56
     assert c.resolution == 3 and c.large_graph_thresh == 1000 and c.pug_exact_umi == 0 and c.small_thresh == 100
     c = pkg.WorkerConfig.for_resolution("cr-like", num_genes=10, num_rows=10).to_c()
     assert c.resolution == 1 and c.large_graph_thresh == 0 and c.pug_exact_umi == 1

@@ -103,7 +103,7 @@ def test_afquant_cli_matches_oracle(tmp_path, oracle, res, usa, compressed, sa):
     assert meta["empty_resolved_cell_numbers"] == [i for i in range(want.n_cells) if want.flags[i] & 4]
 
 
-@pytest.mark.parametrize("res,usa", [("cr-like", True), ("parsimony-em", False), ("parsimony", True), ("trivial", False)])
+@pytest.mark.parametrize("res,usa", [("cr-like", True), ("parsimony-em", False), ("parsimony", True)])
 def test_afquant_cli_dump_eqclasses(tmp_path, oracle, res, usa):
     """-d (write_eqc_counts, quant.rs:229-355): geqc_counts.mtx (cells x classes) + gene_eqclass.txt.gz; class ids are
     arbitrary in the reference (hash + completion order), so the comparison is on (cell, gene set, count)."""
@@ -150,8 +150,45 @@ def test_afquant_cli_dump_eqclasses(tmp_path, oracle, res, usa):
     for i in range(want.n_cells):
         exp = sorted((out_label(lab), c) for lab, c in want.eqclasses.cell(i))
         assert sorted(got.get(i, [])) == exp, (res, i)
-    if res == "trivial":
-        assert n_cls == 0 and nz == 0
+
+
+@pytest.mark.parametrize("summary_stat", [True, False])
+def test_afquant_cli_bootstraps(tmp_path, oracle, summary_stat):
+    """-b N [--summary-stat] (quant.rs:127-210, 1850-1877): alevin/bootstraps_mean.mtx and bootstraps_var.mtx, cells x columns,
+    non-zero entries only; the draws are reproducible here (--boot-seed), so the files equal the oracle's numbers."""
+    s = synth.synth(54, [2500, 700, 150, 40], num_genes=90, txp_per_gene=2, usa=False, dup=0.5, cross=0.35, umi_err=0.02)
+    tg, b, off = make_dir(tmp_path / "in", s, False)
+    out = str(tmp_path / "out")
+    cmd = [CLI, "quant", "-i", str(tmp_path / "in"), "-m", tg, "-o", out, "-r", "cr-like-em", "-b", "9", "--boot-seed", "77"] + (["--summary-stat"] if summary_stat else [])
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert ("Full per-replicate bootstrap output is not yet supported" in r.stderr) == (not summary_stat)
+    rows, cols, trip, feat, meta = read_outputs(out)
+    assert meta["quant_options"]["num_bootstraps"] == 9 and meta["quant_options"]["summary_stat"] is summary_stat
+    want = oracle.quant(cfg_for(s, "cr-like-em", num_bootstraps=9, summary_stat=summary_stat, boot_seed=77), s.tid_to_gid, b, off)
+
+    def read_mtx(name):
+        with open(os.path.join(out, "alevin", name)) as f:
+            assert f.readline().startswith("%%MatrixMarket matrix coordinate real general")
+            f.readline()
+            nr, nc, nz = (int(x) for x in f.readline().split())
+            ent = {(int(a) - 1, int(c) - 1): np.float32(v) for a, c, v in (ln.split() for ln in f.read().splitlines())}
+        assert (nr, nc, nz) == (want.n_cells, s.num_rows, len(ent))
+        return ent
+
+    for name, getter in (("bootstraps_mean.mtx", want.bootstraps.mean), ("bootstraps_var.mtx", want.bootstraps.var)):
+        ent = read_mtx(name)
+        exp = {}
+        for i in range(want.n_cells):
+            c, v = getter(i)
+            for a, x in zip(c.tolist(), v.tolist()):
+                exp[(i, a)] = np.float32(x)
+        assert ent == exp, name
+    assert not any(i == 3 for i, _ in read_mtx("bootstraps_mean.mtx"))   # the 40-read cell took the tiny path: no bootstraps
+    # -b is for the -em resolutions (main.rs:713-728); --summary-stat needs -b (main.rs:307); -d with trivial is refused (main.rs:705-711)
+    for extra, res in ((["-b", "4"], "cr-like"), (["--summary-stat"], "cr-like-em"), (["-d"], "trivial")):
+        r = subprocess.run([CLI, "quant", "-i", str(tmp_path / "in"), "-m", tg, "-o", out, "-r", res] + extra, capture_output=True, text=True)
+        assert r.returncode != 0
 
 
 def test_afquant_cli_quant_subset_and_flag_errors(tmp_path, oracle):
@@ -168,8 +205,8 @@ def test_afquant_cli_quant_subset_and_flag_errors(tmp_path, oracle):
     assert rows == [rad.int_to_seq(int(s.cell_bc[i]), 16) for i in keep] and meta["num_quantified_cells"] == 2
     want = oracle.quant(cfg_for(s, "cr-like"), s.tid_to_gid, b, off[keep])
     assert abs(sum(trip.values()) - float(want.val.sum())) < 1e-3
-    # cr-like does not take --umi-edit-dist 1 (src/main.rs:674-688); -b is refused, not ignored
-    for extra in (["--umi-edit-dist", "1"], ["-b", "10"]):
+    # cr-like does not take --umi-edit-dist 1 (src/main.rs:674-688)
+    for extra in (["--umi-edit-dist", "1"],):
         r = subprocess.run([CLI, "quant", "-i", str(tmp_path / "in"), "-m", tg, "-o", out, "-r", "cr-like"] + extra, capture_output=True, text=True)
         assert r.returncode != 0 and "afquant quant failed" in r.stderr
     os.remove(tmp_path / "in" / "generate_permit_list.json")

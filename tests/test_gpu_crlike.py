@@ -98,6 +98,64 @@ def test_dump_eqclasses(oracle, resolution, usa):
         q.close()
 
 
+@pytest.mark.parametrize("summary_stat", [True, False])
+@pytest.mark.parametrize("resolution,usa", [("cr-like-em", False), ("cr-like-em", True), ("parsimony-em", True), ("parsimony-gene-em", False)])
+def test_bootstraps(oracle, resolution, usa, summary_stat):
+    """-b (em.rs:585-690, multinomial.rs, quant.rs:157-210): per non-tiny cell the mean / variance over the replicates.
+    The reference's generator is unseeded; with the draws restated on Philox (same streams both sides) the device
+    equals the oracle bit for bit, and the summaries behave like a bootstrap (means near the point estimate, total
+    mass = the cell's molecules)."""
+    s = synth.synth(37, [5, 99, 100, 700, 9000, 40000], num_genes=300, usa=usa, dup=0.5, cross=0.3, max_extra_na=5, umi_err=0.02)
+    b, off = s.encode()
+    cfg = cfg_for(s, resolution, num_bootstraps=12, summary_stat=summary_stat, boot_seed=0xC0FFEE1234)
+    q = pkg.Quantifier(cfg, s.tid_to_gid)
+    try:
+        got = q.quant_chunks(b, off, first_cell_index=1000)
+        # the same cells handed over as two batches: the draws hang off the cell index, not the batch
+        g1 = q.quant_chunks(b, off[:3], first_cell_index=1000)
+        g2 = q.quant_chunks(b, off[3:], first_cell_index=1003)
+    finally:
+        q.close()
+    want = oracle.quant(cfg, s.tid_to_gid, b, off, first_cell_index=1000)
+    assert_same_result(got, want, what=resolution)
+    gb, wb = got.bootstraps, want.bootstraps
+    for name in ("mean_ptr", "mean_col", "var_ptr", "var_col"):
+        assert np.array_equal(getattr(gb, name), getattr(wb, name)), name
+    assert np.array_equal(gb.mean_val.view(np.uint32), wb.mean_val.view(np.uint32))
+    assert np.array_equal(gb.var_val.view(np.uint32), wb.var_val.view(np.uint32))
+    for i in range(got.n_cells):
+        part, j = (g1, i) if i < 3 else (g2, i - 3)
+        assert np.array_equal(part.bootstraps.mean(j)[1], gb.mean(i)[1]) and np.array_equal(part.bootstraps.var(j)[0], gb.var(i)[0])
+        mc, mv = gb.mean(i)
+        if got.flags[i] & pkg._abi.CELL_TINY_PATH:
+            assert len(mc) == 0 and len(gb.var(i)[0]) == 0
+            continue
+        assert len(mc) > 0 and np.all(np.diff(mc.astype(np.int64)) > 0)
+        # every replicate redistributes the cell's molecules: the means add up to the point estimate's total (floored alphas aside)
+        _, v = got.row(i)
+        assert abs(float(mv.sum()) - float(v.sum())) <= 0.02 * float(v.sum()) + 1.0
+    assert float(gb.var_val.min()) >= -1e-3 and float(gb.var_val.max()) > 0
+    # another seed: other draws
+    w2 = oracle.quant(cfg_for(s, resolution, num_bootstraps=12, summary_stat=summary_stat, boot_seed=1), s.tid_to_gid, b, off, first_cell_index=1000)
+    assert not np.array_equal(w2.bootstraps.mean_val, wb.mean_val)
+
+
+def test_bootstraps_large_cell(oracle):
+    """A cell with more classes and more expressed genes than the bootstrap kernel keeps in LDS (working arrays in its scratch)."""
+    s = synth.synth(38, [150000], num_genes=30000, usa=False, dup=0.3, cross=0.5, max_extra_na=6, zipf=0.3)
+    b, off = s.encode()
+    cfg = cfg_for(s, "cr-like-em", num_bootstraps=3, summary_stat=True, boot_seed=5, dump_eq=True)
+    got, want, _ = run_both(oracle, cfg, s.tid_to_gid, b, off)
+    assert_same_result(got, want)
+    cls = got.eqclasses.cell(0)
+    n_genes = len({g for lab, _ in cls for g in lab})
+    assert len(cls) > 6144 and n_genes > 6144, (len(cls), n_genes)
+    gb, wb = got.bootstraps, want.bootstraps
+    assert np.array_equal(gb.mean_col, wb.mean_col) and np.array_equal(gb.var_col, wb.var_col)
+    assert np.array_equal(gb.mean_val.view(np.uint32), wb.mean_val.view(np.uint32))
+    assert np.array_equal(gb.var_val.view(np.uint32), wb.var_val.view(np.uint32))
+
+
 @pytest.mark.parametrize("bw,uw", [(1, 1), (2, 2), (8, 8), (2, 4), (4, 2), (8, 4), (1, 8)])
 def test_field_widths(oracle, bw, uw):
     """Unaligned record layouts take the byte-granular walk."""

@@ -53,6 +53,44 @@ def test_prefer_ambig_hand_cases(oracle, route):
         assert [[int(a), int(v)] for a, v in g] == c["expected"]
 
 
+def test_philox_known_answers(oracle):
+    """The bootstrap draws run on Philox4x32-10; the oracle's restatement against the known-answer vectors published
+    with the Random123 library (kat_vectors: philox4x32 10)."""
+    assert oracle.philox4x32_10([0, 0, 0, 0], [0, 0]) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert oracle.philox4x32_10([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert oracle.philox4x32_10([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0]) == \
+        [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+def test_bootstrap_oracle_properties(oracle):
+    """-b restatement (em.rs:585-690): every replicate redistributes the cell's molecules, so the means add up to them;
+    the mean tracks the point estimate, the variance is that of a multinomial share (~ mean for small shares); classes with
+    one gene only (no EM) have exactly multinomial moments; tiny-path cells have no bootstraps; --summary-stat switches the
+    variance formula (population vs n-1), not the mean."""
+    s = pkg.synth.synth(41, [60, 4000], num_genes=40, dup=0.4, cross=0.3, max_extra_na=3)
+    b, off = s.encode()
+    kw = dict(num_genes=s.num_genes, num_rows=s.num_rows, num_bootstraps=200, boot_seed=3)
+    r1 = oracle.quant(pkg.WorkerConfig.for_resolution("cr-like-em", summary_stat=True, **kw), s.tid_to_gid, b, off)
+    r0 = oracle.quant(pkg.WorkerConfig.for_resolution("cr-like-em", summary_stat=False, **kw), s.tid_to_gid, b, off)
+    assert len(r1.bootstraps.mean(0)[0]) == 0 and bool(r1.flags[0] & pkg._abi.CELL_TINY_PATH)
+    g, v = r1.row(1)
+    mc, mv = r1.bootstraps.mean(1)
+    vc, vv = r1.bootstraps.var(1)
+    n_mol = float(v.sum())
+    assert abs(float(mv.sum()) - n_mol) < 1e-3 * n_mol
+    est = dict(zip(g.tolist(), v.tolist()))
+    big = [(c, m) for c, m in zip(mc.tolist(), mv.tolist()) if est.get(c, 0) > 50]
+    assert len(big) > 10 and all(abs(m - est[c]) < 0.15 * est[c] for c, m in big)
+    var = dict(zip(vc.tolist(), vv.tolist()))
+    assert all(0.4 * m < var[c] < 2.5 * m for c, m in big)
+    m0c, m0v = r0.bootstraps.mean(1)
+    assert np.array_equal(m0c, mc) and np.allclose(m0v, mv, rtol=1e-5)
+    v0 = dict(zip(*[x.tolist() for x in r0.bootstraps.var(1)]))
+    assert all(abs(v0[c] * 199.0 / 200.0 - var[c]) <= 2e-3 * var[c] + 1e-3 for c, _ in big)
+    with pytest.raises(Exception):   # main.rs:713-728
+        oracle.quant(pkg.WorkerConfig.for_resolution("cr-like", summary_stat=True, **kw), s.tid_to_gid, b, off)
+
+
 @pytest.mark.parametrize("bw,uw", [(1, 1), (2, 2), (4, 4), (8, 8), (2, 4), (4, 2), (8, 4)])
 def test_field_widths(oracle, bw, uw):
     """Record field widths 1/2/4/8 bytes (src/convert.rs:323-344) decode identically."""
