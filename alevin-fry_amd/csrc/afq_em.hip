@@ -756,7 +756,7 @@ __global__ __launch_bounds__(256) void k_eqc_dump(uint32_t n_cells, const CellMe
 // being those of the oracle's header, so that the two agree bit for bit.  f32 order: a class's denominator adds its
 // label in label order, an alpha adds its classes' shares in class order (pairs (entry, class) sorted) - the order of the
 // sequential loop (em.rs:189-218).  One workgroup per cell.
-constexpr int kBootNT = 512;
+constexpr int kBootNT = 1024;
 constexpr uint32_t kBootLds = 6144;   // classes / support entries whose working arrays live in LDS
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&o)[4]) {
 #pragma unroll
@@ -851,6 +851,11 @@ __global__ __launch_bounds__(kBootNT) void k_boot(const uint64_t* __restrict__ c
         while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (pairs[mid] < key) lo = mid + 1; else hi = mid; }
         seg[s] = lo;
     }
+    uint32_t* pk = sup;   // dead since the dedupe: per sorted pair its class, bit 31 = single-label class
+    for (uint32_t j = tid; j < W; j += kBootNT) {
+        const uint32_t k = (uint32_t)pairs[j];
+        pk[j] = k | ((woff[k + 1] - woff[k] == 1) ? 0x80000000u : 0u);
+    }
     __syncthreads();
     // working arrays: LDS when the cell fits, its scratch otherwise
     const bool in_lds = K <= kBootLds && S <= kBootLds;
@@ -886,7 +891,7 @@ __global__ __launch_bounds__(kBootNT) void k_boot(const uint64_t* __restrict__ c
         if (!needs_em) {
             for (uint32_t s = tid; s < S; s += kBootNT) {
                 float a = 0.0f;
-                for (uint32_t j = seg[s]; j < seg[s + 1]; ++j) a += (float)cntb[(uint32_t)pairs[j]];
+                for (uint32_t j = seg[s]; j < seg[s + 1]; ++j) a += (float)cntb[pk[j] & 0x7FFFFFFFu];
                 ain[s] = a;
             }
         } else {
@@ -913,16 +918,39 @@ __global__ __launch_bounds__(kBootNT) void k_boot(const uint64_t* __restrict__ c
                 }
                 __syncthreads();
                 bool bad = false;
-                for (uint32_t s = tid; s < S; s += kBootNT) {   // (B) alphas_out, classes in order
-                    const float ai = ain[s];
+                for (uint32_t sb = 0; sb < S; sb += kBootNT) {   // (B) alphas_out, classes in order (wave-uniform trip count)
+                    const uint32_t s = sb + tid;
+                    const bool valid = s < S;
+                    const float ai = valid ? ain[s] : 0.0f;
+                    const uint32_t q0 = valid ? seg[s] : 0u, q1 = valid ? seg[s + 1] : 0u;
+                    auto term_at = [&](float a, uint32_t q) -> float {   // a skipped share is +0.0f: leaves the non-negative sum unchanged
+                        const uint32_t e = pk[q], k = e & 0x7FFFFFFFu;
+                        if (e >> 31) return (float)cntb[k];
+                        const float iv = inv[k];
+                        return iv >= 0.0f ? a * iv : 0.0f;
+                    };
+                    const bool heavy = valid && q1 - q0 > kEmHeavy;
                     float o = 0.0f;
-                    for (uint32_t j = seg[s]; j < seg[s + 1]; ++j) {
-                        const uint32_t k = (uint32_t)pairs[j];
-                        if (woff[k + 1] - woff[k] == 1) o += (float)cntb[k];
-                        else { const float iv = inv[k]; if (iv >= 0.0f) { const float c = ai * iv; o += c; } }
+                    if (valid && !heavy) for (uint32_t q = q0; q < q1; ++q) o += term_at(ai, q);
+                    // an entry in many classes (a highly expressed gene) is summed by its whole wave: the 64 loads go out
+                    // together, the additions stay one after the other in class order
+                    for (uint64_t hm = __ballot(heavy); hm; hm &= hm - 1) {
+                        const uint32_t L = (uint32_t)__builtin_ctzll(hm);
+                        const float a_l = bcast_f32(ai, L);
+                        const uint32_t b0 = bcast_u32(q0, L), b1 = bcast_u32(q1, L);
+                        float r = 0.0f;
+                        for (uint32_t base = b0; base < b1; base += 64) {
+                            const uint32_t q = base + lane_id();
+                            const uint32_t tb = __float_as_uint(q < b1 ? term_at(a_l, q) : 0.0f);
+#pragma unroll
+                            for (int i = 0; i < 64; ++i) r += __uint_as_float(__builtin_amdgcn_readlane(tb, i));
+                        }
+                        if (lane_id() == L) o = r;
                     }
-                    if (o > kAlphaCheckCutoff && fabsf(ai - o) > kRelDiffTol) bad = true;
-                    aout[s] = o;
+                    if (valid) {
+                        if (o > kAlphaCheckCutoff && fabsf(ai - o) > kRelDiffTol) bad = true;
+                        aout[s] = o;
+                    }
                 }
                 if (bad) s_flag[1] = 1;
                 __syncthreads();
