@@ -527,7 +527,7 @@ int run_range(afq_ctx* c, Range r, int slot) {
         pa.epool = B.d_epool.as<uint32_t>(); pa.epool_cursor = B.d_epool_cur.as<unsigned long long>(); pa.epool_cap = epool_words;
         pa.t2g = c->d_t2g.as<uint32_t>(); pa.keys0 = ra.keys0; pa.cell_ncols = ra.cell_ncols; pa.lab = ra.lab; pa.lab_cnt = ra.lab_cnt;
         pa.alt = B.d_alt.as<uint32_t>(); pa.st = ra.st; pa.ref_count = c->ref_count; pa.num_genes = g.num_genes; pa.usa = g.usa_mode;
-        pa.num_rows = g.num_rows; pa.em = em ? 1u : 0u; pa.exact_umi = g.pug_exact_umi; pa.large_thresh = g.large_graph_thresh;
+        pa.num_rows = g.num_rows; pa.em = em ? 1u : 0u; pa.exact_umi = g.pug_exact_umi; pa.large_thresh = g.large_graph_thresh; pa.umi32 = g.umi_bytes == 4 ? 1u : 0u;
         pa.hw = 1 + g.bc_bytes / 4 + g.umi_bytes / 4; pa.umi_pairs = std::min<uint32_t>(g.umi_len ? g.umi_len : g.umi_bytes * 4, 22);
         pa.gene_level = (g.resolution == AFQ_RES_PARSIMONY_GENE || g.resolution == AFQ_RES_PARSIMONY_GENE_EM) ? 1u : 0u;
         ScopedTimer t(c, K_PUG, s, &B.launches);

@@ -121,6 +121,7 @@ struct PugCellArgs {
     uint32_t* alt;                // [n_cells] set to 1 when a component took the cr-like fallback
     DevStatus* st;
     uint32_t ref_count, num_genes, usa, num_rows, em, exact_umi, large_thresh, hw, umi_pairs, gene_level;
+    uint32_t umi32;               // the record's UMI field is 4 bytes: UMI and record offset share one sort word
 };
 
 void launch_pug(hipStream_t s, const PugCellArgs& a, uint32_t n_blocks);

@@ -173,134 +173,6 @@ __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ mu
 }
 
 // ---------------------------------------------------------------------------
-// Workgroup sort with the data in registers.  Thread t of wave w holds E
-// elements; element h of lane l is position w*64*E + h*64 + l of the block of
-// N = NT*E elements.  A bitonic compare-exchange at distance j is a cross-lane
-// shuffle (j < 64), a register swap inside the thread (64 <= j < 64*E) or, only
-// for j >= 64*E, a trip through LDS with barriers - 3 such stages for N <= 2048
-// instead of one barrier per stage (45-66) with the data in LDS.
-// Cross-lane exchange lane <-> lane^J on the VALU instead of ds_bpermute (which occupies the LDS pipe, the
-// bottleneck of the bitonic sort): DPP quad permutes for J = 1, 2; two bank-masked DPP row shifts for J = 4, 8;
-// gfx950's v_permlane16_swap / v_permlane32_swap for J = 16, 32 (semantics checked on hardware, scratch/dpp_probe.hip).
-typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
-template <int J>
-__device__ __forceinline__ uint32_t xor_lane32(uint32_t x) {
-    if constexpr (J == 1) return __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false);
-    else if constexpr (J == 2) return __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false);
-    else if constexpr (J == 4) {
-        uint32_t t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);   // row_shl:4 into banks 0,2
-        return __builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false);          // row_shr:4 into banks 1,3
-    } else if constexpr (J == 8) {
-        uint32_t t = __builtin_amdgcn_update_dpp(x, x, 0x108, 0xF, 0x3, false);   // row_shl:8 into banks 0,1
-        return __builtin_amdgcn_update_dpp(t, x, 0x118, 0xF, 0xC, false);          // row_shr:8 into banks 2,3
-    } else if constexpr (J == 16) {
-        const v2u_t p = __builtin_amdgcn_permlane16_swap(x, x, false, false);      // .x = rows {0,0,2,2}, .y = rows {1,1,3,3}
-        return (lane_id() & 16u) ? p.x : p.y;
-    } else {
-        const v2u_t p = __builtin_amdgcn_permlane32_swap(x, x, false, false);      // .x = lower half twice, .y = upper half twice
-        return (lane_id() & 32u) ? p.x : p.y;
-    }
-}
-template <int J, typename T>
-__device__ __forceinline__ T xor_lane(T v);
-template <int J, typename T>
-__device__ __forceinline__ T xor_lane(T v) {
-    if constexpr (sizeof(T) == 8) {
-        const uint32_t lo = xor_lane32<J>((uint32_t)v), hi = xor_lane32<J>((uint32_t)((uint64_t)v >> 32));
-        return (T)(((uint64_t)hi << 32) | lo);
-    } else return (T)xor_lane32<J>((uint32_t)v);
-}
-
-template <int E, int J, typename T>
-__device__ __forceinline__ void lane_stage(T (&a)[E], uint32_t idx0, uint32_t k) {
-    const bool lower = (idx0 & J) == 0;  // J < 64: a property of the lane only
-#pragma unroll
-    for (int h = 0; h < E; ++h) {
-        const bool want_min = lower == (((idx0 + h * 64) & k) == 0);
-        const T o = xor_lane<J, T>(a[h]);
-        // keep own value iff it is on the wanted side of the partner's: one compare, one select
-        a[h] = ((a[h] < o) == want_min) ? a[h] : o;
-    }
-}
-
-template <int E, int JH, typename T>
-__device__ __forceinline__ void reg_stage(T (&a)[E], uint32_t idx0, uint32_t k) {
-#pragma unroll
-    for (int h = 0; h < E; ++h) {
-        if ((h & JH) == 0 && (h | JH) < E) {
-            const bool asc = ((idx0 + h * 64) & k) == 0;
-            const T x = a[h], y = a[h | JH];
-            const bool sw = asc ? (x > y) : (x < y);
-            a[h] = sw ? y : x;
-            a[h | JH] = sw ? x : y;
-        }
-    }
-}
-
-template <int NT, int E, typename T>
-__device__ __forceinline__ void reg_bitonic_sort(T (&a)[E], T* s_x) {
-    constexpr uint32_t N = NT * E;
-    const uint32_t lane = lane_id();
-    const uint32_t wbase = (threadIdx.x >> 6) * 64 * E;
-    for (uint32_t k = 2; k <= N; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            if (j < 64) {
-                switch (j) {
-                    case 1: lane_stage<E, 1, T>(a, wbase + lane, k); break;
-                    case 2: lane_stage<E, 2, T>(a, wbase + lane, k); break;
-                    case 4: lane_stage<E, 4, T>(a, wbase + lane, k); break;
-                    case 8: lane_stage<E, 8, T>(a, wbase + lane, k); break;
-                    case 16: lane_stage<E, 16, T>(a, wbase + lane, k); break;
-                    default: lane_stage<E, 32, T>(a, wbase + lane, k); break;
-                }
-            } else if (j < 64 * E) {
-                // partner is another register of the same thread; keep the indices compile-time
-                if (E >= 2 && j == 64) reg_stage<E, 1, T>(a, wbase + lane, k);
-                else if (E >= 4 && j == 128) reg_stage<E, 2, T>(a, wbase + lane, k);
-                else if (E >= 8 && j == 256) reg_stage<E, 4, T>(a, wbase + lane, k);
-            } else {
-                __syncthreads();
-#pragma unroll
-                for (int h = 0; h < E; ++h) s_x[wbase + h * 64 + lane] = a[h];
-                __syncthreads();
-#pragma unroll
-                for (int h = 0; h < E; ++h) {
-                    const uint32_t idx = wbase + h * 64 + lane;
-                    const T o = s_x[idx ^ j];
-                    const bool want_min = (((idx & j) == 0) == ((idx & k) == 0));
-                    const T mn = a[h] < o ? a[h] : o, mx = a[h] < o ? o : a[h];
-                    a[h] = want_min ? mn : mx;
-                }
-            }
-        }
-    }
-}
-
-// load n (<= NT*E) elements, sort ascending, leave them sorted in s_x[0..n)
-template <int NT, int E, typename T>
-__device__ __forceinline__ void block_sort_to_lds(const T* src, uint32_t n, T* s_x, T sentinel) {
-    T a[E];
-    const uint32_t wbase = (threadIdx.x >> 6) * 64 * E;
-#pragma unroll
-    for (int h = 0; h < E; ++h) {
-        const uint32_t idx = wbase + h * 64 + lane_id();
-        a[h] = idx < n ? src[idx] : sentinel;
-    }
-    reg_bitonic_sort<NT, E, T>(a, s_x);
-    __syncthreads();
-#pragma unroll
-    for (int h = 0; h < E; ++h) s_x[wbase + h * 64 + lane_id()] = a[h];
-    __syncthreads();
-}
-
-template <int NT, typename T>
-__device__ __forceinline__ void block_sort_any(const T* src, uint32_t n, T* s_x, T sentinel) {
-    if (n <= NT) block_sort_to_lds<NT, 1, T>(src, n, s_x, sentinel);
-    else if (n <= 2 * NT) block_sort_to_lds<NT, 2, T>(src, n, s_x, sentinel);
-    else if (n <= 4 * NT) block_sort_to_lds<NT, 4, T>(src, n, s_x, sentinel);
-    else block_sort_to_lds<NT, 8, T>(src, n, s_x, sentinel);
-}
-
 // ---------------------------------------------------------------------------
 // resolve core, shared by the LDS and the global-scratch variants.
 struct ResolveCfg {

@@ -36,12 +36,94 @@ constexpr uint32_t kVidBits = 20;                 // vertices per cell < 2^20
 constexpr uint32_t kMaxGenesPerLabel = 64;        // distinct genes of one molecule the device path carries
 constexpr uint32_t kMaxBigComp = 4096;            // vertices of a component the multi-word cover handles
 
-struct SortRec {
-    uint64_t h, u;
-    uint32_t o, pad;
+// A read as the grouping sort sees it: label key, then UMI and the record it came from in one word - umi << 32 | record
+// dword offset when the UMI field is 4 bytes wide (UMIs up to 16 nt: every 10x chemistry), umi << 20 | read index
+// otherwise (the offset is then looked up).  Sorted by (h, uo): classes contiguous, UMIs ascending inside a class.
+// In memory the record is one little-endian 128-bit integer h << 64 | uo: the sort compares and moves it as that scalar.
+struct __attribute__((aligned(16))) SortRec {
+    uint64_t uo, h;
 };
-__device__ __forceinline__ bool rec_gt(const SortRec& a, const SortRec& b) {
-    return a.h > b.h || (a.h == b.h && (a.u > b.u || (a.u == b.u && a.o > b.o)));
+typedef unsigned __int128 u128;
+__device__ __forceinline__ u128 rec_key(const SortRec& r) { return ((u128)r.h << 64) | r.uo; }
+
+// Sample sort of one cell's reads by one workgroup.  A bitonic network over the whole cell costs (log2 n)^2 / 2 passes;
+// here the reads are split on sampled keys into buckets of ~2048 (one counting pass, one scatter pass) and every bucket
+// is sorted once, in registers (reg_bitonic_sort: cross-lane stages on the VALU, a handful of trips through LDS).
+// Keys are unique (uo ends in the read's offset / index), so the splitters always separate.  A bucket over 4096
+// records (skewed sample) falls back to the network.  tile: LDS for 4096 records; aux: LDS, 6 * 512 + 2 words.
+constexpr uint32_t kSortBucket = 2048, kSortTile = 4096, kSortMaxBuckets = 512;
+// (Not inlined: inside the cell kernel its register-resident tiles would share one allocation with everything that is
+// live across the sort there, and spill in the inner loops.)
+template <int NT>
+__device__ __noinline__ void sample_sort_reads(SortRec* sr, uint32_t* bid, uint32_t R, const uint64_t* rd_h, const uint64_t* rd_u,
+                                               const uint32_t* rd_o, bool wide_umi, SortRec* tile, uint32_t* aux, uint32_t* s_ws) {
+    const uint32_t tid = threadIdx.x;
+    auto load = [&](uint32_t i) {
+        SortRec r;
+        r.h = rd_h[i];
+        r.uo = wide_umi ? (rd_u[i] << kVidBits) | i : (rd_u[i] << 32) | rd_o[i];
+        return r;
+    };
+    const u128 sentinel = ~(u128)0;
+    u128* tile128 = reinterpret_cast<u128*>(tile);
+    auto sort_tile = [&](SortRec* a, uint32_t n) {   // n <= kSortTile, in place
+        u128* a128 = reinterpret_cast<u128*>(a);
+        if (n <= NT) block_sort_to_lds<NT, 1, u128>(a128, n, tile128, sentinel);
+        else if (n <= 2 * NT) block_sort_to_lds<NT, 2, u128>(a128, n, tile128, sentinel);
+        else block_sort_to_lds<NT, 4, u128>(a128, n, tile128, sentinel);
+        for (uint32_t i = tid; i < n; i += NT) a128[i] = tile128[i];
+        __syncthreads();
+    };
+    if (R <= kSortTile) {
+        for (uint32_t i = tid; i < R; i += NT) sr[i] = load(i);
+        __syncthreads();
+        sort_tile(sr, R);
+        return;
+    }
+    uint32_t nb = (R + kSortBucket - 1) / kSortBucket;
+    nb = nb > kSortMaxBuckets ? kSortMaxBuckets : nb;
+    const uint32_t ns = 64 * nb < kSortTile ? 64 * nb : kSortTile;
+    SortRec* spl = reinterpret_cast<SortRec*>(aux);            // [nb - 1] splitters (4 words each)
+    uint32_t* cnt = aux + 4 * kSortMaxBuckets;                  // [nb] bucket sizes, then fill cursors
+    uint32_t* off = cnt + kSortMaxBuckets;                      // [nb + 1]
+    uint32_t* flag = off + kSortMaxBuckets + 1;
+    for (uint32_t i = tid; i < ns; i += NT) sr[i] = load((uint32_t)(((uint64_t)i * R) / ns));
+    for (uint32_t i = tid; i < nb; i += NT) cnt[i] = 0;
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    sort_tile(sr, ns);
+    for (uint32_t j = tid; j + 1 < nb; j += NT) spl[j] = sr[(uint32_t)(((uint64_t)(j + 1) * ns) / nb)];
+    __syncthreads();
+    for (uint32_t i = tid; i < R; i += NT) {
+        const SortRec r = load(i);
+        uint32_t lo = 0, hi = nb - 1;   // bucket = number of splitters below r
+        const u128 rk = rec_key(r);
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (rk > rec_key(spl[mid])) lo = mid + 1; else hi = mid; }
+        bid[i] = lo;
+        atomicAdd(&cnt[lo], 1u);
+    }
+    __syncthreads();
+    {
+        const uint32_t c = tid < nb ? cnt[tid] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<NT>(c, s_ws, tot);
+        if (tid < nb) { off[tid] = ex; cnt[tid] = 0; if (c > kSortTile) *flag = 1; }
+        if (tid == 0) off[nb] = tot;
+        __syncthreads();
+    }
+    const bool fallback = *flag != 0;
+    if (fallback) {   // a bucket the tile cannot hold: the plain network over the whole cell
+        for (uint32_t i = tid; i < R; i += NT) sr[i] = load(i);
+        __syncthreads();
+        tiled_bitonic_sort_by<NT, kSortTile>(reinterpret_cast<u128*>(sr), R, [](u128 a, u128 b) { return a > b; }, tile128);
+        return;
+    }
+    for (uint32_t i = tid; i < R; i += NT) {
+        const uint32_t b = bid[i];
+        sr[off[b] + atomicAdd(&cnt[b], 1u)] = load(i);
+    }
+    __syncthreads();
+    for (uint32_t b = 0; b < nb; ++b) sort_tile(sr + off[b], off[b + 1] - off[b]);
 }
 
 struct PugCtx {
@@ -238,50 +320,26 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     uint32_t* local_idx = wlab + R;                                    // R  : vid -> index inside its component
 
     PUG_MARK(0);
-    // ---- 1. reads sorted by (label hash, umi, offset) ----
+    // ---- 1. reads sorted by (label key, umi, offset) ----
+    const bool wide_umi = A.umi32 == 0;
+    const uint64_t rd_base = A.rd.rd_off[cell];
+    auto rec_umi = [&](const SortRec& r) -> uint64_t { return wide_umi ? r.uo >> kVidBits : r.uo >> 32; };
+    auto rec_off = [&](const SortRec& r) -> uint32_t { return wide_umi ? A.rd.o[rd_base + (r.uo & ((1u << kVidBits) - 1))] : (uint32_t)r.uo; };
     {
-        const uint64_t base = A.rd.rd_off[cell];
-        for (uint32_t i = tid; i < R; i += kPugNT) {
-            SortRec r; r.h = A.rd.h[base + i]; r.u = A.rd.u[base + i]; r.o = A.rd.o[base + i]; r.pad = 0;
-            sr[i] = r;
+        if (wide_umi) {   // the UMI has to leave room for the 20-bit read index
+            for (uint32_t i = tid; i < R; i += kPugNT) if (A.rd.u[rd_base + i] >> (64 - kVidBits)) s_cnt[3] = kErrPugLimit;
+            __syncthreads();
+            if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], cell); return; }
         }
+        uint32_t* bid = reinterpret_cast<uint32_t*>(sr) + 4 * (size_t)R;   // slab A has 6R words, the records take 4R
+        sample_sort_reads<kPugNT>(sr, bid, R, A.rd.h + rd_base, A.rd.u + rd_base, A.rd.o + rd_base, wide_umi,
+                                  reinterpret_cast<SortRec*>(s_big), s_big + 4 * kSortTile, s_ws);
     }
-    __syncthreads();
-    tiled_bitonic_sort_by<kPugNT, 4096>(sr, R, [](const SortRec& a, const SortRec& b) { return rec_gt(a, b); },
-                                        reinterpret_cast<SortRec*>(s_big));
     PUG_MARK(1);
     // ---- 2. vertices = distinct (label, umi); classes = distinct labels ----
-    uint32_t V = 0, K = 0;
-    for (uint32_t base = 0; base < R; base += kPugNT) {
-        const uint32_t i = base + tid;
-        bool vh = false, ch = false;
-        if (i < R) {
-            ch = i == 0 || sr[i].h != sr[i - 1].h;
-            vh = ch || sr[i].u != sr[i - 1].u;
-        }
-        uint32_t tv, tc;
-        const uint32_t ev = block_excl_scan<kPugNT>(vh, s_ws, tv);
-        const uint32_t ec = block_excl_scan<kPugNT>(ch, s_ws, tc);
-        if (i < R) {
-            const uint32_t vi = V + ev;  // index of the vertex whose first read this is (when vh)
-            if (vh) {
-                v_umi[vi] = sr[i].u;
-                v_cls[vi] = K + ec - (ch ? 0 : 1);
-                v_cnt[vi] = 0;
-            }
-            if (ch) {
-                const uint32_t ki = K + ec;
-                c_vstart[ki] = vi;
-                c_rep[ki] = sr[i].o;        // smallest offset of the class's first UMI; min over the class below
-                c_minoff[ki] = 0xFFFFFFFFu;
-            }
-        }
-        V += tv; K += tc;
-    }
-    if (tid == 0) c_vstart[K] = V;
-    __syncthreads();
-    // gene-level EqMap (init_from_chunk_gene_level, eq_class.rs:723-821): a class label is the sorted distinct
-    // gene ids of its ref list; materialise one list per class (the decode grouped reads by a hash of that set)
+    // One pass over the sorted reads: vertex / class heads (two scans), the class's smallest record offset (its first
+    // appearance in the file), and the check that equal non-exact keys are equal labels - each such read against the read
+    // before it, equality chaining through the class.  A vertex's multiplicity is the distance to the next vertex head.
     auto gene_list = [&](uint32_t rec_dw, uint32_t* g) -> uint32_t {
         const Lab l = rec_label(C, rec_dw);
         uint32_t k = 0;
@@ -297,6 +355,49 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         }
         return k;
     };
+    for (uint32_t i = tid; i < R; i += kPugNT) c_minoff[i] = 0xFFFFFFFFu;   // K <= R
+    __syncthreads();
+    uint32_t V = 0, K = 0;
+    for (uint32_t base = 0; base < R; base += kPugNT) {
+        const uint32_t i = base + tid;
+        bool vh = false, ch = false;
+        SortRec cur{0, 0}, prev{0, 0};
+        if (i < R) {
+            cur = sr[i];
+            if (i > 0) prev = sr[i - 1];
+            ch = i == 0 || cur.h != prev.h;
+            vh = ch || rec_umi(cur) != rec_umi(prev);
+        }
+        uint32_t tv, tc;
+        const uint32_t ev = block_excl_scan<kPugNT>(vh, s_ws, tv);
+        const uint32_t ec = block_excl_scan<kPugNT>(ch, s_ws, tc);
+        if (i < R) {
+            const uint32_t vi = V + ev;                   // index of the vertex whose first read this is (when vh)
+            const uint32_t k = K + ec - (ch ? 0 : 1);     // the read's class
+            const uint32_t ro = rec_off(cur);
+            if (vh) { v_umi[vi] = rec_umi(cur); v_cls[vi] = k; v_cnt[vi] = i; }   // v_cnt: head position for now
+            if (ch) { c_vstart[k] = vi; c_rep[k] = ro; }
+            atomicMin(&c_minoff[k], ro);
+            if (!ch && !label_key_is_exact(cur.h)) {
+                const uint32_t po = rec_off(prev);
+                if (!C.gene_level) {
+                    if (!lab_equal(rec_label(C, ro), rec_label(C, po))) s_cnt[3] = kErrLabelHash;
+                } else {
+                    uint32_t g[kMaxGenesPerLabel], gp[kMaxGenesPerLabel];
+                    const uint32_t len = gene_list(ro, g), lenp = gene_list(po, gp);
+                    bool same = len == lenp && len != 0xFFFFFFFFu;
+                    for (uint32_t q = 0; same && q < len; ++q) same = g[q] == gp[q];
+                    if (!same) s_cnt[3] = len == 0xFFFFFFFFu ? kErrPugLimit : kErrLabelHash;
+                }
+            }
+        }
+        V += tv; K += tc;
+    }
+    if (tid == 0) c_vstart[K] = V;
+    __syncthreads();
+    if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], cell); return; }
+    // gene-level EqMap (init_from_chunk_gene_level, eq_class.rs:723-821): a class label is the sorted distinct
+    // gene ids of its ref list; materialise one list per class (the decode grouped reads by a hash of that set)
     if (C.gene_level) {
         uint32_t carry = 0;
         for (uint32_t base = 0; base < K; base += kPugNT) {
@@ -320,43 +421,42 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         const uint32_t k = vv_cls[v];
         return Lab{c_glab + c_goff[k], c_goff[k + 1] - c_goff[k]};
     };
-    // per-read pass: vertex multiplicities, class first appearance, hash-collision check.
-    {
-        // vertices are in read order, so the vertex of read i = (#vertex heads <= i) - 1: a second scan.
-        uint32_t carry = 0;
-        for (uint32_t base = 0; base < R; base += kPugNT) {
-            const uint32_t i = base + tid;
-            bool vh = false;
-            if (i < R) vh = i == 0 || sr[i].h != sr[i - 1].h || sr[i].u != sr[i - 1].u;
-            uint32_t tv;
-            const uint32_t ev = block_excl_scan<kPugNT>(vh, s_ws, tv);
-            if (i < R) {
-                const uint32_t vi = carry + ev + (vh ? 1 : 0) - 1;
-                atomicAdd(&v_cnt[vi], 1u);
-                const uint32_t k = v_cls[vi];
-                atomicMin(&c_minoff[k], sr[i].o);
-                if (label_key_is_exact(sr[i].h)) {
-                    // the key carries the label itself (<= 2 ids): equal keys are equal labels, nothing to re-read
-                } else if (!C.gene_level) {
-                    if (!lab_equal(rec_label(C, sr[i].o), rec_label(C, c_rep[k]))) s_cnt[3] = kErrLabelHash;
-                } else {
-                    uint32_t g[kMaxGenesPerLabel];
-                    const uint32_t len = gene_list(sr[i].o, g);
-                    bool same = len == c_goff[k + 1] - c_goff[k];
-                    for (uint32_t q = 0; same && q < len; ++q) same = g[q] == c_glab[c_goff[k] + q];
-                    if (!same) s_cnt[3] = kErrLabelHash;
-                }
-            }
-            carry += tv;
-        }
-    }
     __syncthreads();
     if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], cell); return; }
     PUG_MARK(2);
     // ---- 3. class ids by first appearance; reference vertex ids ----
-    for (uint32_t k = tid; k < K; k += kPugNT) c_order[k] = k;
+    // c_order[r] = the class that appears r-th in the file.  The classes' first offsets are distinct dwords of the chunk:
+    // one bit each in an LDS map, and a class's rank is the number of bits below its own (no sort); chunks over 2^19
+    // dwords sort the offsets instead.
+    const uint32_t chunk_dw = m.nbytes / 4;
+    if (chunk_dw <= 16384u * 32u) {
+        const uint32_t nw = (chunk_dw + 31) / 32;
+        uint32_t* bm = s_big;
+        uint32_t* bm_rank = s_big + 16384;
+        for (uint32_t w = tid; w < nw; w += kPugNT) bm[w] = 0;
+        __syncthreads();
+        for (uint32_t k = tid; k < K; k += kPugNT) { const uint32_t o = c_minoff[k]; atomicOr(&bm[o >> 5], 1u << (o & 31)); }
+        __syncthreads();
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < nw; base += kPugNT) {
+            const uint32_t w = base + tid;
+            const uint32_t c = w < nw ? (uint32_t)__popc(bm[w]) : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<kPugNT>(c, s_ws, tot);
+            if (w < nw) bm_rank[w] = carry + ex;
+            carry += tot;
+        }
+        __syncthreads();
+        for (uint32_t k = tid; k < K; k += kPugNT) {
+            const uint32_t o = c_minoff[k];
+            c_order[bm_rank[o >> 5] + (uint32_t)__popc(bm[o >> 5] & ((1u << (o & 31)) - 1u))] = k;
+        }
+    } else {
+        for (uint32_t k = tid; k < K; k += kPugNT) c_order[k] = k;
+        __syncthreads();
+        bitonic_sort_by<kPugNT>(c_order, K, [&](uint32_t a, uint32_t b) { return c_minoff[a] > c_minoff[b]; });
+    }
     __syncthreads();
-    bitonic_sort_by<kPugNT>(c_order, K, [&](uint32_t a, uint32_t b) { return c_minoff[a] > c_minoff[b]; });
     {
         uint32_t carry = 0;
         for (uint32_t base = 0; base < K; base += kPugNT) {
@@ -373,7 +473,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     for (uint32_t j = tid; j < V; j += kPugNT) {
         const uint32_t k = v_cls[j];
         const uint32_t vid = c_base[k] + (j - c_vstart[k]);
-        vv_umi[vid] = v_umi[j]; vv_cnt[vid] = v_cnt[j]; vv_rec[vid] = c_rep[k]; vv_cls[vid] = k;
+        vv_umi[vid] = v_umi[j]; vv_cnt[vid] = (j + 1 < V ? v_cnt[j + 1] : R) - v_cnt[j]; vv_rec[vid] = c_rep[k]; vv_cls[vid] = k;
     }
     __syncthreads();
     PUG_MARK(3);
@@ -1013,7 +1113,7 @@ uint64_t pug_scratch_words(uint32_t nrec, uint32_t n_ref, bool gene_level) {
     const uint64_t R = nrec;
     uint64_t ht_cap = 64;
     while (ht_cap < 2 * R) ht_cap <<= 1;
-    return 6 * R + 4 * R + 5 * R + (R + 1) + 4 * R + (R + 2) + (R + 2) + 1 + 2 * ht_cap + (gene_level ? R + 2 + (uint64_t)n_ref + 2 : 0) + 16;
+    return (6 * R + 4 * R + 5 * R + (R + 1) + 4 * R + (R + 2) + (R + 2) + 1 + 2 * ht_cap + (gene_level ? R + 2 + (uint64_t)n_ref + 2 : 0) + 16 + 3) & ~3ull;   // multiple of 4 words: slab A holds 16-byte records
 }
 
 }  // namespace afq
