@@ -358,40 +358,55 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     for (uint32_t i = tid; i < R; i += kPugNT) c_minoff[i] = 0xFFFFFFFFu;   // K <= R
     __syncthreads();
     uint32_t V = 0, K = 0;
-    for (uint32_t base = 0; base < R; base += kPugNT) {
-        const uint32_t i = base + tid;
-        bool vh = false, ch = false;
-        SortRec cur{0, 0}, prev{0, 0};
-        if (i < R) {
-            cur = sr[i];
-            if (i > 0) prev = sr[i - 1];
-            ch = i == 0 || cur.h != prev.h;
-            vh = ch || rec_umi(cur) != rec_umi(prev);
-        }
-        uint32_t tv, tc;
-        const uint32_t ev = block_excl_scan<kPugNT>(vh, s_ws, tv);
-        const uint32_t ec = block_excl_scan<kPugNT>(ch, s_ws, tc);
-        if (i < R) {
-            const uint32_t vi = V + ev;                   // index of the vertex whose first read this is (when vh)
-            const uint32_t k = K + ec - (ch ? 0 : 1);     // the read's class
-            const uint32_t ro = rec_off(cur);
-            if (vh) { v_umi[vi] = rec_umi(cur); v_cls[vi] = k; v_cnt[vi] = i; }   // v_cnt: head position for now
-            if (ch) { c_vstart[k] = vi; c_rep[k] = ro; }
-            atomicMin(&c_minoff[k], ro);
-            if (!ch && !label_key_is_exact(cur.h)) {
-                const uint32_t po = rec_off(prev);
-                if (!C.gene_level) {
-                    if (!lab_equal(rec_label(C, ro), rec_label(C, po))) s_cnt[3] = kErrLabelHash;
-                } else {
-                    uint32_t g[kMaxGenesPerLabel], gp[kMaxGenesPerLabel];
-                    const uint32_t len = gene_list(ro, g), lenp = gene_list(po, gp);
-                    bool same = len == lenp && len != 0xFFFFFFFFu;
-                    for (uint32_t q = 0; same && q < len; ++q) same = g[q] == gp[q];
-                    if (!same) s_cnt[3] = len == 0xFFFFFFFFu ? kErrPugLimit : kErrLabelHash;
-                }
+    constexpr uint32_t kPer = 4;   // consecutive reads per thread: one scan (vertex heads | class heads << 16) per 4096 reads
+    for (uint32_t base = 0; base < R; base += kPer * kPugNT) {
+        const uint32_t i0 = base + kPer * tid;
+        SortRec cur[kPer];
+        SortRec prev{0, 0};
+        if (i0 > 0 && i0 < R) prev = sr[i0 - 1];
+        uint32_t vh = 0, ch = 0, nv = 0, nc = 0;   // bit j: read i0 + j is a vertex / class head
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; ++j) {
+            const uint32_t i = i0 + j;
+            cur[j] = i < R ? sr[i] : SortRec{0, 0};
+            if (i < R) {
+                const SortRec& pv = j ? cur[j - 1] : prev;
+                const bool c = i == 0 || cur[j].h != pv.h;
+                const bool v = c || rec_umi(cur[j]) != rec_umi(pv);
+                ch |= (uint32_t)c << j; vh |= (uint32_t)v << j;
+                nc += c; nv += v;
             }
         }
-        V += tv; K += tc;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<kPugNT>(nv | (nc << 16), s_ws, tot);
+        uint32_t ev = ex & 0xFFFFu, ec = ex >> 16;
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; ++j) {
+            const uint32_t i = i0 + j;
+            if (i < R) {
+                const bool c = (ch >> j) & 1u, v = (vh >> j) & 1u;
+                const uint32_t vi = V + ev;                  // index of the vertex whose first read this is (when v)
+                const uint32_t k = K + ec - (c ? 0 : 1);     // the read's class
+                const uint32_t ro = rec_off(cur[j]);
+                if (v) { v_umi[vi] = rec_umi(cur[j]); v_cls[vi] = k; v_cnt[vi] = i; }   // v_cnt: head position for now
+                if (c) { c_vstart[k] = vi; c_rep[k] = ro; }
+                atomicMin(&c_minoff[k], ro);
+                if (!c && !label_key_is_exact(cur[j].h)) {
+                    const uint32_t po = rec_off(j ? cur[j - 1] : prev);
+                    if (!C.gene_level) {
+                        if (!lab_equal(rec_label(C, ro), rec_label(C, po))) s_cnt[3] = kErrLabelHash;
+                    } else {
+                        uint32_t g[kMaxGenesPerLabel], gp[kMaxGenesPerLabel];
+                        const uint32_t len = gene_list(ro, g), lenp = gene_list(po, gp);
+                        bool same = len == lenp && len != 0xFFFFFFFFu;
+                        for (uint32_t q = 0; same && q < len; ++q) same = g[q] == gp[q];
+                        if (!same) s_cnt[3] = len == 0xFFFFFFFFu ? kErrPugLimit : kErrLabelHash;
+                    }
+                }
+                ev += v; ec += c;
+            }
+        }
+        V += tot & 0xFFFFu; K += tot >> 16;
     }
     if (tid == 0) c_vstart[K] = V;
     __syncthreads();
