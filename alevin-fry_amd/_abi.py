@@ -118,6 +118,7 @@ EXPORTS = [
     "afq_result_release",
     "afq_result_eqclasses",
     "afq_result_bootstraps",
+    "afq_infer",
     "afq_atac_dedup",
     "afq_free",
     "afq_get_kernel_times",

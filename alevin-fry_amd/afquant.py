@@ -248,6 +248,9 @@ def load_library(path: str = LIB_PATH):
     lib.afq_result_eqclasses.restype = C.c_int
     lib.afq_result_bootstraps.argtypes = [p(AfqResult), p(AfqBootstraps)]
     lib.afq_result_bootstraps.restype = C.c_int
+    lib.afq_infer.argtypes = [C.c_void_p, p(C.c_uint32), p(C.c_uint64), C.c_uint32, p(C.c_uint64), p(C.c_uint32), p(C.c_uint32), C.c_uint32,
+                              C.c_uint32, C.c_uint32, p(AfqResult)]
+    lib.afq_infer.restype = C.c_int
     lib.afq_atac_dedup.argtypes = [C.c_void_p, p(C.c_uint32), p(C.c_uint32), p(C.c_uint16), p(C.c_uint64), C.c_uint32,
                                    p(p(C.c_uint64)), p(p(C.c_uint32)), p(p(C.c_uint32)), p(p(C.c_uint16)), p(p(C.c_uint16))]
     lib.afq_atac_dedup.restype = C.c_int
@@ -323,6 +326,23 @@ class Quantifier:
             self._check(self.lib.afq_result_bootstraps(C.byref(res), C.byref(bs)))
             out.bootstraps = bootstraps_from_c(bs)
         return out
+
+    def infer(self, eq_labels, cell_classes, num_alphas: int, usa_mode: bool = False) -> QuantResult:
+        """`alevin-fry infer` (src/infer.rs): eq_labels = list of label lists (global classes); cell_classes = per cell a list of
+        (class id, count) with ascending class ids.  Returns the non-zero abundances per cell."""
+        lab = np.asarray([x for l in eq_labels for x in l], dtype=np.uint32)
+        lp = np.zeros(len(eq_labels) + 1, dtype=np.uint64)
+        lp[1:] = np.cumsum([len(l) for l in eq_labels])
+        cp = np.zeros(len(cell_classes) + 1, dtype=np.uint64)
+        cp[1:] = np.cumsum([len(c) for c in cell_classes])
+        ce = np.asarray([e for c in cell_classes for e, _ in c], dtype=np.uint32)
+        cc = np.asarray([n for c in cell_classes for _, n in c], dtype=np.uint32)
+        u32, u64 = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+        res = AfqResult()
+        self._check(self.lib.afq_infer(self._h, lab.ctypes.data_as(u32), lp.ctypes.data_as(u64), len(eq_labels), cp.ctypes.data_as(u64),
+                                       ce.ctypes.data_as(u32), cc.ctypes.data_as(u32), len(cell_classes), int(num_alphas), 1 if usa_mode else 0,
+                                       C.byref(res)))
+        return result_from_c(res, owner=_ResultOwner(self.lib.afq_result_release, res))
 
     def quant_chunks(self, chunk_bytes, chunk_off, first_cell_index: int = 0) -> QuantResult:
         self.submit(chunk_bytes, chunk_off, first_cell_index)

@@ -1006,6 +1006,92 @@ void afq_result_release(afq_result* res) {
     }
 }
 
+int afq_infer(afq_ctx* c, const uint32_t* eq_labels, const uint64_t* eq_label_ptr, uint32_t n_eq, const uint64_t* cell_ptr,
+              const uint32_t* cell_eq, const uint32_t* cell_count, uint32_t n_cells, uint32_t num_alphas, uint32_t usa_mode,
+              afq_result* out) {
+    if (!c) return AFQ_ERR_INVALID_ARG;
+    if (!eq_labels || !eq_label_ptr || !cell_ptr || !out || (cell_ptr[n_cells] && (!cell_eq || !cell_count))) return fail(c, AFQ_ERR_INVALID_ARG, "null argument");
+    if (c->pending) return fail(c, AFQ_ERR_STATE, "a quant batch is pending on this context");
+    HIP_TRY(c, hipSetDevice(c->device));
+    // per cell: its classes' label lengths, counts and label words, gathered from the global list (row order = class id order)
+    std::vector<uint64_t> cp(n_cells + 1), wp(n_cells + 1), so(n_cells + 1);
+    cp[0] = wp[0] = so[0] = 0;
+    const bool usa = usa_mode != 0;
+    for (uint32_t i = 0; i < n_cells; ++i) {
+        if (cell_ptr[i + 1] < cell_ptr[i]) return fail(c, AFQ_ERR_INVALID_ARG, "cell_ptr must be non-decreasing");
+        uint64_t w = 0;
+        for (uint64_t k = cell_ptr[i]; k < cell_ptr[i + 1]; ++k) {
+            if (cell_eq[k] >= n_eq) return fail(c, AFQ_ERR_BAD_INPUT, "equivalence class id out of range");
+            w += eq_label_ptr[cell_eq[k] + 1] - eq_label_ptr[cell_eq[k]];
+        }
+        cp[i + 1] = cell_ptr[i + 1];
+        wp[i + 1] = wp[i] + w;
+        so[i + 1] = so[i] + ((infer_scratch_words(cell_ptr[i + 1] - cell_ptr[i], w, usa) + 1) & ~1ull);
+    }
+    const uint64_t nk = cp[n_cells], nw = wp[n_cells], wmul = usa ? 3 : 1;
+    std::vector<uint32_t> len(nk), lab(nw);
+    {
+        uint64_t w = 0;
+        for (uint64_t k = 0; k < nk; ++k) {
+            const uint64_t a = eq_label_ptr[cell_eq[k]], b = eq_label_ptr[cell_eq[k] + 1];
+            len[k] = (uint32_t)(b - a);
+            for (uint64_t j = a; j < b; ++j) {
+                if (eq_labels[j] >= num_alphas) return fail(c, AFQ_ERR_BAD_INPUT, "equivalence-class label is outside the alphas");   // em.rs:72-75
+                lab[w++] = eq_labels[j];
+            }
+        }
+    }
+    RangeState& B = c->rs[0];
+    hipStream_t s = B.stream;
+    HIP_TRY(c, B.d_eq_cptr.ensure(8ull * (n_cells + 1))); HIP_TRY(c, B.d_eq_wptr.ensure(8ull * (n_cells + 1)));
+    HIP_TRY(c, B.d_eq_len.ensure(std::max<uint64_t>(4 * nk, 16))); HIP_TRY(c, B.d_eq_cnt.ensure(std::max<uint64_t>(4 * nk, 16)));
+    HIP_TRY(c, B.d_eq_lab.ensure(std::max<uint64_t>(4 * nw, 16)));
+    HIP_TRY(c, B.d_bt_off.ensure(8ull * (n_cells + 1))); HIP_TRY(c, B.d_bt_scratch.ensure(4 * so[n_cells] + 16));
+    HIP_TRY(c, B.d_bt_ns.ensure(4ull * std::max<uint32_t>(n_cells, 1)));
+    HIP_TRY(c, B.d_bt_col.ensure(std::max<uint64_t>(4 * nw * wmul, 16))); HIP_TRY(c, B.d_bt_mean.ensure(std::max<uint64_t>(4 * nw * wmul, 16)));
+    HIP_TRY(c, hipMemcpyAsync(B.d_eq_cptr.p, cp.data(), 8ull * (n_cells + 1), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(B.d_eq_wptr.p, wp.data(), 8ull * (n_cells + 1), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(B.d_bt_off.p, so.data(), 8ull * (n_cells + 1), hipMemcpyHostToDevice, s));
+    if (nk) {
+        HIP_TRY(c, hipMemcpyAsync(B.d_eq_len.p, len.data(), 4 * nk, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(B.d_eq_cnt.p, cell_count, 4 * nk, hipMemcpyHostToDevice, s));
+    }
+    if (nw) HIP_TRY(c, hipMemcpyAsync(B.d_eq_lab.p, lab.data(), 4 * nw, hipMemcpyHostToDevice, s));
+    launch_infer(s, n_cells, B.d_eq_cptr.as<uint64_t>(), B.d_eq_wptr.as<uint64_t>(), B.d_eq_len.as<uint32_t>(), B.d_eq_cnt.as<uint32_t>(),
+                 B.d_eq_lab.as<uint32_t>(), B.d_bt_off.as<uint64_t>(), B.d_bt_scratch.as<uint32_t>(), usa ? 1u : 0u, num_alphas,
+                 B.d_bt_ns.as<uint32_t>(), B.d_bt_col.as<uint32_t>(), B.d_bt_mean.as<float>());
+    std::vector<uint32_t> ns(n_cells), col(nw * wmul);
+    std::vector<float> al(nw * wmul);
+    if (n_cells) HIP_TRY(c, hipMemcpyAsync(ns.data(), B.d_bt_ns.p, 4ull * n_cells, hipMemcpyDeviceToHost, s));
+    if (nw) {
+        HIP_TRY(c, hipMemcpyAsync(col.data(), B.d_bt_col.p, 4 * nw * wmul, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(al.data(), B.d_bt_mean.p, 4 * nw * wmul, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, hipGetLastError());
+    HostResult* R = pool_get(c->pool);
+    R->cell_ptr.push_back(0);
+    uint64_t tot = 0;
+    for (uint32_t i = 0; i < n_cells; ++i) for (uint32_t k = 0; k < ns[i]; ++k) tot += al[wp[i] * wmul + k] > 0.0f;
+    if (R->gene.reserve(tot) || R->val.reserve(tot)) { pool_put(R); return fail(c, AFQ_ERR_HIP, "host allocation failed"); }
+    R->gene.n = R->val.n = tot;
+    uint64_t o = 0;
+    for (uint32_t i = 0; i < n_cells; ++i) {
+        for (uint32_t k = 0; k < ns[i]; ++k) {   // expressed_ind / expressed_vec, infer.rs:233-241
+            const float a = al[wp[i] * wmul + k];
+            if (a > 0.0f) { R->gene.p[o] = col[wp[i] * wmul + k]; R->val.p[o] = a; ++o; }
+        }
+        R->cell_ptr.push_back(o);
+        R->bc.push_back(0); R->nrec.push_back(0); R->flags.push_back(0); R->mmrate.push_back(0.0);
+    }
+    std::memset(out, 0, sizeof(*out));
+    out->n_cells = n_cells; out->nnz = tot;
+    out->cell_ptr = R->cell_ptr.data(); out->gene = R->gene.p; out->val = R->val.p;
+    out->bc = R->bc.data(); out->nrec = R->nrec.data(); out->flags = R->flags.data(); out->mmrate = R->mmrate.data();
+    out->opaque = R;
+    return 0;
+}
+
 int afq_atac_dedup(afq_ctx* c, const uint32_t* ref, const uint32_t* start, const uint16_t* frag_len,
                    const uint64_t* cell_ptr, uint32_t n_cells, uint64_t** out_cell_ptr, uint32_t** out_ref,
                    uint32_t** out_start, uint16_t** out_frag_len, uint16_t** out_count) {

@@ -769,13 +769,19 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
 
-struct BootCfg { uint32_t B, summary_stat; uint64_t seed, first_cell_index; };
+struct BootCfg { uint32_t B, summary_stat; uint64_t seed, first_cell_index; uint32_t usa, uo, ao, pad; };
 
 // per-cell scratch words for K classes with W label words
 uint64_t boot_scratch_words(uint64_t K, uint64_t W, uint32_t B, bool summary_stat) {
     return (K + 1) + 3 * K + 3 * W + 2 * W + (W + 1) + 2 * W + (summary_stat ? 2 * W : (uint64_t)B * W) + 8;
 }
 
+// INFER = true is `alevin-fry infer` (src/infer.rs:31-426) on the same machinery: the classes are a cell's row of the
+// equivalence-class count matrix in column (class id) order, the counts are taken as they are, the start is the
+// informative one ((single-label count + 0.5) * 1e-3, em.rs:376-378), and with USA offsets a label's share goes by
+// get_abundance_for (em.rs:167-187: S and U lean on the gene's A, A on all three) with the sibling statuses in the
+// support (em.rs:95-110).  One EM per cell; o_mean carries the abundances.
+template <bool INFER>
 __global__ __launch_bounds__(kBootNT) void k_boot(const uint64_t* __restrict__ cls_ptr, const uint64_t* __restrict__ word_ptr,
                                                  const uint32_t* __restrict__ g_len, const uint32_t* __restrict__ g_cnt,
                                                  const uint32_t* __restrict__ g_lab, const uint64_t* __restrict__ scr_off,
@@ -789,20 +795,24 @@ __global__ __launch_bounds__(kBootNT) void k_boot(const uint64_t* __restrict__ c
     const uint32_t K = (uint32_t)(cls_ptr[cell + 1] - c0), W = (uint32_t)(word_ptr[cell + 1] - w0);
     if (K == 0) { if (tid == 0) n_support[cell] = 0; return; }   // tiny-path cell (or nothing resolved): no bootstraps
     const uint32_t* len = g_len + c0; const uint32_t* cnt0 = g_cnt + c0; const uint32_t* lab = g_lab + w0;
+    const bool usa = INFER && cfg.usa;
+    const uint32_t Ws = usa ? 3 * W : W;   // support capacity: the label words (+ two sibling statuses each)
     uint32_t* p = scratch + scr_off[cell];
     uint32_t* woff = p; p += K + 1;
     uint32_t* cum_g = p; p += K;
     uint32_t* cntb_g = p; p += K;
     float* inv_g = reinterpret_cast<float*>(p); p += K;
-    uint32_t* sup = p; p += W;
-    uint32_t* supc = p; p += W;
+    uint32_t* sup = p; p += Ws;
+    uint32_t* supc = p; p += Ws;
     uint32_t* widx = p; p += W;
     p += (p - scratch) & 1;   // 8-byte alignment
     uint64_t* pairs = reinterpret_cast<uint64_t*>(p); p += 2 * W;
-    uint32_t* seg = p; p += W + 1;
-    float* ain_g = reinterpret_cast<float*>(p); p += W;
-    float* aout_g = reinterpret_cast<float*>(p); p += W;
+    uint32_t* seg = p; p += Ws + 1;
+    float* ain_g = reinterpret_cast<float*>(p); p += Ws;
+    float* aout_g = reinterpret_cast<float*>(p); p += Ws;
     float* acc = reinterpret_cast<float*>(p);   // summary: sum[W], sq[W]; otherwise the replicates [B][S]
+    uint32_t* sib_a = p;                         // INFER + USA (no sums then): support index of the sibling status(es)
+    uint32_t* sib_b = p + Ws;
     // 1. label offsets, cumulative counts
     uint32_t wo = 0, N = 0, multi = 0;
     for (uint32_t base = 0; base < K; base += kBootNT) {
@@ -819,14 +829,22 @@ __global__ __launch_bounds__(kBootNT) void k_boot(const uint64_t* __restrict__ c
     __syncthreads();
     if (multi) s_flag[0] = 1;
     // 2. possible support: the distinct gene ids, ascending
-    for (uint32_t i = tid; i < W; i += kBootNT) sup[i] = lab[i];
+    for (uint32_t i = tid; i < W; i += kBootNT) {
+        const uint32_t x = lab[i];
+        sup[i] = x;
+        if (usa) {   // prepare_support, em.rs:95-110
+            const uint32_t a = x >= cfg.ao ? x - cfg.uo : (x >= cfg.uo ? x + cfg.uo : x + cfg.ao);
+            sup[W + 2 * i] = a;
+            sup[W + 2 * i + 1] = x >= cfg.ao ? x - cfg.ao : a;
+        }
+    }
     __syncthreads();
     const bool needs_em = s_flag[0] != 0;
-    tiled_bitonic_sort_by<kBootNT, 8192>(sup, W, [](uint32_t a, uint32_t b) { return a > b; }, s_buf);
+    tiled_bitonic_sort_by<kBootNT, 8192>(sup, Ws, [](uint32_t a, uint32_t b) { return a > b; }, s_buf);
     uint32_t S = 0;
-    for (uint32_t base = 0; base < W; base += kBootNT) {
+    for (uint32_t base = 0; base < Ws; base += kBootNT) {
         const uint32_t i = base + tid;
-        const uint32_t h = i < W && (i == 0 || sup[i] != sup[i - 1]);
+        const uint32_t h = i < Ws && (i == 0 || sup[i] != sup[i - 1]);
         uint32_t tot;
         const uint32_t ex = block_excl_scan<kBootNT>(h, s_ws, tot);
         if (h) supc[S + ex] = sup[i];
@@ -834,12 +852,22 @@ __global__ __launch_bounds__(kBootNT) void k_boot(const uint64_t* __restrict__ c
     }
     __syncthreads();
     // 3. label word -> support index; (entry, class) pairs sorted: an entry's classes, ascending
-    for (uint32_t i = tid; i < W; i += kBootNT) {
-        const uint32_t g = lab[i];
+    auto sup_index = [&](uint32_t g) -> uint32_t {
         uint32_t lo = 0, hi = S;
         while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (supc[mid] < g) lo = mid + 1; else hi = mid; }
-        widx[i] = lo;
-    }
+        return lo;
+    };
+    for (uint32_t i = tid; i < W; i += kBootNT) widx[i] = sup_index(lab[i]);
+    if (usa)
+        for (uint32_t s = tid; s < S; s += kBootNT) {   // entries that are labels have their siblings in the support; the others are never asked
+            const uint32_t x = supc[s];
+            uint32_t a = x >= cfg.ao ? x - cfg.uo : (x >= cfg.uo ? x + cfg.uo : x + cfg.ao);
+            a = sup_index(a);
+            sib_a[s] = a < S ? a : 0u;
+            uint32_t b = 0xFFFFFFFFu;
+            if (x >= cfg.ao) { b = sup_index(x - cfg.ao); b = b < S ? b : 0u; }
+            sib_b[s] = b;
+        }
     __syncthreads();
     for (uint32_t k = tid; k < K; k += kBootNT)
         for (uint32_t j = woff[k]; j < woff[k + 1]; ++j) pairs[j] = ((uint64_t)widx[j] << 32) | k;
@@ -864,16 +892,23 @@ __global__ __launch_bounds__(kBootNT) void k_boot(const uint64_t* __restrict__ c
     uint32_t* cntb = in_lds ? s_buf + kBootLds : cntb_g;
     float* ain = in_lds ? reinterpret_cast<float*>(s_buf + 2 * kBootLds) : ain_g;
     float* aout = in_lds ? reinterpret_cast<float*>(s_buf + 3 * kBootLds) : aout_g;
-    if (cfg.summary_stat) for (uint32_t s = tid; s < 2 * S; s += kBootNT) acc[s] = 0.0f;
+    if (!INFER && cfg.summary_stat) for (uint32_t s = tid; s < 2 * S; s += kBootNT) acc[s] = 0.0f;
+    // what a label contributes with: its own abundance, or (USA) the gene's as get_abundance_for adds it up
+    auto abundance = [&](uint32_t s) -> float {
+        if (!usa) return ain[s];
+        const uint32_t b = sib_b[s];
+        if (b != 0xFFFFFFFFu) return (ain[sib_a[s]] + ain[b]) + ain[s];   // ambiguous: unspliced + spliced + ambiguous
+        return ain[sib_a[s]] + ain[s];                                     // unspliced / spliced: ambiguous + own
+    };
     const uint64_t cell_index = cfg.first_cell_index + cell;
     const uint32_t k0 = (uint32_t)cfg.seed, k1 = (uint32_t)(cfg.seed >> 32), ci0 = (uint32_t)cell_index, ci1 = (uint32_t)(cell_index >> 32);
     for (uint32_t b = 0; b < cfg.B; ++b) {
         __syncthreads();
-        // a. multinomial redraw of the class counts
-        if (in_lds) for (uint32_t k = tid; k < K; k += kBootNT) cum[k] = cum_g[k];
-        for (uint32_t k = tid; k < K; k += kBootNT) cntb[k] = 0;
+        // a. multinomial redraw of the class counts (infer: the counts as given)
+        if (!INFER && in_lds) for (uint32_t k = tid; k < K; k += kBootNT) cum[k] = cum_g[k];
+        for (uint32_t k = tid; k < K; k += kBootNT) cntb[k] = INFER ? cnt0[k] : 0u;
         __syncthreads();
-        for (uint32_t q = tid; q < (N + 3) / 4; q += kBootNT) {
+        for (uint32_t q = tid; !INFER && q < (N + 3) / 4; q += kBootNT) {
             uint32_t w[4];
             philox4x32_10(q, b, ci0, ci1, k0, k1, w);
 #pragma unroll
@@ -895,7 +930,13 @@ __global__ __launch_bounds__(kBootNT) void k_boot(const uint64_t* __restrict__ c
                 ain[s] = a;
             }
         } else {
-            for (uint32_t q = tid; q < (S + 3) / 4; q += kBootNT) {
+            if (INFER)
+                for (uint32_t s = tid; s < S; s += kBootNT) {   // EmInitType::Informative, em.rs:376-378
+                    float u = 0.0f;
+                    for (uint32_t j = seg[s]; j < seg[s + 1]; ++j) if (pk[j] >> 31) u += (float)cntb[pk[j] & 0x7FFFFFFFu];
+                    ain[s] = (u + 0.5f) * 1e-3f;
+                }
+            for (uint32_t q = tid; !INFER && q < (S + 3) / 4; q += kBootNT) {
                 uint32_t w[4];
                 philox4x32_10(q, b | 0x80000000u, ci0, ci1, k0, k1, w);
 #pragma unroll
@@ -911,7 +952,7 @@ __global__ __launch_bounds__(kBootNT) void k_boot(const uint64_t* __restrict__ c
                     float v = -1.0f;                              // single label, or denominator 0: no share
                     if (e - a > 1) {
                         float den = 0.0f;
-                        for (uint32_t j = a; j < e; ++j) den += ain[widx[j]];
+                        for (uint32_t j = a; j < e; ++j) den += abundance(widx[j]);
                         if (den > 0.0f) v = (float)cntb[k] / den;
                     }
                     inv[k] = v;
@@ -923,6 +964,7 @@ __global__ __launch_bounds__(kBootNT) void k_boot(const uint64_t* __restrict__ c
                     const bool valid = s < S;
                     const float ai = valid ? ain[s] : 0.0f;
                     const uint32_t q0 = valid ? seg[s] : 0u, q1 = valid ? seg[s + 1] : 0u;
+                    const float ab = (valid && q1 > q0) ? abundance(s) : 0.0f;   // the share's numerator (own abundance outside USA)
                     auto term_at = [&](float a, uint32_t q) -> float {   // a skipped share is +0.0f: leaves the non-negative sum unchanged
                         const uint32_t e = pk[q], k = e & 0x7FFFFFFFu;
                         if (e >> 31) return (float)cntb[k];
@@ -931,12 +973,12 @@ __global__ __launch_bounds__(kBootNT) void k_boot(const uint64_t* __restrict__ c
                     };
                     const bool heavy = valid && q1 - q0 > kEmHeavy;
                     float o = 0.0f;
-                    if (valid && !heavy) for (uint32_t q = q0; q < q1; ++q) o += term_at(ai, q);
+                    if (valid && !heavy) for (uint32_t q = q0; q < q1; ++q) o += term_at(ab, q);
                     // an entry in many classes (a highly expressed gene) is summed by its whole wave: the 64 loads go out
                     // together, the additions stay one after the other in class order
                     for (uint64_t hm = __ballot(heavy); hm; hm &= hm - 1) {
                         const uint32_t L = (uint32_t)__builtin_ctzll(hm);
-                        const float a_l = bcast_f32(ai, L);
+                        const float a_l = bcast_f32(ab, L);
                         const uint32_t b0 = bcast_u32(q0, L), b1 = bcast_u32(q1, L);
                         float r = 0.0f;
                         for (uint32_t base = b0; base < b1; base += 64) {
@@ -966,13 +1008,18 @@ __global__ __launch_bounds__(kBootNT) void k_boot(const uint64_t* __restrict__ c
         }
         __syncthreads();
         // c. running sums (em.rs:662-666) or the replicate itself
-        for (uint32_t s = tid; s < S; s += kBootNT) {
+        for (uint32_t s = tid; !INFER && s < S; s += kBootNT) {
             const float a = ain[s];
             if (cfg.summary_stat) { acc[s] += a; acc[S + s] += a * a; }
             else acc[(uint64_t)b * S + s] = a;
         }
     }
     __syncthreads();
+    if (INFER) {
+        for (uint32_t s = tid; s < S; s += kBootNT) { o_col[w0 * (usa ? 3 : 1) + s] = supc[s]; o_mean[w0 * (usa ? 3 : 1) + s] = ain[s]; }
+        if (tid == 0) n_support[cell] = S;
+        return;
+    }
     // mean / variance per support entry (em.rs:673-683 | quant.rs:185-210); the host keeps the non-zero ones
     const float n = (float)cfg.B;
     for (uint32_t s = tid; s < S; s += kBootNT) {
@@ -1015,8 +1062,22 @@ void launch_boot(hipStream_t s, uint32_t n_cells, const uint64_t* cls_ptr, const
                  const uint32_t* cnt, const uint32_t* lab, const uint64_t* scr_off, uint32_t* scratch, uint32_t B, uint32_t summary_stat,
                  uint64_t seed, uint64_t first_cell_index, uint32_t* n_support, uint32_t* o_col, float* o_mean, float* o_var) {
     if (!n_cells) return;
-    BootCfg cfg{B, summary_stat, seed, first_cell_index};
-    AFQ_LAUNCH(k_boot, n_cells, kBootNT, s, cls_ptr, word_ptr, len, cnt, lab, scr_off, scratch, cfg, n_support, o_col, o_mean, o_var);
+    BootCfg cfg{B, summary_stat, seed, first_cell_index, 0u, 0u, 0u, 0u};
+    AFQ_LAUNCH(k_boot<false>, n_cells, kBootNT, s, cls_ptr, word_ptr, len, cnt, lab, scr_off, scratch, cfg, n_support, o_col, o_mean, o_var);
+}
+
+// per-cell scratch words of the infer kernel for K classes with W label words
+uint64_t infer_scratch_words(uint64_t K, uint64_t W, bool usa) {
+    const uint64_t Ws = usa ? 3 * W : W;
+    return (K + 1) + 3 * K + 2 * Ws + W + 2 * W + (Ws + 1) + 2 * Ws + 2 * Ws + 8;
+}
+
+void launch_infer(hipStream_t s, uint32_t n_cells, const uint64_t* cls_ptr, const uint64_t* word_ptr, const uint32_t* len,
+                  const uint32_t* cnt, const uint32_t* lab, const uint64_t* scr_off, uint32_t* scratch, uint32_t usa, uint32_t num_alphas,
+                  uint32_t* n_support, uint32_t* o_col, float* o_alpha) {
+    if (!n_cells) return;
+    BootCfg cfg{1u, 0u, 0ull, 0ull, usa, num_alphas / 3, (2 * num_alphas) / 3, 0u};   // usa_offsets of infer.rs:107-111
+    AFQ_LAUNCH(k_boot<true>, n_cells, kBootNT, s, cls_ptr, word_ptr, len, cnt, lab, scr_off, scratch, cfg, n_support, o_col, o_alpha, o_alpha);
 }
 
 // words of per-cell EM scratch for nU single-label columns, W label words, M ambiguous molecules

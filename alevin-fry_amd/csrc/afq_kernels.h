@@ -80,6 +80,12 @@ uint64_t boot_scratch_words(uint64_t K, uint64_t W, uint32_t B, bool summary_sta
 void launch_boot(hipStream_t s, uint32_t n_cells, const uint64_t* cls_ptr, const uint64_t* word_ptr, const uint32_t* len,
                  const uint32_t* cnt, const uint32_t* lab, const uint64_t* scr_off, uint32_t* scratch, uint32_t B, uint32_t summary_stat,
                  uint64_t seed, uint64_t first_cell_index, uint32_t* n_support, uint32_t* o_col, float* o_mean, float* o_var);
+// `alevin-fry infer`: one EM per cell over its row of the equivalence-class count matrix (k_boot<true>); outputs per cell at
+// word_ptr[cell] * (usa ? 3 : 1): the support's columns and abundances, n_support of them
+uint64_t infer_scratch_words(uint64_t K, uint64_t W, bool usa);
+void launch_infer(hipStream_t s, uint32_t n_cells, const uint64_t* cls_ptr, const uint64_t* word_ptr, const uint32_t* len,
+                  const uint32_t* cnt, const uint32_t* lab, const uint64_t* scr_off, uint32_t* scratch, uint32_t usa, uint32_t num_alphas,
+                  uint32_t* n_support, uint32_t* o_col, float* o_alpha);
 void launch_boot_compact(hipStream_t s, uint32_t n_cells, const uint64_t* word_ptr, const uint64_t* sup_ptr, const uint32_t* i_col,
                          const float* i_mean, const float* i_var, uint32_t* o_col, float* o_mean, float* o_var);
 void launch_compact_em(hipStream_t s, uint32_t n_cells, const uint64_t* em_off, const uint32_t* scratch, const uint32_t* nnz,

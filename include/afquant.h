@@ -181,6 +181,20 @@ typedef struct afq_bootstraps {
 int afq_result_bootstraps(const afq_result* res, afq_bootstraps* out);
 
 /*
+ * The per-cell work of `alevin-fry infer` (src/infer.rs:31-426): one EM (em_optimize_subset, EmInitType::Informative,
+ * USA offsets (num_alphas/3, 2*num_alphas/3) when usa_mode) per row of an equivalence-class count matrix.
+ *   eq_labels / eq_label_ptr : the global classes (IndexedEqList::init_from_eqc_file): class e = eq_labels[eq_label_ptr[e] ..
+ *                              eq_label_ptr[e+1]), output columns (a gene_eqclass.txt.gz as `quant -d` writes it)
+ *   cell_ptr / cell_eq / cell_count : the count matrix in CSR, class ids ascending within a row (what sprs' to_csr() gives),
+ *                              counts already rounded to integers (infer.rs:389)
+ * `out` gets the non-zero abundances per cell (gene/val ascending by column; bc, nrec, flags are 0).  The context's own
+ * resolution settings play no part.  Release with afq_result_release().
+ */
+int afq_infer(afq_ctx* ctx, const uint32_t* eq_labels, const uint64_t* eq_label_ptr, uint32_t n_eq, const uint64_t* cell_ptr,
+              const uint32_t* cell_eq, const uint32_t* cell_count, uint32_t n_cells, uint32_t num_alphas, uint32_t usa_mode,
+              afq_result* out);
+
+/*
  * Per-cell fragment de-duplication of `alevin-fry atac deduplicate`
  * (src/atac/deduplicate.rs:199-237, HitInfo order src/atac/sort.rs:37-64).
  * Input per cell: the (ref, start, frag_len) of every record that has exactly

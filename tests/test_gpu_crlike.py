@@ -140,6 +140,55 @@ def test_bootstraps(oracle, resolution, usa, summary_stat):
     assert not np.array_equal(w2.bootstraps.mean_val, wb.mean_val)
 
 
+@pytest.mark.parametrize("usa", [False, True])
+def test_infer(oracle, usa):
+    """`alevin-fry infer` (src/infer.rs): one EM per row of an equivalence-class count matrix, classes in column order,
+    informative start, USA offsets when asked.  Input built the way `quant -d` writes it (labels as output columns, class
+    ids in order of first appearance); expected = the oracle's em_optimize_subset restatement on the same rows, bit for bit;
+    and the abundances land near quant's own cr-like-em estimate of the same cells."""
+    s = synth.synth(43, [8, 150, 2500, 30000], num_genes=400, usa=usa, dup=0.5, cross=0.4, max_extra_na=5, umi_err=0.02)
+    b, off = s.encode()
+    ref = oracle.quant(cfg_for(s, "cr-like-em", small_thresh=0, dump_eq=True), s.tid_to_gid, b, off)
+    uo = s.num_rows // 3
+    def col_label(lab):   # gene ids -> output columns, as write_eqc_counts prints them (quant.rs:284-335)
+        if not usa:
+            return tuple(lab)
+        o, k = [], 0
+        while k < len(lab):
+            g = lab[k]
+            if k + 1 < len(lab) and lab[k + 1] >> 1 == g >> 1:
+                o.append((g >> 1) + 2 * uo); k += 2
+            else:
+                o.append((g >> 1) + uo if g & 1 else g >> 1); k += 1
+        return tuple(o)
+    ids, cells = {}, []
+    for i in range(ref.n_cells):
+        row = []
+        for lab, cnt in ref.eqclasses.cell(i):
+            row.append((ids.setdefault(col_label(lab), len(ids)), cnt))
+        cells.append(sorted(row))
+    eq_labels = [list(l) for l, _ in sorted(ids.items(), key=lambda kv: kv[1])]
+    cells.append([])   # a cell with no classes: an empty row
+    q = pkg.Quantifier(cfg_for(s), s.tid_to_gid)
+    try:
+        got = q.infer(eq_labels, cells, s.num_rows, usa_mode=usa)
+    finally:
+        q.close()
+    assert got.n_cells == len(cells) and len(got.row(len(cells) - 1)[0]) == 0
+    for i, row in enumerate(cells[:-1]):
+        alphas, _ = oracle.em([eq_labels[e] for e, _ in row], [c for _, c in row], s.num_rows,
+                              usa_offsets=(uo, 2 * s.num_rows // 3) if usa else None, dense=0)
+        nz = np.flatnonzero(alphas > 0)
+        g, v = got.row(i)
+        assert np.array_equal(g, nz.astype(np.uint32)), i
+        assert np.array_equal(v.view(np.uint32), alphas[nz].astype(np.float32).view(np.uint32)), i
+        # near quant's own estimate (another schedule and class order: only entries well above the 0.01 floor are comparable)
+        rg, rv = ref.row(i)
+        est = dict(zip(rg.tolist(), rv.tolist()))
+        big = [(c, x) for c, x in zip(g.tolist(), v.tolist()) if x >= 0.9]
+        assert len(big) > 0 and all(abs(est.get(c, 0.0) - x) <= 0.05 * x + 0.1 for c, x in big), i
+
+
 def test_bootstraps_large_cell(oracle):
     """A cell with more classes and more expressed genes than the bootstrap kernel keeps in LDS (working arrays in its scratch)."""
     s = synth.synth(38, [150000], num_genes=30000, usa=False, dup=0.3, cross=0.5, max_extra_na=6, zipf=0.3)
