@@ -14,10 +14,33 @@ static void usage() {
                  "usage: afquant quant -i <input-dir> -m <tg-map> -o <output-dir> -r <resolution>\n"
                  "       [-t <threads>] [--small-thresh N] [--umi-edit-dist 0|1] [--large-graph-thresh N]\n"
                  "       [--quant-subset FILE] [--init-uniform] [--use-mtx] [-d] [-b N] [--device N]\n"
-                 "resolutions: trivial cr-like cr-like-em parsimony parsimony-em parsimony-gene parsimony-gene-em\n");
+                 "       [--summary-stat] [--boot-seed S] [--sa-model winner-take-all|prefer-ambig]\n"
+                 "resolutions: trivial cr-like cr-like-em parsimony parsimony-em parsimony-gene parsimony-gene-em\n"
+                 "       afquant infer -c <geqc_counts.mtx> -e <gene_eqclass.txt.gz> -o <output-dir> [--usa] [--quant-subset FILE] [-t N]\n");
 }
 
 int main(int argc, char** argv) {
+    if (argc >= 2 && std::strcmp(argv[1], "infer") == 0) {   // src/main.rs:350-365, 825-847
+        afq_infer_opts io{};
+        auto need2 = [&](int& i) -> const char* { if (i + 1 >= argc) { usage(); std::exit(2); } return argv[++i]; };
+        for (int i = 2; i < argc; ++i) {
+            const std::string a = argv[i];
+            if (a == "-c" || a == "--count-mat") io.count_mat = need2(i);
+            else if (a == "-e" || a == "--eq-labels") io.eq_labels = need2(i);
+            else if (a == "-o" || a == "--output-dir") io.output_dir = need2(i);
+            else if (a == "-t" || a == "--threads") io.num_threads = (uint32_t)std::atoi(need2(i));
+            else if (a == "--usa") io.usa_mode = 1;
+            else if (a == "--quant-subset") io.filter_list = need2(i);
+            else if (a == "--use-mtx") {}
+            else if (a == "--use-eds") { std::fprintf(stderr, "--use-eds is no longer supported. EDS output has been removed as of v0.12.\n"); return 1; }
+            else if (a == "--device") io.device = (uint32_t)std::atoi(need2(i));
+            else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); usage(); return 2; }
+        }
+        if (!io.count_mat || !io.eq_labels || !io.output_dir) { usage(); return 2; }
+        const int rc = afq_infer_files(&io);
+        if (rc) { std::fprintf(stderr, "afquant infer failed (%d): %s\n", rc, afq_host_last_error()); return 1; }
+        return 0;
+    }
     if (argc < 2 || std::strcmp(argv[1], "quant") != 0) { usage(); return 2; }
     afq_quant_opts o{};
     o.small_thresh = 100; o.umi_edit_dist = -1; o.large_graph_thresh = -1; o.num_threads = 0;

@@ -28,6 +28,7 @@
 #include <sys/stat.h>
 #include <thread>
 #include <unistd.h>
+#include <cerrno>
 #include <map>
 #include <unordered_map>
 #include <zlib.h>
@@ -385,6 +386,170 @@ int afq_rad_parse_prelude(const uint8_t* bytes, size_t n, afq_rad_info* out) {
     return 0;
 }
 
+// MatrixMarket as sprs::io::write_matrix_market writes a TriMatI<f32,u32> (coordinate real general, 1-based), from CSR
+static bool write_mtx_file(const std::string& path, uint64_t n_rows, uint64_t n_cols, const std::vector<uint64_t>& rp,
+                       const std::vector<uint32_t>& cols, const std::vector<float>& vals, uint32_t num_threads) {
+    FILE* m = std::fopen(path.c_str(), "w");
+    if (!m) return false;
+    std::fprintf(m, "%%%%MatrixMarket matrix coordinate real general\n%% written by sprs\n%llu %llu %zu\n", (unsigned long long)n_rows, (unsigned long long)n_cols, vals.size());
+    // the entries are formatted by -t threads into per-slice buffers (same text as one fprintf per entry), written in order;
+    // a slice is a run of consecutive entries, its first row found by binary search in the row pointers
+    const size_t nz = vals.size();
+    const unsigned nth = std::max(1u, std::min(num_threads ? num_threads : 1u, 64u));
+    const size_t slice = 1u << 20;
+    for (size_t base = 0; base < nz; base += slice * nth) {
+        std::vector<std::string> bufs(nth);
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nth; ++t) {
+            const size_t a = base + t * slice, b = std::min(nz, a + slice);
+            if (a >= nz) break;
+            th.emplace_back([&, t, a, b]() {
+                std::string& out = bufs[t];
+                out.resize((b - a) * 112);  // 2 x <= 20 digits + an f32 in positional notation (<= 48 chars) + separators
+                char* p = &out[0];
+                size_t row = (size_t)(std::upper_bound(rp.begin(), rp.end(), (uint64_t)a) - rp.begin()) - 1;
+                for (size_t k = a; k < b; ++k) {
+                    while (rp[row + 1] <= k) ++row;   // skips empty rows too
+                    p = put_u64(p, (unsigned long long)row + 1); *p++ = ' ';
+                    p = put_u64(p, (unsigned long long)cols[k] + 1); *p++ = ' ';
+                    p += format_f32(vals[k], p, 64); *p++ = '\n';
+                }
+                out.resize((size_t)(p - &out[0]));
+            });
+        }
+        for (auto& x : th) x.join();
+        for (auto& bsl : bufs) if (!bsl.empty()) std::fwrite(bsl.data(), 1, bsl.size(), m);
+    }
+    std::fclose(m);
+    return true;
+}
+
+// `alevin-fry infer` (src/infer.rs:31-426): files in, EM per row on the device (afq_infer), files out.
+int afq_infer_files(const afq_infer_opts* o) {
+    if (!o || !o->count_mat || !o->eq_labels || !o->output_dir) return hfail(AFQ_ERR_INVALID_ARG, "null option");
+    const std::string cm = o->count_mat, outd = o->output_dir;
+    const size_t slash = cm.find_last_of('/');
+    const std::string parent = slash == std::string::npos ? std::string(".") : cm.substr(0, slash);
+    // count matrix: MatrixMarket coordinate, `real` (what quant writes) or `integer` (infer.rs:61-83); rows are cells
+    uint64_t n_rows = 0, n_cols = 0, nnz = 0;
+    std::vector<std::pair<uint64_t, std::pair<uint32_t, uint32_t>>> trip;   // (row, (class, rounded count))
+    {
+        std::ifstream f(cm);
+        if (!f) return hfail(AFQ_ERR_BAD_INPUT, "cannot open " + cm);
+        std::string line;
+        if (!std::getline(f, line) || line.compare(0, 14, "%%MatrixMarket") != 0) return hfail(AFQ_ERR_BAD_INPUT, "error reading mtx format matrix : no MatrixMarket banner");
+        std::string low = line;
+        for (auto& ch : low) ch = (char)std::tolower((unsigned char)ch);
+        if (low.find("coordinate") == std::string::npos || (low.find("real") == std::string::npos && low.find("integer") == std::string::npos) ||
+            low.find("general") == std::string::npos)
+            return hfail(AFQ_ERR_BAD_INPUT, "error reading mtx format matrix : only `coordinate real|integer general` is read");
+        while (std::getline(f, line)) if (!line.empty() && line[0] != '%') break;
+        if (std::sscanf(line.c_str(), "%llu %llu %llu", (unsigned long long*)&n_rows, (unsigned long long*)&n_cols, (unsigned long long*)&nnz) != 3)
+            return hfail(AFQ_ERR_BAD_INPUT, "error reading mtx format matrix : bad size line");
+        trip.reserve(nnz);
+        unsigned long long r, c2; double v;
+        for (uint64_t k = 0; k < nnz; ++k) {
+            if (!std::getline(f, line) || std::sscanf(line.c_str(), "%llu %llu %lf", &r, &c2, &v) != 3 || r < 1 || r > n_rows || c2 < 1 || c2 > n_cols)
+                return hfail(AFQ_ERR_BAD_INPUT, "error reading mtx format matrix : bad entry");
+            trip.push_back({r - 1, {(uint32_t)(c2 - 1), (uint32_t)std::llround((float)v)}});   // e.1.round() as u32, infer.rs:389
+        }
+    }
+    std::stable_sort(trip.begin(), trip.end(), [](const auto& a, const auto& b) { return a.first != b.first ? a.first < b.first : a.second.first < b.second.first; });
+    // global classes (IndexedEqList::init_from_eqc_file, eq_class.rs:249-298)
+    uint64_t num_genes = 0, num_eqc = 0;
+    std::vector<std::vector<uint32_t>> eq;
+    {
+        gzFile gz = gzopen(o->eq_labels, "rb");
+        if (!gz) return hfail(AFQ_ERR_BAD_INPUT, std::string("cannot open ") + o->eq_labels);
+        std::string txt;
+        char buf[1 << 16];
+        int got;
+        while ((got = gzread(gz, buf, sizeof buf)) > 0) txt.append(buf, (size_t)got);
+        gzclose(gz);
+        std::istringstream is(txt);
+        std::string line;
+        if (!std::getline(is, line)) return hfail(AFQ_ERR_BAD_INPUT, "empty equivalence class file");
+        num_genes = std::strtoull(line.c_str(), nullptr, 10);
+        if (!std::getline(is, line)) return hfail(AFQ_ERR_BAD_INPUT, "truncated equivalence class file");
+        num_eqc = std::strtoull(line.c_str(), nullptr, 10);
+        eq.assign((size_t)num_eqc, {});
+        while (std::getline(is, line)) {
+            std::istringstream ls(line);
+            std::vector<uint32_t> v;
+            unsigned long long x;
+            while (ls >> x) v.push_back((uint32_t)x);
+            if (v.empty()) continue;
+            const uint32_t id = v.back();
+            v.pop_back();
+            if (id >= num_eqc) return hfail(AFQ_ERR_BAD_INPUT, "equivalence class id out of range");
+            eq[id] = std::move(v);
+        }
+    }
+    if (n_cols > num_eqc) return hfail(AFQ_ERR_BAD_INPUT, "the count matrix has more columns than there are equivalence classes");
+    // barcodes of the rows, optional subset (infer.rs:113-147, 360-373)
+    std::vector<std::string> bcs;
+    {
+        std::ifstream f(parent + "/quants_mat_rows.txt");
+        if (!f) return hfail(AFQ_ERR_BAD_INPUT, "Unable to read first barcode from " + parent + "/quants_mat_rows.txt");
+        std::string line;
+        while (std::getline(f, line)) { while (!line.empty() && std::isspace((unsigned char)line.back())) line.pop_back(); if (!line.empty()) bcs.push_back(line); }
+    }
+    std::unordered_set<std::string> keep;
+    const bool filter = o->filter_list != nullptr;
+    if (filter) {
+        std::ifstream f(o->filter_list);
+        if (!f) return hfail(AFQ_ERR_BAD_INPUT, std::string("cannot open ") + o->filter_list);
+        std::string line;
+        while (std::getline(f, line)) { while (!line.empty() && std::isspace((unsigned char)line.back())) line.pop_back(); if (!line.empty()) keep.insert(line); }
+    }
+    std::vector<uint32_t> lab, ce, cc;
+    std::vector<uint64_t> lp(1, 0), cp(1, 0);
+    for (auto& v : eq) { lab.insert(lab.end(), v.begin(), v.end()); lp.push_back(lab.size()); }
+    if (mkdir(outd.c_str(), 0777) != 0 && errno != EEXIST) return hfail(AFQ_ERR_BAD_INPUT, "cannot create " + outd);
+    {
+        std::ifstream in(parent + "/quants_mat_cols.txt", std::ios::binary);
+        if (!in) return hfail(AFQ_ERR_BAD_INPUT, "could not copy column (gene) names to output");
+        std::ofstream out(outd + "/quants_mat_cols.txt", std::ios::binary);
+        out << in.rdbuf();
+    }
+    FILE* rows_f = std::fopen((outd + "/quants_mat_rows.txt").c_str(), "w");
+    if (!rows_f) return hfail(AFQ_ERR_BAD_INPUT, "couldn't create output barcode file");
+    size_t t = 0;
+    uint64_t n_out = 0;
+    for (uint64_t r = 0; r < n_rows && r < bcs.size(); ++r) {   // rows zip barcodes (infer.rs:364)
+        const size_t t0 = t;
+        while (t < trip.size() && trip[t].first == r) ++t;
+        if (filter && !keep.count(bcs[r])) continue;
+        std::fprintf(rows_f, "%s\n", bcs[r].c_str());
+        for (size_t k = t0; k < t; ++k) {
+            if (!ce.empty() && cp.back() < ce.size() && ce.back() == trip[k].second.first) { cc.back() += trip[k].second.second; continue; }   // to_csr sums duplicates
+            ce.push_back(trip[k].second.first); cc.push_back(trip[k].second.second);
+        }
+        cp.push_back(ce.size());
+        ++n_out;
+    }
+    std::fclose(rows_f);
+    afq_config cfg{};
+    cfg.abi_version = AFQ_ABI_VERSION; cfg.resolution = AFQ_RES_CR_LIKE; cfg.num_genes = 1; cfg.num_rows = 1; cfg.small_thresh = 100;
+    cfg.pug_exact_umi = 1; cfg.bc_bytes = 4; cfg.umi_bytes = 4;
+    const uint32_t t2g0 = 0;
+    afq_ctx* ctx = nullptr;
+    int rc = afq_create(&cfg, &t2g0, 1, (int)o->device, &ctx);
+    if (rc) return hfail(rc, afq_last_error(nullptr));
+    afq_result res{};
+    rc = afq_infer(ctx, lab.data(), lp.data(), (uint32_t)num_eqc, cp.data(), ce.data(), cc.data(), (uint32_t)n_out, (uint32_t)num_genes, o->usa_mode, &res);
+    if (rc) { const std::string m = afq_last_error(ctx); afq_destroy(ctx); return hfail(rc, m); }
+    std::vector<uint64_t> rp(res.cell_ptr, res.cell_ptr + res.n_cells + 1);
+    std::vector<uint32_t> cols(res.gene, res.gene + res.nnz);
+    std::vector<float> vals(res.val, res.val + res.nnz);
+    afq_result_release(&res);
+    afq_destroy(ctx);
+    // (num_cells, num_genes) with num_cells = the subset's size when one is given (infer.rs:141, 175-178)
+    if (!write_mtx_file(outd + "/quants_mat.mtx", filter ? keep.size() : n_rows, num_genes, rp, cols, vals, o->num_threads))
+        return hfail(AFQ_ERR_BAD_INPUT, "could not write quants_mat.mtx");
+    return 0;
+}
+
 int afq_quantify(const afq_quant_opts* o) {
     if (!o || !o->input_dir || !o->tg_map || !o->output_dir || !o->resolution) return hfail(AFQ_ERR_INVALID_ARG, "null option");
     const ResolutionInfo* R = nullptr;
@@ -653,42 +818,9 @@ int afq_quantify(const afq_quant_opts* o) {
     if (ctx_eq) afq_destroy(ctx_eq);
     std::fclose(rows_f); std::fclose(feat_f);
     pc.lap("device batches + per-cell rows");
-    // MatrixMarket as sprs::io::write_matrix_market writes a TriMatI<f32,u32> (coordinate real general, 1-based), from CSR
     auto write_mtx = [&](const std::string& path, uint64_t n_rows, uint64_t n_cols, const std::vector<uint64_t>& rp,
                          const std::vector<uint32_t>& cols, const std::vector<float>& vals) -> bool {
-        FILE* m = std::fopen(path.c_str(), "w");
-        if (!m) return false;
-        std::fprintf(m, "%%%%MatrixMarket matrix coordinate real general\n%% written by sprs\n%llu %llu %zu\n", (unsigned long long)n_rows, (unsigned long long)n_cols, vals.size());
-        // the entries are formatted by -t threads into per-slice buffers (same text as one fprintf per entry), written in order;
-        // a slice is a run of consecutive entries, its first row found by binary search in the row pointers
-        const size_t nz = vals.size();
-        const unsigned nth = std::max(1u, std::min(o->num_threads ? o->num_threads : 1u, 64u));
-        const size_t slice = 1u << 20;
-        for (size_t base = 0; base < nz; base += slice * nth) {
-            std::vector<std::string> bufs(nth);
-            std::vector<std::thread> th;
-            for (unsigned t = 0; t < nth; ++t) {
-                const size_t a = base + t * slice, b = std::min(nz, a + slice);
-                if (a >= nz) break;
-                th.emplace_back([&, t, a, b]() {
-                    std::string& out = bufs[t];
-                    out.resize((b - a) * 112);  // 2 x <= 20 digits + an f32 in positional notation (<= 48 chars) + separators
-                    char* p = &out[0];
-                    size_t row = (size_t)(std::upper_bound(rp.begin(), rp.end(), (uint64_t)a) - rp.begin()) - 1;
-                    for (size_t k = a; k < b; ++k) {
-                        while (rp[row + 1] <= k) ++row;   // skips empty rows too
-                        p = put_u64(p, (unsigned long long)row + 1); *p++ = ' ';
-                        p = put_u64(p, (unsigned long long)cols[k] + 1); *p++ = ' ';
-                        p += format_f32(vals[k], p, 64); *p++ = '\n';
-                    }
-                    out.resize((size_t)(p - &out[0]));
-                });
-            }
-            for (auto& x : th) x.join();
-            for (auto& bsl : bufs) if (!bsl.empty()) std::fwrite(bsl.data(), 1, bsl.size(), m);
-        }
-        std::fclose(m);
-        return true;
+        return write_mtx_file(path, n_rows, n_cols, rp, cols, vals, o->num_threads);
     };
     if (!write_mtx(outd + "/alevin/quants_mat.mtx", row_index, cfg.num_rows, row_ptr, all_gene, all_val)) return hfail(AFQ_ERR_BAD_INPUT, "could not create quants_mat.mtx");
     pc.lap("quants_mat.mtx");

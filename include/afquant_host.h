@@ -36,6 +36,21 @@ typedef struct afq_quant_opts {
     uint64_t boot_seed;         /* seed of the bootstrap draws (the reference's are unseeded); --boot-seed, default 0     */
 } afq_quant_opts;
 
+/* The CLI-visible options of `alevin-fry infer` (src/main.rs:350-365). */
+typedef struct afq_infer_opts {
+    const char* count_mat;      /* -c : cells x equivalence classes, MatrixMarket (`geqc_counts.mtx` of `quant -d`); the barcode and
+                                        gene-name files are looked up next to it (quants_mat_rows.txt, quants_mat_cols.txt)        */
+    const char* eq_labels;      /* -e : gene_eqclass.txt.gz                                                                */
+    const char* output_dir;     /* -o                                                                                      */
+    const char* filter_list;    /* --quant-subset, or NULL                                                                 */
+    uint32_t usa_mode;          /* --usa                                                                                   */
+    uint32_t num_threads;       /* -t : threads of the MTX writer                                                          */
+    uint32_t device;
+    uint32_t reserved;
+} afq_infer_opts;
+/* Runs the whole `infer` sub-command (src/infer.rs:31-426): quants_mat.mtx, quants_mat_rows.txt, quants_mat_cols.txt in output_dir. */
+int afq_infer_files(const afq_infer_opts* opts);
+
 /* Runs the whole `quant` sub-command.  Returns 0 or a negative AFQ_ERR_* code; message via afq_host_last_error(). */
 int afq_quantify(const afq_quant_opts* opts);
 const char* afq_host_last_error(void);

@@ -191,6 +191,59 @@ def test_afquant_cli_bootstraps(tmp_path, oracle, summary_stat):
         assert r.returncode != 0
 
 
+@pytest.mark.parametrize("usa", [False, True])
+def test_afquant_cli_infer(tmp_path, oracle, usa):
+    """`afquant infer` (src/infer.rs) on the files `afquant quant -d` wrote: per row the oracle's em_optimize_subset
+    restatement over the row's classes in column order, bit for bit; rows / cols files carried over; --quant-subset."""
+    import gzip
+
+    s = synth.synth(55, [2000, 600, 150, 20], num_genes=80, txp_per_gene=2, usa=usa, dup=0.5, cross=0.4, umi_err=0.02)
+    tg, b, off = make_dir(tmp_path / "in", s, False)
+    out = str(tmp_path / "out")
+    r = subprocess.run([CLI, "quant", "-i", str(tmp_path / "in"), "-m", tg, "-o", out, "-r", "cr-like-em", "-d"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    al = os.path.join(out, "alevin")
+    lines = gzip.open(os.path.join(al, "gene_eqclass.txt.gz"), "rt").read().split("\n")
+    n_cls = int(lines[1])
+    labels = [None] * n_cls
+    for ln in lines[2:2 + n_cls]:
+        t = [int(x) for x in ln.split()]
+        labels[t[-1]] = t[:-1]
+    rows_in = open(os.path.join(al, "quants_mat_rows.txt")).read().split()
+    cells = {i: [] for i in range(len(rows_in))}
+    with open(os.path.join(al, "geqc_counts.mtx")) as f:
+        f.readline(); f.readline(); f.readline()
+        for ln in f.read().splitlines():
+            a, c, v = ln.split()
+            cells[int(a) - 1].append((int(c) - 1, int(round(float(v)))))
+    keep = [0, 2]
+    sub = tmp_path / "subset.txt"
+    sub.write_text("\n".join(rows_in[i] for i in keep) + "\n")
+    for extra, sel in (([], list(range(len(rows_in)))), (["--quant-subset", str(sub)], keep)):
+        out2 = str(tmp_path / ("inf" + str(len(sel))))
+        r = subprocess.run([CLI, "infer", "-c", os.path.join(al, "geqc_counts.mtx"), "-e", os.path.join(al, "gene_eqclass.txt.gz"), "-o", out2, "-t", "2"]
+                           + (["--usa"] if usa else []) + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert open(os.path.join(out2, "quants_mat_rows.txt")).read().split() == [rows_in[i] for i in sel]
+        assert open(os.path.join(out2, "quants_mat_cols.txt")).read() == open(os.path.join(al, "quants_mat_cols.txt")).read()
+        with open(os.path.join(out2, "quants_mat.mtx")) as f:
+            assert f.readline().startswith("%%MatrixMarket matrix coordinate real general")
+            f.readline()
+            nr, nc, nz = (int(x) for x in f.readline().split())
+            ent = {(int(a) - 1, int(c) - 1): np.float32(v) for a, c, v in (ln.split() for ln in f.read().splitlines())}
+        assert (nr, nc, nz) == (len(sel), s.num_rows, len(ent))
+        exp = {}
+        for ri, i in enumerate(sel):
+            row = sorted(cells[i])
+            if not row:
+                continue
+            alphas, _ = oracle.em([labels[e] for e, _ in row], [c for _, c in row], s.num_rows,
+                                  usa_offsets=(s.num_rows // 3, 2 * s.num_rows // 3) if usa else None, dense=0)
+            for c in np.flatnonzero(alphas > 0):
+                exp[(ri, int(c))] = np.float32(alphas[c])
+        assert ent == exp
+
+
 def test_afquant_cli_quant_subset_and_flag_errors(tmp_path, oracle):
     s = synth.synth(52, [900, 500, 300, 100], num_genes=80, dup=0.4)
     tg, b, off = make_dir(tmp_path / "in", s, False)
