@@ -111,6 +111,29 @@ __device__ __forceinline__ void reg_stage(T (&a)[E], uint32_t idx0, uint32_t k) 
     }
 }
 
+// One wave sorts its own 64*E elements (element h of lane l = position h*64 + l) without LDS or barriers: every stage
+// is a cross-lane exchange or a register swap.
+template <int E, typename T>
+__device__ __forceinline__ void wave_bitonic_sort(T (&a)[E]) {
+    constexpr uint32_t N = 64 * E;
+    const uint32_t lane = lane_id();
+    for (uint32_t k = 2; k <= N; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            switch (j) {
+                case 1: lane_stage<E, 1, T>(a, lane, k); break;
+                case 2: lane_stage<E, 2, T>(a, lane, k); break;
+                case 4: lane_stage<E, 4, T>(a, lane, k); break;
+                case 8: lane_stage<E, 8, T>(a, lane, k); break;
+                case 16: lane_stage<E, 16, T>(a, lane, k); break;
+                case 32: lane_stage<E, 32, T>(a, lane, k); break;
+                case 64: if constexpr (E >= 2) reg_stage<E, 1, T>(a, lane, k); break;
+                case 128: if constexpr (E >= 4) reg_stage<E, 2, T>(a, lane, k); break;
+                default: if constexpr (E >= 8) reg_stage<E, 4, T>(a, lane, k); break;
+            }
+        }
+    }
+}
+
 template <int NT, int E, typename T>
 __device__ __forceinline__ void reg_bitonic_sort(T (&a)[E], T* s_x) {
     constexpr uint32_t N = NT * E;

@@ -51,7 +51,7 @@ __device__ __forceinline__ u128 rec_key(const SortRec& r) { return ((u128)r.h <<
 // is sorted once, in registers (reg_bitonic_sort: cross-lane stages on the VALU, a handful of trips through LDS).
 // Keys are unique (uo ends in the read's offset / index), so the splitters always separate.  A bucket over 4096
 // records (skewed sample) falls back to the network.  tile: LDS for 4096 records; aux: LDS, 6 * 512 + 2 words.
-constexpr uint32_t kSortBucket = 2048, kSortTile = 4096, kSortMaxBuckets = 512;
+constexpr uint32_t kSortBucket = 2048, kSortWaveBucket = 256, kSortTile = 4096, kSortMaxBuckets = 512;
 // (Not inlined: inside the cell kernel its register-resident tiles would share one allocation with everything that is
 // live across the sort there, and spill in the inner loops.)
 template <int NT>
@@ -80,7 +80,11 @@ __device__ __noinline__ void sample_sort_reads(SortRec* sr, uint32_t* bid, uint3
         sort_tile(sr, R);
         return;
     }
-    uint32_t nb = (R + kSortBucket - 1) / kSortBucket;
+    // cells up to 2^17 reads: buckets of ~256, each sorted by ONE wave in its registers (512 slots: no LDS, no barriers);
+    // beyond that ~2048 per bucket, sorted by the workgroup
+    const bool wave_buckets = R <= kSortWaveBucket * kSortMaxBuckets;
+    const uint32_t target = wave_buckets ? kSortWaveBucket : kSortBucket;
+    uint32_t nb = (R + target - 1) / target;
     nb = nb > kSortMaxBuckets ? kSortMaxBuckets : nb;
     const uint32_t ns = 64 * nb < kSortTile ? 64 * nb : kSortTile;
     SortRec* spl = reinterpret_cast<SortRec*>(aux);            // [nb - 1] splitters (4 words each)
@@ -123,6 +127,24 @@ __device__ __noinline__ void sample_sort_reads(SortRec* sr, uint32_t* bid, uint3
         sr[off[b] + atomicAdd(&cnt[b], 1u)] = load(i);
     }
     __syncthreads();
+    if (wave_buckets) {
+        constexpr int E = 8;   // 512 slots per wave
+        u128* a128 = reinterpret_cast<u128*>(sr);
+        const uint32_t lane = lane_id();
+        for (uint32_t b = tid >> 6; b < nb; b += NT / 64) {
+            const uint32_t o = off[b], n = off[b + 1] - o;
+            if (n < 2 || n > 64 * E) continue;   // oversize buckets (a skewed sample) are left to the workgroup below
+            u128 a[E];
+#pragma unroll
+            for (int h = 0; h < E; ++h) a[h] = (uint32_t)(h * 64) + lane < n ? a128[o + h * 64 + lane] : sentinel;
+            wave_bitonic_sort<E, u128>(a);
+#pragma unroll
+            for (int h = 0; h < E; ++h) if ((uint32_t)(h * 64) + lane < n) a128[o + h * 64 + lane] = a[h];
+        }
+        __syncthreads();
+        for (uint32_t b = 0; b < nb; ++b) if (off[b + 1] - off[b] > 64 * E) sort_tile(sr + off[b], off[b + 1] - off[b]);
+        return;
+    }
     for (uint32_t b = 0; b < nb; ++b) sort_tile(sr + off[b], off[b + 1] - off[b]);
 }
 
