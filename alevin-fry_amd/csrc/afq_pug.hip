@@ -319,9 +319,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     uint32_t* v_cnt = p; p += R;
     uint32_t* v_cls = p; p += R;
     uint64_t* vv_umi = reinterpret_cast<uint64_t*>(p); p += 2 * (size_t)R;     // slab C (by vertex id)
-    uint32_t* vv_cnt = p; p += R;
-    uint32_t* vv_rec = p; p += R;          // a record (dword offset) carrying the vertex's label
-    uint32_t* vv_cls = p; p += R;
+    uint4* vv = reinterpret_cast<uint4*>(p); p += 4 * (size_t)R;   // per vertex, one 16-byte record = one random access: .x reads, .y class, .z a record (dword offset) carrying its label
     uint32_t* c_vstart = p; p += R + 1;    // slab D (classes, hash order)
     uint32_t* c_minoff = p; p += R;
     uint32_t* c_rep = p; p += R;
@@ -454,8 +452,8 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         __syncthreads();
     }
     auto vlab = [&](uint32_t v) -> Lab {  // label of a vertex: its class's ref list, or gene list at gene level
-        if (!C.gene_level) return rec_label(C, vv_rec[v]);
-        const uint32_t k = vv_cls[v];
+        if (!C.gene_level) return rec_label(C, vv[v].z);
+        const uint32_t k = vv[v].y;
         return Lab{c_glab + c_goff[k], c_goff[k + 1] - c_goff[k]};
     };
     __syncthreads();
@@ -510,7 +508,8 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     for (uint32_t j = tid; j < V; j += kPugNT) {
         const uint32_t k = v_cls[j];
         const uint32_t vid = c_base[k] + (j - c_vstart[k]);
-        vv_umi[vid] = v_umi[j]; vv_cnt[vid] = (j + 1 < V ? v_cnt[j + 1] : R) - v_cnt[j]; vv_rec[vid] = c_rep[k]; vv_cls[vid] = k;
+        vv_umi[vid] = v_umi[j];
+        vv[vid] = make_uint4((j + 1 < V ? v_cnt[j + 1] : R) - v_cnt[j], k, c_rep[k], 0u);
     }
     __syncthreads();
     PUG_MARK(3);
@@ -626,15 +625,17 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         const uint32_t x = (uint32_t)cd & ((1u << kVidBits) - 1);
         const uint64_t pu = cd >> kVidBits;
         const bool same = pu == vv_umi[x];
-        const uint32_t cx = vv_cnt[x], kx = vv_cls[x];
+        const uint4 vx = vv[x];
+        const uint32_t cx = vx.x, kx = vx.y;
         for (uint32_t slot = ht_home(pu);; slot = (slot + 1) & ht_mask) {
             const unsigned long long e = htab[slot];
             if (e == kHtEmpty) break;
             if ((e >> kVidBits) != pu) continue;
             const uint32_t y = (uint32_t)e & ((1u << kVidBits) - 1);
             if (y == x) continue;
-            if (!same && !(vv_cnt[y] < 2 * cx)) continue;
-            if (vv_cls[y] != kx && !lab_overlap(vlab(x), vlab(y))) continue;
+            const uint4 vy = vv[y];
+            if (!same && !(vy.x < 2 * cx)) continue;
+            if (vy.y != kx && !lab_overlap(vlab(x), vlab(y))) continue;
             f(x, y);
         }
     };
@@ -703,7 +704,8 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t x = pr[j] == kNoPair ? 0u : (uint32_t)(pr[j] >> 32) & vmask, y = pr[j] == kNoPair ? 0u : (uint32_t)pr[j] & vmask;
-                cx[j] = vv_cnt[x]; cy[j] = vv_cnt[y]; kx[j] = vv_cls[x]; ky[j] = vv_cls[y];
+                const uint4 va = vv[x], vb = vv[y];
+                cx[j] = va.x; cy[j] = vb.x; kx[j] = va.y; ky[j] = vb.y;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -964,7 +966,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                 const uint32_t ng = genes_of(C, l.n, [&](uint32_t j) { return l.p[j] & 0x7FFFFFFFu; }, g);
                 if (ng == 0xFFFFFFFFu) continue;
                 const uint32_t o = atomicAdd(&s_flag[1], ng);
-                for (uint32_t q = 0; q < ng; ++q) trip[o + q] = make_uint4((uint32_t)vv_umi[v], (uint32_t)(vv_umi[v] >> 32), g[q], vv_cnt[v]);
+                for (uint32_t q = 0; q < ng; ++q) trip[o + q] = make_uint4((uint32_t)vv_umi[v], (uint32_t)(vv_umi[v] >> 32), g[q], vv[v].x);
             }
             __syncthreads();
             const uint32_t nt = s_flag[1];
@@ -1150,7 +1152,7 @@ uint64_t pug_scratch_words(uint32_t nrec, uint32_t n_ref, bool gene_level) {
     const uint64_t R = nrec;
     uint64_t ht_cap = 64;
     while (ht_cap < 2 * R) ht_cap <<= 1;
-    return (6 * R + 4 * R + 5 * R + (R + 1) + 4 * R + (R + 2) + (R + 2) + 1 + 2 * ht_cap + (gene_level ? R + 2 + (uint64_t)n_ref + 2 : 0) + 16 + 3) & ~3ull;   // multiple of 4 words: slab A holds 16-byte records
+    return (6 * R + 4 * R + 6 * R + (R + 1) + 4 * R + (R + 2) + (R + 2) + 1 + 2 * ht_cap + (gene_level ? R + 2 + (uint64_t)n_ref + 2 : 0) + 16 + 3) & ~3ull;   // multiple of 4 words: slab A holds 16-byte records
 }
 
 }  // namespace afq
