@@ -395,7 +395,8 @@ static bool write_mtx_file(const std::string& path, uint64_t n_rows, uint64_t n_
     // the entries are formatted by -t threads into per-slice buffers (same text as one fprintf per entry), written in order;
     // a slice is a run of consecutive entries, its first row found by binary search in the row pointers
     const size_t nz = vals.size();
-    const unsigned nth = std::max(1u, std::min(num_threads ? num_threads : 1u, 64u));
+    // -t defaults to every core in the reference (main.rs:303); 0 = not given
+    const unsigned nth = std::max(1u, std::min(num_threads ? num_threads : std::thread::hardware_concurrency(), 64u));
     const size_t slice = 1u << 20;
     for (size_t base = 0; base < nz; base += slice * nth) {
         std::vector<std::string> bufs(nth);
