@@ -9,7 +9,7 @@
 // to /root/reference):
 //   strategy dispatch            src/quant.rs:794-1026
 //   tiny-cell sparse path        src/quant.rs:469-657, 808-845
-//   cr-like from reads / eqmap   src/pugutils.rs:751-850, 644-749
+//   cr-like from reads / eqmap   src/pugutils.rs:751-850, 644-749; --sa-model prefer-ambig 505-641
 //   EqMap (txp / gene level)     src/eq_class.rs:723-1036
 //   PUG construction             src/pugutils.rs:65-267, src/utils.rs:389-393
 //   WCC                          src/pugutils.rs:278-301
@@ -17,7 +17,9 @@
 //   parsimony cover              src/pugutils.rs:989-1331, 916-982
 //   trivial                      src/pugutils.rs:852-911
 //   USA extraction               src/utils.rs:673-756, 842-926
-//   EM (dense / sparse+USA)      src/em.rs:28-34, 167-582
+//   EM (dense / sparse+USA)      src/em.rs:28-34, 167-582   (ora_em over a row of classes = the per-cell work of src/infer.rs:213-224)
+//   bootstraps (-b)              src/em.rs:585-757, src/multinomial.rs:9-49, src/quant.rs:157-210
+//   gene_eqc as -d sees it       src/quant.rs:1282-1307
 //   ATAC fragment dedup          src/atac/deduplicate.rs:199-237, src/atac/sort.rs:37-64
 //
 // PARITY PINNING.  The reference is Rust and cannot be built here (no cargo /
@@ -32,7 +34,10 @@
 //       (src/pugutils.rs:1090-1110): ascending vertex id here;
 //   (2) the f32 accumulation order of em_update (src/em.rs:464): gene-level
 //       classes in lexicographic label order here.
-// cr-like / trivial / USA extraction are integer-exact and order-independent.
+//   (3) bootstraps: the reference draws from an unseeded ThreadRng - no run of it can be reproduced, parity with it
+//       is statistical by construction; the draws are restated here on Philox4x32-10 (pinned on the published
+//       Random123 known-answer vectors in tests/) with a canonical class / support order, see bootstrap_cell.
+// cr-like (both --sa-model's) / trivial / USA extraction are integer-exact and order-independent.
 
 #include <algorithm>
 #include <cmath>
