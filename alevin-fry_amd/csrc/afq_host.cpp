@@ -595,6 +595,11 @@ int afq_quantify(const afq_quant_opts* o) {
     int rc = parse_prelude(rad.data(), rad.size(), P, true);
     if (rc) return rc;
     if (!P.bc_bytes || !P.umi_bytes) return hfail(AFQ_ERR_UNSUPPORTED, "RAD read tags must hold integer 'b' and 'u' (single-barcode records)");
+    // the device decoders walk `na, b, u, na x u32` records (src/convert.rs:124-144): any other tag layout would be misread, not skipped
+    if (P.read_tags.size() != 2 || P.read_tags[0].name != "b" || P.read_tags[1].name != "u")
+        return hfail(AFQ_ERR_UNSUPPORTED, "RAD read-level tags other than (b, u) are not supported");
+    if (P.aln_tags.size() != 1 || P.aln_tags[0].type != 3)
+        return hfail(AFQ_ERR_UNSUPPORTED, "RAD alignment-level tags other than one u32 (compressed_ori_refid) are not supported");
     uint32_t cblen = 0;
     if (P.file_tag_vals.count("cblen")) cblen = (uint32_t)P.file_tag_vals["cblen"];
     else return hfail(AFQ_ERR_UNSUPPORTED, "no cblen file tag (multi-barcode RAD files are not supported)");

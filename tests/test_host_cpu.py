@@ -94,3 +94,62 @@ def test_rad_prelude_roundtrip(lib):
     pre = rad.rad_prelude(names[:3], 1, 20, 10, bc_bytes=8, umi_bytes=4)
     assert lib.afq_rad_parse_prelude(pre, len(pre), C.byref(info)) == 0 and (info.bc_bytes, info.umi_bytes) == (8, 4)
     assert lib.afq_rad_parse_prelude(pre[:20], 20, C.byref(info)) < 0  # truncated
+
+
+def _quantify(lib, in_dir, tg, out_dir, resolution="cr-like"):
+    class Opts(C.Structure):
+        _fields_ = [("input_dir", C.c_char_p), ("tg_map", C.c_char_p), ("output_dir", C.c_char_p), ("resolution", C.c_char_p),
+                    ("filter_list", C.c_char_p), ("cmdline", C.c_char_p), ("num_threads", C.c_uint32), ("small_thresh", C.c_uint32),
+                    ("umi_edit_dist", C.c_int32), ("large_graph_thresh", C.c_int32), ("init_uniform", C.c_uint32), ("dump_eq", C.c_uint32),
+                    ("num_bootstraps", C.c_uint32), ("device", C.c_uint32), ("batch_bytes", C.c_uint64), ("sa_model", C.c_uint32),
+                    ("summary_stat", C.c_uint32), ("boot_seed", C.c_uint64)]
+
+    o = Opts(str(in_dir).encode(), str(tg).encode(), str(out_dir).encode(), resolution.encode(), None, b"test", 1, 100, -1, -1, 0, 0, 0, 0, 0, 0, 0, 0)
+    lib.afq_quantify.argtypes = [C.POINTER(Opts)]
+    lib.afq_quantify.restype = C.c_int
+    rc = lib.afq_quantify(C.byref(o))
+    return rc, lib.afq_host_last_error().decode()
+
+
+def test_quantify_refuses_record_layouts_it_would_misread(lib, tmp_path):
+    """The device decoders walk `na, b, u, na x u32` records (src/convert.rs:124-144); a RAD file whose read- or
+    alignment-level tags say otherwise (multi-barcode data, extra per-read tags) is refused before anything reaches the
+    device - never decoded on a guess.  All of these fail ahead of the first device call, so they run without a GPU."""
+    import os
+
+    s = pkg.synth.synth(9, [30, 20], num_genes=5)
+    b, off = s.encode()
+    names = [f"t{i}" for i in range(len(s.tid_to_gid))]
+    rows = [(names[i], f"g{int(s.tid_to_gid[i])}") for i in range(len(names))]
+    good = tmp_path / "good"
+    tg = rad.write_quant_input_dir(str(good), b, len(off), names, rows)
+    pre = rad.rad_prelude(names, len(off), 16, 12)
+    raw = open(good / "map.collated.rad", "rb").read()
+    assert raw[:len(pre)] == pre
+
+    def variant(name, new_prelude):
+        d = tmp_path / name
+        os.makedirs(d)
+        for f in ("generate_permit_list.json", "collate.json", "t2g.tsv"):
+            (d / f).write_bytes((good / f).read_bytes())
+        (d / "map.collated.rad").write_bytes(new_prelude + raw[len(pre):])
+        return d
+
+    # an extra read-level tag after (b, u): one more u32 per record that the walk would take for alignment words
+    extra_read = pre.replace((2).to_bytes(2, "little") + b"\x01\x00b\x03" + b"\x01\x00u\x03",
+                             (3).to_bytes(2, "little") + b"\x01\x00b\x03" + b"\x01\x00u\x03" + b"\x01\x00x\x03")
+    assert extra_read != pre
+    rc, msg = _quantify(lib, variant("extra_read", extra_read), tg, tmp_path / "o1")
+    assert rc == pkg._abi.AFQ_ERR_UNSUPPORTED and "read-level tags" in msg
+    # a second alignment-level tag
+    tag = (1).to_bytes(2, "little") + (20).to_bytes(2, "little") + b"compressed_ori_refid" + b"\x03"
+    assert tag in pre
+    extra_aln = pre.replace(tag, (2).to_bytes(2, "little") + tag[2:] + b"\x01\x00p\x03")
+    rc, msg = _quantify(lib, variant("extra_aln", extra_aln), tg, tmp_path / "o2")
+    assert rc == pkg._abi.AFQ_ERR_UNSUPPORTED and "alignment-level tags" in msg
+    # no generate_permit_list.json (src/main.rs:733-734); unknown resolution; -b with a plain resolution (main.rs:713-728)
+    os.remove(good / "generate_permit_list.json")
+    rc, msg = _quantify(lib, good, tg, tmp_path / "o3")
+    assert rc != 0 and "generate_permit_list.json" in msg
+    rc, msg = _quantify(lib, good, tg, tmp_path / "o4", resolution="full")
+    assert rc == pkg._abi.AFQ_ERR_INVALID_ARG
