@@ -438,6 +438,15 @@ def test_many_ranges_pipeline(oracle, monkeypatch):
         b, off = s.encode()
         got, want, st = run_both(oracle, cfg_for(s, res), s.tid_to_gid, b, off)
         assert_same_result(got, want, what=res)
+    # the per-cell extras (-d classes, -b summaries) are appended range by range too
+    cfg = cfg_for(s, "parsimony-em", dump_eq=True, num_bootstraps=3, summary_stat=True, boot_seed=9)
+    got, want, _ = run_both(oracle, cfg, s.tid_to_gid, b, off)
+    assert_same_result(got, want)
+    for i in range(got.n_cells):
+        assert got.eqclasses.cell(i) == want.eqclasses.cell(i), i
+        assert np.array_equal(got.bootstraps.mean(i)[0], want.bootstraps.mean(i)[0]), i
+        assert np.array_equal(got.bootstraps.mean(i)[1].view(np.uint32), want.bootstraps.mean(i)[1].view(np.uint32)), i
+        assert np.array_equal(got.bootstraps.var(i)[1].view(np.uint32), want.bootstraps.var(i)[1].view(np.uint32)), i
 
 
 @pytest.mark.parametrize("usa", [False, True])
