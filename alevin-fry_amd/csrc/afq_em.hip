@@ -757,7 +757,8 @@ __global__ __launch_bounds__(256) void k_eqc_dump(uint32_t n_cells, const CellMe
 // label in label order, an alpha adds its classes' shares in class order (pairs (entry, class) sorted) - the order of the
 // sequential loop (em.rs:189-218).  One workgroup per cell.
 constexpr int kBootNT = 1024;
-constexpr uint32_t kBootLds = 6144;   // classes / support entries whose working arrays live in LDS
+constexpr uint32_t kBootLds = 11264;  // classes / support entries whose working arrays live in LDS (132 KiB)
+constexpr uint32_t kBootHeavy = 32;   // classes above which an entry is summed by its whole wave (one entry at a time)
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&o)[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -787,7 +788,7 @@ __global__ __launch_bounds__(kBootNT) void k_boot(const uint64_t* __restrict__ c
                                                  const uint32_t* __restrict__ g_lab, const uint64_t* __restrict__ scr_off,
                                                  uint32_t* __restrict__ scratch, BootCfg cfg, uint32_t* __restrict__ n_support,
                                                  uint32_t* __restrict__ o_col, float* __restrict__ o_mean, float* __restrict__ o_var) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_buf[4 * kBootLds + 2048];   // sort tile (8192 u32 / 4096 u64), then the EM arrays
+    __shared__ __attribute__((aligned(16))) uint32_t s_buf[3 * kBootLds + 2048];   // sort tile (8192 u32 / 4096 u64), then the EM arrays
     __shared__ uint32_t s_ws[kBootNT / 64];
     __shared__ uint32_t s_flag[2];
     const uint32_t cell = blockIdx.x, tid = threadIdx.x;
@@ -885,13 +886,14 @@ __global__ __launch_bounds__(kBootNT) void k_boot(const uint64_t* __restrict__ c
         pk[j] = k | ((woff[k + 1] - woff[k] == 1) ? 0x80000000u : 0u);
     }
     __syncthreads();
-    // working arrays: LDS when the cell fits, its scratch otherwise
+    // working arrays the rounds read at random (abundances, 1/denominators, counts): LDS when the cell fits, its scratch
+    // otherwise; the new abundances are written and read back by the same thread only and stay in scratch
     const bool in_lds = K <= kBootLds && S <= kBootLds;
     uint32_t* cum = in_lds ? s_buf : cum_g;                                   // draws only; shares its space with inv
     float* inv = in_lds ? reinterpret_cast<float*>(s_buf) : inv_g;
     uint32_t* cntb = in_lds ? s_buf + kBootLds : cntb_g;
     float* ain = in_lds ? reinterpret_cast<float*>(s_buf + 2 * kBootLds) : ain_g;
-    float* aout = in_lds ? reinterpret_cast<float*>(s_buf + 3 * kBootLds) : aout_g;
+    float* aout = aout_g;
     if (!INFER && cfg.summary_stat) for (uint32_t s = tid; s < 2 * S; s += kBootNT) acc[s] = 0.0f;
     // what a label contributes with: its own abundance, or (USA) the gene's as get_abundance_for adds it up
     auto abundance = [&](uint32_t s) -> float {
@@ -971,7 +973,7 @@ __global__ __launch_bounds__(kBootNT) void k_boot(const uint64_t* __restrict__ c
                         const float iv = inv[k];
                         return iv >= 0.0f ? a * iv : 0.0f;
                     };
-                    const bool heavy = valid && q1 - q0 > kEmHeavy;
+                    const bool heavy = valid && q1 - q0 > kBootHeavy;
                     float o = 0.0f;
                     if (valid && !heavy) for (uint32_t q = q0; q < q1; ++q) o += term_at(ab, q);
                     // an entry in many classes (a highly expressed gene) is summed by its whole wave: the 64 loads go out

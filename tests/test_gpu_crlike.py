@@ -198,7 +198,7 @@ def test_bootstraps_large_cell(oracle):
     assert_same_result(got, want)
     cls = got.eqclasses.cell(0)
     n_genes = len({g for lab, _ in cls for g in lab})
-    assert len(cls) > 6144 and n_genes > 6144, (len(cls), n_genes)
+    assert len(cls) > 11264 and n_genes > 11264, (len(cls), n_genes)
     gb, wb = got.bootstraps, want.bootstraps
     assert np.array_equal(gb.mean_col, wb.mean_col) and np.array_equal(gb.var_col, wb.var_col)
     assert np.array_equal(gb.mean_val.view(np.uint32), wb.mean_val.view(np.uint32))
