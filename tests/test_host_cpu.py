@@ -153,3 +153,49 @@ def test_quantify_refuses_record_layouts_it_would_misread(lib, tmp_path):
     assert rc != 0 and "generate_permit_list.json" in msg
     rc, msg = _quantify(lib, good, tg, tmp_path / "o4", resolution="full")
     assert rc == pkg._abi.AFQ_ERR_INVALID_ARG
+
+
+def test_infer_files_input_errors_are_reported(lib, tmp_path):
+    """`afquant infer` (src/infer.rs:61-111): malformed inputs are reported, not crashed on; all of these fail before the
+    first device call."""
+    import gzip
+
+    class IOpts(C.Structure):
+        _fields_ = [("count_mat", C.c_char_p), ("eq_labels", C.c_char_p), ("output_dir", C.c_char_p), ("filter_list", C.c_char_p),
+                    ("usa_mode", C.c_uint32), ("num_threads", C.c_uint32), ("device", C.c_uint32), ("reserved", C.c_uint32)]
+
+    lib.afq_infer_files.argtypes = [C.POINTER(IOpts)]
+    lib.afq_infer_files.restype = C.c_int
+
+    def run(mtx_text, eq_text, rows="ACGT\nTTTT\n", cols="g0\ng1\ng2\n"):
+        d = tmp_path / f"case{run.n}"
+        run.n += 1
+        d.mkdir()
+        (d / "geqc_counts.mtx").write_text(mtx_text)
+        with gzip.open(d / "gene_eqclass.txt.gz", "wt") as f:
+            f.write(eq_text)
+        if rows is not None:
+            (d / "quants_mat_rows.txt").write_text(rows)
+        if cols is not None:
+            (d / "quants_mat_cols.txt").write_text(cols)
+        o = IOpts(str(d / "geqc_counts.mtx").encode(), str(d / "gene_eqclass.txt.gz").encode(), str(d / "out").encode(), None, 0, 1, 0, 0)
+        rc = lib.afq_infer_files(C.byref(o))
+        return rc, lib.afq_host_last_error().decode()
+
+    run.n = 0
+    good_mtx = "%%MatrixMarket matrix coordinate real general\n% written by sprs\n2 2 2\n1 1 3\n2 2 1\n"
+    good_eq = "3\n2\n0\t1\t0\n2\t1\n"
+    rc, msg = run("not a matrix\n", good_eq)
+    assert rc == pkg._abi.AFQ_ERR_BAD_INPUT and "MatrixMarket" in msg
+    rc, msg = run(good_mtx.replace("coordinate real", "array real"), good_eq)
+    assert rc == pkg._abi.AFQ_ERR_BAD_INPUT
+    rc, msg = run(good_mtx.replace("2 2 1\n", "2 9 1\n"), good_eq)          # column beyond the declared size
+    assert rc == pkg._abi.AFQ_ERR_BAD_INPUT and "bad entry" in msg
+    rc, msg = run(good_mtx, "3\n2\n0\t1\t7\n")                                # class id beyond the declared count
+    assert rc == pkg._abi.AFQ_ERR_BAD_INPUT and "out of range" in msg
+    rc, msg = run(good_mtx.replace("2 2 2", "2 5 2"), good_eq)               # more columns than classes
+    assert rc == pkg._abi.AFQ_ERR_BAD_INPUT and "more columns" in msg
+    rc, msg = run(good_mtx, good_eq, rows=None)                               # barcodes live next to the matrix (infer.rs:113-133)
+    assert rc == pkg._abi.AFQ_ERR_BAD_INPUT and "quants_mat_rows.txt" in msg
+    rc, msg = run(good_mtx, good_eq, cols=None)
+    assert rc == pkg._abi.AFQ_ERR_BAD_INPUT and "column (gene) names" in msg
