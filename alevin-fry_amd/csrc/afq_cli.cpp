@@ -1,6 +1,7 @@
-// afq_cli.cpp — `afquant quant …`: the flag surface of `alevin-fry quant` (src/main.rs:294-348 of the reference)
-// in front of afq_quantify() (include/afquant_host.h).  Same spellings and defaults; flags whose feature is not
-// implemented are accepted and refused with a clear message rather than ignored.
+// afq_cli.cpp — `afquant quant …` and `afquant infer …`: the flag surfaces of `alevin-fry quant` (src/main.rs:294-348 of the
+// reference) and `alevin-fry infer` (src/main.rs:350-365) in front of afq_quantify() / afq_infer_files()
+// (include/afquant_host.h).  Same spellings and defaults; what the reference refuses (--use-eds, -b with a plain
+// resolution, -d with trivial, --summary-stat without -b) is refused here too, with its message.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -20,6 +21,11 @@ static void usage() {
 }
 
 int main(int argc, char** argv) {
+    if (argc >= 2 && (std::strcmp(argv[1], "-h") == 0 || std::strcmp(argv[1], "--help") == 0)) { usage(); return 0; }
+    if (argc >= 2 && (std::strcmp(argv[1], "-V") == 0 || std::strcmp(argv[1], "--version") == 0)) {
+        std::printf("afquant-hip 0.1 (alevin-fry 0.18.0 quant / infer semantics, C ABI version %d)\n", AFQ_ABI_VERSION);
+        return 0;
+    }
     if (argc >= 2 && std::strcmp(argv[1], "infer") == 0) {   // src/main.rs:350-365, 825-847
         afq_infer_opts io{};
         auto need2 = [&](int& i) -> const char* { if (i + 1 >= argc) { usage(); std::exit(2); } return argv[++i]; };
