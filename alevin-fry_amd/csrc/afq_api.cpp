@@ -757,7 +757,7 @@ int staged_h2d(afq_ctx* c, uint8_t* dst, const uint8_t* src, size_t n, hipStream
     for (int i = 0; off < n; ++i) {
         const int b = i % 3;
         const size_t len = std::min(kStagePiece, n - off);
-        if (i >= 3) HIP_TRY(c, hipEventSynchronize(c->stage_ev[b]));   // the copy that last used this piece is done
+        HIP_TRY(c, hipEventSynchronize(c->stage_ev[b]));   // the copy that last used this piece (in this call or an earlier one) is done
         std::vector<std::thread> th;
         const size_t slice = (len + nth - 1) / nth;
         for (unsigned t = 0; t < nth; ++t) {
@@ -1120,7 +1120,7 @@ int afq_atac_dedup(afq_ctx* c, const uint32_t* ref, const uint32_t* start, const
     T(d_ocnt.ensure(2 * n1)); T(d_on.ensure(4ull * std::max<uint32_t>(n_cells, 1))); T(d_optr.ensure(8ull * (n_cells + 1)));
     T(d_flag.ensure(4));
     std::vector<uint32_t> on(n_cells);
-    if (e == hipSuccess && n) {
+    if (e == hipSuccess && n) {   // (the pinned staging path of afq_submit was measured here too: no faster for these arrays)
         T(hipMemcpyAsync(d_ref.p, ref, 4 * n, hipMemcpyHostToDevice, s));
         T(hipMemcpyAsync(d_start.p, start, 4 * n, hipMemcpyHostToDevice, s));
         T(hipMemcpyAsync(d_flen.p, frag_len, 2 * n, hipMemcpyHostToDevice, s));
