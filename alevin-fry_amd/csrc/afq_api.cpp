@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -178,6 +179,14 @@ struct afq_ctx {
     DevBuf atac[16];  // afq_atac_dedup's device buffers, kept between calls
     void* stage[3] = {nullptr, nullptr, nullptr};          // pinned staging for large host->device input copies
     hipEvent_t stage_ev[3] = {nullptr, nullptr, nullptr};
+    // afq_submit: the input crosses PCIe range by range while earlier ranges already run (h2d_ev[i] = range i's bytes landed)
+    std::vector<hipEvent_t> h2d_ev;
+    bool h2d_piped = false;
+    std::mutex up_mu;
+    std::condition_variable up_cv;
+    size_t up_enqueued = 0;
+    int up_rc = 0;
+    std::string up_err;
     // Two sets of per-range device state: while the rows of range i cross PCIe, the kernels of range i+1 run.
     RangeState rs[2];
     bool all_aligned = true;  // every chunk offset is a multiple of 4
@@ -291,8 +300,8 @@ int plan_ranges(afq_ctx* c) {
         const uint64_t n_ref = (nbytes - fixed) / 4;
         double nd = (em_res ? 24.0 + 40.0 * (c->cfg.usa_mode ? 3 : 1) : 16.0) * (double)n_ref + 128.0;
         if (pug_res) {  // per read: decode outputs + edge pool; the PUG scratch is per workgroup (sized for the largest cell)
-            nd += 20.0 * nrec + 64.0 * nrec;
-            pug_fixed = std::max(pug_fixed, 4.0 * (double)pug_scratch_words(nrec, (uint32_t)n_ref, true) * pug_max_blocks());
+            nd += 20.0 * nrec + 96.0 * nrec;   // rd_h/rd_u/rd_o + the edge pool (24 words per read), as run_range allocates them
+            pug_fixed = std::max(pug_fixed, 4.0 * (double)pug_scratch_words(nrec, (uint32_t)n_ref, true) * pug_max_blocks() + 4.0 * (double)(1ull << 22));
         }
         if (n_ref > kBucketTarget) nd += 16.0 * (double)(n_ref / kBucketTarget + 1);
         if (nd > mem_budget) return fail(c, AFQ_ERR_OOM, "cell " + std::to_string(i) + " alone exceeds device memory");
@@ -334,7 +343,7 @@ static uint32_t decode_short_records(uint64_t n_ref_words, uint64_t n_records) {
 }
 
 // Plan + enqueue one range of cells on the context's stream.
-int run_range(afq_ctx* c, Range r, int slot) {
+int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
     HostClock hc;
     RangeState& B = c->rs[slot];
     const afq_config& g = c->cfg;
@@ -486,6 +495,7 @@ int run_range(afq_ctx* c, Range r, int slot) {
         RangeState& O = c->rs[slot ^ 1];
         if (O.in_flight && O.kernels_done) HIP_TRY(c, hipStreamWaitEvent(s, O.kernels_done, 0));
     }
+    if (h2d_done) HIP_TRY(c, hipStreamWaitEvent(s, h2d_done, 0));   // afq_submit: this range's input bytes have landed
     hc.lap("run: uploads + memsets");
 
     DecodeArgs da{c->d_bytes, c->n_bytes, B.d_meta.as<CellMeta>(), n, c->d_t2g.as<uint32_t>(), c->ref_count,
@@ -744,15 +754,26 @@ int finish_range(afq_ctx* c, int slot) {
 
 // Large pageable (or file-mapped) input -> device: the runtime's own pageable path is one staging thread (~8 GB/s,
 // slower still when every page of a mapped file faults on first touch); here several threads fill pinned pieces
-// while the previous piece is on the wire.
+// while the previous piece is on the wire.  Memory the caller has pinned (hipHostMalloc / hipHostRegister) goes
+// straight to the DMA engine.
 constexpr size_t kStagePiece = 64u << 20;
-int staged_h2d(afq_ctx* c, uint8_t* dst, const uint8_t* src, size_t n, hipStream_t s) {
-    if (n < 2 * kStagePiece) { HIP_TRY(c, hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, s)); return 0; }
+bool host_ptr_is_pinned(const void* p) {
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+unsigned stage_threads() {
+    if (const char* e = std::getenv("AFQ_STAGE_THREADS")) return (unsigned)std::max(1, std::atoi(e));
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    return std::min(16u, std::max(4u, hw / 4));
+}
+int staged_h2d(afq_ctx* c, uint8_t* dst, const uint8_t* src, size_t n, hipStream_t s, bool pinned) {
+    if (pinned || n < 2 * kStagePiece) { HIP_TRY(c, hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, s)); return 0; }
     for (int i = 0; i < 3; ++i) {
         if (!c->stage[i]) HIP_TRY(c, hipHostMalloc(&c->stage[i], kStagePiece, hipHostMallocDefault));
         if (!c->stage_ev[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming));
     }
-    const unsigned nth = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    const unsigned nth = stage_threads();
     size_t off = 0;
     for (int i = 0; off < n; ++i) {
         const int b = i % 3;
@@ -773,7 +794,8 @@ int staged_h2d(afq_ctx* c, uint8_t* dst, const uint8_t* src, size_t n, hipStream
     return 0;
 }
 
-int submit_common(afq_ctx* c, uint32_t n_cells, uint64_t first_cell_index) {
+// Reset the per-batch state and cut the batch into ranges.
+int begin_batch(afq_ctx* c, uint32_t n_cells, uint64_t first_cell_index) {
     c->n_cells = n_cells;
     c->first_cell_index = first_cell_index;
     if (c->res) pool_put(c->res);
@@ -784,24 +806,43 @@ int submit_common(afq_ctx* c, uint32_t n_cells, uint64_t first_cell_index) {
     c->stats = afq_batch_stats{};
     c->stats.input_bytes = c->n_bytes;
     for (int i = 0; i < K_COUNT; ++i) { c->k_ms[i] = 0; c->k_launches[i] = 0; }
-    int rc = plan_ranges(c);
-    if (rc) return rc;
+    c->h2d_piped = false;
+    return plan_ranges(c);
+}
+
+// Software pipeline over the ranges with two buffer sets: range i is enqueued before range i-1 is
+// finished (sync + compaction + D2H of its rows), so that copy overlaps range i's kernels.  The last range
+// stays in flight until afq_collect.  With h2d_piped, range i's kernels also wait for its input bytes, which an
+// upload thread (or the DMA engine alone, for pinned sources) is still bringing over while earlier ranges run.
+int run_batch(afq_ctx* c) {
     c->next_range = 0;
     c->pending = true;
-    // Software pipeline over the ranges with two buffer sets: range i is enqueued before range i-1 is
-    // finished (sync + compaction + D2H of its rows), so that copy overlaps range i's kernels.  The last range
-    // stays in flight until afq_collect.
     const size_t k = c->ranges.size();
-    for (size_t i = 0; i < k; ++i) {
-        rc = run_range(c, c->ranges[i], (int)(i & 1));
-        if (rc) { c->pending = false; return rc; }
-        if (i > 0) {
-            rc = finish_range(c, (int)((i - 1) & 1));
-            if (rc) { c->pending = false; return rc; }
+    int rc = 0;
+    for (size_t i = 0; i < k && !rc; ++i) {
+        hipEvent_t ev = nullptr;
+        if (c->h2d_piped) {
+            std::unique_lock<std::mutex> lk(c->up_mu);
+            c->up_cv.wait(lk, [&]() { return c->up_enqueued > i || c->up_rc != 0; });
+            if (c->up_rc) { rc = c->up_rc; c->err = c->up_err; break; }
+            ev = c->h2d_ev[i];
         }
+        rc = run_range(c, c->ranges[i], (int)(i & 1), ev);
+        if (!rc && i > 0) rc = finish_range(c, (int)((i - 1) & 1));
+    }
+    if (rc) {
+        c->pending = false;
+        for (auto& rs : c->rs) { if (rs.stream) (void)hipStreamSynchronize(rs.stream); rs.in_flight = false; }
+        return rc;
     }
     c->next_range = k;
     return 0;
+}
+
+// the byte span [first chunk's offset, end of the last chunk) of a range (chunk offsets ascending)
+inline void range_span(const afq_ctx* c, Range r, uint64_t& a, uint64_t& b) {
+    a = c->chunk_off[r.c0];
+    b = c->chunk_off[r.c1 - 1] + c->hdr[2 * (size_t)(r.c1 - 1)];
 }
 
 }  // namespace
@@ -868,6 +909,7 @@ void afq_destroy(afq_ctx* c) {
     for (auto& b : c->atac) b.release();
     for (auto& p : c->stage) if (p) (void)hipHostFree(p);
     for (auto& ev : c->stage_ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : c->h2d_ev) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->res) pool_put(c->res);
     if (c->pool) {
@@ -905,21 +947,61 @@ int afq_submit(afq_ctx* c, const uint8_t* bytes, size_t n_bytes, const uint64_t*
     // dword-aligned although every chunk size is a multiple of 4.  The bytes are copied anyway: land them shifted so
     // that the chunks start on dword boundaries on the device (that is what the walk-free decode and the PUG path need).
     uint32_t shift = 0;
+    bool ascending = true;
     if (n_cells) {
         const uint32_t r = (uint32_t)(chunk_off[0] & 3);
         bool same = true;
-        for (uint32_t i = 1; i < n_cells && same; ++i) same = (chunk_off[i] & 3) == r;
+        for (uint32_t i = 1; i < n_cells; ++i) { same = same && (chunk_off[i] & 3) == r; ascending = ascending && chunk_off[i] >= chunk_off[i - 1]; }
         if (same) shift = (4 - r) & 3;
     }
     HIP_TRY(c, c->d_bytes_own.ensure(n_bytes + shift + 16));
-    if (shift) HIP_TRY(c, hipMemsetAsync(c->d_bytes_own.p, 0, 4, c->stream));
-    if (n_bytes) { int rc2 = staged_h2d(c, (uint8_t*)c->d_bytes_own.p + shift, bytes, n_bytes, c->stream); if (rc2) return rc2; }
-    HIP_TRY(c, hipMemsetAsync((uint8_t*)c->d_bytes_own.p + shift + n_bytes, 0, 16, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller keeps ownership of `bytes`
+    uint8_t* const dst = (uint8_t*)c->d_bytes_own.p + shift;
     if (shift) for (auto& o : c->chunk_off) o += shift;
     c->d_bytes = c->d_bytes_own.as<uint8_t>();
     c->n_bytes = n_bytes + shift;
-    return submit_common(c, n_cells, first_cell_index);
+    rc = begin_batch(c, n_cells, first_cell_index);   // validates the headers, cuts the ranges
+    if (rc) return rc;
+    if (shift) HIP_TRY(c, hipMemsetAsync(c->d_bytes_own.p, 0, 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(dst + n_bytes, 0, 16, c->stream));
+    const bool pinned = n_bytes && host_ptr_is_pinned(bytes) && host_ptr_is_pinned(bytes + n_bytes - 1);
+    const size_t k = c->ranges.size();
+    if (k < 2 || !ascending || std::getenv("AFQ_NO_H2D_PIPELINE")) {
+        if (n_bytes) { int rc2 = staged_h2d(c, dst, bytes, n_bytes, c->stream, pinned); if (rc2) return rc2; }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller keeps ownership of `bytes`
+        return run_batch(c);
+    }
+    // Range by range: the kernels of range i start when ITS bytes have landed, the later ranges are still crossing.
+    while (c->h2d_ev.size() < k) { hipEvent_t e = nullptr; HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->h2d_ev.push_back(e); }
+    c->h2d_piped = true;
+    c->up_enqueued = 0; c->up_rc = 0; c->up_err.clear();
+    auto upload = [&, bytes, pinned, k]() {
+        (void)hipSetDevice(c->device);
+        for (size_t i = 0; i < k; ++i) {
+            uint64_t a, b;
+            range_span(c, c->ranges[i], a, b);   // device-buffer coordinates (shift included)
+            int rc2 = staged_h2d(c, (uint8_t*)c->d_bytes_own.p + a, bytes + (a - shift), (size_t)(b - a), c->stream, pinned);
+            if (!rc2 && hipEventRecord(c->h2d_ev[i], c->stream) != hipSuccess) rc2 = AFQ_ERR_HIP;
+            std::lock_guard<std::mutex> lk(c->up_mu);
+            if (rc2) { c->up_rc = rc2; c->up_err = c->err.empty() ? "input upload failed" : c->err; }
+            c->up_enqueued = i + 1;
+            c->up_cv.notify_all();
+            if (rc2) return;
+        }
+    };
+    if (pinned) {   // nothing for the host to do but enqueue: all copies go out now, in range order
+        upload();
+        rc = run_batch(c);
+    } else {
+        std::thread th(upload);
+        rc = run_batch(c);
+        th.join();
+    }
+    {   // the caller keeps ownership of `bytes`: every copy out of them has finished before this returns
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (!rc && e != hipSuccess) rc = fail(c, AFQ_ERR_HIP, std::string("input upload: ") + hipGetErrorString(e));
+    }
+    c->h2d_piped = false;
+    return rc;
 }
 
 int afq_submit_device(afq_ctx* c, const void* d_bytes, size_t n_bytes, const uint64_t* chunk_off, uint32_t n_cells,
@@ -946,7 +1028,8 @@ int afq_submit_device(afq_ctx* c, const void* d_bytes, size_t n_bytes, const uin
         HIP_TRY(c, hipMemcpyAsync(c->hdr.data(), c->d_hdr.p, 8ull * n_cells, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    return submit_common(c, n_cells, first_cell_index);
+    int rc2 = begin_batch(c, n_cells, first_cell_index);
+    return rc2 ? rc2 : run_batch(c);
 }
 
 int afq_collect(afq_ctx* c, afq_result* out) {
