@@ -307,6 +307,13 @@ class Quantifier:
         self._check(self.lib.afq_submit(self._h, b.ctypes.data_as(C.c_void_p), b.nbytes,
                                         off.ctypes.data_as(C.POINTER(C.c_uint64)), len(off), first_cell_index))
 
+    def submit_ptr(self, h_ptr: int, n_bytes: int, chunk_off, first_cell_index: int = 0):
+        """afq_submit from a raw host address (e.g. pinned memory the caller owns)."""
+        off = np.ascontiguousarray(chunk_off, dtype=np.uint64)
+        self._keep = (off,)
+        self._check(self.lib.afq_submit(self._h, C.c_void_p(h_ptr), n_bytes,
+                                        off.ctypes.data_as(C.POINTER(C.c_uint64)), len(off), first_cell_index))
+
     def submit_device(self, d_ptr: int, n_bytes: int, chunk_off, first_cell_index: int = 0):
         off = np.ascontiguousarray(chunk_off, dtype=np.uint64)
         self._keep = (off,)

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/afquant.h"
 #include "../../include/afquant_host.h"
@@ -14,7 +15,7 @@ static void usage() {
     std::fprintf(stderr,
                  "usage: afquant quant -i <input-dir> -m <tg-map> -o <output-dir> -r <resolution>\n"
                  "       [-t <threads>] [--small-thresh N] [--umi-edit-dist 0|1] [--large-graph-thresh N]\n"
-                 "       [--quant-subset FILE] [--init-uniform] [--use-mtx] [-d] [-b N] [--device N]\n"
+                 "       [--quant-subset FILE] [--init-uniform] [--use-mtx] [-d] [-b N] [--device N | --devices 0,1,...]\n"
                  "       [--summary-stat] [--boot-seed S] [--sa-model winner-take-all|prefer-ambig]\n"
                  "resolutions: trivial cr-like cr-like-em parsimony parsimony-em parsimony-gene parsimony-gene-em\n"
                  "       afquant infer -c <geqc_counts.mtx> -e <gene_eqclass.txt.gz> -o <output-dir> [--usa] [--quant-subset FILE] [-t N]\n");
@@ -51,6 +52,7 @@ int main(int argc, char** argv) {
     afq_quant_opts o{};
     o.small_thresh = 100; o.umi_edit_dist = -1; o.large_graph_thresh = -1; o.num_threads = 0;
     std::string cmdline;
+    std::vector<int32_t> devs;
     for (int i = 0; i < argc; ++i) { if (i) cmdline += ' '; cmdline += argv[i]; }
     o.cmdline = cmdline.c_str();
     auto need = [&](int& i) -> const char* { if (i + 1 >= argc) { usage(); std::exit(2); } return argv[++i]; };
@@ -80,8 +82,12 @@ int main(int argc, char** argv) {
         }
         else if (a == "--multi-sample-output") (void)need(i);
         else if (a == "--device") o.device = (uint32_t)std::atoi(need(i));
+        else if (a == "--devices") {   // comma list of HIP device ordinals: cells are range-partitioned over them
+            for (const char* p = need(i); *p;) { char* e; const long v = std::strtol(p, &e, 10); if (e == p) { std::fprintf(stderr, "--devices wants a comma list of integers\n"); return 2; } devs.push_back((int32_t)v); p = *e == ',' ? e + 1 : e; if (*e && *e != ',') { std::fprintf(stderr, "--devices wants a comma list of integers\n"); return 2; } }
+        }
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); usage(); return 2; }
     }
+    if (!devs.empty()) { o.devices = devs.data(); o.n_devices = (uint32_t)devs.size(); }
     if (!o.input_dir || !o.tg_map || !o.output_dir || !o.resolution) { usage(); return 2; }
     if ((o.summary_stat || o.init_uniform) && !o.num_bootstraps) {   // clap `requires("num-bootstraps")`, main.rs:306-307
         std::fprintf(stderr, "error: the following required arguments were not provided:\n  --num-bootstraps <NUMBOOTSTRAPS>\n");

@@ -8,9 +8,10 @@
 //   --quant-subset filter                src/quant.rs:1523-1536, 1773-1784; src/utils.rs:1074-1095
 //   per-cell stats + featureDump row     src/quant.rs:1150-1262
 //   cols / rows / mtx / quant.json       src/quant.rs:1596-1613, 1786-1847, 1913-1933
-// Not here: -d/--dump-eqclasses, -b/--num-bootstraps, multi-barcode (Flex) records,
-// unmapped_bc_count_collated.bin (libradicl-internal format, not witnessed in the repo: unmapped = 0,
-// which is also the reference's behaviour when the file is missing, src/quant.rs:1485-1494).
+//   worker fan-out                       src/quant.rs:1553-1575, 1678-1765 -> one afq_ctx + host thread per device (--devices),
+//                                        byte-balanced contiguous cell ranges, rows gathered in cell order
+//   multi-barcode (10x Flex) records     src/quant.rs:1354-1373, 2003-2027, 1217-1262
+//   -d / -b outputs                      src/quant.rs:229-355, 1850-1877
 #include <algorithm>
 #include <charconv>
 #include <cmath>
@@ -18,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <sstream>
 #include <memory>
 #include <mutex>
@@ -82,7 +84,6 @@ int format_f32(float v, char* buf, size_t cap) {
     std::memcpy(buf, out.c_str(), out.size() + 1);
     return (int)out.size();
 }
-std::string f32s(float v) { char b[96]; format_f32(v, b, sizeof b); return b; }
 
 // ---------------------------------------------------------------------------
 // snappy: raw block decompress + frame format (stream identifier 0xff, compressed 0x00, uncompressed 0x01,
@@ -149,8 +150,11 @@ struct SnappyChunk { size_t in_off, in_len; uint64_t out_off, ulen; uint32_t crc
 bool snappy_frame_plan(const uint8_t* in, size_t n, std::vector<SnappyChunk>& chunks, uint64_t& total, std::string& err) {
     size_t p = 0;
     total = 0;
+    bool first = true;
     while (p < n) {
         if (p + 4 > n) { err = "truncated snappy frame header"; return false; }
+        if (first && in[p] != 0xff) { err = "snappy stream does not start with its stream identifier"; return false; }   // as snap::read::FrameDecoder
+        first = false;
         const uint8_t type = in[p];
         const size_t len = in[p + 1] | ((size_t)in[p + 2] << 8) | ((size_t)in[p + 3] << 16);
         p += 4;
@@ -163,6 +167,7 @@ bool snappy_frame_plan(const uint8_t* in, size_t n, std::vector<SnappyChunk>& ch
             c.in_off = p + 4; c.in_len = len - 4; c.out_off = total; c.compressed = type == 0x00;
             if (c.compressed) { size_t h; if (!snappy_raw_length(in + c.in_off, c.in_len, c.ulen, h)) { err = "corrupt snappy block"; return false; } }
             else c.ulen = c.in_len;
+            if (c.ulen > 65536) { err = "snappy chunk larger than the frame format's 65536-byte limit"; return false; }
             total += c.ulen;
             chunks.push_back(c);
         } else if (type >= 0x02 && type <= 0x7f) { err = "unskippable reserved snappy chunk"; return false; }
@@ -322,12 +327,15 @@ inline char* put_u64(char* p, unsigned long long v) {
     while (k) *p++ = tmp[--k];
     return p;
 }
-void mkdirs(const std::string& p) {
+// 0 when the directory exists afterwards
+int mkdirs_checked(const std::string& p) {
     std::string cur;
     for (size_t i = 0; i <= p.size(); ++i) {
         if (i == p.size() || p[i] == '/') { if (!cur.empty()) ::mkdir(cur.c_str(), 0755); }
         if (i < p.size()) cur.push_back(p[i]);
     }
+    struct stat st;
+    return (::stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode)) ? 0 : -1;
 }
 std::string json_escape(const std::string& s) {
     std::string o;
@@ -389,40 +397,60 @@ int afq_rad_parse_prelude(const uint8_t* bytes, size_t n, afq_rad_info* out) {
 // MatrixMarket as sprs::io::write_matrix_market writes a TriMatI<f32,u32> (coordinate real general, 1-based), from CSR
 static bool write_mtx_file(const std::string& path, uint64_t n_rows, uint64_t n_cols, const std::vector<uint64_t>& rp,
                        const std::vector<uint32_t>& cols, const std::vector<float>& vals, uint32_t num_threads) {
-    FILE* m = std::fopen(path.c_str(), "w");
-    if (!m) return false;
-    std::fprintf(m, "%%%%MatrixMarket matrix coordinate real general\n%% written by sprs\n%llu %llu %zu\n", (unsigned long long)n_rows, (unsigned long long)n_cols, vals.size());
-    // the entries are formatted by -t threads into per-slice buffers (same text as one fprintf per entry), written in order;
-    // a slice is a run of consecutive entries, its first row found by binary search in the row pointers
+    const int fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return false;
+    char head[160];
+    const int hl = std::snprintf(head, sizeof head, "%%%%MatrixMarket matrix coordinate real general\n%% written by sprs\n%llu %llu %zu\n",
+                                 (unsigned long long)n_rows, (unsigned long long)n_cols, vals.size());
+    bool ok = ::pwrite(fd, head, (size_t)hl, 0) == hl;
+    // the entries are formatted by -t threads into per-slice buffers (same text as one fprintf per entry) and written by the
+    // same threads at their final file offsets; a slice is a run of consecutive entries, its first row found by binary
+    // search in the row pointers
     const size_t nz = vals.size();
     // -t defaults to every core in the reference (main.rs:303); 0 = not given
     const unsigned nth = std::max(1u, std::min(num_threads ? num_threads : std::thread::hardware_concurrency(), 64u));
     const size_t slice = 1u << 20;
-    for (size_t base = 0; base < nz; base += slice * nth) {
+    uint64_t file_off = (uint64_t)hl;
+    for (size_t base = 0; base < nz && ok; base += slice * nth) {
         std::vector<std::string> bufs(nth);
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nth; ++t) {
-            const size_t a = base + t * slice, b = std::min(nz, a + slice);
-            if (a >= nz) break;
-            th.emplace_back([&, t, a, b]() {
-                std::string& out = bufs[t];
-                out.resize((b - a) * 112);  // 2 x <= 20 digits + an f32 in positional notation (<= 48 chars) + separators
-                char* p = &out[0];
-                size_t row = (size_t)(std::upper_bound(rp.begin(), rp.end(), (uint64_t)a) - rp.begin()) - 1;
-                for (size_t k = a; k < b; ++k) {
-                    while (rp[row + 1] <= k) ++row;   // skips empty rows too
-                    p = put_u64(p, (unsigned long long)row + 1); *p++ = ' ';
-                    p = put_u64(p, (unsigned long long)cols[k] + 1); *p++ = ' ';
-                    p += format_f32(vals[k], p, 64); *p++ = '\n';
-                }
-                out.resize((size_t)(p - &out[0]));
-            });
-        }
-        for (auto& x : th) x.join();
-        for (auto& bsl : bufs) if (!bsl.empty()) std::fwrite(bsl.data(), 1, bsl.size(), m);
+        auto each = [&](const std::function<void(unsigned, size_t, size_t)>& f) {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nth; ++t) {
+                const size_t a = base + t * slice, b = std::min(nz, a + slice);
+                if (a >= nz) break;
+                th.emplace_back(f, t, a, b);
+            }
+            for (auto& x : th) x.join();
+        };
+        each([&](unsigned t, size_t a, size_t b) {
+            std::string& out = bufs[t];
+            out.resize((b - a) * 112);  // 2 x <= 20 digits + an f32 in positional notation (<= 48 chars) + separators
+            char* p = &out[0];
+            size_t row = (size_t)(std::upper_bound(rp.begin(), rp.end(), (uint64_t)a) - rp.begin()) - 1;
+            for (size_t k = a; k < b; ++k) {
+                while (rp[row + 1] <= k) ++row;   // skips empty rows too
+                p = put_u64(p, (unsigned long long)row + 1); *p++ = ' ';
+                p = put_u64(p, (unsigned long long)cols[k] + 1); *p++ = ' ';
+                p += format_f32(vals[k], p, 64); *p++ = '\n';
+            }
+            out.resize((size_t)(p - &out[0]));
+        });
+        std::vector<uint64_t> off(nth + 1, file_off);
+        for (unsigned t = 0; t < nth; ++t) off[t + 1] = off[t] + bufs[t].size();
+        std::vector<int> bad(nth, 0);
+        each([&](unsigned t, size_t, size_t) {
+            const std::string& bsl = bufs[t];
+            for (size_t w = 0; w < bsl.size();) {
+                const ssize_t g = ::pwrite(fd, bsl.data() + w, bsl.size() - w, (off_t)(off[t] + w));
+                if (g <= 0) { bad[t] = 1; return; }
+                w += (size_t)g;
+            }
+        });
+        for (int x : bad) if (x) ok = false;
+        file_off = off[nth];
     }
-    std::fclose(m);
-    return true;
+    if (::close(fd) != 0) ok = false;
+    return ok;
 }
 
 // `alevin-fry infer` (src/infer.rs:31-426): files in, EM per row on the device (afq_infer), files out.
@@ -551,6 +579,136 @@ int afq_infer_files(const afq_infer_opts* o) {
     return 0;
 }
 
+// ---- the device side of afq_quantify: one context (+ the -d sibling) per device over a contiguous range of cells ----
+struct FileCloser { void operator()(FILE* f) const { if (f) std::fclose(f); } };
+using FilePtr = std::unique_ptr<FILE, FileCloser>;
+struct CtxCloser { void operator()(afq_ctx* c) const { if (c) afq_destroy(c); } };
+using CtxPtr = std::unique_ptr<afq_ctx, CtxCloser>;
+
+struct DevOut {   // what one device produced for its range of cells, in cell order
+    int rc = 0; std::string err;
+    std::vector<uint32_t> gene; std::vector<float> val; std::vector<uint64_t> row_end;   // CSR (row_end cumulative within this part)
+    std::vector<uint64_t> bc; std::vector<uint32_t> nrec; std::vector<uint8_t> flags;
+    std::vector<uint64_t> eq_cell_end, eq_label_end; std::vector<uint32_t> eq_labels, eq_count;   // -d
+    bool have_eq = false;
+    std::vector<uint64_t> bm_end, bv_end; std::vector<uint32_t> bm_col, bv_col; std::vector<float> bm_val, bv_val;   // -b
+    double t_submit = 0, t_collect = 0;
+};
+
+// Greedy prefix split of the chunk list into `parts` contiguous ranges of about equal bytes (the collated
+// file is ordered largest cells first, so equal cell counts would not balance).
+static std::vector<size_t> balanced_cuts(const std::vector<uint64_t>& nbytes, size_t parts) {
+    std::vector<double> csum(nbytes.size() + 1, 0.0);
+    for (size_t i = 0; i < nbytes.size(); ++i) csum[i + 1] = csum[i] + (double)nbytes[i];
+    std::vector<size_t> cuts(1, 0);
+    for (size_t r = 1; r < parts; ++r) {
+        const double target = csum.back() * (double)r / (double)parts;
+        size_t c = (size_t)(std::lower_bound(csum.begin(), csum.end(), target) - csum.begin());
+        if (c > 0 && c <= nbytes.size() && std::fabs(csum[c - 1] - target) <= std::fabs(csum[std::min(c, nbytes.size())] - target)) --c;
+        cuts.push_back(std::min(std::max(c, cuts.back()), nbytes.size()));
+    }
+    cuts.push_back(nbytes.size());
+    return cuts;
+}
+
+static void run_device_range(const afq_config& cfg, const afq_config* cfg_eq, const std::vector<uint32_t>& t2g, int device,
+                             const uint8_t* rad, const std::vector<uint64_t>& chunk_off, const std::vector<uint64_t>& chunk_nb,
+                             size_t cell0, size_t cell1, uint64_t batch_bytes, bool want_eq, bool res_is_em, DevOut& out) {
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    afq_ctx* raw = nullptr;
+    int rc = afq_create(&cfg, t2g.data(), (uint32_t)t2g.size(), device, &raw);
+    if (rc) { out.rc = rc; out.err = std::string("afq_create: ") + afq_last_error(nullptr); return; }
+    CtxPtr ctx(raw), ctx_eq;
+    if (cfg_eq) {
+        rc = afq_create(cfg_eq, t2g.data(), (uint32_t)t2g.size(), device, &raw);
+        if (rc) { out.rc = rc; out.err = std::string("afq_create: ") + afq_last_error(nullptr); return; }
+        ctx_eq.reset(raw);
+    }
+    for (size_t c0 = cell0; c0 < cell1;) {
+        size_t c1 = c0; uint64_t bytes = 0;
+        while (c1 < cell1) { const uint64_t nb = chunk_nb[c1]; if (c1 > c0 && bytes + nb > batch_bytes) break; bytes += nb; ++c1; }
+        // hand over just this batch's byte span (offsets relative to it), not the whole file
+        const uint64_t span0 = chunk_off[c0];
+        std::vector<uint64_t> rel(c1 - c0);
+        for (size_t k = c0; k < c1; ++k) rel[k - c0] = chunk_off[k] - span0;
+        const uint64_t span1 = chunk_off[c1 - 1] + chunk_nb[c1 - 1];   // with --quant-subset the span also covers chunks that were filtered out
+        auto ta = now();
+        rc = afq_submit(ctx.get(), rad + span0, (size_t)(span1 - span0), rel.data(), (uint32_t)(c1 - c0), c0);
+        auto tb = now();
+        afq_result res{};
+        if (!rc) rc = afq_collect(ctx.get(), &res);
+        out.t_submit += secs(ta, tb); out.t_collect += secs(tb, now());
+        if (rc) { out.rc = rc; out.err = afq_last_error(ctx.get()); return; }
+        if (cfg.num_bootstraps) {   // quant.rs:1270-1277
+            afq_bootstraps bs{};
+            if (afq_result_bootstraps(&res, &bs) == 0) {
+                const uint64_t m0 = out.bm_col.size(), v0 = out.bv_col.size();
+                out.bm_col.insert(out.bm_col.end(), bs.mean_col, bs.mean_col + bs.mean_ptr[bs.n_cells]);
+                out.bm_val.insert(out.bm_val.end(), bs.mean_val, bs.mean_val + bs.mean_ptr[bs.n_cells]);
+                out.bv_col.insert(out.bv_col.end(), bs.var_col, bs.var_col + bs.var_ptr[bs.n_cells]);
+                out.bv_val.insert(out.bv_val.end(), bs.var_val, bs.var_val + bs.var_ptr[bs.n_cells]);
+                for (uint64_t i = 0; i < bs.n_cells; ++i) { out.bm_end.push_back(m0 + bs.mean_ptr[i + 1]); out.bv_end.push_back(v0 + bs.var_ptr[i + 1]); }
+            }
+        }
+        if (want_eq) {
+            afq_result res_eq{};
+            afq_eqclasses ec{};
+            if (ctx_eq) {
+                rc = afq_submit(ctx_eq.get(), rad + span0, (size_t)(span1 - span0), rel.data(), (uint32_t)(c1 - c0), c0);
+                if (!rc) rc = afq_collect(ctx_eq.get(), &res_eq);
+                if (rc) { out.rc = rc; out.err = afq_last_error(ctx_eq.get()); afq_result_release(&res); return; }
+            }
+            const bool have = (ctx_eq || res_is_em) && afq_result_eqclasses(ctx_eq ? &res_eq : &res, &ec) == 0;
+            const uint64_t k0 = out.eq_count.size(), w0 = out.eq_labels.size();
+            if (have) {
+                out.have_eq = true;
+                out.eq_count.insert(out.eq_count.end(), ec.count, ec.count + ec.n_classes);
+                out.eq_labels.insert(out.eq_labels.end(), ec.labels, ec.labels + ec.n_words);
+                for (uint64_t k = 0; k < ec.n_classes; ++k) out.eq_label_end.push_back(w0 + ec.label_ptr[k + 1]);
+            }
+            for (uint64_t i = 0; i < res.n_cells; ++i) out.eq_cell_end.push_back(k0 + (have ? ec.cell_ptr[i + 1] : 0));
+            if (ctx_eq) afq_result_release(&res_eq);
+        }
+        const uint64_t g0 = out.gene.size();
+        out.gene.insert(out.gene.end(), res.gene, res.gene + res.nnz);
+        out.val.insert(out.val.end(), res.val, res.val + res.nnz);
+        for (uint64_t i = 0; i < res.n_cells; ++i) out.row_end.push_back(g0 + res.cell_ptr[i + 1]);
+        out.bc.insert(out.bc.end(), res.bc, res.bc + res.n_cells);
+        out.nrec.insert(out.nrec.end(), res.nrec, res.nrec + res.n_cells);
+        out.flags.insert(out.flags.end(), res.flags, res.flags + res.n_cells);
+        afq_result_release(&res);
+        c0 = c1;
+    }
+}
+
+// collation_manifest.bin (libradicl::collation::CollationManifest, written by src/collate.rs:1861-1890): the names of the
+// samples, indexed by the integer the scatter phase left in barcodes[0].  libradicl's source is not under /root/reference, so
+// the layout read here is a RESTATEMENT of its serde derive under bincode's default options (parity unpinned):
+//   level_names: u64 n, n x (u64 len, bytes);  sample_groups: u64 n, n x { key u64, name: u8 tag (0 None / 1 Some) [u64 len,
+//   bytes], chunk_start u64, num_chunks u64, num_records u64 }
+// The file must tile exactly; anything else is refused.  A sample without a name is called by its key in hex (quant.rs:1364-1368).
+static bool parse_collation_manifest(const std::vector<uint8_t>& b, std::vector<std::string>& names) {
+    Cursor c{b.data(), b.size()};
+    const uint64_t nl = c.get<uint64_t>();
+    if (!c.ok || nl > 64) return false;
+    for (uint64_t i = 0; i < nl; ++i) { const uint64_t l = c.get<uint64_t>(); if (!c.ok || l > 4096) return false; c.str((size_t)l); }
+    const uint64_t ng = c.get<uint64_t>();
+    if (!c.ok || ng > (1u << 24)) return false;
+    for (uint64_t i = 0; i < ng; ++i) {
+        const uint64_t key = c.get<uint64_t>();
+        const uint8_t tag = c.get<uint8_t>();
+        std::string nm;
+        if (tag == 1) { const uint64_t l = c.get<uint64_t>(); if (!c.ok || l > 65536) return false; nm = c.str((size_t)l); }
+        else if (tag == 0) { char hx[32]; std::snprintf(hx, sizeof hx, "%llx", (unsigned long long)key); nm = hx; }
+        else return false;
+        c.get<uint64_t>(); c.get<uint64_t>(); c.get<uint64_t>();
+        if (!c.ok) return false;
+        names.push_back(nm);
+    }
+    return c.p == c.n;
+}
+
 int afq_quantify(const afq_quant_opts* o) {
     if (!o || !o->input_dir || !o->tg_map || !o->output_dir || !o->resolution) return hfail(AFQ_ERR_INVALID_ARG, "null option");
     const ResolutionInfo* R = nullptr;
@@ -587,39 +745,71 @@ int afq_quantify(const afq_quant_opts* o) {
         if (!snappy_frame_plan(mf.p, mf.n, chunks, rad_buf_n, err)) return hfail(AFQ_ERR_BAD_INPUT, "map.collated.rad.sz: " + err);
         rad_buf.reset(new (std::nothrow) uint8_t[rad_buf_n ? rad_buf_n : 1]);
         if (!rad_buf) return hfail(AFQ_ERR_OOM, "map.collated.rad.sz: not enough host memory for the decompressed file");
-        if (!snappy_frame_run(mf.p, chunks, rad_buf.get(), o->num_threads ? o->num_threads : 1, err)) return hfail(AFQ_ERR_BAD_INPUT, "map.collated.rad.sz: " + err);
+        if (!snappy_frame_run(mf.p, chunks, rad_buf.get(), o->num_threads ? o->num_threads : std::max(1u, std::thread::hardware_concurrency()), err)) return hfail(AFQ_ERR_BAD_INPUT, "map.collated.rad.sz: " + err);
     }
     struct { const uint8_t* p; size_t n; const uint8_t* data() const { return p; } size_t size() const { return n; } } rad{compressed ? rad_buf.get() : mf.p, compressed ? (size_t)rad_buf_n : mf.n};
     pc.lap(compressed ? "map + snappy decode" : "map the RAD file");
     RadPrelude P;
     int rc = parse_prelude(rad.data(), rad.size(), P, true);
     if (rc) return rc;
-    if (!P.bc_bytes || !P.umi_bytes) return hfail(AFQ_ERR_UNSUPPORTED, "RAD read tags must hold integer 'b' and 'u' (single-barcode records)");
-    // the device decoders walk `na, b, u, na x u32` records (src/convert.rs:124-144): any other tag layout would be misread, not skipped
-    if (P.read_tags.size() != 2 || P.read_tags[0].name != "b" || P.read_tags[1].name != "u")
-        return hfail(AFQ_ERR_UNSUPPORTED, "RAD read-level tags other than (b, u) are not supported");
+    // Record layout.  Single-barcode scRNA: read tags (b, u).  Multi-barcode (10x Flex; KnownRecordType::RnaShortMultiBC,
+    // src/utils.rs:313-340): file tag num_barcodes = 2, read tags (b0, b1, u) - after collation b0 is the integer sample
+    // index and b1 the cell barcode (src/quant.rs:2003-2027).  The device decoders see (b0, b1) as ONE barcode field of
+    // w0 + w1 bytes: every record of a collated chunk carries the same pair, so candidate detection, the proof and the
+    // reported collate key work unchanged, and the host splits the 64-bit key back into sample index and cell barcode.
+    // (Field order b0, b1, u inside a record = the order of the read-tag section; libradicl's MultiBarcodeReadRecord
+    // writer is not under /root/reference: parity unpinned.)
+    const bool multi_bc = P.file_tag_vals.count("num_barcodes") && P.file_tag_vals["num_barcodes"] > 1;
+    uint32_t w_sample = 0, cblen = 0;
+    if (multi_bc) {
+        if (P.file_tag_vals["num_barcodes"] != 2 || P.read_tags.size() != 3 || P.read_tags[0].name != "b0" || P.read_tags[1].name != "b1" || P.read_tags[2].name != "u")
+            return hfail(AFQ_ERR_UNSUPPORTED, "multi-barcode RAD: only two barcode levels with read tags (b0, b1, u) are supported");
+        const uint32_t w0 = (uint32_t)int_type_bytes(P.read_tags[0].type), w1 = (uint32_t)int_type_bytes(P.read_tags[1].type);
+        P.umi_bytes = (uint32_t)int_type_bytes(P.read_tags[2].type);
+        if (!w0 || w0 != w1 || w0 > 4 || !P.umi_bytes) return hfail(AFQ_ERR_UNSUPPORTED, "multi-barcode RAD: b0 and b1 must be integers of the same width (u8/u16/u32)");
+        w_sample = w0; P.bc_bytes = w0 + w1;
+        if (!P.file_tag_vals.count("b1len")) return hfail(AFQ_ERR_BAD_INPUT, "multi-barcode RAD file should have a \"b1len\" file-level tag");
+        cblen = (uint32_t)P.file_tag_vals["b1len"];
+    } else {
+        if (!P.bc_bytes || !P.umi_bytes) return hfail(AFQ_ERR_UNSUPPORTED, "RAD read tags must hold integer 'b' and 'u' (single-barcode records)");
+        // the device decoders walk `na, b, u, na x u32` records (src/convert.rs:124-144): any other tag layout would be misread, not skipped
+        if (P.read_tags.size() != 2 || P.read_tags[0].name != "b" || P.read_tags[1].name != "u")
+            return hfail(AFQ_ERR_UNSUPPORTED, "RAD read-level tags other than (b, u) are not supported");
+        if (P.file_tag_vals.count("cblen")) cblen = (uint32_t)P.file_tag_vals["cblen"];
+        else return hfail(AFQ_ERR_UNSUPPORTED, "no cblen file tag");
+    }
     if (P.aln_tags.size() != 1 || P.aln_tags[0].type != 3)
         return hfail(AFQ_ERR_UNSUPPORTED, "RAD alignment-level tags other than one u32 (compressed_ori_refid) are not supported");
-    uint32_t cblen = 0;
-    if (P.file_tag_vals.count("cblen")) cblen = (uint32_t)P.file_tag_vals["cblen"];
-    else return hfail(AFQ_ERR_UNSUPPORTED, "no cblen file tag (multi-barcode RAD files are not supported)");
+    std::vector<std::string> sample_names;   // multi-barcode: name of sample i (src/quant.rs:1354-1373)
+    bool have_samples = false;
+    if (file_exists(in + "/collation_manifest.bin")) {
+        std::vector<uint8_t> mb;
+        if (!read_file(in + "/collation_manifest.bin", mb) || !parse_collation_manifest(mb, sample_names))
+            return hfail(AFQ_ERR_UNSUPPORTED, "collation_manifest.bin is not in the layout this build reads (bincode of CollationManifest; see afq_host.cpp)");
+        have_samples = true;
+    }
     // chunk table: hop the nbytes headers (what the producer thread does)
-    std::vector<uint64_t> chunk_off;
+    const uint32_t rec_hdr = 4 + P.bc_bytes + P.umi_bytes;
+    std::vector<uint64_t> chunk_off, chunk_nb;
     for (size_t p = P.first_chunk; p < rad.size();) {
         if (p + 8 > rad.size()) return hfail(AFQ_ERR_BAD_INPUT, "trailing bytes after the last chunk");
-        uint32_t nb; std::memcpy(&nb, rad.data() + p, 4);
+        uint32_t nb, nr; std::memcpy(&nb, rad.data() + p, 4); std::memcpy(&nr, rad.data() + p + 4, 4);
         if (nb < 8 || p + nb > rad.size()) return hfail(AFQ_ERR_BAD_INPUT, "corrupt chunk header");
-        chunk_off.push_back(p); p += nb;
+        if (nr == 0 || nb < 8 + rec_hdr) return hfail(AFQ_ERR_BAD_INPUT, "chunk " + std::to_string(chunk_off.size()) + " holds no record");   // (quant.rs:756 panics)
+        chunk_off.push_back(p); chunk_nb.push_back(nb); p += nb;
     }
-    // --quant-subset (src/quant.rs:1523-1536, 1776)
+    auto cell_key_of = [&](uint64_t raw_bc) -> uint64_t { return multi_bc ? raw_bc >> (8 * w_sample) : raw_bc; };
+    // --quant-subset (src/quant.rs:1523-1536, 1776): the first record's collate key decides
+    size_t subset_size = 0;
     if (o->filter_list) {
         std::ifstream f(o->filter_list);
         if (!f) return hfail(AFQ_ERR_BAD_INPUT, "could not read the --quant-subset file");
         std::unordered_set<uint64_t> keep; std::string line;
         while (std::getline(f, line)) { while (!line.empty() && std::isspace((unsigned char)line.back())) line.pop_back(); uint64_t v; if (!line.empty() && string_to_bc(line, v)) keep.insert(v); }
-        std::vector<uint64_t> kept;
-        for (uint64_t off : chunk_off) { uint64_t bc = 0; std::memcpy(&bc, rad.data() + off + 8 + 4, P.bc_bytes); if (keep.count(bc)) kept.push_back(off); }
-        chunk_off.swap(kept);
+        subset_size = keep.size();
+        std::vector<uint64_t> kept, kept_nb;
+        for (size_t i = 0; i < chunk_off.size(); ++i) { uint64_t bc = 0; std::memcpy(&bc, rad.data() + chunk_off[i] + 8 + 4, P.bc_bytes); if (keep.count(cell_key_of(bc))) { kept.push_back(chunk_off[i]); kept_nb.push_back(chunk_nb[i]); } }
+        chunk_off.swap(kept); chunk_nb.swap(kept_nb);
     }
     // transcript-to-gene map (src/utils.rs:487-662)
     std::unordered_map<std::string, uint32_t> rname_to_id;
@@ -677,22 +867,7 @@ int afq_quantify(const afq_quant_opts* o) {
             cfg_eq.resolution = cfg.resolution == AFQ_RES_CR_LIKE ? AFQ_RES_CR_LIKE_EM : cfg.resolution == AFQ_RES_PARSIMONY ? AFQ_RES_PARSIMONY_EM : AFQ_RES_PARSIMONY_GENE_EM;
         }
     }
-    afq_ctx* ctx = nullptr;
-    afq_ctx* ctx_eq = nullptr;
-    rc = afq_create(&cfg, t2g.data(), (uint32_t)P.ref_count, (int)o->device, &ctx);
-    if (!rc && cfg_eq.dump_eq) {
-        rc = afq_create(&cfg_eq, t2g.data(), (uint32_t)P.ref_count, (int)o->device, &ctx_eq);
-        if (rc) { const std::string m = afq_last_error(nullptr); afq_destroy(ctx); return hfail(rc, m); }
-    }
-    std::map<std::vector<uint32_t>, uint32_t> eq_ids;          // global_eqc: gene set -> class id, ids in order of first appearance
-    std::vector<uint32_t> eq_col, eq_cnt;                       // cell_level_count
-    std::vector<uint64_t> eq_row_ptr(1, 0);                     // cell_offset
-    std::vector<uint32_t> bm_col, bv_col; std::vector<float> bm_val, bv_val;   // BootstrapHelper's mean / variance triplets, as CSR
-    std::vector<uint64_t> bm_ptr(1, 0), bv_ptr(1, 0);
-    if (rc) return hfail(rc, std::string("afq_create: ") + afq_last_error(nullptr));
 
-    mkdirs(outd + "/alevin");
-    FILE* rows_f = std::fopen((outd + "/alevin/quants_mat_rows.txt").c_str(), "w");
     // Unmapped reads per corrected barcode (quant.rs:1484-1494; only CorrectedReads / MappingRate of featureDump use
     // them).  Any failure to read the file means "no unmapped reads", as in the reference.  The layout read here is
     // the bincode HashMap<u64, u32> one (count:u64, then key:u64 value:u32 pairs - atac/collate.rs:258-282 writes it);
@@ -700,13 +875,8 @@ int afq_quantify(const afq_quant_opts* o) {
     // reference tree, so a file that does not tile as the former is reported and ignored.
     std::unordered_map<uint64_t, uint32_t> unmapped;
     {
-        FILE* uf = std::fopen((in + "/unmapped_bc_count_collated.bin").c_str(), "rb");
-        if (uf) {
-            std::vector<uint8_t> ub;
-            uint8_t tmp[1 << 16];
-            size_t got;
-            while ((got = std::fread(tmp, 1, sizeof tmp, uf)) > 0) ub.insert(ub.end(), tmp, tmp + got);
-            std::fclose(uf);
+        std::vector<uint8_t> ub;
+        if (read_file(in + "/unmapped_bc_count_collated.bin", ub)) {
             uint64_t n = 0;
             if (ub.size() >= 8) std::memcpy(&n, ub.data(), 8);
             if (ub.size() >= 8 && n <= (ub.size() - 8) / 12 && ub.size() == 8 + 12 * n) {
@@ -720,127 +890,171 @@ int afq_quantify(const afq_quant_opts* o) {
                 std::fprintf(stderr, "unmapped_bc_count_collated.bin is not in the (count, key/value pairs) layout; unmapped reads are taken as 0\n");
         }
     }
-    FILE* feat_f = std::fopen((outd + "/featureDump.txt").c_str(), "w");
-    FILE* cols_f = std::fopen((outd + "/alevin/quants_mat_cols.txt").c_str(), "w");
-    if (!rows_f || !feat_f || !cols_f) { afq_destroy(ctx); return hfail(AFQ_ERR_BAD_INPUT, "could not create the output files"); }
-    std::fputs("CB\tCorrectedReads\tMappedReads\tDeduplicatedReads\tMappingRate\tDedupRate\tMeanByMax\tNumGenesExpressed\tNumGenesOverMean\n", feat_f);
-    for (auto& g : gene_names) std::fprintf(cols_f, "%s\n", g.c_str());
-    if (usa) { for (auto& g : gene_names) std::fprintf(cols_f, "%s-U\n", g.c_str()); for (auto& g : gene_names) std::fprintf(cols_f, "%s-A\n", g.c_str()); }
-    std::fclose(cols_f);
 
-    // batches of chunks to the device; rows come back in cell order
-    const uint64_t batch_bytes = o->batch_bytes ? o->batch_bytes : (1ull << 30);
-    std::vector<uint32_t> all_gene; std::vector<float> all_val;   // the count matrix as CSR (bulk-appended per batch)
-    std::vector<uint64_t> row_ptr(1, 0);
-    std::vector<uint64_t> alt_cells, empty_cells, tiny_cells;
-    uint64_t total_records = 0, row_index = 0;
-    double t_submit = 0, t_collect = 0, t_rows = 0;
-    auto now = []() { return std::chrono::steady_clock::now(); };
-    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
-    for (size_t c0 = 0; c0 < chunk_off.size();) {
-        size_t c1 = c0; uint64_t bytes = 0;
-        while (c1 < chunk_off.size()) { uint32_t nb; std::memcpy(&nb, rad.data() + chunk_off[c1], 4); if (c1 > c0 && bytes + nb > batch_bytes) break; bytes += nb; ++c1; }
-        // hand over just this batch's byte span (offsets relative to it), not the whole file
-        const uint64_t span0 = chunk_off[c0];
-        std::vector<uint64_t> rel(c1 - c0);
-        for (size_t k = c0; k < c1; ++k) rel[k - c0] = chunk_off[k] - span0;
-        uint32_t last_nb; std::memcpy(&last_nb, rad.data() + chunk_off[c1 - 1], 4);
-        const uint64_t span1 = chunk_off[c1 - 1] + last_nb;   // with --quant-subset the span also covers chunks that were filtered out
-        auto ta = now();
-        rc = afq_submit(ctx, rad.data() + span0, (size_t)(span1 - span0), rel.data(), (uint32_t)(c1 - c0), c0);
-        auto tb = now();
-        afq_result res{};
-        if (!rc) rc = afq_collect(ctx, &res);
-        auto tc = now();
-        t_submit += secs(ta, tb); t_collect += secs(tb, tc);
-        if (rc) { std::string m = afq_last_error(ctx); afq_destroy(ctx); if (ctx_eq) afq_destroy(ctx_eq); std::fclose(rows_f); std::fclose(feat_f); return hfail(rc, m); }
-        if (o->num_bootstraps) {   // quant.rs:1270-1277
-            afq_bootstraps bs{};
-            if (afq_result_bootstraps(&res, &bs) == 0) {
-                bm_col.insert(bm_col.end(), bs.mean_col, bs.mean_col + bs.mean_ptr[bs.n_cells]);
-                bm_val.insert(bm_val.end(), bs.mean_val, bs.mean_val + bs.mean_ptr[bs.n_cells]);
-                bv_col.insert(bv_col.end(), bs.var_col, bs.var_col + bs.var_ptr[bs.n_cells]);
-                bv_val.insert(bv_val.end(), bs.var_val, bs.var_val + bs.var_ptr[bs.n_cells]);
-                const uint64_t m0 = bm_ptr.back(), v0 = bv_ptr.back();
-                for (uint64_t i = 0; i < bs.n_cells; ++i) { bm_ptr.push_back(m0 + bs.mean_ptr[i + 1]); bv_ptr.push_back(v0 + bs.var_ptr[i + 1]); }
-            }
+    // ---- the device work: the worker fan-out of do_quantify (quant.rs:1553-1575, 1678-1765) becomes one context and one
+    // host thread per device over a contiguous, byte-balanced range of cells; no device talks to another ----
+    std::vector<int> devices;
+    if (o->devices && o->n_devices) devices.assign(o->devices, o->devices + o->n_devices); else devices.push_back((int)o->device);
+    if (devices.size() > chunk_off.size() && !chunk_off.empty()) devices.resize(chunk_off.size());
+    const uint64_t batch_bytes = o->batch_bytes ? o->batch_bytes : (16ull << 30);
+    const std::vector<size_t> cuts = balanced_cuts(chunk_nb, devices.size());
+    std::vector<DevOut> parts(devices.size());
+    {
+        auto work = [&](size_t d) {
+            run_device_range(cfg, cfg_eq.dump_eq ? &cfg_eq : nullptr, t2g, devices[d], rad.data(), chunk_off, chunk_nb, cuts[d], cuts[d + 1],
+                             batch_bytes, o->dump_eq != 0, res_is_em, parts[d]);
+        };
+        if (devices.size() == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (size_t d = 0; d < devices.size(); ++d) th.emplace_back(work, d);
+            for (auto& x : th) x.join();
         }
-        if (o->dump_eq) {
-            afq_result res_eq{};
-            afq_eqclasses ec{};
-            if (ctx_eq) {
-                rc = afq_submit(ctx_eq, rad.data() + span0, (size_t)(span1 - span0), rel.data(), (uint32_t)(c1 - c0), c0);
-                if (!rc) rc = afq_collect(ctx_eq, &res_eq);
-                if (rc) { std::string m = afq_last_error(ctx_eq); afq_result_release(&res); afq_destroy(ctx); afq_destroy(ctx_eq); std::fclose(rows_f); std::fclose(feat_f); return hfail(rc, m); }
-            }
-            const bool have = (ctx_eq || res_is_em) && afq_result_eqclasses(ctx_eq ? &res_eq : &res, &ec) == 0;
+    }
+    for (size_t d = 0; d < parts.size(); ++d)
+        if (parts[d].rc) return hfail(parts[d].rc, (devices.size() > 1 ? "device " + std::to_string(devices[d]) + ": " : std::string()) + parts[d].err);
+    if (pc.on) for (size_t d = 0; d < parts.size(); ++d)
+        std::fprintf(stderr, "[afquant]   device %d: cells [%zu, %zu), afq_submit %.3f s, afq_collect %.3f s\n", devices[d], cuts[d], cuts[d + 1], parts[d].t_submit, parts[d].t_collect);
+    pc.lap("device batches");
+
+    // ---- host-side gather in cell order (the only communication the path has) ----
+    const uint64_t row_index = chunk_off.size();
+    std::vector<uint32_t> all_gene; std::vector<float> all_val;
+    std::vector<uint64_t> row_ptr(1, 0), bc_all; std::vector<uint32_t> nrec_all; std::vector<uint8_t> flags_all;
+    std::map<std::vector<uint32_t>, uint32_t> eq_ids;          // global_eqc: gene set -> class id, ids in order of first appearance
+    std::vector<uint32_t> eq_col, eq_cnt;                       // cell_level_count
+    std::vector<uint64_t> eq_row_ptr(1, 0);                     // cell_offset
+    std::vector<uint32_t> bm_col, bv_col; std::vector<float> bm_val, bv_val;   // BootstrapHelper's mean / variance triplets, as CSR
+    std::vector<uint64_t> bm_ptr(1, 0), bv_ptr(1, 0);
+    if (parts.size() == 1) { all_gene.swap(parts[0].gene); all_val.swap(parts[0].val); }
+    else {
+        size_t tot = 0;
+        for (auto& p2 : parts) tot += p2.gene.size();
+        all_gene.reserve(tot); all_val.reserve(tot);
+    }
+    row_ptr.reserve(row_index + 1); bc_all.reserve(row_index); nrec_all.reserve(row_index); flags_all.reserve(row_index);
+    for (auto& p2 : parts) {
+        const uint64_t g0 = row_ptr.back();
+        if (parts.size() > 1) { all_gene.insert(all_gene.end(), p2.gene.begin(), p2.gene.end()); all_val.insert(all_val.end(), p2.val.begin(), p2.val.end()); std::vector<uint32_t>().swap(p2.gene); std::vector<float>().swap(p2.val); }
+        for (uint64_t e : p2.row_end) row_ptr.push_back(g0 + e);
+        bc_all.insert(bc_all.end(), p2.bc.begin(), p2.bc.end());
+        nrec_all.insert(nrec_all.end(), p2.nrec.begin(), p2.nrec.end());
+        flags_all.insert(flags_all.end(), p2.flags.begin(), p2.flags.end());
+        if (o->num_bootstraps && !p2.bm_end.empty()) {
+            const uint64_t m0 = bm_col.size(), v0 = bv_col.size();
+            bm_col.insert(bm_col.end(), p2.bm_col.begin(), p2.bm_col.end()); bm_val.insert(bm_val.end(), p2.bm_val.begin(), p2.bm_val.end());
+            bv_col.insert(bv_col.end(), p2.bv_col.begin(), p2.bv_col.end()); bv_val.insert(bv_val.end(), p2.bv_val.begin(), p2.bv_val.end());
+            for (size_t i = 0; i < p2.bm_end.size(); ++i) { bm_ptr.push_back(m0 + p2.bm_end[i]); bv_ptr.push_back(v0 + p2.bv_end[i]); }
+        }
+        if (o->dump_eq) {   // the global dictionary is filled in cell order (quant.rs:1282-1307), so that ids do not depend on the device count
             std::vector<uint32_t> key;
-            for (uint64_t i = 0; i < res.n_cells; ++i) {
-                if (have)
-                    for (uint64_t k = ec.cell_ptr[i]; k < ec.cell_ptr[i + 1]; ++k) {   // quant.rs:1282-1307
-                        key.assign(ec.labels + ec.label_ptr[k], ec.labels + ec.label_ptr[k + 1]);
-                        auto it = eq_ids.find(key);
-                        if (it == eq_ids.end()) it = eq_ids.emplace(key, (uint32_t)eq_ids.size()).first;
-                        eq_col.push_back(it->second); eq_cnt.push_back(ec.count[k]);
-                    }
+            uint64_t k = 0;
+            for (size_t i = 0; i < p2.eq_cell_end.size(); ++i) {
+                for (; k < p2.eq_cell_end[i]; ++k) {
+                    const uint64_t w0 = k ? p2.eq_label_end[k - 1] : 0, w1 = p2.eq_label_end[k];
+                    key.assign(p2.eq_labels.begin() + (ptrdiff_t)w0, p2.eq_labels.begin() + (ptrdiff_t)w1);
+                    auto it = eq_ids.find(key);
+                    if (it == eq_ids.end()) it = eq_ids.emplace(key, (uint32_t)eq_ids.size()).first;
+                    eq_col.push_back(it->second); eq_cnt.push_back(p2.eq_count[k]);
+                }
                 eq_row_ptr.push_back(eq_col.size());
             }
-            if (ctx_eq) afq_result_release(&res_eq);
         }
-        for (uint64_t i = 0; i < res.n_cells; ++i) {
-            const uint64_t a = res.cell_ptr[i], b = res.cell_ptr[i + 1];
-            const uint64_t cell_num = c0 + i;
-            float sum = 0.0f, mx = 0.0f;  // src/quant.rs:1150-1171 (f32 sum in column order)
-            for (uint64_t k = a; k < b; ++k) { sum += res.val[k]; if (res.val[k] > mx) mx = res.val[k]; }
-            const uint32_t num_expr = (uint32_t)(b - a);
-            const uint32_t nrec = res.nrec[i];
-            const float dedup_rate = sum / (float)nrec;
-            uint64_t num_unmapped = 0;
-            if (!unmapped.empty()) { auto it = unmapped.find(res.bc[i]); if (it != unmapped.end()) num_unmapped = it->second; }
-            const float mapping_rate = (float)nrec / (float)(nrec + num_unmapped);
-            const float mean_expr = sum / (float)num_expr;
-            uint32_t over = 0;
-            for (uint64_t k = a; k < b; ++k) if (res.val[k] > mean_expr) ++over;
-            const float mean_by_max = mean_expr / mx;
-            const std::string bcs = bc_to_string(res.bc[i], cblen);
-            std::fprintf(rows_f, "%s\n", bcs.c_str());
-            std::fprintf(feat_f, "%s\t%llu\t%u\t%s\t%s\t%s\t%s\t%u\t%u\n", bcs.c_str(), (unsigned long long)(nrec + num_unmapped), nrec,
-                         f32s(sum).c_str(), f32s(mapping_rate).c_str(), f32s(dedup_rate).c_str(), f32s(mean_by_max).c_str(), num_expr, over);
-            row_ptr.push_back(row_ptr.back() + (b - a));
-            if (res.flags[i] & AFQ_CELL_ALT_RES) alt_cells.push_back(cell_num);
-            if (res.flags[i] & AFQ_CELL_EMPTY) empty_cells.push_back(cell_num);
-            if (res.flags[i] & AFQ_CELL_TINY_PATH) tiny_cells.push_back(cell_num);
-            total_records += nrec;
-            ++row_index;
-        }
-        all_gene.insert(all_gene.end(), res.gene, res.gene + res.nnz);
-        all_val.insert(all_val.end(), res.val, res.val + res.nnz);
-        afq_result_release(&res);
-        t_rows += secs(tc, now());
-        c0 = c1;
     }
-    if (pc.on) std::fprintf(stderr, "[afquant]   afq_submit %.3f s, afq_collect %.3f s, per-cell rows %.3f s\n", t_submit, t_collect, t_rows);
-    afq_destroy(ctx);
-    if (ctx_eq) afq_destroy(ctx_eq);
-    std::fclose(rows_f); std::fclose(feat_f);
-    pc.lap("device batches + per-cell rows");
+    if (bc_all.size() != row_index) return hfail(AFQ_ERR_STATE, "internal: the devices returned a different number of cells than were submitted");
+    parts.clear();
+
+    // ---- per-cell rows: quants_mat_rows.txt + featureDump.txt (src/quant.rs:1150-1262), formatted by -t threads over
+    // contiguous runs of cells and written in order ----
+    if (mkdirs_checked(outd + "/alevin")) return hfail(AFQ_ERR_BAD_INPUT, "could not create the output directory " + outd + "/alevin");
+    FilePtr rows_f(std::fopen((outd + "/alevin/quants_mat_rows.txt").c_str(), "w"));
+    FilePtr feat_f(std::fopen((outd + "/featureDump.txt").c_str(), "w"));
+    FilePtr cols_f(std::fopen((outd + "/alevin/quants_mat_cols.txt").c_str(), "w"));
+    if (!rows_f || !feat_f || !cols_f) return hfail(AFQ_ERR_BAD_INPUT, "could not create the output files");
+    const bool sample_cols = multi_bc && have_samples;   // sample-prefixed row labels + the sample_name column (quant.rs:1217-1262)
+    std::fputs(have_samples ?   // the header goes by the manifest alone (quant.rs:1603-1613)
+ "CB\tsample_name\tCorrectedReads\tMappedReads\tDeduplicatedReads\tMappingRate\tDedupRate\tMeanByMax\tNumGenesExpressed\tNumGenesOverMean\n"
+                           : "CB\tCorrectedReads\tMappedReads\tDeduplicatedReads\tMappingRate\tDedupRate\tMeanByMax\tNumGenesExpressed\tNumGenesOverMean\n", feat_f.get());
+    for (auto& g : gene_names) std::fprintf(cols_f.get(), "%s\n", g.c_str());
+    if (usa) { for (auto& g : gene_names) std::fprintf(cols_f.get(), "%s-U\n", g.c_str()); for (auto& g : gene_names) std::fprintf(cols_f.get(), "%s-A\n", g.c_str()); }
+    cols_f.reset();
+    std::vector<uint64_t> alt_cells, empty_cells, tiny_cells;
+    uint64_t total_records = 0;
+    {
+        const unsigned nth = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)(o->num_threads ? o->num_threads : std::thread::hardware_concurrency()), 64, row_index / 256 + 1}));
+        std::vector<std::string> rows_txt(nth), feat_txt(nth);
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nth; ++t)
+            th.emplace_back([&, t]() {
+                const uint64_t i0 = row_index * t / nth, i1 = row_index * (t + 1) / nth;
+                std::string &rt = rows_txt[t], &ft = feat_txt[t];
+                char num[64];
+                for (uint64_t i = i0; i < i1; ++i) {
+                    const uint64_t a = row_ptr[i], b = row_ptr[i + 1];
+                    float sum = 0.0f, mx = 0.0f;  // src/quant.rs:1150-1171 (f32 sum in column order)
+                    for (uint64_t k = a; k < b; ++k) { sum += all_val[k]; if (all_val[k] > mx) mx = all_val[k]; }
+                    const uint32_t num_expr = (uint32_t)(b - a);
+                    const uint32_t nrec = nrec_all[i];
+                    const float dedup_rate = sum / (float)nrec;
+                    const uint64_t cell_bc = cell_key_of(bc_all[i]);
+                    uint64_t num_unmapped = 0;
+                    if (!unmapped.empty()) { auto it = unmapped.find(cell_bc); if (it != unmapped.end()) num_unmapped = it->second; }
+                    const float mapping_rate = (float)nrec / (float)(nrec + num_unmapped);
+                    const float mean_expr = sum / (float)num_expr;
+                    uint32_t over = 0;
+                    for (uint64_t k = a; k < b; ++k) if (all_val[k] > mean_expr) ++over;
+                    const float mean_by_max = mean_expr / mx;
+                    const std::string bcs = bc_to_string(cell_bc, cblen);
+                    const std::string* sn = nullptr;
+                    if (sample_cols) { const uint64_t si = bc_all[i] & ((1ull << (8 * w_sample)) - 1); if (si < sample_names.size()) sn = &sample_names[(size_t)si]; }
+                    if (sn) { rt += *sn; rt += '_'; }
+                    rt += bcs; rt += '\n';
+                    ft += bcs; ft += '\t';
+                    if (sn) { ft += *sn; ft += '\t'; }
+                    *put_u64(num, (unsigned long long)(nrec + num_unmapped)) = 0; ft += num; ft += '\t';
+                    *put_u64(num, nrec) = 0; ft += num; ft += '\t';
+                    format_f32(sum, num, sizeof num); ft += num; ft += '\t';
+                    format_f32(mapping_rate, num, sizeof num); ft += num; ft += '\t';
+                    format_f32(dedup_rate, num, sizeof num); ft += num; ft += '\t';
+                    format_f32(mean_by_max, num, sizeof num); ft += num; ft += '\t';
+                    *put_u64(num, num_expr) = 0; ft += num; ft += '\t';
+                    *put_u64(num, over) = 0; ft += num; ft += '\n';
+                }
+            });
+        for (auto& x : th) x.join();
+        for (unsigned t = 0; t < nth; ++t) {
+            std::fwrite(rows_txt[t].data(), 1, rows_txt[t].size(), rows_f.get());
+            std::fwrite(feat_txt[t].data(), 1, feat_txt[t].size(), feat_f.get());
+        }
+        for (uint64_t i = 0; i < row_index; ++i) {
+            if (flags_all[i] & AFQ_CELL_ALT_RES) alt_cells.push_back(i);
+            if (flags_all[i] & AFQ_CELL_EMPTY) empty_cells.push_back(i);
+            if (flags_all[i] & AFQ_CELL_TINY_PATH) tiny_cells.push_back(i);
+            total_records += nrec_all[i];
+        }
+    }
+    rows_f.reset(); feat_f.reset();
+    pc.lap("gather + per-cell rows");
+    // With --quant-subset the reference sizes the matrix (and reports num_quantified_cells) by the SUBSET's size, whether or
+    // not every listed barcode occurs in the file (quant.rs:1529, 1836, 1918); rows exist only for the cells found.
+    const uint64_t num_cells = o->filter_list ? (uint64_t)subset_size : row_index;
     auto write_mtx = [&](const std::string& path, uint64_t n_rows, uint64_t n_cols, const std::vector<uint64_t>& rp,
                          const std::vector<uint32_t>& cols, const std::vector<float>& vals) -> bool {
         return write_mtx_file(path, n_rows, n_cols, rp, cols, vals, o->num_threads);
     };
-    if (!write_mtx(outd + "/alevin/quants_mat.mtx", row_index, cfg.num_rows, row_ptr, all_gene, all_val)) return hfail(AFQ_ERR_BAD_INPUT, "could not create quants_mat.mtx");
+    if (!write_mtx(outd + "/alevin/quants_mat.mtx", num_cells, cfg.num_rows, row_ptr, all_gene, all_val)) return hfail(AFQ_ERR_BAD_INPUT, "could not create quants_mat.mtx");
     pc.lap("quants_mat.mtx");
     // -b: bootstrap summary matrices, cells x num_rows (src/quant.rs:1850-1877; nothing is written when no cell had a bootstrap)
     if (o->num_bootstraps && !bm_val.empty()) {
-        if (!write_mtx(outd + "/alevin/bootstraps_mean.mtx", row_index, cfg.num_rows, bm_ptr, bm_col, bm_val) ||
-            !write_mtx(outd + "/alevin/bootstraps_var.mtx", row_index, cfg.num_rows, bv_ptr, bv_col, bv_val))
+        if (!write_mtx(outd + "/alevin/bootstraps_mean.mtx", num_cells, cfg.num_rows, bm_ptr, bm_col, bm_val) ||
+            !write_mtx(outd + "/alevin/bootstraps_var.mtx", num_cells, cfg.num_rows, bv_ptr, bv_col, bv_val))
             return hfail(AFQ_ERR_BAD_INPUT, "could not write the bootstrap matrices");
         pc.lap("bootstraps_mean.mtx + bootstraps_var.mtx");
     }
     // -d: cells x gene-level equivalence classes + the classes' gene sets (write_eqc_counts, src/quant.rs:229-355)
     if (o->dump_eq) {
         std::vector<float> ev(eq_cnt.begin(), eq_cnt.end());
-        if (!write_mtx(outd + "/alevin/geqc_counts.mtx", row_index, eq_ids.size(), eq_row_ptr, eq_col, ev)) return hfail(AFQ_ERR_BAD_INPUT, "could not write geqc_counts.mtx");
+        if (!write_mtx(outd + "/alevin/geqc_counts.mtx", num_cells, eq_ids.size(), eq_row_ptr, eq_col, ev)) return hfail(AFQ_ERR_BAD_INPUT, "could not write geqc_counts.mtx");
         std::vector<const std::vector<uint32_t>*> by_id(eq_ids.size());
         for (auto& kv : eq_ids) by_id[kv.second] = &kv.first;
         std::string txt = std::to_string(cfg.num_rows) + "\n" + std::to_string(eq_ids.size()) + "\n";
@@ -870,7 +1084,7 @@ int afq_quantify(const afq_quant_opts* o) {
         auto list = [&](const std::vector<uint64_t>& v) { std::string s = "["; for (size_t i = 0; i < v.size(); ++i) { if (i) s += ", "; s += std::to_string(v[i]); } return s + "]"; };
         std::fprintf(j, "{\n  \"cmd\": \"%s\",\n  \"version_str\": \"afquant-hip 0.1 (alevin-fry 0.18.0 quant semantics)\",\n  \"resolution_strategy\": \"%s\",\n",
                      json_escape(o->cmdline ? o->cmdline : "").c_str(), R->debug);
-        std::fprintf(j, "  \"num_quantified_cells\": %llu,\n  \"num_genes\": %u,\n  \"dump_eq\": %s,\n  \"usa_mode\": %s,\n", (unsigned long long)row_index, cfg.num_rows, o->dump_eq ? "true" : "false", usa ? "true" : "false");
+        std::fprintf(j, "  \"num_quantified_cells\": %llu,\n  \"num_genes\": %u,\n  \"dump_eq\": %s,\n  \"usa_mode\": %s,\n", (unsigned long long)num_cells, cfg.num_rows, o->dump_eq ? "true" : "false", usa ? "true" : "false");
         std::fprintf(j, "  \"alt_resolved_cell_numbers\": %s,\n  \"empty_resolved_cell_numbers\": %s,\n  \"num_tiny_cell_resolved\": %zu,\n  \"tiny_cell_resolved_cell_numbers\": %s,\n",
                      list(alt_cells).c_str(), list(empty_cells).c_str(), tiny_cells.size(), list(tiny_cells).c_str());
         std::fprintf(j, "  \"total_records\": %llu,\n  \"quant_options\": {\n    \"input_dir\": \"%s\",\n    \"tg_map\": \"%s\",\n    \"output_dir\": \"%s\",\n    \"num_threads\": %u,\n    \"num_bootstraps\": %u,\n    \"init_uniform\": %s,\n    \"summary_stat\": %s,\n    \"dump_eq\": %s,\n    \"resolution\": \"%s\",\n    \"pug_exact_umi\": %s,\n    \"sa_model\": \"%s\",\n    \"small_thresh\": %u,\n    \"large_graph_thresh\": %u,\n    \"filter_list\": %s%s%s,\n    \"cmdline\": \"%s\"\n  }\n}\n",

@@ -165,6 +165,52 @@ def rad_prelude(ref_names, num_chunks, cblen, ulen, bc_bytes=4, umi_bytes=4, is_
     return bytes(out)
 
 
+def rad_prelude_multi_bc(ref_names, num_chunks, b0len, b1len, ulen, b_bytes=4, umi_bytes=4) -> bytes:
+    """Prelude of a two-level multi-barcode (10x Flex) RAD file as the reference's tests build it
+    (tests/multi_barcode_integration.rs:58-130): file tags num_barcodes, b0len, b1len, ulen (u16) and known_rad_type
+    (string); read tags b0, b1, u; one u32 alignment tag."""
+    out = bytearray()
+    out += bytes([0])
+    out += len(ref_names).to_bytes(8, "little")
+    for n in ref_names:
+        b = n.encode()
+        out += len(b).to_bytes(2, "little") + b
+    out += int(num_chunks).to_bytes(8, "little")
+
+    def tag(name, type_id):
+        b = name.encode()
+        return len(b).to_bytes(2, "little") + b + bytes([type_id])
+
+    out += (5).to_bytes(2, "little") + tag("num_barcodes", 2) + tag("b0len", 2) + tag("b1len", 2) + tag("ulen", 2) + tag("known_rad_type", 8)
+    out += (3).to_bytes(2, "little") + tag("b0", _INT_TYPE_ID[b_bytes]) + tag("b1", _INT_TYPE_ID[b_bytes]) + tag("u", _INT_TYPE_ID[umi_bytes])
+    out += (1).to_bytes(2, "little") + tag("compressed_ori_refid", 3)
+    kind = b"sc_rna_multi_bc"
+    out += (2).to_bytes(2, "little") + int(b0len).to_bytes(2, "little") + int(b1len).to_bytes(2, "little") + int(ulen).to_bytes(2, "little")
+    out += len(kind).to_bytes(2, "little") + kind
+    return bytes(out)
+
+
+def collation_manifest(groups, level_names=("sample", "cell")) -> bytes:
+    """collation_manifest.bin in the layout csrc/afq_host.cpp reads (bincode of libradicl's CollationManifest - a
+    restatement, libradicl's source is not in the reference tree).  groups: (key, name or None, chunk_start, num_chunks,
+    num_records)."""
+    out = bytearray()
+    out += len(level_names).to_bytes(8, "little")
+    for n in level_names:
+        b = n.encode()
+        out += len(b).to_bytes(8, "little") + b
+    out += len(groups).to_bytes(8, "little")
+    for key, name, start, nch, nrec in groups:
+        out += int(key).to_bytes(8, "little")
+        if name is None:
+            out += b"\x00"
+        else:
+            b = name.encode()
+            out += b"\x01" + len(b).to_bytes(8, "little") + b
+        out += int(start).to_bytes(8, "little") + int(nch).to_bytes(8, "little") + int(nrec).to_bytes(8, "little")
+    return bytes(out)
+
+
 def _crc32c(data: bytes) -> int:
     tbl = getattr(_crc32c, "_t", None)
     if tbl is None:
@@ -231,24 +277,26 @@ def snappy_frame_encode(data: bytes, chunk: int = 60000, compress_literal: bool 
 
 
 def write_quant_input_dir(path, chunk_bytes, n_chunks, ref_names, t2g_rows, cblen=16, ulen=12, bc_bytes=4, umi_bytes=4,
-                          compressed=False):
+                          compressed=False, prelude=None):
     """Lay out what `alevin-fry quant -i` expects: generate_permit_list.json, collate.json,
     map.collated.rad[.sz], plus the tg-map next to it.  t2g_rows: list of tab-separated row tuples."""
     import json
     import os
 
     os.makedirs(path, exist_ok=True)
-    data = rad_prelude(ref_names, n_chunks, cblen, ulen, bc_bytes, umi_bytes) + bytes(chunk_bytes)
+    if prelude is None:
+        prelude = rad_prelude(ref_names, n_chunks, cblen, ulen, bc_bytes, umi_bytes)
     with open(os.path.join(path, "generate_permit_list.json"), "w") as f:
         json.dump({"velo_mode": False, "expected_ori": "fw"}, f)
     with open(os.path.join(path, "collate.json"), "w") as f:
         json.dump({"cmd": "synthetic", "version_str": "0.18.0", "compressed_output": bool(compressed)}, f)
     if compressed:
         with open(os.path.join(path, "map.collated.rad.sz"), "wb") as f:
-            f.write(snappy_frame_encode(data))
+            f.write(snappy_frame_encode(prelude + bytes(chunk_bytes)))
     else:
-        with open(os.path.join(path, "map.collated.rad"), "wb") as f:
-            f.write(data)
+        with open(os.path.join(path, "map.collated.rad"), "wb") as f:   # (no concatenated copy: inputs run to gigabytes)
+            f.write(prelude)
+            f.write(memoryview(chunk_bytes))
     tg = os.path.join(path, "t2g.tsv")
     with open(tg, "w") as f:
         for row in t2g_rows:

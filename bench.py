@@ -1,247 +1,569 @@
 #!/usr/bin/env python
-"""bench.py — M reads/s through the `quant` hot path (cr-like) on N MI355X GPUs.
+"""bench.py — M reads/s through the `quant` hot path on N MI355X GPUs (one process per GPU).
 
-A "step" is one pass of the whole hot path (afq_submit_device + afq_collect: decode ->
-bucket -> resolve -> extract -> CSR on the host) over one batch of synthetic collated RAD
-that is already resident in HBM.  Workload at every N: BASELINE.json configs[1] — a
-PBMC-10k-like 10x-v3 collated RAD (11 000 cells, log-normal reads/cell with median 3e4,
-36 601 genes, cr-like), one such shard PER RANK (weak scaling: cells are independent, so
-ranks share nothing on the data path; the only collectives are the timing barrier and a
-max/sum of scalars).
+A "step" is one pass of the whole hot path (afq_submit_device + afq_collect: decode -> bucket ->
+resolve -> extract -> CSR on the host) over one batch of synthetic collated RAD that is already
+resident in HBM.  The input is produced on the device itself by the Philox generator of
+csrc/afq_synth.hip (same bytes as its host twin, include/afquant_synth.h).
 
-One JSON line on rank 0; see DESIGN.md §Measurement for how roofline/cpu_baseline are built.
+  python bench.py --gpus N [--steps K --warmup W]
+
+With N > 1 and no torchrun environment the script spawns its own N ranks (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_*), one per GPU, RCCL for the timing barrier and the scalar reductions;
+launched under torchrun it just joins as a rank.  Headline line = BASELINE.json configs[1]
+(PBMC-10k-like, cr-like), one such sample PER RANK (weak scaling: cells are independent, ranks share
+nothing on the data path).  The same JSON line carries further legs under "also":
+  configs2  configs[2]: USA, parsimony-em on the same cells (N = 1)
+  configs3  configs[3]: the ~10^6-cell x 2*10^4-read data set, cells range-sharded over the ranks
+            (each rank generates and quantifies ITS byte-balanced range: 125 000 cells per GPU)
+  e2e       the crossing included: input starts in pinned host memory (N = 1)
+  cli       `afquant quant` wall on the same input written as a collated RAD directory (N = 1)
+  reference the real `alevin-fry quant`, only if a binary is on the box ($ALEVIN_FRY_BIN / PATH)
+See DESIGN.md §6 for how roofline / cpu_baseline are built.
 """
 import argparse
 import importlib
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402  (imported before libafquant.so: one HIP runtime per process)
-import torch.distributed as dist  # noqa: E402
+METRIC = "M reads/s through quant (PUG dedup+eq-class) at 1/2/4/8 GPUs; cells/s"
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--cells", type=int, default=11000)
+    ap.add_argument("--workload", default="configs1", choices=["configs1", "configs2", "configs3", "atac"],
+                    help="what the headline line measures (default configs1 = the configuration the metric is quoted on)")
+    ap.add_argument("--cells", type=int, default=11000, help="cells per GPU of the PBMC-10k-like sample (configs1/2)")
     ap.add_argument("--median-reads", type=float, default=30000.0)
     ap.add_argument("--sigma", type=float, default=0.6)
     ap.add_argument("--genes", type=int, default=36601)
+    ap.add_argument("--ref-count", type=int, default=199138, help="spliced transcripts (SURVEY §8d config 2)")
+    ap.add_argument("--popularity", default="zipf1.1", choices=["zipf1.1", "pow16"],
+                    help="gene popularity: Zipf(1.1) as SURVEY §8d specifies, or the round-1 stress variant floor(G*x^16)")
     ap.add_argument("--usa", action="store_true")
-    ap.add_argument("--resolution", default="cr-like",
-                    help="default cr-like = configs[1] (the headline line); parsimony-em with --usa = configs[2]")
+    ap.add_argument("--resolution", default=None, help="override the workload's resolution")
     ap.add_argument("--umi-err", type=float, default=0.01)
-    ap.add_argument("--bootstraps", type=int, default=0, help="-b: bootstrap replicates per cell (-em resolutions; extra measurement, not the default)")
-    ap.add_argument("--atac", action="store_true", help="configs[4]: scATAC fragment dedup (extra line, not the default)")
-    ap.add_argument("--frags-per-cell", type=int, default=20000)
+    ap.add_argument("--bootstraps", type=int, default=0)
+    ap.add_argument("--c3-cells", type=int, default=125000, help="configs3: cells per GPU (x8 = the 10^6-cell data set)")
+    ap.add_argument("--c3-mean-reads", type=float, default=20000.0)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="configs3: weak = c3-cells per GPU, strong = c3-cells in total, sharded over the ranks")
+    ap.add_argument("--frags-per-cell", type=int, default=20000, help="atac")
+    ap.add_argument("--also", default="auto", help="comma list of extra legs (configs2,configs3,e2e,cli,reference), 'auto' or 'none'")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) by default; gloo + --share-gpu exercises the N>1 logic on a 1-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0")
-    args = ap.parse_args()
+    return ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.share_gpu:
-        local_rank = 0
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=args.dist_backend, rank=rank, world_size=world)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    rdev = dev if args.dist_backend == "nccl" else torch.device("cpu")  # where the scalar reductions live
 
-    pkg = importlib.import_module("alevin-fry_amd")
-    sn = importlib.import_module("alevin-fry_amd.synth_native")
-    if args.atac:
-        return bench_atac(args, pkg, rank, world, local_rank, dev)
+# ---------------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    """--gpus N without a launcher: start the N ranks ourselves (what `torch.distributed.run` would do)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    sys.exit(rc)
 
-    # ---- synthetic input (config 2), one shard per rank, then resident in HBM -------------
-    t0 = time.time()
-    rad = sn.generate(seed=2 + rank, n_cells=args.cells, median_reads=args.median_reads, sigma=args.sigma,
-                      num_genes=args.genes, txp_per_gene=5, usa=args.usa, umi_err=args.umi_err)
-    t_gen = time.time() - t0
-    d_bytes = torch.from_numpy(rad.data).to(dev)
-    cfg = pkg.WorkerConfig.for_resolution(args.resolution, usa_mode=rad.usa, num_genes=rad.num_genes,
-                                          num_rows=rad.num_rows, profile=True, umi_len=12, num_bootstraps=args.bootstraps, summary_stat=True)  # umi_len: what the RAD header's `ulen` tag says
-    q = pkg.Quantifier(cfg, rad.tid_to_gid, device=local_rank)
 
+class Dist:
+    """Rank bookkeeping + the only collectives the path uses: a barrier and MAX/SUM of a few scalars."""
+
+    def __init__(self, args, torch):
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+        self.backend = args.dist_backend
+        ndev = torch.cuda.device_count()
+        if self.local_rank >= ndev:
+            raise SystemExit(f"rank {self.rank}: no GPU {self.local_rank} on this box ({ndev} visible); --share-gpu shares cuda:0 for testing")
+        self.dev = torch.device("cuda", self.local_rank)
+        torch.cuda.set_device(self.local_rank)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group(backend="nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            else:
+                dist.init_process_group(backend=self.backend, rank=self.rank, world_size=self.world)
+            self.dist = dist
+        self.rdev = self.dev if self.backend == "nccl" else torch.device("cpu")
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.dev)
+        if self.dist:
+            self.dist.barrier()
+
+    def reduce(self, vals, op):
+        if not self.dist:
+            return [float(v) for v in vals]
+        t = self.torch.tensor([float(v) for v in vals], dtype=self.torch.float64, device=self.rdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM)
+        return [float(x) for x in t.cpu()]
+
+    def close(self):
+        if self.dist:
+            self.dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------
+def synth_kw(args, usa):
+    kw = dict(median_reads=args.median_reads, sigma=args.sigma, num_genes=args.genes, usa=usa, umi_err=args.umi_err,
+              ref_count=args.ref_count if args.ref_count >= args.genes else 0)
+    if args.popularity == "pow16":
+        kw.update(zipf=0.0, pow_skew=16.0)
+    return kw
+
+
+def timed_steps(D, q, rad, steps, warmup, first_cell=0):
+    """W untimed + exactly K timed steps, barrier + device sync on both sides; returns (elapsed max over ranks, kernel times, last rows)."""
     res = None
 
     def step():
-        # the host has consumed the previous batch's rows: hand its pinned buffers back to the library's
-        # pool before the next batch needs them (otherwise the pool pins a second 0.3 GB set, ~25 ms once)
         nonlocal res
-        res = None
-        q.submit_device(d_bytes.data_ptr(), d_bytes.numel(), rad.chunk_off)
+        res = None   # the host has consumed the previous rows: their pinned buffers go back to the library's pool
+        q.submit_device(rad.d_ptr, rad.n_bytes, rad.chunk_off, first_cell)
         res = q.collect()
-        return res
 
-    def sync_all():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
-    sync_all()
+    D.sync()
     t0 = time.perf_counter()
     ktimes = {}
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
-        for k, (ms, n) in q.kernel_times().items():  # HIP events on the library's own stream
+        for k, (ms, n) in q.kernel_times().items():   # HIP events on the library's own streams
             a = ktimes.setdefault(k, [0.0, 0])
             a[0] += ms
             a[1] += n
-    torch.cuda.synchronize(dev)
+    D.torch.cuda.synchronize(D.dev)
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        r = torch.tensor([float(rad.n_reads), float(args.cells)], dtype=torch.float64, device=rdev)
-        dist.all_reduce(r, op=dist.ReduceOp.SUM)
-        total_reads, total_cells = float(r[0].item()), float(r[1].item())
-    else:
-        total_reads, total_cells = float(rad.n_reads), float(args.cells)
+    if D.dist:
+        D.dist.barrier()
+    elapsed = D.reduce([elapsed], "max")[0]
+    return elapsed, ktimes, res
 
-    if rank != 0:
-        q.close()
-        if world > 1:
-            dist.destroy_process_group()
-        return
 
-    st = q.batch_stats()
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = total_reads * args.steps / elapsed / 1e6
+def sanity(res, rad):
+    import numpy as np
 
-    # ---- size-independent sanity on the full-size result --------------------------------
-    nnz = int(res.cell_ptr[-1])
-    assert res.n_cells == args.cells and (np.diff(res.cell_ptr.astype(np.int64)) >= 0).all()
-    assert (res.val > 0).all() and float(res.val.sum()) <= rad.n_reads * (1 + 1e-6)
+    assert res.n_cells == len(rad.cell_nrec) and (np.diff(res.cell_ptr.astype(np.int64)) >= 0).all()
+    assert (res.val > 0).all() and float(res.val.sum(dtype=np.float64)) <= rad.n_reads * (1 + 1e-6)
     assert np.array_equal(res.nrec, rad.cell_nrec)
 
-    # ---- roofline of the dominant kernel -------------------------------------------------
-    # algorithmic bytes of one pass: every record read once (12+4*na), the chunk
-    # headers, and 8 B per emitted non-zero.  The dominant kernel is charged with all of them:
-    # it is the share of the path's wall time that decides the path's achieved bandwidth.
-    alg_bytes = float(st["input_bytes"]) + 8.0 * nnz
-    dom = max(ktimes.items(), key=lambda kv: kv[1][0]) if ktimes else None
-    roofline = None
-    if dom:
-        name, (ms_tot, launches) = dom
-        avg_ms = ms_tot / max(1, launches)
-        launches_per_step = launches / args.steps
-        achieved = alg_bytes / launches_per_step / (avg_ms * 1e-3) / 1e9
-        # HBM bytes per launch of that kernel from the committed PMC passes (profiles/*_traffic.json: FETCH_SIZE doubled
-        # per the gfx950 note + WRITE_SIZE); only meaningful for the default workload the profile was taken on
-        traffic = None
-        default_wl = (args.cells, args.median_reads, args.sigma, args.genes, args.usa, args.resolution) == \
-            (11000, 30000.0, 0.6, 36601, False, "cr-like")
-        tfiles = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")) \
-            if os.path.isdir(os.path.join(ROOT, "profiles")) else []
-        if default_wl and tfiles:
-            kern = json.load(open(os.path.join(ROOT, "profiles", tfiles[-1])))["kernels"]
-            alias = {"k_decode_par": ("k_decode_recs", "k_decode_keys", "k_decode_par")}
-            for cand in alias.get(name, (name,)):
-                if cand in kern:
-                    traffic = kern[cand]["bytes_per_launch_fetch_doubled"]
-                    break
-        roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(achieved / 8000.0, 5), "traffic": traffic,
-                    "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
-                    "alg_bytes_per_step": alg_bytes,
-                    "all_kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in ktimes.items()}}
 
-    # ---- CPU baseline: the oracle (a port, not the Rust binary) on a bounded sample ---------
-    cpu = None
-    if world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import oracle as ora
+def roofline_of(ktimes, alg_bytes, steps, traffic_ok):
+    """Dominant kernel = largest summed HIP-event time; it is charged with the path's algorithmic bytes of one launch
+    (every record once, the chunk headers, 8 B per emitted non-zero)."""
+    if not ktimes:
+        return None
+    name, (ms_tot, launches) = max(ktimes.items(), key=lambda kv: kv[1][0])
+    avg_ms = ms_tot / max(1, launches)
+    lps = launches / steps
+    achieved = alg_bytes / lps / (avg_ms * 1e-3) / 1e9
+    traffic = None
+    pdir = os.path.join(ROOT, "profiles")
+    tfiles = sorted(f for f in os.listdir(pdir) if f.endswith("_traffic.json")) if os.path.isdir(pdir) else []
+    if traffic_ok and tfiles:   # HBM bytes per launch from the committed PMC passes; only meaningful for the workload they were taken on
+        kern = json.load(open(os.path.join(pdir, tfiles[-1])))["kernels"]
+        for cand in {"k_decode_par": ("k_decode_recs", "k_decode_keys", "k_decode_par")}.get(name, (name,)):
+            if cand in kern:
+                traffic = kern[cand]["bytes_per_launch_fetch_doubled"]
+                break
+    kernels_ms = sum(v[0] for v in ktimes.values()) / steps
+    return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(achieved / 8000.0, 5), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": lps,
+            "alg_bytes_per_step": alg_bytes,
+            "path_achieved_GBps": round(alg_bytes / (kernels_ms * 1e-3) / 1e9, 2) if kernels_ms else None,   # all kernels together
+            "all_kernels_ms_per_step": {k: round(v[0] / steps, 4) for k, v in ktimes.items()}}
 
-        ora.lib()
-        # sample = every k-th cell so the size mix matches the workload; grow until the budget is used
-        order = np.arange(args.cells)
-        ncores = os.cpu_count() or 1
-        k = max(1, args.cells // max(64, 4 * ncores))
-        done_reads, t_cpu, ncell = 0, 0.0, 0
-        start = 0
-        while t_cpu < args.cpu_seconds and start < k:
-            idx = order[start::k]
-            start += 1
-            offs = rad.chunk_off[idx]
-            tb = time.perf_counter()
-            want = ora.quant(cfg, rad.tid_to_gid, rad.data, offs, n_threads=ncores)
-            t_cpu += time.perf_counter() - tb
-            done_reads += int(rad.cell_nrec[idx].sum())
-            ncell += len(idx)
-            # the sample doubles as a full-size parity check: GPU rows == oracle rows, bit for bit
-            for j, ci in enumerate(idx):
-                g0, v0 = res.row(int(ci))
+
+def cpu_leg(cfg, rad, res, budget_s, min_cells=0, tie_stats=False, tol=None):
+    """The oracle (a C++ port, NOT the Rust binary) on a bounded sample of the same cells, one worker thread per host core;
+    the sample doubles as a full-size parity check: GPU rows == oracle rows (bit for bit unless tol is given)."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as ora
+
+    ora.lib()
+    n = len(rad.cell_nrec)
+    ncores = os.cpu_count() or 1
+    k = max(1, n // max(64, 4 * ncores, min_cells))   # every k-th cell, so the size mix matches the workload
+    done_reads, t_cpu, ncell, start = 0, 0.0, 0, 0
+    ties = np.zeros(4, np.int64)
+    tie_cells = diff_cells = diff_entries = diff_entries_tol = tot_entries = 0
+    while start < k and (t_cpu < budget_s or ncell < min_cells):
+        idx = np.arange(start, n, k)
+        start += 1
+        data, offs = rad.read_cells(idx)
+        tb = time.perf_counter()
+        out = ora.quant(cfg, rad.tid_to_gid, data, offs, n_threads=ncores, want_pug_stats=tie_stats)
+        t_cpu += time.perf_counter() - tb
+        want, ps = out if tie_stats else (out, None)
+        done_reads += int(rad.cell_nrec[idx].sum())
+        ncell += len(idx)
+        for j, ci in enumerate(idx):
+            g0, v0 = res.row(int(ci))
+            g1, v1 = want.row(j)
+            ok = np.array_equal(g0, g1) and (np.array_equal(v0.view(np.uint32), v1.view(np.uint32)) if tol is None
+                                             else np.allclose(v0, v1, rtol=tol, atol=0))
+            assert ok, f"GPU/oracle mismatch on cell {ci}"
+        if tie_stats:
+            ties += ps.sum(0)
+            tie_cells += int((ps[:, 1] > 0).sum())
+            other = ora.quant(cfg, rad.tid_to_gid, data, offs, n_threads=ncores, tie_break_descending=True)
+            for j in range(len(idx)):
                 g1, v1 = want.row(j)
-                assert np.array_equal(g0, g1) and np.array_equal(v0.view(np.uint32), v1.view(np.uint32)), \
-                    f"GPU/oracle mismatch on cell {ci}"
-        cpu = {"value": round(done_reads / t_cpu / 1e6, 4), "unit": "M reads/s", "cores": ncores, "kind": "port",
-               "sample": f"{ncell} of {args.cells} cells (every {k}-th, in rounds), {done_reads} reads, {t_cpu:.1f} s, "
-                         f"C++ restatement (oracle/) with one worker thread per host core over whole cells, input "
-                         f"already parsed from RAM; rows compared bit-exact with the GPU's"}
-
-    out = {
-        "metric": "M reads/s through quant (PUG dedup+eq-class) at 1/2/4/8 GPUs; cells/s",
-        "value": round(value, 3),
-        "unit": "M reads/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "u64",
-        "data": "synthetic",
-        "config": {"workload": ("configs[2]" if (args.usa and args.resolution == "parsimony-em") else "configs[1]") +
-                               f": PBMC-10k-like 10x-v3 collated RAD, {args.resolution}, per GPU: "
-                               f"{args.cells} cells, log-normal reads/cell median {args.median_reads:g} sigma {args.sigma:g}, "
-                               f"{args.genes} genes" + (", USA" if args.usa else ""),
-                   "reads_per_gpu": rad.n_reads, "input_bytes_per_gpu": st["input_bytes"], "resolution": args.resolution, **({"bootstraps": args.bootstraps} if args.bootstraps else {}),
-                   "sharding": f"{world} x independent cell shards, no data-path collective"},
-        "cells_per_s": round(total_cells * args.steps / elapsed, 1),
-        "nnz": nnz,
-        "keys": st["n_keys"],
-        "overflow_buckets": st["n_overflow_buckets"],
-        "gen_seconds": round(t_gen, 1),
-        "roofline": roofline,
-        "cpu_baseline": cpu,
-    }
-    print(json.dumps(out))
-    q.close()
-    if world > 1:
-        dist.destroy_process_group()
+                g2, v2 = other.row(j)
+                cols = np.union1d(g1, g2)
+                a = np.zeros(len(cols), np.float64)
+                b = np.zeros(len(cols), np.float64)
+                a[np.searchsorted(cols, g1)] = v1
+                b[np.searchsorted(cols, g2)] = v2
+                d = a != b
+                tot_entries += len(cols)
+                diff_cells += bool(d.any())
+                diff_entries += int(d.sum())
+                diff_entries_tol += int((np.abs(a - b) > 1e-4 * np.maximum(a, b)).sum())
+    out = {"value": round(done_reads / t_cpu / 1e6, 4), "unit": "M reads/s", "cores": ncores, "kind": "port",
+           "sample": f"{ncell} of {n} cells (every {k}-th, in rounds), {done_reads} reads, {t_cpu:.1f} s, C++ restatement (oracle/) with one "
+                     f"worker thread per host core popping whole cells off a shared queue, input already in RAM; rows compared "
+                     f"{'bit-exact' if tol is None else f'within {tol:g} rel'} with the GPU's"}
+    if tie_stats:   # SURVEY §7 hard part 1: how much of the result hangs on the cover's (unpinned) tie-break
+        out["parsimony_ties"] = {
+            "cells": ncell, "molecules": int(ties[0]), "cells_with_a_tie": tie_cells, "tie_events": int(ties[1]),
+            "molecules_in_tied_components": int(ties[3]),
+            "vs_descending_tie_break": {"cells_differing": diff_cells, "entries_differing": diff_entries,
+                                        "entries_differing_beyond_1e-4_rel": diff_entries_tol, "entries": tot_entries}}
+    return out
 
 
-def bench_atac(args, pkg, rank, world, local_rank, dev):
+def line(D, args, workload, value, elapsed, steps, warmup, cfgd, extra):
+    return {"metric": METRIC, "value": round(value, 3), "unit": "M reads/s", "n_gpus": D.world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(1e3 * elapsed / steps, 3), "higher_is_better": True,
+            "scaling": "strong" if (workload == "configs3" and args.scaling == "strong") else "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic", "config": cfgd, **extra}
+
+
+# ---------------------------------------------------------------------------------------------------------
+def run_pbmc(D, args, pkg, sn, usa, resolution, steps, warmup, cpu_seconds, name, min_cells=0, tie_stats=False):
+    """configs[1] / configs[2]: one PBMC-10k-like sample per rank, generated in HBM."""
+    import numpy as np
+
+    t0 = time.time()
+    rad = sn.generate_device(device=D.local_rank, seed=2 + D.rank, n_cells=args.cells, **synth_kw(args, usa))
+    t_gen = time.time() - t0
+    cfg = pkg.WorkerConfig.for_resolution(resolution, usa_mode=rad.usa, num_genes=rad.num_genes, num_rows=rad.num_rows, profile=True,
+                                          umi_len=12, num_bootstraps=args.bootstraps, summary_stat=True)   # umi_len: the RAD header's `ulen`
+    q = pkg.Quantifier(cfg, rad.tid_to_gid, device=D.local_rank)
+    try:
+        elapsed, ktimes, res = timed_steps(D, q, rad, steps, warmup)
+        total_reads, total_cells = D.reduce([rad.n_reads, args.cells], "sum")
+        if D.rank != 0:
+            return None, rad, q
+        st = q.batch_stats()
+        sanity(res, rad)
+        nnz = int(res.cell_ptr[-1])
+        alg = float(st["input_bytes"]) + 8.0 * nnz
+        default_wl = (args.cells, args.median_reads, args.sigma, args.genes, args.ref_count, args.popularity, args.umi_err) == \
+            (11000, 30000.0, 0.6, 36601, 199138, "zipf1.1", 0.01) and not usa and resolution == "cr-like"
+        roof = roofline_of(ktimes, alg, steps, default_wl)
+        cpu = None
+        if D.world == 1 and not args.no_cpu_baseline and cpu_seconds > 0:
+            cpu = cpu_leg(cfg, rad, res, cpu_seconds, min_cells=min_cells, tie_stats=tie_stats)
+        cfgd = {"workload": f"{name}: PBMC-10k-like 10x-v3 collated RAD, {resolution}, per GPU: {args.cells} cells, log-normal reads/cell "
+                            f"median {args.median_reads:g} sigma {args.sigma:g}, {args.genes} genes / {len(rad.tid_to_gid)} transcripts, "
+                            f"gene popularity {args.popularity}" + (", USA" if usa else "") + "; generated in HBM (Philox)",
+                "reads_per_gpu": rad.n_reads, "input_bytes_per_gpu": st["input_bytes"], "resolution": resolution,
+                **({"bootstraps": args.bootstraps} if args.bootstraps else {}),
+                "sharding": f"{D.world} x independent cell shards, no data-path collective"}
+        out = line(D, args, name, total_reads * steps / elapsed / 1e6, elapsed, steps, warmup, cfgd,
+                   {"cells_per_s": round(total_cells * steps / elapsed, 1), "nnz": nnz, "keys": st["n_keys"],
+                    "overflow_buckets": st["n_overflow_buckets"], "gen_seconds": round(t_gen, 2), "roofline": roof, "cpu_baseline": cpu})
+        return out, rad, q
+    except BaseException:
+        q.close()
+        rad.free()
+        raise
+
+
+def run_configs3(D, args, pkg, sn, steps, warmup):
+    """configs[3]: ~10^6 cells x 2*10^4 reads, cr-like, cells range-sharded over the ranks.  The data set is one Philox
+    stream over GLOBAL cell indices; every rank makes its own byte-balanced range of it directly in HBM."""
+    import numpy as np
+
+    shard = importlib.import_module("alevin-fry_amd.shard")
+    n_total = args.c3_cells * (D.world if args.scaling == "weak" else 1)
+    sigma = 0.6
+    median = args.c3_mean_reads / float(np.exp(sigma * sigma / 2))   # log-normal with the asked-for MEAN
+    kw = synth_kw(args, False)
+    kw.update(median_reads=median, sigma=sigma)
+    p = sn.params(seed=4, n_cells=n_total, **kw)
+    sizes = sn.cell_sizes(p)
+    # records are 12 + 4*na bytes with the same na mix in every cell: balancing reads balances bytes (the ranges a host
+    # would cut from the chunk table of a file, shard.shard_ranges on chunk bytes)
+    c0, c1 = shard.shard_ranges(sizes.astype(np.float64) * 17.5 + 8, D.world)[D.rank]
+    t0 = time.time()
+    rad = sn.generate_device(device=D.local_rank, p=p, sizes=sizes, cell_range=(c0, c1))
+    D.torch.cuda.synchronize(D.dev)
+    t_gen = time.time() - t0
+    cfg = pkg.WorkerConfig.for_resolution("cr-like", num_genes=rad.num_genes, num_rows=rad.num_rows, profile=True, umi_len=12)
+    q = pkg.Quantifier(cfg, rad.tid_to_gid, device=D.local_rank)
+    try:
+        elapsed, ktimes, res = timed_steps(D, q, rad, steps, warmup, first_cell=c0)
+        sanity(res, rad)
+        assert res.first_cell_index == c0
+        st = q.batch_stats()
+        nnz = int(res.cell_ptr[-1])
+        tot_reads, tot_cells, tot_bytes, tot_nnz = D.reduce([rad.n_reads, c1 - c0, st["input_bytes"], nnz], "sum")
+        max_bytes = D.reduce([st["input_bytes"]], "max")[0]
+        if D.rank != 0:
+            return None
+        alg = float(st["input_bytes"]) + 8.0 * nnz
+        cfgd = {"workload": f"configs[3]: synthetic 10x-v3 collated RAD, {int(tot_cells)} cells x ~{args.c3_mean_reads:g} reads/cell (log-normal, "
+                            f"sigma {sigma:g}, largest first), cr-like, cells range-sharded by bytes over {D.world} GPU(s) "
+                            f"({'the full 10^6-cell set is 8 such shards' if args.scaling == 'weak' else 'fixed total'}); generated in HBM shard by shard (Philox, global cell index)",
+                "cells": int(tot_cells), "reads": int(tot_reads), "input_bytes": int(tot_bytes), "rank0_cells": [int(c0), int(c1)],
+                "imbalance_max_over_mean_bytes": round(max_bytes / (tot_bytes / D.world), 4), "resolution": "cr-like",
+                "sharding": f"{D.world} contiguous cell ranges, no data-path collective"}
+        return line(D, args, "configs3", tot_reads * steps / elapsed / 1e6, elapsed, steps, warmup, cfgd,
+                    {"cells_per_s": round(tot_cells * steps / elapsed, 1), "nnz": int(tot_nnz), "gen_seconds": round(t_gen, 2),
+                     "roofline": roofline_of(ktimes, alg, steps, False), "cpu_baseline": None})
+    finally:
+        q.close()
+        rad.free()
+
+
+def run_e2e(D, args, pkg, sn, rad, q, steps):
+    """The crossing included: the input starts in pinned host memory, afq_submit brings it over range by range while the
+    earlier ranges already run (csrc/afq_api.cpp)."""
+    torch = D.torch
+    host = torch.empty(rad.n_bytes, dtype=torch.uint8, pin_memory=True)
+    rc = sn._lib().afq_synth_device_read(D.local_rank, rad.d_ptr, rad.n_bytes, host.data_ptr())
+    assert rc == 0
+    res = None
+    for _ in range(1):
+        q.submit_ptr(host.data_ptr(), rad.n_bytes, rad.chunk_off)
+        res = q.collect()
+    torch.cuda.synchronize(D.dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = None
+        q.submit_ptr(host.data_ptr(), rad.n_bytes, rad.chunk_off)
+        res = q.collect()
+    torch.cuda.synchronize(D.dev)
+    dt = (time.perf_counter() - t0) / steps
+    sanity(res, rad)
+    return {"what": "afq_submit from pinned host memory + afq_collect: H2D of the RAD bytes inside the step, overlapped with the kernels",
+            "value": round(rad.n_reads / dt / 1e6, 3), "unit": "M reads/s", "ms_per_step": round(dt * 1e3, 3),
+            "h2d_GBps_effective": round(rad.n_bytes / dt / 1e9, 2), "steps": steps}, host
+
+
+def write_rad_dir(pkg, rad, host_bytes, path):
+    names = [f"t{i}" for i in range(len(rad.tid_to_gid))]
+    if rad.usa:
+        rows = [(names[i], f"g{int(g) >> 1}", "U" if int(g) & 1 else "S") for i, g in enumerate(rad.tid_to_gid)]
+    else:
+        rows = [(names[i], f"g{int(g)}") for i, g in enumerate(rad.tid_to_gid)]
+    return pkg.rad.write_quant_input_dir(path, host_bytes, len(rad.cell_nrec), names, rows, cblen=16, ulen=12)
+
+
+def run_cli(pkg, rad, host_np, workdir, resolution="cr-like"):
+    """`afquant quant` on the same cells written as a collated-RAD directory: process start to the last output file."""
+    d = os.path.join(workdir, "in")
+    o = os.path.join(workdir, "out")
+    t0 = time.time()
+    tg = write_rad_dir(pkg, rad, host_np, d)
+    t_write = time.time() - t0
+    exe = os.path.join(ROOT, "alevin-fry_amd", "csrc", "afquant")
+    nt = str(os.cpu_count() or 1)
+    best = None
+    for _ in range(2):   # second run: page cache warm, as a pipeline that has just written the file would find it
+        shutil.rmtree(o, ignore_errors=True)
+        t0 = time.perf_counter()
+        p = subprocess.run([exe, "quant", "-i", d, "-m", tg, "-o", o, "-r", resolution, "-t", nt], capture_output=True, text=True)
+        dt = time.perf_counter() - t0
+        if p.returncode != 0:
+            return {"error": p.stderr[-400:]}, d, tg
+        best = dt if best is None else min(best, dt)
+    return {"what": f"afquant quant -r {resolution} -t {nt}: wall from process start to the last output file, map.collated.rad in the page cache",
+            "wall_s": round(best, 3), "value": round(rad.n_reads / best / 1e6, 3), "unit": "M reads/s",
+            "rad_bytes": rad.n_bytes, "write_input_s": round(t_write, 1)}, d, tg
+
+
+def run_reference_binary(rad_dir, tg, rad, workdir, res_rows=None):
+    """If the real alevin-fry is on this box: time its quant on the same directory and diff the counts keyed by
+    (barcode, gene) (scripts/testing/compare_counts.py of the reference does the same through pyroe)."""
+    exe = os.environ.get("ALEVIN_FRY_BIN") or shutil.which("alevin-fry")
+    if not exe:
+        return None
+    import numpy as np
+
+    o = os.path.join(workdir, "ref_out")
+    nt = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    p = subprocess.run([exe, "quant", "-i", rad_dir, "-m", tg, "-o", o, "-r", "cr-like", "-t", str(nt), "--use-mtx"], capture_output=True, text=True)
+    dt = time.perf_counter() - t0
+    if p.returncode != 0:
+        return {"error": (p.stderr or p.stdout)[-400:]}
+    out = {"value": round(rad.n_reads / dt / 1e6, 3), "unit": "M reads/s", "cores": nt, "kind": "reference",
+           "sample": f"`{exe} quant -r cr-like -t {nt}` on the whole input, wall {dt:.1f} s (reads the RAD from the page cache, writes MTX)"}
+    try:
+        ours = os.path.join(workdir, "out", "alevin")
+        theirs = os.path.join(o, "alevin")
+
+        def load(dirp):
+            rows = [l.strip() for l in open(os.path.join(dirp, "quants_mat_rows.txt"))]
+            cols = [l.strip() for l in open(os.path.join(dirp, "quants_mat_cols.txt"))]
+            m = np.loadtxt(os.path.join(dirp, "quants_mat.mtx"), comments="%", skiprows=0)
+            m = m[1:]   # size line
+            return {(rows[int(r) - 1], cols[int(c) - 1]): float(v) for r, c, v in m}
+        a, b = load(ours), load(theirs)
+        keys = set(a) | set(b)
+        nd = sum(1 for k in keys if a.get(k, 0.0) != b.get(k, 0.0))
+        out["count_diff"] = {"entries": len(keys), "differing": nd}
+    except Exception as e:   # the diff is a bonus; the timing stands
+        out["count_diff"] = {"error": repr(e)[:200]}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)
+    import numpy as np  # noqa: F401
+    import torch  # (imported before libafquant.so: one HIP runtime per process)
+
+    D = Dist(args, torch)
+    pkg = importlib.import_module("alevin-fry_amd")
+    sn = importlib.import_module("alevin-fry_amd.synth_native")
+    if args.workload == "atac":
+        return bench_atac(args, pkg, D)
+    also = args.also.split(",") if args.also not in ("auto", "none") else \
+        ([] if args.also == "none" else (["configs2", "configs3", "e2e", "cli", "reference"] if D.world == 1 else ["configs3"]))
+    also = [a for a in also if a and a != args.workload]
+    legs = {}
+    out = None
+    rad = q = None
+    try:
+        if args.workload == "configs3":
+            out = run_configs3(D, args, pkg, sn, args.steps, args.warmup)
+        else:
+            usa = args.usa or args.workload == "configs2"
+            resolution = args.resolution or ("parsimony-em" if args.workload == "configs2" else "cr-like")
+            name = "configs[2]" if (usa and resolution == "parsimony-em") else "configs[1]"
+            out, rad, q = run_pbmc(D, args, pkg, sn, usa, resolution, args.steps, args.warmup, args.cpu_seconds, name,
+                                   min_cells=200 if name == "configs[2]" else 0, tie_stats=name == "configs[2]")
+
+        def leg(name, fn):
+            try:
+                legs[name] = fn()
+            except Exception as e:   # an extra leg must never take the headline line down with it
+                legs[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
+        host = None
+        workdir = None
+        if rad is not None and D.world == 1 and args.workload == "configs1" and not args.usa and (args.resolution in (None, "cr-like")):
+            if "e2e" in also:
+                def f():
+                    nonlocal host
+                    r, host = run_e2e(D, args, pkg, sn, rad, q, max(2, args.steps))
+                    return r
+                leg("e2e", f)
+            if "cli" in also or "reference" in also:
+                workdir = tempfile.mkdtemp(prefix="afq_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+                host_np = host.numpy() if host is not None else rad.to_host()
+                cli_state = {}
+
+                def f():
+                    r, d, tg = run_cli(pkg, rad, host_np, workdir)
+                    cli_state.update(d=d, tg=tg)
+                    return r
+                leg("cli", f)
+                if "reference" in also and cli_state:
+                    leg("reference", lambda: run_reference_binary(cli_state["d"], cli_state["tg"], rad, workdir))
+                    if legs.get("reference") is None:
+                        legs["reference"] = {"skipped": "no alevin-fry binary on this box ($ALEVIN_FRY_BIN / PATH); cpu_baseline is the C++ port"}
+                    elif "value" in legs["reference"] and out is not None:
+                        out["cpu_baseline_reference"] = legs["reference"]
+        if q is not None:
+            q.close()
+            q = None
+        if rad is not None:
+            rad.free()
+            rad = None
+        host = None
+        if workdir:
+            shutil.rmtree(workdir, ignore_errors=True)
+        if "configs2" in also and D.world == 1:
+            def f():
+                o2, r2, q2 = run_pbmc(D, args, pkg, sn, True, "parsimony-em", max(1, min(2, args.steps)), 1,
+                                      min(args.cpu_seconds, 10.0), "configs[2]", min_cells=200, tie_stats=True)
+                q2.close()
+                r2.free()
+                return o2
+            leg("configs2", f)
+        if "configs3" in also:
+            r3 = None
+            try:
+                r3 = run_configs3(D, args, pkg, sn, max(1, min(2, args.steps)), 1)
+            except Exception as e:
+                if D.world > 1:
+                    raise   # all ranks take part in its collectives: no way to carry on half-way
+                r3 = {"error": f"{type(e).__name__}: {e}"[:300]}
+            if D.rank == 0:
+                legs["configs3"] = r3
+        if D.rank == 0 and out is not None:
+            if legs:
+                out["also"] = legs
+            print(json.dumps(out), flush=True)
+    finally:
+        if q is not None:
+            q.close()
+        if rad is not None:
+            rad.free()
+        D.close()
+
+
+def bench_atac(args, pkg, D):
     """BASELINE configs[4]: per-cell ATAC fragment de-duplication (afq_atac_dedup).  The boundary takes and returns host
     arrays (the reference's deduplicate reads them from the sorted RAD), so a step includes both PCIe crossings; the kernel's
     own time comes from the library's HIP-event timers."""
     import ctypes as C
 
+    import numpy as np
+
+    torch = D.torch
     n_cells = args.cells if args.cells != 11000 else 10000
     per = args.frags_per_cell
-    rng = np.random.default_rng(5 + rank)
+    rng = np.random.default_rng(5 + D.rank)
     n = n_cells * per
     ref = rng.integers(0, 25, n, dtype=np.uint32)
     start = rng.integers(0, 150_000_000, n, dtype=np.uint32)
@@ -251,7 +573,7 @@ def bench_atac(args, pkg, rank, world, local_rank, dev):
     ref, start, flen = ref[src], start[src], flen[src]
     cell_ptr = np.arange(n_cells + 1, dtype=np.uint64) * per
     cfg = pkg.WorkerConfig.for_resolution("cr-like", num_genes=1, num_rows=1, profile=True)
-    q = pkg.Quantifier(cfg, np.zeros(1, np.uint32), device=local_rank)
+    q = pkg.Quantifier(cfg, np.zeros(1, np.uint32), device=D.local_rank)
     outs = [C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint16)(), C.POINTER(C.c_uint16)()]
 
     def step():
@@ -266,9 +588,7 @@ def bench_atac(args, pkg, rank, world, local_rank, dev):
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
+    D.sync()
     t0 = time.perf_counter()
     kms, kl, distinct = 0.0, 0, 0
     for _ in range(args.steps):
@@ -276,23 +596,17 @@ def bench_atac(args, pkg, rank, world, local_rank, dev):
         ms, nl = q.kernel_times().get("k_atac_dedup", (0.0, 0))
         kms += ms
         kl += nl
-    torch.cuda.synchronize(dev)
+    torch.cuda.synchronize(D.dev)
     elapsed = time.perf_counter() - t0
-    total = float(n)
-    if world > 1:
-        dist.barrier()
-        rdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
-        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        r = torch.tensor([total], dtype=torch.float64, device=rdev)
-        dist.all_reduce(r, op=dist.ReduceOp.SUM)
-        total = float(r.item())
-    if rank == 0:
+    if D.dist:
+        D.dist.barrier()
+    elapsed = D.reduce([elapsed], "max")[0]
+    total = D.reduce([float(n)], "sum")[0]
+    if D.rank == 0:
         alg = 10.0 * n + 12.0 * distinct   # ref u32 + start u32 + len u16 in; (ref, start, len, count) per distinct fragment out
         avg_ms = kms / max(1, kl)
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if D.world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle as ora
 
@@ -304,7 +618,7 @@ def bench_atac(args, pkg, rank, world, local_rank, dev):
                    "sample": f"first {k} cells ({k * per} fragments), {tc:.1f} s, single-thread C++ restatement (oracle/)"}
         print(json.dumps({
             "metric": "M fragments/s through atac dedup (fragment/barcode dedup path)", "value": round(total * args.steps / elapsed / 1e6, 3),
-            "unit": "M fragments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "M fragments/s", "n_gpus": D.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"configs[4]: scATAC dedup, per GPU: {n_cells} cells x {per} fragments, 25 chromosomes, 20 % exact duplicates; host arrays in, host arrays out (both PCIe crossings inside the step)",
@@ -312,10 +626,9 @@ def bench_atac(args, pkg, rank, world, local_rank, dev):
             "roofline": {"bound": "hbm", "kernel": "k_atac_dedup64", "achieved": round(alg / (avg_ms * 1e-3) / 1e9, 2) if avg_ms else None,
                          "peak": 8000.0, "unit": "GB/s", "frac": round(alg / (avg_ms * 1e-3) / 1e9 / 8000.0, 5) if avg_ms else None,
                          "traffic": None, "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_step": alg},
-            "cpu_baseline": cpu}))
+            "cpu_baseline": cpu}), flush=True)
     q.close()
-    if world > 1:
-        dist.destroy_process_group()
+    D.close()
 
 
 if __name__ == "__main__":

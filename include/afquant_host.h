@@ -30,10 +30,16 @@ typedef struct afq_quant_opts {
     uint32_t dump_eq;           /* -d : also write geqc_counts.mtx + gene_eqclass.txt.gz (quant.rs:229-355)                */
     uint32_t num_bootstraps;    /* -b : bootstrap replicates; writes bootstraps_mean.mtx + bootstraps_var.mtx (quant.rs:1850-1877) */
     uint32_t device;            /* HIP device ordinal                                                                      */
-    uint64_t batch_bytes;       /* chunk bytes handed to the device per afq_submit (0 = 1 GiB)                             */
+    uint64_t batch_bytes;       /* chunk bytes handed to a device per afq_submit (0 = 16 GiB; a batch is pipelined internally) */
     uint32_t sa_model;          /* --sa-model (hidden): afq_sa_model; ignored with a log line outside USA mode (quant.rs:1456) */
     uint32_t summary_stat;      /* --summary-stat (requires -b)                                                            */
     uint64_t boot_seed;         /* seed of the bootstrap draws (the reference's are unseeded); --boot-seed, default 0     */
+    const int32_t* devices;     /* --devices 0,1,... : HIP device ordinals to spread the cells over (NULL / 0 = just `device`).  The
+                                   worker fan-out of do_quantify (quant.rs:1553-1575, 1678-1765): one context and one host thread
+                                   per device over a contiguous, byte-balanced range of cells; rows are gathered in cell order, so
+                                   the output does not depend on the device count                                          */
+    uint32_t n_devices;
+    uint32_t reserved;
 } afq_quant_opts;
 
 /* The CLI-visible options of `alevin-fry infer` (src/main.rs:350-365). */

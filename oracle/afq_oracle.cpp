@@ -40,6 +40,7 @@
 // cr-like (both --sa-model's) / trivial / USA extraction are integer-exact and order-independent.
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -361,7 +362,17 @@ static void collapse_vertices(u32 v, const std::vector<u8>& uncovered, const Pug
     }
 }
 
-struct PugStats { bool alt = false; u64 total = 0, ambiguous = 0, trivial = 0; };
+struct PugStats {
+    bool alt = false; u64 total = 0, ambiguous = 0, trivial = 0;
+    // How much of the cell hangs on the cover's tie-break (the reference scans a HashSet, pugutils.rs:1090-1110, so WHICH of
+    // several equally large monochromatic arborescences is taken first is hash order there and ascending vertex id here):
+    // tie_events = cover rounds that met two maximal candidates with different vertex sets; tie_molecules = molecules
+    // of the components in which that happened (everything resolved after a tie may depend on it).
+    u64 tie_events = 0, tie_components = 0, tie_molecules = 0;
+};
+// 0: ascending vertex id (the canonical order the device reproduces); 1: descending - the other extreme, used only to
+// measure how many counts depend on the choice (ora_set_tie_break)
+static int g_tie_desc = 0;
 
 // get_num_molecules, src/pugutils.rs:989-1331 (HAS_PROBS == false)
 static int parsimony(const Pug& g, const EqMap& m, const u32* t2g, bool gene_level, u32 large_thresh,
@@ -404,17 +415,27 @@ static int parsimony(const Pug& g, const EqMap& m, const u32* t2g, bool gene_lev
         }
         for (u32 v : cv) uncovered[v] = 1;
         size_t remaining = cv.size();
+        bool comp_tie = false; u64 comp_mols = 0;
+        std::vector<u32> best_sorted, cand_sorted;
         while (remaining > 0) {
             best.clear();
             u32 best_txp = UINT32_MAX;
-            for (u32 v : cv) {  // canonical scan order: ascending vertex id (reference: hash order)
+            bool tie_here = false;
+            for (size_t vi = 0; vi < cv.size(); ++vi) {  // canonical scan order: ascending vertex id (reference: hash order)
+                const u32 v = g_tie_desc ? cv[cv.size() - 1 - vi] : cv[vi];
                 if (!uncovered[v]) continue;
                 u32 txp;
                 collapse_vertices(v, uncovered, g, m, cand, txp, visit_stamp, stamp);
                 size_t len = cand.size();
-                if (best.size() < len) { best = cand; best_txp = txp; }
+                if (best.size() < len) { best = cand; best_txp = txp; tie_here = false; best_sorted = cand; std::sort(best_sorted.begin(), best_sorted.end()); }
+                else if (best.size() == len && !tie_here) {
+                    cand_sorted = cand; std::sort(cand_sorted.begin(), cand_sorted.end());
+                    if (cand_sorted != best_sorted) tie_here = true;   // same vertex set = same molecule whatever the start / transcript
+                }
                 if (len == remaining) break;
             }
+            if (tie_here) { st.tie_events++; comp_tie = true; }
+            comp_mols++;
             if (best_txp == UINT32_MAX) { err = "could not find a covering transcript"; return AFQ_ERR_BAD_INPUT; }
             // intersection of labels over the mcc, pugutils.rs:1161-1188
             gtx.clear();
@@ -437,6 +458,7 @@ static int parsimony(const Pug& g, const EqMap& m, const u32* t2g, bool gene_lev
             for (u32 v : best) { uncovered[v] = 0; }
             remaining -= best.size();
         }
+        if (comp_tie) { st.tie_components++; st.tie_molecules += comp_mols; }
     }
     return 0;
 }
@@ -834,6 +856,7 @@ static void tiny_cell(const Cell& c, const u32* t2g, bool usa, u32 num_rows,
 
 struct CellOut {
     std::vector<u32> ind; std::vector<float> val; u8 flags = 0; double mmrate = 0.0; u32 em_iters = 0;
+    u32 pug[4] = {0, 0, 0, 0};   // parsimony: molecules, tie events, components with a tie, molecules of those components
     // cfg.dump_eq: gene_eqc as the -d block sees it (quant.rs:1282-1307), in lexicographic label order
     std::vector<u32> eq_labels, eq_len, eq_count;
     BootOut boot;
@@ -895,6 +918,7 @@ static int quant_cell(const afq_config& cfg, const u32* t2g, u32 ref_count, cons
         int rc = parsimony(g, m, t2g, gl, cfg.large_graph_thresh, eqc, st, err);
         if (rc) return rc;
         if (st.alt) o.flags |= AFQ_CELL_ALT_RES;
+        o.pug[0] = (u32)st.total; o.pug[1] = (u32)st.tie_events; o.pug[2] = (u32)st.tie_components; o.pug[3] = (u32)st.tie_molecules;
         finish(res == AFQ_RES_PARSIMONY || res == AFQ_RES_PARSIMONY_GENE);
     } else { err = "bad resolution"; return AFQ_ERR_INVALID_ARG; }
     for (u32 gidx = 0; gidx < counts.size(); ++gidx)  // quant.rs:1156-1168
@@ -913,7 +937,7 @@ static int quant_cell(const afq_config& cfg, const u32* t2g, u32 ref_count, cons
 
 struct Result {
     std::vector<u64> cell_ptr, bc; std::vector<u32> gene, nrec; std::vector<float> val;
-    std::vector<u8> flags; std::vector<double> mmrate; std::vector<u32> em_iters;
+    std::vector<u8> flags; std::vector<double> mmrate; std::vector<u32> em_iters, pug;
     std::vector<u64> eq_cell_ptr{0}, eq_label_ptr{0}; std::vector<u32> eq_labels, eq_count;
     std::vector<u64> bm_ptr{0}, bv_ptr{0}; std::vector<u32> bm_col, bv_col; std::vector<float> bm_val, bv_val;
     void add_eq(const CellOut& o) {
@@ -956,7 +980,7 @@ int ora_quant(const afq_config* cfg, const uint32_t* t2g, uint32_t ref_count, co
         R->val.insert(R->val.end(), o.val.begin(), o.val.end());
         R->cell_ptr.push_back(R->gene.size());
         R->bc.push_back(c.bc); R->nrec.push_back(c.nrec); R->flags.push_back(o.flags);
-        R->mmrate.push_back(o.mmrate); R->em_iters.push_back(o.em_iters); R->add_eq(o);
+        R->mmrate.push_back(o.mmrate); R->em_iters.push_back(o.em_iters); R->pug.insert(R->pug.end(), o.pug, o.pug + 4); R->add_eq(o);
     }
     out->n_cells = n_cells; out->first_cell_index = first_cell_index; out->nnz = R->gene.size();
     out->cell_ptr = R->cell_ptr.data(); out->gene = R->gene.data(); out->val = R->val.data();
@@ -978,10 +1002,11 @@ int ora_quant_mt(const afq_config* cfg, const uint32_t* t2g, uint32_t ref_count,
     std::vector<int> rcs(n_threads, 0);
     std::vector<std::string> errs(n_threads);
     std::vector<std::thread> th;
+    std::atomic<uint32_t> next{0};   // a shared queue of cells, as the reference's workers pop chunks (quant.rs:733-757)
     for (uint32_t t = 0; t < n_threads; ++t)
         th.emplace_back([&, t]() {
             Cell c; std::string err;
-            for (uint32_t i = t; i < n_cells && rcs[t] == 0; i += n_threads) {
+            for (uint32_t i; (i = next.fetch_add(1)) < n_cells && rcs[t] == 0;) {
                 int rc = chunk_off[i] > n_bytes ? AFQ_ERR_BAD_INPUT
                                                 : parse_chunk(bytes + chunk_off[i], n_bytes - chunk_off[i], cfg->bc_bytes, cfg->umi_bytes, c, err);
                 if (!rc) rc = quant_cell(*cfg, t2g, ref_count, c, 0, outs[i], err, first_cell_index + i);
@@ -998,7 +1023,7 @@ int ora_quant_mt(const afq_config* cfg, const uint32_t* t2g, uint32_t ref_count,
         R->val.insert(R->val.end(), outs[i].val.begin(), outs[i].val.end());
         R->cell_ptr.push_back(R->gene.size());
         R->bc.push_back(bcs[i]); R->nrec.push_back(nrecs[i]); R->flags.push_back(outs[i].flags);
-        R->mmrate.push_back(outs[i].mmrate); R->em_iters.push_back(outs[i].em_iters); R->add_eq(outs[i]);
+        R->mmrate.push_back(outs[i].mmrate); R->em_iters.push_back(outs[i].em_iters); R->pug.insert(R->pug.end(), outs[i].pug, outs[i].pug + 4); R->add_eq(outs[i]);
     }
     out->n_cells = n_cells; out->first_cell_index = first_cell_index; out->nnz = R->gene.size();
     out->cell_ptr = R->cell_ptr.data(); out->gene = R->gene.data(); out->val = R->val.data();
@@ -1007,6 +1032,10 @@ int ora_quant_mt(const afq_config* cfg, const uint32_t* t2g, uint32_t ref_count,
     return 0;
 }
 
+// parsimony resolutions: per cell {molecules, tie events, components with a tie, molecules of those components} (PugStats)
+const uint32_t* ora_result_pug_stats(const afq_result* r) { return r && r->opaque ? ((Result*)r->opaque)->pug.data() : nullptr; }
+// 0 = ascending vertex id (canonical), 1 = descending: the cover's scan order when several maximal arborescences tie
+void ora_set_tie_break(int descending) { g_tie_desc = descending ? 1 : 0; }
 const uint32_t* ora_result_em_iters(const afq_result* r) { return r && r->opaque ? ((Result*)r->opaque)->em_iters.data() : nullptr; }
 
 // cfg.dump_eq: per-cell gene-level classes (same container as afq_result_eqclasses of include/afquant.h)

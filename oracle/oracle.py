@@ -41,6 +41,10 @@ def lib():
         L.ora_result_release.argtypes = [p(_abi.AfqResult)]
         L.ora_result_em_iters.argtypes = [p(_abi.AfqResult)]
         L.ora_result_em_iters.restype = p(C.c_uint32)
+        L.ora_result_pug_stats.argtypes = [p(_abi.AfqResult)]
+        L.ora_result_pug_stats.restype = p(C.c_uint32)
+        L.ora_set_tie_break.argtypes = [C.c_int]
+        L.ora_set_tie_break.restype = None
         L.ora_result_eqclasses.argtypes = [p(_abi.AfqResult), p(_abi.AfqEqclasses)]
         L.ora_result_eqclasses.restype = C.c_int
         L.ora_result_bootstraps.argtypes = [p(_abi.AfqResult), p(_abi.AfqBootstraps)]
@@ -66,10 +70,14 @@ class OracleError(RuntimeError):
         self.code = code
 
 
-def quant(cfg, tid_to_gid, chunk_bytes, chunk_off, first_cell_index=0, force_route=0, want_iters=False, n_threads=1):
+def quant(cfg, tid_to_gid, chunk_bytes, chunk_off, first_cell_index=0, force_route=0, want_iters=False, n_threads=1, want_pug_stats=False,
+          tie_break_descending=False):
     """cfg: WorkerConfig.  Returns QuantResult (same container as the product).
-    n_threads > 1 spreads cells over worker threads (reference dispatch only)."""
+    n_threads > 1 spreads cells over worker threads (reference dispatch only).
+    want_pug_stats: also return u32[n_cells, 4] = molecules, tie events, components with a tie, molecules of those components.
+    tie_break_descending: scan the parsimony cover's candidates in descending vertex id (measures what hangs on the tie-break)."""
     L = lib()
+    L.ora_set_tie_break(1 if tie_break_descending else 0)
     ccfg = cfg.to_c()
     t2g = np.ascontiguousarray(tid_to_gid, dtype=np.uint32)
     b = np.ascontiguousarray(np.frombuffer(chunk_bytes, dtype=np.uint8) if not isinstance(chunk_bytes, np.ndarray) else chunk_bytes)
@@ -96,12 +104,17 @@ def quant(cfg, tid_to_gid, chunk_bytes, chunk_off, first_cell_index=0, force_rou
             bs = _abi.AfqBootstraps()
             L.ora_result_bootstraps(C.byref(res), C.byref(bs))
             out.bootstraps = _afq.bootstraps_from_c(bs)
+        if want_pug_stats:
+            n = out.n_cells
+            ps = np.ctypeslib.as_array(L.ora_result_pug_stats(C.byref(res)), shape=(n, 4)).copy() if n else np.zeros((0, 4), np.uint32)
+            return out, ps
         if want_iters:
             n = out.n_cells
             it = np.ctypeslib.as_array(L.ora_result_em_iters(C.byref(res)), shape=(n,)).copy() if n else np.zeros(0, np.uint32)
             return out, it
         return out
     finally:
+        L.ora_set_tie_break(0)
         L.ora_result_release(C.byref(res))
 
 

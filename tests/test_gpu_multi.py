@@ -1,0 +1,301 @@
+"""GPU tests of what round 2 added around the hot path: the device generator (== its host twin, byte for byte), the
+range-by-range input upload of afq_submit, the multi-device front-end (`afquant quant --devices`, two contexts sharing one
+device), `bench.py --gpus 2` spawning its own ranks, multi-barcode (10x Flex) input, and the reference-binary hook."""
+import importlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from util import ROOT, assert_same_result, cfg_for, pkg
+
+pytestmark = pytest.mark.gpu
+rad = pkg.rad
+synth = pkg.synth
+sn = importlib.import_module("alevin-fry_amd.synth_native")
+shard = importlib.import_module("alevin-fry_amd.shard")
+CLI = os.path.join(ROOT, "alevin-fry_amd", "csrc", "afquant")
+
+
+@pytest.mark.parametrize("kw", [dict(n_cells=300, median_reads=900.0, sigma=1.0, num_genes=500, ref_count=1733),
+                                dict(n_cells=40, median_reads=30000.0, ref_count=199138),
+                                dict(n_cells=200, median_reads=2000.0, num_genes=300, txp_per_gene=3, usa=True, umi_err=0.05),
+                                dict(n_cells=500, median_reads=40.0, sigma=0.3, num_genes=100, pow_skew=16.0, zipf=0.0, umi_len=10)])
+def test_device_generator_writes_the_host_generators_bytes(kw):
+    """csrc/afq_synth.hip: the gfx950 kernels and the host loop run the same integer record model (Philox4x32-10 words
+    against 32-bit thresholds), so the bytes must agree exactly - for the whole set and for a range of it."""
+    h = sn.generate(seed=7, **kw)
+    d = sn.generate_device(device=0, seed=7, **kw)
+    try:
+        assert d.n_bytes == h.n_bytes and np.array_equal(d.chunk_off, h.chunk_off) and np.array_equal(d.cell_nrec, h.cell_nrec)
+        assert np.array_equal(d.to_host(), h.data)
+    finally:
+        d.free()
+    n = kw["n_cells"]
+    c0, c1 = n // 3, (2 * n) // 3
+    dr = sn.generate_device(device=0, seed=7, cell_range=(c0, c1), **kw)
+    try:
+        want, _ = h.read_cells(np.arange(c0, c1))
+        assert np.array_equal(dr.to_host(), want)   # a rank's shard does not depend on what the others make
+    finally:
+        dr.free()
+    # structure: headers tile the buffer, barcodes are distinct, refs ascending and in range
+    w = h.data.view(np.uint32)
+    bcs = set()
+    for c in range(n):
+        o = int(h.chunk_off[c]) // 4
+        assert w[o + 1] == h.cell_nrec[c] and w[o] == (h.chunk_off[c + 1] - h.chunk_off[c] if c + 1 < n else h.n_bytes - h.chunk_off[c])
+        bcs.add(int(w[o + 3]))
+    assert len(bcs) == n
+    na = int(w[int(h.chunk_off[0]) // 4 + 2])
+    refs = w[int(h.chunk_off[0]) // 4 + 5: int(h.chunk_off[0]) // 4 + 5 + na] & 0x7FFFFFFF
+    assert 1 <= na <= 3 and (np.diff(refs.astype(np.int64)) > 0).all() and refs.max() < len(h.tid_to_gid)
+
+
+def test_generated_workload_quantifies_like_the_oracle(oracle):
+    """The generator's output through the device path and through the oracle (USA, parsimony-em): the bench's input is
+    an ordinary collated RAD as far as both are concerned."""
+    d = sn.generate_device(device=0, seed=3, n_cells=60, median_reads=3000.0, num_genes=400, txp_per_gene=4, usa=True, umi_err=0.03)
+    try:
+        for res in ("cr-like", "parsimony-em"):
+            cfg = pkg.WorkerConfig.for_resolution(res, usa_mode=True, num_genes=d.num_genes, num_rows=d.num_rows, umi_len=12)
+            q = pkg.Quantifier(cfg, d.tid_to_gid, device=0)
+            try:
+                q.submit_device(d.d_ptr, d.n_bytes, d.chunk_off)
+                got = q.collect()
+            finally:
+                q.close()
+            want = oracle.quant(cfg, d.tid_to_gid, d.to_host(), d.chunk_off, n_threads=4)
+            assert_same_result(got, want, what=res)
+    finally:
+        d.free()
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+@pytest.mark.parametrize("res", ["cr-like", "parsimony"])
+def test_piped_upload_matches_resident_input(monkeypatch, pinned, res):
+    """afq_submit brings the input over range by range while earlier ranges run (csrc/afq_api.cpp); forced here onto a
+    small batch by capping the per-range memory.  Pageable source = staging thread, pinned source = straight DMA.
+    Chunk offsets are deliberately not dword-aligned in the caller's buffer (a RAD prelude has any length)."""
+    import torch
+
+    s = synth.synth(77, [6000, 5000, 3000, 2500, 900, 700, 400, 300, 120, 80, 33, 5] * 3, num_genes=200, dup=0.4, umi_err=0.02)
+    b, off = s.encode()
+    b = np.concatenate((np.zeros(3, np.uint8), np.asarray(b)))   # shift: offsets become 3 mod 4
+    off = off + 3
+    cfg = cfg_for(s, res)
+    q = pkg.Quantifier(cfg, s.tid_to_gid, device=0)
+    try:
+        monkeypatch.setenv("AFQ_NO_H2D_PIPELINE", "1")
+        want = q.quant_chunks(b, off)
+        monkeypatch.delenv("AFQ_NO_H2D_PIPELINE")
+        monkeypatch.setenv("AFQ_RANGE_BYTES", str(400_000))
+        if pinned:
+            t = torch.empty(len(b), dtype=torch.uint8, pin_memory=True)
+            t.numpy()[:] = b
+            q.submit_ptr(t.data_ptr(), len(b), off)
+            got = q.collect()
+        else:
+            got = q.quant_chunks(b, off)
+        assert_same_result(got, want, what=f"piped upload, pinned={pinned}")
+        got2 = q.quant_chunks(b, off)   # and again on the same context (events / staging pieces are reused)
+        assert_same_result(got2, want)
+    finally:
+        q.close()
+
+
+def test_two_contexts_on_one_device_equal_one_context(oracle):
+    """§8e: cells are independent, so two contexts over byte-balanced contiguous ranges (here both on device 0, running
+    concurrently from two host threads) must reproduce the single-context rows bit for bit."""
+    import threading
+
+    s = synth.synth(91, [5000, 4000, 2600, 1200, 900, 700, 400, 300, 120, 80, 33, 5, 3000, 60], num_genes=250, usa=True, dup=0.5, umi_err=0.02)
+    b, off = s.encode()
+    b = np.asarray(b)
+    nbytes = np.diff(np.concatenate((off, [len(b)]))).astype(np.int64)
+    for res in ("cr-like", "parsimony-em"):
+        cfg = cfg_for(s, res)
+        q = pkg.Quantifier(cfg, s.tid_to_gid, device=0)
+        whole = q.quant_chunks(b, off)
+        q.close()
+        ranges = shard.shard_ranges(nbytes, 2)
+        parts = [None, None]
+        errs = []
+
+        def work(r):
+            try:
+                c0, c1 = ranges[r]
+                qq = pkg.Quantifier(cfg, s.tid_to_gid, device=0)
+                try:
+                    parts[r] = qq.quant_chunks(b, off[c0:c1], first_cell_index=c0)
+                finally:
+                    qq.close()
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        assert parts[1].first_cell_index == ranges[1][0]
+        assert_same_result(shard.concat_results(parts), whole, what=res)
+
+
+def _make_dir(tmp, s):
+    b, off = s.encode()
+    names = [f"T{t}" for t in range(len(s.tid_to_gid))]
+    rows = [(names[t], f"G{g >> 1}", "S" if g % 2 == 0 else "U") if s.usa else (names[t], f"G{g}") for t, g in enumerate(s.tid_to_gid.tolist())]
+    return rad.write_quant_input_dir(str(tmp), np.asarray(b).tobytes(), len(off), names, rows, cblen=16, ulen=s.umi_len), b, off
+
+
+@pytest.mark.parametrize("res,extra", [("cr-like", []), ("parsimony-em", ["-d"]), ("cr-like-em", ["-b", "4", "--summary-stat"])])
+def test_cli_devices_output_is_independent_of_the_device_count(tmp_path, res, extra):
+    """`afquant quant --devices 0,0,0` (three contexts + host threads over byte-balanced cell ranges, rows gathered in cell
+    order, the -d dictionary filled in cell order) writes the same files as `--device 0`."""
+    s = synth.synth(52, [4000, 2500, 1500, 600, 260, 120, 60, 7, 900, 30], num_genes=150, txp_per_gene=3, usa=True, dup=0.5, cross=0.3, umi_err=0.02)
+    tg, _, _ = _make_dir(tmp_path / "in", s)
+    outs = []
+    for name, dev in (("one", ["--device", "0"]), ("three", ["--devices", "0,0,0"])):
+        o = tmp_path / name
+        r = subprocess.run([CLI, "quant", "-i", str(tmp_path / "in"), "-m", tg, "-o", str(o), "-r", res, "-t", "4"] + dev + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs.append(o)
+    files = ["alevin/quants_mat.mtx", "alevin/quants_mat_rows.txt", "alevin/quants_mat_cols.txt", "featureDump.txt"]
+    if "-d" in extra:
+        files += ["alevin/geqc_counts.mtx"]
+    if "-b" in extra:
+        files += ["alevin/bootstraps_mean.mtx", "alevin/bootstraps_var.mtx"]
+    for f in files:
+        assert (outs[0] / f).read_bytes() == (outs[1] / f).read_bytes(), f
+    if "-d" in extra:
+        import gzip
+
+        assert gzip.open(outs[0] / "alevin/gene_eqclass.txt.gz").read() == gzip.open(outs[1] / "alevin/gene_eqclass.txt.gz").read()
+    a, b = (json.load(open(o / "quant.json")) for o in outs)
+    for k in ("num_quantified_cells", "total_records", "alt_resolved_cell_numbers", "empty_resolved_cell_numbers", "tiny_cell_resolved_cell_numbers"):
+        assert a[k] == b[k], k
+    r = subprocess.run([CLI, "quant", "-i", str(tmp_path / "in"), "-m", tg, "-o", str(tmp_path / "bad"), "-r", res, "--devices", "0,99"], capture_output=True, text=True)
+    assert r.returncode != 0 and "device 99" in r.stderr
+
+
+def test_quant_subset_sizes_the_matrix_by_the_subset(tmp_path):
+    """--quant-subset: rows for the cells found, but the MTX row dimension and num_quantified_cells = the subset's size
+    (quant.rs:1529, 1836, 1918), also when a listed barcode is not in the file."""
+    s = synth.synth(53, [500, 300, 120, 60], num_genes=50, dup=0.3)
+    tg, _, _ = _make_dir(tmp_path / "in", s)
+    keep = [rad.int_to_seq(int(s.cell_bc[1]), 16), rad.int_to_seq(int(s.cell_bc[3]), 16), "ACGTACGTACGTACGT"]
+    (tmp_path / "subset.txt").write_text("\n".join(keep) + "\n")
+    o = tmp_path / "out"
+    r = subprocess.run([CLI, "quant", "-i", str(tmp_path / "in"), "-m", tg, "-o", str(o), "-r", "cr-like", "--quant-subset", str(tmp_path / "subset.txt")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (o / "alevin/quants_mat_rows.txt").read_text().split() == keep[:2]
+    size = [l for l in (o / "alevin/quants_mat.mtx").read_text().splitlines() if not l.startswith("%")][0].split()
+    assert int(size[0]) == 3 and json.load(open(o / "quant.json"))["num_quantified_cells"] == 3
+
+
+def test_multi_barcode_flex_quant(tmp_path, oracle):
+    """10x Flex (KnownRecordType::RnaShortMultiBC): records carry (b0 = sample index after collation, b1 = cell barcode,
+    u); rows are labelled sample_cell and featureDump has the sample_name column (src/quant.rs:1217-1262, 1354-1373).
+    Structure as the reference's tests build it (tests/multi_barcode_integration.rs:721-1050): samples x cells x 8 reads,
+    shared cell barcodes across samples; plus the counts against the oracle reading the same bytes with an 8-byte key."""
+    n_samples, cells_per_sample, G = 3, 4, 10
+    names = [f"gene_{i}" for i in range(G)]
+    rng = np.random.default_rng(5)
+    cells = []
+    for si in range(n_samples):          # collation leaves the samples contiguous, b0 = sample ordinal
+        for ci in range(cells_per_sample):
+            cell_bc = (ci * 2654435761) & 0xFFFFFFFF   # the same cell barcodes in every sample
+            nrec = 8 if ci else 300
+            reads = []
+            for r in range(nrec):
+                umi = int(rng.integers(0, 1 << 24)) if ci == 0 else ((si * 100000 + ci * 100 + r) * 2654435761) & 0xFFFFFF
+                refs = [r % G] if ci else sorted({int(rng.integers(0, G)) for _ in range(int(rng.integers(1, 3)))})
+                reads.append((umi, refs))
+            cells.append(((cell_bc << 32) | si, reads))
+    b, off = rad.encode_cells(cells, bc_bytes=8, umi_bytes=4)
+    d = tmp_path / "in"
+    pre = rad.rad_prelude_multi_bc(names, len(cells), 8, 16, 12)
+    tg = rad.write_quant_input_dir(str(d), bytes(b), len(cells), names, [(n, n) for n in names], prelude=pre)
+    groups = [(0xAA + i, None if i == 1 else f"sample_{'abc'[i]}", i * cells_per_sample, cells_per_sample, 0) for i in range(n_samples)]
+    (d / "collation_manifest.bin").write_bytes(rad.collation_manifest(groups))
+    for res in ("trivial", "cr-like", "parsimony"):
+        o = tmp_path / f"out_{res}"
+        r = subprocess.run([CLI, "quant", "-i", str(d), "-m", tg, "-o", str(o), "-r", res, "--small-thresh", "0"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        rows = (o / "alevin/quants_mat_rows.txt").read_text().split()
+        sname = ["sample_a", f"{0xAB:x}", "sample_c"]   # an unnamed sample goes by its key in hex
+        assert rows == [f"{sname[i // cells_per_sample]}_{rad.int_to_seq(((i % cells_per_sample) * 2654435761) & 0xFFFFFFFF, 16)}" for i in range(len(cells))]
+        assert len(set(rows)) == len(rows)
+        feat = [l.split("\t") for l in (o / "featureDump.txt").read_text().splitlines()]
+        assert {len(f) for f in feat} == {10} and feat[0][1] == "sample_name" and len(feat) == len(cells) + 1
+        assert [f[1] for f in feat[1:]] == [sname[i // cells_per_sample] for i in range(len(cells))]
+        cfg = pkg.WorkerConfig.for_resolution(res, num_genes=G, num_rows=G, bc_bytes=8, umi_bytes=4, small_thresh=0)
+        want = oracle.quant(cfg, np.arange(G, dtype=np.uint32), b, off)
+        body = [l for l in (o / "alevin/quants_mat.mtx").read_text().splitlines() if not l.startswith("%")]
+        got = {(int(r) - 1, int(c) - 1): float(v) for r, c, v in (l.split() for l in body[1:])}
+        exp = {(i, int(g)): float(v) for i in range(want.n_cells) for g, v in zip(*want.row(i))}
+        assert got == exp, res
+        if res != "parsimony":   # 8 distinct UMIs on genes 0..7: one molecule each under any strategy (tests/multi_barcode_integration.rs:163-199)
+            assert all(got.get((i, g), 0.0) == 1.0 for i in range(len(cells)) if i % cells_per_sample for g in range(8))
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher environment starts two ranks itself, and the line says n_gpus 2 (here
+    both on cuda:0 over gloo, tiny workloads; the driver's run uses one GPU per rank and RCCL)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--dist-backend", "gloo", "--steps", "2", "--warmup", "1",
+           "--cells", "300", "--median-reads", "2000", "--c3-cells", "2000", "--c3-mean-reads", "300", "--also", "configs3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["workload"].startswith("configs[1]")
+    c3 = line["also"]["configs3"]
+    assert c3["n_gpus"] == 2 and c3["config"]["cells"] == 4000 and c3["value"] > 0
+    assert 0.9 < c3["config"]["imbalance_max_over_mean_bytes"] < 1.3
+
+
+def test_bench_single_gpu_legs_small():
+    """The default legs on a small workload: configs[2] with its tie report, configs[3], the PCIe-inclusive figure, the CLI wall."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cells", "400", "--median-reads", "3000",
+           "--c3-cells", "3000", "--c3-mean-reads", "400", "--cpu-seconds", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0
+    also = line["also"]
+    for k in ("configs2", "configs3", "e2e", "cli"):
+        assert k in also and "error" not in also[k], (k, also.get(k))
+    assert also["configs2"]["cpu_baseline"]["parsimony_ties"]["molecules"] > 0
+    assert also["e2e"]["value"] > 0 and also["cli"]["wall_s"] > 0
+
+
+def test_reference_binary_hook(tmp_path, oracle):
+    """If the real alevin-fry is on this box ($ALEVIN_FRY_BIN or PATH): run its quant on a directory written by our RAD
+    writer and compare counts keyed by (barcode, gene) with the device path - the only check there is against the Rust
+    binary itself (and of the RAD codec against libradicl's reader).  Skipped when there is no binary."""
+    exe = os.environ.get("ALEVIN_FRY_BIN") or shutil.which("alevin-fry")
+    if not exe:
+        pytest.skip("no alevin-fry binary on this box")
+    s = synth.synth(61, [4000, 1500, 600, 260, 120, 60, 7], num_genes=150, txp_per_gene=3, dup=0.5, cross=0.3, umi_err=0.02)
+    tg, b, off = _make_dir(tmp_path / "in", s)
+    ref_out, our_out = tmp_path / "ref", tmp_path / "ours"
+    r = subprocess.run([exe, "quant", "-i", str(tmp_path / "in"), "-m", tg, "-o", str(ref_out), "-r", "cr-like", "-t", "4", "--use-mtx"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([CLI, "quant", "-i", str(tmp_path / "in"), "-m", tg, "-o", str(our_out), "-r", "cr-like"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+    def load(o):
+        rows = (o / "alevin/quants_mat_rows.txt").read_text().split()
+        cols = (o / "alevin/quants_mat_cols.txt").read_text().split()
+        body = [l for l in (o / "alevin/quants_mat.mtx").read_text().splitlines() if not l.startswith("%")]
+        return {(rows[int(r) - 1], cols[int(c) - 1]): float(v) for r, c, v in (l.split() for l in body[1:])}
+
+    assert load(ref_out) == load(our_out)   # cr-like is integer-exact and order-independent

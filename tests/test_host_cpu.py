@@ -102,9 +102,11 @@ def _quantify(lib, in_dir, tg, out_dir, resolution="cr-like"):
                     ("filter_list", C.c_char_p), ("cmdline", C.c_char_p), ("num_threads", C.c_uint32), ("small_thresh", C.c_uint32),
                     ("umi_edit_dist", C.c_int32), ("large_graph_thresh", C.c_int32), ("init_uniform", C.c_uint32), ("dump_eq", C.c_uint32),
                     ("num_bootstraps", C.c_uint32), ("device", C.c_uint32), ("batch_bytes", C.c_uint64), ("sa_model", C.c_uint32),
-                    ("summary_stat", C.c_uint32), ("boot_seed", C.c_uint64)]
+                    ("summary_stat", C.c_uint32), ("boot_seed", C.c_uint64), ("devices", C.POINTER(C.c_int32)), ("n_devices", C.c_uint32),
+                    ("reserved", C.c_uint32)]
 
-    o = Opts(str(in_dir).encode(), str(tg).encode(), str(out_dir).encode(), resolution.encode(), None, b"test", 1, 100, -1, -1, 0, 0, 0, 0, 0, 0, 0, 0)
+    o = Opts(str(in_dir).encode(), str(tg).encode(), str(out_dir).encode(), resolution.encode(), None, b"test", 1, 100, -1, -1, 0, 0, 0, 0, 0, 0, 0, 0,
+             None, 0, 0)
     lib.afq_quantify.argtypes = [C.POINTER(Opts)]
     lib.afq_quantify.restype = C.c_int
     rc = lib.afq_quantify(C.byref(o))
@@ -147,6 +149,21 @@ def test_quantify_refuses_record_layouts_it_would_misread(lib, tmp_path):
     extra_aln = pre.replace(tag, (2).to_bytes(2, "little") + tag[2:] + b"\x01\x00p\x03")
     rc, msg = _quantify(lib, variant("extra_aln", extra_aln), tg, tmp_path / "o2")
     assert rc == pkg._abi.AFQ_ERR_UNSUPPORTED and "alignment-level tags" in msg
+    # a chunk that holds no record (the reference panics on it, quant.rs:756) / a truncated last chunk
+    empty = raw[:len(pre)] + (8).to_bytes(4, "little") + (0).to_bytes(4, "little") + raw[len(pre):]
+    d = variant("empty_chunk", pre)
+    (d / "map.collated.rad").write_bytes(empty)
+    rc, msg = _quantify(lib, d, tg, tmp_path / "o2b")
+    assert rc == pkg._abi.AFQ_ERR_BAD_INPUT and "holds no record" in msg
+    # multi-barcode (Flex) files: three barcode levels / unequal widths are refused, and so is a collation manifest
+    # that does not tile as the layout afq_host.cpp documents
+    mb = rad.rad_prelude_multi_bc(names, len(off), 8, 16, 12)
+    d = variant("mb_manifest", mb)
+    (d / "collation_manifest.bin").write_bytes(b"\x01\x02\x03")
+    rc, msg = _quantify(lib, d, tg, tmp_path / "o2c")
+    assert rc == pkg._abi.AFQ_ERR_UNSUPPORTED and "collation_manifest.bin" in msg
+    rc, msg = _quantify(lib, variant("mb_three", mb.replace(b"\x02\x00\x08\x00\x10\x00", b"\x03\x00\x08\x00\x10\x00")), tg, tmp_path / "o2d")
+    assert rc == pkg._abi.AFQ_ERR_UNSUPPORTED and "two barcode levels" in msg
     # no generate_permit_list.json (src/main.rs:733-734); unknown resolution; -b with a plain resolution (main.rs:713-728)
     os.remove(good / "generate_permit_list.json")
     rc, msg = _quantify(lib, good, tg, tmp_path / "o3")
