@@ -120,9 +120,15 @@ EXPORTS = [
     "afq_result_bootstraps",
     "afq_infer",
     "afq_atac_dedup",
+    "afq_atac_dedup_rad",
     "afq_free",
     "afq_get_kernel_times",
     "afq_get_batch_stats",
     "afq_last_error",
     "afq_abi_version",
 ]
+
+
+class AfqAtacStats(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("n_multimapped", C.c_uint64), ("n_not_mapped_pair", C.c_uint64), ("n_distinct", C.c_uint64),
+                ("n_deduplicated", C.c_uint64), ("n_long_fragments", C.c_uint64), ("n_fallback_cells", C.c_uint64)]

@@ -254,6 +254,9 @@ def load_library(path: str = LIB_PATH):
     lib.afq_atac_dedup.argtypes = [C.c_void_p, p(C.c_uint32), p(C.c_uint32), p(C.c_uint16), p(C.c_uint64), C.c_uint32,
                                    p(p(C.c_uint64)), p(p(C.c_uint32)), p(p(C.c_uint32)), p(p(C.c_uint16)), p(p(C.c_uint16))]
     lib.afq_atac_dedup.restype = C.c_int
+    lib.afq_atac_dedup_rad.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, p(C.c_uint64), C.c_uint32, C.c_uint32, C.c_int, p(p(C.c_uint64)),
+                                       p(p(C.c_uint64)), p(p(C.c_uint32)), p(p(C.c_uint32)), p(p(C.c_uint16)), p(p(C.c_uint16)), p(_abi.AfqAtacStats)]
+    lib.afq_atac_dedup_rad.restype = C.c_int
     lib.afq_free.argtypes = [C.c_void_p]
     lib.afq_free.restype = None
     lib.afq_get_kernel_times.argtypes = [C.c_void_p, p(AfqKernelTime), C.c_uint32]
@@ -386,4 +389,29 @@ class Quantifier:
             return ptr, mk(o_ref, np.uint32), mk(o_start, np.uint32), mk(o_len, np.uint16), mk(o_cnt, np.uint16)
         finally:
             for q in (o_ptr, o_ref, o_start, o_len, o_cnt):
+                self.lib.afq_free(q)
+
+    def atac_dedup_rad(self, chunk_bytes, chunk_off, bc_bytes: int = 4, d_ptr: int = 0, n_bytes: int = 0):
+        """afq_atac_dedup_rad: collated scATAC chunks in (host bytes, or d_ptr/n_bytes for bytes already on the device),
+        (cell_ptr, bc, ref, start, frag_len, count, stats dict) out."""
+        off = np.ascontiguousarray(chunk_off, dtype=np.uint64)
+        n_cells = len(off)
+        if d_ptr:
+            ptr, nb, on_dev = C.c_void_p(d_ptr), n_bytes, 1
+        else:
+            b = np.ascontiguousarray(np.frombuffer(chunk_bytes, dtype=np.uint8) if not isinstance(chunk_bytes, np.ndarray) else chunk_bytes)
+            ptr, nb, on_dev = b.ctypes.data_as(C.c_void_p), b.nbytes, 0
+        o_ptr, o_bc, o_ref, o_start = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)()
+        o_len, o_cnt = C.POINTER(C.c_uint16)(), C.POINTER(C.c_uint16)()
+        st = _abi.AfqAtacStats()
+        self._check(self.lib.afq_atac_dedup_rad(self._h, ptr, nb, off.ctypes.data_as(C.POINTER(C.c_uint64)), n_cells, bc_bytes, on_dev,
+                                                C.byref(o_ptr), C.byref(o_bc), C.byref(o_ref), C.byref(o_start), C.byref(o_len), C.byref(o_cnt), C.byref(st)))
+        try:
+            cp = np.ctypeslib.as_array(o_ptr, shape=(n_cells + 1,)).copy()
+            n = int(cp[-1])
+            mk = lambda p_, dt, k: (np.ctypeslib.as_array(p_, shape=(k,)).astype(dt, copy=True) if k else np.zeros(0, dt))
+            stats = {k: int(getattr(st, k)) for k, _ in st._fields_}
+            return cp, mk(o_bc, np.uint64, n_cells), mk(o_ref, np.uint32, n), mk(o_start, np.uint32, n), mk(o_len, np.uint16, n), mk(o_cnt, np.uint16, n), stats
+        finally:
+            for q in (o_ptr, o_bc, o_ref, o_start, o_len, o_cnt):
                 self.lib.afq_free(q)

@@ -56,9 +56,9 @@ struct DevBuf {
     template <class T> T* as() { return reinterpret_cast<T*>(p); }
 };
 
-enum KernelId { K_GATHER = 0, K_DECODE_PAR, K_DECODE, K_HIST, K_BSCAN, K_SCATTER, K_RESOLVE, K_RESOLVE_BIG, K_PUG, K_CELL_HIST, K_EM, K_BOOT, K_COMPACT, K_ATAC, K_COUNT };
+enum KernelId { K_GATHER = 0, K_DECODE_PAR, K_DECODE, K_HIST, K_BSCAN, K_SCATTER, K_RESOLVE, K_RESOLVE_BIG, K_PUG, K_CELL_HIST, K_EM, K_BOOT, K_COMPACT, K_ATAC, K_ATAC_PARSE, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"k_gather_headers", "k_decode_par", "k_decode", "k_hist", "k_bucket_scan", "k_scatter",
-                                           "k_resolve", "k_resolve_big", "k_pug_cell", "k_cell_hist", "k_em", "k_boot", "k_compact", "k_atac_dedup"};
+                                           "k_resolve", "k_resolve_big", "k_pug_cell", "k_cell_hist", "k_em", "k_boot", "k_compact", "k_atac_dedup", "k_atac_parse"};
 
 struct TimedLaunch { int id; hipEvent_t a, b; };
 
@@ -176,7 +176,7 @@ struct afq_ctx {
     const uint8_t* d_bytes = nullptr;
     size_t n_bytes = 0;
     DevBuf d_chunk_off, d_hdr;
-    DevBuf atac[16];  // afq_atac_dedup's device buffers, kept between calls
+    DevBuf atac[26];  // afq_atac_dedup[_rad]'s device buffers, kept between calls
     void* stage[3] = {nullptr, nullptr, nullptr};          // pinned staging for large host->device input copies
     hipEvent_t stage_ev[3] = {nullptr, nullptr, nullptr};
     // afq_submit: the input crosses PCIe range by range while earlier ranges already run (h2d_ev[i] = range i's bytes landed)
@@ -1175,21 +1175,10 @@ int afq_infer(afq_ctx* c, const uint32_t* eq_labels, const uint64_t* eq_label_pt
     return 0;
 }
 
-int afq_atac_dedup(afq_ctx* c, const uint32_t* ref, const uint32_t* start, const uint16_t* frag_len,
-                   const uint64_t* cell_ptr, uint32_t n_cells, uint64_t** out_cell_ptr, uint32_t** out_ref,
-                   uint32_t** out_start, uint16_t** out_frag_len, uint16_t** out_count) {
-    if (!c) return AFQ_ERR_INVALID_ARG;
-    if (!cell_ptr || !out_cell_ptr || !out_ref || !out_start || !out_frag_len || !out_count)
-        return fail(c, AFQ_ERR_INVALID_ARG, "null argument");
-    if (c->pending) return fail(c, AFQ_ERR_STATE, "a quant batch is pending on this context");
-    HIP_TRY(c, hipSetDevice(c->device));
-    const uint64_t n = cell_ptr[n_cells];
-    if (n && (!ref || !start || !frag_len)) return fail(c, AFQ_ERR_INVALID_ARG, "null argument");
-    for (uint32_t i = 0; i < n_cells; ++i)
-        if (cell_ptr[i + 1] < cell_ptr[i] || cell_ptr[i + 1] - cell_ptr[i] > 0x7FFFFFFFull)
-            return fail(c, AFQ_ERR_INVALID_ARG, "cell_ptr must be non-decreasing");
-    HostClock hc;
-    // device buffers live in the context and are reused by the next call (hipMalloc/hipFree of GBs is not free)
+// Shared back half of the two ATAC entry points: de-duplicate the fragments sitting in d_ref/d_start/d_flen (cell i at
+// d_ptr[i], cell_cnt[i] of them when d_cnt is given, else up to d_ptr[i+1]) and hand the distinct ones out as malloc'd arrays.
+static int atac_dedup_device(afq_ctx* c, uint64_t n, uint32_t n_cells, const uint32_t* d_cnt, uint64_t** out_cell_ptr, uint32_t** out_ref,
+                             uint32_t** out_start, uint16_t** out_frag_len, uint16_t** out_count, HostClock& hc) {
     DevBuf &d_ref = c->atac[0], &d_start = c->atac[1], &d_flen = c->atac[2], &d_ptr = c->atac[3], &d_scr = c->atac[4],
            &d_oref = c->atac[5], &d_ostart = c->atac[6], &d_oflen = c->atac[7], &d_ocnt = c->atac[8], &d_on = c->atac[9],
            &d_optr = c->atac[10], &d_cref = c->atac[11], &d_cstart = c->atac[12], &d_cflen = c->atac[13], &d_ccnt = c->atac[14],
@@ -1198,26 +1187,17 @@ int afq_atac_dedup(afq_ctx* c, const uint32_t* ref, const uint32_t* start, const
     const uint64_t n1 = std::max<uint64_t>(n, 1);
     hipError_t e = hipSuccess;
     auto T = [&](hipError_t x) { if (e == hipSuccess) e = x; };
-    T(d_ref.ensure(4 * n1)); T(d_start.ensure(4 * n1)); T(d_flen.ensure(2 * n1)); T(d_ptr.ensure(8ull * (n_cells + 1)));
     T(d_scr.ensure(16 * n1)); T(d_oref.ensure(4 * n1)); T(d_ostart.ensure(4 * n1)); T(d_oflen.ensure(2 * n1));
     T(d_ocnt.ensure(2 * n1)); T(d_on.ensure(4ull * std::max<uint32_t>(n_cells, 1))); T(d_optr.ensure(8ull * (n_cells + 1)));
     T(d_flag.ensure(4));
-    std::vector<uint32_t> on(n_cells);
-    if (e == hipSuccess && n) {   // (the pinned staging path of afq_submit was measured here too: no faster for these arrays)
-        T(hipMemcpyAsync(d_ref.p, ref, 4 * n, hipMemcpyHostToDevice, s));
-        T(hipMemcpyAsync(d_start.p, start, 4 * n, hipMemcpyHostToDevice, s));
-        T(hipMemcpyAsync(d_flen.p, frag_len, 2 * n, hipMemcpyHostToDevice, s));
-    }
-    if (e == hipSuccess) T(hipMemcpyAsync(d_ptr.p, cell_ptr, 8ull * (n_cells + 1), hipMemcpyHostToDevice, s));
     if (e == hipSuccess) T(hipMemsetAsync(d_flag.p, 0, 4, s));
-    if (hc.on) { T(hipStreamSynchronize(s)); hc.lap("atac: alloc + H2D"); }
+    std::vector<uint32_t> on(n_cells);
     uint32_t wide = 0;
-    for (int i = 0; i < K_COUNT; ++i) { c->k_ms[i] = 0; c->k_launches[i] = 0; }
     if (e == hipSuccess) {
         ScopedTimer t(c, K_ATAC, s);
         launch_atac_dedup64(s, n_cells, d_ref.as<uint32_t>(), d_start.as<uint32_t>(), d_flen.as<uint16_t>(), d_ptr.as<uint64_t>(),
                             d_scr.p, d_oref.as<uint32_t>(), d_ostart.as<uint32_t>(), d_oflen.as<uint16_t>(),
-                            d_ocnt.as<uint16_t>(), d_on.as<uint32_t>(), d_flag.as<uint32_t>());
+                            d_ocnt.as<uint16_t>(), d_on.as<uint32_t>(), d_flag.as<uint32_t>(), d_cnt);
         T(hipGetLastError());
     }
     if (e == hipSuccess) {
@@ -1228,7 +1208,7 @@ int afq_atac_dedup(afq_ctx* c, const uint32_t* ref, const uint32_t* start, const
         ScopedTimer t(c, K_ATAC, s);
         launch_atac_dedup(s, n_cells, d_ref.as<uint32_t>(), d_start.as<uint32_t>(), d_flen.as<uint16_t>(), d_ptr.as<uint64_t>(),
                           d_scr.p, d_oref.as<uint32_t>(), d_ostart.as<uint32_t>(), d_oflen.as<uint16_t>(),
-                          d_ocnt.as<uint16_t>(), d_on.as<uint32_t>());
+                          d_ocnt.as<uint16_t>(), d_on.as<uint32_t>(), d_cnt);
         T(hipGetLastError());
     }
     if (e == hipSuccess && n_cells) T(hipMemcpyAsync(on.data(), d_on.p, 4ull * n_cells, hipMemcpyDeviceToHost, s));
@@ -1269,6 +1249,131 @@ int afq_atac_dedup(afq_ctx* c, const uint32_t* ref, const uint32_t* start, const
         return fail(c, e == hipErrorOutOfMemory ? AFQ_ERR_OOM : AFQ_ERR_HIP, std::string("afq_atac_dedup: ") + hipGetErrorString(e));
     }
     *out_cell_ptr = optr; *out_ref = oref; *out_start = ostart; *out_frag_len = oflen; *out_count = ocnt;
+    return 0;
+}
+
+int afq_atac_dedup(afq_ctx* c, const uint32_t* ref, const uint32_t* start, const uint16_t* frag_len,
+                   const uint64_t* cell_ptr, uint32_t n_cells, uint64_t** out_cell_ptr, uint32_t** out_ref,
+                   uint32_t** out_start, uint16_t** out_frag_len, uint16_t** out_count) {
+    if (!c) return AFQ_ERR_INVALID_ARG;
+    if (!cell_ptr || !out_cell_ptr || !out_ref || !out_start || !out_frag_len || !out_count)
+        return fail(c, AFQ_ERR_INVALID_ARG, "null argument");
+    if (c->pending) return fail(c, AFQ_ERR_STATE, "a quant batch is pending on this context");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint64_t n = cell_ptr[n_cells];
+    if (n && (!ref || !start || !frag_len)) return fail(c, AFQ_ERR_INVALID_ARG, "null argument");
+    for (uint32_t i = 0; i < n_cells; ++i)
+        if (cell_ptr[i + 1] < cell_ptr[i] || cell_ptr[i + 1] - cell_ptr[i] > 0x7FFFFFFFull)
+            return fail(c, AFQ_ERR_INVALID_ARG, "cell_ptr must be non-decreasing");
+    HostClock hc;
+    // device buffers live in the context and are reused by the next call (hipMalloc/hipFree of GBs is not free)
+    DevBuf &d_ref = c->atac[0], &d_start = c->atac[1], &d_flen = c->atac[2], &d_ptr = c->atac[3];
+    hipStream_t s = c->stream;
+    const uint64_t n1 = std::max<uint64_t>(n, 1);
+    hipError_t e = hipSuccess;
+    auto T = [&](hipError_t x) { if (e == hipSuccess) e = x; };
+    T(d_ref.ensure(4 * n1)); T(d_start.ensure(4 * n1)); T(d_flen.ensure(2 * n1)); T(d_ptr.ensure(8ull * (n_cells + 1)));
+    if (e == hipSuccess && n) {   // (the pinned staging path of afq_submit was measured here too: no faster for these arrays)
+        T(hipMemcpyAsync(d_ref.p, ref, 4 * n, hipMemcpyHostToDevice, s));
+        T(hipMemcpyAsync(d_start.p, start, 4 * n, hipMemcpyHostToDevice, s));
+        T(hipMemcpyAsync(d_flen.p, frag_len, 2 * n, hipMemcpyHostToDevice, s));
+    }
+    if (e == hipSuccess) T(hipMemcpyAsync(d_ptr.p, cell_ptr, 8ull * (n_cells + 1), hipMemcpyHostToDevice, s));
+    if (hc.on) { T(hipStreamSynchronize(s)); hc.lap("atac: alloc + H2D"); }
+    if (e != hipSuccess) return fail(c, e == hipErrorOutOfMemory ? AFQ_ERR_OOM : AFQ_ERR_HIP, std::string("afq_atac_dedup: ") + hipGetErrorString(e));
+    for (int i = 0; i < K_COUNT; ++i) { c->k_ms[i] = 0; c->k_launches[i] = 0; }
+    return atac_dedup_device(c, n, n_cells, nullptr, out_cell_ptr, out_ref, out_start, out_frag_len, out_count, hc);
+}
+
+int afq_atac_dedup_rad(afq_ctx* c, const uint8_t* bytes, size_t n_bytes, const uint64_t* chunk_off, uint32_t n_cells, uint32_t bc_bytes,
+                       int bytes_on_device, uint64_t** out_cell_ptr, uint64_t** out_bc, uint32_t** out_ref, uint32_t** out_start,
+                       uint16_t** out_frag_len, uint16_t** out_count, afq_atac_stats* stats) {
+    if (!c) return AFQ_ERR_INVALID_ARG;
+    if ((!bytes && n_bytes) || (!chunk_off && n_cells) || !out_cell_ptr || !out_bc || !out_ref || !out_start || !out_frag_len || !out_count)
+        return fail(c, AFQ_ERR_INVALID_ARG, "null argument");
+    if (!valid_width(bc_bytes)) return fail(c, AFQ_ERR_INVALID_ARG, "bc_bytes must be 1, 2, 4 or 8");
+    if (c->pending) return fail(c, AFQ_ERR_STATE, "a quant batch is pending on this context");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HostClock hc;
+    hipStream_t s = c->stream;
+    // chunk headers (from the host copy, or gathered off the device), capacity offsets = prefix of nrec
+    std::vector<uint32_t> hdr(2ull * n_cells);
+    if (!bytes_on_device) {
+        for (uint32_t i = 0; i < n_cells; ++i) {
+            if (chunk_off[i] + 8 > n_bytes) return fail(c, AFQ_ERR_BAD_INPUT, "cell " + std::to_string(i) + ": chunk offset out of range");
+            std::memcpy(&hdr[2 * i], bytes + chunk_off[i], 8);
+        }
+    } else if (n_cells) {
+        HIP_TRY(c, c->d_chunk_off.ensure(8ull * n_cells));
+        HIP_TRY(c, c->d_hdr.ensure(8ull * n_cells));
+        HIP_TRY(c, hipMemcpyAsync(c->d_chunk_off.p, chunk_off, 8ull * n_cells, hipMemcpyHostToDevice, s));
+        launch_gather_headers(s, bytes, n_bytes, c->d_chunk_off.as<uint64_t>(), n_cells, c->d_hdr.as<uint32_t>());
+        HIP_TRY(c, hipMemcpyAsync(hdr.data(), c->d_hdr.p, 8ull * n_cells, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+    }
+    std::vector<AtacCell> cells(n_cells);
+    std::vector<uint64_t> cap_ptr(n_cells + 1, 0);
+    uint64_t bm_words = 0, n_rec = 0;
+    for (uint32_t i = 0; i < n_cells; ++i) {
+        const uint32_t nb = hdr[2 * i], nr = hdr[2 * i + 1];
+        if (chunk_off[i] + 8 > n_bytes || nb < 8 || chunk_off[i] + nb > n_bytes) return fail(c, AFQ_ERR_BAD_INPUT, "cell " + std::to_string(i) + ": chunk header/size out of range");
+        if ((uint64_t)nr * (4 + bc_bytes) + 8 > nb) return fail(c, AFQ_ERR_BAD_INPUT, "cell " + std::to_string(i) + ": chunk nbytes does not match its records");
+        cells[i] = AtacCell{chunk_off[i], n_rec, bm_words, nb, nr};
+        cap_ptr[i] = n_rec;
+        n_rec += nr;
+        bm_words += 4ull * ((nb + 255) / 256);
+    }
+    cap_ptr[n_cells] = n_rec;
+    DevBuf &d_ref = c->atac[0], &d_start = c->atac[1], &d_flen = c->atac[2], &d_ptr = c->atac[3];
+    DevBuf &d_cells = c->atac[16], &d_bm = c->atac[17], &d_cnt = c->atac[18], &d_bc = c->atac[19], &d_stat = c->atac[20], &d_walk = c->atac[21],
+           &d_nwalk = c->atac[22], &d_status = c->atac[23];
+    const uint64_t n1 = std::max<uint64_t>(n_rec, 1), nc1 = std::max<uint32_t>(n_cells, 1);
+    HIP_TRY(c, d_ref.ensure(4 * n1)); HIP_TRY(c, d_start.ensure(4 * n1)); HIP_TRY(c, d_flen.ensure(2 * n1)); HIP_TRY(c, d_ptr.ensure(8ull * (n_cells + 1)));
+    HIP_TRY(c, d_cells.ensure(sizeof(AtacCell) * nc1)); HIP_TRY(c, d_bm.ensure(8 * std::max<uint64_t>(bm_words, 1))); HIP_TRY(c, d_cnt.ensure(4ull * nc1));
+    HIP_TRY(c, d_bc.ensure(8ull * nc1)); HIP_TRY(c, d_stat.ensure(8ull * nc1)); HIP_TRY(c, d_walk.ensure(4ull * nc1)); HIP_TRY(c, d_nwalk.ensure(4));
+    HIP_TRY(c, d_status.ensure(sizeof(DevStatus)));
+    const uint8_t* d_bytes = bytes;
+    if (!bytes_on_device) {
+        HIP_TRY(c, c->d_bytes_own.ensure(n_bytes + 16));
+        if (n_bytes) { int rc2 = staged_h2d(c, (uint8_t*)c->d_bytes_own.p, bytes, n_bytes, s, host_ptr_is_pinned(bytes) && host_ptr_is_pinned(bytes + n_bytes - 1)); if (rc2) return rc2; }
+        d_bytes = c->d_bytes_own.as<uint8_t>();
+    }
+    if (n_cells) HIP_TRY(c, hipMemcpyAsync(d_cells.p, cells.data(), sizeof(AtacCell) * n_cells, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d_ptr.p, cap_ptr.data(), 8ull * (n_cells + 1), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemsetAsync(d_nwalk.p, 0, 4, s));
+    HIP_TRY(c, hipMemsetAsync(d_status.p, 0, sizeof(DevStatus), s));
+    if (hc.on) { HIP_TRY(c, hipStreamSynchronize(s)); hc.lap("atac: alloc + H2D"); }
+    for (int i = 0; i < K_COUNT; ++i) { c->k_ms[i] = 0; c->k_launches[i] = 0; }
+    {
+        ScopedTimer t(c, K_ATAC_PARSE, s);
+        AtacParseArgs pa{d_bytes, d_cells.as<AtacCell>(), n_cells, bc_bytes, d_bm.as<uint64_t>(), d_ref.as<uint32_t>(), d_start.as<uint32_t>(),
+                         d_flen.as<uint16_t>(), d_cnt.as<uint32_t>(), d_bc.as<uint64_t>(), d_stat.as<uint32_t>(), d_walk.as<uint32_t>(),
+                         d_nwalk.as<uint32_t>(), d_status.as<DevStatus>()};
+        launch_atac_parse(s, pa);
+        HIP_TRY(c, hipGetLastError());
+    }
+    DevStatus st{};
+    std::vector<uint32_t> stat(2ull * n_cells);
+    uint64_t* obc = (uint64_t*)std::malloc(8ull * nc1);
+    if (!obc) return fail(c, AFQ_ERR_OOM, "afq_atac_dedup_rad: host allocation failed");
+    hipError_t e = hipMemcpyAsync(&st, d_status.p, sizeof(st), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && n_cells) e = hipMemcpyAsync(stat.data(), d_stat.p, 8ull * n_cells, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && n_cells) e = hipMemcpyAsync(obc, d_bc.p, 8ull * n_cells, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);   // the caller keeps ownership of `bytes`: the copy out of them is done by now, too
+    if (e != hipSuccess) { std::free(obc); return fail(c, AFQ_ERR_HIP, std::string("afq_atac_dedup_rad: ") + hipGetErrorString(e)); }
+    if (st.err_code) { std::free(obc); return fail(c, AFQ_ERR_BAD_INPUT, "cell " + std::to_string(st.err_cell) + ": chunk nbytes does not match its records"); }
+    int rc = atac_dedup_device(c, n_rec, n_cells, d_cnt.as<uint32_t>(), out_cell_ptr, out_ref, out_start, out_frag_len, out_count, hc);
+    if (rc) { std::free(obc); return rc; }
+    *out_bc = obc;
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->n_records = n_rec;
+        for (uint32_t i = 0; i < n_cells; ++i) { stats->n_multimapped += stat[2 * i]; stats->n_not_mapped_pair += stat[2 * i + 1]; }
+        const uint64_t tot = (*out_cell_ptr)[n_cells];
+        stats->n_distinct = tot;
+        for (uint64_t k = 0; k < tot; ++k) { if ((*out_count)[k] > 1) ++stats->n_deduplicated; if ((*out_frag_len)[k] >= 2000) ++stats->n_long_fragments; }
+        stats->n_fallback_cells = st.n_fallback;
+    }
     return 0;
 }
 

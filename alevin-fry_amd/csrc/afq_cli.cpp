@@ -2,6 +2,7 @@
 // reference) and `alevin-fry infer` (src/main.rs:350-365) in front of afq_quantify() / afq_infer_files()
 // (include/afquant_host.h).  Same spellings and defaults; what the reference refuses (--use-eds, -b with a plain
 // resolution, -d with trivial, --summary-stat without -b) is refused here too, with its message.
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -18,6 +19,7 @@ static void usage() {
                  "       [--quant-subset FILE] [--init-uniform] [--use-mtx] [-d] [-b N] [--device N | --devices 0,1,...]\n"
                  "       [--summary-stat] [--boot-seed S] [--sa-model winner-take-all|prefer-ambig]\n"
                  "resolutions: trivial cr-like cr-like-em parsimony parsimony-em parsimony-gene parsimony-gene-em\n"
+                 "       afquant atac deduplicate -i <input-dir> [-t N] [-d fw|rc] [--device N]\n"
                  "       afquant infer -c <geqc_counts.mtx> -e <gene_eqclass.txt.gz> -o <output-dir> [--usa] [--quant-subset FILE] [-t N]\n");
 }
 
@@ -46,6 +48,28 @@ int main(int argc, char** argv) {
         if (!io.count_mat || !io.eq_labels || !io.output_dir) { usage(); return 2; }
         const int rc = afq_infer_files(&io);
         if (rc) { std::fprintf(stderr, "afquant infer failed (%d): %s\n", rc, afq_host_last_error()); return 1; }
+        return 0;
+    }
+    if (argc >= 3 && std::strcmp(argv[1], "atac") == 0 && std::strcmp(argv[2], "deduplicate") == 0) {   // src/main.rs:942-956, atac/run.rs:128-169
+        afq_atac_dedup_opts ao{};
+        ao.rev = 1;   // --permit-bc-ori defaults to rc
+        auto need3 = [&](int& i) -> const char* { if (i + 1 >= argc) { usage(); std::exit(2); } return argv[++i]; };
+        for (int i = 3; i < argc; ++i) {
+            const std::string a = argv[i];
+            if (a == "-i" || a == "--input-dir") ao.input_dir = need3(i);
+            else if (a == "-t" || a == "--threads") ao.num_threads = (uint32_t)std::atoi(need3(i));
+            else if (a == "-d" || a == "--permit-bc-ori") {
+                std::string v = need3(i);
+                for (auto& ch : v) ch = (char)std::toupper((unsigned char)ch);
+                if (v == "RC") ao.rev = 1; else if (v == "FW") ao.rev = 0;
+                else { std::fprintf(stderr, "invalid barcode orientation %s\n", v.c_str()); return 2; }
+            }
+            else if (a == "--device") ao.device = (uint32_t)std::atoi(need3(i));
+            else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); usage(); return 2; }
+        }
+        if (!ao.input_dir) { usage(); return 2; }
+        const int rc = afq_atac_deduplicate(&ao);
+        if (rc) { std::fprintf(stderr, "afquant atac deduplicate failed (%d): %s\n", rc, afq_host_last_error()); return 1; }
         return 0;
     }
     if (argc < 2 || std::strcmp(argv[1], "quant") != 0) { usage(); return 2; }

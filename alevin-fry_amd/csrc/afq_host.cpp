@@ -682,6 +682,120 @@ static void run_device_range(const afq_config& cfg, const afq_config* cfg_eq, co
     }
 }
 
+// `alevin-fry atac deduplicate` (src/atac/deduplicate.rs:68-309): collated scATAC RAD in, <input_dir>/map.bed out.  The
+// record walk, the na==1 && type==4 filter, the per-cell sort and the run-length count run on the device
+// (afq_atac_dedup_rad); here: the directory protocol, the prelude, and write_bed (deduplicate.rs:37-66).
+int afq_atac_deduplicate(const afq_atac_dedup_opts* o) {
+    if (!o || !o->input_dir) return hfail(AFQ_ERR_INVALID_ARG, "null option");
+    const std::string in = o->input_dir;
+    if (!file_exists(in + "/generate_permit_list.json") || !file_exists(in + "/collate.json"))   // atac/run.rs:149-167
+        return hfail(AFQ_ERR_BAD_INPUT, "The provided input directory lacks a generate_permit_list.json or collate.json file; this should not happen.");
+    std::vector<uint8_t> cj;
+    if (!read_file(in + "/collate.json", cj)) return hfail(AFQ_ERR_BAD_INPUT, "could not open the collate.json file.");
+    std::string cjs(cj.begin(), cj.end());
+    bool compressed = false, have_flag = false;
+    { size_t k = cjs.find("\"compressed_output\""); if (k != std::string::npos) { size_t v = cjs.find_first_not_of(" \t\r\n:", k + 19); have_flag = v != std::string::npos; compressed = have_flag && cjs.compare(v, 4, "true") == 0; } }
+    if (!have_flag) return hfail(AFQ_ERR_BAD_INPUT, "could not read compressed_output field from collate metadata.");
+    PhaseClock pc;
+    MappedFile mf;
+    if (!mf.open(in + (compressed ? "/map.collated.rad.sz" : "/map.collated.rad"))) return hfail(AFQ_ERR_BAD_INPUT, "could not read the collated RAD file (run collate before deduplicate)");
+    std::unique_ptr<uint8_t[]> rad_buf;
+    uint64_t rad_buf_n = 0;
+    const unsigned nthreads = o->num_threads ? o->num_threads : std::max(1u, std::thread::hardware_concurrency());
+    if (compressed) {
+        std::string err;
+        std::vector<SnappyChunk> chunks;
+        if (!snappy_frame_plan(mf.p, mf.n, chunks, rad_buf_n, err)) return hfail(AFQ_ERR_BAD_INPUT, "map.collated.rad.sz: " + err);
+        rad_buf.reset(new (std::nothrow) uint8_t[rad_buf_n ? rad_buf_n : 1]);
+        if (!rad_buf) return hfail(AFQ_ERR_OOM, "map.collated.rad.sz: not enough host memory for the decompressed file");
+        if (!snappy_frame_run(mf.p, chunks, rad_buf.get(), nthreads, err)) return hfail(AFQ_ERR_BAD_INPUT, "map.collated.rad.sz: " + err);
+    }
+    const uint8_t* rad = compressed ? rad_buf.get() : mf.p;
+    const size_t rad_n = compressed ? (size_t)rad_buf_n : mf.n;
+    RadPrelude P;
+    int rc = parse_prelude(rad, rad_n, P, true);
+    if (rc) return rc;
+    // AtacSeqReadRecord: read tag b; alignment tags ref:u32, type:u8, start_pos:u32, frag_len:u16 (tests/atac_integration.rs:110-121)
+    if (P.read_tags.size() != 1 || P.read_tags[0].name != "b" || !P.bc_bytes) return hfail(AFQ_ERR_UNSUPPORTED, "scATAC RAD: the read-level tags must be exactly one integer 'b'");
+    static const struct { const char* name; uint8_t type; } kAln[4] = {{"ref", 3}, {"type", 1}, {"start_pos", 3}, {"frag_len", 2}};
+    bool aln_ok = P.aln_tags.size() == 4;
+    for (size_t i = 0; aln_ok && i < 4; ++i) aln_ok = P.aln_tags[i].name == kAln[i].name && P.aln_tags[i].type == kAln[i].type;
+    if (!aln_ok) return hfail(AFQ_ERR_UNSUPPORTED, "scATAC RAD: the alignment-level tags must be ref:u32, type:u8, start_pos:u32, frag_len:u16");
+    if (!P.file_tag_vals.count("cblen")) return hfail(AFQ_ERR_BAD_INPUT, "tag map must contain cblen");
+    const uint32_t cblen = (uint32_t)P.file_tag_vals["cblen"];
+    std::vector<uint64_t> chunk_off;
+    for (size_t p = P.first_chunk; p < rad_n;) {
+        if (p + 8 > rad_n) return hfail(AFQ_ERR_BAD_INPUT, "trailing bytes after the last chunk");
+        uint32_t nb; std::memcpy(&nb, rad + p, 4);
+        if (nb < 8 || p + nb > rad_n) return hfail(AFQ_ERR_BAD_INPUT, "corrupt chunk header");
+        chunk_off.push_back(p); p += nb;
+    }
+    pc.lap("map + prelude + chunk table");
+    afq_config cfg{};
+    cfg.abi_version = AFQ_ABI_VERSION; cfg.resolution = AFQ_RES_CR_LIKE; cfg.num_genes = 1; cfg.num_rows = 1; cfg.small_thresh = 100;
+    cfg.pug_exact_umi = 1; cfg.bc_bytes = 4; cfg.umi_bytes = 4;
+    const uint32_t t2g0 = 0;
+    afq_ctx* raw = nullptr;
+    rc = afq_create(&cfg, &t2g0, 1, (int)o->device, &raw);
+    if (rc) return hfail(rc, afq_last_error(nullptr));
+    CtxPtr ctx(raw);
+    uint64_t *optr = nullptr, *obc = nullptr; uint32_t *oref = nullptr, *ostart = nullptr; uint16_t *oflen = nullptr, *ocnt = nullptr;
+    afq_atac_stats st{};
+    const uint64_t span0 = chunk_off.empty() ? 0 : chunk_off[0];
+    std::vector<uint64_t> rel(chunk_off.size());
+    for (size_t i = 0; i < chunk_off.size(); ++i) rel[i] = chunk_off[i] - span0;
+    rc = afq_atac_dedup_rad(ctx.get(), rad + span0, rad_n - span0, rel.data(), (uint32_t)chunk_off.size(), P.bc_bytes, 0, &optr, &obc, &oref, &ostart, &oflen, &ocnt, &st);
+    if (rc) return hfail(rc, afq_last_error(ctx.get()));
+    struct Freer { uint64_t* a; uint64_t* b; uint32_t* c2; uint32_t* d; uint16_t* e; uint16_t* f; ~Freer() { afq_free(a); afq_free(b); afq_free(c2); afq_free(d); afq_free(e); afq_free(f); } } fr{optr, obc, oref, ostart, oflen, ocnt};
+    pc.lap("device: parse + dedup");
+    // write_bed (deduplicate.rs:37-66): chr name, start, start + frag_len, barcode (reverse-complemented with -d rc), count;
+    // fragments of 2000 bases and more are counted, not written.  Cells in file order (the reference: worker completion order).
+    const size_t n_cells = chunk_off.size();
+    const unsigned nth = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)nthreads, 64, n_cells / 64 + 1}));
+    std::vector<std::string> txt(nth);
+    std::vector<int> bad(nth, 0);
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nth; ++t)
+            th.emplace_back([&, t]() {
+                std::string& out = txt[t];
+                char num[32];
+                for (size_t i = n_cells * t / nth; i < n_cells * (t + 1) / nth; ++i) {
+                    uint64_t bc = obc[i];
+                    if (o->rev) {   // needletail::bitkmer::reverse_complement
+                        uint64_t r = 0;
+                        for (uint32_t k = 0; k < cblen; ++k) { r = (r << 2) | (3 - (bc & 3)); bc >>= 2; }
+                        bc = r;
+                    }
+                    const std::string bcs = bc_to_string(bc, cblen);
+                    for (uint64_t k = optr[i]; k < optr[i + 1]; ++k) {
+                        if (oflen[k] >= 2000) continue;
+                        if (oref[k] >= P.ref_names.size()) { bad[t] = 1; return; }
+                        out += P.ref_names[oref[k]]; out += '\t';
+                        *put_u64(num, ostart[k]) = 0; out += num; out += '\t';
+                        *put_u64(num, (unsigned long long)(uint32_t)(ostart[k] + (uint32_t)oflen[k])) = 0; out += num; out += '\t';
+                        out += bcs; out += '\t';
+                        *put_u64(num, ocnt[k]) = 0; out += num; out += '\n';
+                    }
+                }
+            });
+        for (auto& x : th) x.join();
+    }
+    for (int b2 : bad) if (b2) return hfail(AFQ_ERR_BAD_INPUT, "a fragment's reference id is beyond the RAD header's reference names");
+    FilePtr bed(std::fopen((in + "/map.bed").c_str(), "w"));
+    if (!bed) return hfail(AFQ_ERR_BAD_INPUT, "could not create map.bed");
+    for (auto& tx : txt) if (!tx.empty() && std::fwrite(tx.data(), 1, tx.size(), bed.get()) != tx.size()) return hfail(AFQ_ERR_BAD_INPUT, "could not write map.bed");
+    bed.reset();
+    pc.lap("map.bed");
+    std::fprintf(stderr, "finished parsing RAD file; processed %llu total records\n", (unsigned long long)st.n_records);
+    std::fprintf(stderr, "Number of records with greater than 1 mapping %llu\n", (unsigned long long)st.n_multimapped);
+    std::fprintf(stderr, "Number of records that are deduplicated %llu\n", (unsigned long long)st.n_deduplicated);
+    std::fprintf(stderr, "Number of records that are not mapped pairs %llu\n", (unsigned long long)st.n_not_mapped_pair);
+    std::fprintf(stderr, "Number of records that have frag length > 2000 %llu\n", (unsigned long long)st.n_long_fragments);
+    if (o->stats_out) *o->stats_out = st;
+    return 0;
+}
+
 // collation_manifest.bin (libradicl::collation::CollationManifest, written by src/collate.rs:1861-1890): the names of the
 // samples, indexed by the integer the scatter phase left in barcodes[0].  libradicl's source is not under /root/reference, so
 // the layout read here is a RESTATEMENT of its serde derive under bincode's default options (parity unpinned):

@@ -92,10 +92,19 @@ void launch_compact_em(hipStream_t s, uint32_t n_cells, const uint64_t* em_off, 
                        const uint64_t* cell_ptr, uint32_t* gene, float* val);
 void launch_atac_dedup(hipStream_t s, uint32_t n_cells, const uint32_t* ref, const uint32_t* start, const uint16_t* flen,
                        const uint64_t* cell_ptr, void* scratch /* 16 B per fragment */, uint32_t* o_ref, uint32_t* o_start,
-                       uint16_t* o_flen, uint16_t* o_cnt, uint32_t* o_n);
+                       uint16_t* o_flen, uint16_t* o_cnt, uint32_t* o_n, const uint32_t* cell_cnt = nullptr);
 void launch_atac_dedup64(hipStream_t s, uint32_t n_cells, const uint32_t* ref, const uint32_t* start, const uint16_t* flen,
                          const uint64_t* cell_ptr, void* scratch, uint32_t* o_ref, uint32_t* o_start, uint16_t* o_flen,
-                         uint16_t* o_cnt, uint32_t* o_n, uint32_t* flag);
+                         uint16_t* o_cnt, uint32_t* o_n, uint32_t* flag, const uint32_t* cell_cnt = nullptr);
+// ATAC records straight from collated-RAD chunks (afq_atac.hip)
+struct AtacCell { uint64_t chunk_off; uint64_t out_off; uint64_t bm_off; uint32_t nbytes; uint32_t nrec; };
+struct AtacParseArgs {
+    const uint8_t* bytes; const AtacCell* cells; uint32_t n_cells; uint32_t bc_bytes;
+    uint64_t* bitmap; uint32_t* o_ref; uint32_t* o_start; uint16_t* o_flen; uint32_t* cell_cnt; uint64_t* cell_bc;
+    uint32_t* cell_stat;   // [n_cells][2]: records with > 1 alignment, records that are not one properly mapped pair
+    uint32_t* walk_list; uint32_t* n_walk; DevStatus* st;
+};
+void launch_atac_parse(hipStream_t s, const AtacParseArgs& a);
 void launch_atac_compact(hipStream_t s, uint32_t n_cells, const uint64_t* cell_ptr, const uint64_t* out_ptr, const uint32_t* i_ref,
                          const uint32_t* i_start, const uint16_t* i_flen, const uint16_t* i_cnt, uint32_t* o_ref, uint32_t* o_start,
                          uint16_t* o_flen, uint16_t* o_cnt);

@@ -948,11 +948,11 @@ __global__ __launch_bounds__(kAtacNT) void k_atac_dedup(const uint32_t* __restri
                                                        const uint64_t* __restrict__ cell_ptr, Frag* __restrict__ scratch,
                                                        uint32_t* __restrict__ o_ref, uint32_t* __restrict__ o_start,
                                                        uint16_t* __restrict__ o_flen, uint16_t* __restrict__ o_cnt,
-                                                       uint32_t* __restrict__ o_n) {
+                                                       uint32_t* __restrict__ o_n, const uint32_t* __restrict__ cell_cnt) {
     __shared__ uint32_t s_ws[kAtacNT / 64];
     const uint32_t cell = blockIdx.x;
     const uint64_t b0 = cell_ptr[cell];
-    const uint32_t n = (uint32_t)(cell_ptr[cell + 1] - b0);
+    const uint32_t n = cell_cnt ? cell_cnt[cell] : (uint32_t)(cell_ptr[cell + 1] - b0);   // cell_cnt: fragments kept by the RAD decode (cell_ptr = capacity)
     Frag* f = scratch + b0;
     for (uint32_t i = threadIdx.x; i < n; i += kAtacNT) {
         Frag x;
@@ -992,12 +992,12 @@ __global__ __launch_bounds__(kAtacNT) void k_atac_dedup64(const uint32_t* __rest
                                                          const uint64_t* __restrict__ cell_ptr, uint64_t* __restrict__ scratch,
                                                          uint32_t* __restrict__ o_ref, uint32_t* __restrict__ o_start,
                                                          uint16_t* __restrict__ o_flen, uint16_t* __restrict__ o_cnt,
-                                                         uint32_t* __restrict__ o_n, uint32_t* __restrict__ flag) {
+                                                         uint32_t* __restrict__ o_n, uint32_t* __restrict__ flag, const uint32_t* __restrict__ cell_cnt) {
     __shared__ uint32_t s_ws[kAtacNT / 64];
     __shared__ __attribute__((aligned(16))) uint64_t s_tile[16384];
     const uint32_t cell = blockIdx.x;
     const uint64_t b0 = cell_ptr[cell];
-    const uint32_t n = (uint32_t)(cell_ptr[cell + 1] - b0);
+    const uint32_t n = cell_cnt ? cell_cnt[cell] : (uint32_t)(cell_ptr[cell + 1] - b0);
     uint64_t* f = scratch + b0;
     bool wide = false;
     for (uint32_t i = threadIdx.x; i < n; i += kAtacNT) {
@@ -1113,18 +1113,18 @@ extern "C" void afq_debug_dump() {
 
 void launch_atac_dedup(hipStream_t s, uint32_t n_cells, const uint32_t* ref, const uint32_t* start, const uint16_t* flen,
                        const uint64_t* cell_ptr, void* scratch, uint32_t* o_ref, uint32_t* o_start, uint16_t* o_flen,
-                       uint16_t* o_cnt, uint32_t* o_n) {
+                       uint16_t* o_cnt, uint32_t* o_n, const uint32_t* cell_cnt) {
     if (!n_cells) return;
     AFQ_LAUNCH(k_atac_dedup, n_cells, kAtacNT, s, ref, start, flen, cell_ptr, reinterpret_cast<Frag*>(scratch), o_ref, o_start,
-               o_flen, o_cnt, o_n);
+               o_flen, o_cnt, o_n, cell_cnt);
 }
 
 void launch_atac_dedup64(hipStream_t s, uint32_t n_cells, const uint32_t* ref, const uint32_t* start, const uint16_t* flen,
                          const uint64_t* cell_ptr, void* scratch, uint32_t* o_ref, uint32_t* o_start, uint16_t* o_flen,
-                         uint16_t* o_cnt, uint32_t* o_n, uint32_t* flag) {
+                         uint16_t* o_cnt, uint32_t* o_n, uint32_t* flag, const uint32_t* cell_cnt) {
     if (!n_cells) return;
     AFQ_LAUNCH(k_atac_dedup64, n_cells, kAtacNT, s, ref, start, flen, cell_ptr, reinterpret_cast<uint64_t*>(scratch), o_ref, o_start,
-               o_flen, o_cnt, o_n, flag);
+               o_flen, o_cnt, o_n, flag, cell_cnt);
 }
 
 void launch_atac_compact(hipStream_t s, uint32_t n_cells, const uint64_t* cell_ptr, const uint64_t* out_ptr, const uint32_t* i_ref,

@@ -247,6 +247,80 @@ int afq_synth_fill(const afq_synth_params* p, const uint32_t* cell_nrec, const u
     return afq_synth_host_fill(p, 0, p->n_cells, cell_nrec, chunk_off, out, total_bytes);
 }
 
+}  // extern "C" (reopened below)
+
+// ---- scATAC (BASELINE configs[4]): host generator of a collated scATAC RAD body ----
+// Record i of cell c: with p_unmapped no alignment, with p_multi two alignments, else one properly mapped pair
+// (type 4) - a copy of record i-1's fragment with p_dup, else chr uniform, start uniform below ref_len, frag_len
+// log-normal clipped to [30, 2500].  Records: na:u32, bc:u32, na x {ref:u32, type:u8, start_pos:u32, frag_len:u16}.
+namespace {
+struct AtacRec { uint32_t na; uint32_t ref[2], start[2]; uint16_t flen[2]; };
+inline void atac_fragment(const afq_synth_atac_params& p, uint64_t cell, uint32_t i, uint32_t k0, uint32_t k1, uint32_t& ref, uint32_t& start, uint16_t& flen) {
+    // walk back over the duplicate chain (every link is decided by its own record's draw)
+    for (;;) {
+        uint32_t w[4];
+        afq_synth::philox(i, (uint32_t)cell, (uint32_t)(cell >> 32), 0x41544143u, k0, k1, w);
+        if (i > 0 && w[0] < thr32(p.p_dup)) { --i; continue; }
+        uint32_t q[4];
+        afq_synth::philox(i, (uint32_t)cell, (uint32_t)(cell >> 32), 0x41544144u, k0, k1, q);
+        ref = afq_synth::below(q[0], p.n_refs);
+        start = afq_synth::below(q[1], p.ref_len);
+        const double u1 = std::max(1e-12, (q[2] + 0.5) / 4294967296.0), u2 = (q[3] + 0.5) / 4294967296.0;
+        const double z = std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
+        flen = (uint16_t)std::min(2500.0, std::max(30.0, std::exp(p.flen_mu + p.flen_sigma * z)));
+        return;
+    }
+}
+inline void atac_record(const afq_synth_atac_params& p, uint64_t cell, uint32_t i, uint32_t k0, uint32_t k1, AtacRec& r) {
+    uint32_t w[4];
+    afq_synth::philox(i, (uint32_t)cell, (uint32_t)(cell >> 32), 0x41544142u, k0, k1, w);
+    const uint32_t tu = thr32(p.p_unmapped), tm = thr32(p.p_unmapped + p.p_multi);
+    if (w[0] < tu) { r.na = 0; return; }
+    atac_fragment(p, cell, i, k0, k1, r.ref[0], r.start[0], r.flen[0]);
+    if (w[0] < tm) { r.na = 2; r.ref[1] = (r.ref[0] + 1) % p.n_refs; r.start[1] = r.start[0] + 250; r.flen[1] = r.flen[0]; }
+    else r.na = 1;
+}
+}  // namespace
+
+extern "C" int afq_synth_atac(const afq_synth_atac_params* p, uint64_t* chunk_off, uint64_t* total_bytes, uint8_t* out) {
+    if (!p || !chunk_off || !total_bytes || p->n_refs == 0 || p->ref_len == 0) return -1;
+    const uint32_t k0 = (uint32_t)p->seed, k1 = (uint32_t)(p->seed >> 32);
+    Model bm{}; bm.bc_salt = (uint32_t)mix(p->seed * 1000003ull + 0xBCull);
+    if (!out) {   // plan: sizes only
+        std::vector<uint64_t> sz(p->n_cells);
+        parallel_for(p->n_cells, p->n_threads, [&](uint32_t c) {
+            uint64_t b = 8;
+            AtacRec r;
+            for (uint32_t i = 0; i < p->frags_per_cell; ++i) { atac_record(*p, c, i, k0, k1, r); b += 8 + 11ull * r.na; }
+            sz[c] = b;
+        });
+        uint64_t off = 0;
+        for (uint32_t c = 0; c < p->n_cells; ++c) { if (sz[c] > 0xFFFFFFFFull) return -2; chunk_off[c] = off; off += sz[c]; }
+        *total_bytes = off;
+        return 0;
+    }
+    parallel_for(p->n_cells, p->n_threads, [&](uint32_t c) {
+        uint8_t* w = out + chunk_off[c];
+        const uint32_t bc = afq_synth::barcode(bm, c);
+        uint64_t k = 8;
+        AtacRec r;
+        for (uint32_t i = 0; i < p->frags_per_cell; ++i) {
+            atac_record(*p, c, i, k0, k1, r);
+            std::memcpy(w + k, &r.na, 4); std::memcpy(w + k + 4, &bc, 4); k += 8;
+            for (uint32_t j = 0; j < r.na; ++j) {
+                const uint8_t ty = 4;
+                std::memcpy(w + k, &r.ref[j], 4); w[k + 4] = ty; std::memcpy(w + k + 5, &r.start[j], 4); std::memcpy(w + k + 9, &r.flen[j], 2);
+                k += 11;
+            }
+        }
+        const uint32_t nb = (uint32_t)k, nr = p->frags_per_cell;
+        std::memcpy(w, &nb, 4); std::memcpy(w + 4, &nr, 4);
+    });
+    return 0;
+}
+
+extern "C" {
+
 int afq_synth_device_generate(const afq_synth_params* p, int device, uint64_t first_cell, uint32_t n, const uint32_t* cell_nrec,
                               uint64_t* chunk_off, uint64_t* total_bytes, void** d_bytes) {
     if (!params_ok(p) || !d_bytes || !total_bytes || (n && (!cell_nrec || !chunk_off))) return -1;

@@ -190,6 +190,46 @@ def rad_prelude_multi_bc(ref_names, num_chunks, b0len, b1len, ulen, b_bytes=4, u
     return bytes(out)
 
 
+def rad_prelude_atac(ref_names, ref_lengths, num_chunks, cblen=16, bc_bytes=4) -> bytes:
+    """Prelude of a scATAC RAD file as piscem writes it and the reference's tests build it (tests/atac_integration.rs:75-131):
+    paired flag set; file tags cblen (u16), known_rad_type (string), ref_lengths (array of u32, u32 length); read tag b;
+    alignment tags ref:u32, type:u8, start_pos:u32, frag_len:u16."""
+    out = bytearray()
+    out += bytes([1])
+    out += len(ref_names).to_bytes(8, "little")
+    for n in ref_names:
+        b = n.encode()
+        out += len(b).to_bytes(2, "little") + b
+    out += int(num_chunks).to_bytes(8, "little")
+
+    def tag(name, type_id, extra=b""):
+        b = name.encode()
+        return len(b).to_bytes(2, "little") + b + bytes([type_id]) + extra
+
+    out += (3).to_bytes(2, "little") + tag("cblen", 2) + tag("known_rad_type", 8) + tag("ref_lengths", 7, bytes([3, 3]))
+    out += (1).to_bytes(2, "little") + tag("b", _INT_TYPE_ID[bc_bytes])
+    out += (4).to_bytes(2, "little") + tag("ref", 3) + tag("type", 1) + tag("start_pos", 3) + tag("frag_len", 2)
+    kind = b"sc_atac"
+    out += int(cblen).to_bytes(2, "little") + len(kind).to_bytes(2, "little") + kind
+    out += len(ref_lengths).to_bytes(4, "little") + b"".join(int(x).to_bytes(4, "little") for x in ref_lengths)
+    return bytes(out)
+
+
+def encode_atac_cells(cells, bc_bytes: int = 4):
+    """cells: list of (bc, [[(ref, type, start, frag_len), ...] per record]).  Returns (bytes, chunk_off[u64])."""
+    out = bytearray()
+    offs = []
+    for bc, recs in cells:
+        offs.append(len(out))
+        body = bytearray()
+        for alns in recs:
+            body += len(alns).to_bytes(4, "little") + int(bc).to_bytes(bc_bytes, "little")
+            for ref, ty, start, fl in alns:
+                body += int(ref).to_bytes(4, "little") + bytes([ty]) + int(start).to_bytes(4, "little") + int(fl).to_bytes(2, "little")
+        out += (len(body) + 8).to_bytes(4, "little") + len(recs).to_bytes(4, "little") + body
+    return bytes(out), np.asarray(offs, dtype=np.uint64)
+
+
 def collation_manifest(groups, level_names=("sample", "cell")) -> bytes:
     """collation_manifest.bin in the layout csrc/afq_host.cpp reads (bincode of libradicl's CollationManifest - a
     restatement, libradicl's source is not in the reference tree).  groups: (key, name or None, chunk_start, num_chunks,

@@ -189,3 +189,28 @@ def generate_device(device=0, cell_range=None, sizes=None, **kw) -> NativeRad:
     if r != 0:
         raise RuntimeError(f"afq_synth_device_generate failed ({r})")
     return NativeRad(None, off, nrec, t2g, ng, nr, bool(p.usa), int(nrec.astype(np.int64).sum()), int(tb.value), c0, int(dp.value or 0), device)
+
+
+class SynthAtacParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_cells", C.c_uint32), ("frags_per_cell", C.c_uint32), ("n_refs", C.c_uint32), ("ref_len", C.c_uint32),
+                ("p_dup", C.c_double), ("p_multi", C.c_double), ("p_unmapped", C.c_double), ("flen_mu", C.c_double), ("flen_sigma", C.c_double),
+                ("n_threads", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+def generate_atac(seed=5, n_cells=10000, frags_per_cell=20000, n_refs=25, ref_len=150_000_000, p_dup=0.2, p_multi=0.05, p_unmapped=0.05,
+                  flen_mu=5.2, flen_sigma=0.6, n_threads=0):
+    """the chunks of a collated scATAC RAD (u32 barcodes).  Returns (bytes uint8, chunk_off uint64)."""
+    lib = _lib()
+    lib.afq_synth_atac.argtypes = [C.POINTER(SynthAtacParams), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p]
+    lib.afq_synth_atac.restype = C.c_int
+    p = SynthAtacParams(seed, n_cells, frags_per_cell, n_refs, ref_len, p_dup, p_multi, p_unmapped, flen_mu, flen_sigma, n_threads or (os.cpu_count() or 1), 0)
+    off = np.zeros(n_cells, np.uint64)
+    tb = C.c_uint64()
+    rc = lib.afq_synth_atac(C.byref(p), off.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(tb), None)
+    if rc:
+        raise RuntimeError(f"afq_synth_atac failed ({rc})")
+    data = np.empty(tb.value, np.uint8)
+    rc = lib.afq_synth_atac(C.byref(p), off.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(tb), data.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise RuntimeError(f"afq_synth_atac failed ({rc})")
+    return data, off

@@ -210,6 +210,26 @@ int afq_atac_dedup(afq_ctx* ctx, const uint32_t* ref, const uint32_t* start,
 void afq_free(void* p);
 
 /*
+ * The same, from the collated-RAD chunks themselves: the record loop of deduplicate.rs:199-218 (walk the
+ * AtacSeqReadRecords `na:u32, bc, na x {ref:u32, type:u8, start_pos:u32, frag_len:u16}` - tests/atac_integration.rs:110-121 -
+ * keep those with exactly one alignment of map_type 4, count the rest) runs on the device in front of the sort.
+ * `bytes` / `chunk_off` as for afq_submit (bytes_on_device != 0: `bytes` is device memory of this context's device).
+ * Outputs as afq_atac_dedup, plus the barcode of every cell; free each with afq_free().
+ */
+typedef struct afq_atac_stats {
+    uint64_t n_records;          /* records read                                                                  */
+    uint64_t n_multimapped;      /* "records with greater than 1 mapping", deduplicate.rs:210-212                 */
+    uint64_t n_not_mapped_pair;  /* neither kept nor multi-mapped (no alignment, or one that is not type 4), :213-215 */
+    uint64_t n_distinct;         /* distinct fragments over all cells                                             */
+    uint64_t n_deduplicated;     /* distinct fragments seen more than once, :222-224                              */
+    uint64_t n_long_fragments;   /* distinct fragments with frag_len >= 2000 (left out of the BED, :47-63)        */
+    uint64_t n_fallback_cells;   /* cells the walk-free parse could not prove and walked record by record         */
+} afq_atac_stats;
+int afq_atac_dedup_rad(afq_ctx* ctx, const uint8_t* bytes, size_t n_bytes, const uint64_t* chunk_off, uint32_t n_cells,
+                       uint32_t bc_bytes, int bytes_on_device, uint64_t** out_cell_ptr, uint64_t** out_bc, uint32_t** out_ref,
+                       uint32_t** out_start, uint16_t** out_frag_len, uint16_t** out_count, afq_atac_stats* stats);
+
+/*
  * Kernel timing of the last collected batch (HIP events on the context's own
  * stream; only when cfg.profile != 0).  Fills up to `cap` entries; returns the
  * number of kernels, or a negative error.  `name[i]` points to static storage.

@@ -14,6 +14,8 @@
 extern "C" {
 #endif
 
+struct afq_atac_stats;
+
 /* QuantOpts (src/prog_opts.rs:24-44) — the CLI-visible options of `alevin-fry quant` (src/main.rs:294-348). */
 typedef struct afq_quant_opts {
     const char* input_dir;      /* -i : directory holding map.collated.rad[.sz], collate.json, generate_permit_list.json */
@@ -56,6 +58,18 @@ typedef struct afq_infer_opts {
 } afq_infer_opts;
 /* Runs the whole `infer` sub-command (src/infer.rs:31-426): quants_mat.mtx, quants_mat_rows.txt, quants_mat_cols.txt in output_dir. */
 int afq_infer_files(const afq_infer_opts* opts);
+
+/* The options of `alevin-fry atac deduplicate` (src/atac/prog_opts.rs:47-55, src/main.rs:942-956). */
+typedef struct afq_atac_dedup_opts {
+    const char* input_dir;      /* -i : directory holding collate.json, generate_permit_list.json, map.collated.rad[.sz]; map.bed is written here */
+    uint32_t num_threads;       /* -t : BED formatting / snappy threads (0 = all cores)                                   */
+    uint32_t rev;               /* -d/--permit-bc-ori rc (the CLI default) : barcodes are written reverse-complemented    */
+    uint32_t device;
+    uint32_t reserved;
+    struct afq_atac_stats* stats_out; /* optional: the counters the reference logs (deduplicate.rs:285-308)               */
+} afq_atac_dedup_opts;
+/* Runs the whole `atac deduplicate` sub-command (src/atac/deduplicate.rs:68-309) on the device: <input_dir>/map.bed. */
+int afq_atac_deduplicate(const afq_atac_dedup_opts* opts);
 
 /* Runs the whole `quant` sub-command.  Returns 0 or a negative AFQ_ERR_* code; message via afq_host_last_error(). */
 int afq_quantify(const afq_quant_opts* opts);

@@ -74,6 +74,21 @@ void afq_synth_device_free(int device, void* d_bytes);
 /* copy n bytes of a device buffer to the host (tests, the CPU leg of the bench) */
 int afq_synth_device_read(int device, const void* d_src, uint64_t n, void* host_dst);
 
+/*
+ * scATAC (configs[4]): the chunks of a collated scATAC RAD file (records `na:u32, bc:u32,
+ * na x {ref:u32, type:u8, start_pos:u32, frag_len:u16}`), host generator.  Call with out = NULL for the chunk offsets
+ * and the total size, then again with a buffer of that size.
+ */
+typedef struct afq_synth_atac_params {
+    uint64_t seed;
+    uint32_t n_cells, frags_per_cell;
+    uint32_t n_refs, ref_len;          /* chromosomes, and the length positions are drawn below        */
+    double p_dup, p_multi, p_unmapped; /* exact duplicate of the previous fragment / two alignments / none */
+    double flen_mu, flen_sigma;        /* log-normal fragment length, clipped to [30, 2500]             */
+    uint32_t n_threads, reserved;
+} afq_synth_atac_params;
+int afq_synth_atac(const afq_synth_atac_params* p, uint64_t* chunk_off, uint64_t* total_bytes, uint8_t* out);
+
 /* Whole data set on the host, as in round 1: sizes + offsets, then the bytes. */
 int afq_synth_plan(const afq_synth_params* p, uint32_t* cell_nrec, uint64_t* chunk_off, uint64_t* total_bytes,
                    uint64_t* total_reads);

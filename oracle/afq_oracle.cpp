@@ -1128,4 +1128,47 @@ int ora_atac_dedup(const uint32_t* ref, const uint32_t* start, const uint16_t* f
     return 0;
 }
 
+
+// The record loop of `alevin-fry atac deduplicate` in front of that sort (src/atac/deduplicate.rs:199-218): walk the
+// AtacSeqReadRecords of every chunk (`na:u32, bc, na x {ref:u32, type:u8, start_pos:u32, frag_len:u16}`,
+// tests/atac_integration.rs:110-121), keep na == 1 && map_type == 4, count na > 1 and the rest; then sort + count as above.
+// stats[0..4] = records, multi-mapped, not a mapped pair, fragments seen more than once, fragments of >= 2000 bases
+// (what write_bed leaves out, deduplicate.rs:47-63).  out_* must hold one entry per record.  Returns 0, or
+// AFQ_ERR_BAD_INPUT when a chunk's records do not tile it.
+int ora_atac_dedup_rad(const uint8_t* bytes, size_t n_bytes, const uint64_t* chunk_off, uint32_t n_cells, uint32_t bc_bytes,
+                       uint64_t* out_cell_ptr, uint64_t* out_bc, uint32_t* out_ref, uint32_t* out_start, uint16_t* out_flen,
+                       uint16_t* out_count, uint64_t* stats) {
+    std::vector<u32> ref, start; std::vector<u16> flen; std::vector<uint64_t> ptr(1, 0);
+    for (int i = 0; i < 5; ++i) stats[i] = 0;
+    const size_t H = 4 + bc_bytes;
+    for (uint32_t c = 0; c < n_cells; ++c) {
+        if (chunk_off[c] + 8 > n_bytes) { g_err = "chunk offset out of range"; return AFQ_ERR_BAD_INPUT; }
+        const uint8_t* ch = bytes + chunk_off[c];
+        u32 nb, nr; std::memcpy(&nb, ch, 4); std::memcpy(&nr, ch + 4, 4);
+        if (nb < 8 || chunk_off[c] + nb > n_bytes) { g_err = "chunk size out of range"; return AFQ_ERR_BAD_INPUT; }
+        size_t p = 8;
+        u64 bc = 0;
+        for (u32 r = 0; r < nr; ++r) {
+            if (p + H > nb) { g_err = "cell " + std::to_string(c) + ": records run past the chunk"; return AFQ_ERR_BAD_INPUT; }
+            u32 na; std::memcpy(&na, ch + p, 4);
+            if (r == 0) std::memcpy(&bc, ch + p + 4, bc_bytes);
+            if ((u64)na * 11 > nb - p - H) { g_err = "cell " + std::to_string(c) + ": records run past the chunk"; return AFQ_ERR_BAD_INPUT; }
+            stats[0]++;
+            if (na == 1 && ch[p + H + 4] == 4) {
+                u32 rf, st; u16 fl;
+                std::memcpy(&rf, ch + p + H, 4); std::memcpy(&st, ch + p + H + 5, 4); std::memcpy(&fl, ch + p + H + 9, 2);
+                ref.push_back(rf); start.push_back(st); flen.push_back(fl);
+            } else if (na > 1) stats[1]++;
+            else stats[2]++;
+            p += H + 11ull * na;
+        }
+        if (p != nb) { g_err = "cell " + std::to_string(c) + ": records do not tile the chunk"; return AFQ_ERR_BAD_INPUT; }
+        out_bc[c] = bc;
+        ptr.push_back(ref.size());
+    }
+    ora_atac_dedup(ref.data(), start.data(), flen.data(), ptr.data(), n_cells, out_cell_ptr, out_ref, out_start, out_flen, out_count);
+    for (uint64_t k = 0; k < out_cell_ptr[n_cells]; ++k) { if (out_count[k] > 1) stats[3]++; if (out_flen[k] >= 2000) stats[4]++; }
+    return 0;
+}
+
 }  // extern "C"

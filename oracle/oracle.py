@@ -60,6 +60,9 @@ def lib():
         L.ora_atac_dedup.argtypes = [p(C.c_uint32), p(C.c_uint32), p(C.c_uint16), p(C.c_uint64), C.c_uint32,
                                      p(C.c_uint64), p(C.c_uint32), p(C.c_uint32), p(C.c_uint16), p(C.c_uint16)]
         L.ora_atac_dedup.restype = C.c_int
+        L.ora_atac_dedup_rad.argtypes = [C.c_void_p, C.c_size_t, p(C.c_uint64), C.c_uint32, C.c_uint32, p(C.c_uint64), p(C.c_uint64),
+                                         p(C.c_uint32), p(C.c_uint32), p(C.c_uint16), p(C.c_uint16), p(C.c_uint64)]
+        L.ora_atac_dedup_rad.restype = C.c_int
         _lib = L
     return _lib
 
@@ -158,3 +161,23 @@ def atac_dedup(ref, start, frag_len, cell_ptr):
                      a(o_ptr, C.c_uint64), a(o_ref, C.c_uint32), a(o_start, C.c_uint32), a(o_len, C.c_uint16), a(o_cnt, C.c_uint16))
     m = int(o_ptr[-1])
     return o_ptr, o_ref[:m], o_start[:m], o_len[:m], o_cnt[:m]
+
+
+def atac_dedup_rad(chunk_bytes, chunk_off, bc_bytes=4):
+    """deduplicate.rs:199-237 from collated scATAC chunks.  Returns (cell_ptr, bc, ref, start, frag_len, count, stats dict)."""
+    L = lib()
+    b = np.ascontiguousarray(np.frombuffer(chunk_bytes, dtype=np.uint8) if not isinstance(chunk_bytes, np.ndarray) else chunk_bytes)
+    off = np.ascontiguousarray(chunk_off, dtype=np.uint64)
+    nc = len(off)
+    cap = max(1, b.nbytes // (4 + bc_bytes))
+    o_ptr = np.zeros(nc + 1, np.uint64); o_bc = np.zeros(max(nc, 1), np.uint64)
+    o_ref = np.zeros(cap, np.uint32); o_start = np.zeros(cap, np.uint32); o_len = np.zeros(cap, np.uint16); o_cnt = np.zeros(cap, np.uint16)
+    st = np.zeros(5, np.uint64)
+    a = lambda x, t: x.ctypes.data_as(C.POINTER(t))
+    rc = L.ora_atac_dedup_rad(b.ctypes.data_as(C.c_void_p), b.nbytes, a(off, C.c_uint64), nc, bc_bytes, a(o_ptr, C.c_uint64), a(o_bc, C.c_uint64),
+                              a(o_ref, C.c_uint32), a(o_start, C.c_uint32), a(o_len, C.c_uint16), a(o_cnt, C.c_uint16), a(st, C.c_uint64))
+    if rc != 0:
+        raise OracleError(rc, L.ora_last_error().decode())
+    m = int(o_ptr[-1])
+    stats = dict(n_records=int(st[0]), n_multimapped=int(st[1]), n_not_mapped_pair=int(st[2]), n_deduplicated=int(st[3]), n_long_fragments=int(st[4]))
+    return o_ptr, o_bc[:nc], o_ref[:m], o_start[:m], o_len[:m], o_cnt[:m], stats

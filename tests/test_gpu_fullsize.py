@@ -110,8 +110,10 @@ def test_parsimony_em_is_deterministic_and_split_invariant(big_pug):
 
 def test_parsimony_em_sampled_cells_against_the_oracle(big_pug, oracle):
     rad, cfg, q, r = big_pug
-    idx = np.array([400, 800, 1100, 1300, 1499])   # PBMC-sized to small cells (the oracle's PUG is slow)
-    want = oracle.quant(cfg, rad.tid_to_gid, rad.data, rad.chunk_off[idx], n_threads=8)
+    import os
+
+    idx = np.arange(3, 1500, 7)   # 214 cells spread over the whole size range (largest-first order), multi-threaded oracle
+    want = oracle.quant(cfg, rad.tid_to_gid, rad.data, rad.chunk_off[idx], n_threads=os.cpu_count() or 8)
     for j, ci in enumerate(idx):
         g0, v0 = r.row(int(ci))
         g1, v1 = want.row(j)

@@ -227,3 +227,39 @@ def test_pug_hand_cases(oracle):
     #  the reference asserts only mass > 0 = fast-path mass, and so do we)
     assert float(r_em.val.sum()) > 0.0 and float(r_tiny.val.sum()) == 0.0
     assert (r_tiny.flags & pkg._abi.CELL_TINY_PATH).all() and not (r_em.flags & pkg._abi.CELL_TINY_PATH).any()
+
+
+def _atac_reference_cells(num_cells=16, good=5, unmapped=2, multimapped=1):
+    """The synthetic scATAC input of the reference's own test (tests/atac_integration.rs:150-224): per cell `good` properly
+    paired unique fragments (type 4, length 120, spread-out starts), `unmapped` records without alignments, `multimapped`
+    records with two alignments placed beyond position 500 000."""
+    cells = []
+    for ci in range(num_cells):
+        bc = ((ci + 1) * 2654435761) & 0xFFFFFFFF
+        recs = [[(r % 2, 4, 1000 + ci * 977 + r * 131, 120)] for r in range(good)]
+        recs += [[] for _ in range(unmapped)]
+        recs += [[(0, 4, 500000 + ci * 13 + r * 7, 110), (1, 4, 500000 + ci * 13 + r * 7 + 250, 115)] for r in range(multimapped)]
+        cells.append((bc, recs))
+    return cells
+
+
+def test_atac_dedup_from_rad_reference_vector(oracle):
+    """atac/deduplicate.rs:199-237 from the records themselves: the reference's structural vector - 16 cells x 5 good
+    fragments => 80 distinct fragments, every count >= 1, no multi-mapping record among them
+    (tests/atac_integration.rs:531-607) - plus the counters the reference logs."""
+    from util import pkg
+
+    cells = _atac_reference_cells()
+    b, off = pkg.rad.encode_atac_cells(cells)
+    ptr, bc, ref, start, flen, cnt, st = oracle.atac_dedup_rad(b, off)
+    assert int(ptr[-1]) == 16 * 5 and (cnt >= 1).all() and (start < 500000).all() and set(ref.tolist()) <= {0, 1}
+    assert (flen == 120).all() and [int(x) for x in bc] == [c[0] for c in cells]
+    assert st == dict(n_records=16 * 8, n_multimapped=16, n_not_mapped_pair=32, n_deduplicated=0, n_long_fragments=0)
+    # duplicates, a long fragment, a one-alignment record that is not a proper pair (type 1), an 8-byte barcode
+    recs = [[(3, 4, 50, 200)], [(3, 4, 50, 200)], [(1, 4, 9, 2000)], [(3, 1, 50, 200)], [(0, 4, 7, 30)], [(3, 4, 50, 199)]]
+    b, off = pkg.rad.encode_atac_cells([(0x1122334455667788, recs)], bc_bytes=8)
+    ptr, bc, ref, start, flen, cnt, st = oracle.atac_dedup_rad(b, off, bc_bytes=8)
+    assert list(zip(ref.tolist(), start.tolist(), flen.tolist(), cnt.tolist())) == [(0, 7, 30, 1), (1, 9, 2000, 1), (3, 50, 199, 1), (3, 50, 200, 2)]
+    assert int(bc[0]) == 0x1122334455667788 and st["n_not_mapped_pair"] == 1 and st["n_deduplicated"] == 1 and st["n_long_fragments"] == 1
+    with pytest.raises(oracle.OracleError):   # records that do not tile their chunk
+        oracle.atac_dedup_rad(b[:4] + (7).to_bytes(4, "little") + b[8:], off, bc_bytes=8)   # header says 7 records, there are 6
