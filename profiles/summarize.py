@@ -16,7 +16,11 @@ def main(tag):
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", f"prof_{tag}")
     out = []
     db = sqlite3.connect(os.path.join(root, "stats", "stats_results.db"))
-    out.append(f"# rocprofv3 --kernel-trace --stats  (tag {tag}; command: python bench.py --steps 3 --warmup 1 --no-cpu-baseline)")
+    cmd = "python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+    if os.path.exists(os.path.join(root, "command.txt")):
+        cmd = open(os.path.join(root, "command.txt")).read().strip().replace(os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + "/", "")
+        cmd = " ".join(w.split("/")[-1] if w.endswith("bench.py") else w for w in cmd.split())
+    out.append(f"# rocprofv3 --kernel-trace --stats  (tag {tag}; command: {cmd})")
     out.append(f"{'kernel':28s} {'calls':>6s} {'total_us':>12s} {'avg_us':>12s} {'pct':>7s}")
     for name, calls, tot, avg, pct in db.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
         out.append(f"{short(name):28s} {calls:6d} {tot/1:12.1f} {avg:12.1f} {pct:7.2f}")
