@@ -121,6 +121,7 @@ EXPORTS = [
     "afq_infer",
     "afq_atac_dedup",
     "afq_atac_dedup_rad",
+    "afq_device_warmup",
     "afq_free",
     "afq_get_kernel_times",
     "afq_get_batch_stats",

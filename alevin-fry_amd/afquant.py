@@ -21,7 +21,7 @@ from . import _abi
 from ._abi import AfqBatchStats, AfqBootstraps, AfqConfig, AfqEqclasses, AfqKernelTime, AfqResult, RESOLUTIONS
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libafquant.so")
+LIB_PATH = os.environ.get("AFQ_LIB_PATH") or os.path.join(_HERE, "csrc", "libafquant.so")   # (AFQ_LIB_PATH: an instrumented build, profiles/ only)
 
 
 class AfqError(RuntimeError):

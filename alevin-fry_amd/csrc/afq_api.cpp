@@ -851,6 +851,11 @@ extern "C" {
 
 int afq_abi_version(void) { return AFQ_ABI_VERSION; }
 
+int afq_device_warmup(int device) {
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return AFQ_ERR_NO_DEVICE; }
+    return hipFree(nullptr) == hipSuccess ? 0 : AFQ_ERR_NO_DEVICE;
+}
+
 const char* afq_last_error(const afq_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
 int afq_create(const afq_config* cfg, const uint32_t* tid_to_gid, uint32_t ref_count, int device, afq_ctx** out) {

@@ -412,7 +412,9 @@ static bool write_mtx_file(const std::string& path, uint64_t n_rows, uint64_t n_
     const size_t slice = 1u << 20;
     uint64_t file_off = (uint64_t)hl;
     for (size_t base = 0; base < nz && ok; base += slice * nth) {
-        std::vector<std::string> bufs(nth);
+        // (plain arrays, not strings: a string would zero-fill its 112 bytes per entry before a tenth of them is written)
+        std::vector<std::unique_ptr<char[]>> bufs(nth);
+        std::vector<size_t> blen(nth, 0);
         auto each = [&](const std::function<void(unsigned, size_t, size_t)>& f) {
             std::vector<std::thread> th;
             for (unsigned t = 0; t < nth; ++t) {
@@ -423,9 +425,9 @@ static bool write_mtx_file(const std::string& path, uint64_t n_rows, uint64_t n_
             for (auto& x : th) x.join();
         };
         each([&](unsigned t, size_t a, size_t b) {
-            std::string& out = bufs[t];
-            out.resize((b - a) * 112);  // 2 x <= 20 digits + an f32 in positional notation (<= 48 chars) + separators
-            char* p = &out[0];
+            bufs[t].reset(new char[(b - a) * 112]);  // 2 x <= 20 digits + an f32 in positional notation (<= 48 chars) + separators
+            char* const p0 = bufs[t].get();
+            char* p = p0;
             size_t row = (size_t)(std::upper_bound(rp.begin(), rp.end(), (uint64_t)a) - rp.begin()) - 1;
             for (size_t k = a; k < b; ++k) {
                 while (rp[row + 1] <= k) ++row;   // skips empty rows too
@@ -433,21 +435,21 @@ static bool write_mtx_file(const std::string& path, uint64_t n_rows, uint64_t n_
                 p = put_u64(p, (unsigned long long)cols[k] + 1); *p++ = ' ';
                 p += format_f32(vals[k], p, 64); *p++ = '\n';
             }
-            out.resize((size_t)(p - &out[0]));
+            blen[t] = (size_t)(p - p0);
         });
         std::vector<uint64_t> off(nth + 1, file_off);
-        for (unsigned t = 0; t < nth; ++t) off[t + 1] = off[t] + bufs[t].size();
+        for (unsigned t = 0; t < nth; ++t) off[t + 1] = off[t] + blen[t];
         std::vector<int> bad(nth, 0);
         each([&](unsigned t, size_t, size_t) {
-            const std::string& bsl = bufs[t];
-            for (size_t w = 0; w < bsl.size();) {
-                const ssize_t g = ::pwrite(fd, bsl.data() + w, bsl.size() - w, (off_t)(off[t] + w));
+            for (size_t w = 0; w < blen[t];) {
+                const ssize_t g = ::pwrite(fd, bufs[t].get() + w, blen[t] - w, (off_t)(off[t] + w));
                 if (g <= 0) { bad[t] = 1; return; }
                 w += (size_t)g;
             }
         });
         for (int x : bad) if (x) ok = false;
         file_off = off[nth];
+        std::fill(blen.begin(), blen.end(), 0);
     }
     if (::close(fd) != 0) ok = false;
     return ok;
@@ -849,6 +851,9 @@ int afq_quantify(const afq_quant_opts* o) {
     bool compressed = false;
     { size_t k = cjs.find("\"compressed_output\""); if (k != std::string::npos) { size_t v = cjs.find_first_not_of(" \t\r\n:", k + 19); compressed = v != std::string::npos && cjs.compare(v, 4, "true") == 0; } }
     PhaseClock pc;
+    // the HIP runtime takes a few hundred ms to come up: let it do so while the prelude and the tg-map are parsed
+    std::thread warm([dev = (int)(o->devices && o->n_devices ? o->devices[0] : (int)o->device)]() { afq_device_warmup(dev); });
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } warm_join{warm};
     MappedFile mf;
     if (!mf.open(in + (compressed ? "/map.collated.rad.sz" : "/map.collated.rad"))) return hfail(AFQ_ERR_BAD_INPUT, "could not read the collated RAD file");
     std::unique_ptr<uint8_t[]> rad_buf;   // (not a vector: no point zero-filling gigabytes that are about to be overwritten)
@@ -1007,6 +1012,9 @@ int afq_quantify(const afq_quant_opts* o) {
 
     // ---- the device work: the worker fan-out of do_quantify (quant.rs:1553-1575, 1678-1765) becomes one context and one
     // host thread per device over a contiguous, byte-balanced range of cells; no device talks to another ----
+    pc.lap("prelude, chunk table, tg-map");
+    if (warm.joinable()) warm.join();
+    pc.lap("(wait for the HIP runtime)");
     std::vector<int> devices;
     if (o->devices && o->n_devices) devices.assign(o->devices, o->devices + o->n_devices); else devices.push_back((int)o->device);
     if (devices.size() > chunk_off.size() && !chunk_off.empty()) devices.resize(chunk_off.size());

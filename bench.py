@@ -235,7 +235,7 @@ def cpu_leg(cfg, rad, res, budget_s, min_cells=0, tie_stats=False, tol=None):
                                              else np.allclose(v0, v1, rtol=tol, atol=0))
             assert ok, f"GPU/oracle mismatch on cell {ci}"
         if tie_stats:
-            ties += ps.sum(0)
+            ties += ps.sum(0).astype(np.int64)
             tie_cells += int((ps[:, 1] > 0).sum())
             other = ora.quant(cfg, rad.tid_to_gid, data, offs, n_threads=ncores, tie_break_descending=True)
             for j in range(len(idx)):

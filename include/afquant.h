@@ -254,6 +254,10 @@ typedef struct afq_batch_stats {
 } afq_batch_stats;
 int afq_get_batch_stats(afq_ctx* ctx, afq_batch_stats* out);
 
+/* Brings the HIP runtime up on `device` (first-call initialisation) - a host can call it from a side thread while it parses its
+   inputs.  Returns 0 or AFQ_ERR_NO_DEVICE. */
+int afq_device_warmup(int device);
+
 const char* afq_last_error(const afq_ctx* ctx); /* ctx may be NULL: last create error */
 int afq_abi_version(void);
 
