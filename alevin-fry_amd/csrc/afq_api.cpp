@@ -540,6 +540,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
         pa.num_rows = g.num_rows; pa.em = em ? 1u : 0u; pa.exact_umi = g.pug_exact_umi; pa.large_thresh = g.large_graph_thresh; pa.umi32 = g.umi_bytes == 4 ? 1u : 0u;
         pa.hw = 1 + g.bc_bytes / 4 + g.umi_bytes / 4; pa.umi_pairs = std::min<uint32_t>(g.umi_len ? g.umi_len : g.umi_bytes * 4, 22);
         pa.gene_level = (g.resolution == AFQ_RES_PARSIMONY_GENE || g.resolution == AFQ_RES_PARSIMONY_GENE_EM) ? 1u : 0u;
+        pa.force_global_route = std::getenv("AFQ_PUG_GLOBAL_ROUTE") ? 1u : 0u;
         ScopedTimer t(c, K_PUG, s, &B.launches);
         launch_pug(s, pa, n_pug_blocks);
     }

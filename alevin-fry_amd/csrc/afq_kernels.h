@@ -137,6 +137,7 @@ struct PugCellArgs {
     DevStatus* st;
     uint32_t ref_count, num_genes, usa, num_rows, em, exact_umi, large_thresh, hw, umi_pairs, gene_level;
     uint32_t umi32;               // the record's UMI field is 4 bytes: UMI and record offset share one sort word
+    uint32_t force_global_route;  // tests: neighbour search through the global-memory hash table for every cell
 };
 
 void launch_pug(hipStream_t s, const PugCellArgs& a, uint32_t n_blocks);

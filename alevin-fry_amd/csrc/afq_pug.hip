@@ -27,14 +27,24 @@ namespace afq {
 
 #ifdef AFQ_PUG_TIMING
 #define PUG_MARK(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 4) tmark[i] = wall_clock64(); } while (0)
+#define PUG_ACC(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 4) { const unsigned long long t_ = wall_clock64(); tacc[i] += t_ - tlast; tlast = t_; } } while (0)
 #else
 #define PUG_MARK(i) do {} while (0)
+#define PUG_ACC(i) do {} while (0)
 #endif
 
 constexpr int kPugNT = 1024;
 constexpr uint32_t kVidBits = 20;                 // vertices per cell < 2^20
 constexpr uint32_t kMaxGenesPerLabel = 64;        // distinct genes of one molecule the device path carries
 constexpr uint32_t kMaxBigComp = 4096;            // vertices of a component the multi-word cover handles
+// Neighbour search out of LDS: the cell's vertices are cut into P = 4^k partitions by the low 2k bits of their UMI and the
+// partitions are taken one at a time through a hash table that lives in the 128 KiB LDS block (key = UMI, value = vertex id |
+// reads | class).  A 1-mismatch probe of a vertex stays in the vertex's own partition unless it changes one of the low k
+// bases, and then it lands in exactly one other partition - so every pass knows which vertices can have a neighbour in it.
+constexpr uint32_t kTabSlots = 8192;              // 64 KiB of keys + 64 KiB of values
+constexpr uint32_t kPartTarget = 3000;            // planned vertices per partition
+constexpr uint32_t kPartMax = 5400;               // a partition above this (skewed UMIs) sends the cell down the global-memory route
+constexpr uint32_t kMaxParts = 1024;
 
 // A read as the grouping sort sees it: label key, then UMI and the record it came from in one word - umi << 32 | record
 // dword offset when the UMI field is 4 bytes wide (UMIs up to 16 nt: every 10x chemistry), umi << 20 | read index
@@ -280,8 +290,12 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     __shared__ uint32_t s_bestv[kPugNT / 64], s_bestsz[kPugNT / 64];
 #ifdef AFQ_PUG_TIMING
     __shared__ unsigned long long tmark[24];
+    __shared__ unsigned long long tacc[8];
+    __shared__ unsigned long long tlast;
 #endif
     __shared__ uint32_t s_next;
+    __shared__ uint32_t s_poff[kMaxParts + 1];
+    __shared__ uint32_t s_filt[2048];   // 2^16-bit presence filter over the UMIs of the partition in the table
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   // Persistent workgroup: takes the next cell of the (largest-first) list until the list is empty.  Its scratch
   // slice is reused cell after cell, so the working set of a CU stays the size of ONE cell instead of wandering
@@ -375,6 +389,12 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         }
         return k;
     };
+    // Per class a 19-bit signature of its label - bit (id mod 19) for every ref (gene at gene level) in it.  Two labels whose
+    // signatures do not meet share no ref, so the neighbour search can drop such a pair on the spot (same-UMI vertices under
+    // the transcripts of one gene are the bulk of its matches, and ids that close never collide mod 19); the others still
+    // get the exact comparison.  Labels of one or two ids are carried in the sort key itself: no read needed for them.
+    uint32_t* c_sig = comp_start;   // (free until the components are listed)
+    auto sig_of = [](uint32_t t) -> uint32_t { return 1u << (t % 19u); };
     for (uint32_t i = tid; i < R; i += kPugNT) c_minoff[i] = 0xFFFFFFFFu;   // K <= R
     __syncthreads();
     uint32_t V = 0, K = 0;
@@ -409,7 +429,19 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                 const uint32_t k = K + ec - (c ? 0 : 1);     // the read's class
                 const uint32_t ro = rec_off(cur[j]);
                 if (v) { v_umi[vi] = rec_umi(cur[j]); v_cls[vi] = k; v_cnt[vi] = i; }   // v_cnt: head position for now
-                if (c) { c_vstart[k] = vi; c_rep[k] = ro; }
+                if (c) {
+                    c_vstart[k] = vi; c_rep[k] = ro;
+                    const uint64_t hk = cur[j].h;
+                    const uint32_t tag = (uint32_t)(hk >> 62);
+                    uint32_t sg = 0;
+                    if (tag == 1) sg = sig_of((uint32_t)hk & 0x7FFFFFFFu);
+                    else if (tag == 2) sg = sig_of((uint32_t)(hk >> 31) & 0x7FFFFFFFu) | sig_of((uint32_t)hk & 0x7FFFFFFFu);
+                    else if (tag == 3) {
+                        if (!C.gene_level) { const Lab l = rec_label(C, ro); for (uint32_t q = 0; q < l.n; ++q) sg |= sig_of(l.p[q] & 0x7FFFFFFFu); }
+                        else { uint32_t g[kMaxGenesPerLabel]; const uint32_t len = gene_list(ro, g); if (len != 0xFFFFFFFFu) for (uint32_t q = 0; q < len; ++q) sg |= sig_of(g[q]); else sg = 0x7FFFFu; }
+                    }
+                    c_sig[k] = sg;
+                }
                 atomicMin(&c_minoff[k], ro);
                 if (!c && !label_key_is_exact(cur[j].h)) {
                     const uint32_t po = rec_off(j ? cur[j - 1] : prev);
@@ -513,18 +545,209 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     }
     __syncthreads();
     PUG_MARK(3);
-    // ---- 4. vertices hashed by UMI for neighbour probing ----
+    // ---- 4. neighbour search ----
+    uint32_t NCAND = 0;
+    uint64_t* cand = nullptr;
+    uint64_t* pairs = nullptr;
+    uint32_t pair_cap = 0;
+    constexpr uint64_t kPairRuled = 1ull << 62, kPairCheck = 1ull << 61;   // LDS route: count rule already applied / labels still to compare
+    bool fast = false;
+#ifdef AFQ_PUG_TIMING
+    if (tid == 0) { for (int q_ = 0; q_ < 8; ++q_) tacc[q_] = 0; tlast = wall_clock64(); }
+#endif
+    {
+        uint32_t lgP = 0;
+        while (lgP < 20 && ((uint64_t)kPartTarget << lgP) < V) lgP += 2;
+        const uint32_t L = C.umi_pairs;
+        if (3 * (L - lgP / 2) > 64 && lgP + 2 <= 2 * L) lgP += 2;   // the per-lane probe mask has 64 bits (UMIs of 22 nt in a tiny cell)
+        const uint32_t P = 1u << lgP;
+        if (P <= kMaxParts && lgP <= 2 * L && 3 * (L - lgP / 2) <= 64 && !A.force_global_route) {
+            uint64_t* pv_umi = v_umi;                                  // slab B is free until the components are listed:
+            uint64_t* pv_info = reinterpret_cast<uint64_t*>(v_cnt);    // the vertices again, grouped by partition
+            for (uint32_t i = tid; i <= P; i += kPugNT) s_poff[i] = 0;
+            if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
+            __syncthreads();
+            for (uint32_t v = tid; v < V; v += kPugNT) atomicAdd(&s_poff[(uint32_t)vv_umi[v] & (P - 1)], 1u);
+            __syncthreads();
+            {   // exclusive offsets (P <= 1024 = one value per thread), oversize check
+                const uint32_t c = tid < P ? s_poff[tid] : 0u;
+                if (c > kPartMax) s_flag[1] = 1;
+                uint32_t tot;
+                const uint32_t ex = block_excl_scan<kPugNT>(c, s_ws, tot);
+                __syncthreads();
+                if (tid < P) s_poff[tid] = ex;
+                if (tid == 0) s_poff[P] = tot;
+                __syncthreads();
+            }
+            if (!s_flag[1]) {
+                uint32_t* fill = s_big;   // per-partition fill cursors (the table is not in use yet)
+                for (uint32_t i = tid; i < P; i += kPugNT) fill[i] = 0;
+                __syncthreads();
+                for (uint32_t v = tid; v < V; v += kPugNT) {
+                    const uint64_t umi = vv_umi[v];
+                    const uint4 q = vv[v];
+                    const uint32_t pp = (uint32_t)umi & (P - 1);
+                    const uint32_t o = s_poff[pp] + atomicAdd(&fill[pp], 1u);
+                    if (umi >> 44) s_flag[1] = 1;   // (the global route reports it)
+                    pv_umi[o] = umi | ((uint64_t)c_sig[q.y] << 44);   // key word of the table: UMI (<= 22 nt) + the label signature
+                    pv_info[o] = (uint64_t)v | ((uint64_t)q.x << 20) | ((uint64_t)q.y << 40);
+                }
+                pair_cap = 2 * V + 4096;
+                if (tid == 0) s_ebase = atomicAdd(A.epool_cursor, 2ull * pair_cap + 2);
+                __syncthreads();
+                if (s_ebase + 2ull * pair_cap + 2 > A.epool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, cell); return; }
+                pairs = reinterpret_cast<uint64_t*>(A.epool + ((s_ebase + 1) & ~1ull));
+              if (!s_flag[1]) {
+                uint64_t* t_key = reinterpret_cast<uint64_t*>(s_big);
+                uint64_t* t_val = t_key + kTabSlots;
+                constexpr uint64_t kEmptyKey = ~0ull;
+                const uint32_t vm = (1u << kVidBits) - 1;
+                // Slot of a UMI = its 13-bit XOR fold.  UMIs are random sequences, so the fold spreads them as well as a
+                // multiplicative hash would, and it is linear: the slot of a one-base neighbour is the vertex's own slot
+                // XOR a constant of the changed base - one instruction per probe where a 64-bit multiply is four
+                // quarter-rate ones (the probes, 1 + 3L per vertex, are the whole cost of this phase).
+                auto fold13 = [](uint64_t u) -> uint32_t { u ^= u >> 26; const uint32_t t = (uint32_t)u & 0x3FFFFFFu; return (t ^ (t >> 13)) & (kTabSlots - 1); };   // 13-bit pieces of up to 52 bits
+                // In front of the table, one bit per UMI in a 2^16-bit map (same kind of fold, 16 bits): a probe that finds its
+                // bit clear has no match - the fate of ~95 % of the 3L one-base probes - and costs a handful of
+                // instructions with no loop.  A lane first collects the probes that pass in a bit mask, then walks the table
+                // for those only: a wave spends table walks on the few probes that can match, not on every probe of every lane.
+                auto fold16 = [](uint64_t u) -> uint32_t { u ^= u >> 32; const uint32_t t = (uint32_t)u; return (t ^ (t >> 16)) & 0xFFFFu; };
+                auto filt = [&](uint32_t h) -> uint32_t { return (s_filt[h >> 5] >> (h & 31u)) & 1u; };
+                // every match of probe UMI `pu` for vertex x: the edge x -> y exists at distance 0, or at distance 1 unless
+                // reads(y) >= 2 * reads(x) (has_edge, pugutils.rs:76-99) - provided the labels overlap, which only classes
+                // that differ still have to show (stage 2)
+                constexpr uint64_t kUmi44 = (1ull << 44) - 1;
+#ifdef AFQ_PUG_TIMING
+                unsigned long long dbg_steps = 0, dbg_probes = 0;
+#define PUG_DBG_STEP ++dbg_steps
+#define PUG_DBG_PROBE ++dbg_probes
+#else
+#define PUG_DBG_STEP
+#define PUG_DBG_PROBE
+#endif
+                auto probe = [&](uint64_t pu, uint32_t slot, uint64_t xinfo, uint32_t xsig, bool same) {
+                    PUG_DBG_PROBE;
+                    for (;; slot = (slot + 1) & (kTabSlots - 1)) {
+                        PUG_DBG_STEP;
+                        const uint64_t k = t_key[slot];
+                        if (k == kEmptyKey) break;
+                        if ((k & kUmi44) != pu) continue;
+                        if (((uint32_t)(k >> 44) & xsig) == 0) continue;   // labels without a common ref: no edge whatever the UMIs
+                        const uint64_t info = t_val[slot];
+                        const uint32_t y = (uint32_t)info & vm, x = (uint32_t)xinfo & vm;
+                        if (y == x) continue;
+                        if (!same && !(((uint32_t)(info >> 20) & vm) < 2 * ((uint32_t)(xinfo >> 20) & vm))) continue;
+                        const uint64_t am = __ballot(true);   // one LDS atomic per wave, not per match
+                        const uint32_t leader = (uint32_t)__builtin_ctzll(am);
+                        uint32_t base = 0;
+                        if (lane == leader) base = atomicAdd(&s_flag[0], (uint32_t)__popcll(am));
+                        base = __builtin_amdgcn_readlane(base, (int)leader);
+                        const uint32_t kk = base + (uint32_t)__popcll(am & ((1ull << lane) - 1));
+                        if (kk < pair_cap)
+                            pairs[kk] = kPairRuled | ((uint32_t)(info >> 40) != (uint32_t)(xinfo >> 40) ? kPairCheck : 0ull) | ((uint64_t)same << 63) | ((uint64_t)x << 32) | y;
+                    }
+                };
+                const uint32_t lowb = lgP / 2;   // bases whose change moves a UMI to another partition
+                PUG_ACC(0);
+                for (uint32_t pp = 0; pp < P; ++pp) {
+                    const uint32_t o0 = s_poff[pp], n = s_poff[pp + 1] - o0;
+                    if (n == 0) continue;
+                    __syncthreads();   // the previous pass is done with the table
+                    for (uint32_t i = tid; i < kTabSlots; i += kPugNT) t_key[i] = kEmptyKey;
+                    for (uint32_t i = tid; i < 2048; i += kPugNT) s_filt[i] = 0;
+                    __syncthreads();
+                    PUG_ACC(1);
+                    for (uint32_t i = tid; i < n; i += kPugNT) {
+                        const uint64_t umi = pv_umi[o0 + i];
+                        uint32_t slot = fold13(umi & kUmi44);
+                        while (atomicCAS(reinterpret_cast<unsigned long long*>(&t_key[slot]), (unsigned long long)kEmptyKey, (unsigned long long)umi) != kEmptyKey)
+                            slot = (slot + 1) & (kTabSlots - 1);   // (equal UMIs under different labels each take a slot of the same run)
+                        t_val[slot] = pv_info[o0 + i];
+                        const uint32_t hb = fold16(umi & kUmi44);
+                        atomicOr(&s_filt[hb >> 5], 1u << (hb & 31u));
+                    }
+                    __syncthreads();
+                    PUG_ACC(2);
+                    // the partition's own vertices: distance 0, and every change of a high base.  Three vertices per thread sit
+                    // in registers while the (base, substitution) loop - uniform, so its constants are scalar - runs over them.
+                    for (uint32_t i0 = tid; i0 < n; i0 += 3 * kPugNT) {
+                        uint64_t mu[3], mi[3];
+                        uint32_t mh[3], ms[3];
+#pragma unroll
+                        for (int m2 = 0; m2 < 3; ++m2) {
+                            const uint32_t i = i0 + m2 * kPugNT;
+                            const uint64_t w = i < n ? pv_umi[o0 + i] : 0ull;
+                            mu[m2] = w & kUmi44; ms[m2] = (uint32_t)(w >> 44);
+                            mi[m2] = i < n ? pv_info[o0 + i] : 0ull;
+                            mh[m2] = fold13(mu[m2]);
+                        }
+#pragma unroll
+                        for (int m2 = 0; m2 < 3; ++m2) if (i0 + m2 * kPugNT < n) probe(mu[m2], mh[m2], mi[m2], ms[m2], true);
+                        if (!C.exact_umi) {
+                            uint64_t pm[3] = {0, 0, 0};   // bit (3 * (b - lowb) + d - 1): that neighbour's filter bit is set
+                            uint32_t mf[3];
+#pragma unroll
+                            for (int m2 = 0; m2 < 3; ++m2) mf[m2] = fold16(mu[m2]);
+                            uint32_t idx = 0;
+                            for (uint32_t b = lowb; b < L; ++b)
+                                for (uint32_t d = 1; d < 4; ++d, ++idx) {
+                                    const uint32_t df = fold16((uint64_t)d << (2 * b));
+#pragma unroll
+                                    for (int m2 = 0; m2 < 3; ++m2) pm[m2] |= (uint64_t)filt(mf[m2] ^ df) << idx;
+                                }
+#pragma unroll
+                            for (int m2 = 0; m2 < 3; ++m2) {
+                                uint64_t todo = i0 + m2 * kPugNT < n ? pm[m2] : 0ull;
+                                while (todo) {
+                                    const uint32_t ix = (uint32_t)__builtin_ctzll(todo);
+                                    todo &= todo - 1;
+                                    const uint32_t b = lowb + ix / 3, d = ix % 3 + 1;
+                                    const uint64_t mask = (uint64_t)d << (2 * b);
+                                    probe(mu[m2] ^ mask, mh[m2] ^ fold13(mask), mi[m2], ms[m2], false);
+                                }
+                            }
+                        }
+                    }
+                    PUG_ACC(3);
+                    if (!C.exact_umi)
+                        for (uint32_t b = 0; b < lowb; ++b)
+                            for (uint32_t d = 1; d < 4; ++d) {   // vertices of the partition one low-base change away: that one change
+                                const uint32_t q = pp ^ (d << (2 * b));
+                                const uint32_t oq = s_poff[q], nq = s_poff[q + 1] - oq;
+                                const uint64_t mask = (uint64_t)d << (2 * b);
+                                for (uint32_t i = tid; i < nq; i += kPugNT) {
+                                    const uint64_t w = pv_umi[oq + i];
+                                    const uint64_t pu = (w & kUmi44) ^ mask;
+                                    if (filt(fold16(pu))) probe(pu, fold13(pu), pv_info[oq + i], (uint32_t)(w >> 44), false);
+                                }
+                            }
+                    PUG_ACC(4);
+                }
+                __syncthreads();
+                fast = s_flag[0] <= pair_cap;
+#ifdef AFQ_PUG_TIMING
+                if (blockIdx.x < 4) { atomicAdd(&tacc[6], dbg_steps); atomicAdd(&tacc[7], dbg_probes); }
+                __syncthreads();
+#endif
+              }   // (more matches than the list holds: a cell full of near-identical UMIs - the global route sizes its lists exactly)
+            }
+            __syncthreads();
+        }
+    }
+    // ---- 4'. the global-memory route (hash table of the vertices by UMI in the cell's scratch, an LDS presence filter in
+    // front of it): cells whose partitions do not fit the LDS table ----
     // (every vertex with a given UMI sits on the probe run that starts at the UMI's home slot)
     constexpr unsigned long long kHtEmpty = ~0ull;
     const uint32_t ht_mask = ht_cap - 1;
     const uint32_t ht_shift = 64 - (uint32_t)__builtin_ctz(ht_cap);
     auto ht_home = [&](uint64_t umi) -> uint32_t { return (uint32_t)((umi * 0xD6E8FEB86659FD93ull) >> ht_shift); };
+    uint32_t* vflag = c_minoff;  // dead after phase 3: 1 = another vertex carries the same UMI
+    if (!fast) {
     for (uint32_t i = tid; i < ht_cap; i += kPugNT) htab[i] = kHtEmpty;
     for (uint32_t i = tid; i < (1u << 15); i += kPugNT) s_bloom[i] = 0;
     for (uint32_t v = tid; v < V; v += kPugNT) if (vv_umi[v] >> (64 - kVidBits)) s_cnt[3] = kErrPugLimit;
     __syncthreads();
     if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], cell); return; }
-    uint32_t* vflag = c_minoff;  // dead after phase 3: 1 = another vertex carries the same UMI
     for (uint32_t v = tid; v < V; v += kPugNT) vflag[v] = 0;
     __syncthreads();
     for (uint32_t v = tid; v < V; v += kPugNT) {
@@ -537,13 +760,16 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
             if ((old >> kVidBits) == umi) { vflag[v] = 1; vflag[(uint32_t)old & ((1u << kVidBits) - 1)] = 1; }
         }
     }
+    }
     PUG_MARK(11);
     auto bloom_bit = [](uint64_t umi) -> uint32_t { return (uint32_t)((umi * kHashMul) >> 44); };
     auto bloom_bit2 = [](uint64_t umi) -> uint32_t { return (uint32_t)(((umi ^ (umi >> 23)) * 0xD6E8FEB86659FD93ull) >> 44); };
+    if (!fast) {
     for (uint32_t v = tid; v < V; v += kPugNT) {
         const uint32_t b = bloom_bit(vv_umi[v]), b2 = bloom_bit2(vv_umi[v]);
         atomicOr(&s_bloom[b >> 5], 1u << (b & 31));
         atomicOr(&s_bloom[b2 >> 5], 1u << (b2 & 31));
+    }
     }
     __syncthreads();
     PUG_MARK(4);
@@ -564,9 +790,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     // (A) candidates (pu << 20 | x) appended in one pass to a list with room for 4V + 4096 of them (one LDS atomic per
     // wave and probe round); a cell whose filter lets more through than that takes the exact two-pass route
     // (count, reserve, write).
-    uint32_t NCAND = 0;
-    uint64_t* cand = nullptr;
-    {
+    if (!fast) {
         const uint32_t cand_cap = 4 * V + 4096;
         if (tid == 0) { s_ebase = atomicAdd(A.epool_cursor, 2ull * cand_cap + 2); s_flag[1] = 0; }
         __syncthreads();
@@ -641,11 +865,13 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     };
     // The UMI matches of the candidates go to a list with room for NCAND + V entries; only a cell with piles of
     // same-UMI vertices can overflow it, and then the candidates are walked the plain way (twice: count, fill).
-    const uint32_t pair_cap = NCAND + V;
+    if (!fast) {
+    pair_cap = NCAND + V;
     if (tid == 0) { s_ebase = atomicAdd(A.epool_cursor, 2ull * pair_cap + 2); s_flag[0] = 0; }
     __syncthreads();
     if (s_ebase + 2ull * pair_cap + 2 > A.epool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, cell); return; }
-    uint64_t* pairs = reinterpret_cast<uint64_t*>(A.epool + ((s_ebase + 1) & ~1ull));
+    pairs = reinterpret_cast<uint64_t*>(A.epool + ((s_ebase + 1) & ~1ull));
+    }
     // Two stages, each with four independent load chains per thread (a probe of the vertex table or of a
     // label is a far random access - the time goes into waiting, not computing):
     //  stage 1 walks the probe run of every candidate and lists the vertices that carry the probed UMI;
@@ -653,7 +879,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     //  of the candidates - and counts the out-degree of the survivors.
     constexpr uint64_t kNoPair = ~0ull;
     const uint32_t vmask = (1u << kVidBits) - 1;
-    for (uint32_t i0 = tid; i0 < NCAND; i0 += 4 * kPugNT) {
+    for (uint32_t i0 = tid; i0 < NCAND; i0 += 4 * kPugNT) {   // (NCAND = 0 on the LDS route: its matches are listed already)
         uint64_t cd[4], ux[4];
         unsigned long long e[4];
         uint32_t slot[4];
@@ -703,6 +929,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                if (fast) { cx[j] = 1; cy[j] = 0; kx[j] = 0; ky[j] = (pr[j] & kPairCheck) ? 1u : 0u; continue; }   // the count rule is applied, classes compared
                 const uint32_t x = pr[j] == kNoPair ? 0u : (uint32_t)(pr[j] >> 32) & vmask, y = pr[j] == kNoPair ? 0u : (uint32_t)pr[j] & vmask;
                 const uint4 va = vv[x], vb = vv[y];
                 cx[j] = va.x; cy[j] = vb.x; kx[j] = va.y; ky[j] = vb.y;
@@ -878,6 +1105,15 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
             if (myl.n <= 4) return t == lr0 || t == lr1 || t == lr2 || t == lr3;
             return lab_contains(myl, t);
         };
+        // the label of the vertex held by lane v, out of that lane's registers (a global read only for labels over four refs):
+        // the cover below walks candidate labels thousands of times per cell
+        auto lane_lab_n = [&](uint32_t v) -> uint32_t { return (uint32_t)__shfl((int)myl.n, (int)v); };
+        auto lane_lab_ref = [&](uint32_t v, uint32_t n_v, uint32_t j) -> uint32_t {
+            if (n_v <= 4) return (uint32_t)__shfl((int)(j == 0 ? lr0 : j == 1 ? lr1 : j == 2 ? lr2 : lr3), (int)v);
+            const uint64_t pa = (uint64_t)(uintptr_t)myl.p;
+            const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)pa, (int)v), hi = (uint32_t)__shfl((int)(uint32_t)(pa >> 32), (int)v);
+            return reinterpret_cast<const uint32_t*>((uintptr_t)(((uint64_t)hi << 32) | lo))[j] & 0x7FFFFFFFu;
+        };
         uint64_t adj = 0;
         if (act)
             for (uint32_t e = deg[myv]; e < deg[myv + 1]; ++e) adj |= 1ull << local_idx[edges[e]];
@@ -888,11 +1124,11 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
             uint32_t best_sz = 0;
             for (uint64_t it = UC; it; it &= it - 1) {   // ascending vertex id
                 const uint32_t v = (uint32_t)__builtin_ctzll(it);
-                const Lab lv = vlab(__shfl(myv, (int)v));
+                const uint32_t lvn = lane_lab_n(v);
                 uint64_t mv = 0;
                 uint32_t mv_sz = 0;
-                for (uint32_t j = 0; j < lv.n; ++j) {
-                    const uint32_t t = lv.p[j] & 0x7FFFFFFFu;
+                for (uint32_t j = 0; j < lvn; ++j) {
+                    const uint32_t t = lane_lab_ref(v, lvn, j);
                     const uint64_t At = __ballot(act && ((UC >> lane) & 1ull) && my_contains(t));
                     uint64_t Rm = 1ull << v, F = Rm;
                     while (F) {
@@ -909,12 +1145,12 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
             if (best == 0) { if (lane == 0) s_cnt[3] = kErrPugLimit; break; }  // vertex with an empty label
             // transcripts common to every vertex of the arborescence (pugutils.rs:1161-1188) -> genes
             const uint32_t fv = (uint32_t)__builtin_ctzll(best);
-            const Lab lf = vlab(__shfl(myv, (int)fv));
+            const uint32_t lfn = lane_lab_n(fv);
             uint32_t g[kMaxGenesPerLabel];
             uint32_t ng = 0;
             bool wide = false;
-            for (uint32_t j = 0; j < lf.n; ++j) {
-                const uint32_t t = lf.p[j] & 0x7FFFFFFFu;
+            for (uint32_t j = 0; j < lfn; ++j) {
+                const uint32_t t = lane_lab_ref(fv, lfn, j);
                 const uint64_t has = __ballot(act && ((best >> lane) & 1ull) && my_contains(t));
                 if (has != best) continue;
                 if (lane == 0) {
@@ -1123,6 +1359,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
 #ifdef AFQ_PUG_TIMING
     if (tid == 0 && blockIdx.x < 4 && (work % 1024) < 4) {
         auto ms = [&](int a, int b) { return (double)(tmark[b] - tmark[a]) / 1e5; };
+        printf("pug lds route: part+scatter=%.2f clear=%.2f insert=%.2f own=%.2f foreign=%.2f ms; probes=%llu run steps=%llu pairs=%u\n", tacc[0] / 1e5, tacc[1] / 1e5, tacc[2] / 1e5, tacc[3] / 1e5, tacc[4] / 1e5, tacc[7], tacc[6], n_pairs);
         printf("pug cell R=%u V=%u K=%u NC=%u nmid=%u nbig=%u: sort=%.2f classes=%.2f umis=%.2f verts=%.2f | htab=%.2f bloom=%.2f cand=%.2f (2pass=%.2f) match+rule=%.2f fill=%.2f | wcc=%.2f comps=%.2f 6a=%.2f mid=%.2f big=%.2f out=%.2f | total=%.2f NCAND=%u E=%u\n",
                R, V, K, NC, n_mid, n_big, ms(0, 1), ms(1, 2), ms(2, 3), 0.0, ms(3, 11), ms(11, 4), ms(4, 12), ms(12, 13), ms(13, 14), ms(14, 5),
                ms(5, 6), ms(6, 7), ms(7, 8), ms(8, 9), 0.0, ms(9, 10), ms(0, 10), NCAND, E);

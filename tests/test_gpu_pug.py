@@ -83,3 +83,46 @@ def test_components_beyond_one_wave(oracle):
         cfg = pkg.WorkerConfig.for_resolution(res, num_genes=3, num_rows=3, small_thresh=0)
         got, want = run_both(oracle, cfg, t2g, b, off)
         assert_same_result(got, want, what=res)
+
+
+def _quant(cfg, t2g, b, off):
+    q = pkg.Quantifier(cfg, t2g)
+    try:
+        return q.quant_chunks(b, off)
+    finally:
+        q.close()
+
+
+@pytest.mark.parametrize("res,usa", [("parsimony", False), ("parsimony-em", True)])
+def test_neighbour_search_routes_agree(oracle, monkeypatch, res, usa):
+    """The neighbour search runs out of an LDS hash table, the vertices cut into 4^k partitions by the low bases of their
+    UMIs (csrc/afq_pug.hip, phase 4); cells whose partitions would not fit take the older route through a hash table in
+    global memory.  Cell sizes for 1, 4, 16 and 64 partitions: both routes against each other, the smaller cells against
+    the oracle too."""
+    sizes = [150000, 30000, 9000, 2000, 400]
+    s = synth.synth(41, sizes, num_genes=2000, txp_per_gene=3, usa=usa, dup=0.3, cross=0.3, umi_err=0.04)
+    b, off = s.encode()
+    cfg = cfg_for(s, res)
+    fast = _quant(cfg, s.tid_to_gid, b, off)
+    monkeypatch.setenv("AFQ_PUG_GLOBAL_ROUTE", "1")
+    slow = _quant(cfg, s.tid_to_gid, b, off)
+    monkeypatch.delenv("AFQ_PUG_GLOBAL_ROUTE")
+    assert_same_result(fast, slow, what="LDS route vs global route")
+    want = oracle.quant(cfg, s.tid_to_gid, b, off[1:], n_threads=4)
+    for j in range(want.n_cells):
+        g0, v0 = fast.row(j + 1)
+        g1, v1 = want.row(j)
+        assert np.array_equal(g0, g1) and np.array_equal(v0.view(np.uint32), v1.view(np.uint32)), f"cell {j + 1}"
+
+
+def test_skewed_umis_fall_back_to_the_global_route(oracle):
+    """UMIs that all share their low bases land in ONE partition; above the table's capacity the cell silently takes the
+    global-memory route - same rows.  (Low bases fixed = e.g. a UMI read with a constant primer tail.)"""
+    rng = np.random.default_rng(8)
+    n = 24000
+    umi = (rng.integers(0, 1 << 16, n).astype(np.int64) << 8) | 0x5A      # 4 constant low bases, 8 random ones
+    reads = [(int(u), [int(t)] if t % 3 else [int(t), int(t) + 1]) for u, t in zip(umi, rng.integers(0, 300, n))]
+    b, off = rad.encode_cells([(9, reads)], 4, 4)
+    t2g = (np.arange(302) // 3).astype(np.uint32)
+    cfg = pkg.WorkerConfig.for_resolution("parsimony", num_genes=101, num_rows=101, umi_len=12)
+    assert_same_result(_quant(cfg, t2g, b, off), oracle.quant(cfg, t2g, b, off))
