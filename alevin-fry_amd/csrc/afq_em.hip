@@ -434,6 +434,9 @@ __global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict
         uint32_t e_cnt[kEmPer], e_sib[kEmPer], e_q0[kEmPer], e_q1[kEmPer];
         float acc[kEmPer];
         const float uni = 1.0f / (float)cfg.num_alphas;
+        if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
+        __syncthreads();
+        uint32_t n_hv_mine = 0;
 #pragma unroll
         for (uint32_t j = 0; j < kEmPer; ++j) {
             const uint32_t a = tid + j * kEmRNT;
@@ -442,9 +445,31 @@ __global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict
                 const uint4 e = ent[a];
                 e_cnt[j] = e.x; e_sib[j] = e.y | (e.z << 16); e_q0[j] = e.w; e_q1[j] = ent[a + 1].w;
                 vin[a] = cfg.init_uniform ? uni : ((float)e.x + 0.5f) * 1e-3f;
+                n_hv_mine += e_q1[j] - e_q0[j] > kEmHeavy;
             }
         }
+        // Entries that sit in many classes (highly expressed genes: hundreds of memberships) are summed by a whole wave each,
+        // the additions one after the other in class order (wave_ordered_sum).  Those entries have the lowest ids, i.e. they
+        // all belong to the threads of wave 0 - left there, one wave walks every long chain of the cell while fifteen wait
+        // at the barrier.  They go on a list in LDS instead (6 words each) and the waves take them in turn.
+        if (n_hv_mine) atomicAdd(&s_flag[1], n_hv_mine);
         if (tid == 0) { vin[Z0] = cfg.init_uniform ? uni : ((float)0u + 0.5f) * 1e-3f; vin[Z1] = 0.0f; }
+        __syncthreads();
+        const uint32_t NH = s_flag[1];
+        const bool hv_list = NH > 0 && need + 6 * NH <= kEmLdsWords;
+        uint32_t* hv = s_mem + need;   // {entry, count, siblings, q0, q1, result} per listed entry
+        uint32_t hv_mask = 0;          // bit j: my entry j is on the list (its owner leaves it alone)
+        if (hv_list) {
+#pragma unroll
+            for (uint32_t j = 0; j < kEmPer; ++j) {
+                const uint32_t a = tid + j * kEmRNT;
+                if (a < A && e_q1[j] - e_q0[j] > kEmHeavy) {
+                    const uint32_t i = atomicAdd(&s_flag[0], 1u);
+                    hv[6 * i] = a; hv[6 * i + 1] = e_cnt[j]; hv[6 * i + 2] = e_sib[j]; hv[6 * i + 3] = e_q0[j]; hv[6 * i + 4] = e_q1[j];
+                    hv_mask |= 1u << j;
+                }
+            }
+        }
         __syncthreads();
         EM2_MARK(1);
         uint32_t it = 0;
@@ -469,7 +494,7 @@ __global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict
 #pragma unroll
             for (uint32_t j = 0; j < kEmPer; ++j) {
                 const uint32_t a = tid + j * kEmRNT;
-                const bool valid = a < A;
+                const bool valid = a < A && !((hv_mask >> j) & 1u);
                 const bool heavy = valid && e_q1[j] - e_q0[j] > kEmHeavy;
                 float x = 0.0f, old = 0.0f, ab = 0.0f;
                 if (valid) {
@@ -493,14 +518,24 @@ __global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict
                     if (x > kAlphaCheckCutoff && fabsf(old - x) > kRelDiffTol) bad = true;
                 }
             }
+            if (hv_list)
+                for (uint32_t i = tid >> 6; i < NH; i += kEmRNT / 64) {   // the listed entries, a wave each, in turn
+                    const uint32_t a = hv[6 * i], hc = hv[6 * i + 1], hs = hv[6 * i + 2];
+                    const float old = vin[a];
+                    const float ab = (vin[hs & 0xFFFFu] + vin[hs >> 16]) + old;
+                    const float x = wave_ordered_sum(hc ? (float)hc : 0.0f, ab, hv[6 * i + 3], hv[6 * i + 4], [&](uint32_t q) { return inv[mb16[q]]; });
+                    if (lane_id() == 0) hv[6 * i + 5] = __float_as_uint(x);
+                    if (x > kAlphaCheckCutoff && fabsf(old - x) > kRelDiffTol) bad = true;
+                }
             if (bad) s_flag[0] = 1;
             __syncthreads();  // every read of the old abundances is done
             conv = s_flag[0] == 0;
 #pragma unroll
             for (uint32_t j = 0; j < kEmPer; ++j) {
                 const uint32_t a = tid + j * kEmRNT;
-                if (a < A) vin[a] = acc[j];
+                if (a < A && !((hv_mask >> j) & 1u)) vin[a] = acc[j];
             }
+            if (hv_list) for (uint32_t i = tid; i < NH; i += kEmRNT) vin[hv[6 * i]] = __uint_as_float(hv[6 * i + 5]);
             if (tid == 0) vin[Z0] = 0.0f;  // inactive entries come out of every round as 0
             ++it;
             __syncthreads();
@@ -537,6 +572,35 @@ __global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict
         float* vin = mid ? reinterpret_cast<float*>(s_mem) : sc.a_in;
         float* vout = sc.a_out;
         float* inv = mid ? reinterpret_cast<float*>(s_mem) + (A + 2) : sc.inv;
+        // ... and the memberships (class ids, 16 bits each) too when there is room: an entry's walk over its classes is then
+        // LDS reads only - out of global memory it is one dependent ~2 us load per class, round after round
+        const bool mb_lds = mid && K <= 65536u && (A + 2) + K + mb_words <= kEmLdsWords;
+        uint16_t* mb16 = reinterpret_cast<uint16_t*>(s_mem + (A + 2) + K);
+        if (mb_lds) for (uint32_t w = threadIdx.x; w < Wc; w += kEmRNT) mb16[w] = (uint16_t)memb[w];
+        auto memb_at = [&](uint32_t q) -> uint32_t { return mb_lds ? (uint32_t)mb16[q] : memb[q]; };
+        // the entries summed by a whole wave (see the on-chip tier): on a list in LDS, taken by the waves in turn
+        const uint32_t hv_base = (A + 2) + K + (mb_lds ? mb_words : 0u);
+        uint32_t* hv = s_mem + hv_base;   // {entry, count, siblings, q0, q1}
+        if (threadIdx.x == 0) { s_flag[0] = 0; s_flag[1] = 0; }
+        __syncthreads();
+        if (mid) {
+            uint32_t mine = 0;
+            for (uint32_t a = threadIdx.x; a < A; a += kEmRNT) mine += ent[a + 1].w - ent[a].w > 2 + kEmHeavy;
+            if (mine) atomicAdd(&s_flag[1], mine);
+        }
+        __syncthreads();
+        const uint32_t NH = s_flag[1];
+        const bool hv_list = mid && NH > 0 && hv_base + 5 * NH <= kEmLdsWords;
+        if (hv_list)
+            for (uint32_t a = threadIdx.x; a < A; a += kEmRNT) {
+                const uint4 e = ent[a];
+                const uint32_t q1 = ent[a + 1].w;
+                if (q1 - e.w > 2 + kEmHeavy) {
+                    const uint32_t i = atomicAdd(&s_flag[0], 1u);
+                    hv[5 * i] = a; hv[5 * i + 1] = e.x; hv[5 * i + 2] = e.y | (e.z << 16); hv[5 * i + 3] = e.w; hv[5 * i + 4] = q1;
+                }
+            }
+        EM2_MARK(1);
         const float uni = 1.0f / (float)cfg.num_alphas;
         for (uint32_t a = threadIdx.x; a < A; a += kEmRNT) vin[a] = cfg.init_uniform ? uni : ((float)ent[a].x + 0.5f) * 1e-3f;
         if (threadIdx.x == 0) { vin[Z0] = cfg.init_uniform ? uni : ((float)0u + 0.5f) * 1e-3f; vin[Z1] = 0.0f; }
@@ -595,15 +659,15 @@ __global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict
                 }
     #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    m0[j] = memb[e[j].w < qe[j] ? e[j].w : 0u];
-                    m1[j] = memb[e[j].w + 1 < qe[j] ? e[j].w + 1 : 0u];
+                    m0[j] = memb_at(e[j].w < qe[j] ? e[j].w : 0u);
+                    m1[j] = memb_at(e[j].w + 1 < qe[j] ? e[j].w + 1 : 0u);
                 }
     #pragma unroll
                 for (int j = 0; j < 4; ++j) { i0[j] = inv[m0[j]]; i1[j] = inv[m1[j]]; }
     #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const uint32_t a = a0 + j * kEmRNT;
-                    const bool valid = a < A;
+                    const bool valid = a < A && !(hv_list && qe[j] - e[j].w > 2 + kEmHeavy);   // (listed entries: below)
                     const bool heavy = valid && qe[j] - e[j].w > 2 + kEmHeavy;
                     float acc = 0.0f, old = 0.0f, ab = 0.0f;
                     if (valid) {
@@ -614,14 +678,14 @@ __global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict
                         if (e[j].w + 1 < qe[j] && i1[j] >= 0.0f) acc += ab * i1[j];
                         if (!heavy)
                             for (uint32_t q = e[j].w + 2; q < qe[j]; ++q) {
-                                const float iv = inv[memb[q]];
+                                const float iv = inv[memb_at(q)];
                                 if (iv >= 0.0f) acc += ab * iv;
                             }
                     }
                     for (uint64_t hm = __ballot(heavy); hm; hm &= hm - 1) {
                         const uint32_t L = (uint32_t)__builtin_ctzll(hm);
                         const float r = wave_ordered_sum(bcast_f32(acc, L), bcast_f32(ab, L), bcast_u32(e[j].w, L) + 2, bcast_u32(qe[j], L),
-                                                         [&](uint32_t q) { return inv[memb[q]]; });
+                                                         [&](uint32_t q) { return inv[memb_at(q)]; });
                         if (lane_id() == L) acc = r;
                     }
                     if (valid) {
@@ -630,6 +694,15 @@ __global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict
                     }
                 }
             }
+            if (hv_list)
+                for (uint32_t i = threadIdx.x >> 6; i < NH; i += kEmRNT / 64) {
+                    const uint32_t a = hv[5 * i], hc = hv[5 * i + 1], hs = hv[5 * i + 2];
+                    const float old = vin[a];
+                    const float ab = (vin[hs & 0xFFFFu] + vin[hs >> 16]) + old;
+                    const float x = wave_ordered_sum(hc ? (float)hc : 0.0f, ab, hv[5 * i + 3], hv[5 * i + 4], [&](uint32_t q) { return inv[memb_at(q)]; });
+                    if (lane_id() == 0) vout[a] = x;
+                    if (x > kAlphaCheckCutoff && fabsf(old - x) > kRelDiffTol) bad = true;
+                }
             if (bad) s_flag[0] = 1;
             __syncthreads();
             conv = s_flag[0] == 0;
@@ -646,6 +719,8 @@ __global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict
                 }
             }
         }
+        it_dbg = it + (mb_lds ? 1000u : 0u) + (mid ? 10000u : 0u);
+        EM2_MARK(2);
         // 6. floor and emit the non-zero alphas in column order (active ids ascend with the column)
         for (uint32_t base = 0; base < A; base += kEmRNT) {
             const uint32_t a = base + threadIdx.x;

@@ -394,6 +394,10 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     // the transcripts of one gene are the bulk of its matches, and ids that close never collide mod 19); the others still
     // get the exact comparison.  Labels of one or two ids are carried in the sort key itself: no read needed for them.
     uint32_t* c_sig = comp_start;   // (free until the components are listed)
+    // Labels of one or two refs - nine in ten - go into the vertex record itself (phase 3): whoever needs a vertex's label
+    // then has it with the one 16-byte access it makes anyway, instead of chasing the record offset into the chunk.
+    uint32_t* c_r0 = reinterpret_cast<uint32_t*>(htab);   // (the table's space is free until the global route, if taken at all)
+    uint32_t* c_r1 = c_r0 + R;
     auto sig_of = [](uint32_t t) -> uint32_t { return 1u << (t % 19u); };
     for (uint32_t i = tid; i < R; i += kPugNT) c_minoff[i] = 0xFFFFFFFFu;   // K <= R
     __syncthreads();
@@ -436,11 +440,13 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                     uint32_t sg = 0;
                     if (tag == 1) sg = sig_of((uint32_t)hk & 0x7FFFFFFFu);
                     else if (tag == 2) sg = sig_of((uint32_t)(hk >> 31) & 0x7FFFFFFFu) | sig_of((uint32_t)hk & 0x7FFFFFFFu);
-                    else if (tag == 3) {
+                    if (tag == 1) { c_r0[k] = (uint32_t)hk & 0x7FFFFFFFu; c_r1[k] = 0; }
+                    else if (tag == 2) { c_r0[k] = (uint32_t)(hk >> 31) & 0x7FFFFFFFu; c_r1[k] = (uint32_t)hk & 0x7FFFFFFFu; }
+                    if (tag == 3) {
                         if (!C.gene_level) { const Lab l = rec_label(C, ro); for (uint32_t q = 0; q < l.n; ++q) sg |= sig_of(l.p[q] & 0x7FFFFFFFu); }
                         else { uint32_t g[kMaxGenesPerLabel]; const uint32_t len = gene_list(ro, g); if (len != 0xFFFFFFFFu) for (uint32_t q = 0; q < len; ++q) sg |= sig_of(g[q]); else sg = 0x7FFFFu; }
                     }
-                    c_sig[k] = sg;
+                    c_sig[k] = sg | (tag << 20);   // bits 20-21: how many refs the label has (3 = more than two: read it from its record)
                 }
                 atomicMin(&c_minoff[k], ro);
                 if (!c && !label_key_is_exact(cur[j].h)) {
@@ -484,7 +490,12 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         __syncthreads();
     }
     auto vlab = [&](uint32_t v) -> Lab {  // label of a vertex: its class's ref list, or gene list at gene level
-        if (!C.gene_level) return rec_label(C, vv[v].z);
+        if (!C.gene_level) {
+            const uint4 q = vv[v];
+            const uint32_t code = q.x >> 20;   // 1 / 2: the refs sit in .z / .w of the vertex record; 0: empty; 3: in the chunk
+            if (code == 3) return rec_label(C, q.z);
+            return Lab{reinterpret_cast<const uint32_t*>(vv + v) + 2, code};
+        }
         const uint32_t k = vv[v].y;
         return Lab{c_glab + c_goff[k], c_goff[k + 1] - c_goff[k]};
     };
@@ -541,7 +552,9 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         const uint32_t k = v_cls[j];
         const uint32_t vid = c_base[k] + (j - c_vstart[k]);
         vv_umi[vid] = v_umi[j];
-        vv[vid] = make_uint4((j + 1 < V ? v_cnt[j + 1] : R) - v_cnt[j], k, c_rep[k], 0u);
+        const uint32_t code = C.gene_level ? 3u : c_sig[k] >> 20;
+        const bool inl = code == 1 || code == 2;
+        vv[vid] = make_uint4(((j + 1 < V ? v_cnt[j + 1] : R) - v_cnt[j]) | (code << 20), k, inl ? c_r0[k] : c_rep[k], inl ? c_r1[k] : 0u);
     }
     __syncthreads();
     PUG_MARK(3);
@@ -589,8 +602,8 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                     const uint32_t pp = (uint32_t)umi & (P - 1);
                     const uint32_t o = s_poff[pp] + atomicAdd(&fill[pp], 1u);
                     if (umi >> 44) s_flag[1] = 1;   // (the global route reports it)
-                    pv_umi[o] = umi | ((uint64_t)c_sig[q.y] << 44);   // key word of the table: UMI (<= 22 nt) + the label signature
-                    pv_info[o] = (uint64_t)v | ((uint64_t)q.x << 20) | ((uint64_t)q.y << 40);
+                    pv_umi[o] = umi | ((uint64_t)(c_sig[q.y] & 0x7FFFFu) << 44);   // key word of the table: UMI (<= 22 nt) + the label signature
+                    pv_info[o] = (uint64_t)v | ((uint64_t)(q.x & 0xFFFFFu) << 20) | ((uint64_t)q.y << 40);
                 }
                 pair_cap = 2 * V + 4096;
                 if (tid == 0) s_ebase = atomicAdd(A.epool_cursor, 2ull * pair_cap + 2);
@@ -710,17 +723,28 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                     }
                     PUG_ACC(3);
                     if (!C.exact_umi)
-                        for (uint32_t b = 0; b < lowb; ++b)
-                            for (uint32_t d = 1; d < 4; ++d) {   // vertices of the partition one low-base change away: that one change
+                        for (uint32_t b = 0; b < lowb; ++b) {   // vertices of the partitions one low-base change away: that one change.
+                            // The three source partitions of a base are read together (three loads in flight per thread; the
+                            // loop is all latency otherwise), the vertex's other word only when the filter lets the probe through.
+                            uint32_t oq[3], nq[3], nmax = 0;
+#pragma unroll
+                            for (uint32_t d = 1; d < 4; ++d) {
                                 const uint32_t q = pp ^ (d << (2 * b));
-                                const uint32_t oq = s_poff[q], nq = s_poff[q + 1] - oq;
-                                const uint64_t mask = (uint64_t)d << (2 * b);
-                                for (uint32_t i = tid; i < nq; i += kPugNT) {
-                                    const uint64_t w = pv_umi[oq + i];
-                                    const uint64_t pu = (w & kUmi44) ^ mask;
-                                    if (filt(fold16(pu))) probe(pu, fold13(pu), pv_info[oq + i], (uint32_t)(w >> 44), false);
+                                oq[d - 1] = s_poff[q]; nq[d - 1] = s_poff[q + 1] - oq[d - 1];
+                                nmax = nq[d - 1] > nmax ? nq[d - 1] : nmax;
+                            }
+                            for (uint32_t i = tid; i < nmax; i += kPugNT) {
+                                uint64_t w[3];
+#pragma unroll
+                                for (int d = 0; d < 3; ++d) w[d] = i < nq[d] ? pv_umi[oq[d] + i] : ~0ull;
+#pragma unroll
+                                for (int d = 0; d < 3; ++d) {
+                                    if (i >= nq[d]) continue;
+                                    const uint64_t pu = (w[d] & kUmi44) ^ ((uint64_t)(d + 1) << (2 * b));
+                                    if (filt(fold16(pu))) probe(pu, fold13(pu), pv_info[oq[d] + i], (uint32_t)(w[d] >> 44), false);
                                 }
                             }
+                        }
                     PUG_ACC(4);
                 }
                 __syncthreads();
@@ -850,7 +874,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         const uint64_t pu = cd >> kVidBits;
         const bool same = pu == vv_umi[x];
         const uint4 vx = vv[x];
-        const uint32_t cx = vx.x, kx = vx.y;
+        const uint32_t cx = vx.x & 0xFFFFFu, kx = vx.y;
         for (uint32_t slot = ht_home(pu);; slot = (slot + 1) & ht_mask) {
             const unsigned long long e = htab[slot];
             if (e == kHtEmpty) break;
@@ -858,7 +882,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
             const uint32_t y = (uint32_t)e & ((1u << kVidBits) - 1);
             if (y == x) continue;
             const uint4 vy = vv[y];
-            if (!same && !(vy.x < 2 * cx)) continue;
+            if (!same && !((vy.x & 0xFFFFFu) < 2 * cx)) continue;
             if (vy.y != kx && !lab_overlap(vlab(x), vlab(y))) continue;
             f(x, y);
         }
@@ -932,7 +956,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                 if (fast) { cx[j] = 1; cy[j] = 0; kx[j] = 0; ky[j] = (pr[j] & kPairCheck) ? 1u : 0u; continue; }   // the count rule is applied, classes compared
                 const uint32_t x = pr[j] == kNoPair ? 0u : (uint32_t)(pr[j] >> 32) & vmask, y = pr[j] == kNoPair ? 0u : (uint32_t)pr[j] & vmask;
                 const uint4 va = vv[x], vb = vv[y];
-                cx[j] = va.x; cy[j] = vb.x; kx[j] = va.y; ky[j] = vb.y;
+                cx[j] = va.x & 0xFFFFFu; cy[j] = vb.x & 0xFFFFFu; kx[j] = va.y; ky[j] = vb.y;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1202,7 +1226,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                 const uint32_t ng = genes_of(C, l.n, [&](uint32_t j) { return l.p[j] & 0x7FFFFFFFu; }, g);
                 if (ng == 0xFFFFFFFFu) continue;
                 const uint32_t o = atomicAdd(&s_flag[1], ng);
-                for (uint32_t q = 0; q < ng; ++q) trip[o + q] = make_uint4((uint32_t)vv_umi[v], (uint32_t)(vv_umi[v] >> 32), g[q], vv[v].x);
+                for (uint32_t q = 0; q < ng; ++q) trip[o + q] = make_uint4((uint32_t)vv_umi[v], (uint32_t)(vv_umi[v] >> 32), g[q], vv[v].x & 0xFFFFFu);
             }
             __syncthreads();
             const uint32_t nt = s_flag[1];
