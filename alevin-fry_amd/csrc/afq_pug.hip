@@ -564,6 +564,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     uint64_t* pairs = nullptr;
     uint32_t pair_cap = 0;
     constexpr uint64_t kPairRuled = 1ull << 62, kPairCheck = 1ull << 61;   // LDS route: count rule already applied / labels still to compare
+    constexpr uint64_t kPairBwd = 1ull << 60, kPairFwd = 1ull << 59;        // which of y -> x, x -> y the pair stands for (the LDS route meets a pair once)
     bool fast = false;
 #ifdef AFQ_PUG_TIMING
     if (tid == 0) { for (int q_ = 0; q_ < 8; ++q_) tacc[q_] = 0; tlast = wall_clock64(); }
@@ -648,8 +649,16 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                         if (((uint32_t)(k >> 44) & xsig) == 0) continue;   // labels without a common ref: no edge whatever the UMIs
                         const uint64_t info = t_val[slot];
                         const uint32_t y = (uint32_t)info & vm, x = (uint32_t)xinfo & vm;
-                        if (y == x) continue;
-                        if (!same && !(((uint32_t)(info >> 20) & vm) < 2 * ((uint32_t)(xinfo >> 20) & vm))) continue;
+                        // A pair of vertices is met ONCE - equal UMIs from the smaller vertex id, one-base neighbours from the
+                        // smaller UMI (the callers only probe upwards) - and both directions are decided here:
+                        // x -> y unless reads(y) >= 2 reads(x), y -> x unless reads(x) >= 2 reads(y); always both at distance 0.
+                        uint64_t dir = kPairFwd | kPairBwd;
+                        if (same) { if (y <= x) continue; }
+                        else {
+                            const uint32_t cy = (uint32_t)(info >> 20) & vm, cx = (uint32_t)(xinfo >> 20) & vm;
+                            dir = (cy < 2 * cx ? kPairFwd : 0ull) | (cx < 2 * cy ? kPairBwd : 0ull);
+                            if (!dir) continue;
+                        }
                         const uint64_t am = __ballot(true);   // one LDS atomic per wave, not per match
                         const uint32_t leader = (uint32_t)__builtin_ctzll(am);
                         uint32_t base = 0;
@@ -657,7 +666,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                         base = __builtin_amdgcn_readlane(base, (int)leader);
                         const uint32_t kk = base + (uint32_t)__popcll(am & ((1ull << lane) - 1));
                         if (kk < pair_cap)
-                            pairs[kk] = kPairRuled | ((uint32_t)(info >> 40) != (uint32_t)(xinfo >> 40) ? kPairCheck : 0ull) | ((uint64_t)same << 63) | ((uint64_t)x << 32) | y;
+                            pairs[kk] = kPairRuled | dir | ((uint32_t)(info >> 40) != (uint32_t)(xinfo >> 40) ? kPairCheck : 0ull) | ((uint64_t)same << 63) | ((uint64_t)x << 32) | y;
                     }
                 };
                 const uint32_t lowb = lgP / 2;   // bases whose change moves a UMI to another partition
@@ -706,7 +715,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                                 for (uint32_t d = 1; d < 4; ++d, ++idx) {
                                     const uint32_t df = fold16((uint64_t)d << (2 * b));
 #pragma unroll
-                                    for (int m2 = 0; m2 < 3; ++m2) pm[m2] |= (uint64_t)filt(mf[m2] ^ df) << idx;
+                                    for (int m2 = 0; m2 < 3; ++m2) pm[m2] |= (uint64_t)(filt(mf[m2] ^ df) & (uint32_t)((mu[m2] ^ ((uint64_t)d << (2 * b))) > mu[m2])) << idx;   // (upwards only)
                                 }
 #pragma unroll
                             for (int m2 = 0; m2 < 3; ++m2) {
@@ -741,7 +750,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                                 for (int d = 0; d < 3; ++d) {
                                     if (i >= nq[d]) continue;
                                     const uint64_t pu = (w[d] & kUmi44) ^ ((uint64_t)(d + 1) << (2 * b));
-                                    if (filt(fold16(pu))) probe(pu, fold13(pu), pv_info[oq[d] + i], (uint32_t)(w[d] >> 44), false);
+                                    if (pu > (w[d] & kUmi44) && filt(fold16(pu))) probe(pu, fold13(pu), pv_info[oq[d] + i], (uint32_t)(w[d] >> 44), false);
                                 }
                             }
                         }
@@ -966,8 +975,9 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                 const bool same = (pr[j] >> 63) != 0;
                 bool keep = same || cy[j] < 2 * cx[j];
                 if (keep && ky[j] != kx[j]) keep = lab_overlap(vlab(x), vlab(y));
-                if (keep) atomicAdd(&deg[x], 1u);
-                pairs[k] = keep ? (((uint64_t)x << 32) | y) : kNoPair;
+                const uint64_t dir = fast ? pr[j] & (kPairFwd | kPairBwd) : kPairFwd;
+                if (keep) { if (dir & kPairFwd) atomicAdd(&deg[x], 1u); if (dir & kPairBwd) atomicAdd(&deg[y], 1u); }
+                pairs[k] = keep ? (dir | ((uint64_t)x << 32) | y) : kNoPair;
             }
         }
     } else {
@@ -995,7 +1005,11 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     if (n_pairs <= pair_cap) {
         for (uint32_t k = tid; k < n_pairs; k += kPugNT) {
             const uint64_t pr = pairs[k];
-            if (pr != ~0ull) { edges[atomicAdd(&c_order[(uint32_t)(pr >> 32)], 1u)] = (uint32_t)pr; tch[(uint32_t)pr] = 1; }
+            if (pr != ~0ull) {
+                const uint32_t x = (uint32_t)(pr >> 32) & vmask, y = (uint32_t)pr & vmask;
+                if (pr & kPairFwd) { edges[atomicAdd(&c_order[x], 1u)] = y; tch[y] = 1; }
+                if (pr & kPairBwd) { edges[atomicAdd(&c_order[y], 1u)] = x; tch[x] = 1; }
+            }
         }
     } else {
         for (uint32_t i = tid; i < NCAND; i += kPugNT)
@@ -1112,19 +1126,72 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         emit_molecule(C, g, ng);
     }
     PUG_MARK(8);
-    // ---- 6b. components of 2..64 vertices: one wave each, adjacency = one 64-bit mask per lane ----
+    // ---- 6b. components of 3..64 vertices: one wave each, adjacency = one 64-bit mask per lane ----
+    // What a wave needs of its component - per vertex the label and the adjacency mask - sits five dependent global reads deep
+    // (list -> component bounds -> vertex id -> vertex record / edge range -> edge targets -> their local index), and a wave
+    // working alone on one component pays that chain in full, a thousand times per cell.  So the gathering is done first,
+    // by all threads over all such components at once (thread per vertex: the chains of a thousand vertices overlap), into
+    // 32-byte records laid out component by component; the cover then reads its records with one access, the next
+    // component's already on their way.
+    uint32_t* mid_off = mid_list + n_mid;   // [n_mid + 1] first record of each listed component (slab B has the room)
+    uint32_t S_mid = 0;
+    for (uint32_t base = 0; base < n_mid; base += kPugNT) {
+        const uint32_t ci = base + tid;
+        const uint32_t n = ci < n_mid ? comp_start[mid_list[ci] + 1] - comp_start[mid_list[ci]] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<kPugNT>(n, s_ws, tot);
+        if (ci < n_mid) mid_off[ci] = S_mid + ex;
+        S_mid += tot;
+    }
+    if (tid == 0) { mid_off[n_mid] = S_mid; s_ebase = atomicAdd(A.epool_cursor, 9ull * S_mid + 4); }
+    __syncthreads();
+    if (s_ebase + 9ull * S_mid + 4 > A.epool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, cell); return; }
+    uint4* mrec = reinterpret_cast<uint4*>(A.epool + ((s_ebase + 3) & ~3ull));   // two per vertex: {vid, label length, ref0 | ptr lo, ref1 | ptr hi}, {ref2, ref3, adjacency}
+    uint32_t* slot_comp = reinterpret_cast<uint32_t*>(mrec + 2 * (size_t)S_mid);
+    for (uint32_t ci = tid; ci < n_mid; ci += kPugNT) {
+        const uint32_t b0 = mid_off[ci], n = mid_off[ci + 1] - b0;
+        for (uint32_t i = 0; i < n; ++i) slot_comp[b0 + i] = ci;
+    }
+    __syncthreads();
+    for (uint32_t sl = tid; sl < S_mid; sl += kPugNT) {
+        const uint32_t ci = slot_comp[sl];
+        const uint32_t v = vid_at(comp_start[mid_list[ci]] + (sl - mid_off[ci]));
+        const Lab l = vlab(v);
+        uint32_t r0 = 0xFFFFFFFFu, r1 = 0xFFFFFFFFu, r2 = 0xFFFFFFFFu, r3 = 0xFFFFFFFFu;
+        if (l.n <= 4) {   // labels are short: up to four refs travel in the record
+            if (l.n > 0) r0 = l.p[0] & 0x7FFFFFFFu;
+            if (l.n > 1) r1 = l.p[1] & 0x7FFFFFFFu;
+            if (l.n > 2) r2 = l.p[2] & 0x7FFFFFFFu;
+            if (l.n > 3) r3 = l.p[3] & 0x7FFFFFFFu;
+        } else { const uint64_t pa = (uint64_t)(uintptr_t)l.p; r0 = (uint32_t)pa; r1 = (uint32_t)(pa >> 32); }
+        uint64_t adj = 0;
+        for (uint32_t e = deg[v]; e < deg[v + 1]; ++e) adj |= 1ull << local_idx[edges[e]];
+        mrec[2 * (size_t)sl] = make_uint4(v, l.n, r0, r1);
+        mrec[2 * (size_t)sl + 1] = make_uint4(r2, r3, (uint32_t)adj, (uint32_t)(adj >> 32));
+    }
+    __syncthreads();
+    {
+      // offsets two components ahead, records one ahead
+      uint32_t ob0 = 0, ob1 = 0, nb0 = 0, nb1 = 0;
+      if (wv < n_mid) { ob0 = mid_off[wv]; ob1 = mid_off[wv + 1]; }
+      if (wv + kPugNT / 64 < n_mid) { nb0 = mid_off[wv + kPugNT / 64]; nb1 = mid_off[wv + kPugNT / 64 + 1]; }
+      uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
+      if (lane < ob1 - ob0) { ra = mrec[2 * (size_t)(ob0 + lane)]; rb = mrec[2 * (size_t)(ob0 + lane) + 1]; }
     for (uint32_t ci = wv; ci < n_mid; ci += kPugNT / 64) {
-        const uint32_t c = mid_list[ci];
-        const uint32_t c0 = comp_start[c], n = comp_start[c + 1] - c0;
+        const uint32_t n = ob1 - ob0;
         const bool act = lane < n;
-        const uint32_t myv = act ? vid_at(c0 + lane) : 0u;
-        const Lab myl = act ? vlab(myv) : Lab{nullptr, 0};
-        // labels are short: keep up to four refs of the lane's label in registers
+        const uint4 qa = ra, qb = rb;
+        {   // next component's records, the one after's offsets
+            ob0 = nb0; ob1 = nb1;
+            ra = make_uint4(0, 0, 0, 0); rb = ra;
+            if (ci + kPugNT / 64 < n_mid && lane < ob1 - ob0) { ra = mrec[2 * (size_t)(ob0 + lane)]; rb = mrec[2 * (size_t)(ob0 + lane) + 1]; }
+            const uint32_t c2 = ci + 2 * (kPugNT / 64);
+            nb0 = c2 < n_mid ? mid_off[c2] : 0u; nb1 = c2 < n_mid ? mid_off[c2 + 1] : 0u;
+        }
+        Lab myl{nullptr, act ? qa.y : 0u};
         uint32_t lr0 = 0xFFFFFFFFu, lr1 = 0xFFFFFFFFu, lr2 = 0xFFFFFFFFu, lr3 = 0xFFFFFFFFu;
-        if (myl.n > 0) lr0 = myl.p[0] & 0x7FFFFFFFu;
-        if (myl.n > 1) lr1 = myl.p[1] & 0x7FFFFFFFu;
-        if (myl.n > 2) lr2 = myl.p[2] & 0x7FFFFFFFu;
-        if (myl.n > 3) lr3 = myl.p[3] & 0x7FFFFFFFu;
+        if (act && myl.n <= 4) { lr0 = qa.z; lr1 = qa.w; lr2 = qb.x; lr3 = qb.y; }
+        else if (act) myl.p = reinterpret_cast<const uint32_t*>((uintptr_t)(((uint64_t)qa.w << 32) | qa.z));
         auto my_contains = [&](uint32_t t) -> bool {
             if (myl.n <= 4) return t == lr0 || t == lr1 || t == lr2 || t == lr3;
             return lab_contains(myl, t);
@@ -1138,9 +1205,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
             const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)pa, (int)v), hi = (uint32_t)__shfl((int)(uint32_t)(pa >> 32), (int)v);
             return reinterpret_cast<const uint32_t*>((uintptr_t)(((uint64_t)hi << 32) | lo))[j] & 0x7FFFFFFFu;
         };
-        uint64_t adj = 0;
-        if (act)
-            for (uint32_t e = deg[myv]; e < deg[myv + 1]; ++e) adj |= 1ull << local_idx[edges[e]];
+        const uint64_t adj = act ? (((uint64_t)qb.w << 32) | qb.z) : 0ull;
         uint64_t UC = n == 64 ? ~0ull : ((1ull << n) - 1);
         while (UC) {
             const uint32_t remaining = (uint32_t)__popcll(UC);
@@ -1190,6 +1255,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
             if (lane == 0) emit_molecule(C, g, wide ? 0xFFFFFFFFu : ng);
             UC &= ~best;
         }
+    }
     }
     __syncthreads();
     PUG_MARK(9);
