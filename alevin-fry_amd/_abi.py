@@ -114,6 +114,7 @@ EXPORTS = [
     "afq_destroy",
     "afq_submit",
     "afq_submit_device",
+    "afq_submit_reader",
     "afq_collect",
     "afq_result_release",
     "afq_result_eqclasses",

@@ -223,6 +223,9 @@ def load_library(path: str = LIB_PATH):
     # host gets /opt/rocm's).  See DESIGN.md "one HIP runtime per process".
     try:
         import torch  # noqa: F401
+
+        if torch.cuda.is_available():
+            torch.cuda.init()   # torch brings its HIP runtime up first; initialising it AFTER this library has used HIP finds no GPU
     except ImportError:
         pass
     if not os.path.exists(path):

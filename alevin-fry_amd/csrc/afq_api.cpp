@@ -768,8 +768,14 @@ unsigned stage_threads() {
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     return std::min(16u, std::max(4u, hw / 4));
 }
-int staged_h2d(afq_ctx* c, uint8_t* dst, const uint8_t* src, size_t n, hipStream_t s, bool pinned) {
-    if (pinned || n < 2 * kStagePiece) { HIP_TRY(c, hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, s)); return 0; }
+struct ByteSource {   // where afq_submit's input comes from: the caller's buffer, or a reader callback (afq_submit_reader)
+    const uint8_t* bytes = nullptr;
+    afq_read_fn read = nullptr;
+    void* user = nullptr;
+};
+int staged_h2d(afq_ctx* c, uint8_t* dst, const uint8_t* src, size_t n, hipStream_t s, bool pinned, const ByteSource* rd = nullptr, uint64_t rd_off = 0) {
+    const bool use_reader = rd && rd->read;
+    if (!use_reader && (pinned || n < 2 * kStagePiece)) { HIP_TRY(c, hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, s)); return 0; }
     for (int i = 0; i < 3; ++i) {
         if (!c->stage[i]) HIP_TRY(c, hipHostMalloc(&c->stage[i], kStagePiece, hipHostMallocDefault));
         if (!c->stage_ev[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming));
@@ -782,12 +788,15 @@ int staged_h2d(afq_ctx* c, uint8_t* dst, const uint8_t* src, size_t n, hipStream
         HIP_TRY(c, hipEventSynchronize(c->stage_ev[b]));   // the copy that last used this piece (in this call or an earlier one) is done
         std::vector<std::thread> th;
         const size_t slice = (len + nth - 1) / nth;
+        std::vector<int> bad(nth, 0);
         for (unsigned t = 0; t < nth; ++t) {
             const size_t a = t * slice, e = std::min(len, a + slice);
             if (a >= e) break;
-            th.emplace_back([=]() { std::memcpy((uint8_t*)c->stage[b] + a, src + off + a, e - a); });
+            if (use_reader) th.emplace_back([=, &bad]() { if (rd->read(rd->user, rd_off + off + a, (uint8_t*)c->stage[b] + a, e - a) != 0) bad[t] = 1; });
+            else th.emplace_back([=]() { std::memcpy((uint8_t*)c->stage[b] + a, src + off + a, e - a); });
         }
         for (auto& x : th) x.join();
+        for (int x : bad) if (x) return fail(c, AFQ_ERR_BAD_INPUT, "the input reader reported an error");
         HIP_TRY(c, hipMemcpyAsync(dst + off, c->stage[b], len, hipMemcpyHostToDevice, s));
         HIP_TRY(c, hipEventRecord(c->stage_ev[b], s));
         off += len;
@@ -932,10 +941,9 @@ void afq_destroy(afq_ctx* c) {
     delete c;
 }
 
-int afq_submit(afq_ctx* c, const uint8_t* bytes, size_t n_bytes, const uint64_t* chunk_off, uint32_t n_cells,
-               uint64_t first_cell_index) {
-    if (!c) return AFQ_ERR_INVALID_ARG;
-    if ((!bytes && n_bytes) || (!chunk_off && n_cells)) return fail(c, AFQ_ERR_INVALID_ARG, "null argument");
+static int submit_host(afq_ctx* c, const ByteSource& src, size_t n_bytes, const uint64_t* chunk_off, const uint32_t* chunk_hdr,
+                       uint32_t n_cells, uint64_t first_cell_index) {
+    const uint8_t* bytes = src.bytes;
     if (c->pending) return fail(c, AFQ_ERR_STATE, "previous batch not collected");
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = check_supported(c);
@@ -945,7 +953,8 @@ int afq_submit(afq_ctx* c, const uint8_t* bytes, size_t n_bytes, const uint64_t*
     for (uint32_t i = 0; i < n_cells; ++i) {
         if (chunk_off[i] + 8 > n_bytes) return fail(c, AFQ_ERR_BAD_INPUT, "cell " + std::to_string(i) + ": chunk offset out of range");
         uint32_t h[2];
-        std::memcpy(h, bytes + chunk_off[i], 8);
+        if (chunk_hdr) { h[0] = chunk_hdr[2 * i]; h[1] = chunk_hdr[2 * i + 1]; }
+        else std::memcpy(h, bytes + chunk_off[i], 8);
         c->hdr[2 * i] = h[0];
         c->hdr[2 * i + 1] = h[1];
     }
@@ -969,10 +978,10 @@ int afq_submit(afq_ctx* c, const uint8_t* bytes, size_t n_bytes, const uint64_t*
     if (rc) return rc;
     if (shift) HIP_TRY(c, hipMemsetAsync(c->d_bytes_own.p, 0, 4, c->stream));
     HIP_TRY(c, hipMemsetAsync(dst + n_bytes, 0, 16, c->stream));
-    const bool pinned = n_bytes && host_ptr_is_pinned(bytes) && host_ptr_is_pinned(bytes + n_bytes - 1);
+    const bool pinned = !src.read && n_bytes && host_ptr_is_pinned(bytes) && host_ptr_is_pinned(bytes + n_bytes - 1);
     const size_t k = c->ranges.size();
     if (k < 2 || !ascending || std::getenv("AFQ_NO_H2D_PIPELINE")) {
-        if (n_bytes) { int rc2 = staged_h2d(c, dst, bytes, n_bytes, c->stream, pinned); if (rc2) return rc2; }
+        if (n_bytes) { int rc2 = staged_h2d(c, dst, bytes, n_bytes, c->stream, pinned, &src, 0); if (rc2) return rc2; }
         HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller keeps ownership of `bytes`
         return run_batch(c);
     }
@@ -980,12 +989,12 @@ int afq_submit(afq_ctx* c, const uint8_t* bytes, size_t n_bytes, const uint64_t*
     while (c->h2d_ev.size() < k) { hipEvent_t e = nullptr; HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->h2d_ev.push_back(e); }
     c->h2d_piped = true;
     c->up_enqueued = 0; c->up_rc = 0; c->up_err.clear();
-    auto upload = [&, bytes, pinned, k]() {
+    auto upload = [&, bytes, pinned, k, shift]() {
         (void)hipSetDevice(c->device);
         for (size_t i = 0; i < k; ++i) {
             uint64_t a, b;
             range_span(c, c->ranges[i], a, b);   // device-buffer coordinates (shift included)
-            int rc2 = staged_h2d(c, (uint8_t*)c->d_bytes_own.p + a, bytes + (a - shift), (size_t)(b - a), c->stream, pinned);
+            int rc2 = staged_h2d(c, (uint8_t*)c->d_bytes_own.p + a, bytes ? bytes + (a - shift) : nullptr, (size_t)(b - a), c->stream, pinned, &src, a - shift);
             if (!rc2 && hipEventRecord(c->h2d_ev[i], c->stream) != hipSuccess) rc2 = AFQ_ERR_HIP;
             std::lock_guard<std::mutex> lk(c->up_mu);
             if (rc2) { c->up_rc = rc2; c->up_err = c->err.empty() ? "input upload failed" : c->err; }
@@ -1008,6 +1017,24 @@ int afq_submit(afq_ctx* c, const uint8_t* bytes, size_t n_bytes, const uint64_t*
     }
     c->h2d_piped = false;
     return rc;
+}
+
+int afq_submit(afq_ctx* c, const uint8_t* bytes, size_t n_bytes, const uint64_t* chunk_off, uint32_t n_cells,
+               uint64_t first_cell_index) {
+    if (!c) return AFQ_ERR_INVALID_ARG;
+    if ((!bytes && n_bytes) || (!chunk_off && n_cells)) return fail(c, AFQ_ERR_INVALID_ARG, "null argument");
+    ByteSource src;
+    src.bytes = bytes;
+    return submit_host(c, src, n_bytes, chunk_off, nullptr, n_cells, first_cell_index);
+}
+
+int afq_submit_reader(afq_ctx* c, afq_read_fn read, void* user, size_t n_bytes, const uint64_t* chunk_off, const uint32_t* chunk_hdr,
+                      uint32_t n_cells, uint64_t first_cell_index) {
+    if (!c) return AFQ_ERR_INVALID_ARG;
+    if (!read || (n_cells && (!chunk_off || !chunk_hdr))) return fail(c, AFQ_ERR_INVALID_ARG, "null argument");
+    ByteSource src;
+    src.read = read; src.user = user;
+    return submit_host(c, src, n_bytes, chunk_off, chunk_hdr, n_cells, first_cell_index);
 }
 
 int afq_submit_device(afq_ctx* c, const void* d_bytes, size_t n_bytes, const uint64_t* chunk_off, uint32_t n_cells,

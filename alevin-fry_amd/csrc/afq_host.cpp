@@ -613,9 +613,23 @@ static std::vector<size_t> balanced_cuts(const std::vector<uint64_t>& nbytes, si
     return cuts;
 }
 
+// the collated file as afq_submit_reader sees it: pread into the library's pinned staging - the page cache is copied once, by
+// several threads, without the page-fault storm that reading the same bytes through a fresh mapping sets off
+struct FileSource { int fd; uint64_t base; };
+static int file_read_cb(void* user, uint64_t offset, void* dst, size_t len) {
+    const FileSource* f = static_cast<const FileSource*>(user);
+    uint8_t* d = static_cast<uint8_t*>(dst);
+    while (len) {
+        const ssize_t g = ::pread(f->fd, d, len, (off_t)(f->base + offset));
+        if (g <= 0) return -1;
+        d += g; offset += (uint64_t)g; len -= (size_t)g;
+    }
+    return 0;
+}
+
 static void run_device_range(const afq_config& cfg, const afq_config* cfg_eq, const std::vector<uint32_t>& t2g, int device,
-                             const uint8_t* rad, const std::vector<uint64_t>& chunk_off, const std::vector<uint64_t>& chunk_nb,
-                             size_t cell0, size_t cell1, uint64_t batch_bytes, bool want_eq, bool res_is_em, DevOut& out) {
+                             const uint8_t* rad, int rad_fd, const std::vector<uint64_t>& chunk_off, const std::vector<uint64_t>& chunk_nb,
+                             const std::vector<uint32_t>& chunk_nr, size_t cell0, size_t cell1, uint64_t batch_bytes, bool want_eq, bool res_is_em, DevOut& out) {
     auto now = []() { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     afq_ctx* raw = nullptr;
@@ -636,7 +650,13 @@ static void run_device_range(const afq_config& cfg, const afq_config* cfg_eq, co
         for (size_t k = c0; k < c1; ++k) rel[k - c0] = chunk_off[k] - span0;
         const uint64_t span1 = chunk_off[c1 - 1] + chunk_nb[c1 - 1];   // with --quant-subset the span also covers chunks that were filtered out
         auto ta = now();
-        rc = afq_submit(ctx.get(), rad + span0, (size_t)(span1 - span0), rel.data(), (uint32_t)(c1 - c0), c0);
+        if (rad_fd >= 0) {   // an uncompressed file: the library pulls the bytes itself (pread into its staging)
+            FileSource fs{rad_fd, span0};
+            std::vector<uint32_t> hdr(2 * (c1 - c0));
+            for (size_t k = c0; k < c1; ++k) { hdr[2 * (k - c0)] = (uint32_t)chunk_nb[k]; hdr[2 * (k - c0) + 1] = chunk_nr[k]; }
+            rc = afq_submit_reader(ctx.get(), file_read_cb, &fs, (size_t)(span1 - span0), rel.data(), hdr.data(), (uint32_t)(c1 - c0), c0);
+        } else
+            rc = afq_submit(ctx.get(), rad + span0, (size_t)(span1 - span0), rel.data(), (uint32_t)(c1 - c0), c0);
         auto tb = now();
         afq_result res{};
         if (!rc) rc = afq_collect(ctx.get(), &res);
@@ -910,12 +930,13 @@ int afq_quantify(const afq_quant_opts* o) {
     // chunk table: hop the nbytes headers (what the producer thread does)
     const uint32_t rec_hdr = 4 + P.bc_bytes + P.umi_bytes;
     std::vector<uint64_t> chunk_off, chunk_nb;
+    std::vector<uint32_t> chunk_nr;
     for (size_t p = P.first_chunk; p < rad.size();) {
         if (p + 8 > rad.size()) return hfail(AFQ_ERR_BAD_INPUT, "trailing bytes after the last chunk");
         uint32_t nb, nr; std::memcpy(&nb, rad.data() + p, 4); std::memcpy(&nr, rad.data() + p + 4, 4);
         if (nb < 8 || p + nb > rad.size()) return hfail(AFQ_ERR_BAD_INPUT, "corrupt chunk header");
         if (nr == 0 || nb < 8 + rec_hdr) return hfail(AFQ_ERR_BAD_INPUT, "chunk " + std::to_string(chunk_off.size()) + " holds no record");   // (quant.rs:756 panics)
-        chunk_off.push_back(p); chunk_nb.push_back(nb); p += nb;
+        chunk_off.push_back(p); chunk_nb.push_back(nb); chunk_nr.push_back(nr); p += nb;
     }
     auto cell_key_of = [&](uint64_t raw_bc) -> uint64_t { return multi_bc ? raw_bc >> (8 * w_sample) : raw_bc; };
     // --quant-subset (src/quant.rs:1523-1536, 1776): the first record's collate key decides
@@ -927,8 +948,9 @@ int afq_quantify(const afq_quant_opts* o) {
         while (std::getline(f, line)) { while (!line.empty() && std::isspace((unsigned char)line.back())) line.pop_back(); uint64_t v; if (!line.empty() && string_to_bc(line, v)) keep.insert(v); }
         subset_size = keep.size();
         std::vector<uint64_t> kept, kept_nb;
-        for (size_t i = 0; i < chunk_off.size(); ++i) { uint64_t bc = 0; std::memcpy(&bc, rad.data() + chunk_off[i] + 8 + 4, P.bc_bytes); if (keep.count(cell_key_of(bc))) { kept.push_back(chunk_off[i]); kept_nb.push_back(chunk_nb[i]); } }
-        chunk_off.swap(kept); chunk_nb.swap(kept_nb);
+        std::vector<uint32_t> kept_nr;
+        for (size_t i = 0; i < chunk_off.size(); ++i) { uint64_t bc = 0; std::memcpy(&bc, rad.data() + chunk_off[i] + 8 + 4, P.bc_bytes); if (keep.count(cell_key_of(bc))) { kept.push_back(chunk_off[i]); kept_nb.push_back(chunk_nb[i]); kept_nr.push_back(chunk_nr[i]); } }
+        chunk_off.swap(kept); chunk_nb.swap(kept_nb); chunk_nr.swap(kept_nr);
     }
     // transcript-to-gene map (src/utils.rs:487-662)
     std::unordered_map<std::string, uint32_t> rname_to_id;
@@ -1023,7 +1045,7 @@ int afq_quantify(const afq_quant_opts* o) {
     std::vector<DevOut> parts(devices.size());
     {
         auto work = [&](size_t d) {
-            run_device_range(cfg, cfg_eq.dump_eq ? &cfg_eq : nullptr, t2g, devices[d], rad.data(), chunk_off, chunk_nb, cuts[d], cuts[d + 1],
+            run_device_range(cfg, cfg_eq.dump_eq ? &cfg_eq : nullptr, t2g, devices[d], rad.data(), compressed ? -1 : mf.fd, chunk_off, chunk_nb, chunk_nr, cuts[d], cuts[d + 1],
                              batch_bytes, o->dump_eq != 0, res_is_em, parts[d]);
         };
         if (devices.size() == 1) work(0);

@@ -12,7 +12,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-from .afquant import LIB_PATH
+from .afquant import LIB_PATH, load_library
 
 
 class SynthParams(C.Structure):
@@ -97,6 +97,7 @@ _LIB = None
 def _lib():
     global _LIB
     if _LIB is None:
+        load_library()   # (one HIP runtime per process: torch's comes up first, see afquant.load_library)
         lib = C.CDLL(LIB_PATH)
         P = C.POINTER
         lib.afq_synth_dims.argtypes = [P(SynthParams), P(C.c_uint32), P(C.c_uint32), P(C.c_uint32)]

@@ -138,6 +138,17 @@ int afq_submit(afq_ctx* ctx, const uint8_t* bytes, size_t n_bytes, const uint64_
                uint32_t n_cells, uint64_t first_cell_index);
 
 /*
+ * Same, for a host that would rather be asked for the bytes than hold them all in memory (the reference's producer reads
+ * the collated file chunk by chunk, src/quant.rs:1773-1784): `read(user, offset, dst, len)` fills dst with bytes
+ * [offset, offset + len) of the chunk stream and returns 0; it is called from several threads at once, with dst in pinned
+ * staging memory, while earlier parts are already on their way to the device (a pread on a file descriptor is all it has
+ * to be).  chunk_hdr = the 8-byte chunk headers (nbytes, nrec per cell), which the host has from walking the chunk table.
+ */
+typedef int (*afq_read_fn)(void* user, uint64_t offset, void* dst, size_t len);
+int afq_submit_reader(afq_ctx* ctx, afq_read_fn read, void* user, size_t n_bytes, const uint64_t* chunk_off,
+                      const uint32_t* chunk_hdr, uint32_t n_cells, uint64_t first_cell_index);
+
+/*
  * Same, for chunk bytes already resident in this context's device memory
  * (what a host that overlaps H2D itself would use; bench.py times this form).
  * `d_bytes` must stay valid until afq_collect returns.  `chunk_off` is host

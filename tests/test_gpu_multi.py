@@ -299,3 +299,44 @@ def test_reference_binary_hook(tmp_path, oracle):
         return {(rows[int(r) - 1], cols[int(c) - 1]): float(v) for r, c, v in (l.split() for l in body[1:])}
 
     assert load(ref_out) == load(our_out)   # cr-like is integer-exact and order-independent
+
+
+def test_submit_reader_pulls_the_bytes_through_a_callback(monkeypatch):
+    """afq_submit_reader: the library asks for byte ranges of the chunk stream (several threads, pinned destinations) instead
+    of being handed a buffer - what the CLI front-end does with pread on the collated file.  Same rows as afq_submit, with
+    one range and with many, and a failing reader is an error, not a hang."""
+    import ctypes as C
+
+    s = synth.synth(78, [6000, 5000, 3000, 2500, 900, 700, 400, 300, 120, 80, 33, 5] * 2, num_genes=200, dup=0.4, umi_err=0.02)
+    b, off = s.encode()
+    b = np.ascontiguousarray(np.asarray(b))
+    cfg = cfg_for(s, "cr-like")
+    q = pkg.Quantifier(cfg, s.tid_to_gid, device=0)
+    READ = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t)
+    calls = []
+
+    def reader(user, offset, dst, n):
+        calls.append((offset, n))
+        C.memmove(dst, b.ctypes.data + offset, n)
+        return 0
+
+    cb = READ(reader)
+    q.lib.afq_submit_reader.argtypes = [C.c_void_p, READ, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint64]
+    q.lib.afq_submit_reader.restype = C.c_int
+    hdr = np.ascontiguousarray(np.stack([b.view(np.uint32)[off // 4], b.view(np.uint32)[off // 4 + 1]], axis=1).astype(np.uint32))
+    o64 = np.ascontiguousarray(off, dtype=np.uint64)
+    try:
+        want = q.quant_chunks(b, off)
+        for rng in (None, "300000"):
+            if rng:
+                monkeypatch.setenv("AFQ_RANGE_BYTES", rng)
+            rc = q.lib.afq_submit_reader(q._h, cb, None, b.nbytes, o64.ctypes.data_as(C.POINTER(C.c_uint64)), hdr.ctypes.data_as(C.POINTER(C.c_uint32)), len(off), 0)
+            assert rc == 0, q.lib.afq_last_error(q._h)
+            assert_same_result(q.collect(), want, what=f"reader, ranges {rng}")
+        assert sum(n for _, n in calls) >= 2 * b.nbytes
+        bad = READ(lambda user, offset, dst, n: -1)
+        rc = q.lib.afq_submit_reader(q._h, bad, None, b.nbytes, o64.ctypes.data_as(C.POINTER(C.c_uint64)), hdr.ctypes.data_as(C.POINTER(C.c_uint32)), len(off), 0)
+        assert rc == pkg._abi.AFQ_ERR_BAD_INPUT
+        assert_same_result(q.quant_chunks(b, off), want)   # the context is usable afterwards
+    finally:
+        q.close()
