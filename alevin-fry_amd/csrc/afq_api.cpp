@@ -863,7 +863,9 @@ int afq_abi_version(void) { return AFQ_ABI_VERSION; }
 
 int afq_device_warmup(int device) {
     if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return AFQ_ERR_NO_DEVICE; }
-    return hipFree(nullptr) == hipSuccess ? 0 : AFQ_ERR_NO_DEVICE;
+    if (hipFree(nullptr) != hipSuccess) return AFQ_ERR_NO_DEVICE;
+    warm_code_object();
+    return 0;
 }
 
 const char* afq_last_error(const afq_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }

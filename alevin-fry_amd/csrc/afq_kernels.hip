@@ -1053,6 +1053,12 @@ __global__ __launch_bounds__(256) void k_atac_compact(const uint64_t* __restrict
 
 
 
+// first touch of a kernel loads the library's code object on the current device (tens of ms): afq_device_warmup does it early
+void warm_code_object() {
+    hipFuncAttributes at{};
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(k_hist));
+}
+
 void launch_hist(hipStream_t s, const ResolveArgs& a) {
     if (!a.n_tiles) return;
     AFQ_LAUNCH(k_hist, a.n_tiles, 256, s, a.multi_cells, a.tile_prefix, a.n_multi, a.meta, a.cell_nkeys, a.keys0, a.cursor);
