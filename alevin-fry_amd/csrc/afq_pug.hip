@@ -18,6 +18,7 @@
 // multi-word masks (one mask word per lane, candidate vertices spread over the waves).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "afq_common.h"
 #include "afq_kernels.h"
@@ -42,7 +43,7 @@ constexpr uint32_t kMaxBigComp = 4096;            // vertices of a component the
 // reads | class).  A 1-mismatch probe of a vertex stays in the vertex's own partition unless it changes one of the low k
 // bases, and then it lands in exactly one other partition - so every pass knows which vertices can have a neighbour in it.
 constexpr uint32_t kTabSlots = 8192;              // 64 KiB of keys + 64 KiB of values
-constexpr uint32_t kPartTarget = 3000;            // planned vertices per partition
+constexpr uint32_t kPartTarget = 4500;            // planned vertices per partition (a pass has a fixed cost in latency: few, well-filled ones)
 constexpr uint32_t kPartMax = 5400;               // a partition above this (skewed UMIs) sends the cell down the global-memory route
 constexpr uint32_t kMaxParts = 1024;
 
@@ -60,13 +61,19 @@ __device__ __forceinline__ u128 rec_key(const SortRec& r) { return ((u128)r.h <<
 // here the reads are split on sampled keys into buckets of ~2048 (one counting pass, one scatter pass) and every bucket
 // is sorted once, in registers (reg_bitonic_sort: cross-lane stages on the VALU, a handful of trips through LDS).
 // Keys are unique (uo ends in the read's offset / index), so the splitters always separate.  A bucket over 4096
-// records (skewed sample) falls back to the network.  tile: LDS for 4096 records; aux: LDS, 6 * 512 + 2 words.
-constexpr uint32_t kSortBucket = 2048, kSortWaveBucket = 256, kSortTile = 4096, kSortMaxBuckets = 512;
+// records (skewed sample) falls back to the network.  tile: LDS for 4096 records; aux: LDS, 6 * 1024 + 2 words.
+constexpr uint32_t kSortBucket = 2048, kSortWaveBucket = 96, kSortWaveMax = 384, kSortTile = 4096, kSortMaxBuckets = 1024;
 // (Not inlined: inside the cell kernel its register-resident tiles would share one allocation with everything that is
 // live across the sort there, and spill in the inner loops.)
+#ifdef AFQ_PUG_TIMING
+#define SORT_MARK(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 4 && tm) tm[i] = wall_clock64(); } while (0)
+#else
+#define SORT_MARK(i) do {} while (0)
+#endif
 template <int NT>
 __device__ __noinline__ void sample_sort_reads(SortRec* sr, uint32_t* bid, uint32_t R, const uint64_t* rd_h, const uint64_t* rd_u,
-                                               const uint32_t* rd_o, bool wide_umi, SortRec* tile, uint32_t* aux, uint32_t* s_ws) {
+                                               const uint32_t* rd_o, bool wide_umi, SortRec* tile, uint32_t* aux, uint32_t* s_ws,
+                                               [[maybe_unused]] unsigned long long* tm = nullptr) {
     const uint32_t tid = threadIdx.x;
     auto load = [&](uint32_t i) {
         SortRec r;
@@ -90,10 +97,14 @@ __device__ __noinline__ void sample_sort_reads(SortRec* sr, uint32_t* bid, uint3
         sort_tile(sr, R);
         return;
     }
-    // cells up to 2^17 reads: buckets of ~256, each sorted by ONE wave in its registers (512 slots: no LDS, no barriers);
-    // beyond that ~2048 per bucket, sorted by the workgroup
-    const bool wave_buckets = R <= kSortWaveBucket * kSortMaxBuckets;
-    const uint32_t target = wave_buckets ? kSortWaveBucket : kSortBucket;
+    // Buckets sorted by ONE wave each in its registers (no LDS, no barriers), in the smallest network that holds the bucket:
+    // 128, 256 or 512 slots.  A bitonic network costs log2(n)^2/2 stages per slot whether the slot holds a record or a
+    // sentinel, so the buckets are planned small (~96 reads: 28 stages in the 128-slot network, three quarters full - the
+    // 512-slot one, half full, was 2.4 x the work per read); cells too big for 1024 such buckets get proportionally larger
+    // ones, and beyond ~400 k reads ~2048 per bucket, sorted by the workgroup.
+    const bool wave_buckets = R <= kSortWaveMax * kSortMaxBuckets;
+    uint32_t target = wave_buckets ? kSortWaveBucket : kSortBucket;
+    if (wave_buckets && (uint64_t)target * kSortMaxBuckets < R) target = (R + kSortMaxBuckets - 1) / kSortMaxBuckets;
     uint32_t nb = (R + target - 1) / target;
     nb = nb > kSortMaxBuckets ? kSortMaxBuckets : nb;
     const uint32_t ns = 64 * nb < kSortTile ? 64 * nb : kSortTile;
@@ -105,18 +116,28 @@ __device__ __noinline__ void sample_sort_reads(SortRec* sr, uint32_t* bid, uint3
     for (uint32_t i = tid; i < nb; i += NT) cnt[i] = 0;
     if (tid == 0) *flag = 0;
     __syncthreads();
+    SORT_MARK(0);
     sort_tile(sr, ns);
     for (uint32_t j = tid; j + 1 < nb; j += NT) spl[j] = sr[(uint32_t)(((uint64_t)(j + 1) * ns) / nb)];
     __syncthreads();
-    for (uint32_t i = tid; i < R; i += NT) {
-        const SortRec r = load(i);
-        uint32_t lo = 0, hi = nb - 1;   // bucket = number of splitters below r
-        const u128 rk = rec_key(r);
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (rk > rec_key(spl[mid])) lo = mid + 1; else hi = mid; }
-        bid[i] = lo;
-        atomicAdd(&cnt[lo], 1u);
+    SORT_MARK(1);
+    for (uint32_t i0 = tid; i0 < R; i0 += 4 * NT) {   // four reads per thread and trip: their loads go out together
+        SortRec r4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r4[j] = i0 + j * NT < R ? load(i0 + j * NT) : SortRec{0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t i = i0 + j * NT;
+            if (i >= R) continue;
+            uint32_t lo = 0, hi = nb - 1;   // bucket = number of splitters below r
+            const u128 rk = rec_key(r4[j]);
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (rk > rec_key(spl[mid])) lo = mid + 1; else hi = mid; }
+            bid[i] = lo;
+            atomicAdd(&cnt[lo], 1u);
+        }
     }
     __syncthreads();
+    SORT_MARK(2);
     {
         const uint32_t c = tid < nb ? cnt[tid] : 0u;
         uint32_t tot;
@@ -132,27 +153,38 @@ __device__ __noinline__ void sample_sort_reads(SortRec* sr, uint32_t* bid, uint3
         tiled_bitonic_sort_by<NT, kSortTile>(reinterpret_cast<u128*>(sr), R, [](u128 a, u128 b) { return a > b; }, tile128);
         return;
     }
-    for (uint32_t i = tid; i < R; i += NT) {
-        const uint32_t b = bid[i];
-        sr[off[b] + atomicAdd(&cnt[b], 1u)] = load(i);
+    for (uint32_t i0 = tid; i0 < R; i0 += 4 * NT) {
+        SortRec r4[4];
+        uint32_t b4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint32_t i = i0 + j * NT; r4[j] = i < R ? load(i) : SortRec{0, 0}; b4[j] = i < R ? bid[i] : 0u; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (i0 + j * NT < R) sr[off[b4[j]] + atomicAdd(&cnt[b4[j]], 1u)] = r4[j];
     }
     __syncthreads();
+    SORT_MARK(3);
     if (wave_buckets) {
-        constexpr int E = 8;   // 512 slots per wave
         u128* a128 = reinterpret_cast<u128*>(sr);
         const uint32_t lane = lane_id();
-        for (uint32_t b = tid >> 6; b < nb; b += NT / 64) {
-            const uint32_t o = off[b], n = off[b + 1] - o;
-            if (n < 2 || n > 64 * E) continue;   // oversize buckets (a skewed sample) are left to the workgroup below
+        auto sort_bucket = [&](auto Etag, uint32_t o, uint32_t n) {
+            constexpr int E = decltype(Etag)::value;
             u128 a[E];
 #pragma unroll
             for (int h = 0; h < E; ++h) a[h] = (uint32_t)(h * 64) + lane < n ? a128[o + h * 64 + lane] : sentinel;
             wave_bitonic_sort<E, u128>(a);
 #pragma unroll
             for (int h = 0; h < E; ++h) if ((uint32_t)(h * 64) + lane < n) a128[o + h * 64 + lane] = a[h];
+        };
+        for (uint32_t b = tid >> 6; b < nb; b += NT / 64) {
+            const uint32_t o = off[b], n = off[b + 1] - o;
+            if (n < 2 || n > 512) continue;   // oversize buckets (a skewed sample) are left to the workgroup below
+            if (n <= 128) sort_bucket(std::integral_constant<int, 2>{}, o, n);
+            else if (n <= 256) sort_bucket(std::integral_constant<int, 4>{}, o, n);
+            else sort_bucket(std::integral_constant<int, 8>{}, o, n);
         }
         __syncthreads();
-        for (uint32_t b = 0; b < nb; ++b) if (off[b + 1] - off[b] > 64 * E) sort_tile(sr + off[b], off[b + 1] - off[b]);
+        SORT_MARK(4);
+        for (uint32_t b = 0; b < nb; ++b) if (off[b + 1] - off[b] > 512) sort_tile(sr + off[b], off[b + 1] - off[b]);
         return;
     }
     for (uint32_t b = 0; b < nb; ++b) sort_tile(sr + off[b], off[b + 1] - off[b]);
@@ -268,6 +300,44 @@ __device__ __forceinline__ void emit_molecule(const PugCtx& c, const uint32_t* g
     c.cols[p] = col;
 }
 
+// emit_molecule for a gene label of one or two ids (g0 < g1) held in registers - nine molecules in ten.  Returns the column
+// the molecule counts for (the CALLER appends it: one reservation per wave, see append_cols) or 0xFFFFFFFF when there is
+// none (dropped, or kept as a two-gene class for the EM - written here).
+__device__ __forceinline__ uint32_t molecule2_column(const PugCtx& c, uint32_t g0, uint32_t g1, uint32_t ng) {
+    uint32_t col = 0xFFFFFFFFu;
+    auto sua = [&](uint32_t g) { return (g & 1u) == 0 ? (g >> 1) : c.uo + (g >> 1); };
+    if (ng == 1) col = c.usa ? sua(g0) : g0;
+    else if (c.usa && ((g0 ^ g1) & ~1u) == 0) col = c.ao + (g0 >> 1);
+    else if (c.em) {
+        const uint32_t off = atomicAdd(&c.s_cnt[1], 2u), di = atomicAdd(&c.s_cnt[2], 1u);
+        if (off + 2 > c.lab_cap || 2 * (di + 1) > c.lab_cap) { c.s_cnt[3] = kErrPugLimit; return 0xFFFFFFFFu; }
+        c.labw[off] = g0; c.labw[off + 1] = g1;
+        c.labd[2 * di] = off; c.labd[2 * di + 1] = 2;
+        return 0xFFFFFFFFu;
+    } else if (c.usa) {
+        const bool s1 = (g0 & 1u) == 0, s2 = (g1 & 1u) == 0;
+        if (s1 && !s2) col = g0 >> 1;
+        else if (!s1 && s2) col = g1 >> 1;
+    }
+    if (col != 0xFFFFFFFFu && col >= c.num_rows) { c.s_cnt[3] = kErrSlotRange; return 0xFFFFFFFFu; }
+    return col;
+}
+// Append one column per lane that has one.  Called by all lanes of the wave together: the lanes share ONE reservation on the
+// cell's column counter - a same-address LDS atomic per molecule is serviced lane by lane, with sixteen waves queueing.
+__device__ __forceinline__ void append_cols(const PugCtx& c, uint32_t col) {
+    const bool has = col != 0xFFFFFFFFu;
+    const uint64_t m = __ballot(has);
+    if (!m) return;
+    const uint32_t lane = lane_id(), leader = (uint32_t)__builtin_ctzll(m);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&c.s_cnt[0], (uint32_t)__popcll(m));
+    base = __builtin_amdgcn_readlane(base, (int)leader);
+    if (has) {
+        const uint32_t p = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        if (p >= c.cols_cap) c.s_cnt[3] = kErrPugLimit; else c.cols[p] = col;
+    }
+}
+
 __device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
 #pragma unroll
@@ -291,6 +361,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
 #ifdef AFQ_PUG_TIMING
     __shared__ unsigned long long tmark[24];
     __shared__ unsigned long long tacc[8];
+    __shared__ unsigned long long tsort[8];
     __shared__ unsigned long long tlast;
 #endif
     __shared__ uint32_t s_next;
@@ -367,7 +438,11 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         }
         uint32_t* bid = reinterpret_cast<uint32_t*>(sr) + 4 * (size_t)R;   // slab A has 6R words, the records take 4R
         sample_sort_reads<kPugNT>(sr, bid, R, A.rd.h + rd_base, A.rd.u + rd_base, A.rd.o + rd_base, wide_umi,
-                                  reinterpret_cast<SortRec*>(s_big), s_big + 4 * kSortTile, s_ws);
+                                  reinterpret_cast<SortRec*>(s_big), s_big + 4 * kSortTile, s_ws
+#ifdef AFQ_PUG_TIMING
+                                  , tsort
+#endif
+                                  );
     }
     PUG_MARK(1);
     // ---- 2. vertices = distinct (label, umi); classes = distinct labels ----
@@ -1094,12 +1169,39 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     // A two-vertex component is always one molecule: it is weakly connected, so one of the two can reach the
     // other through a shared transcript and the greedy cover takes that 2-vertex arborescence first; its label
     // is the transcripts the two labels share (pugutils.rs:1161-1188) - never empty, an edge needs an overlap.
-    for (uint32_t v = tid; v < V; v += kPugNT) {   // vertices without an edge: one molecule each, the label's genes
-        if (deg[v + 1] > deg[v] || tch[v]) continue;
-        const Lab l = vlab(v);
-        uint32_t g[kMaxGenesPerLabel];
-        const uint32_t ng = genes_of(C, l.n, [&](uint32_t j) { return l.p[j] & 0x7FFFFFFFu; }, g);
-        emit_molecule(C, g, ng);
+    // vertices without an edge: one molecule each, the label's genes.  Four vertices per thread and trip, their loads issued
+    // together; labels of one or two refs (in the vertex record) never touch the chunk or a gene array.
+    for (uint32_t v0 = tid; v0 - lane < V; v0 += 4 * kPugNT) {   // wave-uniform trip count (append_cols is a wave-wide call)
+        uint4 q4[4];
+        bool lone[4], shrt[4];
+        uint32_t ga[4], gb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t v = v0 + j * kPugNT;
+            lone[j] = v < V && !(deg[v + 1] > deg[v] || tch[v]);
+            q4[j] = v < V ? vv[v] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t code = q4[j].x >> 20;
+            shrt[j] = lone[j] && !C.gene_level && (code == 1 || code == 2);
+            ga[j] = shrt[j] ? C.t2g[q4[j].z] : 0u;
+            gb[j] = shrt[j] && code == 2 ? C.t2g[q4[j].w] : ga[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t col = 0xFFFFFFFFu;
+            if (lone[j] && shrt[j]) {
+                const uint32_t lo = ga[j] < gb[j] ? ga[j] : gb[j], hi = ga[j] < gb[j] ? gb[j] : ga[j];
+                col = molecule2_column(C, lo, hi, lo == hi ? 1u : 2u);
+            } else if (lone[j]) {
+                const Lab l = vlab(v0 + j * kPugNT);
+                uint32_t g[kMaxGenesPerLabel];
+                const uint32_t ng = genes_of(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; }, g);
+                emit_molecule(C, g, ng);
+            }
+            append_cols(C, col);   // (v0 - lane is wave-uniform: every lane of the wave gets here)
+        }
     }
     for (uint32_t c = tid; c < NC; c += kPugNT) {
         const uint32_t n = comp_start[c + 1] - comp_start[c];
@@ -1449,6 +1551,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
 #ifdef AFQ_PUG_TIMING
     if (tid == 0 && blockIdx.x < 4 && (work % 1024) < 4) {
         auto ms = [&](int a, int b) { return (double)(tmark[b] - tmark[a]) / 1e5; };
+        printf("pug sort: sample-load=%.2f sample-sort=%.2f classify=%.2f scan+scatter=%.2f wave-sorts=%.2f ms\n", (double)(tsort[0] - tmark[0]) / 1e5, (double)(tsort[1] - tsort[0]) / 1e5, (double)(tsort[2] - tsort[1]) / 1e5, (double)(tsort[3] - tsort[2]) / 1e5, (double)(tsort[4] - tsort[3]) / 1e5);
         printf("pug lds route: part+scatter=%.2f clear=%.2f insert=%.2f own=%.2f foreign=%.2f ms; probes=%llu run steps=%llu pairs=%u\n", tacc[0] / 1e5, tacc[1] / 1e5, tacc[2] / 1e5, tacc[3] / 1e5, tacc[4] / 1e5, tacc[7], tacc[6], n_pairs);
         printf("pug cell R=%u V=%u K=%u NC=%u nmid=%u nbig=%u: sort=%.2f classes=%.2f umis=%.2f verts=%.2f | htab=%.2f bloom=%.2f cand=%.2f (2pass=%.2f) match+rule=%.2f fill=%.2f | wcc=%.2f comps=%.2f 6a=%.2f mid=%.2f big=%.2f out=%.2f | total=%.2f NCAND=%u E=%u\n",
                R, V, K, NC, n_mid, n_big, ms(0, 1), ms(1, 2), ms(2, 3), 0.0, ms(3, 11), ms(11, 4), ms(4, 12), ms(12, 13), ms(13, 14), ms(14, 5),
