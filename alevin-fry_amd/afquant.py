@@ -276,6 +276,10 @@ def load_library(path: str = LIB_PATH):
     return lib
 
 
+class _Held(np.ndarray):
+    """ndarray view that keeps the owner of its memory alive."""
+
+
 class Quantifier:
     """One per device: config + tid_to_gid resident on the GPU (afq_ctx)."""
 
@@ -394,7 +398,7 @@ class Quantifier:
             for q in (o_ptr, o_ref, o_start, o_len, o_cnt):
                 self.lib.afq_free(q)
 
-    def atac_dedup_rad(self, chunk_bytes, chunk_off, bc_bytes: int = 4, d_ptr: int = 0, n_bytes: int = 0):
+    def atac_dedup_rad(self, chunk_bytes, chunk_off, bc_bytes: int = 4, d_ptr: int = 0, n_bytes: int = 0, copy: bool = True):
         """afq_atac_dedup_rad: collated scATAC chunks in (host bytes, or d_ptr/n_bytes for bytes already on the device),
         (cell_ptr, bc, ref, start, frag_len, count, stats dict) out."""
         off = np.ascontiguousarray(chunk_off, dtype=np.uint64)
@@ -409,11 +413,30 @@ class Quantifier:
         st = _abi.AfqAtacStats()
         self._check(self.lib.afq_atac_dedup_rad(self._h, ptr, nb, off.ctypes.data_as(C.POINTER(C.c_uint64)), n_cells, bc_bytes, on_dev,
                                                 C.byref(o_ptr), C.byref(o_bc), C.byref(o_ref), C.byref(o_start), C.byref(o_len), C.byref(o_cnt), C.byref(st)))
+        cp = np.ctypeslib.as_array(o_ptr, shape=(n_cells + 1,)).copy()
+        n = int(cp[-1])
+        stats = {k: int(getattr(st, k)) for k, _ in st._fields_}
+        if not copy:   # views over the library's (pinned) arrays, handed back to it when the last view dies
+            import weakref
+
+            lib, ptrs = self.lib, (o_ptr, o_bc, o_ref, o_start, o_len, o_cnt)
+
+            class _Own:
+                pass
+
+            own = _Own()
+            weakref.finalize(own, lambda: [lib.afq_free(q) for q in ptrs])
+
+            def view(p_, k):
+                a = np.ctypeslib.as_array(p_, shape=(max(k, 1),))[:k]
+                a.flags.writeable = False
+                keep = np.ndarray.__new__(_Held, a.shape, a.dtype, a, 0, a.strides)
+                keep._own = own
+                return keep
+
+            return cp, view(o_bc, n_cells), view(o_ref, n), view(o_start, n), view(o_len, n), view(o_cnt, n), stats
         try:
-            cp = np.ctypeslib.as_array(o_ptr, shape=(n_cells + 1,)).copy()
-            n = int(cp[-1])
             mk = lambda p_, dt, k: (np.ctypeslib.as_array(p_, shape=(k,)).astype(dt, copy=True) if k else np.zeros(0, dt))
-            stats = {k: int(getattr(st, k)) for k, _ in st._fields_}
             return cp, mk(o_bc, np.uint64, n_cells), mk(o_ref, np.uint32, n), mk(o_start, np.uint32, n), mk(o_len, np.uint16, n), mk(o_cnt, np.uint16, n), stats
         finally:
             for q in (o_ptr, o_bc, o_ref, o_start, o_len, o_cnt):

@@ -1210,10 +1210,37 @@ int afq_infer(afq_ctx* c, const uint32_t* eq_labels, const uint64_t* eq_label_pt
     return 0;
 }
 
+// The ATAC entry points hand out gigabytes of results: into pageable malloc memory the D2H runs at a fraction of the link.
+// Their output arrays are pinned instead and recycled through a process-wide pool (afq_free returns them to it).
+namespace {
+struct PinnedPool {
+    std::mutex mu;
+    struct Ent { void* p; size_t cap; bool busy; };
+    std::vector<Ent> ents;
+    void* get(size_t n) {
+        std::lock_guard<std::mutex> g(mu);
+        Ent* best = nullptr;
+        for (auto& e : ents) if (!e.busy && e.cap >= n && (!best || e.cap < best->cap)) best = &e;
+        if (best) { best->busy = true; return best->p; }
+        void* q = nullptr;
+        const size_t cap = n + n / 8 + 4096;
+        if (hipHostMalloc(&q, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        ents.push_back({q, cap, true});
+        return q;
+    }
+    bool put(void* p) {
+        std::lock_guard<std::mutex> g(mu);
+        for (auto& e : ents) if (e.p == p) { e.busy = false; return true; }
+        return false;
+    }
+};
+PinnedPool* pinned_pool() { static PinnedPool* P = new PinnedPool(); return P; }
+}  // namespace
+
 // Shared back half of the two ATAC entry points: de-duplicate the fragments sitting in d_ref/d_start/d_flen (cell i at
 // d_ptr[i], cell_cnt[i] of them when d_cnt is given, else up to d_ptr[i+1]) and hand the distinct ones out as malloc'd arrays.
 static int atac_dedup_device(afq_ctx* c, uint64_t n, uint32_t n_cells, const uint32_t* d_cnt, uint64_t** out_cell_ptr, uint32_t** out_ref,
-                             uint32_t** out_start, uint16_t** out_frag_len, uint16_t** out_count, HostClock& hc) {
+                             uint32_t** out_start, uint16_t** out_frag_len, uint16_t** out_count, HostClock& hc, unsigned long long* tally_out = nullptr) {
     DevBuf &d_ref = c->atac[0], &d_start = c->atac[1], &d_flen = c->atac[2], &d_ptr = c->atac[3], &d_scr = c->atac[4],
            &d_oref = c->atac[5], &d_ostart = c->atac[6], &d_oflen = c->atac[7], &d_ocnt = c->atac[8], &d_on = c->atac[9],
            &d_optr = c->atac[10], &d_cref = c->atac[11], &d_cstart = c->atac[12], &d_cflen = c->atac[13], &d_ccnt = c->atac[14],
@@ -1255,32 +1282,36 @@ static int atac_dedup_device(afq_ctx* c, uint64_t n, uint32_t n_cells, const uin
     optr[0] = 0;
     for (uint32_t i = 0; i < n_cells; ++i) optr[i + 1] = optr[i] + on[i];
     const uint64_t tot = optr[n_cells], tot1 = std::max<uint64_t>(tot, 1);
-    uint32_t* oref = (uint32_t*)std::malloc(4 * tot1);
-    uint32_t* ostart = (uint32_t*)std::malloc(4 * tot1);
-    uint16_t* oflen = (uint16_t*)std::malloc(2 * tot1);
-    uint16_t* ocnt = (uint16_t*)std::malloc(2 * tot1);
+    uint32_t* oref = (uint32_t*)pinned_pool()->get(4 * tot1);
+    uint32_t* ostart = (uint32_t*)pinned_pool()->get(4 * tot1);
+    uint16_t* oflen = (uint16_t*)pinned_pool()->get(2 * tot1);
+    uint16_t* ocnt = (uint16_t*)pinned_pool()->get(2 * tot1);
     if (!oref || !ostart || !oflen || !ocnt) {
-        std::free(optr); std::free(oref); std::free(ostart); std::free(oflen); std::free(ocnt);
+        std::free(optr); afq_free(oref); afq_free(ostart); afq_free(oflen); afq_free(ocnt);
         return fail(c, AFQ_ERR_OOM, "afq_atac_dedup: host allocation failed");
     }
     // dense runs on the device, then straight into the caller's arrays
     T(d_cref.ensure(4 * tot1)); T(d_cstart.ensure(4 * tot1)); T(d_cflen.ensure(2 * tot1)); T(d_ccnt.ensure(2 * tot1));
     if (e == hipSuccess) T(hipMemcpyAsync(d_optr.p, optr, 8ull * (n_cells + 1), hipMemcpyHostToDevice, s));
+    DevBuf& d_tally = c->atac[24];
+    T(d_tally.ensure(16));
+    if (e == hipSuccess) T(hipMemsetAsync(d_tally.p, 0, 16, s));
     if (e == hipSuccess && tot) {
         launch_atac_compact(s, n_cells, d_ptr.as<uint64_t>(), d_optr.as<uint64_t>(), d_oref.as<uint32_t>(), d_ostart.as<uint32_t>(),
                             d_oflen.as<uint16_t>(), d_ocnt.as<uint16_t>(), d_cref.as<uint32_t>(), d_cstart.as<uint32_t>(),
-                            d_cflen.as<uint16_t>(), d_ccnt.as<uint16_t>());
+                            d_cflen.as<uint16_t>(), d_ccnt.as<uint16_t>(), tally_out ? d_tally.as<unsigned long long>() : nullptr);
         T(hipGetLastError());
         T(hipMemcpyAsync(oref, d_cref.p, 4 * tot, hipMemcpyDeviceToHost, s));
         T(hipMemcpyAsync(ostart, d_cstart.p, 4 * tot, hipMemcpyDeviceToHost, s));
         T(hipMemcpyAsync(oflen, d_cflen.p, 2 * tot, hipMemcpyDeviceToHost, s));
         T(hipMemcpyAsync(ocnt, d_ccnt.p, 2 * tot, hipMemcpyDeviceToHost, s));
     }
+    if (e == hipSuccess && tally_out) T(hipMemcpyAsync(tally_out, d_tally.p, 16, hipMemcpyDeviceToHost, s));
     if (e == hipSuccess) T(hipStreamSynchronize(s));
     hc.lap("atac: compact + D2H");
     harvest_timers(c);
     if (e != hipSuccess) {
-        std::free(optr); std::free(oref); std::free(ostart); std::free(oflen); std::free(ocnt);
+        std::free(optr); afq_free(oref); afq_free(ostart); afq_free(oflen); afq_free(ocnt);
         return fail(c, e == hipErrorOutOfMemory ? AFQ_ERR_OOM : AFQ_ERR_HIP, std::string("afq_atac_dedup: ") + hipGetErrorString(e));
     }
     *out_cell_ptr = optr; *out_ref = oref; *out_start = ostart; *out_frag_len = oflen; *out_count = ocnt;
@@ -1397,7 +1428,8 @@ int afq_atac_dedup_rad(afq_ctx* c, const uint8_t* bytes, size_t n_bytes, const u
     if (e == hipSuccess) e = hipStreamSynchronize(s);   // the caller keeps ownership of `bytes`: the copy out of them is done by now, too
     if (e != hipSuccess) { std::free(obc); return fail(c, AFQ_ERR_HIP, std::string("afq_atac_dedup_rad: ") + hipGetErrorString(e)); }
     if (st.err_code) { std::free(obc); return fail(c, AFQ_ERR_BAD_INPUT, "cell " + std::to_string(st.err_cell) + ": chunk nbytes does not match its records"); }
-    int rc = atac_dedup_device(c, n_rec, n_cells, d_cnt.as<uint32_t>(), out_cell_ptr, out_ref, out_start, out_frag_len, out_count, hc);
+    unsigned long long tally[2] = {0, 0};
+    int rc = atac_dedup_device(c, n_rec, n_cells, d_cnt.as<uint32_t>(), out_cell_ptr, out_ref, out_start, out_frag_len, out_count, hc, tally);
     if (rc) { std::free(obc); return rc; }
     *out_bc = obc;
     if (stats) {
@@ -1406,13 +1438,13 @@ int afq_atac_dedup_rad(afq_ctx* c, const uint8_t* bytes, size_t n_bytes, const u
         for (uint32_t i = 0; i < n_cells; ++i) { stats->n_multimapped += stat[2 * i]; stats->n_not_mapped_pair += stat[2 * i + 1]; }
         const uint64_t tot = (*out_cell_ptr)[n_cells];
         stats->n_distinct = tot;
-        for (uint64_t k = 0; k < tot; ++k) { if ((*out_count)[k] > 1) ++stats->n_deduplicated; if ((*out_frag_len)[k] >= 2000) ++stats->n_long_fragments; }
+        stats->n_deduplicated = tally[0]; stats->n_long_fragments = tally[1];   // (tallied by the compaction kernel)
         stats->n_fallback_cells = st.n_fallback;
     }
     return 0;
 }
 
-void afq_free(void* p) { std::free(p); }
+void afq_free(void* p) { if (p && !pinned_pool()->put(p)) std::free(p); }
 
 int afq_get_kernel_times(afq_ctx* c, afq_kernel_time* out, uint32_t cap) {
     if (!c || (!out && cap)) return AFQ_ERR_INVALID_ARG;

@@ -48,16 +48,25 @@ __global__ __launch_bounds__(kParseNT) void k_atac_parse(AtacParseArgs a) {
     if (tid == 0) { s_cnt = 0; s_multi = 0; s_non = 0; }
     const bool has_first = nb >= 8 + H;
     const uint64_t bc0 = has_first ? ldbc(ch + 12, a.bc_bytes) : 0;
-    // ---- pass A: candidate bits
-    for (uint32_t base = 0; base < nb; base += kParseNT) {
-        const uint32_t p = base + tid;
-        bool cand = false;
-        if (p >= 8 && p + H <= nb && ldbc(ch + p + 4, a.bc_bytes) == bc0) {
-            const uint32_t na = ld32(ch + p);
-            cand = na <= (nb - p - H) / 11u;
+    // ---- pass A: candidate bits (four tiles of 256 positions per trip: the loads of all four are in flight together -
+    // one position per thread and trip left the loop waiting out one memory round trip per 256 bytes)
+    for (uint32_t base = 0; base < nb; base += 4 * kParseNT) {
+        uint64_t bcv[4];
+        uint32_t nav[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t p = base + j * kParseNT + tid;
+            const bool in = p >= 8 && p + H <= nb;
+            bcv[j] = in ? ldbc(ch + p + 4, a.bc_bytes) : ~bc0;
+            nav[j] = in ? ld32(ch + p) : 0xFFFFFFFFu;
         }
-        const uint64_t m = __ballot(cand);
-        if (lane == 0) bm[p >> 6] = m;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t p = base + j * kParseNT + tid;
+            const bool cand = p >= 8 && p + H <= nb && bcv[j] == bc0 && nav[j] <= (nb - p - H) / 11u;
+            const uint64_t m = __ballot(cand);
+            if (lane == 0 && base + j * kParseNT < nb) bm[p >> 6] = m;
+        }
     }
     __threadfence_block();
     __syncthreads();
@@ -67,36 +76,56 @@ __global__ __launch_bounds__(kParseNT) void k_atac_parse(AtacParseArgs a) {
     uint32_t* o_ref = a.o_ref + c.out_off;
     uint32_t* o_start = a.o_start + c.out_off;
     uint16_t* o_flen = a.o_flen + c.out_off;
-    for (uint32_t base = 0; base < nb; base += kParseNT) {
-        const uint32_t p = base + tid;
-        const uint64_t w = bm[(base >> 6) + wave];   // one word per wave
-        const bool cand = (w >> lane) & 1ull;
-        bool keep = false;
-        uint32_t na = 0;
-        if (cand) {
-            na = ld32(ch + p);
-            const uint32_t sz = H + 11u * na, s = p + sz;
-            const bool ok = s == nb || (s + H <= nb && ((bm[s >> 6] >> (s & 63u)) & 1ull));
-            fail = fail || !ok;
-            ++n_cand; sum += sz;
-            keep = na == 1 && ch[p + H + 4] == 4;
+    for (uint32_t base = 0; base < nb; base += 4 * kParseNT) {   // four tiles per trip again: bitmap words, then the record heads, then the successors
+        bool cand[4], keep[4];
+        uint32_t na[4], ty[4];
+        uint64_t sw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t tb = base + j * kParseNT;
+            const uint64_t w = tb < nb ? bm[(tb >> 6) + wave] : 0ull;   // one word per wave
+            cand[j] = (w >> lane) & 1ull;
         }
-        const uint64_t km = __ballot(keep);
-        const uint64_t mm = __ballot(cand && na > 1), nm = __ballot(cand && !keep && na <= 1);
-        uint32_t slot0 = 0;
-        if (lane == 0) {
-            if (km) slot0 = atomicAdd(&s_cnt, (uint32_t)__popcll(km));
-            if (mm) atomicAdd(&s_multi, (uint32_t)__popcll(mm));
-            if (nm) atomicAdd(&s_non, (uint32_t)__popcll(nm));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t p = base + j * kParseNT + tid;
+            na[j] = cand[j] ? ld32(ch + p) : 0u;
+            ty[j] = cand[j] && p + H + 4 < nb ? ch[p + H + 4] : 0u;
         }
-        slot0 = __shfl(slot0, 0);
-        if (keep) {
-            const uint32_t slot = slot0 + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
-            if (slot < c.nrec) {
-                o_ref[slot] = ld32(ch + p + H);
-                o_start[slot] = ld32(ch + p + H + 5);
-                o_flen[slot] = (uint16_t)ld16(ch + p + H + 9);
-            } else fail = true;   // more candidates than records: the proof cannot hold
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t p = base + j * kParseNT + tid;
+            const uint32_t s = p + H + 11u * na[j];
+            sw[j] = cand[j] && s + H <= nb ? bm[s >> 6] : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t p = base + j * kParseNT + tid;
+            keep[j] = false;
+            if (cand[j]) {
+                const uint32_t sz = H + 11u * na[j], s = p + sz;
+                const bool ok = s == nb || (s + H <= nb && ((sw[j] >> (s & 63u)) & 1ull));
+                fail = fail || !ok;
+                ++n_cand; sum += sz;
+                keep[j] = na[j] == 1 && ty[j] == 4;
+            }
+            const uint64_t km = __ballot(keep[j]);
+            const uint64_t mm = __ballot(cand[j] && na[j] > 1), nm = __ballot(cand[j] && !keep[j] && na[j] <= 1);
+            uint32_t slot0 = 0;
+            if (lane == 0) {
+                if (km) slot0 = atomicAdd(&s_cnt, (uint32_t)__popcll(km));
+                if (mm) atomicAdd(&s_multi, (uint32_t)__popcll(mm));
+                if (nm) atomicAdd(&s_non, (uint32_t)__popcll(nm));
+            }
+            slot0 = __shfl(slot0, 0);
+            if (keep[j]) {
+                const uint32_t slot = slot0 + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+                if (slot < c.nrec) {
+                    o_ref[slot] = ld32(ch + p + H);
+                    o_start[slot] = ld32(ch + p + H + 5);
+                    o_flen[slot] = (uint16_t)ld16(ch + p + H + 9);
+                } else fail = true;   // more candidates than records: the proof cannot hold
+            }
         }
     }
     // block reduction of (count, size sum, fail)

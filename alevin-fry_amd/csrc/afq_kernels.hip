@@ -1034,13 +1034,21 @@ __global__ __launch_bounds__(256) void k_atac_compact(const uint64_t* __restrict
                                                      const uint32_t* __restrict__ i_ref, const uint32_t* __restrict__ i_start,
                                                      const uint16_t* __restrict__ i_flen, const uint16_t* __restrict__ i_cnt,
                                                      uint32_t* __restrict__ o_ref, uint32_t* __restrict__ o_start,
-                                                     uint16_t* __restrict__ o_flen, uint16_t* __restrict__ o_cnt) {
+                                                     uint16_t* __restrict__ o_flen, uint16_t* __restrict__ o_cnt,
+                                                     unsigned long long* __restrict__ tally) {
     const uint32_t cell = blockIdx.x;
     const uint64_t src = cell_ptr[cell], dst = out_ptr[cell];
     const uint32_t n = (uint32_t)(out_ptr[cell + 1] - dst);
+    uint32_t dup = 0, lng = 0;   // fragments seen more than once / of 2000 bases and more (deduplicate.rs:222-224, 47-63)
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const uint16_t fl = i_flen[src + i], ct = i_cnt[src + i];
         o_ref[dst + i] = i_ref[src + i]; o_start[dst + i] = i_start[src + i];
-        o_flen[dst + i] = i_flen[src + i]; o_cnt[dst + i] = i_cnt[src + i];
+        o_flen[dst + i] = fl; o_cnt[dst + i] = ct;
+        dup += ct > 1; lng += fl >= 2000;
+    }
+    if (tally) {
+        for (int d = 32; d; d >>= 1) { dup += __shfl_xor(dup, d); lng += __shfl_xor(lng, d); }
+        if ((threadIdx.x & 63) == 0) { if (dup) atomicAdd(&tally[0], (unsigned long long)dup); if (lng) atomicAdd(&tally[1], (unsigned long long)lng); }
     }
 }
 
@@ -1135,9 +1143,9 @@ void launch_atac_dedup64(hipStream_t s, uint32_t n_cells, const uint32_t* ref, c
 
 void launch_atac_compact(hipStream_t s, uint32_t n_cells, const uint64_t* cell_ptr, const uint64_t* out_ptr, const uint32_t* i_ref,
                          const uint32_t* i_start, const uint16_t* i_flen, const uint16_t* i_cnt, uint32_t* o_ref, uint32_t* o_start,
-                         uint16_t* o_flen, uint16_t* o_cnt) {
+                         uint16_t* o_flen, uint16_t* o_cnt, unsigned long long* tally) {
     if (!n_cells) return;
-    AFQ_LAUNCH(k_atac_compact, n_cells, 256, s, cell_ptr, out_ptr, i_ref, i_start, i_flen, i_cnt, o_ref, o_start, o_flen, o_cnt);
+    AFQ_LAUNCH(k_atac_compact, n_cells, 256, s, cell_ptr, out_ptr, i_ref, i_start, i_flen, i_cnt, o_ref, o_start, o_flen, o_cnt, tally);
 }
 
 void launch_cell_hist(hipStream_t s, const ResolveArgs& a) {

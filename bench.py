@@ -576,7 +576,8 @@ def bench_atac(args, pkg, D):
 
     def step():
         nonlocal res
-        res = q.atac_dedup_rad(None, off, d_ptr=d_bytes.data_ptr(), n_bytes=len(data))
+        res = None   # (the previous step's arrays go back to the library's pinned pool)
+        res = q.atac_dedup_rad(None, off, d_ptr=d_bytes.data_ptr(), n_bytes=len(data), copy=False)
 
     for _ in range(args.warmup):
         step()
