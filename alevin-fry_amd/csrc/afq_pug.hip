@@ -1154,14 +1154,28 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     uint32_t* big_list = v_cnt;                               // > 64 vertices or over the large-graph threshold
     if (tid < 2) s_flag[tid] = 0;
     __syncthreads();
+    // (components of 3..8 vertices first in the list: they are covered eight to a wave, 6b')
+    if (tid == 0) s_next = 0;   // (the work counter's LDS word is free until the next cell)
+    __syncthreads();
+    {
+        uint32_t mine = 0;
+        for (uint32_t c = tid; c < NC; c += kPugNT) { const uint32_t n = comp_start[c + 1] - comp_start[c]; mine += n >= 3 && n <= 8 && n <= C.large_thresh; }
+        if (mine) atomicAdd(&s_next, mine);
+    }
+    __syncthreads();
+    const uint32_t n_tiny = s_next;
+    __syncthreads();
+    if (tid == 0) s_next = 0;
+    __syncthreads();
     for (uint32_t c = tid; c < NC; c += kPugNT) {
         const uint32_t n = comp_start[c + 1] - comp_start[c];
         if (n < 2 || (n == 2 && n <= C.large_thresh)) continue;  // singletons and pairs are resolved lane-parallel below
-        if (n <= 64 && n <= C.large_thresh) mid_list[atomicAdd(&s_flag[0], 1u)] = c;
+        if (n <= 8 && n <= C.large_thresh) mid_list[atomicAdd(&s_next, 1u)] = c;
+        else if (n <= 64 && n <= C.large_thresh) mid_list[n_tiny + atomicAdd(&s_flag[0], 1u)] = c;
         else big_list[atomicAdd(&s_flag[1], 1u)] = c;
     }
     __syncthreads();
-    const uint32_t n_mid = s_flag[0], n_big = s_flag[1];
+    const uint32_t n_mid = n_tiny + s_flag[0], n_big = s_flag[1];
     __syncthreads();
 
     PUG_MARK(7);
@@ -1272,14 +1286,102 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         mrec[2 * (size_t)sl + 1] = make_uint4(r2, r3, (uint32_t)adj, (uint32_t)(adj >> 32));
     }
     __syncthreads();
+    // ---- 6b'. components of 3..8 vertices: EIGHT to a wave, a group of eight lanes each ----
+    // The cover of 6b on segments of the wave: a ballot is cut to the group's byte, the OR over the frontier's adjacency
+    // rows runs over the group's eight lanes, "the label of vertex v" is a shuffle from lane (group base + v), and every
+    // loop runs until the last group of the wave is done with it (idle groups are predicated off).  Such components are
+    // four in five of all that reach the cover; a wave to each left 59 of its 64 lanes without a vertex.
+    {
+        const uint32_t gl = lane & 7u, gbase = lane & ~7u, grp = lane >> 3;
+        auto seg_or8 = [](uint32_t x) -> uint32_t { x |= (uint32_t)__shfl_xor((int)x, 1); x |= (uint32_t)__shfl_xor((int)x, 2); x |= (uint32_t)__shfl_xor((int)x, 4); return x; };
+        for (uint32_t c0 = wv * 8; c0 < n_tiny; c0 += (kPugNT / 64) * 8) {
+            const uint32_t ci = c0 + grp;
+            const bool gvalid = ci < n_tiny;
+            const uint32_t b0 = gvalid ? mid_off[ci] : 0u, n = gvalid ? mid_off[ci + 1] - b0 : 0u;
+            const bool act = gl < n;
+            uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
+            if (act) { qa = mrec[2 * (size_t)(b0 + gl)]; qb = mrec[2 * (size_t)(b0 + gl) + 1]; }
+            Lab myl{nullptr, act ? qa.y : 0u};
+            uint32_t lr0 = 0xFFFFFFFFu, lr1 = 0xFFFFFFFFu, lr2 = 0xFFFFFFFFu, lr3 = 0xFFFFFFFFu;
+            if (act && myl.n <= 4) { lr0 = qa.z; lr1 = qa.w; lr2 = qb.x; lr3 = qb.y; }
+            else if (act) myl.p = reinterpret_cast<const uint32_t*>((uintptr_t)(((uint64_t)qa.w << 32) | qa.z));
+            auto my_contains = [&](uint32_t t) -> bool {
+                if (myl.n <= 4) return t == lr0 || t == lr1 || t == lr2 || t == lr3;
+                return lab_contains(myl, t);
+            };
+            // ref j of the label held by lane `src` (every lane of the wave makes the same three shuffles; n_v, j and src are the caller's)
+            auto ref_of = [&](uint32_t src, uint32_t n_v, uint32_t j, bool on) -> uint32_t {
+                const uint32_t r = (uint32_t)__shfl((int)(j == 0 ? lr0 : j == 1 ? lr1 : j == 2 ? lr2 : lr3), (int)src);
+                const uint64_t pa = (uint64_t)(uintptr_t)myl.p;
+                const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)pa, (int)src), hi = (uint32_t)__shfl((int)(uint32_t)(pa >> 32), (int)src);
+                if (n_v <= 4 || !on) return r;
+                return reinterpret_cast<const uint32_t*>((uintptr_t)(((uint64_t)hi << 32) | lo))[j] & 0x7FFFFFFFu;
+            };
+            const uint32_t adj = act ? (qb.z & 0xFFu) : 0u;   // local indices < 8
+            uint32_t UC = gvalid ? (1u << n) - 1u : 0u;
+            while (__any(UC != 0)) {
+                const uint32_t remaining = (uint32_t)__popc(UC);
+                uint32_t best = 0, best_sz = 0, it = UC;
+                while (__any(it != 0)) {   // candidate start vertices, ascending
+                    const bool g_on = it != 0;
+                    const uint32_t v = g_on ? (uint32_t)__builtin_ctz(it) : 0u;
+                    it &= it - 1;   // (0 stays 0)
+                    const uint32_t lvn_all = (uint32_t)__shfl((int)myl.n, (int)(gbase + v));
+                    const uint32_t lvn = g_on ? lvn_all : 0u;
+                    uint32_t mv = 0, mv_sz = 0;
+                    for (uint32_t j = 0; __any(j < lvn); ++j) {
+                        const bool on = j < lvn;
+                        const uint32_t t = ref_of(gbase + v, lvn, j, on);
+                        const bool has = on && act && ((UC >> gl) & 1u) && my_contains(t);
+                        const uint32_t At = (uint32_t)(__ballot(has) >> gbase) & 0xFFu;
+                        uint32_t Rm = 1u << v, F = on ? Rm : 0u;
+                        while (__any(F != 0)) {
+                            const uint32_t N = seg_or8(((F >> gl) & 1u) ? adj : 0u);
+                            F = N & At & ~Rm;
+                            Rm |= F;
+                        }
+                        const uint32_t sz = (uint32_t)__popc(Rm);
+                        if (on && sz > mv_sz) { mv_sz = sz; mv = Rm; }
+                    }
+                    if (g_on && mv_sz > best_sz) { best_sz = mv_sz; best = mv; }
+                    if (g_on && mv_sz == remaining) it = 0;
+                }
+                const bool g_emit = UC != 0;
+                if (g_emit && best == 0) { if (gl == 0) s_cnt[3] = kErrPugLimit; UC = 0; }  // vertex with an empty label
+                // transcripts common to every vertex of the arborescence (pugutils.rs:1161-1188) -> genes
+                const uint32_t fv = best ? (uint32_t)__builtin_ctz(best) : 0u;
+                const uint32_t lfn_all = (uint32_t)__shfl((int)myl.n, (int)(gbase + fv));
+                const uint32_t lfn = best ? lfn_all : 0u;
+                uint32_t g[kMaxGenesPerLabel];
+                uint32_t ng = 0;
+                bool wide = false;
+                for (uint32_t j = 0; __any(j < lfn); ++j) {
+                    const bool on = j < lfn;
+                    const uint32_t t = ref_of(gbase + fv, lfn, j, on);
+                    const uint32_t hasm = (uint32_t)(__ballot(on && act && ((best >> gl) & 1u) && my_contains(t)) >> gbase) & 0xFFu;
+                    if (on && hasm == best && gl == 0) {
+                        const uint32_t gid = C.gene_level ? t : C.t2g[t];
+                        uint32_t q = 0;
+                        while (q < ng && g[q] < gid) ++q;
+                        if (!(q < ng && g[q] == gid)) {
+                            if (ng == kMaxGenesPerLabel) wide = true;
+                            else { for (uint32_t r = ng; r > q; --r) g[r] = g[r - 1]; g[q] = gid; ++ng; }
+                        }
+                    }
+                }
+                if (best && gl == 0) emit_molecule(C, g, wide ? 0xFFFFFFFFu : ng);
+                UC &= ~best;
+            }
+        }
+    }
     {
       // offsets two components ahead, records one ahead
       uint32_t ob0 = 0, ob1 = 0, nb0 = 0, nb1 = 0;
-      if (wv < n_mid) { ob0 = mid_off[wv]; ob1 = mid_off[wv + 1]; }
-      if (wv + kPugNT / 64 < n_mid) { nb0 = mid_off[wv + kPugNT / 64]; nb1 = mid_off[wv + kPugNT / 64 + 1]; }
+      if (n_tiny + wv < n_mid) { ob0 = mid_off[n_tiny + wv]; ob1 = mid_off[n_tiny + wv + 1]; }
+      if (n_tiny + wv + kPugNT / 64 < n_mid) { nb0 = mid_off[n_tiny + wv + kPugNT / 64]; nb1 = mid_off[n_tiny + wv + kPugNT / 64 + 1]; }
       uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
       if (lane < ob1 - ob0) { ra = mrec[2 * (size_t)(ob0 + lane)]; rb = mrec[2 * (size_t)(ob0 + lane) + 1]; }
-    for (uint32_t ci = wv; ci < n_mid; ci += kPugNT / 64) {
+    for (uint32_t ci = n_tiny + wv; ci < n_mid; ci += kPugNT / 64) {   // components of 9..64 vertices: a wave each
         const uint32_t n = ob1 - ob0;
         const bool act = lane < n;
         const uint4 qa = ra, qb = rb;
