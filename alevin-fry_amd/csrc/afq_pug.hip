@@ -322,6 +322,54 @@ __device__ __forceinline__ uint32_t molecule2_column(const PugCtx& c, uint32_t g
     if (col != 0xFFFFFFFFu && col >= c.num_rows) { c.s_cnt[3] = kErrSlotRange; return 0xFFFFFFFFu; }
     return col;
 }
+// Up to four refs -> their distinct gene ids, ascending, all in registers (r[i] = 0xFFFFFFFF past the label's end).
+// Returns the number of genes; gene i in g[i].  (genes_of with its 64-entry array lives in scratch memory: a load or store
+// there is a trip to global memory, dozens per molecule.)
+__device__ __forceinline__ uint32_t genes_of4(const PugCtx& c, uint32_t (&g)[4], uint32_t n) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g[i] = (uint32_t)i < n ? (c.gene_level ? g[i] : c.t2g[g[i]]) : 0xFFFFFFFFu;
+    auto cs = [&](int a, int b) { const uint32_t lo = g[a] < g[b] ? g[a] : g[b], hi = g[a] < g[b] ? g[b] : g[a]; g[a] = lo; g[b] = hi; };
+    cs(0, 1); cs(2, 3); cs(0, 2); cs(1, 3); cs(1, 2);   // sorting network of four
+    // drop repeats (0xFFFFFFFF sorts last and is never counted)
+    uint32_t o[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    uint32_t k = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool keep = g[i] != 0xFFFFFFFFu && (i == 0 || g[i] != g[i - 1]);
+        if (keep) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if ((uint32_t)q == k) o[q] = g[i];
+            ++k;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g[i] = o[i];
+    return k;
+}
+// emit_molecule for a gene label of up to four ids in registers; like molecule2_column it returns the column (for
+// append_cols) or 0xFFFFFFFF, and writes a multi-gene class for the EM itself.
+__device__ __forceinline__ uint32_t molecule4_column(const PugCtx& c, const uint32_t (&g)[4], uint32_t ng) {
+    if (ng == 0) return 0xFFFFFFFFu;
+    if (ng <= 2) return molecule2_column(c, g[0], g[1], ng);
+    uint32_t col = 0xFFFFFFFFu;
+    if (c.em) {
+        const uint32_t off = atomicAdd(&c.s_cnt[1], ng), di = atomicAdd(&c.s_cnt[2], 1u);
+        if (off + ng > c.lab_cap || 2 * (di + 1) > c.lab_cap) { c.s_cnt[3] = kErrPugLimit; return 0xFFFFFFFFu; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if ((uint32_t)i < ng) c.labw[off + i] = g[i];
+        c.labd[2 * di] = off; c.labd[2 * di + 1] = ng;
+        return 0xFFFFFFFFu;
+    }
+    if (c.usa) {   // 3..10 genes: exactly one spliced gene -> A if its unspliced partner follows it, else S (utils.rs:719-747)
+        uint32_t nsp = 0, sg = 0, nxt = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if ((uint32_t)i < ng && (g[i] & 1u) == 0) { if (nsp == 0) { sg = g[i]; nxt = i + 1 < 4 && (uint32_t)(i + 1) < ng ? g[i + 1] : 0xFFFFFFFFu; } ++nsp; }
+        if (nsp == 1) col = (nxt != 0xFFFFFFFFu && ((sg ^ nxt) & ~1u) == 0) ? c.ao + (sg >> 1) : (sg >> 1);
+    }
+    if (col != 0xFFFFFFFFu && col >= c.num_rows) { c.s_cnt[3] = kErrSlotRange; return 0xFFFFFFFFu; }
+    return col;
+}
 // Append one column per lane that has one.  Called by all lanes of the wave together: the lanes share ONE reservation on the
 // cell's column counter - a same-address LDS atomic per molecule is serviced lane by lane, with sixteen waves queueing.
 __device__ __forceinline__ void append_cols(const PugCtx& c, uint32_t col) {
@@ -1210,36 +1258,62 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                 col = molecule2_column(C, lo, hi, lo == hi ? 1u : 2u);
             } else if (lone[j]) {
                 const Lab l = vlab(v0 + j * kPugNT);
-                uint32_t g[kMaxGenesPerLabel];
-                const uint32_t ng = genes_of(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; }, g);
-                emit_molecule(C, g, ng);
+                if (l.n <= 4) {
+                    uint32_t g4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) g4[q] = (uint32_t)q < l.n ? l.p[q] & 0x7FFFFFFFu : 0xFFFFFFFFu;
+                    const uint32_t ng = genes_of4(C, g4, l.n);
+                    col = molecule4_column(C, g4, ng);
+                } else {
+                    uint32_t g[kMaxGenesPerLabel];
+                    const uint32_t ng = genes_of(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; }, g);
+                    emit_molecule(C, g, ng);
+                }
             }
             append_cols(C, col);   // (v0 - lane is wave-uniform: every lane of the wave gets here)
         }
     }
-    for (uint32_t c = tid; c < NC; c += kPugNT) {
-        const uint32_t n = comp_start[c + 1] - comp_start[c];
-        if (n != 2 || n > C.large_thresh) continue;
-        const Lab l = vlab(vid_at(comp_start[c]));
-        uint32_t g[kMaxGenesPerLabel];
-        uint32_t ng;
-        {
-            const Lab l2 = vlab(vid_at(comp_start[c] + 1));
-            ng = 0;
-            for (uint32_t j = 0; j < l.n && ng != 0xFFFFFFFFu; ++j) {
-                const uint32_t t = l.p[j] & 0x7FFFFFFFu;
-                if (!lab_contains(l2, t)) continue;
-                const uint32_t gid = C.gene_level ? t : C.t2g[t];
-                uint32_t q = 0;
-                while (q < ng && g[q] < gid) ++q;
-                if (q < ng && g[q] == gid) continue;
-                if (ng == kMaxGenesPerLabel) { ng = 0xFFFFFFFFu; break; }
-                for (uint32_t r = ng; r > q; --r) g[r] = g[r - 1];
-                g[q] = gid;
-                ++ng;
+    for (uint32_t c = tid; c - lane < NC; c += kPugNT) {   // (wave-uniform trip count: append_cols is a wave-wide call)
+        uint32_t col = 0xFFFFFFFFu;
+        const uint32_t n = c < NC ? comp_start[c + 1] - comp_start[c] : 0u;
+        if (n == 2 && n <= C.large_thresh) {
+            const Lab l = vlab(vid_at(comp_start[c])), l2 = vlab(vid_at(comp_start[c] + 1));
+            if (l.n <= 4) {   // the shared transcripts of two short labels, in registers
+                uint32_t g4[4];
+                uint32_t k = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    g4[q] = 0xFFFFFFFFu;
+                    if ((uint32_t)q < l.n) {
+                        const uint32_t t = l.p[q] & 0x7FFFFFFFu;
+                        if (lab_contains(l2, t)) {
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) if ((uint32_t)w == k) g4[w] = t;
+                            ++k;
+                        }
+                    }
+                }
+                const uint32_t ng = genes_of4(C, g4, k);
+                col = molecule4_column(C, g4, ng);
+            } else {
+                uint32_t g[kMaxGenesPerLabel];
+                uint32_t ng = 0;
+                for (uint32_t j = 0; j < l.n && ng != 0xFFFFFFFFu; ++j) {
+                    const uint32_t t = l.p[j] & 0x7FFFFFFFu;
+                    if (!lab_contains(l2, t)) continue;
+                    const uint32_t gid = C.gene_level ? t : C.t2g[t];
+                    uint32_t q = 0;
+                    while (q < ng && g[q] < gid) ++q;
+                    if (q < ng && g[q] == gid) continue;
+                    if (ng == kMaxGenesPerLabel) { ng = 0xFFFFFFFFu; break; }
+                    for (uint32_t r = ng; r > q; --r) g[r] = g[r - 1];
+                    g[q] = gid;
+                    ++ng;
+                }
+                emit_molecule(C, g, ng);
             }
         }
-        emit_molecule(C, g, ng);
+        append_cols(C, col);
     }
     PUG_MARK(8);
     // ---- 6b. components of 3..64 vertices: one wave each, adjacency = one 64-bit mask per lane ----
@@ -1352,24 +1426,37 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                 const uint32_t fv = best ? (uint32_t)__builtin_ctz(best) : 0u;
                 const uint32_t lfn_all = (uint32_t)__shfl((int)myl.n, (int)(gbase + fv));
                 const uint32_t lfn = best ? lfn_all : 0u;
-                uint32_t g[kMaxGenesPerLabel];
-                uint32_t ng = 0;
+                uint32_t g[kMaxGenesPerLabel];   // (only for labels over four refs: the array lives in scratch memory)
+                uint32_t ng = 0, k4 = 0;
+                uint32_t c4[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
                 bool wide = false;
+                const bool small = lfn <= 4;
                 for (uint32_t j = 0; __any(j < lfn); ++j) {
                     const bool on = j < lfn;
                     const uint32_t t = ref_of(gbase + fv, lfn, j, on);
                     const uint32_t hasm = (uint32_t)(__ballot(on && act && ((best >> gl) & 1u) && my_contains(t)) >> gbase) & 0xFFu;
                     if (on && hasm == best && gl == 0) {
-                        const uint32_t gid = C.gene_level ? t : C.t2g[t];
-                        uint32_t q = 0;
-                        while (q < ng && g[q] < gid) ++q;
-                        if (!(q < ng && g[q] == gid)) {
-                            if (ng == kMaxGenesPerLabel) wide = true;
-                            else { for (uint32_t r = ng; r > q; --r) g[r] = g[r - 1]; g[q] = gid; ++ng; }
+                        if (small) {
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) if ((uint32_t)w == k4) c4[w] = t;
+                            ++k4;
+                        } else {
+                            const uint32_t gid = C.gene_level ? t : C.t2g[t];
+                            uint32_t q = 0;
+                            while (q < ng && g[q] < gid) ++q;
+                            if (!(q < ng && g[q] == gid)) {
+                                if (ng == kMaxGenesPerLabel) wide = true;
+                                else { for (uint32_t r = ng; r > q; --r) g[r] = g[r - 1]; g[q] = gid; ++ng; }
+                            }
                         }
                     }
                 }
-                if (best && gl == 0) emit_molecule(C, g, wide ? 0xFFFFFFFFu : ng);
+                uint32_t col = 0xFFFFFFFFu;
+                if (best && gl == 0) {
+                    if (small) { const uint32_t n4 = genes_of4(C, c4, k4); col = molecule4_column(C, c4, n4); }
+                    else emit_molecule(C, g, wide ? 0xFFFFFFFFu : ng);
+                }
+                append_cols(C, col);
                 UC &= ~best;
             }
         }
@@ -1439,24 +1526,39 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
             // transcripts common to every vertex of the arborescence (pugutils.rs:1161-1188) -> genes
             const uint32_t fv = (uint32_t)__builtin_ctzll(best);
             const uint32_t lfn = lane_lab_n(fv);
-            uint32_t g[kMaxGenesPerLabel];
-            uint32_t ng = 0;
+            uint32_t g[kMaxGenesPerLabel];   // (only for labels over four refs: the array lives in scratch memory)
+            uint32_t ng = 0, k4 = 0;
+            uint32_t c4[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
             bool wide = false;
+            const bool small = lfn <= 4;
             for (uint32_t j = 0; j < lfn; ++j) {
                 const uint32_t t = lane_lab_ref(fv, lfn, j);
                 const uint64_t has = __ballot(act && ((best >> lane) & 1ull) && my_contains(t));
                 if (has != best) continue;
                 if (lane == 0) {
-                    const uint32_t gid = C.gene_level ? t : C.t2g[t];
-                    uint32_t q = 0;
-                    while (q < ng && g[q] < gid) ++q;
-                    if (!(q < ng && g[q] == gid)) {
-                        if (ng == kMaxGenesPerLabel) wide = true;
-                        else { for (uint32_t r = ng; r > q; --r) g[r] = g[r - 1]; g[q] = gid; ++ng; }
+                    if (small) {
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) if ((uint32_t)w == k4) c4[w] = t;
+                        ++k4;
+                    } else {
+                        const uint32_t gid = C.gene_level ? t : C.t2g[t];
+                        uint32_t q = 0;
+                        while (q < ng && g[q] < gid) ++q;
+                        if (!(q < ng && g[q] == gid)) {
+                            if (ng == kMaxGenesPerLabel) wide = true;
+                            else { for (uint32_t r = ng; r > q; --r) g[r] = g[r - 1]; g[q] = gid; ++ng; }
+                        }
                     }
                 }
             }
-            if (lane == 0) emit_molecule(C, g, wide ? 0xFFFFFFFFu : ng);
+            {
+                uint32_t col = 0xFFFFFFFFu;
+                if (lane == 0) {
+                    if (small) { const uint32_t n4 = genes_of4(C, c4, k4); col = molecule4_column(C, c4, n4); }
+                    else emit_molecule(C, g, wide ? 0xFFFFFFFFu : ng);
+                }
+                append_cols(C, col);
+            }
             UC &= ~best;
         }
     }
