@@ -140,7 +140,7 @@ struct Range { uint32_t c0, c1; };
 
 struct RangeState {
     hipStream_t stream = nullptr;
-    DevBuf d_meta, d_keys0, d_keys1, d_cell_nkeys, d_bucket_cnt, d_bucket_cell, d_multi_cells, d_tile_prefix, d_ncols,
+    DevBuf d_meta, d_keys0, d_keys1, d_cell_nkeys, d_bucket_cnt, d_bucket_cell, d_multi_cells, d_tile_desc, d_ncols,
         d_nnz, d_ovf, d_status, d_bc, d_cell_ptr, d_gene, d_val, d_chk, d_slab_prefix, d_slab_cell, d_cell_bc, d_bdesc, d_lab,
         d_lab_cnt, d_em_off, d_em_scratch, d_em_nnz, d_pug_cells, d_rd_off, d_rd_h, d_rd_u, d_rd_o, d_pug_scr_off,
         d_pug_scratch, d_epool, d_epool_cur, d_alt, d_hist_cells, d_fix, d_em_hdr, d_em_order, d_eq_ncls, d_eq_nw, d_eq_cptr,
@@ -148,12 +148,13 @@ struct RangeState {
         d_bt_cmean, d_bt_cvar;
     ResolveArgs last_ra{};
     std::vector<CellMeta> meta;
+    std::vector<uint2> tile_desc;   // per scatter tile: (cell, tile index inside the cell)
     Range cur{};
     bool in_flight = false;
     hipEvent_t kernels_done = nullptr;
     std::vector<TimedLaunch> launches;  // HIP-event brackets of this range's kernels (cfg.profile)
     std::vector<DevBuf*> all() {
-        return {&d_meta, &d_keys0, &d_keys1, &d_cell_nkeys, &d_bucket_cnt, &d_bucket_cell, &d_multi_cells, &d_tile_prefix,
+        return {&d_meta, &d_keys0, &d_keys1, &d_cell_nkeys, &d_bucket_cnt, &d_bucket_cell, &d_multi_cells, &d_tile_desc,
                 &d_ncols, &d_nnz, &d_ovf, &d_status, &d_bc, &d_cell_ptr, &d_gene, &d_val, &d_chk, &d_slab_prefix, &d_slab_cell,
                 &d_cell_bc, &d_bdesc, &d_lab, &d_lab_cnt, &d_em_off, &d_em_scratch, &d_em_nnz, &d_pug_cells, &d_rd_off, &d_rd_h,
                 &d_rd_u, &d_rd_o, &d_pug_scr_off, &d_pug_scratch, &d_epool, &d_epool_cur, &d_alt, &d_hist_cells, &d_fix, &d_em_hdr, &d_em_order,
@@ -350,11 +351,13 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
     const uint32_t H = hdr_bytes(g);
     const uint32_t n = r.c1 - r.c0;
     B.meta.resize(n);
-    std::vector<uint32_t> multi, tile_prefix, bucket_cell, slab_prefix, pug_cells, hist_cells;
+    B.tile_desc.clear();
+    std::vector<uint32_t> multi, bucket_cell, slab_prefix, pug_cells, hist_cells;
     std::vector<uint64_t> rd_off(n, 0);
     uint64_t n_pug_reads = 0, pug_words = 0;  // pug_words: scratch of the largest parsimony cell
     const bool par = c->all_aligned && decode_par_supported(g.bc_bytes, g.umi_bytes);
     uint64_t key_off = 0, n_buckets = 0, n_tiles = 0, n_slabs = 0;
+    uint32_t max_lg_nb = 0;
     if (par) slab_prefix.reserve(n + 1);
     uint64_t nrec_total = 0;
     for (uint32_t i = 0; i < n; ++i) {
@@ -379,12 +382,14 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
         uint32_t lg = 0;
         if (!mode_is_pug(m.mode)) while (((uint64_t)kBucketTarget << lg) < m.n_ref && lg < kMaxLgNb) ++lg;
         m.lg_nb = lg;
+        max_lg_nb = std::max(max_lg_nb, lg);
         m.bucket_base = (uint32_t)n_buckets;
         n_buckets += 1ull << lg;
         if (lg) {
             multi.push_back(i);
-            tile_prefix.push_back((uint32_t)n_tiles);
-            n_tiles += (m.n_ref + kScatterTileHost - 1) / kScatterTileHost;
+            const uint32_t nt = (m.n_ref + kScatterTileHost - 1) / kScatterTileHost;
+            for (uint32_t t = 0; t < nt; ++t) B.tile_desc.push_back(make_uint2(i, t));
+            n_tiles += nt;
         }
         if (mode_is_pug(m.mode)) {
             pug_cells.push_back(i); rd_off[i] = n_pug_reads; n_pug_reads += m.nrec;
@@ -402,7 +407,6 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
     }
     if (n_buckets >= 0xFFFFFFF0ull || n_tiles >= 0xFFFFFFF0ull || key_off >= (1ull << 40))
         return fail(c, AFQ_ERR_UNSUPPORTED, "batch too large for 32-bit bucket/tile ids");
-    tile_prefix.push_back((uint32_t)n_tiles);
     bucket_cell.resize(n_buckets);
     for (uint32_t i = 0; i < n; ++i) {
         const CellMeta& m = B.meta[i];
@@ -417,7 +421,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
     HIP_TRY(c, B.d_bucket_cnt.ensure(4 * n_buckets));
     HIP_TRY(c, B.d_bucket_cell.ensure(4 * n_buckets));
     HIP_TRY(c, B.d_multi_cells.ensure(4ull * std::max<uint32_t>(n_multi, 1)));
-    HIP_TRY(c, B.d_tile_prefix.ensure(4ull * (n_multi + 1)));
+    HIP_TRY(c, B.d_tile_desc.ensure(8ull * std::max<uint64_t>(n_tiles, 1)));
     HIP_TRY(c, B.d_ncols.ensure(4ull * n));
     HIP_TRY(c, B.d_nnz.ensure(4ull * n));
     HIP_TRY(c, B.d_ovf.ensure(sizeof(OverflowEnt) * std::max<uint64_t>(n_buckets, 1)));
@@ -469,7 +473,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
     HIP_TRY(c, hipMemcpyAsync(B.d_bucket_cell.p, bucket_cell.data(), 4 * n_buckets, hipMemcpyHostToDevice, s));
     if (n_multi) {
         HIP_TRY(c, hipMemcpyAsync(B.d_multi_cells.p, multi.data(), 4ull * n_multi, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemcpyAsync(B.d_tile_prefix.p, tile_prefix.data(), 4ull * (n_multi + 1), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(B.d_tile_desc.p, B.tile_desc.data(), 8ull * n_tiles, hipMemcpyHostToDevice, s));
     }
     HIP_TRY(c, hipMemsetAsync(B.d_bucket_cnt.p, 0, 4 * n_buckets, s));
     HIP_TRY(c, hipMemsetAsync(B.d_nnz.p, 0, 4ull * n, s));
@@ -516,13 +520,13 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
         if (launch_decode(s, da, g.bc_bytes, g.umi_bytes)) return fail(c, AFQ_ERR_INVALID_ARG, "bad field widths");
     }
     ResolveArgs ra{B.d_meta.as<CellMeta>(), B.d_bucket_cell.as<uint32_t>(), B.d_multi_cells.as<uint32_t>(),
-                   B.d_tile_prefix.as<uint32_t>(), B.d_cell_nkeys.as<uint32_t>(), B.d_bucket_cnt.as<uint32_t>(),
+                   B.d_tile_desc.as<uint2>(), B.d_cell_nkeys.as<uint32_t>(), B.d_bucket_cnt.as<uint32_t>(),
                    B.d_keys0.as<uint64_t>(), B.d_keys1.as<uint64_t>(), B.d_ncols.as<uint32_t>(),
                    B.d_nnz.as<uint32_t>(), B.d_ovf.as<OverflowEnt>(), B.d_bdesc.p, em ? B.d_lab.as<uint32_t>() : nullptr,
                    em ? B.d_lab_cnt.as<uint32_t>() : nullptr, B.d_status.as<DevStatus>(),
                    (uint32_t)n_buckets, n_multi, (uint32_t)n_tiles, B.d_hist_cells.as<uint32_t>(),
                    (uint32_t)hist_cells.size(), g.usa_mode, g.num_rows,
-                   (g.usa_mode && g.sa_model == AFQ_SA_PREFER_AMBIG) ? 1u : 0u};
+                   (g.usa_mode && g.sa_model == AFQ_SA_PREFER_AMBIG) ? 1u : 0u, max_lg_nb};
     if (n_multi) {
         { ScopedTimer t(c, K_HIST, s, &B.launches); launch_hist(s, ra); }
         { ScopedTimer t(c, K_BSCAN, s, &B.launches); launch_bucket_scan(s, ra); }

@@ -393,8 +393,15 @@ __global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict
 #ifdef AFQ_EM_TIMING
     __shared__ unsigned long long tm2[6];
 #define EM2_MARK(i) do { __syncthreads(); if (threadIdx.x == 0 && (blockIdx.x % 1000) == 7) tm2[i] = wall_clock64(); } while (0)
+    __shared__ unsigned long long tph[5];
+    unsigned long long tph_t = 0;
+    if (threadIdx.x < 5) tph[threadIdx.x] = 0;
+#define EM2_PH0() do { tph_t = wall_clock64(); } while (0)
+#define EM2_PH(i) do { if (threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); tph[i] += n_ - tph_t; tph_t = n_; } } while (0)
 #else
 #define EM2_MARK(i) do {} while (0)
+#define EM2_PH0() do {} while (0)
+#define EM2_PH(i) do {} while (0)
 #endif
     const uint4 hdr = em_hdr[cell];
     if (hdr.w) return;  // no multi-label class: k_em already wrote the row
@@ -474,6 +481,7 @@ __global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict
         EM2_MARK(1);
         uint32_t it = 0;
         bool conv = true, last_round = false;
+        EM2_PH0();
         while (it < kMinIter || (it < kMaxIter && !conv) || last_round) {
             // (A) per class: denominator in label order (get_abundance_for, em.rs:167-187)
 #pragma unroll
@@ -489,6 +497,7 @@ __global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict
             }
             if (tid == 0) s_flag[0] = 0;
             __syncthreads();
+            EM2_PH(0);
             // (B) per active entry: single-label count, then class contributions in class order
             bool bad = false;
 #pragma unroll
@@ -518,6 +527,7 @@ __global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict
                     if (x > kAlphaCheckCutoff && fabsf(old - x) > kRelDiffTol) bad = true;
                 }
             }
+            EM2_PH(1);
             if (hv_list)
                 for (uint32_t i = tid >> 6; i < NH; i += kEmRNT / 64) {   // the listed entries, a wave each, in turn
                     const uint32_t a = hv[6 * i], hc = hv[6 * i + 1], hs = hv[6 * i + 2];
@@ -527,8 +537,10 @@ __global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict
                     if (lane_id() == 0) hv[6 * i + 5] = __float_as_uint(x);
                     if (x > kAlphaCheckCutoff && fabsf(old - x) > kRelDiffTol) bad = true;
                 }
+            EM2_PH(2);
             if (bad) s_flag[0] = 1;
             __syncthreads();  // every read of the old abundances is done
+            EM2_PH(3);
             conv = s_flag[0] == 0;
 #pragma unroll
             for (uint32_t j = 0; j < kEmPer; ++j) {
@@ -539,6 +551,7 @@ __global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict
             if (tid == 0) vin[Z0] = 0.0f;  // inactive entries come out of every round as 0
             ++it;
             __syncthreads();
+            EM2_PH(4);
             if (cfg.usa) {
                 if (last_round) break;
                 if (it >= kMinIter && conv) {
@@ -553,6 +566,13 @@ __global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict
             }
         }
         it_dbg = it;
+#ifdef AFQ_EM_TIMING
+        if (tid == 0 && (blockIdx.x % 1000) == 7) {
+            uint32_t mx = 0; for (uint32_t i = 0; i < (hv_list ? NH : 0u); ++i) mx = max(mx, hv[6 * i + 4] - hv[6 * i + 3]);
+            printf("em fits A=%u K=%u NH=%u list=%d maxdeg=%u it=%u: A=%.3f B=%.3f list(wave0)=%.3f wait=%.3f wb=%.3f ms\n", A, K, NH, (int)hv_list, mx, it,
+                   (double)tph[0]/1e5, (double)tph[1]/1e5, (double)tph[2]/1e5, (double)tph[3]/1e5, (double)tph[4]/1e5);
+        }
+#endif
         EM2_MARK(2);
         // floor and emit the non-zero alphas in column order (active ids ascend with the column)
         for (uint32_t base = 0; base < A; base += kEmRNT) {

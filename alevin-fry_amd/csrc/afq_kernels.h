@@ -36,7 +36,7 @@ struct ResolveArgs {
     const CellMeta* meta;
     const uint32_t* bucket_cell;
     const uint32_t* multi_cells;
-    const uint32_t* tile_prefix;
+    const uint2* tile_desc;   // per scatter tile: (cell, tile index inside the cell)
     const uint32_t* cell_nkeys;
     uint32_t* cursor;      // per-bucket: count -> exclusive offset -> end offset
     uint64_t* keys0;
@@ -56,6 +56,7 @@ struct ResolveArgs {
     uint32_t usa;
     uint32_t num_rows;
     uint32_t prefer_ambig;       // --sa-model prefer-ambig in USA mode (cr-like, cr-like-em)
+    uint32_t max_lg_nb;          // largest lg_nb of the batch's multi-bucket cells (picks the scatter instance)
 };
 
 void launch_gather_headers(hipStream_t s, const uint8_t* bytes, size_t n_bytes, const uint64_t* chunk_off,

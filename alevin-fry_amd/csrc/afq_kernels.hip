@@ -27,31 +27,16 @@ namespace afq {
 constexpr uint32_t kTileKeys = kScatterTileHost;  // 2048
 constexpr uint32_t kLdsBins = 2048;               // buckets per cell the LDS paths can hold
 
-__device__ __forceinline__ void tile_to_cell(const uint32_t* __restrict__ tile_prefix, uint32_t n_multi,
-                                             uint32_t tile, uint32_t* s_bcast, uint32_t& ci, uint32_t& local_tile) {
-    if (threadIdx.x == 0) {
-        uint32_t lo = 0, hi = n_multi;
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (tile_prefix[mid] <= tile) lo = mid; else hi = mid;
-        }
-        s_bcast[0] = lo;
-    }
-    __syncthreads();
-    ci = s_bcast[0];
-    local_tile = tile - tile_prefix[ci];
-}
-
-__global__ __launch_bounds__(256) void k_hist(const uint32_t* __restrict__ multi_cells,
-                                             const uint32_t* __restrict__ tile_prefix, uint32_t n_multi,
+// tile -> (cell, tile index inside the cell): a table the planner uploads with the batch.  (It used to be a binary
+// search over the cells' tile prefix by thread 0 - fourteen dependent L2 round trips and a barrier in front of every
+// 2048-key tile, more time than the tile's own work.)
+__global__ __launch_bounds__(256) void k_hist(const uint2* __restrict__ tile_desc,
                                              const CellMeta* __restrict__ meta,
                                              const uint32_t* __restrict__ cell_nkeys,
                                              const uint64_t* __restrict__ keys0, uint32_t* __restrict__ bucket_cnt) {
     __shared__ uint32_t s_hist[kLdsBins];
-    __shared__ uint32_t s_b[1];
-    uint32_t ci, lt;
-    tile_to_cell(tile_prefix, n_multi, blockIdx.x, s_b, ci, lt);
-    const uint32_t cell = multi_cells[ci];
+    const uint2 td = tile_desc[blockIdx.x];
+    const uint32_t cell = td.x, lt = td.y;
     const CellMeta m = meta[cell];
     const uint32_t nk = mode_is_pug(m.mode) ? 0u : cell_nkeys[cell];  // PUG cells emit reads, not keys
     const uint32_t t0 = lt * kTileKeys;
@@ -98,21 +83,21 @@ __global__ __launch_bounds__(256) void k_bucket_scan(const uint32_t* __restrict_
 // reserves the tile's range, and the tile is written out bucket-major so the
 // stores of a bucket's run are contiguous.  After the kernel cursor[b] = end
 // offset of bucket b inside its cell's region (start = previous bucket's end).
-__global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ multi_cells,
-                                                const uint32_t* __restrict__ tile_prefix, uint32_t n_multi,
+// BINS: buckets per cell the instance ranks in LDS (a cell with more goes key by key).  Nearly every batch is served
+// by the 512-bin instance, whose 20 KiB of LDS let eight workgroups share a CU instead of five.
+template <uint32_t BINS>
+__global__ __launch_bounds__(256) void k_scatter(const uint2* __restrict__ tile_desc,
                                                 const CellMeta* __restrict__ meta,
                                                 const uint32_t* __restrict__ cell_nkeys,
                                                 const uint64_t* __restrict__ keys0, uint64_t* __restrict__ keys1,
                                                 uint32_t* __restrict__ cursor) {
     constexpr uint32_t E = kTileKeys / 256;
     __shared__ uint64_t s_keys[kTileKeys];
-    __shared__ uint32_t s_cnt[kLdsBins];   // per-bucket count, then tile-local exclusive offset
-    __shared__ uint32_t s_base[kLdsBins];  // global position of the tile's first key of the bucket
+    __shared__ uint32_t s_cnt[BINS];   // per-bucket count, then tile-local exclusive offset
+    __shared__ uint32_t s_base[BINS];  // global position of the tile's first key of the bucket
     __shared__ uint32_t s_ws[4];
-    __shared__ uint32_t s_b[1];
-    uint32_t ci, lt;
-    tile_to_cell(tile_prefix, n_multi, blockIdx.x, s_b, ci, lt);
-    const uint32_t cell = multi_cells[ci];
+    const uint2 td = tile_desc[blockIdx.x];
+    const uint32_t cell = td.x, lt = td.y;
     const CellMeta m = meta[cell];
     const uint32_t nk = mode_is_pug(m.mode) ? 0u : cell_nkeys[cell];  // PUG cells emit reads, not keys
     const uint32_t t0 = lt * kTileKeys;
@@ -122,7 +107,7 @@ __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ mu
     uint64_t* dst = keys1 + m.key_off;
     uint32_t* gcur = cursor + m.bucket_base;
     const uint32_t nb = 1u << m.lg_nb;
-    if (nb > kLdsBins) {  // giant cell: per-key global atomics
+    if (nb > BINS) {  // giant cell: per-key global atomics
         for (uint32_t i = t0 + threadIdx.x; i < t1; i += 256) {
             const uint64_t key = src[i];
             dst[atomicAdd(&gcur[bucket_of(key >> kGeneBits, m.lg_nb)], 1u)] = key;
@@ -1069,7 +1054,7 @@ void warm_code_object() {
 
 void launch_hist(hipStream_t s, const ResolveArgs& a) {
     if (!a.n_tiles) return;
-    AFQ_LAUNCH(k_hist, a.n_tiles, 256, s, a.multi_cells, a.tile_prefix, a.n_multi, a.meta, a.cell_nkeys, a.keys0, a.cursor);
+    AFQ_LAUNCH(k_hist, a.n_tiles, 256, s, a.tile_desc, a.meta, a.cell_nkeys, a.keys0, a.cursor);
 }
 
 void launch_bucket_scan(hipStream_t s, const ResolveArgs& a) {
@@ -1079,8 +1064,10 @@ void launch_bucket_scan(hipStream_t s, const ResolveArgs& a) {
 
 void launch_scatter(hipStream_t s, const ResolveArgs& a) {
     if (!a.n_tiles) return;
-    AFQ_LAUNCH(k_scatter, a.n_tiles, 256, s, a.multi_cells, a.tile_prefix, a.n_multi, a.meta, a.cell_nkeys, a.keys0,
-               a.keys1, a.cursor);
+    if ((1u << a.max_lg_nb) <= 512u)
+        AFQ_LAUNCH(k_scatter<512>, a.n_tiles, 256, s, a.tile_desc, a.meta, a.cell_nkeys, a.keys0, a.keys1, a.cursor);
+    else
+        AFQ_LAUNCH(k_scatter<kLdsBins>, a.n_tiles, 256, s, a.tile_desc, a.meta, a.cell_nkeys, a.keys0, a.keys1, a.cursor);
 }
 
 static ResolveCfg make_rc(const ResolveArgs& a) {
