@@ -912,8 +912,10 @@ __global__ __launch_bounds__(256, 6) void k_decode_keys(const uint8_t* __restric
 // Output positions come from ballots (all first keys, then all second keys, ...), so consecutive lanes write
 // consecutive slots.  Records with more alignments, or reaching past the staged halo, go through a serial
 // per-lane loop that exists once in the code.  Same proof terms as the other two decoders.
+// PUG: the batch has parsimony cells; for those a record is not turned into keys but into one read
+// (label key, UMI, record offset) for k_pug_cell - same rule as k_decode_par<.., true>.
 constexpr uint32_t kInl = 3;
-template <int BW, int UW, bool TRIVIAL>
+template <int BW, int UW, bool TRIVIAL, bool PUG>
 __global__ __launch_bounds__(256, 8) void k_decode_recs(const uint8_t* __restrict__ bytes,
                                                     const CellMeta* __restrict__ meta, uint32_t n_cells,
                                                     const uint32_t* __restrict__ slab_prefix,
@@ -922,8 +924,10 @@ __global__ __launch_bounds__(256, 8) void k_decode_recs(const uint8_t* __restric
                                                     const uint32_t* __restrict__ t2g, uint32_t ref_count,
                                                     uint32_t num_genes, uint64_t* __restrict__ keys0,
                                                     uint32_t* __restrict__ cell_nkeys,
-                                                    uint64_t* __restrict__ bc_out, CellChk* __restrict__ chk) {
+                                                    uint64_t* __restrict__ bc_out, CellChk* __restrict__ chk,
+                                                    [[maybe_unused]] PugOut pug) {
     static_assert(BW % 4 == 0 && UW % 4 == 0, "aligned layouts only");
+    static_assert(!(TRIVIAL && PUG), "trivial and parsimony are different resolutions");
     constexpr uint32_t BWW = BW / 4, UWW = UW / 4, HW = 1 + BWW + UWW;
     constexpr uint32_t kNone = 0xFFFFFFFFu;
     __shared__ uint32_t s_stage[4][kStage];
@@ -1058,6 +1062,9 @@ __global__ __launch_bounds__(256, 8) void k_decode_recs(const uint8_t* __restric
             // alignments: up to kInl inline, all gathers in flight together
             const uint32_t na_eff = fits ? na : 0u;
             const bool slowrec = na_eff > kInl || il + HW + kInl > kStage;
+            // a parsimony cell at transcript level hashes the refs themselves: no gene lookups for it (wave-uniform)
+            const bool pugc = PUG && mode_is_pug(m.mode);
+            const bool pug_txp = pugc && !mode_pug_gene(m.mode);
             uint32_t t[kInl], g[kInl];
             bool v[kInl];
 #pragma unroll
@@ -1066,13 +1073,15 @@ __global__ __launch_bounds__(256, 8) void k_decode_recs(const uint8_t* __restric
                 t[j] = stage[pj < kStage ? pj : kStage - 1] & 0x7FFFFFFFu;
                 v[j] = !slowrec && j < na_eff;
                 if (v[j] && t[j] >= ref_count) { fail = true; v[j] = false; }
-                g[j] = t2g[v[j] ? t[j] : 0u];
+                g[j] = pug_txp ? 0u : t2g[v[j] ? t[j] : 0u];
             }
+            if (!pug_txp) {
 #pragma unroll
-            for (uint32_t j = 0; j < kInl; ++j) {
-                if (v[j] && g[j] >= num_genes) { fail = true; v[j] = false; }
+                for (uint32_t j = 0; j < kInl; ++j) {
+                    if (v[j] && g[j] >= num_genes) { fail = true; v[j] = false; }
 #pragma unroll
-                for (uint32_t q = 0; q < j; ++q) v[j] = v[j] && !(v[q] && g[q] == g[j]);
+                    for (uint32_t q = 0; q < j; ++q) v[j] = v[j] && !(v[q] && g[q] == g[j]);
+                }
             }
             if (triv) {  // only reads whose alignments name one gene count (pugutils.rs:870-891)
                 bool multi = false;
@@ -1104,6 +1113,50 @@ __global__ __launch_bounds__(256, 8) void k_decode_recs(const uint8_t* __restric
                     if (first) f(gj);
                 }
             };
+            if (PUG && pugc) {   // one read per record: (label key, UMI, record offset); see k_decode_par
+                uint64_t lkey;
+                if (pug_txp) {
+                    uint64_t hs = label_hash_init(na_eff);
+                    uint32_t t0 = 0, t1 = 0;
+                    if (!slowrec) {
+#pragma unroll
+                        for (uint32_t j = 0; j < kInl; ++j) if (j < na_eff) hs = label_hash_step(hs, t[j]);
+                        t0 = t[0]; t1 = t[1];
+                    } else {
+                        for (uint32_t j = 0; j < na_eff; ++j) {
+                            const uint32_t tj = ref_at(j);
+                            if (tj >= ref_count) fail = true;
+                            hs = label_hash_step(hs, tj);
+                            if (j == 0) t0 = tj;
+                            if (j == 1) t1 = tj;
+                        }
+                    }
+                    lkey = label_key(hs, na_eff, t0, t1);
+                } else {   // gene level: order-independent hash of the read's distinct genes
+                    uint64_t hs = 0;
+                    uint32_t kc = 0, ga = 0, gb = 0;
+                    auto add = [&](uint32_t gj) { if (kc == 0) ga = gj; else if (kc == 1) gb = gj; ++kc; hs += gene_set_hash_term(gj); };
+                    if (!slowrec) {
+#pragma unroll
+                        for (uint32_t j = 0; j < kInl; ++j) if (v[j]) add(g[j]);
+                    } else for_each_first_gene(add);
+                    hs ^= (uint64_t)kc * kHashMul;
+                    lkey = label_key(hs, kc, ga, gb);
+                }
+                const uint64_t bm = __ballot(act);
+                const uint32_t totp = (uint32_t)__popcll(bm);
+                if (totp) {
+                    uint32_t wbase = 0;
+                    if (lane == 0) wbase = atomicAdd(&cell_nkeys[cur_cell], totp);
+                    wbase = __builtin_amdgcn_readfirstlane(wbase);
+                    if (wbase + totp > m.nrec) fail = true;
+                    else if (act) {
+                        const uint64_t slot = pug.rd_off[cur_cell] + wbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                        pug.h[slot] = lkey; pug.u[slot] = umi; pug.o[slot] = i;
+                    }
+                }
+                continue;
+            }
             const bool any_slow = __any(slowrec && na_eff > 0);
             if (any_slow) {
                 if (slowrec) for_each_first_gene([&](uint32_t) { ++scnt; });
@@ -1183,18 +1236,22 @@ static void launch_decode_par_t(hipStream_t s, const DecodeArgs& a) {
     const uint32_t n_groups = (a.n_slabs + kSlabsPerWave - 1) / kSlabsPerWave;
     const uint32_t n_cols = n_groups < kDecodeCols ? n_groups : kDecodeCols;
     const uint32_t n_waves = n_cols * ((n_groups + n_cols - 1) / n_cols);
-    if (a.pug.h)  // the batch has PUG cells: instance that also emits (label hash, umi, offset) per read
+    if (a.pug.h && a.short_records && !a.trivial)  // the batch has PUG cells: instances that also emit (label key, umi, offset) per read
+        AFQ_LAUNCH((k_decode_recs<BW, UW, false, true>), (n_waves + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix, a.slab_cell,
+                   a.cell_bc, a.n_slabs, a.t2g, a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out,
+                   const_cast<CellChk*>(a.chk), a.pug);
+    else if (a.pug.h)
         AFQ_LAUNCH((k_decode_par<BW, UW, true>), (n_waves + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix, a.slab_cell,
                    a.cell_bc, a.n_slabs, a.t2g, a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out,
                    const_cast<CellChk*>(a.chk), a.pug);
     else if (a.short_records && a.trivial)
-        AFQ_LAUNCH((k_decode_recs<BW, UW, true>), (n_waves + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix, a.slab_cell,
+        AFQ_LAUNCH((k_decode_recs<BW, UW, true, false>), (n_waves + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix, a.slab_cell,
                    a.cell_bc, a.n_slabs, a.t2g, a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out,
-                   const_cast<CellChk*>(a.chk));
+                   const_cast<CellChk*>(a.chk), a.pug);
     else if (a.short_records)
-        AFQ_LAUNCH((k_decode_recs<BW, UW, false>), (n_waves + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix, a.slab_cell,
+        AFQ_LAUNCH((k_decode_recs<BW, UW, false, false>), (n_waves + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix, a.slab_cell,
                    a.cell_bc, a.n_slabs, a.t2g, a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out,
-                   const_cast<CellChk*>(a.chk));
+                   const_cast<CellChk*>(a.chk), a.pug);
     else if (a.trivial)
         AFQ_LAUNCH((k_decode_keys<BW, UW, true>), (n_waves + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix, a.slab_cell,
                    a.cell_bc, a.n_slabs, a.t2g, a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out,

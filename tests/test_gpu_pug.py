@@ -126,3 +126,32 @@ def test_skewed_umis_fall_back_to_the_global_route(oracle):
     t2g = (np.arange(302) // 3).astype(np.uint32)
     cfg = pkg.WorkerConfig.for_resolution("parsimony", num_genes=101, num_rows=101, umi_len=12)
     assert_same_result(_quant(cfg, t2g, b, off), oracle.quant(cfg, t2g, b, off))
+
+
+@pytest.mark.parametrize("decoder", ["recs", "keys"])
+@pytest.mark.parametrize("res", ["parsimony", "parsimony-gene"])
+def test_pug_batches_through_both_decoders(oracle, monkeypatch, decoder, res):
+    """A parsimony batch turns records into reads (label key, UMI, offset) in the decode: the lane-per-record kernel when
+    records are short (AFQ_DECODE=recs, the planner's choice for 10x data), the older per-record walk otherwise
+    (AFQ_DECODE=keys).  Records of every awkward length (around the three inline refs, up to the 64-dword halo), repeated genes, tiny cells that take the cr-like rule next to PUG cells: both against the oracle."""
+    monkeypatch.setenv("AFQ_DECODE", decoder)
+    rng = np.random.default_rng(77)
+    n_txp, n_genes = 900, 300
+    t2g = (rng.permutation(n_txp) % n_genes).astype(np.uint32)
+    lens = [1, 2, 3, 4, 5, 8, 9, 30, 59, 60, 61] if res == "parsimony" else [1, 2, 3, 4, 5, 8, 9, 30]
+    cells = []
+    for ci in range(4):
+        reads = []
+        for rep in range(40 if ci < 3 else 1):
+            for n in rng.permutation(lens):
+                umi = int(rng.integers(0, 1 << 10))   # few UMIs: neighbours and repeats
+                refs = sorted(int(x) for x in rng.choice(n_txp, size=int(n), replace=False)) if n else []
+                reads.append((umi, refs))
+                for _ in range(int(rng.integers(0, 6))):
+                    reads.append((int(rng.integers(0, 1 << 10)), sorted(int(x) for x in rng.choice(n_txp, size=int(rng.integers(1, 4)), replace=False))))
+        cells.append((0x5A5A0000 + ci, reads))
+    b, off = rad.encode_cells(cells, 4, 4)
+    cfg = pkg.WorkerConfig.for_resolution(res, num_genes=n_genes, num_rows=n_genes, small_thresh=100)
+    got, want = run_both(oracle, cfg, t2g, b, off)
+    assert_same_result(got, want)
+    assert got.val.sum() > 0
