@@ -263,7 +263,10 @@ __device__ __forceinline__ uint32_t genes_of(const PugCtx& c, uint32_t n, GetRef
 // One resolved molecule with gene label g[0..ng): a column, a gene-level class for the EM, or nothing.
 // (quant.rs:974-1024 -> extract_counts utils.rs:688-753 / em_optimize(only_unique) em.rs:499-514 / EM)
 __device__ __forceinline__ void emit_molecule(const PugCtx& c, const uint32_t* g, uint32_t ng) {
-    if (ng == 0xFFFFFFFFu) { c.s_cnt[3] = kErrPugLimit; return; }
+    if (ng == 0xFFFFFFFFu) {   // more than kMaxGenesPerLabel genes: no column under any rule (one gene; USA: at most ten) - only the
+        if (c.em) c.s_cnt[3] = kErrPugLimit;   // EM would have to carry the class
+        return;
+    }
     if (ng == 0) return;
     uint32_t col = 0xFFFFFFFFu;
     if (c.em) {

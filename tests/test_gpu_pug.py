@@ -138,7 +138,8 @@ def test_pug_batches_through_both_decoders(oracle, monkeypatch, decoder, res):
     rng = np.random.default_rng(77)
     n_txp, n_genes = 900, 300
     t2g = (rng.permutation(n_txp) % n_genes).astype(np.uint32)
-    lens = [1, 2, 3, 4, 5, 8, 9, 30, 59, 60, 61] if res == "parsimony" else [1, 2, 3, 4, 5, 8, 9, 30]
+    lens = [1, 2, 3, 4, 5, 8, 9, 30, 59, 60, 61]   # (few UMIs: at gene level the cell is one component above --large-graph-thresh,
+    # resolved per UMI, with ties among more genes than the device carries per molecule - dropped, as any tie is without an EM)
     cells = []
     for ci in range(4):
         reads = []
