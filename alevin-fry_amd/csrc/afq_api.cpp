@@ -140,7 +140,7 @@ struct Range { uint32_t c0, c1; };
 
 struct RangeState {
     hipStream_t stream = nullptr;
-    DevBuf d_meta, d_keys0, d_keys1, d_cell_nkeys, d_bucket_cnt, d_bucket_cell, d_multi_cells, d_tile_desc, d_ncols,
+    DevBuf d_meta, d_keys0, d_keys1, d_cell_nkeys, d_bucket_cnt, d_bucket_cell, d_multi_cells, d_tile_desc, d_src_off, d_ncols,
         d_nnz, d_ovf, d_status, d_bc, d_cell_ptr, d_gene, d_val, d_chk, d_slab_prefix, d_slab_cell, d_cell_bc, d_bdesc, d_lab,
         d_lab_cnt, d_em_off, d_em_scratch, d_em_nnz, d_pug_cells, d_rd_off, d_rd_h, d_rd_u, d_rd_o, d_pug_scr_off,
         d_pug_scratch, d_epool, d_epool_cur, d_alt, d_hist_cells, d_fix, d_em_hdr, d_em_order, d_eq_ncls, d_eq_nw, d_eq_cptr,
@@ -154,7 +154,7 @@ struct RangeState {
     hipEvent_t kernels_done = nullptr;
     std::vector<TimedLaunch> launches;  // HIP-event brackets of this range's kernels (cfg.profile)
     std::vector<DevBuf*> all() {
-        return {&d_meta, &d_keys0, &d_keys1, &d_cell_nkeys, &d_bucket_cnt, &d_bucket_cell, &d_multi_cells, &d_tile_desc,
+        return {&d_meta, &d_keys0, &d_keys1, &d_cell_nkeys, &d_bucket_cnt, &d_bucket_cell, &d_multi_cells, &d_tile_desc, &d_src_off,
                 &d_ncols, &d_nnz, &d_ovf, &d_status, &d_bc, &d_cell_ptr, &d_gene, &d_val, &d_chk, &d_slab_prefix, &d_slab_cell,
                 &d_cell_bc, &d_bdesc, &d_lab, &d_lab_cnt, &d_em_off, &d_em_scratch, &d_em_nnz, &d_pug_cells, &d_rd_off, &d_rd_h,
                 &d_rd_u, &d_rd_o, &d_pug_scr_off, &d_pug_scratch, &d_epool, &d_epool_cur, &d_alt, &d_hist_cells, &d_fix, &d_em_hdr, &d_em_order,
@@ -191,6 +191,14 @@ struct afq_ctx {
     // Two sets of per-range device state: while the rows of range i cross PCIe, the kernels of range i+1 run.
     RangeState rs[2];
     bool all_aligned = true;  // every chunk offset is a multiple of 4
+    // 1/2-byte barcode or UMI fields: the batch is rewritten on the device with 4-byte fields (k_widen) and everything
+    // downstream works on that copy - w_off / w_nbytes are the chunks of the copy, chunk_off / hdr stay the caller's
+    bool widen = false;
+    uint32_t eff_bc = 0, eff_umi = 0;
+    std::vector<uint64_t> w_off;
+    std::vector<uint32_t> w_nbytes;
+    uint64_t wide_bytes = 0;
+    DevBuf d_wide;
     ResultPool* pool = nullptr;
     // host planning state
     std::vector<uint64_t> chunk_off;
@@ -259,9 +267,6 @@ bool valid_width(uint32_t w) { return w == 1 || w == 2 || w == 4 || w == 8; }
 // What the device path implements today.  Anything else is refused loudly.
 int check_supported(afq_ctx* c) {
     const afq_config& g = c->cfg;
-    if (g.resolution >= AFQ_RES_PARSIMONY_EM && g.resolution <= AFQ_RES_PARSIMONY_GENE &&
-        !decode_par_supported(g.bc_bytes, g.umi_bytes))
-        return fail(c, AFQ_ERR_UNSUPPORTED, "device parsimony needs 4- or 8-byte barcode/UMI fields");
     if (g.sa_model > AFQ_SA_PREFER_AMBIG) return fail(c, AFQ_ERR_INVALID_ARG, "unknown sa_model");
     if (g.num_bootstraps && !(g.resolution == AFQ_RES_CR_LIKE_EM || g.resolution == AFQ_RES_PARSIMONY_EM || g.resolution == AFQ_RES_PARSIMONY_GENE_EM))
         return fail(c, AFQ_ERR_INVALID_ARG, "bootstrapping can only be used with the cr-like-em, parsimony-em, or parsimony-gene-em resolution strategies");   // main.rs:713-724
@@ -286,7 +291,7 @@ int plan_ranges(afq_ctx* c) {
     const bool pug_res = res >= AFQ_RES_PARSIMONY_EM && res <= AFQ_RES_PARSIMONY_GENE;
     // pass 1: validate the chunk headers, device bytes each cell needs
     std::vector<double> need(c->n_cells);
-    double total_need = 0, pug_fixed = 0;
+    double total_need = 0, pug_fixed = 0, wide_new = 0;
     c->all_aligned = true;
     for (uint32_t i = 0; i < c->n_cells; ++i) {
         const uint64_t off = c->chunk_off[i];
@@ -309,12 +314,33 @@ int plan_ranges(afq_ctx* c) {
         need[i] = nd;
         total_need += nd;
     }
+    // (also: parsimony over 4/8-byte fields whose chunks the caller placed at offsets that are not dword aligned - same copy, nothing widened)
+    c->widen = !decode_par_supported(c->cfg.bc_bytes, c->cfg.umi_bytes) || (pug_res && !c->all_aligned);
+    c->eff_bc = c->cfg.bc_bytes < 4 ? 4 : c->cfg.bc_bytes;
+    c->eff_umi = c->cfg.umi_bytes < 4 ? 4 : c->cfg.umi_bytes;
+    if (c->widen) {
+        const uint32_t delta = c->eff_bc + c->eff_umi - c->cfg.bc_bytes - c->cfg.umi_bytes;
+        c->w_off.resize(c->n_cells);
+        c->w_nbytes.resize(c->n_cells);
+        uint64_t o = 0;
+        for (uint32_t i = 0; i < c->n_cells; ++i) {
+            const uint64_t nb = (uint64_t)c->hdr[2 * i] + (uint64_t)c->hdr[2 * i + 1] * delta;
+            if (nb >= (1ull << 32)) return fail(c, AFQ_ERR_UNSUPPORTED, "cell " + std::to_string(i) + ": chunk over 4 GiB once its fields are widened");
+            c->w_off[i] = o; c->w_nbytes[i] = (uint32_t)nb;
+            o += nb;   // (a multiple of 4: 8 + nrec * (4 + 4|8 + 4|8) + 4 * refs)
+        }
+        c->wide_bytes = o;
+        const size_t had = c->d_wide.cap;
+        HIP_TRY(c, c->d_wide.ensure(o + 16));
+        wide_new = (double)(c->d_wide.cap - had);
+    }
     // pass 2: cut into ranges.  Big batches are cut into a handful of ranges even when memory
     // would allow one, so that the D2H of one range's rows hides under the kernels of the next.  The ranges taper:
     // the last one's compaction + D2H is the only part nothing hides, so it is the smallest.
     static const double kTaper[] = {0.28, 0.56, 0.78, 0.92, 1.0};
     if (pug_fixed > 0.5 * mem_budget) return fail(c, AFQ_ERR_OOM, "the largest parsimony cell's scratch does not fit device memory");
-    double budget = mem_budget - pug_fixed;
+    double budget = mem_budget - pug_fixed - 0.40 * wide_new;   // (the widened copy was allocated after the free-memory query)
+    if (budget <= 0) return fail(c, AFQ_ERR_OOM, "the widened copy of the batch leaves no room for the ranges");
     const bool pipe = c->n_bytes >= (256u << 20) && !std::getenv("AFQ_NO_PIPELINE");  // (profiling: one range, no overlap between kernels)
     if (const char* e = std::getenv("AFQ_RANGE_BYTES")) budget = std::min(budget, std::atof(e));  // tests: force many ranges
     c->ranges.clear();
@@ -347,7 +373,8 @@ static uint32_t decode_short_records(uint64_t n_ref_words, uint64_t n_records) {
 int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
     HostClock hc;
     RangeState& B = c->rs[slot];
-    const afq_config& g = c->cfg;
+    afq_config g = c->cfg;
+    if (c->widen) { g.bc_bytes = c->eff_bc; g.umi_bytes = c->eff_umi; }   // what the kernels see: the widened copy
     const uint32_t H = hdr_bytes(g);
     const uint32_t n = r.c1 - r.c0;
     B.meta.resize(n);
@@ -355,7 +382,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
     std::vector<uint32_t> multi, bucket_cell, slab_prefix, pug_cells, hist_cells;
     std::vector<uint64_t> rd_off(n, 0);
     uint64_t n_pug_reads = 0, pug_words = 0;  // pug_words: scratch of the largest parsimony cell
-    const bool par = c->all_aligned && decode_par_supported(g.bc_bytes, g.umi_bytes);
+    const bool par = (c->widen || c->all_aligned) && decode_par_supported(g.bc_bytes, g.umi_bytes);
     uint64_t key_off = 0, n_buckets = 0, n_tiles = 0, n_slabs = 0;
     uint32_t max_lg_nb = 0;
     if (par) slab_prefix.reserve(n + 1);
@@ -363,8 +390,8 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t ci = r.c0 + i;
         CellMeta& m = B.meta[i];
-        m.chunk_off = c->chunk_off[ci];
-        m.nbytes = c->hdr[2 * ci];
+        m.chunk_off = c->widen ? c->w_off[ci] : c->chunk_off[ci];
+        m.nbytes = c->widen ? c->w_nbytes[ci] : c->hdr[2 * ci];
         m.nrec = c->hdr[2 * ci + 1];
         m.n_ref = (uint32_t)((m.nbytes - 8ull - (uint64_t)m.nrec * H) / 4);
         m.key_off = key_off;
@@ -502,7 +529,16 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
     if (h2d_done) HIP_TRY(c, hipStreamWaitEvent(s, h2d_done, 0));   // afq_submit: this range's input bytes have landed
     hc.lap("run: uploads + memsets");
 
-    DecodeArgs da{c->d_bytes, c->n_bytes, B.d_meta.as<CellMeta>(), n, c->d_t2g.as<uint32_t>(), c->ref_count,
+    const uint8_t* const in_bytes = c->widen ? c->d_wide.as<uint8_t>() : c->d_bytes;
+    const size_t in_n = c->widen ? (size_t)c->wide_bytes : c->n_bytes;
+    if (c->widen) {
+        HIP_TRY(c, B.d_src_off.ensure(8ull * n));
+        HIP_TRY(c, hipMemcpyAsync(B.d_src_off.p, c->chunk_off.data() + r.c0, 8ull * n, hipMemcpyHostToDevice, s));   // (c->chunk_off outlives the batch)
+        ScopedTimer t(c, K_DECODE, s, &B.launches);
+        launch_widen(s, c->d_bytes, c->n_bytes, B.d_src_off.as<uint64_t>(), B.d_meta.as<CellMeta>(), n, c->cfg.bc_bytes, c->cfg.umi_bytes,
+                     c->eff_bc, c->eff_umi, c->d_wide.as<uint8_t>(), B.d_status.as<DevStatus>());
+    }
+    DecodeArgs da{in_bytes, in_n, B.d_meta.as<CellMeta>(), n, c->d_t2g.as<uint32_t>(), c->ref_count,
                   g.num_genes, B.d_keys0.as<uint64_t>(), B.d_cell_nkeys.as<uint32_t>(),
                   B.d_bc.as<uint64_t>(), B.d_status.as<DevStatus>(),
                   par ? B.d_chk.as<CellChk>() : nullptr, B.d_slab_prefix.as<uint32_t>(), B.d_slab_cell.as<uint32_t>(),
@@ -536,7 +572,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
     if (n_multi) { ScopedTimer t(c, K_RESOLVE_BIG, s, &B.launches); launch_resolve_big(s, ra); }
     if (n_pug) {
         PugCellArgs pa{};
-        pa.bytes = c->d_bytes; pa.meta = ra.meta; pa.pug_cells = B.d_pug_cells.as<uint32_t>(); pa.cell_nkeys = ra.cell_nkeys;
+        pa.bytes = in_bytes; pa.meta = ra.meta; pa.pug_cells = B.d_pug_cells.as<uint32_t>(); pa.cell_nkeys = ra.cell_nkeys;
         pa.rd = da.pug; pa.scr_stride = pug_words; pa.scratch = B.d_pug_scratch.as<uint32_t>(); pa.work_counter = B.d_pug_scr_off.as<uint32_t>(); pa.n_pug = n_pug;
         pa.epool = B.d_epool.as<uint32_t>(); pa.epool_cursor = B.d_epool_cur.as<unsigned long long>(); pa.epool_cap = epool_words;
         pa.t2g = c->d_t2g.as<uint32_t>(); pa.keys0 = ra.keys0; pa.cell_ncols = ra.cell_ncols; pa.lab = ra.lab; pa.lab_cnt = ra.lab_cnt;
@@ -925,7 +961,7 @@ void afq_destroy(afq_ctx* c) {
         if (rs.kernels_done) (void)hipEventDestroy(rs.kernels_done);
         if (rs.stream) (void)hipStreamDestroy(rs.stream);
     }
-    DevBuf* bufs[] = {&c->d_t2g, &c->d_bytes_own, &c->d_chunk_off, &c->d_hdr};
+    DevBuf* bufs[] = {&c->d_t2g, &c->d_bytes_own, &c->d_chunk_off, &c->d_hdr, &c->d_wide};
     for (auto b : bufs) b->release();
     for (auto& b : c->atac) b.release();
     for (auto& p : c->stage) if (p) (void)hipHostFree(p);

@@ -13,6 +13,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <algorithm>
+
 #include "afq_common.h"
 #include "afq_kernels.h"
 #include "afq_prims.h"
@@ -224,6 +226,99 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ byte
         atomicAdd(&st->n_keys, (unsigned long long)nk_total);
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// k_widen: chunks whose barcode / UMI fields are 1 or 2 bytes wide (UMIs of up to 8 nt: Drop-seq, CEL-Seq2, inDrop ...;
+// convert.rs:323-344 picks the narrowest integer) have records of 4 + bw + uw + 4 na bytes - nothing in them is dword
+// aligned, and both the walk-free decoders and the parsimony kernel (which reads labels straight out of the chunk)
+// want dwords.  Rather than refusing such input, the batch is rewritten once on the device with both fields widened
+// to 4 bytes (zero-extended; 8 stays 8): record r of a chunk moves from byte s to s + r * delta, delta = the bytes
+// added per record, so every lane that owns a record start knows its destination.  One wave per cell walks the record
+// chain exactly like k_decode does (a record's length is its own na).  Everything downstream sees an ordinary
+// aligned 4/8-byte layout.
+__global__ __launch_bounds__(256) void k_widen(const uint8_t* __restrict__ src, size_t n_src, const uint64_t* __restrict__ src_off,
+                                              const CellMeta* __restrict__ meta, uint32_t n_cells, uint32_t bw, uint32_t uw,
+                                              uint32_t ebw, uint32_t euw, uint8_t* __restrict__ dst, DevStatus* st) {
+    const uint32_t lane = lane_id();
+    const uint32_t HDR = 4 + bw + uw, EHDR = 4 + ebw + euw, delta = EHDR - HDR;
+    auto ld_n = [](const uint8_t* p, uint32_t n) -> uint64_t {
+        uint64_t v = 0;
+        for (uint32_t i = 0; i < n; ++i) v |= (uint64_t)p[i] << (8 * i);
+        return v;
+    };
+    auto st_n = [](uint8_t* p, uint64_t v, uint32_t n) {   // p is dword aligned, n is 4 or 8
+        *reinterpret_cast<uint32_t*>(p) = (uint32_t)v;
+        if (n == 8) *reinterpret_cast<uint32_t*>(p + 4) = (uint32_t)(v >> 32);
+    };
+    for (uint32_t cell = blockIdx.x * 4 + (threadIdx.x >> 6); cell < n_cells; cell += gridDim.x * 4) {
+        const CellMeta m = meta[cell];               // the WIDENED chunk: offset in dst, nbytes, nrec
+        const uint64_t so = src_off[cell];
+        const uint64_t src_nbytes = (uint64_t)m.nbytes - (uint64_t)m.nrec * delta;
+        const uint64_t abase = so & ~3ull;
+        const uint32_t mis = (uint32_t)(so - abase);
+        uint64_t pos = (uint64_t)mis + 8;
+        const uint64_t end = (uint64_t)mis + src_nbytes;
+        uint8_t* const dchunk = dst + m.chunk_off;
+        if (lane == 0) { reinterpret_cast<uint32_t*>(dchunk)[0] = m.nbytes; reinterpret_cast<uint32_t*>(dchunk)[1] = m.nrec; }
+        uint32_t rec_seen = 0;
+        bool bad = false;
+        while (pos < end && !bad) {
+            const uint64_t w = pos >> 8;
+            const uint64_t wbyte = abase + (w << 8) + lane * 4;
+            uint32_t v_cur = 0, v_next = 0;
+            if (wbyte + 4 <= n_src) v_cur = *(const uint32_t*)(src + wbyte);
+            else if (wbyte < n_src) { for (uint64_t q = wbyte; q < n_src; ++q) v_cur |= (uint32_t)src[q] << (8 * (q - wbyte)); }
+            const uint64_t nb = wbyte + 256;
+            if (nb + 4 <= n_src) v_next = *(const uint32_t*)(src + nb);
+            else if (nb < n_src) { for (uint64_t q = nb; q < n_src; ++q) v_next |= (uint32_t)src[q] << (8 * (q - nb)); }
+            const uint64_t wend = ((w + 1) << 8) < end ? ((w + 1) << 8) : end;
+            uint64_t mask = 0, sub0 = 0, sub1 = 0;
+            while (pos < wend) {   // scalar walk over the records that start in this window
+                const uint32_t idx = __builtin_amdgcn_readfirstlane((uint32_t)(pos >> 2) & 63u);
+                uint32_t na = __builtin_amdgcn_readlane(v_cur, idx);
+                const uint32_t sh = ((uint32_t)pos & 3u) * 8u;
+                if (sh) {
+                    const uint32_t hi = idx < 63 ? __builtin_amdgcn_readlane(v_cur, idx + 1) : __builtin_amdgcn_readlane(v_next, 0);
+                    na = (na >> sh) | (hi << (32 - sh));
+                }
+                if ((mask >> idx) & 1ull) { bad = true; pos = end; break; }   // two record starts inside one dword: records are >= 6 bytes, a dword holds one
+                if (pos & 1) sub0 |= 1ull << idx;
+                if (pos & 2) sub1 |= 1ull << idx;
+                mask |= 1ull << idx;
+                const uint64_t rec_bytes = (uint64_t)HDR + 4ull * na;
+                if (pos + rec_bytes > end) { bad = true; pos = end; break; }
+                pos += rec_bytes;
+            }
+            const bool is_start = (mask >> lane) & 1ull;
+            if (is_start && !bad) {
+                const uint32_t rec_idx = rec_seen + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                const uint32_t sub = (uint32_t)((sub0 >> lane) & 1ull) | ((uint32_t)((sub1 >> lane) & 1ull) << 1);
+                const uint64_t roff = abase + (w << 8) + lane * 4 + sub;
+                const uint8_t* rec = src + roff;
+                const uint32_t na = ld_u32(rec, false);
+                const uint64_t drel = (roff - so) + (uint64_t)rec_idx * delta;
+                if (rec_idx < m.nrec && drel + EHDR + 4ull * na <= m.nbytes) {
+                    uint8_t* d = dchunk + drel;
+                    *reinterpret_cast<uint32_t*>(d) = na;
+                    st_n(d + 4, ld_n(rec + 4, bw), ebw);
+                    st_n(d + 4 + ebw, ld_n(rec + 4 + bw, uw), euw);
+                    const uint8_t* rp = rec + HDR;
+                    uint32_t* dr = reinterpret_cast<uint32_t*>(d + EHDR);
+                    for (uint32_t j = 0; j < na; ++j) dr[j] = ld_u32(rp + 4 * j, false);
+                }
+            }
+            rec_seen += (uint32_t)__popcll(mask);
+        }
+        if (bad || rec_seen != m.nrec) { if (lane == 0) set_err(st, kErrRecordWalk, cell); }
+    }
+}
+
+void launch_widen(hipStream_t s, const uint8_t* src, size_t n_src, const uint64_t* src_off, const CellMeta* meta, uint32_t n_cells,
+                  uint32_t bw, uint32_t uw, uint32_t ebw, uint32_t euw, uint8_t* dst, DevStatus* st) {
+    if (!n_cells) return;
+    const uint32_t grid = std::min<uint32_t>((n_cells + 3) / 4, 8192u);
+    AFQ_LAUNCH(k_widen, grid, 256, s, src, n_src, src_off, meta, n_cells, bw, uw, ebw, euw, dst, st);
 }
 
 // Walk-free proof, final step: per cell compare the accumulated candidate count and sizes

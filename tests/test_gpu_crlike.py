@@ -326,8 +326,9 @@ def test_unsupported_requests_fail_loudly():
     """What the device path does not implement is refused with AFQ_ERR_UNSUPPORTED, never approximated."""
     s = synth.synth(6, [50], num_genes=20)
     cells = [(1, [(5, [0])])]
-    b, off = rad.encode_cells(cells, 2, 2)  # parsimony needs dword fields
-    q = pkg.Quantifier(pkg.WorkerConfig.for_resolution("parsimony", num_genes=20, num_rows=20, bc_bytes=2, umi_bytes=2), s.tid_to_gid)
+    b, off = rad.encode_cells(cells, 4, 4)
+    # -d keeps gene-level classes, which only the -em resolutions hold on the device (afq_quantify runs the sibling)
+    q = pkg.Quantifier(pkg.WorkerConfig.for_resolution("parsimony", num_genes=20, num_rows=20, dump_eq=True), s.tid_to_gid)
     try:
         with pytest.raises(pkg.AfqError) as e:
             q.quant_chunks(b, off)

@@ -156,3 +156,53 @@ def test_pug_batches_through_both_decoders(oracle, monkeypatch, decoder, res):
     got, want = run_both(oracle, cfg, t2g, b, off)
     assert_same_result(got, want)
     assert got.val.sum() > 0
+
+
+def _cells_of(s, bc_of):
+    """A SynthRad as the (bc, [(umi, refs)]) lists rad.encode_cells takes (any field widths)."""
+    cells, r, w = [], 0, 0
+    for ci, n in enumerate(s.cell_nrec):
+        reads = []
+        for _ in range(int(n)):
+            na = int(s.na[r])
+            reads.append((int(s.umi[r]), [int(x) for x in s.refs[w:w + na]]))
+            r += 1; w += na
+        cells.append((bc_of(ci), reads))
+    return cells
+
+
+@pytest.mark.parametrize("bw,uw,umi_len", [(4, 2, 8), (2, 2, 8), (2, 1, 4), (1, 2, 7), (8, 2, 8), (2, 8, 12)])
+@pytest.mark.parametrize("res,usa", [("parsimony", False), ("parsimony-em", True), ("cr-like", False)])
+def test_narrow_fields_are_widened_on_the_device(oracle, bw, uw, umi_len, res, usa):
+    """Barcode / UMI fields of 1 or 2 bytes (UMIs of up to 8 nt: Drop-seq, CEL-Seq2, inDrop) make records that are not
+    dword aligned.  The batch is rewritten on the device with 4-byte fields (k_widen) and then takes the ordinary path -
+    parsimony included, which used to refuse such input.  Against the oracle reading the original bytes."""
+    s = synth.synth(90 + bw + uw, [2500, 600, 150, 120, 40, 7], num_genes=300, txp_per_gene=3, usa=usa, umi_len=umi_len, dup=0.4, cross=0.3,
+                    umi_err=0.03, max_extra_na=6)
+    cells = _cells_of(s, lambda ci: 3 + 5 * ci)   # barcodes that fit one byte
+    b, off = rad.encode_cells(cells, bw, uw)
+    cfg = cfg_for(s, res, bc_bytes=bw, umi_bytes=uw, umi_len=umi_len)
+    got, want = run_both(oracle, cfg, s.tid_to_gid, b, off)
+    assert_same_result(got, want)
+    assert got.val.sum() > 0
+    assert list(got.bc) == [3 + 5 * ci for ci in range(len(cells))]
+
+
+def test_parsimony_over_chunks_at_odd_offsets(oracle):
+    """4-byte fields, but the caller's chunks sit at offsets that differ mod 4 (so no single shift aligns them): the
+    batch is repacked on the device by the same kernel (nothing widened) instead of being refused."""
+    s = synth.synth(97, [1800, 300, 45], num_genes=200, txp_per_gene=3, dup=0.4, cross=0.3, umi_err=0.03)
+    b, off = s.encode()
+    b = np.asarray(b, np.uint8)
+    ends = list(off[1:]) + [len(b)]
+    parts, offs, pos = [], [], 0
+    for i, (a, e) in enumerate(zip(off, ends)):
+        pad = i + 1   # 1, 2, 3 bytes of padding in front of the chunks
+        parts.append(np.zeros(pad, np.uint8)); pos += pad
+        offs.append(pos)
+        parts.append(b[int(a):int(e)]); pos += int(e) - int(a)
+    b2 = np.concatenate(parts)
+    cfg = cfg_for(s, "parsimony")
+    got, want = run_both(oracle, cfg, s.tid_to_gid, b2, np.asarray(offs, np.uint64))
+    assert_same_result(got, want)
+    assert got.val.sum() > 0
