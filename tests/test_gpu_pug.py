@@ -206,3 +206,24 @@ def test_parsimony_over_chunks_at_odd_offsets(oracle):
     got, want = run_both(oracle, cfg, s.tid_to_gid, b2, np.asarray(offs, np.uint64))
     assert_same_result(got, want)
     assert got.val.sum() > 0
+
+
+@pytest.mark.parametrize("res", ["parsimony", "cr-like"])
+def test_widened_batch_cut_into_many_ranges(oracle, monkeypatch, res):
+    """The widened copy is made range by range (each range's kernels wait for ITS bytes when the input is piped over
+    PCIe): force a dozen ranges and the pipelined upload on a 2-byte-UMI batch."""
+    monkeypatch.setenv("AFQ_RANGE_BYTES", str(1 << 20))
+    sizes = [900, 700, 650, 600, 500, 450, 400, 300, 250, 200, 150, 120, 110, 90, 60, 30, 8, 2]
+    s = synth.synth(123, sizes, num_genes=300, txp_per_gene=3, umi_len=8, dup=0.4, cross=0.3, umi_err=0.03, max_extra_na=6)
+    cells = _cells_of(s, lambda ci: 100000 + 7 * ci)
+    b, off = rad.encode_cells(cells, 4, 2)
+    cfg = cfg_for(s, res, bc_bytes=4, umi_bytes=2, umi_len=8)
+    q = pkg.Quantifier(cfg, s.tid_to_gid)
+    try:
+        got = q.quant_chunks(b, off)
+        st = q.batch_stats()
+    finally:
+        q.close()
+    want = oracle.quant(cfg, s.tid_to_gid, b, off)
+    assert_same_result(got, want)
+    assert st["n_records"] == sum(sizes) and st["n_fallback_cells"] == 0, st
