@@ -396,20 +396,20 @@ int afq_rad_parse_prelude(const uint8_t* bytes, size_t n, afq_rad_info* out) {
 
 // MatrixMarket as sprs::io::write_matrix_market writes a TriMatI<f32,u32> (coordinate real general, 1-based), from CSR
 static bool write_mtx_file(const std::string& path, uint64_t n_rows, uint64_t n_cols, const std::vector<uint64_t>& rp,
-                       const std::vector<uint32_t>& cols, const std::vector<float>& vals, uint32_t num_threads) {
+                       const uint32_t* cols, const float* vals, size_t nz, uint32_t num_threads) {
     const int fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if (fd < 0) return false;
     char head[160];
     const int hl = std::snprintf(head, sizeof head, "%%%%MatrixMarket matrix coordinate real general\n%% written by sprs\n%llu %llu %zu\n",
-                                 (unsigned long long)n_rows, (unsigned long long)n_cols, vals.size());
+                                 (unsigned long long)n_rows, (unsigned long long)n_cols, nz);
     bool ok = ::pwrite(fd, head, (size_t)hl, 0) == hl;
     // the entries are formatted by -t threads into per-slice buffers (same text as one fprintf per entry) and written by the
     // same threads at their final file offsets; a slice is a run of consecutive entries, its first row found by binary
     // search in the row pointers
-    const size_t nz = vals.size();
-    // -t defaults to every core in the reference (main.rs:303); 0 = not given
-    const unsigned nth = std::max(1u, std::min(num_threads ? num_threads : std::thread::hardware_concurrency(), 64u));
-    const size_t slice = 1u << 20;
+    // -t defaults to every core in the reference (main.rs:303); 0 = not given.  Slices of 2^18 entries: a 40 M-entry matrix
+    // keeps 160 threads busy in one round (at 2^20 it was 41 threads formatting a million entries each)
+    const unsigned nth = std::max(1u, std::min(num_threads ? num_threads : std::thread::hardware_concurrency(), 256u));
+    const size_t slice = 1u << 18;
     uint64_t file_off = (uint64_t)hl;
     for (size_t base = 0; base < nz && ok; base += slice * nth) {
         // (plain arrays, not strings: a string would zero-fill its 112 bytes per entry before a tenth of them is written)
@@ -576,7 +576,7 @@ int afq_infer_files(const afq_infer_opts* o) {
     afq_result_release(&res);
     afq_destroy(ctx);
     // (num_cells, num_genes) with num_cells = the subset's size when one is given (infer.rs:141, 175-178)
-    if (!write_mtx_file(outd + "/quants_mat.mtx", filter ? keep.size() : n_rows, num_genes, rp, cols, vals, o->num_threads))
+    if (!write_mtx_file(outd + "/quants_mat.mtx", filter ? keep.size() : n_rows, num_genes, rp, cols.data(), vals.data(), vals.size(), o->num_threads))
         return hfail(AFQ_ERR_BAD_INPUT, "could not write quants_mat.mtx");
     return 0;
 }
@@ -595,6 +595,14 @@ struct DevOut {   // what one device produced for its range of cells, in cell or
     bool have_eq = false;
     std::vector<uint64_t> bm_end, bv_end; std::vector<uint32_t> bm_col, bv_col; std::vector<float> bm_val, bv_val;   // -b
     double t_submit = 0, t_collect = 0;
+    // a range that went through in ONE batch keeps the library's result (pinned, already paged in) instead of copying its
+    // rows into the vectors above - 330 MB of first-touch page faults on a PBMC-sized run
+    afq_result held{};
+    bool is_held = false;
+    DevOut() = default;
+    DevOut(const DevOut&) = delete;
+    DevOut& operator=(const DevOut&) = delete;
+    ~DevOut() { if (is_held) afq_result_release(&held); }
 };
 
 // Greedy prefix split of the chunk list into `parts` contiguous ranges of about equal bytes (the collated
@@ -693,13 +701,16 @@ static void run_device_range(const afq_config& cfg, const afq_config* cfg_eq, co
             if (ctx_eq) afq_result_release(&res_eq);
         }
         const uint64_t g0 = out.gene.size();
-        out.gene.insert(out.gene.end(), res.gene, res.gene + res.nnz);
-        out.val.insert(out.val.end(), res.val, res.val + res.nnz);
+        const bool whole = c0 == cell0 && c1 == cell1;
+        if (!whole) {
+            out.gene.insert(out.gene.end(), res.gene, res.gene + res.nnz);
+            out.val.insert(out.val.end(), res.val, res.val + res.nnz);
+        }
         for (uint64_t i = 0; i < res.n_cells; ++i) out.row_end.push_back(g0 + res.cell_ptr[i + 1]);
         out.bc.insert(out.bc.end(), res.bc, res.bc + res.n_cells);
         out.nrec.insert(out.nrec.end(), res.nrec, res.nrec + res.n_cells);
         out.flags.insert(out.flags.end(), res.flags, res.flags + res.n_cells);
-        afq_result_release(&res);
+        if (whole) { out.held = res; out.is_held = true; } else afq_result_release(&res);
         c0 = c1;
     }
 }
@@ -1070,16 +1081,21 @@ int afq_quantify(const afq_quant_opts* o) {
     std::vector<uint64_t> eq_row_ptr(1, 0);                     // cell_offset
     std::vector<uint32_t> bm_col, bv_col; std::vector<float> bm_val, bv_val;   // BootstrapHelper's mean / variance triplets, as CSR
     std::vector<uint64_t> bm_ptr(1, 0), bv_ptr(1, 0);
+    auto part_nnz = [](const DevOut& d) -> size_t { return d.is_held ? (size_t)d.held.nnz : d.gene.size(); };
+    const bool one_held = parts.size() == 1 && parts[0].is_held;
     if (parts.size() == 1) { all_gene.swap(parts[0].gene); all_val.swap(parts[0].val); }
     else {
         size_t tot = 0;
-        for (auto& p2 : parts) tot += p2.gene.size();
+        for (auto& p2 : parts) tot += part_nnz(p2);
         all_gene.reserve(tot); all_val.reserve(tot);
     }
     row_ptr.reserve(row_index + 1); bc_all.reserve(row_index); nrec_all.reserve(row_index); flags_all.reserve(row_index);
     for (auto& p2 : parts) {
         const uint64_t g0 = row_ptr.back();
-        if (parts.size() > 1) { all_gene.insert(all_gene.end(), p2.gene.begin(), p2.gene.end()); all_val.insert(all_val.end(), p2.val.begin(), p2.val.end()); std::vector<uint32_t>().swap(p2.gene); std::vector<float>().swap(p2.val); }
+        if (parts.size() > 1) {
+            if (p2.is_held) { all_gene.insert(all_gene.end(), p2.held.gene, p2.held.gene + p2.held.nnz); all_val.insert(all_val.end(), p2.held.val, p2.held.val + p2.held.nnz); }
+            else { all_gene.insert(all_gene.end(), p2.gene.begin(), p2.gene.end()); all_val.insert(all_val.end(), p2.val.begin(), p2.val.end()); std::vector<uint32_t>().swap(p2.gene); std::vector<float>().swap(p2.val); }
+        }
         for (uint64_t e : p2.row_end) row_ptr.push_back(g0 + e);
         bc_all.insert(bc_all.end(), p2.bc.begin(), p2.bc.end());
         nrec_all.insert(nrec_all.end(), p2.nrec.begin(), p2.nrec.end());
@@ -1106,6 +1122,10 @@ int afq_quantify(const afq_quant_opts* o) {
         }
     }
     if (bc_all.size() != row_index) return hfail(AFQ_ERR_STATE, "internal: the devices returned a different number of cells than were submitted");
+    struct HeldResult { afq_result r{}; ~HeldResult() { afq_result_release(&r); } } keep;   // (a result outlives its context)
+    if (one_held) { keep.r = parts[0].held; parts[0].is_held = false; }
+    const uint32_t* const GG = one_held ? keep.r.gene : all_gene.data();
+    const float* const V = one_held ? keep.r.val : all_val.data();
     parts.clear();
 
     // ---- per-cell rows: quants_mat_rows.txt + featureDump.txt (src/quant.rs:1150-1262), formatted by -t threads over
@@ -1136,7 +1156,7 @@ int afq_quantify(const afq_quant_opts* o) {
                 for (uint64_t i = i0; i < i1; ++i) {
                     const uint64_t a = row_ptr[i], b = row_ptr[i + 1];
                     float sum = 0.0f, mx = 0.0f;  // src/quant.rs:1150-1171 (f32 sum in column order)
-                    for (uint64_t k = a; k < b; ++k) { sum += all_val[k]; if (all_val[k] > mx) mx = all_val[k]; }
+                    for (uint64_t k = a; k < b; ++k) { sum += V[k]; if (V[k] > mx) mx = V[k]; }
                     const uint32_t num_expr = (uint32_t)(b - a);
                     const uint32_t nrec = nrec_all[i];
                     const float dedup_rate = sum / (float)nrec;
@@ -1146,7 +1166,7 @@ int afq_quantify(const afq_quant_opts* o) {
                     const float mapping_rate = (float)nrec / (float)(nrec + num_unmapped);
                     const float mean_expr = sum / (float)num_expr;
                     uint32_t over = 0;
-                    for (uint64_t k = a; k < b; ++k) if (all_val[k] > mean_expr) ++over;
+                    for (uint64_t k = a; k < b; ++k) if (V[k] > mean_expr) ++over;
                     const float mean_by_max = mean_expr / mx;
                     const std::string bcs = bc_to_string(cell_bc, cblen);
                     const std::string* sn = nullptr;
@@ -1184,9 +1204,9 @@ int afq_quantify(const afq_quant_opts* o) {
     const uint64_t num_cells = o->filter_list ? (uint64_t)subset_size : row_index;
     auto write_mtx = [&](const std::string& path, uint64_t n_rows, uint64_t n_cols, const std::vector<uint64_t>& rp,
                          const std::vector<uint32_t>& cols, const std::vector<float>& vals) -> bool {
-        return write_mtx_file(path, n_rows, n_cols, rp, cols, vals, o->num_threads);
+        return write_mtx_file(path, n_rows, n_cols, rp, cols.data(), vals.data(), vals.size(), o->num_threads);
     };
-    if (!write_mtx(outd + "/alevin/quants_mat.mtx", num_cells, cfg.num_rows, row_ptr, all_gene, all_val)) return hfail(AFQ_ERR_BAD_INPUT, "could not create quants_mat.mtx");
+    if (!write_mtx_file(outd + "/alevin/quants_mat.mtx", num_cells, cfg.num_rows, row_ptr, GG, V, (size_t)row_ptr.back(), o->num_threads)) return hfail(AFQ_ERR_BAD_INPUT, "could not create quants_mat.mtx");
     pc.lap("quants_mat.mtx");
     // -b: bootstrap summary matrices, cells x num_rows (src/quant.rs:1850-1877; nothing is written when no cell had a bootstrap)
     if (o->num_bootstraps && !bm_val.empty()) {
