@@ -619,7 +619,7 @@ int finish_range(afq_ctx* c, int slot) {
             case kErrUmiWide: return fail(c, AFQ_ERR_UNSUPPORTED, cell + "UMI wider than 22 nt is not supported");
             case kErrSlotRange: return fail(c, AFQ_ERR_BAD_INPUT, cell + "resolved column >= num_rows");
             case kErrLabelHash: return fail(c, AFQ_ERR_UNSUPPORTED, cell + "two ref lists share a 64-bit label hash");
-            case kErrPugLimit: return fail(c, AFQ_ERR_UNSUPPORTED, cell + "a device-side PUG limit was exceeded (2^20 vertices, 4096-vertex component, a class of more than 64 genes for the EM, or a vertex with an empty label)");
+            case kErrPugLimit: return fail(c, AFQ_ERR_UNSUPPORTED, cell + "a device-side PUG limit was exceeded (2^20 reads in the cell, a component of more than 4096 vertices under a raised --large-graph-thresh, or a vertex with an empty label)");
             case kErrPugPool: return fail(c, AFQ_ERR_OOM, cell + "PUG edge pool exhausted");
             default: return fail(c, AFQ_ERR_HIP, cell + "unknown device error");
         }

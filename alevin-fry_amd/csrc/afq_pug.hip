@@ -389,6 +389,56 @@ __device__ __forceinline__ void append_cols(const PugCtx& c, uint32_t col) {
     }
 }
 
+// A class of more than kMaxGenesPerLabel genes for the EM (a read that hits a large gene family: rare, but real data has
+// them), written straight into the cell's label area by ONE lane: cand(j) is the j-th ref of the arborescence's first
+// label - a gene id at gene level - or 0xFFFFFFFF when it is not shared by every vertex; n, the first label's length,
+// bounds the class and is what gets reserved (the label area holds one word per alignment of the cell, and every
+// molecule's first vertex is a different one).  Distinct genes are kept ascending by insertion, in global memory.
+template <typename Cand>
+__device__ __forceinline__ void emit_wide_class(const PugCtx& c, uint32_t n, Cand&& cand) {
+    const uint32_t off = atomicAdd(&c.s_cnt[1], n), di = atomicAdd(&c.s_cnt[2], 1u);
+    if (off + n > c.lab_cap || 2 * (di + 1) > c.lab_cap) { c.s_cnt[3] = kErrPugLimit; return; }
+    uint32_t* w = c.labw + off;
+    uint32_t k = 0;
+    for (uint32_t j = 0; j < n; ++j) {
+        const uint32_t t = cand(j);
+        if (t == 0xFFFFFFFFu) continue;
+        const uint32_t gid = c.gene_level ? t : c.t2g[t];
+        uint32_t lo = 0, hi = k;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (w[mid] < gid) lo = mid + 1; else hi = mid; }
+        if (lo < k && w[lo] == gid) continue;
+        for (uint32_t r = k; r > lo; --r) w[r] = w[r - 1];
+        w[lo] = gid;
+        ++k;
+    }
+    c.labd[2 * di] = off; c.labd[2 * di + 1] = k;
+}
+// the label of the vertex in slot `slot` of the gathered component records (6b): short labels travel in the record
+struct RecLab { Lab l; uint32_t r[4]; };
+__device__ __forceinline__ void rec_lab(const uint4* mrec, size_t slot, RecLab& o) {
+    const uint4 qa = mrec[2 * slot], qb = mrec[2 * slot + 1];
+    o.l.n = qa.y;
+    if (qa.y <= 4) { o.r[0] = qa.z; o.r[1] = qa.w; o.r[2] = qb.x; o.r[3] = qb.y; o.l.p = o.r; }
+    else o.l.p = reinterpret_cast<const uint32_t*>((uintptr_t)(((uint64_t)qa.w << 32) | qa.z));
+}
+// cand() of emit_wide_class for a component held in those records: ref j of the vertex in slot b0 + fv if every vertex
+// of `mask` (bit i = slot b0 + i) has it
+__device__ __forceinline__ void emit_wide_from_records(const PugCtx& c, const uint4* mrec, size_t b0, uint32_t fv, uint64_t mask) {
+    RecLab first;
+    rec_lab(mrec, b0 + fv, first);
+    emit_wide_class(c, first.l.n, [&](uint32_t j) -> uint32_t {
+        const uint32_t t = first.l.p[j] & 0x7FFFFFFFu;
+        for (uint64_t m = mask; m; m &= m - 1) {
+            const uint32_t i = (uint32_t)__builtin_ctzll(m);
+            if (i == fv) continue;
+            RecLab o;
+            rec_lab(mrec, b0 + i, o);
+            if (!lab_contains(o.l, t)) return 0xFFFFFFFFu;
+        }
+        return t;
+    });
+}
+
 __device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
 #pragma unroll
@@ -515,6 +565,27 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         }
         return k;
     };
+    // the same for a read with more distinct genes than kMaxGenesPerLabel (a large gene family; rare): counted, compared and
+    // written by looking back over the refs instead of through a register array
+    auto gene_first_occurrences = [&](uint32_t rec_dw, auto&& f) {
+        const Lab l = rec_label(C, rec_dw);
+        for (uint32_t j = 0; j < l.n; ++j) {
+            const uint32_t gj = C.t2g[l.p[j] & 0x7FFFFFFFu];
+            bool first = true;
+            for (uint32_t q = 0; q < j && first; ++q) first = C.t2g[l.p[q] & 0x7FFFFFFFu] != gj;
+            if (first) f(gj);
+        }
+    };
+    auto gene_subset_slow = [&](uint32_t a_dw, uint32_t b_dw) -> bool {   // every gene of read a is a gene of read b
+        const Lab la = rec_label(C, a_dw), lb = rec_label(C, b_dw);
+        for (uint32_t j = 0; j < la.n; ++j) {
+            const uint32_t gj = C.t2g[la.p[j] & 0x7FFFFFFFu];
+            bool found = false;
+            for (uint32_t q = 0; q < lb.n && !found; ++q) found = C.t2g[lb.p[q] & 0x7FFFFFFFu] == gj;
+            if (!found) return false;
+        }
+        return true;
+    };
     // Per class a 19-bit signature of its label - bit (id mod 19) for every ref (gene at gene level) in it.  Two labels whose
     // signatures do not meet share no ref, so the neighbour search can drop such a pair on the spot (same-UMI vertices under
     // the transcripts of one gene are the bulk of its matches, and ids that close never collide mod 19); the others still
@@ -582,9 +653,10 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                     } else {
                         uint32_t g[kMaxGenesPerLabel], gp[kMaxGenesPerLabel];
                         const uint32_t len = gene_list(ro, g), lenp = gene_list(po, gp);
-                        bool same = len == lenp && len != 0xFFFFFFFFu;
-                        for (uint32_t q = 0; same && q < len; ++q) same = g[q] == gp[q];
-                        if (!same) s_cnt[3] = len == 0xFFFFFFFFu ? kErrPugLimit : kErrLabelHash;
+                        bool same = len == lenp;
+                        if (same && len == 0xFFFFFFFFu) same = gene_subset_slow(ro, po) && gene_subset_slow(po, ro);
+                        else for (uint32_t q = 0; same && q < len; ++q) same = g[q] == gp[q];
+                        if (!same) s_cnt[3] = kErrLabelHash;
                     }
                 }
                 ev += v; ec += c;
@@ -603,12 +675,23 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
             const uint32_t k = base + tid;
             uint32_t g[kMaxGenesPerLabel];
             uint32_t len = k < K ? gene_list(c_rep[k], g) : 0u;
-            if (len == 0xFFFFFFFFu) { s_cnt[3] = kErrPugLimit; len = 0; }
+            const bool widek = len == 0xFFFFFFFFu;
+            if (widek) { len = 0; gene_first_occurrences(c_rep[k], [&](uint32_t) { ++len; }); }
             uint32_t tot;
             const uint32_t ex = block_excl_scan<kPugNT>(len, s_ws, tot);
             if (k < K) {
                 c_goff[k] = carry + ex;
-                for (uint32_t i = 0; i < len; ++i) c_glab[carry + ex + i] = g[i];
+                uint32_t* dstg = c_glab + carry + ex;
+                if (!widek) for (uint32_t i = 0; i < len; ++i) dstg[i] = g[i];
+                else {   // ascending by insertion, in place
+                    uint32_t kk = 0;
+                    gene_first_occurrences(c_rep[k], [&](uint32_t gid) {
+                        uint32_t q = kk;
+                        for (; q > 0 && dstg[q - 1] > gid; --q) dstg[q] = dstg[q - 1];
+                        dstg[q] = gid;
+                        ++kk;
+                    });
+                }
             }
             carry += tot;
         }
@@ -1270,7 +1353,8 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                 } else {
                     uint32_t g[kMaxGenesPerLabel];
                     const uint32_t ng = genes_of(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; }, g);
-                    emit_molecule(C, g, ng);
+                    if (ng == 0xFFFFFFFFu && C.em) emit_wide_class(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; });
+                    else emit_molecule(C, g, ng);
                 }
             }
             append_cols(C, col);   // (v0 - lane is wave-uniform: every lane of the wave gets here)
@@ -1313,7 +1397,9 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                     g[q] = gid;
                     ++ng;
                 }
-                emit_molecule(C, g, ng);
+                if (ng == 0xFFFFFFFFu && C.em)
+                    emit_wide_class(C, l.n, [&](uint32_t j) -> uint32_t { const uint32_t t = l.p[j] & 0x7FFFFFFFu; return lab_contains(l2, t) ? t : 0xFFFFFFFFu; });
+                else emit_molecule(C, g, ng);
             }
         }
         append_cols(C, col);
@@ -1457,6 +1543,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                 uint32_t col = 0xFFFFFFFFu;
                 if (best && gl == 0) {
                     if (small) { const uint32_t n4 = genes_of4(C, c4, k4); col = molecule4_column(C, c4, n4); }
+                    else if (wide && C.em) emit_wide_from_records(C, mrec, b0, fv, best);
                     else emit_molecule(C, g, wide ? 0xFFFFFFFFu : ng);
                 }
                 append_cols(C, col);
@@ -1558,6 +1645,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                 uint32_t col = 0xFFFFFFFFu;
                 if (lane == 0) {
                     if (small) { const uint32_t n4 = genes_of4(C, c4, k4); col = molecule4_column(C, c4, n4); }
+                    else if (wide && C.em) emit_wide_from_records(C, mrec, mid_off[ci], fv, best);
                     else emit_molecule(C, g, wide ? 0xFFFFFFFFu : ng);
                 }
                 append_cols(C, col);
@@ -1578,13 +1666,23 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
             // triplets live in the edge pool: 4 words each (umi lo, umi hi, gene, count)
             if (tid == 0) { s_flag[1] = 0; }
             __syncthreads();
+            // distinct genes of a label that has more of them than kMaxGenesPerLabel: first occurrences, found by looking back
+            auto wide_genes = [&](const Lab& l, auto&& f) {
+                for (uint32_t j = 0; j < l.n; ++j) {
+                    const uint32_t tj = l.p[j] & 0x7FFFFFFFu;
+                    const uint32_t gj = C.gene_level ? tj : C.t2g[tj];
+                    bool first = true;
+                    for (uint32_t q = 0; q < j && first; ++q) { const uint32_t tq = l.p[q] & 0x7FFFFFFFu; first = (C.gene_level ? tq : C.t2g[tq]) != gj; }
+                    if (first) f(gj);
+                }
+            };
             // count triplets
             uint32_t cnt = 0;
             for (uint32_t i = tid; i < n; i += kPugNT) {
                 const Lab l = vlab(vid_at(c0 + i));
                 uint32_t g[kMaxGenesPerLabel];
                 const uint32_t ng = genes_of(C, l.n, [&](uint32_t j) { return l.p[j] & 0x7FFFFFFFu; }, g);
-                if (ng == 0xFFFFFFFFu) s_cnt[3] = kErrPugLimit; else cnt += ng;
+                if (ng == 0xFFFFFFFFu) wide_genes(l, [&](uint32_t) { ++cnt; }); else cnt += ng;
             }
             uint32_t tot;
             (void)block_excl_scan<kPugNT>(cnt, s_ws, tot);
@@ -1599,7 +1697,13 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                 const Lab l = vlab(v);
                 uint32_t g[kMaxGenesPerLabel];
                 const uint32_t ng = genes_of(C, l.n, [&](uint32_t j) { return l.p[j] & 0x7FFFFFFFu; }, g);
-                if (ng == 0xFFFFFFFFu) continue;
+                if (ng == 0xFFFFFFFFu) {   // more genes than g[] holds: the distinct ones, found by looking back (rare)
+                    uint32_t k = 0;
+                    wide_genes(l, [&](uint32_t) { ++k; });
+                    uint32_t o = atomicAdd(&s_flag[1], k);
+                    wide_genes(l, [&](uint32_t gid) { trip[o++] = make_uint4((uint32_t)vv_umi[v], (uint32_t)(vv_umi[v] >> 32), gid, vv[v].x & 0xFFFFFu); });
+                    continue;
+                }
                 const uint32_t o = atomicAdd(&s_flag[1], ng);
                 for (uint32_t q = 0; q < ng; ++q) trip[o + q] = make_uint4((uint32_t)vv_umi[v], (uint32_t)(vv_umi[v] >> 32), g[q], vv[v].x & 0xFFFFFu);
             }
@@ -1616,10 +1720,31 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                 uint32_t nbest = 0, maxc = 0, aggr = 0;
                 uint32_t cu_lo = trip[0].x, cu_hi = trip[0].y, cg = trip[0].z;
                 bool wide = false;
+                uint32_t run0 = 0;   // first triplet of the current UMI
+                // a UMI whose tie set has more genes than best[] holds is a class of its own for the EM: the genes whose
+                // summed count is the maximum, ascending as the triplets are, written straight into the label area
+                auto emit_ties = [&](uint32_t i0, uint32_t i1, uint32_t maxc_) {
+                    auto each_tied = [&](auto&& f) {
+                        for (uint32_t i = i0; i < i1;) {
+                            uint32_t j = i, sum = 0;
+                            for (; j < i1 && trip[j].z == trip[i].z; ++j) sum += trip[j].w;
+                            if (sum == maxc_) f(trip[i].z);
+                            i = j;
+                        }
+                    };
+                    uint32_t k = 0;
+                    each_tied([&](uint32_t) { ++k; });
+                    const uint32_t off = atomicAdd(&C.s_cnt[1], k), di = atomicAdd(&C.s_cnt[2], 1u);
+                    if (off + k > C.lab_cap || 2 * (di + 1) > C.lab_cap) { C.s_cnt[3] = kErrPugLimit; return; }
+                    uint32_t w = off;
+                    each_tied([&](uint32_t gid) { C.labw[w++] = gid; });
+                    C.labd[2 * di] = off; C.labd[2 * di + 1] = k;
+                };
                 for (uint32_t i = 0; i < nt; ++i) {
                     const uint4 t = trip[i];
                     if (t.x != cu_lo || t.y != cu_hi) {
-                        emit_molecule(C, best, wide ? 0xFFFFFFFFu : nbest);
+                        if (wide && C.em) emit_ties(run0, i, maxc); else emit_molecule(C, best, wide ? 0xFFFFFFFFu : nbest);
+                        run0 = i;
                         cu_lo = t.x; cu_hi = t.y; cg = t.z;
                         nbest = 1; best[0] = t.z; aggr = t.w; maxc = t.w; wide = false;
                     } else {
@@ -1632,7 +1757,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                         }
                     }
                 }
-                emit_molecule(C, best, wide ? 0xFFFFFFFFu : nbest);
+                if (wide && C.em) emit_ties(run0, nt, maxc); else emit_molecule(C, best, wide ? 0xFFFFFFFFu : nbest);
             }
             if (tid == 0) A.alt[cell] = 1;  // used_alternative_strategy, pugutils.rs:1070
             __syncthreads();
@@ -1745,7 +1870,17 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                         }
                     }
                 }
-                if (lane == 0) emit_molecule(C, g, wide ? 0xFFFFFFFFu : ng);
+                if (lane == 0) {
+                    if (wide && C.em)
+                        emit_wide_class(C, lf.n, [&](uint32_t j) -> uint32_t {
+                            const uint32_t t = lf.p[j] & 0x7FFFFFFFu;
+                            for (uint32_t cw = 0; cw < nw; ++cw)
+                                for (uint64_t m = s_mask[1][cw]; m; m &= m - 1)
+                                    if (!lab_contains(vlab(vid_at(c0 + cw * 64 + (uint32_t)__builtin_ctzll(m))), t)) return 0xFFFFFFFFu;
+                            return t;
+                        });
+                    else emit_molecule(C, g, wide ? 0xFFFFFFFFu : ng);
+                }
             }
             __syncthreads();
             if (tid < nw) s_mask[0][tid] &= ~s_mask[1][tid];

@@ -227,3 +227,68 @@ def test_widened_batch_cut_into_many_ranges(oracle, monkeypatch, res):
     want = oracle.quant(cfg, s.tid_to_gid, b, off)
     assert_same_result(got, want)
     assert st["n_records"] == sum(sizes) and st["n_fallback_cells"] == 0, st
+
+
+def _umi_neighbours(u, length):
+    """All UMIs one base away from u (2 bits per base)."""
+    out = []
+    for pos in range(length):
+        b = (u >> (2 * pos)) & 3
+        for d in (1, 2, 3):
+            out.append((u & ~(3 << (2 * pos))) | (((b + d) & 3) << (2 * pos)))
+    return out
+
+
+@pytest.mark.parametrize("usa", [False, True])
+@pytest.mark.parametrize("res", ["parsimony-em", "parsimony-gene-em", "parsimony"])
+def test_classes_of_more_than_64_genes(oracle, res, usa):
+    """A read that hits a large gene family gives a molecule whose gene label has more entries than the device carries in
+    registers (64).  Without an EM such a molecule is dropped like any multi-gene one; with an EM it is a class of the
+    cell and has to come out whole - from every place a molecule is emitted: lone vertices, two-vertex components, the
+    eight-to-a-wave cover (3..8 vertices), the wave cover (9..64), the workgroup cover (> 64) and, in the last cell,
+    the winner-take-all fallback above --large-graph-thresh with its tie sets."""
+    L = 12
+    n_genes = 220
+    t2g, num_gene_ids, num_rows = synth.make_t2g(n_genes, 2, usa)
+    n_spliced = 2 * n_genes
+    rng = np.random.default_rng(5 + usa)
+    wide1 = sorted(int(2 * g + rng.integers(0, 2)) for g in rng.choice(n_genes, 90, replace=False))          # 90 genes
+    wide2 = sorted(set(wide1[:80]) | {int(2 * g) for g in rng.choice(n_genes, 30, replace=False)})            # overlaps wide1 in >= 80
+    if usa:   # a few unspliced refs too: S/U pairs of one gene inside a wide class
+        wide1 = sorted(set(wide1) | {n_spliced + int(g) for g in rng.choice(n_genes, 10, replace=False)})
+    short = lambda: sorted(int(x) for x in rng.choice(n_spliced, size=int(rng.integers(1, 4)), replace=False))
+    def far_umis(k):
+        return [int(x) for x in rng.choice(1 << (2 * L), size=k, replace=False)]
+    def star(center, n_nb, lab, reads_center=6):
+        r = [(center, lab)] * reads_center
+        for u in _umi_neighbours(center, L)[:n_nb]:
+            r.append((u, lab))
+        return r
+    cells = []
+    # lone vertices and pairs
+    reads = [(u, wide1) for u in far_umis(5)] + [(u, wide2) for u in far_umis(3)]
+    c = far_umis(2)
+    reads += star(c[0], 1, wide1) + [(c[1], wide1), (_umi_neighbours(c[1], L)[7], wide2)]
+    reads += [(u, short()) for u in far_umis(150)]
+    cells.append((11, reads))
+    # 3..8 and 9..64 vertices
+    c = far_umis(4)
+    reads = star(c[0], 4, wide1) + star(c[1], 6, wide2) + star(c[2], 20, wide1) + star(c[3], 30, wide2, reads_center=1)
+    reads += [(u, short()) for u in far_umis(150)]
+    cells.append((12, reads))
+    # > 64 vertices: a centre, its 36 neighbours and the neighbours of two of them
+    c = far_umis(1)[0]
+    nb = _umi_neighbours(c, L)
+    us = {c, *nb, *_umi_neighbours(nb[0], L), *_umi_neighbours(nb[20], L)}
+    reads = [(u, wide1) for u in sorted(us)] + [(c, wide1)] * 5 + [(u, short()) for u in far_umis(150)]
+    cells.append((13, reads))
+    b, off = rad.encode_cells(cells, 4, 4)
+    cfg = pkg.WorkerConfig.for_resolution(res, usa_mode=usa, num_genes=num_gene_ids, num_rows=num_rows, small_thresh=0)
+    got, want = run_both(oracle, cfg, t2g, b, off)
+    assert_same_result(got, want)
+    assert got.val.sum() > 0
+    # the same cells with every component above three vertices sent down the winner-take-all fallback: ties among > 64 genes
+    cfg2 = pkg.WorkerConfig.for_resolution(res, usa_mode=usa, num_genes=num_gene_ids, num_rows=num_rows, small_thresh=0, large_graph_thresh=3)
+    got2, want2 = run_both(oracle, cfg2, t2g, b, off)
+    assert_same_result(got2, want2)
+    assert (got2.flags & pkg._abi.CELL_ALT_RES).any()
