@@ -56,9 +56,9 @@ struct DevBuf {
     template <class T> T* as() { return reinterpret_cast<T*>(p); }
 };
 
-enum KernelId { K_GATHER = 0, K_DECODE_PAR, K_DECODE, K_HIST, K_BSCAN, K_SCATTER, K_RESOLVE, K_RESOLVE_BIG, K_PUG, K_CELL_HIST, K_EM, K_BOOT, K_COMPACT, K_ATAC, K_ATAC_PARSE, K_COUNT };
+enum KernelId { K_GATHER = 0, K_DECODE_PAR, K_DECODE, K_HIST, K_BSCAN, K_SCATTER, K_RESOLVE, K_RESOLVE_BIG, K_PUG, K_CELL_HIST, K_EM, K_BOOT, K_COMPACT, K_ATAC, K_ATAC_PARSE, K_FIX_SLABS, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"k_gather_headers", "k_decode_par", "k_decode", "k_hist", "k_bucket_scan", "k_scatter",
-                                           "k_resolve", "k_resolve_big", "k_pug_cell", "k_cell_hist", "k_em", "k_boot", "k_compact", "k_atac_dedup", "k_atac_parse"};
+                                           "k_resolve", "k_resolve_big", "k_pug_cell", "k_cell_hist", "k_em", "k_boot", "k_compact", "k_atac_dedup", "k_atac_parse", "k_fix_slabs"};
 
 struct TimedLaunch { int id; hipEvent_t a, b; };
 
@@ -140,7 +140,7 @@ struct Range { uint32_t c0, c1; };
 
 struct RangeState {
     hipStream_t stream = nullptr;
-    DevBuf d_meta, d_keys0, d_keys1, d_cell_nkeys, d_bucket_cnt, d_bucket_cell, d_multi_cells, d_tile_desc, d_src_off, d_ncols,
+    DevBuf d_meta, d_keys0, d_keys1, d_cell_nkeys, d_bucket_cnt, d_bucket_cell, d_multi_cells, d_tile_desc, d_src_off, d_slab_ovf, d_ncols,
         d_nnz, d_ovf, d_status, d_bc, d_cell_ptr, d_gene, d_val, d_chk, d_slab_prefix, d_slab_cell, d_cell_bc, d_bdesc, d_lab,
         d_lab_cnt, d_em_off, d_em_scratch, d_em_nnz, d_pug_cells, d_rd_off, d_rd_h, d_rd_u, d_rd_o, d_pug_scr_off,
         d_pug_scratch, d_epool, d_epool_cur, d_alt, d_hist_cells, d_fix, d_em_hdr, d_em_order, d_eq_ncls, d_eq_nw, d_eq_cptr,
@@ -154,7 +154,7 @@ struct RangeState {
     hipEvent_t kernels_done = nullptr;
     std::vector<TimedLaunch> launches;  // HIP-event brackets of this range's kernels (cfg.profile)
     std::vector<DevBuf*> all() {
-        return {&d_meta, &d_keys0, &d_keys1, &d_cell_nkeys, &d_bucket_cnt, &d_bucket_cell, &d_multi_cells, &d_tile_desc, &d_src_off,
+        return {&d_meta, &d_keys0, &d_keys1, &d_cell_nkeys, &d_bucket_cnt, &d_bucket_cell, &d_multi_cells, &d_tile_desc, &d_src_off, &d_slab_ovf,
                 &d_ncols, &d_nnz, &d_ovf, &d_status, &d_bc, &d_cell_ptr, &d_gene, &d_val, &d_chk, &d_slab_prefix, &d_slab_cell,
                 &d_cell_bc, &d_bdesc, &d_lab, &d_lab_cnt, &d_em_off, &d_em_scratch, &d_em_nnz, &d_pug_cells, &d_rd_off, &d_rd_h,
                 &d_rd_u, &d_rd_o, &d_pug_scr_off, &d_pug_scratch, &d_epool, &d_epool_cur, &d_alt, &d_hist_cells, &d_fix, &d_em_hdr, &d_em_order,
@@ -262,6 +262,14 @@ void harvest_timers(afq_ctx* c, std::vector<TimedLaunch>* list = nullptr) {
 
 uint32_t hdr_bytes(const afq_config& cfg) { return 4 + cfg.bc_bytes + cfg.umi_bytes; }
 
+// Multi-bucket cells are placed into fixed-capacity bucket slabs (no counting pass) unless AFQ_FIXED_SLABS=0;
+// AFQ_SLAB_CAP shrinks the slabs (tests: forces the overflow path).
+bool fixed_slabs() { const char* e = std::getenv("AFQ_FIXED_SLABS"); return !(e && e[0] == '0'); }
+// Default 384 slots for buckets planned at <= 256 keys (kBucketTarget): measured on the bench input, 512 costs the scatter
+// 10 % (a sparser target), 320 already sends a tenth of the cells through the exact placement (profiles/run_r02s.sh).
+constexpr uint32_t kSlabCap = 384;
+uint32_t slab_capacity() { const char* e = std::getenv("AFQ_SLAB_CAP"); const long v = e ? std::atol(e) : 0; return v > 0 ? (uint32_t)v : kSlabCap; }
+
 bool valid_width(uint32_t w) { return w == 1 || w == 2 || w == 4 || w == 8; }
 
 // What the device path implements today.  Anything else is refused loudly.
@@ -309,7 +317,7 @@ int plan_ranges(afq_ctx* c) {
             nd += 20.0 * nrec + 96.0 * nrec;   // rd_h/rd_u/rd_o + the edge pool (24 words per read), as run_range allocates them
             pug_fixed = std::max(pug_fixed, 4.0 * (double)pug_scratch_words(nrec, (uint32_t)n_ref, true) * pug_max_blocks() + 4.0 * (double)(1ull << 22));
         }
-        if (n_ref > kBucketTarget) nd += 16.0 * (double)(n_ref / kBucketTarget + 1);
+        if (n_ref > kBucketTarget) nd += 16.0 * (double)(n_ref / kBucketTarget + 1) + (fixed_slabs() && !pug_res ? 8.0 * 2.0 * slab_capacity() / kBucketTarget * (double)n_ref : 0.0);   // (+ the slabs of keys1: up to 2 x slab capacity slots per kBucketTarget refs)
         if (nd > mem_budget) return fail(c, AFQ_ERR_OOM, "cell " + std::to_string(i) + " alone exceeds device memory");
         need[i] = nd;
         total_need += nd;
@@ -383,8 +391,10 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
     std::vector<uint64_t> rd_off(n, 0);
     uint64_t n_pug_reads = 0, pug_words = 0;  // pug_words: scratch of the largest parsimony cell
     const bool par = (c->widen || c->all_aligned) && decode_par_supported(g.bc_bytes, g.umi_bytes);
-    uint64_t key_off = 0, n_buckets = 0, n_tiles = 0, n_slabs = 0;
+    uint64_t key_off = 0, n_buckets = 0, n_tiles = 0, n_slabs = 0, k1_slots = 0;
     uint32_t max_lg_nb = 0;
+    const bool slabs = fixed_slabs();
+    const uint32_t slab_cap = slab_capacity();
     if (par) slab_prefix.reserve(n + 1);
     uint64_t nrec_total = 0;
     for (uint32_t i = 0; i < n; ++i) {
@@ -412,6 +422,12 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
         max_lg_nb = std::max(max_lg_nb, lg);
         m.bucket_base = (uint32_t)n_buckets;
         n_buckets += 1ull << lg;
+        m.slab_cap = 0; m.k1_off = 0;
+        if (lg && slabs) {
+            m.slab_cap = slab_cap;
+            m.k1_off = k1_slots;
+            k1_slots += std::max<uint64_t>((uint64_t)slab_cap << lg, (uint64_t)m.n_ref + 1);
+        }
         if (lg) {
             multi.push_back(i);
             const uint32_t nt = (m.n_ref + kScatterTileHost - 1) / kScatterTileHost;
@@ -443,7 +459,8 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
 
     HIP_TRY(c, B.d_meta.ensure(sizeof(CellMeta) * n));
     HIP_TRY(c, B.d_keys0.ensure(8 * key_off));
-    HIP_TRY(c, B.d_keys1.ensure((n_multi || !pug_cells.empty()) ? 8 * key_off : 8));  // pair staging of multi-bucket and parsimony cells
+    HIP_TRY(c, B.d_keys1.ensure((n_multi || !pug_cells.empty()) ? 8 * std::max(key_off, k1_slots) : 8));  // bucket slabs, then pair staging of multi-bucket and parsimony cells
+    HIP_TRY(c, B.d_slab_ovf.ensure(4ull * n));
     HIP_TRY(c, B.d_cell_nkeys.ensure(4ull * n));
     HIP_TRY(c, B.d_bucket_cnt.ensure(4 * n_buckets));
     HIP_TRY(c, B.d_bucket_cell.ensure(4 * n_buckets));
@@ -503,6 +520,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
         HIP_TRY(c, hipMemcpyAsync(B.d_tile_desc.p, B.tile_desc.data(), 8ull * n_tiles, hipMemcpyHostToDevice, s));
     }
     HIP_TRY(c, hipMemsetAsync(B.d_bucket_cnt.p, 0, 4 * n_buckets, s));
+    HIP_TRY(c, hipMemsetAsync(B.d_slab_ovf.p, 0, 4ull * n, s));
     HIP_TRY(c, hipMemsetAsync(B.d_nnz.p, 0, 4ull * n, s));
     HIP_TRY(c, hipMemsetAsync(B.d_ncols.p, 0, 4ull * n, s));
     if (em) HIP_TRY(c, hipMemsetAsync(B.d_lab_cnt.p, 0, 8ull * n, s));
@@ -562,11 +580,14 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
                    em ? B.d_lab_cnt.as<uint32_t>() : nullptr, B.d_status.as<DevStatus>(),
                    (uint32_t)n_buckets, n_multi, (uint32_t)n_tiles, B.d_hist_cells.as<uint32_t>(),
                    (uint32_t)hist_cells.size(), g.usa_mode, g.num_rows,
-                   (g.usa_mode && g.sa_model == AFQ_SA_PREFER_AMBIG) ? 1u : 0u, max_lg_nb};
+                   (g.usa_mode && g.sa_model == AFQ_SA_PREFER_AMBIG) ? 1u : 0u, max_lg_nb, B.d_slab_ovf.as<uint32_t>(), slabs ? 1u : 0u};
     if (n_multi) {
-        { ScopedTimer t(c, K_HIST, s, &B.launches); launch_hist(s, ra); }
-        { ScopedTimer t(c, K_BSCAN, s, &B.launches); launch_bucket_scan(s, ra); }
+        if (!slabs) {
+            { ScopedTimer t(c, K_HIST, s, &B.launches); launch_hist(s, ra); }
+            { ScopedTimer t(c, K_BSCAN, s, &B.launches); launch_bucket_scan(s, ra); }
+        }
         { ScopedTimer t(c, K_SCATTER, s, &B.launches); launch_scatter(s, ra); }
+        if (slabs) { ScopedTimer t(c, K_FIX_SLABS, s, &B.launches); launch_fix_slabs(s, ra); }
     }
     { ScopedTimer t(c, K_RESOLVE, s, &B.launches); launch_resolve(s, ra); }
     if (n_multi) { ScopedTimer t(c, K_RESOLVE_BIG, s, &B.launches); launch_resolve_big(s, ra); }

@@ -57,6 +57,8 @@ struct ResolveArgs {
     uint32_t num_rows;
     uint32_t prefer_ambig;       // --sa-model prefer-ambig in USA mode (cr-like, cr-like-em)
     uint32_t max_lg_nb;          // largest lg_nb of the batch's multi-bucket cells (picks the scatter instance)
+    uint32_t* slab_ovf;          // fixed-slab placement: per cell, set when one of its buckets outgrew its slab (the cell is then placed exactly)
+    uint32_t slabs;              // the range's multi-bucket cells use fixed slabs (no k_hist / k_bucket_scan)
 };
 
 void launch_gather_headers(hipStream_t s, const uint8_t* bytes, size_t n_bytes, const uint64_t* chunk_off,
@@ -69,6 +71,7 @@ bool decode_par_supported(uint32_t bw, uint32_t uw);
 int launch_decode_par(hipStream_t s, const DecodeArgs& a, uint32_t bw, uint32_t uw);
 void launch_hist(hipStream_t s, const ResolveArgs& a);
 void launch_bucket_scan(hipStream_t s, const ResolveArgs& a);
+void launch_fix_slabs(hipStream_t s, const ResolveArgs& a);
 void launch_scatter(hipStream_t s, const ResolveArgs& a);
 size_t bucket_desc_bytes();
 uint64_t em_scratch_words(uint32_t nU, uint32_t W, uint32_t M, bool usa);

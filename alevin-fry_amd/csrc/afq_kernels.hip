@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void k_scatter(const uint2* __restrict__ tile_
                                                 const CellMeta* __restrict__ meta,
                                                 const uint32_t* __restrict__ cell_nkeys,
                                                 const uint64_t* __restrict__ keys0, uint64_t* __restrict__ keys1,
-                                                uint32_t* __restrict__ cursor) {
+                                                uint32_t* __restrict__ cursor, uint32_t* __restrict__ slab_ovf) {
     constexpr uint32_t E = kTileKeys / 256;
     __shared__ uint64_t s_keys[kTileKeys];
     __shared__ uint32_t s_cnt[BINS];   // per-bucket count, then tile-local exclusive offset
@@ -104,14 +104,25 @@ __global__ __launch_bounds__(256) void k_scatter(const uint2* __restrict__ tile_
     if (t0 >= nk) return;
     const uint32_t t1 = min(nk, t0 + kTileKeys);
     const uint64_t* src = keys0 + m.key_off;
-    uint64_t* dst = keys1 + m.key_off;
+    // Fixed slabs (m.slab_cap != 0): bucket b owns slots [b * cap, (b + 1) * cap) of the cell's keys1 region and the cursors
+    // start at zero - no counting pass (k_hist) and no scan in front of this kernel.  A bucket that outgrows its slab
+    // (one UMI with hundreds of reads) flags the cell; k_fix_slabs then places that cell exactly, from the counts the
+    // cursors hold by then.  cap = 0: the exact layout behind k_hist + k_bucket_scan (cursors = exclusive offsets).
+    const uint32_t cap = m.slab_cap;
+    uint64_t* dst = keys1 + (cap ? m.k1_off : m.key_off);
     uint32_t* gcur = cursor + m.bucket_base;
     const uint32_t nb = 1u << m.lg_nb;
     if (nb > BINS) {  // giant cell: per-key global atomics
+        bool over = false;
         for (uint32_t i = t0 + threadIdx.x; i < t1; i += 256) {
             const uint64_t key = src[i];
-            dst[atomicAdd(&gcur[bucket_of(key >> kGeneBits, m.lg_nb)], 1u)] = key;
+            const uint32_t b = bucket_of(key >> kGeneBits, m.lg_nb);
+            const uint32_t pos = atomicAdd(&gcur[b], 1u);
+            if (!cap) dst[pos] = key;
+            else if (pos < cap) dst[(uint64_t)b * cap + pos] = key;
+            else over = true;
         }
+        if (over) atomicOr(&slab_ovf[cell], 1u);
         return;
     }
     for (uint32_t b = threadIdx.x; b < nb; b += 256) s_cnt[b] = 0;
@@ -138,7 +149,9 @@ __global__ __launch_bounds__(256) void k_scatter(const uint2* __restrict__ tile_
         const uint32_t ex = block_excl_scan<256>(c, s_ws, tot);
         if (b < nb) {
             s_cnt[b] = carry + ex;
-            s_base[b] = c ? atomicAdd(&gcur[b], c) : 0u;
+            const uint32_t at = c ? atomicAdd(&gcur[b], c) : 0u;
+            s_base[b] = at;
+            if (cap && at + c > cap) atomicOr(&slab_ovf[cell], 1u);
         }
         carry += tot;
     }
@@ -153,7 +166,45 @@ __global__ __launch_bounds__(256) void k_scatter(const uint2* __restrict__ tile_
     for (uint32_t i = threadIdx.x; i < nt; i += 256) {
         const uint64_t kx = s_keys[i];
         const uint32_t b = bucket_of(kx >> kGeneBits, m.lg_nb);
-        dst[s_base[b] + (i - s_cnt[b])] = kx;
+        const uint32_t pos = s_base[b] + (i - s_cnt[b]);
+        if (!cap) dst[pos] = kx;
+        else if (pos < cap) dst[(uint64_t)b * cap + pos] = kx;
+    }
+}
+
+// Cells whose fixed slabs overflowed (normally none): the cursors hold every bucket's true count, so the exact layout is
+// one scan away - buckets back to back from the start of the cell's keys1 region, keys placed one atomic each out of
+// keys0 (still intact).  Afterwards cursor[b] = end offset of bucket b, as after the exact path.
+__global__ __launch_bounds__(256) void k_fix_slabs(const uint32_t* __restrict__ multi_cells, uint32_t n_multi,
+                                                  const CellMeta* __restrict__ meta, const uint32_t* __restrict__ cell_nkeys,
+                                                  const uint64_t* __restrict__ keys0, uint64_t* __restrict__ keys1,
+                                                  uint32_t* __restrict__ cursor, const uint32_t* __restrict__ slab_ovf) {
+    __shared__ uint32_t s_ws[4];
+    for (uint32_t ci = blockIdx.x; ci < n_multi; ci += gridDim.x) {
+        const uint32_t cell = multi_cells[ci];
+        if (!slab_ovf[cell]) continue;
+        const CellMeta m = meta[cell];
+        if (!m.slab_cap || mode_is_pug(m.mode)) continue;
+        const uint32_t nb = 1u << m.lg_nb, nk = cell_nkeys[cell];
+        uint32_t* gcur = cursor + m.bucket_base;
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < nb; base += 256) {
+            const uint32_t b = base + threadIdx.x;
+            const uint32_t c = b < nb ? gcur[b] : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<256>(c, s_ws, tot);
+            if (b < nb) gcur[b] = carry + ex;
+            carry += tot;
+        }
+        __threadfence();
+        __syncthreads();
+        const uint64_t* src = keys0 + m.key_off;
+        uint64_t* dst = keys1 + m.k1_off;
+        for (uint32_t i = threadIdx.x; i < nk; i += 256) {
+            const uint64_t key = src[i];
+            dst[atomicAdd(&gcur[bucket_of(key >> kGeneBits, m.lg_nb)], 1u)] = key;
+        }
+        __syncthreads();
     }
 }
 
@@ -286,7 +337,7 @@ struct BucketDesc {
 
 __global__ void k_bucket_desc(const CellMeta* __restrict__ meta, const uint32_t* __restrict__ bucket_cell,
                               const uint32_t* __restrict__ cell_nkeys, const uint32_t* __restrict__ cursor,
-                              uint32_t n_buckets, BucketDesc* __restrict__ desc) {
+                              const uint32_t* __restrict__ slab_ovf, uint32_t n_buckets, BucketDesc* __restrict__ desc) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_buckets) return;
     const uint32_t cell = bucket_cell[b];
@@ -294,9 +345,11 @@ __global__ void k_bucket_desc(const CellMeta* __restrict__ meta, const uint32_t*
     BucketDesc d;
     d.cell = cell; d.out_off = m.key_off; d.n_ref = m.n_ref;
     if (m.lg_nb == 0) { d.mode_single = m.mode | 0x100u; d.src_off = m.key_off; d.n = mode_is_pug(m.mode) ? 0u : cell_nkeys[cell]; }
-    else {
+    else if (m.slab_cap && !slab_ovf[cell]) {   // fixed slabs: the cursor is the bucket's count
+        d.mode_single = m.mode; d.src_off = m.k1_off + (uint64_t)(b - m.bucket_base) * m.slab_cap; d.n = mode_is_pug(m.mode) ? 0u : cursor[b];
+    } else {
         const uint32_t beg = (b == m.bucket_base) ? 0u : cursor[b - 1];
-        d.mode_single = m.mode; d.src_off = m.key_off + beg; d.n = mode_is_pug(m.mode) ? 0u : cursor[b] - beg;
+        d.mode_single = m.mode; d.src_off = (m.slab_cap ? m.k1_off : m.key_off) + beg; d.n = mode_is_pug(m.mode) ? 0u : cursor[b] - beg;
     }
     desc[b] = d;
 }
@@ -1065,9 +1118,15 @@ void launch_bucket_scan(hipStream_t s, const ResolveArgs& a) {
 void launch_scatter(hipStream_t s, const ResolveArgs& a) {
     if (!a.n_tiles) return;
     if ((1u << a.max_lg_nb) <= 512u)
-        AFQ_LAUNCH(k_scatter<512>, a.n_tiles, 256, s, a.tile_desc, a.meta, a.cell_nkeys, a.keys0, a.keys1, a.cursor);
+        AFQ_LAUNCH(k_scatter<512>, a.n_tiles, 256, s, a.tile_desc, a.meta, a.cell_nkeys, a.keys0, a.keys1, a.cursor, a.slab_ovf);
     else
-        AFQ_LAUNCH(k_scatter<kLdsBins>, a.n_tiles, 256, s, a.tile_desc, a.meta, a.cell_nkeys, a.keys0, a.keys1, a.cursor);
+        AFQ_LAUNCH(k_scatter<kLdsBins>, a.n_tiles, 256, s, a.tile_desc, a.meta, a.cell_nkeys, a.keys0, a.keys1, a.cursor, a.slab_ovf);
+}
+
+void launch_fix_slabs(hipStream_t s, const ResolveArgs& a) {
+    if (!a.n_multi || !a.slabs) return;
+    const uint32_t grid = a.n_multi < 512u ? a.n_multi : 512u;
+    AFQ_LAUNCH(k_fix_slabs, grid, 256, s, a.multi_cells, a.n_multi, a.meta, a.cell_nkeys, a.keys0, a.keys1, a.cursor, a.slab_ovf);
 }
 
 static ResolveCfg make_rc(const ResolveArgs& a) {
@@ -1082,7 +1141,7 @@ void launch_resolve(hipStream_t s, const ResolveArgs& a) {
     ResolveCfg rc = make_rc(a);
     LabArea la{a.lab, a.lab_cnt};
     BucketDesc* desc = reinterpret_cast<BucketDesc*>(a.bucket_desc);
-    AFQ_LAUNCH(k_bucket_desc, (a.n_buckets + 255) / 256, 256, s, a.meta, a.bucket_cell, a.cell_nkeys, a.cursor, a.n_buckets, desc);
+    AFQ_LAUNCH(k_bucket_desc, (a.n_buckets + 255) / 256, 256, s, a.meta, a.bucket_cell, a.cell_nkeys, a.cursor, a.slab_ovf, a.n_buckets, desc);
     const uint32_t n_cols = a.n_buckets < kResolveCols ? a.n_buckets : kResolveCols;
     const uint32_t grid = n_cols * ((a.n_buckets + n_cols - 1) / n_cols);
     if (a.lab)

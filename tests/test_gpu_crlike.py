@@ -552,3 +552,23 @@ def test_giant_cell_beyond_the_lds_histogram(oracle, usa):
     got, want, st = run_both(oracle, cfg_for(s), s.tid_to_gid, b, off)
     assert st["n_buckets"] >= 4096
     assert_same_result(got, want)
+
+
+@pytest.mark.parametrize("env", [{"AFQ_FIXED_SLABS": "0"}, {"AFQ_SLAB_CAP": "8"}, {"AFQ_SLAB_CAP": "200"}, {}])
+@pytest.mark.parametrize("res,usa", [("cr-like", False), ("cr-like", True), ("cr-like-em", True)])
+def test_bucket_placement_routes_agree(oracle, monkeypatch, env, res, usa):
+    """Keys of a multi-bucket cell go to fixed-capacity bucket slabs without a counting pass; a bucket that outgrows its
+    slab sends its cell through the exact placement (scan of the counts the cursors already hold).  The exact route
+    alone (AFQ_FIXED_SLABS=0), slabs so small that every cell overflows (8), slabs that only the heavy-UMI cell
+    overflows (200), and the default: all against the oracle."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    sizes = [60000, 20000, 9000, 5000, 3000, 1200, 700, 300, 90, 12]
+    s = synth.synth(77, sizes, num_genes=600, txp_per_gene=3, usa=usa, dup=0.5, zipf=0.7, cross=0.3, umi_err=0.02, max_extra_na=6)
+    # one UMI with hundreds of reads over a few genes in the second cell: a bucket far above the mean
+    r0 = int(s.cell_nrec[0])
+    s.umi[r0:r0 + 900] = s.umi[r0]
+    b, off = s.encode()
+    got, want, st = run_both(oracle, cfg_for(s, res), s.tid_to_gid, b, off)
+    assert_same_result(got, want, what=str(env))
+    assert got.val.sum() > 0
