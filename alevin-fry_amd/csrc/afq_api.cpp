@@ -1448,7 +1448,7 @@ int afq_atac_dedup_rad(afq_ctx* c, const uint8_t* bytes, size_t n_bytes, const u
         cells[i] = AtacCell{chunk_off[i], n_rec, bm_words, nb, nr};
         cap_ptr[i] = n_rec;
         n_rec += nr;
-        bm_words += 4ull * ((nb + 255) / 256);
+        bm_words += 4ull * (((uint64_t)nb + 3 + 255) / 256);   // four ballots per group of 256 positions (counted from the dword boundary below the chunk)
     }
     cap_ptr[n_cells] = n_rec;
     DevBuf &d_ref = c->atac[0], &d_start = c->atac[1], &d_flen = c->atac[2], &d_ptr = c->atac[3];
@@ -1475,7 +1475,7 @@ int afq_atac_dedup_rad(afq_ctx* c, const uint8_t* bytes, size_t n_bytes, const u
         ScopedTimer t(c, K_ATAC_PARSE, s);
         AtacParseArgs pa{d_bytes, d_cells.as<AtacCell>(), n_cells, bc_bytes, d_bm.as<uint64_t>(), d_ref.as<uint32_t>(), d_start.as<uint32_t>(),
                          d_flen.as<uint16_t>(), d_cnt.as<uint32_t>(), d_bc.as<uint64_t>(), d_stat.as<uint32_t>(), d_walk.as<uint32_t>(),
-                         d_nwalk.as<uint32_t>(), d_status.as<DevStatus>()};
+                         d_nwalk.as<uint32_t>(), d_status.as<DevStatus>(), (uint64_t)n_bytes};
         launch_atac_parse(s, pa);
         HIP_TRY(c, hipGetLastError());
     }

@@ -37,6 +37,16 @@ __device__ __forceinline__ uint64_t ldbc(const uint8_t* p, uint32_t bcb) {
     return *p;
 }
 
+// Pass A reads the chunk as ALIGNED dwords: a thread takes four consecutive byte positions q0 .. q0+3 (q = byte offset from
+// the dword boundary at or below the chunk's first byte) and builds the na and barcode words of each from four loaded
+// dwords with funnel shifts - a quarter of the load instructions of one unaligned pair per position, and every byte of the
+// chunk fetched once per wave instead of eight times.  The candidate bits of a group of 256 positions are four ballots;
+// they are stored AS the ballots (word 4g + k holds positions 256g + 4*lane + k), and pass B addresses them that way.
+// Pass B gives every lane one bitmap word: the lane walks its ~3 set bits (na, successor bit, fragment fields), so a wave
+// has 64 record chains in flight where a lane per position had three or four.
+__device__ __forceinline__ uint32_t bm_word_of(uint32_t q) { return ((q >> 8) << 2) + (q & 3u); }
+__device__ __forceinline__ uint32_t bm_bit_of(uint32_t q) { return (q >> 2) & 63u; }
+
 __global__ __launch_bounds__(kParseNT) void k_atac_parse(AtacParseArgs a) {
     __shared__ uint32_t s_red[3][kParseNT / 64];
     __shared__ uint32_t s_cnt, s_multi, s_non;
@@ -48,95 +58,121 @@ __global__ __launch_bounds__(kParseNT) void k_atac_parse(AtacParseArgs a) {
     if (tid == 0) { s_cnt = 0; s_multi = 0; s_non = 0; }
     const bool has_first = nb >= 8 + H;
     const uint64_t bc0 = has_first ? ldbc(ch + 12, a.bc_bytes) : 0;
-    // ---- pass A: candidate bits (four tiles of 256 positions per trip: the loads of all four are in flight together -
-    // one position per thread and trip left the loop waiting out one memory round trip per 256 bytes)
-    for (uint32_t base = 0; base < nb; base += 4 * kParseNT) {
-        uint64_t bcv[4];
-        uint32_t nav[4];
+    const uint32_t bc0_lo = (uint32_t)bc0, bc0_hi = (uint32_t)(bc0 >> 32);
+    const uint32_t lo_mask = a.bc_bytes >= 4 ? 0xFFFFFFFFu : (1u << (8 * a.bc_bytes)) - 1u;
+    const uint32_t al = (uint32_t)((uintptr_t)ch & 3u);
+    const uint32_t* W = reinterpret_cast<const uint32_t*>(ch - al);
+    const uint64_t w_lim = (a.n_bytes - (c.chunk_off - al)) >> 2;   // whole dwords of the input buffer from W on
+    const uint32_t nq = nb + al;                                     // positions q in [al, nq)
+    const uint32_t n_groups = (nq + 255) >> 8;
+    // ---- pass A: candidate bits, a wave per group of 256 positions, two groups per trip
+    for (uint32_t g0 = wave * 2; g0 < n_groups; g0 += (kParseNT / 64) * 2) {
+        uint32_t d[2][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t p = base + j * kParseNT + tid;
-            const bool in = p >= 8 && p + H <= nb;
-            bcv[j] = in ? ldbc(ch + p + 4, a.bc_bytes) : ~bc0;
-            nav[j] = in ? ld32(ch + p) : 0xFFFFFFFFu;
+        for (int u = 0; u < 2; ++u) {
+            const uint64_t D = (uint64_t)(g0 + u) * 64 + lane;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) d[u][x] = (g0 + u < n_groups && D + x < w_lim && (x < 3 || a.bc_bytes == 8)) ? W[D + x] : 0u;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t p = base + j * kParseNT + tid;
-            const bool cand = p >= 8 && p + H <= nb && bcv[j] == bc0 && nav[j] <= (nb - p - H) / 11u;
-            const uint64_t m = __ballot(cand);
-            if (lane == 0 && base + j * kParseNT < nb) bm[p >> 6] = m;
+        for (int u = 0; u < 2; ++u) {
+            if (g0 + u >= n_groups) break;
+            const uint32_t q0 = (g0 + u) * 256 + 4 * lane;
+            uint64_t m[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t q = q0 + k;
+                const uint32_t na = k ? __builtin_amdgcn_alignbyte(d[u][1], d[u][0], k) : d[u][0];
+                const uint32_t bl = k ? __builtin_amdgcn_alignbyte(d[u][2], d[u][1], k) : d[u][1];
+                const uint32_t bh = k ? __builtin_amdgcn_alignbyte(d[u][3], d[u][2], k) : d[u][2];
+                const uint32_t p = q - al;
+                bool cand = q >= al + 8 && p + H <= nb && (bl & lo_mask) == bc0_lo;
+                if (a.bc_bytes == 8) cand = cand && bh == bc0_hi;
+                cand = cand && na <= (nb - p - H) / 11u;
+                m[k] = __ballot(cand);
+            }
+            if (lane < 4) bm[(uint64_t)(g0 + u) * 4 + lane] = lane == 0 ? m[0] : lane == 1 ? m[1] : lane == 2 ? m[2] : m[3];
         }
     }
     __threadfence_block();
     __syncthreads();
-    // ---- pass B: successor check, counts, kept fragments
+    // ---- pass B: a bitmap word per lane: successor check, counts, kept fragments
     uint32_t n_cand = 0, sum = 0;
     bool fail = false;
     uint32_t* o_ref = a.o_ref + c.out_off;
     uint32_t* o_start = a.o_start + c.out_off;
     uint16_t* o_flen = a.o_flen + c.out_off;
-    for (uint32_t base = 0; base < nb; base += 4 * kParseNT) {   // four tiles per trip again: bitmap words, then the record heads, then the successors
-        bool cand[4], keep[4];
-        uint32_t na[4], ty[4];
-        uint64_t sw[4];
+    const uint32_t n_words = n_groups * 4;
+    uint32_t multi = 0, non = 0;
+    for (uint32_t wi = tid; wi < n_words; wi += kParseNT) {
+        uint64_t w = bm[wi];
+        const uint32_t qbase = (wi >> 2) * 256 + (wi & 3u);
+        const uint32_t nc = (uint32_t)__popcll(w);
+        n_cand += nc;
+        // first the record heads of up to four candidates (independent loads), then their successors
+        uint32_t kept = 0;
+        uint32_t kp[4];   // positions of this word's kept records (more than four: a second round)
+        while (w) {
+            uint32_t pp[4], nn[4], tt[4];
+            int n = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t tb = base + j * kParseNT;
-            const uint64_t w = tb < nb ? bm[(tb >> 6) + wave] : 0ull;   // one word per wave
-            cand[j] = (w >> lane) & 1ull;
-        }
+            for (int x = 0; x < 4; ++x) {
+                pp[x] = 0; nn[x] = 0; tt[x] = 0;
+                if (w) { const uint32_t b = (uint32_t)__builtin_ctzll(w); w &= w - 1; pp[x] = qbase + 4 * b - al; n = x + 1; }
+            }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t p = base + j * kParseNT + tid;
-            na[j] = cand[j] ? ld32(ch + p) : 0u;
-            ty[j] = cand[j] && p + H + 4 < nb ? ch[p + H + 4] : 0u;
-        }
+            for (int x = 0; x < 4; ++x) if (x < n) { nn[x] = ld32(ch + pp[x]); tt[x] = pp[x] + H + 4 < nb ? ch[pp[x] + H + 4] : 0u; }
+            uint64_t sw[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t p = base + j * kParseNT + tid;
-            const uint32_t s = p + H + 11u * na[j];
-            sw[j] = cand[j] && s + H <= nb ? bm[s >> 6] : 0ull;
-        }
+            for (int x = 0; x < 4; ++x) {
+                const uint32_t s = pp[x] + H + 11u * nn[x];
+                sw[x] = (x < n && s + H <= nb) ? bm[bm_word_of(s + al)] : 0ull;
+            }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t p = base + j * kParseNT + tid;
-            keep[j] = false;
-            if (cand[j]) {
-                const uint32_t sz = H + 11u * na[j], s = p + sz;
-                const bool ok = s == nb || (s + H <= nb && ((sw[j] >> (s & 63u)) & 1ull));
+            for (int x = 0; x < 4; ++x) {
+                if (x >= n) continue;
+                const uint32_t sz = H + 11u * nn[x], s = pp[x] + sz;
+                const bool ok = s == nb || (s + H <= nb && ((sw[x] >> bm_bit_of(s + al)) & 1ull));
                 fail = fail || !ok;
-                ++n_cand; sum += sz;
-                keep[j] = na[j] == 1 && ty[j] == 4;
+                sum += sz;
+                const bool keep = nn[x] == 1 && tt[x] == 4;
+                if (keep) {
+                    if (kept == 4) {   // flush the four held back
+                        const uint32_t slot0 = atomicAdd(&s_cnt, 4u);
+#pragma unroll
+                        for (int y = 0; y < 4; ++y) {
+                            if (slot0 + y < c.nrec) { o_ref[slot0 + y] = ld32(ch + kp[y] + H); o_start[slot0 + y] = ld32(ch + kp[y] + H + 5); o_flen[slot0 + y] = (uint16_t)ld16(ch + kp[y] + H + 9); }
+                            else fail = true;
+                        }
+                        kept = 0;
+                    }
+#pragma unroll
+                    for (int y = 0; y < 4; ++y) if ((uint32_t)y == kept) kp[y] = pp[x];
+                    ++kept;
+                } else if (nn[x] > 1) ++multi;
+                else ++non;
             }
-            const uint64_t km = __ballot(keep[j]);
-            const uint64_t mm = __ballot(cand[j] && na[j] > 1), nm = __ballot(cand[j] && !keep[j] && na[j] <= 1);
-            uint32_t slot0 = 0;
-            if (lane == 0) {
-                if (km) slot0 = atomicAdd(&s_cnt, (uint32_t)__popcll(km));
-                if (mm) atomicAdd(&s_multi, (uint32_t)__popcll(mm));
-                if (nm) atomicAdd(&s_non, (uint32_t)__popcll(nm));
-            }
-            slot0 = __shfl(slot0, 0);
-            if (keep[j]) {
-                const uint32_t slot = slot0 + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
-                if (slot < c.nrec) {
-                    o_ref[slot] = ld32(ch + p + H);
-                    o_start[slot] = ld32(ch + p + H + 5);
-                    o_flen[slot] = (uint16_t)ld16(ch + p + H + 9);
-                } else fail = true;   // more candidates than records: the proof cannot hold
+        }
+        if (kept) {
+            const uint32_t slot0 = atomicAdd(&s_cnt, kept);
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                if ((uint32_t)y >= kept) break;
+                if (slot0 + y < c.nrec) { o_ref[slot0 + y] = ld32(ch + kp[y] + H); o_start[slot0 + y] = ld32(ch + kp[y] + H + 5); o_flen[slot0 + y] = (uint16_t)ld16(ch + kp[y] + H + 9); }
+                else fail = true;   // more candidates than records: the proof cannot hold
             }
         }
     }
-    // block reduction of (count, size sum, fail)
+    // block reduction of (count, size sum, fail) and of the two tallies
     uint32_t f = fail ? 1u : 0u;
-    for (int d = 32; d; d >>= 1) { n_cand += __shfl_xor(n_cand, d); sum += __shfl_xor(sum, d); f |= __shfl_xor(f, d); }
-    if (lane == 0) { s_red[0][wave] = n_cand; s_red[1][wave] = sum; s_red[2][wave] = f; }
+    for (int dd = 32; dd; dd >>= 1) { n_cand += __shfl_xor(n_cand, dd); sum += __shfl_xor(sum, dd); f |= __shfl_xor(f, dd); multi += __shfl_xor(multi, dd); non += __shfl_xor(non, dd); }
+    if (lane == 0) { s_red[0][wave] = n_cand; s_red[1][wave] = sum; s_red[2][wave] = f; if (multi) atomicAdd(&s_multi, multi); if (non) atomicAdd(&s_non, non); }
     __syncthreads();
     if (tid == 0) {
         uint32_t cnt = 0, sm = 0, fl = 0;
         for (int w2 = 0; w2 < kParseNT / 64; ++w2) { cnt += s_red[0][w2]; sm += s_red[1][w2]; fl |= s_red[2][w2]; }
-        const bool ok = has_first && !fl && cnt == c.nrec && sm == nb - 8 && ((bm[0] >> 8) & 1ull);
+        const bool first_ok = has_first && ((bm[bm_word_of(8 + al)] >> bm_bit_of(8 + al)) & 1ull);
+        const bool ok = first_ok && !fl && cnt == c.nrec && sm == nb - 8;
         a.cell_bc[cell] = bc0;
         if (ok) {
             a.cell_cnt[cell] = s_cnt; a.cell_stat[2 * cell] = s_multi; a.cell_stat[2 * cell + 1] = s_non;

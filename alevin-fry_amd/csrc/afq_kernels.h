@@ -110,6 +110,7 @@ struct AtacParseArgs {
     uint64_t* bitmap; uint32_t* o_ref; uint32_t* o_start; uint16_t* o_flen; uint32_t* cell_cnt; uint64_t* cell_bc;
     uint32_t* cell_stat;   // [n_cells][2]: records with > 1 alignment, records that are not one properly mapped pair
     uint32_t* walk_list; uint32_t* n_walk; DevStatus* st;
+    uint64_t n_bytes;      // size of the input buffer (aligned dword reads stop there)
 };
 void launch_atac_parse(hipStream_t s, const AtacParseArgs& a);
 void launch_atac_compact(hipStream_t s, uint32_t n_cells, const uint64_t* cell_ptr, const uint64_t* out_ptr, const uint32_t* i_ref,

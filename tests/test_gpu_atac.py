@@ -125,3 +125,31 @@ def test_afquant_atac_deduplicate_writes_the_reference_bed(tmp_path, oracle, rev
     (tmp_path / "in" / "collate.json").write_text(json.dumps({"compressed_output": False}))
     r = subprocess.run([CLI, "atac", "deduplicate", "-i", str(tmp_path / "in")], capture_output=True, text=True)
     assert r.returncode != 0 and "scATAC RAD" in r.stderr
+
+
+@pytest.mark.parametrize("bcb", [1, 2, 4, 8])
+def test_atac_parse_at_every_alignment_and_width(oracle, bcb):
+    """The parse reads the chunk as aligned dwords and rebuilds every byte position's fields with funnel shifts: chunks
+    starting at each of the four byte alignments (records are 4 + bc + 11 na bytes, so successive chunks land on all of
+    them; a pad in front shifts the lot), every barcode width, cells from one record to a few thousand."""
+    rng = np.random.default_rng(40 + bcb)
+    cells = []
+    for ci, n in enumerate([1, 2, 3, 5, 17, 64, 65, 255, 256, 257, 1000, 3000]):
+        recs = []
+        for _ in range(n):
+            k = int(rng.choice([0, 1, 1, 1, 1, 2, 3]))
+            recs.append([(int(rng.integers(0, 25)), int(rng.choice([4, 4, 4, 1, 2])), int(rng.integers(0, 1 << 27)), int(rng.integers(30, 2500)))
+                         for _ in range(k)])
+        cells.append(((37 + 11 * ci) & ((1 << (8 * bcb)) - 1) if bcb < 8 else 0x1122334400000000 + ci, recs))
+    b, off = rad.encode_atac_cells(cells, bc_bytes=bcb)
+    for pad in range(4):
+        data = np.concatenate((np.zeros(pad, np.uint8), np.frombuffer(b, np.uint8)))
+        offs = np.asarray(off, np.uint64) + np.uint64(pad)
+        want = oracle.atac_dedup_rad(data, offs, bc_bytes=bcb)
+        q = _q()
+        try:
+            got = q.atac_dedup_rad(data, offs, bc_bytes=bcb)
+        finally:
+            q.close()
+        _same(got, want)
+        assert got[6]["n_records"] == sum(len(r) for _, r in cells)
