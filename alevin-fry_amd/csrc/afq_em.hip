@@ -286,24 +286,33 @@ __global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta,
     EM_MARK(3);
     // 4. inverted index: for every support entry the classes containing it, ascending class
     tiled_bitonic_sort_by<kEmNT, 4096>(inv_pairs, Wc, [](uint64_t a, uint64_t b) { return a > b; }, reinterpret_cast<uint64_t*>(s_tile));
+    EM_MARK(4);
     // slot_off[s] = first pair with support idx >= s: count the memberships per entry, exclusive scan
     for (uint32_t s = threadIdx.x; s <= S; s += kEmNT) slot_off[s] = 0;
     __syncthreads();
     for (uint32_t q = threadIdx.x; q < Wc; q += kEmNT) atomicAdd(&slot_off[(uint32_t)(inv_pairs[q] >> 32)], 1u);
     __syncthreads();
+    // (the scans below take eight consecutive elements per thread and trip: the support of a PBMC-sized USA cell has
+    // 25 000 entries, and a block scan per 256 of them was a hundred latency-bound round trips through two barriers each)
+    constexpr uint32_t kSc = 8;
     {
         uint32_t carry = 0;
-        for (uint32_t base = 0; base <= S; base += kEmNT) {
-            const uint32_t s = base + threadIdx.x;
-            const uint32_t c = s <= S ? slot_off[s] : 0u;
+        for (uint32_t base = 0; base <= S; base += kSc * kEmNT) {
+            const uint32_t s0 = base + kSc * threadIdx.x;
+            uint32_t v[kSc], sum = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < kSc; ++j) v[j] = s0 + j <= S ? slot_off[s0 + j] : 0u;
+#pragma unroll
+            for (uint32_t j = 0; j < kSc; ++j) { const uint32_t t = v[j]; v[j] = sum; sum += t; }
             uint32_t tot;
-            const uint32_t ex = block_excl_scan<kEmNT>(c, s_ws, tot);
-            if (s <= S) slot_off[s] = carry + ex;
+            const uint32_t ex = block_excl_scan<kEmNT>(sum, s_ws, tot);
+#pragma unroll
+            for (uint32_t j = 0; j < kSc; ++j) if (s0 + j <= S) slot_off[s0 + j] = carry + ex + v[j];
             carry += tot;
         }
     }
     __syncthreads();
-    EM_MARK(4);
+    EM_MARK(5);
     // 4b. The rounds only ever change entries that have a single-label count or sit in some class label
     // ("active"); every other support entry (the USA sibling statuses marked for em.rs:351-356) is produced
     // as 0 by each round.  Compact the active entries and express everything the rounds touch in active ids:
@@ -311,12 +320,20 @@ __global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta,
     // stand for "an inactive sibling" (the initial value in round 1, 0 afterwards) and "no sibling" (0; adding
     // +0.0f to a non-negative float is exact, so one three-term formula serves every status).
     uint32_t A = 0;
-    for (uint32_t base = 0; base < S; base += kEmNT) {
-        const uint32_t s2 = base + threadIdx.x;
-        const uint32_t h = s2 < S && (ucnt[s2] != 0 || slot_off[s2 + 1] > slot_off[s2]);
+    for (uint32_t base = 0; base < S; base += kSc * kEmNT) {
+        const uint32_t s0 = base + kSc * threadIdx.x;
+        uint32_t uc[kSc], so[kSc + 1], sum = 0, hm = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kSc; ++j) uc[j] = s0 + j < S ? ucnt[s0 + j] : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j <= kSc; ++j) so[j] = s0 + j <= S ? slot_off[s0 + j] : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < kSc; ++j) { const bool h = s0 + j < S && (uc[j] != 0 || so[j + 1] > so[j]); hm |= (uint32_t)h << j; sum += h; }
         uint32_t tot;
-        const uint32_t ex = block_excl_scan<kEmNT>(h, s_ws, tot);
-        if (s2 < S) aid[s2] = h ? A + ex : 0xFFFFFFFFu;
+        const uint32_t ex = block_excl_scan<kEmNT>(sum, s_ws, tot);
+        uint32_t run = A + ex;
+#pragma unroll
+        for (uint32_t j = 0; j < kSc; ++j) if (s0 + j < S) { const bool h = (hm >> j) & 1u; aid[s0 + j] = h ? run : 0xFFFFFFFFu; run += h; }
         A += tot;
     }
     __syncthreads();
@@ -326,23 +343,39 @@ __global__ __launch_bounds__(kEmNT) void k_em(const CellMeta* __restrict__ meta,
         const uint32_t a = aid[x];
         return a == 0xFFFFFFFFu ? Z0 : a;
     };
-    for (uint32_t s2 = threadIdx.x; s2 < S; s2 += kEmNT) {
-        const uint32_t a = aid[s2];
-        if (a == 0xFFFFFFFFu) continue;
-        ent[a] = make_uint4(ucnt[s2], amap(sib1[s2]), amap(sib2[s2]), slot_off[s2]);
-        act_col[a] = support[s2];
+    // (four entries / label words per thread and trip, each level of the dependent gathers issued for all four together)
+    for (uint32_t s0 = threadIdx.x; s0 < S; s0 += 4 * kEmNT) {
+        uint32_t a[4], u[4], x1[4], x2[4], so[4], sp[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint32_t s2 = s0 + j * kEmNT; a[j] = s2 < S ? aid[s2] : 0xFFFFFFFFu; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t s2 = s0 + j * kEmNT;
+            const bool on = a[j] != 0xFFFFFFFFu;
+            u[j] = on ? ucnt[s2] : 0u; x1[j] = on ? sib1[s2] : 0xFFFFFFFFu; x2[j] = on ? sib2[s2] : 0xFFFFFFFFu;
+            so[j] = on ? slot_off[s2] : 0u; sp[j] = on ? support[s2] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { x1[j] = amap(x1[j]); x2[j] = amap(x2[j]); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (a[j] != 0xFFFFFFFFu) { ent[a[j]] = make_uint4(u[j], x1[j], x2[j], so[j]); act_col[a[j]] = sp[j]; }
     }
     if (threadIdx.x == 0) ent[A] = make_uint4(0u, Z1, Z1, Wc);
-    for (uint32_t w = threadIdx.x; w < Wc; w += kEmNT) {
-        const uint32_t s2 = cls_sidx[w];
-        lw3[w] = make_uint4(aid[s2], amap(sib1[s2]), amap(sib2[s2]), 0u);
-        memb[w] = (uint32_t)inv_pairs[w];
+    for (uint32_t w0 = threadIdx.x; w0 < Wc; w0 += 4 * kEmNT) {
+        uint32_t s2[4], a0[4], y1[4], y2[4], mb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint32_t w = w0 + j * kEmNT; s2[j] = w < Wc ? cls_sidx[w] : 0u; mb[j] = w < Wc ? (uint32_t)inv_pairs[w] : 0u; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const bool on = w0 + j * kEmNT < Wc; a0[j] = on ? aid[s2[j]] : 0u; y1[j] = on ? sib1[s2[j]] : 0xFFFFFFFFu; y2[j] = on ? sib2[s2[j]] : 0xFFFFFFFFu; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { y1[j] = amap(y1[j]); y2[j] = amap(y2[j]); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint32_t w = w0 + j * kEmNT; if (w < Wc) { lw3[w] = make_uint4(a0[j], y1[j], y2[j], 0u); memb[w] = mb[j]; } }
     }
-    EM_MARK(4);
+    EM_MARK(6);
     if (threadIdx.x == 0) em_hdr[cell] = make_uint4(A, K, Wc, 0u);  // the rounds run in k_em_rounds
 #ifdef AFQ_EM_TIMING
-    EM_MARK(5);
-    if (threadIdx.x == 0 && (blockIdx.x % 1000) == 7) { printf("em setup nrec=%u nU=%u M=%u K=%u S=%u Wc=%u A=%u:", m.nrec, nU, M, K, S, Wc, A); for (int i = 1; i <= 5; ++i) printf(" p%d=%.3fms", i, (double)(tmark[i] - tmark[i - 1]) / 1e5); printf("\n"); }
+    if (threadIdx.x == 0 && (blockIdx.x % 1000) == 7) { printf("em setup nrec=%u nU=%u M=%u K=%u S=%u Wc=%u A=%u:", m.nrec, nU, M, K, S, Wc, A); for (int i = 1; i <= 6; ++i) printf(" p%d=%.3fms", i, (double)(tmark[i] - tmark[i - 1]) / 1e5); printf("\n"); }
 #endif
 }
 
