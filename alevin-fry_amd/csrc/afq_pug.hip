@@ -621,6 +621,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         uint32_t tot;
         const uint32_t ex = block_excl_scan<kPugNT>(nv | (nc << 16), s_ws, tot);
         uint32_t ev = ex & 0xFFFFu, ec = ex >> 16;
+        uint32_t pend_k = 0xFFFFFFFFu, pend_min = 0xFFFFFFFFu;   // the thread's reads of one class share one atomicMin
 #pragma unroll
         for (uint32_t j = 0; j < kPer; ++j) {
             const uint32_t i = i0 + j;
@@ -645,7 +646,8 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                     }
                     c_sig[k] = sg | (tag << 20);   // bits 20-21: how many refs the label has (3 = more than two: read it from its record)
                 }
-                atomicMin(&c_minoff[k], ro);
+                if (k != pend_k) { if (pend_k != 0xFFFFFFFFu) atomicMin(&c_minoff[pend_k], pend_min); pend_k = k; pend_min = ro; }
+                else pend_min = ro < pend_min ? ro : pend_min;
                 if (!c && !label_key_is_exact(cur[j].h)) {
                     const uint32_t po = rec_off(j ? cur[j - 1] : prev);
                     if (!C.gene_level) {
@@ -662,6 +664,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                 ev += v; ec += c;
             }
         }
+        if (pend_k != 0xFFFFFFFFu) atomicMin(&c_minoff[pend_k], pend_min);
         V += tot & 0xFFFFu; K += tot >> 16;
     }
     if (tid == 0) c_vstart[K] = V;
@@ -757,13 +760,36 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         }
     }
     __syncthreads();
-    for (uint32_t j = tid; j < V; j += kPugNT) {
-        const uint32_t k = v_cls[j];
-        const uint32_t vid = c_base[k] + (j - c_vstart[k]);
-        vv_umi[vid] = v_umi[j];
-        const uint32_t code = C.gene_level ? 3u : c_sig[k] >> 20;
-        const bool inl = code == 1 || code == 2;
-        vv[vid] = make_uint4(((j + 1 < V ? v_cnt[j + 1] : R) - v_cnt[j]) | (code << 20), k, inl ? c_r0[k] : c_rep[k], inl ? c_r1[k] : 0u);
+    for (uint32_t j0 = tid; j0 < V; j0 += 4 * kPugNT) {   // four vertices per thread and trip: the class lookups of all four go out together
+        uint32_t k[4], h0[4], h1[4], cb[4], cs[4], sg[4], ra[4], rb[4];
+        uint64_t um[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t j = j0 + q * kPugNT;
+            const bool on = j < V;
+            k[q] = on ? v_cls[j] : 0u; um[q] = on ? v_umi[j] : 0ull;
+            h0[q] = on ? v_cnt[j] : 0u; h1[q] = on && j + 1 < V ? v_cnt[j + 1] : R;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            cb[q] = c_base[k[q]]; cs[q] = c_vstart[k[q]];
+            sg[q] = C.gene_level ? (3u << 20) : c_sig[k[q]];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t code = sg[q] >> 20;
+            const bool inl = code == 1 || code == 2;
+            ra[q] = inl ? c_r0[k[q]] : c_rep[k[q]];
+            rb[q] = inl ? c_r1[k[q]] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t j = j0 + q * kPugNT;
+            if (j >= V) continue;
+            const uint32_t vid = cb[q] + (j - cs[q]);
+            vv_umi[vid] = um[q];
+            vv[vid] = make_uint4((h1[q] - h0[q]) | ((sg[q] >> 20) << 20), k[q], ra[q], rb[q]);
+        }
     }
     __syncthreads();
     PUG_MARK(3);
