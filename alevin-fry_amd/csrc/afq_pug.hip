@@ -1265,6 +1265,48 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         if (h) tl[NT + ex] = v;
         NT += tot;
     }
+    // The labels live in LDS, indexed by a vertex's position in tl (ascending with the vertex id, so the smallest label of
+    // a component is still its smallest vertex): the sweeps are LDS atomics and LDS reads, the edges are read once per
+    // sweep as positions (translated once).  A cell with more than 32 768 touched vertices keeps the labels in global memory.
+    const bool wcc_lds = NT <= (1u << 15);
+    if (wcc_lds) {
+        uint32_t* wl = s_big;
+        __syncthreads();
+        if (tid == 0) s_ebase = atomicAdd(A.epool_cursor, (unsigned long long)E);
+        for (uint32_t i = tid; i < NT; i += kPugNT) { wl[i] = i; local_idx[tl[i]] = i; }
+        __syncthreads();
+        if (s_ebase + E > A.epool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, cell); return; }
+        uint32_t* pedge = A.epool + s_ebase;   // edge targets as positions in tl
+        for (uint32_t i = tid; i < NT; i += kPugNT) {
+            const uint32_t x = tl[i];
+            for (uint32_t e = deg[x]; e < deg[x + 1]; ++e) pedge[e] = local_idx[edges[e]];
+        }
+        __syncthreads();
+        for (;;) {
+            if (tid == 0) s_flag[0] = 0;
+            __syncthreads();
+            bool ch = false;
+            for (uint32_t i = tid; i < NT; i += kPugNT) {
+                const uint32_t x = tl[i];
+                for (uint32_t e = deg[x]; e < deg[x + 1]; ++e) {
+                    const uint32_t j = pedge[e];
+                    const uint32_t a = wl[i], b = wl[j];
+                    if (a < b) { atomicMin(&wl[j], a); ch = true; }
+                    else if (b < a) { atomicMin(&wl[i], b); ch = true; }
+                }
+            }
+            if (ch) s_flag[0] = 1;
+            __syncthreads();
+            for (int it = 0; it < 4; ++it) {
+                for (uint32_t i = tid; i < NT; i += kPugNT) { const uint32_t l = wl[i]; const uint32_t ll = wl[l]; if (ll < l) wl[i] = ll; }
+                __syncthreads();
+            }
+            if (!s_flag[0]) break;
+        }
+        PUG_MARK(6);
+        for (uint32_t i = tid; i < NT; i += kPugNT) { uint32_t l = wl[i]; while (wl[l] != l) l = wl[l]; comp_sorted[i] = ((uint64_t)tl[l] << kVidBits) | tl[i]; }
+        __syncthreads();
+    } else {
     for (uint32_t v = tid; v < V; v += kPugNT) wlab[v] = v;
     __syncthreads();
     for (;;) {
@@ -1292,6 +1334,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     // a label may still point at a non-root after the last sweep; chase it
     for (uint32_t i = tid; i < NT; i += kPugNT) { const uint32_t v = tl[i]; uint32_t l = wlab[v]; while (wlab[l] != l) l = wlab[l]; comp_sorted[i] = ((uint64_t)l << kVidBits) | v; }
     __syncthreads();
+    }
     tiled_bitonic_sort_by<kPugNT, 8192>(comp_sorted, NT, [](uint64_t a, uint64_t b) { return a > b; }, reinterpret_cast<uint64_t*>(s_big));
     uint32_t NC = 0;   // components of two or more vertices
     for (uint32_t base = 0; base < NT; base += kPugNT) {
