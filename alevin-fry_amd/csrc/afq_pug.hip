@@ -306,16 +306,15 @@ __device__ __forceinline__ void emit_molecule(const PugCtx& c, const uint32_t* g
 // emit_molecule for a gene label of one or two ids (g0 < g1) held in registers - nine molecules in ten.  Returns the column
 // the molecule counts for (the CALLER appends it: one reservation per wave, see append_cols) or 0xFFFFFFFF when there is
 // none (dropped, or kept as a two-gene class for the EM - written here).
-__device__ __forceinline__ uint32_t molecule2_column(const PugCtx& c, uint32_t g0, uint32_t g1, uint32_t ng) {
+// cls is set when the molecule is a two-gene class (g0, g1) for the EM: the CALLER stores it, one reservation per wave
+// (append_class2) - two same-address LDS atomics per molecule were queueing the whole CU behind one word.
+__device__ __forceinline__ uint32_t molecule2_column(const PugCtx& c, uint32_t g0, uint32_t g1, uint32_t ng, bool& cls) {
     uint32_t col = 0xFFFFFFFFu;
     auto sua = [&](uint32_t g) { return (g & 1u) == 0 ? (g >> 1) : c.uo + (g >> 1); };
     if (ng == 1) col = c.usa ? sua(g0) : g0;
     else if (c.usa && ((g0 ^ g1) & ~1u) == 0) col = c.ao + (g0 >> 1);
     else if (c.em) {
-        const uint32_t off = atomicAdd(&c.s_cnt[1], 2u), di = atomicAdd(&c.s_cnt[2], 1u);
-        if (off + 2 > c.lab_cap || 2 * (di + 1) > c.lab_cap) { c.s_cnt[3] = kErrPugLimit; return 0xFFFFFFFFu; }
-        c.labw[off] = g0; c.labw[off + 1] = g1;
-        c.labd[2 * di] = off; c.labd[2 * di + 1] = 2;
+        cls = true;
         return 0xFFFFFFFFu;
     } else if (c.usa) {
         const bool s1 = (g0 & 1u) == 0, s2 = (g1 & 1u) == 0;
@@ -351,9 +350,9 @@ __device__ __forceinline__ uint32_t genes_of4(const PugCtx& c, uint32_t (&g)[4],
 }
 // emit_molecule for a gene label of up to four ids in registers; like molecule2_column it returns the column (for
 // append_cols) or 0xFFFFFFFF, and writes a multi-gene class for the EM itself.
-__device__ __forceinline__ uint32_t molecule4_column(const PugCtx& c, const uint32_t (&g)[4], uint32_t ng) {
+__device__ __forceinline__ uint32_t molecule4_column(const PugCtx& c, const uint32_t (&g)[4], uint32_t ng, bool& cls) {
     if (ng == 0) return 0xFFFFFFFFu;
-    if (ng <= 2) return molecule2_column(c, g[0], g[1], ng);
+    if (ng <= 2) return molecule2_column(c, g[0], g[1], ng, cls);   // (cls: the class is (g[0], g[1]))
     uint32_t col = 0xFFFFFFFFu;
     if (c.em) {
         const uint32_t off = atomicAdd(&c.s_cnt[1], ng), di = atomicAdd(&c.s_cnt[2], 1u);
@@ -386,6 +385,25 @@ __device__ __forceinline__ void append_cols(const PugCtx& c, uint32_t col) {
     if (has) {
         const uint32_t p = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
         if (p >= c.cols_cap) c.s_cnt[3] = kErrPugLimit; else c.cols[p] = col;
+    }
+}
+
+// Store one two-gene class per lane that has one (want).  Wave-wide call, like append_cols: one reservation of label words
+// and one of descriptors per wave.
+__device__ __forceinline__ void append_class2(const PugCtx& c, bool want, uint32_t g0, uint32_t g1) {
+    const uint64_t m = __ballot(want);
+    if (!m) return;
+    const uint32_t lane = lane_id(), leader = (uint32_t)__builtin_ctzll(m), n = (uint32_t)__popcll(m);
+    uint32_t off = 0, di = 0;
+    if (lane == leader) { off = atomicAdd(&c.s_cnt[1], 2u * n); di = atomicAdd(&c.s_cnt[2], n); }
+    off = __builtin_amdgcn_readlane(off, (int)leader);
+    di = __builtin_amdgcn_readlane(di, (int)leader);
+    if (want) {
+        const uint32_t r = (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        const uint32_t o = off + 2 * r, d = di + r;
+        if (o + 2 > c.lab_cap || 2 * (d + 1) > c.lab_cap) { c.s_cnt[3] = kErrPugLimit; return; }
+        c.labw[o] = g0; c.labw[o + 1] = g1;
+        c.labd[2 * d] = o; c.labd[2 * d + 1] = 2;
     }
 }
 
@@ -1407,10 +1425,12 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            uint32_t col = 0xFFFFFFFFu;
+            uint32_t col = 0xFFFFFFFFu, k0 = 0, k1 = 0;
+            bool cls = false;
             if (lone[j] && shrt[j]) {
                 const uint32_t lo = ga[j] < gb[j] ? ga[j] : gb[j], hi = ga[j] < gb[j] ? gb[j] : ga[j];
-                col = molecule2_column(C, lo, hi, lo == hi ? 1u : 2u);
+                col = molecule2_column(C, lo, hi, lo == hi ? 1u : 2u, cls);
+                k0 = lo; k1 = hi;
             } else if (lone[j]) {
                 const Lab l = vlab(v0 + j * kPugNT);
                 if (l.n <= 4) {
@@ -1418,7 +1438,8 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) g4[q] = (uint32_t)q < l.n ? l.p[q] & 0x7FFFFFFFu : 0xFFFFFFFFu;
                     const uint32_t ng = genes_of4(C, g4, l.n);
-                    col = molecule4_column(C, g4, ng);
+                    col = molecule4_column(C, g4, ng, cls);
+                    k0 = g4[0]; k1 = g4[1];
                 } else {
                     uint32_t g[kMaxGenesPerLabel];
                     const uint32_t ng = genes_of(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; }, g);
@@ -1427,10 +1448,12 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                 }
             }
             append_cols(C, col);   // (v0 - lane is wave-uniform: every lane of the wave gets here)
+            append_class2(C, cls, k0, k1);
         }
     }
     for (uint32_t c = tid; c - lane < NC; c += kPugNT) {   // (wave-uniform trip count: append_cols is a wave-wide call)
-        uint32_t col = 0xFFFFFFFFu;
+        uint32_t col = 0xFFFFFFFFu, k0 = 0, k1 = 0;
+        bool cls = false;
         const uint32_t n = c < NC ? comp_start[c + 1] - comp_start[c] : 0u;
         if (n == 2 && n <= C.large_thresh) {
             const Lab l = vlab(vid_at(comp_start[c])), l2 = vlab(vid_at(comp_start[c] + 1));
@@ -1450,7 +1473,8 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                     }
                 }
                 const uint32_t ng = genes_of4(C, g4, k);
-                col = molecule4_column(C, g4, ng);
+                col = molecule4_column(C, g4, ng, cls);
+                k0 = g4[0]; k1 = g4[1];
             } else {
                 uint32_t g[kMaxGenesPerLabel];
                 uint32_t ng = 0;
@@ -1472,6 +1496,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
             }
         }
         append_cols(C, col);
+        append_class2(C, cls, k0, k1);
     }
     PUG_MARK(8);
     // ---- 6b. components of 3..64 vertices: one wave each, adjacency = one 64-bit mask per lane ----
@@ -1610,12 +1635,14 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                     }
                 }
                 uint32_t col = 0xFFFFFFFFu;
+                bool cls = false;
                 if (best && gl == 0) {
-                    if (small) { const uint32_t n4 = genes_of4(C, c4, k4); col = molecule4_column(C, c4, n4); }
+                    if (small) { const uint32_t n4 = genes_of4(C, c4, k4); col = molecule4_column(C, c4, n4, cls); }
                     else if (wide && C.em) emit_wide_from_records(C, mrec, b0, fv, best);
                     else emit_molecule(C, g, wide ? 0xFFFFFFFFu : ng);
                 }
                 append_cols(C, col);
+                append_class2(C, cls, c4[0], c4[1]);
                 UC &= ~best;
             }
         }
@@ -1712,12 +1739,14 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
             }
             {
                 uint32_t col = 0xFFFFFFFFu;
+                bool cls = false;
                 if (lane == 0) {
-                    if (small) { const uint32_t n4 = genes_of4(C, c4, k4); col = molecule4_column(C, c4, n4); }
+                    if (small) { const uint32_t n4 = genes_of4(C, c4, k4); col = molecule4_column(C, c4, n4, cls); }
                     else if (wide && C.em) emit_wide_from_records(C, mrec, mid_off[ci], fv, best);
                     else emit_molecule(C, g, wide ? 0xFFFFFFFFu : ng);
                 }
                 append_cols(C, col);
+                append_class2(C, cls, c4[0], c4[1]);
             }
             UC &= ~best;
         }
