@@ -1406,6 +1406,11 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     // is the transcripts the two labels share (pugutils.rs:1161-1188) - never empty, an edge needs an overlap.
     // vertices without an edge: one molecule each, the label's genes.  Four vertices per thread and trip, their loads issued
     // together; labels of one or two refs (in the vertex record) never touch the chunk or a gene array.
+    // Lone vertices whose label has more than two refs (one in ten) need the chunk and a gene lookup per ref - three dependent
+    // reads deep; they are listed here and taken afterwards, a lane each, instead of holding up the wave that met them.
+    uint32_t* long_list = c_minoff;   // (dead since phase 3)
+    if (tid == 0) s_flag[0] = 0;
+    __syncthreads();
     for (uint32_t v0 = tid; v0 - lane < V; v0 += 4 * kPugNT) {   // wave-uniform trip count (append_cols is a wave-wide call)
         uint4 q4[4];
         bool lone[4], shrt[4];
@@ -1431,25 +1436,43 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                 const uint32_t lo = ga[j] < gb[j] ? ga[j] : gb[j], hi = ga[j] < gb[j] ? gb[j] : ga[j];
                 col = molecule2_column(C, lo, hi, lo == hi ? 1u : 2u, cls);
                 k0 = lo; k1 = hi;
-            } else if (lone[j]) {
-                const Lab l = vlab(v0 + j * kPugNT);
-                if (l.n <= 4) {
-                    uint32_t g4[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) g4[q] = (uint32_t)q < l.n ? l.p[q] & 0x7FFFFFFFu : 0xFFFFFFFFu;
-                    const uint32_t ng = genes_of4(C, g4, l.n);
-                    col = molecule4_column(C, g4, ng, cls);
-                    k0 = g4[0]; k1 = g4[1];
-                } else {
-                    uint32_t g[kMaxGenesPerLabel];
-                    const uint32_t ng = genes_of(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; }, g);
-                    if (ng == 0xFFFFFFFFu && C.em) emit_wide_class(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; });
-                    else emit_molecule(C, g, ng);
-                }
+            }
+            const bool later = lone[j] && !shrt[j];
+            const uint64_t lm = __ballot(later);
+            if (lm) {
+                const uint32_t leader = (uint32_t)__builtin_ctzll(lm);
+                uint32_t at = 0;
+                if (lane == leader) at = atomicAdd(&s_flag[0], (uint32_t)__popcll(lm));
+                at = __builtin_amdgcn_readlane(at, (int)leader);
+                if (later) long_list[at + (uint32_t)__popcll(lm & ((1ull << lane) - 1))] = v0 + j * kPugNT;
             }
             append_cols(C, col);   // (v0 - lane is wave-uniform: every lane of the wave gets here)
             append_class2(C, cls, k0, k1);
         }
+    }
+    __syncthreads();
+    const uint32_t n_long = s_flag[0];
+    for (uint32_t i = tid; i - lane < n_long; i += kPugNT) {
+        uint32_t col = 0xFFFFFFFFu, k0 = 0, k1 = 0;
+        bool cls = false;
+        if (i < n_long) {
+            const Lab l = vlab(long_list[i]);
+            if (l.n <= 4) {
+                uint32_t g4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g4[q] = (uint32_t)q < l.n ? l.p[q] & 0x7FFFFFFFu : 0xFFFFFFFFu;
+                const uint32_t ng = genes_of4(C, g4, l.n);
+                col = molecule4_column(C, g4, ng, cls);
+                k0 = g4[0]; k1 = g4[1];
+            } else {
+                uint32_t g[kMaxGenesPerLabel];
+                const uint32_t ng = genes_of(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; }, g);
+                if (ng == 0xFFFFFFFFu && C.em) emit_wide_class(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; });
+                else emit_molecule(C, g, ng);
+            }
+        }
+        append_cols(C, col);
+        append_class2(C, cls, k0, k1);
     }
     for (uint32_t c = tid; c - lane < NC; c += kPugNT) {   // (wave-uniform trip count: append_cols is a wave-wide call)
         uint32_t col = 0xFFFFFFFFu, k0 = 0, k1 = 0;
