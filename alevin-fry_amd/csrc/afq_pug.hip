@@ -1239,13 +1239,18 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     __syncthreads();
     PUG_MARK(14);
     uint32_t E = 0;
-    for (uint32_t base = 0; base < V; base += kPugNT) {
-        const uint32_t x = base + tid;
-        const uint32_t d = x < V ? deg[x] : 0u;
+    for (uint32_t base = 0; base < V; base += 8 * kPugNT) {   // eight consecutive vertices per thread and scan
+        const uint32_t x0 = base + 8 * tid;
+        uint32_t d[8], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = x0 + j < V ? deg[x0 + j] : 0u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const uint32_t t = d[j]; d[j] = sum; sum += t; }
         uint32_t tot;
-        const uint32_t ex = block_excl_scan<kPugNT>(d, s_ws, tot);
+        const uint32_t ex = block_excl_scan<kPugNT>(sum, s_ws, tot);
         __syncthreads();
-        if (x < V) { deg[x] = E + ex; c_order[x] = E + ex; }  // c_order (dead after phase 3) = per-vertex fill cursor
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (x0 + j < V) { deg[x0 + j] = E + ex + d[j]; c_order[x0 + j] = E + ex + d[j]; }  // c_order (dead after phase 3) = per-vertex fill cursor
         E += tot;
     }
     if (tid == 0) {
@@ -1275,12 +1280,20 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     // their own components and are resolved straight from their labels in 6a, without being listed or sorted.
     uint32_t* tl = v_cls;   // slab B is dead: the vertices that have an edge, ascending
     uint32_t NT = 0;
-    for (uint32_t base = 0; base < V; base += kPugNT) {
-        const uint32_t v = base + tid;
-        const bool h = v < V && (deg[v + 1] > deg[v] || tch[v]);
+    for (uint32_t base = 0; base < V; base += 8 * kPugNT) {
+        const uint32_t v0 = base + 8 * tid;
+        uint32_t dg[9], tc[8], hm = 0, sum = 0;
+#pragma unroll
+        for (int j = 0; j <= 8; ++j) dg[j] = v0 + j <= V ? deg[v0 + j] : 0u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tc[j] = v0 + j < V ? tch[v0 + j] : 0u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const bool h = v0 + j < V && (dg[j + 1] > dg[j] || tc[j]); hm |= (uint32_t)h << j; sum += h; }
         uint32_t tot;
-        const uint32_t ex = block_excl_scan<kPugNT>(h, s_ws, tot);
-        if (h) tl[NT + ex] = v;
+        const uint32_t ex = block_excl_scan<kPugNT>(sum, s_ws, tot);
+        uint32_t o = NT + ex;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if ((hm >> j) & 1u) tl[o++] = v0 + j;
         NT += tot;
     }
     // The labels live in LDS, indexed by a vertex's position in tl (ascending with the vertex id, so the smallest label of
