@@ -1204,6 +1204,13 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     }
     __syncthreads();
     const uint32_t n_pairs = s_flag[0];
+    // Out-degrees and fill cursors as 16-bit counters in LDS (two per word, indexed by vertex id) when the cell has at most
+    // 65 536 vertices: the counting and the edge fill are LDS atomics instead of global ones (the search's table is done with
+    // the 128 KiB block by now, the components' labels move in afterwards).
+    const bool lds_deg = fast && n_pairs <= pair_cap && V <= 65536u;
+    uint32_t* cw = s_big;
+    if (lds_deg) { for (uint32_t w = tid; w < (V + 2) / 2; w += kPugNT) cw[w] = 0; __syncthreads(); }
+    auto cw_add = [&](uint32_t v) -> uint32_t { const uint32_t sh = (v & 1u) * 16u; return (atomicAdd(&cw[v >> 1], 1u << sh) >> sh) & 0xFFFFu; };
     if (n_pairs <= pair_cap) {
         for (uint32_t k0 = tid; k0 < n_pairs; k0 += 4 * kPugNT) {
             uint64_t pr[4];
@@ -1229,7 +1236,10 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                 bool keep = same || cy[j] < 2 * cx[j];
                 if (keep && ky[j] != kx[j]) keep = lab_overlap(vlab(x), vlab(y));
                 const uint64_t dir = fast ? pr[j] & (kPairFwd | kPairBwd) : kPairFwd;
-                if (keep) { if (dir & kPairFwd) atomicAdd(&deg[x], 1u); if (dir & kPairBwd) atomicAdd(&deg[y], 1u); }
+                if (keep) {
+                    if (lds_deg) { if (dir & kPairFwd) (void)cw_add(x); if (dir & kPairBwd) (void)cw_add(y); }
+                    else { if (dir & kPairFwd) atomicAdd(&deg[x], 1u); if (dir & kPairBwd) atomicAdd(&deg[y], 1u); }
+                }
                 pairs[k] = keep ? (dir | ((uint64_t)x << 32) | y) : kNoPair;
             }
         }
@@ -1243,7 +1253,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         const uint32_t x0 = base + 8 * tid;
         uint32_t d[8], sum = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) d[j] = x0 + j < V ? deg[x0 + j] : 0u;
+        for (int j = 0; j < 8; ++j) d[j] = x0 + j < V ? (lds_deg ? (cw[(x0 + j) >> 1] >> (((x0 + j) & 1u) * 16u)) & 0xFFFFu : deg[x0 + j]) : 0u;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const uint32_t t = d[j]; d[j] = sum; sum += t; }
         uint32_t tot;
@@ -1260,7 +1270,29 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     __syncthreads();
     if (s_ebase + E > A.epool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, cell); return; }
     uint32_t* edges = A.epool + s_ebase;
-    if (n_pairs <= pair_cap) {
+    if (lds_deg) {
+        for (uint32_t w = tid; w < (V + 2) / 2; w += kPugNT) cw[w] = 0;   // the counters again, as fill cursors
+        __syncthreads();
+        for (uint32_t k0 = tid; k0 < n_pairs; k0 += 2 * kPugNT) {
+            uint64_t pr[2];
+            uint32_t dx[2], dy[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { const uint32_t k = k0 + j * kPugNT; pr[j] = k < n_pairs ? pairs[k] : ~0ull; }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t x = (uint32_t)(pr[j] >> 32) & vmask, y = (uint32_t)pr[j] & vmask;
+                dx[j] = pr[j] != ~0ull && (pr[j] & kPairFwd) ? deg[x] : 0u;
+                dy[j] = pr[j] != ~0ull && (pr[j] & kPairBwd) ? deg[y] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (pr[j] == ~0ull) continue;
+                const uint32_t x = (uint32_t)(pr[j] >> 32) & vmask, y = (uint32_t)pr[j] & vmask;
+                if (pr[j] & kPairFwd) { edges[dx[j] + cw_add(x)] = y; tch[y] = 1; }
+                if (pr[j] & kPairBwd) { edges[dy[j] + cw_add(y)] = x; tch[x] = 1; }
+            }
+        }
+    } else if (n_pairs <= pair_cap) {
         for (uint32_t k = tid; k < n_pairs; k += kPugNT) {
             const uint64_t pr = pairs[k];
             if (pr != ~0ull) {
