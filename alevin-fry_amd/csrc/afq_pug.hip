@@ -767,13 +767,19 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     __syncthreads();
     {
         uint32_t carry = 0;
-        for (uint32_t base = 0; base < K; base += kPugNT) {
-            const uint32_t r = base + tid;
-            const uint32_t k = r < K ? c_order[r] : 0u;
-            const uint32_t nv = r < K ? c_vstart[k + 1] - c_vstart[k] : 0u;
+        for (uint32_t base = 0; base < K; base += 8 * kPugNT) {   // eight classes per thread and scan, their lookups issued together
+            const uint32_t r0 = base + 8 * tid;
+            uint32_t kk[8], nv[8], sum = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) kk[j] = r0 + j < K ? c_order[r0 + j] : 0u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) nv[j] = r0 + j < K ? c_vstart[kk[j] + 1] - c_vstart[kk[j]] : 0u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const uint32_t t = nv[j]; nv[j] = sum; sum += t; }
             uint32_t tot;
-            const uint32_t ex = block_excl_scan<kPugNT>(nv, s_ws, tot);
-            if (r < K) c_base[k] = carry + ex;
+            const uint32_t ex = block_excl_scan<kPugNT>(sum, s_ws, tot);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (r0 + j < K) c_base[kk[j]] = carry + ex + nv[j];
             carry += tot;
         }
     }
