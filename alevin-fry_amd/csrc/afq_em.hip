@@ -528,7 +528,7 @@ __global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict
                     inv[c] = denom > 0.0f ? (float)cnt[c] / denom : -1.0f;
                 }
             }
-            if (tid == 0) s_flag[0] = 0;
+            if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }   // [1]: next listed entry (the waves draw them as they come free)
             __syncthreads();
             EM2_PH(0);
             // (B) per active entry: single-label count, then class contributions in class order
@@ -562,7 +562,11 @@ __global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict
             }
             EM2_PH(1);
             if (hv_list)
-                for (uint32_t i = tid >> 6; i < NH; i += kEmRNT / 64) {   // the listed entries, a wave each, in turn
+                for (;;) {   // the listed entries, a wave each: drawn from a counter, so a wave that met a long chain takes fewer
+                    uint32_t i = 0;
+                    if (lane_id() == 0) i = atomicAdd(&s_flag[1], 1u);
+                    i = __builtin_amdgcn_readfirstlane(i);
+                    if (i >= NH) break;
                     const uint32_t a = hv[6 * i], hc = hv[6 * i + 1], hs = hv[6 * i + 2];
                     const float old = vin[a];
                     const float ab = (vin[hs & 0xFFFFu] + vin[hs >> 16]) + old;
@@ -696,7 +700,7 @@ __global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict
                     inv[c] = denom > 0.0f ? (float)cn[j] / denom : -1.0f;
                 }
             }
-            if (threadIdx.x == 0) s_flag[0] = 0;
+            if (threadIdx.x == 0) { s_flag[0] = 0; s_flag[1] = 0; }
             __syncthreads();
             // (B) per active entry: single-label count, then class contributions in class order
             bool bad = false;
@@ -748,7 +752,11 @@ __global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict
                 }
             }
             if (hv_list)
-                for (uint32_t i = threadIdx.x >> 6; i < NH; i += kEmRNT / 64) {
+                for (;;) {
+                    uint32_t i = 0;
+                    if (lane_id() == 0) i = atomicAdd(&s_flag[1], 1u);
+                    i = __builtin_amdgcn_readfirstlane(i);
+                    if (i >= NH) break;
                     const uint32_t a = hv[5 * i], hc = hv[5 * i + 1], hs = hv[5 * i + 2];
                     const float old = vin[a];
                     const float ab = (vin[hs & 0xFFFFu] + vin[hs >> 16]) + old;
