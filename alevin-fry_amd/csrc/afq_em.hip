@@ -511,6 +511,21 @@ __global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict
             }
         }
         __syncthreads();
+        if (hv_list && NH <= (uint32_t)kEmRNT) {   // longest chains first: a wave that draws the longest last would hold the barrier alone
+            uint32_t r[5] = {0, 0, 0, 0, 0}, rank = 0;
+            if (tid < NH) {
+#pragma unroll
+                for (int x = 0; x < 5; ++x) r[x] = hv[6 * tid + x];
+                const uint32_t dg = r[4] - r[3];
+                for (uint32_t o = 0; o < NH; ++o) { const uint32_t d2 = hv[6 * o + 4] - hv[6 * o + 3]; rank += d2 > dg || (d2 == dg && o < tid); }
+            }
+            __syncthreads();
+            if (tid < NH) {
+#pragma unroll
+                for (int x = 0; x < 5; ++x) hv[6 * rank + x] = r[x];
+            }
+            __syncthreads();
+        }
         EM2_MARK(1);
         uint32_t it = 0;
         bool conv = true, last_round = false;
