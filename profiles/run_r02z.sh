@@ -6,6 +6,7 @@ cd $ROOT
 mkdir -p gpurun_out
 ( time timeout 1500 python -m pytest tests -m gpu -q ) > gpurun_out/r02z_pytest.log 2>&1
 tail -4 gpurun_out/r02z_pytest.log | head -2
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" > gpurun_out/r02z_smoke.log 2>&1; tail -1 gpurun_out/r02z_smoke.log
 ( time timeout 900 python bench.py ) > gpurun_out/r02z_bench.json 2> gpurun_out/r02z_bench.err
 PASSES="stats sq sq2 fetch write" bash profiles/run_prof.sh r2z --workload configs1 > gpurun_out/r02z_prof.log 2>&1
 PASSES="stats sq sq2 fetch write" bash profiles/run_prof.sh r2z_cfg2 --workload configs2 > gpurun_out/r02z_prof_cfg2.log 2>&1
