@@ -189,9 +189,13 @@ def roofline_of(ktimes, alg_bytes, steps, traffic_ok):
     traffic = None
     pdir = os.path.join(ROOT, "profiles")
     tfiles = sorted(f for f in os.listdir(pdir) if f.endswith("_traffic.json")) if os.path.isdir(pdir) else []
+    if traffic_ok == "configs2":
+        tfiles = [f for f in tfiles if f.endswith("configs2_traffic.json")]
+    elif traffic_ok:
+        tfiles = [f for f in tfiles if "configs" not in f]
     if traffic_ok and tfiles:   # HBM bytes per launch from the committed PMC passes; only meaningful for the workload they were taken on
         kern = json.load(open(os.path.join(pdir, tfiles[-1])))["kernels"]
-        for cand in {"k_decode_par": ("k_decode_recs", "k_decode_keys", "k_decode_par")}.get(name, (name,)):
+        for cand in {"k_decode_par": ("k_decode_recs", "k_decode_keys", "k_decode_par"), "k_em": ("k_em_rounds",)}.get(name, (name,)):
             if cand in kern:
                 traffic = kern[cand]["bytes_per_launch_fetch_doubled"]
                 break
@@ -293,7 +297,9 @@ def run_pbmc(D, args, pkg, sn, usa, resolution, steps, warmup, cpu_seconds, name
         alg = float(st["input_bytes"]) + 8.0 * nnz
         default_wl = (args.cells, args.median_reads, args.sigma, args.genes, args.ref_count, args.popularity, args.umi_err) == \
             (11000, 30000.0, 0.6, 36601, 199138, "zipf1.1", 0.01) and not usa and resolution == "cr-like"
-        roof = roofline_of(ktimes, alg, steps, default_wl)
+        sizes_default = (args.cells, args.median_reads, args.sigma, args.genes, args.ref_count, args.popularity, args.umi_err) == \
+            (11000, 30000.0, 0.6, 36601, 199138, "zipf1.1", 0.01)
+        roof = roofline_of(ktimes, alg, steps, default_wl or ("configs2" if sizes_default and usa and resolution == "parsimony-em" else False))
         cpu = None
         if D.world == 1 and not args.no_cpu_baseline and cpu_seconds > 0:
             cpu = cpu_leg(cfg, rad, res, cpu_seconds, min_cells=min_cells, tie_stats=tie_stats)
