@@ -719,7 +719,10 @@ __global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict
             __syncthreads();
             // (B) per active entry: single-label count, then class contributions in class order
             bool bad = false;
-            for (uint32_t a0 = threadIdx.x; a0 - lane_id() < A; a0 += 4 * kEmRNT) {  // wave-uniform trip count: the heavy-entry sums need every lane
+            // four entries of this thread (a0, a0 + 1024, ...): new abundance in out[j] (ok bit j set) - called with a wave-uniform
+            // a0 - lane: the heavy-entry sums need every lane
+            auto four_entries = [&](uint32_t a0, float (&out)[4]) -> uint32_t {
+                uint32_t okm = 0;
                 uint4 e[4];
                 uint32_t qe[4], m0[4], m1[4];
                 float i0[4], i1[4];
@@ -760,10 +763,40 @@ __global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict
                                                          [&](uint32_t q) { return inv[memb_at(q)]; });
                         if (lane_id() == L) acc = r;
                     }
+                    out[j] = acc;
                     if (valid) {
-                        vout[a] = acc;
+                        okm |= 1u << j;
                         if (acc > kAlphaCheckCutoff && fabsf(old - acc) > kRelDiffTol) bad = true;
                     }
+                }
+                return okm;
+            };
+            // Up to 16 384 entries the new abundances wait for the barrier in registers (sixteen per thread) instead of
+            // going out to global memory and back.
+            const bool nv_regs = A <= 16u * kEmRNT;
+            float nv[16];
+            uint32_t nv_ok = 0;
+            if (nv_regs) {
+    #pragma unroll
+                for (int t = 0; t < 16; ++t) nv[t] = 0.0f;
+                uint32_t trip = 0;
+                for (uint32_t a0 = threadIdx.x; a0 - lane_id() < A; a0 += 4 * kEmRNT, ++trip) {   // (one copy of the body; the trip picks the registers)
+                    float o4[4];
+                    const uint32_t okm = four_entries(a0, o4);
+    #pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (trip == (uint32_t)t) {
+    #pragma unroll
+                            for (int j2 = 0; j2 < 4; ++j2) nv[4 * t + j2] = o4[j2];
+                        }
+                    nv_ok |= okm << (4 * trip);
+                }
+            } else {
+                for (uint32_t a0 = threadIdx.x; a0 - lane_id() < A; a0 += 4 * kEmRNT) {
+                    float o4[4];
+                    const uint32_t okm = four_entries(a0, o4);
+    #pragma unroll
+                    for (int j2 = 0; j2 < 4; ++j2) if ((okm >> j2) & 1u) vout[a0 + j2 * kEmRNT] = o4[j2];
                 }
             }
             if (hv_list)
@@ -782,7 +815,12 @@ __global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict
             if (bad) s_flag[0] = 1;
             __syncthreads();
             conv = s_flag[0] == 0;
-            for (uint32_t a = threadIdx.x; a < A; a += kEmRNT) vin[a] = vout[a];
+            if (nv_regs) {
+    #pragma unroll
+                for (int t = 0; t < 16; ++t) if ((nv_ok >> t) & 1u) vin[threadIdx.x + (uint32_t)(t >> 2) * 4u * kEmRNT + (uint32_t)(t & 3) * kEmRNT] = nv[t];
+                if (hv_list) for (uint32_t i = threadIdx.x; i < NH; i += kEmRNT) vin[hv[5 * i]] = vout[hv[5 * i]];
+            } else
+                for (uint32_t a = threadIdx.x; a < A; a += kEmRNT) vin[a] = vout[a];
             if (threadIdx.x == 0) vin[Z0] = 0.0f;  // inactive entries come out of every round as 0
             ++it;
             __syncthreads();
