@@ -185,7 +185,9 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ byte
             const uint32_t o0 = nk_total + ex;
             if (o0 < m.nrec) {
                 const uint64_t slot = pug.rd_off[cell] + o0;
-                pug.h[slot] = lhash; pug.u[slot] = umi; pug.o[slot] = rec_dw;
+                pug.h[slot] = lhash;
+                if (UW == 4) pug.u[slot] = (umi << 32) | rec_dw;   // a 4-byte UMI travels with the record offset in one word (what the sort keys on)
+                else { pug.u[slot] = umi; pug.o[slot] = rec_dw; }
             } else bad = true;
         } else if (kcnt) {
             const uint32_t o0 = nk_total + ex;
@@ -617,7 +619,8 @@ __global__ __launch_bounds__(256, 6) void k_decode_par(const uint8_t* __restrict
             if (pug_rec) {
                 if (kcnt) {
                     const uint64_t slot = pug.rd_off[cur_cell] + wbase + ex;
-                    pug.h[slot] = lhash; pug.u[slot] = umi; pug.o[slot] = i;
+                    pug.h[slot] = lhash;
+                    if (UWW == 1) pug.u[slot] = (umi << 32) | i; else { pug.u[slot] = umi; pug.o[slot] = i; }
                 }
             } else if (kcnt) {
                 uint64_t* dst = keys0 + m.key_off + wbase + ex;
@@ -1247,7 +1250,8 @@ __global__ __launch_bounds__(256, 8) void k_decode_recs(const uint8_t* __restric
                     if (wbase + totp > m.nrec) fail = true;
                     else if (act) {
                         const uint64_t slot = pug.rd_off[cur_cell] + wbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
-                        pug.h[slot] = lkey; pug.u[slot] = umi; pug.o[slot] = i;
+                        pug.h[slot] = lkey;
+                        if (UWW == 1) pug.u[slot] = (umi << 32) | i; else { pug.u[slot] = umi; pug.o[slot] = i; }
                     }
                 }
                 continue;

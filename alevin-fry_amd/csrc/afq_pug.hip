@@ -78,7 +78,7 @@ __device__ __noinline__ void sample_sort_reads(SortRec* sr, uint32_t* bid, uint3
     auto load = [&](uint32_t i) {
         SortRec r;
         r.h = rd_h[i];
-        r.uo = wide_umi ? (rd_u[i] << kVidBits) | i : (rd_u[i] << 32) | rd_o[i];
+        r.uo = wide_umi ? (rd_u[i] << kVidBits) | i : rd_u[i];   // (4-byte UMIs: the decode already wrote umi << 32 | record offset)
         return r;
     };
     const u128 sentinel = ~(u128)0;
