@@ -1215,7 +1215,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     // the 128 KiB block by now, the components' labels move in afterwards).
     const bool lds_deg = fast && n_pairs <= pair_cap && V <= 65536u;
     uint32_t* cw = s_big;
-    if (lds_deg) { for (uint32_t w = tid; w < (V + 2) / 2; w += kPugNT) cw[w] = 0; __syncthreads(); }
+    if (lds_deg) { for (uint32_t w = tid; w < (V + 1) / 2; w += kPugNT) cw[w] = 0; __syncthreads(); }
     auto cw_add = [&](uint32_t v) -> uint32_t { const uint32_t sh = (v & 1u) * 16u; return (atomicAdd(&cw[v >> 1], 1u << sh) >> sh) & 0xFFFFu; };
     if (n_pairs <= pair_cap) {
         for (uint32_t k0 = tid; k0 < n_pairs; k0 += 4 * kPugNT) {
@@ -1277,7 +1277,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     if (s_ebase + E > A.epool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, cell); return; }
     uint32_t* edges = A.epool + s_ebase;
     if (lds_deg) {
-        for (uint32_t w = tid; w < (V + 2) / 2; w += kPugNT) cw[w] = 0;   // the counters again, as fill cursors
+        for (uint32_t w = tid; w < (V + 1) / 2; w += kPugNT) cw[w] = 0;   // the counters again, as fill cursors
         __syncthreads();
         for (uint32_t k0 = tid; k0 < n_pairs; k0 += 2 * kPugNT) {
             uint64_t pr[2];
