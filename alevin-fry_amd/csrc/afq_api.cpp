@@ -1471,27 +1471,135 @@ int afq_atac_dedup_rad(afq_ctx* c, const uint8_t* bytes, size_t n_bytes, const u
     HIP_TRY(c, hipMemsetAsync(d_status.p, 0, sizeof(DevStatus), s));
     if (hc.on) { HIP_TRY(c, hipStreamSynchronize(s)); hc.lap("atac: alloc + H2D"); }
     for (int i = 0; i < K_COUNT; ++i) { c->k_ms[i] = 0; c->k_launches[i] = 0; }
-    {
-        ScopedTimer t(c, K_ATAC_PARSE, s);
-        AtacParseArgs pa{d_bytes, d_cells.as<AtacCell>(), n_cells, bc_bytes, d_bm.as<uint64_t>(), d_ref.as<uint32_t>(), d_start.as<uint32_t>(),
-                         d_flen.as<uint16_t>(), d_cnt.as<uint32_t>(), d_bc.as<uint64_t>(), d_stat.as<uint32_t>(), d_walk.as<uint32_t>(),
-                         d_nwalk.as<uint32_t>(), d_status.as<DevStatus>(), (uint64_t)n_bytes};
-        launch_atac_parse(s, pa);
-        HIP_TRY(c, hipGetLastError());
-    }
     DevStatus st{};
     std::vector<uint32_t> stat(2ull * n_cells);
     uint64_t* obc = (uint64_t*)std::malloc(8ull * nc1);
     if (!obc) return fail(c, AFQ_ERR_OOM, "afq_atac_dedup_rad: host allocation failed");
-    hipError_t e = hipMemcpyAsync(&st, d_status.p, sizeof(st), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess && n_cells) e = hipMemcpyAsync(stat.data(), d_stat.p, 8ull * n_cells, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess && n_cells) e = hipMemcpyAsync(obc, d_bc.p, 8ull * n_cells, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);   // the caller keeps ownership of `bytes`: the copy out of them is done by now, too
-    if (e != hipSuccess) { std::free(obc); return fail(c, AFQ_ERR_HIP, std::string("afq_atac_dedup_rad: ") + hipGetErrorString(e)); }
-    if (st.err_code) { std::free(obc); return fail(c, AFQ_ERR_BAD_INPUT, "cell " + std::to_string(st.err_cell) + ": chunk nbytes does not match its records"); }
     unsigned long long tally[2] = {0, 0};
-    int rc = atac_dedup_device(c, n_rec, n_cells, d_cnt.as<uint32_t>(), out_cell_ptr, out_ref, out_start, out_frag_len, out_count, hc, tally);
-    if (rc) { std::free(obc); return rc; }
+    auto parse_args = [&](uint32_t c0, uint32_t c1, uint32_t* nwalk, DevStatus* dst) {
+        return AtacParseArgs{d_bytes, d_cells.as<AtacCell>() + c0, c1 - c0, bc_bytes, d_bm.as<uint64_t>(), d_ref.as<uint32_t>(), d_start.as<uint32_t>(),
+                             d_flen.as<uint16_t>(), d_cnt.as<uint32_t>() + c0, d_bc.as<uint64_t>() + c0, d_stat.as<uint32_t>() + 2ull * c0,
+                             d_walk.as<uint32_t>() + c0, nwalk, dst, (uint64_t)n_bytes};
+    };
+    // Big batches go through in four ranges of cells: the distinct fragments of range r cross PCIe (1.8 GB for 2*10^8
+    // records: twice the time of all the kernels) on a second stream while the later ranges are still parsed and sorted.
+    const char* pipe_env = std::getenv("AFQ_ATAC_PIPE_BYTES");   // (tests: pipeline small inputs too)
+    const size_t pipe_min = pipe_env ? (size_t)std::atoll(pipe_env) : ((size_t)128 << 20);
+    const bool piped = n_cells >= 8 && n_bytes >= pipe_min && !std::getenv("AFQ_NO_PIPELINE");
+    bool piped_done = false;
+    if (piped) {
+        constexpr uint32_t kR = 4;
+        uint32_t cut[kR + 1];
+        cut[0] = 0;
+        for (uint32_t r = 1; r < kR; ++r) {
+            const uint64_t target = n_rec * r / kR;
+            cut[r] = (uint32_t)(std::lower_bound(cap_ptr.begin(), cap_ptr.begin() + n_cells, target) - cap_ptr.begin());
+            if (cut[r] < cut[r - 1]) cut[r] = cut[r - 1];
+        }
+        cut[kR] = n_cells;
+        DevBuf &d_scr = c->atac[4], &d_oref = c->atac[5], &d_ostart = c->atac[6], &d_oflen = c->atac[7], &d_ocnt = c->atac[8], &d_on = c->atac[9],
+               &d_optr = c->atac[10], &d_cref = c->atac[11], &d_cstart = c->atac[12], &d_cflen = c->atac[13], &d_ccnt = c->atac[14],
+               &d_flag = c->atac[15], &d_tally = c->atac[24], &d_rstat = c->atac[25];
+        hipError_t e = hipSuccess;
+        auto T = [&](hipError_t x) { if (e == hipSuccess) e = x; };
+        T(d_scr.ensure(16 * n1)); T(d_oref.ensure(4 * n1)); T(d_ostart.ensure(4 * n1)); T(d_oflen.ensure(2 * n1)); T(d_ocnt.ensure(2 * n1));
+        T(d_on.ensure(4ull * nc1)); T(d_optr.ensure(8ull * (n_cells + 1))); T(d_flag.ensure(4)); T(d_tally.ensure(16));
+        T(d_cref.ensure(4 * n1)); T(d_cstart.ensure(4 * n1)); T(d_cflen.ensure(2 * n1)); T(d_ccnt.ensure(2 * n1));   // (sized for "nothing is a duplicate")
+        T(d_rstat.ensure(kR * (sizeof(DevStatus) + 16)));
+        uint32_t* oref = (uint32_t*)pinned_pool()->get(4 * n1);
+        uint32_t* ostart = (uint32_t*)pinned_pool()->get(4 * n1);
+        uint16_t* oflen = (uint16_t*)pinned_pool()->get(2 * n1);
+        uint16_t* ocnt = (uint16_t*)pinned_pool()->get(2 * n1);
+        uint64_t* optr = (uint64_t*)std::malloc(8ull * (n_cells + 1));
+        auto drop = [&]() { std::free(optr); afq_free(oref); afq_free(ostart); afq_free(oflen); afq_free(ocnt); };
+        if (!oref || !ostart || !oflen || !ocnt || !optr) { drop(); std::free(obc); return fail(c, AFQ_ERR_OOM, "afq_atac_dedup_rad: host allocation failed"); }
+        hipStream_t s2 = c->rs[0].stream;
+        DevStatus* d_rst = reinterpret_cast<DevStatus*>(d_rstat.p);
+        uint32_t* d_rnw = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(d_rstat.p) + kR * sizeof(DevStatus));
+        // (the per-range counts and flags land in PINNED memory: an async copy into pageable memory holds the host until the
+        // stream gets there, and the ranges would be enqueued one at a time)
+        uint8_t* pin = (uint8_t*)pinned_pool()->get(4ull * nc1 + kR * (sizeof(DevStatus) + 16));
+        if (!pin) { drop(); std::free(obc); return fail(c, AFQ_ERR_OOM, "afq_atac_dedup_rad: host allocation failed"); }
+        uint32_t* on = reinterpret_cast<uint32_t*>(pin);
+        DevStatus* rst = reinterpret_cast<DevStatus*>(pin + 4ull * nc1);
+        uint32_t* wide = reinterpret_cast<uint32_t*>(pin + 4ull * nc1 + kR * sizeof(DevStatus));
+        hipEvent_t ev[kR];
+        for (auto& x : ev) x = get_event(c);
+        T(hipMemsetAsync(d_flag.p, 0, 4, s));
+        T(hipMemsetAsync(d_tally.p, 0, 16, s));
+        T(hipMemsetAsync(d_rstat.p, 0, kR * (sizeof(DevStatus) + 16), s));
+        for (uint32_t r = 0; r < kR && e == hipSuccess; ++r) {
+            const uint32_t c0 = cut[r], nr = cut[r + 1] - c0;
+            { ScopedTimer t(c, K_ATAC_PARSE, s); launch_atac_parse(s, parse_args(c0, cut[r + 1], d_rnw + r, d_rst + r)); }
+            { ScopedTimer t(c, K_ATAC, s);
+              launch_atac_dedup64(s, nr, d_ref.as<uint32_t>(), d_start.as<uint32_t>(), d_flen.as<uint16_t>(), d_ptr.as<uint64_t>() + c0, d_scr.p,
+                                  d_oref.as<uint32_t>(), d_ostart.as<uint32_t>(), d_oflen.as<uint16_t>(), d_ocnt.as<uint16_t>(), d_on.as<uint32_t>() + c0,
+                                  d_flag.as<uint32_t>(), d_cnt.as<uint32_t>() + c0); }
+            T(hipGetLastError());
+            if (nr) T(hipMemcpyAsync(on + c0, d_on.as<uint32_t>() + c0, 4ull * nr, hipMemcpyDeviceToHost, s));
+            T(hipMemcpyAsync(&wide[r], d_flag.p, 4, hipMemcpyDeviceToHost, s));
+            T(hipMemcpyAsync(&rst[r], d_rst + r, sizeof(DevStatus), hipMemcpyDeviceToHost, s));
+            T(hipEventRecord(ev[r], s));
+        }
+        optr[0] = 0;
+        bool redo = false;
+        int bad_rc = 0;
+        for (uint32_t r = 0; r < kR && e == hipSuccess && !redo && !bad_rc; ++r) {
+            const uint32_t c0 = cut[r], c1 = cut[r + 1];
+            T(hipEventSynchronize(ev[r]));
+            if (e != hipSuccess) break;
+            if (wide[r]) { redo = true; break; }   // a reference id >= 65536: the plain route below runs the 16-byte-record kernel
+            if (rst[r].err_code) { bad_rc = fail(c, AFQ_ERR_BAD_INPUT, "cell " + std::to_string(c0 + rst[r].err_cell) + ": chunk nbytes does not match its records"); break; }
+            st.n_fallback += rst[r].n_fallback;
+            for (uint32_t i = c0; i < c1; ++i) optr[i + 1] = optr[i] + on[i];
+            const uint64_t o0 = optr[c0], tot_r = optr[c1] - o0;
+            T(hipMemcpyAsync(d_optr.as<uint64_t>() + c0, optr + c0, 8ull * (c1 - c0 + 1), hipMemcpyHostToDevice, s2));
+            if (tot_r) {
+                launch_atac_compact(s2, c1 - c0, d_ptr.as<uint64_t>() + c0, d_optr.as<uint64_t>() + c0, d_oref.as<uint32_t>(), d_ostart.as<uint32_t>(),
+                                    d_oflen.as<uint16_t>(), d_ocnt.as<uint16_t>(), d_cref.as<uint32_t>(), d_cstart.as<uint32_t>(),
+                                    d_cflen.as<uint16_t>(), d_ccnt.as<uint16_t>(), d_tally.as<unsigned long long>());
+                T(hipGetLastError());
+                T(hipMemcpyAsync(oref + o0, d_cref.as<uint32_t>() + o0, 4 * tot_r, hipMemcpyDeviceToHost, s2));
+                T(hipMemcpyAsync(ostart + o0, d_cstart.as<uint32_t>() + o0, 4 * tot_r, hipMemcpyDeviceToHost, s2));
+                T(hipMemcpyAsync(oflen + o0, d_cflen.as<uint16_t>() + o0, 2 * tot_r, hipMemcpyDeviceToHost, s2));
+                T(hipMemcpyAsync(ocnt + o0, d_ccnt.as<uint16_t>() + o0, 2 * tot_r, hipMemcpyDeviceToHost, s2));
+            }
+        }
+        if (e == hipSuccess && !redo && !bad_rc) {
+            T(hipMemcpyAsync(tally, d_tally.p, 16, hipMemcpyDeviceToHost, s2));
+            if (n_cells) T(hipMemcpyAsync(stat.data(), d_stat.p, 8ull * n_cells, hipMemcpyDeviceToHost, s2));
+            if (n_cells) T(hipMemcpyAsync(obc, d_bc.p, 8ull * n_cells, hipMemcpyDeviceToHost, s2));
+        }
+        (void)hipStreamSynchronize(s);
+        (void)hipStreamSynchronize(s2);
+        for (auto x : ev) c->event_pool.push_back(x);
+        afq_free(pin);
+        harvest_timers(c);
+        hc.lap("atac: ranges (parse, sort, compact, D2H)");
+        if (e != hipSuccess || bad_rc) {
+            drop(); std::free(obc);
+            return bad_rc ? bad_rc : fail(c, e == hipErrorOutOfMemory ? AFQ_ERR_OOM : AFQ_ERR_HIP, std::string("afq_atac_dedup_rad: ") + hipGetErrorString(e));
+        }
+        if (redo) { drop(); st = DevStatus{}; for (int i = 0; i < K_COUNT; ++i) { c->k_ms[i] = 0; c->k_launches[i] = 0; } }
+        else { *out_cell_ptr = optr; *out_ref = oref; *out_start = ostart; *out_frag_len = oflen; *out_count = ocnt; piped_done = true; }
+    }
+    if (!piped_done) {
+        HIP_TRY(c, hipMemsetAsync(d_nwalk.p, 0, 4, s));
+        HIP_TRY(c, hipMemsetAsync(d_status.p, 0, sizeof(DevStatus), s));
+        {
+            ScopedTimer t(c, K_ATAC_PARSE, s);
+            launch_atac_parse(s, parse_args(0, n_cells, d_nwalk.as<uint32_t>(), d_status.as<DevStatus>()));
+            HIP_TRY(c, hipGetLastError());
+        }
+        hipError_t e = hipMemcpyAsync(&st, d_status.p, sizeof(st), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && n_cells) e = hipMemcpyAsync(stat.data(), d_stat.p, 8ull * n_cells, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && n_cells) e = hipMemcpyAsync(obc, d_bc.p, 8ull * n_cells, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);   // the caller keeps ownership of `bytes`: the copy out of them is done by now, too
+        if (e != hipSuccess) { std::free(obc); return fail(c, AFQ_ERR_HIP, std::string("afq_atac_dedup_rad: ") + hipGetErrorString(e)); }
+        if (st.err_code) { std::free(obc); return fail(c, AFQ_ERR_BAD_INPUT, "cell " + std::to_string(st.err_cell) + ": chunk nbytes does not match its records"); }
+        int rc = atac_dedup_device(c, n_rec, n_cells, d_cnt.as<uint32_t>(), out_cell_ptr, out_ref, out_start, out_frag_len, out_count, hc, tally);
+        if (rc) { std::free(obc); return rc; }
+    }
     *out_bc = obc;
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
