@@ -899,9 +899,12 @@ __global__ __launch_bounds__(kHistNT) void k_cell_hist(const uint32_t* __restric
             const uint32_t nbins = min(kBins16, rc.num_rows - lo), nwords = (nbins + 1) / 2;
             for (uint32_t i = threadIdx.x; i < nwords; i += kHistNT) s_hist[i] = 0;
             __syncthreads();
-            for (uint32_t i = threadIdx.x; i < nc; i += kHistNT) {
-                const uint32_t c = cols[i] - lo;
-                if (c < nbins) atomicAdd(&s_hist[c >> 1], 1u << (16 * (c & 1u)));
+            for (uint32_t i0 = threadIdx.x; i0 < nc; i0 += 4 * kHistNT) {   // four columns per thread and trip, their loads in flight together
+                uint32_t cv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cv[e] = i0 + e * kHistNT < nc ? cols[i0 + e * kHistNT] - lo : 0xFFFFFFFFu;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (cv[e] < nbins) atomicAdd(&s_hist[cv[e] >> 1], 1u << (16 * (cv[e] & 1u)));
             }
             __syncthreads();
             for (uint32_t base = 0; base < nwords; base += kHistNT * 2) {
@@ -925,9 +928,12 @@ __global__ __launch_bounds__(kHistNT) void k_cell_hist(const uint32_t* __restric
         const uint32_t nbins = min(kHistBins, rc.num_rows - lo);
         for (uint32_t i = threadIdx.x; i < nbins; i += kHistNT) s_hist[i] = 0;
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < nc; i += kHistNT) {
-            const uint32_t c = cols[i] - lo;
-            if (c < nbins) atomicAdd(&s_hist[c], 1u);
+        for (uint32_t i0 = threadIdx.x; i0 < nc; i0 += 4 * kHistNT) {
+            uint32_t cv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cv[e] = i0 + e * kHistNT < nc ? cols[i0 + e * kHistNT] - lo : 0xFFFFFFFFu;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (cv[e] < nbins) atomicAdd(&s_hist[cv[e]], 1u);
         }
         __syncthreads();
         for (uint32_t base = 0; base < nbins; base += kHistNT * 4) {
