@@ -882,8 +882,10 @@ __global__ __launch_bounds__(kHistNT) void k_cell_hist(const uint32_t* __restric
                                                       const CellMeta* __restrict__ meta,
                                                       const uint64_t* __restrict__ keys0, uint64_t* __restrict__ keys1,
                                                       const uint32_t* __restrict__ cell_ncols,
-                                                      uint32_t* __restrict__ nnz, ResolveCfg rc) {
-    __shared__ uint32_t s_hist[kHistBins];
+                                                      uint32_t* __restrict__ nnz, ResolveCfg rc, uint32_t hist_words) {
+    // hist_words of LDS (dynamic): as many as one pass over a gene-level matrix needs, at most kHistBins - a 36 601-column
+    // matrix takes 73 KiB, and two workgroups share a CU
+    extern __shared__ uint32_t s_hist[];
     __shared__ uint32_t s_ws[kHistNT / 64];
     const uint32_t cell = multi_cells[blockIdx.x];
     const CellMeta m = meta[cell];
@@ -894,7 +896,7 @@ __global__ __launch_bounds__(kHistNT) void k_cell_hist(const uint32_t* __restric
     if (nc < 65536u) {
         // no column can be counted 65536 times: two 16-bit bins per LDS word, 65536 bins per pass - one pass
         // for a gene-level matrix of up to 65536 columns (half the clearing and scanning of the 32-bit version)
-        constexpr uint32_t kBins16 = 2 * kHistBins;
+        const uint32_t kBins16 = 2 * hist_words;
         for (uint32_t lo = 0; lo < rc.num_rows; lo += kBins16) {
             const uint32_t nbins = min(kBins16, rc.num_rows - lo), nwords = (nbins + 1) / 2;
             for (uint32_t i = threadIdx.x; i < nwords; i += kHistNT) s_hist[i] = 0;
@@ -924,8 +926,8 @@ __global__ __launch_bounds__(kHistNT) void k_cell_hist(const uint32_t* __restric
         if (threadIdx.x == 0) nnz[cell] = carry;
         return;
     }
-    for (uint32_t lo = 0; lo < rc.num_rows; lo += kHistBins) {
-        const uint32_t nbins = min(kHistBins, rc.num_rows - lo);
+    for (uint32_t lo = 0; lo < rc.num_rows; lo += hist_words) {
+        const uint32_t nbins = min(hist_words, rc.num_rows - lo);
         for (uint32_t i = threadIdx.x; i < nbins; i += kHistNT) s_hist[i] = 0;
         __syncthreads();
         for (uint32_t i0 = threadIdx.x; i0 < nc; i0 += 4 * kHistNT) {
@@ -1203,7 +1205,10 @@ void launch_atac_compact(hipStream_t s, uint32_t n_cells, const uint64_t* cell_p
 void launch_cell_hist(hipStream_t s, const ResolveArgs& a) {
     if (!a.n_hist) return;
     ResolveCfg rc = make_rc(a);
-    AFQ_LAUNCH(k_cell_hist, a.n_hist, kHistNT, s, a.hist_cells, a.meta, a.keys0, a.keys1, a.cell_ncols, a.nnz, rc);
+    uint32_t words = (a.num_rows + 1) / 2;
+    words = words < 4096u ? 4096u : (words > kHistBins ? kHistBins : words);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cell_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (int)kHistBins);   // (above 64 KiB needs asking)
+    hipLaunchKernelGGL(k_cell_hist, dim3(a.n_hist), dim3(kHistNT), 4 * words, s, a.hist_cells, a.meta, a.keys0, a.keys1, a.cell_ncols, a.nnz, rc, words);
 }
 
 void launch_compact(hipStream_t s, const CellMeta* meta, uint32_t n_cells, const uint64_t* keys0, const uint64_t* keys1,
