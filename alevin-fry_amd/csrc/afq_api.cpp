@@ -345,7 +345,11 @@ int plan_ranges(afq_ctx* c) {
     // pass 2: cut into ranges.  Big batches are cut into a handful of ranges even when memory
     // would allow one, so that the D2H of one range's rows hides under the kernels of the next.  The ranges taper:
     // the last one's compaction + D2H is the only part nothing hides, so it is the smallest.
-    static const double kTaper[] = {0.28, 0.56, 0.78, 0.92, 1.0};
+    // (parsimony: every range ends in the tail of its persistent workgroups and nothing of the next range can share a CU with
+    // them, while its rows are few - three ranges; cr-like: five, tapering, so that the last D2H is small)
+    static const double kTaperCr[] = {0.28, 0.56, 0.78, 0.92, 1.0}, kTaperPug[] = {0.40, 0.76, 1.0, 1.0, 1.0};
+    const double* kTaper = pug_res ? kTaperPug : kTaperCr;
+    const size_t kTaperN = 5;
     if (pug_fixed > 0.5 * mem_budget) return fail(c, AFQ_ERR_OOM, "the largest parsimony cell's scratch does not fit device memory");
     double budget = mem_budget - pug_fixed - 0.40 * wide_new;   // (the widened copy was allocated after the free-memory query)
     if (budget <= 0) return fail(c, AFQ_ERR_OOM, "the widened copy of the batch leaves no room for the ranges");
@@ -356,10 +360,10 @@ int plan_ranges(afq_ctx* c) {
     uint32_t c0 = 0;
     size_t step = 0;
     for (uint32_t i = 0; i < c->n_cells; ++i) {
-        const bool taper_cut = pipe && step + 1 < sizeof(kTaper) / sizeof(kTaper[0]) && done + used >= kTaper[step] * total_need;
+        const bool taper_cut = pipe && step + 1 < kTaperN && kTaper[step] < 1.0 && done + used >= kTaper[step] * total_need;
         if ((used + need[i] > budget || taper_cut) && i > c0) {
             c->ranges.push_back({c0, i}); c0 = i; done += used; used = 0;
-            while (step + 1 < sizeof(kTaper) / sizeof(kTaper[0]) && done >= kTaper[step] * total_need) ++step;
+            while (step + 1 < kTaperN && done >= kTaper[step] * total_need) ++step;
         }
         used += need[i];
     }
