@@ -56,13 +56,14 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* ws, ui
 typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
 template <int J>
 __device__ __forceinline__ uint32_t xor_lane32(uint32_t x) {
-    if constexpr (J == 1) return __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false);
-    else if constexpr (J == 2) return __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false);
+    // (mov_dpp = update_dpp without an old value: every lane is written, so no copy of x is made in front of the DPP move)
+    if constexpr (J == 1) return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, false);
+    else if constexpr (J == 2) return __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, false);
     else if constexpr (J == 4) {
-        uint32_t t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);   // row_shl:4 into banks 0,2
+        uint32_t t = __builtin_amdgcn_mov_dpp(x, 0x104, 0xF, 0x5, false);        // row_shl:4 into banks 0,2
         return __builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false);          // row_shr:4 into banks 1,3
     } else if constexpr (J == 8) {
-        uint32_t t = __builtin_amdgcn_update_dpp(x, x, 0x108, 0xF, 0x3, false);   // row_shl:8 into banks 0,1
+        uint32_t t = __builtin_amdgcn_mov_dpp(x, 0x108, 0xF, 0x3, false);        // row_shl:8 into banks 0,1
         return __builtin_amdgcn_update_dpp(t, x, 0x118, 0xF, 0xC, false);          // row_shr:8 into banks 2,3
     } else if constexpr (J == 16) {
         const v2u_t p = __builtin_amdgcn_permlane16_swap(x, x, false, false);      // .x = rows {0,0,2,2}, .y = rows {1,1,3,3}
@@ -85,15 +86,74 @@ __device__ __forceinline__ T xor_lane(T v) {   // unsigned integers of 4, 8 or 1
     } else return (T)xor_lane32<J>((uint32_t)v);
 }
 
+// a < b.  For 16-byte keys spelled out on the halves with bitwise connectives, so the three compares meet as lane masks
+// on the scalar unit (the compiler's own lowering of the 128-bit compare builds 0/1 values in vector registers: 8
+// vector instructions where this is 3).
+template <typename T>
+__device__ __forceinline__ bool key_lt(T a, T b) {
+    if constexpr (sizeof(T) == 16) {
+        const uint64_t al = (uint64_t)a, ah = (uint64_t)(a >> 64), bl = (uint64_t)b, bh = (uint64_t)(b >> 64);
+        return (ah < bh) | ((ah == bh) & (al < bl));
+    } else return a < b;
+}
+
+// v_permlane16_swap / v_permlane32_swap between TWO registers: the odd rows (J = 16) / the upper half (J = 32) of x
+// change places with the even rows / the lower half of y.  Applied to elements h and h + 1 of a lane this puts every
+// position and its partner at distance J into the same lane - the exchange at that distance becomes a register swap
+// with no redundant compare (each lane decides a different pair), and the same instruction undoes the move.
+template <int J>
+__device__ __forceinline__ void swap_rows32(uint32_t& x, uint32_t& y) {
+    static_assert(J == 16 || J == 32, "row / half swaps only");
+    v2u_t p;
+    if constexpr (J == 16) p = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+    else p = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    x = p.x; y = p.y;
+}
+template <int J, typename T>
+__device__ __forceinline__ void swap_rows(T& x, T& y) {
+    if constexpr (sizeof(T) == 16) {
+        uint32_t xw[4] = {(uint32_t)x, (uint32_t)(x >> 32), (uint32_t)(x >> 64), (uint32_t)(x >> 96)};
+        uint32_t yw[4] = {(uint32_t)y, (uint32_t)(y >> 32), (uint32_t)(y >> 64), (uint32_t)(y >> 96)};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) swap_rows32<J>(xw[w], yw[w]);
+        x = ((T)(((uint64_t)xw[3] << 32) | xw[2]) << 64) | (T)(((uint64_t)xw[1] << 32) | xw[0]);
+        y = ((T)(((uint64_t)yw[3] << 32) | yw[2]) << 64) | (T)(((uint64_t)yw[1] << 32) | yw[0]);
+    } else if constexpr (sizeof(T) == 8) {
+        uint32_t x0 = (uint32_t)x, x1 = (uint32_t)((uint64_t)x >> 32), y0 = (uint32_t)y, y1 = (uint32_t)((uint64_t)y >> 32);
+        swap_rows32<J>(x0, y0); swap_rows32<J>(x1, y1);
+        x = (T)(((uint64_t)x1 << 32) | x0); y = (T)(((uint64_t)y1 << 32) | y0);
+    } else {
+        uint32_t x0 = (uint32_t)x, y0 = (uint32_t)y;
+        swap_rows32<J>(x0, y0);
+        x = (T)x0; y = (T)y0;
+    }
+}
+
 template <int E, int J, typename T>
 __device__ __forceinline__ void lane_stage(T (&a)[E], uint32_t idx0, uint32_t k) {
-    const bool lower = (idx0 & J) == 0;  // J < 64: a property of the lane only
+    if constexpr (E >= 2 && (J == 16 || J == 32)) {
+        // elements h, h + 1 of a lane trade rows: afterwards the lane holds positions p (bit J clear) and p + J
+        const uint32_t lane = idx0 & 63u, second = (lane & J) ? 1u : 0u;
+        const uint32_t p0 = (idx0 & ~63u) + (lane & ~(uint32_t)J);
 #pragma unroll
-    for (int h = 0; h < E; ++h) {
-        const bool want_min = lower == (((idx0 + h * 64) & k) == 0);
-        const T o = xor_lane<J, T>(a[h]);
-        // keep own value iff it is on the wanted side of the partner's: one compare, one select
-        a[h] = ((a[h] < o) == want_min) ? a[h] : o;
+        for (int h = 0; h < E; h += 2) {
+            T x = a[h], y = a[h + 1];
+            swap_rows<J, T>(x, y);
+            const bool asc = ((p0 + ((uint32_t)h + second) * 64u) & k) == 0;
+            const bool sw = key_lt(y, x) == asc;   // (equal keys - sentinels - may swap: no effect)
+            a[h] = sw ? y : x;
+            a[h + 1] = sw ? x : y;
+            swap_rows<J, T>(a[h], a[h + 1]);
+        }
+    } else {
+        const bool lower = (idx0 & J) == 0;  // J < 64: a property of the lane only
+#pragma unroll
+        for (int h = 0; h < E; ++h) {
+            const bool want_min = lower == (((idx0 + h * 64) & k) == 0);
+            const T o = xor_lane<J, T>(a[h]);
+            // keep own value iff it is on the wanted side of the partner's: one compare, one select
+            a[h] = (key_lt(a[h], o) == want_min) ? a[h] : o;
+        }
     }
 }
 
@@ -104,7 +164,7 @@ __device__ __forceinline__ void reg_stage(T (&a)[E], uint32_t idx0, uint32_t k) 
         if ((h & JH) == 0 && (h | JH) < E) {
             const bool asc = ((idx0 + h * 64) & k) == 0;
             const T x = a[h], y = a[h | JH];
-            const bool sw = asc ? (x > y) : (x < y);
+            const bool sw = key_lt(y, x) == asc;   // one compare for both directions (equal keys may swap: no effect)
             a[h] = sw ? y : x;
             a[h | JH] = sw ? x : y;
         }
@@ -165,8 +225,7 @@ __device__ __forceinline__ void reg_bitonic_sort(T (&a)[E], T* s_x) {
                     const uint32_t idx = wbase + h * 64 + lane;
                     const T o = s_x[idx ^ j];
                     const bool want_min = (((idx & j) == 0) == ((idx & k) == 0));
-                    const T mn = a[h] < o ? a[h] : o, mx = a[h] < o ? o : a[h];
-                    a[h] = want_min ? mn : mx;
+                    a[h] = (key_lt(a[h], o) == want_min) ? a[h] : o;
                 }
             }
         }
