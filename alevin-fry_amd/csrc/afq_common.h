@@ -24,8 +24,13 @@ constexpr uint32_t kBucketTarget = 256;  // planned mean keys per bucket
 constexpr uint32_t kMaxLgNb = 20;
 constexpr uint64_t kHashMul = 0x9E3779B97F4A7C15ull;
 
+// Bucket of a UMI inside its cell: a 32-bit multiplicative hash of the UMI folded to one word (UMIs are <= 44 bits; a
+// 64 x 64-bit product is three quarter-rate multiplies on the vector unit, this is one).  Only the device kernels that
+// place and resolve keys use it, so it can be any function of the UMI alone.
 __host__ __device__ inline uint32_t bucket_of(uint64_t umi, uint32_t lg_nb) {
-    return lg_nb == 0 ? 0u : (uint32_t)((umi * kHashMul) >> (64 - lg_nb));
+    const uint32_t lo = (uint32_t)umi, hi = (uint32_t)(umi >> 32);
+    const uint32_t h = (lo ^ (hi << 19) ^ hi) * 0x9E3779B1u;
+    return lg_nb == 0 ? 0u : h >> (32 - lg_nb);
 }
 
 // Per-cell plan computed on the host from the chunk header.

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void k_scatter(const uint2* __restrict__ tile_
     for (uint32_t b = threadIdx.x; b < nb; b += 256) s_cnt[b] = 0;
     __syncthreads();
     uint64_t key[E];
-    uint32_t rank[E];
+    uint32_t rank[E];   // bucket << 16 | rank of the key among the tile's keys of that bucket (both < 2^11)
 #pragma unroll
     for (uint32_t e = 0; e < E; ++e) {
         const uint32_t i = t0 + e * 256 + threadIdx.x;
@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void k_scatter(const uint2* __restrict__ tile_
         rank[e] = 0;
         if (i < t1) {
             key[e] = src[i];
-            rank[e] = atomicAdd(&s_cnt[bucket_of(key[e] >> kGeneBits, m.lg_nb)], 1u);
+            const uint32_t b = bucket_of(key[e] >> kGeneBits, m.lg_nb);
+            rank[e] = (b << 16) | atomicAdd(&s_cnt[b], 1u);
         }
     }
     __syncthreads();
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256) void k_scatter(const uint2* __restrict__ tile_
 #pragma unroll
     for (uint32_t e = 0; e < E; ++e) {
         const uint32_t i = t0 + e * 256 + threadIdx.x;
-        if (i < t1) s_keys[s_cnt[bucket_of(key[e] >> kGeneBits, m.lg_nb)] + rank[e]] = key[e];
+        if (i < t1) s_keys[s_cnt[rank[e] >> 16] + (rank[e] & 0xFFFFu)] = key[e];
     }
     __syncthreads();
     const uint32_t nt = t1 - t0;
@@ -627,16 +628,19 @@ __device__ __forceinline__ bool resolve_bucket_hash(const uint64_t* __restrict__
                 const uint32_t umi = (uint32_t)u64;
                 const unsigned long long mine = ((unsigned long long)umi << 32) | (gene << 12) | 1u;
                 uint32_t slot = ht_slot(umi, cap);
-                bool done = false;
+                // the probe loop only finds the UMI's slot (one exit: the slot was empty - now claimed - or holds this UMI;
+                // an occupied slot's UMI word is never 0xFFFFFFFF); what the hit means is sorted out after it
+                unsigned long long old;
                 for (;;) {
-                    const unsigned long long old = atomicCAS(&s_slot[slot], kEmpty64, mine);
-                    if (old == kEmpty64) { own_slot[h] = slot; done = true; break; }
-                    if ((uint32_t)(old >> 32) == umi) {
-                        if ((((uint32_t)old) >> 12) == gene) { atomicAdd(&s_slot[slot], 1ull); done = true; }
-                        break;
-                    }
+                    old = atomicCAS(&s_slot[slot], kEmpty64, mine);
+                    const uint32_t ou = (uint32_t)(old >> 32);
+                    if (ou == umi || ou == 0xFFFFFFFFu) break;
                     slot = slot + 1 == cap ? 0u : slot + 1;
                 }
+                bool done = true;
+                if ((uint32_t)(old >> 32) == 0xFFFFFFFFu) own_slot[h] = slot;
+                else if ((((uint32_t)old) >> 12) == gene) atomicAdd(&s_slot[slot], 1ull);
+                else done = false;
                 if (!done) {
                     uint32_t* pr = s_pair + slot * (kHtPairs - 1);
 #pragma unroll
