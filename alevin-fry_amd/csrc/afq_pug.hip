@@ -969,13 +969,32 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
                             uint32_t mf[3];
 #pragma unroll
                             for (int m2 = 0; m2 < 3; ++m2) mf[m2] = fold16(mu[m2]);
-                            uint32_t idx = 0;
-                            for (uint32_t b = lowb; b < L; ++b)
-                                for (uint32_t d = 1; d < 4; ++d, ++idx) {
+                            // vertices this trip really holds (uniform): the unused register slots of a short trip are skipped
+                            const uint32_t mcnt = (n - __builtin_amdgcn_readfirstlane(i0 - tid) + kPugNT - 1) / kPugNT;
+                            // Per base: the three substitutions' filter words of all (up to) three vertices are read together
+                            // - nine LDS reads in flight, not one at a time - and the "upwards only" test is a bit test on the
+                            // base itself: d = 1 raises the UMI iff bit 0 of the base is clear, d = 2, 3 iff bit 1 is.
+                            for (uint32_t b = lowb; b < L; ++b) {
+                                uint32_t fw[3][3], fh[3][3];
+#pragma unroll
+                                for (uint32_t d = 1; d < 4; ++d) {
                                     const uint32_t df = fold16((uint64_t)d << (2 * b));
 #pragma unroll
-                                    for (int m2 = 0; m2 < 3; ++m2) pm[m2] |= (uint64_t)(filt(mf[m2] ^ df) & (uint32_t)((mu[m2] ^ ((uint64_t)d << (2 * b))) > mu[m2])) << idx;   // (upwards only)
+                                    for (int m2 = 0; m2 < 3; ++m2) {
+                                        fh[d - 1][m2] = mf[m2] ^ df;
+                                        fw[d - 1][m2] = (uint32_t)m2 < mcnt ? s_filt[fh[d - 1][m2] >> 5] : 0u;
+                                    }
                                 }
+#pragma unroll
+                                for (int m2 = 0; m2 < 3; ++m2) {
+                                    if ((uint32_t)m2 >= mcnt) continue;
+                                    const uint32_t nbase = ~(uint32_t)(mu[m2] >> (2 * b));   // bit 0 / bit 1 set: that bit of the base is clear
+                                    const uint32_t up1 = nbase & 1u, up23 = (nbase >> 1) & 1u;
+                                    const uint32_t g = ((fw[0][m2] >> (fh[0][m2] & 31u)) & up1) | (((fw[1][m2] >> (fh[1][m2] & 31u)) & up23) << 1) |
+                                                       (((fw[2][m2] >> (fh[2][m2] & 31u)) & up23) << 2);
+                                    pm[m2] |= (uint64_t)g << (3 * (b - lowb));
+                                }
+                            }
 #pragma unroll
                             for (int m2 = 0; m2 < 3; ++m2) {
                                 uint64_t todo = i0 + m2 * kPugNT < n ? pm[m2] : 0ull;
