@@ -28,7 +28,7 @@ namespace afq {
 struct EmCfg {
     uint32_t usa, num_alphas, uo, ao, init_uniform;
 };
-constexpr int kEmNT = 256;
+constexpr int kEmNT = 512;   // threads per cell in k_em (256 and 1024 both measured slower on configs[2]: 178 / 181 vs 177 ms per step)
 constexpr float kMinOutputAlpha = 0.01f, kAlphaCheckCutoff = 1e-2f, kRelDiffTol = 1e-2f;
 constexpr uint32_t kMinIter = 2, kMaxIter = 100;
 
