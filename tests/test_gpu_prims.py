@@ -18,7 +18,11 @@ def build_prims_check():
     if os.path.exists(BIN) and os.path.getmtime(BIN) >= max(os.path.getmtime(SRC), os.path.getmtime(hdr)):
         return
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-o", BIN, SRC], check=True)
+    r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-o", BIN + ".new", SRC], capture_output=True, text=True)
+    if r.returncode == 0:
+        os.replace(BIN + ".new", BIN)
+    elif not os.path.exists(BIN):   # (a binary built by build() that only looks older after a copy of the tree is still the one to run)
+        raise RuntimeError("cannot build tests/prims_check.hip:\n" + r.stderr)
 
 
 @pytest.mark.gpu
