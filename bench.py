@@ -15,7 +15,9 @@ launched under torchrun it just joins as a rank.  Headline line = BASELINE.json 
 nothing on the data path).  The same JSON line carries further legs under "also":
   configs2  configs[2]: USA, parsimony-em on the same cells (N = 1)
   configs3  configs[3]: the ~10^6-cell x 2*10^4-read data set, cells range-sharded over the ranks
-            (each rank generates and quantifies ITS byte-balanced range: 125 000 cells per GPU)
+            (each rank generates and quantifies ITS byte-balanced range: 125 000 cells per GPU; every rank checks a
+            sample of its shard against the oracle)
+  atac      configs[4]: scATAC fragment de-duplication from collated-RAD bytes, 10^4 cells x 2*10^4 records per GPU
   e2e       the crossing included: input starts in pinned host memory (N = 1)
   cli       `afquant quant` wall on the same input written as a collated RAD directory (N = 1)
   reference the real `alevin-fry quant`, only if a binary is on the box ($ALEVIN_FRY_BIN / PATH)
@@ -61,7 +63,8 @@ def parse_args():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="configs3: weak = c3-cells per GPU, strong = c3-cells in total, sharded over the ranks")
     ap.add_argument("--frags-per-cell", type=int, default=20000, help="atac")
-    ap.add_argument("--also", default="auto", help="comma list of extra legs (configs2,configs3,e2e,cli,reference), 'auto' or 'none'")
+    ap.add_argument("--atac-cells", type=int, default=10000, help="atac: cells per GPU (configs[4]: 10^4 x 2*10^4 records)")
+    ap.add_argument("--also", default="auto", help="comma list of extra legs (configs2,configs3,atac,e2e,cli,reference), 'auto' or 'none'")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) by default; gloo + --share-gpu exercises the N>1 logic on a 1-GPU box")
@@ -204,10 +207,11 @@ def roofline_of(ktimes, alg_bytes, steps, traffic_ok):
             "frac": round(achieved / 8000.0, 5), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": lps,
             "alg_bytes_per_step": alg_bytes,
             "path_achieved_GBps": round(alg_bytes / (kernels_ms * 1e-3) / 1e9, 2) if kernels_ms else None,   # all kernels together
+            "frac_path": round(alg_bytes / (kernels_ms * 1e-3) / 1e9 / 8000.0, 5) if kernels_ms else None,    # ... as a fraction of HBM peak: the path's own figure
             "all_kernels_ms_per_step": {k: round(v[0] / steps, 4) for k, v in ktimes.items()}}
 
 
-def cpu_leg(cfg, rad, res, budget_s, min_cells=0, tie_stats=False, tol=None):
+def cpu_leg(cfg, rad, res, budget_s, min_cells=0, tie_stats=False, tol=None, n_threads=None):
     """The oracle (a C++ port, NOT the Rust binary) on a bounded sample of the same cells, one worker thread per host core;
     the sample doubles as a full-size parity check: GPU rows == oracle rows (bit for bit unless tol is given)."""
     import numpy as np
@@ -217,7 +221,7 @@ def cpu_leg(cfg, rad, res, budget_s, min_cells=0, tie_stats=False, tol=None):
 
     ora.lib()
     n = len(rad.cell_nrec)
-    ncores = os.cpu_count() or 1
+    ncores = n_threads or os.cpu_count() or 1
     k = max(1, n // max(64, 4 * ncores, min_cells))   # every k-th cell, so the size mix matches the workload
     done_reads, t_cpu, ncell, start = 0, 0.0, 0, 0
     ties = np.zeros(4, np.int64)
@@ -349,8 +353,19 @@ def run_configs3(D, args, pkg, sn, steps, warmup):
         nnz = int(res.cell_ptr[-1])
         tot_reads, tot_cells, tot_bytes, tot_nnz = D.reduce([rad.n_reads, c1 - c0, st["input_bytes"], nnz], "sum")
         max_bytes = D.reduce([st["input_bytes"]], "max")[0]
+        # parity at the shard's size: the oracle on every k-th cell of THIS rank's shard (each rank checks its own), rows
+        # compared bit for bit; rank 0's timing is the reported cpu_baseline
+        cpu = None
+        if not args.no_cpu_baseline and args.cpu_seconds > 0:
+            cpu = cpu_leg(cfg, rad, res, min(args.cpu_seconds, 8.0), min_cells=500,
+                          n_threads=max(1, (os.cpu_count() or 1) // D.world))
+            if D.world > 1:
+                cpu["sample"] += f"; every one of the {D.world} ranks checked its own shard this way ({cpu['cores']} threads each)"
+        checked = D.reduce([1.0 if cpu else 0.0], "sum")[0]
         if D.rank != 0:
             return None
+        if cpu:
+            cpu["ranks_checked"] = int(checked)
         alg = float(st["input_bytes"]) + 8.0 * nnz
         cfgd = {"workload": f"configs[3]: synthetic 10x-v3 collated RAD, {int(tot_cells)} cells x ~{args.c3_mean_reads:g} reads/cell (log-normal, "
                             f"sigma {sigma:g}, largest first), cr-like, cells range-sharded by bytes over {D.world} GPU(s) "
@@ -360,7 +375,7 @@ def run_configs3(D, args, pkg, sn, steps, warmup):
                 "sharding": f"{D.world} contiguous cell ranges, no data-path collective"}
         return line(D, args, "configs3", tot_reads * steps / elapsed / 1e6, elapsed, steps, warmup, cfgd,
                     {"cells_per_s": round(tot_cells * steps / elapsed, 1), "nnz": int(tot_nnz), "gen_seconds": round(t_gen, 2),
-                     "roofline": roofline_of(ktimes, alg, steps, False), "cpu_baseline": None})
+                     "roofline": roofline_of(ktimes, alg, steps, False), "cpu_baseline": cpu})
     finally:
         q.close()
         rad.free()
@@ -476,7 +491,7 @@ def main():
     if args.workload == "atac":
         return bench_atac(args, pkg, D)
     also = args.also.split(",") if args.also not in ("auto", "none") else \
-        ([] if args.also == "none" else (["configs2", "configs3", "e2e", "cli", "reference"] if D.world == 1 else ["configs3"]))
+        ([] if args.also == "none" else (["configs2", "configs3", "atac", "e2e", "cli", "reference"] if D.world == 1 else ["configs3", "atac"]))
     also = [a for a in also if a and a != args.workload]
     legs = {}
     out = None
@@ -549,6 +564,16 @@ def main():
                 r3 = {"error": f"{type(e).__name__}: {e}"[:300]}
             if D.rank == 0:
                 legs["configs3"] = r3
+        if "atac" in also:
+            r4 = None
+            try:
+                r4 = run_atac(args, pkg, D, max(1, min(3, args.steps)), 1)
+            except Exception as e:
+                if D.world > 1:
+                    raise
+                r4 = {"error": f"{type(e).__name__}: {e}"[:300]}
+            if D.rank == 0:
+                legs["atac"] = r4
         if D.rank == 0 and out is not None:
             if legs:
                 out["also"] = legs
@@ -561,16 +586,16 @@ def main():
         D.close()
 
 
-def bench_atac(args, pkg, D):
+def run_atac(args, pkg, D, steps, warmup):
     """BASELINE configs[4]: scATAC fragment / barcode de-duplication from collated-RAD bytes (afq_atac_dedup_rad): the record
     walk with the na == 1 && type == 4 filter, the per-cell sort and the run-length count all on the device.  The chunk
     bytes are resident in HBM when the timed region starts (uploaded once); a step ends with the distinct fragments on the
-    host.  The kernels' own times come from the library's HIP-event timers."""
+    host.  The kernels' own times come from the library's HIP-event timers.  Returns the leg's JSON object (rank 0)."""
     import numpy as np
 
     sn = importlib.import_module("alevin-fry_amd.synth_native")
     torch = D.torch
-    n_cells = args.cells if args.cells != 11000 else 10000
+    n_cells = args.atac_cells
     per = args.frags_per_cell
     t0 = time.time()
     data, off = sn.generate_atac(seed=5 + D.rank, n_cells=n_cells, frags_per_cell=per)
@@ -586,28 +611,31 @@ def bench_atac(args, pkg, D):
         res = None   # (the previous step's arrays go back to the library's pinned pool)
         res = q.atac_dedup_rad(None, off, d_ptr=d_bytes.data_ptr(), n_bytes=len(data), copy=False)
 
-    for _ in range(args.warmup):
-        step()
-    D.sync()
-    t0 = time.perf_counter()
-    kt = {}
-    for _ in range(args.steps):
-        step()
-        for k, (ms, nl) in q.kernel_times().items():
-            a = kt.setdefault(k, [0.0, 0])
-            a[0] += ms
-            a[1] += nl
-    torch.cuda.synchronize(D.dev)
-    elapsed = time.perf_counter() - t0
-    if D.dist:
-        D.dist.barrier()
-    elapsed = D.reduce([elapsed], "max")[0]
-    total = D.reduce([float(n)], "sum")[0]
-    if D.rank == 0:
+    try:
+        for _ in range(warmup):
+            step()
+        D.sync()
+        t0 = time.perf_counter()
+        kt = {}
+        for _ in range(steps):
+            step()
+            for k, (ms, nl) in q.kernel_times().items():
+                a = kt.setdefault(k, [0.0, 0])
+                a[0] += ms
+                a[1] += nl
+        torch.cuda.synchronize(D.dev)
+        elapsed = time.perf_counter() - t0
+        if D.dist:
+            D.dist.barrier()
+        elapsed = D.reduce([elapsed], "max")[0]
+        total = D.reduce([float(n)], "sum")[0]
+        if D.rank != 0:
+            return None
         distinct = int(res[0][-1])
         alg = float(len(data)) + 12.0 * distinct   # every record byte once; (ref, start, len, count) per distinct fragment out
         name, (ms_tot, launches) = max(kt.items(), key=lambda kv: kv[1][0])
         avg_ms = ms_tot / max(1, launches)
+        kernels_ms = sum(v[0] for v in kt.values()) / steps
         cpu = None
         if D.world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -622,10 +650,10 @@ def bench_atac(args, pkg, D):
                 np.array_equal(want[5], res[5][: int(want[0][-1])]), "GPU/oracle mismatch"
             cpu = {"value": round(k * per / tc / 1e6, 3), "unit": "M fragments/s", "cores": 1, "kind": "port",
                    "sample": f"first {k} cells ({k * per} records), {tc:.1f} s, single-thread C++ restatement (oracle/); its fragments compared with the GPU's"}
-        print(json.dumps({
-            "metric": "M fragments/s through atac dedup (fragment/barcode dedup path)", "value": round(total * args.steps / elapsed / 1e6, 3),
-            "unit": "M fragments/s", "n_gpus": D.world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        return {
+            "metric": "M fragments/s through atac dedup (fragment/barcode dedup path)", "value": round(total * steps / elapsed / 1e6, 3),
+            "unit": "M fragments/s", "n_gpus": D.world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(1e3 * elapsed / steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"configs[4]: scATAC dedup from collated-RAD bytes, per GPU: {n_cells} cells x {per} records (20 % exact duplicates, "
                                    f"5 % multi-mapped, 5 % unmapped, 25 chromosomes); bytes resident in HBM, distinct fragments back on the host",
@@ -633,9 +661,21 @@ def bench_atac(args, pkg, D):
             "gen_seconds": round(t_gen, 1),
             "roofline": {"bound": "hbm", "kernel": name, "achieved": round(alg / (avg_ms * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(alg / (avg_ms * 1e-3) / 1e9 / 8000.0, 5), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
-                         "alg_bytes_per_step": alg, "all_kernels_ms_per_step": {k2: round(v[0] / args.steps, 4) for k2, v in kt.items()}},
-            "cpu_baseline": cpu}), flush=True)
-    q.close()
+                         "launches_per_step": launches / steps, "alg_bytes_per_step": alg,
+                         "path_achieved_GBps": round(alg / (kernels_ms * 1e-3) / 1e9, 2) if kernels_ms else None,
+                         "frac_path": round(alg / (kernels_ms * 1e-3) / 1e9 / 8000.0, 5) if kernels_ms else None,
+                         "all_kernels_ms_per_step": {k2: round(v[0] / steps, 4) for k2, v in kt.items()}},
+            "cpu_baseline": cpu}
+    finally:
+        res = None
+        q.close()
+        del d_bytes
+
+
+def bench_atac(args, pkg, D):
+    out = run_atac(args, pkg, D, args.steps, args.warmup)
+    if D.rank == 0:
+        print(json.dumps(out), flush=True)
     D.close()
 
 
