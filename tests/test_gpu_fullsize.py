@@ -137,3 +137,52 @@ def test_crlike_em_on_the_largest_cells_against_the_oracle(big_pug, oracle):
     want = oracle.quant(cfg, rad.tid_to_gid, rad.data, rad.chunk_off[idx], n_threads=8)
     assert (np.diff(got.cell_ptr.astype(np.int64)) > 0).all()
     assert_same_result(got, want)
+
+
+def test_configs3_shard_sample_against_oracle(oracle):
+    """BASELINE configs[3] at the size one GPU holds of it: 125 000 cells x ~2*10^4 reads (2.5 G reads, 43.7 GB) generated
+    in HBM exactly as bench.py's configs3 leg does, cr-like.  >= 500 cells spread over the shard bit-exact against the
+    oracle, and the shard cut in two by shard.shard_ranges and quantified by two contexts == the one-context rows
+    (cells are independent: src/quant.rs:880, 937, 967)."""
+    import importlib
+    import os
+
+    shard = importlib.import_module("alevin-fry_amd.shard")
+    n = 125000
+    sigma = 0.6
+    p = sn.params(seed=4, n_cells=n, median_reads=20000.0 / float(np.exp(sigma * sigma / 2)), sigma=sigma, num_genes=36601, ref_count=199138)
+    sizes = sn.cell_sizes(p)
+    rad = sn.generate_device(device=0, p=p, sizes=sizes, cell_range=(0, n))
+    cfg = pkg.WorkerConfig.for_resolution("cr-like", num_genes=rad.num_genes, num_rows=rad.num_rows, umi_len=12)
+    q = pkg.Quantifier(cfg, rad.tid_to_gid)
+    q2 = None
+    try:
+        q.submit_device(rad.d_ptr, rad.n_bytes, rad.chunk_off, 0)
+        whole = q.collect()
+        assert whole.n_cells == n and np.array_equal(whole.nrec, rad.cell_nrec)
+        idx = np.arange(11, n, 211)                      # 593 cells over the whole size range (largest first)
+        assert len(idx) >= 500
+        data, offs = rad.read_cells(idx)
+        want = oracle.quant(cfg, rad.tid_to_gid, data, offs, n_threads=os.cpu_count() or 8)
+        for j, ci in enumerate(idx):
+            g0, v0 = whole.row(int(ci))
+            g1, v1 = want.row(j)
+            assert np.array_equal(g0, g1) and np.array_equal(v0.view(np.uint32), v1.view(np.uint32)), f"cell {ci} differs from the oracle"
+        # two contexts over the byte-balanced halves == one context
+        (a0, a1), (b0, b1) = shard.shard_ranges(rad.chunk_nbytes(), 2)
+        assert a0 == 0 and a1 == b0 and b1 == n and 0 < a1 < n
+        digest_whole = _digest(whole)
+        whole = None
+        q2 = pkg.Quantifier(cfg, rad.tid_to_gid)
+        parts = []
+        for qq, (c0, c1) in ((q, (a0, a1)), (q2, (b0, b1))):
+            base = int(rad.chunk_off[c0])
+            end = int(rad.chunk_off[c1]) if c1 < n else rad.n_bytes
+            qq.submit_device(rad.d_ptr + base, end - base, rad.chunk_off[c0:c1] - np.uint64(base), c0)
+            parts.append(qq.collect())
+        assert _digest(shard.concat_results(parts)) == digest_whole
+    finally:
+        q.close()
+        if q2 is not None:
+            q2.close()
+        rad.free()
