@@ -56,9 +56,10 @@ struct DevBuf {
     template <class T> T* as() { return reinterpret_cast<T*>(p); }
 };
 
-enum KernelId { K_GATHER = 0, K_DECODE_PAR, K_DECODE, K_HIST, K_BSCAN, K_SCATTER, K_RESOLVE, K_RESOLVE_BIG, K_PUG, K_CELL_HIST, K_EM, K_BOOT, K_COMPACT, K_ATAC, K_ATAC_PARSE, K_FIX_SLABS, K_COUNT };
+enum KernelId { K_GATHER = 0, K_DECODE_PAR, K_DECODE, K_HIST, K_BSCAN, K_SCATTER, K_RESOLVE, K_RESOLVE_BIG, K_PUG, K_CELL_HIST, K_EM, K_BOOT, K_COMPACT, K_ATAC, K_ATAC_PARSE, K_FIX_SLABS, K_P2_SPLIT, K_P2_PART, K_P2_SEARCH, K_P2_LONE, K_P2_GRAPH, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"k_gather_headers", "k_decode_par", "k_decode", "k_hist", "k_bucket_scan", "k_scatter",
-                                           "k_resolve", "k_resolve_big", "k_pug_cell", "k_cell_hist", "k_em", "k_boot", "k_compact", "k_atac_dedup", "k_atac_parse", "k_fix_slabs"};
+                                           "k_resolve", "k_resolve_big", "k_pug_cell", "k_cell_hist", "k_em", "k_boot", "k_compact", "k_atac_dedup", "k_atac_parse", "k_fix_slabs",
+                                           "k_p2_split", "k_p2_part", "k_p2_search", "k_p2_lone", "k_p2_graph"};
 
 struct TimedLaunch { int id; hipEvent_t a, b; };
 
@@ -144,7 +145,7 @@ struct RangeState {
         d_nnz, d_ovf, d_status, d_bc, d_cell_ptr, d_gene, d_val, d_chk, d_slab_prefix, d_slab_cell, d_cell_bc, d_bdesc, d_lab,
         d_lab_cnt, d_em_off, d_em_scratch, d_em_nnz, d_pug_cells, d_rd_off, d_rd_h, d_rd_u, d_rd_o, d_pug_scr_off,
         d_pug_scratch, d_epool, d_epool_cur, d_alt, d_hist_cells, d_fix, d_em_hdr, d_em_order, d_eq_ncls, d_eq_nw, d_eq_cptr,
-        d_eq_wptr, d_eq_len, d_eq_cnt, d_eq_lab, d_bt_off, d_bt_scratch, d_bt_ns, d_bt_col, d_bt_mean, d_bt_var, d_bt_sptr, d_bt_ccol,
+        d_p2_small, d_eq_wptr, d_eq_len, d_eq_cnt, d_eq_lab, d_bt_off, d_bt_scratch, d_bt_ns, d_bt_col, d_bt_mean, d_bt_var, d_bt_sptr, d_bt_ccol,
         d_bt_cmean, d_bt_cvar;
     ResolveArgs last_ra{};
     std::vector<CellMeta> meta;
@@ -157,7 +158,7 @@ struct RangeState {
         return {&d_meta, &d_keys0, &d_keys1, &d_cell_nkeys, &d_bucket_cnt, &d_bucket_cell, &d_multi_cells, &d_tile_desc, &d_src_off, &d_slab_ovf,
                 &d_ncols, &d_nnz, &d_ovf, &d_status, &d_bc, &d_cell_ptr, &d_gene, &d_val, &d_chk, &d_slab_prefix, &d_slab_cell,
                 &d_cell_bc, &d_bdesc, &d_lab, &d_lab_cnt, &d_em_off, &d_em_scratch, &d_em_nnz, &d_pug_cells, &d_rd_off, &d_rd_h,
-                &d_rd_u, &d_rd_o, &d_pug_scr_off, &d_pug_scratch, &d_epool, &d_epool_cur, &d_alt, &d_hist_cells, &d_fix, &d_em_hdr, &d_em_order,
+                &d_rd_u, &d_rd_o, &d_pug_scr_off, &d_pug_scratch, &d_epool, &d_epool_cur, &d_p2_small, &d_alt, &d_hist_cells, &d_fix, &d_em_hdr, &d_em_order,
                 &d_eq_ncls, &d_eq_nw, &d_eq_cptr, &d_eq_wptr, &d_eq_len, &d_eq_cnt, &d_eq_lab, &d_bt_off, &d_bt_scratch, &d_bt_ns, &d_bt_col,
                 &d_bt_mean, &d_bt_var, &d_bt_sptr, &d_bt_ccol, &d_bt_cmean, &d_bt_cvar};
     }
@@ -284,6 +285,27 @@ int check_supported(afq_ctx* c) {
     if (g.umi_len > 4 * g.umi_bytes) return fail(c, AFQ_ERR_INVALID_ARG, "umi_len does not fit the UMI field");
     return 0;
 }
+
+// Layout of RangeState::d_p2_small (u32 words), the per-cell / per-partition / per-tile arrays of the phase-kernel parsimony
+// path: a region that starts zeroed, the arrays the kernels fill, and a region uploaded from the host in one copy.
+struct P2Small {
+    uint64_t pcnt, pair_n, gcnt, fb, ctr, zero_words;          // zeroed: partition counts, per-cell pair counts / counters / flags, work counter
+    uint64_t poff, pcur, pnv, pcell;                           // filled on the device
+    uint64_t up, fb_count, fb_list, order, cells, tiles, up_words, words;   // uploaded
+};
+P2Small p2_small_layout(uint64_t n, uint64_t parts, uint64_t tiles, uint64_t n_pug) {
+    P2Small L{};
+    uint64_t o = 0;
+    L.pcnt = o; o += parts; L.pair_n = o; o += n; L.gcnt = o; o += 4 * n; L.fb = o; o += n; L.ctr = o; o += 8;
+    L.zero_words = o;
+    L.poff = o; o += parts; L.pcur = o; o += parts; L.pnv = o; o += parts; L.pcell = o; o += parts;
+    o = (o + 3) & ~3ull;
+    L.up = o; L.fb_count = o; o += 4; L.fb_list = o; o += n_pug; L.order = o; o += n; o = (o + 3) & ~3ull;
+    L.cells = o; o += n * (sizeof(P2Cell) / 4); L.tiles = o; o += 2 * tiles;
+    L.up_words = o - L.up; L.words = o;
+    return L;
+}
+uint64_t p2_small_bytes(uint64_t n, uint64_t parts, uint64_t tiles, uint64_t n_pug) { return 4 * p2_small_layout(n, parts, tiles, n_pug).words + 64; }
 
 // Split the batch into ranges of cells that fit the memory budget, build nothing yet.
 int plan_ranges(afq_ctx* c) {
@@ -480,6 +502,34 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
     // largest cells first: the persistent workgroups take them in list order, so the long ones do not end up as the tail
     std::stable_sort(pug_cells.begin(), pug_cells.end(), [&](uint32_t a, uint32_t b) { return B.meta[a].nrec > B.meta[b].nrec; });
     if (n_pug && !par) return fail(c, AFQ_ERR_UNSUPPORTED, "device parsimony needs dword-aligned chunk offsets");
+    // Parsimony cells go through the phase kernels of afq_pug2.hip (partition-parallel) unless their labels are
+    // gene-level, their UMI field is wider than 4 bytes or they hold 2^20 reads or more: those - and the cells the phase kernels
+    // hand back - are resolved by the one-workgroup kernel of afq_pug.hip.  AFQ_PUG_ROUTE=mono sends every cell there (tests).
+    std::vector<P2Cell> p2cells;
+    std::vector<uint2> p2tiles;
+    std::vector<uint32_t> p2_up;
+    std::vector<uint32_t> mono_cells;
+    uint64_t p2_parts = 0, p2_pairs = 0;
+    {
+        const char* route = std::getenv("AFQ_PUG_ROUTE");
+        const bool p2_ok = n_pug && g.umi_bytes == 4 && !(g.resolution == AFQ_RES_PARSIMONY_GENE || g.resolution == AFQ_RES_PARSIMONY_GENE_EM) &&
+                           !(route && !std::strcmp(route, "mono"));
+        for (uint32_t ci : pug_cells) {   // (largest first)
+            const CellMeta& m = B.meta[ci];
+            if (!p2_ok || m.nrec >= (1u << 20)) { mono_cells.push_back(ci); continue; }
+            P2Cell pc{};
+            pc.rd_base = rd_off[ci]; pc.pair_base = p2_pairs; pc.cell = ci; pc.R = m.nrec;
+            uint32_t lg = 0;
+            while (((m.nrec + (1u << lg) - 1) >> lg) > kP2PartTarget) ++lg;
+            pc.lgP = lg; pc.part_base = (uint32_t)p2_parts; pc.pair_cap = m.nrec / 2 + 64;
+            p2_parts += 1ull << lg; p2_pairs += pc.pair_cap;
+            const uint32_t j = (uint32_t)p2cells.size();
+            for (uint32_t t = 0; t * kP2TileHost < m.nrec; ++t) p2tiles.push_back(make_uint2(j, t));
+            p2cells.push_back(pc);
+        }
+        if (p2_parts >= 0xFFFFFFF0ull) return fail(c, AFQ_ERR_UNSUPPORTED, "batch too large for 32-bit partition ids");
+    }
+    const uint32_t n_p2 = (uint32_t)p2cells.size();
     hist_cells = multi;
     hist_cells.insert(hist_cells.end(), pug_cells.begin(), pug_cells.end());
     const uint64_t epool_words = 24 * n_pug_reads + (1ull << 22);
@@ -493,6 +543,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
         HIP_TRY(c, B.d_pug_scratch.ensure(4 * pug_words * n_pug_blocks + 64));
         HIP_TRY(c, B.d_epool.ensure(4 * epool_words));
         HIP_TRY(c, B.d_epool_cur.ensure(8));
+        HIP_TRY(c, B.d_p2_small.ensure(p2_small_bytes(n_p2, p2_parts, p2tiles.size(), n_pug)));
     }
     HIP_TRY(c, B.d_alt.ensure(4ull * n));
     HIP_TRY(c, B.d_hist_cells.ensure(4ull * std::max<size_t>(hist_cells.size(), 1)));
@@ -536,6 +587,16 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
         HIP_TRY(c, hipMemcpyAsync(B.d_rd_off.p, rd_off.data(), 8ull * n, hipMemcpyHostToDevice, s));
         HIP_TRY(c, hipMemsetAsync(B.d_pug_scr_off.p, 0, 8, s));
         HIP_TRY(c, hipMemsetAsync(B.d_epool_cur.p, 0, 8, s));
+        const P2Small L = p2_small_layout(n_p2, p2_parts, p2tiles.size(), n_pug);
+        HIP_TRY(c, hipMemsetAsync(B.d_p2_small.p, 0, 4 * L.zero_words, s));
+        p2_up.assign(L.up_words, 0);
+        uint32_t* up = p2_up.data() - L.up;
+        up[L.fb_count] = (uint32_t)mono_cells.size();   // the one-workgroup kernel's list starts with the cells that go there directly
+        std::copy(mono_cells.begin(), mono_cells.end(), up + L.fb_list);
+        for (uint32_t j = 0; j < n_p2; ++j) up[L.order + j] = j;   // (p2cells is largest first already)
+        if (n_p2) std::memcpy(up + L.cells, p2cells.data(), sizeof(P2Cell) * n_p2);
+        if (!p2tiles.empty()) std::memcpy(up + L.tiles, p2tiles.data(), sizeof(uint2) * p2tiles.size());
+        HIP_TRY(c, hipMemcpyAsync(B.d_p2_small.as<uint32_t>() + L.up, p2_up.data(), 4 * L.up_words, hipMemcpyHostToDevice, s));
     }
     HIP_TRY(c, hipMemsetAsync(B.d_status.p, 0, sizeof(DevStatus), s));
     HIP_TRY(c, hipMemsetAsync(B.d_bc.p, 0, 8ull * n, s));
@@ -596,10 +657,52 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
     { ScopedTimer t(c, K_RESOLVE, s, &B.launches); launch_resolve(s, ra); }
     if (n_multi) { ScopedTimer t(c, K_RESOLVE_BIG, s, &B.launches); launch_resolve_big(s, ra); }
     if (n_pug) {
+        const P2Small L = p2_small_layout(n_p2, p2_parts, p2tiles.size(), n_pug);
+        uint32_t* sm = B.d_p2_small.as<uint32_t>();
+        // the big per-read arrays of the phase kernels come out of the edge pool's allocation (24 words per read): key and
+        // UMI words, pair lists, offsets, local ids, flags; what is left is the pool both paths draw their per-cell scratch from
+        uint32_t* ep = B.d_epool.as<uint32_t>();
+        uint64_t eo = 0;
+        P2Args p2{};
+        if (n_p2) {
+            p2.s_h = reinterpret_cast<uint64_t*>(ep + eo); eo += 2 * n_pug_reads;
+            p2.s_u = reinterpret_cast<uint64_t*>(ep + eo); eo += 2 * n_pug_reads;
+            p2.pairs = reinterpret_cast<uint64_t*>(ep + eo); eo += 2 * p2_pairs;
+            p2.v_off = ep + eo; eo += n_pug_reads;
+            p2.lidx = ep + eo; eo += n_pug_reads;
+            p2.v_flag = reinterpret_cast<uint8_t*>(ep + eo); eo += n_pug_reads / 4 + 1;
+            eo = (eo + 3) & ~3ull;
+        }
+        if (eo + (1ull << 20) > epool_words) return fail(c, AFQ_ERR_OOM, "parsimony work arrays do not fit the edge pool");
+        uint32_t* const pool = ep + eo;
+        const unsigned long long pool_cap = epool_words - eo;
+        if (n_p2) {
+            p2.bytes = in_bytes; p2.meta = ra.meta; p2.cells = reinterpret_cast<const P2Cell*>(sm + L.cells);
+            p2.tiles = reinterpret_cast<const uint2*>(sm + L.tiles); p2.order = sm + L.order;
+            p2.rd_h = da.pug.h; p2.rd_u = da.pug.u;
+            p2.pcnt = sm + L.pcnt; p2.poff = sm + L.poff; p2.pcur = sm + L.pcur; p2.pnv = sm + L.pnv; p2.pcell = sm + L.pcell;
+            p2.pair_n = sm + L.pair_n; p2.gcnt = sm + L.gcnt; p2.fb = sm + L.fb; p2.fb_list = sm + L.fb_list; p2.fb_count = sm + L.fb_count;
+            p2.pool = pool; p2.pool_cur = B.d_epool_cur.as<unsigned long long>(); p2.pool_cap = pool_cap;
+            p2.work_counter = sm + L.ctr;
+            p2.cell_nkeys = ra.cell_nkeys; p2.t2g = c->d_t2g.as<uint32_t>(); p2.keys0 = ra.keys0; p2.cell_ncols = ra.cell_ncols;
+            p2.lab = ra.lab; p2.lab_cnt = ra.lab_cnt; p2.st = ra.st;
+            p2.n_cells = n_p2; p2.n_tiles = (uint32_t)p2tiles.size(); p2.n_parts = (uint32_t)p2_parts;
+            p2.part_cap = kP2PartCap;
+            if (const char* e = std::getenv("AFQ_P2_PART_CAP")) p2.part_cap = (uint32_t)std::max(1, std::atoi(e));   // tests: force cells back to the one-workgroup kernel
+            p2.ref_count = c->ref_count; p2.num_genes = g.num_genes; p2.usa = g.usa_mode; p2.num_rows = g.num_rows; p2.em = em ? 1u : 0u;
+            p2.exact_umi = g.pug_exact_umi; p2.large_thresh = g.large_graph_thresh; p2.hw = 1 + g.bc_bytes / 4 + g.umi_bytes / 4;
+            p2.umi_pairs = std::min<uint32_t>(g.umi_len ? g.umi_len : g.umi_bytes * 4, 16);
+            { ScopedTimer t(c, K_P2_SPLIT, s, &B.launches); launch_p2_split(s, p2); }
+            { ScopedTimer t(c, K_P2_PART, s, &B.launches); launch_p2_part(s, p2); }
+            { ScopedTimer t(c, K_P2_SEARCH, s, &B.launches); launch_p2_search(s, p2); }
+            { ScopedTimer t(c, K_P2_LONE, s, &B.launches); launch_p2_lone(s, p2); }
+            { ScopedTimer t(c, K_P2_GRAPH, s, &B.launches); launch_p2_graph(s, p2); }
+        }
         PugCellArgs pa{};
-        pa.bytes = in_bytes; pa.meta = ra.meta; pa.pug_cells = B.d_pug_cells.as<uint32_t>(); pa.cell_nkeys = ra.cell_nkeys;
+        pa.bytes = in_bytes; pa.meta = ra.meta; pa.pug_cells = sm + L.fb_list; pa.cell_nkeys = ra.cell_nkeys;
+        pa.n_pug_dev = sm + L.fb_count;
         pa.rd = da.pug; pa.scr_stride = pug_words; pa.scratch = B.d_pug_scratch.as<uint32_t>(); pa.work_counter = B.d_pug_scr_off.as<uint32_t>(); pa.n_pug = n_pug;
-        pa.epool = B.d_epool.as<uint32_t>(); pa.epool_cursor = B.d_epool_cur.as<unsigned long long>(); pa.epool_cap = epool_words;
+        pa.epool = pool; pa.epool_cursor = B.d_epool_cur.as<unsigned long long>(); pa.epool_cap = pool_cap;
         pa.t2g = c->d_t2g.as<uint32_t>(); pa.keys0 = ra.keys0; pa.cell_ncols = ra.cell_ncols; pa.lab = ra.lab; pa.lab_cnt = ra.lab_cnt;
         pa.alt = B.d_alt.as<uint32_t>(); pa.st = ra.st; pa.ref_count = c->ref_count; pa.num_genes = g.num_genes; pa.usa = g.usa_mode;
         pa.num_rows = g.num_rows; pa.em = em ? 1u : 0u; pa.exact_umi = g.pug_exact_umi; pa.large_thresh = g.large_graph_thresh; pa.umi32 = g.umi_bytes == 4 ? 1u : 0u;

@@ -147,9 +147,46 @@ struct PugCellArgs {
     uint32_t ref_count, num_genes, usa, num_rows, em, exact_umi, large_thresh, hw, umi_pairs, gene_level;
     uint32_t umi32;               // the record's UMI field is 4 bytes: UMI and record offset share one sort word
     uint32_t force_global_route;  // tests: neighbour search through the global-memory hash table for every cell
+    const uint32_t* n_pug_dev;    // when set: the length of pug_cells lives on the device (cells the phase kernels of afq_pug2.hip handed over)
 };
 
 void launch_pug(hipStream_t s, const PugCellArgs& a, uint32_t n_blocks);
+
+// ---- parsimony as phase kernels over UMI partitions (afq_pug2.hip) ----
+struct P2Cell {
+    uint64_t rd_base;     // the cell's first read slot: rd_h / rd_u / s_h / s_u / v_off / v_flag / lidx share the indexing
+    uint64_t pair_base;   // first slot of the cell's pair list
+    uint32_t cell;        // index into meta[]
+    uint32_t R;           // reads
+    uint32_t lgP;         // log2 of the partition count (partition = low lgP bits of the UMI)
+    uint32_t part_base;   // first partition of the cell in the per-partition arrays
+    uint32_t pair_cap;
+    uint32_t pad;
+};
+struct P2Args {
+    const uint8_t* bytes; const CellMeta* meta; const P2Cell* cells; const uint2* tiles; const uint32_t* order;
+    const uint64_t* rd_h; const uint64_t* rd_u;        // the decode's reads: label key, umi << 32 | record offset
+    uint64_t* s_h; uint64_t* s_u;                      // reads grouped by partition, then the vertices (key; umi << 32 | word)
+    uint32_t* v_off; uint8_t* v_flag; uint32_t* lidx;  // vertex: smallest record offset, has-an-edge flag, id among the touched
+    uint32_t* pcnt; uint32_t* poff; uint32_t* pcur; uint32_t* pnv; uint32_t* pcell;   // per partition
+    uint64_t* pairs; uint32_t* pair_n;                 // per cell: vertex pairs with an edge
+    uint32_t* gcnt;                                    // per cell [4]: columns, label words, classes, error
+    uint32_t* fb; uint32_t* fb_list; uint32_t* fb_count;   // cells handed to the one-workgroup kernel
+    uint32_t* pool; unsigned long long* pool_cur; unsigned long long pool_cap;
+    uint32_t* work_counter;
+    const uint32_t* cell_nkeys; const uint32_t* t2g; uint64_t* keys0; uint32_t* cell_ncols; uint32_t* lab; uint32_t* lab_cnt;
+    DevStatus* st;
+    uint32_t n_cells, n_tiles, n_parts, part_cap;
+    uint32_t ref_count, num_genes, usa, num_rows, em, exact_umi, large_thresh, hw, umi_pairs;
+};
+constexpr uint32_t kP2PartTarget = 160;   // planned mean reads per partition (the partition count is a power of two: 80..160)
+constexpr uint32_t kP2PartCap = 256;      // reads one partition may hold (one wave sorts it in registers)
+constexpr uint32_t kP2TileHost = 2048;
+void launch_p2_split(hipStream_t s, const P2Args& a);
+void launch_p2_part(hipStream_t s, const P2Args& a);
+void launch_p2_search(hipStream_t s, const P2Args& a);
+void launch_p2_lone(hipStream_t s, const P2Args& a);
+void launch_p2_graph(hipStream_t s, const P2Args& a);
 uint32_t pug_max_blocks();
 uint64_t pug_scratch_words(uint32_t nrec, uint32_t n_ref, bool gene_level);
 

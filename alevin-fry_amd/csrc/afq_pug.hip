@@ -23,6 +23,7 @@
 #include "afq_common.h"
 #include "afq_kernels.h"
 #include "afq_prims.h"
+#include "afq_pug_common.h"
 
 namespace afq {
 
@@ -36,7 +37,7 @@ namespace afq {
 
 constexpr int kPugNT = 1024;
 constexpr uint32_t kVidBits = 20;                 // vertices per cell < 2^20
-constexpr uint32_t kMaxGenesPerLabel = 64;        // distinct genes of one molecule the device path carries
+
 constexpr uint32_t kMaxBigComp = 4096;            // vertices of a component the multi-word cover handles
 // Neighbour search out of LDS: the cell's vertices are cut into P = 4^k partitions by the low 2k bits of their UMI and the
 // partitions are taken one at a time through a hash table that lives in the 128 KiB LDS block (key = UMI, value = vertex id |
@@ -190,279 +191,6 @@ __device__ __noinline__ void sample_sort_reads(SortRec* sr, uint32_t* bid, uint3
     for (uint32_t b = 0; b < nb; ++b) sort_tile(sr + off[b], off[b + 1] - off[b]);
 }
 
-struct PugCtx {
-    // cell
-    const uint32_t* W;       // chunk dwords
-    uint32_t HW;             // header dwords of a record
-    const uint32_t* t2g;
-    uint32_t ref_count, num_genes;
-    // config
-    uint32_t usa, num_rows, uo, ao, em, exact_umi, large_thresh, umi_pairs, gene_level;
-    // outputs
-    uint32_t* cols;          // the cell's column list (u32), positions from s_ncols
-    uint32_t* labw;          // EM label words
-    uint32_t* labd;          // EM label descriptors (off,len)
-    uint32_t cols_cap, lab_cap;
-    uint32_t* s_cnt;         // LDS: [0] ncols, [1] label words, [2] label count, [3] error flag
-    DevStatus* st;
-    uint32_t cell;
-};
-
-struct Lab {
-    const uint32_t* p;
-    uint32_t n;
-};
-__device__ __forceinline__ Lab rec_label(const PugCtx& c, uint32_t rec_dw) {
-    Lab l;
-    l.n = c.W[rec_dw];
-    l.p = c.W + rec_dw + c.HW;
-    return l;
-}
-__device__ __forceinline__ bool lab_contains(const Lab& l, uint32_t t) {  // refs ascending (pugutils.rs:375)
-    uint32_t lo = 0, hi = l.n;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        const uint32_t v = l.p[mid] & 0x7FFFFFFFu;
-        if (v < t) lo = mid + 1; else hi = mid;
-    }
-    return lo < l.n && (l.p[lo] & 0x7FFFFFFFu) == t;
-}
-__device__ __forceinline__ bool lab_overlap(const Lab& a, const Lab& b) {  // share >= 1 ref (pugutils.rs:187-204)
-    uint32_t i = 0, j = 0;
-    while (i < a.n && j < b.n) {
-        const uint32_t x = a.p[i] & 0x7FFFFFFFu, y = b.p[j] & 0x7FFFFFFFu;
-        if (x == y) return true;
-        if (x < y) ++i; else ++j;
-    }
-    return false;
-}
-__device__ __forceinline__ bool lab_equal(const Lab& a, const Lab& b) {
-    if (a.n != b.n) return false;
-    for (uint32_t i = 0; i < a.n; ++i) if ((a.p[i] ^ b.p[i]) & 0x7FFFFFFFu) return false;
-    return true;
-}
-
-// sorted distinct gene ids of a list of refs (pugutils.rs:1213-1225, 1296-1298); returns the count
-// or 0xFFFFFFFF when more than kMaxGenesPerLabel distinct genes turn up.
-template <typename GetRef>
-__device__ __forceinline__ uint32_t genes_of(const PugCtx& c, uint32_t n, GetRef&& ref, uint32_t* g) {
-    uint32_t k = 0;
-    for (uint32_t j = 0; j < n; ++j) {
-        const uint32_t gid = c.gene_level ? ref(j) : c.t2g[ref(j)];  // gene-level labels already hold gene ids
-        uint32_t p = 0;
-        while (p < k && g[p] < gid) ++p;
-        if (p < k && g[p] == gid) continue;
-        if (k == kMaxGenesPerLabel) return 0xFFFFFFFFu;
-        for (uint32_t q = k; q > p; --q) g[q] = g[q - 1];
-        g[p] = gid;
-        ++k;
-    }
-    return k;
-}
-
-// One resolved molecule with gene label g[0..ng): a column, a gene-level class for the EM, or nothing.
-// (quant.rs:974-1024 -> extract_counts utils.rs:688-753 / em_optimize(only_unique) em.rs:499-514 / EM)
-__device__ __forceinline__ void emit_molecule(const PugCtx& c, const uint32_t* g, uint32_t ng) {
-    if (ng == 0xFFFFFFFFu) {   // more than kMaxGenesPerLabel genes: no column under any rule (one gene; USA: at most ten) - only the
-        if (c.em) c.s_cnt[3] = kErrPugLimit;   // EM would have to carry the class
-        return;
-    }
-    if (ng == 0) return;
-    uint32_t col = 0xFFFFFFFFu;
-    if (c.em) {
-        if (ng == 1) col = !c.usa ? g[0] : ((g[0] & 1u) == 0 ? (g[0] >> 1) : c.uo + (g[0] >> 1));
-        else if (c.usa && ng == 2 && ((g[0] ^ g[1]) & ~1u) == 0) col = c.ao + (g[0] >> 1);
-        else {
-            const uint32_t off = atomicAdd(&c.s_cnt[1], ng), di = atomicAdd(&c.s_cnt[2], 1u);
-            if (off + ng > c.lab_cap || 2 * (di + 1) > c.lab_cap) { c.s_cnt[3] = kErrPugLimit; return; }
-            for (uint32_t i = 0; i < ng; ++i) c.labw[off + i] = g[i];
-            c.labd[2 * di] = off; c.labd[2 * di + 1] = ng;
-            return;
-        }
-    } else if (!c.usa) {
-        if (ng == 1) col = g[0];
-    } else if (ng == 1) {
-        col = (g[0] & 1u) == 0 ? (g[0] >> 1) : c.uo + (g[0] >> 1);
-    } else if (ng == 2) {
-        const bool s1 = (g[0] & 1u) == 0, s2 = (g[1] & 1u) == 0;
-        if (((g[0] ^ g[1]) & ~1u) == 0) col = c.ao + (g[0] >> 1);
-        else if (s1 && !s2) col = g[0] >> 1;
-        else if (!s1 && s2) col = g[1] >> 1;
-    } else if (ng <= 10) {
-        uint32_t nsp = 0, sidx = 0;
-        for (uint32_t i = 0; i < ng; ++i) if ((g[i] & 1u) == 0) { if (nsp == 0) sidx = i; ++nsp; }
-        if (nsp == 1) {
-            const uint32_t sg = g[sidx];
-            col = (sidx + 1 < ng && ((sg ^ g[sidx + 1]) & ~1u) == 0) ? c.ao + (sg >> 1) : (sg >> 1);
-        }
-    }
-    if (col == 0xFFFFFFFFu) return;
-    if (col >= c.num_rows) { c.s_cnt[3] = kErrSlotRange; return; }
-    const uint32_t p = atomicAdd(&c.s_cnt[0], 1u);
-    if (p >= c.cols_cap) { c.s_cnt[3] = kErrPugLimit; return; }
-    c.cols[p] = col;
-}
-
-// emit_molecule for a gene label of one or two ids (g0 < g1) held in registers - nine molecules in ten.  Returns the column
-// the molecule counts for (the CALLER appends it: one reservation per wave, see append_cols) or 0xFFFFFFFF when there is
-// none (dropped, or kept as a two-gene class for the EM - written here).
-// cls is set when the molecule is a two-gene class (g0, g1) for the EM: the CALLER stores it, one reservation per wave
-// (append_class2) - two same-address LDS atomics per molecule were queueing the whole CU behind one word.
-__device__ __forceinline__ uint32_t molecule2_column(const PugCtx& c, uint32_t g0, uint32_t g1, uint32_t ng, bool& cls) {
-    uint32_t col = 0xFFFFFFFFu;
-    auto sua = [&](uint32_t g) { return (g & 1u) == 0 ? (g >> 1) : c.uo + (g >> 1); };
-    if (ng == 1) col = c.usa ? sua(g0) : g0;
-    else if (c.usa && ((g0 ^ g1) & ~1u) == 0) col = c.ao + (g0 >> 1);
-    else if (c.em) {
-        cls = true;
-        return 0xFFFFFFFFu;
-    } else if (c.usa) {
-        const bool s1 = (g0 & 1u) == 0, s2 = (g1 & 1u) == 0;
-        if (s1 && !s2) col = g0 >> 1;
-        else if (!s1 && s2) col = g1 >> 1;
-    }
-    if (col != 0xFFFFFFFFu && col >= c.num_rows) { c.s_cnt[3] = kErrSlotRange; return 0xFFFFFFFFu; }
-    return col;
-}
-// Up to four refs -> their distinct gene ids, ascending, all in registers (r[i] = 0xFFFFFFFF past the label's end).
-// Returns the number of genes; gene i in g[i].  (genes_of with its 64-entry array lives in scratch memory: a load or store
-// there is a trip to global memory, dozens per molecule.)
-__device__ __forceinline__ uint32_t genes_of4(const PugCtx& c, uint32_t (&g)[4], uint32_t n) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) g[i] = (uint32_t)i < n ? (c.gene_level ? g[i] : c.t2g[g[i]]) : 0xFFFFFFFFu;
-    auto cs = [&](int a, int b) { const uint32_t lo = g[a] < g[b] ? g[a] : g[b], hi = g[a] < g[b] ? g[b] : g[a]; g[a] = lo; g[b] = hi; };
-    cs(0, 1); cs(2, 3); cs(0, 2); cs(1, 3); cs(1, 2);   // sorting network of four
-    // drop repeats (0xFFFFFFFF sorts last and is never counted)
-    uint32_t o[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    uint32_t k = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const bool keep = g[i] != 0xFFFFFFFFu && (i == 0 || g[i] != g[i - 1]);
-        if (keep) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) if ((uint32_t)q == k) o[q] = g[i];
-            ++k;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) g[i] = o[i];
-    return k;
-}
-// emit_molecule for a gene label of up to four ids in registers; like molecule2_column it returns the column (for
-// append_cols) or 0xFFFFFFFF, and writes a multi-gene class for the EM itself.
-__device__ __forceinline__ uint32_t molecule4_column(const PugCtx& c, const uint32_t (&g)[4], uint32_t ng, bool& cls) {
-    if (ng == 0) return 0xFFFFFFFFu;
-    if (ng <= 2) return molecule2_column(c, g[0], g[1], ng, cls);   // (cls: the class is (g[0], g[1]))
-    uint32_t col = 0xFFFFFFFFu;
-    if (c.em) {
-        const uint32_t off = atomicAdd(&c.s_cnt[1], ng), di = atomicAdd(&c.s_cnt[2], 1u);
-        if (off + ng > c.lab_cap || 2 * (di + 1) > c.lab_cap) { c.s_cnt[3] = kErrPugLimit; return 0xFFFFFFFFu; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) if ((uint32_t)i < ng) c.labw[off + i] = g[i];
-        c.labd[2 * di] = off; c.labd[2 * di + 1] = ng;
-        return 0xFFFFFFFFu;
-    }
-    if (c.usa) {   // 3..10 genes: exactly one spliced gene -> A if its unspliced partner follows it, else S (utils.rs:719-747)
-        uint32_t nsp = 0, sg = 0, nxt = 0xFFFFFFFFu;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if ((uint32_t)i < ng && (g[i] & 1u) == 0) { if (nsp == 0) { sg = g[i]; nxt = i + 1 < 4 && (uint32_t)(i + 1) < ng ? g[i + 1] : 0xFFFFFFFFu; } ++nsp; }
-        if (nsp == 1) col = (nxt != 0xFFFFFFFFu && ((sg ^ nxt) & ~1u) == 0) ? c.ao + (sg >> 1) : (sg >> 1);
-    }
-    if (col != 0xFFFFFFFFu && col >= c.num_rows) { c.s_cnt[3] = kErrSlotRange; return 0xFFFFFFFFu; }
-    return col;
-}
-// Append one column per lane that has one.  Called by all lanes of the wave together: the lanes share ONE reservation on the
-// cell's column counter - a same-address LDS atomic per molecule is serviced lane by lane, with sixteen waves queueing.
-__device__ __forceinline__ void append_cols(const PugCtx& c, uint32_t col) {
-    const bool has = col != 0xFFFFFFFFu;
-    const uint64_t m = __ballot(has);
-    if (!m) return;
-    const uint32_t lane = lane_id(), leader = (uint32_t)__builtin_ctzll(m);
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(&c.s_cnt[0], (uint32_t)__popcll(m));
-    base = __builtin_amdgcn_readlane(base, (int)leader);
-    if (has) {
-        const uint32_t p = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-        if (p >= c.cols_cap) c.s_cnt[3] = kErrPugLimit; else c.cols[p] = col;
-    }
-}
-
-// Store one two-gene class per lane that has one (want).  Wave-wide call, like append_cols: one reservation of label words
-// and one of descriptors per wave.
-__device__ __forceinline__ void append_class2(const PugCtx& c, bool want, uint32_t g0, uint32_t g1) {
-    const uint64_t m = __ballot(want);
-    if (!m) return;
-    const uint32_t lane = lane_id(), leader = (uint32_t)__builtin_ctzll(m), n = (uint32_t)__popcll(m);
-    uint32_t off = 0, di = 0;
-    if (lane == leader) { off = atomicAdd(&c.s_cnt[1], 2u * n); di = atomicAdd(&c.s_cnt[2], n); }
-    off = __builtin_amdgcn_readlane(off, (int)leader);
-    di = __builtin_amdgcn_readlane(di, (int)leader);
-    if (want) {
-        const uint32_t r = (uint32_t)__popcll(m & ((1ull << lane) - 1));
-        const uint32_t o = off + 2 * r, d = di + r;
-        if (o + 2 > c.lab_cap || 2 * (d + 1) > c.lab_cap) { c.s_cnt[3] = kErrPugLimit; return; }
-        c.labw[o] = g0; c.labw[o + 1] = g1;
-        c.labd[2 * d] = o; c.labd[2 * d + 1] = 2;
-    }
-}
-
-// A class of more than kMaxGenesPerLabel genes for the EM (a read that hits a large gene family: rare, but real data has
-// them), written straight into the cell's label area by ONE lane: cand(j) is the j-th ref of the arborescence's first
-// label - a gene id at gene level - or 0xFFFFFFFF when it is not shared by every vertex; n, the first label's length,
-// bounds the class and is what gets reserved (the label area holds one word per alignment of the cell, and every
-// molecule's first vertex is a different one).  Distinct genes are kept ascending by insertion, in global memory.
-template <typename Cand>
-__device__ __forceinline__ void emit_wide_class(const PugCtx& c, uint32_t n, Cand&& cand) {
-    const uint32_t off = atomicAdd(&c.s_cnt[1], n), di = atomicAdd(&c.s_cnt[2], 1u);
-    if (off + n > c.lab_cap || 2 * (di + 1) > c.lab_cap) { c.s_cnt[3] = kErrPugLimit; return; }
-    uint32_t* w = c.labw + off;
-    uint32_t k = 0;
-    for (uint32_t j = 0; j < n; ++j) {
-        const uint32_t t = cand(j);
-        if (t == 0xFFFFFFFFu) continue;
-        const uint32_t gid = c.gene_level ? t : c.t2g[t];
-        uint32_t lo = 0, hi = k;
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (w[mid] < gid) lo = mid + 1; else hi = mid; }
-        if (lo < k && w[lo] == gid) continue;
-        for (uint32_t r = k; r > lo; --r) w[r] = w[r - 1];
-        w[lo] = gid;
-        ++k;
-    }
-    c.labd[2 * di] = off; c.labd[2 * di + 1] = k;
-}
-// the label of the vertex in slot `slot` of the gathered component records (6b): short labels travel in the record
-struct RecLab { Lab l; uint32_t r[4]; };
-__device__ __forceinline__ void rec_lab(const uint4* mrec, size_t slot, RecLab& o) {
-    const uint4 qa = mrec[2 * slot], qb = mrec[2 * slot + 1];
-    o.l.n = qa.y;
-    if (qa.y <= 4) { o.r[0] = qa.z; o.r[1] = qa.w; o.r[2] = qb.x; o.r[3] = qb.y; o.l.p = o.r; }
-    else o.l.p = reinterpret_cast<const uint32_t*>((uintptr_t)(((uint64_t)qa.w << 32) | qa.z));
-}
-// cand() of emit_wide_class for a component held in those records: ref j of the vertex in slot b0 + fv if every vertex
-// of `mask` (bit i = slot b0 + i) has it
-__device__ __forceinline__ void emit_wide_from_records(const PugCtx& c, const uint4* mrec, size_t b0, uint32_t fv, uint64_t mask) {
-    RecLab first;
-    rec_lab(mrec, b0 + fv, first);
-    emit_wide_class(c, first.l.n, [&](uint32_t j) -> uint32_t {
-        const uint32_t t = first.l.p[j] & 0x7FFFFFFFu;
-        for (uint64_t m = mask; m; m &= m - 1) {
-            const uint32_t i = (uint32_t)__builtin_ctzll(m);
-            if (i == fv) continue;
-            RecLab o;
-            rec_lab(mrec, b0 + i, o);
-            if (!lab_contains(o.l, t)) return 0xFFFFFFFFu;
-        }
-        return t;
-    });
-}
-
-__device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
-    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { lo |= __shfl_xor(lo, d); hi |= __shfl_xor(hi, d); }
-    return ((uint64_t)hi << 32) | lo;
-}
 
 
 __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
@@ -495,7 +223,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     if (tid == 0) s_next = atomicAdd(A.work_counter, 1u);
     __syncthreads();
     const uint32_t work = s_next;
-    if (work >= A.n_pug) return;
+    if (work >= (A.n_pug_dev ? *A.n_pug_dev : A.n_pug)) return;
     const uint32_t cell = A.pug_cells[work];
     const CellMeta m = A.meta[cell];
     const uint32_t R = m.nrec;
@@ -1636,215 +1364,8 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         mrec[2 * (size_t)sl + 1] = make_uint4(r2, r3, (uint32_t)adj, (uint32_t)(adj >> 32));
     }
     __syncthreads();
-    // ---- 6b'. components of 3..8 vertices: EIGHT to a wave, a group of eight lanes each ----
-    // The cover of 6b on segments of the wave: a ballot is cut to the group's byte, the OR over the frontier's adjacency
-    // rows runs over the group's eight lanes, "the label of vertex v" is a shuffle from lane (group base + v), and every
-    // loop runs until the last group of the wave is done with it (idle groups are predicated off).  Such components are
-    // four in five of all that reach the cover; a wave to each left 59 of its 64 lanes without a vertex.
-    {
-        const uint32_t gl = lane & 7u, gbase = lane & ~7u, grp = lane >> 3;
-        auto seg_or8 = [](uint32_t x) -> uint32_t { x |= (uint32_t)__shfl_xor((int)x, 1); x |= (uint32_t)__shfl_xor((int)x, 2); x |= (uint32_t)__shfl_xor((int)x, 4); return x; };
-        for (uint32_t c0 = wv * 8; c0 < n_tiny; c0 += (kPugNT / 64) * 8) {
-            const uint32_t ci = c0 + grp;
-            const bool gvalid = ci < n_tiny;
-            const uint32_t b0 = gvalid ? mid_off[ci] : 0u, n = gvalid ? mid_off[ci + 1] - b0 : 0u;
-            const bool act = gl < n;
-            uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
-            if (act) { qa = mrec[2 * (size_t)(b0 + gl)]; qb = mrec[2 * (size_t)(b0 + gl) + 1]; }
-            Lab myl{nullptr, act ? qa.y : 0u};
-            uint32_t lr0 = 0xFFFFFFFFu, lr1 = 0xFFFFFFFFu, lr2 = 0xFFFFFFFFu, lr3 = 0xFFFFFFFFu;
-            if (act && myl.n <= 4) { lr0 = qa.z; lr1 = qa.w; lr2 = qb.x; lr3 = qb.y; }
-            else if (act) myl.p = reinterpret_cast<const uint32_t*>((uintptr_t)(((uint64_t)qa.w << 32) | qa.z));
-            auto my_contains = [&](uint32_t t) -> bool {
-                if (myl.n <= 4) return t == lr0 || t == lr1 || t == lr2 || t == lr3;
-                return lab_contains(myl, t);
-            };
-            // ref j of the label held by lane `src` (every lane of the wave makes the same three shuffles; n_v, j and src are the caller's)
-            auto ref_of = [&](uint32_t src, uint32_t n_v, uint32_t j, bool on) -> uint32_t {
-                const uint32_t r = (uint32_t)__shfl((int)(j == 0 ? lr0 : j == 1 ? lr1 : j == 2 ? lr2 : lr3), (int)src);
-                const uint64_t pa = (uint64_t)(uintptr_t)myl.p;
-                const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)pa, (int)src), hi = (uint32_t)__shfl((int)(uint32_t)(pa >> 32), (int)src);
-                if (n_v <= 4 || !on) return r;
-                return reinterpret_cast<const uint32_t*>((uintptr_t)(((uint64_t)hi << 32) | lo))[j] & 0x7FFFFFFFu;
-            };
-            const uint32_t adj = act ? (qb.z & 0xFFu) : 0u;   // local indices < 8
-            uint32_t UC = gvalid ? (1u << n) - 1u : 0u;
-            while (__any(UC != 0)) {
-                const uint32_t remaining = (uint32_t)__popc(UC);
-                uint32_t best = 0, best_sz = 0, it = UC;
-                while (__any(it != 0)) {   // candidate start vertices, ascending
-                    const bool g_on = it != 0;
-                    const uint32_t v = g_on ? (uint32_t)__builtin_ctz(it) : 0u;
-                    it &= it - 1;   // (0 stays 0)
-                    const uint32_t lvn_all = (uint32_t)__shfl((int)myl.n, (int)(gbase + v));
-                    const uint32_t lvn = g_on ? lvn_all : 0u;
-                    uint32_t mv = 0, mv_sz = 0;
-                    for (uint32_t j = 0; __any(j < lvn); ++j) {
-                        const bool on = j < lvn;
-                        const uint32_t t = ref_of(gbase + v, lvn, j, on);
-                        const bool has = on && act && ((UC >> gl) & 1u) && my_contains(t);
-                        const uint32_t At = (uint32_t)(__ballot(has) >> gbase) & 0xFFu;
-                        uint32_t Rm = 1u << v, F = on ? Rm : 0u;
-                        while (__any(F != 0)) {
-                            const uint32_t N = seg_or8(((F >> gl) & 1u) ? adj : 0u);
-                            F = N & At & ~Rm;
-                            Rm |= F;
-                        }
-                        const uint32_t sz = (uint32_t)__popc(Rm);
-                        if (on && sz > mv_sz) { mv_sz = sz; mv = Rm; }
-                    }
-                    if (g_on && mv_sz > best_sz) { best_sz = mv_sz; best = mv; }
-                    if (g_on && mv_sz == remaining) it = 0;
-                }
-                const bool g_emit = UC != 0;
-                if (g_emit && best == 0) { if (gl == 0) s_cnt[3] = kErrPugLimit; UC = 0; }  // vertex with an empty label
-                // transcripts common to every vertex of the arborescence (pugutils.rs:1161-1188) -> genes
-                const uint32_t fv = best ? (uint32_t)__builtin_ctz(best) : 0u;
-                const uint32_t lfn_all = (uint32_t)__shfl((int)myl.n, (int)(gbase + fv));
-                const uint32_t lfn = best ? lfn_all : 0u;
-                uint32_t g[kMaxGenesPerLabel];   // (only for labels over four refs: the array lives in scratch memory)
-                uint32_t ng = 0, k4 = 0;
-                uint32_t c4[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-                bool wide = false;
-                const bool small = lfn <= 4;
-                for (uint32_t j = 0; __any(j < lfn); ++j) {
-                    const bool on = j < lfn;
-                    const uint32_t t = ref_of(gbase + fv, lfn, j, on);
-                    const uint32_t hasm = (uint32_t)(__ballot(on && act && ((best >> gl) & 1u) && my_contains(t)) >> gbase) & 0xFFu;
-                    if (on && hasm == best && gl == 0) {
-                        if (small) {
-#pragma unroll
-                            for (int w = 0; w < 4; ++w) if ((uint32_t)w == k4) c4[w] = t;
-                            ++k4;
-                        } else {
-                            const uint32_t gid = C.gene_level ? t : C.t2g[t];
-                            uint32_t q = 0;
-                            while (q < ng && g[q] < gid) ++q;
-                            if (!(q < ng && g[q] == gid)) {
-                                if (ng == kMaxGenesPerLabel) wide = true;
-                                else { for (uint32_t r = ng; r > q; --r) g[r] = g[r - 1]; g[q] = gid; ++ng; }
-                            }
-                        }
-                    }
-                }
-                uint32_t col = 0xFFFFFFFFu;
-                bool cls = false;
-                if (best && gl == 0) {
-                    if (small) { const uint32_t n4 = genes_of4(C, c4, k4); col = molecule4_column(C, c4, n4, cls); }
-                    else if (wide && C.em) emit_wide_from_records(C, mrec, b0, fv, best);
-                    else emit_molecule(C, g, wide ? 0xFFFFFFFFu : ng);
-                }
-                append_cols(C, col);
-                append_class2(C, cls, c4[0], c4[1]);
-                UC &= ~best;
-            }
-        }
-    }
-    {
-      // offsets two components ahead, records one ahead
-      uint32_t ob0 = 0, ob1 = 0, nb0 = 0, nb1 = 0;
-      if (n_tiny + wv < n_mid) { ob0 = mid_off[n_tiny + wv]; ob1 = mid_off[n_tiny + wv + 1]; }
-      if (n_tiny + wv + kPugNT / 64 < n_mid) { nb0 = mid_off[n_tiny + wv + kPugNT / 64]; nb1 = mid_off[n_tiny + wv + kPugNT / 64 + 1]; }
-      uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
-      if (lane < ob1 - ob0) { ra = mrec[2 * (size_t)(ob0 + lane)]; rb = mrec[2 * (size_t)(ob0 + lane) + 1]; }
-    for (uint32_t ci = n_tiny + wv; ci < n_mid; ci += kPugNT / 64) {   // components of 9..64 vertices: a wave each
-        const uint32_t n = ob1 - ob0;
-        const bool act = lane < n;
-        const uint4 qa = ra, qb = rb;
-        {   // next component's records, the one after's offsets
-            ob0 = nb0; ob1 = nb1;
-            ra = make_uint4(0, 0, 0, 0); rb = ra;
-            if (ci + kPugNT / 64 < n_mid && lane < ob1 - ob0) { ra = mrec[2 * (size_t)(ob0 + lane)]; rb = mrec[2 * (size_t)(ob0 + lane) + 1]; }
-            const uint32_t c2 = ci + 2 * (kPugNT / 64);
-            nb0 = c2 < n_mid ? mid_off[c2] : 0u; nb1 = c2 < n_mid ? mid_off[c2 + 1] : 0u;
-        }
-        Lab myl{nullptr, act ? qa.y : 0u};
-        uint32_t lr0 = 0xFFFFFFFFu, lr1 = 0xFFFFFFFFu, lr2 = 0xFFFFFFFFu, lr3 = 0xFFFFFFFFu;
-        if (act && myl.n <= 4) { lr0 = qa.z; lr1 = qa.w; lr2 = qb.x; lr3 = qb.y; }
-        else if (act) myl.p = reinterpret_cast<const uint32_t*>((uintptr_t)(((uint64_t)qa.w << 32) | qa.z));
-        auto my_contains = [&](uint32_t t) -> bool {
-            if (myl.n <= 4) return t == lr0 || t == lr1 || t == lr2 || t == lr3;
-            return lab_contains(myl, t);
-        };
-        // the label of the vertex held by lane v, out of that lane's registers (a global read only for labels over four refs):
-        // the cover below walks candidate labels thousands of times per cell
-        auto lane_lab_n = [&](uint32_t v) -> uint32_t { return (uint32_t)__shfl((int)myl.n, (int)v); };
-        auto lane_lab_ref = [&](uint32_t v, uint32_t n_v, uint32_t j) -> uint32_t {
-            if (n_v <= 4) return (uint32_t)__shfl((int)(j == 0 ? lr0 : j == 1 ? lr1 : j == 2 ? lr2 : lr3), (int)v);
-            const uint64_t pa = (uint64_t)(uintptr_t)myl.p;
-            const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)pa, (int)v), hi = (uint32_t)__shfl((int)(uint32_t)(pa >> 32), (int)v);
-            return reinterpret_cast<const uint32_t*>((uintptr_t)(((uint64_t)hi << 32) | lo))[j] & 0x7FFFFFFFu;
-        };
-        const uint64_t adj = act ? (((uint64_t)qb.w << 32) | qb.z) : 0ull;
-        uint64_t UC = n == 64 ? ~0ull : ((1ull << n) - 1);
-        while (UC) {
-            const uint32_t remaining = (uint32_t)__popcll(UC);
-            uint64_t best = 0;
-            uint32_t best_sz = 0;
-            for (uint64_t it = UC; it; it &= it - 1) {   // ascending vertex id
-                const uint32_t v = (uint32_t)__builtin_ctzll(it);
-                const uint32_t lvn = lane_lab_n(v);
-                uint64_t mv = 0;
-                uint32_t mv_sz = 0;
-                for (uint32_t j = 0; j < lvn; ++j) {
-                    const uint32_t t = lane_lab_ref(v, lvn, j);
-                    const uint64_t At = __ballot(act && ((UC >> lane) & 1ull) && my_contains(t));
-                    uint64_t Rm = 1ull << v, F = Rm;
-                    while (F) {
-                        const uint64_t N = wave_or64(((F >> lane) & 1ull) ? adj : 0ull);
-                        F = N & At & ~Rm;
-                        Rm |= F;
-                    }
-                    const uint32_t sz = (uint32_t)__popcll(Rm);
-                    if (sz > mv_sz) { mv_sz = sz; mv = Rm; }
-                }
-                if (mv_sz > best_sz) { best_sz = mv_sz; best = mv; }
-                if (mv_sz == remaining) break;
-            }
-            if (best == 0) { if (lane == 0) s_cnt[3] = kErrPugLimit; break; }  // vertex with an empty label
-            // transcripts common to every vertex of the arborescence (pugutils.rs:1161-1188) -> genes
-            const uint32_t fv = (uint32_t)__builtin_ctzll(best);
-            const uint32_t lfn = lane_lab_n(fv);
-            uint32_t g[kMaxGenesPerLabel];   // (only for labels over four refs: the array lives in scratch memory)
-            uint32_t ng = 0, k4 = 0;
-            uint32_t c4[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-            bool wide = false;
-            const bool small = lfn <= 4;
-            for (uint32_t j = 0; j < lfn; ++j) {
-                const uint32_t t = lane_lab_ref(fv, lfn, j);
-                const uint64_t has = __ballot(act && ((best >> lane) & 1ull) && my_contains(t));
-                if (has != best) continue;
-                if (lane == 0) {
-                    if (small) {
-#pragma unroll
-                        for (int w = 0; w < 4; ++w) if ((uint32_t)w == k4) c4[w] = t;
-                        ++k4;
-                    } else {
-                        const uint32_t gid = C.gene_level ? t : C.t2g[t];
-                        uint32_t q = 0;
-                        while (q < ng && g[q] < gid) ++q;
-                        if (!(q < ng && g[q] == gid)) {
-                            if (ng == kMaxGenesPerLabel) wide = true;
-                            else { for (uint32_t r = ng; r > q; --r) g[r] = g[r - 1]; g[q] = gid; ++ng; }
-                        }
-                    }
-                }
-            }
-            {
-                uint32_t col = 0xFFFFFFFFu;
-                bool cls = false;
-                if (lane == 0) {
-                    if (small) { const uint32_t n4 = genes_of4(C, c4, k4); col = molecule4_column(C, c4, n4, cls); }
-                    else if (wide && C.em) emit_wide_from_records(C, mrec, mid_off[ci], fv, best);
-                    else emit_molecule(C, g, wide ? 0xFFFFFFFFu : ng);
-                }
-                append_cols(C, col);
-                append_class2(C, cls, c4[0], c4[1]);
-            }
-            UC &= ~best;
-        }
-    }
-    }
+    cover_tiny8<kPugNT / 64>(C, mrec, mid_off, n_tiny, wv, lane);   // 6b': components of 3..8 vertices, eight to a wave (afq_pug_common.h)
+    cover_wave64<kPugNT / 64>(C, mrec, mid_off, n_tiny, n_mid, wv, lane);   // 9..64 vertices: a wave each
     __syncthreads();
     PUG_MARK(9);
     // ---- 6c. larger components, one at a time by the whole workgroup ----

@@ -9,6 +9,18 @@ rad = pkg.rad
 synth = pkg.synth
 
 
+@pytest.fixture(autouse=True, params=["phase-kernels", "one-workgroup", "handed-back"])
+def pug_route(request, monkeypatch):
+    """Every test of this module runs three times: through the partition-parallel phase kernels (csrc/afq_pug2.hip, the
+    default), with every parsimony cell sent to the one-workgroup kernel (csrc/afq_pug.hip), and with the phase kernels'
+    partition capacity cut to 24 reads so that most cells start on the first route and are handed back to the second."""
+    if request.param == "one-workgroup":
+        monkeypatch.setenv("AFQ_PUG_ROUTE", "mono")
+    elif request.param == "handed-back":
+        monkeypatch.setenv("AFQ_P2_PART_CAP", "24")
+    return request.param
+
+
 def run_both(oracle, cfg, t2g, b, off):
     q = pkg.Quantifier(cfg, t2g)
     try:
