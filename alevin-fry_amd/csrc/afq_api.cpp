@@ -289,14 +289,14 @@ int check_supported(afq_ctx* c) {
 // Layout of RangeState::d_p2_small (u32 words), the per-cell / per-partition / per-tile arrays of the phase-kernel parsimony
 // path: a region that starts zeroed, the arrays the kernels fill, and a region uploaded from the host in one copy.
 struct P2Small {
-    uint64_t pcnt, pair_n, gcnt, fb, ctr, zero_words;          // zeroed: partition counts, per-cell pair counts / counters / flags, work counter
+    uint64_t pcnt, pnp, pncls, pn3, gcnt, fb, ctr, zero_words;      // zeroed: per partition reads / pairs / staged classes, per-cell counters / flags, work counter
     uint64_t poff, pcur, pnv, pcell;                           // filled on the device
     uint64_t up, fb_count, fb_list, order, cells, tiles, up_words, words;   // uploaded
 };
 P2Small p2_small_layout(uint64_t n, uint64_t parts, uint64_t tiles, uint64_t n_pug) {
     P2Small L{};
     uint64_t o = 0;
-    L.pcnt = o; o += parts; L.pair_n = o; o += n; L.gcnt = o; o += 4 * n; L.fb = o; o += n; L.ctr = o; o += 8;
+    L.pcnt = o; o += parts; L.pnp = o; o += parts; L.pncls = o; o += parts; L.pn3 = o; o += parts; L.gcnt = o; o += 4 * n; L.fb = o; o += n; L.ctr = o; o += 8;
     L.zero_words = o;
     L.poff = o; o += parts; L.pcur = o; o += parts; L.pnv = o; o += parts; L.pcell = o; o += parts;
     o = (o + 3) & ~3ull;
@@ -516,9 +516,9 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
                            !(route && !std::strcmp(route, "mono"));
         for (uint32_t ci : pug_cells) {   // (largest first)
             const CellMeta& m = B.meta[ci];
-            if (!p2_ok || m.nrec >= (1u << 20)) { mono_cells.push_back(ci); continue; }
+            if (!p2_ok || m.nrec >= (1u << 20) || m.n_ref < m.nrec) { mono_cells.push_back(ci); continue; }   // (n_ref < nrec: records without alignments - the column list is sized by n_ref)
             P2Cell pc{};
-            pc.rd_base = rd_off[ci]; pc.pair_base = p2_pairs; pc.cell = ci; pc.R = m.nrec;
+            pc.rd_base = rd_off[ci]; pc.pair_base = p2_pairs; pc.chunk_off = m.chunk_off; pc.cell = ci; pc.R = m.nrec;
             uint32_t lg = 0;
             while (((m.nrec + (1u << lg) - 1) >> lg) > kP2PartTarget) ++lg;
             pc.lgP = lg; pc.part_base = (uint32_t)p2_parts; pc.pair_cap = m.nrec / 2 + 64;
@@ -667,7 +667,8 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
         if (n_p2) {
             p2.s_h = reinterpret_cast<uint64_t*>(ep + eo); eo += 2 * n_pug_reads;
             p2.s_u = reinterpret_cast<uint64_t*>(ep + eo); eo += 2 * n_pug_reads;
-            p2.pairs = reinterpret_cast<uint64_t*>(ep + eo); eo += 2 * p2_pairs;
+            p2.pairs = reinterpret_cast<uint64_t*>(ep + eo); eo += 2 * n_pug_reads;
+            p2.cstage = reinterpret_cast<uint64_t*>(ep + eo); eo += em ? 2 * n_pug_reads : 0;
             p2.v_off = ep + eo; eo += n_pug_reads;
             p2.lidx = ep + eo; eo += n_pug_reads;
             p2.v_flag = reinterpret_cast<uint8_t*>(ep + eo); eo += n_pug_reads / 4 + 1;
@@ -681,7 +682,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
             p2.tiles = reinterpret_cast<const uint2*>(sm + L.tiles); p2.order = sm + L.order;
             p2.rd_h = da.pug.h; p2.rd_u = da.pug.u;
             p2.pcnt = sm + L.pcnt; p2.poff = sm + L.poff; p2.pcur = sm + L.pcur; p2.pnv = sm + L.pnv; p2.pcell = sm + L.pcell;
-            p2.pair_n = sm + L.pair_n; p2.gcnt = sm + L.gcnt; p2.fb = sm + L.fb; p2.fb_list = sm + L.fb_list; p2.fb_count = sm + L.fb_count;
+            p2.pnp = sm + L.pnp; p2.pncls = sm + L.pncls; p2.pn3 = sm + L.pn3; p2.gcnt = sm + L.gcnt; p2.fb = sm + L.fb; p2.fb_list = sm + L.fb_list; p2.fb_count = sm + L.fb_count;
             p2.pool = pool; p2.pool_cur = B.d_epool_cur.as<unsigned long long>(); p2.pool_cap = pool_cap;
             p2.work_counter = sm + L.ctr;
             p2.cell_nkeys = ra.cell_nkeys; p2.t2g = c->d_t2g.as<uint32_t>(); p2.keys0 = ra.keys0; p2.cell_ncols = ra.cell_ncols;

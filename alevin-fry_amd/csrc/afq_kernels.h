@@ -156,6 +156,7 @@ void launch_pug(hipStream_t s, const PugCellArgs& a, uint32_t n_blocks);
 struct P2Cell {
     uint64_t rd_base;     // the cell's first read slot: rd_h / rd_u / s_h / s_u / v_off / v_flag / lidx share the indexing
     uint64_t pair_base;   // first slot of the cell's pair list
+    uint64_t chunk_off;   // the cell's chunk in the input bytes (= meta[cell].chunk_off)
     uint32_t cell;        // index into meta[]
     uint32_t R;           // reads
     uint32_t lgP;         // log2 of the partition count (partition = low lgP bits of the UMI)
@@ -168,8 +169,9 @@ struct P2Args {
     const uint64_t* rd_h; const uint64_t* rd_u;        // the decode's reads: label key, umi << 32 | record offset
     uint64_t* s_h; uint64_t* s_u;                      // reads grouped by partition, then the vertices (key; umi << 32 | word)
     uint32_t* v_off; uint8_t* v_flag; uint32_t* lidx;  // vertex: smallest record offset, has-an-edge flag, id among the touched
-    uint32_t* pcnt; uint32_t* poff; uint32_t* pcur; uint32_t* pnv; uint32_t* pcell;   // per partition
-    uint64_t* pairs; uint32_t* pair_n;                 // per cell: vertex pairs with an edge
+    uint32_t* pcnt; uint32_t* poff; uint32_t* pcur; uint32_t* pnv; uint32_t* pcell; uint32_t* pn3;   // per partition
+    uint64_t* pairs; uint32_t* pnp;                    // vertex pairs with an edge: a partition's pairs sit at its own slots; per partition: how many
+    uint64_t* cstage; uint32_t* pncls;                 // two-gene classes of lone vertices (em), staged the same way
     uint32_t* gcnt;                                    // per cell [4]: columns, label words, classes, error
     uint32_t* fb; uint32_t* fb_list; uint32_t* fb_count;   // cells handed to the one-workgroup kernel
     uint32_t* pool; unsigned long long* pool_cur; unsigned long long pool_cap;

@@ -29,6 +29,8 @@
 // (nothing is approximated); gene-level labels and UMI fields over 4 bytes go there directly.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 #include "afq_common.h"
@@ -44,7 +46,6 @@ constexpr uint32_t kP2Tile = 2048;        // reads per histogram / scatter tile
 constexpr uint32_t kP2Bins = 2048;        // partitions per cell the tile kernels rank in LDS
 constexpr uint32_t kP2TabSlots = 512;     // hash table of one partition's vertices (<= 256)
 constexpr uint32_t kP2FiltBits = 2048;    // presence filter in front of it
-constexpr uint32_t kP2PairBuf = 128;      // pairs a wave collects in LDS before it reserves room in the cell's list
 constexpr uint32_t kVCntMask = 0x3FFu;    // vertex word: reads (10 bits) | label signature (19 bits) << 10 | key tag << 29
 constexpr uint64_t kPairF = 1ull << 63, kPairB = 1ull << 62;   // pair (x, y): x -> y / y -> x is an edge
 
@@ -83,7 +84,7 @@ __device__ __forceinline__ bool klab_overlap(const KLab& a, const KLab& b) {   /
 
 __device__ __forceinline__ PugCtx make_ctx(const P2Args& A, const P2Cell& c, const CellMeta& m, uint32_t* cnt) {
     PugCtx C;
-    C.W = reinterpret_cast<const uint32_t*>(A.bytes + m.chunk_off);
+    C.W = reinterpret_cast<const uint32_t*>(A.bytes + c.chunk_off);
     C.HW = A.hw; C.t2g = A.t2g; C.ref_count = A.ref_count; C.num_genes = A.num_genes;
     C.usa = A.usa; C.num_rows = A.num_rows; C.uo = A.num_rows / 3; C.ao = 2 * (A.num_rows / 3); C.em = A.em;
     C.exact_umi = A.exact_umi; C.large_thresh = A.large_thresh; C.umi_pairs = A.umi_pairs; C.gene_level = 0;
@@ -118,7 +119,8 @@ __global__ __launch_bounds__(256) void k_p2_hist(P2Args A) {
     for (uint32_t b = threadIdx.x; b < P; b += 256) { const uint32_t v = s_hist[b]; if (v) atomicAdd(&gcnt[b], v); }
 }
 
-// wave per cell: partition offsets inside the cell, the scatter's cursors, partition -> cell, oversize check
+// wave per cell: partition offsets inside the cell, the scatter's cursors, partition -> cell, oversize check.  A cell with a
+// partition over the capacity is flagged and its partition counts are zeroed: the partition kernels then pass over it.
 __global__ __launch_bounds__(256) void k_p2_scan(P2Args A) {
     const uint32_t j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = lane_id();
     if (j >= A.n_cells) return;
@@ -136,14 +138,20 @@ __global__ __launch_bounds__(256) void k_p2_scan(P2Args A) {
         carry += tot;
     }
     const bool bad = A.cell_nkeys[c.cell] != c.R;   // the decode emitted another number of reads than the header announced
-    if (__any(over) && lane == 0) A.fb[j] = 1;
+    if (__any(over)) {
+        if (lane == 0) A.fb[j] = 1;
+        for (uint32_t i = lane; i < P; i += 64) A.pcnt[c.part_base + i] = 0;
+    }
     if (lane == 0 && (bad || carry != c.R)) set_err(A.st, kErrRecordWalk, c.cell);
 }
 
+// STAGED: the tile goes through LDS partition-major, so that a partition's run of the tile leaves in consecutive lanes;
+// otherwise every read is written from its own registers (16 KiB of LDS instead of 48: ten workgroups to a CU instead of three).
+template <bool STAGED>
 __global__ __launch_bounds__(256) void k_p2_scatter(P2Args A) {
     constexpr uint32_t E = kP2Tile / 256;
-    __shared__ uint64_t s_a[kP2Tile];
-    __shared__ uint64_t s_b[kP2Tile];
+    __shared__ uint64_t s_a[STAGED ? kP2Tile : 1];
+    __shared__ uint64_t s_b[STAGED ? kP2Tile : 1];
     __shared__ uint32_t s_cnt[kP2Bins];
     __shared__ uint32_t s_base[kP2Bins];
     __shared__ uint32_t s_ws[4];
@@ -191,18 +199,26 @@ __global__ __launch_bounds__(256) void k_p2_scatter(P2Args A) {
         carry += tot;
     }
     __syncthreads();
+    if constexpr (!STAGED) {
 #pragma unroll
-    for (uint32_t e = 0; e < E; ++e) {
-        const uint32_t i = t0 + e * 256 + threadIdx.x;
-        if (i < t1) { const uint32_t o = s_cnt[rank[e] >> 16] + (rank[e] & 0xFFFFu); s_a[o] = ku[e]; s_b[o] = kh[e]; }
-    }
-    __syncthreads();
-    const uint32_t nt = t1 - t0;
-    for (uint32_t i = threadIdx.x; i < nt; i += 256) {
-        const uint64_t u = s_a[i];
-        const uint32_t b = (uint32_t)(u >> 32) & pm;
-        const uint32_t pos = s_base[b] + (i - s_cnt[b]);
-        du[pos] = u; dh[pos] = s_b[i];
+        for (uint32_t e = 0; e < E; ++e) {
+            const uint32_t i = t0 + e * 256 + threadIdx.x;
+            if (i < t1) { const uint32_t pos = s_base[rank[e] >> 16] + (rank[e] & 0xFFFFu); du[pos] = ku[e]; dh[pos] = kh[e]; }
+        }
+    } else {
+#pragma unroll
+        for (uint32_t e = 0; e < E; ++e) {
+            const uint32_t i = t0 + e * 256 + threadIdx.x;
+            if (i < t1) { const uint32_t o = s_cnt[rank[e] >> 16] + (rank[e] & 0xFFFFu); s_a[o] = ku[e]; s_b[o] = kh[e]; }
+        }
+        __syncthreads();
+        const uint32_t nt = t1 - t0;
+        for (uint32_t i = threadIdx.x; i < nt; i += 256) {
+            const uint64_t u = s_a[i];
+            const uint32_t b = (uint32_t)(u >> 32) & pm;
+            const uint32_t pos = s_base[b] + (i - s_cnt[b]);
+            du[pos] = u; dh[pos] = s_b[i];
+        }
     }
 }
 
@@ -282,20 +298,22 @@ __device__ __forceinline__ void part_body(const P2Args& A, const uint32_t* W, ui
         }
         before += (uint32_t)__popcll(vm[e]);
     }
-    for (uint32_t i = before + lane; i < n; i += 64) su[i] = 0;   // (every load of the partition's reads is long done: they went into the sort)
-    for (uint32_t i = lane; i < n; i += 64) A.v_flag[o + i] = 0;
-    if (lane == 0) A.pnv[gp] = before;
+    for (uint32_t i = before + lane; i < n; i += 64) { su[i] = 0; sh[i] = 0; }   // (every load of the partition's reads is long done: they went into the sort)
+    for (uint32_t i = lane; i < n; i += 64) { A.v_flag[o + i] = 0; A.lidx[o + i] = 0xFFFFFFFFu; }
+    uint32_t n3 = 0;   // vertices under a hashed key (they sort last: the key's tag is its top bits)
+#pragma unroll
+    for (int e = 0; e < E; ++e) n3 += (uint32_t)__popcll(__ballot(vh[e] && (uint32_t)((uint64_t)(a[e] >> 64) >> 62) == 3));
+    if (lane == 0) { A.pnv[gp] = before; A.pn3[gp] = n3; }
 }
 
-__global__ __launch_bounds__(64) void k_p2_part(P2Args A) {
-    const uint32_t gp = blockIdx.x;
-    const uint32_t j = A.pcell[gp];
-    if (A.fb[j]) return;
-    const P2Cell c = A.cells[j];
+__global__ __launch_bounds__(256) void k_p2_part(P2Args A) {
+    const uint32_t gp = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gp >= A.n_parts) return;
     const uint32_t n = A.pcnt[gp];
-    if (n == 0) { if (threadIdx.x == 0) A.pnv[gp] = 0; return; }
+    if (n == 0) { if (lane_id() == 0) A.pnv[gp] = 0; return; }
+    const P2Cell c = A.cells[A.pcell[gp]];
     const uint64_t o = c.rd_base + A.poff[gp];
-    const uint32_t* W = reinterpret_cast<const uint32_t*>(A.bytes + A.meta[c.cell].chunk_off);
+    const uint32_t* W = reinterpret_cast<const uint32_t*>(A.bytes + c.chunk_off);
     if (n <= 128) part_body<2>(A, W, gp, n, o, c.cell);
     else part_body<4>(A, W, gp, n, o, c.cell);
 }
@@ -307,33 +325,53 @@ __global__ __launch_bounds__(64) void k_p2_part(P2Args A) {
 //    vertices is met once - same UMI from the smaller slot, neighbours from the smaller UMI - and both directions of
 //    has_edge (pugutils.rs:76-99) are decided there: x -> y unless reads(y) >= 2 reads(x), always at distance 0, and only
 //    if the labels share a ref.
-__global__ __launch_bounds__(64) void k_p2_search(P2Args A) {
-    __shared__ uint32_t t_umi[kP2TabSlots];
-    __shared__ uint32_t t_word[kP2TabSlots];
-    __shared__ uint16_t t_idx[kP2TabSlots];
-    __shared__ uint32_t s_filt[kP2FiltBits / 32];
-    __shared__ uint64_t s_pair[kP2PairBuf];
-    __shared__ uint32_t s_np, s_at;
-    const uint32_t gp = blockIdx.x, lane = threadIdx.x;
-    const uint32_t j = A.pcell[gp];
-    if (A.fb[j]) return;
-    const P2Cell c = A.cells[j];
+// (Four partitions to a 256-thread workgroup, a wave each with its own slice of LDS and nothing shared: no workgroup barrier;
+// LDS instructions of one wave execute in order, WAVE_SYNC only keeps the compiler from moving code across.)
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+__global__ __launch_bounds__(256) void k_p2_search(P2Args A) {
+    __shared__ uint32_t s_umi[4][kP2TabSlots];
+    __shared__ uint32_t s_word[4][kP2TabSlots];
+    __shared__ uint16_t s_idx[4][kP2TabSlots];
+    __shared__ uint32_t s_filt4[4][kP2FiltBits / 32];
+    __shared__ uint32_t s_np4[4];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t gp = blockIdx.x * 4 + wv;
+    if (gp >= A.n_parts) return;
     const uint32_t nv = A.pnv[gp];
     if (nv == 0) return;
+    const uint32_t j = A.pcell[gp];
+    const P2Cell c = A.cells[j];
+    uint32_t* t_umi = s_umi[wv]; uint32_t* t_word = s_word[wv]; uint16_t* t_idx = s_idx[wv];
+    uint32_t* s_filt = s_filt4[wv]; uint32_t* s_np = &s_np4[wv];
     const uint32_t m = c.lgP, P = 1u << m, p = gp - c.part_base;
     const uint32_t lo_p = A.poff[gp];                 // the partition's first slot inside the cell
+    const uint32_t pcap = A.pcnt[gp];                 // ... and how many it has: the partition's pairs go into its own slots of the pair array
     const uint64_t* ch = A.s_h + c.rd_base;           // the cell's vertex arrays
     const uint64_t* cu = A.s_u + c.rd_base;
     const uint32_t* coff = A.v_off + c.rd_base;
     uint8_t* cflag = A.v_flag + c.rd_base;
-    const uint32_t* W = reinterpret_cast<const uint32_t*>(A.bytes + A.meta[c.cell].chunk_off);
+    uint64_t* ppair = A.pairs + c.rd_base + lo_p;
+    const uint32_t* W = reinterpret_cast<const uint32_t*>(A.bytes + c.chunk_off);
+    // the foreign partitions' places go out first: their latency hides under the table build
+    const uint32_t nfor = A.exact_umi ? 0u : 3 * ((m + 1) / 2);
+    uint32_t f_n = 0, f_o = 0;
+    if (lane < nfor) {
+        const uint32_t low = ((lane % 3 + 1) << (2 * (lane / 3))) & (P - 1);
+        if (low) { const uint32_t q = c.part_base + (p ^ low); f_n = A.pnv[q]; f_o = A.poff[q]; }
+    }
     for (uint32_t i = lane; i < kP2TabSlots; i += 64) t_word[i] = 0;
     if (lane < kP2FiltBits / 32) s_filt[lane] = 0;
-    if (lane == 0) s_np = 0;
-    __syncthreads();
-    for (uint32_t i = lane; i < nv; i += 64) {
-        const uint64_t uw = cu[lo_p + i];
-        const uint32_t umi = (uint32_t)(uw >> 32), word = (uint32_t)uw;
+    if (lane == 0) *s_np = 0;
+    WAVE_SYNC();
+    uint64_t own[4];   // the partition's own vertices stay in registers (<= 256 of them)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) own[r] = (uint32_t)r * 64 + lane < nv ? cu[lo_p + r * 64 + lane] : 0ull;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t i = (uint32_t)r * 64 + lane;
+        if (i >= nv) continue;
+        const uint32_t umi = (uint32_t)(own[r] >> 32), word = (uint32_t)own[r];
         uint32_t slot = fold9(umi);
         while (atomicCAS(&t_word[slot], 0u, word) != 0u) slot = (slot + 1) & (kP2TabSlots - 1);   // (equal UMIs under different labels: consecutive slots of one run)
         t_umi[slot] = umi;
@@ -341,7 +379,7 @@ __global__ __launch_bounds__(64) void k_p2_search(P2Args A) {
         const uint32_t fb = fold11(umi);
         atomicOr(&s_filt[fb >> 5], 1u << (fb & 31u));
     }
-    __syncthreads();
+    WAVE_SYNC();
     auto filt = [&](uint32_t u) -> bool { const uint32_t f = fold11(u); return (s_filt[f >> 5] >> (f & 31u)) & 1u; };
     // every vertex of the table with UMI pu against vertex x (cell slot gx, word xw)
     auto probe = [&](uint32_t pu, uint32_t gx, uint32_t xw, bool same) {
@@ -361,24 +399,21 @@ __global__ __launch_bounds__(64) void k_p2_search(P2Args A) {
             const uint64_t hx = ch[gx], hy = ch[gy];
             if (hx != hy && !klab_overlap(klab(W, A.hw, hx, coff[gx]), klab(W, A.hw, hy, coff[gy]))) continue;
             cflag[gx] = 1; cflag[gy] = 1;
-            const uint64_t pr = dir | ((uint64_t)gx << 31) | gy;
-            const uint32_t at = atomicAdd(&s_np, 1u);
-            if (at < kP2PairBuf) s_pair[at] = pr;
-            else {   // (a partition with more pairs than the buffer: straight to the cell's list)
-                const uint32_t k = atomicAdd(&A.pair_n[j], 1u);
-                if (k < c.pair_cap) A.pairs[c.pair_base + k] = pr;
-            }
+            const uint32_t at = atomicAdd(s_np, 1u);   // (LDS, this wave's own counter)
+            if (at < pcap) ppair[at] = dir | ((uint64_t)gx << 31) | gy;
         }
     };
     const uint32_t L = A.umi_pairs;
     // own vertices
-    for (uint32_t i = lane; i < nv; i += 64) {
-        const uint64_t uw = cu[lo_p + i];
-        const uint32_t umi = (uint32_t)(uw >> 32), xw = (uint32_t)uw;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t i = (uint32_t)r * 64 + lane;
+        if (i >= nv) continue;
+        const uint32_t umi = (uint32_t)(own[r] >> 32), xw = (uint32_t)own[r];
         probe(umi, lo_p + i, xw, true);
         if (A.exact_umi) continue;
         uint64_t pmask = 0;   // bit 3 b + d - 1: that neighbour is larger, stays in the partition and passes the filter
-        for (uint32_t b = 0; b < L; ++b) {
+        for (uint32_t b = m / 2; b < L; ++b) {   // (bases below m / 2 lie inside the low m bits: every change there leaves the partition)
 #pragma unroll
             for (uint32_t d = 1; d < 4; ++d) {
                 const uint32_t mk = d << (2 * b);
@@ -393,106 +428,131 @@ __global__ __launch_bounds__(64) void k_p2_search(P2Args A) {
             probe(umi ^ ((ix % 3 + 1) << (2 * (ix / 3))), lo_p + i, xw, false);
         }
     }
-    // vertices of the partitions one low-bit change away
-    if (!A.exact_umi)
-        for (uint32_t b = 0; 2 * b < m; ++b) {
-            for (uint32_t d = 1; d < 4; ++d) {
-                const uint32_t mk = d << (2 * b), low = mk & (P - 1);
-                if (!low) continue;
-                const uint32_t q = c.part_base + (p ^ low);
-                const uint32_t nq = A.pnv[q], oq = A.poff[q];
-                for (uint32_t i = lane; i < nq; i += 64) {
-                    const uint64_t uw = cu[oq + i];
-                    const uint32_t umi = (uint32_t)(uw >> 32), pu = umi ^ mk;
-                    if (pu > umi && filt(pu)) probe(pu, oq + i, (uint32_t)uw, false);
-                }
-            }
+    // The vertices of the partitions one low-bit change away, a partition at a time (its place is in lane k's registers): the
+    // first 128 vertices of the NEXT partition are on their way while this one goes through the filter and - rarely - the table.
+    auto fetch = [&](uint32_t k, uint64_t (&v)[2], uint32_t& nq, uint32_t& oq) {
+        nq = __builtin_amdgcn_readlane(f_n, k); oq = __builtin_amdgcn_readlane(f_o, k);
+        v[0] = lane < nq ? cu[oq + lane] : 0ull;
+        v[1] = lane + 64 < nq ? cu[oq + 64 + lane] : 0ull;
+    };
+    uint64_t cur[2] = {0, 0}, nxt[2] = {0, 0};
+    uint32_t nq = 0, oq = 0, nq2 = 0, oq2 = 0;
+    if (nfor) fetch(0, cur, nq, oq);
+    for (uint32_t k = 0; k < nfor; ++k) {
+        if (k + 1 < nfor) fetch(k + 1, nxt, nq2, oq2);
+        const uint32_t mk = (k % 3 + 1) << (2 * (k / 3));
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t i = (uint32_t)r * 64 + lane;
+            if (i >= nq) continue;
+            const uint32_t umi = (uint32_t)(cur[r] >> 32), pu = umi ^ mk;
+            if (pu > umi && filt(pu)) probe(pu, oq + i, (uint32_t)cur[r], false);
         }
-    __syncthreads();
-    const uint32_t np = s_np;
-    if (np) {
-        const uint32_t nb = np < kP2PairBuf ? np : kP2PairBuf;
-        if (lane == 0) s_at = atomicAdd(&A.pair_n[j], nb);
-        __syncthreads();
-        const uint32_t at = s_at;
-        for (uint32_t i = lane; i < nb; i += 64) if (at + i < c.pair_cap) A.pairs[c.pair_base + at + i] = s_pair[i];
+        for (uint32_t i = 128 + lane; i < nq; i += 64) {   // (a partition of more than 128 vertices: the rest, plainly)
+            const uint64_t uw = cu[oq + i];
+            const uint32_t umi = (uint32_t)(uw >> 32), pu = umi ^ mk;
+            if (pu > umi && filt(pu)) probe(pu, oq + i, (uint32_t)uw, false);
+        }
+        cur[0] = nxt[0]; cur[1] = nxt[1]; nq = nq2; oq = oq2;
+    }
+    WAVE_SYNC();
+    const uint32_t np = *s_np;
+    if (lane == 0) {
+        A.pnp[gp] = np < pcap ? np : pcap;
+        if (np > pcap) A.fb[j] = 1;   // (more pairs than the partition has slots: the one-workgroup kernel takes the cell)
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // 4. one wave per partition: a vertex without an edge is a component of its own - one molecule, its label's genes
-//    (pugutils.rs:1262-1322).  Columns and two-gene classes are collected per wave and placed with one reservation each.
-__global__ __launch_bounds__(64) void k_p2_lone(P2Args A) {
-    __shared__ uint32_t s_col[256];
-    __shared__ uint32_t s_cls[512];
-    __shared__ uint32_t s_at[3];
-    const uint32_t gp = blockIdx.x, lane = threadIdx.x;
-    const uint32_t j = A.pcell[gp];
-    if (A.fb[j]) return;
+//    (pugutils.rs:1262-1322).  A partition writes its columns into the cell's column list at its own read slots (a lone
+//    vertex of slot i puts its column - or the "no column" filler, which the per-cell histogram passes over - at entry i)
+//    and its two-gene classes for the EM into its slots of a staging array: no reservation, no atomic (every wave of a
+//    cell adding to the cell's counters was the same-address queue this kernel spent its time in).
+__global__ __launch_bounds__(256) void k_p2_lone(P2Args A) {
+    __shared__ uint32_t s_cls4[4][512];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t gp = blockIdx.x * 4 + wv;
+    if (gp >= A.n_parts) return;
+    const uint32_t n = A.pcnt[gp];
+    if (n == 0) return;
     const uint32_t nv = A.pnv[gp];
-    if (nv == 0) return;
+    const uint32_t j = A.pcell[gp];
     const P2Cell c = A.cells[j];
     const CellMeta m = A.meta[c.cell];
     uint32_t* gc = A.gcnt + 4 * (size_t)j;
-    const PugCtx C = make_ctx(A, c, m, gc);   // (the counters are the cell's global ones here: rare paths add to them directly)
-    const uint64_t o = c.rd_base + A.poff[gp];
-    uint32_t ncol = 0, ncls = 0;   // wave-uniform
-    for (uint32_t i = lane; i - lane < nv; i += 64) {
-        uint32_t col = 0xFFFFFFFFu, k0 = 0, k1 = 0;
-        bool cls = false;
-        if (i < nv && !A.v_flag[o + i]) {
-            const uint64_t h = A.s_h[o + i];
-            const uint32_t tag = (uint32_t)(h >> 62);
-            if (tag == 1 || tag == 2) {
-                const uint32_t ga = C.t2g[tag == 1 ? (uint32_t)h & 0x7FFFFFFFu : (uint32_t)(h >> 31) & 0x7FFFFFFFu];
-                const uint32_t gb = tag == 2 ? C.t2g[(uint32_t)h & 0x7FFFFFFFu] : ga;
-                const uint32_t lo = ga < gb ? ga : gb, hi = ga < gb ? gb : ga;
-                col = molecule2_column(C, lo, hi, lo == hi ? 1u : 2u, cls);
-                k0 = lo; k1 = hi;
-            } else if (tag == 3) {
-                const Lab l = rec_label(C, A.v_off[o + i]);
-                if (l.n <= 4) {
-                    uint32_t g4[4];
+    const PugCtx C = make_ctx(A, c, m, gc);   // (the counters are the cell's global ones here: the rare class writes add to them directly)
+    const uint32_t lo_p = A.poff[gp];
+    const uint64_t o = c.rd_base + lo_p;
+    uint32_t* s_cls = s_cls4[wv];
+    uint32_t ncls = 0;   // wave-uniform
+    for (uint32_t i0 = lane; i0 - lane < n; i0 += 128) {
+        uint64_t h2[2];
+        uint32_t fl[2];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) g4[q] = (uint32_t)q < l.n ? l.p[q] & 0x7FFFFFFFu : 0xFFFFFFFFu;
-                    const uint32_t ng = genes_of4(C, g4, l.n);
-                    col = molecule4_column(C, g4, ng, cls);
-                    k0 = g4[0]; k1 = g4[1];
-                } else {
-                    uint32_t g[kMaxGenesPerLabel];
-                    const uint32_t ng = genes_of(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; }, g);
-                    if (ng == 0xFFFFFFFFu && C.em) emit_wide_class(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; });
-                    else col = molecule_column_n(C, g, ng);
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t i = i0 + (uint32_t)r * 64;
+            h2[r] = i < nv ? A.s_h[o + i] : 0ull;
+            fl[r] = i < nv ? A.v_flag[o + i] : 1u;
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t i = i0 + (uint32_t)r * 64;
+            uint32_t col = 0xFFFFFFFFu, k0 = 0, k1 = 0;
+            bool cls = false;
+            if (!fl[r]) {
+                const uint64_t h = h2[r];
+                const uint32_t tag = (uint32_t)(h >> 62);
+                if (tag == 1 || tag == 2) {
+                    const uint32_t ga = C.t2g[tag == 1 ? (uint32_t)h & 0x7FFFFFFFu : (uint32_t)(h >> 31) & 0x7FFFFFFFu];
+                    const uint32_t gb = tag == 2 ? C.t2g[(uint32_t)h & 0x7FFFFFFFu] : ga;
+                    const uint32_t lo = ga < gb ? ga : gb, hi = ga < gb ? gb : ga;
+                    col = molecule2_column(C, lo, hi, lo == hi ? 1u : 2u, cls);
+                    k0 = lo; k1 = hi;
+                } else if (tag == 3) {
+                    const Lab l = rec_label(C, A.v_off[o + i]);
+                    if (l.n <= 4) {
+                        uint32_t g4[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) g4[q] = (uint32_t)q < l.n ? l.p[q] & 0x7FFFFFFFu : 0xFFFFFFFFu;
+                        const uint32_t ng = genes_of4(C, g4, l.n);
+                        col = molecule4_column(C, g4, ng, cls);
+                        k0 = g4[0]; k1 = g4[1];
+                    } else {
+                        uint32_t g[kMaxGenesPerLabel];
+                        const uint32_t ng = genes_of(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; }, g);
+                        if (ng == 0xFFFFFFFFu && C.em) emit_wide_class(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; });
+                        else col = molecule_column_n(C, g, ng);
+                    }
                 }
             }
+            if (i < n) C.cols[lo_p + i] = col;
+            const uint64_t mk = __ballot(cls);
+            if (cls) { const uint32_t q = ncls + (uint32_t)__popcll(mk & ((1ull << lane) - 1)); s_cls[2 * q] = k0; s_cls[2 * q + 1] = k1; }
+            ncls += (uint32_t)__popcll(mk);
         }
-        const uint64_t mc = __ballot(col != 0xFFFFFFFFu), mk = __ballot(cls);
-        if (col != 0xFFFFFFFFu) s_col[ncol + (uint32_t)__popcll(mc & ((1ull << lane) - 1))] = col;
-        if (cls) { const uint32_t r = ncls + (uint32_t)__popcll(mk & ((1ull << lane) - 1)); s_cls[2 * r] = k0; s_cls[2 * r + 1] = k1; }
-        ncol += (uint32_t)__popcll(mc); ncls += (uint32_t)__popcll(mk);
     }
-    __syncthreads();
-    if (lane == 0) {
-        s_at[0] = ncol ? atomicAdd(&gc[0], ncol) : 0u;
-        s_at[1] = ncls ? atomicAdd(&gc[1], 2 * ncls) : 0u;
-        s_at[2] = ncls ? atomicAdd(&gc[2], ncls) : 0u;
-    }
-    __syncthreads();
-    for (uint32_t i = lane; i < ncol; i += 64) { const uint32_t q = s_at[0] + i; if (q >= C.cols_cap) gc[3] = kErrPugLimit; else C.cols[q] = s_col[i]; }
-    for (uint32_t i = lane; i < ncls; i += 64) {
-        const uint32_t w = s_at[1] + 2 * i, d = s_at[2] + i;
-        if (w + 2 > C.lab_cap || 2 * (d + 1) > C.lab_cap) { gc[3] = kErrPugLimit; continue; }
-        C.labw[w] = s_cls[2 * i]; C.labw[w + 1] = s_cls[2 * i + 1];
-        C.labd[2 * d] = w; C.labd[2 * d + 1] = 2;
-    }
+    if (!ncls) return;
+    WAVE_SYNC();
+    uint64_t* stage = A.cstage + o;   // (at most one class per vertex: the partition's own slots hold them; the graph kernel moves them into the cell's label area)
+    for (uint32_t i = lane; i < ncls; i += 64) stage[i] = ((uint64_t)s_cls[2 * i + 1] << 32) | s_cls[2 * i];
+    if (lane == 0) A.pncls[gp] = ncls;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// 5. one 256-thread workgroup per cell: the vertices that have an edge.
+// 5. one workgroup per cell: the vertices that have an edge (about a quarter of them) - components, the two-vertex rule,
+//    the covers.  Everything is sized by the pairs the search left; nothing here walks the cell's reads, and the one pass over
+//    the cell's vertices (class minima, below) reads eight bytes per vertex.
+#ifdef AFQ_PUG_TIMING
+#define G_MARK(i) do { __syncthreads(); if (threadIdx.x == 0) tmark[i] = wall_clock64(); } while (0)
+#else
+#define G_MARK(i) do {} while (0)
+#endif
 constexpr int kGNT = 256;
 constexpr uint32_t kGLds = 8192;          // words of the phase-shared LDS block (32 KiB)
-constexpr uint32_t kGTab = 2048;          // class table slots (keys: 16 KiB, minima: 8 KiB of the block)
-constexpr uint32_t kGTabLoad = 1300;      // classes a slice may bring
+constexpr uint32_t kGTab = 2048;          // class table slots when it lives in LDS (keys: 16 KiB, minima: 8 KiB of the block)
+constexpr uint32_t kGTabLoad = 1200;      // ... and the classes it takes; beyond that the table is carved out of the pool
+constexpr uint32_t kCatPair = 1, kCatTiny = 2, kCatMid = 3;
 
 __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
     __shared__ __attribute__((aligned(16))) uint32_t s_big[kGLds];
@@ -501,6 +561,9 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
     __shared__ uint32_t s_flag[4];
     __shared__ unsigned long long s_ebase;
     __shared__ uint32_t s_next;
+#ifdef AFQ_PUG_TIMING
+    __shared__ unsigned long long tmark[16];
+#endif
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   for (;;) {
     __syncthreads();
@@ -516,18 +579,53 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
         if (tid == 0) { A.fb[j] = 1; A.fb_list[atomicAdd(A.fb_count, 1u)] = c.cell; }
     };
     if (A.fb[j]) { if (tid == 0) A.fb_list[atomicAdd(A.fb_count, 1u)] = c.cell; continue; }
-    const uint32_t n_pairs = A.pair_n[j];
-    if (n_pairs > c.pair_cap) { give_up(); continue; }
     uint32_t* gc = A.gcnt + 4 * (size_t)j;
-    if (tid < 4) { s_cnt[tid] = gc[tid]; s_flag[tid] = 0; }
+    if (tid < 4) { s_cnt[tid] = tid == 0 ? R : gc[tid]; s_flag[tid] = 0; }   // (entries 0..R of the column list belong to the lone-vertex kernel)
     __syncthreads();
     PugCtx C = make_ctx(A, c, m, s_cnt);
     const uint64_t* ch = A.s_h + c.rd_base;
     const uint64_t* cu = A.s_u + c.rd_base;
     const uint32_t* coff = A.v_off + c.rd_base;
-    const uint8_t* cflag = A.v_flag + c.rd_base;
     uint32_t* lidx = A.lidx + c.rd_base;
-    const uint64_t* pairs = A.pairs + c.pair_base;
+    G_MARK(0);
+    // ---- 0. what the partition kernels left per partition: pairs (search), two-gene classes (lone vertices), vertices under
+    //         a hashed label key ----
+    const uint32_t P = 1u << c.lgP;
+    const uint32_t* pnp = A.pnp + c.part_base;
+    const uint32_t* pncls = A.pncls + c.part_base;
+    const uint32_t* pn3 = A.pn3 + c.part_base;
+    const uint32_t* ppoff = A.poff + c.part_base;
+    uint32_t n_pairs = 0, n_cls2 = 0, n3 = 0;
+    uint32_t* ppre = P <= kGLds / 2 ? s_big : nullptr;   // per partition: first pair | first class
+    for (uint32_t base = 0; base < P; base += kGNT) {
+        const uint32_t pp = base + tid;
+        const uint32_t a = pp < P ? pnp[pp] : 0u, b = pp < P ? pncls[pp] : 0u, d = pp < P ? pn3[pp] : 0u;
+        uint32_t ta, tb, td;
+        const uint32_t ea = block_excl_scan<kGNT>(a, s_ws, ta);
+        const uint32_t eb = block_excl_scan<kGNT>(b, s_ws, tb);
+        (void)block_excl_scan<kGNT>(d, s_ws, td);
+        if (ppre && pp < P) { ppre[2 * pp] = n_pairs + ea; ppre[2 * pp + 1] = n_cls2 + eb; }
+        n_pairs += ta; n_cls2 += tb; n3 += td;
+    }
+    __syncthreads();
+    if (!ppre) { give_up(); continue; }   // (more than 4096 partitions: cells of over 650 k reads)
+    if (n_cls2) {   // the lone vertices' classes into the cell's label area (em only)
+        const uint32_t w0 = s_cnt[1], d0 = s_cnt[2];
+        if (w0 + 2 * n_cls2 > C.lab_cap || 2 * (d0 + n_cls2) > C.lab_cap) { if (tid == 0) set_err(A.st, kErrPugLimit, c.cell); return; }
+        const uint64_t* stage = A.cstage + c.rd_base;
+        for (uint32_t pp = tid; pp < P; pp += kGNT) {
+            const uint32_t nk = pncls[pp], at = ppre[2 * pp + 1], so = ppoff[pp];
+            for (uint32_t k = 0; k < nk; ++k) {
+                const uint64_t v = stage[so + k];
+                const uint32_t w = w0 + 2 * (at + k), d = d0 + at + k;
+                C.labw[w] = (uint32_t)v; C.labw[w + 1] = (uint32_t)(v >> 32);
+                C.labd[2 * d] = w; C.labd[2 * d + 1] = 2;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) { s_cnt[1] = w0 + 2 * n_cls2; s_cnt[2] = d0 + n_cls2; }
+        __syncthreads();
+    }
     // ---- scratch out of the pool: everything is sized by the vertices that have an edge ----
     const uint32_t nt_max = min(R, 2 * n_pairs);
     const unsigned long long need = 26ull * nt_max + 2ull * n_pairs + 64;
@@ -536,77 +634,68 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
     if (s_ebase + need > A.pool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, c.cell); return; }
     uint32_t* q = A.pool + ((s_ebase + 3) & ~3ull);
     uint4* mrec = reinterpret_cast<uint4*>(q); q += 8 * (size_t)nt_max;                 // (16-byte aligned)
-    uint64_t* comp_sorted = reinterpret_cast<uint64_t*>(q); q += 2 * (size_t)nt_max;
-    uint64_t* okey = reinterpret_cast<uint64_t*>(q); q += 2 * (size_t)nt_max;
-    uint32_t* tl = q; q += nt_max;            // touched vertices (cell slots), ascending
-    uint32_t* eoff = q; q += nt_max + 2;      // out-degree, then edge offsets
-    uint32_t* ecur = q; q += nt_max;
+    uint64_t* lp = reinterpret_cast<uint64_t*>(q); q += 2 * (size_t)n_pairs;            // pairs over local ids: x | y << 20 | directions << 40
+    uint64_t* okey = reinterpret_cast<uint64_t*>(q); q += 2 * (size_t)nt_max;           // per slot of a listed component: (class minimum, UMI)
+    unsigned long long* adj = reinterpret_cast<unsigned long long*>(q); q += 2 * (size_t)nt_max;   // per vertex: out-neighbours as positions inside its component
+    uint32_t* tl = q; q += nt_max;            // touched vertex -> its slot in the cell
     uint32_t* wlg = q; q += nt_max;           // component labels when they do not fit LDS
-    uint32_t* comp_start = q; q += nt_max + 2;
+    uint32_t* root_of = q; q += nt_max;
+    uint32_t* rcnt = q; q += nt_max;          // per root: vertices of its component, then its place in the lists (category << 28 | index)
+    uint32_t* fill = q; q += nt_max;
     uint32_t* cidx = q; q += nt_max;          // position of a vertex inside its component (reference order)
-    uint32_t* mid_list = q; q += nt_max;      // components of 3..8 vertices first, then 9..64
-    uint32_t* mid_off = q; q += nt_max + 2;
-    uint32_t* slot_comp = q; q += nt_max;
-    uint32_t* cmin = q; q += nt_max;          // smallest record offset of the vertex's class (vertices of listed components)
-    uint32_t* pr_list = q; q += nt_max;       // two-vertex components
-    uint32_t* edges = q;                      // [2 * n_pairs]
-    // ---- 1. the touched vertices, and how many vertices carry a hashed label key ----
-    uint32_t NT = 0, n3 = 0;
-    for (uint32_t base = 0; base < R; base += kGNT) {
-        const uint32_t g = base + tid;
-        const bool valid = g < R && (uint32_t)cu[g] != 0;
-        const bool t = valid && cflag[g];
-        const bool h3 = valid && (ch[g] >> 62) == 3;
-        uint32_t tot;
-        const uint32_t ex = block_excl_scan<kGNT>((uint32_t)t | ((uint32_t)h3 << 16), s_ws, tot);
-        if (t) { const uint32_t li = NT + (ex & 0xFFFFu); if (li < nt_max) { tl[li] = g; lidx[g] = li; } }
-        NT += tot & 0xFFFFu; n3 += tot >> 16;
-    }
-    if (NT > nt_max) { if (tid == 0) set_err(A.st, kErrPugLimit, c.cell); return; }   // (cannot happen: a flag is set with a pair)
-    // ---- 2. edges as adjacency lists over local ids ----
-    for (uint32_t i = tid; i <= NT; i += kGNT) { eoff[i] = 0; if (i < NT) ecur[i] = 0; }
+    uint32_t* lsize = q; q += nt_max;         // per listed component: size
+    uint32_t* mid_off = q; q += nt_max + 2;   // ... first slot
+    uint32_t* slot_v = q; q += nt_max;        // slot -> vertex
+    uint32_t* slot_comp = q; q += nt_max;     // slot -> listed component
+    uint32_t* cmin = q; q += nt_max;          // per slot: smallest record offset of the vertex's class
+    uint32_t* pr_v = q;                       // two-vertex components: their vertices, two by two
+    G_MARK(1);
+    // ---- 1. the touched vertices = the pairs' end points; the first thread to meet one gives it its local id
+    //         (any numbering will do: the reference's order enters through the order keys of step 6 only) ----
+    const uint64_t* psrc = A.pairs + c.rd_base;
+    if (tid == 0) s_flag[3] = 0;
     __syncthreads();
-    for (uint32_t k = tid; k < n_pairs; k += kGNT) {
-        const uint64_t pr = pairs[k];
-        const uint32_t lx = lidx[(uint32_t)(pr >> 31) & 0x7FFFFFFFu], ly = lidx[(uint32_t)pr & 0x7FFFFFFFu];
-        if (pr & kPairF) wg_add(&eoff[lx], 1u);
-        if (pr & kPairB) wg_add(&eoff[ly], 1u);
+    for (uint32_t pp = tid; pp < P; pp += kGNT) {
+        const uint32_t nk = pnp[pp], so = ppoff[pp];
+        for (uint32_t k = 0; k < 2 * nk; ++k) {
+            const uint64_t pr = psrc[so + (k >> 1)];
+            const uint32_t g = (k & 1u) ? (uint32_t)pr & 0x7FFFFFFFu : (uint32_t)(pr >> 31) & 0x7FFFFFFFu;
+            if (__hip_atomic_load(&lidx[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0xFFFFFFFFu) continue;
+            unsigned int expected = 0xFFFFFFFFu;
+            if (__hip_atomic_compare_exchange_strong(&lidx[g], &expected, 0xFFFFFFFEu, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                const uint32_t li = atomicAdd(&s_flag[3], 1u);
+                if (li < nt_max) tl[li] = g;
+                __hip_atomic_store(&lidx[g], li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
     }
     __syncthreads();
-    uint32_t Etot = 0;
-    for (uint32_t base = 0; base < NT; base += kGNT) {
-        const uint32_t i = base + tid;
-        const uint32_t d = i < NT ? eoff[i] : 0u;
-        uint32_t tot;
-        const uint32_t ex = block_excl_scan<kGNT>(d, s_ws, tot);
-        __syncthreads();
-        if (i < NT) eoff[i] = Etot + ex;
-        Etot += tot;
-    }
-    if (tid == 0) eoff[NT] = Etot;
-    __syncthreads();
-    for (uint32_t k = tid; k < n_pairs; k += kGNT) {
-        const uint64_t pr = pairs[k];
-        const uint32_t lx = lidx[(uint32_t)(pr >> 31) & 0x7FFFFFFFu], ly = lidx[(uint32_t)pr & 0x7FFFFFFFu];
-        if (pr & kPairF) edges[eoff[lx] + wg_add(&ecur[lx], 1u)] = ly;
-        if (pr & kPairB) edges[eoff[ly] + wg_add(&ecur[ly], 1u)] = lx;
+    const uint32_t NT = s_flag[3];
+    if (NT > nt_max || NT >= (1u << 20)) { if (tid == 0) set_err(A.st, kErrPugLimit, c.cell); return; }   // (cannot happen: two end points per pair, R < 2^20)
+    for (uint32_t pp = tid; pp < P; pp += kGNT) {
+        const uint32_t nk = pnp[pp], so = ppoff[pp], at = ppre[2 * pp];
+        for (uint32_t k = 0; k < nk; ++k) {
+            const uint64_t pr = psrc[so + k];
+            const uint32_t lx = lidx[(uint32_t)(pr >> 31) & 0x7FFFFFFFu], ly = lidx[(uint32_t)pr & 0x7FFFFFFFu];
+            lp[at + k] = (uint64_t)lx | ((uint64_t)ly << 20) | ((pr >> 62) << 40);
+        }
     }
     __syncthreads();
-    // ---- 3. weakly connected components: min-label propagation + pointer jumping (labels in LDS when they fit) ----
+    G_MARK(2);
+    // ---- 2. weakly connected components over the pair list: min-label propagation + pointer jumping (labels in LDS when they fit) ----
     uint32_t* wl = NT <= kGLds ? s_big : wlg;
-    for (uint32_t i = tid; i < NT; i += kGNT) wl[i] = i;
+    for (uint32_t i = tid; i < NT; i += kGNT) { wl[i] = i; rcnt[i] = 0; fill[i] = 0; adj[i] = 0; }
     __syncthreads();
     for (;;) {
         if (tid == 0) s_flag[0] = 0;
         __syncthreads();
         bool chg = false;
-        for (uint32_t i = tid; i < NT; i += kGNT) {
-            for (uint32_t e = eoff[i]; e < eoff[i + 1]; ++e) {
-                const uint32_t y = edges[e];
-                const uint32_t a = wl[i], b = wl[y];
-                if (a < b) { wg_min(&wl[y], a); chg = true; }
-                else if (b < a) { wg_min(&wl[i], b); chg = true; }
-            }
+        for (uint32_t k = tid; k < n_pairs; k += kGNT) {
+            const uint64_t e = lp[k];
+            const uint32_t x = (uint32_t)e & 0xFFFFFu, y = (uint32_t)(e >> 20) & 0xFFFFFu;
+            const uint32_t a = wl[x], b = wl[y];
+            if (a < b) { wg_min(&wl[y], a); chg = true; }
+            else if (b < a) { wg_min(&wl[x], b); chg = true; }
         }
         if (chg) s_flag[0] = 1;
         __syncthreads();
@@ -616,50 +705,43 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
         }
         if (!s_flag[0]) break;
     }
-    for (uint32_t i = tid; i < NT; i += kGNT) { uint32_t l = wl[i]; while (wl[l] != l) l = wl[l]; comp_sorted[i] = ((uint64_t)l << 20) | i; }
+    G_MARK(3);
+    // ---- 3. the components by counting: sizes per root, then by size pairs / 3..8 / 9..64 (anything else is not for this
+    //         kernel), every listed component's slots, every vertex into its component's next slot ----
+    for (uint32_t i = tid; i < NT; i += kGNT) { uint32_t l = wl[i]; while (wl[l] != l) l = wl[l]; root_of[i] = l; wg_add(&rcnt[l], 1u); }
     __syncthreads();
-    tiled_bitonic_sort_by<kGNT, kGLds / 2>(comp_sorted, NT, [](uint64_t a, uint64_t b) { return a > b; }, reinterpret_cast<uint64_t*>(s_big));
-    uint32_t NC = 0;
+    uint32_t n_pr = 0, n_tiny = 0, n_mid9 = 0;
+    bool big = false;
     for (uint32_t base = 0; base < NT; base += kGNT) {
         const uint32_t i = base + tid;
-        const bool hd = i < NT && (i == 0 || (comp_sorted[i] >> 20) != (comp_sorted[i - 1] >> 20));
-        uint32_t tot;
-        const uint32_t ex = block_excl_scan<kGNT>(hd, s_ws, tot);
-        if (hd) comp_start[NC + ex] = i;
-        NC += tot;
-    }
-    if (tid == 0) comp_start[NC] = NT;
-    __syncthreads();
-    // ---- 4. the components by size: pairs, 3..8, 9..64; anything else is not for this kernel ----
-    {
-        uint32_t tiny = 0;
-        bool big = false;
-        for (uint32_t k = tid; k < NC; k += kGNT) {
-            const uint32_t n = comp_start[k + 1] - comp_start[k];
-            big = big || n > 64 || n > C.large_thresh;
-            tiny += n >= 3 && n <= 8;
+        uint32_t cat = 0;
+        if (i < NT && root_of[i] == i) {
+            const uint32_t n = rcnt[i];
+            if (n > 64 || n > C.large_thresh) big = true;
+            else cat = n == 2 ? kCatPair : n <= 8 ? kCatTiny : kCatMid;
         }
-        if (big) s_flag[1] = 1;
-        if (tiny) atomicAdd(&s_flag[2], tiny);
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<kGNT>((cat == kCatPair) | ((uint32_t)(cat == kCatTiny) << 10) | ((uint32_t)(cat == kCatMid) << 20), s_ws, tot);
+        if (cat) {
+            const uint32_t idx = cat == kCatPair ? n_pr + (ex & 0x3FFu) : cat == kCatTiny ? n_tiny + ((ex >> 10) & 0x3FFu) : n_mid9 + (ex >> 20);
+            const uint32_t n = rcnt[i];
+            rcnt[i] = (cat << 28) | idx;                   // (a root's word is read and written by its own thread only in this pass)
+            if (cat == kCatTiny) lsize[idx] = n;          // (the 9..64 ones are placed behind the small ones once those are counted)
+            else if (cat == kCatMid) fill[i] = n;          // (parked in the root's fill word until then)
+        }
+        n_pr += tot & 0x3FFu; n_tiny += (tot >> 10) & 0x3FFu; n_mid9 += tot >> 20;
     }
+    if (big) s_flag[1] = 1;
     __syncthreads();
     if (s_flag[1]) { give_up(); continue; }
-    const uint32_t n_tiny = s_flag[2];
+    const uint32_t n_mid = n_tiny + n_mid9;
+    for (uint32_t i = tid; i < NT; i += kGNT)
+        if (root_of[i] == i && (rcnt[i] >> 28) == kCatMid) { lsize[n_tiny + (rcnt[i] & 0xFFFFFFFu)] = fill[i]; fill[i] = 0; }
     __syncthreads();
-    if (tid < 4) s_flag[tid] = 0;
-    __syncthreads();
-    for (uint32_t k = tid; k < NC; k += kGNT) {
-        const uint32_t n = comp_start[k + 1] - comp_start[k];
-        if (n == 2) pr_list[atomicAdd(&s_flag[2], 1u)] = k;
-        else if (n <= 8) mid_list[atomicAdd(&s_flag[0], 1u)] = k;
-        else mid_list[n_tiny + atomicAdd(&s_flag[1], 1u)] = k;
-    }
-    __syncthreads();
-    const uint32_t n_mid = n_tiny + s_flag[1], n_pr = s_flag[2];
     uint32_t S_mid = 0;
     for (uint32_t base = 0; base < n_mid; base += kGNT) {
         const uint32_t ci = base + tid;
-        const uint32_t n = ci < n_mid ? comp_start[mid_list[ci] + 1] - comp_start[mid_list[ci]] : 0u;
+        const uint32_t n = ci < n_mid ? lsize[ci] : 0u;
         uint32_t tot;
         const uint32_t ex = block_excl_scan<kGNT>(n, s_ws, tot);
         if (ci < n_mid) mid_off[ci] = S_mid + ex;
@@ -667,86 +749,98 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
     }
     if (tid == 0) mid_off[n_mid] = S_mid;
     __syncthreads();
-    for (uint32_t ci = tid; ci < n_mid; ci += kGNT) {
-        const uint32_t b0 = mid_off[ci], n = mid_off[ci + 1] - b0;
-        for (uint32_t i = 0; i < n; ++i) slot_comp[b0 + i] = ci;
+    for (uint32_t i = tid; i < NT; i += kGNT) {
+        const uint32_t r = root_of[i], rc = rcnt[r], cat = rc >> 28, idx = rc & 0xFFFFFFFu;
+        const uint32_t at = wg_add(&fill[r], 1u);
+        if (cat == kCatPair) pr_v[2 * idx + at] = i;
+        else {
+            const uint32_t ci = cat == kCatTiny ? idx : n_tiny + idx;
+            const uint32_t sl = mid_off[ci] + at;
+            slot_v[sl] = i; slot_comp[sl] = ci;
+        }
     }
     __syncthreads();
-    auto vid_at = [&](uint32_t i) -> uint32_t { return (uint32_t)comp_sorted[i] & 0xFFFFFu; };   // local id
-    // ---- 5. class minima: for the classes of the listed components' vertices (their order decides ties) and for every
-    //         class under a hashed key (equal keys must be equal labels).  The cell's vertices stream through an LDS table
-    //         keyed by label key, a slice of the key space at a time when the classes outnumber it. ----
+    G_MARK(4);
+    // ---- 4. class minima: for the classes of the listed components' vertices (their order decides ties) and for every
+    //         class under a hashed key (equal keys must be equal labels).  The cell's vertex slots stream ONCE through a hash
+    //         table keyed by label key (slots past a partition's last vertex hold key 0: no class) - in LDS when the classes
+    //         are few, out of the pool otherwise.  A vertex under a hashed key is compared with the vertex that held the
+    //         minimum before it - whichever that was, so every vertex of the class is chained to the first one that arrived. ----
     if (n3 || S_mid) {
+        const uint32_t want = n3 + S_mid;   // (vertices, an upper bound of the classes)
+        uint32_t cap = kGTab;
         unsigned long long* t_key = reinterpret_cast<unsigned long long*>(s_big);
         uint32_t* t_min = s_big + 2 * kGTab;
-        const uint32_t n_slices = (n3 + S_mid + kGTabLoad - 1) / kGTabLoad;
-        auto mix = [](uint64_t h) -> uint32_t { return ((uint32_t)h ^ (uint32_t)(h >> 32)) * 0x9E3779B1u; };
-        auto slice_of = [&](uint32_t mx) -> uint32_t { return n_slices == 1 ? 0u : (mx >> 11) % n_slices; };
-        auto find = [&](uint64_t h, uint32_t mx, bool insert) -> uint32_t {   // slot of h, or kGTab
-            uint32_t slot = mx & (kGTab - 1);
-            for (uint32_t step = 0; step < kGTab; ++step, slot = (slot + 1) & (kGTab - 1)) {
-                unsigned long long k = t_key[slot];
+        uint32_t* s_bloom = t_min + kGTab;   // 2048 words left of the block: 4096 bits for the asked-for keys
+        if (want > kGTabLoad) {
+            while (cap < 2 * want) cap <<= 1;
+            if (tid == 0) s_ebase = atomicAdd(A.pool_cur, 3ull * cap + 4);
+            __syncthreads();
+            if (s_ebase + 3ull * cap + 4 > A.pool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, c.cell); return; }
+            t_key = reinterpret_cast<unsigned long long*>(A.pool + ((s_ebase + 1) & ~1ull));
+            t_min = reinterpret_cast<uint32_t*>(t_key + cap);
+        }
+        const uint32_t cmask = cap - 1;
+        auto mix = [](uint64_t h) -> uint32_t { uint32_t x = ((uint32_t)h ^ (uint32_t)(h >> 32)) * 0x9E3779B1u; return x ^ (x >> 15); };
+        auto find = [&](uint64_t h, uint32_t mx, bool insert) -> uint32_t {   // slot of h, or 0xFFFFFFFF
+            uint32_t slot = mx & cmask;
+            for (uint32_t step = 0; step < cap; ++step, slot = (slot + 1) & cmask) {
+                unsigned long long k = __hip_atomic_load(&t_key[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (k == h) return slot;
                 if (k == ~0ull) {
-                    if (!insert) return kGTab;
-                    k = atomicCAS(&t_key[slot], ~0ull, (unsigned long long)h);
-                    if (k == ~0ull || k == h) return slot;
+                    if (!insert) return 0xFFFFFFFFu;
+                    unsigned long long expected = ~0ull;
+                    if (__hip_atomic_compare_exchange_strong(&t_key[slot], &expected, (unsigned long long)h, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return slot;
+                    if (expected == h) return slot;
                 }
             }
-            return kGTab;
+            return 0xFFFFFFFFu;
         };
-        for (uint32_t sl = 0; sl < n_slices; ++sl) {
-            __syncthreads();
-            for (uint32_t i = tid; i < kGTab; i += kGNT) { t_key[i] = ~0ull; t_min[i] = 0xFFFFFFFFu; }
-            __syncthreads();
-            for (uint32_t s = tid; s < S_mid; s += kGNT) {   // the classes that are asked for
-                const uint32_t ci = slot_comp[s];
-                const uint64_t h = ch[tl[vid_at(comp_start[mid_list[ci]] + (s - mid_off[ci]))]];
+        __syncthreads();
+        for (uint32_t i = tid; i < cap; i += kGNT) { t_key[i] = ~0ull; t_min[i] = 0xFFFFFFFFu; }
+        for (uint32_t i = tid; i < 128; i += kGNT) s_bloom[i] = 0;
+        __syncthreads();
+        for (uint32_t s2 = tid; s2 < S_mid; s2 += kGNT) {   // the classes that are asked for
+            const uint64_t h = ch[tl[slot_v[s2]]];
+            const uint32_t mx = mix(h);
+            atomicOr(&s_bloom[(mx >> 20) >> 5], 1u << ((mx >> 20) & 31u));
+            (void)find(h, mx, true);
+        }
+        __syncthreads();
+        for (uint32_t g0 = tid; g0 - tid < R; g0 += 4 * kGNT) {   // four slots per thread and trip, their loads in flight together
+            uint64_t h4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h4[r] = g0 + (uint32_t)r * kGNT < R ? ch[g0 + (uint32_t)r * kGNT] : 0ull;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint64_t h = h4[r];
+                if (h == 0) continue;
                 const uint32_t mx = mix(h);
-                if (slice_of(mx) == sl && find(h, mx, true) == kGTab) s_flag[3] = 1;
-            }
-            __syncthreads();
-            for (uint32_t g = tid; g < R; g += kGNT) {
-                if ((uint32_t)cu[g] == 0) continue;
-                const uint64_t h = ch[g];
-                const uint32_t mx = mix(h);
-                if (slice_of(mx) != sl) continue;
-                const uint32_t slot = find(h, mx, (h >> 62) == 3);
-                if (slot != kGTab) atomicMin(&t_min[slot], coff[g]);
-                else if ((h >> 62) == 3) s_flag[3] = 1;
-            }
-            __syncthreads();
-            if (s_flag[3]) break;
-            if (n3)
-                for (uint32_t g = tid; g < R; g += kGNT) {   // every vertex under a hashed key against its class's first record
-                    if ((uint32_t)cu[g] == 0) continue;
-                    const uint64_t h = ch[g];
-                    if ((h >> 62) != 3) continue;
-                    const uint32_t mx = mix(h);
-                    if (slice_of(mx) != sl) continue;
-                    const uint32_t rep = t_min[find(h, mx, false)], off = coff[g];
-                    if (rep != off && !lab_equal(rec_label(C, off), rec_label(C, rep))) s_cnt[3] = kErrLabelHash;
-                }
-            for (uint32_t s = tid; s < S_mid; s += kGNT) {
-                const uint32_t ci = slot_comp[s];
-                const uint32_t li = vid_at(comp_start[mid_list[ci]] + (s - mid_off[ci]));
-                const uint64_t h = ch[tl[li]];
-                const uint32_t mx = mix(h);
-                if (slice_of(mx) == sl) cmin[li] = t_min[find(h, mx, false)];
+                const bool hashed = (h >> 62) == 3;
+                if (!hashed && !((s_bloom[(mx >> 20) >> 5] >> ((mx >> 20) & 31u)) & 1u)) continue;
+                const uint32_t slot = find(h, mx, hashed);
+                if (slot == 0xFFFFFFFFu) continue;
+                const uint32_t off = coff[g0 + (uint32_t)r * kGNT];
+                const uint32_t old = wg_min(&t_min[slot], off);
+                if (hashed && old != 0xFFFFFFFFu && old != off && !lab_equal(rec_label(C, off), rec_label(C, old))) s_cnt[3] = kErrLabelHash;
             }
         }
         __syncthreads();
-        if (s_flag[3]) { give_up(); continue; }   // (a slice with more classes than the table: cannot happen with the slice count above)
+        for (uint32_t s2 = tid; s2 < S_mid; s2 += kGNT) {
+            const uint64_t h = ch[tl[slot_v[s2]]];
+            cmin[s2] = t_min[find(h, mix(h), false)];
+        }
+        __syncthreads();
         if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], c.cell); return; }
     }
     __syncthreads();
-    // ---- 6. two-vertex components: one molecule, the refs both labels share (pugutils.rs:1161-1188) ----
+    G_MARK(5);
+    // ---- 5. two-vertex components: one molecule, the refs both labels share (pugutils.rs:1161-1188) ----
     for (uint32_t k = tid; k - lane < n_pr; k += kGNT) {   // (wave-uniform trip count: append_cols is a wave-wide call)
         uint32_t col = 0xFFFFFFFFu, k0 = 0, k1 = 0;
         bool cls = false;
         if (k < n_pr) {
-            const uint32_t i0 = comp_start[pr_list[k]];
-            const uint32_t ga = tl[vid_at(i0)], gb = tl[vid_at(i0 + 1)];
+            const uint32_t ga = tl[pr_v[2 * k]], gb = tl[pr_v[2 * k + 1]];
             const KLab l = klab(C.W, C.HW, ch[ga], coff[ga]), l2 = klab(C.W, C.HW, ch[gb], coff[gb]);
             if (l.n <= 4) {
                 uint32_t g4[4];
@@ -789,26 +883,30 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
         append_cols(C, col);
         append_class2(C, cls, k0, k1);
     }
-    // ---- 7. components of 3..64 vertices: their vertices in the reference's order, gathered into the covers' records ----
-    for (uint32_t s = tid; s < S_mid; s += kGNT) {   // order key of every listed vertex; rank inside its component
-        const uint32_t ci = slot_comp[s];
-        const uint32_t li = vid_at(comp_start[mid_list[ci]] + (s - mid_off[ci]));
-        okey[s] = ((uint64_t)cmin[li] << 32) | (uint32_t)(cu[tl[li]] >> 32);
-    }
+    G_MARK(6);
+    // ---- 6. components of 3..64 vertices: their vertices in the reference's order (class by first appearance = smallest
+    //         record offset, then UMI), the edges between them as masks over those positions, gathered into the covers' records ----
+    for (uint32_t s2 = tid; s2 < S_mid; s2 += kGNT) okey[s2] = ((uint64_t)cmin[s2] << 32) | (uint32_t)(cu[tl[slot_v[s2]]] >> 32);
     __syncthreads();
-    for (uint32_t s = tid; s < S_mid; s += kGNT) {
-        const uint32_t ci = slot_comp[s];
+    for (uint32_t s2 = tid; s2 < S_mid; s2 += kGNT) {
+        const uint32_t ci = slot_comp[s2];
         const uint32_t b0 = mid_off[ci], n = mid_off[ci + 1] - b0;
-        const uint64_t mine = okey[s];
+        const uint64_t mine = okey[s2];
         uint32_t rank = 0;
         for (uint32_t i = 0; i < n; ++i) rank += okey[b0 + i] < mine;
-        cidx[vid_at(comp_start[mid_list[ci]] + (s - b0))] = rank;
+        cidx[slot_v[s2]] = rank;
     }
     __syncthreads();
-    for (uint32_t s = tid; s < S_mid; s += kGNT) {
-        const uint32_t ci = slot_comp[s];
-        const uint32_t b0 = mid_off[ci];
-        const uint32_t li = vid_at(comp_start[mid_list[ci]] + (s - b0));
+    for (uint32_t k = tid; k < n_pairs; k += kGNT) {
+        const uint64_t e = lp[k];
+        const uint32_t x = (uint32_t)e & 0xFFFFFu, y = (uint32_t)(e >> 20) & 0xFFFFFu;
+        if ((rcnt[root_of[x]] >> 28) == kCatPair) continue;
+        if (e & (2ull << 40)) __hip_atomic_fetch_or(&adj[x], 1ull << cidx[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // x -> y
+        if (e & (1ull << 40)) __hip_atomic_fetch_or(&adj[y], 1ull << cidx[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // y -> x
+    }
+    __syncthreads();
+    for (uint32_t s2 = tid; s2 < S_mid; s2 += kGNT) {
+        const uint32_t li = slot_v[s2];
         const uint32_t g = tl[li];
         const KLab l = klab(C.W, C.HW, ch[g], coff[g]);
         uint32_t r0 = 0xFFFFFFFFu, r1 = 0xFFFFFFFFu, r2 = 0xFFFFFFFFu, r3 = 0xFFFFFFFFu;
@@ -818,15 +916,24 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
             if (l.n > 2) r2 = l.p[2] & 0x7FFFFFFFu;
             if (l.n > 3) r3 = l.p[3] & 0x7FFFFFFFu;
         } else { const uint64_t pa = (uint64_t)(uintptr_t)l.p; r0 = (uint32_t)pa; r1 = (uint32_t)(pa >> 32); }
-        uint64_t adj = 0;
-        for (uint32_t e = eoff[li]; e < eoff[li + 1]; ++e) adj |= 1ull << cidx[edges[e]];
-        const size_t at = (size_t)b0 + cidx[li];
+        const unsigned long long am = adj[li];
+        const size_t at = (size_t)mid_off[slot_comp[s2]] + cidx[li];
         mrec[2 * at] = make_uint4(g, l.n, r0, r1);
-        mrec[2 * at + 1] = make_uint4(r2, r3, (uint32_t)adj, (uint32_t)(adj >> 32));
+        mrec[2 * at + 1] = make_uint4(r2, r3, (uint32_t)am, (uint32_t)(am >> 32));
     }
     __syncthreads();
+    G_MARK(7);
     cover_tiny8<kGNT / 64>(C, mrec, mid_off, n_tiny, wv, lane);
+    G_MARK(8);
     cover_wave64<kGNT / 64>(C, mrec, mid_off, n_tiny, n_mid, wv, lane);
+    G_MARK(9);
+#ifdef AFQ_PUG_TIMING
+    if (tid == 0 && (work % 512) < 2) {
+        auto us = [&](int a, int b) { return (double)(tmark[b] - tmark[a]) / 100.0; };
+        printf("p2 graph cell R=%u pairs=%u NT=%u n3=%u n_tiny=%u n_mid=%u n_pr=%u S_mid=%u: gather=%.0f touched=%.0f wcc=%.0f comps=%.0f classes=%.0f pairs=%.0f records=%.0f tiny=%.0f mid=%.0f total=%.0f us\n",
+               R, n_pairs, NT, n3, n_tiny, n_mid, n_pr, S_mid, us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(6, 7), us(7, 8), us(8, 9), us(0, 9));
+    }
+#endif
     __syncthreads();
     if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], c.cell); return; }
     if (tid == 0) {
@@ -841,11 +948,12 @@ void launch_p2_split(hipStream_t s, const P2Args& a) {
     if (!a.n_cells) return;
     AFQ_LAUNCH(k_p2_hist, a.n_tiles, 256, s, a);
     AFQ_LAUNCH(k_p2_scan, (a.n_cells + 3) / 4, 256, s, a);
-    AFQ_LAUNCH(k_p2_scatter, a.n_tiles, 256, s, a);
+    static const bool staged = [] { const char* e = getenv("AFQ_P2_SCATTER"); return e && !strcmp(e, "staged"); }();
+    if (staged) AFQ_LAUNCH(k_p2_scatter<true>, a.n_tiles, 256, s, a); else AFQ_LAUNCH(k_p2_scatter<false>, a.n_tiles, 256, s, a);
 }
-void launch_p2_part(hipStream_t s, const P2Args& a) { if (a.n_parts) AFQ_LAUNCH(k_p2_part, a.n_parts, 64, s, a); }
-void launch_p2_search(hipStream_t s, const P2Args& a) { if (a.n_parts) AFQ_LAUNCH(k_p2_search, a.n_parts, 64, s, a); }
-void launch_p2_lone(hipStream_t s, const P2Args& a) { if (a.n_parts) AFQ_LAUNCH(k_p2_lone, a.n_parts, 64, s, a); }
+void launch_p2_part(hipStream_t s, const P2Args& a) { if (a.n_parts) AFQ_LAUNCH(k_p2_part, (a.n_parts + 3) / 4, 256, s, a); }
+void launch_p2_search(hipStream_t s, const P2Args& a) { if (a.n_parts) AFQ_LAUNCH(k_p2_search, (a.n_parts + 3) / 4, 256, s, a); }
+void launch_p2_lone(hipStream_t s, const P2Args& a) { if (a.n_parts) AFQ_LAUNCH(k_p2_lone, (a.n_parts + 3) / 4, 256, s, a); }
 void launch_p2_graph(hipStream_t s, const P2Args& a) {
     if (!a.n_cells) return;
     int dev = 0, cus = 256;
