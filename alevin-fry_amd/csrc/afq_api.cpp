@@ -509,7 +509,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
     std::vector<uint2> p2tiles;
     std::vector<uint32_t> p2_up;
     std::vector<uint32_t> mono_cells;
-    uint64_t p2_parts = 0, p2_pairs = 0;
+    uint64_t p2_parts = 0;
     {
         const char* route = std::getenv("AFQ_PUG_ROUTE");
         const bool p2_ok = n_pug && g.umi_bytes == 4 && !(g.resolution == AFQ_RES_PARSIMONY_GENE || g.resolution == AFQ_RES_PARSIMONY_GENE_EM) &&
@@ -518,11 +518,11 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
             const CellMeta& m = B.meta[ci];
             if (!p2_ok || m.nrec >= (1u << 20) || m.n_ref < m.nrec) { mono_cells.push_back(ci); continue; }   // (n_ref < nrec: records without alignments - the column list is sized by n_ref)
             P2Cell pc{};
-            pc.rd_base = rd_off[ci]; pc.pair_base = p2_pairs; pc.chunk_off = m.chunk_off; pc.cell = ci; pc.R = m.nrec;
+            pc.rd_base = rd_off[ci]; pc.chunk_off = m.chunk_off; pc.cell = ci; pc.R = m.nrec; pc.n_ref = m.n_ref; pc.key_off = m.key_off;
             uint32_t lg = 0;
             while (((m.nrec + (1u << lg) - 1) >> lg) > kP2PartTarget) ++lg;
-            pc.lgP = lg; pc.part_base = (uint32_t)p2_parts; pc.pair_cap = m.nrec / 2 + 64;
-            p2_parts += 1ull << lg; p2_pairs += pc.pair_cap;
+            pc.lgP = lg; pc.part_base = (uint32_t)p2_parts;
+            p2_parts += 1ull << lg;
             const uint32_t j = (uint32_t)p2cells.size();
             for (uint32_t t = 0; t * kP2TileHost < m.nrec; ++t) p2tiles.push_back(make_uint2(j, t));
             p2cells.push_back(pc);
@@ -750,7 +750,8 @@ int finish_range(afq_ctx* c, int slot) {
             case kErrLabelHash: return fail(c, AFQ_ERR_UNSUPPORTED, cell + "two ref lists share a 64-bit label hash");
             case kErrPugLimit: return fail(c, AFQ_ERR_UNSUPPORTED, cell + "a device-side PUG limit was exceeded (2^20 reads in the cell, a component of more than 4096 vertices under a raised --large-graph-thresh, or a vertex with an empty label)");
             case kErrPugPool: return fail(c, AFQ_ERR_OOM, cell + "PUG edge pool exhausted");
-            default: return fail(c, AFQ_ERR_HIP, cell + "unknown device error");
+            case kErrInternal: return fail(c, AFQ_ERR_HIP, cell + "internal consistency check failed in the parsimony kernels");
+            default: return fail(c, AFQ_ERR_HIP, cell + "device error code " + std::to_string(st.err_code) + (st.err_code >= 20 ? " (internal consistency check of the parsimony kernels)" : ""));
         }
     }
     c->stats.n_keys += st.n_keys;

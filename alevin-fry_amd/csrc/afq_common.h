@@ -87,6 +87,7 @@ struct OverflowEnt { uint32_t bucket; uint32_t n; };
 constexpr uint32_t kErrLabelHash = 6;    // two different ref lists with the same 64-bit label hash
 constexpr uint32_t kErrPugLimit = 7;     // a PUG size limit of the device path was exceeded
 constexpr uint32_t kErrPugPool = 8;      // edge pool exhausted
+constexpr uint32_t kErrInternal = 9;     // a consistency check of the device code failed (a bug, never the input)
 
 __host__ __device__ inline bool mode_is_pug(uint32_t m) { return m >= kModePug && m <= kModePugGeneEm; }
 __host__ __device__ inline bool mode_pug_gene(uint32_t m) { return m == kModePugGene || m == kModePugGeneEm; }

@@ -155,14 +155,14 @@ void launch_pug(hipStream_t s, const PugCellArgs& a, uint32_t n_blocks);
 // ---- parsimony as phase kernels over UMI partitions (afq_pug2.hip) ----
 struct P2Cell {
     uint64_t rd_base;     // the cell's first read slot: rd_h / rd_u / s_h / s_u / v_off / v_flag / lidx share the indexing
-    uint64_t pair_base;   // first slot of the cell's pair list
     uint64_t chunk_off;   // the cell's chunk in the input bytes (= meta[cell].chunk_off)
     uint32_t cell;        // index into meta[]
     uint32_t R;           // reads
     uint32_t lgP;         // log2 of the partition count (partition = low lgP bits of the UMI)
     uint32_t part_base;   // first partition of the cell in the per-partition arrays
-    uint32_t pair_cap;
+    uint32_t n_ref;       // alignment words of the cell (= meta[cell].n_ref: sizes the column list and the label area)
     uint32_t pad;
+    uint64_t key_off;     // = meta[cell].key_off
 };
 struct P2Args {
     const uint8_t* bytes; const CellMeta* meta; const P2Cell* cells; const uint2* tiles; const uint32_t* order;

@@ -1099,6 +1099,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
         }
         __syncthreads();
         for (;;) {
+            __syncthreads();   // (all threads have read the previous sweep's flag before it is cleared)
             if (tid == 0) s_flag[0] = 0;
             __syncthreads();
             bool ch = false;
@@ -1126,6 +1127,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     for (uint32_t v = tid; v < V; v += kPugNT) wlab[v] = v;
     __syncthreads();
     for (;;) {
+        __syncthreads();   // (all threads have read the previous sweep's flag before it is cleared)
         if (tid == 0) s_flag[0] = 0;
         __syncthreads();
         bool ch = false;

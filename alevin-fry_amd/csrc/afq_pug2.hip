@@ -45,16 +45,33 @@ typedef unsigned __int128 u128;
 constexpr uint32_t kP2Tile = 2048;        // reads per histogram / scatter tile
 constexpr uint32_t kP2Bins = 2048;        // partitions per cell the tile kernels rank in LDS
 constexpr uint32_t kP2TabSlots = 512;     // hash table of one partition's vertices (<= 256)
-constexpr uint32_t kP2FiltBits = 2048;    // presence filter in front of it
+constexpr uint32_t kP2FiltBits = 4096;    // presence filter in front of it
 constexpr uint32_t kVCntMask = 0x3FFu;    // vertex word: reads (10 bits) | label signature (19 bits) << 10 | key tag << 29
 constexpr uint64_t kPairF = 1ull << 63, kPairB = 1ull << 62;   // pair (x, y): x -> y / y -> x is an edge
 
 __device__ __forceinline__ uint32_t sig_of(uint32_t t) { return 1u << (t % 19u); }
 __device__ __forceinline__ uint32_t fold9(uint32_t u) { u ^= u >> 18; return (u ^ (u >> 9)) & (kP2TabSlots - 1); }       // linear: fold(a ^ b) = fold(a) ^ fold(b)
-__device__ __forceinline__ uint32_t fold11(uint32_t u) { return (u ^ (u >> 11) ^ (u >> 22)) & (kP2FiltBits - 1); }
+__device__ __forceinline__ uint32_t fold11(uint32_t u) { return (u ^ (u >> 12) ^ (u >> 24)) & (kP2FiltBits - 1); }   // (12 bits)
 
-__device__ __forceinline__ uint32_t wg_add(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ uint32_t wg_min(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint32_t wg_add(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t wg_min(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Global-memory atomics in this file are AGENT scope, and a word other waves change with atomics is read with an agent-scope
+// load.  Workgroup-scope atomics looked like the cheaper choice for data only one workgroup touches (they stay in the XCD's
+// L2), but mixed with plain stores and loads they failed one run in two from the second step on - stale keys of the previous
+// step's table "found", counts one short, a cleared word landing on top of an atomic's result - and only a full
+// __threadfence() (L2 write-back) in front of every barrier cured that, at three times the kernel's duration.  Agent-scope
+// atomics with plain initialising stores, __syncthreads() and plain first-touch loads are what afq_pug.hip has done all
+// along; the one extra rule: a line that may sit in this CU's L1 from before another wave's atomic is read past the L1.
+// ... and the same goes for the stores that initialise or overwrite such a word: every access to a word that atomics work
+// on is an agent-scope access (a plain store stays dirty in the XCD's L2 where an agent-scope load or atomic does not look:
+// the class table "found" keys of the previous step's table under a clearing pass that had not reached memory).
+template <typename T>
+__device__ __forceinline__ T ld_l2(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ __forceinline__ void st_l2(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// The barrier between phases that hand each other data through global memory: a wave first waits for its own stores to be
+// acknowledged (s_waitcnt vmcnt(0): stores count in vmcnt on gfx9), then goes to the barrier.
+__device__ __forceinline__ void gsync() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
 
 // ---- labels by key: one or two refs sit in the key itself (afq_common.h label_key), longer ones in the chunk -------------
 struct KLab {
@@ -82,17 +99,17 @@ __device__ __forceinline__ bool klab_overlap(const KLab& a, const KLab& b) {   /
     return lab_overlap(Lab{a.p, a.n}, Lab{b.p, b.n});
 }
 
-__device__ __forceinline__ PugCtx make_ctx(const P2Args& A, const P2Cell& c, const CellMeta& m, uint32_t* cnt) {
+__device__ __forceinline__ PugCtx make_ctx(const P2Args& A, const P2Cell& c, uint32_t* cnt) {
     PugCtx C;
     C.W = reinterpret_cast<const uint32_t*>(A.bytes + c.chunk_off);
     C.HW = A.hw; C.t2g = A.t2g; C.ref_count = A.ref_count; C.num_genes = A.num_genes;
     C.usa = A.usa; C.num_rows = A.num_rows; C.uo = A.num_rows / 3; C.ao = 2 * (A.num_rows / 3); C.em = A.em;
     C.exact_umi = A.exact_umi; C.large_thresh = A.large_thresh; C.umi_pairs = A.umi_pairs; C.gene_level = 0;
-    C.cols = reinterpret_cast<uint32_t*>(A.keys0 + m.key_off);
-    C.cols_cap = 2 * m.n_ref + 2;
-    C.labw = A.lab ? A.lab + 2 * m.key_off : nullptr;
-    C.labd = A.lab ? C.labw + m.n_ref + 1 : nullptr;
-    C.lab_cap = m.n_ref + 1;
+    C.cols = reinterpret_cast<uint32_t*>(A.keys0 + c.key_off);
+    C.cols_cap = 2 * c.n_ref + 2;
+    C.labw = A.lab ? A.lab + 2 * c.key_off : nullptr;
+    C.labd = A.lab ? C.labw + c.n_ref + 1 : nullptr;
+    C.lab_cap = c.n_ref + 1;
     C.s_cnt = cnt; C.st = A.st; C.cell = c.cell;
     return C;
 }
@@ -299,7 +316,7 @@ __device__ __forceinline__ void part_body(const P2Args& A, const uint32_t* W, ui
         before += (uint32_t)__popcll(vm[e]);
     }
     for (uint32_t i = before + lane; i < n; i += 64) { su[i] = 0; sh[i] = 0; }   // (every load of the partition's reads is long done: they went into the sort)
-    for (uint32_t i = lane; i < n; i += 64) { A.v_flag[o + i] = 0; A.lidx[o + i] = 0xFFFFFFFFu; }
+    for (uint32_t i = lane; i < n; i += 64) A.v_flag[o + i] = 0;
     uint32_t n3 = 0;   // vertices under a hashed key (they sort last: the key's tag is its top bits)
 #pragma unroll
     for (int e = 0; e < E; ++e) n3 += (uint32_t)__popcll(__ballot(vh[e] && (uint32_t)((uint64_t)(a[e] >> 64) >> 62) == 3));
@@ -361,7 +378,7 @@ __global__ __launch_bounds__(256) void k_p2_search(P2Args A) {
         if (low) { const uint32_t q = c.part_base + (p ^ low); f_n = A.pnv[q]; f_o = A.poff[q]; }
     }
     for (uint32_t i = lane; i < kP2TabSlots; i += 64) t_word[i] = 0;
-    if (lane < kP2FiltBits / 32) s_filt[lane] = 0;
+    for (uint32_t i = lane; i < kP2FiltBits / 32; i += 64) s_filt[i] = 0;
     if (lane == 0) *s_np = 0;
     WAVE_SYNC();
     uint64_t own[4];   // the partition's own vertices stay in registers (<= 256 of them)
@@ -404,36 +421,51 @@ __global__ __launch_bounds__(256) void k_p2_search(P2Args A) {
         }
     };
     const uint32_t L = A.umi_pairs;
-    // own vertices
+    // A probe UMI that passes the filter (one in twenty) is not looked up on the spot - the whole wave would walk the table for
+    // the one lane that needs it, at nearly every step - but queued per lane; the queues are drained together afterwards, a
+    // handful of table walks per wave instead of one per step.
+    // own vertices: same UMI under another label, and every one-base change that stays in the partition
+    uint64_t oq8 = 0;   // up to eight queued own probes, a byte each: 1 | r << 1 | (3 b + d - 1) << 3 ... (b < 16: 6 bits)
+    uint32_t on = 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const uint32_t i = (uint32_t)r * 64 + lane;
-        if (i >= nv) continue;
+        if ((uint32_t)r * 64 >= nv) break;   // (uniform)
         const uint32_t umi = (uint32_t)(own[r] >> 32), xw = (uint32_t)own[r];
-        probe(umi, lo_p + i, xw, true);
-        if (A.exact_umi) continue;
-        uint64_t pmask = 0;   // bit 3 b + d - 1: that neighbour is larger, stays in the partition and passes the filter
+        if (i < nv) probe(umi, lo_p + i, xw, true);
+        if (A.exact_umi || i >= nv) continue;
         for (uint32_t b = m / 2; b < L; ++b) {   // (bases below m / 2 lie inside the low m bits: every change there leaves the partition)
 #pragma unroll
             for (uint32_t d = 1; d < 4; ++d) {
                 const uint32_t mk = d << (2 * b);
                 if (mk & (P - 1)) continue;
                 const uint32_t pu = umi ^ mk;
-                if (pu > umi && filt(pu)) pmask |= 1ull << (3 * b + d - 1);
+                if (pu > umi && filt(pu)) {
+                    if (on < 8) { oq8 |= (uint64_t)(((3 * b + d - 1) << 2) | (uint32_t)r) << (8 * on); ++on; }
+                    else probe(pu, lo_p + i, xw, false);
+                }
             }
         }
-        while (pmask) {
-            const uint32_t ix = (uint32_t)__builtin_ctzll(pmask);
-            pmask &= pmask - 1;
-            probe(umi ^ ((ix % 3 + 1) << (2 * (ix / 3))), lo_p + i, xw, false);
-        }
+    }
+    for (uint32_t t = 0; __any(t < on); ++t) {
+        if (t >= on) continue;
+        const uint32_t e = (uint32_t)(oq8 >> (8 * t)) & 0xFFu, r = e & 3u, ix = e >> 2;
+        const uint64_t ow = r == 0 ? own[0] : r == 1 ? own[1] : r == 2 ? own[2] : own[3];
+        probe((uint32_t)(ow >> 32) ^ ((ix % 3 + 1) << (2 * (ix / 3))), lo_p + r * 64 + lane, (uint32_t)ow, false);
     }
     // The vertices of the partitions one low-bit change away, a partition at a time (its place is in lane k's registers): the
-    // first 128 vertices of the NEXT partition are on their way while this one goes through the filter and - rarely - the table.
+    // first 128 vertices of the NEXT partition are on their way while this one goes through the filter.
     auto fetch = [&](uint32_t k, uint64_t (&v)[2], uint32_t& nq, uint32_t& oq) {
         nq = __builtin_amdgcn_readlane(f_n, k); oq = __builtin_amdgcn_readlane(f_o, k);
         v[0] = lane < nq ? cu[oq + lane] : 0ull;
         v[1] = lane + 64 < nq ? cu[oq + 64 + lane] : 0ull;
+    };
+    uint32_t fq_pu[4], fq_gx[4], fq_xw[4], fn = 0;   // queued foreign probes
+    auto fpush = [&](uint32_t pu, uint32_t gx, uint32_t xw) {
+        if (fn >= 4) { probe(pu, gx, xw, false); return; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) if ((uint32_t)t == fn) { fq_pu[t] = pu; fq_gx[t] = gx; fq_xw[t] = xw; }
+        ++fn;
     };
     uint64_t cur[2] = {0, 0}, nxt[2] = {0, 0};
     uint32_t nq = 0, oq = 0, nq2 = 0, oq2 = 0;
@@ -446,15 +478,17 @@ __global__ __launch_bounds__(256) void k_p2_search(P2Args A) {
             const uint32_t i = (uint32_t)r * 64 + lane;
             if (i >= nq) continue;
             const uint32_t umi = (uint32_t)(cur[r] >> 32), pu = umi ^ mk;
-            if (pu > umi && filt(pu)) probe(pu, oq + i, (uint32_t)cur[r], false);
+            if (pu > umi && filt(pu)) fpush(pu, oq + i, (uint32_t)cur[r]);
         }
         for (uint32_t i = 128 + lane; i < nq; i += 64) {   // (a partition of more than 128 vertices: the rest, plainly)
             const uint64_t uw = cu[oq + i];
             const uint32_t umi = (uint32_t)(uw >> 32), pu = umi ^ mk;
-            if (pu > umi && filt(pu)) probe(pu, oq + i, (uint32_t)uw, false);
+            if (pu > umi && filt(pu)) fpush(pu, oq + i, (uint32_t)uw);
         }
         cur[0] = nxt[0]; cur[1] = nxt[1]; nq = nq2; oq = oq2;
     }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) if ((uint32_t)t < fn) probe(fq_pu[t], fq_gx[t], fq_xw[t], false);
     WAVE_SYNC();
     const uint32_t np = *s_np;
     if (lane == 0) {
@@ -474,63 +508,63 @@ __global__ __launch_bounds__(256) void k_p2_lone(P2Args A) {
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t gp = blockIdx.x * 4 + wv;
     if (gp >= A.n_parts) return;
-    const uint32_t n = A.pcnt[gp];
+    const uint32_t n = A.pcnt[gp], nv = A.pnv[gp], j = A.pcell[gp], lo_p = A.poff[gp];
     if (n == 0) return;
-    const uint32_t nv = A.pnv[gp];
-    const uint32_t j = A.pcell[gp];
     const P2Cell c = A.cells[j];
-    const CellMeta m = A.meta[c.cell];
     uint32_t* gc = A.gcnt + 4 * (size_t)j;
-    const PugCtx C = make_ctx(A, c, m, gc);   // (the counters are the cell's global ones here: the rare class writes add to them directly)
-    const uint32_t lo_p = A.poff[gp];
+    const PugCtx C = make_ctx(A, c, gc);   // (the counters are the cell's global ones here: the rare class writes add to them directly)
     const uint64_t o = c.rd_base + lo_p;
     uint32_t* s_cls = s_cls4[wv];
     uint32_t ncls = 0;   // wave-uniform
-    for (uint32_t i0 = lane; i0 - lane < n; i0 += 128) {
-        uint64_t h2[2];
-        uint32_t fl[2];
+    // the whole partition (<= 256 slots) at once: four slots per lane, every level of the gather chain issued for all four
+    uint64_t h4[4];
+    uint32_t fl[4], ga[4], gb[4];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const uint32_t i = i0 + (uint32_t)r * 64;
-            h2[r] = i < nv ? A.s_h[o + i] : 0ull;
-            fl[r] = i < nv ? A.v_flag[o + i] : 1u;
-        }
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t i = (uint32_t)r * 64 + lane;
+        h4[r] = i < nv ? A.s_h[o + i] : 0ull;
+        fl[r] = i < nv ? A.v_flag[o + i] : 1u;
+    }
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const uint32_t i = i0 + (uint32_t)r * 64;
-            uint32_t col = 0xFFFFFFFFu, k0 = 0, k1 = 0;
-            bool cls = false;
-            if (!fl[r]) {
-                const uint64_t h = h2[r];
-                const uint32_t tag = (uint32_t)(h >> 62);
-                if (tag == 1 || tag == 2) {
-                    const uint32_t ga = C.t2g[tag == 1 ? (uint32_t)h & 0x7FFFFFFFu : (uint32_t)(h >> 31) & 0x7FFFFFFFu];
-                    const uint32_t gb = tag == 2 ? C.t2g[(uint32_t)h & 0x7FFFFFFFu] : ga;
-                    const uint32_t lo = ga < gb ? ga : gb, hi = ga < gb ? gb : ga;
-                    col = molecule2_column(C, lo, hi, lo == hi ? 1u : 2u, cls);
-                    k0 = lo; k1 = hi;
-                } else if (tag == 3) {
-                    const Lab l = rec_label(C, A.v_off[o + i]);
-                    if (l.n <= 4) {
-                        uint32_t g4[4];
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t tag = (uint32_t)(h4[r] >> 62);
+        const bool shrt = !fl[r] && (tag == 1 || tag == 2);
+        ga[r] = shrt ? C.t2g[tag == 1 ? (uint32_t)h4[r] & 0x7FFFFFFFu : (uint32_t)(h4[r] >> 31) & 0x7FFFFFFFu] : 0u;
+        gb[r] = shrt && tag == 2 ? C.t2g[(uint32_t)h4[r] & 0x7FFFFFFFu] : ga[r];
+    }
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) g4[q] = (uint32_t)q < l.n ? l.p[q] & 0x7FFFFFFFu : 0xFFFFFFFFu;
-                        const uint32_t ng = genes_of4(C, g4, l.n);
-                        col = molecule4_column(C, g4, ng, cls);
-                        k0 = g4[0]; k1 = g4[1];
-                    } else {
-                        uint32_t g[kMaxGenesPerLabel];
-                        const uint32_t ng = genes_of(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; }, g);
-                        if (ng == 0xFFFFFFFFu && C.em) emit_wide_class(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; });
-                        else col = molecule_column_n(C, g, ng);
-                    }
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t i = (uint32_t)r * 64 + lane;
+        if ((uint32_t)r * 64 >= n) break;   // (uniform)
+        uint32_t col = 0xFFFFFFFFu, k0 = 0, k1 = 0;
+        bool cls = false;
+        if (!fl[r]) {
+            const uint32_t tag = (uint32_t)(h4[r] >> 62);
+            if (tag == 1 || tag == 2) {
+                const uint32_t lo = ga[r] < gb[r] ? ga[r] : gb[r], hi = ga[r] < gb[r] ? gb[r] : ga[r];
+                col = molecule2_column(C, lo, hi, lo == hi ? 1u : 2u, cls);
+                k0 = lo; k1 = hi;
+            } else if (tag == 3) {
+                const Lab l = rec_label(C, A.v_off[o + i]);
+                if (l.n <= 4) {
+                    uint32_t g4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) g4[q] = (uint32_t)q < l.n ? l.p[q] & 0x7FFFFFFFu : 0xFFFFFFFFu;
+                    const uint32_t ng = genes_of4(C, g4, l.n);
+                    col = molecule4_column(C, g4, ng, cls);
+                    k0 = g4[0]; k1 = g4[1];
+                } else {
+                    uint32_t g[kMaxGenesPerLabel];
+                    const uint32_t ng = genes_of(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; }, g);
+                    if (ng == 0xFFFFFFFFu && C.em) emit_wide_class(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; });
+                    else col = molecule_column_n(C, g, ng);
                 }
             }
-            if (i < n) C.cols[lo_p + i] = col;
-            const uint64_t mk = __ballot(cls);
-            if (cls) { const uint32_t q = ncls + (uint32_t)__popcll(mk & ((1ull << lane) - 1)); s_cls[2 * q] = k0; s_cls[2 * q + 1] = k1; }
-            ncls += (uint32_t)__popcll(mk);
         }
+        if (i < n) C.cols[lo_p + i] = col;
+        const uint64_t mk = __ballot(cls);
+        if (cls) { const uint32_t q = ncls + (uint32_t)__popcll(mk & ((1ull << lane) - 1)); s_cls[2 * q] = k0; s_cls[2 * q + 1] = k1; }
+        ncls += (uint32_t)__popcll(mk);
     }
     if (!ncls) return;
     WAVE_SYNC();
@@ -573,7 +607,6 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
     if (work >= A.n_cells) return;
     const uint32_t j = A.order[work];
     const P2Cell c = A.cells[j];
-    const CellMeta m = A.meta[c.cell];
     const uint32_t R = c.R;
     auto give_up = [&]() {   // the cell goes to the one-workgroup kernel
         if (tid == 0) { A.fb[j] = 1; A.fb_list[atomicAdd(A.fb_count, 1u)] = c.cell; }
@@ -581,8 +614,8 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
     if (A.fb[j]) { if (tid == 0) A.fb_list[atomicAdd(A.fb_count, 1u)] = c.cell; continue; }
     uint32_t* gc = A.gcnt + 4 * (size_t)j;
     if (tid < 4) { s_cnt[tid] = tid == 0 ? R : gc[tid]; s_flag[tid] = 0; }   // (entries 0..R of the column list belong to the lone-vertex kernel)
-    __syncthreads();
-    PugCtx C = make_ctx(A, c, m, s_cnt);
+    gsync();
+    PugCtx C = make_ctx(A, c, s_cnt);
     const uint64_t* ch = A.s_h + c.rd_base;
     const uint64_t* cu = A.s_u + c.rd_base;
     const uint32_t* coff = A.v_off + c.rd_base;
@@ -607,7 +640,7 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
         if (ppre && pp < P) { ppre[2 * pp] = n_pairs + ea; ppre[2 * pp + 1] = n_cls2 + eb; }
         n_pairs += ta; n_cls2 += tb; n3 += td;
     }
-    __syncthreads();
+    gsync();
     if (!ppre) { give_up(); continue; }   // (more than 4096 partitions: cells of over 650 k reads)
     if (n_cls2) {   // the lone vertices' classes into the cell's label area (em only)
         const uint32_t w0 = s_cnt[1], d0 = s_cnt[2];
@@ -622,15 +655,15 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
                 C.labd[2 * d] = w; C.labd[2 * d + 1] = 2;
             }
         }
-        __syncthreads();
+        gsync();
         if (tid == 0) { s_cnt[1] = w0 + 2 * n_cls2; s_cnt[2] = d0 + n_cls2; }
-        __syncthreads();
+        gsync();
     }
     // ---- scratch out of the pool: everything is sized by the vertices that have an edge ----
     const uint32_t nt_max = min(R, 2 * n_pairs);
     const unsigned long long need = 26ull * nt_max + 2ull * n_pairs + 64;
     if (tid == 0) s_ebase = atomicAdd(A.pool_cur, need);
-    __syncthreads();
+    gsync();
     if (s_ebase + need > A.pool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, c.cell); return; }
     uint32_t* q = A.pool + ((s_ebase + 3) & ~3ull);
     uint4* mrec = reinterpret_cast<uint4*>(q); q += 8 * (size_t)nt_max;                 // (16-byte aligned)
@@ -650,27 +683,25 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
     uint32_t* cmin = q; q += nt_max;          // per slot: smallest record offset of the vertex's class
     uint32_t* pr_v = q;                       // two-vertex components: their vertices, two by two
     G_MARK(1);
-    // ---- 1. the touched vertices = the pairs' end points; the first thread to meet one gives it its local id
-    //         (any numbering will do: the reference's order enters through the order keys of step 6 only) ----
+    // ---- 1. the touched vertices: the search flagged them; a scan over the flags numbers them (any numbering will do: the
+    //         reference's order enters through the order keys of step 6 only) ----
     const uint64_t* psrc = A.pairs + c.rd_base;
-    if (tid == 0) s_flag[3] = 0;
-    __syncthreads();
-    for (uint32_t pp = tid; pp < P; pp += kGNT) {
-        const uint32_t nk = pnp[pp], so = ppoff[pp];
-        for (uint32_t k = 0; k < 2 * nk; ++k) {
-            const uint64_t pr = psrc[so + (k >> 1)];
-            const uint32_t g = (k & 1u) ? (uint32_t)pr & 0x7FFFFFFFu : (uint32_t)(pr >> 31) & 0x7FFFFFFFu;
-            if (__hip_atomic_load(&lidx[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0xFFFFFFFFu) continue;
-            unsigned int expected = 0xFFFFFFFFu;
-            if (__hip_atomic_compare_exchange_strong(&lidx[g], &expected, 0xFFFFFFFEu, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                const uint32_t li = atomicAdd(&s_flag[3], 1u);
-                if (li < nt_max) tl[li] = g;
-                __hip_atomic_store(&lidx[g], li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
+    const uint8_t* cflag = A.v_flag + c.rd_base;
+    uint32_t NT = 0;
+    for (uint32_t base = 0; base < R; base += 4 * kGNT) {
+        const uint32_t g0 = base + 4 * tid;
+        uint32_t f[4], cn = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { f[r] = g0 + r < R ? cflag[g0 + r] : 0u; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cn += f[r] != 0;
+        uint32_t tot;
+        uint32_t li = NT + block_excl_scan<kGNT>(cn, s_ws, tot);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (f[r]) { if (li < nt_max) { tl[li] = g0 + r; lidx[g0 + r] = li; } ++li; }
+        NT += tot;
     }
-    __syncthreads();
-    const uint32_t NT = s_flag[3];
+    gsync();
     if (NT > nt_max || NT >= (1u << 20)) { if (tid == 0) set_err(A.st, kErrPugLimit, c.cell); return; }   // (cannot happen: two end points per pair, R < 2^20)
     for (uint32_t pp = tid; pp < P; pp += kGNT) {
         const uint32_t nk = pnp[pp], so = ppoff[pp], at = ppre[2 * pp];
@@ -680,43 +711,48 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
             lp[at + k] = (uint64_t)lx | ((uint64_t)ly << 20) | ((pr >> 62) << 40);
         }
     }
-    __syncthreads();
+    gsync();
     G_MARK(2);
     // ---- 2. weakly connected components over the pair list: min-label propagation + pointer jumping (labels in LDS when they fit) ----
-    uint32_t* wl = NT <= kGLds ? s_big : wlg;
-    for (uint32_t i = tid; i < NT; i += kGNT) { wl[i] = i; rcnt[i] = 0; fill[i] = 0; adj[i] = 0; }
-    __syncthreads();
+    const bool wl_lds = NT <= kGLds;
+    uint32_t* wl = wl_lds ? s_big : wlg;
+    auto ldw = [&](uint32_t i) -> uint32_t { return wl_lds ? wl[i] : ld_l2(&wl[i]); };
+    for (uint32_t i = tid; i < NT; i += kGNT) { if (wl_lds) wl[i] = i; else st_l2(&wl[i], i); st_l2(&rcnt[i], 0u); st_l2(&fill[i], 0u); st_l2(&adj[i], 0ull); }
+    gsync();
     for (;;) {
+        gsync();   // (every thread has read the previous sweep's flag before it is cleared: without this barrier a wave that
+                   //  lagged a few cycles behind thread 0 read the cleared flag, left the loop alone and took every barrier
+                   //  after it out of step - one run in two failed somewhere, never in the same place)
         if (tid == 0) s_flag[0] = 0;
-        __syncthreads();
+        gsync();
         bool chg = false;
         for (uint32_t k = tid; k < n_pairs; k += kGNT) {
             const uint64_t e = lp[k];
             const uint32_t x = (uint32_t)e & 0xFFFFFu, y = (uint32_t)(e >> 20) & 0xFFFFFu;
-            const uint32_t a = wl[x], b = wl[y];
+            const uint32_t a = ldw(x), b = ldw(y);
             if (a < b) { wg_min(&wl[y], a); chg = true; }
             else if (b < a) { wg_min(&wl[x], b); chg = true; }
         }
         if (chg) s_flag[0] = 1;
-        __syncthreads();
+        gsync();
         for (int it = 0; it < 4; ++it) {
-            for (uint32_t i = tid; i < NT; i += kGNT) { const uint32_t l = wl[i]; const uint32_t ll = wl[l]; if (ll < l) wl[i] = ll; }
-            __syncthreads();
+            for (uint32_t i = tid; i < NT; i += kGNT) { const uint32_t l = ldw(i); const uint32_t ll = ldw(l); if (ll < l) { if (wl_lds) wl[i] = ll; else st_l2(&wl[i], ll); } }
+            gsync();
         }
         if (!s_flag[0]) break;
     }
     G_MARK(3);
     // ---- 3. the components by counting: sizes per root, then by size pairs / 3..8 / 9..64 (anything else is not for this
     //         kernel), every listed component's slots, every vertex into its component's next slot ----
-    for (uint32_t i = tid; i < NT; i += kGNT) { uint32_t l = wl[i]; while (wl[l] != l) l = wl[l]; root_of[i] = l; wg_add(&rcnt[l], 1u); }
-    __syncthreads();
+    for (uint32_t i = tid; i < NT; i += kGNT) { uint32_t l = ldw(i); for (uint32_t nx = ldw(l); nx != l; nx = ldw(l)) l = nx; root_of[i] = l; wg_add(&rcnt[l], 1u); }
+    gsync();
     uint32_t n_pr = 0, n_tiny = 0, n_mid9 = 0;
     bool big = false;
     for (uint32_t base = 0; base < NT; base += kGNT) {
         const uint32_t i = base + tid;
         uint32_t cat = 0;
         if (i < NT && root_of[i] == i) {
-            const uint32_t n = rcnt[i];
+            const uint32_t n = ld_l2(&rcnt[i]);
             if (n > 64 || n > C.large_thresh) big = true;
             else cat = n == 2 ? kCatPair : n <= 8 ? kCatTiny : kCatMid;
         }
@@ -724,20 +760,20 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
         const uint32_t ex = block_excl_scan<kGNT>((cat == kCatPair) | ((uint32_t)(cat == kCatTiny) << 10) | ((uint32_t)(cat == kCatMid) << 20), s_ws, tot);
         if (cat) {
             const uint32_t idx = cat == kCatPair ? n_pr + (ex & 0x3FFu) : cat == kCatTiny ? n_tiny + ((ex >> 10) & 0x3FFu) : n_mid9 + (ex >> 20);
-            const uint32_t n = rcnt[i];
-            rcnt[i] = (cat << 28) | idx;                   // (a root's word is read and written by its own thread only in this pass)
+            const uint32_t n = ld_l2(&rcnt[i]);
+            st_l2(&rcnt[i], (cat << 28) | idx);            // (a root's word is read and written by its own thread only in this pass)
             if (cat == kCatTiny) lsize[idx] = n;          // (the 9..64 ones are placed behind the small ones once those are counted)
-            else if (cat == kCatMid) fill[i] = n;          // (parked in the root's fill word until then)
+            else if (cat == kCatMid) st_l2(&fill[i], n);   // (parked in the root's fill word until then)
         }
         n_pr += tot & 0x3FFu; n_tiny += (tot >> 10) & 0x3FFu; n_mid9 += tot >> 20;
     }
     if (big) s_flag[1] = 1;
-    __syncthreads();
+    gsync();
     if (s_flag[1]) { give_up(); continue; }
     const uint32_t n_mid = n_tiny + n_mid9;
     for (uint32_t i = tid; i < NT; i += kGNT)
-        if (root_of[i] == i && (rcnt[i] >> 28) == kCatMid) { lsize[n_tiny + (rcnt[i] & 0xFFFFFFFu)] = fill[i]; fill[i] = 0; }
-    __syncthreads();
+        if (root_of[i] == i) { const uint32_t rc = ld_l2(&rcnt[i]); if ((rc >> 28) == kCatMid) { lsize[n_tiny + (rc & 0xFFFFFFFu)] = ld_l2(&fill[i]); st_l2(&fill[i], 0u); } }
+    gsync();
     uint32_t S_mid = 0;
     for (uint32_t base = 0; base < n_mid; base += kGNT) {
         const uint32_t ci = base + tid;
@@ -748,9 +784,9 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
         S_mid += tot;
     }
     if (tid == 0) mid_off[n_mid] = S_mid;
-    __syncthreads();
+    gsync();
     for (uint32_t i = tid; i < NT; i += kGNT) {
-        const uint32_t r = root_of[i], rc = rcnt[r], cat = rc >> 28, idx = rc & 0xFFFFFFFu;
+        const uint32_t r = root_of[i], rc = ld_l2(&rcnt[r]), cat = rc >> 28, idx = rc & 0xFFFFFFFu;
         const uint32_t at = wg_add(&fill[r], 1u);
         if (cat == kCatPair) pr_v[2 * idx + at] = i;
         else {
@@ -759,7 +795,7 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
             slot_v[sl] = i; slot_comp[sl] = ci;
         }
     }
-    __syncthreads();
+    gsync();
     G_MARK(4);
     // ---- 4. class minima: for the classes of the listed components' vertices (their order decides ties) and for every
     //         class under a hashed key (equal keys must be equal labels).  The cell's vertex slots stream ONCE through a hash
@@ -775,7 +811,7 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
         if (want > kGTabLoad) {
             while (cap < 2 * want) cap <<= 1;
             if (tid == 0) s_ebase = atomicAdd(A.pool_cur, 3ull * cap + 4);
-            __syncthreads();
+            gsync();
             if (s_ebase + 3ull * cap + 4 > A.pool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, c.cell); return; }
             t_key = reinterpret_cast<unsigned long long*>(A.pool + ((s_ebase + 1) & ~1ull));
             t_min = reinterpret_cast<uint32_t*>(t_key + cap);
@@ -785,55 +821,69 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
         auto find = [&](uint64_t h, uint32_t mx, bool insert) -> uint32_t {   // slot of h, or 0xFFFFFFFF
             uint32_t slot = mx & cmask;
             for (uint32_t step = 0; step < cap; ++step, slot = (slot + 1) & cmask) {
-                unsigned long long k = __hip_atomic_load(&t_key[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                unsigned long long k = ld_l2(&t_key[slot]);
                 if (k == h) return slot;
                 if (k == ~0ull) {
                     if (!insert) return 0xFFFFFFFFu;
                     unsigned long long expected = ~0ull;
-                    if (__hip_atomic_compare_exchange_strong(&t_key[slot], &expected, (unsigned long long)h, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return slot;
+                    if (__hip_atomic_compare_exchange_strong(&t_key[slot], &expected, (unsigned long long)h, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return slot;
                     if (expected == h) return slot;
                 }
             }
             return 0xFFFFFFFFu;
         };
-        __syncthreads();
-        for (uint32_t i = tid; i < cap; i += kGNT) { t_key[i] = ~0ull; t_min[i] = 0xFFFFFFFFu; }
+        gsync();
+        for (uint32_t i = tid; i < cap; i += kGNT) { st_l2(&t_key[i], ~0ull); st_l2(&t_min[i], 0xFFFFFFFFu); }
         for (uint32_t i = tid; i < 128; i += kGNT) s_bloom[i] = 0;
-        __syncthreads();
+        gsync();
         for (uint32_t s2 = tid; s2 < S_mid; s2 += kGNT) {   // the classes that are asked for
             const uint64_t h = ch[tl[slot_v[s2]]];
             const uint32_t mx = mix(h);
             atomicOr(&s_bloom[(mx >> 20) >> 5], 1u << ((mx >> 20) & 31u));
             (void)find(h, mx, true);
         }
-        __syncthreads();
-        for (uint32_t g0 = tid; g0 - tid < R; g0 += 4 * kGNT) {   // four slots per thread and trip, their loads in flight together
-            uint64_t h4[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h4[r] = g0 + (uint32_t)r * kGNT < R ? ch[g0 + (uint32_t)r * kGNT] : 0ull;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const uint64_t h = h4[r];
-                if (h == 0) continue;
-                const uint32_t mx = mix(h);
-                const bool hashed = (h >> 62) == 3;
-                if (!hashed && !((s_bloom[(mx >> 20) >> 5] >> ((mx >> 20) & 31u)) & 1u)) continue;
-                const uint32_t slot = find(h, mx, hashed);
-                if (slot == 0xFFFFFFFFu) continue;
-                const uint32_t off = coff[g0 + (uint32_t)r * kGNT];
+        gsync();
+        // the vertices under a hashed key: they are the last n3 of every partition's vertices (the tag is the key's top bits)
+        const uint32_t* ppnv = A.pnv + c.part_base;
+        for (uint32_t pp = tid; pp < P; pp += kGNT) {
+            const uint32_t k3 = pn3[pp], v1 = ppoff[pp] + ppnv[pp];
+            for (uint32_t g = v1 - k3; g < v1; ++g) {
+                const uint64_t h = ch[g];
+                const uint32_t slot = find(h, mix(h), true);
+                if (slot == 0xFFFFFFFFu || (h >> 62) != 3) { s_cnt[3] = kErrInternal; continue; }
+                const uint32_t off = coff[g];
                 const uint32_t old = wg_min(&t_min[slot], off);
-                if (hashed && old != 0xFFFFFFFFu && old != off && !lab_equal(rec_label(C, off), rec_label(C, old))) s_cnt[3] = kErrLabelHash;
+                if (old != 0xFFFFFFFFu && old != off && !lab_equal(rec_label(C, off), rec_label(C, old))) s_cnt[3] = kErrLabelHash;
             }
         }
-        __syncthreads();
+        // the asked-for classes whose key is the label itself: every vertex slot once, eight per thread and trip in flight
+        if (S_mid)
+            for (uint32_t g0 = tid; g0 - tid < R; g0 += 8 * kGNT) {
+                uint64_t h8[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) h8[r] = g0 + (uint32_t)r * kGNT < R ? ch[g0 + (uint32_t)r * kGNT] : 0ull;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const uint64_t h = h8[r];
+                    if (h == 0 || (h >> 62) == 3) continue;
+                    const uint32_t mx = mix(h);
+                    if (!((s_bloom[(mx >> 20) >> 5] >> ((mx >> 20) & 31u)) & 1u)) continue;
+                    const uint32_t slot = find(h, mx, false);
+                    if (slot != 0xFFFFFFFFu) wg_min(&t_min[slot], coff[g0 + (uint32_t)r * kGNT]);
+                }
+            }
+        gsync();
         for (uint32_t s2 = tid; s2 < S_mid; s2 += kGNT) {
             const uint64_t h = ch[tl[slot_v[s2]]];
-            cmin[s2] = t_min[find(h, mix(h), false)];
+            const uint32_t slot = find(h, mix(h), false);
+            const uint32_t mn = slot == 0xFFFFFFFFu ? 0xFFFFFFFFu : ld_l2(&t_min[slot]);
+            if (mn == 0xFFFFFFFFu) s_cnt[3] = kErrInternal;   // (every asked-for class has at least the vertex that asked)
+            cmin[s2] = mn;
         }
-        __syncthreads();
+        gsync();
         if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], c.cell); return; }
     }
-    __syncthreads();
+    gsync();
     G_MARK(5);
     // ---- 5. two-vertex components: one molecule, the refs both labels share (pugutils.rs:1161-1188) ----
     for (uint32_t k = tid; k - lane < n_pr; k += kGNT) {   // (wave-uniform trip count: append_cols is a wave-wide call)
@@ -887,24 +937,27 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
     // ---- 6. components of 3..64 vertices: their vertices in the reference's order (class by first appearance = smallest
     //         record offset, then UMI), the edges between them as masks over those positions, gathered into the covers' records ----
     for (uint32_t s2 = tid; s2 < S_mid; s2 += kGNT) okey[s2] = ((uint64_t)cmin[s2] << 32) | (uint32_t)(cu[tl[slot_v[s2]]] >> 32);
-    __syncthreads();
+    gsync();
     for (uint32_t s2 = tid; s2 < S_mid; s2 += kGNT) {
         const uint32_t ci = slot_comp[s2];
         const uint32_t b0 = mid_off[ci], n = mid_off[ci + 1] - b0;
         const uint64_t mine = okey[s2];
         uint32_t rank = 0;
-        for (uint32_t i = 0; i < n; ++i) rank += okey[b0 + i] < mine;
+        uint32_t same = 0;
+        for (uint32_t i = 0; i < n; ++i) { rank += okey[b0 + i] < mine; same += okey[b0 + i] == mine; }
+        if (same != 1) s_cnt[3] = kErrInternal;   // (two vertices of one component with the same class and UMI: cannot be)
         cidx[slot_v[s2]] = rank;
     }
-    __syncthreads();
+    gsync();
+    if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], c.cell); return; }
     for (uint32_t k = tid; k < n_pairs; k += kGNT) {
         const uint64_t e = lp[k];
         const uint32_t x = (uint32_t)e & 0xFFFFFu, y = (uint32_t)(e >> 20) & 0xFFFFFu;
-        if ((rcnt[root_of[x]] >> 28) == kCatPair) continue;
-        if (e & (2ull << 40)) __hip_atomic_fetch_or(&adj[x], 1ull << cidx[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // x -> y
-        if (e & (1ull << 40)) __hip_atomic_fetch_or(&adj[y], 1ull << cidx[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // y -> x
+        if ((ld_l2(&rcnt[root_of[x]]) >> 28) == kCatPair) continue;
+        if (e & (2ull << 40)) __hip_atomic_fetch_or(&adj[x], 1ull << cidx[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // x -> y
+        if (e & (1ull << 40)) __hip_atomic_fetch_or(&adj[y], 1ull << cidx[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // y -> x
     }
-    __syncthreads();
+    gsync();
     for (uint32_t s2 = tid; s2 < S_mid; s2 += kGNT) {
         const uint32_t li = slot_v[s2];
         const uint32_t g = tl[li];
@@ -916,12 +969,12 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
             if (l.n > 2) r2 = l.p[2] & 0x7FFFFFFFu;
             if (l.n > 3) r3 = l.p[3] & 0x7FFFFFFFu;
         } else { const uint64_t pa = (uint64_t)(uintptr_t)l.p; r0 = (uint32_t)pa; r1 = (uint32_t)(pa >> 32); }
-        const unsigned long long am = adj[li];
+        const unsigned long long am = ld_l2(&adj[li]);
         const size_t at = (size_t)mid_off[slot_comp[s2]] + cidx[li];
         mrec[2 * at] = make_uint4(g, l.n, r0, r1);
         mrec[2 * at + 1] = make_uint4(r2, r3, (uint32_t)am, (uint32_t)(am >> 32));
     }
-    __syncthreads();
+    gsync();
     G_MARK(7);
     cover_tiny8<kGNT / 64>(C, mrec, mid_off, n_tiny, wv, lane);
     G_MARK(8);
@@ -934,7 +987,7 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
                R, n_pairs, NT, n3, n_tiny, n_mid, n_pr, S_mid, us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(6, 7), us(7, 8), us(8, 9), us(0, 9));
     }
 #endif
-    __syncthreads();
+    gsync();
     if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], c.cell); return; }
     if (tid == 0) {
         A.cell_ncols[c.cell] = s_cnt[0];

@@ -4,7 +4,7 @@ mkdir -p gpurun_out
 TAG=${1:-r03e}
 timeout 420 python -m pytest tests/test_gpu_pug.py -x -q 2>&1 | tail -8 > gpurun_out/${TAG}_pytest.log
 cat gpurun_out/${TAG}_pytest.log
-for V in direct staged; do
+for V in direct; do
 AFQ_P2_SCATTER=$V timeout 300 python bench.py --workload configs2 --steps 2 --warmup 1 --also none --cpu-seconds 3 > gpurun_out/${TAG}_cfg2_$V.json 2> gpurun_out/${TAG}_cfg2.err
 python - <<PY
 import json
