@@ -324,15 +324,15 @@ __device__ __forceinline__ void part_body(const P2Args& A, const uint32_t* W, ui
 }
 
 __global__ __launch_bounds__(256) void k_p2_part(P2Args A) {
-    const uint32_t gp = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (gp >= A.n_parts) return;
-    const uint32_t n = A.pcnt[gp];
-    if (n == 0) { if (lane_id() == 0) A.pnv[gp] = 0; return; }
-    const P2Cell c = A.cells[A.pcell[gp]];
-    const uint64_t o = c.rd_base + A.poff[gp];
-    const uint32_t* W = reinterpret_cast<const uint32_t*>(A.bytes + c.chunk_off);
-    if (n <= 128) part_body<2>(A, W, gp, n, o, c.cell);
-    else part_body<4>(A, W, gp, n, o, c.cell);
+    for (uint32_t gp = blockIdx.x * 4 + (threadIdx.x >> 6); gp < A.n_parts; gp += gridDim.x * 4) {
+        const uint32_t n = A.pcnt[gp];
+        if (n == 0) { if (lane_id() == 0) A.pnv[gp] = 0; continue; }
+        const P2Cell c = A.cells[A.pcell[gp]];
+        const uint64_t o = c.rd_base + A.poff[gp];
+        const uint32_t* W = reinterpret_cast<const uint32_t*>(A.bytes + c.chunk_off);
+        if (n <= 128) part_body<2>(A, W, gp, n, o, c.cell);
+        else part_body<4>(A, W, gp, n, o, c.cell);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -346,21 +346,20 @@ __global__ __launch_bounds__(256) void k_p2_part(P2Args A) {
 // LDS instructions of one wave execute in order, WAVE_SYNC only keeps the compiler from moving code across.)
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
-__global__ __launch_bounds__(256) void k_p2_search(P2Args A) {
-    __shared__ uint32_t s_umi[4][kP2TabSlots];
-    __shared__ uint32_t s_word[4][kP2TabSlots];
-    __shared__ uint16_t s_idx[4][kP2TabSlots];
-    __shared__ uint32_t s_filt4[4][kP2FiltBits / 32];
-    __shared__ uint32_t s_np4[4];
-    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t gp = blockIdx.x * 4 + wv;
-    if (gp >= A.n_parts) return;
+struct SearchLds {
+    uint32_t umi[kP2TabSlots];
+    uint32_t word[kP2TabSlots];
+    uint16_t idx[kP2TabSlots];
+    uint32_t filt[kP2FiltBits / 32];
+    uint32_t np;
+};
+__device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, SearchLds& S, uint32_t lane) {
+    uint32_t* t_umi = S.umi; uint32_t* t_word = S.word; uint16_t* t_idx = S.idx;
+    uint32_t* s_filt = S.filt; uint32_t* s_np = &S.np;
     const uint32_t nv = A.pnv[gp];
     if (nv == 0) return;
     const uint32_t j = A.pcell[gp];
     const P2Cell c = A.cells[j];
-    uint32_t* t_umi = s_umi[wv]; uint32_t* t_word = s_word[wv]; uint16_t* t_idx = s_idx[wv];
-    uint32_t* s_filt = s_filt4[wv]; uint32_t* s_np = &s_np4[wv];
     const uint32_t m = c.lgP, P = 1u << m, p = gp - c.part_base;
     const uint32_t lo_p = A.poff[gp];                 // the partition's first slot inside the cell
     const uint32_t pcap = A.pcnt[gp];                 // ... and how many it has: the partition's pairs go into its own slots of the pair array
@@ -495,6 +494,12 @@ __global__ __launch_bounds__(256) void k_p2_search(P2Args A) {
         A.pnp[gp] = np < pcap ? np : pcap;
         if (np > pcap) A.fb[j] = 1;   // (more pairs than the partition has slots: the one-workgroup kernel takes the cell)
     }
+    WAVE_SYNC();
+}
+__global__ __launch_bounds__(256) void k_p2_search(P2Args A) {
+    __shared__ SearchLds s_lds[4];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t gp = blockIdx.x * 4 + wv; gp < A.n_parts; gp += gridDim.x * 4) search_body(A, gp, s_lds[wv], lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -503,18 +508,13 @@ __global__ __launch_bounds__(256) void k_p2_search(P2Args A) {
 //    vertex of slot i puts its column - or the "no column" filler, which the per-cell histogram passes over - at entry i)
 //    and its two-gene classes for the EM into its slots of a staging array: no reservation, no atomic (every wave of a
 //    cell adding to the cell's counters was the same-address queue this kernel spent its time in).
-__global__ __launch_bounds__(256) void k_p2_lone(P2Args A) {
-    __shared__ uint32_t s_cls4[4][512];
-    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t gp = blockIdx.x * 4 + wv;
-    if (gp >= A.n_parts) return;
+__device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t* s_cls, uint32_t lane) {
     const uint32_t n = A.pcnt[gp], nv = A.pnv[gp], j = A.pcell[gp], lo_p = A.poff[gp];
     if (n == 0) return;
     const P2Cell c = A.cells[j];
     uint32_t* gc = A.gcnt + 4 * (size_t)j;
     const PugCtx C = make_ctx(A, c, gc);   // (the counters are the cell's global ones here: the rare class writes add to them directly)
     const uint64_t o = c.rd_base + lo_p;
-    uint32_t* s_cls = s_cls4[wv];
     uint32_t ncls = 0;   // wave-uniform
     // the whole partition (<= 256 slots) at once: four slots per lane, every level of the gather chain issued for all four
     uint64_t h4[4];
@@ -571,6 +571,12 @@ __global__ __launch_bounds__(256) void k_p2_lone(P2Args A) {
     uint64_t* stage = A.cstage + o;   // (at most one class per vertex: the partition's own slots hold them; the graph kernel moves them into the cell's label area)
     for (uint32_t i = lane; i < ncls; i += 64) stage[i] = ((uint64_t)s_cls[2 * i + 1] << 32) | s_cls[2 * i];
     if (lane == 0) A.pncls[gp] = ncls;
+    WAVE_SYNC();
+}
+__global__ __launch_bounds__(256) void k_p2_lone(P2Args A) {
+    __shared__ uint32_t s_cls4[4][512];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t gp = blockIdx.x * 4 + wv; gp < A.n_parts; gp += gridDim.x * 4) lone_body(A, gp, s_cls4[wv], lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -1004,9 +1010,15 @@ void launch_p2_split(hipStream_t s, const P2Args& a) {
     static const bool staged = [] { const char* e = getenv("AFQ_P2_SCATTER"); return e && !strcmp(e, "staged"); }();
     if (staged) AFQ_LAUNCH(k_p2_scatter<true>, a.n_tiles, 256, s, a); else AFQ_LAUNCH(k_p2_scatter<false>, a.n_tiles, 256, s, a);
 }
-void launch_p2_part(hipStream_t s, const P2Args& a) { if (a.n_parts) AFQ_LAUNCH(k_p2_part, (a.n_parts + 3) / 4, 256, s, a); }
-void launch_p2_search(hipStream_t s, const P2Args& a) { if (a.n_parts) AFQ_LAUNCH(k_p2_search, (a.n_parts + 3) / 4, 256, s, a); }
-void launch_p2_lone(hipStream_t s, const P2Args& a) { if (a.n_parts) AFQ_LAUNCH(k_p2_lone, (a.n_parts + 3) / 4, 256, s, a); }
+static uint32_t p2_grid(uint32_t n_parts) {   // AFQ_P2_GRID caps the workgroups (persistent waves walking the partitions); default: one wave per partition
+    const uint32_t full = (n_parts + 3) / 4;
+    const char* e = getenv("AFQ_P2_GRID");
+    const uint32_t cap = e ? (uint32_t)atoi(e) : 8192u;   // (8192 workgroups of four waves walking the partitions: launching a wave per partition cost the lone-vertex kernel half its time)
+    return cap && cap < full ? cap : full;
+}
+void launch_p2_part(hipStream_t s, const P2Args& a) { if (a.n_parts) AFQ_LAUNCH(k_p2_part, p2_grid(a.n_parts), 256, s, a); }
+void launch_p2_search(hipStream_t s, const P2Args& a) { if (a.n_parts) AFQ_LAUNCH(k_p2_search, p2_grid(a.n_parts), 256, s, a); }
+void launch_p2_lone(hipStream_t s, const P2Args& a) { if (a.n_parts) AFQ_LAUNCH(k_p2_lone, p2_grid(a.n_parts), 256, s, a); }
 void launch_p2_graph(hipStream_t s, const P2Args& a) {
     if (!a.n_cells) return;
     int dev = 0, cus = 256;
