@@ -589,9 +589,9 @@ __global__ __launch_bounds__(256) void k_p2_lone(P2Args A) {
 #define G_MARK(i) do {} while (0)
 #endif
 constexpr int kGNT = 256;
-constexpr uint32_t kGLds = 8192;          // words of the phase-shared LDS block (32 KiB)
-constexpr uint32_t kGTab = 2048;          // class table slots when it lives in LDS (keys: 16 KiB, minima: 8 KiB of the block)
-constexpr uint32_t kGTabLoad = 1200;      // ... and the classes it takes; beyond that the table is carved out of the pool
+constexpr uint32_t kGTab = 4096;          // class table slots when it lives in LDS (keys: 32 KiB, minima: 16 KiB of the block)
+constexpr uint32_t kGTabLoad = 2600;      // ... and the classes it takes; beyond that the table is carved out of the pool
+constexpr uint32_t kGLds = 3 * kGTab + 128;   // words of the phase-shared LDS block (48.5 KiB: three workgroups to a CU, what the registers allow anyway)
 constexpr uint32_t kCatPair = 1, kCatTiny = 2, kCatMid = 3;
 
 __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
@@ -813,7 +813,7 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
         uint32_t cap = kGTab;
         unsigned long long* t_key = reinterpret_cast<unsigned long long*>(s_big);
         uint32_t* t_min = s_big + 2 * kGTab;
-        uint32_t* s_bloom = t_min + kGTab;   // 2048 words left of the block: 4096 bits for the asked-for keys
+        uint32_t* s_bloom = s_big + 3 * kGTab;   // the last 128 words of the block: 4096 bits for the asked-for keys
         if (want > kGTabLoad) {
             while (cap < 2 * want) cap <<= 1;
             if (tid == 0) s_ebase = atomicAdd(A.pool_cur, 3ull * cap + 4);
