@@ -53,22 +53,17 @@ __device__ __forceinline__ uint32_t sig_of(uint32_t t) { return 1u << (t % 19u);
 __device__ __forceinline__ uint32_t fold9(uint32_t u) { u ^= u >> 18; return (u ^ (u >> 9)) & (kP2TabSlots - 1); }       // linear: fold(a ^ b) = fold(a) ^ fold(b)
 __device__ __forceinline__ uint32_t fold11(uint32_t u) { return (u ^ (u >> 12) ^ (u >> 24)) & (kP2FiltBits - 1); }   // (12 bits)
 
-__device__ __forceinline__ uint32_t wg_add(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint32_t wg_min(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// Global-memory atomics in this file are AGENT scope, and a word other waves change with atomics is read with an agent-scope
-// load.  Workgroup-scope atomics looked like the cheaper choice for data only one workgroup touches (they stay in the XCD's
-// L2), but mixed with plain stores and loads they failed one run in two from the second step on - stale keys of the previous
-// step's table "found", counts one short, a cleared word landing on top of an atomic's result - and only a full
-// __threadfence() (L2 write-back) in front of every barrier cured that, at three times the kernel's duration.  Agent-scope
-// atomics with plain initialising stores, __syncthreads() and plain first-touch loads are what afq_pug.hip has done all
-// along; the one extra rule: a line that may sit in this CU's L1 from before another wave's atomic is read past the L1.
-// ... and the same goes for the stores that initialise or overwrite such a word: every access to a word that atomics work
-// on is an agent-scope access (a plain store stays dirty in the XCD's L2 where an agent-scope load or atomic does not look:
-// the class table "found" keys of the previous step's table under a clearing pass that had not reached memory).
+__device__ __forceinline__ uint32_t wg_add(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint32_t wg_min(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// The graph kernel's scratch belongs to one workgroup, so its global-memory atomics are WORKGROUP scope: they execute in the
+// XCD's L2 and cost no fabric traffic (as agent-scope operations the same words were 32 GB of HBM-side traffic per launch).
+// Two rules keep them coherent with the plain accesses around them: a word other waves change with atomics is READ with an
+// atomic too (fetch_or 0: it is answered by the L2, where a plain load may be served by a line this CU's L1 cached before
+// the atomic), and plain stores to such a word are followed by gsync() before the next atomic on it.
 template <typename T>
-__device__ __forceinline__ T ld_l2(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ T ld_l2(const T* p) { return __hip_atomic_fetch_or(const_cast<T*>(p), (T)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 template <typename T>
-__device__ __forceinline__ void st_l2(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_l2(T* p, T v) { *p = v; }
 // The barrier between phases that hand each other data through global memory: a wave first waits for its own stores to be
 // acknowledged (s_waitcnt vmcnt(0): stores count in vmcnt on gfx9), then goes to the barrier.
 __device__ __forceinline__ void gsync() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
@@ -832,7 +827,7 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
                 if (k == ~0ull) {
                     if (!insert) return 0xFFFFFFFFu;
                     unsigned long long expected = ~0ull;
-                    if (__hip_atomic_compare_exchange_strong(&t_key[slot], &expected, (unsigned long long)h, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return slot;
+                    if (__hip_atomic_compare_exchange_strong(&t_key[slot], &expected, (unsigned long long)h, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return slot;
                     if (expected == h) return slot;
                 }
             }
@@ -960,8 +955,8 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
         const uint64_t e = lp[k];
         const uint32_t x = (uint32_t)e & 0xFFFFFu, y = (uint32_t)(e >> 20) & 0xFFFFFu;
         if ((ld_l2(&rcnt[root_of[x]]) >> 28) == kCatPair) continue;
-        if (e & (2ull << 40)) __hip_atomic_fetch_or(&adj[x], 1ull << cidx[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // x -> y
-        if (e & (1ull << 40)) __hip_atomic_fetch_or(&adj[y], 1ull << cidx[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // y -> x
+        if (e & (2ull << 40)) __hip_atomic_fetch_or(&adj[x], 1ull << cidx[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // x -> y
+        if (e & (1ull << 40)) __hip_atomic_fetch_or(&adj[y], 1ull << cidx[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // y -> x
     }
     gsync();
     for (uint32_t s2 = tid; s2 < S_mid; s2 += kGNT) {
