@@ -224,14 +224,15 @@ def cpu_leg(cfg, rad, res, budget_s, min_cells=0, tie_stats=False, tol=None, n_t
     ncores = n_threads or os.cpu_count() or 1
     k = max(1, n // max(64, 4 * ncores, min_cells))   # every k-th cell, so the size mix matches the workload
     done_reads, t_cpu, ncell, start = 0, 0.0, 0, 0
-    ties = np.zeros(4, np.int64)
+    ties = np.zeros(5, np.int64)
     tie_cells = diff_cells = diff_entries = diff_entries_tol = tot_entries = 0
+    em_rel, em_flips, em_entries, em_runs = [], 0, 0, 0
     while start < k and (t_cpu < budget_s or ncell < min_cells):
         idx = np.arange(start, n, k)
         start += 1
         data, offs = rad.read_cells(idx)
         tb = time.perf_counter()
-        out = ora.quant(cfg, rad.tid_to_gid, data, offs, n_threads=ncores, want_pug_stats=tie_stats)
+        out = ora.quant(cfg, rad.tid_to_gid, data, offs, n_threads=ncores, want_pug_stats=tie_stats, check_tie_free=tie_stats)
         t_cpu += time.perf_counter() - tb
         want, ps = out if tie_stats else (out, None)
         done_reads += int(rad.cell_nrec[idx].sum())
@@ -259,6 +260,22 @@ def cpu_leg(cfg, rad, res, budget_s, min_cells=0, tie_stats=False, tol=None, n_t
                 diff_cells += bool(d.any())
                 diff_entries += int(d.sum())
                 diff_entries_tol += int((np.abs(a - b) > 1e-4 * np.maximum(a, b)).sum())
+            if em_runs == 0 and cfg.resolution.endswith("-em"):   # the EM's (unpinned) summation order, on the first round's cells: three shuffles
+                for seed in (11, 12, 13):
+                    perm = ora.quant(cfg, rad.tid_to_gid, data, offs, n_threads=ncores, em_order_seed=seed)
+                    em_runs += 1
+                    for j in range(len(idx)):
+                        g1, v1 = want.row(j)
+                        g2, v2 = perm.row(j)
+                        cols = np.union1d(g1, g2)
+                        a = np.zeros(len(cols), np.float64)
+                        b = np.zeros(len(cols), np.float64)
+                        a[np.searchsorted(cols, g1)] = v1
+                        b[np.searchsorted(cols, g2)] = v2
+                        em_entries += len(cols)
+                        em_flips += int(((a == 0) != (b == 0)).sum())   # entries on either side of the 0.01 output floor (em.rs:568-572)
+                        both = (a > 0) & (b > 0)
+                        em_rel.append(np.abs(a[both] - b[both]) / np.maximum(a[both], b[both]))
     out = {"value": round(done_reads / t_cpu / 1e6, 4), "unit": "M reads/s", "cores": ncores, "kind": "port",
            "sample": f"{ncell} of {n} cells (every {k}-th, in rounds), {done_reads} reads, {t_cpu:.1f} s, C++ restatement (oracle/) with one "
                      f"worker thread per host core popping whole cells off a shared queue, input already in RAM; rows compared "
@@ -267,8 +284,15 @@ def cpu_leg(cfg, rad, res, budget_s, min_cells=0, tie_stats=False, tol=None, n_t
         out["parsimony_ties"] = {
             "cells": ncell, "molecules": int(ties[0]), "cells_with_a_tie": tie_cells, "tie_events": int(ties[1]),
             "molecules_in_tied_components": int(ties[3]),
+            "tie_free_components_differing": int(ties[4]),   # components without a tie event whose cover changes with the scan order: must be 0
             "vs_descending_tie_break": {"cells_differing": diff_cells, "entries_differing": diff_entries,
                                         "entries_differing_beyond_1e-4_rel": diff_entries_tol, "entries": tot_entries}}
+        if em_runs:
+            rel = np.concatenate(em_rel) if em_rel else np.zeros(1)
+            out["em_order_sensitivity"] = {
+                "what": "the oracle's EM with its classes summed in 3 shuffled orders (the reference walks a HashMap, em.rs:464) against the canonical order, same cells",
+                "shuffles": em_runs, "entries": em_entries, "max_rel_diff": float(rel.max()), "p999_rel_diff": float(np.quantile(rel, 0.999)),
+                "entries_beyond_1e-4_rel": int((rel > 1e-4).sum()), "entries_across_the_0.01_floor": em_flips}
     return out
 
 

@@ -369,9 +369,14 @@ struct PugStats {
     // tie_events = cover rounds that met two maximal candidates with different vertex sets; tie_molecules = molecules
     // of the components in which that happened (everything resolved after a tie may depend on it).
     u64 tie_events = 0, tie_components = 0, tie_molecules = 0;
+    // ora_set_tie_break(2): every component is also covered with the scan reversed; tie_free_differing counts components in
+    // which NO tie event was met and whose molecules nevertheless differ between the two scans (must stay 0: what the
+    // tie-break can change is confined to the components that report a tie)
+    u64 tie_free_differing = 0;
 };
 // 0: ascending vertex id (the canonical order the device reproduces); 1: descending - the other extreme, used only to
-// measure how many counts depend on the choice (ora_set_tie_break)
+// measure how many counts depend on the choice (ora_set_tie_break); 2: ascending, and every component checked against its
+// descending cover (PugStats::tie_free_differing)
 static int g_tie_desc = 0;
 
 // get_num_molecules, src/pugutils.rs:989-1331 (HAS_PROBS == false)
@@ -413,50 +418,64 @@ static int parsimony(const Pug& g, const EqMap& m, const u32* t2g, bool gene_lev
             st.alt = true;
             continue;
         }
-        for (u32 v : cv) uncovered[v] = 1;
-        size_t remaining = cv.size();
-        bool comp_tie = false; u64 comp_mols = 0;
-        std::vector<u32> best_sorted, cand_sorted;
-        while (remaining > 0) {
-            best.clear();
-            u32 best_txp = UINT32_MAX;
-            bool tie_here = false;
-            for (size_t vi = 0; vi < cv.size(); ++vi) {  // canonical scan order: ascending vertex id (reference: hash order)
-                const u32 v = g_tie_desc ? cv[cv.size() - 1 - vi] : cv[vi];
-                if (!uncovered[v]) continue;
-                u32 txp;
-                collapse_vertices(v, uncovered, g, m, cand, txp, visit_stamp, stamp);
-                size_t len = cand.size();
-                if (best.size() < len) { best = cand; best_txp = txp; tie_here = false; best_sorted = cand; std::sort(best_sorted.begin(), best_sorted.end()); }
-                else if (best.size() == len && !tie_here) {
-                    cand_sorted = cand; std::sort(cand_sorted.begin(), cand_sorted.end());
-                    if (cand_sorted != best_sorted) tie_here = true;   // same vertex set = same molecule whatever the start / transcript
+        // one cover of the component: molecules (gene labels) in emission order; desc = scan the candidates in descending vertex id
+        auto cover = [&](bool desc, std::vector<std::vector<u32>>& mols, bool& comp_tie, u64& ties) -> int {
+            for (u32 v : cv) uncovered[v] = 1;
+            size_t remaining = cv.size();
+            std::vector<u32> best_sorted, cand_sorted;
+            while (remaining > 0) {
+                best.clear();
+                u32 best_txp = UINT32_MAX;
+                bool tie_here = false;
+                for (size_t vi = 0; vi < cv.size(); ++vi) {  // canonical scan order: ascending vertex id (reference: hash order)
+                    const u32 v = desc ? cv[cv.size() - 1 - vi] : cv[vi];
+                    if (!uncovered[v]) continue;
+                    u32 txp;
+                    collapse_vertices(v, uncovered, g, m, cand, txp, visit_stamp, stamp);
+                    size_t len = cand.size();
+                    if (best.size() < len) { best = cand; best_txp = txp; tie_here = false; best_sorted = cand; std::sort(best_sorted.begin(), best_sorted.end()); }
+                    else if (best.size() == len && !tie_here) {
+                        cand_sorted = cand; std::sort(cand_sorted.begin(), cand_sorted.end());
+                        if (cand_sorted != best_sorted) tie_here = true;   // same vertex set = same molecule whatever the start / transcript
+                    }
+                    if (len == remaining) break;
                 }
-                if (len == remaining) break;
-            }
-            if (tie_here) { st.tie_events++; comp_tie = true; }
-            comp_mols++;
-            if (best_txp == UINT32_MAX) { err = "could not find a covering transcript"; return AFQ_ERR_BAD_INPUT; }
-            // intersection of labels over the mcc, pugutils.rs:1161-1188
-            gtx.clear();
-            for (size_t i = 0; i < best.size(); ++i) {
-                u32 e = g.v_eq[best[i]];
-                const u32* lb = m.lab(e); u32 ln = m.lab_len(e);
-                if (i == 0) gtx.assign(lb, lb + ln);
-                else {
-                    size_t w = 0;
-                    for (u32 t : gtx) if (std::binary_search(lb, lb + ln, t)) gtx[w++] = t;
-                    gtx.resize(w);
+                if (tie_here) { ++ties; comp_tie = true; }
+                if (best_txp == UINT32_MAX) { err = "could not find a covering transcript"; return AFQ_ERR_BAD_INPUT; }
+                // intersection of labels over the mcc, pugutils.rs:1161-1188
+                gtx.clear();
+                for (size_t i = 0; i < best.size(); ++i) {
+                    u32 e = g.v_eq[best[i]];
+                    const u32* lb = m.lab(e); u32 ln = m.lab_len(e);
+                    if (i == 0) gtx.assign(lb, lb + ln);
+                    else {
+                        size_t w = 0;
+                        for (u32 t : gtx) if (std::binary_search(lb, lb + ln, t)) gtx[w++] = t;
+                        gtx.resize(w);
+                    }
                 }
+                label_genes(gtx.data(), (u32)gtx.size(), genes);
+                if (gene_level) { std::sort(genes.begin(), genes.end()); genes.erase(std::unique(genes.begin(), genes.end()), genes.end()); }
+                if (genes.empty()) { err = "no representative gene for a molecule"; return AFQ_ERR_BAD_INPUT; }
+                mols.push_back(genes);
+                for (u32 v : best) { uncovered[v] = 0; }
+                remaining -= best.size();
             }
-            label_genes(gtx.data(), (u32)gtx.size(), genes);
-            if (gene_level) { std::sort(genes.begin(), genes.end()); genes.erase(std::unique(genes.begin(), genes.end()), genes.end()); }
-            if (genes.empty()) { err = "no representative gene for a molecule"; return AFQ_ERR_BAD_INPUT; }
-            st.total++;
-            if (genes.size() > 1) st.ambiguous++;
-            eqc[genes] += 1;
-            for (u32 v : best) { uncovered[v] = 0; }
-            remaining -= best.size();
+            return 0;
+        };
+        std::vector<std::vector<u32>> mols;
+        bool comp_tie = false;
+        u64 ties = 0;
+        if (int rc = cover(g_tie_desc == 1, mols, comp_tie, ties)) return rc;
+        st.tie_events += ties;
+        const u64 comp_mols = mols.size();
+        for (auto& gs : mols) { st.total++; if (gs.size() > 1) st.ambiguous++; eqc[gs] += 1; }
+        if (g_tie_desc == 2 && !comp_tie) {
+            std::vector<std::vector<u32>> other;
+            bool t2 = false; u64 n2 = 0;
+            if (int rc = cover(true, other, t2, n2)) return rc;
+            std::sort(mols.begin(), mols.end()); std::sort(other.begin(), other.end());
+            if (mols != other) st.tie_free_differing++;
         }
         if (comp_tie) { st.tie_components++; st.tie_molecules += comp_mols; }
     }
@@ -563,12 +582,21 @@ static void eqc_to_idx(const GeneEqc& eqc, IdxEq& q) {
 // this restatement fixes: every single-label class first (ascending label), then the
 // multi-label classes in lexicographic order of their gene-level labels (the order the
 // caller built them in).  Integer adds first, fractional ones after, per output index.
+// g_em_perm != 0 (ora_set_em_order): the canonical order is then shuffled with that seed - what the reference's HashMap does
+// to it run by run (em.rs:464, ahash seeded per process) - to measure how much of an EM count hangs on the f32 summation
+// order.  Measurement only: parity tests compare against the canonical order.
+static uint64_t g_em_perm = 0;
 static void canonical_em_order(IdxEq& q) {
     const size_t K = q.count.size();
     std::vector<u32> ord;
     for (u32 c = 0; c < K; ++c) if (q.start[c + 1] - q.start[c] == 1) ord.push_back(c);
     std::stable_sort(ord.begin(), ord.end(), [&](u32 a, u32 b) { return q.labels[q.start[a]] < q.labels[q.start[b]]; });
     for (u32 c = 0; c < K; ++c) if (q.start[c + 1] - q.start[c] != 1) ord.push_back(c);
+    if (g_em_perm) {   // Fisher-Yates under splitmix64(seed, number of classes, first label): any order, the same one for a given cell and seed
+        uint64_t x = g_em_perm ^ (0x9E3779B97F4A7C15ull * (K + 1)) ^ (q.labels.empty() ? 0 : q.labels[0]);
+        auto next = [&]() { x += 0x9E3779B97F4A7C15ull; uint64_t z = x; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+        for (size_t i = ord.size(); i > 1; --i) std::swap(ord[i - 1], ord[next() % i]);
+    }
     IdxEq r; r.start.push_back(0);
     for (u32 c : ord) {
         r.labels.insert(r.labels.end(), q.labels.begin() + q.start[c], q.labels.begin() + q.start[c + 1]);
@@ -856,7 +884,7 @@ static void tiny_cell(const Cell& c, const u32* t2g, bool usa, u32 num_rows,
 
 struct CellOut {
     std::vector<u32> ind; std::vector<float> val; u8 flags = 0; double mmrate = 0.0; u32 em_iters = 0;
-    u32 pug[4] = {0, 0, 0, 0};   // parsimony: molecules, tie events, components with a tie, molecules of those components
+    u32 pug[5] = {0, 0, 0, 0, 0};   // parsimony: molecules, tie events, components with a tie, molecules of those components, tie-free components whose reversed cover differs (mode 2)
     // cfg.dump_eq: gene_eqc as the -d block sees it (quant.rs:1282-1307), in lexicographic label order
     std::vector<u32> eq_labels, eq_len, eq_count;
     BootOut boot;
@@ -918,7 +946,7 @@ static int quant_cell(const afq_config& cfg, const u32* t2g, u32 ref_count, cons
         int rc = parsimony(g, m, t2g, gl, cfg.large_graph_thresh, eqc, st, err);
         if (rc) return rc;
         if (st.alt) o.flags |= AFQ_CELL_ALT_RES;
-        o.pug[0] = (u32)st.total; o.pug[1] = (u32)st.tie_events; o.pug[2] = (u32)st.tie_components; o.pug[3] = (u32)st.tie_molecules;
+        o.pug[0] = (u32)st.total; o.pug[1] = (u32)st.tie_events; o.pug[2] = (u32)st.tie_components; o.pug[3] = (u32)st.tie_molecules; o.pug[4] = (u32)st.tie_free_differing;
         finish(res == AFQ_RES_PARSIMONY || res == AFQ_RES_PARSIMONY_GENE);
     } else { err = "bad resolution"; return AFQ_ERR_INVALID_ARG; }
     for (u32 gidx = 0; gidx < counts.size(); ++gidx)  // quant.rs:1156-1168
@@ -980,7 +1008,7 @@ int ora_quant(const afq_config* cfg, const uint32_t* t2g, uint32_t ref_count, co
         R->val.insert(R->val.end(), o.val.begin(), o.val.end());
         R->cell_ptr.push_back(R->gene.size());
         R->bc.push_back(c.bc); R->nrec.push_back(c.nrec); R->flags.push_back(o.flags);
-        R->mmrate.push_back(o.mmrate); R->em_iters.push_back(o.em_iters); R->pug.insert(R->pug.end(), o.pug, o.pug + 4); R->add_eq(o);
+        R->mmrate.push_back(o.mmrate); R->em_iters.push_back(o.em_iters); R->pug.insert(R->pug.end(), o.pug, o.pug + 5); R->add_eq(o);
     }
     out->n_cells = n_cells; out->first_cell_index = first_cell_index; out->nnz = R->gene.size();
     out->cell_ptr = R->cell_ptr.data(); out->gene = R->gene.data(); out->val = R->val.data();
@@ -1023,7 +1051,7 @@ int ora_quant_mt(const afq_config* cfg, const uint32_t* t2g, uint32_t ref_count,
         R->val.insert(R->val.end(), outs[i].val.begin(), outs[i].val.end());
         R->cell_ptr.push_back(R->gene.size());
         R->bc.push_back(bcs[i]); R->nrec.push_back(nrecs[i]); R->flags.push_back(outs[i].flags);
-        R->mmrate.push_back(outs[i].mmrate); R->em_iters.push_back(outs[i].em_iters); R->pug.insert(R->pug.end(), outs[i].pug, outs[i].pug + 4); R->add_eq(outs[i]);
+        R->mmrate.push_back(outs[i].mmrate); R->em_iters.push_back(outs[i].em_iters); R->pug.insert(R->pug.end(), outs[i].pug, outs[i].pug + 5); R->add_eq(outs[i]);
     }
     out->n_cells = n_cells; out->first_cell_index = first_cell_index; out->nnz = R->gene.size();
     out->cell_ptr = R->cell_ptr.data(); out->gene = R->gene.data(); out->val = R->val.data();
@@ -1032,10 +1060,12 @@ int ora_quant_mt(const afq_config* cfg, const uint32_t* t2g, uint32_t ref_count,
     return 0;
 }
 
-// parsimony resolutions: per cell {molecules, tie events, components with a tie, molecules of those components} (PugStats)
+// parsimony resolutions: per cell {molecules, tie events, components with a tie, molecules of those components, tie-free components that differ under the reversed scan} (PugStats)
 const uint32_t* ora_result_pug_stats(const afq_result* r) { return r && r->opaque ? ((Result*)r->opaque)->pug.data() : nullptr; }
 // 0 = ascending vertex id (canonical), 1 = descending: the cover's scan order when several maximal arborescences tie
-void ora_set_tie_break(int descending) { g_tie_desc = descending ? 1 : 0; }
+void ora_set_tie_break(int mode) { g_tie_desc = mode == 1 || mode == 2 ? mode : 0; }
+// 0 = canonical class order of the EM's f32 sums; otherwise the seed of a shuffle of it (canonical_em_order)
+void ora_set_em_order(uint64_t seed) { g_em_perm = seed; }
 const uint32_t* ora_result_em_iters(const afq_result* r) { return r && r->opaque ? ((Result*)r->opaque)->em_iters.data() : nullptr; }
 
 // cfg.dump_eq: per-cell gene-level classes (same container as afq_result_eqclasses of include/afquant.h)

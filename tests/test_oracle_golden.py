@@ -292,3 +292,31 @@ def test_atac_dedup_from_rad_is_layout_independent(oracle, bcb):
     b4, off4 = pkg.rad.encode_atac_cells(cells, bc_bytes=4)
     ref = oracle.atac_dedup_rad(b4, off4, bc_bytes=4)
     assert [x.tolist() for x in ref[:6]] + [ref[6]] == base
+
+
+def test_tie_free_components_and_em_order_switches(oracle):
+    """The two measurement switches of the oracle (bench.py reports them for configs[2]): covering every component with the
+    scan reversed changes nothing in components that met no tie (pugutils.rs:1090-1146: only the choice between equally
+    large arborescences depends on the scan), and summing the EM's classes in a shuffled order (em.rs:464 walks a
+    HashMap) moves counts by rounding only; with both switches off the result is the canonical one, bit for bit."""
+    import numpy as np
+
+    pkg = __import__("importlib").import_module("alevin-fry_amd")
+    s = pkg.synth.synth(31, [6000, 1500, 700, 260], num_genes=250, txp_per_gene=3, usa=True, dup=0.55, zipf=0.5, cross=0.3,
+                        umi_err=0.03, max_extra_na=5)
+    b, off = s.encode()
+    cfg = pkg.WorkerConfig.for_resolution("parsimony-em", usa_mode=True, num_genes=s.num_genes, num_rows=s.num_rows)
+    base = oracle.quant(cfg, s.tid_to_gid, b, off)
+    chk, ps = oracle.quant(cfg, s.tid_to_gid, b, off, want_pug_stats=True, check_tie_free=True)
+    assert np.array_equal(chk.val.view(np.uint32), base.val.view(np.uint32)) and np.array_equal(chk.gene, base.gene)
+    assert ps[:, 1].sum() > 0, "the input is meant to have ties"
+    assert ps[:, 4].sum() == 0, "a component without a tie event changed with the scan order"
+    moved = 0
+    for seed in (1, 2):
+        o = oracle.quant(cfg, s.tid_to_gid, b, off, em_order_seed=seed)
+        assert np.array_equal(o.cell_ptr, base.cell_ptr) and np.array_equal(o.gene, base.gene)
+        np.testing.assert_allclose(o.val, base.val, rtol=1e-5, atol=0)
+        moved += int((o.val.view(np.uint32) != base.val.view(np.uint32)).sum())
+    assert moved > 0, "a shuffled summation order should move some last bits"
+    again = oracle.quant(cfg, s.tid_to_gid, b, off)
+    assert np.array_equal(again.val.view(np.uint32), base.val.view(np.uint32))
