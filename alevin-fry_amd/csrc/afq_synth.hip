@@ -50,6 +50,9 @@ void build_model(const afq_synth_params& p, HostModel& H) {
     m.thr_cross = thr32(p.cross); m.thr_umi_err = thr32(p.umi_err);
     m.thr_unspl = thr32(p.p_unspliced); m.thr_unspl_both = thr32(p.p_unspliced + p.p_both);
     m.bc_salt = (uint32_t)mix(p.seed * 1000003ull + 0xBCull);
+    m.thr_tail = thr32(p.tail);
+    m.tail_max = p.tail_max ? std::min<uint32_t>(p.tail_max, afq_synth::kMaxRefs) : afq_synth::kMaxRefs;
+    m.family = std::max<uint32_t>(1, std::min<uint32_t>(p.family ? p.family : 8, p.num_genes));
     const uint32_t G = p.num_genes;
     std::vector<double> w(G);
     double tot = 0;
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(kNT) void k_synth_sizes(Model m, uint64_t first_cel
     const uint32_t c = cell_of_tile(tile_prefix, n_cells, tile);
     const uint32_t nrec = cell_nrec[c], n_mol = afq_synth::num_molecules(m, nrec);
     const uint32_t r0 = (tile - tile_prefix[c]) * kTile;
-    uint32_t sum = 0, refs[3], umi;
+    uint32_t sum = 0, refs[afq_synth::kMaxRefs], umi;
     for (uint32_t k = 0; k < kTile / kNT; ++k) {
         const uint32_t r = r0 + k * kNT + tid;
         if (r < nrec) sum += 3u + afq_synth::record<false>(m, first_cell + c, r, n_mol, refs, umi);
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(kNT) void k_synth_fill(Model m, uint64_t first_cell
     if (r0 == 0 && tid == 0) { out[base - 2] = cell_words[c] * 4u; out[base - 1] = nrec; }
     for (uint32_t k = 0; k < kTile / kNT; ++k) {
         const uint32_t r = r0 + k * kNT + tid;
-        uint32_t refs[3], umi = 0, na = 0, sz = 0;
+        uint32_t refs[afq_synth::kMaxRefs], umi = 0, na = 0, sz = 0;
         if (r < nrec) { na = afq_synth::record<true>(m, first_cell + c, r, n_mol, refs, umi); sz = 3u + na; }
         uint32_t inc = sz;
         for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d); if ((int)lane >= d) inc += t; }
@@ -137,6 +140,16 @@ __global__ __launch_bounds__(kNT) void k_synth_fill(Model m, uint64_t first_cell
         __syncthreads();
         uint32_t wbase = 0, total = 0;
         for (uint32_t w = 0; w < kNT / 64; ++w) { const uint32_t v = s_wave[w]; if (w < wave) wbase += v; total += v; }
+        if (m.thr_tail) {   // (records of up to 67 dwords: no staging, every lane writes its own)
+            if (sz) {
+                uint64_t o = base + wbase + inc - sz;
+                out[o++] = na; out[o++] = bc; out[o++] = umi;
+                for (uint32_t j = 0; j < na; ++j) out[o++] = refs[j] | 0x80000000u;
+            }
+            base += total;
+            __syncthreads();
+            continue;
+        }
         if (sz) {
             uint32_t o = wbase + inc - sz;
             s_stage[o++] = na; s_stage[o++] = bc; s_stage[o++] = umi;
@@ -193,7 +206,7 @@ int afq_synth_host_plan(const afq_synth_params* p, uint64_t first_cell, uint32_t
     build_model(*p, H);
     std::vector<uint64_t> sizes(n);
     parallel_for(n, p->n_threads, [&](uint32_t c) {
-        uint32_t refs[3], umi;
+        uint32_t refs[afq_synth::kMaxRefs], umi;
         const uint32_t nm = afq_synth::num_molecules(H.m, cell_nrec[c]);
         uint64_t words = 2;
         for (uint32_t r = 0; r < cell_nrec[c]; ++r) words += 3 + afq_synth::record<false>(H.m, first_cell + c, r, nm, refs, umi);
@@ -220,7 +233,7 @@ int afq_synth_host_fill(const afq_synth_params* p, uint64_t first_cell, uint32_t
         const uint32_t nm = afq_synth::num_molecules(H.m, cell_nrec[c]);
         const uint32_t bc = afq_synth::barcode(H.m, first_cell + c);
         uint64_t k = 2;
-        uint32_t refs[3], umi;
+        uint32_t refs[afq_synth::kMaxRefs], umi;
         for (uint32_t r = 0; r < cell_nrec[c]; ++r) {
             const uint32_t na = afq_synth::record<true>(H.m, first_cell + c, r, nm, refs, umi);
             if ((k + 3 + na) * 4 > lim) { bad = 1; return; }

@@ -22,6 +22,11 @@ struct Model {
     uint32_t thr_cross, thr_umi_err;       // P(an extra ref sits on another gene), P(1-base UMI error)
     uint32_t thr_unspl, thr_unspl_both;    // USA: P(unspliced), P(unspliced or spliced+unspliced)
     uint32_t bc_salt;
+    // label-length tail (na_model "tail"): after the one to three refs above, further refs are added while a draw stays under
+    // thr_tail (a geometric run, at most tail_max refs in all), each on a gene of the read's gene FAMILY - the block of
+    // `family` consecutive gene ids its gene sits in - so that labels of 5..30 refs over more than four genes occur, as they
+    // do against a transcriptome with paralogues; thr_tail = 0: the plain model, byte for byte what it was
+    uint32_t thr_tail, tail_max, family;
     const uint32_t* alias_thr;  // [G] Walker alias table of the gene popularity: threshold / other gene
     const uint32_t* alias_idx;
 };
@@ -58,10 +63,12 @@ __host__ __device__ inline uint32_t barcode(const Model& m, uint64_t cell) {
     return x;
 }
 
-// One record: refs[0..n) ascending and distinct (n <= 3), its UMI.  Returns n.
+constexpr uint32_t kMaxRefs = 64;   // refs of one record at most (tail model)
+
+// One record: refs[0..n) ascending and distinct (n <= 3, or <= tail_max under the tail model), its UMI.  Returns n.
 // FULL = false computes only what the record's size depends on (no UMI).
 template <bool FULL>
-__host__ __device__ inline uint32_t record(const Model& m, uint64_t cell, uint32_t read, uint32_t n_mol, uint32_t (&refs)[3], uint32_t& umi) {
+__host__ __device__ inline uint32_t record(const Model& m, uint64_t cell, uint32_t read, uint32_t n_mol, uint32_t (&refs)[kMaxRefs], uint32_t& umi) {
     const uint32_t cl = (uint32_t)cell, ch = (uint32_t)(cell >> 32);
     uint32_t w[4], q[4];
     philox(read, cl, ch, 0u, m.k0, m.k1, w);   // w0 molecule, w1 na, w2 transcript, w3 splicing state
@@ -97,6 +104,24 @@ __host__ __device__ inline uint32_t record(const Model& m, uint64_t cell, uint32
         if (refs[1] == refs[2]) n = 2;
     }
     if (n > 1 && refs[0] == refs[1]) { refs[1] = refs[2]; --n; }
+    if (m.thr_tail) {   // the tail: more refs on the gene's family, kept ascending and distinct by insertion
+        const uint32_t fam0 = (gene / m.family) * m.family;
+        const uint32_t fam_n = fam0 + m.family <= m.num_genes ? m.family : m.num_genes - fam0;
+        for (uint32_t k = 0; n < m.tail_max; ++k) {
+            uint32_t e[4];
+            philox(read, cl, ch, 0x100u + k, m.k0, m.k1, e);   // e0 one more?, e1 which gene of the family, e2 transcript, e3 unspliced?
+            if (e[0] >= m.thr_tail) break;
+            const uint32_t g = fam0 + below(e[1], fam_n);
+            uint32_t t = first_txp(m, g) + below(e[2], num_txp(m, g));
+            if (m.usa && e[3] < m.thr_unspl) t = m.n_spliced + g;
+            uint32_t at = n;
+            while (at > 0 && refs[at - 1] > t) --at;
+            if (at > 0 && refs[at - 1] == t) continue;
+            for (uint32_t q = n; q > at; --q) refs[q] = refs[q - 1];
+            refs[at] = t;
+            ++n;
+        }
+    }
     if (FULL) {
         uint32_t u = q[0] & m.umi_mask;
         uint32_t x[4];

@@ -37,6 +37,9 @@ class SynthParams(C.Structure):
         ("p_both", C.c_double),
         ("n_threads", C.c_uint32),
         ("ref_count", C.c_uint32),
+        ("tail", C.c_double),
+        ("tail_max", C.c_uint32),
+        ("family", C.c_uint32),
     ]
 
 
@@ -123,11 +126,14 @@ def _lib():
 
 def params(seed=2, n_cells=11000, median_reads=30000.0, sigma=0.6, num_genes=36601, txp_per_gene=5, usa=False,
            umi_len=12, dup=0.4, p_na2=0.2, p_na3=0.1, cross=0.5, umi_err=0.01, zipf=1.1, pow_skew=0.0, p_unspliced=0.35,
-           p_both=0.08, min_reads=1, n_threads=0, ref_count=0) -> SynthParams:
+           p_both=0.08, min_reads=1, n_threads=0, ref_count=0, tail=0.0, tail_max=64, family=8) -> SynthParams:
     """Defaults = SURVEY §8(d) config 2 (PBMC-10k-like); pass ref_count=199138 for its transcriptome size.
-    pow_skew=16 is the round-1 popularity (half of all molecules on gene 0), kept as a stress variant."""
+    pow_skew=16 is the round-1 popularity (half of all molecules on gene 0), kept as a stress variant.
+    tail > 0 is the label-length tail: a geometric run of further refs (P(one more) = tail, at most tail_max per record) on
+    the genes of the read's gene family (blocks of `family` gene ids); 0.6 gives E[na] ~ 3 with labels of 5..30 refs."""
     return SynthParams(seed, n_cells, min_reads, median_reads, sigma, num_genes, txp_per_gene, int(usa), umi_len, dup,
-                       p_na2, p_na3, cross, umi_err, zipf, pow_skew, p_unspliced, p_both, n_threads or (os.cpu_count() or 1), ref_count)
+                       p_na2, p_na3, cross, umi_err, zipf, pow_skew, p_unspliced, p_both, n_threads or (os.cpu_count() or 1), ref_count,
+                       tail, tail_max, family)
 
 
 def _dims(lib, p):

@@ -14,6 +14,8 @@ launched under torchrun it just joins as a rank.  Headline line = BASELINE.json 
 (PBMC-10k-like, cr-like), one such sample PER RANK (weak scaling: cells are independent, ranks share
 nothing on the data path).  The same JSON line carries further legs under "also":
   configs2  configs[2]: USA, parsimony-em on the same cells (N = 1)
+  configs1_tail / configs2_tail   the same two configurations under the label-length tail model (--na-model tail: E[na] ~ 3,
+            labels of 5..30 refs on gene families), oracle-sampled, with the time per input byte against the plain model (N = 1)
   configs3  configs[3]: the ~10^6-cell x 2*10^4-read data set, cells range-sharded over the ranks
             (each rank generates and quantifies ITS byte-balanced range: 125 000 cells per GPU; every rank checks a
             sample of its shard against the oracle)
@@ -54,6 +56,9 @@ def parse_args():
     ap.add_argument("--ref-count", type=int, default=199138, help="spliced transcripts (SURVEY §8d config 2)")
     ap.add_argument("--popularity", default="zipf1.1", choices=["zipf1.1", "pow16"],
                     help="gene popularity: Zipf(1.1) as SURVEY §8d specifies, or the round-1 stress variant floor(G*x^16)")
+    ap.add_argument("--na-model", default="plain", choices=["plain", "tail"],
+                    help="alignments per read: plain = 1..3 (SURVEY 8d), tail = a geometric run of further refs on the gene's family "
+                         "(E[na] ~ 3, labels of 5..30 refs, molecules of more than four genes)")
     ap.add_argument("--usa", action="store_true")
     ap.add_argument("--resolution", default=None, help="override the workload's resolution")
     ap.add_argument("--umi-err", type=float, default=0.01)
@@ -135,9 +140,14 @@ class Dist:
 
 
 # ---------------------------------------------------------------------------------------------------------
-def synth_kw(args, usa):
+TAIL_P = 0.65   # P(one more ref) of the tail model: E[na] ~ 3
+
+
+def synth_kw(args, usa, tail=None):
     kw = dict(median_reads=args.median_reads, sigma=args.sigma, num_genes=args.genes, usa=usa, umi_err=args.umi_err,
               ref_count=args.ref_count if args.ref_count >= args.genes else 0)
+    if (args.na_model == "tail") if tail is None else tail:
+        kw.update(tail=TAIL_P, tail_max=64, family=8)
     if args.popularity == "pow16":
         kw.update(zipf=0.0, pow_skew=16.0)
     return kw
@@ -304,12 +314,13 @@ def line(D, args, workload, value, elapsed, steps, warmup, cfgd, extra):
 
 
 # ---------------------------------------------------------------------------------------------------------
-def run_pbmc(D, args, pkg, sn, usa, resolution, steps, warmup, cpu_seconds, name, min_cells=0, tie_stats=False):
+def run_pbmc(D, args, pkg, sn, usa, resolution, steps, warmup, cpu_seconds, name, min_cells=0, tie_stats=False, tail=None):
     """configs[1] / configs[2]: one PBMC-10k-like sample per rank, generated in HBM."""
     import numpy as np
 
     t0 = time.time()
-    rad = sn.generate_device(device=D.local_rank, seed=2 + D.rank, n_cells=args.cells, **synth_kw(args, usa))
+    tailed = (args.na_model == "tail") if tail is None else tail
+    rad = sn.generate_device(device=D.local_rank, seed=2 + D.rank, n_cells=args.cells, **synth_kw(args, usa, tail))
     t_gen = time.time() - t0
     cfg = pkg.WorkerConfig.for_resolution(resolution, usa_mode=rad.usa, num_genes=rad.num_genes, num_rows=rad.num_rows, profile=True,
                                           umi_len=12, num_bootstraps=args.bootstraps, summary_stat=True)   # umi_len: the RAD header's `ulen`
@@ -324,16 +335,19 @@ def run_pbmc(D, args, pkg, sn, usa, resolution, steps, warmup, cpu_seconds, name
         nnz = int(res.cell_ptr[-1])
         alg = float(st["input_bytes"]) + 8.0 * nnz
         default_wl = (args.cells, args.median_reads, args.sigma, args.genes, args.ref_count, args.popularity, args.umi_err) == \
-            (11000, 30000.0, 0.6, 36601, 199138, "zipf1.1", 0.01) and not usa and resolution == "cr-like"
+            (11000, 30000.0, 0.6, 36601, 199138, "zipf1.1", 0.01) and not usa and resolution == "cr-like" and not tailed
         sizes_default = (args.cells, args.median_reads, args.sigma, args.genes, args.ref_count, args.popularity, args.umi_err) == \
             (11000, 30000.0, 0.6, 36601, 199138, "zipf1.1", 0.01)
-        roof = roofline_of(ktimes, alg, steps, default_wl or ("configs2" if sizes_default and usa and resolution == "parsimony-em" else False))
+        roof = roofline_of(ktimes, alg, steps, default_wl or ("configs2" if sizes_default and usa and resolution == "parsimony-em" and not tailed else False))
         cpu = None
         if D.world == 1 and not args.no_cpu_baseline and cpu_seconds > 0:
             cpu = cpu_leg(cfg, rad, res, cpu_seconds, min_cells=min_cells, tie_stats=tie_stats)
         cfgd = {"workload": f"{name}: PBMC-10k-like 10x-v3 collated RAD, {resolution}, per GPU: {args.cells} cells, log-normal reads/cell "
                             f"median {args.median_reads:g} sigma {args.sigma:g}, {args.genes} genes / {len(rad.tid_to_gid)} transcripts, "
-                            f"gene popularity {args.popularity}" + (", USA" if usa else "") + "; generated in HBM (Philox)",
+                            f"gene popularity {args.popularity}" + (", USA" if usa else "") +
+                            (f", label-length tail (geometric extra refs p={TAIL_P} on gene families of 8, <= 64 refs per read)" if tailed else "") +
+                            "; generated in HBM (Philox)",
+                "mean_refs_per_read": round((st["input_bytes"] - 8.0 * args.cells) / max(1, rad.n_reads) / 4.0 - 3.0, 3),
                 "reads_per_gpu": rad.n_reads, "input_bytes_per_gpu": st["input_bytes"], "resolution": resolution,
                 **({"bootstraps": args.bootstraps} if args.bootstraps else {}),
                 "sharding": f"{D.world} x independent cell shards, no data-path collective"}
@@ -515,7 +529,7 @@ def main():
     if args.workload == "atac":
         return bench_atac(args, pkg, D)
     also = args.also.split(",") if args.also not in ("auto", "none") else \
-        ([] if args.also == "none" else (["configs2", "configs3", "atac", "e2e", "cli", "reference"] if D.world == 1 else ["configs3", "atac"]))
+        ([] if args.also == "none" else (["configs2", "configs1_tail", "configs2_tail", "configs3", "atac", "e2e", "cli", "reference"] if D.world == 1 else ["configs3", "atac"]))
     also = [a for a in also if a and a != args.workload]
     legs = {}
     out = None
@@ -578,6 +592,19 @@ def main():
                 r2.free()
                 return o2
             leg("configs2", f)
+        for tleg, tusa, tres in (("configs1_tail", False, "cr-like"), ("configs2_tail", True, "parsimony-em")):
+            if tleg in also and D.world == 1:
+                def f(tusa=tusa, tres=tres, tleg=tleg):
+                    o2, r2, q2 = run_pbmc(D, args, pkg, sn, tusa, tres, max(1, min(3, args.steps)), 1, min(args.cpu_seconds, 4.0),
+                                          "configs[2]" if tusa else "configs[1]", min_cells=100, tail=True)
+                    q2.close()
+                    r2.free()
+                    base = out if not tusa else legs.get("configs2")
+                    if o2 and base and "ms_per_step" in base:   # time per input byte against the plain model of the same configuration
+                        o2["slowdown_per_input_byte_vs_plain"] = round((o2["ms_per_step"] / o2["config"]["input_bytes_per_gpu"]) /
+                                                                       (base["ms_per_step"] / base["config"]["input_bytes_per_gpu"]), 3)
+                    return o2
+                leg(tleg, f)
         if "configs3" in also:
             r3 = None
             try:

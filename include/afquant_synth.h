@@ -45,6 +45,10 @@ typedef struct afq_synth_params {
     uint32_t n_threads;  /* host generator                             */
     uint32_t ref_count;  /* spliced transcripts in total (SURVEY config 2: 199 138); 0 = num_genes * txp_per_gene:
                             gene g owns ref_count / G transcripts, the first ref_count % G genes one more        */
+    double tail;         /* label-length tail: P(one more ref) of a geometric run of further refs on the gene's family
+                            (0 = off: at most three refs per record, the plain model); 0.6 gives E[na] ~ 3        */
+    uint32_t tail_max;   /* refs per record at most under the tail model (<= 64; 0 = 64)                          */
+    uint32_t family;     /* genes per family: the tail's refs sit on genes of the read's block of `family` gene ids (0 = 8) */
 } afq_synth_params;
 
 /* ref_count (USA: + G unspliced) / gene-id space / output columns implied by the params */

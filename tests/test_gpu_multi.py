@@ -24,7 +24,9 @@ CLI = os.path.join(ROOT, "alevin-fry_amd", "csrc", "afquant")
 @pytest.mark.parametrize("kw", [dict(n_cells=300, median_reads=900.0, sigma=1.0, num_genes=500, ref_count=1733),
                                 dict(n_cells=40, median_reads=30000.0, ref_count=199138),
                                 dict(n_cells=200, median_reads=2000.0, num_genes=300, txp_per_gene=3, usa=True, umi_err=0.05),
-                                dict(n_cells=500, median_reads=40.0, sigma=0.3, num_genes=100, pow_skew=16.0, zipf=0.0, umi_len=10)])
+                                dict(n_cells=500, median_reads=40.0, sigma=0.3, num_genes=100, pow_skew=16.0, zipf=0.0, umi_len=10),
+                                dict(n_cells=120, median_reads=2500.0, num_genes=400, txp_per_gene=4, usa=True, tail=0.65, family=8),
+                                dict(n_cells=60, median_reads=4000.0, num_genes=300, ref_count=1500, tail=0.8, tail_max=64, family=16)])
 def test_device_generator_writes_the_host_generators_bytes(kw):
     """csrc/afq_synth.hip: the gfx950 kernels and the host loop run the same integer record model (Philox4x32-10 words
     against 32-bit thresholds), so the bytes must agree exactly - for the whole set and for a range of it."""
@@ -53,15 +55,18 @@ def test_device_generator_writes_the_host_generators_bytes(kw):
     assert len(bcs) == n
     na = int(w[int(h.chunk_off[0]) // 4 + 2])
     refs = w[int(h.chunk_off[0]) // 4 + 5: int(h.chunk_off[0]) // 4 + 5 + na] & 0x7FFFFFFF
-    assert 1 <= na <= 3 and (np.diff(refs.astype(np.int64)) > 0).all() and refs.max() < len(h.tid_to_gid)
+    assert 1 <= na <= (64 if kw.get("tail") else 3) and (np.diff(refs.astype(np.int64)) > 0).all() and refs.max() < len(h.tid_to_gid)
 
 
-def test_generated_workload_quantifies_like_the_oracle(oracle):
+@pytest.mark.parametrize("tail", [0.0, 0.7])
+def test_generated_workload_quantifies_like_the_oracle(oracle, tail):
     """The generator's output through the device path and through the oracle (USA, parsimony-em): the bench's input is
-    an ordinary collated RAD as far as both are concerned."""
-    d = sn.generate_device(device=0, seed=3, n_cells=60, median_reads=3000.0, num_genes=400, txp_per_gene=4, usa=True, umi_err=0.03)
+    an ordinary collated RAD as far as both are concerned - with the label-length tail too (labels of up to dozens of refs
+    on gene families: the long-record paths of the decoders, hashed label keys, molecules of more than four genes)."""
+    d = sn.generate_device(device=0, seed=3, n_cells=60, median_reads=3000.0, num_genes=400, txp_per_gene=4, usa=True, umi_err=0.03,
+                           tail=tail, family=8)
     try:
-        for res in ("cr-like", "parsimony-em"):
+        for res in ("cr-like", "parsimony-em", "parsimony", "cr-like-em"):
             cfg = pkg.WorkerConfig.for_resolution(res, usa_mode=True, num_genes=d.num_genes, num_rows=d.num_rows, umi_len=12)
             q = pkg.Quantifier(cfg, d.tid_to_gid, device=0)
             try:
