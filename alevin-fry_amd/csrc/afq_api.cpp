@@ -1038,6 +1038,12 @@ int afq_device_warmup(int device) {
     return 0;
 }
 
+int afq_device_pci_bus_id(int device, char* out, size_t out_len) {
+    if (!out || out_len < 13) return AFQ_ERR_INVALID_ARG;
+    if (hipDeviceGetPCIBusId(out, (int)out_len, device) != hipSuccess) { (void)hipGetLastError(); return AFQ_ERR_NO_DEVICE; }
+    return 0;
+}
+
 const char* afq_last_error(const afq_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
 int afq_create(const afq_config* cfg, const uint32_t* tid_to_gid, uint32_t ref_count, int device, afq_ctx** out) {

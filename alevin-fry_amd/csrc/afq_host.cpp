@@ -12,7 +12,9 @@
 //                                        byte-balanced contiguous cell ranges, rows gathered in cell order
 //   multi-barcode (10x Flex) records     src/quant.rs:1354-1373, 2003-2027, 1217-1262
 //   -d / -b outputs                      src/quant.rs:229-355, 1850-1877
+#include <sched.h>
 #include <algorithm>
+#include <atomic>
 #include <charconv>
 #include <cmath>
 #include <cstdio>
@@ -605,22 +607,6 @@ struct DevOut {   // what one device produced for its range of cells, in cell or
     ~DevOut() { if (is_held) afq_result_release(&held); }
 };
 
-// Greedy prefix split of the chunk list into `parts` contiguous ranges of about equal bytes (the collated
-// file is ordered largest cells first, so equal cell counts would not balance).
-static std::vector<size_t> balanced_cuts(const std::vector<uint64_t>& nbytes, size_t parts) {
-    std::vector<double> csum(nbytes.size() + 1, 0.0);
-    for (size_t i = 0; i < nbytes.size(); ++i) csum[i + 1] = csum[i] + (double)nbytes[i];
-    std::vector<size_t> cuts(1, 0);
-    for (size_t r = 1; r < parts; ++r) {
-        const double target = csum.back() * (double)r / (double)parts;
-        size_t c = (size_t)(std::lower_bound(csum.begin(), csum.end(), target) - csum.begin());
-        if (c > 0 && c <= nbytes.size() && std::fabs(csum[c - 1] - target) <= std::fabs(csum[std::min(c, nbytes.size())] - target)) --c;
-        cuts.push_back(std::min(std::max(c, cuts.back()), nbytes.size()));
-    }
-    cuts.push_back(nbytes.size());
-    return cuts;
-}
-
 // the collated file as afq_submit_reader sees it: pread into the library's pinned staging - the page cache is copied once, by
 // several threads, without the page-fault storm that reading the same bytes through a fresh mapping sets off
 struct FileSource { int fd; uint64_t base; };
@@ -635,23 +621,66 @@ static int file_read_cb(void* user, uint64_t offset, void* dst, size_t len) {
     return 0;
 }
 
-static void run_device_range(const afq_config& cfg, const afq_config* cfg_eq, const std::vector<uint32_t>& t2g, int device,
+// Best effort: run the calling thread (and the staging threads it starts) on the CPUs of the NUMA node the device hangs off,
+// so that the context's pinned staging is first touched there and the copies into it do not cross sockets
+// (/sys/bus/pci/devices/<bus id>/numa_node, /sys/devices/system/node/node<N>/cpulist).  Silent when the topology is not exposed.
+static void bind_thread_to_device_node(int device) {
+    char bus[64] = {0};
+    if (afq_device_pci_bus_id(device, bus, sizeof(bus)) != 0) return;
+    for (char* q = bus; *q; ++q) *q = (char)std::tolower((unsigned char)*q);
+    std::vector<uint8_t> f;
+    if (!read_file(std::string("/sys/bus/pci/devices/") + bus + "/numa_node", f) || f.empty()) return;
+    const int node = std::atoi(std::string(f.begin(), f.end()).c_str());
+    if (node < 0) return;
+    if (!read_file("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist", f) || f.empty()) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    const std::string list(f.begin(), f.end());
+    size_t i = 0;
+    int n_set = 0;
+    while (i < list.size()) {   // "0-63,128-191"
+        char* e = nullptr;
+        const long a = std::strtol(list.c_str() + i, &e, 10);
+        if (e == list.c_str() + i) break;
+        long b = a;
+        i = (size_t)(e - list.c_str());
+        if (i < list.size() && list[i] == '-') { b = std::strtol(list.c_str() + i + 1, &e, 10); i = (size_t)(e - list.c_str()); }
+        for (long cpu = a; cpu <= b && cpu < CPU_SETSIZE; ++cpu) { CPU_SET((int)cpu, &set); ++n_set; }
+        if (i < list.size() && list[i] == ',') ++i; else break;
+    }
+    if (n_set) (void)sched_setaffinity(0, sizeof(set), &set);
+}
+
+struct DevStat { double busy_s = 0; uint64_t bytes = 0, cells = 0; uint32_t batches = 0; int rc = 0; std::string err; };
+
+// One device's host thread: its contexts, then batches of cells popped off the shared queue until it is empty - what the
+// reference's workers do with chunks (quant.rs:1553-1575, 1678-1765); the rows of batch b go to parts[b], so the gather in
+// batch order is the gather in cell order whatever device took which batch.
+static void run_device_worker(const afq_config& cfg, const afq_config* cfg_eq, const std::vector<uint32_t>& t2g, int device, bool bind_numa,
                              const uint8_t* rad, int rad_fd, const std::vector<uint64_t>& chunk_off, const std::vector<uint64_t>& chunk_nb,
-                             const std::vector<uint32_t>& chunk_nr, size_t cell0, size_t cell1, uint64_t batch_bytes, bool want_eq, bool res_is_em, DevOut& out) {
+                             const std::vector<uint32_t>& chunk_nr, const std::vector<std::pair<size_t, size_t>>& batches, std::atomic<size_t>& next,
+                             std::atomic<int>& stop, bool want_eq, bool res_is_em, std::vector<DevOut>& parts, DevStat& stat) {
     auto now = []() { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    if (bind_numa) bind_thread_to_device_node(device);
     afq_ctx* raw = nullptr;
     int rc = afq_create(&cfg, t2g.data(), (uint32_t)t2g.size(), device, &raw);
-    if (rc) { out.rc = rc; out.err = std::string("afq_create: ") + afq_last_error(nullptr); return; }
+    if (rc) { stat.rc = rc; stat.err = std::string("afq_create: ") + afq_last_error(nullptr); stop = 1; return; }
     CtxPtr ctx(raw), ctx_eq;
     if (cfg_eq) {
         rc = afq_create(cfg_eq, t2g.data(), (uint32_t)t2g.size(), device, &raw);
-        if (rc) { out.rc = rc; out.err = std::string("afq_create: ") + afq_last_error(nullptr); return; }
+        if (rc) { stat.rc = rc; stat.err = std::string("afq_create: ") + afq_last_error(nullptr); stop = 1; return; }
         ctx_eq.reset(raw);
     }
-    for (size_t c0 = cell0; c0 < cell1;) {
-        size_t c1 = c0; uint64_t bytes = 0;
-        while (c1 < cell1) { const uint64_t nb = chunk_nb[c1]; if (c1 > c0 && bytes + nb > batch_bytes) break; bytes += nb; ++c1; }
+    const bool single = batches.size() == 1;
+    for (;;) {
+        if (stop.load()) return;
+        const size_t bi = next.fetch_add(1);
+        if (bi >= batches.size()) return;
+        DevOut& out = parts[bi];
+        const size_t c0 = batches[bi].first, c1 = batches[bi].second;
+        const auto t_batch = now();
+        {
         // hand over just this batch's byte span (offsets relative to it), not the whole file
         const uint64_t span0 = chunk_off[c0];
         std::vector<uint64_t> rel(c1 - c0);
@@ -669,7 +698,7 @@ static void run_device_range(const afq_config& cfg, const afq_config* cfg_eq, co
         afq_result res{};
         if (!rc) rc = afq_collect(ctx.get(), &res);
         out.t_submit += secs(ta, tb); out.t_collect += secs(tb, now());
-        if (rc) { out.rc = rc; out.err = afq_last_error(ctx.get()); return; }
+        if (rc) { out.rc = rc; out.err = afq_last_error(ctx.get()); stat.rc = rc; stat.err = out.err; stop = 1; return; }
         if (cfg.num_bootstraps) {   // quant.rs:1270-1277
             afq_bootstraps bs{};
             if (afq_result_bootstraps(&res, &bs) == 0) {
@@ -687,7 +716,7 @@ static void run_device_range(const afq_config& cfg, const afq_config* cfg_eq, co
             if (ctx_eq) {
                 rc = afq_submit(ctx_eq.get(), rad + span0, (size_t)(span1 - span0), rel.data(), (uint32_t)(c1 - c0), c0);
                 if (!rc) rc = afq_collect(ctx_eq.get(), &res_eq);
-                if (rc) { out.rc = rc; out.err = afq_last_error(ctx_eq.get()); afq_result_release(&res); return; }
+                if (rc) { out.rc = rc; out.err = afq_last_error(ctx_eq.get()); stat.rc = rc; stat.err = out.err; stop = 1; afq_result_release(&res); return; }
             }
             const bool have = (ctx_eq || res_is_em) && afq_result_eqclasses(ctx_eq ? &res_eq : &res, &ec) == 0;
             const uint64_t k0 = out.eq_count.size(), w0 = out.eq_labels.size();
@@ -701,7 +730,7 @@ static void run_device_range(const afq_config& cfg, const afq_config* cfg_eq, co
             if (ctx_eq) afq_result_release(&res_eq);
         }
         const uint64_t g0 = out.gene.size();
-        const bool whole = c0 == cell0 && c1 == cell1;
+        const bool whole = single;   // (the one batch of a one-device run: its rows stay in the library's pinned result, no copy)
         if (!whole) {
             out.gene.insert(out.gene.end(), res.gene, res.gene + res.nnz);
             out.val.insert(out.val.end(), res.val, res.val + res.nnz);
@@ -711,7 +740,10 @@ static void run_device_range(const afq_config& cfg, const afq_config* cfg_eq, co
         out.nrec.insert(out.nrec.end(), res.nrec, res.nrec + res.n_cells);
         out.flags.insert(out.flags.end(), res.flags, res.flags + res.n_cells);
         if (whole) { out.held = res; out.is_held = true; } else afq_result_release(&res);
-        c0 = c1;
+        }
+        stat.busy_s += secs(t_batch, now());
+        stat.batches += 1; stat.cells += c1 - c0;
+        for (size_t k = c0; k < c1; ++k) stat.bytes += chunk_nb[k];
     }
 }
 
@@ -1051,13 +1083,32 @@ int afq_quantify(const afq_quant_opts* o) {
     std::vector<int> devices;
     if (o->devices && o->n_devices) devices.assign(o->devices, o->devices + o->n_devices); else devices.push_back((int)o->device);
     if (devices.size() > chunk_off.size() && !chunk_off.empty()) devices.resize(chunk_off.size());
-    const uint64_t batch_bytes = o->batch_bytes ? o->batch_bytes : (16ull << 30);
-    const std::vector<size_t> cuts = balanced_cuts(chunk_nb, devices.size());
-    std::vector<DevOut> parts(devices.size());
+    // The queue: contiguous batches of cells in file order (largest cells first, collate.rs:272-274).  One device: as large
+    // as memory allows (batch_bytes).  Several: about eight batches per device, so that the devices finish together whatever
+    // the cells cost (a parsimony cell's time grows faster than its bytes; static byte-balanced cuts gave the first device all
+    // the giant cells) - every device thread pops the next batch when it has finished its last.
+    const uint64_t batch_cap = o->batch_bytes ? o->batch_bytes : (16ull << 30);
+    uint64_t total_bytes = 0;
+    for (uint64_t nb : chunk_nb) total_bytes += nb;
+    uint64_t batch_bytes = batch_cap;
+    if (devices.size() > 1) batch_bytes = std::min<uint64_t>(batch_cap, std::max<uint64_t>(total_bytes / (8 * devices.size()) + 1, 32ull << 20));
+    if (const char* e = std::getenv("AFQ_QUEUE_BATCH_BYTES")) batch_bytes = std::max<uint64_t>(1, (uint64_t)std::atof(e));   // tests: many small batches
+    std::vector<std::pair<size_t, size_t>> batches;
+    for (size_t c0 = 0; c0 < chunk_off.size();) {
+        size_t c1 = c0; uint64_t bytes = 0;
+        while (c1 < chunk_off.size()) { const uint64_t nb = chunk_nb[c1]; if (c1 > c0 && bytes + nb > batch_bytes) break; bytes += nb; ++c1; }
+        batches.emplace_back(c0, c1);
+        c0 = c1;
+    }
+    if (devices.size() > batches.size() && !batches.empty()) devices.resize(batches.size());
+    std::vector<DevOut> parts(batches.size());
+    std::vector<DevStat> dstat(devices.size());
     {
+        std::atomic<size_t> next{0};
+        std::atomic<int> stop{0};
         auto work = [&](size_t d) {
-            run_device_range(cfg, cfg_eq.dump_eq ? &cfg_eq : nullptr, t2g, devices[d], rad.data(), compressed ? -1 : mf.fd, chunk_off, chunk_nb, chunk_nr, cuts[d], cuts[d + 1],
-                             batch_bytes, o->dump_eq != 0, res_is_em, parts[d]);
+            run_device_worker(cfg, cfg_eq.dump_eq ? &cfg_eq : nullptr, t2g, devices[d], devices.size() > 1, rad.data(), compressed ? -1 : mf.fd, chunk_off, chunk_nb, chunk_nr,
+                              batches, next, stop, o->dump_eq != 0, res_is_em, parts, dstat[d]);
         };
         if (devices.size() == 1) work(0);
         else {
@@ -1066,10 +1117,20 @@ int afq_quantify(const afq_quant_opts* o) {
             for (auto& x : th) x.join();
         }
     }
-    for (size_t d = 0; d < parts.size(); ++d)
-        if (parts[d].rc) return hfail(parts[d].rc, (devices.size() > 1 ? "device " + std::to_string(devices[d]) + ": " : std::string()) + parts[d].err);
-    if (pc.on) for (size_t d = 0; d < parts.size(); ++d)
-        std::fprintf(stderr, "[afquant]   device %d: cells [%zu, %zu), afq_submit %.3f s, afq_collect %.3f s\n", devices[d], cuts[d], cuts[d + 1], parts[d].t_submit, parts[d].t_collect);
+    for (size_t d = 0; d < dstat.size(); ++d)
+        if (dstat[d].rc) return hfail(dstat[d].rc, (devices.size() > 1 ? "device " + std::to_string(devices[d]) + ": " : std::string()) + dstat[d].err);
+    if (pc.on) for (size_t d = 0; d < dstat.size(); ++d)
+        std::fprintf(stderr, "[afquant]   device %d: %u batches, %llu cells, %.3f GB, busy %.3f s\n", devices[d], dstat[d].batches, (unsigned long long)dstat[d].cells, (double)dstat[d].bytes / 1e9, dstat[d].busy_s);
+    if (devices.size() > 1) {   // how the queue spread the work: a small extra file next to quant.json (not one of the reference's outputs)
+        FilePtr df(std::fopen((outd + "/afquant_devices.json").c_str(), "w"));
+        if (df) {
+            std::fprintf(df.get(), "{\n  \"batches\": %zu,\n  \"batch_bytes\": %llu,\n  \"devices\": [\n", batches.size(), (unsigned long long)batch_bytes);
+            for (size_t d = 0; d < dstat.size(); ++d)
+                std::fprintf(df.get(), "    {\"device\": %d, \"batches\": %u, \"cells\": %llu, \"bytes\": %llu, \"busy_s\": %.6f}%s\n", devices[d], dstat[d].batches,
+                             (unsigned long long)dstat[d].cells, (unsigned long long)dstat[d].bytes, dstat[d].busy_s, d + 1 < dstat.size() ? "," : "");
+            std::fprintf(df.get(), "  ]\n}\n");
+        }
+    }
     pc.lap("device batches");
 
     // ---- host-side gather in cell order (the only communication the path has) ----

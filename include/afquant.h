@@ -268,6 +268,9 @@ int afq_get_batch_stats(afq_ctx* ctx, afq_batch_stats* out);
 /* Brings the HIP runtime up on `device` (first-call initialisation) - a host can call it from a side thread while it parses its
    inputs.  Returns 0 or AFQ_ERR_NO_DEVICE. */
 int afq_device_warmup(int device);
+/* PCI bus id of `device` ("0000:c1:00.0"), for a host that wants to place its threads and buffers on the device's NUMA node
+   (/sys/bus/pci/devices/<id>/numa_node).  Returns 0, AFQ_ERR_NO_DEVICE or AFQ_ERR_INVALID_ARG (out too small). */
+int afq_device_pci_bus_id(int device, char* out, size_t out_len);
 
 const char* afq_last_error(const afq_ctx* ctx); /* ctx may be NULL: last create error */
 int afq_abi_version(void);

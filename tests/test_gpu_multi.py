@@ -161,14 +161,15 @@ def _make_dir(tmp, s):
 
 @pytest.mark.parametrize("res,extra", [("cr-like", []), ("parsimony-em", ["-d"]), ("cr-like-em", ["-b", "4", "--summary-stat"])])
 def test_cli_devices_output_is_independent_of_the_device_count(tmp_path, res, extra):
-    """`afquant quant --devices 0,0,0` (three contexts + host threads over byte-balanced cell ranges, rows gathered in cell
-    order, the -d dictionary filled in cell order) writes the same files as `--device 0`."""
+    """`afquant quant --devices 0,0,0` (three contexts + host threads popping batches of cells off one queue, rows gathered in
+    cell order, the -d dictionary filled in cell order) writes the same files as `--device 0`."""
     s = synth.synth(52, [4000, 2500, 1500, 600, 260, 120, 60, 7, 900, 30], num_genes=150, txp_per_gene=3, usa=True, dup=0.5, cross=0.3, umi_err=0.02)
     tg, _, _ = _make_dir(tmp_path / "in", s)
     outs = []
     for name, dev in (("one", ["--device", "0"]), ("three", ["--devices", "0,0,0"])):
         o = tmp_path / name
-        r = subprocess.run([CLI, "quant", "-i", str(tmp_path / "in"), "-m", tg, "-o", str(o), "-r", res, "-t", "4"] + dev + extra, capture_output=True, text=True)
+        env = dict(os.environ, AFQ_QUEUE_BATCH_BYTES="30000") if name == "three" else None   # (a queue of several batches even on this small input)
+        r = subprocess.run([CLI, "quant", "-i", str(tmp_path / "in"), "-m", tg, "-o", str(o), "-r", res, "-t", "4"] + dev + extra, capture_output=True, text=True, env=env)
         assert r.returncode == 0, r.stderr
         outs.append(o)
     files = ["alevin/quants_mat.mtx", "alevin/quants_mat_rows.txt", "alevin/quants_mat_cols.txt", "featureDump.txt"]
@@ -185,8 +186,34 @@ def test_cli_devices_output_is_independent_of_the_device_count(tmp_path, res, ex
     a, b = (json.load(open(o / "quant.json")) for o in outs)
     for k in ("num_quantified_cells", "total_records", "alt_resolved_cell_numbers", "empty_resolved_cell_numbers", "tiny_cell_resolved_cell_numbers"):
         assert a[k] == b[k], k
-    r = subprocess.run([CLI, "quant", "-i", str(tmp_path / "in"), "-m", tg, "-o", str(tmp_path / "bad"), "-r", res, "--devices", "0,99"], capture_output=True, text=True)
+    dv = json.load(open(outs[1] / "afquant_devices.json"))
+    assert dv["batches"] >= 3 and sum(d["cells"] for d in dv["devices"]) == 10 and all(d["batches"] >= 1 for d in dv["devices"])
+    r = subprocess.run([CLI, "quant", "-i", str(tmp_path / "in"), "-m", tg, "-o", str(tmp_path / "bad"), "-r", res, "--devices", "0,99"], capture_output=True, text=True,
+                       env=dict(os.environ, AFQ_QUEUE_BATCH_BYTES="30000"))
     assert r.returncode != 0 and "device 99" in r.stderr
+
+
+def test_cli_device_queue_balances_a_largest_first_file(tmp_path):
+    """Dynamic distribution over devices (the reference's workers pop chunks off a queue, quant.rs:1553-1575): a collated file
+    is ordered largest cells first and a parsimony cell's cost grows faster than its bytes, so contiguous byte-balanced cuts
+    would give one device all the expensive cells.  Three contexts on cuda:0 pop fixed-byte batches instead; their busy times
+    must come out within 1.15x of each other and the files must be those of one device."""
+    d = sn.generate(seed=9, n_cells=600, median_reads=12000.0, sigma=0.8, num_genes=2000, txp_per_gene=4, usa=True, umi_err=0.02)
+    names = [f"T{t}" for t in range(len(d.tid_to_gid))]
+    rows = [(names[t], f"G{g >> 1}", "S" if g % 2 == 0 else "U") for t, g in enumerate(d.tid_to_gid.tolist())]
+    tg = rad.write_quant_input_dir(str(tmp_path / "in"), d.data.tobytes(), len(d.chunk_off), names, rows, cblen=16, ulen=12)
+    outs = []
+    for name, dev, env in (("one", ["--device", "0"], None), ("three", ["--devices", "0,0,0"], dict(os.environ, AFQ_QUEUE_BATCH_BYTES=str(d.n_bytes // 90)))):
+        o = tmp_path / name
+        r = subprocess.run([CLI, "quant", "-i", str(tmp_path / "in"), "-m", tg, "-o", str(o), "-r", "parsimony-em", "-t", "8"] + dev, capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        outs.append(o)
+    for f in ("alevin/quants_mat.mtx", "alevin/quants_mat_rows.txt", "alevin/quants_mat_cols.txt", "featureDump.txt"):
+        assert (outs[0] / f).read_bytes() == (outs[1] / f).read_bytes(), f
+    dv = json.load(open(outs[1] / "afquant_devices.json"))
+    busy = [x["busy_s"] for x in dv["devices"]]
+    assert dv["batches"] >= 60 and len(busy) == 3 and sum(x["cells"] for x in dv["devices"]) == 600
+    assert max(busy) <= 1.15 * min(busy), dv
 
 
 def test_quant_subset_sizes_the_matrix_by_the_subset(tmp_path):
