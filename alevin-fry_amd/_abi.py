@@ -49,7 +49,7 @@ class AfqConfig(C.Structure):
         ("profile", C.c_uint32),
         ("umi_len", C.c_uint32),
         ("dump_eq", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("bc_split", C.c_uint32),
         ("num_bootstraps", C.c_uint32),
         ("summary_stat", C.c_uint32),
         ("boot_seed", C.c_uint64),

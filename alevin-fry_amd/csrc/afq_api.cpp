@@ -345,8 +345,8 @@ int plan_ranges(afq_ctx* c) {
         total_need += nd;
     }
     // (also: parsimony over 4/8-byte fields whose chunks the caller placed at offsets that are not dword aligned - same copy, nothing widened)
-    c->widen = !decode_par_supported(c->cfg.bc_bytes, c->cfg.umi_bytes) || (pug_res && !c->all_aligned);
-    c->eff_bc = c->cfg.bc_bytes < 4 ? 4 : c->cfg.bc_bytes;
+    c->widen = c->cfg.bc_split != 0 || !decode_par_supported(c->cfg.bc_bytes, c->cfg.umi_bytes) || (pug_res && !c->all_aligned);
+    c->eff_bc = c->cfg.bc_split ? 8 : (c->cfg.bc_bytes < 4 ? 4 : c->cfg.bc_bytes);
     c->eff_umi = c->cfg.umi_bytes < 4 ? 4 : c->cfg.umi_bytes;
     if (c->widen) {
         const uint32_t delta = c->eff_bc + c->eff_umi - c->cfg.bc_bytes - c->cfg.umi_bytes;
@@ -619,7 +619,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
         HIP_TRY(c, hipMemcpyAsync(B.d_src_off.p, c->chunk_off.data() + r.c0, 8ull * n, hipMemcpyHostToDevice, s));   // (c->chunk_off outlives the batch)
         ScopedTimer t(c, K_DECODE, s, &B.launches);
         launch_widen(s, c->d_bytes, c->n_bytes, B.d_src_off.as<uint64_t>(), B.d_meta.as<CellMeta>(), n, c->cfg.bc_bytes, c->cfg.umi_bytes,
-                     c->eff_bc, c->eff_umi, c->d_wide.as<uint8_t>(), B.d_status.as<DevStatus>());
+                     c->eff_bc, c->eff_umi, c->d_wide.as<uint8_t>(), B.d_status.as<DevStatus>(), c->cfg.bc_split);
     }
     DecodeArgs da{in_bytes, in_n, B.d_meta.as<CellMeta>(), n, c->d_t2g.as<uint32_t>(), c->ref_count,
                   g.num_genes, B.d_keys0.as<uint64_t>(), B.d_cell_nkeys.as<uint32_t>(),
@@ -1051,8 +1051,9 @@ int afq_create(const afq_config* cfg, const uint32_t* tid_to_gid, uint32_t ref_c
     *out = nullptr;
     if (cfg->abi_version != AFQ_ABI_VERSION) return fail(nullptr, AFQ_ERR_INVALID_ARG, "afq_config.abi_version mismatch");
     if (cfg->resolution > AFQ_RES_PARSIMONY_GENE) return fail(nullptr, AFQ_ERR_INVALID_ARG, "bad resolution");
-    if (!valid_width(cfg->bc_bytes) || !valid_width(cfg->umi_bytes))
-        return fail(nullptr, AFQ_ERR_INVALID_ARG, "bc_bytes/umi_bytes must be 1, 2, 4 or 8");
+    const bool split_ok = cfg->bc_split >= 1 && cfg->bc_split <= 4 && cfg->bc_bytes > cfg->bc_split && cfg->bc_bytes - cfg->bc_split <= 4;
+    if ((cfg->bc_split ? !split_ok : !valid_width(cfg->bc_bytes)) || !valid_width(cfg->umi_bytes))
+        return fail(nullptr, AFQ_ERR_INVALID_ARG, "bc_bytes/umi_bytes must be 1, 2, 4 or 8 (bc_split: two barcode integers of 1..4 bytes each)");
     if (cfg->umi_len > 4 * cfg->umi_bytes) return fail(nullptr, AFQ_ERR_INVALID_ARG, "umi_len does not fit the UMI field");
     if (cfg->num_genes == 0 || cfg->num_rows == 0 || ref_count == 0)
         return fail(nullptr, AFQ_ERR_INVALID_ARG, "num_genes, num_rows and ref_count must be non-zero");

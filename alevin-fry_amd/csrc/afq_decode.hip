@@ -241,7 +241,9 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ byte
 // aligned 4/8-byte layout.
 __global__ __launch_bounds__(256) void k_widen(const uint8_t* __restrict__ src, size_t n_src, const uint64_t* __restrict__ src_off,
                                               const CellMeta* __restrict__ meta, uint32_t n_cells, uint32_t bw, uint32_t uw,
-                                              uint32_t ebw, uint32_t euw, uint8_t* __restrict__ dst, DevStatus* st) {
+                                              uint32_t ebw, uint32_t euw, uint8_t* __restrict__ dst, DevStatus* st, uint32_t bsplit) {
+    // bsplit != 0: the barcode field is two integers of bsplit and bw - bsplit bytes (multi-barcode records of unequal widths);
+    // each becomes a dword (ebw = 8)
     const uint32_t lane = lane_id();
     const uint32_t HDR = 4 + bw + uw, EHDR = 4 + ebw + euw, delta = EHDR - HDR;
     auto ld_n = [](const uint8_t* p, uint32_t n) -> uint64_t {
@@ -303,7 +305,8 @@ __global__ __launch_bounds__(256) void k_widen(const uint8_t* __restrict__ src, 
                 if (rec_idx < m.nrec && drel + EHDR + 4ull * na <= m.nbytes) {
                     uint8_t* d = dchunk + drel;
                     *reinterpret_cast<uint32_t*>(d) = na;
-                    st_n(d + 4, ld_n(rec + 4, bw), ebw);
+                    if (bsplit) { st_n(d + 4, ld_n(rec + 4, bsplit), 4); st_n(d + 8, ld_n(rec + 4 + bsplit, bw - bsplit), 4); }
+                    else st_n(d + 4, ld_n(rec + 4, bw), ebw);
                     st_n(d + 4 + ebw, ld_n(rec + 4 + bw, uw), euw);
                     const uint8_t* rp = rec + HDR;
                     uint32_t* dr = reinterpret_cast<uint32_t*>(d + EHDR);
@@ -317,10 +320,10 @@ __global__ __launch_bounds__(256) void k_widen(const uint8_t* __restrict__ src, 
 }
 
 void launch_widen(hipStream_t s, const uint8_t* src, size_t n_src, const uint64_t* src_off, const CellMeta* meta, uint32_t n_cells,
-                  uint32_t bw, uint32_t uw, uint32_t ebw, uint32_t euw, uint8_t* dst, DevStatus* st) {
+                  uint32_t bw, uint32_t uw, uint32_t ebw, uint32_t euw, uint8_t* dst, DevStatus* st, uint32_t bsplit) {
     if (!n_cells) return;
     const uint32_t grid = std::min<uint32_t>((n_cells + 3) / 4, 8192u);
-    AFQ_LAUNCH(k_widen, grid, 256, s, src, n_src, src_off, meta, n_cells, bw, uw, ebw, euw, dst, st);
+    AFQ_LAUNCH(k_widen, grid, 256, s, src, n_src, src_off, meta, n_cells, bw, uw, ebw, euw, dst, st, bsplit);
 }
 
 // Walk-free proof, final step: per cell compare the accumulated candidate count and sizes

@@ -942,14 +942,17 @@ int afq_quantify(const afq_quant_opts* o) {
     // (Field order b0, b1, u inside a record = the order of the read-tag section; libradicl's MultiBarcodeReadRecord
     // writer is not under /root/reference: parity unpinned.)
     const bool multi_bc = P.file_tag_vals.count("num_barcodes") && P.file_tag_vals["num_barcodes"] > 1;
-    uint32_t w_sample = 0, cblen = 0;
+    uint32_t w_sample = 0, cblen = 0, bc_split = 0;
     if (multi_bc) {
         if (P.file_tag_vals["num_barcodes"] != 2 || P.read_tags.size() != 3 || P.read_tags[0].name != "b0" || P.read_tags[1].name != "b1" || P.read_tags[2].name != "u")
             return hfail(AFQ_ERR_UNSUPPORTED, "multi-barcode RAD: only two barcode levels with read tags (b0, b1, u) are supported");
         const uint32_t w0 = (uint32_t)int_type_bytes(P.read_tags[0].type), w1 = (uint32_t)int_type_bytes(P.read_tags[1].type);
         P.umi_bytes = (uint32_t)int_type_bytes(P.read_tags[2].type);
-        if (!w0 || w0 != w1 || w0 > 4 || !P.umi_bytes) return hfail(AFQ_ERR_UNSUPPORTED, "multi-barcode RAD: b0 and b1 must be integers of the same width (u8/u16/u32)");
-        w_sample = w0; P.bc_bytes = w0 + w1;
+        if (!w0 || !w1 || w0 > 4 || w1 > 4 || !P.umi_bytes) return hfail(AFQ_ERR_UNSUPPORTED, "multi-barcode RAD: b0 and b1 must be integers of 1, 2 or 4 bytes (u8/u16/u32)");
+        // A RAD writer picks the narrowest integer per barcode length (an 8-nt sample barcode is a u16, a 16-nt cell barcode a
+        // u32): unequal widths go to the library as a split barcode field, which it rewrites with two dwords (afq_config.bc_split)
+        P.bc_bytes = w0 + w1;
+        if (w0 != w1) { bc_split = w0; w_sample = 4; } else w_sample = w0;
         if (!P.file_tag_vals.count("b1len")) return hfail(AFQ_ERR_BAD_INPUT, "multi-barcode RAD file should have a \"b1len\" file-level tag");
         cblen = (uint32_t)P.file_tag_vals["b1len"];
     } else {
@@ -1036,7 +1039,7 @@ int afq_quantify(const afq_quant_opts* o) {
     }
     cfg.num_genes = usa ? 2 * G : G; cfg.num_rows = usa ? 3 * G : G;  // src/quant.rs:1627-1645
     cfg.small_thresh = o->small_thresh; cfg.large_graph_thresh = large_thresh; cfg.pug_exact_umi = (R->pars && edist == 0) ? 1 : 0;
-    cfg.em_init_uniform = o->init_uniform; cfg.bc_bytes = P.bc_bytes; cfg.umi_bytes = P.umi_bytes; { const uint64_t ul = P.file_tag_vals.count("ulen") ? P.file_tag_vals["ulen"] : 0; cfg.umi_len = ul <= 4ull * P.umi_bytes ? (uint32_t)ul : 0u; }
+    cfg.em_init_uniform = o->init_uniform; cfg.bc_bytes = P.bc_bytes; cfg.bc_split = bc_split; cfg.umi_bytes = P.umi_bytes; { const uint64_t ul = P.file_tag_vals.count("ulen") ? P.file_tag_vals["ulen"] : 0; cfg.umi_len = ul <= 4ull * P.umi_bytes ? (uint32_t)ul : 0u; }
     // -d: the device keeps the gene-level classes only in the -em resolutions (there they are the EM's input); a plain
     // resolution leaves the same classes behind as its -em sibling (same resolution step, different count extraction:
     // quant.rs:882-924, 966-1019), so for it a second context runs the sibling for the classes alone.  `trivial` never

@@ -165,7 +165,7 @@ def rad_prelude(ref_names, num_chunks, cblen, ulen, bc_bytes=4, umi_bytes=4, is_
     return bytes(out)
 
 
-def rad_prelude_multi_bc(ref_names, num_chunks, b0len, b1len, ulen, b_bytes=4, umi_bytes=4) -> bytes:
+def rad_prelude_multi_bc(ref_names, num_chunks, b0len, b1len, ulen, b_bytes=4, umi_bytes=4, b0_bytes=None) -> bytes:
     """Prelude of a two-level multi-barcode (10x Flex) RAD file as the reference's tests build it
     (tests/multi_barcode_integration.rs:58-130): file tags num_barcodes, b0len, b1len, ulen (u16) and known_rad_type
     (string); read tags b0, b1, u; one u32 alignment tag."""
@@ -182,7 +182,7 @@ def rad_prelude_multi_bc(ref_names, num_chunks, b0len, b1len, ulen, b_bytes=4, u
         return len(b).to_bytes(2, "little") + b + bytes([type_id])
 
     out += (5).to_bytes(2, "little") + tag("num_barcodes", 2) + tag("b0len", 2) + tag("b1len", 2) + tag("ulen", 2) + tag("known_rad_type", 8)
-    out += (3).to_bytes(2, "little") + tag("b0", _INT_TYPE_ID[b_bytes]) + tag("b1", _INT_TYPE_ID[b_bytes]) + tag("u", _INT_TYPE_ID[umi_bytes])
+    out += (3).to_bytes(2, "little") + tag("b0", _INT_TYPE_ID[b0_bytes or b_bytes]) + tag("b1", _INT_TYPE_ID[b_bytes]) + tag("u", _INT_TYPE_ID[umi_bytes])
     out += (1).to_bytes(2, "little") + tag("compressed_ori_refid", 3)
     kind = b"sc_rna_multi_bc"
     out += (2).to_bytes(2, "little") + int(b0len).to_bytes(2, "little") + int(b1len).to_bytes(2, "little") + int(ulen).to_bytes(2, "little")

@@ -176,6 +176,7 @@ def timed_steps(D, q, rad, steps, warmup, first_cell=0):
             a[1] += n
     D.torch.cuda.synchronize(D.dev)
     elapsed = time.perf_counter() - t0
+    D.local_elapsed = elapsed   # this rank's own time (the imbalance report compares the ranks' times, not their bytes)
     if D.dist:
         D.dist.barrier()
     elapsed = D.reduce([elapsed], "max")[0]
@@ -391,6 +392,7 @@ def run_configs3(D, args, pkg, sn, steps, warmup):
         nnz = int(res.cell_ptr[-1])
         tot_reads, tot_cells, tot_bytes, tot_nnz = D.reduce([rad.n_reads, c1 - c0, st["input_bytes"], nnz], "sum")
         max_bytes = D.reduce([st["input_bytes"]], "max")[0]
+        t_max, t_sum = D.reduce([D.local_elapsed], "max")[0], D.reduce([D.local_elapsed], "sum")[0]
         # parity at the shard's size: the oracle on every k-th cell of THIS rank's shard (each rank checks its own), rows
         # compared bit for bit; rank 0's timing is the reported cpu_baseline
         cpu = None
@@ -409,7 +411,8 @@ def run_configs3(D, args, pkg, sn, steps, warmup):
                             f"sigma {sigma:g}, largest first), cr-like, cells range-sharded by bytes over {D.world} GPU(s) "
                             f"({'the full 10^6-cell set is 8 such shards' if args.scaling == 'weak' else 'fixed total'}); generated in HBM shard by shard (Philox, global cell index)",
                 "cells": int(tot_cells), "reads": int(tot_reads), "input_bytes": int(tot_bytes), "rank0_cells": [int(c0), int(c1)],
-                "imbalance_max_over_mean_bytes": round(max_bytes / (tot_bytes / D.world), 4), "resolution": "cr-like",
+                "imbalance_max_over_mean_bytes": round(max_bytes / (tot_bytes / D.world), 4),
+                "imbalance_max_over_mean_time": round(t_max / (t_sum / D.world), 4), "resolution": "cr-like",
                 "sharding": f"{D.world} contiguous cell ranges, no data-path collective"}
         return line(D, args, "configs3", tot_reads * steps / elapsed / 1e6, elapsed, steps, warmup, cfgd,
                     {"cells_per_s": round(tot_cells * steps / elapsed, 1), "nnz": int(tot_nnz), "gen_seconds": round(t_gen, 2),

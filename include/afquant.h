@@ -79,7 +79,11 @@ typedef struct afq_config {
                                     cannot differ), so a value that is too SMALL would lose edges: pass 0 when unsure. */
     uint32_t dump_eq;            /* -d / dump_eq (quant.rs:1282-1307): also keep each cell's gene-level equivalence classes,
                                     handed out by afq_result_eqclasses(); -em resolutions only                  */
-    uint32_t reserved;
+    uint32_t bc_split;           /* multi-barcode records (10x Flex: b0 = sample index, b1 = cell barcode) whose two barcode
+                                    integers differ in width: bc_bytes = w0 + w1 (2..8) and bc_split = w0 (1..4, w1 = bc_bytes - w0
+                                    in 1..4).  The batch is rewritten on the device with both as 4-byte fields and the reported
+                                    barcode is b0 | b1 << 32.  0 = the barcode is one field of 1, 2, 4 or 8 bytes (equal-width
+                                    pairs travel that way too: b0 | b1 << 8 w0).                                               */
     /* -b / --num-bootstraps with --summary-stat (src/quant.rs:1028-1038, em.rs:585-757; -em resolutions only, main.rs:713-724):
        per non-tiny cell, num_bootstraps times: the counts of its gene-level classes are redrawn from a multinomial over the
        observed counts and re-estimated by the EM from a random start; afq_result_bootstraps() hands out the per-column mean

@@ -232,8 +232,11 @@ def test_quant_subset_sizes_the_matrix_by_the_subset(tmp_path):
     assert int(size[0]) == 3 and json.load(open(o / "quant.json"))["num_quantified_cells"] == 3
 
 
-def test_multi_barcode_flex_quant(tmp_path, oracle):
-    """10x Flex (KnownRecordType::RnaShortMultiBC): records carry (b0 = sample index after collation, b1 = cell barcode,
+@pytest.mark.parametrize("w0", [4, 2, 1])
+def test_multi_barcode_flex_quant(tmp_path, oracle, w0):
+    """(w0 = bytes of b0: a RAD writer picks the narrowest integer per barcode length, so an 8-nt sample barcode next to a
+    16-nt cell barcode is u16 + u32 - a 6-byte pair the library takes as a split barcode field, afq_config.bc_split.)
+    10x Flex (KnownRecordType::RnaShortMultiBC): records carry (b0 = sample index after collation, b1 = cell barcode,
     u); rows are labelled sample_cell and featureDump has the sample_name column (src/quant.rs:1217-1262, 1354-1373).
     Structure as the reference's tests build it (tests/multi_barcode_integration.rs:721-1050): samples x cells x 8 reads,
     shared cell barcodes across samples; plus the counts against the oracle reading the same bytes with an 8-byte key."""
@@ -251,10 +254,11 @@ def test_multi_barcode_flex_quant(tmp_path, oracle):
                 refs = [r % G] if ci else sorted({int(rng.integers(0, G)) for _ in range(int(rng.integers(1, 3)))})
                 reads.append((umi, refs))
             cells.append(((cell_bc << 32) | si, reads))
-    b, off = rad.encode_cells(cells, bc_bytes=8, umi_bytes=4)
+    b, off = rad.encode_cells(cells, bc_bytes=8, umi_bytes=4)   # what the oracle reads: the pair as one 8-byte key
+    bf, _ = rad.encode_cells([(((bc >> 32) << (8 * w0)) | (bc & 0xFFFFFFFF), reads) for bc, reads in cells], bc_bytes=w0 + 4, umi_bytes=4)
     d = tmp_path / "in"
-    pre = rad.rad_prelude_multi_bc(names, len(cells), 8, 16, 12)
-    tg = rad.write_quant_input_dir(str(d), bytes(b), len(cells), names, [(n, n) for n in names], prelude=pre)
+    pre = rad.rad_prelude_multi_bc(names, len(cells), 8, 16, 12, b0_bytes=w0)
+    tg = rad.write_quant_input_dir(str(d), bytes(bf), len(cells), names, [(n, n) for n in names], prelude=pre)
     groups = [(0xAA + i, None if i == 1 else f"sample_{'abc'[i]}", i * cells_per_sample, cells_per_sample, 0) for i in range(n_samples)]
     (d / "collation_manifest.bin").write_bytes(rad.collation_manifest(groups))
     for res in ("trivial", "cr-like", "parsimony"):
