@@ -372,6 +372,12 @@ class Quantifier:
             self._check(n)
         return {buf[i].name.decode(): (buf[i].ms, buf[i].launches) for i in range(n)}
 
+    def label_rehash_count(self) -> int:
+        """Ranges of cells decoded again under another label-hash function after a collision (parsimony; see afquant.h)."""
+        self.lib.afq_label_rehash_count.restype = C.c_uint64
+        self.lib.afq_label_rehash_count.argtypes = [C.c_void_p]
+        return int(self.lib.afq_label_rehash_count(self._h))
+
     def batch_stats(self) -> dict:
         s = AfqBatchStats()
         self._check(self.lib.afq_get_batch_stats(self._h, C.byref(s)))

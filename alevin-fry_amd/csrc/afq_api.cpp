@@ -151,6 +151,7 @@ struct RangeState {
     std::vector<CellMeta> meta;
     std::vector<uint2> tile_desc;   // per scatter tile: (cell, tile index inside the cell)
     Range cur{};
+    uint32_t hash_try = 0;   // which salt the range's label hashes were made with (a collision re-runs the range under the next)
     bool in_flight = false;
     hipEvent_t kernels_done = nullptr;
     std::vector<TimedLaunch> launches;  // HIP-event brackets of this range's kernels (cfg.profile)
@@ -172,6 +173,7 @@ struct afq_ctx {
     hipStream_t stream = nullptr;
     uint32_t ref_count = 0;
     std::string err;
+    std::mutex err_mu;   // (the upload thread of afq_submit reports through fail() too)
     DevBuf d_t2g;
     // input
     DevBuf d_bytes_own;
@@ -212,6 +214,7 @@ struct afq_ctx {
     HostResult* res = nullptr;
     // stats / timers
     afq_batch_stats stats{};
+    uint64_t n_label_rehash = 0;   // ranges decoded again under another label-hash salt (life of the context)
     std::vector<TimedLaunch> launches;
     std::vector<hipEvent_t> event_pool;
     double k_ms[K_COUNT] = {0};
@@ -221,7 +224,7 @@ struct afq_ctx {
 namespace {
 
 int fail(afq_ctx* c, int code, const std::string& msg) {
-    if (c) c->err = msg; else g_create_err = msg;
+    if (c) { std::lock_guard<std::mutex> g(c->err_mu); c->err = msg; } else g_create_err = msg;
     return code;
 }
 #define HIP_TRY(c, expr)                                                                          \
@@ -322,6 +325,8 @@ int plan_ranges(afq_ctx* c) {
     // pass 1: validate the chunk headers, device bytes each cell needs
     std::vector<double> need(c->n_cells);
     double total_need = 0, pug_fixed = 0, wide_new = 0;
+    const bool use_slabs = fixed_slabs();            // (environment switches: read once per batch, not per cell)
+    const double slab_slots = (double)slab_capacity();
     c->all_aligned = true;
     for (uint32_t i = 0; i < c->n_cells; ++i) {
         const uint64_t off = c->chunk_off[i];
@@ -339,7 +344,7 @@ int plan_ranges(afq_ctx* c) {
             nd += 20.0 * nrec + 96.0 * nrec;   // rd_h/rd_u/rd_o + the edge pool (24 words per read), as run_range allocates them
             pug_fixed = std::max(pug_fixed, 4.0 * (double)pug_scratch_words(nrec, (uint32_t)n_ref, true) * pug_max_blocks() + 4.0 * (double)(1ull << 22));
         }
-        if (n_ref > kBucketTarget) nd += 16.0 * (double)(n_ref / kBucketTarget + 1) + (fixed_slabs() && !pug_res ? 8.0 * 2.0 * slab_capacity() / kBucketTarget * (double)n_ref : 0.0);   // (+ the slabs of keys1: up to 2 x slab capacity slots per kBucketTarget refs)
+        if (n_ref > kBucketTarget) nd += 16.0 * (double)(n_ref / kBucketTarget + 1) + (use_slabs && !pug_res ? 8.0 * 2.0 * slab_slots / kBucketTarget * (double)n_ref : 0.0);   // (+ the slabs of keys1: up to 2 x slab capacity slots per kBucketTarget refs)
         if (nd > mem_budget) return fail(c, AFQ_ERR_OOM, "cell " + std::to_string(i) + " alone exceeds device memory");
         need[i] = nd;
         total_need += nd;
@@ -403,10 +408,24 @@ static uint32_t decode_short_records(uint64_t n_ref_words, uint64_t n_records) {
     return n_ref_words < 2 * n_records ? 1u : 0u;
 }
 
+// Label hashes of a range: salt 0 first; after a collision (two different labels under one 62-bit key) the range is decoded
+// again under another salt.  AFQ_TEST_LABEL_HASH_BITS=n keeps only n bits of the first try's hashes (tests: collisions for certain).
+static uint64_t label_salt(uint32_t hash_try) {
+    uint64_t x = 0x9E3779B97F4A7C15ull * hash_try;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return hash_try ? (x ^ (x >> 31)) : 0ull;
+}
+static uint64_t label_mask(uint32_t hash_try) {
+    if (hash_try == 0) if (const char* e = std::getenv("AFQ_TEST_LABEL_HASH_BITS")) { const int n = std::atoi(e); if (n > 0 && n < 64) return (1ull << n) - 1; }
+    return ~0ull;
+}
+constexpr uint32_t kMaxHashTries = 4;
+
 // Plan + enqueue one range of cells on the context's stream.
-int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
+int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint32_t hash_try = 0) {
     HostClock hc;
     RangeState& B = c->rs[slot];
+    B.hash_try = hash_try;
     afq_config g = c->cfg;
     if (c->widen) { g.bc_bytes = c->eff_bc; g.umi_bytes = c->eff_umi; }   // what the kernels see: the widened copy
     const uint32_t H = hdr_bytes(g);
@@ -627,8 +646,8 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr) {
                   par ? B.d_chk.as<CellChk>() : nullptr, B.d_slab_prefix.as<uint32_t>(), B.d_slab_cell.as<uint32_t>(),
                   B.d_cell_bc.as<uint64_t>(),
                   (uint32_t)n_slabs,
-                  n_pug ? PugOut{B.d_rd_h.as<uint64_t>(), B.d_rd_u.as<uint64_t>(), B.d_rd_o.as<uint32_t>(), B.d_rd_off.as<uint64_t>()}
-                        : PugOut{nullptr, nullptr, nullptr, nullptr},
+                  n_pug ? PugOut{B.d_rd_h.as<uint64_t>(), B.d_rd_u.as<uint64_t>(), B.d_rd_o.as<uint32_t>(), B.d_rd_off.as<uint64_t>(), label_salt(hash_try), label_mask(hash_try)}
+                        : PugOut{nullptr, nullptr, nullptr, nullptr, 0, ~0ull},
                   g.resolution == AFQ_RES_TRIVIAL ? 1u : 0u, decode_short_records(key_off - n, nrec_total), par ? B.d_fix.as<uint32_t>() : nullptr};
     if (par) {
         ScopedTimer t(c, K_DECODE_PAR, s, &B.launches);
@@ -739,6 +758,11 @@ int finish_range(afq_ctx* c, int slot) {
     hc.lap("finish: wait for kernels");
     DevStatus st{};
     HIP_TRY(c, hipMemcpy(&st, B.d_status.p, sizeof(st), hipMemcpyDeviceToHost));
+    if (st.err_code == kErrLabelHash && B.hash_try + 1 < kMaxHashTries) {   // same range, next hash function (the input bytes are still resident)
+        c->n_label_rehash += 1;
+        const int rc = run_range(c, B.cur, slot, nullptr, B.hash_try + 1);
+        return rc ? rc : finish_range(c, slot);
+    }
     if (st.err_code) {
         const std::string cell = "cell " + std::to_string(B.cur.c0 + st.err_cell) + ": ";
         switch (st.err_code) {
@@ -747,7 +771,7 @@ int finish_range(afq_ctx* c, int slot) {
             case kErrGeneRange: return fail(c, AFQ_ERR_BAD_INPUT, cell + "gene id out of range of num_genes");
             case kErrUmiWide: return fail(c, AFQ_ERR_UNSUPPORTED, cell + "UMI wider than 22 nt is not supported");
             case kErrSlotRange: return fail(c, AFQ_ERR_BAD_INPUT, cell + "resolved column >= num_rows");
-            case kErrLabelHash: return fail(c, AFQ_ERR_UNSUPPORTED, cell + "two ref lists share a 64-bit label hash");
+            case kErrLabelHash: return fail(c, AFQ_ERR_UNSUPPORTED, cell + "two ref lists share a 62-bit label hash under four different hash functions");
             case kErrPugLimit: return fail(c, AFQ_ERR_UNSUPPORTED, cell + "a device-side PUG limit was exceeded (2^20 reads in the cell, a component of more than 4096 vertices under a raised --large-graph-thresh, or a vertex with an empty label)");
             case kErrPugPool: return fail(c, AFQ_ERR_OOM, cell + "PUG edge pool exhausted");
             case kErrInternal: return fail(c, AFQ_ERR_HIP, cell + "internal consistency check failed in the parsimony kernels");
@@ -1004,7 +1028,7 @@ int run_batch(afq_ctx* c) {
         if (c->h2d_piped) {
             std::unique_lock<std::mutex> lk(c->up_mu);
             c->up_cv.wait(lk, [&]() { return c->up_enqueued > i || c->up_rc != 0; });
-            if (c->up_rc) { rc = c->up_rc; c->err = c->up_err; break; }
+            if (c->up_rc) { rc = c->up_rc; std::lock_guard<std::mutex> g(c->err_mu); c->err = c->up_err; break; }
             ev = c->h2d_ev[i];
         }
         rc = run_range(c, c->ranges[i], (int)(i & 1), ev);
@@ -1037,6 +1061,8 @@ int afq_device_warmup(int device) {
     warm_code_object();
     return 0;
 }
+
+uint64_t afq_label_rehash_count(const afq_ctx* ctx) { return ctx ? ctx->n_label_rehash : 0; }
 
 int afq_device_pci_bus_id(int device, char* out, size_t out_len) {
     if (!out || out_len < 13) return AFQ_ERR_INVALID_ARG;
@@ -1176,7 +1202,7 @@ static int submit_host(afq_ctx* c, const ByteSource& src, size_t n_bytes, const 
             int rc2 = staged_h2d(c, (uint8_t*)c->d_bytes_own.p + a, bytes ? bytes + (a - shift) : nullptr, (size_t)(b - a), c->stream, pinned, &src, a - shift);
             if (!rc2 && hipEventRecord(c->h2d_ev[i], c->stream) != hipSuccess) rc2 = AFQ_ERR_HIP;
             std::lock_guard<std::mutex> lk(c->up_mu);
-            if (rc2) { c->up_rc = rc2; c->up_err = c->err.empty() ? "input upload failed" : c->err; }
+            if (rc2) { std::lock_guard<std::mutex> g(c->err_mu); c->up_rc = rc2; c->up_err = c->err.empty() ? "input upload failed" : c->err; }
             c->up_enqueued = i + 1;
             c->up_cv.notify_all();
             if (rc2) return;

@@ -106,6 +106,10 @@ struct PugOut {
     uint64_t* u;
     uint32_t* o;
     const uint64_t* rd_off;  // [n_cells] first read slot of a PUG cell
+    // A label of three or more ids is keyed by a 62-bit hash and the kernels check that equal keys are equal labels; when that
+    // check fails (kErrLabelHash) the range is decoded again under another salt - another hash function - instead of being
+    // refused.  mask (all ones; tests: a few bits, so that the first salt collides for certain) is applied to the hash.
+    uint64_t salt, mask;
 };
 __host__ __device__ inline uint64_t label_hash_init(uint32_t na) { return 0x9E3779B97F4A7C15ull ^ na; }
 // The 64-bit class key of a label.  Labels of one or two ids (transcripts at txp level, genes at gene level; ids < 2^31)

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ byte
             const bool ral = ((((uintptr_t)rp) & 3) == 0);
             if (mode_is_pug(m.mode)) { rec_dw = (uint32_t)((roff - m.chunk_off) >> 2); pug_rec = true; }
             if (mode_is_pug(m.mode) && !mode_pug_gene(m.mode)) {  // txp-level PUG: hash of the ref list
-                lhash = label_hash_init(na);
+                lhash = label_hash_init(na) ^ pug.salt;
                 uint32_t t01[2] = {0, 0};
                 for (uint32_t j = 0; j < na; ++j) {
                     const uint32_t t = ld_u32(rp + 4 * j, ral) & 0x7FFFFFFFu;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ byte
                     lhash = label_hash_step(lhash, t);
                     if (j < 2) t01[j] = t;
                 }
-                lhash = label_key(lhash, na, t01[0], t01[1]);
+                lhash = label_key(lhash & pug.mask, na, t01[0], t01[1]);
                 na = 0;
             }
             for (uint32_t j = 0; j < na; ++j) {
@@ -165,16 +165,16 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ byte
                         if (ti < ref_count && t2g[ti] == gj) first = false;
                     }
                     kcnt += first;
-                    if (first && mode_pug_gene(m.mode)) lhash += gene_set_hash_term(gj);
+                    if (first && mode_pug_gene(m.mode)) lhash += gene_set_hash_term(gj ^ (uint32_t)pug.salt);
                 }
             }
             if (mode_pug_gene(m.mode)) {  // gene-level PUG: order-independent hash of the read's gene set
                 if (!ovf) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) if ((uint32_t)i < k) lhash += gene_set_hash_term(g[i]);
+                    for (int i = 0; i < 8; ++i) if ((uint32_t)i < k) lhash += gene_set_hash_term(g[i] ^ (uint32_t)pug.salt);
                 }
                 lhash ^= (uint64_t)kcnt * kHashMul;
-                lhash = label_key(lhash, kcnt, g[0], g[1]);  // (kcnt <= 2 implies !ovf: g[0], g[1] are the read's genes)
+                lhash = label_key(lhash & pug.mask, kcnt, g[0], g[1]);  // (kcnt <= 2 implies !ovf: g[0], g[1] are the read's genes)
             }
         }
         if (m.mode == kModeTrivial && kcnt != 1) kcnt = 0;  // multi-gene reads are discarded (pugutils.rs:870-891)
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(256, 6) void k_decode_par(const uint8_t* __restrict
             uint64_t lhash = 0;
             const bool pug_gene = pug_rec && mode_pug_gene(m.mode);
             if (pug_rec && !pug_gene) {  // txp-level PUG: hash of the ref list
-                lhash = label_hash_init(na);
+                lhash = label_hash_init(na) ^ pug.salt;
                 uint32_t t0 = 0, t1 = 0;
                 for (uint32_t j = 0; j < na; ++j) {
                     const uint32_t t = refw(j);
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256, 6) void k_decode_par(const uint8_t* __restrict
                     if (j == 0) t0 = t;
                     if (j == 1) t1 = t;
                 }
-                lhash = label_key(lhash, na, t0, t1);
+                lhash = label_key(lhash & pug.mask, na, t0, t1);
             }
             if (act && na && (!pug_rec || pug_gene)) {
                 if (ok0) {
@@ -597,16 +597,16 @@ __global__ __launch_bounds__(256, 6) void k_decode_par(const uint8_t* __restrict
                             if (tq < ref_count && t2g[tq] == gj) first = false;
                         }
                         kcnt += first;
-                        if (first && pug_gene) lhash += gene_set_hash_term(gj);
+                        if (first && pug_gene) lhash += gene_set_hash_term(gj ^ (uint32_t)pug.salt);
                     }
                 }
                 if (pug_gene) {  // gene-level PUG: order-independent hash of the read's gene set
                     if (!ovf) {
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) if ((uint32_t)q < k) lhash += gene_set_hash_term(g[q]);
+                        for (int q = 0; q < 8; ++q) if ((uint32_t)q < k) lhash += gene_set_hash_term(g[q] ^ (uint32_t)pug.salt);
                     }
                     lhash ^= (uint64_t)kcnt * kHashMul;
-                    lhash = label_key(lhash, kcnt, g[0], g[1]);  // (kcnt <= 2 implies !ovf: g[0], g[1] are the read's genes)
+                    lhash = label_key(lhash & pug.mask, kcnt, g[0], g[1]);  // (kcnt <= 2 implies !ovf: g[0], g[1] are the read's genes)
                 }
             }
             if (m.mode == kModeTrivial && kcnt != 1) kcnt = 0;  // multi-gene reads are discarded (pugutils.rs:870-891)
@@ -1217,7 +1217,7 @@ __global__ __launch_bounds__(256, 8) void k_decode_recs(const uint8_t* __restric
             if (PUG && pugc) {   // one read per record: (label key, UMI, record offset); see k_decode_par
                 uint64_t lkey;
                 if (pug_txp) {
-                    uint64_t hs = label_hash_init(na_eff);
+                    uint64_t hs = label_hash_init(na_eff) ^ pug.salt;
                     uint32_t t0 = 0, t1 = 0;
                     if (!slowrec) {
 #pragma unroll
@@ -1232,17 +1232,17 @@ __global__ __launch_bounds__(256, 8) void k_decode_recs(const uint8_t* __restric
                             if (j == 1) t1 = tj;
                         }
                     }
-                    lkey = label_key(hs, na_eff, t0, t1);
+                    lkey = label_key(hs & pug.mask, na_eff, t0, t1);
                 } else {   // gene level: order-independent hash of the read's distinct genes
                     uint64_t hs = 0;
                     uint32_t kc = 0, ga = 0, gb = 0;
-                    auto add = [&](uint32_t gj) { if (kc == 0) ga = gj; else if (kc == 1) gb = gj; ++kc; hs += gene_set_hash_term(gj); };
+                    auto add = [&](uint32_t gj) { if (kc == 0) ga = gj; else if (kc == 1) gb = gj; ++kc; hs += gene_set_hash_term(gj ^ (uint32_t)pug.salt); };
                     if (!slowrec) {
 #pragma unroll
                         for (uint32_t j = 0; j < kInl; ++j) if (v[j]) add(g[j]);
                     } else for_each_first_gene(add);
                     hs ^= (uint64_t)kc * kHashMul;
-                    lkey = label_key(hs, kc, ga, gb);
+                    lkey = label_key(hs & pug.mask, kc, ga, gb);
                 }
                 const uint64_t bm = __ballot(act);
                 const uint32_t totp = (uint32_t)__popcll(bm);

@@ -1282,7 +1282,7 @@ int afq_quantify(const afq_quant_opts* o) {
     // -d: cells x gene-level equivalence classes + the classes' gene sets (write_eqc_counts, src/quant.rs:229-355)
     if (o->dump_eq) {
         std::vector<float> ev(eq_cnt.begin(), eq_cnt.end());
-        if (!write_mtx(outd + "/alevin/geqc_counts.mtx", num_cells, eq_ids.size(), eq_row_ptr, eq_col, ev)) return hfail(AFQ_ERR_BAD_INPUT, "could not write geqc_counts.mtx");
+        if (!write_mtx(outd + "/alevin/geqc_counts.mtx", eq_row_ptr.size() - 1 /* the cells processed: geqmap.cell_offset.len(), quant.rs:248-251 */, eq_ids.size(), eq_row_ptr, eq_col, ev)) return hfail(AFQ_ERR_BAD_INPUT, "could not write geqc_counts.mtx");
         std::vector<const std::vector<uint32_t>*> by_id(eq_ids.size());
         for (auto& kv : eq_ids) by_id[kv.second] = &kv.first;
         std::string txt = std::to_string(cfg.num_rows) + "\n" + std::to_string(eq_ids.size()) + "\n";

@@ -268,6 +268,10 @@ typedef struct afq_batch_stats {
     uint64_t n_fallback_cells; /* cells the walk-free decode could not prove and re-decoded sequentially */
 } afq_batch_stats;
 int afq_get_batch_stats(afq_ctx* ctx, afq_batch_stats* out);
+/* Parsimony: labels of three or more ids are keyed by a 62-bit hash; two different labels of one cell under one key are
+   detected on the device, and the range of cells is then decoded again with another hash function instead of being refused
+   (the reference keys its map by the list itself, eq_class.rs:859-903).  How often that happened since afq_create. */
+uint64_t afq_label_rehash_count(const afq_ctx* ctx);
 
 /* Brings the HIP runtime up on `device` (first-call initialisation) - a host can call it from a side thread while it parses its
    inputs.  Returns 0 or AFQ_ERR_NO_DEVICE. */

@@ -304,3 +304,23 @@ def test_classes_of_more_than_64_genes(oracle, res, usa):
     got2, want2 = run_both(oracle, cfg2, t2g, b, off)
     assert_same_result(got2, want2)
     assert (got2.flags & pkg._abi.CELL_ALT_RES).any()
+
+
+@pytest.mark.parametrize("res", ["parsimony", "parsimony-gene-em"])
+def test_label_hash_collision_is_rehashed_not_refused(oracle, monkeypatch, pug_route, res):
+    """Labels of three or more ids are keyed by a 62-bit hash (labels of one or two carry the ids themselves).  With the
+    first try's hashes cut to 3 bits, different labels of a cell share keys for certain: the device notices (equal keys,
+    different lists), and the range is decoded again under another hash function - the rows are the oracle's, nothing is
+    refused (the reference keys by the list itself: eq_class.rs:859-903)."""
+    s = synth.synth(41, [3000, 800, 300, 150], num_genes=60, txp_per_gene=4, dup=0.4, cross=0.6, umi_err=0.03, max_extra_na=6)
+    b, off = s.encode()
+    cfg = cfg_for(s, res, small_thresh=0)
+    want = oracle.quant(cfg, s.tid_to_gid, b, off)
+    monkeypatch.setenv("AFQ_TEST_LABEL_HASH_BITS", "3")
+    q = pkg.Quantifier(cfg, s.tid_to_gid)
+    try:
+        got = q.quant_chunks(b, off)
+        assert q.label_rehash_count() >= 1, "the cut hashes were meant to collide"
+    finally:
+        q.close()
+    assert_same_result(got, want, what=res)
