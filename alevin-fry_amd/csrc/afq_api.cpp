@@ -535,7 +535,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
                            !(route && !std::strcmp(route, "mono"));
         for (uint32_t ci : pug_cells) {   // (largest first)
             const CellMeta& m = B.meta[ci];
-            if (!p2_ok || m.nrec >= (1u << 20) || m.n_ref < m.nrec) { mono_cells.push_back(ci); continue; }   // (n_ref < nrec: records without alignments - the column list is sized by n_ref)
+            if (!p2_ok || m.nrec >= (1u << 22) || m.n_ref < m.nrec) { mono_cells.push_back(ci); continue; }   // (n_ref < nrec: records without alignments - the column list is sized by n_ref)
             P2Cell pc{};
             pc.rd_base = rd_off[ci]; pc.chunk_off = m.chunk_off; pc.cell = ci; pc.R = m.nrec; pc.n_ref = m.n_ref; pc.key_off = m.key_off;
             uint32_t lg = 0;

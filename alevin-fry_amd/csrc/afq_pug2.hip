@@ -630,7 +630,14 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
     const uint32_t* pn3 = A.pn3 + c.part_base;
     const uint32_t* ppoff = A.poff + c.part_base;
     uint32_t n_pairs = 0, n_cls2 = 0, n3 = 0;
-    uint32_t* ppre = P <= kGLds / 2 ? s_big : nullptr;   // per partition: first pair | first class
+    uint32_t* ppre = s_big;   // per partition: first pair | first class (cells of more than 6000 partitions - a million reads - keep it in the pool)
+    if (2 * P > kGLds) {
+        if (tid == 0) s_ebase = atomicAdd(A.pool_cur, 2ull * P + 4);
+        gsync();
+        if (s_ebase + 2ull * P + 4 > A.pool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, c.cell); return; }
+        ppre = A.pool + s_ebase;
+        gsync();
+    }
     for (uint32_t base = 0; base < P; base += kGNT) {
         const uint32_t pp = base + tid;
         const uint32_t a = pp < P ? pnp[pp] : 0u, b = pp < P ? pncls[pp] : 0u, d = pp < P ? pn3[pp] : 0u;
@@ -638,11 +645,10 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
         const uint32_t ea = block_excl_scan<kGNT>(a, s_ws, ta);
         const uint32_t eb = block_excl_scan<kGNT>(b, s_ws, tb);
         (void)block_excl_scan<kGNT>(d, s_ws, td);
-        if (ppre && pp < P) { ppre[2 * pp] = n_pairs + ea; ppre[2 * pp + 1] = n_cls2 + eb; }
+        if (pp < P) { ppre[2 * pp] = n_pairs + ea; ppre[2 * pp + 1] = n_cls2 + eb; }
         n_pairs += ta; n_cls2 += tb; n3 += td;
     }
     gsync();
-    if (!ppre) { give_up(); continue; }   // (more than 4096 partitions: cells of over 650 k reads)
     if (n_cls2) {   // the lone vertices' classes into the cell's label area (em only)
         const uint32_t w0 = s_cnt[1], d0 = s_cnt[2];
         if (w0 + 2 * n_cls2 > C.lab_cap || 2 * (d0 + n_cls2) > C.lab_cap) { if (tid == 0) set_err(A.st, kErrPugLimit, c.cell); return; }
@@ -668,7 +674,7 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
     if (s_ebase + need > A.pool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, c.cell); return; }
     uint32_t* q = A.pool + ((s_ebase + 3) & ~3ull);
     uint4* mrec = reinterpret_cast<uint4*>(q); q += 8 * (size_t)nt_max;                 // (16-byte aligned)
-    uint64_t* lp = reinterpret_cast<uint64_t*>(q); q += 2 * (size_t)n_pairs;            // pairs over local ids: x | y << 20 | directions << 40
+    uint64_t* lp = reinterpret_cast<uint64_t*>(q); q += 2 * (size_t)n_pairs;            // pairs over local ids: x | y << 24 | directions << 48
     uint64_t* okey = reinterpret_cast<uint64_t*>(q); q += 2 * (size_t)nt_max;           // per slot of a listed component: (class minimum, UMI)
     unsigned long long* adj = reinterpret_cast<unsigned long long*>(q); q += 2 * (size_t)nt_max;   // per vertex: out-neighbours as positions inside its component
     uint32_t* tl = q; q += nt_max;            // touched vertex -> its slot in the cell
@@ -703,13 +709,13 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
         NT += tot;
     }
     gsync();
-    if (NT > nt_max || NT >= (1u << 20)) { if (tid == 0) set_err(A.st, kErrPugLimit, c.cell); return; }   // (cannot happen: two end points per pair, R < 2^20)
+    if (NT > nt_max || NT >= (1u << 24)) { if (tid == 0) set_err(A.st, kErrPugLimit, c.cell); return; }   // (cannot happen: two end points per pair, R < 2^22)
     for (uint32_t pp = tid; pp < P; pp += kGNT) {
         const uint32_t nk = pnp[pp], so = ppoff[pp], at = ppre[2 * pp];
         for (uint32_t k = 0; k < nk; ++k) {
             const uint64_t pr = psrc[so + k];
             const uint32_t lx = lidx[(uint32_t)(pr >> 31) & 0x7FFFFFFFu], ly = lidx[(uint32_t)pr & 0x7FFFFFFFu];
-            lp[at + k] = (uint64_t)lx | ((uint64_t)ly << 20) | ((pr >> 62) << 40);
+            lp[at + k] = (uint64_t)lx | ((uint64_t)ly << 24) | ((pr >> 62) << 48);
         }
     }
     gsync();
@@ -729,7 +735,7 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
         bool chg = false;
         for (uint32_t k = tid; k < n_pairs; k += kGNT) {
             const uint64_t e = lp[k];
-            const uint32_t x = (uint32_t)e & 0xFFFFFu, y = (uint32_t)(e >> 20) & 0xFFFFFu;
+            const uint32_t x = (uint32_t)e & 0xFFFFFFu, y = (uint32_t)(e >> 24) & 0xFFFFFFu;
             const uint32_t a = ldw(x), b = ldw(y);
             if (a < b) { wg_min(&wl[y], a); chg = true; }
             else if (b < a) { wg_min(&wl[x], b); chg = true; }
@@ -953,10 +959,10 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
     if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], c.cell); return; }
     for (uint32_t k = tid; k < n_pairs; k += kGNT) {
         const uint64_t e = lp[k];
-        const uint32_t x = (uint32_t)e & 0xFFFFFu, y = (uint32_t)(e >> 20) & 0xFFFFFu;
+        const uint32_t x = (uint32_t)e & 0xFFFFFFu, y = (uint32_t)(e >> 24) & 0xFFFFFFu;
         if ((ld_l2(&rcnt[root_of[x]]) >> 28) == kCatPair) continue;
-        if (e & (2ull << 40)) __hip_atomic_fetch_or(&adj[x], 1ull << cidx[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // x -> y
-        if (e & (1ull << 40)) __hip_atomic_fetch_or(&adj[y], 1ull << cidx[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // y -> x
+        if (e & (2ull << 48)) __hip_atomic_fetch_or(&adj[x], 1ull << cidx[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // x -> y
+        if (e & (1ull << 48)) __hip_atomic_fetch_or(&adj[y], 1ull << cidx[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // y -> x
     }
     gsync();
     for (uint32_t s2 = tid; s2 < S_mid; s2 += kGNT) {

@@ -324,3 +324,24 @@ def test_label_hash_collision_is_rehashed_not_refused(oracle, monkeypatch, pug_r
     finally:
         q.close()
     assert_same_result(got, want, what=res)
+
+
+def test_parsimony_cell_of_more_than_2_pow_20_reads(oracle, pug_route):
+    """The reference has no limit on a cell's reads (quant.rs:733-757).  The one-workgroup kernel numbers a cell's vertices
+    in 20 bits and refuses cells of 2^20 reads or more; the phase kernels take them (up to 2^22): 1.15 M reads of one cell,
+    8 192 UMI partitions, a class table of a few MiB out of the pool - rows bit-exact against the oracle."""
+    if pug_route != "phase-kernels":
+        pytest.skip("the one-workgroup kernel refuses cells of 2^20 reads or more (AFQ_ERR_UNSUPPORTED), by design")
+    import importlib
+
+    sn = importlib.import_module("alevin-fry_amd.synth_native")
+    d = sn.generate(seed=12, n_cells=1, median_reads=1.15e6, sigma=0.0, num_genes=36601, ref_count=199138, umi_err=0.01)
+    assert d.cell_nrec[0] > (1 << 20)
+    cfg = pkg.WorkerConfig.for_resolution("parsimony", num_genes=d.num_genes, num_rows=d.num_rows, umi_len=12)
+    q = pkg.Quantifier(cfg, d.tid_to_gid)
+    try:
+        got = q.quant_chunks(d.data, d.chunk_off)
+    finally:
+        q.close()
+    want = oracle.quant(cfg, d.tid_to_gid, d.data, d.chunk_off)
+    assert_same_result(got, want)
