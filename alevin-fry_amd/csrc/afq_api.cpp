@@ -341,7 +341,7 @@ int plan_ranges(afq_ctx* c) {
         const uint64_t n_ref = (nbytes - fixed) / 4;
         double nd = (em_res ? 24.0 + 40.0 * (c->cfg.usa_mode ? 3 : 1) : 16.0) * (double)n_ref + 128.0;
         if (pug_res) {  // per read: decode outputs + edge pool; the PUG scratch is per workgroup (sized for the largest cell)
-            nd += 20.0 * nrec + 96.0 * nrec;   // rd_h/rd_u/rd_o + the edge pool (24 words per read), as run_range allocates them
+            nd += 20.0 * nrec + 128.0 * nrec;   // rd_h/rd_u/rd_o + the edge pool (32 words per read), as run_range allocates them
             pug_fixed = std::max(pug_fixed, 4.0 * (double)pug_scratch_words(nrec, (uint32_t)n_ref, true) * pug_max_blocks() + 4.0 * (double)(1ull << 22));
         }
         if (n_ref > kBucketTarget) nd += 16.0 * (double)(n_ref / kBucketTarget + 1) + (use_slabs && !pug_res ? 8.0 * 2.0 * slab_slots / kBucketTarget * (double)n_ref : 0.0);   // (+ the slabs of keys1: up to 2 x slab capacity slots per kBucketTarget refs)
@@ -420,6 +420,17 @@ static uint64_t label_mask(uint32_t hash_try) {
     return ~0ull;
 }
 constexpr uint32_t kMaxHashTries = 4;
+
+// Reads that carry many alignments carry many genes: most UMIs then outgrow the three gene counters of a slot of k_resolve's
+// UMI table and their buckets end up sorted after the table has been tried.  Such ranges (two or more alignment words per
+// record on average - the decoders switch on the same figure) sort every bucket at once.  AFQ_RESOLVE=table|sort overrides.
+static uint32_t resolve_sort_only(uint64_t n_ref_words, uint64_t n_records) {
+    if (const char* e = getenv("AFQ_RESOLVE")) {
+        if (!strcmp(e, "sort")) return 1;
+        if (!strcmp(e, "table")) return 0;
+    }
+    return n_ref_words >= 2 * n_records ? 1u : 0u;
+}
 
 // Plan + enqueue one range of cells on the context's stream.
 int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint32_t hash_try = 0) {
@@ -551,7 +562,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     const uint32_t n_p2 = (uint32_t)p2cells.size();
     hist_cells = multi;
     hist_cells.insert(hist_cells.end(), pug_cells.begin(), pug_cells.end());
-    const uint64_t epool_words = 24 * n_pug_reads + (1ull << 22);
+    const uint64_t epool_words = 32 * n_pug_reads + (1ull << 22);   // (the phase kernels' per-read arrays take ten of them, the rest is the pool)
     if (n_pug) {
         HIP_TRY(c, B.d_pug_cells.ensure(4ull * n_pug));
         HIP_TRY(c, B.d_rd_off.ensure(8ull * n));
@@ -664,7 +675,8 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
                    em ? B.d_lab_cnt.as<uint32_t>() : nullptr, B.d_status.as<DevStatus>(),
                    (uint32_t)n_buckets, n_multi, (uint32_t)n_tiles, B.d_hist_cells.as<uint32_t>(),
                    (uint32_t)hist_cells.size(), g.usa_mode, g.num_rows,
-                   (g.usa_mode && g.sa_model == AFQ_SA_PREFER_AMBIG) ? 1u : 0u, max_lg_nb, B.d_slab_ovf.as<uint32_t>(), slabs ? 1u : 0u};
+                   (g.usa_mode && g.sa_model == AFQ_SA_PREFER_AMBIG) ? 1u : 0u, max_lg_nb, B.d_slab_ovf.as<uint32_t>(), slabs ? 1u : 0u,
+                   resolve_sort_only(key_off - n, nrec_total)};
     if (n_multi) {
         if (!slabs) {
             { ScopedTimer t(c, K_HIST, s, &B.launches); launch_hist(s, ra); }

@@ -59,6 +59,7 @@ struct ResolveArgs {
     uint32_t max_lg_nb;          // largest lg_nb of the batch's multi-bucket cells (picks the scatter instance)
     uint32_t* slab_ovf;          // fixed-slab placement: per cell, set when one of its buckets outgrew its slab (the cell is then placed exactly)
     uint32_t slabs;              // the range's multi-bucket cells use fixed slabs (no k_hist / k_bucket_scan)
+    uint32_t sort_only;          // reads of the range average two or more alignments: buckets are resolved by sorting, not through the UMI table
 };
 
 void launch_gather_headers(hipStream_t s, const uint8_t* bytes, size_t n_bytes, const uint64_t* chunk_off,

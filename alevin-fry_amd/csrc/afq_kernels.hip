@@ -216,6 +216,8 @@ struct ResolveCfg {
     uint32_t usa, num_rows, uo, ao;
     uint32_t mode;  // filled per bucket from its descriptor
     uint32_t pa;    // --sa-model prefer-ambig (USA only): reads of a UMI are tallied per gene, S and U together
+    uint32_t sort_only;   // the batch's reads carry many genes each: the UMI table's three counters per slot would overflow for
+                          // most UMIs (and the bucket then be sorted anyway) - every bucket takes the sort path straight away
 };
 __device__ __forceinline__ bool mode_is_em(uint32_t mode) { return mode == kModeCrLikeEm; }
 
@@ -782,7 +784,7 @@ __global__ __launch_bounds__(kResolveNT) void k_resolve(const BucketDesc* __rest
         return;
     }
     const uint32_t bmode = d.mode_single & 0xFFu;
-    if ((bmode == kModeCrLike || (EM && bmode == kModeCrLikeEm && la.lab)) && d.n <= kHtKeys && !rc.pa) {
+    if ((bmode == kModeCrLike || (EM && bmode == kModeCrLikeEm && la.lab)) && d.n <= kHtKeys && !rc.pa && !rc.sort_only) {
         const bool single = (d.mode_single >> 8) != 0;
         unsigned long long* s_slot = reinterpret_cast<unsigned long long*>(s_raw);      // 2 words per slot
         uint32_t* s_pair = s_raw + 2 * kHtCap;                                            // kHtPairs-1 words per slot
@@ -1145,6 +1147,7 @@ static ResolveCfg make_rc(const ResolveArgs& a) {
     ResolveCfg rc;
     rc.usa = a.usa; rc.num_rows = a.num_rows; rc.uo = a.num_rows / 3; rc.ao = 2 * (a.num_rows / 3); rc.mode = 0;
     rc.pa = a.prefer_ambig;
+    rc.sort_only = a.sort_only;
     return rc;
 }
 

@@ -288,7 +288,10 @@ __device__ __forceinline__ void part_body(const P2Args& A, const uint32_t* W, ui
         }
         sig[e] = sg;
     }
-    if (__any(bad)) { if (lane == 0) set_err(A.st, kErrLabelHash, cell); return; }
+    if (__any(bad)) {   // two labels under one key: the range is decoded again under another hash (afq_api.cpp); the kernels behind this one
+        if (lane == 0) { set_err(A.st, kErrLabelHash, cell); A.pnv[gp] = 0; A.pn3[gp] = 0; }   // find an empty partition
+        return;
+    }
     uint32_t before = 0;   // vertices of the rows below e
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -811,12 +814,16 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
     //         minimum before it - whichever that was, so every vertex of the class is chained to the first one that arrived. ----
     if (n3 || S_mid) {
         const uint32_t want = n3 + S_mid;   // (vertices, an upper bound of the classes)
-        uint32_t cap = kGTab;
+        // the table: in LDS when the classes are few; else out of the pool, at most 2^16 slots at a time - a cell with more
+        // classes than that (long labels, or hundreds of thousands of reads) takes the key space in slices, one pass per slice
+        constexpr uint32_t kPoolTab = 1u << 16;
+        uint32_t cap = kGTab, n_slices = 1;
         unsigned long long* t_key = reinterpret_cast<unsigned long long*>(s_big);
         uint32_t* t_min = s_big + 2 * kGTab;
         uint32_t* s_bloom = s_big + 3 * kGTab;   // the last 128 words of the block: 4096 bits for the asked-for keys
         if (want > kGTabLoad) {
-            while (cap < 2 * want) cap <<= 1;
+            n_slices = (uint32_t)((5ull * want / 2 + kPoolTab - 1) / kPoolTab);   // (a slice's share of the classes at most two fifths of the slots)
+            while (cap < kPoolTab && (uint64_t)cap * n_slices < 5ull * want / 2) cap <<= 1;
             if (tid == 0) s_ebase = atomicAdd(A.pool_cur, 3ull * cap + 4);
             gsync();
             if (s_ebase + 3ull * cap + 4 > A.pool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, c.cell); return; }
@@ -825,6 +832,7 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
         }
         const uint32_t cmask = cap - 1;
         auto mix = [](uint64_t h) -> uint32_t { uint32_t x = ((uint32_t)h ^ (uint32_t)(h >> 32)) * 0x9E3779B1u; return x ^ (x >> 15); };
+        auto slice_of = [&](uint64_t h) -> uint32_t { return n_slices == 1 ? 0u : (uint32_t)(((h ^ (h >> 29)) * 0xD6E8FEB86659FD93ull) >> 40) % n_slices; };
         auto find = [&](uint64_t h, uint32_t mx, bool insert) -> uint32_t {   // slot of h, or 0xFFFFFFFF
             uint32_t slot = mx & cmask;
             for (uint32_t step = 0; step < cap; ++step, slot = (slot + 1) & cmask) {
@@ -839,53 +847,59 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
             }
             return 0xFFFFFFFFu;
         };
-        gsync();
-        for (uint32_t i = tid; i < cap; i += kGNT) { st_l2(&t_key[i], ~0ull); st_l2(&t_min[i], 0xFFFFFFFFu); }
-        for (uint32_t i = tid; i < 128; i += kGNT) s_bloom[i] = 0;
-        gsync();
-        for (uint32_t s2 = tid; s2 < S_mid; s2 += kGNT) {   // the classes that are asked for
-            const uint64_t h = ch[tl[slot_v[s2]]];
-            const uint32_t mx = mix(h);
-            atomicOr(&s_bloom[(mx >> 20) >> 5], 1u << ((mx >> 20) & 31u));
-            (void)find(h, mx, true);
-        }
-        gsync();
-        // the vertices under a hashed key: they are the last n3 of every partition's vertices (the tag is the key's top bits)
         const uint32_t* ppnv = A.pnv + c.part_base;
-        for (uint32_t pp = tid; pp < P; pp += kGNT) {
-            const uint32_t k3 = pn3[pp], v1 = ppoff[pp] + ppnv[pp];
-            for (uint32_t g = v1 - k3; g < v1; ++g) {
-                const uint64_t h = ch[g];
-                const uint32_t slot = find(h, mix(h), true);
-                if (slot == 0xFFFFFFFFu || (h >> 62) != 3) { s_cnt[3] = kErrInternal; continue; }
-                const uint32_t off = coff[g];
-                const uint32_t old = wg_min(&t_min[slot], off);
-                if (old != 0xFFFFFFFFu && old != off && !lab_equal(rec_label(C, off), rec_label(C, old))) s_cnt[3] = kErrLabelHash;
+        for (uint32_t sl = 0; sl < n_slices; ++sl) {
+            gsync();
+            for (uint32_t i = tid; i < cap; i += kGNT) { st_l2(&t_key[i], ~0ull); st_l2(&t_min[i], 0xFFFFFFFFu); }
+            for (uint32_t i = tid; i < 128; i += kGNT) s_bloom[i] = 0;
+            gsync();
+            for (uint32_t s2 = tid; s2 < S_mid; s2 += kGNT) {   // the classes that are asked for
+                const uint64_t h = ch[tl[slot_v[s2]]];
+                if (slice_of(h) != sl) continue;
+                const uint32_t mx = mix(h);
+                atomicOr(&s_bloom[(mx >> 20) >> 5], 1u << ((mx >> 20) & 31u));
+                if (find(h, mx, true) == 0xFFFFFFFFu) s_cnt[3] = kErrInternal;
             }
-        }
-        // the asked-for classes whose key is the label itself: every vertex slot once, eight per thread and trip in flight
-        if (S_mid)
-            for (uint32_t g0 = tid; g0 - tid < R; g0 += 8 * kGNT) {
-                uint64_t h8[8];
-#pragma unroll
-                for (int r = 0; r < 8; ++r) h8[r] = g0 + (uint32_t)r * kGNT < R ? ch[g0 + (uint32_t)r * kGNT] : 0ull;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const uint64_t h = h8[r];
-                    if (h == 0 || (h >> 62) == 3) continue;
-                    const uint32_t mx = mix(h);
-                    if (!((s_bloom[(mx >> 20) >> 5] >> ((mx >> 20) & 31u)) & 1u)) continue;
-                    const uint32_t slot = find(h, mx, false);
-                    if (slot != 0xFFFFFFFFu) wg_min(&t_min[slot], coff[g0 + (uint32_t)r * kGNT]);
+            gsync();
+            // the vertices under a hashed key: they are the last n3 of every partition's vertices (the tag is the key's top bits)
+            for (uint32_t pp = tid; pp < P; pp += kGNT) {
+                const uint32_t k3 = pn3[pp], v1 = ppoff[pp] + ppnv[pp];
+                for (uint32_t g = v1 - k3; g < v1; ++g) {
+                    const uint64_t h = ch[g];
+                    if (slice_of(h) != sl) continue;
+                    const uint32_t slot = find(h, mix(h), true);
+                    if (slot == 0xFFFFFFFFu || (h >> 62) != 3) { s_cnt[3] = kErrInternal; continue; }
+                    const uint32_t off = coff[g];
+                    const uint32_t old = wg_min(&t_min[slot], off);
+                    if (old != 0xFFFFFFFFu && old != off && !lab_equal(rec_label(C, off), rec_label(C, old))) s_cnt[3] = kErrLabelHash;
                 }
             }
-        gsync();
-        for (uint32_t s2 = tid; s2 < S_mid; s2 += kGNT) {
-            const uint64_t h = ch[tl[slot_v[s2]]];
-            const uint32_t slot = find(h, mix(h), false);
-            const uint32_t mn = slot == 0xFFFFFFFFu ? 0xFFFFFFFFu : ld_l2(&t_min[slot]);
-            if (mn == 0xFFFFFFFFu) s_cnt[3] = kErrInternal;   // (every asked-for class has at least the vertex that asked)
-            cmin[s2] = mn;
+            // the asked-for classes whose key is the label itself: every vertex slot once, eight per thread and trip in flight
+            if (S_mid)
+                for (uint32_t g0 = tid; g0 - tid < R; g0 += 8 * kGNT) {
+                    uint64_t h8[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) h8[r] = g0 + (uint32_t)r * kGNT < R ? ch[g0 + (uint32_t)r * kGNT] : 0ull;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const uint64_t h = h8[r];
+                        if (h == 0 || (h >> 62) == 3) continue;
+                        const uint32_t mx = mix(h);
+                        if (!((s_bloom[(mx >> 20) >> 5] >> ((mx >> 20) & 31u)) & 1u)) continue;
+                        if (slice_of(h) != sl) continue;
+                        const uint32_t slot = find(h, mx, false);
+                        if (slot != 0xFFFFFFFFu) wg_min(&t_min[slot], coff[g0 + (uint32_t)r * kGNT]);
+                    }
+                }
+            gsync();
+            for (uint32_t s2 = tid; s2 < S_mid; s2 += kGNT) {
+                const uint64_t h = ch[tl[slot_v[s2]]];
+                if (slice_of(h) != sl) continue;
+                const uint32_t slot = find(h, mix(h), false);
+                const uint32_t mn = slot == 0xFFFFFFFFu ? 0xFFFFFFFFu : ld_l2(&t_min[slot]);
+                if (mn == 0xFFFFFFFFu) s_cnt[3] = kErrInternal;   // (every asked-for class has at least the vertex that asked)
+                cmin[s2] = mn;
+            }
         }
         gsync();
         if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], c.cell); return; }
