@@ -669,50 +669,63 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
         if (tid == 0) { s_cnt[1] = w0 + 2 * n_cls2; s_cnt[2] = d0 + n_cls2; }
         gsync();
     }
-    // ---- scratch out of the pool: everything is sized by the vertices that have an edge ----
-    const uint32_t nt_max = min(R, 2 * n_pairs);
-    const unsigned long long need = 26ull * nt_max + 2ull * n_pairs + 64;
-    if (tid == 0) s_ebase = atomicAdd(A.pool_cur, need);
-    gsync();
-    if (s_ebase + need > A.pool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, c.cell); return; }
-    uint32_t* q = A.pool + ((s_ebase + 3) & ~3ull);
-    uint4* mrec = reinterpret_cast<uint4*>(q); q += 8 * (size_t)nt_max;                 // (16-byte aligned)
-    uint64_t* lp = reinterpret_cast<uint64_t*>(q); q += 2 * (size_t)n_pairs;            // pairs over local ids: x | y << 24 | directions << 48
-    uint64_t* okey = reinterpret_cast<uint64_t*>(q); q += 2 * (size_t)nt_max;           // per slot of a listed component: (class minimum, UMI)
-    unsigned long long* adj = reinterpret_cast<unsigned long long*>(q); q += 2 * (size_t)nt_max;   // per vertex: out-neighbours as positions inside its component
+    // ---- scratch out of the pool, in three steps as the sizes become known: the pair list (n_pairs), the per-vertex arrays
+    //      (NT vertices have an edge), the per-slot arrays of the listed components (S_mid) ----
+    auto pool_take = [&](unsigned long long words) -> uint32_t* {   // workgroup-wide call; nullptr = the pool is exhausted (error set)
+        gsync();
+        if (tid == 0) s_ebase = atomicAdd(A.pool_cur, words + 4);
+        gsync();
+        if (s_ebase + words + 4 > A.pool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, c.cell); return nullptr; }
+        return A.pool + ((s_ebase + 3) & ~3ull);
+    };
+    uint32_t* q = pool_take(2ull * n_pairs);
+    if (!q) return;
+    uint64_t* lp = reinterpret_cast<uint64_t*>(q);   // pairs over local ids: x | y << 24 | directions << 48
+    G_MARK(1);
+    // ---- 1. the touched vertices: the search flagged them; a scan over the flags counts them, a second numbers them (any
+    //         numbering will do: the reference's order enters through the order keys of step 6 only) ----
+    const uint64_t* psrc = A.pairs + c.rd_base;
+    const uint8_t* cflag = A.v_flag + c.rd_base;
+    uint32_t NT = 0;
+    for (uint32_t g0 = 4 * tid; g0 < R; g0 += 4 * kGNT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) NT += g0 + r < R && cflag[g0 + r] != 0;
+    }
+    {
+        uint32_t tot;
+        (void)block_excl_scan<kGNT>(NT, s_ws, tot);
+        NT = tot;
+    }
+    if (NT > 2 * n_pairs || NT >= (1u << 24)) { if (tid == 0) set_err(A.st, kErrPugLimit, c.cell); return; }   // (cannot happen: two end points per pair, R < 2^22)
+    const uint32_t nt_max = NT;
+    q = pool_take(9ull * NT + 16);
+    if (!q) return;
     uint32_t* tl = q; q += nt_max;            // touched vertex -> its slot in the cell
     uint32_t* wlg = q; q += nt_max;           // component labels when they do not fit LDS
     uint32_t* root_of = q; q += nt_max;
     uint32_t* rcnt = q; q += nt_max;          // per root: vertices of its component, then its place in the lists (category << 28 | index)
-    uint32_t* fill = q; q += nt_max;
-    uint32_t* cidx = q; q += nt_max;          // position of a vertex inside its component (reference order)
-    uint32_t* lsize = q; q += nt_max;         // per listed component: size
+    uint32_t* fill = q; q += nt_max;          // per root: next free slot of its component; afterwards, per vertex:
+    uint32_t* cidx = fill;                    // ... its position inside its component (reference order)
+    uint32_t* lsize = q; q += nt_max + 2;     // per listed component: size
     uint32_t* mid_off = q; q += nt_max + 2;   // ... first slot
-    uint32_t* slot_v = q; q += nt_max;        // slot -> vertex
-    uint32_t* slot_comp = q; q += nt_max;     // slot -> listed component
-    uint32_t* cmin = q; q += nt_max;          // per slot: smallest record offset of the vertex's class
-    uint32_t* pr_v = q;                       // two-vertex components: their vertices, two by two
-    G_MARK(1);
-    // ---- 1. the touched vertices: the search flagged them; a scan over the flags numbers them (any numbering will do: the
-    //         reference's order enters through the order keys of step 6 only) ----
-    const uint64_t* psrc = A.pairs + c.rd_base;
-    const uint8_t* cflag = A.v_flag + c.rd_base;
-    uint32_t NT = 0;
-    for (uint32_t base = 0; base < R; base += 4 * kGNT) {
-        const uint32_t g0 = base + 4 * tid;
-        uint32_t f[4], cn = 0;
+    uint32_t* pr_v = q; q += nt_max + 2;      // two-vertex components: their vertices, two by two
+    {
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < R; base += 4 * kGNT) {
+            const uint32_t g0 = base + 4 * tid;
+            uint32_t f[4], cn = 0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { f[r] = g0 + r < R ? cflag[g0 + r] : 0u; }
+            for (int r = 0; r < 4; ++r) { f[r] = g0 + r < R ? cflag[g0 + r] : 0u; }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) cn += f[r] != 0;
-        uint32_t tot;
-        uint32_t li = NT + block_excl_scan<kGNT>(cn, s_ws, tot);
+            for (int r = 0; r < 4; ++r) cn += f[r] != 0;
+            uint32_t tot;
+            uint32_t li = carry + block_excl_scan<kGNT>(cn, s_ws, tot);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) if (f[r]) { if (li < nt_max) { tl[li] = g0 + r; lidx[g0 + r] = li; } ++li; }
-        NT += tot;
+            for (int r = 0; r < 4; ++r) if (f[r]) { tl[li] = g0 + r; lidx[g0 + r] = li; ++li; }
+            carry += tot;
+        }
     }
     gsync();
-    if (NT > nt_max || NT >= (1u << 24)) { if (tid == 0) set_err(A.st, kErrPugLimit, c.cell); return; }   // (cannot happen: two end points per pair, R < 2^22)
     for (uint32_t pp = tid; pp < P; pp += kGNT) {
         const uint32_t nk = pnp[pp], so = ppoff[pp], at = ppre[2 * pp];
         for (uint32_t k = 0; k < nk; ++k) {
@@ -727,7 +740,7 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
     const bool wl_lds = NT <= kGLds;
     uint32_t* wl = wl_lds ? s_big : wlg;
     auto ldw = [&](uint32_t i) -> uint32_t { return wl_lds ? wl[i] : ld_l2(&wl[i]); };
-    for (uint32_t i = tid; i < NT; i += kGNT) { if (wl_lds) wl[i] = i; else st_l2(&wl[i], i); st_l2(&rcnt[i], 0u); st_l2(&fill[i], 0u); st_l2(&adj[i], 0ull); }
+    for (uint32_t i = tid; i < NT; i += kGNT) { if (wl_lds) wl[i] = i; else st_l2(&wl[i], i); st_l2(&rcnt[i], 0u); st_l2(&fill[i], 0u); }
     gsync();
     for (;;) {
         gsync();   // (every thread has read the previous sweep's flag before it is cleared: without this barrier a wave that
@@ -794,7 +807,27 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
         S_mid += tot;
     }
     if (tid == 0) mid_off[n_mid] = S_mid;
-    gsync();
+    // per slot of a listed component: its vertex, its component, its class minimum; and one region that first holds the class
+    // table (when it does not fit LDS) and then the order keys, adjacency masks and cover records (12 words per slot)
+    const uint32_t want = n3 + S_mid;   // (vertices, an upper bound of the classes the table will hold)
+    constexpr uint32_t kPoolTab = 1u << 16;
+    uint32_t cap = kGTab, n_slices = 1;
+    if (want > kGTabLoad) {   // at most 2^16 pool slots at a time: a cell with more classes takes the key space in slices, a pass per slice
+        n_slices = (uint32_t)((5ull * want / 2 + kPoolTab - 1) / kPoolTab);
+        while (cap < kPoolTab && (uint64_t)cap * n_slices < 5ull * want / 2) cap <<= 1;
+    }
+    const unsigned long long u_words = std::max<unsigned long long>(want > kGTabLoad ? 3ull * cap + 4 : 0ull, 12ull * S_mid + 8);
+    q = pool_take(3ull * S_mid + 8 + u_words);
+    if (!q) return;
+    uint32_t* slot_v = q; q += S_mid + 2;       // slot -> vertex
+    uint32_t* slot_comp = q; q += S_mid + 2;    // slot -> listed component
+    uint32_t* cmin = q; q += S_mid + 2;         // per slot: smallest record offset of the vertex's class
+    q += (q - A.pool) & 1;                      // (8-byte aligned from here; the first take was 16-byte aligned and sizes above are even or padded)
+    q = A.pool + (((unsigned long long)(q - A.pool) + 3) & ~3ull);
+    uint32_t* const u_base = q;
+    uint4* mrec = reinterpret_cast<uint4*>(u_base);                                   // [2 * S_mid]
+    uint64_t* okey = reinterpret_cast<uint64_t*>(u_base + 8 * (size_t)S_mid);         // [S_mid] (class minimum, UMI)
+    unsigned long long* adjp = reinterpret_cast<unsigned long long*>(u_base + 10 * (size_t)S_mid);   // [S_mid] out-neighbours of the vertex at this position, as positions inside its component
     for (uint32_t i = tid; i < NT; i += kGNT) {
         const uint32_t r = root_of[i], rc = ld_l2(&rcnt[r]), cat = rc >> 28, idx = rc & 0xFFFFFFFu;
         const uint32_t at = wg_add(&fill[r], 1u);
@@ -813,21 +846,12 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
     //         are few, out of the pool otherwise.  A vertex under a hashed key is compared with the vertex that held the
     //         minimum before it - whichever that was, so every vertex of the class is chained to the first one that arrived. ----
     if (n3 || S_mid) {
-        const uint32_t want = n3 + S_mid;   // (vertices, an upper bound of the classes)
-        // the table: in LDS when the classes are few; else out of the pool, at most 2^16 slots at a time - a cell with more
-        // classes than that (long labels, or hundreds of thousands of reads) takes the key space in slices, one pass per slice
-        constexpr uint32_t kPoolTab = 1u << 16;
-        uint32_t cap = kGTab, n_slices = 1;
+        // the table: in LDS when the classes are few; else in the pool region taken above
         unsigned long long* t_key = reinterpret_cast<unsigned long long*>(s_big);
         uint32_t* t_min = s_big + 2 * kGTab;
         uint32_t* s_bloom = s_big + 3 * kGTab;   // the last 128 words of the block: 4096 bits for the asked-for keys
         if (want > kGTabLoad) {
-            n_slices = (uint32_t)((5ull * want / 2 + kPoolTab - 1) / kPoolTab);   // (a slice's share of the classes at most two fifths of the slots)
-            while (cap < kPoolTab && (uint64_t)cap * n_slices < 5ull * want / 2) cap <<= 1;
-            if (tid == 0) s_ebase = atomicAdd(A.pool_cur, 3ull * cap + 4);
-            gsync();
-            if (s_ebase + 3ull * cap + 4 > A.pool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, c.cell); return; }
-            t_key = reinterpret_cast<unsigned long long*>(A.pool + ((s_ebase + 1) & ~1ull));
+            t_key = reinterpret_cast<unsigned long long*>(u_base);
             t_min = reinterpret_cast<uint32_t*>(t_key + cap);
         }
         const uint32_t cmask = cap - 1;
@@ -971,12 +995,16 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
     }
     gsync();
     if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], c.cell); return; }
+    for (uint32_t s2 = tid; s2 < S_mid; s2 += kGNT) st_l2(&adjp[s2], 0ull);
+    gsync();
     for (uint32_t k = tid; k < n_pairs; k += kGNT) {
         const uint64_t e = lp[k];
         const uint32_t x = (uint32_t)e & 0xFFFFFFu, y = (uint32_t)(e >> 24) & 0xFFFFFFu;
-        if ((ld_l2(&rcnt[root_of[x]]) >> 28) == kCatPair) continue;
-        if (e & (2ull << 48)) __hip_atomic_fetch_or(&adj[x], 1ull << cidx[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // x -> y
-        if (e & (1ull << 48)) __hip_atomic_fetch_or(&adj[y], 1ull << cidx[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // y -> x
+        const uint32_t rc = ld_l2(&rcnt[root_of[x]]), cat = rc >> 28;
+        if (cat == kCatPair) continue;
+        const uint32_t b0 = mid_off[cat == kCatTiny ? (rc & 0xFFFFFFFu) : n_tiny + (rc & 0xFFFFFFFu)];   // (x and y share their component)
+        if (e & (2ull << 48)) __hip_atomic_fetch_or(&adjp[b0 + cidx[x]], 1ull << cidx[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // x -> y
+        if (e & (1ull << 48)) __hip_atomic_fetch_or(&adjp[b0 + cidx[y]], 1ull << cidx[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // y -> x
     }
     gsync();
     for (uint32_t s2 = tid; s2 < S_mid; s2 += kGNT) {
@@ -990,8 +1018,8 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
             if (l.n > 2) r2 = l.p[2] & 0x7FFFFFFFu;
             if (l.n > 3) r3 = l.p[3] & 0x7FFFFFFFu;
         } else { const uint64_t pa = (uint64_t)(uintptr_t)l.p; r0 = (uint32_t)pa; r1 = (uint32_t)(pa >> 32); }
-        const unsigned long long am = ld_l2(&adj[li]);
         const size_t at = (size_t)mid_off[slot_comp[s2]] + cidx[li];
+        const unsigned long long am = ld_l2(&adjp[at]);
         mrec[2 * at] = make_uint4(g, l.n, r0, r1);
         mrec[2 * at + 1] = make_uint4(r2, r3, (uint32_t)am, (uint32_t)(am >> 32));
     }

@@ -22,7 +22,8 @@ struct Model {
     uint32_t thr_cross, thr_umi_err;       // P(an extra ref sits on another gene), P(1-base UMI error)
     uint32_t thr_unspl, thr_unspl_both;    // USA: P(unspliced), P(unspliced or spliced+unspliced)
     uint32_t bc_salt;
-    // label-length tail (na_model "tail"): after the one to three refs above, further refs are added while a draw stays under
+    // label-length tail (na_model "tail"): after the one to three refs above, further refs - the same for every read of a
+    // molecule - are added while a draw stays under
     // thr_tail (a geometric run, at most tail_max refs in all), each on a gene of the read's gene FAMILY - the block of
     // `family` consecutive gene ids its gene sits in - so that labels of 5..30 refs over more than four genes occur, as they
     // do against a transcriptome with paralogues; thr_tail = 0: the plain model, byte for byte what it was
@@ -109,7 +110,9 @@ __host__ __device__ inline uint32_t record(const Model& m, uint64_t cell, uint32
         const uint32_t fam_n = fam0 + m.family <= m.num_genes ? m.family : m.num_genes - fam0;
         for (uint32_t k = 0; n < m.tail_max; ++k) {
             uint32_t e[4];
-            philox(read, cl, ch, 0x100u + k, m.k0, m.k1, e);   // e0 one more?, e1 which gene of the family, e2 transcript, e3 unspliced?
+            philox(mol, cl, ch, 0x80000100u + k, m.k0, m.k1, e);   // e0 one more?, e1 which gene of the family, e2 transcript, e3 unspliced?
+            // (drawn per MOLECULE: the reads of a molecule come off the same end of the same transcript and map to the same
+            //  set of paralogues; per-read draws gave every read of a molecule a label of its own)
             if (e[0] >= m.thr_tail) break;
             const uint32_t g = fam0 + below(e[1], fam_n);
             uint32_t t = first_txp(m, g) + below(e[2], num_txp(m, g));
