@@ -222,7 +222,7 @@ def roofline_of(ktimes, alg_bytes, steps, traffic_ok):
             "all_kernels_ms_per_step": {k: round(v[0] / steps, 4) for k, v in ktimes.items()}}
 
 
-def cpu_leg(cfg, rad, res, budget_s, min_cells=0, tie_stats=False, tol=None, n_threads=None):
+def cpu_leg(cfg, rad, res, budget_s, min_cells=0, tie_stats=False, tol=None, n_threads=None, round_cells=None):
     """The oracle (a C++ port, NOT the Rust binary) on a bounded sample of the same cells, one worker thread per host core;
     the sample doubles as a full-size parity check: GPU rows == oracle rows (bit for bit unless tol is given)."""
     import numpy as np
@@ -233,7 +233,7 @@ def cpu_leg(cfg, rad, res, budget_s, min_cells=0, tie_stats=False, tol=None, n_t
     ora.lib()
     n = len(rad.cell_nrec)
     ncores = n_threads or os.cpu_count() or 1
-    k = max(1, n // max(64, 4 * ncores, min_cells))   # every k-th cell, so the size mix matches the workload
+    k = max(1, n // (round_cells or max(64, 4 * ncores, min_cells)))   # every k-th cell, so the size mix matches the workload
     done_reads, t_cpu, ncell, start = 0, 0.0, 0, 0
     ties = np.zeros(5, np.int64)
     tie_cells = diff_cells = diff_entries = diff_entries_tol = tot_entries = 0
@@ -315,7 +315,7 @@ def line(D, args, workload, value, elapsed, steps, warmup, cfgd, extra):
 
 
 # ---------------------------------------------------------------------------------------------------------
-def run_pbmc(D, args, pkg, sn, usa, resolution, steps, warmup, cpu_seconds, name, min_cells=0, tie_stats=False, tail=None):
+def run_pbmc(D, args, pkg, sn, usa, resolution, steps, warmup, cpu_seconds, name, min_cells=0, tie_stats=False, tail=None, round_cells=None):
     """configs[1] / configs[2]: one PBMC-10k-like sample per rank, generated in HBM."""
     import numpy as np
 
@@ -342,7 +342,7 @@ def run_pbmc(D, args, pkg, sn, usa, resolution, steps, warmup, cpu_seconds, name
         roof = roofline_of(ktimes, alg, steps, default_wl or ("configs2" if sizes_default and usa and resolution == "parsimony-em" and not tailed else False))
         cpu = None
         if D.world == 1 and not args.no_cpu_baseline and cpu_seconds > 0:
-            cpu = cpu_leg(cfg, rad, res, cpu_seconds, min_cells=min_cells, tie_stats=tie_stats)
+            cpu = cpu_leg(cfg, rad, res, cpu_seconds, min_cells=min_cells, tie_stats=tie_stats, round_cells=round_cells)
         cfgd = {"workload": f"{name}: PBMC-10k-like 10x-v3 collated RAD, {resolution}, per GPU: {args.cells} cells, log-normal reads/cell "
                             f"median {args.median_reads:g} sigma {args.sigma:g}, {args.genes} genes / {len(rad.tid_to_gid)} transcripts, "
                             f"gene popularity {args.popularity}" + (", USA" if usa else "") +
@@ -598,8 +598,9 @@ def main():
         for tleg, tusa, tres in (("configs1_tail", False, "cr-like"), ("configs2_tail", True, "parsimony-em")):
             if tleg in also and D.world == 1:
                 def f(tusa=tusa, tres=tres, tleg=tleg):
-                    o2, r2, q2 = run_pbmc(D, args, pkg, sn, tusa, tres, max(1, min(3, args.steps)), 1, min(args.cpu_seconds, 4.0),
-                                          "configs[2]" if tusa else "configs[1]", min_cells=100, tail=True)
+                    o2, r2, q2 = run_pbmc(D, args, pkg, sn, tusa, tres, max(1, min(2 if tusa else 3, args.steps)), 1, min(args.cpu_seconds, 4.0),
+                                          "configs[2]" if tusa else "configs[1]", min_cells=100, tail=True,
+                                          round_cells=256 if tusa else None)   # the oracle is ~8x slower on tailed parsimony cells
                     q2.close()
                     r2.free()
                     base = out if not tusa else legs.get("configs2")
