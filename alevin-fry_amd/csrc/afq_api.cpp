@@ -274,6 +274,12 @@ bool fixed_slabs() { const char* e = std::getenv("AFQ_FIXED_SLABS"); return !(e 
 constexpr uint32_t kSlabCap = 384;
 uint32_t slab_capacity() { const char* e = std::getenv("AFQ_SLAB_CAP"); const long v = e ? std::atol(e) : 0; return v > 0 ? (uint32_t)v : kSlabCap; }
 
+// Planned mean keys per bucket: kBucketTarget, or AFQ_BUCKET_TARGET (measurements only).
+uint32_t bucket_target() {
+    static const uint32_t t = [] { const char* e = std::getenv("AFQ_BUCKET_TARGET"); const long v = e ? std::atol(e) : 0; return v >= 32 && v <= 1024 ? (uint32_t)v : kBucketTarget; }();
+    return t;
+}
+
 bool valid_width(uint32_t w) { return w == 1 || w == 2 || w == 4 || w == 8; }
 
 // What the device path implements today.  Anything else is refused loudly.
@@ -344,7 +350,7 @@ int plan_ranges(afq_ctx* c) {
             nd += 20.0 * nrec + 128.0 * nrec;   // rd_h/rd_u/rd_o + the edge pool (32 words per read), as run_range allocates them
             pug_fixed = std::max(pug_fixed, 4.0 * (double)pug_scratch_words(nrec, (uint32_t)n_ref, true) * pug_max_blocks() + 4.0 * (double)(1ull << 22));
         }
-        if (n_ref > kBucketTarget) nd += 16.0 * (double)(n_ref / kBucketTarget + 1) + (use_slabs && !pug_res ? 8.0 * 2.0 * slab_slots / kBucketTarget * (double)n_ref : 0.0);   // (+ the slabs of keys1: up to 2 x slab capacity slots per kBucketTarget refs)
+        if (n_ref > bucket_target()) nd += 16.0 * (double)(n_ref / bucket_target() + 1) + (use_slabs && !pug_res ? 8.0 * 2.0 * slab_slots / bucket_target() * (double)n_ref : 0.0);   // (+ the slabs of keys1: up to 2 x slab capacity slots per kBucketTarget refs)
         if (nd > mem_budget) return fail(c, AFQ_ERR_OOM, "cell " + std::to_string(i) + " alone exceeds device memory");
         need[i] = nd;
         total_need += nd;
@@ -473,7 +479,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
                  : g.resolution == AFQ_RES_PARSIMONY_GENE_EM ? kModePugGeneEm : kModeCrLike;
         // parsimony cells emit reads, not keys: they take no part in the bucket pipeline (one empty bucket, no tiles)
         uint32_t lg = 0;
-        if (!mode_is_pug(m.mode)) while (((uint64_t)kBucketTarget << lg) < m.n_ref && lg < kMaxLgNb) ++lg;
+        if (!mode_is_pug(m.mode)) while (((uint64_t)bucket_target() << lg) < m.n_ref && lg < kMaxLgNb) ++lg;
         m.lg_nb = lg;
         max_lg_nb = std::max(max_lg_nb, lg);
         m.bucket_base = (uint32_t)n_buckets;

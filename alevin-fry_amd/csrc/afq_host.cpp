@@ -1125,6 +1125,7 @@ int afq_quantify(const afq_quant_opts* o) {
     if (pc.on) for (size_t d = 0; d < dstat.size(); ++d)
         std::fprintf(stderr, "[afquant]   device %d: %u batches, %llu cells, %.3f GB, busy %.3f s\n", devices[d], dstat[d].batches, (unsigned long long)dstat[d].cells, (double)dstat[d].bytes / 1e9, dstat[d].busy_s);
     if (devices.size() > 1) {   // how the queue spread the work: a small extra file next to quant.json (not one of the reference's outputs)
+        (void)mkdirs_checked(outd);   // (the writers create it further down; this file comes first)
         FilePtr df(std::fopen((outd + "/afquant_devices.json").c_str(), "w"));
         if (df) {
             std::fprintf(df.get(), "{\n  \"batches\": %zu,\n  \"batch_bytes\": %llu,\n  \"devices\": [\n", batches.size(), (unsigned long long)batch_bytes);

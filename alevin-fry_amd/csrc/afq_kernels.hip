@@ -915,18 +915,29 @@ __global__ __launch_bounds__(kHistNT) void k_cell_hist(const uint32_t* __restric
                 for (int e = 0; e < 4; ++e) if (cv[e] < nbins) atomicAdd(&s_hist[cv[e] >> 1], 1u << (16 * (cv[e] & 1u)));
             }
             __syncthreads();
-            for (uint32_t base = 0; base < nwords; base += kHistNT * 2) {
-                const uint32_t q = base + threadIdx.x * 2;   // two words = four bins per thread
-                uint32_t v[4];
-                const uint32_t w0 = q < nwords ? s_hist[q] : 0u, w1 = q + 1 < nwords ? s_hist[q + 1] : 0u;
-                v[0] = w0 & 0xFFFFu; v[1] = w0 >> 16; v[2] = w1 & 0xFFFFu; v[3] = w1 >> 16;
-                const uint32_t c = (v[0] != 0) + (v[1] != 0) + (v[2] != 0) + (v[3] != 0);
-                uint32_t tot;
-                uint32_t o = carry + block_excl_scan<kHistNT>(c, s_ws, tot);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) if (v[e]) out[o++] = make_uint2(lo + 2 * q + e, v[e]);
-                carry += tot;
+            // compaction in column order with ONE workgroup scan per pass: thread t owns the 32 words (64 bins) from word 32 t,
+            // notes which of its bins are non-zero in a 64-bit mask (its words read in an order rotated by the lane, so that
+            // the lanes of a wave are not all on one LDS bank), and after the scan of the counts walks the set bits.  (A scan per
+            // 2048 words was 16 scans and 48 barriers per pass - most of this kernel's time for a USA matrix of 110 k columns.)
+            const uint32_t w0 = 32 * threadIdx.x;
+            unsigned long long nzm = 0;
+            if (w0 < nwords) {
+#pragma unroll 8
+                for (uint32_t i = 0; i < 32; ++i) {
+                    const uint32_t w = (i + threadIdx.x) & 31u;
+                    const uint32_t v = w0 + w < nwords ? s_hist[w0 + w] : 0u;
+                    nzm |= (unsigned long long)(((v & 0xFFFFu) != 0) | (((v >> 16) != 0) << 1)) << (2 * w);
+                }
             }
+            uint32_t tot;
+            uint32_t o = carry + block_excl_scan<kHistNT>((uint32_t)__popcll(nzm), s_ws, tot);
+            while (nzm) {
+                const uint32_t k = (uint32_t)__builtin_ctzll(nzm);
+                nzm &= nzm - 1;
+                const uint32_t v = s_hist[w0 + (k >> 1)];
+                out[o++] = make_uint2(lo + 2 * w0 + k, (k & 1u) ? v >> 16 : v & 0xFFFFu);
+            }
+            carry += tot;
             __syncthreads();
         }
         if (threadIdx.x == 0) nnz[cell] = carry;

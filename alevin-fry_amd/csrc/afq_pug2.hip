@@ -322,7 +322,9 @@ __device__ __forceinline__ void part_body(const P2Args& A, const uint32_t* W, ui
 }
 
 __global__ __launch_bounds__(256) void k_p2_part(P2Args A) {
-    for (uint32_t gp = blockIdx.x * 4 + (threadIdx.x >> 6); gp < A.n_parts; gp += gridDim.x * 4) {
+    // (the wave's number through readfirstlane: the compiler then knows the partition index is uniform, and everything read per
+    //  partition - its counts, its place, its cell's record - comes through scalar loads into scalar registers)
+    for (uint32_t gp = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); gp < A.n_parts; gp += gridDim.x * 4) {
         const uint32_t n = A.pcnt[gp];
         if (n == 0) { if (lane_id() == 0) A.pnv[gp] = 0; continue; }
         const P2Cell c = A.cells[A.pcell[gp]];
@@ -411,7 +413,8 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
                 dir = (cy < 2 * cx ? kPairF : 0ull) | (cx < 2 * cy ? kPairB : 0ull);
             }
             const uint64_t hx = ch[gx], hy = ch[gy];
-            if (hx != hy && !klab_overlap(klab(W, A.hw, hx, coff[gx]), klab(W, A.hw, hy, coff[gy]))) continue;
+            if ((hx != hy || (uint32_t)(hx >> 62) == 3) &&   // (equal hashed keys are equal labels only once somebody has compared them: here)
+                !klab_overlap(klab(W, A.hw, hx, coff[gx]), klab(W, A.hw, hy, coff[gy]))) continue;
             cflag[gx] = 1; cflag[gy] = 1;
             const uint32_t at = atomicAdd(s_np, 1u);   // (LDS, this wave's own counter)
             if (at < pcap) ppair[at] = dir | ((uint64_t)gx << 31) | gy;
@@ -496,7 +499,7 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
 }
 __global__ __launch_bounds__(256) void k_p2_search(P2Args A) {
     __shared__ SearchLds s_lds[4];
-    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     for (uint32_t gp = blockIdx.x * 4 + wv; gp < A.n_parts; gp += gridDim.x * 4) search_body(A, gp, s_lds[wv], lane);
 }
 
@@ -514,55 +517,61 @@ __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t
     const PugCtx C = make_ctx(A, c, gc);   // (the counters are the cell's global ones here: the rare class writes add to them directly)
     const uint64_t o = c.rd_base + lo_p;
     uint32_t ncls = 0;   // wave-uniform
-    // the whole partition (<= 256 slots) at once: four slots per lane, every level of the gather chain issued for all four
-    uint64_t h4[4];
-    uint32_t fl[4], ga[4], gb[4];
+    // Two rows of 64 slots at a time, every level of the gather chain issued for both rows before anything waits: key / flag /
+    // record offset, then (hashed keys only) the label's length and first four refs out of the chunk, then the genes of all
+    // refs - five dependent trips per partition where a hashed label used to add four of its own per row it occurred in.
+    PugCtx Cg = C;
+    Cg.gene_level = 1;   // (genes_of4 is handed gene ids below: the gathers are done here, for all slots together)
+    for (uint32_t r0 = 0; r0 < n; r0 += 128) {   // (uniform)
+        uint64_t h2[2];
+        uint32_t fl[2], of[2], ln[2], t4[2][4], g4[2][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const uint32_t i = (uint32_t)r * 64 + lane;
-        h4[r] = i < nv ? A.s_h[o + i] : 0ull;
-        fl[r] = i < nv ? A.v_flag[o + i] : 1u;
-    }
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t i = r0 + (uint32_t)r * 64 + lane;
+            h2[r] = i < nv ? A.s_h[o + i] : 0ull;
+            fl[r] = i < nv ? A.v_flag[o + i] : 1u;
+            of[r] = i < nv ? A.v_off[o + i] : 0u;
+        }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const uint32_t tag = (uint32_t)(h4[r] >> 62);
-        const bool shrt = !fl[r] && (tag == 1 || tag == 2);
-        ga[r] = shrt ? C.t2g[tag == 1 ? (uint32_t)h4[r] & 0x7FFFFFFFu : (uint32_t)(h4[r] >> 31) & 0x7FFFFFFFu] : 0u;
-        gb[r] = shrt && tag == 2 ? C.t2g[(uint32_t)h4[r] & 0x7FFFFFFFu] : ga[r];
-    }
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t tag = fl[r] ? 0u : (uint32_t)(h2[r] >> 62);
+            ln[r] = tag == 3 ? C.W[of[r]] : tag;   // (tags 1 and 2 are the label's length)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const uint32_t i = (uint32_t)r * 64 + lane;
-        if ((uint32_t)r * 64 >= n) break;   // (uniform)
-        uint32_t col = 0xFFFFFFFFu, k0 = 0, k1 = 0;
-        bool cls = false;
-        if (!fl[r]) {
-            const uint32_t tag = (uint32_t)(h4[r] >> 62);
-            if (tag == 1 || tag == 2) {
-                const uint32_t lo = ga[r] < gb[r] ? ga[r] : gb[r], hi = ga[r] < gb[r] ? gb[r] : ga[r];
-                col = molecule2_column(C, lo, hi, lo == hi ? 1u : 2u, cls);
-                k0 = lo; k1 = hi;
-            } else if (tag == 3) {
-                const Lab l = rec_label(C, A.v_off[o + i]);
-                if (l.n <= 4) {
-                    uint32_t g4[4];
+            for (int q = 0; q < 4; ++q) t4[r][q] = 0xFFFFFFFFu;
+            if (tag == 1) t4[r][0] = (uint32_t)h2[r] & 0x7FFFFFFFu;
+            else if (tag == 2) { t4[r][0] = (uint32_t)(h2[r] >> 31) & 0x7FFFFFFFu; t4[r][1] = (uint32_t)h2[r] & 0x7FFFFFFFu; }
+            else if (tag == 3) {
+                const uint32_t* lp = C.W + of[r] + C.HW;   // (a hashed label has three refs or more; the fourth dword read may be the next record's first: still inside the padded input)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) g4[q] = (uint32_t)q < l.n ? l.p[q] & 0x7FFFFFFFu : 0xFFFFFFFFu;
-                    const uint32_t ng = genes_of4(C, g4, l.n);
-                    col = molecule4_column(C, g4, ng, cls);
-                    k0 = g4[0]; k1 = g4[1];
-                } else {
-                    uint32_t g[kMaxGenesPerLabel];
-                    const uint32_t ng = genes_of(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; }, g);
-                    if (ng == 0xFFFFFFFFu && C.em) emit_wide_class(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; });
-                    else col = molecule_column_n(C, g, ng);
-                }
+                for (int q = 0; q < 4; ++q) t4[r][q] = lp[q] & 0x7FFFFFFFu;
             }
         }
-        if (i < n) C.cols[lo_p + i] = col;
-        const uint64_t mk = __ballot(cls);
-        if (cls) { const uint32_t q = ncls + (uint32_t)__popcll(mk & ((1ull << lane) - 1)); s_cls[2 * q] = k0; s_cls[2 * q + 1] = k1; }
-        ncls += (uint32_t)__popcll(mk);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g4[r][q] = (uint32_t)q < ln[r] && ln[r] <= 4 ? C.t2g[t4[r][q]] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t i = r0 + (uint32_t)r * 64 + lane;
+            if (r0 + (uint32_t)r * 64 >= n) break;   // (uniform)
+            uint32_t col = 0xFFFFFFFFu, k0 = 0, k1 = 0;
+            bool cls = false;
+            if (ln[r] != 0 && ln[r] <= 4) {
+                const uint32_t ng = genes_of4(Cg, g4[r], ln[r]);
+                col = molecule4_column(C, g4[r], ng, cls);
+                k0 = g4[r][0]; k1 = g4[r][1];
+            } else if (ln[r] > 4) {
+                const Lab l = rec_label(C, of[r]);
+                uint32_t g[kMaxGenesPerLabel];
+                const uint32_t ng = genes_of(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; }, g);
+                if (ng == 0xFFFFFFFFu && C.em) emit_wide_class(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; });
+                else col = molecule_column_n(C, g, ng);
+            }
+            if (i < n) C.cols[lo_p + i] = col;
+            const uint64_t mk = __ballot(cls);
+            if (cls) { const uint32_t q = ncls + (uint32_t)__popcll(mk & ((1ull << lane) - 1)); s_cls[2 * q] = k0; s_cls[2 * q + 1] = k1; }
+            ncls += (uint32_t)__popcll(mk);
+        }
     }
     if (!ncls) return;
     WAVE_SYNC();
@@ -573,7 +582,7 @@ __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t
 }
 __global__ __launch_bounds__(256) void k_p2_lone(P2Args A) {
     __shared__ uint32_t s_cls4[4][512];
-    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     for (uint32_t gp = blockIdx.x * 4 + wv; gp < A.n_parts; gp += gridDim.x * 4) lone_body(A, gp, s_cls4[wv], lane);
 }
 
@@ -588,7 +597,7 @@ __global__ __launch_bounds__(256) void k_p2_lone(P2Args A) {
 #endif
 constexpr int kGNT = 256;
 constexpr uint32_t kGTab = 4096;          // class table slots when it lives in LDS (keys: 32 KiB, minima: 16 KiB of the block)
-constexpr uint32_t kGTabLoad = 2600;      // ... and the classes it takes; beyond that the table is carved out of the pool
+constexpr uint32_t kGTabLoad = 3000;      // ... and the classes it takes; beyond that the table is carved out of the pool
 constexpr uint32_t kGLds = 3 * kGTab + 128;   // words of the phase-shared LDS block (48.5 KiB: three workgroups to a CU, what the registers allow anyway)
 constexpr uint32_t kCatPair = 1, kCatTiny = 2, kCatMid = 3;
 
@@ -630,9 +639,8 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
     const uint32_t P = 1u << c.lgP;
     const uint32_t* pnp = A.pnp + c.part_base;
     const uint32_t* pncls = A.pncls + c.part_base;
-    const uint32_t* pn3 = A.pn3 + c.part_base;
     const uint32_t* ppoff = A.poff + c.part_base;
-    uint32_t n_pairs = 0, n_cls2 = 0, n3 = 0;
+    uint32_t n_pairs = 0, n_cls2 = 0;
     uint32_t* ppre = s_big;   // per partition: first pair | first class (cells of more than 6000 partitions - a million reads - keep it in the pool)
     if (2 * P > kGLds) {
         if (tid == 0) s_ebase = atomicAdd(A.pool_cur, 2ull * P + 4);
@@ -643,13 +651,12 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
     }
     for (uint32_t base = 0; base < P; base += kGNT) {
         const uint32_t pp = base + tid;
-        const uint32_t a = pp < P ? pnp[pp] : 0u, b = pp < P ? pncls[pp] : 0u, d = pp < P ? pn3[pp] : 0u;
-        uint32_t ta, tb, td;
+        const uint32_t a = pp < P ? pnp[pp] : 0u, b = pp < P ? pncls[pp] : 0u;
+        uint32_t ta, tb;
         const uint32_t ea = block_excl_scan<kGNT>(a, s_ws, ta);
         const uint32_t eb = block_excl_scan<kGNT>(b, s_ws, tb);
-        (void)block_excl_scan<kGNT>(d, s_ws, td);
         if (pp < P) { ppre[2 * pp] = n_pairs + ea; ppre[2 * pp + 1] = n_cls2 + eb; }
-        n_pairs += ta; n_cls2 += tb; n3 += td;
+        n_pairs += ta; n_cls2 += tb;
     }
     gsync();
     if (n_cls2) {   // the lone vertices' classes into the cell's label area (em only)
@@ -809,7 +816,7 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
     if (tid == 0) mid_off[n_mid] = S_mid;
     // per slot of a listed component: its vertex, its component, its class minimum; and one region that first holds the class
     // table (when it does not fit LDS) and then the order keys, adjacency masks and cover records (12 words per slot)
-    const uint32_t want = n3 + S_mid;   // (vertices, an upper bound of the classes the table will hold)
+    const uint32_t want = S_mid;   // (vertices: an upper bound of the classes the table will hold)
     constexpr uint32_t kPoolTab = 1u << 16;
     uint32_t cap = kGTab, n_slices = 1;
     if (want > kGTabLoad) {   // at most 2^16 pool slots at a time: a cell with more classes takes the key space in slices, a pass per slice
@@ -840,19 +847,25 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
     }
     gsync();
     G_MARK(4);
-    // ---- 4. class minima: for the classes of the listed components' vertices (their order decides ties) and for every
-    //         class under a hashed key (equal keys must be equal labels).  The cell's vertex slots stream ONCE through a hash
-    //         table keyed by label key (slots past a partition's last vertex hold key 0: no class) - in LDS when the classes
-    //         are few, out of the pool otherwise.  A vertex under a hashed key is compared with the vertex that held the
-    //         minimum before it - whichever that was, so every vertex of the class is chained to the first one that arrived. ----
-    if (n3 || S_mid) {
+    // ---- 4. class minima for the classes of the listed components' vertices: their order decides ties.  The cell's vertex
+    //         slots stream ONCE through a hash table keyed by label key that holds the asked-for classes (slots past a
+    //         partition's last vertex hold key 0: no class) - in LDS when they are few, out of the pool otherwise.  A vertex
+    //         under a HASHED key that finds its key in the table is compared with the vertex that held the minimum before it -
+    //         whichever that was, so every vertex of an asked-for class is chained to the first one that arrived and equal
+    //         keys are shown to be equal labels.  (Classes nobody asks for are not looked at: nothing takes two such vertices
+    //         for one class - the partition kernel compares the reads it merges into a vertex, the search compares labels
+    //         under hashed keys by content.  The pass over every hashed vertex of the cell that used to sit here was a
+    //         third of this phase.) ----
+    if (S_mid) {
         // the table: in LDS when the classes are few; else in the pool region taken above
         unsigned long long* t_key = reinterpret_cast<unsigned long long*>(s_big);
         uint32_t* t_min = s_big + 2 * kGTab;
         uint32_t* s_bloom = s_big + 3 * kGTab;   // the last 128 words of the block: 4096 bits for the asked-for keys
+        uint32_t bloom_shift = 20, bloom_words = 128;
         if (want > kGTabLoad) {
             t_key = reinterpret_cast<unsigned long long*>(u_base);
             t_min = reinterpret_cast<uint32_t*>(t_key + cap);
+            s_bloom = s_big; bloom_shift = 14; bloom_words = 8192;   // (the LDS block is free then: 2^18 bits)
         }
         const uint32_t cmask = cap - 1;
         auto mix = [](uint64_t h) -> uint32_t { uint32_t x = ((uint32_t)h ^ (uint32_t)(h >> 32)) * 0x9E3779B1u; return x ^ (x >> 15); };
@@ -871,58 +884,89 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
             }
             return 0xFFFFFFFFu;
         };
-        const uint32_t* ppnv = A.pnv + c.part_base;
         for (uint32_t sl = 0; sl < n_slices; ++sl) {
             gsync();
             for (uint32_t i = tid; i < cap; i += kGNT) { st_l2(&t_key[i], ~0ull); st_l2(&t_min[i], 0xFFFFFFFFu); }
-            for (uint32_t i = tid; i < 128; i += kGNT) s_bloom[i] = 0;
+            for (uint32_t i = tid; i < bloom_words; i += kGNT) s_bloom[i] = 0;
             gsync();
-            for (uint32_t s2 = tid; s2 < S_mid; s2 += kGNT) {   // the classes that are asked for
-                const uint64_t h = ch[tl[slot_v[s2]]];
-                if (slice_of(h) != sl) continue;
-                const uint32_t mx = mix(h);
-                atomicOr(&s_bloom[(mx >> 20) >> 5], 1u << ((mx >> 20) & 31u));
-                if (find(h, mx, true) == 0xFFFFFFFFu) s_cnt[3] = kErrInternal;
-            }
-            gsync();
-            // the vertices under a hashed key: they are the last n3 of every partition's vertices (the tag is the key's top bits)
-            for (uint32_t pp = tid; pp < P; pp += kGNT) {
-                const uint32_t k3 = pn3[pp], v1 = ppoff[pp] + ppnv[pp];
-                for (uint32_t g = v1 - k3; g < v1; ++g) {
-                    const uint64_t h = ch[g];
-                    if (slice_of(h) != sl) continue;
-                    const uint32_t slot = find(h, mix(h), true);
-                    if (slot == 0xFFFFFFFFu || (h >> 62) != 3) { s_cnt[3] = kErrInternal; continue; }
-                    const uint32_t off = coff[g];
-                    const uint32_t old = wg_min(&t_min[slot], off);
-                    if (old != 0xFFFFFFFFu && old != off && !lab_equal(rec_label(C, off), rec_label(C, old))) s_cnt[3] = kErrLabelHash;
+            // (Every loop below takes four items per thread and level: the loads and L2 atomics of a level go out together and
+            //  are waited for once.  One item at a time, a thread went through five dependent round trips per vertex.)
+            for (uint32_t s0 = tid; s0 - tid < S_mid; s0 += 4 * kGNT) {   // the classes that are asked for
+                uint32_t v4[4];
+                uint64_t h4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v4[r] = s0 + (uint32_t)r * kGNT < S_mid ? slot_v[s0 + (uint32_t)r * kGNT] : 0u;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v4[r] = s0 + (uint32_t)r * kGNT < S_mid ? tl[v4[r]] : 0u;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h4[r] = s0 + (uint32_t)r * kGNT < S_mid ? ch[v4[r]] : 0ull;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (s0 + (uint32_t)r * kGNT >= S_mid || slice_of(h4[r]) != sl) continue;
+                    const uint32_t mx = mix(h4[r]);
+                    atomicOr(&s_bloom[(mx >> bloom_shift) >> 5], 1u << ((mx >> bloom_shift) & 31u));
+                    if (find(h4[r], mx, true) == 0xFFFFFFFFu) s_cnt[3] = kErrInternal;
                 }
             }
-            // the asked-for classes whose key is the label itself: every vertex slot once, eight per thread and trip in flight
-            if (S_mid)
-                for (uint32_t g0 = tid; g0 - tid < R; g0 += 8 * kGNT) {
-                    uint64_t h8[8];
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) h8[r] = g0 + (uint32_t)r * kGNT < R ? ch[g0 + (uint32_t)r * kGNT] : 0ull;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        const uint64_t h = h8[r];
-                        if (h == 0 || (h >> 62) == 3) continue;
-                        const uint32_t mx = mix(h);
-                        if (!((s_bloom[(mx >> 20) >> 5] >> ((mx >> 20) & 31u)) & 1u)) continue;
-                        if (slice_of(h) != sl) continue;
-                        const uint32_t slot = find(h, mx, false);
-                        if (slot != 0xFFFFFFFFu) wg_min(&t_min[slot], coff[g0 + (uint32_t)r * kGNT]);
-                    }
-                }
             gsync();
-            for (uint32_t s2 = tid; s2 < S_mid; s2 += kGNT) {
-                const uint64_t h = ch[tl[slot_v[s2]]];
-                if (slice_of(h) != sl) continue;
-                const uint32_t slot = find(h, mix(h), false);
-                const uint32_t mn = slot == 0xFFFFFFFFu ? 0xFFFFFFFFu : ld_l2(&t_min[slot]);
-                if (mn == 0xFFFFFFFFu) s_cnt[3] = kErrInternal;   // (every asked-for class has at least the vertex that asked)
-                cmin[s2] = mn;
+            // every vertex slot once
+            auto find_on = [&](uint64_t h, uint32_t slot, unsigned long long k) -> uint32_t {   // find(), the first probe already made
+                for (uint32_t step = 0; step < cap; ++step) {
+                    if (k == h) return slot;
+                    if (k == ~0ull) return 0xFFFFFFFFu;
+                    slot = (slot + 1) & cmask;
+                    k = ld_l2(&t_key[slot]);
+                }
+                return 0xFFFFFFFFu;
+            };
+            for (uint32_t g0 = tid; g0 - tid < R; g0 += 4 * kGNT) {
+                uint64_t h4[4];
+                unsigned long long k4[4];
+                uint32_t sl4[4], off4[4], old4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h4[r] = g0 + (uint32_t)r * kGNT < R ? ch[g0 + (uint32_t)r * kGNT] : 0ull;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t mx = mix(h4[r]);
+                    const bool pass = h4[r] != 0 && ((s_bloom[(mx >> bloom_shift) >> 5] >> ((mx >> bloom_shift) & 31u)) & 1u) && slice_of(h4[r]) == sl;
+                    sl4[r] = pass ? mx & cmask : 0xFFFFFFFFu;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) k4[r] = sl4[r] != 0xFFFFFFFFu ? ld_l2(&t_key[sl4[r]]) : ~0ull;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (sl4[r] != 0xFFFFFFFFu) sl4[r] = find_on(h4[r], sl4[r], k4[r]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) off4[r] = sl4[r] != 0xFFFFFFFFu ? coff[g0 + (uint32_t)r * kGNT] : 0u;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) old4[r] = sl4[r] != 0xFFFFFFFFu ? wg_min(&t_min[sl4[r]], off4[r]) : 0xFFFFFFFFu;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (sl4[r] != 0xFFFFFFFFu && (uint32_t)(h4[r] >> 62) == 3 && old4[r] != 0xFFFFFFFFu && old4[r] != off4[r] &&
+                        !lab_equal(rec_label(C, off4[r]), rec_label(C, old4[r]))) s_cnt[3] = kErrLabelHash;
+            }
+            gsync();
+            for (uint32_t s0 = tid; s0 - tid < S_mid; s0 += 4 * kGNT) {
+                uint32_t v4[4], sl4[4];
+                uint64_t h4[4];
+                unsigned long long k4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v4[r] = s0 + (uint32_t)r * kGNT < S_mid ? slot_v[s0 + (uint32_t)r * kGNT] : 0u;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v4[r] = s0 + (uint32_t)r * kGNT < S_mid ? tl[v4[r]] : 0u;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h4[r] = s0 + (uint32_t)r * kGNT < S_mid ? ch[v4[r]] : 0ull;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sl4[r] = s0 + (uint32_t)r * kGNT < S_mid && slice_of(h4[r]) == sl ? mix(h4[r]) & cmask : 0xFFFFFFFFu;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) k4[r] = sl4[r] != 0xFFFFFFFFu ? ld_l2(&t_key[sl4[r]]) : ~0ull;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (sl4[r] == 0xFFFFFFFFu) continue;   // (past the end, or another slice's)
+                    const uint32_t slot = find_on(h4[r], sl4[r], k4[r]);
+                    const uint32_t mn = slot == 0xFFFFFFFFu ? 0xFFFFFFFFu : ld_l2(&t_min[slot]);
+                    if (mn == 0xFFFFFFFFu) s_cnt[3] = kErrInternal;   // (every asked-for class has at least the vertex that asked)
+                    cmin[s0 + (uint32_t)r * kGNT] = mn;
+                }
             }
         }
         gsync();
@@ -1032,8 +1076,8 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
 #ifdef AFQ_PUG_TIMING
     if (tid == 0 && (work % 512) < 2) {
         auto us = [&](int a, int b) { return (double)(tmark[b] - tmark[a]) / 100.0; };
-        printf("p2 graph cell R=%u pairs=%u NT=%u n3=%u n_tiny=%u n_mid=%u n_pr=%u S_mid=%u: gather=%.0f touched=%.0f wcc=%.0f comps=%.0f classes=%.0f pairs=%.0f records=%.0f tiny=%.0f mid=%.0f total=%.0f us\n",
-               R, n_pairs, NT, n3, n_tiny, n_mid, n_pr, S_mid, us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(6, 7), us(7, 8), us(8, 9), us(0, 9));
+        printf("p2 graph cell R=%u pairs=%u NT=%u n_tiny=%u n_mid=%u n_pr=%u S_mid=%u: gather=%.0f touched=%.0f wcc=%.0f comps=%.0f classes=%.0f pairs=%.0f records=%.0f tiny=%.0f mid=%.0f total=%.0f us\n",
+               R, n_pairs, NT, n_tiny, n_mid, n_pr, S_mid, us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(6, 7), us(7, 8), us(8, 9), us(0, 9));
     }
 #endif
     gsync();
