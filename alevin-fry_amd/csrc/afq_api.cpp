@@ -383,6 +383,13 @@ int plan_ranges(afq_ctx* c) {
     static const double kTaperCr[] = {0.28, 0.56, 0.78, 0.92, 1.0}, kTaperPug[] = {0.40, 0.76, 1.0, 1.0, 1.0};
     const double* kTaper = pug_res ? kTaperPug : kTaperCr;
     const size_t kTaperN = 5;
+    static double env_taper[5];
+    if (const char* e = pug_res ? std::getenv("AFQ_PUG_TAPER") : nullptr) {   // measurements: cumulative fractions, e.g. "0.3,0.6,0.85"
+        size_t k = 0;
+        for (const char* q = e; *q && k < 4;) { env_taper[k++] = std::atof(q); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+        while (k < 5) env_taper[k++] = 1.0;
+        kTaper = env_taper;
+    }
     if (pug_fixed > 0.5 * mem_budget) return fail(c, AFQ_ERR_OOM, "the largest parsimony cell's scratch does not fit device memory");
     double budget = mem_budget - pug_fixed - 0.40 * wide_new;   // (the widened copy was allocated after the free-memory query)
     if (budget <= 0) return fail(c, AFQ_ERR_OOM, "the widened copy of the batch leaves no room for the ranges");
@@ -643,7 +650,8 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     {   // this range's kernels start after the previous range's kernels (clean per-kernel timings, no cache
         // thrash between ranges); what overlaps them is the previous range's D2H and this range's enqueue
         RangeState& O = c->rs[slot ^ 1];
-        if (O.in_flight && O.kernels_done) HIP_TRY(c, hipStreamWaitEvent(s, O.kernels_done, 0));
+        static const bool overlap = std::getenv("AFQ_RANGE_OVERLAP") != nullptr;   // (measurements: let the two ranges in flight run side by side)
+        if (O.in_flight && O.kernels_done && !overlap) HIP_TRY(c, hipStreamWaitEvent(s, O.kernels_done, 0));
     }
     if (h2d_done) HIP_TRY(c, hipStreamWaitEvent(s, h2d_done, 0));   // afq_submit: this range's input bytes have landed
     hc.lap("run: uploads + memsets");

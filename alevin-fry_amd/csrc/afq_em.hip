@@ -409,11 +409,11 @@ __device__ __forceinline__ float bcast_f32(float v, uint32_t src_lane) { return 
 // thousand cells in flight that is the memory system's full throughput, for 20-100 rounds).  Here one
 // 1024-thread workgroup takes a cell and keeps everything the rounds touch ON CHIP: abundances, 1/denominators,
 // class offsets/counts, label words and memberships (16-bit ids) in LDS, the per-entry records in registers
-// (8 entries per thread).  A round is then LDS traffic and three barriers.  Cells too big for that (more than
-// 8192 active entries or classes, or > 144 KiB of LDS) run the same arithmetic out of global memory.
+// (kEmPer entries per thread).  A round is then LDS traffic and three barriers.  Cells too big for that (more than
+// kEmPer x 1024 active entries or classes, or > 144 KiB of LDS) run the same arithmetic out of global memory.
 // Arithmetic and its order are unchanged (bit-identical to the oracle).
 constexpr int kEmRNT = 1024;
-constexpr uint32_t kEmPer = 8;
+constexpr uint32_t kEmPer = 10;   // entries per thread in registers (ten cost the same registers and spills as eight: cells of up to 10 240 entries)
 constexpr uint32_t kEmLdsWords = 36 * 1024;
 __global__ __launch_bounds__(kEmRNT) void k_em_rounds(const CellMeta* __restrict__ meta, const uint32_t* __restrict__ nnz_unique,
                                                      const uint32_t* __restrict__ lab_cnt, const uint64_t* __restrict__ em_off,

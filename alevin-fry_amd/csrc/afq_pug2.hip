@@ -694,9 +694,9 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
     const uint64_t* psrc = A.pairs + c.rd_base;
     const uint8_t* cflag = A.v_flag + c.rd_base;
     uint32_t NT = 0;
-    for (uint32_t g0 = 4 * tid; g0 < R; g0 += 4 * kGNT) {
+    for (uint32_t g0 = 16 * tid; g0 < R; g0 += 16 * kGNT) {   // (sixteen flags per thread and trip in flight: this kernel's phases are chains of round trips)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) NT += g0 + r < R && cflag[g0 + r] != 0;
+        for (int r = 0; r < 16; ++r) NT += g0 + r < R && cflag[g0 + r] != 0;
     }
     {
         uint32_t tot;
@@ -718,27 +718,29 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
     uint32_t* pr_v = q; q += nt_max + 2;      // two-vertex components: their vertices, two by two
     {
         uint32_t carry = 0;
-        for (uint32_t base = 0; base < R; base += 4 * kGNT) {
-            const uint32_t g0 = base + 4 * tid;
-            uint32_t f[4], cn = 0;
+        for (uint32_t base = 0; base < R; base += 16 * kGNT) {
+            const uint32_t g0 = base + 16 * tid;
+            uint32_t fm = 0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { f[r] = g0 + r < R ? cflag[g0 + r] : 0u; }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cn += f[r] != 0;
+            for (int r = 0; r < 16; ++r) fm |= (uint32_t)(g0 + r < R && cflag[g0 + r] != 0) << r;
             uint32_t tot;
-            uint32_t li = carry + block_excl_scan<kGNT>(cn, s_ws, tot);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (f[r]) { tl[li] = g0 + r; lidx[g0 + r] = li; ++li; }
+            uint32_t li = carry + block_excl_scan<kGNT>((uint32_t)__popc(fm), s_ws, tot);
+            for (; fm; fm &= fm - 1) { const uint32_t g = g0 + (uint32_t)__builtin_ctz(fm); tl[li] = g; lidx[g] = li; ++li; }
             carry += tot;
         }
     }
     gsync();
-    for (uint32_t pp = tid; pp < P; pp += kGNT) {
+    for (uint32_t pp = tid; pp < P; pp += kGNT) {   // the partition's pairs over touched-vertex numbers, four at a time
         const uint32_t nk = pnp[pp], so = ppoff[pp], at = ppre[2 * pp];
-        for (uint32_t k = 0; k < nk; ++k) {
-            const uint64_t pr = psrc[so + k];
-            const uint32_t lx = lidx[(uint32_t)(pr >> 31) & 0x7FFFFFFFu], ly = lidx[(uint32_t)pr & 0x7FFFFFFFu];
-            lp[at + k] = (uint64_t)lx | ((uint64_t)ly << 24) | ((pr >> 62) << 48);
+        for (uint32_t k0 = 0; k0 < nk; k0 += 4) {
+            uint64_t pr[4];
+            uint32_t lx[4], ly[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pr[r] = k0 + r < nk ? psrc[so + k0 + r] : 0ull;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { lx[r] = k0 + r < nk ? lidx[(uint32_t)(pr[r] >> 31) & 0x7FFFFFFFu] : 0u; ly[r] = k0 + r < nk ? lidx[(uint32_t)pr[r] & 0x7FFFFFFFu] : 0u; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (k0 + r < nk) lp[at + k0 + r] = (uint64_t)lx[r] | ((uint64_t)ly[r] << 24) | ((pr[r] >> 62) << 48);
         }
     }
     gsync();
@@ -889,7 +891,7 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
             for (uint32_t i = tid; i < cap; i += kGNT) { st_l2(&t_key[i], ~0ull); st_l2(&t_min[i], 0xFFFFFFFFu); }
             for (uint32_t i = tid; i < bloom_words; i += kGNT) s_bloom[i] = 0;
             gsync();
-            // (Every loop below takes four items per thread and level: the loads and L2 atomics of a level go out together and
+            // (Every loop below takes four to six items per thread and level: the loads and L2 atomics of a level go out together and
             //  are waited for once.  One item at a time, a thread went through five dependent round trips per vertex.)
             for (uint32_t s0 = tid; s0 - tid < S_mid; s0 += 4 * kGNT) {   // the classes that are asked for
                 uint32_t v4[4];
@@ -919,28 +921,28 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
                 }
                 return 0xFFFFFFFFu;
             };
-            for (uint32_t g0 = tid; g0 - tid < R; g0 += 4 * kGNT) {
-                uint64_t h4[4];
-                unsigned long long k4[4];
-                uint32_t sl4[4], off4[4], old4[4];
+            for (uint32_t g0 = tid; g0 - tid < R; g0 += 6 * kGNT) {
+                uint64_t h4[6];
+                unsigned long long k4[6];
+                uint32_t sl4[6], off4[6], old4[6];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) h4[r] = g0 + (uint32_t)r * kGNT < R ? ch[g0 + (uint32_t)r * kGNT] : 0ull;
+                for (int r = 0; r < 6; ++r) h4[r] = g0 + (uint32_t)r * kGNT < R ? ch[g0 + (uint32_t)r * kGNT] : 0ull;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < 6; ++r) {
                     const uint32_t mx = mix(h4[r]);
                     const bool pass = h4[r] != 0 && ((s_bloom[(mx >> bloom_shift) >> 5] >> ((mx >> bloom_shift) & 31u)) & 1u) && slice_of(h4[r]) == sl;
                     sl4[r] = pass ? mx & cmask : 0xFFFFFFFFu;
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) k4[r] = sl4[r] != 0xFFFFFFFFu ? ld_l2(&t_key[sl4[r]]) : ~0ull;
+                for (int r = 0; r < 6; ++r) k4[r] = sl4[r] != 0xFFFFFFFFu ? ld_l2(&t_key[sl4[r]]) : ~0ull;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (sl4[r] != 0xFFFFFFFFu) sl4[r] = find_on(h4[r], sl4[r], k4[r]);
+                for (int r = 0; r < 6; ++r) if (sl4[r] != 0xFFFFFFFFu) sl4[r] = find_on(h4[r], sl4[r], k4[r]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) off4[r] = sl4[r] != 0xFFFFFFFFu ? coff[g0 + (uint32_t)r * kGNT] : 0u;
+                for (int r = 0; r < 6; ++r) off4[r] = sl4[r] != 0xFFFFFFFFu ? coff[g0 + (uint32_t)r * kGNT] : 0u;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) old4[r] = sl4[r] != 0xFFFFFFFFu ? wg_min(&t_min[sl4[r]], off4[r]) : 0xFFFFFFFFu;
+                for (int r = 0; r < 6; ++r) old4[r] = sl4[r] != 0xFFFFFFFFu ? wg_min(&t_min[sl4[r]], off4[r]) : 0xFFFFFFFFu;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 6; ++r)
                     if (sl4[r] != 0xFFFFFFFFu && (uint32_t)(h4[r] >> 62) == 3 && old4[r] != 0xFFFFFFFFu && old4[r] != off4[r] &&
                         !lab_equal(rec_label(C, off4[r]), rec_label(C, old4[r]))) s_cnt[3] = kErrLabelHash;
             }
