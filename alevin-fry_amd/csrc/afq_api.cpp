@@ -384,7 +384,7 @@ int plan_ranges(afq_ctx* c) {
     const double* kTaper = pug_res ? kTaperPug : kTaperCr;
     const size_t kTaperN = 5;
     static double env_taper[5];
-    if (const char* e = pug_res ? std::getenv("AFQ_PUG_TAPER") : nullptr) {   // measurements: cumulative fractions, e.g. "0.3,0.6,0.85"
+    if (const char* e = std::getenv(pug_res ? "AFQ_PUG_TAPER" : "AFQ_CR_TAPER")) {   // measurements: cumulative fractions, e.g. "0.3,0.6,0.85"
         size_t k = 0;
         for (const char* q = e; *q && k < 4;) { env_taper[k++] = std::atof(q); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
         while (k < 5) env_taper[k++] = 1.0;

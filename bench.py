@@ -447,6 +447,43 @@ def run_e2e(D, args, pkg, sn, rad, q, steps):
             "h2d_GBps_effective": round(rad.n_bytes / dt / 1e9, 2), "steps": steps}, host
 
 
+def run_e2e_ranks(D, args, pkg, sn, rad, q, steps):
+    """The e2e leg at N > 1: every rank brings its own sample over from its own pinned host buffer at the same time (the
+    ranks' PCIe links and the host's memory controllers are shared resources a one-rank run does not see).  Every rank makes
+    the same collective calls whatever happens to it; a failing rank turns the leg into an error on all of them."""
+    torch = D.torch
+    err, host, res, dt = None, None, None, 0.0
+    try:
+        host = torch.empty(rad.n_bytes, dtype=torch.uint8, pin_memory=True)
+        assert sn._lib().afq_synth_device_read(D.local_rank, rad.d_ptr, rad.n_bytes, host.data_ptr()) == 0
+        q.submit_ptr(host.data_ptr(), rad.n_bytes, rad.chunk_off)
+        res = q.collect()
+    except Exception as e:
+        err = e
+    D.sync()
+    t0 = time.perf_counter()
+    try:
+        if err is None:
+            for _ in range(steps):
+                res = None
+                q.submit_ptr(host.data_ptr(), rad.n_bytes, rad.chunk_off)
+                res = q.collect()
+            torch.cuda.synchronize(D.dev)
+            dt = (time.perf_counter() - t0) / steps
+            sanity(res, rad)
+    except Exception as e:
+        err = e
+    D.sync()
+    mx = D.reduce([dt, 1.0 if err is not None else 0.0], "max")
+    tot = D.reduce([rad.n_reads, rad.n_bytes, dt], "sum")
+    if mx[1] > 0:
+        raise RuntimeError(f"e2e leg failed on a rank ({type(err).__name__ if err else 'another rank'}: {err})")
+    return {"what": "afq_submit from pinned host memory + afq_collect on every rank at once: H2D of each rank's RAD bytes inside the step",
+            "value": round(tot[0] / mx[0] / 1e6, 3), "unit": "M reads/s", "ms_per_step": round(mx[0] * 1e3, 3),
+            "h2d_GBps_effective_total": round(tot[1] / mx[0] / 1e9, 2), "n_gpus": D.world,
+            "imbalance_max_over_mean_time": round(mx[0] / (tot[2] / D.world), 3), "steps": steps}
+
+
 def write_rad_dir(pkg, rad, host_bytes, path):
     names = [f"t{i}" for i in range(len(rad.tid_to_gid))]
     if rad.usa:
@@ -532,7 +569,7 @@ def main():
     if args.workload == "atac":
         return bench_atac(args, pkg, D)
     also = args.also.split(",") if args.also not in ("auto", "none") else \
-        ([] if args.also == "none" else (["configs2", "configs1_tail", "configs2_tail", "configs3", "atac", "e2e", "cli", "reference"] if D.world == 1 else ["configs3", "atac"]))
+        ([] if args.also == "none" else (["configs2", "configs1_tail", "configs2_tail", "configs3", "atac", "e2e", "cli", "reference"] if D.world == 1 else ["e2e", "configs3", "atac"]))
     also = [a for a in also if a and a != args.workload]
     legs = {}
     out = None
@@ -578,6 +615,14 @@ def main():
                         legs["reference"] = {"skipped": "no alevin-fry binary on this box ($ALEVIN_FRY_BIN / PATH); cpu_baseline is the C++ port"}
                     elif "value" in legs["reference"] and out is not None:
                         out["cpu_baseline_reference"] = legs["reference"]
+        if rad is not None and D.world > 1 and "e2e" in also and args.workload == "configs1" and not args.usa and (args.resolution in (None, "cr-like")):
+            r_e2e = None
+            try:
+                r_e2e = run_e2e_ranks(D, args, pkg, sn, rad, q, max(2, min(5, args.steps)))
+            except Exception as e:   # (raised on every rank alike: the collectives inside have all been made)
+                r_e2e = {"error": f"{type(e).__name__}: {e}"[:300]}
+            if D.rank == 0:
+                legs["e2e"] = r_e2e
         if q is not None:
             q.close()
             q = None

@@ -287,7 +287,7 @@ def test_bench_spawns_its_own_ranks():
     both on cuda:0 over gloo, tiny workloads; the driver's run uses one GPU per rank and RCCL)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--dist-backend", "gloo", "--steps", "2", "--warmup", "1",
-           "--cells", "300", "--median-reads", "2000", "--c3-cells", "2000", "--c3-mean-reads", "300", "--also", "configs3"]
+           "--cells", "300", "--median-reads", "2000", "--c3-cells", "2000", "--c3-mean-reads", "300", "--also", "e2e,configs3"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
@@ -295,6 +295,8 @@ def test_bench_spawns_its_own_ranks():
     c3 = line["also"]["configs3"]
     assert c3["n_gpus"] == 2 and c3["config"]["cells"] == 4000 and c3["value"] > 0
     assert 0.9 < c3["config"]["imbalance_max_over_mean_bytes"] < 1.3
+    e2e = line["also"]["e2e"]   # every rank from its own pinned host buffer at once
+    assert "error" not in e2e and e2e["n_gpus"] == 2 and e2e["value"] > 0 and e2e["imbalance_max_over_mean_time"] >= 1.0
 
 
 def test_bench_single_gpu_legs_small():
