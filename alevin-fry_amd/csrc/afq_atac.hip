@@ -63,6 +63,19 @@ __global__ __launch_bounds__(kParseNT) void k_atac_parse(AtacParseArgs a) {
     const uint32_t al = (uint32_t)((uintptr_t)ch & 3u);
     const uint32_t* W = reinterpret_cast<const uint32_t*>(ch - al);
     const uint64_t w_lim = (a.n_bytes - (c.chunk_off - al)) >> 2;   // whole dwords of the input buffer from W on
+    const uint32_t w_tail = (uint32_t)((a.n_bytes - (c.chunk_off - al)) & 3u);   // ... and the bytes of a last, partial one
+    // dword i of the chunk's aligned view; the buffer's last dword may be partial (a record of 4 + bc + 11 na bytes ends
+    // anywhere): its bytes are loaded one by one - read as 0 they made a last record with na = 0 fail the proof, and its
+    // cell took the sequential walk for nothing
+    auto ldw = [&](uint64_t i) -> uint32_t {
+        if (i < w_lim) return W[i];
+        if (i > w_lim || !w_tail) return 0u;
+        const uint8_t* b = reinterpret_cast<const uint8_t*>(W + i);
+        uint32_t v = b[0];
+        if (w_tail > 1) v |= (uint32_t)b[1] << 8;
+        if (w_tail > 2) v |= (uint32_t)b[2] << 16;
+        return v;
+    };
     const uint32_t nq = nb + al;                                     // positions q in [al, nq)
     const uint32_t n_groups = (nq + 255) >> 8;
     // ---- pass A: candidate bits, a wave per group of 256 positions, two groups per trip
@@ -72,7 +85,7 @@ __global__ __launch_bounds__(kParseNT) void k_atac_parse(AtacParseArgs a) {
         for (int u = 0; u < 2; ++u) {
             const uint64_t D = (uint64_t)(g0 + u) * 64 + lane;
 #pragma unroll
-            for (int x = 0; x < 4; ++x) d[u][x] = (g0 + u < n_groups && D + x < w_lim && (x < 3 || a.bc_bytes == 8)) ? W[D + x] : 0u;
+            for (int x = 0; x < 4; ++x) d[u][x] = (g0 + u < n_groups && (x < 3 || a.bc_bytes == 8)) ? ldw(D + x) : 0u;
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {

@@ -209,10 +209,16 @@ def roofline_of(ktimes, alg_bytes, steps, traffic_ok):
         tfiles = [f for f in tfiles if "configs" not in f]
     if traffic_ok and tfiles:   # HBM bytes per launch from the committed PMC passes; only meaningful for the workload they were taken on
         kern = json.load(open(os.path.join(pdir, tfiles[-1])))["kernels"]
-        for cand in {"k_decode_par": ("k_decode_recs", "k_decode_keys", "k_decode_par"), "k_em": ("k_em_rounds",)}.get(name, (name,)):
-            if cand in kern:
-                traffic = kern[cand]["bytes_per_launch_fetch_doubled"]
-                break
+        # (a timer of the library may bracket several kernels: their bytes add up; the decode timer brackets whichever decoder ran)
+        parts = {"k_em": ("k_em", "k_em_rounds"), "k_p2_split": ("k_p2_hist", "k_p2_scan", "k_p2_scatter")}.get(name)
+        if parts:
+            got = [kern[k]["bytes_per_launch_fetch_doubled"] for k in parts if k in kern]
+            traffic = sum(got) if got else None
+        else:
+            for cand in {"k_decode_par": ("k_decode_recs", "k_decode_keys", "k_decode_par")}.get(name, (name,)):
+                if cand in kern:
+                    traffic = kern[cand]["bytes_per_launch_fetch_doubled"]
+                    break
     kernels_ms = sum(v[0] for v in ktimes.values()) / steps
     return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
             "frac": round(achieved / 8000.0, 5), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": lps,

@@ -157,3 +157,25 @@ def test_atac_parse_at_every_alignment_and_width(oracle, bcb):
             q.close()
         _same(got, want)
         assert got[6]["n_records"] == sum(len(r) for _, r in cells)
+
+
+@pytest.mark.parametrize("bcb", [1, 2, 4])
+def test_atac_last_record_in_a_partial_dword_needs_no_fallback(oracle, bcb):
+    """A buffer that ends in a partial dword whose last record has no alignments (4 + bc bytes): the walk-free parse takes
+    the buffer's last bytes one by one, so the proof holds and no cell goes to the sequential walk (round-2 advice)."""
+    hits = 0
+    for k in range(1, 6):
+        recs = [[(3, 4, 1000 * i + 7, 120 + i)] for i in range(k)] + [[]]
+        b, off = rad.encode_atac_cells([(5, [[(1, 4, 50, 200)]] * 3), (9, recs)], bc_bytes=bcb)
+        data = np.frombuffer(b, np.uint8)
+        if len(data) % 4 == 0:
+            continue
+        hits += 1
+        q = _q()
+        try:
+            got = q.atac_dedup_rad(data, np.asarray(off, np.uint64), bc_bytes=bcb)
+        finally:
+            q.close()
+        _same(got, oracle.atac_dedup_rad(data, np.asarray(off, np.uint64), bc_bytes=bcb))
+        assert got[6]["n_fallback_cells"] == 0
+    assert hits >= 2
