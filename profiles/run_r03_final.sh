@@ -10,7 +10,7 @@ bash profiles/run_stress.sh 4 2>&1 | tail -4
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -c 300 $O/bench.json; echo
 PASSES="stats fetch write sq" bash profiles/run_prof.sh r03f > $O/prof1.log 2>&1
 PASSES="stats fetch write sq" bash profiles/run_prof.sh r03f_cfg2 --workload configs2 > $O/prof2.log 2>&1
-cd /tmp && export TMPDIR=/tmp
+mkdir -p gpurun_out/prof_r03f_cfg2_alone; cd /tmp && export TMPDIR=/tmp
 AFQ_NO_PIPELINE=1 timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_r03f_cfg2_alone/stats -o stats -- python $GRAFT_REPO_ROOT/bench.py --workload configs2 --steps 3 --warmup 1 --no-cpu-baseline --also none > $GRAFT_REPO_ROOT/gpurun_out/prof_r03f_cfg2_alone/bench_stats.json 2> $GRAFT_REPO_ROOT/$O/alone.err
 cd $GRAFT_REPO_ROOT
 find gpurun_out/prof_r03f_cfg2_alone -size +16M -delete
