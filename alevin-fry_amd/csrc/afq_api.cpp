@@ -546,7 +546,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     std::stable_sort(pug_cells.begin(), pug_cells.end(), [&](uint32_t a, uint32_t b) { return B.meta[a].nrec > B.meta[b].nrec; });
     if (n_pug && !par) return fail(c, AFQ_ERR_UNSUPPORTED, "device parsimony needs dword-aligned chunk offsets");
     // Parsimony cells go through the phase kernels of afq_pug2.hip (partition-parallel) unless their labels are
-    // gene-level, their UMI field is wider than 4 bytes or they hold 2^20 reads or more: those - and the cells the phase kernels
+    // gene-level, their UMI field is wider than 4 bytes or they hold 2^22 reads or more: those - and the cells the phase kernels
     // hand back - are resolved by the one-workgroup kernel of afq_pug.hip.  AFQ_PUG_ROUTE=mono sends every cell there (tests).
     std::vector<P2Cell> p2cells;
     std::vector<uint2> p2tiles;
@@ -798,7 +798,7 @@ int finish_range(afq_ctx* c, int slot) {
             case kErrUmiWide: return fail(c, AFQ_ERR_UNSUPPORTED, cell + "UMI wider than 22 nt is not supported");
             case kErrSlotRange: return fail(c, AFQ_ERR_BAD_INPUT, cell + "resolved column >= num_rows");
             case kErrLabelHash: return fail(c, AFQ_ERR_UNSUPPORTED, cell + "two ref lists share a 62-bit label hash under four different hash functions");
-            case kErrPugLimit: return fail(c, AFQ_ERR_UNSUPPORTED, cell + "a device-side PUG limit was exceeded (2^20 reads in the cell, a component of more than 4096 vertices under a raised --large-graph-thresh, or a vertex with an empty label)");
+            case kErrPugLimit: return fail(c, AFQ_ERR_UNSUPPORTED, cell + "a device-side PUG limit was exceeded (2^22 reads in the cell - 2^20 under gene-level labels or a UMI field over 4 bytes -, a component of more than 4096 vertices under a raised --large-graph-thresh, or a vertex with an empty label)");
             case kErrPugPool: return fail(c, AFQ_ERR_OOM, cell + "PUG edge pool exhausted");
             case kErrInternal: return fail(c, AFQ_ERR_HIP, cell + "internal consistency check failed in the parsimony kernels");
             default: return fail(c, AFQ_ERR_HIP, cell + "device error code " + std::to_string(st.err_code) + (st.err_code >= 20 ? " (internal consistency check of the parsimony kernels)" : ""));

@@ -360,7 +360,8 @@ def run_pbmc(D, args, pkg, sn, usa, resolution, steps, warmup, cpu_seconds, name
                 "sharding": f"{D.world} x independent cell shards, no data-path collective"}
         out = line(D, args, name, total_reads * steps / elapsed / 1e6, elapsed, steps, warmup, cfgd,
                    {"cells_per_s": round(total_cells * steps / elapsed, 1), "nnz": nnz, "keys": st["n_keys"],
-                    "overflow_buckets": st["n_overflow_buckets"], "gen_seconds": round(t_gen, 2), "roofline": roof, "cpu_baseline": cpu})
+                    "overflow_buckets": st["n_overflow_buckets"], "label_rehashes": q.label_rehash_count(), "gen_seconds": round(t_gen, 2),
+                    "roofline": roof, "cpu_baseline": cpu})
         return out, rad, q
     except BaseException:
         q.close()
