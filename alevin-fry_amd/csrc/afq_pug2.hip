@@ -520,6 +520,7 @@ __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t
     // Two rows of 64 slots at a time, every level of the gather chain issued for both rows before anything waits: key / flag /
     // record offset, then (hashed keys only) the label's length and first four refs out of the chunk, then the genes of all
     // refs - five dependent trips per partition where a hashed label used to add four of its own per row it occurred in.
+    const uint32_t cw = 2 + c.R * C.HW + c.n_ref;   // dwords of the chunk
     PugCtx Cg = C;
     Cg.gene_level = 1;   // (genes_of4 is handed gene ids below: the gathers are done here, for all slots together)
     for (uint32_t r0 = 0; r0 < n; r0 += 128) {   // (uniform)
@@ -541,9 +542,9 @@ __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t
             if (tag == 1) t4[r][0] = (uint32_t)h2[r] & 0x7FFFFFFFu;
             else if (tag == 2) { t4[r][0] = (uint32_t)(h2[r] >> 31) & 0x7FFFFFFFu; t4[r][1] = (uint32_t)h2[r] & 0x7FFFFFFFu; }
             else if (tag == 3) {
-                const uint32_t* lp = C.W + of[r] + C.HW;   // (a hashed label has three refs or more; the fourth dword read may be the next record's first: still inside the padded input)
+                const uint32_t* lp = C.W + of[r] + C.HW;   // (a hashed label has three refs or more; the fourth dword read may be the next record's first - never one past the chunk)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) t4[r][q] = lp[q] & 0x7FFFFFFFu;
+                for (int q = 0; q < 4; ++q) t4[r][q] = (q < 3 || of[r] + C.HW + 3 < cw) ? lp[q] & 0x7FFFFFFFu : 0xFFFFFFFFu;
             }
         }
 #pragma unroll
