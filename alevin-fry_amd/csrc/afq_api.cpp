@@ -563,7 +563,8 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
             P2Cell pc{};
             pc.rd_base = rd_off[ci]; pc.chunk_off = m.chunk_off; pc.cell = ci; pc.R = m.nrec; pc.n_ref = m.n_ref; pc.key_off = m.key_off;
             uint32_t lg = 0;
-            while (((m.nrec + (1u << lg) - 1) >> lg) > kP2PartTarget) ++lg;
+            static const uint32_t part_target = [] { const char* e = std::getenv("AFQ_P2_TARGET"); const int v = e ? std::atoi(e) : 0; return v >= 16 && v <= 256 ? (uint32_t)v : kP2PartTarget; }();   // (measurements)
+            while (((m.nrec + (1u << lg) - 1) >> lg) > part_target) ++lg;
             pc.lgP = lg; pc.part_base = (uint32_t)p2_parts;
             p2_parts += 1ull << lg;
             const uint32_t j = (uint32_t)p2cells.size();

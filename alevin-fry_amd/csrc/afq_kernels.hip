@@ -1224,7 +1224,8 @@ void launch_cell_hist(hipStream_t s, const ResolveArgs& a) {
     if (!a.n_hist) return;
     ResolveCfg rc = make_rc(a);
     uint32_t words = (a.num_rows + 1) / 2;
-    words = words < 4096u ? 4096u : (words > kHistBins ? kHistBins : words);
+    static const uint32_t cap = [] { const char* e = getenv("AFQ_HIST_WORDS"); const int v = e ? atoi(e) : 0; return v >= 4096 && v <= (int)kHistBins ? (uint32_t)v : kHistBins; }();   // (measurements: LDS words of a pass)
+    words = words < 4096u ? 4096u : (words > cap ? cap : words);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cell_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (int)kHistBins);   // (above 64 KiB needs asking)
     hipLaunchKernelGGL(k_cell_hist, dim3(a.n_hist), dim3(kHistNT), 4 * words, s, a.hist_cells, a.meta, a.keys0, a.keys1, a.cell_ncols, a.nnz, rc, words);
 }

@@ -1113,7 +1113,8 @@ void launch_p2_graph(hipStream_t s, const P2Args& a) {
     if (!a.n_cells) return;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    const uint32_t nb = a.n_cells < 4u * (uint32_t)cus ? a.n_cells : 4u * (uint32_t)cus;
+    static const uint32_t per_cu = [] { const char* e = getenv("AFQ_P2_GRAPH_WGS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 16 ? (uint32_t)v : 4u; }();   // (measurements: workgroups per CU)
+    const uint32_t nb = a.n_cells < per_cu * (uint32_t)cus ? a.n_cells : per_cu * (uint32_t)cus;
     AFQ_LAUNCH(k_p2_graph, nb, kGNT, s, a);
 }
 
