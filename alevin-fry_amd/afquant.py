@@ -378,6 +378,12 @@ class Quantifier:
         self.lib.afq_label_rehash_count.argtypes = [C.c_void_p]
         return int(self.lib.afq_label_rehash_count(self._h))
 
+    def pool_regrow_count(self) -> int:
+        """Ranges of cells run again with four times the parsimony pool because a cell's graph outgrew it (see afquant.h)."""
+        self.lib.afq_pool_regrow_count.restype = C.c_uint64
+        self.lib.afq_pool_regrow_count.argtypes = [C.c_void_p]
+        return int(self.lib.afq_pool_regrow_count(self._h))
+
     def batch_stats(self) -> dict:
         s = AfqBatchStats()
         self._check(self.lib.afq_get_batch_stats(self._h, C.byref(s)))

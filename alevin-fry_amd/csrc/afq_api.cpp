@@ -152,6 +152,7 @@ struct RangeState {
     std::vector<uint2> tile_desc;   // per scatter tile: (cell, tile index inside the cell)
     Range cur{};
     uint32_t hash_try = 0;   // which salt the range's label hashes were made with (a collision re-runs the range under the next)
+    uint32_t pool_try = 0;   // how often the range was run again with four times the parsimony pool (a cell's graph outgrew it)
     bool in_flight = false;
     hipEvent_t kernels_done = nullptr;
     std::vector<TimedLaunch> launches;  // HIP-event brackets of this range's kernels (cfg.profile)
@@ -215,6 +216,7 @@ struct afq_ctx {
     // stats / timers
     afq_batch_stats stats{};
     uint64_t n_label_rehash = 0;   // ranges decoded again under another label-hash salt (life of the context)
+    uint64_t n_pool_regrow = 0;    // ranges run again with a larger parsimony pool
     std::vector<TimedLaunch> launches;
     std::vector<hipEvent_t> event_pool;
     double k_ms[K_COUNT] = {0};
@@ -433,6 +435,7 @@ static uint64_t label_mask(uint32_t hash_try) {
     return ~0ull;
 }
 constexpr uint32_t kMaxHashTries = 4;
+constexpr uint32_t kMaxPoolTries = 3;   // 32 words per read x 4^3
 
 // Reads that carry many alignments carry many genes: most UMIs then outgrow the three gene counters of a slot of k_resolve's
 // UMI table and their buckets end up sorted after the table has been tried.  Such ranges (two or more alignment words per
@@ -446,10 +449,11 @@ static uint32_t resolve_sort_only(uint64_t n_ref_words, uint64_t n_records) {
 }
 
 // Plan + enqueue one range of cells on the context's stream.
-int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint32_t hash_try = 0) {
+int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint32_t hash_try = 0, uint32_t pool_try = 0) {
     HostClock hc;
     RangeState& B = c->rs[slot];
     B.hash_try = hash_try;
+    B.pool_try = pool_try;
     afq_config g = c->cfg;
     if (c->widen) { g.bc_bytes = c->eff_bc; g.umi_bytes = c->eff_umi; }   // what the kernels see: the widened copy
     const uint32_t H = hdr_bytes(g);
@@ -576,7 +580,10 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     const uint32_t n_p2 = (uint32_t)p2cells.size();
     hist_cells = multi;
     hist_cells.insert(hist_cells.end(), pug_cells.begin(), pug_cells.end());
-    const uint64_t epool_words = 32 * n_pug_reads + (1ull << 22);   // (the phase kernels' per-read arrays take ten of them, the rest is the pool)
+    // (the phase kernels' per-read arrays take ten of the words per read, the rest is the pool; a range whose densest cell outgrows
+    //  it - short UMIs, hundreds of reads per UMI: the pairs of a vertex are no longer a handful - is run again with four times as much)
+    const uint64_t pool_words_per_read = [] { const char* e = std::getenv("AFQ_TEST_POOL_WORDS"); const long v = e ? std::atol(e) : 0; return v >= 12 && v <= 32 ? (uint64_t)v : 32ull; }();   // (tests: a small first pool; read per range - a test sets it for itself)
+    const uint64_t epool_words = ((pool_words_per_read * n_pug_reads + (pool_words_per_read == 32 ? (1ull << 22) : (1ull << 20))) << (2 * pool_try));
     if (n_pug) {
         HIP_TRY(c, B.d_pug_cells.ensure(4ull * n_pug));
         HIP_TRY(c, B.d_rd_off.ensure(8ull * n));
@@ -787,7 +794,12 @@ int finish_range(afq_ctx* c, int slot) {
     HIP_TRY(c, hipMemcpy(&st, B.d_status.p, sizeof(st), hipMemcpyDeviceToHost));
     if (st.err_code == kErrLabelHash && B.hash_try + 1 < kMaxHashTries) {   // same range, next hash function (the input bytes are still resident)
         c->n_label_rehash += 1;
-        const int rc = run_range(c, B.cur, slot, nullptr, B.hash_try + 1);
+        const int rc = run_range(c, B.cur, slot, nullptr, B.hash_try + 1, B.pool_try);
+        return rc ? rc : finish_range(c, slot);
+    }
+    if (st.err_code == kErrPugPool && B.pool_try < kMaxPoolTries) {   // same range, four times the pool (refused only when the device has no room for it)
+        c->n_pool_regrow += 1;
+        const int rc = run_range(c, B.cur, slot, nullptr, B.hash_try, B.pool_try + 1);
         return rc ? rc : finish_range(c, slot);
     }
     if (st.err_code) {
@@ -1090,6 +1102,7 @@ int afq_device_warmup(int device) {
 }
 
 uint64_t afq_label_rehash_count(const afq_ctx* ctx) { return ctx ? ctx->n_label_rehash : 0; }
+uint64_t afq_pool_regrow_count(const afq_ctx* ctx) { return ctx ? ctx->n_pool_regrow : 0; }
 
 int afq_device_pci_bus_id(int device, char* out, size_t out_len) {
     if (!out || out_len < 13) return AFQ_ERR_INVALID_ARG;

@@ -272,6 +272,11 @@ int afq_get_batch_stats(afq_ctx* ctx, afq_batch_stats* out);
    detected on the device, and the range of cells is then decoded again with another hash function instead of being refused
    (the reference keys its map by the list itself, eq_class.rs:859-903).  How often that happened since afq_create. */
 uint64_t afq_label_rehash_count(const afq_ctx* ctx);
+/* Parsimony: the per-cell graphs are built in a pool sized by the range's reads (32 words per read).  A cell whose graph
+   outgrows it (short UMIs: hundreds of reads per UMI, so a vertex has many neighbours) makes the library run the range
+   again with four times the pool, up to three times, before AFQ_ERR_OOM (the reference allocates per graph,
+   pugutils.rs:65-267).  How often that happened since afq_create. */
+uint64_t afq_pool_regrow_count(const afq_ctx* ctx);
 
 /* Brings the HIP runtime up on `device` (first-call initialisation) - a host can call it from a side thread while it parses its
    inputs.  Returns 0 or AFQ_ERR_NO_DEVICE. */

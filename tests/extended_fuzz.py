@@ -1,0 +1,66 @@
+"""One-off extended parity sweep of the parsimony phase kernels (not collected by pytest: run it on a GPU box,
+`python tests/extended_fuzz.py [n_seeds] [first_seed]`).  Bigger cells than tests/test_gpu_fuzz.py (several UMI partitions,
+foreign-partition probes, pool-resident class tables), skewed and short UMIs, long labels; device rows == oracle rows."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from util import assert_same_result, pkg  # noqa: E402
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import oracle as ora  # noqa: E402
+
+synth = pkg.synth
+
+
+def one(seed):
+    rng = np.random.default_rng(77000 + seed)
+    res = ["parsimony", "parsimony-em"][seed % 2]
+    usa = bool(rng.integers(0, 2))
+    sizes = [int(x) for x in rng.choice([1, 30, 300, 900, 2500, 6000, 12000], size=int(rng.integers(2, 6)))]
+    sizes.append(int(rng.choice([15000, 30000, 45000, 70000])))
+    if seed % 7 == 0:
+        sizes.append(int(rng.integers(90000, 130000)))
+    s = synth.synth(5000 + seed, sizes, num_genes=int(rng.choice([17, 300, 3000])), txp_per_gene=int(rng.integers(1, 5)), usa=usa,
+                    dup=float(rng.choice([0.2, 0.5, 0.8])), cross=float(rng.choice([0.0, 0.3, 0.9])),
+                    umi_err=float(rng.choice([0.0, 0.02, 0.1])), max_extra_na=int(rng.choice([0, 2, 6, 20])),
+                    zipf=float(rng.choice([0.0, 0.8, 1.1])), umi_len=int(rng.choice([7, 8, 10, 12])))
+    b, off = s.encode()
+    kw = dict(small_thresh=int(rng.choice([0, 100])))
+    if rng.integers(0, 4) == 0:
+        kw["pug_exact_umi"] = True
+    if rng.integers(0, 4) == 0:
+        kw["large_graph_thresh"] = int(rng.choice([5, 40, 200]))
+    if usa and rng.integers(0, 2):
+        kw["sa_model"] = "prefer-ambig"
+    cfg = pkg.WorkerConfig.for_resolution(res, usa_mode=usa, num_genes=s.num_genes, num_rows=s.num_rows, umi_len=s.umi_len if rng.integers(0, 2) else 0, **kw)
+    q = pkg.Quantifier(cfg, s.tid_to_gid)
+    try:
+        got = q.quant_chunks(b, off)
+        rehash = q.label_rehash_count()
+    finally:
+        q.close()
+    want = ora.quant(cfg, s.tid_to_gid, b, off, n_threads=os.cpu_count() or 1)
+    assert_same_result(got, want, what=f"seed {seed} {res} usa={usa} {kw} sizes={sizes}")
+    return sum(sizes), rehash
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    bad, reads, t0 = 0, 0, time.time()
+    for seed in range(first, first + n):
+        try:
+            r, rh = one(seed)
+            reads += r
+            if rh:
+                print(f"seed {seed}: {rh} range(s) re-keyed", flush=True)
+        except Exception as e:   # noqa: BLE001
+            bad += 1
+            print(f"seed {seed} FAILED: {type(e).__name__}: {str(e)[:300]}", flush=True)
+    print(f"extended fuzz: {n} workloads, {reads} reads, {bad} failures, {time.time() - t0:.0f} s")
+    sys.exit(1 if bad else 0)

@@ -326,6 +326,26 @@ def test_label_hash_collision_is_rehashed_not_refused(oracle, monkeypatch, pug_r
     assert_same_result(got, want, what=res)
 
 
+@pytest.mark.parametrize("res", ["parsimony", "parsimony-em"])
+def test_a_graph_that_outgrows_the_pool_is_run_again_not_refused(oracle, monkeypatch, pug_route, res):
+    """The per-cell graphs live in a pool sized by the range's reads.  Short UMIs (7 nt: 16 384 of them for 40 000 reads) give
+    every vertex many same-UMI and one-base neighbours, and the cell's pairs, components and match lists outgrow a pool planned
+    for sparse graphs: the range is run again with four times the pool (afq_pool_regrow_count) instead of ending in
+    AFQ_ERR_OOM - found by tests/extended_fuzz.py; the reference allocates per graph (pugutils.rs:65-267)."""
+    s = synth.synth(5012, [900, 40000, 300], num_genes=17, txp_per_gene=3, usa=True, dup=0.5, cross=0.9, umi_err=0.02, max_extra_na=6, umi_len=7)
+    b, off = s.encode()
+    cfg = cfg_for(s, res, small_thresh=0)
+    want = oracle.quant(cfg, s.tid_to_gid, b, off)
+    monkeypatch.setenv("AFQ_TEST_POOL_WORDS", "12")
+    q = pkg.Quantifier(cfg, s.tid_to_gid)
+    try:
+        got = q.quant_chunks(b, off)
+        assert q.pool_regrow_count() >= 1, "the small first pool was meant to run out"
+    finally:
+        q.close()
+    assert_same_result(got, want, what=res)
+
+
 def test_parsimony_cell_of_more_than_2_pow_20_reads(oracle, pug_route):
     """The reference has no limit on a cell's reads (quant.rs:733-757).  The one-workgroup kernel numbers a cell's vertices
     in 20 bits and refuses cells of 2^20 reads or more; the phase kernels take them (up to 2^22): 1.15 M reads of one cell,
