@@ -385,7 +385,7 @@ int plan_ranges(afq_ctx* c) {
     static const double kTaperCr[] = {0.28, 0.56, 0.78, 0.92, 1.0}, kTaperPug[] = {0.40, 0.76, 1.0, 1.0, 1.0};
     const double* kTaper = pug_res ? kTaperPug : kTaperCr;
     const size_t kTaperN = 5;
-    static double env_taper[5];
+    double env_taper[5];   // (a local: contexts of several devices plan on their own threads)
     if (const char* e = std::getenv(pug_res ? "AFQ_PUG_TAPER" : "AFQ_CR_TAPER")) {   // measurements: cumulative fractions, e.g. "0.3,0.6,0.85"
         size_t k = 0;
         for (const char* q = e; *q && k < 4;) { env_taper[k++] = std::atof(q); while (*q && *q != ',') ++q; if (*q == ',') ++q; }

@@ -20,6 +20,8 @@ synth = pkg.synth
 def one(seed):
     rng = np.random.default_rng(77000 + seed)
     res = ["parsimony", "parsimony-em"][seed % 2]
+    if seed >= 1000:   # second family: every resolution (gene-level parsimony = the one-workgroup kernel, the cr-like routes, EM)
+        res = ["trivial", "cr-like", "cr-like-em", "parsimony", "parsimony-em", "parsimony-gene", "parsimony-gene-em"][seed % 7]
     usa = bool(rng.integers(0, 2))
     sizes = [int(x) for x in rng.choice([1, 30, 300, 900, 2500, 6000, 12000], size=int(rng.integers(2, 6)))]
     sizes.append(int(rng.choice([15000, 30000, 45000, 70000])))
@@ -37,6 +39,8 @@ def one(seed):
         kw["large_graph_thresh"] = int(rng.choice([5, 40, 200]))
     if usa and rng.integers(0, 2):
         kw["sa_model"] = "prefer-ambig"
+    if res.endswith("em") and rng.integers(0, 2):
+        kw["em_init_uniform"] = True
     cfg = pkg.WorkerConfig.for_resolution(res, usa_mode=usa, num_genes=s.num_genes, num_rows=s.num_rows, umi_len=s.umi_len if rng.integers(0, 2) else 0, **kw)
     q = pkg.Quantifier(cfg, s.tid_to_gid)
     try:
