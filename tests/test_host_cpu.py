@@ -216,3 +216,43 @@ def test_infer_files_input_errors_are_reported(lib, tmp_path):
     assert rc == pkg._abi.AFQ_ERR_BAD_INPUT and "quants_mat_rows.txt" in msg
     rc, msg = run(good_mtx, good_eq, cols=None)
     assert rc == pkg._abi.AFQ_ERR_BAD_INPUT and "column (gene) names" in msg
+
+
+def test_tail_model_of_the_host_generator():
+    """The label-length tail of the workload generator (csrc/afq_synth_model.h, host twin): records stay well formed (refs
+    ascending and distinct, inside the reference), the mean and the maximum are what DESIGN 3.5 quotes (E[na] ~ 3.1 at
+    p = 0.65, never over 64), and the extra refs are drawn per MOLECULE: among reads that share a UMI and their first ref, the
+    share whose lists are equal is the plain model's (whose one to three refs already differ from read to read) - drawn per
+    read, as a first version did, hardly two reads of a molecule would carry the same list."""
+    import importlib
+
+    sn = importlib.import_module("alevin-fry_amd.synth_native")
+    kw = dict(seed=5, n_cells=30, median_reads=6000, sigma=0.4, num_genes=36601, ref_count=199138)
+
+    def scan(r, cap):
+        w = r.data.view(np.uint32)
+        nas, same, diff = [], 0, 0
+        for c in range(30):
+            o = int(r.chunk_off[c]) // 4
+            nrec, p = int(w[o + 1]), o + 2
+            seen = {}
+            for _ in range(nrec):
+                na = int(w[p])
+                refs = w[p + 3:p + 3 + na] & 0x7FFFFFFF
+                assert 1 <= na <= cap and (np.diff(refs.astype(np.int64)) > 0).all() and int(refs.max()) < 199138
+                nas.append(na)
+                key, lab = (int(w[p + 2]), int(refs[0])), tuple(refs.tolist())
+                if key in seen:
+                    same += seen[key] == lab
+                    diff += seen[key] != lab
+                else:
+                    seen[key] = lab
+                p += 3 + na
+        return np.asarray(nas), same, diff
+
+    tailed, plain = sn.generate(tail=0.65, **kw), sn.generate(**kw)
+    nas, same, diff = scan(tailed, 64)
+    nas0, same0, diff0 = scan(plain, 3)
+    assert 2.8 < nas.mean() < 3.5 and nas.max() > 12 and (nas >= 5).mean() > 0.15 and 1.2 < nas0.mean() < 1.6
+    assert plain.n_reads == tailed.n_reads and len(plain.data) < len(tailed.data)   # the same reads, longer records
+    assert same0 > 1000 and same > 0.8 * same0, (same, diff, same0, diff0)
