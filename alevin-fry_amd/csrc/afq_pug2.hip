@@ -17,12 +17,14 @@
 //     and no per-cell scratch slice streamed through HBM phase after phase.
 //   * Only the vertices that HAVE an edge (~15 %) reach the per-cell graph kernel: components, the two-vertex rule and
 //     the arborescence covers (shared with afq_pug.hip through afq_pug_common.h) over compact arrays of touched
-//     vertices, 256 threads and 32 KiB of LDS per cell.
+//     vertices, 256 threads and 48.5 KiB of LDS per cell (three cells to a CU).
 //   * The reference's vertex order (class-major, classes by first appearance, UMIs ascending inside a class) only
 //     decides ties between equal-size arborescences, i.e. only inside components of three or more vertices.  It is
 //     the order of (smallest record offset of the vertex's class, UMI); the class minima are found for the classes that
-//     are asked for - and for every class whose label key is a hash, which is also where equal keys are shown to be
-//     equal labels - by one streaming pass of the cell's vertices through an LDS table.
+//     are asked for - the labels of the vertices in such components - by one streaming pass of the cell's vertices
+//     through a hash table (LDS, or the pool for big cells), which is also where equal HASHED keys of an asked-for class
+//     are shown to be equal labels.  Nothing else takes two vertices for one class: the partition kernel compares the
+//     reads it merges into a vertex, the search compares labels under hashed keys by content.
 //
 // A cell the phase kernels cannot take - a partition over 256 reads (skewed UMIs), a component over 64 vertices or
 // over --large-graph-thresh, more pairs than planned - is flagged and resolved by afq_pug.hip's kernel afterwards
@@ -318,7 +320,7 @@ __device__ __forceinline__ void part_body(const P2Args& A, const uint32_t* W, ui
     uint32_t n3 = 0;   // vertices under a hashed key (they sort last: the key's tag is its top bits)
 #pragma unroll
     for (int e = 0; e < E; ++e) n3 += (uint32_t)__popcll(__ballot(vh[e] && (uint32_t)((uint64_t)(a[e] >> 64) >> 62) == 3));
-    if (lane == 0) { A.pnv[gp] = before; A.pn3[gp] = n3; }
+    if (lane == 0) { A.pnv[gp] = before; A.pn3[gp] = n3; }   // (pn3: no kernel reads it any more - the class step used to walk every hashed vertex)
 }
 
 __global__ __launch_bounds__(256) void k_p2_part(P2Args A) {
