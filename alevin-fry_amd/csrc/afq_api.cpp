@@ -1110,6 +1110,42 @@ int afq_device_pci_bus_id(int device, char* out, size_t out_len) {
     return 0;
 }
 
+// The data chunks of a snappy frame stream undone on the device, one wave per chunk (csrc/afq_snappy.hip).  A building block
+// and its check: the compressed bytes go over, the decoded bytes come back; the front-end (afq_host.cpp) still decodes on the
+// host - what it takes to feed afq_submit_device from here is in DESIGN.md 9.1.
+int afq_snappy_decode_device(int device, const uint8_t* comp, size_t n_comp, const afq_sz_frame* frames, size_t n_frames, uint64_t out_bytes, uint8_t* out) {
+    static_assert(sizeof(afq_sz_frame) == sizeof(SzFrame), "afq_sz_frame and the kernels' SzFrame are one layout");
+    if ((!comp && n_comp) || (!frames && n_frames) || (!out && out_bytes)) return fail(nullptr, AFQ_ERR_INVALID_ARG, "null argument");
+    if (n_frames >= 0xFFFFFFF0ull) return fail(nullptr, AFQ_ERR_UNSUPPORTED, "too many snappy chunks for one call");
+    for (size_t i = 0; i < n_frames; ++i) {
+        const afq_sz_frame& f = frames[i];
+        if (f.in_off > n_comp || f.in_len > n_comp - f.in_off || f.ulen > 65536u || f.out_off > out_bytes || f.ulen > out_bytes - f.out_off ||
+            (!f.compressed && f.in_len != f.ulen))
+            return fail(nullptr, AFQ_ERR_BAD_INPUT, "snappy chunk " + std::to_string(i) + ": out of range of the stream or of the output");
+    }
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, AFQ_ERR_NO_DEVICE, "no such device"); }
+    if (!n_frames) return 0;
+    uint8_t *d_comp = nullptr, *d_out = nullptr;
+    SzFrame* d_fr = nullptr;
+    DevStatus* d_st = nullptr;
+    DevStatus st{};
+    hipError_t e = hipMalloc(&d_comp, n_comp + 16);
+    if (e == hipSuccess) e = hipMalloc(&d_out, out_bytes + 16);
+    if (e == hipSuccess) e = hipMalloc(&d_fr, sizeof(SzFrame) * n_frames);
+    if (e == hipSuccess) e = hipMalloc(&d_st, sizeof(DevStatus));
+    if (e == hipSuccess) e = hipMemcpy(d_comp, comp, n_comp, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_fr, frames, sizeof(SzFrame) * n_frames, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_st, 0, sizeof(DevStatus));
+    if (e == hipSuccess) { launch_snappy_frames(nullptr, d_comp, d_fr, (uint32_t)n_frames, d_out, d_st); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(&st, d_st, sizeof(st), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && !st.err_code && out_bytes) e = hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d_comp); (void)hipFree(d_out); (void)hipFree(d_fr); (void)hipFree(d_st);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, e == hipErrorOutOfMemory ? AFQ_ERR_OOM : AFQ_ERR_HIP, std::string("snappy decode: ") + hipGetErrorString(e)); }
+    if (st.err_code) return fail(nullptr, AFQ_ERR_BAD_INPUT, "corrupt snappy block in chunk " + std::to_string(st.err_cell));
+    return 0;
+}
+
 const char* afq_last_error(const afq_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
 int afq_create(const afq_config* cfg, const uint32_t* tid_to_gid, uint32_t ref_count, int device, afq_ctx** out) {

@@ -278,6 +278,20 @@ uint64_t afq_label_rehash_count(const afq_ctx* ctx);
    pugutils.rs:65-267).  How often that happened since afq_create. */
 uint64_t afq_pool_regrow_count(const afq_ctx* ctx);
 
+/* One data chunk of a snappy frame stream (the format of map.collated.rad.sz: src/quant.rs:373-395, collate.rs:550-554):
+   where its body lies in the stream (after the chunk's 4-byte header and 4-byte CRC), where its bytes go in the output,
+   how many they are (at most 65536) and whether the body is a snappy block (chunk type 0x00) or the bytes themselves (0x01). */
+typedef struct afq_sz_frame {
+    uint64_t in_off, in_len, out_off;
+    uint32_t ulen, compressed;
+} afq_sz_frame;
+/* Undoes the listed chunks on `device`, one wavefront per chunk (csrc/afq_snappy.hip), and returns the out_bytes decoded bytes
+   in `out` (host memory).  The same acceptance rules as snap's decoder - a block that does not decode to exactly its announced
+   length is AFQ_ERR_BAD_INPUT, afq_last_error(NULL) names the chunk; the chunks' CRC-32C words are not checked.  A building
+   block: the front-end of include/afquant_host.h still decodes .rad.sz on the host. */
+int afq_snappy_decode_device(int device, const uint8_t* comp, size_t n_comp, const afq_sz_frame* frames, size_t n_frames, uint64_t out_bytes,
+                             uint8_t* out);
+
 /* Brings the HIP runtime up on `device` (first-call initialisation) - a host can call it from a side thread while it parses its
    inputs.  Returns 0 or AFQ_ERR_NO_DEVICE. */
 int afq_device_warmup(int device);
