@@ -1136,8 +1136,20 @@ int afq_snappy_decode_device(int device, const uint8_t* comp, size_t n_comp, con
     if (e == hipSuccess) e = hipMemcpy(d_comp, comp, n_comp, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_fr, frames, sizeof(SzFrame) * n_frames, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(d_st, 0, sizeof(DevStatus));
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    const bool timed = std::getenv("AFQ_HOST_TIMING") != nullptr;
+    if (timed && e == hipSuccess) { e = hipEventCreate(&ev0); if (e == hipSuccess) e = hipEventCreate(&ev1); if (e == hipSuccess) e = hipEventRecord(ev0, nullptr); }
     if (e == hipSuccess) { launch_snappy_frames(nullptr, d_comp, d_fr, (uint32_t)n_frames, d_out, d_st); e = hipGetLastError(); }
+    if (timed && e == hipSuccess) e = hipEventRecord(ev1, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (timed && e == hipSuccess) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess)
+            std::fprintf(stderr, "[afq host] snappy decode: %zu chunks, %.1f MB -> %.1f MB, kernel %.3f ms (%.1f GB/s of output)\n", n_frames, (double)n_comp / 1e6,
+                         (double)out_bytes / 1e6, ms, ms > 0 ? (double)out_bytes / (ms * 1e6) : 0.0);
+    }
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
     if (e == hipSuccess) e = hipMemcpy(&st, d_st, sizeof(st), hipMemcpyDeviceToHost);
     if (e == hipSuccess && !st.err_code && out_bytes) e = hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost);
     (void)hipFree(d_comp); (void)hipFree(d_out); (void)hipFree(d_fr); (void)hipFree(d_st);
