@@ -77,7 +77,11 @@ __global__ __launch_bounds__(64) void k_snappy_frames(const uint8_t* __restrict_
                 p += nb;
             }
             if (len > kSzBlock || p + len > n || w + len > ulen) { bad = true; break; }
-            for (uint32_t i = lane; i < (uint32_t)len; i += 64) s_out[w + i] = inb[p + i];
+            if (p >= wbase && p + (uint32_t)len <= wend) {   // a literal inside the window (nearly all are short): LDS to LDS, no trip to memory
+                for (uint32_t i = lane; i < (uint32_t)len; i += 64) s_out[w + i] = s_in[p - wbase + i];
+            } else {
+                for (uint32_t i = lane; i < (uint32_t)len; i += 64) s_out[w + i] = inb[p + i];
+            }
             p += (uint32_t)len; w += (uint32_t)len;
         } else {           // copy of earlier output
             uint32_t len, off;
