@@ -146,7 +146,7 @@ struct RangeState {
         d_lab_cnt, d_em_off, d_em_scratch, d_em_nnz, d_pug_cells, d_rd_off, d_rd_h, d_rd_u, d_rd_o, d_pug_scr_off,
         d_pug_scratch, d_epool, d_epool_cur, d_alt, d_hist_cells, d_fix, d_em_hdr, d_em_order, d_eq_ncls, d_eq_nw, d_eq_cptr,
         d_p2_small, d_eq_wptr, d_eq_len, d_eq_cnt, d_eq_lab, d_bt_off, d_bt_scratch, d_bt_ns, d_bt_col, d_bt_mean, d_bt_var, d_bt_sptr, d_bt_ccol,
-        d_bt_cmean, d_bt_cvar;
+        d_bt_cmean, d_bt_cvar, d_em2_off, d_em2_scratch, d_em2_tiers;
     ResolveArgs last_ra{};
     std::vector<CellMeta> meta;
     std::vector<uint2> tile_desc;   // per scatter tile: (cell, tile index inside the cell)
@@ -162,7 +162,7 @@ struct RangeState {
                 &d_cell_bc, &d_bdesc, &d_lab, &d_lab_cnt, &d_em_off, &d_em_scratch, &d_em_nnz, &d_pug_cells, &d_rd_off, &d_rd_h,
                 &d_rd_u, &d_rd_o, &d_pug_scr_off, &d_pug_scratch, &d_epool, &d_epool_cur, &d_p2_small, &d_alt, &d_hist_cells, &d_fix, &d_em_hdr, &d_em_order,
                 &d_eq_ncls, &d_eq_nw, &d_eq_cptr, &d_eq_wptr, &d_eq_len, &d_eq_cnt, &d_eq_lab, &d_bt_off, &d_bt_scratch, &d_bt_ns, &d_bt_col,
-                &d_bt_mean, &d_bt_var, &d_bt_sptr, &d_bt_ccol, &d_bt_cmean, &d_bt_cvar};
+                &d_bt_mean, &d_bt_var, &d_bt_sptr, &d_bt_ccol, &d_bt_cmean, &d_bt_cvar, &d_em2_off, &d_em2_scratch, &d_em2_tiers};
     }
 };
 
@@ -825,6 +825,7 @@ int finish_range(afq_ctx* c, int slot) {
     const bool em = c->cfg.resolution == AFQ_RES_CR_LIKE_EM || c->cfg.resolution == AFQ_RES_PARSIMONY_EM ||
                     c->cfg.resolution == AFQ_RES_PARSIMONY_GENE_EM;
     std::vector<uint32_t> alt(n);
+    bool em2 = false;   // the EM ran in afq_em2.hip: the rows sit in its scratch
     HIP_TRY(c, hipMemcpy(alt.data(), B.d_alt.p, 4ull * n, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(nnz.data(), B.d_nnz.p, 4ull * n, hipMemcpyDeviceToHost));
     if (em) {
@@ -832,22 +833,41 @@ int finish_range(afq_ctx* c, int slot) {
         std::vector<uint32_t> lc(2ull * n);
         std::vector<uint64_t> eoff(n + 1);
         HIP_TRY(c, hipMemcpy(lc.data(), B.d_lab_cnt.p, 8ull * n, hipMemcpyDeviceToHost));
-        eoff[0] = 0;
-        for (uint32_t i = 0; i < n; ++i) eoff[i + 1] = eoff[i] + em_scratch_words(nnz[i], lc[2 * i], lc[2 * i + 1], c->cfg.usa_mode != 0);
-        HIP_TRY(c, B.d_em_off.ensure(8ull * (n + 1)));
-        HIP_TRY(c, B.d_em_scratch.ensure(4 * eoff[n] + 16));
-        HIP_TRY(c, B.d_em_nnz.ensure(4ull * n));
-        HIP_TRY(c, B.d_em_hdr.ensure(16ull * n));
-        HIP_TRY(c, hipMemcpyAsync(B.d_em_off.p, eoff.data(), 8ull * (n + 1), hipMemcpyHostToDevice, s));
+        // The EM runs in order-free fixed-point arithmetic (afq_em2.hip) unless AFQ_EM_ORDER=canonical asks for the sequential f32
+        // sums in canonical class order (afq_em.hip, rounds 1-3) or the output space does not fit the set-up kernel's bitmap.
+        // -d / -b read the cell's classes off the canonical set-up, which then runs as well (set-up only).
+        const char* em_env = std::getenv("AFQ_EM_ORDER");
+        const uint32_t na_em = c->cfg.usa_mode ? c->cfg.num_rows : c->cfg.num_genes;
+        em2 = !(em_env && !std::strcmp(em_env, "canonical")) && em2_supported(na_em);
+        const bool need_classes = c->cfg.dump_eq || c->cfg.num_bootstraps;
         std::vector<uint32_t> em_order(n);
         for (uint32_t i = 0; i < n; ++i) em_order[i] = i;
         std::stable_sort(em_order.begin(), em_order.end(), [&](uint32_t a, uint32_t b) { return B.meta[a].nrec > B.meta[b].nrec; });
         HIP_TRY(c, B.d_em_order.ensure(4ull * n));
         HIP_TRY(c, hipMemcpyAsync(B.d_em_order.p, em_order.data(), 4ull * n, hipMemcpyHostToDevice, s));
-        {
+        HIP_TRY(c, B.d_em_nnz.ensure(4ull * n));
+        if (!em2 || need_classes) {
+            eoff[0] = 0;
+            for (uint32_t i = 0; i < n; ++i) eoff[i + 1] = eoff[i] + em_scratch_words(nnz[i], lc[2 * i], lc[2 * i + 1], c->cfg.usa_mode != 0);
+            HIP_TRY(c, B.d_em_off.ensure(8ull * (n + 1)));
+            HIP_TRY(c, B.d_em_scratch.ensure(4 * eoff[n] + 16));
+            HIP_TRY(c, B.d_em_hdr.ensure(16ull * n));
+            HIP_TRY(c, hipMemcpyAsync(B.d_em_off.p, eoff.data(), 8ull * (n + 1), hipMemcpyHostToDevice, s));
             ScopedTimer t(c, K_EM, s, &B.launches);
             launch_em(s, B.last_ra, n, B.d_em_off.as<uint64_t>(), B.d_em_scratch.as<uint32_t>(), B.d_em_nnz.as<uint32_t>(), B.d_em_hdr.p, B.d_em_order.as<uint32_t>(),
-                      c->cfg.usa_mode ? c->cfg.num_rows : c->cfg.num_genes, c->cfg.em_init_uniform);
+                      na_em, c->cfg.em_init_uniform, !em2);
+        }
+        std::vector<uint64_t> eoff2(n + 1);
+        if (em2) {
+            eoff2[0] = 0;
+            for (uint32_t i = 0; i < n; ++i) eoff2[i + 1] = eoff2[i] + em2_scratch_words(nnz[i], lc[2 * i], lc[2 * i + 1], c->cfg.usa_mode != 0);
+            HIP_TRY(c, B.d_em2_off.ensure(8ull * (n + 1)));
+            HIP_TRY(c, B.d_em2_scratch.ensure(4 * eoff2[n] + 16));
+            HIP_TRY(c, B.d_em2_tiers.ensure(4ull * (8 + 5ull * n)));
+            HIP_TRY(c, hipMemcpyAsync(B.d_em2_off.p, eoff2.data(), 8ull * (n + 1), hipMemcpyHostToDevice, s));
+            ScopedTimer t(c, K_EM, s, &B.launches);
+            launch_em2(s, B.last_ra, n, B.d_em2_off.as<uint64_t>(), B.d_em2_scratch.as<uint32_t>(), B.d_em_nnz.as<uint32_t>(), B.d_em_order.as<uint32_t>(),
+                       B.d_em2_tiers.as<uint32_t>(), na_em, c->cfg.em_init_uniform);
         }
         HIP_TRY(c, hipStreamSynchronize(s));
         HIP_TRY(c, hipMemcpy(nnz.data(), B.d_em_nnz.p, 4ull * n, hipMemcpyDeviceToHost));
@@ -949,7 +969,7 @@ int finish_range(afq_ctx* c, int slot) {
     {
         ScopedTimer t(c, K_COMPACT, s, &B.launches);
         if (em)
-            launch_compact_em(s, n, B.d_em_off.as<uint64_t>(), B.d_em_scratch.as<uint32_t>(), B.d_em_nnz.as<uint32_t>(),
+            launch_compact_em(s, n, (em2 ? B.d_em2_off : B.d_em_off).as<uint64_t>(), (em2 ? B.d_em2_scratch : B.d_em_scratch).as<uint32_t>(), B.d_em_nnz.as<uint32_t>(),
                               B.d_cell_ptr.as<uint64_t>(), B.d_gene.as<uint32_t>(), B.d_val.as<float>());
         else
             launch_compact(s, B.d_meta.as<CellMeta>(), n, B.d_keys0.as<uint64_t>(), B.d_keys1.as<uint64_t>(), B.d_nnz.as<uint32_t>(),

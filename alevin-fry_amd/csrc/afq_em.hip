@@ -1294,12 +1294,12 @@ uint64_t em_scratch_words(uint32_t nU, uint32_t W, uint32_t M, bool usa) {
 }
 
 void launch_em(hipStream_t s, const ResolveArgs& a, uint32_t n_cells, const uint64_t* em_off, uint32_t* scratch,
-               uint32_t* out_nnz, void* em_hdr_v, const uint32_t* em_order, uint32_t num_alphas, uint32_t init_uniform) {
+               uint32_t* out_nnz, void* em_hdr_v, const uint32_t* em_order, uint32_t num_alphas, uint32_t init_uniform, bool rounds) {
     uint4* em_hdr = reinterpret_cast<uint4*>(em_hdr_v);
     if (!n_cells) return;
     EmCfg cfg{a.usa, num_alphas, a.num_rows / 3, 2 * (a.num_rows / 3), init_uniform};
     AFQ_LAUNCH(k_em, n_cells, kEmNT, s, a.meta, a.nnz, a.keys0, a.keys1, a.lab, a.lab_cnt, em_off, scratch, out_nnz, em_hdr, em_order, cfg);
-    AFQ_LAUNCH(k_em_rounds, n_cells, kEmRNT, s, a.meta, a.nnz, a.lab_cnt, em_off, scratch, out_nnz, em_hdr, em_order, cfg);
+    if (rounds) AFQ_LAUNCH(k_em_rounds, n_cells, kEmRNT, s, a.meta, a.nnz, a.lab_cnt, em_off, scratch, out_nnz, em_hdr, em_order, cfg);
 }
 
 void launch_eqc_dump(hipStream_t s, const ResolveArgs& a, uint32_t n_cells, const uint64_t* em_off, const uint32_t* scratch,

@@ -1,0 +1,490 @@
+// afq_em2.hip - the per-cell EM (src/em.rs) with ORDER-FREE arithmetic, round 4.
+//
+// What the reference computes per round (em_update_subset[_usa], em.rs:189-248; em_update, em.rs:458-485): for every
+// gene-level class with label l and count n: D = sum_{g in l} abundance(g); every g in l receives abundance(g) * (n / D);
+// a single-label class adds n to its one entry.  The f32 additions into an entry happen in HashMap order (em.rs:464),
+// i.e. in no order at all: run to run the reference's own low bits move (DESIGN.md section 5 measures how far).
+//
+// Here the shares are accumulated in 64-bit FIXED POINT, which makes the sum independent of any order:
+//     r = 1.0f / D                       (f32, D summed in label order as the reference does)
+//     q = (u64)((abundance(g) * r) * 2^F)  (f32 product, scaled by a power of two - exact -, truncated)
+//     acc[g] += n * q                    (integers: associative, so classes may come in any order, from any lane, atomically)
+//     alpha'[g] = (float)acc[g] * 2^-F   (acc starts at the entry's single-label count << F; one rounding)
+// with F = min(40, 62 - bitlen(nrec)) so that acc < 2^63.  Two consequences shape the kernels:
+//   * n * q is linear in n: a class of count n and n copies of it with count 1 add the same integer.  The device therefore
+//     does NOT group equal labels (no sort, no hash table): every ambiguous molecule is its own class of count 1.  The oracle
+//     (oracle/afq_oracle.cpp, ora_set_em_arith(1)) groups them as the reference does and gets the same bits.
+//   * no inverted index entry -> classes, no serial chains for highly expressed genes: a round is ONE pass over the classes
+//     (gather the label's abundances, D, r, scatter the shares with LDS 64-bit atomics) and one pass over the entries.
+// Against the reference's f32 arithmetic in the oracle's canonical order the results differ like any reordering does
+// (<= 1e-4 relative, north_star's tolerance; tests/test_gpu_em.py); against the oracle in the same arithmetic they are
+// bit-identical.  AFQ_EM_ORDER=canonical keeps the round-1..3 kernels (afq_em.hip: sequential f32 in canonical class order).
+//
+// Only entries that sit in some class label ("live") change from round to round.  An entry with a single-label count that
+// is in no label holds that count from round 1 on; it matters only as a USA sibling (get_abundance_for, em.rs:167-187) of a
+// live entry ("passive": a constant after round 1) and in the output row.  The rounds run over live entries only.
+//
+//   k_em2_setup   per cell: EM labels (USA rewrite utils.rs:865-925) -> live set by bitmap + popcount ranks, sibling links,
+//                 passive siblings, single-label counts, the merge ranks of the output row; picks the cell's tier
+//   k_em2_rounds  per cell, five instances: everything in LDS at 256 / 512 / 1024 threads (38 / 78 / 157 KiB: four, two, one
+//                 cell per CU), abundances + accumulators in LDS with the class lists streamed, everything in global memory
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "afq_common.h"
+#include "afq_kernels.h"
+#include "afq_prims.h"
+
+namespace afq {
+
+namespace {
+constexpr float kMinOutputAlpha2 = 0.01f, kAlphaCheckCutoff2 = 1e-2f, kRelDiffTol2 = 1e-2f;
+constexpr uint32_t kMinIter2 = 2, kMaxIter2 = 100;
+constexpr uint32_t kSibNone = 0xFFFFFFFFu;   // no such sibling status: adds +0.0f
+constexpr uint32_t kSibZero = 0xFFFFFFFEu;   // a sibling status nothing maps to: the start value in round 1, 0 afterwards
+constexpr uint32_t kSibPassive = 0x80000000u;   // | index into pas_val
+constexpr int kSetupNT = 256;
+
+struct Em2Cfg { uint32_t usa, num_alphas, uo, ao, init_uniform, nwb, min_tier; };
+
+// per-cell scratch (u32 words); mirrored by em2_scratch_words
+struct Em2Scratch {
+    uint2* out; uint32_t* hdr; uint32_t *ent_col, *ent_ucnt, *ent_s1, *ent_s2, *ent_ub, *pas_val, *coff, *cw, *pu_col, *pu_cnt, *pu_lb;
+    unsigned long long* g_acc; float *g_ab, *g_v; uint32_t* g_pre;
+};
+__host__ __device__ inline uint64_t em2_pas_cap(uint64_t nU, uint64_t W, bool usa) { return usa ? (nU < 2 * W ? nU : 2 * W) : 0; }
+__device__ __forceinline__ Em2Scratch em2_carve(uint32_t* scratch, uint64_t off, uint32_t nU, uint32_t W, uint32_t M, bool usa) {
+    Em2Scratch e;
+    uint32_t* p = scratch + off;
+    e.out = reinterpret_cast<uint2*>(p); p += 2 * ((uint64_t)nU + W);
+    e.hdr = p; p += 16;
+    e.g_acc = reinterpret_cast<unsigned long long*>(p); p += 2 * ((uint64_t)W + 1);
+    e.ent_col = p; p += W;
+    e.ent_ucnt = p; p += W;
+    e.ent_s1 = p; p += usa ? W : 0;
+    e.ent_s2 = p; p += usa ? W : 0;
+    e.ent_ub = p; p += W;
+    e.pas_val = p; p += em2_pas_cap(nU, W, usa);
+    e.coff = p; p += M + 1;
+    e.cw = p; p += W;
+    e.pu_col = p; p += nU;
+    e.pu_cnt = p; p += nU;
+    e.pu_lb = p; p += nU;
+    e.g_ab = reinterpret_cast<float*>(p); p += usa ? W : 0;
+    e.g_v = reinterpret_cast<float*>(p); p += W + em2_pas_cap(nU, W, usa) + 2;
+    e.g_pre = p; p += W + 1;
+    return e;
+}
+}  // namespace
+
+uint64_t em2_scratch_words(uint32_t nU, uint32_t W, uint32_t M, bool usa) {
+    const uint64_t pc = em2_pas_cap(nU, W, usa);
+    uint64_t w = 2 * ((uint64_t)nU + W) + 16 + 2 * ((uint64_t)W + 1) + 3 * (uint64_t)W + (usa ? 2 * (uint64_t)W : 0) + pc + ((uint64_t)M + 1) + W +
+                 3 * (uint64_t)nU + (usa ? W : 0) + ((uint64_t)W + pc + 2) + ((uint64_t)W + 1);
+    return (w + 3) & ~3ull;   // slices stay 16-byte aligned
+}
+
+// header words
+enum { H_L = 0, H_P, H_K, H_WC, H_NPU, H_FBITS, H_TIER };
+constexpr uint32_t kTierNone = 7;   // no multi-label class: the row is the single-label counts (em.rs:339-341, 499-514)
+// LDS words of the three all-in-LDS instances (4 x 38 KiB, 2 x 78 KiB, 157 KiB: next to the few static words they fit a CU's 160 KiB)
+constexpr uint32_t kT0Words = 9728, kT1Words = 19968, kT2Words = 40192;
+
+__device__ __forceinline__ uint32_t em2_fbits(uint32_t nrec) {
+    const uint32_t bl = 32u - (uint32_t)__builtin_clz(nrec | 1u);
+    const uint32_t f = 62u - bl;
+    return f < 40u ? f : 40u;
+}
+// LDS words of the all-in-LDS layout: acc u64[L] | ab f32[L] (USA) | v f32[L+P+2] | coff u16[K+1] | cw u16[Wc]
+__host__ __device__ inline uint32_t em2_lds_core_words(uint32_t L, uint32_t P, bool usa) { return 2 * L + (usa ? L : 0) + (L + P + 2); }
+__host__ __device__ inline uint32_t em2_lds_all_words(uint32_t L, uint32_t P, uint32_t K, uint32_t Wc, bool usa) {
+    return em2_lds_core_words(L, P, usa) + (K + 2) / 2 + (Wc + 1) / 2 + 2;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kSetupNT) void k_em2_setup(const CellMeta* __restrict__ meta, const uint32_t* __restrict__ nnz_unique,
+                                                        const uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
+                                                        const uint32_t* __restrict__ lab, const uint32_t* __restrict__ lab_cnt,
+                                                        const uint64_t* __restrict__ em_off, uint32_t* __restrict__ scratch,
+                                                        uint32_t* __restrict__ out_nnz, const uint32_t* __restrict__ em_order,
+                                                        uint32_t* __restrict__ tiers /* [8] counters, then 5 lists of n_cells */, uint32_t n_cells,
+                                                        Em2Cfg cfg) {
+    extern __shared__ uint32_t s_bm[];   // bits[nwb], rank[nwb]
+    __shared__ uint32_t s_ws[kSetupNT / 64];
+    __shared__ uint32_t s_P;
+    constexpr int NT = kSetupNT;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t cell = em_order[blockIdx.x];
+    const CellMeta m = meta[cell];
+    const uint32_t nU = nnz_unique[cell];
+    const uint2* U = reinterpret_cast<const uint2*>(((m.lg_nb || mode_is_pug(m.mode)) ? keys1 : keys0) + m.key_off);
+    const uint32_t W = lab_cnt[2 * cell], M = lab_cnt[2 * cell + 1];
+    const uint32_t* lw = lab + 2 * m.key_off;
+    const uint32_t* ld = lw + m.n_ref + 1;
+    const bool usa = cfg.usa != 0;
+    const Em2Scratch sc = em2_carve(scratch, em_off[cell], nU, W, M, usa);
+    if (M == 0) {
+        for (uint32_t i = tid; i < nU; i += NT) sc.out[i] = make_uint2(U[i].x, __float_as_uint((float)U[i].y));
+        if (tid == 0) { out_nnz[cell] = nU; sc.hdr[H_TIER] = kTierNone; }
+        return;
+    }
+    uint32_t* bits = s_bm;
+    uint32_t* rank = s_bm + cfg.nwb;
+    for (uint32_t i = tid; i < cfg.nwb; i += NT) bits[i] = 0;
+    if (tid == 0) s_P = 0;
+    // 1. EM label of every ambiguous molecule (extract_usa_eqmap, utils.rs:865-925: S alone -> g>>1, U alone -> uo + (g>>1),
+    //    an adjacent S,U pair -> ao + (g>>1)); offsets by a scan of the lengths
+    auto em_label = [&](uint32_t mol, uint32_t* dst) -> uint32_t {   // returns the length; writes (and marks the live bitmap) when dst != null
+        const uint32_t o = ld[2 * mol], n = ld[2 * mol + 1];
+        uint32_t w = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t gn = lw[o + i];
+            uint32_t idx = gn;
+            if (usa) {
+                idx = gn >> 1;
+                if (is_spliced(gn)) {
+                    if (i + 1 < n && same_gene(gn, lw[o + i + 1])) { idx += cfg.ao; ++i; }
+                } else idx += cfg.uo;
+            }
+            if (dst) { dst[w] = idx; atomicOr(&bits[idx >> 5], 1u << (idx & 31)); }
+            ++w;
+        }
+        return w;
+    };
+    uint32_t Wc = 0;
+    for (uint32_t base = 0; base < M; base += NT) {
+        const uint32_t i = base + tid;
+        const uint32_t len = i < M ? (usa ? em_label(i, nullptr) : ld[2 * i + 1]) : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<NT>(len, s_ws, tot);   // (its barriers also order the bitmap clear before the marks below)
+        if (i < M) { sc.coff[i] = Wc + ex; em_label(i, sc.cw + Wc + ex); }
+        Wc += tot;
+    }
+    if (tid == 0) sc.coff[M] = Wc;
+    __syncthreads();
+    // 2. live entries = distinct label slots: prefix popcount over the bitmap (ids ascend with the column)
+    uint32_t L = 0;
+    constexpr uint32_t kSc = 8;
+    for (uint32_t base = 0; base < cfg.nwb; base += kSc * NT) {
+        const uint32_t w0 = base + kSc * tid;
+        uint32_t v[kSc], sum = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kSc; ++j) { v[j] = w0 + j < cfg.nwb ? (uint32_t)__popc(bits[w0 + j]) : 0u; }
+#pragma unroll
+        for (uint32_t j = 0; j < kSc; ++j) { const uint32_t t = v[j]; v[j] = sum; sum += t; }
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<NT>(sum, s_ws, tot);
+#pragma unroll
+        for (uint32_t j = 0; j < kSc; ++j) if (w0 + j < cfg.nwb) rank[w0 + j] = L + ex + v[j];
+        L += tot;
+    }
+    __syncthreads();
+    auto is_live = [&](uint32_t x) -> bool { return (bits[x >> 5] >> (x & 31)) & 1u; };
+    auto rank_of = [&](uint32_t x) -> uint32_t { return rank[x >> 5] + (uint32_t)__popc(bits[x >> 5] & ((1u << (x & 31)) - 1u)); };
+    // 3. per live entry: column, sibling statuses (get_abundance_for, em.rs:167-187: S and U lean on the gene's A; A on U and S)
+    for (uint32_t w = tid; w < cfg.nwb; w += NT) {
+        uint32_t b = bits[w], e = rank[w];
+        for (; b; b &= b - 1, ++e) {
+            const uint32_t x = (w << 5) + (uint32_t)__builtin_ctz(b);
+            sc.ent_col[e] = x; sc.ent_ucnt[e] = 0; sc.ent_ub[e] = 0;
+            if (usa) {
+                uint32_t c1, c2 = kSibNone;
+                if (x >= cfg.ao) { c1 = x - cfg.uo; c2 = x - cfg.ao; }
+                else if (x >= cfg.uo) c1 = x + cfg.uo;
+                else c1 = x + cfg.ao;
+                sc.ent_s1[e] = is_live(c1) ? rank_of(c1) : kSibZero;
+                sc.ent_s2[e] = c2 == kSibNone ? kSibNone : (is_live(c2) ? rank_of(c2) : kSibZero);
+            }
+        }
+    }
+    __syncthreads();
+    // 4. the single-label counts: of a live entry -> its count; otherwise the column goes straight to the output row (and, USA,
+    //    becomes a passive sibling of the live entries that read it)
+    uint32_t nPU = 0;
+    for (uint32_t base = 0; base < nU; base += NT) {
+        const uint32_t i = base + tid;
+        uint32_t col = 0, cnt = 0, flag = 0;
+        if (i < nU) {
+            const uint2 u = U[i];
+            col = u.x; cnt = u.y;
+            if (is_live(col)) sc.ent_ucnt[rank_of(col)] = cnt;
+            else {
+                flag = 1;
+                if (usa) {
+                    uint32_t n1 = kSibNone, n2 = kSibNone;   // columns whose abundance reads this one, and through which link
+                    bool second = false;
+                    if (col >= cfg.ao) { n1 = col - cfg.ao; n2 = col - cfg.uo; }          // A: read by the gene's S and U (their first link)
+                    else if (col >= cfg.uo) n1 = col + cfg.uo;                           // U: read by A (first link)
+                    else { n1 = col + cfg.ao; second = true; }                           // S: read by A (second link)
+                    const bool l1 = is_live(n1), l2 = n2 != kSibNone && is_live(n2);
+                    if (l1 || l2) {
+                        const uint32_t pid = atomicAdd(&s_P, 1u);
+                        sc.pas_val[pid] = cnt;
+                        if (l1) (second ? sc.ent_s2 : sc.ent_s1)[rank_of(n1)] = kSibPassive | pid;
+                        if (l2) sc.ent_s1[rank_of(n2)] = kSibPassive | pid;
+                    }
+                }
+            }
+        }
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<NT>(flag, s_ws, tot);
+        if (flag) { const uint32_t j = nPU + ex; sc.pu_col[j] = col; sc.pu_cnt[j] = cnt; sc.pu_lb[j] = rank_of(col); }
+        nPU += tot;
+    }
+    __syncthreads();
+    // 4b. where a live entry lands in the row: behind ent_ub[e] pass-through columns (a step function of e, written by the steps)
+    for (uint32_t j = tid; j < nPU; j += NT) {
+        const uint32_t lo = sc.pu_lb[j], hi = j + 1 < nPU ? sc.pu_lb[j + 1] : L;
+        for (uint32_t e = lo; e < hi; ++e) sc.ent_ub[e] = j + 1;
+    }
+    // 5. label words as live ids
+    for (uint32_t w = tid; w < Wc; w += NT) sc.cw[w] = rank_of(sc.cw[w]);
+    // 6. header, tier
+    if (tid == 0) {
+        const uint32_t P = s_P, K = M;
+        sc.hdr[H_L] = L; sc.hdr[H_P] = P; sc.hdr[H_K] = K; sc.hdr[H_WC] = Wc; sc.hdr[H_NPU] = nPU; sc.hdr[H_FBITS] = em2_fbits(m.nrec);
+        const bool ids16 = L + P + 2 <= 65536u && K < 65535u && Wc <= 65535u;
+        const uint32_t all = em2_lds_all_words(L, P, K, Wc, usa), core = em2_lds_core_words(L, P, usa);
+        uint32_t tier;
+        if (ids16 && all <= kT0Words && L <= 256u * 8u) tier = 0;
+        else if (ids16 && all <= kT1Words && L <= 512u * 8u) tier = 1;
+        else if (ids16 && all <= kT2Words && L <= 1024u * 16u) tier = 2;
+        else if (core <= kT2Words) tier = 3;
+        else tier = 4;
+        if (tier < cfg.min_tier) tier = (cfg.min_tier == 3 && core > kT2Words) ? 4u : cfg.min_tier;   // (tests: every instance on every size)
+        sc.hdr[H_TIER] = tier;
+        const uint32_t at = atomicAdd(&tiers[tier], 1u);
+        tiers[8 + (size_t)tier * n_cells + at] = cell;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The rounds.  MODE 0: everything in LDS, per-entry constants in registers (EPT entries per thread); 1: accumulators,
+// abundances in LDS, class lists and entry constants streamed; 2: everything in global memory (workgroup-scope atomics in L2).
+template <typename T> struct IdLoad;
+template <> struct IdLoad<uint16_t> { static __device__ __forceinline__ uint32_t at(const uint16_t* p, uint32_t i) { return p[i]; } };
+template <> struct IdLoad<uint32_t> { static __device__ __forceinline__ uint32_t at(const uint32_t* p, uint32_t i) { return p[i]; } };
+
+__device__ __forceinline__ void em2_add(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// Barrier between phases.  MODE 2 hands data through global memory: a wave first waits for its own stores to be acknowledged
+// (stores count in vmcnt on gfx9), and a word the other waves change with atomics (L2) is read back with an atomic as well
+// (afq_pug2.hip has the measurements behind both rules).
+template <int MODE>
+__device__ __forceinline__ void em2_sync() {
+    if constexpr (MODE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+// one pass over the classes: D in label order, r = 1 / D, every label word's share into its entry's accumulator
+template <int NT, typename IdT>
+__device__ __forceinline__ void em2_class_pass(const IdT* __restrict__ coff, const IdT* __restrict__ cw, const float* ab,
+                                               unsigned long long* acc, uint32_t K, float scale) {
+    for (uint32_t c0 = threadIdx.x; c0 < K; c0 += 2 * NT) {
+        // two classes per thread and trip, each level of their gathers issued together
+        uint32_t o0[2], n[2], e[2][4];
+        float a[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t c = c0 + j * NT;
+            o0[j] = 0; n[j] = 0;
+            if (c < K) { o0[j] = IdLoad<IdT>::at(coff, c); n[j] = IdLoad<IdT>::at(coff, c + 1) - o0[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) e[j][k] = (uint32_t)k < n[j] ? IdLoad<IdT>::at(cw, o0[j] + k) : 0u;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[j][k] = (uint32_t)k < n[j] ? ab[e[j][k]] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (n[j] == 0) continue;
+            float d = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if ((uint32_t)k < n[j]) d += a[j][k];
+            for (uint32_t k = 4; k < n[j]; ++k) d += ab[IdLoad<IdT>::at(cw, o0[j] + k)];
+            if (!(d > 0.0f)) continue;
+            const float r = 1.0f / d;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((uint32_t)k < n[j]) em2_add(&acc[e[j][k]], (unsigned long long)((a[j][k] * r) * scale));
+            for (uint32_t k = 4; k < n[j]; ++k) {
+                const uint32_t ee = IdLoad<IdT>::at(cw, o0[j] + k);
+                em2_add(&acc[ee], (unsigned long long)((ab[ee] * r) * scale));
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t em2_map_sib(uint32_t s, uint32_t L, uint32_t P) {
+    if (s == kSibNone) return L + P + 1;
+    if (s == kSibZero) return L + P;
+    if (s & kSibPassive) return L + (s & 0x7FFFFFFFu);
+    return s;
+}
+
+template <int NT, int MODE, int EPT, uint32_t LDSW>
+__global__ __launch_bounds__(NT) void k_em2_rounds(const CellMeta* __restrict__ meta, const uint32_t* __restrict__ nnz_unique,
+                                                   const uint32_t* __restrict__ lab_cnt, const uint64_t* __restrict__ em_off,
+                                                   uint32_t* __restrict__ scratch, uint32_t* __restrict__ out_nnz,
+                                                   const uint32_t* __restrict__ tiers, uint32_t n_cells, uint32_t tier, Em2Cfg cfg) {
+    __shared__ uint32_t s_ws[NT / 64];
+    __shared__ uint32_t s_flag[2];
+    __shared__ __attribute__((aligned(16))) uint32_t s_mem[LDSW];
+    if (blockIdx.x >= tiers[tier]) return;
+    const uint32_t cell = tiers[8 + (size_t)tier * n_cells + blockIdx.x];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nU = nnz_unique[cell], W = lab_cnt[2 * cell], M = lab_cnt[2 * cell + 1];
+    const bool usa = cfg.usa != 0;
+    const Em2Scratch sc = em2_carve(scratch, em_off[cell], nU, W, M, usa);
+    const uint32_t L = sc.hdr[H_L], P = sc.hdr[H_P], K = sc.hdr[H_K], Wc = sc.hdr[H_WC], nPU = sc.hdr[H_NPU], F = sc.hdr[H_FBITS];
+    const float scale = __uint_as_float((127u + F) << 23), inv_scale = __uint_as_float((127u - F) << 23);
+    const uint32_t Z0 = L + P, Z1 = L + P + 1;
+    // placement
+    unsigned long long* acc;
+    float *ab, *v;
+    if constexpr (MODE == 2) { acc = sc.g_acc; v = sc.g_v; ab = usa ? sc.g_ab : sc.g_v; }
+    else {
+        acc = reinterpret_cast<unsigned long long*>(s_mem);
+        float* f = reinterpret_cast<float*>(s_mem + 2 * L);
+        ab = f; if (usa) f += L;
+        v = f;
+        if (!usa) ab = v;
+    }
+    const uint16_t* coff16 = nullptr; const uint16_t* cw16 = nullptr;
+    if constexpr (MODE == 0) {
+        uint16_t* c16 = reinterpret_cast<uint16_t*>(s_mem + em2_lds_core_words(L, P, usa));
+        uint16_t* w16 = c16 + ((K + 2) & ~1u);
+        for (uint32_t c = tid; c <= K; c += NT) c16[c] = (uint16_t)sc.coff[c];
+        for (uint32_t w = tid; w < Wc; w += NT) w16[w] = (uint16_t)sc.cw[w];
+        coff16 = c16; cw16 = w16;
+    }
+    const float uni = 1.0f / (float)cfg.num_alphas;
+    auto init_of = [&](uint32_t cnt) -> float { return cfg.init_uniform ? uni : ((float)cnt + 0.5f) * 1e-3f; };
+    // per-entry constants: registers (MODE 0) or streamed
+    [[maybe_unused]] uint32_t r_cnt[EPT], r_sib[EPT];
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const uint32_t e = tid + j * NT;
+            r_cnt[j] = 0; r_sib[j] = 0;
+            if (e < L) {
+                r_cnt[j] = sc.ent_ucnt[e];
+                if (usa) r_sib[j] = em2_map_sib(sc.ent_s1[e], L, P) | (em2_map_sib(sc.ent_s2[e], L, P) << 16);
+                v[e] = init_of(r_cnt[j]);
+                acc[e] = (unsigned long long)r_cnt[j] << F;
+            }
+        }
+    } else {
+        for (uint32_t e = tid; e < L; e += NT) { const uint32_t c = sc.ent_ucnt[e]; v[e] = init_of(c); acc[e] = (unsigned long long)c << F; }
+    }
+    for (uint32_t p = tid; p < P; p += NT) v[L + p] = init_of(sc.pas_val[p]);
+    if (tid == 0) { v[Z0] = init_of(0u); v[Z1] = 0.0f; s_flag[0] = 0; s_flag[1] = 0; }
+    em2_sync<MODE>();
+    uint32_t it = 0;
+    bool conv = true, last_round = false;
+    while (it < kMinIter2 || (it < kMaxIter2 && !conv) || last_round) {
+        if (usa) {   // (C) what a label word contributes with: own + sibling statuses
+            if constexpr (MODE == 0) {
+#pragma unroll
+                for (int j = 0; j < EPT; ++j) {
+                    const uint32_t e = tid + j * NT;
+                    if (e < L) ab[e] = (v[r_sib[j] & 0xFFFFu] + v[r_sib[j] >> 16]) + v[e];
+                }
+            } else {
+                for (uint32_t e = tid; e < L; e += NT)
+                    ab[e] = (v[em2_map_sib(sc.ent_s1[e], L, P)] + v[em2_map_sib(sc.ent_s2[e], L, P)]) + v[e];
+            }
+            em2_sync<MODE>();
+        }
+        // (A+B) classes
+        if constexpr (MODE == 0) em2_class_pass<NT, uint16_t>(coff16, cw16, ab, acc, K, scale);
+        else em2_class_pass<NT, uint32_t>(sc.coff, sc.cw, ab, acc, K, scale);
+        em2_sync<MODE>();
+        // (E) entries: new abundance, convergence vote, accumulator back to the single-label count
+        bool bad = false;
+        if (tid == 0) s_flag[(it + 1) & 1u] = 0;   // the other round's flag: everyone read it before the barrier above
+        auto entry = [&](uint32_t e, uint32_t cnt) {
+            unsigned long long a;
+            if constexpr (MODE == 2) a = __hip_atomic_exchange(&acc[e], (unsigned long long)cnt << F, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else { a = acc[e]; acc[e] = (unsigned long long)cnt << F; }
+            const float x = (float)a * inv_scale;
+            const float old = v[e];
+            if (x > kAlphaCheckCutoff2 && fabsf(old - x) > kRelDiffTol2) bad = true;
+            v[e] = x;
+        };
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) { const uint32_t e = tid + j * NT; if (e < L) entry(e, r_cnt[j]); }
+        } else {
+            for (uint32_t e = tid; e < L; e += NT) entry(e, sc.ent_ucnt[e]);
+        }
+        if (it == 0) {   // an entry outside every label holds its single-label count from the first round on; a status nothing maps to, 0
+            for (uint32_t p = tid; p < P; p += NT) v[L + p] = (float)sc.pas_val[p];
+            if (tid == 0) v[Z0] = 0.0f;
+        }
+        if (bad) s_flag[it & 1u] = 1;
+        em2_sync<MODE>();
+        conv = s_flag[it & 1u] == 0;
+        ++it;
+        if (usa) {   // em_optimize_subset_impl: after the first converged round zero what is below the output floor, one more round (em.rs:391-451)
+            if (last_round) break;
+            if (it >= kMinIter2 && conv) {
+                for (uint32_t e = tid; e < L; e += NT) if (v[e] < kMinOutputAlpha2) v[e] = 0.0f;
+                last_round = true;
+                em2_sync<MODE>();
+            }
+        }
+    }
+    // output row: pass-through columns and the live entries at or above the floor, merged by column
+    uint32_t* pre = MODE == 2 ? sc.g_pre : s_mem;   // (the accumulators are dead)
+    em2_sync<MODE>();
+    uint32_t nout = 0;
+    for (uint32_t base = 0; base < L; base += NT) {
+        const uint32_t e = base + tid;
+        const float x = e < L ? v[e] : 0.0f;
+        const uint32_t h = x >= kMinOutputAlpha2;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<NT>(h, s_ws, tot);
+        if (e < L) {
+            pre[e] = nout + ex;   // (LDS instances: over the dead accumulators - the abundances read above sit behind them)
+            if (h) sc.out[sc.ent_ub[e] + nout + ex] = make_uint2(sc.ent_col[e], __float_as_uint(x));
+        }
+        nout += tot;
+    }
+    if (tid == 0) pre[L] = nout;
+    em2_sync<MODE>();
+    for (uint32_t j = tid; j < nPU; j += NT) sc.out[j + pre[sc.pu_lb[j]]] = make_uint2(sc.pu_col[j], __float_as_uint((float)sc.pu_cnt[j]));
+    if (tid == 0) out_nnz[cell] = nPU + nout;
+}
+
+void launch_em2(hipStream_t s, const ResolveArgs& a, uint32_t n_cells, const uint64_t* em_off, uint32_t* scratch, uint32_t* out_nnz,
+                const uint32_t* em_order, uint32_t* tiers, uint32_t num_alphas, uint32_t init_uniform) {
+    if (!n_cells) return;
+    uint32_t min_tier = 0;
+    if (const char* e = std::getenv("AFQ_EM2_MIN_TIER")) min_tier = (uint32_t)std::min(4, std::max(0, std::atoi(e)));   // (tests; read per range)
+    Em2Cfg cfg{a.usa, num_alphas, a.num_rows / 3, 2 * (a.num_rows / 3), init_uniform, (num_alphas + 31) / 32, min_tier};
+    (void)hipMemsetAsync(tiers, 0, 32, s);
+    hipLaunchKernelGGL(k_em2_setup, dim3(n_cells), dim3(kSetupNT), 8 * cfg.nwb, s, a.meta, a.nnz, a.keys0, a.keys1, a.lab, a.lab_cnt, em_off,
+                       scratch, out_nnz, em_order, tiers, n_cells, cfg);
+#define EM2_ROUNDS(NT, MODE, EPT, LDSW, TIER) \
+    hipLaunchKernelGGL((k_em2_rounds<NT, MODE, EPT, LDSW>), dim3(n_cells), dim3(NT), 0, s, a.meta, a.nnz, a.lab_cnt, em_off, scratch, out_nnz, tiers, n_cells, TIER, cfg)
+    EM2_ROUNDS(1024, 2, 1, 4, 4u);          // largest first: the few cells that run out of global memory are the long ones
+    EM2_ROUNDS(1024, 1, 1, kT2Words, 3u);
+    EM2_ROUNDS(1024, 0, 16, kT2Words, 2u);
+    EM2_ROUNDS(512, 0, 8, kT1Words, 1u);
+    EM2_ROUNDS(256, 0, 8, kT0Words, 0u);
+#undef EM2_ROUNDS
+}
+
+// columns the setup kernel's bitmap + rank table can hold in 64 KiB of LDS; beyond that the EM takes the canonical kernels
+bool em2_supported(uint32_t num_alphas) { return (num_alphas + 31) / 32 <= 8192; }
+
+}  // namespace afq

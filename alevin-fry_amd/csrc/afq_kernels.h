@@ -82,7 +82,13 @@ size_t bucket_desc_bytes();
 uint64_t em_scratch_words(uint32_t nU, uint32_t W, uint32_t M, bool usa);
 void launch_em(hipStream_t s, const ResolveArgs& a, uint32_t n_cells, const uint64_t* em_off, uint32_t* scratch,
                uint32_t* out_nnz, void* em_hdr /* 16 B per cell */, const uint32_t* em_order /* cells, largest first */,
-               uint32_t num_alphas, uint32_t init_uniform);
+               uint32_t num_alphas, uint32_t init_uniform, bool rounds = true /* false: the set-up only (the classes, for -d / -b) */);
+// the EM in order-free fixed-point arithmetic (afq_em2.hip; the default): per-cell scratch words, launcher, and whether the
+// output space fits the set-up kernel's bitmap (otherwise the canonical kernels above run)
+uint64_t em2_scratch_words(uint32_t nU, uint32_t W, uint32_t M, bool usa);
+bool em2_supported(uint32_t num_alphas);
+void launch_em2(hipStream_t s, const ResolveArgs& a, uint32_t n_cells, const uint64_t* em_off, uint32_t* scratch, uint32_t* out_nnz,
+                const uint32_t* em_order, uint32_t* tiers /* 8 + 5 * n_cells words */, uint32_t num_alphas, uint32_t init_uniform);
 // -d: sizes (cls_ptr == null) or fills the per-cell gene-level classes; see k_eqc_dump
 void launch_eqc_dump(hipStream_t s, const ResolveArgs& a, uint32_t n_cells, const uint64_t* em_off, const uint32_t* scratch,
                      const void* em_hdr, uint32_t num_alphas, uint32_t* n_cls, uint32_t* n_words, const uint64_t* cls_ptr,

@@ -617,6 +617,40 @@ static inline float abundance_for(u32 idx, const float* a, u32 uo, u32 ao) {  //
     return a[idx + ao] + a[idx];
 }
 
+// g_em_arith (ora_set_em_arith).  0: the reference's arithmetic - f32 additions into alphas_out, in this oracle's canonical
+// class order (the reference's own order is a HashMap walk, em.rs:464: unpinnable).  1: ORDER-FREE arithmetic, what the
+// device EM computes by default (alevin-fry_amd/csrc/afq_em2.hip): a class's share to an entry is taken as
+//     q = (u64)((abundance * (1.0f / denom)) * 2^F)   truncated fixed point, F = min(40, 62 - bitlen(nrec))
+// and count * q is added to the entry's 64-bit accumulator, which starts at (sum of its single-label counts) << F; the new
+// abundance is (float)acc * 2^-F.  Integer sums do not depend on the order of the classes (so the HashMap question does
+// not arise), nor on whether equal labels were merged (count * q is linear in count).  It is NOT the reference's f32
+// sequence: tests require it within north_star's 1e-4 of mode 0, and the device bit-identical to it.
+static int g_em_arith = 0;
+static inline u32 em_fbits(u32 nrec) {
+    u32 bl = 0; for (u32 x = nrec | 1u; x; x >>= 1) ++bl;
+    const u32 f = 62u - bl;
+    return f < 40u ? f : 40u;
+}
+static void em_update_fixed(const IdxEq& q, const float* ain, u64* acc, bool usa, u32 uo, u32 ao, u32 F) {
+    const float scale = std::ldexp(1.0f, (int)F);
+    for (size_t c = 0; c + 1 < q.start.size(); ++c) {
+        const u32* lab = q.labels.data() + q.start[c];
+        const u32 n = q.start[c + 1] - q.start[c];
+        if (n > 1) {
+            float denom = 0.0f;
+            for (u32 j = 0; j < n; ++j) denom += usa ? abundance_for(lab[j], ain, uo, ao) : ain[lab[j]];
+            if (denom > 0.0f) {
+                const float r = 1.0f / denom;
+                for (u32 j = 0; j < n; ++j) {
+                    const float ab = usa ? abundance_for(lab[j], ain, uo, ao) : ain[lab[j]];
+                    const float u = ab * r;
+                    acc[lab[j]] += (u64)q.count[c] * (u64)(u * scale);
+                }
+            }
+        } else acc[lab[0]] += (u64)q.count[c] << F;
+    }
+}
+
 // one EM round: em_update (em.rs:458-485), em_update_subset[_usa] (em.rs:189-248)
 static void em_update(const IdxEq& q, const float* ain, float* aout, bool usa, u32 uo, u32 ao) {
     for (size_t c = 0; c + 1 < q.start.size(); ++c) {
@@ -639,7 +673,7 @@ static void em_update(const IdxEq& q, const float* ain, float* aout, bool usa, u
 
 // em_optimize, src/em.rs:487-582 (dense over num_alphas)
 static void em_optimize_dense(const GeneEqc& eqc, u32 num_alphas, bool only_unique, bool init_uniform,
-                              std::vector<float>& alphas, u32* iters_out, bool canon = false) {
+                              std::vector<float>& alphas, u32* iters_out, bool canon = false, u32 fixed_bits = 0) {
     IdxEq q; eqc_to_idx(eqc, q);
     if (canon) canonical_em_order(q);
     std::vector<float> ain(num_alphas, 0.0f), aout(num_alphas, 0.0f);
@@ -650,8 +684,13 @@ static void em_optimize_dense(const GeneEqc& eqc, u32 num_alphas, bool only_uniq
     float uni = 1.0f / (float)num_alphas;
     for (u32 i = 0; i < num_alphas; ++i) ain[i] = init_uniform ? uni : (ain[i] + 0.5f) * 1e-3f;
     u32 it = 0; bool conv = true;
+    std::vector<u64> acc(fixed_bits ? num_alphas : 0, 0);
+    const float inv_scale = std::ldexp(1.0f, -(int)fixed_bits);
     while (it < MIN_ITER || (it < MAX_ITER && !conv)) {
-        em_update(q, ain.data(), aout.data(), false, 0, 0);
+        if (fixed_bits) {
+            em_update_fixed(q, ain.data(), acc.data(), false, 0, 0, fixed_bits);
+            for (u32 i = 0; i < num_alphas; ++i) { aout[i] = (float)acc[i] * inv_scale; acc[i] = 0; }
+        } else em_update(q, ain.data(), aout.data(), false, 0, 0);
         conv = true;
         for (u32 i = 0; i < num_alphas; ++i) {
             if (aout[i] > ALPHA_CHECK_CUTOFF) {
@@ -673,7 +712,7 @@ static void em_optimize_dense(const GeneEqc& eqc, u32 num_alphas, bool only_uniq
 // must agree bit for bit with the sparse-support variant.
 static void em_optimize_subset(const IdxEq& q, u32 num_alphas, bool only_unique, bool init_uniform,
                                bool usa, u32 uo, u32 ao, std::vector<float>& alphas, u32* iters_out,
-                               bool full_support = false) {
+                               bool full_support = false, u32 fixed_bits = 0) {
     std::vector<float> ain(num_alphas, 0.0f), aout(num_alphas, 0.0f);
     bool needs_em = false;
     for (size_t c = 0; c + 1 < q.start.size(); ++c) {
@@ -699,8 +738,13 @@ static void em_optimize_subset(const IdxEq& q, u32 num_alphas, bool only_unique,
     float uni = 1.0f / (float)num_alphas;
     for (u32 i : support) ain[i] = init_uniform ? uni : (ain[i] + 0.5f) * 1e-3f;
     u32 it = 0; bool conv = true, last_round = false;
+    std::vector<u64> acc(fixed_bits ? num_alphas : 0, 0);
+    const float inv_scale = std::ldexp(1.0f, -(int)fixed_bits);
     while (it < MIN_ITER || (it < MAX_ITER && !conv) || last_round) {
-        em_update(q, ain.data(), aout.data(), usa, uo, ao);
+        if (fixed_bits) {
+            em_update_fixed(q, ain.data(), acc.data(), usa, uo, ao, fixed_bits);
+            for (u32 i : support) { aout[i] = (float)acc[i] * inv_scale; acc[i] = 0; }
+        } else em_update(q, ain.data(), aout.data(), usa, uo, ao);
         conv = true;
         for (u32 i : support) {
             if (aout[i] > ALPHA_CHECK_CUTOFF) {
@@ -924,8 +968,8 @@ static int quant_cell(const afq_config& cfg, const u32* t2g, u32 ref_count, cons
         else if (usa) {
             IdxEq q; extract_usa_eqmap(eqc, cfg.num_rows, q);
             canonical_em_order(q);
-            em_optimize_subset(q, cfg.num_rows, false, init_uni, true, uo, ao, counts, &o.em_iters);
-        } else em_optimize_dense(eqc, cfg.num_genes, only_unique, init_uni, counts, &o.em_iters, true);
+            em_optimize_subset(q, cfg.num_rows, false, init_uni, true, uo, ao, counts, &o.em_iters, false, g_em_arith ? em_fbits(c.nrec) : 0u);
+        } else em_optimize_dense(eqc, cfg.num_genes, only_unique, init_uni, counts, &o.em_iters, true, g_em_arith ? em_fbits(c.nrec) : 0u);
     };
     u32 res = cfg.resolution;
     if (res == AFQ_RES_CR_LIKE || res == AFQ_RES_CR_LIKE_EM) {
@@ -1066,6 +1110,8 @@ const uint32_t* ora_result_pug_stats(const afq_result* r) { return r && r->opaqu
 void ora_set_tie_break(int mode) { g_tie_desc = mode == 1 || mode == 2 ? mode : 0; }
 // 0 = canonical class order of the EM's f32 sums; otherwise the seed of a shuffle of it (canonical_em_order)
 void ora_set_em_order(uint64_t seed) { g_em_perm = seed; }
+// 0 = the reference's f32 sums (canonical class order); 1 = the order-free fixed-point accumulation of the device EM (em_update_fixed)
+void ora_set_em_arith(int mode) { g_em_arith = mode == 1 ? 1 : 0; }
 const uint32_t* ora_result_em_iters(const afq_result* r) { return r && r->opaque ? ((Result*)r->opaque)->em_iters.data() : nullptr; }
 
 // cfg.dump_eq: per-cell gene-level classes (same container as afq_result_eqclasses of include/afquant.h)

@@ -47,6 +47,8 @@ def lib():
         L.ora_set_tie_break.restype = None
         L.ora_set_em_order.argtypes = [C.c_uint64]
         L.ora_set_em_order.restype = None
+        L.ora_set_em_arith.argtypes = [C.c_int]
+        L.ora_set_em_arith.restype = None
         L.ora_result_eqclasses.argtypes = [p(_abi.AfqResult), p(_abi.AfqEqclasses)]
         L.ora_result_eqclasses.restype = C.c_int
         L.ora_result_bootstraps.argtypes = [p(_abi.AfqResult), p(_abi.AfqBootstraps)]
@@ -76,16 +78,21 @@ class OracleError(RuntimeError):
 
 
 def quant(cfg, tid_to_gid, chunk_bytes, chunk_off, first_cell_index=0, force_route=0, want_iters=False, n_threads=1, want_pug_stats=False,
-          tie_break_descending=False, check_tie_free=False, em_order_seed=0):
+          tie_break_descending=False, check_tie_free=False, em_order_seed=0, em_arith="reference"):
     """cfg: WorkerConfig.  Returns QuantResult (same container as the product).
     n_threads > 1 spreads cells over worker threads (reference dispatch only).
     want_pug_stats: also return u32[n_cells, 5] = molecules, tie events, components with a tie, molecules of those components,
         tie-free components whose cover differs under the reversed scan (counted with check_tie_free only; must be 0).
     tie_break_descending: scan the parsimony cover's candidates in descending vertex id (measures what hangs on the tie-break).
-    em_order_seed: non-zero = the EM sums its classes in a shuffled order (what the reference's HashMap does, em.rs:464)."""
+    em_order_seed: non-zero = the EM sums its classes in a shuffled order (what the reference's HashMap does, em.rs:464).
+    em_arith: "reference" = the reference's f32 additions (canonical class order); "fixed" = the order-free fixed-point
+        accumulation the device EM computes by default (afq_oracle.cpp em_update_fixed) - the device must match it bit for bit,
+        and it must stay within north_star's 1e-4 of "reference"."""
     L = lib()
     L.ora_set_tie_break(1 if tie_break_descending else (2 if check_tie_free else 0))
     L.ora_set_em_order(int(em_order_seed))
+    assert em_arith in ("reference", "fixed")
+    L.ora_set_em_arith(1 if em_arith == "fixed" else 0)
     ccfg = cfg.to_c()
     t2g = np.ascontiguousarray(tid_to_gid, dtype=np.uint32)
     b = np.ascontiguousarray(np.frombuffer(chunk_bytes, dtype=np.uint8) if not isinstance(chunk_bytes, np.ndarray) else chunk_bytes)
@@ -124,6 +131,7 @@ def quant(cfg, tid_to_gid, chunk_bytes, chunk_off, first_cell_index=0, force_rou
     finally:
         L.ora_set_tie_break(0)
         L.ora_set_em_order(0)
+        L.ora_set_em_arith(0)
         L.ora_result_release(C.byref(res))
 
 

@@ -1,0 +1,99 @@
+"""The device EM (csrc/afq_em2.hip: order-free fixed-point sums) against the oracle in BOTH arithmetics.
+
+north_star: EM resolutions "within 1e-4 relative".  The device does not replay the reference's f32 additions (their order is
+a HashMap walk, em.rs:464 - the reference itself does not repeat it run to run); it accumulates each round's shares as
+integers.  What is required of it:
+  * against the oracle's restatement of the reference's arithmetic (canonical class order): the same non-zero entries
+    (the 0.01 output floor, em.rs:568-572, cuts the same ones) and every value within 1e-4 relative;
+  * against the oracle's restatement of the fixed-point arithmetic (em_update_fixed): bit-identical;
+  * AFQ_EM_ORDER=canonical: the sequential f32 kernels of rounds 1-3, bit-identical to the reference arithmetic."""
+import numpy as np
+import pytest
+
+from util import assert_same_result, cfg_for, pkg
+
+pytestmark = pytest.mark.gpu
+synth = pkg.synth
+
+EM_RES = ["cr-like-em", "parsimony-em", "parsimony-gene-em"]
+
+
+def _device(cfg, s, b, off):
+    q = pkg.Quantifier(cfg, s.tid_to_gid)
+    try:
+        return q.quant_chunks(b, off)
+    finally:
+        q.close()
+
+
+def _workload(usa, seed=5, sizes=None, **kw):
+    sizes = sizes or [30000, 9000, 4000, 1500, 700, 260, 250, 120, 99, 40, 3]
+    args = dict(num_genes=400, txp_per_gene=3, usa=usa, dup=0.5, zipf=0.6, cross=0.4, umi_err=0.02, max_extra_na=5)
+    args.update(kw)
+    s = synth.synth(seed, sizes, **args)
+    return s, *s.encode()
+
+
+def assert_within_tolerance(got, want, what=""):
+    """Same rows (= the same entries survive the output floor), values within north_star's 1e-4."""
+    assert np.array_equal(got.cell_ptr, want.cell_ptr), what + " rows differ in length"
+    assert np.array_equal(got.gene, want.gene), what + " different entries are non-zero"
+    np.testing.assert_allclose(got.val, want.val, rtol=1e-4, atol=0, err_msg=what)
+
+
+@pytest.mark.parametrize("usa", [False, True])
+@pytest.mark.parametrize("res", EM_RES)
+def test_em_default_within_1e4_of_the_reference_arithmetic(oracle_module, res, usa):
+    s, b, off = _workload(usa)
+    cfg = cfg_for(s, res)
+    got = _device(cfg, s, b, off)
+    want = oracle_module.quant(cfg, s.tid_to_gid, b, off, em_arith="reference")
+    assert_within_tolerance(got, want, f"{res} usa={usa}")
+    assert np.array_equal(got.flags, want.flags) and np.array_equal(got.bc, want.bc)
+    assert not np.array_equal(got.val.view(np.uint32), want.val.view(np.uint32))   # (it IS another arithmetic: some low bits differ)
+
+
+@pytest.mark.parametrize("usa", [False, True])
+@pytest.mark.parametrize("res", EM_RES)
+def test_em_default_is_bit_identical_to_the_fixed_point_oracle(oracle_module, res, usa):
+    s, b, off = _workload(usa, seed=6)
+    cfg = cfg_for(s, res)
+    assert_same_result(_device(cfg, s, b, off), oracle_module.quant(cfg, s.tid_to_gid, b, off, em_arith="fixed"), what=f"{res} usa={usa}")
+
+
+@pytest.mark.parametrize("usa", [False, True])
+@pytest.mark.parametrize("res", EM_RES)
+def test_em_canonical_order_is_bit_identical_to_the_reference_arithmetic(oracle_module, monkeypatch, res, usa):
+    monkeypatch.setenv("AFQ_EM_ORDER", "canonical")
+    s, b, off = _workload(usa, seed=7)
+    cfg = cfg_for(s, res)
+    assert_same_result(_device(cfg, s, b, off), oracle_module.quant(cfg, s.tid_to_gid, b, off, em_arith="reference"), what=f"{res} usa={usa}")
+
+
+@pytest.mark.parametrize("init_uniform", [False, True])
+def test_em_init_uniform(oracle_module, init_uniform):
+    s, b, off = _workload(True, seed=8)
+    cfg = cfg_for(s, "cr-like-em", em_init_uniform=init_uniform)
+    assert_same_result(_device(cfg, s, b, off), oracle_module.quant(cfg, s.tid_to_gid, b, off, em_arith="fixed"))
+
+
+@pytest.mark.parametrize("tier", [1, 2, 3, 4])
+@pytest.mark.parametrize("usa", [False, True])
+def test_every_instance_of_the_rounds_kernel_agrees(oracle_module, monkeypatch, tier, usa):
+    """The rounds kernel has five instances by cell size (all in LDS at 256 / 512 / 1024 threads, lists streamed, everything in
+    global memory); AFQ_EM2_MIN_TIER sends every cell to the given one or a larger one: the sums are integers, the rows
+    must not move by a bit."""
+    monkeypatch.setenv("AFQ_EM2_MIN_TIER", str(tier))
+    s, b, off = _workload(usa, seed=9)
+    cfg = cfg_for(s, "parsimony-em")
+    assert_same_result(_device(cfg, s, b, off), oracle_module.quant(cfg, s.tid_to_gid, b, off, em_arith="fixed"), what=f"tier {tier}")
+
+
+def test_em_long_labels_and_many_classes(oracle_module):
+    """Labels of up to a dozen genes (the class pass keeps four label words in registers and walks the rest), a cell big
+    enough for the 1024-thread instance, duplicated classes (the device does not merge equal labels: count * q is linear)."""
+    s, b, off = _workload(True, seed=10, sizes=[120000, 50000, 800], num_genes=3000, cross=0.7, max_extra_na=12, dup=0.3)
+    cfg = cfg_for(s, "cr-like-em")
+    got = _device(cfg, s, b, off)
+    assert_same_result(got, oracle_module.quant(cfg, s.tid_to_gid, b, off, em_arith="fixed", n_threads=4))
+    assert_within_tolerance(got, oracle_module.quant(cfg, s.tid_to_gid, b, off, em_arith="reference", n_threads=4))
