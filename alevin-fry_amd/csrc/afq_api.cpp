@@ -153,6 +153,7 @@ struct RangeState {
     Range cur{};
     uint32_t hash_try = 0;   // which salt the range's label hashes were made with (a collision re-runs the range under the next)
     uint32_t pool_try = 0;   // how often the range was run again with four times the parsimony pool (a cell's graph outgrew it)
+    bool em_inline = false;  // the EM was enqueued behind the range's kernels (offsets made on the device); finish_range only checks that its scratch sufficed
     bool in_flight = false;
     hipEvent_t kernels_done = nullptr;
     std::vector<TimedLaunch> launches;  // HIP-event brackets of this range's kernels (cfg.profile)
@@ -217,6 +218,7 @@ struct afq_ctx {
     afq_batch_stats stats{};
     uint64_t n_label_rehash = 0;   // ranges decoded again under another label-hash salt (life of the context)
     uint64_t n_pool_regrow = 0;    // ranges run again with a larger parsimony pool
+    uint64_t n_em_resized = 0;     // ranges whose EM scratch was sized on the host after the device-side plan did not fit
     std::vector<TimedLaunch> launches;
     std::vector<hipEvent_t> event_pool;
     double k_ms[K_COUNT] = {0};
@@ -651,6 +653,34 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     }
     HIP_TRY(c, hipMemsetAsync(B.d_status.p, 0, sizeof(DevStatus), s));
     HIP_TRY(c, hipMemsetAsync(B.d_bc.p, 0, 8ull * n, s));
+    // EM resolutions: the EM follows the range's kernels on the device (afq_em2.hip; k_em2_plan packs the cells' scratch slices from
+    // the counts the kernels leave) - no trip to the host between resolution and EM.  Its scratch is set aside from an upper
+    // bound of the cells' label areas (a fraction of it: real cells use a tenth); if that ever falls short the kernels return at
+    // once and finish_range sizes the EM itself.  -d / -b read the classes off the canonical set-up and take that route too.
+    uint64_t em2_cap = 0;
+    const uint32_t na_em = g.usa_mode ? g.num_rows : g.num_genes;
+    {
+        const char* em_env = std::getenv("AFQ_EM_ORDER");
+        B.em_inline = em && !(em_env && !std::strcmp(em_env, "canonical")) && em2_supported(na_em) && !(g.dump_eq || g.num_bootstraps);
+    }
+    if (B.em_inline) {
+        double worst = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t cap1 = B.meta[i].n_ref + 1;
+            worst += (double)em2_scratch_words(std::min(cap1, na_em), cap1, cap1 / 2, g.usa_mode != 0);
+        }
+        static const double frac = [] { const char* e = std::getenv("AFQ_EM2_SCRATCH_FRAC"); const double v = e ? std::atof(e) : 0.0; return v > 0 && v <= 1 ? v : 0.35; }();   // (tests: a sliver, so that the fallback runs)
+        em2_cap = (uint64_t)std::max(worst * frac, 4096.0);
+        std::vector<uint32_t> em_order(n);
+        for (uint32_t i = 0; i < n; ++i) em_order[i] = i;
+        std::stable_sort(em_order.begin(), em_order.end(), [&](uint32_t a, uint32_t b) { return B.meta[a].nrec > B.meta[b].nrec; });
+        HIP_TRY(c, B.d_em_order.ensure(4ull * n));
+        HIP_TRY(c, hipMemcpyAsync(B.d_em_order.p, em_order.data(), 4ull * n, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, B.d_em_nnz.ensure(4ull * n));
+        HIP_TRY(c, B.d_em2_off.ensure(8ull * (n + 1)));
+        HIP_TRY(c, B.d_em2_scratch.ensure(4 * em2_cap + 16));
+        HIP_TRY(c, B.d_em2_tiers.ensure(4ull * (8 + 5ull * n)));
+    }
     // the host copies above are sourced from stack/vector memory: make sure they are consumed.  They only touch
     // this slot's buffers (idle since the range before last was finished), so they - and this wait - do not
     // depend on the range still executing in the other slot; the kernels below do:
@@ -767,6 +797,11 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
         launch_pug(s, pa, n_pug_blocks);
     }
     if (!hist_cells.empty()) { ScopedTimer t(c, K_CELL_HIST, s, &B.launches); launch_cell_hist(s, ra); }
+    if (B.em_inline) {
+        ScopedTimer t(c, K_EM, s, &B.launches);
+        launch_em2(s, ra, n, B.d_em2_off.as<uint64_t>(), B.d_em2_scratch.as<uint32_t>(), B.d_em_nnz.as<uint32_t>(), B.d_em_order.as<uint32_t>(),
+                   B.d_em2_tiers.as<uint32_t>(), na_em, g.em_init_uniform, em2_cap);
+    }
     HIP_TRY(c, hipGetLastError());
     if (!B.kernels_done) HIP_TRY(c, hipEventCreateWithFlags(&B.kernels_done, hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(B.kernels_done, s));
@@ -828,8 +863,16 @@ int finish_range(afq_ctx* c, int slot) {
     bool em2 = false;   // the EM ran in afq_em2.hip: the rows sit in its scratch
     HIP_TRY(c, hipMemcpy(alt.data(), B.d_alt.p, 4ull * n, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(nnz.data(), B.d_nnz.p, 4ull * n, hipMemcpyDeviceToHost));
-    if (em) {
-        // per-cell EM (src/em.rs) over the single-label counts + the ambiguous molecules' labels
+    if (em && B.em_inline) {   // the EM ran behind the range's kernels: did its scratch suffice?
+        uint32_t short_of_scratch = 0;
+        HIP_TRY(c, hipMemcpy(&short_of_scratch, B.d_em2_tiers.as<uint32_t>() + 7, 4, hipMemcpyDeviceToHost));
+        if (!short_of_scratch) {
+            em2 = true;
+            HIP_TRY(c, hipMemcpy(nnz.data(), B.d_em_nnz.p, 4ull * n, hipMemcpyDeviceToHost));
+        } else c->n_em_resized += 1;
+    }
+    if (em && !em2) {
+        // per-cell EM (src/em.rs) over the single-label counts + the ambiguous molecules' labels, sized on the host
         std::vector<uint32_t> lc(2ull * n);
         std::vector<uint64_t> eoff(n + 1);
         HIP_TRY(c, hipMemcpy(lc.data(), B.d_lab_cnt.p, 8ull * n, hipMemcpyDeviceToHost));
@@ -1123,6 +1166,7 @@ int afq_device_warmup(int device) {
 
 uint64_t afq_label_rehash_count(const afq_ctx* ctx) { return ctx ? ctx->n_label_rehash : 0; }
 uint64_t afq_pool_regrow_count(const afq_ctx* ctx) { return ctx ? ctx->n_pool_regrow : 0; }
+uint64_t afq_em_resize_count(const afq_ctx* ctx) { return ctx ? ctx->n_em_resized : 0; }
 
 int afq_device_pci_bus_id(int device, char* out, size_t out_len) {
     if (!out || out_len < 13) return AFQ_ERR_INVALID_ARG;

@@ -54,7 +54,7 @@ struct Em2Cfg { uint32_t usa, num_alphas, uo, ao, init_uniform, nwb, min_tier; }
 // per-cell scratch (u32 words); mirrored by em2_scratch_words
 struct Em2Scratch {
     uint2* out; uint32_t* hdr; uint32_t *ent_col, *ent_ucnt, *ent_s1, *ent_s2, *ent_ub, *pas_val, *coff, *cw, *pu_col, *pu_cnt, *pu_lb;
-    unsigned long long* g_acc; float *g_ab, *g_v; uint32_t* g_pre;
+    unsigned long long* g_acc; float *g_ab, *g_v; uint32_t *g_pre, *nid;
 };
 __host__ __device__ inline uint64_t em2_pas_cap(uint64_t nU, uint64_t W, bool usa) { return usa ? (nU < 2 * W ? nU : 2 * W) : 0; }
 __device__ __forceinline__ Em2Scratch em2_carve(uint32_t* scratch, uint64_t off, uint32_t nU, uint32_t W, uint32_t M, bool usa) {
@@ -77,19 +77,21 @@ __device__ __forceinline__ Em2Scratch em2_carve(uint32_t* scratch, uint64_t off,
     e.g_ab = reinterpret_cast<float*>(p); p += usa ? W : 0;
     e.g_v = reinterpret_cast<float*>(p); p += W + em2_pas_cap(nU, W, usa) + 2;
     e.g_pre = p; p += W + 1;
+    e.nid = p; p += W;
     return e;
 }
 }  // namespace
 
-uint64_t em2_scratch_words(uint32_t nU, uint32_t W, uint32_t M, bool usa) {
+__host__ __device__ inline uint64_t em2_words(uint32_t nU, uint32_t W, uint32_t M, bool usa) {
     const uint64_t pc = em2_pas_cap(nU, W, usa);
     uint64_t w = 2 * ((uint64_t)nU + W) + 16 + 2 * ((uint64_t)W + 1) + 3 * (uint64_t)W + (usa ? 2 * (uint64_t)W : 0) + pc + ((uint64_t)M + 1) + W +
-                 3 * (uint64_t)nU + (usa ? W : 0) + ((uint64_t)W + pc + 2) + ((uint64_t)W + 1);
+                 3 * (uint64_t)nU + (usa ? W : 0) + ((uint64_t)W + pc + 2) + ((uint64_t)W + 1) + W;
     return (w + 3) & ~3ull;   // slices stay 16-byte aligned
 }
+uint64_t em2_scratch_words(uint32_t nU, uint32_t W, uint32_t M, bool usa) { return em2_words(nU, W, M, usa); }
 
 // header words
-enum { H_L = 0, H_P, H_K, H_WC, H_NPU, H_FBITS, H_TIER };
+enum { H_L = 0, H_P, H_K, H_WC, H_NPU, H_FBITS, H_TIER, H_NHOT };
 constexpr uint32_t kTierNone = 7;   // no multi-label class: the row is the single-label counts (em.rs:339-341, 499-514)
 // LDS words of the three all-in-LDS instances (4 x 38 KiB, 2 x 78 KiB, 157 KiB: next to the few static words they fit a CU's 160 KiB)
 constexpr uint32_t kT0Words = 9728, kT1Words = 19968, kT2Words = 40192;
@@ -101,9 +103,16 @@ __device__ __forceinline__ uint32_t em2_fbits(uint32_t nrec) {
 }
 // LDS words of the all-in-LDS layout: acc u64[L] | ab f32[L] (USA) | v f32[L+P+2] | coff u16[K+1] | cw u16[Wc]
 __host__ __device__ inline uint32_t em2_lds_core_words(uint32_t L, uint32_t P, bool usa) { return 2 * L + (usa ? L : 0) + (L + P + 2); }
+// entries whose state the largest instance keeps in LDS when a cell does not fit whole (acc u64 + ab f32 (USA) + v f32 each)
+__host__ __device__ inline uint32_t em2_hot_cap(bool usa) { return kT2Words / (usa ? 4u : 3u); }
 __host__ __device__ inline uint32_t em2_lds_all_words(uint32_t L, uint32_t P, uint32_t K, uint32_t Wc, bool usa) {
     return em2_lds_core_words(L, P, usa) + (K + 2) / 2 + (Wc + 1) / 2 + 2;
 }
+
+// The barrier between phases that hand each other data through GLOBAL memory: a wave first waits for its own stores to be
+// acknowledged (stores count in vmcnt on gfx9), then goes to the barrier; a word the other waves change with atomics (L2) is
+// read back with an atomic as well (afq_pug2.hip has the measurements behind both rules).
+__device__ __forceinline__ void em2_gsync() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kSetupNT) void k_em2_setup(const CellMeta* __restrict__ meta, const uint32_t* __restrict__ nnz_unique,
@@ -116,8 +125,10 @@ __global__ __launch_bounds__(kSetupNT) void k_em2_setup(const CellMeta* __restri
     extern __shared__ uint32_t s_bm[];   // bits[nwb], rank[nwb]
     __shared__ uint32_t s_ws[kSetupNT / 64];
     __shared__ uint32_t s_P;
+    __shared__ uint32_t s_hist[64], s_pick[3];
     constexpr int NT = kSetupNT;
     const uint32_t tid = threadIdx.x;
+    if (tiers[7]) return;   // (the scratch the host set aside is too small: it sizes the EM itself)
     const uint32_t cell = em_order[blockIdx.x];
     const CellMeta m = meta[cell];
     const uint32_t nU = nnz_unique[cell];
@@ -243,28 +254,76 @@ __global__ __launch_bounds__(kSetupNT) void k_em2_setup(const CellMeta* __restri
     }
     // 5. label words as live ids
     for (uint32_t w = tid; w < Wc; w += NT) sc.cw[w] = rank_of(sc.cw[w]);
-    // 6. header, tier
-    if (tid == 0) {
-        const uint32_t P = s_P, K = M;
-        sc.hdr[H_L] = L; sc.hdr[H_P] = P; sc.hdr[H_K] = K; sc.hdr[H_WC] = Wc; sc.hdr[H_NPU] = nPU; sc.hdr[H_FBITS] = em2_fbits(m.nrec);
+    // 6. tier (every thread: the values are uniform)
+    const uint32_t P = s_P, K = M;
+    uint32_t tier;
+    {
         const bool ids16 = L + P + 2 <= 65536u && K < 65535u && Wc <= 65535u;
         const uint32_t all = em2_lds_all_words(L, P, K, Wc, usa), core = em2_lds_core_words(L, P, usa);
-        uint32_t tier;
         if (ids16 && all <= kT0Words && L <= 256u * 8u) tier = 0;
         else if (ids16 && all <= kT1Words && L <= 512u * 8u) tier = 1;
         else if (ids16 && all <= kT2Words && L <= 1024u * 16u) tier = 2;
         else if (core <= kT2Words) tier = 3;
         else tier = 4;
-        if (tier < cfg.min_tier) tier = (cfg.min_tier == 3 && core > kT2Words) ? 4u : cfg.min_tier;   // (tests: every instance on every size)
-        sc.hdr[H_TIER] = tier;
+        if (tier < cfg.min_tier) tier = cfg.min_tier;   // (tests: every instance on every size)
+    }
+    uint32_t H = L;
+    if (tier == 4) {
+        // 7. A cell whose state does not fit LDS keeps the entries that take most of the traffic there - the ones in most
+        // classes (gene popularity is Zipf: a few entries sit in a tenth of all labels) - and the rest in global memory:
+        // entries are renumbered hot first (state id = nid[entry]; entries stay in column order for the output row).
+        uint32_t* deg = sc.g_pre;
+        em2_gsync();   // (label words as live ids, written above by other threads)
+        for (uint32_t e = tid; e < L; e += NT) deg[e] = 0;
+        if (tid < 64) s_hist[tid] = 0;
+        em2_gsync();
+        for (uint32_t w = tid; w < Wc; w += NT) atomicAdd(&deg[sc.cw[w]], 1u);
+        em2_gsync();
+        for (uint32_t e = tid; e < L; e += NT) { const uint32_t d = __hip_atomic_load(&deg[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicAdd(&s_hist[d < 63u ? d : 63u], 1u); }
+        em2_gsync();
+        if (tid == 0) {   // every degree above t is hot; of degree t, the first `extra` entries
+            const uint32_t cap = cfg.min_tier == 4 && (L + 1) / 2 < em2_hot_cap(usa) ? (L + 1) / 2 : em2_hot_cap(usa);   // (tests force small cells here: half of them cold)
+            uint32_t t = 63, n = 0;
+            while (t > 0 && n + s_hist[t] <= cap) { n += s_hist[t]; --t; }
+            const uint32_t extra = t > 0 ? (cap - n < s_hist[t] ? cap - n : s_hist[t]) : 0u;
+            s_pick[0] = t; s_pick[1] = extra; s_pick[2] = n + extra;
+        }
+        em2_gsync();
+        const uint32_t t = s_pick[0], extra = s_pick[1];
+        H = s_pick[2];
+        uint32_t eq_before = 0, hot_before = 0;
+        for (uint32_t base = 0; base < L; base += NT) {
+            const uint32_t e = base + tid;
+            uint32_t d = 0;
+            if (e < L) { d = __hip_atomic_load(&deg[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); d = d < 63u ? d : 63u; }
+            const uint32_t eq = e < L && d == t && t > 0;
+            uint32_t tot_eq, tot_hot;
+            const uint32_t eqr = eq_before + block_excl_scan<NT>(eq, s_ws, tot_eq);
+            const uint32_t hot = e < L && (d > t || (eq && eqr < extra));
+            const uint32_t hr = hot_before + block_excl_scan<NT>(hot, s_ws, tot_hot);
+            if (e < L) sc.nid[e] = hot ? hr : H + (e - hr);
+            eq_before += tot_eq; hot_before += tot_hot;
+        }
+        em2_gsync();
+        for (uint32_t w = tid; w < Wc; w += NT) sc.cw[w] = sc.nid[sc.cw[w]];
+        if (usa)
+            for (uint32_t e = tid; e < L; e += NT) {
+                const uint32_t a = sc.ent_s1[e], b = sc.ent_s2[e];
+                if (!(a & kSibPassive)) sc.ent_s1[e] = sc.nid[a];
+                if (!(b & kSibPassive)) sc.ent_s2[e] = sc.nid[b];
+            }
+    }
+    if (tid == 0) {
+        sc.hdr[H_L] = L; sc.hdr[H_P] = P; sc.hdr[H_K] = K; sc.hdr[H_WC] = Wc; sc.hdr[H_NPU] = nPU; sc.hdr[H_FBITS] = em2_fbits(m.nrec);
+        sc.hdr[H_TIER] = tier; sc.hdr[H_NHOT] = H;
         const uint32_t at = atomicAdd(&tiers[tier], 1u);
         tiers[8 + (size_t)tier * n_cells + at] = cell;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// The rounds.  MODE 0: everything in LDS, per-entry constants in registers (EPT entries per thread); 1: accumulators,
-// abundances in LDS, class lists and entry constants streamed; 2: everything in global memory (workgroup-scope atomics in L2).
+// The rounds.  MODE 0: everything in LDS, per-entry constants in registers (EPT entries per thread); 1: accumulators and
+// abundances in LDS, class lists and entry constants streamed.  (Cells beyond that: k_em2_rounds_hybrid below.)
 template <typename T> struct IdLoad;
 template <> struct IdLoad<uint16_t> { static __device__ __forceinline__ uint32_t at(const uint16_t* p, uint32_t i) { return p[i]; } };
 template <> struct IdLoad<uint32_t> { static __device__ __forceinline__ uint32_t at(const uint32_t* p, uint32_t i) { return p[i]; } };
@@ -272,15 +331,6 @@ template <> struct IdLoad<uint32_t> { static __device__ __forceinline__ uint32_t
 __device__ __forceinline__ void em2_add(unsigned long long* p, unsigned long long v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// Barrier between phases.  MODE 2 hands data through global memory: a wave first waits for its own stores to be acknowledged
-// (stores count in vmcnt on gfx9), and a word the other waves change with atomics (L2) is read back with an atomic as well
-// (afq_pug2.hip has the measurements behind both rules).
-template <int MODE>
-__device__ __forceinline__ void em2_sync() {
-    if constexpr (MODE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-}
-
 // one pass over the classes: D in label order, r = 1 / D, every label word's share into its entry's accumulator
 template <int NT, typename IdT>
 __device__ __forceinline__ void em2_class_pass(const IdT* __restrict__ coff, const IdT* __restrict__ cw, const float* ab,
@@ -330,6 +380,16 @@ __device__ __forceinline__ uint32_t em2_map_sib(uint32_t s, uint32_t L, uint32_t
     return s;
 }
 
+#ifdef AFQ_EM_TIMING
+__device__ unsigned long long g_em2_dbg[32768][4];
+__device__ uint32_t g_em2_dbg_n;
+__global__ void k_em2_dbg_dump() {
+    const uint32_t n = g_em2_dbg_n < 32768 ? g_em2_dbg_n : 32768;
+    for (uint32_t i = 0; i < n; ++i) printf("em2 blk %llx %llu %llu %llu\n", g_em2_dbg[i][0], g_em2_dbg[i][1], g_em2_dbg[i][2], g_em2_dbg[i][3]);
+    printf("em2 blk end of launch\n");
+    g_em2_dbg_n = 0;
+}
+#endif
 template <int NT, int MODE, int EPT, uint32_t LDSW>
 __global__ __launch_bounds__(NT) void k_em2_rounds(const CellMeta* __restrict__ meta, const uint32_t* __restrict__ nnz_unique,
                                                    const uint32_t* __restrict__ lab_cnt, const uint64_t* __restrict__ em_off,
@@ -338,6 +398,9 @@ __global__ __launch_bounds__(NT) void k_em2_rounds(const CellMeta* __restrict__ 
     __shared__ uint32_t s_ws[NT / 64];
     __shared__ uint32_t s_flag[2];
     __shared__ __attribute__((aligned(16))) uint32_t s_mem[LDSW];
+#ifdef AFQ_EM_TIMING
+    const unsigned long long t_entry = wall_clock64();
+#endif
     if (blockIdx.x >= tiers[tier]) return;
     const uint32_t cell = tiers[8 + (size_t)tier * n_cells + blockIdx.x];
     const uint32_t tid = threadIdx.x;
@@ -350,8 +413,7 @@ __global__ __launch_bounds__(NT) void k_em2_rounds(const CellMeta* __restrict__ 
     // placement
     unsigned long long* acc;
     float *ab, *v;
-    if constexpr (MODE == 2) { acc = sc.g_acc; v = sc.g_v; ab = usa ? sc.g_ab : sc.g_v; }
-    else {
+    {
         acc = reinterpret_cast<unsigned long long*>(s_mem);
         float* f = reinterpret_cast<float*>(s_mem + 2 * L);
         ab = f; if (usa) f += L;
@@ -387,10 +449,18 @@ __global__ __launch_bounds__(NT) void k_em2_rounds(const CellMeta* __restrict__ 
     }
     for (uint32_t p = tid; p < P; p += NT) v[L + p] = init_of(sc.pas_val[p]);
     if (tid == 0) { v[Z0] = init_of(0u); v[Z1] = 0.0f; s_flag[0] = 0; s_flag[1] = 0; }
-    em2_sync<MODE>();
+    __syncthreads();
+#ifdef AFQ_EM_TIMING
+    unsigned long long tph[4] = {0, 0, 0, 0}, tph_t = wall_clock64();
+    const unsigned long long t_begin = tph_t;
+#define EM2T(i) do { if (tid == 0) { const unsigned long long n_ = wall_clock64(); tph[i] += n_ - tph_t; tph_t = n_; } } while (0)
+#else
+#define EM2T(i) do {} while (0)
+#endif
     uint32_t it = 0;
     bool conv = true, last_round = false;
     while (it < kMinIter2 || (it < kMaxIter2 && !conv) || last_round) {
+        EM2T(3);
         if (usa) {   // (C) what a label word contributes with: own + sibling statuses
             if constexpr (MODE == 0) {
 #pragma unroll
@@ -402,19 +472,20 @@ __global__ __launch_bounds__(NT) void k_em2_rounds(const CellMeta* __restrict__ 
                 for (uint32_t e = tid; e < L; e += NT)
                     ab[e] = (v[em2_map_sib(sc.ent_s1[e], L, P)] + v[em2_map_sib(sc.ent_s2[e], L, P)]) + v[e];
             }
-            em2_sync<MODE>();
+            __syncthreads();
         }
         // (A+B) classes
         if constexpr (MODE == 0) em2_class_pass<NT, uint16_t>(coff16, cw16, ab, acc, K, scale);
         else em2_class_pass<NT, uint32_t>(sc.coff, sc.cw, ab, acc, K, scale);
-        em2_sync<MODE>();
+        EM2T(0);
+        __syncthreads();
+        EM2T(1);
         // (E) entries: new abundance, convergence vote, accumulator back to the single-label count
         bool bad = false;
         if (tid == 0) s_flag[(it + 1) & 1u] = 0;   // the other round's flag: everyone read it before the barrier above
         auto entry = [&](uint32_t e, uint32_t cnt) {
-            unsigned long long a;
-            if constexpr (MODE == 2) a = __hip_atomic_exchange(&acc[e], (unsigned long long)cnt << F, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else { a = acc[e]; acc[e] = (unsigned long long)cnt << F; }
+            const unsigned long long a = acc[e];
+            acc[e] = (unsigned long long)cnt << F;
             const float x = (float)a * inv_scale;
             const float old = v[e];
             if (x > kAlphaCheckCutoff2 && fabsf(old - x) > kRelDiffTol2) bad = true;
@@ -431,7 +502,8 @@ __global__ __launch_bounds__(NT) void k_em2_rounds(const CellMeta* __restrict__ 
             if (tid == 0) v[Z0] = 0.0f;
         }
         if (bad) s_flag[it & 1u] = 1;
-        em2_sync<MODE>();
+        __syncthreads();
+        EM2T(2);
         conv = s_flag[it & 1u] == 0;
         ++it;
         if (usa) {   // em_optimize_subset_impl: after the first converged round zero what is below the output floor, one more round (em.rs:391-451)
@@ -439,13 +511,13 @@ __global__ __launch_bounds__(NT) void k_em2_rounds(const CellMeta* __restrict__ 
             if (it >= kMinIter2 && conv) {
                 for (uint32_t e = tid; e < L; e += NT) if (v[e] < kMinOutputAlpha2) v[e] = 0.0f;
                 last_round = true;
-                em2_sync<MODE>();
+                __syncthreads();
             }
         }
     }
     // output row: pass-through columns and the live entries at or above the floor, merged by column
-    uint32_t* pre = MODE == 2 ? sc.g_pre : s_mem;   // (the accumulators are dead)
-    em2_sync<MODE>();
+    uint32_t* pre = s_mem;   // (over the accumulators, which are dead)
+    __syncthreads();
     uint32_t nout = 0;
     for (uint32_t base = 0; base < L; base += NT) {
         const uint32_t e = base + tid;
@@ -460,28 +532,214 @@ __global__ __launch_bounds__(NT) void k_em2_rounds(const CellMeta* __restrict__ 
         nout += tot;
     }
     if (tid == 0) pre[L] = nout;
-    em2_sync<MODE>();
+    __syncthreads();
     for (uint32_t j = tid; j < nPU; j += NT) sc.out[j + pre[sc.pu_lb[j]]] = make_uint2(sc.pu_col[j], __float_as_uint((float)sc.pu_cnt[j]));
     if (tid == 0) out_nnz[cell] = nPU + nout;
+#ifdef AFQ_EM_TIMING
+    if (tid == 0 && (blockIdx.x % 100) == 3 && cfg.min_tier == 9)
+        printf("em2 rounds tier=%u NT=%d L=%u P=%u K=%u Wc=%u nPU=%u it=%u: C+classes(thread 0)=%.1f wait=%.1f entries=%.1f other=%.1f total=%.1f us\n", tier, NT, L, P, K, Wc, nPU, it,
+               (double)tph[0] / 100.0, (double)tph[1] / 100.0, (double)tph[2] / 100.0, (double)tph[3] / 100.0, (double)(wall_clock64() - t_begin) / 100.0);
+    if (tid == 0) {
+        uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const uint32_t at = atomicAdd(&g_em2_dbg_n, 1u);
+        if (at < 32768) { g_em2_dbg[at][0] = ((unsigned long long)tier << 56) | ((unsigned long long)(xcc & 0xf) << 48) | ((unsigned long long)(hw & 0xffff) << 32) | blockIdx.x;
+                          g_em2_dbg[at][1] = t_entry; g_em2_dbg[at][2] = t_begin; g_em2_dbg[at][3] = wall_clock64(); }
+    }
+#endif
 }
 
-void launch_em2(hipStream_t s, const ResolveArgs& a, uint32_t n_cells, const uint64_t* em_off, uint32_t* scratch, uint32_t* out_nnz,
-                const uint32_t* em_order, uint32_t* tiers, uint32_t num_alphas, uint32_t init_uniform) {
+// ---------------------------------------------------------------------------------------------------------------------------
+// The rounds of a cell whose state does not fit LDS (k_em2_setup step 7): state ids below H - the entries in most classes -
+// live in LDS (accumulator, contribution, abundance), the others in the cell's global scratch, as do the class lists and
+// the per-entry constants.  A hot entry takes its atomics in LDS; a cold one is in one or two classes: its atomics go to L2
+// without meeting another.  Same arithmetic, same bits.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_em2_rounds_hybrid(const uint32_t* __restrict__ nnz_unique, const uint32_t* __restrict__ lab_cnt,
+                                                          const uint64_t* __restrict__ em_off, uint32_t* __restrict__ scratch,
+                                                          uint32_t* __restrict__ out_nnz, const uint32_t* __restrict__ tiers, uint32_t n_cells,
+                                                          uint32_t tier, Em2Cfg cfg) {
+    __shared__ uint32_t s_ws[NT / 64];
+    __shared__ uint32_t s_flag[2];
+    __shared__ __attribute__((aligned(16))) uint32_t s_mem[kT2Words];
+#ifdef AFQ_EM_TIMING
+    const unsigned long long t_entry = wall_clock64();
+#endif
+    if (blockIdx.x >= tiers[tier]) return;
+    const uint32_t cell = tiers[8 + (size_t)tier * n_cells + blockIdx.x];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nU = nnz_unique[cell], W = lab_cnt[2 * cell], M = lab_cnt[2 * cell + 1];
+    const bool usa = cfg.usa != 0;
+    const Em2Scratch sc = em2_carve(scratch, em_off[cell], nU, W, M, usa);
+    const uint32_t L = sc.hdr[H_L], P = sc.hdr[H_P], K = sc.hdr[H_K], nPU = sc.hdr[H_NPU], F = sc.hdr[H_FBITS], H = sc.hdr[H_NHOT];
+    const float scale = __uint_as_float((127u + F) << 23), inv_scale = __uint_as_float((127u - F) << 23);
+    const uint32_t Z0 = L + P, Z1 = L + P + 1;
+    unsigned long long* acc_h = reinterpret_cast<unsigned long long*>(s_mem);
+    float* v_h = reinterpret_cast<float*>(s_mem + 2 * H);
+    float* ab_h = usa ? v_h + H : v_h;
+    unsigned long long* acc_g = sc.g_acc;
+    float* v_g = sc.g_v;
+    float* ab_g = usa ? sc.g_ab : sc.g_v;
+    auto V = [&](uint32_t s2) -> float { return s2 < H ? v_h[s2] : v_g[s2]; };
+    auto setV = [&](uint32_t s2, float x) { if (s2 < H) v_h[s2] = x; else v_g[s2] = x; };
+    auto AB = [&](uint32_t s2) -> float { return s2 < H ? ab_h[s2] : ab_g[s2]; };
+    auto add = [&](uint32_t s2, unsigned long long q) { if (s2 < H) em2_add(&acc_h[s2], q); else em2_add(&acc_g[s2], q); };   // (LDS or L2: never a flat atomic)
+    const float uni = 1.0f / (float)cfg.num_alphas;
+    auto init_of = [&](uint32_t cnt) -> float { return cfg.init_uniform ? uni : ((float)cnt + 0.5f) * 1e-3f; };
+    for (uint32_t e = tid; e < L; e += NT) {
+        const uint32_t s2 = sc.nid[e], c = sc.ent_ucnt[e];
+        setV(s2, init_of(c));
+        if (s2 < H) acc_h[s2] = (unsigned long long)c << F; else acc_g[s2] = (unsigned long long)c << F;
+    }
+    for (uint32_t p = tid; p < P; p += NT) v_g[L + p] = init_of(sc.pas_val[p]);
+    if (tid == 0) { v_g[Z0] = init_of(0u); v_g[Z1] = 0.0f; s_flag[0] = 0; s_flag[1] = 0; }
+    em2_gsync();
+    uint32_t it = 0;
+    bool conv = true, last_round = false;
+    while (it < kMinIter2 || (it < kMaxIter2 && !conv) || last_round) {
+        if (usa) {
+            for (uint32_t e = tid; e < L; e += NT) {
+                const uint32_t s2 = sc.nid[e];
+                const float x = (V(em2_map_sib(sc.ent_s1[e], L, P)) + V(em2_map_sib(sc.ent_s2[e], L, P))) + V(s2);
+                if (s2 < H) ab_h[s2] = x; else ab_g[s2] = x;
+            }
+            em2_gsync();
+        }
+        for (uint32_t c0 = tid; c0 < K; c0 += 2 * NT) {   // (as em2_class_pass, over state ids)
+            uint32_t o0[2], n[2], e[2][4];
+            float a[2][4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t c = c0 + j * NT;
+                o0[j] = 0; n[j] = 0;
+                if (c < K) { o0[j] = sc.coff[c]; n[j] = sc.coff[c + 1] - o0[j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e[j][k] = (uint32_t)k < n[j] ? sc.cw[o0[j] + k] : 0u;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[j][k] = (uint32_t)k < n[j] ? AB(e[j][k]) : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (n[j] == 0) continue;
+                float d = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if ((uint32_t)k < n[j]) d += a[j][k];
+                for (uint32_t k = 4; k < n[j]; ++k) d += AB(sc.cw[o0[j] + k]);
+                if (!(d > 0.0f)) continue;
+                const float r = 1.0f / d;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if ((uint32_t)k < n[j]) add(e[j][k], (unsigned long long)((a[j][k] * r) * scale));
+                for (uint32_t k = 4; k < n[j]; ++k) { const uint32_t ee = sc.cw[o0[j] + k]; add(ee, (unsigned long long)((AB(ee) * r) * scale)); }
+            }
+        }
+        em2_gsync();
+        bool bad = false;
+        if (tid == 0) s_flag[(it + 1) & 1u] = 0;
+        for (uint32_t e = tid; e < L; e += NT) {
+            const uint32_t s2 = sc.nid[e];
+            const unsigned long long fresh = (unsigned long long)sc.ent_ucnt[e] << F;
+            unsigned long long a;
+            if (s2 < H) { a = acc_h[s2]; acc_h[s2] = fresh; }
+            else a = __hip_atomic_exchange(&acc_g[s2], fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const float x = (float)a * inv_scale;
+            const float old = V(s2);
+            if (x > kAlphaCheckCutoff2 && fabsf(old - x) > kRelDiffTol2) bad = true;
+            setV(s2, x);
+        }
+        if (it == 0) {
+            for (uint32_t p = tid; p < P; p += NT) v_g[L + p] = (float)sc.pas_val[p];
+            if (tid == 0) v_g[Z0] = 0.0f;
+        }
+        if (bad) s_flag[it & 1u] = 1;
+        em2_gsync();
+        conv = s_flag[it & 1u] == 0;
+        ++it;
+        if (usa) {
+            if (last_round) break;
+            if (it >= kMinIter2 && conv) {
+                for (uint32_t e = tid; e < L; e += NT) { const uint32_t s2 = sc.nid[e]; if (V(s2) < kMinOutputAlpha2) setV(s2, 0.0f); }
+                last_round = true;
+                em2_gsync();
+            }
+        }
+    }
+    uint32_t* pre = sc.g_pre;
+    uint32_t nout = 0;
+    for (uint32_t base = 0; base < L; base += NT) {
+        const uint32_t e = base + tid;
+        const float x = e < L ? V(sc.nid[e]) : 0.0f;
+        const uint32_t h = x >= kMinOutputAlpha2;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<NT>(h, s_ws, tot);
+        if (e < L) {
+            pre[e] = nout + ex;
+            if (h) sc.out[sc.ent_ub[e] + nout + ex] = make_uint2(sc.ent_col[e], __float_as_uint(x));
+        }
+        nout += tot;
+    }
+    if (tid == 0) pre[L] = nout;
+    em2_gsync();
+    for (uint32_t j = tid; j < nPU; j += NT) sc.out[j + pre[sc.pu_lb[j]]] = make_uint2(sc.pu_col[j], __float_as_uint((float)sc.pu_cnt[j]));
+    if (tid == 0) out_nnz[cell] = nPU + nout;
+#ifdef AFQ_EM_TIMING
+    if (tid == 0) {
+        const uint32_t at = atomicAdd(&g_em2_dbg_n, 1u);
+        if (at < 32768) { g_em2_dbg[at][0] = ((unsigned long long)tier << 56) | blockIdx.x; g_em2_dbg[at][1] = t_entry; g_em2_dbg[at][2] = t_entry; g_em2_dbg[at][3] = wall_clock64(); }
+        if ((blockIdx.x % 100) == 3) printf("em2 hybrid L=%u H=%u P=%u K=%u it=%u total=%.1f us\n", L, H, P, K, it, (double)(wall_clock64() - t_entry) / 100.0);
+    }
+#endif
+}
+
+// Where each cell's scratch slice starts, on the device (so that the EM follows the range's other kernels without a trip to
+// the host): exact sizes from the counts the resolution kernels left, packed; tiers[7] is set when the packed total exceeds
+// what the host allocated - every kernel below then returns at once and the host sizes the EM itself (afq_api.cpp).
+__global__ __launch_bounds__(1024) void k_em2_plan(const uint32_t* __restrict__ nnz_unique, const uint32_t* __restrict__ lab_cnt, uint32_t n_cells,
+                                                   uint32_t usa, unsigned long long cap_words, uint64_t* __restrict__ em_off, uint32_t* __restrict__ tiers,
+                                                   const DevStatus* __restrict__ st) {
+    __shared__ unsigned long long s_sum[1024];
+    if (st->err_code) { if (threadIdx.x == 0) tiers[7] = 1; return; }   // (the range failed: its counts are not to be trusted; the host reports the error)
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n_cells + 1023u) / 1024u, i0 = tid * per, i1 = i0 + per < n_cells ? i0 + per : n_cells;
+    unsigned long long sum = 0;
+    for (uint32_t i = i0; i < i1; ++i) sum += em2_words(nnz_unique[i], lab_cnt[2 * i], lab_cnt[2 * i + 1], usa != 0);
+    s_sum[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long run = 0;
+        for (uint32_t t = 0; t < 1024; ++t) { const unsigned long long x = s_sum[t]; s_sum[t] = run; run += x; }
+        em_off[n_cells] = run;
+        if (run > cap_words) tiers[7] = 1;
+    }
+    __syncthreads();
+    unsigned long long off = s_sum[tid];
+    for (uint32_t i = i0; i < i1; ++i) { em_off[i] = off; off += em2_words(nnz_unique[i], lab_cnt[2 * i], lab_cnt[2 * i + 1], usa != 0); }
+}
+
+void launch_em2(hipStream_t s, const ResolveArgs& a, uint32_t n_cells, uint64_t* em_off, uint32_t* scratch, uint32_t* out_nnz,
+                const uint32_t* em_order, uint32_t* tiers, uint32_t num_alphas, uint32_t init_uniform, uint64_t plan_cap_words) {
     if (!n_cells) return;
     uint32_t min_tier = 0;
     if (const char* e = std::getenv("AFQ_EM2_MIN_TIER")) min_tier = (uint32_t)std::min(4, std::max(0, std::atoi(e)));   // (tests; read per range)
     Em2Cfg cfg{a.usa, num_alphas, a.num_rows / 3, 2 * (a.num_rows / 3), init_uniform, (num_alphas + 31) / 32, min_tier};
     (void)hipMemsetAsync(tiers, 0, 32, s);
+    if (plan_cap_words) hipLaunchKernelGGL(k_em2_plan, dim3(1), dim3(1024), 0, s, a.nnz, a.lab_cnt, n_cells, a.usa, (unsigned long long)plan_cap_words, em_off, tiers, a.st);
     hipLaunchKernelGGL(k_em2_setup, dim3(n_cells), dim3(kSetupNT), 8 * cfg.nwb, s, a.meta, a.nnz, a.keys0, a.keys1, a.lab, a.lab_cnt, em_off,
                        scratch, out_nnz, em_order, tiers, n_cells, cfg);
 #define EM2_ROUNDS(NT, MODE, EPT, LDSW, TIER) \
     hipLaunchKernelGGL((k_em2_rounds<NT, MODE, EPT, LDSW>), dim3(n_cells), dim3(NT), 0, s, a.meta, a.nnz, a.lab_cnt, em_off, scratch, out_nnz, tiers, n_cells, TIER, cfg)
-    EM2_ROUNDS(1024, 2, 1, 4, 4u);          // largest first: the few cells that run out of global memory are the long ones
+    hipLaunchKernelGGL(k_em2_rounds_hybrid<1024>, dim3(n_cells), dim3(1024), 0, s, a.nnz, a.lab_cnt, em_off, scratch, out_nnz, tiers, n_cells, 4u, cfg);   // largest first
     EM2_ROUNDS(1024, 1, 1, kT2Words, 3u);
     EM2_ROUNDS(1024, 0, 16, kT2Words, 2u);
     EM2_ROUNDS(512, 0, 8, kT1Words, 1u);
     EM2_ROUNDS(256, 0, 8, kT0Words, 0u);
 #undef EM2_ROUNDS
+#ifdef AFQ_EM_TIMING
+    hipLaunchKernelGGL(k_em2_dbg_dump, dim3(1), dim3(1), 0, s);
+#endif
 }
 
 // columns the setup kernel's bitmap + rank table can hold in 64 KiB of LDS; beyond that the EM takes the canonical kernels

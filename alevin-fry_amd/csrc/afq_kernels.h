@@ -87,8 +87,11 @@ void launch_em(hipStream_t s, const ResolveArgs& a, uint32_t n_cells, const uint
 // output space fits the set-up kernel's bitmap (otherwise the canonical kernels above run)
 uint64_t em2_scratch_words(uint32_t nU, uint32_t W, uint32_t M, bool usa);
 bool em2_supported(uint32_t num_alphas);
-void launch_em2(hipStream_t s, const ResolveArgs& a, uint32_t n_cells, const uint64_t* em_off, uint32_t* scratch, uint32_t* out_nnz,
-                const uint32_t* em_order, uint32_t* tiers /* 8 + 5 * n_cells words */, uint32_t num_alphas, uint32_t init_uniform);
+// plan_cap_words != 0: the per-cell offsets are made on the device (k_em2_plan) from the counts the range's kernels left, packed
+// into a scratch buffer of that many words; tiers[7] != 0 afterwards = it did not fit and nothing ran
+void launch_em2(hipStream_t s, const ResolveArgs& a, uint32_t n_cells, uint64_t* em_off, uint32_t* scratch, uint32_t* out_nnz,
+                const uint32_t* em_order, uint32_t* tiers /* 8 + 5 * n_cells words */, uint32_t num_alphas, uint32_t init_uniform,
+                uint64_t plan_cap_words = 0);
 // -d: sizes (cls_ptr == null) or fills the per-cell gene-level classes; see k_eqc_dump
 void launch_eqc_dump(hipStream_t s, const ResolveArgs& a, uint32_t n_cells, const uint64_t* em_off, const uint32_t* scratch,
                      const void* em_hdr, uint32_t num_alphas, uint32_t* n_cls, uint32_t* n_words, const uint64_t* cls_ptr,

@@ -277,6 +277,9 @@ uint64_t afq_label_rehash_count(const afq_ctx* ctx);
    again with four times the pool, up to three times, before AFQ_ERR_OOM (the reference allocates per graph,
    pugutils.rs:65-267).  How often that happened since afq_create. */
 uint64_t afq_pool_regrow_count(const afq_ctx* ctx);
+/* EM resolutions: ranges whose EM did not fit the device scratch set aside for it ahead of time and was sized on the host
+ * instead (one extra trip to the host for that range; results identical).  Diagnostics only. */
+uint64_t afq_em_resize_count(const afq_ctx* ctx);
 
 /* One data chunk of a snappy frame stream (the format of map.collated.rad.sz: src/quant.rs:373-395, collate.rs:550-554):
    where its body lies in the stream (after the chunk's 4-byte header and 4-byte CRC), where its bytes go in the output,

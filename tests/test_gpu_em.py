@@ -10,7 +10,7 @@ integers.  What is required of it:
 import numpy as np
 import pytest
 
-from util import assert_same_result, cfg_for, pkg
+from util import ROOT, assert_same_result, cfg_for, pkg
 
 pytestmark = pytest.mark.gpu
 synth = pkg.synth
@@ -97,3 +97,31 @@ def test_em_long_labels_and_many_classes(oracle_module):
     got = _device(cfg, s, b, off)
     assert_same_result(got, oracle_module.quant(cfg, s.tid_to_gid, b, off, em_arith="fixed", n_threads=4))
     assert_within_tolerance(got, oracle_module.quant(cfg, s.tid_to_gid, b, off, em_arith="reference", n_threads=4))
+
+
+def test_em_scratch_short_of_the_plan_is_sized_on_the_host(oracle_module, monkeypatch):
+    """The EM follows a range's kernels on the device, in scratch set aside from an upper bound ahead of time; with next to
+    nothing set aside (AFQ_EM2_SCRATCH_FRAC) the device-side plan does not fit, the kernels return at once and the host sizes the
+    EM itself: same rows, and the counter says so."""
+    s, b, off = _workload(True, seed=12)
+    cfg = cfg_for(s, "parsimony-em")
+    want = oracle_module.quant(cfg, s.tid_to_gid, b, off, em_arith="fixed")
+    q = pkg.Quantifier(cfg, s.tid_to_gid)
+    try:
+        assert_same_result(q.quant_chunks(b, off), want)
+        assert q.em_resize_count() == 0
+    finally:
+        q.close()
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests'); import numpy as np\n"
+            "from util import pkg, cfg_for\n"
+            "s = pkg.synth.synth(12, [30000, 9000, 4000, 1500, 700, 260, 250, 120, 99, 40, 3], num_genes=400, txp_per_gene=3, usa=True, dup=0.5, zipf=0.6, cross=0.4, umi_err=0.02, max_extra_na=5)\n"
+            "b, off = s.encode(); q = pkg.Quantifier(cfg_for(s, 'parsimony-em'), s.tid_to_gid); r = q.quant_chunks(b, off)\n"
+            "print(q.em_resize_count(), r.val.view(np.uint32).sum(dtype=np.uint64), len(r.gene))\n") % (ROOT, ROOT)
+    import os
+    env = dict(os.environ, AFQ_EM2_SCRATCH_FRAC="0.00001")   # (read once per process: a process of its own)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-500:]
+    n_resized, vsum, nnz = out.stdout.split()[-3:]
+    assert int(n_resized) >= 1 and int(nnz) == len(want.gene) and int(vsum) == int(want.val.view(np.uint32).sum(dtype=np.uint64))
