@@ -191,38 +191,50 @@ def sanity(res, rad):
     assert np.array_equal(res.nrec, rad.cell_nrec)
 
 
-def roofline_of(ktimes, alg_bytes, steps, traffic_ok):
+# timers of the library that bracket several kernels: their bytes add up (the decode timer brackets whichever decoder ran)
+BRACKETS = {"k_em": ("k_em2_plan", "k_em2_setup", "k_em2_rounds", "k_em2_rounds_hybrid", "k_em", "k_em_rounds"),
+            "k_p2_split": ("k_p2_hist", "k_p2_scan", "k_p2_scatter"),
+            "k_decode_par": ("k_slab_setup", "k_decode_recs", "k_decode_keys", "k_decode_par", "k_verify_cells"),
+            "k_scatter": ("k_scatter",), "k_resolve": ("k_bucket_desc", "k_resolve"), "k_resolve_big": ("k_resolve_mid", "k_resolve_big"),
+            "k_atac_dedup": ("k_atac_dedup64", "k_atac_dedup"), "k_atac_parse": ("k_atac_parse",)}
+
+
+def traffic_of(tag, name, launches_per_step):
+    """HBM bytes per launch of the timer `name` from the committed PMC passes of the leg `tag` (profiles/rNN[_tag]_traffic.json,
+    written by profiles/traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this very command): 2 x FETCH_SIZE + WRITE_SIZE
+    of every kernel the timer brackets, summed over the profiled steps, per launch of the bracket.  None when the leg has no pass."""
+    pdir = os.path.join(ROOT, "profiles")
+    if tag is None or not os.path.isdir(pdir):
+        return None
+    suffix = f"_{tag}_traffic.json" if tag else "_traffic.json"
+    files = sorted(f for f in os.listdir(pdir) if f.endswith(suffix) and (tag or f.count("_") == 1))
+    if not files:
+        return None
+    d = json.load(open(os.path.join(pdir, files[-1])))
+    kern, steps_prof = d["kernels"], d.get("steps_profiled")
+    parts = [k for k in BRACKETS.get(name, (name,)) if k in kern]
+    if not parts:
+        return None
+    if steps_prof and all("bytes_total_fetch_doubled" in kern[k] for k in parts):
+        return int(sum(kern[k]["bytes_total_fetch_doubled"] for k in parts) / (steps_prof * launches_per_step))
+    return sum(kern[k]["bytes_per_launch_fetch_doubled"] for k in parts)   # (files of rounds 1-3: per dispatch of each kernel)
+
+
+def roofline_of(ktimes, alg_bytes, steps, traffic_tag, ms_per_step=None):
     """Dominant kernel = largest summed HIP-event time; it is charged with the path's algorithmic bytes of one launch
-    (every record once, the chunk headers, 8 B per emitted non-zero)."""
+    (every record once, the chunk headers, 8 B per emitted non-zero).  frac_step = the whole step's algorithmic
+    bytes over the step's wall time, as a fraction of HBM peak."""
     if not ktimes:
         return None
     name, (ms_tot, launches) = max(ktimes.items(), key=lambda kv: kv[1][0])
     avg_ms = ms_tot / max(1, launches)
     lps = launches / steps
     achieved = alg_bytes / lps / (avg_ms * 1e-3) / 1e9
-    traffic = None
-    pdir = os.path.join(ROOT, "profiles")
-    tfiles = sorted(f for f in os.listdir(pdir) if f.endswith("_traffic.json")) if os.path.isdir(pdir) else []
-    if traffic_ok == "configs2":
-        tfiles = [f for f in tfiles if f.endswith("configs2_traffic.json")]
-    elif traffic_ok:
-        tfiles = [f for f in tfiles if "configs" not in f]
-    if traffic_ok and tfiles:   # HBM bytes per launch from the committed PMC passes; only meaningful for the workload they were taken on
-        kern = json.load(open(os.path.join(pdir, tfiles[-1])))["kernels"]
-        # (a timer of the library may bracket several kernels: their bytes add up; the decode timer brackets whichever decoder ran)
-        parts = {"k_em": ("k_em", "k_em_rounds"), "k_p2_split": ("k_p2_hist", "k_p2_scan", "k_p2_scatter")}.get(name)
-        if parts:
-            got = [kern[k]["bytes_per_launch_fetch_doubled"] for k in parts if k in kern]
-            traffic = sum(got) if got else None
-        else:
-            for cand in {"k_decode_par": ("k_decode_recs", "k_decode_keys", "k_decode_par")}.get(name, (name,)):
-                if cand in kern:
-                    traffic = kern[cand]["bytes_per_launch_fetch_doubled"]
-                    break
     kernels_ms = sum(v[0] for v in ktimes.values()) / steps
     return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-            "frac": round(achieved / 8000.0, 5), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": lps,
+            "frac": round(achieved / 8000.0, 5), "traffic": traffic_of(traffic_tag, name, lps), "avg_launch_ms": round(avg_ms, 4), "launches_per_step": lps,
             "alg_bytes_per_step": alg_bytes,
+            "frac_step": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / 8000.0, 5) if ms_per_step else None,
             "path_achieved_GBps": round(alg_bytes / (kernels_ms * 1e-3) / 1e9, 2) if kernels_ms else None,   # all kernels together
             "frac_path": round(alg_bytes / (kernels_ms * 1e-3) / 1e9 / 8000.0, 5) if kernels_ms else None,    # ... as a fraction of HBM peak: the path's own figure
             "all_kernels_ms_per_step": {k: round(v[0] / steps, 4) for k, v in ktimes.items()}}
@@ -370,11 +382,14 @@ def run_pbmc(D, args, pkg, sn, usa, resolution, steps, warmup, cpu_seconds, name
         sanity(res, rad)
         nnz = int(res.cell_ptr[-1])
         alg = float(st["input_bytes"]) + 8.0 * nnz
-        default_wl = (args.cells, args.median_reads, args.sigma, args.genes, args.ref_count, args.popularity, args.umi_err) == \
-            (11000, 30000.0, 0.6, 36601, 199138, "zipf1.1", 0.01) and not usa and resolution == "cr-like" and not tailed
         sizes_default = (args.cells, args.median_reads, args.sigma, args.genes, args.ref_count, args.popularity, args.umi_err) == \
             (11000, 30000.0, 0.6, 36601, 199138, "zipf1.1", 0.01)
-        roof = roofline_of(ktimes, alg, steps, default_wl or ("configs2" if sizes_default and usa and resolution == "parsimony-em" and not tailed else False))
+        ttag = None   # which committed counter passes belong to this workload
+        if sizes_default and not usa and resolution == "cr-like":
+            ttag = "configs1_tail" if tailed else ""
+        elif sizes_default and usa and resolution == "parsimony-em":
+            ttag = "configs2_tail" if tailed else "configs2"
+        roof = roofline_of(ktimes, alg, steps, ttag, 1e3 * elapsed / steps)
         cpu = None
         if D.world == 1 and not args.no_cpu_baseline and cpu_seconds > 0:
             cpu = cpu_leg(cfg, rad, res, cpu_seconds, min_cells=min_cells, tie_stats=tie_stats, round_cells=round_cells)
@@ -389,7 +404,10 @@ def run_pbmc(D, args, pkg, sn, usa, resolution, steps, warmup, cpu_seconds, name
                 "sharding": f"{D.world} x independent cell shards, no data-path collective"}
         out = line(D, args, name, total_reads * steps / elapsed / 1e6, elapsed, steps, warmup, cfgd,
                    {"cells_per_s": round(total_cells * steps / elapsed, 1), "nnz": nnz, "keys": st["n_keys"],
-                    "overflow_buckets": st["n_overflow_buckets"], "label_rehashes": q.label_rehash_count(), "gen_seconds": round(t_gen, 2),
+                    "overflow_buckets": st["n_overflow_buckets"],
+                    "retries": {"label_rehashes": q.label_rehash_count(), "pool_regrows": q.pool_regrow_count(), "em_resizes": q.em_resize_count(),
+                                "what": "ranges run again under another label hash / with a larger parsimony pool, EMs sized on the host after all - since the context was made (warm-up included)"},
+                    "gen_seconds": round(t_gen, 2),
                     "roofline": roof, "cpu_baseline": cpu})
         return out, rad, q
     except BaseException:
@@ -452,7 +470,9 @@ def run_configs3(D, args, pkg, sn, steps, warmup):
                 "sharding": f"{D.world} contiguous cell ranges, no data-path collective"}
         return line(D, args, "configs3", tot_reads * steps / elapsed / 1e6, elapsed, steps, warmup, cfgd,
                     {"cells_per_s": round(tot_cells * steps / elapsed, 1), "nnz": int(tot_nnz), "gen_seconds": round(t_gen, 2),
-                     "roofline": roofline_of(ktimes, alg, steps, False), "cpu_baseline": cpu})
+                     "retries": {"label_rehashes": q.label_rehash_count(), "pool_regrows": q.pool_regrow_count(), "em_resizes": q.em_resize_count()},
+                     "roofline": roofline_of(ktimes, alg, steps, "configs3" if (args.c3_cells, args.c3_mean_reads, args.genes, args.ref_count) == (125000, 20000.0, 36601, 199138) else None,
+                                             1e3 * elapsed / steps), "cpu_baseline": cpu})
     finally:
         q.close()
         rad.free()
@@ -790,23 +810,39 @@ def run_atac(args, pkg, D, steps, warmup):
             return None
         distinct = int(res[0][-1])
         alg = float(len(data)) + 12.0 * distinct   # every record byte once; (ref, start, len, count) per distinct fragment out
-        name, (ms_tot, launches) = max(kt.items(), key=lambda kv: kv[1][0])
-        avg_ms = ms_tot / max(1, launches)
-        kernels_ms = sum(v[0] for v in kt.values()) / steps
         cpu = None
         if D.world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle as ora
+            from concurrent.futures import ThreadPoolExecutor
 
-            k = max(1, min(n_cells, int(20e6 // per)))
-            end = int(off[k]) if k < n_cells else len(data)
+            # the oracle on the first k cells, one slice of cells per host core (ctypes drops the GIL inside the call); every field
+            # of every distinct fragment compared with the GPU's
+            ncores = os.cpu_count() or 1
+            k = max(1, min(n_cells, int(40e6 // per)))
+            bounds = np.linspace(0, k, min(ncores, k) + 1).astype(np.int64)
+            ends = [int(off[c]) if c < n_cells else len(data) for c in bounds]
+
+            def part(i):
+                c0, c1 = int(bounds[i]), int(bounds[i + 1])
+                return ora.atac_dedup_rad(data[int(off[c0]):ends[i + 1]], off[c0:c1] - off[c0])
             tb = time.perf_counter()
-            want = ora.atac_dedup_rad(data[:end], off[:k])
+            with ThreadPoolExecutor(max_workers=ncores) as ex:
+                parts = list(ex.map(part, range(len(bounds) - 1)))
             tc = time.perf_counter() - tb
-            assert np.array_equal(want[0], res[0][: k + 1]) and np.array_equal(want[2], res[2][: int(want[0][-1])]) and \
-                np.array_equal(want[5], res[5][: int(want[0][-1])]), "GPU/oracle mismatch"
-            cpu = {"value": round(k * per / tc / 1e6, 3), "unit": "M fragments/s", "cores": 1, "kind": "port",
-                   "sample": f"first {k} cells ({k * per} records), {tc:.1f} s, single-thread C++ restatement (oracle/); its fragments compared with the GPU's"}
+            pos = 0
+            for i, want in enumerate(parts):
+                c0, c1 = int(bounds[i]), int(bounds[i + 1])
+                nfr = int(want[0][-1])
+                assert np.array_equal(want[0] + pos, res[0][c0:c1 + 1]), "GPU/oracle mismatch (fragments per cell)"
+                for f_ in (2, 3, 4, 5):   # ref, start, frag_len, count
+                    assert np.array_equal(want[f_], res[f_][pos:pos + nfr]), f"GPU/oracle mismatch (field {f_})"
+                assert np.array_equal(want[1], res[1][c0:c1]), "GPU/oracle mismatch (barcodes)"
+                pos += nfr
+            cpu = {"value": round(k * per / tc / 1e6, 3), "unit": "M fragments/s", "cores": ncores, "kind": "port",
+                   "sample": f"first {k} cells ({k * per} records), {tc:.1f} s, C++ restatement (oracle/), one slice of cells per host core; "
+                             f"cell_ptr, barcode, ref, start, frag_len and count of every distinct fragment compared with the GPU's"}
+        roof = roofline_of(kt, alg, steps, "atac" if (n_cells, per) == (10000, 20000) else None, 1e3 * elapsed / steps)
         return {
             "metric": "M fragments/s through atac dedup (fragment/barcode dedup path)", "value": round(total * steps / elapsed / 1e6, 3),
             "unit": "M fragments/s", "n_gpus": D.world, "steps": steps, "warmup": warmup,
@@ -815,14 +851,7 @@ def run_atac(args, pkg, D, steps, warmup):
             "config": {"workload": f"configs[4]: scATAC dedup from collated-RAD bytes, per GPU: {n_cells} cells x {per} records (20 % exact duplicates, "
                                    f"5 % multi-mapped, 5 % unmapped, 25 chromosomes); bytes resident in HBM, distinct fragments back on the host",
                        "records_per_gpu": n, "input_bytes_per_gpu": int(len(data)), "distinct": distinct, "stats": res[6]},
-            "gen_seconds": round(t_gen, 1),
-            "roofline": {"bound": "hbm", "kernel": name, "achieved": round(alg / (avg_ms * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(alg / (avg_ms * 1e-3) / 1e9 / 8000.0, 5), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
-                         "launches_per_step": launches / steps, "alg_bytes_per_step": alg,
-                         "path_achieved_GBps": round(alg / (kernels_ms * 1e-3) / 1e9, 2) if kernels_ms else None,
-                         "frac_path": round(alg / (kernels_ms * 1e-3) / 1e9 / 8000.0, 5) if kernels_ms else None,
-                         "all_kernels_ms_per_step": {k2: round(v[0] / steps, 4) for k2, v in kt.items()}},
-            "cpu_baseline": cpu}
+            "gen_seconds": round(t_gen, 1), "roofline": roof, "cpu_baseline": cpu}
     finally:
         res = None
         q.close()
