@@ -5,7 +5,7 @@ infrastructure) can share the struct definitions without loading the HIP library
 """
 import ctypes as C
 
-AFQ_ABI_VERSION = 2
+AFQ_ABI_VERSION = 3
 
 AFQ_OK = 0
 AFQ_ERR_INVALID_ARG = -1
@@ -67,7 +67,6 @@ class AfqResult(C.Structure):
         ("bc", C.POINTER(C.c_uint64)),
         ("nrec", C.POINTER(C.c_uint32)),
         ("flags", C.POINTER(C.c_uint8)),
-        ("mmrate", C.POINTER(C.c_double)),
         ("opaque", C.c_void_p),
     ]
 
@@ -122,7 +121,7 @@ EXPORTS = [
     "afq_infer",
     "afq_atac_dedup",
     "afq_atac_dedup_rad",
-    "afq_device_warmup", "afq_device_pci_bus_id", "afq_label_rehash_count", "afq_pool_regrow_count", "afq_em_resize_count", "afq_snappy_decode_device",
+    "afq_device_warmup", "afq_device_pci_bus_id", "afq_label_rehash_count", "afq_pool_regrow_count", "afq_em_resize_count",
     "afq_free",
     "afq_get_kernel_times",
     "afq_get_batch_stats",

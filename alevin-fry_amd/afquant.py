@@ -96,7 +96,6 @@ class QuantResult:
     bc: np.ndarray
     nrec: np.ndarray
     flags: np.ndarray
-    mmrate: np.ndarray
 
     @property
     def n_cells(self) -> int:
@@ -204,7 +203,7 @@ def result_from_c(res: AfqResult, owner=None) -> QuantResult:
     z = owner is not None
     out = QuantResult(int(res.first_cell_index), arr(res.cell_ptr, n + 1, np.uint64), arr(res.gene, nnz, np.uint32, z),
                       arr(res.val, nnz, np.float32, z), arr(res.bc, n, np.uint64), arr(res.nrec, n, np.uint32),
-                      arr(res.flags, n, np.uint8), arr(res.mmrate, n, np.float64))
+                      arr(res.flags, n, np.uint8))
     out._owner = owner
     return out
 
@@ -459,70 +458,3 @@ class Quantifier:
         finally:
             for q in (o_ptr, o_bc, o_ref, o_start, o_len, o_cnt):
                 self.lib.afq_free(q)
-
-
-# ---- snappy frame streams (map.collated.rad.sz) undone on the device: a building block, see include/afquant.h -----------------
-class SzFrame(C.Structure):
-    _fields_ = [("in_off", C.c_uint64), ("in_len", C.c_uint64), ("out_off", C.c_uint64), ("ulen", C.c_uint32), ("compressed", C.c_uint32)]
-
-
-def snappy_frame_plan(stream: bytes):
-    """The data chunks of a snappy frame stream as (in_off, in_len, out_off, ulen, compressed) and the decoded size - what
-    snap::read::FrameDecoder walks (src/quant.rs:373-395): stream identifier 0xff, compressed 0x00, uncompressed 0x01 chunks
-    (4-byte masked CRC-32C first), 0x80..0xfe skipped, 0x02..0x7f refused."""
-    b = memoryview(stream)
-    p, total, frames = 0, 0, []
-    if len(b) < 4 or b[0] != 0xFF:
-        raise ValueError("snappy stream does not start with its stream identifier")
-    while p < len(b):
-        if p + 4 > len(b):
-            raise ValueError("truncated snappy frame header")
-        typ, ln = b[p], b[p + 1] | (b[p + 2] << 8) | (b[p + 3] << 16)
-        p += 4
-        if p + ln > len(b):
-            raise ValueError("truncated snappy frame chunk")
-        if typ in (0x00, 0x01):
-            if ln < 4:
-                raise ValueError("snappy chunk too short")
-            body, blen = p + 4, ln - 4
-            if typ == 0x00:
-                ulen, shift, q = 0, 0, body
-                while True:
-                    if q >= body + blen or shift > 35:
-                        raise ValueError("corrupt snappy block")
-                    v = b[q]
-                    q += 1
-                    ulen |= (v & 0x7F) << shift
-                    if not v & 0x80:
-                        break
-                    shift += 7
-            else:
-                ulen = blen
-            if ulen > 65536:
-                raise ValueError("snappy chunk larger than the frame format's 65536-byte limit")
-            frames.append((body, blen, total, ulen, 1 if typ == 0x00 else 0))
-            total += ulen
-        elif typ == 0xFF:
-            if bytes(b[p:p + ln]) != b"sNaPpY":
-                raise ValueError("bad snappy stream identifier")
-        elif 0x02 <= typ <= 0x7F:
-            raise ValueError("unskippable reserved snappy chunk")
-        p += ln
-    return frames, total
-
-
-def snappy_decode_device(stream: bytes, device: int = 0) -> np.ndarray:
-    """A snappy frame stream decoded by the device kernel (one wave per chunk): compressed bytes over, decoded bytes back."""
-    lib = load_library()
-    frames, total = snappy_frame_plan(stream)
-    arr = (SzFrame * max(1, len(frames)))(*[SzFrame(*f) for f in frames])
-    src = np.frombuffer(bytes(stream), dtype=np.uint8)
-    out = np.empty(total, np.uint8)
-    lib.afq_snappy_decode_device.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(SzFrame), C.c_size_t, C.c_uint64, C.c_void_p]
-    lib.afq_snappy_decode_device.restype = C.c_int
-    lib.afq_last_error.restype = C.c_char_p
-    lib.afq_last_error.argtypes = [C.c_void_p]
-    rc = lib.afq_snappy_decode_device(device, src.ctypes.data_as(C.c_void_p), src.nbytes, arr, len(frames), total, out.ctypes.data_as(C.c_void_p))
-    if rc != 0:
-        raise AfqError(rc, (lib.afq_last_error(None) or b"").decode())
-    return out

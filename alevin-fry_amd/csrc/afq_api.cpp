@@ -89,7 +89,6 @@ struct HostResult {
     PinnedVec<uint32_t> gene;
     PinnedVec<float> val;
     std::vector<uint8_t> flags;
-    std::vector<double> mmrate;
     // -d: gene-level equivalence classes per cell (cfg.dump_eq): CSR cell -> classes -> label words
     std::vector<uint64_t> eq_cell_ptr, eq_label_ptr;
     std::vector<uint32_t> eq_labels, eq_count;
@@ -99,7 +98,7 @@ struct HostResult {
     std::vector<float> bm_val, bv_val;
     ResultPool* pool = nullptr;
     void clear() {
-        cell_ptr.clear(); bc.clear(); nrec.clear(); flags.clear(); mmrate.clear(); gene.n = 0; val.n = 0;
+        cell_ptr.clear(); bc.clear(); nrec.clear(); flags.clear(); gene.n = 0; val.n = 0;
         eq_cell_ptr.clear(); eq_label_ptr.clear(); eq_labels.clear(); eq_count.clear();
         bm_ptr.clear(); bv_ptr.clear(); bm_col.clear(); bv_col.clear(); bm_val.clear(); bv_val.clear();
     }
@@ -846,7 +845,7 @@ int finish_range(afq_ctx* c, int slot) {
             case kErrUmiWide: return fail(c, AFQ_ERR_UNSUPPORTED, cell + "UMI wider than 22 nt is not supported");
             case kErrSlotRange: return fail(c, AFQ_ERR_BAD_INPUT, cell + "resolved column >= num_rows");
             case kErrLabelHash: return fail(c, AFQ_ERR_UNSUPPORTED, cell + "two ref lists share a 62-bit label hash under four different hash functions");
-            case kErrPugLimit: return fail(c, AFQ_ERR_UNSUPPORTED, cell + "a device-side PUG limit was exceeded (2^22 reads in the cell - 2^20 under gene-level labels or a UMI field over 4 bytes -, a component of more than 4096 vertices under a raised --large-graph-thresh, or a vertex with an empty label)");
+            case kErrPugLimit: return fail(c, AFQ_ERR_UNSUPPORTED, cell + "a device-side PUG limit was exceeded: 2^22 reads in the cell; 2^20 reads when the cell needs the one-workgroup kernel (gene-level labels, a UMI field over 4 bytes, or a cell of 2^20..2^22 reads the partition kernels handed back: a UMI partition over 256 reads or a component over 64 vertices / over --large-graph-thresh); a component of more than 4096 vertices under a raised --large-graph-thresh; or a vertex with an empty label");
             case kErrPugPool: return fail(c, AFQ_ERR_OOM, cell + "PUG edge pool exhausted");
             case kErrInternal: return fail(c, AFQ_ERR_HIP, cell + "internal consistency check failed in the parsimony kernels");
             default: return fail(c, AFQ_ERR_HIP, cell + "device error code " + std::to_string(st.err_code) + (st.err_code >= 20 ? " (internal consistency check of the parsimony kernels)" : ""));
@@ -1042,7 +1041,6 @@ int finish_range(afq_ctx* c, int slot) {
         R.bc.push_back(bc[i]);
         R.nrec.push_back(nrec);
         R.flags.push_back(f);
-        R.mmrate.push_back(0.0);
     }
     harvest_timers(c, &B.launches);
     hc.lap("finish: host result");
@@ -1171,54 +1169,6 @@ uint64_t afq_em_resize_count(const afq_ctx* ctx) { return ctx ? ctx->n_em_resize
 int afq_device_pci_bus_id(int device, char* out, size_t out_len) {
     if (!out || out_len < 13) return AFQ_ERR_INVALID_ARG;
     if (hipDeviceGetPCIBusId(out, (int)out_len, device) != hipSuccess) { (void)hipGetLastError(); return AFQ_ERR_NO_DEVICE; }
-    return 0;
-}
-
-// The data chunks of a snappy frame stream undone on the device, one wave per chunk (csrc/afq_snappy.hip).  A building block
-// and its check: the compressed bytes go over, the decoded bytes come back; the front-end (afq_host.cpp) still decodes on the
-// host - what it takes to feed afq_submit_device from here is in DESIGN.md 9.1.
-int afq_snappy_decode_device(int device, const uint8_t* comp, size_t n_comp, const afq_sz_frame* frames, size_t n_frames, uint64_t out_bytes, uint8_t* out) {
-    static_assert(sizeof(afq_sz_frame) == sizeof(SzFrame), "afq_sz_frame and the kernels' SzFrame are one layout");
-    if ((!comp && n_comp) || (!frames && n_frames) || (!out && out_bytes)) return fail(nullptr, AFQ_ERR_INVALID_ARG, "null argument");
-    if (n_frames >= 0xFFFFFFF0ull) return fail(nullptr, AFQ_ERR_UNSUPPORTED, "too many snappy chunks for one call");
-    for (size_t i = 0; i < n_frames; ++i) {
-        const afq_sz_frame& f = frames[i];
-        if (f.in_off > n_comp || f.in_len > n_comp - f.in_off || f.ulen > 65536u || f.out_off > out_bytes || f.ulen > out_bytes - f.out_off ||
-            (!f.compressed && f.in_len != f.ulen))
-            return fail(nullptr, AFQ_ERR_BAD_INPUT, "snappy chunk " + std::to_string(i) + ": out of range of the stream or of the output");
-    }
-    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, AFQ_ERR_NO_DEVICE, "no such device"); }
-    if (!n_frames) return 0;
-    uint8_t *d_comp = nullptr, *d_out = nullptr;
-    SzFrame* d_fr = nullptr;
-    DevStatus* d_st = nullptr;
-    DevStatus st{};
-    hipError_t e = hipMalloc(&d_comp, n_comp + 16);
-    if (e == hipSuccess) e = hipMalloc(&d_out, out_bytes + 16);
-    if (e == hipSuccess) e = hipMalloc(&d_fr, sizeof(SzFrame) * n_frames);
-    if (e == hipSuccess) e = hipMalloc(&d_st, sizeof(DevStatus));
-    if (e == hipSuccess) e = hipMemcpy(d_comp, comp, n_comp, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_fr, frames, sizeof(SzFrame) * n_frames, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(d_st, 0, sizeof(DevStatus));
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    const bool timed = std::getenv("AFQ_HOST_TIMING") != nullptr;
-    if (timed && e == hipSuccess) { e = hipEventCreate(&ev0); if (e == hipSuccess) e = hipEventCreate(&ev1); if (e == hipSuccess) e = hipEventRecord(ev0, nullptr); }
-    if (e == hipSuccess) { launch_snappy_frames(nullptr, d_comp, d_fr, (uint32_t)n_frames, d_out, d_st); e = hipGetLastError(); }
-    if (timed && e == hipSuccess) e = hipEventRecord(ev1, nullptr);
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (timed && e == hipSuccess) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess)
-            std::fprintf(stderr, "[afq host] snappy decode: %zu chunks, %.1f MB -> %.1f MB, kernel %.3f ms (%.1f GB/s of output)\n", n_frames, (double)n_comp / 1e6,
-                         (double)out_bytes / 1e6, ms, ms > 0 ? (double)out_bytes / (ms * 1e6) : 0.0);
-    }
-    if (ev0) (void)hipEventDestroy(ev0);
-    if (ev1) (void)hipEventDestroy(ev1);
-    if (e == hipSuccess) e = hipMemcpy(&st, d_st, sizeof(st), hipMemcpyDeviceToHost);
-    if (e == hipSuccess && !st.err_code && out_bytes) e = hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost);
-    (void)hipFree(d_comp); (void)hipFree(d_out); (void)hipFree(d_fr); (void)hipFree(d_st);
-    if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, e == hipErrorOutOfMemory ? AFQ_ERR_OOM : AFQ_ERR_HIP, std::string("snappy decode: ") + hipGetErrorString(e)); }
-    if (st.err_code) return fail(nullptr, AFQ_ERR_BAD_INPUT, "corrupt snappy block in chunk " + std::to_string(st.err_cell));
     return 0;
 }
 
@@ -1441,7 +1391,6 @@ int afq_collect(afq_ctx* c, afq_result* out) {
     out->bc = R->bc.data();
     out->nrec = R->nrec.data();
     out->flags = R->flags.data();
-    out->mmrate = R->mmrate.data();
     out->opaque = R;
     return 0;
 }
@@ -1555,12 +1504,12 @@ int afq_infer(afq_ctx* c, const uint32_t* eq_labels, const uint64_t* eq_label_pt
             if (a > 0.0f) { R->gene.p[o] = col[wp[i] * wmul + k]; R->val.p[o] = a; ++o; }
         }
         R->cell_ptr.push_back(o);
-        R->bc.push_back(0); R->nrec.push_back(0); R->flags.push_back(0); R->mmrate.push_back(0.0);
+        R->bc.push_back(0); R->nrec.push_back(0); R->flags.push_back(0);
     }
     std::memset(out, 0, sizeof(*out));
     out->n_cells = n_cells; out->nnz = tot;
     out->cell_ptr = R->cell_ptr.data(); out->gene = R->gene.p; out->val = R->val.p;
-    out->bc = R->bc.data(); out->nrec = R->nrec.data(); out->flags = R->flags.data(); out->mmrate = R->mmrate.data();
+    out->bc = R->bc.data(); out->nrec = R->nrec.data(); out->flags = R->flags.data();
     out->opaque = R;
     return 0;
 }

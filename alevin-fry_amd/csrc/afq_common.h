@@ -88,7 +88,6 @@ constexpr uint32_t kErrLabelHash = 6;    // two different ref lists with the sam
 constexpr uint32_t kErrPugLimit = 7;     // a PUG size limit of the device path was exceeded
 constexpr uint32_t kErrPugPool = 8;      // edge pool exhausted
 constexpr uint32_t kErrInternal = 9;     // a consistency check of the device code failed (a bug, never the input)
-constexpr uint32_t kErrSnappy = 10;      // a snappy block that does not decode to the length its chunk announces (err_cell = chunk index)
 
 __host__ __device__ inline bool mode_is_pug(uint32_t m) { return m >= kModePug && m <= kModePugGeneEm; }
 __host__ __device__ inline bool mode_pug_gene(uint32_t m) { return m == kModePugGene || m == kModePugGeneEm; }

@@ -66,9 +66,6 @@ void launch_gather_headers(hipStream_t s, const uint8_t* bytes, size_t n_bytes, 
                            uint32_t n_cells, uint32_t* hdr);
 int launch_decode(hipStream_t s, const DecodeArgs& a, uint32_t bw, uint32_t uw);
 // chunks with 1/2-byte barcode or UMI fields rewritten with 4-byte ones (meta: the widened chunks; src_off: where each cell's chunk sits in src)
-// one data chunk of a snappy frame stream (= afq_sz_frame of include/afquant.h)
-struct SzFrame { uint64_t in_off, in_len, out_off; uint32_t ulen, compressed; };
-void launch_snappy_frames(hipStream_t s, const uint8_t* comp, const SzFrame* frames, uint32_t n_frames, uint8_t* out, DevStatus* st);
 
 void launch_widen(hipStream_t s, const uint8_t* src, size_t n_src, const uint64_t* src_off, const CellMeta* meta, uint32_t n_cells,
                   uint32_t bw, uint32_t uw, uint32_t ebw, uint32_t euw, uint8_t* dst, DevStatus* st, uint32_t bsplit = 0);

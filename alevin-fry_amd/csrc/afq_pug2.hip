@@ -500,6 +500,7 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
     WAVE_SYNC();
 }
 __global__ __launch_bounds__(256) void k_p2_search(P2Args A) {
+    if (A.st->err_code) return;   // an earlier kernel of the range failed (e.g. kErrLabelHash in k_p2_part, which then leaves its partition's vertices unwritten): nothing behind it may read that state - the host runs the range again or reports the error
     __shared__ SearchLds s_lds[4];
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     for (uint32_t gp = blockIdx.x * 4 + wv; gp < A.n_parts; gp += gridDim.x * 4) search_body(A, gp, s_lds[wv], lane);
@@ -584,6 +585,7 @@ __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t
     WAVE_SYNC();
 }
 __global__ __launch_bounds__(256) void k_p2_lone(P2Args A) {
+    if (A.st->err_code) return;   // an earlier kernel of the range failed (e.g. kErrLabelHash in k_p2_part, which then leaves its partition's vertices unwritten): nothing behind it may read that state - the host runs the range again or reports the error
     __shared__ uint32_t s_cls4[4][512];
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     for (uint32_t gp = blockIdx.x * 4 + wv; gp < A.n_parts; gp += gridDim.x * 4) lone_body(A, gp, s_cls4[wv], lane);
@@ -605,6 +607,7 @@ constexpr uint32_t kGLds = 3 * kGTab + 128;   // words of the phase-shared LDS b
 constexpr uint32_t kCatPair = 1, kCatTiny = 2, kCatMid = 3;
 
 __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
+    if (A.st->err_code) return;   // an earlier kernel of the range failed (e.g. kErrLabelHash in k_p2_part, which then leaves its partition's vertices unwritten): nothing behind it may read that state - the host runs the range again or reports the error
     __shared__ __attribute__((aligned(16))) uint32_t s_big[kGLds];
     __shared__ uint32_t s_ws[kGNT / 64];
     __shared__ uint32_t s_cnt[4];

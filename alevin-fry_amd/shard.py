@@ -38,7 +38,7 @@ def concat_results(parts) -> QuantResult:
     if not parts:
         z = np.zeros(0)
         return QuantResult(0, np.zeros(1, np.uint64), z.astype(np.uint32), z.astype(np.float32), z.astype(np.uint64),
-                           z.astype(np.uint32), z.astype(np.uint8), z.astype(np.float64))
+                           z.astype(np.uint32), z.astype(np.uint8))
     ptr = [np.zeros(1, np.uint64)]
     base = np.uint64(0)
     for p in parts:
@@ -46,14 +46,14 @@ def concat_results(parts) -> QuantResult:
         base = base + p.cell_ptr[-1]
     cat = lambda f: np.concatenate([getattr(p, f) for p in parts])
     return QuantResult(parts[0].first_cell_index, np.concatenate(ptr), cat("gene"), cat("val"), cat("bc"),
-                       cat("nrec"), cat("flags"), cat("mmrate"))
+                       cat("nrec"), cat("flags"))
 
 
 def gather_results(local: QuantResult | None, dist, dst: int = 0):
     """Host-side gather of the shards on `dst` (the only communication the path has)."""
     world = dist.get_world_size()
     payload = None if local is None else (local.first_cell_index, np.asarray(local.cell_ptr), np.asarray(local.gene).copy(),
-                                          np.asarray(local.val).copy(), local.bc, local.nrec, local.flags, local.mmrate)
+                                          np.asarray(local.val).copy(), local.bc, local.nrec, local.flags)
     out = [None] * world if dist.get_rank() == dst else None
     dist.gather_object(payload, out, dst=dst)
     if dist.get_rank() != dst:

@@ -69,7 +69,7 @@ def parse_args():
                     help="configs3: weak = c3-cells per GPU, strong = c3-cells in total, sharded over the ranks")
     ap.add_argument("--frags-per-cell", type=int, default=20000, help="atac")
     ap.add_argument("--atac-cells", type=int, default=10000, help="atac: cells per GPU (configs[4]: 10^4 x 2*10^4 records)")
-    ap.add_argument("--also", default="auto", help="comma list of extra legs (configs2,configs1_tail,configs2_tail,configs3,atac,e2e,cli,reference,sz_decode), 'auto' or 'none'")
+    ap.add_argument("--also", default="auto", help="comma list of extra legs (configs2,configs1_tail,configs2_tail,configs3,atac,e2e,cli,reference), 'auto' or 'none'")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) by default; gloo + --share-gpu exercises the N>1 logic on a 1-GPU box")
@@ -540,25 +540,6 @@ def run_e2e_ranks(D, args, pkg, sn, rad, q, steps):
             "imbalance_max_over_mean_time": round(mx[0] / (tot[2] / D.world), 3), "steps": steps}
 
 
-def run_sz_decode():
-    """The device snappy-frame decoder (csrc/afq_snappy.hip; not yet wired into the front-end) on a collated RAD that
-    Google's snappy compressed: profiles/run_r03_snappy.py in a process of its own (it sets AFQ_HOST_TIMING, which would
-    clutter this one), the kernel time read off the library's own report."""
-    import re
-    import subprocess
-
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "run_r03_snappy.py"), "400"], capture_output=True, text=True, timeout=180)
-    if r.returncode != 0:
-        raise RuntimeError((r.stderr or r.stdout)[-300:])
-    m = re.findall(r"snappy decode: (\d+) chunks, ([0-9.]+) MB -> ([0-9.]+) MB, kernel ([0-9.]+) ms", r.stderr)
-    if not m or "decoded bytes equal the input" not in r.stdout:
-        raise RuntimeError("no kernel time in the decoder's report")
-    chunks, comp_mb, out_mb, ms = m[-1]
-    return {"what": "k_snappy_frames: a collated RAD through Google's snappy (pyarrow), 64 KiB chunks, decoded on the device and compared with the input",
-            "value": round(float(out_mb) / float(ms), 2), "unit": "GB/s of decoded output", "kernel_ms": float(ms), "chunks": int(chunks),
-            "compressed_MB": float(comp_mb), "decoded_MB": float(out_mb), "ratio": round(float(out_mb) / float(comp_mb), 2)}
-
-
 def write_rad_dir(pkg, rad, host_bytes, path):
     names = [f"t{i}" for i in range(len(rad.tid_to_gid))]
     if rad.usa:
@@ -644,7 +625,7 @@ def main():
     if args.workload == "atac":
         return bench_atac(args, pkg, D)
     also = args.also.split(",") if args.also not in ("auto", "none") else \
-        ([] if args.also == "none" else (["configs2", "configs1_tail", "configs2_tail", "configs3", "atac", "e2e", "cli", "reference", "sz_decode"] if D.world == 1 else ["e2e", "configs3", "atac"]))
+        ([] if args.also == "none" else (["configs2", "configs1_tail", "configs2_tail", "configs3", "atac", "e2e", "cli", "reference"] if D.world == 1 else ["e2e", "configs3", "atac"]))
     also = [a for a in also if a and a != args.workload]
     legs = {}
     out = None
@@ -707,8 +688,6 @@ def main():
         host = None
         if workdir:
             shutil.rmtree(workdir, ignore_errors=True)
-        if "sz_decode" in also and D.world == 1:
-            leg("sz_decode", run_sz_decode)
         if "configs2" in also and D.world == 1:
             def f():
                 o2, r2, q2 = run_pbmc(D, args, pkg, sn, True, "parsimony-em", max(1, min(2, args.steps)), 1,

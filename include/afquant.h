@@ -23,13 +23,21 @@
 extern "C" {
 #endif
 
-#define AFQ_ABI_VERSION 2
+#define AFQ_ABI_VERSION 3   /* 3: afq_result.mmrate and afq_snappy_decode_device are gone, afq_em_resize_count is new */
 
 /* error codes */
 #define AFQ_OK 0
 #define AFQ_ERR_INVALID_ARG (-1)  /* null pointer, bad enum, inconsistent sizes  */
 #define AFQ_ERR_BAD_INPUT (-2)    /* malformed chunk bytes / ref id out of range */
 #define AFQ_ERR_UNSUPPORTED (-3)  /* valid request the device path cannot take   */
+/* What AFQ_ERR_UNSUPPORTED stands for today (the reference has none of these limits, quant.rs:733-757; never approximated, the
+ * whole batch is refused and afq_last_error names the cell):
+ *   - UMIs over 22 nt, gene-id spaces over 2^20, more than two barcode levels;
+ *   - parsimony: a cell of 2^22 reads or more; a cell of 2^20 .. 2^22 reads goes through the partition-parallel kernels and is
+ *     fine as long as they can finish it - when they have to hand it to the one-workgroup kernel (a UMI partition over 256
+ *     reads: skewed or very short UMIs; a connected component over 64 vertices or over --large-graph-thresh; gene-level labels
+ *     or an 8-byte UMI field send every cell there) that kernel's 2^20-read limit applies;
+ *   - parsimony: a component over 4096 vertices under a --large-graph-thresh raised beyond that. */
 #define AFQ_ERR_HIP (-4)          /* a HIP runtime call failed                   */
 #define AFQ_ERR_NO_DEVICE (-5)    /* no usable gfx950 device                     */
 #define AFQ_ERR_STATE (-6)        /* call sequence error (collect before submit) */
@@ -114,7 +122,8 @@ typedef struct afq_result {
     const uint64_t* bc;       /* [n_cells] collate_key of the cell's first record (quant.rs:757)  */
     const uint32_t* nrec;     /* [n_cells] records in the chunk                                   */
     const uint8_t* flags;     /* [n_cells] AFQ_CELL_*                                             */
-    const double* mmrate;     /* [n_cells] multi-mapping rate, `trivial` only (quant.rs:936) else 0 */
+    /* (`trivial` also computes a multi-mapping rate in the reference, pugutils.rs:909 - stored at quant.rs:936 and never read
+       or written anywhere: it is not part of the result) */
     void* opaque;
 } afq_result;
 
@@ -280,20 +289,6 @@ uint64_t afq_pool_regrow_count(const afq_ctx* ctx);
 /* EM resolutions: ranges whose EM did not fit the device scratch set aside for it ahead of time and was sized on the host
  * instead (one extra trip to the host for that range; results identical).  Diagnostics only. */
 uint64_t afq_em_resize_count(const afq_ctx* ctx);
-
-/* One data chunk of a snappy frame stream (the format of map.collated.rad.sz: src/quant.rs:373-395, collate.rs:550-554):
-   where its body lies in the stream (after the chunk's 4-byte header and 4-byte CRC), where its bytes go in the output,
-   how many they are (at most 65536) and whether the body is a snappy block (chunk type 0x00) or the bytes themselves (0x01). */
-typedef struct afq_sz_frame {
-    uint64_t in_off, in_len, out_off;
-    uint32_t ulen, compressed;
-} afq_sz_frame;
-/* Undoes the listed chunks on `device`, one wavefront per chunk (csrc/afq_snappy.hip), and returns the out_bytes decoded bytes
-   in `out` (host memory).  The same acceptance rules as snap's decoder - a block that does not decode to exactly its announced
-   length is AFQ_ERR_BAD_INPUT, afq_last_error(NULL) names the chunk; the chunks' CRC-32C words are not checked.  A building
-   block: the front-end of include/afquant_host.h still decodes .rad.sz on the host. */
-int afq_snappy_decode_device(int device, const uint8_t* comp, size_t n_comp, const afq_sz_frame* frames, size_t n_frames, uint64_t out_bytes,
-                             uint8_t* out);
 
 /* Brings the HIP runtime up on `device` (first-call initialisation) - a host can call it from a side thread while it parses its
    inputs.  Returns 0 or AFQ_ERR_NO_DEVICE. */

@@ -1057,7 +1057,7 @@ int ora_quant(const afq_config* cfg, const uint32_t* t2g, uint32_t ref_count, co
     out->n_cells = n_cells; out->first_cell_index = first_cell_index; out->nnz = R->gene.size();
     out->cell_ptr = R->cell_ptr.data(); out->gene = R->gene.data(); out->val = R->val.data();
     out->bc = R->bc.data(); out->nrec = R->nrec.data(); out->flags = R->flags.data();
-    out->mmrate = R->mmrate.data(); out->opaque = R;
+    out->opaque = R;   // (R->mmrate: `trivial`'s multi-mapping rate, kept for ora_result_mmrate; the reference never reads its own, quant.rs:936)
     return 0;
 }
 
@@ -1100,7 +1100,7 @@ int ora_quant_mt(const afq_config* cfg, const uint32_t* t2g, uint32_t ref_count,
     out->n_cells = n_cells; out->first_cell_index = first_cell_index; out->nnz = R->gene.size();
     out->cell_ptr = R->cell_ptr.data(); out->gene = R->gene.data(); out->val = R->val.data();
     out->bc = R->bc.data(); out->nrec = R->nrec.data(); out->flags = R->flags.data();
-    out->mmrate = R->mmrate.data(); out->opaque = R;
+    out->opaque = R;   // (R->mmrate: `trivial`'s multi-mapping rate, kept for ora_result_mmrate; the reference never reads its own, quant.rs:936)
     return 0;
 }
 
@@ -1112,6 +1112,8 @@ void ora_set_tie_break(int mode) { g_tie_desc = mode == 1 || mode == 2 ? mode : 
 void ora_set_em_order(uint64_t seed) { g_em_perm = seed; }
 // 0 = the reference's f32 sums (canonical class order); 1 = the order-free fixed-point accumulation of the device EM (em_update_fixed)
 void ora_set_em_arith(int mode) { g_em_arith = mode == 1 ? 1 : 0; }
+// `trivial`: the multi-mapping rate get_num_molecules_trivial_discard_all_ambig returns next to the counts (pugutils.rs:909)
+const double* ora_result_mmrate(const afq_result* r) { return r && r->opaque ? ((Result*)r->opaque)->mmrate.data() : nullptr; }
 const uint32_t* ora_result_em_iters(const afq_result* r) { return r && r->opaque ? ((Result*)r->opaque)->em_iters.data() : nullptr; }
 
 // cfg.dump_eq: per-cell gene-level classes (same container as afq_result_eqclasses of include/afquant.h)
