@@ -220,6 +220,7 @@ def load_library(path: str = LIB_PATH):
     # soname; a process must hold exactly one HIP/HSA runtime, so when torch is installed it is
     # imported first and the library binds to the runtime torch already mapped (a torch-free
     # host gets /opt/rocm's).  See DESIGN.md "one HIP runtime per process".
+    os.environ.setdefault("GPU_FORCE_BLIT_COPY_SIZE", "0")   # copies on the DMA engines, not as blit kernels next to the path's own (only if the HIP runtime is not up yet)
     try:
         import torch  # noqa: F401
 

@@ -145,7 +145,10 @@ struct RangeState {
         d_lab_cnt, d_em_off, d_em_scratch, d_em_nnz, d_pug_cells, d_rd_off, d_rd_h, d_rd_u, d_rd_o, d_pug_scr_off,
         d_pug_scratch, d_epool, d_epool_cur, d_alt, d_hist_cells, d_fix, d_em_hdr, d_em_order, d_eq_ncls, d_eq_nw, d_eq_cptr,
         d_p2_small, d_eq_wptr, d_eq_len, d_eq_cnt, d_eq_lab, d_bt_off, d_bt_scratch, d_bt_ns, d_bt_col, d_bt_mean, d_bt_var, d_bt_sptr, d_bt_ccol,
-        d_bt_cmean, d_bt_cvar, d_em2_off, d_em2_scratch, d_em2_tiers;
+        d_bt_cmean, d_bt_cvar, d_em2_off, d_em2_scratch, d_em2_tiers, d_arena;
+    PinnedVec<uint8_t> h_arena;   // the range's small uploads, gathered (RangeInit)
+    DevBuf d_pack;
+    PinnedVec<uint32_t> h_pack;   // what the host reads when the range is done (k_pack_small), landed by the range's own stream
     ResolveArgs last_ra{};
     std::vector<CellMeta> meta;
     std::vector<uint2> tile_desc;   // per scatter tile: (cell, tile index inside the cell)
@@ -162,7 +165,7 @@ struct RangeState {
                 &d_cell_bc, &d_bdesc, &d_lab, &d_lab_cnt, &d_em_off, &d_em_scratch, &d_em_nnz, &d_pug_cells, &d_rd_off, &d_rd_h,
                 &d_rd_u, &d_rd_o, &d_pug_scr_off, &d_pug_scratch, &d_epool, &d_epool_cur, &d_p2_small, &d_alt, &d_hist_cells, &d_fix, &d_em_hdr, &d_em_order,
                 &d_eq_ncls, &d_eq_nw, &d_eq_cptr, &d_eq_wptr, &d_eq_len, &d_eq_cnt, &d_eq_lab, &d_bt_off, &d_bt_scratch, &d_bt_ns, &d_bt_col,
-                &d_bt_mean, &d_bt_var, &d_bt_sptr, &d_bt_ccol, &d_bt_cmean, &d_bt_cvar, &d_em2_off, &d_em2_scratch, &d_em2_tiers};
+                &d_bt_mean, &d_bt_var, &d_bt_sptr, &d_bt_ccol, &d_bt_cmean, &d_bt_cvar, &d_em2_off, &d_em2_scratch, &d_em2_tiers, &d_arena, &d_pack};
     }
 };
 
@@ -449,6 +452,44 @@ static uint32_t resolve_sort_only(uint64_t n_ref_words, uint64_t n_records) {
     return n_ref_words >= 2 * n_records ? 1u : 0u;
 }
 
+// The clears and small uploads of one range, collected and issued as ONE pinned-arena H2D copy + ONE kernel (k_range_init).
+struct RangeInit {
+    struct Pending { void* dst; const void* src; size_t bytes; };
+    std::vector<Pending> ops;
+    void zero(void* dst, size_t bytes) { if (bytes) ops.push_back({dst, nullptr, bytes}); }
+    void upload(void* dst, const void* src, size_t bytes) { if (bytes) ops.push_back({dst, src, bytes}); }
+    int flush(afq_ctx* c, RangeState& B, hipStream_t s);
+};
+int RangeInit::flush(afq_ctx* c, RangeState& B, hipStream_t s) {
+    size_t total = 0;
+    for (const Pending& o : ops) if (o.src) total += (o.bytes + 15) & ~size_t(15);
+    if (total) {
+        B.h_arena.n = 0;
+        HIP_TRY(c, B.h_arena.reserve(total));
+        HIP_TRY(c, B.d_arena.ensure(total));
+    }
+    size_t at = 0;
+    RangeInitOps k{};
+    auto launch = [&]() { if (k.n) launch_range_init(s, k, B.d_arena.as<uint8_t>()); k.n = 0; };
+    std::vector<RangeInitOp> all;
+    for (const Pending& o : ops) {
+        if (o.src) {
+            std::memcpy(B.h_arena.p + at, o.src, o.bytes);
+            all.push_back({o.dst, (uint64_t)at, (uint64_t)o.bytes});
+            at += (o.bytes + 15) & ~size_t(15);
+        } else all.push_back({o.dst, ~0ull, (uint64_t)o.bytes});
+    }
+    if (total) HIP_TRY(c, hipMemcpyAsync(B.d_arena.p, B.h_arena.p, total, hipMemcpyHostToDevice, s));   // (pinned source: the stream sync behind the uploads covers its reuse)
+    for (const RangeInitOp& o : all) {
+        k.op[k.n++] = o;
+        if (k.n == kRangeInitOps) launch();
+    }
+    launch();
+    HIP_TRY(c, hipGetLastError());
+    ops.clear();
+    return 0;
+}
+
 // Plan + enqueue one range of cells on the context's stream.
 int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint32_t hash_try = 0, uint32_t pool_try = 0) {
     HostClock hc;
@@ -615,32 +656,33 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
 
     hc.lap("run: plan + ensure buffers");
     hipStream_t s = B.stream;
+    RangeInit init;   // every clear and every small upload of the range: one H2D copy + one kernel (flushed below)
     if (par) {
-        HIP_TRY(c, hipMemcpyAsync(B.d_slab_prefix.p, slab_prefix.data(), 4ull * (n + 1), hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemsetAsync(B.d_chk.p, 0, sizeof(CellChk) * n, s));
-        HIP_TRY(c, hipMemsetAsync(B.d_cell_nkeys.p, 0, 4ull * n, s));
+        init.upload(B.d_slab_prefix.p, slab_prefix.data(), 4ull * (n + 1));
+        init.zero(B.d_chk.p, sizeof(CellChk) * n);
+        init.zero(B.d_cell_nkeys.p, 4ull * n);
     }
-    HIP_TRY(c, hipMemcpyAsync(B.d_meta.p, B.meta.data(), sizeof(CellMeta) * n, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(B.d_bucket_cell.p, bucket_cell.data(), 4 * n_buckets, hipMemcpyHostToDevice, s));
+    init.upload(B.d_meta.p, B.meta.data(), sizeof(CellMeta) * n);
+    init.upload(B.d_bucket_cell.p, bucket_cell.data(), 4 * n_buckets);
     if (n_multi) {
-        HIP_TRY(c, hipMemcpyAsync(B.d_multi_cells.p, multi.data(), 4ull * n_multi, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemcpyAsync(B.d_tile_desc.p, B.tile_desc.data(), 8ull * n_tiles, hipMemcpyHostToDevice, s));
+        init.upload(B.d_multi_cells.p, multi.data(), 4ull * n_multi);
+        init.upload(B.d_tile_desc.p, B.tile_desc.data(), 8ull * n_tiles);
     }
-    HIP_TRY(c, hipMemsetAsync(B.d_bucket_cnt.p, 0, 4 * n_buckets, s));
-    HIP_TRY(c, hipMemsetAsync(B.d_slab_ovf.p, 0, 4ull * n, s));
-    HIP_TRY(c, hipMemsetAsync(B.d_nnz.p, 0, 4ull * n, s));
-    HIP_TRY(c, hipMemsetAsync(B.d_ncols.p, 0, 4ull * n, s));
-    if (em) HIP_TRY(c, hipMemsetAsync(B.d_lab_cnt.p, 0, 8ull * n, s));
-    HIP_TRY(c, hipMemsetAsync(B.d_alt.p, 0, 4ull * n, s));
+    init.zero(B.d_bucket_cnt.p, 4 * n_buckets);
+    init.zero(B.d_slab_ovf.p, 4ull * n);
+    init.zero(B.d_nnz.p, 4ull * n);
+    init.zero(B.d_ncols.p, 4ull * n);
+    if (em) init.zero(B.d_lab_cnt.p, 8ull * n);
+    init.zero(B.d_alt.p, 4ull * n);
     if (!hist_cells.empty())
-        HIP_TRY(c, hipMemcpyAsync(B.d_hist_cells.p, hist_cells.data(), 4ull * hist_cells.size(), hipMemcpyHostToDevice, s));
+        init.upload(B.d_hist_cells.p, hist_cells.data(), 4ull * hist_cells.size());
     if (n_pug) {
-        HIP_TRY(c, hipMemcpyAsync(B.d_pug_cells.p, pug_cells.data(), 4ull * n_pug, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemcpyAsync(B.d_rd_off.p, rd_off.data(), 8ull * n, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemsetAsync(B.d_pug_scr_off.p, 0, 8, s));
-        HIP_TRY(c, hipMemsetAsync(B.d_epool_cur.p, 0, 8, s));
+        init.upload(B.d_pug_cells.p, pug_cells.data(), 4ull * n_pug);
+        init.upload(B.d_rd_off.p, rd_off.data(), 8ull * n);
+        init.zero(B.d_pug_scr_off.p, 8);
+        init.zero(B.d_epool_cur.p, 8);
         const P2Small L = p2_small_layout(n_p2, p2_parts, p2tiles.size(), n_pug);
-        HIP_TRY(c, hipMemsetAsync(B.d_p2_small.p, 0, 4 * L.zero_words, s));
+        init.zero(B.d_p2_small.p, 4 * L.zero_words);
         p2_up.assign(L.up_words, 0);
         uint32_t* up = p2_up.data() - L.up;
         up[L.fb_count] = (uint32_t)mono_cells.size();   // the one-workgroup kernel's list starts with the cells that go there directly
@@ -648,15 +690,16 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
         for (uint32_t j = 0; j < n_p2; ++j) up[L.order + j] = j;   // (p2cells is largest first already)
         if (n_p2) std::memcpy(up + L.cells, p2cells.data(), sizeof(P2Cell) * n_p2);
         if (!p2tiles.empty()) std::memcpy(up + L.tiles, p2tiles.data(), sizeof(uint2) * p2tiles.size());
-        HIP_TRY(c, hipMemcpyAsync(B.d_p2_small.as<uint32_t>() + L.up, p2_up.data(), 4 * L.up_words, hipMemcpyHostToDevice, s));
+        init.upload(B.d_p2_small.as<uint32_t>() + L.up, p2_up.data(), 4 * L.up_words);
     }
-    HIP_TRY(c, hipMemsetAsync(B.d_status.p, 0, sizeof(DevStatus), s));
-    HIP_TRY(c, hipMemsetAsync(B.d_bc.p, 0, 8ull * n, s));
+    init.zero(B.d_status.p, sizeof(DevStatus));
+    init.zero(B.d_bc.p, 8ull * n);
     // EM resolutions: the EM follows the range's kernels on the device (afq_em2.hip; k_em2_plan packs the cells' scratch slices from
     // the counts the kernels leave) - no trip to the host between resolution and EM.  Its scratch is set aside from an upper
     // bound of the cells' label areas (a fraction of it: real cells use a tenth); if that ever falls short the kernels return at
     // once and finish_range sizes the EM itself.  -d / -b read the classes off the canonical set-up and take that route too.
     uint64_t em2_cap = 0;
+    std::vector<uint32_t> em_order;
     const uint32_t na_em = g.usa_mode ? g.num_rows : g.num_genes;
     {
         const char* em_env = std::getenv("AFQ_EM_ORDER");
@@ -670,16 +713,19 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
         }
         static const double frac = [] { const char* e = std::getenv("AFQ_EM2_SCRATCH_FRAC"); const double v = e ? std::atof(e) : 0.0; return v > 0 && v <= 1 ? v : 0.35; }();   // (tests: a sliver, so that the fallback runs)
         em2_cap = (uint64_t)std::max(worst * frac, 4096.0);
-        std::vector<uint32_t> em_order(n);
+        em_order.resize(n);
         for (uint32_t i = 0; i < n; ++i) em_order[i] = i;
         std::stable_sort(em_order.begin(), em_order.end(), [&](uint32_t a, uint32_t b) { return B.meta[a].nrec > B.meta[b].nrec; });
         HIP_TRY(c, B.d_em_order.ensure(4ull * n));
-        HIP_TRY(c, hipMemcpyAsync(B.d_em_order.p, em_order.data(), 4ull * n, hipMemcpyHostToDevice, s));
+        init.upload(B.d_em_order.p, em_order.data(), 4ull * n);
+        HIP_TRY(c, B.d_em2_tiers.ensure(4ull * (8 + 5ull * n)));
+        init.zero(B.d_em2_tiers.p, 32);
         HIP_TRY(c, B.d_em_nnz.ensure(4ull * n));
         HIP_TRY(c, B.d_em2_off.ensure(8ull * (n + 1)));
         HIP_TRY(c, B.d_em2_scratch.ensure(4 * em2_cap + 16));
         HIP_TRY(c, B.d_em2_tiers.ensure(4ull * (8 + 5ull * n)));
     }
+    if (const int rc = init.flush(c, B, s)) return rc;
     // the host copies above are sourced from stack/vector memory: make sure they are consumed.  They only touch
     // this slot's buffers (idle since the range before last was finished), so they - and this wait - do not
     // depend on the range still executing in the other slot; the kernels below do:
@@ -804,6 +850,14 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     HIP_TRY(c, hipGetLastError());
     if (!B.kernels_done) HIP_TRY(c, hipEventCreateWithFlags(&B.kernels_done, hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(B.kernels_done, s));
+    {   // what finish_range reads first, on its way to pinned memory behind the kernels
+        const size_t words = kPackHdrWords + 5ull * n;
+        HIP_TRY(c, B.d_pack.ensure(4 * words));
+        HIP_TRY(c, B.h_pack.reserve(words));
+        launch_pack_small(s, B.d_status.as<DevStatus>(), B.em_inline ? B.d_em2_tiers.as<uint32_t>() + 7 : nullptr, B.d_alt.as<uint32_t>(), B.d_nnz.as<uint32_t>(),
+                          B.em_inline ? B.d_em_nnz.as<uint32_t>() : nullptr, B.d_bc.as<uint64_t>(), n, B.d_pack.as<uint32_t>());
+        HIP_TRY(c, hipMemcpyAsync(B.h_pack.p, B.d_pack.p, 4 * words, hipMemcpyDeviceToHost, s));
+    }
     hc.lap("run: enqueue kernels");
     B.last_ra = ra;
     B.cur = r;
@@ -825,7 +879,8 @@ int finish_range(afq_ctx* c, int slot) {
     HIP_TRY(c, hipStreamSynchronize(s));
     hc.lap("finish: wait for kernels");
     DevStatus st{};
-    HIP_TRY(c, hipMemcpy(&st, B.d_status.p, sizeof(st), hipMemcpyDeviceToHost));
+    std::memcpy(&st, B.h_pack.p, sizeof(st));   // (k_pack_small's block, copied out by the range's stream)
+    const uint32_t* const pk = B.h_pack.p + kPackHdrWords;
     if (st.err_code == kErrLabelHash && B.hash_try + 1 < kMaxHashTries) {   // same range, next hash function (the input bytes are still resident)
         c->n_label_rehash += 1;
         const int rc = run_range(c, B.cur, slot, nullptr, B.hash_try + 1, B.pool_try);
@@ -860,14 +915,13 @@ int finish_range(afq_ctx* c, int slot) {
                     c->cfg.resolution == AFQ_RES_PARSIMONY_GENE_EM;
     std::vector<uint32_t> alt(n);
     bool em2 = false;   // the EM ran in afq_em2.hip: the rows sit in its scratch
-    HIP_TRY(c, hipMemcpy(alt.data(), B.d_alt.p, 4ull * n, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(nnz.data(), B.d_nnz.p, 4ull * n, hipMemcpyDeviceToHost));
+    std::memcpy(alt.data(), pk, 4ull * n);
+    std::memcpy(nnz.data(), pk + n, 4ull * n);
     if (em && B.em_inline) {   // the EM ran behind the range's kernels: did its scratch suffice?
-        uint32_t short_of_scratch = 0;
-        HIP_TRY(c, hipMemcpy(&short_of_scratch, B.d_em2_tiers.as<uint32_t>() + 7, 4, hipMemcpyDeviceToHost));
+        const uint32_t short_of_scratch = B.h_pack.p[8];
         if (!short_of_scratch) {
             em2 = true;
-            HIP_TRY(c, hipMemcpy(nnz.data(), B.d_em_nnz.p, 4ull * n, hipMemcpyDeviceToHost));
+            std::memcpy(nnz.data(), pk + 2ull * n, 4ull * n);
         } else c->n_em_resized += 1;
     }
     if (em && !em2) {
@@ -999,7 +1053,7 @@ int finish_range(afq_ctx* c, int slot) {
             }
         }
     }
-    HIP_TRY(c, hipMemcpy(bc.data(), B.d_bc.p, 8ull * n, hipMemcpyDeviceToHost));
+    std::memcpy(bc.data(), pk + 3ull * n, 8ull * n);
     ptr[0] = 0;
     for (uint32_t i = 0; i < n; ++i) ptr[i + 1] = ptr[i] + nnz[i];
     const uint64_t tot = ptr[n];

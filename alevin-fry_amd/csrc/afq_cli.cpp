@@ -24,6 +24,10 @@ static void usage() {
 }
 
 int main(int argc, char** argv) {
+    // The rows of a range come back over PCIe while the next range's kernels run: that copy belongs on the DMA engines.  Left to
+    // itself the HIP runtime moves some of these copies with blit kernels on the compute queue, where they take a millisecond of
+    // the next decode (profiles/r04_timeline_*.txt); this keeps every copy on SDMA.  Read by the runtime at its first call.
+    setenv("GPU_FORCE_BLIT_COPY_SIZE", "0", 0);
     if (argc >= 2 && (std::strcmp(argv[1], "-h") == 0 || std::strcmp(argv[1], "--help") == 0)) { usage(); return 0; }
     if (argc >= 2 && (std::strcmp(argv[1], "-V") == 0 || std::strcmp(argv[1], "--version") == 0)) {
         std::printf("afquant-hip 0.1 (alevin-fry 0.18.0 quant / infer semantics, C ABI version %d)\n", AFQ_ABI_VERSION);

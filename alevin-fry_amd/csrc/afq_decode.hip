@@ -1303,6 +1303,66 @@ __global__ __launch_bounds__(256, 8) void k_decode_recs(const uint8_t* __restric
     flush_chk();
 }
 
+// ---------------------------------------------------------------------------
+// What a range needs before its first kernel, in ONE launch: every buffer that starts at zero is cleared and every small host
+// table is moved from the range's upload arena (one H2D copy) to its buffer.  It used to be some twenty hipMemsetAsync /
+// hipMemcpyAsync calls per range - each its own blit kernel on the compute queue.
+__global__ __launch_bounds__(256) void k_range_init(RangeInitOps ops, const uint8_t* __restrict__ arena) {
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x, gsz = (size_t)gridDim.x * 256;
+    for (uint32_t i = 0; i < ops.n; ++i) {
+        const RangeInitOp op = ops.op[i];
+        uint8_t* dst = reinterpret_cast<uint8_t*>(op.dst);
+        const uint8_t* src = op.src_off == ~0ull ? nullptr : arena + op.src_off;
+        const uintptr_t al = reinterpret_cast<uintptr_t>(dst) | (src ? reinterpret_cast<uintptr_t>(src) : 0);
+        if ((al & 15) == 0) {   // (hipMalloc'ed buffers and the arena's 16-byte slots: nearly always)
+            const size_t n16 = op.bytes / 16;
+            uint4* d4 = reinterpret_cast<uint4*>(dst);
+            const uint4* s4 = reinterpret_cast<const uint4*>(src);
+            for (size_t k = gid; k < n16; k += gsz) d4[k] = src ? s4[k] : make_uint4(0u, 0u, 0u, 0u);
+            for (size_t k = n16 * 16 + gid; k < op.bytes; k += gsz) dst[k] = src ? src[k] : (uint8_t)0;
+        } else if ((al & 3) == 0) {
+            const size_t n4 = op.bytes / 4;
+            uint32_t* d1 = reinterpret_cast<uint32_t*>(dst);
+            const uint32_t* s1 = reinterpret_cast<const uint32_t*>(src);
+            for (size_t k = gid; k < n4; k += gsz) d1[k] = src ? s1[k] : 0u;
+            for (size_t k = n4 * 4 + gid; k < op.bytes; k += gsz) dst[k] = src ? src[k] : (uint8_t)0;
+        } else {
+            for (size_t k = gid; k < op.bytes; k += gsz) dst[k] = src ? src[k] : (uint8_t)0;
+        }
+    }
+}
+void launch_range_init(hipStream_t s, const RangeInitOps& ops, const uint8_t* arena) {
+    if (!ops.n) return;
+    size_t most = 0;
+    for (uint32_t i = 0; i < ops.n; ++i) most = most > ops.op[i].bytes ? most : (size_t)ops.op[i].bytes;
+    size_t grid = (most / 16 + 255) / 256;
+    grid = grid < 1 ? 1 : (grid > 2048 ? 2048 : grid);
+    AFQ_LAUNCH(k_range_init, (uint32_t)grid, 256, s, ops, arena);
+}
+
+// The handful of per-cell words the host reads when a range is done (status block, flags, row lengths, barcodes), packed into one
+// buffer at the end of the range's kernels and copied out by ONE async D2H into pinned memory (it was four synchronous copies).
+// Layout (u32 words): [0..7] DevStatus, [8] the EM's "scratch too small" flag, [16, 16+n) alt, then n nnz, n EM nnz, 2n barcode.
+__global__ __launch_bounds__(256) void k_pack_small(const DevStatus* __restrict__ st, const uint32_t* __restrict__ em_flag, const uint32_t* __restrict__ alt,
+                                                    const uint32_t* __restrict__ nnz, const uint32_t* __restrict__ em_nnz,
+                                                    const uint64_t* __restrict__ bc, uint32_t n, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < sizeof(DevStatus) / 4) out[i] = reinterpret_cast<const uint32_t*>(st)[i];
+    if (i == 8) out[8] = em_flag ? *em_flag : 0u;
+    if (i < n) {
+        out[16 + i] = alt[i];
+        out[16 + n + i] = nnz[i];
+        out[16 + 2 * (size_t)n + i] = em_nnz ? em_nnz[i] : 0u;
+        const uint64_t b = bc[i];
+        out[16 + 3 * (size_t)n + 2 * (size_t)i] = (uint32_t)b;
+        out[16 + 3 * (size_t)n + 2 * (size_t)i + 1] = (uint32_t)(b >> 32);
+    }
+}
+void launch_pack_small(hipStream_t s, const DevStatus* st, const uint32_t* em_flag, const uint32_t* alt, const uint32_t* nnz, const uint32_t* em_nnz,
+                       const uint64_t* bc, uint32_t n, uint32_t* out) {
+    AFQ_LAUNCH(k_pack_small, (std::max(n, 16u) + 255) / 256, 256, s, st, em_flag, alt, nnz, em_nnz, bc, n, out);
+}
+
 void launch_gather_headers(hipStream_t s, const uint8_t* bytes, size_t n_bytes, const uint64_t* chunk_off,
                            uint32_t n_cells, uint32_t* hdr) {
     if (!n_cells) return;

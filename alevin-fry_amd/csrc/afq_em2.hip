@@ -725,7 +725,7 @@ void launch_em2(hipStream_t s, const ResolveArgs& a, uint32_t n_cells, uint64_t*
     uint32_t min_tier = 0;
     if (const char* e = std::getenv("AFQ_EM2_MIN_TIER")) min_tier = (uint32_t)std::min(4, std::max(0, std::atoi(e)));   // (tests; read per range)
     Em2Cfg cfg{a.usa, num_alphas, a.num_rows / 3, 2 * (a.num_rows / 3), init_uniform, (num_alphas + 31) / 32, min_tier};
-    (void)hipMemsetAsync(tiers, 0, 32, s);
+    if (!plan_cap_words) (void)hipMemsetAsync(tiers, 0, 32, s);   // (with a device-side plan the range's init kernel has cleared the counters)
     if (plan_cap_words) hipLaunchKernelGGL(k_em2_plan, dim3(1), dim3(1024), 0, s, a.nnz, a.lab_cnt, n_cells, a.usa, (unsigned long long)plan_cap_words, em_off, tiers, a.st);
     hipLaunchKernelGGL(k_em2_setup, dim3(n_cells), dim3(kSetupNT), 8 * cfg.nwb, s, a.meta, a.nnz, a.keys0, a.keys1, a.lab, a.lab_cnt, em_off,
                        scratch, out_nnz, em_order, tiers, n_cells, cfg);

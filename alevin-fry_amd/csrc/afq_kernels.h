@@ -62,6 +62,14 @@ struct ResolveArgs {
     uint32_t sort_only;          // reads of the range average two or more alignments: buckets are resolved by sorting, not through the UMI table
 };
 
+// one launch that clears / fills a range's small buffers (k_range_init): dst <- zeros (src_off == ~0) or arena[src_off ...)
+struct RangeInitOp { void* dst; uint64_t src_off; uint64_t bytes; };
+constexpr uint32_t kRangeInitOps = 32;
+struct RangeInitOps { RangeInitOp op[kRangeInitOps]; uint32_t n; };
+void launch_range_init(hipStream_t s, const RangeInitOps& ops, const uint8_t* arena);
+constexpr uint32_t kPackHdrWords = 16;   // k_pack_small: words in front of the per-cell arrays
+void launch_pack_small(hipStream_t s, const DevStatus* st, const uint32_t* em_flag, const uint32_t* alt, const uint32_t* nnz, const uint32_t* em_nnz,
+                       const uint64_t* bc, uint32_t n, uint32_t* out);
 void launch_gather_headers(hipStream_t s, const uint8_t* bytes, size_t n_bytes, const uint64_t* chunk_off,
                            uint32_t n_cells, uint32_t* hdr);
 int launch_decode(hipStream_t s, const DecodeArgs& a, uint32_t bw, uint32_t uw);

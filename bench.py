@@ -38,6 +38,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# (before the HIP runtime comes up with `import torch`: device<->host copies on the DMA engines, never as blit kernels on the compute
+#  queue - the rows of a range come back while the next range's kernels run; INTEGRATION.md "runtime settings")
+os.environ.setdefault("GPU_FORCE_BLIT_COPY_SIZE", "0")
 
 METRIC = "M reads/s through quant (PUG dedup+eq-class) at 1/2/4/8 GPUs; cells/s"
 

@@ -299,6 +299,25 @@ def test_bench_spawns_its_own_ranks():
     assert "error" not in e2e and e2e["n_gpus"] == 2 and e2e["value"] > 0 and e2e["imbalance_max_over_mean_time"] >= 1.0
 
 
+def test_bench_eight_ranks_bookkeeping_on_one_gpu():
+    """The driver's `--gpus 8` shape on the one GPU a box has: eight ranks (gloo, all on cuda:0), the configs[3] data set cut into
+    eight byte-balanced ranges with every rank generating and checking its own, the e2e and atac legs' collectives made by all
+    eight.  What it cannot show is eight devices' throughput; what it does show is that no rank's bookkeeping is off."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--share-gpu", "--dist-backend", "gloo", "--steps", "2", "--warmup", "1",
+           "--cells", "200", "--median-reads", "1500", "--c3-cells", "4000", "--c3-mean-reads", "300", "--atac-cells", "60", "--frags-per-cell", "400",
+           "--cpu-seconds", "1", "--also", "e2e,configs3,atac"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["value"] > 0 and line["scaling"] == "weak"
+    c3 = line["also"]["configs3"]
+    assert "error" not in c3 and c3["n_gpus"] == 8 and c3["config"]["cells"] == 8 * 4000 and c3["cpu_baseline"]["ranks_checked"] == 8
+    assert 0.9 < c3["config"]["imbalance_max_over_mean_bytes"] < 1.3
+    assert line["also"]["e2e"]["n_gpus"] == 8 and "error" not in line["also"]["e2e"]
+    assert line["also"]["atac"]["n_gpus"] == 8 and "error" not in line["also"]["atac"]
+
+
 def test_bench_single_gpu_legs_small():
     """The default legs on a small workload: configs[2] with its tie report, configs[3], the PCIe-inclusive figure, the CLI wall."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
