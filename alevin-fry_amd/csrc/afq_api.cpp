@@ -304,14 +304,14 @@ int check_supported(afq_ctx* c) {
 // Layout of RangeState::d_p2_small (u32 words), the per-cell / per-partition / per-tile arrays of the phase-kernel parsimony
 // path: a region that starts zeroed, the arrays the kernels fill, and a region uploaded from the host in one copy.
 struct P2Small {
-    uint64_t pcnt, pnp, pncls, pn3, gcnt, fb, ctr, zero_words;      // zeroed: per partition reads / pairs / staged classes, per-cell counters / flags, work counter
+    uint64_t pcnt, pnp, pncls, pn3, gcnt, fb, ctr, gdesc, zero_words;      // zeroed: per partition reads / pairs / staged classes, per-cell counters / flags, work counter
     uint64_t poff, pcur, pnv, pcell;                           // filled on the device
     uint64_t up, fb_count, fb_list, order, cells, tiles, up_words, words;   // uploaded
 };
 P2Small p2_small_layout(uint64_t n, uint64_t parts, uint64_t tiles, uint64_t n_pug) {
     P2Small L{};
     uint64_t o = 0;
-    L.pcnt = o; o += parts; L.pnp = o; o += parts; L.pncls = o; o += parts; L.pn3 = o; o += parts; L.gcnt = o; o += 4 * n; L.fb = o; o += n; L.ctr = o; o += 8;
+    L.pcnt = o; o += parts; L.pnp = o; o += parts; L.pncls = o; o += parts; L.pn3 = o; o += parts; L.gcnt = o; o += 4 * n; L.fb = o; o += n; L.ctr = o; o += 8; L.gdesc = o; o += 16 * n;
     L.zero_words = o;
     L.poff = o; o += parts; L.pcur = o; o += parts; L.pnv = o; o += parts; L.pcell = o; o += parts;
     o = (o + 3) & ~3ull;
@@ -812,10 +812,15 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
             p2.pcnt = sm + L.pcnt; p2.poff = sm + L.poff; p2.pcur = sm + L.pcur; p2.pnv = sm + L.pnv; p2.pcell = sm + L.pcell;
             p2.pnp = sm + L.pnp; p2.pncls = sm + L.pncls; p2.pn3 = sm + L.pn3; p2.gcnt = sm + L.gcnt; p2.fb = sm + L.fb; p2.fb_list = sm + L.fb_list; p2.fb_count = sm + L.fb_count;
             p2.pool = pool; p2.pool_cur = B.d_epool_cur.as<unsigned long long>(); p2.pool_cap = pool_cap;
-            p2.work_counter = sm + L.ctr;
+            p2.work_counter = sm + L.ctr; p2.work_counter2 = sm + L.ctr + 1; p2.gdesc = sm + L.gdesc;
             p2.cell_nkeys = ra.cell_nkeys; p2.t2g = c->d_t2g.as<uint32_t>(); p2.keys0 = ra.keys0; p2.cell_ncols = ra.cell_ncols;
             p2.lab = ra.lab; p2.lab_cnt = ra.lab_cnt; p2.st = ra.st;
             p2.n_cells = n_p2; p2.n_tiles = (uint32_t)p2tiles.size(); p2.n_parts = (uint32_t)p2_parts;
+            {
+                const uint32_t big_reads = [] { const char* e = std::getenv("AFQ_P2_BIG_READS"); const long v = e ? std::atol(e) : 0; return v > 0 ? (uint32_t)v : 60000u; }();   // (measurements / tests: read per range; 60 000: configs[2] graph kernels 30.9 -> 28.5 ms per step against 100 000)
+                p2.n_big = 0;
+                while (p2.n_big < n_p2 && p2cells[p2.n_big].R >= big_reads) ++p2.n_big;   // (p2cells is largest first)
+            }
             p2.part_cap = kP2PartCap;
             if (const char* e = std::getenv("AFQ_P2_PART_CAP")) p2.part_cap = (uint32_t)std::max(1, std::atoi(e));   // tests: force cells back to the one-workgroup kernel
             p2.ref_count = c->ref_count; p2.num_genes = g.num_genes; p2.usa = g.usa_mode; p2.num_rows = g.num_rows; p2.em = em ? 1u : 0u;

@@ -195,10 +195,12 @@ struct P2Args {
     uint32_t* fb; uint32_t* fb_list; uint32_t* fb_count;   // cells handed to the one-workgroup kernel
     uint32_t* pool; unsigned long long* pool_cur; unsigned long long pool_cap;
     uint32_t* work_counter;
+    uint32_t* work_counter2; uint32_t* gdesc;          // the cover kernel's cell counter; per cell [16]: what the graph kernel hands it (k_p2_graph -> k_p2_cover)
     const uint32_t* cell_nkeys; const uint32_t* t2g; uint64_t* keys0; uint32_t* cell_ncols; uint32_t* lab; uint32_t* lab_cnt;
     DevStatus* st;
     uint32_t n_cells, n_tiles, n_parts, part_cap;
     uint32_t ref_count, num_genes, usa, num_rows, em, exact_umi, large_thresh, hw, umi_pairs;
+    uint32_t n_big;   // the first n_big cells of `order` (largest first) are big enough for a 1024-thread graph workgroup each
 };
 constexpr uint32_t kP2PartTarget = 160;   // planned mean reads per partition (the partition count is a power of two: 80..160)
 constexpr uint32_t kP2PartCap = 256;      // reads one partition may hold (one wave sorts it in registers)

@@ -601,15 +601,22 @@ __global__ __launch_bounds__(256) void k_p2_lone(P2Args A) {
 #define G_MARK(i) do {} while (0)
 #endif
 constexpr int kGNT = 256;
-constexpr uint32_t kGTab = 4096;          // class table slots when it lives in LDS (keys: 32 KiB, minima: 16 KiB of the block)
-constexpr uint32_t kGTabLoad = 3000;      // ... and the classes it takes; beyond that the table is carved out of the pool
+#ifndef AFQ_GTAB
+#define AFQ_GTAB 4096
+#endif
+#ifndef AFQ_GRAPH_WPE
+#define AFQ_GRAPH_WPE 3
+#endif
+constexpr uint32_t kGTab = AFQ_GTAB;          // class table slots when it lives in LDS (keys: 32 KiB, minima: 16 KiB of the block)
+constexpr uint32_t kGTabLoad = AFQ_GTAB * 3 / 4 - 72;      // ... and the classes it takes; beyond that the table is carved out of the pool
 constexpr uint32_t kGLds = 3 * kGTab + 128;   // words of the phase-shared LDS block (48.5 KiB: three workgroups to a CU, what the registers allow anyway)
 constexpr uint32_t kCatPair = 1, kCatTiny = 2, kCatMid = 3;
 
-__global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
+template <int GNT>
+__global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, uint32_t work_hi, uint32_t* counter) {
     if (A.st->err_code) return;   // an earlier kernel of the range failed (e.g. kErrLabelHash in k_p2_part, which then leaves its partition's vertices unwritten): nothing behind it may read that state - the host runs the range again or reports the error
     __shared__ __attribute__((aligned(16))) uint32_t s_big[kGLds];
-    __shared__ uint32_t s_ws[kGNT / 64];
+    __shared__ uint32_t s_ws[GNT / 64];
     __shared__ uint32_t s_cnt[4];
     __shared__ uint32_t s_flag[4];
     __shared__ unsigned long long s_ebase;
@@ -617,13 +624,13 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
 #ifdef AFQ_PUG_TIMING
     __shared__ unsigned long long tmark[16];
 #endif
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t tid = threadIdx.x;
   for (;;) {
     __syncthreads();
-    if (tid == 0) s_next = atomicAdd(A.work_counter, 1u);
+    if (tid == 0) s_next = work_lo + atomicAdd(counter, 1u);
     __syncthreads();
     const uint32_t work = s_next;
-    if (work >= A.n_cells) return;
+    if (work >= work_hi) return;
     const uint32_t j = A.order[work];
     const P2Cell c = A.cells[j];
     const uint32_t R = c.R;
@@ -655,12 +662,12 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
         ppre = A.pool + s_ebase;
         gsync();
     }
-    for (uint32_t base = 0; base < P; base += kGNT) {
+    for (uint32_t base = 0; base < P; base += GNT) {
         const uint32_t pp = base + tid;
         const uint32_t a = pp < P ? pnp[pp] : 0u, b = pp < P ? pncls[pp] : 0u;
         uint32_t ta, tb;
-        const uint32_t ea = block_excl_scan<kGNT>(a, s_ws, ta);
-        const uint32_t eb = block_excl_scan<kGNT>(b, s_ws, tb);
+        const uint32_t ea = block_excl_scan<GNT>(a, s_ws, ta);
+        const uint32_t eb = block_excl_scan<GNT>(b, s_ws, tb);
         if (pp < P) { ppre[2 * pp] = n_pairs + ea; ppre[2 * pp + 1] = n_cls2 + eb; }
         n_pairs += ta; n_cls2 += tb;
     }
@@ -669,7 +676,7 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
         const uint32_t w0 = s_cnt[1], d0 = s_cnt[2];
         if (w0 + 2 * n_cls2 > C.lab_cap || 2 * (d0 + n_cls2) > C.lab_cap) { if (tid == 0) set_err(A.st, kErrPugLimit, c.cell); return; }
         const uint64_t* stage = A.cstage + c.rd_base;
-        for (uint32_t pp = tid; pp < P; pp += kGNT) {
+        for (uint32_t pp = tid; pp < P; pp += GNT) {
             const uint32_t nk = pncls[pp], at = ppre[2 * pp + 1], so = ppoff[pp];
             for (uint32_t k = 0; k < nk; ++k) {
                 const uint64_t v = stage[so + k];
@@ -700,13 +707,13 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
     const uint64_t* psrc = A.pairs + c.rd_base;
     const uint8_t* cflag = A.v_flag + c.rd_base;
     uint32_t NT = 0;
-    for (uint32_t g0 = 16 * tid; g0 < R; g0 += 16 * kGNT) {   // (sixteen flags per thread and trip in flight: this kernel's phases are chains of round trips)
+    for (uint32_t g0 = 16 * tid; g0 < R; g0 += 16 * GNT) {   // (sixteen flags per thread and trip in flight: this kernel's phases are chains of round trips)
 #pragma unroll
         for (int r = 0; r < 16; ++r) NT += g0 + r < R && cflag[g0 + r] != 0;
     }
     {
         uint32_t tot;
-        (void)block_excl_scan<kGNT>(NT, s_ws, tot);
+        (void)block_excl_scan<GNT>(NT, s_ws, tot);
         NT = tot;
     }
     if (NT > 2 * n_pairs || NT >= (1u << 24)) { if (tid == 0) set_err(A.st, kErrPugLimit, c.cell); return; }   // (cannot happen: two end points per pair, R < 2^22)
@@ -724,19 +731,19 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
     uint32_t* pr_v = q; q += nt_max + 2;      // two-vertex components: their vertices, two by two
     {
         uint32_t carry = 0;
-        for (uint32_t base = 0; base < R; base += 16 * kGNT) {
+        for (uint32_t base = 0; base < R; base += 16 * GNT) {
             const uint32_t g0 = base + 16 * tid;
             uint32_t fm = 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) fm |= (uint32_t)(g0 + r < R && cflag[g0 + r] != 0) << r;
             uint32_t tot;
-            uint32_t li = carry + block_excl_scan<kGNT>((uint32_t)__popc(fm), s_ws, tot);
+            uint32_t li = carry + block_excl_scan<GNT>((uint32_t)__popc(fm), s_ws, tot);
             for (; fm; fm &= fm - 1) { const uint32_t g = g0 + (uint32_t)__builtin_ctz(fm); tl[li] = g; lidx[g] = li; ++li; }
             carry += tot;
         }
     }
     gsync();
-    for (uint32_t pp = tid; pp < P; pp += kGNT) {   // the partition's pairs over touched-vertex numbers, four at a time
+    for (uint32_t pp = tid; pp < P; pp += GNT) {   // the partition's pairs over touched-vertex numbers, four at a time
         const uint32_t nk = pnp[pp], so = ppoff[pp], at = ppre[2 * pp];
         for (uint32_t k0 = 0; k0 < nk; k0 += 4) {
             uint64_t pr[4];
@@ -755,7 +762,7 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
     const bool wl_lds = NT <= kGLds;
     uint32_t* wl = wl_lds ? s_big : wlg;
     auto ldw = [&](uint32_t i) -> uint32_t { return wl_lds ? wl[i] : ld_l2(&wl[i]); };
-    for (uint32_t i = tid; i < NT; i += kGNT) { if (wl_lds) wl[i] = i; else st_l2(&wl[i], i); st_l2(&rcnt[i], 0u); st_l2(&fill[i], 0u); }
+    for (uint32_t i = tid; i < NT; i += GNT) { if (wl_lds) wl[i] = i; else st_l2(&wl[i], i); st_l2(&rcnt[i], 0u); st_l2(&fill[i], 0u); }
     gsync();
     for (;;) {
         gsync();   // (every thread has read the previous sweep's flag before it is cleared: without this barrier a wave that
@@ -764,7 +771,7 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
         if (tid == 0) s_flag[0] = 0;
         gsync();
         bool chg = false;
-        for (uint32_t k = tid; k < n_pairs; k += kGNT) {
+        for (uint32_t k = tid; k < n_pairs; k += GNT) {
             const uint64_t e = lp[k];
             const uint32_t x = (uint32_t)e & 0xFFFFFFu, y = (uint32_t)(e >> 24) & 0xFFFFFFu;
             const uint32_t a = ldw(x), b = ldw(y);
@@ -774,7 +781,7 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
         if (chg) s_flag[0] = 1;
         gsync();
         for (int it = 0; it < 4; ++it) {
-            for (uint32_t i = tid; i < NT; i += kGNT) { const uint32_t l = ldw(i); const uint32_t ll = ldw(l); if (ll < l) { if (wl_lds) wl[i] = ll; else st_l2(&wl[i], ll); } }
+            for (uint32_t i = tid; i < NT; i += GNT) { const uint32_t l = ldw(i); const uint32_t ll = ldw(l); if (ll < l) { if (wl_lds) wl[i] = ll; else st_l2(&wl[i], ll); } }
             gsync();
         }
         if (!s_flag[0]) break;
@@ -782,11 +789,11 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
     G_MARK(3);
     // ---- 3. the components by counting: sizes per root, then by size pairs / 3..8 / 9..64 (anything else is not for this
     //         kernel), every listed component's slots, every vertex into its component's next slot ----
-    for (uint32_t i = tid; i < NT; i += kGNT) { uint32_t l = ldw(i); for (uint32_t nx = ldw(l); nx != l; nx = ldw(l)) l = nx; root_of[i] = l; wg_add(&rcnt[l], 1u); }
+    for (uint32_t i = tid; i < NT; i += GNT) { uint32_t l = ldw(i); for (uint32_t nx = ldw(l); nx != l; nx = ldw(l)) l = nx; root_of[i] = l; wg_add(&rcnt[l], 1u); }
     gsync();
     uint32_t n_pr = 0, n_tiny = 0, n_mid9 = 0;
     bool big = false;
-    for (uint32_t base = 0; base < NT; base += kGNT) {
+    for (uint32_t base = 0; base < NT; base += GNT) {
         const uint32_t i = base + tid;
         uint32_t cat = 0;
         if (i < NT && root_of[i] == i) {
@@ -794,30 +801,31 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
             if (n > 64 || n > C.large_thresh) big = true;
             else cat = n == 2 ? kCatPair : n <= 8 ? kCatTiny : kCatMid;
         }
-        uint32_t tot;
-        const uint32_t ex = block_excl_scan<kGNT>((cat == kCatPair) | ((uint32_t)(cat == kCatTiny) << 10) | ((uint32_t)(cat == kCatMid) << 20), s_ws, tot);
+        uint32_t tot, tot_mid;   // (two scans: three counts of up to GNT = 1024 do not fit one word)
+        const uint32_t ex = block_excl_scan<GNT>((cat == kCatPair) | ((uint32_t)(cat == kCatTiny) << 16), s_ws, tot);
+        const uint32_t ex_mid = block_excl_scan<GNT>((uint32_t)(cat == kCatMid), s_ws, tot_mid);
         if (cat) {
-            const uint32_t idx = cat == kCatPair ? n_pr + (ex & 0x3FFu) : cat == kCatTiny ? n_tiny + ((ex >> 10) & 0x3FFu) : n_mid9 + (ex >> 20);
+            const uint32_t idx = cat == kCatPair ? n_pr + (ex & 0xFFFFu) : cat == kCatTiny ? n_tiny + (ex >> 16) : n_mid9 + ex_mid;
             const uint32_t n = ld_l2(&rcnt[i]);
             st_l2(&rcnt[i], (cat << 28) | idx);            // (a root's word is read and written by its own thread only in this pass)
             if (cat == kCatTiny) lsize[idx] = n;          // (the 9..64 ones are placed behind the small ones once those are counted)
             else if (cat == kCatMid) st_l2(&fill[i], n);   // (parked in the root's fill word until then)
         }
-        n_pr += tot & 0x3FFu; n_tiny += (tot >> 10) & 0x3FFu; n_mid9 += tot >> 20;
+        n_pr += tot & 0xFFFFu; n_tiny += tot >> 16; n_mid9 += tot_mid;
     }
     if (big) s_flag[1] = 1;
     gsync();
     if (s_flag[1]) { give_up(); continue; }
     const uint32_t n_mid = n_tiny + n_mid9;
-    for (uint32_t i = tid; i < NT; i += kGNT)
+    for (uint32_t i = tid; i < NT; i += GNT)
         if (root_of[i] == i) { const uint32_t rc = ld_l2(&rcnt[i]); if ((rc >> 28) == kCatMid) { lsize[n_tiny + (rc & 0xFFFFFFFu)] = ld_l2(&fill[i]); st_l2(&fill[i], 0u); } }
     gsync();
     uint32_t S_mid = 0;
-    for (uint32_t base = 0; base < n_mid; base += kGNT) {
+    for (uint32_t base = 0; base < n_mid; base += GNT) {
         const uint32_t ci = base + tid;
         const uint32_t n = ci < n_mid ? lsize[ci] : 0u;
         uint32_t tot;
-        const uint32_t ex = block_excl_scan<kGNT>(n, s_ws, tot);
+        const uint32_t ex = block_excl_scan<GNT>(n, s_ws, tot);
         if (ci < n_mid) mid_off[ci] = S_mid + ex;
         S_mid += tot;
     }
@@ -843,7 +851,7 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
     uint4* mrec = reinterpret_cast<uint4*>(u_base);                                   // [2 * S_mid]
     uint64_t* okey = reinterpret_cast<uint64_t*>(u_base + 8 * (size_t)S_mid);         // [S_mid] (class minimum, UMI)
     unsigned long long* adjp = reinterpret_cast<unsigned long long*>(u_base + 10 * (size_t)S_mid);   // [S_mid] out-neighbours of the vertex at this position, as positions inside its component
-    for (uint32_t i = tid; i < NT; i += kGNT) {
+    for (uint32_t i = tid; i < NT; i += GNT) {
         const uint32_t r = root_of[i], rc = ld_l2(&rcnt[r]), cat = rc >> 28, idx = rc & 0xFFFFFFFu;
         const uint32_t at = wg_add(&fill[r], 1u);
         if (cat == kCatPair) pr_v[2 * idx + at] = i;
@@ -873,7 +881,8 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
         if (want > kGTabLoad) {
             t_key = reinterpret_cast<unsigned long long*>(u_base);
             t_min = reinterpret_cast<uint32_t*>(t_key + cap);
-            s_bloom = s_big; bloom_shift = 14; bloom_words = 8192;   // (the LDS block is free then: 2^18 bits)
+            s_bloom = s_big;   // (the LDS block is free then: 2^18 bits of it, or 2^17 under a smaller block)
+            bloom_words = kGLds >= 8192 ? 8192 : 4096; bloom_shift = kGLds >= 8192 ? 14 : 15;
         }
         const uint32_t cmask = cap - 1;
         auto mix = [](uint64_t h) -> uint32_t { uint32_t x = ((uint32_t)h ^ (uint32_t)(h >> 32)) * 0x9E3779B1u; return x ^ (x >> 15); };
@@ -894,23 +903,23 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
         };
         for (uint32_t sl = 0; sl < n_slices; ++sl) {
             gsync();
-            for (uint32_t i = tid; i < cap; i += kGNT) { st_l2(&t_key[i], ~0ull); st_l2(&t_min[i], 0xFFFFFFFFu); }
-            for (uint32_t i = tid; i < bloom_words; i += kGNT) s_bloom[i] = 0;
+            for (uint32_t i = tid; i < cap; i += GNT) { st_l2(&t_key[i], ~0ull); st_l2(&t_min[i], 0xFFFFFFFFu); }
+            for (uint32_t i = tid; i < bloom_words; i += GNT) s_bloom[i] = 0;
             gsync();
             // (Every loop below takes four to six items per thread and level: the loads and L2 atomics of a level go out together and
             //  are waited for once.  One item at a time, a thread went through five dependent round trips per vertex.)
-            for (uint32_t s0 = tid; s0 - tid < S_mid; s0 += 4 * kGNT) {   // the classes that are asked for
+            for (uint32_t s0 = tid; s0 - tid < S_mid; s0 += 4 * GNT) {   // the classes that are asked for
                 uint32_t v4[4];
                 uint64_t h4[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v4[r] = s0 + (uint32_t)r * kGNT < S_mid ? slot_v[s0 + (uint32_t)r * kGNT] : 0u;
+                for (int r = 0; r < 4; ++r) v4[r] = s0 + (uint32_t)r * GNT < S_mid ? slot_v[s0 + (uint32_t)r * GNT] : 0u;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v4[r] = s0 + (uint32_t)r * kGNT < S_mid ? tl[v4[r]] : 0u;
+                for (int r = 0; r < 4; ++r) v4[r] = s0 + (uint32_t)r * GNT < S_mid ? tl[v4[r]] : 0u;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) h4[r] = s0 + (uint32_t)r * kGNT < S_mid ? ch[v4[r]] : 0ull;
+                for (int r = 0; r < 4; ++r) h4[r] = s0 + (uint32_t)r * GNT < S_mid ? ch[v4[r]] : 0ull;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (s0 + (uint32_t)r * kGNT >= S_mid || slice_of(h4[r]) != sl) continue;
+                    if (s0 + (uint32_t)r * GNT >= S_mid || slice_of(h4[r]) != sl) continue;
                     const uint32_t mx = mix(h4[r]);
                     atomicOr(&s_bloom[(mx >> bloom_shift) >> 5], 1u << ((mx >> bloom_shift) & 31u));
                     if (find(h4[r], mx, true) == 0xFFFFFFFFu) s_cnt[3] = kErrInternal;
@@ -927,12 +936,12 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
                 }
                 return 0xFFFFFFFFu;
             };
-            for (uint32_t g0 = tid; g0 - tid < R; g0 += 6 * kGNT) {
+            for (uint32_t g0 = tid; g0 - tid < R; g0 += 6 * GNT) {
                 uint64_t h4[6];
                 unsigned long long k4[6];
                 uint32_t sl4[6], off4[6], old4[6];
 #pragma unroll
-                for (int r = 0; r < 6; ++r) h4[r] = g0 + (uint32_t)r * kGNT < R ? ch[g0 + (uint32_t)r * kGNT] : 0ull;
+                for (int r = 0; r < 6; ++r) h4[r] = g0 + (uint32_t)r * GNT < R ? ch[g0 + (uint32_t)r * GNT] : 0ull;
 #pragma unroll
                 for (int r = 0; r < 6; ++r) {
                     const uint32_t mx = mix(h4[r]);
@@ -944,7 +953,7 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
 #pragma unroll
                 for (int r = 0; r < 6; ++r) if (sl4[r] != 0xFFFFFFFFu) sl4[r] = find_on(h4[r], sl4[r], k4[r]);
 #pragma unroll
-                for (int r = 0; r < 6; ++r) off4[r] = sl4[r] != 0xFFFFFFFFu ? coff[g0 + (uint32_t)r * kGNT] : 0u;
+                for (int r = 0; r < 6; ++r) off4[r] = sl4[r] != 0xFFFFFFFFu ? coff[g0 + (uint32_t)r * GNT] : 0u;
 #pragma unroll
                 for (int r = 0; r < 6; ++r) old4[r] = sl4[r] != 0xFFFFFFFFu ? wg_min(&t_min[sl4[r]], off4[r]) : 0xFFFFFFFFu;
 #pragma unroll
@@ -953,18 +962,18 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
                         !lab_equal(rec_label(C, off4[r]), rec_label(C, old4[r]))) s_cnt[3] = kErrLabelHash;
             }
             gsync();
-            for (uint32_t s0 = tid; s0 - tid < S_mid; s0 += 4 * kGNT) {
+            for (uint32_t s0 = tid; s0 - tid < S_mid; s0 += 4 * GNT) {
                 uint32_t v4[4], sl4[4];
                 uint64_t h4[4];
                 unsigned long long k4[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v4[r] = s0 + (uint32_t)r * kGNT < S_mid ? slot_v[s0 + (uint32_t)r * kGNT] : 0u;
+                for (int r = 0; r < 4; ++r) v4[r] = s0 + (uint32_t)r * GNT < S_mid ? slot_v[s0 + (uint32_t)r * GNT] : 0u;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v4[r] = s0 + (uint32_t)r * kGNT < S_mid ? tl[v4[r]] : 0u;
+                for (int r = 0; r < 4; ++r) v4[r] = s0 + (uint32_t)r * GNT < S_mid ? tl[v4[r]] : 0u;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) h4[r] = s0 + (uint32_t)r * kGNT < S_mid ? ch[v4[r]] : 0ull;
+                for (int r = 0; r < 4; ++r) h4[r] = s0 + (uint32_t)r * GNT < S_mid ? ch[v4[r]] : 0ull;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sl4[r] = s0 + (uint32_t)r * kGNT < S_mid && slice_of(h4[r]) == sl ? mix(h4[r]) & cmask : 0xFFFFFFFFu;
+                for (int r = 0; r < 4; ++r) sl4[r] = s0 + (uint32_t)r * GNT < S_mid && slice_of(h4[r]) == sl ? mix(h4[r]) & cmask : 0xFFFFFFFFu;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) k4[r] = sl4[r] != 0xFFFFFFFFu ? ld_l2(&t_key[sl4[r]]) : ~0ull;
 #pragma unroll
@@ -973,7 +982,7 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
                     const uint32_t slot = find_on(h4[r], sl4[r], k4[r]);
                     const uint32_t mn = slot == 0xFFFFFFFFu ? 0xFFFFFFFFu : ld_l2(&t_min[slot]);
                     if (mn == 0xFFFFFFFFu) s_cnt[3] = kErrInternal;   // (every asked-for class has at least the vertex that asked)
-                    cmin[s0 + (uint32_t)r * kGNT] = mn;
+                    cmin[s0 + (uint32_t)r * GNT] = mn;
                 }
             }
         }
@@ -982,6 +991,104 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
     }
     gsync();
     G_MARK(5);
+    G_MARK(6);
+    // ---- 6. components of 3..64 vertices: their vertices in the reference's order (class by first appearance = smallest
+    //         record offset, then UMI), the edges between them as masks over those positions, gathered into the covers' records ----
+    for (uint32_t s2 = tid; s2 < S_mid; s2 += GNT) okey[s2] = ((uint64_t)cmin[s2] << 32) | (uint32_t)(cu[tl[slot_v[s2]]] >> 32);
+    gsync();
+    for (uint32_t s2 = tid; s2 < S_mid; s2 += GNT) {
+        const uint32_t ci = slot_comp[s2];
+        const uint32_t b0 = mid_off[ci], n = mid_off[ci + 1] - b0;
+        const uint64_t mine = okey[s2];
+        uint32_t rank = 0;
+        uint32_t same = 0;
+        for (uint32_t i = 0; i < n; ++i) { rank += okey[b0 + i] < mine; same += okey[b0 + i] == mine; }
+        if (same != 1) s_cnt[3] = kErrInternal;   // (two vertices of one component with the same class and UMI: cannot be)
+        cidx[slot_v[s2]] = rank;
+    }
+    gsync();
+    if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], c.cell); return; }
+    for (uint32_t s2 = tid; s2 < S_mid; s2 += GNT) st_l2(&adjp[s2], 0ull);
+    gsync();
+    for (uint32_t k = tid; k < n_pairs; k += GNT) {
+        const uint64_t e = lp[k];
+        const uint32_t x = (uint32_t)e & 0xFFFFFFu, y = (uint32_t)(e >> 24) & 0xFFFFFFu;
+        const uint32_t rc = ld_l2(&rcnt[root_of[x]]), cat = rc >> 28;
+        if (cat == kCatPair) continue;
+        const uint32_t b0 = mid_off[cat == kCatTiny ? (rc & 0xFFFFFFFu) : n_tiny + (rc & 0xFFFFFFFu)];   // (x and y share their component)
+        if (e & (2ull << 48)) __hip_atomic_fetch_or(&adjp[b0 + cidx[x]], 1ull << cidx[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // x -> y
+        if (e & (1ull << 48)) __hip_atomic_fetch_or(&adjp[b0 + cidx[y]], 1ull << cidx[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // y -> x
+    }
+    gsync();
+    for (uint32_t s2 = tid; s2 < S_mid; s2 += GNT) {
+        const uint32_t li = slot_v[s2];
+        const uint32_t g = tl[li];
+        const KLab l = klab(C.W, C.HW, ch[g], coff[g]);
+        uint32_t r0 = 0xFFFFFFFFu, r1 = 0xFFFFFFFFu, r2 = 0xFFFFFFFFu, r3 = 0xFFFFFFFFu;
+        if (l.n <= 4) {
+            if (l.n > 0) r0 = klab_ref(l, 0);
+            if (l.n > 1) r1 = klab_ref(l, 1);
+            if (l.n > 2) r2 = l.p[2] & 0x7FFFFFFFu;
+            if (l.n > 3) r3 = l.p[3] & 0x7FFFFFFFu;
+        } else { const uint64_t pa = (uint64_t)(uintptr_t)l.p; r0 = (uint32_t)pa; r1 = (uint32_t)(pa >> 32); }
+        const size_t at = (size_t)mid_off[slot_comp[s2]] + cidx[li];
+        const unsigned long long am = ld_l2(&adjp[at]);
+        mrec[2 * at] = make_uint4(g, l.n, r0, r1);
+        mrec[2 * at + 1] = make_uint4(r2, r3, (uint32_t)am, (uint32_t)(am >> 32));
+    }
+    gsync();
+    G_MARK(7);
+#ifdef AFQ_PUG_TIMING
+    if (tid == 0 && (work % 512) < 2) {
+        auto us = [&](int a, int b) { return (double)(tmark[b] - tmark[a]) / 100.0; };
+        printf("p2 graph cell R=%u pairs=%u NT=%u n_tiny=%u n_mid=%u n_pr=%u S_mid=%u: gather=%.0f touched=%.0f wcc=%.0f comps=%.0f classes=%.0f records=%.0f total=%.0f us\n",
+               R, n_pairs, NT, n_tiny, n_mid, n_pr, S_mid, us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(6, 7), us(0, 7));
+    }
+#endif
+    if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], c.cell); return; }
+    // what the cover kernel (k_p2_cover) takes over: where the cell's lists lie in the pool, how many there are, the cell's counters
+    if (tid == 0) {
+        uint32_t* d = A.gdesc + 16 * (size_t)j;
+        auto put = [&](int at, const void* ptr) { const unsigned long long o = (unsigned long long)(reinterpret_cast<const uint32_t*>(ptr) - A.pool); d[at] = (uint32_t)o; d[at + 1] = (uint32_t)(o >> 32); };
+        d[1] = n_pr; d[2] = n_tiny; d[3] = n_mid;
+        put(4, tl); put(6, pr_v); put(8, mid_off); put(10, mrec);
+        d[12] = s_cnt[0]; d[13] = s_cnt[1]; d[14] = s_cnt[2];
+        d[0] = 1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// 6. one workgroup per cell again, but a kernel of its own: the molecules of the components the graph kernel listed - the
+//    two-vertex rule and the arborescence covers (afq_pug_common.h).  They need none of the graph kernel's LDS and a third of its
+//    registers; as one kernel the pair was 168 VGPRs with 98 SGPRs spilled and three workgroups to a CU.
+__global__ __launch_bounds__(kGNT) void k_p2_cover(P2Args A) {
+    if (A.st->err_code) return;
+    __shared__ uint32_t s_cnt[4];
+    __shared__ uint32_t s_next;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) s_next = atomicAdd(A.work_counter2, 1u);
+    __syncthreads();
+    const uint32_t work = s_next;
+    if (work >= A.n_cells) return;
+    const uint32_t j = A.order[work];
+    const uint32_t* d = A.gdesc + 16 * (size_t)j;
+    if (d[0] != 1) continue;   // handed to the one-workgroup kernel, or failed (the error is set)
+    const P2Cell c = A.cells[j];
+    if (tid < 3) s_cnt[tid] = d[12 + tid];
+    if (tid == 3) s_cnt[3] = 0;
+    __syncthreads();
+    const PugCtx C = make_ctx(A, c, s_cnt);
+    const uint64_t* ch = A.s_h + c.rd_base;
+    const uint32_t* coff = A.v_off + c.rd_base;
+    auto at = [&](int k) -> const uint32_t* { return A.pool + (((unsigned long long)d[k + 1] << 32) | d[k]); };
+    const uint32_t n_pr = d[1], n_tiny = d[2], n_mid = d[3];
+    const uint32_t* tl = at(4);
+    const uint32_t* pr_v = at(6);
+    const uint32_t* mid_off = at(8);
+    const uint4* mrec = reinterpret_cast<const uint4*>(at(10));
     // ---- 5. two-vertex components: one molecule, the refs both labels share (pugutils.rs:1161-1188) ----
     for (uint32_t k = tid; k - lane < n_pr; k += kGNT) {   // (wave-uniform trip count: append_cols is a wave-wide call)
         uint32_t col = 0xFFFFFFFFu, k0 = 0, k1 = 0;
@@ -1030,64 +1137,8 @@ __global__ __launch_bounds__(kGNT) void k_p2_graph(P2Args A) {
         append_cols(C, col);
         append_class2(C, cls, k0, k1);
     }
-    G_MARK(6);
-    // ---- 6. components of 3..64 vertices: their vertices in the reference's order (class by first appearance = smallest
-    //         record offset, then UMI), the edges between them as masks over those positions, gathered into the covers' records ----
-    for (uint32_t s2 = tid; s2 < S_mid; s2 += kGNT) okey[s2] = ((uint64_t)cmin[s2] << 32) | (uint32_t)(cu[tl[slot_v[s2]]] >> 32);
-    gsync();
-    for (uint32_t s2 = tid; s2 < S_mid; s2 += kGNT) {
-        const uint32_t ci = slot_comp[s2];
-        const uint32_t b0 = mid_off[ci], n = mid_off[ci + 1] - b0;
-        const uint64_t mine = okey[s2];
-        uint32_t rank = 0;
-        uint32_t same = 0;
-        for (uint32_t i = 0; i < n; ++i) { rank += okey[b0 + i] < mine; same += okey[b0 + i] == mine; }
-        if (same != 1) s_cnt[3] = kErrInternal;   // (two vertices of one component with the same class and UMI: cannot be)
-        cidx[slot_v[s2]] = rank;
-    }
-    gsync();
-    if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], c.cell); return; }
-    for (uint32_t s2 = tid; s2 < S_mid; s2 += kGNT) st_l2(&adjp[s2], 0ull);
-    gsync();
-    for (uint32_t k = tid; k < n_pairs; k += kGNT) {
-        const uint64_t e = lp[k];
-        const uint32_t x = (uint32_t)e & 0xFFFFFFu, y = (uint32_t)(e >> 24) & 0xFFFFFFu;
-        const uint32_t rc = ld_l2(&rcnt[root_of[x]]), cat = rc >> 28;
-        if (cat == kCatPair) continue;
-        const uint32_t b0 = mid_off[cat == kCatTiny ? (rc & 0xFFFFFFFu) : n_tiny + (rc & 0xFFFFFFFu)];   // (x and y share their component)
-        if (e & (2ull << 48)) __hip_atomic_fetch_or(&adjp[b0 + cidx[x]], 1ull << cidx[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // x -> y
-        if (e & (1ull << 48)) __hip_atomic_fetch_or(&adjp[b0 + cidx[y]], 1ull << cidx[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // y -> x
-    }
-    gsync();
-    for (uint32_t s2 = tid; s2 < S_mid; s2 += kGNT) {
-        const uint32_t li = slot_v[s2];
-        const uint32_t g = tl[li];
-        const KLab l = klab(C.W, C.HW, ch[g], coff[g]);
-        uint32_t r0 = 0xFFFFFFFFu, r1 = 0xFFFFFFFFu, r2 = 0xFFFFFFFFu, r3 = 0xFFFFFFFFu;
-        if (l.n <= 4) {
-            if (l.n > 0) r0 = klab_ref(l, 0);
-            if (l.n > 1) r1 = klab_ref(l, 1);
-            if (l.n > 2) r2 = l.p[2] & 0x7FFFFFFFu;
-            if (l.n > 3) r3 = l.p[3] & 0x7FFFFFFFu;
-        } else { const uint64_t pa = (uint64_t)(uintptr_t)l.p; r0 = (uint32_t)pa; r1 = (uint32_t)(pa >> 32); }
-        const size_t at = (size_t)mid_off[slot_comp[s2]] + cidx[li];
-        const unsigned long long am = ld_l2(&adjp[at]);
-        mrec[2 * at] = make_uint4(g, l.n, r0, r1);
-        mrec[2 * at + 1] = make_uint4(r2, r3, (uint32_t)am, (uint32_t)(am >> 32));
-    }
-    gsync();
-    G_MARK(7);
     cover_tiny8<kGNT / 64>(C, mrec, mid_off, n_tiny, wv, lane);
-    G_MARK(8);
     cover_wave64<kGNT / 64>(C, mrec, mid_off, n_tiny, n_mid, wv, lane);
-    G_MARK(9);
-#ifdef AFQ_PUG_TIMING
-    if (tid == 0 && (work % 512) < 2) {
-        auto us = [&](int a, int b) { return (double)(tmark[b] - tmark[a]) / 100.0; };
-        printf("p2 graph cell R=%u pairs=%u NT=%u n_tiny=%u n_mid=%u n_pr=%u S_mid=%u: gather=%.0f touched=%.0f wcc=%.0f comps=%.0f classes=%.0f pairs=%.0f records=%.0f tiny=%.0f mid=%.0f total=%.0f us\n",
-               R, n_pairs, NT, n_tiny, n_mid, n_pr, S_mid, us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(6, 7), us(7, 8), us(8, 9), us(0, 9));
-    }
-#endif
     gsync();
     if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], c.cell); return; }
     if (tid == 0) {
@@ -1119,8 +1170,17 @@ void launch_p2_graph(hipStream_t s, const P2Args& a) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     static const uint32_t per_cu = [] { const char* e = getenv("AFQ_P2_GRAPH_WGS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 16 ? (uint32_t)v : 4u; }();   // (measurements: workgroups per CU)
-    const uint32_t nb = a.n_cells < per_cu * (uint32_t)cus ? a.n_cells : per_cu * (uint32_t)cus;
-    AFQ_LAUNCH(k_p2_graph, nb, kGNT, s, a);
+    // The cells come largest first.  A cell is one workgroup's from its first phase to its last, and a range's graph kernel is not
+    // over before its largest cell is (a 290 k-read cell: 15 ms at 256 threads - twice what the rest of its range takes on the whole
+    // chip): the first n_big cells - those of 60 000 reads or more (AFQ_P2_BIG_READS) - get 1024 threads each, in a launch of their own.
+    const uint32_t n_big = a.n_big < a.n_cells ? a.n_big : a.n_cells;
+    if (n_big) AFQ_LAUNCH(k_p2_graph<1024>, n_big < (uint32_t)cus ? n_big : (uint32_t)cus, 1024, s, a, 0u, n_big, a.work_counter + 2);
+    const uint32_t rest = a.n_cells - n_big;
+    const uint32_t nb = rest < per_cu * (uint32_t)cus ? rest : per_cu * (uint32_t)cus;
+    if (rest) AFQ_LAUNCH(k_p2_graph<kGNT>, nb, kGNT, s, a, n_big, a.n_cells, a.work_counter);
+    static const uint32_t cover_per_cu = [] { const char* e = getenv("AFQ_P2_COVER_WGS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 16 ? (uint32_t)v : 6u; }();
+    const uint32_t nc = a.n_cells < cover_per_cu * (uint32_t)cus ? a.n_cells : cover_per_cu * (uint32_t)cus;
+    AFQ_LAUNCH(k_p2_cover, nc, kGNT, s, a);
 }
 
 }  // namespace afq

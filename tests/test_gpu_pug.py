@@ -9,15 +9,18 @@ rad = pkg.rad
 synth = pkg.synth
 
 
-@pytest.fixture(autouse=True, params=["phase-kernels", "one-workgroup", "handed-back"])
+@pytest.fixture(autouse=True, params=["phase-kernels", "one-workgroup", "handed-back", "graph-1024"])
 def pug_route(request, monkeypatch):
-    """Every test of this module runs three times: through the partition-parallel phase kernels (csrc/afq_pug2.hip, the
-    default), with every parsimony cell sent to the one-workgroup kernel (csrc/afq_pug.hip), and with the phase kernels'
-    partition capacity cut to 24 reads so that most cells start on the first route and are handed back to the second."""
+    """Every test of this module runs four times: through the partition-parallel phase kernels (csrc/afq_pug2.hip, the
+    default), with every parsimony cell sent to the one-workgroup kernel (csrc/afq_pug.hip), with the phase kernels'
+    partition capacity cut to 24 reads so that most cells start on the first route and are handed back to the second, and with
+    every cell of 300 reads or more given the 1024-thread instance of the graph kernel (by default: cells of 60 000 reads)."""
     if request.param == "one-workgroup":
         monkeypatch.setenv("AFQ_PUG_ROUTE", "mono")
     elif request.param == "handed-back":
         monkeypatch.setenv("AFQ_P2_PART_CAP", "24")
+    elif request.param == "graph-1024":
+        monkeypatch.setenv("AFQ_P2_BIG_READS", "300")
     return request.param
 
 
