@@ -738,6 +738,122 @@ __device__ __forceinline__ bool resolve_bucket_hash(const uint64_t* __restrict__
     return true;
 }
 
+// ---- hash-table resolution of a cr-like bucket whose UMIs carry ANY number of genes (one wave) ----
+// Reads off gene families map to five, ten, thirty transcripts of as many genes; a molecule's reads then put that many keys
+// under its UMI and the three counters of resolve_bucket_hash's slot overflow for most UMIs (the bucket is then sorted after all:
+// a batch that averages two or more alignments per record used to take the sort path outright, 34 G keys/s).  Here nothing
+// overflows.  Two tables: T1 keyed by (UMI, gene) counts the reads of each pair; T2 keyed by UMI collects, with atomics, the
+// order-free aggregates the rule table needs (col_from_candidates): the largest count, how many genes reach it, how many
+// of those are spliced, the smallest winner, the smallest spliced winner, and whether an unspliced winner's spliced sibling
+// is a winner too.  The lane that claimed a UMI's T2 slot emits its column.  cr-like only (cr-like-em wants the winners as a list).
+constexpr uint32_t kH2Cap = kHtKeys + kHtKeys / 2;
+constexpr uint32_t kH2Words = 2 * kH2Cap /* T1 */ + 2 * kH2Cap /* T2 key | max */ + 3 * kH2Cap /* agg, gmin, smin */ + kHtKeys /* columns */;
+__device__ __forceinline__ bool resolve_bucket_hash2(const uint64_t* __restrict__ src, uint32_t n, const ResolveCfg& rc, uint32_t* s_raw,
+                                                     DevStatus* st, uint32_t cell, uint32_t& nc_out, uint32_t*& s_cols_out) {
+    constexpr uint32_t E = kHtKeys / 64;
+    constexpr unsigned long long kEmpty64 = ~0ull;
+    const uint32_t lane = threadIdx.x;
+    unsigned long long* t1 = reinterpret_cast<unsigned long long*>(s_raw);
+    unsigned long long* t2 = t1 + kH2Cap;
+    uint32_t* agg = s_raw + 4 * kH2Cap;    // winners: count | spliced ones << 10 | "a winner's spliced sibling wins too" << 31
+    uint32_t* gmin = agg + kH2Cap;
+    uint32_t* smin = gmin + kH2Cap;
+    uint32_t* s_cols = smin + kH2Cap;
+    uint64_t key[E];
+#pragma unroll
+    for (uint32_t h = 0; h < E; ++h) key[h] = h * 64 + lane < n ? src[h * 64 + lane] : 0ull;
+    uint32_t cap = (n + (n >> 1) + 63) & ~63u;
+    cap = cap < 128 ? 128 : cap;
+    for (uint32_t i = lane; i < cap; i += 64) { t1[i] = kEmpty64; t2[i] = kEmpty64; agg[i] = 0; gmin[i] = 0xFFFFFFFFu; smin[i] = 0xFFFFFFFFu; }
+    __syncthreads();
+    bool bad = false;
+    uint32_t s1[E], s2[E];   // my pair's T1 slot when I claimed it; its UMI's T2 slot; bit 31 of s2: I claimed that one too
+#pragma unroll
+    for (uint32_t h = 0; h < E; ++h) { s1[h] = kNoCol; s2[h] = kNoCol; }
+#pragma unroll
+    for (uint32_t h = 0; h < E; ++h) {
+        if (h * 64 >= n) break;
+        if (h * 64 + lane < n) {
+            const uint64_t u64 = key[h] >> kGeneBits;
+            const uint32_t gene = (uint32_t)key[h] & kGeneMask;
+            if (u64 >= 0xFFFFFFFFull) bad = true;
+            else {
+                const uint32_t umi = (uint32_t)u64;
+                const unsigned long long mine = ((unsigned long long)umi << 32) | (gene << 12) | 1u;
+                uint32_t slot = ht_slot(umi ^ (gene * 0x9E3779B1u), cap);
+                unsigned long long old;
+                for (;;) {   // one exit: the slot was empty (now mine) or holds this (UMI, gene)
+                    old = atomicCAS(&t1[slot], kEmpty64, mine);
+                    if (old == kEmpty64 || (old >> 12) == (mine >> 12)) break;
+                    slot = slot + 1 == cap ? 0u : slot + 1;
+                }
+                if (old != kEmpty64) atomicAdd(&t1[slot], 1ull);
+                else {
+                    s1[h] = slot;
+                    const unsigned long long um = (unsigned long long)umi << 32;
+                    uint32_t q = ht_slot(umi, cap);
+                    for (;;) {
+                        old = atomicCAS(&t2[q], kEmpty64, um);
+                        if (old == kEmpty64 || (uint32_t)(old >> 32) == umi) break;
+                        q = q + 1 == cap ? 0u : q + 1;
+                    }
+                    s2[h] = q | (old == kEmpty64 ? 0x80000000u : 0u);
+                }
+            }
+        }
+    }
+    if (__any(bad)) return false;   // a UMI that does not fit the slot word: the sort path takes the bucket (nothing global was written)
+    __syncthreads();
+#pragma unroll
+    for (uint32_t h = 0; h < E; ++h)   // the largest read count of each UMI
+        if (s1[h] != kNoCol) atomicMax(&t2[s2[h] & 0x7FFFFFFFu], (t2[s2[h] & 0x7FFFFFFFu] & 0xFFFFFFFF00000000ull) | ((uint32_t)t1[s1[h]] & 0xFFFu));
+    __syncthreads();
+#pragma unroll
+    for (uint32_t h = 0; h < E; ++h) {   // the winners' aggregates
+        if (s1[h] == kNoCol) continue;
+        const uint32_t q = s2[h] & 0x7FFFFFFFu;
+        const uint32_t cnt = (uint32_t)t1[s1[h]] & 0xFFFu, mx = (uint32_t)t2[q] & 0xFFFu;
+        if (cnt != mx) continue;
+        const uint32_t gene = (uint32_t)key[h] & kGeneMask, umi = (uint32_t)(key[h] >> kGeneBits);
+        const bool sp = rc.usa && is_spliced(gene);
+        atomicAdd(&agg[q], 1u | (sp ? 1u << 10 : 0u));
+        atomicMin(&gmin[q], gene);
+        if (sp) atomicMin(&smin[q], gene);
+        if (rc.usa && !sp) {   // does this unspliced winner's spliced sibling win too?
+            const unsigned long long want = ((unsigned long long)umi << 32) | ((gene - 1) << 12);
+            for (uint32_t slot = ht_slot(umi ^ ((gene - 1) * 0x9E3779B1u), cap);; slot = slot + 1 == cap ? 0u : slot + 1) {
+                const unsigned long long e = t1[slot];
+                if (e == kEmpty64) break;
+                if ((e >> 12) == (want >> 12)) { if (((uint32_t)e & 0xFFFu) == mx) atomicOr(&agg[q], 1u << 31); break; }
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t nc = 0;
+#pragma unroll
+    for (uint32_t h = 0; h < E; ++h) {
+        if (h * 64 >= n) break;
+        uint32_t col = kNoCol;
+        if (s2[h] != kNoCol && (s2[h] >> 31)) {   // (same rule table as col_from_candidates, on the aggregates)
+            const uint32_t q = s2[h] & 0x7FFFFFFFu, a = agg[q];
+            const uint32_t nb = a & 0x3FFu, nsp = (a >> 10) & 0x3FFu, g1 = gmin[q], sg = smin[q];
+            const bool followed = a >> 31;
+            if (!rc.usa) col = nb == 1 ? g1 : kNoCol;
+            else if (nb == 1) col = is_spliced(g1) ? (g1 >> 1) : rc.uo + (g1 >> 1);
+            else if (nb == 2) col = followed ? rc.ao + (sg >> 1) : (nsp == 1 ? sg >> 1 : kNoCol);
+            else if (nb <= 10 && nsp == 1) col = followed ? rc.ao + (sg >> 1) : (sg >> 1);
+            if (col != kNoCol && col >= rc.num_rows) { set_err(st, kErrSlotRange, cell); col = kNoCol; }
+        }
+        const uint64_t m = __ballot(col != kNoCol);
+        if (col != kNoCol) s_cols[nc + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = col;
+        nc += (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    nc_out = nc;
+    s_cols_out = s_cols;
+    return true;
+}
+
 // One wave per bucket (up to kBucketCap keys).  Small workgroups keep many buckets
 // in flight per CU, which is what hides the load -> group -> reserve -> store latency
 // chain; blocks that run together are spread over different cells (column-major walk)
@@ -747,7 +863,7 @@ __device__ __forceinline__ bool resolve_bucket_hash(const uint64_t* __restrict__
 constexpr int kResolveNT = 64;
 constexpr uint32_t kResolveCols = 8192;
 static_assert(kBucketCap <= kResolveNT * 8, "bucket cap <= 8 keys per thread");
-template <bool EM>
+template <bool EM, bool MULTI>
 __global__ __launch_bounds__(kResolveNT) void k_resolve(const BucketDesc* __restrict__ desc, uint32_t n_buckets,
                                                        uint64_t* __restrict__ keys0,
                                                        const uint64_t* __restrict__ keys1,
@@ -757,7 +873,8 @@ __global__ __launch_bounds__(kResolveNT) void k_resolve(const BucketDesc* __rest
     // one LDS block carved two ways: the hash table (slot UMIs | counters), or the sort path's arrays
     constexpr uint32_t kSortWords = 2 * kBucketCap + kBucketCap / 2 + kBucketCap + (EM ? 2 * kBucketCap : 0);
     constexpr uint32_t kHashWords = kHtCap * (1 + kHtPairs) + 2 * kHtOvf + kHtCap / 32 + 2 + kHtKeys + (EM ? 2 * kHtKeys : 0);
-    constexpr uint32_t kWords = kSortWords > kHashWords ? kSortWords : kHashWords;
+    constexpr uint32_t kWords01 = kSortWords > kHashWords ? kSortWords : kHashWords;
+    constexpr uint32_t kWords = MULTI && kH2Words > kWords01 ? kH2Words : kWords01;
     __shared__ __attribute__((aligned(16))) uint32_t s_raw[kWords];
     __shared__ uint32_t s_ws[kResolveNT / 64];
     __shared__ uint32_t s_misc[6];
@@ -784,6 +901,19 @@ __global__ __launch_bounds__(kResolveNT) void k_resolve(const BucketDesc* __rest
         return;
     }
     const uint32_t bmode = d.mode_single & 0xFFu;
+    if constexpr (MULTI) {   // a batch of many-gene reads: cr-like buckets through the two-table path; everything else is sorted
+        if (bmode == kModeCrLike && d.n <= kHtKeys && !rc.pa) {
+            if (threadIdx.x < 6) s_misc[threadIdx.x] = 0;
+            uint32_t nc = 0;
+            uint32_t* h2cols = nullptr;
+            if (resolve_bucket_hash2(((d.mode_single >> 8) ? keys0 : keys1) + d.src_off, d.n, rc, s_raw, st, d.cell, nc, h2cols)) {
+                // the tables are dead: their space is the tail's scratch (sorted columns, run starts); the columns sit behind them
+                bucket_tail<kResolveNT>(d, keys0, cell_ncols, nnz, h2cols, nc, s_raw, reinterpret_cast<uint16_t*>(s_raw + kHtKeys), s_ws, s_misc);
+                return;
+            }
+            __syncthreads();
+        }
+    }
     if ((bmode == kModeCrLike || (EM && bmode == kModeCrLikeEm && la.lab)) && d.n <= kHtKeys && !rc.pa && !rc.sort_only) {
         const bool single = (d.mode_single >> 8) != 0;
         unsigned long long* s_slot = reinterpret_cast<unsigned long long*>(s_raw);      // 2 words per slot
@@ -1170,10 +1300,13 @@ void launch_resolve(hipStream_t s, const ResolveArgs& a) {
     AFQ_LAUNCH(k_bucket_desc, (a.n_buckets + 255) / 256, 256, s, a.meta, a.bucket_cell, a.cell_nkeys, a.cursor, a.slab_ovf, a.n_buckets, desc);
     const uint32_t n_cols = a.n_buckets < kResolveCols ? a.n_buckets : kResolveCols;
     const uint32_t grid = n_cols * ((a.n_buckets + n_cols - 1) / n_cols);
+    static const bool no_h2 = getenv("AFQ_RESOLVE_NO_H2") != nullptr;   // (measurements: many-gene batches through the sort path, as before round 4)
     if (a.lab)
-        AFQ_LAUNCH(k_resolve<true>, grid, kResolveNT, s, desc, a.n_buckets, a.keys0, a.keys1, a.cell_ncols, a.nnz, a.ovf_list, a.st, rc, la);
+        AFQ_LAUNCH((k_resolve<true, false>), grid, kResolveNT, s, desc, a.n_buckets, a.keys0, a.keys1, a.cell_ncols, a.nnz, a.ovf_list, a.st, rc, la);
+    else if (a.sort_only && !no_h2)
+        AFQ_LAUNCH((k_resolve<false, true>), grid, kResolveNT, s, desc, a.n_buckets, a.keys0, a.keys1, a.cell_ncols, a.nnz, a.ovf_list, a.st, rc, la);
     else
-        AFQ_LAUNCH(k_resolve<false>, grid, kResolveNT, s, desc, a.n_buckets, a.keys0, a.keys1, a.cell_ncols, a.nnz, a.ovf_list, a.st, rc, la);
+        AFQ_LAUNCH((k_resolve<false, false>), grid, kResolveNT, s, desc, a.n_buckets, a.keys0, a.keys1, a.cell_ncols, a.nnz, a.ovf_list, a.st, rc, la);
 }
 
 void launch_resolve_big(hipStream_t s, const ResolveArgs& a) {
