@@ -338,7 +338,7 @@ int plan_ranges(afq_ctx* c) {
     std::vector<double> need(c->n_cells);
     double total_need = 0, pug_fixed = 0, wide_new = 0;
     const bool use_slabs = fixed_slabs();            // (environment switches: read once per batch, not per cell)
-    const double slab_slots = (double)slab_capacity();
+    const double slab_slots = (double)std::max<uint32_t>(slab_capacity(), 512u);   // (ranges of many-gene reads take 512-slot slabs: run_range)
     c->all_aligned = true;
     for (uint32_t i = 0; i < c->n_cells; ++i) {
         const uint64_t off = c->chunk_off[i];
@@ -509,7 +509,18 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     uint64_t key_off = 0, n_buckets = 0, n_tiles = 0, n_slabs = 0, k1_slots = 0;
     uint32_t max_lg_nb = 0;
     const bool slabs = fixed_slabs();
-    const uint32_t slab_cap = slab_capacity();
+    uint32_t slab_cap = slab_capacity();
+    {   // reads of many genes each (the range averages two or more alignment words per record): all keys of a UMI share a bucket, so
+        // the buckets' sizes spread and 384-slot slabs overflow in a tenth of the cells (k_fix_slabs: 3.5 of 41 ms on the tail
+        // model); such ranges get 512-slot slabs (AFQ_SLAB_CAP still overrides)
+        uint64_t words = 0, recs = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t ci = r.c0 + i;
+            const uint64_t nb = c->widen ? c->w_nbytes[ci] : c->hdr[2 * ci], nr = c->hdr[2 * ci + 1];
+            words += (nb - 8ull - nr * H) / 4; recs += nr;
+        }
+        if (!std::getenv("AFQ_SLAB_CAP") && resolve_sort_only(words, recs)) slab_cap = std::max<uint32_t>(slab_cap, 512u);
+    }
     if (par) slab_prefix.reserve(n + 1);
     uint64_t nrec_total = 0;
     for (uint32_t i = 0; i < n; ++i) {
