@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kSetupNT) void k_em2_setup(const CellMeta* __restri
     extern __shared__ uint32_t s_bm[];   // bits[nwb], rank[nwb]
     __shared__ uint32_t s_ws[kSetupNT / 64];
     __shared__ uint32_t s_P;
-    __shared__ uint32_t s_hist[64], s_pick[3];
+    __shared__ uint32_t s_hist[64], s_pick[3], s_len_cur[64], s_len_cbase[64], s_len_wbase[64], s_long_words, s_len_cur63w;
     constexpr int NT = kSetupNT;
     const uint32_t tid = threadIdx.x;
     if (tiers[7]) return;   // (the scratch the host set aside is too small: it sizes the EM itself)
@@ -166,17 +166,55 @@ __global__ __launch_bounds__(kSetupNT) void k_em2_setup(const CellMeta* __restri
         }
         return w;
     };
-    uint32_t Wc = 0;
-    for (uint32_t base = 0; base < M; base += NT) {
-        const uint32_t i = base + tid;
-        const uint32_t len = i < M ? (usa ? em_label(i, nullptr) : ld[2 * i + 1]) : 0u;
-        uint32_t tot;
-        const uint32_t ex = block_excl_scan<NT>(len, s_ws, tot);   // (its barriers also order the bitmap clear before the marks below)
-        if (i < M) { sc.coff[i] = Wc + ex; em_label(i, sc.cw + Wc + ex); }
-        Wc += tot;
+    // The classes are laid out LONGEST LABEL FIRST (their order is free: every sum over classes is an integer sum).  A thread of
+    // the rounds takes one class and walks its label; with the classes as they come, a wave walks as far as its longest label
+    // (gene families: labels of 5, 10, 30 genes next to the usual pairs - the rounds' class pass then ran at the pace of the
+    // longest of 64 labels, every step a dependent load).  Sorted by length a wave's labels are the same length.  Counting sort:
+    // classes of one length sit in one run, so a class's words are at run base + rank x length and no per-class scan is needed
+    // (lengths of 63 and more share a run and take their words from a cursor).
+    if (tid < 64) { s_hist[tid] = 0; s_len_cur[tid] = 0; }
+    if (tid == 0) { s_long_words = 0; s_len_cur63w = 0; }
+    __syncthreads();
+    for (uint32_t i = tid; i < M; i += NT) {
+        const uint32_t len = usa ? em_label(i, nullptr) : ld[2 * i + 1];
+        atomicAdd(&s_hist[len < 63u ? len : 63u], 1u);
+        if (len >= 63u) atomicAdd(&s_long_words, len);
+    }
+    __syncthreads();
+    if (tid == 0) {   // runs from the longest labels down: class positions and word offsets
+        uint32_t cpos = 0, wpos = 0;
+        for (int b = 63; b >= 0; --b) {
+            s_len_cbase[b] = cpos; s_len_wbase[b] = wpos;
+            cpos += s_hist[b];
+            wpos += b == 63 ? s_long_words : (uint32_t)b * s_hist[b];
+        }
+        s_long_words = wpos;   // (now: all label words)
+    }
+    __syncthreads();
+    const uint32_t Wc = s_long_words;
+    for (uint32_t i = tid; i < M; i += NT) {
+        const uint32_t len = usa ? em_label(i, nullptr) : ld[2 * i + 1];
+        const uint32_t b = len < 63u ? len : 63u;
+        const uint32_t rk = atomicAdd(&s_len_cur[b], 1u);
+        const uint32_t off = s_len_wbase[b] + (b < 63u ? rk * len : atomicAdd(&s_len_cur63w, len));
+        sc.coff[s_len_cbase[b] + rk] = off;
+        em_label(i, sc.cw + off);
     }
     if (tid == 0) sc.coff[M] = Wc;
     __syncthreads();
+    if (s_hist[63]) {   // the 63+ run took its words in arrival order: its offsets must ascend with the class index (coff[c + 1] ends class c)
+        // (rare: re-number the run's classes by offset - a serial pass of one thread over a handful of classes)
+        if (tid == 0) {
+            const uint32_t c0 = s_len_cbase[63], n63 = s_hist[63];
+            for (uint32_t a = 1; a < n63; ++a) {   // insertion sort by offset
+                const uint32_t v = sc.coff[c0 + a];
+                uint32_t j = a;
+                for (; j > 0 && sc.coff[c0 + j - 1] > v; --j) sc.coff[c0 + j] = sc.coff[c0 + j - 1];
+                sc.coff[c0 + j] = v;
+            }
+        }
+        __syncthreads();
+    }
     // 2. live entries = distinct label slots: prefix popcount over the bitmap (ids ascend with the column)
     uint32_t L = 0;
     constexpr uint32_t kSc = 8;
@@ -359,15 +397,28 @@ __device__ __forceinline__ void em2_class_pass(const IdT* __restrict__ coff, con
             float d = 0.0f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) if ((uint32_t)k < n[j]) d += a[j][k];
-            for (uint32_t k = 4; k < n[j]; ++k) d += ab[IdLoad<IdT>::at(cw, o0[j] + k)];
+            for (uint32_t k = 4; k < n[j]; k += 4) {   // (longer labels: four words a step, their loads in flight together, the additions in label order)
+                uint32_t e4[4]; float a4[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) e4[t] = k + t < n[j] ? IdLoad<IdT>::at(cw, o0[j] + k + t) : 0u;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) a4[t] = k + t < n[j] ? ab[e4[t]] : 0.0f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) if (k + t < n[j]) d += a4[t];
+            }
             if (!(d > 0.0f)) continue;
             const float r = 1.0f / d;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if ((uint32_t)k < n[j]) em2_add(&acc[e[j][k]], (unsigned long long)((a[j][k] * r) * scale));
-            for (uint32_t k = 4; k < n[j]; ++k) {
-                const uint32_t ee = IdLoad<IdT>::at(cw, o0[j] + k);
-                em2_add(&acc[ee], (unsigned long long)((ab[ee] * r) * scale));
+            for (uint32_t k = 4; k < n[j]; k += 4) {
+                uint32_t e4[4]; float a4[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) e4[t] = k + t < n[j] ? IdLoad<IdT>::at(cw, o0[j] + k + t) : 0u;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) a4[t] = k + t < n[j] ? ab[e4[t]] : 0.0f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) if (k + t < n[j]) em2_add(&acc[e4[t]], (unsigned long long)((a4[t] * r) * scale));
             }
         }
     }
@@ -628,12 +679,28 @@ __global__ __launch_bounds__(NT) void k_em2_rounds_hybrid(const uint32_t* __rest
                 float d = 0.0f;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) if ((uint32_t)k < n[j]) d += a[j][k];
-                for (uint32_t k = 4; k < n[j]; ++k) d += AB(sc.cw[o0[j] + k]);
+                for (uint32_t k = 4; k < n[j]; k += 4) {
+                    uint32_t e4[4]; float a4[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) e4[t] = k + t < n[j] ? sc.cw[o0[j] + k + t] : 0u;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) a4[t] = k + t < n[j] ? AB(e4[t]) : 0.0f;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) if (k + t < n[j]) d += a4[t];
+                }
                 if (!(d > 0.0f)) continue;
                 const float r = 1.0f / d;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) if ((uint32_t)k < n[j]) add(e[j][k], (unsigned long long)((a[j][k] * r) * scale));
-                for (uint32_t k = 4; k < n[j]; ++k) { const uint32_t ee = sc.cw[o0[j] + k]; add(ee, (unsigned long long)((AB(ee) * r) * scale)); }
+                for (uint32_t k = 4; k < n[j]; k += 4) {
+                    uint32_t e4[4]; float a4[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) e4[t] = k + t < n[j] ? sc.cw[o0[j] + k + t] : 0u;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) a4[t] = k + t < n[j] ? AB(e4[t]) : 0.0f;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) if (k + t < n[j]) add(e4[t], (unsigned long long)((a4[t] * r) * scale));
+                }
             }
         }
         em2_gsync();

@@ -265,3 +265,21 @@ def test_afquant_cli_quant_subset_and_flag_errors(tmp_path, oracle):
     os.remove(tmp_path / "in" / "generate_permit_list.json")
     r = subprocess.run([CLI, "quant", "-i", str(tmp_path / "in"), "-m", tg, "-o", out, "-r", "cr-like"], capture_output=True, text=True)
     assert r.returncode != 0 and "generate_permit_list.json" in r.stderr
+
+
+@pytest.mark.parametrize("usa", [False, True])
+def test_reference_pin_directory_against_our_own_cli(tmp_path, usa):
+    """tests/make_reference_pin.py writes the directory with which an alevin-fry 0.18 binary pins the oracle; here `afquant quant`
+    stands where alevin-fry would: its output files are joined with the expected counts by the script's own `compare`
+    (barcode strings, USA column names, MatrixMarket indices all have to line up)."""
+    import subprocess
+    import sys
+
+    script = os.path.join(ROOT, "tests", "make_reference_pin.py")
+    d = tmp_path / "pin"
+    r = subprocess.run([sys.executable, script, "make", str(d)] + (["--usa"] if usa else []), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([CLI, "quant", "-i", str(d / "in"), "-m", str(d / "in" / "t2g.tsv"), "-o", str(d / "ref_out"), "-r", "cr-like", "-t", "4"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([sys.executable, script, "compare", str(d)], capture_output=True, text=True)
+    assert r.returncode == 0 and "differing 0," in r.stdout and "only expected 0," in r.stdout, r.stdout + r.stderr

@@ -2,11 +2,12 @@
 the snappy frame decoder and the RAD prelude parser (include/afquant_host.h)."""
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import pytest
 
-from util import pkg
+from util import ROOT, pkg
 
 rad = pkg.rad
 
@@ -256,3 +257,36 @@ def test_tail_model_of_the_host_generator():
     assert 2.8 < nas.mean() < 3.5 and nas.max() > 12 and (nas >= 5).mean() > 0.15 and 1.2 < nas0.mean() < 1.6
     assert plain.n_reads == tailed.n_reads and len(plain.data) < len(tailed.data)   # the same reads, longer records
     assert same0 > 1000 and same > 0.8 * same0, (same, diff, same0, diff0)
+
+
+def test_reference_pin_script_round_trip(tmp_path):
+    """tests/make_reference_pin.py: `make` writes the input directory + the oracle's counts keyed by (barcode, gene); `compare`
+    joins an alevin-fry output directory with them.  Here the "output directory" is written from the expected counts themselves
+    (MatrixMarket, rows and columns shuffled as the reference's are: completion order) - the join must come out clean, and a
+    changed count must be seen."""
+    import random
+    import subprocess
+    import sys
+
+    script = os.path.join(ROOT, "tests", "make_reference_pin.py")
+    d = tmp_path / "pin"
+    r = subprocess.run([sys.executable, script, "make", str(d), "--usa", "--resolution", "cr-like"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (d / "in" / "map.collated.rad").exists() and (d / "RUN.sh").exists()
+    ent = [l.split("\t") for l in (d / "expected_counts.tsv").read_text().splitlines()]
+    assert len(ent) > 100
+    rows = sorted({e[0] for e in ent}); cols = sorted({e[1] for e in ent})
+    random.Random(3).shuffle(rows); random.Random(4).shuffle(cols)
+    out = d / "ref_out" / "alevin"
+    out.mkdir(parents=True)
+    (out / "quants_mat_rows.txt").write_text("\n".join(rows) + "\n")
+    (out / "quants_mat_cols.txt").write_text("\n".join(cols) + "\n")
+    ri = {b: i + 1 for i, b in enumerate(rows)}; ci = {g: i + 1 for i, g in enumerate(cols)}
+    body = [f"{ri[b]} {ci[g]} {float(v)}" for b, g, v in ent]
+    (out / "quants_mat.mtx").write_text("%%MatrixMarket matrix coordinate real general\n" + f"{len(rows)} {len(cols)} {len(body)}\n" + "\n".join(body) + "\n")
+    r = subprocess.run([sys.executable, script, "compare", str(d)], capture_output=True, text=True)
+    assert r.returncode == 0 and "differing 0," in r.stdout, r.stdout + r.stderr
+    body[5] = " ".join(body[5].split()[:2] + ["7777.0"])
+    (out / "quants_mat.mtx").write_text("%%MatrixMarket matrix coordinate real general\n" + f"{len(rows)} {len(cols)} {len(body)}\n" + "\n".join(body) + "\n")
+    r = subprocess.run([sys.executable, script, "compare", str(d)], capture_output=True, text=True)
+    assert r.returncode == 1 and "differing 1," in r.stdout
