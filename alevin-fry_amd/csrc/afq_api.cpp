@@ -155,6 +155,7 @@ struct RangeState {
     Range cur{};
     uint32_t hash_try = 0;   // which salt the range's label hashes were made with (a collision re-runs the range under the next)
     uint32_t pool_try = 0;   // how often the range was run again with four times the parsimony pool (a cell's graph outgrew it)
+    uint64_t att_records = 0, att_ref_words = 0, att_buckets = 0;   // what the current attempt added to the batch statistics
     bool em_inline = false;  // the EM was enqueued behind the range's kernels (offsets made on the device); finish_range only checks that its scratch sufficed
     bool in_flight = false;
     hipEvent_t kernels_done = nullptr;
@@ -878,6 +879,8 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     B.last_ra = ra;
     B.cur = r;
     B.in_flight = true;
+    // (a range that is run again - another label hash, a larger pool - counts once: finish_range takes the failed attempt back)
+    B.att_records = nrec_total; B.att_ref_words = key_off; B.att_buckets = n_buckets;
     c->stats.n_records += nrec_total;
     c->stats.n_ref_words += key_off;
     c->stats.n_buckets += n_buckets;
@@ -897,15 +900,24 @@ int finish_range(afq_ctx* c, int slot) {
     DevStatus st{};
     std::memcpy(&st, B.h_pack.p, sizeof(st));   // (k_pack_small's block, copied out by the range's stream)
     const uint32_t* const pk = B.h_pack.p + kPackHdrWords;
+    auto take_back_attempt = [&]() {   // the failed attempt's share of the statistics and its kernel timings
+        c->stats.n_records -= B.att_records; c->stats.n_ref_words -= B.att_ref_words; c->stats.n_buckets -= B.att_buckets;
+        for (TimedLaunch& t : B.launches) { c->event_pool.push_back(t.a); c->event_pool.push_back(t.b); }   // (back to the pool, not into the kernel times)
+        B.launches.clear();
+    };
     if (st.err_code == kErrLabelHash && B.hash_try + 1 < kMaxHashTries) {   // same range, next hash function (the input bytes are still resident)
         c->n_label_rehash += 1;
+        take_back_attempt();
         const int rc = run_range(c, B.cur, slot, nullptr, B.hash_try + 1, B.pool_try);
         return rc ? rc : finish_range(c, slot);
     }
     if (st.err_code == kErrPugPool && B.pool_try < kMaxPoolTries) {   // same range, four times the pool (refused only when the device has no room for it)
         c->n_pool_regrow += 1;
+        take_back_attempt();
         const int rc = run_range(c, B.cur, slot, nullptr, B.hash_try, B.pool_try + 1);
-        return rc ? rc : finish_range(c, slot);
+        const int rc2 = rc ? rc : finish_range(c, slot);
+        B.d_epool.release();   // the enlarged pool (x4 ... x64) is this range's alone: the next range plans its own
+        return rc2;
     }
     if (st.err_code) {
         const std::string cell = "cell " + std::to_string(B.cur.c0 + st.err_cell) + ": ";
