@@ -27,7 +27,7 @@ def main(path):
     starts = [i for i, x in enumerate(ev) if x[3].startswith("k_gather_headers") or x[3].startswith("k_atac_parse")]
     i0 = starts[-1] if starts else 0
     # (a step's planning precedes its first kernel by host time only; its uploads come right before)
-    while i0 > 0 and ev[i0 - 1][2] == "C" and ev[i0][0] - ev[i0 - 1][1] < 300000:
+    while i0 > 0 and ev[i0 - 1][2] == "C" and "HOST_TO_DEVICE" in ev[i0 - 1][3] and ev[i0][0] - ev[i0 - 1][1] < 300000:
         i0 -= 1
     step = ev[i0:]
     t0 = step[0][0]

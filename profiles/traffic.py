@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """HBM-side bytes per launch from the FETCH_SIZE / WRITE_SIZE passes of run_prof.sh -> profiles/<round>_traffic.json
-(read by bench.py for roofline.traffic).  Usage: python profiles/traffic.py r1g r01g"""
+(read by bench.py for roofline.traffic).  Usage: python profiles/traffic.py <gpurun tag> <output name> [output dir]"""
 import json
 import os
 import sqlite3
@@ -25,7 +25,7 @@ def per_launch(db_path, counter, totals=None):
     return {k: tot[k] / max(1, len(disp[k])) for k in tot}
 
 
-def main(tag, rnd):
+def main(tag, rnd, outdir=None):
     here = os.path.dirname(os.path.abspath(__file__))
     root = os.path.join(os.path.dirname(here), "gpurun_out", f"prof_{tag}")
     ft, wt = {}, {}
@@ -47,7 +47,7 @@ def main(tag, rnd):
         out["kernels"][k] = {"FETCH_SIZE_KB_per_launch": round(fk, 1), "WRITE_SIZE_KB_per_launch": round(wk, 1),
                              "bytes_per_launch_raw": int((fk + wk) * 1024), "bytes_per_launch_fetch_doubled": int((2 * fk + wk) * 1024),
                              "dispatches": ft[k][1], "bytes_total_fetch_doubled": int((2 * ft[k][0] + wt.get(k, (0.0, 0))[0]) * 1024)}
-    with open(os.path.join(here, f"{rnd}_traffic.json"), "w") as fh:
+    with open(os.path.join(outdir or here, f"{rnd}_traffic.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     for k in ("k_hist", "k_resolve", "k_decode_recs", "k_scatter"):
         if k in out["kernels"]:
@@ -55,4 +55,4 @@ def main(tag, rnd):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
