@@ -147,8 +147,7 @@ struct RangeState {
         d_p2_small, d_eq_wptr, d_eq_len, d_eq_cnt, d_eq_lab, d_bt_off, d_bt_scratch, d_bt_ns, d_bt_col, d_bt_mean, d_bt_var, d_bt_sptr, d_bt_ccol,
         d_bt_cmean, d_bt_cvar, d_em2_off, d_em2_scratch, d_em2_tiers, d_arena;
     PinnedVec<uint8_t> h_arena;   // the range's small uploads, gathered (RangeInit)
-    DevBuf d_pack;
-    PinnedVec<uint32_t> h_pack;   // what the host reads when the range is done (k_pack_small), landed by the range's own stream
+    PinnedVec<uint32_t> h_pack;   // what the host reads when the range is done: k_pack_small writes it from the device
     ResolveArgs last_ra{};
     std::vector<CellMeta> meta;
     std::vector<uint2> tile_desc;   // per scatter tile: (cell, tile index inside the cell)
@@ -166,7 +165,7 @@ struct RangeState {
                 &d_cell_bc, &d_bdesc, &d_lab, &d_lab_cnt, &d_em_off, &d_em_scratch, &d_em_nnz, &d_pug_cells, &d_rd_off, &d_rd_h,
                 &d_rd_u, &d_rd_o, &d_pug_scr_off, &d_pug_scratch, &d_epool, &d_epool_cur, &d_p2_small, &d_alt, &d_hist_cells, &d_fix, &d_em_hdr, &d_em_order,
                 &d_eq_ncls, &d_eq_nw, &d_eq_cptr, &d_eq_wptr, &d_eq_len, &d_eq_cnt, &d_eq_lab, &d_bt_off, &d_bt_scratch, &d_bt_ns, &d_bt_col,
-                &d_bt_mean, &d_bt_var, &d_bt_sptr, &d_bt_ccol, &d_bt_cmean, &d_bt_cvar, &d_em2_off, &d_em2_scratch, &d_em2_tiers, &d_arena, &d_pack};
+                &d_bt_mean, &d_bt_var, &d_bt_sptr, &d_bt_ccol, &d_bt_cmean, &d_bt_cvar, &d_em2_off, &d_em2_scratch, &d_em2_tiers, &d_arena};
     }
 };
 
@@ -387,14 +386,14 @@ int plan_ranges(afq_ctx* c) {
     // the last one's compaction + D2H is the only part nothing hides, so it is the smallest.
     // (parsimony: every range ends in the tail of its persistent workgroups and nothing of the next range can share a CU with
     // them, while its rows are few - three ranges; cr-like: five, tapering, so that the last D2H is small)
-    static const double kTaperCr[] = {0.28, 0.56, 0.78, 0.92, 1.0}, kTaperPug[] = {0.40, 0.76, 1.0, 1.0, 1.0};
+    static const double kTaperCr[] = {0.28, 0.56, 0.78, 0.92, 1.0, 1.0, 1.0, 1.0}, kTaperPug[] = {0.40, 0.76, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
     const double* kTaper = pug_res ? kTaperPug : kTaperCr;
-    const size_t kTaperN = 5;
-    double env_taper[5];   // (a local: contexts of several devices plan on their own threads)
-    if (const char* e = std::getenv(pug_res ? "AFQ_PUG_TAPER" : "AFQ_CR_TAPER")) {   // measurements: cumulative fractions, e.g. "0.3,0.6,0.85"
+    const size_t kTaperN = 8;
+    double env_taper[8];   // (a local: contexts of several devices plan on their own threads)
+    if (const char* e = std::getenv(pug_res ? "AFQ_PUG_TAPER" : "AFQ_CR_TAPER")) {   // measurements: cumulative fractions, e.g. "0.3,0.6,0.85" (up to seven cuts)
         size_t k = 0;
-        for (const char* q = e; *q && k < 4;) { env_taper[k++] = std::atof(q); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
-        while (k < 5) env_taper[k++] = 1.0;
+        for (const char* q = e; *q && k < 7;) { env_taper[k++] = std::atof(q); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+        while (k < 8) env_taper[k++] = 1.0;
         kTaper = env_taper;
     }
     if (pug_fixed > 0.5 * mem_budget) return fail(c, AFQ_ERR_OOM, "the largest parsimony cell's scratch does not fit device memory");
@@ -867,13 +866,16 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     HIP_TRY(c, hipGetLastError());
     if (!B.kernels_done) HIP_TRY(c, hipEventCreateWithFlags(&B.kernels_done, hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(B.kernels_done, s));
-    {   // what finish_range reads first, on its way to pinned memory behind the kernels
+    {   // what finish_range reads first: written by the last kernel of the range STRAIGHT into pinned host memory (20 bytes per cell over
+        // PCIe).  An async D2H copy here instead would sit in the copy queue until the range's kernels are done - with the NEXT range's
+        // upload queued behind it: the next range then started 150 us after this one ended instead of right behind it (seen in the
+        // timeline: 0.45 ms per step).
         const size_t words = kPackHdrWords + 5ull * n;
-        HIP_TRY(c, B.d_pack.ensure(4 * words));
         HIP_TRY(c, B.h_pack.reserve(words));
+        void* d_view = nullptr;
+        HIP_TRY(c, hipHostGetDevicePointer(&d_view, B.h_pack.p, 0));
         launch_pack_small(s, B.d_status.as<DevStatus>(), B.em_inline ? B.d_em2_tiers.as<uint32_t>() + 7 : nullptr, B.d_alt.as<uint32_t>(), B.d_nnz.as<uint32_t>(),
-                          B.em_inline ? B.d_em_nnz.as<uint32_t>() : nullptr, B.d_bc.as<uint64_t>(), n, B.d_pack.as<uint32_t>());
-        HIP_TRY(c, hipMemcpyAsync(B.h_pack.p, B.d_pack.p, 4 * words, hipMemcpyDeviceToHost, s));
+                          B.em_inline ? B.d_em_nnz.as<uint32_t>() : nullptr, B.d_bc.as<uint64_t>(), n, reinterpret_cast<uint32_t*>(d_view));
     }
     hc.lap("run: enqueue kernels");
     B.last_ra = ra;
@@ -898,7 +900,7 @@ int finish_range(afq_ctx* c, int slot) {
     HIP_TRY(c, hipStreamSynchronize(s));
     hc.lap("finish: wait for kernels");
     DevStatus st{};
-    std::memcpy(&st, B.h_pack.p, sizeof(st));   // (k_pack_small's block, copied out by the range's stream)
+    std::memcpy(&st, B.h_pack.p, sizeof(st));   // (k_pack_small wrote it there, behind the range's kernels)
     const uint32_t* const pk = B.h_pack.p + kPackHdrWords;
     auto take_back_attempt = [&]() {   // the failed attempt's share of the statistics and its kernel timings
         c->stats.n_records -= B.att_records; c->stats.n_ref_words -= B.att_ref_words; c->stats.n_buckets -= B.att_buckets;
