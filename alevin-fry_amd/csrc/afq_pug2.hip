@@ -423,37 +423,51 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
         }
     };
     const uint32_t L = A.umi_pairs;
-    // A probe UMI that passes the filter (one in twenty) is not looked up on the spot - the whole wave would walk the table for
-    // the one lane that needs it, at nearly every step - but queued per lane; the queues are drained together afterwards, a
-    // handful of table walks per wave instead of one per step.
-    // own vertices: same UMI under another label, and every one-base change that stays in the partition
-    uint64_t oq8 = 0;   // up to eight queued own probes, a byte each: 1 | r << 1 | (3 b + d - 1) << 3 ... (b < 16: 6 bits)
-    uint32_t on = 0;
+    // own vertices: same UMI under another label, and every one-base change that stays in the partition.  The filter checks are
+    // branch-free - a probe that passes (one in thirty, nearly always a false positive) sets its bit in a per-lane mask, and the
+    // masks are drained together afterwards: a handful of table walks per wave instead of a divergent one at nearly every step,
+    // and no exec-mask bookkeeping per probe (the kernel was as busy on its scalar unit as on its vector units).  The fold of the
+    // filter is linear, so a probe's filter bit is fold(umi) ^ fold(change): one XOR per probe, the change's fold a scalar.
+    // "met once, from the smaller UMI": umi ^ (d << 2b) > umi iff the top bit of d is clear in the base - a bit test.
+    uint64_t hits[4] = {0, 0, 0, 0};   // bit 3 (b - m/2) + d - 1 of row r: the change d of base b passed the filter
+    const uint32_t b_lo = m / 2;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const uint32_t i = (uint32_t)r * 64 + lane;
         if ((uint32_t)r * 64 >= nv) break;   // (uniform)
         const uint32_t umi = (uint32_t)(own[r] >> 32), xw = (uint32_t)own[r];
         if (i < nv) probe(umi, lo_p + i, xw, true);
-        if (A.exact_umi || i >= nv) continue;
-        for (uint32_t b = m / 2; b < L; ++b) {   // (bases below m / 2 lie inside the low m bits: every change there leaves the partition)
+        if (A.exact_umi) continue;
+        const uint32_t fu = fold11(umi);
+        const bool valid = i < nv;
+        uint64_t h = 0;
+        for (uint32_t b = b_lo; b < L; ++b) {   // (bases below m / 2 lie inside the low m bits: every change there leaves the partition)
+            const uint32_t c0 = (umi >> (2 * b)) & 1u, c1 = (umi >> (2 * b + 1)) & 1u;
 #pragma unroll
             for (uint32_t d = 1; d < 4; ++d) {
                 const uint32_t mk = d << (2 * b);
-                if (mk & (P - 1)) continue;
-                const uint32_t pu = umi ^ mk;
-                if (pu > umi && filt(pu)) {
-                    if (on < 8) { oq8 |= (uint64_t)(((3 * b + d - 1) << 2) | (uint32_t)r) << (8 * on); ++on; }
-                    else probe(pu, lo_p + i, xw, false);
-                }
+                if (mk & (P - 1)) continue;   // (scalar: only the base that straddles bit m)
+                const uint32_t f = fu ^ fold11(mk);
+                const uint32_t bit = (s_filt[f >> 5] >> (f & 31u)) & 1u;
+                const uint32_t up = d == 1 ? (c0 ^ 1u) : (c1 ^ 1u);
+                h |= (uint64_t)(bit & up) << (3 * (b - b_lo) + d - 1);
             }
         }
+        hits[r] = valid ? h : 0ull;
     }
-    for (uint32_t t = 0; __any(t < on); ++t) {
-        if (t >= on) continue;
-        const uint32_t e = (uint32_t)(oq8 >> (8 * t)) & 0xFFu, r = e & 3u, ix = e >> 2;
-        const uint64_t ow = r == 0 ? own[0] : r == 1 ? own[1] : r == 2 ? own[2] : own[3];
-        probe((uint32_t)(ow >> 32) ^ ((ix % 3 + 1) << (2 * (ix / 3))), lo_p + r * 64 + lane, (uint32_t)ow, false);
+    for (;;) {   // drain: every lane takes its next passed probe, whichever row it is in (static register indices: no scratch)
+        const bool mine = (hits[0] | hits[1] | hits[2] | hits[3]) != 0;
+        if (!__any(mine)) break;
+        if (mine) {
+            uint32_t r = 0;
+            uint64_t hr = 0, ow = 0;
+            if (hits[0]) { r = 0; hr = hits[0]; ow = own[0]; hits[0] &= hits[0] - 1; }
+            else if (hits[1]) { r = 1; hr = hits[1]; ow = own[1]; hits[1] &= hits[1] - 1; }
+            else if (hits[2]) { r = 2; hr = hits[2]; ow = own[2]; hits[2] &= hits[2] - 1; }
+            else { r = 3; hr = hits[3]; ow = own[3]; hits[3] &= hits[3] - 1; }
+            const uint32_t ix = (uint32_t)__builtin_ctzll(hr);
+            probe((uint32_t)(ow >> 32) ^ ((ix % 3 + 1) << (2 * (b_lo + ix / 3))), lo_p + r * 64 + lane, (uint32_t)ow, false);
+        }
     }
     // The vertices of the partitions one low-bit change away, a partition at a time (its place is in lane k's registers): the
     // first 128 vertices of the NEXT partition are on their way while this one goes through the filter.
@@ -462,35 +476,42 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
         v[0] = lane < nq ? cu[oq + lane] : 0ull;
         v[1] = lane + 64 < nq ? cu[oq + 64 + lane] : 0ull;
     };
-    uint32_t fq_pu[4], fq_gx[4], fq_xw[4], fn = 0;   // queued foreign probes
-    auto fpush = [&](uint32_t pu, uint32_t gx, uint32_t xw) {
-        if (fn >= 4) { probe(pu, gx, xw, false); return; }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) if ((uint32_t)t == fn) { fq_pu[t] = pu; fq_gx[t] = gx; fq_xw[t] = xw; }
-        ++fn;
-    };
+    // (their filter checks are branch-free too: a passed probe is a bit (partition k, row r) in a per-lane mask; the drain fetches
+    //  that vertex again - it is in the cache - instead of carrying a queue of (probe, slot, word) triples in registers)
+    uint64_t fhits = 0;   // bit 2 k + r (k < 24: three changes of at most eight low bases)
     uint64_t cur[2] = {0, 0}, nxt[2] = {0, 0};
     uint32_t nq = 0, oq = 0, nq2 = 0, oq2 = 0;
     if (nfor) fetch(0, cur, nq, oq);
     for (uint32_t k = 0; k < nfor; ++k) {
         if (k + 1 < nfor) fetch(k + 1, nxt, nq2, oq2);
         const uint32_t mk = (k % 3 + 1) << (2 * (k / 3));
+        const uint32_t fm = fold11(mk), tb = 2 * (k / 3) + (k % 3 == 0 ? 0u : 1u);   // (scalar) the change's fold; the bit of the base that decides "umi ^ mk > umi"
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const uint32_t i = (uint32_t)r * 64 + lane;
-            if (i >= nq) continue;
-            const uint32_t umi = (uint32_t)(cur[r] >> 32), pu = umi ^ mk;
-            if (pu > umi && filt(pu)) fpush(pu, oq + i, (uint32_t)cur[r]);
+            const uint32_t umi = (uint32_t)(cur[r] >> 32);
+            const uint32_t f = fold11(umi) ^ fm;
+            const uint32_t ok = (i < nq ? 1u : 0u) & (((umi >> tb) & 1u) ^ 1u) & ((s_filt[f >> 5] >> (f & 31u)) & 1u);
+            fhits |= (uint64_t)ok << (2 * k + (uint32_t)r);
         }
         for (uint32_t i = 128 + lane; i < nq; i += 64) {   // (a partition of more than 128 vertices: the rest, plainly)
             const uint64_t uw = cu[oq + i];
             const uint32_t umi = (uint32_t)(uw >> 32), pu = umi ^ mk;
-            if (pu > umi && filt(pu)) fpush(pu, oq + i, (uint32_t)uw);
+            if (pu > umi && filt(pu)) probe(pu, oq + i, (uint32_t)uw, false);
         }
         cur[0] = nxt[0]; cur[1] = nxt[1]; nq = nq2; oq = oq2;
     }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) if ((uint32_t)t < fn) probe(fq_pu[t], fq_gx[t], fq_xw[t], false);
+    for (; __any(fhits != 0);) {
+        const uint32_t ix = fhits ? (uint32_t)__builtin_ctzll(fhits) : 0u;
+        const uint32_t k = ix >> 1, r = ix & 1u;
+        const uint32_t base = (uint32_t)__shfl((int)f_o, (int)k);   // (every lane takes part in the shuffle: a lane that sat out would hand its neighbour a zero)
+        if (fhits) {
+            fhits &= fhits - 1;
+            const uint32_t gx = base + r * 64 + lane;
+            const uint64_t uw = cu[gx];
+            probe((uint32_t)(uw >> 32) ^ ((k % 3 + 1) << (2 * (k / 3))), gx, (uint32_t)uw, false);
+        }
+    }
     WAVE_SYNC();
     const uint32_t np = *s_np;
     if (lane == 0) {
