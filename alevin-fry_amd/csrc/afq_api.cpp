@@ -828,7 +828,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
             p2.lab = ra.lab; p2.lab_cnt = ra.lab_cnt; p2.st = ra.st;
             p2.n_cells = n_p2; p2.n_tiles = (uint32_t)p2tiles.size(); p2.n_parts = (uint32_t)p2_parts;
             {
-                const uint32_t big_reads = [] { const char* e = std::getenv("AFQ_P2_BIG_READS"); const long v = e ? std::atol(e) : 0; return v > 0 ? (uint32_t)v : 60000u; }();   // (measurements / tests: read per range; 60 000: configs[2] graph kernels 30.9 -> 28.5 ms per step against 100 000)
+                const uint32_t big_reads = [] { const char* e = std::getenv("AFQ_P2_BIG_READS"); const long v = e ? std::atol(e) : 0; return v > 0 ? (uint32_t)v : 25000u; }();   // (measurements / tests: read per range; configs[2] graph kernels per step: 100 000: 30.9 ms, 60 000: 28.4, 40 000: 26.7, 25 000: 25.7, 12 000 and below: 25.4)
                 p2.n_big = 0;
                 while (p2.n_big < n_p2 && p2cells[p2.n_big].R >= big_reads) ++p2.n_big;   // (p2cells is largest first)
             }

@@ -629,14 +629,16 @@ constexpr int kGNT = 256;
 #define AFQ_GRAPH_WPE 3
 #endif
 constexpr uint32_t kGTab = AFQ_GTAB;          // class table slots when it lives in LDS (keys: 32 KiB, minima: 16 KiB of the block)
-constexpr uint32_t kGTabLoad = AFQ_GTAB * 3 / 4 - 72;      // ... and the classes it takes; beyond that the table is carved out of the pool
-constexpr uint32_t kGLds = 3 * kGTab + 128;   // words of the phase-shared LDS block (48.5 KiB: three workgroups to a CU, what the registers allow anyway)
+// (it takes 3/4 of its slots less a margin in classes; beyond that the table is carved out of the pool)
 constexpr uint32_t kCatPair = 1, kCatTiny = 2, kCatMid = 3;
 
 template <int GNT>
 __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, uint32_t work_hi, uint32_t* counter) {
     if (A.st->err_code) return;   // an earlier kernel of the range failed (e.g. kErrLabelHash in k_p2_part, which then leaves its partition's vertices unwritten): nothing behind it may read that state - the host runs the range again or reports the error
-    __shared__ __attribute__((aligned(16))) uint32_t s_big[kGLds];
+    // (the 1024-thread instance is alone on its CU - 16 waves at 128 VGPRs - and takes a class table twice the size: cells of 40-80 k
+    //  reads ask for 3 000-6 000 classes, and out of the pool the class step cost them twice as much: 244 against 124 us at 40 k reads)
+    constexpr uint32_t GTab = GNT >= 1024 ? 2 * kGTab : kGTab, GTabLoad = GTab * 3 / 4 - 72, GBloomWords = GNT >= 1024 ? 512 : 128, GLds = 3 * GTab + GBloomWords;
+    __shared__ __attribute__((aligned(16))) uint32_t s_big[GLds];
     __shared__ uint32_t s_ws[GNT / 64];
     __shared__ uint32_t s_cnt[4];
     __shared__ uint32_t s_flag[4];
@@ -676,7 +678,7 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
     const uint32_t* ppoff = A.poff + c.part_base;
     uint32_t n_pairs = 0, n_cls2 = 0;
     uint32_t* ppre = s_big;   // per partition: first pair | first class (cells of more than 6000 partitions - a million reads - keep it in the pool)
-    if (2 * P > kGLds) {
+    if (2 * P > GLds) {
         if (tid == 0) s_ebase = atomicAdd(A.pool_cur, 2ull * P + 4);
         gsync();
         if (s_ebase + 2ull * P + 4 > A.pool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, c.cell); return; }
@@ -780,7 +782,7 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
     gsync();
     G_MARK(2);
     // ---- 2. weakly connected components over the pair list: min-label propagation + pointer jumping (labels in LDS when they fit) ----
-    const bool wl_lds = NT <= kGLds;
+    const bool wl_lds = NT <= GLds;
     uint32_t* wl = wl_lds ? s_big : wlg;
     auto ldw = [&](uint32_t i) -> uint32_t { return wl_lds ? wl[i] : ld_l2(&wl[i]); };
     for (uint32_t i = tid; i < NT; i += GNT) { if (wl_lds) wl[i] = i; else st_l2(&wl[i], i); st_l2(&rcnt[i], 0u); st_l2(&fill[i], 0u); }
@@ -855,12 +857,12 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
     // table (when it does not fit LDS) and then the order keys, adjacency masks and cover records (12 words per slot)
     const uint32_t want = S_mid;   // (vertices: an upper bound of the classes the table will hold)
     constexpr uint32_t kPoolTab = 1u << 16;
-    uint32_t cap = kGTab, n_slices = 1;
-    if (want > kGTabLoad) {   // at most 2^16 pool slots at a time: a cell with more classes takes the key space in slices, a pass per slice
+    uint32_t cap = GTab, n_slices = 1;
+    if (want > GTabLoad) {   // at most 2^16 pool slots at a time: a cell with more classes takes the key space in slices, a pass per slice
         n_slices = (uint32_t)((5ull * want / 2 + kPoolTab - 1) / kPoolTab);
         while (cap < kPoolTab && (uint64_t)cap * n_slices < 5ull * want / 2) cap <<= 1;
     }
-    const unsigned long long u_words = std::max<unsigned long long>(want > kGTabLoad ? 3ull * cap + 4 : 0ull, 12ull * S_mid + 8);
+    const unsigned long long u_words = std::max<unsigned long long>(want > GTabLoad ? 3ull * cap + 4 : 0ull, 12ull * S_mid + 8);
     q = pool_take(3ull * S_mid + 8 + u_words);
     if (!q) return;
     uint32_t* slot_v = q; q += S_mid + 2;       // slot -> vertex
@@ -896,14 +898,14 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
     if (S_mid) {
         // the table: in LDS when the classes are few; else in the pool region taken above
         unsigned long long* t_key = reinterpret_cast<unsigned long long*>(s_big);
-        uint32_t* t_min = s_big + 2 * kGTab;
-        uint32_t* s_bloom = s_big + 3 * kGTab;   // the last 128 words of the block: 4096 bits for the asked-for keys
-        uint32_t bloom_shift = 20, bloom_words = 128;
-        if (want > kGTabLoad) {
+        uint32_t* t_min = s_big + 2 * GTab;
+        uint32_t* s_bloom = s_big + 3 * GTab;   // the last words of the block: 4096 (16 384) bits for the asked-for keys
+        uint32_t bloom_shift = GBloomWords == 512 ? 18 : 20, bloom_words = GBloomWords;
+        if (want > GTabLoad) {
             t_key = reinterpret_cast<unsigned long long*>(u_base);
             t_min = reinterpret_cast<uint32_t*>(t_key + cap);
             s_bloom = s_big;   // (the LDS block is free then: 2^18 bits of it, or 2^17 under a smaller block)
-            bloom_words = kGLds >= 8192 ? 8192 : 4096; bloom_shift = kGLds >= 8192 ? 14 : 15;
+            bloom_words = GLds >= 8192 ? 8192 : 4096; bloom_shift = GLds >= 8192 ? 14 : 15;
         }
         const uint32_t cmask = cap - 1;
         auto mix = [](uint64_t h) -> uint32_t { uint32_t x = ((uint32_t)h ^ (uint32_t)(h >> 32)) * 0x9E3779B1u; return x ^ (x >> 15); };
@@ -1083,17 +1085,18 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
 // 6. one workgroup per cell again, but a kernel of its own: the molecules of the components the graph kernel listed - the
 //    two-vertex rule and the arborescence covers (afq_pug_common.h).  They need none of the graph kernel's LDS and a third of its
 //    registers; as one kernel the pair was 168 VGPRs with 98 SGPRs spilled and three workgroups to a CU.
-__global__ __launch_bounds__(kGNT) void k_p2_cover(P2Args A) {
+template <int CNT>
+__global__ __launch_bounds__(CNT) void k_p2_cover(P2Args A, uint32_t work_lo, uint32_t work_hi, uint32_t* counter) {
     if (A.st->err_code) return;
     __shared__ uint32_t s_cnt[4];
     __shared__ uint32_t s_next;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   for (;;) {
     __syncthreads();
-    if (tid == 0) s_next = atomicAdd(A.work_counter2, 1u);
+    if (tid == 0) s_next = work_lo + atomicAdd(counter, 1u);
     __syncthreads();
     const uint32_t work = s_next;
-    if (work >= A.n_cells) return;
+    if (work >= work_hi) return;
     const uint32_t j = A.order[work];
     const uint32_t* d = A.gdesc + 16 * (size_t)j;
     if (d[0] != 1) continue;   // handed to the one-workgroup kernel, or failed (the error is set)
@@ -1111,7 +1114,7 @@ __global__ __launch_bounds__(kGNT) void k_p2_cover(P2Args A) {
     const uint32_t* mid_off = at(8);
     const uint4* mrec = reinterpret_cast<const uint4*>(at(10));
     // ---- 5. two-vertex components: one molecule, the refs both labels share (pugutils.rs:1161-1188) ----
-    for (uint32_t k = tid; k - lane < n_pr; k += kGNT) {   // (wave-uniform trip count: append_cols is a wave-wide call)
+    for (uint32_t k = tid; k - lane < n_pr; k += CNT) {   // (wave-uniform trip count: append_cols is a wave-wide call)
         uint32_t col = 0xFFFFFFFFu, k0 = 0, k1 = 0;
         bool cls = false;
         if (k < n_pr) {
@@ -1158,8 +1161,8 @@ __global__ __launch_bounds__(kGNT) void k_p2_cover(P2Args A) {
         append_cols(C, col);
         append_class2(C, cls, k0, k1);
     }
-    cover_tiny8<kGNT / 64>(C, mrec, mid_off, n_tiny, wv, lane);
-    cover_wave64<kGNT / 64>(C, mrec, mid_off, n_tiny, n_mid, wv, lane);
+    cover_tiny8<CNT / 64>(C, mrec, mid_off, n_tiny, wv, lane);
+    cover_wave64<CNT / 64>(C, mrec, mid_off, n_tiny, n_mid, wv, lane);
     gsync();
     if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], c.cell); return; }
     if (tid == 0) {
@@ -1193,15 +1196,18 @@ void launch_p2_graph(hipStream_t s, const P2Args& a) {
     static const uint32_t per_cu = [] { const char* e = getenv("AFQ_P2_GRAPH_WGS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 16 ? (uint32_t)v : 4u; }();   // (measurements: workgroups per CU)
     // The cells come largest first.  A cell is one workgroup's from its first phase to its last, and a range's graph kernel is not
     // over before its largest cell is (a 290 k-read cell: 15 ms at 256 threads - twice what the rest of its range takes on the whole
-    // chip): the first n_big cells - those of 60 000 reads or more (AFQ_P2_BIG_READS) - get 1024 threads each, in a launch of their own.
+    // chip): the first n_big cells - those of 25 000 reads or more (AFQ_P2_BIG_READS) - get 1024 threads each, in a launch of their own.
     const uint32_t n_big = a.n_big < a.n_cells ? a.n_big : a.n_cells;
     if (n_big) AFQ_LAUNCH(k_p2_graph<1024>, n_big < (uint32_t)cus ? n_big : (uint32_t)cus, 1024, s, a, 0u, n_big, a.work_counter + 2);
     const uint32_t rest = a.n_cells - n_big;
     const uint32_t nb = rest < per_cu * (uint32_t)cus ? rest : per_cu * (uint32_t)cus;
-    if (rest) AFQ_LAUNCH(k_p2_graph<kGNT>, nb, kGNT, s, a, n_big, a.n_cells, a.work_counter);
+    static const bool g512 = [] { const char* e = getenv("AFQ_P2_GRAPH_NT"); return e && atoi(e) == 512; }();   // (measurements)
+    if (rest && g512) AFQ_LAUNCH(k_p2_graph<512>, nb, 512, s, a, n_big, a.n_cells, a.work_counter);
+    else if (rest) AFQ_LAUNCH(k_p2_graph<kGNT>, nb, kGNT, s, a, n_big, a.n_cells, a.work_counter);
     static const uint32_t cover_per_cu = [] { const char* e = getenv("AFQ_P2_COVER_WGS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 16 ? (uint32_t)v : 6u; }();
     const uint32_t nc = a.n_cells < cover_per_cu * (uint32_t)cus ? a.n_cells : cover_per_cu * (uint32_t)cus;
-    AFQ_LAUNCH(k_p2_cover, nc, kGNT, s, a);
+    if (n_big) AFQ_LAUNCH(k_p2_cover<1024>, n_big < (uint32_t)cus ? n_big : (uint32_t)cus, 1024, s, a, 0u, n_big, a.work_counter + 3);   // (the big cells' covers likewise)
+    if (rest) AFQ_LAUNCH(k_p2_cover<kGNT>, nc < rest ? nc : rest, kGNT, s, a, n_big, a.n_cells, a.work_counter2);
 }
 
 }  // namespace afq

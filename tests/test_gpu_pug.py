@@ -14,7 +14,7 @@ def pug_route(request, monkeypatch):
     """Every test of this module runs four times: through the partition-parallel phase kernels (csrc/afq_pug2.hip, the
     default), with every parsimony cell sent to the one-workgroup kernel (csrc/afq_pug.hip), with the phase kernels'
     partition capacity cut to 24 reads so that most cells start on the first route and are handed back to the second, and with
-    every cell of 300 reads or more given the 1024-thread instance of the graph kernel (by default: cells of 60 000 reads)."""
+    every cell of 300 reads or more given the 1024-thread instance of the graph kernel (by default: cells of 25 000 reads)."""
     if request.param == "one-workgroup":
         monkeypatch.setenv("AFQ_PUG_ROUTE", "mono")
     elif request.param == "handed-back":
