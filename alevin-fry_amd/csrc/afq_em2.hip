@@ -370,29 +370,30 @@ __device__ __forceinline__ void em2_add(unsigned long long* p, unsigned long lon
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // one pass over the classes: D in label order, r = 1 / D, every label word's share into its entry's accumulator
-template <int NT, typename IdT>
+template <int NT, int CPT, typename IdT>
 __device__ __forceinline__ void em2_class_pass(const IdT* __restrict__ coff, const IdT* __restrict__ cw, const float* ab,
                                                unsigned long long* acc, uint32_t K, float scale) {
-    for (uint32_t c0 = threadIdx.x; c0 < K; c0 += 2 * NT) {
-        // two classes per thread and trip, each level of their gathers issued together
-        uint32_t o0[2], n[2], e[2][4];
-        float a[2][4];
+    for (uint32_t c0 = threadIdx.x; c0 < K; c0 += CPT * NT) {
+        // CPT classes per thread and trip, each level of their gathers issued together (two out of LDS; four when the lists stream
+        // from global memory: a trip is then a chain of L2 round trips, and the chains of one thread are all it has in flight)
+        uint32_t o0[CPT], n[CPT], e[CPT][4];
+        float a[CPT][4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < CPT; ++j) {
             const uint32_t c = c0 + j * NT;
             o0[j] = 0; n[j] = 0;
             if (c < K) { o0[j] = IdLoad<IdT>::at(coff, c); n[j] = IdLoad<IdT>::at(coff, c + 1) - o0[j]; }
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < CPT; ++j)
 #pragma unroll
             for (int k = 0; k < 4; ++k) e[j][k] = (uint32_t)k < n[j] ? IdLoad<IdT>::at(cw, o0[j] + k) : 0u;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < CPT; ++j)
 #pragma unroll
             for (int k = 0; k < 4; ++k) a[j][k] = (uint32_t)k < n[j] ? ab[e[j][k]] : 0.0f;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < CPT; ++j) {
             if (n[j] == 0) continue;
             float d = 0.0f;
 #pragma unroll
@@ -526,8 +527,8 @@ __global__ __launch_bounds__(NT) void k_em2_rounds(const CellMeta* __restrict__ 
             __syncthreads();
         }
         // (A+B) classes
-        if constexpr (MODE == 0) em2_class_pass<NT, uint16_t>(coff16, cw16, ab, acc, K, scale);
-        else em2_class_pass<NT, uint32_t>(sc.coff, sc.cw, ab, acc, K, scale);
+        if constexpr (MODE == 0) em2_class_pass<NT, 2, uint16_t>(coff16, cw16, ab, acc, K, scale);
+        else em2_class_pass<NT, 4, uint32_t>(sc.coff, sc.cw, ab, acc, K, scale);
         EM2T(0);
         __syncthreads();
         EM2T(1);
@@ -649,32 +650,41 @@ __global__ __launch_bounds__(NT) void k_em2_rounds_hybrid(const uint32_t* __rest
     bool conv = true, last_round = false;
     while (it < kMinIter2 || (it < kMaxIter2 && !conv) || last_round) {
         if (usa) {
-            for (uint32_t e = tid; e < L; e += NT) {
-                const uint32_t s2 = sc.nid[e];
-                const float x = (V(em2_map_sib(sc.ent_s1[e], L, P)) + V(em2_map_sib(sc.ent_s2[e], L, P))) + V(s2);
-                if (s2 < H) ab_h[s2] = x; else ab_g[s2] = x;
+            for (uint32_t e0 = tid; e0 < L; e0 += 4 * NT) {   // (four entries per thread and trip: their index loads, then their gathers, in flight together)
+                uint32_t s2[4], q1[4], q2[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t e = e0 + j * NT;
+                    const bool ok = e < L;
+                    s2[j] = ok ? sc.nid[e] : 0u; q1[j] = ok ? sc.ent_s1[e] : kSibNone; q2[j] = ok ? sc.ent_s2[e] : kSibNone;
+                }
+                float x[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] = (V(em2_map_sib(q1[j], L, P)) + V(em2_map_sib(q2[j], L, P))) + V(s2[j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (e0 + j * NT < L) { if (s2[j] < H) ab_h[s2[j]] = x[j]; else ab_g[s2[j]] = x[j]; }
             }
             em2_gsync();
         }
-        for (uint32_t c0 = tid; c0 < K; c0 += 2 * NT) {   // (as em2_class_pass, over state ids)
-            uint32_t o0[2], n[2], e[2][4];
-            float a[2][4];
+        for (uint32_t c0 = tid; c0 < K; c0 += 4 * NT) {   // (as em2_class_pass, over state ids, four classes per thread and trip)
+            uint32_t o0[4], n[4], e[4][4];
+            float a[4][4];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < 4; ++j) {
                 const uint32_t c = c0 + j * NT;
                 o0[j] = 0; n[j] = 0;
                 if (c < K) { o0[j] = sc.coff[c]; n[j] = sc.coff[c + 1] - o0[j]; }
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) e[j][k] = (uint32_t)k < n[j] ? sc.cw[o0[j] + k] : 0u;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) a[j][k] = (uint32_t)k < n[j] ? AB(e[j][k]) : 0.0f;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < 4; ++j) {
                 if (n[j] == 0) continue;
                 float d = 0.0f;
 #pragma unroll
@@ -706,16 +716,28 @@ __global__ __launch_bounds__(NT) void k_em2_rounds_hybrid(const uint32_t* __rest
         em2_gsync();
         bool bad = false;
         if (tid == 0) s_flag[(it + 1) & 1u] = 0;
-        for (uint32_t e = tid; e < L; e += NT) {
-            const uint32_t s2 = sc.nid[e];
-            const unsigned long long fresh = (unsigned long long)sc.ent_ucnt[e] << F;
-            unsigned long long a;
-            if (s2 < H) { a = acc_h[s2]; acc_h[s2] = fresh; }
-            else a = __hip_atomic_exchange(&acc_g[s2], fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const float x = (float)a * inv_scale;
-            const float old = V(s2);
-            if (x > kAlphaCheckCutoff2 && fabsf(old - x) > kRelDiffTol2) bad = true;
-            setV(s2, x);
+        for (uint32_t e0 = tid; e0 < L; e0 += 4 * NT) {
+            uint32_t s2[4], uc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const uint32_t e = e0 + j * NT; s2[j] = e < L ? sc.nid[e] : 0u; uc[j] = e < L ? sc.ent_ucnt[e] : 0u; }
+            unsigned long long a[4];
+            float old[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = 0; old[j] = 0.0f;
+                if (e0 + j * NT >= L) continue;
+                const unsigned long long fresh = (unsigned long long)uc[j] << F;
+                if (s2[j] < H) { a[j] = acc_h[s2[j]]; acc_h[s2[j]] = fresh; }
+                else a[j] = __hip_atomic_exchange(&acc_g[s2[j]], fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                old[j] = V(s2[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (e0 + j * NT >= L) continue;
+                const float x = (float)a[j] * inv_scale;
+                if (x > kAlphaCheckCutoff2 && fabsf(old[j] - x) > kRelDiffTol2) bad = true;
+                setV(s2[j], x);
+            }
         }
         if (it == 0) {
             for (uint32_t p = tid; p < P; p += NT) v_g[L + p] = (float)sc.pas_val[p];
