@@ -221,6 +221,7 @@ struct afq_ctx {
     uint64_t n_label_rehash = 0;   // ranges decoded again under another label-hash salt (life of the context)
     uint64_t n_pool_regrow = 0;    // ranges run again with a larger parsimony pool
     uint64_t n_em_resized = 0;     // ranges whose EM scratch was sized on the host after the device-side plan did not fit
+    uint32_t retry_cuts = 0;       // how many times the range being finished has been cut around a failing cell (finish_range)
     std::vector<TimedLaunch> launches;
     std::vector<hipEvent_t> event_pool;
     double k_ms[K_COUNT] = {0};
@@ -907,19 +908,35 @@ int finish_range(afq_ctx* c, int slot) {
         for (TimedLaunch& t : B.launches) { c->event_pool.push_back(t.a); c->event_pool.push_back(t.b); }   // (back to the pool, not into the kernel times)
         B.launches.clear();
     };
-    if (st.err_code == kErrLabelHash && B.hash_try + 1 < kMaxHashTries) {   // same range, next hash function (the input bytes are still resident)
-        c->n_label_rehash += 1;
+    // A label-hash collision or a graph that outgrew the pool names its cell.  The range is cut around that cell: the cells before
+    // and behind it run again as they were, the cell itself ALONE under the next hash function / with four times the pool - a pool
+    // for one cell, not for the range (a range sized to fill the device cannot have its pool quadrupled), and the other cells keep
+    // their hashes.  Every cut costs the range a re-run, so a range that keeps failing (every cell of it dense, or - in the tests -
+    // every label colliding) goes back to the round-3 answer after three cuts: the whole range under the next setting.
+    const bool rehash = st.err_code == kErrLabelHash && B.hash_try + 1 < kMaxHashTries;
+    const bool regrow = st.err_code == kErrPugPool && B.pool_try < kMaxPoolTries;
+    if (rehash || regrow) {
+        (rehash ? c->n_label_rehash : c->n_pool_regrow) += 1;
         take_back_attempt();
-        const int rc = run_range(c, B.cur, slot, nullptr, B.hash_try + 1, B.pool_try);
-        return rc ? rc : finish_range(c, slot);
-    }
-    if (st.err_code == kErrPugPool && B.pool_try < kMaxPoolTries) {   // same range, four times the pool (refused only when the device has no room for it)
-        c->n_pool_regrow += 1;
-        take_back_attempt();
-        const int rc = run_range(c, B.cur, slot, nullptr, B.hash_try, B.pool_try + 1);
-        const int rc2 = rc ? rc : finish_range(c, slot);
-        B.d_epool.release();   // the enlarged pool (x4 ... x64) is this range's alone: the next range plans its own
-        return rc2;
+        const Range whole = B.cur;
+        const uint32_t ht = B.hash_try, pt = B.pool_try, bad = whole.c0 + std::min(st.err_cell, whole.c1 - whole.c0 - 1);
+        int rc = 0;
+        if (whole.c1 - whole.c0 > 1 && c->retry_cuts < 3) {
+            c->retry_cuts += 1;
+            const Range parts[3] = {{whole.c0, bad}, {bad, bad + 1}, {bad + 1, whole.c1}};
+            for (int k = 0; k < 3 && !rc; ++k) {
+                if (parts[k].c1 == parts[k].c0) continue;
+                const bool the_cell = k == 1;
+                rc = run_range(c, parts[k], slot, nullptr, ht + (the_cell && rehash ? 1 : 0), pt + (the_cell && regrow ? 1 : 0));
+                if (!rc) rc = finish_range(c, slot);
+            }
+            c->retry_cuts -= 1;
+        } else {
+            rc = run_range(c, whole, slot, nullptr, ht + (rehash ? 1 : 0), pt + (regrow ? 1 : 0));
+            if (!rc) rc = finish_range(c, slot);
+        }
+        if (regrow) B.d_epool.release();   // the enlarged pool is that attempt's alone: the next range plans its own
+        return rc;
     }
     if (st.err_code) {
         const std::string cell = "cell " + std::to_string(B.cur.c0 + st.err_cell) + ": ";
