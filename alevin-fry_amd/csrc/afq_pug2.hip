@@ -312,6 +312,7 @@ __device__ __forceinline__ void part_body(const P2Args& A, const uint32_t* W, ui
             sh[vi] = h;
             su[vi] = (uo & 0xFFFFFFFF00000000ull) | (next - i) | (sig[e] << 10) | ((uint32_t)(h >> 62) << 29);
             A.v_off[o + vi] = (uint32_t)uo;
+            A.lidx[o + vi] = (uint32_t)(uo >> 32);   // the vertex's UMI on its own: what the search of the neighbouring partitions fetches (the graph kernel reuses the array afterwards)
         }
         before += (uint32_t)__popcll(vm[e]);
     }
@@ -471,15 +472,16 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
     }
     // The vertices of the partitions one low-bit change away, a partition at a time (its place is in lane k's registers): the
     // first 128 vertices of the NEXT partition are on their way while this one goes through the filter.
-    auto fetch = [&](uint32_t k, uint64_t (&v)[2], uint32_t& nq, uint32_t& oq) {
+    const uint32_t* cl = A.lidx + c.rd_base;   // UMIs only (k_p2_part): four bytes per foreign vertex instead of eight - this fetch is 12 of the 13 partitions a search reads
+    auto fetch = [&](uint32_t k, uint32_t (&v)[2], uint32_t& nq, uint32_t& oq) {
         nq = __builtin_amdgcn_readlane(f_n, k); oq = __builtin_amdgcn_readlane(f_o, k);
-        v[0] = lane < nq ? cu[oq + lane] : 0ull;
-        v[1] = lane + 64 < nq ? cu[oq + 64 + lane] : 0ull;
+        v[0] = lane < nq ? cl[oq + lane] : 0u;
+        v[1] = lane + 64 < nq ? cl[oq + 64 + lane] : 0u;
     };
     // (their filter checks are branch-free too: a passed probe is a bit (partition k, row r) in a per-lane mask; the drain fetches
     //  that vertex again - it is in the cache - instead of carrying a queue of (probe, slot, word) triples in registers)
     uint64_t fhits = 0;   // bit 2 k + r (k < 24: three changes of at most eight low bases)
-    uint64_t cur[2] = {0, 0}, nxt[2] = {0, 0};
+    uint32_t cur[2] = {0, 0}, nxt[2] = {0, 0};
     uint32_t nq = 0, oq = 0, nq2 = 0, oq2 = 0;
     if (nfor) fetch(0, cur, nq, oq);
     for (uint32_t k = 0; k < nfor; ++k) {
@@ -489,15 +491,14 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const uint32_t i = (uint32_t)r * 64 + lane;
-            const uint32_t umi = (uint32_t)(cur[r] >> 32);
+            const uint32_t umi = cur[r];
             const uint32_t f = fold11(umi) ^ fm;
             const uint32_t ok = (i < nq ? 1u : 0u) & (((umi >> tb) & 1u) ^ 1u) & ((s_filt[f >> 5] >> (f & 31u)) & 1u);
             fhits |= (uint64_t)ok << (2 * k + (uint32_t)r);
         }
         for (uint32_t i = 128 + lane; i < nq; i += 64) {   // (a partition of more than 128 vertices: the rest, plainly)
-            const uint64_t uw = cu[oq + i];
-            const uint32_t umi = (uint32_t)(uw >> 32), pu = umi ^ mk;
-            if (pu > umi && filt(pu)) probe(pu, oq + i, (uint32_t)uw, false);
+            const uint32_t umi = cl[oq + i], pu = umi ^ mk;
+            if (pu > umi && filt(pu)) probe(pu, oq + i, (uint32_t)cu[oq + i], false);
         }
         cur[0] = nxt[0]; cur[1] = nxt[1]; nq = nq2; oq = oq2;
     }
