@@ -121,7 +121,7 @@ EXPORTS = [
     "afq_infer",
     "afq_atac_dedup",
     "afq_atac_dedup_rad",
-    "afq_device_warmup", "afq_device_pci_bus_id", "afq_label_rehash_count", "afq_pool_regrow_count", "afq_em_resize_count",
+    "afq_device_warmup", "afq_device_pci_bus_id", "afq_label_rehash_count", "afq_pool_regrow_count", "afq_em_resize_count", "afq_mono_cell_count",
     "afq_free",
     "afq_get_kernel_times",
     "afq_get_batch_stats",

@@ -384,6 +384,12 @@ class Quantifier:
         self.lib.afq_pool_regrow_count.argtypes = [C.c_void_p]
         return int(self.lib.afq_pool_regrow_count(self._h))
 
+    def mono_cell_count(self) -> int:
+        """Parsimony cells resolved by the one-workgroup kernel (afq_mono_cell_count)."""
+        self.lib.afq_mono_cell_count.restype = C.c_uint64
+        self.lib.afq_mono_cell_count.argtypes = [C.c_void_p]
+        return int(self.lib.afq_mono_cell_count(self._h))
+
     def em_resize_count(self) -> int:
         """Ranges whose EM scratch had to be sized on the host (the device-side plan did not fit what was set aside)."""
         self.lib.afq_em_resize_count.restype = C.c_uint64

@@ -220,6 +220,7 @@ struct afq_ctx {
     afq_batch_stats stats{};
     uint64_t n_label_rehash = 0;   // ranges decoded again under another label-hash salt (life of the context)
     uint64_t n_pool_regrow = 0;    // ranges run again with a larger parsimony pool
+    uint64_t n_mono_cells = 0;     // parsimony cells resolved by the one-workgroup kernel (sent there directly, or handed back by the phase kernels)
     uint64_t n_em_resized = 0;     // ranges whose EM scratch was sized on the host after the device-side plan did not fit
     uint32_t retry_cuts = 0;       // how many times the range being finished has been cut around a failing cell (finish_range)
     std::vector<TimedLaunch> launches;
@@ -830,6 +831,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
             p2.n_cells = n_p2; p2.n_tiles = (uint32_t)p2tiles.size(); p2.n_parts = (uint32_t)p2_parts;
             {
                 const uint32_t big_reads = [] { const char* e = std::getenv("AFQ_P2_BIG_READS"); const long v = e ? std::atol(e) : 0; return v > 0 ? (uint32_t)v : 25000u; }();   // (measurements / tests: read per range; configs[2] graph kernels per step: 100 000: 30.9 ms, 60 000: 28.4, 40 000: 26.7, 25 000: 25.7, 12 000 and below: 25.4)
+                p2.max_comp = [] { const char* e = std::getenv("AFQ_P2_MAX_COMP"); const long v = e ? std::atol(e) : 0; return v >= 64 && v <= (long)kP2MaxComp ? (uint32_t)v : kP2MaxComp; }();   // (tests: 64 = larger components are handed back, as before round 4)
                 p2.n_big = 0;
                 while (p2.n_big < n_p2 && p2cells[p2.n_big].R >= big_reads) ++p2.n_big;   // (p2cells is largest first)
             }
@@ -876,7 +878,8 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
         void* d_view = nullptr;
         HIP_TRY(c, hipHostGetDevicePointer(&d_view, B.h_pack.p, 0));
         launch_pack_small(s, B.d_status.as<DevStatus>(), B.em_inline ? B.d_em2_tiers.as<uint32_t>() + 7 : nullptr, B.d_alt.as<uint32_t>(), B.d_nnz.as<uint32_t>(),
-                          B.em_inline ? B.d_em_nnz.as<uint32_t>() : nullptr, B.d_bc.as<uint64_t>(), n, reinterpret_cast<uint32_t*>(d_view));
+                          B.em_inline ? B.d_em_nnz.as<uint32_t>() : nullptr, B.d_bc.as<uint64_t>(),
+                          n_pug ? B.d_p2_small.as<uint32_t>() + p2_small_layout(n_p2, p2_parts, p2tiles.size(), n_pug).fb_count : nullptr, n, reinterpret_cast<uint32_t*>(d_view));
     }
     hc.lap("run: enqueue kernels");
     B.last_ra = ra;
@@ -956,6 +959,7 @@ int finish_range(afq_ctx* c, int slot) {
     c->stats.n_keys += st.n_keys;
     c->stats.n_overflow_buckets += st.n_overflow;
     c->stats.n_fallback_cells += st.n_fallback;
+    c->n_mono_cells += B.h_pack.p[9];
     std::vector<uint32_t> nnz(n);
     std::vector<uint64_t> bc(n), ptr(n + 1);
     const bool em = c->cfg.resolution == AFQ_RES_CR_LIKE_EM || c->cfg.resolution == AFQ_RES_PARSIMONY_EM ||
@@ -1266,6 +1270,7 @@ int afq_device_warmup(int device) {
 uint64_t afq_label_rehash_count(const afq_ctx* ctx) { return ctx ? ctx->n_label_rehash : 0; }
 uint64_t afq_pool_regrow_count(const afq_ctx* ctx) { return ctx ? ctx->n_pool_regrow : 0; }
 uint64_t afq_em_resize_count(const afq_ctx* ctx) { return ctx ? ctx->n_em_resized : 0; }
+uint64_t afq_mono_cell_count(const afq_ctx* ctx) { return ctx ? ctx->n_mono_cells : 0; }
 
 int afq_device_pci_bus_id(int device, char* out, size_t out_len) {
     if (!out || out_len < 13) return AFQ_ERR_INVALID_ARG;

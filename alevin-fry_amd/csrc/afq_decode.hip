@@ -1345,10 +1345,11 @@ void launch_range_init(hipStream_t s, const RangeInitOps& ops, const uint8_t* ar
 // Layout (u32 words): [0..7] DevStatus, [8] the EM's "scratch too small" flag, [16, 16+n) alt, then n nnz, n EM nnz, 2n barcode.
 __global__ __launch_bounds__(256) void k_pack_small(const DevStatus* __restrict__ st, const uint32_t* __restrict__ em_flag, const uint32_t* __restrict__ alt,
                                                     const uint32_t* __restrict__ nnz, const uint32_t* __restrict__ em_nnz,
-                                                    const uint64_t* __restrict__ bc, uint32_t n, uint32_t* __restrict__ out) {
+                                                    const uint64_t* __restrict__ bc, const uint32_t* __restrict__ n_mono, uint32_t n, uint32_t* __restrict__ out) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < sizeof(DevStatus) / 4) out[i] = reinterpret_cast<const uint32_t*>(st)[i];
     if (i == 8) out[8] = em_flag ? *em_flag : 0u;
+    if (i == 9) out[9] = n_mono ? *n_mono : 0u;
     if (i < n) {
         out[16 + i] = alt[i];
         out[16 + n + i] = nnz[i];
@@ -1359,8 +1360,8 @@ __global__ __launch_bounds__(256) void k_pack_small(const DevStatus* __restrict_
     }
 }
 void launch_pack_small(hipStream_t s, const DevStatus* st, const uint32_t* em_flag, const uint32_t* alt, const uint32_t* nnz, const uint32_t* em_nnz,
-                       const uint64_t* bc, uint32_t n, uint32_t* out) {
-    AFQ_LAUNCH(k_pack_small, (std::max(n, 16u) + 255) / 256, 256, s, st, em_flag, alt, nnz, em_nnz, bc, n, out);
+                       const uint64_t* bc, const uint32_t* n_mono, uint32_t n, uint32_t* out) {
+    AFQ_LAUNCH(k_pack_small, (std::max(n, 16u) + 255) / 256, 256, s, st, em_flag, alt, nnz, em_nnz, bc, n_mono, n, out);
 }
 
 void launch_gather_headers(hipStream_t s, const uint8_t* bytes, size_t n_bytes, const uint64_t* chunk_off,

@@ -69,7 +69,7 @@ struct RangeInitOps { RangeInitOp op[kRangeInitOps]; uint32_t n; };
 void launch_range_init(hipStream_t s, const RangeInitOps& ops, const uint8_t* arena);
 constexpr uint32_t kPackHdrWords = 16;   // k_pack_small: words in front of the per-cell arrays
 void launch_pack_small(hipStream_t s, const DevStatus* st, const uint32_t* em_flag, const uint32_t* alt, const uint32_t* nnz, const uint32_t* em_nnz,
-                       const uint64_t* bc, uint32_t n, uint32_t* out);
+                       const uint64_t* bc, const uint32_t* n_mono, uint32_t n, uint32_t* out);
 void launch_gather_headers(hipStream_t s, const uint8_t* bytes, size_t n_bytes, const uint64_t* chunk_off,
                            uint32_t n_cells, uint32_t* hdr);
 int launch_decode(hipStream_t s, const DecodeArgs& a, uint32_t bw, uint32_t uw);
@@ -183,6 +183,7 @@ struct P2Cell {
     uint32_t pad;
     uint64_t key_off;     // = meta[cell].key_off
 };
+constexpr uint32_t kP2MaxComp = 4096;   // 64 mask words, one per lane: the workgroup cover of k_p2_cover (afq_pug_common.h)
 struct P2Args {
     const uint8_t* bytes; const CellMeta* meta; const P2Cell* cells; const uint2* tiles; const uint32_t* order;
     const uint64_t* rd_h; const uint64_t* rd_u;        // the decode's reads: label key, umi << 32 | record offset
@@ -200,6 +201,7 @@ struct P2Args {
     DevStatus* st;
     uint32_t n_cells, n_tiles, n_parts, part_cap;
     uint32_t ref_count, num_genes, usa, num_rows, em, exact_umi, large_thresh, hw, umi_pairs;
+    uint32_t max_comp;   // vertices of the largest component the phase kernels cover themselves (kP2MaxComp; tests: AFQ_P2_MAX_COMP)
     uint32_t n_big;   // the first n_big cells of `order` (largest first) are big enough for a 1024-thread graph workgroup each
 };
 constexpr uint32_t kP2PartTarget = 160;   // planned mean reads per partition (the partition count is a power of two: 80..160)

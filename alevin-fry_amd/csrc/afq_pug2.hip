@@ -356,6 +356,13 @@ struct SearchLds {
     uint32_t filt[kP2FiltBits / 32];
     uint32_t np;
 };
+// OVER: the second pass over the partitions that found more pairs than they have slots of their own - k vertices of one UMI whose
+// labels overlap are k (k - 1) / 2 pairs (reads of one molecule that hit different members of a gene family), so a partition of n
+// reads can hold up to n^2 / 2.  The first pass left the count in pnp: the list gets that many slots out of the pool, the
+// partition's first own slot says where (the graph kernel tells by pnp > pcnt), and the search runs again.  (Until round 4 such a
+// cell went to the one-workgroup kernel: on the label-tail workload that kernel was 40 ms of the 370 ms step.  A kernel of its
+// own, not a second trip through a loop here: the loop took the search from 79 to 127 VGPRs.)
+template <bool OVER>
 __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, SearchLds& S, uint32_t lane) {
     uint32_t* t_umi = S.umi; uint32_t* t_word = S.word; uint16_t* t_idx = S.idx;
     uint32_t* s_filt = S.filt; uint32_t* s_np = &S.np;
@@ -365,13 +372,25 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
     const P2Cell c = A.cells[j];
     const uint32_t m = c.lgP, P = 1u << m, p = gp - c.part_base;
     const uint32_t lo_p = A.poff[gp];                 // the partition's first slot inside the cell
-    const uint32_t pcap = A.pcnt[gp];                 // ... and how many it has: the partition's pairs go into its own slots of the pair array
+    uint32_t pcap = A.pcnt[gp];                       // ... and how many it has: the partition's pairs go into its own slots of the pair array
+    if (OVER && A.pnp[gp] <= pcap) return;
     const uint64_t* ch = A.s_h + c.rd_base;           // the cell's vertex arrays
     const uint64_t* cu = A.s_u + c.rd_base;
     const uint32_t* coff = A.v_off + c.rd_base;
     uint8_t* cflag = A.v_flag + c.rd_base;
     uint64_t* ppair = A.pairs + c.rd_base + lo_p;
     const uint32_t* W = reinterpret_cast<const uint32_t*>(A.bytes + c.chunk_off);
+    if (OVER) {
+        const uint32_t np = A.pnp[gp];
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(A.pool_cur, 2ull * np + 2);
+        base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+        if (base + 2ull * np + 2 > A.pool_cap) { if (lane == 0) { set_err(A.st, kErrPugPool, c.cell); A.pnp[gp] = 0; } return; }   // (the host runs the cell again with a larger pool)
+        base = (base + 1) & ~1ull;
+        if (lane == 0) ppair[0] = base;
+        ppair = reinterpret_cast<uint64_t*>(A.pool + base);
+        pcap = np;
+    }
     // the foreign partitions' places go out first: their latency hides under the table build
     const uint32_t nfor = A.exact_umi ? 0u : 3 * ((m + 1) / 2);
     uint32_t f_n = 0, f_o = 0;
@@ -515,17 +534,24 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
     }
     WAVE_SYNC();
     const uint32_t np = *s_np;
-    if (lane == 0) {
-        A.pnp[gp] = np < pcap ? np : pcap;
-        if (np > pcap) A.fb[j] = 1;   // (more pairs than the partition has slots: the one-workgroup kernel takes the cell)
-    }
+    if (lane == 0 && !OVER) A.pnp[gp] = np;   // (more than pcap: the second pass takes the partition)
     WAVE_SYNC();
 }
 __global__ __launch_bounds__(256) void k_p2_search(P2Args A) {
     if (A.st->err_code) return;   // an earlier kernel of the range failed (e.g. kErrLabelHash in k_p2_part, which then leaves its partition's vertices unwritten): nothing behind it may read that state - the host runs the range again or reports the error
     __shared__ SearchLds s_lds[4];
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    for (uint32_t gp = blockIdx.x * 4 + wv; gp < A.n_parts; gp += gridDim.x * 4) search_body(A, gp, s_lds[wv], lane);
+    for (uint32_t gp = blockIdx.x * 4 + wv; gp < A.n_parts; gp += gridDim.x * 4) search_body<false>(A, gp, s_lds[wv], lane);
+}
+__global__ __launch_bounds__(256) void k_p2_search_over(P2Args A) {
+    if (A.st->err_code) return;
+    __shared__ SearchLds s_lds[4];
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    for (uint32_t g0 = (blockIdx.x * 4 + wv) * 64; g0 < A.n_parts; g0 += gridDim.x * 256) {   // 64 partitions' counts at a time, a lane each
+        const uint32_t gp = g0 + lane;
+        uint64_t over = __ballot(gp < A.n_parts && A.pnp[gp] > A.pcnt[gp]);
+        for (; over; over &= over - 1) search_body<true>(A, g0 + (uint32_t)__builtin_ctzll(over), s_lds[wv], lane);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -631,7 +657,7 @@ constexpr int kGNT = 256;
 #endif
 constexpr uint32_t kGTab = AFQ_GTAB;          // class table slots when it lives in LDS (keys: 32 KiB, minima: 16 KiB of the block)
 // (it takes 3/4 of its slots less a margin in classes; beyond that the table is carved out of the pool)
-constexpr uint32_t kCatPair = 1, kCatTiny = 2, kCatMid = 3;
+constexpr uint32_t kCatPair = 1, kCatTiny = 2, kCatMid = 3, kCatBig = 4;
 
 template <int GNT>
 __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, uint32_t work_hi, uint32_t* counter) {
@@ -675,6 +701,7 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
     //         a hashed label key ----
     const uint32_t P = 1u << c.lgP;
     const uint32_t* pnp = A.pnp + c.part_base;
+    const uint32_t* pcn = A.pcnt + c.part_base;
     const uint32_t* pncls = A.pncls + c.part_base;
     const uint32_t* ppoff = A.poff + c.part_base;
     uint32_t n_pairs = 0, n_cls2 = 0;
@@ -769,11 +796,12 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
     gsync();
     for (uint32_t pp = tid; pp < P; pp += GNT) {   // the partition's pairs over touched-vertex numbers, four at a time
         const uint32_t nk = pnp[pp], so = ppoff[pp], at = ppre[2 * pp];
+        const uint64_t* src = nk > pcn[pp] ? reinterpret_cast<const uint64_t*>(A.pool + psrc[so]) : psrc + so;   // (more pairs than own slots: the search put the list into the pool)
         for (uint32_t k0 = 0; k0 < nk; k0 += 4) {
             uint64_t pr[4];
             uint32_t lx[4], ly[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pr[r] = k0 + r < nk ? psrc[so + k0 + r] : 0ull;
+            for (int r = 0; r < 4; ++r) pr[r] = k0 + r < nk ? src[k0 + r] : 0ull;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { lx[r] = k0 + r < nk ? lidx[(uint32_t)(pr[r] >> 31) & 0x7FFFFFFFu] : 0u; ly[r] = k0 + r < nk ? lidx[(uint32_t)pr[r] & 0x7FFFFFFFu] : 0u; }
 #pragma unroll
@@ -811,49 +839,54 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
         if (!s_flag[0]) break;
     }
     G_MARK(3);
-    // ---- 3. the components by counting: sizes per root, then by size pairs / 3..8 / 9..64 (anything else is not for this
-    //         kernel), every listed component's slots, every vertex into its component's next slot ----
+    // ---- 3. the components by counting: sizes per root, then by size pairs / 3..8 / 9..64 / 65..4096 (anything else - a
+    //         component above --large-graph-thresh, which the reference resolves winner-take-all - is not for this kernel),
+    //         every listed component's slots, every vertex into its component's next slot ----
     for (uint32_t i = tid; i < NT; i += GNT) { uint32_t l = ldw(i); for (uint32_t nx = ldw(l); nx != l; nx = ldw(l)) l = nx; root_of[i] = l; wg_add(&rcnt[l], 1u); }
     gsync();
-    uint32_t n_pr = 0, n_tiny = 0, n_mid9 = 0;
+    uint32_t n_pr = 0, n_tiny = 0, n_mid9 = 0, n_bigc = 0;
     bool big = false;
     for (uint32_t base = 0; base < NT; base += GNT) {
         const uint32_t i = base + tid;
         uint32_t cat = 0;
         if (i < NT && root_of[i] == i) {
             const uint32_t n = ld_l2(&rcnt[i]);
-            if (n > 64 || n > C.large_thresh) big = true;
-            else cat = n == 2 ? kCatPair : n <= 8 ? kCatTiny : kCatMid;
+            if (n > A.max_comp || n > C.large_thresh) big = true;
+            else cat = n == 2 ? kCatPair : n <= 8 ? kCatTiny : n <= 64 ? kCatMid : kCatBig;
         }
         uint32_t tot, tot_mid;   // (two scans: three counts of up to GNT = 1024 do not fit one word)
         const uint32_t ex = block_excl_scan<GNT>((cat == kCatPair) | ((uint32_t)(cat == kCatTiny) << 16), s_ws, tot);
-        const uint32_t ex_mid = block_excl_scan<GNT>((uint32_t)(cat == kCatMid), s_ws, tot_mid);
+        const uint32_t ex_mid = block_excl_scan<GNT>((uint32_t)(cat == kCatMid) | ((uint32_t)(cat == kCatBig) << 16), s_ws, tot_mid);
         if (cat) {
-            const uint32_t idx = cat == kCatPair ? n_pr + (ex & 0xFFFFu) : cat == kCatTiny ? n_tiny + (ex >> 16) : n_mid9 + ex_mid;
+            const uint32_t idx = cat == kCatPair ? n_pr + (ex & 0xFFFFu) : cat == kCatTiny ? n_tiny + (ex >> 16) : cat == kCatMid ? n_mid9 + (ex_mid & 0xFFFFu) : n_bigc + (ex_mid >> 16);
             const uint32_t n = ld_l2(&rcnt[i]);
             st_l2(&rcnt[i], (cat << 28) | idx);            // (a root's word is read and written by its own thread only in this pass)
             if (cat == kCatTiny) lsize[idx] = n;          // (the 9..64 ones are placed behind the small ones once those are counted)
-            else if (cat == kCatMid) st_l2(&fill[i], n);   // (parked in the root's fill word until then)
+            else if (cat != kCatPair) st_l2(&fill[i], n);   // (parked in the root's fill word until then)
         }
-        n_pr += tot & 0xFFFFu; n_tiny += tot >> 16; n_mid9 += tot_mid;
+        n_pr += tot & 0xFFFFu; n_tiny += tot >> 16; n_mid9 += tot_mid & 0xFFFFu; n_bigc += tot_mid >> 16;
     }
     if (big) s_flag[1] = 1;
     gsync();
     if (s_flag[1]) { give_up(); continue; }
-    const uint32_t n_mid = n_tiny + n_mid9;
+    const uint32_t n_mid = n_tiny + n_mid9, n_all = n_mid + n_bigc;   // the list: 3..8, then 9..64, then 65..4096
+    auto listed_at = [&](uint32_t cat, uint32_t idx) -> uint32_t { return cat == kCatTiny ? idx : cat == kCatMid ? n_tiny + idx : n_mid + idx; };
     for (uint32_t i = tid; i < NT; i += GNT)
-        if (root_of[i] == i) { const uint32_t rc = ld_l2(&rcnt[i]); if ((rc >> 28) == kCatMid) { lsize[n_tiny + (rc & 0xFFFFFFFu)] = ld_l2(&fill[i]); st_l2(&fill[i], 0u); } }
+        if (root_of[i] == i) {
+            const uint32_t rc = ld_l2(&rcnt[i]), cat = rc >> 28;
+            if (cat == kCatMid || cat == kCatBig) { lsize[listed_at(cat, rc & 0xFFFFFFFu)] = ld_l2(&fill[i]); st_l2(&fill[i], 0u); }
+        }
     gsync();
     uint32_t S_mid = 0;
-    for (uint32_t base = 0; base < n_mid; base += GNT) {
+    for (uint32_t base = 0; base < n_all; base += GNT) {
         const uint32_t ci = base + tid;
-        const uint32_t n = ci < n_mid ? lsize[ci] : 0u;
+        const uint32_t n = ci < n_all ? lsize[ci] : 0u;
         uint32_t tot;
         const uint32_t ex = block_excl_scan<GNT>(n, s_ws, tot);
-        if (ci < n_mid) mid_off[ci] = S_mid + ex;
+        if (ci < n_all) mid_off[ci] = S_mid + ex;
         S_mid += tot;
     }
-    if (tid == 0) mid_off[n_mid] = S_mid;
+    if (tid == 0) mid_off[n_all] = S_mid;
     // per slot of a listed component: its vertex, its component, its class minimum; and one region that first holds the class
     // table (when it does not fit LDS) and then the order keys, adjacency masks and cover records (12 words per slot)
     const uint32_t want = S_mid;   // (vertices: an upper bound of the classes the table will hold)
@@ -875,12 +908,31 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
     uint4* mrec = reinterpret_cast<uint4*>(u_base);                                   // [2 * S_mid]
     uint64_t* okey = reinterpret_cast<uint64_t*>(u_base + 8 * (size_t)S_mid);         // [S_mid] (class minimum, UMI)
     unsigned long long* adjp = reinterpret_cast<unsigned long long*>(u_base + 10 * (size_t)S_mid);   // [S_mid] out-neighbours of the vertex at this position, as positions inside its component
+    // components of more than 64 vertices: their adjacency as rows of ceil(n / 64) mask words, n rows each, in a region of its own;
+    // where a component's rows start (in 64-bit words) takes over its entry of lsize[], which is read for the last time above
+    uint32_t* const rowoff = lsize + n_mid;
+    unsigned long long* rows = nullptr;
+    if (n_bigc) {
+        uint32_t rows_tot = 0;
+        for (uint32_t base = 0; base < n_bigc; base += GNT) {
+            const uint32_t b = base + tid;
+            const uint32_t n = b < n_bigc ? mid_off[n_mid + b + 1] - mid_off[n_mid + b] : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<GNT>(n * ((n + 63) / 64), s_ws, tot);
+            if (b < n_bigc) rowoff[b] = rows_tot + ex;
+            rows_tot += tot;
+        }
+        uint32_t* rq = pool_take(2ull * rows_tot + 4);
+        if (!rq) return;
+        rows = reinterpret_cast<unsigned long long*>(rq);
+        for (uint32_t i = tid; i < rows_tot; i += GNT) st_l2(&rows[i], 0ull);
+    }
     for (uint32_t i = tid; i < NT; i += GNT) {
         const uint32_t r = root_of[i], rc = ld_l2(&rcnt[r]), cat = rc >> 28, idx = rc & 0xFFFFFFFu;
         const uint32_t at = wg_add(&fill[r], 1u);
         if (cat == kCatPair) pr_v[2 * idx + at] = i;
         else {
-            const uint32_t ci = cat == kCatTiny ? idx : n_tiny + idx;
+            const uint32_t ci = listed_at(cat, idx);
             const uint32_t sl = mid_off[ci] + at;
             slot_v[sl] = i; slot_comp[sl] = ci;
         }
@@ -1039,7 +1091,15 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
         const uint32_t x = (uint32_t)e & 0xFFFFFFu, y = (uint32_t)(e >> 24) & 0xFFFFFFu;
         const uint32_t rc = ld_l2(&rcnt[root_of[x]]), cat = rc >> 28;
         if (cat == kCatPair) continue;
-        const uint32_t b0 = mid_off[cat == kCatTiny ? (rc & 0xFFFFFFFu) : n_tiny + (rc & 0xFFFFFFFu)];   // (x and y share their component)
+        if (cat == kCatBig) {
+            const uint32_t b = rc & 0xFFFFFFFu, n = mid_off[n_mid + b + 1] - mid_off[n_mid + b], nw = (n + 63) / 64;
+            unsigned long long* rw = rows + rowoff[b];
+            const uint32_t ix = cidx[x], iy = cidx[y];
+            if (e & (2ull << 48)) __hip_atomic_fetch_or(&rw[(size_t)ix * nw + (iy >> 6)], 1ull << (iy & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // x -> y
+            if (e & (1ull << 48)) __hip_atomic_fetch_or(&rw[(size_t)iy * nw + (ix >> 6)], 1ull << (ix & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // y -> x
+            continue;
+        }
+        const uint32_t b0 = mid_off[listed_at(cat, rc & 0xFFFFFFFu)];   // (x and y share their component)
         if (e & (2ull << 48)) __hip_atomic_fetch_or(&adjp[b0 + cidx[x]], 1ull << cidx[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // x -> y
         if (e & (1ull << 48)) __hip_atomic_fetch_or(&adjp[b0 + cidx[y]], 1ull << cidx[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // y -> x
     }
@@ -1074,8 +1134,13 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
     if (tid == 0) {
         uint32_t* d = A.gdesc + 16 * (size_t)j;
         auto put = [&](int at, const void* ptr) { const unsigned long long o = (unsigned long long)(reinterpret_cast<const uint32_t*>(ptr) - A.pool); d[at] = (uint32_t)o; d[at + 1] = (uint32_t)(o >> 32); };
-        d[1] = n_pr; d[2] = n_tiny; d[3] = n_mid;
+        d[1] = n_pr; d[2] = n_tiny; d[3] = n_mid; d[15] = n_bigc;
         put(4, tl); put(6, pr_v); put(8, mid_off); put(10, mrec);
+        if (n_bigc) {   // (where the rows and their offsets lie: behind the list's last offset - there are at most NT / 65 + (NT - 65) / 3 + 1 listed components and NT + 2 words)
+            const unsigned long long ro = (unsigned long long)(reinterpret_cast<const uint32_t*>(rows) - A.pool), oo = (unsigned long long)(rowoff - A.pool);
+            mid_off[n_all + 1] = (uint32_t)ro; mid_off[n_all + 2] = (uint32_t)(ro >> 32);
+            mid_off[n_all + 3] = (uint32_t)oo; mid_off[n_all + 4] = (uint32_t)(oo >> 32);
+        }
         d[12] = s_cnt[0]; d[13] = s_cnt[1]; d[14] = s_cnt[2];
         d[0] = 1;
     }
@@ -1091,6 +1156,8 @@ __global__ __launch_bounds__(CNT) void k_p2_cover(P2Args A, uint32_t work_lo, ui
     if (A.st->err_code) return;
     __shared__ uint32_t s_cnt[4];
     __shared__ uint32_t s_next;
+    __shared__ uint64_t s_mask[2][64];                     // the workgroup cover: uncovered vertices, the round's arborescence
+    __shared__ uint32_t s_bestv[CNT / 64], s_bestsz[CNT / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   for (;;) {
     __syncthreads();
@@ -1164,6 +1231,12 @@ __global__ __launch_bounds__(CNT) void k_p2_cover(P2Args A, uint32_t work_lo, ui
     }
     cover_tiny8<CNT / 64>(C, mrec, mid_off, n_tiny, wv, lane);
     cover_wave64<CNT / 64>(C, mrec, mid_off, n_tiny, n_mid, wv, lane);
+    if (const uint32_t n_bigc = d[15]) {   // 65..4096 vertices: the graph kernel left their adjacency as rows of mask words
+        const uint32_t* x = mid_off + n_mid + n_bigc + 1;
+        const uint64_t* rows = reinterpret_cast<const uint64_t*>(A.pool + (((unsigned long long)x[1] << 32) | x[0]));
+        const uint32_t* rowoff = A.pool + (((unsigned long long)x[3] << 32) | x[2]);
+        cover_big<CNT / 64>(C, mrec, mid_off, n_mid, n_bigc, rowoff, rows, s_mask, s_bestv, s_bestsz, wv, lane);
+    }
     gsync();
     if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], c.cell); return; }
     if (tid == 0) {
@@ -1188,7 +1261,11 @@ static uint32_t p2_grid(uint32_t n_parts) {   // AFQ_P2_GRID caps the workgroups
     return cap && cap < full ? cap : full;
 }
 void launch_p2_part(hipStream_t s, const P2Args& a) { if (a.n_parts) AFQ_LAUNCH(k_p2_part, p2_grid(a.n_parts), 256, s, a); }
-void launch_p2_search(hipStream_t s, const P2Args& a) { if (a.n_parts) AFQ_LAUNCH(k_p2_search, p2_grid(a.n_parts), 256, s, a); }
+void launch_p2_search(hipStream_t s, const P2Args& a) {
+    if (!a.n_parts) return;
+    AFQ_LAUNCH(k_p2_search, p2_grid(a.n_parts), 256, s, a);
+    AFQ_LAUNCH(k_p2_search_over, std::min((a.n_parts + 255) / 256, 2048u), 256, s, a);   // (the partitions with more pairs than slots, normally none: two counts per partition are read)
+}
 void launch_p2_lone(hipStream_t s, const P2Args& a) { if (a.n_parts) AFQ_LAUNCH(k_p2_lone, p2_grid(a.n_parts), 256, s, a); }
 void launch_p2_graph(hipStream_t s, const P2Args& a) {
     if (!a.n_cells) return;

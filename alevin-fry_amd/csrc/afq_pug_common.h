@@ -511,4 +511,137 @@ __device__ __forceinline__ void cover_wave64(const PugCtx& C, const uint4* mrec,
     }
     }
 
+    // ---- 6c'. components of 65..4096 vertices, one at a time by the whole workgroup ----
+    // The same greedy cover over multi-word masks: lane l of a wave holds mask word l, the component's adjacency is n rows of
+    // nw = ceil(n / 64) words (`rows`), the uncovered set and the round's best arborescence sit in LDS (s_mask[0], s_mask[1]).
+    // The candidates of a round - the uncovered vertices, ascending - are dealt to the waves; the winner is the largest
+    // arborescence, the smallest vertex among equals (the reference takes the first it meets in ascending order: pugutils.rs:1090-1160).
+__device__ __forceinline__ bool rec_contains(const uint4& qa, const uint4& qb, uint32_t t) {
+    if (qa.y <= 4) return t == qa.z || t == qa.w || t == qb.x || t == qb.y;   // (unused places hold 0xFFFFFFFF: no ref)
+    const Lab l{reinterpret_cast<const uint32_t*>((uintptr_t)(((uint64_t)qa.w << 32) | qa.z)), qa.y};
+    return lab_contains(l, t);
+}
+template <int NWAVES>
+__device__ __forceinline__ void cover_big(const PugCtx& C, const uint4* mrec, const uint32_t* mid_off, uint32_t first, uint32_t count,
+                                          const uint32_t* rowoff, const uint64_t* rows_base, uint64_t (*s_mask)[64], uint32_t* s_bestv, uint32_t* s_bestsz,
+                                          uint32_t wv, uint32_t lane)
+{
+    const uint32_t tid = wv * 64 + lane;
+    for (uint32_t b = 0; b < count; ++b) {
+        const uint32_t c0 = mid_off[first + b], n = mid_off[first + b + 1] - c0, nw = (n + 63) / 64;
+        const uint64_t* rows = rows_base + rowoff[b];
+        __syncthreads();
+        if (tid < nw) s_mask[0][tid] = (tid + 1 < nw || (n & 63) == 0) ? ~0ull : ((1ull << (n & 63)) - 1);
+        __syncthreads();
+        for (;;) {
+            uint32_t rem = 0;
+            for (uint32_t w = 0; w < nw; ++w) rem += (uint32_t)__popcll(s_mask[0][w]);
+            if (rem == 0) break;
+            uint32_t my_best_sz = 0, my_best_v = 0xFFFFFFFFu;
+            uint64_t my_best_word = 0;   // lane l: word l of this wave's best arborescence
+            const uint64_t ucw = lane < nw ? s_mask[0][lane] : 0ull;
+            uint32_t seen = 0;
+            for (uint32_t w = 0; w < nw && my_best_sz != rem; ++w) {
+                uint64_t bits = s_mask[0][w];
+                for (; bits; bits &= bits - 1, ++seen) {
+                    if (seen % (NWAVES) != wv) continue;
+                    const uint32_t v = w * 64 + (uint32_t)__builtin_ctzll(bits);
+                    RecLab lv;
+                    rec_lab(mrec, (size_t)c0 + v, lv);
+                    uint64_t mvw = 0;
+                    uint32_t mv_sz = 0;
+                    for (uint32_t j = 0; j < lv.l.n; ++j) {
+                        const uint32_t t = lv.l.p[j] & 0x7FFFFFFFu;
+                        uint64_t Aw = 0;   // uncovered vertices whose label has t: 64 vertices per step, a lane each
+                        for (uint32_t cw = 0; cw < nw; ++cw) {
+                            const uint32_t i = cw * 64 + lane;
+                            const uint64_t ucword = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(ucw >> 32), (int)cw) << 32) | (uint32_t)__shfl((int)(uint32_t)ucw, (int)cw);
+                            bool in = i < n && ((ucword >> lane) & 1ull);
+                            if (in) { const uint4 qa = mrec[2 * ((size_t)c0 + i)], qb = mrec[2 * ((size_t)c0 + i) + 1]; in = rec_contains(qa, qb, t); }
+                            const uint64_t word = __ballot(in);
+                            if (lane == cw) Aw = word;
+                        }
+                        uint64_t Rw = (lane == (v >> 6)) ? (1ull << (v & 63)) : 0ull, Fw = Rw;
+                        for (;;) {
+                            uint64_t Nw = 0;   // OR of the rows of the frontier's vertices
+                            for (uint32_t fw = 0; fw < nw; ++fw) {
+                                uint64_t fb = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(Fw >> 32), (int)fw) << 32) | (uint32_t)__shfl((int)(uint32_t)Fw, (int)fw);
+                                for (; fb; fb &= fb - 1) {
+                                    const uint32_t x = fw * 64 + (uint32_t)__builtin_ctzll(fb);
+                                    if (lane < nw) Nw |= rows[(size_t)x * nw + lane];
+                                }
+                            }
+                            Fw = Nw & Aw & ~Rw;
+                            Rw |= Fw;
+                            if (!__any(Fw != 0)) break;
+                        }
+                        uint32_t sz = (uint32_t)__popcll(Rw);
+#pragma unroll
+                        for (int dd = 32; dd > 0; dd >>= 1) sz += __shfl_xor(sz, dd);
+                        if (sz > mv_sz) { mv_sz = sz; mvw = Rw; }
+                    }
+                    if (mv_sz > my_best_sz) { my_best_sz = mv_sz; my_best_v = v; my_best_word = mvw; }
+                    if (my_best_sz == rem) break;   // (everything that is left: no later candidate is larger, none of this wave's is earlier)
+                }
+            }
+            if (lane == 0) { s_bestv[wv] = my_best_v; s_bestsz[wv] = my_best_sz; }
+            __syncthreads();
+            uint32_t win = 0;
+            for (uint32_t w = 1; w < (uint32_t)(NWAVES); ++w)
+                if (s_bestsz[w] > s_bestsz[win] || (s_bestsz[w] == s_bestsz[win] && s_bestv[w] < s_bestv[win])) win = w;
+            if (s_bestsz[win] == 0) { if (tid == 0) C.s_cnt[3] = kErrPugLimit; break; }   // a vertex with an empty label
+            if (wv == win && lane < nw) s_mask[1][lane] = my_best_word;
+            __syncthreads();
+            if (wv == 0) {   // the refs every vertex of the arborescence has (pugutils.rs:1161-1188) -> genes
+                uint32_t fv = 0xFFFFFFFFu;
+                for (uint32_t w = 0; w < nw && fv == 0xFFFFFFFFu; ++w) if (s_mask[1][w]) fv = w * 64 + (uint32_t)__builtin_ctzll(s_mask[1][w]);
+                RecLab lf;
+                rec_lab(mrec, (size_t)c0 + fv, lf);
+                auto all_have = [&](uint32_t t) -> bool {   // wave-wide
+                    for (uint32_t cw = 0; cw < nw; ++cw) {
+                        const uint32_t i = cw * 64 + lane;
+                        bool miss = i < n && ((s_mask[1][cw] >> lane) & 1ull);
+                        if (miss) { const uint4 qa = mrec[2 * ((size_t)c0 + i)], qb = mrec[2 * ((size_t)c0 + i) + 1]; miss = !rec_contains(qa, qb, t); }
+                        if (__any(miss)) return false;
+                    }
+                    return true;
+                };
+                uint32_t g[kMaxGenesPerLabel];
+                uint32_t ng = 0;
+                bool wide = false;
+                for (uint32_t j = 0; j < lf.l.n; ++j) {
+                    const uint32_t t = lf.l.p[j] & 0x7FFFFFFFu;
+                    if (!all_have(t)) continue;
+                    if (lane == 0) {
+                        const uint32_t gid = C.gene_level ? t : C.t2g[t];
+                        uint32_t q = 0;
+                        while (q < ng && g[q] < gid) ++q;
+                        if (!(q < ng && g[q] == gid)) {
+                            if (ng == kMaxGenesPerLabel) wide = true;
+                            else { for (uint32_t r = ng; r > q; --r) g[r] = g[r - 1]; g[q] = gid; ++ng; }
+                        }
+                    }
+                }
+                if (lane == 0) {
+                    if (wide && C.em)
+                        emit_wide_class(C, lf.l.n, [&](uint32_t j) -> uint32_t {
+                            const uint32_t t = lf.l.p[j] & 0x7FFFFFFFu;
+                            for (uint32_t cw = 0; cw < nw; ++cw)
+                                for (uint64_t m = s_mask[1][cw]; m; m &= m - 1) {
+                                    const size_t sl = (size_t)c0 + cw * 64 + (uint32_t)__builtin_ctzll(m);
+                                    if (!rec_contains(mrec[2 * sl], mrec[2 * sl + 1], t)) return 0xFFFFFFFFu;
+                                }
+                            return t;
+                        });
+                    else emit_molecule(C, g, wide ? 0xFFFFFFFFu : ng);
+                }
+            }
+            __syncthreads();
+            if (tid < nw) s_mask[0][tid] &= ~s_mask[1][tid];
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace afq

@@ -289,6 +289,10 @@ uint64_t afq_pool_regrow_count(const afq_ctx* ctx);
 /* EM resolutions: ranges whose EM did not fit the device scratch set aside for it ahead of time and was sized on the host
  * instead (one extra trip to the host for that range; results identical).  Diagnostics only. */
 uint64_t afq_em_resize_count(const afq_ctx* ctx);
+/* Parsimony: cells resolved by the one-workgroup kernel instead of the partition-parallel phase kernels - sent there directly
+ * (gene-level parsimony, 8-byte UMIs) or handed back (a UMI partition of more than 256 reads, a component above
+ * --large-graph-thresh or of more than 4096 vertices).  Results identical; diagnostics only. */
+uint64_t afq_mono_cell_count(const afq_ctx* ctx);
 
 /* Brings the HIP runtime up on `device` (first-call initialisation) - a host can call it from a side thread while it parses its
    inputs.  Returns 0 or AFQ_ERR_NO_DEVICE. */

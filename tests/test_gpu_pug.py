@@ -368,3 +368,73 @@ def test_parsimony_cell_of_more_than_2_pow_20_reads(oracle, pug_route):
         q.close()
     want = oracle.quant(cfg, d.tid_to_gid, d.data, d.chunk_off)
     assert_same_result(got, want)
+
+
+@pytest.mark.parametrize("res,usa", [("parsimony", False), ("parsimony-em", True)])
+def test_components_of_65_to_4096_vertices_stay_with_the_phase_kernels(oracle, monkeypatch, pug_route, res, usa):
+    """Short UMIs in a cell of a few thousand reads chain hundreds of vertices into one component.  Up to 4096 vertices (and
+    --large-graph-thresh) the phase kernels cover such a component themselves, a workgroup to it (cover_big in
+    csrc/afq_pug_common.h); until round 4 its cell went back to the one-workgroup kernel.  afq_mono_cell_count says which
+    kernel had the cells; AFQ_P2_MAX_COMP=64 brings the old routing back - same rows (pugutils.rs:1004-1200)."""
+    # (components of 2499, 1117, 132, 70 vertices without the USA labels, of 2552, 1119, 192 with them)
+    s = synth.synth(6107, [3000, 1500, 700, 300, 90], num_genes=4, txp_per_gene=3, usa=usa, dup=0.35, cross=0.5, umi_err=0.05, max_extra_na=5, umi_len=5)
+    b, off = s.encode()
+    cfg = cfg_for(s, res, small_thresh=0, large_graph_thresh=4096)
+    want = oracle.quant(cfg, s.tid_to_gid, b, off)
+
+    def run():
+        q = pkg.Quantifier(cfg, s.tid_to_gid)
+        try:
+            return q.quant_chunks(b, off), q.mono_cell_count()
+        finally:
+            q.close()
+
+    got, n_mono = run()
+    assert_same_result(got, want, what=res)
+    if pug_route in ("phase-kernels", "graph-1024"):
+        assert n_mono == 0, "no cell should have needed the one-workgroup kernel"
+        monkeypatch.setenv("AFQ_P2_MAX_COMP", "64")
+        got64, n_mono64 = run()
+        assert n_mono64 >= 3, "the cells were meant to hold components of more than 64 vertices"
+        assert_same_result(got64, want, what=res + ", components over 64 vertices handed back")
+    elif pug_route == "one-workgroup":
+        assert n_mono == 5
+
+
+@pytest.mark.parametrize("res", ["parsimony", "parsimony-em"])
+def test_more_pairs_than_reads_stay_with_the_phase_kernels(oracle, pug_route, res):
+    """Reads of one molecule that hit different members of a gene family: one UMI under a dozen labels that all overlap - every
+    two of them are a pair (66 pairs for 12 reads), and the partition's pair list outgrows its own slots, one per read.  The
+    search then takes the list's slots out of the pool in a second pass (k_p2_search_over); until round 4 the whole cell went to
+    the one-workgroup kernel (has_edge at distance 0: pugutils.rs:76-99)."""
+    rng = np.random.default_rng(991)
+    n_txp = 64                                  # eight families of eight transcripts, a gene per transcript pair
+    t2g = (np.arange(n_txp) // 2).astype(np.uint32)
+    cells = []
+    for ci, n_umi in enumerate([400, 120, 30, 5]):
+        reads = []
+        umis = rng.choice(1 << 20, size=n_umi, replace=False)
+        for u in umis:
+            fam = int(rng.integers(0, 8)) * 8
+            anchor = fam + int(rng.integers(0, 8))
+            for _ in range(int(rng.integers(6, 14))):
+                extra = rng.choice(8, size=int(rng.integers(0, 5)), replace=False)
+                lab = sorted({anchor} | {fam + int(e) for e in extra})
+                umi = int(u)
+                if rng.random() < 0.1:
+                    umi ^= 1 << (2 * int(rng.integers(0, 10)))   # a one-base neighbour now and then
+                reads.append((umi, lab))
+        order = rng.permutation(len(reads))
+        cells.append((1000 + ci, [reads[i] for i in order]))
+    b, off = rad.encode_cells(cells, 4, 4)
+    cfg = pkg.WorkerConfig.for_resolution(res, num_genes=n_txp // 2, num_rows=n_txp // 2, small_thresh=0)
+    want = oracle.quant(cfg, t2g, b, off)
+    q = pkg.Quantifier(cfg, t2g)
+    try:
+        got = q.quant_chunks(b, off)
+        n_mono = q.mono_cell_count()
+    finally:
+        q.close()
+    assert_same_result(got, want, what=res)
+    if pug_route in ("phase-kernels", "graph-1024"):
+        assert n_mono == 0, "no cell should have needed the one-workgroup kernel"
