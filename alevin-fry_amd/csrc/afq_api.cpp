@@ -612,8 +612,10 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     std::vector<uint32_t> p2_up;
     std::vector<uint32_t> mono_cells;
     uint64_t p2_parts = 0;
+    uint32_t p2_tile = kP2TileHost;
     {
         const char* route = std::getenv("AFQ_PUG_ROUTE");
+        p2_tile = [] { const char* e = std::getenv("AFQ_P2_TILE"); const int v = e ? std::atoi(e) : 0; return v == 4096 || v == 8192 || v == 2048 ? (uint32_t)v : kP2TileHost; }();
         const bool p2_ok = n_pug && g.umi_bytes == 4 && !(g.resolution == AFQ_RES_PARSIMONY_GENE || g.resolution == AFQ_RES_PARSIMONY_GENE_EM) &&
                            !(route && !std::strcmp(route, "mono"));
         for (uint32_t ci : pug_cells) {   // (largest first)
@@ -627,7 +629,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
             pc.lgP = lg; pc.part_base = (uint32_t)p2_parts;
             p2_parts += 1ull << lg;
             const uint32_t j = (uint32_t)p2cells.size();
-            for (uint32_t t = 0; t * kP2TileHost < m.nrec; ++t) p2tiles.push_back(make_uint2(j, t));
+            for (uint32_t t = 0; t * p2_tile < m.nrec; ++t) p2tiles.push_back(make_uint2(j, t));
             p2cells.push_back(pc);
         }
         if (p2_parts >= 0xFFFFFFF0ull) return fail(c, AFQ_ERR_UNSUPPORTED, "batch too large for 32-bit partition ids");
@@ -832,6 +834,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
             {
                 const uint32_t big_reads = [] { const char* e = std::getenv("AFQ_P2_BIG_READS"); const long v = e ? std::atol(e) : 0; return v > 0 ? (uint32_t)v : 25000u; }();   // (measurements / tests: read per range; configs[2] graph kernels per step: 100 000: 30.9 ms, 60 000: 28.4, 40 000: 26.7, 25 000: 25.7, 12 000 and below: 25.4)
                 p2.max_comp = [] { const char* e = std::getenv("AFQ_P2_MAX_COMP"); const long v = e ? std::atol(e) : 0; return v >= 64 && v <= (long)kP2MaxComp ? (uint32_t)v : kP2MaxComp; }();   // (tests: 64 = larger components are handed back, as before round 4)
+                p2.tile = p2_tile;
                 p2.n_big = 0;
                 while (p2.n_big < n_p2 && p2cells[p2.n_big].R >= big_reads) ++p2.n_big;   // (p2cells is largest first)
             }

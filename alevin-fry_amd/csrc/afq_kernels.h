@@ -201,12 +201,13 @@ struct P2Args {
     DevStatus* st;
     uint32_t n_cells, n_tiles, n_parts, part_cap;
     uint32_t ref_count, num_genes, usa, num_rows, em, exact_umi, large_thresh, hw, umi_pairs;
+    uint32_t tile;       // reads per tile of k_p2_hist / k_p2_scatter: 2048, 4096 or 8192
     uint32_t max_comp;   // vertices of the largest component the phase kernels cover themselves (kP2MaxComp; tests: AFQ_P2_MAX_COMP)
     uint32_t n_big;   // the first n_big cells of `order` (largest first) are big enough for a 1024-thread graph workgroup each
 };
 constexpr uint32_t kP2PartTarget = 160;   // planned mean reads per partition (the partition count is a power of two: 80..160)
 constexpr uint32_t kP2PartCap = 256;      // reads one partition may hold (one wave sorts it in registers)
-constexpr uint32_t kP2TileHost = 2048;
+constexpr uint32_t kP2TileHost = 4096;   // reads per histogram / scatter tile unless AFQ_P2_TILE says 2048 or 8192 (P2Args.tile)
 void launch_p2_split(hipStream_t s, const P2Args& a);
 void launch_p2_part(hipStream_t s, const P2Args& a);
 void launch_p2_search(hipStream_t s, const P2Args& a);

@@ -90,13 +90,18 @@ __global__ __launch_bounds__(256) void k_scatter(const uint2* __restrict__ tile_
                                                 const CellMeta* __restrict__ meta,
                                                 const uint32_t* __restrict__ cell_nkeys,
                                                 const uint64_t* __restrict__ keys0, uint64_t* __restrict__ keys1,
-                                                uint32_t* __restrict__ cursor, uint32_t* __restrict__ slab_ovf) {
+                                                uint32_t* __restrict__ cursor, uint32_t* __restrict__ slab_ovf, uint32_t n_tiles) {
     constexpr uint32_t E = kTileKeys / 256;
     __shared__ uint64_t s_keys[kTileKeys];
     __shared__ uint32_t s_cnt[BINS];   // per-bucket count, then tile-local exclusive offset
     __shared__ uint32_t s_base[BINS];  // global position of the tile's first key of the bucket
     __shared__ uint32_t s_ws[4];
-    const uint2 td = tile_desc[blockIdx.x];
+    // Workgroups are dealt to the eight XCDs round-robin, each XCD with an L2 of its own; the tiles go to them in runs of sixteen
+    // (a median cell), so that the runs a cell's consecutive tiles add to one bucket meet in one L2 instead of reaching memory
+    // as partial lines from two.  (The grid is a multiple of 128.)
+    const uint32_t xr = blockIdx.x / 8, tile = ((xr / 16) * 8 + blockIdx.x % 8) * 16 + xr % 16;
+    if (tile >= n_tiles) return;
+    const uint2 td = tile_desc[tile];
     const uint32_t cell = td.x, lt = td.y;
     const CellMeta m = meta[cell];
     const uint32_t nk = mode_is_pug(m.mode) ? 0u : cell_nkeys[cell];  // PUG cells emit reads, not keys
@@ -1273,9 +1278,9 @@ void launch_bucket_scan(hipStream_t s, const ResolveArgs& a) {
 void launch_scatter(hipStream_t s, const ResolveArgs& a) {
     if (!a.n_tiles) return;
     if ((1u << a.max_lg_nb) <= 512u)
-        AFQ_LAUNCH(k_scatter<512>, a.n_tiles, 256, s, a.tile_desc, a.meta, a.cell_nkeys, a.keys0, a.keys1, a.cursor, a.slab_ovf);
+        AFQ_LAUNCH(k_scatter<512>, (a.n_tiles + 127) / 128 * 128, 256, s, a.tile_desc, a.meta, a.cell_nkeys, a.keys0, a.keys1, a.cursor, a.slab_ovf, a.n_tiles);
     else
-        AFQ_LAUNCH(k_scatter<kLdsBins>, a.n_tiles, 256, s, a.tile_desc, a.meta, a.cell_nkeys, a.keys0, a.keys1, a.cursor, a.slab_ovf);
+        AFQ_LAUNCH(k_scatter<kLdsBins>, (a.n_tiles + 127) / 128 * 128, 256, s, a.tile_desc, a.meta, a.cell_nkeys, a.keys0, a.keys1, a.cursor, a.slab_ovf, a.n_tiles);
 }
 
 void launch_fix_slabs(hipStream_t s, const ResolveArgs& a) {

@@ -44,7 +44,6 @@ namespace afq {
 
 typedef unsigned __int128 u128;
 
-constexpr uint32_t kP2Tile = 2048;        // reads per histogram / scatter tile
 constexpr uint32_t kP2Bins = 2048;        // partitions per cell the tile kernels rank in LDS
 constexpr uint32_t kP2TabSlots = 512;     // hash table of one partition's vertices (<= 256)
 constexpr uint32_t kP2FiltBits = 4096;    // presence filter in front of it
@@ -118,7 +117,7 @@ __global__ __launch_bounds__(256) void k_p2_hist(P2Args A) {
     __shared__ uint32_t s_hist[kP2Bins];
     const uint2 td = A.tiles[blockIdx.x];
     const P2Cell c = A.cells[td.x];
-    const uint32_t t0 = td.y * kP2Tile, t1 = min(c.R, t0 + kP2Tile);
+    const uint32_t t0 = td.y * A.tile, t1 = min(c.R, t0 + A.tile);
     const uint64_t* src = A.rd_u + c.rd_base;
     uint32_t* gcnt = A.pcnt + c.part_base;
     const uint32_t P = 1u << c.lgP, pm = P - 1;
@@ -159,17 +158,28 @@ __global__ __launch_bounds__(256) void k_p2_scan(P2Args A) {
     if (lane == 0 && (bad || carry != c.R)) set_err(A.st, kErrRecordWalk, c.cell);
 }
 
-// STAGED: the tile goes through LDS partition-major, so that a partition's run of the tile leaves in consecutive lanes;
-// otherwise every read is written from its own registers (16 KiB of LDS instead of 48: ten workgroups to a CU instead of three).
-template <bool STAGED>
-__global__ __launch_bounds__(256) void k_p2_scatter(P2Args A) {
-    constexpr uint32_t E = kP2Tile / 256;
+// STAGED (the default, with NT = 512): the tile goes through LDS partition-major, so that a partition's run of the tile leaves in
+// consecutive lanes of one store; otherwise every read is written from its own registers, its run's other reads by other waves at
+// other times.  Measured on configs[2] (395 M reads per step, 6.3 GB of payload each way): direct, 2048-read tiles: 7.9 ms and
+// WRITE_SIZE 20.9 GB per step - the runs were 64 bytes, written eight bytes at a time through an L2 that holds a few MB of the
+// lines all its workgroups have open; direct with 8192-read tiles: 6.4 ms, still 19.5 GB; staged with 4096-read tiles (80 KiB of
+// LDS, two workgroups to a CU): 5.1 ms and 7.0 GB.  NT threads take a tile of 8 NT reads.
+template <bool STAGED, int NT>
+__global__ __launch_bounds__(NT) void k_p2_scatter(P2Args A) {
+    constexpr uint32_t E = 8, kP2Tile = E * NT;
     __shared__ uint64_t s_a[STAGED ? kP2Tile : 1];
     __shared__ uint64_t s_b[STAGED ? kP2Tile : 1];
     __shared__ uint32_t s_cnt[kP2Bins];
     __shared__ uint32_t s_base[kP2Bins];
-    __shared__ uint32_t s_ws[4];
-    const uint2 td = A.tiles[blockIdx.x];
+    __shared__ uint32_t s_ws[NT / 64];
+    // Workgroups go to the eight XCDs round-robin, each XCD with an L2 of its own.  A tile leaves a run of about eight reads per
+    // partition - 64 bytes of each array, seldom on a line boundary - and the next run of that partition comes from the cell's next
+    // tile: with tile = blockIdx the two halves of a line were written through two L2s and reached memory as two partial writes
+    // (WRITE_SIZE 20.9 GB per step for 6.3 GB of payload).  So the tiles go to the XCDs in runs of sixteen (a 30 000-read cell):
+    // a cell's tiles pass through one L2 one behind the other and their runs meet there.
+    const uint32_t r = blockIdx.x / 8, tile = ((r / 16) * 8 + blockIdx.x % 8) * 16 + r % 16;   // (the grid is a multiple of 128)
+    if (tile >= A.n_tiles) return;
+    const uint2 td = A.tiles[tile];
     const uint32_t j = td.x;
     if (A.fb[j]) return;
     const P2Cell c = A.cells[j];
@@ -181,20 +191,20 @@ __global__ __launch_bounds__(256) void k_p2_scatter(P2Args A) {
     uint32_t* gcur = A.pcur + c.part_base;
     const uint32_t P = 1u << c.lgP, pm = P - 1;
     if (P > kP2Bins) {   // giant cell: one atomic per read
-        for (uint32_t i = t0 + threadIdx.x; i < t1; i += 256) {
+        for (uint32_t i = t0 + threadIdx.x; i < t1; i += NT) {
             const uint64_t u = su[i];
             const uint32_t pos = atomicAdd(&gcur[(uint32_t)(u >> 32) & pm], 1u);
             du[pos] = u; dh[pos] = sh[i];
         }
         return;
     }
-    for (uint32_t b = threadIdx.x; b < P; b += 256) s_cnt[b] = 0;
+    for (uint32_t b = threadIdx.x; b < P; b += NT) s_cnt[b] = 0;
     __syncthreads();
     uint64_t ku[E], kh[E];
     uint32_t rank[E];
 #pragma unroll
     for (uint32_t e = 0; e < E; ++e) {
-        const uint32_t i = t0 + e * 256 + threadIdx.x;
+        const uint32_t i = t0 + e * NT + threadIdx.x;
         ku[e] = 0; kh[e] = 0; rank[e] = 0;
         if (i < t1) {
             ku[e] = su[i]; kh[e] = sh[i];
@@ -204,11 +214,11 @@ __global__ __launch_bounds__(256) void k_p2_scatter(P2Args A) {
     }
     __syncthreads();
     uint32_t carry = 0;
-    for (uint32_t base = 0; base < P; base += 256) {
+    for (uint32_t base = 0; base < P; base += NT) {
         const uint32_t b = base + threadIdx.x;
         const uint32_t v = b < P ? s_cnt[b] : 0u;
         uint32_t tot;
-        const uint32_t ex = block_excl_scan<256>(v, s_ws, tot);
+        const uint32_t ex = block_excl_scan<NT>(v, s_ws, tot);
         if (b < P) { s_cnt[b] = carry + ex; s_base[b] = v ? atomicAdd(&gcur[b], v) : 0u; }
         carry += tot;
     }
@@ -216,18 +226,18 @@ __global__ __launch_bounds__(256) void k_p2_scatter(P2Args A) {
     if constexpr (!STAGED) {
 #pragma unroll
         for (uint32_t e = 0; e < E; ++e) {
-            const uint32_t i = t0 + e * 256 + threadIdx.x;
+            const uint32_t i = t0 + e * NT + threadIdx.x;
             if (i < t1) { const uint32_t pos = s_base[rank[e] >> 16] + (rank[e] & 0xFFFFu); du[pos] = ku[e]; dh[pos] = kh[e]; }
         }
     } else {
 #pragma unroll
         for (uint32_t e = 0; e < E; ++e) {
-            const uint32_t i = t0 + e * 256 + threadIdx.x;
+            const uint32_t i = t0 + e * NT + threadIdx.x;
             if (i < t1) { const uint32_t o = s_cnt[rank[e] >> 16] + (rank[e] & 0xFFFFu); s_a[o] = ku[e]; s_b[o] = kh[e]; }
         }
         __syncthreads();
         const uint32_t nt = t1 - t0;
-        for (uint32_t i = threadIdx.x; i < nt; i += 256) {
+        for (uint32_t i = threadIdx.x; i < nt; i += NT) {
             const uint64_t u = s_a[i];
             const uint32_t b = (uint32_t)(u >> 32) & pm;
             const uint32_t pos = s_base[b] + (i - s_cnt[b]);
@@ -541,7 +551,15 @@ __global__ __launch_bounds__(256) void k_p2_search(P2Args A) {
     if (A.st->err_code) return;   // an earlier kernel of the range failed (e.g. kErrLabelHash in k_p2_part, which then leaves its partition's vertices unwritten): nothing behind it may read that state - the host runs the range again or reports the error
     __shared__ SearchLds s_lds[4];
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    for (uint32_t gp = blockIdx.x * 4 + wv; gp < A.n_parts; gp += gridDim.x * 4) search_body<false>(A, gp, s_lds[wv], lane);
+    // The partitions go to the XCDs (workgroups x, x + 8, ... share one: they are dealt round-robin) in runs of 1024 - a few cells:
+    // a search reads its partition's neighbours, up to a dozen partitions of the same cell, and with a cell's partitions spread over
+    // all eight XCDs every L2 fetched every partition for itself (FETCH_SIZE 36 GB per step: eight times the vertices).
+    // (the grid is a multiple of 2048: 256 workgroups = 1024 waves take a run, side by side)
+    const uint32_t r = blockIdx.x / 8, x = blockIdx.x % 8, n_runs = (A.n_parts + 1023) / 1024;
+    for (uint32_t run = (r / 256) * 8 + x; run < n_runs; run += gridDim.x / 256) {
+        const uint32_t gp = run * 1024 + (r % 256) * 4 + wv;
+        if (gp < A.n_parts) search_body<false>(A, gp, s_lds[wv], lane);
+    }
 }
 __global__ __launch_bounds__(256) void k_p2_search_over(P2Args A) {
     if (A.st->err_code) return;
@@ -1251,8 +1269,13 @@ void launch_p2_split(hipStream_t s, const P2Args& a) {
     if (!a.n_cells) return;
     AFQ_LAUNCH(k_p2_hist, a.n_tiles, 256, s, a);
     AFQ_LAUNCH(k_p2_scan, (a.n_cells + 3) / 4, 256, s, a);
-    static const bool staged = [] { const char* e = getenv("AFQ_P2_SCATTER"); return e && !strcmp(e, "staged"); }();
-    if (staged) AFQ_LAUNCH(k_p2_scatter<true>, a.n_tiles, 256, s, a); else AFQ_LAUNCH(k_p2_scatter<false>, a.n_tiles, 256, s, a);
+    static const bool staged = [] { const char* e = getenv("AFQ_P2_SCATTER"); return !(e && !strcmp(e, "direct")); }();   // (measurements: "direct" = every read written from its own registers)
+    const uint32_t grid = (a.n_tiles + 127) / 128 * 128;
+    if (a.tile == 8192) AFQ_LAUNCH((k_p2_scatter<false, 1024>), grid, 1024, s, a);
+    else if (a.tile == 4096 && staged) AFQ_LAUNCH((k_p2_scatter<true, 512>), grid, 512, s, a);
+    else if (a.tile == 4096) AFQ_LAUNCH((k_p2_scatter<false, 512>), grid, 512, s, a);
+    else if (staged) AFQ_LAUNCH((k_p2_scatter<true, 256>), grid, 256, s, a);
+    else AFQ_LAUNCH((k_p2_scatter<false, 256>), grid, 256, s, a);
 }
 static uint32_t p2_grid(uint32_t n_parts) {   // AFQ_P2_GRID caps the workgroups (persistent waves walking the partitions); default: one wave per partition
     const uint32_t full = (n_parts + 3) / 4;
@@ -1263,7 +1286,7 @@ static uint32_t p2_grid(uint32_t n_parts) {   // AFQ_P2_GRID caps the workgroups
 void launch_p2_part(hipStream_t s, const P2Args& a) { if (a.n_parts) AFQ_LAUNCH(k_p2_part, p2_grid(a.n_parts), 256, s, a); }
 void launch_p2_search(hipStream_t s, const P2Args& a) {
     if (!a.n_parts) return;
-    AFQ_LAUNCH(k_p2_search, p2_grid(a.n_parts), 256, s, a);
+    AFQ_LAUNCH(k_p2_search, (p2_grid(a.n_parts) + 2047) / 2048 * 2048, 256, s, a);
     AFQ_LAUNCH(k_p2_search_over, std::min((a.n_parts + 255) / 256, 2048u), 256, s, a);   // (the partitions with more pairs than slots, normally none: two counts per partition are read)
 }
 void launch_p2_lone(hipStream_t s, const P2Args& a) { if (a.n_parts) AFQ_LAUNCH(k_p2_lone, p2_grid(a.n_parts), 256, s, a); }
