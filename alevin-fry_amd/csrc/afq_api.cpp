@@ -829,7 +829,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
             p2.pool = pool; p2.pool_cur = B.d_epool_cur.as<unsigned long long>(); p2.pool_cap = pool_cap;
             p2.work_counter = sm + L.ctr; p2.work_counter2 = sm + L.ctr + 1; p2.gdesc = sm + L.gdesc;
             p2.cell_nkeys = ra.cell_nkeys; p2.t2g = c->d_t2g.as<uint32_t>(); p2.keys0 = ra.keys0; p2.cell_ncols = ra.cell_ncols;
-            p2.lab = ra.lab; p2.lab_cnt = ra.lab_cnt; p2.st = ra.st;
+            p2.lab = ra.lab; p2.lab_cnt = ra.lab_cnt; p2.st = ra.st; p2.alt = B.d_alt.as<uint32_t>();
             p2.n_cells = n_p2; p2.n_tiles = (uint32_t)p2tiles.size(); p2.n_parts = (uint32_t)p2_parts;
             {
                 const uint32_t big_reads = [] { const char* e = std::getenv("AFQ_P2_BIG_READS"); const long v = e ? std::atol(e) : 0; return v > 0 ? (uint32_t)v : 25000u; }();   // (measurements / tests: read per range; configs[2] graph kernels per step: 100 000: 30.9 ms, 60 000: 28.4, 40 000: 26.7, 25 000: 25.7, 12 000 and below: 25.4)

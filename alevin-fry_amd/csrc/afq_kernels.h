@@ -199,6 +199,7 @@ struct P2Args {
     uint32_t* work_counter2; uint32_t* gdesc;          // the cover kernel's cell counter; per cell [16]: what the graph kernel hands it (k_p2_graph -> k_p2_cover)
     const uint32_t* cell_nkeys; const uint32_t* t2g; uint64_t* keys0; uint32_t* cell_ncols; uint32_t* lab; uint32_t* lab_cnt;
     DevStatus* st;
+    uint32_t* alt;                                     // [cells of the range] set to 1 when a component took the winner-take-all fallback
     uint32_t n_cells, n_tiles, n_parts, part_cap;
     uint32_t ref_count, num_genes, usa, num_rows, em, exact_umi, large_thresh, hw, umi_pairs;
     uint32_t tile;       // reads per tile of k_p2_hist / k_p2_scatter: 2048, 4096 or 8192

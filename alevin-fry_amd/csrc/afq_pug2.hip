@@ -675,7 +675,7 @@ constexpr int kGNT = 256;
 #endif
 constexpr uint32_t kGTab = AFQ_GTAB;          // class table slots when it lives in LDS (keys: 32 KiB, minima: 16 KiB of the block)
 // (it takes 3/4 of its slots less a margin in classes; beyond that the table is carved out of the pool)
-constexpr uint32_t kCatPair = 1, kCatTiny = 2, kCatMid = 3, kCatBig = 4;
+constexpr uint32_t kCatPair = 1, kCatTiny = 2, kCatMid = 3, kCatBig = 4, kCatLarge = 5;   // (Large: above --large-graph-thresh, resolved winner-take-all)
 
 template <int GNT>
 __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, uint32_t work_hi, uint32_t* counter) {
@@ -796,7 +796,7 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
     uint32_t* fill = q; q += nt_max;          // per root: next free slot of its component; afterwards, per vertex:
     uint32_t* cidx = fill;                    // ... its position inside its component (reference order)
     uint32_t* lsize = q; q += nt_max + 2;     // per listed component: size
-    uint32_t* mid_off = q; q += nt_max + 2;   // ... first slot
+    uint32_t* mid_off = q; q += nt_max + 10;  // ... first slot (and behind the last one eight words for the cover kernel: see the end)
     uint32_t* pr_v = q; q += nt_max + 2;      // two-vertex components: their vertices, two by two
     {
         uint32_t carry = 0;
@@ -858,8 +858,10 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
     }
     G_MARK(3);
     // ---- 3. the components by counting: sizes per root, then by size pairs / 3..8 / 9..64 / 65..4096 (anything else - a
-    //         component above --large-graph-thresh, which the reference resolves winner-take-all - is not for this kernel),
-    //         every listed component's slots, every vertex into its component's next slot ----
+    //         component of more than 4096 vertices that is still under --large-graph-thresh - is not for this kernel), every
+    //         listed component's slots, every vertex into its component's next slot.  A component above --large-graph-thresh
+    //         needs no order and no edges: its vertices are listed apart (lg_v), the cover kernel resolves it winner-take-all
+    //         (pugutils.rs:916-982) ----
     for (uint32_t i = tid; i < NT; i += GNT) { uint32_t l = ldw(i); for (uint32_t nx = ldw(l); nx != l; nx = ldw(l)) l = nx; root_of[i] = l; wg_add(&rcnt[l], 1u); }
     gsync();
     uint32_t n_pr = 0, n_tiny = 0, n_mid9 = 0, n_bigc = 0;
@@ -869,15 +871,18 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
         uint32_t cat = 0;
         if (i < NT && root_of[i] == i) {
             const uint32_t n = ld_l2(&rcnt[i]);
-            if (n > A.max_comp || n > C.large_thresh) big = true;
+            if (n > C.large_thresh) cat = kCatLarge;
+            else if (n > A.max_comp) big = true;
             else cat = n == 2 ? kCatPair : n <= 8 ? kCatTiny : n <= 64 ? kCatMid : kCatBig;
         }
         uint32_t tot, tot_mid;   // (two scans: three counts of up to GNT = 1024 do not fit one word)
         const uint32_t ex = block_excl_scan<GNT>((cat == kCatPair) | ((uint32_t)(cat == kCatTiny) << 16), s_ws, tot);
         const uint32_t ex_mid = block_excl_scan<GNT>((uint32_t)(cat == kCatMid) | ((uint32_t)(cat == kCatBig) << 16), s_ws, tot_mid);
         if (cat) {
-            const uint32_t idx = cat == kCatPair ? n_pr + (ex & 0xFFFFu) : cat == kCatTiny ? n_tiny + (ex >> 16) : cat == kCatMid ? n_mid9 + (ex_mid & 0xFFFFu) : n_bigc + (ex_mid >> 16);
             const uint32_t n = ld_l2(&rcnt[i]);
+            const uint32_t idx = cat == kCatLarge ? atomicAdd(&s_flag[2], 1u)   // (few, and their order is free: an LDS counter instead of a third scan)
+                                 : cat == kCatPair ? n_pr + (ex & 0xFFFFu) : cat == kCatTiny ? n_tiny + (ex >> 16) : cat == kCatMid ? n_mid9 + (ex_mid & 0xFFFFu) : n_bigc + (ex_mid >> 16);
+            if (cat == kCatLarge) atomicAdd(&s_flag[3], n);
             st_l2(&rcnt[i], (cat << 28) | idx);            // (a root's word is read and written by its own thread only in this pass)
             if (cat == kCatTiny) lsize[idx] = n;          // (the 9..64 ones are placed behind the small ones once those are counted)
             else if (cat != kCatPair) st_l2(&fill[i], n);   // (parked in the root's fill word until then)
@@ -887,14 +892,28 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
     if (big) s_flag[1] = 1;
     gsync();
     if (s_flag[1]) { give_up(); continue; }
+    const uint32_t n_large = s_flag[2], S_large = s_flag[3];
+    uint32_t* lg_off = nullptr;   // per component above the threshold: its first entry of lg_v (n_large + 1 offsets)
+    uint32_t* lg_v = nullptr;     // ... its vertices (touched-vertex numbers)
+    if (n_large) {
+        q = pool_take(n_large + 2ull + S_large);
+        if (!q) return;
+        lg_off = q; lg_v = q + n_large + 2;
+    }
     const uint32_t n_mid = n_tiny + n_mid9, n_all = n_mid + n_bigc;   // the list: 3..8, then 9..64, then 65..4096
     auto listed_at = [&](uint32_t cat, uint32_t idx) -> uint32_t { return cat == kCatTiny ? idx : cat == kCatMid ? n_tiny + idx : n_mid + idx; };
     for (uint32_t i = tid; i < NT; i += GNT)
         if (root_of[i] == i) {
             const uint32_t rc = ld_l2(&rcnt[i]), cat = rc >> 28;
             if (cat == kCatMid || cat == kCatBig) { lsize[listed_at(cat, rc & 0xFFFFFFFu)] = ld_l2(&fill[i]); st_l2(&fill[i], 0u); }
+            else if (cat == kCatLarge) { lg_off[rc & 0xFFFFFFFu] = ld_l2(&fill[i]); st_l2(&fill[i], 0u); }
         }
     gsync();
+    if (tid == 0 && n_large) {   // sizes -> offsets (a handful)
+        uint32_t acc = 0;
+        for (uint32_t b = 0; b < n_large; ++b) { const uint32_t t = lg_off[b]; lg_off[b] = acc; acc += t; }
+        lg_off[n_large] = acc;
+    }
     uint32_t S_mid = 0;
     for (uint32_t base = 0; base < n_all; base += GNT) {
         const uint32_t ci = base + tid;
@@ -949,6 +968,7 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
         const uint32_t r = root_of[i], rc = ld_l2(&rcnt[r]), cat = rc >> 28, idx = rc & 0xFFFFFFFu;
         const uint32_t at = wg_add(&fill[r], 1u);
         if (cat == kCatPair) pr_v[2 * idx + at] = i;
+        else if (cat == kCatLarge) lg_v[lg_off[idx] + at] = i;
         else {
             const uint32_t ci = listed_at(cat, idx);
             const uint32_t sl = mid_off[ci] + at;
@@ -1108,7 +1128,7 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
         const uint64_t e = lp[k];
         const uint32_t x = (uint32_t)e & 0xFFFFFFu, y = (uint32_t)(e >> 24) & 0xFFFFFFu;
         const uint32_t rc = ld_l2(&rcnt[root_of[x]]), cat = rc >> 28;
-        if (cat == kCatPair) continue;
+        if (cat == kCatPair || cat == kCatLarge) continue;
         if (cat == kCatBig) {
             const uint32_t b = rc & 0xFFFFFFFu, n = mid_off[n_mid + b + 1] - mid_off[n_mid + b], nw = (n + 63) / 64;
             unsigned long long* rw = rows + rowoff[b];
@@ -1152,12 +1172,14 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
     if (tid == 0) {
         uint32_t* d = A.gdesc + 16 * (size_t)j;
         auto put = [&](int at, const void* ptr) { const unsigned long long o = (unsigned long long)(reinterpret_cast<const uint32_t*>(ptr) - A.pool); d[at] = (uint32_t)o; d[at + 1] = (uint32_t)(o >> 32); };
-        d[1] = n_pr; d[2] = n_tiny; d[3] = n_mid; d[15] = n_bigc;
+        d[1] = n_pr; d[2] = n_tiny; d[3] = n_mid; d[15] = n_bigc | (n_large ? 0x80000000u : 0u);
         put(4, tl); put(6, pr_v); put(8, mid_off); put(10, mrec);
-        if (n_bigc) {   // (where the rows and their offsets lie: behind the list's last offset - there are at most NT / 65 + (NT - 65) / 3 + 1 listed components and NT + 2 words)
-            const unsigned long long ro = (unsigned long long)(reinterpret_cast<const uint32_t*>(rows) - A.pool), oo = (unsigned long long)(rowoff - A.pool);
+        if (n_bigc || n_large) {   // (where the rows, their offsets and the lists of the components above the threshold lie: behind the list's last offset)
+            const unsigned long long ro = n_bigc ? (unsigned long long)(reinterpret_cast<const uint32_t*>(rows) - A.pool) : 0ull, oo = (unsigned long long)(rowoff - A.pool);
+            const unsigned long long lo = n_large ? (unsigned long long)(lg_off - A.pool) : 0ull;
             mid_off[n_all + 1] = (uint32_t)ro; mid_off[n_all + 2] = (uint32_t)(ro >> 32);
             mid_off[n_all + 3] = (uint32_t)oo; mid_off[n_all + 4] = (uint32_t)(oo >> 32);
+            mid_off[n_all + 5] = n_large; mid_off[n_all + 6] = (uint32_t)lo; mid_off[n_all + 7] = (uint32_t)(lo >> 32);
         }
         d[12] = s_cnt[0]; d[13] = s_cnt[1]; d[14] = s_cnt[2];
         d[0] = 1;
@@ -1169,6 +1191,116 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
 // 6. one workgroup per cell again, but a kernel of its own: the molecules of the components the graph kernel listed - the
 //    two-vertex rule and the arborescence covers (afq_pug_common.h).  They need none of the graph kernel's LDS and a third of its
 //    registers; as one kernel the pair was 168 VGPRs with 98 SGPRs spilled and three workgroups to a CU.
+// get_num_molecules_large_component (pugutils.rs:916-982) for the components above --large-graph-thresh of one cell: the
+// (UMI, gene, reads) triplets of the component's vertices, sorted by the workgroup; per UMI the gene(s) with the most reads
+// (resolve_num_molecules_crlike_from_vec, pugutils.rs:644-749).  Rare; thread 0 walks the sorted triplets.  false = the pool
+// is exhausted (the error is set).
+template <int CNT>
+__device__ __forceinline__ bool cover_large(const P2Args& A, const PugCtx& C, const P2Cell& c, const uint32_t* tl, const uint32_t* lg_off, const uint32_t* lg_v,
+                                            uint32_t n_large, uint32_t* s_ws, uint32_t* s_nt, unsigned long long* s_base) {
+    const uint32_t tid = threadIdx.x;
+    const uint64_t* ch = A.s_h + c.rd_base;
+    const uint64_t* cu = A.s_u + c.rd_base;
+    const uint32_t* coff = A.v_off + c.rd_base;
+    // distinct genes of a label that has more of them than kMaxGenesPerLabel: first occurrences, found by looking back
+    auto wide_genes = [&](const KLab& l, auto&& f) {
+        for (uint32_t j = 0; j < l.n; ++j) {
+            const uint32_t gj = C.t2g[klab_ref(l, j)];
+            bool first = true;
+            for (uint32_t q = 0; q < j && first; ++q) first = C.t2g[klab_ref(l, q)] != gj;
+            if (first) f(gj);
+        }
+    };
+    for (uint32_t b = 0; b < n_large; ++b) {
+        const uint32_t v0 = lg_off[b], n = lg_off[b + 1] - v0;
+        uint32_t cnt = 0;
+        for (uint32_t i = tid; i < n; i += CNT) {
+            const uint32_t g = tl[lg_v[v0 + i]];
+            const KLab l = klab(C.W, C.HW, ch[g], coff[g]);
+            uint32_t gg[kMaxGenesPerLabel];
+            const uint32_t ng = genes_of(C, l.n, [&](uint32_t j) { return klab_ref(l, j); }, gg);
+            if (ng == 0xFFFFFFFFu) wide_genes(l, [&](uint32_t) { ++cnt; }); else cnt += ng;
+        }
+        uint32_t tot;
+        (void)block_excl_scan<CNT>(cnt, s_ws, tot);
+        __syncthreads();
+        if (tid == 0) { *s_base = atomicAdd(A.pool_cur, 4ull * tot + 4); *s_nt = 0; }
+        __syncthreads();
+        if (*s_base + 4ull * tot + 4 > A.pool_cap) { if (tid == 0) set_err(A.st, kErrPugPool, c.cell); return false; }
+        uint4* trip = reinterpret_cast<uint4*>(A.pool + ((*s_base + 3) & ~3ull));   // (umi, 0, gene, reads)
+        for (uint32_t i = tid; i < n; i += CNT) {
+            const uint32_t g = tl[lg_v[v0 + i]];
+            const uint64_t uw = cu[g];
+            const KLab l = klab(C.W, C.HW, ch[g], coff[g]);
+            uint32_t gg[kMaxGenesPerLabel];
+            const uint32_t ng = genes_of(C, l.n, [&](uint32_t j) { return klab_ref(l, j); }, gg);
+            if (ng == 0xFFFFFFFFu) {
+                uint32_t k = 0;
+                wide_genes(l, [&](uint32_t) { ++k; });
+                uint32_t o = atomicAdd(s_nt, k);
+                wide_genes(l, [&](uint32_t gid) { trip[o++] = make_uint4((uint32_t)(uw >> 32), 0u, gid, (uint32_t)uw & kVCntMask); });
+                continue;
+            }
+            const uint32_t o = atomicAdd(s_nt, ng);
+            for (uint32_t q = 0; q < ng; ++q) trip[o + q] = make_uint4((uint32_t)(uw >> 32), 0u, gg[q], (uint32_t)uw & kVCntMask);
+        }
+        __syncthreads();
+        const uint32_t nt = *s_nt;
+        bitonic_sort_by<CNT>(trip, nt, [](const uint4& x, const uint4& y) {
+            if (x.x != y.x) return x.x > y.x;
+            if (x.z != y.z) return x.z > y.z;
+            return x.w > y.w;
+        });
+        if (tid == 0 && nt) {
+            uint32_t best[kMaxGenesPerLabel];
+            uint32_t nbest = 0, maxc = 0, aggr = 0;
+            uint32_t cur_umi = trip[0].x, cg = trip[0].z;
+            bool wide = false;
+            uint32_t run0 = 0;   // first triplet of the current UMI
+            // a UMI whose tie set has more genes than best[] holds is a class of its own for the EM: the genes whose summed count
+            // is the maximum, ascending as the triplets are, written straight into the label area
+            auto emit_ties = [&](uint32_t i0, uint32_t i1, uint32_t maxc_) {
+                auto each_tied = [&](auto&& f) {
+                    for (uint32_t i = i0; i < i1;) {
+                        uint32_t j = i, sum = 0;
+                        for (; j < i1 && trip[j].z == trip[i].z; ++j) sum += trip[j].w;
+                        if (sum == maxc_) f(trip[i].z);
+                        i = j;
+                    }
+                };
+                uint32_t k = 0;
+                each_tied([&](uint32_t) { ++k; });
+                const uint32_t off = atomicAdd(&C.s_cnt[1], k), di = atomicAdd(&C.s_cnt[2], 1u);
+                if (off + k > C.lab_cap || 2 * (di + 1) > C.lab_cap) { C.s_cnt[3] = kErrPugLimit; return; }
+                uint32_t w = off;
+                each_tied([&](uint32_t gid) { C.labw[w++] = gid; });
+                C.labd[2 * di] = off; C.labd[2 * di + 1] = k;
+            };
+            for (uint32_t i = 0; i < nt; ++i) {
+                const uint4 t = trip[i];
+                if (i == 0 || t.x != cur_umi) {
+                    if (i) { if (wide && C.em) emit_ties(run0, i, maxc); else emit_molecule(C, best, wide ? 0xFFFFFFFFu : nbest); }
+                    run0 = i;
+                    cur_umi = t.x; cg = t.z;
+                    nbest = 1; best[0] = t.z; aggr = t.w; maxc = t.w; wide = false;
+                } else {
+                    if (t.z == cg) aggr += t.w; else { aggr = t.w; cg = t.z; }
+                    if (aggr > maxc) {
+                        maxc = aggr;
+                        if (!(nbest == 1 && best[0] == t.z)) { nbest = 1; best[0] = t.z; wide = false; }
+                    } else if (aggr == maxc) {
+                        if (nbest == kMaxGenesPerLabel) wide = true; else best[nbest++] = t.z;
+                    }
+                }
+            }
+            if (wide && C.em) emit_ties(run0, nt, maxc); else emit_molecule(C, best, wide ? 0xFFFFFFFFu : nbest);
+        }
+        if (tid == 0) A.alt[c.cell] = 1;   // used_alternative_strategy, pugutils.rs:1070
+        __syncthreads();
+    }
+    return true;
+}
+
 template <int CNT>
 __global__ __launch_bounds__(CNT) void k_p2_cover(P2Args A, uint32_t work_lo, uint32_t work_hi, uint32_t* counter) {
     if (A.st->err_code) return;
@@ -1176,6 +1308,9 @@ __global__ __launch_bounds__(CNT) void k_p2_cover(P2Args A, uint32_t work_lo, ui
     __shared__ uint32_t s_next;
     __shared__ uint64_t s_mask[2][64];                     // the workgroup cover: uncovered vertices, the round's arborescence
     __shared__ uint32_t s_bestv[CNT / 64], s_bestsz[CNT / 64];
+    __shared__ uint32_t s_ws[CNT / 64];
+    __shared__ uint32_t s_nt;
+    __shared__ unsigned long long s_ebase;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   for (;;) {
     __syncthreads();
@@ -1249,11 +1384,18 @@ __global__ __launch_bounds__(CNT) void k_p2_cover(P2Args A, uint32_t work_lo, ui
     }
     cover_tiny8<CNT / 64>(C, mrec, mid_off, n_tiny, wv, lane);
     cover_wave64<CNT / 64>(C, mrec, mid_off, n_tiny, n_mid, wv, lane);
-    if (const uint32_t n_bigc = d[15]) {   // 65..4096 vertices: the graph kernel left their adjacency as rows of mask words
-        const uint32_t* x = mid_off + n_mid + n_bigc + 1;
+    const uint32_t n_bigc = d[15] & 0x7FFFFFFFu;
+    const uint32_t* x = mid_off + n_mid + n_bigc + 1;   // (eight words behind the list's last offset)
+    if (n_bigc) {   // 65..4096 vertices: the graph kernel left their adjacency as rows of mask words
         const uint64_t* rows = reinterpret_cast<const uint64_t*>(A.pool + (((unsigned long long)x[1] << 32) | x[0]));
         const uint32_t* rowoff = A.pool + (((unsigned long long)x[3] << 32) | x[2]);
         cover_big<CNT / 64>(C, mrec, mid_off, n_mid, n_bigc, rowoff, rows, s_mask, s_bestv, s_bestsz, wv, lane);
+    }
+    if (d[15] >> 31) {   // components above --large-graph-thresh
+        const uint32_t n_large = x[4];
+        const uint32_t* lg_off = A.pool + (((unsigned long long)x[6] << 32) | x[5]);
+        __syncthreads();
+        if (!cover_large<CNT>(A, C, c, tl, lg_off, lg_off + n_large + 2, n_large, s_ws, &s_nt, &s_ebase)) return;
     }
     gsync();
     if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], c.cell); return; }

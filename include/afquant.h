@@ -34,9 +34,10 @@ extern "C" {
  * whole batch is refused and afq_last_error names the cell):
  *   - UMIs over 22 nt, gene-id spaces over 2^20, more than two barcode levels;
  *   - parsimony: a cell of 2^22 reads or more; a cell of 2^20 .. 2^22 reads goes through the partition-parallel kernels and is
- *     fine as long as they can finish it - when they have to hand it to the one-workgroup kernel (a UMI partition over 256
- *     reads: skewed or very short UMIs; a connected component over 64 vertices or over --large-graph-thresh; gene-level labels
- *     or an 8-byte UMI field send every cell there) that kernel's 2^20-read limit applies;
+ *     fine as long as they can finish it - whatever its graph looks like under the default --large-graph-thresh: components of
+ *     any size, pair lists of any length.  Only when they have to hand it to the one-workgroup kernel (a UMI partition over 256
+ *     reads: UMIs that share their low bases, e.g. a constant primer tail; gene-level labels or an 8-byte UMI field send every
+ *     cell there) that kernel's 2^20-read limit applies;
  *   - parsimony: a component over 4096 vertices under a --large-graph-thresh raised beyond that. */
 #define AFQ_ERR_HIP (-4)          /* a HIP runtime call failed                   */
 #define AFQ_ERR_NO_DEVICE (-5)    /* no usable gfx950 device                     */
@@ -290,8 +291,8 @@ uint64_t afq_pool_regrow_count(const afq_ctx* ctx);
  * instead (one extra trip to the host for that range; results identical).  Diagnostics only. */
 uint64_t afq_em_resize_count(const afq_ctx* ctx);
 /* Parsimony: cells resolved by the one-workgroup kernel instead of the partition-parallel phase kernels - sent there directly
- * (gene-level parsimony, 8-byte UMIs) or handed back (a UMI partition of more than 256 reads, a component above
- * --large-graph-thresh or of more than 4096 vertices).  Results identical; diagnostics only. */
+ * (gene-level parsimony, 8-byte UMIs) or handed back (a UMI partition of more than 256 reads; a component of more than 4096
+ * vertices under a --large-graph-thresh raised beyond that).  Results identical; diagnostics only. */
 uint64_t afq_mono_cell_count(const afq_ctx* ctx);
 
 /* Brings the HIP runtime up on `device` (first-call initialisation) - a host can call it from a side thread while it parses its
