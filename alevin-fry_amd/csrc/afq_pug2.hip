@@ -499,8 +499,10 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
             probe((uint32_t)(ow >> 32) ^ ((ix % 3 + 1) << (2 * (b_lo + ix / 3))), lo_p + r * 64 + lane, (uint32_t)ow, false);
         }
     }
-    // The vertices of the partitions one low-bit change away, a partition at a time (its place is in lane k's registers): the
-    // first 128 vertices of the NEXT partition are on their way while this one goes through the filter.
+    // The vertices of the partitions one low-bit change away, FOUR partitions at a time (their places are in lanes k .. k + 3's
+    // registers): the eight loads of a batch go out together and are waited for once.  A partition at a time with the next one's
+    // load behind it, every load's latency was in the open - a partition takes some thirty instructions to go through the filter -
+    // twelve round trips one after the other in a kernel whose wave spends 49 us on a partition, nine tenths of it waiting.
     const uint32_t* cl = A.lidx + c.rd_base;   // UMIs only (k_p2_part): four bytes per foreign vertex instead of eight - this fetch is 12 of the 13 partitions a search reads
     auto fetch = [&](uint32_t k, uint32_t (&v)[2], uint32_t& nq, uint32_t& oq) {
         nq = __builtin_amdgcn_readlane(f_n, k); oq = __builtin_amdgcn_readlane(f_o, k);
@@ -510,26 +512,33 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
     // (their filter checks are branch-free too: a passed probe is a bit (partition k, row r) in a per-lane mask; the drain fetches
     //  that vertex again - it is in the cache - instead of carrying a queue of (probe, slot, word) triples in registers)
     uint64_t fhits = 0;   // bit 2 k + r (k < 24: three changes of at most eight low bases)
-    uint32_t cur[2] = {0, 0}, nxt[2] = {0, 0};
-    uint32_t nq = 0, oq = 0, nq2 = 0, oq2 = 0;
-    if (nfor) fetch(0, cur, nq, oq);
-    for (uint32_t k = 0; k < nfor; ++k) {
-        if (k + 1 < nfor) fetch(k + 1, nxt, nq2, oq2);
-        const uint32_t mk = (k % 3 + 1) << (2 * (k / 3));
-        const uint32_t fm = fold11(mk), tb = 2 * (k / 3) + (k % 3 == 0 ? 0u : 1u);   // (scalar) the change's fold; the bit of the base that decides "umi ^ mk > umi"
+    for (uint32_t k0 = 0; k0 < nfor; k0 += 4) {
+        uint32_t fv[4][2], fnq[4], foq[4];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const uint32_t i = (uint32_t)r * 64 + lane;
-            const uint32_t umi = cur[r];
-            const uint32_t f = fold11(umi) ^ fm;
-            const uint32_t ok = (i < nq ? 1u : 0u) & (((umi >> tb) & 1u) ^ 1u) & ((s_filt[f >> 5] >> (f & 31u)) & 1u);
-            fhits |= (uint64_t)ok << (2 * k + (uint32_t)r);
+        for (int j = 0; j < 4; ++j) {
+            fnq[j] = 0; foq[j] = 0; fv[j][0] = 0; fv[j][1] = 0;
+            if (k0 + (uint32_t)j < nfor) fetch(k0 + (uint32_t)j, fv[j], fnq[j], foq[j]);
         }
-        for (uint32_t i = 128 + lane; i < nq; i += 64) {   // (a partition of more than 128 vertices: the rest, plainly)
-            const uint32_t umi = cl[oq + i], pu = umi ^ mk;
-            if (pu > umi && filt(pu)) probe(pu, oq + i, (uint32_t)cu[oq + i], false);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t k = k0 + (uint32_t)j;
+            if (k >= nfor) break;   // (uniform)
+            const uint32_t nq = fnq[j], oq = foq[j];
+            const uint32_t mk = (k % 3 + 1) << (2 * (k / 3));
+            const uint32_t fm = fold11(mk), tb = 2 * (k / 3) + (k % 3 == 0 ? 0u : 1u);   // (scalar) the change's fold; the bit of the base that decides "umi ^ mk > umi"
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint32_t i = (uint32_t)r * 64 + lane;
+                const uint32_t umi = fv[j][r];
+                const uint32_t f = fold11(umi) ^ fm;
+                const uint32_t ok = (i < nq ? 1u : 0u) & (((umi >> tb) & 1u) ^ 1u) & ((s_filt[f >> 5] >> (f & 31u)) & 1u);
+                fhits |= (uint64_t)ok << (2 * k + (uint32_t)r);
+            }
+            for (uint32_t i = 128 + lane; i < nq; i += 64) {   // (a partition of more than 128 vertices: the rest, plainly)
+                const uint32_t umi = cl[oq + i], pu = umi ^ mk;
+                if (pu > umi && filt(pu)) probe(pu, oq + i, (uint32_t)cu[oq + i], false);
+            }
         }
-        cur[0] = nxt[0]; cur[1] = nxt[1]; nq = nq2; oq = oq2;
     }
     for (; __any(fhits != 0);) {
         const uint32_t ix = fhits ? (uint32_t)__builtin_ctzll(fhits) : 0u;
@@ -547,7 +556,7 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
     if (lane == 0 && !OVER) A.pnp[gp] = np;   // (more than pcap: the second pass takes the partition)
     WAVE_SYNC();
 }
-__global__ __launch_bounds__(256) void k_p2_search(P2Args A) {
+__global__ __launch_bounds__(256, 6) void k_p2_search(P2Args A) {
     if (A.st->err_code) return;   // an earlier kernel of the range failed (e.g. kErrLabelHash in k_p2_part, which then leaves its partition's vertices unwritten): nothing behind it may read that state - the host runs the range again or reports the error
     __shared__ SearchLds s_lds[4];
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
