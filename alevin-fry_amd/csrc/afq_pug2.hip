@@ -110,6 +110,20 @@ __device__ __forceinline__ PugCtx make_ctx(const P2Args& A, const P2Cell& c, uin
     return C;
 }
 
+// The partition kernels' walk (a wave per partition, persistent workgroups): the partitions go to the XCDs - workgroups x, x + 8,
+// ... share one, they are dealt round-robin - in runs of 1024, a few cells each, 256 workgroups side by side on a run.  A cell's
+// partitions then meet in ONE L2: the search reads a partition's dozen neighbours, the partition and lone-vertex kernels read the
+// labels of the cell's chunk.  (With a cell's partitions spread over all eight XCDs the search's FETCH_SIZE was 36 GB per
+// configs[2] step, eight times the vertices; in runs 19.9 GB.)  The grid is a multiple of 2048.
+template <typename F>
+__device__ __forceinline__ void for_each_partition_in_runs(uint32_t n_parts, uint32_t wv, F&& f) {
+    const uint32_t r = blockIdx.x / 8, x = blockIdx.x % 8, n_runs = (n_parts + 1023) / 1024;
+    for (uint32_t run = (r / 256) * 8 + x; run < n_runs; run += gridDim.x / 256) {
+        const uint32_t gp = run * 1024 + (r % 256) * 4 + wv;
+        if (gp < n_parts) f(gp);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // 1. reads -> partitions (count, offsets, placement): the exact layout, so that a partition is a dense run of the cell's
 //    read slots and its size picks the sort network.
@@ -337,15 +351,15 @@ __device__ __forceinline__ void part_body(const P2Args& A, const uint32_t* W, ui
 __global__ __launch_bounds__(256) void k_p2_part(P2Args A) {
     // (the wave's number through readfirstlane: the compiler then knows the partition index is uniform, and everything read per
     //  partition - its counts, its place, its cell's record - comes through scalar loads into scalar registers)
-    for (uint32_t gp = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); gp < A.n_parts; gp += gridDim.x * 4) {
+    for_each_partition_in_runs(A.n_parts, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), [&](uint32_t gp) {
         const uint32_t n = A.pcnt[gp];
-        if (n == 0) { if (lane_id() == 0) A.pnv[gp] = 0; continue; }
+        if (n == 0) { if (lane_id() == 0) A.pnv[gp] = 0; return; }
         const P2Cell c = A.cells[A.pcell[gp]];
         const uint64_t o = c.rd_base + A.poff[gp];
         const uint32_t* W = reinterpret_cast<const uint32_t*>(A.bytes + c.chunk_off);
         if (n <= 128) part_body<2>(A, W, gp, n, o, c.cell);
         else part_body<4>(A, W, gp, n, o, c.cell);
-    }
+    });
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -560,15 +574,7 @@ __global__ __launch_bounds__(256, 6) void k_p2_search(P2Args A) {
     if (A.st->err_code) return;   // an earlier kernel of the range failed (e.g. kErrLabelHash in k_p2_part, which then leaves its partition's vertices unwritten): nothing behind it may read that state - the host runs the range again or reports the error
     __shared__ SearchLds s_lds[4];
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    // The partitions go to the XCDs (workgroups x, x + 8, ... share one: they are dealt round-robin) in runs of 1024 - a few cells:
-    // a search reads its partition's neighbours, up to a dozen partitions of the same cell, and with a cell's partitions spread over
-    // all eight XCDs every L2 fetched every partition for itself (FETCH_SIZE 36 GB per step: eight times the vertices).
-    // (the grid is a multiple of 2048: 256 workgroups = 1024 waves take a run, side by side)
-    const uint32_t r = blockIdx.x / 8, x = blockIdx.x % 8, n_runs = (A.n_parts + 1023) / 1024;
-    for (uint32_t run = (r / 256) * 8 + x; run < n_runs; run += gridDim.x / 256) {
-        const uint32_t gp = run * 1024 + (r % 256) * 4 + wv;
-        if (gp < A.n_parts) search_body<false>(A, gp, s_lds[wv], lane);
-    }
+    for_each_partition_in_runs(A.n_parts, wv, [&](uint32_t gp) { search_body<false>(A, gp, s_lds[wv], lane); });
 }
 __global__ __launch_bounds__(256) void k_p2_search_over(P2Args A) {
     if (A.st->err_code) return;
@@ -663,7 +669,7 @@ __global__ __launch_bounds__(256) void k_p2_lone(P2Args A) {
     if (A.st->err_code) return;   // an earlier kernel of the range failed (e.g. kErrLabelHash in k_p2_part, which then leaves its partition's vertices unwritten): nothing behind it may read that state - the host runs the range again or reports the error
     __shared__ uint32_t s_cls4[4][512];
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    for (uint32_t gp = blockIdx.x * 4 + wv; gp < A.n_parts; gp += gridDim.x * 4) lone_body(A, gp, s_cls4[wv], lane);
+    for_each_partition_in_runs(A.n_parts, wv, [&](uint32_t gp) { lone_body(A, gp, s_cls4[wv], lane); });
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -1434,13 +1440,13 @@ static uint32_t p2_grid(uint32_t n_parts) {   // AFQ_P2_GRID caps the workgroups
     const uint32_t cap = e ? (uint32_t)atoi(e) : 8192u;   // (8192 workgroups of four waves walking the partitions: launching a wave per partition cost the lone-vertex kernel half its time)
     return cap && cap < full ? cap : full;
 }
-void launch_p2_part(hipStream_t s, const P2Args& a) { if (a.n_parts) AFQ_LAUNCH(k_p2_part, p2_grid(a.n_parts), 256, s, a); }
+void launch_p2_part(hipStream_t s, const P2Args& a) { if (a.n_parts) AFQ_LAUNCH(k_p2_part, (p2_grid(a.n_parts) + 2047) / 2048 * 2048, 256, s, a); }
 void launch_p2_search(hipStream_t s, const P2Args& a) {
     if (!a.n_parts) return;
     AFQ_LAUNCH(k_p2_search, (p2_grid(a.n_parts) + 2047) / 2048 * 2048, 256, s, a);
     AFQ_LAUNCH(k_p2_search_over, std::min((a.n_parts + 255) / 256, 2048u), 256, s, a);   // (the partitions with more pairs than slots, normally none: two counts per partition are read)
 }
-void launch_p2_lone(hipStream_t s, const P2Args& a) { if (a.n_parts) AFQ_LAUNCH(k_p2_lone, p2_grid(a.n_parts), 256, s, a); }
+void launch_p2_lone(hipStream_t s, const P2Args& a) { if (a.n_parts) AFQ_LAUNCH(k_p2_lone, (p2_grid(a.n_parts) + 2047) / 2048 * 2048, 256, s, a); }
 void launch_p2_graph(hipStream_t s, const P2Args& a) {
     if (!a.n_cells) return;
     int dev = 0, cus = 256;
