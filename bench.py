@@ -196,7 +196,8 @@ def sanity(res, rad):
 
 # timers of the library that bracket several kernels: their bytes add up (the decode timer brackets whichever decoder ran)
 BRACKETS = {"k_em": ("k_em2_plan", "k_em2_setup", "k_em2_rounds", "k_em2_rounds_hybrid", "k_em", "k_em_rounds"),
-            "k_p2_split": ("k_p2_hist", "k_p2_scan", "k_p2_scatter"),
+            "k_p2_split": ("k_p2_hist", "k_p2_scan", "k_p2_scatter"), "k_p2_search": ("k_p2_search", "k_p2_search_over"),
+            "k_p2_graph": ("k_p2_graph", "k_p2_cover"),
             "k_decode_par": ("k_slab_setup", "k_decode_recs", "k_decode_keys", "k_decode_par", "k_verify_cells"),
             "k_scatter": ("k_scatter",), "k_resolve": ("k_bucket_desc", "k_resolve"), "k_resolve_big": ("k_resolve_mid", "k_resolve_big"),
             "k_atac_dedup": ("k_atac_dedup64", "k_atac_dedup"), "k_atac_parse": ("k_atac_parse",)}
