@@ -1875,6 +1875,8 @@ int afq_atac_dedup_rad(afq_ctx* c, const uint8_t* bytes, size_t n_bytes, const u
         uint32_t* on = reinterpret_cast<uint32_t*>(pin);
         DevStatus* rst = reinterpret_cast<DevStatus*>(pin + 4ull * nc1);
         uint32_t* wide = reinterpret_cast<uint32_t*>(pin + 4ull * nc1 + kR * sizeof(DevStatus));
+        uint32_t* pin_dev = nullptr;   // the same block as the device sees it
+        T(hipHostGetDevicePointer(reinterpret_cast<void**>(&pin_dev), pin, 0));
         hipEvent_t ev[kR];
         for (auto& x : ev) x = get_event(c);
         T(hipMemsetAsync(d_flag.p, 0, 4, s));
@@ -1888,9 +1890,10 @@ int afq_atac_dedup_rad(afq_ctx* c, const uint8_t* bytes, size_t n_bytes, const u
                                   d_oref.as<uint32_t>(), d_ostart.as<uint32_t>(), d_oflen.as<uint16_t>(), d_ocnt.as<uint16_t>(), d_on.as<uint32_t>() + c0,
                                   d_flag.as<uint32_t>(), d_cnt.as<uint32_t>() + c0); }
             T(hipGetLastError());
-            if (nr) T(hipMemcpyAsync(on + c0, d_on.as<uint32_t>() + c0, 4ull * nr, hipMemcpyDeviceToHost, s));
-            T(hipMemcpyAsync(&wide[r], d_flag.p, 4, hipMemcpyDeviceToHost, s));
-            T(hipMemcpyAsync(&rst[r], d_rst + r, sizeof(DevStatus), hipMemcpyDeviceToHost, s));
+            // (the range's counts, flag and status go to the pinned block by a kernel, not as copies: see k_copy_words3)
+            launch_copy_words3(s, d_on.as<uint32_t>() + c0, nr, pin_dev + c0, d_flag.as<uint32_t>(), 1, pin_dev + (wide - on) + r,
+                               reinterpret_cast<const uint32_t*>(d_rst + r), (uint32_t)(sizeof(DevStatus) / 4), pin_dev + (reinterpret_cast<uint32_t*>(rst + r) - on));
+            T(hipGetLastError());
             T(hipEventRecord(ev[r], s));
         }
         optr[0] = 0;

@@ -1364,6 +1364,24 @@ void launch_pack_small(hipStream_t s, const DevStatus* st, const uint32_t* em_fl
     AFQ_LAUNCH(k_pack_small, (std::max(n, 16u) + 255) / 256, 256, s, st, em_flag, alt, nnz, em_nnz, bc, n_mono, n, out);
 }
 
+// Three small device arrays into (host-mapped, pinned) memory by a kernel: what the host reads between two ranges of a pipelined
+// batch.  As async D2H copies they queue on a DMA engine - behind the previous range's gigabyte of results when the runtime has
+// given both streams the same engine, which it does or does not depending on what the process did before (seen in the ATAC leg:
+// 38 ms per step on its own, 66 ms behind the other legs).
+__global__ __launch_bounds__(256) void k_copy_words3(const uint32_t* __restrict__ a, uint32_t na, uint32_t* __restrict__ da,
+                                                     const uint32_t* __restrict__ b, uint32_t nb, uint32_t* __restrict__ db,
+                                                     const uint32_t* __restrict__ c, uint32_t nc, uint32_t* __restrict__ dc) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < na; i += gridDim.x * 256) da[i] = a[i];
+    if (blockIdx.x == 0) {
+        for (uint32_t i = threadIdx.x; i < nb; i += 256) db[i] = b[i];
+        for (uint32_t i = threadIdx.x; i < nc; i += 256) dc[i] = c[i];
+    }
+}
+void launch_copy_words3(hipStream_t s, const uint32_t* a, uint32_t na, uint32_t* da, const uint32_t* b, uint32_t nb, uint32_t* db,
+                        const uint32_t* c, uint32_t nc, uint32_t* dc) {
+    AFQ_LAUNCH(k_copy_words3, std::max(1u, std::min(64u, (na + 255) / 256)), 256, s, a, na, da, b, nb, db, c, nc, dc);
+}
+
 void launch_gather_headers(hipStream_t s, const uint8_t* bytes, size_t n_bytes, const uint64_t* chunk_off,
                            uint32_t n_cells, uint32_t* hdr) {
     if (!n_cells) return;

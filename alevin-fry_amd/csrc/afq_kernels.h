@@ -68,6 +68,8 @@ constexpr uint32_t kRangeInitOps = 32;
 struct RangeInitOps { RangeInitOp op[kRangeInitOps]; uint32_t n; };
 void launch_range_init(hipStream_t s, const RangeInitOps& ops, const uint8_t* arena);
 constexpr uint32_t kPackHdrWords = 16;   // k_pack_small: words in front of the per-cell arrays
+void launch_copy_words3(hipStream_t s, const uint32_t* a, uint32_t na, uint32_t* da, const uint32_t* b, uint32_t nb, uint32_t* db,
+                        const uint32_t* c, uint32_t nc, uint32_t* dc);
 void launch_pack_small(hipStream_t s, const DevStatus* st, const uint32_t* em_flag, const uint32_t* alt, const uint32_t* nnz, const uint32_t* em_nnz,
                        const uint64_t* bc, const uint32_t* n_mono, uint32_t n, uint32_t* out);
 void launch_gather_headers(hipStream_t s, const uint8_t* bytes, size_t n_bytes, const uint64_t* chunk_off,
