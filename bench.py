@@ -244,7 +244,57 @@ def roofline_of(ktimes, alg_bytes, steps, traffic_tag, ms_per_step=None):
             "all_kernels_ms_per_step": {k: round(v[0] / steps, 4) for k, v in ktimes.items()}}
 
 
-def cpu_leg(cfg, rad, res, budget_s, min_cells=0, tie_stats=False, tol=None, n_threads=None, round_cells=None):
+# ---------------------------------------------------------------------------------------------------------
+# Where the submitting thread runs.  The host side of a step - planning, the pinned arena, reading the packed status, the row
+# pointers - talks to the device over PCIe; from the CPUs of the socket the GPU does not hang off, a configs[1] step was
+# 15.9 ms instead of 13.5 (taskset on a two-socket box).  Every rank therefore binds itself to the CPUs of its device's NUMA
+# node (what `afquant --devices` does for its worker threads, csrc/afq_host.cpp), and goes back to all CPUs for the oracle legs.
+_AFFINITY = {"all": None, "node": None, "id": None}
+
+
+def bind_to_device_node(torch, dev_index):
+    if not hasattr(os, "sched_setaffinity") or os.environ.get("AFQ_BENCH_NO_BIND"):
+        return None
+    try:
+        _AFFINITY["all"] = os.sched_getaffinity(0)
+        pr = torch.cuda.get_device_properties(dev_index)
+        bus = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bus}/numa_node").read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= _AFFINITY["all"]
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            _AFFINITY["node"] = cpus
+            _AFFINITY["id"] = node
+            return node
+    except Exception:
+        pass
+    return None
+
+
+class all_cpus:
+    """The oracle's worker threads inherit the affinity of the thread that starts them: all CPUs for the CPU legs."""
+
+    def __enter__(self):
+        if _AFFINITY["node"]:
+            os.sched_setaffinity(0, _AFFINITY["all"])
+
+    def __exit__(self, *exc):
+        if _AFFINITY["node"]:
+            os.sched_setaffinity(0, _AFFINITY["node"])
+
+
+def cpu_leg(*a, **kw):
+    with all_cpus():
+        return _cpu_leg(*a, **kw)
+
+
+def _cpu_leg(cfg, rad, res, budget_s, min_cells=0, tie_stats=False, tol=None, n_threads=None, round_cells=None):
     """The oracle (a C++ port, NOT the Rust binary) on a bounded sample of the same cells, one worker thread per host core;
     the sample doubles as a full-size parity check: GPU rows == oracle rows (bit for bit unless tol is given)."""
     import numpy as np
@@ -405,7 +455,8 @@ def run_pbmc(D, args, pkg, sn, usa, resolution, steps, warmup, cpu_seconds, name
                 "mean_refs_per_read": round((st["input_bytes"] - 8.0 * args.cells) / max(1, rad.n_reads) / 4.0 - 3.0, 3),
                 "reads_per_gpu": rad.n_reads, "input_bytes_per_gpu": st["input_bytes"], "resolution": resolution,
                 **({"bootstraps": args.bootstraps} if args.bootstraps else {}),
-                "sharding": f"{D.world} x independent cell shards, no data-path collective"}
+                "sharding": f"{D.world} x independent cell shards, no data-path collective",
+                "host_thread": (f"bound to the CPUs of NUMA node {_AFFINITY['id']} (the device's)" if _AFFINITY["id"] is not None else "not bound")}
         out = line(D, args, name, total_reads * steps / elapsed / 1e6, elapsed, steps, warmup, cfgd,
                    {"cells_per_s": round(total_cells * steps / elapsed, 1), "nnz": nnz, "keys": st["n_keys"],
                     "overflow_buckets": st["n_overflow_buckets"],
@@ -567,7 +618,8 @@ def run_cli(pkg, rad, host_np, workdir, resolution="cr-like"):
     for _ in range(3):   # best of three: page cache warm, as a pipeline that has just written the file would find it
         shutil.rmtree(o, ignore_errors=True)
         t0 = time.perf_counter()
-        p = subprocess.run([exe, "quant", "-i", d, "-m", tg, "-o", o, "-r", resolution, "-t", nt], capture_output=True, text=True)
+        with all_cpus():   # (a process of its own: it places its threads itself)
+            p = subprocess.run([exe, "quant", "-i", d, "-m", tg, "-o", o, "-r", resolution, "-t", nt], capture_output=True, text=True)
         dt = time.perf_counter() - t0
         if p.returncode != 0:
             return {"error": p.stderr[-400:]}, d, tg
@@ -590,7 +642,8 @@ def run_reference_binary(rad_dir, tg, rad, workdir, res_rows=None):
     o = os.path.join(workdir, "ref_out")
     nt = os.cpu_count() or 1
     t0 = time.perf_counter()
-    p = subprocess.run([exe, "quant", "-i", rad_dir, "-m", tg, "-o", o, "-r", "cr-like", "-t", str(nt), "--use-mtx"], capture_output=True, text=True)
+    with all_cpus():
+        p = subprocess.run([exe, "quant", "-i", rad_dir, "-m", tg, "-o", o, "-r", "cr-like", "-t", str(nt), "--use-mtx"], capture_output=True, text=True)
     dt = time.perf_counter() - t0
     if p.returncode != 0:
         return {"error": (p.stderr or p.stdout)[-400:]}
@@ -624,6 +677,7 @@ def main():
     import torch  # (imported before libafquant.so: one HIP runtime per process)
 
     D = Dist(args, torch)
+    numa_node = bind_to_device_node(torch, D.local_rank)
     pkg = importlib.import_module("alevin-fry_amd")
     sn = importlib.import_module("alevin-fry_amd.synth_native")
     if args.workload == "atac":
@@ -810,7 +864,7 @@ def run_atac(args, pkg, D, steps, warmup):
                 c0, c1 = int(bounds[i]), int(bounds[i + 1])
                 return ora.atac_dedup_rad(data[int(off[c0]):ends[i + 1]], off[c0:c1] - off[c0])
             tb = time.perf_counter()
-            with ThreadPoolExecutor(max_workers=ncores) as ex:
+            with all_cpus(), ThreadPoolExecutor(max_workers=ncores) as ex:
                 parts = list(ex.map(part, range(len(bounds) - 1)))
             tc = time.perf_counter() - tb
             pos = 0
