@@ -568,6 +568,7 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
     WAVE_SYNC();
     const uint32_t np = *s_np;
     if (lane == 0 && !OVER) A.pnp[gp] = np;   // (more than pcap: the second pass takes the partition)
+    if (lane == 0 && OVER && np != pcap) set_err(A.st, kErrInternal, c.cell);   // (the same search twice: the same pairs)
     WAVE_SYNC();
 }
 __global__ __launch_bounds__(256, 6) void k_p2_search(P2Args A) {

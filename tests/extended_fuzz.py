@@ -46,11 +46,17 @@ def one(seed):
     try:
         got = q.quant_chunks(b, off)
         rehash = q.label_rehash_count()
+        one.mono += q.mono_cell_count()
+        one.regrow += q.pool_regrow_count()
     finally:
         q.close()
-    want = ora.quant(cfg, s.tid_to_gid, b, off, n_threads=os.cpu_count() or 1)
+    # (EM resolutions: the oracle in the device's order-free fixed-point arithmetic - bit-identical by construction)
+    want = ora.quant(cfg, s.tid_to_gid, b, off, n_threads=os.cpu_count() or 1, em_arith="reference" if os.environ.get("AFQ_EM_ORDER") == "canonical" else "fixed")
     assert_same_result(got, want, what=f"seed {seed} {res} usa={usa} {kw} sizes={sizes}")
     return sum(sizes), rehash
+
+
+one.mono = one.regrow = 0
 
 
 if __name__ == "__main__":
@@ -66,5 +72,5 @@ if __name__ == "__main__":
         except Exception as e:   # noqa: BLE001
             bad += 1
             print(f"seed {seed} FAILED: {type(e).__name__}: {str(e)[:300]}", flush=True)
-    print(f"extended fuzz: {n} workloads, {reads} reads, {bad} failures, {time.time() - t0:.0f} s")
+    print(f"extended fuzz: {n} workloads, {reads} reads, {bad} failures, {one.mono} cells through the one-workgroup kernel, {one.regrow} pool re-grows, {time.time() - t0:.0f} s")
     sys.exit(1 if bad else 0)
