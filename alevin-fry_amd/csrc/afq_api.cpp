@@ -61,7 +61,7 @@ const char* const kKernelNames[K_COUNT] = {"k_gather_headers", "k_decode_par", "
                                            "k_resolve", "k_resolve_big", "k_pug_cell", "k_cell_hist", "k_em", "k_boot", "k_compact", "k_atac_dedup", "k_atac_parse", "k_fix_slabs",
                                            "k_p2_split", "k_p2_part", "k_p2_search", "k_p2_lone", "k_p2_graph"};
 
-struct TimedLaunch { int id; hipEvent_t a, b; };
+struct TimedLaunch { int id; hipEvent_t a, b; bool own_a = true; };   // own_a false: a is the b of the bracket in front (TimerChain) - it goes back to the event pool once
 
 // Pinned, grow-only host array (D2H lands here directly; handed to the caller zero-copy).
 template <class T>
@@ -155,6 +155,8 @@ struct RangeState {
     uint32_t hash_try = 0;   // which salt the range's label hashes were made with (a collision re-runs the range under the next)
     uint32_t pool_try = 0;   // how often the range was run again with four times the parsimony pool (a cell's graph outgrew it)
     uint64_t att_records = 0, att_ref_words = 0, att_buckets = 0;   // what the current attempt added to the batch statistics
+    bool chained = false;    // the rows' compaction was enqueued behind the range's kernels (row offsets made on the device, k_row_ptr) ...
+    uint64_t chain_cap = 0;  // ... against d_gene / d_val of this many entries: finish_range compacts again, after growing them, if the range has more
     bool em_inline = false;  // the EM was enqueued behind the range's kernels (offsets made on the device); finish_range only checks that its scratch sufficed
     bool in_flight = false;
     hipEvent_t kernels_done = nullptr;
@@ -261,13 +263,67 @@ struct ScopedTimer {
     }
 };
 
+// The brackets of a range's kernels.  An event between two kernels of a stream is not free: the timeline of a configs[1] step
+// (profiles/r04_timeline_configs1.txt) shows 10-14 us between two kernels wherever one bracket ended and the next began - two
+// event packets - and nothing between kernels of one bracket.  At seven brackets per cr-like range, five ranges per step, that
+// was ~0.35 ms of a 13.6 ms step spent on being timed.  A range's brackets therefore share their events - the end of one is the
+// start of the next: ONE packet between two timed kernels - and the 5 us kernels around the large ones are timed with their
+// neighbour (the proof's fix-up decode with the decoder, k_fix_slabs with the scatter, k_resolve_mid / k_resolve_big with
+// k_resolve).  AFQ_TIMER_MODE=pair is the old arrangement (two events per bracket, every bracket its own), =chain shares the
+// events but keeps every bracket (measurements).
+enum TimerMode { kTimerPair = 0, kTimerChain = 1, kTimerMerged = 2 };
+TimerMode timer_mode() {
+    static const TimerMode m = [] {
+        const char* e = std::getenv("AFQ_TIMER_MODE");
+        if (e && !std::strcmp(e, "pair")) return kTimerPair;
+        if (e && !std::strcmp(e, "chain")) return kTimerChain;
+        return kTimerMerged;
+    }();
+    return m;
+}
+struct TimerChain {
+    afq_ctx* c; hipStream_t s; std::vector<TimedLaunch>* sink; bool par;
+    hipEvent_t last = nullptr; int id = -1; bool last_shared = false;   // last: the event the open bracket started on; shared: it also ended the bracket in front
+    TimerChain(afq_ctx* c_, hipStream_t s_, std::vector<TimedLaunch>* sink_, bool par_) : c(c_), s(s_), sink(sink_), par(par_) {}
+    int fold(int k) const {
+        if (timer_mode() != kTimerMerged) return k;
+        if (k == K_DECODE && par) return K_DECODE_PAR;   // (without the walk-free decoders k_decode IS the decode and keeps its name)
+        if (k == K_FIX_SLABS) return K_SCATTER;
+        if (k == K_RESOLVE_BIG) return K_RESOLVE;
+        return k;
+    }
+    // the kernels enqueued from here on belong to bracket `next` (-1: to none)
+    void seg(int next) {
+        if (!c->cfg.profile) return;
+        if (next >= 0) next = fold(next);
+        if (next == id) return;
+        if (timer_mode() == kTimerPair) {
+            if (id >= 0) { hipEvent_t b = get_event(c); (void)hipEventRecord(b, s); sink->push_back({id, last, b, true}); }
+            last = nullptr;
+            if (next >= 0) { last = get_event(c); (void)hipEventRecord(last, s); }
+            id = next;
+            return;
+        }
+        hipEvent_t e = get_event(c);   // (next != id: a bracket ends here, or one begins, or both)
+        (void)hipEventRecord(e, s);
+        if (id >= 0) sink->push_back({id, last, e, !last_shared});
+        last_shared = id >= 0;
+        last = next >= 0 ? e : nullptr;
+        id = next;
+    }
+    void end() { seg(-1); }
+};
+void recycle_events(afq_ctx* c, const TimedLaunch& t) {
+    if (t.own_a) c->event_pool.push_back(t.a);
+    c->event_pool.push_back(t.b);
+}
+
 void harvest_timers(afq_ctx* c, std::vector<TimedLaunch>* list = nullptr) {
     if (list) { c->launches.insert(c->launches.end(), list->begin(), list->end()); list->clear(); }
     for (auto& t : c->launches) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { c->k_ms[t.id] += ms; c->k_launches[t.id] += 1; }
-        c->event_pool.push_back(t.a);
-        c->event_pool.push_back(t.b);
+        recycle_events(c, t);
     }
     c->launches.clear();
 }
@@ -524,6 +580,9 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
         if (!std::getenv("AFQ_SLAB_CAP") && resolve_sort_only(words, recs)) slab_cap = std::max<uint32_t>(slab_cap, 512u);
     }
     if (par) slab_prefix.reserve(n + 1);
+    // bucket -> cell and scatter tile -> (cell, tile): written on the device from the cells' plans (k_fill_tables) unless
+    // AFQ_DEVICE_TABLES=0 (measurements: the host fills and uploads them, as until late in round 4)
+    static const bool device_tables = [] { const char* e = std::getenv("AFQ_DEVICE_TABLES"); return !(e && e[0] == '0'); }();
     uint64_t nrec_total = 0;
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t ci = r.c0 + i;
@@ -550,7 +609,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
         max_lg_nb = std::max(max_lg_nb, lg);
         m.bucket_base = (uint32_t)n_buckets;
         n_buckets += 1ull << lg;
-        m.slab_cap = 0; m.k1_off = 0;
+        m.slab_cap = 0; m.k1_off = 0; m.tile_base = 0;
         if (lg && slabs) {
             m.slab_cap = slab_cap;
             m.k1_off = k1_slots;
@@ -559,7 +618,8 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
         if (lg) {
             multi.push_back(i);
             const uint32_t nt = (m.n_ref + kScatterTileHost - 1) / kScatterTileHost;
-            for (uint32_t t = 0; t < nt; ++t) B.tile_desc.push_back(make_uint2(i, t));
+            m.tile_base = (uint32_t)n_tiles;   // (n_tiles is checked against 32 bits below)
+            if (!device_tables) for (uint32_t t = 0; t < nt; ++t) B.tile_desc.push_back(make_uint2(i, t));
             n_tiles += nt;
         }
         if (mode_is_pug(m.mode)) {
@@ -578,10 +638,12 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     }
     if (n_buckets >= 0xFFFFFFF0ull || n_tiles >= 0xFFFFFFF0ull || key_off >= (1ull << 40))
         return fail(c, AFQ_ERR_UNSUPPORTED, "batch too large for 32-bit bucket/tile ids");
-    bucket_cell.resize(n_buckets);
-    for (uint32_t i = 0; i < n; ++i) {
-        const CellMeta& m = B.meta[i];
-        std::fill(bucket_cell.begin() + m.bucket_base, bucket_cell.begin() + m.bucket_base + (1u << m.lg_nb), i);
+    if (!device_tables) {
+        bucket_cell.resize(n_buckets);
+        for (uint32_t i = 0; i < n; ++i) {
+            const CellMeta& m = B.meta[i];
+            std::fill(bucket_cell.begin() + m.bucket_base, bucket_cell.begin() + m.bucket_base + (1u << m.lg_nb), i);
+        }
     }
     const uint32_t n_multi = (uint32_t)multi.size();
 
@@ -678,10 +740,10 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
         init.zero(B.d_cell_nkeys.p, 4ull * n);
     }
     init.upload(B.d_meta.p, B.meta.data(), sizeof(CellMeta) * n);
-    init.upload(B.d_bucket_cell.p, bucket_cell.data(), 4 * n_buckets);
+    if (!device_tables) init.upload(B.d_bucket_cell.p, bucket_cell.data(), 4 * n_buckets);
     if (n_multi) {
         init.upload(B.d_multi_cells.p, multi.data(), 4ull * n_multi);
-        init.upload(B.d_tile_desc.p, B.tile_desc.data(), 8ull * n_tiles);
+        if (!device_tables) init.upload(B.d_tile_desc.p, B.tile_desc.data(), 8ull * n_tiles);
     }
     init.zero(B.d_bucket_cnt.p, 4 * n_buckets);
     init.zero(B.d_slab_ovf.p, 4ull * n);
@@ -741,6 +803,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
         HIP_TRY(c, B.d_em2_tiers.ensure(4ull * (8 + 5ull * n)));
     }
     if (const int rc = init.flush(c, B, s)) return rc;
+    if (device_tables) launch_fill_tables(s, B.d_meta.as<CellMeta>(), n, B.d_bucket_cell.as<uint32_t>(), B.d_tile_desc.as<uint2>());
     // the host copies above are sourced from stack/vector memory: make sure they are consumed.  They only touch
     // this slot's buffers (idle since the range before last was finished), so they - and this wait - do not
     // depend on the range still executing in the other slot; the kernels below do:
@@ -756,10 +819,11 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
 
     const uint8_t* const in_bytes = c->widen ? c->d_wide.as<uint8_t>() : c->d_bytes;
     const size_t in_n = c->widen ? (size_t)c->wide_bytes : c->n_bytes;
+    TimerChain tc(c, s, &B.launches, par);   // the brackets of the range's kernels (HIP events; cfg.profile)
     if (c->widen) {
         HIP_TRY(c, B.d_src_off.ensure(8ull * n));
         HIP_TRY(c, hipMemcpyAsync(B.d_src_off.p, c->chunk_off.data() + r.c0, 8ull * n, hipMemcpyHostToDevice, s));   // (c->chunk_off outlives the batch)
-        ScopedTimer t(c, K_DECODE, s, &B.launches);
+        tc.seg(K_DECODE);
         launch_widen(s, c->d_bytes, c->n_bytes, B.d_src_off.as<uint64_t>(), B.d_meta.as<CellMeta>(), n, c->cfg.bc_bytes, c->cfg.umi_bytes,
                      c->eff_bc, c->eff_umi, c->d_wide.as<uint8_t>(), B.d_status.as<DevStatus>(), c->cfg.bc_split);
     }
@@ -773,12 +837,12 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
                         : PugOut{nullptr, nullptr, nullptr, nullptr, 0, ~0ull},
                   g.resolution == AFQ_RES_TRIVIAL ? 1u : 0u, decode_short_records(key_off - n, nrec_total), par ? B.d_fix.as<uint32_t>() : nullptr};
     if (par) {
-        ScopedTimer t(c, K_DECODE_PAR, s, &B.launches);
-        if (launch_decode_par(s, da, g.bc_bytes, g.umi_bytes)) return fail(c, AFQ_ERR_INVALID_ARG, "bad field widths");
+        tc.seg(K_DECODE_PAR);
+        if (launch_decode_par(s, da, g.bc_bytes, g.umi_bytes)) { tc.end(); return fail(c, AFQ_ERR_INVALID_ARG, "bad field widths"); }
     }
     {   // sequential walk: the whole decode for unaligned layouts, the verified fix-up otherwise
-        ScopedTimer t(c, K_DECODE, s, &B.launches);
-        if (launch_decode(s, da, g.bc_bytes, g.umi_bytes)) return fail(c, AFQ_ERR_INVALID_ARG, "bad field widths");
+        tc.seg(K_DECODE);
+        if (launch_decode(s, da, g.bc_bytes, g.umi_bytes)) { tc.end(); return fail(c, AFQ_ERR_INVALID_ARG, "bad field widths"); }
     }
     ResolveArgs ra{B.d_meta.as<CellMeta>(), B.d_bucket_cell.as<uint32_t>(), B.d_multi_cells.as<uint32_t>(),
                    B.d_tile_desc.as<uint2>(), B.d_cell_nkeys.as<uint32_t>(), B.d_bucket_cnt.as<uint32_t>(),
@@ -791,14 +855,14 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
                    resolve_sort_only(key_off - n, nrec_total)};
     if (n_multi) {
         if (!slabs) {
-            { ScopedTimer t(c, K_HIST, s, &B.launches); launch_hist(s, ra); }
-            { ScopedTimer t(c, K_BSCAN, s, &B.launches); launch_bucket_scan(s, ra); }
+            tc.seg(K_HIST); launch_hist(s, ra);
+            tc.seg(K_BSCAN); launch_bucket_scan(s, ra);
         }
-        { ScopedTimer t(c, K_SCATTER, s, &B.launches); launch_scatter(s, ra); }
-        if (slabs) { ScopedTimer t(c, K_FIX_SLABS, s, &B.launches); launch_fix_slabs(s, ra); }
+        tc.seg(K_SCATTER); launch_scatter(s, ra);
+        if (slabs) { tc.seg(K_FIX_SLABS); launch_fix_slabs(s, ra); }
     }
-    { ScopedTimer t(c, K_RESOLVE, s, &B.launches); launch_resolve(s, ra); }
-    if (n_multi) { ScopedTimer t(c, K_RESOLVE_BIG, s, &B.launches); launch_resolve_big(s, ra); }
+    tc.seg(K_RESOLVE); launch_resolve(s, ra);
+    if (n_multi) { tc.seg(K_RESOLVE_BIG); launch_resolve_big(s, ra); }
     if (n_pug) {
         const P2Small L = p2_small_layout(n_p2, p2_parts, p2tiles.size(), n_pug);
         uint32_t* sm = B.d_p2_small.as<uint32_t>();
@@ -817,7 +881,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
             p2.v_flag = reinterpret_cast<uint8_t*>(ep + eo); eo += n_pug_reads / 4 + 1;
             eo = (eo + 3) & ~3ull;
         }
-        if (eo + (1ull << 20) > epool_words) return fail(c, AFQ_ERR_OOM, "parsimony work arrays do not fit the edge pool");
+        if (eo + (1ull << 20) > epool_words) { tc.end(); return fail(c, AFQ_ERR_OOM, "parsimony work arrays do not fit the edge pool"); }
         uint32_t* const pool = ep + eo;
         const unsigned long long pool_cap = epool_words - eo;
         if (n_p2) {
@@ -843,11 +907,11 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
             p2.ref_count = c->ref_count; p2.num_genes = g.num_genes; p2.usa = g.usa_mode; p2.num_rows = g.num_rows; p2.em = em ? 1u : 0u;
             p2.exact_umi = g.pug_exact_umi; p2.large_thresh = g.large_graph_thresh; p2.hw = 1 + g.bc_bytes / 4 + g.umi_bytes / 4;
             p2.umi_pairs = std::min<uint32_t>(g.umi_len ? g.umi_len : g.umi_bytes * 4, 16);
-            { ScopedTimer t(c, K_P2_SPLIT, s, &B.launches); launch_p2_split(s, p2); }
-            { ScopedTimer t(c, K_P2_PART, s, &B.launches); launch_p2_part(s, p2); }
-            { ScopedTimer t(c, K_P2_SEARCH, s, &B.launches); launch_p2_search(s, p2); }
-            { ScopedTimer t(c, K_P2_LONE, s, &B.launches); launch_p2_lone(s, p2); }
-            { ScopedTimer t(c, K_P2_GRAPH, s, &B.launches); launch_p2_graph(s, p2); }
+            tc.seg(K_P2_SPLIT); launch_p2_split(s, p2);
+            tc.seg(K_P2_PART); launch_p2_part(s, p2);
+            tc.seg(K_P2_SEARCH); launch_p2_search(s, p2);
+            tc.seg(K_P2_LONE); launch_p2_lone(s, p2);
+            tc.seg(K_P2_GRAPH); launch_p2_graph(s, p2);
         }
         PugCellArgs pa{};
         pa.bytes = in_bytes; pa.meta = ra.meta; pa.pug_cells = sm + L.fb_list; pa.cell_nkeys = ra.cell_nkeys;
@@ -860,18 +924,25 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
         pa.hw = 1 + g.bc_bytes / 4 + g.umi_bytes / 4; pa.umi_pairs = std::min<uint32_t>(g.umi_len ? g.umi_len : g.umi_bytes * 4, 22);
         pa.gene_level = (g.resolution == AFQ_RES_PARSIMONY_GENE || g.resolution == AFQ_RES_PARSIMONY_GENE_EM) ? 1u : 0u;
         pa.force_global_route = std::getenv("AFQ_PUG_GLOBAL_ROUTE") ? 1u : 0u;
-        ScopedTimer t(c, K_PUG, s, &B.launches);
+        tc.seg(K_PUG);
         launch_pug(s, pa, n_pug_blocks);
     }
-    if (!hist_cells.empty()) { ScopedTimer t(c, K_CELL_HIST, s, &B.launches); launch_cell_hist(s, ra); }
+    // What the next range's kernels wait for.  A range without an EM ends in the per-cell histograms - a workgroup per cell, 73 KiB
+    // of LDS each at 36 601 columns, two to a CU, most of their time spent waiting on LDS - and the 5 us kernels behind them: the
+    // next range's decoder (issue-bound, 9 KiB of LDS per workgroup) may start next to them (AFQ_TAIL_OVERLAP=0: behind them).
+    static const bool tail_overlap = [] { const char* e = std::getenv("AFQ_TAIL_OVERLAP"); return !(e && e[0] == '0'); }();
+    if (!B.kernels_done) HIP_TRY(c, hipEventCreateWithFlags(&B.kernels_done, hipEventDisableTiming));
+    const bool early_done = tail_overlap && !em && !hist_cells.empty();
+    if (early_done) { tc.seg(K_CELL_HIST); HIP_TRY(c, hipEventRecord(B.kernels_done, s)); }   // (the bracket's event first: one packet train)
+    if (!hist_cells.empty()) { tc.seg(K_CELL_HIST); launch_cell_hist(s, ra); }
     if (B.em_inline) {
-        ScopedTimer t(c, K_EM, s, &B.launches);
+        tc.seg(K_EM);
         launch_em2(s, ra, n, B.d_em2_off.as<uint64_t>(), B.d_em2_scratch.as<uint32_t>(), B.d_em_nnz.as<uint32_t>(), B.d_em_order.as<uint32_t>(),
                    B.d_em2_tiers.as<uint32_t>(), na_em, g.em_init_uniform, em2_cap);
     }
+    tc.end();
     HIP_TRY(c, hipGetLastError());
-    if (!B.kernels_done) HIP_TRY(c, hipEventCreateWithFlags(&B.kernels_done, hipEventDisableTiming));
-    HIP_TRY(c, hipEventRecord(B.kernels_done, s));
+    if (!early_done) HIP_TRY(c, hipEventRecord(B.kernels_done, s));
     {   // what finish_range reads first: written by the last kernel of the range STRAIGHT into pinned host memory (20 bytes per cell over
         // PCIe).  An async D2H copy here instead would sit in the copy queue until the range's kernels are done - with the NEXT range's
         // upload queued behind it: the next range then started 150 us after this one ended instead of right behind it (seen in the
@@ -883,6 +954,24 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
         launch_pack_small(s, B.d_status.as<DevStatus>(), B.em_inline ? B.d_em2_tiers.as<uint32_t>() + 7 : nullptr, B.d_alt.as<uint32_t>(), B.d_nnz.as<uint32_t>(),
                           B.em_inline ? B.d_em_nnz.as<uint32_t>() : nullptr, B.d_bc.as<uint64_t>(),
                           n_pug ? B.d_p2_small.as<uint32_t>() + p2_small_layout(n_p2, p2_parts, p2tiles.size(), n_pug).fb_count : nullptr, n, reinterpret_cast<uint32_t*>(d_view));
+    }
+    // The rows' compaction follows at once, with row offsets made on the device - it used to wait for the host to read the row
+    // lengths, sum them and send the offsets back: 0.27 ms between the last kernel of a batch's last range and its compaction,
+    // with nothing else for the device to do (profiles/r04_timeline_configs1.txt).  The buffers are the slot's as they stand (they
+    // grow to the largest range seen); a range with more entries is compacted by finish_range as before.  EM resolutions take their
+    // rows out of the EM's scratch (finish_range).  AFQ_CHAIN_COMPACT=0: never.
+    static const bool chain_compact = [] { const char* e = std::getenv("AFQ_CHAIN_COMPACT"); return !(e && e[0] == '0'); }();
+    B.chained = false;
+    if (chain_compact && !em) {
+        HIP_TRY(c, B.d_cell_ptr.ensure(8ull * (n + 1)));
+        B.chain_cap = std::min(B.d_gene.cap, B.d_val.cap) / 4;
+        tc.seg(K_COMPACT);
+        launch_row_ptr(s, B.d_nnz.as<uint32_t>(), n, B.d_cell_ptr.as<uint64_t>());
+        launch_compact(s, B.d_meta.as<CellMeta>(), n, B.d_keys0.as<uint64_t>(), B.d_keys1.as<uint64_t>(), B.d_nnz.as<uint32_t>(),
+                       B.d_cell_ptr.as<uint64_t>(), B.d_gene.as<uint32_t>(), B.d_val.as<float>(), B.chain_cap);
+        tc.end();
+        HIP_TRY(c, hipGetLastError());
+        B.chained = true;
     }
     hc.lap("run: enqueue kernels");
     B.last_ra = ra;
@@ -911,7 +1000,7 @@ int finish_range(afq_ctx* c, int slot) {
     const uint32_t* const pk = B.h_pack.p + kPackHdrWords;
     auto take_back_attempt = [&]() {   // the failed attempt's share of the statistics and its kernel timings
         c->stats.n_records -= B.att_records; c->stats.n_ref_words -= B.att_ref_words; c->stats.n_buckets -= B.att_buckets;
-        for (TimedLaunch& t : B.launches) { c->event_pool.push_back(t.a); c->event_pool.push_back(t.b); }   // (back to the pool, not into the kernel times)
+        for (TimedLaunch& t : B.launches) recycle_events(c, t);   // (back to the pool, not into the kernel times)
         B.launches.clear();
     };
     // A label-hash collision or a graph that outgrew the pool names its cell.  The range is cut around that cell: the cells before
@@ -1112,11 +1201,12 @@ int finish_range(afq_ctx* c, int slot) {
     for (uint32_t i = 0; i < n; ++i) ptr[i + 1] = ptr[i] + nnz[i];
     const uint64_t tot = ptr[n];
     hc.lap("finish: small D2H + prefix");
-    HIP_TRY(c, B.d_cell_ptr.ensure(8ull * (n + 1)));
-    HIP_TRY(c, B.d_gene.ensure(std::max<uint64_t>(4 * tot, 16)));
-    HIP_TRY(c, B.d_val.ensure(std::max<uint64_t>(4 * tot, 16)));
-    HIP_TRY(c, hipMemcpyAsync(B.d_cell_ptr.p, ptr.data(), 8ull * (n + 1), hipMemcpyHostToDevice, s));
-    {
+    const bool compacted = B.chained && !em && tot <= B.chain_cap;   // the compaction behind the range's kernels had room for every row
+    if (!compacted) {
+        HIP_TRY(c, B.d_cell_ptr.ensure(8ull * (n + 1)));
+        HIP_TRY(c, B.d_gene.ensure(std::max<uint64_t>(4 * tot, 16)));
+        HIP_TRY(c, B.d_val.ensure(std::max<uint64_t>(4 * tot, 16)));
+        HIP_TRY(c, hipMemcpyAsync(B.d_cell_ptr.p, ptr.data(), 8ull * (n + 1), hipMemcpyHostToDevice, s));
         ScopedTimer t(c, K_COMPACT, s, &B.launches);
         if (em)
             launch_compact_em(s, n, (em2 ? B.d_em2_off : B.d_em_off).as<uint64_t>(), (em2 ? B.d_em2_scratch : B.d_em_scratch).as<uint32_t>(), B.d_em_nnz.as<uint32_t>(),

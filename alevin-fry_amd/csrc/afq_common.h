@@ -44,6 +44,7 @@ struct CellMeta {
     uint32_t lg_nb;        // log2(#buckets)
     uint32_t mode;         // kModeCrLike / kModeTrivial: how this cell is resolved (tiny cells are always cr-like)
     uint32_t slab_cap;     // multi-bucket cells placed without a counting pass: every bucket owns slab_cap slots of keys1 (0: exact layout)
+    uint32_t tile_base;    // multi-bucket cells: the cell's first scatter tile (k_fill_tables writes the range's tile table from it)
     uint64_t k1_off;       // ... starting here (the cell's region holds max(nb * slab_cap, n_ref + 1) slots)
 };
 

@@ -1109,13 +1109,17 @@ __global__ __launch_bounds__(kHistNT) void k_cell_hist(const uint32_t* __restric
 
 // ---------------------------------------------------------------------------
 // staging pairs -> final CSR (wave per cell)
+// (cap: how many entries gene / val hold.  The compaction that is enqueued right behind a range's kernels - row offsets from
+//  k_row_ptr, no trip to the host in between - runs against the buffers as they were when the range was enqueued; rows that
+//  do not fit are left where they are and the host, which sees the same total, compacts them after growing the buffers.)
 __global__ __launch_bounds__(256) void k_compact(const CellMeta* __restrict__ meta, uint32_t n_cells,
                                                 const uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
                                                 const uint32_t* __restrict__ nnz,
                                                 const uint64_t* __restrict__ cell_ptr, uint32_t* __restrict__ gene,
-                                                float* __restrict__ val) {
+                                                float* __restrict__ val, uint64_t cap) {
     const uint32_t cell = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (cell >= n_cells) return;
+    if (cell_ptr[n_cells] > cap) return;
     const CellMeta m = meta[cell];
     const uint2* src = reinterpret_cast<const uint2*>(((m.lg_nb || mode_is_pug(m.mode)) ? keys1 : keys0) + m.key_off);
     const uint32_t n = nnz[cell];
@@ -1369,9 +1373,47 @@ void launch_cell_hist(hipStream_t s, const ResolveArgs& a) {
 }
 
 void launch_compact(hipStream_t s, const CellMeta* meta, uint32_t n_cells, const uint64_t* keys0, const uint64_t* keys1,
-                    const uint32_t* nnz, const uint64_t* cell_ptr, uint32_t* gene, float* val) {
+                    const uint32_t* nnz, const uint64_t* cell_ptr, uint32_t* gene, float* val, uint64_t cap) {
     if (!n_cells) return;
-    AFQ_LAUNCH(k_compact, (n_cells + 3) / 4, 256, s, meta, n_cells, keys0, keys1, nnz, cell_ptr, gene, val);
+    AFQ_LAUNCH(k_compact, (n_cells + 3) / 4, 256, s, meta, n_cells, keys0, keys1, nnz, cell_ptr, gene, val, cap);
+}
+
+// Row offsets of a range from its row lengths, on the device (one workgroup: n is a range's cells): cell_ptr[i] = nnz[0] + ... +
+// nnz[i - 1], cell_ptr[n] = the range's entries.  The host makes the same sums from the packed block it reads anyway; this
+// copy lets the compaction follow the range's kernels without waiting for the host.
+__global__ __launch_bounds__(1024) void k_row_ptr(const uint32_t* __restrict__ nnz, uint32_t n, uint64_t* __restrict__ cell_ptr) {
+    __shared__ uint32_t s_ws[16];
+    uint64_t carry = 0;
+    for (uint32_t base = 0; base < n; base += 1024) {   // (a row has at most 2^20 entries: 1024 of them fit 32 bits)
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? nnz[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<1024>(v, s_ws, tot);
+        if (i < n) cell_ptr[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) cell_ptr[n] = carry;
+}
+// The two tables of a range that only restate the cells' plans - bucket -> cell (k_bucket_desc's lookup) and scatter tile ->
+// (cell, tile of the cell) - written from the plans, a wave per cell.  They are 4 bytes per bucket and 8 per tile (2.8 + 0.5 MB
+// for the first range of a PBMC-10k batch) and used to be filled on the host and uploaded in front of the range's first kernel.
+__global__ __launch_bounds__(256) void k_fill_tables(const CellMeta* __restrict__ meta, uint32_t n_cells, uint32_t* __restrict__ bucket_cell,
+                                                    uint2* __restrict__ tile_desc) {
+    const uint32_t cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (cell >= n_cells) return;
+    const CellMeta m = meta[cell];
+    const uint32_t nb = 1u << m.lg_nb;
+    for (uint32_t b = lane_id(); b < nb; b += 64) bucket_cell[m.bucket_base + b] = cell;
+    if (m.lg_nb == 0) return;   // (single-bucket and parsimony cells have no tiles)
+    const uint32_t nt = (m.n_ref + kTileKeys - 1) / kTileKeys;
+    for (uint32_t t = lane_id(); t < nt; t += 64) tile_desc[m.tile_base + t] = make_uint2(cell, t);
+}
+void launch_fill_tables(hipStream_t s, const CellMeta* meta, uint32_t n_cells, uint32_t* bucket_cell, uint2* tile_desc) {
+    if (!n_cells) return;
+    AFQ_LAUNCH(k_fill_tables, (n_cells + 3) / 4, 256, s, meta, n_cells, bucket_cell, tile_desc);
+}
+void launch_row_ptr(hipStream_t s, const uint32_t* nnz, uint32_t n, uint64_t* cell_ptr) {
+    AFQ_LAUNCH(k_row_ptr, 1, 1024, s, nnz, n, cell_ptr);
 }
 
 }  // namespace afq

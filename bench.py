@@ -198,8 +198,12 @@ def sanity(res, rad):
 BRACKETS = {"k_em": ("k_em2_plan", "k_em2_setup", "k_em2_rounds", "k_em2_rounds_hybrid", "k_em", "k_em_rounds"),
             "k_p2_split": ("k_p2_hist", "k_p2_scan", "k_p2_scatter"), "k_p2_search": ("k_p2_search", "k_p2_search_over"),
             "k_p2_graph": ("k_p2_graph", "k_p2_cover"),
-            "k_decode_par": ("k_slab_setup", "k_decode_recs", "k_decode_keys", "k_decode_par", "k_verify_cells"),
-            "k_scatter": ("k_scatter",), "k_resolve": ("k_bucket_desc", "k_resolve"), "k_resolve_big": ("k_resolve_mid", "k_resolve_big"),
+            # (since late round 4 the 5 us kernels around the large ones are timed with them - one HIP event between two timed kernels
+            #  instead of two per bracket, csrc/afq_api.cpp: TimerChain - so the decode bracket also holds the proof's fix-up decode,
+            #  the scatter bracket k_fix_slabs, the resolve bracket k_resolve_mid / k_resolve_big)
+            "k_decode_par": ("k_slab_setup", "k_decode_recs", "k_decode_keys", "k_decode_par", "k_verify_cells", "k_decode"),
+            "k_scatter": ("k_scatter", "k_fix_slabs"), "k_resolve": ("k_bucket_desc", "k_resolve", "k_resolve_mid", "k_resolve_big"),
+            "k_compact": ("k_row_ptr", "k_compact", "k_compact_em"),
             "k_atac_dedup": ("k_atac_dedup64", "k_atac_dedup"), "k_atac_parse": ("k_atac_parse",)}
 
 
