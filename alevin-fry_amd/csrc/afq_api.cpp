@@ -804,10 +804,11 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     }
     if (const int rc = init.flush(c, B, s)) return rc;
     if (device_tables) launch_fill_tables(s, B.d_meta.as<CellMeta>(), n, B.d_bucket_cell.as<uint32_t>(), B.d_tile_desc.as<uint2>());
-    // the host copies above are sourced from stack/vector memory: make sure they are consumed.  They only touch
-    // this slot's buffers (idle since the range before last was finished), so they - and this wait - do not
-    // depend on the range still executing in the other slot; the kernels below do:
-    HIP_TRY(c, hipStreamSynchronize(s));
+    // (the uploads come out of the slot's pinned arena, which the next range of this slot fills only after finish_range has
+    //  waited for this one; until the arena existed they came out of the vectors above, hence the wait here.  AFQ_INIT_SYNC=0
+    //  drops it: the host goes on to enqueue the range's kernels while the arena copy is on its way - measurements.)
+    static const bool init_sync = [] { const char* e = std::getenv("AFQ_INIT_SYNC"); return !(e && e[0] == '0'); }();
+    if (init_sync) HIP_TRY(c, hipStreamSynchronize(s));
     {   // this range's kernels start after the previous range's kernels (clean per-kernel timings, no cache
         // thrash between ranges); what overlaps them is the previous range's D2H and this range's enqueue
         RangeState& O = c->rs[slot ^ 1];
@@ -1549,6 +1550,7 @@ int afq_submit_device(afq_ctx* c, const void* d_bytes, size_t n_bytes, const uin
     if ((!d_bytes && n_bytes) || (!chunk_off && n_cells)) return fail(c, AFQ_ERR_INVALID_ARG, "null argument");
     if (((uintptr_t)d_bytes) & 3) return fail(c, AFQ_ERR_INVALID_ARG, "device buffer must be 4-byte aligned");
     if (c->pending) return fail(c, AFQ_ERR_STATE, "previous batch not collected");
+    HostClock hc;
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = check_supported(c);
     if (rc) return rc;
@@ -1567,7 +1569,9 @@ int afq_submit_device(afq_ctx* c, const void* d_bytes, size_t n_bytes, const uin
         HIP_TRY(c, hipMemcpyAsync(c->hdr.data(), c->d_hdr.p, 8ull * n_cells, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
+    hc.lap("submit: chunk headers");
     int rc2 = begin_batch(c, n_cells, first_cell_index);
+    hc.lap("submit: plan ranges");
     return rc2 ? rc2 : run_batch(c);
 }
 

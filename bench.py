@@ -186,6 +186,18 @@ def timed_steps(D, q, rad, steps, warmup, first_cell=0):
     return elapsed, ktimes, res
 
 
+def rows_crc(res):
+    """CRC-32 of the last step's rows (row offsets, columns, values, barcodes): one number to compare runs of the same workload under different switches."""
+    import zlib
+
+    import numpy as np
+
+    c = 0
+    for a in (res.cell_ptr, res.gene, res.val, res.bc):
+        c = zlib.crc32(np.ascontiguousarray(a).view(np.uint8), c)
+    return c
+
+
 def sanity(res, rad):
     import numpy as np
 
@@ -467,6 +479,7 @@ def run_pbmc(D, args, pkg, sn, usa, resolution, steps, warmup, cpu_seconds, name
                     "retries": {"label_rehashes": q.label_rehash_count(), "pool_regrows": q.pool_regrow_count(), "em_resizes": q.em_resize_count(),
                                 "what": "ranges run again under another label hash / with a larger parsimony pool, EMs sized on the host after all - since the context was made (warm-up included)"},
                     "gen_seconds": round(t_gen, 2),
+                    **({"rows_crc32": rows_crc(res)} if os.environ.get("AFQ_BENCH_CRC") else {}),   # (measurement scripts: the same rows under every switch)
                     "roofline": roof, "cpu_baseline": cpu})
         return out, rad, q
     except BaseException:
