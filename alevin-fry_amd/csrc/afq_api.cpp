@@ -272,21 +272,20 @@ struct ScopedTimer {
 // k_resolve).  AFQ_TIMER_MODE=pair is the old arrangement (two events per bracket, every bracket its own), =chain shares the
 // events but keeps every bracket (measurements).
 enum TimerMode { kTimerPair = 0, kTimerChain = 1, kTimerMerged = 2 };
-TimerMode timer_mode() {
-    static const TimerMode m = [] {
-        const char* e = std::getenv("AFQ_TIMER_MODE");
-        if (e && !std::strcmp(e, "pair")) return kTimerPair;
-        if (e && !std::strcmp(e, "chain")) return kTimerChain;
-        return kTimerMerged;
-    }();
-    return m;
+TimerMode timer_mode() {   // (read per range: tests and measurement scripts switch it between batches)
+    const char* e = std::getenv("AFQ_TIMER_MODE");
+    if (e && !std::strcmp(e, "pair")) return kTimerPair;
+    if (e && !std::strcmp(e, "chain")) return kTimerChain;
+    return kTimerMerged;
 }
+bool env_on(const char* name) { const char* e = std::getenv(name); return !(e && e[0] == '0'); }   // switches that are on unless NAME=0
 struct TimerChain {
     afq_ctx* c; hipStream_t s; std::vector<TimedLaunch>* sink; bool par;
+    const TimerMode mode = timer_mode();
     hipEvent_t last = nullptr; int id = -1; bool last_shared = false;   // last: the event the open bracket started on; shared: it also ended the bracket in front
     TimerChain(afq_ctx* c_, hipStream_t s_, std::vector<TimedLaunch>* sink_, bool par_) : c(c_), s(s_), sink(sink_), par(par_) {}
     int fold(int k) const {
-        if (timer_mode() != kTimerMerged) return k;
+        if (mode != kTimerMerged) return k;
         if (k == K_DECODE && par) return K_DECODE_PAR;   // (without the walk-free decoders k_decode IS the decode and keeps its name)
         if (k == K_FIX_SLABS) return K_SCATTER;
         if (k == K_RESOLVE_BIG) return K_RESOLVE;
@@ -297,7 +296,7 @@ struct TimerChain {
         if (!c->cfg.profile) return;
         if (next >= 0) next = fold(next);
         if (next == id) return;
-        if (timer_mode() == kTimerPair) {
+        if (mode == kTimerPair) {
             if (id >= 0) { hipEvent_t b = get_event(c); (void)hipEventRecord(b, s); sink->push_back({id, last, b, true}); }
             last = nullptr;
             if (next >= 0) { last = get_event(c); (void)hipEventRecord(last, s); }
@@ -582,7 +581,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     if (par) slab_prefix.reserve(n + 1);
     // bucket -> cell and scatter tile -> (cell, tile): written on the device from the cells' plans (k_fill_tables) unless
     // AFQ_DEVICE_TABLES=0 (measurements: the host fills and uploads them, as until late in round 4)
-    static const bool device_tables = [] { const char* e = std::getenv("AFQ_DEVICE_TABLES"); return !(e && e[0] == '0'); }();
+    const bool device_tables = env_on("AFQ_DEVICE_TABLES");
     uint64_t nrec_total = 0;
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t ci = r.c0 + i;
@@ -807,7 +806,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     // (the uploads come out of the slot's pinned arena, which the next range of this slot fills only after finish_range has
     //  waited for this one; until the arena existed they came out of the vectors above, hence the wait here.  AFQ_INIT_SYNC=0
     //  drops it: the host goes on to enqueue the range's kernels while the arena copy is on its way - measurements.)
-    static const bool init_sync = [] { const char* e = std::getenv("AFQ_INIT_SYNC"); return !(e && e[0] == '0'); }();
+    const bool init_sync = env_on("AFQ_INIT_SYNC");
     if (init_sync) HIP_TRY(c, hipStreamSynchronize(s));
     {   // this range's kernels start after the previous range's kernels (clean per-kernel timings, no cache
         // thrash between ranges); what overlaps them is the previous range's D2H and this range's enqueue
@@ -928,10 +927,12 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
         tc.seg(K_PUG);
         launch_pug(s, pa, n_pug_blocks);
     }
-    // What the next range's kernels wait for.  A range without an EM ends in the per-cell histograms - a workgroup per cell, 73 KiB
-    // of LDS each at 36 601 columns, two to a CU, most of their time spent waiting on LDS - and the 5 us kernels behind them: the
-    // next range's decoder (issue-bound, 9 KiB of LDS per workgroup) may start next to them (AFQ_TAIL_OVERLAP=0: behind them).
-    static const bool tail_overlap = [] { const char* e = std::getenv("AFQ_TAIL_OVERLAP"); return !(e && e[0] == '0'); }();
+    // What the next range's kernels wait for: all of this range's.  (AFQ_TAIL_OVERLAP=1 lets them start beside the per-cell
+    // histograms a range without an EM ends in - measured on the headline and not kept: the decoder fills every SIMD at eight
+    // waves, the histogram workgroups - 73 KiB of LDS each - get a CU only as decoder workgroups drain, the bracket of
+    // k_cell_hist grows from 0.56 to 3.3 ms per step and the range's rows start across PCIe that much later: 12.97 -> 15.38 ms
+    // per step, profiles/run_r04aa.sh.)
+    const bool tail_overlap = [] { const char* e = std::getenv("AFQ_TAIL_OVERLAP"); return e && e[0] == '1'; }();
     if (!B.kernels_done) HIP_TRY(c, hipEventCreateWithFlags(&B.kernels_done, hipEventDisableTiming));
     const bool early_done = tail_overlap && !em && !hist_cells.empty();
     if (early_done) { tc.seg(K_CELL_HIST); HIP_TRY(c, hipEventRecord(B.kernels_done, s)); }   // (the bracket's event first: one packet train)
@@ -961,7 +962,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     // with nothing else for the device to do (profiles/r04_timeline_configs1.txt).  The buffers are the slot's as they stand (they
     // grow to the largest range seen); a range with more entries is compacted by finish_range as before.  EM resolutions take their
     // rows out of the EM's scratch (finish_range).  AFQ_CHAIN_COMPACT=0: never.
-    static const bool chain_compact = [] { const char* e = std::getenv("AFQ_CHAIN_COMPACT"); return !(e && e[0] == '0'); }();
+    const bool chain_compact = env_on("AFQ_CHAIN_COMPACT");
     B.chained = false;
     if (chain_compact && !em) {
         HIP_TRY(c, B.d_cell_ptr.ensure(8ull * (n + 1)));

@@ -450,6 +450,41 @@ def test_many_ranges_pipeline(oracle, monkeypatch):
         assert np.array_equal(got.bootstraps.var(i)[1].view(np.uint32), want.bootstraps.var(i)[1].view(np.uint32)), i
 
 
+@pytest.mark.parametrize("ranges", ["one", "many"])
+@pytest.mark.parametrize("resolution", ["cr-like", "trivial", "parsimony", "cr-like-em"])
+def test_context_reused_across_batches(oracle, monkeypatch, resolution, ranges):
+    """One context, batch after batch (what a host streaming a file does, and every bench step after the first).  The rows of a
+    range are compacted behind its kernels into the slot's row buffers as the previous batches left them (k_row_ptr + k_compact;
+    csrc/afq_api.cpp: run_range / finish_range): a first batch finds none (the host compacts after allocating), a repeat fits, a
+    larger batch does not fit and is compacted again once the buffers have grown, a smaller one fits with room to spare.  Same
+    rows as the oracle every time - in both orders of sizes, with one range per batch and with many (two slots taking turns),
+    with the range pipeline's other switches in their old positions - and the same rows with that compaction switched off."""
+    if ranges == "many":
+        monkeypatch.setenv("AFQ_RANGE_BYTES", "150000")
+    s = synth.synth(52, [6000, 5000, 3000, 2500, 1500, 800, 300, 90, 20, 3], num_genes=400, txp_per_gene=2, dup=0.4, cross=0.3, umi_err=0.02)
+    b, off = s.encode()
+    n = len(off)
+    cfg = cfg_for(s, resolution)
+
+    def batch(a, e):
+        lo, hi = int(off[a]), (int(off[e]) if e < n else len(b))
+        return b[lo:hi], np.asarray(off[a:e], np.uint64) - np.uint64(lo)
+
+    growing = [(n - 2, n), (n // 2, n), (n // 2, n), (0, n), (0, n), (2, n)]   # tiny, larger, repeat, whole, repeat, a little less
+    for cuts, env in ((growing, {}), (growing[::-1], {}), (growing, {"AFQ_TIMER_MODE": "pair", "AFQ_TAIL_OVERLAP": "1", "AFQ_DEVICE_TABLES": "0"}),
+                      (growing, {"AFQ_CHAIN_COMPACT": "0"})):
+        with monkeypatch.context() as mp:
+            for k, v in env.items():
+                mp.setenv(k, v)
+            q = pkg.Quantifier(cfg, s.tid_to_gid)
+            try:
+                for a, e in cuts:
+                    bb, oo = batch(a, e)
+                    assert_same_result(q.quant_chunks(bb, oo), oracle.quant(cfg, s.tid_to_gid, bb, oo), what=f"{resolution} cells [{a}, {e}) {env}")
+            finally:
+                q.close()
+
+
 @pytest.mark.parametrize("usa", [False, True])
 @pytest.mark.parametrize("pad_reads", [0, 3000])
 def test_tie_shapes_and_wide_umis(oracle, usa, pad_reads):
