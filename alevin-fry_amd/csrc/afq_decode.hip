@@ -390,7 +390,10 @@ __global__ __launch_bounds__(256) void k_slab_setup(const uint8_t* __restrict__ 
 // the sequential k_decode, so a barcode-valued UMI/ref word costs time, never
 // correctness.  Keys of a cell land in arbitrary order (wave-level atomic
 // reservation); order is re-established by the bucket sort.
-constexpr uint32_t kSlabsPerWave = 4;
+#ifndef AFQ_SLABS_PER_WAVE
+#define AFQ_SLABS_PER_WAVE 4
+#endif
+constexpr uint32_t kSlabsPerWave = AFQ_SLABS_PER_WAVE;   // (measurement builds: 2, 8)
 constexpr uint32_t kHalo = 64;
 constexpr uint32_t kDecodeCols = 8192;
 constexpr uint32_t kStage = kSlabWords + kHalo;  // 320 dwords = 5 per lane
@@ -755,12 +758,12 @@ __global__ __launch_bounds__(256, 6) void k_decode_keys(const uint8_t* __restric
     auto issue_slab_loads = [&](uint32_t s0) {
         if (s0 + kStage <= nwords) {
 #pragma unroll
-            for (int r = 0; r < 5; ++r) R[r] = W[s0 + r * 64 + lane];
+            for (int r = 0; r < 5; ++r) R[r] = AFQ_LD_DECODE(&W[s0 + r * 64 + lane]);
         } else {
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
                 const uint32_t i = s0 + r * 64 + lane;
-                R[r] = i < nwords ? W[i] : 0u;
+                R[r] = i < nwords ? AFQ_LD_DECODE(&W[i]) : 0u;
             }
         }
     };
@@ -1081,12 +1084,12 @@ __global__ __launch_bounds__(256, 8) void k_decode_recs(const uint8_t* __restric
     auto issue_slab_loads = [&](uint32_t s0) {
         if (s0 + kStage <= nwords) {
 #pragma unroll
-            for (int r = 0; r < 5; ++r) R[r] = W[s0 + r * 64 + lane];
+            for (int r = 0; r < 5; ++r) R[r] = AFQ_LD_DECODE(&W[s0 + r * 64 + lane]);
         } else {
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
                 const uint32_t i = s0 + r * 64 + lane;
-                R[r] = i < nwords ? W[i] : 0u;
+                R[r] = i < nwords ? AFQ_LD_DECODE(&W[i]) : 0u;
             }
         }
     };

@@ -221,6 +221,9 @@ void launch_p2_graph(hipStream_t s, const P2Args& a);
 uint32_t pug_max_blocks();
 uint64_t pug_scratch_words(uint32_t nrec, uint32_t n_ref, bool gene_level);
 
-constexpr uint32_t kScatterTileHost = 2048;  // keys per histogram/scatter tile
+#ifndef AFQ_SCATTER_TILE
+#define AFQ_SCATTER_TILE 2048
+#endif
+constexpr uint32_t kScatterTileHost = AFQ_SCATTER_TILE;  // keys per histogram/scatter tile (measurement builds: 4096)
 
 }  // namespace afq

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void k_scatter(const uint2* __restrict__ tile_
         key[e] = kKeySentinel;
         rank[e] = 0;
         if (i < t1) {
-            key[e] = src[i];
+            key[e] = AFQ_LD_SCATTER(&src[i]);
             const uint32_t b = bucket_of(key[e] >> kGeneBits, m.lg_nb);
             rank[e] = (b << 16) | atomicAdd(&s_cnt[b], 1u);
         }
@@ -605,7 +605,7 @@ __device__ __forceinline__ bool resolve_bucket_hash(const uint64_t* __restrict__
 #endif
     uint64_t key[E];
 #pragma unroll
-    for (uint32_t h = 0; h < E; ++h) key[h] = h * 64 + lane < n ? src[h * 64 + lane] : 0ull;
+    for (uint32_t h = 0; h < E; ++h) key[h] = h * 64 + lane < n ? AFQ_LD_RESOLVE(&src[h * 64 + lane]) : 0ull;
     uint32_t cap = (n + (n >> 1) + 63) & ~63u;   // multiples of 64 slots: 1.5 n rounded up
     cap = cap < 128 ? 128 : cap;
     {

@@ -453,6 +453,26 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* a, uint32_t 
 __device__ __forceinline__ bool is_spliced(uint32_t g) { return (g & 1u) == 0; }
 __device__ __forceinline__ bool same_gene(uint32_t a, uint32_t b) { return (a & ~1u) == (b & ~1u); }
 
+// Loads of data a kernel reads once (the input bytes in the decoders, keys0 in the scatter, keys1 in the resolve) can be marked
+// non-temporal by measurement builds (make variant DEFS=-DAFQ_NT_DECODE ...): the default build loads them plainly.
+template <typename T>
+__device__ __forceinline__ T ld_nt(const T* p) { return __builtin_nontemporal_load(p); }
+#ifdef AFQ_NT_DECODE
+#define AFQ_LD_DECODE(p) ld_nt(p)
+#else
+#define AFQ_LD_DECODE(p) (*(p))
+#endif
+#ifdef AFQ_NT_SCATTER
+#define AFQ_LD_SCATTER(p) ld_nt(p)
+#else
+#define AFQ_LD_SCATTER(p) (*(p))
+#endif
+#ifdef AFQ_NT_RESOLVE
+#define AFQ_LD_RESOLVE(p) ld_nt(p)
+#else
+#define AFQ_LD_RESOLVE(p) (*(p))
+#endif
+
 #define AFQ_LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
 
 }  // namespace afq
