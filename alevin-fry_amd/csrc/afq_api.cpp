@@ -155,8 +155,6 @@ struct RangeState {
     uint32_t hash_try = 0;   // which salt the range's label hashes were made with (a collision re-runs the range under the next)
     uint32_t pool_try = 0;   // how often the range was run again with four times the parsimony pool (a cell's graph outgrew it)
     uint64_t att_records = 0, att_ref_words = 0, att_buckets = 0;   // what the current attempt added to the batch statistics
-    hipStream_t tail = nullptr;   // AFQ_TAIL_OVERLAP=2 (measurements): a high-priority stream for the kernels behind a range's resolve
-    bool tail_used = false;
     bool chained = false;    // the rows' compaction was enqueued behind the range's kernels (row offsets made on the device, k_row_ptr) ...
     uint64_t chain_cap = 0;  // ... against d_gene / d_val of this many entries: finish_range compacts again, after growing them, if the range has more
     bool em_inline = false;  // the EM was enqueued behind the range's kernels (offsets made on the device); finish_range only checks that its scratch sufficed
@@ -445,7 +443,10 @@ int plan_ranges(afq_ctx* c) {
     // the last one's compaction + D2H is the only part nothing hides, so it is the smallest.
     // (parsimony: every range ends in the tail of its persistent workgroups and nothing of the next range can share a CU with
     // them, while its rows are few - three ranges; cr-like: five, tapering, so that the last D2H is small)
-    static const double kTaperCr[] = {0.28, 0.56, 0.78, 0.92, 1.0, 1.0, 1.0, 1.0}, kTaperPug[] = {0.40, 0.76, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
+    // (late round 4, cr-like: a range's rows take about half as long to cross PCIe as its kernels run - more for ranges of small
+    //  cells, whose rows are longer per read - so every range is 0.6 of the one before it: six ranges, the last 3.3 % of the work;
+    //  28/28/22/14/8 % left 0.65 ms of the last range's rows in the open.  12.96-13.26 -> 12.48-12.68 ms, profiles/run_r04ad.sh)
+    static const double kTaperCr[] = {0.419, 0.671, 0.822, 0.913, 0.967, 1.0, 1.0, 1.0}, kTaperPug[] = {0.40, 0.76, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
     const double* kTaper = pug_res ? kTaperPug : kTaperCr;
     const size_t kTaperN = 8;
     double env_taper[8];   // (a local: contexts of several devices plan on their own threads)
@@ -933,38 +934,20 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     // histograms a range without an EM ends in - measured on the headline and not kept: the decoder fills every SIMD at eight
     // waves, the histogram workgroups - 73 KiB of LDS each - get a CU only as decoder workgroups drain, the bracket of
     // k_cell_hist grows from 0.56 to 3.3 ms per step and the range's rows start across PCIe that much later: 12.97 -> 15.38 ms
-    // per step, profiles/run_r04aa.sh.)
-    // AFQ_TAIL_OVERLAP=2: the same, with the histograms and everything behind them on a stream of the highest priority the
-    // device offers (B.tail): a histogram workgroup is then first in line for whatever a finishing decoder workgroup frees.
-    const int tail_overlap = [] { const char* e = std::getenv("AFQ_TAIL_OVERLAP"); return e && (e[0] == '1' || e[0] == '2') ? e[0] - '0' : 0; }();
+    // per step, profiles/run_r04aa.sh.  The same with the histograms on a stream of the device's highest priority: 3.4 ms,
+    // 13.1 -> 15.0 ms per step, profiles/run_r04ad.sh - queue priority does not put a 73 KiB workgroup in front of the
+    // decoder's 9 KiB ones.)
+    const bool tail_overlap = [] { const char* e = std::getenv("AFQ_TAIL_OVERLAP"); return e && e[0] == '1'; }();
     if (!B.kernels_done) HIP_TRY(c, hipEventCreateWithFlags(&B.kernels_done, hipEventDisableTiming));
     const bool early_done = tail_overlap && !em && !hist_cells.empty();
-    hipStream_t st = s;   // the stream of the range's last kernels
-    B.tail_used = false;
-    if (early_done) {
-        tc.seg(K_CELL_HIST);   // (the bracket's event first: one packet train)
-        HIP_TRY(c, hipEventRecord(B.kernels_done, s));
-        if (tail_overlap == 2) {
-            if (!B.tail) {
-                int least = 0, greatest = 0;
-                HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
-                HIP_TRY(c, hipStreamCreateWithPriority(&B.tail, hipStreamNonBlocking, greatest));
-            }
-            tc.end();
-            HIP_TRY(c, hipStreamWaitEvent(B.tail, B.kernels_done, 0));
-            st = B.tail;
-            B.tail_used = true;
-        }
-    }
-    TimerChain tc2(c, st, &B.launches, par);   // (the brackets of the kernels on the tail stream, when there is one)
-    TimerChain& tt = st == s ? tc : tc2;
-    if (!hist_cells.empty()) { tt.seg(K_CELL_HIST); launch_cell_hist(st, ra); }
+    if (early_done) { tc.seg(K_CELL_HIST); HIP_TRY(c, hipEventRecord(B.kernels_done, s)); }   // (the bracket's event first: one packet train)
+    if (!hist_cells.empty()) { tc.seg(K_CELL_HIST); launch_cell_hist(s, ra); }
     if (B.em_inline) {
         tc.seg(K_EM);
         launch_em2(s, ra, n, B.d_em2_off.as<uint64_t>(), B.d_em2_scratch.as<uint32_t>(), B.d_em_nnz.as<uint32_t>(), B.d_em_order.as<uint32_t>(),
                    B.d_em2_tiers.as<uint32_t>(), na_em, g.em_init_uniform, em2_cap);
     }
-    tt.end();
+    tc.end();
     HIP_TRY(c, hipGetLastError());
     if (!early_done) HIP_TRY(c, hipEventRecord(B.kernels_done, s));
     {   // what finish_range reads first: written by the last kernel of the range STRAIGHT into pinned host memory (20 bytes per cell over
@@ -975,7 +958,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
         HIP_TRY(c, B.h_pack.reserve(words));
         void* d_view = nullptr;
         HIP_TRY(c, hipHostGetDevicePointer(&d_view, B.h_pack.p, 0));
-        launch_pack_small(st, B.d_status.as<DevStatus>(), B.em_inline ? B.d_em2_tiers.as<uint32_t>() + 7 : nullptr, B.d_alt.as<uint32_t>(), B.d_nnz.as<uint32_t>(),
+        launch_pack_small(s, B.d_status.as<DevStatus>(), B.em_inline ? B.d_em2_tiers.as<uint32_t>() + 7 : nullptr, B.d_alt.as<uint32_t>(), B.d_nnz.as<uint32_t>(),
                           B.em_inline ? B.d_em_nnz.as<uint32_t>() : nullptr, B.d_bc.as<uint64_t>(),
                           n_pug ? B.d_p2_small.as<uint32_t>() + p2_small_layout(n_p2, p2_parts, p2tiles.size(), n_pug).fb_count : nullptr, n, reinterpret_cast<uint32_t*>(d_view));
     }
@@ -989,11 +972,11 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     if (chain_compact && !em) {
         HIP_TRY(c, B.d_cell_ptr.ensure(8ull * (n + 1)));
         B.chain_cap = std::min(B.d_gene.cap, B.d_val.cap) / 4;
-        tt.seg(K_COMPACT);
-        launch_row_ptr(st, B.d_nnz.as<uint32_t>(), n, B.d_cell_ptr.as<uint64_t>());
-        launch_compact(st, B.d_meta.as<CellMeta>(), n, B.d_keys0.as<uint64_t>(), B.d_keys1.as<uint64_t>(), B.d_nnz.as<uint32_t>(),
+        tc.seg(K_COMPACT);
+        launch_row_ptr(s, B.d_nnz.as<uint32_t>(), n, B.d_cell_ptr.as<uint64_t>());
+        launch_compact(s, B.d_meta.as<CellMeta>(), n, B.d_keys0.as<uint64_t>(), B.d_keys1.as<uint64_t>(), B.d_nnz.as<uint32_t>(),
                        B.d_cell_ptr.as<uint64_t>(), B.d_gene.as<uint32_t>(), B.d_val.as<float>(), B.chain_cap);
-        tt.end();
+        tc.end();
         HIP_TRY(c, hipGetLastError());
         B.chained = true;
     }
@@ -1018,7 +1001,6 @@ int finish_range(afq_ctx* c, int slot) {
     const uint32_t n = B.cur.c1 - B.cur.c0;
     hipStream_t s = B.stream;
     HIP_TRY(c, hipStreamSynchronize(s));
-    if (B.tail_used) HIP_TRY(c, hipStreamSynchronize(B.tail));   // (AFQ_TAIL_OVERLAP=2: the range's last kernels ran there)
     hc.lap("finish: wait for kernels");
     DevStatus st{};
     std::memcpy(&st, B.h_pack.p, sizeof(st));   // (k_pack_small wrote it there, behind the range's kernels)
@@ -1448,7 +1430,6 @@ void afq_destroy(afq_ctx* c) {
         if (rs.stream) (void)hipStreamSynchronize(rs.stream);
         for (DevBuf* b : rs.all()) b->release();
         if (rs.kernels_done) (void)hipEventDestroy(rs.kernels_done);
-        if (rs.tail) { (void)hipStreamSynchronize(rs.tail); (void)hipStreamDestroy(rs.tail); }
         if (rs.stream) (void)hipStreamDestroy(rs.stream);
     }
     DevBuf* bufs[] = {&c->d_t2g, &c->d_bytes_own, &c->d_chunk_off, &c->d_hdr, &c->d_wide};

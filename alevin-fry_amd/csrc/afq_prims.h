@@ -453,8 +453,11 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* a, uint32_t 
 __device__ __forceinline__ bool is_spliced(uint32_t g) { return (g & 1u) == 0; }
 __device__ __forceinline__ bool same_gene(uint32_t a, uint32_t b) { return (a & ~1u) == (b & ~1u); }
 
-// Loads of data a kernel reads once (the input bytes in the decoders, keys0 in the scatter, keys1 in the resolve) can be marked
-// non-temporal by measurement builds (make variant DEFS=-DAFQ_NT_DECODE ...): the default build loads them plainly.
+// Loads of data a kernel reads once.  Measured on the headline (profiles/run_r04ac.sh, three rounds, per step): the bucket's keys
+// in k_resolve non-temporal: 4.42 -> 4.35 ms, and k_cell_hist behind it 0.554 -> 0.529 (what the resolve leaves in L2 is the
+// column lists the histograms read) - kept; the input bytes in k_decode_recs: 4.47 -> 4.60 (the next slab's halo is this slab's
+// tail); keys0 in k_scatter: 2.61 -> 2.57 but k_resolve 4.42 -> 4.46 - neither kept (make variant DEFS=-DAFQ_NT_DECODE / _SCATTER;
+// -DAFQ_PLAIN_RESOLVE_LOADS for the resolve's old loads).
 template <typename T>
 __device__ __forceinline__ T ld_nt(const T* p) { return __builtin_nontemporal_load(p); }
 #ifdef AFQ_NT_DECODE
@@ -467,10 +470,10 @@ __device__ __forceinline__ T ld_nt(const T* p) { return __builtin_nontemporal_lo
 #else
 #define AFQ_LD_SCATTER(p) (*(p))
 #endif
-#ifdef AFQ_NT_RESOLVE
-#define AFQ_LD_RESOLVE(p) ld_nt(p)
-#else
+#ifdef AFQ_PLAIN_RESOLVE_LOADS
 #define AFQ_LD_RESOLVE(p) (*(p))
+#else
+#define AFQ_LD_RESOLVE(p) ld_nt(p)
 #endif
 
 #define AFQ_LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
