@@ -395,7 +395,10 @@ __global__ __launch_bounds__(256) void k_slab_setup(const uint8_t* __restrict__ 
 #endif
 constexpr uint32_t kSlabsPerWave = AFQ_SLABS_PER_WAVE;   // (measured on the headline, k_decode_recs per step: 2: 4.64-4.70 ms, 4: 4.46-4.47, 8: 4.41-4.42, 16: 4.30-4.31 on another box where 8 gave 4.28-4.32; profiles/run_r04ac.sh, run_r04ad.sh)
 constexpr uint32_t kHalo = 64;
-constexpr uint32_t kDecodeCols = 8192;
+#ifndef AFQ_DECODE_COLS
+#define AFQ_DECODE_COLS 8192
+#endif
+constexpr uint32_t kDecodeCols = AFQ_DECODE_COLS;
 constexpr uint32_t kStage = kSlabWords + kHalo;  // 320 dwords = 5 per lane
 
 template <int BW, int UW, bool PUG>

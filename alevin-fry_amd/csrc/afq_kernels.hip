@@ -25,6 +25,10 @@ namespace afq {
 // they were issued per record), so counts are first combined in LDS over a tile
 // of kTileKeys keys and flushed with one atomic per non-empty bucket per tile.
 constexpr uint32_t kTileKeys = kScatterTileHost;  // 2048
+#ifndef AFQ_SCATTER_RUN
+#define AFQ_SCATTER_RUN 16
+#endif
+constexpr uint32_t kScatterRun = AFQ_SCATTER_RUN;   // consecutive tiles one XCD takes (k_scatter)
 constexpr uint32_t kLdsBins = 2048;               // buckets per cell the LDS paths can hold
 
 // tile -> (cell, tile index inside the cell): a table the planner uploads with the batch.  (It used to be a binary
@@ -99,7 +103,8 @@ __global__ __launch_bounds__(256) void k_scatter(const uint2* __restrict__ tile_
     // Workgroups are dealt to the eight XCDs round-robin, each XCD with an L2 of its own; the tiles go to them in runs of sixteen
     // (a median cell), so that the runs a cell's consecutive tiles add to one bucket meet in one L2 instead of reaching memory
     // as partial lines from two.  (The grid is a multiple of 128.)
-    const uint32_t xr = blockIdx.x / 8, tile = ((xr / 16) * 8 + blockIdx.x % 8) * 16 + xr % 16;
+    constexpr uint32_t kRun = kScatterRun;   // (the grid is a multiple of 8 * kRun: launch_scatter)
+    const uint32_t xr = blockIdx.x / 8, tile = ((xr / kRun) * 8 + blockIdx.x % 8) * kRun + xr % kRun;
     if (tile >= n_tiles) return;
     const uint2 td = tile_desc[tile];
     const uint32_t cell = td.x, lt = td.y;
@@ -1282,9 +1287,9 @@ void launch_bucket_scan(hipStream_t s, const ResolveArgs& a) {
 void launch_scatter(hipStream_t s, const ResolveArgs& a) {
     if (!a.n_tiles) return;
     if ((1u << a.max_lg_nb) <= 512u)
-        AFQ_LAUNCH(k_scatter<512>, (a.n_tiles + 127) / 128 * 128, 256, s, a.tile_desc, a.meta, a.cell_nkeys, a.keys0, a.keys1, a.cursor, a.slab_ovf, a.n_tiles);
+        AFQ_LAUNCH(k_scatter<512>, (a.n_tiles + 8 * kScatterRun - 1) / (8 * kScatterRun) * (8 * kScatterRun), 256, s, a.tile_desc, a.meta, a.cell_nkeys, a.keys0, a.keys1, a.cursor, a.slab_ovf, a.n_tiles);
     else
-        AFQ_LAUNCH(k_scatter<kLdsBins>, (a.n_tiles + 127) / 128 * 128, 256, s, a.tile_desc, a.meta, a.cell_nkeys, a.keys0, a.keys1, a.cursor, a.slab_ovf, a.n_tiles);
+        AFQ_LAUNCH(k_scatter<kLdsBins>, (a.n_tiles + 8 * kScatterRun - 1) / (8 * kScatterRun) * (8 * kScatterRun), 256, s, a.tile_desc, a.meta, a.cell_nkeys, a.keys0, a.keys1, a.cursor, a.slab_ovf, a.n_tiles);
 }
 
 void launch_fix_slabs(hipStream_t s, const ResolveArgs& a) {

@@ -171,8 +171,12 @@ def timed_steps(D, q, rad, steps, warmup, first_cell=0):
     D.sync()
     t0 = time.perf_counter()
     ktimes = {}
+    trace = os.environ.get("AFQ_BENCH_STEP_TIMES")   # (measurement scripts: every step's own wall time on stderr)
     for _ in range(steps):
+        ts = time.perf_counter()
         step()
+        if trace:
+            print(f"[bench] step {1e3 * (time.perf_counter() - ts):.3f} ms", file=sys.stderr)
         for k, (ms, n) in q.kernel_times().items():   # HIP events on the library's own streams
             a = ktimes.setdefault(k, [0.0, 0])
             a[0] += ms
