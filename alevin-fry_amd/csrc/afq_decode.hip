@@ -10,6 +10,8 @@
 //   k_decode_recs     walk-free decode, one lane per record with inline alignments (short records)
 //   k_verify_cells    last step of the walk-free proof
 #include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -694,7 +696,15 @@ extern "C" void afq_debug_dump_decode() {
 // same proof terms as k_decode_par (count, sizes, successor check).
 // A record that starts before the wave's first slab is found by a cooperative backward scan (64 dwords per
 // step); inside the wave it is carried from slab to slab.
-template <int BW, int UW, bool TRIVIAL>
+// HD (round 4, late): which alignment word is the first of its record to name its gene is decided through an LDS hash table
+// keyed by (record of the slab, gene) - every alignment word inserts itself with its position, the smallest position under a key
+// stays - instead of by comparing with the three dwords before it and, for records of more than four alignments, by a serial
+// scan back to the record's first alignment (a loop per lane, as long as the slab's longest record: on reads of E[na] = 3 with a
+// geometric tail the kernel spent as many instructions on its scalar unit as on its vector units, both at 72 % of their issue
+// slots).  The table's cost does not depend on the records' lengths.  The words a record that started before the slab has in
+// front of it are looked up in the table (not inserted: any number of them), and a hit means "named before this slab".
+constexpr uint32_t kHdLg = 9, kHdSlots = 1u << kHdLg;   // 256 alignment words per slab at most: the table is at most half full
+template <int BW, int UW, bool TRIVIAL, bool HD = false>
 __global__ __launch_bounds__(256, 6) void k_decode_keys(const uint8_t* __restrict__ bytes,
                                                     const CellMeta* __restrict__ meta, uint32_t n_cells,
                                                     const uint32_t* __restrict__ slab_prefix,
@@ -708,13 +718,18 @@ __global__ __launch_bounds__(256, 6) void k_decode_keys(const uint8_t* __restric
     constexpr uint32_t BWW = BW / 4, UWW = UW / 4, HW = 1 + BWW + UWW;
     constexpr uint32_t kNone = 0xFFFFFFFFu;
     __shared__ uint32_t s_stage[4][kStage];
-    __shared__ uint32_t s_gene[4][4 + kSlabWords];   // [4 pad] + gene of every alignment word of the slab (kNone elsewhere)
-    __shared__ uint32_t s_first[4][kSlabWords];  // dword index of the first alignment word of the dword's record
+    static_assert(!(TRIVIAL && HD), "the trivial rule keeps the scan");
+    __shared__ uint32_t s_gene[4][HD ? 1 : 4 + kSlabWords];   // [4 pad] + gene of every alignment word of the slab (kNone elsewhere)
+    __shared__ uint32_t s_first[4][HD ? 1 : kSlabWords];  // dword index of the first alignment word of the dword's record
+    __shared__ uint32_t s_tkey[4][HD ? kHdSlots : 1];     // HD: record-of-the-slab << 20 | gene (kNone: free) ...
+    __shared__ uint32_t s_tpos[4][HD ? kHdSlots : 1];     // ... and the smallest position (dword of the slab + 1; 0: an earlier slab) that named it
     const uint32_t lane = lane_id();
     const uint32_t wv = threadIdx.x >> 6;
     uint32_t* stage = s_stage[wv];
     uint32_t* gene_l = s_gene[wv];
     uint32_t* first_l = s_first[wv];
+    [[maybe_unused]] uint32_t* tkey = s_tkey[wv];
+    [[maybe_unused]] uint32_t* tpos = s_tpos[wv];
     const uint32_t n_groups = (n_slabs + kSlabsPerWave - 1) / kSlabsPerWave;
     const uint32_t n_cols = min(n_groups, kDecodeCols);
     const uint32_t n_rows = (n_groups + n_cols - 1) / n_cols;
@@ -819,7 +834,10 @@ __global__ __launch_bounds__(256, 6) void k_decode_keys(const uint8_t* __restric
         for (int r = 0; r < 5; ++r) stage[r * 64 + lane] = R[r];
 #pragma unroll
         for (int r = 0; r < 4; ++r) own[r] = R[r];
-        if (lane < 4) gene_l[lane] = kNone;  // pad in front of the slab's genes (the duplicate test looks back 3)
+        if constexpr (HD) {
+#pragma unroll
+            for (uint32_t k = 0; k < kHdSlots / 64; ++k) { tkey[k * 64 + lane] = kNone; tpos[k * 64 + lane] = kNone; }
+        } else if (lane < 4) gene_l[lane] = kNone;  // pad in front of the slab's genes (the duplicate test looks back 3)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -849,6 +867,7 @@ __global__ __launch_bounds__(256, 6) void k_decode_keys(const uint8_t* __restric
         // which record is each dword in; alignment words gather their gene
         uint32_t gid[4], ulo[4], uhi[4];
         uint32_t pos[4];               // index of the dword among its record's alignment words, kNone if it is not one
+        [[maybe_unused]] uint32_t rid[4];   // HD: the dword's record - its header's place in the slab + 1, 0 for the record the slab starts in
         uint32_t last_before = kNone;  // il of the last candidate in the windows before r (wave-uniform)
         const uint32_t cin_na_eff = cin_s != kNone ? cin_na : 0u;
         bool slow = false;
@@ -872,9 +891,12 @@ __global__ __launch_bounds__(256, 6) void k_decode_keys(const uint8_t* __restric
             // straight-line gather (lanes that are not alignment words read entry 0): the four windows' loads stay in flight together
             gid[r] = t2g[isref ? t : 0u];
             pos[r] = isref ? p : kNone;
-            first_l[il] = fr;
-            // more alignments back than the fast duplicate test covers, or some of them in an earlier slab
-            slow = slow || (isref && p > 0 && (p > 3 || fr < s0)) || (triv && isref && p == 0 && na > 1);
+            if constexpr (HD) rid[r] = in_stage ? sc + 1u : 0u;
+            else {
+                first_l[il] = fr;
+                // more alignments back than the fast duplicate test covers, or some of them in an earlier slab
+                slow = slow || (isref && p > 0 && (p > 3 || fr < s0)) || (triv && isref && p == 0 && na > 1);
+            }
             if (mk[r]) last_before = (uint32_t)(r * 64 + 63) - (uint32_t)__builtin_clzll(mk[r]);
         }
         // (2) proof terms of the records that start here
@@ -919,61 +941,113 @@ __global__ __launch_bounds__(256, 6) void k_decode_keys(const uint8_t* __restric
             ncin_s = s0 + last_before; ncin_na = stage[last_before]; ncin_ulo = stage[last_before + 1 + BWW];
             ncin_uhi = UWW == 2 ? stage[last_before + 2 + BWW] : 0u;
         }
+        uint64_t bal[4];
+        uint32_t tot = 0;
+        if constexpr (HD) {
+            uint32_t hslot[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const bool isref = pos[r] != kNone;
-            if (isref && gid[r] >= num_genes) fail = true;
-            gid[r] = (isref && gid[r] < num_genes) ? gid[r] : kNone;
-            gene_l[4 + r * 64 + lane] = gid[r];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        DT_MARK(3);
-        if (__any(slow)) {
-            // one copy of the general rule; a dword that loses clears its gene (a duplicate's own first
-            // occurrence stays, so clearing never hides a gene from a later dword of the record)
-#pragma unroll 1
-            for (uint32_t r = 0; r < 4; ++r) {
-                const uint32_t il = r * 64 + lane, i = s0 + il;
-                const uint32_t g = gene_l[4 + il], fr = first_l[il];
-                if (g == kNone || i < fr) continue;
-                const uint32_t p = i - fr;
-                bool lose = false;
-                if (triv) {  // only reads whose alignments name one gene count (pugutils.rs:870-891)
-                    if (p > 0) continue;  // handled by the fast rule below (never emits)
-                    const uint32_t S = fr - HW;
-                    const uint32_t na = S >= s0 ? stage[S - s0] : W[S];
-                    for (uint32_t q = fr + 1; q < fr + na && q < nwords && !lose; ++q) lose = gene_at(q, s0) != g;
-                    if (lose) gene_l[4 + il] = kNone - 1;  // "not a single-gene read", still a gene for nobody else
-                } else {
-                    if (!(p > 3 || (p > 0 && fr < s0))) continue;
-                    for (uint32_t q = fr; q < i && !lose; ++q) lose = gene_at(q, s0) == g;
-                    if (lose) gene_l[4 + il] = kNone;
+            for (int r = 0; r < 4; ++r) {
+                const bool isref = pos[r] != kNone;
+                if (isref && gid[r] >= num_genes) fail = true;
+                gid[r] = (isref && gid[r] < num_genes) ? gid[r] : kNone;
+                hslot[r] = 0;
+                if (gid[r] != kNone) {   // (record, gene) -> the smallest position that names it
+                    const uint32_t key = (rid[r] << 20) | gid[r];
+                    uint32_t slot = (key * 0x9E3779B1u) >> (32 - kHdLg);
+                    for (;;) {
+                        const uint32_t old = atomicCAS(&tkey[slot], kNone, key);
+                        if (old == kNone || old == key) break;
+                        slot = (slot + 1) & (kHdSlots - 1);
+                    }
+                    atomicMin(&tpos[slot], (uint32_t)(r * 64) + lane + 1u);
+                    hslot[r] = slot;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-        // first occurrence of the gene inside its record
-        uint64_t bal[4];
-        uint32_t tot = 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const uint32_t il = r * 64 + lane;
-            const uint32_t g0 = gene_l[4 + il], g1 = gene_l[3 + il], g2 = gene_l[2 + il], g3 = gene_l[1 + il];
-            const uint32_t p = pos[r];
-            bool e = gid[r] != kNone;
-            if (triv) e = e && p == 0 && g0 == gid[r];
-            else {
-                const bool deep = p > 3 || p > il;  // the slow loop decided (p > il: the record started before the slab)
-                const bool dup = (p >= 1 && g1 == gid[r]) || (p >= 2 && g2 == gid[r]) || (p >= 3 && g3 == gid[r]);
-                e = e && !(deep ? g0 == kNone : dup);
+            DT_MARK(3);
+            if (cin_s != kNone && cin_s + HW < s0) {   // the record the slab starts in: what its alignments in front of the slab named counts as named
+                const uint32_t cfr = cin_s + HW;
+                const uint32_t cend = min(s0, cfr + min(cin_na, nwords));
+                for (uint32_t q0 = cfr; q0 < cend; q0 += 64) {
+                    const uint32_t q = q0 + lane;
+                    const uint32_t t = q < cend ? W[q] & 0x7FFFFFFFu : kNone;
+                    const uint32_t g = t < ref_count ? t2g[t] : kNone;
+                    if (g < num_genes) {
+                        for (uint32_t slot = (g * 0x9E3779B1u) >> (32 - kHdLg);; slot = (slot + 1) & (kHdSlots - 1)) {   // (key = record 0 << 20 | g)
+                            const uint32_t k = tkey[slot];
+                            if (k == g) tpos[slot] = 0u;
+                            if (k == g || k == kNone) break;
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-            bal[r] = __ballot(e);
-            gid[r] = e ? gid[r] : kNone;
-            tot += (uint32_t)__popcll(bal[r]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool e = gid[r] != kNone && tpos[hslot[r]] == (uint32_t)(r * 64) + lane + 1u;
+                bal[r] = __ballot(e);
+                gid[r] = e ? gid[r] : kNone;
+                tot += (uint32_t)__popcll(bal[r]);
+            }
+        } else {
+    #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool isref = pos[r] != kNone;
+                if (isref && gid[r] >= num_genes) fail = true;
+                gid[r] = (isref && gid[r] < num_genes) ? gid[r] : kNone;
+                gene_l[4 + r * 64 + lane] = gid[r];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            DT_MARK(3);
+            if (__any(slow)) {
+                // one copy of the general rule; a dword that loses clears its gene (a duplicate's own first
+                // occurrence stays, so clearing never hides a gene from a later dword of the record)
+    #pragma unroll 1
+                for (uint32_t r = 0; r < 4; ++r) {
+                    const uint32_t il = r * 64 + lane, i = s0 + il;
+                    const uint32_t g = gene_l[4 + il], fr = first_l[il];
+                    if (g == kNone || i < fr) continue;
+                    const uint32_t p = i - fr;
+                    bool lose = false;
+                    if (triv) {  // only reads whose alignments name one gene count (pugutils.rs:870-891)
+                        if (p > 0) continue;  // handled by the fast rule below (never emits)
+                        const uint32_t S = fr - HW;
+                        const uint32_t na = S >= s0 ? stage[S - s0] : W[S];
+                        for (uint32_t q = fr + 1; q < fr + na && q < nwords && !lose; ++q) lose = gene_at(q, s0) != g;
+                        if (lose) gene_l[4 + il] = kNone - 1;  // "not a single-gene read", still a gene for nobody else
+                    } else {
+                        if (!(p > 3 || (p > 0 && fr < s0))) continue;
+                        for (uint32_t q = fr; q < i && !lose; ++q) lose = gene_at(q, s0) == g;
+                        if (lose) gene_l[4 + il] = kNone;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            // first occurrence of the gene inside its record
+    #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t il = r * 64 + lane;
+                const uint32_t g0 = gene_l[4 + il], g1 = gene_l[3 + il], g2 = gene_l[2 + il], g3 = gene_l[1 + il];
+                const uint32_t p = pos[r];
+                bool e = gid[r] != kNone;
+                if (triv) e = e && p == 0 && g0 == gid[r];
+                else {
+                    const bool deep = p > 3 || p > il;  // the slow loop decided (p > il: the record started before the slab)
+                    const bool dup = (p >= 1 && g1 == gid[r]) || (p >= 2 && g2 == gid[r]) || (p >= 3 && g3 == gid[r]);
+                    e = e && !(deep ? g0 == kNone : dup);
+                }
+                bal[r] = __ballot(e);
+                gid[r] = e ? gid[r] : kNone;
+                tot += (uint32_t)__popcll(bal[r]);
+            }
         }
         DT_MARK(4);
         if (tot) {
@@ -1416,6 +1490,9 @@ int launch_decode(hipStream_t s, const DecodeArgs& a, uint32_t bw, uint32_t uw) 
     return -1;
 }
 
+// AFQ_DECODE_DEDUP=hash: k_decode_keys finds a record's first mention of a gene through an LDS hash table (HD) instead of the
+// look-back compares and the serial scan; read per launch (tests run both).
+static bool decode_keys_hash_dedup() { const char* e = getenv("AFQ_DECODE_DEDUP"); return e && !strcmp(e, "hash"); }
 template <int BW, int UW>
 static void launch_decode_par_t(hipStream_t s, const DecodeArgs& a) {
     AFQ_LAUNCH((k_slab_setup<BW, UW>), (a.n_cells + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix,
@@ -1441,6 +1518,10 @@ static void launch_decode_par_t(hipStream_t s, const DecodeArgs& a) {
                    const_cast<CellChk*>(a.chk), a.pug);
     else if (a.trivial)
         AFQ_LAUNCH((k_decode_keys<BW, UW, true>), (n_waves + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix, a.slab_cell,
+                   a.cell_bc, a.n_slabs, a.t2g, a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out,
+                   const_cast<CellChk*>(a.chk));
+    else if (decode_keys_hash_dedup())
+        AFQ_LAUNCH((k_decode_keys<BW, UW, false, true>), (n_waves + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix, a.slab_cell,
                    a.cell_bc, a.n_slabs, a.t2g, a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out,
                    const_cast<CellChk*>(a.chk));
     else

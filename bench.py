@@ -48,8 +48,8 @@ METRIC = "M reads/s through quant (PUG dedup+eq-class) at 1/2/4/8 GPUs; cells/s"
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)   # (one of a process's first three steps can take 7 ms longer than the others - seen in half the runs, whatever the library's switches: profiles/run_r04af.sh)
     ap.add_argument("--workload", default="configs1", choices=["configs1", "configs2", "configs3", "atac"],
                     help="what the headline line measures (default configs1 = the configuration the metric is quoted on)")
     ap.add_argument("--cells", type=int, default=11000, help="cells per GPU of the PBMC-10k-like sample (configs1/2)")

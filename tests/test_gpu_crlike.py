@@ -525,14 +525,44 @@ def test_tie_shapes_and_wide_umis(oracle, usa, pad_reads):
     assert got.val.sum() > 0
 
 
-@pytest.mark.parametrize("decoder", ["recs", "keys"])
+def set_decoder(monkeypatch, decoder):
+    """recs: one lane per record; keys: one lane per dword, a record's repeated genes found by look-back compares and a scan;
+    keys-hash: one lane per dword, repeated genes found through an LDS hash table (AFQ_DECODE_DEDUP=hash)."""
+    monkeypatch.setenv("AFQ_DECODE", "keys" if decoder == "keys-hash" else decoder)
+    if decoder == "keys-hash":
+        monkeypatch.setenv("AFQ_DECODE_DEDUP", "hash")
+    else:
+        monkeypatch.delenv("AFQ_DECODE_DEDUP", raising=False)
+
+
+@pytest.mark.parametrize("decoder", ["keys", "keys-hash"])
+@pytest.mark.parametrize("usa", [False, True])
+def test_many_gene_reads_both_dedups(oracle, monkeypatch, decoder, usa):
+    """Reads of many alignments that repeat genes (the bench's label-length tail: geometric extra refs on gene families, up to
+    64 per read): which alignment of a read is the first to name its gene decides the read's keys.  Cells from a handful of
+    reads to many buckets; the lane-per-dword decoder with both ways of finding the repeats, against the oracle."""
+    import importlib
+
+    sn = importlib.import_module("alevin-fry_amd.synth_native")
+    set_decoder(monkeypatch, decoder)
+    d = sn.generate(seed=13 + usa, n_cells=90, median_reads=2500.0, sigma=1.4, num_genes=300, txp_per_gene=4, usa=usa, umi_err=0.02,
+                    tail=0.75, tail_max=64, family=8)
+    for resolution in ("cr-like", "cr-like-em"):
+        cfg = pkg.WorkerConfig.for_resolution(resolution, usa_mode=usa, num_genes=d.num_genes, num_rows=d.num_rows, umi_len=12)
+        got, want, st = run_both(oracle, cfg, d.tid_to_gid, d.data, d.chunk_off)
+        assert_same_result(got, want, what=f"{resolution} usa={usa} {decoder}")
+        assert st["n_fallback_cells"] == 0
+
+
+@pytest.mark.parametrize("decoder", ["recs", "keys", "keys-hash"])
 @pytest.mark.parametrize("resolution", ["cr-like", "trivial"])
 def test_long_and_straddling_records(oracle, monkeypatch, decoder, resolution):
     """Records of every awkward length for the walk-free decoders: 0 alignments, just around the inline limits
     (3, 4), around the 64-dword halo, around a whole 256-dword slab, and thousands of alignments (a record that
     spans many slabs, so later slabs start in the middle of it).  Alignments repeat genes on purpose.  Both
-    decoders (one lane per record / one lane per dword) must agree with the oracle bit for bit."""
-    monkeypatch.setenv("AFQ_DECODE", decoder)
+    decoders (one lane per record / one lane per dword, the latter with both ways of finding a record's repeated genes) must
+    agree with the oracle bit for bit."""
+    set_decoder(monkeypatch, decoder)
     rng = np.random.default_rng(5)
     n_txp, n_genes = 6000, 700
     t2g = (rng.permutation(n_txp) % n_genes).astype(np.uint32)
