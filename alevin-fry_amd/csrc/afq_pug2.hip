@@ -594,6 +594,65 @@ __global__ __launch_bounds__(256) void k_p2_search_over(P2Args A) {
 //    vertex of slot i puts its column - or the "no column" filler, which the per-cell histogram passes over - at entry i)
 //    and its two-gene classes for the EM into its slots of a staging array: no reservation, no atomic (every wave of a
 //    cell adding to the cell's counters was the same-address queue this kernel spent its time in).
+// The column of ONE lone vertex whose label has 5..64 refs, by its whole wave: lane j looks up the gene of ref j, the wave sorts
+// the genes in its registers, the distinct ones are the heads of their runs - genes_of and molecule_column_n (afq_pug_common.h:
+// quant.rs:974-1024 -> utils.rs:688-753 / em.rs:499-514) without the 64-entry array a single lane keeps in scratch memory
+// (every load and store there a trip to global memory, an insertion sort of them per molecule: on labels of E[na] = 3 with a
+// geometric tail that loop was four fifths of this kernel, 28.7 against 5.9 ms per step).  Returns the column (wave-uniform) or
+// 0xFFFFFFFF when the molecule has none - dropped, or kept as a gene-level class for the EM, which is written here.
+__device__ __forceinline__ uint32_t wave_label_column(const PugCtx& c, uint32_t rec_dw, uint32_t n, uint32_t lane) {
+    const uint32_t* lp = c.W + rec_dw + c.HW;
+    uint32_t g[1];
+    g[0] = lane < n ? c.t2g[lp[lane] & 0x7FFFFFFFu] : 0xFFFFFFFFu;
+    wave_bitonic_sort<1, uint32_t>(g);   // ascending, the padding behind the genes
+    const uint32_t gs = g[0];
+    const uint32_t prev = __shfl_up(gs, 1);
+    const bool head = gs != 0xFFFFFFFFu && (lane == 0 || gs != prev);
+    const uint64_t hm = __ballot(head);
+    const uint32_t ng = (uint32_t)__popcll(hm);
+    if (ng == 0) return 0xFFFFFFFFu;
+    const uint32_t b0 = (uint32_t)__builtin_ctzll(hm);
+    const uint64_t hm1 = hm & (hm - 1);
+    const uint32_t g0 = (uint32_t)__shfl((int)gs, (int)b0);
+    const uint32_t g1 = hm1 ? (uint32_t)__shfl((int)gs, (int)__builtin_ctzll(hm1)) : 0xFFFFFFFFu;
+    auto sua = [&](uint32_t x) { return (x & 1u) == 0 ? (x >> 1) : c.uo + (x >> 1); };
+    uint32_t col = 0xFFFFFFFFu;
+    if (c.em) {
+        if (ng == 1) col = !c.usa ? g0 : sua(g0);
+        else if (c.usa && ng == 2 && ((g0 ^ g1) & ~1u) == 0) col = c.ao + (g0 >> 1);
+        else {   // a gene-level class: its genes ascending, one word per distinct gene
+            uint32_t off = 0, di = 0;
+            if (lane == 0) { off = atomicAdd(&c.s_cnt[1], ng); di = atomicAdd(&c.s_cnt[2], 1u); }
+            off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off); di = (uint32_t)__builtin_amdgcn_readfirstlane((int)di);
+            if (off + ng > c.lab_cap || 2 * (di + 1) > c.lab_cap) { if (lane == 0) c.s_cnt[3] = kErrPugLimit; return 0xFFFFFFFFu; }
+            if (head) c.labw[off + (uint32_t)__popcll(hm & ((1ull << lane) - 1))] = gs;
+            if (lane == 0) { c.labd[2 * di] = off; c.labd[2 * di + 1] = ng; }
+            return 0xFFFFFFFFu;
+        }
+    } else if (!c.usa) {
+        if (ng == 1) col = g0;
+    } else if (ng == 1) {
+        col = sua(g0);
+    } else if (ng == 2) {
+        const bool s1 = (g0 & 1u) == 0, s2 = (g1 & 1u) == 0;
+        if (((g0 ^ g1) & ~1u) == 0) col = c.ao + (g0 >> 1);
+        else if (s1 && !s2) col = g0 >> 1;
+        else if (!s1 && s2) col = g1 >> 1;
+    } else if (ng <= 10) {   // exactly one spliced gene among them: it, or - with its unspliced sibling right behind it - ambiguous
+        const uint64_t sm = __ballot(head && (gs & 1u) == 0);
+        if (__popcll(sm) == 1) {
+            const uint32_t ls = (uint32_t)__builtin_ctzll(sm);
+            const uint32_t sg = (uint32_t)__shfl((int)gs, (int)ls);
+            const uint64_t nm = ls == 63 ? 0ull : hm & ~((2ull << ls) - 1);
+            const uint32_t gn = nm ? (uint32_t)__shfl((int)gs, (int)__builtin_ctzll(nm)) : 0xFFFFFFFFu;
+            col = (nm && ((sg ^ gn) & ~1u) == 0) ? c.ao + (sg >> 1) : (sg >> 1);
+        }
+    }
+    if (col == 0xFFFFFFFFu) return col;
+    if (col >= c.num_rows) { if (lane == 0) c.s_cnt[3] = kErrSlotRange; return 0xFFFFFFFFu; }
+    return col;
+}
+
 __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t* s_cls, uint32_t lane) {
     const uint32_t n = A.pcnt[gp], nv = A.pnv[gp], j = A.pcell[gp], lo_p = A.poff[gp];
     if (n == 0) return;
@@ -646,12 +705,19 @@ __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t
                 const uint32_t ng = genes_of4(Cg, g4[r], ln[r]);
                 col = molecule4_column(C, g4[r], ng, cls);
                 k0 = g4[r][0]; k1 = g4[r][1];
-            } else if (ln[r] > 4) {
+            } else if (ln[r] > (A.lone_coop ? 64u : 4u)) {
                 const Lab l = rec_label(C, of[r]);
                 uint32_t g[kMaxGenesPerLabel];
                 const uint32_t ng = genes_of(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; }, g);
                 if (ng == 0xFFFFFFFFu && C.em) emit_wide_class(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; });
                 else col = molecule_column_n(C, g, ng);
+            }
+            if (A.lone_coop) {   // labels of 5..64 refs: the wave takes them one after the other (wave_label_column)
+                for (uint64_t lm = __ballot(ln[r] > 4 && ln[r] <= 64); lm; lm &= lm - 1) {
+                    const uint32_t b = (uint32_t)__builtin_ctzll(lm);
+                    const uint32_t cb = wave_label_column(C, (uint32_t)__shfl((int)of[r], (int)b), (uint32_t)__shfl((int)ln[r], (int)b), lane);
+                    if (lane == b) col = cb;
+                }
             }
             if (i < n) C.cols[lo_p + i] = col;
             const uint64_t mk = __ballot(cls);

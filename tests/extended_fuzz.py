@@ -17,7 +17,47 @@ import oracle as ora  # noqa: E402
 synth = pkg.synth
 
 
+def one_tailed(seed):
+    """Third family (seeds from 2000): the bench's label-tail model out of the native generator - reads of up to 64 alignments on
+    gene families - through a decoder picked per seed (the planner's choice, lane per record, lane per dword with either way of
+    finding a record's repeated genes) and every resolution."""
+    import importlib
+
+    sn = importlib.import_module("alevin-fry_amd.synth_native")
+    rng = np.random.default_rng(99000 + seed)
+    res = ["cr-like", "cr-like-em", "trivial", "parsimony", "parsimony-em", "cr-like", "cr-like-em"][seed % 7]
+    usa = bool(rng.integers(0, 2))
+    dec = [None, "recs", "keys", "keys", "keys"][int(rng.integers(0, 5))]
+    dedup = ["hash", "scan"][int(rng.integers(0, 2))]
+    coop = str(int(rng.integers(0, 2)))   # k_p2_lone: labels of 5..64 refs by the wave or by their lane
+    for k, v in (("AFQ_DECODE", dec), ("AFQ_DECODE_DEDUP", dedup), ("AFQ_P2_LONE_COOP", coop)):
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    d = sn.generate(seed=seed, n_cells=int(rng.choice([8, 40, 150])), median_reads=float(rng.choice([300.0, 2500.0, 9000.0])), sigma=float(rng.choice([0.5, 1.3])),
+                    num_genes=int(rng.choice([40, 400, 3000])), txp_per_gene=int(rng.integers(1, 6)), usa=usa, umi_err=float(rng.choice([0.0, 0.02])),
+                    tail=float(rng.choice([0.5, 0.65, 0.8, 0.9])), tail_max=int(rng.choice([8, 64])), family=int(rng.choice([4, 8, 16])))
+    kw = dict(small_thresh=int(rng.choice([0, 100])))
+    if usa and rng.integers(0, 2):
+        kw["sa_model"] = "prefer-ambig"
+    cfg = pkg.WorkerConfig.for_resolution(res, usa_mode=usa, num_genes=d.num_genes, num_rows=d.num_rows, umi_len=12, **kw)
+    q = pkg.Quantifier(cfg, d.tid_to_gid)
+    try:
+        got = q.quant_chunks(d.data, d.chunk_off)
+        rehash = q.label_rehash_count()
+    finally:
+        q.close()
+        for k in ("AFQ_DECODE", "AFQ_DECODE_DEDUP", "AFQ_P2_LONE_COOP"):
+            os.environ.pop(k, None)
+    want = ora.quant(cfg, d.tid_to_gid, d.data, d.chunk_off, n_threads=os.cpu_count() or 1, em_arith="reference" if os.environ.get("AFQ_EM_ORDER") == "canonical" else "fixed")
+    assert_same_result(got, want, what=f"seed {seed} {res} usa={usa} decoder={dec} dedup={dedup} lone_coop={coop} {kw} cells={len(d.chunk_off)}")
+    return int(d.n_reads), rehash
+
+
 def one(seed):
+    if seed >= 2000:
+        return one_tailed(seed)
     rng = np.random.default_rng(77000 + seed)
     res = ["parsimony", "parsimony-em"][seed % 2]
     if seed >= 1000:   # second family: every resolution (gene-level parsimony = the one-workgroup kernel, the cr-like routes, EM)

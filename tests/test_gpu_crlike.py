@@ -529,10 +529,7 @@ def set_decoder(monkeypatch, decoder):
     """recs: one lane per record; keys: one lane per dword, a record's repeated genes found by look-back compares and a scan;
     keys-hash: one lane per dword, repeated genes found through an LDS hash table (AFQ_DECODE_DEDUP=hash)."""
     monkeypatch.setenv("AFQ_DECODE", "keys" if decoder == "keys-hash" else decoder)
-    if decoder == "keys-hash":
-        monkeypatch.setenv("AFQ_DECODE_DEDUP", "hash")
-    else:
-        monkeypatch.delenv("AFQ_DECODE_DEDUP", raising=False)
+    monkeypatch.setenv("AFQ_DECODE_DEDUP", "hash" if decoder == "keys-hash" else "scan")   # (hash is the default)
 
 
 @pytest.mark.parametrize("decoder", ["keys", "keys-hash"])
