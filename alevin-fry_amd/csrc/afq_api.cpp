@@ -1223,6 +1223,7 @@ int finish_range(afq_ctx* c, int slot) {
             launch_compact(s, B.d_meta.as<CellMeta>(), n, B.d_keys0.as<uint64_t>(), B.d_keys1.as<uint64_t>(), B.d_nnz.as<uint32_t>(),
                            B.d_cell_ptr.as<uint64_t>(), B.d_gene.as<uint32_t>(), B.d_val.as<float>());
     }
+    if (compacted && env_on("AFQ_D2H_NOP")) launch_nop(s);   // (measurements: the rows' copies enqueued behind a kernel that is still pending, as they were when the compaction was enqueued here)
     HostResult& R = *c->res;
     const size_t g0 = R.gene.n;
     HIP_TRY(c, R.gene.reserve(g0 + tot));
