@@ -1223,7 +1223,11 @@ int finish_range(afq_ctx* c, int slot) {
             launch_compact(s, B.d_meta.as<CellMeta>(), n, B.d_keys0.as<uint64_t>(), B.d_keys1.as<uint64_t>(), B.d_nnz.as<uint32_t>(),
                            B.d_cell_ptr.as<uint64_t>(), B.d_gene.as<uint32_t>(), B.d_val.as<float>());
     }
-    if (compacted && env_on("AFQ_D2H_NOP")) launch_nop(s);   // (measurements: the rows' copies enqueued behind a kernel that is still pending, as they were when the compaction was enqueued here)
+    // (the row offsets still go up, although the device has made its own: under rocprofv3 the runtime moved the rows' two copies
+    //  with __amd_rocclr_copyBuffer kernels - 27 % of the GPU time of a profiled step, next to the following range's decoder -
+    //  whenever the command in front of them on the stream was a kernel; behind a small upload they stay on the DMA engines, as
+    //  they did while the compaction was enqueued from here.  profiles/run_r04ak.sh, run_r04al.sh, run_r04am.sh)
+    if (compacted && env_on("AFQ_D2H_LEAD")) HIP_TRY(c, hipMemcpyAsync(B.d_cell_ptr.p, ptr.data(), 8ull * (n + 1), hipMemcpyHostToDevice, s));
     HostResult& R = *c->res;
     const size_t g0 = R.gene.n;
     HIP_TRY(c, R.gene.reserve(g0 + tot));

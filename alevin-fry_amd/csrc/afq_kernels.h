@@ -144,7 +144,6 @@ void launch_cell_hist(hipStream_t s, const ResolveArgs& a);
 void launch_compact(hipStream_t s, const CellMeta* meta, uint32_t n_cells, const uint64_t* keys0, const uint64_t* keys1,
                     const uint32_t* nnz, const uint64_t* cell_ptr, uint32_t* gene, float* val, uint64_t cap = ~0ull);
 void launch_fill_tables(hipStream_t s, const CellMeta* meta, uint32_t n_cells, uint32_t* bucket_cell, uint2* tile_desc);   // bucket -> cell and tile -> (cell, tile) from the cells' plans
-void launch_nop(hipStream_t s);
 void launch_row_ptr(hipStream_t s, const uint32_t* nnz, uint32_t n, uint64_t* cell_ptr);   // row lengths -> row offsets (+ total at [n])
 
 // ---- parsimony (afq_pug.hip) ----

@@ -1417,9 +1417,6 @@ void launch_fill_tables(hipStream_t s, const CellMeta* meta, uint32_t n_cells, u
     if (!n_cells) return;
     AFQ_LAUNCH(k_fill_tables, (n_cells + 3) / 4, 256, s, meta, n_cells, bucket_cell, tile_desc);
 }
-// (see finish_range: a copy enqueued on an idle stream)
-__global__ void k_nop() {}
-void launch_nop(hipStream_t s) { AFQ_LAUNCH(k_nop, 1, 64, s); }
 void launch_row_ptr(hipStream_t s, const uint32_t* nnz, uint32_t n, uint64_t* cell_ptr) {
     AFQ_LAUNCH(k_row_ptr, 1, 1024, s, nnz, n, cell_ptr);
 }
