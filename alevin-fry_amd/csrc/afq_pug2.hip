@@ -653,6 +653,72 @@ __device__ __forceinline__ uint32_t wave_label_column(const PugCtx& c, uint32_t 
     return col;
 }
 
+// The column of a lone vertex whose label has 5..8 refs, by its own lane with everything in registers: three in four of the labels
+// over four refs on the tail model, and a wave per vertex (wave_label_column) is two dependent round trips to memory per vertex, one
+// vertex after the other - the lanes of a row make theirs together.  g: the genes of the label's refs, 0xFFFFFFFF past its end, in any
+// order.  A 19-exchange network sorts them, repeats become padding, a second pass moves the padding behind the distinct genes;
+// then the rules of molecule_column_n (afq_pug_common.h) with every index a constant.
+__device__ __forceinline__ void sort8(uint32_t (&a)[8]) {
+#define AFQ_CE(i, j) { const uint32_t lo_ = min(a[i], a[j]), hi_ = max(a[i], a[j]); a[i] = lo_; a[j] = hi_; }
+    AFQ_CE(0, 1) AFQ_CE(2, 3) AFQ_CE(4, 5) AFQ_CE(6, 7)
+    AFQ_CE(0, 2) AFQ_CE(1, 3) AFQ_CE(4, 6) AFQ_CE(5, 7)
+    AFQ_CE(1, 2) AFQ_CE(5, 6) AFQ_CE(0, 4) AFQ_CE(3, 7)
+    AFQ_CE(1, 5) AFQ_CE(2, 6)
+    AFQ_CE(1, 4) AFQ_CE(3, 6)
+    AFQ_CE(2, 4) AFQ_CE(3, 5)
+    AFQ_CE(3, 4)
+#undef AFQ_CE
+}
+__device__ __forceinline__ uint32_t molecule8_column(const PugCtx& c, uint32_t (&g)[8]) {
+    constexpr uint32_t kNo = 0xFFFFFFFFu;
+    sort8(g);
+    uint32_t d[8];
+    d[0] = g[0];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) d[q] = g[q] == g[q - 1] ? kNo : g[q];
+    sort8(d);
+    uint32_t ng = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ng += d[q] != kNo ? 1u : 0u;
+    if (ng == 0) return kNo;
+    const uint32_t g0 = d[0], g1 = d[1];
+    auto sua = [&](uint32_t x) { return (x & 1u) == 0 ? (x >> 1) : c.uo + (x >> 1); };
+    uint32_t col = kNo;
+    if (c.em) {
+        if (ng == 1) col = !c.usa ? g0 : sua(g0);
+        else if (c.usa && ng == 2 && ((g0 ^ g1) & ~1u) == 0) col = c.ao + (g0 >> 1);
+        else {   // a gene-level class for the EM: its genes ascending
+            const uint32_t off = atomicAdd(&c.s_cnt[1], ng), di = atomicAdd(&c.s_cnt[2], 1u);
+            if (off + ng > c.lab_cap || 2 * (di + 1) > c.lab_cap) { c.s_cnt[3] = kErrPugLimit; return kNo; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if ((uint32_t)q < ng) c.labw[off + q] = d[q];
+            c.labd[2 * di] = off; c.labd[2 * di + 1] = ng;
+            return kNo;
+        }
+    } else if (!c.usa) {
+        if (ng == 1) col = g0;
+    } else if (ng == 1) {
+        col = sua(g0);
+    } else if (ng == 2) {
+        const bool s1 = (g0 & 1u) == 0, s2 = (g1 & 1u) == 0;
+        if (((g0 ^ g1) & ~1u) == 0) col = c.ao + (g0 >> 1);
+        else if (s1 && !s2) col = g0 >> 1;
+        else if (!s1 && s2) col = g1 >> 1;
+    } else {   // 3..8 genes (the rule holds up to ten): exactly one spliced gene among them - it, or with its unspliced sibling right behind it: ambiguous
+        uint32_t nsp = 0, sg = 0, nx = kNo;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if ((uint32_t)q < ng && (d[q] & 1u) == 0) { if (nsp == 0) { sg = d[q]; nx = q + 1 < 8 ? d[q + 1 < 8 ? q + 1 : 7] : kNo; } ++nsp; }
+        if (nsp == 1) col = (nx != kNo && ((sg ^ nx) & ~1u) == 0) ? c.ao + (sg >> 1) : (sg >> 1);
+    }
+    if (col == kNo) return col;
+    if (col >= c.num_rows) { c.s_cnt[3] = kErrSlotRange; return kNo; }
+    return col;
+}
+
+// L8: labels of 5..8 refs by their own lane (molecule8_column; AFQ_P2_LONE_COOP=2) - an instance of its own: its eight-entry arrays
+// are registers of every lane whether or not a label needs them.
+template <bool L8>
 __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t* s_cls, uint32_t lane) {
     const uint32_t n = A.pcnt[gp], nv = A.pnv[gp], j = A.pcell[gp], lo_p = A.poff[gp];
     if (n == 0) return;
@@ -668,8 +734,9 @@ __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t
     PugCtx Cg = C;
     Cg.gene_level = 1;   // (genes_of4 is handed gene ids below: the gathers are done here, for all slots together)
     for (uint32_t r0 = 0; r0 < n; r0 += 128) {   // (uniform)
+        constexpr int NR = L8 ? 8 : 4;   // refs of a label a lane looks at itself
         uint64_t h2[2];
-        uint32_t fl[2], of[2], ln[2], t4[2][4], g4[2][4];
+        uint32_t fl[2], of[2], ln[2], t4[2][NR], g4[2][NR];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const uint32_t i = r0 + (uint32_t)r * 64 + lane;
@@ -682,19 +749,23 @@ __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t
             const uint32_t tag = fl[r] ? 0u : (uint32_t)(h2[r] >> 62);
             ln[r] = tag == 3 ? C.W[of[r]] : tag;   // (tags 1 and 2 are the label's length)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) t4[r][q] = 0xFFFFFFFFu;
+            for (int q = 0; q < NR; ++q) t4[r][q] = 0xFFFFFFFFu;
             if (tag == 1) t4[r][0] = (uint32_t)h2[r] & 0x7FFFFFFFu;
             else if (tag == 2) { t4[r][0] = (uint32_t)(h2[r] >> 31) & 0x7FFFFFFFu; t4[r][1] = (uint32_t)h2[r] & 0x7FFFFFFFu; }
             else if (tag == 3) {
                 const uint32_t* lp = C.W + of[r] + C.HW;   // (a hashed label has three refs or more; the fourth dword read may be the next record's first - never one past the chunk)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) t4[r][q] = (q < 3 || of[r] + C.HW + 3 < cw) ? lp[q] & 0x7FFFFFFFu : 0xFFFFFFFFu;
+                if constexpr (L8) {   // (the label's length is not here yet: the next four dwords, if the chunk has them, whatever they are)
+#pragma unroll
+                    for (int q = 4; q < 8; ++q) t4[r][q] = of[r] + C.HW + (uint32_t)q < cw ? lp[q] & 0x7FFFFFFFu : 0xFFFFFFFFu;
+                }
             }
         }
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) g4[r][q] = (uint32_t)q < ln[r] && ln[r] <= 4 ? C.t2g[t4[r][q]] : 0xFFFFFFFFu;
+            for (int q = 0; q < NR; ++q) g4[r][q] = (uint32_t)q < ln[r] && ln[r] <= (uint32_t)NR ? C.t2g[t4[r][q]] : 0xFFFFFFFFu;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const uint32_t i = r0 + (uint32_t)r * 64 + lane;
@@ -702,9 +773,12 @@ __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t
             uint32_t col = 0xFFFFFFFFu, k0 = 0, k1 = 0;
             bool cls = false;
             if (ln[r] != 0 && ln[r] <= 4) {
-                const uint32_t ng = genes_of4(Cg, g4[r], ln[r]);
-                col = molecule4_column(C, g4[r], ng, cls);
-                k0 = g4[r][0]; k1 = g4[r][1];
+                uint32_t q4[4] = {g4[r][0], g4[r][1], g4[r][2], g4[r][3]};
+                const uint32_t ng = genes_of4(Cg, q4, ln[r]);
+                col = molecule4_column(C, q4, ng, cls);
+                k0 = q4[0]; k1 = q4[1];
+            } else if (L8 && ln[r] <= 8 && ln[r] != 0) {
+                if constexpr (L8) col = molecule8_column(C, g4[r]);
             } else if (ln[r] > (A.lone_coop ? 64u : 4u)) {
                 const Lab l = rec_label(C, of[r]);
                 uint32_t g[kMaxGenesPerLabel];
@@ -713,7 +787,7 @@ __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t
                 else col = molecule_column_n(C, g, ng);
             }
             if (A.lone_coop) {   // labels of 5..64 refs: the wave takes them one after the other (wave_label_column)
-                for (uint64_t lm = __ballot(ln[r] > 4 && ln[r] <= 64); lm; lm &= lm - 1) {
+                for (uint64_t lm = __ballot(ln[r] > (uint32_t)NR && ln[r] <= 64); lm; lm &= lm - 1) {
                     const uint32_t b = (uint32_t)__builtin_ctzll(lm);
                     const uint32_t cb = wave_label_column(C, (uint32_t)__shfl((int)of[r], (int)b), (uint32_t)__shfl((int)ln[r], (int)b), lane);
                     if (lane == b) col = cb;
@@ -732,11 +806,12 @@ __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t
     if (lane == 0) A.pncls[gp] = ncls;
     WAVE_SYNC();
 }
+template <bool L8>
 __global__ __launch_bounds__(256) void k_p2_lone(P2Args A) {
     if (A.st->err_code) return;   // an earlier kernel of the range failed (e.g. kErrLabelHash in k_p2_part, which then leaves its partition's vertices unwritten): nothing behind it may read that state - the host runs the range again or reports the error
     __shared__ uint32_t s_cls4[4][512];
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    for_each_partition_in_runs(A.n_parts, wv, [&](uint32_t gp) { lone_body(A, gp, s_cls4[wv], lane); });
+    for_each_partition_in_runs(A.n_parts, wv, [&](uint32_t gp) { lone_body<L8>(A, gp, s_cls4[wv], lane); });
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -1513,7 +1588,11 @@ void launch_p2_search(hipStream_t s, const P2Args& a) {
     AFQ_LAUNCH(k_p2_search, (p2_grid(a.n_parts) + 2047) / 2048 * 2048, 256, s, a);
     AFQ_LAUNCH(k_p2_search_over, std::min((a.n_parts + 255) / 256, 2048u), 256, s, a);   // (the partitions with more pairs than slots, normally none: two counts per partition are read)
 }
-void launch_p2_lone(hipStream_t s, const P2Args& a) { if (a.n_parts) AFQ_LAUNCH(k_p2_lone, (p2_grid(a.n_parts) + 2047) / 2048 * 2048, 256, s, a); }
+void launch_p2_lone(hipStream_t s, const P2Args& a) {
+    if (!a.n_parts) return;
+    if (a.lone_coop >= 2) AFQ_LAUNCH(k_p2_lone<true>, (p2_grid(a.n_parts) + 2047) / 2048 * 2048, 256, s, a);
+    else AFQ_LAUNCH(k_p2_lone<false>, (p2_grid(a.n_parts) + 2047) / 2048 * 2048, 256, s, a);
+}
 void launch_p2_graph(hipStream_t s, const P2Args& a) {
     if (!a.n_cells) return;
     int dev = 0, cus = 256;

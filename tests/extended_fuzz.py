@@ -18,7 +18,7 @@ synth = pkg.synth
 
 
 def one_tailed(seed):
-    """Third family (seeds from 2000): the bench's label-tail model out of the native generator - reads of up to 64 alignments on
+    """Third family (seeds from 2000; from 3000: parsimony with AFQ_P2_LONE_COOP=2): the bench's label-tail model out of the native generator - reads of up to 64 alignments on
     gene families - through a decoder picked per seed (the planner's choice, lane per record, lane per dword with either way of
     finding a record's repeated genes) and every resolution."""
     import importlib
@@ -29,7 +29,9 @@ def one_tailed(seed):
     usa = bool(rng.integers(0, 2))
     dec = [None, "recs", "keys", "keys", "keys"][int(rng.integers(0, 5))]
     dedup = ["hash", "scan"][int(rng.integers(0, 2))]
-    coop = str(int(rng.integers(0, 2)))   # k_p2_lone: labels of 5..64 refs by the wave or by their lane
+    coop = str(int(rng.integers(0, 3)))   # k_p2_lone: labels over four refs by their lane in scratch memory (0), by the wave (1), 5..8 refs by the lane in registers and 9..64 by the wave (2)
+    if seed >= 3000:   # fourth family: parsimony only, the lone-vertex kernel's per-lane route for labels of 5..8 refs
+        res, coop = ["parsimony", "parsimony-em"][seed % 2], "2"
     for k, v in (("AFQ_DECODE", dec), ("AFQ_DECODE_DEDUP", dedup), ("AFQ_P2_LONE_COOP", coop)):
         if v is None:
             os.environ.pop(k, None)

@@ -290,3 +290,67 @@ def test_reference_pin_script_round_trip(tmp_path):
     (out / "quants_mat.mtx").write_text("%%MatrixMarket matrix coordinate real general\n" + f"{len(rows)} {len(cols)} {len(body)}\n" + "\n".join(body) + "\n")
     r = subprocess.run([sys.executable, script, "compare", str(d)], capture_output=True, text=True)
     assert r.returncode == 1 and "differing 1," in r.stdout
+
+
+def test_molecule8_column_is_the_general_rule_on_host(tmp_path):
+    """csrc/afq_pug2.hip: molecule8_column (a label of 5..8 refs resolved in eight registers: a 19-exchange sorting network, repeats
+    to padding, a second pass) must give what genes_of + molecule_column_n (afq_pug_common.h) give - column, EM class words and
+    descriptors, error codes.  The functions' own source text is compiled for the host with a stand-in PugCtx and run on 1.6 M
+    random labels (small gene spaces: many repeats and spliced / unspliced siblings), USA and not, EM and not."""
+    import shutil
+    import subprocess
+
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    src = open(os.path.join(ROOT, "alevin-fry_amd", "csrc", "afq_pug2.hip")).read()
+    com = open(os.path.join(ROOT, "alevin-fry_amd", "csrc", "afq_pug_common.h")).read()
+
+    def grab(text, start, end):
+        a = text.index(start)
+        return text[a:text.index(end, a)]
+
+    parts = [grab(com, "template <typename GetRef>\n__device__ __forceinline__ uint32_t genes_of(", "// One resolved molecule with gene label"),
+             grab(com, "__device__ __forceinline__ uint32_t molecule_column_n(", "__device__ __forceinline__ void emit_molecule("),
+             grab(src, "__device__ __forceinline__ void sort8", "__device__ __forceinline__ uint32_t molecule8_column"),
+             grab(src, "__device__ __forceinline__ uint32_t molecule8_column", "// L8: labels of 5..8 refs by their own lane")]
+    host = r'''#include <cstdint>
+#include <cstdio>
+#include <algorithm>
+#include <random>
+#define __device__
+#define __forceinline__ inline
+using std::min; using std::max;
+constexpr uint32_t kMaxGenesPerLabel = 64, kErrPugLimit = 7, kErrSlotRange = 9;
+struct PugCtx { const uint32_t* t2g; uint32_t gene_level, usa, em, num_rows, uo, ao, lab_cap; uint32_t* labw; uint32_t* labd; uint32_t* s_cnt; };
+static uint32_t atomicAdd(uint32_t* p, uint32_t v) { uint32_t o = *p; *p += v; return o; }
+''' + "".join(parts) + r'''
+int main() {
+    std::mt19937 rng(7);
+    long n = 0, bad = 0;
+    for (int usa = 0; usa < 2; ++usa) for (int em = 0; em < 2; ++em) for (int it = 0; it < 400000; ++it) {
+        const uint32_t G = usa ? 2 * (3 + rng() % 6) : 4 + rng() % 8;
+        const uint32_t rows = usa ? (G / 2) * 3 - (it % 5 == 0 ? 2 : 0) : G - (it % 5 == 0 ? 1 : 0);   // (now and then a column out of range: the error path)
+        uint32_t la[64], da[64], lb[64], db[64], ca[4] = {0, 0, 0, 0}, cb[4] = {0, 0, 0, 0};
+        PugCtx A{nullptr, 1, (uint32_t)usa, (uint32_t)em, rows, ((G / 2) * 3) / 3, 2 * (((G / 2) * 3) / 3), (uint32_t)(it % 7 == 0 ? 3 : 40), la, da, ca};
+        PugCtx B = A; B.labw = lb; B.labd = db; B.s_cnt = cb;
+        const uint32_t len = 5 + rng() % 4;
+        uint32_t refs[8], g8[8];
+        for (uint32_t q = 0; q < 8; ++q) { refs[q] = rng() % G; g8[q] = q < len ? refs[q] : 0xFFFFFFFFu; }
+        uint32_t g[kMaxGenesPerLabel];
+        const uint32_t ng = genes_of(A, len, [&](uint32_t j) { return refs[j]; }, g);
+        const uint32_t want = molecule_column_n(A, g, ng);
+        const uint32_t got = molecule8_column(B, g8);
+        bool same = want == got && ca[1] == cb[1] && ca[2] == cb[2] && ca[3] == cb[3];
+        for (uint32_t k = 0; same && k < ca[1] && k < 40; ++k) same = la[k] == lb[k];
+        for (uint32_t k = 0; same && k < 2 * ca[2] && k < 40; ++k) same = da[k] == db[k];
+        ++n; if (!same) { if (bad < 5) printf("MISMATCH usa=%d em=%d len=%u want=%u got=%u\n", usa, em, len, want, got); ++bad; }
+    }
+    printf("%ld cases, %ld mismatches\n", n, bad);
+    return bad != 0;
+}
+'''
+    (tmp_path / "t.cpp").write_text(host)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", str(tmp_path / "t"), str(tmp_path / "t.cpp")], check=True, capture_output=True)
+    r = subprocess.run([str(tmp_path / "t")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 mismatches" in r.stdout
