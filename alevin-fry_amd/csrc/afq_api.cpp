@@ -905,7 +905,11 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
                 p2.n_big = 0;
                 while (p2.n_big < n_p2 && p2cells[p2.n_big].R >= big_reads) ++p2.n_big;   // (p2cells is largest first)
             }
-            p2.lone_coop = [] { const char* e = std::getenv("AFQ_P2_LONE_COOP"); return e && e[0] >= '0' && e[0] <= '2' ? (uint32_t)(e[0] - '0') : 1u; }();   // (0: by the lane alone, in scratch memory; 1: 5..64 refs by the wave; 2: 5..8 by the lane in registers, 9..64 by the wave)
+            // k_p2_lone, labels over four refs: 0: by the vertex's lane alone, in scratch memory (rounds 3-4); 1: labels of 5..64 refs by the
+            // wave; 2: 5..8 by the lane in eight registers, 9..64 by the wave - an instance of 86 instead of 69 VGPRs, five waves per SIMD
+            // instead of seven: on the tail model k_p2_lone 25.1 -> 16.5 ms per step, on the plain one 5.6 -> 7.3 (profiles/run_r04ao.sh).
+            // The range's own figure decides, the one that picks its decoder: two or more alignment words per record.
+            p2.lone_coop = [&] { const char* e = std::getenv("AFQ_P2_LONE_COOP"); return e && e[0] >= '0' && e[0] <= '2' ? (uint32_t)(e[0] - '0') : (key_off - n >= 2 * nrec_total ? 2u : 1u); }();
             p2.part_cap = kP2PartCap;
             if (const char* e = std::getenv("AFQ_P2_PART_CAP")) p2.part_cap = (uint32_t)std::max(1, std::atoi(e));   // tests: force cells back to the one-workgroup kernel
             p2.ref_count = c->ref_count; p2.num_genes = g.num_genes; p2.usa = g.usa_mode; p2.num_rows = g.num_rows; p2.em = em ? 1u : 0u;
