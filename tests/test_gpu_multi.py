@@ -59,23 +59,31 @@ def test_device_generator_writes_the_host_generators_bytes(kw):
 
 
 @pytest.mark.parametrize("tail", [0.0, 0.7])
-def test_generated_workload_quantifies_like_the_oracle(oracle, tail):
+def test_generated_workload_quantifies_like_the_oracle(oracle, monkeypatch, tail):
     """The generator's output through the device path and through the oracle (USA, parsimony-em): the bench's input is
     an ordinary collated RAD as far as both are concerned - with the label-length tail too (labels of up to dozens of refs
-    on gene families: the long-record paths of the decoders, hashed label keys, molecules of more than four genes)."""
+    on gene families: the long-record paths of the decoders, hashed label keys, molecules of more than four genes).  On the
+    tailed input the parsimony resolutions also run with each way the lone-vertex kernel has of resolving a label of more than
+    four refs (AFQ_P2_LONE_COOP: by its lane in scratch memory, by the wave, 5..8 refs by the lane in registers; the default picks
+    by range)."""
     d = sn.generate_device(device=0, seed=3, n_cells=60, median_reads=3000.0, num_genes=400, txp_per_gene=4, usa=True, umi_err=0.03,
                            tail=tail, family=8)
     try:
+        host = d.to_host()
         for res in ("cr-like", "parsimony-em", "parsimony", "cr-like-em"):
             cfg = pkg.WorkerConfig.for_resolution(res, usa_mode=True, num_genes=d.num_genes, num_rows=d.num_rows, umi_len=12)
-            q = pkg.Quantifier(cfg, d.tid_to_gid, device=0)
-            try:
-                q.submit_device(d.d_ptr, d.n_bytes, d.chunk_off)
-                got = q.collect()
-            finally:
-                q.close()
-            want = oracle.quant(cfg, d.tid_to_gid, d.to_host(), d.chunk_off, n_threads=4)
-            assert_same_result(got, want, what=res)
+            want = oracle.quant(cfg, d.tid_to_gid, host, d.chunk_off, n_threads=4)
+            for lone in ((None, "0", "1", "2") if tail and res.startswith("parsimony") else (None,)):
+                with monkeypatch.context() as mp:
+                    if lone is not None:
+                        mp.setenv("AFQ_P2_LONE_COOP", lone)
+                    q = pkg.Quantifier(cfg, d.tid_to_gid, device=0)
+                    try:
+                        q.submit_device(d.d_ptr, d.n_bytes, d.chunk_off)
+                        got = q.collect()
+                    finally:
+                        q.close()
+                assert_same_result(got, want, what=f"{res} AFQ_P2_LONE_COOP={lone}")
     finally:
         d.free()
 
