@@ -354,3 +354,171 @@ int main() {
     r = subprocess.run([str(tmp_path / "t")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 mismatches" in r.stdout
+
+
+def test_crlike_rule_functions_are_the_oracles_on_host(tmp_path):
+    """csrc/afq_kernels.hip: col_from_pairs (a UMI's three in-slot (gene, reads) counters -> column) and col_from_candidates (the
+    same rule table on order-free aggregates, any number of genes) are the device's statement of the winner-take-all rule with
+    the USA spliced / unspliced / ambiguous table (quant.rs:557-605, utils.rs:688-753).  Their own source text is compiled for the
+    host and asked every UMI of one to five genes out of six gene ids with one to three reads each, USA and not; the oracle
+    (crlike_walk + extract_counts in oracle/afq_oracle.cpp) is asked the same UMIs, one per cell.  No GPU."""
+    import itertools
+    import shutil
+    import subprocess
+    import sys
+
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as ora
+
+    cases = []   # (usa, ((gene, reads), ...))
+    for usa in (0, 1):
+        for k in range(1, 6):
+            for genes in itertools.combinations(range(6), k):
+                for counts in itertools.product((1, 2, 3) if k <= 3 else (1, 2), repeat=k):
+                    cases.append((usa, tuple(zip(genes, counts))))
+    # the oracle: every case a cell of its own holding one UMI; a read = one alignment to transcript g (tid_to_gid = identity)
+    want = []
+    for usa in (0, 1):
+        sub = [c for c in cases if c[0] == usa]
+        cells = [(100 + i, [(7, [g]) for g, n in gc for _ in range(n)]) for i, (_, gc) in enumerate(sub)]
+        b, off = rad.encode_cells(cells, 4, 4)
+        cfg = pkg.WorkerConfig.for_resolution("cr-like", usa_mode=bool(usa), num_genes=6, num_rows=9 if usa else 6, small_thresh=0)
+        res = ora.quant(cfg, np.arange(6, dtype=np.uint32), b, off)
+        for i in range(len(sub)):
+            g, v = res.row(i)
+            assert len(g) <= 1 and all(x == 1.0 for x in v)
+            want.append(int(g[0]) if len(g) else 0xFFFFFFFF)
+    src = open(os.path.join(ROOT, "alevin-fry_amd", "csrc", "afq_kernels.hip")).read()
+
+    def grab(start, end):
+        a = src.index(start)
+        return src[a:src.index(end, a)]
+
+    host = r'''#include <cstdint>
+#include <cstdio>
+#include <algorithm>
+#define __device__
+#define __forceinline__ inline
+using std::max;
+struct ResolveCfg { uint32_t usa, num_rows, uo, ao, mode, pa, sort_only; };
+static inline bool is_spliced(uint32_t g) { return (g & 1u) == 0; }
+static inline bool same_gene(uint32_t a, uint32_t b) { return (a & ~1u) == (b & ~1u); }
+constexpr uint32_t kNoCol = 0xFFFFFFFFu;
+''' + grab("__device__ __forceinline__ uint32_t col_from_pairs(", "// A UMI seen with more than kHtPairs genes parks") + \
+        grab("template <typename ForEach>\n__device__ __forceinline__ uint32_t col_from_candidates(", "// cr-like-em: a UMI whose winners are one output column") + r'''
+int main() {
+    unsigned usa, k;
+    while (scanf("%u %u", &usa, &k) == 2) {
+        uint32_t g[8], c[8];
+        for (unsigned i = 0; i < k; ++i) if (scanf("%u %u", &g[i], &c[i]) != 2) return 2;
+        const ResolveCfg rc{usa, usa ? 9u : 6u, 3u, 6u, 0u, 0u, 0u};
+        uint32_t a = kNoCol;
+        if (k <= 3) {
+            uint32_t p[3] = {0, 0, 0};   // (an unused counter: 0 reads)
+            for (unsigned i = 0; i < k; ++i) p[(i + g[0]) % 3] = (g[i] << 12) | c[i];   // the counters in any slot order
+            a = col_from_pairs(p[0], p[1], p[2], rc);
+        }
+        const uint32_t b = col_from_candidates([&](auto&& f) { for (unsigned i = 0; i < k; ++i) f(g[k - 1 - i], c[k - 1 - i]); }, rc);
+        printf("%u %u\n", a, b);
+    }
+    return 0;
+}
+'''
+    (tmp_path / "t.cpp").write_text(host)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", str(tmp_path / "t"), str(tmp_path / "t.cpp")], check=True, capture_output=True)
+    text = "".join(f"{usa} {len(gc)} " + " ".join(f"{g} {n}" for g, n in gc) + "\n" for usa, gc in cases)
+    r = subprocess.run([str(tmp_path / "t")], input=text, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = [tuple(int(x) for x in line.split()) for line in r.stdout.splitlines()]
+    assert len(got) == len(cases) == len(want)
+    for (usa, gc), (a, b), w in zip(cases, got, want):
+        assert b == w, ("col_from_candidates", usa, gc, b, w)
+        if len(gc) <= 3:
+            assert a == w, ("col_from_pairs", usa, gc, a, w)
+
+
+def test_parsimony_molecule_rules_are_the_oracles_on_host(tmp_path):
+    """csrc/afq_pug_common.h: how a resolved molecule's label becomes a count - genes_of4 + molecule4_column (labels of up to four
+    refs, in registers; molecule2_column for one or two genes) and genes_of + molecule_column_n (any label) - against the oracle's
+    `parsimony` on cells of ONE read (one vertex, no edge: the molecule is the read's label; quant.rs:974-1024, utils.rs:688-753).
+    Every label of one to six of nine transcripts (two spliced transcripts per gene and, in USA mode, the genes' unspliced ones),
+    USA and not.  The functions' own source text, compiled for the host.  No GPU."""
+    import itertools
+    import shutil
+    import subprocess
+    import sys
+
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as ora
+
+    t2g = {0: [0, 0, 1, 1, 2, 2, 3, 4, 5], 1: [0, 0, 2, 2, 4, 4, 1, 3, 5]}   # non-USA: six genes; USA: gene ids 2g (spliced) / 2g + 1 (unspliced)
+    labels = [lab for k in range(1, 7) for lab in itertools.combinations(range(9), k)]
+    want = {}
+    for usa in (0, 1):
+        cells = [(500 + i, [(3, list(lab))]) for i, lab in enumerate(labels)]
+        b, off = rad.encode_cells(cells, 4, 4)
+        cfg = pkg.WorkerConfig.for_resolution("parsimony", usa_mode=bool(usa), num_genes=6, num_rows=9 if usa else 6, small_thresh=0)
+        res = ora.quant(cfg, np.asarray(t2g[usa], np.uint32), b, off)
+        for i, lab in enumerate(labels):
+            g, v = res.row(i)
+            assert len(g) <= 1 and all(x == 1.0 for x in v)
+            want[(usa, lab)] = int(g[0]) if len(g) else 0xFFFFFFFF
+    com = open(os.path.join(ROOT, "alevin-fry_amd", "csrc", "afq_pug_common.h")).read()
+
+    def grab(start, end):
+        a = com.index(start)
+        return com[a:com.index(end, a)]
+
+    host = r'''#include <cstdint>
+#include <cstdio>
+#define __device__
+#define __forceinline__ inline
+constexpr uint32_t kMaxGenesPerLabel = 64, kErrPugLimit = 7, kErrSlotRange = 9;
+struct PugCtx { const uint32_t* t2g; uint32_t gene_level, usa, em, num_rows, uo, ao, lab_cap; uint32_t* labw; uint32_t* labd; uint32_t* s_cnt; };
+static uint32_t atomicAdd(uint32_t* p, uint32_t v) { uint32_t o = *p; *p += v; return o; }
+''' + grab("template <typename GetRef>\n__device__ __forceinline__ uint32_t genes_of(", "// One resolved molecule with gene label") + \
+        grab("__device__ __forceinline__ uint32_t molecule_column_n(", "__device__ __forceinline__ void emit_molecule(") + \
+        grab("__device__ __forceinline__ uint32_t molecule2_column(", "// Up to four refs -> their distinct gene ids") + \
+        grab("__device__ __forceinline__ uint32_t genes_of4(", "// Append one column per lane that has one.") + r'''
+int main() {
+    static const uint32_t T2G[2][9] = {{0, 0, 1, 1, 2, 2, 3, 4, 5}, {0, 0, 2, 2, 4, 4, 1, 3, 5}};
+    unsigned usa, k;
+    while (scanf("%u %u", &usa, &k) == 2) {
+        uint32_t t[8];
+        for (unsigned i = 0; i < k; ++i) if (scanf("%u", &t[i]) != 1) return 2;
+        uint32_t cnt[4] = {0, 0, 0, 0}, lw[64], ld[64];
+        PugCtx C{T2G[usa], 0, usa, 0, usa ? 9u : 6u, 3u, 6u, 64, lw, ld, cnt};
+        uint32_t g[kMaxGenesPerLabel];
+        const uint32_t ng = genes_of(C, k, [&](uint32_t j) { return t[j]; }, g);
+        const uint32_t a = molecule_column_n(C, g, ng);
+        uint32_t b = 0xFFFFFFFEu;   // (no answer: the label has more than four refs)
+        if (k <= 4) {
+            uint32_t g4[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            for (unsigned i = 0; i < k; ++i) g4[i] = t[k - 1 - i];   // (any order)
+            bool cls = false;
+            const uint32_t n4 = genes_of4(C, g4, k);
+            b = molecule4_column(C, g4, n4, cls);
+            if (cls) return 3;   // (classes are the EM's)
+        }
+        printf("%u %u %u\n", a, b, cnt[3]);
+    }
+    return 0;
+}
+'''
+    (tmp_path / "t.cpp").write_text(host)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", str(tmp_path / "t"), str(tmp_path / "t.cpp")], check=True, capture_output=True)
+    order = [(usa, lab) for usa in (0, 1) for lab in labels]
+    text = "".join(f"{usa} {len(lab)} " + " ".join(str(x) for x in lab) + "\n" for usa, lab in order)
+    r = subprocess.run([str(tmp_path / "t")], input=text, capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stderr)
+    got = [tuple(int(x) for x in line.split()) for line in r.stdout.splitlines()]
+    assert len(got) == len(order)
+    for key, (a, b, err) in zip(order, got):
+        assert err == 0, key
+        assert a == want[key], ("molecule_column_n", key, a, want[key])
+        if len(key[1]) <= 4:
+            assert b == want[key], ("molecule4_column", key, b, want[key])
