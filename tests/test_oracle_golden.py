@@ -321,39 +321,3 @@ def test_tie_free_components_and_em_order_switches(oracle):
     again = oracle.quant(cfg, s.tid_to_gid, b, off)
     assert np.array_equal(again.val.view(np.uint32), base.val.view(np.uint32))
 
-
-def test_fixed_point_em_is_order_free_and_within_tolerance(oracle):
-    """The arithmetic the device EM computes (csrc/afq_em2.hip; oracle: em_update_fixed): a round's shares are added as 64-bit
-    fixed-point integers, so the classes may come in ANY order - the rows must be bit-identical under shuffled class orders (the
-    reference's own f32 sums move in their last bits under the same shuffles, test above) - and they must stay within north_star's
-    1e-4 relative of the reference arithmetic with the same entries non-zero, up to entries that sit on the 0.01 output floor
-    (em.rs: min_output_alpha).  cr-like-em and parsimony-em, USA and not.  No GPU: this pins the contract the device is held to."""
-    import numpy as np
-
-    pkg = __import__("importlib").import_module("alevin-fry_amd")
-    for usa in (False, True):
-        s = pkg.synth.synth(77 + usa, [9000, 2500, 800, 300, 120], num_genes=180, txp_per_gene=3, usa=usa, dup=0.5, zipf=0.6, cross=0.35,
-                            umi_err=0.03, max_extra_na=6)
-        b, off = s.encode()
-        for res in ("cr-like-em", "parsimony-em"):
-            cfg = pkg.WorkerConfig.for_resolution(res, usa_mode=usa, num_genes=s.num_genes, num_rows=s.num_rows)
-            ref = oracle.quant(cfg, s.tid_to_gid, b, off)
-            fx = oracle.quant(cfg, s.tid_to_gid, b, off, em_arith="fixed")
-            for seed in (3, 4, 5):
-                sh = oracle.quant(cfg, s.tid_to_gid, b, off, em_arith="fixed", em_order_seed=seed)
-                assert np.array_equal(sh.cell_ptr, fx.cell_ptr) and np.array_equal(sh.gene, fx.gene), (res, usa, seed)
-                assert np.array_equal(sh.val.view(np.uint32), fx.val.view(np.uint32)), (res, usa, seed, "fixed-point sums must not depend on the class order")
-            # against the reference arithmetic: rows entry by entry
-            n_beyond = n_floor = n_entries = 0
-            for i in range(ref.n_cells):
-                (ga, va), (gb, vb) = ref.row(i), fx.row(i)
-                da, db = dict(zip(ga.tolist(), va.tolist())), dict(zip(gb.tolist(), vb.tolist()))
-                for g in set(da) | set(db):
-                    x, y = da.get(g, 0.0), db.get(g, 0.0)
-                    n_entries += 1
-                    if (x == 0.0) != (y == 0.0):
-                        n_floor += 1
-                        assert max(x, y) < 0.0101, (res, usa, i, g, x, y)   # only an entry at the 0.01 floor may appear / vanish
-                    elif abs(x - y) > 1e-4 * max(abs(x), abs(y)):
-                        n_beyond += 1
-            assert n_entries > 500 and n_beyond == 0 and n_floor <= max(1, n_entries // 2000), (res, usa, n_entries, n_beyond, n_floor)
