@@ -483,6 +483,16 @@ __device__ __forceinline__ void resolve_bucket_lds(const BucketDesc& d, uint64_t
 }
 
 
+// The sort path as k_resolve calls it: a call, not an inlined body.  Nearly every bucket is finished by one of the hash paths; with
+// the sort inlined behind them the kernel kept the scalars of all three paths alive together (127 SGPRs spilled).
+template <int NT>
+__device__ __attribute__((noinline)) void resolve_bucket_lds_call(const BucketDesc& d, uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
+                                                                  uint32_t* __restrict__ cell_ncols, uint32_t* __restrict__ nnz, DevStatus* st,
+                                                                  const ResolveCfg& rc, const LabArea& la, uint64_t* s_keys, uint16_t* s_run, uint32_t* s_cols,
+                                                                  uint32_t* s_lab, uint32_t* s_ldesc, uint32_t* s_ws, uint32_t* s_misc) {
+    resolve_bucket_lds<NT>(d, keys0, keys1, cell_ncols, nnz, st, rc, la, s_keys, s_run, s_cols, s_lab, s_ldesc, s_ws, s_misc);
+}
+
 // ---- hash-table resolution of a cr-like bucket (one wave) ----
 // A bucket holds every (umi, gene) key of the UMIs that hash to it, so the winner-take-all rule needs no
 // order, only grouping: the wave inserts its keys into an LDS open-addressing table keyed by UMI whose slots
@@ -945,8 +955,11 @@ __global__ __launch_bounds__(kResolveNT) void k_resolve(const BucketDesc* __rest
         }
         __syncthreads();
     }
-    resolve_bucket_lds<kResolveNT>(d, keys0, keys1, cell_ncols, nnz, st, rc, la, s_keys, s_run, s_cols, s_lab, s_ldesc, s_ws,
-                                   s_misc);
+#ifdef AFQ_RESOLVE_SORT_CALL
+    resolve_bucket_lds_call<kResolveNT>(d, keys0, keys1, cell_ncols, nnz, st, rc, la, s_keys, s_run, s_cols, s_lab, s_ldesc, s_ws, s_misc);
+#else
+    resolve_bucket_lds<kResolveNT>(d, keys0, keys1, cell_ncols, nnz, st, rc, la, s_keys, s_run, s_cols, s_lab, s_ldesc, s_ws, s_misc);
+#endif
 }
 
 // Buckets over the 2-wave cap but within LDS reach (<= kMidCap keys): persistent

@@ -46,13 +46,16 @@ typedef unsigned __int128 u128;
 
 constexpr uint32_t kP2Bins = 2048;        // partitions per cell the tile kernels rank in LDS
 constexpr uint32_t kP2TabSlots = 512;     // hash table of one partition's vertices (<= 256)
-constexpr uint32_t kP2FiltBits = 4096;    // presence filter in front of it
+#ifndef AFQ_P2_FILT_LG
+#define AFQ_P2_FILT_LG 12
+#endif
+constexpr uint32_t kP2FiltLg = AFQ_P2_FILT_LG, kP2FiltBits = 1u << kP2FiltLg;    // presence filter in front of it
 constexpr uint32_t kVCntMask = 0x3FFu;    // vertex word: reads (10 bits) | label signature (19 bits) << 10 | key tag << 29
 constexpr uint64_t kPairF = 1ull << 63, kPairB = 1ull << 62;   // pair (x, y): x -> y / y -> x is an edge
 
 __device__ __forceinline__ uint32_t sig_of(uint32_t t) { return 1u << (t % 19u); }
 __device__ __forceinline__ uint32_t fold9(uint32_t u) { u ^= u >> 18; return (u ^ (u >> 9)) & (kP2TabSlots - 1); }       // linear: fold(a ^ b) = fold(a) ^ fold(b)
-__device__ __forceinline__ uint32_t fold11(uint32_t u) { return (u ^ (u >> 12) ^ (u >> 24)) & (kP2FiltBits - 1); }   // (12 bits)
+__device__ __forceinline__ uint32_t fold11(uint32_t u) { return (u ^ (u >> kP2FiltLg) ^ (u >> (2 * kP2FiltLg))) & (kP2FiltBits - 1); }   // (kP2FiltLg bits of a UMI of <= 32 bits; linear too)
 
 __device__ __forceinline__ uint32_t wg_add(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ uint32_t wg_min(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -260,6 +263,9 @@ __global__ __launch_bounds__(NT) void k_p2_scatter(P2Args A) {
     }
 }
 
+// (LDS instructions of one wave execute in order; WAVE_SYNC only keeps the compiler from moving code across.)
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // 2. one wave per partition: reads sorted by (label key, UMI, record offset) in registers -> vertices.
 //    Vertex i of the partition takes read slot i of the partition: s_h = label key, s_u = umi << 32 | word
@@ -371,7 +377,6 @@ __global__ __launch_bounds__(256) void k_p2_part(P2Args A) {
 //    if the labels share a ref.
 // (Four partitions to a 256-thread workgroup, a wave each with its own slice of LDS and nothing shared: no workgroup barrier;
 // LDS instructions of one wave execute in order, WAVE_SYNC only keeps the compiler from moving code across.)
-#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
 struct SearchLds {
     uint32_t umi[kP2TabSlots];
@@ -985,34 +990,38 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
     }
     gsync();
     G_MARK(2);
-    // ---- 2. weakly connected components over the pair list: min-label propagation + pointer jumping (labels in LDS when they fit) ----
+    // ---- 2. weakly connected components over the pair list: union-find with compare-and-swap hooking (parents in LDS when they
+    //         fit, else in the pool through workgroup-scope L2 atomics).  A root is only ever hooked under a SMALLER vertex, so
+    //         the parent pointers cannot close a cycle; find() shortens the path it walks (a racing shortcut still points at an
+    //         ancestor).  ONE pass over the pairs and one barrier - rounds 3-4 swept the pairs until no label moved, four
+    //         pointer-jumping sweeps and six barriers per sweep (a fifth of this kernel on the largest cells) ----
     const bool wl_lds = NT <= GLds;
     uint32_t* wl = wl_lds ? s_big : wlg;
-    auto ldw = [&](uint32_t i) -> uint32_t { return wl_lds ? wl[i] : ld_l2(&wl[i]); };
+    auto ldw = [&](uint32_t i) -> uint32_t { return wl_lds ? __hip_atomic_load(&wl[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : ld_l2(&wl[i]); };
     for (uint32_t i = tid; i < NT; i += GNT) { if (wl_lds) wl[i] = i; else st_l2(&wl[i], i); st_l2(&rcnt[i], 0u); st_l2(&fill[i], 0u); }
     gsync();
-    for (;;) {
-        gsync();   // (every thread has read the previous sweep's flag before it is cleared: without this barrier a wave that
-                   //  lagged a few cycles behind thread 0 read the cleared flag, left the loop alone and took every barrier
-                   //  after it out of step - one run in two failed somewhere, never in the same place)
-        if (tid == 0) s_flag[0] = 0;
-        gsync();
-        bool chg = false;
+    {
+        auto find = [&](uint32_t i) -> uint32_t {
+            uint32_t p = ldw(i);
+            while (p != i) {
+                const uint32_t gp2 = ldw(p);
+                if (gp2 != p) wg_min(&wl[i], gp2);   // path halving (a min: never lengthens a path another thread just shortened)
+                i = p; p = gp2;
+            }
+            return i;
+        };
         for (uint32_t k = tid; k < n_pairs; k += GNT) {
             const uint64_t e = lp[k];
-            const uint32_t x = (uint32_t)e & 0xFFFFFFu, y = (uint32_t)(e >> 24) & 0xFFFFFFu;
-            const uint32_t a = ldw(x), b = ldw(y);
-            if (a < b) { wg_min(&wl[y], a); chg = true; }
-            else if (b < a) { wg_min(&wl[x], b); chg = true; }
+            uint32_t a = find((uint32_t)e & 0xFFFFFFu), b = find((uint32_t)(e >> 24) & 0xFFFFFFu);
+            while (a != b) {
+                if (a < b) { const uint32_t t = a; a = b; b = t; }   // the larger root goes under the smaller
+                uint32_t expected = a;
+                if (__hip_atomic_compare_exchange_strong(&wl[a], &expected, b, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                a = find(expected); b = find(b);   // (a had been hooked by somebody else meanwhile: go on from where it hangs now)
+            }
         }
-        if (chg) s_flag[0] = 1;
-        gsync();
-        for (int it = 0; it < 4; ++it) {
-            for (uint32_t i = tid; i < NT; i += GNT) { const uint32_t l = ldw(i); const uint32_t ll = ldw(l); if (ll < l) { if (wl_lds) wl[i] = ll; else st_l2(&wl[i], ll); } }
-            gsync();
-        }
-        if (!s_flag[0]) break;
     }
+    gsync();
     G_MARK(3);
     // ---- 3. the components by counting: sizes per root, then by size pairs / 3..8 / 9..64 / 65..4096 (anything else - a
     //         component of more than 4096 vertices that is still under --large-graph-thresh - is not for this kernel), every

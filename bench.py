@@ -264,6 +264,23 @@ def roofline_of(ktimes, alg_bytes, steps, traffic_tag, ms_per_step=None):
             "all_kernels_ms_per_step": {k: round(v[0] / steps, 4) for k, v in ktimes.items()}}
 
 
+def legs_summary(legs):
+    """{leg: [value, ms_per_step, roofline.frac, roofline.frac_step]} for the legs that were timed, {leg: "error: ..."} /
+    {leg: "skipped: ..."} for the others: what a reader who only has the tail of the line needs of every leg."""
+    s = {}
+    for name, o in legs.items():
+        if not isinstance(o, dict):
+            s[name] = None
+        elif "error" in o:
+            s[name] = "error: " + str(o["error"])[:80]
+        elif "skipped" in o:
+            s[name] = "skipped: " + str(o["skipped"])[:60]
+        else:
+            r = o.get("roofline") or {}
+            s[name] = [o.get("value"), o.get("ms_per_step", o.get("wall_s")), r.get("frac"), r.get("frac_step")]
+    return s
+
+
 # ---------------------------------------------------------------------------------------------------------
 # Where the submitting thread runs.  The host side of a step - planning, the pinned arena, reading the packed status, the row
 # pointers - talks to the device over PCIe; from the CPUs of the socket the GPU does not hang off, a configs[1] step was
@@ -812,6 +829,9 @@ def main():
         if D.rank == 0 and out is not None:
             if legs:
                 out["also"] = legs
+                # The line is ~20 KB and a log keeps its tail: the last key is a few hundred bytes with every leg's
+                # [value (M reads/s, atac: M fragments/s), ms per step, roofline.frac, roofline.frac_step] - or its error / skip reason.
+                out["legs"] = legs_summary(legs)
             print(json.dumps(out), flush=True)
     finally:
         if q is not None:

@@ -21,7 +21,7 @@ leg() {   # name, bench flags...
 }
 leg configs2 --workload configs2
 leg configs2_tail --workload configs2 --na-model tail
-leg configs3 --workload configs3
+# configs3 is retaken with all legs at the end of the round (profiles/run_r05_final.sh)
 cd "$GRAFT_REPO_ROOT"
 if [ -f alevin-fry_amd/csrc/libafquant_timing.so ]; then
   AFQ_LIB_PATH=$GRAFT_REPO_ROOT/alevin-fry_amd/csrc/libafquant_timing.so timeout 300 python bench.py --workload configs2 --na-model tail --steps 1 --warmup 0 --also none --no-cpu-baseline > $O/tail_clocks.txt 2> $O/tail_clocks.err

@@ -8,8 +8,9 @@ from collections import defaultdict
 
 
 def short(name):
-    n = name.split("(")[0].replace("void ", "").replace("afq::", "")
-    return n
+    # "void afq::(anonymous namespace)::k_atac_parse(afq::AtacArgs)": the namespace's parenthesis is not the argument list's
+    n = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("afq::", "")
+    return n.strip() or name
 
 
 def main(tag):

@@ -9,7 +9,8 @@ from collections import defaultdict
 
 
 def short(name):
-    return name.split("(")[0].replace("void ", "").replace("afq::", "").split("<")[0]
+    n = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("afq::", "").split("<")[0].strip()
+    return n or name
 
 
 def per_launch(db_path, counter, totals=None):

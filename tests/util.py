@@ -40,3 +40,63 @@ def assert_same_result(a, b, exact=True, rtol=0.0, what=""):
 
 def cfg_for(s, resolution="cr-like", **kw):
     return pkg.WorkerConfig.for_resolution(resolution, usa_mode=s.usa, num_genes=s.num_genes, num_rows=s.num_rows, **kw)
+
+
+EM_FLOOR = 0.01   # em.rs:568-572: abundances below it leave the row
+
+
+def em_row_differences(row_a, row_b):
+    """Two EM rows (columns ascending, values above the 0.01 output floor of em.rs:568-572) entry by entry:
+    (entries, entries of both rows beyond 1e-4 relative, entries only one row holds, those of them whose surviving value is more
+    than 1e-4 above the floor, largest relative difference of the common entries).  An entry only one row holds crossed the floor;
+    when the survivor is within 1e-4 of 0.01 the two abundances are as close as north_star asks wherever the other one lies
+    in [0.01 (1 - 1e-4), 0.01) - a crossing further up is a real difference."""
+    (g0, v0), (g1, v1) = row_a, row_b
+    cols = np.union1d(g0, g1)
+    a = np.zeros(len(cols), np.float64)
+    b = np.zeros(len(cols), np.float64)
+    a[np.searchsorted(cols, g0)] = v0
+    b[np.searchsorted(cols, g1)] = v1
+    both = (a > 0) & (b > 0)
+    rel = np.abs(a[both] - b[both]) / np.maximum(a[both], b[both])
+    one = (a == 0) != (b == 0)
+    off = one & (np.maximum(a, b) > EM_FLOOR * (1 + 1e-4))
+    return len(cols), int((rel > 1e-4).sum()), int(one.sum()), int(off.sum()), float(rel.max()) if len(rel) else 0.0
+
+
+def assert_em_within_the_reference_envelope(got, oracle_module, cfg, tid_to_gid, data, offs, rows_of_got=None, n_threads=None, what=""):
+    """north_star's bar for the EM resolutions, at any size: the device rows against the oracle IN THE REFERENCE'S ARITHMETIC
+    (f32 sums, canonical class order; oracle/afq_oracle.cpp em_update <- src/em.rs:189-248, 455-533).  The reference itself
+    sums its classes in a HashMap's order (em.rs:464), so two of its own runs can leave an entry on either side of the 0.01
+    output floor, or - when a cell's round count changes with it - apart by more than 1e-4.  That envelope is MEASURED here, on
+    the same cells: the oracle under three shuffled class orders against its canonical order.  The device must stay inside it:
+    no more entries beyond 1e-4 and no more floor crossings away from the floor than the reference's own reorderings produce
+    (0 and 0 on every sample seen so far); crossings AT the floor (survivor within 1e-4 of 0.01) are within the tolerance and
+    are reported.  Returns the counts."""
+    n_threads = n_threads or os.cpu_count() or 8
+    want = oracle_module.quant(cfg, tid_to_gid, data, offs, n_threads=n_threads, em_arith="reference")
+    n = want.n_cells
+    rows = rows_of_got if rows_of_got is not None else [got.row(j) for j in range(n)]
+
+    def tally(rows_x):
+        t = np.zeros(5)
+        for j in range(n):
+            e, far, cross, off, mx = em_row_differences(rows_x[j], want.row(j))
+            t[:4] += (e, far, cross, off)
+            t[4] = max(t[4], mx)
+        return t
+
+    dev = tally(rows)
+    env = np.zeros(5)
+    for seed in (11, 12, 13):
+        perm = oracle_module.quant(cfg, tid_to_gid, data, offs, n_threads=n_threads, em_arith="reference", em_order_seed=seed)
+        t = tally([perm.row(j) for j in range(n)])
+        env[:4] += t[:4]
+        env[4] = max(env[4], t[4])
+    out = {"entries": int(dev[0]), "device_beyond_1e-4_rel": int(dev[1]), "device_floor_crossings": int(dev[2]),
+           "device_floor_crossings_off_the_floor": int(dev[3]), "device_max_rel_diff": dev[4],
+           "beyond_1e-4_allowed_by_shuffle_envelope": int(env[1]), "floor_crossings_of_the_shuffle_envelope": int(env[2]),
+           "floor_crossings_off_the_floor_allowed_by_shuffle_envelope": int(env[3]), "envelope_max_rel_diff": env[4]}
+    assert out["device_beyond_1e-4_rel"] <= out["beyond_1e-4_allowed_by_shuffle_envelope"], f"{what} {out}"
+    assert out["device_floor_crossings_off_the_floor"] <= out["floor_crossings_off_the_floor_allowed_by_shuffle_envelope"], f"{what} {out}"
+    return out
