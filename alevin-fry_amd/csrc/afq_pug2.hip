@@ -47,7 +47,7 @@ typedef unsigned __int128 u128;
 constexpr uint32_t kP2Bins = 2048;        // partitions per cell the tile kernels rank in LDS
 constexpr uint32_t kP2TabSlots = 512;     // hash table of one partition's vertices (<= 256)
 #ifndef AFQ_P2_FILT_LG
-#define AFQ_P2_FILT_LG 12
+#define AFQ_P2_FILT_LG 13
 #endif
 constexpr uint32_t kP2FiltLg = AFQ_P2_FILT_LG, kP2FiltBits = 1u << kP2FiltLg;    // presence filter in front of it
 constexpr uint32_t kVCntMask = 0x3FFu;    // vertex word: reads (10 bits) | label signature (19 bits) << 10 | key tag << 29

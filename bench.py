@@ -77,6 +77,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) by default; gloo + --share-gpu exercises the N>1 logic on a 1-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0")
+    ap.add_argument("--plan-only", action="store_true",
+                    help="no kernels: every rank prints the device bytes each leg would hold against the free memory of its GPU, the host its pinned "
+                         "total against MemAvailable; exit code 0 when everything fits, 1 otherwise (the first thing to run on an 8-GPU node)")
     return ap.parse_args()
 
 
@@ -92,10 +95,22 @@ def spawn_ranks(args):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    # A rank that dies (no such GPU, hipSetDevice failed, out of memory) must not leave the others waiting at a barrier for the
+    # process group's timeout: the first non-zero exit ends the job - the others are stopped by their exact pids.
     rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            r = p.poll()
+            if r is None:
+                continue
+            alive.remove(p)
+            if r != 0 and rc == 0:
+                rc = r
+                print(f"[bench] rank {procs.index(p)} exited with code {r}: stopping the other {len(alive)} rank(s)", file=sys.stderr, flush=True)
+                for q in alive:
+                    q.terminate()
     sys.exit(rc)
 
 
@@ -112,7 +127,11 @@ class Dist:
         if self.local_rank >= ndev:
             raise SystemExit(f"rank {self.rank}: no GPU {self.local_rank} on this box ({ndev} visible); --share-gpu shares cuda:0 for testing")
         self.dev = torch.device("cuda", self.local_rank)
-        torch.cuda.set_device(self.local_rank)
+        try:
+            torch.cuda.set_device(self.local_rank)
+            torch.cuda.mem_get_info(self.local_rank)   # (the first call that really talks to the device)
+        except Exception as e:   # one clear line instead of a barrier the other ranks would hang in
+            raise SystemExit(f"rank {self.rank}: GPU {self.local_rank} cannot be used ({type(e).__name__}: {str(e)[:200]})")
         self.dist = None
         if self.world > 1:
             import torch.distributed as dist
@@ -707,6 +726,103 @@ def run_reference_binary(rad_dir, tg, rad, workdir, res_rows=None):
 
 
 # ---------------------------------------------------------------------------------------------------------
+def plan_only(D, args):
+    """bench.py --gpus N --plan-only: what every leg of this command would hold on this rank's GPU and in pinned host memory,
+    against what is there - without generating a byte or launching a kernel.  The input sizes are exact (the generator's own
+    planner, afq_synth_host_plan, over the cells this rank would make); the library's side mirrors plan_ranges (csrc/afq_api.cpp):
+    it sizes a range to 40 % of the memory that is free once the input is resident and keeps two range buffer sets alive, so a leg
+    fits when its input leaves room for its largest cell's buffers twice over - the figure printed is the library's need for the
+    WHOLE leg (what it would take if memory were no object) and what it will actually take.  Every rank prints one JSON line; rank 0
+    adds the host's pinned total against MemAvailable.  Returns the exit code: 0 = every leg fits on every rank."""
+    import ctypes as C
+
+    import numpy as np
+
+    sn = importlib.import_module("alevin-fry_amd.synth_native")
+    shard = importlib.import_module("alevin-fry_amd.shard")
+    free_b, total_b = D.torch.cuda.mem_get_info(D.local_rank)
+    lib = sn._lib()
+
+    def planned(p, sizes, c0, c1):
+        nrec = np.ascontiguousarray(sizes[c0:c1])
+        off = np.zeros(len(nrec), np.uint64)
+        tb = C.c_uint64()
+        r = lib.afq_synth_host_plan(C.byref(p), c0, len(nrec), nrec.ctypes.data_as(C.POINTER(C.c_uint32)), off.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(tb))
+        if r:
+            raise RuntimeError(f"afq_synth_host_plan failed ({r})")
+        reads = int(nrec.astype(np.int64).sum())
+        n_ref = (int(tb.value) - 8 * len(nrec) - 12 * reads) // 4     # records are 12 header bytes + 4 per alignment
+        return int(tb.value), reads, n_ref, int(nrec.max()) if len(nrec) else 0
+
+    def lib_need(reads, n_ref, usa, resolution):   # plan_ranges' `need`, summed over the leg's cells
+        em = resolution.endswith("-em")
+        pug = resolution.startswith("parsimony")
+        nd = ((24.0 + 40.0 * (3 if usa else 1)) if em else 16.0) * n_ref
+        if pug:
+            nd += 148.0 * reads
+        return nd * 1.1   # (+ bucket tables and slabs: a few per cent)
+
+    legs = {}
+    names = [args.workload] + ([] if args.also == "none" else (["configs2", "configs1_tail", "configs2_tail", "configs3", "atac", "e2e"] if D.world == 1 else ["e2e", "configs3", "atac"]))
+    pinned = 0
+    for name in dict.fromkeys(names):
+        if name == "atac":
+            inp = int(args.atac_cells) * int(args.frags_per_cell) * 19   # ~19 bytes per record of the scATAC chunks
+            need = 2.0 * inp
+            legs[name] = {"input_bytes": inp, "library_need_bytes": int(need)}
+            continue
+        if name == "e2e":
+            base = legs.get("configs1")
+            if base:
+                legs[name] = {"input_bytes": 0, "library_need_bytes": base["library_need_bytes"], "pinned_host_bytes": base["input_bytes"]}
+                pinned = base["input_bytes"]
+            continue
+        if name == "configs3":
+            n_total = args.c3_cells * (D.world if args.scaling == "weak" else 1)
+            sigma = 0.6
+            kw = synth_kw(args, False)
+            kw.update(median_reads=args.c3_mean_reads / float(np.exp(sigma * sigma / 2)), sigma=sigma)
+            p = sn.params(seed=4, n_cells=n_total, **kw)
+            sizes = sn.cell_sizes(p)
+            c0, c1 = shard.shard_ranges(sizes.astype(np.float64) * 17.5 + 8, D.world)[D.rank]
+            usa, res = False, "cr-like"
+        else:
+            tail = name.endswith("_tail") or (name == args.workload and args.na_model == "tail")
+            usa = name.startswith("configs2") or (name == args.workload and args.usa)
+            res = "parsimony-em" if name.startswith("configs2") else (args.resolution or "cr-like")
+            p = sn.params(seed=2 + D.rank, n_cells=args.cells, **synth_kw(args, usa, tail))
+            sizes = sn.cell_sizes(p)
+            c0, c1 = 0, args.cells
+        inp, reads, n_ref, largest = planned(p, sizes, c0, c1)
+        legs[name] = {"input_bytes": inp, "reads": reads, "library_need_bytes": int(lib_need(reads, n_ref, usa, res)), "resolution": res}
+    ok = True
+    for name, leg in legs.items():
+        room = free_b - leg["input_bytes"]
+        takes = min(leg["library_need_bytes"], int(0.8 * max(0, room)))          # two range buffer sets of <= 40 % of what is free each
+        leg["resident_peak_bytes"] = leg["input_bytes"] + takes
+        leg["ranges_at_least"] = max(1, int(np.ceil(leg["library_need_bytes"] / max(1.0, 0.4 * room)))) if room > 0 else None
+        leg["fits"] = bool(room > 0 and leg["library_need_bytes"] / max(1, leg.get("reads", 1)) * 300000 < 0.4 * room)   # a 300 k-read cell's buffers fit one set
+        ok = ok and leg["fits"]
+    out = {"plan_only": True, "rank": D.rank, "world": D.world, "device": D.local_rank, "device_free_bytes": int(free_b), "device_total_bytes": int(total_b),
+           "legs": legs, "fits": ok}
+    pinned_all = D.reduce([pinned + 0.3e9], "sum")[0]   # + every rank's pinned result pool
+    all_ok = D.reduce([1.0 if ok else 0.0], "sum")[0] == D.world
+    if D.rank == 0:
+        avail = None
+        try:
+            for ln in open("/proc/meminfo"):
+                if ln.startswith("MemAvailable:"):
+                    avail = int(ln.split()[1]) * 1024
+        except OSError:
+            pass
+        out["host"] = {"pinned_bytes_all_ranks": int(pinned_all), "mem_available_bytes": avail, "fits": bool(avail is None or pinned_all < 0.8 * avail)}
+        all_ok = all_ok and out["host"]["fits"]
+    print(json.dumps(out), flush=True)
+    D.close()
+    return 0 if all_ok else 1
+
+
+# ---------------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -715,6 +831,8 @@ def main():
     import torch  # (imported before libafquant.so: one HIP runtime per process)
 
     D = Dist(args, torch)
+    if args.plan_only:
+        sys.exit(plan_only(D, args))
     numa_node = bind_to_device_node(torch, D.local_rank)
     pkg = importlib.import_module("alevin-fry_amd")
     sn = importlib.import_module("alevin-fry_amd.synth_native")

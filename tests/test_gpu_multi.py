@@ -308,6 +308,28 @@ def test_bench_spawns_its_own_ranks():
     assert "error" not in e2e and e2e["n_gpus"] == 2 and e2e["value"] > 0 and e2e["imbalance_max_over_mean_time"] >= 1.0
 
 
+def test_bench_plan_only_prints_every_ranks_memory_plan():
+    """`bench.py --gpus N --plan-only` (the first thing to run on an 8-GPU node): no kernel, every rank one JSON line with the bytes
+    each leg would hold against its GPU's free memory, rank 0 the host's pinned total against MemAvailable; exit code 0 = it fits."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--dist-backend", "gloo", "--plan-only"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert sorted(l["rank"] for l in lines) == [0, 1] and all(l["plan_only"] and l["fits"] for l in lines)
+    l0 = [l for l in lines if l["rank"] == 0][0]
+    assert l0["host"]["fits"] and l0["host"]["pinned_bytes_all_ranks"] > 2 * 6e9          # two ranks' e2e buffers
+    c1, c3 = l0["legs"]["configs1"], l0["legs"]["configs3"]
+    assert 6.5e9 < c1["input_bytes"] < 7.3e9 and 3.5e8 < c1["reads"] < 4.5e8              # the headline's sample, to the byte the generator would make
+    assert 4.0e10 < c3["input_bytes"] < 4.8e10 and c3["resident_peak_bytes"] < l0["device_total_bytes"]
+    # a rank without a device ends the job with one line instead of a barrier the others hang in
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--plan-only"]   # (no --share-gpu: rank 1 asks for cuda:1)
+    import torch
+    if torch.cuda.device_count() == 1:
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode != 0 and "no GPU 1" in r.stderr and "stopping the other" in r.stderr
+
+
 def test_bench_eight_ranks_bookkeeping_on_one_gpu():
     """The driver's `--gpus 8` shape on the one GPU a box has: eight ranks (gloo, all on cuda:0), the configs[3] data set cut into
     eight byte-balanced ranges with every rank generating and checking its own, the e2e and atac legs' collectives made by all
