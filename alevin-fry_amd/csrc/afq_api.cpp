@@ -904,6 +904,10 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
                 p2.tile = p2_tile;
                 p2.n_big = 0;
                 while (p2.n_big < n_p2 && p2cells[p2.n_big].R >= big_reads) ++p2.n_big;   // (p2cells is largest first)
+                p2.defer_min = [] { const char* e = std::getenv("AFQ_P2_DEFER_MIN"); return e ? (uint32_t)std::max(0L, std::atol(e)) : 0xFFFFFFFFu; }();   // (tests: 0 = every cell takes the set-aside route)
+                p2.n_huge = 0;
+                const uint32_t huge_reads = big_reads < 25000u ? big_reads : std::max(100000u, big_reads);   // (a test that lowers the one threshold means both instances)
+                while (p2.n_huge < p2.n_big && p2cells[p2.n_huge].R >= huge_reads) ++p2.n_huge;
             }
             // k_p2_lone, labels over four refs: 0: by the vertex's lane alone, in scratch memory (rounds 3-4); 1: labels of 5..64 refs by the
             // wave; 2: 5..8 by the lane in eight registers, 9..64 by the wave - an instance of 86 instead of 69 VGPRs, five waves per SIMD

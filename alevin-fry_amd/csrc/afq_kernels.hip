@@ -483,16 +483,6 @@ __device__ __forceinline__ void resolve_bucket_lds(const BucketDesc& d, uint64_t
 }
 
 
-// The sort path as k_resolve calls it: a call, not an inlined body.  Nearly every bucket is finished by one of the hash paths; with
-// the sort inlined behind them the kernel kept the scalars of all three paths alive together (127 SGPRs spilled).
-template <int NT>
-__device__ __attribute__((noinline)) void resolve_bucket_lds_call(const BucketDesc& d, uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
-                                                                  uint32_t* __restrict__ cell_ncols, uint32_t* __restrict__ nnz, DevStatus* st,
-                                                                  const ResolveCfg& rc, const LabArea& la, uint64_t* s_keys, uint16_t* s_run, uint32_t* s_cols,
-                                                                  uint32_t* s_lab, uint32_t* s_ldesc, uint32_t* s_ws, uint32_t* s_misc) {
-    resolve_bucket_lds<NT>(d, keys0, keys1, cell_ncols, nnz, st, rc, la, s_keys, s_run, s_cols, s_lab, s_ldesc, s_ws, s_misc);
-}
-
 // ---- hash-table resolution of a cr-like bucket (one wave) ----
 // A bucket holds every (umi, gene) key of the UMIs that hash to it, so the winner-take-all rule needs no
 // order, only grouping: the wave inserts its keys into an LDS open-addressing table keyed by UMI whose slots
@@ -767,6 +757,8 @@ __device__ __forceinline__ bool resolve_bucket_hash(const uint64_t* __restrict__
 // of those are spliced, the smallest winner, the smallest spliced winner, and whether an unspliced winner's spliced sibling
 // is a winner too.  The lane that claimed a UMI's T2 slot emits its column.  cr-like only (cr-like-em wants the winners as a list).
 constexpr uint32_t kH2Cap = kHtKeys + kHtKeys / 2;
+static_assert(kHtKeys < (1u << 10), "resolve_bucket_hash2 packs a UMI's winner count and its spliced-winner count into 10-bit fields of agg");
+static_assert(kHtKeys < (1u << 12), "... and the reads of a (UMI, gene) pair into 12 bits of the T1 / T2 words");
 constexpr uint32_t kH2Words = 2 * kH2Cap /* T1 */ + 2 * kH2Cap /* T2 key | max */ + 3 * kH2Cap /* agg, gmin, smin */ + kHtKeys /* columns */;
 __device__ __forceinline__ bool resolve_bucket_hash2(const uint64_t* __restrict__ src, uint32_t n, const ResolveCfg& rc, uint32_t* s_raw,
                                                      DevStatus* st, uint32_t cell, uint32_t& nc_out, uint32_t*& s_cols_out) {
@@ -955,11 +947,8 @@ __global__ __launch_bounds__(kResolveNT) void k_resolve(const BucketDesc* __rest
         }
         __syncthreads();
     }
-#ifdef AFQ_RESOLVE_SORT_CALL
-    resolve_bucket_lds_call<kResolveNT>(d, keys0, keys1, cell_ncols, nnz, st, rc, la, s_keys, s_run, s_cols, s_lab, s_ldesc, s_ws, s_misc);
-#else
-    resolve_bucket_lds<kResolveNT>(d, keys0, keys1, cell_ncols, nnz, st, rc, la, s_keys, s_run, s_cols, s_lab, s_ldesc, s_ws, s_misc);
-#endif
+    resolve_bucket_lds<kResolveNT>(d, keys0, keys1, cell_ncols, nnz, st, rc, la, s_keys, s_run, s_cols, s_lab, s_ldesc, s_ws,
+                                   s_misc);
 }
 
 // Buckets over the 2-wave cap but within LDS reach (<= kMidCap keys): persistent

@@ -949,7 +949,7 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
     }
     if (NT > 2 * n_pairs || NT >= (1u << 24)) { if (tid == 0) set_err(A.st, kErrPugLimit, c.cell); return; }   // (cannot happen: two end points per pair, R < 2^22)
     const uint32_t nt_max = NT;
-    q = pool_take(9ull * NT + 16);
+    q = pool_take(9ull * NT + 18);
     if (!q) return;
     uint32_t* tl = q; q += nt_max;            // touched vertex -> its slot in the cell
     uint32_t* wlg = q; q += nt_max;           // component labels when they do not fit LDS
@@ -958,7 +958,7 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
     uint32_t* fill = q; q += nt_max;          // per root: next free slot of its component; afterwards, per vertex:
     uint32_t* cidx = fill;                    // ... its position inside its component (reference order)
     uint32_t* lsize = q; q += nt_max + 2;     // per listed component: size
-    uint32_t* mid_off = q; q += nt_max + 10;  // ... first slot (and behind the last one eight words for the cover kernel: see the end)
+    uint32_t* mid_off = q; q += nt_max + 12;  // ... first slot (and behind the last one ten words for the cover kernels: see the end)
     uint32_t* pr_v = q; q += nt_max + 2;      // two-vertex components: their vertices, two by two
     {
         uint32_t carry = 0;
@@ -1087,12 +1087,25 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
         uint32_t tot;
         const uint32_t ex = block_excl_scan<GNT>(n, s_ws, tot);
         if (ci < n_all) mid_off[ci] = S_mid + ex;
+        if (ci == n_mid && ci < n_all) s_flag[0] = S_mid + ex;   // the first slot of the components of more than 64 vertices
         S_mid += tot;
     }
     if (tid == 0) mid_off[n_all] = S_mid;
+    gsync();
+    // The reference's vertex order inside a component only decides TIES between equal-size arborescences.  Components of up to
+    // 64 vertices are therefore covered in whatever order their vertices took their slots (k_p2_cover), a component is set
+    // aside at the first round that does meet a tie, and k_p2_tied finds the class minima for those alone - one in a dozen -
+    // and finishes them in the reference's order.  The components of more than 64 vertices (rare; cover_big has no notion of
+    // being set aside) still get their order here: S_lo.. are their slots.
+    // A cell whose classes fit the LDS table keeps round 4's way (every listed component ordered here, the covers in that order):
+    // setting aside costs a kernel of its own with a chain of dependent steps per cell (k_p2_tied) - a third of the components of
+    // three or more vertices meet a tie - and only pays where the class step is expensive: the big cells of a sample and every
+    // cell whose reads carry long labels, whose classes go to a table in the pool (measured, profiles/round5_05_tied.txt).
+    const bool defer = S_mid > (A.defer_min == 0xFFFFFFFFu ? GTabLoad : A.defer_min);
+    const uint32_t S_lo = !defer ? 0u : n_bigc ? s_flag[0] : S_mid;
     // per slot of a listed component: its vertex, its component, its class minimum; and one region that first holds the class
     // table (when it does not fit LDS) and then the order keys, adjacency masks and cover records (12 words per slot)
-    const uint32_t want = S_mid;   // (vertices: an upper bound of the classes the table will hold)
+    const uint32_t want = S_mid - S_lo;   // (vertices: an upper bound of the classes the table will hold)
     constexpr uint32_t kPoolTab = 1u << 16;
     uint32_t cap = GTab, n_slices = 1;
     if (want > GTabLoad) {   // at most 2^16 pool slots at a time: a cell with more classes takes the key space in slices, a pass per slice
@@ -1100,7 +1113,7 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
         while (cap < kPoolTab && (uint64_t)cap * n_slices < 5ull * want / 2) cap <<= 1;
     }
     const unsigned long long u_words = std::max<unsigned long long>(want > GTabLoad ? 3ull * cap + 4 : 0ull, 12ull * S_mid + 8);
-    q = pool_take(3ull * S_mid + 8 + u_words);
+    q = pool_take(3ull * S_mid + 8 + u_words + 4ull * n_mid + 16);
     if (!q) return;
     uint32_t* slot_v = q; q += S_mid + 2;       // slot -> vertex
     uint32_t* slot_comp = q; q += S_mid + 2;    // slot -> listed component
@@ -1111,6 +1124,9 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
     uint4* mrec = reinterpret_cast<uint4*>(u_base);                                   // [2 * S_mid]
     uint64_t* okey = reinterpret_cast<uint64_t*>(u_base + 8 * (size_t)S_mid);         // [S_mid] (class minimum, UMI)
     unsigned long long* adjp = reinterpret_cast<unsigned long long*>(u_base + 10 * (size_t)S_mid);   // [S_mid] out-neighbours of the vertex at this position, as positions inside its component
+    // the components k_p2_cover sets aside at a tie: two counters (3..8 vertices, 9..64), then four words per component
+    // (list index, the vertices still uncovered as a 64-bit mask over its slots, a running key count for k_p2_tied's batches)
+    uint32_t* const tied = u_base + ((u_words + 3) & ~3ull);
     // components of more than 64 vertices: their adjacency as rows of ceil(n / 64) mask words, n rows each, in a region of its own;
     // where a component's rows start (in 64-bit words) takes over its entry of lsize[], which is read for the last time above
     uint32_t* const rowoff = lsize + n_mid;
@@ -1152,7 +1168,7 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
     //         for one class - the partition kernel compares the reads it merges into a vertex, the search compares labels
     //         under hashed keys by content.  The pass over every hashed vertex of the cell that used to sit here was a
     //         third of this phase.) ----
-    if (S_mid) {
+    if (want) {
         // the table: in LDS when the classes are few; else in the pool region taken above
         unsigned long long* t_key = reinterpret_cast<unsigned long long*>(s_big);
         uint32_t* t_min = s_big + 2 * GTab;
@@ -1188,7 +1204,7 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
             gsync();
             // (Every loop below takes four to six items per thread and level: the loads and L2 atomics of a level go out together and
             //  are waited for once.  One item at a time, a thread went through five dependent round trips per vertex.)
-            for (uint32_t s0 = tid; s0 - tid < S_mid; s0 += 4 * GNT) {   // the classes that are asked for
+            for (uint32_t s0 = S_lo + tid; s0 - tid < S_mid; s0 += 4 * GNT) {   // the classes that are asked for
                 uint32_t v4[4];
                 uint64_t h4[4];
 #pragma unroll
@@ -1242,7 +1258,7 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
                         !lab_equal(rec_label(C, off4[r]), rec_label(C, old4[r]))) s_cnt[3] = kErrLabelHash;
             }
             gsync();
-            for (uint32_t s0 = tid; s0 - tid < S_mid; s0 += 4 * GNT) {
+            for (uint32_t s0 = S_lo + tid; s0 - tid < S_mid; s0 += 4 * GNT) {
                 uint32_t v4[4], sl4[4];
                 uint64_t h4[4];
                 unsigned long long k4[4];
@@ -1274,11 +1290,12 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
     G_MARK(6);
     // ---- 6. components of 3..64 vertices: their vertices in the reference's order (class by first appearance = smallest
     //         record offset, then UMI), the edges between them as masks over those positions, gathered into the covers' records ----
-    for (uint32_t s2 = tid; s2 < S_mid; s2 += GNT) okey[s2] = ((uint64_t)cmin[s2] << 32) | (uint32_t)(cu[tl[slot_v[s2]]] >> 32);
+    for (uint32_t s2 = S_lo + tid; s2 < S_mid; s2 += GNT) okey[s2] = ((uint64_t)cmin[s2] << 32) | (uint32_t)(cu[tl[slot_v[s2]]] >> 32);
     gsync();
     for (uint32_t s2 = tid; s2 < S_mid; s2 += GNT) {
         const uint32_t ci = slot_comp[s2];
         const uint32_t b0 = mid_off[ci], n = mid_off[ci + 1] - b0;
+        if (s2 < S_lo) { cidx[slot_v[s2]] = s2 - b0; continue; }   // (up to 64 vertices: the slot order; k_p2_tied reorders the few that need it)
         const uint64_t mine = okey[s2];
         uint32_t rank = 0;
         uint32_t same = 0;
@@ -1347,8 +1364,13 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
             mid_off[n_all + 3] = (uint32_t)oo; mid_off[n_all + 4] = (uint32_t)(oo >> 32);
             mid_off[n_all + 5] = n_large; mid_off[n_all + 6] = (uint32_t)lo; mid_off[n_all + 7] = (uint32_t)(lo >> 32);
         }
+        {
+            const unsigned long long to = (unsigned long long)(tied - A.pool);
+            mid_off[n_all + 8] = (uint32_t)to; mid_off[n_all + 9] = (uint32_t)(to >> 32);
+            tied[0] = 0; tied[1] = 0;
+        }
         d[12] = s_cnt[0]; d[13] = s_cnt[1]; d[14] = s_cnt[2];
-        d[0] = 1;
+        d[0] = defer ? 3u : 1u;   // bit 0: the lists are there; bit 1: components of up to 64 vertices lie in slot order (kCoverDefer)
     }
   }
 }
@@ -1468,7 +1490,7 @@ __device__ __forceinline__ bool cover_large(const P2Args& A, const PugCtx& C, co
 }
 
 template <int CNT>
-__global__ __launch_bounds__(CNT) void k_p2_cover(P2Args A, uint32_t work_lo, uint32_t work_hi, uint32_t* counter) {
+__global__ __launch_bounds__(CNT, CNT == 256 ? 4 : 1) void k_p2_cover(P2Args A, uint32_t work_lo, uint32_t work_hi, uint32_t* counter) {
     if (A.st->err_code) return;
     __shared__ uint32_t s_cnt[4];
     __shared__ uint32_t s_next;
@@ -1486,7 +1508,8 @@ __global__ __launch_bounds__(CNT) void k_p2_cover(P2Args A, uint32_t work_lo, ui
     if (work >= work_hi) return;
     const uint32_t j = A.order[work];
     const uint32_t* d = A.gdesc + 16 * (size_t)j;
-    if (d[0] != 1) continue;   // handed to the one-workgroup kernel, or failed (the error is set)
+    if (!(d[0] & 1u)) continue;   // handed to the one-workgroup kernel, or failed (the error is set)
+    const bool defer = (d[0] & 2u) != 0;
     const P2Cell c = A.cells[j];
     if (tid < 3) s_cnt[tid] = d[12 + tid];
     if (tid == 3) s_cnt[3] = 0;
@@ -1548,10 +1571,18 @@ __global__ __launch_bounds__(CNT) void k_p2_cover(P2Args A, uint32_t work_lo, ui
         append_cols(C, col);
         append_class2(C, cls, k0, k1);
     }
-    cover_tiny8<CNT / 64>(C, mrec, mid_off, n_tiny, wv, lane);
-    cover_wave64<CNT / 64>(C, mrec, mid_off, n_tiny, n_mid, wv, lane);
     const uint32_t n_bigc = d[15] & 0x7FFFFFFFu;
-    const uint32_t* x = mid_off + n_mid + n_bigc + 1;   // (eight words behind the list's last offset)
+    const uint32_t* x = mid_off + n_mid + n_bigc + 1;   // (ten words behind the list's last offset)
+    // The records of these components lie in slot order, not in the reference's: a round with ONE largest arborescence does not
+    // depend on the order; at the first round that meets a tie the component is set aside for k_p2_tied (afq_pug_common.h).
+    uint32_t* const tied = A.pool + (((unsigned long long)x[8] << 32) | x[7]);
+    if (defer) {
+        cover_tiny8<CNT / 64, kCoverDefer>(C, mrec, mid_off, n_tiny, wv, lane, tied, tied + 4);
+        cover_wave64<CNT / 64, kCoverDefer>(C, mrec, mid_off, n_tiny, n_mid, wv, lane, tied + 1, tied + 4 + 4 * (size_t)n_tiny);
+    } else {   // (the graph kernel ordered this cell's components itself)
+        cover_tiny8<CNT / 64>(C, mrec, mid_off, n_tiny, wv, lane);
+        cover_wave64<CNT / 64>(C, mrec, mid_off, n_tiny, n_mid, wv, lane);
+    }
     if (n_bigc) {   // 65..4096 vertices: the graph kernel left their adjacency as rows of mask words
         const uint64_t* rows = reinterpret_cast<const uint64_t*>(A.pool + (((unsigned long long)x[1] << 32) | x[0]));
         const uint32_t* rowoff = A.pool + (((unsigned long long)x[3] << 32) | x[2]);
@@ -1563,6 +1594,216 @@ __global__ __launch_bounds__(CNT) void k_p2_cover(P2Args A, uint32_t work_lo, ui
         __syncthreads();
         if (!cover_large<CNT>(A, C, c, tl, lg_off, lg_off + n_large + 2, n_large, s_ws, &s_nt, &s_ebase)) return;
     }
+    gsync();
+    if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], c.cell); return; }
+    if (tid == 0) {
+        A.cell_ncols[c.cell] = s_cnt[0];
+        if (A.lab_cnt) { A.lab_cnt[2 * c.cell] = s_cnt[1]; A.lab_cnt[2 * c.cell + 1] = s_cnt[2]; }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// 7. one workgroup per cell once more: the components k_p2_cover set aside because a round met a TIE between equal-size
+//    arborescences - there, and only there, the reference's vertex order decides (class by first appearance = smallest record
+//    offset of the label in the cell, then UMI; pugutils.rs:1090-1160 takes the first largest arborescence it meets).  Round 4
+//    found the class minima for EVERY vertex of every component of three or more vertices inside k_p2_graph - a third to a half of
+//    that kernel; a dozenth of the components need them.  Per batch of set-aside components (as many as the LDS table holds
+//    classes for): their uncovered vertices' label keys into the table, the cell's vertex slots streamed ONCE through it (the
+//    smallest record offset per asked-for class; a vertex under a HASHED key that hits an asked-for class is compared with the
+//    one that held the minimum before it - equal keys are thereby shown to be equal labels), then a wave per component puts its
+//    records into the reference's order (rank by (class minimum, UMI), adjacency masks and the uncovered mask renumbered).  The
+//    covers then RESUME them (kCoverResume) from where they stopped.
+template <int CNT>
+__global__ __launch_bounds__(CNT) void k_p2_tied(P2Args A, uint32_t work_lo, uint32_t work_hi, uint32_t* counter) {
+    if (A.st->err_code) return;
+    constexpr uint32_t TSlots = CNT >= 1024 ? 8192u : 4096u, TKeys = TSlots * 3 / 8, BloomWords = TSlots / 16;   // (a batch holds < TKeys + 64 classes: load <= 0.4)
+    __shared__ unsigned long long t_key[TSlots];
+    __shared__ uint32_t t_min[TSlots];
+    __shared__ uint32_t s_bloom[BloomWords];
+    __shared__ uint32_t s_cnt[4];
+    __shared__ uint32_t s_next;
+    __shared__ uint32_t s_ws[CNT / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) s_next = work_lo + atomicAdd(counter, 1u);
+    __syncthreads();
+    const uint32_t work = s_next;
+    if (work >= work_hi) return;
+    const uint32_t j = A.order[work];
+    const uint32_t* d = A.gdesc + 16 * (size_t)j;
+    if (d[0] != 3) continue;   // nothing was set aside (the graph kernel ordered the cell's components itself), or the cell was handed to the one-workgroup kernel, or failed
+    const P2Cell c = A.cells[j];
+    auto at = [&](int k) -> uint32_t* { return A.pool + (((unsigned long long)d[k + 1] << 32) | d[k]); };
+    const uint32_t n_tiny = d[2], n_mid = d[3], n_bigc = d[15] & 0x7FFFFFFFu;
+    const uint32_t* mid_off = at(8);
+    uint4* mrec = reinterpret_cast<uint4*>(at(10));
+    const uint32_t* x = mid_off + n_mid + n_bigc + 1;
+    uint32_t* const tied = A.pool + (((unsigned long long)x[8] << 32) | x[7]);
+    const uint32_t nA = tied[0], nB = tied[1], nE = nA + nB;
+    if (nE == 0) continue;
+    uint32_t* const listA = tied + 4;
+    uint32_t* const listB = tied + 4 + 4 * (size_t)n_tiny;
+    auto entry = [&](uint32_t e) -> uint32_t* { return e < nA ? listA + 4 * (size_t)e : listB + 4 * (size_t)(e - nA); };
+    if (tid == 0) { s_cnt[0] = A.cell_ncols[c.cell]; s_cnt[1] = A.lab_cnt ? A.lab_cnt[2 * c.cell] : 0u; s_cnt[2] = A.lab_cnt ? A.lab_cnt[2 * c.cell + 1] : 0u; s_cnt[3] = 0; }
+    __syncthreads();
+    const PugCtx C = make_ctx(A, c, s_cnt);
+    const uint64_t* ch = A.s_h + c.rd_base;
+    const uint64_t* cu = A.s_u + c.rd_base;
+    const uint32_t* coff = A.v_off + c.rd_base;
+    const uint32_t R = c.R;
+    // the entries' running key counts (a key per uncovered vertex) cut the list into batches
+    uint32_t n_keys = 0;
+    for (uint32_t base = 0; base < nE; base += CNT) {
+        const uint32_t e = base + tid;
+        uint32_t k = 0;
+        if (e < nE) { const uint32_t* en = entry(e); k = (uint32_t)__popc(en[1]) + (uint32_t)__popc(en[2]); }
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<CNT>(k, s_ws, tot);
+        if (e < nE) entry(e)[3] = n_keys + ex;
+        n_keys += tot;
+    }
+    gsync();
+    const uint32_t n_batches = (n_keys + TKeys - 1) / TKeys;
+    auto mix = [](uint64_t h) -> uint32_t { uint32_t v = ((uint32_t)h ^ (uint32_t)(h >> 32)) * 0x9E3779B1u; return v ^ (v >> 15); };
+    auto bloom_at = [&](uint32_t mx) -> uint32_t { return (mx >> 16) & (BloomWords * 32 - 1); };
+    auto find = [&](uint64_t h, uint32_t mx, bool insert) -> uint32_t {   // slot of h, or 0xFFFFFFFF
+        uint32_t slot = mx & (TSlots - 1);
+        for (uint32_t step = 0; step < TSlots; ++step, slot = (slot + 1) & (TSlots - 1)) {
+            const unsigned long long k = __hip_atomic_load(&t_key[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (k == h) return slot;
+            if (k == ~0ull) {
+                if (!insert) return 0xFFFFFFFFu;
+                const unsigned long long old = atomicCAS(&t_key[slot], ~0ull, (unsigned long long)h);
+                if (old == ~0ull || old == h) return slot;
+            }
+        }
+        return 0xFFFFFFFFu;
+    };
+    for (uint32_t b = 0; b < n_batches; ++b) {
+        __syncthreads();
+        for (uint32_t i = tid; i < TSlots; i += CNT) { t_key[i] = ~0ull; t_min[i] = 0xFFFFFFFFu; }
+        for (uint32_t i = tid; i < BloomWords; i += CNT) s_bloom[i] = 0;
+        __syncthreads();
+        // the classes that are asked for: the labels of the batch's uncovered vertices
+        for (uint32_t e = tid; e < nE; e += CNT) {
+            const uint32_t* en = entry(e);
+            if (en[3] / TKeys != b) continue;
+            const uint32_t b0 = mid_off[en[0]];
+            for (uint64_t m = ((uint64_t)en[2] << 32) | en[1]; m; m &= m - 1) {
+                const uint32_t g = mrec[2 * (size_t)(b0 + (uint32_t)__builtin_ctzll(m))].x;
+                const uint64_t h = ch[g];
+                const uint32_t mx = mix(h);
+                atomicOr(&s_bloom[bloom_at(mx) >> 5], 1u << (bloom_at(mx) & 31u));
+                if (find(h, mx, true) == 0xFFFFFFFFu) s_cnt[3] = kErrInternal;
+            }
+        }
+        __syncthreads();
+        // every vertex slot of the cell once (slots past a partition's last vertex hold key 0: no class), six per thread and trip
+        for (uint32_t g0 = tid; g0 - tid < R; g0 += 6 * CNT) {
+            uint64_t h6[6];
+            uint32_t sl6[6], off6[6], old6[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) h6[r] = g0 + (uint32_t)r * CNT < R ? ch[g0 + (uint32_t)r * CNT] : 0ull;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const uint32_t mx = mix(h6[r]);
+                const bool pass = h6[r] != 0 && ((s_bloom[bloom_at(mx) >> 5] >> (bloom_at(mx) & 31u)) & 1u);
+                sl6[r] = pass ? find(h6[r], mx, false) : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int r = 0; r < 6; ++r) off6[r] = sl6[r] != 0xFFFFFFFFu ? coff[g0 + (uint32_t)r * CNT] : 0u;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) old6[r] = sl6[r] != 0xFFFFFFFFu ? atomicMin(&t_min[sl6[r]], off6[r]) : 0xFFFFFFFFu;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+                if (sl6[r] != 0xFFFFFFFFu && (uint32_t)(h6[r] >> 62) == 3 && old6[r] != 0xFFFFFFFFu && old6[r] != off6[r] &&
+                    !lab_equal(rec_label(C, off6[r]), rec_label(C, old6[r]))) s_cnt[3] = kErrLabelHash;
+        }
+        __syncthreads();
+        // The batch's components, their records into the reference's order.  An order key: the vertices still uncovered by
+        // (class minimum, UMI), the covered ones behind them as they lie.  Components of up to eight vertices (the list of
+        // cover_tiny8) EIGHT to a wave, a group of eight lanes each - a wave to each was a chain of five dependent round trips
+        // per component, two dozen components one after the other per wave: most of this kernel's time.
+        auto order_key = [&](bool act, uint32_t pos, uint64_t uc, uint32_t g) -> uint64_t {
+            if (!act) return ~0ull;
+            if (!((uc >> pos) & 1ull)) return (1ull << 63) | pos;
+            const uint64_t h = ch[g];
+            const uint32_t slot = find(h, mix(h), false);
+            const uint32_t mn = slot == 0xFFFFFFFFu ? 0xFFFFFFFFu : t_min[slot];
+            if (mn >> 31) s_cnt[3] = kErrInternal;   // (every asked-for class has at least the vertex that asked; record offsets are dword offsets inside a chunk: below 2^30)
+            return ((uint64_t)(mn & 0x7FFFFFFFu) << 32) | (uint32_t)(cu[g] >> 32);
+        };
+        {
+            const uint32_t gl = lane & 7u, gbase = lane & ~7u, grp = lane >> 3;
+            for (uint32_t e0 = wv * 8; e0 < nA; e0 += (CNT / 64) * 8) {   // (uniform per wave)
+                const uint32_t e = e0 + grp;
+                uint32_t* en = listA + 4 * (size_t)(e < nA ? e : 0u);
+                const bool mine = e < nA && en[3] / TKeys == b;
+                const uint32_t ci = mine ? en[0] : 0u;
+                const uint32_t uc = mine ? en[1] & 0xFFu : 0u;
+                const uint32_t b0 = mine ? mid_off[ci] : 0u, n = mine ? mid_off[ci + 1] - b0 : 0u;
+                const bool act = gl < n;
+                uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
+                if (act) { qa = mrec[2 * (size_t)(b0 + gl)]; qb = mrec[2 * (size_t)(b0 + gl) + 1]; }
+                const uint64_t key = order_key(act, gl, uc, qa.x);
+                uint32_t rank = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 8; ++k) {
+                    const uint64_t kk = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(key >> 32), (int)(gbase + k)) << 32) | (uint32_t)__shfl((int)(uint32_t)key, (int)(gbase + k));
+                    rank += k < n && kk < key ? 1u : 0u;
+                    if (act && k < n && k != gl && kk == key) s_cnt[3] = kErrInternal;   // (two vertices of one component with the same class and UMI: cannot be)
+                }
+                const uint32_t adj = qb.z & 0xFFu;
+                uint32_t nadj = 0, nuc = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 8; ++k) {
+                    const uint32_t rk = (uint32_t)__shfl((int)rank, (int)(gbase + k));
+                    if (k < n && ((adj >> k) & 1u)) nadj |= 1u << rk;
+                    if (k < n && ((uc >> k) & 1u)) nuc |= 1u << rk;
+                }
+                if (act) {   // (every lane holds its record in registers: the slots can be overwritten)
+                    mrec[2 * (size_t)(b0 + rank)] = qa;
+                    mrec[2 * (size_t)(b0 + rank) + 1] = make_uint4(qb.x, qb.y, nadj, 0u);
+                }
+                if (mine && gl == 0) { en[1] = nuc; en[2] = 0u; }
+            }
+        }
+        for (uint32_t e = wv; e < nB; e += CNT / 64) {   // 9..64 vertices: a wave each (uniform per wave)
+            uint32_t* en = listB + 4 * (size_t)e;
+            if (en[3] / TKeys != b) continue;
+            const uint32_t ci = en[0];
+            const uint64_t uc = ((uint64_t)en[2] << 32) | en[1];
+            const uint32_t b0 = mid_off[ci], n = mid_off[ci + 1] - b0;
+            const bool act = lane < n;
+            uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
+            if (act) { qa = mrec[2 * (size_t)(b0 + lane)]; qb = mrec[2 * (size_t)(b0 + lane) + 1]; }
+            const uint64_t key = order_key(act, lane, uc, qa.x);
+            uint32_t rank = 0;
+            for (uint32_t k = 0; k < n; ++k) {
+                const uint64_t kk = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), (int)k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, (int)k);
+                rank += kk < key ? 1u : 0u;
+                if (kk == key && k != lane && act) s_cnt[3] = kErrInternal;
+            }
+            const uint64_t adj = ((uint64_t)qb.w << 32) | qb.z;
+            uint64_t nadj = 0, nuc = 0;
+            for (uint32_t k = 0; k < n; ++k) {
+                const uint32_t rk = (uint32_t)__builtin_amdgcn_readlane((int)rank, (int)k);
+                if ((adj >> k) & 1ull) nadj |= 1ull << rk;
+                if ((uc >> k) & 1ull) nuc |= 1ull << rk;
+            }
+            if (act) {
+                mrec[2 * (size_t)(b0 + rank)] = qa;
+                mrec[2 * (size_t)(b0 + rank) + 1] = make_uint4(qb.x, qb.y, (uint32_t)nadj, (uint32_t)(nadj >> 32));
+            }
+            if (lane == 0) { en[1] = (uint32_t)nuc; en[2] = (uint32_t)(nuc >> 32); }
+        }
+    }
+    gsync();
+    if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], c.cell); return; }
+    cover_tiny8<CNT / 64, kCoverResume>(C, mrec, mid_off, nA, wv, lane, nullptr, listA);
+    cover_wave64<CNT / 64, kCoverResume>(C, mrec, mid_off, 0u, nB, wv, lane, nullptr, listB);
     gsync();
     if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], c.cell); return; }
     if (tid == 0) {
@@ -1621,6 +1862,12 @@ void launch_p2_graph(hipStream_t s, const P2Args& a) {
     const uint32_t nc = a.n_cells < cover_per_cu * (uint32_t)cus ? a.n_cells : cover_per_cu * (uint32_t)cus;
     if (n_big) AFQ_LAUNCH(k_p2_cover<1024>, n_big < (uint32_t)cus ? n_big : (uint32_t)cus, 1024, s, a, 0u, n_big, a.work_counter + 3);   // (the big cells' covers likewise)
     if (rest) AFQ_LAUNCH(k_p2_cover<kGNT>, nc < rest ? nc : rest, kGNT, s, a, n_big, a.n_cells, a.work_counter2);
+    // ... and the components the covers set aside at a tie, in the reference's order (k_p2_tied: 49 / 98 KiB of LDS)
+    // (256 threads and three cells to a CU for all but the cells of 100 000 reads or more: what a cell's set-aside components cost is a
+    //  chain of a dozen dependent steps, not work - one 1024-thread workgroup per CU took 6.4 ms per configs[2] step for what this does in a fraction)
+    const uint32_t n_huge = a.n_huge < n_big ? a.n_huge : n_big, rest_t = a.n_cells - n_huge;
+    if (n_huge) AFQ_LAUNCH(k_p2_tied<1024>, n_huge < (uint32_t)cus ? n_huge : (uint32_t)cus, 1024, s, a, 0u, n_huge, a.work_counter + 5);
+    if (rest_t) AFQ_LAUNCH(k_p2_tied<kGNT>, rest_t < 3 * (uint32_t)cus ? rest_t : 3 * (uint32_t)cus, kGNT, s, a, n_huge, a.n_cells, a.work_counter + 4);
 }
 
 }  // namespace afq

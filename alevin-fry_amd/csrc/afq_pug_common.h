@@ -300,14 +300,29 @@ __device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
     // rows runs over the group's eight lanes, "the label of vertex v" is a shuffle from lane (group base + v), and every
     // loop runs until the last group of the wave is done with it (idle groups are predicated off).  Such components are
     // four in five of all that reach the cover; a wave to each left 59 of its 64 lanes without a vertex.
-template <int NWAVES>
-__device__ __forceinline__ void cover_tiny8(const PugCtx& C, const uint4* mrec, const uint32_t* mid_off, uint32_t n_tiny, uint32_t wv, uint32_t lane)
+// The covers run in one of three ways (MODE):
+//   kCoverOrdered  the records of a component lie in the reference's vertex order (class by first appearance, then UMI): ties
+//                  between equal-size arborescences go to the first one met, as in the reference (afq_pug.hip; cover_big).
+//   kCoverDefer    the records lie in NO particular order (afq_pug2.hip's k_p2_cover).  A round whose largest arborescence is
+//                  unique does not depend on the order - same winner, same molecule, same vertices left; at the first round that
+//                  meets two different vertex sets of the largest size the component is SET ASIDE: its list index and the mask
+//                  of its uncovered vertices go to `tied` (four words per entry behind a counter), nothing is emitted for it
+//                  from that round on.
+//   kCoverResume   the set-aside components, their records meanwhile put into the reference's order by k_p2_tied: `tied` is
+//                  the list (n_list entries), a component starts from the uncovered vertices its entry holds.
+constexpr int kCoverOrdered = 0, kCoverDefer = 1, kCoverResume = 2;
+// tied: kCoverDefer: [0] the list's counter, entries from tied + 4 (this list's region); kCoverResume: the first entry.
+template <int NWAVES, int MODE = kCoverOrdered>
+__device__ __forceinline__ void cover_tiny8(const PugCtx& C, const uint4* mrec, const uint32_t* mid_off, uint32_t n_tiny, uint32_t wv, uint32_t lane,
+                                            uint32_t* tied_cnt = nullptr, uint32_t* tied = nullptr)
     {
         const uint32_t gl = lane & 7u, gbase = lane & ~7u, grp = lane >> 3;
         auto seg_or8 = [](uint32_t x) -> uint32_t { x |= (uint32_t)__shfl_xor((int)x, 1); x |= (uint32_t)__shfl_xor((int)x, 2); x |= (uint32_t)__shfl_xor((int)x, 4); return x; };
-        for (uint32_t c0 = wv * 8; c0 < n_tiny; c0 += (NWAVES) * 8) {
-            const uint32_t ci = c0 + grp;
-            const bool gvalid = ci < n_tiny;
+        for (uint32_t c0 = wv * 8; c0 < n_tiny; c0 += (NWAVES) * 8) {   // (kCoverResume: n_tiny = entries of the list)
+            const bool gvalid = c0 + grp < n_tiny;
+            uint32_t ci = c0 + grp;
+            uint32_t uc0 = 0xFFu;
+            if constexpr (MODE == kCoverResume) { ci = gvalid ? tied[4 * (c0 + grp)] : 0u; uc0 = gvalid ? tied[4 * (c0 + grp) + 1] & 0xFFu : 0u; }
             const uint32_t b0 = gvalid ? mid_off[ci] : 0u, n = gvalid ? mid_off[ci + 1] - b0 : 0u;
             const bool act = gl < n;
             uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
@@ -329,10 +344,11 @@ __device__ __forceinline__ void cover_tiny8(const PugCtx& C, const uint4* mrec, 
                 return reinterpret_cast<const uint32_t*>((uintptr_t)(((uint64_t)hi << 32) | lo))[j] & 0x7FFFFFFFu;
             };
             const uint32_t adj = act ? (qb.z & 0xFFu) : 0u;   // local indices < 8
-            uint32_t UC = gvalid ? (1u << n) - 1u : 0u;
+            uint32_t UC = gvalid ? ((1u << n) - 1u) & uc0 : 0u;
             while (__any(UC != 0)) {
                 const uint32_t remaining = (uint32_t)__popc(UC);
                 uint32_t best = 0, best_sz = 0, it = UC;
+                bool tie = false;   // (kCoverDefer) two different vertex sets of the largest size so far
                 while (__any(it != 0)) {   // candidate start vertices, ascending
                     const bool g_on = it != 0;
                     const uint32_t v = g_on ? (uint32_t)__builtin_ctz(it) : 0u;
@@ -340,6 +356,7 @@ __device__ __forceinline__ void cover_tiny8(const PugCtx& C, const uint4* mrec, 
                     const uint32_t lvn_all = (uint32_t)__shfl((int)myl.n, (int)(gbase + v));
                     const uint32_t lvn = g_on ? lvn_all : 0u;
                     uint32_t mv = 0, mv_sz = 0;
+                    bool tie_v = false;
                     for (uint32_t j = 0; __any(j < lvn); ++j) {
                         const bool on = j < lvn;
                         const uint32_t t = ref_of(gbase + v, lvn, j, on);
@@ -352,10 +369,18 @@ __device__ __forceinline__ void cover_tiny8(const PugCtx& C, const uint4* mrec, 
                             Rm |= F;
                         }
                         const uint32_t sz = (uint32_t)__popc(Rm);
-                        if (on && sz > mv_sz) { mv_sz = sz; mv = Rm; }
+                        if (on && sz > mv_sz) { mv_sz = sz; mv = Rm; tie_v = false; }
+                        else if (MODE == kCoverDefer && on && sz == mv_sz && Rm != mv) tie_v = true;
                     }
-                    if (g_on && mv_sz > best_sz) { best_sz = mv_sz; best = mv; }
+                    if (g_on && mv_sz > best_sz) { best_sz = mv_sz; best = mv; tie = tie_v; }
+                    else if (MODE == kCoverDefer && g_on && mv_sz == best_sz && (mv != best || tie_v)) tie = true;
                     if (g_on && mv_sz == remaining) it = 0;
+                }
+                if constexpr (MODE == kCoverDefer) {
+                    if (tie && best != 0) {   // set aside (every lane of the group holds the same tie / UC)
+                        if (gl == 0) { const uint32_t e = atomicAdd(tied_cnt, 1u); tied[4 * e] = ci; tied[4 * e + 1] = UC; tied[4 * e + 2] = 0u; }
+                        UC = 0; best = 0;
+                    }
                 }
                 const bool g_emit = UC != 0;
                 if (g_emit && best == 0) { if (gl == 0) C.s_cnt[3] = kErrPugLimit; UC = 0; }  // vertex with an empty label
@@ -403,17 +428,22 @@ __device__ __forceinline__ void cover_tiny8(const PugCtx& C, const uint4* mrec, 
     }
 
 // ---- components of 9..64 vertices (entries n_tiny.. of the list): one wave each, adjacency = one 64-bit mask per lane ----
-template <int NWAVES>
-__device__ __forceinline__ void cover_wave64(const PugCtx& C, const uint4* mrec, const uint32_t* mid_off, uint32_t n_tiny, uint32_t n_mid, uint32_t wv, uint32_t lane)
+// (kCoverResume: the components are entries n_tiny.. n_mid - 1 of the LIST `tied`, i.e. call it with n_tiny = 0, n_mid = entries)
+template <int NWAVES, int MODE = kCoverOrdered>
+__device__ __forceinline__ void cover_wave64(const PugCtx& C, const uint4* mrec, const uint32_t* mid_off, uint32_t n_tiny, uint32_t n_mid, uint32_t wv, uint32_t lane,
+                                             uint32_t* tied_cnt = nullptr, uint32_t* tied = nullptr)
     {
+      // which component entry e of the walk is, and where its slots begin and end
+      auto comp_of = [&](uint32_t e) -> uint32_t { if constexpr (MODE == kCoverResume) return tied[4 * e]; else return e; };
       // offsets two components ahead, records one ahead
       uint32_t ob0 = 0, ob1 = 0, nb0 = 0, nb1 = 0;
-      if (n_tiny + wv < n_mid) { ob0 = mid_off[n_tiny + wv]; ob1 = mid_off[n_tiny + wv + 1]; }
-      if (n_tiny + wv + NWAVES < n_mid) { nb0 = mid_off[n_tiny + wv + NWAVES]; nb1 = mid_off[n_tiny + wv + NWAVES + 1]; }
+      if (n_tiny + wv < n_mid) { const uint32_t cc = comp_of(n_tiny + wv); ob0 = mid_off[cc]; ob1 = mid_off[cc + 1]; }
+      if (n_tiny + wv + NWAVES < n_mid) { const uint32_t cc = comp_of(n_tiny + wv + NWAVES); nb0 = mid_off[cc]; nb1 = mid_off[cc + 1]; }
       uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
       if (lane < ob1 - ob0) { ra = mrec[2 * (size_t)(ob0 + lane)]; rb = mrec[2 * (size_t)(ob0 + lane) + 1]; }
     for (uint32_t ci = n_tiny + wv; ci < n_mid; ci += NWAVES) {   // components of 9..64 vertices: a wave each
         const uint32_t n = ob1 - ob0;
+        const uint32_t cb0 = ob0;   // this component's first slot
         const bool act = lane < n;
         const uint4 qa = ra, qb = rb;
         {   // next component's records, the one after's offsets
@@ -421,7 +451,8 @@ __device__ __forceinline__ void cover_wave64(const PugCtx& C, const uint4* mrec,
             ra = make_uint4(0, 0, 0, 0); rb = ra;
             if (ci + NWAVES < n_mid && lane < ob1 - ob0) { ra = mrec[2 * (size_t)(ob0 + lane)]; rb = mrec[2 * (size_t)(ob0 + lane) + 1]; }
             const uint32_t c2 = ci + 2 * (NWAVES);
-            nb0 = c2 < n_mid ? mid_off[c2] : 0u; nb1 = c2 < n_mid ? mid_off[c2 + 1] : 0u;
+            const uint32_t cc = c2 < n_mid ? comp_of(c2) : 0u;
+            nb0 = c2 < n_mid ? mid_off[cc] : 0u; nb1 = c2 < n_mid ? mid_off[cc + 1] : 0u;
         }
         Lab myl{nullptr, act ? qa.y : 0u};
         uint32_t lr0 = 0xFFFFFFFFu, lr1 = 0xFFFFFFFFu, lr2 = 0xFFFFFFFFu, lr3 = 0xFFFFFFFFu;
@@ -442,15 +473,18 @@ __device__ __forceinline__ void cover_wave64(const PugCtx& C, const uint4* mrec,
         };
         const uint64_t adj = act ? (((uint64_t)qb.w << 32) | qb.z) : 0ull;
         uint64_t UC = n == 64 ? ~0ull : ((1ull << n) - 1);
+        if constexpr (MODE == kCoverResume) UC &= ((uint64_t)tied[4 * ci + 2] << 32) | tied[4 * ci + 1];
         while (UC) {
             const uint32_t remaining = (uint32_t)__popcll(UC);
             uint64_t best = 0;
             uint32_t best_sz = 0;
+            bool tie = false;   // (kCoverDefer) two different vertex sets of the largest size so far
             for (uint64_t it = UC; it; it &= it - 1) {   // ascending vertex id
                 const uint32_t v = (uint32_t)__builtin_ctzll(it);
                 const uint32_t lvn = lane_lab_n(v);
                 uint64_t mv = 0;
                 uint32_t mv_sz = 0;
+                bool tie_v = false;
                 for (uint32_t j = 0; j < lvn; ++j) {
                     const uint32_t t = lane_lab_ref(v, lvn, j);
                     const uint64_t At = __ballot(act && ((UC >> lane) & 1ull) && my_contains(t));
@@ -461,12 +495,20 @@ __device__ __forceinline__ void cover_wave64(const PugCtx& C, const uint4* mrec,
                         Rm |= F;
                     }
                     const uint32_t sz = (uint32_t)__popcll(Rm);
-                    if (sz > mv_sz) { mv_sz = sz; mv = Rm; }
+                    if (sz > mv_sz) { mv_sz = sz; mv = Rm; tie_v = false; }
+                    else if (MODE == kCoverDefer && sz == mv_sz && Rm != mv) tie_v = true;
                 }
-                if (mv_sz > best_sz) { best_sz = mv_sz; best = mv; }
+                if (mv_sz > best_sz) { best_sz = mv_sz; best = mv; tie = tie_v; }
+                else if (MODE == kCoverDefer && mv_sz == best_sz && (mv != best || tie_v)) tie = true;
                 if (mv_sz == remaining) break;
             }
             if (best == 0) { if (lane == 0) C.s_cnt[3] = kErrPugLimit; break; }  // vertex with an empty label
+            if constexpr (MODE == kCoverDefer) {
+                if (tie) {   // set aside (wave-uniform)
+                    if (lane == 0) { const uint32_t e = atomicAdd(tied_cnt, 1u); tied[4 * e] = ci; tied[4 * e + 1] = (uint32_t)UC; tied[4 * e + 2] = (uint32_t)(UC >> 32); }
+                    break;
+                }
+            }
             // transcripts common to every vertex of the arborescence (pugutils.rs:1161-1188) -> genes
             const uint32_t fv = (uint32_t)__builtin_ctzll(best);
             const uint32_t lfn = lane_lab_n(fv);
@@ -500,7 +542,7 @@ __device__ __forceinline__ void cover_wave64(const PugCtx& C, const uint4* mrec,
                 bool cls = false;
                 if (lane == 0) {
                     if (small) { const uint32_t n4 = genes_of4(C, c4, k4); col = molecule4_column(C, c4, n4, cls); }
-                    else if (wide && C.em) emit_wide_from_records(C, mrec, mid_off[ci], fv, best);
+                    else if (wide && C.em) emit_wide_from_records(C, mrec, cb0, fv, best);
                     else emit_molecule(C, g, wide ? 0xFFFFFFFFu : ng);
                 }
                 append_cols(C, col);

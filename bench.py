@@ -769,12 +769,12 @@ def plan_only(D, args):
         if name == "atac":
             inp = int(args.atac_cells) * int(args.frags_per_cell) * 19   # ~19 bytes per record of the scATAC chunks
             need = 2.0 * inp
-            legs[name] = {"input_bytes": inp, "library_need_bytes": int(need)}
+            legs[name] = {"input_bytes": inp, "reads": int(args.atac_cells) * int(args.frags_per_cell), "library_need_bytes": int(need)}
             continue
         if name == "e2e":
             base = legs.get("configs1")
             if base:
-                legs[name] = {"input_bytes": 0, "library_need_bytes": base["library_need_bytes"], "pinned_host_bytes": base["input_bytes"]}
+                legs[name] = {"input_bytes": 0, "reads": base["reads"], "library_need_bytes": base["library_need_bytes"], "pinned_host_bytes": base["input_bytes"]}
                 pinned = base["input_bytes"]
             continue
         if name == "configs3":

@@ -75,6 +75,10 @@ def one(seed):
                     zipf=float(rng.choice([0.0, 0.8, 1.1])), umi_len=int(rng.choice([7, 8, 10, 12])))
     b, off = s.encode()
     kw = dict(small_thresh=int(rng.choice([0, 100])))
+    if seed % 3 == 1:   # every third workload: tied components set aside in every cell (k_p2_tied), not only in those whose classes outgrow the LDS table
+        os.environ["AFQ_P2_DEFER_MIN"] = "0"
+    else:
+        os.environ.pop("AFQ_P2_DEFER_MIN", None)
     if rng.integers(0, 4) == 0:
         kw["pug_exact_umi"] = True
     if rng.integers(0, 4) == 0:

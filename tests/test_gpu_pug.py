@@ -9,18 +9,23 @@ rad = pkg.rad
 synth = pkg.synth
 
 
-@pytest.fixture(autouse=True, params=["phase-kernels", "one-workgroup", "handed-back", "graph-1024"])
+@pytest.fixture(autouse=True, params=["phase-kernels", "one-workgroup", "handed-back", "graph-1024", "ties-set-aside"])
 def pug_route(request, monkeypatch):
-    """Every test of this module runs four times: through the partition-parallel phase kernels (csrc/afq_pug2.hip, the
+    """Every test of this module runs five times: through the partition-parallel phase kernels (csrc/afq_pug2.hip, the
     default), with every parsimony cell sent to the one-workgroup kernel (csrc/afq_pug.hip), with the phase kernels'
-    partition capacity cut to 24 reads so that most cells start on the first route and are handed back to the second, and with
-    every cell of 300 reads or more given the 1024-thread instance of the graph kernel (by default: cells of 25 000 reads)."""
+    partition capacity cut to 24 reads so that most cells start on the first route and are handed back to the second, with
+    every cell of 300 reads or more given the 1024-thread instances of the graph / cover / tie kernels (by default: cells of
+    25 000 reads), and with EVERY cell covering its components in slot order and setting the tied ones aside for k_p2_tied (by
+    default only the cells whose classes outgrow the graph kernel's LDS table: big cells, long labels)."""
     if request.param == "one-workgroup":
         monkeypatch.setenv("AFQ_PUG_ROUTE", "mono")
     elif request.param == "handed-back":
         monkeypatch.setenv("AFQ_P2_PART_CAP", "24")
     elif request.param == "graph-1024":
         monkeypatch.setenv("AFQ_P2_BIG_READS", "300")
+        monkeypatch.setenv("AFQ_P2_DEFER_MIN", "0")
+    elif request.param == "ties-set-aside":
+        monkeypatch.setenv("AFQ_P2_DEFER_MIN", "0")
     return request.param
 
 
