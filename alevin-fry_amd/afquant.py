@@ -220,7 +220,9 @@ def load_library(path: str = LIB_PATH):
     # soname; a process must hold exactly one HIP/HSA runtime, so when torch is installed it is
     # imported first and the library binds to the runtime torch already mapped (a torch-free
     # host gets /opt/rocm's).  See DESIGN.md "one HIP runtime per process".
-    os.environ.setdefault("GPU_FORCE_BLIT_COPY_SIZE", "0")   # copies on the DMA engines, not as blit kernels next to the path's own (only if the HIP runtime is not up yet)
+    # (GPU_FORCE_BLIT_COPY_SIZE=0 - copies on the DMA engines, not as blit kernels next to the path's own - is the HOST's to set
+    #  before its HIP runtime comes up: bench.py, the afquant CLI and tests/conftest.py do; a binding does not edit its host's
+    #  environment.  afq_create says so once on stderr when it is missing.  INTEGRATION.md "runtime settings")
     try:
         import torch  # noqa: F401
 

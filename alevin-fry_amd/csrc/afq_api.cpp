@@ -20,6 +20,7 @@
 
 #include "../../include/afquant.h"
 #include "afq_common.h"
+#include "afq_hooks.h"
 #include "afq_kernels.h"
 
 using namespace afq;
@@ -150,7 +151,6 @@ struct RangeState {
     PinnedVec<uint32_t> h_pack;   // what the host reads when the range is done: k_pack_small writes it from the device
     ResolveArgs last_ra{};
     std::vector<CellMeta> meta;
-    std::vector<uint2> tile_desc;   // per scatter tile: (cell, tile index inside the cell)
     Range cur{};
     uint32_t hash_try = 0;   // which salt the range's label hashes were made with (a collision re-runs the range under the next)
     uint32_t pool_try = 0;   // how often the range was run again with four times the parsimony pool (a cell's graph outgrew it)
@@ -269,23 +269,12 @@ struct ScopedTimer {
 // was ~0.35 ms of a 13.6 ms step spent on being timed.  A range's brackets therefore share their events - the end of one is the
 // start of the next: ONE packet between two timed kernels - and the 5 us kernels around the large ones are timed with their
 // neighbour (the proof's fix-up decode with the decoder, k_fix_slabs with the scatter, k_resolve_mid / k_resolve_big with
-// k_resolve).  AFQ_TIMER_MODE=pair is the old arrangement (two events per bracket, every bracket its own), =chain shares the
-// events but keeps every bracket (measurements).
-enum TimerMode { kTimerPair = 0, kTimerChain = 1, kTimerMerged = 2 };
-TimerMode timer_mode() {   // (read per range: tests and measurement scripts switch it between batches)
-    const char* e = std::getenv("AFQ_TIMER_MODE");
-    if (e && !std::strcmp(e, "pair")) return kTimerPair;
-    if (e && !std::strcmp(e, "chain")) return kTimerChain;
-    return kTimerMerged;
-}
-bool env_on(const char* name) { const char* e = std::getenv(name); return !(e && e[0] == '0'); }   // switches that are on unless NAME=0
+// k_resolve).
 struct TimerChain {
     afq_ctx* c; hipStream_t s; std::vector<TimedLaunch>* sink; bool par;
-    const TimerMode mode = timer_mode();
     hipEvent_t last = nullptr; int id = -1; bool last_shared = false;   // last: the event the open bracket started on; shared: it also ended the bracket in front
     TimerChain(afq_ctx* c_, hipStream_t s_, std::vector<TimedLaunch>* sink_, bool par_) : c(c_), s(s_), sink(sink_), par(par_) {}
     int fold(int k) const {
-        if (mode != kTimerMerged) return k;
         if (k == K_DECODE && par) return K_DECODE_PAR;   // (without the walk-free decoders k_decode IS the decode and keeps its name)
         if (k == K_FIX_SLABS) return K_SCATTER;
         if (k == K_RESOLVE_BIG) return K_RESOLVE;
@@ -296,13 +285,6 @@ struct TimerChain {
         if (!c->cfg.profile) return;
         if (next >= 0) next = fold(next);
         if (next == id) return;
-        if (mode == kTimerPair) {
-            if (id >= 0) { hipEvent_t b = get_event(c); (void)hipEventRecord(b, s); sink->push_back({id, last, b, true}); }
-            last = nullptr;
-            if (next >= 0) { last = get_event(c); (void)hipEventRecord(last, s); }
-            id = next;
-            return;
-        }
         hipEvent_t e = get_event(c);   // (next != id: a bracket ends here, or one begins, or both)
         (void)hipEventRecord(e, s);
         if (id >= 0) sink->push_back({id, last, e, !last_shared});
@@ -329,19 +311,15 @@ void harvest_timers(afq_ctx* c, std::vector<TimedLaunch>* list = nullptr) {
 
 uint32_t hdr_bytes(const afq_config& cfg) { return 4 + cfg.bc_bytes + cfg.umi_bytes; }
 
-// Multi-bucket cells are placed into fixed-capacity bucket slabs (no counting pass) unless AFQ_FIXED_SLABS=0;
-// AFQ_SLAB_CAP shrinks the slabs (tests: forces the overflow path).
-bool fixed_slabs() { const char* e = std::getenv("AFQ_FIXED_SLABS"); return !(e && e[0] == '0'); }
+// Multi-bucket cells are placed into fixed-capacity bucket slabs (no counting pass) unless AFQ_TEST_FIXED_SLABS=0;
+// AFQ_TEST_SLAB_CAP shrinks the slabs (tests: forces the overflow path).
+bool fixed_slabs() { return !test_hook_is("FIXED_SLABS", "0"); }
 // Default 384 slots for buckets planned at <= 256 keys (kBucketTarget): measured on the bench input, 512 costs the scatter
 // 10 % (a sparser target), 320 already sends a tenth of the cells through the exact placement (profiles/run_r02s.sh).
 constexpr uint32_t kSlabCap = 384;
-uint32_t slab_capacity() { const char* e = std::getenv("AFQ_SLAB_CAP"); const long v = e ? std::atol(e) : 0; return v > 0 ? (uint32_t)v : kSlabCap; }
+uint32_t slab_capacity() { const long v = test_hook_long("SLAB_CAP", 0); return v > 0 ? (uint32_t)v : kSlabCap; }
 
-// Planned mean keys per bucket: kBucketTarget, or AFQ_BUCKET_TARGET (measurements only).
-uint32_t bucket_target() {
-    static const uint32_t t = [] { const char* e = std::getenv("AFQ_BUCKET_TARGET"); const long v = e ? std::atol(e) : 0; return v >= 32 && v <= 1024 ? (uint32_t)v : kBucketTarget; }();
-    return t;
-}
+uint32_t bucket_target() { return kBucketTarget; }   // planned mean keys per bucket
 
 bool valid_width(uint32_t w) { return w == 1 || w == 2 || w == 4 || w == 8; }
 
@@ -449,18 +427,11 @@ int plan_ranges(afq_ctx* c) {
     static const double kTaperCr[] = {0.419, 0.671, 0.822, 0.913, 0.967, 1.0, 1.0, 1.0}, kTaperPug[] = {0.40, 0.76, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
     const double* kTaper = pug_res ? kTaperPug : kTaperCr;
     const size_t kTaperN = 8;
-    double env_taper[8];   // (a local: contexts of several devices plan on their own threads)
-    if (const char* e = std::getenv(pug_res ? "AFQ_PUG_TAPER" : "AFQ_CR_TAPER")) {   // measurements: cumulative fractions, e.g. "0.3,0.6,0.85" (up to seven cuts)
-        size_t k = 0;
-        for (const char* q = e; *q && k < 7;) { env_taper[k++] = std::atof(q); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
-        while (k < 8) env_taper[k++] = 1.0;
-        kTaper = env_taper;
-    }
     if (pug_fixed > 0.5 * mem_budget) return fail(c, AFQ_ERR_OOM, "the largest parsimony cell's scratch does not fit device memory");
     double budget = mem_budget - pug_fixed - 0.40 * wide_new;   // (the widened copy was allocated after the free-memory query)
     if (budget <= 0) return fail(c, AFQ_ERR_OOM, "the widened copy of the batch leaves no room for the ranges");
-    const bool pipe = c->n_bytes >= (256u << 20) && !std::getenv("AFQ_NO_PIPELINE");  // (profiling: one range, no overlap between kernels)
-    if (const char* e = std::getenv("AFQ_RANGE_BYTES")) budget = std::min(budget, std::atof(e));  // tests: force many ranges
+    const bool pipe = c->n_bytes >= (256u << 20);
+    if (const char* e = test_hook("RANGE_BYTES")) budget = std::min(budget, std::atof(e));  // tests: force many ranges
     c->ranges.clear();
     double used = 0, done = 0;
     uint32_t c0 = 0;
@@ -478,9 +449,9 @@ int plan_ranges(afq_ctx* c) {
 }
 
 // Which walk-free decoder suits the batch: lane-per-record when records are short (few alignment words each),
-// lane-per-dword otherwise.  AFQ_DECODE=recs|keys overrides (tests run both).
+// lane-per-dword otherwise.  AFQ_TEST_DECODE=recs|keys overrides (tests run both).
 static uint32_t decode_short_records(uint64_t n_ref_words, uint64_t n_records) {
-    if (const char* e = getenv("AFQ_DECODE")) {
+    if (const char* e = test_hook("DECODE")) {
         if (!strcmp(e, "recs")) return 1;
         if (!strcmp(e, "keys")) return 0;
     }
@@ -495,7 +466,7 @@ static uint64_t label_salt(uint32_t hash_try) {
     return hash_try ? (x ^ (x >> 31)) : 0ull;
 }
 static uint64_t label_mask(uint32_t hash_try) {
-    if (hash_try == 0) if (const char* e = std::getenv("AFQ_TEST_LABEL_HASH_BITS")) { const int n = std::atoi(e); if (n > 0 && n < 64) return (1ull << n) - 1; }
+    if (hash_try == 0) { const long n = test_hook_long("LABEL_HASH_BITS", 0); if (n > 0 && n < 64) return (1ull << n) - 1; }
     return ~0ull;
 }
 constexpr uint32_t kMaxHashTries = 4;
@@ -503,12 +474,8 @@ constexpr uint32_t kMaxPoolTries = 3;   // 32 words per read x 4^3
 
 // Reads that carry many alignments carry many genes: most UMIs then outgrow the three gene counters of a slot of k_resolve's
 // UMI table and their buckets end up sorted after the table has been tried.  Such ranges (two or more alignment words per
-// record on average - the decoders switch on the same figure) sort every bucket at once.  AFQ_RESOLVE=table|sort overrides.
+// record on average - the decoders switch on the same figure) sort every bucket at once.
 static uint32_t resolve_sort_only(uint64_t n_ref_words, uint64_t n_records) {
-    if (const char* e = getenv("AFQ_RESOLVE")) {
-        if (!strcmp(e, "sort")) return 1;
-        if (!strcmp(e, "table")) return 0;
-    }
     return n_ref_words >= 2 * n_records ? 1u : 0u;
 }
 
@@ -561,8 +528,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     const uint32_t H = hdr_bytes(g);
     const uint32_t n = r.c1 - r.c0;
     B.meta.resize(n);
-    B.tile_desc.clear();
-    std::vector<uint32_t> multi, bucket_cell, slab_prefix, pug_cells, hist_cells;
+    std::vector<uint32_t> multi, slab_prefix, pug_cells, hist_cells;
     std::vector<uint64_t> rd_off(n, 0);
     uint64_t n_pug_reads = 0, pug_words = 0;  // pug_words: scratch of the largest parsimony cell
     const bool par = (c->widen || c->all_aligned) && decode_par_supported(g.bc_bytes, g.umi_bytes);
@@ -572,19 +538,17 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     uint32_t slab_cap = slab_capacity();
     {   // reads of many genes each (the range averages two or more alignment words per record): all keys of a UMI share a bucket, so
         // the buckets' sizes spread and 384-slot slabs overflow in a tenth of the cells (k_fix_slabs: 3.5 of 41 ms on the tail
-        // model); such ranges get 512-slot slabs (AFQ_SLAB_CAP still overrides)
+        // model); such ranges get 512-slot slabs (AFQ_TEST_SLAB_CAP still overrides)
         uint64_t words = 0, recs = 0;
         for (uint32_t i = 0; i < n; ++i) {
             const uint32_t ci = r.c0 + i;
             const uint64_t nb = c->widen ? c->w_nbytes[ci] : c->hdr[2 * ci], nr = c->hdr[2 * ci + 1];
             words += (nb - 8ull - nr * H) / 4; recs += nr;
         }
-        if (!std::getenv("AFQ_SLAB_CAP") && resolve_sort_only(words, recs)) slab_cap = std::max<uint32_t>(slab_cap, 512u);
+        if (!test_hook("SLAB_CAP") && resolve_sort_only(words, recs)) slab_cap = std::max<uint32_t>(slab_cap, 512u);
     }
     if (par) slab_prefix.reserve(n + 1);
-    // bucket -> cell and scatter tile -> (cell, tile): written on the device from the cells' plans (k_fill_tables) unless
-    // AFQ_DEVICE_TABLES=0 (measurements: the host fills and uploads them, as until late in round 4)
-    const bool device_tables = env_on("AFQ_DEVICE_TABLES");
+    // bucket -> cell and scatter tile -> (cell, tile) are written on the device from the cells' plans (k_fill_tables)
     uint64_t nrec_total = 0;
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t ci = r.c0 + i;
@@ -621,7 +585,6 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
             multi.push_back(i);
             const uint32_t nt = (m.n_ref + kScatterTileHost - 1) / kScatterTileHost;
             m.tile_base = (uint32_t)n_tiles;   // (n_tiles is checked against 32 bits below)
-            if (!device_tables) for (uint32_t t = 0; t < nt; ++t) B.tile_desc.push_back(make_uint2(i, t));
             n_tiles += nt;
         }
         if (mode_is_pug(m.mode)) {
@@ -640,13 +603,6 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     }
     if (n_buckets >= 0xFFFFFFF0ull || n_tiles >= 0xFFFFFFF0ull || key_off >= (1ull << 40))
         return fail(c, AFQ_ERR_UNSUPPORTED, "batch too large for 32-bit bucket/tile ids");
-    if (!device_tables) {
-        bucket_cell.resize(n_buckets);
-        for (uint32_t i = 0; i < n; ++i) {
-            const CellMeta& m = B.meta[i];
-            std::fill(bucket_cell.begin() + m.bucket_base, bucket_cell.begin() + m.bucket_base + (1u << m.lg_nb), i);
-        }
-    }
     const uint32_t n_multi = (uint32_t)multi.size();
 
     HIP_TRY(c, B.d_meta.ensure(sizeof(CellMeta) * n));
@@ -670,16 +626,15 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     if (n_pug && !par) return fail(c, AFQ_ERR_UNSUPPORTED, "device parsimony needs dword-aligned chunk offsets");
     // Parsimony cells go through the phase kernels of afq_pug2.hip (partition-parallel) unless their labels are
     // gene-level, their UMI field is wider than 4 bytes or they hold 2^22 reads or more: those - and the cells the phase kernels
-    // hand back - are resolved by the one-workgroup kernel of afq_pug.hip.  AFQ_PUG_ROUTE=mono sends every cell there (tests).
+    // hand back - are resolved by the one-workgroup kernel of afq_pug.hip.  AFQ_TEST_PUG_ROUTE=mono sends every cell there (tests).
     std::vector<P2Cell> p2cells;
     std::vector<uint2> p2tiles;
     std::vector<uint32_t> p2_up;
     std::vector<uint32_t> mono_cells;
     uint64_t p2_parts = 0;
-    uint32_t p2_tile = kP2TileHost;
+    const uint32_t p2_tile = kP2TileHost;
     {
-        const char* route = std::getenv("AFQ_PUG_ROUTE");
-        p2_tile = [] { const char* e = std::getenv("AFQ_P2_TILE"); const int v = e ? std::atoi(e) : 0; return v == 4096 || v == 8192 || v == 2048 ? (uint32_t)v : kP2TileHost; }();
+        const char* route = test_hook("PUG_ROUTE");
         const bool p2_ok = n_pug && g.umi_bytes == 4 && !(g.resolution == AFQ_RES_PARSIMONY_GENE || g.resolution == AFQ_RES_PARSIMONY_GENE_EM) &&
                            !(route && !std::strcmp(route, "mono"));
         for (uint32_t ci : pug_cells) {   // (largest first)
@@ -688,8 +643,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
             P2Cell pc{};
             pc.rd_base = rd_off[ci]; pc.chunk_off = m.chunk_off; pc.cell = ci; pc.R = m.nrec; pc.n_ref = m.n_ref; pc.key_off = m.key_off;
             uint32_t lg = 0;
-            static const uint32_t part_target = [] { const char* e = std::getenv("AFQ_P2_TARGET"); const int v = e ? std::atoi(e) : 0; return v >= 16 && v <= 256 ? (uint32_t)v : kP2PartTarget; }();   // (measurements)
-            while (((m.nrec + (1u << lg) - 1) >> lg) > part_target) ++lg;
+            while (((m.nrec + (1u << lg) - 1) >> lg) > kP2PartTarget) ++lg;
             pc.lgP = lg; pc.part_base = (uint32_t)p2_parts;
             p2_parts += 1ull << lg;
             const uint32_t j = (uint32_t)p2cells.size();
@@ -703,7 +657,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     hist_cells.insert(hist_cells.end(), pug_cells.begin(), pug_cells.end());
     // (the phase kernels' per-read arrays take ten of the words per read, the rest is the pool; a range whose densest cell outgrows
     //  it - short UMIs, hundreds of reads per UMI: the pairs of a vertex are no longer a handful - is run again with four times as much)
-    const uint64_t pool_words_per_read = [] { const char* e = std::getenv("AFQ_TEST_POOL_WORDS"); const long v = e ? std::atol(e) : 0; return v >= 12 && v <= 32 ? (uint64_t)v : 32ull; }();   // (tests: a small first pool; read per range - a test sets it for itself)
+    const uint64_t pool_words_per_read = [] { const long v = test_hook_long("POOL_WORDS", 0); return v >= 12 && v <= 32 ? (uint64_t)v : 32ull; }();   // (tests: a small first pool; read per range - a test sets it for itself)
     const uint64_t epool_words = ((pool_words_per_read * n_pug_reads + (pool_words_per_read == 32 ? (1ull << 22) : (1ull << 20))) << (2 * pool_try));
     if (n_pug) {
         HIP_TRY(c, B.d_pug_cells.ensure(4ull * n_pug));
@@ -742,10 +696,8 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
         init.zero(B.d_cell_nkeys.p, 4ull * n);
     }
     init.upload(B.d_meta.p, B.meta.data(), sizeof(CellMeta) * n);
-    if (!device_tables) init.upload(B.d_bucket_cell.p, bucket_cell.data(), 4 * n_buckets);
     if (n_multi) {
         init.upload(B.d_multi_cells.p, multi.data(), 4ull * n_multi);
-        if (!device_tables) init.upload(B.d_tile_desc.p, B.tile_desc.data(), 8ull * n_tiles);
     }
     init.zero(B.d_bucket_cnt.p, 4 * n_buckets);
     init.zero(B.d_slab_ovf.p, 4ull * n);
@@ -781,8 +733,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     std::vector<uint32_t> em_order;
     const uint32_t na_em = g.usa_mode ? g.num_rows : g.num_genes;
     {
-        const char* em_env = std::getenv("AFQ_EM_ORDER");
-        B.em_inline = em && !(em_env && !std::strcmp(em_env, "canonical")) && em2_supported(na_em) && !(g.dump_eq || g.num_bootstraps);
+        B.em_inline = em && !em_order_canonical() && em2_supported(na_em) && !(g.dump_eq || g.num_bootstraps);
     }
     if (B.em_inline) {
         double worst = 0;
@@ -790,7 +741,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
             const uint32_t cap1 = B.meta[i].n_ref + 1;
             worst += (double)em2_scratch_words(std::min(cap1, na_em), cap1, cap1 / 2, g.usa_mode != 0);
         }
-        static const double frac = [] { const char* e = std::getenv("AFQ_EM2_SCRATCH_FRAC"); const double v = e ? std::atof(e) : 0.0; return v > 0 && v <= 1 ? v : 0.35; }();   // (tests: a sliver, so that the fallback runs)
+        const double frac = [] { const char* e = test_hook("EM2_SCRATCH_FRAC"); const double v = e ? std::atof(e) : 0.0; return v > 0 && v <= 1 ? v : 0.35; }();   // (tests: a sliver, so that the fallback runs; read per range like the other hooks)
         em2_cap = (uint64_t)std::max(worst * frac, 4096.0);
         em_order.resize(n);
         for (uint32_t i = 0; i < n; ++i) em_order[i] = i;
@@ -805,17 +756,14 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
         HIP_TRY(c, B.d_em2_tiers.ensure(4ull * (8 + 5ull * n)));
     }
     if (const int rc = init.flush(c, B, s)) return rc;
-    if (device_tables) launch_fill_tables(s, B.d_meta.as<CellMeta>(), n, B.d_bucket_cell.as<uint32_t>(), B.d_tile_desc.as<uint2>());
+    launch_fill_tables(s, B.d_meta.as<CellMeta>(), n, B.d_bucket_cell.as<uint32_t>(), B.d_tile_desc.as<uint2>());
     // (the uploads come out of the slot's pinned arena, which the next range of this slot fills only after finish_range has
-    //  waited for this one; until the arena existed they came out of the vectors above, hence the wait here.  AFQ_INIT_SYNC=0
-    //  drops it: the host goes on to enqueue the range's kernels while the arena copy is on its way - measurements.)
-    const bool init_sync = env_on("AFQ_INIT_SYNC");
-    if (init_sync) HIP_TRY(c, hipStreamSynchronize(s));
+    //  waited for this one; until the arena existed they came out of the vectors above, hence the wait here)
+    HIP_TRY(c, hipStreamSynchronize(s));
     {   // this range's kernels start after the previous range's kernels (clean per-kernel timings, no cache
         // thrash between ranges); what overlaps them is the previous range's D2H and this range's enqueue
         RangeState& O = c->rs[slot ^ 1];
-        static const bool overlap = std::getenv("AFQ_RANGE_OVERLAP") != nullptr;   // (measurements: let the two ranges in flight run side by side)
-        if (O.in_flight && O.kernels_done && !overlap) HIP_TRY(c, hipStreamWaitEvent(s, O.kernels_done, 0));
+        if (O.in_flight && O.kernels_done) HIP_TRY(c, hipStreamWaitEvent(s, O.kernels_done, 0));
     }
     if (h2d_done) HIP_TRY(c, hipStreamWaitEvent(s, h2d_done, 0));   // afq_submit: this range's input bytes have landed
     hc.lap("run: uploads + memsets");
@@ -899,23 +847,20 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
             p2.lab = ra.lab; p2.lab_cnt = ra.lab_cnt; p2.st = ra.st; p2.alt = B.d_alt.as<uint32_t>();
             p2.n_cells = n_p2; p2.n_tiles = (uint32_t)p2tiles.size(); p2.n_parts = (uint32_t)p2_parts;
             {
-                const uint32_t big_reads = [] { const char* e = std::getenv("AFQ_P2_BIG_READS"); const long v = e ? std::atol(e) : 0; return v > 0 ? (uint32_t)v : 25000u; }();   // (measurements / tests: read per range; configs[2] graph kernels per step: 100 000: 30.9 ms, 60 000: 28.4, 40 000: 26.7, 25 000: 25.7, 12 000 and below: 25.4)
-                p2.max_comp = [] { const char* e = std::getenv("AFQ_P2_MAX_COMP"); const long v = e ? std::atol(e) : 0; return v >= 64 && v <= (long)kP2MaxComp ? (uint32_t)v : kP2MaxComp; }();   // (tests: 64 = larger components are handed back, as before round 4)
+                const uint32_t big_reads = [] { const char* e = test_hook("P2_BIG_READS"); const long v = e ? std::atol(e) : 0; return v > 0 ? (uint32_t)v : 15000u; }();   // (tests: read per range; configs[2] graph + cover + tie kernels per step, round 5: 60 000: 24.6 ms, 40 000: 23.9, 25 000: 22.2-23.1, 15 000: 20.3-20.5)
+                p2.max_comp = [] { const long v = test_hook_long("P2_MAX_COMP", 0); return v >= 64 && v <= (long)kP2MaxComp ? (uint32_t)v : kP2MaxComp; }();   // (tests: 64 = larger components are handed back, as before round 4)
                 p2.tile = p2_tile;
                 p2.n_big = 0;
                 while (p2.n_big < n_p2 && p2cells[p2.n_big].R >= big_reads) ++p2.n_big;   // (p2cells is largest first)
-                p2.defer_min = [] { const char* e = std::getenv("AFQ_P2_DEFER_MIN"); return e ? (uint32_t)std::max(0L, std::atol(e)) : 0xFFFFFFFFu; }();   // (tests: 0 = every cell takes the set-aside route)
-                p2.n_huge = 0;
-                const uint32_t huge_reads = big_reads < 25000u ? big_reads : std::max(100000u, big_reads);   // (a test that lowers the one threshold means both instances)
-                while (p2.n_huge < p2.n_big && p2cells[p2.n_huge].R >= huge_reads) ++p2.n_huge;
+                p2.defer_min = [] { const char* e = test_hook("P2_DEFER_MIN"); return e ? (uint32_t)std::max(0L, std::atol(e)) : 0xFFFFFFFFu; }();   // (tests: 0 = every cell takes the set-aside route)
             }
             // k_p2_lone, labels over four refs: 0: by the vertex's lane alone, in scratch memory (rounds 3-4); 1: labels of 5..64 refs by the
             // wave; 2: 5..8 by the lane in eight registers, 9..64 by the wave - an instance of 86 instead of 69 VGPRs, five waves per SIMD
             // instead of seven: on the tail model k_p2_lone 25.1 -> 16.5 ms per step, on the plain one 5.6 -> 7.3 (profiles/run_r04ao.sh).
             // The range's own figure decides, the one that picks its decoder: two or more alignment words per record.
-            p2.lone_coop = [&] { const char* e = std::getenv("AFQ_P2_LONE_COOP"); return e && e[0] >= '0' && e[0] <= '2' ? (uint32_t)(e[0] - '0') : (key_off - n >= 2 * nrec_total ? 2u : 1u); }();
+            p2.lone_coop = [&] { const char* e = test_hook("P2_LONE_COOP"); return e && e[0] >= '0' && e[0] <= '2' ? (uint32_t)(e[0] - '0') : (key_off - n >= 2 * nrec_total ? 2u : 1u); }();
             p2.part_cap = kP2PartCap;
-            if (const char* e = std::getenv("AFQ_P2_PART_CAP")) p2.part_cap = (uint32_t)std::max(1, std::atoi(e));   // tests: force cells back to the one-workgroup kernel
+            if (const char* e = test_hook("P2_PART_CAP")) p2.part_cap = (uint32_t)std::max(1, std::atoi(e));   // tests: force cells back to the one-workgroup kernel
             p2.ref_count = c->ref_count; p2.num_genes = g.num_genes; p2.usa = g.usa_mode; p2.num_rows = g.num_rows; p2.em = em ? 1u : 0u;
             p2.exact_umi = g.pug_exact_umi; p2.large_thresh = g.large_graph_thresh; p2.hw = 1 + g.bc_bytes / 4 + g.umi_bytes / 4;
             p2.umi_pairs = std::min<uint32_t>(g.umi_len ? g.umi_len : g.umi_bytes * 4, 16);
@@ -935,21 +880,18 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
         pa.num_rows = g.num_rows; pa.em = em ? 1u : 0u; pa.exact_umi = g.pug_exact_umi; pa.large_thresh = g.large_graph_thresh; pa.umi32 = g.umi_bytes == 4 ? 1u : 0u;
         pa.hw = 1 + g.bc_bytes / 4 + g.umi_bytes / 4; pa.umi_pairs = std::min<uint32_t>(g.umi_len ? g.umi_len : g.umi_bytes * 4, 22);
         pa.gene_level = (g.resolution == AFQ_RES_PARSIMONY_GENE || g.resolution == AFQ_RES_PARSIMONY_GENE_EM) ? 1u : 0u;
-        pa.force_global_route = std::getenv("AFQ_PUG_GLOBAL_ROUTE") ? 1u : 0u;
+        pa.force_global_route = test_hook("PUG_GLOBAL_ROUTE") ? 1u : 0u;
         tc.seg(K_PUG);
         launch_pug(s, pa, n_pug_blocks);
     }
-    // What the next range's kernels wait for: all of this range's.  (AFQ_TAIL_OVERLAP=1 lets them start beside the per-cell
-    // histograms a range without an EM ends in - measured on the headline and not kept: the decoder fills every SIMD at eight
+    // What the next range's kernels wait for: all of this range's.  (Letting them start beside the per-cell histograms a range
+    // without an EM ends in was measured on the headline in round 4 and not kept: the decoder fills every SIMD at eight
     // waves, the histogram workgroups - 73 KiB of LDS each - get a CU only as decoder workgroups drain, the bracket of
     // k_cell_hist grows from 0.56 to 3.3 ms per step and the range's rows start across PCIe that much later: 12.97 -> 15.38 ms
     // per step, profiles/run_r04aa.sh.  The same with the histograms on a stream of the device's highest priority: 3.4 ms,
     // 13.1 -> 15.0 ms per step, profiles/run_r04ad.sh - queue priority does not put a 73 KiB workgroup in front of the
     // decoder's 9 KiB ones.)
-    const bool tail_overlap = [] { const char* e = std::getenv("AFQ_TAIL_OVERLAP"); return e && e[0] == '1'; }();
     if (!B.kernels_done) HIP_TRY(c, hipEventCreateWithFlags(&B.kernels_done, hipEventDisableTiming));
-    const bool early_done = tail_overlap && !em && !hist_cells.empty();
-    if (early_done) { tc.seg(K_CELL_HIST); HIP_TRY(c, hipEventRecord(B.kernels_done, s)); }   // (the bracket's event first: one packet train)
     if (!hist_cells.empty()) { tc.seg(K_CELL_HIST); launch_cell_hist(s, ra); }
     if (B.em_inline) {
         tc.seg(K_EM);
@@ -958,7 +900,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     }
     tc.end();
     HIP_TRY(c, hipGetLastError());
-    if (!early_done) HIP_TRY(c, hipEventRecord(B.kernels_done, s));
+    HIP_TRY(c, hipEventRecord(B.kernels_done, s));
     {   // what finish_range reads first: written by the last kernel of the range STRAIGHT into pinned host memory (20 bytes per cell over
         // PCIe).  An async D2H copy here instead would sit in the copy queue until the range's kernels are done - with the NEXT range's
         // upload queued behind it: the next range then started 150 us after this one ended instead of right behind it (seen in the
@@ -975,10 +917,9 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     // lengths, sum them and send the offsets back: 0.27 ms between the last kernel of a batch's last range and its compaction,
     // with nothing else for the device to do (profiles/r04_timeline_configs1.txt).  The buffers are the slot's as they stand (they
     // grow to the largest range seen); a range with more entries is compacted by finish_range as before.  EM resolutions take their
-    // rows out of the EM's scratch (finish_range).  AFQ_CHAIN_COMPACT=0: never.
-    const bool chain_compact = env_on("AFQ_CHAIN_COMPACT");
+    // rows out of the EM's scratch (finish_range).
     B.chained = false;
-    if (chain_compact && !em) {
+    if (!em) {
         HIP_TRY(c, B.d_cell_ptr.ensure(8ull * (n + 1)));
         B.chain_cap = std::min(B.d_gene.cap, B.d_val.cap) / 4;
         tc.seg(K_COMPACT);
@@ -1091,9 +1032,8 @@ int finish_range(afq_ctx* c, int slot) {
         // The EM runs in order-free fixed-point arithmetic (afq_em2.hip) unless AFQ_EM_ORDER=canonical asks for the sequential f32
         // sums in canonical class order (afq_em.hip, rounds 1-3) or the output space does not fit the set-up kernel's bitmap.
         // -d / -b read the cell's classes off the canonical set-up, which then runs as well (set-up only).
-        const char* em_env = std::getenv("AFQ_EM_ORDER");
         const uint32_t na_em = c->cfg.usa_mode ? c->cfg.num_rows : c->cfg.num_genes;
-        em2 = !(em_env && !std::strcmp(em_env, "canonical")) && em2_supported(na_em);
+        em2 = !em_order_canonical() && em2_supported(na_em);
         const bool need_classes = c->cfg.dump_eq || c->cfg.num_bootstraps;
         std::vector<uint32_t> em_order(n);
         for (uint32_t i = 0; i < n; ++i) em_order[i] = i;
@@ -1235,7 +1175,7 @@ int finish_range(afq_ctx* c, int slot) {
     //  with __amd_rocclr_copyBuffer kernels - 27 % of the GPU time of a profiled step, next to the following range's decoder -
     //  whenever the command in front of them on the stream was a kernel; behind a small upload they stay on the DMA engines, as
     //  they did while the compaction was enqueued from here.  profiles/run_r04ak.sh, run_r04al.sh, run_r04am.sh)
-    if (compacted && env_on("AFQ_D2H_LEAD")) HIP_TRY(c, hipMemcpyAsync(B.d_cell_ptr.p, ptr.data(), 8ull * (n + 1), hipMemcpyHostToDevice, s));
+    if (compacted) HIP_TRY(c, hipMemcpyAsync(B.d_cell_ptr.p, ptr.data(), 8ull * (n + 1), hipMemcpyHostToDevice, s));
     HostResult& R = *c->res;
     const size_t g0 = R.gene.n;
     HIP_TRY(c, R.gene.reserve(g0 + tot));
@@ -1277,7 +1217,6 @@ bool host_ptr_is_pinned(const void* p) {
     return at.type == hipMemoryTypeHost;
 }
 unsigned stage_threads() {
-    if (const char* e = std::getenv("AFQ_STAGE_THREADS")) return (unsigned)std::max(1, std::atoi(e));
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     return std::min(16u, std::max(4u, hw / 4));
 }
@@ -1398,6 +1337,15 @@ int afq_create(const afq_config* cfg, const uint32_t* tid_to_gid, uint32_t ref_c
     if (!cfg || !tid_to_gid || !out) return fail(nullptr, AFQ_ERR_INVALID_ARG, "null argument");
     *out = nullptr;
     if (cfg->abi_version != AFQ_ABI_VERSION) return fail(nullptr, AFQ_ERR_INVALID_ARG, "afq_config.abi_version mismatch");
+    {   // one line, once per process, when the host has not asked for copies on the DMA engines (the library cannot: the runtime
+        // reads the setting when it comes up, which is before this call; INTEGRATION.md "runtime settings")
+        static std::once_flag noted;
+        std::call_once(noted, [] {
+            const char* e = std::getenv("GPU_FORCE_BLIT_COPY_SIZE");
+            if (!(e && e[0] == '0' && e[1] == 0))
+                std::fprintf(stderr, "[afquant] GPU_FORCE_BLIT_COPY_SIZE=0 is not set: the runtime may move a range's rows with blit kernels on the compute queue, beside the next range's kernels (set it before the HIP runtime starts)\n");
+        });
+    }
     if (cfg->resolution > AFQ_RES_PARSIMONY_GENE) return fail(nullptr, AFQ_ERR_INVALID_ARG, "bad resolution");
     const bool split_ok = cfg->bc_split >= 1 && cfg->bc_split <= 4 && cfg->bc_bytes > cfg->bc_split && cfg->bc_bytes - cfg->bc_split <= 4;
     if ((cfg->bc_split ? !split_ok : !valid_width(cfg->bc_bytes)) || !valid_width(cfg->umi_bytes))
@@ -1507,7 +1455,7 @@ static int submit_host(afq_ctx* c, const ByteSource& src, size_t n_bytes, const 
     HIP_TRY(c, hipMemsetAsync(dst + n_bytes, 0, 16, c->stream));
     const bool pinned = !src.read && n_bytes && host_ptr_is_pinned(bytes) && host_ptr_is_pinned(bytes + n_bytes - 1);
     const size_t k = c->ranges.size();
-    if (k < 2 || !ascending || std::getenv("AFQ_NO_H2D_PIPELINE")) {
+    if (k < 2 || !ascending || test_hook("NO_H2D_PIPELINE")) {
         if (n_bytes) { int rc2 = staged_h2d(c, dst, bytes, n_bytes, c->stream, pinned, &src, 0); if (rc2) return rc2; }
         HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller keeps ownership of `bytes`
         return run_batch(c);
@@ -1949,9 +1897,9 @@ int afq_atac_dedup_rad(afq_ctx* c, const uint8_t* bytes, size_t n_bytes, const u
     };
     // Big batches go through in four ranges of cells: the distinct fragments of range r cross PCIe (1.8 GB for 2*10^8
     // records: twice the time of all the kernels) on a second stream while the later ranges are still parsed and sorted.
-    const char* pipe_env = std::getenv("AFQ_ATAC_PIPE_BYTES");   // (tests: pipeline small inputs too)
+    const char* pipe_env = test_hook("ATAC_PIPE_BYTES");   // (tests: pipeline small inputs too)
     const size_t pipe_min = pipe_env ? (size_t)std::atoll(pipe_env) : ((size_t)128 << 20);
-    const bool piped = n_cells >= 8 && n_bytes >= pipe_min && !std::getenv("AFQ_NO_PIPELINE");
+    const bool piped = n_cells >= 8 && n_bytes >= pipe_min;
     bool piped_done = false;
     if (piped) {
         constexpr uint32_t kR = 4;

@@ -18,6 +18,7 @@
 #include <algorithm>
 
 #include "afq_common.h"
+#include "afq_hooks.h"
 #include "afq_kernels.h"
 #include "afq_prims.h"
 
@@ -1490,10 +1491,10 @@ int launch_decode(hipStream_t s, const DecodeArgs& a, uint32_t bw, uint32_t uw) 
     return -1;
 }
 
-// k_decode_keys finds a record's first mention of a gene through an LDS hash table (HD); AFQ_DECODE_DEDUP=scan: by the look-back
+// k_decode_keys finds a record's first mention of a gene through an LDS hash table (HD); AFQ_TEST_DECODE_DEDUP=scan: by the look-back
 // compares and the serial scan of rounds 2-4 (read per launch: tests run both).  Label-tail workload (configs1_tail, 9.66 GB):
 // 14.54 -> 9.01 ms per step, the step 35.0 -> 29.4 ms (profiles/run_r04ah.sh).
-static bool decode_keys_hash_dedup() { const char* e = getenv("AFQ_DECODE_DEDUP"); return !(e && !strcmp(e, "scan")); }
+static bool decode_keys_hash_dedup() { return !test_hook_is("DECODE_DEDUP", "scan"); }
 template <int BW, int UW>
 static void launch_decode_par_t(hipStream_t s, const DecodeArgs& a) {
     AFQ_LAUNCH((k_slab_setup<BW, UW>), (a.n_cells + 3) / 4, 256, s, a.bytes, a.meta, a.n_cells, a.slab_prefix,

@@ -36,6 +36,7 @@
 #include <algorithm>
 
 #include "afq_common.h"
+#include "afq_hooks.h"
 #include "afq_kernels.h"
 #include "afq_prims.h"
 
@@ -812,7 +813,7 @@ void launch_em2(hipStream_t s, const ResolveArgs& a, uint32_t n_cells, uint64_t*
                 const uint32_t* em_order, uint32_t* tiers, uint32_t num_alphas, uint32_t init_uniform, uint64_t plan_cap_words) {
     if (!n_cells) return;
     uint32_t min_tier = 0;
-    if (const char* e = std::getenv("AFQ_EM2_MIN_TIER")) min_tier = (uint32_t)std::min(4, std::max(0, std::atoi(e)));   // (tests; read per range)
+    if (const char* e = test_hook("EM2_MIN_TIER")) min_tier = (uint32_t)std::min(4, std::max(0, std::atoi(e)));   // (tests; read per range)
     Em2Cfg cfg{a.usa, num_alphas, a.num_rows / 3, 2 * (a.num_rows / 3), init_uniform, (num_alphas + 31) / 32, min_tier};
     if (!plan_cap_words) (void)hipMemsetAsync(tiers, 0, 32, s);   // (with a device-side plan the range's init kernel has cleared the counters)
     if (plan_cap_words) hipLaunchKernelGGL(k_em2_plan, dim3(1), dim3(1024), 0, s, a.nnz, a.lab_cnt, n_cells, a.usa, (unsigned long long)plan_cap_words, em_off, tiers, a.st);

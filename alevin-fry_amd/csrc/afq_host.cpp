@@ -41,6 +41,7 @@
 
 #include "../../include/afquant.h"
 #include "../../include/afquant_host.h"
+#include "afq_hooks.h"
 
 namespace {
 
@@ -1095,7 +1096,7 @@ int afq_quantify(const afq_quant_opts* o) {
     for (uint64_t nb : chunk_nb) total_bytes += nb;
     uint64_t batch_bytes = batch_cap;
     if (devices.size() > 1) batch_bytes = std::min<uint64_t>(batch_cap, std::max<uint64_t>(total_bytes / (8 * devices.size()) + 1, 32ull << 20));
-    if (const char* e = std::getenv("AFQ_QUEUE_BATCH_BYTES")) batch_bytes = std::max<uint64_t>(1, (uint64_t)std::atof(e));   // tests: many small batches
+    if (const char* e = afq::test_hook("QUEUE_BATCH_BYTES")) batch_bytes = std::max<uint64_t>(1, (uint64_t)std::atof(e));   // tests: many small batches
     std::vector<std::pair<size_t, size_t>> batches;
     for (size_t c0 = 0; c0 < chunk_off.size();) {
         size_t c1 = c0; uint64_t bytes = 0;

@@ -1316,10 +1316,9 @@ void launch_resolve(hipStream_t s, const ResolveArgs& a) {
     AFQ_LAUNCH(k_bucket_desc, (a.n_buckets + 255) / 256, 256, s, a.meta, a.bucket_cell, a.cell_nkeys, a.cursor, a.slab_ovf, a.n_buckets, desc);
     const uint32_t n_cols = a.n_buckets < kResolveCols ? a.n_buckets : kResolveCols;
     const uint32_t grid = n_cols * ((a.n_buckets + n_cols - 1) / n_cols);
-    static const bool no_h2 = getenv("AFQ_RESOLVE_NO_H2") != nullptr;   // (measurements: many-gene batches through the sort path, as before round 4)
     if (a.lab)
         AFQ_LAUNCH((k_resolve<true, false>), grid, kResolveNT, s, desc, a.n_buckets, a.keys0, a.keys1, a.cell_ncols, a.nnz, a.ovf_list, a.st, rc, la);
-    else if (a.sort_only && !no_h2)
+    else if (a.sort_only)
         AFQ_LAUNCH((k_resolve<false, true>), grid, kResolveNT, s, desc, a.n_buckets, a.keys0, a.keys1, a.cell_ncols, a.nnz, a.ovf_list, a.st, rc, la);
     else
         AFQ_LAUNCH((k_resolve<false, false>), grid, kResolveNT, s, desc, a.n_buckets, a.keys0, a.keys1, a.cell_ncols, a.nnz, a.ovf_list, a.st, rc, la);
@@ -1373,8 +1372,7 @@ void launch_cell_hist(hipStream_t s, const ResolveArgs& a) {
     if (!a.n_hist) return;
     ResolveCfg rc = make_rc(a);
     uint32_t words = (a.num_rows + 1) / 2;
-    static const uint32_t cap = [] { const char* e = getenv("AFQ_HIST_WORDS"); const int v = e ? atoi(e) : 0; return v >= 4096 && v <= (int)kHistBins ? (uint32_t)v : kHistBins; }();   // (measurements: LDS words of a pass)
-    words = words < 4096u ? 4096u : (words > cap ? cap : words);
+    words = words < 4096u ? 4096u : (words > kHistBins ? kHistBins : words);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cell_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (int)kHistBins);   // (above 64 KiB needs asking)
     hipLaunchKernelGGL(k_cell_hist, dim3(a.n_hist), dim3(kHistNT), 4 * words, s, a.hist_cells, a.meta, a.keys0, a.keys1, a.cell_ncols, a.nnz, rc, words);
 }

@@ -1084,7 +1084,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     // The labels live in LDS, indexed by a vertex's position in tl (ascending with the vertex id, so the smallest label of
     // a component is still its smallest vertex): the sweeps are LDS atomics and LDS reads, the edges are read once per
     // sweep as positions (translated once).  A cell with more than 32 768 touched vertices keeps the labels in global memory.
-    const bool wcc_lds = NT <= (1u << 15) && !A.force_global_route;   // (AFQ_PUG_GLOBAL_ROUTE: tests keep the global-memory variants covered)
+    const bool wcc_lds = NT <= (1u << 15) && !A.force_global_route;   // (AFQ_TEST_PUG_GLOBAL_ROUTE: tests keep the global-memory variants covered)
     if (wcc_lds) {
         uint32_t* wl = s_big;
         __syncthreads();

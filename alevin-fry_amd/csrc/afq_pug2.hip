@@ -175,17 +175,18 @@ __global__ __launch_bounds__(256) void k_p2_scan(P2Args A) {
     if (lane == 0 && (bad || carry != c.R)) set_err(A.st, kErrRecordWalk, c.cell);
 }
 
-// STAGED (the default, with NT = 512): the tile goes through LDS partition-major, so that a partition's run of the tile leaves in
-// consecutive lanes of one store; otherwise every read is written from its own registers, its run's other reads by other waves at
-// other times.  Measured on configs[2] (395 M reads per step, 6.3 GB of payload each way): direct, 2048-read tiles: 7.9 ms and
+// The tile goes through LDS partition-major, so that a partition's run of the tile leaves in consecutive lanes of one store
+// (written straight from each read's own registers, its run's other reads by other waves at other times, was "direct" in rounds
+// 3-4).  Measured on configs[2] (395 M reads per step, 6.3 GB of payload each way): direct, 2048-read tiles: 7.9 ms and
 // WRITE_SIZE 20.9 GB per step - the runs were 64 bytes, written eight bytes at a time through an L2 that holds a few MB of the
 // lines all its workgroups have open; direct with 8192-read tiles: 6.4 ms, still 19.5 GB; staged with 4096-read tiles (80 KiB of
 // LDS, two workgroups to a CU): 5.1 ms and 7.0 GB.  NT threads take a tile of 8 NT reads.
-template <bool STAGED, int NT>
+template <int NT>
 __global__ __launch_bounds__(NT) void k_p2_scatter(P2Args A) {
     constexpr uint32_t E = 8, kP2Tile = E * NT;
-    __shared__ uint64_t s_a[STAGED ? kP2Tile : 1];
-    __shared__ uint64_t s_b[STAGED ? kP2Tile : 1];
+    static_assert(kP2Tile == kP2TileHost, "the host cuts the cells into tiles of kP2TileHost reads");
+    __shared__ uint64_t s_a[kP2Tile];
+    __shared__ uint64_t s_b[kP2Tile];
     __shared__ uint32_t s_cnt[kP2Bins];
     __shared__ uint32_t s_base[kP2Bins];
     __shared__ uint32_t s_ws[NT / 64];
@@ -240,13 +241,7 @@ __global__ __launch_bounds__(NT) void k_p2_scatter(P2Args A) {
         carry += tot;
     }
     __syncthreads();
-    if constexpr (!STAGED) {
-#pragma unroll
-        for (uint32_t e = 0; e < E; ++e) {
-            const uint32_t i = t0 + e * NT + threadIdx.x;
-            if (i < t1) { const uint32_t pos = s_base[rank[e] >> 16] + (rank[e] & 0xFFFFu); du[pos] = ku[e]; dh[pos] = kh[e]; }
-        }
-    } else {
+    {
 #pragma unroll
         for (uint32_t e = 0; e < E; ++e) {
             const uint32_t i = t0 + e * NT + threadIdx.x;
@@ -721,7 +716,7 @@ __device__ __forceinline__ uint32_t molecule8_column(const PugCtx& c, uint32_t (
     return col;
 }
 
-// L8: labels of 5..8 refs by their own lane (molecule8_column; AFQ_P2_LONE_COOP=2) - an instance of its own: its eight-entry arrays
+// L8: labels of 5..8 refs by their own lane (molecule8_column; AFQ_TEST_P2_LONE_COOP=2) - an instance of its own: its eight-entry arrays
 // are registers of every lane whether or not a label needs them.
 template <bool L8>
 __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t* s_cls, uint32_t lane) {
@@ -1818,56 +1813,38 @@ void launch_p2_split(hipStream_t s, const P2Args& a) {
     if (!a.n_cells) return;
     AFQ_LAUNCH(k_p2_hist, a.n_tiles, 256, s, a);
     AFQ_LAUNCH(k_p2_scan, (a.n_cells + 3) / 4, 256, s, a);
-    static const bool staged = [] { const char* e = getenv("AFQ_P2_SCATTER"); return !(e && !strcmp(e, "direct")); }();   // (measurements: "direct" = every read written from its own registers)
-    const uint32_t grid = (a.n_tiles + 127) / 128 * 128;
-    if (a.tile == 8192) AFQ_LAUNCH((k_p2_scatter<false, 1024>), grid, 1024, s, a);
-    else if (a.tile == 4096 && staged) AFQ_LAUNCH((k_p2_scatter<true, 512>), grid, 512, s, a);
-    else if (a.tile == 4096) AFQ_LAUNCH((k_p2_scatter<false, 512>), grid, 512, s, a);
-    else if (staged) AFQ_LAUNCH((k_p2_scatter<true, 256>), grid, 256, s, a);
-    else AFQ_LAUNCH((k_p2_scatter<false, 256>), grid, 256, s, a);
+    AFQ_LAUNCH((k_p2_scatter<512>), (a.n_tiles + 127) / 128 * 128, 512, s, a);   // (tiles of kP2TileHost = 8 x 512 reads)
 }
-static uint32_t p2_grid(uint32_t n_parts) {   // AFQ_P2_GRID caps the workgroups (persistent waves walking the partitions); default: one wave per partition
-    const uint32_t full = (n_parts + 3) / 4;
-    const char* e = getenv("AFQ_P2_GRID");
-    const uint32_t cap = e ? (uint32_t)atoi(e) : 8192u;   // (8192 workgroups of four waves walking the partitions: launching a wave per partition cost the lone-vertex kernel half its time)
-    return cap && cap < full ? cap : full;
-}
-void launch_p2_part(hipStream_t s, const P2Args& a) { if (a.n_parts) AFQ_LAUNCH(k_p2_part, (p2_grid(a.n_parts) + 2047) / 2048 * 2048, 256, s, a); }
+// 8192 persistent workgroups of four waves walk the partitions (a wave per partition as its own workgroup cost the lone-vertex
+// kernel half its time in dispatch; 4096 and 16384 are within 1 ms); the grid is a multiple of 2048 (for_each_partition_in_runs)
+static uint32_t p2_grid(uint32_t n_parts) { const uint32_t full = (n_parts + 3) / 4; return ((full < 8192u ? full : 8192u) + 2047) / 2048 * 2048; }
+void launch_p2_part(hipStream_t s, const P2Args& a) { if (a.n_parts) AFQ_LAUNCH(k_p2_part, p2_grid(a.n_parts), 256, s, a); }
 void launch_p2_search(hipStream_t s, const P2Args& a) {
     if (!a.n_parts) return;
-    AFQ_LAUNCH(k_p2_search, (p2_grid(a.n_parts) + 2047) / 2048 * 2048, 256, s, a);
+    AFQ_LAUNCH(k_p2_search, p2_grid(a.n_parts), 256, s, a);
     AFQ_LAUNCH(k_p2_search_over, std::min((a.n_parts + 255) / 256, 2048u), 256, s, a);   // (the partitions with more pairs than slots, normally none: two counts per partition are read)
 }
 void launch_p2_lone(hipStream_t s, const P2Args& a) {
     if (!a.n_parts) return;
-    if (a.lone_coop >= 2) AFQ_LAUNCH(k_p2_lone<true>, (p2_grid(a.n_parts) + 2047) / 2048 * 2048, 256, s, a);
-    else AFQ_LAUNCH(k_p2_lone<false>, (p2_grid(a.n_parts) + 2047) / 2048 * 2048, 256, s, a);
+    if (a.lone_coop >= 2) AFQ_LAUNCH(k_p2_lone<true>, p2_grid(a.n_parts), 256, s, a);
+    else AFQ_LAUNCH(k_p2_lone<false>, p2_grid(a.n_parts), 256, s, a);
 }
 void launch_p2_graph(hipStream_t s, const P2Args& a) {
     if (!a.n_cells) return;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    static const uint32_t per_cu = [] { const char* e = getenv("AFQ_P2_GRAPH_WGS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 16 ? (uint32_t)v : 4u; }();   // (measurements: workgroups per CU)
     // The cells come largest first.  A cell is one workgroup's from its first phase to its last, and a range's graph kernel is not
     // over before its largest cell is (a 290 k-read cell: 15 ms at 256 threads - twice what the rest of its range takes on the whole
-    // chip): the first n_big cells - those of 25 000 reads or more (AFQ_P2_BIG_READS) - get 1024 threads each, in a launch of their own.
-    const uint32_t n_big = a.n_big < a.n_cells ? a.n_big : a.n_cells;
-    if (n_big) AFQ_LAUNCH(k_p2_graph<1024>, n_big < (uint32_t)cus ? n_big : (uint32_t)cus, 1024, s, a, 0u, n_big, a.work_counter + 2);
-    const uint32_t rest = a.n_cells - n_big;
-    const uint32_t nb = rest < per_cu * (uint32_t)cus ? rest : per_cu * (uint32_t)cus;
-    static const bool g512 = [] { const char* e = getenv("AFQ_P2_GRAPH_NT"); return e && atoi(e) == 512; }();   // (measurements)
-    if (rest && g512) AFQ_LAUNCH(k_p2_graph<512>, nb, 512, s, a, n_big, a.n_cells, a.work_counter);
-    else if (rest) AFQ_LAUNCH(k_p2_graph<kGNT>, nb, kGNT, s, a, n_big, a.n_cells, a.work_counter);
-    static const uint32_t cover_per_cu = [] { const char* e = getenv("AFQ_P2_COVER_WGS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 16 ? (uint32_t)v : 6u; }();
-    const uint32_t nc = a.n_cells < cover_per_cu * (uint32_t)cus ? a.n_cells : cover_per_cu * (uint32_t)cus;
-    if (n_big) AFQ_LAUNCH(k_p2_cover<1024>, n_big < (uint32_t)cus ? n_big : (uint32_t)cus, 1024, s, a, 0u, n_big, a.work_counter + 3);   // (the big cells' covers likewise)
-    if (rest) AFQ_LAUNCH(k_p2_cover<kGNT>, nc < rest ? nc : rest, kGNT, s, a, n_big, a.n_cells, a.work_counter2);
-    // ... and the components the covers set aside at a tie, in the reference's order (k_p2_tied: 49 / 98 KiB of LDS)
-    // (256 threads and three cells to a CU for all but the cells of 100 000 reads or more: what a cell's set-aside components cost is a
-    //  chain of a dozen dependent steps, not work - one 1024-thread workgroup per CU took 6.4 ms per configs[2] step for what this does in a fraction)
-    const uint32_t n_huge = a.n_huge < n_big ? a.n_huge : n_big, rest_t = a.n_cells - n_huge;
-    if (n_huge) AFQ_LAUNCH(k_p2_tied<1024>, n_huge < (uint32_t)cus ? n_huge : (uint32_t)cus, 1024, s, a, 0u, n_huge, a.work_counter + 5);
-    if (rest_t) AFQ_LAUNCH(k_p2_tied<kGNT>, rest_t < 3 * (uint32_t)cus ? rest_t : 3 * (uint32_t)cus, kGNT, s, a, n_huge, a.n_cells, a.work_counter + 4);
+    // chip): the first n_big cells - those of 15 000 reads or more - get 1024 threads each, in launches of their own; the others
+    // 256 threads, four (graph: 147 VGPRs, 48.5 KiB of LDS), six (cover) and three (ties: 49 KiB) workgroups to a CU.
+    const uint32_t n_big = a.n_big < a.n_cells ? a.n_big : a.n_cells, rest = a.n_cells - n_big, ucus = (uint32_t)cus;
+    if (n_big) AFQ_LAUNCH(k_p2_graph<1024>, std::min(n_big, ucus), 1024, s, a, 0u, n_big, a.work_counter + 2);
+    if (rest) AFQ_LAUNCH(k_p2_graph<kGNT>, std::min(rest, 4 * ucus), kGNT, s, a, n_big, a.n_cells, a.work_counter);
+    if (n_big) AFQ_LAUNCH(k_p2_cover<1024>, std::min(n_big, ucus), 1024, s, a, 0u, n_big, a.work_counter + 3);   // (the big cells' covers likewise)
+    if (rest) AFQ_LAUNCH(k_p2_cover<kGNT>, std::min(rest, 6 * ucus), kGNT, s, a, n_big, a.n_cells, a.work_counter2);
+    // ... and the components the covers set aside at a tie, in the reference's order
+    if (n_big) AFQ_LAUNCH(k_p2_tied<1024>, std::min(n_big, ucus), 1024, s, a, 0u, n_big, a.work_counter + 5);
+    if (rest) AFQ_LAUNCH(k_p2_tied<kGNT>, std::min(rest, 3 * ucus), kGNT, s, a, n_big, a.n_cells, a.work_counter + 4);
 }
 
 }  // namespace afq

@@ -950,6 +950,10 @@ def main():
                 # The line is ~20 KB and a log keeps its tail: the last key is a few hundred bytes with every leg's
                 # [value (M reads/s, atac: M fragments/s), ms per step, roofline.frac, roofline.frac_step] - or its error / skip reason.
                 out["legs"] = legs_summary(legs)
+            out["runtime_settings"] = {"GPU_FORCE_BLIT_COPY_SIZE": os.environ.get("GPU_FORCE_BLIT_COPY_SIZE"),
+                                       "what": "0 = device<->host copies on the DMA engines; set by this script before the HIP runtime came up unless the caller's environment said otherwise"}
+            if legs:
+                out["legs"] = out.pop("legs")   # (stays the last key)
             print(json.dumps(out), flush=True)
     finally:
         if q is not None:

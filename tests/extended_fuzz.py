@@ -18,7 +18,7 @@ synth = pkg.synth
 
 
 def one_tailed(seed):
-    """Third family (seeds from 2000; from 3000: parsimony with AFQ_P2_LONE_COOP=2): the bench's label-tail model out of the native generator - reads of up to 64 alignments on
+    """Third family (seeds from 2000; from 3000: parsimony with AFQ_TEST_P2_LONE_COOP=2): the bench's label-tail model out of the native generator - reads of up to 64 alignments on
     gene families - through a decoder picked per seed (the planner's choice, lane per record, lane per dword with either way of
     finding a record's repeated genes) and every resolution."""
     import importlib
@@ -32,7 +32,7 @@ def one_tailed(seed):
     coop = str(int(rng.integers(0, 3)))   # k_p2_lone: labels over four refs by their lane in scratch memory (0), by the wave (1), 5..8 refs by the lane in registers and 9..64 by the wave (2)
     if seed >= 3000:   # fourth family: parsimony only, the lone-vertex kernel's per-lane route for labels of 5..8 refs
         res, coop = ["parsimony", "parsimony-em"][seed % 2], "2"
-    for k, v in (("AFQ_DECODE", dec), ("AFQ_DECODE_DEDUP", dedup), ("AFQ_P2_LONE_COOP", coop)):
+    for k, v in (("AFQ_TEST_DECODE", dec), ("AFQ_TEST_DECODE_DEDUP", dedup), ("AFQ_TEST_P2_LONE_COOP", coop)):
         if v is None:
             os.environ.pop(k, None)
         else:
@@ -50,7 +50,7 @@ def one_tailed(seed):
         rehash = q.label_rehash_count()
     finally:
         q.close()
-        for k in ("AFQ_DECODE", "AFQ_DECODE_DEDUP", "AFQ_P2_LONE_COOP"):
+        for k in ("AFQ_TEST_DECODE", "AFQ_TEST_DECODE_DEDUP", "AFQ_TEST_P2_LONE_COOP"):
             os.environ.pop(k, None)
     want = ora.quant(cfg, d.tid_to_gid, d.data, d.chunk_off, n_threads=os.cpu_count() or 1, em_arith="reference" if os.environ.get("AFQ_EM_ORDER") == "canonical" else "fixed")
     assert_same_result(got, want, what=f"seed {seed} {res} usa={usa} decoder={dec} dedup={dedup} lone_coop={coop} {kw} cells={len(d.chunk_off)}")
@@ -76,9 +76,9 @@ def one(seed):
     b, off = s.encode()
     kw = dict(small_thresh=int(rng.choice([0, 100])))
     if seed % 3 == 1:   # every third workload: tied components set aside in every cell (k_p2_tied), not only in those whose classes outgrow the LDS table
-        os.environ["AFQ_P2_DEFER_MIN"] = "0"
+        os.environ["AFQ_TEST_P2_DEFER_MIN"] = "0"
     else:
-        os.environ.pop("AFQ_P2_DEFER_MIN", None)
+        os.environ.pop("AFQ_TEST_P2_DEFER_MIN", None)
     if rng.integers(0, 4) == 0:
         kw["pug_exact_umi"] = True
     if rng.integers(0, 4) == 0:

@@ -50,7 +50,7 @@ def test_atac_from_rad_matches_oracle_on_generated_cells(oracle, monkeypatch, pi
     host bytes and device-resident bytes; cells of 1 .. 40 000 records and an empty-record chunk.  piped: the batch goes
     through in four ranges whose results cross PCIe under the later ranges' kernels (what inputs over 128 MB do)."""
     if piped:
-        monkeypatch.setenv("AFQ_ATAC_PIPE_BYTES", "1")
+        monkeypatch.setenv("AFQ_TEST_ATAC_PIPE_BYTES", "1")
     d, off = sn.generate_atac(seed=9, n_cells=300, frags_per_cell=3000, flen_sigma=1.2)
     big, boff = sn.generate_atac(seed=10, n_cells=2, frags_per_cell=40000)
     tiny_b, tiny_off = rad.encode_atac_cells([(7, [[(2, 4, 10, 100)]]), (8, [[]]), (9, [[(0, 4, 1, 1)], [(0, 4, 1, 1)]])])

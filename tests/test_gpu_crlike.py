@@ -430,9 +430,9 @@ def test_crlike_em_overflow_paths(oracle):
 
 
 def test_many_ranges_pipeline(oracle, monkeypatch):
-    """A batch cut into many ranges (forced by AFQ_RANGE_BYTES) goes through the two-buffer-set pipeline
+    """A batch cut into many ranges (forced by AFQ_TEST_RANGE_BYTES) goes through the two-buffer-set pipeline
     and yields the same rows in the same cell order."""
-    monkeypatch.setenv("AFQ_RANGE_BYTES", "200000")
+    monkeypatch.setenv("AFQ_TEST_RANGE_BYTES", "200000")
     sizes = [5000, 3000, 2500, 2000, 1500, 1200, 900, 600, 300, 120, 60, 20, 5, 1]
     for res in ("cr-like", "cr-like-em", "parsimony-em"):
         s = synth.synth(41, sizes, num_genes=200, txp_per_gene=3, dup=0.5, cross=0.4, umi_err=0.02)
@@ -457,10 +457,9 @@ def test_context_reused_across_batches(oracle, monkeypatch, resolution, ranges):
     range are compacted behind its kernels into the slot's row buffers as the previous batches left them (k_row_ptr + k_compact;
     csrc/afq_api.cpp: run_range / finish_range): a first batch finds none (the host compacts after allocating), a repeat fits, a
     larger batch does not fit and is compacted again once the buffers have grown, a smaller one fits with room to spare.  Same
-    rows as the oracle every time - in both orders of sizes, with one range per batch and with many (two slots taking turns),
-    with the range pipeline's other switches in their old positions - and the same rows with that compaction switched off."""
+    rows as the oracle every time - in both orders of sizes, with one range per batch and with many (two slots taking turns)."""
     if ranges == "many":
-        monkeypatch.setenv("AFQ_RANGE_BYTES", "150000")
+        monkeypatch.setenv("AFQ_TEST_RANGE_BYTES", "150000")
     s = synth.synth(52, [6000, 5000, 3000, 2500, 1500, 800, 300, 90, 20, 3], num_genes=400, txp_per_gene=2, dup=0.4, cross=0.3, umi_err=0.02)
     b, off = s.encode()
     n = len(off)
@@ -471,18 +470,14 @@ def test_context_reused_across_batches(oracle, monkeypatch, resolution, ranges):
         return b[lo:hi], np.asarray(off[a:e], np.uint64) - np.uint64(lo)
 
     growing = [(n - 2, n), (n // 2, n), (n // 2, n), (0, n), (0, n), (2, n)]   # tiny, larger, repeat, whole, repeat, a little less
-    for cuts, env in ((growing, {}), (growing[::-1], {}), (growing, {"AFQ_TIMER_MODE": "pair", "AFQ_TAIL_OVERLAP": "1", "AFQ_DEVICE_TABLES": "0"}),
-                      (growing, {"AFQ_CHAIN_COMPACT": "0"})):
-        with monkeypatch.context() as mp:
-            for k, v in env.items():
-                mp.setenv(k, v)
-            q = pkg.Quantifier(cfg, s.tid_to_gid)
-            try:
-                for a, e in cuts:
-                    bb, oo = batch(a, e)
-                    assert_same_result(q.quant_chunks(bb, oo), oracle.quant(cfg, s.tid_to_gid, bb, oo), what=f"{resolution} cells [{a}, {e}) {env}")
-            finally:
-                q.close()
+    for cuts in (growing, growing[::-1]):
+        q = pkg.Quantifier(cfg, s.tid_to_gid)
+        try:
+            for a, e in cuts:
+                bb, oo = batch(a, e)
+                assert_same_result(q.quant_chunks(bb, oo), oracle.quant(cfg, s.tid_to_gid, bb, oo), what=f"{resolution} cells [{a}, {e})")
+        finally:
+            q.close()
 
 
 @pytest.mark.parametrize("usa", [False, True])
@@ -527,9 +522,9 @@ def test_tie_shapes_and_wide_umis(oracle, usa, pad_reads):
 
 def set_decoder(monkeypatch, decoder):
     """recs: one lane per record; keys: one lane per dword, a record's repeated genes found by look-back compares and a scan;
-    keys-hash: one lane per dword, repeated genes found through an LDS hash table (AFQ_DECODE_DEDUP=hash)."""
-    monkeypatch.setenv("AFQ_DECODE", "keys" if decoder == "keys-hash" else decoder)
-    monkeypatch.setenv("AFQ_DECODE_DEDUP", "hash" if decoder == "keys-hash" else "scan")   # (hash is the default)
+    keys-hash: one lane per dword, repeated genes found through an LDS hash table (AFQ_TEST_DECODE_DEDUP=hash)."""
+    monkeypatch.setenv("AFQ_TEST_DECODE", "keys" if decoder == "keys-hash" else decoder)
+    monkeypatch.setenv("AFQ_TEST_DECODE_DEDUP", "hash" if decoder == "keys-hash" else "scan")   # (hash is the default)
 
 
 @pytest.mark.parametrize("decoder", ["keys", "keys-hash"])
@@ -616,12 +611,12 @@ def test_giant_cell_beyond_the_lds_histogram(oracle, usa):
     assert_same_result(got, want)
 
 
-@pytest.mark.parametrize("env", [{"AFQ_FIXED_SLABS": "0"}, {"AFQ_SLAB_CAP": "8"}, {"AFQ_SLAB_CAP": "200"}, {}])
+@pytest.mark.parametrize("env", [{"AFQ_TEST_FIXED_SLABS": "0"}, {"AFQ_TEST_SLAB_CAP": "8"}, {"AFQ_TEST_SLAB_CAP": "200"}, {}])
 @pytest.mark.parametrize("res,usa", [("cr-like", False), ("cr-like", True), ("cr-like-em", True)])
 def test_bucket_placement_routes_agree(oracle, monkeypatch, env, res, usa):
     """Keys of a multi-bucket cell go to fixed-capacity bucket slabs without a counting pass; a bucket that outgrows its
     slab sends its cell through the exact placement (scan of the counts the cursors already hold).  The exact route
-    alone (AFQ_FIXED_SLABS=0), slabs so small that every cell overflows (8), slabs that only the heavy-UMI cell
+    alone (AFQ_TEST_FIXED_SLABS=0), slabs so small that every cell overflows (8), slabs that only the heavy-UMI cell
     overflows (200), and the default: all against the oracle."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)

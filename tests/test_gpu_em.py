@@ -81,9 +81,9 @@ def test_em_init_uniform(oracle_module, init_uniform):
 @pytest.mark.parametrize("usa", [False, True])
 def test_every_instance_of_the_rounds_kernel_agrees(oracle_module, monkeypatch, tier, usa):
     """The rounds kernel has five instances by cell size (all in LDS at 256 / 512 / 1024 threads, lists streamed, everything in
-    global memory); AFQ_EM2_MIN_TIER sends every cell to the given one or a larger one: the sums are integers, the rows
+    global memory); AFQ_TEST_EM2_MIN_TIER sends every cell to the given one or a larger one: the sums are integers, the rows
     must not move by a bit."""
-    monkeypatch.setenv("AFQ_EM2_MIN_TIER", str(tier))
+    monkeypatch.setenv("AFQ_TEST_EM2_MIN_TIER", str(tier))
     s, b, off = _workload(usa, seed=9)
     cfg = cfg_for(s, "parsimony-em")
     assert_same_result(_device(cfg, s, b, off), oracle_module.quant(cfg, s.tid_to_gid, b, off, em_arith="fixed"), what=f"tier {tier}")
@@ -101,7 +101,7 @@ def test_em_long_labels_and_many_classes(oracle_module):
 
 def test_em_scratch_short_of_the_plan_is_sized_on_the_host(oracle_module, monkeypatch):
     """The EM follows a range's kernels on the device, in scratch set aside from an upper bound ahead of time; with next to
-    nothing set aside (AFQ_EM2_SCRATCH_FRAC) the device-side plan does not fit, the kernels return at once and the host sizes the
+    nothing set aside (AFQ_TEST_EM2_SCRATCH_FRAC) the device-side plan does not fit, the kernels return at once and the host sizes the
     EM itself: same rows, and the counter says so."""
     s, b, off = _workload(True, seed=12)
     cfg = cfg_for(s, "parsimony-em")
@@ -120,7 +120,7 @@ def test_em_scratch_short_of_the_plan_is_sized_on_the_host(oracle_module, monkey
             "b, off = s.encode(); q = pkg.Quantifier(cfg_for(s, 'parsimony-em'), s.tid_to_gid); r = q.quant_chunks(b, off)\n"
             "print(q.em_resize_count(), r.val.view(np.uint32).sum(dtype=np.uint64), len(r.gene))\n") % (ROOT, ROOT)
     import os
-    env = dict(os.environ, AFQ_EM2_SCRATCH_FRAC="0.00001")   # (read once per process: a process of its own)
+    env = dict(os.environ, AFQ_TEST_EM2_SCRATCH_FRAC="0.00001")   # (read once per process: a process of its own)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-500:]
     n_resized, vsum, nnz = out.stdout.split()[-3:]

@@ -66,8 +66,8 @@ def test_any_split_of_the_batch_gives_the_same_rows(big):
 
 def test_range_planning_and_decoder_choice_do_not_matter(big, monkeypatch):
     rad, cfg, q, r = big
-    monkeypatch.setenv("AFQ_RANGE_BYTES", "7e8")   # ~15 ranges instead of 5
-    monkeypatch.setenv("AFQ_DECODE", "keys")       # lane-per-dword decoder instead of lane-per-record
+    monkeypatch.setenv("AFQ_TEST_RANGE_BYTES", "7e8")   # ~15 ranges instead of 5
+    monkeypatch.setenv("AFQ_TEST_DECODE", "keys")       # lane-per-dword decoder instead of lane-per-record
     assert _digest(q.quant_chunks(rad.data, rad.chunk_off)) == _digest(r)
 
 

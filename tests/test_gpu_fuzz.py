@@ -18,7 +18,7 @@ def test_random_workloads_match_the_oracle(oracle, seed, monkeypatch):
     rng = np.random.default_rng(1000 + seed)
     res = RES[seed % len(RES)]
     if res.startswith("parsimony") and (seed // len(RES)) % 2:   # every other parsimony workload: tied components set aside in every cell (k_p2_tied)
-        monkeypatch.setenv("AFQ_P2_DEFER_MIN", "0")
+        monkeypatch.setenv("AFQ_TEST_P2_DEFER_MIN", "0")
     usa = bool(rng.integers(0, 2))
     sizes = [int(x) for x in rng.choice([1, 2, 7, 40, 99, 100, 101, 250, 251, 600, 1500, 4000], size=int(rng.integers(3, 9)))]
     if seed % 5 == 0:

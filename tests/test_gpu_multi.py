@@ -64,7 +64,7 @@ def test_generated_workload_quantifies_like_the_oracle(oracle, monkeypatch, tail
     an ordinary collated RAD as far as both are concerned - with the label-length tail too (labels of up to dozens of refs
     on gene families: the long-record paths of the decoders, hashed label keys, molecules of more than four genes).  On the
     tailed input the parsimony resolutions also run with each way the lone-vertex kernel has of resolving a label of more than
-    four refs (AFQ_P2_LONE_COOP: by its lane in scratch memory, by the wave, 5..8 refs by the lane in registers; the default picks
+    four refs (AFQ_TEST_P2_LONE_COOP: by its lane in scratch memory, by the wave, 5..8 refs by the lane in registers; the default picks
     by range)."""
     d = sn.generate_device(device=0, seed=3, n_cells=60, median_reads=3000.0, num_genes=400, txp_per_gene=4, usa=True, umi_err=0.03,
                            tail=tail, family=8)
@@ -76,14 +76,14 @@ def test_generated_workload_quantifies_like_the_oracle(oracle, monkeypatch, tail
             for lone in ((None, "0", "1", "2") if tail and res.startswith("parsimony") else (None,)):
                 with monkeypatch.context() as mp:
                     if lone is not None:
-                        mp.setenv("AFQ_P2_LONE_COOP", lone)
+                        mp.setenv("AFQ_TEST_P2_LONE_COOP", lone)
                     q = pkg.Quantifier(cfg, d.tid_to_gid, device=0)
                     try:
                         q.submit_device(d.d_ptr, d.n_bytes, d.chunk_off)
                         got = q.collect()
                     finally:
                         q.close()
-                assert_same_result(got, want, what=f"{res} AFQ_P2_LONE_COOP={lone}")
+                assert_same_result(got, want, what=f"{res} AFQ_TEST_P2_LONE_COOP={lone}")
     finally:
         d.free()
 
@@ -103,10 +103,10 @@ def test_piped_upload_matches_resident_input(monkeypatch, pinned, res):
     cfg = cfg_for(s, res)
     q = pkg.Quantifier(cfg, s.tid_to_gid, device=0)
     try:
-        monkeypatch.setenv("AFQ_NO_H2D_PIPELINE", "1")
+        monkeypatch.setenv("AFQ_TEST_NO_H2D_PIPELINE", "1")
         want = q.quant_chunks(b, off)
-        monkeypatch.delenv("AFQ_NO_H2D_PIPELINE")
-        monkeypatch.setenv("AFQ_RANGE_BYTES", str(400_000))
+        monkeypatch.delenv("AFQ_TEST_NO_H2D_PIPELINE")
+        monkeypatch.setenv("AFQ_TEST_RANGE_BYTES", str(400_000))
         if pinned:
             t = torch.empty(len(b), dtype=torch.uint8, pin_memory=True)
             t.numpy()[:] = b
@@ -176,7 +176,7 @@ def test_cli_devices_output_is_independent_of_the_device_count(tmp_path, res, ex
     outs = []
     for name, dev in (("one", ["--device", "0"]), ("three", ["--devices", "0,0,0"])):
         o = tmp_path / name
-        env = dict(os.environ, AFQ_QUEUE_BATCH_BYTES="30000") if name == "three" else None   # (a queue of several batches even on this small input)
+        env = dict(os.environ, AFQ_TEST_QUEUE_BATCH_BYTES="30000") if name == "three" else None   # (a queue of several batches even on this small input)
         r = subprocess.run([CLI, "quant", "-i", str(tmp_path / "in"), "-m", tg, "-o", str(o), "-r", res, "-t", "4"] + dev + extra, capture_output=True, text=True, env=env)
         assert r.returncode == 0, r.stderr
         outs.append(o)
@@ -197,7 +197,7 @@ def test_cli_devices_output_is_independent_of_the_device_count(tmp_path, res, ex
     dv = json.load(open(outs[1] / "afquant_devices.json"))
     assert dv["batches"] >= 3 and sum(d["cells"] for d in dv["devices"]) == 10 and all(d["batches"] >= 1 for d in dv["devices"])
     r = subprocess.run([CLI, "quant", "-i", str(tmp_path / "in"), "-m", tg, "-o", str(tmp_path / "bad"), "-r", res, "--devices", "0,99"], capture_output=True, text=True,
-                       env=dict(os.environ, AFQ_QUEUE_BATCH_BYTES="30000"))
+                       env=dict(os.environ, AFQ_TEST_QUEUE_BATCH_BYTES="30000"))
     assert r.returncode != 0 and "device 99" in r.stderr
 
 
@@ -212,7 +212,7 @@ def test_cli_device_queue_balances_a_largest_first_file(tmp_path):
     rows = [(names[t], f"G{g >> 1}", "S" if g % 2 == 0 else "U") for t, g in enumerate(d.tid_to_gid.tolist())]
     tg = rad.write_quant_input_dir(str(tmp_path / "in"), d.data.tobytes(), len(d.chunk_off), names, rows, cblen=16, ulen=12)
     outs = []
-    for name, dev, env in (("one", ["--device", "0"], None), ("three", ["--devices", "0,0,0"], dict(os.environ, AFQ_QUEUE_BATCH_BYTES=str(d.n_bytes // 90)))):
+    for name, dev, env in (("one", ["--device", "0"], None), ("three", ["--devices", "0,0,0"], dict(os.environ, AFQ_TEST_QUEUE_BATCH_BYTES=str(d.n_bytes // 90)))):
         o = tmp_path / name
         r = subprocess.run([CLI, "quant", "-i", str(tmp_path / "in"), "-m", tg, "-o", str(o), "-r", "parsimony-em", "-t", "8"] + dev, capture_output=True, text=True, env=env)
         assert r.returncode == 0, r.stderr
@@ -417,7 +417,7 @@ def test_submit_reader_pulls_the_bytes_through_a_callback(monkeypatch):
         want = q.quant_chunks(b, off)
         for rng in (None, "300000"):
             if rng:
-                monkeypatch.setenv("AFQ_RANGE_BYTES", rng)
+                monkeypatch.setenv("AFQ_TEST_RANGE_BYTES", rng)
             rc = q.lib.afq_submit_reader(q._h, cb, None, b.nbytes, o64.ctypes.data_as(C.POINTER(C.c_uint64)), hdr.ctypes.data_as(C.POINTER(C.c_uint32)), len(off), 0)
             assert rc == 0, q.lib.afq_last_error(q._h)
             assert_same_result(q.collect(), want, what=f"reader, ranges {rng}")

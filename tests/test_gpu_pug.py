@@ -18,14 +18,14 @@ def pug_route(request, monkeypatch):
     25 000 reads), and with EVERY cell covering its components in slot order and setting the tied ones aside for k_p2_tied (by
     default only the cells whose classes outgrow the graph kernel's LDS table: big cells, long labels)."""
     if request.param == "one-workgroup":
-        monkeypatch.setenv("AFQ_PUG_ROUTE", "mono")
+        monkeypatch.setenv("AFQ_TEST_PUG_ROUTE", "mono")
     elif request.param == "handed-back":
-        monkeypatch.setenv("AFQ_P2_PART_CAP", "24")
+        monkeypatch.setenv("AFQ_TEST_P2_PART_CAP", "24")
     elif request.param == "graph-1024":
-        monkeypatch.setenv("AFQ_P2_BIG_READS", "300")
-        monkeypatch.setenv("AFQ_P2_DEFER_MIN", "0")
+        monkeypatch.setenv("AFQ_TEST_P2_BIG_READS", "300")
+        monkeypatch.setenv("AFQ_TEST_P2_DEFER_MIN", "0")
     elif request.param == "ties-set-aside":
-        monkeypatch.setenv("AFQ_P2_DEFER_MIN", "0")
+        monkeypatch.setenv("AFQ_TEST_P2_DEFER_MIN", "0")
     return request.param
 
 
@@ -124,9 +124,9 @@ def test_neighbour_search_routes_agree(oracle, monkeypatch, res, usa):
     b, off = s.encode()
     cfg = cfg_for(s, res)
     fast = _quant(cfg, s.tid_to_gid, b, off)
-    monkeypatch.setenv("AFQ_PUG_GLOBAL_ROUTE", "1")
+    monkeypatch.setenv("AFQ_TEST_PUG_GLOBAL_ROUTE", "1")
     slow = _quant(cfg, s.tid_to_gid, b, off)
-    monkeypatch.delenv("AFQ_PUG_GLOBAL_ROUTE")
+    monkeypatch.delenv("AFQ_TEST_PUG_GLOBAL_ROUTE")
     assert_same_result(fast, slow, what="LDS route vs global route")
     want = oracle.quant(cfg, s.tid_to_gid, b, off[1:], n_threads=4)
     for j in range(want.n_cells):
@@ -152,9 +152,9 @@ def test_skewed_umis_fall_back_to_the_global_route(oracle):
 @pytest.mark.parametrize("res", ["parsimony", "parsimony-gene"])
 def test_pug_batches_through_both_decoders(oracle, monkeypatch, decoder, res):
     """A parsimony batch turns records into reads (label key, UMI, offset) in the decode: the lane-per-record kernel when
-    records are short (AFQ_DECODE=recs, the planner's choice for 10x data), the older per-record walk otherwise
-    (AFQ_DECODE=keys).  Records of every awkward length (around the three inline refs, up to the 64-dword halo), repeated genes, tiny cells that take the cr-like rule next to PUG cells: both against the oracle."""
-    monkeypatch.setenv("AFQ_DECODE", decoder)
+    records are short (AFQ_TEST_DECODE=recs, the planner's choice for 10x data), the older per-record walk otherwise
+    (AFQ_TEST_DECODE=keys).  Records of every awkward length (around the three inline refs, up to the 64-dword halo), repeated genes, tiny cells that take the cr-like rule next to PUG cells: both against the oracle."""
+    monkeypatch.setenv("AFQ_TEST_DECODE", decoder)
     rng = np.random.default_rng(77)
     n_txp, n_genes = 900, 300
     t2g = (rng.permutation(n_txp) % n_genes).astype(np.uint32)
@@ -232,7 +232,7 @@ def test_parsimony_over_chunks_at_odd_offsets(oracle):
 def test_widened_batch_cut_into_many_ranges(oracle, monkeypatch, res):
     """The widened copy is made range by range (each range's kernels wait for ITS bytes when the input is piped over
     PCIe): force a dozen ranges and the pipelined upload on a 2-byte-UMI batch."""
-    monkeypatch.setenv("AFQ_RANGE_BYTES", str(1 << 20))
+    monkeypatch.setenv("AFQ_TEST_RANGE_BYTES", str(1 << 20))
     sizes = [900, 700, 650, 600, 500, 450, 400, 300, 250, 200, 150, 120, 110, 90, 60, 30, 8, 2]
     s = synth.synth(123, sizes, num_genes=300, txp_per_gene=3, umi_len=8, dup=0.4, cross=0.3, umi_err=0.03, max_extra_na=6)
     cells = _cells_of(s, lambda ci: 100000 + 7 * ci)
@@ -382,7 +382,7 @@ def test_components_of_65_to_4096_vertices_stay_with_the_phase_kernels(oracle, m
     """Short UMIs in a cell of a few thousand reads chain hundreds of vertices into one component.  Up to 4096 vertices (and
     --large-graph-thresh) the phase kernels cover such a component themselves, a workgroup to it (cover_big in
     csrc/afq_pug_common.h); until round 4 its cell went back to the one-workgroup kernel.  afq_mono_cell_count says which
-    kernel had the cells; AFQ_P2_MAX_COMP=64 brings the old routing back - same rows (pugutils.rs:1004-1200).  Under the default
+    kernel had the cells; AFQ_TEST_P2_MAX_COMP=64 brings the old routing back - same rows (pugutils.rs:1004-1200).  Under the default
     --large-graph-thresh of 1000 the two largest components are resolved winner-take-all instead (pugutils.rs:916-982) - by the
     phase kernels as well (cover_large in csrc/afq_pug2.hip), and the cells are flagged."""
     # (components of 2499, 1117, 132, 70 vertices without the USA labels, of 2552, 1119, 192 with them)
@@ -403,7 +403,7 @@ def test_components_of_65_to_4096_vertices_stay_with_the_phase_kernels(oracle, m
     assert_same_result(got, want, what=res)
     if pug_route in ("phase-kernels", "graph-1024"):
         assert n_mono == 0, "no cell should have needed the one-workgroup kernel"
-        monkeypatch.setenv("AFQ_P2_MAX_COMP", "64")
+        monkeypatch.setenv("AFQ_TEST_P2_MAX_COMP", "64")
         got64, n_mono64 = run()
         assert n_mono64 >= 1, "the cells were meant to hold components of more than 64 vertices"
         assert_same_result(got64, want, what=res + ", components over 64 vertices handed back")
