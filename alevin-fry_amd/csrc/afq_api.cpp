@@ -159,6 +159,7 @@ struct RangeState {
     uint64_t chain_cap = 0;  // ... against d_gene / d_val of this many entries: finish_range compacts again, after growing them, if the range has more
     bool em_inline = false;  // the EM was enqueued behind the range's kernels (offsets made on the device); finish_range only checks that its scratch sufficed
     bool in_flight = false;
+    bool pug_cell_launched = true;   // the range's k_pug_cell launch was made (else a handed-back cell means: run the range again)
     hipEvent_t kernels_done = nullptr;
     std::vector<TimedLaunch> launches;  // HIP-event brackets of this range's kernels (cfg.profile)
     std::vector<DevBuf*> all() {
@@ -224,6 +225,7 @@ struct afq_ctx {
     uint64_t n_pool_regrow = 0;    // ranges run again with a larger parsimony pool
     uint64_t n_mono_cells = 0;     // parsimony cells resolved by the one-workgroup kernel (sent there directly, or handed back by the phase kernels)
     uint64_t n_em_resized = 0;     // ranges whose EM scratch was sized on the host after the device-side plan did not fit
+    bool handback_seen = false;    // the phase kernels have handed a cell back to the one-workgroup kernel in some range of this context
     uint32_t retry_cuts = 0;       // how many times the range being finished has been cut around a failing cell (finish_range)
     std::vector<TimedLaunch> launches;
     std::vector<hipEvent_t> event_pool;
@@ -346,7 +348,7 @@ struct P2Small {
 P2Small p2_small_layout(uint64_t n, uint64_t parts, uint64_t tiles, uint64_t n_pug) {
     P2Small L{};
     uint64_t o = 0;
-    L.pcnt = o; o += parts; L.pnp = o; o += parts; L.pncls = o; o += parts; L.pn3 = o; o += parts; L.gcnt = o; o += 4 * n; L.fb = o; o += n; L.ctr = o; o += 8; L.gdesc = o; o += 16 * n;
+    L.pcnt = o; o += parts; L.pnp = o; o += parts; L.pncls = o; o += parts; L.pn3 = o; o += parts; L.gcnt = o; o += 4 * n; L.fb = o; o += n; L.ctr = o; o += 12; L.gdesc = o; o += 16 * n;
     L.zero_words = o;
     L.poff = o; o += parts; L.pcur = o; o += parts; L.pnv = o; o += parts; L.pcell = o; o += parts;
     o = (o + 3) & ~3ull;
@@ -881,9 +883,13 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
         pa.hw = 1 + g.bc_bytes / 4 + g.umi_bytes / 4; pa.umi_pairs = std::min<uint32_t>(g.umi_len ? g.umi_len : g.umi_bytes * 4, 22);
         pa.gene_level = (g.resolution == AFQ_RES_PARSIMONY_GENE || g.resolution == AFQ_RES_PARSIMONY_GENE_EM) ? 1u : 0u;
         pa.force_global_route = test_hook("PUG_GLOBAL_ROUTE") ? 1u : 0u;
-        tc.seg(K_PUG);
-        launch_pug(s, pa, n_pug_blocks);
-    }
+        // The one-workgroup kernel is 0.36 ms of a range even when its list is empty and whatever its grid (its private segment -
+        // 138 spilled registers per lane - is set up per dispatch: 1.1 ms of a configs[2] step that hands no cell back).  It is
+        // therefore launched only when the host sent it cells itself or this context has seen the phase kernels hand one back;
+        // the first range that does (finish_range reads the count) is run again, with the kernel, once in a context's life.
+        B.pug_cell_launched = !mono_cells.empty() || c->handback_seen;
+        if (B.pug_cell_launched) { tc.seg(K_PUG); launch_pug(s, pa, n_pug_blocks); }
+    } else B.pug_cell_launched = true;
     // What the next range's kernels wait for: all of this range's.  (Letting them start beside the per-cell histograms a range
     // without an EM ends in was measured on the headline in round 4 and not kept: the decoder fills every SIMD at eight
     // waves, the histogram workgroups - 73 KiB of LDS each - get a CU only as decoder workgroups drain, the bracket of
@@ -988,6 +994,13 @@ int finish_range(afq_ctx* c, int slot) {
             if (!rc) rc = finish_range(c, slot);
         }
         if (regrow) B.d_epool.release();   // the enlarged pool is that attempt's alone: the next range plans its own
+        return rc;
+    }
+    if (!st.err_code && !B.pug_cell_launched && B.h_pack.p[9]) {   // cells were handed back and the kernel that takes them was not launched
+        c->handback_seen = true;
+        take_back_attempt();
+        int rc = run_range(c, B.cur, slot, nullptr, B.hash_try, B.pool_try);
+        if (!rc) rc = finish_range(c, slot);
         return rc;
     }
     if (st.err_code) {
@@ -1895,18 +1908,22 @@ int afq_atac_dedup_rad(afq_ctx* c, const uint8_t* bytes, size_t n_bytes, const u
                              d_flen.as<uint16_t>(), d_cnt.as<uint32_t>() + c0, d_bc.as<uint64_t>() + c0, d_stat.as<uint32_t>() + 2ull * c0,
                              d_walk.as<uint32_t>() + c0, nwalk, dst, (uint64_t)n_bytes};
     };
-    // Big batches go through in four ranges of cells: the distinct fragments of range r cross PCIe (1.8 GB for 2*10^8
-    // records: twice the time of all the kernels) on a second stream while the later ranges are still parsed and sorted.
+    // Big batches go through in six ranges of cells: the distinct fragments of range r cross PCIe on a second stream while the
+    // later ranges are still parsed and sorted.  The rows are the long pole - 1.8 GB for 2*10^8 records is 34 ms at the 52 GB/s the
+    // link gives (the e2e leg), against 19 ms for all the kernels - so what matters is how soon the FIRST rows can leave: the
+    // ranges GROW (5, 10, 15, 20, 25, 25 % of the records; four equal ranges kept the link idle for the first quarter of the
+    // kernels), the opposite of the cr-like taper, whose rows are short and whose last range's copy is what nothing hides.
     const char* pipe_env = test_hook("ATAC_PIPE_BYTES");   // (tests: pipeline small inputs too)
     const size_t pipe_min = pipe_env ? (size_t)std::atoll(pipe_env) : ((size_t)128 << 20);
     const bool piped = n_cells >= 8 && n_bytes >= pipe_min;
     bool piped_done = false;
     if (piped) {
-        constexpr uint32_t kR = 4;
+        constexpr uint32_t kR = 6;
+        static const double kGrow[kR] = {0.05, 0.15, 0.30, 0.50, 0.75, 1.0};
         uint32_t cut[kR + 1];
         cut[0] = 0;
         for (uint32_t r = 1; r < kR; ++r) {
-            const uint64_t target = n_rec * r / kR;
+            const uint64_t target = (uint64_t)((double)n_rec * kGrow[r - 1]);
             cut[r] = (uint32_t)(std::lower_bound(cap_ptr.begin(), cap_ptr.begin() + n_cells, target) - cap_ptr.begin());
             if (cut[r] < cut[r - 1]) cut[r] = cut[r - 1];
         }

@@ -208,11 +208,13 @@ struct P2Args {
     uint32_t ref_count, num_genes, usa, num_rows, em, exact_umi, large_thresh, hw, umi_pairs;
     uint32_t tile;       // reads per tile of k_p2_hist / k_p2_scatter: 2048, 4096 or 8192
     uint32_t max_comp;   // vertices of the largest component the phase kernels cover themselves (kP2MaxComp; tests: AFQ_TEST_P2_MAX_COMP)
-    uint32_t n_big;   // the first n_big cells of `order` (largest first) are big enough for a 1024-thread workgroup each (k_p2_graph, k_p2_cover, k_p2_tied)
+    uint32_t n_big;   // the first n_big cells of `order` (largest first: 15 000 reads or more) get a 1024-thread workgroup each in k_p2_graph / k_p2_cover / k_p2_tied
     uint32_t defer_min;   // a cell sets the tied components of its covers aside (k_p2_tied) when its listed components hold more vertices than this; 0xFFFFFFFF: than the graph kernel's LDS class table takes (tests: 0 = every cell)
     uint32_t lone_coop;   // k_p2_lone: a lone vertex whose label has 5..64 refs is resolved by its whole wave (0: by its lane alone, as until late in round 4 - tests, measurements)
 };
-constexpr uint32_t kP2PartTarget = 160;   // planned mean reads per partition (the partition count is a power of two: 80..160)
+constexpr uint32_t kP2PartTarget = 144;   // planned mean reads per partition (the partition count is a power of two: 72..144).  It was 160 until round 5: of a
+                                          // sample's 11 000 cells the one or two whose mean sat just under 160 had a partition over the capacity below (245-260 reads in
+                                          // the largest of 1024 partitions) and were handed back - and k_pug_cell costs 0.4-3 ms per launch whatever it is given
 constexpr uint32_t kP2PartCap = 256;      // reads one partition may hold (one wave sorts it in registers)
 constexpr uint32_t kP2TileHost = 4096;   // reads per histogram / scatter tile (P2Args.tile; k_p2_scatter<512>: 8 reads per thread)
 void launch_p2_split(hipStream_t s, const P2Args& a);

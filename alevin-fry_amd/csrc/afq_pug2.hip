@@ -47,7 +47,7 @@ typedef unsigned __int128 u128;
 constexpr uint32_t kP2Bins = 2048;        // partitions per cell the tile kernels rank in LDS
 constexpr uint32_t kP2TabSlots = 512;     // hash table of one partition's vertices (<= 256)
 #ifndef AFQ_P2_FILT_LG
-#define AFQ_P2_FILT_LG 13
+#define AFQ_P2_FILT_LG 12
 #endif
 constexpr uint32_t kP2FiltLg = AFQ_P2_FILT_LG, kP2FiltBits = 1u << kP2FiltLg;    // presence filter in front of it
 constexpr uint32_t kVCntMask = 0x3FFu;    // vertex word: reads (10 bits) | label signature (19 bits) << 10 | key tag << 29
@@ -373,6 +373,9 @@ __global__ __launch_bounds__(256) void k_p2_part(P2Args A) {
 // (Four partitions to a 256-thread workgroup, a wave each with its own slice of LDS and nothing shared: no workgroup barrier;
 // LDS instructions of one wave execute in order, WAVE_SYNC only keeps the compiler from moving code across.)
 
+#ifndef AFQ_P2_SEARCH_WGS
+#define AFQ_P2_SEARCH_WGS 7   // workgroups per CU the search is compiled for: 72 VGPRs (five spilled), 22.5 KiB of LDS with the 2^12-bit filter.  Measured per configs[2] step: 4 -> 33.5 ms, 5 -> 28.0, 6 -> 25.5 (24.9 with a 2^13-bit filter, which no longer fits seven times), 7 -> 23.7
+#endif
 struct SearchLds {
     uint32_t umi[kP2TabSlots];
     uint32_t word[kP2TabSlots];
@@ -571,7 +574,7 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
     if (lane == 0 && OVER && np != pcap) set_err(A.st, kErrInternal, c.cell);   // (the same search twice: the same pairs)
     WAVE_SYNC();
 }
-__global__ __launch_bounds__(256, 6) void k_p2_search(P2Args A) {
+__global__ __launch_bounds__(256, AFQ_P2_SEARCH_WGS) void k_p2_search(P2Args A) {
     if (A.st->err_code) return;   // an earlier kernel of the range failed (e.g. kErrLabelHash in k_p2_part, which then leaves its partition's vertices unwritten): nothing behind it may read that state - the host runs the range again or reports the error
     __shared__ SearchLds s_lds[4];
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
@@ -1833,18 +1836,22 @@ void launch_p2_graph(hipStream_t s, const P2Args& a) {
     if (!a.n_cells) return;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    // The cells come largest first.  A cell is one workgroup's from its first phase to its last, and a range's graph kernel is not
-    // over before its largest cell is (a 290 k-read cell: 15 ms at 256 threads - twice what the rest of its range takes on the whole
-    // chip): the first n_big cells - those of 15 000 reads or more - get 1024 threads each, in launches of their own; the others
-    // 256 threads, four (graph: 147 VGPRs, 48.5 KiB of LDS), six (cover) and three (ties: 49 KiB) workgroups to a CU.
+    // The cells come largest first.  A cell is one workgroup's from its first phase to its last - a chain of some forty dependent
+    // steps, whatever its size - and a range's kernel is not over before its largest cell is (a 290 k-read cell: 15 ms at 256
+    // threads, twice what the rest of its range takes on the whole chip): the first n_big cells - 15 000 reads or more - get 1024
+    // threads each, a CU to themselves, in launches of their own; the others 256 threads, four (graph: 147 VGPRs, 48.5 KiB of LDS),
+    // four (cover) and three (ties: 49 KiB) workgroups to a CU.  (Round 5 measured 512-thread workgroups at 128 VGPRs, two cells to a
+    // CU, for the cells of 15 000...60 000 / ...100 000 reads: graph + cover + ties 21.8 / 24.1 ms per configs[2] step against 20.4.)
+    // Work counters: graph 0 / 2, cover 1 / 3, ties 4 / 5 (256 / 1024 threads).
     const uint32_t n_big = a.n_big < a.n_cells ? a.n_big : a.n_cells, rest = a.n_cells - n_big, ucus = (uint32_t)cus;
-    if (n_big) AFQ_LAUNCH(k_p2_graph<1024>, std::min(n_big, ucus), 1024, s, a, 0u, n_big, a.work_counter + 2);
-    if (rest) AFQ_LAUNCH(k_p2_graph<kGNT>, std::min(rest, 4 * ucus), kGNT, s, a, n_big, a.n_cells, a.work_counter);
-    if (n_big) AFQ_LAUNCH(k_p2_cover<1024>, std::min(n_big, ucus), 1024, s, a, 0u, n_big, a.work_counter + 3);   // (the big cells' covers likewise)
-    if (rest) AFQ_LAUNCH(k_p2_cover<kGNT>, std::min(rest, 6 * ucus), kGNT, s, a, n_big, a.n_cells, a.work_counter2);
+    uint32_t* const wc = a.work_counter;
+    if (n_big) AFQ_LAUNCH(k_p2_graph<1024>, std::min(n_big, ucus), 1024, s, a, 0u, n_big, wc + 2);
+    if (rest) AFQ_LAUNCH(k_p2_graph<kGNT>, std::min(rest, 4 * ucus), kGNT, s, a, n_big, a.n_cells, wc);
+    if (n_big) AFQ_LAUNCH(k_p2_cover<1024>, std::min(n_big, ucus), 1024, s, a, 0u, n_big, wc + 3);
+    if (rest) AFQ_LAUNCH(k_p2_cover<kGNT>, std::min(rest, 4 * ucus), kGNT, s, a, n_big, a.n_cells, wc + 1);
     // ... and the components the covers set aside at a tie, in the reference's order
-    if (n_big) AFQ_LAUNCH(k_p2_tied<1024>, std::min(n_big, ucus), 1024, s, a, 0u, n_big, a.work_counter + 5);
-    if (rest) AFQ_LAUNCH(k_p2_tied<kGNT>, std::min(rest, 3 * ucus), kGNT, s, a, n_big, a.n_cells, a.work_counter + 4);
+    if (n_big) AFQ_LAUNCH(k_p2_tied<1024>, std::min(n_big, ucus), 1024, s, a, 0u, n_big, wc + 5);
+    if (rest) AFQ_LAUNCH(k_p2_tied<kGNT>, std::min(rest, 3 * ucus), kGNT, s, a, n_big, a.n_cells, wc + 4);
 }
 
 }  // namespace afq

@@ -72,7 +72,7 @@ def parse_args():
                     help="configs3: weak = c3-cells per GPU, strong = c3-cells in total, sharded over the ranks")
     ap.add_argument("--frags-per-cell", type=int, default=20000, help="atac")
     ap.add_argument("--atac-cells", type=int, default=10000, help="atac: cells per GPU (configs[4]: 10^4 x 2*10^4 records)")
-    ap.add_argument("--also", default="auto", help="comma list of extra legs (configs2,configs1_tail,configs2_tail,configs3,atac,e2e,cli,reference), 'auto' or 'none'")
+    ap.add_argument("--also", default="auto", help="comma list of extra legs (configs2,configs1_tail,configs2_tail,configs3,atac,e2e,cli,cli_sz,cli_pug,reference), 'auto' or 'none'")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) by default; gloo + --share-gpu exercises the N>1 logic on a 1-GPU box")
@@ -517,6 +517,7 @@ def run_pbmc(D, args, pkg, sn, usa, resolution, steps, warmup, cpu_seconds, name
                    {"cells_per_s": round(total_cells * steps / elapsed, 1), "nnz": nnz, "keys": st["n_keys"],
                     "overflow_buckets": st["n_overflow_buckets"],
                     "retries": {"label_rehashes": q.label_rehash_count(), "pool_regrows": q.pool_regrow_count(), "em_resizes": q.em_resize_count(),
+                                "cells_through_the_one_workgroup_kernel": q.mono_cell_count(),
                                 "what": "ranges run again under another label hash / with a larger parsimony pool, EMs sized on the host after all - since the context was made (warm-up included)"},
                     "gen_seconds": round(t_gen, 2),
                     **({"rows_crc32": rows_crc(res)} if os.environ.get("AFQ_BENCH_CRC") else {}),   # (measurement scripts: the same rows under every switch)
@@ -652,22 +653,25 @@ def run_e2e_ranks(D, args, pkg, sn, rad, q, steps):
             "imbalance_max_over_mean_time": round(mx[0] / (tot[2] / D.world), 3), "steps": steps}
 
 
-def write_rad_dir(pkg, rad, host_bytes, path):
+def write_rad_dir(pkg, rad, host_bytes, path, n_cells=None, compressed=False):
     names = [f"t{i}" for i in range(len(rad.tid_to_gid))]
     if rad.usa:
         rows = [(names[i], f"g{int(g) >> 1}", "U" if int(g) & 1 else "S") for i, g in enumerate(rad.tid_to_gid)]
     else:
         rows = [(names[i], f"g{int(g)}") for i, g in enumerate(rad.tid_to_gid)]
-    return pkg.rad.write_quant_input_dir(path, host_bytes, len(rad.cell_nrec), names, rows, cblen=16, ulen=12)
+    return pkg.rad.write_quant_input_dir(path, host_bytes, len(rad.cell_nrec) if n_cells is None else n_cells, names, rows, cblen=16, ulen=12,
+                                         compressed=compressed)
 
 
-def run_cli(pkg, rad, host_np, workdir, resolution="cr-like"):
-    """`afquant quant` on the same cells written as a collated-RAD directory: process start to the last output file."""
-    d = os.path.join(workdir, "in")
-    o = os.path.join(workdir, "out")
+def run_cli(pkg, rad, host_np, workdir, resolution="cr-like", n_cells=None, compressed=False, sub="in"):
+    """`afquant quant` on the same cells written as a collated-RAD directory: process start to the last output file.
+    n_cells: only the first n_cells chunks (host_np holds exactly their bytes); compressed: map.collated.rad.sz (snappy frames)."""
+    d = os.path.join(workdir, sub)
+    o = os.path.join(workdir, sub + "_out")
     t0 = time.time()
-    tg = write_rad_dir(pkg, rad, host_np, d)
+    tg = write_rad_dir(pkg, rad, host_np, d, n_cells=n_cells, compressed=compressed)
     t_write = time.time() - t0
+    n_reads = rad.n_reads if n_cells is None else int(rad.cell_nrec[:n_cells].astype("int64").sum())
     exe = os.path.join(ROOT, "alevin-fry_amd", "csrc", "afquant")
     nt = str(os.cpu_count() or 1)
     best = None
@@ -683,9 +687,10 @@ def run_cli(pkg, rad, host_np, workdir, resolution="cr-like"):
         if os.environ.get("AFQ_HOST_TIMING"):
             sys.stderr.write(p.stderr)
         best = dt if best is None else min(best, dt)
-    return {"what": f"afquant quant -r {resolution} -t {nt}: wall from process start to the last output file, map.collated.rad in the page cache (best of 3)",
-            "wall_s": round(best, 3), "value": round(rad.n_reads / best / 1e6, 3), "unit": "M reads/s",
-            "rad_bytes": rad.n_bytes, "write_input_s": round(t_write, 1)}, d, tg
+    return {"what": f"afquant quant -r {resolution} -t {nt}: wall from process start to the last output file, map.collated.rad{'.sz (snappy frames, undone by the host threads)' if compressed else ''} in the page cache (best of 3)"
+                    + (f"; the first {n_cells} cells of the sample" if n_cells is not None else ""),
+            "wall_s": round(best, 3), "value": round(n_reads / best / 1e6, 3), "unit": "M reads/s", "reads": n_reads,
+            "rad_bytes": int(len(host_np)), "write_input_s": round(t_write, 1)}, d, tg
 
 
 def run_reference_binary(rad_dir, tg, rad, workdir, res_rows=None):
@@ -839,7 +844,7 @@ def main():
     if args.workload == "atac":
         return bench_atac(args, pkg, D)
     also = args.also.split(",") if args.also not in ("auto", "none") else \
-        ([] if args.also == "none" else (["configs2", "configs1_tail", "configs2_tail", "configs3", "atac", "e2e", "cli", "reference"] if D.world == 1 else ["e2e", "configs3", "atac"]))
+        ([] if args.also == "none" else (["configs2", "configs1_tail", "configs2_tail", "configs3", "atac", "e2e", "cli", "cli_sz", "cli_pug", "reference"] if D.world == 1 else ["e2e", "configs3", "atac"]))
     also = [a for a in also if a and a != args.workload]
     legs = {}
     out = None
@@ -879,6 +884,14 @@ def main():
                     cli_state.update(d=d, tg=tg)
                     return r
                 leg("cli", f)
+                if "cli_sz" in also:   # the compressed front end (src/quant.rs:373-395): the first tenth of the sample as snappy frames
+                    def fz():
+                        nz = max(1, len(rad.cell_nrec) // 10)
+                        nbz = int(rad.chunk_off[nz]) if nz < len(rad.cell_nrec) else rad.n_bytes
+                        r, _, _ = run_cli(pkg, rad, host_np[:nbz], workdir, n_cells=nz, compressed=True, sub="in_sz")
+                        shutil.rmtree(os.path.join(workdir, "in_sz"), ignore_errors=True)
+                        return r
+                    leg("cli_sz", fz)
                 if "reference" in also and cli_state:
                     leg("reference", lambda: run_reference_binary(cli_state["d"], cli_state["tg"], rad, workdir))
                     if legs.get("reference") is None:
@@ -907,6 +920,15 @@ def main():
                 o2, r2, q2 = run_pbmc(D, args, pkg, sn, True, "parsimony-em", max(1, min(2, args.steps)), 1,
                                       min(args.cpu_seconds, 10.0), "configs[2]", min_cells=200, tie_stats=True)
                 q2.close()
+                if "cli_pug" in also and o2:   # the front end on the USA sample: afquant quant -r parsimony-em
+                    wd = tempfile.mkdtemp(prefix="afq_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+                    try:
+                        rc, _, _ = run_cli(pkg, r2, r2.to_host(), wd, resolution="parsimony-em")
+                        legs["cli_pug"] = rc
+                    except Exception as e:
+                        legs["cli_pug"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                    finally:
+                        shutil.rmtree(wd, ignore_errors=True)
                 r2.free()
                 return o2
             leg("configs2", f)

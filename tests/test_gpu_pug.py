@@ -15,7 +15,7 @@ def pug_route(request, monkeypatch):
     default), with every parsimony cell sent to the one-workgroup kernel (csrc/afq_pug.hip), with the phase kernels'
     partition capacity cut to 24 reads so that most cells start on the first route and are handed back to the second, with
     every cell of 300 reads or more given the 1024-thread instances of the graph / cover / tie kernels (by default: cells of
-    25 000 reads), and with EVERY cell covering its components in slot order and setting the tied ones aside for k_p2_tied (by
+    15 000 reads), and with EVERY cell covering its components in slot order and setting the tied ones aside for k_p2_tied (by
     default only the cells whose classes outgrow the graph kernel's LDS table: big cells, long labels)."""
     if request.param == "one-workgroup":
         monkeypatch.setenv("AFQ_TEST_PUG_ROUTE", "mono")
