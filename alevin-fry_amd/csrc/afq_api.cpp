@@ -317,7 +317,7 @@ uint32_t hdr_bytes(const afq_config& cfg) { return 4 + cfg.bc_bytes + cfg.umi_by
 // AFQ_TEST_SLAB_CAP shrinks the slabs (tests: forces the overflow path).
 bool fixed_slabs() { return !test_hook_is("FIXED_SLABS", "0"); }
 // Default 384 slots for buckets planned at <= 256 keys (kBucketTarget): measured on the bench input, 512 costs the scatter
-// 10 % (a sparser target), 320 already sends a tenth of the cells through the exact placement (profiles/run_r02s.sh).
+// 10 % (a sparser target), 320 already sends a tenth of the cells through the exact placement (profiles/history/run_r02s.sh).
 constexpr uint32_t kSlabCap = 384;
 uint32_t slab_capacity() { const long v = test_hook_long("SLAB_CAP", 0); return v > 0 ? (uint32_t)v : kSlabCap; }
 
@@ -425,7 +425,7 @@ int plan_ranges(afq_ctx* c) {
     // them, while its rows are few - three ranges; cr-like: five, tapering, so that the last D2H is small)
     // (late round 4, cr-like: a range's rows take about half as long to cross PCIe as its kernels run - more for ranges of small
     //  cells, whose rows are longer per read - so every range is 0.6 of the one before it: six ranges, the last 3.3 % of the work;
-    //  28/28/22/14/8 % left 0.65 ms of the last range's rows in the open.  12.96-13.26 -> 12.48-12.68 ms, profiles/run_r04ad.sh)
+    //  28/28/22/14/8 % left 0.65 ms of the last range's rows in the open.  12.96-13.26 -> 12.48-12.68 ms, profiles/history/run_r04ad.sh)
     static const double kTaperCr[] = {0.419, 0.671, 0.822, 0.913, 0.967, 1.0, 1.0, 1.0}, kTaperPug[] = {0.40, 0.76, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
     const double* kTaper = pug_res ? kTaperPug : kTaperCr;
     const size_t kTaperN = 8;
@@ -858,7 +858,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
             }
             // k_p2_lone, labels over four refs: 0: by the vertex's lane alone, in scratch memory (rounds 3-4); 1: labels of 5..64 refs by the
             // wave; 2: 5..8 by the lane in eight registers, 9..64 by the wave - an instance of 86 instead of 69 VGPRs, five waves per SIMD
-            // instead of seven: on the tail model k_p2_lone 25.1 -> 16.5 ms per step, on the plain one 5.6 -> 7.3 (profiles/run_r04ao.sh).
+            // instead of seven: on the tail model k_p2_lone 25.1 -> 16.5 ms per step, on the plain one 5.6 -> 7.3 (profiles/history/run_r04ao.sh).
             // The range's own figure decides, the one that picks its decoder: two or more alignment words per record.
             p2.lone_coop = [&] { const char* e = test_hook("P2_LONE_COOP"); return e && e[0] >= '0' && e[0] <= '2' ? (uint32_t)(e[0] - '0') : (key_off - n >= 2 * nrec_total ? 2u : 1u); }();
             p2.part_cap = kP2PartCap;
@@ -894,8 +894,8 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     // without an EM ends in was measured on the headline in round 4 and not kept: the decoder fills every SIMD at eight
     // waves, the histogram workgroups - 73 KiB of LDS each - get a CU only as decoder workgroups drain, the bracket of
     // k_cell_hist grows from 0.56 to 3.3 ms per step and the range's rows start across PCIe that much later: 12.97 -> 15.38 ms
-    // per step, profiles/run_r04aa.sh.  The same with the histograms on a stream of the device's highest priority: 3.4 ms,
-    // 13.1 -> 15.0 ms per step, profiles/run_r04ad.sh - queue priority does not put a 73 KiB workgroup in front of the
+    // per step, profiles/history/run_r04aa.sh.  The same with the histograms on a stream of the device's highest priority: 3.4 ms,
+    // 13.1 -> 15.0 ms per step, profiles/history/run_r04ad.sh - queue priority does not put a 73 KiB workgroup in front of the
     // decoder's 9 KiB ones.)
     if (!B.kernels_done) HIP_TRY(c, hipEventCreateWithFlags(&B.kernels_done, hipEventDisableTiming));
     if (!hist_cells.empty()) { tc.seg(K_CELL_HIST); launch_cell_hist(s, ra); }
@@ -979,7 +979,17 @@ int finish_range(afq_ctx* c, int slot) {
         const Range whole = B.cur;
         const uint32_t ht = B.hash_try, pt = B.pool_try, bad = whole.c0 + std::min(st.err_cell, whole.c1 - whole.c0 - 1);
         int rc = 0;
-        if (whole.c1 - whole.c0 > 1 && c->retry_cuts < 3) {
+        // A label-hash collision names its cell.  A pool that ran out names the cell that asked LAST, not the one whose graph outgrew
+        // it (the pool is one bump allocator for the range): the whole range runs again with four times the pool, and only when the
+        // device has no room for that is the range cut - around the named cell for want of a better one; a hog that fails again in its
+        // part is cut again (three cuts at most, then the round-3 answer: the error).
+        bool cut = rehash;
+        if (regrow) {
+            rc = run_range(c, whole, slot, nullptr, ht, pt + 1);
+            if (!rc) rc = finish_range(c, slot);
+            else if (rc == AFQ_ERR_OOM) { cut = true; rc = 0; }
+        }
+        if (cut && whole.c1 - whole.c0 > 1 && c->retry_cuts < 3) {
             c->retry_cuts += 1;
             const Range parts[3] = {{whole.c0, bad}, {bad, bad + 1}, {bad + 1, whole.c1}};
             for (int k = 0; k < 3 && !rc; ++k) {
@@ -989,7 +999,7 @@ int finish_range(afq_ctx* c, int slot) {
                 if (!rc) rc = finish_range(c, slot);
             }
             c->retry_cuts -= 1;
-        } else {
+        } else if (cut) {
             rc = run_range(c, whole, slot, nullptr, ht + (rehash ? 1 : 0), pt + (regrow ? 1 : 0));
             if (!rc) rc = finish_range(c, slot);
         }
@@ -1187,7 +1197,7 @@ int finish_range(afq_ctx* c, int slot) {
     // (the row offsets still go up, although the device has made its own: under rocprofv3 the runtime moved the rows' two copies
     //  with __amd_rocclr_copyBuffer kernels - 27 % of the GPU time of a profiled step, next to the following range's decoder -
     //  whenever the command in front of them on the stream was a kernel; behind a small upload they stay on the DMA engines, as
-    //  they did while the compaction was enqueued from here.  profiles/run_r04ak.sh, run_r04al.sh, run_r04am.sh)
+    //  they did while the compaction was enqueued from here.  profiles/history/run_r04ak.sh, run_r04al.sh, run_r04am.sh)
     if (compacted) HIP_TRY(c, hipMemcpyAsync(B.d_cell_ptr.p, ptr.data(), 8ull * (n + 1), hipMemcpyHostToDevice, s));
     HostResult& R = *c->res;
     const size_t g0 = R.gene.n;

@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void k_slab_setup(const uint8_t* __restrict__ 
 #ifndef AFQ_SLABS_PER_WAVE
 #define AFQ_SLABS_PER_WAVE 8
 #endif
-constexpr uint32_t kSlabsPerWave = AFQ_SLABS_PER_WAVE;   // (measured on the headline, k_decode_recs per step: 2: 4.64-4.70 ms, 4: 4.46-4.47, 8: 4.41-4.42, 16: 4.30-4.31 on another box where 8 gave 4.28-4.32; profiles/run_r04ac.sh, run_r04ad.sh)
+constexpr uint32_t kSlabsPerWave = AFQ_SLABS_PER_WAVE;   // (measured on the headline, k_decode_recs per step: 2: 4.64-4.70 ms, 4: 4.46-4.47, 8: 4.41-4.42, 16: 4.30-4.31 on another box where 8 gave 4.28-4.32; profiles/history/run_r04ac.sh, run_r04ad.sh)
 constexpr uint32_t kHalo = 64;
 #ifndef AFQ_DECODE_COLS
 #define AFQ_DECODE_COLS 8192
@@ -1493,7 +1493,7 @@ int launch_decode(hipStream_t s, const DecodeArgs& a, uint32_t bw, uint32_t uw) 
 
 // k_decode_keys finds a record's first mention of a gene through an LDS hash table (HD); AFQ_TEST_DECODE_DEDUP=scan: by the look-back
 // compares and the serial scan of rounds 2-4 (read per launch: tests run both).  Label-tail workload (configs1_tail, 9.66 GB):
-// 14.54 -> 9.01 ms per step, the step 35.0 -> 29.4 ms (profiles/run_r04ah.sh).
+// 14.54 -> 9.01 ms per step, the step 35.0 -> 29.4 ms (profiles/history/run_r04ah.sh).
 static bool decode_keys_hash_dedup() { return !test_hook_is("DECODE_DEDUP", "scan"); }
 template <int BW, int UW>
 static void launch_decode_par_t(hipStream_t s, const DecodeArgs& a) {

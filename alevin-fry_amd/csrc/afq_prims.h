@@ -453,7 +453,7 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* a, uint32_t 
 __device__ __forceinline__ bool is_spliced(uint32_t g) { return (g & 1u) == 0; }
 __device__ __forceinline__ bool same_gene(uint32_t a, uint32_t b) { return (a & ~1u) == (b & ~1u); }
 
-// Loads of data a kernel reads once.  Measured on the headline (profiles/run_r04ac.sh, three rounds, per step): the bucket's keys
+// Loads of data a kernel reads once.  Measured on the headline (profiles/history/run_r04ac.sh, three rounds, per step): the bucket's keys
 // in k_resolve non-temporal: 4.42 -> 4.35 ms, and k_cell_hist behind it 0.554 -> 0.529 (what the resolve leaves in L2 is the
 // column lists the histograms read) - kept; the input bytes in k_decode_recs: 4.47 -> 4.60 (the next slab's halo is this slab's
 // tail); keys0 in k_scatter: 2.61 -> 2.57 but k_resolve 4.42 -> 4.46 - neither kept (make variant DEFS=-DAFQ_NT_DECODE / _SCATTER;
