@@ -376,13 +376,16 @@ __global__ __launch_bounds__(256) void k_p2_part(P2Args A) {
 #ifndef AFQ_P2_SEARCH_WGS
 #define AFQ_P2_SEARCH_WGS 7   // workgroups per CU the search is compiled for: 72 VGPRs (five spilled), 22.5 KiB of LDS with the 2^12-bit filter.  Measured per configs[2] step: 4 -> 33.5 ms, 5 -> 28.0, 6 -> 25.5 (24.9 with a 2^13-bit filter, which no longer fits seven times), 7 -> 23.7
 #endif
+constexpr uint32_t kP2MatchQ = 64;   // matches a partition's walks park before they are checked (more: checked where they are met)
 struct SearchLds {
     uint32_t umi[kP2TabSlots];
     uint32_t word[kP2TabSlots];
-    uint16_t idx[kP2TabSlots];
+    uint8_t idx[kP2TabSlots];           // (a partition holds at most 256 vertices)
     uint32_t filt[kP2FiltBits / 32];
-    uint32_t np;
+    uint2 q[kP2MatchQ];                 // .x = vertex x (slot inside the cell); .y = table slot of y | same-UMI << 9 | reads of x << 10
+    uint32_t np, nq;
 };
+static_assert(kP2PartCap <= 256, "SearchLds::idx is a byte");
 // OVER: the second pass over the partitions that found more pairs than they have slots of their own - k vertices of one UMI whose
 // labels overlap are k (k - 1) / 2 pairs (reads of one molecule that hit different members of a gene family), so a partition of n
 // reads can hold up to n^2 / 2.  The first pass left the count in pnp: the list gets that many slots out of the pool, the
@@ -391,7 +394,7 @@ struct SearchLds {
 // own, not a second trip through a loop here: the loop took the search from 79 to 127 VGPRs.)
 template <bool OVER>
 __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, SearchLds& S, uint32_t lane) {
-    uint32_t* t_umi = S.umi; uint32_t* t_word = S.word; uint16_t* t_idx = S.idx;
+    uint32_t* t_umi = S.umi; uint32_t* t_word = S.word; uint8_t* t_idx = S.idx;
     uint32_t* s_filt = S.filt; uint32_t* s_np = &S.np;
     const uint32_t nv = A.pnv[gp];
     if (nv == 0) return;
@@ -427,7 +430,7 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
     }
     for (uint32_t i = lane; i < kP2TabSlots; i += 64) t_word[i] = 0;
     for (uint32_t i = lane; i < kP2FiltBits / 32; i += 64) s_filt[i] = 0;
-    if (lane == 0) *s_np = 0;
+    if (lane == 0) { *s_np = 0; S.nq = 0; }
     WAVE_SYNC();
     uint64_t own[4];   // the partition's own vertices stay in registers (<= 256 of them)
 #pragma unroll
@@ -440,12 +443,29 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
         uint32_t slot = fold9(umi);
         while (atomicCAS(&t_word[slot], 0u, word) != 0u) slot = (slot + 1) & (kP2TabSlots - 1);   // (equal UMIs under different labels: consecutive slots of one run)
         t_umi[slot] = umi;
-        t_idx[slot] = (uint16_t)i;
+        t_idx[slot] = (uint8_t)i;
         const uint32_t fb = fold11(umi);
         atomicOr(&s_filt[fb >> 5], 1u << (fb & 31u));
     }
     WAVE_SYNC();
     auto filt = [&](uint32_t u) -> bool { const uint32_t f = fold11(u); return (s_filt[f >> 5] >> (f & 31u)) & 1u; };
+    // every vertex of the table with UMI pu against vertex x (cell slot gx, word xw)
+    // A MATCH - x against the table's vertex y in `slot`: UMIs as asked, signatures with a ref in common - still needs the two
+    // labels compared, which is a chain of dependent global loads (label keys, record offsets, for hashed keys the ref lists).
+    // Met where it is found - inside a table walk that one or two lanes of the wave are still in - every walk that found one
+    // paid for that chain with the rest of the wave idle: some seven times per partition, two thirds of this kernel's wave cycles.
+    // The walks therefore only PARK their matches (up to kP2MatchQ per partition, in LDS); they are checked afterwards, a lane
+    // each, the chain paid once per 64 of them.
+    auto check = [&](uint32_t gx, uint32_t slot, uint32_t cx, bool same) {
+        const uint32_t w = t_word[slot], gy = lo_p + t_idx[slot], cy = w & kVCntMask;
+        const uint64_t dir = same ? (kPairF | kPairB) : ((cy < 2 * cx ? kPairF : 0ull) | (cx < 2 * cy ? kPairB : 0ull));
+        const uint64_t hx = ch[gx], hy = ch[gy];
+        if ((hx != hy || (uint32_t)(hx >> 62) == 3) &&   // (equal hashed keys are equal labels only once somebody has compared them: here)
+            !klab_overlap(klab(W, A.hw, hx, coff[gx]), klab(W, A.hw, hy, coff[gy]))) return;
+        cflag[gx] = 1; cflag[gy] = 1;
+        const uint32_t at = atomicAdd(s_np, 1u);   // (LDS, this wave's own counter)
+        if (at < pcap) ppair[at] = dir | ((uint64_t)gx << 31) | gy;
+    };
     // every vertex of the table with UMI pu against vertex x (cell slot gx, word xw)
     auto probe = [&](uint32_t pu, uint32_t gx, uint32_t xw, bool same) {
         const uint32_t xsig = (xw >> 10) & 0x7FFFFu, cx = xw & kVCntMask;
@@ -454,19 +474,10 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
             if (!w) break;
             if (t_umi[slot] != pu) continue;
             if ((((w >> 10) & 0x7FFFFu) & xsig) == 0) continue;   // no ref in common whatever the UMIs
-            const uint32_t gy = lo_p + t_idx[slot];
-            uint64_t dir = kPairF | kPairB;
-            if (same) { if (gy <= gx) continue; }
-            else {
-                const uint32_t cy = w & kVCntMask;
-                dir = (cy < 2 * cx ? kPairF : 0ull) | (cx < 2 * cy ? kPairB : 0ull);
-            }
-            const uint64_t hx = ch[gx], hy = ch[gy];
-            if ((hx != hy || (uint32_t)(hx >> 62) == 3) &&   // (equal hashed keys are equal labels only once somebody has compared them: here)
-                !klab_overlap(klab(W, A.hw, hx, coff[gx]), klab(W, A.hw, hy, coff[gy]))) continue;
-            cflag[gx] = 1; cflag[gy] = 1;
-            const uint32_t at = atomicAdd(s_np, 1u);   // (LDS, this wave's own counter)
-            if (at < pcap) ppair[at] = dir | ((uint64_t)gx << 31) | gy;
+            if (same && lo_p + t_idx[slot] <= gx) continue;       // (a same-UMI pair is met once, from the smaller slot)
+            const uint32_t at = atomicAdd(&S.nq, 1u);
+            if (at < kP2MatchQ) S.q[at] = make_uint2(gx, slot | ((same ? 1u : 0u) << 9) | (cx << 10));
+            else check(gx, slot, cx, same);
         }
     };
     const uint32_t L = A.umi_pairs;
@@ -567,6 +578,11 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
             const uint64_t uw = cu[gx];
             probe((uint32_t)(uw >> 32) ^ ((k % 3 + 1) << (2 * (k / 3))), gx, (uint32_t)uw, false);
         }
+    }
+    WAVE_SYNC();
+    {   // the parked matches, a lane each
+        const uint32_t nq = min(S.nq, kP2MatchQ);
+        if (lane < nq) { const uint2 e = S.q[lane]; check(e.x, e.y & 0x1FFu, e.y >> 10, ((e.y >> 9) & 1u) != 0); }
     }
     WAVE_SYNC();
     const uint32_t np = *s_np;
