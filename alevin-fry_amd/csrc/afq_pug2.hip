@@ -1509,6 +1509,7 @@ __global__ __launch_bounds__(CNT, CNT == 256 ? 4 : 1) void k_p2_cover(P2Args A, 
     __shared__ uint32_t s_cnt[4];
     __shared__ uint32_t s_next;
     __shared__ uint64_t s_mask[2][64];                     // the workgroup cover: uncovered vertices, the round's arborescence
+    __shared__ uint32_t s_stage[CNT / 64][64 * kStageRefs];   // labels of 5..16 refs of the components a wave is covering (afq_pug_common.h): 4 KiB per wave
     __shared__ uint32_t s_bestv[CNT / 64], s_bestsz[CNT / 64];
     __shared__ uint32_t s_ws[CNT / 64];
     __shared__ uint32_t s_nt;
@@ -1541,9 +1542,28 @@ __global__ __launch_bounds__(CNT, CNT == 256 ? 4 : 1) void k_p2_cover(P2Args A, 
     for (uint32_t k = tid; k - lane < n_pr; k += CNT) {   // (wave-uniform trip count: append_cols is a wave-wide call)
         uint32_t col = 0xFFFFFFFFu, k0 = 0, k1 = 0;
         bool cls = false;
+        KLab l{0, 0xFFFFFFFFu, 0xFFFFFFFFu, nullptr}, l2 = l;
         if (k < n_pr) {
             const uint32_t ga = tl[pr_v[2 * k]], gb = tl[pr_v[2 * k + 1]];
-            const KLab l = klab(C.W, C.HW, ch[ga], coff[ga]), l2 = klab(C.W, C.HW, ch[gb], coff[gb]);
+            l = klab(C.W, C.HW, ch[ga], coff[ga]); l2 = klab(C.W, C.HW, ch[gb], coff[gb]);
+        }
+        // (labels of up to kStageRefs refs out of the chunk: the second one goes to this lane's row of the wave's LDS stage, the first
+        //  one's refs into registers - both as loads issued together - and "is ref t of the first label in the second" is a search in
+        //  LDS; ref by ref through global memory a pair of long labels was a chain of some forty dependent loads)
+        const bool lds2 = l2.p && l2.n <= kStageRefs;
+        uint32_t* const row = s_stage[wv] + lane * kStageRefs;
+        if (__any(lds2)) {
+            uint32_t t2[kStageRefs];
+#pragma unroll
+            for (uint32_t q = 0; q < kStageRefs; ++q) t2[q] = lds2 && q < l2.n ? l2.p[q] & 0x7FFFFFFFu : 0xFFFFFFFFu;
+            if (lds2) {
+#pragma unroll
+                for (uint32_t q = 0; q < kStageRefs; ++q) row[q] = t2[q];
+            }
+            WAVE_SYNC();
+        }
+        auto in_l2 = [&](uint32_t t) -> bool { return lds2 ? stage_contains(row, l2.n, t) : klab_contains(l2, t); };
+        if (k < n_pr) {
             if (l.n <= 4) {
                 uint32_t g4[4];
                 uint32_t kk = 0;
@@ -1552,7 +1572,7 @@ __global__ __launch_bounds__(CNT, CNT == 256 ? 4 : 1) void k_p2_cover(P2Args A, 
                     g4[qq] = 0xFFFFFFFFu;
                     if ((uint32_t)qq < l.n) {
                         const uint32_t t = klab_ref(l, qq);
-                        if (klab_contains(l2, t)) {
+                        if (in_l2(t)) {
 #pragma unroll
                             for (int w = 0; w < 4; ++w) if ((uint32_t)w == kk) g4[w] = t;
                             ++kk;
@@ -1562,12 +1582,32 @@ __global__ __launch_bounds__(CNT, CNT == 256 ? 4 : 1) void k_p2_cover(P2Args A, 
                 const uint32_t ng = genes_of4(C, g4, kk);
                 col = molecule4_column(C, g4, ng, cls);
                 k0 = g4[0]; k1 = g4[1];
+            } else if (l.n <= kStageRefs) {
+                uint32_t t1[kStageRefs];
+#pragma unroll
+                for (uint32_t q = 0; q < kStageRefs; ++q) t1[q] = q < l.n ? l.p[q] & 0x7FFFFFFFu : 0xFFFFFFFFu;          // the first label's refs, together
+#pragma unroll
+                for (uint32_t q = 0; q < kStageRefs; ++q) t1[q] = t1[q] != 0xFFFFFFFFu && in_l2(t1[q]) ? C.t2g[t1[q]] : 0xFFFFFFFFu;   // the shared ones' genes, together
+                uint32_t g[kMaxGenesPerLabel];
+                uint32_t ng = 0;
+#pragma unroll
+                for (uint32_t q = 0; q < kStageRefs; ++q) {
+                    const uint32_t gid = t1[q];
+                    if (gid == 0xFFFFFFFFu) continue;
+                    uint32_t qq = 0;
+                    while (qq < ng && g[qq] < gid) ++qq;
+                    if (qq < ng && g[qq] == gid) continue;
+                    for (uint32_t r = ng; r > qq; --r) g[r] = g[r - 1];
+                    g[qq] = gid;
+                    ++ng;
+                }
+                emit_molecule(C, g, ng);
             } else {
                 uint32_t g[kMaxGenesPerLabel];
                 uint32_t ng = 0;
                 for (uint32_t jj = 0; jj < l.n && ng != 0xFFFFFFFFu; ++jj) {
                     const uint32_t t = l.p[jj] & 0x7FFFFFFFu;
-                    if (!klab_contains(l2, t)) continue;
+                    if (!in_l2(t)) continue;
                     const uint32_t gid = C.t2g[t];
                     uint32_t qq = 0;
                     while (qq < ng && g[qq] < gid) ++qq;
@@ -1578,7 +1618,7 @@ __global__ __launch_bounds__(CNT, CNT == 256 ? 4 : 1) void k_p2_cover(P2Args A, 
                     ++ng;
                 }
                 if (ng == 0xFFFFFFFFu && C.em)
-                    emit_wide_class(C, l.n, [&](uint32_t jj) -> uint32_t { const uint32_t t = l.p[jj] & 0x7FFFFFFFu; return klab_contains(l2, t) ? t : 0xFFFFFFFFu; });
+                    emit_wide_class(C, l.n, [&](uint32_t jj) -> uint32_t { const uint32_t t = l.p[jj] & 0x7FFFFFFFu; return in_l2(t) ? t : 0xFFFFFFFFu; });
                 else emit_molecule(C, g, ng);
             }
         }
@@ -1591,11 +1631,11 @@ __global__ __launch_bounds__(CNT, CNT == 256 ? 4 : 1) void k_p2_cover(P2Args A, 
     // depend on the order; at the first round that meets a tie the component is set aside for k_p2_tied (afq_pug_common.h).
     uint32_t* const tied = A.pool + (((unsigned long long)x[8] << 32) | x[7]);
     if (defer) {
-        cover_tiny8<CNT / 64, kCoverDefer>(C, mrec, mid_off, n_tiny, wv, lane, tied, tied + 4);
-        cover_wave64<CNT / 64, kCoverDefer>(C, mrec, mid_off, n_tiny, n_mid, wv, lane, tied + 1, tied + 4 + 4 * (size_t)n_tiny);
+        cover_tiny8<CNT / 64, kCoverDefer>(C, mrec, mid_off, n_tiny, wv, lane, tied, tied + 4, s_stage[wv]);
+        cover_wave64<CNT / 64, kCoverDefer>(C, mrec, mid_off, n_tiny, n_mid, wv, lane, tied + 1, tied + 4 + 4 * (size_t)n_tiny, s_stage[wv]);
     } else {   // (the graph kernel ordered this cell's components itself)
-        cover_tiny8<CNT / 64>(C, mrec, mid_off, n_tiny, wv, lane);
-        cover_wave64<CNT / 64>(C, mrec, mid_off, n_tiny, n_mid, wv, lane);
+        cover_tiny8<CNT / 64>(C, mrec, mid_off, n_tiny, wv, lane, nullptr, nullptr, s_stage[wv]);
+        cover_wave64<CNT / 64>(C, mrec, mid_off, n_tiny, n_mid, wv, lane, nullptr, nullptr, s_stage[wv]);
     }
     if (n_bigc) {   // 65..4096 vertices: the graph kernel left their adjacency as rows of mask words
         const uint64_t* rows = reinterpret_cast<const uint64_t*>(A.pool + (((unsigned long long)x[1] << 32) | x[0]));
@@ -1816,8 +1856,9 @@ __global__ __launch_bounds__(CNT) void k_p2_tied(P2Args A, uint32_t work_lo, uin
     }
     gsync();
     if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], c.cell); return; }
-    cover_tiny8<CNT / 64, kCoverResume>(C, mrec, mid_off, nA, wv, lane, nullptr, listA);
-    cover_wave64<CNT / 64, kCoverResume>(C, mrec, mid_off, 0u, nB, wv, lane, nullptr, listB);
+    uint32_t* const stage = reinterpret_cast<uint32_t*>(t_key) + (size_t)wv * 64 * kStageRefs;   // (the class table is dead: 4 KiB of it per wave stage the labels)
+    cover_tiny8<CNT / 64, kCoverResume>(C, mrec, mid_off, nA, wv, lane, nullptr, listA, stage);
+    cover_wave64<CNT / 64, kCoverResume>(C, mrec, mid_off, 0u, nB, wv, lane, nullptr, listB, stage);
     gsync();
     if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], c.cell); return; }
     if (tid == 0) {

@@ -311,10 +311,25 @@ __device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
 //   kCoverResume   the set-aside components, their records meanwhile put into the reference's order by k_p2_tied: `tied` is
 //                  the list (n_list entries), a component starts from the uncovered vertices its entry holds.
 constexpr int kCoverOrdered = 0, kCoverDefer = 1, kCoverResume = 2;
+// Labels of 5..kStageRefs refs are STAGED in LDS for the time their component is covered (`stage`: 64 x kStageRefs words per wave, or
+// nullptr): the covers ask "does the label of vertex v hold ref t" and "what is ref j of the label of vertex v" once per candidate
+// start, ref and round - through global memory each question was a dependent load (a binary search: four), one after the other, and
+// on reads with long labels (the label-tail model) that chain was the cover kernel: 52 of a 287 ms step.  Short labels travel in the
+// record as before; longer ones than kStageRefs stay in the chunk.
+constexpr uint32_t kStageRefs = 16;
+__device__ __forceinline__ bool stage_contains(const uint32_t* row, uint32_t n, uint32_t t) {   // row: n <= kStageRefs refs, ascending, in LDS
+    uint32_t lo = 0, hi = n;
+#pragma unroll
+    for (int step = 0; step < 5; ++step) {   // (2^5 > kStageRefs)
+        if (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (row[mid] < t) lo = mid + 1; else hi = mid; }
+    }
+    return lo < n && row[lo] == t;
+}
+static_assert(kStageRefs <= 32, "stage_contains makes five halving steps");
 // tied: kCoverDefer: [0] the list's counter, entries from tied + 4 (this list's region); kCoverResume: the first entry.
 template <int NWAVES, int MODE = kCoverOrdered>
 __device__ __forceinline__ void cover_tiny8(const PugCtx& C, const uint4* mrec, const uint32_t* mid_off, uint32_t n_tiny, uint32_t wv, uint32_t lane,
-                                            uint32_t* tied_cnt = nullptr, uint32_t* tied = nullptr)
+                                            uint32_t* tied_cnt = nullptr, uint32_t* tied = nullptr, uint32_t* stage = nullptr)
     {
         const uint32_t gl = lane & 7u, gbase = lane & ~7u, grp = lane >> 3;
         auto seg_or8 = [](uint32_t x) -> uint32_t { x |= (uint32_t)__shfl_xor((int)x, 1); x |= (uint32_t)__shfl_xor((int)x, 2); x |= (uint32_t)__shfl_xor((int)x, 4); return x; };
@@ -331,8 +346,21 @@ __device__ __forceinline__ void cover_tiny8(const PugCtx& C, const uint4* mrec, 
             uint32_t lr0 = 0xFFFFFFFFu, lr1 = 0xFFFFFFFFu, lr2 = 0xFFFFFFFFu, lr3 = 0xFFFFFFFFu;
             if (act && myl.n <= 4) { lr0 = qa.z; lr1 = qa.w; lr2 = qb.x; lr3 = qb.y; }
             else if (act) myl.p = reinterpret_cast<const uint32_t*>((uintptr_t)(((uint64_t)qa.w << 32) | qa.z));
+            const bool staged = stage && act && myl.n > 4 && myl.n <= kStageRefs;   // (decided by the label's length alone: any lane can tell for any other)
+            if (stage && __any(staged)) {
+                __builtin_amdgcn_wave_barrier();   // (the rows of the batch before are no longer read)
+                uint32_t tmp[kStageRefs];
+#pragma unroll
+                for (uint32_t q = 0; q < kStageRefs; ++q) tmp[q] = staged && q < myl.n ? myl.p[q] & 0x7FFFFFFFu : 0xFFFFFFFFu;   // (the loads go out together)
+                if (staged) {
+#pragma unroll
+                    for (uint32_t q = 0; q < kStageRefs; ++q) stage[lane * kStageRefs + q] = tmp[q];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
             auto my_contains = [&](uint32_t t) -> bool {
                 if (myl.n <= 4) return t == lr0 || t == lr1 || t == lr2 || t == lr3;
+                if (staged) return stage_contains(stage + lane * kStageRefs, myl.n, t);
                 return lab_contains(myl, t);
             };
             // ref j of the label held by lane `src` (every lane of the wave makes the same three shuffles; n_v, j and src are the caller's)
@@ -341,6 +369,7 @@ __device__ __forceinline__ void cover_tiny8(const PugCtx& C, const uint4* mrec, 
                 const uint64_t pa = (uint64_t)(uintptr_t)myl.p;
                 const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)pa, (int)src), hi = (uint32_t)__shfl((int)(uint32_t)(pa >> 32), (int)src);
                 if (n_v <= 4 || !on) return r;
+                if (stage && n_v <= kStageRefs) return stage[src * kStageRefs + j];   // (src's label is staged: its length says so)
                 return reinterpret_cast<const uint32_t*>((uintptr_t)(((uint64_t)hi << 32) | lo))[j] & 0x7FFFFFFFu;
             };
             const uint32_t adj = act ? (qb.z & 0xFFu) : 0u;   // local indices < 8
@@ -393,11 +422,16 @@ __device__ __forceinline__ void cover_tiny8(const PugCtx& C, const uint4* mrec, 
                 uint32_t c4[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
                 bool wide = false;
                 const bool small = lfn <= 4;
+                // (a staged first label: the refs every vertex holds are only MARKED in the loop - cm - and their genes looked up by the
+                //  group's lanes together afterwards; one lane looking them up inside the loop made one dependent load per ref)
+                const bool fstaged = stage && lfn > 4 && lfn <= kStageRefs && !C.gene_level;
+                uint32_t cm = 0;
                 for (uint32_t j = 0; __any(j < lfn); ++j) {
                     const bool on = j < lfn;
                     const uint32_t t = ref_of(gbase + fv, lfn, j, on);
                     const uint32_t hasm = (uint32_t)(__ballot(on && act && ((best >> gl) & 1u) && my_contains(t)) >> gbase) & 0xFFu;
-                    if (on && hasm == best && gl == 0) {
+                    if (on && hasm == best && fstaged) cm |= 1u << j;
+                    else if (on && hasm == best && gl == 0) {
                         if (small) {
 #pragma unroll
                             for (int w = 0; w < 4; ++w) if ((uint32_t)w == k4) c4[w] = t;
@@ -410,6 +444,24 @@ __device__ __forceinline__ void cover_tiny8(const PugCtx& C, const uint4* mrec, 
                                 if (ng == kMaxGenesPerLabel) wide = true;
                                 else { for (uint32_t r = ng; r > q; --r) g[r] = g[r - 1]; g[q] = gid; ++ng; }
                             }
+                        }
+                    }
+                }
+                if (stage && __any(fstaged)) {   // the marked refs' genes: lane gl of the group takes refs gl and gl + 8 of the first label's row, in place
+                    uint32_t* row = stage + (gbase + fv) * kStageRefs;
+                    uint32_t ga = 0xFFFFFFFFu, gb2 = 0xFFFFFFFFu;
+                    if (fstaged && ((cm >> gl) & 1u)) ga = C.t2g[row[gl]];
+                    if (fstaged && ((cm >> (gl + 8)) & 1u)) gb2 = C.t2g[row[gl + 8]];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (fstaged) { row[gl] = ga; row[gl + 8] = gb2; }   // (the first vertex is covered from this round on: its row is free)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (fstaged && gl == 0) {
+                        for (uint32_t j = 0; j < lfn; ++j) {
+                            const uint32_t gid = row[j];
+                            if (gid == 0xFFFFFFFFu) continue;
+                            uint32_t q = 0;
+                            while (q < ng && g[q] < gid) ++q;
+                            if (!(q < ng && g[q] == gid)) { for (uint32_t r = ng; r > q; --r) g[r] = g[r - 1]; g[q] = gid; ++ng; }   // (at most kStageRefs genes)
                         }
                     }
                 }
@@ -431,7 +483,7 @@ __device__ __forceinline__ void cover_tiny8(const PugCtx& C, const uint4* mrec, 
 // (kCoverResume: the components are entries n_tiny.. n_mid - 1 of the LIST `tied`, i.e. call it with n_tiny = 0, n_mid = entries)
 template <int NWAVES, int MODE = kCoverOrdered>
 __device__ __forceinline__ void cover_wave64(const PugCtx& C, const uint4* mrec, const uint32_t* mid_off, uint32_t n_tiny, uint32_t n_mid, uint32_t wv, uint32_t lane,
-                                             uint32_t* tied_cnt = nullptr, uint32_t* tied = nullptr)
+                                             uint32_t* tied_cnt = nullptr, uint32_t* tied = nullptr, uint32_t* stage = nullptr)
     {
       // which component entry e of the walk is, and where its slots begin and end
       auto comp_of = [&](uint32_t e) -> uint32_t { if constexpr (MODE == kCoverResume) return tied[4 * e]; else return e; };
@@ -458,8 +510,21 @@ __device__ __forceinline__ void cover_wave64(const PugCtx& C, const uint4* mrec,
         uint32_t lr0 = 0xFFFFFFFFu, lr1 = 0xFFFFFFFFu, lr2 = 0xFFFFFFFFu, lr3 = 0xFFFFFFFFu;
         if (act && myl.n <= 4) { lr0 = qa.z; lr1 = qa.w; lr2 = qb.x; lr3 = qb.y; }
         else if (act) myl.p = reinterpret_cast<const uint32_t*>((uintptr_t)(((uint64_t)qa.w << 32) | qa.z));
+        const bool staged = stage && act && myl.n > 4 && myl.n <= kStageRefs;
+        if (stage && __any(staged)) {
+            __builtin_amdgcn_wave_barrier();   // (the rows of the component before are no longer read)
+            uint32_t tmp[kStageRefs];
+#pragma unroll
+            for (uint32_t q = 0; q < kStageRefs; ++q) tmp[q] = staged && q < myl.n ? myl.p[q] & 0x7FFFFFFFu : 0xFFFFFFFFu;
+            if (staged) {
+#pragma unroll
+                for (uint32_t q = 0; q < kStageRefs; ++q) stage[lane * kStageRefs + q] = tmp[q];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
         auto my_contains = [&](uint32_t t) -> bool {
             if (myl.n <= 4) return t == lr0 || t == lr1 || t == lr2 || t == lr3;
+            if (staged) return stage_contains(stage + lane * kStageRefs, myl.n, t);
             return lab_contains(myl, t);
         };
         // the label of the vertex held by lane v, out of that lane's registers (a global read only for labels over four refs):
@@ -467,6 +532,7 @@ __device__ __forceinline__ void cover_wave64(const PugCtx& C, const uint4* mrec,
         auto lane_lab_n = [&](uint32_t v) -> uint32_t { return (uint32_t)__shfl((int)myl.n, (int)v); };
         auto lane_lab_ref = [&](uint32_t v, uint32_t n_v, uint32_t j) -> uint32_t {
             if (n_v <= 4) return (uint32_t)__shfl((int)(j == 0 ? lr0 : j == 1 ? lr1 : j == 2 ? lr2 : lr3), (int)v);
+            if (stage && n_v <= kStageRefs) return stage[v * kStageRefs + j];
             const uint64_t pa = (uint64_t)(uintptr_t)myl.p;
             const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)pa, (int)v), hi = (uint32_t)__shfl((int)(uint32_t)(pa >> 32), (int)v);
             return reinterpret_cast<const uint32_t*>((uintptr_t)(((uint64_t)hi << 32) | lo))[j] & 0x7FFFFFFFu;
@@ -517,10 +583,13 @@ __device__ __forceinline__ void cover_wave64(const PugCtx& C, const uint4* mrec,
             uint32_t c4[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
             bool wide = false;
             const bool small = lfn <= 4;
+            const bool fstaged = stage && lfn > 4 && lfn <= kStageRefs && !C.gene_level;   // (as in cover_tiny8: mark, then look the genes up together)
+            uint32_t cm = 0;
             for (uint32_t j = 0; j < lfn; ++j) {
                 const uint32_t t = lane_lab_ref(fv, lfn, j);
                 const uint64_t has = __ballot(act && ((best >> lane) & 1ull) && my_contains(t));
                 if (has != best) continue;
+                if (fstaged) { cm |= 1u << j; continue; }
                 if (lane == 0) {
                     if (small) {
 #pragma unroll
@@ -534,6 +603,23 @@ __device__ __forceinline__ void cover_wave64(const PugCtx& C, const uint4* mrec,
                             if (ng == kMaxGenesPerLabel) wide = true;
                             else { for (uint32_t r = ng; r > q; --r) g[r] = g[r - 1]; g[q] = gid; ++ng; }
                         }
+                    }
+                }
+            }
+            if (fstaged) {   // (wave-uniform)
+                uint32_t* row = stage + fv * kStageRefs;
+                uint32_t ga = 0xFFFFFFFFu;
+                if (lane < lfn && ((cm >> lane) & 1u)) ga = C.t2g[row[lane]];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane < kStageRefs) row[lane] = ga;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane == 0) {
+                    for (uint32_t j = 0; j < lfn; ++j) {
+                        const uint32_t gid = row[j];
+                        if (gid == 0xFFFFFFFFu) continue;
+                        uint32_t q = 0;
+                        while (q < ng && g[q] < gid) ++q;
+                        if (!(q < ng && g[q] == gid)) { for (uint32_t r = ng; r > q; --r) g[r] = g[r - 1]; g[q] = gid; ++ng; }
                     }
                 }
             }
