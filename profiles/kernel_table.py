@@ -34,7 +34,7 @@ def main(tag, min_pct=0.8):
         if not m:
             continue
         name, calls, tot, avg, pct = m.group(1).strip(), int(m.group(2)), float(m.group(3)), float(m.group(4)), float(m.group(5))
-        if pct < min_pct:
+        if pct < min_pct or name.startswith("k_synth"):
             continue
         r = res.get(name, ("?",) * 5)
         lds = f"{int(r[3]) / 1024:.1f} KiB" if r[3] != "?" else "?"
