@@ -212,7 +212,10 @@ struct P2Args {
     uint32_t defer_min;   // a cell sets the tied components of its covers aside (k_p2_tied) when its listed components hold more vertices than this; 0xFFFFFFFF: than the graph kernel's LDS class table takes (tests: 0 = every cell)
     uint32_t lone_coop;   // k_p2_lone: a lone vertex whose label has 5..64 refs is resolved by its whole wave (0: by its lane alone, as until late in round 4 - tests, measurements)
 };
-constexpr uint32_t kP2PartTarget = 144;   // planned mean reads per partition (the partition count is a power of two: 72..144).  It was 160 until round 5: of a
+#ifndef AFQ_P2_PART_TARGET
+#define AFQ_P2_PART_TARGET 144
+#endif
+constexpr uint32_t kP2PartTarget = AFQ_P2_PART_TARGET;   // planned mean reads per partition (the partition count is a power of two: 72..144).  It was 160 until round 5: of a
                                           // sample's 11 000 cells the one or two whose mean sat just under 160 had a partition over the capacity below (245-260 reads in
                                           // the largest of 1024 partitions) and were handed back - and k_pug_cell costs 0.4-3 ms per launch whatever it is given
 constexpr uint32_t kP2PartCap = 256;      // reads one partition may hold (one wave sorts it in registers)
