@@ -388,7 +388,10 @@ int plan_ranges(afq_ctx* c) {
         if (fixed > nbytes || ((nbytes - fixed) & 3))
             return fail(c, AFQ_ERR_BAD_INPUT, "cell " + std::to_string(i) + ": chunk nbytes does not match its records");
         const uint64_t n_ref = (nbytes - fixed) / 4;
-        double nd = (em_res ? 24.0 + 40.0 * (c->cfg.usa_mode ? 3 : 1) : 16.0) * (double)n_ref + 128.0;
+        // (EM resolutions: the canonical kernels' scratch is 40 B per ref and output space; the fixed-point EM sets aside ~25-30 B per ref
+        //  behind the range's kernels and, when that plan falls short, the host sizes it exactly - up to three times as much: the larger of
+        //  the two is what a range sized to fill the device must have room for)
+        double nd = (em_res ? 24.0 + std::max(40.0 * (c->cfg.usa_mode ? 3 : 1), 90.0) : 16.0) * (double)n_ref + 128.0;
         if (pug_res) {  // per read: decode outputs + edge pool; the PUG scratch is per workgroup (sized for the largest cell)
             nd += 20.0 * nrec + 128.0 * nrec;   // rd_h/rd_u/rd_o + the edge pool (32 words per read), as run_range allocates them
             pug_fixed = std::max(pug_fixed, 4.0 * (double)pug_scratch_words(nrec, (uint32_t)n_ref, true) * pug_max_blocks() + 4.0 * (double)(1ull << 22));

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AFQ_ABI_VERSION 3   /* 3: afq_result.mmrate and afq_snappy_decode_device are gone, afq_em_resize_count is new */
+#define AFQ_ABI_VERSION 3   /* 3: afq_result.mmrate and afq_snappy_decode_device are gone, afq_em_resize_count and afq_mono_cell_count are new */
 
 /* error codes */
 #define AFQ_OK 0
