@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -187,7 +188,7 @@ struct afq_ctx {
     const uint8_t* d_bytes = nullptr;
     size_t n_bytes = 0;
     DevBuf d_chunk_off, d_hdr;
-    DevBuf atac[26];  // afq_atac_dedup[_rad]'s device buffers, kept between calls
+    DevBuf atac[27];  // afq_atac_dedup[_rad]'s device buffers, kept between calls
     void* stage[3] = {nullptr, nullptr, nullptr};          // pinned staging for large host->device input copies
     hipEvent_t stage_ev[3] = {nullptr, nullptr, nullptr};
     // afq_submit: the input crosses PCIe range by range while earlier ranges already run (h2d_ev[i] = range i's bytes landed)
@@ -1921,18 +1922,21 @@ int afq_atac_dedup_rad(afq_ctx* c, const uint8_t* bytes, size_t n_bytes, const u
                              d_flen.as<uint16_t>(), d_cnt.as<uint32_t>() + c0, d_bc.as<uint64_t>() + c0, d_stat.as<uint32_t>() + 2ull * c0,
                              d_walk.as<uint32_t>() + c0, nwalk, dst, (uint64_t)n_bytes};
     };
-    // Big batches go through in six ranges of cells: the distinct fragments of range r cross PCIe on a second stream while the
-    // later ranges are still parsed and sorted.  The rows are the long pole - 1.8 GB for 2*10^8 records is 34 ms at the 52 GB/s the
-    // link gives (the e2e leg), against 19 ms for all the kernels - so what matters is how soon the FIRST rows can leave: the
-    // ranges GROW (5, 10, 15, 20, 25, 25 % of the records; four equal ranges kept the link idle for the first quarter of the
-    // kernels), the opposite of the cr-like taper, whose rows are short and whose last range's copy is what nothing hides.
+    // Big batches go through in eight ranges of cells: the distinct fragments of range r cross PCIe on a second stream while the
+    // later ranges are still parsed and sorted.  The rows are the long pole - 12 bytes a row, 1.8 GB for 2*10^8 records, 34 ms at
+    // the 52 GB/s the link gives (the e2e leg), against 20 ms for all the kernels - so (round 5) the ref column stays on the device
+    // (8 bytes a row cross, 23 ms; the host writes the column from a list of runs, below), and what matters then is how soon the
+    // FIRST rows can leave and how few are left when the last kernel ends: the ranges GROW (4, 8, 12, 14, 15, 16, 16, 15 % of the
+    // records; four equal ranges kept the link idle for the first quarter of the kernels), the opposite of the cr-like taper,
+    // whose rows are short.  Measured and not kept: the parse of range r+1 on a stream of its own next to the sort of range r
+    // (the sort's workgroups wait for CUs behind the parse's: 12.7 -> 18.3 ms of sort, 28.6 -> 30.9 ms a step).
     const char* pipe_env = test_hook("ATAC_PIPE_BYTES");   // (tests: pipeline small inputs too)
     const size_t pipe_min = pipe_env ? (size_t)std::atoll(pipe_env) : ((size_t)128 << 20);
     const bool piped = n_cells >= 8 && n_bytes >= pipe_min;
     bool piped_done = false;
     if (piped) {
-        constexpr uint32_t kR = 6;
-        static const double kGrow[kR] = {0.05, 0.15, 0.30, 0.50, 0.75, 1.0};
+        constexpr uint32_t kR = 8;
+        static const double kGrow[kR] = {0.04, 0.12, 0.24, 0.38, 0.53, 0.69, 0.85, 1.0};
         uint32_t cut[kR + 1];
         cut[0] = 0;
         for (uint32_t r = 1; r < kR; ++r) {
@@ -1943,20 +1947,27 @@ int afq_atac_dedup_rad(afq_ctx* c, const uint8_t* bytes, size_t n_bytes, const u
         cut[kR] = n_cells;
         DevBuf &d_scr = c->atac[4], &d_oref = c->atac[5], &d_ostart = c->atac[6], &d_oflen = c->atac[7], &d_ocnt = c->atac[8], &d_on = c->atac[9],
                &d_optr = c->atac[10], &d_cref = c->atac[11], &d_cstart = c->atac[12], &d_cflen = c->atac[13], &d_ccnt = c->atac[14],
-               &d_flag = c->atac[15], &d_tally = c->atac[24], &d_rstat = c->atac[25];
+               &d_flag = c->atac[15], &d_tally = c->atac[24], &d_rstat = c->atac[25], &d_runctr = c->atac[26];
         hipError_t e = hipSuccess;
         auto T = [&](hipError_t x) { if (e == hipSuccess) e = x; };
         T(d_scr.ensure(16 * n1)); T(d_oref.ensure(4 * n1)); T(d_ostart.ensure(4 * n1)); T(d_oflen.ensure(2 * n1)); T(d_ocnt.ensure(2 * n1));
         T(d_on.ensure(4ull * nc1)); T(d_optr.ensure(8ull * (n_cells + 1))); T(d_flag.ensure(4)); T(d_tally.ensure(16));
         T(d_cref.ensure(4 * n1)); T(d_cstart.ensure(4 * n1)); T(d_cflen.ensure(2 * n1)); T(d_ccnt.ensure(2 * n1));   // (sized for "nothing is a duplicate")
-        T(d_rstat.ensure(kR * (sizeof(DevStatus) + 16)));
+        T(d_rstat.ensure(kR * (sizeof(DevStatus) + 16))); T(d_runctr.ensure(4));
+        // The ref column does not cross PCIe: a cell's rows are sorted by ref first, so the column is a few runs per cell - the
+        // compaction kernel lists them (first row, length, ref: 16 bytes a run, written straight into pinned host memory) and
+        // host threads write the column from the list while the other three columns (8 of the 12 bytes of a row) are on the link.
+        // A list that overflows (more than 64 runs per cell on average: thousands of contigs) sends the column itself, as before.
+        const long cap_hook = test_hook_long("ATAC_RUN_CAP", -1);   // (tests: force the overflow)
+        const uint32_t run_cap = cap_hook >= 0 ? (uint32_t)cap_hook : (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 20, 64ull * n_cells), 1u << 28);
+        uint4* runs = (uint4*)pinned_pool()->get(16ull * std::max<uint32_t>(run_cap, 1));
         uint32_t* oref = (uint32_t*)pinned_pool()->get(4 * n1);
         uint32_t* ostart = (uint32_t*)pinned_pool()->get(4 * n1);
         uint16_t* oflen = (uint16_t*)pinned_pool()->get(2 * n1);
         uint16_t* ocnt = (uint16_t*)pinned_pool()->get(2 * n1);
         uint64_t* optr = (uint64_t*)std::malloc(8ull * (n_cells + 1));
-        auto drop = [&]() { std::free(optr); afq_free(oref); afq_free(ostart); afq_free(oflen); afq_free(ocnt); };
-        if (!oref || !ostart || !oflen || !ocnt || !optr) { drop(); std::free(obc); return fail(c, AFQ_ERR_OOM, "afq_atac_dedup_rad: host allocation failed"); }
+        auto drop = [&]() { std::free(optr); afq_free(oref); afq_free(ostart); afq_free(oflen); afq_free(ocnt); afq_free(runs); };
+        if (!oref || !ostart || !oflen || !ocnt || !optr || !runs) { drop(); std::free(obc); return fail(c, AFQ_ERR_OOM, "afq_atac_dedup_rad: host allocation failed"); }
         hipStream_t s2 = c->rs[0].stream;
         DevStatus* d_rst = reinterpret_cast<DevStatus*>(d_rstat.p);
         uint32_t* d_rnw = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(d_rstat.p) + kR * sizeof(DevStatus));
@@ -1967,10 +1978,42 @@ int afq_atac_dedup_rad(afq_ctx* c, const uint8_t* bytes, size_t n_bytes, const u
         uint32_t* on = reinterpret_cast<uint32_t*>(pin);
         DevStatus* rst = reinterpret_cast<DevStatus*>(pin + 4ull * nc1);
         uint32_t* wide = reinterpret_cast<uint32_t*>(pin + 4ull * nc1 + kR * sizeof(DevStatus));
+        volatile uint32_t* snap = wide + kR;   // the run counter as it stood after each range's compaction (the block has four words per range)
         uint32_t* pin_dev = nullptr;   // the same block as the device sees it
         T(hipHostGetDevicePointer(reinterpret_cast<void**>(&pin_dev), pin, 0));
-        hipEvent_t ev[kR];
+        uint4* runs_dev = nullptr;
+        T(hipHostGetDevicePointer(reinterpret_cast<void**>(&runs_dev), runs, 0));
+        hipEvent_t ev[kR], ev2[kR];
         for (auto& x : ev) x = get_event(c);
+        for (auto& x : ev2) x = get_event(c);
+        T(hipMemsetAsync(d_runctr.p, 0, 4, s));
+        // the threads that write the ref column: thread 0 waits for a range's list (the event after its compaction), all fill
+        std::atomic<int> recorded{0}, listed{0}, stop{0};
+        const unsigned nfill = stage_threads();
+        std::vector<std::thread> fillers;
+        if (e == hipSuccess) {
+            for (unsigned t = 0; t < nfill; ++t)
+                fillers.emplace_back([&, t]() {
+                    if (t == 0) (void)hipSetDevice(c->device);
+                    uint32_t lo = 0;
+                    for (uint32_t r = 0; r < kR; ++r) {
+                        if (t == 0) {
+                            while (recorded.load(std::memory_order_acquire) <= (int)r) { if (stop.load(std::memory_order_relaxed)) return; std::this_thread::sleep_for(std::chrono::microseconds(20)); }
+                            if (hipEventSynchronize(ev2[r]) != hipSuccess) { (void)hipGetLastError(); stop.store(1); return; }
+                            listed.store((int)r + 1, std::memory_order_release);
+                        } else {
+                            while (listed.load(std::memory_order_acquire) <= (int)r) { if (stop.load(std::memory_order_relaxed)) return; std::this_thread::sleep_for(std::chrono::microseconds(20)); }
+                        }
+                        const uint32_t hi = snap[r];
+                        if (hi > run_cap) return;   // this range's column and every later one come as copies
+                        for (uint32_t i = lo + t; i < hi; i += nfill) {
+                            const uint4 q = runs[i];
+                            std::fill_n(oref + (((uint64_t)q.y << 32) | q.x), (size_t)q.z, q.w);
+                        }
+                        lo = hi;
+                    }
+                });
+        }
         T(hipMemsetAsync(d_flag.p, 0, 4, s));
         T(hipMemsetAsync(d_tally.p, 0, 16, s));
         T(hipMemsetAsync(d_rstat.p, 0, kR * (sizeof(DevStatus) + 16), s));
@@ -2004,15 +2047,28 @@ int afq_atac_dedup_rad(afq_ctx* c, const uint8_t* bytes, size_t n_bytes, const u
             if (tot_r) {
                 launch_atac_compact(s2, c1 - c0, d_ptr.as<uint64_t>() + c0, d_optr.as<uint64_t>() + c0, d_oref.as<uint32_t>(), d_ostart.as<uint32_t>(),
                                     d_oflen.as<uint16_t>(), d_ocnt.as<uint16_t>(), d_cref.as<uint32_t>(), d_cstart.as<uint32_t>(),
-                                    d_cflen.as<uint16_t>(), d_ccnt.as<uint16_t>(), d_tally.as<unsigned long long>());
+                                    d_cflen.as<uint16_t>(), d_ccnt.as<uint16_t>(), d_tally.as<unsigned long long>(), runs_dev, d_runctr.as<uint32_t>(), run_cap);
                 T(hipGetLastError());
-                T(hipMemcpyAsync(oref + o0, d_cref.as<uint32_t>() + o0, 4 * tot_r, hipMemcpyDeviceToHost, s2));
+            }
+            launch_copy_words3(s2, d_runctr.as<uint32_t>(), 1, pin_dev + (const_cast<uint32_t*>(snap) - on) + r, nullptr, 0, nullptr, nullptr, 0, nullptr);
+            T(hipGetLastError());
+            T(hipEventRecord(ev2[r], s2));
+            if (e == hipSuccess) recorded.store((int)r + 1, std::memory_order_release);
+            if (tot_r) {
                 T(hipMemcpyAsync(ostart + o0, d_cstart.as<uint32_t>() + o0, 4 * tot_r, hipMemcpyDeviceToHost, s2));
                 T(hipMemcpyAsync(oflen + o0, d_cflen.as<uint16_t>() + o0, 2 * tot_r, hipMemcpyDeviceToHost, s2));
                 T(hipMemcpyAsync(ocnt + o0, d_ccnt.as<uint16_t>() + o0, 2 * tot_r, hipMemcpyDeviceToHost, s2));
             }
         }
+        if (e != hipSuccess || redo || bad_rc) stop.store(1);
+        for (auto& th : fillers) th.join();
         if (e == hipSuccess && !redo && !bad_rc) {
+            T(hipEventSynchronize(ev2[kR - 1]));   // (every range's count is on the host; the fillers stop at the first list that overflowed)
+            for (uint32_t r = 0; r < kR && e == hipSuccess; ++r)
+                if (snap[r] > run_cap) {
+                    const uint64_t o0 = optr[cut[r]], tot_r = optr[cut[r + 1]] - o0;
+                    if (tot_r) T(hipMemcpyAsync(oref + o0, d_cref.as<uint32_t>() + o0, 4 * tot_r, hipMemcpyDeviceToHost, s2));
+                }
             T(hipMemcpyAsync(tally, d_tally.p, 16, hipMemcpyDeviceToHost, s2));
             if (n_cells) T(hipMemcpyAsync(stat.data(), d_stat.p, 8ull * n_cells, hipMemcpyDeviceToHost, s2));
             if (n_cells) T(hipMemcpyAsync(obc, d_bc.p, 8ull * n_cells, hipMemcpyDeviceToHost, s2));
@@ -2020,7 +2076,8 @@ int afq_atac_dedup_rad(afq_ctx* c, const uint8_t* bytes, size_t n_bytes, const u
         (void)hipStreamSynchronize(s);
         (void)hipStreamSynchronize(s2);
         for (auto x : ev) c->event_pool.push_back(x);
-        afq_free(pin);
+        for (auto x : ev2) c->event_pool.push_back(x);
+        afq_free(pin); afq_free(runs); runs = nullptr;
         harvest_timers(c);
         hc.lap("atac: ranges (parse, sort, compact, D2H)");
         if (e != hipSuccess || bad_rc) {

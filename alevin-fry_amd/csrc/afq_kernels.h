@@ -136,7 +136,8 @@ struct AtacParseArgs {
 void launch_atac_parse(hipStream_t s, const AtacParseArgs& a);
 void launch_atac_compact(hipStream_t s, uint32_t n_cells, const uint64_t* cell_ptr, const uint64_t* out_ptr, const uint32_t* i_ref,
                          const uint32_t* i_start, const uint16_t* i_flen, const uint16_t* i_cnt, uint32_t* o_ref, uint32_t* o_start,
-                         uint16_t* o_flen, uint16_t* o_cnt, unsigned long long* tally = nullptr);
+                         uint16_t* o_flen, uint16_t* o_cnt, unsigned long long* tally = nullptr, uint4* runs = nullptr, uint32_t* run_ctr = nullptr,
+                         uint32_t run_cap = 0);
 void warm_code_object();
 void launch_resolve(hipStream_t s, const ResolveArgs& a);
 void launch_resolve_big(hipStream_t s, const ResolveArgs& a);

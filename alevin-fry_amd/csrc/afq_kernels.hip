@@ -1244,16 +1244,31 @@ __global__ __launch_bounds__(256) void k_atac_compact(const uint64_t* __restrict
                                                      const uint16_t* __restrict__ i_flen, const uint16_t* __restrict__ i_cnt,
                                                      uint32_t* __restrict__ o_ref, uint32_t* __restrict__ o_start,
                                                      uint16_t* __restrict__ o_flen, uint16_t* __restrict__ o_cnt,
-                                                     unsigned long long* __restrict__ tally) {
+                                                     unsigned long long* __restrict__ tally, uint4* __restrict__ runs,
+                                                     uint32_t* __restrict__ run_ctr, uint32_t run_cap) {
     const uint32_t cell = blockIdx.x;
     const uint64_t src = cell_ptr[cell], dst = out_ptr[cell];
     const uint32_t n = (uint32_t)(out_ptr[cell + 1] - dst);
     uint32_t dup = 0, lng = 0;   // fragments seen more than once / of 2000 bases and more (deduplicate.rs:222-224, 47-63)
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
         const uint16_t fl = i_flen[src + i], ct = i_cnt[src + i];
-        o_ref[dst + i] = i_ref[src + i]; o_start[dst + i] = i_start[src + i];
+        const uint32_t r = i_ref[src + i];
+        o_ref[dst + i] = r; o_start[dst + i] = i_start[src + i];
         o_flen[dst + i] = fl; o_cnt[dst + i] = ct;
         dup += ct > 1; lng += fl >= 2000;
+        // A cell's rows are in (ref, start, frag_len) order, so its ref column is a few runs: (first row, length, ref) of each
+        // goes to the host's list - `runs` is host memory as the device sees it - and the column itself stays here (the host
+        // writes it from the list while the other three columns cross PCIe; afq_api.cpp).  The row that starts a run finds its end
+        // by bisection.
+        if (runs && (i == 0 || i_ref[src + i - 1] != r)) {
+            uint32_t lo = i + 1, hi = n;
+            while (lo < hi) {
+                const uint32_t mid = lo + ((hi - lo) >> 1);
+                if (i_ref[src + mid] == r) lo = mid + 1; else hi = mid;
+            }
+            const uint32_t at = atomicAdd(run_ctr, 1u);
+            if (at < run_cap) runs[at] = make_uint4((uint32_t)(dst + i), (uint32_t)((dst + i) >> 32), lo - i, r);
+        }
     }
     if (tally) {
         for (int d = 32; d; d >>= 1) { dup += __shfl_xor(dup, d); lng += __shfl_xor(lng, d); }
@@ -1363,9 +1378,10 @@ void launch_atac_dedup64(hipStream_t s, uint32_t n_cells, const uint32_t* ref, c
 
 void launch_atac_compact(hipStream_t s, uint32_t n_cells, const uint64_t* cell_ptr, const uint64_t* out_ptr, const uint32_t* i_ref,
                          const uint32_t* i_start, const uint16_t* i_flen, const uint16_t* i_cnt, uint32_t* o_ref, uint32_t* o_start,
-                         uint16_t* o_flen, uint16_t* o_cnt, unsigned long long* tally) {
+                         uint16_t* o_flen, uint16_t* o_cnt, unsigned long long* tally, uint4* runs, uint32_t* run_ctr, uint32_t run_cap) {
     if (!n_cells) return;
-    AFQ_LAUNCH(k_atac_compact, n_cells, 256, s, cell_ptr, out_ptr, i_ref, i_start, i_flen, i_cnt, o_ref, o_start, o_flen, o_cnt, tally);
+    AFQ_LAUNCH(k_atac_compact, n_cells, 256, s, cell_ptr, out_ptr, i_ref, i_start, i_flen, i_cnt, o_ref, o_start, o_flen, o_cnt, tally, runs, run_ctr,
+               run_cap);
 }
 
 void launch_cell_hist(hipStream_t s, const ResolveArgs& a) {

@@ -44,13 +44,19 @@ def test_atac_from_rad_reference_vector(oracle):
         assert int(got[0][-1]) == 80 and got[6]["n_fallback_cells"] == 0
 
 
-@pytest.mark.parametrize("piped", [False, True])
+@pytest.mark.parametrize("piped", [False, True, "run-list-overflows-midway", "no-run-list"])
 def test_atac_from_rad_matches_oracle_on_generated_cells(oracle, monkeypatch, piped):
     """config-5-like cells (20 % exact duplicates, 5 % multi-mapped, 5 % unmapped, log-normal lengths incl. >= 2000),
     host bytes and device-resident bytes; cells of 1 .. 40 000 records and an empty-record chunk.  piped: the batch goes
-    through in four ranges whose results cross PCIe under the later ranges' kernels (what inputs over 128 MB do)."""
+    through in six ranges whose results cross PCIe under the later ranges' kernels (what inputs over 128 MB do); the ref column
+    of a range is written on the host from the device's list of (first row, length, ref) runs - or copied like the other
+    columns from the range on in which that list overflows (forced here: after 400 runs; from the first one)."""
     if piped:
         monkeypatch.setenv("AFQ_TEST_ATAC_PIPE_BYTES", "1")
+    if piped == "run-list-overflows-midway":
+        monkeypatch.setenv("AFQ_TEST_ATAC_RUN_CAP", "400")
+    if piped == "no-run-list":
+        monkeypatch.setenv("AFQ_TEST_ATAC_RUN_CAP", "0")
     d, off = sn.generate_atac(seed=9, n_cells=300, frags_per_cell=3000, flen_sigma=1.2)
     big, boff = sn.generate_atac(seed=10, n_cells=2, frags_per_cell=40000)
     tiny_b, tiny_off = rad.encode_atac_cells([(7, [[(2, 4, 10, 100)]]), (8, [[]]), (9, [[(0, 4, 1, 1)], [(0, 4, 1, 1)]])])
