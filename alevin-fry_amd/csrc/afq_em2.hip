@@ -370,41 +370,60 @@ template <> struct IdLoad<uint32_t> { static __device__ __forceinline__ uint32_t
 __device__ __forceinline__ void em2_add(unsigned long long* p, unsigned long long v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// one pass over the classes: D in label order, r = 1 / D, every label word's share into its entry's accumulator
-template <int NT, int CPT, typename IdT>
-__device__ __forceinline__ void em2_class_pass(const IdT* __restrict__ coff, const IdT* __restrict__ cw, const float* ab,
-                                               unsigned long long* acc, uint32_t K, float scale) {
+// One pass over the classes: D in label order, r = 1 / D, every label word's share into its entry's accumulator.
+//
+// Every load of a trip is UNCONDITIONAL, at an index clamped into the arrays, and its value is masked afterwards.  A load
+// under `k < n ? load : 0` sits in a divergent block of its own, and the wait-count pass cannot count across those: it put
+// `s_waitcnt vmcnt(0)` in front of every gather whose index came from an earlier (conditional) load, so the sixteen gathers
+// of a trip went out one L2 round trip after the other (round 5: the ISA of k_em2_rounds_hybrid).  In straight-line code a
+// level's loads issue back to back and the trip is three round trips deep: offsets, label words, abundances.
+// `load(e)`: what the memory holds for state id e (nothing but loads), `pick(e, raw)`: its abundance out of that; a scheduling
+// barrier between a level's loads and their first use keeps the scheduler from sinking each load to its use (it does, to save
+// registers, which serialises them again).  `add(e, q)`: q into e's accumulator.  CPT classes per thread and trip.
+template <int NT, int CPT, typename IdT, typename Load, typename Pick, typename Add>
+__device__ __forceinline__ void em2_class_pass(const IdT* __restrict__ coff, const IdT* __restrict__ cw, uint32_t K, float scale, Load load, Pick pick,
+                                               Add add) {
     for (uint32_t c0 = threadIdx.x; c0 < K; c0 += CPT * NT) {
-        // CPT classes per thread and trip, each level of their gathers issued together (two out of LDS; four when the lists stream
-        // from global memory: a trip is then a chain of L2 round trips, and the chains of one thread are all it has in flight)
         uint32_t o0[CPT], n[CPT], e[CPT][4];
         float a[CPT][4];
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
             const uint32_t c = c0 + j * NT;
-            o0[j] = 0; n[j] = 0;
-            if (c < K) { o0[j] = IdLoad<IdT>::at(coff, c); n[j] = IdLoad<IdT>::at(coff, c + 1) - o0[j]; }
+            const uint32_t cc = c < K ? c : K - 1;
+            o0[j] = IdLoad<IdT>::at(coff, cc);
+            const uint32_t o1 = IdLoad<IdT>::at(coff, cc + 1);
+            n[j] = c < K ? o1 - o0[j] : 0u;
         }
 #pragma unroll
         for (int j = 0; j < CPT; ++j)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) e[j][k] = (uint32_t)k < n[j] ? IdLoad<IdT>::at(cw, o0[j] + k) : 0u;
+            for (int k = 0; k < 4; ++k) e[j][k] = IdLoad<IdT>::at(cw, o0[j] + ((uint32_t)k < n[j] ? (uint32_t)k : 0u));   // (a class has two words or more: o0 is a word of the list)
+        decltype(load(0u)) raw[CPT][4];
 #pragma unroll
         for (int j = 0; j < CPT; ++j)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a[j][k] = (uint32_t)k < n[j] ? ab[e[j][k]] : 0.0f;
+            for (int k = 0; k < 4; ++k) raw[j][k] = load(e[j][k]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < CPT; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[j][k] = (uint32_t)k < n[j] ? pick(e[j][k], raw[j][k]) : 0.0f;
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
             if (n[j] == 0) continue;
             float d = 0.0f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) if ((uint32_t)k < n[j]) d += a[j][k];
-            for (uint32_t k = 4; k < n[j]; k += 4) {   // (longer labels: four words a step, their loads in flight together, the additions in label order)
+            for (uint32_t k = 4; k < n[j]; k += 4) {   // (longer labels: four words a step, the additions in label order)
                 uint32_t e4[4]; float a4[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) e4[t] = k + t < n[j] ? IdLoad<IdT>::at(cw, o0[j] + k + t) : 0u;
+                for (int t = 0; t < 4; ++t) e4[t] = IdLoad<IdT>::at(cw, o0[j] + (k + t < n[j] ? k + t : 0u));
+                decltype(load(0u)) r4[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) a4[t] = k + t < n[j] ? ab[e4[t]] : 0.0f;
+                for (int t = 0; t < 4; ++t) r4[t] = load(e4[t]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) a4[t] = pick(e4[t], r4[t]);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) if (k + t < n[j]) d += a4[t];
             }
@@ -412,15 +431,19 @@ __device__ __forceinline__ void em2_class_pass(const IdT* __restrict__ coff, con
             const float r = 1.0f / d;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if ((uint32_t)k < n[j]) em2_add(&acc[e[j][k]], (unsigned long long)((a[j][k] * r) * scale));
+                if ((uint32_t)k < n[j]) add(e[j][k], (unsigned long long)((a[j][k] * r) * scale));
             for (uint32_t k = 4; k < n[j]; k += 4) {
                 uint32_t e4[4]; float a4[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) e4[t] = k + t < n[j] ? IdLoad<IdT>::at(cw, o0[j] + k + t) : 0u;
+                for (int t = 0; t < 4; ++t) e4[t] = IdLoad<IdT>::at(cw, o0[j] + (k + t < n[j] ? k + t : 0u));
+                decltype(load(0u)) r4[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) a4[t] = k + t < n[j] ? ab[e4[t]] : 0.0f;
+                for (int t = 0; t < 4; ++t) r4[t] = load(e4[t]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) if (k + t < n[j]) em2_add(&acc[e4[t]], (unsigned long long)((a4[t] * r) * scale));
+                for (int t = 0; t < 4; ++t) a4[t] = pick(e4[t], r4[t]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) if (k + t < n[j]) add(e4[t], (unsigned long long)((a4[t] * r) * scale));
             }
         }
     }
@@ -528,8 +551,13 @@ __global__ __launch_bounds__(NT) void k_em2_rounds(const CellMeta* __restrict__ 
             __syncthreads();
         }
         // (A+B) classes
-        if constexpr (MODE == 0) em2_class_pass<NT, 2, uint16_t>(coff16, cw16, ab, acc, K, scale);
-        else em2_class_pass<NT, 4, uint32_t>(sc.coff, sc.cw, ab, acc, K, scale);
+        {
+            auto load = [&](uint32_t e) -> float { return ab[e]; };
+            auto pick = [](uint32_t, float x) -> float { return x; };
+            auto add = [&](uint32_t e, unsigned long long q) { em2_add(&acc[e], q); };
+            if constexpr (MODE == 0) em2_class_pass<NT, 2, uint16_t>(coff16, cw16, K, scale, load, pick, add);
+            else em2_class_pass<NT, 4, uint32_t>(sc.coff, sc.cw, K, scale, load, pick, add);
+        }
         EM2T(0);
         __syncthreads();
         EM2T(1);
@@ -589,7 +617,7 @@ __global__ __launch_bounds__(NT) void k_em2_rounds(const CellMeta* __restrict__ 
     for (uint32_t j = tid; j < nPU; j += NT) sc.out[j + pre[sc.pu_lb[j]]] = make_uint2(sc.pu_col[j], __float_as_uint((float)sc.pu_cnt[j]));
     if (tid == 0) out_nnz[cell] = nPU + nout;
 #ifdef AFQ_EM_TIMING
-    if (tid == 0 && (blockIdx.x % 100) == 3 && cfg.min_tier == 9)
+    if (tid == 0 && (blockIdx.x % 100) == 3)
         printf("em2 rounds tier=%u NT=%d L=%u P=%u K=%u Wc=%u nPU=%u it=%u: C+classes(thread 0)=%.1f wait=%.1f entries=%.1f other=%.1f total=%.1f us\n", tier, NT, L, P, K, Wc, nPU, it,
                (double)tph[0] / 100.0, (double)tph[1] / 100.0, (double)tph[2] / 100.0, (double)tph[3] / 100.0, (double)(wall_clock64() - t_begin) / 100.0);
     if (tid == 0) {
@@ -633,23 +661,37 @@ __global__ __launch_bounds__(NT) void k_em2_rounds_hybrid(const uint32_t* __rest
     unsigned long long* acc_g = sc.g_acc;
     float* v_g = sc.g_v;
     float* ab_g = usa ? sc.g_ab : sc.g_v;
-    auto V = [&](uint32_t s2) -> float { return s2 < H ? v_h[s2] : v_g[s2]; };
-    auto setV = [&](uint32_t s2, float x) { if (s2 < H) v_h[s2] = x; else v_g[s2] = x; };
-    auto AB = [&](uint32_t s2) -> float { return s2 < H ? ab_h[s2] : ab_g[s2]; };
-    auto add = [&](uint32_t s2, unsigned long long q) { if (s2 < H) em2_add(&acc_h[s2], q); else em2_add(&acc_g[s2], q); };   // (LDS or L2: never a flat atomic)
+    // A state id is read from BOTH homes, each at an index that is valid there, and the answer picked afterwards: `hot ? lds[i] :
+    // global[i]` compiles to a FLAT load of a selected pointer (slower than either, and it counts in both wait counters), and a
+    // load under a branch stops the loads behind it (em2_class_pass).  Writes and atomics take two `if`s, not an if / else, so
+    // that the two sides are not merged into one flat instruction.
+    auto V = [&](uint32_t s2) -> float { const bool hot = s2 < H; const float xh = v_h[hot ? s2 : 0u], xg = v_g[hot ? 0u : s2]; return hot ? xh : xg; };
+    auto setV = [&](uint32_t s2, float x) { if (s2 < H) v_h[s2] = x; if (s2 >= H) v_g[s2] = x; };
+    auto ab_load = [&](uint32_t s2) -> float2 { const bool hot = s2 < H; return make_float2(ab_h[hot ? s2 : 0u], ab_g[hot ? 0u : s2]); };
+    auto ab_pick = [&](uint32_t s2, float2 x) -> float { return s2 < H ? x.x : x.y; };
+    auto add = [&](uint32_t s2, unsigned long long q) { if (s2 < H) em2_add(&acc_h[s2], q); if (s2 >= H) em2_add(&acc_g[s2], q); };   // (LDS or L2: never a flat atomic)
     const float uni = 1.0f / (float)cfg.num_alphas;
     auto init_of = [&](uint32_t cnt) -> float { return cfg.init_uniform ? uni : ((float)cnt + 0.5f) * 1e-3f; };
     for (uint32_t e = tid; e < L; e += NT) {
         const uint32_t s2 = sc.nid[e], c = sc.ent_ucnt[e];
         setV(s2, init_of(c));
-        if (s2 < H) acc_h[s2] = (unsigned long long)c << F; else acc_g[s2] = (unsigned long long)c << F;
+        if (s2 < H) acc_h[s2] = (unsigned long long)c << F;
+        if (s2 >= H) acc_g[s2] = (unsigned long long)c << F;
     }
     for (uint32_t p = tid; p < P; p += NT) v_g[L + p] = init_of(sc.pas_val[p]);
     if (tid == 0) { v_g[Z0] = init_of(0u); v_g[Z1] = 0.0f; s_flag[0] = 0; s_flag[1] = 0; }
     em2_gsync();
+#ifdef AFQ_EM_TIMING
+    unsigned long long hph[5] = {0, 0, 0, 0, 0}, hph_t = wall_clock64();
+    const unsigned long long h_begin = hph_t;
+#define EM2H(i) do { if (tid == 0) { const unsigned long long n_ = wall_clock64(); hph[i] += n_ - hph_t; hph_t = n_; } } while (0)
+#else
+#define EM2H(i) do {} while (0)
+#endif
     uint32_t it = 0;
     bool conv = true, last_round = false;
     while (it < kMinIter2 || (it < kMaxIter2 && !conv) || last_round) {
+        EM2H(4);
         if (usa) {
             for (uint32_t e0 = tid; e0 < L; e0 += 4 * NT) {   // (four entries per thread and trip: their index loads, then their gathers, in flight together)
                 uint32_t s2[4], q1[4], q2[4];
@@ -657,80 +699,45 @@ __global__ __launch_bounds__(NT) void k_em2_rounds_hybrid(const uint32_t* __rest
                 for (int j = 0; j < 4; ++j) {
                     const uint32_t e = e0 + j * NT;
                     const bool ok = e < L;
-                    s2[j] = ok ? sc.nid[e] : 0u; q1[j] = ok ? sc.ent_s1[e] : kSibNone; q2[j] = ok ? sc.ent_s2[e] : kSibNone;
+                    const uint32_t ee = ok ? e : 0u;   // (loads unconditional, see em2_class_pass)
+                    const uint32_t t0 = sc.nid[ee], t1 = sc.ent_s1[ee], t2 = sc.ent_s2[ee];
+                    s2[j] = ok ? t0 : 0u; q1[j] = ok ? t1 : kSibNone; q2[j] = ok ? t2 : kSibNone;
                 }
                 float x[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) x[j] = (V(em2_map_sib(q1[j], L, P)) + V(em2_map_sib(q2[j], L, P))) + V(s2[j]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (e0 + j * NT < L) { if (s2[j] < H) ab_h[s2[j]] = x[j]; else ab_g[s2[j]] = x[j]; }
+                for (int j = 0; j < 4; ++j) if (e0 + j * NT < L) { if (s2[j] < H) ab_h[s2[j]] = x[j]; if (s2[j] >= H) ab_g[s2[j]] = x[j]; }
             }
             em2_gsync();
         }
-        for (uint32_t c0 = tid; c0 < K; c0 += 4 * NT) {   // (as em2_class_pass, over state ids, four classes per thread and trip)
-            uint32_t o0[4], n[4], e[4][4];
-            float a[4][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t c = c0 + j * NT;
-                o0[j] = 0; n[j] = 0;
-                if (c < K) { o0[j] = sc.coff[c]; n[j] = sc.coff[c + 1] - o0[j]; }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) e[j][k] = (uint32_t)k < n[j] ? sc.cw[o0[j] + k] : 0u;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) a[j][k] = (uint32_t)k < n[j] ? AB(e[j][k]) : 0.0f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (n[j] == 0) continue;
-                float d = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if ((uint32_t)k < n[j]) d += a[j][k];
-                for (uint32_t k = 4; k < n[j]; k += 4) {
-                    uint32_t e4[4]; float a4[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) e4[t] = k + t < n[j] ? sc.cw[o0[j] + k + t] : 0u;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) a4[t] = k + t < n[j] ? AB(e4[t]) : 0.0f;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) if (k + t < n[j]) d += a4[t];
-                }
-                if (!(d > 0.0f)) continue;
-                const float r = 1.0f / d;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if ((uint32_t)k < n[j]) add(e[j][k], (unsigned long long)((a[j][k] * r) * scale));
-                for (uint32_t k = 4; k < n[j]; k += 4) {
-                    uint32_t e4[4]; float a4[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) e4[t] = k + t < n[j] ? sc.cw[o0[j] + k + t] : 0u;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) a4[t] = k + t < n[j] ? AB(e4[t]) : 0.0f;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) if (k + t < n[j]) add(e4[t], (unsigned long long)((a4[t] * r) * scale));
-                }
-            }
-        }
+        EM2H(0);
+        em2_class_pass<NT, 4, uint32_t>(sc.coff, sc.cw, K, scale, ab_load, ab_pick, add);
+        EM2H(1);
         em2_gsync();
+        EM2H(2);
         bool bad = false;
         if (tid == 0) s_flag[(it + 1) & 1u] = 0;
         for (uint32_t e0 = tid; e0 < L; e0 += 4 * NT) {
             uint32_t s2[4], uc[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const uint32_t e = e0 + j * NT; s2[j] = e < L ? sc.nid[e] : 0u; uc[j] = e < L ? sc.ent_ucnt[e] : 0u; }
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t e = e0 + j * NT, ee = e < L ? e : 0u;
+                const uint32_t t0 = sc.nid[ee], t1 = sc.ent_ucnt[ee];
+                s2[j] = e < L ? t0 : 0u; uc[j] = e < L ? t1 : 0u;
+            }
             unsigned long long a[4];
             float old[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                a[j] = 0; old[j] = 0.0f;
-                if (e0 + j * NT >= L) continue;
+                const bool ok = e0 + j * NT < L, hot = s2[j] < H;
                 const unsigned long long fresh = (unsigned long long)uc[j] << F;
-                if (s2[j] < H) { a[j] = acc_h[s2[j]]; acc_h[s2[j]] = fresh; }
-                else a[j] = __hip_atomic_exchange(&acc_g[s2[j]], fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const unsigned long long ah = acc_h[hot ? s2[j] : 0u];
                 old[j] = V(s2[j]);
+                if (ok && hot) acc_h[s2[j]] = fresh;
+                unsigned long long ag = 0;
+                if (ok && !hot) ag = __hip_atomic_exchange(&acc_g[s2[j]], fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                a[j] = hot ? ah : ag;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -746,6 +753,7 @@ __global__ __launch_bounds__(NT) void k_em2_rounds_hybrid(const uint32_t* __rest
         }
         if (bad) s_flag[it & 1u] = 1;
         em2_gsync();
+        EM2H(3);
         conv = s_flag[it & 1u] == 0;
         ++it;
         if (usa) {
@@ -779,7 +787,9 @@ __global__ __launch_bounds__(NT) void k_em2_rounds_hybrid(const uint32_t* __rest
     if (tid == 0) {
         const uint32_t at = atomicAdd(&g_em2_dbg_n, 1u);
         if (at < 32768) { g_em2_dbg[at][0] = ((unsigned long long)tier << 56) | blockIdx.x; g_em2_dbg[at][1] = t_entry; g_em2_dbg[at][2] = t_entry; g_em2_dbg[at][3] = wall_clock64(); }
-        if ((blockIdx.x % 100) == 3) printf("em2 hybrid L=%u H=%u P=%u K=%u it=%u total=%.1f us\n", L, H, P, K, it, (double)(wall_clock64() - t_entry) / 100.0);
+        if ((blockIdx.x % 100) == 3) printf("em2 hybrid L=%u H=%u P=%u K=%u Wc=%u it=%u: C=%.1f classes(thread 0)=%.1f wait=%.1f entries=%.1f other=%.1f rounds=%.1f total=%.1f us\n", L, H, P, K, sc.hdr[H_WC], it,
+                                            (double)hph[0] / 100.0, (double)hph[1] / 100.0, (double)hph[2] / 100.0, (double)hph[3] / 100.0, (double)hph[4] / 100.0,
+                                            (double)(wall_clock64() - h_begin) / 100.0, (double)(wall_clock64() - t_entry) / 100.0);
     }
 #endif
 }
