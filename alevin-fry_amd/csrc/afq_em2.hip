@@ -49,20 +49,27 @@ constexpr uint32_t kSibNone = 0xFFFFFFFFu;   // no such sibling status: adds +0.
 constexpr uint32_t kSibZero = 0xFFFFFFFEu;   // a sibling status nothing maps to: the start value in round 1, 0 afterwards
 constexpr uint32_t kSibPassive = 0x80000000u;   // | index into pas_val
 constexpr int kSetupNT = 256;
+#ifndef AFQ_EM2_CPT_STREAM
+#define AFQ_EM2_CPT_STREAM 4
+#endif
+constexpr int kCptS = AFQ_EM2_CPT_STREAM;
 
-struct Em2Cfg { uint32_t usa, num_alphas, uo, ao, init_uniform, nwb, min_tier; };
+struct Em2Cfg { uint32_t usa, num_alphas, uo, ao, init_uniform, nwb, min_tier, force_wide; };
 
 // per-cell scratch (u32 words); mirrored by em2_scratch_words
 struct Em2Scratch {
     uint2* out; uint32_t* hdr; uint32_t *ent_col, *ent_ucnt, *ent_s1, *ent_s2, *ent_ub, *pas_val, *coff, *cw, *pu_col, *pu_cnt, *pu_lb;
-    unsigned long long* g_acc; float *g_ab, *g_v; uint32_t *g_pre, *nid;
+    unsigned long long* g_acc; float *g_ab, *g_v; uint32_t *g_pre, *nid; uint16_t* cw16;
 };
+// header: 16 scalar words, then the class runs (up to 64 of {first class, first word, label length (0: the run of 63+, offsets in
+// coff), one past the last class})
+constexpr uint32_t kHdrWords = 16 + 4 * 64;
 __host__ __device__ inline uint64_t em2_pas_cap(uint64_t nU, uint64_t W, bool usa) { return usa ? (nU < 2 * W ? nU : 2 * W) : 0; }
 __device__ __forceinline__ Em2Scratch em2_carve(uint32_t* scratch, uint64_t off, uint32_t nU, uint32_t W, uint32_t M, bool usa) {
     Em2Scratch e;
     uint32_t* p = scratch + off;
     e.out = reinterpret_cast<uint2*>(p); p += 2 * ((uint64_t)nU + W);
-    e.hdr = p; p += 16;
+    e.hdr = p; p += kHdrWords;
     e.g_acc = reinterpret_cast<unsigned long long*>(p); p += 2 * ((uint64_t)W + 1);
     e.ent_col = p; p += W;
     e.ent_ucnt = p; p += W;
@@ -79,20 +86,21 @@ __device__ __forceinline__ Em2Scratch em2_carve(uint32_t* scratch, uint64_t off,
     e.g_v = reinterpret_cast<float*>(p); p += W + em2_pas_cap(nU, W, usa) + 2;
     e.g_pre = p; p += W + 1;
     e.nid = p; p += W;
+    e.cw16 = reinterpret_cast<uint16_t*>(p); p += (W + 1) / 2 + 1;
     return e;
 }
 }  // namespace
 
 __host__ __device__ inline uint64_t em2_words(uint32_t nU, uint32_t W, uint32_t M, bool usa) {
     const uint64_t pc = em2_pas_cap(nU, W, usa);
-    uint64_t w = 2 * ((uint64_t)nU + W) + 16 + 2 * ((uint64_t)W + 1) + 3 * (uint64_t)W + (usa ? 2 * (uint64_t)W : 0) + pc + ((uint64_t)M + 1) + W +
-                 3 * (uint64_t)nU + (usa ? W : 0) + ((uint64_t)W + pc + 2) + ((uint64_t)W + 1) + W;
+    uint64_t w = 2 * ((uint64_t)nU + W) + kHdrWords + 2 * ((uint64_t)W + 1) + 3 * (uint64_t)W + (usa ? 2 * (uint64_t)W : 0) + pc + ((uint64_t)M + 1) + W +
+                 3 * (uint64_t)nU + (usa ? W : 0) + ((uint64_t)W + pc + 2) + ((uint64_t)W + 1) + W + (((uint64_t)W + 1) / 2 + 1);
     return (w + 3) & ~3ull;   // slices stay 16-byte aligned
 }
 uint64_t em2_scratch_words(uint32_t nU, uint32_t W, uint32_t M, bool usa) { return em2_words(nU, W, M, usa); }
 
 // header words
-enum { H_L = 0, H_P, H_K, H_WC, H_NPU, H_FBITS, H_TIER, H_NHOT };
+enum { H_L = 0, H_P, H_K, H_WC, H_NPU, H_FBITS, H_TIER, H_NHOT, H_NRUN, H_NARROW, H_C4 };
 constexpr uint32_t kTierNone = 7;   // no multi-label class: the row is the single-label counts (em.rs:339-341, 499-514)
 // LDS words of the three all-in-LDS instances (4 x 38 KiB, 2 x 78 KiB, 157 KiB: next to the few static words they fit a CU's 160 KiB)
 constexpr uint32_t kT0Words = 9728, kT1Words = 19968, kT2Words = 40192;
@@ -108,6 +116,13 @@ __host__ __device__ inline uint32_t em2_lds_core_words(uint32_t L, uint32_t P, b
 __host__ __device__ inline uint32_t em2_hot_cap(bool usa) { return kT2Words / (usa ? 4u : 3u); }
 __host__ __device__ inline uint32_t em2_lds_all_words(uint32_t L, uint32_t P, uint32_t K, uint32_t Wc, bool usa) {
     return em2_lds_core_words(L, P, usa) + (K + 2) / 2 + (Wc + 1) / 2 + 2;
+}
+
+__device__ __forceinline__ uint32_t em2_map_sib(uint32_t s, uint32_t L, uint32_t P) {
+    if (s == kSibNone) return L + P + 1;
+    if (s == kSibZero) return L + P;
+    if (s & kSibPassive) return L + (s & 0x7FFFFFFFu);
+    return s;
 }
 
 // The barrier between phases that hand each other data through GLOBAL memory: a wave first waits for its own stores to be
@@ -190,6 +205,14 @@ __global__ __launch_bounds__(kSetupNT) void k_em2_setup(const CellMeta* __restri
             wpos += b == 63 ? s_long_words : (uint32_t)b * s_hist[b];
         }
         s_long_words = wpos;   // (now: all label words)
+        uint32_t r = 0;   // the runs as the rounds read them: a class's words are at first word + (class - first class) x length
+        for (int b = 63; b >= 0; --b)
+            if (s_hist[b]) {
+                uint32_t* q = sc.hdr + 16 + 4 * r++;
+                q[0] = s_len_cbase[b]; q[1] = s_len_wbase[b]; q[2] = b == 63 ? 0u : (uint32_t)b; q[3] = s_len_cbase[b] + s_hist[b];
+            }
+        sc.hdr[H_NRUN] = r;
+        sc.hdr[H_C4] = s_len_cbase[4];   // classes before this one have labels of more than four words
     }
     __syncthreads();
     const uint32_t Wc = s_long_words;
@@ -291,22 +314,29 @@ __global__ __launch_bounds__(kSetupNT) void k_em2_setup(const CellMeta* __restri
         const uint32_t lo = sc.pu_lb[j], hi = j + 1 < nPU ? sc.pu_lb[j + 1] : L;
         for (uint32_t e = lo; e < hi; ++e) sc.ent_ub[e] = j + 1;
     }
-    // 5. label words as live ids
-    for (uint32_t w = tid; w < Wc; w += NT) sc.cw[w] = rank_of(sc.cw[w]);
-    // 6. tier (every thread: the values are uniform)
+    // 5. tier (every thread: the values are uniform)
     const uint32_t P = s_P, K = M;
+    const bool narrow = L + P + 2 <= 65536u;   // every state id (entries, passive siblings, the two constants) fits 16 bits
     uint32_t tier;
     {
-        const bool ids16 = L + P + 2 <= 65536u && K < 65535u && Wc <= 65535u;
+        const bool ids16 = narrow && K < 65535u && Wc <= 65535u;
         const uint32_t all = em2_lds_all_words(L, P, K, Wc, usa), core = em2_lds_core_words(L, P, usa);
         if (ids16 && all <= kT0Words && L <= 256u * 8u) tier = 0;
         else if (ids16 && all <= kT1Words && L <= 512u * 8u) tier = 1;
         else if (ids16 && all <= kT2Words && L <= 1024u * 16u) tier = 2;
-        else if (core <= kT2Words) tier = 3;
+        else if (core <= kT2Words) tier = 3;   // (at most ~13 000 entries: always narrow)
         else tier = 4;
         if (tier < cfg.min_tier) tier = cfg.min_tier;   // (tests: every instance on every size)
     }
+    // 6. label words as live ids.  Tiers 3 and 4 stream the class lists from memory every round and are bound by those bytes
+    //    (round 5: 4.3-4.6 TB/s in every phase of a round), so they get the words as 16-bit ids next to the 32-bit ones.
+    for (uint32_t w = tid; w < Wc; w += NT) {
+        const uint32_t id = rank_of(sc.cw[w]);
+        sc.cw[w] = id;
+        if (tier == 3) sc.cw16[w] = (uint16_t)id;
+    }
     uint32_t H = L;
+    const bool narrow4 = narrow && !cfg.force_wide;   // (tests: the 32-bit route of the largest instance on small cells)
     if (tier == 4) {
         // 7. A cell whose state does not fit LDS keeps the entries that take most of the traffic there - the ones in most
         // classes (gene popularity is Zipf: a few entries sit in a tenth of all labels) - and the rest in global memory:
@@ -344,17 +374,35 @@ __global__ __launch_bounds__(kSetupNT) void k_em2_setup(const CellMeta* __restri
             eq_before += tot_eq; hot_before += tot_hot;
         }
         em2_gsync();
-        for (uint32_t w = tid; w < Wc; w += NT) sc.cw[w] = sc.nid[sc.cw[w]];
-        if (usa)
+        for (uint32_t w = tid; w < Wc; w += NT) {
+            const uint32_t id = sc.nid[sc.cw[w]];
+            sc.cw[w] = id;
+            if (narrow4) sc.cw16[w] = (uint16_t)id;
+        }
+        // What the rounds read per entry, in STATE order (they walk state ids, not entries: no nid[] per round): the single-label
+        // counts over the degree table, which is dead now, and - 16-bit ids - both sibling links in one word over ent_s2.
+        uint32_t* st_cnt = sc.g_pre;
+        for (uint32_t e = tid; e < L; e += NT) st_cnt[sc.nid[e]] = sc.ent_ucnt[e];
+        if (usa) {
             for (uint32_t e = tid; e < L; e += NT) {
-                const uint32_t a = sc.ent_s1[e], b = sc.ent_s2[e];
-                if (!(a & kSibPassive)) sc.ent_s1[e] = sc.nid[a];
-                if (!(b & kSibPassive)) sc.ent_s2[e] = sc.nid[b];
+                uint32_t a = sc.ent_s1[e], b = sc.ent_s2[e];
+                if (!(a & kSibPassive)) a = sc.nid[a];   // (the three special values have the top bit set, too)
+                if (!(b & kSibPassive)) b = sc.nid[b];
+                if (narrow4) sc.ent_s1[e] = em2_map_sib(a, L, P) | (em2_map_sib(b, L, P) << 16);
+                else { sc.ent_s1[e] = a; sc.ent_s2[e] = b; }
             }
+            if (narrow4) {
+                em2_gsync();   // (every ent_s2[e] has been read)
+                for (uint32_t e = tid; e < L; e += NT) sc.ent_s2[sc.nid[e]] = sc.ent_s1[e];
+            }
+        }
+    } else if (usa) {   // tiers 0-3 (state id = entry): both sibling links, as the ids the rounds index with, in one word
+        em2_gsync();   // (step 4 wrote links of other threads' entries)
+        for (uint32_t e = tid; e < L; e += NT) sc.ent_s1[e] = em2_map_sib(sc.ent_s1[e], L, P) | (em2_map_sib(sc.ent_s2[e], L, P) << 16);
     }
     if (tid == 0) {
         sc.hdr[H_L] = L; sc.hdr[H_P] = P; sc.hdr[H_K] = K; sc.hdr[H_WC] = Wc; sc.hdr[H_NPU] = nPU; sc.hdr[H_FBITS] = em2_fbits(m.nrec);
-        sc.hdr[H_TIER] = tier; sc.hdr[H_NHOT] = H;
+        sc.hdr[H_TIER] = tier; sc.hdr[H_NHOT] = H; sc.hdr[H_NARROW] = narrow4 ? 1u : 0u;
         const uint32_t at = atomicAdd(&tiers[tier], 1u);
         tiers[8 + (size_t)tier * n_cells + at] = cell;
     }
@@ -367,8 +415,13 @@ template <typename T> struct IdLoad;
 template <> struct IdLoad<uint16_t> { static __device__ __forceinline__ uint32_t at(const uint16_t* p, uint32_t i) { return p[i]; } };
 template <> struct IdLoad<uint32_t> { static __device__ __forceinline__ uint32_t at(const uint32_t* p, uint32_t i) { return p[i]; } };
 
+
 __device__ __forceinline__ void em2_add(unsigned long long* p, unsigned long long v) {
+#ifdef AFQ_EM2_EXPERIMENT_NOADD
+    if (v == 0x123456789ull) *p = v;   // (timing experiment: the pass without its atomics; wrong rows)
+#else
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
 }
 // One pass over the classes: D in label order, r = 1 / D, every label word's share into its entry's accumulator.
 //
@@ -380,41 +433,71 @@ __device__ __forceinline__ void em2_add(unsigned long long* p, unsigned long lon
 // `load(e)`: what the memory holds for state id e (nothing but loads), `pick(e, raw)`: its abundance out of that; a scheduling
 // barrier between a level's loads and their first use keeps the scheduler from sinking each load to its use (it does, to save
 // registers, which serialises them again).  `add(e, q)`: q into e's accumulator.  CPT classes per thread and trip.
-template <int NT, int CPT, typename IdT, typename Load, typename Pick, typename Add>
-__device__ __forceinline__ void em2_class_pass(const IdT* __restrict__ coff, const IdT* __restrict__ cw, uint32_t K, float scale, Load load, Pick pick,
-                                               Add add) {
-    for (uint32_t c0 = threadIdx.x; c0 < K; c0 += CPT * NT) {
-        uint32_t o0[CPT], n[CPT], e[CPT][4];
-        float a[CPT][4];
+// `locate(c, ok, o0, n)`: first word and length of class c (ok: c < K; otherwise any valid word and length 0) - from the offset
+// table (LocateByOffsets) or from the cell's runs of equal-length classes (LocateByRuns: no bytes from memory).
+template <typename IdT>
+struct LocateByOffsets {   // coff[c] .. coff[c + 1]
+    const IdT* coff; uint32_t K;
+    __device__ __forceinline__ void operator()(uint32_t c, bool ok, uint32_t& o0, uint32_t& n) const {
+        const uint32_t cc = ok ? c : K - 1;
+        o0 = IdLoad<IdT>::at(coff, cc);
+        const uint32_t o1 = IdLoad<IdT>::at(coff, cc + 1);
+        n = ok ? o1 - o0 : 0u;
+    }
+};
+// The classes of a cell are laid out longest label first, equal lengths in one run (k_em2_setup): class c of a run starts at
+// first word + (c - first class) x length.  A thread's classes ascend, so it walks the run list (LDS, up to 64 entries) with a
+// cursor.  The run of labels of 63 words and more has its offsets in coff.
+struct LocateByRuns {
+    const uint4* runs; const uint32_t* coff; uint32_t ri; uint4 run;
+    __device__ __forceinline__ LocateByRuns(const uint4* r, const uint32_t* c) : runs(r), coff(c), ri(0), run(r[0]) {}
+    __device__ __forceinline__ void operator()(uint32_t c, bool ok, uint32_t& o0, uint32_t& n) {
+        o0 = 0; n = 0;
+        if (!ok) return;
+        while (c >= run.w) run = runs[++ri];
+        o0 = run.y + (c - run.x) * run.z; n = run.z;
+        if (run.z == 0) { o0 = coff[c]; n = coff[c + 1] - o0; }
+    }
+};
+template <int NT, int CPT, int EW, typename IdT, typename Locate, typename Load, typename Pick, typename Add>
+__device__ __forceinline__ void em2_class_pass(const IdT* __restrict__ cw, uint32_t c_begin, uint32_t c_end, float scale, Locate& locate, Load load, Pick pick,
+                                               Add add, unsigned long long* tq = nullptr) {
+#ifdef AFQ_EM_TIMING   // (thread 0's clock per level of a trip; the waits it forces are not in the product build)
+    unsigned long long tq_t = wall_clock64();
+#define EM2Q(i) do { if (tq && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long n_ = wall_clock64(); tq[i] += n_ - tq_t; tq_t = n_; } } while (0)
+#else
+#define EM2Q(i) do {} while (0)
+#endif
+    // classes [c_begin, c_end), CPT per thread and trip, the first EW words of each label in registers
+    for (uint32_t c0 = c_begin + threadIdx.x; c0 < c_end; c0 += CPT * NT) {
+        uint32_t o0[CPT], n[CPT], e[CPT][EW];
+        float a[CPT][EW];
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) {
-            const uint32_t c = c0 + j * NT;
-            const uint32_t cc = c < K ? c : K - 1;
-            o0[j] = IdLoad<IdT>::at(coff, cc);
-            const uint32_t o1 = IdLoad<IdT>::at(coff, cc + 1);
-            n[j] = c < K ? o1 - o0[j] : 0u;
-        }
+        for (int j = 0; j < CPT; ++j) { const uint32_t c = c0 + j * NT; locate(c, c < c_end, o0[j], n[j]); }
+        EM2Q(0);
 #pragma unroll
         for (int j = 0; j < CPT; ++j)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) e[j][k] = IdLoad<IdT>::at(cw, o0[j] + ((uint32_t)k < n[j] ? (uint32_t)k : 0u));   // (a class has two words or more: o0 is a word of the list)
-        decltype(load(0u)) raw[CPT][4];
+            for (int k = 0; k < EW; ++k) e[j][k] = IdLoad<IdT>::at(cw, o0[j] + ((uint32_t)k < n[j] ? (uint32_t)k : 0u));
+        EM2Q(1);
+        decltype(load(0u)) raw[CPT][EW];
 #pragma unroll
         for (int j = 0; j < CPT; ++j)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) raw[j][k] = load(e[j][k]);
+            for (int k = 0; k < EW; ++k) raw[j][k] = load(e[j][k]);
+        EM2Q(2);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < CPT; ++j)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a[j][k] = (uint32_t)k < n[j] ? pick(e[j][k], raw[j][k]) : 0.0f;
+            for (int k = 0; k < EW; ++k) a[j][k] = (uint32_t)k < n[j] ? pick(e[j][k], raw[j][k]) : 0.0f;
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
             if (n[j] == 0) continue;
             float d = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) if ((uint32_t)k < n[j]) d += a[j][k];
-            for (uint32_t k = 4; k < n[j]; k += 4) {   // (longer labels: four words a step, the additions in label order)
+            for (int k = 0; k < EW; ++k) if ((uint32_t)k < n[j]) d += a[j][k];
+            for (uint32_t k = EW; k < n[j]; k += 4) {   // (longer labels: four words a step, the additions in label order)
                 uint32_t e4[4]; float a4[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) e4[t] = IdLoad<IdT>::at(cw, o0[j] + (k + t < n[j] ? k + t : 0u));
@@ -430,9 +513,9 @@ __device__ __forceinline__ void em2_class_pass(const IdT* __restrict__ coff, con
             if (!(d > 0.0f)) continue;
             const float r = 1.0f / d;
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < EW; ++k)
                 if ((uint32_t)k < n[j]) add(e[j][k], (unsigned long long)((a[j][k] * r) * scale));
-            for (uint32_t k = 4; k < n[j]; k += 4) {
+            for (uint32_t k = EW; k < n[j]; k += 4) {
                 uint32_t e4[4]; float a4[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) e4[t] = IdLoad<IdT>::at(cw, o0[j] + (k + t < n[j] ? k + t : 0u));
@@ -446,14 +529,19 @@ __device__ __forceinline__ void em2_class_pass(const IdT* __restrict__ coff, con
                 for (int t = 0; t < 4; ++t) if (k + t < n[j]) add(e4[t], (unsigned long long)((a4[t] * r) * scale));
             }
         }
+        EM2Q(3);
     }
 }
-
-__device__ __forceinline__ uint32_t em2_map_sib(uint32_t s, uint32_t L, uint32_t P) {
-    if (s == kSibNone) return L + P + 1;
-    if (s == kSibZero) return L + P;
-    if (s & kSibPassive) return L + (s & 0x7FFFFFFFu);
-    return s;
+// The streamed instances: the classes are laid out longest label first, so the labels beyond four words are the first c4
+// classes.  They go through with eight words in registers, half as many classes per thread; one class after the other in the
+// four-word form each of them was a chain of two round trips per four further words, twice (sum, shares), and a tailed cell's
+// first trip took as long as the other four together (round 5, thread 0's clock per level: 35 of a round's 50 us).
+template <int NT, typename IdT, typename Load, typename Pick, typename Add>
+__device__ __forceinline__ void em2_class_pass_runs(const IdT* __restrict__ cw, const uint4* runs, const uint32_t* coff, uint32_t c4, uint32_t K, float scale,
+                                                    Load load, Pick pick, Add add, unsigned long long* tq = nullptr) {
+    LocateByRuns loc(runs, coff);
+    em2_class_pass<NT, kCptS / 2, 8, IdT>(cw, 0u, c4, scale, loc, load, pick, add, tq);
+    em2_class_pass<NT, kCptS, 4, IdT>(cw, c4, K, scale, loc, load, pick, add, tq);
 }
 
 #ifdef AFQ_EM_TIMING
@@ -474,6 +562,7 @@ __global__ __launch_bounds__(NT) void k_em2_rounds(const CellMeta* __restrict__ 
     __shared__ uint32_t s_ws[NT / 64];
     __shared__ uint32_t s_flag[2];
     __shared__ __attribute__((aligned(16))) uint32_t s_mem[LDSW];
+    __shared__ uint4 s_run[MODE == 1 ? 64 : 1];
 #ifdef AFQ_EM_TIMING
     const unsigned long long t_entry = wall_clock64();
 #endif
@@ -484,6 +573,9 @@ __global__ __launch_bounds__(NT) void k_em2_rounds(const CellMeta* __restrict__ 
     const bool usa = cfg.usa != 0;
     const Em2Scratch sc = em2_carve(scratch, em_off[cell], nU, W, M, usa);
     const uint32_t L = sc.hdr[H_L], P = sc.hdr[H_P], K = sc.hdr[H_K], Wc = sc.hdr[H_WC], nPU = sc.hdr[H_NPU], F = sc.hdr[H_FBITS];
+    if constexpr (MODE == 1) {
+        if (tid < sc.hdr[H_NRUN]) { const uint32_t* q = sc.hdr + 16 + 4 * tid; s_run[tid] = make_uint4(q[0], q[1], q[2], q[3]); }
+    }
     const float scale = __uint_as_float((127u + F) << 23), inv_scale = __uint_as_float((127u - F) << 23);
     const uint32_t Z0 = L + P, Z1 = L + P + 1;
     // placement
@@ -515,7 +607,7 @@ __global__ __launch_bounds__(NT) void k_em2_rounds(const CellMeta* __restrict__ 
             r_cnt[j] = 0; r_sib[j] = 0;
             if (e < L) {
                 r_cnt[j] = sc.ent_ucnt[e];
-                if (usa) r_sib[j] = em2_map_sib(sc.ent_s1[e], L, P) | (em2_map_sib(sc.ent_s2[e], L, P) << 16);
+                if (usa) r_sib[j] = sc.ent_s1[e];   // (both links, as indices into v)
                 v[e] = init_of(r_cnt[j]);
                 acc[e] = (unsigned long long)r_cnt[j] << F;
             }
@@ -545,8 +637,14 @@ __global__ __launch_bounds__(NT) void k_em2_rounds(const CellMeta* __restrict__ 
                     if (e < L) ab[e] = (v[r_sib[j] & 0xFFFFu] + v[r_sib[j] >> 16]) + v[e];
                 }
             } else {
-                for (uint32_t e = tid; e < L; e += NT)
-                    ab[e] = (v[em2_map_sib(sc.ent_s1[e], L, P)] + v[em2_map_sib(sc.ent_s2[e], L, P)]) + v[e];
+                for (uint32_t e0 = tid; e0 < L; e0 += 4 * NT) {   // (four entries per thread and trip, their loads unconditional: em2_class_pass)
+                    uint32_t sb[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const uint32_t e = e0 + j * NT; sb[j] = sc.ent_s1[e < L ? e : 0u]; }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const uint32_t e = e0 + j * NT; if (e < L) ab[e] = (v[sb[j] & 0xFFFFu] + v[sb[j] >> 16]) + v[e]; }
+                }
             }
             __syncthreads();
         }
@@ -555,8 +653,8 @@ __global__ __launch_bounds__(NT) void k_em2_rounds(const CellMeta* __restrict__ 
             auto load = [&](uint32_t e) -> float { return ab[e]; };
             auto pick = [](uint32_t, float x) -> float { return x; };
             auto add = [&](uint32_t e, unsigned long long q) { em2_add(&acc[e], q); };
-            if constexpr (MODE == 0) em2_class_pass<NT, 2, uint16_t>(coff16, cw16, K, scale, load, pick, add);
-            else em2_class_pass<NT, 4, uint32_t>(sc.coff, sc.cw, K, scale, load, pick, add);
+            if constexpr (MODE == 0) { LocateByOffsets<uint16_t> loc{coff16, K}; em2_class_pass<NT, 2, 4, uint16_t>(cw16, 0u, K, scale, loc, load, pick, add); }
+            else em2_class_pass_runs<NT, uint16_t>(sc.cw16, s_run, sc.coff, sc.hdr[H_C4], K, scale, load, pick, add);
         }
         EM2T(0);
         __syncthreads();
@@ -576,7 +674,14 @@ __global__ __launch_bounds__(NT) void k_em2_rounds(const CellMeta* __restrict__ 
 #pragma unroll
             for (int j = 0; j < EPT; ++j) { const uint32_t e = tid + j * NT; if (e < L) entry(e, r_cnt[j]); }
         } else {
-            for (uint32_t e = tid; e < L; e += NT) entry(e, sc.ent_ucnt[e]);
+            for (uint32_t e0 = tid; e0 < L; e0 += 4 * NT) {
+                uint32_t uc[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const uint32_t e = e0 + j * NT; uc[j] = sc.ent_ucnt[e < L ? e : 0u]; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const uint32_t e = e0 + j * NT; if (e < L) entry(e, uc[j]); }
+            }
         }
         if (it == 0) {   // an entry outside every label holds its single-label count from the first round on; a status nothing maps to, 0
             for (uint32_t p = tid; p < P; p += NT) v[L + p] = (float)sc.pas_val[p];
@@ -643,6 +748,7 @@ __global__ __launch_bounds__(NT) void k_em2_rounds_hybrid(const uint32_t* __rest
     __shared__ uint32_t s_ws[NT / 64];
     __shared__ uint32_t s_flag[2];
     __shared__ __attribute__((aligned(16))) uint32_t s_mem[kT2Words];
+    __shared__ uint4 s_run[64];
 #ifdef AFQ_EM_TIMING
     const unsigned long long t_entry = wall_clock64();
 #endif
@@ -653,6 +759,10 @@ __global__ __launch_bounds__(NT) void k_em2_rounds_hybrid(const uint32_t* __rest
     const bool usa = cfg.usa != 0;
     const Em2Scratch sc = em2_carve(scratch, em_off[cell], nU, W, M, usa);
     const uint32_t L = sc.hdr[H_L], P = sc.hdr[H_P], K = sc.hdr[H_K], nPU = sc.hdr[H_NPU], F = sc.hdr[H_FBITS], H = sc.hdr[H_NHOT];
+    const uint32_t c4 = sc.hdr[H_C4];
+    const bool narrow = sc.hdr[H_NARROW] != 0;   // 16-bit state ids: label words in cw16, both sibling links of state s in ent_s2[s]
+    const uint32_t* st_cnt = sc.g_pre;           // single-label counts in state order (until the output row takes the array back)
+    if (tid < sc.hdr[H_NRUN]) { const uint32_t* q = sc.hdr + 16 + 4 * tid; s_run[tid] = make_uint4(q[0], q[1], q[2], q[3]); }
     const float scale = __uint_as_float((127u + F) << 23), inv_scale = __uint_as_float((127u - F) << 23);
     const uint32_t Z0 = L + P, Z1 = L + P + 1;
     unsigned long long* acc_h = reinterpret_cast<unsigned long long*>(s_mem);
@@ -682,7 +792,7 @@ __global__ __launch_bounds__(NT) void k_em2_rounds_hybrid(const uint32_t* __rest
     if (tid == 0) { v_g[Z0] = init_of(0u); v_g[Z1] = 0.0f; s_flag[0] = 0; s_flag[1] = 0; }
     em2_gsync();
 #ifdef AFQ_EM_TIMING
-    unsigned long long hph[5] = {0, 0, 0, 0, 0}, hph_t = wall_clock64();
+    unsigned long long hph[5] = {0, 0, 0, 0, 0}, hq[4] = {0, 0, 0, 0}, hph_t = wall_clock64();
     const unsigned long long h_begin = hph_t;
 #define EM2H(i) do { if (tid == 0) { const unsigned long long n_ = wall_clock64(); hph[i] += n_ - hph_t; hph_t = n_; } } while (0)
 #else
@@ -692,8 +802,21 @@ __global__ __launch_bounds__(NT) void k_em2_rounds_hybrid(const uint32_t* __rest
     bool conv = true, last_round = false;
     while (it < kMinIter2 || (it < kMaxIter2 && !conv) || last_round) {
         EM2H(4);
-        if (usa) {
-            for (uint32_t e0 = tid; e0 < L; e0 += 4 * NT) {   // (four entries per thread and trip: their index loads, then their gathers, in flight together)
+        if (usa && narrow) {   // (C) by state id: one word holds both links
+            for (uint32_t s0 = tid; s0 < L; s0 += 4 * NT) {   // (four states per thread and trip: their link loads, then their gathers, in flight together)
+                uint32_t sb[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const uint32_t st = s0 + j * NT; sb[j] = sc.ent_s2[st < L ? st : 0u]; }
+                __builtin_amdgcn_sched_barrier(0);
+                float x[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const uint32_t st = s0 + j * NT; x[j] = (V(sb[j] & 0xFFFFu) + V(sb[j] >> 16)) + V(st < L ? st : 0u); }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const uint32_t st = s0 + j * NT; if (st < L) { if (st < H) ab_h[st] = x[j]; if (st >= H) ab_g[st] = x[j]; } }
+            }
+            em2_gsync();
+        } else if (usa) {   // (ids beyond 16 bits: by entry, through nid)
+            for (uint32_t e0 = tid; e0 < L; e0 += 4 * NT) {
                 uint32_t s2[4], q1[4], q2[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -712,39 +835,43 @@ __global__ __launch_bounds__(NT) void k_em2_rounds_hybrid(const uint32_t* __rest
             em2_gsync();
         }
         EM2H(0);
-        em2_class_pass<NT, 4, uint32_t>(sc.coff, sc.cw, K, scale, ab_load, ab_pick, add);
+#ifdef AFQ_EM_TIMING
+        unsigned long long* const tq = hq;
+#else
+        unsigned long long* const tq = nullptr;
+#endif
+        if (narrow) em2_class_pass_runs<NT, uint16_t>(sc.cw16, s_run, sc.coff, c4, K, scale, ab_load, ab_pick, add, tq);
+        else em2_class_pass_runs<NT, uint32_t>(sc.cw, s_run, sc.coff, c4, K, scale, ab_load, ab_pick, add, tq);
         EM2H(1);
         em2_gsync();
         EM2H(2);
         bool bad = false;
         if (tid == 0) s_flag[(it + 1) & 1u] = 0;
-        for (uint32_t e0 = tid; e0 < L; e0 += 4 * NT) {
-            uint32_t s2[4], uc[4];
+        for (uint32_t s0 = tid; s0 < L; s0 += 4 * NT) {   // (E) by state id
+            uint32_t uc[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t e = e0 + j * NT, ee = e < L ? e : 0u;
-                const uint32_t t0 = sc.nid[ee], t1 = sc.ent_ucnt[ee];
-                s2[j] = e < L ? t0 : 0u; uc[j] = e < L ? t1 : 0u;
-            }
+            for (int j = 0; j < 4; ++j) { const uint32_t st = s0 + j * NT; uc[j] = st_cnt[st < L ? st : 0u]; }
             unsigned long long a[4];
             float old[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const bool ok = e0 + j * NT < L, hot = s2[j] < H;
+                const uint32_t st = s0 + j * NT;
+                const bool ok = st < L, hot = st < H;
                 const unsigned long long fresh = (unsigned long long)uc[j] << F;
-                const unsigned long long ah = acc_h[hot ? s2[j] : 0u];
-                old[j] = V(s2[j]);
-                if (ok && hot) acc_h[s2[j]] = fresh;
+                const unsigned long long ah = acc_h[hot ? st : 0u];
+                old[j] = V(ok ? st : 0u);
+                if (ok && hot) acc_h[st] = fresh;
                 unsigned long long ag = 0;
-                if (ok && !hot) ag = __hip_atomic_exchange(&acc_g[s2[j]], fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (ok && !hot) ag = __hip_atomic_exchange(&acc_g[st], fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 a[j] = hot ? ah : ag;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (e0 + j * NT >= L) continue;
+                const uint32_t st = s0 + j * NT;
+                if (st >= L) continue;
                 const float x = (float)a[j] * inv_scale;
                 if (x > kAlphaCheckCutoff2 && fabsf(old[j] - x) > kRelDiffTol2) bad = true;
-                setV(s2[j], x);
+                setV(st, x);
             }
         }
         if (it == 0) {
@@ -759,7 +886,7 @@ __global__ __launch_bounds__(NT) void k_em2_rounds_hybrid(const uint32_t* __rest
         if (usa) {
             if (last_round) break;
             if (it >= kMinIter2 && conv) {
-                for (uint32_t e = tid; e < L; e += NT) { const uint32_t s2 = sc.nid[e]; if (V(s2) < kMinOutputAlpha2) setV(s2, 0.0f); }
+                for (uint32_t st = tid; st < L; st += NT) if (V(st) < kMinOutputAlpha2) setV(st, 0.0f);
                 last_round = true;
                 em2_gsync();
             }
@@ -787,6 +914,7 @@ __global__ __launch_bounds__(NT) void k_em2_rounds_hybrid(const uint32_t* __rest
     if (tid == 0) {
         const uint32_t at = atomicAdd(&g_em2_dbg_n, 1u);
         if (at < 32768) { g_em2_dbg[at][0] = ((unsigned long long)tier << 56) | blockIdx.x; g_em2_dbg[at][1] = t_entry; g_em2_dbg[at][2] = t_entry; g_em2_dbg[at][3] = wall_clock64(); }
+        if ((blockIdx.x % 100) == 3) printf("em2 hybrid class pass, thread 0: locate=%.1f words=%.1f gathers=%.1f sums+shares=%.1f us\n", (double)hq[0] / 100.0, (double)hq[1] / 100.0, (double)hq[2] / 100.0, (double)hq[3] / 100.0);
         if ((blockIdx.x % 100) == 3) printf("em2 hybrid L=%u H=%u P=%u K=%u Wc=%u it=%u: C=%.1f classes(thread 0)=%.1f wait=%.1f entries=%.1f other=%.1f rounds=%.1f total=%.1f us\n", L, H, P, K, sc.hdr[H_WC], it,
                                             (double)hph[0] / 100.0, (double)hph[1] / 100.0, (double)hph[2] / 100.0, (double)hph[3] / 100.0, (double)hph[4] / 100.0,
                                             (double)(wall_clock64() - h_begin) / 100.0, (double)(wall_clock64() - t_entry) / 100.0);
@@ -824,7 +952,7 @@ void launch_em2(hipStream_t s, const ResolveArgs& a, uint32_t n_cells, uint64_t*
     if (!n_cells) return;
     uint32_t min_tier = 0;
     if (const char* e = test_hook("EM2_MIN_TIER")) min_tier = (uint32_t)std::min(4, std::max(0, std::atoi(e)));   // (tests; read per range)
-    Em2Cfg cfg{a.usa, num_alphas, a.num_rows / 3, 2 * (a.num_rows / 3), init_uniform, (num_alphas + 31) / 32, min_tier};
+    Em2Cfg cfg{a.usa, num_alphas, a.num_rows / 3, 2 * (a.num_rows / 3), init_uniform, (num_alphas + 31) / 32, min_tier, test_hook_is("EM2_WIDE_IDS", "1") ? 1u : 0u};
     if (!plan_cap_words) (void)hipMemsetAsync(tiers, 0, 32, s);   // (with a device-side plan the range's init kernel has cleared the counters)
     if (plan_cap_words) hipLaunchKernelGGL(k_em2_plan, dim3(1), dim3(1024), 0, s, a.nnz, a.lab_cnt, n_cells, a.usa, (unsigned long long)plan_cap_words, em_off, tiers, a.st);
     hipLaunchKernelGGL(k_em2_setup, dim3(n_cells), dim3(kSetupNT), 8 * cfg.nwb, s, a.meta, a.nnz, a.keys0, a.keys1, a.lab, a.lab_cnt, em_off,

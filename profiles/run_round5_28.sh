@@ -1,0 +1,10 @@
+#!/bin/bash
+# round 5, call 28: the label lengths of a tailed cell's EM classes (timing build prints one cell's runs)
+cd "$GRAFT_REPO_ROOT" || exit 1
+python -c "import torch" 2>/dev/null
+O=$GRAFT_REPO_ROOT/gpurun_out/round5_28; mkdir -p $O
+L=$GRAFT_REPO_ROOT/alevin-fry_amd/csrc
+for m in plain tail; do
+  env AFQ_LIB_PATH=$L/libafquant_timing.so timeout 300 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --also none --workload configs2 --na-model $m 2>&1 | grep "^em2 run" > $O/runs_$m.txt
+  echo $m; head -70 $O/runs_$m.txt | tr '\n' ';'
+done

@@ -1,0 +1,23 @@
+#!/bin/bash
+# round 5, call 29: the EM's once-per-round lists loaded non-temporally (so that they do not evict the cold entries' state from L2) against plain loads
+cd "$GRAFT_REPO_ROOT" || exit 1
+python -c "import torch" 2>/dev/null
+O=$GRAFT_REPO_ROOT/gpurun_out/round5_29; mkdir -p $O
+L=$GRAFT_REPO_ROOT/alevin-fry_amd/csrc
+one() {  # name, lib, then bench flags
+  local N=$1 LIB=$2; shift 2
+  env AFQ_LIB_PATH=$LIB timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --also none "$@" > $O/$N.json 2> $O/$N.err
+  python - "$N" "$O/$N.json" <<'P'
+import json, sys
+try:
+    d = json.load(open(sys.argv[2]))
+    k = d["roofline"]["all_kernels_ms_per_step"]
+    print(sys.argv[1], d["ms_per_step"], {a: round(b, 2) for a, b in k.items() if a in ("k_em",)})
+except Exception as e:
+    print(sys.argv[1], "FAILED", e)
+P
+}
+for v in "" _nont; do
+  one c2$v $L/libafquant$v.so --workload configs2
+  one c2t$v $L/libafquant$v.so --workload configs2 --na-model tail
+done

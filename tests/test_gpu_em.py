@@ -77,12 +77,16 @@ def test_em_init_uniform(oracle_module, init_uniform):
     assert_same_result(_device(cfg, s, b, off), oracle_module.quant(cfg, s.tid_to_gid, b, off, em_arith="fixed"))
 
 
-@pytest.mark.parametrize("tier", [1, 2, 3, 4])
+@pytest.mark.parametrize("tier", [1, 2, 3, 4, "4-wide-ids"])
 @pytest.mark.parametrize("usa", [False, True])
 def test_every_instance_of_the_rounds_kernel_agrees(oracle_module, monkeypatch, tier, usa):
-    """The rounds kernel has five instances by cell size (all in LDS at 256 / 512 / 1024 threads, lists streamed, everything in
-    global memory); AFQ_TEST_EM2_MIN_TIER sends every cell to the given one or a larger one: the sums are integers, the rows
-    must not move by a bit."""
+    """The rounds kernel has five instances by cell size (all in LDS at 256 / 512 / 1024 threads, lists streamed, hot entries in
+    LDS and the rest in global memory); AFQ_TEST_EM2_MIN_TIER sends every cell to the given one or a larger one: the sums are
+    integers, the rows must not move by a bit.  The streamed instances read 16-bit state ids (label words, both sibling links
+    in one word) unless a cell has more than 65 534 of them; AFQ_TEST_EM2_WIDE_IDS takes small cells down that 32-bit route."""
+    if tier == "4-wide-ids":
+        monkeypatch.setenv("AFQ_TEST_EM2_WIDE_IDS", "1")
+        tier = 4
     monkeypatch.setenv("AFQ_TEST_EM2_MIN_TIER", str(tier))
     s, b, off = _workload(usa, seed=9)
     cfg = cfg_for(s, "parsimony-em")
@@ -97,6 +101,18 @@ def test_em_long_labels_and_many_classes(oracle_module):
     got = _device(cfg, s, b, off)
     assert_same_result(got, oracle_module.quant(cfg, s.tid_to_gid, b, off, em_arith="fixed", n_threads=4))
     assert_within_tolerance(got, oracle_module.quant(cfg, s.tid_to_gid, b, off, em_arith="reference", n_threads=4))
+
+
+@pytest.mark.parametrize("tier", [0, 3, 4])
+def test_em_labels_of_more_than_63_genes(oracle_module, monkeypatch, tier):
+    """The streamed instances find a class's words from the runs of equal-length classes; labels of 63 words and more share one
+    run whose offsets come from the offset table instead.  Reads with up to 90 further alignments: labels of every length from
+    2 to beyond 63 in one cell, through the all-in-LDS instance and both streamed ones."""
+    monkeypatch.setenv("AFQ_TEST_EM2_MIN_TIER", str(tier))
+    s, b, off = _workload(False, seed=13, sizes=[20000, 3000, 150], num_genes=2000, cross=0.8, max_extra_na=90, dup=0.3)
+    cfg = cfg_for(s, "cr-like-em")
+    want = oracle_module.quant(cfg, s.tid_to_gid, b, off, em_arith="fixed", n_threads=4)
+    assert_same_result(_device(cfg, s, b, off), want, what=f"tier {tier}")
 
 
 def test_em_scratch_short_of_the_plan_is_sized_on_the_host(oracle_module, monkeypatch):
