@@ -454,7 +454,7 @@ struct LocateByRuns {
     __device__ __forceinline__ void operator()(uint32_t c, bool ok, uint32_t& o0, uint32_t& n) {
         o0 = 0; n = 0;
         if (!ok) return;
-        while (c >= run.w) run = runs[++ri];
+        while (c >= run.w && ri < 63u) run = runs[++ri];   // (bounded: a list that does not cover c must not hang the kernel)
         o0 = run.y + (c - run.x) * run.z; n = run.z;
         if (run.z == 0) { o0 = coff[c]; n = coff[c + 1] - o0; }
     }
