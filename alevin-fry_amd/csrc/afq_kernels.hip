@@ -534,17 +534,27 @@ __device__ __forceinline__ uint32_t col_from_pairs(uint32_t p0, uint32_t p1, uin
 // gene" means for ascending ids 2g, 2g+1.
 constexpr uint32_t kHtOvf = 64;
 constexpr uint32_t kHtMerge = 8;   // genes of one UMI the in-register merge holds (more: the bucket takes the sort path)
-template <typename ForEach>
-__device__ __forceinline__ uint32_t col_from_candidates(ForEach&& for_each, const ResolveCfg& rc) {
+// (gene, reads) candidates in registers, a count of 0 = no candidate.  Plain unrolled loops over the two arrays: as a callback
+// that walked them (a lambda handed a lambda) the aggregates below were captured by reference twice over, stayed in memory -
+// scratch - and every candidate was a store and two loads away from the next (round 5: 108 of the kernel's scratch instructions).
+template <int N>
+__device__ __forceinline__ uint32_t col_from_candidates(const uint32_t (&cg)[N], const uint32_t (&cc)[N], const ResolveCfg& rc) {
     uint32_t maxc = 0;
-    for_each([&](uint32_t, uint32_t c) { maxc = c > maxc ? c : maxc; });
+#pragma unroll
+    for (int q = 0; q < N; ++q) maxc = cc[q] > maxc ? cc[q] : maxc;
     uint32_t nb = 0, g1 = kNoCol, g2 = kNoCol, nsp = 0, first_sp = kNoCol;
-    for_each([&](uint32_t g, uint32_t c) {
-        if (c != maxc) return;
-        ++nb;
-        if (g < g1) { g2 = g1; g1 = g; } else if (g < g2) g2 = g;
-        if (is_spliced(g)) { ++nsp; first_sp = g < first_sp ? g : first_sp; }
-    });
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        const uint32_t g = cg[q];
+        const bool w = cc[q] != 0 && cc[q] == maxc;
+        nb += w;
+        const bool lt1 = w && g < g1, lt2 = w && !lt1 && g < g2;
+        g2 = lt1 ? g1 : (lt2 ? g : g2);
+        g1 = lt1 ? g : g1;
+        const bool sp = w && is_spliced(g);
+        nsp += sp;
+        first_sp = sp && g < first_sp ? g : first_sp;
+    }
     if (!rc.usa) return nb == 1 ? g1 : kNoCol;
     if (nb == 1) return is_spliced(g1) ? (g1 >> 1) : rc.uo + (g1 >> 1);
     if (nb == 2) {
@@ -555,7 +565,8 @@ __device__ __forceinline__ uint32_t col_from_candidates(ForEach&& for_each, cons
     }
     if (nb > 10 || nsp != 1) return kNoCol;
     bool followed = false;
-    for_each([&](uint32_t g, uint32_t c) { if (c == maxc && g == first_sp + 1) followed = true; });
+#pragma unroll
+    for (int q = 0; q < N; ++q) followed = followed || (cc[q] != 0 && cc[q] == maxc && cg[q] == first_sp + 1);
     return followed ? rc.ao + (first_sp >> 1) : (first_sp >> 1);
 }
 
@@ -709,10 +720,7 @@ __device__ __forceinline__ bool resolve_bucket_hash(const uint64_t* __restrict__
                     }
                 }
                 if (!em) {
-                    col = col_from_candidates([&](auto&& f) {
-#pragma unroll
-                        for (uint32_t q = 0; q < kHtMerge; ++q) if (cc[q]) f(cg[q], cc[q]);
-                    }, rc);
+                    col = col_from_candidates(cg, cc, rc);
                 } else if (!bad) {
                     uint32_t maxc = 0, nb = 0, g1 = kNoCol, g2 = kNoCol;
 #pragma unroll

@@ -1588,20 +1588,12 @@ __global__ __launch_bounds__(CNT, CNT == 256 ? 4 : 1) void k_p2_cover(P2Args A, 
                 for (uint32_t q = 0; q < kStageRefs; ++q) t1[q] = q < l.n ? l.p[q] & 0x7FFFFFFFu : 0xFFFFFFFFu;          // the first label's refs, together
 #pragma unroll
                 for (uint32_t q = 0; q < kStageRefs; ++q) t1[q] = t1[q] != 0xFFFFFFFFu && in_l2(t1[q]) ? C.t2g[t1[q]] : 0xFFFFFFFFu;   // the shared ones' genes, together
-                uint32_t g[kMaxGenesPerLabel];
-                uint32_t ng = 0;
+                // (sorted and distinct in the lane's row of the stage - the second label's refs there have been looked at - not in an
+                //  array of the lane's own, which would live in scratch memory)
 #pragma unroll
-                for (uint32_t q = 0; q < kStageRefs; ++q) {
-                    const uint32_t gid = t1[q];
-                    if (gid == 0xFFFFFFFFu) continue;
-                    uint32_t qq = 0;
-                    while (qq < ng && g[qq] < gid) ++qq;
-                    if (qq < ng && g[qq] == gid) continue;
-                    for (uint32_t r = ng; r > qq; --r) g[r] = g[r - 1];
-                    g[qq] = gid;
-                    ++ng;
-                }
-                emit_molecule(C, g, ng);
+                for (uint32_t q = 0; q < kStageRefs; ++q) row[q] = t1[q];
+                const uint32_t ng = sort_unique_in_row(row, kStageRefs);
+                emit_molecule(C, row, ng);
             } else {
                 uint32_t g[kMaxGenesPerLabel];
                 uint32_t ng = 0;

@@ -126,6 +126,23 @@ __device__ __forceinline__ uint32_t molecule_column_n(const PugCtx& c, const uin
     if (col >= c.num_rows) { c.s_cnt[3] = kErrSlotRange; return 0xFFFFFFFFu; }
     return col;
 }
+// The gene ids in row[0 .. n) (0xFFFFFFFF: none) -> sorted, distinct, in front; returns how many.  In place, by insertion: the
+// sorted prefix is never longer than the part already read.  `row` is a lane's row of the wave's LDS stage: the same walk over
+// an array of the lane's own (`g[]` above) runs in scratch memory, a round trip to the cache per step.
+__device__ __forceinline__ uint32_t sort_unique_in_row(uint32_t* row, uint32_t n) {
+    uint32_t ns = 0;
+    for (uint32_t j = 0; j < n; ++j) {
+        const uint32_t gid = row[j];
+        if (gid == 0xFFFFFFFFu) continue;
+        uint32_t q = 0;
+        while (q < ns && row[q] < gid) ++q;
+        if (q < ns && row[q] == gid) continue;
+        for (uint32_t r = ns; r > q; --r) row[r] = row[r - 1];
+        row[q] = gid;
+        ++ns;
+    }
+    return ns;
+}
 __device__ __forceinline__ void emit_molecule(const PugCtx& c, const uint32_t* g, uint32_t ng) {
     const uint32_t col = molecule_column_n(c, g, ng);
     if (col == 0xFFFFFFFFu) return;
@@ -417,10 +434,10 @@ __device__ __forceinline__ void cover_tiny8(const PugCtx& C, const uint4* mrec, 
                 const uint32_t fv = best ? (uint32_t)__builtin_ctz(best) : 0u;
                 const uint32_t lfn_all = (uint32_t)__shfl((int)myl.n, (int)(gbase + fv));
                 const uint32_t lfn = best ? lfn_all : 0u;
-                uint32_t g[kMaxGenesPerLabel];   // (only for labels over four refs: the array lives in scratch memory)
+                uint32_t g[kMaxGenesPerLabel];   // (only for unstaged labels over four refs: the array lives in scratch memory)
                 uint32_t ng = 0, k4 = 0;
                 uint32_t c4[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-                bool wide = false;
+                bool wide = false, in_row = false;
                 const bool small = lfn <= 4;
                 // (a staged first label: the refs every vertex holds are only MARKED in the loop - cm - and their genes looked up by the
                 //  group's lanes together afterwards; one lane looking them up inside the loop made one dependent load per ref)
@@ -455,20 +472,13 @@ __device__ __forceinline__ void cover_tiny8(const PugCtx& C, const uint4* mrec, 
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     if (fstaged) { row[gl] = ga; row[gl + 8] = gb2; }   // (the first vertex is covered from this round on: its row is free)
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    if (fstaged && gl == 0) {
-                        for (uint32_t j = 0; j < lfn; ++j) {
-                            const uint32_t gid = row[j];
-                            if (gid == 0xFFFFFFFFu) continue;
-                            uint32_t q = 0;
-                            while (q < ng && g[q] < gid) ++q;
-                            if (!(q < ng && g[q] == gid)) { for (uint32_t r = ng; r > q; --r) g[r] = g[r - 1]; g[q] = gid; ++ng; }   // (at most kStageRefs genes)
-                        }
-                    }
+                    if (fstaged && gl == 0) { ng = sort_unique_in_row(row, lfn); in_row = true; }
                 }
                 uint32_t col = 0xFFFFFFFFu;
                 bool cls = false;
                 if (best && gl == 0) {
                     if (small) { const uint32_t n4 = genes_of4(C, c4, k4); col = molecule4_column(C, c4, n4, cls); }
+                    else if (in_row) col = molecule_column_n(C, stage + (gbase + fv) * kStageRefs, ng);
                     else if (wide && C.em) emit_wide_from_records(C, mrec, b0, fv, best);
                     else emit_molecule(C, g, wide ? 0xFFFFFFFFu : ng);
                 }
@@ -578,7 +588,7 @@ __device__ __forceinline__ void cover_wave64(const PugCtx& C, const uint4* mrec,
             // transcripts common to every vertex of the arborescence (pugutils.rs:1161-1188) -> genes
             const uint32_t fv = (uint32_t)__builtin_ctzll(best);
             const uint32_t lfn = lane_lab_n(fv);
-            uint32_t g[kMaxGenesPerLabel];   // (only for labels over four refs: the array lives in scratch memory)
+            uint32_t g[kMaxGenesPerLabel];   // (only for unstaged labels over four refs: the array lives in scratch memory)
             uint32_t ng = 0, k4 = 0;
             uint32_t c4[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
             bool wide = false;
@@ -613,21 +623,14 @@ __device__ __forceinline__ void cover_wave64(const PugCtx& C, const uint4* mrec,
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 if (lane < kStageRefs) row[lane] = ga;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (lane == 0) {
-                    for (uint32_t j = 0; j < lfn; ++j) {
-                        const uint32_t gid = row[j];
-                        if (gid == 0xFFFFFFFFu) continue;
-                        uint32_t q = 0;
-                        while (q < ng && g[q] < gid) ++q;
-                        if (!(q < ng && g[q] == gid)) { for (uint32_t r = ng; r > q; --r) g[r] = g[r - 1]; g[q] = gid; ++ng; }
-                    }
-                }
+                if (lane == 0) ng = sort_unique_in_row(row, lfn);
             }
             {
                 uint32_t col = 0xFFFFFFFFu;
                 bool cls = false;
                 if (lane == 0) {
                     if (small) { const uint32_t n4 = genes_of4(C, c4, k4); col = molecule4_column(C, c4, n4, cls); }
+                    else if (fstaged) col = molecule_column_n(C, stage + fv * kStageRefs, ng);
                     else if (wide && C.em) emit_wide_from_records(C, mrec, cb0, fv, best);
                     else emit_molecule(C, g, wide ? 0xFFFFFFFFu : ng);
                 }
