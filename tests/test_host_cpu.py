@@ -407,7 +407,7 @@ static inline bool is_spliced(uint32_t g) { return (g & 1u) == 0; }
 static inline bool same_gene(uint32_t a, uint32_t b) { return (a & ~1u) == (b & ~1u); }
 constexpr uint32_t kNoCol = 0xFFFFFFFFu;
 ''' + grab("__device__ __forceinline__ uint32_t col_from_pairs(", "// A UMI seen with more than kHtPairs genes parks") + \
-        grab("template <typename ForEach>\n__device__ __forceinline__ uint32_t col_from_candidates(", "// cr-like-em: a UMI whose winners are one output column") + r'''
+        grab("template <int N>\n__device__ __forceinline__ uint32_t col_from_candidates(", "// cr-like-em: a UMI whose winners are one output column") + r'''
 int main() {
     unsigned usa, k;
     while (scanf("%u %u", &usa, &k) == 2) {
@@ -420,7 +420,10 @@ int main() {
             for (unsigned i = 0; i < k; ++i) p[(i + g[0]) % 3] = (g[i] << 12) | c[i];   // the counters in any slot order
             a = col_from_pairs(p[0], p[1], p[2], rc);
         }
-        const uint32_t b = col_from_candidates([&](auto&& f) { for (unsigned i = 0; i < k; ++i) f(g[k - 1 - i], c[k - 1 - i]); }, rc);
+        uint32_t cg[8], cc[8];   // (the merge's register arrays: candidates in any order, a count of 0 = no candidate)
+        for (unsigned i = 0; i < 8; ++i) { cg[i] = kNoCol; cc[i] = 0; }
+        for (unsigned i = 0; i < k; ++i) { cg[(3 * i + 1) % 8] = g[k - 1 - i]; cc[(3 * i + 1) % 8] = c[k - 1 - i]; }
+        const uint32_t b = col_from_candidates(cg, cc, rc);
         printf("%u %u\n", a, b);
     }
     return 0;
