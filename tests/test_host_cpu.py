@@ -525,3 +525,125 @@ int main() {
         assert a == want[key], ("molecule_column_n", key, a, want[key])
         if len(key[1]) <= 4:
             assert b == want[key], ("molecule4_column", key, b, want[key])
+
+
+def test_em_class_lookup_by_runs_is_the_offset_table_on_host(tmp_path):
+    """csrc/afq_em2.hip: the streamed EM instances do not read a class's offset from the offset table every round - the set-up
+    lays the classes out longest label first, equal lengths in one run, and `LocateByRuns` computes (first word, length) of
+    class c from the run list with a cursor (labels of 63 words and more share a run that keeps its offsets).  The struct's own
+    source text, compiled for the host, against the offset table on random label-length mixes: every class, walked the way the
+    kernel's threads walk them (ascending, strides of 1024 and 2048 from any start), and past the end.  No GPU."""
+    import shutil
+    import subprocess
+
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    src = open(os.path.join(ROOT, "alevin-fry_amd", "csrc", "afq_em2.hip")).read()
+    a = src.index("struct LocateByRuns {")
+    struct_text = src[a:src.index("};", a) + 2]
+    host = r'''#include <cstdint>
+#include <cstdio>
+#include <vector>
+#define __device__
+#define __forceinline__ inline
+struct uint4 { uint32_t x, y, z, w; };
+''' + struct_text + r'''
+int main() {
+    unsigned n_runs, K;
+    if (scanf("%u %u", &n_runs, &K) != 2) return 2;
+    std::vector<uint4> runs(64, uint4{0xFFFFFFFFu, 0, 0, 0xFFFFFFFFu});   // (what the kernel's LDS holds behind the list is not read: c < K)
+    for (unsigned r = 0; r < n_runs; ++r) if (scanf("%u %u %u %u", &runs[r].x, &runs[r].y, &runs[r].z, &runs[r].w) != 4) return 2;
+    std::vector<uint32_t> coff(K + 1);
+    for (unsigned c = 0; c <= K; ++c) if (scanf("%u", &coff[c]) != 1) return 2;
+    unsigned long long bad = 0, seen = 0;
+    for (unsigned stride : {1024u, 2048u, 1u})
+        for (unsigned start = 0; start < stride && start < K; start += (stride == 1u ? 1u : 37u)) {
+            LocateByRuns loc(runs.data(), coff.data());
+            for (unsigned c = start; c < K + 3 * stride; c += stride) {
+                uint32_t o0 = 123, n = 456;
+                loc(c, c < K, o0, n);
+                if (c < K) { ++seen; if (o0 != coff[c] || n != coff[c + 1] - coff[c]) ++bad; }
+                else if (o0 != 0 || n != 0) ++bad;
+            }
+        }
+    printf("%llu %llu\n", seen, bad);
+    return 0;
+}
+'''
+    (tmp_path / "t.cpp").write_text(host)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", str(tmp_path / "t"), str(tmp_path / "t.cpp")], check=True, capture_output=True)
+    rng = np.random.default_rng(5)
+    for case in range(6):
+        # label lengths: mostly 2..6, a tail to 62, sometimes a few of 63 and more (one run, lengths as they come)
+        n_cls = int(rng.integers(1, 9000))
+        lens = np.minimum(2 + rng.geometric(0.45, n_cls) - 1, 62)
+        if case % 2:
+            lens[rng.integers(0, n_cls, 5)] = rng.integers(63, 200, 5)
+        if case == 4:
+            lens[:] = 3   # one run
+        hist = np.bincount(np.minimum(lens, 63), minlength=64)
+        # the set-up's layout (k_em2_setup step 1): runs from the longest labels down; the 63+ run first, its offsets ascending
+        order = np.argsort(-np.minimum(lens, 63), kind="stable")
+        sl = lens[order]
+        coff = np.concatenate(([0], np.cumsum(sl))).astype(np.uint32)
+        runs, cpos, wpos = [], 0, 0
+        for b in range(63, -1, -1):
+            if hist[b]:
+                runs.append((cpos, wpos, 0 if b == 63 else b, cpos + int(hist[b])))
+            wpos += int(sl[cpos:cpos + hist[b]].sum())
+            cpos += int(hist[b])
+        text = f"{len(runs)} {n_cls}\n" + "\n".join(" ".join(map(str, r)) for r in runs) + "\n" + " ".join(map(str, coff)) + "\n"
+        r = subprocess.run([str(tmp_path / "t")], input=text, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        seen, bad = map(int, r.stdout.split())
+        assert seen >= n_cls and bad == 0, (case, n_cls, seen, bad)
+
+
+def test_sort_unique_in_row_on_host(tmp_path):
+    """csrc/afq_pug_common.h: the covers sort a staged label's gene ids where they lie - in place in a lane's LDS row, by insertion,
+    the sorted prefix never longer than the part already read.  The function's own source text on the host: every row of up to
+    16 slots over a small alphabet with holes (0xFFFFFFFF), against sorted(set()).  No GPU."""
+    import shutil
+    import subprocess
+
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    src = open(os.path.join(ROOT, "alevin-fry_amd", "csrc", "afq_pug_common.h")).read()
+    a = src.index("__device__ __forceinline__ uint32_t sort_unique_in_row(")
+    fn = src[a:src.index("\n}\n", a) + 3]
+    host = r'''#include <cstdint>
+#include <cstdio>
+#define __device__
+#define __forceinline__ inline
+''' + fn + r'''
+int main() {
+    unsigned n;
+    while (scanf("%u", &n) == 1) {
+        uint32_t row[16];
+        for (unsigned i = 0; i < 16; ++i) row[i] = 0xDEADBEEFu;
+        for (unsigned i = 0; i < n; ++i) if (scanf("%u", &row[i]) != 1) return 2;
+        const uint32_t k = sort_unique_in_row(row, n);
+        printf("%u", k);
+        for (unsigned i = 0; i < k; ++i) printf(" %u", row[i]);
+        printf("\n");
+    }
+    return 0;
+}
+'''
+    (tmp_path / "t.cpp").write_text(host)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", str(tmp_path / "t"), str(tmp_path / "t.cpp")], check=True, capture_output=True)
+    rng = np.random.default_rng(6)
+    rows = []
+    for _ in range(4000):
+        n = int(rng.integers(0, 17))
+        v = rng.integers(0, 9, n).astype(np.uint64) * 1000 + 7
+        v[rng.random(n) < 0.3] = 0xFFFFFFFF
+        rows.append([int(x) for x in v])
+    text = "".join(f"{len(r)} " + " ".join(map(str, r)) + "\n" for r in rows)
+    out = subprocess.run([str(tmp_path / "t")], input=text, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    got = [[int(x) for x in ln.split()] for ln in out.stdout.splitlines()]
+    assert len(got) == len(rows)
+    for r, g in zip(rows, got):
+        want = sorted(set(x for x in r if x != 0xFFFFFFFF))
+        assert g[0] == len(want) and g[1:] == want, (r, g, want)
