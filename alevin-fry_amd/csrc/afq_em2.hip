@@ -49,6 +49,9 @@ constexpr uint32_t kSibNone = 0xFFFFFFFFu;   // no such sibling status: adds +0.
 constexpr uint32_t kSibZero = 0xFFFFFFFEu;   // a sibling status nothing maps to: the start value in round 1, 0 afterwards
 constexpr uint32_t kSibPassive = 0x80000000u;   // | index into pas_val
 constexpr int kSetupNT = 256;
+#ifndef AFQ_EM2_PAIRS_PASS
+#define AFQ_EM2_PAIRS_PASS 1
+#endif
 #ifndef AFQ_EM2_CPT_STREAM
 #define AFQ_EM2_CPT_STREAM 4
 #endif
@@ -100,7 +103,7 @@ __host__ __device__ inline uint64_t em2_words(uint32_t nU, uint32_t W, uint32_t 
 uint64_t em2_scratch_words(uint32_t nU, uint32_t W, uint32_t M, bool usa) { return em2_words(nU, W, M, usa); }
 
 // header words
-enum { H_L = 0, H_P, H_K, H_WC, H_NPU, H_FBITS, H_TIER, H_NHOT, H_NRUN, H_NARROW, H_C4 };
+enum { H_L = 0, H_P, H_K, H_WC, H_NPU, H_FBITS, H_TIER, H_NHOT, H_NRUN, H_NARROW, H_C4, H_C2 };
 constexpr uint32_t kTierNone = 7;   // no multi-label class: the row is the single-label counts (em.rs:339-341, 499-514)
 // LDS words of the three all-in-LDS instances (4 x 38 KiB, 2 x 78 KiB, 157 KiB: next to the few static words they fit a CU's 160 KiB)
 constexpr uint32_t kT0Words = 9728, kT1Words = 19968, kT2Words = 40192;
@@ -213,6 +216,7 @@ __global__ __launch_bounds__(kSetupNT) void k_em2_setup(const CellMeta* __restri
             }
         sc.hdr[H_NRUN] = r;
         sc.hdr[H_C4] = s_len_cbase[4];   // classes before this one have labels of more than four words
+        sc.hdr[H_C2] = s_len_cbase[2];   // ... of more than two
     }
     __syncthreads();
     const uint32_t Wc = s_long_words;
@@ -536,12 +540,20 @@ __device__ __forceinline__ void em2_class_pass(const IdT* __restrict__ cw, uint3
 // classes.  They go through with eight words in registers, half as many classes per thread; one class after the other in the
 // four-word form each of them was a chain of two round trips per four further words, twice (sum, shares), and a tailed cell's
 // first trip took as long as the other four together (round 5, thread 0's clock per level: 35 of a round's 50 us).
+// ... and the labels of one or two words - most classes: two in three on the tailed model, five in six on the plain one - the last
+// K - c2: with two words in registers, eight classes per thread (in the four-word form half of their loads and gathers were
+// issued for nothing; the pass is bound by instruction issue).
 template <int NT, typename IdT, typename Load, typename Pick, typename Add>
-__device__ __forceinline__ void em2_class_pass_runs(const IdT* __restrict__ cw, const uint4* runs, const uint32_t* coff, uint32_t c4, uint32_t K, float scale,
-                                                    Load load, Pick pick, Add add, unsigned long long* tq = nullptr) {
+__device__ __forceinline__ void em2_class_pass_runs(const IdT* __restrict__ cw, const uint4* runs, const uint32_t* coff, uint32_t c4, uint32_t c2, uint32_t K,
+                                                    float scale, Load load, Pick pick, Add add, unsigned long long* tq = nullptr) {
     LocateByRuns loc(runs, coff);
     em2_class_pass<NT, kCptS / 2, 8, IdT>(cw, 0u, c4, scale, loc, load, pick, add, tq);
-    em2_class_pass<NT, kCptS, 4, IdT>(cw, c4, K, scale, loc, load, pick, add, tq);
+    em2_class_pass<NT, kCptS, 4, IdT>(cw, c4, c2, scale, loc, load, pick, add, tq);
+#if AFQ_EM2_PAIRS_PASS
+    em2_class_pass<NT, 2 * kCptS, 2, IdT>(cw, c2, K, scale, loc, load, pick, add, tq);
+#else
+    em2_class_pass<NT, kCptS, 4, IdT>(cw, c2, K, scale, loc, load, pick, add, tq);
+#endif
 }
 
 #ifdef AFQ_EM_TIMING
@@ -654,7 +666,7 @@ __global__ __launch_bounds__(NT) void k_em2_rounds(const CellMeta* __restrict__ 
             auto pick = [](uint32_t, float x) -> float { return x; };
             auto add = [&](uint32_t e, unsigned long long q) { em2_add(&acc[e], q); };
             if constexpr (MODE == 0) { LocateByOffsets<uint16_t> loc{coff16, K}; em2_class_pass<NT, 2, 4, uint16_t>(cw16, 0u, K, scale, loc, load, pick, add); }
-            else em2_class_pass_runs<NT, uint16_t>(sc.cw16, s_run, sc.coff, sc.hdr[H_C4], K, scale, load, pick, add);
+            else em2_class_pass_runs<NT, uint16_t>(sc.cw16, s_run, sc.coff, sc.hdr[H_C4], sc.hdr[H_C2], K, scale, load, pick, add);
         }
         EM2T(0);
         __syncthreads();
@@ -759,7 +771,7 @@ __global__ __launch_bounds__(NT) void k_em2_rounds_hybrid(const uint32_t* __rest
     const bool usa = cfg.usa != 0;
     const Em2Scratch sc = em2_carve(scratch, em_off[cell], nU, W, M, usa);
     const uint32_t L = sc.hdr[H_L], P = sc.hdr[H_P], K = sc.hdr[H_K], nPU = sc.hdr[H_NPU], F = sc.hdr[H_FBITS], H = sc.hdr[H_NHOT];
-    const uint32_t c4 = sc.hdr[H_C4];
+    const uint32_t c4 = sc.hdr[H_C4], c2 = sc.hdr[H_C2];
     const bool narrow = sc.hdr[H_NARROW] != 0;   // 16-bit state ids: label words in cw16, both sibling links of state s in ent_s2[s]
     const uint32_t* st_cnt = sc.g_pre;           // single-label counts in state order (until the output row takes the array back)
     if (tid < sc.hdr[H_NRUN]) { const uint32_t* q = sc.hdr + 16 + 4 * tid; s_run[tid] = make_uint4(q[0], q[1], q[2], q[3]); }
@@ -840,8 +852,8 @@ __global__ __launch_bounds__(NT) void k_em2_rounds_hybrid(const uint32_t* __rest
 #else
         unsigned long long* const tq = nullptr;
 #endif
-        if (narrow) em2_class_pass_runs<NT, uint16_t>(sc.cw16, s_run, sc.coff, c4, K, scale, ab_load, ab_pick, add, tq);
-        else em2_class_pass_runs<NT, uint32_t>(sc.cw, s_run, sc.coff, c4, K, scale, ab_load, ab_pick, add, tq);
+        if (narrow) em2_class_pass_runs<NT, uint16_t>(sc.cw16, s_run, sc.coff, c4, c2, K, scale, ab_load, ab_pick, add, tq);
+        else em2_class_pass_runs<NT, uint32_t>(sc.cw, s_run, sc.coff, c4, c2, K, scale, ab_load, ab_pick, add, tq);
         EM2H(1);
         em2_gsync();
         EM2H(2);

@@ -4,7 +4,6 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 python -c "import torch" 2>/dev/null
 O=$GRAFT_REPO_ROOT/gpurun_out/round5_final; mkdir -p $O
-( time timeout 900 python -m pytest tests -m gpu -q ) > $O/tests.log 2>&1; tail -4 $O/tests.log | grep -v "^$"
 leg() {   # tag, bench flags...
   local N=$1; shift
   PASSES="stats sq fetch write" bash profiles/run_prof.sh $N "$@" > /dev/null 2>&1
@@ -14,6 +13,8 @@ leg() {   # tag, bench flags...
   rm -rf gpurun_out/prof_$N
   echo "$N: $(sed -n 3p $O/${N}_rocprof.txt | cut -c1-100)"
 }
+# (the line first, the suite last: if the call is cut short by the round's GPU budget, it is the suite's log that is missing)
+( time timeout 900 python bench.py --steps 20 --warmup 5 ) > $O/r05_bench.json 2> $O/bench.err; tail -c 1500 $O/r05_bench.json; echo; tail -3 $O/bench.err
 leg r05
 leg r05_configs2 --workload configs2
 leg r05_configs1_tail --na-model tail
@@ -22,5 +23,5 @@ leg r05_configs3 --workload configs3
 leg r05_atac --workload atac
 cd "$GRAFT_REPO_ROOT"
 cp $O/r05*_traffic.json profiles/ 2>/dev/null   # (the line's roofline.traffic is looked up in profiles/: this box's passes)
-( time timeout 900 python bench.py --steps 20 --warmup 5 ) > $O/r05_bench.json 2> $O/bench.err; tail -c 1500 $O/r05_bench.json; echo; tail -3 $O/bench.err
+( time timeout 900 python -m pytest tests -m gpu -q ) > $O/tests.log 2>&1; tail -4 $O/tests.log | grep -v "^$"
 ls $O
