@@ -647,3 +647,83 @@ int main() {
     for r, g in zip(rows, got):
         want = sorted(set(x for x in r if x != 0xFFFFFFFF))
         assert g[0] == len(want) and g[1:] == want, (r, g, want)
+
+
+def test_atac_ref_runs_rebuild_the_column_on_host(tmp_path):
+    """csrc/afq_kernels.hip, k_atac_compact: the ref column of the scATAC rows does not cross PCIe - a cell's rows are sorted by ref
+    first, the kernel lists the column's runs (the row that starts one finds its end by bisection) and the host writes the column
+    from the list (afq_api.cpp: std::fill_n per run).  The kernel's own source text run thread by thread on the host (blockIdx /
+    threadIdx as plain variables), then the host's fill: the column must come back, on cells of no row, one row, one ref, a ref
+    per row and the usual few dozen runs, with source and destination offsets that differ (the compaction).  A list that is too
+    short loses runs and nothing else (the library then copies the column).  No GPU."""
+    import shutil
+    import subprocess
+
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    src = open(os.path.join(ROOT, "alevin-fry_amd", "csrc", "afq_kernels.hip")).read()
+    a = src.index("__global__ __launch_bounds__(256) void k_atac_compact(")
+    fn = src[a:src.index("\n}\n", a) + 3]
+    host = r'''#include <cstdint>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+#define __global__
+#define __launch_bounds__(x)
+#define __restrict__
+struct uint4 { uint32_t x, y, z, w; };
+static inline uint4 make_uint4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return uint4{a, b, c, d}; }
+static struct { unsigned x; } blockIdx, threadIdx;
+template <typename T> static inline T atomicAdd(T* p, T v) { const T o = *p; *p += v; return o; }
+static inline uint32_t __shfl_xor(uint32_t v, int) { return 0 * v; }
+''' + fn + r'''
+int main() {
+    unsigned n_cells, cap;
+    if (scanf("%u %u", &n_cells, &cap) != 2) return 2;
+    std::vector<uint64_t> cell_ptr(n_cells + 1), out_ptr(n_cells + 1);
+    std::vector<uint32_t> cnt(n_cells);
+    uint64_t in_total = 0, out_total = 0;
+    for (unsigned c = 0; c < n_cells; ++c) {
+        unsigned gap;
+        if (scanf("%u %u", &cnt[c], &gap) != 2) return 2;
+        cell_ptr[c] = in_total; out_ptr[c] = out_total;
+        in_total += cnt[c] + gap; out_total += cnt[c];   // (the input keeps a cell's capacity, the output is dense)
+    }
+    cell_ptr[n_cells] = in_total; out_ptr[n_cells] = out_total;
+    std::vector<uint32_t> i_ref(in_total + 1, 0xABCDu), i_start(in_total + 1, 7), o_ref(out_total + 1), o_start(out_total + 1);
+    std::vector<uint16_t> i_flen(in_total + 1, 100), i_cnt(in_total + 1, 1), o_flen(out_total + 1), o_cnt(out_total + 1);
+    for (unsigned c = 0; c < n_cells; ++c)
+        for (unsigned i = 0; i < cnt[c]; ++i) if (scanf("%u", &i_ref[cell_ptr[c] + i]) != 1) return 2;
+    std::vector<uint4> runs(cap ? cap : 1);
+    uint32_t ctr = 0;
+    for (unsigned c = 0; c < n_cells; ++c)
+        for (unsigned t = 0; t < 256; ++t) {
+            blockIdx.x = c; threadIdx.x = t;
+            k_atac_compact(cell_ptr.data(), out_ptr.data(), i_ref.data(), i_start.data(), i_flen.data(), i_cnt.data(), o_ref.data(), o_start.data(),
+                           o_flen.data(), o_cnt.data(), nullptr, runs.data(), &ctr, cap);
+        }
+    // the host's side (afq_api.cpp): the column from the list, into an array that holds something else
+    std::vector<uint32_t> col(out_total + 1, 0xFFFFFFFFu);
+    const uint32_t have = std::min(ctr, cap);
+    for (uint32_t i = 0; i < have; ++i) { const uint4 q = runs[i]; std::fill_n(col.begin() + ((((uint64_t)q.y) << 32) | q.x), (size_t)q.z, q.w); }
+    uint64_t wrong = 0, unset = 0;
+    for (uint64_t i = 0; i < out_total; ++i) { if (col[i] == 0xFFFFFFFFu) ++unset; else if (col[i] != o_ref[i]) ++wrong; }
+    printf("%u %llu %llu %llu\n", ctr, (unsigned long long)out_total, (unsigned long long)wrong, (unsigned long long)unset);
+    return 0;
+}
+'''
+    (tmp_path / "t.cpp").write_text(host)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", str(tmp_path / "t"), str(tmp_path / "t.cpp")], check=True, capture_output=True)
+    rng = np.random.default_rng(7)
+    cells = [np.zeros(0, np.int64), np.array([5]), np.full(700, 3), np.arange(600)]   # no row, one row, one ref, a ref per row
+    for _ in range(40):
+        n = int(rng.integers(1, 3000))
+        cells.append(np.sort(rng.integers(0, int(rng.integers(1, 40)), n)))
+    true_runs = sum(int(1 + np.count_nonzero(np.diff(c))) for c in cells if len(c))
+    for cap in (1 << 20, true_runs, true_runs // 2):
+        text = f"{len(cells)} {cap}\n" + "".join(f"{len(c)} {int(rng.integers(0, 50))}\n" for c in cells) + " ".join(" ".join(map(str, c)) for c in cells) + "\n"
+        r = subprocess.run([str(tmp_path / "t")], input=text, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        ctr, total, wrong, unset = map(int, r.stdout.split())
+        assert ctr == true_runs and total == sum(len(c) for c in cells) and wrong == 0
+        assert (unset == 0) == (cap >= true_runs)   # (every row written exactly when the list held every run)
