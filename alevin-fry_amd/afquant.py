@@ -211,6 +211,29 @@ def result_from_c(res: AfqResult, owner=None) -> QuantResult:
 _lib = None
 
 
+def configure_runtime():
+    """Runtime settings the path wants, set while they can still take effect: GPU_FORCE_BLIT_COPY_SIZE=0 (device<->host copies on
+    the DMA engines, not as blit kernels on the compute queue next to the path's own kernels) is read by the HIP runtime when it
+    comes up, so it is set here only when NO HIP runtime is mapped into the process yet (torch not imported, libamdhip64 not
+    loaded) and the host has not said otherwise.  A host whose runtime is already up keeps its own setting; afq_create notes a
+    missing one on stderr.  Returns True when the setting is in place."""
+    import sys
+
+    if "GPU_FORCE_BLIT_COPY_SIZE" in os.environ:
+        return os.environ["GPU_FORCE_BLIT_COPY_SIZE"] == "0"
+    mapped = "torch" in sys.modules
+    if not mapped:
+        try:
+            with open("/proc/self/maps") as f:
+                mapped = "libamdhip64" in f.read()
+        except OSError:
+            mapped = False
+    if mapped:
+        return False
+    os.environ["GPU_FORCE_BLIT_COPY_SIZE"] = "0"
+    return True
+
+
 def load_library(path: str = LIB_PATH):
     """dlopen the HIP library and declare prototypes.  Raises if it is not built."""
     global _lib
@@ -220,9 +243,11 @@ def load_library(path: str = LIB_PATH):
     # soname; a process must hold exactly one HIP/HSA runtime, so when torch is installed it is
     # imported first and the library binds to the runtime torch already mapped (a torch-free
     # host gets /opt/rocm's).  See DESIGN.md "one HIP runtime per process".
-    # (GPU_FORCE_BLIT_COPY_SIZE=0 - copies on the DMA engines, not as blit kernels next to the path's own - is the HOST's to set
-    #  before its HIP runtime comes up: bench.py, the afquant CLI and tests/conftest.py do; a binding does not edit its host's
-    #  environment.  afq_create says so once on stderr when it is missing.  INTEGRATION.md "runtime settings")
+    # (GPU_FORCE_BLIT_COPY_SIZE=0 - copies on the DMA engines, not as blit kernels next to the path's own - must be in the environment
+    #  before the HIP runtime comes up: bench.py, the afquant CLI and tests/conftest.py set it; configure_runtime() sets it for a Python
+    #  host that imports this binding before any HIP runtime is mapped and has not chosen a value itself.  afq_create says so once on
+    #  stderr when it is missing.  INTEGRATION.md "runtime settings")
+    configure_runtime()
     try:
         import torch  # noqa: F401
 

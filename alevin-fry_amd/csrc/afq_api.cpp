@@ -989,9 +989,15 @@ int finish_range(afq_ctx* c, int slot) {
         // part is cut again (three cuts at most, then the round-3 answer: the error).
         bool cut = rehash;
         if (regrow) {
-            rc = run_range(c, whole, slot, nullptr, ht, pt + 1);
-            if (!rc) rc = finish_range(c, slot);
-            else if (rc == AFQ_ERR_OOM) { cut = true; rc = 0; }
+            // (a range sized to fill the device has no room for four times its pool: ask before trying - a failed hipMalloc frees the
+            //  pool, costs a full set-up and leaves hipErrorOutOfMemory as the runtime's last error, which the next range would report)
+            size_t free_b = 0, total_b = 0;
+            const bool room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b + (double)B.d_epool.cap > 4.2 * (double)B.d_epool.cap;
+            if (room) {
+                rc = run_range(c, whole, slot, nullptr, ht, pt + 1);
+                if (!rc) rc = finish_range(c, slot);
+            } else rc = AFQ_ERR_OOM;
+            if (rc == AFQ_ERR_OOM) { cut = true; rc = 0; (void)hipGetLastError(); { std::lock_guard<std::mutex> g(c->err_mu); c->err.clear(); } }
         }
         if (cut && whole.c1 - whole.c0 > 1 && c->retry_cuts < 3) {
             c->retry_cuts += 1;
@@ -1959,8 +1965,11 @@ int afq_atac_dedup_rad(afq_ctx* c, const uint8_t* bytes, size_t n_bytes, const u
         // host threads write the column from the list while the other three columns (8 of the 12 bytes of a row) are on the link.
         // A list that overflows (more than 64 runs per cell on average: thousands of contigs) sends the column itself, as before.
         const long cap_hook = test_hook_long("ATAC_RUN_CAP", -1);   // (tests: force the overflow)
-        const uint32_t run_cap = cap_hook >= 0 ? (uint32_t)cap_hook : (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 20, 64ull * n_cells), 1u << 28);
+        // (at most 2^22 runs = 64 MiB of pinned memory whatever the number of barcodes - an unfiltered sample has a million of them; a
+        //  list that does not fit, or that the host has no pinned memory for, is the overflow case: the column crosses as a copy)
+        uint32_t run_cap = cap_hook >= 0 ? (uint32_t)cap_hook : (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 20, 64ull * n_cells), 1u << 22);
         uint4* runs = (uint4*)pinned_pool()->get(16ull * std::max<uint32_t>(run_cap, 1));
+        if (!runs) { run_cap = 0; runs = (uint4*)pinned_pool()->get(16); }
         uint32_t* oref = (uint32_t*)pinned_pool()->get(4 * n1);
         uint32_t* ostart = (uint32_t*)pinned_pool()->get(4 * n1);
         uint16_t* oflen = (uint16_t*)pinned_pool()->get(2 * n1);

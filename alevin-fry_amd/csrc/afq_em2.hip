@@ -421,11 +421,7 @@ template <> struct IdLoad<uint32_t> { static __device__ __forceinline__ uint32_t
 
 
 __device__ __forceinline__ void em2_add(unsigned long long* p, unsigned long long v) {
-#ifdef AFQ_EM2_EXPERIMENT_NOADD
-    if (v == 0x123456789ull) *p = v;   // (timing experiment: the pass without its atomics; wrong rows)
-#else
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
 }
 // One pass over the classes: D in label order, r = 1 / D, every label word's share into its entry's accumulator.
 //

@@ -70,8 +70,8 @@ def assert_em_within_the_reference_envelope(got, oracle_module, cfg, tid_to_gid,
     sums its classes in a HashMap's order (em.rs:464), so two of its own runs can leave an entry on either side of the 0.01
     output floor, or - when a cell's round count changes with it - apart by more than 1e-4.  That envelope is MEASURED here, on
     the same cells: the oracle under three shuffled class orders against its canonical order.  The device must stay inside it:
-    no more entries beyond 1e-4 and no more floor crossings away from the floor than the reference's own reorderings produce
-    (0 and 0 on every sample seen so far); crossings AT the floor (survivor within 1e-4 of 0.01) are within the tolerance and
+    no more entries beyond 1e-4 and no more floor crossings away from the floor than the WORST SINGLE one of the reference's own
+    reorderings produces (the maximum over the three shuffles, not their sum; 0 and 0 on every sample seen so far); crossings AT the floor (survivor within 1e-4 of 0.01) are within the tolerance and
     are reported.  Returns the counts."""
     n_threads = n_threads or os.cpu_count() or 8
     want = oracle_module.quant(cfg, tid_to_gid, data, offs, n_threads=n_threads, em_arith="reference")
@@ -87,12 +87,10 @@ def assert_em_within_the_reference_envelope(got, oracle_module, cfg, tid_to_gid,
         return t
 
     dev = tally(rows)
-    env = np.zeros(5)
+    env = np.zeros(5)   # the LARGEST count any single reordering produced (not their sum: the device is one run, not three)
     for seed in (11, 12, 13):
         perm = oracle_module.quant(cfg, tid_to_gid, data, offs, n_threads=n_threads, em_arith="reference", em_order_seed=seed)
-        t = tally([perm.row(j) for j in range(n)])
-        env[:4] += t[:4]
-        env[4] = max(env[4], t[4])
+        env = np.maximum(env, tally([perm.row(j) for j in range(n)]))
     out = {"entries": int(dev[0]), "device_beyond_1e-4_rel": int(dev[1]), "device_floor_crossings": int(dev[2]),
            "device_floor_crossings_off_the_floor": int(dev[3]), "device_max_rel_diff": dev[4],
            "beyond_1e-4_allowed_by_shuffle_envelope": int(env[1]), "floor_crossings_of_the_shuffle_envelope": int(env[2]),
