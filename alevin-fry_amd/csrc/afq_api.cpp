@@ -342,16 +342,19 @@ int check_supported(afq_ctx* c) {
 // Layout of RangeState::d_p2_small (u32 words), the per-cell / per-partition / per-tile arrays of the phase-kernel parsimony
 // path: a region that starts zeroed, the arrays the kernels fill, and a region uploaded from the host in one copy.
 struct P2Small {
-    uint64_t pcnt, pnp, pncls, pn3, gcnt, fb, ctr, gdesc, zero_words;      // zeroed: per partition reads / pairs / staged classes, per-cell counters / flags, work counter
-    uint64_t poff, pcur, pnv, pcell;                           // filled on the device
+    uint64_t pcnt, pnp, pncls, pn3, gcnt, fb, ctr, gdesc, pfd, pfc, zero_words;      // zeroed: per partition reads / pairs / staged classes, per-cell counters / flags, work counter, the range-wide graph build's per-range and per-cell blocks
+    uint64_t poff, pcur, pnv, pcell, tcount, tbase, old_list;  // filled on the device
     uint64_t up, fb_count, fb_list, order, cells, tiles, up_words, words;   // uploaded
 };
 P2Small p2_small_layout(uint64_t n, uint64_t parts, uint64_t tiles, uint64_t n_pug) {
     P2Small L{};
     uint64_t o = 0;
-    L.pcnt = o; o += parts; L.pnp = o; o += parts; L.pncls = o; o += parts; L.pn3 = o; o += parts; L.gcnt = o; o += 4 * n; L.fb = o; o += n; L.ctr = o; o += 12; L.gdesc = o; o += 16 * n;
+    L.pcnt = o; o += parts; L.pnp = o; o += parts; L.pncls = o; o += parts; L.pn3 = o; o += parts; L.gcnt = o; o += 4 * n; L.fb = o; o += n; L.ctr = o; o += 12; L.gdesc = o; o += kGDescWords * n;
+    o = (o + 1) & ~1ull;   // (8-byte fields from here)
+    L.pfd = o; o += (sizeof(PfDev) + 3) / 4; L.pfc = o; o += n * (sizeof(PfCell) / 4);
     L.zero_words = o;
     L.poff = o; o += parts; L.pcur = o; o += parts; L.pnv = o; o += parts; L.pcell = o; o += parts;
+    L.tcount = o; o += tiles; L.tbase = o; o += tiles + 1; L.old_list = o; o += n;
     o = (o + 3) & ~3ull;
     L.up = o; L.fb_count = o; o += 4; L.fb_list = o; o += n_pug; L.order = o; o += n; o = (o + 3) & ~3ull;
     L.cells = o; o += n * (sizeof(P2Cell) / 4); L.tiles = o; o += 2 * tiles;
@@ -849,6 +852,11 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
             p2.pnp = sm + L.pnp; p2.pncls = sm + L.pncls; p2.pn3 = sm + L.pn3; p2.gcnt = sm + L.gcnt; p2.fb = sm + L.fb; p2.fb_list = sm + L.fb_list; p2.fb_count = sm + L.fb_count;
             p2.pool = pool; p2.pool_cur = B.d_epool_cur.as<unsigned long long>(); p2.pool_cap = pool_cap;
             p2.work_counter = sm + L.ctr; p2.work_counter2 = sm + L.ctr + 1; p2.gdesc = sm + L.gdesc;
+            p2.tcount = sm + L.tcount; p2.tbase = sm + L.tbase; p2.old_list = sm + L.old_list;
+            p2.pfd = reinterpret_cast<PfDev*>(sm + L.pfd); p2.pfc = reinterpret_cast<PfCell*>(sm + L.pfc);
+            // The graph phase: range-wide flat kernels (afq_pugflat.hip) unless the range's reads outgrow their 32-bit slot numbers
+            // (>= 2^31 parsimony reads in ONE range: the per-cell kernel then takes every cell) or a test asks for the per-cell kernel.
+            p2.graph_flat = (n_pug_reads < (1ull << 31) && !test_hook_is("P2_GRAPH", "cell")) ? 1u : 0u;
             p2.cell_nkeys = ra.cell_nkeys; p2.t2g = c->d_t2g.as<uint32_t>(); p2.keys0 = ra.keys0; p2.cell_ncols = ra.cell_ncols;
             p2.lab = ra.lab; p2.lab_cnt = ra.lab_cnt; p2.st = ra.st; p2.alt = B.d_alt.as<uint32_t>();
             p2.n_cells = n_p2; p2.n_tiles = (uint32_t)p2tiles.size(); p2.n_parts = (uint32_t)p2_parts;
@@ -874,7 +882,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
             tc.seg(K_P2_PART); launch_p2_part(s, p2);
             tc.seg(K_P2_SEARCH); launch_p2_search(s, p2);
             tc.seg(K_P2_LONE); launch_p2_lone(s, p2);
-            tc.seg(K_P2_GRAPH); launch_p2_graph(s, p2);
+            tc.seg(K_P2_GRAPH); launch_p2_graph(s, p2, n_pug_reads);
         }
         PugCellArgs pa{};
         pa.bytes = in_bytes; pa.meta = ra.meta; pa.pug_cells = sm + L.fb_list; pa.cell_nkeys = ra.cell_nkeys;

@@ -39,79 +39,10 @@
 #include "afq_kernels.h"
 #include "afq_prims.h"
 #include "afq_pug_common.h"
+#include "afq_p2_shared.h"
 
 namespace afq {
 
-typedef unsigned __int128 u128;
-
-constexpr uint32_t kP2Bins = 2048;        // partitions per cell the tile kernels rank in LDS
-constexpr uint32_t kP2TabSlots = 512;     // hash table of one partition's vertices (<= 256)
-#ifndef AFQ_P2_FILT_LG
-#define AFQ_P2_FILT_LG 12
-#endif
-constexpr uint32_t kP2FiltLg = AFQ_P2_FILT_LG, kP2FiltBits = 1u << kP2FiltLg;    // presence filter in front of it
-constexpr uint32_t kVCntMask = 0x3FFu;    // vertex word: reads (10 bits) | label signature (19 bits) << 10 | key tag << 29
-constexpr uint64_t kPairF = 1ull << 63, kPairB = 1ull << 62;   // pair (x, y): x -> y / y -> x is an edge
-
-__device__ __forceinline__ uint32_t sig_of(uint32_t t) { return 1u << (t % 19u); }
-__device__ __forceinline__ uint32_t fold9(uint32_t u) { u ^= u >> 18; return (u ^ (u >> 9)) & (kP2TabSlots - 1); }       // linear: fold(a ^ b) = fold(a) ^ fold(b)
-__device__ __forceinline__ uint32_t fold11(uint32_t u) { return (u ^ (u >> kP2FiltLg) ^ (u >> (2 * kP2FiltLg))) & (kP2FiltBits - 1); }   // (kP2FiltLg bits of a UMI of <= 32 bits; linear too)
-
-__device__ __forceinline__ uint32_t wg_add(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ uint32_t wg_min(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-// The graph kernel's scratch belongs to one workgroup, so its global-memory atomics are WORKGROUP scope: they execute in the
-// XCD's L2 and cost no fabric traffic (as agent-scope operations the same words were 32 GB of HBM-side traffic per launch).
-// Two rules keep them coherent with the plain accesses around them: a word other waves change with atomics is READ with an
-// atomic too (fetch_or 0: it is answered by the L2, where a plain load may be served by a line this CU's L1 cached before
-// the atomic), and plain stores to such a word are followed by gsync() before the next atomic on it.
-template <typename T>
-__device__ __forceinline__ T ld_l2(const T* p) { return __hip_atomic_fetch_or(const_cast<T*>(p), (T)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-template <typename T>
-__device__ __forceinline__ void st_l2(T* p, T v) { *p = v; }
-// The barrier between phases that hand each other data through global memory: a wave first waits for its own stores to be
-// acknowledged (s_waitcnt vmcnt(0): stores count in vmcnt on gfx9), then goes to the barrier.
-__device__ __forceinline__ void gsync() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
-
-// ---- labels by key: one or two refs sit in the key itself (afq_common.h label_key), longer ones in the chunk -------------
-struct KLab {
-    uint32_t n;          // refs
-    uint32_t r0, r1;     // tags 1, 2
-    const uint32_t* p;   // tag 3: the refs in the chunk (orientation bit still on)
-};
-__device__ __forceinline__ KLab klab(const uint32_t* W, uint32_t HW, uint64_t h, uint32_t off) {
-    KLab l{0, 0xFFFFFFFFu, 0xFFFFFFFFu, nullptr};
-    const uint32_t tag = (uint32_t)(h >> 62);
-    if (tag == 1) { l.n = 1; l.r0 = (uint32_t)h & 0x7FFFFFFFu; }
-    else if (tag == 2) { l.n = 2; l.r0 = (uint32_t)(h >> 31) & 0x7FFFFFFFu; l.r1 = (uint32_t)h & 0x7FFFFFFFu; }
-    else if (tag == 3) { l.n = W[off]; l.p = W + off + HW; }
-    return l;
-}
-__device__ __forceinline__ uint32_t klab_ref(const KLab& l, uint32_t j) { return l.p ? (l.p[j] & 0x7FFFFFFFu) : (j == 0 ? l.r0 : l.r1); }
-__device__ __forceinline__ bool klab_contains(const KLab& l, uint32_t t) {
-    if (!l.p) return t == l.r0 || t == l.r1;   // (t is a ref id < 2^31, never the 0xFFFFFFFF filler)
-    return lab_contains(Lab{l.p, l.n}, t);
-}
-__device__ __forceinline__ bool klab_overlap(const KLab& a, const KLab& b) {   // share >= 1 ref (pugutils.rs:187-204)
-    if (a.n == 0 || b.n == 0) return false;
-    if (!a.p) return klab_contains(b, a.r0) || (a.n > 1 && klab_contains(b, a.r1));
-    if (!b.p) return klab_contains(a, b.r0) || (b.n > 1 && klab_contains(a, b.r1));
-    return lab_overlap(Lab{a.p, a.n}, Lab{b.p, b.n});
-}
-
-__device__ __forceinline__ PugCtx make_ctx(const P2Args& A, const P2Cell& c, uint32_t* cnt) {
-    PugCtx C;
-    C.W = reinterpret_cast<const uint32_t*>(A.bytes + c.chunk_off);
-    C.HW = A.hw; C.t2g = A.t2g; C.ref_count = A.ref_count; C.num_genes = A.num_genes;
-    C.usa = A.usa; C.num_rows = A.num_rows; C.uo = A.num_rows / 3; C.ao = 2 * (A.num_rows / 3); C.em = A.em;
-    C.exact_umi = A.exact_umi; C.large_thresh = A.large_thresh; C.umi_pairs = A.umi_pairs; C.gene_level = 0;
-    C.cols = reinterpret_cast<uint32_t*>(A.keys0 + c.key_off);
-    C.cols_cap = 2 * c.n_ref + 2;
-    C.labw = A.lab ? A.lab + 2 * c.key_off : nullptr;
-    C.labd = A.lab ? C.labw + c.n_ref + 1 : nullptr;
-    C.lab_cap = c.n_ref + 1;
-    C.s_cnt = cnt; C.st = A.st; C.cell = c.cell;
-    return C;
-}
 
 // The partition kernels' walk (a wave per partition, persistent workgroups): the partitions go to the XCDs - workgroups x, x + 8,
 // ... share one, they are dealt round-robin - in runs of 1024, a few cells each, 256 workgroups side by side on a run.  A cell's
@@ -854,7 +785,10 @@ constexpr uint32_t kGTab = AFQ_GTAB;          // class table slots when it lives
 constexpr uint32_t kCatPair = 1, kCatTiny = 2, kCatMid = 3, kCatBig = 4, kCatLarge = 5;   // (Large: above --large-graph-thresh, resolved winner-take-all)
 
 template <int GNT>
-__global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, uint32_t work_hi, uint32_t* counter) {
+__global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, const uint32_t* list, const uint32_t* n_list, uint32_t work_lo, uint32_t work_hi, uint32_t* counter) {
+    // list: the cells to take, entries work_lo .. work_hi - 1 (n_list: the list's length lives on the device - the cells the range-wide
+    // build of afq_pugflat.hip routed here because one of their components has more than 64 vertices)
+    if (n_list) work_hi = *n_list;
     if (A.st->err_code) return;   // an earlier kernel of the range failed (e.g. kErrLabelHash in k_p2_part, which then leaves its partition's vertices unwritten): nothing behind it may read that state - the host runs the range again or reports the error
     // (the 1024-thread instance is alone on its CU - 16 waves at 128 VGPRs - and takes a class table twice the size: cells of 40-80 k
     //  reads ask for 3 000-6 000 classes, and out of the pool the class step cost them twice as much: 244 against 124 us at 40 k reads)
@@ -875,7 +809,7 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
     __syncthreads();
     const uint32_t work = s_next;
     if (work >= work_hi) return;
-    const uint32_t j = A.order[work];
+    const uint32_t j = list[work];
     const P2Cell c = A.cells[j];
     const uint32_t R = c.R;
     auto give_up = [&]() {   // the cell goes to the one-workgroup kernel
@@ -988,6 +922,7 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
         }
     }
     gsync();
+    const uint32_t* const flat_tl = A.graph_flat ? A.pool + A.pfd->tl : nullptr;
     for (uint32_t pp = tid; pp < P; pp += GNT) {   // the partition's pairs over touched-vertex numbers, four at a time
         const uint32_t nk = pnp[pp], so = ppoff[pp], at = ppre[2 * pp];
         const uint64_t* src = nk > pcn[pp] ? reinterpret_cast<const uint64_t*>(A.pool + psrc[so]) : psrc + so;   // (more pairs than own slots: the search put the list into the pool)
@@ -996,6 +931,11 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
             uint32_t lx[4], ly[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) pr[r] = k0 + r < nk ? src[k0 + r] : 0ull;
+            if (flat_tl) {   // (the range-wide build has rewritten the pairs over ITS dense numbers: back to slots of the cell first)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (k0 + r < nk) pr[r] = (pr[r] & (kPairF | kPairB)) | ((uint64_t)(flat_tl[(uint32_t)(pr[r] >> 31) & 0x7FFFFFFFu] - (uint32_t)c.rd_base) << 31) | (flat_tl[(uint32_t)pr[r] & 0x7FFFFFFFu] - (uint32_t)c.rd_base);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) { lx[r] = k0 + r < nk ? lidx[(uint32_t)(pr[r] >> 31) & 0x7FFFFFFFu] : 0u; ly[r] = k0 + r < nk ? lidx[(uint32_t)pr[r] & 0x7FFFFFFFu] : 0u; }
 #pragma unroll
@@ -1367,7 +1307,7 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
     if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], c.cell); return; }
     // what the cover kernel (k_p2_cover) takes over: where the cell's lists lie in the pool, how many there are, the cell's counters
     if (tid == 0) {
-        uint32_t* d = A.gdesc + 16 * (size_t)j;
+        uint32_t* d = A.gdesc + kGDescWords * (size_t)j;
         auto put = [&](int at, const void* ptr) { const unsigned long long o = (unsigned long long)(reinterpret_cast<const uint32_t*>(ptr) - A.pool); d[at] = (uint32_t)o; d[at + 1] = (uint32_t)(o >> 32); };
         d[1] = n_pr; d[2] = n_tiny; d[3] = n_mid; d[15] = n_bigc | (n_large ? 0x80000000u : 0u);
         put(4, tl); put(6, pr_v); put(8, mid_off); put(10, mrec);
@@ -1378,11 +1318,8 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, uint32_t work_lo, ui
             mid_off[n_all + 3] = (uint32_t)oo; mid_off[n_all + 4] = (uint32_t)(oo >> 32);
             mid_off[n_all + 5] = n_large; mid_off[n_all + 6] = (uint32_t)lo; mid_off[n_all + 7] = (uint32_t)(lo >> 32);
         }
-        {
-            const unsigned long long to = (unsigned long long)(tied - A.pool);
-            mid_off[n_all + 8] = (uint32_t)to; mid_off[n_all + 9] = (uint32_t)(to >> 32);
-            tied[0] = 0; tied[1] = 0;
-        }
+        put(16, tied);
+        tied[0] = 0; tied[1] = 0;
         d[12] = s_cnt[0]; d[13] = s_cnt[1]; d[14] = s_cnt[2];
         d[0] = defer ? 3u : 1u;   // bit 0: the lists are there; bit 1: components of up to 64 vertices lie in slot order (kCoverDefer)
     }
@@ -1522,7 +1459,7 @@ __global__ __launch_bounds__(CNT, CNT == 256 ? 4 : 1) void k_p2_cover(P2Args A, 
     const uint32_t work = s_next;
     if (work >= work_hi) return;
     const uint32_t j = A.order[work];
-    const uint32_t* d = A.gdesc + 16 * (size_t)j;
+    const uint32_t* d = A.gdesc + kGDescWords * (size_t)j;
     if (!(d[0] & 1u)) continue;   // handed to the one-workgroup kernel, or failed (the error is set)
     const bool defer = (d[0] & 2u) != 0;
     const P2Cell c = A.cells[j];
@@ -1534,7 +1471,7 @@ __global__ __launch_bounds__(CNT, CNT == 256 ? 4 : 1) void k_p2_cover(P2Args A, 
     const uint32_t* coff = A.v_off + c.rd_base;
     auto at = [&](int k) -> const uint32_t* { return A.pool + (((unsigned long long)d[k + 1] << 32) | d[k]); };
     const uint32_t n_pr = d[1], n_tiny = d[2], n_mid = d[3];
-    const uint32_t* tl = at(4);
+    const uint32_t* tl = (d[4] & d[5]) == 0xFFFFFFFFu ? nullptr : at(4);   // (the range-wide build lists slots of the cell, not touched-vertex numbers)
     const uint32_t* pr_v = at(6);
     const uint32_t* mid_off = at(8);
     const uint4* mrec = reinterpret_cast<const uint4*>(at(10));
@@ -1544,7 +1481,7 @@ __global__ __launch_bounds__(CNT, CNT == 256 ? 4 : 1) void k_p2_cover(P2Args A, 
         bool cls = false;
         KLab l{0, 0xFFFFFFFFu, 0xFFFFFFFFu, nullptr}, l2 = l;
         if (k < n_pr) {
-            const uint32_t ga = tl[pr_v[2 * k]], gb = tl[pr_v[2 * k + 1]];
+            const uint32_t ga = tl ? tl[pr_v[2 * k]] : pr_v[2 * k], gb = tl ? tl[pr_v[2 * k + 1]] : pr_v[2 * k + 1];
             l = klab(C.W, C.HW, ch[ga], coff[ga]); l2 = klab(C.W, C.HW, ch[gb], coff[gb]);
         }
         // (labels of up to kStageRefs refs out of the chunk: the second one goes to this lane's row of the wave's LDS stage, the first
@@ -1618,10 +1555,10 @@ __global__ __launch_bounds__(CNT, CNT == 256 ? 4 : 1) void k_p2_cover(P2Args A, 
         append_class2(C, cls, k0, k1);
     }
     const uint32_t n_bigc = d[15] & 0x7FFFFFFFu;
-    const uint32_t* x = mid_off + n_mid + n_bigc + 1;   // (ten words behind the list's last offset)
+    const uint32_t* x = mid_off + n_mid + n_bigc + 1;   // (eight words behind the list's last offset: read only where the per-cell graph kernel listed larger components)
     // The records of these components lie in slot order, not in the reference's: a round with ONE largest arborescence does not
     // depend on the order; at the first round that meets a tie the component is set aside for k_p2_tied (afq_pug_common.h).
-    uint32_t* const tied = A.pool + (((unsigned long long)x[8] << 32) | x[7]);
+    uint32_t* const tied = A.pool + (((unsigned long long)d[17] << 32) | d[16]);
     if (defer) {
         cover_tiny8<CNT / 64, kCoverDefer>(C, mrec, mid_off, n_tiny, wv, lane, tied, tied + 4, s_stage[wv]);
         cover_wave64<CNT / 64, kCoverDefer>(C, mrec, mid_off, n_tiny, n_mid, wv, lane, tied + 1, tied + 4 + 4 * (size_t)n_tiny, s_stage[wv]);
@@ -1678,15 +1615,14 @@ __global__ __launch_bounds__(CNT) void k_p2_tied(P2Args A, uint32_t work_lo, uin
     const uint32_t work = s_next;
     if (work >= work_hi) return;
     const uint32_t j = A.order[work];
-    const uint32_t* d = A.gdesc + 16 * (size_t)j;
+    const uint32_t* d = A.gdesc + kGDescWords * (size_t)j;
     if (d[0] != 3) continue;   // nothing was set aside (the graph kernel ordered the cell's components itself), or the cell was handed to the one-workgroup kernel, or failed
     const P2Cell c = A.cells[j];
     auto at = [&](int k) -> uint32_t* { return A.pool + (((unsigned long long)d[k + 1] << 32) | d[k]); };
-    const uint32_t n_tiny = d[2], n_mid = d[3], n_bigc = d[15] & 0x7FFFFFFFu;
+    const uint32_t n_tiny = d[2];
     const uint32_t* mid_off = at(8);
     uint4* mrec = reinterpret_cast<uint4*>(at(10));
-    const uint32_t* x = mid_off + n_mid + n_bigc + 1;
-    uint32_t* const tied = A.pool + (((unsigned long long)x[8] << 32) | x[7]);
+    uint32_t* const tied = A.pool + (((unsigned long long)d[17] << 32) | d[16]);
     const uint32_t nA = tied[0], nB = tied[1], nE = nA + nB;
     if (nE == 0) continue;
     uint32_t* const listA = tied + 4;
@@ -1881,12 +1817,12 @@ void launch_p2_lone(hipStream_t s, const P2Args& a) {
     if (a.lone_coop >= 2) AFQ_LAUNCH(k_p2_lone<true>, p2_grid(a.n_parts), 256, s, a);
     else AFQ_LAUNCH(k_p2_lone<false>, p2_grid(a.n_parts), 256, s, a);
 }
-void launch_p2_graph(hipStream_t s, const P2Args& a) {
+void launch_p2_graph(hipStream_t s, const P2Args& a, uint64_t n_reads) {
     if (!a.n_cells) return;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    // The cells come largest first.  A cell is one workgroup's from its first phase to its last - a chain of some forty dependent
-    // steps, whatever its size - and a range's kernel is not over before its largest cell is (a 290 k-read cell: 15 ms at 256
+    // The cells come largest first.  In the per-cell kernels a cell is one workgroup's from its first phase to its last - a chain of
+    // dependent steps, whatever its size - and a range's kernel is not over before its largest cell is (a 290 k-read cell: 15 ms at 256
     // threads, twice what the rest of its range takes on the whole chip): the first n_big cells - 15 000 reads or more - get 1024
     // threads each, a CU to themselves, in launches of their own; the others 256 threads, four (graph: 147 VGPRs, 48.5 KiB of LDS),
     // four (cover) and three (ties: 49 KiB) workgroups to a CU.  (Round 5 measured 512-thread workgroups at 128 VGPRs, two cells to a
@@ -1894,8 +1830,15 @@ void launch_p2_graph(hipStream_t s, const P2Args& a) {
     // Work counters: graph 0 / 2, cover 1 / 3, ties 4 / 5 (256 / 1024 threads).
     const uint32_t n_big = a.n_big < a.n_cells ? a.n_big : a.n_cells, rest = a.n_cells - n_big, ucus = (uint32_t)cus;
     uint32_t* const wc = a.work_counter;
-    if (n_big) AFQ_LAUNCH(k_p2_graph<1024>, std::min(n_big, ucus), 1024, s, a, 0u, n_big, wc + 2);
-    if (rest) AFQ_LAUNCH(k_p2_graph<kGNT>, std::min(rest, 4 * ucus), kGNT, s, a, n_big, a.n_cells, wc);
+    if (a.graph_flat) {
+        // Round 6: the graph phase is range-wide flat kernels (afq_pugflat.hip); the per-cell graph kernel only takes the cells that
+        // build routes to it - a component of more than 64 vertices, whose order and adjacency rows it makes - off a list on the device.
+        launch_pf_build(s, a, n_reads);
+        AFQ_LAUNCH(k_p2_graph<1024>, std::min(a.n_cells, ucus), 1024, s, a, a.old_list, &a.pfd->n_old, 0u, 0u, wc + 2);
+    } else {
+        if (n_big) AFQ_LAUNCH(k_p2_graph<1024>, std::min(n_big, ucus), 1024, s, a, a.order, (const uint32_t*)nullptr, 0u, n_big, wc + 2);
+        if (rest) AFQ_LAUNCH(k_p2_graph<kGNT>, std::min(rest, 4 * ucus), kGNT, s, a, a.order, (const uint32_t*)nullptr, n_big, a.n_cells, wc);
+    }
     if (n_big) AFQ_LAUNCH(k_p2_cover<1024>, std::min(n_big, ucus), 1024, s, a, 0u, n_big, wc + 3);
     if (rest) AFQ_LAUNCH(k_p2_cover<kGNT>, std::min(rest, 4 * ucus), kGNT, s, a, n_big, a.n_cells, wc + 1);
     // ... and the components the covers set aside at a tie, in the reference's order

@@ -77,8 +77,10 @@ def one(seed):
     kw = dict(small_thresh=int(rng.choice([0, 100])))
     if seed % 3 == 1:   # every third workload: tied components set aside in every cell (k_p2_tied), not only in those whose classes outgrow the LDS table
         os.environ["AFQ_TEST_P2_DEFER_MIN"] = "0"
+        os.environ["AFQ_TEST_P2_GRAPH"] = "cell"   # ... through the per-cell graph kernel (by default: the range-wide flat build)
     else:
         os.environ.pop("AFQ_TEST_P2_DEFER_MIN", None)
+        os.environ.pop("AFQ_TEST_P2_GRAPH", None)
     if rng.integers(0, 4) == 0:
         kw["pug_exact_umi"] = True
     if rng.integers(0, 4) == 0:

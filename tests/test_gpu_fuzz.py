@@ -17,7 +17,8 @@ def test_random_workloads_match_the_oracle(oracle, seed, monkeypatch):
     --sa-model, --small-thresh 0, exact-UMI parsimony, uniform EM start, -d, -b (both summaries)."""
     rng = np.random.default_rng(1000 + seed)
     res = RES[seed % len(RES)]
-    if res.startswith("parsimony") and (seed // len(RES)) % 2:   # every other parsimony workload: tied components set aside in every cell (k_p2_tied)
+    if res.startswith("parsimony") and (seed // len(RES)) % 2:   # every other parsimony workload: the per-cell graph kernel of rounds 3-5 for every cell (by default the range-wide flat build, csrc/afq_pugflat.hip), tied components set aside in every cell (k_p2_tied)
+        monkeypatch.setenv("AFQ_TEST_P2_GRAPH", "cell")
         monkeypatch.setenv("AFQ_TEST_P2_DEFER_MIN", "0")
     usa = bool(rng.integers(0, 2))
     sizes = [int(x) for x in rng.choice([1, 2, 7, 40, 99, 100, 101, 250, 251, 600, 1500, 4000], size=int(rng.integers(3, 9)))]

@@ -9,22 +9,30 @@ rad = pkg.rad
 synth = pkg.synth
 
 
-@pytest.fixture(autouse=True, params=["phase-kernels", "one-workgroup", "handed-back", "graph-1024", "ties-set-aside"])
+@pytest.fixture(autouse=True, params=["phase-kernels", "one-workgroup", "handed-back", "cover-1024", "graph-per-cell", "graph-per-cell-1024", "graph-per-cell-ties-set-aside"])
 def pug_route(request, monkeypatch):
-    """Every test of this module runs five times: through the partition-parallel phase kernels (csrc/afq_pug2.hip, the
-    default), with every parsimony cell sent to the one-workgroup kernel (csrc/afq_pug.hip), with the phase kernels'
-    partition capacity cut to 24 reads so that most cells start on the first route and are handed back to the second, with
-    every cell of 300 reads or more given the 1024-thread instances of the graph / cover / tie kernels (by default: cells of
-    15 000 reads), and with EVERY cell covering its components in slot order and setting the tied ones aside for k_p2_tied (by
-    default only the cells whose classes outgrow the graph kernel's LDS table: big cells, long labels)."""
+    """Every test of this module runs seven times: through the partition-parallel phase kernels with the range-wide flat graph
+    build (csrc/afq_pug2.hip + csrc/afq_pugflat.hip, the default; a cell with a component of more than 64 vertices is routed to
+    the per-cell graph kernel from there), with every parsimony cell sent to the one-workgroup kernel (csrc/afq_pug.hip), with the
+    phase kernels' partition capacity cut to 24 reads so that most cells start on the first route and are handed back to the
+    second, with every cell of 300 reads or more given the 1024-thread instances of the cover / tie kernels (by default: cells
+    of 15 000 reads), and three times with the per-cell graph kernel of rounds 3-5 for EVERY cell (AFQ_TEST_P2_GRAPH=cell): as
+    it decides itself, with its 1024-thread instance from 300 reads, and with every cell covering its components in slot order
+    and setting the tied ones aside for k_p2_tied (what the flat build always does)."""
     if request.param == "one-workgroup":
         monkeypatch.setenv("AFQ_TEST_PUG_ROUTE", "mono")
     elif request.param == "handed-back":
         monkeypatch.setenv("AFQ_TEST_P2_PART_CAP", "24")
-    elif request.param == "graph-1024":
+    elif request.param == "cover-1024":
+        monkeypatch.setenv("AFQ_TEST_P2_BIG_READS", "300")
+    elif request.param == "graph-per-cell":
+        monkeypatch.setenv("AFQ_TEST_P2_GRAPH", "cell")
+    elif request.param == "graph-per-cell-1024":
+        monkeypatch.setenv("AFQ_TEST_P2_GRAPH", "cell")
         monkeypatch.setenv("AFQ_TEST_P2_BIG_READS", "300")
         monkeypatch.setenv("AFQ_TEST_P2_DEFER_MIN", "0")
-    elif request.param == "ties-set-aside":
+    elif request.param == "graph-per-cell-ties-set-aside":
+        monkeypatch.setenv("AFQ_TEST_P2_GRAPH", "cell")
         monkeypatch.setenv("AFQ_TEST_P2_DEFER_MIN", "0")
     return request.param
 
@@ -359,7 +367,7 @@ def test_parsimony_cell_of_more_than_2_pow_20_reads(oracle, pug_route):
     """The reference has no limit on a cell's reads (quant.rs:733-757).  The one-workgroup kernel numbers a cell's vertices
     in 20 bits and refuses cells of 2^20 reads or more; the phase kernels take them (up to 2^22): 1.15 M reads of one cell,
     8 192 UMI partitions, a class table of a few MiB out of the pool - rows bit-exact against the oracle."""
-    if pug_route != "phase-kernels":
+    if pug_route not in ("phase-kernels", "graph-per-cell"):
         pytest.skip("the one-workgroup kernel refuses cells of 2^20 reads or more (AFQ_ERR_UNSUPPORTED), by design")
     import importlib
 
@@ -401,7 +409,7 @@ def test_components_of_65_to_4096_vertices_stay_with_the_phase_kernels(oracle, m
 
     got, n_mono = run()
     assert_same_result(got, want, what=res)
-    if pug_route in ("phase-kernels", "graph-1024"):
+    if pug_route in ("phase-kernels", "cover-1024", "graph-per-cell", "graph-per-cell-1024"):
         assert n_mono == 0, "no cell should have needed the one-workgroup kernel"
         monkeypatch.setenv("AFQ_TEST_P2_MAX_COMP", "64")
         got64, n_mono64 = run()
@@ -446,5 +454,5 @@ def test_more_pairs_than_reads_stay_with_the_phase_kernels(oracle, pug_route, re
     finally:
         q.close()
     assert_same_result(got, want, what=res)
-    if pug_route in ("phase-kernels", "graph-1024"):
+    if pug_route in ("phase-kernels", "cover-1024", "graph-per-cell", "graph-per-cell-1024"):
         assert n_mono == 0, "no cell should have needed the one-workgroup kernel"
