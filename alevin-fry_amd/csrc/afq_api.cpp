@@ -153,6 +153,7 @@ struct RangeState {
     ResolveArgs last_ra{};
     std::vector<CellMeta> meta;
     Range cur{};
+    const PfDev* pf_stats_src = nullptr; uint64_t pf_stats_reads = 0, pf_stats_parts = 0;   // AFQ_TEST_PF_STATS
     uint32_t hash_try = 0;   // which salt the range's label hashes were made with (a collision re-runs the range under the next)
     uint32_t pool_try = 0;   // how often the range was run again with four times the parsimony pool (a cell's graph outgrew it)
     uint64_t att_records = 0, att_ref_words = 0, att_buckets = 0;   // what the current attempt added to the batch statistics
@@ -342,8 +343,8 @@ int check_supported(afq_ctx* c) {
 // Layout of RangeState::d_p2_small (u32 words), the per-cell / per-partition / per-tile arrays of the phase-kernel parsimony
 // path: a region that starts zeroed, the arrays the kernels fill, and a region uploaded from the host in one copy.
 struct P2Small {
-    uint64_t pcnt, pnp, pncls, pn3, gcnt, fb, ctr, gdesc, pfd, pfc, zero_words;      // zeroed: per partition reads / pairs / staged classes, per-cell counters / flags, work counter, the range-wide graph build's per-range and per-cell blocks
-    uint64_t poff, pcur, pnv, pcell, tcount, tbase, old_list;  // filled on the device
+    uint64_t pcnt, pnp, pncls, pn3, gcnt, fb, ctr, gdesc, pfd, route, zero_words;      // zeroed: per partition reads / pairs / staged classes, per-cell counters / flags, work counter, the range-wide graph build's block and per-cell routing flags
+    uint64_t poff, pcur, pnv, pcell, tq, bq, old_list, nta, nba, pcpre, pbq, npa;  // filled on the device (nta / nba: entries per tile quantity / per block quantity)
     uint64_t up, fb_count, fb_list, order, cells, tiles, up_words, words;   // uploaded
 };
 P2Small p2_small_layout(uint64_t n, uint64_t parts, uint64_t tiles, uint64_t n_pug) {
@@ -351,10 +352,12 @@ P2Small p2_small_layout(uint64_t n, uint64_t parts, uint64_t tiles, uint64_t n_p
     uint64_t o = 0;
     L.pcnt = o; o += parts; L.pnp = o; o += parts; L.pncls = o; o += parts; L.pn3 = o; o += parts; L.gcnt = o; o += 4 * n; L.fb = o; o += n; L.ctr = o; o += 12; L.gdesc = o; o += kGDescWords * n;
     o = (o + 1) & ~1ull;   // (8-byte fields from here)
-    L.pfd = o; o += (sizeof(PfDev) + 3) / 4; L.pfc = o; o += n * (sizeof(PfCell) / 4);
+    L.pfd = o; o += (sizeof(PfDev) + 3) / 4; L.route = o; o += n;
     L.zero_words = o;
     L.poff = o; o += parts; L.pcur = o; o += parts; L.pnv = o; o += parts; L.pcell = o; o += parts;
-    L.tcount = o; o += tiles; L.tbase = o; o += tiles + 1; L.old_list = o; o += n;
+    L.nba = (tiles + 1 + 1023) / 1024; L.nta = L.nba * 1024;   // (six quantities per tile, scanned in blocks of 1024 tiles; entry `tiles` is the end)
+    L.tq = o; o += 6 * L.nta; L.bq = o; o += 6 * L.nba; L.old_list = o; o += n;
+    L.npa = (parts + 1 + 1023) / 1024 * 1024; L.pcpre = o; o += L.npa; L.pbq = o; o += L.npa / 1024;
     o = (o + 3) & ~3ull;
     L.up = o; L.fb_count = o; o += 4; L.fb_list = o; o += n_pug; L.order = o; o += n; o = (o + 3) & ~3ull;
     L.cells = o; o += n * (sizeof(P2Cell) / 4); L.tiles = o; o += 2 * tiles;
@@ -656,6 +659,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
             pc.lgP = lg; pc.part_base = (uint32_t)p2_parts;
             p2_parts += 1ull << lg;
             const uint32_t j = (uint32_t)p2cells.size();
+            pc.tile0 = (uint32_t)p2tiles.size();
             for (uint32_t t = 0; t * p2_tile < m.nrec; ++t) p2tiles.push_back(make_uint2(j, t));
             p2cells.push_back(pc);
         }
@@ -852,8 +856,9 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
             p2.pnp = sm + L.pnp; p2.pncls = sm + L.pncls; p2.pn3 = sm + L.pn3; p2.gcnt = sm + L.gcnt; p2.fb = sm + L.fb; p2.fb_list = sm + L.fb_list; p2.fb_count = sm + L.fb_count;
             p2.pool = pool; p2.pool_cur = B.d_epool_cur.as<unsigned long long>(); p2.pool_cap = pool_cap;
             p2.work_counter = sm + L.ctr; p2.work_counter2 = sm + L.ctr + 1; p2.gdesc = sm + L.gdesc;
-            p2.tcount = sm + L.tcount; p2.tbase = sm + L.tbase; p2.old_list = sm + L.old_list;
-            p2.pfd = reinterpret_cast<PfDev*>(sm + L.pfd); p2.pfc = reinterpret_cast<PfCell*>(sm + L.pfc);
+            p2.tq = sm + L.tq; p2.bq = sm + L.bq; p2.nta = (uint32_t)L.nta; p2.nba = (uint32_t)L.nba; p2.old_list = sm + L.old_list;
+            p2.pfd = reinterpret_cast<PfDev*>(sm + L.pfd); p2.route = sm + L.route;
+            p2.pcpre = sm + L.pcpre; p2.pbq = sm + L.pbq; p2.npa = (uint32_t)L.npa;
             // The graph phase: range-wide flat kernels (afq_pugflat.hip) unless the range's reads outgrow their 32-bit slot numbers
             // (>= 2^31 parsimony reads in ONE range: the per-cell kernel then takes every cell) or a test asks for the per-cell kernel.
             p2.graph_flat = (n_pug_reads < (1ull << 31) && !test_hook_is("P2_GRAPH", "cell")) ? 1u : 0u;
@@ -883,6 +888,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
             tc.seg(K_P2_SEARCH); launch_p2_search(s, p2);
             tc.seg(K_P2_LONE); launch_p2_lone(s, p2);
             tc.seg(K_P2_GRAPH); launch_p2_graph(s, p2, n_pug_reads);
+            B.pf_stats_src = p2.graph_flat && test_hook("PF_STATS") ? p2.pfd : nullptr; B.pf_stats_reads = n_pug_reads; B.pf_stats_parts = p2_parts;
         }
         PugCellArgs pa{};
         pa.bytes = in_bytes; pa.meta = ra.meta; pa.pug_cells = sm + L.fb_list; pa.cell_nkeys = ra.cell_nkeys;
@@ -1023,6 +1029,13 @@ int finish_range(afq_ctx* c, int slot) {
         }
         if (regrow) B.d_epool.release();   // the enlarged pool is that attempt's alone: the next range plans its own
         return rc;
+    }
+    if (B.pf_stats_src) {   // AFQ_TEST_PF_STATS: the sizes of the range's flat graph build, on stderr (measurement scripts)
+        PfDev d{};
+        if (hipMemcpy(&d, B.pf_stats_src, sizeof(d), hipMemcpyDeviceToHost) == hipSuccess)
+            std::fprintf(stderr, "[afq] flat graph build: reads %llu partitions %llu vertices_with_an_edge %u two_vertex_components %u listed_components %u record_slots %u cells_routed_to_the_per_cell_kernel %u\n",
+                         (unsigned long long)B.pf_stats_reads, (unsigned long long)B.pf_stats_parts, d.T, d.NP, d.NC, d.S, d.n_old);
+        B.pf_stats_src = nullptr;
     }
     if (!st.err_code && !B.pug_cell_launched && B.h_pack.p[9]) {   // cells were handed back and the kernel that takes them was not launched
         c->handback_seen = true;

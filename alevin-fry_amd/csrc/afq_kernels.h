@@ -185,21 +185,14 @@ struct P2Cell {
     uint32_t lgP;         // log2 of the partition count (partition = low lgP bits of the UMI)
     uint32_t part_base;   // first partition of the cell in the per-partition arrays
     uint32_t n_ref;       // alignment words of the cell (= meta[cell].n_ref: sizes the column list and the label area)
-    uint32_t pad;
+    uint32_t tile0;       // the cell's first tile (its tiles are consecutive)
     uint64_t key_off;     // = meta[cell].key_off
 };
 constexpr uint32_t kP2MaxComp = 4096;   // 64 mask words, one per lane: the workgroup cover of k_p2_cover (afq_pug_common.h)
 constexpr uint32_t kGDescWords = 20;    // per cell: what the graph phase hands the cover kernels (P2Args.gdesc)
-// The range-wide graph build (afq_pugflat.hip).  Per cell: counted by k_pf_cats, placed by k_pf_cscan, filled by k_pf_alloc.
-struct PfCell {
-    uint32_t n_pr, n_tiny, n_mid, S_tiny, S_mid;   // components of two / 3..8 / 9..64 vertices, record slots of the latter two
-    uint32_t route;                                // a component of more than 64 vertices: the per-cell graph kernel takes the cell
-    uint32_t pr_base, comp_base, slot_base, pad;   // the cell's runs of the range-wide lists: pairs, components (3..8 then 9..64), record slots
-    unsigned long long fill_pr, fill_tiny, fill_mid;   // components taken | record slots taken << 32
-};
-static_assert(sizeof(PfCell) == 64, "PfCell");
-struct PfDev {   // one per range, filled on the device: offsets are u32 words into the pool
-    unsigned long long tl, tcell, par, cnt, rk;    // per vertex that has an edge [T]
+// The range-wide graph build (afq_pugflat.hip): one block per range, filled on the device.  Offsets are u32 words into the pool.
+struct PfDev {
+    unsigned long long par, cnt, rk, pos, tl, loff, tcell, lh;   // per vertex that has an edge [T]: root, component size -> first slot, position | size class, record slot, slot inside the cell, label offset, label key
     unsigned long long prv, midoff, mrec, tied;    // two-vertex components (two slots each), first record slot per listed component (+ the end), 32-byte records, the covers' set-aside lists
     uint32_t T, NP, NC, S;
     uint32_t n_old, pad[3];                        // cells routed to the per-cell graph kernel (old_list)
@@ -226,7 +219,10 @@ struct P2Args {
     uint32_t max_comp;   // vertices of the largest component the phase kernels cover themselves (kP2MaxComp; tests: AFQ_TEST_P2_MAX_COMP)
     uint32_t n_big;   // the first n_big cells of `order` (largest first: 15 000 reads or more) get a 1024-thread workgroup each in k_p2_graph / k_p2_cover / k_p2_tied
     uint32_t defer_min;   // a cell sets the tied components of its covers aside (k_p2_tied) when its listed components hold more vertices than this; 0xFFFFFFFF: than the graph kernel's LDS class table takes (tests: 0 = every cell)
-    uint32_t* tcount; uint32_t* tbase; PfCell* pfc; PfDev* pfd; uint32_t* old_list;   // the range-wide graph build: per tile, per cell, per range
+    // the range-wide graph build: six per-tile quantities and their scans (tq: nta entries each; bq: per block of 1024 tiles, nba each),
+    // per cell: routed to the per-cell graph kernel; the range's block; the list of routed cells
+    uint32_t* tq; uint32_t* bq; uint32_t nta, nba; uint32_t* route; PfDev* pfd; uint32_t* old_list;
+    uint32_t* pcpre; uint32_t* pbq; uint32_t npa;      // the scan of the lone vertices' staged class counts over the partitions (npa entries, blocks of 1024)
     uint32_t graph_flat;  // the graph phase as range-wide kernels (afq_pugflat.hip); 0: the per-cell kernel for every cell (tests: AFQ_TEST_P2_GRAPH=cell)
     uint32_t lone_coop;   // k_p2_lone: a lone vertex whose label has 5..64 refs is resolved by its whole wave (0: by its lane alone, as until late in round 4 - tests, measurements)
 };
@@ -244,6 +240,7 @@ void launch_p2_search(hipStream_t s, const P2Args& a);
 void launch_p2_lone(hipStream_t s, const P2Args& a);
 void launch_p2_graph(hipStream_t s, const P2Args& a, uint64_t n_reads);
 void launch_pf_build(hipStream_t s, const P2Args& a, uint64_t n_reads);
+void launch_pf_cover(hipStream_t s, const P2Args& a);
 uint32_t pug_max_blocks();
 uint64_t pug_scratch_words(uint32_t nrec, uint32_t n_ref, bool gene_level);
 

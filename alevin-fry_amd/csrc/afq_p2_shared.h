@@ -83,4 +83,93 @@ __device__ __forceinline__ PugCtx make_ctx(const P2Args& A, const P2Cell& c, uin
     return C;
 }
 
+// (LDS instructions of one wave execute in order; WAVE_SYNC only keeps the compiler from moving code across.)
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+// The two-vertex components of one cell: one molecule each, the refs both labels share (pugutils.rs:1161-1188).  The NT threads of
+// the workgroup take the n_pr components of pr_v (two vertices each; tl: touched-vertex number -> slot, or nullptr when the list
+// holds slots); stage_wave: this wave's 64 x kStageRefs words of LDS.  Workgroup-wide call.
+template <int NT>
+__device__ __forceinline__ void p2_cover_pairs(const PugCtx& C, const uint64_t* ch, const uint32_t* coff, const uint32_t* tl, const uint32_t* pr_v, uint32_t n_pr, uint32_t* stage_wave) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    for (uint32_t k = tid; k - lane < n_pr; k += NT) {   // (wave-uniform trip count: append_cols is a wave-wide call)
+        uint32_t col = 0xFFFFFFFFu, k0 = 0, k1 = 0;
+        bool cls = false;
+        KLab l{0, 0xFFFFFFFFu, 0xFFFFFFFFu, nullptr}, l2 = l;
+        if (k < n_pr) {
+            const uint32_t ga = tl ? tl[pr_v[2 * k]] : pr_v[2 * k], gb = tl ? tl[pr_v[2 * k + 1]] : pr_v[2 * k + 1];
+            l = klab(C.W, C.HW, ch[ga], coff[ga]); l2 = klab(C.W, C.HW, ch[gb], coff[gb]);
+        }
+        // (labels of up to kStageRefs refs out of the chunk: the second one goes to this lane's row of the wave's LDS stage, the first
+        //  one's refs into registers - both as loads issued together - and "is ref t of the first label in the second" is a search in
+        //  LDS; ref by ref through global memory a pair of long labels was a chain of some forty dependent loads)
+        const bool lds2 = l2.p && l2.n <= kStageRefs;
+        uint32_t* const row = stage_wave + lane * kStageRefs;
+        if (__any(lds2)) {
+            uint32_t t2[kStageRefs];
+#pragma unroll
+            for (uint32_t q = 0; q < kStageRefs; ++q) t2[q] = lds2 && q < l2.n ? l2.p[q] & 0x7FFFFFFFu : 0xFFFFFFFFu;
+            if (lds2) {
+#pragma unroll
+                for (uint32_t q = 0; q < kStageRefs; ++q) row[q] = t2[q];
+            }
+            WAVE_SYNC();
+        }
+        auto in_l2 = [&](uint32_t t) -> bool { return lds2 ? stage_contains(row, l2.n, t) : klab_contains(l2, t); };
+        if (k < n_pr) {
+            if (l.n <= 4) {
+                uint32_t g4[4];
+                uint32_t kk = 0;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    g4[qq] = 0xFFFFFFFFu;
+                    if ((uint32_t)qq < l.n) {
+                        const uint32_t t = klab_ref(l, qq);
+                        if (in_l2(t)) {
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) if ((uint32_t)w == kk) g4[w] = t;
+                            ++kk;
+                        }
+                    }
+                }
+                const uint32_t ng = genes_of4(C, g4, kk);
+                col = molecule4_column(C, g4, ng, cls);
+                k0 = g4[0]; k1 = g4[1];
+            } else if (l.n <= kStageRefs) {
+                uint32_t t1[kStageRefs];
+#pragma unroll
+                for (uint32_t q = 0; q < kStageRefs; ++q) t1[q] = q < l.n ? l.p[q] & 0x7FFFFFFFu : 0xFFFFFFFFu;          // the first label's refs, together
+#pragma unroll
+                for (uint32_t q = 0; q < kStageRefs; ++q) t1[q] = t1[q] != 0xFFFFFFFFu && in_l2(t1[q]) ? C.t2g[t1[q]] : 0xFFFFFFFFu;   // the shared ones' genes, together
+                // (sorted and distinct in the lane's row of the stage - the second label's refs there have been looked at - not in an
+                //  array of the lane's own, which would live in scratch memory)
+#pragma unroll
+                for (uint32_t q = 0; q < kStageRefs; ++q) row[q] = t1[q];
+                const uint32_t ng = sort_unique_in_row(row, kStageRefs);
+                emit_molecule(C, row, ng);
+            } else {
+                uint32_t g[kMaxGenesPerLabel];
+                uint32_t ng = 0;
+                for (uint32_t jj = 0; jj < l.n && ng != 0xFFFFFFFFu; ++jj) {
+                    const uint32_t t = l.p[jj] & 0x7FFFFFFFu;
+                    if (!in_l2(t)) continue;
+                    const uint32_t gid = C.t2g[t];
+                    uint32_t qq = 0;
+                    while (qq < ng && g[qq] < gid) ++qq;
+                    if (qq < ng && g[qq] == gid) continue;
+                    if (ng == kMaxGenesPerLabel) { ng = 0xFFFFFFFFu; break; }
+                    for (uint32_t r = ng; r > qq; --r) g[r] = g[r - 1];
+                    g[qq] = gid;
+                    ++ng;
+                }
+                if (ng == 0xFFFFFFFFu && C.em)
+                    emit_wide_class(C, l.n, [&](uint32_t jj) -> uint32_t { const uint32_t t = l.p[jj] & 0x7FFFFFFFu; return in_l2(t) ? t : 0xFFFFFFFFu; });
+                else emit_molecule(C, g, ng);
+            }
+        }
+        append_cols(C, col);
+        append_class2(C, cls, k0, k1);
+    }
+}
+
 }  // namespace afq

@@ -189,8 +189,6 @@ __global__ __launch_bounds__(NT) void k_p2_scatter(P2Args A) {
     }
 }
 
-// (LDS instructions of one wave execute in order; WAVE_SYNC only keeps the compiler from moving code across.)
-#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // 2. one wave per partition: reads sorted by (label key, UMI, record offset) in registers -> vertices.
@@ -922,7 +920,7 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, const uint32_t* list
         }
     }
     gsync();
-    const uint32_t* const flat_tl = A.graph_flat ? A.pool + A.pfd->tl : nullptr;
+    const uint32_t flat_t0 = A.graph_flat ? A.tq[c.tile0] + A.bq[c.tile0 >> 10] : 0u;   // the cell's first dense number (afq_pugflat.hip: the scan of the tiles' vertex counts)
     for (uint32_t pp = tid; pp < P; pp += GNT) {   // the partition's pairs over touched-vertex numbers, four at a time
         const uint32_t nk = pnp[pp], so = ppoff[pp], at = ppre[2 * pp];
         const uint64_t* src = nk > pcn[pp] ? reinterpret_cast<const uint64_t*>(A.pool + psrc[so]) : psrc + so;   // (more pairs than own slots: the search put the list into the pool)
@@ -931,13 +929,18 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, const uint32_t* list
             uint32_t lx[4], ly[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) pr[r] = k0 + r < nk ? src[k0 + r] : 0ull;
-            if (flat_tl) {   // (the range-wide build has rewritten the pairs over ITS dense numbers: back to slots of the cell first)
+            if (A.graph_flat) {
+                // (the range-wide build has rewritten the pairs over ITS dense numbers - slot order through the range, cell by cell;
+                //  step 1 above numbers the cell's vertices in slot order too: the same numbers less the cell's first)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (k0 + r < nk) pr[r] = (pr[r] & (kPairF | kPairB)) | ((uint64_t)(flat_tl[(uint32_t)(pr[r] >> 31) & 0x7FFFFFFFu] - (uint32_t)c.rd_base) << 31) | (flat_tl[(uint32_t)pr[r] & 0x7FFFFFFFu] - (uint32_t)c.rd_base);
+                for (int r = 0; r < 4; ++r) {
+                    lx[r] = k0 + r < nk ? ((uint32_t)(pr[r] >> 31) & 0x7FFFFFFFu) - flat_t0 : 0u; ly[r] = k0 + r < nk ? ((uint32_t)pr[r] & 0x7FFFFFFFu) - flat_t0 : 0u;
+                    if (lx[r] >= NT || ly[r] >= NT) s_cnt[3] = kErrInternal;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { lx[r] = k0 + r < nk ? lidx[(uint32_t)(pr[r] >> 31) & 0x7FFFFFFFu] : 0u; ly[r] = k0 + r < nk ? lidx[(uint32_t)pr[r] & 0x7FFFFFFFu] : 0u; }
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { lx[r] = k0 + r < nk ? lidx[(uint32_t)(pr[r] >> 31) & 0x7FFFFFFFu] : 0u; ly[r] = k0 + r < nk ? lidx[(uint32_t)pr[r] & 0x7FFFFFFFu] : 0u; }
 #pragma unroll
             for (int r = 0; r < 4; ++r) if (k0 + r < nk) lp[at + k0 + r] = (uint64_t)lx[r] | ((uint64_t)ly[r] << 24) | ((pr[r] >> 62) << 48);
         }
@@ -1441,8 +1444,9 @@ __device__ __forceinline__ bool cover_large(const P2Args& A, const PugCtx& C, co
 }
 
 template <int CNT>
-__global__ __launch_bounds__(CNT, CNT == 256 ? 4 : 1) void k_p2_cover(P2Args A, uint32_t work_lo, uint32_t work_hi, uint32_t* counter) {
+__global__ __launch_bounds__(CNT, CNT == 256 ? 4 : 1) void k_p2_cover(P2Args A, const uint32_t* list, const uint32_t* n_list, uint32_t work_lo, uint32_t work_hi, uint32_t* counter) {
     if (A.st->err_code) return;
+    if (n_list) work_hi = *n_list;   // (the cells the range-wide build routed to the per-cell kernels: a list on the device)
     __shared__ uint32_t s_cnt[4];
     __shared__ uint32_t s_next;
     __shared__ uint64_t s_mask[2][64];                     // the workgroup cover: uncovered vertices, the round's arborescence
@@ -1458,7 +1462,7 @@ __global__ __launch_bounds__(CNT, CNT == 256 ? 4 : 1) void k_p2_cover(P2Args A, 
     __syncthreads();
     const uint32_t work = s_next;
     if (work >= work_hi) return;
-    const uint32_t j = A.order[work];
+    const uint32_t j = list[work];
     const uint32_t* d = A.gdesc + kGDescWords * (size_t)j;
     if (!(d[0] & 1u)) continue;   // handed to the one-workgroup kernel, or failed (the error is set)
     const bool defer = (d[0] & 2u) != 0;
@@ -1475,85 +1479,7 @@ __global__ __launch_bounds__(CNT, CNT == 256 ? 4 : 1) void k_p2_cover(P2Args A, 
     const uint32_t* pr_v = at(6);
     const uint32_t* mid_off = at(8);
     const uint4* mrec = reinterpret_cast<const uint4*>(at(10));
-    // ---- 5. two-vertex components: one molecule, the refs both labels share (pugutils.rs:1161-1188) ----
-    for (uint32_t k = tid; k - lane < n_pr; k += CNT) {   // (wave-uniform trip count: append_cols is a wave-wide call)
-        uint32_t col = 0xFFFFFFFFu, k0 = 0, k1 = 0;
-        bool cls = false;
-        KLab l{0, 0xFFFFFFFFu, 0xFFFFFFFFu, nullptr}, l2 = l;
-        if (k < n_pr) {
-            const uint32_t ga = tl ? tl[pr_v[2 * k]] : pr_v[2 * k], gb = tl ? tl[pr_v[2 * k + 1]] : pr_v[2 * k + 1];
-            l = klab(C.W, C.HW, ch[ga], coff[ga]); l2 = klab(C.W, C.HW, ch[gb], coff[gb]);
-        }
-        // (labels of up to kStageRefs refs out of the chunk: the second one goes to this lane's row of the wave's LDS stage, the first
-        //  one's refs into registers - both as loads issued together - and "is ref t of the first label in the second" is a search in
-        //  LDS; ref by ref through global memory a pair of long labels was a chain of some forty dependent loads)
-        const bool lds2 = l2.p && l2.n <= kStageRefs;
-        uint32_t* const row = s_stage[wv] + lane * kStageRefs;
-        if (__any(lds2)) {
-            uint32_t t2[kStageRefs];
-#pragma unroll
-            for (uint32_t q = 0; q < kStageRefs; ++q) t2[q] = lds2 && q < l2.n ? l2.p[q] & 0x7FFFFFFFu : 0xFFFFFFFFu;
-            if (lds2) {
-#pragma unroll
-                for (uint32_t q = 0; q < kStageRefs; ++q) row[q] = t2[q];
-            }
-            WAVE_SYNC();
-        }
-        auto in_l2 = [&](uint32_t t) -> bool { return lds2 ? stage_contains(row, l2.n, t) : klab_contains(l2, t); };
-        if (k < n_pr) {
-            if (l.n <= 4) {
-                uint32_t g4[4];
-                uint32_t kk = 0;
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    g4[qq] = 0xFFFFFFFFu;
-                    if ((uint32_t)qq < l.n) {
-                        const uint32_t t = klab_ref(l, qq);
-                        if (in_l2(t)) {
-#pragma unroll
-                            for (int w = 0; w < 4; ++w) if ((uint32_t)w == kk) g4[w] = t;
-                            ++kk;
-                        }
-                    }
-                }
-                const uint32_t ng = genes_of4(C, g4, kk);
-                col = molecule4_column(C, g4, ng, cls);
-                k0 = g4[0]; k1 = g4[1];
-            } else if (l.n <= kStageRefs) {
-                uint32_t t1[kStageRefs];
-#pragma unroll
-                for (uint32_t q = 0; q < kStageRefs; ++q) t1[q] = q < l.n ? l.p[q] & 0x7FFFFFFFu : 0xFFFFFFFFu;          // the first label's refs, together
-#pragma unroll
-                for (uint32_t q = 0; q < kStageRefs; ++q) t1[q] = t1[q] != 0xFFFFFFFFu && in_l2(t1[q]) ? C.t2g[t1[q]] : 0xFFFFFFFFu;   // the shared ones' genes, together
-                // (sorted and distinct in the lane's row of the stage - the second label's refs there have been looked at - not in an
-                //  array of the lane's own, which would live in scratch memory)
-#pragma unroll
-                for (uint32_t q = 0; q < kStageRefs; ++q) row[q] = t1[q];
-                const uint32_t ng = sort_unique_in_row(row, kStageRefs);
-                emit_molecule(C, row, ng);
-            } else {
-                uint32_t g[kMaxGenesPerLabel];
-                uint32_t ng = 0;
-                for (uint32_t jj = 0; jj < l.n && ng != 0xFFFFFFFFu; ++jj) {
-                    const uint32_t t = l.p[jj] & 0x7FFFFFFFu;
-                    if (!in_l2(t)) continue;
-                    const uint32_t gid = C.t2g[t];
-                    uint32_t qq = 0;
-                    while (qq < ng && g[qq] < gid) ++qq;
-                    if (qq < ng && g[qq] == gid) continue;
-                    if (ng == kMaxGenesPerLabel) { ng = 0xFFFFFFFFu; break; }
-                    for (uint32_t r = ng; r > qq; --r) g[r] = g[r - 1];
-                    g[qq] = gid;
-                    ++ng;
-                }
-                if (ng == 0xFFFFFFFFu && C.em)
-                    emit_wide_class(C, l.n, [&](uint32_t jj) -> uint32_t { const uint32_t t = l.p[jj] & 0x7FFFFFFFu; return in_l2(t) ? t : 0xFFFFFFFFu; });
-                else emit_molecule(C, g, ng);
-            }
-        }
-        append_cols(C, col);
-        append_class2(C, cls, k0, k1);
-    }
+    p2_cover_pairs<CNT>(C, ch, coff, tl, pr_v, n_pr, s_stage[wv]);
     const uint32_t n_bigc = d[15] & 0x7FFFFFFFu;
     const uint32_t* x = mid_off + n_mid + n_bigc + 1;   // (eight words behind the list's last offset: read only where the per-cell graph kernel listed larger components)
     // The records of these components lie in slot order, not in the reference's: a round with ONE largest arborescence does not
@@ -1834,13 +1760,15 @@ void launch_p2_graph(hipStream_t s, const P2Args& a, uint64_t n_reads) {
         // Round 6: the graph phase is range-wide flat kernels (afq_pugflat.hip); the per-cell graph kernel only takes the cells that
         // build routes to it - a component of more than 64 vertices, whose order and adjacency rows it makes - off a list on the device.
         launch_pf_build(s, a, n_reads);
+        launch_pf_cover(s, a);   // (the covers of every cell the build did not route away: a workgroup per tile)
         AFQ_LAUNCH(k_p2_graph<1024>, std::min(a.n_cells, ucus), 1024, s, a, a.old_list, &a.pfd->n_old, 0u, 0u, wc + 2);
+        AFQ_LAUNCH(k_p2_cover<1024>, std::min(a.n_cells, ucus), 1024, s, a, a.old_list, &a.pfd->n_old, 0u, 0u, wc + 3);
     } else {
         if (n_big) AFQ_LAUNCH(k_p2_graph<1024>, std::min(n_big, ucus), 1024, s, a, a.order, (const uint32_t*)nullptr, 0u, n_big, wc + 2);
         if (rest) AFQ_LAUNCH(k_p2_graph<kGNT>, std::min(rest, 4 * ucus), kGNT, s, a, a.order, (const uint32_t*)nullptr, n_big, a.n_cells, wc);
+        if (n_big) AFQ_LAUNCH(k_p2_cover<1024>, std::min(n_big, ucus), 1024, s, a, a.order, (const uint32_t*)nullptr, 0u, n_big, wc + 3);
+        if (rest) AFQ_LAUNCH(k_p2_cover<kGNT>, std::min(rest, 4 * ucus), kGNT, s, a, a.order, (const uint32_t*)nullptr, n_big, a.n_cells, wc + 1);
     }
-    if (n_big) AFQ_LAUNCH(k_p2_cover<1024>, std::min(n_big, ucus), 1024, s, a, 0u, n_big, wc + 3);
-    if (rest) AFQ_LAUNCH(k_p2_cover<kGNT>, std::min(rest, 4 * ucus), kGNT, s, a, n_big, a.n_cells, wc + 1);
     // ... and the components the covers set aside at a tie, in the reference's order
     if (n_big) AFQ_LAUNCH(k_p2_tied<1024>, std::min(n_big, ucus), 1024, s, a, 0u, n_big, wc + 5);
     if (rest) AFQ_LAUNCH(k_p2_tied<kGNT>, std::min(rest, 3 * ucus), kGNT, s, a, n_big, a.n_cells, wc + 4);

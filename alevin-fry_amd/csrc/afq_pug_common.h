@@ -346,13 +346,17 @@ static_assert(kStageRefs <= 32, "stage_contains makes five halving steps");
 // tied: kCoverDefer: [0] the list's counter, entries from tied + 4 (this list's region); kCoverResume: the first entry.
 template <int NWAVES, int MODE = kCoverOrdered>
 __device__ __forceinline__ void cover_tiny8(const PugCtx& C, const uint4* mrec, const uint32_t* mid_off, uint32_t n_tiny, uint32_t wv, uint32_t lane,
-                                            uint32_t* tied_cnt = nullptr, uint32_t* tied = nullptr, uint32_t* stage = nullptr)
+                                            uint32_t* tied_cnt = nullptr, uint32_t* tied = nullptr, uint32_t* stage = nullptr, uint32_t ci_base = 0,
+                                            const uint16_t* idx = nullptr)
+    // (ci_base, kCoverDefer: what a set-aside component's index is counted from - the caller covers a slice of a cell's list, mid_off points
+    //  at the slice; idx: the n_tiny components to take, as indices into the slice - the ones cover_lane4 below left over)
     {
         const uint32_t gl = lane & 7u, gbase = lane & ~7u, grp = lane >> 3;
         auto seg_or8 = [](uint32_t x) -> uint32_t { x |= (uint32_t)__shfl_xor((int)x, 1); x |= (uint32_t)__shfl_xor((int)x, 2); x |= (uint32_t)__shfl_xor((int)x, 4); return x; };
         for (uint32_t c0 = wv * 8; c0 < n_tiny; c0 += (NWAVES) * 8) {   // (kCoverResume: n_tiny = entries of the list)
             const bool gvalid = c0 + grp < n_tiny;
             uint32_t ci = c0 + grp;
+            if (idx) ci = gvalid ? idx[c0 + grp] : 0u;
             uint32_t uc0 = 0xFFu;
             if constexpr (MODE == kCoverResume) { ci = gvalid ? tied[4 * (c0 + grp)] : 0u; uc0 = gvalid ? tied[4 * (c0 + grp) + 1] & 0xFFu : 0u; }
             const uint32_t b0 = gvalid ? mid_off[ci] : 0u, n = gvalid ? mid_off[ci + 1] - b0 : 0u;
@@ -424,7 +428,7 @@ __device__ __forceinline__ void cover_tiny8(const PugCtx& C, const uint4* mrec, 
                 }
                 if constexpr (MODE == kCoverDefer) {
                     if (tie && best != 0) {   // set aside (every lane of the group holds the same tie / UC)
-                        if (gl == 0) { const uint32_t e = atomicAdd(tied_cnt, 1u); tied[4 * e] = ci; tied[4 * e + 1] = UC; tied[4 * e + 2] = 0u; }
+                        if (gl == 0) { const uint32_t e = atomicAdd(tied_cnt, 1u); tied[4 * e] = ci + ci_base; tied[4 * e + 1] = UC; tied[4 * e + 2] = 0u; }
                         UC = 0; best = 0;
                     }
                 }
@@ -489,11 +493,107 @@ __device__ __forceinline__ void cover_tiny8(const PugCtx& C, const uint4* mrec, 
         }
     }
 
+// ---- components of 3..4 vertices whose labels hold at most four refs each: ONE LANE per component ----
+// Nine in ten of the components that reach the covers (a molecule read under two or three UMIs one base apart; labels of one or two
+// transcripts, which travel in the records).  cover_tiny8 gives such a component eight lanes, five of them idle, and pays a ballot
+// or a shuffle for every "who has ref t" / "whose label is it"; here the whole component - four labels of four refs, four
+// adjacency nibbles - sits in one lane's registers, every loop is unrolled over constant indices, and a wave covers 64 components
+// at a time.  Same rule, step for step (pugutils.rs:1094-1188): candidates ascending, refs in label order, the first largest
+// arborescence wins; kCoverDefer sets a component aside at the first round with two different largest vertex sets.
+// Wave-wide call: lane's component = records b0 .. b0 + n - 1 (n = 0: none), uc0 = the vertices still uncovered, ci = its index for
+// the set-aside list.  (kCoverResume: uc0 comes from the list, no tie is tracked - the records are in the reference's order.)
+template <int MODE>
+__device__ __forceinline__ void cover_lane4(const PugCtx& C, const uint4* mrec, uint32_t b0, uint32_t n, uint32_t uc0, uint32_t ci,
+                                            uint32_t* tied_cnt = nullptr, uint32_t* tied = nullptr) {
+    constexpr uint32_t kNo = 0xFFFFFFFFu;
+    uint32_t rf[4][4], ln[4], adjm = 0;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        uint4 qa = make_uint4(0, 0, kNo, kNo), qb = make_uint4(kNo, kNo, 0, 0);
+        if ((uint32_t)v < n) { qa = mrec[2 * (size_t)(b0 + v)]; qb = mrec[2 * (size_t)(b0 + v) + 1]; }
+        ln[v] = qa.y; rf[v][0] = qa.z; rf[v][1] = qa.w; rf[v][2] = qb.x; rf[v][3] = qb.y;
+        adjm |= (qb.z & 0xFu) << (4 * v);
+    }
+    auto has = [&](int u, uint32_t t) -> bool { return t == rf[u][0] || t == rf[u][1] || t == rf[u][2] || t == rf[u][3]; };
+    uint32_t UC = n ? uc0 & ((1u << n) - 1u) : 0u;
+    while (__any(UC != 0)) {
+        const uint32_t remaining = (uint32_t)__popc(UC);
+        uint32_t best = 0, best_sz = 0;
+        bool tie = false, done = false;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const bool von = !done && ((UC >> v) & 1u);
+            uint32_t mv = 0, mv_sz = 0;
+            bool tie_v = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool on = von && (uint32_t)j < ln[v];
+                const uint32_t t = rf[v][j];
+                uint32_t At = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) At |= (((UC >> u) & 1u) && has(u, t)) ? 1u << u : 0u;
+                uint32_t Rm = 1u << v;
+#pragma unroll
+                for (int step = 0; step < 3; ++step) {   // (a path through four vertices has three edges)
+                    uint32_t N = 0;
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) N |= ((Rm >> x) & 1u) ? (adjm >> (4 * x)) & 0xFu : 0u;
+                    Rm |= N & At;
+                }
+                const uint32_t sz = (uint32_t)__popc(Rm);
+                if (on && sz > mv_sz) { mv_sz = sz; mv = Rm; tie_v = false; }
+                else if (MODE == kCoverDefer && on && sz == mv_sz && Rm != mv) tie_v = true;
+            }
+            if (von && mv_sz > best_sz) { best_sz = mv_sz; best = mv; tie = tie_v; }
+            else if (MODE == kCoverDefer && von && mv_sz == best_sz && (mv != best || tie_v)) tie = true;
+            if (von && mv_sz == remaining) done = true;
+        }
+        if constexpr (MODE == kCoverDefer) {   // set aside: one reservation per wave
+            const bool aside = UC != 0 && tie && best != 0;
+            const uint64_t m = __ballot(aside);
+            if (m) {
+                const uint32_t lane = lane_id(), leader = (uint32_t)__builtin_ctzll(m);
+                uint32_t e0 = 0;
+                if (lane == leader) e0 = atomicAdd(tied_cnt, (uint32_t)__popcll(m));
+                e0 = (uint32_t)__builtin_amdgcn_readlane((int)e0, (int)leader);
+                if (aside) {
+                    const uint32_t e = e0 + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+                    tied[4 * e] = ci; tied[4 * e + 1] = UC; tied[4 * e + 2] = 0u;
+                    UC = 0; best = 0;
+                }
+            }
+        }
+        if (UC != 0 && best == 0) { C.s_cnt[3] = kErrPugLimit; UC = 0; }   // a vertex with an empty label
+        // the refs every vertex of the arborescence holds (pugutils.rs:1161-1188) -> genes -> the molecule's column or class
+        const uint32_t fv = best ? (uint32_t)__builtin_ctz(best) : 0u;
+        const uint32_t lfn = best ? (fv == 0 ? ln[0] : fv == 1 ? ln[1] : fv == 2 ? ln[2] : ln[3]) : 0u;
+        uint32_t c4[4] = {kNo, kNo, kNo, kNo}, k4 = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t t = fv == 0 ? rf[0][j] : fv == 1 ? rf[1][j] : fv == 2 ? rf[2][j] : rf[3][j];
+            bool all = (uint32_t)j < lfn;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) all = all && (!((best >> u) & 1u) || has(u, t));
+            if (all) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) if ((uint32_t)w == k4) c4[w] = t;
+                ++k4;
+            }
+        }
+        uint32_t col = kNo;
+        bool cls = false;
+        if (best) { const uint32_t n4 = genes_of4(C, c4, k4); col = molecule4_column(C, c4, n4, cls); }
+        append_cols(C, col);
+        append_class2(C, cls, c4[0], c4[1]);
+        UC &= ~best;
+    }
+}
+
 // ---- components of 9..64 vertices (entries n_tiny.. of the list): one wave each, adjacency = one 64-bit mask per lane ----
 // (kCoverResume: the components are entries n_tiny.. n_mid - 1 of the LIST `tied`, i.e. call it with n_tiny = 0, n_mid = entries)
 template <int NWAVES, int MODE = kCoverOrdered>
 __device__ __forceinline__ void cover_wave64(const PugCtx& C, const uint4* mrec, const uint32_t* mid_off, uint32_t n_tiny, uint32_t n_mid, uint32_t wv, uint32_t lane,
-                                             uint32_t* tied_cnt = nullptr, uint32_t* tied = nullptr, uint32_t* stage = nullptr)
+                                             uint32_t* tied_cnt = nullptr, uint32_t* tied = nullptr, uint32_t* stage = nullptr, uint32_t ci_base = 0)
     {
       // which component entry e of the walk is, and where its slots begin and end
       auto comp_of = [&](uint32_t e) -> uint32_t { if constexpr (MODE == kCoverResume) return tied[4 * e]; else return e; };
@@ -581,7 +681,7 @@ __device__ __forceinline__ void cover_wave64(const PugCtx& C, const uint4* mrec,
             if (best == 0) { if (lane == 0) C.s_cnt[3] = kErrPugLimit; break; }  // vertex with an empty label
             if constexpr (MODE == kCoverDefer) {
                 if (tie) {   // set aside (wave-uniform)
-                    if (lane == 0) { const uint32_t e = atomicAdd(tied_cnt, 1u); tied[4 * e] = ci; tied[4 * e + 1] = (uint32_t)UC; tied[4 * e + 2] = (uint32_t)(UC >> 32); }
+                    if (lane == 0) { const uint32_t e = atomicAdd(tied_cnt, 1u); tied[4 * e] = ci + ci_base; tied[4 * e + 1] = (uint32_t)UC; tied[4 * e + 2] = (uint32_t)(UC >> 32); }
                     break;
                 }
             }

@@ -7,16 +7,19 @@
 // dependent steps behind workgroup barriers (k_p2_graph: 128 VGPRs, 40 spilled, 98 KB of LDS, 39.8 GB per configs[2] step
 // for a union-find).  Here every step is one kernel over the whole range of cells:
 //
-//   k_pf_count / k_pf_tscan / k_pf_number   the vertices that have an edge (the search flagged them) get dense numbers t in
-//                                 [0, T): a tile of 4096 read slots counts its flags, one workgroup scans the tile counts,
+//   k_pf_count / k_pf_number      the vertices that have an edge (the search flagged them) get dense numbers t in [0, T), in slot
+//                                 order: a tile of 4096 read slots counts its flags, the tile counts are scanned (k_pf_scan1/2),
 //                                 the tiles number their vertices.  Everything behind this works on dense arrays of T entries.
 //   k_pf_union                    one thread per PAIR: compare-and-swap hooking union-find on par[T] (the larger root under the
 //                                 smaller, path halving by atomic min); the pair is rewritten over dense numbers where it lies.
 //   k_pf_root                     one thread per vertex: its root, its position inside its component (an atomic counter per root).
-//   k_pf_cats / k_pf_classes / k_pf_cscan   component sizes -> per cell: how many components of two / 3..8 / 9..64 vertices and
-//                                 how many record slots; a cell with a larger component is routed to the per-cell kernel (rare);
-//                                 one workgroup scans the cells: every cell's components become a contiguous run of the
-//                                 range-wide lists (pairs | 3..8 | 9..64), the lists come out of the pool in one step.
+//   k_pf_cats, k_pf_scan1/2       per tile: how many of its roots head a component of two / 3..8 / 9..64 vertices, how many record
+//                                 slots those take; a cell with a larger component is routed to the per-cell kernel (rare).  The
+//                                 scan of the tile counts IS the layout: a cell's tiles are consecutive, so every cell's
+//                                 components become a contiguous run of the range-wide lists (pairs | 3..8 | 9..64) and every
+//                                 tile knows where its roots' entries go - no counter, no atomic, the same lists every run.
+//   k_pf_cells                    a workgroup per cell: the descriptor the cover kernels read, the lone vertices' staged classes
+//                                 into the cell's label area.
 //   k_pf_alloc / k_pf_place / k_pf_adj      roots take their list entry and record slots, vertices write their 32-byte cover
 //                                 records, pairs OR their directions into the records' adjacency masks.
 //
@@ -44,26 +47,67 @@ namespace {
 
 constexpr uint32_t kCatShift = 29, kRankMask = (1u << kCatShift) - 1u;
 constexpr uint32_t kFCatPair = 1, kFCatTiny = 2, kFCatMid = 3;
+constexpr uint32_t kNoPos = 0xFFFFFFFFu;
+// per-tile quantities (P2Args.tq, one array of nta entries each): vertices with an edge; then, of the tile's roots, components of
+// two / 3..8 / 9..64 vertices and the record slots of the latter two
+constexpr uint32_t kQTouched = 0, kQPr = 1, kQTiny = 2, kQMid = 3, kQSTiny = 4, kQSMid = 5;
 
 __device__ __forceinline__ uint32_t ag_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // size class of a component of n vertices; 0: not for the flat lists - more than 64 vertices, or above --large-graph-thresh (resolved
 // winner-take-all, pugutils.rs:916-982): the per-cell kernel takes the cell
 __device__ __forceinline__ uint32_t cat_of(uint32_t n, uint32_t large_thresh) { return n > large_thresh ? 0u : n == 2 ? kFCatPair : n <= 8 ? kFCatTiny : n <= 64 ? kFCatMid : 0u; }
 
-// the dense arrays of the touched vertices, out of the pool (k_pf_tscan put them there)
+// the scanned tile quantity q in front of tile i (i = n_tiles: the total): the scan inside the tile's block of 1024 + the blocks before it
+__device__ __forceinline__ uint32_t pf_g(const P2Args& A, uint32_t q, uint32_t i) { return A.tq[(size_t)q * A.nta + i] + A.bq[(size_t)q * A.nba + (i >> 10)]; }
+
+// the dense arrays of the vertices that have an edge, out of the pool (k_pf_scan2 put them there)
 struct PfV {
     uint32_t T;
-    uint32_t* tl;      // t -> read slot (range-wide: rd_base + slot inside the cell)
-    uint32_t* tcell;   // t -> cell (index into P2Args.cells)
     uint32_t* par;     // union-find parent; after k_pf_root: the root
-    uint32_t* cnt;     // root: vertices of its component (k_pf_root); then where its component lies (k_pf_alloc)
-    uint32_t* rk;      // position inside the component | category << 29 (roots, k_pf_alloc)
+    uint32_t* cnt;     // root: vertices of its component (k_pf_root); then the component's first record slot / pair entry (k_pf_alloc)
+    uint32_t* rk;      // position inside the component (k_pf_root) | size class << 29 (roots, k_pf_alloc)
+    uint32_t* pos;     // the vertex's record slot, kNoPos without a record (k_pf_place)
+    uint32_t* tl;      // the vertex's slot inside its cell
+    uint32_t* loff;    // its label's record offset (hashed label keys only: labels of one or two refs sit in the key)
+    uint32_t* tcell;   // its cell (index into P2Args.cells)
+    uint64_t* lh;      // its label key
 };
 __device__ __forceinline__ PfV pf_v(const P2Args& A) {
     const PfDev& D = *A.pfd;
     PfV v;
-    v.T = D.T; v.tl = A.pool + D.tl; v.tcell = A.pool + D.tcell; v.par = A.pool + D.par; v.cnt = A.pool + D.cnt; v.rk = A.pool + D.rk;
+    v.T = D.T; v.par = A.pool + D.par; v.cnt = A.pool + D.cnt; v.rk = A.pool + D.rk; v.pos = A.pool + D.pos;
+    v.tl = A.pool + D.tl; v.loff = A.pool + D.loff; v.tcell = A.pool + D.tcell; v.lh = reinterpret_cast<uint64_t*>(A.pool + D.lh);
     return v;
+}
+
+__device__ __forceinline__ uint32_t nz4(uint32_t w) {   // bit k: byte k of w is not zero
+    w |= w >> 4; w |= w >> 2; w |= w >> 1; w &= 0x01010101u;
+    return (w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u);
+}
+// The flags of slots [t0, t1) of a cell (vf: the cell's first flag), sixteen to a thread as one aligned 16-byte load: f(slot, number
+// inside the tile) for every flagged slot, in slot order.  Workgroup-wide call, 256 threads; returns how many there are.
+template <typename F>
+__device__ __forceinline__ uint32_t pf_tile_flags(const uint8_t* vf, uint32_t t0, uint32_t t1, uint32_t* s_ws, F&& f) {
+    const uintptr_t a = (uintptr_t)(vf + t0), b = (uintptr_t)(vf + t1);
+    const uintptr_t c0 = a >> 4, c1 = (b - 1) >> 4;
+    uint32_t carry = 0;
+    for (uintptr_t cb = c0; cb <= c1; cb += 256) {   // (uniform; a tile of 4096 slots: 256 or 257 chunks)
+        const uintptr_t c = cb + threadIdx.x;
+        uint32_t fm = 0;
+        if (c <= c1) {
+            const uint4 w = *reinterpret_cast<const uint4*>(c << 4);
+            fm = nz4(w.x) | (nz4(w.y) << 4) | (nz4(w.z) << 8) | (nz4(w.w) << 12);
+            const uintptr_t lo = c << 4;
+            if (lo < a) fm &= 0xFFFFu << (uint32_t)(a - lo);
+            if (lo + 16 > b) fm &= 0xFFFFu >> (uint32_t)(lo + 16 - b);
+        }
+        uint32_t tot;
+        uint32_t k = carry + block_excl_scan<256>((uint32_t)__popc(fm), s_ws, tot);
+        const uint32_t gbase = (uint32_t)((c << 4) - (uintptr_t)vf);   // (before the cell's first flag in a tile's first chunk: the masked bits make up for it)
+        for (; fm; fm &= fm - 1, ++k) f(gbase + (uint32_t)__builtin_ctz(fm), k);
+        carry += tot;
+    }
+    return carry;
 }
 
 }  // namespace
@@ -79,76 +123,121 @@ __global__ __launch_bounds__(256) void k_pf_count(P2Args A) {
     if (!A.fb[j]) {   // (a cell k_p2_scan handed back has no vertices, and its flags were never cleared)
         const P2Cell c = A.cells[j];
         const uint32_t t0 = td.y * A.tile, t1 = min(c.R, t0 + A.tile);
-        const uint8_t* f = A.v_flag + c.rd_base;
-        for (uint32_t g0 = t0 + 16 * threadIdx.x; g0 < t1; g0 += 16 * 256) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) n += g0 + r < t1 && f[g0 + r] != 0;
-        }
+        n = pf_tile_flags(A.v_flag + c.rd_base, t0, t1, s_ws, [](uint32_t, uint32_t) {});
     }
-    uint32_t tot;
-    (void)block_excl_scan<256>(n, s_ws, tot);
-    if (threadIdx.x == 0) A.tcount[blockIdx.x] = tot;
+    if (threadIdx.x == 0) A.tq[(size_t)kQTouched * A.nta + blockIdx.x] = n;
 }
 
-// one workgroup: tile counts -> tile offsets, T, and the dense arrays out of the pool
-__global__ __launch_bounds__(1024) void k_pf_tscan(P2Args A) {
+// The scan of Q per-tile quantities, two levels: a workgroup per 1024 tiles scans its tiles in place and leaves its totals, one
+// workgroup scans the totals (and takes what the totals size out of the pool).  Entry n_tiles is the end: its scan is the sum.
+// q0 > 0 (the component counts): the tiles of a cell that is routed to the per-cell kernel count nothing.
+template <int Q>
+__global__ __launch_bounds__(1024) void k_pf_scan1(P2Args A, uint32_t q0) {
     if (A.st->err_code) return;
     __shared__ uint32_t s_ws[16];
-    uint32_t carry = 0;
-    for (uint32_t b = 0; b < A.n_tiles; b += 1024) {
-        const uint32_t i = b + threadIdx.x;
-        const uint32_t v = i < A.n_tiles ? A.tcount[i] : 0u;
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    const bool live = i < A.n_tiles && !(q0 > 0 && A.route[A.tiles[i].x]);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        uint32_t* a = A.tq + (size_t)(q0 + q) * A.nta;
+        const uint32_t v = live ? a[i] : 0u;
         uint32_t tot;
         const uint32_t ex = block_excl_scan<1024>(v, s_ws, tot);
-        if (i < A.n_tiles) A.tbase[i] = carry + ex;
-        carry += tot;
+        if (i < A.nta) a[i] = ex;
+        if (threadIdx.x == 0) A.bq[(size_t)(q0 + q) * A.nba + blockIdx.x] = tot;
     }
-    if (threadIdx.x == 0) {
-        PfDev& D = *A.pfd;
-        const unsigned long long T = carry, words = 5 * T + 16;
+}
+template <int Q>
+__global__ __launch_bounds__(1024) void k_pf_scan2(P2Args A, uint32_t q0) {
+    if (A.st->err_code) return;
+    __shared__ uint32_t s_ws[16];
+    __shared__ uint32_t s_tot[Q];
+    const uint32_t nb = (A.n_tiles + 1 + 1023) / 1024;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        uint32_t* a = A.bq + (size_t)(q0 + q) * A.nba;
+        uint32_t carry = 0;
+        for (uint32_t b0 = 0; b0 < nb; b0 += 1024) {
+            const uint32_t b = b0 + threadIdx.x;
+            const uint32_t v = b < nb ? a[b] : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<1024>(v, s_ws, tot);
+            if (b < nb) a[b] = carry + ex;
+            carry += tot;
+        }
+        if (threadIdx.x == 0) s_tot[q] = carry;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    PfDev& D = *A.pfd;
+    if (q0 == 0) {   // T vertices have an edge: their dense arrays
+        const unsigned long long T = s_tot[0], words = 9 * T + 16;
         const unsigned long long base = atomicAdd(A.pool_cur, words);
         if (base + words > A.pool_cap || T >= (1u << 31)) { set_err(A.st, T >= (1u << 31) ? kErrPugLimit : kErrPugPool, 0); D.T = 0; return; }
         unsigned long long o = (base + 3) & ~3ull;
-        D.tl = o; o += T; D.tcell = o; o += T; D.par = o; o += T; D.cnt = o; o += T; D.rk = o;
+        D.lh = o; o += 2 * T;   // (8-byte entries first: o is a multiple of four words)
+        D.par = o; o += T; D.cnt = o; o += T; D.rk = o; o += T; D.pos = o; o += T; D.tl = o; o += T; D.loff = o; o += T; D.tcell = o;
         D.T = (uint32_t)T;
-        A.tbase[A.n_tiles] = (uint32_t)T;
+    } else if (Q >= 5) {   // the lists: pairs, first record slot per listed component (+ the end), records, the covers' set-aside lists
+        const unsigned long long NP = s_tot[0], NC = (unsigned long long)s_tot[1] + s_tot[Q >= 5 ? 2 : 0], S = (unsigned long long)s_tot[Q >= 5 ? 3 : 0] + s_tot[Q >= 5 ? 4 : 0];
+        const unsigned long long words = 2 * NP + 4 + (NC + 4) + 8 * S + 8 + 4 * (NC + A.n_cells) + 8;
+        const unsigned long long base = atomicAdd(A.pool_cur, words);
+        if (base + words > A.pool_cap || S >= (1ull << 32)) { set_err(A.st, kErrPugPool, 0); return; }
+        unsigned long long o = (base + 3) & ~3ull;
+        D.mrec = o; o += 8 * S + 4;            // (16-byte aligned: uint4 records)
+        D.prv = o; o += 2 * NP + 2;
+        D.midoff = o; o += NC + 2;
+        o = (o + 3) & ~3ull;
+        D.tied = o;
+        D.NP = (uint32_t)NP; D.NC = (uint32_t)NC; D.S = (uint32_t)S;
+        A.pool[D.midoff + NC] = (uint32_t)S;   // the list's last offset
     }
 }
 
 __global__ __launch_bounds__(256) void k_pf_number(P2Args A) {
     if (A.st->err_code) return;
     __shared__ uint32_t s_ws[4];
+    __shared__ uint16_t s_g[4096 + 16];
     const uint2 td = A.tiles[blockIdx.x];
     const uint32_t j = td.x;
     if (A.fb[j]) return;
     const PfV V = pf_v(A);
     const P2Cell c = A.cells[j];
     const uint32_t t0 = td.y * A.tile, t1 = min(c.R, t0 + A.tile);
-    const uint8_t* f = A.v_flag + c.rd_base;
     uint32_t* lidx = A.lidx + c.rd_base;
-    uint32_t carry = A.tbase[blockIdx.x];
-    for (uint32_t base = t0; base < t1; base += 16 * 256) {   // (one trip: a tile is 4096 slots)
-        const uint32_t g0 = base + 16 * threadIdx.x;
-        uint32_t fm = 0;
+    const uint64_t* ch = A.s_h + c.rd_base;
+    const uint32_t* coff = A.v_off + c.rd_base;
+    const uint32_t tb = pf_g(A, kQTouched, blockIdx.x);
+    const uint32_t nt = pf_tile_flags(A.v_flag + c.rd_base, t0, t1, s_ws, [&](uint32_t g, uint32_t k) { s_g[k] = (uint16_t)(g - t0); });
+    __syncthreads();
+    // The vertex's label key (and, for a hashed key, where its label lies) into the dense arrays as well: the covers and the record
+    // builder ask for the labels of these vertices - one in four slots - and every such gather out of the per-slot arrays fetched
+    // a 64-byte line for 8 or 4 bytes; here the lines are read once, by neighbouring lanes, and everybody behind reads dense arrays.
+    // (Four vertices to a thread and trip: the gathers of a trip go out together.)
+    for (uint32_t k0 = threadIdx.x; k0 < nt; k0 += 1024) {
+        uint32_t g[4], off[4];
+        uint64_t h[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) fm |= (uint32_t)(g0 + r < t1 && f[g0 + r] != 0) << r;
-        uint32_t tot;
-        uint32_t t = carry + block_excl_scan<256>((uint32_t)__popc(fm), s_ws, tot);
-        for (; fm; fm &= fm - 1, ++t) {
-            const uint32_t g = g0 + (uint32_t)__builtin_ctz(fm);
-            lidx[g] = t;
-            V.tl[t] = (uint32_t)c.rd_base + g; V.tcell[t] = j; V.par[t] = t; V.cnt[t] = 0; V.rk[t] = 0;
+        for (int r = 0; r < 4; ++r) { const uint32_t k = k0 + 256u * (uint32_t)r; g[r] = k < nt ? t0 + s_g[k] : t0; h[r] = k < nt ? ch[g[r]] : 0ull; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) off[r] = (uint32_t)(h[r] >> 62) == 3 ? coff[g[r]] : 0u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t k = k0 + 256u * (uint32_t)r, t = tb + k;
+            if (k >= nt) continue;
+            lidx[g[r]] = t;
+            V.par[t] = t; V.cnt[t] = 0; V.tl[t] = g[r]; V.tcell[t] = j; V.lh[t] = h[r]; V.loff[t] = off[r];
         }
-        carry += tot;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // The pairs the search left, a workgroup over 256 consecutive partitions at a time: every thread brings one partition's count and
 // place, a scan lays the partitions' pairs end to end, and the threads take the pairs of the 256 partitions evenly - a partition
-// holds anything from none to hundreds.  f(where the pair lies, first read slot of its cell).
+// holds anything from none to hundreds - FOUR to a thread and trip, so that a trip's chains of dependent loads run side by side.
+// f(where the four pairs lie (nullptr: none), first read slot of each one's cell).
 template <typename F>
-__device__ __forceinline__ void pf_for_each_pair(const P2Args& A, uint32_t* s_start, unsigned long long* s_src, uint32_t* s_rdb, uint32_t* s_ws, F&& f) {
+__device__ __forceinline__ void pf_for_each_pair4(const P2Args& A, uint32_t* s_start, unsigned long long* s_src, uint32_t* s_rdb, uint32_t* s_ws, F&& f) {
     for (uint32_t p0 = blockIdx.x * 256; p0 < A.n_parts; p0 += gridDim.x * 256) {
         const uint32_t gp = p0 + threadIdx.x;
         uint32_t np = 0, rdb = 0;
@@ -167,10 +256,21 @@ __device__ __forceinline__ void pf_for_each_pair(const P2Args& A, uint32_t* s_st
         const uint32_t ex = block_excl_scan<256>(np, s_ws, tot);
         s_start[threadIdx.x] = ex; s_src[threadIdx.x] = src; s_rdb[threadIdx.x] = rdb;
         __syncthreads();
-        for (uint32_t t = threadIdx.x; t < tot; t += 256) {
-            uint32_t lo = 0, hi = 256;   // the last partition that starts at or before t: the one t falls into (empty ones share their start with the next)
-            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_start[mid] <= t) lo = mid; else hi = mid; }
-            f(reinterpret_cast<uint64_t*>((uintptr_t)s_src[lo]) + (t - s_start[lo]), s_rdb[lo]);
+        for (uint32_t t = threadIdx.x; t < tot; t += 1024) {
+            uint64_t* sp[4];
+            uint32_t rb[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t tt = t + 256u * (uint32_t)r;
+                sp[r] = nullptr; rb[r] = 0;
+                if (tt < tot) {
+                    uint32_t lo = 0, hi = 256;   // the last partition that starts at or before tt: the one tt falls into (empty ones share their start with the next)
+                    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_start[mid] <= tt) lo = mid; else hi = mid; }
+                    sp[r] = reinterpret_cast<uint64_t*>((uintptr_t)s_src[lo]) + (tt - s_start[lo]);
+                    rb[r] = s_rdb[lo];
+                }
+            }
+            f(sp, rb);
         }
         __syncthreads();
     }
@@ -186,8 +286,7 @@ __global__ __launch_bounds__(256) void k_pf_union(P2Args A) {
     __shared__ uint32_t s_ws[4];
     const PfV V = pf_v(A);
     uint32_t* par = V.par;
-    auto find = [&](uint32_t i) -> uint32_t {
-        uint32_t p = ag_ld(&par[i]);
+    auto find_from = [&](uint32_t i, uint32_t p) -> uint32_t {   // p = par[i], read already
         while (p != i) {
             const uint32_t gp2 = ag_ld(&par[p]);
             if (gp2 != p) __hip_atomic_fetch_min(&par[i], gp2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -195,241 +294,277 @@ __global__ __launch_bounds__(256) void k_pf_union(P2Args A) {
         }
         return i;
     };
-    pf_for_each_pair(A, s_start, s_src, s_rdb, s_ws, [&](uint64_t* sp, uint32_t rdb) {
-        const uint64_t e = *sp;
-        const uint32_t tx = A.lidx[(size_t)rdb + ((uint32_t)(e >> 31) & 0x7FFFFFFFu)], ty = A.lidx[(size_t)rdb + ((uint32_t)e & 0x7FFFFFFFu)];
-        *sp = (e & (kPairF | kPairB)) | ((uint64_t)tx << 31) | ty;   // the pair over dense numbers, where it lay (k_pf_adj, and the per-cell kernel for the cells routed to it)
-        if (tx >= V.T || ty >= V.T) { set_err(A.st, kErrInternal, 0); return; }
-        uint32_t a = find(tx), b = find(ty);
-        while (a != b) {
-            if (a < b) { const uint32_t t = a; a = b; b = t; }
-            uint32_t expected = a;
-            if (__hip_atomic_compare_exchange_strong(&par[a], &expected, b, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-            a = find(expected); b = find(b);
+    pf_for_each_pair4(A, s_start, s_src, s_rdb, s_ws, [&](uint64_t* (&sp)[4], uint32_t (&rb)[4]) {
+        uint64_t e[4];
+        uint32_t tx[4], ty[4], px[4], py[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = sp[r] ? *sp[r] : 0ull;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            tx[r] = sp[r] ? A.lidx[(size_t)rb[r] + ((uint32_t)(e[r] >> 31) & 0x7FFFFFFFu)] : 0u;
+            ty[r] = sp[r] ? A.lidx[(size_t)rb[r] + ((uint32_t)e[r] & 0x7FFFFFFFu)] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (sp[r] && (tx[r] >= V.T || ty[r] >= V.T)) { set_err(A.st, kErrInternal, 0); sp[r] = nullptr; }
+            // the pair over dense numbers, where it lay (k_pf_adj, and the per-cell kernel for the cells routed to it)
+            if (sp[r]) *sp[r] = (e[r] & (kPairF | kPairB)) | ((uint64_t)tx[r] << 31) | ty[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { px[r] = sp[r] ? ag_ld(&par[tx[r]]) : 0u; py[r] = sp[r] ? ag_ld(&par[ty[r]]) : 0u; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (!sp[r]) continue;
+            uint32_t a = find_from(tx[r], px[r]), b = find_from(ty[r], py[r]);
+            while (a != b) {
+                if (a < b) { const uint32_t t = a; a = b; b = t; }
+                uint32_t expected = a;
+                if (__hip_atomic_compare_exchange_strong(&par[a], &expected, b, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                a = find_from(a, expected); b = find_from(b, ag_ld(&par[b]));
+            }
         }
     });
 }
 
-// 3. one thread per vertex: its root (written over its parent: later kernels read it with one load), its position inside its component
+// 3. one thread per vertex (four to a thread and trip): its root (written over its parent: later kernels read it with one load),
+//    its position inside its component
 __global__ __launch_bounds__(256) void k_pf_root(P2Args A) {
     if (A.st->err_code) return;
     const PfV V = pf_v(A);
-    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < V.T; t += gridDim.x * 256) {
-        uint32_t r = t;
-        for (uint32_t p = V.par[r]; p != r; p = V.par[r]) r = p;
-        V.rk[t] = atomicAdd(&V.cnt[r], 1u);
-        if (r != t) V.par[t] = r;   // (a walk through t meanwhile meets the old parent or the root: both are ancestors)
-    }
-}
-
-// 4. one thread per root: its component's size class into its cell's counts.  The lanes of a wave nearly always share a cell
-//    (dense numbers run cell by cell): one atomic per wave, count and cell; a wave across a cell boundary takes its cells in turn.
-__global__ __launch_bounds__(256) void k_pf_cats(P2Args A) {
-    if (A.st->err_code) return;
-    const PfV V = pf_v(A);
-    const uint32_t lane = lane_id();
-    for (uint32_t t0 = (blockIdx.x * 256 + threadIdx.x) & ~63u; t0 < V.T; t0 += gridDim.x * 256) {   // (wave-uniform trip count)
-        const uint32_t t = t0 + lane;
-        const bool root = t < V.T && V.par[t] == t;
-        const uint32_t n = root ? V.cnt[t] : 0u, j = root ? V.tcell[t] : 0u;
-        const uint32_t cat = root ? cat_of(n, A.large_thresh) : 0u;
-        for (uint64_t left = __ballot(root); left;) {
-            const uint32_t jj = (uint32_t)__builtin_amdgcn_readlane((int)j, (int)__builtin_ctzll(left));
-            const bool mine = root && j == jj;
-            left &= ~__ballot(mine);
-            PfCell* pc = A.pfc + jj;
-            const uint32_t npr = (uint32_t)__popcll(__ballot(mine && cat == kFCatPair)), nti = (uint32_t)__popcll(__ballot(mine && cat == kFCatTiny)),
-                           nmi = (uint32_t)__popcll(__ballot(mine && cat == kFCatMid));
-            uint32_t sti = mine && cat == kFCatTiny ? n : 0u, smi = mine && cat == kFCatMid ? n : 0u;
+    for (uint32_t t0 = blockIdx.x * 1024 + threadIdx.x; t0 < V.T; t0 += gridDim.x * 1024) {
+        uint32_t r[4], p[4];
+        bool on[4];
 #pragma unroll
-            for (int d = 32; d > 0; d >>= 1) { sti += __shfl_xor(sti, d); smi += __shfl_xor(smi, d); }
-            const bool big = __any(mine && cat == 0);
-            if (lane == 0) {
-                if (npr) atomicAdd(&pc->n_pr, npr);
-                if (nti) { atomicAdd(&pc->n_tiny, nti); atomicAdd(&pc->S_tiny, sti); }
-                if (nmi) { atomicAdd(&pc->n_mid, nmi); atomicAdd(&pc->S_mid, smi); }
-                if (big) atomicOr(&pc->route, 1u);   // a component of more than 64 vertices: the cell goes to the per-cell kernel
-            }
+        for (int i = 0; i < 4; ++i) { const uint32_t t = t0 + 256u * (uint32_t)i; on[i] = t < V.T; r[i] = t; p[i] = on[i] ? V.par[t] : t; }
+        for (bool go = true; go;) {
+            go = false;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (p[i] != r[i]) { r[i] = p[i]; p[i] = V.par[r[i]]; go = true; }
+        }
+        uint32_t k[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) k[i] = on[i] ? atomicAdd(&V.cnt[r[i]], 1u) : 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t t = t0 + 256u * (uint32_t)i;
+            if (!on[i]) continue;
+            V.rk[t] = k[i];
+            if (r[i] != t) V.par[t] = r[i];   // (a walk through t meanwhile meets the old parent or the root: both are ancestors)
         }
     }
 }
 
-// 5. a wave per cell: the lone vertices' two-gene classes (k_p2_lone staged them at their partitions' slots) into the cell's label
-//    area, and the cell's counters as the covers start from them (em only for the classes; always for the counters).
-__global__ __launch_bounds__(256) void k_pf_classes(P2Args A) {
+// 4. a workgroup per tile: the size classes of the components its roots head -> the tile's five counts.  A cell that holds a
+//    component for the per-cell kernel is flagged (its tiles then count nothing in the scan).
+__global__ __launch_bounds__(256) void k_pf_cats(P2Args A) {
     if (A.st->err_code) return;
-    const uint32_t j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = lane_id();
-    if (j >= A.n_cells || A.fb[j] || A.pfc[j].route) return;   // (the per-cell kernel moves the classes of the cells routed to it itself)
+    __shared__ uint32_t s_c[5];
+    const uint32_t i = blockIdx.x, j = A.tiles[i].x, lane = lane_id();
+    if (threadIdx.x < 5) s_c[threadIdx.x] = 0;
+    __syncthreads();
+    if (!A.fb[j]) {
+        const PfV V = pf_v(A);
+        const uint32_t tb = pf_g(A, kQTouched, i), te = pf_g(A, kQTouched, i + 1);
+        bool big = false;
+        for (uint32_t t0 = tb; t0 < te; t0 += 256) {   // (uniform)
+            const uint32_t t = t0 + threadIdx.x;
+            const bool root = t < te && V.par[t] == t;
+            const uint32_t n = root ? V.cnt[t] : 0u;
+            const uint32_t cat = root ? cat_of(n, A.large_thresh) : 0u;
+            big = big || (root && cat == 0);
+            const uint32_t npr = (uint32_t)__popcll(__ballot(cat == kFCatPair)), nti = (uint32_t)__popcll(__ballot(cat == kFCatTiny)), nmi = (uint32_t)__popcll(__ballot(cat == kFCatMid));
+            uint32_t sti = cat == kFCatTiny ? n : 0u, smi = cat == kFCatMid ? n : 0u;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) { sti += __shfl_xor(sti, d); smi += __shfl_xor(smi, d); }
+            if (lane == 0) {
+                if (npr) atomicAdd(&s_c[0], npr);
+                if (nti) { atomicAdd(&s_c[1], nti); atomicAdd(&s_c[3], sti); }
+                if (nmi) { atomicAdd(&s_c[2], nmi); atomicAdd(&s_c[4], smi); }
+            }
+        }
+        if (__any(big) && lane == 0) A.route[j] = 1;   // (the same word from every tile that finds one: any of them will do)
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) A.tq[(size_t)(kQPr + threadIdx.x) * A.nta + i] = s_c[threadIdx.x];
+}
+
+// 5. The lone vertices' two-gene classes (em only): k_p2_lone staged them at their partitions' slots, a count per partition.  The scan
+//    of the counts over the range's partitions (two levels, as for the tiles; a cell's partitions are consecutive) says where a
+//    partition's classes go in its cell's label area; a thread per partition moves them.
+__device__ __forceinline__ uint32_t pf_pc(const P2Args& A, uint32_t gp) { return A.pcpre[gp] + A.pbq[gp >> 10]; }   // staged classes in front of partition gp (gp = n_parts: all)
+__global__ __launch_bounds__(1024) void k_pf_pscan1(P2Args A) {
+    if (A.st->err_code) return;
+    __shared__ uint32_t s_ws[16];
+    const uint32_t gp = blockIdx.x * 1024 + threadIdx.x;
+    const uint32_t v = gp < A.n_parts ? A.pncls[gp] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan<1024>(v, s_ws, tot);
+    A.pcpre[gp] = ex;
+    if (threadIdx.x == 0) A.pbq[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(1024) void k_pf_pscan2(P2Args A) {
+    if (A.st->err_code) return;
+    __shared__ uint32_t s_ws[16];
+    const uint32_t nb = (A.n_parts + 1 + 1023) / 1024;
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < nb; b0 += 1024) {
+        const uint32_t b = b0 + threadIdx.x;
+        const uint32_t v = b < nb ? A.pbq[b] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<1024>(v, s_ws, tot);
+        if (b < nb) A.pbq[b] = carry + ex;
+        carry += tot;
+    }
+}
+__global__ __launch_bounds__(256) void k_pf_move(P2Args A) {
+    if (A.st->err_code) return;
+    for (uint32_t gp = blockIdx.x * 256 + threadIdx.x; gp < A.n_parts; gp += gridDim.x * 256) {
+        const uint32_t nk = A.pncls[gp];
+        if (!nk) continue;
+        const uint32_t j = A.pcell[gp];
+        if (A.fb[j] || A.route[j]) continue;   // (the per-cell kernel moves the classes of the cells routed to it itself)
+        const P2Cell& c = A.cells[j];
+        const uint32_t* gc = A.gcnt + 4 * (size_t)j;
+        const uint32_t at = pf_pc(A, gp) - pf_pc(A, c.part_base), w0 = gc[1], d0 = gc[2], lab_cap = c.n_ref + 1;
+        uint32_t* labw = A.lab + 2 * c.key_off;
+        uint32_t* labd = labw + c.n_ref + 1;
+        const uint64_t* stage = A.cstage + c.rd_base + A.poff[gp];
+        for (uint32_t k = 0; k < nk; ++k) {
+            const uint64_t v = stage[k];
+            const uint32_t w = w0 + 2 * (at + k), d = d0 + at + k;
+            if (w + 2 > lab_cap || 2 * (d + 1) > lab_cap) break;   // (k_pf_cells reports it)
+            labw[w] = (uint32_t)v; labw[w + 1] = (uint32_t)(v >> 32);
+            labd[2 * d] = w; labd[2 * d + 1] = 2;
+        }
+    }
+}
+
+// ... and a thread per cell: the descriptor the cover kernels read (the same words the per-cell graph kernel leaves) and the cell's
+//    counters as the covers start from them.  A cell k_p2_scan handed back goes onto the one-workgroup kernel's list, a cell with a
+//    component of more than 64 vertices onto the per-cell graph kernel's.
+__global__ __launch_bounds__(256) void k_pf_cells(P2Args A) {
+    if (A.st->err_code) return;
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= A.n_cells) return;
     const P2Cell c = A.cells[j];
+    PfDev& D = *A.pfd;
+    if (A.fb[j]) { A.fb_list[atomicAdd(A.fb_count, 1u)] = c.cell; return; }   // (a partition over the capacity)
+    if (A.route[j]) { A.old_list[atomicAdd(&D.n_old, 1u)] = j; return; }       // (it moves its classes and writes its descriptor itself)
     uint32_t* gc = A.gcnt + 4 * (size_t)j;
     uint32_t w0 = gc[1], d0 = gc[2];
     if (A.em && A.lab) {
-        uint32_t* labw = A.lab + 2 * c.key_off;
-        uint32_t* labd = labw + c.n_ref + 1;
-        const uint32_t lab_cap = c.n_ref + 1;
-        const uint64_t* stage = A.cstage + c.rd_base;
-        const uint32_t P = 1u << c.lgP;
-        bool over = false;
-        for (uint32_t base = 0; base < P; base += 64) {
-            const uint32_t pp = base + lane;
-            const uint32_t nk = pp < P ? A.pncls[c.part_base + pp] : 0u;
-            uint32_t tot;
-            const uint32_t at = wave_excl_scan(nk, tot);
-            if (tot == 0) continue;
-            if (w0 + 2 * tot > lab_cap || 2 * (d0 + tot) > lab_cap) { over = true; break; }
-            const uint32_t so = nk ? A.poff[c.part_base + pp] : 0u;
-            for (uint32_t k = 0; k < nk; ++k) {
-                const uint64_t v = stage[so + k];
-                const uint32_t w = w0 + 2 * (at + k), d = d0 + at + k;
-                labw[w] = (uint32_t)v; labw[w + 1] = (uint32_t)(v >> 32);
-                labd[2 * d] = w; labd[2 * d + 1] = 2;
-            }
-            w0 += 2 * tot; d0 += tot;
-        }
-        if (over) { if (lane == 0) set_err(A.st, kErrPugLimit, c.cell); return; }
+        const uint32_t tot = pf_pc(A, c.part_base + (1u << c.lgP)) - pf_pc(A, c.part_base), lab_cap = c.n_ref + 1;
+        if (w0 + 2 * tot > lab_cap || 2 * (d0 + tot) > lab_cap) { set_err(A.st, kErrPugLimit, c.cell); return; }
+        w0 += 2 * tot; d0 += tot;
     }
-    if (lane == 0) { gc[0] = c.R; gc[1] = w0; gc[2] = d0; }   // (entries 0..R of the column list belong to the lone-vertex kernel)
+    gc[0] = c.R; gc[1] = w0; gc[2] = d0;   // (entries 0..R of the column list belong to the lone-vertex kernel)
+    const uint32_t i0 = c.tile0, i1 = c.tile0 + (c.R + A.tile - 1) / A.tile;
+    const uint32_t pr0 = pf_g(A, kQPr, i0), ti0 = pf_g(A, kQTiny, i0), mi0 = pf_g(A, kQMid, i0);
+    const uint32_t n_pr = pf_g(A, kQPr, i1) - pr0, n_tiny = pf_g(A, kQTiny, i1) - ti0, n_mid = pf_g(A, kQMid, i1) - mi0;
+    const uint32_t comp_base = ti0 + mi0;
+    uint32_t* d = A.gdesc + kGDescWords * (size_t)j;
+    auto put = [&](int at, unsigned long long o) { d[at] = (uint32_t)o; d[at + 1] = (uint32_t)(o >> 32); };
+    const unsigned long long tied = D.tied + 4ull * (j + comp_base);
+    d[1] = n_pr; d[2] = n_tiny; d[3] = n_tiny + n_mid; d[15] = 0;
+    d[4] = 0xFFFFFFFFu; d[5] = 0xFFFFFFFFu;   // (no table from touched-vertex numbers to slots)
+    put(6, D.prv + 2ull * pr0); put(8, D.midoff + comp_base); put(10, D.mrec); put(16, tied);
+    d[12] = c.R; d[13] = w0; d[14] = d0;
+    uint32_t* tp = A.pool + tied;
+    tp[0] = 0; tp[1] = 0; tp[2] = 0; tp[3] = 0;
+    d[0] = 3u;   // the lists are there, in slot order (kCoverDefer)
 }
 
-// 6. one workgroup: the cells' counts -> where every cell's components and record slots lie in the range-wide lists, the lists out
-//    of the pool, the descriptors the cover kernels read (the same sixteen-plus words per cell the per-cell graph kernel leaves).
-__global__ __launch_bounds__(1024) void k_pf_cscan(P2Args A) {
-    if (A.st->err_code) return;
-    __shared__ uint32_t s_ws[16];
-    __shared__ uint32_t s_ok;
-    __shared__ unsigned long long s_off[4];   // mrec, prv, midoff, tied
-    PfDev& D = *A.pfd;
-    uint32_t c_pr = 0, c_comp = 0, c_slot = 0;
-    for (uint32_t b = 0; b < A.n_cells; b += 1024) {
-        const uint32_t j = b + threadIdx.x;
-        uint32_t npr = 0, ncomp = 0, nslot = 0;
-        if (j < A.n_cells) {
-            PfCell& pc = A.pfc[j];
-            const bool fbk = A.fb[j] != 0, old = !fbk && pc.route != 0;
-            if (fbk || old) { pc.n_pr = 0; pc.n_tiny = 0; pc.n_mid = 0; pc.S_tiny = 0; pc.S_mid = 0; }
-            if (fbk) A.fb_list[atomicAdd(A.fb_count, 1u)] = A.cells[j].cell;   // (k_p2_scan flagged it: a partition over the capacity)
-            if (old) A.old_list[atomicAdd(&D.n_old, 1u)] = j;
-            npr = pc.n_pr; ncomp = pc.n_tiny + pc.n_mid; nslot = pc.S_tiny + pc.S_mid;
-        }
-        uint32_t t0, t1, t2;
-        const uint32_t e0 = block_excl_scan<1024>(npr, s_ws, t0);
-        const uint32_t e1 = block_excl_scan<1024>(ncomp, s_ws, t1);
-        const uint32_t e2 = block_excl_scan<1024>(nslot, s_ws, t2);
-        if (j < A.n_cells) { PfCell& pc = A.pfc[j]; pc.pr_base = c_pr + e0; pc.comp_base = c_comp + e1; pc.slot_base = c_slot + e2; }
-        c_pr += t0; c_comp += t1; c_slot += t2;
-    }
-    if (threadIdx.x == 0) {
-        const unsigned long long NP = c_pr, NC = c_comp, S = c_slot;
-        const unsigned long long words = 2 * NP + 4 + (NC + 4) + 8 * S + 8 + 4 * (NC + A.n_cells) + 8;
-        const unsigned long long base = atomicAdd(A.pool_cur, words);
-        s_ok = base + words <= A.pool_cap;
-        if (!s_ok) set_err(A.st, kErrPugPool, 0);
-        else {
-            unsigned long long o = (base + 3) & ~3ull;
-            D.mrec = o; o += 8 * S + 4;            // (16-byte aligned: uint4 records)
-            D.prv = o; o += 2 * NP + 2;
-            D.midoff = o; o += NC + 2;
-            o = (o + 3) & ~3ull;
-            D.tied = o;
-            D.NP = (uint32_t)NP; D.NC = (uint32_t)NC; D.S = (uint32_t)S;
-            A.pool[D.midoff + NC] = (uint32_t)S;   // the list's last offset
-            s_off[0] = D.mrec; s_off[1] = D.prv; s_off[2] = D.midoff; s_off[3] = D.tied;
-        }
-    }
-    __syncthreads();
-    if (!s_ok) return;
-    for (uint32_t j = threadIdx.x; j < A.n_cells; j += 1024) {
-        const PfCell& pc = A.pfc[j];
-        if (A.fb[j] || pc.route) continue;   // handed back (descriptor stays 0), or the per-cell graph kernel writes it
-        uint32_t* d = A.gdesc + kGDescWords * (size_t)j;
-        auto put = [&](int at, unsigned long long o) { d[at] = (uint32_t)o; d[at + 1] = (uint32_t)(o >> 32); };
-        const unsigned long long tied = s_off[3] + 4ull * (j + pc.comp_base);
-        d[1] = pc.n_pr; d[2] = pc.n_tiny; d[3] = pc.n_tiny + pc.n_mid; d[15] = 0;
-        d[4] = 0xFFFFFFFFu; d[5] = 0xFFFFFFFFu;   // (no table from touched-vertex numbers to slots: the lists hold slots)
-        put(6, s_off[1] + 2ull * pc.pr_base); put(8, s_off[2] + pc.comp_base); put(10, s_off[0]); put(16, tied);
-        const uint32_t* gc = A.gcnt + 4 * (size_t)j;
-        d[12] = gc[0]; d[13] = gc[1]; d[14] = gc[2];
-        uint32_t* tp = A.pool + tied;
-        tp[0] = 0; tp[1] = 0; tp[2] = 0; tp[3] = 0;
-        d[0] = 3u;   // the lists are there, in slot order (kCoverDefer)
-    }
-}
-
-// 7. one thread per root: its component's entry of its cell's run of the lists, its record slots
+// 6. a workgroup per tile: its roots take their entries of the cell's run of the lists and their record slots - where the scans of
+//    the tile counts say, in slot order inside the tile (two packed scans per 256 roots: counts of the three classes, record slots)
 __global__ __launch_bounds__(256) void k_pf_alloc(P2Args A) {
     if (A.st->err_code) return;
+    __shared__ uint32_t s_ws[4];
+    const uint32_t i = blockIdx.x, j = A.tiles[i].x;
+    if (A.fb[j]) return;
     const PfV V = pf_v(A);
-    const PfDev& D = *A.pfd;
-    uint32_t* mid_off = A.pool + D.midoff;
-    const uint32_t lane = lane_id();
-    for (uint32_t t0 = (blockIdx.x * 256 + threadIdx.x) & ~63u; t0 < V.T; t0 += gridDim.x * 256) {
-        const uint32_t t = t0 + lane;
-        const bool root = t < V.T && V.par[t] == t;
-        const uint32_t n = root ? V.cnt[t] : 0u, j = root ? V.tcell[t] : 0u;
-        uint32_t cat = root ? cat_of(n, A.large_thresh) : 0u;
-        uint32_t where = 0;
-        for (uint64_t left = __ballot(root); left;) {
-            const uint32_t jj = (uint32_t)__builtin_amdgcn_readlane((int)j, (int)__builtin_ctzll(left));
-            const bool mine = root && j == jj;
-            left &= ~__ballot(mine);
-            PfCell* pc = A.pfc + jj;
-            if (pc->route) { if (mine) cat = 0; continue; }   // (the cell is the per-cell kernel's)
-            // one reservation per wave, cell and size class: components | record slots << 32
-            auto take = [&](bool on, uint32_t sz, unsigned long long* ctr, uint32_t& idx, uint32_t& sl) {
-                const uint64_t m = __ballot(on);
-                if (!m) return;
-                uint32_t tot;
-                const uint32_t ex = wave_excl_scan(on ? sz : 0u, tot);
-                unsigned long long b0 = 0;
-                const uint32_t leader = (uint32_t)__builtin_ctzll(m);
-                if (lane == leader) b0 = atomicAdd(ctr, (unsigned long long)__popcll(m) | ((unsigned long long)tot << 32));
-                const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b0, (int)leader), bhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b0 >> 32), (int)leader);
-                idx = blo + (uint32_t)__popcll(m & ((1ull << lane) - 1)); sl = bhi + ex;
-            };
-            uint32_t idx = 0, sl = 0;
-            take(mine && cat == kFCatPair, 2u, &pc->fill_pr, idx, sl);
-            if (mine && cat == kFCatPair) where = 2 * (pc->pr_base + idx);
-            take(mine && cat == kFCatTiny, n, &pc->fill_tiny, idx, sl);
-            if (mine && cat == kFCatTiny) { where = pc->slot_base + sl; mid_off[pc->comp_base + idx] = where; }
-            take(mine && cat == kFCatMid, n, &pc->fill_mid, idx, sl);
-            if (mine && cat == kFCatMid) { where = pc->slot_base + pc->S_tiny + sl; mid_off[pc->comp_base + pc->n_tiny + idx] = where; }
+    const uint32_t tb = pf_g(A, kQTouched, i), te = pf_g(A, kQTouched, i + 1);
+    if (A.route[j]) {   // the per-cell kernel's: no entry, no record
+        for (uint32_t t = tb + threadIdx.x; t < te; t += 256) if (V.par[t] == t) { V.cnt[t] = 0; V.rk[t] &= kRankMask; }
+        return;
+    }
+    const P2Cell& c = A.cells[j];
+    const uint32_t i0 = c.tile0, i1 = c.tile0 + (c.R + A.tile - 1) / A.tile;
+    const uint32_t ti0 = pf_g(A, kQTiny, i0), mi0 = pf_g(A, kQMid, i0), sti0 = pf_g(A, kQSTiny, i0), smi0 = pf_g(A, kQSMid, i0);
+    const uint32_t n_tiny = pf_g(A, kQTiny, i1) - ti0, S_tiny = pf_g(A, kQSTiny, i1) - sti0;
+    const uint32_t comp_base = ti0 + mi0, slot_base = sti0 + smi0;
+    uint32_t c_pr = pf_g(A, kQPr, i);                                      // next pair entry (range-wide)
+    uint32_t c_ti = comp_base + (pf_g(A, kQTiny, i) - ti0), c_mi = comp_base + n_tiny + (pf_g(A, kQMid, i) - mi0);   // next list entries
+    uint32_t s_ti = slot_base + (pf_g(A, kQSTiny, i) - sti0), s_mi = slot_base + S_tiny + (pf_g(A, kQSMid, i) - smi0);   // next record slots
+    uint32_t* mid_off = A.pool + A.pfd->midoff;
+    for (uint32_t t0 = tb; t0 < te; t0 += 256) {   // (uniform)
+        const uint32_t t = t0 + threadIdx.x;
+        const bool root = t < te && V.par[t] == t;
+        const uint32_t n = root ? V.cnt[t] : 0u;
+        const uint32_t cat = root ? cat_of(n, A.large_thresh) : 0u;
+        // (up to 256 roots per trip: three 10-bit counts in one word; record slots: <= 2048 and <= 16384)
+        const uint32_t vc = (cat == kFCatPair ? 1u : 0u) | (cat == kFCatTiny ? 1u << 10 : 0u) | (cat == kFCatMid ? 1u << 20 : 0u);
+        const uint32_t vs = (cat == kFCatTiny ? n : 0u) | (cat == kFCatMid ? n << 12 : 0u);
+        uint32_t totc, tots;
+        const uint32_t exc = block_excl_scan<256>(vc, s_ws, totc);
+        const uint32_t exs = block_excl_scan<256>(vs, s_ws, tots);
+        if (root) {
+            uint32_t where = 0;
+            if (cat == kFCatPair) where = 2 * (c_pr + (exc & 0x3FFu));
+            else if (cat == kFCatTiny) { where = s_ti + (exs & 0xFFFu); mid_off[c_ti + ((exc >> 10) & 0x3FFu)] = where; }
+            else if (cat == kFCatMid) { where = s_mi + (exs >> 12); mid_off[c_mi + (exc >> 20)] = where; }
+            V.cnt[t] = where;
+            V.rk[t] = (V.rk[t] & kRankMask) | (cat << kCatShift);
         }
-        if (root) { V.cnt[t] = where; V.rk[t] = (V.rk[t] & kRankMask) | (cat << kCatShift); }
+        c_pr += totc & 0x3FFu; c_ti += (totc >> 10) & 0x3FFu; c_mi += totc >> 20;
+        s_ti += tots & 0xFFFu; s_mi += tots >> 12;
     }
 }
 
-// 8. one thread per vertex: into the pair list, or its 32-byte cover record (vertex slot, label length, up to four refs - a longer
-//    label: where it lies in the chunk -, adjacency mask, filled by k_pf_adj)
+// 7. one thread per vertex (two to a thread and trip): into the pair list, or its 32-byte cover record (vertex slot, label length, up to
+//    four refs - a longer label: where it lies in the chunk -, adjacency mask, filled by k_pf_adj).  Everything it reads is dense.
 __global__ __launch_bounds__(256) void k_pf_place(P2Args A) {
     if (A.st->err_code) return;
     const PfV V = pf_v(A);
     const PfDev& D = *A.pfd;
     uint32_t* pr_v = A.pool + D.prv;
     uint4* mrec = reinterpret_cast<uint4*>(A.pool + D.mrec);
-    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < V.T; t += gridDim.x * 256) {
-        const uint32_t r = V.par[t];
-        const uint32_t rkr = V.rk[r], cat = rkr >> kCatShift;
-        if (!cat) continue;
-        const uint32_t where = V.cnt[r], k = V.rk[t] & kRankMask;
-        const P2Cell& c = A.cells[V.tcell[t]];
-        const uint32_t s = V.tl[t], g = s - (uint32_t)c.rd_base;
-        if (cat == kFCatPair) { pr_v[where + k] = g; continue; }
-        const uint32_t* W = reinterpret_cast<const uint32_t*>(A.bytes + c.chunk_off);
-        const KLab l = klab(W, A.hw, A.s_h[s], A.v_off[s]);
-        uint32_t r0 = 0xFFFFFFFFu, r1 = 0xFFFFFFFFu, r2 = 0xFFFFFFFFu, r3 = 0xFFFFFFFFu;
-        if (l.n <= 4) {
-            if (l.n > 0) r0 = klab_ref(l, 0);
-            if (l.n > 1) r1 = klab_ref(l, 1);
-            if (l.n > 2) r2 = l.p[2] & 0x7FFFFFFFu;
-            if (l.n > 3) r3 = l.p[3] & 0x7FFFFFFFu;
-        } else { const uint64_t pa = (uint64_t)(uintptr_t)l.p; r0 = (uint32_t)pa; r1 = (uint32_t)(pa >> 32); }
-        const size_t at = (size_t)where + k;
-        mrec[2 * at] = make_uint4(g, l.n, r0, r1);
-        mrec[2 * at + 1] = make_uint4(r2, r3, 0u, 0u);
+    for (uint32_t t0 = blockIdx.x * 512 + threadIdx.x; t0 < V.T; t0 += gridDim.x * 512) {
+        uint32_t r[2], where[2], cat[2], kk[2], off[2], g[2];
+        uint64_t h[2];
+        bool on[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { const uint32_t t = t0 + 256u * (uint32_t)q; on[q] = t < V.T; r[q] = on[q] ? V.par[t] : 0u; kk[q] = on[q] ? V.rk[t] & kRankMask : 0u; h[q] = on[q] ? V.lh[t] : 0ull; off[q] = on[q] ? V.loff[t] : 0u; g[q] = on[q] ? V.tl[t] : 0u; }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { where[q] = on[q] ? V.cnt[r[q]] : 0u; cat[q] = on[q] ? V.rk[r[q]] >> kCatShift : 0u; }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (!on[q]) continue;
+            const uint32_t t = t0 + 256u * (uint32_t)q;
+            if (cat[q] != kFCatTiny && cat[q] != kFCatMid) {
+                V.pos[t] = kNoPos;
+                if (cat[q] == kFCatPair) pr_v[where[q] + kk[q]] = t;   // (the dense number: the two-vertex rule reads the label out of the dense arrays)
+                continue;
+            }
+            uint32_t n = (uint32_t)(h[q] >> 62), r0 = 0xFFFFFFFFu, r1 = 0xFFFFFFFFu, r2 = 0xFFFFFFFFu, r3 = 0xFFFFFFFFu;
+            if (n == 1) r0 = (uint32_t)h[q] & 0x7FFFFFFFu;
+            else if (n == 2) { r0 = (uint32_t)(h[q] >> 31) & 0x7FFFFFFFu; r1 = (uint32_t)h[q] & 0x7FFFFFFFu; }
+            else if (n == 3) {   // a hashed key: the label lies in its record
+                const P2Cell& c = A.cells[V.tcell[t]];
+                const uint32_t* W = reinterpret_cast<const uint32_t*>(A.bytes + c.chunk_off);
+                n = W[off[q]];
+                const uint32_t* lp = W + off[q] + A.hw;
+                if (n <= 4) { r0 = lp[0] & 0x7FFFFFFFu; r1 = lp[1] & 0x7FFFFFFFu; r2 = lp[2] & 0x7FFFFFFFu; if (n > 3) r3 = lp[3] & 0x7FFFFFFFu; }
+                else { const uint64_t pa = (uint64_t)(uintptr_t)lp; r0 = (uint32_t)pa; r1 = (uint32_t)(pa >> 32); }
+            }
+            const size_t at = (size_t)where[q] + kk[q];
+            V.pos[t] = (uint32_t)at;
+            mrec[2 * at] = make_uint4(g[q], n, r0, r1);
+            mrec[2 * at + 1] = make_uint4(r2, r3, 0u, 0u);
+        }
     }
 }
 
-// 9. one thread per pair once more: its directions into the adjacency masks of its end points' records (pairs of a two-vertex
+// 8. one thread per pair once more: its directions into the adjacency masks of its end points' records (pairs of a two-vertex
 //    component need none: the two-vertex rule does not look at directions)
 __global__ __launch_bounds__(256) void k_pf_adj(P2Args A) {
     if (A.st->err_code) return;
@@ -439,17 +574,120 @@ __global__ __launch_bounds__(256) void k_pf_adj(P2Args A) {
     __shared__ uint32_t s_ws[4];
     const PfV V = pf_v(A);
     uint4* mrec = reinterpret_cast<uint4*>(A.pool + A.pfd->mrec);
-    pf_for_each_pair(A, s_start, s_src, s_rdb, s_ws, [&](uint64_t* sp, uint32_t) {
-        const uint64_t e = *sp;
-        const uint32_t tx = (uint32_t)(e >> 31) & 0x7FFFFFFFu, ty = (uint32_t)e & 0x7FFFFFFFu;
-        const uint32_t r = V.par[tx];
-        const uint32_t cat = V.rk[r] >> kCatShift;
-        if (cat != kFCatTiny && cat != kFCatMid) return;
-        const size_t b0 = V.cnt[r];
-        const uint32_t kx = V.rk[tx] & kRankMask, ky = V.rk[ty] & kRankMask;
-        if (e & kPairF) __hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(&mrec[2 * (b0 + kx) + 1].z), 1ull << ky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // x -> y
-        if (e & kPairB) __hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(&mrec[2 * (b0 + ky) + 1].z), 1ull << kx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // y -> x
+    pf_for_each_pair4(A, s_start, s_src, s_rdb, s_ws, [&](uint64_t* (&sp)[4], uint32_t (&)[4]) {
+        uint64_t e[4];
+        uint32_t px[4], py[4], kx[4], ky[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = sp[r] ? *sp[r] : 0ull;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t tx = (uint32_t)(e[r] >> 31) & 0x7FFFFFFFu, ty = (uint32_t)e[r] & 0x7FFFFFFFu;
+            px[r] = sp[r] ? V.pos[tx] : kNoPos; py[r] = sp[r] ? V.pos[ty] : kNoPos;
+            kx[r] = sp[r] ? V.rk[tx] & kRankMask : 0u; ky[r] = sp[r] ? V.rk[ty] & kRankMask : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (px[r] == kNoPos || py[r] == kNoPos) continue;
+            if (e[r] & kPairF) __hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(&mrec[2 * (size_t)px[r] + 1].z), 1ull << ky[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // x -> y
+            if (e[r] & kPairB) __hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(&mrec[2 * (size_t)py[r] + 1].z), 1ull << kx[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // y -> x
+        }
     });
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// 9. the covers, a workgroup per TILE: the two-vertex rule and the arborescence covers (afq_pug_common.h, unchanged in rule) over the
+//    components the tile's roots head - its slice of the cell's pair list, of the 3..8 list (eight components to a wave) and of the
+//    9..64 list (a wave each).  Rounds 4-5 gave a cell's components to ONE workgroup (k_p2_cover: a 36 000-read cell's 3 800
+//    components one batch after the other, 1024 threads and a CU to itself); a cell's ~9 tiles now run side by side, eight workgroups
+//    to a CU.  Columns and classes go to the cell's lists through its counters in global memory (one reservation per wave and
+//    batch); a component whose round meets a tie is set aside on the cell's list for k_p2_tied, as before.
+struct PcTile {   // what a cover workgroup needs of its tile
+    uint32_t j, n_tiny, comp_base, p0, n_pr, a0, na, b0, nb;
+};
+__device__ __forceinline__ PcTile pc_tile(const P2Args& A, const P2Cell& c, uint32_t i, uint32_t j) {
+    PcTile t;
+    const uint32_t i0 = c.tile0, i1 = c.tile0 + (c.R + A.tile - 1) / A.tile;
+    const uint32_t ti0 = pf_g(A, kQTiny, i0), mi0 = pf_g(A, kQMid, i0);
+    t.j = j; t.n_tiny = pf_g(A, kQTiny, i1) - ti0; t.comp_base = ti0 + mi0;
+    t.p0 = pf_g(A, kQPr, i); t.n_pr = pf_g(A, kQPr, i + 1) - t.p0;
+    t.a0 = pf_g(A, kQTiny, i) - ti0; t.na = pf_g(A, kQTiny, i + 1) - ti0 - t.a0;                      // the tile's slice of the cell's 3..8 list
+    t.b0 = t.n_tiny + (pf_g(A, kQMid, i) - mi0); t.nb = t.n_tiny + (pf_g(A, kQMid, i + 1) - mi0) - t.b0;   // ... of its 9..64 list
+    return t;
+}
+// (three kernels, not one: together they were 104 VGPRs and four waves per SIMD - the two-vertex rule alone runs at eight)
+__global__ __launch_bounds__(256) void k_pc_pairs(P2Args A) {
+    if (A.st->err_code) return;
+    __shared__ uint32_t s_stage[4][64 * kStageRefs];
+    const uint32_t i = blockIdx.x, j = A.tiles[i].x;
+    if (A.fb[j] || A.route[j]) return;
+    const P2Cell c = A.cells[j];
+    const PfDev& D = *A.pfd;
+    const PugCtx C = make_ctx(A, c, A.gcnt + 4 * (size_t)j);
+    const uint32_t p0 = pf_g(A, kQPr, i), n_pr = pf_g(A, kQPr, i + 1) - p0;
+    // (the list holds dense numbers, the labels' keys lie in the dense arrays)
+    p2_cover_pairs<256>(C, reinterpret_cast<const uint64_t*>(A.pool + D.lh), A.pool + D.loff, nullptr, A.pool + D.prv + 2ull * p0, n_pr, s_stage[threadIdx.x >> 6]);
+}
+__global__ __launch_bounds__(256) void k_pc_small(P2Args A) {
+    if (A.st->err_code) return;
+    __shared__ uint32_t s_stage[4][64 * kStageRefs];
+    __shared__ uint16_t s_slow[1368];   // (a tile of 4096 slots holds at most 1365 components of three vertices)
+    __shared__ uint32_t s_nslow;
+    const uint32_t i = blockIdx.x, j = A.tiles[i].x;
+    if (A.fb[j] || A.route[j]) return;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_nslow = 0;
+    __syncthreads();
+    const P2Cell c = A.cells[j];
+    const PfDev& D = *A.pfd;
+    const PugCtx C = make_ctx(A, c, A.gcnt + 4 * (size_t)j);
+    const PcTile T = pc_tile(A, c, i, j);
+    const uint4* mrec = reinterpret_cast<const uint4*>(A.pool + D.mrec);
+    const uint32_t* mid_off = A.pool + D.midoff + T.comp_base;
+    uint32_t* const tied = A.pool + D.tied + 4ull * (j + T.comp_base);
+    // components of 3..4 vertices under short labels: a lane each (cover_lane4); what is left - five vertices or more, a label of more
+    // than four refs - eight to a wave as before
+    for (uint32_t c0 = wv * 64; c0 < T.na; c0 += 256) {   // (uniform per wave)
+        const uint32_t ci = c0 + lane;
+        uint32_t b0c = 0, n = 0;
+        if (ci < T.na) { b0c = mid_off[T.a0 + ci]; n = mid_off[T.a0 + ci + 1] - b0c; }
+        bool fast = n != 0 && n <= 4;
+        if (fast) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) if ((uint32_t)v < n) fast = fast && mrec[2 * (size_t)(b0c + v)].y <= 4;
+        }
+        if (n != 0 && !fast) s_slow[atomicAdd(&s_nslow, 1u)] = (uint16_t)ci;
+        cover_lane4<kCoverDefer>(C, mrec, b0c, fast ? n : 0u, 0xFu, T.a0 + ci, tied, tied + 4);
+    }
+    __syncthreads();
+    cover_tiny8<4, kCoverDefer>(C, mrec, mid_off + T.a0, s_nslow, wv, lane, tied, tied + 4, s_stage[wv], T.a0, s_slow);
+}
+__global__ __launch_bounds__(256) void k_pc_mid(P2Args A) {
+    if (A.st->err_code) return;
+    __shared__ uint32_t s_stage[4][64 * kStageRefs];
+    const uint32_t i = blockIdx.x, j = A.tiles[i].x;
+    if (A.fb[j] || A.route[j]) return;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const P2Cell c = A.cells[j];
+    const PcTile T = pc_tile(A, c, i, j);
+    if (!T.nb) return;
+    const PfDev& D = *A.pfd;
+    const PugCtx C = make_ctx(A, c, A.gcnt + 4 * (size_t)j);
+    const uint4* mrec = reinterpret_cast<const uint4*>(A.pool + D.mrec);
+    const uint32_t* mid_off = A.pool + D.midoff + T.comp_base;
+    uint32_t* const tied = A.pool + D.tied + 4ull * (j + T.comp_base);
+    cover_wave64<4, kCoverDefer>(C, mrec, mid_off + T.b0, 0u, T.nb, wv, lane, tied + 1, tied + 4 + 4 * (size_t)T.n_tiny, s_stage[wv], T.b0);
+}
+// ... and a thread per cell: what the covers left in the cell's counters (an error of theirs, the lengths of its column list and
+// label area) to where the kernels behind them read it
+__global__ __launch_bounds__(256) void k_pc_finish(P2Args A) {
+    if (A.st->err_code) return;
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= A.n_cells || A.fb[j] || A.route[j]) return;
+    const uint32_t* gc = A.gcnt + 4 * (size_t)j;
+    const uint32_t cell = A.cells[j].cell;
+    if (gc[3]) { set_err(A.st, gc[3], cell); return; }
+    A.cell_ncols[cell] = gc[0];
+    if (A.lab_cnt) { A.lab_cnt[2 * cell] = gc[1]; A.lab_cnt[2 * cell + 1] = gc[2]; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -457,19 +695,33 @@ static uint32_t pf_grid(uint64_t items_upper, uint32_t per_wg) { const uint64_t 
 
 void launch_pf_build(hipStream_t s, const P2Args& a, uint64_t n_reads) {
     if (!a.n_cells) return;
+    const uint32_t nb = (a.n_tiles + 1 + 1023) / 1024;
     AFQ_LAUNCH(k_pf_count, a.n_tiles, 256, s, a);
-    AFQ_LAUNCH(k_pf_tscan, 1, 1024, s, a);
+    AFQ_LAUNCH(k_pf_scan1<1>, nb, 1024, s, a, 0u);
+    AFQ_LAUNCH(k_pf_scan2<1>, 1, 1024, s, a, 0u);
     AFQ_LAUNCH(k_pf_number, a.n_tiles, 256, s, a);
     AFQ_LAUNCH(k_pf_union, pf_grid(a.n_parts, 256), 256, s, a);
-    // (T is known on the device only: grids from the reads, an upper bound of it; the kernels walk to T)
-    const uint32_t gv = pf_grid(n_reads / 4 + 1, 256);
-    AFQ_LAUNCH(k_pf_root, gv, 256, s, a);
-    AFQ_LAUNCH(k_pf_cats, gv, 256, s, a);
-    AFQ_LAUNCH(k_pf_classes, (a.n_cells + 3) / 4, 256, s, a);
-    AFQ_LAUNCH(k_pf_cscan, 1, 1024, s, a);
-    AFQ_LAUNCH(k_pf_alloc, gv, 256, s, a);
-    AFQ_LAUNCH(k_pf_place, gv, 256, s, a);
+    // (T is known on the device only: the grid from the reads, an upper bound of it; the kernel walks to T)
+    AFQ_LAUNCH(k_pf_root, pf_grid(n_reads / 4 + 1, 1024), 256, s, a);
+    AFQ_LAUNCH(k_pf_cats, a.n_tiles, 256, s, a);
+    AFQ_LAUNCH(k_pf_scan1<5>, nb, 1024, s, a, 1u);
+    AFQ_LAUNCH(k_pf_scan2<5>, 1, 1024, s, a, 1u);
+    if (a.em && a.lab) {
+        AFQ_LAUNCH(k_pf_pscan1, a.npa / 1024, 1024, s, a);
+        AFQ_LAUNCH(k_pf_pscan2, 1, 1024, s, a);
+        AFQ_LAUNCH(k_pf_move, pf_grid(a.n_parts, 256), 256, s, a);   // (gcnt[1], [2] still hold what k_p2_lone left: k_pf_cells raises them afterwards)
+    }
+    AFQ_LAUNCH(k_pf_cells, (a.n_cells + 255) / 256, 256, s, a);
+    AFQ_LAUNCH(k_pf_alloc, a.n_tiles, 256, s, a);
+    AFQ_LAUNCH(k_pf_place, pf_grid(n_reads / 4 + 1, 512), 256, s, a);
     AFQ_LAUNCH(k_pf_adj, pf_grid(a.n_parts, 256), 256, s, a);
+}
+void launch_pf_cover(hipStream_t s, const P2Args& a) {
+    if (!a.n_cells) return;
+    AFQ_LAUNCH(k_pc_pairs, a.n_tiles, 256, s, a);
+    AFQ_LAUNCH(k_pc_small, a.n_tiles, 256, s, a);
+    AFQ_LAUNCH(k_pc_mid, a.n_tiles, 256, s, a);
+    AFQ_LAUNCH(k_pc_finish, (a.n_cells + 255) / 256, 256, s, a);
 }
 
 }  // namespace afq
