@@ -344,7 +344,7 @@ int check_supported(afq_ctx* c) {
 // path: a region that starts zeroed, the arrays the kernels fill, and a region uploaded from the host in one copy.
 struct P2Small {
     uint64_t pcnt, pnp, pncls, pn3, gcnt, fb, ctr, gdesc, pfd, route, zero_words;      // zeroed: per partition reads / pairs / staged classes, per-cell counters / flags, work counter, the range-wide graph build's block and per-cell routing flags
-    uint64_t poff, pcur, pnv, pcell, tq, bq, old_list, nta, nba, pcpre, pbq, npa;  // filled on the device (nta / nba: entries per tile quantity / per block quantity)
+    uint64_t poff, pcur, pnv, pcell, tq, bq, old_list, nta, nba, pcpre, pbq, npa, ptile;  // filled on the device (nta / nba: entries per tile quantity / per block quantity)
     uint64_t up, fb_count, fb_list, order, cells, tiles, up_words, words;   // uploaded
 };
 P2Small p2_small_layout(uint64_t n, uint64_t parts, uint64_t tiles, uint64_t n_pug) {
@@ -358,6 +358,7 @@ P2Small p2_small_layout(uint64_t n, uint64_t parts, uint64_t tiles, uint64_t n_p
     L.nba = (tiles + 1 + 1023) / 1024; L.nta = L.nba * 1024;   // (six quantities per tile, scanned in blocks of 1024 tiles; entry `tiles` is the end)
     L.tq = o; o += 6 * L.nta; L.bq = o; o += 6 * L.nba; L.old_list = o; o += n;
     L.npa = (parts + 1 + 1023) / 1024 * 1024; L.pcpre = o; o += L.npa; L.pbq = o; o += L.npa / 1024;
+    o = (o + 15) & ~15ull; L.ptile = o; o += tiles * (sizeof(PfTile) / 4);
     o = (o + 3) & ~3ull;
     L.up = o; L.fb_count = o; o += 4; L.fb_list = o; o += n_pug; L.order = o; o += n; o = (o + 3) & ~3ull;
     L.cells = o; o += n * (sizeof(P2Cell) / 4); L.tiles = o; o += 2 * tiles;
@@ -858,7 +859,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
             p2.work_counter = sm + L.ctr; p2.work_counter2 = sm + L.ctr + 1; p2.gdesc = sm + L.gdesc;
             p2.tq = sm + L.tq; p2.bq = sm + L.bq; p2.nta = (uint32_t)L.nta; p2.nba = (uint32_t)L.nba; p2.old_list = sm + L.old_list;
             p2.pfd = reinterpret_cast<PfDev*>(sm + L.pfd); p2.route = sm + L.route;
-            p2.pcpre = sm + L.pcpre; p2.pbq = sm + L.pbq; p2.npa = (uint32_t)L.npa;
+            p2.pcpre = sm + L.pcpre; p2.pbq = sm + L.pbq; p2.npa = (uint32_t)L.npa; p2.ptile = reinterpret_cast<PfTile*>(sm + L.ptile);
             // The graph phase: range-wide flat kernels (afq_pugflat.hip) unless the range's reads outgrow their 32-bit slot numbers
             // (>= 2^31 parsimony reads in ONE range: the per-cell kernel then takes every cell) or a test asks for the per-cell kernel.
             p2.graph_flat = (n_pug_reads < (1ull << 31) && !test_hook_is("P2_GRAPH", "cell")) ? 1u : 0u;

@@ -192,11 +192,21 @@ constexpr uint32_t kP2MaxComp = 4096;   // 64 mask words, one per lane: the work
 constexpr uint32_t kGDescWords = 20;    // per cell: what the graph phase hands the cover kernels (P2Args.gdesc)
 // The range-wide graph build (afq_pugflat.hip): one block per range, filled on the device.  Offsets are u32 words into the pool.
 struct PfDev {
-    unsigned long long par, cnt, rk, pos, tl, loff, tcell, lh;   // per vertex that has an edge [T]: root, component size -> first slot, position | size class, record slot, slot inside the cell, label offset, label key
-    unsigned long long prv, midoff, mrec, tied;    // two-vertex components (two slots each), first record slot per listed component (+ the end), 32-byte records, the covers' set-aside lists
+    unsigned long long par, cnt, rk, umi, rc, tl, loff, tcell, lh;   // per vertex that has an edge [T]: root, component size -> first slot, position | size class, UMI, reads, slot inside the cell, label offset, its cell, label key
+    unsigned long long prv, midoff, mrec, tied, slow;    // two-vertex components (two slots each), first record slot per listed component (+ the end), 32-byte records, the covers' set-aside lists
     uint32_t T, NP, NC, S;
     uint32_t n_old, pad[3];                        // cells routed to the per-cell graph kernel (old_list)
 };
+struct PfTile {   // per tile (k_pf_tiles): what the workgroups that take a tile's roots and components need of it, in one 64-byte load
+    uint32_t j, live;               // its cell; 0: the cell is not the flat kernels' (handed back, or routed to the per-cell kernel)
+    uint32_t tb, te;                // its vertices' dense numbers
+    uint32_t comp_base, n_tiny;     // the cell's run of the component list, its 3..8 components
+    uint32_t p0, n_pr;              // the tile's slice of the pair list (range-wide entries)
+    uint32_t a0, na, b0, nb;        // ... of the cell's 3..8 list and of its 9..64 list (entries counted from the cell's first)
+    uint32_t s_ti, s_mi;            // first record slots of the two slices
+    uint32_t pad[2];
+};
+static_assert(sizeof(PfTile) == 64, "PfTile");
 struct P2Args {
     const uint8_t* bytes; const CellMeta* meta; const P2Cell* cells; const uint2* tiles; const uint32_t* order;
     const uint64_t* rd_h; const uint64_t* rd_u;        // the decode's reads: label key, umi << 32 | record offset
@@ -222,6 +232,7 @@ struct P2Args {
     // the range-wide graph build: six per-tile quantities and their scans (tq: nta entries each; bq: per block of 1024 tiles, nba each),
     // per cell: routed to the per-cell graph kernel; the range's block; the list of routed cells
     uint32_t* tq; uint32_t* bq; uint32_t nta, nba; uint32_t* route; PfDev* pfd; uint32_t* old_list;
+    PfTile* ptile;
     uint32_t* pcpre; uint32_t* pbq; uint32_t npa;      // the scan of the lone vertices' staged class counts over the partitions (npa entries, blocks of 1024)
     uint32_t graph_flat;  // the graph phase as range-wide kernels (afq_pugflat.hip); 0: the per-cell kernel for every cell (tests: AFQ_TEST_P2_GRAPH=cell)
     uint32_t lone_coop;   // k_p2_lone: a lone vertex whose label has 5..64 refs is resolved by its whole wave (0: by its lane alone, as until late in round 4 - tests, measurements)

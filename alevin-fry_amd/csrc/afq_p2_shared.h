@@ -79,7 +79,7 @@ __device__ __forceinline__ PugCtx make_ctx(const P2Args& A, const P2Cell& c, uin
     C.labw = A.lab ? A.lab + 2 * c.key_off : nullptr;
     C.labd = A.lab ? C.labw + c.n_ref + 1 : nullptr;
     C.lab_cap = c.n_ref + 1;
-    C.s_cnt = cnt; C.st = A.st; C.cell = c.cell;
+    C.s_cnt = cnt; C.st = A.st; C.cell = c.cell; C.adj_umi = 0;
     return C;
 }
 

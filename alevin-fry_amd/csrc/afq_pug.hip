@@ -240,7 +240,7 @@ __global__ __launch_bounds__(kPugNT) void k_pug_cell(PugCellArgs A) {
     C.labw = A.lab ? A.lab + 2 * m.key_off : nullptr;
     C.labd = A.lab ? C.labw + m.n_ref + 1 : nullptr;
     C.lab_cap = m.n_ref + 1;
-    C.s_cnt = s_cnt; C.st = A.st; C.cell = cell;
+    C.s_cnt = s_cnt; C.st = A.st; C.cell = cell; C.adj_umi = 0;
     if (A.cell_nkeys[cell] != R) { if (tid == 0) set_err(A.st, kErrRecordWalk, cell); return; }
     if (R >= (1u << kVidBits)) { if (tid == 0) set_err(A.st, kErrPugLimit, cell); return; }
 

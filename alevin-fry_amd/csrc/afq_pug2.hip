@@ -267,11 +267,13 @@ __device__ __forceinline__ void part_body(const P2Args& A, const uint32_t* W, ui
             su[vi] = (uo & 0xFFFFFFFF00000000ull) | (next - i) | (sig[e] << 10) | ((uint32_t)(h >> 62) << 29);
             A.v_off[o + vi] = (uint32_t)uo;
             A.lidx[o + vi] = (uint32_t)(uo >> 32);   // the vertex's UMI on its own: what the search of the neighbouring partitions fetches (the graph kernel reuses the array afterwards)
+            // the flag byte: bit 0 "has an edge" (the search sets it), above it the vertex's reads, 127 = "127 or more: see s_u" - the
+            // range-wide graph build reads the flags anyway and gets the read counts of the vertices it numbers with them
+            A.v_flag[o + vi] = (uint8_t)(min(next - i, 127u) << 1);
         }
         before += (uint32_t)__popcll(vm[e]);
     }
-    for (uint32_t i = before + lane; i < n; i += 64) { su[i] = 0; sh[i] = 0; }   // (every load of the partition's reads is long done: they went into the sort)
-    for (uint32_t i = lane; i < n; i += 64) A.v_flag[o + i] = 0;
+    for (uint32_t i = before + lane; i < n; i += 64) { su[i] = 0; sh[i] = 0; A.v_flag[o + i] = 0; }   // (every load of the partition's reads is long done: they went into the sort)
     uint32_t n3 = 0;   // vertices under a hashed key (they sort last: the key's tag is its top bits)
 #pragma unroll
     for (int e = 0; e < E; ++e) n3 += (uint32_t)__popcll(__ballot(vh[e] && (uint32_t)((uint64_t)(a[e] >> 64) >> 62) == 3));
@@ -391,7 +393,7 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
         const uint64_t hx = ch[gx], hy = ch[gy];
         if ((hx != hy || (uint32_t)(hx >> 62) == 3) &&   // (equal hashed keys are equal labels only once somebody has compared them: here)
             !klab_overlap(klab(W, A.hw, hx, coff[gx]), klab(W, A.hw, hy, coff[gy]))) return;
-        cflag[gx] = 1; cflag[gy] = 1;
+        cflag[gx] |= 1; cflag[gy] |= 1;   // (bit 0; the bits above it hold the vertex's reads and never change: lanes that race here write the same byte)
         const uint32_t at = atomicAdd(s_np, 1u);   // (LDS, this wave's own counter)
         if (at < pcap) ppair[at] = dir | ((uint64_t)gx << 31) | gy;
     };
@@ -689,7 +691,7 @@ __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t
         for (int r = 0; r < 2; ++r) {
             const uint32_t i = r0 + (uint32_t)r * 64 + lane;
             h2[r] = i < nv ? A.s_h[o + i] : 0ull;
-            fl[r] = i < nv ? A.v_flag[o + i] : 1u;
+            fl[r] = i < nv ? (A.v_flag[o + i] & 1u) : 1u;
             of[r] = i < nv ? A.v_off[o + i] : 0u;
         }
 #pragma unroll
@@ -886,7 +888,7 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, const uint32_t* list
     uint32_t NT = 0;
     for (uint32_t g0 = 16 * tid; g0 < R; g0 += 16 * GNT) {   // (sixteen flags per thread and trip in flight: this kernel's phases are chains of round trips)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) NT += g0 + r < R && cflag[g0 + r] != 0;
+        for (int r = 0; r < 16; ++r) NT += g0 + r < R && (cflag[g0 + r] & 1u) != 0;
     }
     {
         uint32_t tot;
@@ -912,7 +914,7 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, const uint32_t* list
             const uint32_t g0 = base + 16 * tid;
             uint32_t fm = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) fm |= (uint32_t)(g0 + r < R && cflag[g0 + r] != 0) << r;
+            for (int r = 0; r < 16; ++r) fm |= (uint32_t)(g0 + r < R && (cflag[g0 + r] & 1u) != 0) << r;
             uint32_t tot;
             uint32_t li = carry + block_excl_scan<GNT>((uint32_t)__popc(fm), s_ws, tot);
             for (; fm; fm &= fm - 1) { const uint32_t g = g0 + (uint32_t)__builtin_ctz(fm); tl[li] = g; lidx[g] = li; ++li; }
@@ -920,7 +922,6 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, const uint32_t* list
         }
     }
     gsync();
-    const uint32_t flat_t0 = A.graph_flat ? A.tq[c.tile0] + A.bq[c.tile0 >> 10] : 0u;   // the cell's first dense number (afq_pugflat.hip: the scan of the tiles' vertex counts)
     for (uint32_t pp = tid; pp < P; pp += GNT) {   // the partition's pairs over touched-vertex numbers, four at a time
         const uint32_t nk = pnp[pp], so = ppoff[pp], at = ppre[2 * pp];
         const uint64_t* src = nk > pcn[pp] ? reinterpret_cast<const uint64_t*>(A.pool + psrc[so]) : psrc + so;   // (more pairs than own slots: the search put the list into the pool)
@@ -929,18 +930,8 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, const uint32_t* list
             uint32_t lx[4], ly[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) pr[r] = k0 + r < nk ? src[k0 + r] : 0ull;
-            if (A.graph_flat) {
-                // (the range-wide build has rewritten the pairs over ITS dense numbers - slot order through the range, cell by cell;
-                //  step 1 above numbers the cell's vertices in slot order too: the same numbers less the cell's first)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    lx[r] = k0 + r < nk ? ((uint32_t)(pr[r] >> 31) & 0x7FFFFFFFu) - flat_t0 : 0u; ly[r] = k0 + r < nk ? ((uint32_t)pr[r] & 0x7FFFFFFFu) - flat_t0 : 0u;
-                    if (lx[r] >= NT || ly[r] >= NT) s_cnt[3] = kErrInternal;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { lx[r] = k0 + r < nk ? lidx[(uint32_t)(pr[r] >> 31) & 0x7FFFFFFFu] : 0u; ly[r] = k0 + r < nk ? lidx[(uint32_t)pr[r] & 0x7FFFFFFFu] : 0u; }
-            }
+            for (int r = 0; r < 4; ++r) { lx[r] = k0 + r < nk ? lidx[(uint32_t)(pr[r] >> 31) & 0x7FFFFFFFu] : 0u; ly[r] = k0 + r < nk ? lidx[(uint32_t)pr[r] & 0x7FFFFFFFu] : 0u; }
 #pragma unroll
             for (int r = 0; r < 4; ++r) if (k0 + r < nk) lp[at + k0 + r] = (uint64_t)lx[r] | ((uint64_t)ly[r] << 24) | ((pr[r] >> 62) << 48);
         }
@@ -1542,7 +1533,7 @@ __global__ __launch_bounds__(CNT) void k_p2_tied(P2Args A, uint32_t work_lo, uin
     if (work >= work_hi) return;
     const uint32_t j = A.order[work];
     const uint32_t* d = A.gdesc + kGDescWords * (size_t)j;
-    if (d[0] != 3) continue;   // nothing was set aside (the graph kernel ordered the cell's components itself), or the cell was handed to the one-workgroup kernel, or failed
+    if ((d[0] & 3u) != 3u) continue;   // nothing was set aside (the graph kernel ordered the cell's components itself), or the cell was handed to the one-workgroup kernel, or failed
     const P2Cell c = A.cells[j];
     auto at = [&](int k) -> uint32_t* { return A.pool + (((unsigned long long)d[k + 1] << 32) | d[k]); };
     const uint32_t n_tiny = d[2];
@@ -1556,7 +1547,9 @@ __global__ __launch_bounds__(CNT) void k_p2_tied(P2Args A, uint32_t work_lo, uin
     auto entry = [&](uint32_t e) -> uint32_t* { return e < nA ? listA + 4 * (size_t)e : listB + 4 * (size_t)(e - nA); };
     if (tid == 0) { s_cnt[0] = A.cell_ncols[c.cell]; s_cnt[1] = A.lab_cnt ? A.lab_cnt[2 * c.cell] : 0u; s_cnt[2] = A.lab_cnt ? A.lab_cnt[2 * c.cell + 1] : 0u; s_cnt[3] = 0; }
     __syncthreads();
-    const PugCtx C = make_ctx(A, c, s_cnt);
+    PugCtx C = make_ctx(A, c, s_cnt);
+    const bool umi_recs = (d[0] & 4u) != 0;   // the range-wide build's records: (UMI, reads) where the per-cell graph kernel's hold the adjacency mask - the covers work the edges out (umi_edge), and a reordered record keeps its two words
+    C.adj_umi = umi_recs ? 1u : 0u;
     const uint64_t* ch = A.s_h + c.rd_base;
     const uint64_t* cu = A.s_u + c.rd_base;
     const uint32_t* coff = A.v_off + c.rd_base;
@@ -1673,7 +1666,7 @@ __global__ __launch_bounds__(CNT) void k_p2_tied(P2Args A, uint32_t work_lo, uin
                 }
                 if (act) {   // (every lane holds its record in registers: the slots can be overwritten)
                     mrec[2 * (size_t)(b0 + rank)] = qa;
-                    mrec[2 * (size_t)(b0 + rank) + 1] = make_uint4(qb.x, qb.y, nadj, 0u);
+                    mrec[2 * (size_t)(b0 + rank) + 1] = umi_recs ? qb : make_uint4(qb.x, qb.y, nadj, 0u);
                 }
                 if (mine && gl == 0) { en[1] = nuc; en[2] = 0u; }
             }
@@ -1703,7 +1696,7 @@ __global__ __launch_bounds__(CNT) void k_p2_tied(P2Args A, uint32_t work_lo, uin
             }
             if (act) {
                 mrec[2 * (size_t)(b0 + rank)] = qa;
-                mrec[2 * (size_t)(b0 + rank) + 1] = make_uint4(qb.x, qb.y, (uint32_t)nadj, (uint32_t)(nadj >> 32));
+                mrec[2 * (size_t)(b0 + rank) + 1] = umi_recs ? qb : make_uint4(qb.x, qb.y, (uint32_t)nadj, (uint32_t)(nadj >> 32));
             }
             if (lane == 0) { en[1] = (uint32_t)nuc; en[2] = (uint32_t)(nuc >> 32); }
         }

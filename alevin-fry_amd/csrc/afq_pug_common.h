@@ -30,7 +30,20 @@ struct PugCtx {
     uint32_t* s_cnt;         // LDS: [0] ncols, [1] label words, [2] label count, [3] error flag
     DevStatus* st;
     uint32_t cell;
+    uint32_t adj_umi;        // the cover records carry (UMI, reads) in place of an adjacency mask: the covers work the edges out themselves (umi_edge)
 };
+// has_edge(x -> y) from the two vertices' UMIs and read counts (pugutils.rs:76-99, utils.rs:389-393; the rule k_p2_search's check()
+// writes into a pair's direction bits): the same UMI - or one base apart and reads(y) < 2 reads(x); under --umi-edit-dist 0 the same
+// UMI only.  (The labels must share a ref as well: the caller's test.)  Inside a component every such pair IS an edge the search
+// found - it finds every pair of a cell's vertices that passes this rule and the label test - so a cover that holds a component's
+// vertices can work its edges out itself instead of having them delivered (a pass over the pair list with two atomics per pair).
+__device__ __forceinline__ bool umi_edge(uint32_t ux, uint32_t cx, uint32_t uy, uint32_t cy, uint32_t exact_umi) {
+    const uint32_t x = ux ^ uy;
+    if (x == 0) return true;
+    if (exact_umi) return false;
+    const uint32_t nz = (x | (x >> 1)) & 0x55555555u;   // one bit per base that differs
+    return (nz & (nz - 1)) == 0 && cy < 2 * cx;
+}
 
 struct Lab {
     const uint32_t* p;
@@ -393,7 +406,22 @@ __device__ __forceinline__ void cover_tiny8(const PugCtx& C, const uint4* mrec, 
                 if (stage && n_v <= kStageRefs) return stage[src * kStageRefs + j];   // (src's label is staged: its length says so)
                 return reinterpret_cast<const uint32_t*>((uintptr_t)(((uint64_t)hi << 32) | lo))[j] & 0x7FFFFFFFu;
             };
-            const uint32_t adj = act ? (qb.z & 0xFFu) : 0u;   // local indices < 8
+            uint32_t adj = act ? (qb.z & 0xFFu) : 0u;   // local indices < 8
+            if (C.adj_umi) {   // (wave-uniform) the record holds (UMI, reads): my out-neighbours are the group's vertices whose label shares a ref with mine and that umi_edge lets me reach
+                adj = 0;
+                for (uint32_t k = 0; k < 8; ++k) {
+                    const uint32_t uk = (uint32_t)__shfl((int)qb.z, (int)(gbase + k)), ck = (uint32_t)__shfl((int)qb.w, (int)(gbase + k));
+                    const uint32_t lkn_all = (uint32_t)__shfl((int)myl.n, (int)(gbase + k));
+                    const uint32_t lkn = k < n ? lkn_all : 0u;
+                    bool ov = false;
+                    for (uint32_t j = 0; __any(j < lkn); ++j) {
+                        const bool on = j < lkn;
+                        const uint32_t t = ref_of(gbase + k, lkn, j, on);
+                        ov = ov || (on && act && my_contains(t));
+                    }
+                    if (act && k < n && k != gl && ov && umi_edge(qb.z, qb.w, uk, ck, C.exact_umi)) adj |= 1u << k;
+                }
+            }
             uint32_t UC = gvalid ? ((1u << n) - 1u) & uc0 : 0u;
             while (__any(UC != 0)) {
                 const uint32_t remaining = (uint32_t)__popc(UC);
@@ -506,15 +534,30 @@ template <int MODE>
 __device__ __forceinline__ void cover_lane4(const PugCtx& C, const uint4* mrec, uint32_t b0, uint32_t n, uint32_t uc0, uint32_t ci,
                                             uint32_t* tied_cnt = nullptr, uint32_t* tied = nullptr) {
     constexpr uint32_t kNo = 0xFFFFFFFFu;
-    uint32_t rf[4][4], ln[4], adjm = 0;
+    uint32_t rf[4][4], ln[4], um[4], rc[4], adjm = 0;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         uint4 qa = make_uint4(0, 0, kNo, kNo), qb = make_uint4(kNo, kNo, 0, 0);
         if ((uint32_t)v < n) { qa = mrec[2 * (size_t)(b0 + v)]; qb = mrec[2 * (size_t)(b0 + v) + 1]; }
         ln[v] = qa.y; rf[v][0] = qa.z; rf[v][1] = qa.w; rf[v][2] = qb.x; rf[v][3] = qb.y;
+        um[v] = qb.z; rc[v] = qb.w;
         adjm |= (qb.z & 0xFu) << (4 * v);
     }
     auto has = [&](int u, uint32_t t) -> bool { return t == rf[u][0] || t == rf[u][1] || t == rf[u][2] || t == rf[u][3]; };
+    if (C.adj_umi) {   // (wave-uniform) the records hold (UMI, reads) in place of the mask: the edges from umi_edge and the labels
+        adjm = 0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int u = v + 1; u < 4; ++u) {
+                bool ov = false;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ov = ov || ((uint32_t)j < ln[v] && has(u, rf[v][j]));
+                ov = ov && (uint32_t)u < n;
+                if (ov && umi_edge(um[v], rc[v], um[u], rc[u], C.exact_umi)) adjm |= 1u << (4 * v + u);
+                if (ov && umi_edge(um[u], rc[u], um[v], rc[v], C.exact_umi)) adjm |= 1u << (4 * u + v);
+            }
+    }
     uint32_t UC = n ? uc0 & ((1u << n) - 1u) : 0u;
     while (__any(UC != 0)) {
         const uint32_t remaining = (uint32_t)__popc(UC);
@@ -647,7 +690,17 @@ __device__ __forceinline__ void cover_wave64(const PugCtx& C, const uint4* mrec,
             const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)pa, (int)v), hi = (uint32_t)__shfl((int)(uint32_t)(pa >> 32), (int)v);
             return reinterpret_cast<const uint32_t*>((uintptr_t)(((uint64_t)hi << 32) | lo))[j] & 0x7FFFFFFFu;
         };
-        const uint64_t adj = act ? (((uint64_t)qb.w << 32) | qb.z) : 0ull;
+        uint64_t adj = act ? (((uint64_t)qb.w << 32) | qb.z) : 0ull;
+        if (C.adj_umi) {   // (wave-uniform) as in cover_tiny8: the record holds (UMI, reads), the edges are worked out here
+            adj = 0;
+            for (uint32_t k = 0; k < n; ++k) {
+                const uint32_t uk = (uint32_t)__shfl((int)qb.z, (int)k), ck = (uint32_t)__shfl((int)qb.w, (int)k);
+                const uint32_t lkn = lane_lab_n(k);
+                bool ov = false;
+                for (uint32_t j = 0; j < lkn; ++j) { const uint32_t t = lane_lab_ref(k, lkn, j); ov = ov || (act && my_contains(t)); }
+                if (act && k != lane && ov && umi_edge(qb.z, qb.w, uk, ck, C.exact_umi)) adj |= 1ull << k;
+            }
+        }
         uint64_t UC = n == 64 ? ~0ull : ((1ull << n) - 1);
         if constexpr (MODE == kCoverResume) UC &= ((uint64_t)tied[4 * ci + 2] << 32) | tied[4 * ci + 1];
         while (UC) {

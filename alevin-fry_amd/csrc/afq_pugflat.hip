@@ -11,7 +11,7 @@
 //                                 order: a tile of 4096 read slots counts its flags, the tile counts are scanned (k_pf_scan1/2),
 //                                 the tiles number their vertices.  Everything behind this works on dense arrays of T entries.
 //   k_pf_union                    one thread per PAIR: compare-and-swap hooking union-find on par[T] (the larger root under the
-//                                 smaller, path halving by atomic min); the pair is rewritten over dense numbers where it lies.
+//                                 smaller, path halving by atomic min).
 //   k_pf_root                     one thread per vertex: its root, its position inside its component (an atomic counter per root).
 //   k_pf_cats, k_pf_scan1/2       per tile: how many of its roots head a component of two / 3..8 / 9..64 vertices, how many record
 //                                 slots those take; a cell with a larger component is routed to the per-cell kernel (rare).  The
@@ -20,8 +20,11 @@
 //                                 tile knows where its roots' entries go - no counter, no atomic, the same lists every run.
 //   k_pf_cells                    a workgroup per cell: the descriptor the cover kernels read, the lone vertices' staged classes
 //                                 into the cell's label area.
-//   k_pf_alloc / k_pf_place / k_pf_adj      roots take their list entry and record slots, vertices write their 32-byte cover
-//                                 records, pairs OR their directions into the records' adjacency masks.
+//   k_pf_alloc / k_pf_place       roots take their list entry and record slots, vertices write their 32-byte cover records: label,
+//                                 UMI, reads.  The pairs are not looked at again: inside a component EVERY two vertices that pass
+//                                 has_edge's rule are an edge the search found, so the covers work a component's edges out of its
+//                                 vertices' UMIs, reads and labels (umi_edge, afq_pug_common.h) - a pass over the pair list with two
+//                                 atomics per pair into 32-byte records (0.64 ms per launch) is what that replaces.
 //
 // The covers (k_p2_cover, k_p2_tied) then read per-cell descriptors exactly as the per-cell graph kernel wrote them: records in
 // slot order, ties set aside (kCoverDefer).
@@ -47,7 +50,6 @@ namespace {
 
 constexpr uint32_t kCatShift = 29, kRankMask = (1u << kCatShift) - 1u;
 constexpr uint32_t kFCatPair = 1, kFCatTiny = 2, kFCatMid = 3;
-constexpr uint32_t kNoPos = 0xFFFFFFFFu;
 // per-tile quantities (P2Args.tq, one array of nta entries each): vertices with an edge; then, of the tile's roots, components of
 // two / 3..8 / 9..64 vertices and the record slots of the latter two
 constexpr uint32_t kQTouched = 0, kQPr = 1, kQTiny = 2, kQMid = 3, kQSTiny = 4, kQSMid = 5;
@@ -66,7 +68,8 @@ struct PfV {
     uint32_t* par;     // union-find parent; after k_pf_root: the root
     uint32_t* cnt;     // root: vertices of its component (k_pf_root); then the component's first record slot / pair entry (k_pf_alloc)
     uint32_t* rk;      // position inside the component (k_pf_root) | size class << 29 (roots, k_pf_alloc)
-    uint32_t* pos;     // the vertex's record slot, kNoPos without a record (k_pf_place)
+    uint32_t* umi;     // its UMI
+    uint32_t* rc;      // its reads
     uint32_t* tl;      // the vertex's slot inside its cell
     uint32_t* loff;    // its label's record offset (hashed label keys only: labels of one or two refs sit in the key)
     uint32_t* tcell;   // its cell (index into P2Args.cells)
@@ -75,17 +78,17 @@ struct PfV {
 __device__ __forceinline__ PfV pf_v(const P2Args& A) {
     const PfDev& D = *A.pfd;
     PfV v;
-    v.T = D.T; v.par = A.pool + D.par; v.cnt = A.pool + D.cnt; v.rk = A.pool + D.rk; v.pos = A.pool + D.pos;
+    v.T = D.T; v.par = A.pool + D.par; v.cnt = A.pool + D.cnt; v.rk = A.pool + D.rk; v.umi = A.pool + D.umi; v.rc = A.pool + D.rc;
     v.tl = A.pool + D.tl; v.loff = A.pool + D.loff; v.tcell = A.pool + D.tcell; v.lh = reinterpret_cast<uint64_t*>(A.pool + D.lh);
     return v;
 }
 
-__device__ __forceinline__ uint32_t nz4(uint32_t w) {   // bit k: byte k of w is not zero
-    w |= w >> 4; w |= w >> 2; w |= w >> 1; w &= 0x01010101u;
+__device__ __forceinline__ uint32_t nz4(uint32_t w) {   // bit k: bit 0 of byte k of w ("has an edge"; the bits above it: the vertex's reads, k_p2_part)
+    w &= 0x01010101u;
     return (w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u);
 }
 // The flags of slots [t0, t1) of a cell (vf: the cell's first flag), sixteen to a thread as one aligned 16-byte load: f(slot, number
-// inside the tile) for every flagged slot, in slot order.  Workgroup-wide call, 256 threads; returns how many there are.
+// inside the tile, flag byte) for every flagged slot, in slot order.  Workgroup-wide call, 256 threads; returns how many there are.
 template <typename F>
 __device__ __forceinline__ uint32_t pf_tile_flags(const uint8_t* vf, uint32_t t0, uint32_t t1, uint32_t* s_ws, F&& f) {
     const uintptr_t a = (uintptr_t)(vf + t0), b = (uintptr_t)(vf + t1);
@@ -94,8 +97,9 @@ __device__ __forceinline__ uint32_t pf_tile_flags(const uint8_t* vf, uint32_t t0
     for (uintptr_t cb = c0; cb <= c1; cb += 256) {   // (uniform; a tile of 4096 slots: 256 or 257 chunks)
         const uintptr_t c = cb + threadIdx.x;
         uint32_t fm = 0;
+        uint4 w = make_uint4(0, 0, 0, 0);
         if (c <= c1) {
-            const uint4 w = *reinterpret_cast<const uint4*>(c << 4);
+            w = *reinterpret_cast<const uint4*>(c << 4);
             fm = nz4(w.x) | (nz4(w.y) << 4) | (nz4(w.z) << 8) | (nz4(w.w) << 12);
             const uintptr_t lo = c << 4;
             if (lo < a) fm &= 0xFFFFu << (uint32_t)(a - lo);
@@ -104,7 +108,11 @@ __device__ __forceinline__ uint32_t pf_tile_flags(const uint8_t* vf, uint32_t t0
         uint32_t tot;
         uint32_t k = carry + block_excl_scan<256>((uint32_t)__popc(fm), s_ws, tot);
         const uint32_t gbase = (uint32_t)((c << 4) - (uintptr_t)vf);   // (before the cell's first flag in a tile's first chunk: the masked bits make up for it)
-        for (; fm; fm &= fm - 1, ++k) f(gbase + (uint32_t)__builtin_ctz(fm), k);
+        for (; fm; fm &= fm - 1, ++k) {
+            const uint32_t b = (uint32_t)__builtin_ctz(fm);
+            const uint32_t word = b < 4 ? w.x : b < 8 ? w.y : b < 12 ? w.z : w.w;
+            f(gbase + b, k, (word >> (8 * (b & 3u))) & 0xFFu);
+        }
         carry += tot;
     }
     return carry;
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(256) void k_pf_count(P2Args A) {
     if (!A.fb[j]) {   // (a cell k_p2_scan handed back has no vertices, and its flags were never cleared)
         const P2Cell c = A.cells[j];
         const uint32_t t0 = td.y * A.tile, t1 = min(c.R, t0 + A.tile);
-        n = pf_tile_flags(A.v_flag + c.rd_base, t0, t1, s_ws, [](uint32_t, uint32_t) {});
+        n = pf_tile_flags(A.v_flag + c.rd_base, t0, t1, s_ws, [](uint32_t, uint32_t, uint32_t) {});
     }
     if (threadIdx.x == 0) A.tq[(size_t)kQTouched * A.nta + blockIdx.x] = n;
 }
@@ -171,16 +179,16 @@ __global__ __launch_bounds__(1024) void k_pf_scan2(P2Args A, uint32_t q0) {
     if (threadIdx.x != 0) return;
     PfDev& D = *A.pfd;
     if (q0 == 0) {   // T vertices have an edge: their dense arrays
-        const unsigned long long T = s_tot[0], words = 9 * T + 16;
+        const unsigned long long T = s_tot[0], words = 10 * T + 16;
         const unsigned long long base = atomicAdd(A.pool_cur, words);
         if (base + words > A.pool_cap || T >= (1u << 31)) { set_err(A.st, T >= (1u << 31) ? kErrPugLimit : kErrPugPool, 0); D.T = 0; return; }
         unsigned long long o = (base + 3) & ~3ull;
         D.lh = o; o += 2 * T;   // (8-byte entries first: o is a multiple of four words)
-        D.par = o; o += T; D.cnt = o; o += T; D.rk = o; o += T; D.pos = o; o += T; D.tl = o; o += T; D.loff = o; o += T; D.tcell = o;
+        D.par = o; o += T; D.cnt = o; o += T; D.rk = o; o += T; D.umi = o; o += T; D.rc = o; o += T; D.tl = o; o += T; D.loff = o; o += T; D.tcell = o;
         D.T = (uint32_t)T;
     } else if (Q >= 5) {   // the lists: pairs, first record slot per listed component (+ the end), records, the covers' set-aside lists
         const unsigned long long NP = s_tot[0], NC = (unsigned long long)s_tot[1] + s_tot[Q >= 5 ? 2 : 0], S = (unsigned long long)s_tot[Q >= 5 ? 3 : 0] + s_tot[Q >= 5 ? 4 : 0];
-        const unsigned long long words = 2 * NP + 4 + (NC + 4) + 8 * S + 8 + 4 * (NC + A.n_cells) + 8;
+        const unsigned long long words = 2 * NP + 4 + (NC + 4) + 8 * S + 8 + 4 * (NC + A.n_cells) + 8 + NC / 2 + 4;
         const unsigned long long base = atomicAdd(A.pool_cur, words);
         if (base + words > A.pool_cap || S >= (1ull << 32)) { set_err(A.st, kErrPugPool, 0); return; }
         unsigned long long o = (base + 3) & ~3ull;
@@ -188,7 +196,8 @@ __global__ __launch_bounds__(1024) void k_pf_scan2(P2Args A, uint32_t q0) {
         D.prv = o; o += 2 * NP + 2;
         D.midoff = o; o += NC + 2;
         o = (o + 3) & ~3ull;
-        D.tied = o;
+        D.tied = o; o += 4 * (NC + A.n_cells) + 4;
+        D.slow = o;   // (16-bit entries, one per listed component)
         D.NP = (uint32_t)NP; D.NC = (uint32_t)NC; D.S = (uint32_t)S;
         A.pool[D.midoff + NC] = (uint32_t)S;   // the list's last offset
     }
@@ -198,6 +207,7 @@ __global__ __launch_bounds__(256) void k_pf_number(P2Args A) {
     if (A.st->err_code) return;
     __shared__ uint32_t s_ws[4];
     __shared__ uint16_t s_g[4096 + 16];
+    __shared__ uint8_t s_rc[4096 + 16];
     const uint2 td = A.tiles[blockIdx.x];
     const uint32_t j = td.x;
     if (A.fb[j]) return;
@@ -206,27 +216,30 @@ __global__ __launch_bounds__(256) void k_pf_number(P2Args A) {
     const uint32_t t0 = td.y * A.tile, t1 = min(c.R, t0 + A.tile);
     uint32_t* lidx = A.lidx + c.rd_base;
     const uint64_t* ch = A.s_h + c.rd_base;
+    const uint64_t* cu = A.s_u + c.rd_base;
     const uint32_t* coff = A.v_off + c.rd_base;
     const uint32_t tb = pf_g(A, kQTouched, blockIdx.x);
-    const uint32_t nt = pf_tile_flags(A.v_flag + c.rd_base, t0, t1, s_ws, [&](uint32_t g, uint32_t k) { s_g[k] = (uint16_t)(g - t0); });
+    const uint32_t nt = pf_tile_flags(A.v_flag + c.rd_base, t0, t1, s_ws, [&](uint32_t g, uint32_t k, uint32_t fb) { s_g[k] = (uint16_t)(g - t0); s_rc[k] = (uint8_t)(fb >> 1); });
     __syncthreads();
     // The vertex's label key (and, for a hashed key, where its label lies) into the dense arrays as well: the covers and the record
     // builder ask for the labels of these vertices - one in four slots - and every such gather out of the per-slot arrays fetched
     // a 64-byte line for 8 or 4 bytes; here the lines are read once, by neighbouring lanes, and everybody behind reads dense arrays.
     // (Four vertices to a thread and trip: the gathers of a trip go out together.)
+    // (the vertex's UMI lies in lidx - k_p2_part left it there for the search - on the very line its dense number is about to be
+    //  written to; its reads came with its flag: 127 stands for "127 or more", which s_u knows)
     for (uint32_t k0 = threadIdx.x; k0 < nt; k0 += 1024) {
-        uint32_t g[4], off[4];
+        uint32_t g[4], off[4], um[4], rc[4];
         uint64_t h[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const uint32_t k = k0 + 256u * (uint32_t)r; g[r] = k < nt ? t0 + s_g[k] : t0; h[r] = k < nt ? ch[g[r]] : 0ull; }
+        for (int r = 0; r < 4; ++r) { const uint32_t k = k0 + 256u * (uint32_t)r; g[r] = k < nt ? t0 + s_g[k] : t0; rc[r] = k < nt ? s_rc[k] : 0u; h[r] = k < nt ? ch[g[r]] : 0ull; um[r] = k < nt ? lidx[g[r]] : 0u; }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) off[r] = (uint32_t)(h[r] >> 62) == 3 ? coff[g[r]] : 0u;
+        for (int r = 0; r < 4; ++r) { off[r] = (uint32_t)(h[r] >> 62) == 3 ? coff[g[r]] : 0u; if (rc[r] == 127) rc[r] = (uint32_t)cu[g[r]] & kVCntMask; }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const uint32_t k = k0 + 256u * (uint32_t)r, t = tb + k;
             if (k >= nt) continue;
             lidx[g[r]] = t;
-            V.par[t] = t; V.cnt[t] = 0; V.tl[t] = g[r]; V.tcell[t] = j; V.lh[t] = h[r]; V.loff[t] = off[r];
+            V.par[t] = t; V.cnt[t] = 0; V.tl[t] = g[r]; V.tcell[t] = j; V.lh[t] = h[r]; V.loff[t] = off[r]; V.umi[t] = um[r]; V.rc[t] = rc[r];
         }
     }
 }
@@ -307,8 +320,6 @@ __global__ __launch_bounds__(256) void k_pf_union(P2Args A) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (sp[r] && (tx[r] >= V.T || ty[r] >= V.T)) { set_err(A.st, kErrInternal, 0); sp[r] = nullptr; }
-            // the pair over dense numbers, where it lay (k_pf_adj, and the per-cell kernel for the cells routed to it)
-            if (sp[r]) *sp[r] = (e[r] & (kPairF | kPairB)) | ((uint64_t)tx[r] << 31) | ty[r];
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) { px[r] = sp[r] ? ag_ld(&par[tx[r]]) : 0u; py[r] = sp[r] ? ag_ld(&par[ty[r]]) : 0u; }
@@ -418,24 +429,44 @@ __global__ __launch_bounds__(1024) void k_pf_pscan2(P2Args A) {
 }
 __global__ __launch_bounds__(256) void k_pf_move(P2Args A) {
     if (A.st->err_code) return;
-    for (uint32_t gp = blockIdx.x * 256 + threadIdx.x; gp < A.n_parts; gp += gridDim.x * 256) {
-        const uint32_t nk = A.pncls[gp];
-        if (!nk) continue;
-        const uint32_t j = A.pcell[gp];
-        if (A.fb[j] || A.route[j]) continue;   // (the per-cell kernel moves the classes of the cells routed to it itself)
-        const P2Cell& c = A.cells[j];
-        const uint32_t* gc = A.gcnt + 4 * (size_t)j;
-        const uint32_t at = pf_pc(A, gp) - pf_pc(A, c.part_base), w0 = gc[1], d0 = gc[2], lab_cap = c.n_ref + 1;
-        uint32_t* labw = A.lab + 2 * c.key_off;
-        uint32_t* labd = labw + c.n_ref + 1;
-        const uint64_t* stage = A.cstage + c.rd_base + A.poff[gp];
-        for (uint32_t k = 0; k < nk; ++k) {
-            const uint64_t v = stage[k];
-            const uint32_t w = w0 + 2 * (at + k), d = d0 + at + k;
-            if (w + 2 > lab_cap || 2 * (d + 1) > lab_cap) break;   // (k_pf_cells reports it)
+    // (256 partitions to a workgroup, their classes laid end to end by a scan and taken by the threads evenly - a partition stages
+    //  anything from none to dozens; a thread per partition walking its own classes took 0.34 ms per launch)
+    __shared__ uint32_t s_start[256], s_nref[256], s_d[256], s_w[256], s_ws[4];
+    __shared__ unsigned long long s_src[256], s_lab[256];
+    for (uint32_t p0 = blockIdx.x * 256; p0 < A.n_parts; p0 += gridDim.x * 256) {
+        const uint32_t gp = p0 + threadIdx.x;
+        uint32_t nk = 0, nref = 0, d0 = 0, w0 = 0;
+        unsigned long long src = 0, lab = 0;
+        if (gp < A.n_parts) {
+            nk = A.pncls[gp];
+            const uint32_t j = nk ? A.pcell[gp] : 0u;
+            if (nk && (A.fb[j] || A.route[j])) nk = 0;   // (the per-cell kernel moves the classes of the cells routed to it itself)
+            if (nk) {
+                const P2Cell& c = A.cells[j];
+                const uint32_t* gc = A.gcnt + 4 * (size_t)j;
+                const uint32_t at = pf_pc(A, gp) - pf_pc(A, c.part_base);
+                d0 = gc[2] + at; w0 = gc[1] + 2 * at; nref = c.n_ref;
+                src = (unsigned long long)(uintptr_t)(A.cstage + c.rd_base + A.poff[gp]);
+                lab = (unsigned long long)(uintptr_t)(A.lab + 2 * c.key_off);
+            }
+        }
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<256>(nk, s_ws, tot);
+        s_start[threadIdx.x] = ex; s_src[threadIdx.x] = src; s_lab[threadIdx.x] = lab; s_nref[threadIdx.x] = nref; s_d[threadIdx.x] = d0; s_w[threadIdx.x] = w0;
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < tot; t += 256) {
+            uint32_t lo = 0, hi = 256;   // the last partition that starts at or before t
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_start[mid] <= t) lo = mid; else hi = mid; }
+            const uint32_t k = t - s_start[lo];
+            const uint64_t v = reinterpret_cast<const uint64_t*>((uintptr_t)s_src[lo])[k];
+            uint32_t* labw = reinterpret_cast<uint32_t*>((uintptr_t)s_lab[lo]);
+            const uint32_t lab_cap = s_nref[lo] + 1, w = s_w[lo] + 2 * k, d = s_d[lo] + k;
+            if (w + 2 > lab_cap || 2 * (d + 1) > lab_cap) continue;   // (k_pf_cells reports it)
+            uint32_t* labd = labw + lab_cap;
             labw[w] = (uint32_t)v; labw[w + 1] = (uint32_t)(v >> 32);
             labd[2 * d] = w; labd[2 * d + 1] = 2;
         }
+        __syncthreads();
     }
 }
 
@@ -471,7 +502,30 @@ __global__ __launch_bounds__(256) void k_pf_cells(P2Args A) {
     d[12] = c.R; d[13] = w0; d[14] = d0;
     uint32_t* tp = A.pool + tied;
     tp[0] = 0; tp[1] = 0; tp[2] = 0; tp[3] = 0;
-    d[0] = 3u;   // the lists are there, in slot order (kCoverDefer)
+    d[0] = 7u;   // the lists are there (1), in slot order (2: kCoverDefer), records with (UMI, reads) in place of adjacency masks (4)
+}
+
+// ... and a thread per tile: where the tile's slices of the lists lie, gathered once (the workgroups that take a tile - k_pf_alloc, the
+// covers - used to start with a dozen dependent loads each to work this out: with 33 000 workgroups per range and four to eight to
+// a CU that start-up was most of their time)
+__global__ __launch_bounds__(256) void k_pf_tiles(P2Args A) {
+    if (A.st->err_code) return;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= A.n_tiles) return;
+    const uint32_t j = A.tiles[i].x;
+    const P2Cell& c = A.cells[j];
+    PfTile t{};
+    t.j = j; t.live = !(A.fb[j] || A.route[j]);
+    t.tb = pf_g(A, kQTouched, i); t.te = pf_g(A, kQTouched, i + 1);
+    const uint32_t i0 = c.tile0, i1 = c.tile0 + (c.R + A.tile - 1) / A.tile;
+    const uint32_t ti0 = pf_g(A, kQTiny, i0), mi0 = pf_g(A, kQMid, i0), sti0 = pf_g(A, kQSTiny, i0), smi0 = pf_g(A, kQSMid, i0);
+    const uint32_t S_tiny = pf_g(A, kQSTiny, i1) - sti0, slot_base = sti0 + smi0;
+    t.n_tiny = pf_g(A, kQTiny, i1) - ti0; t.comp_base = ti0 + mi0;
+    t.p0 = pf_g(A, kQPr, i); t.n_pr = pf_g(A, kQPr, i + 1) - t.p0;
+    t.a0 = pf_g(A, kQTiny, i) - ti0; t.na = pf_g(A, kQTiny, i + 1) - ti0 - t.a0;
+    t.b0 = t.n_tiny + (pf_g(A, kQMid, i) - mi0); t.nb = t.n_tiny + (pf_g(A, kQMid, i + 1) - mi0) - t.b0;
+    t.s_ti = slot_base + (pf_g(A, kQSTiny, i) - sti0); t.s_mi = slot_base + S_tiny + (pf_g(A, kQSMid, i) - smi0);
+    A.ptile[i] = t;
 }
 
 // 6. a workgroup per tile: its roots take their entries of the cell's run of the lists and their record slots - where the scans of
@@ -479,22 +533,13 @@ __global__ __launch_bounds__(256) void k_pf_cells(P2Args A) {
 __global__ __launch_bounds__(256) void k_pf_alloc(P2Args A) {
     if (A.st->err_code) return;
     __shared__ uint32_t s_ws[4];
-    const uint32_t i = blockIdx.x, j = A.tiles[i].x;
-    if (A.fb[j]) return;
+    const PfTile T = A.ptile[blockIdx.x];
+    if (!T.live) return;   // (the per-cell kernel's, or handed back: no entry, no record - k_pf_place passes over roots without a size class)
     const PfV V = pf_v(A);
-    const uint32_t tb = pf_g(A, kQTouched, i), te = pf_g(A, kQTouched, i + 1);
-    if (A.route[j]) {   // the per-cell kernel's: no entry, no record
-        for (uint32_t t = tb + threadIdx.x; t < te; t += 256) if (V.par[t] == t) { V.cnt[t] = 0; V.rk[t] &= kRankMask; }
-        return;
-    }
-    const P2Cell& c = A.cells[j];
-    const uint32_t i0 = c.tile0, i1 = c.tile0 + (c.R + A.tile - 1) / A.tile;
-    const uint32_t ti0 = pf_g(A, kQTiny, i0), mi0 = pf_g(A, kQMid, i0), sti0 = pf_g(A, kQSTiny, i0), smi0 = pf_g(A, kQSMid, i0);
-    const uint32_t n_tiny = pf_g(A, kQTiny, i1) - ti0, S_tiny = pf_g(A, kQSTiny, i1) - sti0;
-    const uint32_t comp_base = ti0 + mi0, slot_base = sti0 + smi0;
-    uint32_t c_pr = pf_g(A, kQPr, i);                                      // next pair entry (range-wide)
-    uint32_t c_ti = comp_base + (pf_g(A, kQTiny, i) - ti0), c_mi = comp_base + n_tiny + (pf_g(A, kQMid, i) - mi0);   // next list entries
-    uint32_t s_ti = slot_base + (pf_g(A, kQSTiny, i) - sti0), s_mi = slot_base + S_tiny + (pf_g(A, kQSMid, i) - smi0);   // next record slots
+    const uint32_t tb = T.tb, te = T.te;
+    uint32_t c_pr = T.p0;                                                  // next pair entry (range-wide)
+    uint32_t c_ti = T.comp_base + T.a0, c_mi = T.comp_base + T.b0;         // next list entries
+    uint32_t s_ti = T.s_ti, s_mi = T.s_mi;                                 // next record slots
     uint32_t* mid_off = A.pool + A.pfd->midoff;
     for (uint32_t t0 = tb; t0 < te; t0 += 256) {   // (uniform)
         const uint32_t t = t0 + threadIdx.x;
@@ -521,7 +566,7 @@ __global__ __launch_bounds__(256) void k_pf_alloc(P2Args A) {
 }
 
 // 7. one thread per vertex (two to a thread and trip): into the pair list, or its 32-byte cover record (vertex slot, label length, up to
-//    four refs - a longer label: where it lies in the chunk -, adjacency mask, filled by k_pf_adj).  Everything it reads is dense.
+//    four refs - a longer label: where it lies in the chunk -, UMI, reads).  Everything it reads is dense.
 __global__ __launch_bounds__(256) void k_pf_place(P2Args A) {
     if (A.st->err_code) return;
     const PfV V = pf_v(A);
@@ -541,7 +586,6 @@ __global__ __launch_bounds__(256) void k_pf_place(P2Args A) {
             if (!on[q]) continue;
             const uint32_t t = t0 + 256u * (uint32_t)q;
             if (cat[q] != kFCatTiny && cat[q] != kFCatMid) {
-                V.pos[t] = kNoPos;
                 if (cat[q] == kFCatPair) pr_v[where[q] + kk[q]] = t;   // (the dense number: the two-vertex rule reads the label out of the dense arrays)
                 continue;
             }
@@ -557,41 +601,10 @@ __global__ __launch_bounds__(256) void k_pf_place(P2Args A) {
                 else { const uint64_t pa = (uint64_t)(uintptr_t)lp; r0 = (uint32_t)pa; r1 = (uint32_t)(pa >> 32); }
             }
             const size_t at = (size_t)where[q] + kk[q];
-            V.pos[t] = (uint32_t)at;
             mrec[2 * at] = make_uint4(g[q], n, r0, r1);
-            mrec[2 * at + 1] = make_uint4(r2, r3, 0u, 0u);
+            mrec[2 * at + 1] = make_uint4(r2, r3, V.umi[t], V.rc[t]);
         }
     }
-}
-
-// 8. one thread per pair once more: its directions into the adjacency masks of its end points' records (pairs of a two-vertex
-//    component need none: the two-vertex rule does not look at directions)
-__global__ __launch_bounds__(256) void k_pf_adj(P2Args A) {
-    if (A.st->err_code) return;
-    __shared__ uint32_t s_start[256];
-    __shared__ unsigned long long s_src[256];
-    __shared__ uint32_t s_rdb[256];
-    __shared__ uint32_t s_ws[4];
-    const PfV V = pf_v(A);
-    uint4* mrec = reinterpret_cast<uint4*>(A.pool + A.pfd->mrec);
-    pf_for_each_pair4(A, s_start, s_src, s_rdb, s_ws, [&](uint64_t* (&sp)[4], uint32_t (&)[4]) {
-        uint64_t e[4];
-        uint32_t px[4], py[4], kx[4], ky[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) e[r] = sp[r] ? *sp[r] : 0ull;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const uint32_t tx = (uint32_t)(e[r] >> 31) & 0x7FFFFFFFu, ty = (uint32_t)e[r] & 0x7FFFFFFFu;
-            px[r] = sp[r] ? V.pos[tx] : kNoPos; py[r] = sp[r] ? V.pos[ty] : kNoPos;
-            kx[r] = sp[r] ? V.rk[tx] & kRankMask : 0u; ky[r] = sp[r] ? V.rk[ty] & kRankMask : 0u;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (px[r] == kNoPos || py[r] == kNoPos) continue;
-            if (e[r] & kPairF) __hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(&mrec[2 * (size_t)px[r] + 1].z), 1ull << ky[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // x -> y
-            if (e[r] & kPairB) __hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(&mrec[2 * (size_t)py[r] + 1].z), 1ull << kx[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // y -> x
-        }
-    });
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -601,52 +614,41 @@ __global__ __launch_bounds__(256) void k_pf_adj(P2Args A) {
 //    components one batch after the other, 1024 threads and a CU to itself); a cell's ~9 tiles now run side by side, eight workgroups
 //    to a CU.  Columns and classes go to the cell's lists through its counters in global memory (one reservation per wave and
 //    batch); a component whose round meets a tie is set aside on the cell's list for k_p2_tied, as before.
-struct PcTile {   // what a cover workgroup needs of its tile
-    uint32_t j, n_tiny, comp_base, p0, n_pr, a0, na, b0, nb;
-};
-__device__ __forceinline__ PcTile pc_tile(const P2Args& A, const P2Cell& c, uint32_t i, uint32_t j) {
-    PcTile t;
-    const uint32_t i0 = c.tile0, i1 = c.tile0 + (c.R + A.tile - 1) / A.tile;
-    const uint32_t ti0 = pf_g(A, kQTiny, i0), mi0 = pf_g(A, kQMid, i0);
-    t.j = j; t.n_tiny = pf_g(A, kQTiny, i1) - ti0; t.comp_base = ti0 + mi0;
-    t.p0 = pf_g(A, kQPr, i); t.n_pr = pf_g(A, kQPr, i + 1) - t.p0;
-    t.a0 = pf_g(A, kQTiny, i) - ti0; t.na = pf_g(A, kQTiny, i + 1) - ti0 - t.a0;                      // the tile's slice of the cell's 3..8 list
-    t.b0 = t.n_tiny + (pf_g(A, kQMid, i) - mi0); t.nb = t.n_tiny + (pf_g(A, kQMid, i + 1) - mi0) - t.b0;   // ... of its 9..64 list
-    return t;
-}
 // (three kernels, not one: together they were 104 VGPRs and four waves per SIMD - the two-vertex rule alone runs at eight)
 __global__ __launch_bounds__(256) void k_pc_pairs(P2Args A) {
     if (A.st->err_code) return;
     __shared__ uint32_t s_stage[4][64 * kStageRefs];
-    const uint32_t i = blockIdx.x, j = A.tiles[i].x;
-    if (A.fb[j] || A.route[j]) return;
+    const PfTile T = A.ptile[blockIdx.x];
+    if (!T.live || !T.n_pr) return;
+    const uint32_t j = T.j, p0 = T.p0, n_pr = T.n_pr;
     const P2Cell c = A.cells[j];
     const PfDev& D = *A.pfd;
-    const PugCtx C = make_ctx(A, c, A.gcnt + 4 * (size_t)j);
-    const uint32_t p0 = pf_g(A, kQPr, i), n_pr = pf_g(A, kQPr, i + 1) - p0;
+    PugCtx C = make_ctx(A, c, A.gcnt + 4 * (size_t)j);
+    C.adj_umi = 1;
     // (the list holds dense numbers, the labels' keys lie in the dense arrays)
     p2_cover_pairs<256>(C, reinterpret_cast<const uint64_t*>(A.pool + D.lh), A.pool + D.loff, nullptr, A.pool + D.prv + 2ull * p0, n_pr, s_stage[threadIdx.x >> 6]);
 }
-__global__ __launch_bounds__(256) void k_pc_small(P2Args A) {
+// components of 3..4 vertices under short labels: a LANE each (cover_lane4), a WAVE per tile (a tile holds ~115 components of 3..8
+// vertices: as a 256-thread workgroup per tile two of its four waves had nothing to do, and at four workgroups to a CU the kernel
+// was the latency of one tile's chain of loads, over and over).  What is left - five vertices or more, a label of more than four
+// refs - goes onto the tile's slice of a list for k_pc_tiny8.
+__global__ __launch_bounds__(256) void k_pc_lane4(P2Args A) {
     if (A.st->err_code) return;
-    __shared__ uint32_t s_stage[4][64 * kStageRefs];
-    __shared__ uint16_t s_slow[1368];   // (a tile of 4096 slots holds at most 1365 components of three vertices)
-    __shared__ uint32_t s_nslow;
-    const uint32_t i = blockIdx.x, j = A.tiles[i].x;
-    if (A.fb[j] || A.route[j]) return;
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_nslow = 0;
-    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= A.n_tiles) return;
+    const PfTile T = A.ptile[i];
+    if (!T.live || !T.na) return;
+    const uint32_t j = T.j;
     const P2Cell c = A.cells[j];
     const PfDev& D = *A.pfd;
-    const PugCtx C = make_ctx(A, c, A.gcnt + 4 * (size_t)j);
-    const PcTile T = pc_tile(A, c, i, j);
+    PugCtx C = make_ctx(A, c, A.gcnt + 4 * (size_t)j);
+    C.adj_umi = 1;
     const uint4* mrec = reinterpret_cast<const uint4*>(A.pool + D.mrec);
     const uint32_t* mid_off = A.pool + D.midoff + T.comp_base;
     uint32_t* const tied = A.pool + D.tied + 4ull * (j + T.comp_base);
-    // components of 3..4 vertices under short labels: a lane each (cover_lane4); what is left - five vertices or more, a label of more
-    // than four refs - eight to a wave as before
-    for (uint32_t c0 = wv * 64; c0 < T.na; c0 += 256) {   // (uniform per wave)
+    uint16_t* slow = reinterpret_cast<uint16_t*>(A.pool + D.slow) + T.comp_base + T.a0;   // (one entry per component of the list: the tile's slice)
+    uint32_t nslow = 0;
+    for (uint32_t c0 = 0; c0 < T.na; c0 += 64) {   // (uniform)
         const uint32_t ci = c0 + lane;
         uint32_t b0c = 0, n = 0;
         if (ci < T.na) { b0c = mid_off[T.a0 + ci]; n = mid_off[T.a0 + ci + 1] - b0c; }
@@ -655,23 +657,42 @@ __global__ __launch_bounds__(256) void k_pc_small(P2Args A) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) if ((uint32_t)v < n) fast = fast && mrec[2 * (size_t)(b0c + v)].y <= 4;
         }
-        if (n != 0 && !fast) s_slow[atomicAdd(&s_nslow, 1u)] = (uint16_t)ci;
+        const uint64_t sm = __ballot(n != 0 && !fast);
+        if (n != 0 && !fast) slow[nslow + (uint32_t)__popcll(sm & ((1ull << lane) - 1))] = (uint16_t)ci;
+        nslow += (uint32_t)__popcll(sm);
         cover_lane4<kCoverDefer>(C, mrec, b0c, fast ? n : 0u, 0xFu, T.a0 + ci, tied, tied + 4);
     }
-    __syncthreads();
-    cover_tiny8<4, kCoverDefer>(C, mrec, mid_off + T.a0, s_nslow, wv, lane, tied, tied + 4, s_stage[wv], T.a0, s_slow);
+    if (lane == 0) A.ptile[i].pad[0] = nslow;
+}
+// ... and what cover_lane4 left over, eight components to a wave (cover_tiny8), a wave per tile again
+__global__ __launch_bounds__(256) void k_pc_tiny8(P2Args A) {
+    if (A.st->err_code) return;
+    __shared__ uint32_t s_stage[4][64 * kStageRefs];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, i = blockIdx.x * 4 + wv;
+    if (i >= A.n_tiles) return;
+    const PfTile T = A.ptile[i];
+    if (!T.live || !T.na || !T.pad[0]) return;
+    const uint32_t j = T.j;
+    const P2Cell c = A.cells[j];
+    const PfDev& D = *A.pfd;
+    PugCtx C = make_ctx(A, c, A.gcnt + 4 * (size_t)j);
+    C.adj_umi = 1;
+    const uint4* mrec = reinterpret_cast<const uint4*>(A.pool + D.mrec);
+    const uint32_t* mid_off = A.pool + D.midoff + T.comp_base;
+    uint32_t* const tied = A.pool + D.tied + 4ull * (j + T.comp_base);
+    const uint16_t* slow = reinterpret_cast<const uint16_t*>(A.pool + D.slow) + T.comp_base + T.a0;
+    cover_tiny8<1, kCoverDefer>(C, mrec, mid_off + T.a0, T.pad[0], 0u, lane, tied, tied + 4, s_stage[wv], T.a0, slow);
 }
 __global__ __launch_bounds__(256) void k_pc_mid(P2Args A) {
     if (A.st->err_code) return;
     __shared__ uint32_t s_stage[4][64 * kStageRefs];
-    const uint32_t i = blockIdx.x, j = A.tiles[i].x;
-    if (A.fb[j] || A.route[j]) return;
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const PfTile T = A.ptile[blockIdx.x];
+    if (!T.live || !T.nb) return;
+    const uint32_t j = T.j, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const P2Cell c = A.cells[j];
-    const PcTile T = pc_tile(A, c, i, j);
-    if (!T.nb) return;
     const PfDev& D = *A.pfd;
-    const PugCtx C = make_ctx(A, c, A.gcnt + 4 * (size_t)j);
+    PugCtx C = make_ctx(A, c, A.gcnt + 4 * (size_t)j);
+    C.adj_umi = 1;
     const uint4* mrec = reinterpret_cast<const uint4*>(A.pool + D.mrec);
     const uint32_t* mid_off = A.pool + D.midoff + T.comp_base;
     uint32_t* const tied = A.pool + D.tied + 4ull * (j + T.comp_base);
@@ -712,14 +733,15 @@ void launch_pf_build(hipStream_t s, const P2Args& a, uint64_t n_reads) {
         AFQ_LAUNCH(k_pf_move, pf_grid(a.n_parts, 256), 256, s, a);   // (gcnt[1], [2] still hold what k_p2_lone left: k_pf_cells raises them afterwards)
     }
     AFQ_LAUNCH(k_pf_cells, (a.n_cells + 255) / 256, 256, s, a);
+    AFQ_LAUNCH(k_pf_tiles, (a.n_tiles + 255) / 256, 256, s, a);
     AFQ_LAUNCH(k_pf_alloc, a.n_tiles, 256, s, a);
     AFQ_LAUNCH(k_pf_place, pf_grid(n_reads / 4 + 1, 512), 256, s, a);
-    AFQ_LAUNCH(k_pf_adj, pf_grid(a.n_parts, 256), 256, s, a);
 }
 void launch_pf_cover(hipStream_t s, const P2Args& a) {
     if (!a.n_cells) return;
     AFQ_LAUNCH(k_pc_pairs, a.n_tiles, 256, s, a);
-    AFQ_LAUNCH(k_pc_small, a.n_tiles, 256, s, a);
+    AFQ_LAUNCH(k_pc_lane4, (a.n_tiles + 3) / 4, 256, s, a);
+    AFQ_LAUNCH(k_pc_tiny8, (a.n_tiles + 3) / 4, 256, s, a);
     AFQ_LAUNCH(k_pc_mid, a.n_tiles, 256, s, a);
     AFQ_LAUNCH(k_pc_finish, (a.n_cells + 255) / 256, 256, s, a);
 }
