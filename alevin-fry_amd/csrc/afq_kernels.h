@@ -193,7 +193,7 @@ constexpr uint32_t kGDescWords = 20;    // per cell: what the graph phase hands 
 // The range-wide graph build (afq_pugflat.hip): one block per range, filled on the device.  Offsets are u32 words into the pool.
 struct PfDev {
     unsigned long long par, cnt, rk, umi, rc, tl, loff, tcell, lh;   // per vertex that has an edge [T]: root, component size -> first slot, position | size class, UMI, reads, slot inside the cell, label offset, its cell, label key
-    unsigned long long prv, midoff, mrec, tied, slow;    // two-vertex components (two slots each), first record slot per listed component (+ the end), 32-byte records, the covers' set-aside lists
+    unsigned long long prv, midoff, mrec, tied, slow, cmv;    // two-vertex components (two slots each), first record slot per listed component (+ the end), 32-byte records, the covers' set-aside lists
     uint32_t T, NP, NC, S;
     uint32_t n_old, pad[3];                        // cells routed to the per-cell graph kernel (old_list)
 };
@@ -252,6 +252,7 @@ void launch_p2_lone(hipStream_t s, const P2Args& a);
 void launch_p2_graph(hipStream_t s, const P2Args& a, uint64_t n_reads);
 void launch_pf_build(hipStream_t s, const P2Args& a, uint64_t n_reads);
 void launch_pf_cover(hipStream_t s, const P2Args& a);
+void launch_pf_resume(hipStream_t s, const P2Args& a);
 uint32_t pug_max_blocks();
 uint64_t pug_scratch_words(uint32_t nrec, uint32_t n_ref, bool gene_level);
 

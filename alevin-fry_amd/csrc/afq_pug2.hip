@@ -1514,9 +1514,16 @@ __global__ __launch_bounds__(CNT, CNT == 256 ? 4 : 1) void k_p2_cover(P2Args A, 
 //    one that held the minimum before it - equal keys are thereby shown to be equal labels), then a wave per component puts its
 //    records into the reference's order (rank by (class minimum, UMI), adjacency masks and the uncovered mask renumbered).  The
 //    covers then RESUME them (kCoverResume) from where they stopped.
-template <int CNT>
-__global__ __launch_bounds__(CNT) void k_p2_tied(P2Args A, uint32_t work_lo, uint32_t work_hi, uint32_t* counter) {
+// CMIN_ONLY (round 6, the cells of the range-wide graph build): the kernel stops behind the class minima - it leaves, per uncovered
+// vertex of a set-aside component, its class's smallest record offset beside the vertex's record (PfDev.cmv) - and the components
+// are put in order and resumed by k_pc_resume (afq_pugflat.hip), a lane / eight lanes / a wave each across the whole range.  In
+// this kernel that resume was half of a cell's time: three batches of eight components per wave, one behind the other, while
+// the other cells of the range waited for the CU (profiles/round6_14).  The other instance (the cells the build routed to the
+// per-cell kernels: list, n_list) goes on as before.
+template <int CNT, bool CMIN_ONLY>
+__global__ __launch_bounds__(CNT) void k_p2_tied(P2Args A, const uint32_t* list, const uint32_t* n_list, uint32_t work_lo, uint32_t work_hi, uint32_t* counter) {
     if (A.st->err_code) return;
+    if (n_list) work_hi = *n_list;
     constexpr uint32_t TSlots = CNT >= 1024 ? 8192u : 4096u, TKeys = TSlots * 3 / 8, BloomWords = TSlots / 16;   // (a batch holds < TKeys + 64 classes: load <= 0.4)
     __shared__ unsigned long long t_key[TSlots];
     __shared__ uint32_t t_min[TSlots];
@@ -1524,6 +1531,11 @@ __global__ __launch_bounds__(CNT) void k_p2_tied(P2Args A, uint32_t work_lo, uin
     __shared__ uint32_t s_cnt[4];
     __shared__ uint32_t s_next;
     __shared__ uint32_t s_ws[CNT / 64];
+#ifdef AFQ_PUG_TIMING
+    __shared__ unsigned long long tmark[8];
+    unsigned long long t_keys = 0, t_stream = 0, t_order = 0;
+#define T_ADD(acc, code) do { __syncthreads(); const unsigned long long t0__ = wall_clock64(); code; __syncthreads(); acc += wall_clock64() - t0__; } while (0)
+#endif
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   for (;;) {
     __syncthreads();
@@ -1531,8 +1543,9 @@ __global__ __launch_bounds__(CNT) void k_p2_tied(P2Args A, uint32_t work_lo, uin
     __syncthreads();
     const uint32_t work = s_next;
     if (work >= work_hi) return;
-    const uint32_t j = A.order[work];
+    const uint32_t j = list[work];
     const uint32_t* d = A.gdesc + kGDescWords * (size_t)j;
+    if (CMIN_ONLY != ((d[0] & 4u) != 0)) continue;   // (the range-wide build's cells / the per-cell graph kernel's: an instance each)
     if ((d[0] & 3u) != 3u) continue;   // nothing was set aside (the graph kernel ordered the cell's components itself), or the cell was handed to the one-workgroup kernel, or failed
     const P2Cell c = A.cells[j];
     auto at = [&](int k) -> uint32_t* { return A.pool + (((unsigned long long)d[k + 1] << 32) | d[k]); };
@@ -1567,6 +1580,7 @@ __global__ __launch_bounds__(CNT) void k_p2_tied(P2Args A, uint32_t work_lo, uin
     }
     gsync();
     const uint32_t n_batches = (n_keys + TKeys - 1) / TKeys;
+    G_MARK(0);
     auto mix = [](uint64_t h) -> uint32_t { uint32_t v = ((uint32_t)h ^ (uint32_t)(h >> 32)) * 0x9E3779B1u; return v ^ (v >> 15); };
     auto bloom_at = [&](uint32_t mx) -> uint32_t { return (mx >> 16) & (BloomWords * 32 - 1); };
     auto find = [&](uint64_t h, uint32_t mx, bool insert) -> uint32_t {   // slot of h, or 0xFFFFFFFF
@@ -1587,6 +1601,7 @@ __global__ __launch_bounds__(CNT) void k_p2_tied(P2Args A, uint32_t work_lo, uin
         for (uint32_t i = tid; i < TSlots; i += CNT) { t_key[i] = ~0ull; t_min[i] = 0xFFFFFFFFu; }
         for (uint32_t i = tid; i < BloomWords; i += CNT) s_bloom[i] = 0;
         __syncthreads();
+        G_MARK(1);
         // the classes that are asked for: the labels of the batch's uncovered vertices
         for (uint32_t e = tid; e < nE; e += CNT) {
             const uint32_t* en = entry(e);
@@ -1601,6 +1616,7 @@ __global__ __launch_bounds__(CNT) void k_p2_tied(P2Args A, uint32_t work_lo, uin
             }
         }
         __syncthreads();
+        G_MARK(2);
         // every vertex slot of the cell once (slots past a partition's last vertex hold key 0: no class), six per thread and trip
         for (uint32_t g0 = tid; g0 - tid < R; g0 += 6 * CNT) {
             uint64_t h6[6];
@@ -1623,6 +1639,24 @@ __global__ __launch_bounds__(CNT) void k_p2_tied(P2Args A, uint32_t work_lo, uin
                     !lab_equal(rec_label(C, off6[r]), rec_label(C, old6[r]))) s_cnt[3] = kErrLabelHash;
         }
         __syncthreads();
+        G_MARK(3);
+        if constexpr (CMIN_ONLY) {   // the minima to where k_pc_resume reads them: beside the records
+            uint32_t* cmv = A.pool + A.pfd->cmv;
+            for (uint32_t e = tid; e < nE; e += CNT) {
+                const uint32_t* en = entry(e);
+                if (en[3] / TKeys != b) continue;
+                const uint32_t b0 = mid_off[en[0]];
+                for (uint64_t m = ((uint64_t)en[2] << 32) | en[1]; m; m &= m - 1) {
+                    const uint32_t at = b0 + (uint32_t)__builtin_ctzll(m);
+                    const uint64_t h = ch[mrec[2 * (size_t)at].x];
+                    const uint32_t slot = find(h, mix(h), false);
+                    const uint32_t mn = slot == 0xFFFFFFFFu ? 0xFFFFFFFFu : t_min[slot];
+                    if (mn >> 31) s_cnt[3] = kErrInternal;   // (every asked-for class has at least the vertex that asked; record offsets are dword offsets inside a chunk: below 2^30)
+                    cmv[at] = mn;
+                }
+            }
+            continue;
+        }
         // The batch's components, their records into the reference's order.  An order key: the vertices still uncovered by
         // (class minimum, UMI), the covered ones behind them as they lie.  Components of up to eight vertices (the list of
         // cover_tiny8) EIGHT to a wave, a group of eight lanes each - a wave to each was a chain of five dependent round trips
@@ -1703,10 +1737,20 @@ __global__ __launch_bounds__(CNT) void k_p2_tied(P2Args A, uint32_t work_lo, uin
     }
     gsync();
     if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], c.cell); return; }
+    if constexpr (CMIN_ONLY) continue;
+    G_MARK(4);
     uint32_t* const stage = reinterpret_cast<uint32_t*>(t_key) + (size_t)wv * 64 * kStageRefs;   // (the class table is dead: 4 KiB of it per wave stage the labels)
     cover_tiny8<CNT / 64, kCoverResume>(C, mrec, mid_off, nA, wv, lane, nullptr, listA, stage);
     cover_wave64<CNT / 64, kCoverResume>(C, mrec, mid_off, 0u, nB, wv, lane, nullptr, listB, stage);
     gsync();
+    G_MARK(5);
+#ifdef AFQ_PUG_TIMING
+    if (tid == 0 && (work % 512) < 2) {
+        auto us = [&](int a, int b) { return (double)(tmark[b] - tmark[a]) / 100.0; };
+        printf("p2 tied cell R=%u entries=%u+%u keys=%u batches=%u: init=%.0f keys=%.0f stream=%.0f order=%.0f resume=%.0f total=%.0f us (last batch's marks)\n",
+               R, nA, nB, n_keys, n_batches, us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(0, 5));
+    }
+#endif
     if (s_cnt[3]) { if (tid == 0) set_err(A.st, s_cnt[3], c.cell); return; }
     if (tid == 0) {
         A.cell_ncols[c.cell] = s_cnt[0];
@@ -1756,6 +1800,12 @@ void launch_p2_graph(hipStream_t s, const P2Args& a, uint64_t n_reads) {
         launch_pf_cover(s, a);   // (the covers of every cell the build did not route away: a workgroup per tile)
         AFQ_LAUNCH(k_p2_graph<1024>, std::min(a.n_cells, ucus), 1024, s, a, a.old_list, &a.pfd->n_old, 0u, 0u, wc + 2);
         AFQ_LAUNCH(k_p2_cover<1024>, std::min(a.n_cells, ucus), 1024, s, a, a.old_list, &a.pfd->n_old, 0u, 0u, wc + 3);
+        // the ties: the class minima per cell (the first half of k_p2_tied), order and resume range-wide; the routed cells as before
+        if (n_big) AFQ_LAUNCH((k_p2_tied<1024, true>), std::min(n_big, ucus), 1024, s, a, a.order, (const uint32_t*)nullptr, 0u, n_big, wc + 5);
+        if (rest) AFQ_LAUNCH((k_p2_tied<kGNT, true>), std::min(rest, 3 * ucus), kGNT, s, a, a.order, (const uint32_t*)nullptr, n_big, a.n_cells, wc + 4);
+        launch_pf_resume(s, a);
+        AFQ_LAUNCH((k_p2_tied<1024, false>), std::min(a.n_cells, ucus), 1024, s, a, a.old_list, &a.pfd->n_old, 0u, 0u, wc + 6);
+        return;
     } else {
         if (n_big) AFQ_LAUNCH(k_p2_graph<1024>, std::min(n_big, ucus), 1024, s, a, a.order, (const uint32_t*)nullptr, 0u, n_big, wc + 2);
         if (rest) AFQ_LAUNCH(k_p2_graph<kGNT>, std::min(rest, 4 * ucus), kGNT, s, a, a.order, (const uint32_t*)nullptr, n_big, a.n_cells, wc);
@@ -1763,8 +1813,8 @@ void launch_p2_graph(hipStream_t s, const P2Args& a, uint64_t n_reads) {
         if (rest) AFQ_LAUNCH(k_p2_cover<kGNT>, std::min(rest, 4 * ucus), kGNT, s, a, a.order, (const uint32_t*)nullptr, n_big, a.n_cells, wc + 1);
     }
     // ... and the components the covers set aside at a tie, in the reference's order
-    if (n_big) AFQ_LAUNCH(k_p2_tied<1024>, std::min(n_big, ucus), 1024, s, a, 0u, n_big, wc + 5);
-    if (rest) AFQ_LAUNCH(k_p2_tied<kGNT>, std::min(rest, 3 * ucus), kGNT, s, a, n_big, a.n_cells, wc + 4);
+    if (n_big) AFQ_LAUNCH((k_p2_tied<1024, false>), std::min(n_big, ucus), 1024, s, a, a.order, (const uint32_t*)nullptr, 0u, n_big, wc + 5);
+    if (rest) AFQ_LAUNCH((k_p2_tied<kGNT, false>), std::min(rest, 3 * ucus), kGNT, s, a, a.order, (const uint32_t*)nullptr, n_big, a.n_cells, wc + 4);
 }
 
 }  // namespace afq

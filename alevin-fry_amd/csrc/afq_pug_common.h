@@ -371,7 +371,7 @@ __device__ __forceinline__ void cover_tiny8(const PugCtx& C, const uint4* mrec, 
             uint32_t ci = c0 + grp;
             if (idx) ci = gvalid ? idx[c0 + grp] : 0u;
             uint32_t uc0 = 0xFFu;
-            if constexpr (MODE == kCoverResume) { ci = gvalid ? tied[4 * (c0 + grp)] : 0u; uc0 = gvalid ? tied[4 * (c0 + grp) + 1] & 0xFFu : 0u; }
+            if constexpr (MODE == kCoverResume) { const uint32_t e = ci; ci = gvalid ? tied[4 * e] : 0u; uc0 = gvalid ? tied[4 * e + 1] & 0xFFu : 0u; }   // (idx: the list ENTRIES to take)
             const uint32_t b0 = gvalid ? mid_off[ci] : 0u, n = gvalid ? mid_off[ci + 1] - b0 : 0u;
             const bool act = gl < n;
             uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
@@ -530,35 +530,75 @@ __device__ __forceinline__ void cover_tiny8(const PugCtx& C, const uint4* mrec, 
 // arborescence wins; kCoverDefer sets a component aside at the first round with two different largest vertex sets.
 // Wave-wide call: lane's component = records b0 .. b0 + n - 1 (n = 0: none), uc0 = the vertices still uncovered, ci = its index for
 // the set-aside list.  (kCoverResume: uc0 comes from the list, no tie is tracked - the records are in the reference's order.)
-template <int MODE>
-__device__ __forceinline__ void cover_lane4(const PugCtx& C, const uint4* mrec, uint32_t b0, uint32_t n, uint32_t uc0, uint32_t ci,
-                                            uint32_t* tied_cnt = nullptr, uint32_t* tied = nullptr) {
+struct Lane4 {   // a component of up to four vertices in one lane's registers
+    uint32_t rf[4][4];   // the labels' refs (0xFFFFFFFF past a label's end)
+    uint32_t ln[4];      // the labels' lengths (<= 4)
+    uint32_t um[4], rc[4];   // records with (UMI, reads): those; else the adjacency mask's words
+    uint32_t adjm;       // out-neighbours of vertex v: bits 4 v .. 4 v + 3
+};
+__device__ __forceinline__ void lane4_load(const PugCtx& C, const uint4* mrec, uint32_t b0, uint32_t n, Lane4& L) {
     constexpr uint32_t kNo = 0xFFFFFFFFu;
-    uint32_t rf[4][4], ln[4], um[4], rc[4], adjm = 0;
+    L.adjm = 0;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         uint4 qa = make_uint4(0, 0, kNo, kNo), qb = make_uint4(kNo, kNo, 0, 0);
         if ((uint32_t)v < n) { qa = mrec[2 * (size_t)(b0 + v)]; qb = mrec[2 * (size_t)(b0 + v) + 1]; }
-        ln[v] = qa.y; rf[v][0] = qa.z; rf[v][1] = qa.w; rf[v][2] = qb.x; rf[v][3] = qb.y;
-        um[v] = qb.z; rc[v] = qb.w;
-        adjm |= (qb.z & 0xFu) << (4 * v);
+        L.ln[v] = qa.y; L.rf[v][0] = qa.z; L.rf[v][1] = qa.w; L.rf[v][2] = qb.x; L.rf[v][3] = qb.y;
+        L.um[v] = qb.z; L.rc[v] = qb.w;
+        L.adjm |= (qb.z & 0xFu) << (4 * v);
     }
-    auto has = [&](int u, uint32_t t) -> bool { return t == rf[u][0] || t == rf[u][1] || t == rf[u][2] || t == rf[u][3]; };
     if (C.adj_umi) {   // (wave-uniform) the records hold (UMI, reads) in place of the mask: the edges from umi_edge and the labels
-        adjm = 0;
+        L.adjm = 0;
 #pragma unroll
         for (int v = 0; v < 4; ++v)
 #pragma unroll
             for (int u = v + 1; u < 4; ++u) {
                 bool ov = false;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ov = ov || ((uint32_t)j < ln[v] && has(u, rf[v][j]));
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t t = L.rf[v][j];
+                    ov = ov || ((uint32_t)j < L.ln[v] && (t == L.rf[u][0] || t == L.rf[u][1] || t == L.rf[u][2] || t == L.rf[u][3]));
+                }
                 ov = ov && (uint32_t)u < n;
-                if (ov && umi_edge(um[v], rc[v], um[u], rc[u], C.exact_umi)) adjm |= 1u << (4 * v + u);
-                if (ov && umi_edge(um[u], rc[u], um[v], rc[v], C.exact_umi)) adjm |= 1u << (4 * u + v);
+                if (ov && umi_edge(L.um[v], L.rc[v], L.um[u], L.rc[u], C.exact_umi)) L.adjm |= 1u << (4 * v + u);
+                if (ov && umi_edge(L.um[u], L.rc[u], L.um[v], L.rc[v], C.exact_umi)) L.adjm |= 1u << (4 * u + v);
             }
     }
-    uint32_t UC = n ? uc0 & ((1u << n) - 1u) : 0u;
+}
+// The vertices of L renumbered: vertex v becomes vertex rank[v] (a permutation of 0..3; vertices past the component's end keep
+// their places) - labels, adjacency rows and columns, and the mask uc.  Every index a constant: selects, no memory.
+__device__ __forceinline__ void lane4_permute(Lane4& L, const uint32_t (&rank)[4], uint32_t& uc) {
+    Lane4 P;
+    P.adjm = 0;
+    uint32_t nuc = 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        P.ln[p] = 0; P.um[p] = 0; P.rc[p] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) P.rf[p][j] = 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        uint32_t row = 0;   // v's out-neighbours under the new numbers
+#pragma unroll
+        for (int u = 0; u < 4; ++u) row |= ((L.adjm >> (4 * v + u)) & 1u) << rank[u];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (rank[v] != (uint32_t)p) continue;
+            P.ln[p] = L.ln[v]; P.um[p] = L.um[v]; P.rc[p] = L.rc[v];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) P.rf[p][j] = L.rf[v][j];
+            P.adjm |= row << (4 * p);
+        }
+        nuc |= ((uc >> v) & 1u) << rank[v];
+    }
+    L = P; uc = nuc;
+}
+// The cover rounds of the component in L from the uncovered vertices UC on.  Wave-wide call (a lane without a component: UC = 0).
+template <int MODE>
+__device__ __forceinline__ void lane4_rounds(const PugCtx& C, const Lane4& L, uint32_t UC, uint32_t ci, uint32_t* tied_cnt, uint32_t* tied) {
+    constexpr uint32_t kNo = 0xFFFFFFFFu;
+    auto has = [&](int u, uint32_t t) -> bool { return t == L.rf[u][0] || t == L.rf[u][1] || t == L.rf[u][2] || t == L.rf[u][3]; };
     while (__any(UC != 0)) {
         const uint32_t remaining = (uint32_t)__popc(UC);
         uint32_t best = 0, best_sz = 0;
@@ -570,8 +610,8 @@ __device__ __forceinline__ void cover_lane4(const PugCtx& C, const uint4* mrec, 
             bool tie_v = false;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const bool on = von && (uint32_t)j < ln[v];
-                const uint32_t t = rf[v][j];
+                const bool on = von && (uint32_t)j < L.ln[v];
+                const uint32_t t = L.rf[v][j];
                 uint32_t At = 0;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) At |= (((UC >> u) & 1u) && has(u, t)) ? 1u << u : 0u;
@@ -580,7 +620,7 @@ __device__ __forceinline__ void cover_lane4(const PugCtx& C, const uint4* mrec, 
                 for (int step = 0; step < 3; ++step) {   // (a path through four vertices has three edges)
                     uint32_t N = 0;
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) N |= ((Rm >> x) & 1u) ? (adjm >> (4 * x)) & 0xFu : 0u;
+                    for (int x = 0; x < 4; ++x) N |= ((Rm >> x) & 1u) ? (L.adjm >> (4 * x)) & 0xFu : 0u;
                     Rm |= N & At;
                 }
                 const uint32_t sz = (uint32_t)__popc(Rm);
@@ -609,11 +649,11 @@ __device__ __forceinline__ void cover_lane4(const PugCtx& C, const uint4* mrec, 
         if (UC != 0 && best == 0) { C.s_cnt[3] = kErrPugLimit; UC = 0; }   // a vertex with an empty label
         // the refs every vertex of the arborescence holds (pugutils.rs:1161-1188) -> genes -> the molecule's column or class
         const uint32_t fv = best ? (uint32_t)__builtin_ctz(best) : 0u;
-        const uint32_t lfn = best ? (fv == 0 ? ln[0] : fv == 1 ? ln[1] : fv == 2 ? ln[2] : ln[3]) : 0u;
+        const uint32_t lfn = best ? (fv == 0 ? L.ln[0] : fv == 1 ? L.ln[1] : fv == 2 ? L.ln[2] : L.ln[3]) : 0u;
         uint32_t c4[4] = {kNo, kNo, kNo, kNo}, k4 = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t t = fv == 0 ? rf[0][j] : fv == 1 ? rf[1][j] : fv == 2 ? rf[2][j] : rf[3][j];
+            const uint32_t t = fv == 0 ? L.rf[0][j] : fv == 1 ? L.rf[1][j] : fv == 2 ? L.rf[2][j] : L.rf[3][j];
             bool all = (uint32_t)j < lfn;
 #pragma unroll
             for (int u = 0; u < 4; ++u) all = all && (!((best >> u) & 1u) || has(u, t));
@@ -630,6 +670,13 @@ __device__ __forceinline__ void cover_lane4(const PugCtx& C, const uint4* mrec, 
         append_class2(C, cls, c4[0], c4[1]);
         UC &= ~best;
     }
+}
+template <int MODE>
+__device__ __forceinline__ void cover_lane4(const PugCtx& C, const uint4* mrec, uint32_t b0, uint32_t n, uint32_t uc0, uint32_t ci,
+                                            uint32_t* tied_cnt = nullptr, uint32_t* tied = nullptr) {
+    Lane4 L;
+    lane4_load(C, mrec, b0, n, L);
+    lane4_rounds<MODE>(C, L, n ? uc0 & ((1u << n) - 1u) : 0u, ci, tied_cnt, tied);
 }
 
 // ---- components of 9..64 vertices (entries n_tiny.. of the list): one wave each, adjacency = one 64-bit mask per lane ----

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(1024) void k_pf_scan2(P2Args A, uint32_t q0) {
         D.T = (uint32_t)T;
     } else if (Q >= 5) {   // the lists: pairs, first record slot per listed component (+ the end), records, the covers' set-aside lists
         const unsigned long long NP = s_tot[0], NC = (unsigned long long)s_tot[1] + s_tot[Q >= 5 ? 2 : 0], S = (unsigned long long)s_tot[Q >= 5 ? 3 : 0] + s_tot[Q >= 5 ? 4 : 0];
-        const unsigned long long words = 2 * NP + 4 + (NC + 4) + 8 * S + 8 + 4 * (NC + A.n_cells) + 8 + NC / 2 + 4;
+        const unsigned long long words = 2 * NP + 4 + (NC + 4) + 8 * S + 8 + 4 * (NC + A.n_cells) + 8 + NC / 2 + 4 + S + 4;
         const unsigned long long base = atomicAdd(A.pool_cur, words);
         if (base + words > A.pool_cap || S >= (1ull << 32)) { set_err(A.st, kErrPugPool, 0); return; }
         unsigned long long o = (base + 3) & ~3ull;
@@ -197,7 +197,8 @@ __global__ __launch_bounds__(1024) void k_pf_scan2(P2Args A, uint32_t q0) {
         D.midoff = o; o += NC + 2;
         o = (o + 3) & ~3ull;
         D.tied = o; o += 4 * (NC + A.n_cells) + 4;
-        D.slow = o;   // (16-bit entries, one per listed component)
+        D.slow = o; o += NC / 2 + 2;   // (16-bit entries, one per listed component)
+        D.cmv = o;                    // per record slot: its class's smallest record offset (k_p2_tied, for the vertices of set-aside components)
         D.NP = (uint32_t)NP; D.NC = (uint32_t)NC; D.S = (uint32_t)S;
         A.pool[D.midoff + NC] = (uint32_t)S;   // the list's last offset
     }
@@ -698,6 +699,146 @@ __global__ __launch_bounds__(256) void k_pc_mid(P2Args A) {
     uint32_t* const tied = A.pool + D.tied + 4ull * (j + T.comp_base);
     cover_wave64<4, kCoverDefer>(C, mrec, mid_off + T.b0, 0u, T.nb, wv, lane, tied + 1, tied + 4 + 4 * (size_t)T.n_tiny, s_stage[wv], T.b0);
 }
+// 10. the components the covers set aside at a tie, once k_p2_tied has left their classes' smallest record offsets beside their
+//     records (PfDev.cmv): into the reference's order - class by first appearance, then UMI (pugutils.rs:1090-1160 takes the first
+//     largest arborescence it meets) - and on with their covers.  A cell's two lists are dealt to the waves of its tiles, 64
+//     entries at a time: a component of 3..4 vertices under short labels is renumbered and finished in ONE LANE's registers
+//     (lane4_permute, lane4_rounds); the others have their records rewritten in order - a group of eight lanes, or the wave, per
+//     component - and cover_tiny8 / cover_wave64 resume them.  (The UMI of an order key lies in the record: nothing here reads a
+//     per-slot array.)
+__global__ __launch_bounds__(256) void k_pc_resume(P2Args A) {
+    if (A.st->err_code) return;
+    __shared__ uint32_t s_stage[4][64 * kStageRefs];
+    __shared__ uint16_t s_slow[4][64];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, i = blockIdx.x * 4 + wv;
+    if (i >= A.n_tiles) return;
+    const PfTile T = A.ptile[i];
+    if (!T.live) return;
+    const uint32_t j = T.j;
+    const PfDev& D = *A.pfd;
+    uint32_t* tied = A.pool + D.tied + 4ull * (j + T.comp_base);
+    const uint32_t nA = tied[0], nB = tied[1];
+    if (!(nA | nB)) return;
+    const P2Cell c = A.cells[j];
+    const uint32_t wg = i - c.tile0, n_wg = (c.R + A.tile - 1) / A.tile;
+    uint32_t* gc = A.gcnt + 4 * (size_t)j;
+    PugCtx C = make_ctx(A, c, gc);
+    C.adj_umi = 1;
+    uint32_t* listA = tied + 4;
+    uint32_t* listB = tied + 4 + 4 * (size_t)T.n_tiny;
+    const uint32_t* mid_off = A.pool + D.midoff + T.comp_base;
+    uint4* mrec = reinterpret_cast<uint4*>(A.pool + D.mrec);
+    const uint32_t* cmv = A.pool + D.cmv;
+    // the order key of the vertex in record slot `at`: still uncovered: (its class's smallest record offset, its UMI); covered: behind them, as it lies
+    auto order_key = [&](bool act, uint32_t pos, uint64_t uc, uint32_t at, uint32_t umi) -> uint64_t {
+        if (!act) return ~0ull;
+        if (!((uc >> pos) & 1ull)) return (1ull << 63) | pos;
+        const uint32_t mn = cmv[at];
+        if (mn >> 31) gc[3] = kErrInternal;
+        return ((uint64_t)(mn & 0x7FFFFFFFu) << 32) | umi;
+    };
+    // ---- the 3..8 list ----
+    for (uint32_t e0 = wg * 64; e0 < nA; e0 += n_wg * 64) {   // (uniform per wave)
+        const uint32_t e = e0 + lane;
+        uint32_t b0c = 0, n = 0, uc = 0, ci = 0;
+        uint32_t* en = listA + 4 * (size_t)(e < nA ? e : 0u);
+        if (e < nA) { ci = en[0]; uc = en[1] & 0xFFu; b0c = mid_off[ci]; n = mid_off[ci + 1] - b0c; }
+        bool fast = n != 0 && n <= 4;
+        Lane4 L;
+        lane4_load(C, mrec, b0c, fast ? n : 0u, L);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) fast = fast && L.ln[v] <= 4;
+        const uint64_t sm = __ballot(n != 0 && !fast);
+        if (n != 0 && !fast) s_slow[wv][__popcll(sm & ((1ull << lane) - 1))] = (uint16_t)lane;   // (the entry's place in this trip's 64)
+        const uint32_t nslow = (uint32_t)__popcll(sm);
+        if (!fast) uc = 0;
+        uint64_t key[4];
+        uint32_t rank[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) key[v] = order_key(fast && (uint32_t)v < n, (uint32_t)v, uc, b0c + (uint32_t)v, L.um[v]);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            rank[v] = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                rank[v] += (u != v && key[u] < key[v]) ? 1u : 0u;
+                if (u < v && key[u] == key[v] && key[v] != ~0ull) gc[3] = kErrInternal;   // (two vertices of one component with the same class and UMI: cannot be)
+            }
+            if (!(fast && (uint32_t)v < n)) rank[v] = (uint32_t)v;   // (past the component's end: they stay where they are)
+        }
+        lane4_permute(L, rank, uc);
+        lane4_rounds<kCoverResume>(C, L, uc, ci, nullptr, nullptr);
+        if (!nslow) continue;   // (uniform)
+        // the others: their records into the reference's order where they lie (a group of eight lanes per component), then cover_tiny8 resumes them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {
+            const uint32_t gl = lane & 7u, gbase = lane & ~7u, grp = lane >> 3;
+            for (uint32_t q0 = 0; q0 < nslow; q0 += 8) {   // (uniform)
+                const uint32_t q = q0 + grp;
+                const bool mine = q < nslow;
+                uint32_t* en2 = listA + 4 * (size_t)(e0 + (mine ? s_slow[wv][q] : 0u));
+                const uint32_t ci2 = mine ? en2[0] : 0u;
+                const uint32_t uc2 = mine ? en2[1] & 0xFFu : 0u;
+                const uint32_t b0 = mine ? mid_off[ci2] : 0u, n2 = mine ? mid_off[ci2 + 1] - b0 : 0u;
+                const bool act = gl < n2;
+                uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
+                if (act) { qa = mrec[2 * (size_t)(b0 + gl)]; qb = mrec[2 * (size_t)(b0 + gl) + 1]; }
+                const uint64_t key2 = order_key(act, gl, uc2, b0 + gl, qb.z);
+                uint32_t rk = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 8; ++k) {
+                    const uint64_t kk = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(key2 >> 32), (int)(gbase + k)) << 32) | (uint32_t)__shfl((int)(uint32_t)key2, (int)(gbase + k));
+                    rk += k < n2 && kk < key2 ? 1u : 0u;
+                    if (act && k < n2 && k != gl && kk == key2) gc[3] = kErrInternal;
+                }
+                uint32_t nuc = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 8; ++k) {
+                    const uint32_t rkk = (uint32_t)__shfl((int)rk, (int)(gbase + k));
+                    if (k < n2 && ((uc2 >> k) & 1u)) nuc |= 1u << rkk;
+                }
+                if (act) {   // (every lane holds its record in registers: the slots can be overwritten; the records keep their (UMI, reads))
+                    mrec[2 * (size_t)(b0 + rk)] = qa;
+                    mrec[2 * (size_t)(b0 + rk) + 1] = qb;
+                }
+                if (mine && gl == 0) { en2[1] = nuc; en2[2] = 0u; }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        cover_tiny8<1, kCoverResume>(C, mrec, mid_off, nslow, 0u, lane, nullptr, listA + 4 * (size_t)e0, s_stage[wv], 0u, s_slow[wv]);
+    }
+    // ---- the 9..64 list: this wave's run of it, a component at a time ----
+    const uint32_t b_per = (nB + n_wg - 1) / n_wg, b_lo = min(nB, wg * b_per), b_hi = min(nB, b_lo + b_per);
+    for (uint32_t e = b_lo; e < b_hi; ++e) {   // (uniform)
+        uint32_t* en = listB + 4 * (size_t)e;
+        const uint32_t ci = en[0];
+        const uint64_t uc = ((uint64_t)en[2] << 32) | en[1];
+        const uint32_t b0 = mid_off[ci], n = mid_off[ci + 1] - b0;
+        const bool act = lane < n;
+        uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
+        if (act) { qa = mrec[2 * (size_t)(b0 + lane)]; qb = mrec[2 * (size_t)(b0 + lane) + 1]; }
+        const uint64_t key = order_key(act, lane, uc, b0 + lane, qb.z);
+        uint32_t rk = 0;
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint64_t kk = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), (int)k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, (int)k);
+            rk += kk < key ? 1u : 0u;
+            if (kk == key && k != lane && act) gc[3] = kErrInternal;
+        }
+        uint64_t nuc = 0;
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint32_t rkk = (uint32_t)__builtin_amdgcn_readlane((int)rk, (int)k);
+            if ((uc >> k) & 1ull) nuc |= 1ull << rkk;
+        }
+        if (act) { mrec[2 * (size_t)(b0 + rk)] = qa; mrec[2 * (size_t)(b0 + rk) + 1] = qb; }
+        if (lane == 0) { en[1] = (uint32_t)nuc; en[2] = (uint32_t)(nuc >> 32); }
+    }
+    if (b_hi > b_lo) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        cover_wave64<1, kCoverResume>(C, mrec, mid_off, 0u, b_hi - b_lo, 0u, lane, nullptr, listB + 4 * (size_t)b_lo, s_stage[wv]);
+    }
+}
 // ... and a thread per cell: what the covers left in the cell's counters (an error of theirs, the lengths of its column list and
 // label area) to where the kernels behind them read it
 __global__ __launch_bounds__(256) void k_pc_finish(P2Args A) {
@@ -743,6 +884,10 @@ void launch_pf_cover(hipStream_t s, const P2Args& a) {
     AFQ_LAUNCH(k_pc_lane4, (a.n_tiles + 3) / 4, 256, s, a);
     AFQ_LAUNCH(k_pc_tiny8, (a.n_tiles + 3) / 4, 256, s, a);
     AFQ_LAUNCH(k_pc_mid, a.n_tiles, 256, s, a);
+}
+void launch_pf_resume(hipStream_t s, const P2Args& a) {
+    if (!a.n_cells) return;
+    AFQ_LAUNCH(k_pc_resume, (a.n_tiles + 3) / 4, 256, s, a);
     AFQ_LAUNCH(k_pc_finish, (a.n_cells + 255) / 256, 256, s, a);
 }
 
