@@ -353,9 +353,11 @@ __global__ __launch_bounds__(256) void k_pf_root(P2Args A) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) if (p[i] != r[i]) { r[i] = p[i]; p[i] = V.par[r[i]]; go = true; }
         }
+        // (a root is vertex 0 of its component and counts nothing: its counter ends at the component's size less one - a component in
+        //  eight has three vertices or more, so more than two atomics in five are roots' and never made)
         uint32_t k[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) k[i] = on[i] ? atomicAdd(&V.cnt[r[i]], 1u) : 0u;
+        for (int i = 0; i < 4; ++i) k[i] = on[i] && r[i] != t0 + 256u * (uint32_t)i ? atomicAdd(&V.cnt[r[i]], 1u) + 1u : 0u;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t t = t0 + 256u * (uint32_t)i;
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256) void k_pf_cats(P2Args A) {
         for (uint32_t t0 = tb; t0 < te; t0 += 256) {   // (uniform)
             const uint32_t t = t0 + threadIdx.x;
             const bool root = t < te && V.par[t] == t;
-            const uint32_t n = root ? V.cnt[t] : 0u;
+            const uint32_t n = root ? V.cnt[t] + 1u : 0u;   // (the root itself is not counted: k_pf_root)
             const uint32_t cat = root ? cat_of(n, A.large_thresh) : 0u;
             big = big || (root && cat == 0);
             const uint32_t npr = (uint32_t)__popcll(__ballot(cat == kFCatPair)), nti = (uint32_t)__popcll(__ballot(cat == kFCatTiny)), nmi = (uint32_t)__popcll(__ballot(cat == kFCatMid));
@@ -545,7 +547,7 @@ __global__ __launch_bounds__(256) void k_pf_alloc(P2Args A) {
     for (uint32_t t0 = tb; t0 < te; t0 += 256) {   // (uniform)
         const uint32_t t = t0 + threadIdx.x;
         const bool root = t < te && V.par[t] == t;
-        const uint32_t n = root ? V.cnt[t] : 0u;
+        const uint32_t n = root ? V.cnt[t] + 1u : 0u;
         const uint32_t cat = root ? cat_of(n, A.large_thresh) : 0u;
         // (up to 256 roots per trip: three 10-bit counts in one word; record slots: <= 2048 and <= 16384)
         const uint32_t vc = (cat == kFCatPair ? 1u : 0u) | (cat == kFCatTiny ? 1u << 10 : 0u) | (cat == kFCatMid ? 1u << 20 : 0u);
