@@ -89,7 +89,9 @@ __device__ __forceinline__ PugCtx make_ctx(const P2Args& A, const P2Cell& c, uin
 // The two-vertex components of one cell: one molecule each, the refs both labels share (pugutils.rs:1161-1188).  The NT threads of
 // the workgroup take the n_pr components of pr_v (two vertices each; tl: touched-vertex number -> slot, or nullptr when the list
 // holds slots); stage_wave: this wave's 64 x kStageRefs words of LDS.  Workgroup-wide call.
-template <int NT>
+// (GL: as in cover_tiny8 - a first label of more refs than the stage holds has its shared refs' genes sorted in the first gene row
+//  behind the wave's stage, its lanes one after the other, not in a private array.)
+template <int NT, bool GL = false>
 __device__ __forceinline__ void p2_cover_pairs(const PugCtx& C, const uint64_t* ch, const uint32_t* coff, const uint32_t* tl, const uint32_t* pr_v, uint32_t n_pr, uint32_t* stage_wave) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     for (uint32_t k = tid; k - lane < n_pr; k += NT) {   // (wave-uniform trip count: append_cols is a wave-wide call)
@@ -147,8 +149,30 @@ __device__ __forceinline__ void p2_cover_pairs(const PugCtx& C, const uint64_t* 
                 for (uint32_t q = 0; q < kStageRefs; ++q) row[q] = t1[q];
                 const uint32_t ng = sort_unique_in_row(row, kStageRefs);
                 emit_molecule(C, row, ng);
-            } else {
+            } else if (!GL) {
                 uint32_t g[kMaxGenesPerLabel];
+                uint32_t ng = 0;
+                for (uint32_t jj = 0; jj < l.n && ng != 0xFFFFFFFFu; ++jj) {
+                    const uint32_t t = l.p[jj] & 0x7FFFFFFFu;
+                    if (!in_l2(t)) continue;
+                    const uint32_t gid = C.t2g[t];
+                    uint32_t qq = 0;
+                    while (qq < ng && g[qq] < gid) ++qq;
+                    if (qq < ng && g[qq] == gid) continue;
+                    if (ng == kMaxGenesPerLabel) { ng = 0xFFFFFFFFu; break; }
+                    for (uint32_t r = ng; r > qq; --r) g[r] = g[r - 1];
+                    g[qq] = gid;
+                    ++ng;
+                }
+                if (ng == 0xFFFFFFFFu && C.em)
+                    emit_wide_class(C, l.n, [&](uint32_t jj) -> uint32_t { const uint32_t t = l.p[jj] & 0x7FFFFFFFu; return in_l2(t) ? t : 0xFFFFFFFFu; });
+                else emit_molecule(C, g, ng);
+            }
+        }
+        if constexpr (GL) {   // first labels of more than kStageRefs refs (rare): the lanes that hold one, one after the other, through one LDS gene row
+            for (uint64_t lm = __ballot(k < n_pr && l.n > kStageRefs); lm; lm &= lm - 1) {
+                if (lane != (uint32_t)__builtin_ctzll(lm)) continue;
+                uint32_t* const g = stage_wave + 64 * kStageRefs;
                 uint32_t ng = 0;
                 for (uint32_t jj = 0; jj < l.n && ng != 0xFFFFFFFFu; ++jj) {
                     const uint32_t t = l.p[jj] & 0x7FFFFFFFu;

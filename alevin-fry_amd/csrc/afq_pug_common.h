@@ -300,19 +300,23 @@ __device__ __forceinline__ void rec_lab(const uint4* mrec, size_t slot, RecLab& 
     if (qa.y <= 4) { o.r[0] = qa.z; o.r[1] = qa.w; o.r[2] = qb.x; o.r[3] = qb.y; o.l.p = o.r; }
     else o.l.p = reinterpret_cast<const uint32_t*>((uintptr_t)(((uint64_t)qa.w << 32) | qa.z));
 }
+__device__ __forceinline__ bool rec_contains(const uint4& qa, const uint4& qb, uint32_t t) {
+    if (qa.y <= 4) return t == qa.z || t == qa.w || t == qb.x || t == qb.y;   // (unused places hold 0xFFFFFFFF: no ref)
+    const Lab l{reinterpret_cast<const uint32_t*>((uintptr_t)(((uint64_t)qa.w << 32) | qa.z)), qa.y};
+    return lab_contains(l, t);
+}
 // cand() of emit_wide_class for a component held in those records: ref j of the vertex in slot b0 + fv if every vertex
-// of `mask` (bit i = slot b0 + i) has it
+// of `mask` (bit i = slot b0 + i) has it.  (Everything out of the records' own words: a RecLab points into a private array, which
+// puts it - and 72 bytes of every lane of the calling kernel - into scratch memory.)
 __device__ __forceinline__ void emit_wide_from_records(const PugCtx& c, const uint4* mrec, size_t b0, uint32_t fv, uint64_t mask) {
-    RecLab first;
-    rec_lab(mrec, b0 + fv, first);
-    emit_wide_class(c, first.l.n, [&](uint32_t j) -> uint32_t {
-        const uint32_t t = first.l.p[j] & 0x7FFFFFFFu;
+    const uint4 fa = mrec[2 * (b0 + fv)], fb = mrec[2 * (b0 + fv) + 1];
+    const uint32_t* fp = fa.y > 4 ? reinterpret_cast<const uint32_t*>((uintptr_t)(((uint64_t)fa.w << 32) | fa.z)) : nullptr;
+    emit_wide_class(c, fa.y, [&](uint32_t j) -> uint32_t {
+        const uint32_t t = fp ? fp[j] & 0x7FFFFFFFu : (j == 0 ? fa.z : j == 1 ? fa.w : j == 2 ? fb.x : fb.y);
         for (uint64_t m = mask; m; m &= m - 1) {
             const uint32_t i = (uint32_t)__builtin_ctzll(m);
             if (i == fv) continue;
-            RecLab o;
-            rec_lab(mrec, b0 + i, o);
-            if (!lab_contains(o.l, t)) return 0xFFFFFFFFu;
+            if (!rec_contains(mrec[2 * (b0 + i)], mrec[2 * (b0 + i) + 1], t)) return 0xFFFFFFFFu;
         }
         return t;
     });
@@ -347,6 +351,7 @@ constexpr int kCoverOrdered = 0, kCoverDefer = 1, kCoverResume = 2;
 // on reads with long labels (the label-tail model) that chain was the cover kernel: 52 of a 287 ms step.  Short labels travel in the
 // record as before; longer ones than kStageRefs stay in the chunk.
 constexpr uint32_t kStageRefs = 16;
+constexpr uint32_t kStageWordsGL = 64 * kStageRefs + 8 * kMaxGenesPerLabel;   // a wave's stage with the gene rows behind it (the GL instances of the covers)
 __device__ __forceinline__ bool stage_contains(const uint32_t* row, uint32_t n, uint32_t t) {   // row: n <= kStageRefs refs, ascending, in LDS
     uint32_t lo = 0, hi = n;
 #pragma unroll
@@ -357,7 +362,10 @@ __device__ __forceinline__ bool stage_contains(const uint32_t* row, uint32_t n, 
 }
 static_assert(kStageRefs <= 32, "stage_contains makes five halving steps");
 // tied: kCoverDefer: [0] the list's counter, entries from tied + 4 (this list's region); kCoverResume: the first entry.
-template <int NWAVES, int MODE = kCoverOrdered>
+// GL: the genes of a molecule whose first label has more refs than the stage holds are gathered and sorted in LDS - eight rows of
+// kMaxGenesPerLabel words behind the stage's 64 x kStageRefs, a row per group - not in a private array of the group's first lane: that
+// array is indexed at run time and therefore lives in scratch memory (336 bytes per lane of every kernel that calls this, set up per dispatch).
+template <int NWAVES, int MODE = kCoverOrdered, bool GL = false>
 __device__ __forceinline__ void cover_tiny8(const PugCtx& C, const uint4* mrec, const uint32_t* mid_off, uint32_t n_tiny, uint32_t wv, uint32_t lane,
                                             uint32_t* tied_cnt = nullptr, uint32_t* tied = nullptr, uint32_t* stage = nullptr, uint32_t ci_base = 0,
                                             const uint16_t* idx = nullptr)
@@ -466,7 +474,8 @@ __device__ __forceinline__ void cover_tiny8(const PugCtx& C, const uint4* mrec, 
                 const uint32_t fv = best ? (uint32_t)__builtin_ctz(best) : 0u;
                 const uint32_t lfn_all = (uint32_t)__shfl((int)myl.n, (int)(gbase + fv));
                 const uint32_t lfn = best ? lfn_all : 0u;
-                uint32_t g[kMaxGenesPerLabel];   // (only for unstaged labels over four refs: the array lives in scratch memory)
+                uint32_t gpriv[GL ? 1 : kMaxGenesPerLabel];   // (only for unstaged labels over four refs; !GL: the array lives in scratch memory)
+                uint32_t* const g = GL ? stage + 64 * kStageRefs + grp * kMaxGenesPerLabel : gpriv;
                 uint32_t ng = 0, k4 = 0;
                 uint32_t c4[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
                 bool wide = false, in_row = false;
@@ -681,7 +690,7 @@ __device__ __forceinline__ void cover_lane4(const PugCtx& C, const uint4* mrec, 
 
 // ---- components of 9..64 vertices (entries n_tiny.. of the list): one wave each, adjacency = one 64-bit mask per lane ----
 // (kCoverResume: the components are entries n_tiny.. n_mid - 1 of the LIST `tied`, i.e. call it with n_tiny = 0, n_mid = entries)
-template <int NWAVES, int MODE = kCoverOrdered>
+template <int NWAVES, int MODE = kCoverOrdered, bool GL = false>
 __device__ __forceinline__ void cover_wave64(const PugCtx& C, const uint4* mrec, const uint32_t* mid_off, uint32_t n_tiny, uint32_t n_mid, uint32_t wv, uint32_t lane,
                                              uint32_t* tied_cnt = nullptr, uint32_t* tied = nullptr, uint32_t* stage = nullptr, uint32_t ci_base = 0)
     {
@@ -788,7 +797,8 @@ __device__ __forceinline__ void cover_wave64(const PugCtx& C, const uint4* mrec,
             // transcripts common to every vertex of the arborescence (pugutils.rs:1161-1188) -> genes
             const uint32_t fv = (uint32_t)__builtin_ctzll(best);
             const uint32_t lfn = lane_lab_n(fv);
-            uint32_t g[kMaxGenesPerLabel];   // (only for unstaged labels over four refs: the array lives in scratch memory)
+            uint32_t gpriv[GL ? 1 : kMaxGenesPerLabel];   // (only for unstaged labels over four refs; !GL: the array lives in scratch memory)
+            uint32_t* const g = GL ? stage + 64 * kStageRefs : gpriv;   // (GL: the first gene row behind the stage, lane 0's)
             uint32_t ng = 0, k4 = 0;
             uint32_t c4[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
             bool wide = false;
@@ -847,11 +857,6 @@ __device__ __forceinline__ void cover_wave64(const PugCtx& C, const uint4* mrec,
     // nw = ceil(n / 64) words (`rows`), the uncovered set and the round's best arborescence sit in LDS (s_mask[0], s_mask[1]).
     // The candidates of a round - the uncovered vertices, ascending - are dealt to the waves; the winner is the largest
     // arborescence, the smallest vertex among equals (the reference takes the first it meets in ascending order: pugutils.rs:1090-1160).
-__device__ __forceinline__ bool rec_contains(const uint4& qa, const uint4& qb, uint32_t t) {
-    if (qa.y <= 4) return t == qa.z || t == qa.w || t == qb.x || t == qb.y;   // (unused places hold 0xFFFFFFFF: no ref)
-    const Lab l{reinterpret_cast<const uint32_t*>((uintptr_t)(((uint64_t)qa.w << 32) | qa.z)), qa.y};
-    return lab_contains(l, t);
-}
 template <int NWAVES>
 __device__ __forceinline__ void cover_big(const PugCtx& C, const uint4* mrec, const uint32_t* mid_off, uint32_t first, uint32_t count,
                                           const uint32_t* rowoff, const uint64_t* rows_base, uint64_t (*s_mask)[64], uint32_t* s_bestv, uint32_t* s_bestsz,

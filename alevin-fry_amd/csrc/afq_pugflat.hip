@@ -620,7 +620,7 @@ __global__ __launch_bounds__(256) void k_pf_place(P2Args A) {
 // (three kernels, not one: together they were 104 VGPRs and four waves per SIMD - the two-vertex rule alone runs at eight)
 __global__ __launch_bounds__(256) void k_pc_pairs(P2Args A) {
     if (A.st->err_code) return;
-    __shared__ uint32_t s_stage[4][64 * kStageRefs];
+    __shared__ uint32_t s_stage[4][64 * kStageRefs + kMaxGenesPerLabel];   // (per wave: 64 label rows and ONE gene row behind them: the lanes that need it take turns)
     const PfTile T = A.ptile[blockIdx.x];
     if (!T.live || !T.n_pr) return;
     const uint32_t j = T.j, p0 = T.p0, n_pr = T.n_pr;
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(256) void k_pc_pairs(P2Args A) {
     PugCtx C = make_ctx(A, c, A.gcnt + 4 * (size_t)j);
     C.adj_umi = 1;
     // (the list holds dense numbers, the labels' keys lie in the dense arrays)
-    p2_cover_pairs<256>(C, reinterpret_cast<const uint64_t*>(A.pool + D.lh), A.pool + D.loff, nullptr, A.pool + D.prv + 2ull * p0, n_pr, s_stage[threadIdx.x >> 6]);
+    p2_cover_pairs<256, true>(C, reinterpret_cast<const uint64_t*>(A.pool + D.lh), A.pool + D.loff, nullptr, A.pool + D.prv + 2ull * p0, n_pr, s_stage[threadIdx.x >> 6]);
 }
 // components of 3..4 vertices under short labels: a LANE each (cover_lane4), a WAVE per tile (a tile holds ~115 components of 3..8
 // vertices: as a 256-thread workgroup per tile two of its four waves had nothing to do, and at four workgroups to a CU the kernel
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(256) void k_pc_lane4(P2Args A) {
 // ... and what cover_lane4 left over, eight components to a wave (cover_tiny8), a wave per tile again
 __global__ __launch_bounds__(256) void k_pc_tiny8(P2Args A) {
     if (A.st->err_code) return;
-    __shared__ uint32_t s_stage[4][64 * kStageRefs];
+    __shared__ uint32_t s_stage[4][kStageWordsGL];   // (per wave: 64 label rows, and eight gene rows behind them - the GL instances of the covers)
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, i = blockIdx.x * 4 + wv;
     if (i >= A.n_tiles) return;
     const PfTile T = A.ptile[i];
@@ -684,11 +684,11 @@ __global__ __launch_bounds__(256) void k_pc_tiny8(P2Args A) {
     const uint32_t* mid_off = A.pool + D.midoff + T.comp_base;
     uint32_t* const tied = A.pool + D.tied + 4ull * (j + T.comp_base);
     const uint16_t* slow = reinterpret_cast<const uint16_t*>(A.pool + D.slow) + T.comp_base + T.a0;
-    cover_tiny8<1, kCoverDefer>(C, mrec, mid_off + T.a0, T.pad[0], 0u, lane, tied, tied + 4, s_stage[wv], T.a0, slow);
+    cover_tiny8<1, kCoverDefer, true>(C, mrec, mid_off + T.a0, T.pad[0], 0u, lane, tied, tied + 4, s_stage[wv], T.a0, slow);
 }
 __global__ __launch_bounds__(256) void k_pc_mid(P2Args A) {
     if (A.st->err_code) return;
-    __shared__ uint32_t s_stage[4][64 * kStageRefs];
+    __shared__ uint32_t s_stage[4][kStageWordsGL];   // (per wave: 64 label rows, and eight gene rows behind them - the GL instances of the covers)
     const PfTile T = A.ptile[blockIdx.x];
     if (!T.live || !T.nb) return;
     const uint32_t j = T.j, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(256) void k_pc_mid(P2Args A) {
     const uint4* mrec = reinterpret_cast<const uint4*>(A.pool + D.mrec);
     const uint32_t* mid_off = A.pool + D.midoff + T.comp_base;
     uint32_t* const tied = A.pool + D.tied + 4ull * (j + T.comp_base);
-    cover_wave64<4, kCoverDefer>(C, mrec, mid_off + T.b0, 0u, T.nb, wv, lane, tied + 1, tied + 4 + 4 * (size_t)T.n_tiny, s_stage[wv], T.b0);
+    cover_wave64<4, kCoverDefer, true>(C, mrec, mid_off + T.b0, 0u, T.nb, wv, lane, tied + 1, tied + 4 + 4 * (size_t)T.n_tiny, s_stage[wv], T.b0);
 }
 // 10. the components the covers set aside at a tie, once k_p2_tied has left their classes' smallest record offsets beside their
 //     records (PfDev.cmv): into the reference's order - class by first appearance, then UMI (pugutils.rs:1090-1160 takes the first
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256) void k_pc_mid(P2Args A) {
 //     per-slot array.)
 __global__ __launch_bounds__(256) void k_pc_resume(P2Args A) {
     if (A.st->err_code) return;
-    __shared__ uint32_t s_stage[4][64 * kStageRefs];
+    __shared__ uint32_t s_stage[4][kStageWordsGL];   // (per wave: 64 label rows, and eight gene rows behind them - the GL instances of the covers)
     __shared__ uint16_t s_slow[4][64];
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, i = blockIdx.x * 4 + wv;
     if (i >= A.n_tiles) return;
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256) void k_pc_resume(P2Args A) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        cover_tiny8<1, kCoverResume>(C, mrec, mid_off, nslow, 0u, lane, nullptr, listA + 4 * (size_t)e0, s_stage[wv], 0u, s_slow[wv]);
+        cover_tiny8<1, kCoverResume, true>(C, mrec, mid_off, nslow, 0u, lane, nullptr, listA + 4 * (size_t)e0, s_stage[wv], 0u, s_slow[wv]);
     }
     // ---- the 9..64 list: this wave's run of it, a component at a time ----
     const uint32_t b_per = (nB + n_wg - 1) / n_wg, b_lo = min(nB, wg * b_per), b_hi = min(nB, b_lo + b_per);
@@ -838,7 +838,7 @@ __global__ __launch_bounds__(256) void k_pc_resume(P2Args A) {
     if (b_hi > b_lo) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        cover_wave64<1, kCoverResume>(C, mrec, mid_off, 0u, b_hi - b_lo, 0u, lane, nullptr, listB + 4 * (size_t)b_lo, s_stage[wv]);
+        cover_wave64<1, kCoverResume, true>(C, mrec, mid_off, 0u, b_hi - b_lo, 0u, lane, nullptr, listB + 4 * (size_t)b_lo, s_stage[wv]);
     }
 }
 // ... and a thread per cell: what the covers left in the cell's counters (an error of theirs, the lengths of its column list and
