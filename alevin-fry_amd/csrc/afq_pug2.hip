@@ -1623,14 +1623,16 @@ __global__ __launch_bounds__(CNT) void k_p2_tied(P2Args A, const uint32_t* list,
             uint32_t sl6[6], off6[6], old6[6];
 #pragma unroll
             for (int r = 0; r < 6; ++r) h6[r] = g0 + (uint32_t)r * CNT < R ? ch[g0 + (uint32_t)r * CNT] : 0ull;
+            // (the record offsets with the keys, for every slot: asked for only where a key hits the table they were a second round trip
+            //  per trip behind the first, in a kernel whose cell is six trips long; the asked-for classes are the common ones anyway)
+#pragma unroll
+            for (int r = 0; r < 6; ++r) off6[r] = g0 + (uint32_t)r * CNT < R ? coff[g0 + (uint32_t)r * CNT] : 0u;
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
                 const uint32_t mx = mix(h6[r]);
                 const bool pass = h6[r] != 0 && ((s_bloom[bloom_at(mx) >> 5] >> (bloom_at(mx) & 31u)) & 1u);
                 sl6[r] = pass ? find(h6[r], mx, false) : 0xFFFFFFFFu;
             }
-#pragma unroll
-            for (int r = 0; r < 6; ++r) off6[r] = sl6[r] != 0xFFFFFFFFu ? coff[g0 + (uint32_t)r * CNT] : 0u;
 #pragma unroll
             for (int r = 0; r < 6; ++r) old6[r] = sl6[r] != 0xFFFFFFFFu ? atomicMin(&t_min[sl6[r]], off6[r]) : 0xFFFFFFFFu;
 #pragma unroll
