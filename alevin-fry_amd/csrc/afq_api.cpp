@@ -1273,7 +1273,7 @@ bool host_ptr_is_pinned(const void* p) {
 }
 unsigned stage_threads() {
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    return std::min(16u, std::max(4u, hw / 4));
+    return std::min(32u, std::max(4u, hw / 4));
 }
 struct ByteSource {   // where afq_submit's input comes from: the caller's buffer, or a reader callback (afq_submit_reader)
     const uint8_t* bytes = nullptr;
@@ -1287,28 +1287,59 @@ int staged_h2d(afq_ctx* c, uint8_t* dst, const uint8_t* src, size_t n, hipStream
         if (!c->stage[i]) HIP_TRY(c, hipHostMalloc(&c->stage[i], kStagePiece, hipHostMallocDefault));
         if (!c->stage_ev[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming));
     }
+    // The filler threads live for the whole copy (round 6; rounds 1-5 spawned and joined sixteen per 64 MiB piece: 100 pieces of a
+    // PBMC-10k RAD, half a millisecond of thread start-up in front of every one - `afquant quant` spent 0.4 of its second here at
+    // 17 GB/s): the submitting thread hands out a piece number, every filler fills its slice of that piece, the last one says so.
     const unsigned nth = stage_threads();
-    size_t off = 0;
-    for (int i = 0; off < n; ++i) {
-        const int b = i % 3;
-        const size_t len = std::min(kStagePiece, n - off);
-        HIP_TRY(c, hipEventSynchronize(c->stage_ev[b]));   // the copy that last used this piece (in this call or an earlier one) is done
-        std::vector<std::thread> th;
-        const size_t slice = (len + nth - 1) / nth;
-        std::vector<int> bad(nth, 0);
-        for (unsigned t = 0; t < nth; ++t) {
+    const size_t n_pieces = (n + kStagePiece - 1) / kStagePiece;
+    // (they SLEEP between pieces - a condition variable, not a spin: a parsimony range's kernels run for tens of milliseconds, the next
+    //  range's pieces wait for them, and thirty-two fillers yielding in a loop on the CPUs of the device's NUMA node starved the
+    //  submitting thread and the runtime's own: `afquant quant -r parsimony-em` 1.35 -> 2.14 s when they spun)
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    long go = -1;                 // the piece the fillers may fill
+    unsigned done = 0;            // slices of that piece filled
+    bool quit = false;
+    std::atomic<int> bad{0};
+    auto filler = [&](unsigned t) {
+        for (size_t i = 0; i < n_pieces; ++i) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_go.wait(lk, [&] { return go >= (long)i || quit; });
+                if (quit) return;
+            }
+            const size_t off = i * kStagePiece, len = std::min(kStagePiece, n - off), slice = (len + nth - 1) / nth;
             const size_t a = t * slice, e = std::min(len, a + slice);
-            if (a >= e) break;
-            if (use_reader) th.emplace_back([=, &bad]() { if (rd->read(rd->user, rd_off + off + a, (uint8_t*)c->stage[b] + a, e - a) != 0) bad[t] = 1; });
-            else th.emplace_back([=]() { std::memcpy((uint8_t*)c->stage[b] + a, src + off + a, e - a); });
+            uint8_t* dstp = (uint8_t*)c->stage[i % 3];
+            if (a < e) {
+                if (use_reader) { if (rd->read(rd->user, rd_off + off + a, dstp + a, e - a) != 0) bad.store(1); }
+                else std::memcpy(dstp + a, src + off + a, e - a);
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            if (++done == nth) cv_done.notify_one();
         }
-        for (auto& x : th) x.join();
-        for (int x : bad) if (x) return fail(c, AFQ_ERR_BAD_INPUT, "the input reader reported an error");
-        HIP_TRY(c, hipMemcpyAsync(dst + off, c->stage[b], len, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipEventRecord(c->stage_ev[b], s));
-        off += len;
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nth; ++t) th.emplace_back(filler, t);
+    int rc = 0;
+    for (size_t i = 0; i < n_pieces && !rc; ++i) {
+        const int bsel = (int)(i % 3);
+        const size_t off = i * kStagePiece, len = std::min(kStagePiece, n - off);
+        if (hipEventSynchronize(c->stage_ev[bsel]) != hipSuccess) { rc = fail(c, AFQ_ERR_HIP, "hipEventSynchronize (staging) failed"); break; }   // the copy that last used this piece (in this call or an earlier one) is done
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            done = 0; go = (long)i;
+            cv_go.notify_all();
+            cv_done.wait(lk, [&] { return done == nth; });
+        }
+        if (bad.load()) { rc = fail(c, AFQ_ERR_BAD_INPUT, "the input reader reported an error"); break; }
+        if (hipMemcpyAsync(dst + off, c->stage[bsel], len, hipMemcpyHostToDevice, s) != hipSuccess || hipEventRecord(c->stage_ev[bsel], s) != hipSuccess)
+            rc = fail(c, AFQ_ERR_HIP, "hipMemcpyAsync (staging) failed");
     }
-    return 0;
+    { std::lock_guard<std::mutex> lk(mu); quit = true; }
+    cv_go.notify_all();
+    for (auto& x : th) x.join();
+    return rc;
 }
 
 // Reset the per-batch state and cut the batch into ranges.
