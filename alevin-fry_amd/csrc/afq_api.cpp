@@ -401,7 +401,7 @@ int plan_ranges(afq_ctx* c) {
         //  the two is what a range sized to fill the device must have room for)
         double nd = (em_res ? 24.0 + std::max(40.0 * (c->cfg.usa_mode ? 3 : 1), 90.0) : 16.0) * (double)n_ref + 128.0;
         if (pug_res) {  // per read: decode outputs + edge pool; the PUG scratch is per workgroup (sized for the largest cell)
-            nd += 20.0 * nrec + 128.0 * nrec;   // rd_h/rd_u/rd_o + the edge pool (32 words per read), as run_range allocates them
+            nd += 20.0 * nrec + 96.0 * nrec;   // rd_h/rd_u/rd_o + the edge pool (24 words per read), as run_range allocates them
             pug_fixed = std::max(pug_fixed, 4.0 * (double)pug_scratch_words(nrec, (uint32_t)n_ref, true) * pug_max_blocks() + 4.0 * (double)(1ull << 22));
         }
         if (n_ref > bucket_target()) nd += 16.0 * (double)(n_ref / bucket_target() + 1) + (use_slabs && !pug_res ? 8.0 * 2.0 * slab_slots / bucket_target() * (double)n_ref : 0.0);   // (+ the slabs of keys1: up to 2 x slab capacity slots per kBucketTarget refs)
@@ -671,8 +671,11 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     hist_cells.insert(hist_cells.end(), pug_cells.begin(), pug_cells.end());
     // (the phase kernels' per-read arrays take ten of the words per read, the rest is the pool; a range whose densest cell outgrows
     //  it - short UMIs, hundreds of reads per UMI: the pairs of a vertex are no longer a handful - is run again with four times as much)
-    const uint64_t pool_words_per_read = [] { const long v = test_hook_long("POOL_WORDS", 0); return v >= 12 && v <= 32 ? (uint64_t)v : 32ull; }();   // (tests: a small first pool; read per range - a test sets it for itself)
-    const uint64_t epool_words = ((pool_words_per_read * n_pug_reads + (pool_words_per_read == 32 ? (1ull << 22) : (1ull << 20))) << (2 * pool_try));
+    // (24 words per read since round 6, 32 before: the range-wide graph build takes 3.6 words per read out of the pool on the bench sample
+    //  and 8.8 under the label-tail model, next to the 10.25 of the per-read arrays - profiles/round6_01_10_flat_graph.txt, call 26 -
+    //  and a first parsimony range of a PBMC-10k sample is 5 GB of hipMalloc less)
+    const uint64_t pool_words_per_read = [] { const long v = test_hook_long("POOL_WORDS", 0); return v >= 12 && v <= 32 ? (uint64_t)v : 24ull; }();   // (tests: a small first pool; read per range - a test sets it for itself)
+    const uint64_t epool_words = ((pool_words_per_read * n_pug_reads + (pool_words_per_read >= 24 ? (1ull << 22) : (1ull << 20))) << (2 * pool_try));
     if (n_pug) {
         HIP_TRY(c, B.d_pug_cells.ensure(4ull * n_pug));
         HIP_TRY(c, B.d_rd_off.ensure(8ull * n));
@@ -1033,9 +1036,10 @@ int finish_range(afq_ctx* c, int slot) {
     }
     if (B.pf_stats_src) {   // AFQ_TEST_PF_STATS: the sizes of the range's flat graph build, on stderr (measurement scripts)
         PfDev d{};
-        if (hipMemcpy(&d, B.pf_stats_src, sizeof(d), hipMemcpyDeviceToHost) == hipSuccess)
-            std::fprintf(stderr, "[afq] flat graph build: reads %llu partitions %llu vertices_with_an_edge %u two_vertex_components %u listed_components %u record_slots %u cells_routed_to_the_per_cell_kernel %u\n",
-                         (unsigned long long)B.pf_stats_reads, (unsigned long long)B.pf_stats_parts, d.T, d.NP, d.NC, d.S, d.n_old);
+        unsigned long long pool_used = 0;
+        if (hipMemcpy(&d, B.pf_stats_src, sizeof(d), hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(&pool_used, B.d_epool_cur.p, 8, hipMemcpyDeviceToHost) == hipSuccess)
+            std::fprintf(stderr, "[afq] flat graph build: reads %llu partitions %llu vertices_with_an_edge %u two_vertex_components %u listed_components %u record_slots %u cells_routed_to_the_per_cell_kernel %u pool_words_used %llu (%.2f per read; the per-read arrays take 10.25 more)\n",
+                         (unsigned long long)B.pf_stats_reads, (unsigned long long)B.pf_stats_parts, d.T, d.NP, d.NC, d.S, d.n_old, pool_used, (double)pool_used / (double)std::max<uint64_t>(1, B.pf_stats_reads));
         B.pf_stats_src = nullptr;
     }
     if (!st.err_code && !B.pug_cell_launched && B.h_pack.p[9]) {   // cells were handed back and the kernel that takes them was not launched

@@ -15,9 +15,11 @@
 //     one other partition - so the search of a partition is its own vertices plus one pass over the vertices of the
 //     partitions a low-bit change away.  Thousands of independent waves, 64-thread workgroups, no workgroup barriers,
 //     and no per-cell scratch slice streamed through HBM phase after phase.
-//   * Only the vertices that HAVE an edge (~15 %) reach the per-cell graph kernel: components, the two-vertex rule and
-//     the arborescence covers (shared with afq_pug.hip through afq_pug_common.h) over compact arrays of touched
-//     vertices, 256 threads and 48.5 KiB of LDS per cell (three cells to a CU).
+//   * Only the vertices that HAVE an edge (a quarter) reach the graph phase: components, the two-vertex rule and the
+//     arborescence covers (shared with afq_pug.hip through afq_pug_common.h).  Since round 6 that phase is the range-wide
+//     kernels of afq_pugflat.hip; the per-cell kernels below (k_p2_graph, k_p2_cover, k_p2_tied<., false>) take the cells it
+//     routes to them - a component of more than 64 vertices - and k_p2_tied<., true> finds the class minima of the
+//     components the flat covers set aside (AFQ_TEST_P2_GRAPH=cell: the per-cell kernels for every cell, as in rounds 3-5).
 //   * The reference's vertex order (class-major, classes by first appearance, UMIs ascending inside a class) only
 //     decides ties between equal-size arborescences, i.e. only inside components of three or more vertices.  It is
 //     the order of (smallest record offset of the vertex's class, UMI); the class minima are found for the classes that
