@@ -929,6 +929,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
     tc.end();
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(B.kernels_done, s));
+    PackSmallArgs pack{};
     {   // what finish_range reads first: written by the last kernel of the range STRAIGHT into pinned host memory (20 bytes per cell over
         // PCIe).  An async D2H copy here instead would sit in the copy queue until the range's kernels are done - with the NEXT range's
         // upload queued behind it: the next range then started 150 us after this one ended instead of right behind it (seen in the
@@ -937,9 +938,11 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
         HIP_TRY(c, B.h_pack.reserve(words));
         void* d_view = nullptr;
         HIP_TRY(c, hipHostGetDevicePointer(&d_view, B.h_pack.p, 0));
-        launch_pack_small(s, B.d_status.as<DevStatus>(), B.em_inline ? B.d_em2_tiers.as<uint32_t>() + 7 : nullptr, B.d_alt.as<uint32_t>(), B.d_nnz.as<uint32_t>(),
-                          B.em_inline ? B.d_em_nnz.as<uint32_t>() : nullptr, B.d_bc.as<uint64_t>(),
-                          n_pug ? B.d_p2_small.as<uint32_t>() + p2_small_layout(n_p2, p2_parts, p2tiles.size(), n_pug).fb_count : nullptr, n, reinterpret_cast<uint32_t*>(d_view));
+        pack = PackSmallArgs{B.d_status.as<DevStatus>(), B.em_inline ? B.d_em2_tiers.as<uint32_t>() + 7 : nullptr, B.d_alt.as<uint32_t>(),
+                             B.em_inline ? B.d_em_nnz.as<uint32_t>() : nullptr, B.d_bc.as<uint64_t>(),
+                             n_pug ? B.d_p2_small.as<uint32_t>() + p2_small_layout(n_p2, p2_parts, p2tiles.size(), n_pug).fb_count : nullptr, reinterpret_cast<uint32_t*>(d_view)};
+        // (resolutions without an EM: k_row_ptr below packs it in its own launch - one 5 us kernel and one boundary less per range)
+        if (em) launch_pack_small(s, pack.st, pack.em_flag, pack.alt, B.d_nnz.as<uint32_t>(), pack.em_nnz, pack.bc, pack.n_mono, n, pack.out);
     }
     // The rows' compaction follows at once, with row offsets made on the device - it used to wait for the host to read the row
     // lengths, sum them and send the offsets back: 0.27 ms between the last kernel of a batch's last range and its compaction,
@@ -951,7 +954,7 @@ int run_range(afq_ctx* c, Range r, int slot, hipEvent_t h2d_done = nullptr, uint
         HIP_TRY(c, B.d_cell_ptr.ensure(8ull * (n + 1)));
         B.chain_cap = std::min(B.d_gene.cap, B.d_val.cap) / 4;
         tc.seg(K_COMPACT);
-        launch_row_ptr(s, B.d_nnz.as<uint32_t>(), n, B.d_cell_ptr.as<uint64_t>());
+        launch_row_ptr(s, B.d_nnz.as<uint32_t>(), n, B.d_cell_ptr.as<uint64_t>(), pack);
         launch_compact(s, B.d_meta.as<CellMeta>(), n, B.d_keys0.as<uint64_t>(), B.d_keys1.as<uint64_t>(), B.d_nnz.as<uint32_t>(),
                        B.d_cell_ptr.as<uint64_t>(), B.d_gene.as<uint32_t>(), B.d_val.as<float>(), B.chain_cap);
         tc.end();

@@ -8,7 +8,7 @@
 //   k_decode_par      walk-free decode, one lane per record (general; emits the parsimony per-read records)
 //   k_decode_keys     walk-free decode, one lane per dword (flat in record length)
 //   k_decode_recs     walk-free decode, one lane per record with inline alignments (short records)
-//   k_verify_cells    last step of the walk-free proof
+//   (k_verify_cells, the last step of the walk-free proof - DESIGN.md section 4 - is the first phase of k_decode's fix-up mode since round 6)
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <cstring>
@@ -56,15 +56,38 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ byte
                                                uint32_t num_genes, uint64_t* __restrict__ keys0,
                                                uint32_t* __restrict__ cell_nkeys,
                                                uint64_t* __restrict__ bc_out, DevStatus* st,
-                                               const uint32_t* __restrict__ fix_list, PugOut pug) {
+                                               const CellChk* __restrict__ chk, PugOut pug) {
     constexpr uint32_t HDR = 4 + BW + UW;
     constexpr bool AL = (BW % 4 == 0) && (UW % 4 == 0);
     const uint32_t lane = lane_id();
-    // plain mode: wave w takes cell w.  Fix-up mode (after a walk-free decoder): the waves loop over the
-    // cells k_verify_cells listed as failing the proof (normally none) and re-decode them here.
-    const uint32_t n_work = fix_list ? st->n_fallback : n_cells;
-  for (uint32_t work = blockIdx.x * 4 + (threadIdx.x >> 6); work < n_work; work += gridDim.x * 4) {
-    const uint32_t cell = fix_list ? fix_list[work] : work;
+    // plain mode: wave w takes cell w.  Fix-up mode (chk: after a walk-free decoder): the workgroup first takes the last step of
+    // the walk-free proof for its 256 cells, a thread each (the accumulated candidate count and sizes against
+    // the chunk header; cells that pass add their key count to the batch total, one atomic per workgroup), and its waves then
+    // re-decode the cells that failed it (normally none) right here.  (Until round 6 the proof's last step was a kernel of its own,
+    // k_verify_cells, with a list in global memory between the two: one 5 us launch and one boundary more per range.)
+    __shared__ unsigned long long s_sum;
+    __shared__ uint32_t s_nfail;
+    __shared__ uint32_t s_fail[256];
+    if (chk) {
+        if (threadIdx.x == 0) { s_sum = 0; s_nfail = 0; }
+        __syncthreads();
+        const uint32_t vc = blockIdx.x * 256 + threadIdx.x;
+        unsigned long long keys = 0;
+        if (vc < n_cells) {
+            const CellMeta vm = meta[vc];
+            const CellChk c = chk[vc];
+            if (c.fail == 0 && c.count == vm.nrec && c.words == vm.nbytes / 4 - 2) keys = cell_nkeys[vc];
+            else s_fail[atomicAdd(&s_nfail, 1u)] = vc;
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) keys += __shfl_xor(keys, d);
+        if (lane == 0 && keys) atomicAdd(&s_sum, keys);
+        __syncthreads();
+        if (threadIdx.x == 0) { if (s_sum) atomicAdd(&st->n_keys, s_sum); if (s_nfail) atomicAdd(&st->n_fallback, s_nfail); }
+    }
+    const uint32_t n_work = chk ? s_nfail : n_cells;
+  for (uint32_t work = chk ? (threadIdx.x >> 6) : blockIdx.x * 4 + (threadIdx.x >> 6); work < n_work; work += chk ? 4u : gridDim.x * 4) {
+    const uint32_t cell = chk ? s_fail[work] : work;
     const CellMeta m = meta[cell];
     const uint64_t abase = m.chunk_off & ~3ull;         // dword-aligned base of the walk
     const uint32_t mis = (uint32_t)(m.chunk_off - abase);
@@ -327,31 +350,6 @@ void launch_widen(hipStream_t s, const uint8_t* src, size_t n_src, const uint64_
     if (!n_cells) return;
     const uint32_t grid = std::min<uint32_t>((n_cells + 3) / 4, 8192u);
     AFQ_LAUNCH(k_widen, grid, 256, s, src, n_src, src_off, meta, n_cells, bw, uw, ebw, euw, dst, st, bsplit);
-}
-
-// Walk-free proof, final step: per cell compare the accumulated candidate count and sizes
-// with the chunk header; cells that pass add their key count to the batch total (one atomic per workgroup),
-// cells that fail are listed for the sequential re-decode.
-__global__ __launch_bounds__(256) void k_verify_cells(const CellMeta* __restrict__ meta, uint32_t n_cells,
-                                                     const CellChk* __restrict__ chk,
-                                                     const uint32_t* __restrict__ cell_nkeys, DevStatus* st,
-                                                     uint32_t* __restrict__ fix_list) {
-    __shared__ unsigned long long s_sum;
-    if (threadIdx.x == 0) s_sum = 0;
-    __syncthreads();
-    const uint32_t cell = blockIdx.x * 256 + threadIdx.x;
-    unsigned long long keys = 0;
-    if (cell < n_cells) {
-        const CellMeta m = meta[cell];
-        const CellChk c = chk[cell];
-        if (c.fail == 0 && c.count == m.nrec && c.words == m.nbytes / 4 - 2) keys = cell_nkeys[cell];
-        else fix_list[atomicAdd(&st->n_fallback, 1u)] = cell;
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) keys += __shfl_xor(keys, d);
-    if (lane_id() == 0 && keys) atomicAdd(&s_sum, keys);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_sum) atomicAdd(&st->n_keys, s_sum);
 }
 
 // ---------------------------------------------------------------------------
@@ -1471,13 +1469,9 @@ void launch_gather_headers(hipStream_t s, const uint8_t* bytes, size_t n_bytes, 
 
 template <int BW, int UW>
 static void launch_decode_t(hipStream_t s, const DecodeArgs& a) {
-    uint32_t grid = (a.n_cells + 3) / 4;
-    if (a.chk) {  // fix-up mode: verify every cell's proof, then a modest persistent grid walks the (normally empty) list
-        AFQ_LAUNCH(k_verify_cells, (a.n_cells + 255) / 256, 256, s, a.meta, a.n_cells, a.chk, a.cell_nkeys, a.st, a.fix_list);
-        grid = grid < 1024 ? grid : 1024;
-    }
+    const uint32_t grid = a.chk ? (a.n_cells + 255) / 256 : (a.n_cells + 3) / 4;   // (fix-up mode: a workgroup verifies 256 cells' proofs and re-decodes the ones that failed)
     AFQ_LAUNCH((k_decode<BW, UW>), grid, 256, s, a.bytes, a.n_bytes, a.meta, a.n_cells, a.t2g,
-               a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out, a.st, a.chk ? a.fix_list : nullptr, a.pug);
+               a.ref_count, a.num_genes, a.keys0, a.cell_nkeys, a.bc_out, a.st, a.chk, a.pug);
 }
 
 int launch_decode(hipStream_t s, const DecodeArgs& a, uint32_t bw, uint32_t uw) {

@@ -145,7 +145,8 @@ void launch_cell_hist(hipStream_t s, const ResolveArgs& a);
 void launch_compact(hipStream_t s, const CellMeta* meta, uint32_t n_cells, const uint64_t* keys0, const uint64_t* keys1,
                     const uint32_t* nnz, const uint64_t* cell_ptr, uint32_t* gene, float* val, uint64_t cap = ~0ull);
 void launch_fill_tables(hipStream_t s, const CellMeta* meta, uint32_t n_cells, uint32_t* bucket_cell, uint2* tile_desc);   // bucket -> cell and tile -> (cell, tile) from the cells' plans
-void launch_row_ptr(hipStream_t s, const uint32_t* nnz, uint32_t n, uint64_t* cell_ptr);   // row lengths -> row offsets (+ total at [n])
+struct PackSmallArgs { const DevStatus* st; const uint32_t* em_flag; const uint32_t* alt; const uint32_t* em_nnz; const uint64_t* bc; const uint32_t* n_mono; uint32_t* out; };   // what k_pack_small packs (out: pinned host memory as the device sees it)
+void launch_row_ptr(hipStream_t s, const uint32_t* nnz, uint32_t n, uint64_t* cell_ptr, const PackSmallArgs& pk);   // row lengths -> row offsets (+ total at [n]); pk.out != nullptr: and k_pack_small's work in the same launch
 
 // ---- parsimony (afq_pug.hip) ----
 struct PugCellArgs {

@@ -959,13 +959,45 @@ __global__ __launch_bounds__(kResolveNT) void k_resolve(const BucketDesc* __rest
                                    s_misc);
 }
 
+// Buckets beyond LDS reach (one UMI carried by thousands of reads, adversarial
+// input): same algorithm with the bucket sorted in place in keys1 (normalised
+// bitonic network, any n) and the run table in the upper half of the cell's keys0
+// slots.  Workgroup-wide call (k_resolve_mid's loop over the overflow list).
+constexpr int kBigNT = 1024;   // (= kMidNT: one kernel takes both kinds of overflow bucket)
+__device__ __forceinline__ void resolve_bucket_global(const BucketDesc& d, const CellMeta* __restrict__ meta, uint64_t* __restrict__ keys0, uint64_t* __restrict__ keys1,
+                                                      uint32_t* __restrict__ cell_ncols, DevStatus* st, const ResolveCfg& rc, const LabArea& la, uint32_t* s_ws) {
+    const uint32_t n = d.n;
+    const uint32_t n_ref = meta[d.cell].n_ref;
+    const uint32_t beg = (uint32_t)(d.src_off - d.out_off);
+    uint64_t* keys = keys1 + d.src_off;
+    // keys0 region of the cell = 2*n_ref words: words [0, n_ref) hold the column list (<= nkeys <= n_ref
+    // entries); the run table of this bucket (<= n entries) lives at words [n_ref + beg, n_ref + beg + n),
+    // disjoint between buckets because their [beg, beg+n) key ranges are.
+    uint32_t* run = reinterpret_cast<uint32_t*>(keys0 + d.out_off) + n_ref + beg;
+    __syncthreads();
+    bitonic_sort<kBigNT>(keys, n);
+    uint32_t* cols = reinterpret_cast<uint32_t*>(keys0 + d.out_off);
+    ResolveCfg rcb = rc;
+    rcb.mode = d.mode_single & 0xFFu;
+    resolve_sorted<kBigNT>(keys, n, run, s_ws, rcb, [&](uint32_t col) {
+        if (col >= rc.num_rows) { set_err(st, kErrSlotRange, d.cell); return; }
+        cols[atomicAdd(&cell_ncols[d.cell], 1u)] = col;
+    }, [&](uint32_t nb) -> uint32_t* {
+        return la.lab ? lab_alloc_global(la, d.cell, d.out_off, d.n_ref, nb) : nullptr;
+    });
+    __syncthreads();
+}
+
 // Buckets over the 2-wave cap but within LDS reach (<= kMidCap keys): persistent
 // 1024-thread workgroups loop over the overflow list.
 constexpr int kMidNT = 1024;
+static_assert(kBigNT == kMidNT, "one kernel takes both kinds of overflow bucket");
 constexpr uint32_t kMidCap = kMidNT * 8;
-__global__ __launch_bounds__(kMidNT) void k_resolve_mid(const BucketDesc* __restrict__ desc,
+// (Round 6: ONE launch for both kinds of overflow bucket - up to kMidCap keys: sorted in LDS; beyond: in place in keys1, below.  The
+//  list is nearly always empty, and a second 5 us launch with its boundary was paid per range for it.)
+__global__ __launch_bounds__(kMidNT) void k_resolve_mid(const BucketDesc* __restrict__ desc, const CellMeta* __restrict__ meta,
                                                        uint64_t* __restrict__ keys0,
-                                                       const uint64_t* __restrict__ keys1,
+                                                       uint64_t* __restrict__ keys1,
                                                        uint32_t* __restrict__ cell_ncols, uint32_t* __restrict__ nnz,
                                                        const OverflowEnt* __restrict__ ovf_list, DevStatus* st,
                                                        ResolveCfg rc, LabArea la) {
@@ -979,49 +1011,10 @@ __global__ __launch_bounds__(kMidNT) void k_resolve_mid(const BucketDesc* __rest
     uint32_t* s_ldesc = nullptr;
     const uint32_t novf = st->n_overflow;
     for (uint32_t e = blockIdx.x; e < novf; e += gridDim.x) {
-        if (ovf_list[e].n > kMidCap) continue;
         const BucketDesc d = desc[ovf_list[e].bucket];
+        if (ovf_list[e].n > kMidCap) { resolve_bucket_global(d, meta, keys0, keys1, cell_ncols, st, rc, la, s_ws); continue; }   // (uniform)
         __syncthreads();
         resolve_bucket_lds<kMidNT>(d, keys0, keys1, cell_ncols, nnz, st, rc, la, s_keys, s_run, s_cols, s_lab, s_ldesc, s_ws, s_misc);
-        __syncthreads();
-    }
-}
-
-// Buckets beyond LDS reach (one UMI carried by thousands of reads, adversarial
-// input): same algorithm with the bucket sorted in place in keys1 (normalised
-// bitonic network, any n) and the run table in the upper half of the cell's keys0
-// slots.  Persistent blocks loop over the overflow list.
-constexpr int kBigNT = 1024;
-__global__ __launch_bounds__(kBigNT) void k_resolve_big(const BucketDesc* __restrict__ desc,
-                                                       const CellMeta* __restrict__ meta,
-                                                       uint64_t* __restrict__ keys0, uint64_t* __restrict__ keys1,
-                                                       uint32_t* __restrict__ cell_ncols,
-                                                       const OverflowEnt* __restrict__ ovf_list, DevStatus* st,
-                                                       ResolveCfg rc, LabArea la) {
-    __shared__ uint32_t s_ws[kBigNT / 64];
-    const uint32_t novf = st->n_overflow;
-    for (uint32_t e = blockIdx.x; e < novf; e += gridDim.x) {
-        if (ovf_list[e].n <= kMidCap) continue;
-        const BucketDesc d = desc[ovf_list[e].bucket];
-        const uint32_t n = d.n;
-        const uint32_t n_ref = meta[d.cell].n_ref;
-        const uint32_t beg = (uint32_t)(d.src_off - d.out_off);
-        uint64_t* keys = keys1 + d.src_off;
-        // keys0 region of the cell = 2*n_ref words: words [0, n_ref) hold the column list (<= nkeys <= n_ref
-        // entries); the run table of this bucket (<= n entries) lives at words [n_ref + beg, n_ref + beg + n),
-        // disjoint between buckets because their [beg, beg+n) key ranges are.
-        uint32_t* run = reinterpret_cast<uint32_t*>(keys0 + d.out_off) + n_ref + beg;
-        __syncthreads();
-        bitonic_sort<kBigNT>(keys, n);
-        uint32_t* cols = reinterpret_cast<uint32_t*>(keys0 + d.out_off);
-        ResolveCfg rcb = rc;
-        rcb.mode = d.mode_single & 0xFFu;
-        resolve_sorted<kBigNT>(keys, n, run, s_ws, rcb, [&](uint32_t col) {
-            if (col >= rc.num_rows) { set_err(st, kErrSlotRange, d.cell); return; }
-            cols[atomicAdd(&cell_ncols[d.cell], 1u)] = col;
-        }, [&](uint32_t nb) -> uint32_t* {
-            return la.lab ? lab_alloc_global(la, d.cell, d.out_off, d.n_ref, nb) : nullptr;
-        });
         __syncthreads();
     }
 }
@@ -1352,8 +1345,7 @@ void launch_resolve_big(hipStream_t s, const ResolveArgs& a) {
     ResolveCfg rc = make_rc(a);
     LabArea la{a.lab, a.lab_cnt};
     BucketDesc* desc = reinterpret_cast<BucketDesc*>(a.bucket_desc);
-    AFQ_LAUNCH(k_resolve_mid, 256, kMidNT, s, desc, a.keys0, a.keys1, a.cell_ncols, a.nnz, a.ovf_list, a.st, rc, la);
-    AFQ_LAUNCH(k_resolve_big, 256, kBigNT, s, desc, a.meta, a.keys0, a.keys1, a.cell_ncols, a.ovf_list, a.st, rc, la);
+    AFQ_LAUNCH(k_resolve_mid, 256, kMidNT, s, desc, a.meta, a.keys0, a.keys1, a.cell_ncols, a.nnz, a.ovf_list, a.st, rc, la);   // (the buckets beyond LDS reach too)
 }
 
 
@@ -1410,8 +1402,25 @@ void launch_compact(hipStream_t s, const CellMeta* meta, uint32_t n_cells, const
 // Row offsets of a range from its row lengths, on the device (one workgroup: n is a range's cells): cell_ptr[i] = nnz[0] + ... +
 // nnz[i - 1], cell_ptr[n] = the range's entries.  The host makes the same sums from the packed block it reads anyway; this
 // copy lets the compaction follow the range's kernels without waiting for the host.
-__global__ __launch_bounds__(1024) void k_row_ptr(const uint32_t* __restrict__ nnz, uint32_t n, uint64_t* __restrict__ cell_ptr) {
+// (Round 6: the same launch packs what the host reads when the range is done - status block, flags, row lengths, barcodes, into
+//  pinned host memory: k_pack_small's work, which was a 5 us launch of its own in front of this one; pk.out == nullptr: not asked.)
+__global__ __launch_bounds__(1024) void k_row_ptr(const uint32_t* __restrict__ nnz, uint32_t n, uint64_t* __restrict__ cell_ptr, PackSmallArgs pk) {
     __shared__ uint32_t s_ws[16];
+    if (pk.out) {
+        for (uint32_t i = threadIdx.x; i < (n > 16u ? n : 16u); i += 1024) {
+            if (i < sizeof(DevStatus) / 4) pk.out[i] = reinterpret_cast<const uint32_t*>(pk.st)[i];
+            if (i == 8) pk.out[8] = pk.em_flag ? *pk.em_flag : 0u;
+            if (i == 9) pk.out[9] = pk.n_mono ? *pk.n_mono : 0u;
+            if (i < n) {
+                pk.out[16 + i] = pk.alt[i];
+                pk.out[16 + n + i] = nnz[i];
+                pk.out[16 + 2 * (size_t)n + i] = pk.em_nnz ? pk.em_nnz[i] : 0u;
+                const uint64_t b = pk.bc[i];
+                pk.out[16 + 3 * (size_t)n + 2 * (size_t)i] = (uint32_t)b;
+                pk.out[16 + 3 * (size_t)n + 2 * (size_t)i + 1] = (uint32_t)(b >> 32);
+            }
+        }
+    }
     uint64_t carry = 0;
     for (uint32_t base = 0; base < n; base += 1024) {   // (a row has at most 2^20 entries: 1024 of them fit 32 bits)
         const uint32_t i = base + threadIdx.x;
@@ -1441,8 +1450,8 @@ void launch_fill_tables(hipStream_t s, const CellMeta* meta, uint32_t n_cells, u
     if (!n_cells) return;
     AFQ_LAUNCH(k_fill_tables, (n_cells + 3) / 4, 256, s, meta, n_cells, bucket_cell, tile_desc);
 }
-void launch_row_ptr(hipStream_t s, const uint32_t* nnz, uint32_t n, uint64_t* cell_ptr) {
-    AFQ_LAUNCH(k_row_ptr, 1, 1024, s, nnz, n, cell_ptr);
+void launch_row_ptr(hipStream_t s, const uint32_t* nnz, uint32_t n, uint64_t* cell_ptr, const PackSmallArgs& pk) {
+    AFQ_LAUNCH(k_row_ptr, 1, 1024, s, nnz, n, cell_ptr, pk);
 }
 
 }  // namespace afq
