@@ -727,3 +727,149 @@ int main() {
         ctr, total, wrong, unset = map(int, r.stdout.split())
         assert ctr == true_runs and total == sum(len(c) for c in cells) and wrong == 0
         assert (unset == 0) == (cap >= true_runs)   # (every row written exactly when the list held every run)
+
+
+def test_lane_per_component_cover_is_the_oracles_on_host(tmp_path):
+    """csrc/afq_pug_common.h: the cover of a component of up to four vertices in ONE lane's registers (Lane4: lane4_load with the
+    edges worked out from the records' (UMI, reads) by umi_edge, lane4_rounds, lane4_permute - what k_pc_lane4 / k_pc_resume of
+    csrc/afq_pugflat.hip run since round 6) against the oracle's `parsimony` (pugutils.rs:76-99, 1048-1261) on cells that hold 2..4
+    vertices with labels of 1..4 refs, UMIs equal / one base / two bases apart, 1..4 reads each, USA and not, --umi-edit-dist 0 and
+    1.  Both ways the device takes: (a) the records in the reference's vertex order, ties broken by position (kCoverOrdered);
+    (b) the records in ANY order, a component set aside at its first tie (kCoverDefer), its uncovered vertices renumbered into the
+    reference's order (lane4_permute) and resumed (kCoverResume).  The functions' own source text, compiled for the host; a "wave"
+    of one lane.  No GPU."""
+    import shutil
+    import subprocess
+    import sys
+    from collections import Counter
+
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as ora
+
+    t2g = {0: [0, 0, 1, 1, 2, 2, 3, 4, 5], 1: [0, 0, 2, 2, 4, 4, 1, 3, 5]}
+    rng = np.random.default_rng(606)
+    cases = []   # (usa, exact, [(label, umi, reads)] in "any order", refpos per vertex)
+    want = []
+    for usa in (0, 1):
+        for exact in (0, 1):
+            sub, cells = [], []
+            for i in range(12000 if not exact else 3000):
+                n = int(rng.integers(2, 5))
+                base = int(rng.integers(0, 1 << 16))
+                verts = []
+                while len(verts) < n:
+                    k = int(rng.integers(1, 5))
+                    lab = tuple(sorted(int(x) for x in rng.choice(9, size=k, replace=False)))
+                    u = base
+                    for _ in range(int(rng.choice([0, 0, 1, 1, 2]))):
+                        u ^= int(rng.integers(1, 4)) << (2 * int(rng.integers(0, 8)))
+                    if any(v[0] == lab and v[1] == u for v in verts):
+                        continue
+                    verts.append((lab, u, int(rng.choice([1, 1, 2, 3, 4]))))
+                recs = [(u, list(lab)) for lab, u, r in verts for _ in range(r)]
+                recs = [recs[j] for j in rng.permutation(len(recs))]
+                first = {}
+                for j, (u, lab) in enumerate(recs):
+                    first.setdefault(tuple(lab), j)
+                order = sorted(range(n), key=lambda v: (first[verts[v][0]], verts[v][1]))
+                refpos = [order.index(v) for v in range(n)]
+                sub.append((usa, exact, verts, refpos))
+                cells.append((1000 + i, recs))
+            b, off = rad.encode_cells(cells, 4, 4)
+            cfg = pkg.WorkerConfig.for_resolution("parsimony", usa_mode=bool(usa), num_genes=6, num_rows=9 if usa else 6, small_thresh=0,
+                                                  pug_exact_umi=bool(exact))
+            res = ora.quant(cfg, np.asarray(t2g[usa], np.uint32), b, off)
+            for i in range(len(sub)):
+                g, v = res.row(i)
+                assert all(float(x).is_integer() for x in v)
+                want.append(Counter({int(a): int(x) for a, x in zip(g, v)}))
+            cases += sub
+    com = open(os.path.join(ROOT, "alevin-fry_amd", "csrc", "afq_pug_common.h")).read()
+
+    def grab(start, end):
+        a = com.index(start)
+        return com[a:com.index(end, a)]
+
+    host = r'''#include <cstdint>
+#include <cstdio>
+#include <algorithm>
+#define __device__
+#define __forceinline__ inline
+struct uint4 { uint32_t x, y, z, w; };
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+struct DevStatus;
+constexpr uint32_t kMaxGenesPerLabel = 64, kErrPugLimit = 7, kErrSlotRange = 9;
+constexpr int kCoverOrdered = 0, kCoverDefer = 1, kCoverResume = 2;
+// a wave of one lane
+static inline uint32_t lane_id() { return 0; }
+static inline uint64_t __ballot(bool b) { return b ? 1ull : 0ull; }
+static inline bool __any(bool b) { return b; }
+static inline int __popc(uint32_t x) { return __builtin_popcount(x); }
+static inline int __popcll(uint64_t x) { return __builtin_popcountll(x); }
+#define __builtin_amdgcn_readlane(x, l) (x)
+static uint32_t atomicAdd(uint32_t* p, uint32_t v) { uint32_t o = *p; *p += v; return o; }
+''' + grab("struct PugCtx {", "struct Lab {") + \
+        grab("__device__ __forceinline__ uint32_t molecule2_column(", "// A class of more than kMaxGenesPerLabel genes for the EM") + \
+        grab("struct Lane4 {", "// ---- components of 9..64 vertices") + r'''
+int main() {
+    static const uint32_t T2G[2][9] = {{0, 0, 1, 1, 2, 2, 3, 4, 5}, {0, 0, 2, 2, 4, 4, 1, 3, 5}};
+    unsigned usa, exact, n;
+    while (scanf("%u %u %u", &usa, &exact, &n) == 3) {
+        uint4 rec[8], ord[8];
+        uint32_t refpos[4] = {0, 1, 2, 3};
+        for (unsigned v = 0; v < n; ++v) {
+            unsigned ln, r[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, um, rc;
+            if (scanf("%u", &ln) != 1) return 2;
+            for (unsigned j = 0; j < ln; ++j) if (scanf("%u", &r[j]) != 1) return 2;
+            if (scanf("%u %u %u", &um, &rc, &refpos[v]) != 3) return 2;
+            rec[2 * v] = make_uint4(0, ln, r[0], r[1]); rec[2 * v + 1] = make_uint4(r[2], r[3], um, rc);
+        }
+        for (unsigned v = 0; v < n; ++v) { ord[2 * refpos[v]] = rec[2 * v]; ord[2 * refpos[v] + 1] = rec[2 * v + 1]; }
+        for (int way = 0; way < 2; ++way) {
+            uint32_t cnt[4] = {0, 0, 0, 0}, cols[16], lw[16], ld[16], tied_cnt = 0, tied[8];
+            PugCtx C{};
+            C.t2g = T2G[usa]; C.usa = usa; C.num_rows = usa ? 9u : 6u; C.uo = 3; C.ao = 6; C.exact_umi = exact;
+            C.cols = cols; C.cols_cap = 16; C.labw = lw; C.labd = ld; C.lab_cap = 16; C.s_cnt = cnt; C.adj_umi = 1;
+            if (way == 0) cover_lane4<kCoverOrdered>(C, ord, 0, n, (1u << n) - 1u, 0);
+            else {
+                Lane4 L;
+                lane4_load(C, rec, 0, n, L);
+                lane4_rounds<kCoverDefer>(C, L, (1u << n) - 1u, 5, &tied_cnt, tied);
+                if (tied_cnt) {   // set aside: what k_pc_resume does with the entry
+                    if (tied_cnt != 1 || tied[0] != 5) return 4;
+                    uint32_t uc = tied[1], rank[4];
+                    uint64_t key[4];
+                    for (unsigned v = 0; v < 4; ++v) key[v] = v >= n ? ~0ull : ((uc >> v) & 1u) ? (uint64_t)refpos[v] : (1ull << 63) | v;
+                    for (unsigned v = 0; v < 4; ++v) { rank[v] = 0; for (unsigned u = 0; u < 4; ++u) rank[v] += (u != v && key[u] < key[v]) ? 1u : 0u; if (v >= n) rank[v] = v; }
+                    lane4_permute(L, rank, uc);
+                    lane4_rounds<kCoverResume>(C, L, uc, 5, nullptr, nullptr);
+                }
+            }
+            if (cnt[3]) return 3;
+            std::sort(cols, cols + cnt[0]);
+            printf("%u %u", tied_cnt, cnt[0]);
+            for (uint32_t k = 0; k < cnt[0]; ++k) printf(" %u", cols[k]);
+            printf("\n");
+        }
+    }
+    return 0;
+}
+'''
+    (tmp_path / "t.cpp").write_text(host)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", str(tmp_path / "t"), str(tmp_path / "t.cpp")], check=True, capture_output=True)
+    text = "".join(f"{usa} {exact} {len(verts)} " + " ".join(f"{len(lab)} " + " ".join(str(x) for x in lab) + f" {u} {r} {p}" for (lab, u, r), p in zip(verts, refpos)) + "\n"
+                   for usa, exact, verts, refpos in cases)
+    r = subprocess.run([str(tmp_path / "t")], input=text, capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stderr)
+    lines = [[int(x) for x in line.split()] for line in r.stdout.splitlines()]
+    assert len(lines) == 2 * len(cases)
+    set_aside = 0
+    for i, (case, w) in enumerate(zip(cases, want)):
+        for way in (0, 1):
+            tied, ncol, *cols = lines[2 * i + way]
+            assert ncol == len(cols)
+            assert Counter(cols) == w, (("ordered", "set aside + resumed")[way], case, cols, w)
+        set_aside += lines[2 * i + 1][0]
+    assert set_aside > len(cases) // 50   # the tie path was walked (a few percent of these components meet a tie)
