@@ -671,7 +671,7 @@ __device__ __forceinline__ uint32_t molecule8_column(const PugCtx& c, uint32_t (
 // L8: labels of 5..8 refs by their own lane (molecule8_column; AFQ_TEST_P2_LONE_COOP=2) - an instance of its own: its eight-entry arrays
 // are registers of every lane whether or not a label needs them.
 template <bool L8>
-__device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t* s_cls, uint32_t lane) {
+__device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t* s_cls, uint32_t* s_g, uint32_t lane) {
     const uint32_t n = A.pcnt[gp], nv = A.pnv[gp], j = A.pcell[gp], lo_p = A.poff[gp];
     if (n == 0) return;
     const P2Cell c = A.cells[j];
@@ -731,12 +731,6 @@ __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t
                 k0 = q4[0]; k1 = q4[1];
             } else if (L8 && ln[r] <= 8 && ln[r] != 0) {
                 if constexpr (L8) col = molecule8_column(C, g4[r]);
-            } else if (ln[r] > (A.lone_coop ? 64u : 4u)) {
-                const Lab l = rec_label(C, of[r]);
-                uint32_t g[kMaxGenesPerLabel];
-                const uint32_t ng = genes_of(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; }, g);
-                if (ng == 0xFFFFFFFFu && C.em) emit_wide_class(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; });
-                else col = molecule_column_n(C, g, ng);
             }
             if (A.lone_coop) {   // labels of 5..64 refs: the wave takes them one after the other (wave_label_column)
                 for (uint64_t lm = __ballot(ln[r] > (uint32_t)NR && ln[r] <= 64); lm; lm &= lm - 1) {
@@ -750,6 +744,22 @@ __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t
             if (cls) { const uint32_t q = ncls + (uint32_t)__popcll(mk & ((1ull << lane) - 1)); s_cls[2 * q] = k0; s_cls[2 * q + 1] = k1; }
             ncls += (uint32_t)__popcll(mk);
         }
+        // labels of more than 64 refs (without the cooperative path: of more than four): one lane after the other, its genes in the
+        // wave's LDS row - 64 words of a lane's own were 272 bytes of scratch per lane of every wave, for a label in ten thousand.
+        // (Behind the rows' loop, where the gathered refs and genes are dead: inside it the kernel lost its seventh wave per SIMD.)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (r0 + (uint32_t)r * 64 >= n) break;   // (uniform)
+            for (uint64_t wm = __ballot(!(L8 && ln[r] <= 8) && ln[r] > (A.lone_coop ? 64u : 4u)); wm; wm &= wm - 1) {
+                if (lane == (uint32_t)__builtin_ctzll(wm)) {
+                    const Lab l = rec_label(C, of[r]);
+                    const uint32_t ng = genes_of(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; }, s_g);
+                    if (ng == 0xFFFFFFFFu && C.em) emit_wide_class(C, l.n, [&](uint32_t j2) { return l.p[j2] & 0x7FFFFFFFu; });
+                    else C.cols[lo_p + r0 + (uint32_t)r * 64 + lane] = molecule_column_n(C, s_g, ng);
+                }
+                WAVE_SYNC();
+            }
+        }
     }
     if (!ncls) return;
     WAVE_SYNC();
@@ -762,8 +772,9 @@ template <bool L8>
 __global__ __launch_bounds__(256) void k_p2_lone(P2Args A) {
     if (A.st->err_code) return;   // an earlier kernel of the range failed (e.g. kErrLabelHash in k_p2_part, which then leaves its partition's vertices unwritten): nothing behind it may read that state - the host runs the range again or reports the error
     __shared__ uint32_t s_cls4[4][512];
+    __shared__ uint32_t s_g4[4][kMaxGenesPerLabel];   // (a wave's row for the genes of a label of more than 64 refs)
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    for_each_partition_in_runs(A.n_parts, wv, [&](uint32_t gp) { lone_body<L8>(A, gp, s_cls4[wv], lane); });
+    for_each_partition_in_runs(A.n_parts, wv, [&](uint32_t gp) { lone_body<L8>(A, gp, s_cls4[wv], s_g4[wv], lane); });
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
