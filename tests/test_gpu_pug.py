@@ -456,3 +456,71 @@ def test_more_pairs_than_reads_stay_with_the_phase_kernels(oracle, pug_route, re
     assert_same_result(got, want, what=res)
     if pug_route in ("phase-kernels", "cover-1024", "graph-per-cell", "graph-per-cell-1024"):
         assert n_mono == 0, "no cell should have needed the one-workgroup kernel"
+
+
+def _grid_component(n, t, hi):
+    """n vertices (UMI, label, reads) of ONE component: the first n points of the 4 x 4 x 4 x 4 grid over four UMI bases (point i is
+    one base away from the point with its highest non-zero digit cleared, so every prefix is connected); labels of 1, 2, 6 and 2
+    refs that all hold transcript t (every 1-Hamming pair is an edge candidate), 1..3 reads (edges in one direction only)."""
+    out = []
+    for i in range(n):
+        umi = hi | (i & 3) | (((i >> 2) & 3) << 4) | (((i >> 4) & 3) << 10) | (((i >> 6) & 3) << 20)
+        lab = ([t], [t, t + 2], [t, t + 1, t + 2, t + 3, t + 4, t + 5], [t, t + 4])[i % 4]
+        out.append((umi, lab, 1 + (i * 7) % 3))
+    return out
+
+
+@pytest.mark.parametrize("thresh", [0, 60, 8])
+@pytest.mark.parametrize("res,usa", [("parsimony", False), ("parsimony-em", True)])
+def test_component_sizes_at_every_boundary_of_the_flat_build(oracle, res, usa, thresh):
+    """csrc/afq_pugflat.hip sorts a range's components by size into the covers' lists: 2 vertices (k_pc_pairs), 3..4 (a lane each,
+    k_pc_lane4 - the ones with a label of more than four refs go to its eight-lane list), 5..8 (k_pc_tiny8), 9..64 (k_pc_mid, a wave
+    each), more than 64 (the whole cell to the per-cell kernels) and, above --large-graph-thresh, the winner-take-all fallback.
+    One component of every size on both sides of each boundary, alone in a small cell, all of them in one cell, and all of them in a
+    cell of three tiles whose records are shuffled (class first appearance = the tie-break order); --large-graph-thresh at its
+    default, at 60 (the 63..100-vertex components fall back) and at 8."""
+    rng = np.random.default_rng(77)
+    sizes = [2, 3, 4, 5, 8, 9, 16, 63, 64, 65, 100]
+    comps = [_grid_component(n, 8 * k, (k + 1) << 26 if k % 2 else 0) for k, n in enumerate(sizes)]   # (a transcript block of its own per component: no edges between them)
+    n_t = 8 * len(sizes) + 64
+    def recs_of(cs, filler=0):
+        r = [(u, lab) for c in cs for u, lab, reads in c for _ in range(reads)]
+        r += [(int(rng.integers(0, 1 << 24)), [8 * len(sizes) + int(rng.integers(0, 64))]) for _ in range(filler)]
+        return [r[j] for j in rng.permutation(len(r))]
+    cells = [(100 + k, recs_of([c])) for k, c in enumerate(comps)]
+    cells.append((300, recs_of(comps)))
+    cells.append((301, recs_of(comps[:9])))           # (no component beyond 64 vertices: the cell stays with the flat build)
+    cells.append((302, recs_of(comps, filler=9000)))
+    cells.append((303, recs_of(comps[:9], filler=9000)))
+    b, off = rad.encode_cells(cells, 4, 4)
+    G = n_t // 2
+    t2g = (np.arange(n_t, dtype=np.uint32) // 2 * 2 + (np.arange(n_t, dtype=np.uint32) & 1)) if usa else np.arange(n_t, dtype=np.uint32) // 2
+    kw = dict(large_graph_thresh=thresh) if thresh else {}
+    cfg = pkg.WorkerConfig.for_resolution(res, usa_mode=usa, num_genes=2 * G if usa else G, num_rows=3 * G if usa else G, small_thresh=0, **kw)
+    got, want = run_both(oracle, cfg, t2g, b, off)
+    if thresh:
+        assert (want.flags & pkg._abi.CELL_ALT_RES).any()
+    assert_same_result(got, want, what=f"{res} usa={usa} thresh={thresh}")
+
+
+@pytest.mark.parametrize("res", ["parsimony", "parsimony-em"])
+def test_edge_directions_from_read_counts_beyond_the_flag_bytes_127(oracle, res):
+    """The flat build's cover records carry (UMI, reads) and the covers decide has_edge themselves (x -> y one base apart iff
+    reads(y) < 2 reads(x), pugutils.rs:88-97); k_p2_part hands the reads over in seven bits of the vertex's flag byte, 127 standing
+    for "127 or more: ask the count array".  Paths a - b - c with reads (2 m, m, 2 m) need two molecules (b reaches neither end),
+    (2 m - 1, m, 2 m - 1) one; m on both sides of 127 and of 64, beside a 300-read vertex with 1000- and 599-read neighbours."""
+    cells, k = [], 0
+    for m, big in [(63, 126), (63, 125), (64, 128), (64, 127), (126, 252), (126, 251), (127, 254), (127, 253), (128, 256), (128, 255), (200, 400), (200, 399), (300, 1000), (300, 599)]:
+        base = (k + 1) << 8
+        a, c = base ^ 1, base ^ (1 << 2)
+        recs = [(a, [2 * k])] * big + [(base, [2 * k, 2 * k + 1])] * m + [(c, [2 * k])] * big
+        cells.append((500 + k, recs))
+        k += 1
+    cells.append((600, [r for _, rs in cells for r in rs]))   # all of them in one cell
+    b, off = rad.encode_cells(cells, 4, 4)
+    n_t = 2 * k
+    cfg = pkg.WorkerConfig.for_resolution(res, num_genes=n_t, num_rows=n_t, small_thresh=0)
+    got, want = run_both(oracle, cfg, np.arange(n_t, dtype=np.uint32), b, off)
+    per_cell = [sum(v for _, v in row) for row in rows_of(want)]
+    assert per_cell[0] != per_cell[1] and per_cell[6] != per_cell[7] and per_cell[12] != per_cell[13]   # (the direction rule decides the molecule count)
+    assert_same_result(got, want, what=res)
