@@ -422,29 +422,36 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
     // "met once, from the smaller UMI": umi ^ (d << 2b) > umi iff the top bit of d is clear in the base - a bit test.
     uint64_t hits[4] = {0, 0, 0, 0};   // bit 3 (b - m/2) + d - 1 of row r: the change d of base b passed the filter
     const uint32_t b_lo = m / 2;
+    // (the changes outside, the rows inside: a change's fold, its shift and the bit that decides "met from the smaller UMI" are scalar
+    //  work - with the rows outside they were computed for every row again, and the kernel was as busy on its scalar unit as on its
+    //  vector units: 17.75 -> 17.24 ms per configs[2] step)
+    uint32_t fu[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const uint32_t i = (uint32_t)r * 64 + lane;
+        fu[r] = fold11((uint32_t)(own[r] >> 32));
         if ((uint32_t)r * 64 >= nv) break;   // (uniform)
-        const uint32_t umi = (uint32_t)(own[r] >> 32), xw = (uint32_t)own[r];
-        if (i < nv) probe(umi, lo_p + i, xw, true);
-        if (A.exact_umi) continue;
-        const uint32_t fu = fold11(umi);
-        const bool valid = i < nv;
-        uint64_t h = 0;
+        if (i < nv) probe((uint32_t)(own[r] >> 32), lo_p + i, (uint32_t)own[r], true);
+    }
+    if (!A.exact_umi) {
         for (uint32_t b = b_lo; b < L; ++b) {   // (bases below m / 2 lie inside the low m bits: every change there leaves the partition)
-            const uint32_t c0 = (umi >> (2 * b)) & 1u, c1 = (umi >> (2 * b + 1)) & 1u;
 #pragma unroll
             for (uint32_t d = 1; d < 4; ++d) {
                 const uint32_t mk = d << (2 * b);
                 if (mk & (P - 1)) continue;   // (scalar: only the base that straddles bit m)
-                const uint32_t f = fu ^ fold11(mk);
-                const uint32_t bit = (s_filt[f >> 5] >> (f & 31u)) & 1u;
-                const uint32_t up = d == 1 ? (c0 ^ 1u) : (c1 ^ 1u);
-                h |= (uint64_t)(bit & up) << (3 * (b - b_lo) + d - 1);
+                const uint32_t fm = fold11(mk), tb = 2 * b + (d == 1 ? 0u : 1u), sh = 3 * (b - b_lo) + d - 1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {   // (the rows' count as a compile-time constant - four instances of this loop, the rows' filter words asked for together - measured 19.7 against 17.2 ms: 14 VGPRs spilled instead of 8)
+                    if ((uint32_t)r * 64 >= nv) break;   // (uniform)
+                    const uint32_t f = fu[r] ^ fm;
+                    const uint32_t bit = (s_filt[f >> 5] >> (f & 31u)) & 1u;
+                    const uint32_t up = (((uint32_t)(own[r] >> 32) >> tb) & 1u) ^ 1u;
+                    hits[r] |= (uint64_t)(bit & up) << sh;
+                }
             }
         }
-        hits[r] = valid ? h : 0ull;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if ((uint32_t)r * 64 + lane >= nv) hits[r] = 0ull;
     }
     for (;;) {   // drain: every lane takes its next passed probe, whichever row it is in (static register indices: no scratch)
         const bool mine = (hits[0] | hits[1] | hits[2] | hits[3]) != 0;
