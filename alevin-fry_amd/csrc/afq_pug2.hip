@@ -314,7 +314,6 @@ struct SearchLds {
     uint32_t umi[kP2TabSlots];
     uint32_t word[kP2TabSlots];
     uint8_t idx[kP2TabSlots];           // (a partition holds at most 256 vertices)
-    uint32_t filt[kP2FiltBits / 32];
     uint2 q[kP2MatchQ];                 // .x = vertex x (slot inside the cell); .y = table slot of y | same-UMI << 9 | reads of x << 10
     uint32_t np, nq;
 };
@@ -325,10 +324,30 @@ static_assert(kP2PartCap <= 256, "SearchLds::idx is a byte");
 // partition's first own slot says where (the graph kernel tells by pnp > pcnt), and the search runs again.  (Until round 4 such a
 // cell went to the one-workgroup kernel: on the label-tail workload that kernel was 40 ms of the 370 ms step.  A kernel of its
 // own, not a second trip through a loop here: the loop took the search from 79 to 127 VGPRs.)
+#ifdef AFQ_SEARCH_TIMING
+__device__ unsigned long long g_search_t[10];
+#define S_MARK(i) do { const unsigned long long n_ = clock64(); if (lane == 0) atomicAdd(&g_search_t[i], n_ - st_); st_ = n_; } while (0)
+__global__ void k_search_timing_dump() {
+    unsigned long long tot = 0;
+    for (int i = 0; i < 8; ++i) tot += g_search_t[i];
+    printf("search wave cycles: setup+build %.1f%% same-umi %.1f%% own filter %.1f%% own drain %.1f%% foreign fetch+filter %.1f%% foreign drain %.1f%% parked checks %.1f%% tail %.1f%% (partitions %llu, %.0f cycles each)\n",
+           100.0 * g_search_t[0] / tot, 100.0 * g_search_t[1] / tot, 100.0 * g_search_t[2] / tot, 100.0 * g_search_t[3] / tot, 100.0 * g_search_t[4] / tot,
+           100.0 * g_search_t[5] / tot, 100.0 * g_search_t[6] / tot, 100.0 * g_search_t[7] / tot, g_search_t[8], (double)tot / (double)g_search_t[8]);
+    for (int i = 0; i < 10; ++i) g_search_t[i] = 0;
+}
+#else
+#define S_MARK(i) do {} while (0)
+#endif
 template <bool OVER>
-__device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, SearchLds& S, uint32_t lane) {
+__device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, SearchLds& S, uint32_t* filt_all, uint32_t wv, uint32_t lane) {
+    // filt_all: the four waves' presence filters, one behind the other in an array aligned to its own size - a filter word's byte
+    // offset is then (wave's offset | word's offset), and the word of fold(umi) ^ fold(change) is at offset(umi) ^ offset(change):
+    // ONE exclusive-or per probe, the array's address in the instruction's offset field
     uint32_t* t_umi = S.umi; uint32_t* t_word = S.word; uint8_t* t_idx = S.idx;
-    uint32_t* s_filt = S.filt; uint32_t* s_np = &S.np;
+    uint32_t* s_filt = filt_all + wv * (kP2FiltBits / 32); uint32_t* s_np = &S.np;
+#ifdef AFQ_SEARCH_TIMING
+    unsigned long long st_ = clock64();
+#endif
     const uint32_t nv = A.pnv[gp];
     if (nv == 0) return;
     const uint32_t j = A.pcell[gp];
@@ -381,6 +400,7 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
         atomicOr(&s_filt[fb >> 5], 1u << (fb & 31u));
     }
     WAVE_SYNC();
+    S_MARK(0);
     auto filt = [&](uint32_t u) -> bool { const uint32_t f = fold11(u); return (s_filt[f >> 5] >> (f & 31u)) & 1u; };
     // every vertex of the table with UMI pu against vertex x (cell slot gx, word xw)
     // A MATCH - x against the table's vertex y in `slot`: UMIs as asked, signatures with a ref in common - still needs the two
@@ -393,9 +413,14 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
         const uint32_t w = t_word[slot], gy = lo_p + t_idx[slot], cy = w & kVCntMask;
         const uint64_t dir = same ? (kPairF | kPairB) : ((cy < 2 * cx ? kPairF : 0ull) | (cx < 2 * cy ? kPairB : 0ull));
         const uint64_t hx = ch[gx], hy = ch[gy];
+        const uint32_t ox = coff[gx], oy = coff[gy];   // (asked for with the keys, whether or not the labels turn out to be hashed ones: not a round trip of their own behind them)
+        __builtin_amdgcn_sched_barrier(0);
         if ((hx != hy || (uint32_t)(hx >> 62) == 3) &&   // (equal hashed keys are equal labels only once somebody has compared them: here)
-            !klab_overlap(klab(W, A.hw, hx, coff[gx]), klab(W, A.hw, hy, coff[gy]))) return;
-        cflag[gx] |= 1; cflag[gy] |= 1;   // (bit 0; the bits above it hold the vertex's reads and never change: lanes that race here write the same byte)
+            !klab_overlap(klab(W, A.hw, hx, ox), klab(W, A.hw, hy, oy))) return;
+        // (bit 0; the bits above it hold the vertex's reads, min(reads, 127), as k_p2_part left them - both counts are at hand, so the
+        //  byte is WRITTEN, not read and written back: a dependent round trip to memory less in a phase that is nothing but such
+        //  trips.  Lanes that race here write the same byte.)
+        cflag[gx] = (uint8_t)((min(cx, 127u) << 1) | 1u); cflag[gy] = (uint8_t)((min(cy, 127u) << 1) | 1u);
         const uint32_t at = atomicAdd(s_np, 1u);   // (LDS, this wave's own counter)
         if (at < pcap) ppair[at] = dir | ((uint64_t)gx << 31) | gy;
     };
@@ -420,53 +445,67 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
     // and no exec-mask bookkeeping per probe (the kernel was as busy on its scalar unit as on its vector units).  The fold of the
     // filter is linear, so a probe's filter bit is fold(umi) ^ fold(change): one XOR per probe, the change's fold a scalar.
     // "met once, from the smaller UMI": umi ^ (d << 2b) > umi iff the top bit of d is clear in the base - a bit test.
-    uint64_t hits[4] = {0, 0, 0, 0};   // bit 3 (b - m/2) + d - 1 of row r: the change d of base b passed the filter
+    // The passed probes of row r: bit 2 b of ha[r] - base b's change 1; bit 2 b + 1 of ha[r] - its change 2; bit 2 b + 1 of hb[r] - its
+    // change 3: each at the bit of the UMI that decides whether the change makes the UMI larger, so "from the smaller UMI" is one AND
+    // with ~umi per row behind the loop instead of a test per probe.  The changes outside, the rows inside: a change's fold, its
+    // offset and its bit are scalar work.  Per change and row: two exclusive-ors, the filter word, a bit-field extract, a
+    // shift-or (until late round 6: eleven vector instructions and, with the rows outside, as many scalar ones).
+    uint32_t ha[4] = {0, 0, 0, 0}, hb[4] = {0, 0, 0, 0};
     const uint32_t b_lo = m / 2;
-    // (the changes outside, the rows inside: a change's fold, its shift and the bit that decides "met from the smaller UMI" are scalar
-    //  work - with the rows outside they were computed for every row again, and the kernel was as busy on its scalar unit as on its
-    //  vector units: 17.75 -> 17.24 ms per configs[2] step)
-    uint32_t fu[4];
+    uint32_t fu[4], fo[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { fu[r] = fold11((uint32_t)(own[r] >> 32)); fo[r] = (wv * (kP2FiltBits / 8)) | ((fu[r] >> 5) << 2); }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const uint32_t i = (uint32_t)r * 64 + lane;
-        fu[r] = fold11((uint32_t)(own[r] >> 32));
         if ((uint32_t)r * 64 >= nv) break;   // (uniform)
         if (i < nv) probe((uint32_t)(own[r] >> 32), lo_p + i, (uint32_t)own[r], true);
     }
+    S_MARK(1);
     if (!A.exact_umi) {
+        const char* fbase = reinterpret_cast<const char*>(filt_all);
         for (uint32_t b = b_lo; b < L; ++b) {   // (bases below m / 2 lie inside the low m bits: every change there leaves the partition)
 #pragma unroll
             for (uint32_t d = 1; d < 4; ++d) {
                 const uint32_t mk = d << (2 * b);
                 if (mk & (P - 1)) continue;   // (scalar: only the base that straddles bit m)
-                const uint32_t fm = fold11(mk), tb = 2 * b + (d == 1 ? 0u : 1u), sh = 3 * (b - b_lo) + d - 1;
+                const uint32_t fm = fold11(mk), fmo = (fm >> 5) << 2, tb = 2 * b + (d == 1 ? 0u : 1u);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {   // (the rows' count as a compile-time constant - four instances of this loop, the rows' filter words asked for together - measured 19.7 against 17.2 ms: 14 VGPRs spilled instead of 8)
+                for (int r = 0; r < 4; ++r) {   // (measured and not kept: the rows' count as a compile-time constant, four instances of this loop - 19.7 against 17.2 ms, 14 VGPRs spilled instead of 8; all four rows whether the partition has them or not, their filter words asked for together - 16.96 against 16.73)
                     if ((uint32_t)r * 64 >= nv) break;   // (uniform)
-                    const uint32_t f = fu[r] ^ fm;
-                    const uint32_t bit = (s_filt[f >> 5] >> (f & 31u)) & 1u;
-                    const uint32_t up = (((uint32_t)(own[r] >> 32) >> tb) & 1u) ^ 1u;
-                    hits[r] |= (uint64_t)(bit & up) << sh;
+                    const uint32_t w = *reinterpret_cast<const uint32_t*>(fbase + (fo[r] ^ fmo));
+                    const uint32_t bit = (w >> ((fu[r] ^ fm) & 31u)) & 1u;
+                    if (d == 3) hb[r] |= bit << tb; else ha[r] |= bit << tb;
                 }
             }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) if ((uint32_t)r * 64 + lane >= nv) hits[r] = 0ull;
-    }
-    for (;;) {   // drain: every lane takes its next passed probe, whichever row it is in (static register indices: no scratch)
-        const bool mine = (hits[0] | hits[1] | hits[2] | hits[3]) != 0;
-        if (!__any(mine)) break;
-        if (mine) {
-            uint32_t r = 0;
-            uint64_t hr = 0, ow = 0;
-            if (hits[0]) { r = 0; hr = hits[0]; ow = own[0]; hits[0] &= hits[0] - 1; }
-            else if (hits[1]) { r = 1; hr = hits[1]; ow = own[1]; hits[1] &= hits[1] - 1; }
-            else if (hits[2]) { r = 2; hr = hits[2]; ow = own[2]; hits[2] &= hits[2] - 1; }
-            else { r = 3; hr = hits[3]; ow = own[3]; hits[3] &= hits[3] - 1; }
-            const uint32_t ix = (uint32_t)__builtin_ctzll(hr);
-            probe((uint32_t)(ow >> 32) ^ ((ix % 3 + 1) << (2 * (b_lo + ix / 3))), lo_p + r * 64 + lane, (uint32_t)ow, false);
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t keep = (uint32_t)r * 64 + lane < nv ? ~(uint32_t)(own[r] >> 32) : 0u;
+            ha[r] &= keep; hb[r] &= keep;
         }
     }
+    S_MARK(2);
+    for (;;) {   // drain: every lane takes its next passed probe, whichever row it is in (static register indices: no scratch)
+        const bool mine = (ha[0] | ha[1] | ha[2] | ha[3] | hb[0] | hb[1] | hb[2] | hb[3]) != 0;
+        if (!__any(mine)) break;
+        if (mine) {
+            uint32_t r = 0, hw = 0, three = 0;
+            uint64_t ow = 0;
+            if (ha[0]) { r = 0; hw = ha[0]; ow = own[0]; ha[0] &= ha[0] - 1; }
+            else if (ha[1]) { r = 1; hw = ha[1]; ow = own[1]; ha[1] &= ha[1] - 1; }
+            else if (ha[2]) { r = 2; hw = ha[2]; ow = own[2]; ha[2] &= ha[2] - 1; }
+            else if (ha[3]) { r = 3; hw = ha[3]; ow = own[3]; ha[3] &= ha[3] - 1; }
+            else if (hb[0]) { r = 0; hw = hb[0]; ow = own[0]; three = 1; hb[0] &= hb[0] - 1; }
+            else if (hb[1]) { r = 1; hw = hb[1]; ow = own[1]; three = 1; hb[1] &= hb[1] - 1; }
+            else if (hb[2]) { r = 2; hw = hb[2]; ow = own[2]; three = 1; hb[2] &= hb[2] - 1; }
+            else { r = 3; hw = hb[3]; ow = own[3]; three = 1; hb[3] &= hb[3] - 1; }
+            const uint32_t pos = (uint32_t)__builtin_ctz(hw);
+            const uint32_t d = three ? 3u : 1u + (pos & 1u);
+            probe((uint32_t)(ow >> 32) ^ (d << (pos & ~1u)), lo_p + r * 64 + lane, (uint32_t)ow, false);
+        }
+    }
+    S_MARK(3);
     // The vertices of the partitions one low-bit change away, FOUR partitions at a time (their places are in lanes k .. k + 3's
     // registers): the eight loads of a batch go out together and are waited for once.  A partition at a time with the next one's
     // load behind it, every load's latency was in the open - a partition takes some thirty instructions to go through the filter -
@@ -508,6 +547,7 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
             }
         }
     }
+    S_MARK(4);
     for (; __any(fhits != 0);) {
         const uint32_t ix = fhits ? (uint32_t)__builtin_ctzll(fhits) : 0u;
         const uint32_t k = ix >> 1, r = ix & 1u;
@@ -520,30 +560,38 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
         }
     }
     WAVE_SYNC();
+    S_MARK(5);
     {   // the parked matches, a lane each
         const uint32_t nq = min(S.nq, kP2MatchQ);
         if (lane < nq) { const uint2 e = S.q[lane]; check(e.x, e.y & 0x1FFu, e.y >> 10, ((e.y >> 9) & 1u) != 0); }
     }
     WAVE_SYNC();
+    S_MARK(6);
     const uint32_t np = *s_np;
     if (lane == 0 && !OVER) A.pnp[gp] = np;   // (more than pcap: the second pass takes the partition)
     if (lane == 0 && OVER && np != pcap) set_err(A.st, kErrInternal, c.cell);   // (the same search twice: the same pairs)
     WAVE_SYNC();
+    S_MARK(7);
+#ifdef AFQ_SEARCH_TIMING
+    if (lane == 0) atomicAdd(&g_search_t[8], 1ull);
+#endif
 }
 __global__ __launch_bounds__(256, AFQ_P2_SEARCH_WGS) void k_p2_search(P2Args A) {
     if (A.st->err_code) return;   // an earlier kernel of the range failed (e.g. kErrLabelHash in k_p2_part, which then leaves its partition's vertices unwritten): nothing behind it may read that state - the host runs the range again or reports the error
     __shared__ SearchLds s_lds[4];
+    __shared__ __attribute__((aligned(kP2FiltBits / 8))) uint32_t s_filt4[4 * (kP2FiltBits / 32)];
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    for_each_partition_in_runs(A.n_parts, wv, [&](uint32_t gp) { search_body<false>(A, gp, s_lds[wv], lane); });
+    for_each_partition_in_runs(A.n_parts, wv, [&](uint32_t gp) { search_body<false>(A, gp, s_lds[wv], s_filt4, wv, lane); });
 }
 __global__ __launch_bounds__(256) void k_p2_search_over(P2Args A) {
     if (A.st->err_code) return;
     __shared__ SearchLds s_lds[4];
+    __shared__ __attribute__((aligned(kP2FiltBits / 8))) uint32_t s_filt4[4 * (kP2FiltBits / 32)];
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     for (uint32_t g0 = (blockIdx.x * 4 + wv) * 64; g0 < A.n_parts; g0 += gridDim.x * 256) {   // 64 partitions' counts at a time, a lane each
         const uint32_t gp = g0 + lane;
         uint64_t over = __ballot(gp < A.n_parts && A.pnp[gp] > A.pcnt[gp]);
-        for (; over; over &= over - 1) search_body<true>(A, g0 + (uint32_t)__builtin_ctzll(over), s_lds[wv], lane);
+        for (; over; over &= over - 1) search_body<true>(A, g0 + (uint32_t)__builtin_ctzll(over), s_lds[wv], s_filt4, wv, lane);
     }
 }
 
@@ -1795,6 +1843,9 @@ void launch_p2_part(hipStream_t s, const P2Args& a) { if (a.n_parts) AFQ_LAUNCH(
 void launch_p2_search(hipStream_t s, const P2Args& a) {
     if (!a.n_parts) return;
     AFQ_LAUNCH(k_p2_search, p2_grid(a.n_parts), 256, s, a);
+#ifdef AFQ_SEARCH_TIMING
+    hipLaunchKernelGGL(k_search_timing_dump, dim3(1), dim3(1), 0, s);
+#endif
     AFQ_LAUNCH(k_p2_search_over, std::min((a.n_parts + 255) / 256, 2048u), 256, s, a);   // (the partitions with more pairs than slots, normally none: two counts per partition are read)
 }
 void launch_p2_lone(hipStream_t s, const P2Args& a) {
