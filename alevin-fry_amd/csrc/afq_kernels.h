@@ -249,6 +249,7 @@ constexpr uint32_t kP2TileHost = 4096;   // reads per histogram / scatter tile (
 void launch_p2_split(hipStream_t s, const P2Args& a);
 void launch_p2_part(hipStream_t s, const P2Args& a);
 void launch_p2_search(hipStream_t s, const P2Args& a);
+void launch_p2_check(hipStream_t s, const P2Args& a);   // (afq_pugflat.hip; launch_p2_search ends with it)
 void launch_p2_lone(hipStream_t s, const P2Args& a);
 void launch_p2_graph(hipStream_t s, const P2Args& a, uint64_t n_reads);
 void launch_pf_build(hipStream_t s, const P2Args& a, uint64_t n_reads);

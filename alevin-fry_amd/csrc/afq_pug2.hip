@@ -309,13 +309,11 @@ __global__ __launch_bounds__(256) void k_p2_part(P2Args A) {
 #ifndef AFQ_P2_SEARCH_WGS
 #define AFQ_P2_SEARCH_WGS 7   // workgroups per CU the search is compiled for: 72 VGPRs (five spilled), 22.5 KiB of LDS with the 2^12-bit filter.  Measured per configs[2] step: 4 -> 33.5 ms, 5 -> 28.0, 6 -> 25.5 (24.9 with a 2^13-bit filter, which no longer fits seven times), 7 -> 23.7
 #endif
-constexpr uint32_t kP2MatchQ = 64;   // matches a partition's walks park before they are checked (more: checked where they are met)
 struct SearchLds {
     uint32_t umi[kP2TabSlots];
     uint32_t word[kP2TabSlots];
     uint8_t idx[kP2TabSlots];           // (a partition holds at most 256 vertices)
-    uint2 q[kP2MatchQ];                 // .x = vertex x (slot inside the cell); .y = table slot of y | same-UMI << 9 | reads of x << 10
-    uint32_t np, nq;
+    uint32_t np;
 };
 static_assert(kP2PartCap <= 256, "SearchLds::idx is a byte");
 // OVER: the second pass over the partitions that found more pairs than they have slots of their own - k vertices of one UMI whose
@@ -330,7 +328,7 @@ __device__ unsigned long long g_search_t[10];
 __global__ void k_search_timing_dump() {
     unsigned long long tot = 0;
     for (int i = 0; i < 8; ++i) tot += g_search_t[i];
-    printf("search wave cycles: setup+build %.1f%% same-umi %.1f%% own filter %.1f%% own drain %.1f%% foreign fetch+filter %.1f%% foreign drain %.1f%% parked checks %.1f%% tail %.1f%% (partitions %llu, %.0f cycles each)\n",
+    printf("search wave cycles: setup+build %.1f%% same-umi %.1f%% own filter %.1f%% own drain %.1f%% foreign fetch+filter %.1f%% foreign drain %.1f%% (unused) %.1f%% tail %.1f%% (partitions %llu, %.0f cycles each)\n",
            100.0 * g_search_t[0] / tot, 100.0 * g_search_t[1] / tot, 100.0 * g_search_t[2] / tot, 100.0 * g_search_t[3] / tot, 100.0 * g_search_t[4] / tot,
            100.0 * g_search_t[5] / tot, 100.0 * g_search_t[6] / tot, 100.0 * g_search_t[7] / tot, g_search_t[8], (double)tot / (double)g_search_t[8]);
     for (int i = 0; i < 10; ++i) g_search_t[i] = 0;
@@ -356,12 +354,8 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
     const uint32_t lo_p = A.poff[gp];                 // the partition's first slot inside the cell
     uint32_t pcap = A.pcnt[gp];                       // ... and how many it has: the partition's pairs go into its own slots of the pair array
     if (OVER && A.pnp[gp] <= pcap) return;
-    const uint64_t* ch = A.s_h + c.rd_base;           // the cell's vertex arrays
-    const uint64_t* cu = A.s_u + c.rd_base;
-    const uint32_t* coff = A.v_off + c.rd_base;
-    uint8_t* cflag = A.v_flag + c.rd_base;
+    const uint64_t* cu = A.s_u + c.rd_base;           // the cell's vertices: UMI << 32 | word
     uint64_t* ppair = A.pairs + c.rd_base + lo_p;
-    const uint32_t* W = reinterpret_cast<const uint32_t*>(A.bytes + c.chunk_off);
     if (OVER) {
         const uint32_t np = A.pnp[gp];
         unsigned long long base = 0;
@@ -382,7 +376,7 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
     }
     for (uint32_t i = lane; i < kP2TabSlots; i += 64) t_word[i] = 0;
     for (uint32_t i = lane; i < kP2FiltBits / 32; i += 64) s_filt[i] = 0;
-    if (lane == 0) { *s_np = 0; S.nq = 0; }
+    if (lane == 0) *s_np = 0;
     WAVE_SYNC();
     uint64_t own[4];   // the partition's own vertices stay in registers (<= 256 of them)
 #pragma unroll
@@ -402,29 +396,17 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
     WAVE_SYNC();
     S_MARK(0);
     auto filt = [&](uint32_t u) -> bool { const uint32_t f = fold11(u); return (s_filt[f >> 5] >> (f & 31u)) & 1u; };
-    // every vertex of the table with UMI pu against vertex x (cell slot gx, word xw)
-    // A MATCH - x against the table's vertex y in `slot`: UMIs as asked, signatures with a ref in common - still needs the two
-    // labels compared, which is a chain of dependent global loads (label keys, record offsets, for hashed keys the ref lists).
-    // Met where it is found - inside a table walk that one or two lanes of the wave are still in - every walk that found one
-    // paid for that chain with the rest of the wave idle: some seven times per partition, two thirds of this kernel's wave cycles.
-    // The walks therefore only PARK their matches (up to kP2MatchQ per partition, in LDS); they are checked afterwards, a lane
-    // each, the chain paid once per 64 of them.
-    auto check = [&](uint32_t gx, uint32_t slot, uint32_t cx, bool same) {
-        const uint32_t w = t_word[slot], gy = lo_p + t_idx[slot], cy = w & kVCntMask;
-        const uint64_t dir = same ? (kPairF | kPairB) : ((cy < 2 * cx ? kPairF : 0ull) | (cx < 2 * cy ? kPairB : 0ull));
-        const uint64_t hx = ch[gx], hy = ch[gy];
-        const uint32_t ox = coff[gx], oy = coff[gy];   // (asked for with the keys, whether or not the labels turn out to be hashed ones: not a round trip of their own behind them)
-        __builtin_amdgcn_sched_barrier(0);
-        if ((hx != hy || (uint32_t)(hx >> 62) == 3) &&   // (equal hashed keys are equal labels only once somebody has compared them: here)
-            !klab_overlap(klab(W, A.hw, hx, ox), klab(W, A.hw, hy, oy))) return;
-        // (bit 0; the bits above it hold the vertex's reads, min(reads, 127), as k_p2_part left them - both counts are at hand, so the
-        //  byte is WRITTEN, not read and written back: a dependent round trip to memory less in a phase that is nothing but such
-        //  trips.  Lanes that race here write the same byte.)
-        cflag[gx] = (uint8_t)((min(cx, 127u) << 1) | 1u); cflag[gy] = (uint8_t)((min(cy, 127u) << 1) | 1u);
-        const uint32_t at = atomicAdd(s_np, 1u);   // (LDS, this wave's own counter)
-        if (at < pcap) ppair[at] = dir | ((uint64_t)gx << 31) | gy;
-    };
-    // every vertex of the table with UMI pu against vertex x (cell slot gx, word xw)
+    // Every vertex of the table with UMI pu against vertex x (cell slot gx, word xw).  A MATCH - x against the table's vertex y in
+    // `slot`: UMIs as asked, signatures with a ref in common - is written down as a CANDIDATE pair with both directions of has_edge
+    // decided (the read counts are at hand).  Whether the two labels really share a ref is a chain of dependent global loads (label
+    // keys, record offsets, for hashed keys the ref lists): until late round 6 that chain ran here - first inside the table walk
+    // that found the match, one or two lanes of the wave still in it (two thirds of the kernel's wave cycles), then, rounds 5-6,
+    // parked and checked a lane each at the partition's end (still 38 % of them: per-phase clocks, AFQ_SEARCH_TIMING) - and is now
+    // k_p2_check's (afq_pugflat.hip), a thread per candidate over the whole range, which has no chain to wait for: it clears the
+    // candidates that fail and flags the end points of the others.  (The search flagging the end points of its candidates itself -
+    // byte stores of known values, no atomics in k_p2_check - was measured: a vertex that loses all its candidates then goes through
+    // the graph phase as a component of one vertex, correctly, but there are enough of them to cost that phase 2.2 ms per configs[2]
+    // step for 0.8 saved here.)
     auto probe = [&](uint32_t pu, uint32_t gx, uint32_t xw, bool same) {
         const uint32_t xsig = (xw >> 10) & 0x7FFFFu, cx = xw & kVCntMask;
         for (uint32_t slot = fold9(pu);; slot = (slot + 1) & (kP2TabSlots - 1)) {
@@ -432,10 +414,11 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
             if (!w) break;
             if (t_umi[slot] != pu) continue;
             if ((((w >> 10) & 0x7FFFFu) & xsig) == 0) continue;   // no ref in common whatever the UMIs
-            if (same && lo_p + t_idx[slot] <= gx) continue;       // (a same-UMI pair is met once, from the smaller slot)
-            const uint32_t at = atomicAdd(&S.nq, 1u);
-            if (at < kP2MatchQ) S.q[at] = make_uint2(gx, slot | ((same ? 1u : 0u) << 9) | (cx << 10));
-            else check(gx, slot, cx, same);
+            const uint32_t gy = lo_p + t_idx[slot], cy = w & kVCntMask;
+            if (same && gy <= gx) continue;                       // (a same-UMI pair is met once, from the smaller slot)
+            const uint64_t dir = same ? (kPairF | kPairB) : ((cy < 2 * cx ? kPairF : 0ull) | (cx < 2 * cy ? kPairB : 0ull));
+            const uint32_t at = atomicAdd(s_np, 1u);   // (LDS, this wave's own counter)
+            if (at < pcap) ppair[at] = dir | ((uint64_t)gx << 31) | gy;
         }
     };
     const uint32_t L = A.umi_pairs;
@@ -561,11 +544,6 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
     }
     WAVE_SYNC();
     S_MARK(5);
-    {   // the parked matches, a lane each
-        const uint32_t nq = min(S.nq, kP2MatchQ);
-        if (lane < nq) { const uint2 e = S.q[lane]; check(e.x, e.y & 0x1FFu, e.y >> 10, ((e.y >> 9) & 1u) != 0); }
-    }
-    WAVE_SYNC();
     S_MARK(6);
     const uint32_t np = *s_np;
     if (lane == 0 && !OVER) A.pnp[gp] = np;   // (more than pcap: the second pass takes the partition)
@@ -1001,7 +979,7 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, const uint32_t* list
 #pragma unroll
             for (int r = 0; r < 4; ++r) { lx[r] = k0 + r < nk ? lidx[(uint32_t)(pr[r] >> 31) & 0x7FFFFFFFu] : 0u; ly[r] = k0 + r < nk ? lidx[(uint32_t)pr[r] & 0x7FFFFFFFu] : 0u; }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (k0 + r < nk) lp[at + k0 + r] = (uint64_t)lx[r] | ((uint64_t)ly[r] << 24) | ((pr[r] >> 62) << 48);
+            for (int r = 0; r < 4; ++r) if (k0 + r < nk) lp[at + k0 + r] = (pr[r] >> 62) ? (uint64_t)lx[r] | ((uint64_t)ly[r] << 24) | ((pr[r] >> 62) << 48) : 0ull;   // (0: a candidate k_p2_check cleared - the loops over lp skip it)
         }
     }
     gsync();
@@ -1028,6 +1006,7 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, const uint32_t* list
         };
         for (uint32_t k = tid; k < n_pairs; k += GNT) {
             const uint64_t e = lp[k];
+            if (!e) continue;
             uint32_t a = find((uint32_t)e & 0xFFFFFFu), b = find((uint32_t)(e >> 24) & 0xFFFFFFu);
             while (a != b) {
                 if (a < b) { const uint32_t t = a; a = b; b = t; }   // the larger root goes under the smaller
@@ -1325,6 +1304,7 @@ __global__ __launch_bounds__(GNT) void k_p2_graph(P2Args A, const uint32_t* list
     gsync();
     for (uint32_t k = tid; k < n_pairs; k += GNT) {
         const uint64_t e = lp[k];
+        if (!e) continue;
         const uint32_t x = (uint32_t)e & 0xFFFFFFu, y = (uint32_t)(e >> 24) & 0xFFFFFFu;
         const uint32_t rc = ld_l2(&rcnt[root_of[x]]), cat = rc >> 28;
         if (cat == kCatPair || cat == kCatLarge) continue;
@@ -1847,6 +1827,7 @@ void launch_p2_search(hipStream_t s, const P2Args& a) {
     hipLaunchKernelGGL(k_search_timing_dump, dim3(1), dim3(1), 0, s);
 #endif
     AFQ_LAUNCH(k_p2_search_over, std::min((a.n_parts + 255) / 256, 2048u), 256, s, a);   // (the partitions with more pairs than slots, normally none: two counts per partition are read)
+    launch_p2_check(s, a);   // (the candidates that fail the label test cleared, the end points of the others flagged: afq_pugflat.hip)
 }
 void launch_p2_lone(hipStream_t s, const P2Args& a) {
     if (!a.n_parts) return;

@@ -290,6 +290,88 @@ __device__ __forceinline__ void pf_for_each_pair4(const P2Args& A, uint32_t* s_s
     }
 }
 
+// 0. (behind the search, before anything reads a flag) one thread per CANDIDATE pair - k_p2_search writes down every two vertices
+//    whose UMIs are as has_edge wants them and whose label signatures share a bit; whether the labels share a REF (pugutils.rs:187-204)
+//    takes the label keys, for hashed keys the record offsets and the ref lists in the chunk: dependent gathers, which a wave that
+//    owns a partition waits for one after the other and a thread per candidate over the whole range does not notice.  A candidate
+//    that fails is cleared (0: no direction bit - every loop over pairs skips it); the end points of the others get bit 0 of their
+//    flag bytes.
+__global__ __launch_bounds__(256) void k_p2_check(P2Args A) {
+    if (A.st->err_code) return;
+    __shared__ uint32_t s_start[256];
+    __shared__ unsigned long long s_src[256];
+    __shared__ uint32_t s_cellj[256];
+    __shared__ uint32_t s_ws[4];
+    for (uint32_t p0 = blockIdx.x * 256; p0 < A.n_parts; p0 += gridDim.x * 256) {
+        const uint32_t gp = p0 + threadIdx.x;
+        uint32_t np = 0, cj = 0;
+        unsigned long long src = 0;
+        if (gp < A.n_parts) {
+            np = A.pnp[gp];
+            if (np) {
+                cj = A.pcell[gp];
+                const unsigned long long so = A.cells[cj].rd_base + A.poff[gp];
+                src = np > A.pcnt[gp] ? (unsigned long long)(uintptr_t)(A.pool + A.pairs[so]) : (unsigned long long)(uintptr_t)(A.pairs + so);
+            }
+        }
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<256>(np, s_ws, tot);
+        s_start[threadIdx.x] = ex; s_src[threadIdx.x] = src; s_cellj[threadIdx.x] = cj;
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < tot; t += 512) {   // (two candidates per thread and trip: their gathers side by side)
+            uint64_t* sp[2];
+            uint64_t e[2], hx[2], hy[2];
+            uint32_t ox[2], oy[2], gx[2], gy[2], cj2[2];
+            unsigned long long rb[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint32_t tt = t + 256u * (uint32_t)r;
+                sp[r] = nullptr; cj2[r] = 0;
+                if (tt < tot) {
+                    uint32_t lo = 0, hi = 256;   // the last partition that starts at or before tt
+                    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_start[mid] <= tt) lo = mid; else hi = mid; }
+                    sp[r] = reinterpret_cast<uint64_t*>((uintptr_t)s_src[lo]) + (tt - s_start[lo]);
+                    cj2[r] = s_cellj[lo];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) { e[r] = sp[r] ? *sp[r] : 0ull; rb[r] = A.cells[cj2[r]].rd_base; }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                gx[r] = (uint32_t)(e[r] >> 31) & 0x7FFFFFFFu; gy[r] = (uint32_t)e[r] & 0x7FFFFFFFu;
+                const bool on = sp[r] != nullptr;
+                hx[r] = on ? A.s_h[rb[r] + gx[r]] : 0ull; hy[r] = on ? A.s_h[rb[r] + gy[r]] : 0ull;
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {   // (the record offsets of hashed labels only: one or two refs sit in the key)
+                ox[r] = sp[r] && (uint32_t)(hx[r] >> 62) == 3 ? A.v_off[rb[r] + gx[r]] : 0u;
+                oy[r] = sp[r] && (uint32_t)(hy[r] >> 62) == 3 ? A.v_off[rb[r] + gy[r]] : 0u;
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (!sp[r]) continue;
+                bool ok = true;
+                if (hx[r] != hy[r] || (uint32_t)(hx[r] >> 62) == 3) {   // (equal hashed keys are equal labels only once somebody has compared them: here)
+                    const uint32_t* W = reinterpret_cast<const uint32_t*>(A.bytes + A.cells[cj2[r]].chunk_off);
+                    ok = klab_overlap(klab(W, A.hw, hx[r], ox[r]), klab(W, A.hw, hy[r], oy[r]));
+                }
+                if (!ok) { *sp[r] = 0ull; continue; }
+                const unsigned long long ax = rb[r] + gx[r], ay = rb[r] + gy[r];
+                // (bit 0 of both end points' flag bytes.  A byte read and, if the bit is not there yet, a byte written: threads that race
+                //  on a byte write the same value - the bits above bit 0 are k_p2_part's and do not change - and a byte store leaves
+                //  its neighbours alone.  As atomic ORs on the bytes' words: 1.07 ms per launch against 0.86; no flags at all: 0.87.)
+                const uint8_t fx = A.v_flag[ax], fy = A.v_flag[ay];
+                if (!(fx & 1u)) A.v_flag[ax] = fx | 1u;
+                if (!(fy & 1u)) A.v_flag[ay] = fy | 1u;
+            }
+        }
+        __syncthreads();
+    }
+}
+void launch_p2_check(hipStream_t s, const P2Args& a) {
+    if (a.n_parts) AFQ_LAUNCH(k_p2_check, std::min((a.n_parts + 255) / 256, 4096u), 256, s, a);
+}
+
 // 2. components: one thread per pair.  A root is only ever hooked under a SMALLER vertex (no cycle); find() halves the path it
 //    walks with an atomic min (a racing shortcut still points at an ancestor).
 __global__ __launch_bounds__(256) void k_pf_union(P2Args A) {
@@ -312,7 +394,7 @@ __global__ __launch_bounds__(256) void k_pf_union(P2Args A) {
         uint64_t e[4];
         uint32_t tx[4], ty[4], px[4], py[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) e[r] = sp[r] ? *sp[r] : 0ull;
+        for (int r = 0; r < 4; ++r) { e[r] = sp[r] ? *sp[r] : 0ull; if (!e[r]) sp[r] = nullptr; }   // (0: a candidate k_p2_check cleared)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             tx[r] = sp[r] ? A.lidx[(size_t)rb[r] + ((uint32_t)(e[r] >> 31) & 0x7FFFFFFFu)] : 0u;
