@@ -306,6 +306,9 @@ __global__ __launch_bounds__(256) void k_p2_part(P2Args A) {
 // (Four partitions to a 256-thread workgroup, a wave each with its own slice of LDS and nothing shared: no workgroup barrier;
 // LDS instructions of one wave execute in order, WAVE_SYNC only keeps the compiler from moving code across.)
 
+#ifndef AFQ_SEARCH_FB
+#define AFQ_SEARCH_FB 4   // foreign partitions fetched together
+#endif
 #ifndef AFQ_P2_SEARCH_WGS
 #define AFQ_P2_SEARCH_WGS 7   // workgroups per CU the search is compiled for: 72 VGPRs (five spilled), 22.5 KiB of LDS with the 2^12-bit filter.  Measured per configs[2] step: 4 -> 33.5 ms, 5 -> 28.0, 6 -> 25.5 (24.9 with a 2^13-bit filter, which no longer fits seven times), 7 -> 23.7
 #endif
@@ -502,15 +505,15 @@ __device__ __forceinline__ void search_body(const P2Args& A, uint32_t gp, Search
     // (their filter checks are branch-free too: a passed probe is a bit (partition k, row r) in a per-lane mask; the drain fetches
     //  that vertex again - it is in the cache - instead of carrying a queue of (probe, slot, word) triples in registers)
     uint64_t fhits = 0;   // bit 2 k + r (k < 24: three changes of at most eight low bases)
-    for (uint32_t k0 = 0; k0 < nfor; k0 += 4) {
-        uint32_t fv[4][2], fnq[4], foq[4];
+    for (uint32_t k0 = 0; k0 < nfor; k0 += AFQ_SEARCH_FB) {
+        uint32_t fv[AFQ_SEARCH_FB][2], fnq[AFQ_SEARCH_FB], foq[AFQ_SEARCH_FB];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < AFQ_SEARCH_FB; ++j) {
             fnq[j] = 0; foq[j] = 0; fv[j][0] = 0; fv[j][1] = 0;
             if (k0 + (uint32_t)j < nfor) fetch(k0 + (uint32_t)j, fv[j], fnq[j], foq[j]);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < AFQ_SEARCH_FB; ++j) {
             const uint32_t k = k0 + (uint32_t)j;
             if (k >= nfor) break;   // (uniform)
             const uint32_t nq = fnq[j], oq = foq[j];

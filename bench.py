@@ -231,7 +231,7 @@ def sanity(res, rad):
 
 # timers of the library that bracket several kernels: their bytes add up (the decode timer brackets whichever decoder ran)
 BRACKETS = {"k_em": ("k_em2_plan", "k_em2_setup", "k_em2_rounds", "k_em2_rounds_hybrid", "k_em", "k_em_rounds"),
-            "k_p2_split": ("k_p2_hist", "k_p2_scan", "k_p2_scatter"), "k_p2_search": ("k_p2_search", "k_p2_search_over"),
+            "k_p2_split": ("k_p2_hist", "k_p2_scan", "k_p2_scatter"), "k_p2_search": ("k_p2_search", "k_p2_search_over", "k_p2_check"),
             "k_p2_graph": ("k_pf_count", "k_pf_tscan", "k_pf_number", "k_pf_union", "k_pf_root", "k_pf_cats", "k_pf_classes", "k_pf_cscan", "k_pf_alloc", "k_pf_place", "k_pf_adj",
                            "k_p2_graph", "k_p2_cover", "k_p2_tied"), "k_p2_part": ("k_p2_part",),
             # (since late round 4 the 5 us kernels around the large ones are timed with them - one HIP event between two timed kernels
