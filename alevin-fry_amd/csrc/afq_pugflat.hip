@@ -296,6 +296,10 @@ __device__ __forceinline__ void pf_for_each_pair4(const P2Args& A, uint32_t* s_s
 //    owns a partition waits for one after the other and a thread per candidate over the whole range does not notice.  A candidate
 //    that fails is cleared (0: no direction bit - every loop over pairs skips it); the end points of the others get bit 0 of their
 //    flag bytes.
+#ifdef AFQ_CHECK_COUNT
+__device__ unsigned long long g_check_n[2];
+__global__ void k_check_count_dump() { printf("k_p2_check: %llu candidates, %llu cleared\n", g_check_n[0], g_check_n[1]); g_check_n[0] = g_check_n[1] = 0; }
+#endif
 __global__ __launch_bounds__(256) void k_p2_check(P2Args A) {
     if (A.st->err_code) return;
     __shared__ uint32_t s_start[256];
@@ -355,6 +359,9 @@ __global__ __launch_bounds__(256) void k_p2_check(P2Args A) {
                     const uint32_t* W = reinterpret_cast<const uint32_t*>(A.bytes + A.cells[cj2[r]].chunk_off);
                     ok = klab_overlap(klab(W, A.hw, hx[r], ox[r]), klab(W, A.hw, hy[r], oy[r]));
                 }
+#ifdef AFQ_CHECK_COUNT
+                atomicAdd(&g_check_n[0], 1ull); if (!ok) atomicAdd(&g_check_n[1], 1ull);
+#endif
                 if (!ok) { *sp[r] = 0ull; continue; }
                 const unsigned long long ax = rb[r] + gx[r], ay = rb[r] + gy[r];
                 // (bit 0 of both end points' flag bytes.  A byte read and, if the bit is not there yet, a byte written: threads that race
@@ -370,6 +377,9 @@ __global__ __launch_bounds__(256) void k_p2_check(P2Args A) {
 }
 void launch_p2_check(hipStream_t s, const P2Args& a) {
     if (a.n_parts) AFQ_LAUNCH(k_p2_check, std::min((a.n_parts + 255) / 256, 4096u), 256, s, a);
+#ifdef AFQ_CHECK_COUNT
+    hipLaunchKernelGGL(k_check_count_dump, dim3(1), dim3(1), 0, s);
+#endif
 }
 
 // 2. components: one thread per pair.  A root is only ever hooked under a SMALLER vertex (no cycle); find() halves the path it

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Markdown table of a leg's kernels from the committed evidence: profiles/<tag>_rocprof.txt (rocprofv3 --kernel-trace --stats of
-`bench.py --steps 3 --warmup 1`: four steps) and profiles/r05_resource_usage.txt.  Usage: python profiles/kernel_table.py r05_configs2 [min_pct]"""
+`bench.py --steps 3 --warmup 1`: four steps) and profiles/rNN_resource_usage.txt of the same round (the tag's first three letters).
+Usage: python profiles/kernel_table.py r06_configs2 [min_pct]"""
 import os
 import re
 import sys
@@ -8,9 +9,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def resources():
+def resources(tag):
     out = {}
-    p = os.path.join(HERE, "r05_resource_usage.txt")
+    p = os.path.join(HERE, tag[:3] + "_resource_usage.txt")
     if not os.path.exists(p):
         return out
     for ln in open(p):
@@ -23,7 +24,7 @@ def resources():
 
 
 def main(tag, min_pct=0.8):
-    res = resources()
+    res = resources(tag)
     rows = []
     for ln in open(os.path.join(HERE, f"{tag}_rocprof.txt")):
         if ln.startswith("#") or ln.startswith("kernel") or not ln.strip():
