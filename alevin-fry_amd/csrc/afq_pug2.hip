@@ -804,8 +804,11 @@ __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t
     if (lane == 0) A.pncls[gp] = ncls;
     WAVE_SYNC();
 }
+#ifndef AFQ_LONE_WPE
+#define AFQ_LONE_WPE 7   // waves per SIMD k_p2_lone<false> is compiled for
+#endif
 template <bool L8>
-__global__ __launch_bounds__(256) void k_p2_lone(P2Args A) {
+__global__ __launch_bounds__(256, L8 ? 5 : AFQ_LONE_WPE) void k_p2_lone(P2Args A) {
     if (A.st->err_code) return;   // an earlier kernel of the range failed (e.g. kErrLabelHash in k_p2_part, which then leaves its partition's vertices unwritten): nothing behind it may read that state - the host runs the range again or reports the error
     __shared__ uint32_t s_cls4[4][512];
     __shared__ uint32_t s_g4[4][kMaxGenesPerLabel];   // (a wave's row for the genes of a label of more than 64 refs)

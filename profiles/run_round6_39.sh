@@ -1,0 +1,8 @@
+#!/bin/bash
+# round 6, call 39: the extended parity sweep (320 workloads) on the code with k_p2_check
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=$GRAFT_REPO_ROOT/gpurun_out/round6_39; mkdir -p $O
+( timeout 1500 python tests/extended_fuzz.py 150 0 2>&1 | tail -6 ) | tee $O/fuzz_0.txt
+( timeout 900 python tests/extended_fuzz.py 70 1000 2>&1 | tail -4 ) | tee $O/fuzz_1000.txt
+( timeout 900 python tests/extended_fuzz.py 60 2000 2>&1 | tail -4 ) | tee $O/fuzz_2000.txt
+( timeout 900 python tests/extended_fuzz.py 40 3000 2>&1 | tail -4 ) | tee $O/fuzz_3000.txt
