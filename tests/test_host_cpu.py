@@ -873,3 +873,72 @@ int main() {
             assert Counter(cols) == w, (("ordered", "set aside + resumed")[way], case, cols, w)
         set_aside += lines[2 * i + 1][0]
     assert set_aside > len(cases) // 50   # the tie path was walked (a few percent of these components meet a tie)
+
+
+def test_label_overlap_by_key_is_set_intersection_on_host(tmp_path):
+    """csrc/afq_p2_shared.h + afq_pug_common.h: `klab` / `klab_overlap` - do two labels share a ref (pugutils.rs:187-204)? - is the
+    whole of k_p2_check's decision about a candidate pair (csrc/afq_pugflat.hip, round 6) and of the covers' edge test.  A label of
+    one or two refs sits in its 64-bit key (tag 1, 2), a longer one in the chunk behind its record header (tag 3: the refs ascending,
+    the orientation bit still on).  The functions' own source text, compiled for the host, against a set intersection on 400 000
+    random pairs of labels of 1..9 refs out of 12.  No GPU."""
+    import shutil
+    import subprocess
+
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    com = open(os.path.join(ROOT, "alevin-fry_amd", "csrc", "afq_pug_common.h")).read()
+    sh = open(os.path.join(ROOT, "alevin-fry_amd", "csrc", "afq_p2_shared.h")).read()
+
+    def grab(text, start, end):
+        a = text.index(start)
+        return text[a:text.index(end, a)]
+
+    host = r'''#include <cstdint>
+#include <cstdio>
+#include <random>
+#include <set>
+#include <vector>
+#include <algorithm>
+#define __device__
+#define __forceinline__ inline
+struct PugCtx { const uint32_t* W; uint32_t HW; };
+''' + grab(com, "struct Lab {", "__device__ __forceinline__ bool lab_equal(") + grab(sh, "struct KLab {", "__device__ __forceinline__ PugCtx make_ctx(") + r'''
+int main() {
+    std::mt19937 rng(11);
+    const uint32_t HW = 3;
+    long n = 0, bad = 0, yes = 0;
+    for (int it = 0; it < 400000; ++it) {
+        std::vector<uint32_t> W(4, 0xDEADBEEFu);
+        std::set<uint32_t> refs[2];
+        uint64_t key[2];
+        uint32_t off[2] = {0, 0};
+        for (int s = 0; s < 2; ++s) {
+            const uint32_t len = 1 + rng() % 9;
+            while (refs[s].size() < len) refs[s].insert(rng() % 12 + (it % 3 == 0 ? 1000000u : 0u));
+            std::vector<uint32_t> v(refs[s].begin(), refs[s].end());
+            if (len == 1) key[s] = (1ull << 62) | v[0];
+            else if (len == 2) key[s] = (2ull << 62) | ((uint64_t)v[0] << 31) | v[1];
+            else {
+                key[s] = (3ull << 62) | (rng() & 0xFFFFFFu);   // (the hash itself is never looked at here)
+                off[s] = (uint32_t)W.size();
+                W.push_back(len); W.push_back(0x11111111u); W.push_back(0x22222222u);   // the record header: na, barcode, UMI
+                for (uint32_t r : v) W.push_back(r | ((rng() & 1u) << 31));              // refs ascending, orientation bit on or off
+                W.push_back(0x7FFFFFFFu);
+            }
+        }
+        bool want = false;
+        for (uint32_t r : refs[0]) want = want || refs[1].count(r);
+        const bool got = klab_overlap(klab(W.data(), HW, key[0], off[0]), klab(W.data(), HW, key[1], off[1]));
+        const bool rev = klab_overlap(klab(W.data(), HW, key[1], off[1]), klab(W.data(), HW, key[0], off[0]));
+        ++n; yes += want;
+        if (got != want || rev != want) { if (bad < 5) printf("MISMATCH it=%d want=%d got=%d rev=%d\n", it, (int)want, (int)got, (int)rev); ++bad; }
+    }
+    printf("%ld pairs (%ld share a ref), %ld mismatches\n", n, yes, bad);
+    return bad != 0 || yes < n / 10 || yes > 9 * n / 10;
+}
+'''
+    (tmp_path / "t.cpp").write_text(host)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", str(tmp_path / "t"), str(tmp_path / "t.cpp")], check=True, capture_output=True)
+    r = subprocess.run([str(tmp_path / "t")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert " 0 mismatches" in r.stdout
