@@ -704,10 +704,26 @@ __device__ __forceinline__ uint32_t molecule8_column(const PugCtx& c, uint32_t (
     return col;
 }
 
+#ifdef AFQ_LONE_TIMING
+__device__ unsigned long long g_lone_t[10];
+#define L_MARK(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long n_ = clock64(); if (lane == 0) atomicAdd(&g_lone_t[i], n_ - lt_); lt_ = n_; } while (0)
+__global__ void k_lone_timing_dump() {
+    unsigned long long tot = 0;
+    for (int i = 0; i < 7; ++i) tot += g_lone_t[i];
+    printf("lone wave cycles: head (scalar chain) %.1f%% keys+flags+offsets %.1f%% label words %.1f%% genes %.1f%% rules+stores %.1f%% coop labels %.1f%% classes %.1f%% (partitions %llu)\n",
+           100.0 * g_lone_t[0] / tot, 100.0 * g_lone_t[1] / tot, 100.0 * g_lone_t[2] / tot, 100.0 * g_lone_t[3] / tot, 100.0 * g_lone_t[4] / tot, 100.0 * g_lone_t[5] / tot, 100.0 * g_lone_t[6] / tot, g_lone_t[8]);
+    for (int i = 0; i < 10; ++i) g_lone_t[i] = 0;
+}
+#else
+#define L_MARK(i) do {} while (0)
+#endif
 // L8: labels of 5..8 refs by their own lane (molecule8_column; AFQ_TEST_P2_LONE_COOP=2) - an instance of its own: its eight-entry arrays
 // are registers of every lane whether or not a label needs them.
 template <bool L8>
 __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t* s_cls, uint32_t* s_g, uint32_t lane) {
+#ifdef AFQ_LONE_TIMING
+    unsigned long long lt_ = clock64();
+#endif
     const uint32_t n = A.pcnt[gp], nv = A.pnv[gp], j = A.pcell[gp], lo_p = A.poff[gp];
     if (n == 0) return;
     const P2Cell c = A.cells[j];
@@ -721,6 +737,7 @@ __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t
     const uint32_t cw = 2 + c.R * C.HW + c.n_ref;   // dwords of the chunk
     PugCtx Cg = C;
     Cg.gene_level = 1;   // (genes_of4 is handed gene ids below: the gathers are done here, for all slots together)
+    L_MARK(0);
     for (uint32_t r0 = 0; r0 < n; r0 += 128) {   // (uniform)
         constexpr int NR = L8 ? 8 : 4;   // refs of a label a lane looks at itself
         uint64_t h2[2];
@@ -732,6 +749,7 @@ __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t
             fl[r] = i < nv ? (A.v_flag[o + i] & 1u) : 1u;
             of[r] = i < nv ? A.v_off[o + i] : 0u;
         }
+        L_MARK(1);
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const uint32_t tag = fl[r] ? 0u : (uint32_t)(h2[r] >> 62);
@@ -750,10 +768,12 @@ __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t
                 }
             }
         }
+        L_MARK(2);
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int q = 0; q < NR; ++q) g4[r][q] = (uint32_t)q < ln[r] && ln[r] <= (uint32_t)NR ? C.t2g[t4[r][q]] : 0xFFFFFFFFu;
+        L_MARK(3);
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const uint32_t i = r0 + (uint32_t)r * 64 + lane;
@@ -780,6 +800,7 @@ __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t
             if (cls) { const uint32_t q = ncls + (uint32_t)__popcll(mk & ((1ull << lane) - 1)); s_cls[2 * q] = k0; s_cls[2 * q + 1] = k1; }
             ncls += (uint32_t)__popcll(mk);
         }
+        L_MARK(4);
         // labels of more than 64 refs (without the cooperative path: of more than four): one lane after the other, its genes in the
         // wave's LDS row - 64 words of a lane's own were 272 bytes of scratch per lane of every wave, for a label in ten thousand.
         // (Behind the rows' loop, where the gathered refs and genes are dead: inside it the kernel lost its seventh wave per SIMD.)
@@ -797,12 +818,17 @@ __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t
             }
         }
     }
+    L_MARK(5);
+#ifdef AFQ_LONE_TIMING
+    if (lane == 0) atomicAdd(&g_lone_t[8], 1ull);
+#endif
     if (!ncls) return;
     WAVE_SYNC();
     uint64_t* stage = A.cstage + o;   // (at most one class per vertex: the partition's own slots hold them; the graph kernel moves them into the cell's label area)
     for (uint32_t i = lane; i < ncls; i += 64) stage[i] = ((uint64_t)s_cls[2 * i + 1] << 32) | s_cls[2 * i];
     if (lane == 0) A.pncls[gp] = ncls;
     WAVE_SYNC();
+    L_MARK(6);
 }
 #ifndef AFQ_LONE_WPE
 #define AFQ_LONE_WPE 7   // waves per SIMD k_p2_lone<false> is compiled for
@@ -1839,6 +1865,9 @@ void launch_p2_lone(hipStream_t s, const P2Args& a) {
     if (!a.n_parts) return;
     if (a.lone_coop >= 2) AFQ_LAUNCH(k_p2_lone<true>, p2_grid(a.n_parts), 256, s, a);
     else AFQ_LAUNCH(k_p2_lone<false>, p2_grid(a.n_parts), 256, s, a);
+#ifdef AFQ_LONE_TIMING
+    hipLaunchKernelGGL(k_lone_timing_dump, dim3(1), dim3(1), 0, s);
+#endif
 }
 void launch_p2_graph(hipStream_t s, const P2Args& a, uint64_t n_reads) {
     if (!a.n_cells) return;
