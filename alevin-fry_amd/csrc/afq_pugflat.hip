@@ -300,6 +300,9 @@ __device__ __forceinline__ void pf_for_each_pair4(const P2Args& A, uint32_t* s_s
 __device__ unsigned long long g_check_n[2];
 __global__ void k_check_count_dump() { printf("k_p2_check: %llu candidates, %llu cleared\n", g_check_n[0], g_check_n[1]); g_check_n[0] = g_check_n[1] = 0; }
 #endif
+#ifndef AFQ_CHECK_PER
+#define AFQ_CHECK_PER 2
+#endif
 __global__ __launch_bounds__(256) void k_p2_check(P2Args A) {
     if (A.st->err_code) return;
     __shared__ uint32_t s_start[256];
@@ -322,13 +325,13 @@ __global__ __launch_bounds__(256) void k_p2_check(P2Args A) {
         const uint32_t ex = block_excl_scan<256>(np, s_ws, tot);
         s_start[threadIdx.x] = ex; s_src[threadIdx.x] = src; s_cellj[threadIdx.x] = cj;
         __syncthreads();
-        for (uint32_t t = threadIdx.x; t < tot; t += 512) {   // (two candidates per thread and trip: their gathers side by side)
-            uint64_t* sp[2];
-            uint64_t e[2], hx[2], hy[2];
-            uint32_t ox[2], oy[2], gx[2], gy[2], cj2[2];
-            unsigned long long rb[2];
+        for (uint32_t t = threadIdx.x; t < tot; t += 256 * AFQ_CHECK_PER) {   // (AFQ_CHECK_PER candidates per thread and trip: their gathers side by side)
+            uint64_t* sp[AFQ_CHECK_PER];
+            uint64_t e[AFQ_CHECK_PER], hx[AFQ_CHECK_PER], hy[AFQ_CHECK_PER];
+            uint32_t ox[AFQ_CHECK_PER], oy[AFQ_CHECK_PER], gx[AFQ_CHECK_PER], gy[AFQ_CHECK_PER], cj2[AFQ_CHECK_PER];
+            unsigned long long rb[AFQ_CHECK_PER];
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
+            for (int r = 0; r < AFQ_CHECK_PER; ++r) {
                 const uint32_t tt = t + 256u * (uint32_t)r;
                 sp[r] = nullptr; cj2[r] = 0;
                 if (tt < tot) {
@@ -339,20 +342,20 @@ __global__ __launch_bounds__(256) void k_p2_check(P2Args A) {
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 2; ++r) { e[r] = sp[r] ? *sp[r] : 0ull; rb[r] = A.cells[cj2[r]].rd_base; }
+            for (int r = 0; r < AFQ_CHECK_PER; ++r) { e[r] = sp[r] ? *sp[r] : 0ull; rb[r] = A.cells[cj2[r]].rd_base; }
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
+            for (int r = 0; r < AFQ_CHECK_PER; ++r) {
                 gx[r] = (uint32_t)(e[r] >> 31) & 0x7FFFFFFFu; gy[r] = (uint32_t)e[r] & 0x7FFFFFFFu;
                 const bool on = sp[r] != nullptr;
                 hx[r] = on ? A.s_h[rb[r] + gx[r]] : 0ull; hy[r] = on ? A.s_h[rb[r] + gy[r]] : 0ull;
             }
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {   // (the record offsets of hashed labels only: one or two refs sit in the key)
+            for (int r = 0; r < AFQ_CHECK_PER; ++r) {   // (the record offsets of hashed labels only: one or two refs sit in the key)
                 ox[r] = sp[r] && (uint32_t)(hx[r] >> 62) == 3 ? A.v_off[rb[r] + gx[r]] : 0u;
                 oy[r] = sp[r] && (uint32_t)(hy[r] >> 62) == 3 ? A.v_off[rb[r] + gy[r]] : 0u;
             }
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
+            for (int r = 0; r < AFQ_CHECK_PER; ++r) {
                 if (!sp[r]) continue;
                 bool ok = true;
                 if (hx[r] != hy[r] || (uint32_t)(hx[r] >> 62) == 3) {   // (equal hashed keys are equal labels only once somebody has compared them: here)
