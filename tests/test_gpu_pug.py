@@ -524,3 +524,39 @@ def test_edge_directions_from_read_counts_beyond_the_flag_bytes_127(oracle, res)
     per_cell = [sum(v for _, v in row) for row in rows_of(want)]
     assert per_cell[0] != per_cell[1] and per_cell[6] != per_cell[7] and per_cell[12] != per_cell[13]   # (the direction rule decides the molecule count)
     assert_same_result(got, want, what=res)
+
+
+@pytest.mark.parametrize("res", ["parsimony", "parsimony-em"])
+def test_candidate_pairs_whose_labels_share_no_ref_are_cleared(oracle, res):
+    """k_p2_search (late round 6) writes a CANDIDATE pair for every two vertices whose UMIs are as has_edge wants them and whose
+    19-bit label signatures share a bit - ref t sets bit t % 19 - and k_p2_check (a thread per candidate) compares the labels and
+    clears the candidates that share no ref (pugutils.rs:187-204).  Cells made of such near-misses: refs 19 apart under UMIs one base
+    apart or equal, one / two / five refs a label (inline and hashed keys), beside true edges; a vertex all of whose candidates are
+    cleared must come out as the lone molecule it is, one with a true and a false candidate as a component of two."""
+    rng = np.random.default_rng(5)
+    cells = []
+    for k in range(40):
+        recs = []
+        for q in range(60):
+            u = int(rng.integers(0, 1 << 24))
+            t = int(rng.integers(0, 19))
+            kind = q % 6
+            if kind == 0:     # one base apart, single refs 19 apart: a candidate, no edge
+                recs += [(u, [t])] * 2 + [(u ^ 1, [t + 19])]
+            elif kind == 1:   # the same UMI under two labels 19 apart
+                recs += [(u, [t]), (u, [t + 38])]
+            elif kind == 2:   # two refs a label, signatures overlap in both bits, no ref in common
+                recs += [(u, [t, t + 57])] * 2 + [(u ^ (2 << 6), [t + 19, t + 38])]
+            elif kind == 3:   # hashed labels (five refs) that share signature bits only
+                recs += [(u, [t, t + 19, t + 38, t + 57, t + 76])] + [(u ^ (3 << 10), [t + 95, t + 114, t + 133, t + 152, t + 171])] * 2
+            elif kind == 4:   # a true edge beside a false candidate at the same vertex
+                recs += [(u, [t])] * 3 + [(u ^ 1, [t])] + [(u ^ (1 << 4), [t + 19])]
+            else:             # hashed against inline: one shared ref / none
+                recs += [(u, [t, t + 19, t + 38])] + [(u ^ 2, [t + 19])] + [(u ^ (1 << 8), [t + 57])]
+        recs = [recs[j] for j in rng.permutation(len(recs))]
+        cells.append((900 + k, recs))
+    b, off = rad.encode_cells(cells, 4, 4)
+    n_t = 200
+    cfg = pkg.WorkerConfig.for_resolution(res, num_genes=n_t, num_rows=n_t, small_thresh=0)
+    got, want = run_both(oracle, cfg, np.arange(n_t, dtype=np.uint32), b, off)
+    assert_same_result(got, want, what=res)
