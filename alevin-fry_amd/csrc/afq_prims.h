@@ -363,24 +363,33 @@ __device__ __forceinline__ void tiled_bitonic_sort_by(T* a, uint32_t n, Gt gt, T
             if (gt(x, y)) { tile[l] = y; tile[r] = x; }
         }
     };
+    // A tile that holds only lim < TILE elements (a cell's last one) needs the comparators inside the first P = 2^ceil(log2 lim) of its
+    // slots only: a comparator (l, r) of a stage with partner distance j < P has both ends below P exactly when its index is below
+    // P / 2, one with j >= P - or a mirror stage of a level above P - has r >= P >= lim and does nothing.  (Until late round 6 every
+    // stage walked all TILE / 2 comparator indices of every tile: a scATAC cell of 18 000 fragments paid for its second tile of
+    // 1 616 as for its first of 16 384.)
+    auto pow2_at_least = [](uint32_t x) { uint32_t p = 2; while (p < x) p <<= 1; return p; };
     // stages with distance < TILE for level k (kk = min(k, TILE) gives the first in-tile stage), tile by tile
     auto tile_pass = [&](uint32_t k, bool with_mirror) {
         for (uint32_t t0 = 0; t0 < n; t0 += TILE) {
             const uint32_t lim = (n - t0 < TILE) ? n - t0 : TILE;
+            const uint32_t P = pow2_at_least(lim), hp = P >> 1;   // (uniform)
             __syncthreads();
             for (uint32_t i = threadIdx.x; i < lim; i += NT) tile[i] = a[t0 + i];
             __syncthreads();
             const uint32_t kk = k < TILE ? k : TILE;
-            if (with_mirror) {  // only when k <= TILE: the whole level lives in the tile
+            if (with_mirror && kk <= P) {  // only when k <= TILE: the whole level lives in the tile
                 const uint32_t hk = kk >> 1;
-                for (uint32_t i = threadIdx.x; i < TILE / 2; i += NT) {
+                for (uint32_t i = threadIdx.x; i < hp; i += NT) {
                     const uint32_t blk = i / hk, o = i - blk * hk;
                     ce_tile(blk * kk + o, blk * kk + (kk - 1 - o), lim);
                 }
                 __syncthreads();
             }
-            for (uint32_t j = with_mirror ? (kk >> 2) : (TILE >> 1); j > 0; j >>= 1) {
-                for (uint32_t i = threadIdx.x; i < TILE / 2; i += NT) {
+            uint32_t j0 = with_mirror ? (kk >> 2) : (TILE >> 1);
+            if (j0 > hp) j0 = hp;
+            for (uint32_t j = j0; j > 0; j >>= 1) {
+                for (uint32_t i = threadIdx.x; i < hp; i += NT) {
                     const uint32_t l = ((i & ~(j - 1)) << 1) | (i & (j - 1));
                     ce_tile(l, l + j, lim);
                 }
@@ -394,18 +403,19 @@ __device__ __forceinline__ void tiled_bitonic_sort_by(T* a, uint32_t n, Gt gt, T
     {
         for (uint32_t t0 = 0; t0 < n; t0 += TILE) {
             const uint32_t lim = (n - t0 < TILE) ? n - t0 : TILE;
+            const uint32_t P = pow2_at_least(lim), hp = P >> 1;   // (uniform; the tile's elements are sorted after level P)
             __syncthreads();
             for (uint32_t i = threadIdx.x; i < lim; i += NT) tile[i] = a[t0 + i];
             __syncthreads();
-            for (uint32_t k = 2; k <= TILE && k <= np2; k <<= 1) {
+            for (uint32_t k = 2; k <= P && k <= np2; k <<= 1) {
                 const uint32_t hk = k >> 1;
-                for (uint32_t i = threadIdx.x; i < TILE / 2; i += NT) {
+                for (uint32_t i = threadIdx.x; i < hp; i += NT) {
                     const uint32_t blk = i / hk, o = i - blk * hk;
                     ce_tile(blk * k + o, blk * k + (k - 1 - o), lim);
                 }
                 __syncthreads();
                 for (uint32_t j = hk >> 1; j > 0; j >>= 1) {
-                    for (uint32_t i = threadIdx.x; i < TILE / 2; i += NT) {
+                    for (uint32_t i = threadIdx.x; i < hp; i += NT) {
                         const uint32_t l = ((i & ~(j - 1)) << 1) | (i & (j - 1));
                         ce_tile(l, l + j, lim);
                     }

@@ -139,6 +139,41 @@ static int check_scan(std::mt19937_64& g) {
     return 0;
 }
 
+// tiled_bitonic_sort_by: one workgroup sorts a[0, n) in place through an LDS tile of TILE elements - every fill of the last
+// tile (none, one element, just under / at / just over a power of two, a full tile), one to five tiles
+template <int NT, uint32_t TILE, typename T>
+__global__ __launch_bounds__(NT) void k_tiled_sort(T* a, uint32_t n, uint32_t stride) {
+    __shared__ T s_tile[TILE];
+    tiled_bitonic_sort_by<NT, TILE>(a + (size_t)blockIdx.x * stride, n, [](T x, T y) { return x > y; }, s_tile);
+}
+template <int NT, uint32_t TILE, typename T>
+static int check_tiled(std::mt19937_64& g, std::vector<uint32_t> sizes) {
+    constexpr uint32_t B = 3;
+    for (int narrow = 0; narrow < 2; ++narrow)
+        for (uint32_t n : sizes) {
+            std::vector<T> h((size_t)n * B + 1);
+            for (auto& x : h) x = rnd<T>(g, narrow);
+            T* d;
+            CK(hipMalloc(&d, sizeof(T) * h.size()));
+            CK(hipMemcpy(d, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL((k_tiled_sort<NT, TILE, T>), dim3(B), dim3(NT), 0, 0, d, n, n);
+            std::vector<T> got(h.size());
+            CK(hipMemcpy(got.data(), d, sizeof(T) * h.size(), hipMemcpyDeviceToHost));
+            CK(hipFree(d));
+            for (uint32_t b = 0; b < B; ++b) {
+                std::vector<T> want(h.begin() + (size_t)b * n, h.begin() + (size_t)(b + 1) * n);
+                std::sort(want.begin(), want.end());
+                if (!std::equal(want.begin(), want.end(), got.begin() + (size_t)b * n)) {
+                    std::printf("tiled sort mismatch: bytes=%zu NT=%d TILE=%u n=%u narrow=%d block=%u\n", sizeof(T), NT, TILE, n, narrow, b);
+                    return 1;
+                }
+            }
+            if (got.back() != h.back()) { std::printf("tiled sort wrote past its end: TILE=%u n=%u\n", TILE, n); return 1; }
+            ++n_checks;
+        }
+    return 0;
+}
+
 int main() {
     std::mt19937_64 g(20260927);
     int rc = 0;
@@ -151,6 +186,10 @@ int main() {
     RUN((check_block<1024, 1, u128>(g))); RUN((check_block<1024, 2, u128>(g))); RUN((check_block<1024, 4, u128>(g)));
     RUN((check_block<1024, 1, uint64_t>(g))); RUN((check_block<1024, 2, uint64_t>(g))); RUN((check_block<1024, 4, uint64_t>(g))); RUN((check_block<1024, 8, uint64_t>(g)));
     RUN((check_block<1024, 4, uint32_t>(g)));
+    RUN((check_tiled<256, 1024, uint64_t>(g, {1, 2, 3, 5, 63, 64, 65, 511, 512, 513, 1023, 1024, 1025, 1026, 1029, 1100, 1279, 1280, 1281, 1536, 1537, 2047, 2048, 2049, 2052, 2600, 3071, 3073, 4096, 4097, 4500, 5121})));
+    RUN((check_tiled<256, 1024, uint32_t>(g, {1, 2, 7, 1000, 1024, 1025, 1153, 2048, 2049, 3000, 4099})));
+    RUN((check_tiled<1024, 4096, u128>(g, {4095, 4096, 4097, 4100, 4609, 6000, 8192, 8193, 9000})));
+    RUN((check_tiled<1024, 16384, uint64_t>(g, {16383, 16384, 16385, 18000, 20000, 24577, 32768, 33000})));   // (k_atac_dedup64's instance: a cell of 18 000 fragments)
     RUN((check_scan<64>(g))); RUN((check_scan<256>(g))); RUN((check_scan<1024>(g)));
     CK(hipDeviceSynchronize());
     if (rc) return rc;
