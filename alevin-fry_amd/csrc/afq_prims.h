@@ -369,6 +369,35 @@ __device__ __forceinline__ void tiled_bitonic_sort_by(T* a, uint32_t n, Gt gt, T
     // stage walked all TILE / 2 comparator indices of every tile: a scATAC cell of 18 000 fragments paid for its second tile of
     // 1 616 as for its first of 16 384.)
     auto pow2_at_least = [](uint32_t x) { uint32_t p = 2; while (p < x) p <<= 1; return p; };
+    // The half-cleaner stages of a level two at a time: the comparators of the stages with partner distances j and j / 2 that touch the
+    // four elements base, base + j/2, base + j, base + 3j/2 touch nothing else, so a thread that holds the four does both stages in
+    // registers - half the LDS reads and writes and half the barriers of a level's tail (each stage by itself: two 8- or 16-byte reads
+    // and up to two writes per comparator, a barrier per stage; the scATAC sort of 16 384 keys was 105 such visits, now 63).
+    // Elements at lim and beyond do not exist (the network treats them as +infinity): the four indices ascend, so do their validities.
+    auto stages_from = [&](uint32_t j0, uint32_t hp, uint32_t lim) {
+        uint32_t j = j0;
+        for (; j >= 2; j >>= 2) {
+            const uint32_t h = j >> 1;
+            for (uint32_t i = threadIdx.x; i < (hp >> 1); i += NT) {
+                const uint32_t b = ((i & ~(h - 1)) << 2) | (i & (h - 1));
+                if (b + h >= lim) continue;   // (fewer than two of the four exist: no comparator)
+                const bool v2 = b + j < lim, v3 = b + j + h < lim;
+                T x0 = tile[b], x1 = tile[b + h], x2 = v2 ? tile[b + j] : x1, x3 = v3 ? tile[b + j + h] : x1;
+                if (v2 && gt(x0, x2)) { const T t = x0; x0 = x2; x2 = t; }
+                if (v3 && gt(x1, x3)) { const T t = x1; x1 = x3; x3 = t; }
+                if (gt(x0, x1)) { const T t = x0; x0 = x1; x1 = t; }
+                if (v3 && gt(x2, x3)) { const T t = x2; x2 = x3; x3 = t; }
+                tile[b] = x0; tile[b + h] = x1;
+                if (v2) tile[b + j] = x2;
+                if (v3) tile[b + j + h] = x3;
+            }
+            __syncthreads();
+        }
+        if (j == 1) {   // (an odd number of stages: the last one by itself)
+            for (uint32_t i = threadIdx.x; i < hp; i += NT) ce_tile(i << 1, (i << 1) + 1, lim);
+            __syncthreads();
+        }
+    };
     // stages with distance < TILE for level k (kk = min(k, TILE) gives the first in-tile stage), tile by tile
     auto tile_pass = [&](uint32_t k, bool with_mirror) {
         for (uint32_t t0 = 0; t0 < n; t0 += TILE) {
@@ -388,13 +417,7 @@ __device__ __forceinline__ void tiled_bitonic_sort_by(T* a, uint32_t n, Gt gt, T
             }
             uint32_t j0 = with_mirror ? (kk >> 2) : (TILE >> 1);
             if (j0 > hp) j0 = hp;
-            for (uint32_t j = j0; j > 0; j >>= 1) {
-                for (uint32_t i = threadIdx.x; i < hp; i += NT) {
-                    const uint32_t l = ((i & ~(j - 1)) << 1) | (i & (j - 1));
-                    ce_tile(l, l + j, lim);
-                }
-                __syncthreads();
-            }
+            stages_from(j0, hp, lim);
             for (uint32_t i = threadIdx.x; i < lim; i += NT) a[t0 + i] = tile[i];
         }
         __syncthreads();
@@ -414,13 +437,7 @@ __device__ __forceinline__ void tiled_bitonic_sort_by(T* a, uint32_t n, Gt gt, T
                     ce_tile(blk * k + o, blk * k + (k - 1 - o), lim);
                 }
                 __syncthreads();
-                for (uint32_t j = hk >> 1; j > 0; j >>= 1) {
-                    for (uint32_t i = threadIdx.x; i < hp; i += NT) {
-                        const uint32_t l = ((i & ~(j - 1)) << 1) | (i & (j - 1));
-                        ce_tile(l, l + j, lim);
-                    }
-                    __syncthreads();
-                }
+                stages_from(hk >> 1, hp, lim);
             }
             for (uint32_t i = threadIdx.x; i < lim; i += NT) a[t0 + i] = tile[i];
         }
