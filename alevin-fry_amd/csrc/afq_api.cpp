@@ -1272,7 +1272,11 @@ int finish_range(afq_ctx* c, int slot) {
 // slower still when every page of a mapped file faults on first touch); here several threads fill pinned pieces
 // while the previous piece is on the wire.  Memory the caller has pinned (hipHostMalloc / hipHostRegister) goes
 // straight to the DMA engine.
-constexpr size_t kStagePiece = 64u << 20;
+// (Piece size and thread count, late round 6, `afquant quant` on the 6.9 GB sample in /dev/shm, best of three per box: 32 threads x 64 MiB
+//  0.96 s, 64 x 64 1.10, 128 x 64 1.05, 32 x 256 1.27, 8 x 64 0.92, 16 x 16 0.84, 16 x 32 0.82, 8 x 16 0.87 - the reads of a tmpfs file
+//  do not scale past some sixteen threads, 17-19 GB/s whatever the scheme.  Every filler a pipeline of its own - its own two pinned
+//  pieces, its own stream, no meeting per piece - was built and measured too: 1.05-1.38 s, worse with more threads.  Not kept.)
+static const size_t kStagePiece = (size_t)std::max(1L, test_hook_long("STAGE_PIECE_MB", 32)) << 20;   // (the hook: the staged path on small inputs, and the measurement above)
 bool host_ptr_is_pinned(const void* p) {
     hipPointerAttribute_t at{};
     if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -1280,7 +1284,9 @@ bool host_ptr_is_pinned(const void* p) {
 }
 unsigned stage_threads() {
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    return std::min(32u, std::max(4u, hw / 4));
+    const long forced = test_hook_long("STAGE_THREADS", 0);
+    if (forced > 0) return (unsigned)std::min(256L, forced);
+    return std::min(16u, std::max(4u, hw / 4));
 }
 struct ByteSource {   // where afq_submit's input comes from: the caller's buffer, or a reader callback (afq_submit_reader)
     const uint8_t* bytes = nullptr;
@@ -1297,6 +1303,7 @@ int staged_h2d(afq_ctx* c, uint8_t* dst, const uint8_t* src, size_t n, hipStream
     // The filler threads live for the whole copy (round 6; rounds 1-5 spawned and joined sixteen per 64 MiB piece: 100 pieces of a
     // PBMC-10k RAD, half a millisecond of thread start-up in front of every one - `afquant quant` spent 0.4 of its second here at
     // 17 GB/s): the submitting thread hands out a piece number, every filler fills its slice of that piece, the last one says so.
+    // (sixteen of them since late round 6, and pieces of 32 MiB: see kStagePiece)
     const unsigned nth = stage_threads();
     const size_t n_pieces = (n + kStagePiece - 1) / kStagePiece;
     // (they SLEEP between pieces - a condition variable, not a spin: a parsimony range's kernels run for tens of milliseconds, the next
