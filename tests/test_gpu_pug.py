@@ -526,13 +526,15 @@ def test_edge_directions_from_read_counts_beyond_the_flag_bytes_127(oracle, res)
     assert_same_result(got, want, what=res)
 
 
+@pytest.mark.parametrize("ref_base", [0, 600000])
 @pytest.mark.parametrize("res", ["parsimony", "parsimony-em"])
-def test_candidate_pairs_whose_labels_share_no_ref_are_cleared(oracle, res):
+def test_candidate_pairs_whose_labels_share_no_ref_are_cleared(oracle, res, ref_base):
     """k_p2_search (late round 6) writes a CANDIDATE pair for every two vertices whose UMIs are as has_edge wants them and whose
     19-bit label signatures share a bit - ref t sets bit t % 19 - and k_p2_check (a thread per candidate) compares the labels and
     clears the candidates that share no ref (pugutils.rs:187-204).  Cells made of such near-misses: refs 19 apart under UMIs one base
     apart or equal, one / two / five refs a label (inline and hashed keys), beside true edges; a vertex all of whose candidates are
-    cleared must come out as the lone molecule it is, one with a true and a false candidate as a component of two."""
+    cleared must come out as the lone molecule it is, one with a true and a false candidate as a component of two.
+    ref_base 600000: the same with ref ids beyond 19 bits (a transcriptome of more than half a million refs)."""
     rng = np.random.default_rng(5)
     cells = []
     for k in range(40):
@@ -553,10 +555,12 @@ def test_candidate_pairs_whose_labels_share_no_ref_are_cleared(oracle, res):
                 recs += [(u, [t])] * 3 + [(u ^ 1, [t])] + [(u ^ (1 << 4), [t + 19])]
             else:             # hashed against inline: one shared ref / none
                 recs += [(u, [t, t + 19, t + 38])] + [(u ^ 2, [t + 19])] + [(u ^ (1 << 8), [t + 57])]
-        recs = [recs[j] for j in rng.permutation(len(recs))]
+        recs = [(u, [ref_base + t for t in lab]) for u, lab in (recs[j] for j in rng.permutation(len(recs)))]
         cells.append((900 + k, recs))
     b, off = rad.encode_cells(cells, 4, 4)
-    n_t = 200
-    cfg = pkg.WorkerConfig.for_resolution(res, num_genes=n_t, num_rows=n_t, small_thresh=0)
-    got, want = run_both(oracle, cfg, np.arange(n_t, dtype=np.uint32), b, off)
-    assert_same_result(got, want, what=res)
+    n_g = 200
+    t2g = np.zeros(ref_base + n_g, dtype=np.uint32)
+    t2g[ref_base:] = np.arange(n_g, dtype=np.uint32)
+    cfg = pkg.WorkerConfig.for_resolution(res, num_genes=n_g, num_rows=n_g, small_thresh=0)
+    got, want = run_both(oracle, cfg, t2g, b, off)
+    assert_same_result(got, want, what=f"{res} ref_base={ref_base}")
