@@ -719,14 +719,17 @@ __global__ void k_lone_timing_dump() {
 #endif
 // L8: labels of 5..8 refs by their own lane (molecule8_column; AFQ_TEST_P2_LONE_COOP=2) - an instance of its own: its eight-entry arrays
 // are registers of every lane whether or not a label needs them.
-template <bool L8>
-__device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t* s_cls, uint32_t* s_g, uint32_t lane) {
+#ifndef AFQ_LONE_ROWS
+#define AFQ_LONE_ROWS 2
+#endif
+// FLAT (late round 6): the rows are any run of a cell's slots, not a partition's - a slot past its partition's vertices holds a zero
+// key (k_p2_part), which is "no label", so a slot needs no partition to be resolved; only a staged two-gene class (em) does, and
+// the lane that has one works its partition out of the vertex's UMI and takes the next place in that partition's stage.
+template <bool L8, bool FLAT>
+__device__ __forceinline__ void lone_rows(const P2Args& A, const P2Cell& c, uint32_t j, uint32_t lo_p, uint32_t n, uint32_t nv, uint32_t gp, uint32_t* s_cls, uint32_t* s_g, uint32_t lane) {
 #ifdef AFQ_LONE_TIMING
     unsigned long long lt_ = clock64();
 #endif
-    const uint32_t n = A.pcnt[gp], nv = A.pnv[gp], j = A.pcell[gp], lo_p = A.poff[gp];
-    if (n == 0) return;
-    const P2Cell c = A.cells[j];
     uint32_t* gc = A.gcnt + 4 * (size_t)j;
     const PugCtx C = make_ctx(A, c, gc);   // (the counters are the cell's global ones here: the rare class writes add to them directly)
     const uint64_t o = c.rd_base + lo_p;
@@ -738,12 +741,13 @@ __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t
     PugCtx Cg = C;
     Cg.gene_level = 1;   // (genes_of4 is handed gene ids below: the gathers are done here, for all slots together)
     L_MARK(0);
-    for (uint32_t r0 = 0; r0 < n; r0 += 128) {   // (uniform)
+    constexpr int RW = FLAT ? AFQ_LONE_ROWS : 2;   // rows of 64 slots in flight per trip
+    for (uint32_t r0 = 0; r0 < n; r0 += 64 * RW) {   // (uniform)
         constexpr int NR = L8 ? 8 : 4;   // refs of a label a lane looks at itself
-        uint64_t h2[2];
-        uint32_t fl[2], of[2], ln[2], t4[2][NR], g4[2][NR];
+        uint64_t h2[RW];
+        uint32_t fl[RW], of[RW], ln[RW], t4[RW][NR], g4[RW][NR];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < RW; ++r) {
             const uint32_t i = r0 + (uint32_t)r * 64 + lane;
             h2[r] = i < nv ? A.s_h[o + i] : 0ull;
             fl[r] = i < nv ? (A.v_flag[o + i] & 1u) : 1u;
@@ -751,7 +755,7 @@ __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t
         }
         L_MARK(1);
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < RW; ++r) {
             const uint32_t tag = fl[r] ? 0u : (uint32_t)(h2[r] >> 62);
             ln[r] = tag == 3 ? C.W[of[r]] : tag;   // (tags 1 and 2 are the label's length)
 #pragma unroll
@@ -770,12 +774,12 @@ __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t
         }
         L_MARK(2);
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+        for (int r = 0; r < RW; ++r)
 #pragma unroll
             for (int q = 0; q < NR; ++q) g4[r][q] = (uint32_t)q < ln[r] && ln[r] <= (uint32_t)NR ? C.t2g[t4[r][q]] : 0xFFFFFFFFu;
         L_MARK(3);
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < RW; ++r) {
             const uint32_t i = r0 + (uint32_t)r * 64 + lane;
             if (r0 + (uint32_t)r * 64 >= n) break;   // (uniform)
             uint32_t col = 0xFFFFFFFFu, k0 = 0, k1 = 0;
@@ -796,16 +800,24 @@ __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t
                 }
             }
             if (i < n) C.cols[lo_p + i] = col;
-            const uint64_t mk = __ballot(cls);
-            if (cls) { const uint32_t q = ncls + (uint32_t)__popcll(mk & ((1ull << lane) - 1)); s_cls[2 * q] = k0; s_cls[2 * q + 1] = k1; }
-            ncls += (uint32_t)__popcll(mk);
+            if constexpr (FLAT) {
+                if (cls) {   // (one vertex in a dozen: its partition from its UMI's low bits, the next place of that partition's stage)
+                    const uint32_t gq = c.part_base + ((uint32_t)(A.s_u[o + i] >> 32) & ((1u << c.lgP) - 1u));
+                    const uint32_t k = atomicAdd(&A.pncls[gq], 1u);
+                    A.cstage[c.rd_base + A.poff[gq] + k] = ((uint64_t)k1 << 32) | k0;
+                }
+            } else {
+                const uint64_t mk = __ballot(cls);
+                if (cls) { const uint32_t q = ncls + (uint32_t)__popcll(mk & ((1ull << lane) - 1)); s_cls[2 * q] = k0; s_cls[2 * q + 1] = k1; }
+                ncls += (uint32_t)__popcll(mk);
+            }
         }
         L_MARK(4);
         // labels of more than 64 refs (without the cooperative path: of more than four): one lane after the other, its genes in the
         // wave's LDS row - 64 words of a lane's own were 272 bytes of scratch per lane of every wave, for a label in ten thousand.
         // (Behind the rows' loop, where the gathered refs and genes are dead: inside it the kernel lost its seventh wave per SIMD.)
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < RW; ++r) {
             if (r0 + (uint32_t)r * 64 >= n) break;   // (uniform)
             for (uint64_t wm = __ballot(!(L8 && ln[r] <= 8) && ln[r] > (A.lone_coop ? 64u : 4u)); wm; wm &= wm - 1) {
                 if (lane == (uint32_t)__builtin_ctzll(wm)) {
@@ -822,13 +834,20 @@ __device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t
 #ifdef AFQ_LONE_TIMING
     if (lane == 0) atomicAdd(&g_lone_t[8], 1ull);
 #endif
-    if (!ncls) return;
+    if (FLAT || !ncls) return;
     WAVE_SYNC();
     uint64_t* stage = A.cstage + o;   // (at most one class per vertex: the partition's own slots hold them; the graph kernel moves them into the cell's label area)
     for (uint32_t i = lane; i < ncls; i += 64) stage[i] = ((uint64_t)s_cls[2 * i + 1] << 32) | s_cls[2 * i];
     if (lane == 0) A.pncls[gp] = ncls;
     WAVE_SYNC();
     L_MARK(6);
+}
+template <bool L8>
+__device__ __forceinline__ void lone_body(const P2Args& A, uint32_t gp, uint32_t* s_cls, uint32_t* s_g, uint32_t lane) {
+    const uint32_t n = A.pcnt[gp], nv = A.pnv[gp], j = A.pcell[gp], lo_p = A.poff[gp];
+    if (n == 0) return;
+    const P2Cell c = A.cells[j];
+    lone_rows<L8, false>(A, c, j, lo_p, n, nv, gp, s_cls, s_g, lane);
 }
 #ifndef AFQ_LONE_WPE
 #define AFQ_LONE_WPE 7   // waves per SIMD k_p2_lone<false> is compiled for
@@ -840,6 +859,23 @@ __global__ __launch_bounds__(256, L8 ? 5 : AFQ_LONE_WPE) void k_p2_lone(P2Args A
     __shared__ uint32_t s_g4[4][kMaxGenesPerLabel];   // (a wave's row for the genes of a label of more than 64 refs)
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     for_each_partition_in_runs(A.n_parts, wv, [&](uint32_t gp) { lone_body<L8>(A, gp, s_cls4[wv], s_g4[wv], lane); });
+}
+// ... and over the range's tiles of 4096 slots, a wave per 256 slots of one: no partition's head (three dependent scalar loads in front
+// of everything), no half-empty rows at a partition's end, no staging of classes through LDS.
+#ifndef AFQ_LONE_FLAT
+#define AFQ_LONE_FLAT 1
+#endif
+template <bool L8>
+__global__ __launch_bounds__(256, L8 ? 5 : AFQ_LONE_WPE) void k_pl_lone(P2Args A) {
+    if (A.st->err_code) return;
+    __shared__ uint32_t s_g4[4][kMaxGenesPerLabel];
+    const uint2 td = A.tiles[blockIdx.x];
+    const uint32_t j = td.x;
+    if (A.fb[j]) return;   // (handed back by k_p2_scan: the one-workgroup kernel's)
+    const P2Cell c = A.cells[j];
+    const uint32_t t0 = td.y * A.tile, t1 = min(c.R, t0 + A.tile);
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    for (uint32_t lo = t0 + wv * 256; lo < t1; lo += 1024) { const uint32_t n = min(256u, t1 - lo); lone_rows<L8, true>(A, c, j, lo, n, n, 0u, nullptr, s_g4[wv], lane); }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -1863,7 +1899,10 @@ void launch_p2_search(hipStream_t s, const P2Args& a) {
 }
 void launch_p2_lone(hipStream_t s, const P2Args& a) {
     if (!a.n_parts) return;
-    if (a.lone_coop >= 2) AFQ_LAUNCH(k_p2_lone<true>, p2_grid(a.n_parts), 256, s, a);
+    if (AFQ_LONE_FLAT) {
+        if (a.lone_coop >= 2) AFQ_LAUNCH(k_pl_lone<true>, a.n_tiles, 256, s, a);
+        else AFQ_LAUNCH(k_pl_lone<false>, a.n_tiles, 256, s, a);
+    } else if (a.lone_coop >= 2) AFQ_LAUNCH(k_p2_lone<true>, p2_grid(a.n_parts), 256, s, a);
     else AFQ_LAUNCH(k_p2_lone<false>, p2_grid(a.n_parts), 256, s, a);
 #ifdef AFQ_LONE_TIMING
     hipLaunchKernelGGL(k_lone_timing_dump, dim3(1), dim3(1), 0, s);

@@ -232,8 +232,9 @@ def sanity(res, rad):
 # timers of the library that bracket several kernels: their bytes add up (the decode timer brackets whichever decoder ran)
 BRACKETS = {"k_em": ("k_em2_plan", "k_em2_setup", "k_em2_rounds", "k_em2_rounds_hybrid", "k_em", "k_em_rounds"),
             "k_p2_split": ("k_p2_hist", "k_p2_scan", "k_p2_scatter"), "k_p2_search": ("k_p2_search", "k_p2_search_over", "k_p2_check"),
-            "k_p2_graph": ("k_pf_count", "k_pf_tscan", "k_pf_number", "k_pf_union", "k_pf_root", "k_pf_cats", "k_pf_classes", "k_pf_cscan", "k_pf_alloc", "k_pf_place", "k_pf_adj",
-                           "k_p2_graph", "k_p2_cover", "k_p2_tied"), "k_p2_part": ("k_p2_part",),
+            "k_p2_graph": ("k_pf_count", "k_pf_scan1", "k_pf_scan2", "k_pf_number", "k_pf_union", "k_pf_root", "k_pf_cats", "k_pf_pscan1", "k_pf_pscan2", "k_pf_move", "k_pf_cells",
+                           "k_pf_tiles", "k_pf_alloc", "k_pf_place", "k_pc_pairs", "k_pc_lane4", "k_pc_tiny8", "k_pc_mid", "k_pc_resume", "k_pc_finish",
+                           "k_p2_graph", "k_p2_cover", "k_p2_tied"), "k_p2_part": ("k_p2_part",), "k_p2_lone": ("k_pl_lone", "k_p2_lone"),
             # (since late round 4 the 5 us kernels around the large ones are timed with them - one HIP event between two timed kernels
             #  instead of two per bracket, csrc/afq_api.cpp: TimerChain - so the decode bracket also holds the proof's fix-up decode,
             #  the scatter bracket k_fix_slabs, the resolve bracket k_resolve_mid / k_resolve_big)
